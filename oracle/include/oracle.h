@@ -1,0 +1,97 @@
+/* ORACLE — test infrastructure only.
+ *
+ * C interface of the CPU restatement of lars-frogner/Impact's per-frame voxel physics path.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+ * the product (impact_amd/, include/impact_voxel_hip.h) never links or calls it.
+ *
+ * Parity pinning status: the reference is Rust and cannot be built here, so the
+ * oracle is pinned against the reference's own known-answer tests re-typed in tests/test_oracle_*.py
+ * (adjacency patterns, occupied ranges, chunk flag bits, vertex/index material packing, inertia of
+ * boxes/chunks, sphere-collision outcomes). Bit-level behaviour of the un-vendored glam 0.30.10 /
+ * simdnoise 3.1.7 / fastrand 2.3.0 crates is "parity unpinned" (see DESIGN.md).
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_object orc_object;
+typedef struct orc_mesh orc_mesh;
+
+/* SDFNode (generation/sdf/atomic.rs:62-81); same 32-byte layout as ivx_sdf_node */
+typedef struct {
+    uint32_t kind; /* 0 sphere 1 capsule 2 box 3 translation 4 rotation 5 scaling 7 union 8 subtraction 9 intersection */
+    uint32_t child1, child2, pad;
+    float p[4];
+} orc_sdf_node;
+
+/* ProcessedSDFNode (atomic.rs:83-102); same 128-byte layout as ivx_sdf_processed_node */
+typedef struct {
+    uint32_t kind, leaf_count;
+    float transform[16]; /* column-major, root -> node space */
+    float domain_lo[3], domain_hi[3];
+    float margin;
+    float a, b, c;
+    uint32_t reserved[4];
+} orc_sdf_processed_node;
+
+/* per-chunk state in dense (all chunks stored) form; same 8-byte layout as ivx_chunk_info */
+typedef struct {
+    uint8_t kind;     /* 0 void, 1 uniform, 2 non-uniform (after derived state) */
+    uint8_t gen_kind; /* kind right after generation */
+    uint8_t flags;    /* VoxelChunkFlags (object.rs:163-188); 0 for void/uniform */
+    uint8_t uniform_type;
+    uint16_t face_dist; /* 2 bits per face at bit 2*(2*dim+side): 0 empty 1 full 2 mixed */
+    uint8_t region_count, boundary_region_count;
+} orc_chunk_info;
+
+/* generators ------------------------------------------------------------------------------- */
+int orc_sdf_compile(const orc_sdf_node* nodes, int n, uint32_t root, orc_sdf_processed_node* out, int cap,
+                    float domain[6], int* stack_size);
+orc_object* orc_object_from_sdf(const orc_sdf_node* nodes, int n, uint32_t root, float voxel_extent, uint8_t voxel_type);
+/* OffsetBoxVoxelGenerator (object.rs:3387-3504), voxel extent 0.25 */
+orc_object* orc_object_from_box(const int shape[3], const int offset[3], uint8_t type, int8_t sd, uint8_t flags);
+/* ManualVoxelGenerator<N> (object.rs:3393-3561): cells[n*n*n] (i,j,k) order, non-zero = maximally inside */
+orc_object* orc_object_from_manual(int n, const uint8_t* cells, const int offset[3]);
+/* dense chunk-tiled planes; emptiness = sd >= 0, void = sd > 100 (generation.rs:336-355) */
+orc_object* orc_object_from_dense(const int chunk_counts[3], float voxel_extent, const int8_t* sdf, const uint8_t* type);
+void orc_object_free(orc_object*);
+
+void orc_update_occupied_voxel_ranges(orc_object*);
+void orc_compute_all_derived_state(orc_object*);
+/* out: cc[3], stored non-uniform chunk count, occ_chunk lo/hi x3, occ_voxel lo/hi x3, grid shape[3] */
+void orc_object_info(const orc_object*, int32_t out[19]);
+float orc_object_extent(const orc_object*);
+/* dense chunk-tiled export: arrays of n_chunks*4096 (index = chunk*4096 + (i<<8|j<<4|k)) */
+void orc_export_dense(const orc_object*, int8_t* sdf, uint8_t* type, uint8_t* flags, uint8_t* local_labels, orc_chunk_info* info);
+/* reference (sparse) layout: data_offset per chunk (-1 if not stored), AoS voxels (type,sd,flags) */
+void orc_export_sparse(const orc_object*, int32_t* data_offsets, uint8_t* voxels_aos3, uint8_t* labels);
+
+/* mesh ------------------------------------------------------------------------------------- */
+orc_mesh* orc_mesh_recreate(const orc_object*);
+void orc_mesh_counts(const orc_mesh*, uint32_t out[3]); /* vertices, indices, submeshes */
+/* submeshes: 16 u32 each = chunk[3], index_offset, index_count, obscured[8], vertex_offset, vertex_count, 0 */
+void orc_mesh_get(const orc_mesh*, float* positions, float* normals, uint32_t* indices, uint8_t* index_materials, uint32_t* submeshes);
+void orc_mesh_free(orc_mesh*);
+void orc_vertex_materials(const uint8_t has_voxel[8], const uint8_t materials[8], uint8_t out_indices[8], uint8_t out_weights[8]);
+void orc_index_materials(const uint8_t vm_indices[24], const uint8_t vm_weights[24], uint8_t out[24]);
+
+/* inertia ---------------------------------------------------------------------------------- */
+void orc_inertia(const orc_object*, const float densities[256], float out32[10], double out64[10]);
+void orc_derive_inertial_properties(const float moments[10], float out[22]);
+
+/* connected regions -------------------------------------------------------------------------- */
+/* labels: dense x-major (nx,ny,nz) u32, 0xFFFFFFFF for empty; returns component count; labels may be NULL */
+uint32_t orc_region_labels(const orc_object*, uint32_t* labels);
+
+/* quantisation helpers (lib.rs:197-222) */
+int8_t orc_sd_from_f32(float v);
+float orc_sd_to_f32(int8_t e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,327 @@
+// ORACLE (test infrastructure only — never linked into the product library).
+// C interface (oracle/include/oracle.h) over the restatement in this directory.
+#include <cstring>
+#include <memory>
+
+#include "../include/oracle.h"
+#include "orc_mesh.hpp"
+#include "orc_sdf.hpp"
+
+namespace orc {
+void inertia_moments_f32(const VoxelObject& obj, const float* dens, float out32[10]);
+void inertia_moments_f64(const VoxelObject& obj, const float* dens, double out[10]);
+void derive_inertial_properties(const float m[10], float out[22]);
+uint32_t canonical_region_labels(const VoxelObject& obj, uint32_t* labels);
+
+// OffsetBoxVoxelGenerator (object.rs:3387-3504)
+struct BoxGenerator : Generator {
+    int shape[3], offset[3];
+    Voxel voxel;
+    float voxel_extent() const override { return 0.25f; }
+    void grid_shape(int out[3]) const override {
+        for (int d = 0; d < 3; ++d) out[d] = offset[d] + shape[d];
+    }
+    ChunkSparseness generate_chunk(Voxel* v, const int o[3]) const override {
+        bool only_empty = true, is_void = true;
+        int idx = 0;
+        for (int i = o[0]; i < o[0] + CHUNK; ++i)
+            for (int j = o[1]; j < o[1] + CHUNK; ++j)
+                for (int k = o[2]; k < o[2] + CHUNK; ++k) {
+                    bool in = i >= offset[0] && i < offset[0] + shape[0] && j >= offset[1] && j < offset[1] + shape[1] &&
+                              k >= offset[2] && k < offset[2] + shape[2];
+                    if (in) {
+                        if (!voxel.empty()) only_empty = false;
+                        if (voxel.sd != 127) is_void = false;
+                        v[idx] = voxel;
+                    } else {
+                        v[idx] = voxel_max_outside();
+                    }
+                    idx++;
+                }
+        return {only_empty, is_void};
+    }
+};
+
+// ManualVoxelGenerator<N> (object.rs:3393-3561)
+struct ManualGenerator : Generator {
+    int n;
+    std::vector<uint8_t> cells;
+    int offset[3];
+    float voxel_extent() const override { return 0.25f; }
+    void grid_shape(int out[3]) const override {
+        for (int d = 0; d < 3; ++d) out[d] = offset[d] + n;
+    }
+    ChunkSparseness generate_chunk(Voxel* v, const int o[3]) const override {
+        bool is_void = true;
+        int idx = 0;
+        for (int i = o[0]; i < o[0] + CHUNK; ++i)
+            for (int j = o[1]; j < o[1] + CHUNK; ++j)
+                for (int k = o[2]; k < o[2] + CHUNK; ++k) {
+                    bool in = i >= offset[0] && i < offset[0] + n && j >= offset[1] && j < offset[1] + n && k >= offset[2] &&
+                              k < offset[2] + n && cells[((size_t)(i - offset[0]) * n + (j - offset[1])) * n + (k - offset[2])] != 0;
+                    if (in) {
+                        is_void = false;
+                        v[idx] = voxel_max_inside(0);
+                    } else {
+                        v[idx] = voxel_max_outside();
+                    }
+                    idx++;
+                }
+        return {is_void, is_void};
+    }
+};
+
+// Dense chunk-tiled planes presented as a generator (classification as generation.rs:336-355).
+struct DenseGenerator : Generator {
+    int cc[3];
+    float extent;
+    const int8_t* sdf;
+    const uint8_t* type;
+    float voxel_extent() const override { return extent; }
+    void grid_shape(int out[3]) const override {
+        for (int d = 0; d < 3; ++d) out[d] = cc[d] * CHUNK;
+    }
+    ChunkSparseness generate_chunk(Voxel* v, const int o[3]) const override {
+        size_t c = ((size_t)(o[0] / CHUNK) * cc[1] + (o[1] / CHUNK)) * cc[2] + (o[2] / CHUNK);
+        bool only_empty = true, is_void = true;
+        for (int idx = 0; idx < CHUNK_VOXELS; ++idx) {
+            int8_t sd = sdf[c * CHUNK_VOXELS + idx];
+            uint8_t t = type[c * CHUNK_VOXELS + idx];
+            if (sd < 0) {
+                only_empty = false;
+                is_void = false;
+                v[idx] = Voxel{t, sd, 0};
+            } else {
+                if (!sd_is_void(sd)) is_void = false;
+                v[idx] = Voxel{t, sd, F_EMPTY};
+            }
+        }
+        return {only_empty, is_void};
+    }
+};
+}  // namespace orc
+
+using namespace orc;
+
+struct orc_object {
+    VoxelObject obj;
+    int shape[3];
+};
+struct orc_mesh {
+    Mesh mesh;
+};
+
+static orc_object* make_object(const Generator& g) {
+    orc_object* o = new orc_object();
+    g.grid_shape(o->shape);
+    generate_without_derived_state(o->obj, g);
+    return o;
+}
+
+extern "C" {
+
+int orc_sdf_compile(const orc_sdf_node* nodes, int n, uint32_t root, orc_sdf_processed_node* out, int cap, float domain[6],
+                    int* stack_size) {
+    static_assert(sizeof(orc_sdf_node) == sizeof(SdfNode), "layout");
+    SdfGenerator g;
+    if (!g.build(reinterpret_cast<const SdfNode*>(nodes), n, root)) return -1;
+    if ((int)g.nodes.size() > cap) return -(int)g.nodes.size();
+    for (size_t i = 0; i < g.nodes.size(); ++i) {
+        const ProcessedNode& p = g.nodes[i];
+        orc_sdf_processed_node& q = out[i];
+        std::memset(&q, 0, sizeof(q));
+        q.kind = p.kind;
+        q.leaf_count = p.leaf_count;
+        for (int c = 0; c < 4; ++c)
+            for (int r = 0; r < 4; ++r) q.transform[c * 4 + r] = p.transform.c[c][r];
+        q.domain_lo[0] = p.domain_with_margin.lo.x;
+        q.domain_lo[1] = p.domain_with_margin.lo.y;
+        q.domain_lo[2] = p.domain_with_margin.lo.z;
+        q.domain_hi[0] = p.domain_with_margin.hi.x;
+        q.domain_hi[1] = p.domain_with_margin.hi.y;
+        q.domain_hi[2] = p.domain_with_margin.hi.z;
+        q.margin = p.margin;
+        q.a = p.a;
+        q.b = p.b;
+        q.c = p.c;
+    }
+    domain[0] = g.domain.lo.x;
+    domain[1] = g.domain.lo.y;
+    domain[2] = g.domain.lo.z;
+    domain[3] = g.domain.hi.x;
+    domain[4] = g.domain.hi.y;
+    domain[5] = g.domain.hi.z;
+    *stack_size = g.stack_size;
+    return (int)g.nodes.size();
+}
+
+orc_object* orc_object_from_sdf(const orc_sdf_node* nodes, int n, uint32_t root, float voxel_extent, uint8_t voxel_type) {
+    SdfVoxelGenerator g;
+    if (!g.sdf.build(reinterpret_cast<const SdfNode*>(nodes), n, root)) return nullptr;
+    g.init(voxel_extent, voxel_type);
+    return make_object(g);
+}
+
+orc_object* orc_object_from_box(const int shape[3], const int offset[3], uint8_t type, int8_t sd, uint8_t flags) {
+    BoxGenerator g;
+    for (int d = 0; d < 3; ++d) {
+        g.shape[d] = shape[d];
+        g.offset[d] = offset[d];
+    }
+    g.voxel = Voxel{type, sd, flags};
+    return make_object(g);
+}
+
+orc_object* orc_object_from_manual(int n, const uint8_t* cells, const int offset[3]) {
+    ManualGenerator g;
+    g.n = n;
+    g.cells.assign(cells, cells + (size_t)n * n * n);
+    for (int d = 0; d < 3; ++d) g.offset[d] = offset[d];
+    return make_object(g);
+}
+
+orc_object* orc_object_from_dense(const int chunk_counts[3], float voxel_extent, const int8_t* sdf, const uint8_t* type) {
+    DenseGenerator g;
+    for (int d = 0; d < 3; ++d) g.cc[d] = chunk_counts[d];
+    g.extent = voxel_extent;
+    g.sdf = sdf;
+    g.type = type;
+    return make_object(g);
+}
+
+void orc_object_free(orc_object* o) { delete o; }
+void orc_update_occupied_voxel_ranges(orc_object* o) { update_occupied_voxel_ranges(o->obj); }
+void orc_compute_all_derived_state(orc_object* o) { compute_all_derived_state(o->obj); }
+float orc_object_extent(const orc_object* o) { return o->obj.extent; }
+
+void orc_object_info(const orc_object* o, int32_t out[19]) {
+    const VoxelObject& v = o->obj;
+    out[0] = v.cc[0];
+    out[1] = v.cc[1];
+    out[2] = v.cc[2];
+    out[3] = (int32_t)(v.voxels.size() >> 12);
+    for (int d = 0; d < 3; ++d) {
+        out[4 + 2 * d] = v.occ_chunk[d][0];
+        out[5 + 2 * d] = v.occ_chunk[d][1];
+        out[10 + 2 * d] = v.occ_voxel[d][0];
+        out[11 + 2 * d] = v.occ_voxel[d][1];
+        out[16 + d] = o->shape[d];
+    }
+}
+
+void orc_export_dense(const orc_object* o, int8_t* sdf, uint8_t* type, uint8_t* flags, uint8_t* local_labels, orc_chunk_info* info) {
+    const VoxelObject& v = o->obj;
+    int n = v.n_chunks();
+    for (int c = 0; c < n; ++c) {
+        const Chunk& ch = v.chunks[c];
+        orc_chunk_info ci{};
+        ci.kind = ch.kind;
+        ci.gen_kind = ch.gen_kind;
+        if (ch.kind == K_NONUNIFORM) {
+            ci.flags = ch.flags;
+            for (int d = 0; d < 3; ++d)
+                for (int s = 0; s < 2; ++s) ci.face_dist |= (uint16_t)(ch.face[d][s] << (2 * (2 * d + s)));
+            ci.region_count = (uint8_t)ch.region_count;
+            ci.boundary_region_count = (uint8_t)ch.boundary_region_count;
+        } else if (ch.kind == K_UNIFORM) {
+            ci.uniform_type = ch.uniform_voxel.type;
+            ci.face_dist = 0x555;
+            ci.region_count = 1;
+            ci.boundary_region_count = 1;
+        }
+        if (info) info[c] = ci;
+        for (int idx = 0; idx < CHUNK_VOXELS; ++idx) {
+            Voxel x;
+            uint8_t lab;
+            if (ch.kind == K_VOID) {
+                x = voxel_max_outside();
+                lab = 255;
+            } else if (ch.kind == K_UNIFORM) {
+                x = ch.uniform_voxel;
+                lab = 0;
+            } else {
+                x = v.voxels[((size_t)ch.data_offset << 12) + idx];
+                lab = v.labels[((size_t)ch.data_offset << 12) + idx];
+            }
+            size_t g = (size_t)c * CHUNK_VOXELS + idx;
+            if (sdf) sdf[g] = x.sd;
+            if (type) type[g] = x.type;
+            if (flags) flags[g] = x.flags;
+            if (local_labels) local_labels[g] = lab;
+        }
+    }
+}
+
+void orc_export_sparse(const orc_object* o, int32_t* data_offsets, uint8_t* voxels_aos3, uint8_t* labels) {
+    const VoxelObject& v = o->obj;
+    int n = v.n_chunks();
+    for (int c = 0; c < n; ++c) data_offsets[c] = v.chunks[c].kind == K_NONUNIFORM ? (int32_t)v.chunks[c].data_offset : -1;
+    if (voxels_aos3) std::memcpy(voxels_aos3, v.voxels.data(), v.voxels.size() * 3);
+    if (labels) std::memcpy(labels, v.labels.data(), v.labels.size());
+}
+
+orc_mesh* orc_mesh_recreate(const orc_object* o) {
+    orc_mesh* m = new orc_mesh();
+    mesh_recreate(o->obj, m->mesh);
+    return m;
+}
+void orc_mesh_counts(const orc_mesh* m, uint32_t out[3]) {
+    out[0] = (uint32_t)m->mesh.positions.size();
+    out[1] = (uint32_t)m->mesh.indices.size();
+    out[2] = (uint32_t)m->mesh.submeshes.size();
+}
+void orc_mesh_get(const orc_mesh* m, float* positions, float* normals, uint32_t* indices, uint8_t* index_materials, uint32_t* submeshes) {
+    const Mesh& mesh = m->mesh;
+    if (positions) std::memcpy(positions, mesh.positions.data(), mesh.positions.size() * 12);
+    if (normals) std::memcpy(normals, mesh.normals.data(), mesh.normals.size() * 12);
+    if (indices) std::memcpy(indices, mesh.indices.data(), mesh.indices.size() * 4);
+    if (index_materials) std::memcpy(index_materials, mesh.index_materials.data(), mesh.index_materials.size() * 8);
+    if (submeshes)
+        for (size_t s = 0; s < mesh.submeshes.size(); ++s) {
+            const Submesh& sm = mesh.submeshes[s];
+            uint32_t* q = submeshes + 16 * s;
+            q[0] = sm.chunk[0];
+            q[1] = sm.chunk[1];
+            q[2] = sm.chunk[2];
+            q[3] = sm.index_offset;
+            q[4] = sm.index_count;
+            std::memcpy(q + 5, sm.obscured, 32);
+            q[13] = sm.vertex_offset;
+            q[14] = sm.vertex_count;
+            q[15] = 0;
+        }
+}
+void orc_mesh_free(orc_mesh* m) { delete m; }
+
+void orc_vertex_materials(const uint8_t has_voxel[8], const uint8_t materials[8], uint8_t out_indices[8], uint8_t out_weights[8]) {
+    bool has[8];
+    for (int i = 0; i < 8; ++i) has[i] = has_voxel[i] != 0;
+    VertexMaterials vm;
+    vertex_materials_compute(has, materials, vm);
+    std::memcpy(out_indices, vm.indices, 8);
+    std::memcpy(out_weights, vm.weights, 8);
+}
+void orc_index_materials(const uint8_t vm_indices[24], const uint8_t vm_weights[24], uint8_t out[24]) {
+    VertexMaterials vm[3];
+    for (int v = 0; v < 3; ++v) {
+        std::memcpy(vm[v].indices, vm_indices + 8 * v, 8);
+        std::memcpy(vm[v].weights, vm_weights + 8 * v, 8);
+    }
+    const VertexMaterials* p[3] = {&vm[0], &vm[1], &vm[2]};
+    IndexMaterials im[3];
+    index_materials_for_triangle(p, im);
+    std::memcpy(out, im, 24);
+}
+
+void orc_inertia(const orc_object* o, const float densities[256], float out32[10], double out64[10]) {
+    if (out32) inertia_moments_f32(o->obj, densities, out32);
+    if (out64) inertia_moments_f64(o->obj, densities, out64);
+}
+void orc_derive_inertial_properties(const float moments[10], float out[22]) { derive_inertial_properties(moments, out); }
+
+uint32_t orc_region_labels(const orc_object* o, uint32_t* labels) { return canonical_region_labels(o->obj, labels); }
+
+int8_t orc_sd_from_f32(float v) { return sd_from_f32(v); }
+float orc_sd_to_f32(int8_t e) { return sd_to_f32(e); }
+
+}  // extern "C"

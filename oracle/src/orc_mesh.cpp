@@ -1,0 +1,291 @@
+// ORACLE (test infrastructure only — never linked into the product library).
+//
+// CPU restatement of the chunk SDF padding fill, Surface Nets mesher and full mesh rebuild:
+//   fill_sdf_for_chunk_if_exposed + padding fills   object/sdf.rs:156-508
+//   gradient from corner samples                    object/sdf.rs:603-633
+//   compute_surface_nets_mesh                       object/sdf/surface_nets.rs:131-637
+//   CUBE_CORNERS / CUBE_EDGES                       object/sdf/surface_nets.rs:639-674
+//   VoxelObjectMesh::recreate                       mesh.rs:286-354, 559-577
+//   ChunkSubmesh obscuredness table                 mesh.rs:611-635
+#include "orc_mesh.hpp"
+
+#include <cstring>
+
+namespace orc {
+
+static const int G = 18;        // SDF_GRID_SIZE (object/sdf.rs:35)
+static const int G2 = G * G;
+static const int GCELLS = G * G * G;
+
+struct ChunkSdf {
+    float values[GCELLS];
+    uint8_t types[GCELLS];
+    bool adj_non_uniform[3][2];
+};
+
+static inline int gidx(int i, int j, int k) { return i * G2 + j * G + k; }
+
+// object/sdf.rs:478-508 applied per padded cell. The reference copies faces/edges/corners with
+// positional Loop3 pairs; every padded cell (a,b,c) maps to object voxel (16*ci + a - 1, ...), so a
+// per-cell gather is equivalent. Void (or outside-grid) neighbours leave `types` untouched (stale),
+// which is unobservable: only negative-distance corners contribute materials (surface_nets.rs:215,471).
+static void fill_sdf(const VoxelObject& obj, int ci, int cj, int ck, ChunkSdf& sdf) {
+    for (int a = 0; a < G; ++a)
+        for (int b = 0; b < G; ++b)
+            for (int c = 0; c < G; ++c) {
+                int oi = ci * CHUNK + a - 1, oj = cj * CHUNK + b - 1, ok = ck * CHUNK + c - 1;
+                const Chunk* ch = (oi < 0 || oj < 0 || ok < 0) ? nullptr : obj.chunk_at(oi >> 4, oj >> 4, ok >> 4);
+                int g = gidx(a, b, c);
+                if (!ch || ch->kind == K_VOID) {
+                    sdf.values[g] = sd_to_f32(127);
+                } else if (ch->kind == K_UNIFORM) {
+                    sdf.values[g] = sd_to_f32(-128);
+                    sdf.types[g] = ch->uniform_voxel.type;
+                } else {
+                    const Voxel& v = obj.voxels[((size_t)ch->data_offset << 12) + (((oi & 15) << 8) | ((oj & 15) << 4) | (ok & 15))];
+                    sdf.values[g] = sd_to_f32(v.sd);
+                    sdf.types[g] = v.type;
+                }
+            }
+    const int d[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int dim = 0; dim < 3; ++dim)
+        for (int side = 0; side < 2; ++side) {
+            int s = side ? 1 : -1;
+            const Chunk* ch = obj.chunk_at(ci + s * d[dim][0], cj + s * d[dim][1], ck + s * d[dim][2]);
+            sdf.adj_non_uniform[dim][side] = ch && ch->kind == K_NONUNIFORM;
+        }
+}
+
+static const int CUBE_CORNERS[8][3] = {{0, 0, 0}, {0, 0, 1}, {0, 1, 0}, {0, 1, 1}, {1, 0, 0}, {1, 0, 1}, {1, 1, 0}, {1, 1, 1}};
+static const int CUBE_EDGES[12][2] = {{0, 1}, {0, 2}, {0, 4}, {1, 3}, {1, 5}, {2, 3}, {2, 6}, {3, 7}, {4, 5}, {4, 6}, {5, 7}, {6, 7}};
+
+// surface_nets.rs:384-418
+static V3 centroid_of_edge_intersections(const float* d) {
+    int count = 0;
+    V3 sum{0, 0, 0};
+    for (int e = 0; e < 12; ++e) {
+        int c1 = CUBE_EDGES[e][0], c2 = CUBE_EDGES[e][1];
+        float d1 = d[c1], d2 = d[c2];
+        if (sign_neg(d1) != sign_neg(d2)) {
+            count += 1;
+            float interp1 = d1 / (d1 - d2);
+            float interp2 = 1.0f - interp1;
+            V3 p1 = v3((float)CUBE_CORNERS[c1][0], (float)CUBE_CORNERS[c1][1], (float)CUBE_CORNERS[c1][2]);
+            V3 p2 = v3((float)CUBE_CORNERS[c2][0], (float)CUBE_CORNERS[c2][1], (float)CUBE_CORNERS[c2][2]);
+            V3 p = interp2 * p1 + interp1 * p2;
+            sum = sum + p;
+        }
+    }
+    return div_recip(sum, (float)count);
+}
+
+// object/sdf.rs:603-633
+static V3 gradient_from_corners(const float* d, V3 o) {
+    V3 p00 = v3(d[4], d[2], d[1]), n00 = v3(d[0], d[0], d[0]);
+    V3 p01 = v3(d[5], d[6], d[3]), n01 = v3(d[1], d[4], d[2]);
+    V3 p10 = v3(d[6], d[3], d[5]), n10 = v3(d[2], d[1], d[4]);
+    V3 p11 = v3(d[7], d[7], d[7]), n11 = v3(d[3], d[5], d[6]);
+    V3 d00 = p00 - n00, d01 = p01 - n01, d10 = p10 - n10, d11 = p11 - n11;
+    V3 r = v3s(1.0f) - o;
+    auto yzx = [](V3 v) { return v3(v.y, v.z, v.x); };
+    auto zxy = [](V3 v) { return v3(v.z, v.x, v.y); };
+    return ((cmul(cmul(yzx(r), zxy(r)), d00) + cmul(cmul(yzx(r), zxy(o)), d01)) + cmul(cmul(yzx(o), zxy(r)), d10)) +
+           cmul(cmul(yzx(o), zxy(o)), d11);
+}
+
+// surface_nets.rs:428-522
+void vertex_materials_compute(const bool has_voxel[8], const uint8_t mat[8], VertexMaterials& m) {
+    std::memset(&m, 0, sizeof(m));
+    uint8_t map[256];
+    std::memset(map, 255, sizeof(map));
+    int count = 0;
+    for (int c = 0; c < 8; ++c)
+        if (has_voxel[c]) {
+            uint8_t idx = map[mat[c]];
+            if (idx == 255) {
+                m.indices[count] = mat[c];
+                m.weights[count] = 1;
+                map[mat[c]] = (uint8_t)count;
+                count += 1;
+            } else {
+                m.weights[idx] += 1;
+            }
+        }
+    m.indices[7] = (uint8_t)count;
+    // sorting_network_7 (surface_nets.rs:428-446), 17 compare-and-swaps in source order
+    static const int NET[17][2] = {{0, 6}, {1, 5}, {2, 4}, {0, 3}, {1, 2}, {4, 5}, {0, 1}, {2, 3}, {4, 6},
+                                   {5, 6}, {1, 4}, {3, 5}, {1, 2}, {3, 4}, {5, 6}, {2, 3}, {4, 5}};
+    for (int s = 0; s < 17; ++s) {
+        int i = NET[s][0], j = NET[s][1];
+        if (m.weights[i] < m.weights[j]) {
+            std::swap(m.indices[i], m.indices[j]);
+            std::swap(m.weights[i], m.weights[j]);
+        }
+    }
+}
+
+// surface_nets.rs:558-637
+void index_materials_for_triangle(const VertexMaterials* vm[3], IndexMaterials out[3]) {
+    auto mcount = [](const VertexMaterials* v) { return (int)v->indices[7]; };
+    if (mcount(vm[0]) == 1 && mcount(vm[1]) == 1 && mcount(vm[2]) == 1) {
+        uint8_t index = vm[0]->indices[0];
+        if (vm[1]->indices[0] == index && vm[2]->indices[0] == index) {
+            IndexMaterials im{{index, 0, 0, 0}, {1, 0, 0, 0}};
+            out[0] = out[1] = out[2] = im;
+            return;
+        }
+    }
+    uint8_t top[4] = {0, 0, 0, 0};
+    int n_top = 0;
+    bool is_top[256];
+    std::memset(is_top, 0, sizeof(is_top));
+    int off[3] = {0, 0, 0};
+    for (int t = 0; t < 4; ++t) {
+        uint8_t w[3];
+        for (int i = 0; i < 3; ++i) w[i] = vm[i]->weights[off[i]];
+        int mx = (w[0] >= w[1]) ? ((w[0] >= w[2]) ? 0 : 2) : ((w[1] >= w[2]) ? 1 : 2);
+        if (w[mx] == 0) break;
+        top[t] = vm[mx]->indices[off[mx]];
+        n_top += 1;
+        is_top[top[t]] = true;
+        for (int i = 0; i < 3; ++i)
+            while (off[i] < mcount(vm[i]) && is_top[vm[i]->indices[off[i]]]) off[i] += 1;
+    }
+    for (int v = 0; v < 3; ++v) {
+        IndexMaterials im{{top[0], top[1], top[2], top[3]}, {0, 0, 0, 0}};
+        for (int i = 0; i < n_top; ++i)
+            for (int j = 0; j < mcount(vm[v]); ++j)
+                if (vm[v]->indices[j] == top[i]) {
+                    im.weights[i] = vm[v]->weights[j];
+                    break;
+                }
+        out[v] = im;
+    }
+}
+
+struct SurfaceNetsBuffer {
+    std::vector<V3> positions, normals;
+    std::vector<VertexMaterials> vmats;
+    std::vector<IndexMaterials> imats;
+    std::vector<uint16_t> indices;
+    std::vector<uint32_t> surf;  // packed i | j<<8 | k<<16
+    std::vector<uint16_t> surf_lin;
+    uint16_t map[GCELLS];
+};
+
+// surface_nets.rs:336-381
+static void maybe_make_quad(const ChunkSdf& sdf, const SurfaceNetsBuffer& buf, int p1, int p2, int axis_b, int axis_c,
+                            std::vector<uint16_t>& indices) {
+    float d1 = sdf.values[p1], d2 = sdf.values[p2];
+    bool n1 = sign_neg(d1), n2 = sign_neg(d2);
+    bool negative_face;
+    if (n1 && !n2) negative_face = false;
+    else if (!n1 && n2) negative_face = true;
+    else return;
+    uint16_t v1 = buf.map[p1], v2 = buf.map[p1 - axis_b], v3_ = buf.map[p1 - axis_c], v4 = buf.map[p1 - axis_b - axis_c];
+    V3 q1 = buf.positions[v1], q2 = buf.positions[v2], q3 = buf.positions[v3_], q4 = buf.positions[v4];
+    uint16_t quad[6];
+    if (length(q1 - q4) < length(q2 - q3)) {
+        if (negative_face) { uint16_t q[6] = {v1, v4, v2, v1, v3_, v4}; std::memcpy(quad, q, sizeof(q)); }
+        else { uint16_t q[6] = {v1, v2, v4, v1, v4, v3_}; std::memcpy(quad, q, sizeof(q)); }
+    } else if (negative_face) { uint16_t q[6] = {v2, v3_, v4, v2, v1, v3_}; std::memcpy(quad, q, sizeof(q)); }
+    else { uint16_t q[6] = {v2, v4, v3_, v2, v3_, v1}; std::memcpy(quad, q, sizeof(q)); }
+    indices.insert(indices.end(), quad, quad + 6);
+}
+
+// surface_nets.rs:131-303
+static void compute_surface_nets_mesh(const ChunkSdf& sdf, float extent, V3 offset, SurfaceNetsBuffer& buf) {
+    buf.positions.clear();
+    buf.normals.clear();
+    buf.vmats.clear();
+    buf.imats.clear();
+    buf.indices.clear();
+    buf.surf.clear();
+    buf.surf_lin.clear();
+    for (int i = 0; i < GCELLS; ++i) buf.map[i] = 0xFFFF;
+    for (int i = 0; i < G - 1; ++i)
+        for (int j = 0; j < G - 1; ++j)
+            for (int k = 0; k < G - 1; ++k) {
+                int lin = gidx(i, j, k);
+                float cd[8];
+                bool has[8];
+                int num_neg = 0;
+                for (int c = 0; c < 8; ++c) {
+                    cd[c] = sdf.values[lin + gidx(CUBE_CORNERS[c][0], CUBE_CORNERS[c][1], CUBE_CORNERS[c][2])];
+                    has[c] = sign_neg(cd[c]);
+                    if (has[c]) num_neg += 1;
+                }
+                if (num_neg == 0 || num_neg == 8) continue;
+                uint8_t mats[8];
+                for (int c = 0; c < 8; ++c) mats[c] = sdf.types[lin + gidx(CUBE_CORNERS[c][0], CUBE_CORNERS[c][1], CUBE_CORNERS[c][2])];
+                V3 centroid = centroid_of_edge_intersections(cd);
+                V3 gradient = gradient_from_corners(cd, centroid);
+                V3 normal = normalize(gradient);
+                VertexMaterials vm;
+                vertex_materials_compute(has, mats, vm);
+                V3 position = extent * (centroid + v3((float)i, (float)j, (float)k)) + offset;
+                buf.map[lin] = (uint16_t)buf.positions.size();
+                buf.surf.push_back((uint32_t)i | ((uint32_t)j << 8) | ((uint32_t)k << 16));
+                buf.surf_lin.push_back((uint16_t)lin);
+                buf.positions.push_back(position);
+                buf.normals.push_back(normal);
+                buf.vmats.push_back(vm);
+            }
+    int upper[3] = {G - 1, G - 1, G - 1};
+    for (int d = 0; d < 3; ++d)
+        if (sdf.adj_non_uniform[d][1]) upper[d] -= 1;
+    for (size_t s = 0; s < buf.surf.size(); ++s) {
+        int i = buf.surf[s] & 255, j = (buf.surf[s] >> 8) & 255, k = (buf.surf[s] >> 16) & 255;
+        int p = buf.surf_lin[s];
+        if (j != 0 && k != 0 && i < upper[0]) maybe_make_quad(sdf, buf, p, p + G2, G, 1, buf.indices);
+        if (i != 0 && k != 0 && j < upper[1]) maybe_make_quad(sdf, buf, p, p + G, 1, G2, buf.indices);
+        if (i != 0 && j != 0 && k < upper[2]) maybe_make_quad(sdf, buf, p, p + 1, G2, G, buf.indices);
+    }
+    buf.imats.resize(buf.indices.size());
+    for (size_t t = 0; t + 2 < buf.indices.size(); t += 3) {
+        const VertexMaterials* vm[3] = {&buf.vmats[buf.indices[t]], &buf.vmats[buf.indices[t + 1]], &buf.vmats[buf.indices[t + 2]]};
+        index_materials_for_triangle(vm, &buf.imats[t]);
+    }
+}
+
+// mesh.rs:286-354
+void mesh_recreate(const VoxelObject& obj, Mesh& mesh) {
+    mesh = Mesh{};
+    static thread_local ChunkSdf sdf;
+    static thread_local SurfaceNetsBuffer buf;
+    std::memset(sdf.types, TYPE_DUMMY, sizeof(sdf.types));
+    for (int i = 0; i < GCELLS; ++i) sdf.values[i] = 0.0f;
+    float chunk_extent = (float)CHUNK * obj.extent;
+    for (int ci = 0; ci < obj.cc[0]; ++ci)
+        for (int cj = 0; cj < obj.cc[1]; ++cj)
+            for (int ck = 0; ck < obj.cc[2]; ++ck) {
+                const Chunk& c = obj.chunks[obj.cidx(ci, cj, ck)];
+                if (!(c.kind == K_NONUNIFORM && (c.flags & CF_FULLY_OBSCURED) != CF_FULLY_OBSCURED)) continue;
+                fill_sdf(obj, ci, cj, ck, sdf);
+                V3 offset = v3((float)ci * chunk_extent - 0.5f * obj.extent, (float)cj * chunk_extent - 0.5f * obj.extent,
+                               (float)ck * chunk_extent - 0.5f * obj.extent);
+                compute_surface_nets_mesh(sdf, obj.extent, offset, buf);
+                if (buf.indices.empty()) continue;
+                uint32_t voff = (uint32_t)mesh.positions.size();
+                Submesh sm{};
+                sm.chunk[0] = (uint32_t)ci;
+                sm.chunk[1] = (uint32_t)cj;
+                sm.chunk[2] = (uint32_t)ck;
+                sm.index_offset = (uint32_t)mesh.indices.size();
+                sm.index_count = (uint32_t)buf.indices.size();
+                sm.vertex_offset = voff;
+                sm.vertex_count = (uint32_t)buf.positions.size();
+                const uint8_t OX[2] = {CF_OBSC_X_DN, CF_OBSC_X_UP}, OY[2] = {CF_OBSC_Y_DN, CF_OBSC_Y_UP}, OZ[2] = {CF_OBSC_Z_DN, CF_OBSC_Z_UP};
+                for (int a = 0; a < 2; ++a)
+                    for (int b = 0; b < 2; ++b)
+                        for (int cc = 0; cc < 2; ++cc)
+                            sm.obscured[a][b][cc] = ((c.flags & OX[a]) && (c.flags & OY[b]) && (c.flags & OZ[cc])) ? 1u : 0u;
+                mesh.submeshes.push_back(sm);
+                mesh.positions.insert(mesh.positions.end(), buf.positions.begin(), buf.positions.end());
+                mesh.normals.insert(mesh.normals.end(), buf.normals.begin(), buf.normals.end());
+                mesh.index_materials.insert(mesh.index_materials.end(), buf.imats.begin(), buf.imats.end());
+                for (uint16_t ix : buf.indices) mesh.indices.push_back(voff + (uint32_t)ix);
+            }
+}
+
+}  // namespace orc

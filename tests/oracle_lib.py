@@ -1,0 +1,259 @@
+"""ctypes binding of oracle/liboracle.so (the CPU restatement of the reference).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg as the checker. The product package `impact_amd` never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+
+CHUNK_INFO_DTYPE = np.dtype(
+    [
+        ("kind", "u1"),
+        ("gen_kind", "u1"),
+        ("flags", "u1"),
+        ("uniform_type", "u1"),
+        ("face_dist", "<u2"),
+        ("region_count", "u1"),
+        ("boundary_region_count", "u1"),
+    ]
+)
+assert CHUNK_INFO_DTYPE.itemsize == 8
+
+
+def build_oracle(force: bool = False) -> str:
+    srcs = [os.path.join(ORACLE_DIR, "src", f) for f in os.listdir(os.path.join(ORACLE_DIR, "src"))]
+    srcs.append(os.path.join(ORACLE_DIR, "include", "oracle.h"))
+    stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build_oracle()
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.orc_sdf_compile.restype = C.c_int
+        L.orc_sdf_compile.argtypes = [vp, C.c_int, C.c_uint32, vp, C.c_int, vp, vp]
+        L.orc_object_from_sdf.restype = vp
+        L.orc_object_from_sdf.argtypes = [vp, C.c_int, C.c_uint32, C.c_float, C.c_uint8]
+        L.orc_object_from_box.restype = vp
+        L.orc_object_from_box.argtypes = [vp, vp, C.c_uint8, C.c_int8, C.c_uint8]
+        L.orc_object_from_manual.restype = vp
+        L.orc_object_from_manual.argtypes = [C.c_int, vp, vp]
+        L.orc_object_from_dense.restype = vp
+        L.orc_object_from_dense.argtypes = [vp, C.c_float, vp, vp]
+        L.orc_object_free.argtypes = [vp]
+        L.orc_update_occupied_voxel_ranges.argtypes = [vp]
+        L.orc_compute_all_derived_state.argtypes = [vp]
+        L.orc_object_info.argtypes = [vp, vp]
+        L.orc_object_extent.restype = C.c_float
+        L.orc_object_extent.argtypes = [vp]
+        L.orc_export_dense.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.orc_export_sparse.argtypes = [vp, vp, vp, vp]
+        L.orc_mesh_recreate.restype = vp
+        L.orc_mesh_recreate.argtypes = [vp]
+        L.orc_mesh_counts.argtypes = [vp, vp]
+        L.orc_mesh_get.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.orc_mesh_free.argtypes = [vp]
+        L.orc_vertex_materials.argtypes = [vp, vp, vp, vp]
+        L.orc_index_materials.argtypes = [vp, vp, vp]
+        L.orc_inertia.argtypes = [vp, vp, vp, vp]
+        L.orc_derive_inertial_properties.argtypes = [vp, vp]
+        L.orc_region_labels.restype = C.c_uint32
+        L.orc_region_labels.argtypes = [vp, vp]
+        L.orc_sd_from_f32.restype = C.c_int8
+        L.orc_sd_from_f32.argtypes = [C.c_float]
+        L.orc_sd_to_f32.restype = C.c_float
+        L.orc_sd_to_f32.argtypes = [C.c_int8]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def tiled_to_dense(a: np.ndarray, cc) -> np.ndarray:
+    """chunk-tiled (n_chunks*4096) -> x-major dense (nx,ny,nz)."""
+    cx, cy, cz = cc
+    return a.reshape(cx, cy, cz, 16, 16, 16).transpose(0, 3, 1, 4, 2, 5).reshape(cx * 16, cy * 16, cz * 16)
+
+
+def dense_to_tiled(a: np.ndarray) -> np.ndarray:
+    nx, ny, nz = a.shape
+    cx, cy, cz = nx // 16, ny // 16, nz // 16
+    return np.ascontiguousarray(a.reshape(cx, 16, cy, 16, cz, 16).transpose(0, 2, 4, 1, 3, 5)).reshape(-1)
+
+
+def canonicalize_labels(lab: np.ndarray, empty) -> np.ndarray:
+    """Relabel components by order of first occurrence in the flattened array (empty -> 0xFFFFFFFF)."""
+    flat = lab.reshape(-1)
+    out = np.full(flat.shape, 0xFFFFFFFF, dtype=np.uint32)
+    mask = flat != empty
+    vals = flat[mask]
+    uniq, first = np.unique(vals, return_index=True)
+    order = np.argsort(first, kind="stable")
+    rank = np.empty_like(order)
+    rank[order] = np.arange(order.size)
+    out[mask] = rank[np.searchsorted(uniq, vals)].astype(np.uint32)
+    return out.reshape(lab.shape)
+
+
+class OracleMesh:
+    def __init__(self, positions, normals, indices, index_materials, submeshes):
+        self.positions, self.normals, self.indices = positions, normals, indices
+        self.index_materials, self.submeshes = index_materials, submeshes
+
+
+class OracleObject:
+    def __init__(self, handle):
+        if not handle:
+            raise RuntimeError("oracle object construction failed")
+        self.h = C.c_void_p(handle)
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().orc_object_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    @classmethod
+    def from_sdf(cls, graph, voxel_extent=1.0, voxel_type=0):
+        nodes = graph.nodes()
+        return cls(lib().orc_object_from_sdf(_p(nodes), len(nodes), graph.root_node_id, voxel_extent, voxel_type))
+
+    @classmethod
+    def from_box(cls, shape, offset=(0, 0, 0), voxel=(0, -128, 0)):
+        s = np.asarray(shape, dtype=np.int32)
+        o = np.asarray(offset, dtype=np.int32)
+        return cls(lib().orc_object_from_box(_p(s), _p(o), voxel[0], voxel[1], voxel[2]))
+
+    @classmethod
+    def from_manual(cls, cells, offset=(0, 0, 0)):
+        c = np.ascontiguousarray(np.asarray(cells, dtype=np.uint8))
+        n = c.shape[0]
+        assert c.shape == (n, n, n)
+        o = np.asarray(offset, dtype=np.int32)
+        return cls(lib().orc_object_from_manual(n, _p(c), _p(o)))
+
+    @classmethod
+    def from_dense(cls, cc, sdf_tiled, type_tiled, voxel_extent=1.0):
+        ccs = np.asarray(cc, dtype=np.int32)
+        sdf_tiled = np.ascontiguousarray(sdf_tiled, dtype=np.int8)
+        type_tiled = np.ascontiguousarray(type_tiled, dtype=np.uint8)
+        return cls(lib().orc_object_from_dense(_p(ccs), voxel_extent, _p(sdf_tiled), _p(type_tiled)))
+
+    def update_occupied_voxel_ranges(self):
+        lib().orc_update_occupied_voxel_ranges(self.h)
+
+    def compute_all_derived_state(self):
+        lib().orc_compute_all_derived_state(self.h)
+
+    def info(self):
+        out = np.zeros(19, dtype=np.int32)
+        lib().orc_object_info(self.h, _p(out))
+        return {
+            "chunk_counts": tuple(int(x) for x in out[0:3]),
+            "stored_chunks": int(out[3]),
+            "occupied_chunk_ranges": [(int(out[4 + 2 * d]), int(out[5 + 2 * d])) for d in range(3)],
+            "occupied_voxel_ranges": [(int(out[10 + 2 * d]), int(out[11 + 2 * d])) for d in range(3)],
+            "grid_shape": tuple(int(x) for x in out[16:19]),
+        }
+
+    @property
+    def chunk_counts(self):
+        return self.info()["chunk_counts"]
+
+    def export_dense(self):
+        cc = self.chunk_counts
+        n = cc[0] * cc[1] * cc[2]
+        sdf = np.empty(n * 4096, dtype=np.int8)
+        typ = np.empty(n * 4096, dtype=np.uint8)
+        flg = np.empty(n * 4096, dtype=np.uint8)
+        lab = np.empty(n * 4096, dtype=np.uint8)
+        info = np.zeros(n, dtype=CHUNK_INFO_DTYPE)
+        lib().orc_export_dense(self.h, _p(sdf), _p(typ), _p(flg), _p(lab), _p(info))
+        return sdf, typ, flg, lab, info
+
+    def export_sparse(self):
+        inf = self.info()
+        cc = inf["chunk_counts"]
+        n = cc[0] * cc[1] * cc[2]
+        offs = np.empty(n, dtype=np.int32)
+        vox = np.empty((inf["stored_chunks"] * 4096, 3), dtype=np.uint8)
+        lab = np.empty(inf["stored_chunks"] * 4096, dtype=np.uint8)
+        lib().orc_export_sparse(self.h, _p(offs), _p(vox), _p(lab))
+        return offs, vox, lab
+
+    def voxel_flags(self, i, j, k):
+        """flags of the voxel at object indices, or None if empty (get_voxel_if_occupied)."""
+        cc = self.chunk_counts
+        _, _, flg, _, _ = self.export_dense()
+        c = ((i >> 4) * cc[1] + (j >> 4)) * cc[2] + (k >> 4)
+        f = int(flg[c * 4096 + (((i & 15) << 8) | ((j & 15) << 4) | (k & 15))])
+        return None if (f & 1) else f
+
+    def mesh(self) -> OracleMesh:
+        L = lib()
+        m = C.c_void_p(L.orc_mesh_recreate(self.h))
+        cnt = np.zeros(3, dtype=np.uint32)
+        L.orc_mesh_counts(m, _p(cnt))
+        nv, ni, ns = (int(x) for x in cnt)
+        pos = np.empty((nv, 3), dtype=np.float32)
+        nrm = np.empty((nv, 3), dtype=np.float32)
+        idx = np.empty(ni, dtype=np.uint32)
+        im = np.empty((ni, 8), dtype=np.uint8)
+        sub = np.empty((ns, 16), dtype=np.uint32)
+        L.orc_mesh_get(m, _p(pos), _p(nrm), _p(idx), _p(im), _p(sub))
+        L.orc_mesh_free(m)
+        return OracleMesh(pos, nrm, idx, im, sub)
+
+    def inertia(self, densities=None):
+        d = np.ones(256, dtype=np.float32) if densities is None else np.ascontiguousarray(densities, dtype=np.float32)
+        o32 = np.zeros(10, dtype=np.float32)
+        o64 = np.zeros(10, dtype=np.float64)
+        lib().orc_inertia(self.h, _p(d), _p(o32), _p(o64))
+        return o32, o64
+
+    def region_labels(self, want_labels=True):
+        cc = self.chunk_counts
+        lab = np.empty((cc[0] * 16, cc[1] * 16, cc[2] * 16), dtype=np.uint32) if want_labels else None
+        n = lib().orc_region_labels(self.h, _p(lab))
+        return int(n), lab
+
+
+def sdf_compile(graph):
+    from impact_amd.sdf_graph import PROCESSED_NODE_DTYPE
+
+    nodes = graph.nodes()
+    out = np.zeros(4 * max(1, len(nodes)) + 64, dtype=PROCESSED_NODE_DTYPE)
+    dom = np.zeros(6, dtype=np.float32)
+    ss = C.c_int(0)
+    n = lib().orc_sdf_compile(_p(nodes), len(nodes), graph.root_node_id, _p(out), len(out), _p(dom), C.byref(ss))
+    if n < 0:
+        raise RuntimeError("oracle sdf compile failed")
+    return out[:n].copy(), dom, ss.value
+
+
+def derive_inertial_properties(moments32):
+    m = np.ascontiguousarray(moments32, dtype=np.float32)
+    out = np.zeros(22, dtype=np.float32)
+    lib().orc_derive_inertial_properties(_p(m), _p(out))
+    return {"mass": float(out[0]), "com": out[1:4].copy(), "inertia": out[4:13].reshape(3, 3).T.copy(), "inverse": out[13:22].reshape(3, 3).T.copy()}
