@@ -1,0 +1,134 @@
+"""ctypes binding of libimpact_voxel_hip.so — the exact C ABI declared in include/impact_voxel_hip.h.
+
+This is the same surface a Rust `define_lib!` binding would see. There is no CPU
+fallback anywhere in this package: if the shared library is missing or no gfx950 device is present,
+calls raise `IvxError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("IMPACT_VOXEL_HIP_LIB", os.path.join(_HERE, "lib", "libimpact_voxel_hip.so"))
+
+IVX_OK, IVX_ERR_INVALID, IVX_ERR_HIP, IVX_ERR_CAPACITY, IVX_ERR_STATE = 0, 1, 2, 3, 4
+
+CHUNK_INFO_DTYPE = np.dtype(
+    [
+        ("kind", "u1"),
+        ("gen_kind", "u1"),
+        ("flags", "u1"),
+        ("uniform_type", "u1"),
+        ("face_dist", "<u2"),
+        ("region_count", "u1"),
+        ("boundary_region_count", "u1"),
+    ]
+)
+SUBMESH_DTYPE = np.dtype(
+    [
+        ("chunk_indices", "<u4", (3,)),
+        ("index_offset", "<u4"),
+        ("index_count", "<u4"),
+        ("is_obscured_from_direction", "<u4", (2, 2, 2)),
+        ("vertex_offset", "<u4"),
+        ("vertex_count", "<u4"),
+        ("reserved", "<u4"),
+    ]
+)
+MOMENTS_DTYPE = np.dtype([("m64", "<f8", (10,)), ("m32", "<f4", (10,)), ("reserved", "<u4", (2,))])
+REGION_DESC_DTYPE = np.dtype(
+    [
+        ("root_chunk", "<u4"),
+        ("root_region", "<u4"),
+        ("voxel_count", "<u8"),
+        ("lo", "<u4", (3,)),
+        ("hi", "<u4", (3,)),
+        ("non_uniform_chunk_count", "<u4"),
+        ("chunk_count", "<u4"),
+        ("moments", "<f8", (10,)),
+    ]
+)
+MESH_COUNTS_DTYPE = np.dtype([("n_vertices", "<u4"), ("n_indices", "<u4"), ("n_submeshes", "<u4"), ("reserved", "<u4")])
+assert CHUNK_INFO_DTYPE.itemsize == 8 and SUBMESH_DTYPE.itemsize == 64
+assert MOMENTS_DTYPE.itemsize == 128 and REGION_DESC_DTYPE.itemsize == 128
+
+# every symbol include/impact_voxel_hip.h declares
+EXPORTED_SYMBOLS = [
+    "ivx_init", "ivx_shutdown", "ivx_last_error", "ivx_synchronize", "ivx_stream",
+    "ivx_grid_create", "ivx_grid_destroy", "ivx_grid_upload_dense", "ivx_grid_download_dense", "ivx_grid_device_ptr",
+    "ivx_sdf_compile", "ivx_sdf_grid_shape", "ivx_sdf_sample",
+    "ivx_derive_state", "ivx_occupied_ranges",
+    "ivx_remesh", "ivx_mesh_download", "ivx_mesh_device_ptr",
+    "ivx_inertia",
+    "ivx_label_regions", "ivx_region_labels_download", "ivx_regions_describe",
+    "ivx_halo_bytes", "ivx_halo_pack", "ivx_halo_unpack", "ivx_halo_clear",
+]
+
+
+class IvxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ivx error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (fails loudly when it is missing: there is no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IvxError(IVX_ERR_HIP, f"{LIB_PATH} not found — run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, i32, sz, f32 = C.c_void_p, C.c_uint32, C.c_int, C.c_size_t, C.c_float
+    sig = {
+        "ivx_init": (i32, [i32, vp, C.POINTER(vp)]),
+        "ivx_shutdown": (None, [vp]),
+        "ivx_last_error": (C.c_char_p, []),
+        "ivx_synchronize": (i32, [vp]),
+        "ivx_stream": (vp, [vp]),
+        "ivx_grid_create": (i32, [vp, vp, f32, u32, u32, C.POINTER(vp)]),
+        "ivx_grid_destroy": (None, [vp]),
+        "ivx_grid_upload_dense": (i32, [vp, vp, vp, sz]),
+        "ivx_grid_download_dense": (i32, [vp, vp, vp, vp, vp, vp, sz]),
+        "ivx_grid_device_ptr": (vp, [vp, i32]),
+        "ivx_sdf_compile": (i32, [vp, sz, u32, vp, sz, C.POINTER(sz), vp, C.POINTER(u32)]),
+        "ivx_sdf_grid_shape": (i32, [vp, vp, vp]),
+        "ivx_sdf_sample": (i32, [vp, vp, sz, u32, vp, vp, C.c_uint8]),
+        "ivx_derive_state": (i32, [vp]),
+        "ivx_occupied_ranges": (i32, [vp, vp]),
+        "ivx_remesh": (i32, [vp, vp]),
+        "ivx_mesh_download": (i32, [vp, vp, vp, vp, vp, vp]),
+        "ivx_mesh_device_ptr": (vp, [vp, i32]),
+        "ivx_inertia": (i32, [vp, vp, vp]),
+        "ivx_label_regions": (i32, [vp, C.POINTER(u32)]),
+        "ivx_region_labels_download": (i32, [vp, vp, sz]),
+        "ivx_regions_describe": (i32, [vp, vp, vp, sz, C.POINTER(sz)]),
+        "ivx_halo_bytes": (sz, [vp]),
+        "ivx_halo_pack": (i32, [vp, i32, vp]),
+        "ivx_halo_unpack": (i32, [vp, i32, vp]),
+        "ivx_halo_clear": (i32, [vp, i32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(code):
+    if code != IVX_OK:
+        raise IvxError(code, lib().ivx_last_error().decode("utf-8", "replace"))
+
+
+def ptr(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)

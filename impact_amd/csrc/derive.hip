@@ -1,0 +1,232 @@
+// a4 — derived voxel/chunk state in one sweep: six-neighbour adjacency flags, face distributions,
+// chunk obscuredness, uniform-chunk demotion. One workgroup per chunk, one thread per (i,j) row.
+//
+// The reference computes this sequentially and statefully (engine/crates/impact_voxel/src/object.rs):
+//   update_internal_adjacencies               object.rs:2673-2756
+//   update_mutual_face_adjacencies            object.rs:2077-2528
+//   convert_to_non_uniform_if_uniform         object.rs:2530-2550
+//   face distributions / obscuredness         object.rs:2889-3040
+// Its fixed point is a pure function of voxel emptiness, which is what this kernel evaluates:
+//   * non-empty voxel: HAS_ADJACENT_<dir> = neighbour voxel (possibly in the adjacent chunk) is non-empty;
+//   * empty voxel: IS_EMPTY only — except on a chunk face whose own distribution is Mixed while the
+//     adjoining face of the neighbour chunk is Full, where `add_all_outward_adjacencies_for_face`
+//     (object.rs:2552-2600) sets the outward flag on every voxel of the face, empty ones included;
+//   * face distribution = Empty/Full/Mixed by the number of non-empty voxels on the face;
+//   * IS_OBSCURED_<dir> = adjoining face of the neighbour chunk is Full;
+//   * a chunk generated Uniform stays Uniform iff all six adjoining neighbour faces are Full.
+// The oracle replays the reference's sequential procedure; tests require bit-equal flags.
+//
+// Traffic: reads 1 B/voxel (sdf sign) + six neighbour faces, writes 1 B/voxel (flags). Emptiness of the
+// 16 voxels of a row is a 16-bit mask; the 18x18 halo of masks sits in LDS.
+#include "ivx_internal.hpp"
+
+namespace {
+
+struct DeriveParams {
+    uint32_t cx, cy, cz;
+};
+
+__device__ __forceinline__ uint32_t row_mask(uint4 s) {
+    // bit k set <=> voxel k non-empty <=> sd < 0 (sign bit of byte k)
+    uint32_t w[4] = {s.x, s.y, s.z, s.w};
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t sb = w[q] & 0x80808080u;
+        m |= (((sb >> 7) & 1u) | ((sb >> 14) & 2u) | ((sb >> 21) & 4u) | ((sb >> 28) & 8u)) << (4 * q);
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(256) void k_derive(GridView g, uint8_t* __restrict__ flags_out, ivx_chunk_info* __restrict__ info) {
+    __shared__ uint32_t occ[18][18];  // non-empty masks of rows (i+1, j+1); halo rows from neighbour chunks
+    __shared__ uint32_t cnt[12];      // own face non-empty counts [0..6), neighbour face non-empty counts [6..12)
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_chunks = g.cx * g.cy * g.cz;
+    const uint32_t chunk = ivx_xcd_remap(blockIdx.x, n_chunks);
+    const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
+    const int ti = tid >> 4, tj = tid & 15;
+
+    if (tid < 12) cnt[tid] = 0;
+    const size_t base = (size_t)chunk * IVX_CHUNK_VOXELS;
+    const uint32_t m = row_mask(*reinterpret_cast<const uint4*>(g.sdf + base + (size_t)tid * 16));
+    occ[ti + 1][tj + 1] = m;
+
+    // neighbour rows across the x and y faces: 16 threads each load one 16-byte row
+    uint32_t zlo = 0, zhi = 0;  // neighbour voxel across the z faces for this (i,j)
+    {
+        // z faces: one byte per thread from the adjacent chunk in k
+        if (ck > 0) zlo = ((uint8_t)g.sdf[base - IVX_CHUNK_VOXELS + tid * 16 + 15] >> 7) & 1u;
+        if (ck + 1 < (int)g.cz) zhi = ((uint8_t)g.sdf[base + IVX_CHUNK_VOXELS + tid * 16] >> 7) & 1u;
+    }
+    if (tid < 64) {
+        const int f = tid >> 4, r = tid & 15;  // f: 0 x-, 1 x+, 2 y-, 3 y+
+        uint32_t nm = 0;
+        if (f == 0) {
+            if (ci > 0) nm = row_mask(*reinterpret_cast<const uint4*>(g.sdf + base - (size_t)g.cy * g.cz * IVX_CHUNK_VOXELS + (15 * 256 + r * 16)));
+            else if (g.ghost_sdf[0]) nm = row_mask(*reinterpret_cast<const uint4*>(g.ghost_sdf[0] + ((size_t)(cj * g.cz + ck) * 256 + r * 16)));
+            occ[0][r + 1] = nm;
+        } else if (f == 1) {
+            if (ci + 1 < (int)g.cx) nm = row_mask(*reinterpret_cast<const uint4*>(g.sdf + base + (size_t)g.cy * g.cz * IVX_CHUNK_VOXELS + (r * 16)));
+            else if (g.ghost_sdf[1]) nm = row_mask(*reinterpret_cast<const uint4*>(g.ghost_sdf[1] + ((size_t)(cj * g.cz + ck) * 256 + r * 16)));
+            occ[17][r + 1] = nm;
+        } else if (f == 2) {
+            if (cj > 0) nm = row_mask(*reinterpret_cast<const uint4*>(g.sdf + base - (size_t)g.cz * IVX_CHUNK_VOXELS + (r * 256 + 15 * 16)));
+            occ[r + 1][0] = nm;
+        } else {
+            if (cj + 1 < (int)g.cy) nm = row_mask(*reinterpret_cast<const uint4*>(g.sdf + base + (size_t)g.cz * IVX_CHUNK_VOXELS + (r * 256)));
+            occ[r + 1][17] = nm;
+        }
+    }
+    __syncthreads();
+
+    // face populations: own faces and adjoining neighbour faces
+    {
+        const uint32_t pc = __popc(m);
+        if (ti == 0) atomicAdd(&cnt[0], pc);
+        if (ti == 15) atomicAdd(&cnt[1], pc);
+        if (tj == 0) atomicAdd(&cnt[2], pc);
+        if (tj == 15) atomicAdd(&cnt[3], pc);
+        const uint32_t z0 = __syncthreads_count((int)(m & 1u));
+        const uint32_t z1 = __syncthreads_count((int)((m >> 15) & 1u));
+        const uint32_t nz0 = __syncthreads_count((int)zlo);
+        const uint32_t nz1 = __syncthreads_count((int)zhi);
+        if (tid < 16) {
+            atomicAdd(&cnt[6], __popc(occ[0][tid + 1]));
+            atomicAdd(&cnt[7], __popc(occ[17][tid + 1]));
+            atomicAdd(&cnt[8], __popc(occ[tid + 1][0]));
+            atomicAdd(&cnt[9], __popc(occ[tid + 1][17]));
+        }
+        if (tid == 0) {
+            cnt[4] = z0;
+            cnt[5] = z1;
+            cnt[10] = nz0;
+            cnt[11] = nz1;
+        }
+    }
+    __syncthreads();
+
+    uint32_t own_fd[6], nbr_full = 0, own_mixed = 0;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+        uint32_t c = cnt[f];
+        own_fd[f] = c == 0 ? FD_EMPTY : (c == 256 ? FD_FULL : FD_MIXED);
+        if (own_fd[f] == FD_MIXED) own_mixed |= 1u << f;
+        if (cnt[6 + f] == 256) nbr_full |= 1u << f;
+    }
+
+    // flags for the 16 voxels of this row
+    const uint32_t xdn = occ[ti][tj + 1], xup = occ[ti + 2][tj + 1];
+    const uint32_t ydn = occ[ti + 1][tj], yup = occ[ti + 1][tj + 2];
+    const uint32_t zdn = (m << 1) | zlo, zup = (m >> 1) | (zhi << 15);
+    // outward flag for EMPTY voxels on a Mixed face whose neighbour face is Full (object.rs:2439-2454)
+    const uint32_t quirk = own_mixed & nbr_full;
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        uint32_t f;
+        if ((m >> k) & 1u) {
+            f = (((xdn >> k) & 1u) ? VF_X_DN : 0u) | (((xup >> k) & 1u) ? VF_X_UP : 0u) | (((ydn >> k) & 1u) ? VF_Y_DN : 0u) |
+                (((yup >> k) & 1u) ? VF_Y_UP : 0u) | (((zdn >> k) & 1u) ? VF_Z_DN : 0u) | (((zup >> k) & 1u) ? VF_Z_UP : 0u);
+        } else {
+            f = VF_EMPTY;
+            if (ti == 0 && (quirk & 1u)) f |= VF_X_DN;
+            if (ti == 15 && (quirk & 2u)) f |= VF_X_UP;
+            if (tj == 0 && (quirk & 4u)) f |= VF_Y_DN;
+            if (tj == 15 && (quirk & 8u)) f |= VF_Y_UP;
+            if (k == 0 && (quirk & 16u)) f |= VF_Z_DN;
+            if (k == 15 && (quirk & 32u)) f |= VF_Z_UP;
+        }
+        w[k >> 2] |= f << (8 * (k & 3));
+    }
+    *reinterpret_cast<uint4*>(flags_out + base + (size_t)tid * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+
+    if (tid == 0) {
+        ivx_chunk_info ci_ = info[chunk];
+        const uint32_t gen = ci_.gen_kind;
+        uint32_t kind = gen;
+        if (gen == KIND_UNIFORM && nbr_full != 0x3Fu) kind = KIND_NONUNIFORM;
+        ci_.kind = (uint8_t)kind;
+        if (kind == KIND_NONUNIFORM) {
+            // bit layout: X_DN,Y_DN,Z_DN,X_UP,Y_UP,Z_UP <- faces f = 2*dim+side
+            uint32_t ob = 0;
+#pragma unroll
+            for (int f = 0; f < 6; ++f)
+                if ((nbr_full >> f) & 1u) ob |= 1u << ((f & 1) * 3 + (f >> 1));
+            const bool only_empty = (cnt[0] | cnt[1] | cnt[2] | cnt[3] | cnt[4] | cnt[5]) == 0 && (ci_.flags & CF_ONLY_EMPTY);
+            ci_.flags = (uint8_t)(ob | (only_empty ? CF_ONLY_EMPTY : 0u));
+            uint32_t fd = 0;
+#pragma unroll
+            for (int f = 0; f < 6; ++f) fd |= own_fd[f] << (2 * f);
+            ci_.face_dist = (uint16_t)fd;
+            ci_.uniform_type = 0;
+        } else if (kind == KIND_UNIFORM) {
+            ci_.flags = 0;
+            ci_.face_dist = 0x555;
+            ci_.uniform_type = g.type[base];
+        } else {
+            ci_.flags = 0;
+            ci_.face_dist = 0;
+        }
+        info[chunk] = ci_;
+    }
+}
+
+// update_occupied_ranges (object.rs:1149-1280): tight [lo,hi) ranges of non-empty chunks and voxels.
+// out[0..6) chunk lo/hi per dim, out[6..12) voxel lo/hi per dim; caller pre-fills lo = UINT_MAX, hi = 0.
+__global__ __launch_bounds__(256) void k_occupied(GridView g, const uint8_t* __restrict__ flags, uint32_t* __restrict__ out) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_chunks = g.cx * g.cy * g.cz;
+    const uint32_t chunk = ivx_xcd_remap(blockIdx.x, n_chunks);
+    if (g.info[chunk].kind == KIND_VOID) return;
+    const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
+    const int ti = tid >> 4, tj = tid & 15;
+    uint4 f = *reinterpret_cast<const uint4*>(flags + (size_t)chunk * IVX_CHUNK_VOXELS + (size_t)tid * 16);
+    uint32_t w[4] = {f.x, f.y, f.z, f.w};
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (!((w[k >> 2] >> (8 * (k & 3))) & VF_EMPTY)) m |= 1u << k;
+    __shared__ uint32_t red[6];  // in-chunk min/max of i, j, k over non-empty voxels
+    if (tid < 6) red[tid] = (tid & 1) ? 0u : 16u;
+    __syncthreads();
+    if (m) {
+        atomicMin(&red[0], (uint32_t)ti);
+        atomicMax(&red[1], (uint32_t)ti + 1);
+        atomicMin(&red[2], (uint32_t)tj);
+        atomicMax(&red[3], (uint32_t)tj + 1);
+        atomicMin(&red[4], (uint32_t)(__ffs(m) - 1));
+        atomicMax(&red[5], (uint32_t)(32 - __clz(m)));
+    }
+    __syncthreads();
+    if (red[1] == 0) return;  // only empty voxels
+    if (tid < 12) {
+        // bounds are monotone, so a (possibly stale) plain read can only cause a redundant atomic
+        const uint32_t c[3] = {(uint32_t)ci, (uint32_t)cj, (uint32_t)ck};
+        const uint32_t d = (tid % 6) >> 1;
+        const bool is_max = tid & 1;
+        const uint32_t v = tid < 6 ? c[d] + (is_max ? 1u : 0u) : c[d] * 16u + red[tid - 6];
+        const uint32_t cur = __hip_atomic_load(&out[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (is_max) {
+            if (v > cur) atomicMax(&out[tid], v);
+        } else {
+            if (v < cur) atomicMin(&out[tid], v);
+        }
+    }
+}
+
+}  // namespace
+
+int ivx_launch_derive(ivx_grid* g) {
+    GridView v = ivx_view(g);
+    hipLaunchKernelGGL(k_derive, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, v, g->flags, g->info);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+int ivx_launch_occupied(ivx_grid* g, uint32_t* d_out) {
+    GridView v = ivx_view(g);
+    hipLaunchKernelGGL(k_occupied, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, v, g->flags, d_out);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}

@@ -1,0 +1,517 @@
+// C ABI entry points of libimpact_voxel_hip.so (see include/impact_voxel_hip.h for the contract and
+// the reference interfaces each function replaces). Host-side orchestration only: every compute call
+// launches the HIP kernels in this directory on the context's stream.
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "ivx_internal.hpp"
+
+static thread_local char g_error[512] = "";
+
+void ivx_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+
+template <class T>
+int dev_alloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) return IVX_OK;
+    IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    return IVX_OK;
+}
+
+int ensure_host_scratch(ivx_grid* g, size_t bytes) {
+    if (g->host_scratch_bytes >= bytes) return IVX_OK;
+    if (g->host_scratch) (void)hipHostFree(g->host_scratch);
+    g->host_scratch = nullptr;
+    g->host_scratch_bytes = 0;
+    IVX_HIP_CHECK(hipHostMalloc(&g->host_scratch, bytes, hipHostMallocDefault));
+    g->host_scratch_bytes = bytes;
+    return IVX_OK;
+}
+
+// Host<->device copies: the stream is idle at every API boundary, so plain blocking copies are the
+// simplest correct form (pageable host memory; no stream-ordered allocator involved).
+int d2h(ivx_grid* g, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return IVX_OK;
+    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    IVX_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return IVX_OK;
+}
+int h2d(ivx_grid* g, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return IVX_OK;
+    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    IVX_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return IVX_OK;
+}
+int ensure_dev_scratch(ivx_grid* g, size_t bytes) {
+    if (g->dev_scratch_bytes >= bytes) return IVX_OK;
+    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    if (g->dev_scratch) (void)hipFree(g->dev_scratch);
+    g->dev_scratch = nullptr;
+    g->dev_scratch_bytes = 0;
+    IVX_HIP_CHECK(hipMalloc(&g->dev_scratch, bytes));
+    g->dev_scratch_bytes = bytes;
+    return IVX_OK;
+}
+
+int ensure_mesh_capacity(ivx_grid* g, size_t nv, size_t ni, size_t ns) {
+    if (nv > g->vcap) {
+        size_t cap = std::max(nv, g->vcap * 2);
+        if (g->positions) (void)hipFree(g->positions);
+        if (g->normals) (void)hipFree(g->normals);
+        if (g->vertex_materials) (void)hipFree(g->vertex_materials);
+        g->positions = g->normals = nullptr;
+        g->vertex_materials = nullptr;
+        g->vcap = 0;
+        int rc;
+        if ((rc = dev_alloc(&g->positions, cap * 3))) return rc;
+        if ((rc = dev_alloc(&g->normals, cap * 3))) return rc;
+        if ((rc = dev_alloc(&g->vertex_materials, cap * 16))) return rc;
+        g->vcap = cap;
+    }
+    if (ni > g->icap) {
+        size_t cap = std::max(ni, g->icap * 2);
+        if (g->indices) (void)hipFree(g->indices);
+        if (g->index_materials) (void)hipFree(g->index_materials);
+        g->indices = nullptr;
+        g->index_materials = nullptr;
+        g->icap = 0;
+        int rc;
+        if ((rc = dev_alloc(&g->indices, cap))) return rc;
+        if ((rc = dev_alloc(&g->index_materials, cap * 8))) return rc;
+        g->icap = cap;
+    }
+    if (ns > g->scap) {
+        size_t cap = std::max(ns, g->scap * 2);
+        if (g->submeshes) (void)hipFree(g->submeshes);
+        g->submeshes = nullptr;
+        g->scap = 0;
+        int rc;
+        if ((rc = dev_alloc(&g->submeshes, cap))) return rc;
+        g->scap = cap;
+    }
+    return IVX_OK;
+}
+
+__global__ __launch_bounds__(256) void k_halo_pack(GridView g, uint32_t side, int8_t* __restrict__ out_sdf, uint8_t* __restrict__ out_type,
+                                                   ivx_chunk_info* __restrict__ out_info) {
+    const uint32_t col = blockIdx.x;  // cj*cz + ck
+    const uint32_t tid = threadIdx.x;
+    const uint32_t ci = side ? g.cx - 1 : 0u;
+    const uint32_t chunk = ci * g.cy * g.cz + col;
+    const size_t src = (size_t)chunk * IVX_CHUNK_VOXELS + ((side ? 15u : 0u) << 8) + tid;
+    out_sdf[(size_t)col * 256 + tid] = g.sdf[src];
+    out_type[(size_t)col * 256 + tid] = g.type[src];
+    if (tid == 0) out_info[col] = g.info[chunk];
+}
+
+}  // namespace
+
+int ivx_launch_halo_pack(ivx_grid* g, int side, void* buf) {
+    const size_t cols = (size_t)g->cc[1] * g->cc[2];
+    int8_t* o_sdf = static_cast<int8_t*>(buf);
+    uint8_t* o_type = static_cast<uint8_t*>(buf) + cols * 256;
+    ivx_chunk_info* o_info = reinterpret_cast<ivx_chunk_info*>(static_cast<uint8_t*>(buf) + cols * 512);
+    GridView v = ivx_view(g);
+    hipLaunchKernelGGL(k_halo_pack, dim3((uint32_t)cols), dim3(256), 0, g->ctx->stream, v, (uint32_t)side, o_sdf, o_type, o_info);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+extern "C" {
+
+const char* ivx_last_error(void) { return g_error; }
+
+int ivx_init(int device_id, void* stream, ivx_ctx** out) {
+    IVX_REQUIRE(out, IVX_ERR_INVALID, "ivx_init: null output pointer");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        ivx_set_error("ivx_init: no HIP device available (%s); this library has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+        return IVX_ERR_HIP;
+    }
+    IVX_REQUIRE(device_id >= 0 && device_id < count, IVX_ERR_INVALID, "ivx_init: device %d out of range (0..%d)", device_id, count - 1);
+    IVX_HIP_CHECK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    IVX_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        ivx_set_error("ivx_init: device %d is %s; this library is built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
+        return IVX_ERR_HIP;
+    }
+    ivx_ctx* c = new (std::nothrow) ivx_ctx();
+    IVX_REQUIRE(c, IVX_ERR_CAPACITY, "ivx_init: out of host memory");
+    c->device = device_id;
+    if (stream) {
+        c->stream = static_cast<hipStream_t>(stream);
+        c->own_stream = false;
+    } else {
+        hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (se != hipSuccess) {
+            ivx_set_error("ivx_init: hipStreamCreate failed: %s", hipGetErrorString(se));
+            delete c;
+            return IVX_ERR_HIP;
+        }
+        c->own_stream = true;
+    }
+    *out = c;
+    return IVX_OK;
+}
+
+void ivx_shutdown(ivx_ctx* c) {
+    if (!c) return;
+    (void)hipStreamSynchronize(c->stream);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int ivx_synchronize(ivx_ctx* c) {
+    IVX_REQUIRE(c, IVX_ERR_INVALID, "ivx_synchronize: null context");
+    IVX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return IVX_OK;
+}
+
+void* ivx_stream(ivx_ctx* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
+
+int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32_t x_chunk_offset, uint32_t global_x_chunks, ivx_grid** out) {
+    IVX_REQUIRE(c && cc && out, IVX_ERR_INVALID, "ivx_grid_create: null argument");
+    *out = nullptr;
+    IVX_REQUIRE(cc[0] > 0 && cc[1] > 0 && cc[2] > 0, IVX_ERR_INVALID, "ivx_grid_create: empty chunk grid");
+    IVX_REQUIRE(voxel_extent > 0.0f, IVX_ERR_INVALID, "ivx_grid_create: voxel extent must be positive");
+    const uint64_t n64 = (uint64_t)cc[0] * cc[1] * cc[2];
+    // GlobalRegionLabel packs the chunk index in 24 bits (split_detection.rs:1539-1571)
+    IVX_REQUIRE(n64 <= (1u << 24), IVX_ERR_CAPACITY, "ivx_grid_create: more than 2^24 chunks");
+    IVX_HIP_CHECK(hipSetDevice(c->device));
+    ivx_grid* g = new (std::nothrow) ivx_grid();
+    IVX_REQUIRE(g, IVX_ERR_CAPACITY, "ivx_grid_create: out of host memory");
+    memset(g, 0, sizeof(*g));
+    g->ctx = c;
+    for (int d = 0; d < 3; ++d) g->cc[d] = cc[d];
+    g->n_chunks = (uint32_t)n64;
+    g->n_vox = (size_t)n64 * IVX_CHUNK_VOXELS;
+    g->extent = voxel_extent;
+    g->x_off = x_chunk_offset;
+    g->gx = global_x_chunks ? global_x_chunks : cc[0];
+    const size_t cols = (size_t)cc[1] * cc[2];
+    int rc = IVX_OK;
+    auto A = [&](int r) {
+        if (rc == IVX_OK && r != IVX_OK) rc = r;
+    };
+    A(dev_alloc(&g->sdf, g->n_vox));
+    A(dev_alloc(&g->type, g->n_vox));
+    A(dev_alloc(&g->flags, g->n_vox));
+    A(dev_alloc(&g->llabel, g->n_vox));
+    A(dev_alloc(&g->info, (size_t)g->n_chunks));
+    for (int s = 0; s < 2; ++s) {
+        A(dev_alloc(&g->ghost_sdf[s], cols * 256));
+        A(dev_alloc(&g->ghost_type[s], cols * 256));
+        A(dev_alloc(&g->ghost_info[s], cols));
+    }
+    A(dev_alloc(&g->chunk_counts, (size_t)g->n_chunks * 2));
+    A(dev_alloc(&g->chunk_offsets, (size_t)g->n_chunks * 3 + 8));
+    g->partial_blocks = 2048;
+    A(dev_alloc(&g->partials, g->partial_blocks * 10 + 16));
+    A(dev_alloc(&g->rparent, (size_t)g->n_chunks * 256));
+    A(dev_alloc(&g->rcompid, (size_t)g->n_chunks * 256));
+    A(dev_alloc(&g->rscalar, (size_t)64));
+    A(dev_alloc(&g->ccl_scratch, (size_t)g->n_chunks * 2));
+    A(dev_alloc(&g->dens_dev, (size_t)256));
+    if (rc != IVX_OK) {
+        ivx_grid_destroy(g);
+        return rc;
+    }
+    if (hipMemsetAsync(g->info, 0, sizeof(ivx_chunk_info) * g->n_chunks, c->stream) != hipSuccess) {
+        ivx_set_error("ivx_grid_create: memset failed");
+        ivx_grid_destroy(g);
+        return IVX_ERR_HIP;
+    }
+    *out = g;
+    return IVX_OK;
+}
+
+void ivx_grid_destroy(ivx_grid* g) {
+    if (!g) return;
+    (void)hipStreamSynchronize(g->ctx->stream);
+    void* ptrs[] = {g->sdf, g->type, g->flags, g->llabel, g->info, g->ghost_sdf[0], g->ghost_sdf[1], g->ghost_type[0], g->ghost_type[1],
+                    g->ghost_info[0], g->ghost_info[1], g->chunk_counts, g->chunk_offsets, g->positions, g->normals, g->indices,
+                    g->index_materials, g->vertex_materials, g->submeshes, g->partials, g->rparent, g->rcompid, g->rscalar, g->ccl_scratch, g->dens_dev, g->dev_scratch};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (g->host_scratch) (void)hipHostFree(g->host_scratch);
+    delete g;
+}
+
+int ivx_grid_upload_dense(ivx_grid* g, const int8_t* sdf, const uint8_t* type, size_t n_voxels) {
+    IVX_REQUIRE(g && sdf && type, IVX_ERR_INVALID, "ivx_grid_upload_dense: null argument");
+    IVX_REQUIRE(n_voxels == g->n_vox, IVX_ERR_INVALID, "ivx_grid_upload_dense: expected %zu voxels, got %zu", g->n_vox, n_voxels);
+    int rc;
+    if ((rc = h2d(g, g->sdf, sdf, g->n_vox))) return rc;
+    if ((rc = h2d(g, g->type, type, g->n_vox))) return rc;
+    if ((rc = ivx_launch_classify(g))) return rc;
+    g->mesh_valid = 0;
+    g->regions_valid = 0;
+    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    return IVX_OK;
+}
+
+int ivx_grid_download_dense(ivx_grid* g, int8_t* sdf, uint8_t* type, uint8_t* flags, uint8_t* local_labels, ivx_chunk_info* info, size_t n_voxels) {
+    IVX_REQUIRE(g, IVX_ERR_INVALID, "ivx_grid_download_dense: null grid");
+    IVX_REQUIRE(n_voxels == g->n_vox, IVX_ERR_INVALID, "ivx_grid_download_dense: expected %zu voxels, got %zu", g->n_vox, n_voxels);
+    int rc;
+    if (sdf && (rc = d2h(g, sdf, g->sdf, g->n_vox))) return rc;
+    if (type && (rc = d2h(g, type, g->type, g->n_vox))) return rc;
+    if (flags && (rc = d2h(g, flags, g->flags, g->n_vox))) return rc;
+    if (local_labels && (rc = d2h(g, local_labels, g->llabel, g->n_vox))) return rc;
+    if (info && (rc = d2h(g, info, g->info, sizeof(ivx_chunk_info) * g->n_chunks))) return rc;
+    return IVX_OK;
+}
+
+void* ivx_grid_device_ptr(ivx_grid* g, int which) {
+    if (!g) return nullptr;
+    switch (which) {
+        case 0: return g->sdf;
+        case 1: return g->type;
+        case 2: return g->flags;
+        case 3: return g->llabel;
+        case 4: return g->info;
+        case 5: return g->rparent;
+        default: return nullptr;
+    }
+}
+
+int ivx_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* nodes, size_t n_nodes, uint32_t stack_size, const uint32_t grid_shape[3],
+                   const float shifted_grid_center[3], uint8_t voxel_type) {
+    IVX_REQUIRE(g && grid_shape && shifted_grid_center, IVX_ERR_INVALID, "ivx_sdf_sample: null argument");
+    IVX_REQUIRE(n_nodes == 0 || nodes, IVX_ERR_INVALID, "ivx_sdf_sample: null node array");
+    for (int d = 0; d < 3; ++d) {
+        const uint32_t cap = (d == 0 ? g->gx : g->cc[d]) * 16u;
+        IVX_REQUIRE(grid_shape[d] <= cap, IVX_ERR_INVALID, "ivx_sdf_sample: grid shape %u exceeds the chunk grid (%u voxels) along axis %d", grid_shape[d], cap, d);
+    }
+    // validate the node program against the stack the kernel will use
+    int depth = 0, max_depth = 0;
+    for (size_t i = 0; i < n_nodes; ++i) {
+        const uint32_t k = nodes[i].kind;
+        IVX_REQUIRE(k <= 9 && k != 6, IVX_ERR_INVALID, "ivx_sdf_sample: unsupported node kind %u", k);
+        if (k <= 2) max_depth = std::max(max_depth, ++depth);
+        else if (k >= 7) {
+            IVX_REQUIRE(depth >= 2, IVX_ERR_INVALID, "ivx_sdf_sample: malformed node program (combination without two operands)");
+            --depth;
+        } else if (k == 5) {
+            IVX_REQUIRE(depth >= 1, IVX_ERR_INVALID, "ivx_sdf_sample: malformed node program (scaling without operand)");
+        }
+    }
+    IVX_REQUIRE(n_nodes == 0 || depth == 1, IVX_ERR_INVALID, "ivx_sdf_sample: malformed node program (final stack depth %d)", depth);
+    IVX_REQUIRE((uint32_t)max_depth <= stack_size || n_nodes == 0, IVX_ERR_INVALID, "ivx_sdf_sample: stack_size %u < required %d", stack_size, max_depth);
+    int rc;
+    if ((rc = ensure_dev_scratch(g, std::max<size_t>(n_nodes, 1) * sizeof(ivx_sdf_processed_node)))) return rc;
+    if ((rc = h2d(g, g->dev_scratch, nodes, n_nodes * sizeof(ivx_sdf_processed_node)))) return rc;
+    rc = ivx_launch_sdf_sample(g, static_cast<const ivx_sdf_processed_node*>(g->dev_scratch), (uint32_t)n_nodes, (uint32_t)max_depth, grid_shape,
+                               shifted_grid_center, voxel_type);
+    if (rc) return rc;
+    g->mesh_valid = 0;
+    g->regions_valid = 0;
+    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    return IVX_OK;
+}
+
+int ivx_derive_state(ivx_grid* g) {
+    IVX_REQUIRE(g, IVX_ERR_INVALID, "ivx_derive_state: null grid");
+    int rc = ivx_launch_derive(g);
+    if (rc) return rc;
+    g->mesh_valid = 0;
+    g->regions_valid = 0;
+    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    return IVX_OK;
+}
+
+int ivx_occupied_ranges(ivx_grid* g, uint32_t out[12]) {
+    IVX_REQUIRE(g && out, IVX_ERR_INVALID, "ivx_occupied_ranges: null argument");
+    uint32_t init[12];
+    for (int i = 0; i < 12; ++i) init[i] = (i & 1) ? 0u : 0xFFFFFFFFu;
+    uint32_t* d = g->rscalar + 16;
+    int rc;
+    if ((rc = h2d(g, d, init, sizeof(init)))) return rc;
+    if ((rc = ivx_launch_occupied(g, d))) return rc;
+    if ((rc = d2h(g, out, d, sizeof(init)))) return rc;
+    if (out[1] == 0) {  // no non-empty voxel (object.rs:1177-1190)
+        for (int i = 0; i < 12; ++i) out[i] = 0;
+    } else {
+        out[0] += g->x_off;
+        out[1] += g->x_off;
+        out[6] += g->x_off * 16u;
+        out[7] += g->x_off * 16u;
+    }
+    return IVX_OK;
+}
+
+int ivx_remesh(ivx_grid* g, ivx_mesh_counts* out) {
+    IVX_REQUIRE(g && out, IVX_ERR_INVALID, "ivx_remesh: null argument");
+    int rc;
+    if ((rc = ivx_launch_sn_count(g))) return rc;
+    if ((rc = ivx_launch_sn_scan(g))) return rc;
+    uint32_t totals[3];
+    if ((rc = d2h(g, totals, g->chunk_offsets + 2 * (size_t)g->n_chunks, sizeof(totals)))) return rc;
+    if ((rc = ensure_mesh_capacity(g, totals[0], totals[1], totals[2]))) return rc;
+    if (totals[1] > 0 && (rc = ivx_launch_sn_emit(g))) return rc;
+    g->mesh_counts.n_vertices = totals[0];
+    g->mesh_counts.n_indices = totals[1];
+    g->mesh_counts.n_submeshes = totals[2];
+    g->mesh_counts.reserved = 0;
+    g->mesh_valid = 1;
+    *out = g->mesh_counts;
+    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    return IVX_OK;
+}
+
+int ivx_mesh_download(ivx_grid* g, float* positions, float* normals, uint32_t* indices, uint8_t* index_materials, ivx_submesh* submeshes) {
+    IVX_REQUIRE(g, IVX_ERR_INVALID, "ivx_mesh_download: null grid");
+    IVX_REQUIRE(g->mesh_valid, IVX_ERR_STATE, "ivx_mesh_download: call ivx_remesh first");
+    const size_t nv = g->mesh_counts.n_vertices, ni = g->mesh_counts.n_indices, ns = g->mesh_counts.n_submeshes;
+    int rc;
+    if (positions && (rc = d2h(g, positions, g->positions, nv * 12))) return rc;
+    if (normals && (rc = d2h(g, normals, g->normals, nv * 12))) return rc;
+    if (indices && (rc = d2h(g, indices, g->indices, ni * 4))) return rc;
+    if (index_materials && (rc = d2h(g, index_materials, g->index_materials, ni * 8))) return rc;
+    if (submeshes && (rc = d2h(g, submeshes, g->submeshes, ns * sizeof(ivx_submesh)))) return rc;
+    return IVX_OK;
+}
+
+void* ivx_mesh_device_ptr(ivx_grid* g, int which) {
+    if (!g || !g->mesh_valid) return nullptr;
+    switch (which) {
+        case 0: return g->positions;
+        case 1: return g->normals;
+        case 2: return g->indices;
+        case 3: return g->index_materials;
+        case 4: return g->submeshes;
+        default: return nullptr;
+    }
+}
+
+int ivx_inertia(ivx_grid* g, const float densities[256], ivx_moments* out) {
+    IVX_REQUIRE(g && densities && out, IVX_ERR_INVALID, "ivx_inertia: null argument");
+    double* out_dev = g->partials + g->partial_blocks * 10;
+    int rc;
+    if ((rc = h2d(g, g->dens_dev, densities, 256 * sizeof(float)))) return rc;
+    if ((rc = ivx_launch_inertia(g, g->dens_dev, out_dev))) return rc;
+    if ((rc = d2h(g, out->m64, out_dev, 10 * sizeof(double)))) return rc;
+    for (int i = 0; i < 10; ++i) out->m32[i] = (float)out->m64[i];
+    out->reserved[0] = out->reserved[1] = 0;
+    return IVX_OK;
+}
+
+int ivx_label_regions(ivx_grid* g, uint32_t* region_count) {
+    IVX_REQUIRE(g && region_count, IVX_ERR_INVALID, "ivx_label_regions: null argument");
+    int rc;
+    if ((rc = ivx_launch_ccl_local(g))) return rc;
+    if ((rc = ivx_launch_ccl_merge(g))) return rc;
+    if ((rc = ivx_launch_ccl_resolve(g))) return rc;
+    uint32_t sc[2];
+    if ((rc = d2h(g, sc, g->rscalar, sizeof(sc)))) return rc;
+    IVX_REQUIRE((sc[1] & 1u) == 0, IVX_ERR_CAPACITY,
+                "ivx_label_regions: a chunk has more than 254 local regions (the reference's CHUNK_MAX_REGIONS limit, split_detection.rs:145-157)");
+    g->region_count = sc[0];
+    g->regions_valid = 1;
+    *region_count = sc[0];
+    return IVX_OK;
+}
+
+int ivx_region_labels_download(ivx_grid* g, uint32_t* labels, size_t n_voxels) {
+    IVX_REQUIRE(g && labels, IVX_ERR_INVALID, "ivx_region_labels_download: null argument");
+    IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "ivx_region_labels_download: call ivx_label_regions first");
+    IVX_REQUIRE(n_voxels == g->n_vox, IVX_ERR_INVALID, "ivx_region_labels_download: expected %zu voxels, got %zu", g->n_vox, n_voxels);
+    int rc;
+    if ((rc = ensure_dev_scratch(g, g->n_vox * sizeof(uint32_t)))) return rc;
+    if ((rc = ivx_launch_ccl_dense_labels(g, static_cast<uint32_t*>(g->dev_scratch)))) return rc;
+    return d2h(g, labels, g->dev_scratch, g->n_vox * sizeof(uint32_t));
+}
+
+int ivx_regions_describe(ivx_grid* g, const float densities[256], ivx_region_desc* out, size_t cap, size_t* n_out) {
+    IVX_REQUIRE(g && densities && out && n_out, IVX_ERR_INVALID, "ivx_regions_describe: null argument");
+    IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "ivx_regions_describe: call ivx_label_regions first");
+    const uint32_t n = g->region_count;
+    *n_out = n;
+    IVX_REQUIRE(n <= cap, IVX_ERR_CAPACITY, "ivx_regions_describe: %u regions exceed capacity %zu", n, cap);
+    if (n == 0) return IVX_OK;
+    const size_t bytes = ivx_region_stats_bytes(n);
+    int rc;
+    if ((rc = ensure_dev_scratch(g, bytes))) return rc;
+    if ((rc = h2d(g, g->dens_dev, densities, 256 * sizeof(float)))) return rc;
+    if ((rc = ivx_launch_region_stats(g, g->dens_dev, g->dev_scratch, n))) return rc;
+    std::vector<char> h(bytes);
+    if ((rc = d2h(g, h.data(), g->dev_scratch, bytes))) return rc;
+    const char* p = h.data();
+    const unsigned long long* count = reinterpret_cast<const unsigned long long*>(p);
+    p += 8 * (size_t)n;
+    const double* mom = reinterpret_cast<const double*>(p);
+    p += 80 * (size_t)n;
+    const uint32_t* lo = reinterpret_cast<const uint32_t*>(p);
+    p += 12 * (size_t)n;
+    const uint32_t* hi = reinterpret_cast<const uint32_t*>(p);
+    p += 12 * (size_t)n;
+    const uint32_t* nu = reinterpret_cast<const uint32_t*>(p);
+    p += 4 * (size_t)n;
+    const uint32_t* ch = reinterpret_cast<const uint32_t*>(p);
+    p += 4 * (size_t)n;
+    const uint32_t* root = reinterpret_cast<const uint32_t*>(p);
+    const double e = (double)g->extent, e2 = e * e, e3 = e2 * e, e4 = e2 * e2, e5 = e4 * e;
+    for (uint32_t r = 0; r < n; ++r) {
+        ivx_region_desc& o = out[r];
+        o.root_chunk = root[r] >> 8;
+        o.root_region = root[r] & 255u;
+        o.voxel_count = count[r];
+        for (int d3 = 0; d3 < 3; ++d3) {
+            o.lo[d3] = lo[3 * r + d3];
+            o.hi[d3] = hi[3 * r + d3];
+        }
+        o.non_uniform_chunk_count = nu[r];
+        o.chunk_count = ch[r];
+        for (int q = 0; q < 10; ++q) {
+            const double f = q == 0 ? e3 : (q <= 3 ? 0.5 * e4 : (q <= 6 ? (1.0 / 3.0) * e5 : 0.25 * e5));
+            o.moments[q] = mom[10 * (size_t)r + q] * f;
+        }
+    }
+    return IVX_OK;
+}
+
+size_t ivx_halo_bytes(ivx_grid* g) {
+    if (!g) return 0;
+    const size_t cols = (size_t)g->cc[1] * g->cc[2];
+    return cols * (256 + 256 + sizeof(ivx_chunk_info));
+}
+
+int ivx_halo_pack(ivx_grid* g, int side, void* device_buf) {
+    IVX_REQUIRE(g && device_buf && (side == 0 || side == 1), IVX_ERR_INVALID, "ivx_halo_pack: bad argument");
+    int rc = ivx_launch_halo_pack(g, side, device_buf);
+    if (rc) return rc;
+    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    return IVX_OK;
+}
+
+int ivx_halo_unpack(ivx_grid* g, int side, const void* device_buf) {
+    IVX_REQUIRE(g && device_buf && (side == 0 || side == 1), IVX_ERR_INVALID, "ivx_halo_unpack: bad argument");
+    const size_t cols = (size_t)g->cc[1] * g->cc[2];
+    hipStream_t s = g->ctx->stream;
+    const uint8_t* b = static_cast<const uint8_t*>(device_buf);
+    IVX_HIP_CHECK(hipMemcpyAsync(g->ghost_sdf[side], b, cols * 256, hipMemcpyDeviceToDevice, s));
+    IVX_HIP_CHECK(hipMemcpyAsync(g->ghost_type[side], b + cols * 256, cols * 256, hipMemcpyDeviceToDevice, s));
+    IVX_HIP_CHECK(hipMemcpyAsync(g->ghost_info[side], b + cols * 512, cols * sizeof(ivx_chunk_info), hipMemcpyDeviceToDevice, s));
+    g->has_ghost[side] = 1;
+    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    return IVX_OK;
+}
+
+int ivx_halo_clear(ivx_grid* g, int side) {
+    IVX_REQUIRE(g && (side == 0 || side == 1), IVX_ERR_INVALID, "ivx_halo_clear: bad argument");
+    g->has_ghost[side] = 0;
+    return IVX_OK;
+}
+
+}  // extern "C"

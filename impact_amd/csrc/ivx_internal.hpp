@@ -1,0 +1,159 @@
+// Internal definitions shared by the HIP translation units of libimpact_voxel_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/impact_voxel_hip.h"
+
+#define IVX_CHUNK 16
+#define IVX_CHUNK_VOXELS 4096
+
+// VoxelFlags (impact_voxel/src/lib.rs:75-101)
+#define VF_EMPTY 0x01u
+#define VF_X_DN 0x04u
+#define VF_Y_DN 0x08u
+#define VF_Z_DN 0x10u
+#define VF_X_UP 0x20u
+#define VF_Y_UP 0x40u
+#define VF_Z_UP 0x80u
+// VoxelChunkFlags (impact_voxel/src/object.rs:163-188)
+#define CF_ONLY_EMPTY 0x40u
+#define CF_FULLY_OBSCURED 0x3Fu
+#define KIND_VOID 0
+#define KIND_UNIFORM 1
+#define KIND_NONUNIFORM 2
+#define FD_EMPTY 0
+#define FD_FULL 1
+#define FD_MIXED 2
+#define TYPE_DUMMY 255
+#define SD_VOID_LIMIT 100
+
+struct ivx_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+};
+
+struct ivx_grid {
+    ivx_ctx* ctx;
+    uint32_t cc[3];
+    uint32_t n_chunks;
+    size_t n_vox;
+    float extent;
+    uint32_t x_off, gx;  // slab offset in chunks and global chunk count along x
+    // planes
+    int8_t* sdf;
+    uint8_t* type;
+    uint8_t* flags;
+    uint8_t* llabel;
+    ivx_chunk_info* info;
+    // ghost x-face layers [side]: face planes in (cj,ck)-tiled (j,k) order + chunk info of the layer
+    int8_t* ghost_sdf[2];
+    uint8_t* ghost_type[2];
+    ivx_chunk_info* ghost_info[2];
+    uint32_t* ghost_rlabel[2];  // global region node of the neighbour's face voxel (0xFFFFFFFF empty)
+    int has_ghost[2];
+    // mesh state
+    uint32_t* chunk_counts;   // [n_chunks*2]: vertex count, index count
+    uint32_t* chunk_offsets;  // [n_chunks*2 + 4]: exclusive vertex/index offsets, then totals v,i,submeshes
+    float* positions;
+    float* normals;
+    uint32_t* indices;
+    uint8_t* index_materials;
+    uint8_t* vertex_materials;  // 16 B per vertex scratch
+    ivx_submesh* submeshes;
+    size_t vcap, icap, scap;
+    ivx_mesh_counts mesh_counts;
+    int mesh_valid;
+    // inertia / reductions scratch
+    double* partials;  // [n_blocks*16]
+    size_t partial_blocks;
+    // regions
+    uint32_t* rparent;   // [n_chunks*256] global DSF parent per (chunk, local region)
+    uint32_t* rcompid;   // [n_chunks*256] component id per node (after resolve)
+    uint32_t* rscalar;   // small scalars: [0] region count, [1] error flags
+    uint32_t* ccl_scratch;  // [2*n_chunks]: per-chunk root counts and exclusive offsets
+    uint32_t region_count;
+    int regions_valid;
+    float* dens_dev;        // [256] voxel type densities
+    void* dev_scratch;      // grown on demand (node programs, dense label export, region statistics)
+    size_t dev_scratch_bytes;
+    // host pinned scratch
+    void* host_scratch;
+    size_t host_scratch_bytes;
+};
+
+void ivx_set_error(const char* fmt, ...);
+
+#define IVX_HIP_CHECK(expr)                                                                          \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            ivx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return IVX_ERR_HIP;                                                                      \
+        }                                                                                            \
+    } while (0)
+
+#define IVX_REQUIRE(cond, code, ...)     \
+    do {                                 \
+        if (!(cond)) {                   \
+            ivx_set_error(__VA_ARGS__);  \
+            return code;                 \
+        }                                \
+    } while (0)
+
+// XCD-aware bijective block -> work-item remap: blocks b and b+8 share an XCD (its L2), so give each
+// XCD a contiguous range of chunks (neighbouring chunks then share an L2).
+__device__ __forceinline__ uint32_t ivx_xcd_remap(uint32_t b, uint32_t n) {
+    uint32_t q = n >> 3, r = n & 7u, x = b & 7u, p = b >> 3;
+    uint32_t base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + p;
+}
+
+struct GridView {
+    uint32_t cx, cy, cz;
+    const int8_t* sdf;
+    const uint8_t* type;
+    const int8_t* ghost_sdf[2];
+    const uint8_t* ghost_type[2];
+    const ivx_chunk_info* info;
+    const ivx_chunk_info* ghost_info[2];
+};
+
+static inline GridView ivx_view(const ivx_grid* g) {
+    GridView v;
+    v.cx = g->cc[0];
+    v.cy = g->cc[1];
+    v.cz = g->cc[2];
+    v.sdf = g->sdf;
+    v.type = g->type;
+    v.info = g->info;
+    for (int s = 0; s < 2; ++s) {
+        v.ghost_sdf[s] = g->has_ghost[s] ? g->ghost_sdf[s] : nullptr;
+        v.ghost_type[s] = g->has_ghost[s] ? g->ghost_type[s] : nullptr;
+        v.ghost_info[s] = g->has_ghost[s] ? g->ghost_info[s] : nullptr;
+    }
+    return v;
+}
+
+// kernels (one launcher per stage; all asynchronous on ctx->stream)
+int ivx_launch_classify(ivx_grid* g);
+int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, uint32_t n_nodes, uint32_t stack_size,
+                          const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type);
+int ivx_launch_derive(ivx_grid* g);
+int ivx_launch_occupied(ivx_grid* g, uint32_t* d_out);
+int ivx_launch_sn_count(ivx_grid* g);
+int ivx_launch_sn_scan(ivx_grid* g);
+int ivx_launch_sn_emit(ivx_grid* g);
+int ivx_launch_inertia(ivx_grid* g, const float* d_dens, double* d_out10);
+int ivx_launch_ccl_local(ivx_grid* g);
+int ivx_launch_ccl_merge(ivx_grid* g);
+int ivx_launch_ccl_resolve(ivx_grid* g);
+int ivx_launch_ccl_dense_labels(ivx_grid* g, uint32_t* d_labels);
+int ivx_launch_halo_pack(ivx_grid* g, int side, void* buf);
+int ivx_launch_region_stats(ivx_grid* g, const float* d_dens, void* d_buf, uint32_t n);
+static inline size_t ivx_region_stats_bytes(uint32_t n) { return (size_t)n * (8 + 80 + 12 + 12 + 4 + 4 + 4); }

@@ -1,0 +1,312 @@
+// a3 — SDF sample: atomic SDF graph -> quantised voxels + chunk classification, one workgroup per
+// 16^3 chunk, one thread per (i,j) row of 16 voxels along k.
+//
+// Reference behaviour reproduced (engine/crates/impact_voxel/src/):
+//   SDFVoxelGenerator::generate_chunk                 generation.rs:293-371
+//   SDFGenerator::compute_signed_distances_for_block  generation/sdf/atomic.rs:633-875
+//   update_signed_distances_for_block[_packed]        generation/sdf/atomic.rs:1601-1658
+//   block test positions                              generation/sdf/atomic.rs:1661-1797
+//   primitives / smooth ops                           atomic.rs:1183-1291, generation/sdf.rs:47-102
+//   VoxelSignedDistance::from_f32                     lib.rs:197-201
+//   VoxelChunk::create_for_generated_voxels           object.rs:1890-1964
+//
+// Mapping to CDNA4: the reference's per-block "stack machine" of 4096-float arrays lives in LDS as
+// stack[level][k][thread] (bank-conflict free: consecutive lanes hit consecutive banks); each thread
+// only ever touches its own 16-voxel row, so the only barriers are around the 14 block test positions
+// of a combination node. Positions advance along k by repeated `pos += dz` exactly like the reference
+// loop, which keeps results bit-identical (no FMA: built with -ffp-contract=off; IEEE sqrt/div).
+// The row is written back as one 16-byte store per plane per thread (4 KiB contiguous per workgroup).
+// HBM traffic: 2 B/voxel written (sdf + type), nothing read.
+#include "ivx_internal.hpp"
+
+namespace {
+
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 add(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 scale(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ float len3(V3 a) { return sqrtf(dot3(a, a)); }
+__device__ __forceinline__ float min_rs(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float max_rs(float a, float b) { return (b > a) ? b : a; }
+__device__ __forceinline__ bool sneg(float f) { return (__float_as_uint(f) >> 31) != 0; }
+__device__ __forceinline__ uint32_t negmask(V3 a) { return (sneg(a.x) ? 1u : 0u) | (sneg(a.y) ? 2u : 0u) | (sneg(a.z) ? 4u : 0u); }
+
+struct Box {
+    V3 lo, hi;
+};
+// impact_geometry/src/axis_aligned_box.rs:253-268
+__device__ __forceinline__ bool contains_box(Box self, Box o) { return (negmask(sub(o.lo, self.lo)) | negmask(sub(self.hi, o.hi))) == 0; }
+__device__ __forceinline__ bool lies_outside(Box self, Box o) { return (negmask(sub(o.hi, self.lo)) | negmask(sub(self.hi, o.lo))) != 0; }
+
+// glam Mat4::transform_point3a order: ((c0*x + c1*y) + c2*z) + c3
+__device__ __forceinline__ V3 xform_point(const float* m, V3 p) {
+    V3 r = scale(mk(m[0], m[1], m[2]), p.x);
+    r = add(scale(mk(m[4], m[5], m[6]), p.y), r);
+    r = add(scale(mk(m[8], m[9], m[10]), p.z), r);
+    r = add(mk(m[12], m[13], m[14]), r);
+    return r;
+}
+// axis_aligned_box.rs:350-366
+__device__ __forceinline__ Box aabb_of_transformed(Box b, const float* m) {
+    V3 c = xform_point(m, scale(add(b.lo, b.hi), 0.5f));
+    V3 h = scale(sub(b.hi, b.lo), 0.5f);
+    V3 a0 = mk(fabsf(m[0]), fabsf(m[1]), fabsf(m[2]));
+    V3 a1 = mk(fabsf(m[4]), fabsf(m[5]), fabsf(m[6]));
+    V3 a2 = mk(fabsf(m[8]), fabsf(m[9]), fabsf(m[10]));
+    V3 he = add(add(scale(a0, h.x), scale(a1, h.y)), scale(a2, h.z));
+    return {sub(c, he), add(c, he)};
+}
+
+// generation/sdf.rs:89-92
+__device__ __forceinline__ float smooth_union(float d1, float d2, float s, float q) {
+    float h = max_rs(s - fabsf(d1 - d2), 0.0f);
+    return min_rs(d1, d2) - (h * h) * q;
+}
+__device__ __forceinline__ float combine(uint32_t kind, float a, float b, float s, float q) {
+    if (kind == 7u) return s == 0.0f ? min_rs(a, b) : smooth_union(a, b, s, q);
+    if (kind == 8u) return s == 0.0f ? max_rs(a, -b) : -smooth_union(-a, b, s, q);
+    return s == 0.0f ? max_rs(a, b) : -smooth_union(-a, -b, s, q);
+}
+
+// lib.rs:197-201: (v * 50.0) as i8 — truncate toward zero, saturate, NaN -> 0
+__device__ __forceinline__ int sd_from_f32(float v) {
+    float s = v * 50.0f;
+    if (s != s) return 0;
+    if (s >= 127.0f) return 127;
+    if (s <= -128.0f) return -128;
+    return (int)s;
+}
+
+struct SampleParams {
+    uint32_t cx, cy, cz, x_off;
+    uint32_t shape[3];
+    float shifted_center[3];
+    uint32_t n_nodes, stack_size;
+    uint32_t voxel_type;
+};
+
+__device__ __forceinline__ uint4 pack16(const int* v) {
+    uint32_t w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        w[q] = (uint32_t)(v[4 * q] & 0xFF) | ((uint32_t)(v[4 * q + 1] & 0xFF) << 8) | ((uint32_t)(v[4 * q + 2] & 0xFF) << 16) |
+               ((uint32_t)(v[4 * q + 3] & 0xFF) << 24);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Tail shared by sampling and classification (generation.rs:327-371 + object.rs:1890-1964): given the
+// thread's 16 quantised distances (and types), classify the chunk, canonicalise void chunks to
+// maximally-outside voxels (the reference drops their data, object/sdf.rs:486-489) and store.
+__device__ __forceinline__ void classify_and_store(int* sd, uint4 types, bool types_uniform_in, uint8_t first_type, int8_t* sdf_out,
+                                                   uint8_t* type_out, ivx_chunk_info* info_out, uint32_t chunk, uint32_t tid,
+                                                   bool set_type, uint32_t voxel_type) {
+    bool any_nonempty = false, any_nonvoid = false, all_inside = true;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        any_nonempty |= sd[k] < 0;
+        any_nonvoid |= sd[k] <= SD_VOID_LIMIT;
+        all_inside &= sd[k] == -128;
+    }
+    int only_empty = !__syncthreads_or(any_nonempty ? 1 : 0);
+    int is_void = !__syncthreads_or(any_nonvoid ? 1 : 0);
+    int uniform = __syncthreads_and((all_inside && types_uniform_in) ? 1 : 0);
+    uint32_t kind = is_void ? KIND_VOID : ((!only_empty && uniform) ? KIND_UNIFORM : KIND_NONUNIFORM);
+    if (is_void) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sd[k] = 127;
+        types = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    } else if (set_type) {
+        // SameVoxelTypeGenerator: every voxel of a chunk with >=1 non-empty voxel gets the type,
+        // all-empty chunks keep VoxelType::dummy() (generation.rs:348-365, voxel_type.rs:88-96)
+        uint32_t t = only_empty ? 0xFFFFFFFFu : voxel_type * 0x01010101u;
+        types = make_uint4(t, t, t, t);
+        first_type = only_empty ? (uint8_t)TYPE_DUMMY : (uint8_t)voxel_type;
+    }
+    size_t base = (size_t)chunk * IVX_CHUNK_VOXELS + (size_t)tid * 16;
+    *reinterpret_cast<uint4*>(sdf_out + base) = pack16(sd);
+    *reinterpret_cast<uint4*>(type_out + base) = types;
+    if (tid == 0) {
+        ivx_chunk_info ci;
+        ci.kind = (uint8_t)kind;
+        ci.gen_kind = (uint8_t)kind;
+        ci.flags = (kind == KIND_NONUNIFORM && only_empty) ? (uint8_t)CF_ONLY_EMPTY : (uint8_t)0;
+        ci.uniform_type = kind == KIND_UNIFORM ? first_type : (uint8_t)0;
+        ci.face_dist = 0;
+        ci.region_count = 0;
+        ci.boundary_region_count = 0;
+        info_out[chunk] = ci;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sdf_sample(SampleParams p, const ivx_sdf_processed_node* __restrict__ nodes,
+                                                    int8_t* __restrict__ sdf_out, uint8_t* __restrict__ type_out,
+                                                    ivx_chunk_info* __restrict__ info_out) {
+    extern __shared__ float stack[];  // [stack_size][16][256]
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_chunks = p.cx * p.cy * p.cz;
+    const uint32_t chunk = ivx_xcd_remap(blockIdx.x, n_chunks);
+    const uint32_t ck = chunk % p.cz, cj = (chunk / p.cz) % p.cy, ci = chunk / (p.cz * p.cy);
+    const uint32_t oi = (ci + p.x_off) * 16u, oj = cj * 16u, ok = ck * 16u;
+    const uint32_t ti = tid >> 4, tj = tid & 15u;
+
+    int sd[16];
+    if (p.n_nodes == 0 || oi >= p.shape[0] || oj >= p.shape[1] || ok >= p.shape[2]) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sd[k] = 127;
+        classify_and_store(sd, make_uint4(0, 0, 0, 0), true, 0, sdf_out, type_out, info_out, chunk, tid, true, p.voxel_type);
+        return;
+    }
+
+    const V3 origin_root = sub(mk((float)oi, (float)oj, (float)ok), mk(p.shifted_center[0], p.shifted_center[1], p.shifted_center[2]));
+    const Box block{origin_root, add(origin_root, mk(16.0f, 16.0f, 16.0f))};
+
+    uint32_t top = 0;
+    for (uint32_t n = 0; n < p.n_nodes; ++n) {
+        const ivx_sdf_processed_node* nd = nodes + n;
+        const uint32_t kind = nd->kind;
+        if (kind <= 2u) {
+            float* d = stack + (size_t)top * IVX_CHUNK_VOXELS + tid;
+            const float margin = nd->margin;
+            const Box bn = aabb_of_transformed(block, nd->transform);
+            const Box dom{mk(nd->domain_lo[0], nd->domain_lo[1], nd->domain_lo[2]), mk(nd->domain_hi[0], nd->domain_hi[1], nd->domain_hi[2])};
+            V3 ih;
+            if (kind == 0u) {
+                float e = nd->a * 0.57735026f + (-margin);
+                ih = mk(e, e, e);
+            } else if (kind == 1u) {
+                float e = nd->b * 0.57735026f + (-margin);
+                ih = mk(e, e + nd->a, e);
+            } else {
+                ih = mk(nd->a + (-margin), nd->b + (-margin), nd->c + (-margin));
+            }
+            const Box interior{mk(-ih.x, -ih.y, -ih.z), ih};
+            if (lies_outside(dom, bn)) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) d[k * 256] = margin;
+            } else if (contains_box(interior, bn)) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) d[k * 256] = -margin;
+            } else {
+                const float* m = nd->transform;
+                const V3 origin = xform_point(m, origin_root);
+                const V3 dx = mk(m[0], m[1], m[2]), dy = mk(m[4], m[5], m[6]), dz = mk(m[8], m[9], m[10]);
+                const V3 opx = add(origin, scale(dx, (float)ti));
+                V3 pos = add(opx, scale(dy, (float)tj));
+                const float pa = nd->a, pb = nd->b, pc = nd->c;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    float v;
+                    if (kind == 0u) {
+                        v = len3(pos) - pa;
+                    } else if (kind == 1u) {
+                        V3 q = pos;
+                        float c = q.y;
+                        if (c < -pa) c = -pa;
+                        if (c > pa) c = pa;
+                        q.y -= c;
+                        v = len3(q) - pb;
+                    } else {
+                        V3 q = mk(fabsf(pos.x) - pa, fabsf(pos.y) - pb, fabsf(pos.z) - pc);
+                        V3 qp = mk(max_rs(q.x, 0.0f), max_rs(q.y, 0.0f), max_rs(q.z, 0.0f));
+                        v = len3(qp) + min_rs(max_rs(max_rs(q.x, q.y), q.z), 0.0f);
+                    }
+                    d[k * 256] = v;
+                    pos = add(pos, dz);
+                }
+            }
+            top += 1;
+        } else if (kind == 5u) {
+            float* d = stack + (size_t)(top - 1) * IVX_CHUNK_VOXELS + tid;
+            const float s = nd->a;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) d[k * 256] *= s;
+        } else if (kind >= 7u) {
+            top -= 1;
+            float* d1 = stack + (size_t)(top - 1) * IVX_CHUNK_VOXELS;
+            const float* d2 = stack + (size_t)top * IVX_CHUNK_VOXELS;
+            const float s = nd->a, q = nd->b, margin = nd->margin;
+            const Box bn = aabb_of_transformed(block, nd->transform);
+            const Box dom{mk(nd->domain_lo[0], nd->domain_lo[1], nd->domain_lo[2]), mk(nd->domain_hi[0], nd->domain_hi[1], nd->domain_hi[2])};
+            bool apply = !lies_outside(dom, bn);
+            if (!apply) {  // workgroup-uniform branch
+                __syncthreads();
+                // distinct flat indices of the 26 test positions: 8 corners + 6 face centres
+                const int TI[14] = {0, 15, 0, 0, 15, 15, 0, 15, 0, 15, 8, 8, 8, 8};
+                const int TJ[14] = {0, 0, 15, 0, 15, 0, 15, 15, 8, 8, 0, 15, 8, 8};
+                const int TK[14] = {0, 0, 0, 15, 0, 15, 15, 15, 8, 8, 8, 8, 0, 15};
+                bool all_pass = true;
+#pragma unroll
+                for (int t = 0; t < 14; ++t) {
+                    int off = TK[t] * 256 + (TI[t] * 16 + TJ[t]);
+                    all_pass = all_pass && (combine(kind, d1[off], d2[off], s, q) >= margin);
+                }
+                apply = !all_pass;
+                __syncthreads();
+            }
+            if (apply) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) d1[k * 256 + tid] = combine(kind, d1[k * 256 + tid], d2[k * 256 + tid], s, q);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        float v = stack[k * 256 + tid];
+        bool in_grid = (oi + ti) < p.shape[0] && (oj + tj) < p.shape[1] && (ok + (uint32_t)k) < p.shape[2];
+        sd[k] = in_grid ? sd_from_f32(v) : 127;
+    }
+    classify_and_store(sd, make_uint4(0, 0, 0, 0), true, 0, sdf_out, type_out, info_out, chunk, tid, true, p.voxel_type);
+}
+
+// Classification of uploaded dense voxels (ChunkedVoxelGenerator contract, generation.rs:41-67).
+__global__ __launch_bounds__(256) void k_classify(uint32_t n_chunks, int8_t* __restrict__ sdf, uint8_t* __restrict__ type,
+                                                  ivx_chunk_info* __restrict__ info) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t chunk = ivx_xcd_remap(blockIdx.x, n_chunks);
+    size_t base = (size_t)chunk * IVX_CHUNK_VOXELS + (size_t)tid * 16;
+    uint4 s = *reinterpret_cast<const uint4*>(sdf + base);
+    uint4 t = *reinterpret_cast<const uint4*>(type + base);
+    const uint8_t first_type = type[(size_t)chunk * IVX_CHUNK_VOXELS];
+    uint32_t sw[4] = {s.x, s.y, s.z, s.w};
+    int sd[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sd[k] = (int)(int8_t)((sw[k >> 2] >> (8 * (k & 3))) & 0xFF);
+    uint32_t ft = first_type * 0x01010101u;
+    bool types_uniform = t.x == ft && t.y == ft && t.z == ft && t.w == ft;
+    classify_and_store(sd, t, types_uniform, first_type, sdf, type, info, chunk, tid, false, 0);
+}
+
+}  // namespace
+
+int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, uint32_t n_nodes, uint32_t stack_size,
+                          const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type) {
+    SampleParams p;
+    p.cx = g->cc[0];
+    p.cy = g->cc[1];
+    p.cz = g->cc[2];
+    p.x_off = g->x_off;
+    for (int d = 0; d < 3; ++d) {
+        p.shape[d] = shape[d];
+        p.shifted_center[d] = shifted_center[d];
+    }
+    p.n_nodes = n_nodes;
+    p.stack_size = stack_size;
+    p.voxel_type = voxel_type;
+    size_t lds = (size_t)(stack_size ? stack_size : 1) * IVX_CHUNK_VOXELS * sizeof(float);
+    IVX_REQUIRE(lds <= 160 * 1024, IVX_ERR_CAPACITY, "SDF graph needs a forward stack of %u blocks (> 10 fit the 160 KiB LDS)", stack_size);
+    IVX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sdf_sample), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_sdf_sample, dim3(g->n_chunks), dim3(256), lds, g->ctx->stream, p, d_nodes, g->sdf, g->type, g->info);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+int ivx_launch_classify(ivx_grid* g) {
+    hipLaunchKernelGGL(k_classify, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, g->n_chunks, g->sdf, g->type, g->info);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}

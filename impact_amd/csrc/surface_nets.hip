@@ -1,0 +1,577 @@
+// a5-a7 — padded chunk SDF + Surface Nets + mesh assembly (full rebuild), one workgroup per exposed
+// chunk. Three launches: count -> scan (chunk-linear exclusive offsets) -> emit.
+//
+// Reference behaviour reproduced (engine/crates/impact_voxel/src/):
+//   for_each_exposed_chunk_with_sdf / padding fills     object/sdf.rs:156-508
+//   compute_surface_nets_mesh                           object/sdf/surface_nets.rs:131-148
+//   estimate_surface_nets_surface (vertex scan order)   surface_nets.rs:152-244
+//   centroid_of_edge_intersections, CUBE_EDGES          surface_nets.rs:384-418, 661-674
+//   trilinear gradient                                  object/sdf.rs:603-633
+//   make_all_surface_nets_quads / diagonal split        surface_nets.rs:251-381
+//   SurfaceNetsVertexMaterials::compute + sort network  surface_nets.rs:428-522
+//   calculate_index_materials_for_triangle              surface_nets.rs:559-637
+//   VoxelObjectMesh::recreate (concatenation, offsets)  mesh.rs:286-354, 559-577
+//   ChunkSubmesh obscuredness table                     mesh.rs:611-635
+//
+// CDNA4 mapping: the 18^3 padded tile (i8 distance + u8 type) is staged in LDS (11.4 KiB); the
+// reference's sequential (i,j,k) vertex order is reproduced by ordered stream compaction — 64-lane
+// ballot + popcount prefix inside each wave, wave totals through LDS, a running base across the 20
+// passes of 256 cubes. Quads are compacted the same way over vertices (<=3 quads each, X then Y then Z).
+// Exact f32 arithmetic (no FMA, IEEE div/sqrt) keeps the diagonal choice and hence the index buffer
+// bit-identical to the reference.
+#include "ivx_internal.hpp"
+
+namespace {
+
+constexpr int G = 18, G2 = 324, GCELLS = 5832, NCUBES = 4913;
+
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 add(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 mul(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ V3 scale(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float len3(V3 a) { return sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z); }
+__device__ __forceinline__ bool sneg(float f) { return (__float_as_uint(f) >> 31) != 0; }
+// VoxelSignedDistance::to_f32 (lib.rs:220-222)
+__device__ __forceinline__ float decode(int8_t e) { return (float)e * 0.02f; }
+
+struct SnParams {
+    GridView g;
+    float extent;
+    uint32_t x_off;
+};
+
+// Fetch the voxel at object indices (relative to this slab); outside the grid / void -> (127, 255).
+__device__ __forceinline__ void fetch(const GridView& g, int gi, int gj, int gk, int8_t& sd, uint8_t& ty) {
+    sd = 127;
+    ty = TYPE_DUMMY;
+    if (gj < 0 || gk < 0 || gj >= (int)g.cy * 16 || gk >= (int)g.cz * 16) return;
+    if (gi < 0) {
+        if (g.ghost_sdf[0]) {
+            size_t o = (size_t)((gj >> 4) * g.cz + (gk >> 4)) * 256 + (((gj & 15) << 4) | (gk & 15));
+            sd = g.ghost_sdf[0][o];
+            ty = g.ghost_type[0][o];
+        }
+        return;
+    }
+    if (gi >= (int)g.cx * 16) {
+        if (g.ghost_sdf[1]) {
+            size_t o = (size_t)((gj >> 4) * g.cz + (gk >> 4)) * 256 + (((gj & 15) << 4) | (gk & 15));
+            sd = g.ghost_sdf[1][o];
+            ty = g.ghost_type[1][o];
+        }
+        return;
+    }
+    size_t o = ((size_t)(((gi >> 4) * g.cy + (gj >> 4)) * g.cz + (gk >> 4)) << 12) + (((gi & 15) << 8) | ((gj & 15) << 4) | (gk & 15));
+    sd = g.sdf[o];
+    ty = g.type[o];
+}
+
+__device__ __forceinline__ uint32_t neighbour_kind(const GridView& g, int ci, int cj, int ck) {
+    if (cj < 0 || ck < 0 || cj >= (int)g.cy || ck >= (int)g.cz) return KIND_VOID;
+    if (ci < 0) return g.ghost_info[0] ? g.ghost_info[0][cj * g.cz + ck].kind : (uint32_t)KIND_VOID;
+    if (ci >= (int)g.cx) return g.ghost_info[1] ? g.ghost_info[1][cj * g.cz + ck].kind : (uint32_t)KIND_VOID;
+    return g.info[(ci * g.cy + cj) * g.cz + ck].kind;
+}
+
+__device__ __forceinline__ void load_tile(const GridView& g, int ci, int cj, int ck, int8_t* s_sd, uint8_t* s_ty, uint32_t tid) {
+    for (int c = tid; c < GCELLS; c += 256) {
+        int a = c / G2, r = c - a * G2, b = r / G, cc = r - b * G;
+        int8_t sd;
+        uint8_t ty;
+        fetch(g, ci * 16 + a - 1, cj * 16 + b - 1, ck * 16 + cc - 1, sd, ty);
+        s_sd[c] = sd;
+        s_ty[c] = ty;
+    }
+}
+
+// Ordered block-wide exclusive prefix of `val` (<= 3 per thread) in thread order; returns the prefix and
+// adds the block total to `base` (same value in every thread).
+__device__ __forceinline__ uint32_t block_prefix(uint32_t val, uint32_t* s_wsum, uint32_t tid, uint32_t& total) {
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    uint32_t incl = val;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t n = __shfl_up(incl, o, 64);
+        if (lane >= (uint32_t)o) incl += n;
+    }
+    if (lane == 63u) s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t w0 = s_wsum[0], w1 = s_wsum[1], w2 = s_wsum[2], w3 = s_wsum[3];
+    uint32_t wbase = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
+    total = w0 + w1 + w2 + w3;
+    __syncthreads();
+    return wbase + incl - val;
+}
+
+__device__ __forceinline__ uint32_t block_prefix_flag(bool flag, uint32_t* s_wsum, uint32_t tid, uint32_t& total) {
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const unsigned long long b = __ballot(flag);
+    const uint32_t pre = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0u) s_wsum[wave] = __popcll(b);
+    __syncthreads();
+    uint32_t w0 = s_wsum[0], w1 = s_wsum[1], w2 = s_wsum[2], w3 = s_wsum[3];
+    uint32_t wbase = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
+    total = w0 + w1 + w2 + w3;
+    __syncthreads();
+    return wbase + pre;
+}
+
+__device__ __forceinline__ bool cube_has_vertex(const int8_t* s_sd, int lin) {
+    // sign test of the 8 corners (surface_nets.rs:209-224); decoded 0 is +0.0 => outside
+    uint32_t neg = (s_sd[lin] < 0) + (s_sd[lin + 1] < 0) + (s_sd[lin + G] < 0) + (s_sd[lin + G + 1] < 0) + (s_sd[lin + G2] < 0) +
+                   (s_sd[lin + G2 + 1] < 0) + (s_sd[lin + G2 + G] < 0) + (s_sd[lin + G2 + G + 1] < 0);
+    return neg != 0 && neg != 8;
+}
+
+// number of quads (and which) emitted for the surface cube at (i,j,k): bit0 X edge, bit1 Y, bit2 Z
+__device__ __forceinline__ uint32_t quad_mask(const int8_t* s_sd, int lin, int i, int j, int k, const int* upper) {
+    const bool n0 = s_sd[lin] < 0;
+    uint32_t m = 0;
+    if (j != 0 && k != 0 && i < upper[0] && (n0 != (s_sd[lin + G2] < 0))) m |= 1u;
+    if (i != 0 && k != 0 && j < upper[1] && (n0 != (s_sd[lin + G] < 0))) m |= 2u;
+    if (i != 0 && j != 0 && k < upper[2] && (n0 != (s_sd[lin + 1] < 0))) m |= 4u;
+    return m;
+}
+
+__device__ __forceinline__ bool chunk_exposed(const ivx_chunk_info& ci) {
+    return ci.kind == KIND_NONUNIFORM && (ci.flags & CF_FULLY_OBSCURED) != CF_FULLY_OBSCURED;
+}
+
+__global__ __launch_bounds__(256) void k_sn_count(SnParams p, uint32_t* __restrict__ counts) {
+    __shared__ int8_t s_sd[GCELLS];
+    __shared__ uint8_t s_ty[GCELLS];
+    __shared__ uint32_t s_acc[2];
+    const GridView& g = p.g;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_chunks = g.cx * g.cy * g.cz;
+    const uint32_t chunk = ivx_xcd_remap(blockIdx.x, n_chunks);
+    const ivx_chunk_info info = g.info[chunk];
+    if (!chunk_exposed(info)) {
+        if (tid == 0) {
+            counts[2 * chunk] = 0;
+            counts[2 * chunk + 1] = 0;
+        }
+        return;
+    }
+    const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
+    if (tid < 2) s_acc[tid] = 0;
+    load_tile(g, ci, cj, ck, s_sd, s_ty, tid);
+    int upper[3] = {G - 1, G - 1, G - 1};
+    if (neighbour_kind(g, ci + 1, cj, ck) == KIND_NONUNIFORM) upper[0] -= 1;
+    if (neighbour_kind(g, ci, cj + 1, ck) == KIND_NONUNIFORM) upper[1] -= 1;
+    if (neighbour_kind(g, ci, cj, ck + 1) == KIND_NONUNIFORM) upper[2] -= 1;
+    __syncthreads();
+    uint32_t nv = 0, nq = 0;
+    for (int q = tid; q < NCUBES; q += 256) {
+        int i = q / 289, r = q - i * 289, j = r / 17, k = r - j * 17;
+        int lin = i * G2 + j * G + k;
+        if (cube_has_vertex(s_sd, lin)) {
+            nv += 1;
+            nq += __popc(quad_mask(s_sd, lin, i, j, k, upper));
+        }
+    }
+    atomicAdd(&s_acc[0], nv);
+    atomicAdd(&s_acc[1], nq);
+    __syncthreads();
+    if (tid == 0) {
+        counts[2 * chunk] = s_acc[0];
+        counts[2 * chunk + 1] = s_acc[1] * 6u;
+    }
+}
+
+// Exclusive scan over chunks in chunk-linear order of (vertices, indices, submesh) with chunks whose
+// index count is zero contributing nothing (mesh.rs:321-323). offsets[2c], offsets[2c+1]; totals at
+// offsets[2n..2n+3); submesh rank at ranks[c].
+__global__ __launch_bounds__(1024) void k_sn_scan(uint32_t n_chunks, const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
+                                                  uint32_t* __restrict__ ranks) {
+    __shared__ uint32_t s[3][1024];
+    __shared__ uint32_t carry[3];
+    const uint32_t tid = threadIdx.x;
+    if (tid < 3) carry[tid] = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_chunks; base += 1024) {
+        uint32_t c = base + tid;
+        uint32_t v = 0, i = 0, sm = 0;
+        if (c < n_chunks) {
+            i = counts[2 * c + 1];
+            v = i ? counts[2 * c] : 0u;
+            sm = i ? 1u : 0u;
+        }
+        s[0][tid] = v;
+        s[1][tid] = i;
+        s[2][tid] = sm;
+        __syncthreads();
+        for (uint32_t o = 1; o < 1024; o <<= 1) {
+            uint32_t a0 = 0, a1 = 0, a2 = 0;
+            if (tid >= o) {
+                a0 = s[0][tid - o];
+                a1 = s[1][tid - o];
+                a2 = s[2][tid - o];
+            }
+            __syncthreads();
+            s[0][tid] += a0;
+            s[1][tid] += a1;
+            s[2][tid] += a2;
+            __syncthreads();
+        }
+        if (c < n_chunks) {
+            offsets[2 * c] = carry[0] + s[0][tid] - v;
+            offsets[2 * c + 1] = carry[1] + s[1][tid] - i;
+            ranks[c] = carry[2] + s[2][tid] - sm;
+        }
+        __syncthreads();
+        if (tid == 1023) {
+            carry[0] += s[0][1023];
+            carry[1] += s[1][1023];
+            carry[2] += s[2][1023];
+        }
+        __syncthreads();
+    }
+    if (tid < 3) offsets[2 * n_chunks + tid] = carry[tid];
+}
+
+// ---- vertex / index materials ----------------------------------------------------------------
+struct VMat {
+    unsigned long long ind, wgt;  // 8 material indices (byte 7 = count) and 8 weights, byte e at bits 8e
+};
+
+__device__ __forceinline__ VMat vertex_materials(const bool* has, const uint8_t* mat) {
+    uint32_t ind[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wgt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t count = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        if (has[c]) {
+            int found = -1;
+#pragma unroll
+            for (int e = 0; e < 7; ++e)
+                if (found < 0 && (uint32_t)e < count && ind[e] == mat[c]) found = e;
+            if (found < 0) {
+#pragma unroll
+                for (int e = 0; e < 7; ++e)
+                    if ((uint32_t)e == count) {
+                        ind[e] = mat[c];
+                        wgt[e] = 1;
+                    }
+                count += 1;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 7; ++e)
+                    if (e == found) wgt[e] += 1;
+            }
+        }
+    }
+    ind[7] = count;
+    // sorting_network_7 (surface_nets.rs:428-446) on weights, descending, 17 compare-and-swaps
+#define CSWAP(i, j)                  \
+    if (wgt[i] < wgt[j]) {           \
+        uint32_t t = wgt[i];         \
+        wgt[i] = wgt[j];             \
+        wgt[j] = t;                  \
+        t = ind[i];                  \
+        ind[i] = ind[j];             \
+        ind[j] = t;                  \
+    }
+    CSWAP(0, 6) CSWAP(1, 5) CSWAP(2, 4) CSWAP(0, 3) CSWAP(1, 2) CSWAP(4, 5) CSWAP(0, 1) CSWAP(2, 3) CSWAP(4, 6) CSWAP(5, 6)
+    CSWAP(1, 4) CSWAP(3, 5) CSWAP(1, 2) CSWAP(3, 4) CSWAP(5, 6) CSWAP(2, 3) CSWAP(4, 5)
+#undef CSWAP
+    VMat r{0ull, 0ull};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        r.ind |= (unsigned long long)(ind[e] & 0xFF) << (8 * e);
+        r.wgt |= (unsigned long long)(wgt[e] & 0xFF) << (8 * e);
+    }
+    return r;
+}
+
+__device__ __forceinline__ uint32_t byte_at(unsigned long long v, uint32_t e) { return (uint32_t)(v >> (8 * e)) & 0xFFu; }
+
+// calculate_index_materials_for_triangle (surface_nets.rs:559-637): out[3] = 8 bytes each (indices[4], weights[4])
+__device__ __forceinline__ void index_materials(const VMat vm[3], unsigned long long out[3]) {
+    const uint32_t cnt0 = byte_at(vm[0].ind, 7), cnt1 = byte_at(vm[1].ind, 7), cnt2 = byte_at(vm[2].ind, 7);
+    if (cnt0 == 1 && cnt1 == 1 && cnt2 == 1) {
+        const uint32_t index = byte_at(vm[0].ind, 0);
+        if (byte_at(vm[1].ind, 0) == index && byte_at(vm[2].ind, 0) == index) {
+            unsigned long long im = (unsigned long long)index | (1ull << 32);
+            out[0] = out[1] = out[2] = im;
+            return;
+        }
+    }
+    const uint32_t cnt[3] = {cnt0, cnt1, cnt2};
+    uint32_t top[4] = {0, 0, 0, 0};
+    uint32_t n_top = 0;
+    uint32_t off[3] = {0, 0, 0};
+    bool done = false;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (!done) {
+            uint32_t w[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) w[i] = byte_at(vm[i].wgt, off[i]);
+            int mx = (w[0] >= w[1]) ? ((w[0] >= w[2]) ? 0 : 2) : ((w[1] >= w[2]) ? 1 : 2);
+            uint32_t wmx = mx == 0 ? w[0] : (mx == 1 ? w[1] : w[2]);
+            if (wmx == 0) {
+                done = true;
+            } else {
+                uint32_t ti = mx == 0 ? byte_at(vm[0].ind, off[0]) : (mx == 1 ? byte_at(vm[1].ind, off[1]) : byte_at(vm[2].ind, off[2]));
+                top[t] = ti;
+                n_top = t + 1;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    for (int guard = 0; guard < 8; ++guard) {
+                        if (off[i] >= cnt[i]) break;
+                        uint32_t x = byte_at(vm[i].ind, off[i]);
+                        bool is_top = false;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) is_top |= ((uint32_t)u < n_top && top[u] == x);
+                        if (!is_top) break;
+                        off[i] += 1;
+                    }
+                }
+            }
+        }
+    }
+    const unsigned long long tops = (unsigned long long)top[0] | ((unsigned long long)top[1] << 8) | ((unsigned long long)top[2] << 16) |
+                                    ((unsigned long long)top[3] << 24);
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        unsigned long long wts = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if ((uint32_t)i < n_top) {
+                uint32_t wv = 0;
+                bool found = false;
+                for (uint32_t j = 0; j < cnt[v]; ++j) {
+                    if (!found && byte_at(vm[v].ind, j) == top[i]) {
+                        wv = byte_at(vm[v].wgt, j);
+                        found = true;
+                    }
+                }
+                wts |= (unsigned long long)wv << (8 * i);
+            }
+        }
+        out[v] = tops | (wts << 32);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sn_emit(SnParams p, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+                                                 const uint32_t* __restrict__ ranks, float* __restrict__ positions, float* __restrict__ normals,
+                                                 uint32_t* __restrict__ indices, unsigned long long* __restrict__ imats,
+                                                 uint4* __restrict__ vmats, ivx_submesh* __restrict__ submeshes) {
+    __shared__ int8_t s_sd[GCELLS];
+    __shared__ uint8_t s_ty[GCELLS];
+    __shared__ uint16_t s_map[GCELLS];
+    __shared__ uint16_t s_surf[NCUBES];
+    __shared__ uint32_t s_wsum[4];
+    const GridView& g = p.g;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_chunks = g.cx * g.cy * g.cz;
+    const uint32_t chunk = ivx_xcd_remap(blockIdx.x, n_chunks);
+    const uint32_t icount = counts[2 * chunk + 1];
+    if (icount == 0) return;
+    const uint32_t vcount = counts[2 * chunk];
+    const uint32_t voff = offsets[2 * chunk], ioff = offsets[2 * chunk + 1];
+    const ivx_chunk_info info = g.info[chunk];
+    const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
+    load_tile(g, ci, cj, ck, s_sd, s_ty, tid);
+    int upper[3] = {G - 1, G - 1, G - 1};
+    if (neighbour_kind(g, ci + 1, cj, ck) == KIND_NONUNIFORM) upper[0] -= 1;
+    if (neighbour_kind(g, ci, cj + 1, ck) == KIND_NONUNIFORM) upper[1] -= 1;
+    if (neighbour_kind(g, ci, cj, ck + 1) == KIND_NONUNIFORM) upper[2] -= 1;
+
+    if (tid == 0) {
+        ivx_submesh sm;
+        sm.chunk_indices[0] = (uint32_t)ci + p.x_off;
+        sm.chunk_indices[1] = (uint32_t)cj;
+        sm.chunk_indices[2] = (uint32_t)ck;
+        sm.index_offset = ioff;
+        sm.index_count = icount;
+        // bits: X_DN 0, Y_DN 1, Z_DN 2, X_UP 3, Y_UP 4, Z_UP 5 (mesh.rs:611-635)
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b)
+                for (int c = 0; c < 2; ++c)
+                    sm.is_obscured_from_direction[a][b][c] =
+                        (((info.flags >> (3 * a)) & 1u) && ((info.flags >> (3 * b + 1)) & 1u) && ((info.flags >> (3 * c + 2)) & 1u)) ? 1u : 0u;
+        sm.vertex_offset = voff;
+        sm.vertex_count = vcount;
+        sm.reserved = 0;
+        submeshes[ranks[chunk]] = sm;
+    }
+    __syncthreads();
+
+    // mesh.rs:559-577
+    const float chunk_extent = p.extent * 16.0f;
+    const V3 pos_offset = mk((float)(ci + (int)p.x_off) * chunk_extent - 0.5f * p.extent, (float)cj * chunk_extent - 0.5f * p.extent,
+                             (float)ck * chunk_extent - 0.5f * p.extent);
+
+    // ---- phase A: vertices in (i,j,k) cube order --------------------------------------------
+    uint32_t vbase = 0;
+    for (int q0 = 0; q0 < NCUBES; q0 += 256) {
+        const int q = q0 + (int)tid;
+        int i = 0, j = 0, k = 0, lin = 0;
+        bool has_vertex = false;
+        if (q < NCUBES) {
+            i = q / 289;
+            int r = q - i * 289;
+            j = r / 17;
+            k = r - j * 17;
+            lin = i * G2 + j * G + k;
+            has_vertex = cube_has_vertex(s_sd, lin);
+        }
+        uint32_t total;
+        const uint32_t v = vbase + block_prefix_flag(has_vertex, s_wsum, tid, total);
+        vbase += total;
+        if (has_vertex) {
+            const int co[8] = {0, 1, G, G + 1, G2, G2 + 1, G2 + G, G2 + G + 1};
+            float d[8];
+            bool has[8];
+            uint8_t mats[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                int8_t e = s_sd[lin + co[c]];
+                d[c] = decode(e);
+                has[c] = e < 0;
+                mats[c] = s_ty[lin + co[c]];
+            }
+            // centroid of edge intersections (surface_nets.rs:384-418)
+            const int E1[12] = {0, 0, 0, 1, 1, 2, 2, 3, 4, 4, 5, 6};
+            const int E2[12] = {1, 2, 4, 3, 5, 3, 6, 7, 5, 6, 7, 7};
+            int count = 0;
+            V3 sum = mk(0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                const int c1 = E1[e], c2 = E2[e];
+                const float d1 = d[c1], d2 = d[c2];
+                if (sneg(d1) != sneg(d2)) {
+                    count += 1;
+                    const float interp1 = d1 / (d1 - d2);
+                    const float interp2 = 1.0f - interp1;
+                    const V3 p1 = mk((float)((c1 >> 2) & 1), (float)((c1 >> 1) & 1), (float)(c1 & 1));
+                    const V3 p2 = mk((float)((c2 >> 2) & 1), (float)((c2 >> 1) & 1), (float)(c2 & 1));
+                    sum = add(sum, add(scale(p1, interp2), scale(p2, interp1)));
+                }
+            }
+            const float rc = 1.0f / (float)count;
+            const V3 centroid = scale(sum, rc);
+            // trilinear gradient (object/sdf.rs:603-633)
+            const V3 d00 = sub(mk(d[4], d[2], d[1]), mk(d[0], d[0], d[0]));
+            const V3 d01 = sub(mk(d[5], d[6], d[3]), mk(d[1], d[4], d[2]));
+            const V3 d10 = sub(mk(d[6], d[3], d[5]), mk(d[2], d[1], d[4]));
+            const V3 d11 = sub(mk(d[7], d[7], d[7]), mk(d[3], d[5], d[6]));
+            const V3 o = centroid;
+            const V3 r = sub(mk(1.0f, 1.0f, 1.0f), o);
+            const V3 r_yzx = mk(r.y, r.z, r.x), r_zxy = mk(r.z, r.x, r.y), o_yzx = mk(o.y, o.z, o.x), o_zxy = mk(o.z, o.x, o.y);
+            const V3 grad = add(add(add(mul(mul(r_yzx, r_zxy), d00), mul(mul(r_yzx, o_zxy), d01)), mul(mul(o_yzx, r_zxy), d10)),
+                                mul(mul(o_yzx, o_zxy), d11));
+            const float gl = len3(grad);
+            const V3 normal = mk(grad.x / gl, grad.y / gl, grad.z / gl);
+            const V3 position = add(scale(add(centroid, mk((float)i, (float)j, (float)k)), p.extent), pos_offset);
+            const VMat vm = vertex_materials(has, mats);
+            s_map[lin] = (uint16_t)v;
+            s_surf[v] = (uint16_t)lin;
+            const size_t gv = (size_t)voff + v;
+            positions[3 * gv + 0] = position.x;
+            positions[3 * gv + 1] = position.y;
+            positions[3 * gv + 2] = position.z;
+            normals[3 * gv + 0] = normal.x;
+            normals[3 * gv + 1] = normal.y;
+            normals[3 * gv + 2] = normal.z;
+            vmats[gv] = make_uint4((uint32_t)vm.ind, (uint32_t)(vm.ind >> 32), (uint32_t)vm.wgt, (uint32_t)(vm.wgt >> 32));
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- phase B: quads in surface-point order, X then Y then Z edge (surface_nets.rs:263-301) --
+    uint32_t qbase = 0;
+    for (uint32_t v0 = 0; v0 < vcount; v0 += 256) {
+        const uint32_t v = v0 + tid;
+        uint32_t qm = 0;
+        int lin = 0, i = 0, j = 0, k = 0;
+        if (v < vcount) {
+            lin = s_surf[v];
+            i = lin / G2;
+            int r = lin - i * G2;
+            j = r / G;
+            k = r - j * G;
+            qm = quad_mask(s_sd, lin, i, j, k, upper);
+        }
+        uint32_t total;
+        uint32_t qoff = qbase + block_prefix(__popc(qm), s_wsum, tid, total);
+        qbase += total;
+#pragma unroll
+        for (int axis = 0; axis < 3; ++axis) {
+            if (!((qm >> axis) & 1u)) continue;
+            const int p2o = axis == 0 ? G2 : (axis == 1 ? G : 1);
+            const int ab = axis == 0 ? G : (axis == 1 ? 1 : G2);
+            const int ac = axis == 0 ? 1 : (axis == 1 ? G2 : G);
+            const bool n1 = s_sd[lin] < 0;
+            (void)p2o;
+            const bool negative_face = !n1;  // (false,true) => negative face (surface_nets.rs:348-352)
+            const uint32_t v1 = s_map[lin], v2 = s_map[lin - ab], v3 = s_map[lin - ac], v4 = s_map[lin - ab - ac];
+            const float* P = positions + 3 * (size_t)voff;
+            const V3 q1 = mk(P[3 * v1], P[3 * v1 + 1], P[3 * v1 + 2]), q2 = mk(P[3 * v2], P[3 * v2 + 1], P[3 * v2 + 2]);
+            const V3 q3 = mk(P[3 * v3], P[3 * v3 + 1], P[3 * v3 + 2]), q4 = mk(P[3 * v4], P[3 * v4 + 1], P[3 * v4 + 2]);
+            uint32_t quad[6];
+            if (len3(sub(q1, q4)) < len3(sub(q2, q3))) {
+                if (negative_face) { quad[0] = v1; quad[1] = v4; quad[2] = v2; quad[3] = v1; quad[4] = v3; quad[5] = v4; }
+                else { quad[0] = v1; quad[1] = v2; quad[2] = v4; quad[3] = v1; quad[4] = v4; quad[5] = v3; }
+            } else if (negative_face) { quad[0] = v2; quad[1] = v3; quad[2] = v4; quad[3] = v2; quad[4] = v1; quad[5] = v3; }
+            else { quad[0] = v2; quad[1] = v4; quad[2] = v3; quad[3] = v2; quad[4] = v3; quad[5] = v1; }
+            const size_t io = (size_t)ioff + (size_t)qoff * 6;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) indices[io + t] = voff + quad[t];
+#pragma unroll
+            for (int tri = 0; tri < 2; ++tri) {
+                VMat vm[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    uint4 raw = vmats[(size_t)voff + quad[3 * tri + c]];
+                    vm[c].ind = (unsigned long long)raw.x | ((unsigned long long)raw.y << 32);
+                    vm[c].wgt = (unsigned long long)raw.z | ((unsigned long long)raw.w << 32);
+                }
+                unsigned long long im[3];
+                index_materials(vm, im);
+                imats[io + 3 * tri + 0] = im[0];
+                imats[io + 3 * tri + 1] = im[1];
+                imats[io + 3 * tri + 2] = im[2];
+            }
+            qoff += 1;
+        }
+    }
+}
+
+}  // namespace
+
+static SnParams make_params(ivx_grid* g) {
+    SnParams p;
+    p.g = ivx_view(g);
+    p.extent = g->extent;
+    p.x_off = g->x_off;
+    return p;
+}
+
+int ivx_launch_sn_count(ivx_grid* g) {
+    hipLaunchKernelGGL(k_sn_count, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+int ivx_launch_sn_scan(ivx_grid* g) {
+    // ranks are stored after the offsets/totals block
+    hipLaunchKernelGGL(k_sn_scan, dim3(1), dim3(1024), 0, g->ctx->stream, g->n_chunks, g->chunk_counts, g->chunk_offsets,
+                       g->chunk_offsets + 2 * (size_t)g->n_chunks + 4);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+int ivx_launch_sn_emit(ivx_grid* g) {
+    hipLaunchKernelGGL(k_sn_emit, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts, g->chunk_offsets,
+                       g->chunk_offsets + 2 * (size_t)g->n_chunks + 4, g->positions, g->normals, g->indices,
+                       reinterpret_cast<unsigned long long*>(g->index_materials), reinterpret_cast<uint4*>(g->vertex_materials), g->submeshes);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}

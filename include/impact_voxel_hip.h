@@ -1,0 +1,182 @@
+/* impact_voxel_hip.h — C ABI of libimpact_voxel_hip.so
+ *
+ * MI355X (gfx950) implementation of the per-frame deformable-voxel physics step of
+ * lars-frogner/Impact, exposed as a flat C ABI so that the reference's own Rust loader
+ * `define_lib!` (interop/dynamic_lib/src/macros.rs:17-183) can bind it: FFI-primitive arguments
+ * only, complex data as caller-allocated (ptr, len) buffers in the little-endian layouts documented
+ * here, no heap ownership crosses the boundary, errors are status codes (0 = ok) with a message
+ * available from ivx_last_error(). See INTEGRATION.md for the Rust-side binding.
+ *
+ * Every entry point cites the reference interface it stands in for (paths relative to
+ * engine/crates/). There is NO CPU fallback: every compute entry point runs HIP kernels and fails
+ * with IVX_ERR_HIP if no gfx950 device is usable.
+ *
+ * Device data layout ("dense chunk-tiled SoA"): the object's chunk grid (cx,cy,cz) is stored
+ * completely (void and uniform chunks included); chunk c = (ci*cy + cj)*cz + ck owns 4096 bytes in
+ * each plane at offset c*4096, voxel (i,j,k) at (i<<8)|(j<<4)|k — the reference's own chunk and
+ * voxel index math (impact_voxel/src/object.rs:3140-3199). Planes: sdf (i8 quantised signed
+ * distance, impact_voxel/src/lib.rs:154-222), type (u8 VoxelType), flags (u8 VoxelFlags,
+ * lib.rs:75-101), local region label (u8, object/split_detection.rs:125,154).
+ */
+#ifndef IMPACT_VOXEL_HIP_H
+#define IMPACT_VOXEL_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IVX_OK 0
+#define IVX_ERR_INVALID 1   /* bad argument / shape mismatch */
+#define IVX_ERR_HIP 2       /* HIP runtime error or no usable device */
+#define IVX_ERR_CAPACITY 3  /* caller buffer too small / internal limit exceeded */
+#define IVX_ERR_STATE 4     /* call order violated (e.g. mesh download before remesh) */
+
+typedef struct ivx_ctx ivx_ctx;
+typedef struct ivx_grid ivx_grid;
+
+/* SDFNode — impact_voxel/src/generation/sdf/atomic.rs:62-181. 32 bytes.
+ * kind: 0 sphere{p0=radius} 1 capsule{p0=segment_length,p1=radius} 2 box{p0..2=extents}
+ *       3 translation{child1,p0..2} 4 rotation{child1,p=quat xyzw} 5 scaling{child1,p0}
+ *       7 union 8 subtraction 9 intersection {child1,child2,p0=smoothness}
+ * (6 = multifractal noise is not supported: simdnoise is an un-vendored dependency) */
+typedef struct {
+    uint32_t kind, child1, child2, pad;
+    float p[4];
+} ivx_sdf_node;
+
+/* ProcessedSDFNode — atomic.rs:83-102 (+ constructor-derived parameters). 128 bytes. */
+typedef struct {
+    uint32_t kind, leaf_count;
+    float transform[16]; /* column-major root->node space */
+    float domain_lo[3], domain_hi[3]; /* domain_with_margin */
+    float margin;
+    float a, b, c; /* sphere a=r | capsule a=half_segment b=r | box half extents | scaling a=s | binary a=smoothness b=0.25/a */
+    uint32_t reserved[4];
+} ivx_sdf_processed_node;
+
+/* Per-chunk state (VoxelChunk / NonUniformVoxelChunk, object.rs:95-126,163-188; split_detection.rs:82-88). 8 bytes. */
+typedef struct {
+    uint8_t kind;      /* 0 void, 1 uniform, 2 non-uniform — after ivx_derive_state */
+    uint8_t gen_kind;  /* kind right after generation/upload (object.rs:1890-1964) */
+    uint8_t flags;     /* VoxelChunkFlags bits 0-5 IS_OBSCURED_{X,Y,Z}_DN,{X,Y,Z}_UP, bit 6 HAS_ONLY_EMPTY_VOXELS; 0 for void/uniform */
+    uint8_t uniform_type;
+    uint16_t face_dist; /* FaceVoxelDistribution, 2 bits per face at bit 2*(2*dim+side): 0 empty 1 full 2 mixed */
+    uint8_t region_count, boundary_region_count; /* after ivx_label_regions */
+} ivx_chunk_info;
+
+/* ChunkSubmesh (impact_voxel/src/mesh.rs:94-103) + the chunk's vertex range (mesh.rs:145). 64 bytes. */
+typedef struct {
+    uint32_t chunk_indices[3];
+    uint32_t index_offset, index_count;
+    uint32_t is_obscured_from_direction[2][2][2];
+    uint32_t vertex_offset, vertex_count, reserved;
+} ivx_submesh;
+
+typedef struct {
+    uint32_t n_vertices, n_indices, n_submeshes, reserved;
+} ivx_mesh_counts;
+
+/* VoxelObjectInertialPropertyManager (impact_voxel/src/object/inertia.rs:20-25): mass, first moments,
+ * moments of inertia (xx,yy,zz), products (xy,yz,zx) about the grid origin. f64 is what the kernels
+ * accumulate in; f32 is the value rounded for the reference's struct. */
+typedef struct {
+    double m64[10];
+    float m32[10];
+    uint32_t reserved[2];
+} ivx_moments;
+
+/* One connected region of the object (result of VoxelObject::count_regions /
+ * find_two_disconnected_regions, object/split_detection.rs:193-301, plus what
+ * extract_disconnected_region needs to pick and size a fragment, object/extraction.rs:121-295). */
+typedef struct {
+    uint32_t root_chunk, root_region; /* GlobalRegionLabel of the representative local region */
+    uint64_t voxel_count;
+    uint32_t lo[3], hi[3]; /* occupied voxel range [lo, hi) */
+    uint32_t non_uniform_chunk_count, chunk_count;
+    double moments[10];
+} ivx_region_desc;
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* One context per process and GPU (the engine holds the voxel / rigid-body managers behind one
+ * write lock per stage, engine/src/tasks.rs:394-395,1040,1047 — calls on a ctx are serialised by
+ * the caller). `stream` may be NULL (library-owned stream) or a hipStream_t to run on. */
+int ivx_init(int device_id, void* stream, ivx_ctx** out);
+void ivx_shutdown(ivx_ctx*);
+const char* ivx_last_error(void); /* thread-local, library-owned string */
+int ivx_synchronize(ivx_ctx*);
+void* ivx_stream(ivx_ctx*); /* the hipStream_t kernels are launched on */
+
+/* ---- grid (VoxelObject storage, object.rs:45-57) ---------------------------------------------- */
+/* chunk_counts = ceil(grid_shape/16) (object.rs:321). x_chunk_offset / global_x_chunks describe an
+ * x-slab of a larger grid for domain decomposition (0 and cx for a whole object). */
+int ivx_grid_create(ivx_ctx*, const uint32_t chunk_counts[3], float voxel_extent, uint32_t x_chunk_offset,
+                    uint32_t global_x_chunks, ivx_grid** out);
+void ivx_grid_destroy(ivx_grid*);
+/* dense chunk-tiled host planes -> device + classification of every chunk as the generator would
+ * (generation.rs:336-355, object.rs:1890-1964). Replaces VoxelObject::generate_without_derived_state
+ * for callers that bring their own voxels (ChunkedVoxelGenerator, generation.rs:41-67). */
+int ivx_grid_upload_dense(ivx_grid*, const int8_t* sdf, const uint8_t* type, size_t n_voxels);
+/* device -> host; any pointer may be NULL */
+int ivx_grid_download_dense(ivx_grid*, int8_t* sdf, uint8_t* type, uint8_t* flags, uint8_t* local_labels, ivx_chunk_info* info,
+                            size_t n_voxels);
+/* device pointers of the planes: 0 sdf, 1 type, 2 flags, 3 local labels, 4 chunk info, 5 global region parents */
+void* ivx_grid_device_ptr(ivx_grid*, int which);
+
+/* ---- a3: SDF sample ----------------------------------------------------------------------------- */
+/* SDFGenerator::new_in (atomic.rs:228-596): host-side graph compile, no GPU work. */
+int ivx_sdf_compile(const ivx_sdf_node* nodes, size_t n_nodes, uint32_t root, ivx_sdf_processed_node* out, size_t cap,
+                    size_t* n_out, float domain[6], uint32_t* stack_size);
+/* SDFVoxelGenerator::new (generation.rs:207-258): grid shape and shifted grid centre from the domain */
+int ivx_sdf_grid_shape(const float domain[6], uint32_t grid_shape[3], float shifted_grid_center[3]);
+/* VoxelObject::generate_without_derived_state with an SDFVoxelGenerator + SameVoxelTypeGenerator
+ * (object.rs:267-404, generation.rs:293-371, atomic.rs:633-875). grid_shape is the GLOBAL shape. */
+int ivx_sdf_sample(ivx_grid*, const ivx_sdf_processed_node* nodes, size_t n_nodes, uint32_t stack_size,
+                   const uint32_t grid_shape[3], const float shifted_grid_center[3], uint8_t voxel_type);
+
+/* ---- a4: derived state -------------------------------------------------------------------------- */
+/* VoxelObject::compute_all_derived_state minus region labelling (object.rs:1136-1145): voxel adjacency
+ * flags, face distributions, chunk obscuredness, uniform-chunk demotion. */
+int ivx_derive_state(ivx_grid*);
+/* VoxelObject::update_occupied_ranges (object.rs:1149-1198): out = chunk lo/hi x3, voxel lo/hi x3 */
+int ivx_occupied_ranges(ivx_grid*, uint32_t out[12]);
+
+/* ---- a5-a7: remesh ------------------------------------------------------------------------------ */
+/* VoxelObjectMesh::recreate (mesh.rs:286-354): padded chunk SDF + Surface Nets for every exposed chunk,
+ * concatenated in chunk-linear order. Results stay on the device until downloaded. */
+int ivx_remesh(ivx_grid*, ivx_mesh_counts* out);
+/* positions/normals: 3 f32 per vertex; indices u32; index_materials 8 u8 per index
+ * (VoxelMeshIndexMaterials, mesh.rs:77-82); any pointer may be NULL */
+int ivx_mesh_download(ivx_grid*, float* positions, float* normals, uint32_t* indices, uint8_t* index_materials,
+                      ivx_submesh* submeshes);
+/* device pointers of the mesh buffers (hand-off to a renderer without a host round trip):
+ * 0 positions, 1 normals, 2 indices, 3 index materials, 4 submeshes */
+void* ivx_mesh_device_ptr(ivx_grid*, int which);
+
+/* ---- a8: mass / inertia ------------------------------------------------------------------------- */
+/* VoxelObjectInertialPropertyManager::initialized_from (object/inertia.rs:125-136, 615-790) */
+int ivx_inertia(ivx_grid*, const float densities[256], ivx_moments* out);
+
+/* ---- a9-a11: connected regions / split ---------------------------------------------------------- */
+/* update_local_connected_regions_for_all_chunks + resolve_connected_regions_between_all_chunks
+ * (object/split_detection.rs:305-487); region_count = VoxelObject::count_regions (255-301) */
+int ivx_label_regions(ivx_grid*, uint32_t* region_count);
+/* dense u32 component id per voxel (chunk-tiled; 0xFFFFFFFF = empty), ids = rank of the component's
+ * representative region in chunk scan order */
+int ivx_region_labels_download(ivx_grid*, uint32_t* labels, size_t n_voxels);
+/* per-region descriptors in id order (find_two_disconnected_regions = the first two) */
+int ivx_regions_describe(ivx_grid*, const float densities[256], ivx_region_desc* out, size_t cap, size_t* n_out);
+
+/* ---- multi-GPU: x-slab halos ----------------------------------------------------- */
+/* Face planes of (sdf,type) and boundary chunk info, packed contiguously for torch.distributed /
+ * RCCL send-recv: bytes = ivx_halo_bytes(). side 0 = lower x face, 1 = upper x face. The buffers are
+ * device pointers owned by the caller (e.g. a torch tensor). */
+size_t ivx_halo_bytes(ivx_grid*);
+int ivx_halo_pack(ivx_grid*, int side, void* device_buf);
+int ivx_halo_unpack(ivx_grid*, int side, const void* device_buf); /* install as ghost layer on `side` */
+int ivx_halo_clear(ivx_grid*, int side);                          /* no neighbour: outside the grid */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,90 @@
+"""Shared helpers for the GPU-vs-oracle parity tests."""
+from __future__ import annotations
+
+import numpy as np
+
+import oracle_lib as ol
+from impact_amd.voxel import SDFVoxelGenerator, VoxelObject, VoxelObjectInertialPropertyManager, VoxelObjectMesh
+
+
+def oracle_from_graph(graph, extent=1.0, vtype=0):
+    o = ol.OracleObject.from_sdf(graph, extent, vtype)
+    return o
+
+
+def gpu_from_graph(ctx, graph, extent=1.0, vtype=0):
+    gen = SDFVoxelGenerator(extent, graph, vtype)
+    return VoxelObject.generate_without_derived_state(ctx, gen)
+
+
+def assert_generated_equal(o: ol.OracleObject, g: VoxelObject):
+    """voxel bytes and chunk classification right after generation"""
+    o_sdf, o_typ, _, _, o_info = o.export_dense()
+    g_sdf, g_typ, _, _, g_info = g.download(flags=False, labels=False)
+    assert o.chunk_counts == g.chunk_counts
+    np.testing.assert_array_equal(g_info["gen_kind"], o_info["gen_kind"])
+    np.testing.assert_array_equal(g_sdf, o_sdf)
+    np.testing.assert_array_equal(g_typ, o_typ)
+
+
+def assert_derived_equal(o: ol.OracleObject, g: VoxelObject, check_regions=True):
+    """flags, chunk kinds/flags/face distributions (+ local region counts)"""
+    o_sdf, o_typ, o_flg, o_lab, o_info = o.export_dense()
+    g_sdf, g_typ, g_flg, g_lab, g_info = g.download()
+    np.testing.assert_array_equal(g_sdf, o_sdf)
+    np.testing.assert_array_equal(g_typ, o_typ)
+    np.testing.assert_array_equal(g_flg, o_flg)
+    for f in ("kind", "gen_kind", "flags", "face_dist", "uniform_type"):
+        np.testing.assert_array_equal(g_info[f], o_info[f], err_msg=f)
+    if check_regions:
+        for f in ("region_count", "boundary_region_count"):
+            np.testing.assert_array_equal(g_info[f], o_info[f], err_msg=f)
+        # local labels: same partition inside every chunk (canonical relabelling)
+        n = g.n_chunks
+        gl = g_lab.reshape(n, 4096)
+        olab = o_lab.reshape(n, 4096)
+        np.testing.assert_array_equal(gl == 255, olab == 255)
+        for c in np.nonzero(g_info["region_count"] > 1)[0]:
+            np.testing.assert_array_equal(ol.canonicalize_labels(gl[c].astype(np.uint32), 255),
+                                          ol.canonicalize_labels(olab[c].astype(np.uint32), 255))
+
+
+def assert_mesh_equal(o: ol.OracleObject, g: VoxelObject, exact_normals=True):
+    om = o.mesh()
+    gm = VoxelObjectMesh.create(g)
+    pos, nrm, idx, im, sub = gm.download()
+    assert gm.n_vertices() == om.positions.shape[0]
+    assert gm.n_indices() == om.indices.shape[0]
+    assert gm.n_chunks() == om.submeshes.shape[0]
+    np.testing.assert_array_equal(idx, om.indices)  # bit-exact triangle index buffer
+    np.testing.assert_array_equal(pos.view(np.uint32), om.positions.view(np.uint32))  # bit-exact f32
+    np.testing.assert_array_equal(im, om.index_materials)
+    if exact_normals:
+        np.testing.assert_array_equal(nrm.view(np.uint32), om.normals.view(np.uint32))
+    else:
+        np.testing.assert_allclose(nrm, om.normals, rtol=0, atol=2e-7)
+    if len(sub):
+        np.testing.assert_array_equal(sub["chunk_indices"], om.submeshes[:, 0:3])
+        np.testing.assert_array_equal(sub["index_offset"], om.submeshes[:, 3])
+        np.testing.assert_array_equal(sub["index_count"], om.submeshes[:, 4])
+        np.testing.assert_array_equal(sub["is_obscured_from_direction"].reshape(-1, 8), om.submeshes[:, 5:13])
+        np.testing.assert_array_equal(sub["vertex_offset"], om.submeshes[:, 13])
+        np.testing.assert_array_equal(sub["vertex_count"], om.submeshes[:, 14])
+    return gm
+
+
+def assert_inertia_equal(o: ol.OracleObject, g: VoxelObject, densities=None, rtol=1e-5):
+    d = np.ones(256, dtype=np.float32) if densities is None else densities
+    _, o64 = o.inertia(d)
+    mgr = VoxelObjectInertialPropertyManager.initialized_from(g, d)
+    scale = np.maximum(np.abs(o64), 1e-300)
+    assert np.all(np.abs(mgr.m64 - o64) <= rtol * scale + 1e-12), (mgr.m64, o64)
+    return mgr
+
+
+def assert_regions_equal(o: ol.OracleObject, g: VoxelObject):
+    n, olab = o.region_labels()
+    assert g.count_regions() == n
+    glab = ol.tiled_to_dense(g.region_labels(), g.chunk_counts)
+    np.testing.assert_array_equal(ol.canonicalize_labels(glab, 0xFFFFFFFF), ol.canonicalize_labels(olab, 0xFFFFFFFF))
+    return n
