@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the voxel hot path (BASELINE.json metric:
+"voxels stepped/sec + remesh tris/sec, 512^3 grid, 1/2/4/8 MI355X").
+
+A step = one pass of the per-frame voxel path over one SDF-defined grid that is already resident in
+HBM: SDF sample -> derived state (flags, chunk state, occupied ranges) -> connected regions ->
+Surface Nets remesh -> mass/inertia reduction. N = 1: the config-2 asteroid scaled x2.05 (502^3 grid ->
+32^3 chunks = 512^3 stored voxels). N > 1 (one process per GPU, launched by torch.distributed.run): weak
+scaling — N such asteroids joined by a thin bar, the (512 N) x 512 x 512 grid split into x-slabs of
+32 chunk planes per rank, one-voxel face halos and boundary chunk state exchanged over RCCL
+(torch.distributed "nccl"), cross-rank region equivalences all-gathered, moments all-reduced.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the byte counts behind `roofline`).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def stage_bytes(n_voxels, n_chunks, exposed_chunks, n_vertices, n_indices):
+    """Algorithmic HBM bytes per launch of each stage."""
+    return {
+        "sdf_sample": 2.0 * n_voxels,                        # W sdf + type
+        "derive": 2.0 * n_voxels,                            # R sdf, W flags
+        "occupied": 1.0 * n_voxels,                          # R flags
+        "ccl_local": 2.0 * n_voxels,                         # R flags, W label
+        "ccl_merge": 3 * 2 * 256.0 * n_chunks,               # label face pairs across +x,+y,+z
+        "ccl_resolve": 3 * 4 * 256.0 * n_chunks * 0 + 16.0 * n_chunks,  # (chunk,region) table entries actually in use ~ few per chunk
+        "sn_count": 2.0 * 5832 * exposed_chunks,             # 18^3 padded sdf + type per exposed chunk
+        "sn_scan": 20.0 * n_chunks,                          # counts in, offsets/ranks out
+        "sn_emit": 2.0 * 5832 * exposed_chunks + 40.0 * n_vertices + 12.0 * n_indices,  # tile + (pos,nrm,vmat) + (idx u32, imat 8B)
+        "inertia": 2.0 * n_voxels,                           # R flags + type
+    }
+
+
+def cpu_baseline(scale):
+    """The oracle (single thread, -O2) over the same workload, timed on this box's host cores."""
+    import oracle_lib as ol
+    from impact_amd import scenes
+
+    graph = scenes.asteroid_scene(scale)
+    t0 = time.perf_counter()
+    o = ol.OracleObject.from_sdf(graph, 1.0, 0)
+    o.update_occupied_voxel_ranges()
+    o.compute_all_derived_state()
+    t1 = time.perf_counter()
+    m = o.mesh()
+    t2 = time.perf_counter()
+    o.inertia()
+    t3 = time.perf_counter()
+    cc = o.chunk_counts
+    nvox = cc[0] * cc[1] * cc[2] * 4096
+    return {
+        "value": nvox / (t3 - t0),
+        "unit": "voxels/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"full N=1 workload once ({cc[0] * 16}^3 stored voxels): generate+derive {t1 - t0:.2f}s, remesh {t2 - t1:.2f}s "
+                  f"({m.indices.size // 3 / (t2 - t1):.3g} tris/s), inertia {t3 - t2:.2f}s; single thread",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scale", type=float, default=2.05, help="asteroid scale (2.05 -> 512^3 stored grid)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+
+    import torch
+
+    from impact_amd import capi, scenes
+    from impact_amd.voxel import Context, SDFVoxelGenerator, VoxelObject
+
+    torch.cuda.set_device(local_rank)
+    ctx = Context(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    dens = np.ones(256, dtype=np.float32)
+    if world == 1:
+        gen = SDFVoxelGenerator(1.0, scenes.asteroid_scene(args.scale), 0)
+        cc = gen.chunk_counts()
+        obj = VoxelObject(ctx, cc, 1.0)
+        obj.set_sdf_program(gen)
+        obj.set_densities(dens)
+
+        def step():
+            return obj.step(capi.STAGE_ALL)
+
+        workload = f"config-2 SDF asteroid x{args.scale} -> {gen.grid_shape()[0]}^3 grid = {cc[0] * 16}^3 stored voxels ({obj.n_chunks} chunks)"
+        parallelism = "single GPU"
+    else:
+        from impact_amd.distributed import SlabStepper
+
+        stepper = SlabStepper(ctx, scenes.asteroid_row_scene(world, args.scale), dens, rank, world, dist, torch)
+        obj = stepper.obj
+
+        def step():
+            return stepper.step()
+
+        workload = (f"{world} config-2 asteroids x{args.scale} in a row joined by a bar -> {stepper.global_shape} grid, "
+                    f"x-slabs of {obj.chunk_counts[0]} chunk planes per rank ({obj.n_chunks} chunks/rank)")
+        parallelism = f"x-slab domain decomposition over {world} GPUs, 1-voxel RCCL halos"
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    barrier()
+    t0 = time.perf_counter()
+    stage_sum = np.zeros(capi.N_TIMED_STAGES, dtype=np.float64)
+    for _ in range(args.steps):
+        res = step()
+        stage_sum += res["stage_ms"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    n_vox_rank = obj.n_voxels
+    n_vox_total = n_vox_rank * world
+    tris_rank = int(res["mesh"]["n_indices"]) // 3
+    if dist is not None:
+        t = torch.tensor([tris_rank], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t)
+        tris_total = int(t.item())
+    else:
+        tris_total = tris_rank
+    stage_ms = stage_sum / args.steps
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    if rank == 0:
+        # roofline of the dominant kernel (largest average launch duration measured with HIP events on the
+        # library's stream), algorithmic bytes from DESIGN.md
+        _, _, _, _, info = obj.download(sdf=False, types=False, flags=False, labels=False)
+        exposed = int(np.count_nonzero((info["kind"] == 2) & ((info["flags"] & 0x3F) != 0x3F)))
+        sb = stage_bytes(n_vox_rank, obj.n_chunks, exposed, int(res["mesh"]["n_vertices"]), int(res["mesh"]["n_indices"]))
+        dom = int(np.argmax(stage_ms))
+        name = capi.STAGE_NAMES[dom]
+        achieved = sb[name] / (stage_ms[dom] * 1e-3) / 1e9
+        remesh_ms = float(stage_ms[6] + stage_ms[7] + stage_ms[8])
+        out = {
+            "metric": "voxels stepped/sec + remesh tris/sec, 512^3 grid, 1/2/4/8 MI355X",
+            "value": n_vox_total / (elapsed / args.steps),
+            "unit": "voxels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "i8 voxels, f32 SDF/mesh arithmetic, f64 moments",
+            "data": "synthetic",
+            "config": {"workload": workload, "parallelism": parallelism, "voxels_per_gpu": n_vox_rank, "regions": int(res["region_count"]),
+                       "triangles": tris_total, "vertices_rank0": int(res["mesh"]["n_vertices"]), "exposed_chunks_rank0": exposed},
+            "remesh_tris_per_s": tris_rank / (remesh_ms * 1e-3) if remesh_ms > 0 else None,
+            "remesh_ms": remesh_ms,
+            "stage_ms": {capi.STAGE_NAMES[i]: round(float(stage_ms[i]), 4) for i in range(capi.N_TIMED_STAGES)},
+            "stage_gbs": {capi.STAGE_NAMES[i]: round(sb[capi.STAGE_NAMES[i]] / (stage_ms[i] * 1e-3) / 1e9, 1) if stage_ms[i] > 0 else None
+                          for i in range(capi.N_TIMED_STAGES)},
+            "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.scale)
+        elif world == 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    obj.close()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

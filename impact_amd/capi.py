@@ -52,6 +52,21 @@ REGION_DESC_DTYPE = np.dtype(
     ]
 )
 MESH_COUNTS_DTYPE = np.dtype([("n_vertices", "<u4"), ("n_indices", "<u4"), ("n_submeshes", "<u4"), ("reserved", "<u4")])
+N_TIMED_STAGES = 10
+STAGE_NAMES = ["sdf_sample", "derive", "occupied", "ccl_local", "ccl_merge", "ccl_resolve", "sn_count", "sn_scan", "sn_emit", "inertia"]
+STAGE_SAMPLE, STAGE_DERIVE, STAGE_OCCUPIED, STAGE_REGIONS, STAGE_REMESH, STAGE_INERTIA, STAGE_ALL = 1, 2, 4, 8, 16, 32, 63
+STEP_RESULT_DTYPE = np.dtype(
+    [
+        ("mesh", MESH_COUNTS_DTYPE),
+        ("region_count", "<u4"),
+        ("occupied", "<u4", (12,)),
+        ("reserved", "<u4", (3,)),
+        ("moments", MOMENTS_DTYPE),
+        ("stage_ms", "<f4", (N_TIMED_STAGES,)),
+        ("reserved2", "<f4", (2,)),
+    ]
+)
+assert STEP_RESULT_DTYPE.itemsize == 256
 assert CHUNK_INFO_DTYPE.itemsize == 8 and SUBMESH_DTYPE.itemsize == 64
 assert MOMENTS_DTYPE.itemsize == 128 and REGION_DESC_DTYPE.itemsize == 128
 
@@ -64,6 +79,7 @@ EXPORTED_SYMBOLS = [
     "ivx_remesh", "ivx_mesh_download", "ivx_mesh_device_ptr",
     "ivx_inertia",
     "ivx_label_regions", "ivx_region_labels_download", "ivx_regions_describe",
+    "ivx_grid_set_sdf_program", "ivx_grid_set_densities", "ivx_voxel_step",
     "ivx_halo_bytes", "ivx_halo_pack", "ivx_halo_unpack", "ivx_halo_clear",
 ]
 
@@ -109,6 +125,9 @@ def lib():
         "ivx_label_regions": (i32, [vp, C.POINTER(u32)]),
         "ivx_region_labels_download": (i32, [vp, vp, sz]),
         "ivx_regions_describe": (i32, [vp, vp, vp, sz, C.POINTER(sz)]),
+        "ivx_grid_set_sdf_program": (i32, [vp, vp, sz, u32, vp, vp, C.c_uint8]),
+        "ivx_grid_set_densities": (i32, [vp, vp]),
+        "ivx_voxel_step": (i32, [vp, u32, vp]),
         "ivx_halo_bytes": (sz, [vp]),
         "ivx_halo_pack": (i32, [vp, i32, vp]),
         "ivx_halo_unpack": (i32, [vp, i32, vp]),

@@ -224,6 +224,18 @@ int ivx_launch_derive(ivx_grid* g) {
     return IVX_OK;
 }
 
+namespace {
+__global__ void k_occupied_init(uint32_t* out) {
+    if (threadIdx.x < 12) out[threadIdx.x] = (threadIdx.x & 1) ? 0u : 0xFFFFFFFFu;
+}
+}  // namespace
+
+int ivx_launch_occupied_init(ivx_grid* g, uint32_t* d_out) {
+    hipLaunchKernelGGL(k_occupied_init, dim3(1), dim3(64), 0, g->ctx->stream, d_out);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
 int ivx_launch_occupied(ivx_grid* g, uint32_t* d_out) {
     GridView v = ivx_view(g);
     hipLaunchKernelGGL(k_occupied, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, v, g->flags, d_out);

@@ -241,10 +241,12 @@ void ivx_grid_destroy(ivx_grid* g) {
     (void)hipStreamSynchronize(g->ctx->stream);
     void* ptrs[] = {g->sdf, g->type, g->flags, g->llabel, g->info, g->ghost_sdf[0], g->ghost_sdf[1], g->ghost_type[0], g->ghost_type[1],
                     g->ghost_info[0], g->ghost_info[1], g->chunk_counts, g->chunk_offsets, g->positions, g->normals, g->indices,
-                    g->index_materials, g->vertex_materials, g->submeshes, g->partials, g->rparent, g->rcompid, g->rscalar, g->ccl_scratch, g->dens_dev, g->dev_scratch};
+                    g->index_materials, g->vertex_materials, g->submeshes, g->partials, g->rparent, g->rcompid, g->rscalar, g->ccl_scratch, g->dens_dev, g->dev_scratch, g->prog_nodes};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->host_scratch) (void)hipHostFree(g->host_scratch);
+    if (g->ev_ready)
+        for (int i = 0; i < 12; ++i) (void)hipEventDestroy(g->ev[i]);
     delete g;
 }
 
@@ -477,6 +479,155 @@ int ivx_regions_describe(ivx_grid* g, const float densities[256], ivx_region_des
             const double f = q == 0 ? e3 : (q <= 3 ? 0.5 * e4 : (q <= 6 ? (1.0 / 3.0) * e5 : 0.25 * e5));
             o.moments[q] = mom[10 * (size_t)r + q] * f;
         }
+    }
+    return IVX_OK;
+}
+
+int ivx_grid_set_sdf_program(ivx_grid* g, const ivx_sdf_processed_node* nodes, size_t n_nodes, uint32_t stack_size, const uint32_t grid_shape[3],
+                             const float shifted_grid_center[3], uint8_t voxel_type) {
+    IVX_REQUIRE(g && grid_shape && shifted_grid_center && (n_nodes == 0 || nodes), IVX_ERR_INVALID, "ivx_grid_set_sdf_program: null argument");
+    int depth = 0, max_depth = 0;
+    for (size_t i = 0; i < n_nodes; ++i) {
+        const uint32_t k = nodes[i].kind;
+        IVX_REQUIRE(k <= 9 && k != 6, IVX_ERR_INVALID, "ivx_grid_set_sdf_program: unsupported node kind %u", k);
+        if (k <= 2) max_depth = std::max(max_depth, ++depth);
+        else if (k >= 7) {
+            IVX_REQUIRE(depth >= 2, IVX_ERR_INVALID, "ivx_grid_set_sdf_program: malformed node program");
+            --depth;
+        } else if (k == 5) {
+            IVX_REQUIRE(depth >= 1, IVX_ERR_INVALID, "ivx_grid_set_sdf_program: malformed node program");
+        }
+    }
+    IVX_REQUIRE(n_nodes == 0 || depth == 1, IVX_ERR_INVALID, "ivx_grid_set_sdf_program: malformed node program (final stack depth %d)", depth);
+    IVX_REQUIRE(n_nodes == 0 || (uint32_t)max_depth <= stack_size, IVX_ERR_INVALID, "ivx_grid_set_sdf_program: stack_size too small");
+    for (int d = 0; d < 3; ++d) {
+        const uint32_t cap = (d == 0 ? g->gx : g->cc[d]) * 16u;
+        IVX_REQUIRE(grid_shape[d] <= cap, IVX_ERR_INVALID, "ivx_grid_set_sdf_program: grid shape exceeds the chunk grid along axis %d", d);
+    }
+    if (n_nodes > g->prog_cap) {
+        IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+        if (g->prog_nodes) (void)hipFree(g->prog_nodes);
+        g->prog_nodes = nullptr;
+        g->prog_cap = 0;
+        int rc = dev_alloc(&g->prog_nodes, n_nodes);
+        if (rc) return rc;
+        g->prog_cap = (uint32_t)n_nodes;
+    }
+    int rc = h2d(g, g->prog_nodes, nodes, n_nodes * sizeof(ivx_sdf_processed_node));
+    if (rc) return rc;
+    g->prog_n = (uint32_t)n_nodes;
+    g->prog_stack = (uint32_t)max_depth;
+    for (int d = 0; d < 3; ++d) {
+        g->prog_shape[d] = grid_shape[d];
+        g->prog_center[d] = shifted_grid_center[d];
+    }
+    g->prog_type = voxel_type;
+    return IVX_OK;
+}
+
+int ivx_grid_set_densities(ivx_grid* g, const float densities[256]) {
+    IVX_REQUIRE(g && densities, IVX_ERR_INVALID, "ivx_grid_set_densities: null argument");
+    int rc = h2d(g, g->dens_dev, densities, 256 * sizeof(float));
+    if (rc) return rc;
+    g->has_dens = 1;
+    return IVX_OK;
+}
+
+int ivx_voxel_step(ivx_grid* g, uint32_t stages, ivx_step_result* out) {
+    IVX_REQUIRE(g && out, IVX_ERR_INVALID, "ivx_voxel_step: null argument");
+    IVX_REQUIRE(!(stages & IVX_STAGE_SAMPLE) || g->prog_n > 0, IVX_ERR_STATE, "ivx_voxel_step: no SDF program resident (ivx_grid_set_sdf_program)");
+    IVX_REQUIRE(!(stages & IVX_STAGE_INERTIA) || g->has_dens, IVX_ERR_STATE, "ivx_voxel_step: no densities resident (ivx_grid_set_densities)");
+    hipStream_t s = g->ctx->stream;
+    if (!g->ev_ready) {
+        for (int i = 0; i < 12; ++i) IVX_HIP_CHECK(hipEventCreate(&g->ev[i]));
+        g->ev_ready = 1;
+    }
+    memset(out, 0, sizeof(*out));
+    int rc;
+    uint32_t* d_occ = g->rscalar + 16;
+#define EV(i) IVX_HIP_CHECK(hipEventRecord(g->ev[i], s))
+    EV(0);
+    if (stages & IVX_STAGE_SAMPLE) {
+        if ((rc = ivx_launch_sdf_sample(g, g->prog_nodes, g->prog_n, g->prog_stack, g->prog_shape, g->prog_center, g->prog_type))) return rc;
+        g->mesh_valid = 0;
+        g->regions_valid = 0;
+    }
+    EV(1);
+    if (stages & IVX_STAGE_DERIVE)
+        if ((rc = ivx_launch_derive(g))) return rc;
+    EV(2);
+    if (stages & IVX_STAGE_OCCUPIED) {
+        // lo = 0xFFFFFFFF / hi = 0 pattern: two memsets instead of a host upload
+        IVX_HIP_CHECK(hipMemsetAsync(d_occ, 0, 12 * sizeof(uint32_t), s));
+        if ((rc = ivx_launch_occupied_init(g, d_occ))) return rc;
+        if ((rc = ivx_launch_occupied(g, d_occ))) return rc;
+    }
+    EV(3);
+    if (stages & IVX_STAGE_REGIONS)
+        if ((rc = ivx_launch_ccl_local(g))) return rc;
+    EV(4);
+    if (stages & IVX_STAGE_REGIONS)
+        if ((rc = ivx_launch_ccl_merge(g))) return rc;
+    EV(5);
+    if (stages & IVX_STAGE_REGIONS)
+        if ((rc = ivx_launch_ccl_resolve(g))) return rc;
+    EV(6);
+    uint32_t totals[3] = {0, 0, 0};
+    if (stages & IVX_STAGE_REMESH) {
+        if ((rc = ivx_launch_sn_count(g))) return rc;
+        EV(7);
+        if ((rc = ivx_launch_sn_scan(g))) return rc;
+        EV(8);
+        // the only mid-step host round trip: exact mesh sizes (12 bytes) to size the output buffers
+        if ((rc = d2h(g, totals, g->chunk_offsets + 2 * (size_t)g->n_chunks, sizeof(totals)))) return rc;
+        if ((rc = ensure_mesh_capacity(g, totals[0], totals[1], totals[2]))) return rc;
+        IVX_HIP_CHECK(hipEventRecord(g->ev[11], s));
+        if (totals[1] > 0 && (rc = ivx_launch_sn_emit(g))) return rc;
+        g->mesh_counts.n_vertices = totals[0];
+        g->mesh_counts.n_indices = totals[1];
+        g->mesh_counts.n_submeshes = totals[2];
+        g->mesh_valid = 1;
+    } else {
+        EV(7);
+        EV(8);
+        IVX_HIP_CHECK(hipEventRecord(g->ev[11], s));
+    }
+    EV(9);
+    if (stages & IVX_STAGE_INERTIA)
+        if ((rc = ivx_launch_inertia(g, g->dens_dev, g->partials + g->partial_blocks * 10))) return rc;
+    EV(10);
+#undef EV
+    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    // results: region count + error flag, occupied ranges, moments — three tiny copies after the sync
+    if (stages & IVX_STAGE_REGIONS) {
+        uint32_t sc[2];
+        IVX_HIP_CHECK(hipMemcpy(sc, g->rscalar, sizeof(sc), hipMemcpyDeviceToHost));
+        IVX_REQUIRE((sc[1] & 1u) == 0, IVX_ERR_CAPACITY, "ivx_voxel_step: a chunk has more than 254 local regions");
+        g->region_count = sc[0];
+        g->regions_valid = 1;
+        out->region_count = sc[0];
+    }
+    if (stages & IVX_STAGE_OCCUPIED) {
+        IVX_HIP_CHECK(hipMemcpy(out->occupied, d_occ, 12 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (out->occupied[1] == 0) {
+            for (int i = 0; i < 12; ++i) out->occupied[i] = 0;
+        } else {
+            out->occupied[0] += g->x_off;
+            out->occupied[1] += g->x_off;
+            out->occupied[6] += g->x_off * 16u;
+            out->occupied[7] += g->x_off * 16u;
+        }
+    }
+    if (stages & IVX_STAGE_INERTIA) {
+        IVX_HIP_CHECK(hipMemcpy(out->moments.m64, g->partials + g->partial_blocks * 10, 10 * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 10; ++i) out->moments.m32[i] = (float)out->moments.m64[i];
+    }
+    out->mesh = g->mesh_counts;
+    for (int i = 0; i < IVX_N_TIMED_STAGES; ++i) {
+        float ms = 0.0f;
+        const int a = (i == 8) ? 11 : i, b = i + 1;  // sn_emit is timed from after the host round trip
+        if (hipEventElapsedTime(&ms, g->ev[a], g->ev[b]) != hipSuccess) ms = 0.0f;
+        out->stage_ms[i] = ms;
     }
     return IVX_OK;
 }

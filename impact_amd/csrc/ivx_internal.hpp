@@ -82,6 +82,16 @@ struct ivx_grid {
     float* dens_dev;        // [256] voxel type densities
     void* dev_scratch;      // grown on demand (node programs, dense label export, region statistics)
     size_t dev_scratch_bytes;
+    // resident SDF program (ivx_grid_set_sdf_program)
+    ivx_sdf_processed_node* prog_nodes;
+    uint32_t prog_n, prog_cap, prog_stack;
+    uint32_t prog_shape[3];
+    float prog_center[3];
+    uint8_t prog_type;
+    int has_dens;
+    double* moments_dev;  // [10]
+    hipEvent_t ev[12];
+    int ev_ready;
     // host pinned scratch
     void* host_scratch;
     size_t host_scratch_bytes;
@@ -146,6 +156,7 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
                           const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type);
 int ivx_launch_derive(ivx_grid* g);
 int ivx_launch_occupied(ivx_grid* g, uint32_t* d_out);
+int ivx_launch_occupied_init(ivx_grid* g, uint32_t* d_out);
 int ivx_launch_sn_count(ivx_grid* g);
 int ivx_launch_sn_scan(ivx_grid* g);
 int ivx_launch_sn_emit(ivx_grid* g);

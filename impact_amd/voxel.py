@@ -181,6 +181,27 @@ class VoxelObject:
         check(capi.lib().ivx_grid_upload_dense(obj.h, ptr(s), ptr(t), s.size))
         return obj
 
+    # ---- whole step over resident inputs ----------------------------------------------------
+    def set_sdf_program(self, generator: SDFVoxelGenerator):
+        g = generator.sdf_generator
+        shape = np.asarray(generator.grid_shape(), dtype=np.uint32)
+        check(capi.lib().ivx_grid_set_sdf_program(self.h, ptr(g.nodes) if len(g.nodes) else None, len(g.nodes), g.required_forward_stack_size,
+                                                  ptr(shape), ptr(generator.shifted_grid_center), generator.voxel_type))
+
+    def set_densities(self, densities):
+        d = np.zeros(256, dtype=np.float32)
+        src = np.asarray(densities, dtype=np.float32)
+        d[: src.size] = src
+        check(capi.lib().ivx_grid_set_densities(self.h, ptr(d)))
+
+    def step(self, stages: int = capi.STAGE_ALL) -> np.ndarray:
+        """one pass of the voxel hot path (`ivx_voxel_step`) over device-resident inputs"""
+        out = np.zeros(1, dtype=capi.STEP_RESULT_DTYPE)
+        check(capi.lib().ivx_voxel_step(self.h, stages, ptr(out)))
+        if stages & capi.STAGE_REGIONS:
+            self._region_count = int(out[0]["region_count"])
+        return out[0]
+
     # ---- derived state ----------------------------------------------------------------------
     def derive_state(self):
         check(capi.lib().ivx_derive_state(self.h))

@@ -167,6 +167,35 @@ int ivx_region_labels_download(ivx_grid*, uint32_t* labels, size_t n_voxels);
 /* per-region descriptors in id order (find_two_disconnected_regions = the first two) */
 int ivx_regions_describe(ivx_grid*, const float densities[256], ivx_region_desc* out, size_t cap, size_t* n_out);
 
+/* ---- whole voxel step (resident inputs, minimal host synchronisation) ---------------------------- */
+/* The per-frame chain the engine runs for a voxel object — generate (engine/src/setup/scene/voxel.rs:33 ->
+ * impact_voxel/src/setup.rs:555-579), derived state, mesh (engine/src/tasks.rs:376-399) and inertial
+ * properties (setup.rs:581-616) — as ONE call over inputs that already live in HBM. `stages` selects
+ * what runs; results come back in one small struct. Stage durations are measured with HIP events on
+ * the context's stream (no extra synchronisation). */
+#define IVX_STAGE_SAMPLE 1u
+#define IVX_STAGE_DERIVE 2u
+#define IVX_STAGE_OCCUPIED 4u
+#define IVX_STAGE_REGIONS 8u
+#define IVX_STAGE_REMESH 16u
+#define IVX_STAGE_INERTIA 32u
+#define IVX_STAGE_ALL 63u
+#define IVX_N_TIMED_STAGES 10 /* sample, derive, occupied, ccl_local, ccl_merge, ccl_resolve, sn_count, sn_scan, sn_emit, inertia */
+typedef struct {
+    ivx_mesh_counts mesh;
+    uint32_t region_count;
+    uint32_t occupied[12];
+    uint32_t reserved[3];
+    ivx_moments moments;
+    float stage_ms[IVX_N_TIMED_STAGES];
+    float reserved2[2];
+} ivx_step_result;
+/* make the compiled SDF program / the voxel-type densities resident on the device */
+int ivx_grid_set_sdf_program(ivx_grid*, const ivx_sdf_processed_node* nodes, size_t n_nodes, uint32_t stack_size,
+                             const uint32_t grid_shape[3], const float shifted_grid_center[3], uint8_t voxel_type);
+int ivx_grid_set_densities(ivx_grid*, const float densities[256]);
+int ivx_voxel_step(ivx_grid*, uint32_t stages, ivx_step_result* out);
+
 /* ---- multi-GPU: x-slab halos ----------------------------------------------------- */
 /* Face planes of (sdf,type) and boundary chunk info, packed contiguously for torch.distributed /
  * RCCL send-recv: bytes = ivx_halo_bytes(). side 0 = lower x face, 1 = upper x face. The buffers are
