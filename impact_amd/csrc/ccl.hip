@@ -276,27 +276,25 @@ __global__ __launch_bounds__(256) void k_ccl_flatten(GridView g, uint32_t* __res
 
 __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t n, const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t* __restrict__ total) {
     __shared__ uint32_t s[1024];
-    __shared__ uint32_t carry;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) carry = 0;
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t c0 = min(tid * per, n), c1 = min(c0 + per, n);
+    uint32_t sum = 0;
+    for (uint32_t c = c0; c < c1; ++c) sum += in[c];
+    s[tid] = sum;
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
-        const uint32_t c = base + tid;
-        const uint32_t v = c < n ? in[c] : 0u;
-        s[tid] = v;
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        uint32_t a = tid >= o ? s[tid - o] : 0u;
         __syncthreads();
-        for (uint32_t o = 1; o < 1024; o <<= 1) {
-            uint32_t a = tid >= o ? s[tid - o] : 0u;
-            __syncthreads();
-            s[tid] += a;
-            __syncthreads();
-        }
-        if (c < n) out[c] = carry + s[tid] - v;
-        __syncthreads();
-        if (tid == 1023) carry += s[1023];
+        s[tid] += a;
         __syncthreads();
     }
-    if (tid == 0) *total = carry;
+    uint32_t run = s[tid] - sum;
+    for (uint32_t c = c0; c < c1; ++c) {
+        out[c] = run;
+        run += in[c];
+    }
+    if (tid == 1023) *total = s[1023];
 }
 
 // component ids: rank of the root node in (chunk, region) order; non-roots copy their root's id

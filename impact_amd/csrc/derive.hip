@@ -38,7 +38,8 @@ __device__ __forceinline__ uint32_t row_mask(uint4 s) {
     return m;
 }
 
-__global__ __launch_bounds__(256) void k_derive(GridView g, uint8_t* __restrict__ flags_out, ivx_chunk_info* __restrict__ info) {
+__global__ __launch_bounds__(256) void k_derive(GridView g, uint8_t* __restrict__ flags_out, ivx_chunk_info* __restrict__ info,
+                                                uint32_t* __restrict__ bbox) {
     __shared__ uint32_t occ[18][18];  // non-empty masks of rows (i+1, j+1); halo rows from neighbour chunks
     __shared__ uint32_t cnt[12];      // own face non-empty counts [0..6), neighbour face non-empty counts [6..12)
     const uint32_t tid = threadIdx.x;
@@ -79,6 +80,29 @@ __global__ __launch_bounds__(256) void k_derive(GridView g, uint8_t* __restrict_
         }
     }
     __syncthreads();
+
+    // occupied sub-box of the chunk (for update_occupied_ranges, object.rs:1149-1280): lanes 0..15 of
+    // wave 0 OR the row masks along j (-> i occupancy + k bits) and along i (-> j occupancy)
+    if (tid < 16) {
+        uint32_t a = 0, b = 0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            a |= occ[tid + 1][t + 1];
+            b |= occ[t + 1][tid + 1];
+        }
+        const uint32_t bi = (uint32_t)__ballot(a != 0) & 0xFFFFu, bj = (uint32_t)__ballot(b != 0) & 0xFFFFu;
+        uint32_t ku = a;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) ku |= __shfl_xor(ku, o, 16);
+        if (tid == 0) {
+            uint32_t packed = 0;
+            if (bi) {
+                packed = 0x80000000u | (uint32_t)(__ffs(bi) - 1) | ((uint32_t)(31 - __clz(bi)) << 4) | ((uint32_t)(__ffs(bj) - 1) << 8) |
+                         ((uint32_t)(31 - __clz(bj)) << 12) | ((uint32_t)(__ffs(ku) - 1) << 16) | ((uint32_t)(31 - __clz(ku)) << 20);
+            }
+            bbox[chunk] = packed;
+        }
+    }
 
     // face populations: own faces and adjoining neighbour faces
     {
@@ -172,73 +196,51 @@ __global__ __launch_bounds__(256) void k_derive(GridView g, uint8_t* __restrict_
     }
 }
 
-// update_occupied_ranges (object.rs:1149-1280): tight [lo,hi) ranges of non-empty chunks and voxels.
-// out[0..6) chunk lo/hi per dim, out[6..12) voxel lo/hi per dim; caller pre-fills lo = UINT_MAX, hi = 0.
-__global__ __launch_bounds__(256) void k_occupied(GridView g, const uint8_t* __restrict__ flags, uint32_t* __restrict__ out) {
+// update_occupied_ranges (object.rs:1149-1280): tight [lo,hi) ranges of non-empty chunks and voxels from
+// the per-chunk boxes written by k_derive. out[0..6) chunk lo/hi per dim, out[6..12) voxel lo/hi per dim.
+__global__ __launch_bounds__(1024) void k_occupied_reduce(uint32_t cx, uint32_t cy, uint32_t cz, const uint32_t* __restrict__ bbox,
+                                                          uint32_t* __restrict__ out) {
+    __shared__ uint32_t red[12];
     const uint32_t tid = threadIdx.x;
-    const uint32_t n_chunks = g.cx * g.cy * g.cz;
-    const uint32_t chunk = ivx_xcd_remap(blockIdx.x, n_chunks);
-    if (g.info[chunk].kind == KIND_VOID) return;
-    const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
-    const int ti = tid >> 4, tj = tid & 15;
-    uint4 f = *reinterpret_cast<const uint4*>(flags + (size_t)chunk * IVX_CHUNK_VOXELS + (size_t)tid * 16);
-    uint32_t w[4] = {f.x, f.y, f.z, f.w};
-    uint32_t m = 0;
+    if (tid < 12) red[tid] = (tid & 1) ? 0u : 0xFFFFFFFFu;
+    __syncthreads();
+    uint32_t v[12];
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
-        if (!((w[k >> 2] >> (8 * (k & 3))) & VF_EMPTY)) m |= 1u << k;
-    __shared__ uint32_t red[6];  // in-chunk min/max of i, j, k over non-empty voxels
-    if (tid < 6) red[tid] = (tid & 1) ? 0u : 16u;
-    __syncthreads();
-    if (m) {
-        atomicMin(&red[0], (uint32_t)ti);
-        atomicMax(&red[1], (uint32_t)ti + 1);
-        atomicMin(&red[2], (uint32_t)tj);
-        atomicMax(&red[3], (uint32_t)tj + 1);
-        atomicMin(&red[4], (uint32_t)(__ffs(m) - 1));
-        atomicMax(&red[5], (uint32_t)(32 - __clz(m)));
-    }
-    __syncthreads();
-    if (red[1] == 0) return;  // only empty voxels
-    if (tid < 12) {
-        // bounds are monotone, so a (possibly stale) plain read can only cause a redundant atomic
-        const uint32_t c[3] = {(uint32_t)ci, (uint32_t)cj, (uint32_t)ck};
-        const uint32_t d = (tid % 6) >> 1;
-        const bool is_max = tid & 1;
-        const uint32_t v = tid < 6 ? c[d] + (is_max ? 1u : 0u) : c[d] * 16u + red[tid - 6];
-        const uint32_t cur = __hip_atomic_load(&out[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (is_max) {
-            if (v > cur) atomicMax(&out[tid], v);
-        } else {
-            if (v < cur) atomicMin(&out[tid], v);
+    for (int q = 0; q < 12; ++q) v[q] = (q & 1) ? 0u : 0xFFFFFFFFu;
+    const uint32_t n = cx * cy * cz;
+    for (uint32_t c = tid; c < n; c += 1024) {
+        const uint32_t p = bbox[c];
+        if (!(p & 0x80000000u)) continue;
+        const uint32_t ck = c % cz, cj = (c / cz) % cy, ci = c / (cz * cy);
+        const uint32_t cc[3] = {ci, cj, ck};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            v[2 * d] = min(v[2 * d], cc[d]);
+            v[2 * d + 1] = max(v[2 * d + 1], cc[d] + 1);
+            v[6 + 2 * d] = min(v[6 + 2 * d], cc[d] * 16u + ((p >> (8 * d)) & 15u));
+            v[7 + 2 * d] = max(v[7 + 2 * d], cc[d] * 16u + ((p >> (8 * d + 4)) & 15u) + 1u);
         }
     }
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+        if (q & 1) atomicMax(&red[q], v[q]);
+        else atomicMin(&red[q], v[q]);
+    }
+    __syncthreads();
+    if (tid < 12) out[tid] = red[tid];
 }
 
 }  // namespace
 
 int ivx_launch_derive(ivx_grid* g) {
     GridView v = ivx_view(g);
-    hipLaunchKernelGGL(k_derive, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, v, g->flags, g->info);
-    IVX_HIP_CHECK(hipGetLastError());
-    return IVX_OK;
-}
-
-namespace {
-__global__ void k_occupied_init(uint32_t* out) {
-    if (threadIdx.x < 12) out[threadIdx.x] = (threadIdx.x & 1) ? 0u : 0xFFFFFFFFu;
-}
-}  // namespace
-
-int ivx_launch_occupied_init(ivx_grid* g, uint32_t* d_out) {
-    hipLaunchKernelGGL(k_occupied_init, dim3(1), dim3(64), 0, g->ctx->stream, d_out);
+    hipLaunchKernelGGL(k_derive, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, v, g->flags, g->info, g->chunk_bbox);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 
 int ivx_launch_occupied(ivx_grid* g, uint32_t* d_out) {
-    GridView v = ivx_view(g);
-    hipLaunchKernelGGL(k_occupied, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, v, g->flags, d_out);
+    hipLaunchKernelGGL(k_occupied_reduce, dim3(1), dim3(1024), 0, g->ctx->stream, g->cc[0], g->cc[1], g->cc[2], g->chunk_bbox, d_out);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

@@ -76,14 +76,27 @@ __global__ __launch_bounds__(256) void k_inertia(GridView g, uint32_t x_off, con
     if (tid < 10) partials[(size_t)blockIdx.x * 10 + tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
 }
 
-__global__ __launch_bounds__(64) void k_inertia_final(uint32_t n_blocks, float extent, const double* __restrict__ partials, double* __restrict__ out) {
+// fixed-order (bitwise reproducible) reduction of the per-block partials: each of 256 threads sums a
+// strided subset in index order, then a fixed tree combines them
+__global__ __launch_bounds__(256) void k_inertia_final(uint32_t n_blocks, float extent, const double* __restrict__ partials, double* __restrict__ out) {
+    __shared__ double s_red[256];
     const uint32_t tid = threadIdx.x;
-    if (tid >= 10) return;
-    double s = 0.0;
-    for (uint32_t b = 0; b < n_blocks; ++b) s += partials[(size_t)b * 10 + tid];
-    const double e = (double)extent, e2 = e * e, e3 = e2 * e, e4 = e2 * e2, e5 = e4 * e;
-    const double f = tid == 0 ? e3 : (tid <= 3 ? 0.5 * e4 : (tid <= 6 ? (1.0 / 3.0) * e5 : 0.25 * e5));
-    out[tid] = s * f;
+    for (int q = 0; q < 10; ++q) {
+        double s = 0.0;
+        for (uint32_t b = tid; b < n_blocks; b += 256) s += partials[(size_t)b * 10 + q];
+        s_red[tid] = s;
+        __syncthreads();
+        for (uint32_t o = 128; o > 0; o >>= 1) {
+            if (tid < o) s_red[tid] += s_red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const double e = (double)extent, e2 = e * e, e3 = e2 * e, e4 = e2 * e2, e5 = e4 * e;
+            const double f = q == 0 ? e3 : (q <= 3 ? 0.5 * e4 : (q <= 6 ? (1.0 / 3.0) * e5 : 0.25 * e5));
+            out[q] = s_red[0] * f;
+        }
+        __syncthreads();
+    }
 }
 
 }  // namespace
@@ -96,7 +109,7 @@ int ivx_launch_inertia(ivx_grid* g, const float* d_dens, double* d_out10) {
     }
     GridView v = ivx_view(g);
     hipLaunchKernelGGL(k_inertia, dim3(blocks), dim3(256), 0, g->ctx->stream, v, g->x_off, g->flags, d_dens, g->partials);
-    hipLaunchKernelGGL(k_inertia_final, dim3(1), dim3(64), 0, g->ctx->stream, blocks, g->extent, g->partials, d_out10);
+    hipLaunchKernelGGL(k_inertia_final, dim3(1), dim3(256), 0, g->ctx->stream, blocks, g->extent, g->partials, d_out10);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

@@ -209,6 +209,7 @@ int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32
     A(dev_alloc(&g->flags, g->n_vox));
     A(dev_alloc(&g->llabel, g->n_vox));
     A(dev_alloc(&g->info, (size_t)g->n_chunks));
+    A(dev_alloc(&g->chunk_bbox, (size_t)g->n_chunks));
     for (int s = 0; s < 2; ++s) {
         A(dev_alloc(&g->ghost_sdf[s], cols * 256));
         A(dev_alloc(&g->ghost_type[s], cols * 256));
@@ -241,7 +242,7 @@ void ivx_grid_destroy(ivx_grid* g) {
     (void)hipStreamSynchronize(g->ctx->stream);
     void* ptrs[] = {g->sdf, g->type, g->flags, g->llabel, g->info, g->ghost_sdf[0], g->ghost_sdf[1], g->ghost_type[0], g->ghost_type[1],
                     g->ghost_info[0], g->ghost_info[1], g->chunk_counts, g->chunk_offsets, g->positions, g->normals, g->indices,
-                    g->index_materials, g->vertex_materials, g->submeshes, g->partials, g->rparent, g->rcompid, g->rscalar, g->ccl_scratch, g->dens_dev, g->dev_scratch, g->prog_nodes};
+                    g->index_materials, g->vertex_materials, g->submeshes, g->partials, g->rparent, g->rcompid, g->rscalar, g->ccl_scratch, g->dens_dev, g->dev_scratch, g->prog_nodes, g->chunk_bbox};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->host_scratch) (void)hipHostFree(g->host_scratch);
@@ -335,13 +336,10 @@ int ivx_derive_state(ivx_grid* g) {
 
 int ivx_occupied_ranges(ivx_grid* g, uint32_t out[12]) {
     IVX_REQUIRE(g && out, IVX_ERR_INVALID, "ivx_occupied_ranges: null argument");
-    uint32_t init[12];
-    for (int i = 0; i < 12; ++i) init[i] = (i & 1) ? 0u : 0xFFFFFFFFu;
     uint32_t* d = g->rscalar + 16;
     int rc;
-    if ((rc = h2d(g, d, init, sizeof(init)))) return rc;
     if ((rc = ivx_launch_occupied(g, d))) return rc;
-    if ((rc = d2h(g, out, d, sizeof(init)))) return rc;
+    if ((rc = d2h(g, out, d, 12 * sizeof(uint32_t)))) return rc;
     if (out[1] == 0) {  // no non-empty voxel (object.rs:1177-1190)
         for (int i = 0; i < 12; ++i) out[i] = 0;
     } else {
@@ -557,9 +555,6 @@ int ivx_voxel_step(ivx_grid* g, uint32_t stages, ivx_step_result* out) {
         if ((rc = ivx_launch_derive(g))) return rc;
     EV(2);
     if (stages & IVX_STAGE_OCCUPIED) {
-        // lo = 0xFFFFFFFF / hi = 0 pattern: two memsets instead of a host upload
-        IVX_HIP_CHECK(hipMemsetAsync(d_occ, 0, 12 * sizeof(uint32_t), s));
-        if ((rc = ivx_launch_occupied_init(g, d_occ))) return rc;
         if ((rc = ivx_launch_occupied(g, d_occ))) return rc;
     }
     EV(3);

@@ -51,6 +51,7 @@ struct ivx_grid {
     uint8_t* flags;
     uint8_t* llabel;
     ivx_chunk_info* info;
+    uint32_t* chunk_bbox;  // per chunk: bit31 valid | min/max i,j,k (4 bits each) of non-empty voxels
     // ghost x-face layers [side]: face planes in (cj,ck)-tiled (j,k) order + chunk info of the layer
     int8_t* ghost_sdf[2];
     uint8_t* ghost_type[2];
@@ -156,7 +157,6 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
                           const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type);
 int ivx_launch_derive(ivx_grid* g);
 int ivx_launch_occupied(ivx_grid* g, uint32_t* d_out);
-int ivx_launch_occupied_init(ivx_grid* g, uint32_t* d_out);
 int ivx_launch_sn_count(ivx_grid* g);
 int ivx_launch_sn_scan(ivx_grid* g);
 int ivx_launch_sn_emit(ivx_grid* g);

@@ -72,6 +72,42 @@ __device__ __forceinline__ float combine(uint32_t kind, float a, float b, float 
     return s == 0.0f ? max_rs(a, b) : -smooth_union(-a, -b, s, q);
 }
 
+
+// Element-wise application of one combination over the thread's 16 voxels, specialised so that no
+// branch on the (workgroup-uniform) operator kind / smoothness sits inside the unrolled loop.
+template <int KIND, bool SMOOTH>
+__device__ __forceinline__ float combine_t(float a, float b, float s, float q) {
+    if (KIND == 7) return SMOOTH ? smooth_union(a, b, s, q) : min_rs(a, b);
+    if (KIND == 8) return SMOOTH ? -smooth_union(-a, b, s, q) : max_rs(a, -b);
+    return SMOOTH ? -smooth_union(-a, -b, s, q) : max_rs(a, b);
+}
+template <int KIND, bool SMOOTH>
+__device__ __forceinline__ void apply_rows(float* d1, const float* d2, bool c1, bool c2, float v1, float v2, float s, float q) {
+    if (c1) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d1[k * 256] = combine_t<KIND, SMOOTH>(v1, d2[k * 256], s, q);
+    } else if (c2) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d1[k * 256] = combine_t<KIND, SMOOTH>(d1[k * 256], v2, s, q);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d1[k * 256] = combine_t<KIND, SMOOTH>(d1[k * 256], d2[k * 256], s, q);
+    }
+}
+__device__ __forceinline__ void apply_rows_dispatch(uint32_t kind, float* d1, const float* d2, bool c1, bool c2, float v1, float v2, float s, float q) {
+    const bool smooth = s != 0.0f;
+    if (kind == 7u) {
+        if (smooth) apply_rows<7, true>(d1, d2, c1, c2, v1, v2, s, q);
+        else apply_rows<7, false>(d1, d2, c1, c2, v1, v2, s, q);
+    } else if (kind == 8u) {
+        if (smooth) apply_rows<8, true>(d1, d2, c1, c2, v1, v2, s, q);
+        else apply_rows<8, false>(d1, d2, c1, c2, v1, v2, s, q);
+    } else {
+        if (smooth) apply_rows<9, true>(d1, d2, c1, c2, v1, v2, s, q);
+        else apply_rows<9, false>(d1, d2, c1, c2, v1, v2, s, q);
+    }
+}
+
 // lib.rs:197-201: (v * 50.0) as i8 — truncate toward zero, saturate, NaN -> 0
 __device__ __forceinline__ int sd_from_f32(float v) {
     float s = v * 50.0f;
@@ -142,7 +178,170 @@ __device__ __forceinline__ void classify_and_store(int* sd, uint4 types, bool ty
     }
 }
 
-__global__ __launch_bounds__(256) void k_sdf_sample(SampleParams p, const ivx_sdf_processed_node* __restrict__ nodes,
+// Block-level decision of one node (the reference's whole-block early-outs, atomic.rs:654-668,
+// 788-806): leaves -> 0 evaluate, 1 constant +margin, 2 constant -margin; combinations -> 0 apply,
+// 1 node domain lies outside the block (apply only if a test position fails).
+__device__ __forceinline__ uint32_t node_mode(const ivx_sdf_processed_node* nd, Box block) {
+    const uint32_t kind = nd->kind;
+    if (kind > 2u && kind < 7u) return 0u;
+    const Box bn = aabb_of_transformed(block, nd->transform);
+    const Box dom{mk(nd->domain_lo[0], nd->domain_lo[1], nd->domain_lo[2]), mk(nd->domain_hi[0], nd->domain_hi[1], nd->domain_hi[2])};
+    const bool outside = lies_outside(dom, bn);
+    if (kind >= 7u) return outside ? 1u : 0u;
+    if (outside) return 1u;
+    const float margin = nd->margin;
+    V3 ih;
+    if (kind == 0u) {
+        float e = nd->a * 0.57735026f + (-margin);
+        ih = mk(e, e, e);
+    } else if (kind == 1u) {
+        float e = nd->b * 0.57735026f + (-margin);
+        ih = mk(e, e + nd->a, e);
+    } else {
+        ih = mk(nd->a + (-margin), nd->b + (-margin), nd->c + (-margin));
+    }
+    const Box interior{mk(-ih.x, -ih.y, -ih.z), ih};
+    return contains_box(interior, bn) ? 2u : 0u;
+}
+
+
+// Per-chunk scalar pre-pass (one THREAD per chunk): runs the node program on a conservative INTERVAL
+// [lo, hi] of each stack level over the chunk, with exact tracking of block constants.
+//   * leaf in a fill mode (the reference's whole-block early-outs): exact constant +-margin;
+//   * evaluated leaf: distance bounds from the node-space AABB of the chunk, widened by a rounding slack;
+//   * every combination is monotone in its operands (union/intersection increasing in both,
+//     subtraction increasing in the first and decreasing in the second; smooth forms have partial
+//     derivatives in [0,1]), so bounds propagate through the same f32 formulas;
+//   * a combination whose apply decision needs per-voxel test values takes the hull of both outcomes.
+// Outcome per chunk: an exact constant (chunk finished), "every voxel quantises to +127" (root lo >=
+// 2.54 + one quantisation step), "every voxel quantises to -128" (root hi <= -2.56 - one step), or NaN =
+// evaluate per voxel. The saturating quantisation (lib.rs:197-201) makes the two bound cases exact.
+__device__ __forceinline__ float slack(float v) { return 1e-3f + 1e-5f * fabsf(v); }
+
+__device__ __forceinline__ void leaf_bounds(const ivx_sdf_processed_node* nd, Box bn, float& lo, float& hi) {
+    const uint32_t kind = nd->kind;
+    V3 blo = bn.lo, bhi = bn.hi;
+    if (kind == 1u) {  // capsule: y -= clamp(y, -h, h) is monotone in y
+        const float h = nd->a;
+        float cl = blo.y < -h ? -h : (blo.y > h ? h : blo.y), ch = bhi.y < -h ? -h : (bhi.y > h ? h : bhi.y);
+        blo.y -= cl;
+        bhi.y -= ch;
+    }
+    // per-component bounds of |p|
+    const V3 amin = mk((blo.x <= 0.0f && bhi.x >= 0.0f) ? 0.0f : fminf(fabsf(blo.x), fabsf(bhi.x)),
+                       (blo.y <= 0.0f && bhi.y >= 0.0f) ? 0.0f : fminf(fabsf(blo.y), fabsf(bhi.y)),
+                       (blo.z <= 0.0f && bhi.z >= 0.0f) ? 0.0f : fminf(fabsf(blo.z), fabsf(bhi.z)));
+    const V3 amax = mk(fmaxf(fabsf(blo.x), fabsf(bhi.x)), fmaxf(fabsf(blo.y), fabsf(bhi.y)), fmaxf(fabsf(blo.z), fabsf(bhi.z)));
+    if (kind == 2u) {
+        const V3 qlo = mk(amin.x - nd->a, amin.y - nd->b, amin.z - nd->c), qhi = mk(amax.x - nd->a, amax.y - nd->b, amax.z - nd->c);
+        lo = len3(mk(fmaxf(qlo.x, 0.0f), fmaxf(qlo.y, 0.0f), fmaxf(qlo.z, 0.0f))) + fminf(fmaxf(fmaxf(qlo.x, qlo.y), qlo.z), 0.0f);
+        hi = len3(mk(fmaxf(qhi.x, 0.0f), fmaxf(qhi.y, 0.0f), fmaxf(qhi.z, 0.0f))) + fminf(fmaxf(fmaxf(qhi.x, qhi.y), qhi.z), 0.0f);
+    } else {
+        const float r = kind == 0u ? nd->a : nd->b;
+        lo = len3(amin) - r;
+        hi = len3(amax) - r;
+    }
+    lo -= slack(lo);
+    hi += slack(hi);
+}
+
+__global__ __launch_bounds__(256) void k_sdf_prepass(SampleParams p, const ivx_sdf_processed_node* __restrict__ nodes,
+                                                     float* __restrict__ chunk_const) {
+    __shared__ float s_lo[16][256];
+    __shared__ float s_hi[16][256];
+    const uint32_t n_chunks = p.cx * p.cy * p.cz;
+    const uint32_t chunk = blockIdx.x * 256u + threadIdx.x;
+    if (chunk >= n_chunks) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t ck = chunk % p.cz, cj = (chunk / p.cz) % p.cy, ci = chunk / (p.cz * p.cy);
+    const uint32_t oi = (ci + p.x_off) * 16u, oj = cj * 16u, ok = ck * 16u;
+    const V3 origin_root = sub(mk((float)oi, (float)oj, (float)ok), mk(p.shifted_center[0], p.shifted_center[1], p.shifted_center[2]));
+    const Box block{origin_root, add(origin_root, mk(16.0f, 16.0f, 16.0f))};
+    uint32_t top = 0, cmask = 0;  // cmask bit: level is an EXACT block constant (lo == hi == value)
+    for (uint32_t n = 0; n < p.n_nodes; ++n) {
+        const ivx_sdf_processed_node* nd = nodes + n;
+        const uint32_t kind = nd->kind;
+        if (kind <= 2u) {
+            const uint32_t mode = node_mode(nd, block);
+            if (mode == 1u || mode == 2u) {
+                const float v = mode == 1u ? nd->margin : -nd->margin;
+                s_lo[top][tid] = v;
+                s_hi[top][tid] = v;
+                cmask |= 1u << top;
+            } else {
+                float lo, hi;
+                leaf_bounds(nd, aabb_of_transformed(block, nd->transform), lo, hi);
+                s_lo[top][tid] = lo;
+                s_hi[top][tid] = hi;
+                cmask &= ~(1u << top);
+            }
+            top += 1;
+        } else if (kind == 5u) {
+            s_lo[top - 1][tid] = s_lo[top - 1][tid] * nd->a;
+            s_hi[top - 1][tid] = s_hi[top - 1][tid] * nd->a;
+        } else if (kind >= 7u) {
+            top -= 1;
+            const bool c1 = (cmask >> (top - 1)) & 1u, c2 = (cmask >> top) & 1u;
+            const float lo1 = s_lo[top - 1][tid], hi1 = s_hi[top - 1][tid], lo2 = s_lo[top][tid], hi2 = s_hi[top][tid];
+            const float s = nd->a, q = nd->b;
+            const bool must_apply = node_mode(nd, block) == 0u;
+            if (c1 && c2) {
+                const float r = combine(kind, lo1, lo2, s, q);
+                if (must_apply || !(r >= nd->margin)) {
+                    s_lo[top - 1][tid] = r;
+                    s_hi[top - 1][tid] = r;
+                }
+            } else {
+                // absorption: an exact constant operand that the other operand can never come within
+                // the smoothing distance of is the result, exactly (h = 0 in generation/sdf.rs:89-92)
+                bool absorbed = false;
+                float av = 0.0f;
+                const float slk = slack(lo1) + slack(lo2) + slack(hi1) + slack(hi2);
+                if (kind == 7u) {
+                    if (c1 && lo2 >= lo1 + s + slk) { absorbed = true; av = lo1; }
+                    else if (c2 && must_apply && lo1 >= lo2 + s + slk) { absorbed = true; av = lo2; }
+                } else if (kind == 9u) {
+                    if (c1 && hi2 <= lo1 - s - slk) { absorbed = true; av = lo1; }
+                    else if (c2 && must_apply && hi1 <= lo2 - s - slk) { absorbed = true; av = lo2; }
+                } else {
+                    if (c1 && lo2 >= -lo1 + s + slk) { absorbed = true; av = lo1; }
+                    else if (c2 && must_apply && hi1 <= -lo2 - s - slk) { absorbed = true; av = -lo2; }
+                }
+                if (absorbed) {
+                    s_lo[top - 1][tid] = av;
+                    s_hi[top - 1][tid] = av;
+                    cmask |= 1u << (top - 1);
+                    continue;
+                }
+                float rlo, rhi;
+                if (kind == 8u) {  // subtraction: decreasing in the second operand
+                    rlo = combine(kind, lo1, hi2, s, q);
+                    rhi = combine(kind, hi1, lo2, s, q);
+                } else {
+                    rlo = combine(kind, lo1, lo2, s, q);
+                    rhi = combine(kind, hi1, hi2, s, q);
+                }
+                rlo -= slack(rlo);
+                rhi += slack(rhi);
+                if (!must_apply) {  // may also stay operand 1
+                    rlo = fminf(rlo, lo1);
+                    rhi = fmaxf(rhi, hi1);
+                }
+                s_lo[top - 1][tid] = rlo;
+                s_hi[top - 1][tid] = rhi;
+                cmask &= ~(1u << (top - 1));
+            }
+        }
+    }
+    const float lo = s_lo[0][tid], hi = s_hi[0][tid];
+    float out = __uint_as_float(0x7FC00000u);  // NaN = evaluate per voxel
+    if (cmask & 1u) out = lo;
+    else if (lo >= 2.54f + 0.02f) out = 1000.0f;    // every voxel quantises to +127
+    else if (hi <= -2.56f - 0.02f) out = -1000.0f;  // every voxel quantises to -128
+    chunk_const[chunk] = out;
+}
+
+__global__ __launch_bounds__(256) void k_sdf_sample(SampleParams p, const float* __restrict__ chunk_const, const ivx_sdf_processed_node* __restrict__ nodes,
                                                     int8_t* __restrict__ sdf_out, uint8_t* __restrict__ type_out,
                                                     ivx_chunk_info* __restrict__ info_out) {
     extern __shared__ float stack[];  // [stack_size][16][256]
@@ -161,102 +360,142 @@ __global__ __launch_bounds__(256) void k_sdf_sample(SampleParams p, const ivx_sd
         return;
     }
 
+    {
+        const float cv = chunk_const[chunk];
+        if (cv == cv) {  // the pre-pass proved the whole chunk to be one constant distance
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                bool in_grid = (oi + ti) < p.shape[0] && (oj + tj) < p.shape[1] && (ok + (uint32_t)k) < p.shape[2];
+                sd[k] = in_grid ? sd_from_f32(cv) : 127;
+            }
+            classify_and_store(sd, make_uint4(0, 0, 0, 0), true, 0, sdf_out, type_out, info_out, chunk, tid, true, p.voxel_type);
+            return;
+        }
+    }
+
     const V3 origin_root = sub(mk((float)oi, (float)oj, (float)ok), mk(p.shifted_center[0], p.shifted_center[1], p.shifted_center[2]));
     const Box block{origin_root, add(origin_root, mk(16.0f, 16.0f, 16.0f))};
 
+    // Control flow is kept wave-uniform and scalar: node parameters come from read-only global memory at
+    // uniform addresses (scalar loads), every node's block-level decision (the reference's whole-block
+    // early-outs) is taken by one LANE per node, 64 nodes at a time, and broadcast as two 64-bit ballot
+    // masks held in SGPRs. All waves compute identical masks, so no barrier is needed for them.
+    //
+    // Block-constant propagation: a stack level whose 4096 values are all equal (`fill(+-margin)`) is
+    // kept as one scalar; combining two constants yields a constant. Element-wise results are unchanged
+    // (same op on equal inputs), but chunks far from the surface do no per-voxel work at all.
+    __shared__ float s_cval_all[4][16];  // one copy per wave: waves drift apart between barriers
+    float* s_cval = s_cval_all[tid >> 6];
+    const uint32_t lane = tid & 63u;
     uint32_t top = 0;
-    for (uint32_t n = 0; n < p.n_nodes; ++n) {
-        const ivx_sdf_processed_node* nd = nodes + n;
-        const uint32_t kind = nd->kind;
-        if (kind <= 2u) {
-            float* d = stack + (size_t)top * IVX_CHUNK_VOXELS + tid;
-            const float margin = nd->margin;
-            const Box bn = aabb_of_transformed(block, nd->transform);
-            const Box dom{mk(nd->domain_lo[0], nd->domain_lo[1], nd->domain_lo[2]), mk(nd->domain_hi[0], nd->domain_hi[1], nd->domain_hi[2])};
-            V3 ih;
-            if (kind == 0u) {
-                float e = nd->a * 0.57735026f + (-margin);
-                ih = mk(e, e, e);
-            } else if (kind == 1u) {
-                float e = nd->b * 0.57735026f + (-margin);
-                ih = mk(e, e + nd->a, e);
-            } else {
-                ih = mk(nd->a + (-margin), nd->b + (-margin), nd->c + (-margin));
-            }
-            const Box interior{mk(-ih.x, -ih.y, -ih.z), ih};
-            if (lies_outside(dom, bn)) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) d[k * 256] = margin;
-            } else if (contains_box(interior, bn)) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) d[k * 256] = -margin;
-            } else {
-                const float* m = nd->transform;
-                const V3 origin = xform_point(m, origin_root);
-                const V3 dx = mk(m[0], m[1], m[2]), dy = mk(m[4], m[5], m[6]), dz = mk(m[8], m[9], m[10]);
-                const V3 opx = add(origin, scale(dx, (float)ti));
-                V3 pos = add(opx, scale(dy, (float)tj));
-                const float pa = nd->a, pb = nd->b, pc = nd->c;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    float v;
+    uint32_t cmask = 0;  // bit l set: level l is block-constant, value in s_cval[l]
+    for (uint32_t g0 = 0; g0 < p.n_nodes; g0 += 64u) {
+        const uint32_t mine = g0 + lane;
+        const uint32_t my_mode = mine < p.n_nodes ? node_mode(nodes + mine, block) : 0u;
+        const unsigned long long mk1 = __ballot(my_mode == 1u), mk2 = __ballot(my_mode == 2u);
+        const uint32_t cnt = min(64u, p.n_nodes - g0);
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const ivx_sdf_processed_node* nd = nodes + g0 + j;
+            const uint32_t kind = __builtin_amdgcn_readfirstlane(nd->kind);
+            const uint32_t mode = ((mk1 >> j) & 1ull) ? 1u : (((mk2 >> j) & 1ull) ? 2u : 0u);
+            if (kind <= 2u) {
+                const float margin = nd->margin;
+                if (mode == 1u) {
+                    s_cval[top] = margin;
+                    cmask |= 1u << top;
+                } else if (mode == 2u) {
+                    s_cval[top] = -margin;
+                    cmask |= 1u << top;
+                } else {
+                    float* d = stack + (size_t)top * IVX_CHUNK_VOXELS + tid;
+                    cmask &= ~(1u << top);
+                    const float* m = nd->transform;
+                    const V3 origin = xform_point(m, origin_root);
+                    const V3 dx = mk(m[0], m[1], m[2]), dy = mk(m[4], m[5], m[6]), dz = mk(m[8], m[9], m[10]);
+                    const V3 opx = add(origin, scale(dx, (float)ti));
+                    V3 pos = add(opx, scale(dy, (float)tj));
+                    const float pa = nd->a, pb = nd->b, pc = nd->c;
                     if (kind == 0u) {
-                        v = len3(pos) - pa;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            d[k * 256] = len3(pos) - pa;
+                            pos = add(pos, dz);
+                        }
                     } else if (kind == 1u) {
-                        V3 q = pos;
-                        float c = q.y;
-                        if (c < -pa) c = -pa;
-                        if (c > pa) c = pa;
-                        q.y -= c;
-                        v = len3(q) - pb;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            V3 q = pos;
+                            float c = q.y;
+                            if (c < -pa) c = -pa;
+                            if (c > pa) c = pa;
+                            q.y -= c;
+                            d[k * 256] = len3(q) - pb;
+                            pos = add(pos, dz);
+                        }
                     } else {
-                        V3 q = mk(fabsf(pos.x) - pa, fabsf(pos.y) - pb, fabsf(pos.z) - pc);
-                        V3 qp = mk(max_rs(q.x, 0.0f), max_rs(q.y, 0.0f), max_rs(q.z, 0.0f));
-                        v = len3(qp) + min_rs(max_rs(max_rs(q.x, q.y), q.z), 0.0f);
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            V3 q = mk(fabsf(pos.x) - pa, fabsf(pos.y) - pb, fabsf(pos.z) - pc);
+                            V3 qp = mk(max_rs(q.x, 0.0f), max_rs(q.y, 0.0f), max_rs(q.z, 0.0f));
+                            d[k * 256] = len3(qp) + min_rs(max_rs(max_rs(q.x, q.y), q.z), 0.0f);
+                            pos = add(pos, dz);
+                        }
                     }
-                    d[k * 256] = v;
-                    pos = add(pos, dz);
                 }
-            }
-            top += 1;
-        } else if (kind == 5u) {
-            float* d = stack + (size_t)(top - 1) * IVX_CHUNK_VOXELS + tid;
-            const float s = nd->a;
+                top += 1;
+            } else if (kind == 5u) {
+                const float s = nd->a;
+                if ((cmask >> (top - 1)) & 1u) {
+                    s_cval[top - 1] = s_cval[top - 1] * s;
+                } else {
+                    float* d = stack + (size_t)(top - 1) * IVX_CHUNK_VOXELS + tid;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) d[k * 256] *= s;
-        } else if (kind >= 7u) {
-            top -= 1;
-            float* d1 = stack + (size_t)(top - 1) * IVX_CHUNK_VOXELS;
-            const float* d2 = stack + (size_t)top * IVX_CHUNK_VOXELS;
-            const float s = nd->a, q = nd->b, margin = nd->margin;
-            const Box bn = aabb_of_transformed(block, nd->transform);
-            const Box dom{mk(nd->domain_lo[0], nd->domain_lo[1], nd->domain_lo[2]), mk(nd->domain_hi[0], nd->domain_hi[1], nd->domain_hi[2])};
-            bool apply = !lies_outside(dom, bn);
-            if (!apply) {  // workgroup-uniform branch
-                __syncthreads();
-                // distinct flat indices of the 26 test positions: 8 corners + 6 face centres
-                const int TI[14] = {0, 15, 0, 0, 15, 15, 0, 15, 0, 15, 8, 8, 8, 8};
-                const int TJ[14] = {0, 0, 15, 0, 15, 0, 15, 15, 8, 8, 0, 15, 8, 8};
-                const int TK[14] = {0, 0, 0, 15, 0, 15, 15, 15, 8, 8, 8, 8, 0, 15};
-                bool all_pass = true;
-#pragma unroll
-                for (int t = 0; t < 14; ++t) {
-                    int off = TK[t] * 256 + (TI[t] * 16 + TJ[t]);
-                    all_pass = all_pass && (combine(kind, d1[off], d2[off], s, q) >= margin);
+                    for (int k = 0; k < 16; ++k) d[k * 256] *= s;
                 }
-                apply = !all_pass;
-                __syncthreads();
-            }
-            if (apply) {
+            } else if (kind >= 7u) {
+                top -= 1;
+                float* d1 = stack + (size_t)(top - 1) * IVX_CHUNK_VOXELS;
+                const float* d2 = stack + (size_t)top * IVX_CHUNK_VOXELS;
+                const bool c1 = (cmask >> (top - 1)) & 1u, c2 = (cmask >> top) & 1u;
+                const float v1 = c1 ? s_cval[top - 1] : 0.0f, v2 = c2 ? s_cval[top] : 0.0f;
+                const float s = nd->a, q = nd->b, margin = nd->margin;
+                bool apply = mode == 0u;
+                if (!apply) {  // workgroup-uniform branch
+                    if (c1 && c2) {
+                        apply = __builtin_amdgcn_readfirstlane(!(combine(kind, v1, v2, s, q) >= margin) ? 1 : 0) != 0;
+                    } else {
+                        __syncthreads();
+                        // distinct flat indices of the 26 test positions: 8 corners + 6 face centres
+                        const int TI[14] = {0, 15, 0, 0, 15, 15, 0, 15, 0, 15, 8, 8, 8, 8};
+                        const int TJ[14] = {0, 0, 15, 0, 15, 0, 15, 15, 8, 8, 0, 15, 8, 8};
+                        const int TK[14] = {0, 0, 0, 15, 0, 15, 15, 15, 8, 8, 8, 8, 0, 15};
+                        bool all_pass = true;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) d1[k * 256 + tid] = combine(kind, d1[k * 256 + tid], d2[k * 256 + tid], s, q);
+                        for (int t = 0; t < 14; ++t) {
+                            int off = TK[t] * 256 + (TI[t] * 16 + TJ[t]);
+                            all_pass = all_pass && (combine(kind, c1 ? v1 : d1[off], c2 ? v2 : d2[off], s, q) >= margin);
+                        }
+                        apply = __builtin_amdgcn_readfirstlane(all_pass ? 0 : 1) != 0;
+                        __syncthreads();
+                    }
+                }
+                if (apply) {
+                    if (c1 && c2) {
+                        s_cval[top - 1] = combine(kind, v1, v2, s, q);
+                    } else {
+apply_rows_dispatch(kind, d1 + tid, d2 + tid, c1, c2, v1, v2, s, q);
+                        cmask &= ~(1u << (top - 1));
+                    }
+                }
             }
         }
     }
 
+    const bool root_const = cmask & 1u;
+    const float root_val = root_const ? s_cval[0] : 0.0f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        float v = stack[k * 256 + tid];
+        float v = root_const ? root_val : stack[k * 256 + tid];
         bool in_grid = (oi + ti) < p.shape[0] && (oj + tj) < p.shape[1] && (ok + (uint32_t)k) < p.shape[2];
         sd[k] = in_grid ? sd_from_f32(v) : 127;
     }
@@ -298,9 +537,11 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
     p.stack_size = stack_size;
     p.voxel_type = voxel_type;
     size_t lds = (size_t)(stack_size ? stack_size : 1) * IVX_CHUNK_VOXELS * sizeof(float);
-    IVX_REQUIRE(lds <= 160 * 1024, IVX_ERR_CAPACITY, "SDF graph needs a forward stack of %u blocks (> 10 fit the 160 KiB LDS)", stack_size);
+    IVX_REQUIRE(lds <= 159 * 1024, IVX_ERR_CAPACITY, "SDF graph needs a forward stack of %u blocks (at most 9 fit the 160 KiB LDS)", stack_size);
     IVX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sdf_sample), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_sdf_sample, dim3(g->n_chunks), dim3(256), lds, g->ctx->stream, p, d_nodes, g->sdf, g->type, g->info);
+    float* chunk_const = reinterpret_cast<float*>(g->chunk_bbox);  // scratch: rewritten by ivx_derive_state afterwards
+    if (n_nodes) hipLaunchKernelGGL(k_sdf_prepass, dim3((g->n_chunks + 255u) / 256u), dim3(256), 0, g->ctx->stream, p, d_nodes, chunk_const);
+    hipLaunchKernelGGL(k_sdf_sample, dim3(g->n_chunks), dim3(256), lds, g->ctx->stream, p, chunk_const, d_nodes, g->sdf, g->type, g->info);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

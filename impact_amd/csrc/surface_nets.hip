@@ -188,50 +188,54 @@ __global__ __launch_bounds__(256) void k_sn_count(SnParams p, uint32_t* __restri
 // offsets[2n..2n+3); submesh rank at ranks[c].
 __global__ __launch_bounds__(1024) void k_sn_scan(uint32_t n_chunks, const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
                                                   uint32_t* __restrict__ ranks) {
+    // each thread owns a contiguous run of chunks: local sums -> one block scan of 1024 partials -> write
     __shared__ uint32_t s[3][1024];
-    __shared__ uint32_t carry[3];
     const uint32_t tid = threadIdx.x;
-    if (tid < 3) carry[tid] = 0;
+    const uint32_t per = (n_chunks + 1023u) / 1024u;
+    const uint32_t c0 = min(tid * per, n_chunks), c1 = min(c0 + per, n_chunks);
+    uint32_t sv = 0, si = 0, ss = 0;
+    for (uint32_t c = c0; c < c1; ++c) {
+        const uint32_t i = counts[2 * c + 1];
+        if (i) {
+            sv += counts[2 * c];
+            si += i;
+            ss += 1;
+        }
+    }
+    s[0][tid] = sv;
+    s[1][tid] = si;
+    s[2][tid] = ss;
     __syncthreads();
-    for (uint32_t base = 0; base < n_chunks; base += 1024) {
-        uint32_t c = base + tid;
-        uint32_t v = 0, i = 0, sm = 0;
-        if (c < n_chunks) {
-            i = counts[2 * c + 1];
-            v = i ? counts[2 * c] : 0u;
-            sm = i ? 1u : 0u;
-        }
-        s[0][tid] = v;
-        s[1][tid] = i;
-        s[2][tid] = sm;
-        __syncthreads();
-        for (uint32_t o = 1; o < 1024; o <<= 1) {
-            uint32_t a0 = 0, a1 = 0, a2 = 0;
-            if (tid >= o) {
-                a0 = s[0][tid - o];
-                a1 = s[1][tid - o];
-                a2 = s[2][tid - o];
-            }
-            __syncthreads();
-            s[0][tid] += a0;
-            s[1][tid] += a1;
-            s[2][tid] += a2;
-            __syncthreads();
-        }
-        if (c < n_chunks) {
-            offsets[2 * c] = carry[0] + s[0][tid] - v;
-            offsets[2 * c + 1] = carry[1] + s[1][tid] - i;
-            ranks[c] = carry[2] + s[2][tid] - sm;
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        uint32_t a0 = 0, a1 = 0, a2 = 0;
+        if (tid >= o) {
+            a0 = s[0][tid - o];
+            a1 = s[1][tid - o];
+            a2 = s[2][tid - o];
         }
         __syncthreads();
-        if (tid == 1023) {
-            carry[0] += s[0][1023];
-            carry[1] += s[1][1023];
-            carry[2] += s[2][1023];
-        }
+        s[0][tid] += a0;
+        s[1][tid] += a1;
+        s[2][tid] += a2;
         __syncthreads();
     }
-    if (tid < 3) offsets[2 * n_chunks + tid] = carry[tid];
+    uint32_t rv = s[0][tid] - sv, ri = s[1][tid] - si, rs = s[2][tid] - ss;
+    for (uint32_t c = c0; c < c1; ++c) {
+        const uint32_t i = counts[2 * c + 1];
+        offsets[2 * c] = rv;
+        offsets[2 * c + 1] = ri;
+        ranks[c] = rs;
+        if (i) {
+            rv += counts[2 * c];
+            ri += i;
+            rs += 1;
+        }
+    }
+    if (tid == 1023) {
+        offsets[2 * n_chunks] = s[0][1023];
+        offsets[2 * n_chunks + 1] = s[1][1023];
+        offsets[2 * n_chunks + 2] = s[2][1023];
+    }
 }
 
 // ---- vertex / index materials ----------------------------------------------------------------
