@@ -84,6 +84,11 @@ EXPORTED_SYMBOLS = [
 ]
 
 
+def extra_struct_sizes():
+    """name -> (dtype, size the header documents) for the structs not asserted above"""
+    return {}
+
+
 class IvxError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"ivx error {code}: {msg}")

@@ -76,6 +76,8 @@ void orc_mesh_counts(const orc_mesh*, uint32_t out[3]); /* vertices, indices, su
 /* submeshes: 16 u32 each = chunk[3], index_offset, index_count, obscured[8], vertex_offset, vertex_count, 0 */
 void orc_mesh_get(const orc_mesh*, float* positions, float* normals, uint32_t* indices, uint8_t* index_materials, uint32_t* submeshes);
 void orc_mesh_free(orc_mesh*);
+/* padded 18^3 chunk SDF (object/sdf.rs:181-508); returns 0 if the chunk is not an exposed non-uniform chunk */
+int orc_chunk_sdf(const orc_object*, int ci, int cj, int ck, float* values5832, uint8_t* types5832);
 void orc_vertex_materials(const uint8_t has_voxel[8], const uint8_t materials[8], uint8_t out_indices[8], uint8_t out_weights[8]);
 void orc_index_materials(const uint8_t vm_indices[24], const uint8_t vm_weights[24], uint8_t out[24]);
 

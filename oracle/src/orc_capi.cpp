@@ -292,6 +292,9 @@ void orc_mesh_get(const orc_mesh* m, float* positions, float* normals, uint32_t*
         }
 }
 void orc_mesh_free(orc_mesh* m) { delete m; }
+int orc_chunk_sdf(const orc_object* o, int ci, int cj, int ck, float* values5832, uint8_t* types5832) {
+    return chunk_sdf_if_exposed(o->obj, ci, cj, ck, values5832, types5832) ? 1 : 0;
+}
 
 void orc_vertex_materials(const uint8_t has_voxel[8], const uint8_t materials[8], uint8_t out_indices[8], uint8_t out_weights[8]) {
     bool has[8];

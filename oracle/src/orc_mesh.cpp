@@ -248,6 +248,18 @@ static void compute_surface_nets_mesh(const ChunkSdf& sdf, float extent, V3 offs
     }
 }
 
+// object/sdf.rs:181-213 for one chunk (used by the validate_sdf restatement in tests/)
+bool chunk_sdf_if_exposed(const VoxelObject& obj, int ci, int cj, int ck, float* values, uint8_t* types) {
+    const Chunk* c = obj.chunk_at(ci, cj, ck);
+    if (!c || !(c->kind == K_NONUNIFORM && (c->flags & CF_FULLY_OBSCURED) != CF_FULLY_OBSCURED)) return false;
+    static thread_local ChunkSdf sdf;
+    std::memset(sdf.types, TYPE_DUMMY, sizeof(sdf.types));
+    fill_sdf(obj, ci, cj, ck, sdf);
+    std::memcpy(values, sdf.values, sizeof(sdf.values));
+    std::memcpy(types, sdf.types, sizeof(sdf.types));
+    return true;
+}
+
 // mesh.rs:286-354
 void mesh_recreate(const VoxelObject& obj, Mesh& mesh) {
     mesh = Mesh{};

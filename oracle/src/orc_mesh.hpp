@@ -33,5 +33,6 @@ struct Mesh {
 void vertex_materials_compute(const bool has_voxel[8], const uint8_t mat[8], VertexMaterials& m);
 void index_materials_for_triangle(const VertexMaterials* vm[3], IndexMaterials out[3]);
 void mesh_recreate(const VoxelObject& obj, Mesh& mesh);
+bool chunk_sdf_if_exposed(const VoxelObject& obj, int ci, int cj, int ck, float* values, uint8_t* types);
 
 }  // namespace orc

@@ -70,6 +70,8 @@ def lib():
         L.orc_mesh_counts.argtypes = [vp, vp]
         L.orc_mesh_get.argtypes = [vp, vp, vp, vp, vp, vp]
         L.orc_mesh_free.argtypes = [vp]
+        L.orc_chunk_sdf.restype = C.c_int
+        L.orc_chunk_sdf.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
         L.orc_vertex_materials.argtypes = [vp, vp, vp, vp]
         L.orc_index_materials.argtypes = [vp, vp, vp]
         L.orc_inertia.argtypes = [vp, vp, vp, vp]
@@ -224,6 +226,14 @@ class OracleObject:
         L.orc_mesh_get(m, _p(pos), _p(nrm), _p(idx), _p(im), _p(sub))
         L.orc_mesh_free(m)
         return OracleMesh(pos, nrm, idx, im, sub)
+
+    def chunk_sdf(self, ci, cj, ck):
+        """padded 18^3 (values f32, types u8) of an exposed non-uniform chunk, or None"""
+        val = np.empty((18, 18, 18), dtype=np.float32)
+        typ = np.empty((18, 18, 18), dtype=np.uint8)
+        if not lib().orc_chunk_sdf(self.h, ci, cj, ck, _p(val), _p(typ)):
+            return None
+        return val, typ
 
     def inertia(self, densities=None):
         d = np.ones(256, dtype=np.float32) if densities is None else np.ascontiguousarray(densities, dtype=np.float32)

@@ -1,0 +1,118 @@
+"""CPU-side checks of the product boundary: the C-ABI library loads, exports every symbol that
+include/impact_voxel_hip.h declares, its struct layouts match the header, the host-only entry points
+(SDF graph compile, grid shape) agree with the oracle, and compute entry points fail loudly without a
+GPU (no CPU fallback). No kernels are launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from impact_amd import capi, scenes
+from impact_amd.sdf_graph import NODE_DTYPE, PROCESSED_NODE_DTYPE, SDFGraph, SDFNode
+from impact_amd.voxel import SDFGenerator, SDFVoxelGenerator
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "impact_voxel_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ivx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.lib()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"libimpact_voxel_hip.so does not export {n}"
+    assert sorted(capi.EXPORTED_SYMBOLS) == names, "capi.EXPORTED_SYMBOLS is out of sync with the header"
+
+
+def test_struct_sizes_match_header():
+    # sizes the header documents (ivx_sdf_node 32, ivx_sdf_processed_node 128, ivx_chunk_info 8, ivx_submesh 64, ...)
+    assert NODE_DTYPE.itemsize == 32 and PROCESSED_NODE_DTYPE.itemsize == 128
+    assert capi.CHUNK_INFO_DTYPE.itemsize == 8 and capi.SUBMESH_DTYPE.itemsize == 64
+    assert capi.MOMENTS_DTYPE.itemsize == 128 and capi.REGION_DESC_DTYPE.itemsize == 128
+    assert capi.MESH_COUNTS_DTYPE.itemsize == 16 and capi.STEP_RESULT_DTYPE.itemsize == 256
+    for name, dt in capi.extra_struct_sizes().items():
+        assert dt[0].itemsize == dt[1], name
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """In this container there is no GPU: ivx_init must return IVX_ERR_HIP with a message."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    rc = capi.lib().ivx_init(0, None, C.byref(h))
+    assert rc == capi.IVX_ERR_HIP
+    assert b"no CPU fallback" in capi.lib().ivx_last_error() or b"HIP" in capi.lib().ivx_last_error()
+    from impact_amd.voxel import Context
+
+    with pytest.raises(capi.IvxError):
+        Context(0)
+
+
+def graphs():
+    yield "box", scenes.box_scene()
+    yield "sphere", scenes.sphere_scene(20.0)
+    yield "two_spheres", scenes.two_spheres_scene()
+    yield "asteroid", scenes.asteroid_scene()
+    yield "asteroid_x2", scenes.asteroid_scene(2.05)
+    yield "fracture", scenes.fracture_scene()
+    g = SDFGraph()
+    c = g.add_node(SDFNode.new_capsule(20.0, 9.0))
+    r = g.add_node(SDFNode.new_rotation_from_axis_angle(c, (1.0, 2.0, 3.0), 0.7))
+    s = g.add_node(SDFNode.new_scaling(r, 1.3))
+    g.add_node(SDFNode.new_translation(s, (3.25, -1.5, 0.75)))
+    yield "capsule", g
+    g = SDFGraph()
+    a = g.add_node(SDFNode.new_sphere(22.0))
+    b = g.add_node(SDFNode.new_box((30.0, 50.0, 30.0)))
+    i = g.add_node(SDFNode.new_intersection(a, b, 3.0))
+    g.add_node(SDFNode.new_subtraction(i, g.add_node(SDFNode.new_translation(g.add_node(SDFNode.new_sphere(9.0)), (14.0, 0.0, 0.0))), 2.0))
+    yield "smooth", g
+
+
+@pytest.mark.parametrize("name,graph", list(graphs()), ids=[n for n, _ in graphs()])
+def test_sdf_compile_matches_oracle(name, graph):
+    """ivx_sdf_compile (host code of the product, SDFGenerator::new_in atomic.rs:228-596) against the
+    oracle's independent restatement: identical processed node list, domain and stack size."""
+    gen = SDFGenerator(graph)
+    o_nodes, o_dom, o_ss = ol.sdf_compile(graph)
+    assert len(gen.nodes) == len(o_nodes)
+    assert gen.required_forward_stack_size == o_ss
+    np.testing.assert_array_equal(gen.domain.view(np.uint32), o_dom.view(np.uint32))
+    for f in ("kind", "leaf_count"):
+        np.testing.assert_array_equal(gen.nodes[f], o_nodes[f])
+    for f in ("transform", "domain_lo", "domain_hi", "margin", "a", "b", "c"):
+        np.testing.assert_array_equal(np.ascontiguousarray(gen.nodes[f]).view(np.uint32), np.ascontiguousarray(o_nodes[f]).view(np.uint32), err_msg=f)
+
+
+def test_grid_shape_rule():
+    """generation.rs:207-258: grid = ceil(domain extents) + 2; config shapes of BASELINE.json"""
+    assert SDFVoxelGenerator(1.0, scenes.box_scene()).grid_shape() == (32, 32, 32)
+    assert SDFVoxelGenerator(1.0, scenes.asteroid_scene()).chunk_counts() == (16, 16, 16)
+    assert SDFVoxelGenerator(1.0, scenes.asteroid_scene(2.05)).chunk_counts() == (32, 32, 32)
+    assert SDFVoxelGenerator(1.0, scenes.fracture_scene()).chunk_counts() == (16, 16, 16)
+    for name, g in graphs():
+        if name in ("asteroid", "asteroid_x2", "fracture"):
+            continue  # large grids: their oracle objects are built in the GPU parity tests
+        assert SDFVoxelGenerator(1.0, g).grid_shape() == ol.OracleObject.from_sdf(g).info()["grid_shape"]
+
+
+def test_compile_rejects_bad_graphs():
+    g = SDFGraph()
+    g.add_node(SDFNode._mk(6))  # multifractal noise: unsupported (simdnoise is not vendored)
+    with pytest.raises(capi.IvxError):
+        SDFGenerator(g)
+    g = SDFGraph()
+    g.add_node(SDFNode.new_translation(5, (0, 0, 0)))  # child id out of range
+    with pytest.raises(capi.IvxError):
+        SDFGenerator(g)
