@@ -95,14 +95,21 @@ def main():
     from impact_amd import capi, scenes
     from impact_amd.voxel import Context, SDFVoxelGenerator, VoxelObject
 
-    torch.cuda.set_device(local_rank)
-    ctx = Context(local_rank)
+    # one rank per GPU; on a box with fewer GPUs than ranks (single-GPU protocol check with the gloo
+    # backend) ranks share devices
+    device = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(device)
+    ctx = Context(device)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
 
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("IVX_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
 
     dens = np.ones(256, dtype=np.float32)
     if world == 1:
@@ -118,17 +125,23 @@ def main():
         workload = f"config-2 SDF asteroid x{args.scale} -> {gen.grid_shape()[0]}^3 grid = {cc[0] * 16}^3 stored voxels ({obj.n_chunks} chunks)"
         parallelism = "single GPU"
     else:
-        from impact_amd.distributed import SlabStepper
+        from impact_amd.distributed import SlabStepper, TorchComm
 
-        stepper = SlabStepper(ctx, scenes.asteroid_row_scene(world, args.scale), dens, rank, world, dist, torch)
+        stepper = SlabStepper(ctx, scenes.asteroid_row_scene(world, args.scale), dens, rank, world, torch)
+        comm = TorchComm(dist, torch, rank, world)
         obj = stepper.obj
 
-        def step():
-            return stepper.step()
+        class _Res(dict):
+            pass
 
-        workload = (f"{world} config-2 asteroids x{args.scale} in a row joined by a bar -> {stepper.global_shape} grid, "
-                    f"x-slabs of {obj.chunk_counts[0]} chunk planes per rank ({obj.n_chunks} chunks/rank)")
-        parallelism = f"x-slab domain decomposition over {world} GPUs, 1-voxel RCCL halos"
+        def step():
+            r = comm.run(stepper)
+            return {"stage_ms": r.stage_ms, "mesh": {"n_vertices": r.mesh_counts[0], "n_indices": r.mesh_counts[1]},
+                    "region_count": r.region_count}
+
+        workload = (f"{world} config-2 asteroids x{args.scale} in a row joined by a bar -> {stepper.global_shape} stored grid, "
+                    f"x-slabs of {obj.chunk_counts[0]} chunk planes per rank ({obj.n_chunks} chunks on rank 0)")
+        parallelism = f"x-slab domain decomposition over {world} GPUs, 1-voxel halos + region equivalences over RCCL"
 
     def barrier():
         if dist is not None:
@@ -152,7 +165,12 @@ def main():
         elapsed = float(t.item())
 
     n_vox_rank = obj.n_voxels
-    n_vox_total = n_vox_rank * world
+    if dist is not None:
+        t = torch.tensor([n_vox_rank], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t)
+        n_vox_total = int(t.item())
+    else:
+        n_vox_total = n_vox_rank
     tris_rank = int(res["mesh"]["n_indices"]) // 3
     if dist is not None:
         t = torch.tensor([tris_rank], dtype=torch.int64, device="cuda")

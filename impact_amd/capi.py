@@ -81,6 +81,7 @@ EXPORTED_SYMBOLS = [
     "ivx_label_regions", "ivx_region_labels_download", "ivx_regions_describe",
     "ivx_grid_set_sdf_program", "ivx_grid_set_densities", "ivx_voxel_step",
     "ivx_halo_bytes", "ivx_halo_pack", "ivx_halo_unpack", "ivx_halo_clear",
+    "ivx_region_face_bytes", "ivx_region_face_labels", "ivx_region_face_pairs",
 ]
 
 
@@ -137,6 +138,9 @@ def lib():
         "ivx_halo_pack": (i32, [vp, i32, vp]),
         "ivx_halo_unpack": (i32, [vp, i32, vp]),
         "ivx_halo_clear": (i32, [vp, i32]),
+        "ivx_region_face_bytes": (sz, [vp]),
+        "ivx_region_face_labels": (i32, [vp, i32, vp]),
+        "ivx_region_face_pairs": (i32, [vp, i32, vp, vp, sz, C.POINTER(sz)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

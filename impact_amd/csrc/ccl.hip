@@ -341,6 +341,36 @@ __global__ __launch_bounds__(256) void k_ccl_dense(uint32_t n_chunks, const uint
 }
 
 
+// ---- cross-slab (multi-GPU) region exchange: component id of every voxel of an x face, and the
+// distinct (own component, neighbour component) pairs across that face. Together with an all-gather
+// of the pairs this is the cross-chunk connection step of the reference's global resolve
+// (split_detection.rs:323-487, 1046-1325) carried across ranks.
+__global__ __launch_bounds__(256) void k_face_ids(GridView g, uint32_t side, const uint8_t* __restrict__ labels,
+                                                  const uint32_t* __restrict__ rcompid, uint32_t* __restrict__ out) {
+    const uint32_t col = blockIdx.x, tid = threadIdx.x;
+    const uint32_t chunk = (side ? g.cx - 1 : 0u) * g.cy * g.cz + col;
+    const uint32_t l = labels[(size_t)chunk * IVX_CHUNK_VOXELS + ((side ? 15u : 0u) << 8) + tid];
+    out[(size_t)col * 256 + tid] = l == 255u ? NODE_NONE : rcompid[chunk * 256u + l];
+}
+
+__global__ __launch_bounds__(256) void k_face_pairs(GridView g, uint32_t side, const uint8_t* __restrict__ labels,
+                                                    const uint32_t* __restrict__ rcompid, const uint32_t* __restrict__ nbr,
+                                                    uint32_t* __restrict__ n_pairs, uint2* __restrict__ pairs, uint32_t cap) {
+    const uint32_t col = blockIdx.x, tid = threadIdx.x;
+    const uint32_t chunk = (side ? g.cx - 1 : 0u) * g.cy * g.cz + col;
+    const uint32_t l = labels[(size_t)chunk * IVX_CHUNK_VOXELS + ((side ? 15u : 0u) << 8) + tid];
+    const uint32_t a = l == 255u ? NODE_NONE : rcompid[chunk * 256u + l];
+    const uint32_t b = nbr[(size_t)col * 256 + tid];
+    const bool both = a != NODE_NONE && b != NODE_NONE;
+    // drop repeats along the lane order (one wave = four rows of 16 face voxels)
+    const uint32_t pa = __shfl_up(a, 1, 64), pb = __shfl_up(b, 1, 64);
+    const bool dup = (tid & 63u) != 0 && pa == a && pb == b;
+    if (both && !dup) {
+        const uint32_t slot = atomicAdd(n_pairs, 1u);
+        if (slot < cap) pairs[slot] = make_uint2(a, b);
+    }
+}
+
 // ---- per-region statistics (what extract_disconnected_region needs to pick and size a fragment,
 // object/extraction.rs:121-295, plus the moments the PropertyTransferrer would move, inertia.rs:341-560)
 __device__ __forceinline__ double wsum_d(double v) {
@@ -493,6 +523,22 @@ int ivx_launch_ccl_resolve(ivx_grid* g) {
 
 int ivx_launch_ccl_dense_labels(ivx_grid* g, uint32_t* d_labels) {
     hipLaunchKernelGGL(k_ccl_dense, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, g->n_chunks, g->llabel, g->rcompid, d_labels);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+int ivx_launch_face_ids(ivx_grid* g, int side, uint32_t* d_out) {
+    GridView v = ivx_view(g);
+    hipLaunchKernelGGL(k_face_ids, dim3(g->cc[1] * g->cc[2]), dim3(256), 0, g->ctx->stream, v, (uint32_t)side, g->llabel, g->rcompid, d_out);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+int ivx_launch_face_pairs(ivx_grid* g, int side, const uint32_t* d_nbr, uint32_t* d_count, void* d_pairs, uint32_t cap) {
+    GridView v = ivx_view(g);
+    IVX_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t), g->ctx->stream));
+    hipLaunchKernelGGL(k_face_pairs, dim3(g->cc[1] * g->cc[2]), dim3(256), 0, g->ctx->stream, v, (uint32_t)side, g->llabel, g->rcompid, d_nbr,
+                       d_count, static_cast<uint2*>(d_pairs), cap);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

@@ -481,6 +481,44 @@ int ivx_regions_describe(ivx_grid* g, const float densities[256], ivx_region_des
     return IVX_OK;
 }
 
+size_t ivx_region_face_bytes(ivx_grid* g) { return g ? (size_t)g->cc[1] * g->cc[2] * 256 * sizeof(uint32_t) : 0; }
+
+int ivx_region_face_labels(ivx_grid* g, int side, void* device_buf) {
+    IVX_REQUIRE(g && device_buf && (side == 0 || side == 1), IVX_ERR_INVALID, "ivx_region_face_labels: bad argument");
+    IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "ivx_region_face_labels: call ivx_label_regions first");
+    int rc = ivx_launch_face_ids(g, side, static_cast<uint32_t*>(device_buf));
+    if (rc) return rc;
+    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    return IVX_OK;
+}
+
+int ivx_region_face_pairs(ivx_grid* g, int side, const void* neighbour_face_labels, uint32_t* pairs, size_t cap, size_t* n_out) {
+    IVX_REQUIRE(g && neighbour_face_labels && n_out && (side == 0 || side == 1) && (pairs || cap == 0), IVX_ERR_INVALID,
+                "ivx_region_face_pairs: bad argument");
+    IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "ivx_region_face_pairs: call ivx_label_regions first");
+    const size_t face = (size_t)g->cc[1] * g->cc[2] * 256;
+    int rc;
+    if ((rc = ensure_dev_scratch(g, 16 + face * 8))) return rc;
+    uint32_t* d_count = static_cast<uint32_t*>(g->dev_scratch);
+    void* d_pairs = static_cast<char*>(g->dev_scratch) + 16;
+    if ((rc = ivx_launch_face_pairs(g, side, static_cast<const uint32_t*>(neighbour_face_labels), d_count, d_pairs, (uint32_t)face))) return rc;
+    uint32_t n = 0;
+    if ((rc = d2h(g, &n, d_count, sizeof(n)))) return rc;
+    std::vector<uint64_t> h(n);
+    if ((rc = d2h(g, h.data(), d_pairs, (size_t)n * 8))) return rc;
+    // uint2{a,b} little-endian -> key a (low word) | b (high word); order by (a, b)
+    for (auto& k : h) k = (k << 32) | (k >> 32);
+    std::sort(h.begin(), h.end());
+    h.erase(std::unique(h.begin(), h.end()), h.end());
+    *n_out = h.size();
+    IVX_REQUIRE(h.size() <= cap, IVX_ERR_CAPACITY, "ivx_region_face_pairs: %zu pairs exceed capacity %zu", h.size(), cap);
+    for (size_t i = 0; i < h.size(); ++i) {
+        pairs[2 * i] = (uint32_t)(h[i] >> 32);
+        pairs[2 * i + 1] = (uint32_t)(h[i] & 0xFFFFFFFFu);
+    }
+    return IVX_OK;
+}
+
 int ivx_grid_set_sdf_program(ivx_grid* g, const ivx_sdf_processed_node* nodes, size_t n_nodes, uint32_t stack_size, const uint32_t grid_shape[3],
                              const float shifted_grid_center[3], uint8_t voxel_type) {
     IVX_REQUIRE(g && grid_shape && shifted_grid_center && (n_nodes == 0 || nodes), IVX_ERR_INVALID, "ivx_grid_set_sdf_program: null argument");

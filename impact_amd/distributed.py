@@ -1,0 +1,308 @@
+"""Domain decomposition of one voxel grid into x-slabs, one slab per GPU / process.
+
+The reference runs this path in a single process (no collectives anywhere in lars-frogner/Impact); the
+decomposition is the part of this build that has no reference counterpart. What crosses ranks:
+
+  1. after SDF sampling: the one-voxel x-face planes of (sdf, type) + the face layer's chunk state
+     -> neighbours' ghost layers (adjacency flags, face distributions, uniform-chunk demotion and the
+     18^3 Surface-Nets padding all read one voxel across the chunk face: object.rs:2077-2528,
+     object/sdf.rs:181-508);
+  2. after derived state + slab-local region labelling: the same planes again (now carrying the
+     post-demotion chunk kind the mesher's upper-layer rule needs, surface_nets.rs:252-261) and the face
+     planes of slab-local component ids;
+  3. one all-gather of a small record per rank: region equivalences across each rank's upper face,
+     component count, the 10 mass moments, occupied ranges and mesh sizes. Every rank then finishes the
+     same union-find (the cross-chunk resolve of split_detection.rs:323-487 carried across ranks).
+
+Slabs are chunk-aligned, so a rank talks to at most two neighbours and each message is a contiguous
+plane: RCCL send/recv over one xGMI link per neighbour; nothing is reduced in bulk.
+
+The per-slab protocol is written ONCE as a generator (`SlabStepper.phases`) that yields communication
+requests. `TorchComm` serves them with torch.distributed (backend "nccl" = RCCL on device tensors, or
+"gloo" through host staging); `run_slabs_in_process` serves them for several slabs living in one process
+on one GPU, which is how the GPU parity tests check the decomposition against the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import capi
+from .capi import check, ptr
+from .voxel import Context, SDFVoxelGenerator, VoxelObject
+
+NONE = 0xFFFFFFFF
+
+# fixed-size record every rank contributes to the final all-gather (int64 words)
+MAX_PAIRS = 1024
+REC_WORDS = 2 + 12 + 4 + 10 + 2 * MAX_PAIRS  # n_regions, n_pairs | occupied[12] | mesh v,i,s,pad | moments f64 bits | pairs
+
+
+@dataclass
+class Exchange:
+    """send `lo` to rank-1 and `hi` to rank+1 (byte buffers, device pointers); the reply is
+    (from_lo, from_hi) device pointers, or None where there is no neighbour"""
+    lo: "DeviceBuffer"
+    hi: "DeviceBuffer"
+    recv_lo: "DeviceBuffer"
+    recv_hi: "DeviceBuffer"
+
+
+@dataclass
+class AllGather:
+    record: np.ndarray  # int64[REC_WORDS]
+
+
+@dataclass
+class SlabResult:
+    region_count: int = 0                 # global number of connected regions
+    local_region_count: int = 0
+    region_of_local: np.ndarray = None    # global region id of every slab-local component
+    moments: np.ndarray = None            # global 10 moments (f64), summed in rank order
+    occupied: np.ndarray = None           # global occupied chunk/voxel ranges (12 u32)
+    mesh_counts: tuple = (0, 0, 0)        # this slab's vertices, indices, submeshes
+    vertex_offset: int = 0                # offset of this slab's vertices in the global mesh
+    index_offset: int = 0
+    total_triangles: int = 0
+    stage_ms: np.ndarray = field(default_factory=lambda: np.zeros(capi.N_TIMED_STAGES))
+
+
+class DeviceBuffer:
+    """A device allocation the comm layer can address: wraps a torch uint8 CUDA tensor."""
+
+    def __init__(self, torch, nbytes, device):
+        self.t = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+        self.nbytes = int(nbytes)
+
+    @property
+    def ptr(self) -> int:
+        return self.t.data_ptr()
+
+
+def slab_ranges(global_x_chunks: int, world: int):
+    """chunk-aligned x ranges, as even as possible, in rank order"""
+    base, rem = divmod(global_x_chunks, world)
+    out, x = [], 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((x, x + n))
+        x += n
+    return out
+
+
+def resolve_global_regions(records: np.ndarray):
+    """All ranks' records -> (global region count, per-rank arrays mapping slab-local component ->
+    global region id (ids ordered by first occurrence in rank, component order), summed moments,
+    global occupied ranges, per-rank mesh counts). Pure host code, identical on every rank."""
+    world = records.shape[0]
+    counts = [int(records[r, 0]) for r in range(world)]
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    parent = np.arange(offs[-1], dtype=np.int64)
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+
+    for r in range(world - 1):
+        n_pairs = int(records[r, 1])
+        if n_pairs > MAX_PAIRS:
+            raise capi.IvxError(capi.IVX_ERR_CAPACITY, f"rank {r}: {n_pairs} cross-slab region pairs exceed MAX_PAIRS={MAX_PAIRS}")
+        pairs = records[r, 28:28 + 2 * n_pairs].reshape(-1, 2)
+        for a, b in pairs:
+            ra, rb = find(offs[r] + int(a)), find(offs[r + 1] + int(b))
+            if ra != rb:
+                if ra < rb:
+                    parent[rb] = ra
+                else:
+                    parent[ra] = rb
+    roots = np.array([find(i) for i in range(offs[-1])], dtype=np.int64)
+    uniq, inv = np.unique(roots, return_inverse=True)  # roots are minimal members => ordered by first occurrence
+    region_of = [inv[offs[r]:offs[r + 1]].astype(np.uint32) for r in range(world)]
+    moments = np.zeros(10, dtype=np.float64)
+    for r in range(world):  # fixed rank order: bitwise reproducible
+        moments += records[r, 18:28].view(np.float64)
+    occ = np.zeros(12, dtype=np.uint32)
+    have = [r for r in range(world) if records[r, 3] > 0]
+    if have:
+        o = np.stack([records[r, 2:14] for r in have]).astype(np.uint32)
+        for q in range(12):
+            occ[q] = o[:, q].max() if (q & 1) else o[:, q].min()
+    mesh = [(int(records[r, 14]), int(records[r, 15]), int(records[r, 16])) for r in range(world)]
+    return len(uniq), region_of, moments, occ, mesh
+
+
+class SlabStepper:
+    """One x-slab of a global SDF-defined grid and its per-step protocol."""
+
+    def __init__(self, ctx: Context, graph, densities, rank: int, world: int, torch, voxel_extent: float = 1.0, voxel_type: int = 0):
+        self.rank, self.world, self.torch = rank, world, torch
+        self.gen = SDFVoxelGenerator(voxel_extent, graph, voxel_type)
+        cc = self.gen.chunk_counts()
+        if cc[0] < world:
+            raise ValueError(f"{cc[0]} chunk planes cannot be split over {world} ranks")
+        self.global_chunk_counts = cc
+        self.global_shape = tuple(c * 16 for c in cc)
+        x0, x1 = slab_ranges(cc[0], world)[rank]
+        self.x_range = (x0, x1)
+        self.obj = VoxelObject(ctx, (x1 - x0, cc[1], cc[2]), voxel_extent, x0, cc[0])
+        self.obj.set_sdf_program(self.gen)
+        self.obj.set_densities(densities)
+        dev = torch.device("cuda", ctx.device)
+        hb = self.obj.halo_bytes()
+        fb = int(capi.lib().ivx_region_face_bytes(self.obj.h))
+        self.halo_bytes, self.face_bytes = hb, fb
+        # send/recv buffers for both sides: [halo | face ids]
+        self.send = [DeviceBuffer(torch, hb + fb, dev) for _ in range(2)]
+        self.recv = [DeviceBuffer(torch, hb + fb, dev) for _ in range(2)]
+        self.has_lo, self.has_hi = rank > 0, rank + 1 < world
+        self.last = None
+
+    def close(self):
+        self.obj.close()
+
+    # -- protocol -------------------------------------------------------------------------------
+    def _install_ghosts(self):
+        for side, has in ((0, self.has_lo), (1, self.has_hi)):
+            if has:
+                self.obj.halo_unpack(side, self.recv[side].ptr)
+            else:
+                self.obj.halo_clear(side)
+
+    def phases(self):
+        """generator: yields Exchange / AllGather requests, receives their results, returns SlabResult"""
+        obj, L = self.obj, capi.lib()
+        res = SlabResult()
+        # 1. sample, exchange face planes
+        r1 = obj.step(capi.STAGE_SAMPLE)
+        for side in (0, 1):
+            obj.halo_pack(side, self.send[side].ptr)
+        yield Exchange(self.send[0], self.send[1], self.recv[0], self.recv[1])
+        self._install_ghosts()
+        # 2. derived state + slab-local regions; exchange planes again (+ component ids of the faces)
+        r2 = obj.step(capi.STAGE_DERIVE | capi.STAGE_OCCUPIED | capi.STAGE_REGIONS)
+        for side in (0, 1):
+            obj.halo_pack(side, self.send[side].ptr)
+            check(L.ivx_region_face_labels(obj.h, side, C.c_void_p(self.send[side].ptr + self.halo_bytes)))
+        yield Exchange(self.send[0], self.send[1], self.recv[0], self.recv[1])
+        self._install_ghosts()
+        rec = np.zeros(REC_WORDS, dtype=np.int64)
+        n_local = int(r2["region_count"])
+        rec[0] = n_local
+        if self.has_hi:
+            pairs = np.zeros(2 * MAX_PAIRS, dtype=np.uint32)
+            n = C.c_size_t(0)
+            check(L.ivx_region_face_pairs(obj.h, 1, C.c_void_p(self.recv[1].ptr + self.halo_bytes), ptr(pairs), MAX_PAIRS, C.byref(n)))
+            rec[1] = n.value
+            rec[28:28 + 2 * n.value] = pairs[: 2 * n.value]
+        # 3. remesh + inertia (ghost layers in place), then the one small all-gather
+        r3 = obj.step(capi.STAGE_REMESH | capi.STAGE_INERTIA)
+        rec[2:14] = r2["occupied"]
+        rec[14], rec[15], rec[16] = int(r3["mesh"]["n_vertices"]), int(r3["mesh"]["n_indices"]), int(r3["mesh"]["n_submeshes"])
+        rec[18:28] = np.ascontiguousarray(r3["moments"]["m64"]).view(np.int64)
+        records = yield AllGather(rec)
+        n_regions, region_of, moments, occ, mesh = resolve_global_regions(records)
+        res.region_count = n_regions
+        res.local_region_count = n_local
+        res.region_of_local = region_of[self.rank]
+        res.moments = moments
+        res.occupied = occ
+        res.mesh_counts = mesh[self.rank]
+        res.vertex_offset = sum(m[0] for m in mesh[: self.rank])
+        res.index_offset = sum(m[1] for m in mesh[: self.rank])
+        res.total_triangles = sum(m[1] for m in mesh) // 3
+        res.stage_ms = np.asarray(r1["stage_ms"], dtype=np.float64) + r2["stage_ms"] + r3["stage_ms"]
+        self.last = res
+        return res
+
+
+class TorchComm:
+    """Serves the protocol's requests with torch.distributed point-to-point and all-gather calls.
+    backend "nccl" (= RCCL over xGMI): device tensors go straight into send/recv; backend "gloo":
+    staged through host memory (used for CPU protocol tests and single-GPU multi-process checks)."""
+
+    def __init__(self, dist, torch, rank: int, world: int):
+        self.dist, self.torch, self.rank, self.world = dist, torch, rank, world
+        self.on_device = dist.get_backend() == "nccl"
+
+    def exchange(self, req: Exchange):
+        dist, torch = self.dist, self.torch
+        ops, staged = [], []
+        for peer, sbuf, rbuf in ((self.rank - 1, req.lo, req.recv_lo), (self.rank + 1, req.hi, req.recv_hi)):
+            if peer < 0 or peer >= self.world:
+                continue
+            if self.on_device:
+                ops.append(dist.P2POp(dist.isend, sbuf.t, peer))
+                ops.append(dist.P2POp(dist.irecv, rbuf.t, peer))
+            else:
+                s_host = sbuf.t.cpu()
+                r_host = torch.empty_like(s_host)
+                ops.append(dist.P2POp(dist.isend, s_host, peer))
+                ops.append(dist.P2POp(dist.irecv, r_host, peer))
+                staged.append((rbuf, r_host))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for rbuf, r_host in staged:
+            rbuf.t.copy_(r_host)
+        if self.on_device or staged:
+            torch.cuda.synchronize()
+
+    def all_gather(self, rec: np.ndarray) -> np.ndarray:
+        torch, dist = self.torch, self.dist
+        t = torch.from_numpy(rec)
+        if self.on_device:
+            t = t.cuda()
+        out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t.reshape(-1))
+        return out.cpu().numpy().reshape((self.world,) + tuple(rec.shape))
+
+    def run(self, stepper: SlabStepper) -> SlabResult:
+        gen = stepper.phases()
+        reply = None
+        try:
+            while True:
+                req = gen.send(reply)
+                if isinstance(req, Exchange):
+                    self.exchange(req)
+                    reply = None
+                else:
+                    reply = self.all_gather(req.record)
+        except StopIteration as stop:
+            return stop.value
+
+
+def run_slabs_in_process(steppers):
+    """Drive several slabs that live in ONE process (one GPU) in lock step, moving halo buffers with
+    device-to-device copies. Same protocol code as the distributed run; used by the GPU parity tests."""
+    gens = [s.phases() for s in steppers]
+    replies = [None] * len(gens)
+    results = [None] * len(gens)
+    live = True
+    while live:
+        reqs = []
+        for i, g in enumerate(gens):
+            try:
+                reqs.append(g.send(replies[i]))
+            except StopIteration as stop:
+                results[i] = stop.value
+                reqs.append(None)
+        if all(r is None for r in reqs):
+            break
+        if any(r is None for r in reqs):
+            raise RuntimeError("slab protocols fell out of step")
+        if isinstance(reqs[0], Exchange):
+            for i, r in enumerate(reqs):
+                if i > 0:
+                    reqs[i - 1].recv_hi.t.copy_(r.lo.t)
+                if i + 1 < len(reqs):
+                    reqs[i + 1].recv_lo.t.copy_(r.hi.t)
+            steppers[0].torch.cuda.synchronize()
+            replies = [None] * len(gens)
+        else:
+            records = np.stack([r.record for r in reqs])
+            replies = [records] * len(gens)
+    return results

@@ -75,15 +75,23 @@ def fracture_scene(scale: float = 1.0) -> SDFGraph:
     return g
 
 
-def asteroid_row_scene(n: int, scale: float = 2.0) -> SDFGraph:
-    """Weak-scaling workload: `n` config-2 asteroids (each scaled by `scale`) side by side along x with
-    a small overlap so that neighbouring slabs are physically connected across the rank boundary."""
+def asteroid_row_scene(n: int, scale: float = 2.05, bar_width: float | None = None) -> SDFGraph:
+    """Weak-scaling workload: `n` config-2 asteroids (each scaled by `scale`) in a row along x, one per
+    x-slab, joined by a thin box so that the body is ONE connected region that crosses every slab
+    boundary. The pitch is the single asteroid's own stored grid width (a whole number of chunks), so
+    with n ranks every slab holds exactly the N=1 workload: global grid = (n * pitch) x pitch x pitch."""
+    from .voxel import SDFVoxelGenerator  # host-side graph compile only
+
+    pitch = 16.0 * SDFVoxelGenerator(1.0, asteroid_scene(scale)).chunk_counts()[0]
     g = SDFGraph()
-    pitch = 256.0 * scale
     acc = None
     for r in range(n):
         body = _asteroid_body(g, scale)
         if n > 1:
             body = g.add_node(SDFNode.new_translation(body, (pitch * (r - 0.5 * (n - 1)), 0.0, 0.0)))
         acc = body if acc is None else g.add_node(SDFNode.new_union(acc, body, 0.0))
+    if n > 1:
+        w = 12.0 * scale if bar_width is None else bar_width
+        bar = g.add_node(SDFNode.new_box((pitch * (n - 1), w, w)))
+        g.add_node(SDFNode.new_union(acc, bar, 0.0))
     return g

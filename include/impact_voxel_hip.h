@@ -205,6 +205,17 @@ int ivx_halo_pack(ivx_grid*, int side, void* device_buf);
 int ivx_halo_unpack(ivx_grid*, int side, const void* device_buf); /* install as ghost layer on `side` */
 int ivx_halo_clear(ivx_grid*, int side);                          /* no neighbour: outside the grid */
 
+/* Cross-slab connected regions: after ivx_label_regions on every slab, exchange the face planes of
+ * component ids with the x neighbours, list the distinct (own component, neighbour component) pairs
+ * that touch across the face, all-gather the pairs and finish the union on the host. This carries the
+ * reference's cross-chunk region connections (object/split_detection.rs:323-487, 1046-1325) across ranks.
+ * ivx_region_face_labels writes cy*cz*256 u32 (0xFFFFFFFF = empty voxel) to a DEVICE buffer;
+ * ivx_region_face_pairs takes the neighbour's plane (device) and returns sorted unique pairs
+ * (pairs[2i] = own id, pairs[2i+1] = neighbour id) in HOST memory. */
+size_t ivx_region_face_bytes(ivx_grid*);
+int ivx_region_face_labels(ivx_grid*, int side, void* device_buf);
+int ivx_region_face_pairs(ivx_grid*, int side, const void* neighbour_face_labels_device, uint32_t* pairs, size_t cap, size_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

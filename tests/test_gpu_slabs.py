@@ -1,0 +1,115 @@
+"""GPU parity of the x-slab domain decomposition (impact_amd/distributed.py): several slabs of one grid
+live in ONE process on one GPU and run the same per-slab protocol the multi-GPU bench runs; halos move by
+device copies instead of RCCL. Everything is compared with the oracle on the WHOLE grid: voxel bytes,
+flags, chunk state, concatenated mesh (bit-exact index buffer after the per-slab vertex offset),
+moments (1e-5 rel), occupied ranges and the connected-region partition."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from impact_amd import capi, scenes
+from impact_amd.distributed import SlabStepper, run_slabs_in_process
+
+pytestmark = pytest.mark.gpu
+
+
+def run_and_compare(ctx, graph, world, expect_regions=None, extent=1.0):
+    import torch
+
+    dens = np.linspace(0.5, 2.0, 256).astype(np.float32)
+    o = ol.OracleObject.from_sdf(graph, extent, 0)
+    o.update_occupied_voxel_ranges()
+    o.compute_all_derived_state()
+    steppers = [SlabStepper(ctx, graph, dens, r, world, torch, extent) for r in range(world)]
+    try:
+        for _ in range(2):  # twice: the second pass starts from a dirty state (ghosts, labels, mesh buffers)
+            results = run_slabs_in_process(steppers)
+        cc = o.chunk_counts
+        assert steppers[0].global_chunk_counts == cc
+        o_sdf, o_typ, o_flg, o_lab, o_info = o.export_dense()
+        per_chunk = cc[1] * cc[2]
+        # voxel planes + chunk state, slab by slab
+        for s in steppers:
+            x0, x1 = s.x_range
+            sl = slice(x0 * per_chunk * 4096, x1 * per_chunk * 4096)
+            g_sdf, g_typ, g_flg, g_lab, g_info = s.obj.download()
+            np.testing.assert_array_equal(g_sdf, o_sdf[sl])
+            np.testing.assert_array_equal(g_typ, o_typ[sl])
+            np.testing.assert_array_equal(g_flg, o_flg[sl])
+            oi = o_info[x0 * per_chunk:x1 * per_chunk]
+            for f in ("kind", "gen_kind", "flags", "face_dist", "uniform_type", "region_count", "boundary_region_count"):
+                np.testing.assert_array_equal(g_info[f], oi[f], err_msg=f"{f} slab {s.rank}")
+        # mesh: concatenation of the slab meshes in rank order
+        om = o.mesh()
+        pos, nrm, idx, im, sub = [], [], [], [], []
+        from impact_amd.voxel import VoxelObjectMesh
+
+        for s, r in zip(steppers, results):
+            m = VoxelObjectMesh(s.obj)
+            m.counts = np.zeros((), dtype=capi.MESH_COUNTS_DTYPE)
+            m.counts["n_vertices"], m.counts["n_indices"], m.counts["n_submeshes"] = r.mesh_counts
+            p, n, i, mat, sm = m.download()
+            pos.append(p)
+            nrm.append(n)
+            idx.append(i + np.uint32(r.vertex_offset))
+            im.append(mat)
+            sm = sm.copy()
+            sm["index_offset"] += r.index_offset
+            sm["vertex_offset"] += r.vertex_offset
+            sub.append(sm)
+        pos, nrm, idx, im, sub = np.concatenate(pos), np.concatenate(nrm), np.concatenate(idx), np.concatenate(im), np.concatenate(sub)
+        np.testing.assert_array_equal(idx, om.indices)
+        np.testing.assert_array_equal(pos.view(np.uint32), om.positions.view(np.uint32))
+        np.testing.assert_array_equal(nrm.view(np.uint32), om.normals.view(np.uint32))
+        np.testing.assert_array_equal(im, om.index_materials)
+        np.testing.assert_array_equal(sub["chunk_indices"], om.submeshes[:, 0:3])
+        np.testing.assert_array_equal(sub["index_offset"], om.submeshes[:, 3])
+        np.testing.assert_array_equal(sub["vertex_offset"], om.submeshes[:, 13])
+        assert results[0].total_triangles == om.indices.size // 3
+        # moments, occupied ranges
+        _, o64 = o.inertia(dens)
+        for r in results:
+            np.testing.assert_allclose(r.moments, o64, rtol=1e-5)
+            np.testing.assert_array_equal(r.moments, results[0].moments)  # identical on every rank
+        info = o.info()
+        occ = results[0].occupied
+        assert [(int(occ[2 * d]), int(occ[2 * d + 1])) for d in range(3)] == info["occupied_chunk_ranges"]
+        assert [(int(occ[6 + 2 * d]), int(occ[7 + 2 * d])) for d in range(3)] == info["occupied_voxel_ranges"]
+        # connected regions: same count and same partition of the voxels
+        n_o, olab = o.region_labels()
+        assert all(r.region_count == n_o for r in results)
+        if expect_regions is not None:
+            assert n_o == expect_regions
+        glab = []
+        for s, r in zip(steppers, results):
+            loc = s.obj.region_labels()
+            out = np.full(loc.shape, 0xFFFFFFFF, dtype=np.uint32)
+            m = loc != 0xFFFFFFFF
+            out[m] = r.region_of_local[loc[m]]
+            glab.append(out)
+        glab = ol.tiled_to_dense(np.concatenate(glab), cc)
+        np.testing.assert_array_equal(ol.canonicalize_labels(glab, 0xFFFFFFFF), ol.canonicalize_labels(olab, 0xFFFFFFFF))
+    finally:
+        for s in steppers:
+            s.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_asteroid_256_in_slabs(ctx, world):
+    """BASELINE config 2 body, split in 2 and 4 x-slabs (config 5's decomposition at 1/4 scale)"""
+    run_and_compare(ctx, scenes.asteroid_scene(), world, expect_regions=1)
+
+
+def test_fracture_256_in_3_slabs(ctx):
+    """config 3: 8 octants; an uneven 3-way split puts a slab boundary inside four of them"""
+    run_and_compare(ctx, scenes.fracture_scene(), 3, expect_regions=8)
+
+
+def test_asteroid_row_in_slabs(ctx):
+    """the weak-scaling bench workload at small scale: one body per slab joined by a bar"""
+    run_and_compare(ctx, scenes.asteroid_row_scene(3, 0.25), 3, expect_regions=1)
+
+
+def test_two_spheres_cut_between(ctx):
+    """a slab boundary in the gap between two bodies: empty ghost planes, two regions"""
+    run_and_compare(ctx, scenes.two_spheres_scene(25.0, 60.0), 2, expect_regions=2, extent=0.5)
