@@ -104,6 +104,13 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch (ROCm wheel) bundles its own HIP runtime; two runtimes in one process cannot both own the GPU
+    # ("No HIP GPUs are available" in whichever initialises second). Importing torch first makes this
+    # library bind to the runtime torch already loaded, so device buffers and streams can be shared.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise IvxError(IVX_ERR_HIP, f"{LIB_PATH} not found — run `python -c 'import __graft_entry__ as g; g.build()'`")
     L = C.CDLL(LIB_PATH)

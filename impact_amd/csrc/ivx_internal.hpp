@@ -91,6 +91,8 @@ struct ivx_grid {
     uint8_t prog_type;
     int has_dens;
     double* moments_dev;  // [10]
+    uint32_t* samp_len;   // [n_chunks] length of the chunk's compact SDF program (sampler pre-pass)
+    void* samp_ops;       // [n_chunks * 128] uint2 ops
     hipEvent_t ev[12];
     int ev_ready;
     // host pinned scratch

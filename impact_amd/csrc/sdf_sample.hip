@@ -245,40 +245,85 @@ __device__ __forceinline__ void leaf_bounds(const ivx_sdf_processed_node* nd, Bo
     hi += slack(hi);
 }
 
-__global__ __launch_bounds__(256) void k_sdf_prepass(SampleParams p, const ivx_sdf_processed_node* __restrict__ nodes,
-                                                     float* __restrict__ chunk_const) {
-    __shared__ float s_lo[16][256];
-    __shared__ float s_hi[16][256];
+// The node program is staged through LDS in tiles: per-node parameter fetches from HBM at ~1 us of
+// dependent latency each were the whole cost of large programs (hundreds of nodes). Stride 33 dwords
+// keeps lane-per-node reads conflict free.
+constexpr int NODE_TILE = 64;
+// Compact per-chunk program emitted by the pre-pass: op word = opcode<<28 | node kind<<24 | node index;
+// OP_CONST carries the folded constant in the second word.
+constexpr uint32_t OP_CAP = 128u, OP_OVERFLOW = 0xFFFFFFFFu;
+constexpr uint32_t OP_CONST = 0u, OP_LEAF = 1u, OP_SCALE = 2u, OP_COMBINE = 3u, OP_COMBINE_OUTSIDE = 4u;
+constexpr int PRE_T = 64;
+struct PaddedNode {
+    ivx_sdf_processed_node n;
+    uint32_t pad;
+};
+static_assert(sizeof(PaddedNode) == 132, "node tile stride");
+__device__ __forceinline__ void load_node_tile(PaddedNode* tile, const ivx_sdf_processed_node* src, uint32_t count, uint32_t tid, uint32_t nthreads) {
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+    uint32_t* d = reinterpret_cast<uint32_t*>(tile);
+    for (uint32_t i = tid; i < count * 32u; i += nthreads) d[(i >> 5) * 33u + (i & 31u)] = s[i];
+}
+
+__global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx_sdf_processed_node* __restrict__ nodes,
+                                                       float* __restrict__ chunk_const, uint32_t* __restrict__ prog_len,
+                                                       uint2* __restrict__ prog_ops) {
+    __shared__ float s_lo[16][PRE_T];
+    __shared__ float s_hi[16][PRE_T];
+    __shared__ uint16_t s_start[16][PRE_T];  // op-stream position where each stack level's steps begin
+    __shared__ PaddedNode s_nodes[NODE_TILE];
     const uint32_t n_chunks = p.cx * p.cy * p.cz;
-    const uint32_t chunk = blockIdx.x * 256u + threadIdx.x;
-    if (chunk >= n_chunks) return;
     const uint32_t tid = threadIdx.x;
+    // out-of-range threads still take part in the tile loads and barriers; they redo the last chunk
+    const uint32_t chunk = min(blockIdx.x * PRE_T + tid, n_chunks - 1u);
     const uint32_t ck = chunk % p.cz, cj = (chunk / p.cz) % p.cy, ci = chunk / (p.cz * p.cy);
     const uint32_t oi = (ci + p.x_off) * 16u, oj = cj * 16u, ok = ck * 16u;
     const V3 origin_root = sub(mk((float)oi, (float)oj, (float)ok), mk(p.shifted_center[0], p.shifted_center[1], p.shifted_center[2]));
     const Box block{origin_root, add(origin_root, mk(16.0f, 16.0f, 16.0f))};
     uint32_t top = 0, cmask = 0;  // cmask bit: level is an EXACT block constant (lo == hi == value)
+    // Compact program of this chunk: steps of constant sub-expressions collapse into one OP_CONST (the
+    // steps of a stack level are a contiguous tail of the stream, so folding = truncate + re-emit).
+    uint2* ops = prog_ops + (size_t)chunk * OP_CAP;
+    uint32_t pos = 0;
+    auto emit = [&](uint32_t w, uint32_t v) {
+        if (pos < OP_CAP) ops[pos] = make_uint2(w, v);
+        pos += 1;
+    };
     for (uint32_t n = 0; n < p.n_nodes; ++n) {
-        const ivx_sdf_processed_node* nd = nodes + n;
+        if ((n % NODE_TILE) == 0u) {  // stage the next tile of the node program in LDS (one coalesced round trip)
+            __syncthreads();
+            load_node_tile(s_nodes, nodes + n, min((uint32_t)NODE_TILE, p.n_nodes - n), tid, PRE_T);
+            __syncthreads();
+        }
+        const ivx_sdf_processed_node* nd = &s_nodes[n % NODE_TILE].n;
         const uint32_t kind = nd->kind;
         if (kind <= 2u) {
             const uint32_t mode = node_mode(nd, block);
+            s_start[top][tid] = (uint16_t)min(pos, 0xFFFFu);
             if (mode == 1u || mode == 2u) {
                 const float v = mode == 1u ? nd->margin : -nd->margin;
                 s_lo[top][tid] = v;
                 s_hi[top][tid] = v;
                 cmask |= 1u << top;
+                emit(OP_CONST << 28, __float_as_uint(v));
             } else {
                 float lo, hi;
                 leaf_bounds(nd, aabb_of_transformed(block, nd->transform), lo, hi);
                 s_lo[top][tid] = lo;
                 s_hi[top][tid] = hi;
                 cmask &= ~(1u << top);
+                emit((OP_LEAF << 28) | (kind << 24) | n, 0u);
             }
             top += 1;
         } else if (kind == 5u) {
             s_lo[top - 1][tid] = s_lo[top - 1][tid] * nd->a;
             s_hi[top - 1][tid] = s_hi[top - 1][tid] * nd->a;
+            if ((cmask >> (top - 1)) & 1u) {
+                pos = s_start[top - 1][tid];
+                emit(OP_CONST << 28, __float_as_uint(s_lo[top - 1][tid]));
+            } else {
+                emit((OP_SCALE << 28) | (kind << 24) | n, 0u);
+            }
         } else if (kind >= 7u) {
             top -= 1;
             const bool c1 = (cmask >> (top - 1)) & 1u, c2 = (cmask >> top) & 1u;
@@ -291,6 +336,8 @@ __global__ __launch_bounds__(256) void k_sdf_prepass(SampleParams p, const ivx_s
                     s_lo[top - 1][tid] = r;
                     s_hi[top - 1][tid] = r;
                 }
+                pos = s_start[top - 1][tid];
+                emit(OP_CONST << 28, __float_as_uint(s_lo[top - 1][tid]));
             } else {
                 // absorption: an exact constant operand that the other operand can never come within
                 // the smoothing distance of is the result, exactly (h = 0 in generation/sdf.rs:89-92)
@@ -311,8 +358,11 @@ __global__ __launch_bounds__(256) void k_sdf_prepass(SampleParams p, const ivx_s
                     s_lo[top - 1][tid] = av;
                     s_hi[top - 1][tid] = av;
                     cmask |= 1u << (top - 1);
+                    pos = s_start[top - 1][tid];
+                    emit(OP_CONST << 28, __float_as_uint(av));
                     continue;
                 }
+                emit(((must_apply ? OP_COMBINE : OP_COMBINE_OUTSIDE) << 28) | (kind << 24) | n, 0u);
                 float rlo, rhi;
                 if (kind == 8u) {  // subtraction: decreasing in the second operand
                     rlo = combine(kind, lo1, hi2, s, q);
@@ -339,9 +389,88 @@ __global__ __launch_bounds__(256) void k_sdf_prepass(SampleParams p, const ivx_s
     else if (lo >= 2.54f + 0.02f) out = 1000.0f;    // every voxel quantises to +127
     else if (hi <= -2.56f - 0.02f) out = -1000.0f;  // every voxel quantises to -128
     chunk_const[chunk] = out;
+    prog_len[chunk] = pos <= OP_CAP ? pos : OP_OVERFLOW;
 }
 
-__global__ __launch_bounds__(256) void k_sdf_sample(SampleParams p, const float* __restrict__ chunk_const, const ivx_sdf_processed_node* __restrict__ nodes,
+// ---- per-voxel evaluation ----------------------------------------------------------------------
+// One stack-machine step each; shared by the compact per-chunk program (normal path) and the full
+// node program (fallback when a chunk's compact program overflows OP_CAP).
+__device__ __forceinline__ void eval_leaf(const ivx_sdf_processed_node* nd, uint32_t kind, float* d, V3 origin_root, uint32_t ti, uint32_t tj) {
+    const float* m = nd->transform;
+    const V3 origin = xform_point(m, origin_root);
+    const V3 dx = mk(m[0], m[1], m[2]), dy = mk(m[4], m[5], m[6]), dz = mk(m[8], m[9], m[10]);
+    const V3 opx = add(origin, scale(dx, (float)ti));
+    V3 pos = add(opx, scale(dy, (float)tj));
+    const float pa = nd->a, pb = nd->b, pc = nd->c;
+    if (kind == 0u) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            d[k * 256] = len3(pos) - pa;
+            pos = add(pos, dz);
+        }
+    } else if (kind == 1u) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            V3 q = pos;
+            float c = q.y;
+            if (c < -pa) c = -pa;
+            if (c > pa) c = pa;
+            q.y -= c;
+            d[k * 256] = len3(q) - pb;
+            pos = add(pos, dz);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            V3 q = mk(fabsf(pos.x) - pa, fabsf(pos.y) - pb, fabsf(pos.z) - pc);
+            V3 qp = mk(max_rs(q.x, 0.0f), max_rs(q.y, 0.0f), max_rs(q.z, 0.0f));
+            d[k * 256] = len3(qp) + min_rs(max_rs(max_rs(q.x, q.y), q.z), 0.0f);
+            pos = add(pos, dz);
+        }
+    }
+}
+
+// Combination of levels top-1 and top (after the caller decremented `top`). `outside` = the node's
+// domain lies outside the block, so the reference applies it only if one of the 14 distinct block test
+// positions fails `value >= margin` (atomic.rs:788-806, 1661-1797).
+__device__ __forceinline__ void combine_levels(uint32_t kind, float s, float q, float margin, bool outside, uint32_t top, float* stack,
+                                               float* s_cval, uint32_t& cmask, uint32_t tid) {
+    float* d1 = stack + (size_t)(top - 1) * IVX_CHUNK_VOXELS;
+    const float* d2 = stack + (size_t)top * IVX_CHUNK_VOXELS;
+    const bool c1 = (cmask >> (top - 1)) & 1u, c2 = (cmask >> top) & 1u;
+    const float v1 = c1 ? s_cval[top - 1] : 0.0f, v2 = c2 ? s_cval[top] : 0.0f;
+    bool apply = !outside;
+    if (!apply) {  // workgroup-uniform branch
+        if (c1 && c2) {
+            apply = __builtin_amdgcn_readfirstlane(!(combine(kind, v1, v2, s, q) >= margin) ? 1 : 0) != 0;
+        } else {
+            __syncthreads();
+            // distinct flat indices of the 26 test positions: 8 corners + 6 face centres
+            const int TI[14] = {0, 15, 0, 0, 15, 15, 0, 15, 0, 15, 8, 8, 8, 8};
+            const int TJ[14] = {0, 0, 15, 0, 15, 0, 15, 15, 8, 8, 0, 15, 8, 8};
+            const int TK[14] = {0, 0, 0, 15, 0, 15, 15, 15, 8, 8, 8, 8, 0, 15};
+            bool all_pass = true;
+#pragma unroll
+            for (int t = 0; t < 14; ++t) {
+                int off = TK[t] * 256 + (TI[t] * 16 + TJ[t]);
+                all_pass = all_pass && (combine(kind, c1 ? v1 : d1[off], c2 ? v2 : d2[off], s, q) >= margin);
+            }
+            apply = __builtin_amdgcn_readfirstlane(all_pass ? 0 : 1) != 0;
+            __syncthreads();
+        }
+    }
+    if (apply) {
+        if (c1 && c2) {
+            s_cval[top - 1] = combine(kind, v1, v2, s, q);
+        } else {
+            apply_rows_dispatch(kind, d1 + tid, d2 + tid, c1, c2, v1, v2, s, q);
+            cmask &= ~(1u << (top - 1));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sdf_sample(SampleParams p, const float* __restrict__ chunk_const, const uint32_t* __restrict__ prog_len,
+                                                    const uint2* __restrict__ prog_ops, const ivx_sdf_processed_node* __restrict__ nodes,
                                                     int8_t* __restrict__ sdf_out, uint8_t* __restrict__ type_out,
                                                     ivx_chunk_info* __restrict__ info_out) {
     extern __shared__ float stack[];  // [stack_size][16][256]
@@ -376,116 +505,109 @@ __global__ __launch_bounds__(256) void k_sdf_sample(SampleParams p, const float*
     const V3 origin_root = sub(mk((float)oi, (float)oj, (float)ok), mk(p.shifted_center[0], p.shifted_center[1], p.shifted_center[2]));
     const Box block{origin_root, add(origin_root, mk(16.0f, 16.0f, 16.0f))};
 
-    // Control flow is kept wave-uniform and scalar: node parameters come from read-only global memory at
-    // uniform addresses (scalar loads), every node's block-level decision (the reference's whole-block
-    // early-outs) is taken by one LANE per node, 64 nodes at a time, and broadcast as two 64-bit ballot
-    // masks held in SGPRs. All waves compute identical masks, so no barrier is needed for them.
-    //
-    // Block-constant propagation: a stack level whose 4096 values are all equal (`fill(+-margin)`) is
-    // kept as one scalar; combining two constants yields a constant. Element-wise results are unchanged
-    // (same op on equal inputs), but chunks far from the surface do no per-voxel work at all.
+    // Control flow is wave-uniform and scalar. Block-constant propagation: a stack level whose 4096
+    // values are all equal (`fill(+-margin)`) is kept as one scalar; combining two constants yields a
+    // constant. Element-wise results are unchanged (same op on equal inputs).
     __shared__ float s_cval_all[4][16];  // one copy per wave: waves drift apart between barriers
     float* s_cval = s_cval_all[tid >> 6];
     const uint32_t lane = tid & 63u;
     uint32_t top = 0;
     uint32_t cmask = 0;  // bit l set: level l is block-constant, value in s_cval[l]
-    for (uint32_t g0 = 0; g0 < p.n_nodes; g0 += 64u) {
-        const uint32_t mine = g0 + lane;
-        const uint32_t my_mode = mine < p.n_nodes ? node_mode(nodes + mine, block) : 0u;
-        const unsigned long long mk1 = __ballot(my_mode == 1u), mk2 = __ballot(my_mode == 2u);
-        const uint32_t cnt = min(64u, p.n_nodes - g0);
-        for (uint32_t j = 0; j < cnt; ++j) {
-            const ivx_sdf_processed_node* nd = nodes + g0 + j;
-            const uint32_t kind = __builtin_amdgcn_readfirstlane(nd->kind);
-            const uint32_t mode = ((mk1 >> j) & 1ull) ? 1u : (((mk2 >> j) & 1ull) ? 2u : 0u);
-            if (kind <= 2u) {
-                const float margin = nd->margin;
-                if (mode == 1u) {
-                    s_cval[top] = margin;
-                    cmask |= 1u << top;
-                } else if (mode == 2u) {
-                    s_cval[top] = -margin;
-                    cmask |= 1u << top;
-                } else {
-                    float* d = stack + (size_t)top * IVX_CHUNK_VOXELS + tid;
-                    cmask &= ~(1u << top);
-                    const float* m = nd->transform;
-                    const V3 origin = xform_point(m, origin_root);
-                    const V3 dx = mk(m[0], m[1], m[2]), dy = mk(m[4], m[5], m[6]), dz = mk(m[8], m[9], m[10]);
-                    const V3 opx = add(origin, scale(dx, (float)ti));
-                    V3 pos = add(opx, scale(dy, (float)tj));
-                    const float pa = nd->a, pb = nd->b, pc = nd->c;
-                    if (kind == 0u) {
+
+    const uint32_t len = __builtin_amdgcn_readfirstlane(prog_len[chunk]);
+    if (len != OP_OVERFLOW) {
+        // ---- compact program written by the pre-pass for this chunk: only the steps that need per-voxel
+        // work plus folded constants. Lane i holds op i (two rounds for OP_CAP = 128) and the scalar
+        // parameters of its node, so the serial walk below never waits on memory.
+        const uint2* ops = prog_ops + (size_t)chunk * OP_CAP;
+        uint32_t my_w[2], my_v[2];
+        float my_s[2], my_q[2], my_m[2];
 #pragma unroll
-                        for (int k = 0; k < 16; ++k) {
-                            d[k * 256] = len3(pos) - pa;
-                            pos = add(pos, dz);
-                        }
-                    } else if (kind == 1u) {
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) {
-                            V3 q = pos;
-                            float c = q.y;
-                            if (c < -pa) c = -pa;
-                            if (c > pa) c = pa;
-                            q.y -= c;
-                            d[k * 256] = len3(q) - pb;
-                            pos = add(pos, dz);
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) {
-                            V3 q = mk(fabsf(pos.x) - pa, fabsf(pos.y) - pb, fabsf(pos.z) - pc);
-                            V3 qp = mk(max_rs(q.x, 0.0f), max_rs(q.y, 0.0f), max_rs(q.z, 0.0f));
-                            d[k * 256] = len3(qp) + min_rs(max_rs(max_rs(q.x, q.y), q.z), 0.0f);
-                            pos = add(pos, dz);
-                        }
-                    }
-                }
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t i = lane + 64u * r;
+            uint2 o = make_uint2(0u, 0u);
+            if (i < len) o = ops[i];
+            my_w[r] = o.x;
+            my_v[r] = o.y;
+            const uint32_t opc = o.x >> 28;
+            const ivx_sdf_processed_node* nd = nodes + (o.x & 0xFFFFFFu);
+            my_s[r] = 0.0f, my_q[r] = 0.0f, my_m[r] = 0.0f;
+            if (i < len && opc >= OP_SCALE) {
+                my_s[r] = nd->a;
+                my_q[r] = nd->b;
+                my_m[r] = nd->margin;
+            }
+        }
+        for (uint32_t i = 0; i < len; ++i) {
+            const uint32_t l = i & 63u;
+            uint32_t w, v;
+            float s, q, margin;
+            if (i < 64u) {
+                w = __builtin_amdgcn_readlane(my_w[0], l);
+                v = __builtin_amdgcn_readlane(my_v[0], l);
+                s = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s[0]), l));
+                q = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_q[0]), l));
+                margin = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_m[0]), l));
+            } else {
+                w = __builtin_amdgcn_readlane(my_w[1], l);
+                v = __builtin_amdgcn_readlane(my_v[1], l);
+                s = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s[1]), l));
+                q = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_q[1]), l));
+                margin = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_m[1]), l));
+            }
+            const uint32_t opc = w >> 28, kind = (w >> 24) & 15u;
+            if (opc == OP_CONST) {
+                s_cval[top] = __uint_as_float(v);
+                cmask |= 1u << top;
                 top += 1;
-            } else if (kind == 5u) {
-                const float s = nd->a;
-                if ((cmask >> (top - 1)) & 1u) {
-                    s_cval[top - 1] = s_cval[top - 1] * s;
-                } else {
-                    float* d = stack + (size_t)(top - 1) * IVX_CHUNK_VOXELS + tid;
+            } else if (opc == OP_LEAF) {
+                cmask &= ~(1u << top);
+                eval_leaf(nodes + (w & 0xFFFFFFu), kind, stack + (size_t)top * IVX_CHUNK_VOXELS + tid, origin_root, ti, tj);
+                top += 1;
+            } else if (opc == OP_SCALE) {
+                // constant levels were folded by the pre-pass: the level is per-voxel here
+                float* d = stack + (size_t)(top - 1) * IVX_CHUNK_VOXELS + tid;
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) d[k * 256] *= s;
-                }
-            } else if (kind >= 7u) {
+                for (int k = 0; k < 16; ++k) d[k * 256] *= s;
+            } else {
                 top -= 1;
-                float* d1 = stack + (size_t)(top - 1) * IVX_CHUNK_VOXELS;
-                const float* d2 = stack + (size_t)top * IVX_CHUNK_VOXELS;
-                const bool c1 = (cmask >> (top - 1)) & 1u, c2 = (cmask >> top) & 1u;
-                const float v1 = c1 ? s_cval[top - 1] : 0.0f, v2 = c2 ? s_cval[top] : 0.0f;
-                const float s = nd->a, q = nd->b, margin = nd->margin;
-                bool apply = mode == 0u;
-                if (!apply) {  // workgroup-uniform branch
-                    if (c1 && c2) {
-                        apply = __builtin_amdgcn_readfirstlane(!(combine(kind, v1, v2, s, q) >= margin) ? 1 : 0) != 0;
+                combine_levels(kind, s, q, margin, opc == OP_COMBINE_OUTSIDE, top, stack, s_cval, cmask, tid);
+            }
+        }
+    } else {
+        // ---- fallback: the full node program; every node's block-level decision (the reference's
+        // whole-block early-outs) is taken by one LANE per node, 64 nodes at a time, and broadcast as
+        // two 64-bit ballot masks held in SGPRs.
+        for (uint32_t g0 = 0; g0 < p.n_nodes; g0 += 64u) {
+            const uint32_t mine = g0 + lane;
+            const uint32_t my_mode = mine < p.n_nodes ? node_mode(nodes + mine, block) : 0u;
+            const unsigned long long mk1 = __ballot(my_mode == 1u), mk2 = __ballot(my_mode == 2u);
+            const uint32_t cnt = min(64u, p.n_nodes - g0);
+            for (uint32_t j = 0; j < cnt; ++j) {
+                const ivx_sdf_processed_node* nd = nodes + g0 + j;
+                const uint32_t kind = __builtin_amdgcn_readfirstlane(nd->kind);
+                const uint32_t mode = ((mk1 >> j) & 1ull) ? 1u : (((mk2 >> j) & 1ull) ? 2u : 0u);
+                if (kind <= 2u) {
+                    if (mode != 0u) {
+                        s_cval[top] = mode == 1u ? nd->margin : -nd->margin;
+                        cmask |= 1u << top;
                     } else {
-                        __syncthreads();
-                        // distinct flat indices of the 26 test positions: 8 corners + 6 face centres
-                        const int TI[14] = {0, 15, 0, 0, 15, 15, 0, 15, 0, 15, 8, 8, 8, 8};
-                        const int TJ[14] = {0, 0, 15, 0, 15, 0, 15, 15, 8, 8, 0, 15, 8, 8};
-                        const int TK[14] = {0, 0, 0, 15, 0, 15, 15, 15, 8, 8, 8, 8, 0, 15};
-                        bool all_pass = true;
+                        cmask &= ~(1u << top);
+                        eval_leaf(nd, kind, stack + (size_t)top * IVX_CHUNK_VOXELS + tid, origin_root, ti, tj);
+                    }
+                    top += 1;
+                } else if (kind == 5u) {
+                    const float s = nd->a;
+                    if ((cmask >> (top - 1)) & 1u) {
+                        s_cval[top - 1] = s_cval[top - 1] * s;
+                    } else {
+                        float* d = stack + (size_t)(top - 1) * IVX_CHUNK_VOXELS + tid;
 #pragma unroll
-                        for (int t = 0; t < 14; ++t) {
-                            int off = TK[t] * 256 + (TI[t] * 16 + TJ[t]);
-                            all_pass = all_pass && (combine(kind, c1 ? v1 : d1[off], c2 ? v2 : d2[off], s, q) >= margin);
-                        }
-                        apply = __builtin_amdgcn_readfirstlane(all_pass ? 0 : 1) != 0;
-                        __syncthreads();
+                        for (int k = 0; k < 16; ++k) d[k * 256] *= s;
                     }
-                }
-                if (apply) {
-                    if (c1 && c2) {
-                        s_cval[top - 1] = combine(kind, v1, v2, s, q);
-                    } else {
-apply_rows_dispatch(kind, d1 + tid, d2 + tid, c1, c2, v1, v2, s, q);
-                        cmask &= ~(1u << (top - 1));
-                    }
+                } else if (kind >= 7u) {
+                    top -= 1;
+                    combine_levels(kind, nd->a, nd->b, nd->margin, mode != 0u, top, stack, s_cval, cmask, tid);
                 }
             }
         }
@@ -537,11 +659,16 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
     p.stack_size = stack_size;
     p.voxel_type = voxel_type;
     size_t lds = (size_t)(stack_size ? stack_size : 1) * IVX_CHUNK_VOXELS * sizeof(float);
-    IVX_REQUIRE(lds <= 159 * 1024, IVX_ERR_CAPACITY, "SDF graph needs a forward stack of %u blocks (at most 9 fit the 160 KiB LDS)", stack_size);
+    IVX_REQUIRE(lds <= 150 * 1024, IVX_ERR_CAPACITY, "SDF graph needs a forward stack of %u blocks (at most 9 fit the 160 KiB LDS)", stack_size);
     IVX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sdf_sample), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     float* chunk_const = reinterpret_cast<float*>(g->chunk_bbox);  // scratch: rewritten by ivx_derive_state afterwards
-    if (n_nodes) hipLaunchKernelGGL(k_sdf_prepass, dim3((g->n_chunks + 255u) / 256u), dim3(256), 0, g->ctx->stream, p, d_nodes, chunk_const);
-    hipLaunchKernelGGL(k_sdf_sample, dim3(g->n_chunks), dim3(256), lds, g->ctx->stream, p, chunk_const, d_nodes, g->sdf, g->type, g->info);
+    if (!g->samp_ops) {  // per-chunk compact programs (8 B x OP_CAP per chunk) + their lengths
+        IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_len), sizeof(uint32_t) * g->n_chunks));
+        IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_ops), sizeof(uint2) * (size_t)OP_CAP * g->n_chunks));
+    }
+    uint2* ops = reinterpret_cast<uint2*>(g->samp_ops);
+    if (n_nodes) hipLaunchKernelGGL(k_sdf_prepass, dim3((g->n_chunks + PRE_T - 1) / PRE_T), dim3(PRE_T), 0, g->ctx->stream, p, d_nodes, chunk_const, g->samp_len, ops);
+    hipLaunchKernelGGL(k_sdf_sample, dim3(g->n_chunks), dim3(256), lds, g->ctx->stream, p, chunk_const, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
