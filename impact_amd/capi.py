@@ -70,6 +70,45 @@ assert STEP_RESULT_DTYPE.itemsize == 256
 assert CHUNK_INFO_DTYPE.itemsize == 8 and SUBMESH_DTYPE.itemsize == 64
 assert MOMENTS_DTYPE.itemsize == 128 and REGION_DESC_DTYPE.itemsize == 128
 
+# rigid bodies / contacts (impact_physics) — reference #[repr(C)] layouts
+RIGID_BODY_DTYPE = np.dtype(
+    [
+        ("mass", "<f4"),
+        ("inertia", "<f4", (9,)),       # Matrix3C, column-major
+        ("inv_inertia", "<f4", (9,)),
+        ("position", "<f4", (3,)),
+        ("orientation", "<f4", (4,)),   # x, y, z, w
+        ("momentum", "<f4", (3,)),
+        ("angular_momentum", "<f4", (3,)),
+        ("total_force", "<f4", (3,)),
+        ("total_torque", "<f4", (3,)),
+    ]
+)
+KINEMATIC_BODY_DTYPE = np.dtype(
+    [("position", "<f4", (3,)), ("orientation", "<f4", (4,)), ("velocity", "<f4", (3,)), ("angular_axis", "<f4", (3,)), ("angular_speed", "<f4")]
+)
+CONTACT_DTYPE = np.dtype(
+    [
+        ("id", "<u8"),
+        ("body_a", "<u4"),
+        ("body_b", "<u4"),
+        ("position", "<f4", (3,)),
+        ("normal", "<f4", (3,)),
+        ("depth", "<f4"),
+        ("restitution", "<f4"),
+        ("static_friction", "<f4"),
+        ("dynamic_friction", "<f4"),
+        ("flags", "<u4"),
+        ("pad", "<u4"),
+    ]
+)
+SOLVER_CONFIG_DTYPE = np.dtype(
+    [("n_iterations", "<u4"), ("old_impulse_weight", "<f4"), ("n_positional_correction_iterations", "<u4"), ("positional_correction_factor", "<f4")]
+)
+KINEMATIC_BIT = 0x80000000
+CONTACT_MANIFOLD_START = 1
+assert RIGID_BODY_DTYPE.itemsize == 152 and KINEMATIC_BODY_DTYPE.itemsize == 56 and CONTACT_DTYPE.itemsize == 64
+
 # every symbol include/impact_voxel_hip.h declares
 EXPORTED_SYMBOLS = [
     "ivx_init", "ivx_shutdown", "ivx_last_error", "ivx_synchronize", "ivx_stream",

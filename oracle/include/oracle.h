@@ -89,6 +89,65 @@ void orc_derive_inertial_properties(const float moments[10], float out[22]);
 /* labels: dense x-major (nx,ny,nz) u32, 0xFFFFFFFF for empty; returns component count; labels may be NULL */
 uint32_t orc_region_labels(const orc_object*, uint32_t* labels);
 
+/* rigid bodies + sequential-impulses contact solver (impact_physics) ----------------------------- */
+typedef struct orc_physics orc_physics;
+/* DynamicRigidBody, #[repr(C)] 152 bytes (impact_physics/src/rigid_body.rs:94-103); matrices column-major,
+ * orientation = (x, y, z, w) */
+typedef struct {
+    float mass;
+    float inertia[9], inv_inertia[9];
+    float position[3];
+    float orientation[4];
+    float momentum[3], angular_momentum[3];
+    float total_force[3], total_torque[3];
+} orc_rigid_body;
+/* KinematicRigidBody, 56 bytes (rigid_body.rs:108-117); angular velocity = unit axis + speed */
+typedef struct {
+    float position[3];
+    float orientation[4];
+    float velocity[3];
+    float angular_axis[3];
+    float angular_speed;
+} orc_kinematic_body;
+/* ContactWithID flattened (constraint/contact.rs:23-57) + the two rigid bodies; body index bit 31 =
+ * kinematic body. flags bit 0: first contact of a manifold (one collision). 64 bytes. */
+typedef struct {
+    uint64_t id;
+    uint32_t body_a, body_b;
+    float position[3];
+    float normal[3];
+    float depth;
+    float restitution, static_friction, dynamic_friction;
+    uint32_t flags, pad;
+} orc_contact;
+/* ConstraintSolverConfig (constraint/solver.rs:41-57, 374-384) */
+typedef struct {
+    uint32_t n_iterations;
+    float old_impulse_weight;
+    uint32_t n_positional_correction_iterations;
+    float positional_correction_factor;
+} orc_solver_config;
+
+orc_physics* orc_physics_create(void);
+void orc_physics_free(orc_physics*);
+void orc_physics_set_config(orc_physics*, const orc_solver_config*);
+void orc_physics_set_bodies(orc_physics*, const orc_rigid_body* dyn, int n_dyn, const orc_kinematic_body* kin, int n_kin);
+void orc_physics_get_bodies(const orc_physics*, orc_rigid_body* dyn, orc_kinematic_body* kin);
+void orc_rigid_body_new(orc_rigid_body* out, float mass, const float inertia[9], const float inv_inertia[9], const float position[3],
+                        const float orientation[4], const float velocity[3], const float angular_velocity[3]);
+void orc_rigid_body_motion(const orc_rigid_body*, float velocity[3], float angular_velocity[3]);
+int orc_sphere_sphere_contact(const float ca[3], float ra, const float cb[3], float rb, float position[3], float normal[3], float* depth);
+int orc_sphere_plane_contact(const float c[3], float r, const float plane_normal[3], float plane_displacement, float position[3],
+                             float normal[3], float* depth);
+int orc_physics_prepare(orc_physics*, const orc_contact*, int n);
+int orc_physics_prepared_body_count(const orc_physics*);
+void orc_physics_contact_order(const orc_physics*, uint64_t* ids);
+void orc_physics_accumulated_impulses(const orc_physics*, float* out3n);
+void orc_physics_advance_momenta(orc_physics*, float dt);
+void orc_physics_solve(orc_physics*);
+void orc_physics_advance_configurations(orc_physics*, float dt);
+int orc_physics_step(orc_physics*, const orc_contact*, int n, float dt);
+
 /* quantisation helpers (lib.rs:197-222) */
 int8_t orc_sd_from_f32(float v);
 float orc_sd_to_f32(int8_t e);

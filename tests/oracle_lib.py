@@ -82,6 +82,28 @@ def lib():
         L.orc_sd_from_f32.argtypes = [C.c_float]
         L.orc_sd_to_f32.restype = C.c_float
         L.orc_sd_to_f32.argtypes = [C.c_int8]
+        L.orc_physics_create.restype = vp
+        L.orc_physics_free.argtypes = [vp]
+        L.orc_physics_set_config.argtypes = [vp, vp]
+        L.orc_physics_set_bodies.argtypes = [vp, vp, C.c_int, vp, C.c_int]
+        L.orc_physics_get_bodies.argtypes = [vp, vp, vp]
+        L.orc_rigid_body_new.argtypes = [vp, C.c_float, vp, vp, vp, vp, vp, vp]
+        L.orc_rigid_body_motion.argtypes = [vp, vp, vp]
+        L.orc_sphere_sphere_contact.restype = C.c_int
+        L.orc_sphere_sphere_contact.argtypes = [vp, C.c_float, vp, C.c_float, vp, vp, vp]
+        L.orc_sphere_plane_contact.restype = C.c_int
+        L.orc_sphere_plane_contact.argtypes = [vp, C.c_float, vp, C.c_float, vp, vp, vp]
+        L.orc_physics_prepare.restype = C.c_int
+        L.orc_physics_prepare.argtypes = [vp, vp, C.c_int]
+        L.orc_physics_prepared_body_count.restype = C.c_int
+        L.orc_physics_prepared_body_count.argtypes = [vp]
+        L.orc_physics_contact_order.argtypes = [vp, vp]
+        L.orc_physics_accumulated_impulses.argtypes = [vp, vp]
+        L.orc_physics_advance_momenta.argtypes = [vp, C.c_float]
+        L.orc_physics_solve.argtypes = [vp]
+        L.orc_physics_advance_configurations.argtypes = [vp, C.c_float]
+        L.orc_physics_step.restype = C.c_int
+        L.orc_physics_step.argtypes = [vp, vp, C.c_int, C.c_float]
         _lib = L
     return _lib
 
@@ -267,3 +289,113 @@ def derive_inertial_properties(moments32):
     out = np.zeros(22, dtype=np.float32)
     lib().orc_derive_inertial_properties(_p(m), _p(out))
     return {"mass": float(out[0]), "com": out[1:4].copy(), "inertia": out[4:13].reshape(3, 3).T.copy(), "inverse": out[13:22].reshape(3, 3).T.copy()}
+
+
+# ---- rigid bodies + contact solver --------------------------------------------------------------
+def rigid_body_new(mass, inertia, position, orientation=(0, 0, 0, 1), velocity=(0, 0, 0), angular_velocity=(0, 0, 0)):
+    """DynamicRigidBody::new (rigid_body.rs:411-441); inertia = 3x3 about the centre of mass (body frame)"""
+    from impact_amd.capi import RIGID_BODY_DTYPE
+
+    out = np.zeros(1, dtype=RIGID_BODY_DTYPE)
+    I = np.asarray(inertia, dtype=np.float64).reshape(3, 3)
+    Ic = np.ascontiguousarray(I.T.reshape(-1), dtype=np.float32)  # column-major
+    Iinv = np.ascontiguousarray(np.linalg.inv(I).T.reshape(-1), dtype=np.float32)
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+    lib().orc_rigid_body_new(_p(out), float(mass), _p(Ic), _p(Iinv), _p(f(position)), _p(f(orientation)), _p(f(velocity)), _p(f(angular_velocity)))
+    return out[0]
+
+
+def uniform_sphere_body(radius, density, position, velocity=(0, 0, 0)):
+    """InertialProperties::of_uniform_sphere (inertia.rs:155-168) in f32 like the reference"""
+    f32 = np.float32
+    mass = f32(f32(4.0 / 3.0) * f32(np.pi) * f32(radius) ** 3) * f32(density)
+    moi = f32(f32(2.0 / 5.0) * mass) * f32(radius) ** 2
+    return rigid_body_new(float(mass), np.eye(3) * float(moi), position, velocity=velocity)
+
+
+def body_motion(body):
+    v = np.zeros(3, dtype=np.float32)
+    w = np.zeros(3, dtype=np.float32)
+    b = np.array([body])
+    lib().orc_rigid_body_motion(_p(b), _p(v), _p(w))
+    return v, w
+
+
+def sphere_sphere_contact(ca, ra, cb, rb):
+    pos, nrm, d = np.zeros(3, np.float32), np.zeros(3, np.float32), C.c_float(0)
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+    if not lib().orc_sphere_sphere_contact(_p(f(ca)), ra, _p(f(cb)), rb, _p(pos), _p(nrm), C.byref(d)):
+        return None
+    return pos, nrm, d.value
+
+
+def sphere_plane_contact(c, r, plane_normal=(0, 1, 0), displacement=0.0):
+    pos, nrm, d = np.zeros(3, np.float32), np.zeros(3, np.float32), C.c_float(0)
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+    if not lib().orc_sphere_plane_contact(_p(f(c)), r, _p(f(plane_normal)), displacement, _p(pos), _p(nrm), C.byref(d)):
+        return None
+    return pos, nrm, d.value
+
+
+class OraclePhysics:
+    """RigidBodyManager + ConstraintManager of the reference, restated (oracle/src/orc_physics.cpp)"""
+
+    def __init__(self, dynamic, kinematic=None, config=None):
+        from impact_amd.capi import KINEMATIC_BODY_DTYPE, RIGID_BODY_DTYPE, SOLVER_CONFIG_DTYPE
+
+        self.h = C.c_void_p(lib().orc_physics_create())
+        self.n_dyn = len(dynamic)
+        kin = np.zeros(0, dtype=KINEMATIC_BODY_DTYPE) if kinematic is None else np.ascontiguousarray(kinematic, dtype=KINEMATIC_BODY_DTYPE)
+        self.n_kin = len(kin)
+        dyn = np.ascontiguousarray(dynamic, dtype=RIGID_BODY_DTYPE)
+        lib().orc_physics_set_bodies(self.h, _p(dyn), len(dyn), _p(kin), len(kin))
+        if config is not None:
+            cfg = np.zeros(1, dtype=SOLVER_CONFIG_DTYPE)
+            cfg[0] = config
+            lib().orc_physics_set_config(self.h, _p(cfg))
+
+    def __del__(self):
+        try:
+            lib().orc_physics_free(self.h)
+        except Exception:
+            pass
+
+    def bodies(self):
+        from impact_amd.capi import KINEMATIC_BODY_DTYPE, RIGID_BODY_DTYPE
+
+        dyn = np.zeros(self.n_dyn, dtype=RIGID_BODY_DTYPE)
+        kin = np.zeros(self.n_kin, dtype=KINEMATIC_BODY_DTYPE)
+        lib().orc_physics_get_bodies(self.h, _p(dyn), _p(kin))
+        return dyn, kin
+
+    def prepare(self, contacts):
+        c = np.ascontiguousarray(contacts)
+        self.n_prepared = lib().orc_physics_prepare(self.h, _p(c), len(c))
+        return self.n_prepared
+
+    def prepared_body_count(self):
+        return lib().orc_physics_prepared_body_count(self.h)
+
+    def contact_order(self):
+        ids = np.zeros(self.n_prepared, dtype=np.uint64)
+        lib().orc_physics_contact_order(self.h, _p(ids))
+        return ids
+
+    def accumulated_impulses(self):
+        out = np.zeros((self.n_prepared, 3), dtype=np.float32)
+        lib().orc_physics_accumulated_impulses(self.h, _p(out))
+        return out
+
+    def advance_momenta(self, dt):
+        lib().orc_physics_advance_momenta(self.h, dt)
+
+    def solve(self):
+        lib().orc_physics_solve(self.h)
+
+    def advance_configurations(self, dt):
+        lib().orc_physics_advance_configurations(self.h, dt)
+
+    def step(self, contacts, dt):
+        c = np.ascontiguousarray(contacts)
+        self.n_prepared = lib().orc_physics_step(self.h, _p(c), len(c), dt)
+        return self.n_prepared
