@@ -105,6 +105,10 @@ CONTACT_DTYPE = np.dtype(
 SOLVER_CONFIG_DTYPE = np.dtype(
     [("n_iterations", "<u4"), ("old_impulse_weight", "<f4"), ("n_positional_correction_iterations", "<u4"), ("positional_correction_factor", "<f4")]
 )
+PHYSICS_RESULT_DTYPE = np.dtype(
+    [("n_contacts", "<u4"), ("n_bodies", "<u4"), ("n_levels", "<u4", (2,)), ("stage_ms", "<f4", (5,)), ("reserved", "<u4", (3,))]
+)
+PHYSICS_STAGE_NAMES = ["prepare", "pre_solve", "solve", "post_solve", "total"]
 KINEMATIC_BIT = 0x80000000
 CONTACT_MANIFOLD_START = 1
 assert RIGID_BODY_DTYPE.itemsize == 152 and KINEMATIC_BODY_DTYPE.itemsize == 56 and CONTACT_DTYPE.itemsize == 64
@@ -121,12 +125,18 @@ EXPORTED_SYMBOLS = [
     "ivx_grid_set_sdf_program", "ivx_grid_set_densities", "ivx_voxel_step",
     "ivx_halo_bytes", "ivx_halo_pack", "ivx_halo_unpack", "ivx_halo_clear",
     "ivx_region_face_bytes", "ivx_region_face_labels", "ivx_region_face_pairs",
+    "ivx_world_create", "ivx_world_destroy", "ivx_world_set_bodies", "ivx_world_get_bodies", "ivx_world_set_contacts",
+    "ivx_world_step", "ivx_world_prepare", "ivx_world_advance_momenta", "ivx_world_solve", "ivx_world_advance_configurations",
+    "ivx_world_contact_state",
 ]
 
 
 def extra_struct_sizes():
     """name -> (dtype, size the header documents) for the structs not asserted above"""
-    return {}
+    return {
+        "ivx_rigid_body": (RIGID_BODY_DTYPE, 152), "ivx_kinematic_body": (KINEMATIC_BODY_DTYPE, 56), "ivx_contact": (CONTACT_DTYPE, 64),
+        "ivx_solver_config": (SOLVER_CONFIG_DTYPE, 16), "ivx_physics_result": (PHYSICS_RESULT_DTYPE, 48),
+    }
 
 
 class IvxError(RuntimeError):
@@ -187,6 +197,17 @@ def lib():
         "ivx_region_face_bytes": (sz, [vp]),
         "ivx_region_face_labels": (i32, [vp, i32, vp]),
         "ivx_region_face_pairs": (i32, [vp, i32, vp, vp, sz, C.POINTER(sz)]),
+        "ivx_world_create": (i32, [vp, vp, C.POINTER(vp)]),
+        "ivx_world_destroy": (None, [vp]),
+        "ivx_world_set_bodies": (i32, [vp, vp, sz, vp, sz]),
+        "ivx_world_get_bodies": (i32, [vp, vp, vp]),
+        "ivx_world_set_contacts": (i32, [vp, vp, sz, C.POINTER(sz)]),
+        "ivx_world_step": (i32, [vp, f32, vp]),
+        "ivx_world_prepare": (i32, [vp]),
+        "ivx_world_advance_momenta": (i32, [vp, f32]),
+        "ivx_world_solve": (i32, [vp]),
+        "ivx_world_advance_configurations": (i32, [vp, f32]),
+        "ivx_world_contact_state": (i32, [vp, vp, vp, sz, C.POINTER(sz)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

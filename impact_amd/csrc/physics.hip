@@ -1,0 +1,393 @@
+// a15-a19 — rigid-body step and sequential-impulses contact solve on the GPU.
+//
+// Reference behaviour reproduced (engine/crates/impact_physics/src):
+//   ConstrainedBody::from_dynamic/kinematic_rigid_body      constraint.rs:476-523
+//   Contact::prepare (effective masses, tangents, targets)  constraint/contact.rs:233-310, 788-832
+//   can_use_warm_impulses_from + old_impulse_weight         contact.rs:313-327, solver.rs:406-432
+//   advance_momentum / angular momentum                     rigid_body.rs:373-378, 708-721
+//   synchronize_prepared_constrained_body_velocities        solver.rs:217-228, 543-569
+//   warm impulses, sequential sweeps, clamp, apply          solver.rs:242-262, 481-528; contact.rs:329-438
+//   positional correction                                   solver.rs:276-289; contact.rs:440-517, 835-843
+//   write-back (synchronize_momentum / angular momentum)    solver.rs:571-602; rigid_body.rs:687-702
+//   advance_position / advance_orientation                  rigid_body.rs:723-742, 1013-1034
+//
+// The reference's solver is a Gauss–Seidel sweep whose result depends on the order of the contacts.
+// That order is kept EXACTLY: the host turns the sequence (warm pass, n velocity sweeps | m positional
+// sweeps) x (contacts in cache order) into dependency levels — an item's level is one more than the
+// latest earlier item that touches one of its two dynamic bodies — and this kernel executes one level
+// at a time with all items of a level in parallel. Items of a level share no dynamic body, so the
+// result is what the sequential loop produces, operation for operation; successive sweeps overlap
+// wherever the contact graph allows (a wavefront), which is where the parallelism comes from.
+// Kinematic bodies are never changed by an impulse (inverse mass 0), so they are read-only here and
+// create no dependencies.
+//
+// One workgroup of 1024 threads walks the levels (a level is ~10^2 contacts; the chain of levels is
+// the critical path, so more workgroups would only add grid-wide barriers). f32 throughout, no FMA
+// contraction, IEEE sqrt/div — same operation order as the oracle.
+#include "ivx_internal.hpp"
+#include "physics_internal.hpp"
+
+namespace {
+
+struct V3 {
+    float x, y, z;
+};
+struct Q4 {
+    float x, y, z, w;
+};
+struct M3 {
+    V3 c0, c1, c2;
+};
+__device__ __forceinline__ V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 ld3(const float* p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ void st3(float* p, V3 v) {
+    p[0] = v.x;
+    p[1] = v.y;
+    p[2] = v.z;
+}
+__device__ __forceinline__ Q4 ldq(const float* p) { return Q4{p[0], p[1], p[2], p[3]}; }
+__device__ __forceinline__ void stq(float* p, Q4 q) {
+    p[0] = q.x;
+    p[1] = q.y;
+    p[2] = q.z;
+    p[3] = q.w;
+}
+__device__ __forceinline__ M3 ldm(const float* p) { return M3{ld3(p), ld3(p + 3), ld3(p + 6)}; }
+__device__ __forceinline__ void stm(float* p, const M3& m) {
+    st3(p, m.c0);
+    st3(p + 3, m.c1);
+    st3(p + 6, m.c2);
+}
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+__device__ __forceinline__ V3 div_elem(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ V3 div_recip(V3 a, float s) {
+    const float r = 1.0f / s;
+    return {a.x * r, a.y * r, a.z * r};
+}
+__device__ __forceinline__ V3 mul(const M3& m, V3 v) { return (m.c0 * v.x + m.c1 * v.y) + m.c2 * v.z; }
+__device__ __forceinline__ M3 transpose(const M3& m) {
+    return {{m.c0.x, m.c1.x, m.c2.x}, {m.c0.y, m.c1.y, m.c2.y}, {m.c0.z, m.c1.z, m.c2.z}};
+}
+__device__ __forceinline__ M3 mul(const M3& a, const M3& b) { return {mul(a, b.c0), mul(a, b.c1), mul(a, b.c2)}; }
+// glam Mat3A::from_quat
+__device__ __forceinline__ M3 m3_from_quat(Q4 q) {
+    const float x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
+    const float xx = q.x * x2, xy = q.x * y2, xz = q.x * z2;
+    const float yy = q.y * y2, yz = q.y * z2, zz = q.z * z2;
+    const float wx = q.w * x2, wy = q.w * y2, wz = q.w * z2;
+    return {{1.0f - (yy + zz), xy + wz, xz - wy}, {xy - wz, 1.0f - (xx + zz), yz + wx}, {xz + wy, yz - wx, 1.0f - (xx + yy)}};
+}
+__device__ __forceinline__ M3 rotated(const M3& m, Q4 q) {  // R M R^T (inertia.rs:401-404, 429-432)
+    const M3 r = m3_from_quat(q);
+    return mul(mul(r, m), transpose(r));
+}
+__device__ __forceinline__ Q4 conj(Q4 q) { return {-q.x, -q.y, -q.z, q.w}; }
+__device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
+    return {a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
+            a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+__device__ __forceinline__ Q4 qnormalize(Q4 q) {
+    const float l = sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
+    return {q.x / l, q.y / l, q.z / l, q.w / l};
+}
+// glam Quat::mul_vec3a
+__device__ __forceinline__ V3 qrot(Q4 q, V3 v) {
+    const V3 b = mk(q.x, q.y, q.z);
+    const float b2 = dot(b, b);
+    return (v * (q.w * q.w - b2) + b * (dot(v, b) * 2.0f)) + cross(b, v) * (q.w * 2.0f);
+}
+__device__ __forceinline__ float max_rs(float a, float b) { return (b > a) ? b : a; }
+
+// AngularVelocity::from_vector (quantities.rs:160-172): unit axis + speed, zero at or below f32::EPSILON
+struct AngVel {
+    V3 axis;
+    float speed;
+};
+__device__ __forceinline__ AngVel angvel_from_vector(V3 w) {
+    const float n2 = dot(w, w);
+    const float eps = 1.1920929e-07f;
+    if (n2 > eps * eps) {
+        const float n = sqrtf(n2);
+        return {div_elem(w, n), n};
+    }
+    return {mk(0.0f, 1.0f, 0.0f), 0.0f};
+}
+__device__ __forceinline__ V3 angvel_vector(AngVel a) { return a.axis * a.speed; }
+
+__device__ __forceinline__ V3 body_velocity(const ivx_rigid_body& b) { return div_recip(ld3(b.momentum), b.mass); }
+__device__ __forceinline__ AngVel body_angular_velocity(const ivx_rigid_body& b) {
+    return angvel_from_vector(mul(rotated(ldm(b.inv_inertia), ldq(b.orientation)), ld3(b.angular_momentum)));
+}
+
+// ---- per-body kernels ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prepare_bodies(uint32_t n_dyn, uint32_t n_kin, const ivx_rigid_body* __restrict__ dyn,
+                                                        const ivx_kinematic_body* __restrict__ kin, PhysBody* __restrict__ cb,
+                                                        uint8_t* __restrict__ touched) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_dyn + n_kin) return;
+    PhysBody c;
+    if (i < n_dyn) {
+        const ivx_rigid_body b = dyn[i];
+        c.inv_mass = 1.0f / b.mass;
+        stm(c.inv_inertia, rotated(ldm(b.inv_inertia), ldq(b.orientation)));
+        st3(c.pos, ld3(b.position));
+        stq(c.q, ldq(b.orientation));
+        st3(c.v, body_velocity(b));
+        st3(c.w, angvel_vector(body_angular_velocity(b)));
+        touched[i] = 0;
+    } else {
+        const ivx_kinematic_body k = kin[i - n_dyn];
+        c.inv_mass = 0.0f;
+        for (int e = 0; e < 9; ++e) c.inv_inertia[e] = 0.0f;
+        st3(c.pos, ld3(k.position));
+        stq(c.q, ldq(k.orientation));
+        st3(c.v, ld3(k.velocity));
+        st3(c.w, ld3(k.angular_axis) * k.angular_speed);
+    }
+    c.pad = 0.0f;
+    cb[i] = c;
+}
+
+__device__ __forceinline__ V3 to_world(const float* pos, const float* q, V3 p) { return qrot(ldq(q), p) + ld3(pos); }
+__device__ __forceinline__ V3 to_body(const float* pos, const float* q, V3 p) { return qrot(conj(ldq(q)), p - ld3(pos)); }
+__device__ __forceinline__ V3 point_velocity(V3 v, V3 w, V3 disp) { return v + cross(w, disp); }
+__device__ __forceinline__ float effective_mass(float ima, const M3& iia, float imb, const M3& iib, V3 da, V3 db, V3 dir) {
+    const V3 ca = cross(da, dir), cb = cross(db, dir);
+    return 1.0f / (((ima + imb) + dot(ca, mul(iia, ca))) + dot(cb, mul(iib, cb)));
+}
+
+__global__ __launch_bounds__(256) void k_prepare_contacts(uint32_t n, uint32_t n_dyn, const ivx_contact* __restrict__ contacts,
+                                                          const int32_t* __restrict__ prev_slot, const PhysBody* __restrict__ cb,
+                                                          const PhysContact* __restrict__ prev_pc, const float4* __restrict__ prev_acc,
+                                                          uint32_t n_prev, float old_impulse_weight, PhysContact* __restrict__ pc,
+                                                          float4* __restrict__ acc, uint8_t* __restrict__ touched) {
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= n) return;
+    const ivx_contact c = contacts[s];
+    const uint32_t ia = (c.body_a & IVX_KINEMATIC_BODY) ? n_dyn + (c.body_a & 0x7FFFFFFFu) : c.body_a;
+    const uint32_t ib = (c.body_b & IVX_KINEMATIC_BODY) ? n_dyn + (c.body_b & 0x7FFFFFFFu) : c.body_b;
+    const PhysBody a = cb[ia], b = cb[ib];
+    const V3 pos = ld3(c.position), normal = ld3(c.normal);
+    PhysContact p;
+    st3(p.local_a, to_body(a.pos, a.q, pos - normal * c.depth));
+    st3(p.local_b, to_body(b.pos, b.q, pos));
+    const V3 da = pos - ld3(a.pos), db = pos - ld3(b.pos);
+    // construct_tangent_vectors (contact.rs:813-832)
+    const V3 traw = fabsf(normal.x) < 0.57735f ? mk(0.0f, normal.z, -normal.y) : mk(normal.y, -normal.x, 0.0f);
+    const V3 t1 = div_elem(traw, sqrtf(dot(traw, traw)));
+    const V3 t2 = cross(normal, t1);
+    st3(p.normal, normal);
+    st3(p.tangent, t1);
+    st3(p.bitangent, t2);
+    const M3 iia = ldm(a.inv_inertia), iib = ldm(b.inv_inertia);
+    p.m_n = effective_mass(a.inv_mass, iia, b.inv_mass, iib, da, db, normal);
+    p.m_t = effective_mass(a.inv_mass, iia, b.inv_mass, iib, da, db, t1);
+    p.m_b = effective_mass(a.inv_mass, iia, b.inv_mass, iib, da, db, t2);
+    const V3 rel = point_velocity(ld3(a.v), ld3(a.w), da) - point_velocity(ld3(b.v), ld3(b.w), db);
+    const float sep = dot(normal, rel);
+    p.target = fabsf(sep) >= 0.4f ? -c.restitution * sep : 0.0f;
+    const float d1 = dot(rel, t1), d2 = dot(rel, t2);
+    p.friction = (d1 * d1 + d2 * d2) >= 1e-4f ? c.dynamic_friction : c.static_friction;
+    p.ia = ia;
+    p.ib = ib;
+    p.pad[0] = p.pad[1] = 0;
+    float4 a4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int32_t ps = prev_slot ? prev_slot[s] : (s < n_prev ? (int32_t)s : -1);
+    if (ps >= 0) {
+        const PhysContact o = prev_pc[ps];
+        if (dot(normal, ld3(o.normal)) > 1.0f - 1e-2f && dot(t1, ld3(o.tangent)) > 1.0f - 1e-2f) {
+            const float4 oa = prev_acc[ps];
+            a4 = make_float4(oa.x * old_impulse_weight, oa.y * old_impulse_weight, oa.z * old_impulse_weight, 0.0f);
+        }
+    }
+    pc[s] = p;
+    acc[s] = a4;
+    if (ia < n_dyn) touched[ia] = 1;
+    if (ib < n_dyn) touched[ib] = 1;
+}
+
+__global__ __launch_bounds__(256) void k_pre_solve(uint32_t n_dyn, float dt, ivx_rigid_body* __restrict__ dyn, PhysBody* __restrict__ cb) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_dyn) return;
+    ivx_rigid_body b = dyn[i];
+    st3(b.momentum, ld3(b.momentum) + ld3(b.total_force) * dt);
+    st3(b.angular_momentum, ld3(b.angular_momentum) + ld3(b.total_torque) * dt);
+    st3(dyn[i].momentum, ld3(b.momentum));
+    st3(dyn[i].angular_momentum, ld3(b.angular_momentum));
+    // the constrained copy keeps the configuration and world inverse inertia from prepare time
+    st3(cb[i].v, body_velocity(b));
+    st3(cb[i].w, angvel_vector(body_angular_velocity(b)));
+}
+
+__global__ __launch_bounds__(256) void k_post_solve(uint32_t n_dyn, uint32_t n_kin, float dt, int write_back, int advance,
+                                                    const PhysBody* __restrict__ cb, const uint8_t* __restrict__ touched,
+                                                    ivx_rigid_body* __restrict__ dyn, ivx_kinematic_body* __restrict__ kin) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_dyn + n_kin) return;
+    if (i < n_dyn) {
+        ivx_rigid_body b = dyn[i];
+        if (write_back && touched[i]) {
+            const PhysBody c = cb[i];
+            st3(b.position, ld3(c.pos));
+            stq(b.orientation, ldq(c.q));
+            st3(b.momentum, ld3(c.v) * b.mass);
+            st3(b.angular_momentum, mul(rotated(ldm(b.inertia), ldq(b.orientation)), angvel_vector(angvel_from_vector(ld3(c.w)))));
+        }
+        if (advance) {
+            st3(b.position, ld3(b.position) + body_velocity(b) * dt);
+            const AngVel av = body_angular_velocity(b);
+            const float angle = av.speed * dt;
+            const float s = sinf(0.5f * angle), co = cosf(0.5f * angle);
+            const V3 im = av.axis * s;
+            stq(b.orientation, qnormalize(qmul(Q4{im.x, im.y, im.z, co}, ldq(b.orientation))));
+        }
+        dyn[i] = b;
+    } else if (advance) {
+        ivx_kinematic_body k = kin[i - n_dyn];
+        st3(k.position, ld3(k.position) + ld3(k.velocity) * dt);
+        const float angle = k.angular_speed * dt;
+        const float s = sinf(0.5f * angle), co = cosf(0.5f * angle);
+        const V3 im = ld3(k.angular_axis) * s;
+        stq(k.orientation, qnormalize(qmul(Q4{im.x, im.y, im.z, co}, ldq(k.orientation))));
+        kin[i - n_dyn] = k;
+    }
+}
+
+// ---- the solve -----------------------------------------------------------------------------------
+__device__ __forceinline__ void apply_impulses(const PhysContact& p, PhysBody* cb, uint32_t n_dyn, V3 pb, float in, float it, float ib_) {
+    const V3 dp = (ld3(p.normal) * in + ld3(p.tangent) * it) + ld3(p.bitangent) * ib_;
+    PhysBody& a = cb[p.ia];
+    PhysBody& b = cb[p.ib];
+    if (p.ia < n_dyn) {
+        const V3 da = pb - ld3(a.pos);
+        st3(a.v, ld3(a.v) + dp * a.inv_mass);
+        st3(a.w, ld3(a.w) + mul(ldm(a.inv_inertia), cross(da, dp)));
+    }
+    if (p.ib < n_dyn) {
+        const V3 db = pb - ld3(b.pos);
+        st3(b.v, ld3(b.v) - dp * b.inv_mass);
+        st3(b.w, ld3(b.w) - mul(ldm(b.inv_inertia), cross(db, dp)));
+    }
+}
+
+__device__ __forceinline__ Q4 pseudo_advanced(Q4 q, V3 w) {  // contact.rs:835-843, quantities.rs:372-378
+    const V3 h = w * 0.5f;
+    const Q4 d = qmul(Q4{h.x, h.y, h.z, 0.0f}, q);
+    return qnormalize(Q4{q.x + d.x, q.y + d.y, q.z + d.z, q.w + d.w});
+}
+
+__device__ __forceinline__ void run_item(uint32_t item, uint32_t n_dyn, float factor, const PhysContact* __restrict__ pcs, float4* __restrict__ accs,
+                                         PhysBody* __restrict__ cb) {
+    const uint32_t s = item & 0x0FFFFFFFu, type = item >> 28;
+    const PhysContact p = pcs[s];
+    PhysBody& a = cb[p.ia];
+    PhysBody& b = cb[p.ib];
+    if (type == PHYS_ITEM_POSITIONAL) {
+        const V3 n = ld3(p.normal);
+        const V3 pa = to_world(a.pos, a.q, ld3(p.local_a)), pb = to_world(b.pos, b.q, ld3(p.local_b));
+        const float depth = dot(n, pb - pa);
+        if (depth <= 0.0f) return;
+        const V3 da = pb - ld3(a.pos), db = pb - ld3(b.pos);
+        const M3 iia = ldm(a.inv_inertia), iib = ldm(b.inv_inertia);
+        const float m = effective_mass(a.inv_mass, iia, b.inv_mass, iib, da, db, n);
+        const V3 dp = n * (m * factor * depth);
+        if (p.ia < n_dyn) {
+            st3(a.pos, ld3(a.pos) + dp * a.inv_mass);
+            stq(a.q, pseudo_advanced(ldq(a.q), mul(iia, cross(da, dp))));
+        }
+        if (p.ib < n_dyn) {
+            st3(b.pos, ld3(b.pos) + dp * (-b.inv_mass));
+            stq(b.q, pseudo_advanced(ldq(b.q), mul(M3{-iib.c0, -iib.c1, -iib.c2}, cross(db, dp))));
+        }
+        return;
+    }
+    const V3 pb = to_world(b.pos, b.q, ld3(p.local_b));
+    float4 acc = accs[s];
+    if (type == PHYS_ITEM_WARM) {
+        apply_impulses(p, cb, n_dyn, pb, acc.x, acc.y, acc.z);
+        return;
+    }
+    // compute_impulses -> clamp -> apply the difference (solver.rs:496-528)
+    const V3 da = pb - ld3(a.pos), db = pb - ld3(b.pos);
+    const V3 rel = point_velocity(ld3(a.v), ld3(a.w), da) - point_velocity(ld3(b.v), ld3(b.w), db);
+    const float sep = dot(ld3(p.normal), rel);
+    const float cn = -p.m_n * (sep - p.target), ct = -p.m_t * dot(ld3(p.tangent), rel), cbi = -p.m_b * dot(ld3(p.bitangent), rel);
+    const float un = acc.x + cn, ut = acc.y + ct, ub = acc.z + cbi;
+    const float nn = max_rs(0.0f, un);
+    const float max_t = p.friction * nn;
+    const float mag = sqrtf(ut * ut + ub * ub);
+    const float sc = mag > max_t ? max_t / mag : 1.0f;
+    const float nt = ut * sc, nb = ub * sc;
+    accs[s] = make_float4(nn, nt, nb, 0.0f);
+    apply_impulses(p, cb, n_dyn, pb, nn - acc.x, nt - acc.y, nb - acc.z);
+}
+
+__global__ __launch_bounds__(1024) void k_solve(uint32_t n_dyn, float factor, const PhysContact* __restrict__ pcs, float4* __restrict__ accs,
+                                                PhysBody* __restrict__ cb, const uint32_t* __restrict__ items,
+                                                const uint32_t* __restrict__ level_start, uint32_t n_levels) {
+    __shared__ uint32_t s_start[PHYS_LEVEL_TILE + 1];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t l0 = 0; l0 < n_levels; l0 += PHYS_LEVEL_TILE) {
+        const uint32_t cnt = min((uint32_t)PHYS_LEVEL_TILE, n_levels - l0);
+        __syncthreads();
+        for (uint32_t i = tid; i <= cnt; i += 1024u) s_start[i] = level_start[l0 + i];
+        __syncthreads();
+        for (uint32_t l = 0; l < cnt; ++l) {
+            const uint32_t e = s_start[l + 1];
+            for (uint32_t i = s_start[l] + tid; i < e; i += 1024u) run_item(items[i], n_dyn, factor, pcs, accs, cb);
+            __syncthreads();  // workgroup-scope release/acquire of the body state before the next level
+        }
+    }
+}
+
+}  // namespace
+
+int ivx_launch_phys_prepare_bodies(ivx_world* w) {
+    const uint32_t n = w->n_dyn + w->n_kin;
+    if (n == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_prepare_bodies, dim3((n + 255u) / 256u), dim3(256), 0, w->ctx->stream, w->n_dyn, w->n_kin, w->dyn, w->kin, w->cb, w->touched);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+int ivx_launch_phys_prepare_contacts(ivx_world* w, const int32_t* d_prev_slot) {
+    if (w->n_contacts == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_prepare_contacts, dim3((w->n_contacts + 255u) / 256u), dim3(256), 0, w->ctx->stream, w->n_contacts, w->n_dyn, w->contacts,
+                       d_prev_slot, w->cb, w->pc[w->cur ^ 1], reinterpret_cast<const float4*>(w->acc[w->cur ^ 1]), w->n_prev,
+                       w->cfg.old_impulse_weight, w->pc[w->cur], reinterpret_cast<float4*>(w->acc[w->cur]), w->touched);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+int ivx_launch_phys_pre_solve(ivx_world* w, float dt) {
+    if (w->n_dyn == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_pre_solve, dim3((w->n_dyn + 255u) / 256u), dim3(256), 0, w->ctx->stream, w->n_dyn, dt, w->dyn, w->cb);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+int ivx_launch_phys_solve(ivx_world* w) {
+    if (w->n_contacts == 0) return IVX_OK;
+    for (int phase = 0; phase < 2; ++phase) {
+        if (w->n_levels[phase] == 0) continue;
+        hipLaunchKernelGGL(k_solve, dim3(1), dim3(1024), 0, w->ctx->stream, w->n_dyn, w->cfg.positional_correction_factor, w->pc[w->cur],
+                           reinterpret_cast<float4*>(w->acc[w->cur]), w->cb, w->items + w->item_offset[phase], w->level_start + w->level_offset[phase],
+                           w->n_levels[phase]);
+    }
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+int ivx_launch_phys_post_solve(ivx_world* w, float dt, int write_back, int advance) {
+    const uint32_t n = w->n_dyn + w->n_kin;
+    if (n == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_post_solve, dim3((n + 255u) / 256u), dim3(256), 0, w->ctx->stream, w->n_dyn, w->n_kin, dt, write_back, advance, w->cb, w->touched,
+                       w->dyn, w->kin);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}

@@ -1,0 +1,479 @@
+// C ABI of the rigid-body / contact-solver part (include/impact_voxel_hip.h, "a15-a19") and its host-side
+// bookkeeping: everything that is inherently sequential and tiny per item in the reference —
+//   * interlock analysis of a manifold and its separating contact     constraint/contact.rs:610-780
+//   * ConstraintCache order + warm-start source of every contact      constraint/solver.rs:386-452
+//   * the dependency schedule of the sweeps (see physics.hip)
+// — runs here once per contact set; all arithmetic on body state runs in the kernels of physics.hip.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "physics_internal.hpp"
+
+namespace {
+
+template <class T>
+int grow(T** p, size_t* cap, size_t need, hipStream_t s) {
+    if (need <= *cap) return IVX_OK;
+    size_t ncap = std::max(need, *cap * 2);
+    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(p), ncap * sizeof(T)));
+    *cap = ncap;
+    return IVX_OK;
+}
+
+struct H3 {
+    float x, y, z;
+};
+inline H3 h3(const float* p) { return {p[0], p[1], p[2]}; }
+inline H3 operator+(H3 a, H3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline H3 operator-(H3 a, H3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline H3 operator-(H3 a) { return {-a.x, -a.y, -a.z}; }
+inline H3 operator*(H3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline float hdot(H3 a, H3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline H3 hcross(H3 a, H3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+
+// impact_math/src/random/splitmix.rs:4-15
+inline uint64_t splitmix(uint64_t state) {
+    state += 0x9E3779B97F4A7C15ull;
+    uint64_t z = state;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+inline uint64_t splitmix2(uint64_t a, uint64_t b) { return splitmix(a ^ splitmix(b)); }
+
+// objects_in_contact_are_interlocked (contact.rs:610-636)
+bool manifold_interlocked(const ivx_contact* c, size_t n) {
+    float abs_sum = 0.0f;
+    H3 vec{0, 0, 0};
+    for (size_t i = 0; i < n; ++i) {
+        if (c[i].depth <= 0.0f) continue;
+        abs_sum += c[i].depth;
+        vec = vec + h3(c[i].normal) * c[i].depth;
+    }
+    if (abs_sum < 1e-6f) return false;
+    return hdot(vec, vec) / (abs_sum * abs_sum) < 0.1f;
+}
+
+template <class F>
+H3 max_displacement(const ivx_contact* c, size_t n, F map) {  // contact.rs:691-712
+    float best = -INFINITY;
+    size_t bi = n, bj = n;
+    for (size_t i = 0; i + 1 < n; ++i)
+        for (size_t j = i + 1; j < n; ++j) {
+            const H3 d = map(h3(c[i].position)) - map(h3(c[j].position));
+            const float s = hdot(d, d);
+            if (s > best) {
+                best = s;
+                bi = i;
+                bj = j;
+            }
+        }
+    if (bi == n) return {0, 0, 0};
+    return map(h3(c[bj].position)) - map(h3(c[bi].position));
+}
+bool unit_if_above(H3 v, float min_norm, H3& out) {
+    const float n2 = hdot(v, v);
+    if (!(n2 > min_norm * min_norm)) return false;
+    const float n = std::sqrt(n2);
+    out = {v.x / n, v.y / n, v.z / n};
+    return true;
+}
+// create_contact_separating_along_axis (contact.rs:714-780)
+bool separate_along(H3 com_a_minus_b, const ivx_contact* c, size_t n, H3 axis, ivx_contact& out) {
+    if (hdot(axis, com_a_minus_b) < 0.0f) axis = -axis;
+    float lo = INFINITY, hi = -INFINITY;
+    size_t i0 = n, i1 = n;
+    for (size_t i = 0; i < n; ++i) {
+        const float d = hdot(h3(c[i].position), axis);
+        if (d < lo) {
+            lo = d;
+            i0 = i;
+        }
+        if (d > hi) {
+            hi = d;
+            i1 = i;
+        }
+    }
+    if (i0 == i1) return false;
+    out = c[i0];
+    out.normal[0] = axis.x;
+    out.normal[1] = axis.y;
+    out.normal[2] = axis.z;
+    out.depth = hi - lo;
+    out.restitution = 0.0f;
+    out.static_friction = INFINITY;
+    out.dynamic_friction = INFINITY;
+    out.id = splitmix2(c[i0].id, c[i1].id);
+    return true;
+}
+// create_separating_contact_for_interlocked_objects (contact.rs:638-689)
+bool separating_contact(H3 com_a_minus_b, const ivx_contact* c, size_t n, ivx_contact& out) {
+    if (n == 0) return false;
+    H3 major, middle, minor;
+    if (!unit_if_above(max_displacement(c, n, [](H3 p) { return p; }), 1e-6f, major)) return false;
+    const H3 md = max_displacement(c, n, [&](H3 p) { return p - major * hdot(p, major); });
+    if (!unit_if_above(md, 1e-6f, middle)) return separate_along(com_a_minus_b, c, n, major, out);
+    if (!unit_if_above(hcross(major, middle), 1e-4f, minor)) return separate_along(com_a_minus_b, c, n, major, out);
+    if (separate_along(com_a_minus_b, c, n, minor, out)) return true;
+    return separate_along(com_a_minus_b, c, n, middle, out);
+}
+
+int fetch_body_position(ivx_world* w, uint32_t ref, float out[3]) {
+    IVX_HIP_CHECK(hipStreamSynchronize(w->ctx->stream));
+    const void* src = (ref & IVX_KINEMATIC_BODY) ? static_cast<const void*>(w->kin[ref & 0x7FFFFFFFu].position)
+                                                 : static_cast<const void*>(w->dyn[ref].position);
+    IVX_HIP_CHECK(hipMemcpy(out, src, 12, hipMemcpyDeviceToHost));
+    return IVX_OK;
+}
+
+// Dependency levels of the item sequence (pass-major, contacts in cache order inside a pass); items of
+// one level touch pairwise different dynamic bodies. Appends to items/level_start.
+void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_t type, uint32_t n_passes, int phase) {
+    const uint32_t n = w->n_contacts, nb = w->n_dyn;
+    w->item_offset[phase] = (uint32_t)w->items_host.size();
+    w->level_offset[phase] = (uint32_t)w->level_start_host.size();
+    const uint32_t total_passes = n_first + n_passes;
+    const size_t total = (size_t)total_passes * n;
+    w->n_levels[phase] = 0;
+    if (total == 0) {
+        w->level_start_host.push_back(0);
+        return;
+    }
+    std::vector<uint32_t>& lvl = w->scratch_level;
+    std::vector<uint32_t>& last = w->scratch_last;
+    lvl.resize(total);
+    last.assign(nb, 0u);
+    uint32_t max_level = 0;
+    size_t k = 0;
+    for (uint32_t pass = 0; pass < total_passes; ++pass)
+        for (uint32_t s = 0; s < n; ++s, ++k) {
+            const ivx_contact& c = w->ordered[s];
+            uint32_t l = 0;
+            if (!(c.body_a & IVX_KINEMATIC_BODY)) l = std::max(l, last[c.body_a]);
+            if (!(c.body_b & IVX_KINEMATIC_BODY)) l = std::max(l, last[c.body_b]);
+            l += 1;
+            if (!(c.body_a & IVX_KINEMATIC_BODY)) last[c.body_a] = l;
+            if (!(c.body_b & IVX_KINEMATIC_BODY)) last[c.body_b] = l;
+            lvl[k] = l;
+            max_level = std::max(max_level, l);
+        }
+    // counting sort by level (stable)
+    const size_t ls0 = w->level_start_host.size();
+    w->level_start_host.resize(ls0 + max_level + 1, 0u);
+    uint32_t* start = w->level_start_host.data() + ls0;
+    for (size_t i = 0; i < total; ++i) start[lvl[i]] += 1;  // start[l] = count of level l (l >= 1), start[0] = 0
+    uint32_t run = 0;
+    for (uint32_t l = 1; l <= max_level; ++l) {
+        const uint32_t c = start[l];
+        start[l] = run;  // start of level l (1-based) stored at index l; shifted below
+        run += c;
+    }
+    // start[l] for l in 1..max_level are begin offsets; build final [0..max_level] = begin of level l+1, end sentinel
+    const size_t it0 = w->items_host.size();
+    w->items_host.resize(it0 + total);
+    std::vector<uint32_t> cursor(start + 1, start + max_level + 1);
+    k = 0;
+    for (uint32_t pass = 0; pass < total_passes; ++pass) {
+        const uint32_t ty = pass < n_first ? first_type : type;
+        for (uint32_t s = 0; s < n; ++s, ++k) w->items_host[it0 + cursor[lvl[k] - 1]++] = s | (ty << 28);
+    }
+    for (uint32_t l = 0; l < max_level; ++l) start[l] = start[l + 1];
+    start[max_level] = (uint32_t)total;
+    w->n_levels[phase] = max_level;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ivx_world_create(ivx_ctx* c, const ivx_solver_config* cfg, ivx_world** out) {
+    IVX_REQUIRE(c && out, IVX_ERR_INVALID, "ivx_world_create: null argument");
+    *out = nullptr;
+    ivx_world* w = new (std::nothrow) ivx_world();
+    IVX_REQUIRE(w, IVX_ERR_CAPACITY, "ivx_world_create: out of host memory");
+    w->ctx = c;
+    if (cfg) w->cfg = *cfg;
+    else w->cfg = ivx_solver_config{8u, 0.4f, 3u, 0.2f};  // ConstraintSolverConfig::default (solver.rs:374-384)
+    IVX_REQUIRE(w->cfg.n_iterations + w->cfg.n_positional_correction_iterations < 4096, IVX_ERR_INVALID, "ivx_world_create: too many iterations");
+    *out = w;
+    return IVX_OK;
+}
+
+void ivx_world_destroy(ivx_world* w) {
+    if (!w) return;
+    (void)hipStreamSynchronize(w->ctx->stream);
+    void* ptrs[] = {w->dyn, w->kin, w->cb, w->touched, w->contacts, w->prev_slot, w->pc[0], w->pc[1], w->acc[0], w->acc[1], w->items, w->level_start};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (w->ev_ready)
+        for (int i = 0; i < 5; ++i) (void)hipEventDestroy(w->ev[i]);
+    delete w;
+}
+
+int ivx_world_set_bodies(ivx_world* w, const ivx_rigid_body* dyn, size_t n_dyn, const ivx_kinematic_body* kin, size_t n_kin) {
+    IVX_REQUIRE(w && (dyn || n_dyn == 0) && (kin || n_kin == 0), IVX_ERR_INVALID, "ivx_world_set_bodies: null argument");
+    IVX_REQUIRE(n_dyn < IVX_KINEMATIC_BODY && n_kin < IVX_KINEMATIC_BODY, IVX_ERR_CAPACITY, "ivx_world_set_bodies: too many bodies");
+    for (size_t i = 0; i < n_dyn; ++i) IVX_REQUIRE(dyn[i].mass > 0.0f, IVX_ERR_INVALID, "ivx_world_set_bodies: body %zu has non-positive mass", i);
+    hipStream_t s = w->ctx->stream;
+    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    const size_t need = n_dyn + n_kin;
+    if (need > w->body_cap) {
+        void* ptrs[] = {w->dyn, w->kin, w->cb, w->touched};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+        w->dyn = nullptr, w->kin = nullptr, w->cb = nullptr, w->touched = nullptr;
+        w->body_cap = 0;
+        const size_t cap = std::max<size_t>(need, 64);
+        IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->dyn), cap * sizeof(ivx_rigid_body)));
+        IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->kin), cap * sizeof(ivx_kinematic_body)));
+        IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->cb), cap * sizeof(PhysBody)));
+        IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->touched), cap));
+        w->body_cap = cap;
+    }
+    if (n_dyn) IVX_HIP_CHECK(hipMemcpy(w->dyn, dyn, n_dyn * sizeof(ivx_rigid_body), hipMemcpyHostToDevice));
+    if (n_kin) IVX_HIP_CHECK(hipMemcpy(w->kin, kin, n_kin * sizeof(ivx_kinematic_body), hipMemcpyHostToDevice));
+    const bool resized = w->n_dyn != n_dyn || w->n_kin != n_kin;
+    w->n_dyn = (uint32_t)n_dyn;
+    w->n_kin = (uint32_t)n_kin;
+    if (resized) w->schedule_valid = 0;
+    w->prepared_fresh = 0;
+    return IVX_OK;
+}
+
+int ivx_world_get_bodies(ivx_world* w, ivx_rigid_body* dyn, ivx_kinematic_body* kin) {
+    IVX_REQUIRE(w, IVX_ERR_INVALID, "ivx_world_get_bodies: null world");
+    IVX_HIP_CHECK(hipStreamSynchronize(w->ctx->stream));
+    if (dyn && w->n_dyn) IVX_HIP_CHECK(hipMemcpy(dyn, w->dyn, w->n_dyn * sizeof(ivx_rigid_body), hipMemcpyDeviceToHost));
+    if (kin && w->n_kin) IVX_HIP_CHECK(hipMemcpy(kin, w->kin, w->n_kin * sizeof(ivx_kinematic_body), hipMemcpyDeviceToHost));
+    return IVX_OK;
+}
+
+int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, size_t* n_prepared) {
+    IVX_REQUIRE(w && (contacts || n == 0), IVX_ERR_INVALID, "ivx_world_set_contacts: null argument");
+    IVX_REQUIRE(n < (1u << 28), IVX_ERR_CAPACITY, "ivx_world_set_contacts: more than 2^28 contacts");
+    for (size_t i = 0; i < n; ++i) {
+        const ivx_contact& c = contacts[i];
+        const uint32_t la = (c.body_a & IVX_KINEMATIC_BODY) ? w->n_kin : w->n_dyn, lb = (c.body_b & IVX_KINEMATIC_BODY) ? w->n_kin : w->n_dyn;
+        IVX_REQUIRE((c.body_a & 0x7FFFFFFFu) < la && (c.body_b & 0x7FFFFFFFu) < lb, IVX_ERR_INVALID, "ivx_world_set_contacts: contact %zu refers to a missing body", i);
+        IVX_REQUIRE(c.body_a != c.body_b, IVX_ERR_INVALID, "ivx_world_set_contacts: contact %zu joins a body with itself", i);
+    }
+    int rc;
+    // 1. manifolds: interlock replacement (constraint.rs:237-249)
+    w->effective.clear();
+    size_t i = 0;
+    while (i < n) {
+        size_t j = i + 1;
+        while (j < n && !(contacts[j].flags & IVX_CONTACT_MANIFOLD_START)) ++j;
+        const ivx_contact* m = contacts + i;
+        const size_t cnt = j - i;
+        bool replaced = false;
+        if (manifold_interlocked(m, cnt)) {
+            float pa[3], pb[3];
+            if ((rc = fetch_body_position(w, m[0].body_a, pa))) return rc;
+            if ((rc = fetch_body_position(w, m[0].body_b, pb))) return rc;
+            ivx_contact sep;
+            if (separating_contact(h3(pa) - h3(pb), m, cnt, sep)) {
+                sep.body_a = m[0].body_a;
+                sep.body_b = m[0].body_b;
+                w->effective.push_back(sep);
+                replaced = true;
+            }
+        }
+        if (!replaced) w->effective.insert(w->effective.end(), m, m + cnt);
+        i = j;
+    }
+    // 2. ConstraintCache::register_prepared_constraint + remove_unprepared_constraints (solver.rs:406-452)
+    for (uint32_t e = 0; e < w->effective.size(); ++e) {
+        const uint64_t id = w->effective[e].id;
+        auto it = w->index_of.find(id);
+        if (it != w->index_of.end()) {
+            ivx_world::Entry& en = w->cache[it->second];
+            en.src = e;
+            en.prepared = true;
+        } else {
+            w->index_of.emplace(id, (uint32_t)w->cache.size());
+            w->cache.push_back(ivx_world::Entry{id, -1, e, true});
+        }
+    }
+    size_t idx = 0, len = w->cache.size();
+    while (idx < len) {
+        if (w->cache[idx].prepared) {
+            ++idx;
+        } else {
+            w->index_of.erase(w->cache[idx].id);
+            w->cache[idx] = w->cache[len - 1];
+            w->cache.pop_back();
+            --len;
+            if (idx < len) w->index_of[w->cache[idx].id] = (uint32_t)idx;
+        }
+    }
+    const uint32_t nc = (uint32_t)w->cache.size();
+    w->ordered.resize(nc);
+    w->prev_slot_host.resize(nc);
+    for (uint32_t s = 0; s < nc; ++s) {
+        ivx_world::Entry& en = w->cache[s];
+        w->ordered[s] = w->effective[en.src];
+        w->prev_slot_host[s] = en.prev_slot;
+        en.prev_slot = (int32_t)s;
+        en.prepared = false;
+    }
+    w->n_prev = w->n_contacts;  // size of the state arrays written by the previous prepare
+    w->n_contacts = nc;
+    // 3. dependency schedules: (warm pass + velocity sweeps) and (positional sweeps)
+    w->items_host.clear();
+    w->level_start_host.clear();
+    build_schedule(w, PHYS_ITEM_WARM, 1u, PHYS_ITEM_VELOCITY, w->cfg.n_iterations, 0);
+    build_schedule(w, PHYS_ITEM_POSITIONAL, 0u, PHYS_ITEM_POSITIONAL, w->cfg.n_positional_correction_iterations, 1);
+    // 4. upload
+    hipStream_t s = w->ctx->stream;
+    size_t cap = w->contact_cap;
+    if (nc > cap) {
+        IVX_HIP_CHECK(hipStreamSynchronize(s));
+        const size_t ncap = std::max<size_t>(nc, std::max<size_t>(cap * 2, 256));
+        // the previous state (pc/acc of the last solve) must survive the growth
+        ivx_contact* nc_buf = nullptr;
+        int32_t* np = nullptr;
+        PhysContact* npc[2] = {nullptr, nullptr};
+        float* nacc[2] = {nullptr, nullptr};
+        IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&nc_buf), ncap * sizeof(ivx_contact)));
+        IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&np), ncap * sizeof(int32_t)));
+        for (int b = 0; b < 2; ++b) {
+            IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&npc[b]), ncap * sizeof(PhysContact)));
+            IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&nacc[b]), ncap * 4 * sizeof(float)));
+            if (w->pc[b] && w->n_prev) {
+                IVX_HIP_CHECK(hipMemcpy(npc[b], w->pc[b], w->n_prev * sizeof(PhysContact), hipMemcpyDeviceToDevice));
+                IVX_HIP_CHECK(hipMemcpy(nacc[b], w->acc[b], w->n_prev * 4 * sizeof(float), hipMemcpyDeviceToDevice));
+            }
+            if (w->pc[b]) (void)hipFree(w->pc[b]);
+            if (w->acc[b]) (void)hipFree(w->acc[b]);
+            w->pc[b] = npc[b];
+            w->acc[b] = nacc[b];
+        }
+        if (w->contacts) (void)hipFree(w->contacts);
+        if (w->prev_slot) (void)hipFree(w->prev_slot);
+        w->contacts = nc_buf;
+        w->prev_slot = np;
+        w->contact_cap = ncap;
+    }
+    if ((rc = grow(&w->items, &w->item_cap, w->items_host.size(), s))) return rc;
+    if ((rc = grow(&w->level_start, &w->level_cap, w->level_start_host.size(), s))) return rc;
+    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    if (nc) {
+        IVX_HIP_CHECK(hipMemcpy(w->contacts, w->ordered.data(), nc * sizeof(ivx_contact), hipMemcpyHostToDevice));
+        IVX_HIP_CHECK(hipMemcpy(w->prev_slot, w->prev_slot_host.data(), nc * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    if (!w->items_host.empty()) IVX_HIP_CHECK(hipMemcpy(w->items, w->items_host.data(), w->items_host.size() * 4, hipMemcpyHostToDevice));
+    IVX_HIP_CHECK(hipMemcpy(w->level_start, w->level_start_host.data(), w->level_start_host.size() * 4, hipMemcpyHostToDevice));
+    w->schedule_valid = 1;
+    // 5. device part of prepare_constraints: gather bodies, prepare every contact, warm-start bookkeeping
+    w->cur ^= 1;
+    if ((rc = ivx_launch_phys_prepare_bodies(w))) return rc;
+    if ((rc = ivx_launch_phys_prepare_contacts(w, w->prev_slot))) return rc;
+    w->prepared_fresh = 1;
+    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    if (n_prepared) *n_prepared = nc;
+    return IVX_OK;
+}
+
+// prepare_constraints again over the resident contact set: same ids, same order (every id is "known from
+// the previous solve"), warm impulses from the last solve
+int ivx_world_prepare(ivx_world* w) {
+    IVX_REQUIRE(w, IVX_ERR_INVALID, "ivx_world_prepare: null world");
+    IVX_REQUIRE(w->schedule_valid || w->n_contacts == 0, IVX_ERR_STATE, "ivx_world_prepare: call ivx_world_set_contacts after changing the bodies");
+    int rc;
+    w->cur ^= 1;
+    w->n_prev = w->n_contacts;
+    if ((rc = ivx_launch_phys_prepare_bodies(w))) return rc;
+    if ((rc = ivx_launch_phys_prepare_contacts(w, nullptr))) return rc;
+    w->prepared_fresh = 1;
+    return IVX_OK;
+}
+
+int ivx_world_advance_momenta(ivx_world* w, float dt) {
+    IVX_REQUIRE(w, IVX_ERR_INVALID, "ivx_world_advance_momenta: null world");
+    return ivx_launch_phys_pre_solve(w, dt);
+}
+
+int ivx_world_solve(ivx_world* w) {
+    IVX_REQUIRE(w, IVX_ERR_INVALID, "ivx_world_solve: null world");
+    IVX_REQUIRE(w->prepared_fresh, IVX_ERR_STATE, "ivx_world_solve: no prepared constraints (ivx_world_set_contacts / ivx_world_prepare)");
+    int rc;
+    if ((rc = ivx_launch_phys_solve(w))) return rc;
+    if ((rc = ivx_launch_phys_post_solve(w, 0.0f, 1, 0))) return rc;
+    w->prepared_fresh = 0;
+    return IVX_OK;
+}
+
+int ivx_world_advance_configurations(ivx_world* w, float dt) {
+    IVX_REQUIRE(w, IVX_ERR_INVALID, "ivx_world_advance_configurations: null world");
+    return ivx_launch_phys_post_solve(w, dt, 0, 1);
+}
+
+int ivx_world_step(ivx_world* w, float dt, ivx_physics_result* out) {
+    IVX_REQUIRE(w, IVX_ERR_INVALID, "ivx_world_step: null world");
+    hipStream_t s = w->ctx->stream;
+    if (!w->ev_ready) {
+        for (int i = 0; i < 5; ++i) IVX_HIP_CHECK(hipEventCreate(&w->ev[i]));
+        w->ev_ready = 1;
+    }
+    int rc;
+    IVX_HIP_CHECK(hipEventRecord(w->ev[0], s));
+    if (!w->prepared_fresh)
+        if ((rc = ivx_world_prepare(w))) return rc;
+    IVX_HIP_CHECK(hipEventRecord(w->ev[1], s));
+    if ((rc = ivx_launch_phys_pre_solve(w, dt))) return rc;
+    IVX_HIP_CHECK(hipEventRecord(w->ev[2], s));
+    if ((rc = ivx_launch_phys_solve(w))) return rc;
+    IVX_HIP_CHECK(hipEventRecord(w->ev[3], s));
+    if ((rc = ivx_launch_phys_post_solve(w, dt, 1, 1))) return rc;
+    IVX_HIP_CHECK(hipEventRecord(w->ev[4], s));
+    w->prepared_fresh = 0;
+    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    if (out) {
+        memset(out, 0, sizeof(*out));
+        out->n_contacts = w->n_contacts;
+        out->n_levels[0] = w->n_levels[0];
+        out->n_levels[1] = w->n_levels[1];
+        uint32_t nb = 0;
+        {
+            std::vector<uint8_t> t(w->n_dyn);
+            if (w->n_dyn) IVX_HIP_CHECK(hipMemcpy(t.data(), w->touched, w->n_dyn, hipMemcpyDeviceToHost));
+            for (uint8_t x : t) nb += x;
+            std::vector<uint8_t> kt(w->n_kin, 0);
+            for (const ivx_contact& c : w->ordered) {
+                if (c.body_a & IVX_KINEMATIC_BODY) kt[c.body_a & 0x7FFFFFFFu] = 1;
+                if (c.body_b & IVX_KINEMATIC_BODY) kt[c.body_b & 0x7FFFFFFFu] = 1;
+            }
+            for (uint8_t x : kt) nb += x;
+        }
+        out->n_bodies = nb;
+        for (int i = 0; i < 4; ++i)
+            if (hipEventElapsedTime(&out->stage_ms[i], w->ev[i], w->ev[i + 1]) != hipSuccess) out->stage_ms[i] = 0.0f;
+        if (hipEventElapsedTime(&out->stage_ms[4], w->ev[0], w->ev[4]) != hipSuccess) out->stage_ms[4] = 0.0f;
+    }
+    return IVX_OK;
+}
+
+int ivx_world_contact_state(ivx_world* w, uint64_t* ids, float* impulses3, size_t cap, size_t* n_out) {
+    IVX_REQUIRE(w && n_out, IVX_ERR_INVALID, "ivx_world_contact_state: null argument");
+    *n_out = w->n_contacts;
+    IVX_REQUIRE(w->n_contacts <= cap, IVX_ERR_CAPACITY, "ivx_world_contact_state: %u contacts exceed capacity %zu", w->n_contacts, cap);
+    if (ids)
+        for (uint32_t s = 0; s < w->n_contacts; ++s) ids[s] = w->cache[s].id;
+    if (impulses3 && w->n_contacts) {
+        IVX_HIP_CHECK(hipStreamSynchronize(w->ctx->stream));
+        std::vector<float> a((size_t)w->n_contacts * 4);
+        IVX_HIP_CHECK(hipMemcpy(a.data(), w->acc[w->cur], a.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t s = 0; s < w->n_contacts; ++s)
+            for (int q = 0; q < 3; ++q) impulses3[3 * (size_t)s + q] = a[4 * (size_t)s + q];
+    }
+    return IVX_OK;
+}
+
+}  // extern "C"

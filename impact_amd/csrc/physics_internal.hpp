@@ -1,0 +1,79 @@
+// Device-side layouts and the host-side world object of the rigid-body / contact-solver part
+// (a15-a19). See physics.hip for the kernels and physics_api.hip for the bookkeeping.
+#pragma once
+#include <cstdint>
+#include <unordered_map>
+#include <vector>
+
+#include "ivx_internal.hpp"
+
+// ConstrainedBody (impact_physics/src/constraint.rs:137-150), 96 bytes. Dynamic bodies first (same index as
+// in the rigid-body array), kinematic bodies after them.
+struct PhysBody {
+    float inv_mass;
+    float inv_inertia[9];  // world space, column-major
+    float pos[3];
+    float q[4];
+    float v[3];
+    float w[3];
+    float pad;
+};
+static_assert(sizeof(PhysBody) == 96, "PhysBody layout");
+
+// PreparedContact (constraint/contact.rs:63-86) + the constrained-body indices of its pair, 96 bytes
+struct PhysContact {
+    float local_a[3], local_b[3], normal[3], tangent[3], bitangent[3];
+    float m_n, m_t, m_b, friction, target;
+    uint32_t ia, ib;
+    uint32_t pad[2];
+};
+static_assert(sizeof(PhysContact) == 96, "PhysContact layout");
+
+#define PHYS_ITEM_WARM 0u
+#define PHYS_ITEM_VELOCITY 1u
+#define PHYS_ITEM_POSITIONAL 2u
+#define PHYS_LEVEL_TILE 4096
+
+struct ivx_world {
+    ivx_ctx* ctx;
+    ivx_solver_config cfg;
+    uint32_t n_dyn, n_kin;
+    size_t body_cap;
+    ivx_rigid_body* dyn;
+    ivx_kinematic_body* kin;
+    PhysBody* cb;
+    uint8_t* touched;
+    // contacts of the current step, in ConstraintCache order (= solve order)
+    uint32_t n_contacts, n_prev;
+    size_t contact_cap, item_cap, level_cap;
+    ivx_contact* contacts;
+    int32_t* prev_slot;
+    PhysContact* pc[2];
+    float* acc[2];  // float4 per contact
+    int cur;
+    uint32_t* items;
+    uint32_t* level_start;
+    uint32_t n_levels[2], item_offset[2], level_offset[2];
+    int schedule_valid, prepared_fresh;
+    hipEvent_t ev[5];
+    int ev_ready;
+    // host-side ConstraintCache<ContactID, _> bookkeeping (constraint/solver.rs:60-66, 386-452)
+    struct Entry {
+        uint64_t id;
+        int32_t prev_slot;
+        uint32_t src;
+        bool prepared;
+    };
+    std::vector<Entry> cache;
+    std::unordered_map<uint64_t, uint32_t> index_of;
+    std::vector<ivx_contact> effective;  // contacts of this step after interlock replacement
+    std::vector<ivx_contact> ordered;
+    std::vector<int32_t> prev_slot_host;
+    std::vector<uint32_t> items_host, level_start_host, scratch_level, scratch_last;
+};
+
+int ivx_launch_phys_prepare_bodies(ivx_world* w);
+int ivx_launch_phys_prepare_contacts(ivx_world* w, const int32_t* d_prev_slot);
+int ivx_launch_phys_pre_solve(ivx_world* w, float dt);
+int ivx_launch_phys_solve(ivx_world* w);
+int ivx_launch_phys_post_solve(ivx_world* w, float dt, int write_back, int advance);

@@ -95,3 +95,76 @@ def asteroid_row_scene(n: int, scale: float = 2.05, bar_width: float | None = No
         bar = g.add_node(SDFNode.new_box((pitch * (n - 1), w, w)))
         g.add_node(SDFNode.new_union(acc, bar, 0.0))
     return g
+
+
+# ---- rigid-body pile (BASELINE config 4) ----------------------------------------------------------------
+def _splitmix(state: int) -> int:
+    """impact_math/src/random/splitmix.rs:4-10"""
+    m = (1 << 64) - 1
+    state = (state + 0x9E3779B97F4A7C15) & m
+    z = state
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    return z ^ (z >> 31)
+
+
+def contact_id(a: int, b: int, *indices: int) -> int:
+    """`ContactID::from_two_u64_and_n_indices` (impact_physics/src/constraint/contact.rs:180-199)"""
+    cid = _splitmix(a ^ _splitmix(b))
+    for i in indices:
+        cid = _splitmix(cid ^ _splitmix(i))
+    return cid
+
+
+def sphere_pile_scene(n: int = 16, spacing: float = 0.95, radius: float = 0.5, points_per_pair: int = 4, gravity: float = -9.81,
+                      restitution: float = 0.4, static_friction: float = 0.7, dynamic_friction: float = 0.5):
+    """Config 4: an n^3 lattice of unit-density spheres (5 % overlap at spacing 0.95, cf. the reference's
+    `setup_stationary_overlapping_spheres`, engine/src/benchmark/benchmarks/constraint.rs:308-329) with the
+    6-neighbour contacts as an explicit list: per touching pair `points_per_pair` contact points on a square
+    inside the overlap circle, in the order (body_a, body_b, k); sphere-sphere geometry as in
+    impact_physics/src/collision/collidable/sphere.rs:105-136 (normal from B to A, position on B).
+    n = 16 -> 4096 bodies, 11 520 pairs, 46 080 contacts. Returns (bodies, contacts)."""
+    import numpy as np
+
+    from .capi import CONTACT_DTYPE, CONTACT_MANIFOLD_START
+    from .physics import uniform_sphere_body
+
+    f32 = np.float32
+    idx = np.arange(n ** 3)
+    ix, iy, iz = idx // (n * n), (idx // n) % n, idx % n
+    pos = np.stack([ix, iy, iz], axis=1).astype(np.float32) * f32(spacing)
+    proto = uniform_sphere_body(radius, 1.0, (0.0, 0.0, 0.0))
+    bodies = np.repeat(np.array([proto]), n ** 3)
+    bodies["position"] = pos
+    bodies["total_force"][:, 1] = f32(gravity) * proto["mass"]
+    pairs = []
+    for axis, stride in ((2, 1), (1, n), (0, n * n)):  # +z, +y, +x neighbours of body a, sorted below
+        coord = (ix, iy, iz)[axis]
+        a = idx[coord < n - 1]
+        pairs.append(np.stack([a, a + stride, np.full_like(a, axis)], axis=1))
+    pairs = np.concatenate(pairs)
+    pairs = pairs[np.lexsort((pairs[:, 1], pairs[:, 0]))]
+    depth = f32(2.0 * radius) - f32(spacing)
+    rho = f32(0.1)
+    offs = [(-1, -1), (1, -1), (1, 1), (-1, 1)][:points_per_pair] if points_per_pair <= 4 else None
+    contacts = np.zeros(len(pairs) * points_per_pair, dtype=CONTACT_DTYPE)
+    k = 0
+    for a, b, axis in pairs:
+        normal = np.zeros(3, dtype=np.float32)
+        normal[axis] = -1.0  # (centre_a - centre_b) / distance: b = a + stride lies at larger coordinate
+        u = np.zeros(3, dtype=np.float32)
+        v = np.zeros(3, dtype=np.float32)
+        u[(axis + 1) % 3] = 1.0
+        v[(axis + 2) % 3] = 1.0
+        base = pos[b] + f32(radius) * normal
+        for q, (su, sv) in enumerate(offs):
+            c = contacts[k]
+            c["id"] = contact_id(int(a), int(b), q)
+            c["body_a"], c["body_b"] = a, b
+            c["position"] = base + rho * (f32(su) * u + f32(sv) * v)
+            c["normal"] = normal
+            c["depth"] = depth
+            c["restitution"], c["static_friction"], c["dynamic_friction"] = restitution, static_friction, dynamic_friction
+            c["flags"] = CONTACT_MANIFOLD_START if q == 0 else 0
+            k += 1
+    return bodies, contacts

@@ -216,6 +216,79 @@ size_t ivx_region_face_bytes(ivx_grid*);
 int ivx_region_face_labels(ivx_grid*, int side, void* device_buf);
 int ivx_region_face_pairs(ivx_grid*, int side, const void* neighbour_face_labels_device, uint32_t* pairs, size_t cap, size_t* n_out);
 
+/* ---- a15-a19: rigid bodies + sequential-impulses contact solve (engine/crates/impact_physics) ----- */
+/* DynamicRigidBody, #[repr(C)], 152 bytes (src/rigid_body.rs:94-103). Matrices are Matrix3C (column-major),
+ * orientation is UnitQuaternionC (x, y, z, w). */
+typedef struct {
+    float mass;
+    float inertia[9], inv_inertia[9]; /* InertiaTensorC about the centre of mass, body frame (src/inertia.rs:41-47) */
+    float position[3];
+    float orientation[4];
+    float momentum[3], angular_momentum[3];
+    float total_force[3], total_torque[3];
+} ivx_rigid_body;
+/* KinematicRigidBody, 56 bytes (src/rigid_body.rs:108-117): AngularVelocityC = unit axis + angular speed */
+typedef struct {
+    float position[3];
+    float orientation[4];
+    float velocity[3];
+    float angular_axis[3];
+    float angular_speed;
+} ivx_kinematic_body;
+/* One ContactWithID of a collision (src/constraint/contact.rs:23-57) with the two rigid bodies it acts on.
+ * body_a/body_b index the dynamic bodies; bit 31 set = index into the kinematic bodies. position =
+ * ContactGeometry::position (point on B), normal = surface normal of B, depth = penetration depth; the
+ * three response parameters are the already combined ones (src/material.rs:43-52). flags bit 0 marks the
+ * first contact of a manifold (one Collision): interlock analysis works per manifold
+ * (contact.rs:610-689). 64 bytes. */
+typedef struct {
+    uint64_t id; /* ContactID */
+    uint32_t body_a, body_b;
+    float position[3];
+    float normal[3];
+    float depth;
+    float restitution, static_friction, dynamic_friction;
+    uint32_t flags, reserved;
+} ivx_contact;
+#define IVX_KINEMATIC_BODY 0x80000000u
+#define IVX_CONTACT_MANIFOLD_START 1u
+/* ConstraintSolverConfig (src/constraint/solver.rs:41-57; defaults 8, 0.4, 3, 0.2 at 374-384) */
+typedef struct {
+    uint32_t n_iterations;
+    float old_impulse_weight;
+    uint32_t n_positional_correction_iterations;
+    float positional_correction_factor;
+} ivx_solver_config;
+typedef struct {
+    uint32_t n_contacts;   /* prepared contacts (after interlock replacement and cache clean-up) */
+    uint32_t n_bodies;     /* constrained bodies (touched by >= 1 contact) */
+    uint32_t n_levels[2];  /* dependency levels of the velocity and the positional schedule */
+    float stage_ms[5];     /* prepare, pre-solve (momenta + velocity sync), solve, write-back + configurations, total */
+    uint32_t reserved[3];
+} ivx_physics_result;
+
+/* RigidBodyManager + ConstraintManager of one simulation (src/rigid_body.rs:71-78, src/constraint.rs:33-39) */
+typedef struct ivx_world ivx_world;
+int ivx_world_create(ivx_ctx*, const ivx_solver_config*, ivx_world** out);
+void ivx_world_destroy(ivx_world*);
+int ivx_world_set_bodies(ivx_world*, const ivx_rigid_body* dynamic, size_t n_dynamic, const ivx_kinematic_body* kinematic, size_t n_kinematic);
+int ivx_world_get_bodies(ivx_world*, ivx_rigid_body* dynamic, ivx_kinematic_body* kinematic); /* either may be NULL */
+/* The collisions of this step (what CollisionWorld hands to ConstraintManager::prepare_constraints,
+ * src/constraint.rs:193-265). Host side: interlock replacement, the ConstraintCache bookkeeping that fixes
+ * the solve order and the warm-start source of every contact (solver.rs:386-452), and the dependency
+ * schedule that lets the GPU run the reference's sequential sweeps in parallel with identical results. */
+int ivx_world_set_contacts(ivx_world*, const ivx_contact*, size_t n, size_t* n_prepared);
+/* perform_physics_step (src/lib.rs:31-110) without force generators / motion drivers: prepare constraints ->
+ * advance momenta -> synchronise velocities, warm start, n_iterations sweeps, positional correction,
+ * write back -> advance configurations. The stages are also exposed one by one. */
+int ivx_world_step(ivx_world*, float dt, ivx_physics_result* out);
+int ivx_world_prepare(ivx_world*);
+int ivx_world_advance_momenta(ivx_world*, float dt);
+int ivx_world_solve(ivx_world*);
+int ivx_world_advance_configurations(ivx_world*, float dt);
+/* ContactIDs in solve order and their accumulated (normal, tangent, bitangent) impulses after the last solve */
+int ivx_world_contact_state(ivx_world*, uint64_t* ids, float* impulses3, size_t cap, size_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,180 @@
+"""GPU parity of the rigid-body step + sequential-impulses contact solve (through the ivx_world_* C ABI)
+against the oracle, plus the reference's own sphere-collision outcomes (impact_physics/tests/constraint.rs)
+checked directly on the GPU results. Bar: body state within 1e-5 relative; ContactID order identical."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import physics_util as pu
+from impact_amd import scenes
+from impact_amd.capi import CONTACT_DTYPE, KINEMATIC_BIT
+from impact_amd.physics import ConstraintSolverConfig, PhysicsWorld, uniform_sphere_body
+
+pytestmark = pytest.mark.gpu
+
+
+def contact(cid, a, b, geom, restitution, mu_s=0.0, mu_d=0.0, first=True):
+    c = np.zeros((), dtype=CONTACT_DTYPE)
+    c["id"], c["body_a"], c["body_b"] = cid, a, b
+    c["position"], c["normal"], c["depth"] = geom
+    c["restitution"], c["static_friction"], c["dynamic_friction"] = restitution, mu_s, mu_d
+    c["flags"] = 1 if first else 0
+    return c
+
+
+def velocity(b):
+    return b["momentum"] / b["mass"]
+
+
+def binary(ctx, sa, sb, va, vb, config=(1, 0.4, 0, 0.2)):
+    dyn = np.array([uniform_sphere_body(0.5, s[3], s[0], s[2]) for s in (sa, sb)])
+    g = ol.sphere_sphere_contact(sa[0], sa[1], sb[0], sb[1])
+    cs = np.array([contact(7, 0, 1, g, max(sa[4], sb[4]))])
+    w, o = pu.make_pair(ctx, dyn, config=config)
+    assert w.prepare_constraints(cs) == 1 and o.prepare(cs) == 1
+    w.compute_and_apply_constrained_state()
+    o.solve()
+    gd, _ = w.bodies()
+    for b, s, ve in zip(gd, (sa, sb), (va, vb)):
+        np.testing.assert_array_equal(b["position"], np.float32(s[0]))
+        np.testing.assert_array_equal(b["orientation"], np.float32([0, 0, 0, 1]))
+        np.testing.assert_allclose(velocity(b), ve, rtol=0, atol=1e-6)
+        assert np.abs(b["angular_momentum"]).max() <= 1e-6
+    pu.assert_bodies_close(gd, o.bodies()[0])
+    w.close()
+
+
+def test_reference_sphere_collisions(ctx):
+    """tests/constraint.rs:339-457: head-on equal mass, very massive, inelastic, grazing"""
+    binary(ctx, ((0, 0, 0), 1.0, (0.5, 0, 0), 1.0, 1.0), ((2.0 - 1e-6, 0, 0), 1.0, (0, 0, 0), 1.0, 1.0), (0, 0, 0), (0.5, 0, 0))
+    binary(ctx, ((0, 0, 0), 1.0, (0.5, 0, 0), 1.0, 1.0), ((2.0 - 1e-6, 0, 0), 1.0, (0, 0, 0), 1e9, 1.0), (-0.5, 0, 0), (0, 0, 0))
+    binary(ctx, ((0, 0, 0), 1.0, (0.5, 0, 0), 1.0, 0.0), ((2.0 - 1e-6, 0, 0), 1.0, (0, 0, 0), 1.0, 0.0), (0.25, 0, 0), (0.25, 0, 0))
+    off = float(np.float32(np.sqrt(np.float32(2.0))))
+    binary(ctx, ((1e-6, 0, 0), 1.0, (0.5, 0, 0), 1.0, 1.0), ((off, off, 0), 1.0, (-0.5, 0, 0), 1.0, 1.0), (0, -0.5, 0), (0, 0.5, 0))
+
+
+def test_reference_sphere_on_static_plane(ctx):
+    """tests/constraint.rs:459-514 (kinematic body = static plane)"""
+    s = ((0.0, 1.0 - 1e-6, 0.0), 1.0, (0.5, -0.6, 0.0), 1.0, 1.0)
+    dyn = np.array([uniform_sphere_body(0.5, s[3], s[0], s[2])])
+    g = ol.sphere_plane_contact(s[0], s[1])
+    cs = np.array([contact(9, 0, KINEMATIC_BIT | 0, g, 1.0)])
+    w, o = pu.make_pair(ctx, dyn, pu.static_plane(), config=(1, 0.4, 0, 0.2))
+    assert w.prepare_constraints(cs) == 1 and o.prepare(cs) == 1
+    w.compute_and_apply_constrained_state()
+    o.solve()
+    gd, gk = w.bodies()
+    np.testing.assert_allclose(velocity(gd[0]), (0.5, 0.6, 0.0), rtol=0, atol=1e-6)
+    pu.assert_bodies_close(gd, o.bodies()[0])
+    np.testing.assert_array_equal(gk["position"], 0)
+    w.close()
+
+
+def test_reference_position_correction(ctx):
+    """tests/constraint.rs:516-576"""
+    pen = 0.2
+    spheres = [((0.5 * pen, 0, 0), 1.0), ((2.0 - 0.5 * pen, 0, 0), 1.0)]
+    dyn = np.array([uniform_sphere_body(0.5, 1.0, s[0]) for s in spheres])
+    g = ol.sphere_sphere_contact(spheres[0][0], 1.0, spheres[1][0], 1.0)
+    cs = np.array([contact(3, 0, 1, g, 1.0)])
+    w, o = pu.make_pair(ctx, dyn, config=(0, 0.4, 1, 1.0))
+    w.prepare_constraints(cs)
+    o.prepare(cs)
+    w.compute_and_apply_constrained_state()
+    o.solve()
+    gd, _ = w.bodies()
+    for idx, b in enumerate(gd):
+        np.testing.assert_allclose(b["position"], (2.0 * idx, 0, 0), rtol=0, atol=1e-6)
+        np.testing.assert_array_equal(b["orientation"], np.float32([0, 0, 0, 1]))
+        assert (b["momentum"] == 0).all()
+    pu.assert_bodies_close(gd, o.bodies()[0])
+    w.close()
+
+
+@pytest.mark.parametrize("n,steps", [(3, 4), (6, 3)])
+def test_small_piles_step_by_step(ctx, n, steps):
+    """lattice piles under gravity: several steps with the contact list handed over again every step
+    (cache hits, warm starting with weight 0.4), state + contact order + impulses vs the oracle"""
+    bodies, contacts = scenes.sphere_pile_scene(n)
+    w, o = pu.make_pair(ctx, bodies)
+    for s in range(steps):
+        r = pu.step_both(w, o, contacts, 0.005)
+        pu.assert_bodies_close(w.bodies()[0], o.bodies()[0], what=f"step {s}: ")
+        pu.compare_contact_state(w, o)
+    assert int(r["n_bodies"]) == n ** 3
+    w.close()
+
+
+def test_config4_pile_4096_bodies(ctx):
+    """BASELINE config 4: 16^3 = 4096 spheres, 46 080 contacts, 8 + 3 iterations, dt 0.005"""
+    bodies, contacts = scenes.sphere_pile_scene(16)
+    assert len(bodies) == 4096 and len(contacts) == 46080
+    w, o = pu.make_pair(ctx, bodies)
+    for s in range(2):
+        r = pu.step_both(w, o, contacts, 0.005)
+        pu.assert_bodies_close(w.bodies()[0], o.bodies()[0], what=f"step {s}: ")
+    pu.compare_contact_state(w, o)
+    # a further step over the RESIDENT contact set (what bench.py times) = prepare_constraints again with the same list
+    o.step(contacts, 0.005)
+    w.step(0.005)
+    pu.assert_bodies_close(w.bodies()[0], o.bodies()[0], what="resident step: ")
+    assert int(r["n_levels"][0]) > 0 and int(r["n_levels"][1]) > 0
+    w.close()
+
+
+def test_contacts_come_and_go(ctx):
+    """ConstraintCache order after removals (swap_remove) and additions, with spinning / moving bodies and
+    friction; ragged inputs: empty contact list, bodies without contacts"""
+    rng = np.random.default_rng(5)
+    bodies, contacts = scenes.sphere_pile_scene(4)
+    bodies["momentum"] += rng.normal(0, 0.05, bodies["momentum"].shape).astype(np.float32)
+    bodies["angular_momentum"] += rng.normal(0, 0.01, bodies["angular_momentum"].shape).astype(np.float32)
+    w, o = pu.make_pair(ctx, bodies)
+    manifolds = contacts.reshape(-1, 4)
+    keep_sets = [np.arange(len(manifolds)), np.arange(0, len(manifolds), 2), np.arange(len(manifolds))[::-1][:40], np.array([], dtype=int),
+                 np.arange(5, len(manifolds))]
+    for s, keep in enumerate(keep_sets):
+        cs = manifolds[keep].reshape(-1) if len(keep) else np.zeros(0, dtype=CONTACT_DTYPE)
+        pu.step_both(w, o, cs, 0.004)
+        pu.assert_bodies_close(w.bodies()[0], o.bodies()[0], what=f"set {s}: ")
+        if len(cs):
+            pu.compare_contact_state(w, o)
+    w.close()
+
+
+def test_interlocked_manifold(ctx):
+    """contact.rs:610-780 through the GPU path: opposing penetration vectors are replaced by one
+    separating contact (needs the bodies' current positions from the device)"""
+    dyn = np.array([uniform_sphere_body(0.5, 1.0, (0, 0.3, 0)), uniform_sphere_body(0.5, 1.0, (0, 0, 0))])
+    pts = [(-1.0, 0.0, 0.0), (1.0, 0.0, 0.0), (0.0, 0.1, 1.0), (0.0, -0.1, -1.0)]
+    nrm = [(1, 0, 0), (-1, 0, 0), (0, 0, 1), (0, 0, -1)]
+    cs = np.array([contact(20 + k, 0, 1, (pts[k], nrm[k], 0.1), 0.5, 0.7, 0.5, first=(k == 0)) for k in range(4)])
+    w, o = pu.make_pair(ctx, dyn)
+    for _ in range(2):
+        r = pu.step_both(w, o, cs, 0.01)
+        assert int(r["n_contacts"]) == 1
+        pu.assert_bodies_close(w.bodies()[0], o.bodies()[0])
+        pu.compare_contact_state(w, o)
+    w.close()
+
+
+def test_free_bodies_integrate_exactly_like_the_oracle(ctx):
+    """no contacts: momenta advance by force and torque, positions by velocity, orientations by the exact
+    axis-angle rotation (rigid_body.rs:708-742, 1013-1034); anisotropic inertia, 20 steps"""
+    rng = np.random.default_rng(1)
+    n = 64
+    dyn = []
+    for i in range(n):
+        I = np.diag(rng.uniform(0.5, 2.0, 3))
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        dyn.append(ol.rigid_body_new(rng.uniform(0.5, 3.0), I, rng.normal(size=3), q, rng.normal(size=3), rng.normal(size=3)))
+    dyn = np.array(dyn)
+    dyn["total_force"] = rng.normal(size=(n, 3)).astype(np.float32)
+    dyn["total_torque"] = rng.normal(size=(n, 3)).astype(np.float32)
+    w, o = pu.make_pair(ctx, dyn)
+    none = np.zeros(0, dtype=CONTACT_DTYPE)
+    for _ in range(20):
+        pu.step_both(w, o, none, 0.01)
+    pu.assert_bodies_close(w.bodies()[0], o.bodies()[0])
+    w.close()
