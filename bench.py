@@ -4,11 +4,15 @@
 
 A step = one pass of the per-frame voxel path over one SDF-defined grid that is already resident in
 HBM: SDF sample -> derived state (flags, chunk state, occupied ranges) -> connected regions ->
-Surface Nets remesh -> mass/inertia reduction. N = 1: the config-2 asteroid scaled x2.05 (502^3 grid ->
-32^3 chunks = 512^3 stored voxels). N > 1 (one process per GPU, launched by torch.distributed.run): weak
-scaling — N such asteroids joined by a thin bar, the (512 N) x 512 x 512 grid split into x-slabs of
-32 chunk planes per rank, one-voxel face halos and boundary chunk state exchanged over RCCL
-(torch.distributed "nccl"), cross-rank region equivalences all-gathered, moments all-reduced.
+Surface Nets remesh -> mass/inertia reduction -> rigid-body step of the object's own body (momenta,
+constraint solve over its — empty — contact list, configuration). N = 1: the config-2 asteroid scaled
+x2.05 (502^3 grid -> 32^3 chunks = 512^3 stored voxels). N > 1 (one process per GPU, launched by
+torch.distributed.run): weak scaling — N such asteroids in a row joined by a thin bar, one per x-slab of
+32 chunk planes, one-voxel face halos and boundary chunk state exchanged over RCCL (torch.distributed
+"nccl"), cross-rank region equivalences and the 10 mass moments in one small all-gather.
+
+The rigid-body solver's own workload (BASELINE config 4: 4096 bodies, 46 080 contacts) does not scale
+with voxels; it is timed separately on rank 0 and reported under "pile" in the same JSON line.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the byte counts behind `roofline`).
 """
@@ -73,6 +77,50 @@ def cpu_baseline(scale):
     }
 
 
+def pile_benchmark(ctx, with_cpu, steps=10):
+    """BASELINE config 4 on one GPU: 16^3 spheres, 46 080 contacts resident in HBM, 8 velocity + 3 positional
+    sweeps per step in the reference's exact order (dependency-level schedule)."""
+    from impact_amd import capi, scenes
+    from impact_amd.physics import PhysicsWorld
+
+    bodies, contacts = scenes.sphere_pile_scene(16)
+    w = PhysicsWorld(ctx)
+    w.set_bodies(bodies)
+    t0 = time.perf_counter()
+    w.prepare_constraints(contacts)
+    host_ms = 1e3 * (time.perf_counter() - t0)
+    for _ in range(2):
+        w.step(0.005)
+    acc = np.zeros(5)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        acc += w.step(0.005)["stage_ms"]
+    wall = (time.perf_counter() - t0) / steps
+    r = w.step(0.005)
+    sweeps = 1 + 8 + 3
+    out = {
+        "workload": "16^3 lattice of unit-density spheres r=0.5 at spacing 0.95: 4096 bodies, 46080 contacts, dt 0.005, 8+3 sweeps + warm start",
+        "ms_per_step": 1e3 * wall,
+        "contact_sweeps_per_s": len(contacts) * sweeps / wall,
+        "levels": [int(r["n_levels"][0]), int(r["n_levels"][1])],
+        "stage_ms": {k: round(float(v) / steps, 4) for k, v in zip(capi.PHYSICS_STAGE_NAMES, acc)},
+        "set_contacts_host_ms": round(host_ms, 3),
+    }
+    if with_cpu:
+        import oracle_lib as ol
+
+        o = ol.OraclePhysics(bodies, config=(8, 0.4, 3, 0.2))
+        o.step(contacts, 0.005)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            o.step(contacts, 0.005)
+        cpu = (time.perf_counter() - t0) / 5
+        out["cpu_baseline"] = {"value": len(contacts) * sweeps / cpu, "unit": "contact sweeps/s", "cores": 1, "kind": "port",
+                               "sample": f"same pile, 5 steps, {1e3 * cpu:.1f} ms/step, single thread"}
+    w.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +128,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scale", type=float, default=2.05, help="asteroid scale (2.05 -> 512^3 stored grid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pile", action="store_true", help="skip the separate rigid-body pile timing (config 4)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,6 +161,13 @@ def main():
             dist.init_process_group(backend)
 
     dens = np.ones(256, dtype=np.float32)
+    # the voxel object's own rigid body (setup_dynamic_rigid_body_for_voxel_object, impact_voxel/src/setup.rs:581-616):
+    # integrated every step; its contact list is empty in this workload
+    from impact_amd.physics import PhysicsWorld, uniform_sphere_body
+
+    body_world = PhysicsWorld(ctx)
+    body_world.set_bodies(np.array([uniform_sphere_body(100.0, 1.0, (0.0, 0.0, 0.0), (0.1, 0.0, 0.0))]))
+    body_world.prepare_constraints(np.zeros(0, dtype=capi.CONTACT_DTYPE))
     if world == 1:
         gen = SDFVoxelGenerator(1.0, scenes.asteroid_scene(args.scale), 0)
         cc = gen.chunk_counts()
@@ -120,7 +176,9 @@ def main():
         obj.set_densities(dens)
 
         def step():
-            return obj.step(capi.STAGE_ALL)
+            r = obj.step(capi.STAGE_ALL)
+            body_world.step(0.005)
+            return r
 
         workload = f"config-2 SDF asteroid x{args.scale} -> {gen.grid_shape()[0]}^3 grid = {cc[0] * 16}^3 stored voxels ({obj.n_chunks} chunks)"
         parallelism = "single GPU"
@@ -136,6 +194,7 @@ def main():
 
         def step():
             r = comm.run(stepper)
+            body_world.step(0.005)
             return {"stage_ms": r.stage_ms, "mesh": {"n_vertices": r.mesh_counts[0], "n_indices": r.mesh_counts[1]},
                     "region_count": r.region_count}
 
@@ -218,10 +277,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.scale)
         elif world == 1:
             out["cpu_baseline"] = None
+        if not args.no_pile:
+            out["pile"] = pile_benchmark(ctx, with_cpu=(world == 1 and not args.no_cpu_baseline))
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    body_world.close()
     obj.close()
     ctx.close()
 
