@@ -116,12 +116,12 @@ assert RIGID_BODY_DTYPE.itemsize == 152 and KINEMATIC_BODY_DTYPE.itemsize == 56 
 # every symbol include/impact_voxel_hip.h declares
 EXPORTED_SYMBOLS = [
     "ivx_init", "ivx_shutdown", "ivx_last_error", "ivx_synchronize", "ivx_stream",
-    "ivx_grid_create", "ivx_grid_destroy", "ivx_grid_upload_dense", "ivx_grid_download_dense", "ivx_grid_device_ptr",
+    "ivx_grid_create", "ivx_grid_destroy", "ivx_grid_upload_dense", "ivx_grid_download_dense", "ivx_grid_device_ptr", "ivx_grid_chunk_counts",
     "ivx_sdf_compile", "ivx_sdf_grid_shape", "ivx_sdf_sample",
     "ivx_derive_state", "ivx_occupied_ranges",
     "ivx_remesh", "ivx_mesh_download", "ivx_mesh_device_ptr",
     "ivx_inertia",
-    "ivx_label_regions", "ivx_region_labels_download", "ivx_regions_describe",
+    "ivx_label_regions", "ivx_region_labels_download", "ivx_regions_describe", "ivx_split_off_smallest_region",
     "ivx_grid_set_sdf_program", "ivx_grid_set_densities", "ivx_voxel_step",
     "ivx_halo_bytes", "ivx_halo_pack", "ivx_halo_unpack", "ivx_halo_clear",
     "ivx_region_face_bytes", "ivx_region_face_labels", "ivx_region_face_pairs",
@@ -175,6 +175,7 @@ def lib():
         "ivx_grid_upload_dense": (i32, [vp, vp, vp, sz]),
         "ivx_grid_download_dense": (i32, [vp, vp, vp, vp, vp, vp, sz]),
         "ivx_grid_device_ptr": (vp, [vp, i32]),
+        "ivx_grid_chunk_counts": (i32, [vp, vp]),
         "ivx_sdf_compile": (i32, [vp, sz, u32, vp, sz, C.POINTER(sz), vp, C.POINTER(u32)]),
         "ivx_sdf_grid_shape": (i32, [vp, vp, vp]),
         "ivx_sdf_sample": (i32, [vp, vp, sz, u32, vp, vp, C.c_uint8]),
@@ -187,6 +188,7 @@ def lib():
         "ivx_label_regions": (i32, [vp, C.POINTER(u32)]),
         "ivx_region_labels_download": (i32, [vp, vp, sz]),
         "ivx_regions_describe": (i32, [vp, vp, vp, sz, C.POINTER(sz)]),
+        "ivx_split_off_smallest_region": (i32, [vp, C.POINTER(vp), vp, C.POINTER(i32), vp]),
         "ivx_grid_set_sdf_program": (i32, [vp, vp, sz, u32, vp, vp, C.c_uint8]),
         "ivx_grid_set_densities": (i32, [vp, vp]),
         "ivx_voxel_step": (i32, [vp, u32, vp]),

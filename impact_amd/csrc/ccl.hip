@@ -199,6 +199,122 @@ __global__ __launch_bounds__(256) void k_ccl_local(GridView g, const uint8_t* __
     }
 }
 
+// ---- exact local numbering for chunks with several regions ----------------------------------------
+// The reference numbers the regions of a chunk in an order that depends on which voxel its sequential
+// union-find left as the root of each set (split_detection.rs:700-831: a boundary-touching set is labelled
+// when the face loops reach its ROOT voxel, or the first face voxel visited if the root is interior).
+// That root is a product of the scan order and has no parallel closed form, so for the (rare) chunks
+// that hold two or more regions one lane replays the reference's sequence in LDS: unions in (i,j,k)
+// order over the *_UP flags, the six face loops of Loop3::over_full_boundary (utils.rs:247-322), then
+// the interior sets. Chunks with a single region (label 0 everywhere) keep the parallel result. The
+// partition is the same either way; this pass makes the label VALUES equal to the reference's.
+__device__ __forceinline__ uint32_t seq_find(uint16_t* par, uint32_t x) {
+    uint32_t r = x;
+    while (par[r] != r) r = par[r];
+    while (par[x] != r) {  // full compression, as find_root_for_voxel_and_compress_path (split_detection.rs:1786-1802)
+        const uint32_t n = par[x];
+        par[x] = (uint16_t)r;
+        x = n;
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(64) void k_ccl_local_exact(GridView g, const uint8_t* __restrict__ flags, uint8_t* __restrict__ labels,
+                                                        ivx_chunk_info* __restrict__ info, uint32_t* __restrict__ rparent,
+                                                        uint32_t* __restrict__ rscalar) {
+    __shared__ uint16_t s_par[IVX_CHUNK_VOXELS];
+    __shared__ uint8_t s_flg[IVX_CHUNK_VOXELS];
+    __shared__ uint8_t s_lab[IVX_CHUNK_VOXELS];
+    __shared__ uint32_t s_counts[2];
+    const uint32_t chunk = blockIdx.x, tid = threadIdx.x;
+    if (info[chunk].region_count < 2) return;
+    const size_t base = (size_t)chunk * IVX_CHUNK_VOXELS;
+    for (uint32_t i = tid; i < 256u; i += 64u) reinterpret_cast<uint4*>(s_flg)[i] = reinterpret_cast<const uint4*>(flags + base)[i];
+    for (uint32_t i = tid; i < IVX_CHUNK_VOXELS; i += 64u) {
+        s_par[i] = (uint16_t)i;
+        s_lab[i] = 255;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (uint32_t idx = 0; idx < IVX_CHUNK_VOXELS; ++idx) {
+            const uint32_t f = s_flg[idx];
+            if (f & VF_EMPTY) continue;
+            const uint32_t i = idx >> 8, j = (idx >> 4) & 15u, k = idx & 15u;
+            const uint32_t root = seq_find(s_par, idx);
+            if (i < 15u && (f & VF_X_UP)) {
+                const uint32_t r = seq_find(s_par, idx + 256u);
+                if (r != root) s_par[r] = (uint16_t)root;
+            }
+            if (j < 15u && (f & VF_Y_UP)) {
+                const uint32_t r = seq_find(s_par, idx + 16u);
+                if (r != root) s_par[r] = (uint16_t)root;
+            }
+            if (k < 15u && (f & VF_Z_UP)) {
+                const uint32_t r = seq_find(s_par, idx + 1u);
+                if (r != root) s_par[r] = (uint16_t)root;
+            }
+        }
+        uint32_t current = 0;
+        auto visit = [&](uint32_t idx) {
+            if (s_flg[idx] & VF_EMPTY) return;
+            const uint32_t set_id = seq_find(s_par, idx);
+            const uint32_t si = set_id >> 8, sj = (set_id >> 4) & 15u, sk = set_id & 15u;
+            const bool root_interior = si > 0 && si < 15u && sj > 0 && sj < 15u && sk > 0 && sk < 15u;
+            if (set_id == idx) {
+                s_lab[idx] = (uint8_t)current;
+                current = min(current + 1u, 255u);
+            } else if (root_interior) {
+                s_par[set_id] = (uint16_t)idx;  // make_voxel_root (split_detection.rs:1877-1882)
+                s_par[idx] = (uint16_t)idx;
+                s_lab[idx] = (uint8_t)current;
+                current = min(current + 1u, 255u);
+            }
+        };
+        for (uint32_t side = 0; side < 2; ++side)  // X-, X+
+            for (uint32_t j = 0; j < 16; ++j)
+                for (uint32_t k = 0; k < 16; ++k) visit(((side ? 15u : 0u) << 8) | (j << 4) | k);
+        for (uint32_t side = 0; side < 2; ++side)  // Y-, Y+ (i interior)
+            for (uint32_t i = 1; i < 15; ++i)
+                for (uint32_t k = 0; k < 16; ++k) visit((i << 8) | ((side ? 15u : 0u) << 4) | k);
+        for (uint32_t side = 0; side < 2; ++side)  // Z-, Z+ (i, j interior)
+            for (uint32_t i = 1; i < 15; ++i)
+                for (uint32_t j = 1; j < 15; ++j) visit((i << 8) | (j << 4) | (side ? 15u : 0u));
+        const uint32_t nb = current;
+        for (uint32_t i = 1; i < 15; ++i)
+            for (uint32_t j = 1; j < 15; ++j)
+                for (uint32_t k = 1; k < 15; ++k) {
+                    const uint32_t idx = (i << 8) | (j << 4) | k;
+                    if (s_par[idx] == idx && !(s_flg[idx] & VF_EMPTY)) {
+                        s_lab[idx] = (uint8_t)current;
+                        current = min(current + 1u, 255u);
+                    }
+                }
+        s_counts[0] = nb;
+        s_counts[1] = current;
+    }
+    __syncthreads();
+    for (uint32_t idx = tid; idx < IVX_CHUNK_VOXELS; idx += 64u) {
+        uint32_t lab = 255;
+        if (!(s_flg[idx] & VF_EMPTY)) {
+            uint32_t r = idx;
+            while (s_par[r] != r) r = s_par[r];
+            lab = s_lab[r];
+        }
+        labels[base + idx] = (uint8_t)lab;
+    }
+    uint32_t total = s_counts[1];
+    if (total > 254u) {
+        if (tid == 0) atomicOr(&rscalar[1], 1u);
+        total = 254u;
+    }
+    uint32_t* rp = rparent + (size_t)chunk * 256;
+    for (uint32_t r = tid; r < 256u; r += 64u) rp[r] = r < total ? chunk * 256u + r : NODE_NONE;
+    if (tid == 0) {
+        info[chunk].region_count = (uint8_t)total;
+        info[chunk].boundary_region_count = (uint8_t)(s_counts[0] < 254u ? s_counts[0] : 254u);
+    }
+}
+
 // ---- level 2 ---------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t g_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t g_find(uint32_t* par, uint32_t x) {
@@ -483,8 +599,14 @@ __global__ __launch_bounds__(256) void k_region_stats(GridView g, uint32_t x_off
                 atomicMax(&out.hi[(size_t)comp * 3 + (q - 4)], max(max(s_u[0][q], s_u[1][q]), max(s_u[2][q], s_u[3][q])));
             }
             if (tid == 17) {
-                atomicAdd(&out.chunks[comp], 1u);
-                if (info.kind == KIND_NONUNIFORM) atomicAdd(&out.nu_chunks[comp], 1u);
+                // a chunk counts once per component even when several of its local regions belong to it
+                // (`found_region` in extraction.rs:163-205)
+                bool first = true;
+                for (uint32_t q = 0; q < r; ++q) first = first && rcompid[chunk * 256u + q] != comp;
+                if (first) {
+                    atomicAdd(&out.chunks[comp], 1u);
+                    if (info.kind == KIND_NONUNIFORM) atomicAdd(&out.nu_chunks[comp], 1u);
+                }
                 if (rparent[node] == node) out.root[comp] = node;
             }
         }
@@ -498,6 +620,7 @@ int ivx_launch_ccl_local(ivx_grid* g) {
     GridView v = ivx_view(g);
     IVX_HIP_CHECK(hipMemsetAsync(g->rscalar, 0, 16 * sizeof(uint32_t), g->ctx->stream));
     hipLaunchKernelGGL(k_ccl_local, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, v, g->flags, g->llabel, g->info, g->rparent, g->rscalar);
+    hipLaunchKernelGGL(k_ccl_local_exact, dim3(g->n_chunks), dim3(64), 0, g->ctx->stream, v, g->flags, g->llabel, g->info, g->rparent, g->rscalar);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

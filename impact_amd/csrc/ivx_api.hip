@@ -276,6 +276,12 @@ int ivx_grid_download_dense(ivx_grid* g, int8_t* sdf, uint8_t* type, uint8_t* fl
     return IVX_OK;
 }
 
+int ivx_grid_chunk_counts(ivx_grid* g, uint32_t out[3]) {
+    IVX_REQUIRE(g && out, IVX_ERR_INVALID, "ivx_grid_chunk_counts: null argument");
+    for (int d = 0; d < 3; ++d) out[d] = g->cc[d];
+    return IVX_OK;
+}
+
 void* ivx_grid_device_ptr(ivx_grid* g, int which) {
     if (!g) return nullptr;
     switch (which) {
@@ -433,18 +439,14 @@ int ivx_region_labels_download(ivx_grid* g, uint32_t* labels, size_t n_voxels) {
     return d2h(g, labels, g->dev_scratch, g->n_vox * sizeof(uint32_t));
 }
 
-int ivx_regions_describe(ivx_grid* g, const float densities[256], ivx_region_desc* out, size_t cap, size_t* n_out) {
-    IVX_REQUIRE(g && densities && out && n_out, IVX_ERR_INVALID, "ivx_regions_describe: null argument");
-    IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "ivx_regions_describe: call ivx_label_regions first");
+static int describe_regions_internal(ivx_grid* g, const float* d_dens, std::vector<ivx_region_desc>& out) {
     const uint32_t n = g->region_count;
-    *n_out = n;
-    IVX_REQUIRE(n <= cap, IVX_ERR_CAPACITY, "ivx_regions_describe: %u regions exceed capacity %zu", n, cap);
+    out.assign(n, ivx_region_desc{});
     if (n == 0) return IVX_OK;
     const size_t bytes = ivx_region_stats_bytes(n);
     int rc;
     if ((rc = ensure_dev_scratch(g, bytes))) return rc;
-    if ((rc = h2d(g, g->dens_dev, densities, 256 * sizeof(float)))) return rc;
-    if ((rc = ivx_launch_region_stats(g, g->dens_dev, g->dev_scratch, n))) return rc;
+    if ((rc = ivx_launch_region_stats(g, d_dens, g->dev_scratch, n))) return rc;
     std::vector<char> h(bytes);
     if ((rc = d2h(g, h.data(), g->dev_scratch, bytes))) return rc;
     const char* p = h.data();
@@ -478,6 +480,109 @@ int ivx_regions_describe(ivx_grid* g, const float densities[256], ivx_region_des
             o.moments[q] = mom[10 * (size_t)r + q] * f;
         }
     }
+    return IVX_OK;
+}
+
+int ivx_regions_describe(ivx_grid* g, const float densities[256], ivx_region_desc* out, size_t cap, size_t* n_out) {
+    IVX_REQUIRE(g && densities && out && n_out, IVX_ERR_INVALID, "ivx_regions_describe: null argument");
+    IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "ivx_regions_describe: call ivx_label_regions first");
+    const uint32_t n = g->region_count;
+    *n_out = n;
+    IVX_REQUIRE(n <= cap, IVX_ERR_CAPACITY, "ivx_regions_describe: %u regions exceed capacity %zu", n, cap);
+    int rc;
+    if ((rc = h2d(g, g->dens_dev, densities, 256 * sizeof(float)))) return rc;
+    g->has_dens = 1;
+    std::vector<ivx_region_desc> d;
+    if ((rc = describe_regions_internal(g, g->dens_dev, d))) return rc;
+    for (uint32_t r = 0; r < n; ++r) out[r] = d[r];
+    return IVX_OK;
+}
+
+static int rederive(ivx_grid* g) {
+    int rc;
+    if ((rc = ivx_launch_derive(g))) return rc;
+    if ((rc = ivx_launch_ccl_local(g))) return rc;
+    if ((rc = ivx_launch_ccl_merge(g))) return rc;
+    if ((rc = ivx_launch_ccl_resolve(g))) return rc;
+    uint32_t sc[2];
+    if ((rc = d2h(g, sc, g->rscalar, sizeof(sc)))) return rc;
+    IVX_REQUIRE((sc[1] & 1u) == 0, IVX_ERR_CAPACITY, "a chunk has more than 254 local regions");
+    g->region_count = sc[0];
+    g->regions_valid = 1;
+    g->mesh_valid = 0;
+    return IVX_OK;
+}
+
+int ivx_split_off_smallest_region(ivx_grid* parent, ivx_grid** child, uint32_t origin_offset_in_parent[3], int* outcome, ivx_region_desc* moved) {
+    IVX_REQUIRE(parent && child && origin_offset_in_parent && outcome, IVX_ERR_INVALID, "ivx_split_off_smallest_region: null argument");
+    *child = nullptr;
+    *outcome = 0;
+    IVX_REQUIRE(parent->regions_valid, IVX_ERR_STATE, "ivx_split_off_smallest_region: call ivx_label_regions first");
+    IVX_REQUIRE(parent->x_off == 0 && parent->gx == parent->cc[0] && !parent->has_ghost[0] && !parent->has_ghost[1], IVX_ERR_STATE,
+                "ivx_split_off_smallest_region: not available on a slab of a decomposed grid");
+    if (parent->region_count < 2) return IVX_OK;
+    int rc;
+    if (!parent->has_dens) {
+        float ones[256];
+        for (float& x : ones) x = 1.0f;
+        if ((rc = h2d(parent, parent->dens_dev, ones, sizeof(ones)))) return rc;
+        parent->has_dens = 1;
+    }
+    std::vector<ivx_region_desc> d;
+    if ((rc = describe_regions_internal(parent, parent->dens_dev, d))) return rc;
+    // the first two regions in scan order; the one with fewer non-uniform chunks goes, ties by chunk count,
+    // then the second (extraction.rs:255-271)
+    uint32_t pick;
+    if (d[0].non_uniform_chunk_count != d[1].non_uniform_chunk_count) pick = d[0].non_uniform_chunk_count < d[1].non_uniform_chunk_count ? 0u : 1u;
+    else pick = d[0].chunk_count < d[1].chunk_count ? 0u : 1u;
+    const ivx_region_desc& r = d[pick];
+    if (moved) *moved = r;
+    uint32_t lo[3], cc[3];
+    for (int q = 0; q < 3; ++q) {
+        lo[q] = r.lo[q] >> 4;
+        cc[q] = ((r.hi[q] - 1u) >> 4) - lo[q] + 1u;
+    }
+    const uint32_t uniform_count = r.chunk_count - r.non_uniform_chunk_count;
+    const bool discard = uniform_count == 0 && r.voxel_count < 8;  // NON_EMPTY_VOXEL_THRESHOLD (object.rs:203)
+    ivx_grid* c = nullptr;
+    if (!discard && (rc = ivx_grid_create(parent->ctx, cc, parent->extent, 0, 0, &c))) return rc;
+    if ((rc = ivx_launch_split_move(parent, c, lo, cc, pick))) {
+        ivx_grid_destroy(c);
+        return rc;
+    }
+    for (int q = 0; q < 3; ++q) origin_offset_in_parent[q] = lo[q] * 16u;
+    if (c && cc[0] <= 2 && cc[1] <= 2 && cc[2] <= 2 && uniform_count == 0 && cc[0] * cc[1] * cc[2] > 1 && r.hi[0] - r.lo[0] <= 14 &&
+        r.hi[1] - r.lo[1] <= 14 && r.hi[2] - r.lo[2] <= 14) {
+        uint32_t off[3];
+        for (int q = 0; q < 3; ++q) {
+            const uint32_t rel = r.lo[q] - lo[q] * 16u;
+            off[q] = rel > 0 ? rel - 1u : 0u;
+        }
+        const uint32_t one[3] = {1, 1, 1};
+        ivx_grid* single = nullptr;
+        if ((rc = ivx_grid_create(parent->ctx, one, parent->extent, 0, 0, &single))) {
+            ivx_grid_destroy(c);
+            return rc;
+        }
+        if ((rc = ivx_launch_split_repack(c, single, off))) {
+            ivx_grid_destroy(c);
+            ivx_grid_destroy(single);
+            return rc;
+        }
+        ivx_grid_destroy(c);
+        c = single;
+        for (int q = 0; q < 3; ++q) origin_offset_in_parent[q] += off[q];
+    }
+    if ((rc = rederive(parent))) {
+        ivx_grid_destroy(c);
+        return rc;
+    }
+    if (c && (rc = rederive(c))) {
+        ivx_grid_destroy(c);
+        return rc;
+    }
+    *child = c;
+    *outcome = c ? 1 : 2;
     return IVX_OK;
 }
 

@@ -242,6 +242,9 @@ class VoxelObject:
             self.label_regions()
         return self._region_count
 
+    def is_effectively_empty(self) -> bool:
+        return self.count_regions() == 0
+
     def region_labels(self) -> np.ndarray:
         out = np.empty(self.n_voxels, dtype=np.uint32)
         check(capi.lib().ivx_region_labels_download(self.h, ptr(out), out.size))
@@ -262,6 +265,34 @@ class VoxelObject:
             return None
         r = self.describe_regions()
         return [(int(r[i]["root_chunk"]), int(r[i]["root_region"])) for i in range(2)]
+
+    def extract_any_disconnected_region(self):
+        """`VoxelObject::extract_any_disconnected_region` (object/extraction.rs:78-119). Returns
+        (outcome, child VoxelObject or None, origin_offset_in_parent, descriptor of the removed region):
+        outcome 0 = nothing to split, 1 = extracted, 2 = removed but too small to become an object."""
+        child = C.c_void_p()
+        origin = np.zeros(3, dtype=np.uint32)
+        outcome = C.c_int(0)
+        moved = np.zeros(1, dtype=capi.REGION_DESC_DTYPE)
+        check(capi.lib().ivx_split_off_smallest_region(self.h, C.byref(child), ptr(origin), C.byref(outcome), ptr(moved)))
+        self._region_count = None if outcome.value else self._region_count
+        obj = None
+        if outcome.value == 1:
+            obj = VoxelObject.__new__(VoxelObject)
+            obj.ctx = self.ctx
+            obj.h = child
+            obj.voxel_extent = self.voxel_extent
+            obj.x_chunk_offset = 0
+            ccs = np.zeros(3, dtype=np.uint32)
+            check(capi.lib().ivx_grid_chunk_counts(child, ptr(ccs)))
+            cc = tuple(int(x) for x in ccs)
+            obj.chunk_counts = cc
+            obj.n_chunks = int(np.prod(cc))
+            obj.n_voxels = obj.n_chunks * CHUNK_VOXEL_COUNT
+            obj.occupied_chunk_ranges = obj.occupied_voxel_ranges = None
+            obj._region_count = None
+            _live_grids.add(obj)
+        return int(outcome.value), obj, tuple(int(x) for x in origin), moved[0]
 
     # ---- halos -----------------------------------------------------------------------------------
     def halo_bytes(self) -> int:

@@ -120,6 +120,7 @@ int ivx_grid_upload_dense(ivx_grid*, const int8_t* sdf, const uint8_t* type, siz
 /* device -> host; any pointer may be NULL */
 int ivx_grid_download_dense(ivx_grid*, int8_t* sdf, uint8_t* type, uint8_t* flags, uint8_t* local_labels, ivx_chunk_info* info,
                             size_t n_voxels);
+int ivx_grid_chunk_counts(ivx_grid*, uint32_t out[3]);
 /* device pointers of the planes: 0 sdf, 1 type, 2 flags, 3 local labels, 4 chunk info, 5 global region parents */
 void* ivx_grid_device_ptr(ivx_grid*, int which);
 
@@ -166,6 +167,17 @@ int ivx_label_regions(ivx_grid*, uint32_t* region_count);
 int ivx_region_labels_download(ivx_grid*, uint32_t* labels, size_t n_voxels);
 /* per-region descriptors in id order (find_two_disconnected_regions = the first two) */
 int ivx_regions_describe(ivx_grid*, const float densities[256], ivx_region_desc* out, size_t cap, size_t* n_out);
+
+/* VoxelObject::extract_any_disconnected_region (object/extraction.rs:78-596, 1901-2123): if the object consists of
+ * several regions, the smaller of the first two (fewest non-uniform chunks, ties by chunk count, then the second)
+ * is moved into a NEW grid whose chunk grid is the region's chunk box (repacked into a single chunk when it is
+ * at most 2x2x2 chunks and at most 14 voxels wide); the parent loses those voxels. Both grids come back with
+ * derived state and regions recomputed. outcome: 0 = one region, nothing done; 1 = *child is the new object
+ * (caller destroys it), origin_offset_in_parent in voxels; 2 = the region had fewer than 8 voxels and was removed
+ * without creating an object. `moved` (optional) receives the descriptor of the removed region — voxel count, box and
+ * the mass moments the reference's PropertyTransferrer would have carried over (object/inertia.rs:341-560), for the
+ * densities last set with ivx_grid_set_densities / ivx_regions_describe (1.0 if never set). */
+int ivx_split_off_smallest_region(ivx_grid* parent, ivx_grid** child, uint32_t origin_offset_in_parent[3], int* outcome, ivx_region_desc* moved);
 
 /* ---- whole voxel step (resident inputs, minimal host synchronisation) ---------------------------- */
 /* The per-frame chain the engine runs for a voxel object — generate (engine/src/setup/scene/voxel.rs:33 ->

@@ -148,6 +148,9 @@ void orc_physics_solve(orc_physics*);
 void orc_physics_advance_configurations(orc_physics*, float dt);
 int orc_physics_step(orc_physics*, const orc_contact*, int n, float dt);
 
+/* split the smaller of the first two disconnected regions off (object/extraction.rs:78-596, 1901-2123) */
+int orc_split_off_smallest_region(orc_object* parent, orc_object** child, int origin_offset_in_parent[3]);
+
 /* quantisation helpers (lib.rs:197-222) */
 int8_t orc_sd_from_f32(float v);
 float orc_sd_to_f32(int8_t e);

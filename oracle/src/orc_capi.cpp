@@ -12,6 +12,7 @@ void inertia_moments_f32(const VoxelObject& obj, const float* dens, float out32[
 void inertia_moments_f64(const VoxelObject& obj, const float* dens, double out[10]);
 void derive_inertial_properties(const float m[10], float out[22]);
 uint32_t canonical_region_labels(const VoxelObject& obj, uint32_t* labels);
+int split_off_smallest_region(VoxelObject& parent, VoxelObject& child, int origin[3]);
 
 // OffsetBoxVoxelGenerator (object.rs:3387-3504)
 struct BoxGenerator : Generator {
@@ -323,6 +324,21 @@ void orc_inertia(const orc_object* o, const float densities[256], float out32[10
 void orc_derive_inertial_properties(const float moments[10], float out[22]) { derive_inertial_properties(moments, out); }
 
 uint32_t orc_region_labels(const orc_object* o, uint32_t* labels) { return canonical_region_labels(o->obj, labels); }
+
+// extract_any_disconnected_region (object/extraction.rs:78-119): returns the outcome (0 none, 1 extracted, 2 removed
+// but discarded); *child is a new object (free with orc_object_free) when the outcome is 1
+int orc_split_off_smallest_region(orc_object* parent, orc_object** child, int origin_offset_in_parent[3]) {
+    orc_object* c = new orc_object();
+    int rc = split_off_smallest_region(parent->obj, c->obj, origin_offset_in_parent);
+    if (rc == 1) {
+        for (int d = 0; d < 3; ++d) c->shape[d] = c->obj.cc[d] * CHUNK;
+        *child = c;
+    } else {
+        delete c;
+        *child = nullptr;
+    }
+    return rc;
+}
 
 int8_t orc_sd_from_f32(float v) { return sd_from_f32(v); }
 float orc_sd_to_f32(int8_t e) { return sd_to_f32(e); }

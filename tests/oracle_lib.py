@@ -82,6 +82,8 @@ def lib():
         L.orc_sd_from_f32.argtypes = [C.c_float]
         L.orc_sd_to_f32.restype = C.c_float
         L.orc_sd_to_f32.argtypes = [C.c_int8]
+        L.orc_split_off_smallest_region.restype = C.c_int
+        L.orc_split_off_smallest_region.argtypes = [vp, C.POINTER(vp), vp]
         L.orc_physics_create.restype = vp
         L.orc_physics_free.argtypes = [vp]
         L.orc_physics_set_config.argtypes = [vp, vp]
@@ -256,6 +258,13 @@ class OracleObject:
         if not lib().orc_chunk_sdf(self.h, ci, cj, ck, _p(val), _p(typ)):
             return None
         return val, typ
+
+    def split_off_smallest_region(self):
+        """-> (outcome, child OracleObject or None, origin offset in parent voxels)"""
+        child = C.c_void_p()
+        origin = np.zeros(3, dtype=np.int32)
+        rc = lib().orc_split_off_smallest_region(self.h, C.byref(child), _p(origin))
+        return rc, (OracleObject(child.value) if rc == 1 else None), tuple(int(x) for x in origin)
 
     def inertia(self, densities=None):
         d = np.ones(256, dtype=np.float32) if densities is None else np.ascontiguousarray(densities, dtype=np.float32)
