@@ -121,7 +121,7 @@ EXPORTED_SYMBOLS = [
     "ivx_derive_state", "ivx_occupied_ranges",
     "ivx_remesh", "ivx_mesh_download", "ivx_mesh_device_ptr",
     "ivx_inertia",
-    "ivx_label_regions", "ivx_region_labels_download", "ivx_regions_describe", "ivx_split_off_smallest_region",
+    "ivx_label_regions", "ivx_region_labels_download", "ivx_regions_describe", "ivx_split_off_smallest_region", "ivx_clip_polyhedron",
     "ivx_grid_set_sdf_program", "ivx_grid_set_densities", "ivx_voxel_step",
     "ivx_halo_bytes", "ivx_halo_pack", "ivx_halo_unpack", "ivx_halo_clear",
     "ivx_region_face_bytes", "ivx_region_face_labels", "ivx_region_face_pairs",
@@ -189,6 +189,7 @@ def lib():
         "ivx_region_labels_download": (i32, [vp, vp, sz]),
         "ivx_regions_describe": (i32, [vp, vp, vp, sz, C.POINTER(sz)]),
         "ivx_split_off_smallest_region": (i32, [vp, C.POINTER(vp), vp, C.POINTER(i32), vp]),
+        "ivx_clip_polyhedron": (i32, [vp, vp, sz, vp, i32, C.POINTER(vp), vp, C.POINTER(i32)]),
         "ivx_grid_set_sdf_program": (i32, [vp, vp, sz, u32, vp, vp, C.c_uint8]),
         "ivx_grid_set_densities": (i32, [vp, vp]),
         "ivx_voxel_step": (i32, [vp, u32, vp]),

@@ -586,6 +586,100 @@ int ivx_split_off_smallest_region(ivx_grid* parent, ivx_grid** child, uint32_t o
     return IVX_OK;
 }
 
+// complete_extracted_voxel_object (extraction.rs:1901-2123) for a freshly filled child grid: discard rule, single-chunk
+// repack, derived state. On return *pc is the final child (or nullptr when discarded).
+static int complete_extracted(ivx_grid* parent, ivx_grid** pc, uint32_t origin[3]) {
+    ivx_grid* c = *pc;
+    int rc;
+    std::vector<ivx_chunk_info> info(c->n_chunks);
+    if ((rc = d2h(c, info.data(), c->info, sizeof(ivx_chunk_info) * c->n_chunks))) return rc;
+    uint32_t uniform_count = 0;
+    for (const ivx_chunk_info& i : info) uniform_count += i.gen_kind == KIND_UNIFORM;
+    // non-empty voxel count and tight voxel box of the child: derive (flags + per-chunk boxes), unit-density mass
+    if ((rc = ivx_launch_derive(c))) return rc;
+    uint32_t* d_occ = c->rscalar + 16;
+    if ((rc = ivx_launch_occupied(c, d_occ))) return rc;
+    uint32_t occ[12];
+    if ((rc = d2h(c, occ, d_occ, sizeof(occ)))) return rc;
+    float ones[256];
+    for (float& x : ones) x = 1.0f;
+    if ((rc = h2d(c, c->dens_dev, ones, sizeof(ones)))) return rc;
+    double* out_dev = c->partials + c->partial_blocks * 10;
+    if ((rc = ivx_launch_inertia(c, c->dens_dev, out_dev))) return rc;
+    double m0 = 0.0;
+    if ((rc = d2h(c, &m0, out_dev, sizeof(double)))) return rc;
+    const double e = (double)c->extent;
+    const unsigned long long non_empty = (unsigned long long)(m0 / (e * e * e) + 0.5);
+    if (uniform_count == 0 && non_empty < 8) {  // NON_EMPTY_VOXEL_THRESHOLD (object.rs:203)
+        ivx_grid_destroy(c);
+        *pc = nullptr;
+        return IVX_OK;
+    }
+    if (c->cc[0] <= 2 && c->cc[1] <= 2 && c->cc[2] <= 2 && uniform_count == 0 && c->n_chunks > 1 && occ[1] != 0 && occ[7] - occ[6] <= 14 &&
+        occ[9] - occ[8] <= 14 && occ[11] - occ[10] <= 14) {
+        uint32_t off[3];
+        for (int q = 0; q < 3; ++q) off[q] = occ[6 + 2 * q] > 0 ? occ[6 + 2 * q] - 1u : 0u;
+        const uint32_t one[3] = {1, 1, 1};
+        ivx_grid* single = nullptr;
+        if ((rc = ivx_grid_create(parent->ctx, one, parent->extent, 0, 0, &single))) return rc;
+        if ((rc = ivx_launch_split_repack(c, single, off))) {
+            ivx_grid_destroy(single);
+            return rc;
+        }
+        ivx_grid_destroy(c);
+        c = single;
+        *pc = c;
+        for (int q = 0; q < 3; ++q) origin[q] += off[q];
+    }
+    return rederive(c);
+}
+
+int ivx_clip_polyhedron(ivx_grid* parent, const float* planes4, size_t n_planes, const float aabb[6], int copy, ivx_grid** child,
+                        uint32_t origin_offset_in_parent[3], int* outcome) {
+    IVX_REQUIRE(parent && planes4 && aabb && child && origin_offset_in_parent && outcome, IVX_ERR_INVALID, "ivx_clip_polyhedron: null argument");
+    *child = nullptr;
+    *outcome = 0;
+    IVX_REQUIRE(n_planes >= 1 && n_planes <= 64, IVX_ERR_CAPACITY, "ivx_clip_polyhedron: 1..64 planes supported, got %zu", n_planes);
+    IVX_REQUIRE(parent->regions_valid, IVX_ERR_STATE, "ivx_clip_polyhedron: the object needs its derived state (ivx_derive_state + ivx_label_regions)");
+    IVX_REQUIRE(parent->x_off == 0 && parent->gx == parent->cc[0] && !parent->has_ghost[0] && !parent->has_ghost[1], IVX_ERR_STATE,
+                "ivx_clip_polyhedron: not available on a slab of a decomposed grid");
+    int rc;
+    // voxel_ranges_in_object_touching_aab (object/intersection.rs:693-782) of the AABB expanded by 2.54
+    uint32_t* d_occ = parent->rscalar + 16;
+    if ((rc = ivx_launch_occupied(parent, d_occ))) return rc;
+    uint32_t occ[12];
+    if ((rc = d2h(parent, occ, d_occ, sizeof(occ)))) return rc;
+    if (occ[1] == 0) return IVX_OK;
+    uint32_t lo[3], cc[3];
+    for (int q = 0; q < 3; ++q) {
+        const float l = aabb[q] - 2.54f, h = aabb[3 + q] + 2.54f;
+        const float fl = floorf(l);
+        const long s = (long)(fl > 0.0f ? fl : 0.0f), e = (long)ceilf(h);
+        const long vlo = std::max<long>((long)occ[6 + 2 * q], s), vhi = std::min<long>((long)occ[7 + 2 * q], std::max<long>(e, 0));
+        if (vlo >= vhi) return IVX_OK;
+        lo[q] = (uint32_t)(vlo / 16);
+        cc[q] = (uint32_t)((vhi + 15) / 16) - lo[q];
+    }
+    ivx_grid* c = nullptr;
+    if ((rc = ivx_grid_create(parent->ctx, cc, parent->extent, 0, 0, &c))) return rc;
+    if ((rc = ivx_launch_clip(parent, c, lo, cc, planes4, (uint32_t)n_planes, copy ? 0 : 1))) {
+        ivx_grid_destroy(c);
+        return rc;
+    }
+    for (int q = 0; q < 3; ++q) origin_offset_in_parent[q] = lo[q] * 16u;
+    if (!copy && (rc = rederive(parent))) {
+        ivx_grid_destroy(c);
+        return rc;
+    }
+    if ((rc = complete_extracted(parent, &c, origin_offset_in_parent))) {
+        if (c) ivx_grid_destroy(c);
+        return rc;
+    }
+    *child = c;
+    *outcome = c ? 1 : 2;
+    return IVX_OK;
+}
+
 size_t ivx_region_face_bytes(ivx_grid* g) { return g ? (size_t)g->cc[1] * g->cc[2] * 256 * sizeof(uint32_t) : 0; }
 
 int ivx_region_face_labels(ivx_grid* g, int side, void* device_buf) {

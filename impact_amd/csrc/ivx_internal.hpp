@@ -171,6 +171,7 @@ int ivx_launch_halo_pack(ivx_grid* g, int side, void* buf);
 int ivx_launch_face_ids(ivx_grid* g, int side, uint32_t* d_out);
 int ivx_launch_face_pairs(ivx_grid* g, int side, const uint32_t* d_nbr, uint32_t* d_count, void* d_pairs, uint32_t cap);
 int ivx_launch_split_move(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], const uint32_t cc[3], uint32_t target);
+int ivx_launch_clip(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], const uint32_t cc[3], const float* planes4, uint32_t n_planes, int extract);
 int ivx_launch_split_repack(ivx_grid* src, ivx_grid* dst, const uint32_t off[3]);
 int ivx_launch_region_stats(ivx_grid* g, const float* d_dens, void* d_buf, uint32_t n);
 static inline size_t ivx_region_stats_bytes(uint32_t n) { return (size_t)n * (8 + 80 + 12 + 12 + 4 + 4 + 4); }

@@ -153,6 +153,160 @@ __global__ __launch_bounds__(256) void k_split_repack(uint32_t scx, uint32_t scy
     }
 }
 
+// ---- a12: polyhedron clip -------------------------------------------------------------------------
+// extract_polyhedron_with_property_transferrer (extraction.rs:639-1270) / copy_polyhedron_with_property_computer
+// (1301-1768). Per chunk of the box: Void in the parent or wholly beyond an outer plane (shifted out by 2.54) ->
+// Void; wholly inside every inner plane (shifted in by 2.56) -> moved / copied unchanged; otherwise per voxel
+//   d          = quantise(max over the intersecting planes of n.(centre) - displacement)   (row form, 1771-1804)
+//   polyhedron = max(sdf, d)            parent (extract only) = max(sdf, complement(d))
+// with chunks that end up with no non-empty voxel and only "void" distances (> 100) dropped to Void.
+#define IVX_MAX_CLIP_PLANES 64
+struct ClipParams {
+    GridView p;
+    uint32_t lo[3], cc[3];
+    uint32_t n_planes;
+    int extract;
+    float planes[IVX_MAX_CLIP_PLANES][4];
+};
+
+__device__ __forceinline__ float plane_sd(const float* pl, float x, float y, float z) { return ((pl[0] * x + pl[1] * y) + pl[2] * z) - pl[3]; }
+__device__ __forceinline__ int sd_clamped(float v) {  // VoxelSignedDistance::from_f32_array (lib.rs:207-216)
+    float s = v * 50.0f;
+    s = s < -128.0f ? -128.0f : (s > 127.0f ? 127.0f : s);
+    return (int)s;
+}
+__device__ __forceinline__ int sd_complement(int e) {  // lib.rs:266-268
+    const int a = e == 127 ? 127 : e + 1;
+    return a == -128 ? 127 : -a;
+}
+
+__global__ __launch_bounds__(256) void k_clip(ClipParams cp, int8_t* __restrict__ p_sdf, uint8_t* __restrict__ p_type, ivx_chunk_info* __restrict__ p_info,
+                                              int8_t* __restrict__ c_sdf, uint8_t* __restrict__ c_type, ivx_chunk_info* __restrict__ c_info) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t cchunk = blockIdx.x;
+    const uint32_t ck = cchunk % cp.cc[2], cj = (cchunk / cp.cc[2]) % cp.cc[1], ci = cchunk / (cp.cc[2] * cp.cc[1]);
+    const uint32_t I = ci + cp.lo[0], J = cj + cp.lo[1], K = ck + cp.lo[2];
+    const uint32_t pchunk = (I * cp.p.cy + J) * cp.p.cz + K;
+    const ivx_chunk_info pinfo = p_info[pchunk];
+    const size_t pb = (size_t)pchunk * IVX_CHUNK_VOXELS + (size_t)tid * 16, cb = (size_t)cchunk * IVX_CHUNK_VOXELS + (size_t)tid * 16;
+    const uint4 void_sd = make_uint4(0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu);
+    const uint4 void_ty = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    ivx_chunk_info vinfo;
+    vinfo.kind = vinfo.gen_kind = KIND_VOID;
+    vinfo.flags = 0;
+    vinfo.uniform_type = 0;
+    vinfo.face_dist = 0;
+    vinfo.region_count = vinfo.boundary_region_count = 0;
+    // chunk vs planes: identical in every thread (uniform control flow)
+    const float blo[3] = {(float)(I * 16u), (float)(J * 16u), (float)(K * 16u)};
+    const float bhi[3] = {(float)((I + 1u) * 16u), (float)((J + 1u) * 16u), (float)((K + 1u) * 16u)};
+    bool outside = pinfo.kind == KIND_VOID;
+    unsigned long long isect = 0ull;
+    if (!outside) {
+        for (uint32_t q = 0; q < cp.n_planes; ++q) {
+            const float* pl = cp.planes[q];
+            float mn[3], mx[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const bool neg = (__float_as_uint(pl[d]) >> 31) != 0;
+                mn[d] = neg ? bhi[d] : blo[d];
+                mx[d] = neg ? blo[d] : bhi[d];
+            }
+            const float outer[4] = {pl[0], pl[1], pl[2], pl[3] + 2.54f}, inner[4] = {pl[0], pl[1], pl[2], pl[3] - 2.56f};
+            if (plane_sd(outer, mn[0], mn[1], mn[2]) > 0.0f) outside = true;
+            if (!(plane_sd(inner, mx[0], mx[1], mx[2]) < 0.0f)) isect |= 1ull << q;
+        }
+    }
+    if (outside) {
+        *reinterpret_cast<uint4*>(c_sdf + cb) = void_sd;
+        *reinterpret_cast<uint4*>(c_type + cb) = void_ty;
+        if (tid == 0) c_info[cchunk] = vinfo;
+        return;
+    }
+    const uint4 s4 = *reinterpret_cast<const uint4*>(p_sdf + pb);
+    const uint4 t4 = *reinterpret_cast<const uint4*>(p_type + pb);
+    if (isect == 0ull) {  // wholly inside
+        *reinterpret_cast<uint4*>(c_sdf + cb) = s4;
+        *reinterpret_cast<uint4*>(c_type + cb) = t4;
+        if (cp.extract) {
+            *reinterpret_cast<uint4*>(p_sdf + pb) = void_sd;
+            *reinterpret_cast<uint4*>(p_type + pb) = void_ty;
+        }
+        if (tid == 0) {
+            ivx_chunk_info ci_ = vinfo;
+            ci_.kind = ci_.gen_kind = pinfo.kind;
+            ci_.uniform_type = pinfo.uniform_type;
+            ci_.flags = pinfo.flags & CF_ONLY_EMPTY;
+            c_info[cchunk] = ci_;
+            if (cp.extract) p_info[pchunk] = vinfo;
+        }
+        return;
+    }
+    const uint32_t ti = tid >> 4, tj = tid & 15u;
+    const float rx = (blo[0] + 0.5f) + (float)ti, ry = (blo[1] + 0.5f) + (float)tj, rz = (blo[2] + 0.5f) + 0.0f;
+    float md[16];
+    bool first = true;
+    for (uint32_t q = 0; q < cp.n_planes; ++q) {
+        if (!((isect >> q) & 1ull)) continue;
+        const float* pl = cp.planes[q];
+        const float base = plane_sd(pl, rx, ry, rz), step = pl[2];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float v = base + step * (float)k;
+            md[k] = first ? v : fmaxf(md[k], v);
+        }
+        first = false;
+    }
+    uint32_t sw[4] = {s4.x, s4.y, s4.z, s4.w}, cw[4] = {0, 0, 0, 0}, pw[4] = {0, 0, 0, 0};
+    bool poly_nonempty = false, poly_nonvoid = false, par_nonempty = false, par_nonvoid = false;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int orig = (int)(int8_t)((sw[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+        const int d = sd_clamped(md[k]);
+        const int ps = orig > d ? orig : d;
+        const int comp = sd_complement(d);
+        const int qs = orig > comp ? orig : comp;
+        poly_nonempty |= ps < 0;
+        poly_nonvoid |= ps <= SD_VOID_LIMIT;
+        par_nonempty |= qs < 0;
+        par_nonvoid |= qs <= SD_VOID_LIMIT;
+        cw[k >> 2] |= (uint32_t)(ps & 0xFF) << (8 * (k & 3));
+        pw[k >> 2] |= (uint32_t)(qs & 0xFF) << (8 * (k & 3));
+    }
+    const int poly_ne = __syncthreads_or(poly_nonempty), poly_nv = __syncthreads_or(poly_nonvoid);
+    const int par_ne = __syncthreads_or(par_nonempty), par_nv = __syncthreads_or(par_nonvoid);
+    if (!poly_ne && !poly_nv) {
+        *reinterpret_cast<uint4*>(c_sdf + cb) = void_sd;
+        *reinterpret_cast<uint4*>(c_type + cb) = void_ty;
+        if (tid == 0) c_info[cchunk] = vinfo;
+    } else {
+        *reinterpret_cast<uint4*>(c_sdf + cb) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+        *reinterpret_cast<uint4*>(c_type + cb) = t4;
+        if (tid == 0) {
+            ivx_chunk_info ci_ = vinfo;
+            ci_.kind = ci_.gen_kind = KIND_NONUNIFORM;
+            ci_.flags = poly_ne ? 0 : CF_ONLY_EMPTY;
+            c_info[cchunk] = ci_;
+        }
+    }
+    if (cp.extract) {
+        if (!par_ne && !par_nv) {
+            *reinterpret_cast<uint4*>(p_sdf + pb) = void_sd;
+            *reinterpret_cast<uint4*>(p_type + pb) = void_ty;
+            if (tid == 0) p_info[pchunk] = vinfo;
+        } else {
+            *reinterpret_cast<uint4*>(p_sdf + pb) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+            if (tid == 0) {
+                ivx_chunk_info pi_ = pinfo;
+                pi_.kind = pi_.gen_kind = KIND_NONUNIFORM;  // convert_to_non_uniform_if_uniform (object.rs:2530-2550)
+                pi_.flags = par_ne ? 0 : CF_ONLY_EMPTY;
+                pi_.uniform_type = 0;
+                p_info[pchunk] = pi_;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int ivx_launch_split_move(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], const uint32_t cc[3], uint32_t target) {
@@ -173,6 +327,23 @@ int ivx_launch_split_move(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3
 int ivx_launch_split_repack(ivx_grid* src, ivx_grid* dst, const uint32_t off[3]) {
     hipLaunchKernelGGL(k_split_repack, dim3(1), dim3(256), 0, src->ctx->stream, src->cc[0], src->cc[1], src->cc[2], off[0], off[1], off[2], src->sdf,
                        src->type, dst->sdf, dst->type, dst->info);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+int ivx_launch_clip(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], const uint32_t cc[3], const float* planes4, uint32_t n_planes, int extract) {
+    ClipParams cp;
+    cp.p = ivx_view(parent);
+    for (int d = 0; d < 3; ++d) {
+        cp.lo[d] = lo[d];
+        cp.cc[d] = cc[d];
+    }
+    cp.n_planes = n_planes;
+    cp.extract = extract;
+    memset(cp.planes, 0, sizeof(cp.planes));
+    memcpy(cp.planes, planes4, sizeof(float) * 4 * n_planes);
+    hipLaunchKernelGGL(k_clip, dim3(cc[0] * cc[1] * cc[2]), dim3(256), 0, parent->ctx->stream, cp, parent->sdf, parent->type, parent->info, child->sdf,
+                       child->type, child->info);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

@@ -266,6 +266,42 @@ class VoxelObject:
         r = self.describe_regions()
         return [(int(r[i]["root_chunk"]), int(r[i]["root_region"])) for i in range(2)]
 
+    def _wrap_child(self, handle):
+        obj = VoxelObject.__new__(VoxelObject)
+        obj.ctx = self.ctx
+        obj.h = handle
+        obj.voxel_extent = self.voxel_extent
+        obj.x_chunk_offset = 0
+        ccs = np.zeros(3, dtype=np.uint32)
+        check(capi.lib().ivx_grid_chunk_counts(handle, ptr(ccs)))
+        obj.chunk_counts = tuple(int(x) for x in ccs)
+        obj.n_chunks = int(np.prod(obj.chunk_counts))
+        obj.n_voxels = obj.n_chunks * CHUNK_VOXEL_COUNT
+        obj.occupied_chunk_ranges = obj.occupied_voxel_ranges = None
+        obj._region_count = None
+        _live_grids.add(obj)
+        return obj
+
+    def _clip(self, normalized_aabb, normalized_face_planes, copy):
+        pl = np.ascontiguousarray(normalized_face_planes, dtype=np.float32).reshape(-1, 4)
+        bb = np.ascontiguousarray(normalized_aabb, dtype=np.float32).reshape(6)
+        child = C.c_void_p()
+        origin = np.zeros(3, dtype=np.uint32)
+        outcome = C.c_int(0)
+        check(capi.lib().ivx_clip_polyhedron(self.h, ptr(pl), len(pl), ptr(bb), 1 if copy else 0, C.byref(child), ptr(origin), C.byref(outcome)))
+        if not copy and outcome.value:
+            self._region_count = None
+        obj = self._wrap_child(child) if outcome.value == 1 else None
+        return int(outcome.value), obj, tuple(int(x) for x in origin)
+
+    def extract_polyhedron(self, normalized_aabb, normalized_face_planes):
+        """`VoxelObject::extract_polyhedron` (object/extraction.rs:604-617): planes = n x (unit normal, displacement)"""
+        return self._clip(normalized_aabb, normalized_face_planes, False)
+
+    def copy_polyhedron(self, normalized_aabb, normalized_face_planes):
+        """`VoxelObject::copy_polyhedron` (object/extraction.rs:1278-1291)"""
+        return self._clip(normalized_aabb, normalized_face_planes, True)
+
     def extract_any_disconnected_region(self):
         """`VoxelObject::extract_any_disconnected_region` (object/extraction.rs:78-119). Returns
         (outcome, child VoxelObject or None, origin_offset_in_parent, descriptor of the removed region):
@@ -278,20 +314,7 @@ class VoxelObject:
         self._region_count = None if outcome.value else self._region_count
         obj = None
         if outcome.value == 1:
-            obj = VoxelObject.__new__(VoxelObject)
-            obj.ctx = self.ctx
-            obj.h = child
-            obj.voxel_extent = self.voxel_extent
-            obj.x_chunk_offset = 0
-            ccs = np.zeros(3, dtype=np.uint32)
-            check(capi.lib().ivx_grid_chunk_counts(child, ptr(ccs)))
-            cc = tuple(int(x) for x in ccs)
-            obj.chunk_counts = cc
-            obj.n_chunks = int(np.prod(cc))
-            obj.n_voxels = obj.n_chunks * CHUNK_VOXEL_COUNT
-            obj.occupied_chunk_ranges = obj.occupied_voxel_ranges = None
-            obj._region_count = None
-            _live_grids.add(obj)
+            obj = self._wrap_child(child)
         return int(outcome.value), obj, tuple(int(x) for x in origin), moved[0]
 
     # ---- halos -----------------------------------------------------------------------------------

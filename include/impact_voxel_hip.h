@@ -179,6 +179,14 @@ int ivx_regions_describe(ivx_grid*, const float densities[256], ivx_region_desc*
  * densities last set with ivx_grid_set_densities / ivx_regions_describe (1.0 if never set). */
 int ivx_split_off_smallest_region(ivx_grid* parent, ivx_grid** child, uint32_t origin_offset_in_parent[3], int* outcome, ivx_region_desc* moved);
 
+/* VoxelObject::extract_polyhedron / copy_polyhedron (object/extraction.rs:604-1768): the part of the object inside the convex
+ * polyhedron given by `n_planes` face planes (planes4 = n x {unit normal x,y,z, displacement}, outward normals) and its AABB
+ * (lower xyz, upper xyz), all in the object's normalized model space (voxel units, grid corner at the origin). copy = 0
+ * removes the polyhedron from the parent (which keeps max(sdf, complement(d))), copy = 1 leaves the parent untouched.
+ * Outcome and child conventions as for ivx_split_off_smallest_region; outcome 0 = the AABB misses the object. */
+int ivx_clip_polyhedron(ivx_grid* parent, const float* planes4, size_t n_planes, const float aabb[6], int copy, ivx_grid** child,
+                        uint32_t origin_offset_in_parent[3], int* outcome);
+
 /* ---- whole voxel step (resident inputs, minimal host synchronisation) ---------------------------- */
 /* The per-frame chain the engine runs for a voxel object — generate (engine/src/setup/scene/voxel.rs:33 ->
  * impact_voxel/src/setup.rs:555-579), derived state, mesh (engine/src/tasks.rs:376-399) and inertial

@@ -151,6 +151,11 @@ int orc_physics_step(orc_physics*, const orc_contact*, int n, float dt);
 /* split the smaller of the first two disconnected regions off (object/extraction.rs:78-596, 1901-2123) */
 int orc_split_off_smallest_region(orc_object* parent, orc_object** child, int origin_offset_in_parent[3]);
 
+/* extract_polyhedron (mode 0) / copy_polyhedron (mode 1) (object/extraction.rs:604-1768): planes4 = n x (unit normal xyz,
+ * displacement), aabb = lower xyz + upper xyz, both in voxel units relative to the grid corner */
+int orc_clip_polyhedron(orc_object* parent, const float* planes4, int n_planes, const float aabb[6], int mode, orc_object** child,
+                        int origin_offset_in_parent[3]);
+
 /* quantisation helpers (lib.rs:197-222) */
 int8_t orc_sd_from_f32(float v);
 float orc_sd_to_f32(int8_t e);

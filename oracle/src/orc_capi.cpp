@@ -13,6 +13,7 @@ void inertia_moments_f64(const VoxelObject& obj, const float* dens, double out[1
 void derive_inertial_properties(const float m[10], float out[22]);
 uint32_t canonical_region_labels(const VoxelObject& obj, uint32_t* labels);
 int split_off_smallest_region(VoxelObject& parent, VoxelObject& child, int origin[3]);
+int clip_polyhedron(VoxelObject& parent, const float* planes, int n_planes, const float aabb[6], int mode, VoxelObject& child, int origin[3]);
 
 // OffsetBoxVoxelGenerator (object.rs:3387-3504)
 struct BoxGenerator : Generator {
@@ -330,6 +331,21 @@ uint32_t orc_region_labels(const orc_object* o, uint32_t* labels) { return canon
 int orc_split_off_smallest_region(orc_object* parent, orc_object** child, int origin_offset_in_parent[3]) {
     orc_object* c = new orc_object();
     int rc = split_off_smallest_region(parent->obj, c->obj, origin_offset_in_parent);
+    if (rc == 1) {
+        for (int d = 0; d < 3; ++d) c->shape[d] = c->obj.cc[d] * CHUNK;
+        *child = c;
+    } else {
+        delete c;
+        *child = nullptr;
+    }
+    return rc;
+}
+
+// extract_polyhedron (mode 0) / copy_polyhedron (mode 1) (object/extraction.rs:604-1768); same outcome convention
+int orc_clip_polyhedron(orc_object* parent, const float* planes4, int n_planes, const float aabb[6], int mode, orc_object** child,
+                        int origin_offset_in_parent[3]) {
+    orc_object* c = new orc_object();
+    int rc = clip_polyhedron(parent->obj, planes4, n_planes, aabb, mode, c->obj, origin_offset_in_parent);
     if (rc == 1) {
         for (int d = 0; d < 3; ++d) c->shape[d] = c->obj.cc[d] * CHUNK;
         *child = c;

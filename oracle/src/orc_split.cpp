@@ -15,6 +15,7 @@
 // (never rewritten on faces whose distribution is Empty) and are not part of the comparison.
 #include <algorithm>
 #include <climits>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -269,6 +270,242 @@ int split_off_smallest_region(VoxelObject& parent, VoxelObject& child, int origi
             child = single;
         }
     }
+    compute_all_derived_state(child);
+    reset_occupied_chunk_ranges(child);
+    return 1;
+}
+
+}  // namespace orc
+
+// ---------------------------------------------------------------------------------------------
+// Polyhedron clip: extract_polyhedron_with_property_transferrer (object/extraction.rs:639-1270) and
+// copy_polyhedron_with_property_computer (1301-1768). Planes are (unit normal, displacement) in normalized
+// model space (voxel units, grid corner at the origin); aabb = lower xyz, upper xyz.
+namespace orc {
+
+static inline float plane_sd(const float* p, float x, float y, float z) { return ((p[0] * x + p[1] * y) + p[2] * z) - p[3]; }
+static inline bool sign_bit(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return (u >> 31) != 0;
+}
+// VoxelSignedDistance::from_f32_array (lib.rs:207-216)
+static inline int8_t sd_from_f32_clamped(float v) {
+    float s = v * 50.0f;
+    s = s < -128.0f ? -128.0f : (s > 127.0f ? 127.0f : s);  // f32::clamp (NaN propagates; not reachable here)
+    return (int8_t)(int)s;
+}
+static inline int8_t sd_complement(int8_t e) {  // lib.rs:266-268: saturating_add(1).saturating_neg()
+    int a = e == 127 ? 127 : e + 1;
+    int n = a == -128 ? 127 : -a;
+    return (int8_t)n;
+}
+
+// mode 0 = extract (parent loses the polyhedron), 1 = copy. outcome as split_off_smallest_region.
+int clip_polyhedron(VoxelObject& parent, const float* planes, int n_planes, const float aabb[6], int mode, VoxelObject& child, int origin[3]) {
+    const float EXT = SD_MAX_F32, INT = -SD_MIN_F32;
+    int vlo[3], vhi[3], clo[3], chi[3], ccounts[3];
+    for (int d = 0; d < 3; ++d) {
+        const float lo = aabb[d] - EXT, hi = aabb[3 + d] + EXT;
+        const float fl = std::floor(lo);
+        const long s = (long)(fl > 0.0f ? fl : 0.0f), e = (long)std::ceil(hi);
+        vlo[d] = std::max<long>(parent.occ_voxel[d][0], s);
+        vhi[d] = std::min<long>(parent.occ_voxel[d][1], std::max<long>(e, 0));
+        if (vlo[d] >= vhi[d]) return 0;
+        clo[d] = vlo[d] / CHUNK;
+        chi[d] = (vhi[d] + CHUNK - 1) / CHUNK;
+        ccounts[d] = chi[d] - clo[d];
+    }
+    child = VoxelObject{};
+    child.extent = parent.extent;
+    for (int d = 0; d < 3; ++d) child.cc[d] = ccounts[d];
+    int uniform_count = 0;
+    std::vector<int> isect(n_planes);
+    for (int I = clo[0]; I < chi[0]; ++I)
+        for (int J = clo[1]; J < chi[1]; ++J)
+            for (int K = clo[2]; K < chi[2]; ++K) {
+                const int ci = parent.cidx(I, J, K);
+                Chunk rc;  // void
+                Chunk& pc = parent.chunks[ci];
+                if (pc.kind == K_VOID) {
+                    child.chunks.push_back(rc);
+                    continue;
+                }
+                const float blo[3] = {(float)(I * CHUNK), (float)(J * CHUNK), (float)(K * CHUNK)};
+                const float bhi[3] = {(float)((I + 1) * CHUNK), (float)((J + 1) * CHUNK), (float)((K + 1) * CHUNK)};
+                bool outside = false;
+                int n_isect = 0;
+                for (int p = 0; p < n_planes; ++p) {
+                    const float* pl = planes + 4 * p;
+                    // minimum / maximum corner along the normal (axis_aligned_box.rs:494-507): a negative
+                    // component picks the upper coordinate for the minimum corner
+                    float mn[3], mx[3];
+                    for (int d = 0; d < 3; ++d) {
+                        const bool neg = sign_bit(pl[d]);
+                        mn[d] = neg ? bhi[d] : blo[d];
+                        mx[d] = neg ? blo[d] : bhi[d];
+                    }
+                    const float outer[4] = {pl[0], pl[1], pl[2], pl[3] + EXT}, inner[4] = {pl[0], pl[1], pl[2], pl[3] - INT};
+                    if (plane_sd(outer, mn[0], mn[1], mn[2]) > 0.0f) outside = true;
+                    if (!(plane_sd(inner, mx[0], mx[1], mx[2]) < 0.0f)) isect[n_isect++] = p;
+                }
+                if (outside) {
+                    child.chunks.push_back(rc);
+                    continue;
+                }
+                if (n_isect == 0) {  // fully inside
+                    if (pc.kind == K_NONUNIFORM) {
+                        Voxel* pv = &parent.voxels[(size_t)pc.data_offset << 12];
+                        rc.kind = rc.gen_kind = K_NONUNIFORM;
+                        rc.data_offset = (uint32_t)(child.voxels.size() >> 12);
+                        rc.flags = pc.flags & CF_ONLY_EMPTY;
+                        for (int d = 0; d < 3; ++d)
+                            for (int s = 0; s < 2; ++s) rc.face[d][s] = pc.face[d][s];
+                        child.voxels.insert(child.voxels.end(), pv, pv + CHUNK_VOXELS);
+                        if (mode == 0) {
+                            for (int idx = 0; idx < CHUNK_VOXELS; ++idx) pv[idx] = voxel_max_outside();
+                            pc = Chunk{};
+                        }
+                    } else {
+                        rc = pc;
+                        rc.gen_kind = K_UNIFORM;
+                        uniform_count += 1;
+                        if (mode == 0) pc = Chunk{};
+                    }
+                    child.chunks.push_back(rc);
+                    continue;
+                }
+                // intersecting chunk
+                std::vector<Voxel> tmp(CHUNK_VOXELS);
+                Voxel* pv = nullptr;
+                if (pc.kind == K_UNIFORM) {
+                    if (mode == 0) {  // convert_to_non_uniform_if_uniform (object.rs:2530-2550)
+                        const size_t start = parent.voxels.size();
+                        parent.voxels.resize(start + CHUNK_VOXELS, pc.uniform_voxel);
+                        parent.labels.resize(start + CHUNK_VOXELS, 0);
+                        pc.kind = K_NONUNIFORM;
+                        pc.data_offset = (uint32_t)(start >> 12);
+                        pv = &parent.voxels[start];
+                        std::copy(pv, pv + CHUNK_VOXELS, tmp.begin());
+                    } else {
+                        std::fill(tmp.begin(), tmp.end(), pc.uniform_voxel);
+                    }
+                } else {
+                    pv = &parent.voxels[(size_t)pc.data_offset << 12];
+                    std::copy(pv, pv + CHUNK_VOXELS, tmp.begin());
+                    if (mode == 1) pv = nullptr;
+                }
+                const float lvp[3] = {blo[0] + 0.5f, blo[1] + 0.5f, blo[2] + 0.5f};
+                bool parent_only_empty = true, poly_only_empty = true, parent_all_void = true, poly_all_void = true;
+                for (int i = 0; i < CHUNK; ++i)
+                    for (int j = 0; j < CHUNK; ++j) {
+                        const float rx = lvp[0] + (float)i, ry = lvp[1] + (float)j, rz = lvp[2] + 0.0f;
+                        float md[CHUNK];
+                        for (int q = 0; q < n_isect; ++q) {
+                            const float* pl = planes + 4 * isect[q];
+                            const float base = plane_sd(pl, rx, ry, rz), step = pl[2];
+                            for (int k = 0; k < CHUNK; ++k) {
+                                const float v = base + step * (float)k;
+                                md[k] = q == 0 ? v : (v > md[k] ? v : (md[k] != md[k] ? v : md[k]));  // f32::max
+                            }
+                        }
+                        for (int k = 0; k < CHUNK; ++k) {
+                            const int idx = lin(i, j, k);
+                            const int8_t d = sd_from_f32_clamped(md[k]);
+                            Voxel& poly = tmp[idx];
+                            const int8_t orig = poly.sd;
+                            poly.sd = std::max(orig, d);
+                            if (poly.sd < 0) {
+                                poly.flags &= (uint8_t)~F_EMPTY;
+                                poly_only_empty = false;
+                            } else {
+                                poly.flags |= F_EMPTY;
+                            }
+                            if (!sd_is_void(poly.sd)) poly_all_void = false;
+                            if (pv) {
+                                Voxel& par = pv[idx];
+                                par.sd = std::max(orig, sd_complement(d));
+                                if (poly.sd < 0) par.flags |= F_EMPTY;
+                                if (par.sd < 0) parent_only_empty = false;
+                                if (!sd_is_void(par.sd)) parent_all_void = false;
+                            }
+                        }
+                    }
+                if (pv) {
+                    if (parent_only_empty && parent_all_void) {
+                        for (int idx = 0; idx < CHUNK_VOXELS; ++idx) pv[idx] = voxel_max_outside();
+                        pc = Chunk{};
+                    } else {
+                        pc.flags = 0;
+                        update_all_internal_state(pc, pv);
+                    }
+                }
+                if (!(poly_only_empty && poly_all_void)) {
+                    rc.kind = rc.gen_kind = K_NONUNIFORM;
+                    rc.data_offset = (uint32_t)(child.voxels.size() >> 12);
+                    child.voxels.insert(child.voxels.end(), tmp.begin(), tmp.end());
+                    update_all_internal_state(rc, &child.voxels[(size_t)rc.data_offset << 12]);
+                }
+                child.chunks.push_back(rc);
+            }
+    child.labels.assign(child.voxels.size(), 0);
+    if (mode == 0) {
+        for (Chunk& c : parent.chunks)
+            if (c.kind == K_NONUNIFORM) c.flags &= CF_ONLY_EMPTY;
+        compute_all_derived_state(parent);
+        reset_occupied_chunk_ranges(parent);
+    }
+    if (uniform_count == 0) {
+        int non_empty = 0;
+        for (const Voxel& v : child.voxels) non_empty += v.empty() ? 0 : 1;
+        if (non_empty < 8) return 2;
+    }
+    for (int d = 0; d < 3; ++d) origin[d] = clo[d] * CHUNK;
+    if (ccounts[0] <= 2 && ccounts[1] <= 2 && ccounts[2] <= 2 && uniform_count == 0 && ccounts[0] * ccounts[1] * ccounts[2] > 1) {
+        int olo[3] = {INT_MAX, INT_MAX, INT_MAX}, ohi[3] = {0, 0, 0};
+        for (int I = 0; I < ccounts[0]; ++I)
+            for (int J = 0; J < ccounts[1]; ++J)
+                for (int K = 0; K < ccounts[2]; ++K) {
+                    const Chunk& c = child.chunks[child.cidx(I, J, K)];
+                    if (c.kind != K_NONUNIFORM) continue;
+                    const Voxel* v = &child.voxels[(size_t)c.data_offset << 12];
+                    for (int idx = 0; idx < CHUNK_VOXELS; ++idx)
+                        if (!v[idx].empty()) {
+                            const int p[3] = {I * CHUNK + (idx >> 8), J * CHUNK + ((idx >> 4) & 15), K * CHUNK + (idx & 15)};
+                            for (int d = 0; d < 3; ++d) {
+                                olo[d] = std::min(olo[d], p[d]);
+                                ohi[d] = std::max(ohi[d], p[d] + 1);
+                            }
+                        }
+                }
+        if (ohi[0] - olo[0] <= CHUNK - 2 && ohi[1] - olo[1] <= CHUNK - 2 && ohi[2] - olo[2] <= CHUNK - 2) {
+            int off[3];
+            for (int d = 0; d < 3; ++d) off[d] = olo[d] > 0 ? olo[d] - 1 : 0;
+            VoxelObject single;
+            single.extent = child.extent;
+            single.cc[0] = single.cc[1] = single.cc[2] = 1;
+            single.voxels.assign(CHUNK_VOXELS, voxel_max_outside());
+            for (int i = 0; i < CHUNK; ++i)
+                for (int j = 0; j < CHUNK; ++j)
+                    for (int k = 0; k < CHUNK; ++k) {
+                        const int s[3] = {off[0] + i, off[1] + j, off[2] + k};
+                        if (s[0] >= ccounts[0] * CHUNK || s[1] >= ccounts[1] * CHUNK || s[2] >= ccounts[2] * CHUNK) continue;
+                        const Chunk& c = child.chunks[child.cidx(s[0] >> 4, s[1] >> 4, s[2] >> 4)];
+                        if (c.kind != K_NONUNIFORM) continue;
+                        single.voxels[lin(i, j, k)] = child.voxels[((size_t)c.data_offset << 12) + lin(s[0] & 15, s[1] & 15, s[2] & 15)];
+                    }
+            Chunk sc;
+            sc.kind = sc.gen_kind = K_NONUNIFORM;
+            sc.data_offset = 0;
+            update_all_internal_state(sc, single.voxels.data());
+            single.chunks.push_back(sc);
+            single.labels.assign(CHUNK_VOXELS, 0);
+            for (int d = 0; d < 3; ++d) origin[d] += off[d];
+            child = single;
+        }
+    }
+    for (Chunk& c : child.chunks)
+        if (c.kind == K_NONUNIFORM) c.flags &= CF_ONLY_EMPTY;
     compute_all_derived_state(child);
     reset_occupied_chunk_ranges(child);
     return 1;

@@ -84,6 +84,8 @@ def lib():
         L.orc_sd_to_f32.argtypes = [C.c_int8]
         L.orc_split_off_smallest_region.restype = C.c_int
         L.orc_split_off_smallest_region.argtypes = [vp, C.POINTER(vp), vp]
+        L.orc_clip_polyhedron.restype = C.c_int
+        L.orc_clip_polyhedron.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.POINTER(vp), vp]
         L.orc_physics_create.restype = vp
         L.orc_physics_free.argtypes = [vp]
         L.orc_physics_set_config.argtypes = [vp, vp]
@@ -264,6 +266,15 @@ class OracleObject:
         child = C.c_void_p()
         origin = np.zeros(3, dtype=np.int32)
         rc = lib().orc_split_off_smallest_region(self.h, C.byref(child), _p(origin))
+        return rc, (OracleObject(child.value) if rc == 1 else None), tuple(int(x) for x in origin)
+
+    def clip_polyhedron(self, planes, aabb, copy=False):
+        """extract_polyhedron / copy_polyhedron -> (outcome, child or None, origin offset)"""
+        pl = np.ascontiguousarray(planes, dtype=np.float32).reshape(-1, 4)
+        bb = np.ascontiguousarray(aabb, dtype=np.float32).reshape(6)
+        child = C.c_void_p()
+        origin = np.zeros(3, dtype=np.int32)
+        rc = lib().orc_clip_polyhedron(self.h, _p(pl), len(pl), _p(bb), 1 if copy else 0, C.byref(child), _p(origin))
         return rc, (OracleObject(child.value) if rc == 1 else None), tuple(int(x) for x in origin)
 
     def inertia(self, densities=None):
