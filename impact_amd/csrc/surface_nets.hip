@@ -23,7 +23,11 @@
 
 namespace {
 
-constexpr int G = 18, G2 = 324, GCELLS = 5832, NCUBES = 4913;
+constexpr int G = 18, NROWS = 324, NCROWS = 289, NCUBES = 4913;
+// LDS tile: 18 x 18 rows of 18 bytes along k; a row occupies RS = 24 bytes with cell c at byte 3 + c, so the 16
+// interior cells (c = 1..16, the chunk's own k-row) sit 4-byte aligned and are written as four words.
+constexpr int RS = 24, TILE_BYTES = NROWS * RS;
+__device__ __forceinline__ int tix(int a, int b, int c) { return (a * G + b) * RS + 3 + c; }
 
 struct V3 {
     float x, y, z;
@@ -44,30 +48,45 @@ struct SnParams {
     uint32_t x_off;
 };
 
-// Fetch the voxel at object indices (relative to this slab); outside the grid / void -> (127, 255).
-__device__ __forceinline__ void fetch(const GridView& g, int gi, int gj, int gk, int8_t& sd, uint8_t& ty) {
-    sd = 127;
-    ty = TYPE_DUMMY;
-    if (gj < 0 || gk < 0 || gj >= (int)g.cy * 16 || gk >= (int)g.cz * 16) return;
-    if (gi < 0) {
-        if (g.ghost_sdf[0]) {
-            size_t o = (size_t)((gj >> 4) * g.cz + (gk >> 4)) * 256 + (((gj & 15) << 4) | (gk & 15));
-            sd = g.ghost_sdf[0][o];
-            ty = g.ghost_type[0][o];
-        }
-        return;
+// One padded row (fixed gi, gj; cells gk = ck*16 - 1 .. ck*16 + 16) of the object, relative to this slab. Outside the
+// grid / void -> (127, 255) (object/sdf.rs:410-508: void neighbours pad with +2.54).
+__device__ __forceinline__ void fetch_row(const GridView& g, int gi, int gj, int ck, uint32_t sd[6], uint32_t ty[6]) {
+    // sd/ty: [0] = cell 0 (byte), [1..4] = the 16 interior cells (words), [5] = cell 17 (byte)
+    sd[0] = sd[5] = 0x7Fu;
+    ty[0] = ty[5] = 0xFFu;
+    sd[1] = sd[2] = sd[3] = sd[4] = 0x7F7F7F7Fu;
+    ty[1] = ty[2] = ty[3] = ty[4] = 0xFFFFFFFFu;
+    if (gj < 0 || gj >= (int)g.cy * 16) return;
+    const int8_t* ps;
+    const uint8_t* pt;
+    size_t row;        // offset of (.., gj, k = 0) inside the chunk / ghost column
+    size_t kstride;    // offset between consecutive chunks along k
+    if (gi < 0 || gi >= (int)g.cx * 16) {
+        const int side = gi < 0 ? 0 : 1;
+        if (!g.ghost_sdf[side]) return;
+        ps = g.ghost_sdf[side];
+        pt = g.ghost_type[side];
+        row = (size_t)((gj >> 4) * g.cz) * 256 + ((gj & 15) << 4);
+        kstride = 256;
+    } else {
+        ps = g.sdf;
+        pt = g.type;
+        row = ((size_t)(((gi >> 4) * g.cy + (gj >> 4)) * g.cz) << 12) + (((gi & 15) << 8) | ((gj & 15) << 4));
+        kstride = IVX_CHUNK_VOXELS;
     }
-    if (gi >= (int)g.cx * 16) {
-        if (g.ghost_sdf[1]) {
-            size_t o = (size_t)((gj >> 4) * g.cz + (gk >> 4)) * 256 + (((gj & 15) << 4) | (gk & 15));
-            sd = g.ghost_sdf[1][o];
-            ty = g.ghost_type[1][o];
-        }
-        return;
+    const size_t o = row + (size_t)ck * kstride;
+    const uint4 s4 = *reinterpret_cast<const uint4*>(ps + o);
+    const uint4 t4 = *reinterpret_cast<const uint4*>(pt + o);
+    sd[1] = s4.x, sd[2] = s4.y, sd[3] = s4.z, sd[4] = s4.w;
+    ty[1] = t4.x, ty[2] = t4.y, ty[3] = t4.z, ty[4] = t4.w;
+    if (ck > 0) {
+        sd[0] = (uint8_t)ps[o - kstride + 15];
+        ty[0] = pt[o - kstride + 15];
     }
-    size_t o = ((size_t)(((gi >> 4) * g.cy + (gj >> 4)) * g.cz + (gk >> 4)) << 12) + (((gi & 15) << 8) | ((gj & 15) << 4) | (gk & 15));
-    sd = g.sdf[o];
-    ty = g.type[o];
+    if (ck + 1 < (int)g.cz) {
+        sd[5] = (uint8_t)ps[o + kstride];
+        ty[5] = pt[o + kstride];
+    }
 }
 
 __device__ __forceinline__ uint32_t neighbour_kind(const GridView& g, int ci, int cj, int ck) {
@@ -77,19 +96,42 @@ __device__ __forceinline__ uint32_t neighbour_kind(const GridView& g, int ci, in
     return g.info[(ci * g.cy + cj) * g.cz + ck].kind;
 }
 
-__device__ __forceinline__ void load_tile(const GridView& g, int ci, int cj, int ck, int8_t* s_sd, uint8_t* s_ty, uint32_t tid) {
-    for (int c = tid; c < GCELLS; c += 256) {
-        int a = c / G2, r = c - a * G2, b = r / G, cc = r - b * G;
-        int8_t sd;
-        uint8_t ty;
-        fetch(g, ci * 16 + a - 1, cj * 16 + b - 1, ck * 16 + cc - 1, sd, ty);
-        s_sd[c] = sd;
-        s_ty[c] = ty;
+// sign bits of 16 packed i8 -> 16-bit mask
+__device__ __forceinline__ uint32_t neg16(const uint32_t w[4]) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t sb = w[q] & 0x80808080u;
+        m |= (((sb >> 7) & 1u) | ((sb >> 14) & 2u) | ((sb >> 21) & 4u) | ((sb >> 28) & 8u)) << (4 * q);
+    }
+    return m;
+}
+
+// Stage the 18^3 padded tile: 324 rows, one 16-byte plane load each (+ two halo bytes). s_neg[r] = 18-bit mask of
+// negative distances (decoded 0 is +0.0 => outside, surface_nets.rs:209-224). s_sd / s_ty may be null (count pass).
+__device__ __forceinline__ void load_tile(const GridView& g, int ci, int cj, int ck, uint8_t* s_sd, uint8_t* s_ty, uint32_t* s_neg, uint32_t tid) {
+    for (int r = tid; r < NROWS; r += 256) {
+        const int a = r / G, b = r - a * G;
+        uint32_t sd[6], ty[6];
+        fetch_row(g, ci * 16 + a - 1, cj * 16 + b - 1, ck, sd, ty);
+        s_neg[r] = ((sd[0] >> 7) & 1u) | (neg16(sd + 1) << 1) | (((sd[5] >> 7) & 1u) << 17);
+        if (s_sd) {
+            uint8_t* ds = s_sd + r * RS;
+            uint8_t* dt = s_ty + r * RS;
+            ds[3] = (uint8_t)sd[0];
+            dt[3] = (uint8_t)ty[0];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                reinterpret_cast<uint32_t*>(ds + 4)[q] = sd[1 + q];
+                reinterpret_cast<uint32_t*>(dt + 4)[q] = ty[1 + q];
+            }
+            ds[20] = (uint8_t)sd[5];
+            dt[20] = (uint8_t)ty[5];
+        }
     }
 }
 
-// Ordered block-wide exclusive prefix of `val` (<= 3 per thread) in thread order; returns the prefix and
-// adds the block total to `base` (same value in every thread).
+// Ordered block-wide exclusive prefix of `val` in thread order; `total` = block sum (same in every thread).
 __device__ __forceinline__ uint32_t block_prefix(uint32_t val, uint32_t* s_wsum, uint32_t tid, uint32_t& total) {
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     uint32_t incl = val;
@@ -107,43 +149,34 @@ __device__ __forceinline__ uint32_t block_prefix(uint32_t val, uint32_t* s_wsum,
     return wbase + incl - val;
 }
 
-__device__ __forceinline__ uint32_t block_prefix_flag(bool flag, uint32_t* s_wsum, uint32_t tid, uint32_t& total) {
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
-    const unsigned long long b = __ballot(flag);
-    const uint32_t pre = __popcll(b & ((1ull << lane) - 1ull));
-    if (lane == 0u) s_wsum[wave] = __popcll(b);
-    __syncthreads();
-    uint32_t w0 = s_wsum[0], w1 = s_wsum[1], w2 = s_wsum[2], w3 = s_wsum[3];
-    uint32_t wbase = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
-    total = w0 + w1 + w2 + w3;
-    __syncthreads();
-    return wbase + pre;
-}
-
-__device__ __forceinline__ bool cube_has_vertex(const int8_t* s_sd, int lin) {
-    // sign test of the 8 corners (surface_nets.rs:209-224); decoded 0 is +0.0 => outside
-    uint32_t neg = (s_sd[lin] < 0) + (s_sd[lin + 1] < 0) + (s_sd[lin + G] < 0) + (s_sd[lin + G + 1] < 0) + (s_sd[lin + G2] < 0) +
-                   (s_sd[lin + G2 + 1] < 0) + (s_sd[lin + G2 + G] < 0) + (s_sd[lin + G2 + G + 1] < 0);
-    return neg != 0 && neg != 8;
-}
-
-// number of quads (and which) emitted for the surface cube at (i,j,k): bit0 X edge, bit1 Y, bit2 Z
-__device__ __forceinline__ uint32_t quad_mask(const int8_t* s_sd, int lin, int i, int j, int k, const int* upper) {
-    const bool n0 = s_sd[lin] < 0;
-    uint32_t m = 0;
-    if (j != 0 && k != 0 && i < upper[0] && (n0 != (s_sd[lin + G2] < 0))) m |= 1u;
-    if (i != 0 && k != 0 && j < upper[1] && (n0 != (s_sd[lin + G] < 0))) m |= 2u;
-    if (i != 0 && j != 0 && k < upper[2] && (n0 != (s_sd[lin + 1] < 0))) m |= 4u;
-    return m;
+// Bit k of the results refers to the cube (i, j, k) of cube row cr = i*17 + j (k = 0..16):
+//   vbits: the cube holds a vertex (its 8 corner signs are mixed, surface_nets.rs:209-224)
+//   qx/qy/qz: it emits the quad of its X / Y / Z edge (maybe_make_surface_nets_quad, surface_nets.rs:251-334)
+__device__ __forceinline__ void cube_row_bits(const uint32_t* s_neg, int i, int j, const int* upper, uint32_t& vbits, uint32_t& qx, uint32_t& qy,
+                                              uint32_t& qz) {
+    const uint32_t r00 = s_neg[i * G + j], r01 = s_neg[i * G + j + 1], r10 = s_neg[(i + 1) * G + j], r11 = s_neg[(i + 1) * G + j + 1];
+    const uint32_t o = r00 | r01 | r10 | r11, a = r00 & r01 & r10 & r11;
+    vbits = ((o | (o >> 1)) & ~(a & (a >> 1))) & 0x1FFFFu;
+    const uint32_t knz = 0x1FFFEu;  // k != 0
+    qx = (j != 0 && i < upper[0]) ? ((r00 ^ r10) & knz) : 0u;
+    qy = (i != 0 && j < upper[1]) ? ((r00 ^ r01) & knz) : 0u;
+    qz = (i != 0 && j != 0) ? ((r00 ^ (r00 >> 1)) & ((1u << upper[2]) - 1u)) : 0u;
 }
 
 __device__ __forceinline__ bool chunk_exposed(const ivx_chunk_info& ci) {
     return ci.kind == KIND_NONUNIFORM && (ci.flags & CF_FULLY_OBSCURED) != CF_FULLY_OBSCURED;
 }
 
+__device__ __forceinline__ void upper_limits(const GridView& g, int ci, int cj, int ck, int* upper) {
+    // the upper layer of cubes belongs to the upper neighbour chunk when that chunk is non-uniform (surface_nets.rs:252-261)
+    upper[0] = upper[1] = upper[2] = G - 1;
+    if (neighbour_kind(g, ci + 1, cj, ck) == KIND_NONUNIFORM) upper[0] -= 1;
+    if (neighbour_kind(g, ci, cj + 1, ck) == KIND_NONUNIFORM) upper[1] -= 1;
+    if (neighbour_kind(g, ci, cj, ck + 1) == KIND_NONUNIFORM) upper[2] -= 1;
+}
+
 __global__ __launch_bounds__(256) void k_sn_count(SnParams p, uint32_t* __restrict__ counts) {
-    __shared__ int8_t s_sd[GCELLS];
-    __shared__ uint8_t s_ty[GCELLS];
+    __shared__ uint32_t s_neg[NROWS];
     __shared__ uint32_t s_acc[2];
     const GridView& g = p.g;
     const uint32_t tid = threadIdx.x;
@@ -159,20 +192,16 @@ __global__ __launch_bounds__(256) void k_sn_count(SnParams p, uint32_t* __restri
     }
     const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
     if (tid < 2) s_acc[tid] = 0;
-    load_tile(g, ci, cj, ck, s_sd, s_ty, tid);
-    int upper[3] = {G - 1, G - 1, G - 1};
-    if (neighbour_kind(g, ci + 1, cj, ck) == KIND_NONUNIFORM) upper[0] -= 1;
-    if (neighbour_kind(g, ci, cj + 1, ck) == KIND_NONUNIFORM) upper[1] -= 1;
-    if (neighbour_kind(g, ci, cj, ck + 1) == KIND_NONUNIFORM) upper[2] -= 1;
+    load_tile(g, ci, cj, ck, nullptr, nullptr, s_neg, tid);
+    int upper[3];
+    upper_limits(g, ci, cj, ck, upper);
     __syncthreads();
     uint32_t nv = 0, nq = 0;
-    for (int q = tid; q < NCUBES; q += 256) {
-        int i = q / 289, r = q - i * 289, j = r / 17, k = r - j * 17;
-        int lin = i * G2 + j * G + k;
-        if (cube_has_vertex(s_sd, lin)) {
-            nv += 1;
-            nq += __popc(quad_mask(s_sd, lin, i, j, k, upper));
-        }
+    for (int cr = tid; cr < NCROWS; cr += 256) {
+        uint32_t vb, qx, qy, qz;
+        cube_row_bits(s_neg, cr / 17, cr % 17, upper, vb, qx, qy, qz);
+        nv += __popc(vb);
+        nq += __popc(qx) + __popc(qy) + __popc(qz);
     }
     atomicAdd(&s_acc[0], nv);
     atomicAdd(&s_acc[1], nq);
@@ -365,10 +394,12 @@ __global__ __launch_bounds__(256) void k_sn_emit(SnParams p, const uint32_t* __r
                                                  const uint32_t* __restrict__ ranks, float* __restrict__ positions, float* __restrict__ normals,
                                                  uint32_t* __restrict__ indices, unsigned long long* __restrict__ imats,
                                                  uint4* __restrict__ vmats, ivx_submesh* __restrict__ submeshes) {
-    __shared__ int8_t s_sd[GCELLS];
-    __shared__ uint8_t s_ty[GCELLS];
-    __shared__ uint16_t s_map[GCELLS];
-    __shared__ uint16_t s_surf[NCUBES];
+    __shared__ __attribute__((aligned(16))) uint8_t s_sd[TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ty[TILE_BYTES];
+    __shared__ uint32_t s_neg[NROWS];
+    __shared__ uint32_t s_vbase[NCROWS + 1];  // first vertex of every cube row
+    __shared__ uint16_t s_surf[NCUBES];       // vertex -> cube id (cube row * 17 + k)
+    __shared__ uint16_t s_map[NCUBES];        // cube id -> vertex
     __shared__ uint32_t s_wsum[4];
     const GridView& g = p.g;
     const uint32_t tid = threadIdx.x;
@@ -380,11 +411,9 @@ __global__ __launch_bounds__(256) void k_sn_emit(SnParams p, const uint32_t* __r
     const uint32_t voff = offsets[2 * chunk], ioff = offsets[2 * chunk + 1];
     const ivx_chunk_info info = g.info[chunk];
     const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
-    load_tile(g, ci, cj, ck, s_sd, s_ty, tid);
-    int upper[3] = {G - 1, G - 1, G - 1};
-    if (neighbour_kind(g, ci + 1, cj, ck) == KIND_NONUNIFORM) upper[0] -= 1;
-    if (neighbour_kind(g, ci, cj + 1, ck) == KIND_NONUNIFORM) upper[1] -= 1;
-    if (neighbour_kind(g, ci, cj, ck + 1) == KIND_NONUNIFORM) upper[2] -= 1;
+    load_tile(g, ci, cj, ck, s_sd, s_ty, s_neg, tid);
+    int upper[3];
+    upper_limits(g, ci, cj, ck, upper);
 
     if (tid == 0) {
         ivx_submesh sm;
@@ -406,85 +435,100 @@ __global__ __launch_bounds__(256) void k_sn_emit(SnParams p, const uint32_t* __r
     }
     __syncthreads();
 
+    // ---- vertex order: cubes in (i,j,k) scan order (surface_nets.rs:158-185) = cube rows in order, bits ascending.
+    // Thread t owns cube rows 2t and 2t+1 so that thread order = row order for the ordered prefix.
+    {
+        uint32_t vb[2] = {0, 0};
+        const int r0 = 2 * (int)tid;
+        for (int q = 0; q < 2; ++q) {
+            const int cr = r0 + q;
+            if (cr < NCROWS) {
+                uint32_t qx, qy, qz;
+                cube_row_bits(s_neg, cr / 17, cr % 17, upper, vb[q], qx, qy, qz);
+            }
+        }
+        uint32_t total;
+        uint32_t base = block_prefix(__popc(vb[0]) + __popc(vb[1]), s_wsum, tid, total);
+        for (int q = 0; q < 2; ++q) {
+            const int cr = r0 + q;
+            if (cr < NCROWS) {
+                s_vbase[cr] = base;
+                uint32_t m = vb[q];
+                while (m) {
+                    const int k = __ffs(m) - 1;
+                    m &= m - 1;
+                    s_surf[base] = (uint16_t)(cr * 17 + k);
+                    s_map[cr * 17 + k] = (uint16_t)base;
+                    base += 1;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
     // mesh.rs:559-577
     const float chunk_extent = p.extent * 16.0f;
     const V3 pos_offset = mk((float)(ci + (int)p.x_off) * chunk_extent - 0.5f * p.extent, (float)cj * chunk_extent - 0.5f * p.extent,
                              (float)ck * chunk_extent - 0.5f * p.extent);
 
-    // ---- phase A: vertices in (i,j,k) cube order --------------------------------------------
-    uint32_t vbase = 0;
-    for (int q0 = 0; q0 < NCUBES; q0 += 256) {
-        const int q = q0 + (int)tid;
-        int i = 0, j = 0, k = 0, lin = 0;
-        bool has_vertex = false;
-        if (q < NCUBES) {
-            i = q / 289;
-            int r = q - i * 289;
-            j = r / 17;
-            k = r - j * 17;
-            lin = i * G2 + j * G + k;
-            has_vertex = cube_has_vertex(s_sd, lin);
-        }
-        uint32_t total;
-        const uint32_t v = vbase + block_prefix_flag(has_vertex, s_wsum, tid, total);
-        vbase += total;
-        if (has_vertex) {
-            const int co[8] = {0, 1, G, G + 1, G2, G2 + 1, G2 + G, G2 + G + 1};
-            float d[8];
-            bool has[8];
-            uint8_t mats[8];
+    // ---- phase A: one thread per vertex (dense) -------------------------------------------------
+    for (uint32_t v = tid; v < vcount; v += 256) {
+        const int cid = s_surf[v];
+        const int cr = cid / 17, k = cid - cr * 17, i = cr / 17, j = cr - i * 17;
+        const int t0 = tix(i, j, k);
+        const int co[8] = {0, 1, RS, RS + 1, G * RS, G * RS + 1, G * RS + RS, G * RS + RS + 1};
+        float d[8];
+        bool has[8];
+        uint8_t mats[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                int8_t e = s_sd[lin + co[c]];
-                d[c] = decode(e);
-                has[c] = e < 0;
-                mats[c] = s_ty[lin + co[c]];
-            }
-            // centroid of edge intersections (surface_nets.rs:384-418)
-            const int E1[12] = {0, 0, 0, 1, 1, 2, 2, 3, 4, 4, 5, 6};
-            const int E2[12] = {1, 2, 4, 3, 5, 3, 6, 7, 5, 6, 7, 7};
-            int count = 0;
-            V3 sum = mk(0.0f, 0.0f, 0.0f);
-#pragma unroll
-            for (int e = 0; e < 12; ++e) {
-                const int c1 = E1[e], c2 = E2[e];
-                const float d1 = d[c1], d2 = d[c2];
-                if (sneg(d1) != sneg(d2)) {
-                    count += 1;
-                    const float interp1 = d1 / (d1 - d2);
-                    const float interp2 = 1.0f - interp1;
-                    const V3 p1 = mk((float)((c1 >> 2) & 1), (float)((c1 >> 1) & 1), (float)(c1 & 1));
-                    const V3 p2 = mk((float)((c2 >> 2) & 1), (float)((c2 >> 1) & 1), (float)(c2 & 1));
-                    sum = add(sum, add(scale(p1, interp2), scale(p2, interp1)));
-                }
-            }
-            const float rc = 1.0f / (float)count;
-            const V3 centroid = scale(sum, rc);
-            // trilinear gradient (object/sdf.rs:603-633)
-            const V3 d00 = sub(mk(d[4], d[2], d[1]), mk(d[0], d[0], d[0]));
-            const V3 d01 = sub(mk(d[5], d[6], d[3]), mk(d[1], d[4], d[2]));
-            const V3 d10 = sub(mk(d[6], d[3], d[5]), mk(d[2], d[1], d[4]));
-            const V3 d11 = sub(mk(d[7], d[7], d[7]), mk(d[3], d[5], d[6]));
-            const V3 o = centroid;
-            const V3 r = sub(mk(1.0f, 1.0f, 1.0f), o);
-            const V3 r_yzx = mk(r.y, r.z, r.x), r_zxy = mk(r.z, r.x, r.y), o_yzx = mk(o.y, o.z, o.x), o_zxy = mk(o.z, o.x, o.y);
-            const V3 grad = add(add(add(mul(mul(r_yzx, r_zxy), d00), mul(mul(r_yzx, o_zxy), d01)), mul(mul(o_yzx, r_zxy), d10)),
-                                mul(mul(o_yzx, o_zxy), d11));
-            const float gl = len3(grad);
-            const V3 normal = mk(grad.x / gl, grad.y / gl, grad.z / gl);
-            const V3 position = add(scale(add(centroid, mk((float)i, (float)j, (float)k)), p.extent), pos_offset);
-            const VMat vm = vertex_materials(has, mats);
-            s_map[lin] = (uint16_t)v;
-            s_surf[v] = (uint16_t)lin;
-            const size_t gv = (size_t)voff + v;
-            positions[3 * gv + 0] = position.x;
-            positions[3 * gv + 1] = position.y;
-            positions[3 * gv + 2] = position.z;
-            normals[3 * gv + 0] = normal.x;
-            normals[3 * gv + 1] = normal.y;
-            normals[3 * gv + 2] = normal.z;
-            vmats[gv] = make_uint4((uint32_t)vm.ind, (uint32_t)(vm.ind >> 32), (uint32_t)vm.wgt, (uint32_t)(vm.wgt >> 32));
+        for (int c = 0; c < 8; ++c) {
+            const int8_t e = (int8_t)s_sd[t0 + co[c]];
+            d[c] = decode(e);
+            has[c] = e < 0;
+            mats[c] = s_ty[t0 + co[c]];
         }
+        // centroid of edge intersections (surface_nets.rs:384-418)
+        const int E1[12] = {0, 0, 0, 1, 1, 2, 2, 3, 4, 4, 5, 6};
+        const int E2[12] = {1, 2, 4, 3, 5, 3, 6, 7, 5, 6, 7, 7};
+        int count = 0;
+        V3 sum = mk(0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+            const int c1 = E1[e], c2 = E2[e];
+            const float d1 = d[c1], d2 = d[c2];
+            if (sneg(d1) != sneg(d2)) {
+                count += 1;
+                const float interp1 = d1 / (d1 - d2);
+                const float interp2 = 1.0f - interp1;
+                const V3 p1 = mk((float)((c1 >> 2) & 1), (float)((c1 >> 1) & 1), (float)(c1 & 1));
+                const V3 p2 = mk((float)((c2 >> 2) & 1), (float)((c2 >> 1) & 1), (float)(c2 & 1));
+                sum = add(sum, add(scale(p1, interp2), scale(p2, interp1)));
+            }
+        }
+        const float rc = 1.0f / (float)count;
+        const V3 centroid = scale(sum, rc);
+        // trilinear gradient (object/sdf.rs:603-633)
+        const V3 d00 = sub(mk(d[4], d[2], d[1]), mk(d[0], d[0], d[0]));
+        const V3 d01 = sub(mk(d[5], d[6], d[3]), mk(d[1], d[4], d[2]));
+        const V3 d10 = sub(mk(d[6], d[3], d[5]), mk(d[2], d[1], d[4]));
+        const V3 d11 = sub(mk(d[7], d[7], d[7]), mk(d[3], d[5], d[6]));
+        const V3 o = centroid;
+        const V3 r = sub(mk(1.0f, 1.0f, 1.0f), o);
+        const V3 r_yzx = mk(r.y, r.z, r.x), r_zxy = mk(r.z, r.x, r.y), o_yzx = mk(o.y, o.z, o.x), o_zxy = mk(o.z, o.x, o.y);
+        const V3 grad = add(add(add(mul(mul(r_yzx, r_zxy), d00), mul(mul(r_yzx, o_zxy), d01)), mul(mul(o_yzx, r_zxy), d10)),
+                            mul(mul(o_yzx, o_zxy), d11));
+        const float gl = len3(grad);
+        const V3 normal = mk(grad.x / gl, grad.y / gl, grad.z / gl);
+        const V3 position = add(scale(add(centroid, mk((float)i, (float)j, (float)k)), p.extent), pos_offset);
+        const VMat vm = vertex_materials(has, mats);
+        const size_t gv = (size_t)voff + v;
+        positions[3 * gv + 0] = position.x;
+        positions[3 * gv + 1] = position.y;
+        positions[3 * gv + 2] = position.z;
+        normals[3 * gv + 0] = normal.x;
+        normals[3 * gv + 1] = normal.y;
+        normals[3 * gv + 2] = normal.z;
+        vmats[gv] = make_uint4((uint32_t)vm.ind, (uint32_t)(vm.ind >> 32), (uint32_t)vm.wgt, (uint32_t)(vm.wgt >> 32));
     }
     __threadfence_block();
     __syncthreads();
@@ -494,14 +538,16 @@ __global__ __launch_bounds__(256) void k_sn_emit(SnParams p, const uint32_t* __r
     for (uint32_t v0 = 0; v0 < vcount; v0 += 256) {
         const uint32_t v = v0 + tid;
         uint32_t qm = 0;
-        int lin = 0, i = 0, j = 0, k = 0;
+        int cid = 0, i = 0, j = 0, k = 0;
         if (v < vcount) {
-            lin = s_surf[v];
-            i = lin / G2;
-            int r = lin - i * G2;
-            j = r / G;
-            k = r - j * G;
-            qm = quad_mask(s_sd, lin, i, j, k, upper);
+            cid = s_surf[v];
+            const int cr = cid / 17;
+            k = cid - cr * 17;
+            i = cr / 17;
+            j = cr - i * 17;
+            uint32_t vb, qx, qy, qz;
+            cube_row_bits(s_neg, i, j, upper, vb, qx, qy, qz);
+            qm = ((qx >> k) & 1u) | (((qy >> k) & 1u) << 1) | (((qz >> k) & 1u) << 2);
         }
         uint32_t total;
         uint32_t qoff = qbase + block_prefix(__popc(qm), s_wsum, tid, total);
@@ -509,13 +555,12 @@ __global__ __launch_bounds__(256) void k_sn_emit(SnParams p, const uint32_t* __r
 #pragma unroll
         for (int axis = 0; axis < 3; ++axis) {
             if (!((qm >> axis) & 1u)) continue;
-            const int p2o = axis == 0 ? G2 : (axis == 1 ? G : 1);
-            const int ab = axis == 0 ? G : (axis == 1 ? 1 : G2);
-            const int ac = axis == 0 ? 1 : (axis == 1 ? G2 : G);
-            const bool n1 = s_sd[lin] < 0;
-            (void)p2o;
+            // neighbouring cubes across the two other axes: (axis_b, axis_c) = (Y,Z), (Z,X), (X,Y)
+            const int ab = axis == 0 ? 17 : (axis == 1 ? 1 : 289);
+            const int ac = axis == 0 ? 1 : (axis == 1 ? 289 : 17);
+            const bool n1 = (int8_t)s_sd[tix(i, j, k)] < 0;
             const bool negative_face = !n1;  // (false,true) => negative face (surface_nets.rs:348-352)
-            const uint32_t v1 = s_map[lin], v2 = s_map[lin - ab], v3 = s_map[lin - ac], v4 = s_map[lin - ab - ac];
+            const uint32_t v1 = s_map[cid], v2 = s_map[cid - ab], v3 = s_map[cid - ac], v4 = s_map[cid - ab - ac];
             const float* P = positions + 3 * (size_t)voff;
             const V3 q1 = mk(P[3 * v1], P[3 * v1 + 1], P[3 * v1 + 2]), q2 = mk(P[3 * v2], P[3 * v2 + 1], P[3 * v2 + 2]);
             const V3 q3 = mk(P[3 * v3], P[3 * v3 + 1], P[3 * v3 + 2]), q4 = mk(P[3 * v4], P[3 * v4 + 1], P[3 * v4 + 2]);
