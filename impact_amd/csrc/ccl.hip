@@ -72,7 +72,7 @@ __device__ __forceinline__ uint32_t prefix_ordered(uint32_t val, uint32_t* s_wsu
 
 __global__ __launch_bounds__(256) void k_ccl_local(GridView g, const uint8_t* __restrict__ flags, uint8_t* __restrict__ labels,
                                                    ivx_chunk_info* __restrict__ info, uint32_t* __restrict__ rparent,
-                                                   uint32_t* __restrict__ rscalar) {
+                                                   uint32_t* __restrict__ rscalar, uint32_t* __restrict__ multi_list) {
     __shared__ uint32_t s_par[IVX_CHUNK_VOXELS];
     __shared__ uint32_t s_mask[256];
     __shared__ uint32_t s_touch[128];  // bit per voxel index: root touches the chunk boundary
@@ -87,15 +87,20 @@ __global__ __launch_bounds__(256) void k_ccl_local(GridView g, const uint8_t* __
     uint32_t* rp = rparent + (size_t)chunk * 256;
 
     uint32_t m = 0;
-    if (kind != KIND_VOID) m = flags_mask(*reinterpret_cast<const uint4*>(flags + base));
-    const int all_full = __syncthreads_and(m == 0xFFFFu);
-    const int any = __syncthreads_or(m != 0);
+    // a Void chunk has no voxels and a chunk generated Uniform is one solid region whether or not it was demoted
+    // since: neither needs its flags read
+    const uint32_t gen_kind = g.info[chunk].gen_kind;
+    const bool known = kind == KIND_VOID || gen_kind == KIND_UNIFORM;
+    if (!known) m = flags_mask(*reinterpret_cast<const uint4*>(flags + base));
+    const int all_full = known ? (kind != KIND_VOID) : __syncthreads_and(m == 0xFFFFu);
+    const int any = known ? (kind != KIND_VOID) : __syncthreads_or(m != 0);
     if (!any || all_full) {
         // no voxels, or one solid region touching every face
         const uint32_t lab = any ? 0u : 0xFFFFFFFFu;
         *reinterpret_cast<uint4*>(labels + base) = make_uint4(lab, lab, lab, lab);
-        rp[tid] = (any && tid == 0) ? chunk * 256u : NODE_NONE;
+        // only slots below region_count are ever read (flatten / assign / find walk valid nodes only)
         if (tid == 0) {
+            rp[0] = any ? chunk * 256u : NODE_NONE;
             info[chunk].region_count = any ? 1 : 0;
             info[chunk].boundary_region_count = any ? 1 : 0;
         }
@@ -192,10 +197,12 @@ __global__ __launch_bounds__(256) void k_ccl_local(GridView g, const uint8_t* __
         if (tid == 0) atomicOr(&rscalar[1], 1u);  // more regions than the reference's CHUNK_MAX_REGIONS allows
         total = 254u;
     }
-    rp[tid] = tid < total ? chunk * 256u + tid : NODE_NONE;
+    if (tid < total) rp[tid] = chunk * 256u + tid;
     if (tid == 0) {
         info[chunk].region_count = (uint8_t)total;
         info[chunk].boundary_region_count = (uint8_t)(nb_total < 254u ? nb_total : 254u);
+        // chunks with several regions get the reference's exact numbering from k_ccl_local_exact
+        if (total >= 2u) multi_list[atomicAdd(&rscalar[2], 1u)] = chunk;
     }
 }
 
@@ -221,13 +228,17 @@ __device__ __forceinline__ uint32_t seq_find(uint16_t* par, uint32_t x) {
 
 __global__ __launch_bounds__(64) void k_ccl_local_exact(GridView g, const uint8_t* __restrict__ flags, uint8_t* __restrict__ labels,
                                                         ivx_chunk_info* __restrict__ info, uint32_t* __restrict__ rparent,
-                                                        uint32_t* __restrict__ rscalar) {
+                                                        uint32_t* __restrict__ rscalar, const uint32_t* __restrict__ multi_list) {
     __shared__ uint16_t s_par[IVX_CHUNK_VOXELS];
     __shared__ uint8_t s_flg[IVX_CHUNK_VOXELS];
     __shared__ uint8_t s_lab[IVX_CHUNK_VOXELS];
     __shared__ uint32_t s_counts[2];
-    const uint32_t chunk = blockIdx.x, tid = threadIdx.x;
-    if (info[chunk].region_count < 2) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_multi = rscalar[2];
+    // bounded grid-stride walk over the (usually empty) list of multi-region chunks
+    for (uint32_t li = blockIdx.x; li < n_multi; li += gridDim.x) {
+    const uint32_t chunk = multi_list[li];
+    __syncthreads();
     const size_t base = (size_t)chunk * IVX_CHUNK_VOXELS;
     for (uint32_t i = tid; i < 256u; i += 64u) reinterpret_cast<uint4*>(s_flg)[i] = reinterpret_cast<const uint4*>(flags + base)[i];
     for (uint32_t i = tid; i < IVX_CHUNK_VOXELS; i += 64u) {
@@ -313,6 +324,7 @@ __global__ __launch_bounds__(64) void k_ccl_local_exact(GridView g, const uint8_
         info[chunk].region_count = (uint8_t)total;
         info[chunk].boundary_region_count = (uint8_t)(s_counts[0] < 254u ? s_counts[0] : 254u);
     }
+    }
 }
 
 // ---- level 2 ---------------------------------------------------------------------------------
@@ -343,7 +355,9 @@ __global__ __launch_bounds__(256) void k_ccl_merge(GridView g, const uint8_t* __
     const uint32_t tid = threadIdx.x;
     const uint32_t n_chunks = g.cx * g.cy * g.cz;
     const uint32_t chunk = ivx_xcd_remap(blockIdx.x, n_chunks);
-    if (g.info[chunk].region_count == 0) return;
+    const ivx_chunk_info oinfo = g.info[chunk];
+    if (oinfo.region_count == 0) return;
+    const uint32_t own_kind = oinfo.kind, own_fd = oinfo.face_dist, own_rc = oinfo.region_count;
     const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
     const int a = tid >> 4, b = tid & 15;
     const uint8_t* own = labels + (size_t)chunk * IVX_CHUNK_VOXELS;
@@ -352,7 +366,17 @@ __global__ __launch_bounds__(256) void k_ccl_merge(GridView g, const uint8_t* __
         const int ni = ci + (dim == 0), nj = cj + (dim == 1), nk = ck + (dim == 2);
         if (ni >= (int)g.cx || nj >= (int)g.cy || nk >= (int)g.cz) continue;
         const uint32_t nchunk = (ni * g.cy + nj) * g.cz + nk;
-        if (g.info[nchunk].region_count == 0) continue;
+        const ivx_chunk_info ninfo = g.info[nchunk];
+        if (ninfo.region_count == 0) continue;
+        // face distributions decide most pairs without touching the label planes: an Empty face joins nothing,
+        // two Full faces of single-region chunks join exactly (region 0, region 0)
+        const uint32_t fd_own = own_kind == KIND_UNIFORM ? (uint32_t)FD_FULL : ((own_fd >> (2 * (2 * dim + 1))) & 3u);
+        const uint32_t fd_nbr = ninfo.kind == KIND_UNIFORM ? (uint32_t)FD_FULL : (((uint32_t)ninfo.face_dist >> (2 * (2 * dim))) & 3u);
+        if (fd_own == FD_EMPTY || fd_nbr == FD_EMPTY) continue;
+        if (fd_own == FD_FULL && fd_nbr == FD_FULL && own_rc == 1 && ninfo.region_count == 1) {
+            if (tid == 0) g_union(rparent, chunk * 256u, nchunk * 256u);
+            continue;
+        }
         const uint8_t* nb = labels + (size_t)nchunk * IVX_CHUNK_VOXELS;
         uint32_t la, lb;
         if (dim == 0) {
@@ -373,75 +397,79 @@ __global__ __launch_bounds__(256) void k_ccl_merge(GridView g, const uint8_t* __
     }
 }
 
-// flatten the forest and count the roots per chunk
-__global__ __launch_bounds__(256) void k_ccl_flatten(GridView g, uint32_t* __restrict__ rparent, uint32_t* __restrict__ root_counts) {
-    const uint32_t tid = threadIdx.x;
-    const uint32_t chunk = blockIdx.x;
-    const uint32_t rc = g.info[chunk].region_count;
-    bool is_root = false;
-    if (tid < rc) {
-        const uint32_t node = chunk * 256u + tid;
+// flatten the forest and count the roots per chunk (one thread per chunk: almost every chunk has 0-2 regions)
+__global__ __launch_bounds__(256) void k_ccl_flatten(GridView g, uint32_t* __restrict__ rparent, uint32_t* __restrict__ root_counts,
+                                                     uint32_t* __restrict__ group_sums) {
+    __shared__ uint32_t s_w[4];
+    const uint32_t chunk = blockIdx.x * 256u + threadIdx.x;
+    const bool live = chunk < g.cx * g.cy * g.cz;
+    const uint32_t rc = live ? g.info[chunk].region_count : 0u;
+    uint32_t n = 0;
+    for (uint32_t r = 0; r < rc; ++r) {
+        const uint32_t node = chunk * 256u + r;
         const uint32_t root = g_find(rparent, node);
-        is_root = root == node;
-        // safe while other workgroups still walk the forest: the parent only moves closer to the root
-        if (!is_root) __hip_atomic_store(rparent + node, root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (root == node) n += 1;
+        // safe while other threads still walk the forest: the parent only moves closer to the root
+        else __hip_atomic_store(rparent + node, root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    const uint32_t n = __syncthreads_count(is_root ? 1 : 0);
-    if (tid == 0) root_counts[chunk] = n;
-}
-
-__global__ __launch_bounds__(1024) void k_scan_u32(uint32_t n, const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t* __restrict__ total) {
-    __shared__ uint32_t s[1024];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (n + 1023u) / 1024u;
-    const uint32_t c0 = min(tid * per, n), c1 = min(c0 + per, n);
-    uint32_t sum = 0;
-    for (uint32_t c = c0; c < c1; ++c) sum += in[c];
-    s[tid] = sum;
+    if (live) root_counts[chunk] = n;
+    // total of this group of 256 chunks (first level of the two-level scan)
+    uint32_t t = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+    if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = t;
     __syncthreads();
-    for (uint32_t o = 1; o < 1024; o <<= 1) {
-        uint32_t a = tid >= o ? s[tid - o] : 0u;
-        __syncthreads();
-        s[tid] += a;
-        __syncthreads();
-    }
-    uint32_t run = s[tid] - sum;
-    for (uint32_t c = c0; c < c1; ++c) {
-        out[c] = run;
-        run += in[c];
-    }
-    if (tid == 1023) *total = s[1023];
+    if (threadIdx.x == 0) group_sums[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
 
-// component ids: rank of the root node in (chunk, region) order; non-roots copy their root's id
+// Second level of the two-level exclusive scan: block b scans its 256 values on top of the sum of the group totals
+// before it (every block adds up those few totals itself, so there is no third launch).
+__global__ __launch_bounds__(256) void k_scan_groups(uint32_t n, const uint32_t* __restrict__ in, const uint32_t* __restrict__ group_sums,
+                                                     uint32_t* __restrict__ out, uint32_t* __restrict__ total) {
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_base;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t part = 0;
+    for (uint32_t b = tid; b < blockIdx.x; b += 256u) part += group_sums[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+    if (lane == 0) s_w[wave] = part;
+    __syncthreads();
+    if (tid == 0) s_base = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    __syncthreads();
+    const uint32_t base = s_base;
+    const uint32_t c = blockIdx.x * 256u + tid;
+    const uint32_t v = c < n ? in[c] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= (uint32_t)o) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63u) s_w[wave] = incl;
+    __syncthreads();
+    const uint32_t w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
+    const uint32_t wbase = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
+    if (c < n) out[c] = base + wbase + incl - v;
+    if (blockIdx.x == gridDim.x - 1 && tid == 255) *total = base + w0 + w1 + w2 + w3;
+}
+
+// component ids: rank of the root node in (chunk, region) order; a non-root takes the id of its root, computed from the
+// root's chunk offset and the root's rank among the roots of that chunk
 __global__ __launch_bounds__(256) void k_ccl_assign(GridView g, const uint32_t* __restrict__ rparent, const uint32_t* __restrict__ root_offsets,
                                                     uint32_t* __restrict__ rcompid) {
-    __shared__ uint32_t s_wsum[4];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t chunk = blockIdx.x;
+    const uint32_t chunk = blockIdx.x * 256u + threadIdx.x;
+    if (chunk >= g.cx * g.cy * g.cz) return;
     const uint32_t rc = g.info[chunk].region_count;
-    const uint32_t node = chunk * 256u + tid;
-    const bool is_root = tid < rc && rparent[node] == node;
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
-    const unsigned long long bal = __ballot(is_root);
-    const uint32_t pre = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) s_wsum[wave] = __popcll(bal);
-    __syncthreads();
-    uint32_t wb = 0;
-    for (uint32_t w = 0; w < wave; ++w) wb += s_wsum[w];
-    if (is_root) rcompid[node] = root_offsets[chunk] + wb + pre;
-    else if (tid < rc) rcompid[node] = NODE_NONE;  // filled by k_ccl_propagate
-    else rcompid[node] = NODE_NONE;
-}
-
-__global__ __launch_bounds__(256) void k_ccl_propagate(GridView g, const uint32_t* __restrict__ rparent, uint32_t* __restrict__ rcompid) {
-    const uint32_t tid = threadIdx.x;
-    const uint32_t chunk = blockIdx.x;
-    const uint32_t rc = g.info[chunk].region_count;
-    if (tid >= rc) return;
-    const uint32_t node = chunk * 256u + tid;
-    const uint32_t root = rparent[node];
-    if (root != node) rcompid[node] = rcompid[root];
+    for (uint32_t r = 0; r < rc; ++r) {
+        const uint32_t node = chunk * 256u + r;
+        const uint32_t root = rparent[node];  // flattened: the root itself
+        const uint32_t rchunk = root >> 8, rr = root & 255u;
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < rr; ++q) rank += rparent[rchunk * 256u + q] == rchunk * 256u + q;
+        rcompid[node] = root_offsets[rchunk] + rank;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_ccl_dense(uint32_t n_chunks, const uint8_t* __restrict__ labels, const uint32_t* __restrict__ rcompid,
@@ -619,8 +647,11 @@ __global__ __launch_bounds__(256) void k_region_stats(GridView g, uint32_t x_off
 int ivx_launch_ccl_local(ivx_grid* g) {
     GridView v = ivx_view(g);
     IVX_HIP_CHECK(hipMemsetAsync(g->rscalar, 0, 16 * sizeof(uint32_t), g->ctx->stream));
-    hipLaunchKernelGGL(k_ccl_local, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, v, g->flags, g->llabel, g->info, g->rparent, g->rscalar);
-    hipLaunchKernelGGL(k_ccl_local_exact, dim3(g->n_chunks), dim3(64), 0, g->ctx->stream, v, g->flags, g->llabel, g->info, g->rparent, g->rscalar);
+    uint32_t* multi_list = g->ccl_scratch;  // reused by the resolve pass afterwards
+    hipLaunchKernelGGL(k_ccl_local, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, v, g->flags, g->llabel, g->info, g->rparent, g->rscalar, multi_list);
+    const uint32_t exact_blocks = g->n_chunks < 2048u ? g->n_chunks : 2048u;
+    hipLaunchKernelGGL(k_ccl_local_exact, dim3(exact_blocks), dim3(64), 0, g->ctx->stream, v, g->flags, g->llabel, g->info, g->rparent, g->rscalar,
+                       multi_list);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -636,10 +667,11 @@ int ivx_launch_ccl_resolve(ivx_grid* g) {
     GridView v = ivx_view(g);
     uint32_t* root_counts = g->ccl_scratch;
     uint32_t* root_offsets = g->ccl_scratch + g->n_chunks;
-    hipLaunchKernelGGL(k_ccl_flatten, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, v, g->rparent, root_counts);
-    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, g->ctx->stream, g->n_chunks, root_counts, root_offsets, g->rscalar);
-    hipLaunchKernelGGL(k_ccl_assign, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, v, g->rparent, root_offsets, g->rcompid);
-    hipLaunchKernelGGL(k_ccl_propagate, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, v, g->rparent, g->rcompid);
+    const uint32_t nb = (g->n_chunks + 255u) / 256u;
+    uint32_t* group_sums = g->group_sums;
+    hipLaunchKernelGGL(k_ccl_flatten, dim3(nb), dim3(256), 0, g->ctx->stream, v, g->rparent, root_counts, group_sums);
+    hipLaunchKernelGGL(k_scan_groups, dim3(nb), dim3(256), 0, g->ctx->stream, g->n_chunks, root_counts, group_sums, root_offsets, g->rscalar);
+    hipLaunchKernelGGL(k_ccl_assign, dim3(nb), dim3(256), 0, g->ctx->stream, v, g->rparent, root_offsets, g->rcompid);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

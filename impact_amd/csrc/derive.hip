@@ -48,8 +48,39 @@ __global__ __launch_bounds__(256) void k_derive(GridView g, uint8_t* __restrict_
     const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
     const int ti = tid >> 4, tj = tid & 15;
 
-    if (tid < 12) cnt[tid] = 0;
     const size_t base = (size_t)chunk * IVX_CHUNK_VOXELS;
+    // Fast paths by chunk class (the 8-byte chunk records instead of the 4 KiB planes): a Void chunk has only
+    // EMPTY flags; a chunk generated Uniform whose six neighbours were generated Uniform too is solid all
+    // round. Neither needs a voxel read; both still write their flags plane.
+    {
+        const uint32_t gen = info[chunk].gen_kind;
+        bool fast = gen == KIND_VOID;
+        uint32_t fill = VF_EMPTY * 0x01010101u;
+        if (gen == KIND_UNIFORM) {
+            const bool inner = ci > 0 && cj > 0 && ck > 0 && ci + 1 < (int)g.cx && cj + 1 < (int)g.cy && ck + 1 < (int)g.cz;
+            if (inner) {
+                const uint32_t sx = g.cy * g.cz, sy = g.cz;
+                fast = info[chunk - sx].gen_kind == KIND_UNIFORM && info[chunk + sx].gen_kind == KIND_UNIFORM &&
+                       info[chunk - sy].gen_kind == KIND_UNIFORM && info[chunk + sy].gen_kind == KIND_UNIFORM &&
+                       info[chunk - 1].gen_kind == KIND_UNIFORM && info[chunk + 1].gen_kind == KIND_UNIFORM;
+                fill = 0xFCFCFCFCu;
+            }
+        }
+        if (fast) {  // uniform across the workgroup
+            *reinterpret_cast<uint4*>(flags_out + base + (size_t)tid * 16) = make_uint4(fill, fill, fill, fill);
+            if (tid == 0) {
+                ivx_chunk_info ci_ = info[chunk];
+                ci_.kind = (uint8_t)gen;
+                ci_.flags = 0;
+                ci_.face_dist = gen == KIND_UNIFORM ? 0x555 : 0;
+                ci_.uniform_type = gen == KIND_UNIFORM ? g.type[base] : (uint8_t)0;
+                info[chunk] = ci_;
+                bbox[chunk] = gen == KIND_UNIFORM ? (0x80000000u | (15u << 4) | (15u << 12) | (15u << 20)) : 0u;
+            }
+            return;
+        }
+    }
+    if (tid < 12) cnt[tid] = 0;
     const uint32_t m = row_mask(*reinterpret_cast<const uint4*>(g.sdf + base + (size_t)tid * 16));
     occ[ti + 1][tj + 1] = m;
 
@@ -197,37 +228,52 @@ __global__ __launch_bounds__(256) void k_derive(GridView g, uint8_t* __restrict_
 }
 
 // update_occupied_ranges (object.rs:1149-1280): tight [lo,hi) ranges of non-empty chunks and voxels from
-// the per-chunk boxes written by k_derive. out[0..6) chunk lo/hi per dim, out[6..12) voxel lo/hi per dim.
-__global__ __launch_bounds__(1024) void k_occupied_reduce(uint32_t cx, uint32_t cy, uint32_t cz, const uint32_t* __restrict__ bbox,
-                                                          uint32_t* __restrict__ out) {
+// the per-chunk boxes written by k_derive. raw[0..6) = minima (chunk lo xyz, voxel lo xyz), raw[6..12) = maxima
+// (chunk hi xyz, voxel hi xyz); the launcher presets them to 0xFFFFFFFF / 0.
+__global__ __launch_bounds__(256) void k_occupied_reduce(uint32_t cx, uint32_t cy, uint32_t cz, const uint32_t* __restrict__ bbox,
+                                                          uint32_t* __restrict__ raw) {
     __shared__ uint32_t red[12];
     const uint32_t tid = threadIdx.x;
-    if (tid < 12) red[tid] = (tid & 1) ? 0u : 0xFFFFFFFFu;
+    if (tid < 12) red[tid] = tid < 6 ? 0xFFFFFFFFu : 0u;
     __syncthreads();
-    uint32_t v[12];
-#pragma unroll
-    for (int q = 0; q < 12; ++q) v[q] = (q & 1) ? 0u : 0xFFFFFFFFu;
     const uint32_t n = cx * cy * cz;
-    for (uint32_t c = tid; c < n; c += 1024) {
-        const uint32_t p = bbox[c];
-        if (!(p & 0x80000000u)) continue;
-        const uint32_t ck = c % cz, cj = (c / cz) % cy, ci = c / (cz * cy);
-        const uint32_t cc[3] = {ci, cj, ck};
+    const uint32_t c = blockIdx.x * 256u + tid;
+    uint32_t p = c < n ? bbox[c] : 0u;
+    if (__syncthreads_or((int)(p >> 31))) {
+        uint32_t v[12];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            v[2 * d] = min(v[2 * d], cc[d]);
-            v[2 * d + 1] = max(v[2 * d + 1], cc[d] + 1);
-            v[6 + 2 * d] = min(v[6 + 2 * d], cc[d] * 16u + ((p >> (8 * d)) & 15u));
-            v[7 + 2 * d] = max(v[7 + 2 * d], cc[d] * 16u + ((p >> (8 * d + 4)) & 15u) + 1u);
+        for (int q = 0; q < 12; ++q) v[q] = q < 6 ? 0xFFFFFFFFu : 0u;
+        if (p & 0x80000000u) {
+            const uint32_t ck = c % cz, cj = (c / cz) % cy, ci = c / (cz * cy);
+            const uint32_t cc[3] = {ci, cj, ck};
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                v[d] = cc[d];
+                v[6 + d] = cc[d] + 1;
+                v[3 + d] = cc[d] * 16u + ((p >> (8 * d)) & 15u);
+                v[9 + d] = cc[d] * 16u + ((p >> (8 * d + 4)) & 15u) + 1u;
+            }
         }
-    }
+        // wave-level min/max first: the 12 LDS words would otherwise serialise every lane's atomics
 #pragma unroll
-    for (int q = 0; q < 12; ++q) {
-        if (q & 1) atomicMax(&red[q], v[q]);
-        else atomicMin(&red[q], v[q]);
+        for (int q = 0; q < 12; ++q) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t t = __shfl_xor(v[q], o, 64);
+                v[q] = q < 6 ? min(v[q], t) : max(v[q], t);
+            }
+        }
+        if ((tid & 63u) == 0) {
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                if (q < 6) atomicMin(&red[q], v[q]);
+                else atomicMax(&red[q], v[q]);
+            }
+        }
+        __syncthreads();
+        if (tid < 6) atomicMin(&raw[tid], red[tid]);
+        else if (tid < 12) atomicMax(&raw[tid], red[tid]);
     }
-    __syncthreads();
-    if (tid < 12) out[tid] = red[tid];
 }
 
 }  // namespace
@@ -239,8 +285,28 @@ int ivx_launch_derive(ivx_grid* g) {
     return IVX_OK;
 }
 
-int ivx_launch_occupied(ivx_grid* g, uint32_t* d_out) {
-    hipLaunchKernelGGL(k_occupied_reduce, dim3(1), dim3(1024), 0, g->ctx->stream, g->cc[0], g->cc[1], g->cc[2], g->chunk_bbox, d_out);
+int ivx_launch_occupied(ivx_grid* g, uint32_t* d_raw) {
+    IVX_HIP_CHECK(hipMemsetAsync(d_raw, 0xFF, 6 * sizeof(uint32_t), g->ctx->stream));
+    IVX_HIP_CHECK(hipMemsetAsync(d_raw + 6, 0, 6 * sizeof(uint32_t), g->ctx->stream));
+    hipLaunchKernelGGL(k_occupied_reduce, dim3((g->n_chunks + 255u) / 256u), dim3(256), 0, g->ctx->stream, g->cc[0], g->cc[1], g->cc[2], g->chunk_bbox, d_raw);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
+}
+
+// raw minima/maxima -> the public layout: chunk lo/hi x3, voxel lo/hi x3 (all zero for an empty object)
+void ivx_occupied_from_raw(const ivx_grid* g, const uint32_t raw[12], uint32_t out[12]) {
+    if (raw[6] == 0) {  // no non-empty voxel (object.rs:1177-1190)
+        for (int i = 0; i < 12; ++i) out[i] = 0;
+        return;
+    }
+    for (int d = 0; d < 3; ++d) {
+        out[2 * d] = raw[d];
+        out[2 * d + 1] = raw[6 + d];
+        out[6 + 2 * d] = raw[3 + d];
+        out[7 + 2 * d] = raw[9 + d];
+    }
+    out[0] += g->x_off;
+    out[1] += g->x_off;
+    out[6] += g->x_off * 16u;
+    out[7] += g->x_off * 16u;
 }

@@ -34,8 +34,32 @@ __global__ __launch_bounds__(256) void k_inertia(GridView g, uint32_t x_off, con
     double s[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t b = blockIdx.x; b < n_chunks; b += gridDim.x) {
         const uint32_t chunk = ivx_xcd_remap(b, n_chunks);
-        if (g.info[chunk].kind == KIND_VOID) continue;
+        const ivx_chunk_info cinfo = g.info[chunk];
+        if (cinfo.kind == KIND_VOID) continue;
         const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
+        if (cinfo.gen_kind == KIND_UNIFORM) {
+            // a chunk generated Uniform is 4096 voxels of one type (compute_moments_for_uniform_chunk,
+            // inertia.rs:703-754): the row sums are closed forms of the chunk's k range, no plane reads
+            const double d = (double)s_dens[g.type[(size_t)chunk * IVX_CHUNK_VOXELS]];
+            const double I = (double)((ci + (int)x_off) * 16 + ti), J = (double)(cj * 16 + tj), K0 = (double)(ck * 16);
+            const double qx = 2.0 * I + 1.0, qy = 2.0 * J + 1.0;
+            const double cx = 3.0 * I * I + 3.0 * I + 1.0, cy = 3.0 * J * J + 3.0 * J + 1.0;
+            // sum_{K=K0}^{K0+15} (2K+1) = 32 K0 + 256;  sum (3K^2+3K+1) = (K0+16)^3 - K0^3
+            const double D = 16.0 * d, Dz1 = d * (32.0 * K0 + 256.0);
+            const double K1 = K0 + 16.0;
+            const double Dz2 = d * (K1 * K1 * K1 - K0 * K0 * K0);
+            s[0] += D;
+            s[1] += D * qx;
+            s[2] += D * qy;
+            s[3] += Dz1;
+            s[4] += D * cy + Dz2;
+            s[5] += D * cx + Dz2;
+            s[6] += D * (cx + cy);
+            s[7] += D * qx * qy;
+            s[8] += qy * Dz1;
+            s[9] += qx * Dz1;
+            continue;
+        }
         const size_t o = (size_t)chunk * IVX_CHUNK_VOXELS + (size_t)tid * 16;
         const uint4 f = *reinterpret_cast<const uint4*>(flags + o);
         const uint4 t = *reinterpret_cast<const uint4*>(g.type + o);
@@ -76,40 +100,31 @@ __global__ __launch_bounds__(256) void k_inertia(GridView g, uint32_t x_off, con
     if (tid < 10) partials[(size_t)blockIdx.x * 10 + tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
 }
 
-// fixed-order (bitwise reproducible) reduction of the per-block partials: each of 256 threads sums a
-// strided subset in index order, then a fixed tree combines them
-__global__ __launch_bounds__(256) void k_inertia_final(uint32_t n_blocks, float extent, const double* __restrict__ partials, double* __restrict__ out) {
-    __shared__ double s_red[256];
-    const uint32_t tid = threadIdx.x;
-    for (int q = 0; q < 10; ++q) {
-        double s = 0.0;
-        for (uint32_t b = tid; b < n_blocks; b += 256) s += partials[(size_t)b * 10 + q];
-        s_red[tid] = s;
-        __syncthreads();
-        for (uint32_t o = 128; o > 0; o >>= 1) {
-            if (tid < o) s_red[tid] += s_red[tid + o];
-            __syncthreads();
-        }
-        if (tid == 0) {
-            const double e = (double)extent, e2 = e * e, e3 = e2 * e, e4 = e2 * e2, e5 = e4 * e;
-            const double f = q == 0 ? e3 : (q <= 3 ? 0.5 * e4 : (q <= 6 ? (1.0 / 3.0) * e5 : 0.25 * e5));
-            out[q] = s_red[0] * f;
-        }
-        __syncthreads();
+// fixed-order (bitwise reproducible) reduction of the per-block partials: wave q sums moment q — every lane a
+// strided subset in index order, then a fixed shuffle tree
+__global__ __launch_bounds__(640) void k_inertia_final(uint32_t n_blocks, float extent, const double* __restrict__ partials, double* __restrict__ out) {
+    const uint32_t q = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    double s = 0.0;
+    for (uint32_t b = lane; b < n_blocks; b += 64) s += partials[(size_t)b * 10 + q];
+    s = wave_sum(s);
+    if (lane == 0) {
+        const double e = (double)extent, e2 = e * e, e3 = e2 * e, e4 = e2 * e2, e5 = e4 * e;
+        const double f = q == 0 ? e3 : (q <= 3 ? 0.5 * e4 : (q <= 6 ? (1.0 / 3.0) * e5 : 0.25 * e5));
+        out[q] = s * f;
     }
 }
 
 }  // namespace
 
 int ivx_launch_inertia(ivx_grid* g, const float* d_dens, double* d_out10) {
-    uint32_t blocks = g->n_chunks < 2048u ? g->n_chunks : 2048u;
+    uint32_t blocks = g->n_chunks < 1024u ? g->n_chunks : 1024u;
     if (blocks > g->partial_blocks) {
         ivx_set_error("internal: partial buffer too small");
         return IVX_ERR_CAPACITY;
     }
     GridView v = ivx_view(g);
     hipLaunchKernelGGL(k_inertia, dim3(blocks), dim3(256), 0, g->ctx->stream, v, g->x_off, g->flags, d_dens, g->partials);
-    hipLaunchKernelGGL(k_inertia_final, dim3(1), dim3(256), 0, g->ctx->stream, blocks, g->extent, g->partials, d_out10);
+    hipLaunchKernelGGL(k_inertia_final, dim3(1), dim3(640), 0, g->ctx->stream, blocks, g->extent, g->partials, d_out10);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

@@ -223,6 +223,7 @@ int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32
     A(dev_alloc(&g->rcompid, (size_t)g->n_chunks * 256));
     A(dev_alloc(&g->rscalar, (size_t)64));
     A(dev_alloc(&g->ccl_scratch, (size_t)g->n_chunks * 2));
+    A(dev_alloc(&g->group_sums, (size_t)((g->n_chunks + 255u) / 256u) * 4 + 4));
     A(dev_alloc(&g->dens_dev, (size_t)256));
     if (rc != IVX_OK) {
         ivx_grid_destroy(g);
@@ -242,7 +243,7 @@ void ivx_grid_destroy(ivx_grid* g) {
     (void)hipStreamSynchronize(g->ctx->stream);
     void* ptrs[] = {g->sdf, g->type, g->flags, g->llabel, g->info, g->ghost_sdf[0], g->ghost_sdf[1], g->ghost_type[0], g->ghost_type[1],
                     g->ghost_info[0], g->ghost_info[1], g->chunk_counts, g->chunk_offsets, g->positions, g->normals, g->indices,
-                    g->index_materials, g->vertex_materials, g->submeshes, g->partials, g->rparent, g->rcompid, g->rscalar, g->ccl_scratch, g->dens_dev, g->dev_scratch, g->prog_nodes, g->chunk_bbox, g->samp_len, g->samp_ops};
+                    g->index_materials, g->vertex_materials, g->submeshes, g->partials, g->rparent, g->rcompid, g->rscalar, g->ccl_scratch, g->group_sums, g->dens_dev, g->dev_scratch, g->prog_nodes, g->chunk_bbox, g->samp_len, g->samp_ops};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->host_scratch) (void)hipHostFree(g->host_scratch);
@@ -345,15 +346,9 @@ int ivx_occupied_ranges(ivx_grid* g, uint32_t out[12]) {
     uint32_t* d = g->rscalar + 16;
     int rc;
     if ((rc = ivx_launch_occupied(g, d))) return rc;
-    if ((rc = d2h(g, out, d, 12 * sizeof(uint32_t)))) return rc;
-    if (out[1] == 0) {  // no non-empty voxel (object.rs:1177-1190)
-        for (int i = 0; i < 12; ++i) out[i] = 0;
-    } else {
-        out[0] += g->x_off;
-        out[1] += g->x_off;
-        out[6] += g->x_off * 16u;
-        out[7] += g->x_off * 16u;
-    }
+    uint32_t raw[12];
+    if ((rc = d2h(g, raw, d, 12 * sizeof(uint32_t)))) return rc;
+    ivx_occupied_from_raw(g, raw, out);
     return IVX_OK;
 }
 
@@ -599,8 +594,9 @@ static int complete_extracted(ivx_grid* parent, ivx_grid** pc, uint32_t origin[3
     if ((rc = ivx_launch_derive(c))) return rc;
     uint32_t* d_occ = c->rscalar + 16;
     if ((rc = ivx_launch_occupied(c, d_occ))) return rc;
-    uint32_t occ[12];
-    if ((rc = d2h(c, occ, d_occ, sizeof(occ)))) return rc;
+    uint32_t occ[12], occ_raw[12];
+    if ((rc = d2h(c, occ_raw, d_occ, sizeof(occ_raw)))) return rc;
+    ivx_occupied_from_raw(c, occ_raw, occ);
     float ones[256];
     for (float& x : ones) x = 1.0f;
     if ((rc = h2d(c, c->dens_dev, ones, sizeof(ones)))) return rc;
@@ -647,8 +643,9 @@ int ivx_clip_polyhedron(ivx_grid* parent, const float* planes4, size_t n_planes,
     // voxel_ranges_in_object_touching_aab (object/intersection.rs:693-782) of the AABB expanded by 2.54
     uint32_t* d_occ = parent->rscalar + 16;
     if ((rc = ivx_launch_occupied(parent, d_occ))) return rc;
-    uint32_t occ[12];
-    if ((rc = d2h(parent, occ, d_occ, sizeof(occ)))) return rc;
+    uint32_t occ[12], occ_raw[12];
+    if ((rc = d2h(parent, occ_raw, d_occ, sizeof(occ_raw)))) return rc;
+    ivx_occupied_from_raw(parent, occ_raw, occ);
     if (occ[1] == 0) return IVX_OK;
     uint32_t lo[3], cc[3];
     for (int q = 0; q < 3; ++q) {
@@ -840,15 +837,9 @@ int ivx_voxel_step(ivx_grid* g, uint32_t stages, ivx_step_result* out) {
         out->region_count = sc[0];
     }
     if (stages & IVX_STAGE_OCCUPIED) {
-        IVX_HIP_CHECK(hipMemcpy(out->occupied, d_occ, 12 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        if (out->occupied[1] == 0) {
-            for (int i = 0; i < 12; ++i) out->occupied[i] = 0;
-        } else {
-            out->occupied[0] += g->x_off;
-            out->occupied[1] += g->x_off;
-            out->occupied[6] += g->x_off * 16u;
-            out->occupied[7] += g->x_off * 16u;
-        }
+        uint32_t raw[12];
+        IVX_HIP_CHECK(hipMemcpy(raw, d_occ, 12 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        ivx_occupied_from_raw(g, raw, out->occupied);
     }
     if (stages & IVX_STAGE_INERTIA) {
         IVX_HIP_CHECK(hipMemcpy(out->moments.m64, g->partials + g->partial_blocks * 10, 10 * sizeof(double), hipMemcpyDeviceToHost));

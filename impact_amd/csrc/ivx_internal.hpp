@@ -78,6 +78,7 @@ struct ivx_grid {
     uint32_t* rcompid;   // [n_chunks*256] component id per node (after resolve)
     uint32_t* rscalar;   // small scalars: [0] region count, [1] error flags
     uint32_t* ccl_scratch;  // [2*n_chunks]: per-chunk root counts and exclusive offsets
+    uint32_t* group_sums;   // [4 * ceil(n_chunks/256)]: first-level totals of the two-level scans
     uint32_t region_count;
     int regions_valid;
     float* dens_dev;        // [256] voxel type densities
@@ -158,7 +159,8 @@ int ivx_launch_classify(ivx_grid* g);
 int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, uint32_t n_nodes, uint32_t stack_size,
                           const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type);
 int ivx_launch_derive(ivx_grid* g);
-int ivx_launch_occupied(ivx_grid* g, uint32_t* d_out);
+int ivx_launch_occupied(ivx_grid* g, uint32_t* d_raw);
+void ivx_occupied_from_raw(const ivx_grid* g, const uint32_t raw[12], uint32_t out[12]);
 int ivx_launch_sn_count(ivx_grid* g);
 int ivx_launch_sn_scan(ivx_grid* g);
 int ivx_launch_sn_emit(ivx_grid* g);

@@ -175,7 +175,7 @@ __device__ __forceinline__ void upper_limits(const GridView& g, int ci, int cj, 
     if (neighbour_kind(g, ci, cj, ck + 1) == KIND_NONUNIFORM) upper[2] -= 1;
 }
 
-__global__ __launch_bounds__(256) void k_sn_count(SnParams p, uint32_t* __restrict__ counts) {
+__global__ __launch_bounds__(256) void k_sn_count(SnParams p, uint32_t* __restrict__ counts, uint32_t* __restrict__ group_sums) {
     __shared__ uint32_t s_neg[NROWS];
     __shared__ uint32_t s_acc[2];
     const GridView& g = p.g;
@@ -209,61 +209,87 @@ __global__ __launch_bounds__(256) void k_sn_count(SnParams p, uint32_t* __restri
     if (tid == 0) {
         counts[2 * chunk] = s_acc[0];
         counts[2 * chunk + 1] = s_acc[1] * 6u;
+        if (s_acc[1]) {  // first level of the scan over chunks: totals per group of 256 chunks (vertices, indices, submeshes)
+            uint32_t* gs = group_sums + 3 * (chunk >> 8);
+            atomicAdd(gs, s_acc[0]);
+            atomicAdd(gs + 1, s_acc[1] * 6u);
+            atomicAdd(gs + 2, 1u);
+        }
     }
 }
 
 // Exclusive scan over chunks in chunk-linear order of (vertices, indices, submesh) with chunks whose
 // index count is zero contributing nothing (mesh.rs:321-323). offsets[2c], offsets[2c+1]; totals at
 // offsets[2n..2n+3); submesh rank at ranks[c].
-__global__ __launch_bounds__(1024) void k_sn_scan(uint32_t n_chunks, const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
-                                                  uint32_t* __restrict__ ranks) {
-    // each thread owns a contiguous run of chunks: local sums -> one block scan of 1024 partials -> write
-    __shared__ uint32_t s[3][1024];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (n_chunks + 1023u) / 1024u;
-    const uint32_t c0 = min(tid * per, n_chunks), c1 = min(c0 + per, n_chunks);
-    uint32_t sv = 0, si = 0, ss = 0;
-    for (uint32_t c = c0; c < c1; ++c) {
-        const uint32_t i = counts[2 * c + 1];
-        if (i) {
-            sv += counts[2 * c];
-            si += i;
-            ss += 1;
-        }
+__global__ __launch_bounds__(256) void k_sn_scan(uint32_t n_chunks, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ group_sums,
+                                                 uint32_t* __restrict__ offsets, uint32_t* __restrict__ ranks) {
+    // block b = chunks [256 b, 256 b + 256): base = totals of the groups before it, then an ordered block prefix
+    __shared__ uint32_t s_w[3][4];
+    __shared__ uint32_t s_base[3];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t p0 = 0, p1 = 0, p2 = 0;
+    for (uint32_t b = tid; b < blockIdx.x; b += 256u) {
+        p0 += group_sums[3 * b];
+        p1 += group_sums[3 * b + 1];
+        p2 += group_sums[3 * b + 2];
     }
-    s[0][tid] = sv;
-    s[1][tid] = si;
-    s[2][tid] = ss;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        p0 += __shfl_down(p0, o, 64);
+        p1 += __shfl_down(p1, o, 64);
+        p2 += __shfl_down(p2, o, 64);
+    }
+    if (lane == 0) {
+        s_w[0][wave] = p0;
+        s_w[1][wave] = p1;
+        s_w[2][wave] = p2;
+    }
     __syncthreads();
-    for (uint32_t o = 1; o < 1024; o <<= 1) {
-        uint32_t a0 = 0, a1 = 0, a2 = 0;
-        if (tid >= o) {
-            a0 = s[0][tid - o];
-            a1 = s[1][tid - o];
-            a2 = s[2][tid - o];
-        }
-        __syncthreads();
-        s[0][tid] += a0;
-        s[1][tid] += a1;
-        s[2][tid] += a2;
-        __syncthreads();
-    }
-    uint32_t rv = s[0][tid] - sv, ri = s[1][tid] - si, rs = s[2][tid] - ss;
-    for (uint32_t c = c0; c < c1; ++c) {
-        const uint32_t i = counts[2 * c + 1];
-        offsets[2 * c] = rv;
-        offsets[2 * c + 1] = ri;
-        ranks[c] = rs;
-        if (i) {
-            rv += counts[2 * c];
-            ri += i;
-            rs += 1;
+    if (tid < 3) s_base[tid] = (s_w[tid][0] + s_w[tid][1]) + (s_w[tid][2] + s_w[tid][3]);
+    __syncthreads();
+    const uint32_t b0 = s_base[0], b1 = s_base[1], b2 = s_base[2];
+    const uint32_t c = blockIdx.x * 256u + tid;
+    uint2 vi = make_uint2(0u, 0u);
+    if (c < n_chunks) vi = reinterpret_cast<const uint2*>(counts)[c];
+    const uint32_t on = vi.y != 0u;
+    const uint32_t sv = on ? vi.x : 0u, si = vi.y, ss = on;
+    uint32_t iv = sv, ii = si, is = ss;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t a0 = __shfl_up(iv, o, 64), a1 = __shfl_up(ii, o, 64), a2 = __shfl_up(is, o, 64);
+        if (lane >= (uint32_t)o) {
+            iv += a0;
+            ii += a1;
+            is += a2;
         }
     }
-    if (tid == 1023) {
-        offsets[2 * n_chunks] = s[0][1023];
-        offsets[2 * n_chunks + 1] = s[1][1023];
-        offsets[2 * n_chunks + 2] = s[2][1023];
+    __syncthreads();
+    if (lane == 63u) {
+        s_w[0][wave] = iv;
+        s_w[1][wave] = ii;
+        s_w[2][wave] = is;
+    }
+    __syncthreads();
+    uint32_t wv = 0, wi = 0, ws = 0, tv = 0, ti = 0, ts = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; ++w) {
+        if (w < wave) {
+            wv += s_w[0][w];
+            wi += s_w[1][w];
+            ws += s_w[2][w];
+        }
+        tv += s_w[0][w];
+        ti += s_w[1][w];
+        ts += s_w[2][w];
+    }
+    if (c < n_chunks) {
+        reinterpret_cast<uint2*>(offsets)[c] = make_uint2(b0 + wv + iv - sv, b1 + wi + ii - si);
+        ranks[c] = b2 + ws + is - ss;
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        offsets[2 * n_chunks] = b0 + tv;
+        offsets[2 * n_chunks + 1] = b1 + ti;
+        offsets[2 * n_chunks + 2] = b2 + ts;
     }
 }
 
@@ -604,15 +630,17 @@ static SnParams make_params(ivx_grid* g) {
 }
 
 int ivx_launch_sn_count(ivx_grid* g) {
-    hipLaunchKernelGGL(k_sn_count, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts);
+    const uint32_t groups = (g->n_chunks + 255u) / 256u;
+    IVX_HIP_CHECK(hipMemsetAsync(g->group_sums, 0, sizeof(uint32_t) * 3 * groups, g->ctx->stream));
+    hipLaunchKernelGGL(k_sn_count, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts, g->group_sums);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 
 int ivx_launch_sn_scan(ivx_grid* g) {
     // ranks are stored after the offsets/totals block
-    hipLaunchKernelGGL(k_sn_scan, dim3(1), dim3(1024), 0, g->ctx->stream, g->n_chunks, g->chunk_counts, g->chunk_offsets,
-                       g->chunk_offsets + 2 * (size_t)g->n_chunks + 4);
+    hipLaunchKernelGGL(k_sn_scan, dim3((g->n_chunks + 255u) / 256u), dim3(256), 0, g->ctx->stream, g->n_chunks, g->chunk_counts, g->group_sums,
+                       g->chunk_offsets, g->chunk_offsets + 2 * (size_t)g->n_chunks + 4);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
