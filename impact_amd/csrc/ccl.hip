@@ -70,27 +70,29 @@ __device__ __forceinline__ uint32_t prefix_ordered(uint32_t val, uint32_t* s_wsu
     return wbase + incl - val;
 }
 
+// Level 1, parallel part: decides for every chunk whether it holds 0, 1 or several regions. One region (the
+// overwhelmingly common case) needs no numbering: label 0 on every non-empty voxel. Chunks with several regions
+// go on a list for k_ccl_local_exact, which owns their labels, counts and region table.
+// Union-find over the RUNS of non-empty voxels along k (a thread owns the <= 8 runs of its 16-voxel row); the node of a
+// run is the voxel index of its first voxel, links go through LDS atomicMin (root = smallest index).
 __global__ __launch_bounds__(256) void k_ccl_local(GridView g, const uint8_t* __restrict__ flags, uint8_t* __restrict__ labels,
                                                    ivx_chunk_info* __restrict__ info, uint32_t* __restrict__ rparent,
                                                    uint32_t* __restrict__ rscalar, uint32_t* __restrict__ multi_list) {
     __shared__ uint32_t s_par[IVX_CHUNK_VOXELS];
     __shared__ uint32_t s_mask[256];
-    __shared__ uint32_t s_touch[128];  // bit per voxel index: root touches the chunk boundary
-    __shared__ uint8_t s_rid[IVX_CHUNK_VOXELS];
-    __shared__ uint32_t s_wsum[4];
     const uint32_t tid = threadIdx.x;
     const uint32_t n_chunks = g.cx * g.cy * g.cz;
     const uint32_t chunk = ivx_xcd_remap(blockIdx.x, n_chunks);
     const int ti = tid >> 4, tj = tid & 15;
     const size_t base = (size_t)chunk * IVX_CHUNK_VOXELS + (size_t)tid * 16;
-    const uint32_t kind = g.info[chunk].kind;
+    const ivx_chunk_info cinfo = g.info[chunk];
+    const uint32_t kind = cinfo.kind;
     uint32_t* rp = rparent + (size_t)chunk * 256;
 
     uint32_t m = 0;
     // a Void chunk has no voxels and a chunk generated Uniform is one solid region whether or not it was demoted
     // since: neither needs its flags read
-    const uint32_t gen_kind = g.info[chunk].gen_kind;
-    const bool known = kind == KIND_VOID || gen_kind == KIND_UNIFORM;
+    const bool known = kind == KIND_VOID || cinfo.gen_kind == KIND_UNIFORM;
     if (!known) m = flags_mask(*reinterpret_cast<const uint4*>(flags + base));
     const int all_full = known ? (kind != KIND_VOID) : __syncthreads_and(m == 0xFFFFu);
     const int any = known ? (kind != KIND_VOID) : __syncthreads_or(m != 0);
@@ -107,102 +109,76 @@ __global__ __launch_bounds__(256) void k_ccl_local(GridView g, const uint8_t* __
         return;
     }
 
-    // 1. runs along k inside the row
+    // 1. one node per run, keyed by the voxel index of its first voxel
     s_mask[tid] = m;
-    if (tid < 128) s_touch[tid] = 0;
+    const uint32_t starts = m & ~(m << 1);
     {
-        uint32_t run = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const uint32_t idx = tid * 16 + k;
-            const bool ne = (m >> k) & 1u;
-            const bool prev = k > 0 && ((m >> (k - 1)) & 1u);
-            if (ne && !prev) run = idx;
-            s_par[idx] = ne ? run : idx;
+        uint32_t r = starts;
+        while (r) {
+            const int k = __ffs(r) - 1;
+            r &= r - 1;
+            s_par[tid * 16 + k] = tid * 16 + k;
         }
     }
     __syncthreads();
-    // 2. join rows across +x and +y
+    // 2. join runs across +x and +y: one union per run of the overlap between the two rows
     {
         const uint32_t mx = ti < 15 ? s_mask[tid + 16] : 0u;
         const uint32_t my = tj < 15 ? s_mask[tid + 1] : 0u;
+        const uint32_t sx = mx & ~(mx << 1), sy = my & ~(my << 1);
         uint32_t bx = m & mx, by = m & my;
-        // one union per overlapping run pair is enough: take the first voxel of every run of the overlap
         bx &= ~(bx << 1);
         by &= ~(by << 1);
         while (bx) {
             const int k = __ffs(bx) - 1;
             bx &= bx - 1;
-            lds_union(s_par, tid * 16 + k, (tid + 16) * 16 + k);
+            const uint32_t lowk = (2u << k) - 1u;  // bits 0..k
+            const uint32_t a = tid * 16 + (31 - __clz(starts & lowk)), b = (tid + 16) * 16 + (31 - __clz(sx & lowk));
+            lds_union(s_par, a, b);
         }
         while (by) {
             const int k = __ffs(by) - 1;
             by &= by - 1;
-            lds_union(s_par, tid * 16 + k, (tid + 1) * 16 + k);
+            const uint32_t lowk = (2u << k) - 1u;
+            const uint32_t a = tid * 16 + (31 - __clz(starts & lowk)), b = (tid + 1) * 16 + (31 - __clz(sy & lowk));
+            lds_union(s_par, a, b);
         }
     }
     __syncthreads();
-    // 3. flatten + mark boundary-touching roots
-    uint32_t roots[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const uint32_t idx = tid * 16 + k;
-        roots[k] = ((m >> k) & 1u) ? lds_find(s_par, idx) : NODE_NONE;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        if (roots[k] != NODE_NONE) {
-            s_par[tid * 16 + k] = roots[k];
-            const bool on_boundary = ti == 0 || ti == 15 || tj == 0 || tj == 15 || k == 0 || k == 15;
-            if (on_boundary) atomicOr(&s_touch[roots[k] >> 5], 1u << (roots[k] & 31u));
+    // 3. count the roots; does any voxel lie on the chunk boundary?
+    uint32_t n_roots = 0;
+    {
+        uint32_t r = starts;
+        while (r) {
+            const int k = __ffs(r) - 1;
+            r &= r - 1;
+            n_roots += s_par[tid * 16 + k] == tid * 16 + (uint32_t)k;
         }
     }
+    const bool edge_row = ti == 0 || ti == 15 || tj == 0 || tj == 15;
+    const int touches = __syncthreads_or(edge_row ? (m != 0) : ((m & 0x8001u) != 0));
+    // (a root keeps itself as parent, every other node points somewhere else, so no flattening is needed to count)
+    __shared__ uint32_t s_cnt;
+    if (tid == 0) s_cnt = 0;
     __syncthreads();
-    // 4. number the regions: boundary-touching roots first, then interior roots, both in voxel-index order
-    uint32_t nb_row = 0, ni_row = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const uint32_t idx = tid * 16 + k;
-        if (roots[k] == idx) {
-            if ((s_touch[idx >> 5] >> (idx & 31u)) & 1u) nb_row += 1;
-            else ni_row += 1;
-        }
-    }
-    uint32_t nb_total, ni_total;
-    uint32_t nb_pre = prefix_ordered(nb_row, s_wsum, tid, nb_total);
-    uint32_t ni_pre = prefix_ordered(ni_row, s_wsum, tid, ni_total);
-    ni_pre += nb_total;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const uint32_t idx = tid * 16 + k;
-        if (roots[k] == idx) {
-            uint32_t id;
-            if ((s_touch[idx >> 5] >> (idx & 31u)) & 1u) id = nb_pre++;
-            else id = ni_pre++;
-            s_rid[idx] = (uint8_t)(id < 254u ? id : 254u);
-        }
-    }
+    if (n_roots) atomicAdd(&s_cnt, n_roots);
     __syncthreads();
-    // 5. per-voxel labels, region table
-    uint32_t w[4] = {0, 0, 0, 0};
+    const uint32_t rc = s_cnt;
+    if (rc == 1u) {
+        uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const uint32_t lab = roots[k] != NODE_NONE ? (uint32_t)s_rid[roots[k]] : 255u;
-        w[k >> 2] |= lab << (8 * (k & 3));
-    }
-    *reinterpret_cast<uint4*>(labels + base) = make_uint4(w[0], w[1], w[2], w[3]);
-    uint32_t total = nb_total + ni_total;
-    if (total > 254u) {
-        if (tid == 0) atomicOr(&rscalar[1], 1u);  // more regions than the reference's CHUNK_MAX_REGIONS allows
-        total = 254u;
-    }
-    if (tid < total) rp[tid] = chunk * 256u + tid;
-    if (tid == 0) {
-        info[chunk].region_count = (uint8_t)total;
-        info[chunk].boundary_region_count = (uint8_t)(nb_total < 254u ? nb_total : 254u);
-        // chunks with several regions get the reference's exact numbering from k_ccl_local_exact
-        if (total >= 2u) multi_list[atomicAdd(&rscalar[2], 1u)] = chunk;
+        for (int k = 0; k < 16; ++k)
+            if (!((m >> k) & 1u)) w[k >> 2] |= 0xFFu << (8 * (k & 3));
+        *reinterpret_cast<uint4*>(labels + base) = make_uint4(w[0], w[1], w[2], w[3]);
+        if (tid == 0) {
+            rp[0] = chunk * 256u;
+            info[chunk].region_count = 1;
+            info[chunk].boundary_region_count = touches ? 1 : 0;
+        }
+    } else if (tid == 0) {
+        // several regions: the reference's numbering is reproduced by k_ccl_local_exact
+        info[chunk].region_count = (uint8_t)(rc < 254u ? rc : 254u);
+        multi_list[atomicAdd(&rscalar[2], 1u)] = chunk;
     }
 }
 
