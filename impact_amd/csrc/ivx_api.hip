@@ -223,6 +223,7 @@ int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32
     A(dev_alloc(&g->rcompid, (size_t)g->n_chunks * 256));
     A(dev_alloc(&g->rscalar, (size_t)64));
     A(dev_alloc(&g->ccl_scratch, (size_t)g->n_chunks * 2));
+    A(dev_alloc(&g->sn_list, (size_t)g->n_chunks));
     A(dev_alloc(&g->group_sums, (size_t)((g->n_chunks + 255u) / 256u) * 4 + 4));
     A(dev_alloc(&g->dens_dev, (size_t)256));
     if (rc != IVX_OK) {
@@ -243,7 +244,7 @@ void ivx_grid_destroy(ivx_grid* g) {
     (void)hipStreamSynchronize(g->ctx->stream);
     void* ptrs[] = {g->sdf, g->type, g->flags, g->llabel, g->info, g->ghost_sdf[0], g->ghost_sdf[1], g->ghost_type[0], g->ghost_type[1],
                     g->ghost_info[0], g->ghost_info[1], g->chunk_counts, g->chunk_offsets, g->positions, g->normals, g->indices,
-                    g->index_materials, g->vertex_materials, g->submeshes, g->partials, g->rparent, g->rcompid, g->rscalar, g->ccl_scratch, g->group_sums, g->dens_dev, g->dev_scratch, g->prog_nodes, g->chunk_bbox, g->samp_len, g->samp_ops};
+                    g->index_materials, g->vertex_materials, g->submeshes, g->partials, g->rparent, g->rcompid, g->rscalar, g->ccl_scratch, g->group_sums, g->sn_list, g->dens_dev, g->dev_scratch, g->prog_nodes, g->chunk_bbox, g->samp_len, g->samp_ops};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->host_scratch) (void)hipHostFree(g->host_scratch);

@@ -78,6 +78,7 @@ struct ivx_grid {
     uint32_t* rcompid;   // [n_chunks*256] component id per node (after resolve)
     uint32_t* rscalar;   // small scalars: [0] region count, [1] error flags
     uint32_t* ccl_scratch;  // [2*n_chunks]: per-chunk root counts and exclusive offsets
+    uint32_t* sn_list;      // [n_chunks] chunks that emit a mesh this remesh (written by k_sn_count)
     uint32_t* group_sums;   // [4 * ceil(n_chunks/256)]: first-level totals of the two-level scans
     uint32_t region_count;
     int regions_valid;

@@ -267,7 +267,8 @@ __device__ __forceinline__ void load_node_tile(PaddedNode* tile, const ivx_sdf_p
 
 __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx_sdf_processed_node* __restrict__ nodes,
                                                        float* __restrict__ chunk_const, uint32_t* __restrict__ prog_len,
-                                                       uint2* __restrict__ prog_ops) {
+                                                       uint2* __restrict__ prog_ops, uint32_t* __restrict__ eval_count,
+                                                       uint32_t* __restrict__ eval_list) {
     __shared__ float s_lo[16][PRE_T];
     __shared__ float s_hi[16][PRE_T];
     __shared__ uint16_t s_start[16][PRE_T];  // op-stream position where each stack level's steps begin
@@ -388,8 +389,13 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
     if (cmask & 1u) out = lo;
     else if (lo >= 2.54f + 0.02f) out = 1000.0f;    // every voxel quantises to +127
     else if (hi <= -2.56f - 0.02f) out = -1000.0f;  // every voxel quantises to -128
-    chunk_const[chunk] = out;
-    prog_len[chunk] = pos <= OP_CAP ? pos : OP_OVERFLOW;
+    if (oi >= p.shape[0] || oj >= p.shape[1] || ok >= p.shape[2]) out = 1000.0f;  // beyond the generator's grid: all +127
+    if (blockIdx.x * PRE_T + tid < n_chunks) {  // (tail threads replay the last chunk: they must not list it twice)
+        chunk_const[chunk] = out;
+        prog_len[chunk] = pos <= OP_CAP ? pos : OP_OVERFLOW;
+        // chunks that need per-voxel evaluation go on a list for k_sdf_eval (order is irrelevant)
+        if (out != out) eval_list[atomicAdd(eval_count, 1u)] = chunk;
+    }
 }
 
 // ---- per-voxel evaluation ----------------------------------------------------------------------
@@ -469,38 +475,44 @@ __device__ __forceinline__ void combine_levels(uint32_t kind, float s, float q, 
     }
 }
 
-__global__ __launch_bounds__(256) void k_sdf_sample(SampleParams p, const float* __restrict__ chunk_const, const uint32_t* __restrict__ prog_len,
-                                                    const uint2* __restrict__ prog_ops, const ivx_sdf_processed_node* __restrict__ nodes,
-                                                    int8_t* __restrict__ sdf_out, uint8_t* __restrict__ type_out,
-                                                    ivx_chunk_info* __restrict__ info_out) {
-    extern __shared__ float stack[];  // [stack_size][16][256]
+// Chunks the pre-pass proved constant (and everything when the program is empty): no LDS, one 16-byte store per plane
+// and thread. Kept apart from k_sdf_eval so that these ~90 % of the workgroups are not throttled by the evaluator's
+// 48-64 KiB of LDS per workgroup.
+__global__ __launch_bounds__(256) void k_sdf_fill(SampleParams p, const float* __restrict__ chunk_const, int8_t* __restrict__ sdf_out,
+                                                  uint8_t* __restrict__ type_out, ivx_chunk_info* __restrict__ info_out) {
     const uint32_t tid = threadIdx.x;
     const uint32_t n_chunks = p.cx * p.cy * p.cz;
     const uint32_t chunk = ivx_xcd_remap(blockIdx.x, n_chunks);
     const uint32_t ck = chunk % p.cz, cj = (chunk / p.cz) % p.cy, ci = chunk / (p.cz * p.cy);
     const uint32_t oi = (ci + p.x_off) * 16u, oj = cj * 16u, ok = ck * 16u;
     const uint32_t ti = tid >> 4, tj = tid & 15u;
-
+    float cv = 1000.0f;
+    if (p.n_nodes != 0) cv = chunk_const[chunk];
+    if (cv != cv) return;  // evaluated by k_sdf_eval
     int sd[16];
-    if (p.n_nodes == 0 || oi >= p.shape[0] || oj >= p.shape[1] || ok >= p.shape[2]) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) sd[k] = 127;
-        classify_and_store(sd, make_uint4(0, 0, 0, 0), true, 0, sdf_out, type_out, info_out, chunk, tid, true, p.voxel_type);
-        return;
+    for (int k = 0; k < 16; ++k) {
+        bool in_grid = (oi + ti) < p.shape[0] && (oj + tj) < p.shape[1] && (ok + (uint32_t)k) < p.shape[2];
+        sd[k] = in_grid ? sd_from_f32(cv) : 127;
     }
+    classify_and_store(sd, make_uint4(0, 0, 0, 0), true, 0, sdf_out, type_out, info_out, chunk, tid, true, p.voxel_type);
+}
 
-    {
-        const float cv = chunk_const[chunk];
-        if (cv == cv) {  // the pre-pass proved the whole chunk to be one constant distance
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                bool in_grid = (oi + ti) < p.shape[0] && (oj + tj) < p.shape[1] && (ok + (uint32_t)k) < p.shape[2];
-                sd[k] = in_grid ? sd_from_f32(cv) : 127;
-            }
-            classify_and_store(sd, make_uint4(0, 0, 0, 0), true, 0, sdf_out, type_out, info_out, chunk, tid, true, p.voxel_type);
-            return;
-        }
-    }
+__global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t* __restrict__ eval_count, const uint32_t* __restrict__ eval_list,
+                                                  const uint32_t* __restrict__ prog_len, const uint2* __restrict__ prog_ops,
+                                                  const ivx_sdf_processed_node* __restrict__ nodes, int8_t* __restrict__ sdf_out,
+                                                  uint8_t* __restrict__ type_out, ivx_chunk_info* __restrict__ info_out) {
+    extern __shared__ float stack[];  // [stack_size][16][256]
+    const uint32_t tid = threadIdx.x;
+    const uint32_t ti = tid >> 4, tj = tid & 15u;
+    const uint32_t n_eval = eval_count[0];
+    // bounded grid-stride walk over the list of chunks to evaluate
+    for (uint32_t li = blockIdx.x; li < n_eval; li += gridDim.x) {
+    __syncthreads();  // the previous chunk's LDS use is over
+    const uint32_t chunk = eval_list[li];
+    const uint32_t ck = chunk % p.cz, cj = (chunk / p.cz) % p.cy, ci = chunk / (p.cz * p.cy);
+    const uint32_t oi = (ci + p.x_off) * 16u, oj = cj * 16u, ok = ck * 16u;
+    int sd[16];
 
     const V3 origin_root = sub(mk((float)oi, (float)oj, (float)ok), mk(p.shifted_center[0], p.shifted_center[1], p.shifted_center[2]));
     const Box block{origin_root, add(origin_root, mk(16.0f, 16.0f, 16.0f))};
@@ -622,6 +634,7 @@ __global__ __launch_bounds__(256) void k_sdf_sample(SampleParams p, const float*
         sd[k] = in_grid ? sd_from_f32(v) : 127;
     }
     classify_and_store(sd, make_uint4(0, 0, 0, 0), true, 0, sdf_out, type_out, info_out, chunk, tid, true, p.voxel_type);
+    }
 }
 
 // Classification of uploaded dense voxels (ChunkedVoxelGenerator contract, generation.rs:41-67).
@@ -660,15 +673,26 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
     p.voxel_type = voxel_type;
     size_t lds = (size_t)(stack_size ? stack_size : 1) * IVX_CHUNK_VOXELS * sizeof(float);
     IVX_REQUIRE(lds <= 150 * 1024, IVX_ERR_CAPACITY, "SDF graph needs a forward stack of %u blocks (at most 9 fit the 160 KiB LDS)", stack_size);
-    IVX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sdf_sample), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    IVX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sdf_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     float* chunk_const = reinterpret_cast<float*>(g->chunk_bbox);  // scratch: rewritten by ivx_derive_state afterwards
-    if (!g->samp_ops) {  // per-chunk compact programs (8 B x OP_CAP per chunk) + their lengths
-        IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_len), sizeof(uint32_t) * g->n_chunks));
+    if (!g->samp_ops) {  // per-chunk compact programs (8 B x OP_CAP per chunk) + their lengths, then [count, list of chunks to evaluate]
+        IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_len), sizeof(uint32_t) * (2 * (size_t)g->n_chunks + 4)));
         IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_ops), sizeof(uint2) * (size_t)OP_CAP * g->n_chunks));
     }
     uint2* ops = reinterpret_cast<uint2*>(g->samp_ops);
-    if (n_nodes) hipLaunchKernelGGL(k_sdf_prepass, dim3((g->n_chunks + PRE_T - 1) / PRE_T), dim3(PRE_T), 0, g->ctx->stream, p, d_nodes, chunk_const, g->samp_len, ops);
-    hipLaunchKernelGGL(k_sdf_sample, dim3(g->n_chunks), dim3(256), lds, g->ctx->stream, p, chunk_const, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info);
+    uint32_t* eval_count = g->samp_len + g->n_chunks;
+    uint32_t* eval_list = eval_count + 4;
+    if (n_nodes) {
+        IVX_HIP_CHECK(hipMemsetAsync(eval_count, 0, sizeof(uint32_t), g->ctx->stream));
+        hipLaunchKernelGGL(k_sdf_prepass, dim3((g->n_chunks + PRE_T - 1) / PRE_T), dim3(PRE_T), 0, g->ctx->stream, p, d_nodes, chunk_const, g->samp_len, ops,
+                           eval_count, eval_list);
+    }
+    hipLaunchKernelGGL(k_sdf_fill, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, p, chunk_const, g->sdf, g->type, g->info);
+    if (n_nodes) {
+        const uint32_t eval_blocks = g->n_chunks < 4096u ? g->n_chunks : 4096u;
+        hipLaunchKernelGGL(k_sdf_eval, dim3(eval_blocks), dim3(256), lds, g->ctx->stream, p, eval_count, eval_list, g->samp_len, ops, d_nodes, g->sdf, g->type,
+                           g->info);
+    }
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

@@ -175,7 +175,8 @@ __device__ __forceinline__ void upper_limits(const GridView& g, int ci, int cj, 
     if (neighbour_kind(g, ci, cj, ck + 1) == KIND_NONUNIFORM) upper[2] -= 1;
 }
 
-__global__ __launch_bounds__(256) void k_sn_count(SnParams p, uint32_t* __restrict__ counts, uint32_t* __restrict__ group_sums) {
+__global__ __launch_bounds__(256) void k_sn_count(SnParams p, uint32_t* __restrict__ counts, uint32_t* __restrict__ group_sums,
+                                                  uint32_t* __restrict__ emit_count, uint32_t* __restrict__ emit_list) {
     __shared__ uint32_t s_neg[NROWS];
     __shared__ uint32_t s_acc[2];
     const GridView& g = p.g;
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256) void k_sn_count(SnParams p, uint32_t* __restri
             atomicAdd(gs, s_acc[0]);
             atomicAdd(gs + 1, s_acc[1] * 6u);
             atomicAdd(gs + 2, 1u);
+            emit_list[atomicAdd(emit_count, 1u)] = chunk;  // chunks with a mesh, for k_sn_emit (order irrelevant)
         }
     }
 }
@@ -419,7 +421,8 @@ __device__ __forceinline__ void index_materials(const VMat vm[3], unsigned long 
 __global__ __launch_bounds__(256) void k_sn_emit(SnParams p, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
                                                  const uint32_t* __restrict__ ranks, float* __restrict__ positions, float* __restrict__ normals,
                                                  uint32_t* __restrict__ indices, unsigned long long* __restrict__ imats,
-                                                 uint4* __restrict__ vmats, ivx_submesh* __restrict__ submeshes) {
+                                                 uint4* __restrict__ vmats, ivx_submesh* __restrict__ submeshes, const uint32_t* __restrict__ emit_count,
+                                                 const uint32_t* __restrict__ emit_list) {
     __shared__ __attribute__((aligned(16))) uint8_t s_sd[TILE_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t s_ty[TILE_BYTES];
     __shared__ uint32_t s_neg[NROWS];
@@ -429,10 +432,12 @@ __global__ __launch_bounds__(256) void k_sn_emit(SnParams p, const uint32_t* __r
     __shared__ uint32_t s_wsum[4];
     const GridView& g = p.g;
     const uint32_t tid = threadIdx.x;
-    const uint32_t n_chunks = g.cx * g.cy * g.cz;
-    const uint32_t chunk = ivx_xcd_remap(blockIdx.x, n_chunks);
+    const uint32_t n_emit = emit_count[0];
+    // bounded grid-stride walk over the chunks that have a mesh
+    for (uint32_t li = blockIdx.x; li < n_emit; li += gridDim.x) {
+    __syncthreads();
+    const uint32_t chunk = emit_list[li];
     const uint32_t icount = counts[2 * chunk + 1];
-    if (icount == 0) return;
     const uint32_t vcount = counts[2 * chunk];
     const uint32_t voff = offsets[2 * chunk], ioff = offsets[2 * chunk + 1];
     const ivx_chunk_info info = g.info[chunk];
@@ -617,6 +622,7 @@ __global__ __launch_bounds__(256) void k_sn_emit(SnParams p, const uint32_t* __r
             qoff += 1;
         }
     }
+    }
 }
 
 }  // namespace
@@ -631,8 +637,9 @@ static SnParams make_params(ivx_grid* g) {
 
 int ivx_launch_sn_count(ivx_grid* g) {
     const uint32_t groups = (g->n_chunks + 255u) / 256u;
-    IVX_HIP_CHECK(hipMemsetAsync(g->group_sums, 0, sizeof(uint32_t) * 3 * groups, g->ctx->stream));
-    hipLaunchKernelGGL(k_sn_count, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts, g->group_sums);
+    IVX_HIP_CHECK(hipMemsetAsync(g->group_sums, 0, sizeof(uint32_t) * (3 * groups + 1), g->ctx->stream));
+    hipLaunchKernelGGL(k_sn_count, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts, g->group_sums,
+                       g->group_sums + 3 * groups, g->sn_list);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -646,9 +653,12 @@ int ivx_launch_sn_scan(ivx_grid* g) {
 }
 
 int ivx_launch_sn_emit(ivx_grid* g) {
-    hipLaunchKernelGGL(k_sn_emit, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts, g->chunk_offsets,
+    const uint32_t groups = (g->n_chunks + 255u) / 256u;
+    const uint32_t blocks = g->n_chunks < 4096u ? g->n_chunks : 4096u;
+    hipLaunchKernelGGL(k_sn_emit, dim3(blocks), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts, g->chunk_offsets,
                        g->chunk_offsets + 2 * (size_t)g->n_chunks + 4, g->positions, g->normals, g->indices,
-                       reinterpret_cast<unsigned long long*>(g->index_materials), reinterpret_cast<uint4*>(g->vertex_materials), g->submeshes);
+                       reinterpret_cast<unsigned long long*>(g->index_materials), reinterpret_cast<uint4*>(g->vertex_materials), g->submeshes,
+                       g->group_sums + 3 * groups, g->sn_list);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
