@@ -116,7 +116,7 @@ assert RIGID_BODY_DTYPE.itemsize == 152 and KINEMATIC_BODY_DTYPE.itemsize == 56 
 # every symbol include/impact_voxel_hip.h declares
 EXPORTED_SYMBOLS = [
     "ivx_init", "ivx_shutdown", "ivx_last_error", "ivx_synchronize", "ivx_stream",
-    "ivx_grid_create", "ivx_grid_destroy", "ivx_grid_upload_dense", "ivx_grid_download_dense", "ivx_grid_device_ptr", "ivx_grid_chunk_counts",
+    "ivx_grid_create", "ivx_grid_destroy", "ivx_grid_upload_dense", "ivx_grid_download_dense", "ivx_grid_device_ptr", "ivx_grid_chunk_counts", "ivx_grid_stage_counters",
     "ivx_sdf_compile", "ivx_sdf_grid_shape", "ivx_sdf_sample",
     "ivx_derive_state", "ivx_occupied_ranges",
     "ivx_remesh", "ivx_mesh_download", "ivx_mesh_device_ptr",
@@ -176,6 +176,7 @@ def lib():
         "ivx_grid_download_dense": (i32, [vp, vp, vp, vp, vp, vp, sz]),
         "ivx_grid_device_ptr": (vp, [vp, i32]),
         "ivx_grid_chunk_counts": (i32, [vp, vp]),
+        "ivx_grid_stage_counters": (i32, [vp, vp]),
         "ivx_sdf_compile": (i32, [vp, sz, u32, vp, sz, C.POINTER(sz), vp, C.POINTER(u32)]),
         "ivx_sdf_grid_shape": (i32, [vp, vp, vp]),
         "ivx_sdf_sample": (i32, [vp, vp, sz, u32, vp, vp, C.c_uint8]),

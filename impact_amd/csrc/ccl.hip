@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void k_region_stats(GridView g, uint32_t x_off
 
 int ivx_launch_ccl_local(ivx_grid* g) {
     GridView v = ivx_view(g);
-    IVX_HIP_CHECK(hipMemsetAsync(g->rscalar, 0, 16 * sizeof(uint32_t), g->ctx->stream));
+    if (!g->scratch_preset) IVX_HIP_CHECK(hipMemsetAsync(g->rscalar, 0, 16 * sizeof(uint32_t), g->ctx->stream));
     uint32_t* multi_list = g->ccl_scratch;  // reused by the resolve pass afterwards
     hipLaunchKernelGGL(k_ccl_local, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, v, g->flags, g->llabel, g->info, g->rparent, g->rscalar, multi_list);
     const uint32_t exact_blocks = g->n_chunks < 2048u ? g->n_chunks : 2048u;

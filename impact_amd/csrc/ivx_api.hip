@@ -284,6 +284,18 @@ int ivx_grid_chunk_counts(ivx_grid* g, uint32_t out[3]) {
     return IVX_OK;
 }
 
+int ivx_grid_stage_counters(ivx_grid* g, uint32_t out[4]) {
+    IVX_REQUIRE(g && out, IVX_ERR_INVALID, "ivx_grid_stage_counters: null argument");
+    for (int i = 0; i < 4; ++i) out[i] = 0;
+    int rc;
+    const uint32_t groups = (g->n_chunks + 255u) / 256u;
+    if (g->samp_len && (rc = d2h(g, &out[0], g->samp_len + g->n_chunks, sizeof(uint32_t)))) return rc;  // chunks evaluated per voxel by the sampler
+    if ((rc = d2h(g, &out[1], g->rscalar + 2, sizeof(uint32_t)))) return rc;                            // chunks with several local regions
+    if ((rc = d2h(g, &out[2], g->group_sums + groups + 3 * groups, sizeof(uint32_t)))) return rc;       // chunks that emitted a mesh
+    out[3] = g->n_chunks;
+    return IVX_OK;
+}
+
 void* ivx_grid_device_ptr(ivx_grid* g, int which) {
     if (!g) return nullptr;
     switch (which) {
@@ -779,6 +791,14 @@ int ivx_voxel_step(ivx_grid* g, uint32_t stages, ivx_step_result* out) {
     int rc;
     uint32_t* d_occ = g->rscalar + 16;
 #define EV(i) IVX_HIP_CHECK(hipEventRecord(g->ev[i], s))
+    if (stages & IVX_STAGE_SAMPLE)
+        if ((rc = ivx_sampler_buffers(g))) return rc;
+    if ((rc = ivx_launch_step_preset(g))) return rc;
+    g->scratch_preset = 1;
+    struct PresetGuard {
+        ivx_grid* g;
+        ~PresetGuard() { g->scratch_preset = 0; }
+    } preset_guard{g};
     EV(0);
     if (stages & IVX_STAGE_SAMPLE) {
         if ((rc = ivx_launch_sdf_sample(g, g->prog_nodes, g->prog_n, g->prog_stack, g->prog_shape, g->prog_center, g->prog_type))) return rc;

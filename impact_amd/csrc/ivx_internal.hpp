@@ -82,6 +82,7 @@ struct ivx_grid {
     uint32_t* group_sums;   // [4 * ceil(n_chunks/256)]: first-level totals of the two-level scans
     uint32_t region_count;
     int regions_valid;
+    int scratch_preset;  // inside ivx_voxel_step: k_step_preset already initialised the stages' scratch words
     float* dens_dev;        // [256] voxel type densities
     void* dev_scratch;      // grown on demand (node programs, dense label export, region statistics)
     size_t dev_scratch_bytes;
@@ -160,6 +161,8 @@ int ivx_launch_classify(ivx_grid* g);
 int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, uint32_t n_nodes, uint32_t stack_size,
                           const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type);
 int ivx_launch_derive(ivx_grid* g);
+int ivx_launch_step_preset(ivx_grid* g);
+int ivx_sampler_buffers(ivx_grid* g);
 int ivx_launch_occupied(ivx_grid* g, uint32_t* d_raw);
 void ivx_occupied_from_raw(const ivx_grid* g, const uint32_t raw[12], uint32_t out[12]);
 int ivx_launch_sn_count(ivx_grid* g);

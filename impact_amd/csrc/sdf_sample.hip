@@ -363,6 +363,19 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
                     emit(OP_CONST << 28, __float_as_uint(av));
                     continue;
                 }
+                // identity: a constant second operand that the first can never come within the smoothing distance of
+                // leaves the first operand unchanged, voxel for voxel (min/max picks it and h = 0), whether or not the
+                // reference applies the node — drop the operand and the combination from the chunk's program
+                if (c2) {
+                    bool ident;
+                    if (kind == 7u) ident = hi1 <= lo2 - s - slk;
+                    else if (kind == 9u) ident = lo1 >= lo2 + s + slk;
+                    else ident = lo1 >= -lo2 + s + slk;
+                    if (ident) {
+                        pos = s_start[top][tid];
+                        continue;
+                    }
+                }
                 emit(((must_apply ? OP_COMBINE : OP_COMBINE_OUTSIDE) << 28) | (kind << 24) | n, 0u);
                 float rlo, rhi;
                 if (kind == 8u) {  // subtraction: decreasing in the second operand
@@ -657,6 +670,13 @@ __global__ __launch_bounds__(256) void k_classify(uint32_t n_chunks, int8_t* __r
 
 }  // namespace
 
+int ivx_sampler_buffers(ivx_grid* g) {
+    if (g->samp_ops) return IVX_OK;
+    IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_len), sizeof(uint32_t) * (2 * (size_t)g->n_chunks + 4)));
+    IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_ops), sizeof(uint2) * (size_t)OP_CAP * g->n_chunks));
+    return IVX_OK;
+}
+
 int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, uint32_t n_nodes, uint32_t stack_size,
                           const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type) {
     SampleParams p;
@@ -675,15 +695,15 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
     IVX_REQUIRE(lds <= 150 * 1024, IVX_ERR_CAPACITY, "SDF graph needs a forward stack of %u blocks (at most 9 fit the 160 KiB LDS)", stack_size);
     IVX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sdf_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     float* chunk_const = reinterpret_cast<float*>(g->chunk_bbox);  // scratch: rewritten by ivx_derive_state afterwards
-    if (!g->samp_ops) {  // per-chunk compact programs (8 B x OP_CAP per chunk) + their lengths, then [count, list of chunks to evaluate]
-        IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_len), sizeof(uint32_t) * (2 * (size_t)g->n_chunks + 4)));
-        IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_ops), sizeof(uint2) * (size_t)OP_CAP * g->n_chunks));
+    {
+        int rc_b = ivx_sampler_buffers(g);
+        if (rc_b) return rc_b;
     }
     uint2* ops = reinterpret_cast<uint2*>(g->samp_ops);
     uint32_t* eval_count = g->samp_len + g->n_chunks;
     uint32_t* eval_list = eval_count + 4;
     if (n_nodes) {
-        IVX_HIP_CHECK(hipMemsetAsync(eval_count, 0, sizeof(uint32_t), g->ctx->stream));
+        if (!g->scratch_preset) IVX_HIP_CHECK(hipMemsetAsync(eval_count, 0, sizeof(uint32_t), g->ctx->stream));
         hipLaunchKernelGGL(k_sdf_prepass, dim3((g->n_chunks + PRE_T - 1) / PRE_T), dim3(PRE_T), 0, g->ctx->stream, p, d_nodes, chunk_const, g->samp_len, ops,
                            eval_count, eval_list);
     }

@@ -637,16 +637,17 @@ static SnParams make_params(ivx_grid* g) {
 
 int ivx_launch_sn_count(ivx_grid* g) {
     const uint32_t groups = (g->n_chunks + 255u) / 256u;
-    IVX_HIP_CHECK(hipMemsetAsync(g->group_sums, 0, sizeof(uint32_t) * (3 * groups + 1), g->ctx->stream));
-    hipLaunchKernelGGL(k_sn_count, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts, g->group_sums,
-                       g->group_sums + 3 * groups, g->sn_list);
+    uint32_t* gs = g->group_sums + groups;  // the first `groups` words belong to the region resolve
+    if (!g->scratch_preset) IVX_HIP_CHECK(hipMemsetAsync(gs, 0, sizeof(uint32_t) * (3 * groups + 1), g->ctx->stream));
+    hipLaunchKernelGGL(k_sn_count, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts, gs, gs + 3 * groups, g->sn_list);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 
 int ivx_launch_sn_scan(ivx_grid* g) {
     // ranks are stored after the offsets/totals block
-    hipLaunchKernelGGL(k_sn_scan, dim3((g->n_chunks + 255u) / 256u), dim3(256), 0, g->ctx->stream, g->n_chunks, g->chunk_counts, g->group_sums,
+    hipLaunchKernelGGL(k_sn_scan, dim3((g->n_chunks + 255u) / 256u), dim3(256), 0, g->ctx->stream, g->n_chunks, g->chunk_counts,
+                       g->group_sums + (g->n_chunks + 255u) / 256u,
                        g->chunk_offsets, g->chunk_offsets + 2 * (size_t)g->n_chunks + 4);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
@@ -658,7 +659,7 @@ int ivx_launch_sn_emit(ivx_grid* g) {
     hipLaunchKernelGGL(k_sn_emit, dim3(blocks), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts, g->chunk_offsets,
                        g->chunk_offsets + 2 * (size_t)g->n_chunks + 4, g->positions, g->normals, g->indices,
                        reinterpret_cast<unsigned long long*>(g->index_materials), reinterpret_cast<uint4*>(g->vertex_materials), g->submeshes,
-                       g->group_sums + 3 * groups, g->sn_list);
+                       g->group_sums + groups + 3 * groups, g->sn_list);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

@@ -202,6 +202,11 @@ class VoxelObject:
             self._region_count = int(out[0]["region_count"])
         return out[0]
 
+    def stage_counters(self):
+        out = np.zeros(4, dtype=np.uint32)
+        check(capi.lib().ivx_grid_stage_counters(self.h, ptr(out)))
+        return {"evaluated_chunks": int(out[0]), "multi_region_chunks": int(out[1]), "meshed_chunks": int(out[2]), "chunks": int(out[3])}
+
     # ---- derived state ----------------------------------------------------------------------
     def derive_state(self):
         check(capi.lib().ivx_derive_state(self.h))

@@ -121,6 +121,9 @@ int ivx_grid_upload_dense(ivx_grid*, const int8_t* sdf, const uint8_t* type, siz
 int ivx_grid_download_dense(ivx_grid*, int8_t* sdf, uint8_t* type, uint8_t* flags, uint8_t* local_labels, ivx_chunk_info* info,
                             size_t n_voxels);
 int ivx_grid_chunk_counts(ivx_grid*, uint32_t out[3]);
+/* diagnostics of the last step: chunks the sampler evaluated per voxel, chunks with several local regions, chunks that
+ * emitted a mesh, total chunks */
+int ivx_grid_stage_counters(ivx_grid*, uint32_t out[4]);
 /* device pointers of the planes: 0 sdf, 1 type, 2 flags, 3 local labels, 4 chunk info, 5 global region parents */
 void* ivx_grid_device_ptr(ivx_grid*, int which);
 
