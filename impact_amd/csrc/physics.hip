@@ -259,21 +259,15 @@ __global__ __launch_bounds__(256) void k_post_solve(uint32_t n_dyn, uint32_t n_k
 }
 
 // ---- the solve -----------------------------------------------------------------------------------
-__device__ __forceinline__ void apply_impulses(const PhysContact& p, PhysBody* cb, uint32_t n_dyn, V3 pb, float in, float it, float ib_) {
-    const V3 dp = (ld3(p.normal) * in + ld3(p.tangent) * it) + ld3(p.bitangent) * ib_;
-    PhysBody& a = cb[p.ia];
-    PhysBody& b = cb[p.ib];
-    if (p.ia < n_dyn) {
-        const V3 da = pb - ld3(a.pos);
-        st3(a.v, ld3(a.v) + dp * a.inv_mass);
-        st3(a.w, ld3(a.w) + mul(ldm(a.inv_inertia), cross(da, dp)));
-    }
-    if (p.ib < n_dyn) {
-        const V3 db = pb - ld3(b.pos);
-        st3(b.v, ld3(b.v) - dp * b.inv_mass);
-        st3(b.w, ld3(b.w) - mul(ldm(b.inv_inertia), cross(db, dp)));
-    }
-}
+// An item is a CHAIN: up to 15 contacts that follow each other in the solve order and act on the same pair of bodies
+// (the contact points of one manifold). No other constraint can come between them, so one thread runs them back to back
+// with the pair's state in registers — a quarter of the levels for four-point manifolds, and no barrier inside a manifold.
+// item word: bits 0-23 first contact slot, 24-27 chain length, 28-31 type.
+struct PairState {  // the part of the two bodies a phase changes
+    V3 va, wa, vb, wb;  // velocity phase
+    V3 pa, pb;          // positional phase
+    Q4 qa, qb;
+};
 
 __device__ __forceinline__ Q4 pseudo_advanced(Q4 q, V3 w) {  // contact.rs:835-843, quantities.rs:372-378
     const V3 h = w * 0.5f;
@@ -281,40 +275,57 @@ __device__ __forceinline__ Q4 pseudo_advanced(Q4 q, V3 w) {  // contact.rs:835-8
     return qnormalize(Q4{q.x + d.x, q.y + d.y, q.z + d.z, q.w + d.w});
 }
 
-__device__ __forceinline__ void run_item(uint32_t item, uint32_t n_dyn, float factor, const PhysContact* __restrict__ pcs, float4* __restrict__ accs,
-                                         PhysBody* __restrict__ cb) {
-    const uint32_t s = item & 0x0FFFFFFFu, type = item >> 28;
-    const PhysContact p = pcs[s];
-    PhysBody& a = cb[p.ia];
-    PhysBody& b = cb[p.ib];
+struct PairStatic {
+    float ima, imb;
+    M3 iia, iib;
+    V3 pos_a, pos_b;  // velocity phase only (configuration is fixed there)
+    Q4 q_b;
+    bool dyn_a, dyn_b;
+};
+
+__device__ __forceinline__ void apply_pair(const PhysContact& p, const PairStatic& st, PairState& x, V3 pb, float in, float it, float ib_) {
+    const V3 dp = (ld3(p.normal) * in + ld3(p.tangent) * it) + ld3(p.bitangent) * ib_;
+    if (st.dyn_a) {
+        const V3 da = pb - st.pos_a;
+        x.va = x.va + dp * st.ima;
+        x.wa = x.wa + mul(st.iia, cross(da, dp));
+    }
+    if (st.dyn_b) {
+        const V3 db = pb - st.pos_b;
+        x.vb = x.vb - dp * st.imb;
+        x.wb = x.wb - mul(st.iib, cross(db, dp));
+    }
+}
+
+// one contact of a chain; `type` is uniform over the chain
+__device__ __forceinline__ void run_contact(uint32_t type, const PhysContact& p, const PairStatic& st, PairState& x, float factor, float4* __restrict__ acc_slot) {
     if (type == PHYS_ITEM_POSITIONAL) {
         const V3 n = ld3(p.normal);
-        const V3 pa = to_world(a.pos, a.q, ld3(p.local_a)), pb = to_world(b.pos, b.q, ld3(p.local_b));
+        const V3 pa = qrot(x.qa, ld3(p.local_a)) + x.pa, pb = qrot(x.qb, ld3(p.local_b)) + x.pb;
         const float depth = dot(n, pb - pa);
         if (depth <= 0.0f) return;
-        const V3 da = pb - ld3(a.pos), db = pb - ld3(b.pos);
-        const M3 iia = ldm(a.inv_inertia), iib = ldm(b.inv_inertia);
-        const float m = effective_mass(a.inv_mass, iia, b.inv_mass, iib, da, db, n);
+        const V3 da = pb - x.pa, db = pb - x.pb;
+        const float m = effective_mass(st.ima, st.iia, st.imb, st.iib, da, db, n);
         const V3 dp = n * (m * factor * depth);
-        if (p.ia < n_dyn) {
-            st3(a.pos, ld3(a.pos) + dp * a.inv_mass);
-            stq(a.q, pseudo_advanced(ldq(a.q), mul(iia, cross(da, dp))));
+        if (st.dyn_a) {
+            x.pa = x.pa + dp * st.ima;
+            x.qa = pseudo_advanced(x.qa, mul(st.iia, cross(da, dp)));
         }
-        if (p.ib < n_dyn) {
-            st3(b.pos, ld3(b.pos) + dp * (-b.inv_mass));
-            stq(b.q, pseudo_advanced(ldq(b.q), mul(M3{-iib.c0, -iib.c1, -iib.c2}, cross(db, dp))));
+        if (st.dyn_b) {
+            x.pb = x.pb + dp * (-st.imb);
+            x.qb = pseudo_advanced(x.qb, mul(M3{-st.iib.c0, -st.iib.c1, -st.iib.c2}, cross(db, dp)));
         }
         return;
     }
-    const V3 pb = to_world(b.pos, b.q, ld3(p.local_b));
-    float4 acc = accs[s];
+    const V3 pb = qrot(st.q_b, ld3(p.local_b)) + st.pos_b;
+    const float4 acc = *acc_slot;
     if (type == PHYS_ITEM_WARM) {
-        apply_impulses(p, cb, n_dyn, pb, acc.x, acc.y, acc.z);
+        apply_pair(p, st, x, pb, acc.x, acc.y, acc.z);
         return;
     }
     // compute_impulses -> clamp -> apply the difference (solver.rs:496-528)
-    const V3 da = pb - ld3(a.pos), db = pb - ld3(b.pos);
-    const V3 rel = point_velocity(ld3(a.v), ld3(a.w), da) - point_velocity(ld3(b.v), ld3(b.w), db);
+    const V3 da = pb - st.pos_a, db = pb - st.pos_b;
+    const V3 rel = point_velocity(x.va, x.wa, da) - point_velocity(x.vb, x.wb, db);
     const float sep = dot(ld3(p.normal), rel);
     const float cn = -p.m_n * (sep - p.target), ct = -p.m_t * dot(ld3(p.tangent), rel), cbi = -p.m_b * dot(ld3(p.bitangent), rel);
     const float un = acc.x + cn, ut = acc.y + ct, ub = acc.z + cbi;
@@ -323,26 +334,154 @@ __device__ __forceinline__ void run_item(uint32_t item, uint32_t n_dyn, float fa
     const float mag = sqrtf(ut * ut + ub * ub);
     const float sc = mag > max_t ? max_t / mag : 1.0f;
     const float nt = ut * sc, nb = ub * sc;
-    accs[s] = make_float4(nn, nt, nb, 0.0f);
-    apply_impulses(p, cb, n_dyn, pb, nn - acc.x, nt - acc.y, nb - acc.z);
+    *acc_slot = make_float4(nn, nt, nb, 0.0f);
+    apply_pair(p, st, x, pb, nn - acc.x, nt - acc.y, nb - acc.z);
 }
 
-__global__ __launch_bounds__(1024) void k_solve(uint32_t n_dyn, float factor, const PhysContact* __restrict__ pcs, float4* __restrict__ accs,
-                                                PhysBody* __restrict__ cb, const uint32_t* __restrict__ items,
+// LDS = true: the phase's mutable state of the dynamic bodies lives in s_dyn (velocity: 6 floats v,w; positional: 7 floats
+// position, orientation); false: in the PhysBody array in HBM. The prepared contacts (and accumulated impulses) of a chain are
+// fetched four at a time so that their HBM latencies overlap each other and the loads of the pair's static data.
+template <bool LDS, int PHASE>
+__device__ __forceinline__ void run_chain(uint32_t item, uint2 bodies, uint32_t n_dyn, float factor, const PhysContact* __restrict__ pcs,
+                                          float4* __restrict__ accs, PhysBody* __restrict__ cb, float* s_dyn) {
+    const uint32_t s0 = item & 0x00FFFFFFu, len = (item >> 24) & 15u, type = item >> 28;
+    const uint32_t ia = bodies.x, ib = bodies.y;
+    PhysContact p[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if ((uint32_t)c < len) p[c] = pcs[s0 + c];
+    const PhysBody& A = cb[ia];
+    const PhysBody& B = cb[ib];
+    PairStatic st;
+    st.ima = A.inv_mass;
+    st.imb = B.inv_mass;
+    st.iia = ldm(A.inv_inertia);
+    st.iib = ldm(B.inv_inertia);
+    st.dyn_a = ia < n_dyn;
+    st.dyn_b = ib < n_dyn;
+    PairState x;
+    if (PHASE == 0) {
+        st.pos_a = ld3(A.pos);
+        st.pos_b = ld3(B.pos);
+        st.q_b = ldq(B.q);
+        if (LDS && st.dyn_a) {
+            x.va = ld3(s_dyn + 6 * ia);
+            x.wa = ld3(s_dyn + 6 * ia + 3);
+        } else {
+            x.va = ld3(A.v);
+            x.wa = ld3(A.w);
+        }
+        if (LDS && st.dyn_b) {
+            x.vb = ld3(s_dyn + 6 * ib);
+            x.wb = ld3(s_dyn + 6 * ib + 3);
+        } else {
+            x.vb = ld3(B.v);
+            x.wb = ld3(B.w);
+        }
+    } else {
+        if (LDS && st.dyn_a) {
+            x.pa = ld3(s_dyn + 7 * ia);
+            x.qa = ldq(s_dyn + 7 * ia + 3);
+        } else {
+            x.pa = ld3(A.pos);
+            x.qa = ldq(A.q);
+        }
+        if (LDS && st.dyn_b) {
+            x.pb = ld3(s_dyn + 7 * ib);
+            x.qb = ldq(s_dyn + 7 * ib + 3);
+        } else {
+            x.pb = ld3(B.pos);
+            x.qb = ldq(B.q);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if ((uint32_t)c < len) run_contact(type, p[c], st, x, factor, accs + s0 + c);
+    for (uint32_t c = 4; c < len; ++c) {  // manifolds with more than four points
+        const PhysContact q = pcs[s0 + c];
+        run_contact(type, q, st, x, factor, accs + s0 + c);
+    }
+    if (PHASE == 0) {
+        if (st.dyn_a) {
+            float* d = LDS ? s_dyn + 6 * ia : cb[ia].v;
+            st3(d, x.va);
+            st3(LDS ? d + 3 : cb[ia].w, x.wa);
+        }
+        if (st.dyn_b) {
+            float* d = LDS ? s_dyn + 6 * ib : cb[ib].v;
+            st3(d, x.vb);
+            st3(LDS ? d + 3 : cb[ib].w, x.wb);
+        }
+    } else {
+        if (st.dyn_a) {
+            st3(LDS ? s_dyn + 7 * ia : cb[ia].pos, x.pa);
+            stq(LDS ? s_dyn + 7 * ia + 3 : cb[ia].q, x.qa);
+        }
+        if (st.dyn_b) {
+            st3(LDS ? s_dyn + 7 * ib : cb[ib].pos, x.pb);
+            stq(LDS ? s_dyn + 7 * ib + 3 : cb[ib].q, x.qb);
+        }
+    }
+}
+
+// 512 threads: a chain keeps ~150 values live (pair state, statics, the prepared contact); 1024 threads would cap the
+// kernel at 128 VGPRs and spill a third of them to scratch
+constexpr uint32_t SOLVE_THREADS = 512u;
+template <bool LDS, int PHASE>
+__global__ __launch_bounds__(SOLVE_THREADS) void k_solve(uint32_t n_dyn, float factor, const PhysContact* __restrict__ pcs, float4* __restrict__ accs,
+                                                PhysBody* __restrict__ cb, const uint32_t* __restrict__ items, const uint2* __restrict__ item_bodies,
                                                 const uint32_t* __restrict__ level_start, uint32_t n_levels) {
+    extern __shared__ float s_dyn[];
     __shared__ uint32_t s_start[PHYS_LEVEL_TILE + 1];
     const uint32_t tid = threadIdx.x;
+    if (LDS)
+        for (uint32_t i = tid; i < n_dyn; i += SOLVE_THREADS) {
+            const PhysBody& b = cb[i];
+            if (PHASE == 0) {
+                st3(s_dyn + 6 * i, ld3(b.v));
+                st3(s_dyn + 6 * i + 3, ld3(b.w));
+            } else {
+                st3(s_dyn + 7 * i, ld3(b.pos));
+                stq(s_dyn + 7 * i + 3, ldq(b.q));
+            }
+        }
     for (uint32_t l0 = 0; l0 < n_levels; l0 += PHYS_LEVEL_TILE) {
         const uint32_t cnt = min((uint32_t)PHYS_LEVEL_TILE, n_levels - l0);
         __syncthreads();
-        for (uint32_t i = tid; i <= cnt; i += 1024u) s_start[i] = level_start[l0 + i];
+        for (uint32_t i = tid; i <= cnt; i += SOLVE_THREADS) s_start[i] = level_start[l0 + i];
         __syncthreads();
+        // the item word and body pair of this thread's first chain of the next level are fetched one level ahead
+        uint32_t nxt_item = 0;
+        uint2 nxt_bodies = make_uint2(0u, 0u);
+        if (s_start[0] + tid < s_start[1]) {
+            nxt_item = items[s_start[0] + tid];
+            nxt_bodies = item_bodies[s_start[0] + tid];
+        }
         for (uint32_t l = 0; l < cnt; ++l) {
-            const uint32_t e = s_start[l + 1];
-            for (uint32_t i = s_start[l] + tid; i < e; i += 1024u) run_item(items[i], n_dyn, factor, pcs, accs, cb);
+            const uint32_t b = s_start[l], e = s_start[l + 1];
+            const uint32_t cur_item = nxt_item;
+            const uint2 cur_bodies = nxt_bodies;
+            if (l + 1 < cnt && e + tid < s_start[l + 2]) {
+                nxt_item = items[e + tid];
+                nxt_bodies = item_bodies[e + tid];
+            }
+            if (b + tid < e) run_chain<LDS, PHASE>(cur_item, cur_bodies, n_dyn, factor, pcs, accs, cb, s_dyn);
+            for (uint32_t i = b + tid + SOLVE_THREADS; i < e; i += SOLVE_THREADS)
+                run_chain<LDS, PHASE>(items[i], item_bodies[i], n_dyn, factor, pcs, accs, cb, s_dyn);
             __syncthreads();  // workgroup-scope release/acquire of the body state before the next level
         }
     }
+    if (LDS)
+        for (uint32_t i = tid; i < n_dyn; i += SOLVE_THREADS) {
+            PhysBody& b = cb[i];
+            if (PHASE == 0) {
+                st3(b.v, ld3(s_dyn + 6 * i));
+                st3(b.w, ld3(s_dyn + 6 * i + 3));
+            } else {
+                st3(b.pos, ld3(s_dyn + 7 * i));
+                stq(b.q, ldq(s_dyn + 7 * i + 3));
+            }
+        }
 }
 
 }  // namespace
@@ -371,15 +510,32 @@ int ivx_launch_phys_pre_solve(ivx_world* w, float dt) {
     return IVX_OK;
 }
 
+template <bool LDS, int PHASE>
+static int launch_solve(ivx_world* w, size_t lds) {
+    if (LDS) IVX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve<LDS, PHASE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_solve<LDS, PHASE>), dim3(1), dim3(SOLVE_THREADS), LDS ? lds : 0, w->ctx->stream, w->n_dyn, w->cfg.positional_correction_factor, w->pc[w->cur],
+                       reinterpret_cast<float4*>(w->acc[w->cur]), w->cb, w->items + w->item_offset[PHASE],
+                       reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], w->level_start + w->level_offset[PHASE],
+                       w->n_levels[PHASE]);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
 int ivx_launch_phys_solve(ivx_world* w) {
     if (w->n_contacts == 0) return IVX_OK;
-    for (int phase = 0; phase < 2; ++phase) {
-        if (w->n_levels[phase] == 0) continue;
-        hipLaunchKernelGGL(k_solve, dim3(1), dim3(1024), 0, w->ctx->stream, w->n_dyn, w->cfg.positional_correction_factor, w->pc[w->cur],
-                           reinterpret_cast<float4*>(w->acc[w->cur]), w->cb, w->items + w->item_offset[phase], w->level_start + w->level_offset[phase],
-                           w->n_levels[phase]);
+    int rc;
+    // the phase's mutable body state (24 / 28 bytes per dynamic body) goes to LDS when it fits one CU
+    const size_t lds0 = (size_t)w->n_dyn * 24, lds1 = (size_t)w->n_dyn * 28;
+    if (w->n_levels[0]) {
+        if (lds0 <= 140 * 1024) rc = launch_solve<true, 0>(w, lds0);
+        else rc = launch_solve<false, 0>(w, 0);
+        if (rc) return rc;
     }
-    IVX_HIP_CHECK(hipGetLastError());
+    if (w->n_levels[1]) {
+        if (lds1 <= 140 * 1024) rc = launch_solve<true, 1>(w, lds1);
+        else rc = launch_solve<false, 1>(w, 0);
+        if (rc) return rc;
+    }
     return IVX_OK;
 }
 

@@ -132,14 +132,28 @@ int fetch_body_position(ivx_world* w, uint32_t ref, float out[3]) {
     return IVX_OK;
 }
 
-// Dependency levels of the item sequence (pass-major, contacts in cache order inside a pass); items of
-// one level touch pairwise different dynamic bodies. Appends to items/level_start.
+// Chains: maximal runs (<= 15) of contacts that are consecutive in the solve order and act on the same (body_a, body_b).
+void build_chains(ivx_world* w) {
+    w->chain_start.clear();
+    const uint32_t n = w->n_contacts;
+    uint32_t s = 0;
+    while (s < n) {
+        uint32_t e = s + 1;
+        while (e < n && e - s < 15u && w->ordered[e].body_a == w->ordered[s].body_a && w->ordered[e].body_b == w->ordered[s].body_b) ++e;
+        w->chain_start.push_back(s);
+        s = e;
+    }
+    w->chain_start.push_back(n);
+}
+
+// Dependency levels of the item sequence (pass-major, chains in cache order inside a pass); items of one level touch
+// pairwise different dynamic bodies. Appends to items/level_start.
 void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_t type, uint32_t n_passes, int phase) {
-    const uint32_t n = w->n_contacts, nb = w->n_dyn;
+    const uint32_t nch = (uint32_t)w->chain_start.size() - 1u, nb = w->n_dyn;
     w->item_offset[phase] = (uint32_t)w->items_host.size();
     w->level_offset[phase] = (uint32_t)w->level_start_host.size();
     const uint32_t total_passes = n_first + n_passes;
-    const size_t total = (size_t)total_passes * n;
+    const size_t total = (size_t)total_passes * nch;
     w->n_levels[phase] = 0;
     if (total == 0) {
         w->level_start_host.push_back(0);
@@ -152,8 +166,8 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
     uint32_t max_level = 0;
     size_t k = 0;
     for (uint32_t pass = 0; pass < total_passes; ++pass)
-        for (uint32_t s = 0; s < n; ++s, ++k) {
-            const ivx_contact& c = w->ordered[s];
+        for (uint32_t ch = 0; ch < nch; ++ch, ++k) {
+            const ivx_contact& c = w->ordered[w->chain_start[ch]];
             uint32_t l = 0;
             if (!(c.body_a & IVX_KINEMATIC_BODY)) l = std::max(l, last[c.body_a]);
             if (!(c.body_b & IVX_KINEMATIC_BODY)) l = std::max(l, last[c.body_b]);
@@ -171,17 +185,24 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
     uint32_t run = 0;
     for (uint32_t l = 1; l <= max_level; ++l) {
         const uint32_t c = start[l];
-        start[l] = run;  // start of level l (1-based) stored at index l; shifted below
+        start[l] = run;  // begin of level l (1-based)
         run += c;
     }
-    // start[l] for l in 1..max_level are begin offsets; build final [0..max_level] = begin of level l+1, end sentinel
     const size_t it0 = w->items_host.size();
     w->items_host.resize(it0 + total);
+    w->item_bodies_host.resize(2 * (it0 + total));
     std::vector<uint32_t> cursor(start + 1, start + max_level + 1);
     k = 0;
     for (uint32_t pass = 0; pass < total_passes; ++pass) {
         const uint32_t ty = pass < n_first ? first_type : type;
-        for (uint32_t s = 0; s < n; ++s, ++k) w->items_host[it0 + cursor[lvl[k] - 1]++] = s | (ty << 28);
+        for (uint32_t ch = 0; ch < nch; ++ch, ++k) {
+            const uint32_t s0 = w->chain_start[ch], len = w->chain_start[ch + 1] - s0;
+            const size_t slot = it0 + cursor[lvl[k] - 1]++;
+            w->items_host[slot] = s0 | (len << 24) | (ty << 28);
+            const ivx_contact& c = w->ordered[s0];
+            w->item_bodies_host[2 * slot] = (c.body_a & IVX_KINEMATIC_BODY) ? w->n_dyn + (c.body_a & 0x7FFFFFFFu) : c.body_a;
+            w->item_bodies_host[2 * slot + 1] = (c.body_b & IVX_KINEMATIC_BODY) ? w->n_dyn + (c.body_b & 0x7FFFFFFFu) : c.body_b;
+        }
     }
     for (uint32_t l = 0; l < max_level; ++l) start[l] = start[l + 1];
     start[max_level] = (uint32_t)total;
@@ -208,7 +229,7 @@ int ivx_world_create(ivx_ctx* c, const ivx_solver_config* cfg, ivx_world** out) 
 void ivx_world_destroy(ivx_world* w) {
     if (!w) return;
     (void)hipStreamSynchronize(w->ctx->stream);
-    void* ptrs[] = {w->dyn, w->kin, w->cb, w->touched, w->contacts, w->prev_slot, w->pc[0], w->pc[1], w->acc[0], w->acc[1], w->items, w->level_start};
+    void* ptrs[] = {w->dyn, w->kin, w->cb, w->touched, w->contacts, w->prev_slot, w->pc[0], w->pc[1], w->acc[0], w->acc[1], w->items, w->item_bodies, w->level_start};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (w->ev_ready)
@@ -256,7 +277,7 @@ int ivx_world_get_bodies(ivx_world* w, ivx_rigid_body* dyn, ivx_kinematic_body* 
 
 int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, size_t* n_prepared) {
     IVX_REQUIRE(w && (contacts || n == 0), IVX_ERR_INVALID, "ivx_world_set_contacts: null argument");
-    IVX_REQUIRE(n < (1u << 28), IVX_ERR_CAPACITY, "ivx_world_set_contacts: more than 2^28 contacts");
+    IVX_REQUIRE(n < (1u << 24), IVX_ERR_CAPACITY, "ivx_world_set_contacts: more than 2^24 contacts");
     for (size_t i = 0; i < n; ++i) {
         const ivx_contact& c = contacts[i];
         const uint32_t la = (c.body_a & IVX_KINEMATIC_BODY) ? w->n_kin : w->n_dyn, lb = (c.body_b & IVX_KINEMATIC_BODY) ? w->n_kin : w->n_dyn;
@@ -327,7 +348,9 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
     w->n_contacts = nc;
     // 3. dependency schedules: (warm pass + velocity sweeps) and (positional sweeps)
     w->items_host.clear();
+    w->item_bodies_host.clear();
     w->level_start_host.clear();
+    build_chains(w);
     build_schedule(w, PHYS_ITEM_WARM, 1u, PHYS_ITEM_VELOCITY, w->cfg.n_iterations, 0);
     build_schedule(w, PHYS_ITEM_POSITIONAL, 0u, PHYS_ITEM_POSITIONAL, w->cfg.n_positional_correction_iterations, 1);
     // 4. upload
@@ -362,13 +385,17 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
         w->contact_cap = ncap;
     }
     if ((rc = grow(&w->items, &w->item_cap, w->items_host.size(), s))) return rc;
+    if ((rc = grow(&w->item_bodies, &w->item_bodies_cap, w->item_bodies_host.size(), s))) return rc;
     if ((rc = grow(&w->level_start, &w->level_cap, w->level_start_host.size(), s))) return rc;
     IVX_HIP_CHECK(hipStreamSynchronize(s));
     if (nc) {
         IVX_HIP_CHECK(hipMemcpy(w->contacts, w->ordered.data(), nc * sizeof(ivx_contact), hipMemcpyHostToDevice));
         IVX_HIP_CHECK(hipMemcpy(w->prev_slot, w->prev_slot_host.data(), nc * sizeof(int32_t), hipMemcpyHostToDevice));
     }
-    if (!w->items_host.empty()) IVX_HIP_CHECK(hipMemcpy(w->items, w->items_host.data(), w->items_host.size() * 4, hipMemcpyHostToDevice));
+    if (!w->items_host.empty()) {
+        IVX_HIP_CHECK(hipMemcpy(w->items, w->items_host.data(), w->items_host.size() * 4, hipMemcpyHostToDevice));
+        IVX_HIP_CHECK(hipMemcpy(w->item_bodies, w->item_bodies_host.data(), w->item_bodies_host.size() * 4, hipMemcpyHostToDevice));
+    }
     IVX_HIP_CHECK(hipMemcpy(w->level_start, w->level_start_host.data(), w->level_start_host.size() * 4, hipMemcpyHostToDevice));
     w->schedule_valid = 1;
     // 5. device part of prepare_constraints: gather bodies, prepare every contact, warm-start bookkeeping

@@ -45,13 +45,14 @@ struct ivx_world {
     uint8_t* touched;
     // contacts of the current step, in ConstraintCache order (= solve order)
     uint32_t n_contacts, n_prev;
-    size_t contact_cap, item_cap, level_cap;
+    size_t contact_cap, item_cap, item_bodies_cap, level_cap;
     ivx_contact* contacts;
     int32_t* prev_slot;
     PhysContact* pc[2];
     float* acc[2];  // float4 per contact
     int cur;
     uint32_t* items;
+    uint32_t* item_bodies;  // uint2 per item: constrained-body indices of the chain's pair
     uint32_t* level_start;
     uint32_t n_levels[2], item_offset[2], level_offset[2];
     int schedule_valid, prepared_fresh;
@@ -69,7 +70,7 @@ struct ivx_world {
     std::vector<ivx_contact> effective;  // contacts of this step after interlock replacement
     std::vector<ivx_contact> ordered;
     std::vector<int32_t> prev_slot_host;
-    std::vector<uint32_t> items_host, level_start_host, scratch_level, scratch_last;
+    std::vector<uint32_t> item_bodies_host, items_host, level_start_host, scratch_level, scratch_last, chain_start;
 };
 
 int ivx_launch_phys_prepare_bodies(ivx_world* w);
