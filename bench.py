@@ -34,20 +34,52 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
+STAGE_KERNELS = {  # which kernels make up a timed stage (names as rocprofv3 reports them)
+    "sdf_sample": ["k_sdf_prepass", "k_sdf_fill", "k_sdf_eval"],
+    "derive": ["k_derive"],
+    "occupied": ["k_occupied_reduce"],
+    "ccl_local": ["k_ccl_local", "k_ccl_local_exact"],
+    "ccl_merge": ["k_ccl_merge"],
+    "ccl_resolve": ["k_ccl_flatten", "k_scan_groups", "k_ccl_assign"],
+    "sn_count": ["k_sn_count"],
+    "sn_scan": ["k_sn_scan"],
+    "sn_emit": ["k_sn_emit"],
+    "inertia": ["k_inertia", "k_inertia_final"],
+}
+
+
 def stage_bytes(n_voxels, n_chunks, exposed_chunks, n_vertices, n_indices):
-    """Algorithmic HBM bytes per launch of each stage."""
+    """Algorithmic HBM bytes per launch of each stage: SURVEY.md §8(d)'s per-voxel figures x the voxels of the launch for the
+    plane sweeps; the mesher is charged only for the padded tiles of the chunks it meshes (it skips the others by their
+    8-byte chunk record) plus its output."""
     return {
         "sdf_sample": 2.0 * n_voxels,                        # W sdf + type
         "derive": 2.0 * n_voxels,                            # R sdf, W flags
-        "occupied": 1.0 * n_voxels,                          # R flags
+        "occupied": 4.0 * n_chunks,                          # R one packed box per chunk
         "ccl_local": 2.0 * n_voxels,                         # R flags, W label
         "ccl_merge": 3 * 2 * 256.0 * n_chunks,               # label face pairs across +x,+y,+z
-        "ccl_resolve": 3 * 4 * 256.0 * n_chunks * 0 + 16.0 * n_chunks,  # (chunk,region) table entries actually in use ~ few per chunk
-        "sn_count": 2.0 * 5832 * exposed_chunks,             # 18^3 padded sdf + type per exposed chunk
+        "ccl_resolve": 16.0 * n_chunks,                      # (chunk, region) table entries in use, a few per chunk
+        "sn_count": 1.0 * 5832 * exposed_chunks,             # 18^3 padded sdf per exposed chunk
         "sn_scan": 20.0 * n_chunks,                          # counts in, offsets/ranks out
         "sn_emit": 2.0 * 5832 * exposed_chunks + 40.0 * n_vertices + 12.0 * n_indices,  # tile + (pos,nrm,vmat) + (idx u32, imat 8B)
         "inertia": 2.0 * n_voxels,                           # R flags + type
     }
+
+
+def measured_traffic(stage):
+    """HBM bytes per launch of the stage's kernels from the committed PMC passes (profiles/round1/pmc_traffic.json, produced by
+    tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE rocprofv3 runs of this same workload), or None."""
+    path = os.path.join(ROOT, "profiles", "round1", "pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    total, found = 0.0, False
+    for k in STAGE_KERNELS.get(stage, []):
+        if k in d:
+            total += d[k]["hbm_bytes"]
+            found = True
+    return total if found else None
 
 
 def cpu_baseline(scale):
@@ -245,6 +277,7 @@ def main():
         # library's stream), algorithmic bytes from DESIGN.md
         _, _, _, _, info = obj.download(sdf=False, types=False, flags=False, labels=False)
         exposed = int(np.count_nonzero((info["kind"] == 2) & ((info["flags"] & 0x3F) != 0x3F)))
+        counters = obj.stage_counters()
         sb = stage_bytes(n_vox_rank, obj.n_chunks, exposed, int(res["mesh"]["n_vertices"]), int(res["mesh"]["n_indices"]))
         dom = int(np.argmax(stage_ms))
         name = capi.STAGE_NAMES[dom]
@@ -264,14 +297,18 @@ def main():
             "dtype": "i8 voxels, f32 SDF/mesh arithmetic, f64 moments",
             "data": "synthetic",
             "config": {"workload": workload, "parallelism": parallelism, "voxels_per_gpu": n_vox_rank, "regions": int(res["region_count"]),
-                       "triangles": tris_total, "vertices_rank0": int(res["mesh"]["n_vertices"]), "exposed_chunks_rank0": exposed},
+                       "triangles": tris_total, "vertices_rank0": int(res["mesh"]["n_vertices"]), "exposed_chunks_rank0": exposed,
+                       "evaluated_chunks_rank0": counters["evaluated_chunks"], "meshed_chunks_rank0": counters["meshed_chunks"]},
             "remesh_tris_per_s": tris_rank / (remesh_ms * 1e-3) if remesh_ms > 0 else None,
             "remesh_ms": remesh_ms,
             "stage_ms": {capi.STAGE_NAMES[i]: round(float(stage_ms[i]), 4) for i in range(capi.N_TIMED_STAGES)},
             "stage_gbs": {capi.STAGE_NAMES[i]: round(sb[capi.STAGE_NAMES[i]] / (stage_ms[i] * 1e-3) / 1e9, 1) if stage_ms[i] > 0 else None
                           for i in range(capi.N_TIMED_STAGES)},
-            "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None},
+            "roofline": {"bound": "hbm", "kernel": "+".join(STAGE_KERNELS[name]), "stage": name, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes": sb[name],
+                         "traffic": measured_traffic(name) if world == 1 and abs(args.scale - 2.05) < 1e-9 else None},
+            "step_roofline": {"algorithmic_bytes": float(sum(sb.values())), "achieved": float(sum(sb.values())) / (float(stage_ms.sum()) * 1e-3) / 1e9,
+                              "unit": "GB/s", "frac": float(sum(sb.values())) / (float(stage_ms.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.scale)
