@@ -122,7 +122,9 @@ EXPORTED_SYMBOLS = [
     "ivx_remesh", "ivx_mesh_download", "ivx_mesh_device_ptr",
     "ivx_inertia",
     "ivx_label_regions", "ivx_region_labels_download", "ivx_regions_describe", "ivx_split_off_smallest_region", "ivx_clip_polyhedron",
-    "ivx_grid_set_sdf_program", "ivx_grid_set_densities", "ivx_voxel_step",
+    "ivx_grid_set_sdf_program", "ivx_grid_set_densities", "ivx_voxel_step", "ivx_voxel_step_enqueue", "ivx_voxel_step_collect",
+    "ivx_halo_pack_enqueue", "ivx_halo_unpack_enqueue", "ivx_region_face_labels_enqueue", "ivx_region_face_pairs_enqueue",
+    "ivx_step_record_words", "ivx_step_record_enqueue",
     "ivx_halo_bytes", "ivx_halo_pack", "ivx_halo_unpack", "ivx_halo_clear",
     "ivx_region_face_bytes", "ivx_region_face_labels", "ivx_region_face_pairs",
     "ivx_world_create", "ivx_world_destroy", "ivx_world_set_bodies", "ivx_world_get_bodies", "ivx_world_set_contacts",
@@ -194,6 +196,14 @@ def lib():
         "ivx_grid_set_sdf_program": (i32, [vp, vp, sz, u32, vp, vp, C.c_uint8]),
         "ivx_grid_set_densities": (i32, [vp, vp]),
         "ivx_voxel_step": (i32, [vp, u32, vp]),
+        "ivx_voxel_step_enqueue": (i32, [vp, u32]),
+        "ivx_voxel_step_collect": (i32, [vp, vp]),
+        "ivx_halo_pack_enqueue": (i32, [vp, i32, vp]),
+        "ivx_halo_unpack_enqueue": (i32, [vp, i32, vp]),
+        "ivx_region_face_labels_enqueue": (i32, [vp, i32, vp]),
+        "ivx_region_face_pairs_enqueue": (i32, [vp, i32, vp]),
+        "ivx_step_record_words": (sz, []),
+        "ivx_step_record_enqueue": (i32, [vp, vp]),
         "ivx_halo_bytes": (sz, [vp]),
         "ivx_halo_pack": (i32, [vp, i32, vp]),
         "ivx_halo_unpack": (i32, [vp, i32, vp]),

@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void k_face_ids(GridView g, uint32_t side, con
 
 __global__ __launch_bounds__(256) void k_face_pairs(GridView g, uint32_t side, const uint8_t* __restrict__ labels,
                                                     const uint32_t* __restrict__ rcompid, const uint32_t* __restrict__ nbr,
-                                                    uint32_t* __restrict__ n_pairs, uint2* __restrict__ pairs, uint32_t cap) {
+                                                    uint32_t* __restrict__ n_pairs, uint2* __restrict__ pairs, uint32_t cap, uint32_t* __restrict__ seen) {
     const uint32_t col = blockIdx.x, tid = threadIdx.x;
     const uint32_t chunk = (side ? g.cx - 1 : 0u) * g.cy * g.cz + col;
     const uint32_t l = labels[(size_t)chunk * IVX_CHUNK_VOXELS + ((side ? 15u : 0u) << 8) + tid];
@@ -486,8 +486,52 @@ __global__ __launch_bounds__(256) void k_face_pairs(GridView g, uint32_t side, c
     const uint32_t pa = __shfl_up(a, 1, 64), pb = __shfl_up(b, 1, 64);
     const bool dup = (tid & 63u) != 0 && pa == a && pb == b;
     if (both && !dup) {
-        const uint32_t slot = atomicAdd(n_pairs, 1u);
-        if (slot < cap) pairs[slot] = make_uint2(a, b);
+        // pairs of small ids (the usual case: a handful of components per slab) are listed once, via a 64 x 64 bit table
+        bool fresh = true;
+        if (seen && a < 64u && b < 64u) {
+            const uint32_t bit = a * 64u + b;
+            fresh = !((atomicOr(&seen[bit >> 5], 1u << (bit & 31u)) >> (bit & 31u)) & 1u);
+        }
+        if (fresh) {
+            const uint32_t slot = atomicAdd(n_pairs, 1u);
+            if (slot < cap) pairs[slot] = make_uint2(a, b);
+        }
+    }
+}
+
+// Everything the other ranks need from this slab after a step, as one fixed-size record of 64-bit words written on the
+// device so that it can go straight into an all-gather (impact_amd/distributed.py): [0] components, [1] pairs across the
+// upper face, [2..14) occupied ranges (public layout, global coordinates), [14..17) mesh totals, [18..28) moments (f64
+// bit patterns), [28..28+2*max_pairs) the pairs.
+__global__ __launch_bounds__(256) void k_step_record(const uint32_t* __restrict__ rscalar, const uint32_t* __restrict__ pair_count,
+                                                     const uint2* __restrict__ pairs, const uint32_t* __restrict__ mesh_totals,
+                                                     const double* __restrict__ moments, uint32_t x_off, uint32_t max_pairs,
+                                                     unsigned long long* __restrict__ rec) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t np = pair_count ? min(pair_count[0], 0xFFFFFFFFu) : 0u;
+    if (tid == 0) {
+        rec[0] = rscalar[0];
+        rec[1] = np;  // may exceed max_pairs: the reader reports the overflow
+        const uint32_t* raw = rscalar + 16;
+        if (raw[6] == 0) {
+            for (int i = 0; i < 12; ++i) rec[2 + i] = 0;
+        } else {
+            for (int d = 0; d < 3; ++d) {
+                rec[2 + 2 * d] = raw[d] + (d == 0 ? x_off : 0u);
+                rec[3 + 2 * d] = raw[6 + d] + (d == 0 ? x_off : 0u);
+                rec[8 + 2 * d] = raw[3 + d] + (d == 0 ? x_off * 16u : 0u);
+                rec[9 + 2 * d] = raw[9 + d] + (d == 0 ? x_off * 16u : 0u);
+            }
+        }
+        rec[14] = mesh_totals[0];
+        rec[15] = mesh_totals[1];
+        rec[16] = mesh_totals[2];
+        rec[17] = rscalar[1];  // error flags
+    }
+    if (tid < 10) rec[18 + tid] = (unsigned long long)__double_as_longlong(moments[tid]);
+    for (uint32_t i = tid; i < min(np, max_pairs); i += 256u) {
+        rec[28 + 2 * i] = pairs[i].x;
+        rec[29 + 2 * i] = pairs[i].y;
     }
 }
 
@@ -665,11 +709,20 @@ int ivx_launch_face_ids(ivx_grid* g, int side, uint32_t* d_out) {
     return IVX_OK;
 }
 
-int ivx_launch_face_pairs(ivx_grid* g, int side, const uint32_t* d_nbr, uint32_t* d_count, void* d_pairs, uint32_t cap) {
+int ivx_launch_face_pairs(ivx_grid* g, int side, const uint32_t* d_nbr, uint32_t* d_count, void* d_pairs, uint32_t cap, uint32_t* d_seen) {
     GridView v = ivx_view(g);
     IVX_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t), g->ctx->stream));
+    if (d_seen) IVX_HIP_CHECK(hipMemsetAsync(d_seen, 0, 128 * sizeof(uint32_t), g->ctx->stream));
     hipLaunchKernelGGL(k_face_pairs, dim3(g->cc[1] * g->cc[2]), dim3(256), 0, g->ctx->stream, v, (uint32_t)side, g->llabel, g->rcompid, d_nbr,
-                       d_count, static_cast<uint2*>(d_pairs), cap);
+                       d_count, static_cast<uint2*>(d_pairs), cap, d_seen);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+int ivx_launch_step_record(ivx_grid* g, const uint32_t* d_pair_count, const void* d_pairs, uint32_t max_pairs, void* d_record) {
+    hipLaunchKernelGGL(k_step_record, dim3(1), dim3(256), 0, g->ctx->stream, g->rscalar, d_pair_count, static_cast<const uint2*>(d_pairs),
+                       g->chunk_offsets + 2 * (size_t)g->n_chunks, g->partials + g->partial_blocks * 10, g->x_off, max_pairs,
+                       static_cast<unsigned long long*>(d_record));
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

@@ -278,21 +278,21 @@ __global__ __launch_bounds__(256) void k_occupied_reduce(uint32_t cx, uint32_t c
 
 // One launch that presets every small scratch word the stages of a whole step start from (instead of five memsets):
 // region scalars, occupied-range minima/maxima, Surface-Nets group totals + list counter, the sampler's list counter.
-__global__ __launch_bounds__(256) void k_step_preset(uint32_t* __restrict__ rscalar, uint32_t* __restrict__ sn_sums, uint32_t n_sn,
+__global__ __launch_bounds__(256) void k_step_preset(uint32_t stages, uint32_t* __restrict__ rscalar, uint32_t* __restrict__ sn_sums, uint32_t n_sn,
                                                      uint32_t* __restrict__ eval_count) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < 16u) rscalar[i] = 0u;
-    if (i < 12u) rscalar[16 + i] = i < 6u ? 0xFFFFFFFFu : 0u;
-    if (i < n_sn) sn_sums[i] = 0u;
-    if (i == 0 && eval_count) eval_count[0] = 0u;
+    if ((stages & IVX_STAGE_REGIONS) && i < 16u) rscalar[i] = 0u;
+    if ((stages & IVX_STAGE_OCCUPIED) && i < 12u) rscalar[16 + i] = i < 6u ? 0xFFFFFFFFu : 0u;
+    if ((stages & IVX_STAGE_REMESH) && i < n_sn) sn_sums[i] = 0u;
+    if ((stages & IVX_STAGE_SAMPLE) && i == 0 && eval_count) eval_count[0] = 0u;
 }
 
 }  // namespace
 
-int ivx_launch_step_preset(ivx_grid* g) {
+int ivx_launch_step_preset(ivx_grid* g, uint32_t stages) {
     const uint32_t groups = (g->n_chunks + 255u) / 256u;
     const uint32_t n_sn = 3 * groups + 1;
-    hipLaunchKernelGGL(k_step_preset, dim3((n_sn + 255u) / 256u), dim3(256), 0, g->ctx->stream, g->rscalar, g->group_sums + groups, n_sn,
+    hipLaunchKernelGGL(k_step_preset, dim3((n_sn + 255u) / 256u), dim3(256), 0, g->ctx->stream, stages, g->rscalar, g->group_sums + groups, n_sn,
                        g->samp_len ? g->samp_len + g->n_chunks : nullptr);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;

@@ -244,12 +244,12 @@ void ivx_grid_destroy(ivx_grid* g) {
     (void)hipStreamSynchronize(g->ctx->stream);
     void* ptrs[] = {g->sdf, g->type, g->flags, g->llabel, g->info, g->ghost_sdf[0], g->ghost_sdf[1], g->ghost_type[0], g->ghost_type[1],
                     g->ghost_info[0], g->ghost_info[1], g->chunk_counts, g->chunk_offsets, g->positions, g->normals, g->indices,
-                    g->index_materials, g->vertex_materials, g->submeshes, g->partials, g->rparent, g->rcompid, g->rscalar, g->ccl_scratch, g->group_sums, g->sn_list, g->dens_dev, g->dev_scratch, g->prog_nodes, g->chunk_bbox, g->samp_len, g->samp_ops};
+                    g->index_materials, g->vertex_materials, g->submeshes, g->partials, g->rparent, g->rcompid, g->rscalar, g->ccl_scratch, g->group_sums, g->sn_list, g->dens_dev, g->dev_scratch, g->prog_nodes, g->chunk_bbox, g->samp_len, g->samp_ops, g->pairs_dev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->host_scratch) (void)hipHostFree(g->host_scratch);
     if (g->ev_ready)
-        for (int i = 0; i < 12; ++i) (void)hipEventDestroy(g->ev[i]);
+        for (int i = 0; i < 2 * IVX_N_TIMED_STAGES; ++i) (void)hipEventDestroy(g->ev[i]);
     delete g;
 }
 
@@ -710,7 +710,7 @@ int ivx_region_face_pairs(ivx_grid* g, int side, const void* neighbour_face_labe
     if ((rc = ensure_dev_scratch(g, 16 + face * 8))) return rc;
     uint32_t* d_count = static_cast<uint32_t*>(g->dev_scratch);
     void* d_pairs = static_cast<char*>(g->dev_scratch) + 16;
-    if ((rc = ivx_launch_face_pairs(g, side, static_cast<const uint32_t*>(neighbour_face_labels), d_count, d_pairs, (uint32_t)face))) return rc;
+    if ((rc = ivx_launch_face_pairs(g, side, static_cast<const uint32_t*>(neighbour_face_labels), d_count, d_pairs, (uint32_t)face, nullptr))) return rc;
     uint32_t n = 0;
     if ((rc = d2h(g, &n, d_count, sizeof(n)))) return rc;
     std::vector<uint64_t> h(n);
@@ -778,89 +778,117 @@ int ivx_grid_set_densities(ivx_grid* g, const float densities[256]) {
     return IVX_OK;
 }
 
-int ivx_voxel_step(ivx_grid* g, uint32_t stages, ivx_step_result* out) {
-    IVX_REQUIRE(g && out, IVX_ERR_INVALID, "ivx_voxel_step: null argument");
+static const uint32_t kStageOfTimed[IVX_N_TIMED_STAGES] = {IVX_STAGE_SAMPLE, IVX_STAGE_DERIVE, IVX_STAGE_OCCUPIED, IVX_STAGE_REGIONS, IVX_STAGE_REGIONS,
+                                                           IVX_STAGE_REGIONS, IVX_STAGE_REMESH,  IVX_STAGE_REMESH,   IVX_STAGE_REMESH,  IVX_STAGE_INERTIA};
+
+int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
+    IVX_REQUIRE(g, IVX_ERR_INVALID, "ivx_voxel_step_enqueue: null grid");
     IVX_REQUIRE(!(stages & IVX_STAGE_SAMPLE) || g->prog_n > 0, IVX_ERR_STATE, "ivx_voxel_step: no SDF program resident (ivx_grid_set_sdf_program)");
     IVX_REQUIRE(!(stages & IVX_STAGE_INERTIA) || g->has_dens, IVX_ERR_STATE, "ivx_voxel_step: no densities resident (ivx_grid_set_densities)");
     hipStream_t s = g->ctx->stream;
     if (!g->ev_ready) {
-        for (int i = 0; i < 12; ++i) IVX_HIP_CHECK(hipEventCreate(&g->ev[i]));
+        for (int i = 0; i < 2 * IVX_N_TIMED_STAGES; ++i) IVX_HIP_CHECK(hipEventCreate(&g->ev[i]));
         g->ev_ready = 1;
     }
-    memset(out, 0, sizeof(*out));
     int rc;
     uint32_t* d_occ = g->rscalar + 16;
-#define EV(i) IVX_HIP_CHECK(hipEventRecord(g->ev[i], s))
     if (stages & IVX_STAGE_SAMPLE)
         if ((rc = ivx_sampler_buffers(g))) return rc;
-    if ((rc = ivx_launch_step_preset(g))) return rc;
+    // one launch presets the scratch words of the stages in this call (a phase of the multi-GPU protocol must not wipe
+    // what an earlier phase of the same step left: only the requested stages' words are touched)
+    if ((rc = ivx_launch_step_preset(g, stages))) return rc;
     g->scratch_preset = 1;
     struct PresetGuard {
         ivx_grid* g;
         ~PresetGuard() { g->scratch_preset = 0; }
     } preset_guard{g};
-    EV(0);
+#define T0(i) IVX_HIP_CHECK(hipEventRecord(g->ev[2 * (i)], s))
+#define T1(i)                                                  \
+    IVX_HIP_CHECK(hipEventRecord(g->ev[2 * (i) + 1], s)); \
+    g->timed_mask |= 1u << (i)
     if (stages & IVX_STAGE_SAMPLE) {
+        T0(0);
         if ((rc = ivx_launch_sdf_sample(g, g->prog_nodes, g->prog_n, g->prog_stack, g->prog_shape, g->prog_center, g->prog_type))) return rc;
+        T1(0);
         g->mesh_valid = 0;
         g->regions_valid = 0;
     }
-    EV(1);
-    if (stages & IVX_STAGE_DERIVE)
+    if (stages & IVX_STAGE_DERIVE) {
+        T0(1);
         if ((rc = ivx_launch_derive(g))) return rc;
-    EV(2);
+        T1(1);
+    }
     if (stages & IVX_STAGE_OCCUPIED) {
+        T0(2);
         if ((rc = ivx_launch_occupied(g, d_occ))) return rc;
+        T1(2);
     }
-    EV(3);
-    if (stages & IVX_STAGE_REGIONS)
-        if ((rc = ivx_launch_ccl_local(g))) return rc;
-    EV(4);
-    if (stages & IVX_STAGE_REGIONS)
-        if ((rc = ivx_launch_ccl_merge(g))) return rc;
-    EV(5);
-    if (stages & IVX_STAGE_REGIONS)
-        if ((rc = ivx_launch_ccl_resolve(g))) return rc;
-    EV(6);
-    uint32_t totals[3] = {0, 0, 0};
-    if (stages & IVX_STAGE_REMESH) {
-        if ((rc = ivx_launch_sn_count(g))) return rc;
-        EV(7);
-        if ((rc = ivx_launch_sn_scan(g))) return rc;
-        EV(8);
-        // the only mid-step host round trip: exact mesh sizes (12 bytes) to size the output buffers
-        if ((rc = d2h(g, totals, g->chunk_offsets + 2 * (size_t)g->n_chunks, sizeof(totals)))) return rc;
-        if ((rc = ensure_mesh_capacity(g, totals[0], totals[1], totals[2]))) return rc;
-        IVX_HIP_CHECK(hipEventRecord(g->ev[11], s));
-        if (totals[1] > 0 && (rc = ivx_launch_sn_emit(g))) return rc;
-        g->mesh_counts.n_vertices = totals[0];
-        g->mesh_counts.n_indices = totals[1];
-        g->mesh_counts.n_submeshes = totals[2];
-        g->mesh_valid = 1;
-    } else {
-        EV(7);
-        EV(8);
-        IVX_HIP_CHECK(hipEventRecord(g->ev[11], s));
-    }
-    EV(9);
-    if (stages & IVX_STAGE_INERTIA)
-        if ((rc = ivx_launch_inertia(g, g->dens_dev, g->partials + g->partial_blocks * 10))) return rc;
-    EV(10);
-#undef EV
-    IVX_HIP_CHECK(hipStreamSynchronize(s));
-    // results: region count + error flag, occupied ranges, moments — three tiny copies after the sync
     if (stages & IVX_STAGE_REGIONS) {
-        uint32_t sc[2];
-        IVX_HIP_CHECK(hipMemcpy(sc, g->rscalar, sizeof(sc), hipMemcpyDeviceToHost));
+        T0(3);
+        if ((rc = ivx_launch_ccl_local(g))) return rc;
+        T1(3);
+        T0(4);
+        if ((rc = ivx_launch_ccl_merge(g))) return rc;
+        T1(4);
+        T0(5);
+        if ((rc = ivx_launch_ccl_resolve(g))) return rc;
+        T1(5);
+    }
+    if (stages & IVX_STAGE_REMESH) {
+        T0(6);
+        if ((rc = ivx_launch_sn_count(g))) return rc;
+        T1(6);
+        T0(7);
+        if ((rc = ivx_launch_sn_scan(g))) return rc;
+        T1(7);
+        // no host round trip for the mesh sizes: the emit pass writes into the buffers of the previous step and skips what
+        // does not fit; ivx_voxel_step_collect grows the buffers and repeats the pass in that (rare) case
+        T0(8);
+        if ((rc = ivx_launch_sn_emit(g))) return rc;
+        T1(8);
+        g->mesh_valid = 0;
+    }
+    if (stages & IVX_STAGE_INERTIA) {
+        T0(9);
+        if ((rc = ivx_launch_inertia(g, g->dens_dev, g->partials + g->partial_blocks * 10))) return rc;
+        T1(9);
+    }
+#undef T0
+#undef T1
+    g->pending_stages |= stages;
+    return IVX_OK;
+}
+
+int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out) {
+    IVX_REQUIRE(g && out, IVX_ERR_INVALID, "ivx_voxel_step_collect: null argument");
+    hipStream_t s = g->ctx->stream;
+    memset(out, 0, sizeof(*out));
+    const uint32_t stages = g->pending_stages;
+    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    // the small results of every stage: region scalars + occupied minima/maxima (28 words), mesh totals, moments
+    uint32_t sc[28];
+    IVX_HIP_CHECK(hipMemcpy(sc, g->rscalar, sizeof(sc), hipMemcpyDeviceToHost));
+    if (stages & IVX_STAGE_REGIONS) {
         IVX_REQUIRE((sc[1] & 1u) == 0, IVX_ERR_CAPACITY, "ivx_voxel_step: a chunk has more than 254 local regions");
         g->region_count = sc[0];
         g->regions_valid = 1;
         out->region_count = sc[0];
     }
-    if (stages & IVX_STAGE_OCCUPIED) {
-        uint32_t raw[12];
-        IVX_HIP_CHECK(hipMemcpy(raw, d_occ, 12 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        ivx_occupied_from_raw(g, raw, out->occupied);
+    if (stages & IVX_STAGE_OCCUPIED) ivx_occupied_from_raw(g, sc + 16, out->occupied);
+    if (stages & IVX_STAGE_REMESH) {
+        uint32_t totals[3];
+        IVX_HIP_CHECK(hipMemcpy(totals, g->chunk_offsets + 2 * (size_t)g->n_chunks, sizeof(totals), hipMemcpyDeviceToHost));
+        if (totals[0] > g->vcap || totals[1] > g->icap || totals[2] > g->scap) {
+            int rc;
+            if ((rc = ensure_mesh_capacity(g, totals[0], totals[1], totals[2]))) return rc;
+            if ((rc = ivx_launch_sn_emit(g))) return rc;
+            IVX_HIP_CHECK(hipStreamSynchronize(s));
+        }
+        g->mesh_counts.n_vertices = totals[0];
+        g->mesh_counts.n_indices = totals[1];
+        g->mesh_counts.n_submeshes = totals[2];
+        g->mesh_counts.reserved = 0;
+        g->mesh_valid = 1;
     }
     if (stages & IVX_STAGE_INERTIA) {
         IVX_HIP_CHECK(hipMemcpy(out->moments.m64, g->partials + g->partial_blocks * 10, 10 * sizeof(double), hipMemcpyDeviceToHost));
@@ -869,11 +897,21 @@ int ivx_voxel_step(ivx_grid* g, uint32_t stages, ivx_step_result* out) {
     out->mesh = g->mesh_counts;
     for (int i = 0; i < IVX_N_TIMED_STAGES; ++i) {
         float ms = 0.0f;
-        const int a = (i == 8) ? 11 : i, b = i + 1;  // sn_emit is timed from after the host round trip
-        if (hipEventElapsedTime(&ms, g->ev[a], g->ev[b]) != hipSuccess) ms = 0.0f;
+        if ((g->timed_mask >> i) & 1u)
+            if (hipEventElapsedTime(&ms, g->ev[2 * i], g->ev[2 * i + 1]) != hipSuccess) ms = 0.0f;
         out->stage_ms[i] = ms;
     }
+    (void)kStageOfTimed;
+    g->pending_stages = 0;
+    g->timed_mask = 0;
     return IVX_OK;
+}
+
+int ivx_voxel_step(ivx_grid* g, uint32_t stages, ivx_step_result* out) {
+    IVX_REQUIRE(g && out, IVX_ERR_INVALID, "ivx_voxel_step: null argument");
+    int rc = ivx_voxel_step_enqueue(g, stages);
+    if (rc) return rc;
+    return ivx_voxel_step_collect(g, out);
 }
 
 size_t ivx_halo_bytes(ivx_grid* g) {
@@ -901,6 +939,58 @@ int ivx_halo_unpack(ivx_grid* g, int side, const void* device_buf) {
     g->has_ghost[side] = 1;
     IVX_HIP_CHECK(hipStreamSynchronize(s));
     return IVX_OK;
+}
+
+int ivx_halo_pack_enqueue(ivx_grid* g, int side, void* device_buf) {
+    IVX_REQUIRE(g && device_buf && (side == 0 || side == 1), IVX_ERR_INVALID, "ivx_halo_pack_enqueue: bad argument");
+    return ivx_launch_halo_pack(g, side, device_buf);
+}
+
+int ivx_halo_unpack_enqueue(ivx_grid* g, int side, const void* device_buf) {
+    IVX_REQUIRE(g && device_buf && (side == 0 || side == 1), IVX_ERR_INVALID, "ivx_halo_unpack_enqueue: bad argument");
+    const size_t cols = (size_t)g->cc[1] * g->cc[2];
+    hipStream_t s = g->ctx->stream;
+    const uint8_t* b = static_cast<const uint8_t*>(device_buf);
+    IVX_HIP_CHECK(hipMemcpyAsync(g->ghost_sdf[side], b, cols * 256, hipMemcpyDeviceToDevice, s));
+    IVX_HIP_CHECK(hipMemcpyAsync(g->ghost_type[side], b + cols * 256, cols * 256, hipMemcpyDeviceToDevice, s));
+    IVX_HIP_CHECK(hipMemcpyAsync(g->ghost_info[side], b + cols * 512, cols * sizeof(ivx_chunk_info), hipMemcpyDeviceToDevice, s));
+    g->has_ghost[side] = 1;
+    return IVX_OK;
+}
+
+int ivx_region_face_labels_enqueue(ivx_grid* g, int side, void* device_buf) {
+    IVX_REQUIRE(g && device_buf && (side == 0 || side == 1), IVX_ERR_INVALID, "ivx_region_face_labels_enqueue: bad argument");
+    return ivx_launch_face_ids(g, side, static_cast<uint32_t*>(device_buf));
+}
+
+static int ensure_pairs(ivx_grid* g) {
+    if (g->pairs_dev) return IVX_OK;
+    IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->pairs_dev), sizeof(uint32_t) * (4 + 128 + 2 * (size_t)IVX_MAX_FACE_PAIRS)));
+    IVX_HIP_CHECK(hipMemsetAsync(g->pairs_dev, 0, sizeof(uint32_t) * (4 + 128), g->ctx->stream));
+    return IVX_OK;
+}
+
+int ivx_region_face_pairs_enqueue(ivx_grid* g, int side, const void* neighbour_face_labels) {
+    IVX_REQUIRE(g && neighbour_face_labels && (side == 0 || side == 1), IVX_ERR_INVALID, "ivx_region_face_pairs_enqueue: bad argument");
+    int rc = ensure_pairs(g);
+    if (rc) return rc;
+    rc = ivx_launch_face_pairs(g, side, static_cast<const uint32_t*>(neighbour_face_labels), g->pairs_dev, g->pairs_dev + 4 + 128, IVX_MAX_FACE_PAIRS,
+                               g->pairs_dev + 4);
+    if (rc) return rc;
+    g->pairs_enqueued = 1;
+    return IVX_OK;
+}
+
+size_t ivx_step_record_words(void) { return 28 + 2 * (size_t)IVX_MAX_FACE_PAIRS; }
+
+int ivx_step_record_enqueue(ivx_grid* g, void* device_record) {
+    IVX_REQUIRE(g && device_record, IVX_ERR_INVALID, "ivx_step_record_enqueue: null argument");
+    int rc = ensure_pairs(g);
+    if (rc) return rc;
+    if (!g->pairs_enqueued) IVX_HIP_CHECK(hipMemsetAsync(g->pairs_dev, 0, sizeof(uint32_t), g->ctx->stream));
+    rc = ivx_launch_step_record(g, g->pairs_dev, g->pairs_dev + 4 + 128, IVX_MAX_FACE_PAIRS, device_record);
+    g->pairs_enqueued = 0;
+    return rc;
 }
 
 int ivx_halo_clear(ivx_grid* g, int side) {

@@ -11,6 +11,7 @@
 
 #define IVX_CHUNK 16
 #define IVX_CHUNK_VOXELS 4096
+#define IVX_MAX_FACE_PAIRS 4096
 
 // VoxelFlags (impact_voxel/src/lib.rs:75-101)
 #define VF_EMPTY 0x01u
@@ -96,8 +97,12 @@ struct ivx_grid {
     double* moments_dev;  // [10]
     uint32_t* samp_len;   // [n_chunks] length of the chunk's compact SDF program (sampler pre-pass)
     void* samp_ops;       // [n_chunks * 128] uint2 ops
-    hipEvent_t ev[12];
+    hipEvent_t ev[2 * IVX_N_TIMED_STAGES];  // start/stop per timed stage
     int ev_ready;
+    uint32_t pending_stages;  // stages enqueued since the last collect
+    uint32_t timed_mask;      // timed stages whose events were recorded since the last collect
+    uint32_t* pairs_dev;      // [4 + 128 + 2 * IVX_MAX_FACE_PAIRS]: count, seen table, (own, neighbour) component pairs across the upper x face
+    int pairs_enqueued;
     // host pinned scratch
     void* host_scratch;
     size_t host_scratch_bytes;
@@ -161,7 +166,7 @@ int ivx_launch_classify(ivx_grid* g);
 int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, uint32_t n_nodes, uint32_t stack_size,
                           const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type);
 int ivx_launch_derive(ivx_grid* g);
-int ivx_launch_step_preset(ivx_grid* g);
+int ivx_launch_step_preset(ivx_grid* g, uint32_t stages);
 int ivx_sampler_buffers(ivx_grid* g);
 int ivx_launch_occupied(ivx_grid* g, uint32_t* d_raw);
 void ivx_occupied_from_raw(const ivx_grid* g, const uint32_t raw[12], uint32_t out[12]);
@@ -175,7 +180,8 @@ int ivx_launch_ccl_resolve(ivx_grid* g);
 int ivx_launch_ccl_dense_labels(ivx_grid* g, uint32_t* d_labels);
 int ivx_launch_halo_pack(ivx_grid* g, int side, void* buf);
 int ivx_launch_face_ids(ivx_grid* g, int side, uint32_t* d_out);
-int ivx_launch_face_pairs(ivx_grid* g, int side, const uint32_t* d_nbr, uint32_t* d_count, void* d_pairs, uint32_t cap);
+int ivx_launch_face_pairs(ivx_grid* g, int side, const uint32_t* d_nbr, uint32_t* d_count, void* d_pairs, uint32_t cap, uint32_t* d_seen);
+int ivx_launch_step_record(ivx_grid* g, const uint32_t* d_pair_count, const void* d_pairs, uint32_t max_pairs, void* d_record);
 int ivx_launch_split_move(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], const uint32_t cc[3], uint32_t target);
 int ivx_launch_clip(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], const uint32_t cc[3], const float* planes4, uint32_t n_planes, int extract);
 int ivx_launch_split_repack(ivx_grid* src, ivx_grid* dst, const uint32_t off[3]);

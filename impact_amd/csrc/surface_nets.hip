@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void k_sn_emit(SnParams p, const uint32_t* __r
                                                  const uint32_t* __restrict__ ranks, float* __restrict__ positions, float* __restrict__ normals,
                                                  uint32_t* __restrict__ indices, unsigned long long* __restrict__ imats,
                                                  uint4* __restrict__ vmats, ivx_submesh* __restrict__ submeshes, const uint32_t* __restrict__ emit_count,
-                                                 const uint32_t* __restrict__ emit_list) {
+                                                 const uint32_t* __restrict__ emit_list, uint32_t vcap, uint32_t icap, uint32_t scap) {
     __shared__ __attribute__((aligned(16))) uint8_t s_sd[TILE_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t s_ty[TILE_BYTES];
     __shared__ uint32_t s_neg[NROWS];
@@ -440,6 +440,9 @@ __global__ __launch_bounds__(256) void k_sn_emit(SnParams p, const uint32_t* __r
     const uint32_t icount = counts[2 * chunk + 1];
     const uint32_t vcount = counts[2 * chunk];
     const uint32_t voff = offsets[2 * chunk], ioff = offsets[2 * chunk + 1];
+    // the output buffers keep the capacity of earlier steps; a mesh that outgrew them is re-emitted after the host has
+    // grown the buffers (ivx_voxel_step_collect) — nothing is ever written past the end
+    if ((size_t)voff + vcount > vcap || (size_t)ioff + icount > icap || ranks[chunk] >= scap) continue;
     const ivx_chunk_info info = g.info[chunk];
     const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
     load_tile(g, ci, cj, ck, s_sd, s_ty, s_neg, tid);
@@ -659,7 +662,7 @@ int ivx_launch_sn_emit(ivx_grid* g) {
     hipLaunchKernelGGL(k_sn_emit, dim3(blocks), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts, g->chunk_offsets,
                        g->chunk_offsets + 2 * (size_t)g->n_chunks + 4, g->positions, g->normals, g->indices,
                        reinterpret_cast<unsigned long long*>(g->index_materials), reinterpret_cast<uint4*>(g->vertex_materials), g->submeshes,
-                       g->group_sums + groups + 3 * groups, g->sn_list);
+                       g->group_sums + groups + 3 * groups, g->sn_list, (uint32_t)g->vcap, (uint32_t)g->icap, (uint32_t)g->scap);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

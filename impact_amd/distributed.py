@@ -10,9 +10,14 @@ decomposition is the part of this build that has no reference counterpart. What 
   2. after derived state + slab-local region labelling: the same planes again (now carrying the
      post-demotion chunk kind the mesher's upper-layer rule needs, surface_nets.rs:252-261) and the face
      planes of slab-local component ids;
-  3. one all-gather of a small record per rank: region equivalences across each rank's upper face,
-     component count, the 10 mass moments, occupied ranges and mesh sizes. Every rank then finishes the
-     same union-find (the cross-chunk resolve of split_detection.rs:323-487 carried across ranks).
+  3. one all-gather of a small record per rank, written on the device (`ivx_step_record_enqueue`): region
+     equivalences across each rank's upper face, component count, the 10 mass moments, occupied ranges and
+     mesh sizes. Every rank then finishes the same union-find (the cross-chunk resolve of
+     split_detection.rs:323-487 carried across ranks).
+
+Everything between the first kernel of a step and that all-gather is stream-ordered on the library's HIP stream
+(torch sees it as an ExternalStream): kernels, halo packing, RCCL traffic and unpacking follow each other without a
+host wait; the host blocks once per step, when it reads the gathered records.
 
 Slabs are chunk-aligned, so a rank talks to at most two neighbours and each message is a contiguous
 plane: RCCL send/recv over one xGMI link per neighbour; nothing is reduced in bulk.
@@ -36,8 +41,8 @@ from .voxel import Context, SDFVoxelGenerator, VoxelObject
 NONE = 0xFFFFFFFF
 
 # fixed-size record every rank contributes to the final all-gather (int64 words)
-MAX_PAIRS = 1024
-REC_WORDS = 2 + 12 + 4 + 10 + 2 * MAX_PAIRS  # n_regions, n_pairs | occupied[12] | mesh v,i,s,pad | moments f64 bits | pairs
+MAX_PAIRS = 4096  # IVX_MAX_FACE_PAIRS
+REC_WORDS = 2 + 12 + 4 + 10 + 2 * MAX_PAIRS  # n_regions, n_pairs | occupied[12] | mesh v,i,s,flags | moments f64 bits | pairs
 
 
 @dataclass
@@ -52,7 +57,7 @@ class Exchange:
 
 @dataclass
 class AllGather:
-    record: np.ndarray  # int64[REC_WORDS]
+    record: "DeviceBuffer"  # int64[REC_WORDS] on the device
 
 
 @dataclass
@@ -72,8 +77,9 @@ class SlabResult:
 class DeviceBuffer:
     """A device allocation the comm layer can address: wraps a torch uint8 CUDA tensor."""
 
-    def __init__(self, torch, nbytes, device):
-        self.t = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+    def __init__(self, torch, nbytes, device, dtype=None):
+        dtype = dtype or torch.uint8
+        self.t = torch.zeros(max(int(nbytes) // torch.empty(0, dtype=dtype).element_size(), 1), dtype=dtype, device=device)
         self.nbytes = int(nbytes)
 
     @property
@@ -158,6 +164,10 @@ class SlabStepper:
         # send/recv buffers for both sides: [halo | face ids]
         self.send = [DeviceBuffer(torch, hb + fb, dev) for _ in range(2)]
         self.recv = [DeviceBuffer(torch, hb + fb, dev) for _ in range(2)]
+        self.record = DeviceBuffer(torch, 8 * REC_WORDS, dev, torch.int64)
+        assert int(capi.lib().ivx_step_record_words()) == REC_WORDS
+        # torch work issued by the comm layer (copies, RCCL) is ordered on the library's stream
+        self.stream = torch.cuda.ExternalStream(ctx.stream, device=dev)
         self.has_lo, self.has_hi = rank > 0, rank + 1 < world
         self.last = None
 
@@ -168,45 +178,41 @@ class SlabStepper:
     def _install_ghosts(self):
         for side, has in ((0, self.has_lo), (1, self.has_hi)):
             if has:
-                self.obj.halo_unpack(side, self.recv[side].ptr)
+                self.obj.halo_unpack_enqueue(side, self.recv[side].ptr)
             else:
                 self.obj.halo_clear(side)
 
     def phases(self):
-        """generator: yields Exchange / AllGather requests, receives their results, returns SlabResult"""
+        """generator: yields Exchange / AllGather requests, receives their results, returns SlabResult. Nothing in here
+        waits for the GPU until the gathered records are read."""
         obj, L = self.obj, capi.lib()
         res = SlabResult()
         # 1. sample, exchange face planes
-        r1 = obj.step(capi.STAGE_SAMPLE)
+        obj.step_enqueue(capi.STAGE_SAMPLE)
         for side in (0, 1):
-            obj.halo_pack(side, self.send[side].ptr)
+            obj.halo_pack_enqueue(side, self.send[side].ptr)
         yield Exchange(self.send[0], self.send[1], self.recv[0], self.recv[1])
         self._install_ghosts()
         # 2. derived state + slab-local regions; exchange planes again (+ component ids of the faces)
-        r2 = obj.step(capi.STAGE_DERIVE | capi.STAGE_OCCUPIED | capi.STAGE_REGIONS)
+        obj.step_enqueue(capi.STAGE_DERIVE | capi.STAGE_OCCUPIED | capi.STAGE_REGIONS)
         for side in (0, 1):
-            obj.halo_pack(side, self.send[side].ptr)
-            check(L.ivx_region_face_labels(obj.h, side, C.c_void_p(self.send[side].ptr + self.halo_bytes)))
+            obj.halo_pack_enqueue(side, self.send[side].ptr)
+            check(L.ivx_region_face_labels_enqueue(obj.h, side, C.c_void_p(self.send[side].ptr + self.halo_bytes)))
         yield Exchange(self.send[0], self.send[1], self.recv[0], self.recv[1])
         self._install_ghosts()
-        rec = np.zeros(REC_WORDS, dtype=np.int64)
-        n_local = int(r2["region_count"])
-        rec[0] = n_local
         if self.has_hi:
-            pairs = np.zeros(2 * MAX_PAIRS, dtype=np.uint32)
-            n = C.c_size_t(0)
-            check(L.ivx_region_face_pairs(obj.h, 1, C.c_void_p(self.recv[1].ptr + self.halo_bytes), ptr(pairs), MAX_PAIRS, C.byref(n)))
-            rec[1] = n.value
-            rec[28:28 + 2 * n.value] = pairs[: 2 * n.value]
-        # 3. remesh + inertia (ghost layers in place), then the one small all-gather
-        r3 = obj.step(capi.STAGE_REMESH | capi.STAGE_INERTIA)
-        rec[2:14] = r2["occupied"]
-        rec[14], rec[15], rec[16] = int(r3["mesh"]["n_vertices"]), int(r3["mesh"]["n_indices"]), int(r3["mesh"]["n_submeshes"])
-        rec[18:28] = np.ascontiguousarray(r3["moments"]["m64"]).view(np.int64)
-        records = yield AllGather(rec)
+            check(L.ivx_region_face_pairs_enqueue(obj.h, 1, C.c_void_p(self.recv[1].ptr + self.halo_bytes)))
+        # 3. remesh + inertia (ghost layers in place), the slab's record, then the one small all-gather
+        obj.step_enqueue(capi.STAGE_REMESH | capi.STAGE_INERTIA)
+        check(L.ivx_step_record_enqueue(obj.h, C.c_void_p(self.record.ptr)))
+        records = yield AllGather(self.record)
+        r = obj.step_collect()  # the stream is already idle: stage timings + mesh-buffer check
+        flags = int(records[self.rank, 17])
+        if flags & 1:
+            raise capi.IvxError(capi.IVX_ERR_CAPACITY, "a chunk has more than 254 local regions")
         n_regions, region_of, moments, occ, mesh = resolve_global_regions(records)
         res.region_count = n_regions
-        res.local_region_count = n_local
+        res.local_region_count = int(records[self.rank, 0])
         res.region_of_local = region_of[self.rank]
         res.moments = moments
         res.occupied = occ
@@ -214,7 +220,7 @@ class SlabStepper:
         res.vertex_offset = sum(m[0] for m in mesh[: self.rank])
         res.index_offset = sum(m[1] for m in mesh[: self.rank])
         res.total_triangles = sum(m[1] for m in mesh) // 3
-        res.stage_ms = np.asarray(r1["stage_ms"], dtype=np.float64) + r2["stage_ms"] + r3["stage_ms"]
+        res.stage_ms = np.asarray(r["stage_ms"], dtype=np.float64)
         self.last = res
         return res
 
@@ -247,62 +253,65 @@ class TorchComm:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
         for rbuf, r_host in staged:
-            rbuf.t.copy_(r_host)
-        if self.on_device or staged:
-            torch.cuda.synchronize()
+            rbuf.t.copy_(r_host)  # enqueued on the current (= the library's) stream
 
-    def all_gather(self, rec: np.ndarray) -> np.ndarray:
+    def all_gather(self, rec) -> np.ndarray:
+        """rec: DeviceBuffer (int64 words on the device) or a host numpy array -> (world, words) numpy"""
         torch, dist = self.torch, self.dist
-        t = torch.from_numpy(rec)
-        if self.on_device:
+        t = rec.t if isinstance(rec, DeviceBuffer) else torch.from_numpy(rec)
+        if self.on_device and not t.is_cuda:
             t = t.cuda()
+        if not self.on_device and t.is_cuda:
+            t = t.cpu()  # waits for the stream
         out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out, t.reshape(-1))
-        return out.cpu().numpy().reshape((self.world,) + tuple(rec.shape))
+        return out.cpu().numpy().reshape(self.world, -1)
 
     def run(self, stepper: SlabStepper) -> SlabResult:
         gen = stepper.phases()
         reply = None
-        try:
-            while True:
-                req = gen.send(reply)
-                if isinstance(req, Exchange):
-                    self.exchange(req)
-                    reply = None
-                else:
-                    reply = self.all_gather(req.record)
-        except StopIteration as stop:
-            return stop.value
+        with self.torch.cuda.stream(stepper.stream):
+            try:
+                while True:
+                    req = gen.send(reply)
+                    if isinstance(req, Exchange):
+                        self.exchange(req)
+                        reply = None
+                    else:
+                        reply = self.all_gather(req.record)
+            except StopIteration as stop:
+                return stop.value
 
 
 def run_slabs_in_process(steppers):
-    """Drive several slabs that live in ONE process (one GPU) in lock step, moving halo buffers with
-    device-to-device copies. Same protocol code as the distributed run; used by the GPU parity tests."""
+    """Drive several slabs that live in ONE process (one GPU, one context, hence one stream) in lock step, moving halo
+    buffers with device-to-device copies. Same protocol code as the distributed run; used by the GPU parity tests."""
+    torch = steppers[0].torch
     gens = [s.phases() for s in steppers]
     replies = [None] * len(gens)
     results = [None] * len(gens)
-    live = True
-    while live:
-        reqs = []
-        for i, g in enumerate(gens):
-            try:
-                reqs.append(g.send(replies[i]))
-            except StopIteration as stop:
-                results[i] = stop.value
-                reqs.append(None)
-        if all(r is None for r in reqs):
-            break
-        if any(r is None for r in reqs):
-            raise RuntimeError("slab protocols fell out of step")
-        if isinstance(reqs[0], Exchange):
-            for i, r in enumerate(reqs):
-                if i > 0:
-                    reqs[i - 1].recv_hi.t.copy_(r.lo.t)
-                if i + 1 < len(reqs):
-                    reqs[i + 1].recv_lo.t.copy_(r.hi.t)
-            steppers[0].torch.cuda.synchronize()
-            replies = [None] * len(gens)
-        else:
-            records = np.stack([r.record for r in reqs])
-            replies = [records] * len(gens)
+    with torch.cuda.stream(steppers[0].stream):
+        while True:
+            reqs = []
+            for i, g in enumerate(gens):
+                try:
+                    reqs.append(g.send(replies[i]))
+                except StopIteration as stop:
+                    results[i] = stop.value
+                    reqs.append(None)
+            if all(r is None for r in reqs):
+                break
+            if any(r is None for r in reqs):
+                raise RuntimeError("slab protocols fell out of step")
+            if isinstance(reqs[0], Exchange):
+                # the send buffers are read before anything overwrites them: all copies are enqueued here, in order
+                for i, r in enumerate(reqs):
+                    if i > 0:
+                        reqs[i - 1].recv_hi.t.copy_(r.lo.t)
+                    if i + 1 < len(reqs):
+                        reqs[i + 1].recv_lo.t.copy_(r.hi.t)
+                replies = [None] * len(gens)
+            else:
+                records = torch.stack([r.record.t for r in reqs]).cpu().numpy()
+                replies = [records] * len(gens)
     return results

@@ -207,6 +207,17 @@ class VoxelObject:
         check(capi.lib().ivx_grid_stage_counters(self.h, ptr(out)))
         return {"evaluated_chunks": int(out[0]), "multi_region_chunks": int(out[1]), "meshed_chunks": int(out[2]), "chunks": int(out[3])}
 
+    def step_enqueue(self, stages: int = capi.STAGE_ALL):
+        """launch the kernels of `stages` without waiting (`ivx_voxel_step_enqueue`)"""
+        check(capi.lib().ivx_voxel_step_enqueue(self.h, stages))
+
+    def step_collect(self) -> np.ndarray:
+        """wait once and fetch the results of everything enqueued since the last collect (`ivx_voxel_step_collect`)"""
+        out = np.zeros(1, dtype=capi.STEP_RESULT_DTYPE)
+        check(capi.lib().ivx_voxel_step_collect(self.h, ptr(out)))
+        self._region_count = int(out[0]["region_count"])
+        return out[0]
+
     # ---- derived state ----------------------------------------------------------------------
     def derive_state(self):
         check(capi.lib().ivx_derive_state(self.h))
@@ -331,6 +342,12 @@ class VoxelObject:
 
     def halo_unpack(self, side: int, device_ptr: int):
         check(capi.lib().ivx_halo_unpack(self.h, side, C.c_void_p(device_ptr)))
+
+    def halo_pack_enqueue(self, side: int, device_ptr: int):
+        check(capi.lib().ivx_halo_pack_enqueue(self.h, side, C.c_void_p(device_ptr)))
+
+    def halo_unpack_enqueue(self, side: int, device_ptr: int):
+        check(capi.lib().ivx_halo_unpack_enqueue(self.h, side, C.c_void_p(device_ptr)))
 
     def halo_clear(self, side: int):
         check(capi.lib().ivx_halo_clear(self.h, side))

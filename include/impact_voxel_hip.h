@@ -218,6 +218,12 @@ int ivx_grid_set_sdf_program(ivx_grid*, const ivx_sdf_processed_node* nodes, siz
                              const uint32_t grid_shape[3], const float shifted_grid_center[3], uint8_t voxel_type);
 int ivx_grid_set_densities(ivx_grid*, const float densities[256]);
 int ivx_voxel_step(ivx_grid*, uint32_t stages, ivx_step_result* out);
+/* The same in two halves: enqueue launches the kernels of `stages` and returns without waiting (several calls may follow
+ * each other, e.g. the phases of the multi-GPU protocol with halo traffic in between); collect waits once, fetches the
+ * results of everything enqueued since the last collect and, if the mesh outgrew the buffers kept from earlier steps,
+ * grows them and repeats the emit pass. */
+int ivx_voxel_step_enqueue(ivx_grid*, uint32_t stages);
+int ivx_voxel_step_collect(ivx_grid*, ivx_step_result* out);
 
 /* ---- multi-GPU: x-slab halos ----------------------------------------------------- */
 /* Face planes of (sdf,type) and boundary chunk info, packed contiguously for torch.distributed /
@@ -227,6 +233,9 @@ size_t ivx_halo_bytes(ivx_grid*);
 int ivx_halo_pack(ivx_grid*, int side, void* device_buf);
 int ivx_halo_unpack(ivx_grid*, int side, const void* device_buf); /* install as ghost layer on `side` */
 int ivx_halo_clear(ivx_grid*, int side);                          /* no neighbour: outside the grid */
+/* stream-ordered variants (no host wait): for callers whose communication runs on the context's stream */
+int ivx_halo_pack_enqueue(ivx_grid*, int side, void* device_buf);
+int ivx_halo_unpack_enqueue(ivx_grid*, int side, const void* device_buf);
 
 /* Cross-slab connected regions: after ivx_label_regions on every slab, exchange the face planes of
  * component ids with the x neighbours, list the distinct (own component, neighbour component) pairs
@@ -238,6 +247,14 @@ int ivx_halo_clear(ivx_grid*, int side);                          /* no neighbou
 size_t ivx_region_face_bytes(ivx_grid*);
 int ivx_region_face_labels(ivx_grid*, int side, void* device_buf);
 int ivx_region_face_pairs(ivx_grid*, int side, const void* neighbour_face_labels_device, uint32_t* pairs, size_t cap, size_t* n_out);
+/* Stream-ordered form of the same exchange, ending in ONE fixed-size record per slab that is written on the device and can go
+ * straight into an all-gather: ivx_step_record_words() 64-bit words = [0] components of the slab, [1] number of (own,
+ * neighbour) pairs across the upper face, [2..14) occupied ranges, [14..17) mesh vertices / indices / submeshes, [17] error
+ * flags, [18..28) the 10 moments (f64 bit patterns), [28..) the pairs (at most 4096). */
+int ivx_region_face_labels_enqueue(ivx_grid*, int side, void* device_buf);
+int ivx_region_face_pairs_enqueue(ivx_grid*, int side, const void* neighbour_face_labels_device);
+size_t ivx_step_record_words(void);
+int ivx_step_record_enqueue(ivx_grid*, void* device_record);
 
 /* ---- a15-a19: rigid bodies + sequential-impulses contact solve (engine/crates/impact_physics) ----- */
 /* DynamicRigidBody, #[repr(C)], 152 bytes (src/rigid_body.rs:94-103). Matrices are Matrix3C (column-major),
