@@ -287,7 +287,24 @@ __global__ __launch_bounds__(256) void k_step_preset(uint32_t stages, uint32_t* 
     if ((stages & IVX_STAGE_SAMPLE) && i == 0 && eval_count) eval_count[0] = 0u;
 }
 
+// gathers the small results of a step into one host-mapped block: [0..28) region scalars + occupied minima/maxima,
+// [28..31) mesh totals, [32..52) the 10 moments (f64 as two words each)
+__global__ __launch_bounds__(64) void k_result_gather(const uint32_t* __restrict__ rscalar, const uint32_t* __restrict__ mesh_totals,
+                                                      const double* __restrict__ moments, uint32_t* __restrict__ host_block) {
+    const uint32_t t = threadIdx.x;
+    if (t < 28u) host_block[t] = rscalar[t];
+    if (t < 3u) host_block[28 + t] = mesh_totals[t];
+    if (t < 20u) host_block[32 + t] = reinterpret_cast<const uint32_t*>(moments)[t];
+}
+
 }  // namespace
+
+int ivx_launch_result_gather(ivx_grid* g, uint32_t* host_block_dev) {
+    hipLaunchKernelGGL(k_result_gather, dim3(1), dim3(64), 0, g->ctx->stream, g->rscalar, g->chunk_offsets + 2 * (size_t)g->n_chunks,
+                       g->partials + g->partial_blocks * 10, host_block_dev);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
 
 int ivx_launch_step_preset(ivx_grid* g, uint32_t stages) {
     const uint32_t groups = (g->n_chunks + 255u) / 256u;

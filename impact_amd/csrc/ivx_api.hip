@@ -29,6 +29,7 @@ int dev_alloc(T** p, size_t count) {
 int ensure_host_scratch(ivx_grid* g, size_t bytes) {
     if (g->host_scratch_bytes >= bytes) return IVX_OK;
     if (g->host_scratch) (void)hipHostFree(g->host_scratch);
+    if (g->result_host) (void)hipHostFree(g->result_host);
     g->host_scratch = nullptr;
     g->host_scratch_bytes = 0;
     IVX_HIP_CHECK(hipHostMalloc(&g->host_scratch, bytes, hipHostMallocDefault));
@@ -248,6 +249,7 @@ void ivx_grid_destroy(ivx_grid* g) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->host_scratch) (void)hipHostFree(g->host_scratch);
+    if (g->result_host) (void)hipHostFree(g->result_host);
     if (g->ev_ready)
         for (int i = 0; i < 2 * IVX_N_TIMED_STAGES; ++i) (void)hipEventDestroy(g->ev[i]);
     delete g;
@@ -802,9 +804,17 @@ int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
         ivx_grid* g;
         ~PresetGuard() { g->scratch_preset = 0; }
     } preset_guard{g};
-#define T0(i) IVX_HIP_CHECK(hipEventRecord(g->ev[2 * (i)], s))
+    // a stage's duration runs from the stop event of the stage enqueued just before it, when there is one
+    hipEvent_t* last_stop = nullptr;
+#define T0(i)                                                  \
+    if (last_stop) g->ev_start_ref[i] = last_stop;             \
+    else {                                                     \
+        IVX_HIP_CHECK(hipEventRecord(g->ev[2 * (i)], s));      \
+        g->ev_start_ref[i] = &g->ev[2 * (i)];                  \
+    }
 #define T1(i)                                                  \
-    IVX_HIP_CHECK(hipEventRecord(g->ev[2 * (i) + 1], s)); \
+    IVX_HIP_CHECK(hipEventRecord(g->ev[2 * (i) + 1], s));      \
+    last_stop = &g->ev[2 * (i) + 1];                           \
     g->timed_mask |= 1u << (i)
     if (stages & IVX_STAGE_SAMPLE) {
         T0(0);
@@ -864,10 +874,18 @@ int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out) {
     hipStream_t s = g->ctx->stream;
     memset(out, 0, sizeof(*out));
     const uint32_t stages = g->pending_stages;
+    // the small results of every stage (region scalars + occupied minima/maxima, mesh totals, moments) arrive in one
+    // host-mapped block written by a last tiny kernel: one wait, no copies
+    if (!g->result_host) {
+        IVX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&g->result_host), 64 * sizeof(uint32_t), hipHostMallocMapped));
+        IVX_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&g->result_host_dev), g->result_host, 0));
+    }
+    {
+        int rc = ivx_launch_result_gather(g, g->result_host_dev);
+        if (rc) return rc;
+    }
     IVX_HIP_CHECK(hipStreamSynchronize(s));
-    // the small results of every stage: region scalars + occupied minima/maxima (28 words), mesh totals, moments
-    uint32_t sc[28];
-    IVX_HIP_CHECK(hipMemcpy(sc, g->rscalar, sizeof(sc), hipMemcpyDeviceToHost));
+    const uint32_t* sc = g->result_host;
     if (stages & IVX_STAGE_REGIONS) {
         IVX_REQUIRE((sc[1] & 1u) == 0, IVX_ERR_CAPACITY, "ivx_voxel_step: a chunk has more than 254 local regions");
         g->region_count = sc[0];
@@ -876,8 +894,7 @@ int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out) {
     }
     if (stages & IVX_STAGE_OCCUPIED) ivx_occupied_from_raw(g, sc + 16, out->occupied);
     if (stages & IVX_STAGE_REMESH) {
-        uint32_t totals[3];
-        IVX_HIP_CHECK(hipMemcpy(totals, g->chunk_offsets + 2 * (size_t)g->n_chunks, sizeof(totals), hipMemcpyDeviceToHost));
+        const uint32_t totals[3] = {sc[28], sc[29], sc[30]};
         if (totals[0] > g->vcap || totals[1] > g->icap || totals[2] > g->scap) {
             int rc;
             if ((rc = ensure_mesh_capacity(g, totals[0], totals[1], totals[2]))) return rc;
@@ -891,14 +908,14 @@ int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out) {
         g->mesh_valid = 1;
     }
     if (stages & IVX_STAGE_INERTIA) {
-        IVX_HIP_CHECK(hipMemcpy(out->moments.m64, g->partials + g->partial_blocks * 10, 10 * sizeof(double), hipMemcpyDeviceToHost));
+        memcpy(out->moments.m64, sc + 32, 10 * sizeof(double));
         for (int i = 0; i < 10; ++i) out->moments.m32[i] = (float)out->moments.m64[i];
     }
     out->mesh = g->mesh_counts;
     for (int i = 0; i < IVX_N_TIMED_STAGES; ++i) {
         float ms = 0.0f;
         if ((g->timed_mask >> i) & 1u)
-            if (hipEventElapsedTime(&ms, g->ev[2 * i], g->ev[2 * i + 1]) != hipSuccess) ms = 0.0f;
+            if (hipEventElapsedTime(&ms, *g->ev_start_ref[i], g->ev[2 * i + 1]) != hipSuccess) ms = 0.0f;
         out->stage_ms[i] = ms;
     }
     (void)kStageOfTimed;

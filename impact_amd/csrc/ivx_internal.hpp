@@ -99,6 +99,9 @@ struct ivx_grid {
     void* samp_ops;       // [n_chunks * 128] uint2 ops
     hipEvent_t ev[2 * IVX_N_TIMED_STAGES];  // start/stop per timed stage
     int ev_ready;
+    uint32_t* result_host;      // 64 words of host-mapped pinned memory the gather kernel writes the step's small results to
+    uint32_t* result_host_dev;  // its device-side address
+    hipEvent_t* ev_start_ref[IVX_N_TIMED_STAGES];  // the event a stage's duration starts from (the previous stage's stop when adjacent)
     uint32_t pending_stages;  // stages enqueued since the last collect
     uint32_t timed_mask;      // timed stages whose events were recorded since the last collect
     uint32_t* pairs_dev;      // [4 + 128 + 2 * IVX_MAX_FACE_PAIRS]: count, seen table, (own, neighbour) component pairs across the upper x face
@@ -167,6 +170,7 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
                           const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type);
 int ivx_launch_derive(ivx_grid* g);
 int ivx_launch_step_preset(ivx_grid* g, uint32_t stages);
+int ivx_launch_result_gather(ivx_grid* g, uint32_t* host_block_dev);
 int ivx_sampler_buffers(ivx_grid* g);
 int ivx_launch_occupied(ivx_grid* g, uint32_t* d_raw);
 void ivx_occupied_from_raw(const ivx_grid* g, const uint32_t raw[12], uint32_t out[12]);
