@@ -77,13 +77,25 @@ __device__ __forceinline__ uint32_t prefix_ordered(uint32_t val, uint32_t* s_wsu
 // run is the voxel index of its first voxel, links go through LDS atomicMin (root = smallest index).
 __global__ __launch_bounds__(256) void k_ccl_local(GridView g, const uint8_t* __restrict__ flags, uint8_t* __restrict__ labels,
                                                    ivx_chunk_info* __restrict__ info, uint32_t* __restrict__ rparent,
-                                                   uint32_t* __restrict__ rscalar, uint32_t* __restrict__ multi_list) {
+                                                   uint32_t* __restrict__ rscalar, uint32_t* __restrict__ multi_list,
+                                                   const uint8_t* __restrict__ chunk_class, const uint32_t* __restrict__ work_counts,
+                                                   const uint32_t* __restrict__ active_list) {
     __shared__ uint32_t s_par[IVX_CHUNK_VOXELS];
     __shared__ uint32_t s_mask[256];
+    __shared__ uint32_t s_cnt;
     const uint32_t tid = threadIdx.x;
     const uint32_t n_chunks = g.cx * g.cy * g.cz;
-    const uint32_t chunk = ivx_xcd_remap(blockIdx.x, n_chunks);
     const int ti = tid >> 4, tj = tid & 15;
+    // prologue, one thread per chunk of the grid: the chunks k_chunk_pre settled (Void: no region; Uniform: one region that is
+    // its own node until the merge pass links it) have no voxels to look at
+    {
+        const uint32_t c = blockIdx.x * 256u + tid;
+        if (c < n_chunks && chunk_class[c] && g.info[c].kind == KIND_UNIFORM) rparent[(size_t)c * 256] = c * 256u;
+    }
+    const uint32_t n_active = work_counts[0];
+    for (uint32_t li = ivx_xcd_remap(blockIdx.x, gridDim.x); li < n_active; li += gridDim.x) {
+    __syncthreads();  // the previous chunk's LDS use is over
+    const uint32_t chunk = active_list[li];
     const size_t base = (size_t)chunk * IVX_CHUNK_VOXELS + (size_t)tid * 16;
     const ivx_chunk_info cinfo = g.info[chunk];
     const uint32_t kind = cinfo.kind;
@@ -99,14 +111,14 @@ __global__ __launch_bounds__(256) void k_ccl_local(GridView g, const uint8_t* __
     if (!any || all_full) {
         // no voxels, or one solid region touching every face
         const uint32_t lab = any ? 0u : 0xFFFFFFFFu;
-        *reinterpret_cast<uint4*>(labels + base) = make_uint4(lab, lab, lab, lab);
+        if (kind == KIND_NONUNIFORM) *reinterpret_cast<uint4*>(labels + base) = make_uint4(lab, lab, lab, lab);  // else: compact planes
         // only slots below region_count are ever read (flatten / assign / find walk valid nodes only)
         if (tid == 0) {
             rp[0] = any ? chunk * 256u : NODE_NONE;
             info[chunk].region_count = any ? 1 : 0;
             info[chunk].boundary_region_count = any ? 1 : 0;
         }
-        return;
+        continue;
     }
 
     // 1. one node per run, keyed by the voxel index of its first voxel
@@ -158,7 +170,6 @@ __global__ __launch_bounds__(256) void k_ccl_local(GridView g, const uint8_t* __
     const bool edge_row = ti == 0 || ti == 15 || tj == 0 || tj == 15;
     const int touches = __syncthreads_or(edge_row ? (m != 0) : ((m & 0x8001u) != 0));
     // (a root keeps itself as parent, every other node points somewhere else, so no flattening is needed to count)
-    __shared__ uint32_t s_cnt;
     if (tid == 0) s_cnt = 0;
     __syncthreads();
     if (n_roots) atomicAdd(&s_cnt, n_roots);
@@ -179,6 +190,7 @@ __global__ __launch_bounds__(256) void k_ccl_local(GridView g, const uint8_t* __
         // several regions: the reference's numbering is reproduced by k_ccl_local_exact
         info[chunk].region_count = (uint8_t)(rc < 254u ? rc : 254u);
         multi_list[atomicAdd(&rscalar[2], 1u)] = chunk;
+    }
     }
 }
 
@@ -305,9 +317,16 @@ __global__ __launch_bounds__(64) void k_ccl_local_exact(GridView g, const uint8_
 
 // ---- level 2 ---------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t g_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// find with path halving: a node's parent only ever moves to an ancestor, and ancestors have smaller indices (unions hang the
+// larger root under the smaller), so shortening with atomicMin is safe beside concurrent unions and other finds
 __device__ __forceinline__ uint32_t g_find(uint32_t* par, uint32_t x) {
-    uint32_t p;
-    while ((p = g_load(par + x)) != x) x = p;
+    uint32_t p = g_load(par + x);
+    while (p != x) {
+        const uint32_t gp = g_load(par + p);
+        if (gp != p) atomicMin(par + x, gp);
+        x = p;
+        p = gp;
+    }
     return x;
 }
 __device__ __forceinline__ void g_union(uint32_t* par, uint32_t a, uint32_t b) {
@@ -326,50 +345,111 @@ __device__ __forceinline__ void g_union(uint32_t* par, uint32_t a, uint32_t b) {
     }
 }
 
-// one workgroup per chunk; joins its regions with the regions of the +x, +y, +z neighbour chunks
-__global__ __launch_bounds__(256) void k_ccl_merge(GridView g, const uint8_t* __restrict__ labels, uint32_t* __restrict__ rparent) {
-    const uint32_t tid = threadIdx.x;
-    const uint32_t n_chunks = g.cx * g.cy * g.cz;
-    const uint32_t chunk = ivx_xcd_remap(blockIdx.x, n_chunks);
-    const ivx_chunk_info oinfo = g.info[chunk];
-    if (oinfo.region_count == 0) return;
-    const uint32_t own_kind = oinfo.kind, own_fd = oinfo.face_dist, own_rc = oinfo.region_count;
-    const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
-    const int a = tid >> 4, b = tid & 15;
-    const uint8_t* own = labels + (size_t)chunk * IVX_CHUNK_VOXELS;
+// Solid chunks (generated Uniform: one region, six Full faces, demoted or not) make up the bulk of a body, and joining them
+// pairwise through the forest costs a chain of dependent global loads per pair. They are joined by structure instead: one
+// WAVE per (ci, cj) column of chunks, lane = ck. A run of solid chunks along k hangs directly under the first chunk of the
+// run (plain stores: those nodes are nobody's root yet); where a run overlaps a run of the +y / +x neighbour column, the two
+// run heads are joined once. k_ccl_merge then leaves solid-solid pairs alone.
+__global__ __launch_bounds__(256) void k_ccl_merge_solid(GridView g, uint32_t* __restrict__ rparent) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t col = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (col >= g.cx * g.cy) return;
+    const uint32_t cj = col % g.cy, ci = col / g.cy;
+    // heads of the solid runs that reach the end of the previous 64-chunk segment: this column, the +y and the +x column
+    uint32_t carry[3] = {NODE_NONE, NODE_NONE, NODE_NONE};
+    const uint32_t cols[3] = {col, col + 1u, col + g.cy};
+    for (uint32_t k0 = 0; k0 < g.cz; k0 += 64u) {
+        const uint32_t ck = k0 + lane;
+        const bool in = ck < g.cz;
+        const uint32_t chunk = col * g.cz + ck;
+        bool solid[3];
+        solid[0] = in && g.info[chunk].gen_kind == KIND_UNIFORM;
+        solid[1] = in && cj + 1 < g.cy && g.info[chunk + g.cz].gen_kind == KIND_UNIFORM;
+        solid[2] = in && ci + 1 < g.cx && g.info[chunk + g.cy * g.cz].gen_kind == KIND_UNIFORM;
+        unsigned long long m[3];
+        uint32_t head[3];
 #pragma unroll
-    for (int dim = 0; dim < 3; ++dim) {
+        for (int q = 0; q < 3; ++q) {
+            m[q] = __ballot(solid[q]);
+            // node of the first chunk of the run of column q that contains this lane (runs continue across segments)
+            const unsigned long long gaps = ~m[q] & ((1ull << lane) - 1ull);
+            const uint32_t hs = gaps ? 64u - (uint32_t)__clzll(gaps) : 0u;
+            head[q] = (hs == 0u && carry[q] != NODE_NONE) ? carry[q] : (cols[q] * g.cz + k0 + hs) * 256u;
+        }
+        if (solid[0]) {
+            if (head[0] != chunk * 256u) rparent[(size_t)chunk * 256] = head[0];
+            // one union of run heads per overlap of this column's runs with a neighbour column's runs (heads are never
+            // written by the plain stores above, so the atomics of g_union are safe beside them)
+#pragma unroll
+            for (int q = 1; q < 3; ++q) {
+                const unsigned long long common = m[0] & m[q];
+                if (solid[q] && (lane == 0 || !((common >> (lane - 1)) & 1ull))) g_union(rparent, head[0], head[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            // the run containing lane 63, if any, carries its head into the next segment
+            const uint32_t h63 = __shfl(head[q], 63, 64);
+            carry[q] = ((m[q] >> 63) & 1ull) ? h63 : NODE_NONE;
+        }
+    }
+}
+
+// Pairs of single-region chunks (nearly all pairs that are not solid-solid): one THREAD per (active chunk, direction) joins
+// the chunk's region with the +x, +y or +z neighbour's across a face where k_derive saw a touching voxel pair. No label
+// plane is read.
+__global__ __launch_bounds__(256) void k_ccl_merge_single(GridView g, const uint8_t* __restrict__ touch, uint32_t* __restrict__ rparent,
+                                                          const uint32_t* __restrict__ work_counts, const uint32_t* __restrict__ active_list) {
+    const uint32_t n_items = work_counts[0] * 3u;
+    for (uint32_t it = blockIdx.x * 256u + threadIdx.x; it < n_items; it += gridDim.x * 256u) {
+        const uint32_t chunk = active_list[it / 3u];
+        const int dim = (int)(it % 3u);
+        if (!((touch[chunk] >> dim) & 1u)) continue;
+        const ivx_chunk_info oinfo = g.info[chunk];
+        if (oinfo.region_count != 1) continue;  // none, or several: k_ccl_merge_multi
+        const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
         const int ni = ci + (dim == 0), nj = cj + (dim == 1), nk = ck + (dim == 2);
         if (ni >= (int)g.cx || nj >= (int)g.cy || nk >= (int)g.cz) continue;
         const uint32_t nchunk = (ni * g.cy + nj) * g.cz + nk;
         const ivx_chunk_info ninfo = g.info[nchunk];
-        if (ninfo.region_count == 0) continue;
-        // face distributions decide most pairs without touching the label planes: an Empty face joins nothing,
-        // two Full faces of single-region chunks join exactly (region 0, region 0)
-        const uint32_t fd_own = own_kind == KIND_UNIFORM ? (uint32_t)FD_FULL : ((own_fd >> (2 * (2 * dim + 1))) & 3u);
-        const uint32_t fd_nbr = ninfo.kind == KIND_UNIFORM ? (uint32_t)FD_FULL : (((uint32_t)ninfo.face_dist >> (2 * (2 * dim))) & 3u);
-        if (fd_own == FD_EMPTY || fd_nbr == FD_EMPTY) continue;
-        if (fd_own == FD_FULL && fd_nbr == FD_FULL && own_rc == 1 && ninfo.region_count == 1) {
-            if (tid == 0) g_union(rparent, chunk * 256u, nchunk * 256u);
-            continue;
+        if (ninfo.region_count != 1) continue;
+        if (oinfo.gen_kind == KIND_UNIFORM && ninfo.gen_kind == KIND_UNIFORM) continue;  // joined by k_ccl_merge_solid
+        g_union(rparent, chunk * 256u, nchunk * 256u);
+    }
+}
+
+// Chunks with several regions (the list k_ccl_local made): one workgroup per such chunk joins its regions with those of
+// all SIX neighbours through the label planes (a single-region neighbour does not look at this pair itself).
+__global__ __launch_bounds__(256) void k_ccl_merge_multi(GridView g, const uint8_t* __restrict__ labels, uint32_t* __restrict__ rparent,
+                                                         const uint32_t* __restrict__ rscalar, const uint32_t* __restrict__ multi_list) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_multi = rscalar[2];
+    const int a = tid >> 4, b = tid & 15;
+    for (uint32_t li = blockIdx.x; li < n_multi; li += gridDim.x) {
+        const uint32_t chunk = multi_list[li];
+        const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
+        const uint8_t* own = labels + (size_t)chunk * IVX_CHUNK_VOXELS;  // a chunk with several regions is NonUniform: it has planes
+#pragma unroll
+        for (int f = 0; f < 6; ++f) {
+            const int dim = f >> 1, up = f & 1;
+            const int ni = ci + (dim == 0 ? (up ? 1 : -1) : 0), nj = cj + (dim == 1 ? (up ? 1 : -1) : 0), nk = ck + (dim == 2 ? (up ? 1 : -1) : 0);
+            if (ni < 0 || nj < 0 || nk < 0 || ni >= (int)g.cx || nj >= (int)g.cy || nk >= (int)g.cz) continue;
+            const uint32_t nchunk = (ni * g.cy + nj) * g.cz + nk;
+            const ivx_chunk_info ninfo = g.info[nchunk];
+            if (ninfo.region_count == 0) continue;
+            const uint8_t* nb = labels + (size_t)nchunk * IVX_CHUNK_VOXELS;
+            const uint32_t so = up ? 15u : 0u, sn = up ? 0u : 15u;  // own / neighbour layer along `dim`
+            const uint32_t oo = dim == 0 ? ((so << 8) | (a << 4) | b) : (dim == 1 ? ((a << 8) | (so << 4) | b) : ((a << 8) | (b << 4) | so));
+            const uint32_t on = dim == 0 ? ((sn << 8) | (a << 4) | b) : (dim == 1 ? ((a << 8) | (sn << 4) | b) : ((a << 8) | (b << 4) | sn));
+            const uint32_t la = own[oo];
+            // a Uniform neighbour is region 0 everywhere and has no label plane (compact planes)
+            const uint32_t lb = ninfo.kind == KIND_NONUNIFORM ? (uint32_t)nb[on] : 0u;
+            const bool both = la != 255u && lb != 255u;
+            const uint32_t pair = both ? ((la << 8) | lb) : 0xFFFFFFFFu;
+            const uint32_t prev = __shfl_up(pair, 1, 64);
+            const bool dup = (tid & 63u) != 0 && prev == pair;
+            if (both && !dup) g_union(rparent, chunk * 256u + la, nchunk * 256u + lb);
         }
-        const uint8_t* nb = labels + (size_t)nchunk * IVX_CHUNK_VOXELS;
-        uint32_t la, lb;
-        if (dim == 0) {
-            la = own[(15 << 8) | (a << 4) | b];
-            lb = nb[(0 << 8) | (a << 4) | b];
-        } else if (dim == 1) {
-            la = own[(a << 8) | (15 << 4) | b];
-            lb = nb[(a << 8) | (0 << 4) | b];
-        } else {
-            la = own[(a << 8) | (b << 4) | 15];
-            lb = nb[(a << 8) | (b << 4) | 0];
-        }
-        const bool both = la != 255u && lb != 255u;
-        const uint32_t pair = both ? ((la << 8) | lb) : 0xFFFFFFFFu;
-        const uint32_t prev = __shfl_up(pair, 1, 64);
-        const bool dup = (tid & 63u) != 0 && prev == pair;
-        if (both && !dup) g_union(rparent, chunk * 256u + la, nchunk * 256u + lb);
     }
 }
 
@@ -469,7 +549,8 @@ __global__ __launch_bounds__(256) void k_face_ids(GridView g, uint32_t side, con
                                                   const uint32_t* __restrict__ rcompid, uint32_t* __restrict__ out) {
     const uint32_t col = blockIdx.x, tid = threadIdx.x;
     const uint32_t chunk = (side ? g.cx - 1 : 0u) * g.cy * g.cz + col;
-    const uint32_t l = labels[(size_t)chunk * IVX_CHUNK_VOXELS + ((side ? 15u : 0u) << 8) + tid];
+    const uint32_t ckind = g.info[chunk].kind;
+    const uint32_t l = ckind != KIND_NONUNIFORM ? ivx_uniform_label(ckind) : labels[(size_t)chunk * IVX_CHUNK_VOXELS + ((side ? 15u : 0u) << 8) + tid];
     out[(size_t)col * 256 + tid] = l == 255u ? NODE_NONE : rcompid[chunk * 256u + l];
 }
 
@@ -478,7 +559,8 @@ __global__ __launch_bounds__(256) void k_face_pairs(GridView g, uint32_t side, c
                                                     uint32_t* __restrict__ n_pairs, uint2* __restrict__ pairs, uint32_t cap, uint32_t* __restrict__ seen) {
     const uint32_t col = blockIdx.x, tid = threadIdx.x;
     const uint32_t chunk = (side ? g.cx - 1 : 0u) * g.cy * g.cz + col;
-    const uint32_t l = labels[(size_t)chunk * IVX_CHUNK_VOXELS + ((side ? 15u : 0u) << 8) + tid];
+    const uint32_t ckind = g.info[chunk].kind;
+    const uint32_t l = ckind != KIND_NONUNIFORM ? ivx_uniform_label(ckind) : labels[(size_t)chunk * IVX_CHUNK_VOXELS + ((side ? 15u : 0u) << 8) + tid];
     const uint32_t a = l == 255u ? NODE_NONE : rcompid[chunk * 256u + l];
     const uint32_t b = nbr[(size_t)col * 256 + tid];
     const bool both = a != NODE_NONE && b != NODE_NONE;
@@ -668,7 +750,9 @@ int ivx_launch_ccl_local(ivx_grid* g) {
     GridView v = ivx_view(g);
     if (!g->scratch_preset) IVX_HIP_CHECK(hipMemsetAsync(g->rscalar, 0, 16 * sizeof(uint32_t), g->ctx->stream));
     uint32_t* multi_list = g->ccl_scratch;  // reused by the resolve pass afterwards
-    hipLaunchKernelGGL(k_ccl_local, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, v, g->flags, g->llabel, g->info, g->rparent, g->rscalar, multi_list);
+    g->planes_compact = 1;
+    hipLaunchKernelGGL(k_ccl_local, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->flags, g->llabel, g->info, g->rparent, g->rscalar, multi_list,
+                       g->chunk_class, g->work_counts, g->active_list);
     const uint32_t exact_blocks = g->n_chunks < 2048u ? g->n_chunks : 2048u;
     hipLaunchKernelGGL(k_ccl_local_exact, dim3(exact_blocks), dim3(64), 0, g->ctx->stream, v, g->flags, g->llabel, g->info, g->rparent, g->rscalar,
                        multi_list);
@@ -678,7 +762,11 @@ int ivx_launch_ccl_local(ivx_grid* g) {
 
 int ivx_launch_ccl_merge(ivx_grid* g) {
     GridView v = ivx_view(g);
-    hipLaunchKernelGGL(k_ccl_merge, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, v, g->llabel, g->rparent);
+    hipLaunchKernelGGL(k_ccl_merge_solid, dim3((g->cc[0] * g->cc[1] + 3u) / 4u), dim3(256), 0, g->ctx->stream, v, g->rparent);
+    uint32_t single_blocks = (3u * ivx_list_grid(g) + 255u) / 256u;
+    hipLaunchKernelGGL(k_ccl_merge_single, dim3(single_blocks), dim3(256), 0, g->ctx->stream, v, g->chunk_touch, g->rparent, g->work_counts, g->active_list);
+    const uint32_t multi_blocks = g->n_chunks < 256u ? g->n_chunks : 256u;
+    hipLaunchKernelGGL(k_ccl_merge_multi, dim3(multi_blocks), dim3(256), 0, g->ctx->stream, v, g->llabel, g->rparent, g->rscalar, g->ccl_scratch);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -697,6 +785,10 @@ int ivx_launch_ccl_resolve(ivx_grid* g) {
 }
 
 int ivx_launch_ccl_dense_labels(ivx_grid* g, uint32_t* d_labels) {
+    {
+        int rc = ivx_ensure_dense(g);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(k_ccl_dense, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, g->n_chunks, g->llabel, g->rcompid, d_labels);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
@@ -749,6 +841,10 @@ int ivx_launch_region_stats(ivx_grid* g, const float* d_dens, void* d_buf, uint3
     IVX_HIP_CHECK(hipMemsetAsync(o.lo, 0xFF, sizeof(uint32_t) * 3 * n, g->ctx->stream));
     IVX_HIP_CHECK(hipMemsetAsync(o.hi, 0, sizeof(uint32_t) * (3 + 1 + 1 + 1) * n, g->ctx->stream));
     GridView v = ivx_view(g);
+    {
+        int rc = ivx_ensure_dense(g);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(k_region_stats, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, v, g->x_off, g->llabel, g->rparent, g->rcompid, d_dens, o);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;

@@ -38,75 +38,122 @@ __device__ __forceinline__ uint32_t row_mask(uint4 s) {
     return m;
 }
 
-__global__ __launch_bounds__(256) void k_derive(GridView g, uint8_t* __restrict__ flags_out, ivx_chunk_info* __restrict__ info,
-                                                uint32_t* __restrict__ bbox) {
-    __shared__ uint32_t occ[18][18];  // non-empty masks of rows (i+1, j+1); halo rows from neighbour chunks
-    __shared__ uint32_t cnt[12];      // own face non-empty counts [0..6), neighbour face non-empty counts [6..12)
-    const uint32_t tid = threadIdx.x;
-    const uint32_t n_chunks = g.cx * g.cy * g.cz;
-    const uint32_t chunk = ivx_xcd_remap(blockIdx.x, n_chunks);
-    const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
-    const int ti = tid >> 4, tj = tid & 15;
+// non-empty mask of one 16-voxel row of chunk `c` (row offset `off` inside the chunk). Chunks generated Void / Uniform
+// are known from their record; their planes are not read (and need not hold data: compact planes).
+__device__ __forceinline__ uint32_t nbr_row_mask(const GridView& g, const ivx_chunk_info* info, size_t c, uint32_t off) {
+    const uint32_t gen = info[c].gen_kind;
+    if (gen != KIND_NONUNIFORM) return gen == KIND_UNIFORM ? 0xFFFFu : 0u;
+    return row_mask(*reinterpret_cast<const uint4*>(g.sdf + c * IVX_CHUNK_VOXELS + off));
+}
 
-    const size_t base = (size_t)chunk * IVX_CHUNK_VOXELS;
-    // Fast paths by chunk class (the 8-byte chunk records instead of the 4 KiB planes): a Void chunk has only
-    // EMPTY flags; a chunk generated Uniform whose six neighbours were generated Uniform too is solid all
-    // round. Neither needs a voxel read; both still write their flags plane.
-    {
-        const uint32_t gen = info[chunk].gen_kind;
-        bool fast = gen == KIND_VOID;
-        uint32_t fill = VF_EMPTY * 0x01010101u;
+// One THREAD per chunk: settles every chunk whose derived state follows from the chunk records alone and lists the others
+// (the "active" chunks) for the workgroup-per-chunk kernels. A Void chunk has no voxels; a chunk generated Uniform whose six
+// neighbours were generated Uniform too is solid all round and stays Uniform. Neither has planes (compact planes), so all of
+// their per-step state is the record, the occupied sub-box, one region and empty mesh counts.
+__global__ __launch_bounds__(256) void k_chunk_pre(GridView g, ivx_chunk_info* __restrict__ info, uint32_t* __restrict__ bbox,
+                                                   uint32_t* __restrict__ mesh_counts, uint8_t* __restrict__ chunk_class,
+                                                   uint32_t* __restrict__ work_counts, uint32_t* __restrict__ active_list) {
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_base;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n_chunks = g.cx * g.cy * g.cz;
+    const uint32_t chunk = blockIdx.x * 256u + tid;
+    const bool live = chunk < n_chunks;
+    bool settled = false;
+    if (live) {
+        const ivx_chunk_info own = info[chunk];
+        const uint32_t gen = own.gen_kind;
+        settled = gen == KIND_VOID;
         if (gen == KIND_UNIFORM) {
-            const bool inner = ci > 0 && cj > 0 && ck > 0 && ci + 1 < (int)g.cx && cj + 1 < (int)g.cy && ck + 1 < (int)g.cz;
-            if (inner) {
+            const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
+            if (ci > 0 && cj > 0 && ck > 0 && ci + 1 < (int)g.cx && cj + 1 < (int)g.cy && ck + 1 < (int)g.cz) {
                 const uint32_t sx = g.cy * g.cz, sy = g.cz;
-                fast = info[chunk - sx].gen_kind == KIND_UNIFORM && info[chunk + sx].gen_kind == KIND_UNIFORM &&
-                       info[chunk - sy].gen_kind == KIND_UNIFORM && info[chunk + sy].gen_kind == KIND_UNIFORM &&
-                       info[chunk - 1].gen_kind == KIND_UNIFORM && info[chunk + 1].gen_kind == KIND_UNIFORM;
-                fill = 0xFCFCFCFCu;
+                settled = info[chunk - sx].gen_kind == KIND_UNIFORM && info[chunk + sx].gen_kind == KIND_UNIFORM &&
+                          info[chunk - sy].gen_kind == KIND_UNIFORM && info[chunk + sy].gen_kind == KIND_UNIFORM &&
+                          info[chunk - 1].gen_kind == KIND_UNIFORM && info[chunk + 1].gen_kind == KIND_UNIFORM;
             }
         }
-        if (fast) {  // uniform across the workgroup
-            *reinterpret_cast<uint4*>(flags_out + base + (size_t)tid * 16) = make_uint4(fill, fill, fill, fill);
-            if (tid == 0) {
-                ivx_chunk_info ci_ = info[chunk];
-                ci_.kind = (uint8_t)gen;
-                ci_.flags = 0;
-                ci_.face_dist = gen == KIND_UNIFORM ? 0x555 : 0;
-                ci_.uniform_type = gen == KIND_UNIFORM ? g.type[base] : (uint8_t)0;
-                info[chunk] = ci_;
-                bbox[chunk] = gen == KIND_UNIFORM ? (0x80000000u | (15u << 4) | (15u << 12) | (15u << 20)) : 0u;
-            }
-            return;
+        if (settled) {
+            const bool solid = gen == KIND_UNIFORM;
+            ivx_chunk_info rec = own;
+            rec.kind = (uint8_t)gen;
+            rec.flags = 0;
+            rec.face_dist = solid ? 0x555 : 0;
+            // a chunk demoted by an earlier pass has its planes written out and its record's type cleared
+            rec.uniform_type = solid ? (own.kind == KIND_NONUNIFORM ? g.type[(size_t)chunk * IVX_CHUNK_VOXELS] : own.uniform_type) : (uint8_t)0;
+            rec.region_count = solid ? 1 : 0;
+            rec.boundary_region_count = solid ? 1 : 0;
+            info[chunk] = rec;
+            bbox[chunk] = solid ? (0x80000000u | (15u << 4) | (15u << 12) | (15u << 20)) : 0u;
+            mesh_counts[2 * chunk] = 0;
+            mesh_counts[2 * chunk + 1] = 0;
         }
+        chunk_class[chunk] = settled ? 1 : 0;
     }
-    if (tid < 12) cnt[tid] = 0;
-    const uint32_t m = row_mask(*reinterpret_cast<const uint4*>(g.sdf + base + (size_t)tid * 16));
+    // ordered append of this block's active chunks (one atomic per block; the list stays nearly sorted, so neighbouring
+    // list entries are neighbouring chunks)
+    const bool active = live && !settled;
+    const unsigned long long bal = __ballot(active);
+    if (lane == 0) s_w[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (tid == 0) s_base = atomicAdd(&work_counts[0], (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
+    __syncthreads();
+    if (active) {
+        uint32_t off = s_base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        for (uint32_t w = 0; w < wave; ++w) off += s_w[w];
+        active_list[off] = chunk;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_derive(GridView g, int8_t* __restrict__ sdf_rw, uint8_t* __restrict__ type_rw, uint8_t* __restrict__ flags_out,
+                                                ivx_chunk_info* __restrict__ info, uint32_t* __restrict__ bbox, uint8_t* __restrict__ touch,
+                                                const uint32_t* __restrict__ work_counts, const uint32_t* __restrict__ active_list) {
+    __shared__ uint32_t occ[18][18];  // non-empty masks of rows (i+1, j+1); halo rows from neighbour chunks
+    __shared__ uint32_t cnt[13];      // own face non-empty counts [0..6), neighbour face non-empty counts [6..12), [12] touch bits
+    const uint32_t tid = threadIdx.x;
+    const int ti = tid >> 4, tj = tid & 15;
+    const uint32_t n_active = work_counts[0];
+    // bounded walk over the active list (virtual block ids give each XCD a contiguous stretch of it)
+    for (uint32_t li = ivx_xcd_remap(blockIdx.x, gridDim.x); li < n_active; li += gridDim.x) {
+    __syncthreads();  // the previous chunk's LDS use is over
+    const uint32_t chunk = active_list[li];
+    const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
+    const size_t base = (size_t)chunk * IVX_CHUNK_VOXELS;
+    const ivx_chunk_info own_info = info[chunk];
+    if (tid < 13) cnt[tid] = 0;
+    const bool own_uniform = own_info.gen_kind == KIND_UNIFORM;
+    const uint32_t m = own_uniform ? 0xFFFFu : row_mask(*reinterpret_cast<const uint4*>(g.sdf + base + (size_t)tid * 16));
     occ[ti + 1][tj + 1] = m;
 
     // neighbour rows across the x and y faces: 16 threads each load one 16-byte row
     uint32_t zlo = 0, zhi = 0;  // neighbour voxel across the z faces for this (i,j)
     {
         // z faces: one byte per thread from the adjacent chunk in k
-        if (ck > 0) zlo = ((uint8_t)g.sdf[base - IVX_CHUNK_VOXELS + tid * 16 + 15] >> 7) & 1u;
-        if (ck + 1 < (int)g.cz) zhi = ((uint8_t)g.sdf[base + IVX_CHUNK_VOXELS + tid * 16] >> 7) & 1u;
+        if (ck > 0) {
+            const uint32_t gen = info[chunk - 1].gen_kind;
+            zlo = gen != KIND_NONUNIFORM ? (gen == KIND_UNIFORM ? 1u : 0u) : (((uint8_t)g.sdf[base - IVX_CHUNK_VOXELS + tid * 16 + 15] >> 7) & 1u);
+        }
+        if (ck + 1 < (int)g.cz) {
+            const uint32_t gen = info[chunk + 1].gen_kind;
+            zhi = gen != KIND_NONUNIFORM ? (gen == KIND_UNIFORM ? 1u : 0u) : (((uint8_t)g.sdf[base + IVX_CHUNK_VOXELS + tid * 16] >> 7) & 1u);
+        }
     }
     if (tid < 64) {
         const int f = tid >> 4, r = tid & 15;  // f: 0 x-, 1 x+, 2 y-, 3 y+
         uint32_t nm = 0;
         if (f == 0) {
-            if (ci > 0) nm = row_mask(*reinterpret_cast<const uint4*>(g.sdf + base - (size_t)g.cy * g.cz * IVX_CHUNK_VOXELS + (15 * 256 + r * 16)));
+            if (ci > 0) nm = nbr_row_mask(g, info, (size_t)chunk - (size_t)g.cy * g.cz, 15 * 256 + r * 16);
             else if (g.ghost_sdf[0]) nm = row_mask(*reinterpret_cast<const uint4*>(g.ghost_sdf[0] + ((size_t)(cj * g.cz + ck) * 256 + r * 16)));
             occ[0][r + 1] = nm;
         } else if (f == 1) {
-            if (ci + 1 < (int)g.cx) nm = row_mask(*reinterpret_cast<const uint4*>(g.sdf + base + (size_t)g.cy * g.cz * IVX_CHUNK_VOXELS + (r * 16)));
+            if (ci + 1 < (int)g.cx) nm = nbr_row_mask(g, info, (size_t)chunk + (size_t)g.cy * g.cz, r * 16);
             else if (g.ghost_sdf[1]) nm = row_mask(*reinterpret_cast<const uint4*>(g.ghost_sdf[1] + ((size_t)(cj * g.cz + ck) * 256 + r * 16)));
             occ[17][r + 1] = nm;
         } else if (f == 2) {
-            if (cj > 0) nm = row_mask(*reinterpret_cast<const uint4*>(g.sdf + base - (size_t)g.cz * IVX_CHUNK_VOXELS + (r * 256 + 15 * 16)));
+            if (cj > 0) nm = nbr_row_mask(g, info, (size_t)chunk - g.cz, r * 256 + 15 * 16);
             occ[r + 1][0] = nm;
         } else {
-            if (cj + 1 < (int)g.cy) nm = row_mask(*reinterpret_cast<const uint4*>(g.sdf + base + (size_t)g.cz * IVX_CHUNK_VOXELS + (r * 256)));
+            if (cj + 1 < (int)g.cy) nm = nbr_row_mask(g, info, (size_t)chunk + g.cz, r * 256);
             occ[r + 1][17] = nm;
         }
     }
@@ -158,6 +205,11 @@ __global__ __launch_bounds__(256) void k_derive(GridView g, uint8_t* __restrict_
             cnt[10] = nz0;
             cnt[11] = nz1;
         }
+        // does a non-empty voxel of the +x / +y / +z face meet a non-empty voxel of the neighbour chunk? (what joins the
+        // regions of two single-region chunks, k_ccl_merge_single)
+        const uint32_t tb = ((ti == 15 && (m & occ[17][tj + 1])) ? 1u : 0u) | ((tj == 15 && (m & occ[ti + 1][17])) ? 2u : 0u) |
+                            ((((m >> 15) & 1u) & zhi) ? 4u : 0u);
+        if (tb) atomicOr(&cnt[12], tb);
     }
     __syncthreads();
 
@@ -194,13 +246,25 @@ __global__ __launch_bounds__(256) void k_derive(GridView g, uint8_t* __restrict_
         }
         w[k >> 2] |= f << (8 * (k & 3));
     }
-    *reinterpret_cast<uint4*>(flags_out + base + (size_t)tid * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    // (cnt[] and the record's gen_kind are the same for every thread, so is `kind`)
+    const uint32_t gen = own_info.gen_kind;
+    uint32_t kind = gen;
+    if (gen == KIND_UNIFORM && nbr_full != 0x3Fu) kind = KIND_NONUNIFORM;
+    // the planes of a Uniform chunk that was demoted before hold its voxels already; its record no longer has the type
+    const uint32_t utype = own_uniform ? (own_info.kind == KIND_NONUNIFORM ? (uint32_t)g.type[base] : (uint32_t)own_info.uniform_type) : 0u;
+    if (kind == KIND_NONUNIFORM) {
+        *reinterpret_cast<uint4*>(flags_out + base + (size_t)tid * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+        if (own_uniform && own_info.kind != KIND_NONUNIFORM) {
+            // convert_to_non_uniform_if_uniform (object.rs:2530-2550): the demoted chunk gets its 4096 voxels
+            const uint32_t t4 = utype * 0x01010101u;
+            *reinterpret_cast<uint4*>(sdf_rw + base + (size_t)tid * 16) = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+            *reinterpret_cast<uint4*>(type_rw + base + (size_t)tid * 16) = make_uint4(t4, t4, t4, t4);
+        }
+    }
 
     if (tid == 0) {
-        ivx_chunk_info ci_ = info[chunk];
-        const uint32_t gen = ci_.gen_kind;
-        uint32_t kind = gen;
-        if (gen == KIND_UNIFORM && nbr_full != 0x3Fu) kind = KIND_NONUNIFORM;
+        touch[chunk] = (uint8_t)cnt[12];
+        ivx_chunk_info ci_ = own_info;
         ci_.kind = (uint8_t)kind;
         if (kind == KIND_NONUNIFORM) {
             // bit layout: X_DN,Y_DN,Z_DN,X_UP,Y_UP,Z_UP <- faces f = 2*dim+side
@@ -218,12 +282,13 @@ __global__ __launch_bounds__(256) void k_derive(GridView g, uint8_t* __restrict_
         } else if (kind == KIND_UNIFORM) {
             ci_.flags = 0;
             ci_.face_dist = 0x555;
-            ci_.uniform_type = g.type[base];
+            ci_.uniform_type = (uint8_t)utype;
         } else {
             ci_.flags = 0;
             ci_.face_dist = 0;
         }
         info[chunk] = ci_;
+    }
     }
 }
 
@@ -279,29 +344,56 @@ __global__ __launch_bounds__(256) void k_occupied_reduce(uint32_t cx, uint32_t c
 // One launch that presets every small scratch word the stages of a whole step start from (instead of five memsets):
 // region scalars, occupied-range minima/maxima, Surface-Nets group totals + list counter, the sampler's list counter.
 __global__ __launch_bounds__(256) void k_step_preset(uint32_t stages, uint32_t* __restrict__ rscalar, uint32_t* __restrict__ sn_sums, uint32_t n_sn,
-                                                     uint32_t* __restrict__ eval_count) {
+                                                     uint32_t* __restrict__ eval_count, uint32_t* __restrict__ work_counts) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if ((stages & IVX_STAGE_REGIONS) && i < 16u) rscalar[i] = 0u;
     if ((stages & IVX_STAGE_OCCUPIED) && i < 12u) rscalar[16 + i] = i < 6u ? 0xFFFFFFFFu : 0u;
     if ((stages & IVX_STAGE_REMESH) && i < n_sn) sn_sums[i] = 0u;
     if ((stages & IVX_STAGE_SAMPLE) && i == 0 && eval_count) eval_count[0] = 0u;
+    if ((stages & IVX_STAGE_SAMPLE) && i == 0) work_counts[1] = 0u;
+    if ((stages & IVX_STAGE_DERIVE) && i == 0) work_counts[0] = 0u;
 }
 
 // gathers the small results of a step into one host-mapped block: [0..28) region scalars + occupied minima/maxima,
-// [28..31) mesh totals, [32..52) the 10 moments (f64 as two words each)
+// [28..31) mesh totals, [31] active chunks, [32..52) the 10 moments (f64 as two words each)
 __global__ __launch_bounds__(64) void k_result_gather(const uint32_t* __restrict__ rscalar, const uint32_t* __restrict__ mesh_totals,
-                                                      const double* __restrict__ moments, uint32_t* __restrict__ host_block) {
+                                                      const double* __restrict__ moments, const uint32_t* __restrict__ work_counts,
+                                                      uint32_t* __restrict__ host_block) {
     const uint32_t t = threadIdx.x;
+    if (t == 31u) host_block[31] = work_counts[0];  // length of the active list (sizes the next step's list-driven grids)
     if (t < 28u) host_block[t] = rscalar[t];
     if (t < 3u) host_block[28 + t] = mesh_totals[t];
     if (t < 20u) host_block[32 + t] = reinterpret_cast<const uint32_t*>(moments)[t];
 }
 
+// writes out the planes of the chunks that are only a record (Void / Uniform), for callers that want whole planes
+__global__ __launch_bounds__(256) void k_materialize(uint32_t n_chunks, const ivx_chunk_info* __restrict__ info, int8_t* __restrict__ sdf,
+                                                     uint8_t* __restrict__ type, uint8_t* __restrict__ flags, uint8_t* __restrict__ labels) {
+    const uint32_t chunk = ivx_xcd_remap(blockIdx.x, n_chunks);
+    const ivx_chunk_info ci = info[chunk];
+    if (ci.kind == KIND_NONUNIFORM) return;
+    const size_t o = (size_t)chunk * IVX_CHUNK_VOXELS + (size_t)threadIdx.x * 16;
+    const uint32_t s = ivx_uniform_sdf(ci.kind) * 0x01010101u, t = ivx_uniform_type(ci) * 0x01010101u;
+    const uint32_t f = ivx_uniform_flags(ci.kind) * 0x01010101u, l = ivx_uniform_label(ci.kind) * 0x01010101u;
+    *reinterpret_cast<uint4*>(sdf + o) = make_uint4(s, s, s, s);
+    *reinterpret_cast<uint4*>(type + o) = make_uint4(t, t, t, t);
+    *reinterpret_cast<uint4*>(flags + o) = make_uint4(f, f, f, f);
+    *reinterpret_cast<uint4*>(labels + o) = make_uint4(l, l, l, l);
+}
+
 }  // namespace
+
+int ivx_ensure_dense(ivx_grid* g) {
+    if (!g->planes_compact) return IVX_OK;
+    hipLaunchKernelGGL(k_materialize, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, g->n_chunks, g->info, g->sdf, g->type, g->flags, g->llabel);
+    IVX_HIP_CHECK(hipGetLastError());
+    g->planes_compact = 0;
+    return IVX_OK;
+}
 
 int ivx_launch_result_gather(ivx_grid* g, uint32_t* host_block_dev) {
     hipLaunchKernelGGL(k_result_gather, dim3(1), dim3(64), 0, g->ctx->stream, g->rscalar, g->chunk_offsets + 2 * (size_t)g->n_chunks,
-                       g->partials + g->partial_blocks * 10, host_block_dev);
+                       g->partials + g->partial_blocks * 10, g->work_counts, host_block_dev);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -310,14 +402,19 @@ int ivx_launch_step_preset(ivx_grid* g, uint32_t stages) {
     const uint32_t groups = (g->n_chunks + 255u) / 256u;
     const uint32_t n_sn = 3 * groups + 1;
     hipLaunchKernelGGL(k_step_preset, dim3((n_sn + 255u) / 256u), dim3(256), 0, g->ctx->stream, stages, g->rscalar, g->group_sums + groups, n_sn,
-                       g->samp_len ? g->samp_len + g->n_chunks : nullptr);
+                       g->samp_len ? g->samp_len + g->n_chunks : nullptr, g->work_counts);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 
 int ivx_launch_derive(ivx_grid* g) {
     GridView v = ivx_view(g);
-    hipLaunchKernelGGL(k_derive, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, v, g->flags, g->info, g->chunk_bbox);
+    if (!g->scratch_preset) IVX_HIP_CHECK(hipMemsetAsync(g->work_counts, 0, sizeof(uint32_t), g->ctx->stream));
+    hipLaunchKernelGGL(k_chunk_pre, dim3((g->n_chunks + 255u) / 256u), dim3(256), 0, g->ctx->stream, v, g->info, g->chunk_bbox, g->chunk_counts,
+                       g->chunk_class, g->work_counts, g->active_list);
+    hipLaunchKernelGGL(k_derive, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->sdf, g->type, g->flags, g->info, g->chunk_bbox,
+                       g->chunk_touch, g->work_counts, g->active_list);
+    g->planes_compact = 1;
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

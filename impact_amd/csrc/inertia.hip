@@ -9,9 +9,9 @@
 //   so this kernel accumulates the integer forms in f64 (order-independent to ~1e-16) and applies the
 //   e^3, e^4/2, e^5/3, e^5/4 factors once. Parity gate: 1e-5 relative against the f64 oracle.
 //
-// Sweep: grid-stride over chunks, one thread per (i,j) row, 2 B/voxel read (flags + type as two
-// 16-byte loads per thread); per-block partials reduced in a fixed order by a second tiny launch
-// (bitwise reproducible, no float atomics).
+// Sweep: NonUniform chunks (the active list) one workgroup each, one thread per (i,j) row, 2 B/voxel read (flags + type
+// as two 16-byte loads per thread) into a per-chunk slot; Uniform chunks are closed forms; the slots and closed forms
+// are summed in chunk order by k_inertia_sum and a fixed-order final launch (bitwise reproducible, no float atomics).
 #include "ivx_internal.hpp"
 
 namespace {
@@ -22,44 +22,22 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_inertia(GridView g, uint32_t x_off, const uint8_t* __restrict__ flags,
-                                                 const float* __restrict__ dens, double* __restrict__ partials) {
+// Moments of the NonUniform chunks, one workgroup per listed chunk, into the chunk's own slot (so the order of the
+// final sum does not depend on the order of the list).
+__global__ __launch_bounds__(256) void k_inertia_dense(GridView g, uint32_t x_off, const uint8_t* __restrict__ flags,
+                                                       const float* __restrict__ dens, double* __restrict__ chunk_moments,
+                                                       const uint32_t* __restrict__ work_counts, const uint32_t* __restrict__ active_list) {
     __shared__ float s_dens[256];
     __shared__ double s_red[4][10];
     const uint32_t tid = threadIdx.x;
     s_dens[tid] = dens[tid];
-    __syncthreads();
-    const uint32_t n_chunks = g.cx * g.cy * g.cz;
     const int ti = tid >> 4, tj = tid & 15;
-    double s[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t b = blockIdx.x; b < n_chunks; b += gridDim.x) {
-        const uint32_t chunk = ivx_xcd_remap(b, n_chunks);
-        const ivx_chunk_info cinfo = g.info[chunk];
-        if (cinfo.kind == KIND_VOID) continue;
+    const uint32_t n_active = work_counts[0];
+    for (uint32_t li = ivx_xcd_remap(blockIdx.x, gridDim.x); li < n_active; li += gridDim.x) {
+        __syncthreads();  // s_dens ready / the previous chunk's s_red use is over
+        const uint32_t chunk = active_list[li];
+        if (g.info[chunk].kind != KIND_NONUNIFORM) continue;  // Uniform chunks are closed forms in k_inertia_sum
         const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
-        if (cinfo.gen_kind == KIND_UNIFORM) {
-            // a chunk generated Uniform is 4096 voxels of one type (compute_moments_for_uniform_chunk,
-            // inertia.rs:703-754): the row sums are closed forms of the chunk's k range, no plane reads
-            const double d = (double)s_dens[g.type[(size_t)chunk * IVX_CHUNK_VOXELS]];
-            const double I = (double)((ci + (int)x_off) * 16 + ti), J = (double)(cj * 16 + tj), K0 = (double)(ck * 16);
-            const double qx = 2.0 * I + 1.0, qy = 2.0 * J + 1.0;
-            const double cx = 3.0 * I * I + 3.0 * I + 1.0, cy = 3.0 * J * J + 3.0 * J + 1.0;
-            // sum_{K=K0}^{K0+15} (2K+1) = 32 K0 + 256;  sum (3K^2+3K+1) = (K0+16)^3 - K0^3
-            const double D = 16.0 * d, Dz1 = d * (32.0 * K0 + 256.0);
-            const double K1 = K0 + 16.0;
-            const double Dz2 = d * (K1 * K1 * K1 - K0 * K0 * K0);
-            s[0] += D;
-            s[1] += D * qx;
-            s[2] += D * qy;
-            s[3] += Dz1;
-            s[4] += D * cy + Dz2;
-            s[5] += D * cx + Dz2;
-            s[6] += D * (cx + cy);
-            s[7] += D * qx * qy;
-            s[8] += qy * Dz1;
-            s[9] += qx * Dz1;
-            continue;
-        }
         const size_t o = (size_t)chunk * IVX_CHUNK_VOXELS + (size_t)tid * 16;
         const uint4 f = *reinterpret_cast<const uint4*>(flags + o);
         const uint4 t = *reinterpret_cast<const uint4*>(g.type + o);
@@ -79,21 +57,55 @@ __global__ __launch_bounds__(256) void k_inertia(GridView g, uint32_t x_off, con
                 Dz2 += d * (3.0 * K * K + 3.0 * K + 1.0);
             }
         }
-        s[0] += D;
-        s[1] += D * qx;
-        s[2] += D * qy;
-        s[3] += Dz1;
-        s[4] += D * cy + Dz2;
-        s[5] += D * cx + Dz2;
-        s[6] += D * (cx + cy);
-        s[7] += D * qx * qy;
-        s[8] += qy * Dz1;
-        s[9] += qx * Dz1;
+        const double s[10] = {D, D * qx, D * qy, Dz1, D * cy + Dz2, D * cx + Dz2, D * (cx + cy), D * qx * qy, qy * Dz1, qx * Dz1};
+        const uint32_t lane = tid & 63u, wave = tid >> 6;
+#pragma unroll
+        for (int m = 0; m < 10; ++m) {
+            const double v = wave_sum(s[m]);
+            if (lane == 0) s_red[wave][m] = v;
+        }
+        __syncthreads();
+        if (tid < 10) chunk_moments[(size_t)chunk * 10 + tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+    }
+}
+
+// Sum over chunks in chunk order, one THREAD per chunk: a Uniform chunk is 4096 voxels of one type
+// (compute_moments_for_uniform_chunk, inertia.rs:703-754) and its moments are closed forms of its origin
+// [sum_{X=X0}^{X0+15} (2X+1) = 32 X0 + 256; sum (3X^2+3X+1) = (X0+16)^3 - X0^3]; a NonUniform chunk contributes its slot.
+__global__ __launch_bounds__(256) void k_inertia_sum(GridView g, uint32_t x_off, const float* __restrict__ dens,
+                                                     const double* __restrict__ chunk_moments, double* __restrict__ partials) {
+    __shared__ double s_red[4][10];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_chunks = g.cx * g.cy * g.cz;
+    double s[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t chunk = blockIdx.x * 256u + tid; chunk < n_chunks; chunk += gridDim.x * 256u) {
+        const ivx_chunk_info ci_ = g.info[chunk];
+        if (ci_.kind == KIND_UNIFORM) {
+            const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
+            const double d = (double)dens[ci_.uniform_type];
+            const double I0 = (double)((ci + (int)x_off) * 16), J0 = (double)(cj * 16), K0 = (double)(ck * 16);
+            const double a1x = 32.0 * I0 + 256.0, a1y = 32.0 * J0 + 256.0, a1z = 32.0 * K0 + 256.0;
+            const double I1 = I0 + 16.0, J1 = J0 + 16.0, K1 = K0 + 16.0;
+            const double a2x = I1 * I1 * I1 - I0 * I0 * I0, a2y = J1 * J1 * J1 - J0 * J0 * J0, a2z = K1 * K1 * K1 - K0 * K0 * K0;
+            s[0] += 4096.0 * d;
+            s[1] += 256.0 * d * a1x;
+            s[2] += 256.0 * d * a1y;
+            s[3] += 256.0 * d * a1z;
+            s[4] += 256.0 * d * (a2y + a2z);
+            s[5] += 256.0 * d * (a2x + a2z);
+            s[6] += 256.0 * d * (a2x + a2y);
+            s[7] += 16.0 * d * a1x * a1y;
+            s[8] += 16.0 * d * a1y * a1z;
+            s[9] += 16.0 * d * a1x * a1z;
+        } else if (ci_.kind == KIND_NONUNIFORM) {
+#pragma unroll
+            for (int m = 0; m < 10; ++m) s[m] += chunk_moments[(size_t)chunk * 10 + m];
+        }
     }
     const uint32_t lane = tid & 63u, wave = tid >> 6;
 #pragma unroll
     for (int m = 0; m < 10; ++m) {
-        double v = wave_sum(s[m]);
+        const double v = wave_sum(s[m]);
         if (lane == 0) s_red[wave][m] = v;
     }
     __syncthreads();
@@ -117,13 +129,12 @@ __global__ __launch_bounds__(640) void k_inertia_final(uint32_t n_blocks, float 
 }  // namespace
 
 int ivx_launch_inertia(ivx_grid* g, const float* d_dens, double* d_out10) {
-    uint32_t blocks = g->n_chunks < 1024u ? g->n_chunks : 1024u;
-    if (blocks > g->partial_blocks) {
-        ivx_set_error("internal: partial buffer too small");
-        return IVX_ERR_CAPACITY;
-    }
+    uint32_t blocks = (g->n_chunks + 255u) / 256u;
+    if (blocks > g->partial_blocks) blocks = (uint32_t)g->partial_blocks;
     GridView v = ivx_view(g);
-    hipLaunchKernelGGL(k_inertia, dim3(blocks), dim3(256), 0, g->ctx->stream, v, g->x_off, g->flags, d_dens, g->partials);
+    hipLaunchKernelGGL(k_inertia_dense, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->x_off, g->flags, d_dens, g->chunk_moments, g->work_counts,
+                       g->active_list);
+    hipLaunchKernelGGL(k_inertia_sum, dim3(blocks), dim3(256), 0, g->ctx->stream, v, g->x_off, d_dens, g->chunk_moments, g->partials);
     hipLaunchKernelGGL(k_inertia_final, dim3(1), dim3(640), 0, g->ctx->stream, blocks, g->extent, g->partials, d_out10);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;

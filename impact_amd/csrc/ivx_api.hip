@@ -108,9 +108,11 @@ __global__ __launch_bounds__(256) void k_halo_pack(GridView g, uint32_t side, in
     const uint32_t ci = side ? g.cx - 1 : 0u;
     const uint32_t chunk = ci * g.cy * g.cz + col;
     const size_t src = (size_t)chunk * IVX_CHUNK_VOXELS + ((side ? 15u : 0u) << 8) + tid;
-    out_sdf[(size_t)col * 256 + tid] = g.sdf[src];
-    out_type[(size_t)col * 256 + tid] = g.type[src];
-    if (tid == 0) out_info[col] = g.info[chunk];
+    const ivx_chunk_info rec = g.info[chunk];
+    const bool dense = rec.kind == KIND_NONUNIFORM;  // else the chunk is its record (compact planes)
+    out_sdf[(size_t)col * 256 + tid] = dense ? g.sdf[src] : (int8_t)ivx_uniform_sdf(rec.kind);
+    out_type[(size_t)col * 256 + tid] = dense ? g.type[src] : (uint8_t)ivx_uniform_type(rec);
+    if (tid == 0) out_info[col] = rec;
 }
 
 }  // namespace
@@ -227,6 +229,12 @@ int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32
     A(dev_alloc(&g->sn_list, (size_t)g->n_chunks));
     A(dev_alloc(&g->group_sums, (size_t)((g->n_chunks + 255u) / 256u) * 4 + 4));
     A(dev_alloc(&g->dens_dev, (size_t)256));
+    A(dev_alloc(&g->work_counts, (size_t)8));
+    A(dev_alloc(&g->active_list, (size_t)g->n_chunks));
+    A(dev_alloc(&g->fill_list, (size_t)g->n_chunks));
+    A(dev_alloc(&g->chunk_class, (size_t)g->n_chunks));
+    A(dev_alloc(&g->chunk_touch, (size_t)g->n_chunks));
+    A(dev_alloc(&g->chunk_moments, (size_t)g->n_chunks * 10));
     if (rc != IVX_OK) {
         ivx_grid_destroy(g);
         return rc;
@@ -245,7 +253,8 @@ void ivx_grid_destroy(ivx_grid* g) {
     (void)hipStreamSynchronize(g->ctx->stream);
     void* ptrs[] = {g->sdf, g->type, g->flags, g->llabel, g->info, g->ghost_sdf[0], g->ghost_sdf[1], g->ghost_type[0], g->ghost_type[1],
                     g->ghost_info[0], g->ghost_info[1], g->chunk_counts, g->chunk_offsets, g->positions, g->normals, g->indices,
-                    g->index_materials, g->vertex_materials, g->submeshes, g->partials, g->rparent, g->rcompid, g->rscalar, g->ccl_scratch, g->group_sums, g->sn_list, g->dens_dev, g->dev_scratch, g->prog_nodes, g->chunk_bbox, g->samp_len, g->samp_ops, g->pairs_dev};
+                    g->index_materials, g->vertex_materials, g->submeshes, g->partials, g->rparent, g->rcompid, g->rscalar, g->ccl_scratch, g->group_sums, g->sn_list, g->dens_dev, g->dev_scratch, g->prog_nodes, g->chunk_bbox, g->samp_len, g->samp_ops, g->pairs_dev,
+                    g->work_counts, g->active_list, g->fill_list, g->chunk_class, g->chunk_moments, g->chunk_touch};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->host_scratch) (void)hipHostFree(g->host_scratch);
@@ -272,6 +281,7 @@ int ivx_grid_download_dense(ivx_grid* g, int8_t* sdf, uint8_t* type, uint8_t* fl
     IVX_REQUIRE(g, IVX_ERR_INVALID, "ivx_grid_download_dense: null grid");
     IVX_REQUIRE(n_voxels == g->n_vox, IVX_ERR_INVALID, "ivx_grid_download_dense: expected %zu voxels, got %zu", g->n_vox, n_voxels);
     int rc;
+    if ((sdf || type || flags || local_labels) && (rc = ivx_ensure_dense(g))) return rc;  // Void / Uniform chunks are written out on demand
     if (sdf && (rc = d2h(g, sdf, g->sdf, g->n_vox))) return rc;
     if (type && (rc = d2h(g, type, g->type, g->n_vox))) return rc;
     if (flags && (rc = d2h(g, flags, g->flags, g->n_vox))) return rc;
@@ -300,6 +310,7 @@ int ivx_grid_stage_counters(ivx_grid* g, uint32_t out[4]) {
 
 void* ivx_grid_device_ptr(ivx_grid* g, int which) {
     if (!g) return nullptr;
+    if (which >= 0 && which < 4 && ivx_ensure_dense(g) != IVX_OK) return nullptr;  // whole planes for the caller (stream-ordered)
     switch (which) {
         case 0: return g->sdf;
         case 1: return g->type;
@@ -886,6 +897,7 @@ int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out) {
     }
     IVX_HIP_CHECK(hipStreamSynchronize(s));
     const uint32_t* sc = g->result_host;
+    if (sc[31]) g->last_active = sc[31];
     if (stages & IVX_STAGE_REGIONS) {
         IVX_REQUIRE((sc[1] & 1u) == 0, IVX_ERR_CAPACITY, "ivx_voxel_step: a chunk has more than 254 local regions");
         g->region_count = sc[0];

@@ -83,6 +83,17 @@ struct ivx_grid {
     uint32_t* group_sums;   // [4 * ceil(n_chunks/256)]: first-level totals of the two-level scans
     uint32_t region_count;
     int regions_valid;
+    // list-driven stages: k_chunk_pre settles every chunk whose per-step state follows from the chunk records alone (Void,
+    // and Uniform chunks surrounded by Uniform chunks: ~85 % of a solid body's chunks) with one THREAD each and lists the
+    // rest; the workgroup-per-chunk kernels then walk that list instead of being launched once per chunk of the grid.
+    uint32_t* work_counts;  // [8]: [0] chunks on the active list, [1] chunks on the sampler's fill list
+    uint32_t* active_list;  // [n_chunks]
+    uint32_t* fill_list;    // [n_chunks] chunks the sampler pre-pass proved constant but not Void / Uniform
+    uint8_t* chunk_class;   // [n_chunks] 1: settled by k_chunk_pre
+    uint8_t* chunk_touch;   // [n_chunks] active chunks: bit d set = a voxel pair touches across the +x/+y/+z face (k_derive)
+    double* chunk_moments;  // [n_chunks * 10] moments of the NonUniform chunks (fixed summation order whatever the list order)
+    uint32_t last_active;   // host: active-list length seen by the last collect (sizes the list-driven grids)
+    int planes_compact;  // planes of Void/Uniform chunks may be stale (see ivx_ensure_dense)
     int scratch_preset;  // inside ivx_voxel_step: k_step_preset already initialised the stages' scratch words
     float* dens_dev;        // [256] voxel type densities
     void* dev_scratch;      // grown on demand (node programs, dense label export, region statistics)
@@ -138,6 +149,16 @@ __device__ __forceinline__ uint32_t ivx_xcd_remap(uint32_t b, uint32_t n) {
     return base + p;
 }
 
+// Compact planes: the four voxel planes of a chunk hold data only while the chunk is NonUniform. A Void or Uniform chunk is
+// one voxel, as in the reference's store (VoxelChunk::{Void, Uniform}, object.rs:96-119): maximally outside with the dummy
+// type, or maximally inside with `uniform_type`; every neighbour present (flags 0xFC) and one region (label 0) when Uniform.
+// Kernels on the step path synthesise those bytes from the 8-byte chunk record; `ivx_ensure_dense` writes them out
+// for callers that want whole planes.
+__device__ __forceinline__ uint32_t ivx_uniform_sdf(uint32_t kind) { return kind == KIND_UNIFORM ? 0x80u : 0x7Fu; }
+__device__ __forceinline__ uint32_t ivx_uniform_type(const ivx_chunk_info& ci) { return ci.kind == KIND_UNIFORM ? (uint32_t)ci.uniform_type : 0xFFu; }
+__device__ __forceinline__ uint32_t ivx_uniform_flags(uint32_t kind) { return kind == KIND_UNIFORM ? 0xFCu : (uint32_t)VF_EMPTY; }
+__device__ __forceinline__ uint32_t ivx_uniform_label(uint32_t kind) { return kind == KIND_UNIFORM ? 0u : 0xFFu; }
+
 struct GridView {
     uint32_t cx, cy, cz;
     const int8_t* sdf;
@@ -147,6 +168,16 @@ struct GridView {
     const ivx_chunk_info* info;
     const ivx_chunk_info* ghost_info[2];
 };
+
+// grid of a list-driven launch: about one workgroup per listed chunk (the length of the previous step's list is the
+// estimate; a longer list is covered by the grid-stride walk), never fewer than one thread per chunk of the grid for
+// the kernels that settle per-chunk words in a prologue
+static inline uint32_t ivx_list_grid(const ivx_grid* g) {
+    uint32_t n = g->last_active ? g->last_active + g->last_active / 8u + 64u : 8192u;
+    const uint32_t lo = (g->n_chunks + 255u) / 256u;
+    if (n > g->n_chunks) n = g->n_chunks;
+    return n < lo ? lo : n;
+}
 
 static inline GridView ivx_view(const ivx_grid* g) {
     GridView v;
@@ -169,6 +200,7 @@ int ivx_launch_classify(ivx_grid* g);
 int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, uint32_t n_nodes, uint32_t stack_size,
                           const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type);
 int ivx_launch_derive(ivx_grid* g);
+int ivx_ensure_dense(ivx_grid* g);
 int ivx_launch_step_preset(ivx_grid* g, uint32_t stages);
 int ivx_launch_result_gather(ivx_grid* g, uint32_t* host_block_dev);
 int ivx_sampler_buffers(ivx_grid* g);

@@ -139,7 +139,7 @@ __device__ __forceinline__ uint4 pack16(const int* v) {
 // maximally-outside voxels (the reference drops their data, object/sdf.rs:486-489) and store.
 __device__ __forceinline__ void classify_and_store(int* sd, uint4 types, bool types_uniform_in, uint8_t first_type, int8_t* sdf_out,
                                                    uint8_t* type_out, ivx_chunk_info* info_out, uint32_t chunk, uint32_t tid,
-                                                   bool set_type, uint32_t voxel_type) {
+                                                   bool set_type, uint32_t voxel_type, bool compact) {
     bool any_nonempty = false, any_nonvoid = false, all_inside = true;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -162,9 +162,11 @@ __device__ __forceinline__ void classify_and_store(int* sd, uint4 types, bool ty
         types = make_uint4(t, t, t, t);
         first_type = only_empty ? (uint8_t)TYPE_DUMMY : (uint8_t)voxel_type;
     }
-    size_t base = (size_t)chunk * IVX_CHUNK_VOXELS + (size_t)tid * 16;
-    *reinterpret_cast<uint4*>(sdf_out + base) = pack16(sd);
-    *reinterpret_cast<uint4*>(type_out + base) = types;
+    if (kind == KIND_NONUNIFORM || !compact) {  // Void / Uniform chunks are their 8-byte record (compact planes)
+        size_t base = (size_t)chunk * IVX_CHUNK_VOXELS + (size_t)tid * 16;
+        *reinterpret_cast<uint4*>(sdf_out + base) = pack16(sd);
+        *reinterpret_cast<uint4*>(type_out + base) = types;
+    }
     if (tid == 0) {
         ivx_chunk_info ci;
         ci.kind = (uint8_t)kind;
@@ -268,7 +270,8 @@ __device__ __forceinline__ void load_node_tile(PaddedNode* tile, const ivx_sdf_p
 __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx_sdf_processed_node* __restrict__ nodes,
                                                        float* __restrict__ chunk_const, uint32_t* __restrict__ prog_len,
                                                        uint2* __restrict__ prog_ops, uint32_t* __restrict__ eval_count,
-                                                       uint32_t* __restrict__ eval_list) {
+                                                       uint32_t* __restrict__ eval_list, ivx_chunk_info* __restrict__ info_out,
+                                                       uint32_t* __restrict__ fill_count, uint32_t* __restrict__ fill_list) {
     __shared__ float s_lo[16][PRE_T];
     __shared__ float s_hi[16][PRE_T];
     __shared__ uint16_t s_start[16][PRE_T];  // op-stream position where each stack level's steps begin
@@ -397,8 +400,9 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
             }
         }
     }
-    const float lo = s_lo[0][tid], hi = s_hi[0][tid];
+    const float lo = p.n_nodes ? s_lo[0][tid] : 1000.0f, hi = p.n_nodes ? s_hi[0][tid] : 1000.0f;  // no program: empty space
     float out = __uint_as_float(0x7FC00000u);  // NaN = evaluate per voxel
+    if (p.n_nodes == 0u) cmask = 1u;
     if (cmask & 1u) out = lo;
     else if (lo >= 2.54f + 0.02f) out = 1000.0f;    // every voxel quantises to +127
     else if (hi <= -2.56f - 0.02f) out = -1000.0f;  // every voxel quantises to -128
@@ -407,7 +411,30 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
         chunk_const[chunk] = out;
         prog_len[chunk] = pos <= OP_CAP ? pos : OP_OVERFLOW;
         // chunks that need per-voxel evaluation go on a list for k_sdf_eval (order is irrelevant)
-        if (out != out) eval_list[atomicAdd(eval_count, 1u)] = chunk;
+        if (out != out) {
+            eval_list[atomicAdd(eval_count, 1u)] = chunk;
+        } else {
+            // A constant chunk is classified right here (create_for_generated_voxels, object.rs:1890-1964): every voxel
+            // void (> +2.0) -> Void, every voxel maximally inside -> Uniform; such a chunk is its record and has no planes to
+            // write (compact planes). Any other constant, or a chunk that straddles the generator's grid (voxels beyond it
+            // are +127), is written out by k_sdf_fill.
+            const int sdq = sd_from_f32(out);
+            const bool whole = oi + 16u <= p.shape[0] && oj + 16u <= p.shape[1] && ok + 16u <= p.shape[2];
+            const bool is_void = sdq > SD_VOID_LIMIT;  // voxels beyond the grid are void too
+            const bool is_uniform = whole && sdq == -128;
+            if (is_void || is_uniform) {
+                ivx_chunk_info rec;
+                rec.kind = rec.gen_kind = (uint8_t)(is_void ? KIND_VOID : KIND_UNIFORM);
+                rec.flags = 0;
+                rec.uniform_type = is_uniform ? (uint8_t)p.voxel_type : (uint8_t)0;
+                rec.face_dist = 0;
+                rec.region_count = 0;
+                rec.boundary_region_count = 0;
+                info_out[chunk] = rec;
+            } else {
+                fill_list[atomicAdd(fill_count, 1u)] = chunk;
+            }
+        }
     }
 }
 
@@ -491,24 +518,26 @@ __device__ __forceinline__ void combine_levels(uint32_t kind, float s, float q, 
 // Chunks the pre-pass proved constant (and everything when the program is empty): no LDS, one 16-byte store per plane
 // and thread. Kept apart from k_sdf_eval so that these ~90 % of the workgroups are not throttled by the evaluator's
 // 48-64 KiB of LDS per workgroup.
-__global__ __launch_bounds__(256) void k_sdf_fill(SampleParams p, const float* __restrict__ chunk_const, int8_t* __restrict__ sdf_out,
+__global__ __launch_bounds__(256) void k_sdf_fill(SampleParams p, const float* __restrict__ chunk_const, const uint32_t* __restrict__ fill_count,
+                                                  const uint32_t* __restrict__ fill_list, int8_t* __restrict__ sdf_out,
                                                   uint8_t* __restrict__ type_out, ivx_chunk_info* __restrict__ info_out) {
     const uint32_t tid = threadIdx.x;
-    const uint32_t n_chunks = p.cx * p.cy * p.cz;
-    const uint32_t chunk = ivx_xcd_remap(blockIdx.x, n_chunks);
-    const uint32_t ck = chunk % p.cz, cj = (chunk / p.cz) % p.cy, ci = chunk / (p.cz * p.cy);
-    const uint32_t oi = (ci + p.x_off) * 16u, oj = cj * 16u, ok = ck * 16u;
     const uint32_t ti = tid >> 4, tj = tid & 15u;
-    float cv = 1000.0f;
-    if (p.n_nodes != 0) cv = chunk_const[chunk];
-    if (cv != cv) return;  // evaluated by k_sdf_eval
-    int sd[16];
+    const uint32_t n_fill = fill_count[0];
+    // bounded grid-stride walk over the (short) list of constant chunks that are neither Void nor Uniform
+    for (uint32_t li = blockIdx.x; li < n_fill; li += gridDim.x) {
+        const uint32_t chunk = fill_list[li];
+        const uint32_t ck = chunk % p.cz, cj = (chunk / p.cz) % p.cy, ci = chunk / (p.cz * p.cy);
+        const uint32_t oi = (ci + p.x_off) * 16u, oj = cj * 16u, ok = ck * 16u;
+        const float cv = chunk_const[chunk];
+        int sd[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        bool in_grid = (oi + ti) < p.shape[0] && (oj + tj) < p.shape[1] && (ok + (uint32_t)k) < p.shape[2];
-        sd[k] = in_grid ? sd_from_f32(cv) : 127;
+        for (int k = 0; k < 16; ++k) {
+            bool in_grid = (oi + ti) < p.shape[0] && (oj + tj) < p.shape[1] && (ok + (uint32_t)k) < p.shape[2];
+            sd[k] = in_grid ? sd_from_f32(cv) : 127;
+        }
+        classify_and_store(sd, make_uint4(0, 0, 0, 0), true, 0, sdf_out, type_out, info_out, chunk, tid, true, p.voxel_type, true);
     }
-    classify_and_store(sd, make_uint4(0, 0, 0, 0), true, 0, sdf_out, type_out, info_out, chunk, tid, true, p.voxel_type);
 }
 
 __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t* __restrict__ eval_count, const uint32_t* __restrict__ eval_list,
@@ -646,7 +675,7 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
         bool in_grid = (oi + ti) < p.shape[0] && (oj + tj) < p.shape[1] && (ok + (uint32_t)k) < p.shape[2];
         sd[k] = in_grid ? sd_from_f32(v) : 127;
     }
-    classify_and_store(sd, make_uint4(0, 0, 0, 0), true, 0, sdf_out, type_out, info_out, chunk, tid, true, p.voxel_type);
+    classify_and_store(sd, make_uint4(0, 0, 0, 0), true, 0, sdf_out, type_out, info_out, chunk, tid, true, p.voxel_type, true);
     }
 }
 
@@ -665,7 +694,7 @@ __global__ __launch_bounds__(256) void k_classify(uint32_t n_chunks, int8_t* __r
     for (int k = 0; k < 16; ++k) sd[k] = (int)(int8_t)((sw[k >> 2] >> (8 * (k & 3))) & 0xFF);
     uint32_t ft = first_type * 0x01010101u;
     bool types_uniform = t.x == ft && t.y == ft && t.z == ft && t.w == ft;
-    classify_and_store(sd, t, types_uniform, first_type, sdf, type, info, chunk, tid, false, 0);
+    classify_and_store(sd, t, types_uniform, first_type, sdf, type, info, chunk, tid, false, 0, false);
 }
 
 }  // namespace
@@ -702,12 +731,15 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
     uint2* ops = reinterpret_cast<uint2*>(g->samp_ops);
     uint32_t* eval_count = g->samp_len + g->n_chunks;
     uint32_t* eval_list = eval_count + 4;
-    if (n_nodes) {
-        if (!g->scratch_preset) IVX_HIP_CHECK(hipMemsetAsync(eval_count, 0, sizeof(uint32_t), g->ctx->stream));
-        hipLaunchKernelGGL(k_sdf_prepass, dim3((g->n_chunks + PRE_T - 1) / PRE_T), dim3(PRE_T), 0, g->ctx->stream, p, d_nodes, chunk_const, g->samp_len, ops,
-                           eval_count, eval_list);
+    if (!g->scratch_preset) {
+        IVX_HIP_CHECK(hipMemsetAsync(eval_count, 0, sizeof(uint32_t), g->ctx->stream));
+        IVX_HIP_CHECK(hipMemsetAsync(g->work_counts + 1, 0, sizeof(uint32_t), g->ctx->stream));
     }
-    hipLaunchKernelGGL(k_sdf_fill, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, p, chunk_const, g->sdf, g->type, g->info);
+    hipLaunchKernelGGL(k_sdf_prepass, dim3((g->n_chunks + PRE_T - 1) / PRE_T), dim3(PRE_T), 0, g->ctx->stream, p, d_nodes, chunk_const, g->samp_len, ops,
+                       eval_count, eval_list, g->info, g->work_counts + 1, g->fill_list);
+    g->planes_compact = 1;
+    hipLaunchKernelGGL(k_sdf_fill, dim3(g->n_chunks < 1024u ? g->n_chunks : 1024u), dim3(256), 0, g->ctx->stream, p, chunk_const, g->work_counts + 1,
+                       g->fill_list, g->sdf, g->type, g->info);
     if (n_nodes) {
         const uint32_t eval_blocks = g->n_chunks < 4096u ? g->n_chunks : 4096u;
         hipLaunchKernelGGL(k_sdf_eval, dim3(eval_blocks), dim3(256), lds, g->ctx->stream, p, eval_count, eval_list, g->samp_len, ops, d_nodes, g->sdf, g->type,

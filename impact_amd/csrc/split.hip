@@ -317,6 +317,10 @@ int ivx_launch_split_move(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3
         sp.cc[d] = cc[d];
     }
     sp.target = target;
+    {  // these kernels read and rewrite whole planes
+        int rc = ivx_ensure_dense(parent);
+        if (rc) return rc;
+    }
     const uint32_t n = cc[0] * cc[1] * cc[2];
     hipLaunchKernelGGL(k_split_move, dim3(n), dim3(256), 0, parent->ctx->stream, sp, parent->llabel, parent->rcompid, parent->sdf, parent->type,
                        parent->info, child ? child->sdf : nullptr, child ? child->type : nullptr, child ? child->info : nullptr);
@@ -325,6 +329,10 @@ int ivx_launch_split_move(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3
 }
 
 int ivx_launch_split_repack(ivx_grid* src, ivx_grid* dst, const uint32_t off[3]) {
+    {
+        int rc = ivx_ensure_dense(src);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(k_split_repack, dim3(1), dim3(256), 0, src->ctx->stream, src->cc[0], src->cc[1], src->cc[2], off[0], off[1], off[2], src->sdf,
                        src->type, dst->sdf, dst->type, dst->info);
     IVX_HIP_CHECK(hipGetLastError());
@@ -340,6 +348,10 @@ int ivx_launch_clip(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], con
     }
     cp.n_planes = n_planes;
     cp.extract = extract;
+    {
+        int rc = ivx_ensure_dense(parent);
+        if (rc) return rc;
+    }
     memset(cp.planes, 0, sizeof(cp.planes));
     memcpy(cp.planes, planes4, sizeof(float) * 4 * n_planes);
     hipLaunchKernelGGL(k_clip, dim3(cc[0] * cc[1] * cc[2]), dim3(256), 0, parent->ctx->stream, cp, parent->sdf, parent->type, parent->info, child->sdf,

@@ -75,6 +75,33 @@ __device__ __forceinline__ void fetch_row(const GridView& g, int gi, int gj, int
         kstride = IVX_CHUNK_VOXELS;
     }
     const size_t o = row + (size_t)ck * kstride;
+    if (kstride == IVX_CHUNK_VOXELS) {
+        // inside the slab a Void / Uniform chunk is its record, not its planes (compact planes)
+        const ivx_chunk_info* ip = g.info + (o >> 12);
+        const ivx_chunk_info c1 = ip[0];
+        if (c1.kind == KIND_NONUNIFORM) {
+            const uint4 s4 = *reinterpret_cast<const uint4*>(ps + o);
+            const uint4 t4 = *reinterpret_cast<const uint4*>(pt + o);
+            sd[1] = s4.x, sd[2] = s4.y, sd[3] = s4.z, sd[4] = s4.w;
+            ty[1] = t4.x, ty[2] = t4.y, ty[3] = t4.z, ty[4] = t4.w;
+        } else {
+            sd[1] = sd[2] = sd[3] = sd[4] = ivx_uniform_sdf(c1.kind) * 0x01010101u;
+            ty[1] = ty[2] = ty[3] = ty[4] = ivx_uniform_type(c1) * 0x01010101u;
+        }
+        if (ck > 0) {
+            const ivx_chunk_info c0 = ip[-1];
+            const bool dense = c0.kind == KIND_NONUNIFORM;
+            sd[0] = dense ? (uint32_t)(uint8_t)ps[o - kstride + 15] : ivx_uniform_sdf(c0.kind);
+            ty[0] = dense ? (uint32_t)pt[o - kstride + 15] : ivx_uniform_type(c0);
+        }
+        if (ck + 1 < (int)g.cz) {
+            const ivx_chunk_info c2 = ip[1];
+            const bool dense = c2.kind == KIND_NONUNIFORM;
+            sd[5] = dense ? (uint32_t)(uint8_t)ps[o + kstride] : ivx_uniform_sdf(c2.kind);
+            ty[5] = dense ? (uint32_t)pt[o + kstride] : ivx_uniform_type(c2);
+        }
+        return;
+    }
     const uint4 s4 = *reinterpret_cast<const uint4*>(ps + o);
     const uint4 t4 = *reinterpret_cast<const uint4*>(pt + o);
     sd[1] = s4.x, sd[2] = s4.y, sd[3] = s4.z, sd[4] = s4.w;
@@ -175,21 +202,25 @@ __device__ __forceinline__ void upper_limits(const GridView& g, int ci, int cj, 
     if (neighbour_kind(g, ci, cj, ck + 1) == KIND_NONUNIFORM) upper[2] -= 1;
 }
 
+// Walks the active list (the chunks k_chunk_pre settled have no mesh and got their zero counts there).
 __global__ __launch_bounds__(256) void k_sn_count(SnParams p, uint32_t* __restrict__ counts, uint32_t* __restrict__ group_sums,
-                                                  uint32_t* __restrict__ emit_count, uint32_t* __restrict__ emit_list) {
+                                                  uint32_t* __restrict__ emit_count, uint32_t* __restrict__ emit_list,
+                                                  const uint32_t* __restrict__ work_counts, const uint32_t* __restrict__ active_list) {
     __shared__ uint32_t s_neg[NROWS];
     __shared__ uint32_t s_acc[2];
     const GridView& g = p.g;
     const uint32_t tid = threadIdx.x;
-    const uint32_t n_chunks = g.cx * g.cy * g.cz;
-    const uint32_t chunk = ivx_xcd_remap(blockIdx.x, n_chunks);
+    const uint32_t n_active = work_counts[0];
+    for (uint32_t li = ivx_xcd_remap(blockIdx.x, gridDim.x); li < n_active; li += gridDim.x) {
+    __syncthreads();  // the previous chunk's LDS use is over
+    const uint32_t chunk = active_list[li];
     const ivx_chunk_info info = g.info[chunk];
     if (!chunk_exposed(info)) {
         if (tid == 0) {
             counts[2 * chunk] = 0;
             counts[2 * chunk + 1] = 0;
         }
-        return;
+        continue;
     }
     const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
     if (tid < 2) s_acc[tid] = 0;
@@ -217,6 +248,7 @@ __global__ __launch_bounds__(256) void k_sn_count(SnParams p, uint32_t* __restri
             atomicAdd(gs + 2, 1u);
             emit_list[atomicAdd(emit_count, 1u)] = chunk;  // chunks with a mesh, for k_sn_emit (order irrelevant)
         }
+    }
     }
 }
 
@@ -642,7 +674,8 @@ int ivx_launch_sn_count(ivx_grid* g) {
     const uint32_t groups = (g->n_chunks + 255u) / 256u;
     uint32_t* gs = g->group_sums + groups;  // the first `groups` words belong to the region resolve
     if (!g->scratch_preset) IVX_HIP_CHECK(hipMemsetAsync(gs, 0, sizeof(uint32_t) * (3 * groups + 1), g->ctx->stream));
-    hipLaunchKernelGGL(k_sn_count, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts, gs, gs + 3 * groups, g->sn_list);
+    hipLaunchKernelGGL(k_sn_count, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts, gs, gs + 3 * groups, g->sn_list,
+                       g->work_counts, g->active_list);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

@@ -124,7 +124,9 @@ int ivx_grid_chunk_counts(ivx_grid*, uint32_t out[3]);
 /* diagnostics of the last step: chunks the sampler evaluated per voxel, chunks with several local regions, chunks that
  * emitted a mesh, total chunks */
 int ivx_grid_stage_counters(ivx_grid*, uint32_t out[4]);
-/* device pointers of the planes: 0 sdf, 1 type, 2 flags, 3 local labels, 4 chunk info, 5 global region parents */
+/* device pointers of the planes: 0 sdf, 1 type, 2 flags, 3 local labels, 4 chunk info, 5 global region parents. Between
+ * steps the planes of Void / Uniform chunks are not kept up to date (such a chunk is its 8-byte record, as in the
+ * reference's store, object.rs:96-119); asking for a plane pointer (0-3) enqueues the kernel that writes them out. */
 void* ivx_grid_device_ptr(ivx_grid*, int which);
 
 /* ---- a3: SDF sample ----------------------------------------------------------------------------- */

@@ -1,0 +1,16 @@
+#!/bin/bash
+# per-kernel durations of the default bench workload (rocprofv3 kernel trace -> CSV summary on stdout)
+# usage (GPU box): tools/kernel_trace.sh <tag> [bench args]
+tag=${1:-kt}; shift
+out=$PWD/gpurun_out/$tag
+mkdir -p "$out"
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d "$out/trace" -o trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pile "$@" > "$out/trace_stdout.log" 2>&1
+python tools/rocpd_stats.py "$(ls "$out"/trace/*.db | tail -1)" > "$out/kernel_stats.csv"
+rm -rf "$out/trace"
+python - "$out/kernel_stats.csv" <<'PY'
+import csv, sys, re
+for r in csv.DictReader(open(sys.argv[1])):
+    name = re.sub(r"\(.*", "", r["Name"].replace("(anonymous namespace)::", "").replace("void ", ""))
+    print(f"{name:28s} {int(r['Calls']):4d} {float(r['AverageNs'])/1000:9.1f} us")
+PY
