@@ -95,17 +95,16 @@ __global__ __launch_bounds__(256) void k_ccl_local(GridView g, const uint8_t* __
     const uint32_t n_active = work_counts[0];
     for (uint32_t li = ivx_xcd_remap(blockIdx.x, gridDim.x); li < n_active; li += gridDim.x) {
     __syncthreads();  // the previous chunk's LDS use is over
-    const uint32_t chunk = active_list[li];
+    const uint32_t entry = active_list[li];  // chunk + kinds (written by k_derive): no trip to the chunk record
+    const uint32_t chunk = IVX_LIST_CHUNK(entry);
     const size_t base = (size_t)chunk * IVX_CHUNK_VOXELS + (size_t)tid * 16;
-    const ivx_chunk_info cinfo = g.info[chunk];
-    const uint32_t kind = cinfo.kind;
+    const uint32_t kind = IVX_LIST_KIND(entry);
     uint32_t* rp = rparent + (size_t)chunk * 256;
 
-    uint32_t m = 0;
     // a Void chunk has no voxels and a chunk generated Uniform is one solid region whether or not it was demoted
-    // since: neither needs its flags read
-    const bool known = kind == KIND_VOID || cinfo.gen_kind == KIND_UNIFORM;
-    if (!known) m = flags_mask(*reinterpret_cast<const uint4*>(flags + base));
+    // since: neither needs its flags
+    const bool known = kind == KIND_VOID || IVX_LIST_GEN(entry) == KIND_UNIFORM;
+    const uint32_t m = known ? 0u : flags_mask(*reinterpret_cast<const uint4*>(flags + base));
     const int all_full = known ? (kind != KIND_VOID) : __syncthreads_and(m == 0xFFFFu);
     const int any = known ? (kind != KIND_VOID) : __syncthreads_or(m != 0);
     if (!any || all_full) {
@@ -345,76 +344,61 @@ __device__ __forceinline__ void g_union(uint32_t* par, uint32_t a, uint32_t b) {
     }
 }
 
-// Solid chunks (generated Uniform: one region, six Full faces, demoted or not) make up the bulk of a body, and joining them
-// pairwise through the forest costs a chain of dependent global loads per pair. They are joined by structure instead: one
-// WAVE per (ci, cj) column of chunks, lane = ck. A run of solid chunks along k hangs directly under the first chunk of the
-// run (plain stores: those nodes are nobody's root yet); where a run overlaps a run of the +y / +x neighbour column, the two
-// run heads are joined once. k_ccl_merge then leaves solid-solid pairs alone.
-__global__ __launch_bounds__(256) void k_ccl_merge_solid(GridView g, uint32_t* __restrict__ rparent) {
+// Level 2 for single-region chunks (all but a handful). Joining chunks pairwise through the forest costs a chain of dependent
+// global loads and atomics per pair, nearly all of them on the one root of the body. They are joined by structure instead:
+// one WAVE per (ci, cj) column of chunks, lane = ck. Two single-region chunks stacked along k are linked when k_derive saw a
+// voxel pair touch across their face; a run of linked chunks hangs directly under its first chunk (plain stores: those
+// nodes are nobody's root yet). Where a chunk touches its +y / +x neighbour, the heads of the two runs are joined, once
+// per stretch over which both runs continue. Chunks with several regions are left to k_ccl_merge_multi.
+__global__ __launch_bounds__(256) void k_ccl_merge_columns(GridView g, const uint8_t* __restrict__ touch, uint32_t* __restrict__ rparent) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t col = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (col >= g.cx * g.cy) return;
     const uint32_t cj = col % g.cy, ci = col / g.cy;
-    // heads of the solid runs that reach the end of the previous 64-chunk segment: this column, the +y and the +x column
+    // heads of the runs that reach the end of the previous 64-chunk segment: this column, the +y and the +x column
     uint32_t carry[3] = {NODE_NONE, NODE_NONE, NODE_NONE};
     const uint32_t cols[3] = {col, col + 1u, col + g.cy};
+    const bool has[3] = {true, cj + 1 < g.cy, ci + 1 < g.cx};
+    const unsigned long long below = (1ull << lane) - 1ull;
     for (uint32_t k0 = 0; k0 < g.cz; k0 += 64u) {
         const uint32_t ck = k0 + lane;
         const bool in = ck < g.cz;
-        const uint32_t chunk = col * g.cz + ck;
-        bool solid[3];
-        solid[0] = in && g.info[chunk].gen_kind == KIND_UNIFORM;
-        solid[1] = in && cj + 1 < g.cy && g.info[chunk + g.cz].gen_kind == KIND_UNIFORM;
-        solid[2] = in && ci + 1 < g.cx && g.info[chunk + g.cy * g.cz].gen_kind == KIND_UNIFORM;
-        unsigned long long m[3];
+        bool single[3];
+        unsigned long long lm[3];
         uint32_t head[3];
+        uint32_t own_touch = 0;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            m[q] = __ballot(solid[q]);
+            single[q] = false;
+            bool linkz = false;
+            if (in && has[q]) {
+                const uint32_t c = cols[q] * g.cz + ck;
+                const uint32_t tb = touch[c];
+                single[q] = g.info[c].region_count == 1;
+                if (q == 0) own_touch = tb;
+                if (single[q] && ck + 1 < g.cz && ((tb >> 2) & 1u)) linkz = g.info[c + 1].region_count == 1;
+            }
+            lm[q] = __ballot(linkz);
             // node of the first chunk of the run of column q that contains this lane (runs continue across segments)
-            const unsigned long long gaps = ~m[q] & ((1ull << lane) - 1ull);
+            const unsigned long long gaps = ~lm[q] & below;
             const uint32_t hs = gaps ? 64u - (uint32_t)__clzll(gaps) : 0u;
             head[q] = (hs == 0u && carry[q] != NODE_NONE) ? carry[q] : (cols[q] * g.cz + k0 + hs) * 256u;
         }
-        if (solid[0]) {
-            if (head[0] != chunk * 256u) rparent[(size_t)chunk * 256] = head[0];
-            // one union of run heads per overlap of this column's runs with a neighbour column's runs (heads are never
-            // written by the plain stores above, so the atomics of g_union are safe beside them)
+        const uint32_t node = (col * g.cz + ck) * 256u;
+        if (single[0] && head[0] != node) rparent[node] = head[0];
 #pragma unroll
-            for (int q = 1; q < 3; ++q) {
-                const unsigned long long common = m[0] & m[q];
-                if (solid[q] && (lane == 0 || !((common >> (lane - 1)) & 1ull))) g_union(rparent, head[0], head[q]);
-            }
+        for (int q = 1; q < 3; ++q) {
+            const bool link = single[0] && single[q] && ((own_touch >> (q == 1 ? 1 : 0)) & 1u);
+            const unsigned long long links = __ballot(link);
+            // the lane below joined the same two runs already
+            const bool dup = lane != 0 && ((links >> (lane - 1)) & 1ull) && ((lm[0] >> (lane - 1)) & 1ull) && ((lm[q] >> (lane - 1)) & 1ull);
+            if (link && !dup) g_union(rparent, head[0], head[q]);
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            // the run containing lane 63, if any, carries its head into the next segment
             const uint32_t h63 = __shfl(head[q], 63, 64);
-            carry[q] = ((m[q] >> 63) & 1ull) ? h63 : NODE_NONE;
+            carry[q] = ((lm[q] >> 63) & 1ull) ? h63 : NODE_NONE;
         }
-    }
-}
-
-// Pairs of single-region chunks (nearly all pairs that are not solid-solid): one THREAD per (active chunk, direction) joins
-// the chunk's region with the +x, +y or +z neighbour's across a face where k_derive saw a touching voxel pair. No label
-// plane is read.
-__global__ __launch_bounds__(256) void k_ccl_merge_single(GridView g, const uint8_t* __restrict__ touch, uint32_t* __restrict__ rparent,
-                                                          const uint32_t* __restrict__ work_counts, const uint32_t* __restrict__ active_list) {
-    const uint32_t n_items = work_counts[0] * 3u;
-    for (uint32_t it = blockIdx.x * 256u + threadIdx.x; it < n_items; it += gridDim.x * 256u) {
-        const uint32_t chunk = active_list[it / 3u];
-        const int dim = (int)(it % 3u);
-        if (!((touch[chunk] >> dim) & 1u)) continue;
-        const ivx_chunk_info oinfo = g.info[chunk];
-        if (oinfo.region_count != 1) continue;  // none, or several: k_ccl_merge_multi
-        const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
-        const int ni = ci + (dim == 0), nj = cj + (dim == 1), nk = ck + (dim == 2);
-        if (ni >= (int)g.cx || nj >= (int)g.cy || nk >= (int)g.cz) continue;
-        const uint32_t nchunk = (ni * g.cy + nj) * g.cz + nk;
-        const ivx_chunk_info ninfo = g.info[nchunk];
-        if (ninfo.region_count != 1) continue;
-        if (oinfo.gen_kind == KIND_UNIFORM && ninfo.gen_kind == KIND_UNIFORM) continue;  // joined by k_ccl_merge_solid
-        g_union(rparent, chunk * 256u, nchunk * 256u);
     }
 }
 
@@ -762,9 +746,7 @@ int ivx_launch_ccl_local(ivx_grid* g) {
 
 int ivx_launch_ccl_merge(ivx_grid* g) {
     GridView v = ivx_view(g);
-    hipLaunchKernelGGL(k_ccl_merge_solid, dim3((g->cc[0] * g->cc[1] + 3u) / 4u), dim3(256), 0, g->ctx->stream, v, g->rparent);
-    uint32_t single_blocks = (3u * ivx_list_grid(g) + 255u) / 256u;
-    hipLaunchKernelGGL(k_ccl_merge_single, dim3(single_blocks), dim3(256), 0, g->ctx->stream, v, g->chunk_touch, g->rparent, g->work_counts, g->active_list);
+    hipLaunchKernelGGL(k_ccl_merge_columns, dim3((g->cc[0] * g->cc[1] + 3u) / 4u), dim3(256), 0, g->ctx->stream, v, g->chunk_touch, g->rparent);
     const uint32_t multi_blocks = g->n_chunks < 256u ? g->n_chunks : 256u;
     hipLaunchKernelGGL(k_ccl_merge_multi, dim3(multi_blocks), dim3(256), 0, g->ctx->stream, v, g->llabel, g->rparent, g->rscalar, g->ccl_scratch);
     IVX_HIP_CHECK(hipGetLastError());

@@ -40,10 +40,12 @@ __device__ __forceinline__ uint32_t row_mask(uint4 s) {
 
 // non-empty mask of one 16-voxel row of chunk `c` (row offset `off` inside the chunk). Chunks generated Void / Uniform
 // are known from their record; their planes are not read (and need not hold data: compact planes).
+// (the row is fetched whatever the record says — the plane exists, only its content may be stale — so that the two loads
+// overlap instead of forming a dependent chain; these kernels are bound by such chains, not by bandwidth)
 __device__ __forceinline__ uint32_t nbr_row_mask(const GridView& g, const ivx_chunk_info* info, size_t c, uint32_t off) {
     const uint32_t gen = info[c].gen_kind;
-    if (gen != KIND_NONUNIFORM) return gen == KIND_UNIFORM ? 0xFFFFu : 0u;
-    return row_mask(*reinterpret_cast<const uint4*>(g.sdf + c * IVX_CHUNK_VOXELS + off));
+    const uint32_t rm = row_mask(*reinterpret_cast<const uint4*>(g.sdf + c * IVX_CHUNK_VOXELS + off));
+    return gen == KIND_NONUNIFORM ? rm : (gen == KIND_UNIFORM ? 0xFFFFu : 0u);
 }
 
 // One THREAD per chunk: settles every chunk whose derived state follows from the chunk records alone and lists the others
@@ -51,7 +53,7 @@ __device__ __forceinline__ uint32_t nbr_row_mask(const GridView& g, const ivx_ch
 // neighbours were generated Uniform too is solid all round and stays Uniform. Neither has planes (compact planes), so all of
 // their per-step state is the record, the occupied sub-box, one region and empty mesh counts.
 __global__ __launch_bounds__(256) void k_chunk_pre(GridView g, ivx_chunk_info* __restrict__ info, uint32_t* __restrict__ bbox,
-                                                   uint32_t* __restrict__ mesh_counts, uint8_t* __restrict__ chunk_class,
+                                                   uint32_t* __restrict__ mesh_counts, uint8_t* __restrict__ chunk_class, uint8_t* __restrict__ touch,
                                                    uint32_t* __restrict__ work_counts, uint32_t* __restrict__ active_list) {
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_base;
@@ -87,6 +89,7 @@ __global__ __launch_bounds__(256) void k_chunk_pre(GridView g, ivx_chunk_info* _
             bbox[chunk] = solid ? (0x80000000u | (15u << 4) | (15u << 12) | (15u << 20)) : 0u;
             mesh_counts[2 * chunk] = 0;
             mesh_counts[2 * chunk + 1] = 0;
+            touch[chunk] = solid ? 7 : 0;  // a settled solid chunk touches its three upper neighbours (all solid)
         }
         chunk_class[chunk] = settled ? 1 : 0;
     }
@@ -107,7 +110,8 @@ __global__ __launch_bounds__(256) void k_chunk_pre(GridView g, ivx_chunk_info* _
 
 __global__ __launch_bounds__(256) void k_derive(GridView g, int8_t* __restrict__ sdf_rw, uint8_t* __restrict__ type_rw, uint8_t* __restrict__ flags_out,
                                                 ivx_chunk_info* __restrict__ info, uint32_t* __restrict__ bbox, uint8_t* __restrict__ touch,
-                                                const uint32_t* __restrict__ work_counts, const uint32_t* __restrict__ active_list) {
+                                                uint16_t* __restrict__ signs,
+                                                const uint32_t* __restrict__ work_counts, uint32_t* __restrict__ active_list) {
     __shared__ uint32_t occ[18][18];  // non-empty masks of rows (i+1, j+1); halo rows from neighbour chunks
     __shared__ uint32_t cnt[13];      // own face non-empty counts [0..6), neighbour face non-empty counts [6..12), [12] touch bits
     const uint32_t tid = threadIdx.x;
@@ -116,14 +120,16 @@ __global__ __launch_bounds__(256) void k_derive(GridView g, int8_t* __restrict__
     // bounded walk over the active list (virtual block ids give each XCD a contiguous stretch of it)
     for (uint32_t li = ivx_xcd_remap(blockIdx.x, gridDim.x); li < n_active; li += gridDim.x) {
     __syncthreads();  // the previous chunk's LDS use is over
-    const uint32_t chunk = active_list[li];
+    const uint32_t chunk = IVX_LIST_CHUNK(active_list[li]);
     const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
     const size_t base = (size_t)chunk * IVX_CHUNK_VOXELS;
     const ivx_chunk_info own_info = info[chunk];
+    const uint32_t own_row_mask = row_mask(*reinterpret_cast<const uint4*>(g.sdf + base + (size_t)tid * 16));  // used only if the chunk has planes
     if (tid < 13) cnt[tid] = 0;
     const bool own_uniform = own_info.gen_kind == KIND_UNIFORM;
-    const uint32_t m = own_uniform ? 0xFFFFu : row_mask(*reinterpret_cast<const uint4*>(g.sdf + base + (size_t)tid * 16));
+    const uint32_t m = own_uniform ? 0xFFFFu : own_row_mask;
     occ[ti + 1][tj + 1] = m;
+    signs[(size_t)chunk * 256 + tid] = (uint16_t)m;  // for the mesher's count pass
 
     // neighbour rows across the x and y faces: 16 threads each load one 16-byte row
     uint32_t zlo = 0, zhi = 0;  // neighbour voxel across the z faces for this (i,j)
@@ -131,11 +137,13 @@ __global__ __launch_bounds__(256) void k_derive(GridView g, int8_t* __restrict__
         // z faces: one byte per thread from the adjacent chunk in k
         if (ck > 0) {
             const uint32_t gen = info[chunk - 1].gen_kind;
-            zlo = gen != KIND_NONUNIFORM ? (gen == KIND_UNIFORM ? 1u : 0u) : (((uint8_t)g.sdf[base - IVX_CHUNK_VOXELS + tid * 16 + 15] >> 7) & 1u);
+            const uint32_t bit = ((uint8_t)g.sdf[base - IVX_CHUNK_VOXELS + tid * 16 + 15] >> 7) & 1u;
+            zlo = gen == KIND_NONUNIFORM ? bit : (gen == KIND_UNIFORM ? 1u : 0u);
         }
         if (ck + 1 < (int)g.cz) {
             const uint32_t gen = info[chunk + 1].gen_kind;
-            zhi = gen != KIND_NONUNIFORM ? (gen == KIND_UNIFORM ? 1u : 0u) : (((uint8_t)g.sdf[base + IVX_CHUNK_VOXELS + tid * 16] >> 7) & 1u);
+            const uint32_t bit = ((uint8_t)g.sdf[base + IVX_CHUNK_VOXELS + tid * 16] >> 7) & 1u;
+            zhi = gen == KIND_NONUNIFORM ? bit : (gen == KIND_UNIFORM ? 1u : 0u);
         }
     }
     if (tid < 64) {
@@ -264,6 +272,10 @@ __global__ __launch_bounds__(256) void k_derive(GridView g, int8_t* __restrict__
 
     if (tid == 0) {
         touch[chunk] = (uint8_t)cnt[12];
+        {  // the list entry carries what the later stages need from the record
+            const bool obscured = kind == KIND_NONUNIFORM && nbr_full == 0x3Fu;
+            active_list[li] = chunk | (kind << 24) | (gen << 26) | ((kind == KIND_NONUNIFORM && !obscured) ? (1u << 28) : 0u);
+        }
         ivx_chunk_info ci_ = own_info;
         ci_.kind = (uint8_t)kind;
         if (kind == KIND_NONUNIFORM) {
@@ -411,9 +423,9 @@ int ivx_launch_derive(ivx_grid* g) {
     GridView v = ivx_view(g);
     if (!g->scratch_preset) IVX_HIP_CHECK(hipMemsetAsync(g->work_counts, 0, sizeof(uint32_t), g->ctx->stream));
     hipLaunchKernelGGL(k_chunk_pre, dim3((g->n_chunks + 255u) / 256u), dim3(256), 0, g->ctx->stream, v, g->info, g->chunk_bbox, g->chunk_counts,
-                       g->chunk_class, g->work_counts, g->active_list);
+                       g->chunk_class, g->chunk_touch, g->work_counts, g->active_list);
     hipLaunchKernelGGL(k_derive, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->sdf, g->type, g->flags, g->info, g->chunk_bbox,
-                       g->chunk_touch, g->work_counts, g->active_list);
+                       g->chunk_touch, g->chunk_signs, g->work_counts, g->active_list);
     g->planes_compact = 1;
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;

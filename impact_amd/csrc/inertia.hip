@@ -22,6 +22,29 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// Sum over the wave on the VALU's DPP path (the shuffle form above goes through the LDS crossbar, two ds_bpermute per step
+// and double; ten of those chains per chunk made k_inertia_dense wait on LDS for a third of its time). Rows of 16 lanes
+// are summed with row_shr 1/2/4/8 (lanes shifted in from outside the row read zero), lane 15 of each row then holds the
+// row total; the four row totals are read as scalars and added in a fixed order. Every lane returns the wave total.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_f64<0x111>(v);  // row_shr:1
+    v += dpp_f64<0x112>(v);  // row_shr:2
+    v += dpp_f64<0x114>(v);  // row_shr:4
+    v += dpp_f64<0x118>(v);  // row_shr:8
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double r[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * q + 15), __builtin_amdgcn_readlane(lo, 16 * q + 15));
+    return (r[0] + r[1]) + (r[2] + r[3]);
+}
+
 // Moments of the NonUniform chunks, one workgroup per listed chunk, into the chunk's own slot (so the order of the
 // final sum does not depend on the order of the list).
 __global__ __launch_bounds__(256) void k_inertia_dense(GridView g, uint32_t x_off, const uint8_t* __restrict__ flags,
@@ -35,8 +58,9 @@ __global__ __launch_bounds__(256) void k_inertia_dense(GridView g, uint32_t x_of
     const uint32_t n_active = work_counts[0];
     for (uint32_t li = ivx_xcd_remap(blockIdx.x, gridDim.x); li < n_active; li += gridDim.x) {
         __syncthreads();  // s_dens ready / the previous chunk's s_red use is over
-        const uint32_t chunk = active_list[li];
-        if (g.info[chunk].kind != KIND_NONUNIFORM) continue;  // Uniform chunks are closed forms in k_inertia_sum
+        const uint32_t entry = active_list[li];
+        const uint32_t chunk = IVX_LIST_CHUNK(entry);
+        if (IVX_LIST_KIND(entry) != KIND_NONUNIFORM) continue;  // Uniform chunks are closed forms in k_inertia_sum
         const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
         const size_t o = (size_t)chunk * IVX_CHUNK_VOXELS + (size_t)tid * 16;
         const uint4 f = *reinterpret_cast<const uint4*>(flags + o);
@@ -61,7 +85,7 @@ __global__ __launch_bounds__(256) void k_inertia_dense(GridView g, uint32_t x_of
         const uint32_t lane = tid & 63u, wave = tid >> 6;
 #pragma unroll
         for (int m = 0; m < 10; ++m) {
-            const double v = wave_sum(s[m]);
+            const double v = wave_sum_dpp(s[m]);
             if (lane == 0) s_red[wave][m] = v;
         }
         __syncthreads();

@@ -152,6 +152,7 @@ int ivx_init(int device_id, void* stream, ivx_ctx** out) {
     ivx_ctx* c = new (std::nothrow) ivx_ctx();
     IVX_REQUIRE(c, IVX_ERR_CAPACITY, "ivx_init: out of host memory");
     c->device = device_id;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (stream) {
         c->stream = static_cast<hipStream_t>(stream);
         c->own_stream = false;
@@ -234,6 +235,7 @@ int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32
     A(dev_alloc(&g->fill_list, (size_t)g->n_chunks));
     A(dev_alloc(&g->chunk_class, (size_t)g->n_chunks));
     A(dev_alloc(&g->chunk_touch, (size_t)g->n_chunks));
+    A(dev_alloc(&g->chunk_signs, (size_t)g->n_chunks * 256));
     A(dev_alloc(&g->chunk_moments, (size_t)g->n_chunks * 10));
     if (rc != IVX_OK) {
         ivx_grid_destroy(g);
@@ -254,7 +256,7 @@ void ivx_grid_destroy(ivx_grid* g) {
     void* ptrs[] = {g->sdf, g->type, g->flags, g->llabel, g->info, g->ghost_sdf[0], g->ghost_sdf[1], g->ghost_type[0], g->ghost_type[1],
                     g->ghost_info[0], g->ghost_info[1], g->chunk_counts, g->chunk_offsets, g->positions, g->normals, g->indices,
                     g->index_materials, g->vertex_materials, g->submeshes, g->partials, g->rparent, g->rcompid, g->rscalar, g->ccl_scratch, g->group_sums, g->sn_list, g->dens_dev, g->dev_scratch, g->prog_nodes, g->chunk_bbox, g->samp_len, g->samp_ops, g->pairs_dev,
-                    g->work_counts, g->active_list, g->fill_list, g->chunk_class, g->chunk_moments, g->chunk_touch};
+                    g->work_counts, g->active_list, g->fill_list, g->chunk_class, g->chunk_moments, g->chunk_touch, g->chunk_signs};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->host_scratch) (void)hipHostFree(g->host_scratch);
@@ -300,10 +302,9 @@ int ivx_grid_stage_counters(ivx_grid* g, uint32_t out[4]) {
     IVX_REQUIRE(g && out, IVX_ERR_INVALID, "ivx_grid_stage_counters: null argument");
     for (int i = 0; i < 4; ++i) out[i] = 0;
     int rc;
-    const uint32_t groups = (g->n_chunks + 255u) / 256u;
     if (g->samp_len && (rc = d2h(g, &out[0], g->samp_len + g->n_chunks, sizeof(uint32_t)))) return rc;  // chunks evaluated per voxel by the sampler
     if ((rc = d2h(g, &out[1], g->rscalar + 2, sizeof(uint32_t)))) return rc;                            // chunks with several local regions
-    if ((rc = d2h(g, &out[2], g->group_sums + groups + 3 * groups, sizeof(uint32_t)))) return rc;       // chunks that emitted a mesh
+    if ((rc = d2h(g, &out[2], g->chunk_offsets + 2 * (size_t)g->n_chunks + 2, sizeof(uint32_t)))) return rc;  // chunks that emitted a mesh
     out[3] = g->n_chunks;
     return IVX_OK;
 }

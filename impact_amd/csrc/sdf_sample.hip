@@ -407,13 +407,12 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
     else if (lo >= 2.54f + 0.02f) out = 1000.0f;    // every voxel quantises to +127
     else if (hi <= -2.56f - 0.02f) out = -1000.0f;  // every voxel quantises to -128
     if (oi >= p.shape[0] || oj >= p.shape[1] || ok >= p.shape[2]) out = 1000.0f;  // beyond the generator's grid: all +127
-    if (blockIdx.x * PRE_T + tid < n_chunks) {  // (tail threads replay the last chunk: they must not list it twice)
+    const bool mine = blockIdx.x * PRE_T + tid < n_chunks;  // (tail threads replay the last chunk: they must not list it twice)
+    bool to_fill = false;
+    if (mine) {
         chunk_const[chunk] = out;
         prog_len[chunk] = pos <= OP_CAP ? pos : OP_OVERFLOW;
-        // chunks that need per-voxel evaluation go on a list for k_sdf_eval (order is irrelevant)
-        if (out != out) {
-            eval_list[atomicAdd(eval_count, 1u)] = chunk;
-        } else {
+        if (out == out) {
             // A constant chunk is classified right here (create_for_generated_voxels, object.rs:1890-1964): every voxel
             // void (> +2.0) -> Void, every voxel maximally inside -> Uniform; such a chunk is its record and has no planes to
             // write (compact planes). Any other constant, or a chunk that straddles the generator's grid (voxels beyond it
@@ -432,9 +431,24 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
                 rec.boundary_region_count = 0;
                 info_out[chunk] = rec;
             } else {
-                fill_list[atomicAdd(fill_count, 1u)] = chunk;
+                to_fill = true;
             }
         }
+    }
+    // chunks that need per-voxel evaluation go on a list for k_sdf_eval, constant chunks with planes to write on one for
+    // k_sdf_fill (order is irrelevant); one atomic per wave and list (the block is one wave)
+    static_assert(PRE_T == 64, "the list appends below assume one wave per block");
+    {
+        const unsigned long long below = (1ull << tid) - 1ull;
+        const bool ev = mine && out != out;
+        const unsigned long long be = __ballot(ev), bf = __ballot(to_fill);
+        uint32_t base_e = 0, base_f = 0;
+        if (tid == 0 && be) base_e = atomicAdd(eval_count, (uint32_t)__popcll(be));
+        if (tid == 0 && bf) base_f = atomicAdd(fill_count, (uint32_t)__popcll(bf));
+        base_e = __shfl(base_e, 0, 64);
+        base_f = __shfl(base_f, 0, 64);
+        if (ev) eval_list[base_e + (uint32_t)__popcll(be & below)] = chunk;
+        if (to_fill) fill_list[base_f + (uint32_t)__popcll(bf & below)] = chunk;
     }
 }
 

@@ -77,28 +77,29 @@ __device__ __forceinline__ void fetch_row(const GridView& g, int gi, int gj, int
     const size_t o = row + (size_t)ck * kstride;
     if (kstride == IVX_CHUNK_VOXELS) {
         // inside the slab a Void / Uniform chunk is its record, not its planes (compact planes)
+        // (record and plane rows are fetched side by side and the record picks afterwards: the planes exist for every
+        // chunk, only their content may be stale, and a dependent load chain costs more here than the extra bytes)
         const ivx_chunk_info* ip = g.info + (o >> 12);
         const ivx_chunk_info c1 = ip[0];
-        if (c1.kind == KIND_NONUNIFORM) {
-            const uint4 s4 = *reinterpret_cast<const uint4*>(ps + o);
-            const uint4 t4 = *reinterpret_cast<const uint4*>(pt + o);
-            sd[1] = s4.x, sd[2] = s4.y, sd[3] = s4.z, sd[4] = s4.w;
-            ty[1] = t4.x, ty[2] = t4.y, ty[3] = t4.z, ty[4] = t4.w;
-        } else {
-            sd[1] = sd[2] = sd[3] = sd[4] = ivx_uniform_sdf(c1.kind) * 0x01010101u;
-            ty[1] = ty[2] = ty[3] = ty[4] = ivx_uniform_type(c1) * 0x01010101u;
-        }
+        const uint4 s4 = *reinterpret_cast<const uint4*>(ps + o);
+        const uint4 t4 = *reinterpret_cast<const uint4*>(pt + o);
+        const bool d1 = c1.kind == KIND_NONUNIFORM;
+        const uint32_t us = ivx_uniform_sdf(c1.kind) * 0x01010101u, ut = ivx_uniform_type(c1) * 0x01010101u;
+        sd[1] = d1 ? s4.x : us, sd[2] = d1 ? s4.y : us, sd[3] = d1 ? s4.z : us, sd[4] = d1 ? s4.w : us;
+        ty[1] = d1 ? t4.x : ut, ty[2] = d1 ? t4.y : ut, ty[3] = d1 ? t4.z : ut, ty[4] = d1 ? t4.w : ut;
         if (ck > 0) {
             const ivx_chunk_info c0 = ip[-1];
+            const uint32_t bs = (uint8_t)ps[o - kstride + 15], bt = pt[o - kstride + 15];
             const bool dense = c0.kind == KIND_NONUNIFORM;
-            sd[0] = dense ? (uint32_t)(uint8_t)ps[o - kstride + 15] : ivx_uniform_sdf(c0.kind);
-            ty[0] = dense ? (uint32_t)pt[o - kstride + 15] : ivx_uniform_type(c0);
+            sd[0] = dense ? bs : ivx_uniform_sdf(c0.kind);
+            ty[0] = dense ? bt : ivx_uniform_type(c0);
         }
         if (ck + 1 < (int)g.cz) {
             const ivx_chunk_info c2 = ip[1];
+            const uint32_t bs = (uint8_t)ps[o + kstride], bt = pt[o + kstride];
             const bool dense = c2.kind == KIND_NONUNIFORM;
-            sd[5] = dense ? (uint32_t)(uint8_t)ps[o + kstride] : ivx_uniform_sdf(c2.kind);
-            ty[5] = dense ? (uint32_t)pt[o + kstride] : ivx_uniform_type(c2);
+            sd[5] = dense ? bs : ivx_uniform_sdf(c2.kind);
+            ty[5] = dense ? bt : ivx_uniform_type(c2);
         }
         return;
     }
@@ -116,13 +117,6 @@ __device__ __forceinline__ void fetch_row(const GridView& g, int gi, int gj, int
     }
 }
 
-__device__ __forceinline__ uint32_t neighbour_kind(const GridView& g, int ci, int cj, int ck) {
-    if (cj < 0 || ck < 0 || cj >= (int)g.cy || ck >= (int)g.cz) return KIND_VOID;
-    if (ci < 0) return g.ghost_info[0] ? g.ghost_info[0][cj * g.cz + ck].kind : (uint32_t)KIND_VOID;
-    if (ci >= (int)g.cx) return g.ghost_info[1] ? g.ghost_info[1][cj * g.cz + ck].kind : (uint32_t)KIND_VOID;
-    return g.info[(ci * g.cy + cj) * g.cz + ck].kind;
-}
-
 // sign bits of 16 packed i8 -> 16-bit mask
 __device__ __forceinline__ uint32_t neg16(const uint32_t w[4]) {
     uint32_t m = 0;
@@ -134,11 +128,53 @@ __device__ __forceinline__ uint32_t neg16(const uint32_t w[4]) {
     return m;
 }
 
+// The 18 sign bits of one padded row from the per-row masks k_derive left (count pass): bit 0 = cell -1 (bit 15 of the row in
+// the chunk below along k), bits 1..16 the row itself, bit 17 = cell 16 (bit 0 of the chunk above). A chunk that is not
+// NonUniform has no masks: all negative when Uniform, none when Void. Rows of a ghost layer come from the ghost planes.
+__device__ __forceinline__ uint32_t fetch_row_signs(const GridView& g, int gi, int gj, int ck) {
+    if (gj < 0 || gj >= (int)g.cy * 16) return 0u;
+    if (gi < 0 || gi >= (int)g.cx * 16) {
+        uint32_t sd[6], ty[6];
+        fetch_row(g, gi, gj, ck, sd, ty);
+        return ((sd[0] >> 7) & 1u) | (neg16(sd + 1) << 1) | (((sd[5] >> 7) & 1u) << 17);
+    }
+    const uint32_t chunk = ((gi >> 4) * g.cy + (gj >> 4)) * g.cz + ck;
+    const uint32_t row = ((gi & 15) << 4) | (gj & 15);
+    const ivx_chunk_info* ip = g.info + chunk;
+    const uint16_t* sp = g.signs + (size_t)chunk * 256 + row;
+    // (records and masks are fetched side by side; the record picks afterwards)
+    const uint32_t k1 = ip[0].kind, m1 = sp[0];
+    uint32_t bits = (k1 == KIND_NONUNIFORM ? m1 : (k1 == KIND_UNIFORM ? 0xFFFFu : 0u)) << 1;
+    if (ck > 0) {
+        const uint32_t k0 = ip[-1].kind, m0 = sp[-256];
+        bits |= k0 == KIND_NONUNIFORM ? ((m0 >> 15) & 1u) : (k0 == KIND_UNIFORM ? 1u : 0u);
+    }
+    if (ck + 1 < (int)g.cz) {
+        const uint32_t k2 = ip[1].kind, m2 = sp[256];
+        bits |= (k2 == KIND_NONUNIFORM ? (m2 & 1u) : (k2 == KIND_UNIFORM ? 1u : 0u)) << 17;
+    }
+    return bits;
+}
+
+__device__ __forceinline__ uint32_t neighbour_kind(const GridView& g, int ci, int cj, int ck) {
+    if (cj < 0 || ck < 0 || cj >= (int)g.cy || ck >= (int)g.cz) return KIND_VOID;
+    if (ci < 0) return g.ghost_info[0] ? g.ghost_info[0][cj * g.cz + ck].kind : (uint32_t)KIND_VOID;
+    if (ci >= (int)g.cx) return g.ghost_info[1] ? g.ghost_info[1][cj * g.cz + ck].kind : (uint32_t)KIND_VOID;
+    return g.info[(ci * g.cy + cj) * g.cz + ck].kind;
+}
+
 // Stage the 18^3 padded tile: 324 rows, one 16-byte plane load each (+ two halo bytes). s_neg[r] = 18-bit mask of
 // negative distances (decoded 0 is +0.0 => outside, surface_nets.rs:209-224). s_sd / s_ty may be null (count pass).
 __device__ __forceinline__ void load_tile(const GridView& g, int ci, int cj, int ck, uint8_t* s_sd, uint8_t* s_ty, uint32_t* s_neg, uint32_t tid) {
-    for (int r = tid; r < NROWS; r += 256) {
+#pragma unroll
+    for (int it = 0; it < (NROWS + 255) / 256; ++it) {  // unrolled: the loads of both rounds are in flight together
+        const int r = (int)tid + 256 * it;
+        if (r >= NROWS) break;
         const int a = r / G, b = r - a * G;
+        if (!s_sd) {  // count pass: signs only
+            s_neg[r] = fetch_row_signs(g, ci * 16 + a - 1, cj * 16 + b - 1, ck);
+            continue;
+        }
         uint32_t sd[6], ty[6];
         fetch_row(g, ci * 16 + a - 1, cj * 16 + b - 1, ck, sd, ty);
         s_neg[r] = ((sd[0] >> 7) & 1u) | (neg16(sd + 1) << 1) | (((sd[5] >> 7) & 1u) << 17);
@@ -204,7 +240,7 @@ __device__ __forceinline__ void upper_limits(const GridView& g, int ci, int cj, 
 
 // Walks the active list (the chunks k_chunk_pre settled have no mesh and got their zero counts there).
 __global__ __launch_bounds__(256) void k_sn_count(SnParams p, uint32_t* __restrict__ counts, uint32_t* __restrict__ group_sums,
-                                                  uint32_t* __restrict__ emit_count, uint32_t* __restrict__ emit_list,
+
                                                   const uint32_t* __restrict__ work_counts, const uint32_t* __restrict__ active_list) {
     __shared__ uint32_t s_neg[NROWS];
     __shared__ uint32_t s_acc[2];
@@ -213,9 +249,9 @@ __global__ __launch_bounds__(256) void k_sn_count(SnParams p, uint32_t* __restri
     const uint32_t n_active = work_counts[0];
     for (uint32_t li = ivx_xcd_remap(blockIdx.x, gridDim.x); li < n_active; li += gridDim.x) {
     __syncthreads();  // the previous chunk's LDS use is over
-    const uint32_t chunk = active_list[li];
-    const ivx_chunk_info info = g.info[chunk];
-    if (!chunk_exposed(info)) {
+    const uint32_t entry = active_list[li];
+    const uint32_t chunk = IVX_LIST_CHUNK(entry);
+    if (!IVX_LIST_EXPOSED(entry)) {
         if (tid == 0) {
             counts[2 * chunk] = 0;
             counts[2 * chunk + 1] = 0;
@@ -246,7 +282,6 @@ __global__ __launch_bounds__(256) void k_sn_count(SnParams p, uint32_t* __restri
             atomicAdd(gs, s_acc[0]);
             atomicAdd(gs + 1, s_acc[1] * 6u);
             atomicAdd(gs + 2, 1u);
-            emit_list[atomicAdd(emit_count, 1u)] = chunk;  // chunks with a mesh, for k_sn_emit (order irrelevant)
         }
     }
     }
@@ -256,7 +291,7 @@ __global__ __launch_bounds__(256) void k_sn_count(SnParams p, uint32_t* __restri
 // index count is zero contributing nothing (mesh.rs:321-323). offsets[2c], offsets[2c+1]; totals at
 // offsets[2n..2n+3); submesh rank at ranks[c].
 __global__ __launch_bounds__(256) void k_sn_scan(uint32_t n_chunks, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ group_sums,
-                                                 uint32_t* __restrict__ offsets, uint32_t* __restrict__ ranks) {
+                                                 uint32_t* __restrict__ offsets, uint32_t* __restrict__ ranks, uint32_t* __restrict__ emit_list) {
     // block b = chunks [256 b, 256 b + 256): base = totals of the groups before it, then an ordered block prefix
     __shared__ uint32_t s_w[3][4];
     __shared__ uint32_t s_base[3];
@@ -319,6 +354,9 @@ __global__ __launch_bounds__(256) void k_sn_scan(uint32_t n_chunks, const uint32
     if (c < n_chunks) {
         reinterpret_cast<uint2*>(offsets)[c] = make_uint2(b0 + wv + iv - sv, b1 + wi + ii - si);
         ranks[c] = b2 + ws + is - ss;
+        // the chunks with a mesh, in chunk order, for k_sn_emit (a list built here costs nothing; appending to it from the
+        // count pass meant thousands of returning atomics on one address)
+        if (on) emit_list[b2 + ws + is - ss] = c;
     }
     if (blockIdx.x == gridDim.x - 1 && tid == 0) {
         offsets[2 * n_chunks] = b0 + tv;
@@ -464,7 +502,7 @@ __global__ __launch_bounds__(256) void k_sn_emit(SnParams p, const uint32_t* __r
     __shared__ uint32_t s_wsum[4];
     const GridView& g = p.g;
     const uint32_t tid = threadIdx.x;
-    const uint32_t n_emit = emit_count[0];
+    const uint32_t n_emit = emit_count[0];  // = number of submeshes (k_sn_scan's third total)
     // bounded grid-stride walk over the chunks that have a mesh
     for (uint32_t li = blockIdx.x; li < n_emit; li += gridDim.x) {
     __syncthreads();
@@ -674,8 +712,7 @@ int ivx_launch_sn_count(ivx_grid* g) {
     const uint32_t groups = (g->n_chunks + 255u) / 256u;
     uint32_t* gs = g->group_sums + groups;  // the first `groups` words belong to the region resolve
     if (!g->scratch_preset) IVX_HIP_CHECK(hipMemsetAsync(gs, 0, sizeof(uint32_t) * (3 * groups + 1), g->ctx->stream));
-    hipLaunchKernelGGL(k_sn_count, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts, gs, gs + 3 * groups, g->sn_list,
-                       g->work_counts, g->active_list);
+    hipLaunchKernelGGL(k_sn_count, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts, gs, g->work_counts, g->active_list);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -684,18 +721,17 @@ int ivx_launch_sn_scan(ivx_grid* g) {
     // ranks are stored after the offsets/totals block
     hipLaunchKernelGGL(k_sn_scan, dim3((g->n_chunks + 255u) / 256u), dim3(256), 0, g->ctx->stream, g->n_chunks, g->chunk_counts,
                        g->group_sums + (g->n_chunks + 255u) / 256u,
-                       g->chunk_offsets, g->chunk_offsets + 2 * (size_t)g->n_chunks + 4);
+                       g->chunk_offsets, g->chunk_offsets + 2 * (size_t)g->n_chunks + 4, g->sn_list);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 
 int ivx_launch_sn_emit(ivx_grid* g) {
-    const uint32_t groups = (g->n_chunks + 255u) / 256u;
     const uint32_t blocks = g->n_chunks < 4096u ? g->n_chunks : 4096u;
     hipLaunchKernelGGL(k_sn_emit, dim3(blocks), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts, g->chunk_offsets,
                        g->chunk_offsets + 2 * (size_t)g->n_chunks + 4, g->positions, g->normals, g->indices,
                        reinterpret_cast<unsigned long long*>(g->index_materials), reinterpret_cast<uint4*>(g->vertex_materials), g->submeshes,
-                       g->group_sums + groups + 3 * groups, g->sn_list, (uint32_t)g->vcap, (uint32_t)g->icap, (uint32_t)g->scap);
+                       g->chunk_offsets + 2 * (size_t)g->n_chunks + 2, g->sn_list, (uint32_t)g->vcap, (uint32_t)g->icap, (uint32_t)g->scap);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
