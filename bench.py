@@ -36,15 +36,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 
 STAGE_KERNELS = {  # which kernels make up a timed stage (names as rocprofv3 reports them)
     "sdf_sample": ["k_sdf_prepass", "k_sdf_fill", "k_sdf_eval"],
-    "derive": ["k_derive"],
+    "derive": ["k_chunk_pre", "k_derive"],
     "occupied": ["k_occupied_reduce"],
     "ccl_local": ["k_ccl_local", "k_ccl_local_exact"],
-    "ccl_merge": ["k_ccl_merge"],
+    "ccl_merge": ["k_ccl_merge_columns", "k_ccl_merge_multi"],
     "ccl_resolve": ["k_ccl_flatten", "k_scan_groups", "k_ccl_assign"],
     "sn_count": ["k_sn_count"],
     "sn_scan": ["k_sn_scan"],
     "sn_emit": ["k_sn_emit"],
-    "inertia": ["k_inertia", "k_inertia_final"],
+    "inertia": ["k_inertia_dense", "k_inertia_sum", "k_inertia_final"],
 }
 
 
@@ -208,9 +208,10 @@ def main():
         obj.set_densities(dens)
 
         def step():
-            r = obj.step(capi.STAGE_ALL)
-            body_world.step(0.005)
-            return r
+            # the voxel stages and the object's rigid-body step are enqueued back to back; one wait covers both
+            obj.step_enqueue(capi.STAGE_ALL)
+            body_world.step_enqueue(0.005)
+            return obj.step_collect()
 
         workload = f"config-2 SDF asteroid x{args.scale} -> {gen.grid_shape()[0]}^3 grid = {cc[0] * 16}^3 stored voxels ({obj.n_chunks} chunks)"
         parallelism = "single GPU"
@@ -225,8 +226,8 @@ def main():
             pass
 
         def step():
+            body_world.step_enqueue(0.005)  # on the same stream, ahead of the slab's kernels; the protocol's one wait covers it
             r = comm.run(stepper)
-            body_world.step(0.005)
             return {"stage_ms": r.stage_ms, "mesh": {"n_vertices": r.mesh_counts[0], "n_indices": r.mesh_counts[1]},
                     "region_count": r.region_count}
 

@@ -128,7 +128,7 @@ EXPORTED_SYMBOLS = [
     "ivx_halo_bytes", "ivx_halo_pack", "ivx_halo_unpack", "ivx_halo_clear",
     "ivx_region_face_bytes", "ivx_region_face_labels", "ivx_region_face_pairs",
     "ivx_world_create", "ivx_world_destroy", "ivx_world_set_bodies", "ivx_world_get_bodies", "ivx_world_set_contacts",
-    "ivx_world_step", "ivx_world_prepare", "ivx_world_advance_momenta", "ivx_world_solve", "ivx_world_advance_configurations",
+    "ivx_world_step", "ivx_world_step_enqueue", "ivx_world_prepare", "ivx_world_advance_momenta", "ivx_world_solve", "ivx_world_advance_configurations",
     "ivx_world_contact_state",
 ]
 
@@ -217,6 +217,7 @@ def lib():
         "ivx_world_get_bodies": (i32, [vp, vp, vp]),
         "ivx_world_set_contacts": (i32, [vp, vp, sz, C.POINTER(sz)]),
         "ivx_world_step": (i32, [vp, f32, vp]),
+        "ivx_world_step_enqueue": (i32, [vp, f32]),
         "ivx_world_prepare": (i32, [vp]),
         "ivx_world_advance_momenta": (i32, [vp, f32]),
         "ivx_world_solve": (i32, [vp]),

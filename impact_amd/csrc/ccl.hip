@@ -171,7 +171,10 @@ __global__ __launch_bounds__(256) void k_ccl_local(GridView g, const uint8_t* __
     // (a root keeps itself as parent, every other node points somewhere else, so no flattening is needed to count)
     if (tid == 0) s_cnt = 0;
     __syncthreads();
-    if (n_roots) atomicAdd(&s_cnt, n_roots);
+    {
+        const uint32_t wr = ivx_wave_sum(n_roots);
+        if ((tid & 63u) == 0 && wr) atomicAdd(&s_cnt, wr);
+    }
     __syncthreads();
     const uint32_t rc = s_cnt;
     if (rc == 1u) {

@@ -192,32 +192,49 @@ __global__ __launch_bounds__(256) void k_derive(GridView g, int8_t* __restrict__
 
     // face populations: own faces and adjoining neighbour faces
     {
+        // All counts are reduced in registers (DPP rows of 16 lanes = one i each, ballots, scalar lane reads); one lane per
+        // wave then adds the wave's part to LDS.
+        const uint32_t wave = tid >> 6, lane = tid & 63u;
         const uint32_t pc = __popc(m);
-        if (ti == 0) atomicAdd(&cnt[0], pc);
-        if (ti == 15) atomicAdd(&cnt[1], pc);
-        if (tj == 0) atomicAdd(&cnt[2], pc);
-        if (tj == 15) atomicAdd(&cnt[3], pc);
-        const uint32_t z0 = __syncthreads_count((int)(m & 1u));
-        const uint32_t z1 = __syncthreads_count((int)((m >> 15) & 1u));
-        const uint32_t nz0 = __syncthreads_count((int)zlo);
-        const uint32_t nz1 = __syncthreads_count((int)zhi);
-        if (tid < 16) {
-            atomicAdd(&cnt[6], __popc(occ[0][tid + 1]));
-            atomicAdd(&cnt[7], __popc(occ[17][tid + 1]));
-            atomicAdd(&cnt[8], __popc(occ[tid + 1][0]));
-            atomicAdd(&cnt[9], __popc(occ[tid + 1][17]));
-        }
-        if (tid == 0) {
-            cnt[4] = z0;
-            cnt[5] = z1;
-            cnt[10] = nz0;
-            cnt[11] = nz1;
-        }
+        const uint32_t rs = ivx_row16_sum(pc);  // lane 15 of a row: voxels of the rows with this i
+        const uint32_t x_lo = (uint32_t)__builtin_amdgcn_readlane((int)rs, 15), x_hi = (uint32_t)__builtin_amdgcn_readlane((int)rs, 63);
+        // y faces: j = 0 / j = 15 are lanes 0,16,32,48 / 15,31,47,63 of every wave
+        const uint32_t y_lo = ((uint32_t)__builtin_amdgcn_readlane((int)pc, 0) + (uint32_t)__builtin_amdgcn_readlane((int)pc, 16)) +
+                              ((uint32_t)__builtin_amdgcn_readlane((int)pc, 32) + (uint32_t)__builtin_amdgcn_readlane((int)pc, 48));
+        const uint32_t y_hi = ((uint32_t)__builtin_amdgcn_readlane((int)pc, 15) + (uint32_t)__builtin_amdgcn_readlane((int)pc, 31)) +
+                              ((uint32_t)__builtin_amdgcn_readlane((int)pc, 47) + (uint32_t)__builtin_amdgcn_readlane((int)pc, 63));
+        const uint32_t z0 = (uint32_t)__popcll(__ballot((m & 1u) != 0)), z1 = (uint32_t)__popcll(__ballot(((m >> 15) & 1u) != 0));
+        const uint32_t nz0 = (uint32_t)__popcll(__ballot(zlo != 0)), nz1 = (uint32_t)__popcll(__ballot(zhi != 0));
         // does a non-empty voxel of the +x / +y / +z face meet a non-empty voxel of the neighbour chunk? (what joins the
-        // regions of two single-region chunks, k_ccl_merge_single)
-        const uint32_t tb = ((ti == 15 && (m & occ[17][tj + 1])) ? 1u : 0u) | ((tj == 15 && (m & occ[ti + 1][17])) ? 2u : 0u) |
-                            ((((m >> 15) & 1u) & zhi) ? 4u : 0u);
-        if (tb) atomicOr(&cnt[12], tb);
+        // regions of two single-region chunks, k_ccl_merge_columns)
+        const uint32_t tb = (__ballot(ti == 15 && (m & occ[17][tj + 1]) != 0) ? 1u : 0u) | (__ballot(tj == 15 && (m & occ[ti + 1][17]) != 0) ? 2u : 0u) |
+                            (__ballot((((m >> 15) & 1u) & zhi) != 0) ? 4u : 0u);
+        // neighbour faces: 16 halo rows each, summed by the first DPP row of wave 0
+        uint32_t nf[4] = {0, 0, 0, 0};
+        if (wave == 0) {
+            const uint32_t t = lane & 15u;
+            nf[0] = ivx_row16_sum(__popc(occ[0][t + 1]));
+            nf[1] = ivx_row16_sum(__popc(occ[17][t + 1]));
+            nf[2] = ivx_row16_sum(__popc(occ[t + 1][0]));
+            nf[3] = ivx_row16_sum(__popc(occ[t + 1][17]));
+        }
+        if (lane == 15u && wave == 0) {
+            cnt[0] = x_lo;  // i = 0 lives in wave 0, i = 15 in wave 3: single writers
+            cnt[6] = nf[0];
+            cnt[7] = nf[1];
+            cnt[8] = nf[2];
+            cnt[9] = nf[3];
+        }
+        if (lane == 15u && wave == 3) cnt[1] = x_hi;
+        if (lane == 0) {
+            atomicAdd(&cnt[2], y_lo);
+            atomicAdd(&cnt[3], y_hi);
+            atomicAdd(&cnt[4], z0);
+            atomicAdd(&cnt[5], z1);
+            atomicAdd(&cnt[10], nz0);
+            atomicAdd(&cnt[11], nz1);
+            if (tb) atomicOr(&cnt[12], tb);
+        }
     }
     __syncthreads();
 
@@ -236,23 +253,25 @@ __global__ __launch_bounds__(256) void k_derive(GridView g, int8_t* __restrict__
     const uint32_t zdn = (m << 1) | zlo, zup = (m >> 1) | (zhi << 15);
     // outward flag for EMPTY voxels on a Mixed face whose neighbour face is Full (object.rs:2439-2454)
     const uint32_t quirk = own_mixed & nbr_full;
-    uint32_t w[4] = {0, 0, 0, 0};
+    // Per direction, the 16-bit mask of voxels that carry its flag: non-empty voxels whose neighbour is non-empty, plus (the
+    // quirk) the empty voxels of a face. A 4-bit nibble is spread to one bit per byte with a multiply (bit i -> bit 8i:
+    // the partial products i, i+7, i+14, i+21 never collide), so a flags word costs 7 spreads instead of 4 x 7 tests.
+    const uint32_t e = ~m & 0xFFFFu;
+    uint32_t dm[6];
+    dm[0] = (m & xdn) | ((ti == 0 && (quirk & 1u)) ? e : 0u);
+    dm[1] = (m & ydn) | ((tj == 0 && (quirk & 4u)) ? e : 0u);
+    dm[2] = (m & zdn) | ((quirk & 16u) ? (e & 1u) : 0u);
+    dm[3] = (m & xup) | ((ti == 15 && (quirk & 2u)) ? e : 0u);
+    dm[4] = (m & yup) | ((tj == 15 && (quirk & 8u)) ? e : 0u);
+    dm[5] = (m & zup) | ((quirk & 32u) ? (e & 0x8000u) : 0u);
+    uint32_t w[4];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        uint32_t f;
-        if ((m >> k) & 1u) {
-            f = (((xdn >> k) & 1u) ? VF_X_DN : 0u) | (((xup >> k) & 1u) ? VF_X_UP : 0u) | (((ydn >> k) & 1u) ? VF_Y_DN : 0u) |
-                (((yup >> k) & 1u) ? VF_Y_UP : 0u) | (((zdn >> k) & 1u) ? VF_Z_DN : 0u) | (((zup >> k) & 1u) ? VF_Z_UP : 0u);
-        } else {
-            f = VF_EMPTY;
-            if (ti == 0 && (quirk & 1u)) f |= VF_X_DN;
-            if (ti == 15 && (quirk & 2u)) f |= VF_X_UP;
-            if (tj == 0 && (quirk & 4u)) f |= VF_Y_DN;
-            if (tj == 15 && (quirk & 8u)) f |= VF_Y_UP;
-            if (k == 0 && (quirk & 16u)) f |= VF_Z_DN;
-            if (k == 15 && (quirk & 32u)) f |= VF_Z_UP;
-        }
-        w[k >> 2] |= f << (8 * (k & 3));
+    for (int q = 0; q < 4; ++q) {
+        auto spread = [](uint32_t nib) { return __umul24(nib, 0x00204081u) & 0x01010101u; };
+        uint32_t v = spread((e >> (4 * q)) & 0xFu);  // VF_EMPTY = bit 0
+#pragma unroll
+        for (int d = 0; d < 6; ++d) v |= spread((dm[d] >> (4 * q)) & 0xFu) << (2 + d);  // VF_X_DN = 1 << 2, ... VF_Z_UP = 1 << 7
+        w[q] = v;
     }
     // (cnt[] and the record's gen_kind are the same for every thread, so is `kind`)
     const uint32_t gen = own_info.gen_kind;

@@ -162,6 +162,24 @@ __device__ __forceinline__ uint32_t ivx_uniform_type(const ivx_chunk_info& ci) {
 __device__ __forceinline__ uint32_t ivx_uniform_flags(uint32_t kind) { return kind == KIND_UNIFORM ? 0xFCu : (uint32_t)VF_EMPTY; }
 __device__ __forceinline__ uint32_t ivx_uniform_label(uint32_t kind) { return kind == KIND_UNIFORM ? 0u : 0xFFu; }
 
+// Sums on the VALU's DPP path. LDS atomics of many lanes on one address cost ~100 cycles per lane on this part (measured:
+// the 90 such lane-operations k_derive's first wave used to issue took 5 us, half the life of its workgroup), so counts
+// are reduced in registers and only one lane per wave touches LDS.
+//   ivx_row16_sum: inclusive prefix sum inside every aligned group of 16 lanes (a DPP row); lane 15 of a row = row total.
+//   ivx_wave_sum:  total of the 64 lanes, in every lane.
+__device__ __forceinline__ uint32_t ivx_row16_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);  // row_shr:1, lanes shifted in read 0
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);  // row_shr:8
+    return v;
+}
+__device__ __forceinline__ uint32_t ivx_wave_sum(uint32_t v) {
+    v = ivx_row16_sum(v);
+    return ((uint32_t)__builtin_amdgcn_readlane((int)v, 15) + (uint32_t)__builtin_amdgcn_readlane((int)v, 31)) +
+           ((uint32_t)__builtin_amdgcn_readlane((int)v, 47) + (uint32_t)__builtin_amdgcn_readlane((int)v, 63));
+}
+
 struct GridView {
     uint32_t cx, cy, cz;
     const int8_t* sdf;

@@ -442,8 +442,8 @@ int ivx_world_advance_configurations(ivx_world* w, float dt) {
     return ivx_launch_phys_post_solve(w, dt, 0, 1);
 }
 
-int ivx_world_step(ivx_world* w, float dt, ivx_physics_result* out) {
-    IVX_REQUIRE(w, IVX_ERR_INVALID, "ivx_world_step: null world");
+int ivx_world_step_enqueue(ivx_world* w, float dt) {
+    IVX_REQUIRE(w, IVX_ERR_INVALID, "ivx_world_step_enqueue: null world");
     hipStream_t s = w->ctx->stream;
     if (!w->ev_ready) {
         for (int i = 0; i < 5; ++i) IVX_HIP_CHECK(hipEventCreate(&w->ev[i]));
@@ -461,7 +461,13 @@ int ivx_world_step(ivx_world* w, float dt, ivx_physics_result* out) {
     if ((rc = ivx_launch_phys_post_solve(w, dt, 1, 1))) return rc;
     IVX_HIP_CHECK(hipEventRecord(w->ev[4], s));
     w->prepared_fresh = 0;
-    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    return IVX_OK;
+}
+
+int ivx_world_step(ivx_world* w, float dt, ivx_physics_result* out) {
+    int rc = ivx_world_step_enqueue(w, dt);
+    if (rc) return rc;
+    IVX_HIP_CHECK(hipStreamSynchronize(w->ctx->stream));
     if (out) {
         memset(out, 0, sizeof(*out));
         out->n_contacts = w->n_contacts;

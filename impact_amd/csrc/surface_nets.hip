@@ -271,8 +271,13 @@ __global__ __launch_bounds__(256) void k_sn_count(SnParams p, uint32_t* __restri
         nv += __popc(vb);
         nq += __popc(qx) + __popc(qy) + __popc(qz);
     }
-    atomicAdd(&s_acc[0], nv);
-    atomicAdd(&s_acc[1], nq);
+    {  // wave totals in registers, one LDS add per wave (same-address LDS atomics of many lanes are very slow)
+        const uint32_t wv = ivx_wave_sum(nv), wq = ivx_wave_sum(nq);
+        if ((tid & 63u) == 0) {
+            atomicAdd(&s_acc[0], wv);
+            atomicAdd(&s_acc[1], wq);
+        }
+    }
     __syncthreads();
     if (tid == 0) {
         counts[2 * chunk] = s_acc[0];

@@ -114,6 +114,11 @@ class PhysicsWorld:
         check(capi.lib().ivx_world_step(self.h, step_duration, ptr(out)))
         return out[0]
 
+    def step_enqueue(self, step_duration: float) -> None:
+        """the same step, only enqueued on the context's stream (`ivx_world_step_enqueue`); read the bodies back with
+        `get_bodies` after the next wait on the stream"""
+        check(capi.lib().ivx_world_step_enqueue(self.h, step_duration))
+
     def perform_physics_step(self, contacts, step_duration: float) -> np.ndarray:
         self.prepare_constraints(contacts)
         return self.step(step_duration)

@@ -324,6 +324,10 @@ int ivx_world_set_contacts(ivx_world*, const ivx_contact*, size_t n, size_t* n_p
  * advance momenta -> synchronise velocities, warm start, n_iterations sweeps, positional correction,
  * write back -> advance configurations. The stages are also exposed one by one. */
 int ivx_world_step(ivx_world*, float dt, ivx_physics_result* out);
+/* the same step, only enqueued on the context's stream (no wait, no result): lets the rigid-body step of a frame run
+ * behind the voxel step of the same frame with a single wait for both (ivx_voxel_step_collect / ivx_synchronize);
+ * the bodies are read back with ivx_world_get_bodies when they are needed */
+int ivx_world_step_enqueue(ivx_world*, float dt);
 int ivx_world_prepare(ivx_world*);
 int ivx_world_advance_momenta(ivx_world*, float dt);
 int ivx_world_solve(ivx_world*);
