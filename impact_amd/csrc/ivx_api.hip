@@ -227,7 +227,7 @@ int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32
     A(dev_alloc(&g->rcompid, (size_t)g->n_chunks * 256));
     A(dev_alloc(&g->rscalar, (size_t)64));
     A(dev_alloc(&g->ccl_scratch, (size_t)g->n_chunks * 2));
-    A(dev_alloc(&g->sn_list, (size_t)g->n_chunks));
+    A(dev_alloc(&g->sn_list, (size_t)g->n_chunks * 4));  // one uint4 record per meshed chunk
     A(dev_alloc(&g->group_sums, (size_t)((g->n_chunks + 255u) / 256u) * 4 + 4));
     A(dev_alloc(&g->dens_dev, (size_t)256));
     A(dev_alloc(&g->work_counts, (size_t)8));
@@ -319,6 +319,9 @@ void* ivx_grid_device_ptr(ivx_grid* g, int which) {
         case 3: return g->llabel;
         case 4: return g->info;
         case 5: return g->rparent;
+#ifdef IVX_WG_TRACE
+        case 6: return g->chunk_moments;
+#endif
         default: return nullptr;
     }
 }

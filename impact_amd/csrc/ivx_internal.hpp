@@ -80,7 +80,7 @@ struct ivx_grid {
     uint32_t* rcompid;   // [n_chunks*256] component id per node (after resolve)
     uint32_t* rscalar;   // small scalars: [0] region count, [1] error flags
     uint32_t* ccl_scratch;  // [2*n_chunks]: per-chunk root counts and exclusive offsets
-    uint32_t* sn_list;      // [n_chunks] chunks that emit a mesh this remesh (written by k_sn_count)
+    uint32_t* sn_list;      // [n_chunks] uint4 records of the chunks that emit a mesh this remesh, in submesh order (written by k_sn_scan)
     uint32_t* group_sums;   // [4 * ceil(n_chunks/256)]: first-level totals of the two-level scans
     uint32_t region_count;
     int regions_valid;
@@ -180,11 +180,28 @@ __device__ __forceinline__ uint32_t ivx_wave_sum(uint32_t v) {
            ((uint32_t)__builtin_amdgcn_readlane((int)v, 47) + (uint32_t)__builtin_amdgcn_readlane((int)v, 63));
 }
 
+// Workgroup timeline probes for the list-driven kernels: IVX_T(g, entry, slot) stores the 100 MHz wall clock of wave 0.
+// Compiled in only by `make TRACE=1`; this is how the cost of same-address LDS atomics and of the dependent load chains
+// in these kernels was found (rocprofv3 counters alone did not show it).
+#ifdef IVX_WG_TRACE
+#define IVX_T(g, entry, slot)                                                        \
+    do {                                                                             \
+        if (threadIdx.x == 0) (g).trace[(size_t)(entry) * 8 + (slot)] = wall_clock64(); \
+    } while (0)
+#else
+#define IVX_T(g, entry, slot) \
+    do {                      \
+    } while (0)
+#endif
+
 struct GridView {
     uint32_t cx, cy, cz;
     const int8_t* sdf;
     const uint8_t* type;
     const uint16_t* signs;
+#ifdef IVX_WG_TRACE
+    unsigned long long* trace;  // developer build (make TRACE=1): 8 timestamps per list entry, see tools/wg_trace.py
+#endif
     const int8_t* ghost_sdf[2];
     const uint8_t* ghost_type[2];
     const ivx_chunk_info* info;
@@ -219,6 +236,9 @@ static inline GridView ivx_view(const ivx_grid* g) {
     v.sdf = g->sdf;
     v.type = g->type;
     v.signs = g->chunk_signs;
+#ifdef IVX_WG_TRACE
+    v.trace = reinterpret_cast<unsigned long long*>(g->chunk_moments);  // (the inertia stage is not run while tracing)
+#endif
     v.info = g->info;
     for (int s = 0; s < 2; ++s) {
         v.ghost_sdf[s] = g->has_ghost[s] ? g->ghost_sdf[s] : nullptr;

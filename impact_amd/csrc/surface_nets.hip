@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void k_sn_count(SnParams p, uint32_t* __restri
 // index count is zero contributing nothing (mesh.rs:321-323). offsets[2c], offsets[2c+1]; totals at
 // offsets[2n..2n+3); submesh rank at ranks[c].
 __global__ __launch_bounds__(256) void k_sn_scan(uint32_t n_chunks, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ group_sums,
-                                                 uint32_t* __restrict__ offsets, uint32_t* __restrict__ ranks, uint32_t* __restrict__ emit_list) {
+                                                 uint32_t* __restrict__ offsets, uint32_t* __restrict__ ranks, uint4* __restrict__ emit_items) {
     // block b = chunks [256 b, 256 b + 256): base = totals of the groups before it, then an ordered block prefix
     __shared__ uint32_t s_w[3][4];
     __shared__ uint32_t s_base[3];
@@ -361,7 +361,9 @@ __global__ __launch_bounds__(256) void k_sn_scan(uint32_t n_chunks, const uint32
         ranks[c] = b2 + ws + is - ss;
         // the chunks with a mesh, in chunk order, for k_sn_emit (a list built here costs nothing; appending to it from the
         // count pass meant thousands of returning atomics on one address)
-        if (on) emit_list[b2 + ws + is - ss] = c;
+        // one record per meshed chunk: chunk, vertex offset, index offset, vertex count | quads << 16 — everything the emit
+        // pass needs to start loading its tile after a single fetch
+        if (on) emit_items[b2 + ws + is - ss] = make_uint4(c, b0 + wv + iv - sv, b1 + wi + ii - si, vi.x | ((vi.y / 6u) << 16));
     }
     if (blockIdx.x == gridDim.x - 1 && tid == 0) {
         offsets[2 * n_chunks] = b0 + tv;
@@ -493,11 +495,13 @@ __device__ __forceinline__ void index_materials(const VMat vm[3], unsigned long 
     }
 }
 
-__global__ __launch_bounds__(256) void k_sn_emit(SnParams p, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-                                                 const uint32_t* __restrict__ ranks, float* __restrict__ positions, float* __restrict__ normals,
+// (amdgpu_waves_per_eu(4): keeps the kernel at <= 128 VGPRs so that four workgroups fit a CU; the LDS footprint, ~38 KB, allows
+// four as well. The kernel is bound by the latency of a workgroup's serial phases, so residency is what buys throughput.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_sn_emit(SnParams p, float* __restrict__ positions, float* __restrict__ normals,
                                                  uint32_t* __restrict__ indices, unsigned long long* __restrict__ imats,
                                                  uint4* __restrict__ vmats, ivx_submesh* __restrict__ submeshes, const uint32_t* __restrict__ emit_count,
-                                                 const uint32_t* __restrict__ emit_list, uint32_t vcap, uint32_t icap, uint32_t scap) {
+                                                 const uint4* __restrict__ emit_items, uint32_t vcap, uint32_t icap, uint32_t scap) {
+    __shared__ uint16_t s_quad[768];  // quads of the current batch of 256 vertices: cube id | axis << 13
     __shared__ __attribute__((aligned(16))) uint8_t s_sd[TILE_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t s_ty[TILE_BYTES];
     __shared__ uint32_t s_neg[NROWS];
@@ -511,13 +515,13 @@ __global__ __launch_bounds__(256) void k_sn_emit(SnParams p, const uint32_t* __r
     // bounded grid-stride walk over the chunks that have a mesh
     for (uint32_t li = blockIdx.x; li < n_emit; li += gridDim.x) {
     __syncthreads();
-    const uint32_t chunk = emit_list[li];
-    const uint32_t icount = counts[2 * chunk + 1];
-    const uint32_t vcount = counts[2 * chunk];
-    const uint32_t voff = offsets[2 * chunk], ioff = offsets[2 * chunk + 1];
+    IVX_T(g, li, 0);
+    const uint4 item = emit_items[li];  // the list is in submesh order: entry li is submesh li
+    const uint32_t chunk = item.x, voff = item.y, ioff = item.z;
+    const uint32_t vcount = item.w & 0xFFFFu, icount = (item.w >> 16) * 6u;
     // the output buffers keep the capacity of earlier steps; a mesh that outgrew them is re-emitted after the host has
     // grown the buffers (ivx_voxel_step_collect) — nothing is ever written past the end
-    if ((size_t)voff + vcount > vcap || (size_t)ioff + icount > icap || ranks[chunk] >= scap) continue;
+    if ((size_t)voff + vcount > vcap || (size_t)ioff + icount > icap || li >= scap) continue;
     const ivx_chunk_info info = g.info[chunk];
     const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
     load_tile(g, ci, cj, ck, s_sd, s_ty, s_neg, tid);
@@ -540,9 +544,11 @@ __global__ __launch_bounds__(256) void k_sn_emit(SnParams p, const uint32_t* __r
         sm.vertex_offset = voff;
         sm.vertex_count = vcount;
         sm.reserved = 0;
-        submeshes[ranks[chunk]] = sm;
+        submeshes[li] = sm;
     }
+    IVX_T(g, li, 1);  // tile loaded (this wave's part)
     __syncthreads();
+    IVX_T(g, li, 2);
 
     // ---- vertex order: cubes in (i,j,k) scan order (surface_nets.rs:158-185) = cube rows in order, bits ascending.
     // Thread t owns cube rows 2t and 2t+1 so that thread order = row order for the ordered prefix.
@@ -574,6 +580,7 @@ __global__ __launch_bounds__(256) void k_sn_emit(SnParams p, const uint32_t* __r
         }
     }
     __syncthreads();
+    IVX_T(g, li, 3);  // vertex order built
 
     // mesh.rs:559-577
     const float chunk_extent = p.extent * 16.0f;
@@ -641,35 +648,42 @@ __global__ __launch_bounds__(256) void k_sn_emit(SnParams p, const uint32_t* __r
     }
     __threadfence_block();
     __syncthreads();
+    IVX_T(g, li, 4);  // vertices written
 
-    // ---- phase B: quads in surface-point order, X then Y then Z edge (surface_nets.rs:263-301) --
+    // ---- phase B: quads in surface-point order, X then Y then Z edge (surface_nets.rs:263-301). Per batch of 256 vertices
+    // the quads are first listed in that order (ordered prefix over the vertices' quad counts), then handled one THREAD per
+    // quad: a vertex emits up to three quads, and walking them inside its thread made every pass three quads long.
     uint32_t qbase = 0;
     for (uint32_t v0 = 0; v0 < vcount; v0 += 256) {
         const uint32_t v = v0 + tid;
         uint32_t qm = 0;
-        int cid = 0, i = 0, j = 0, k = 0;
+        uint32_t cid = 0;
         if (v < vcount) {
             cid = s_surf[v];
             const int cr = cid / 17;
-            k = cid - cr * 17;
-            i = cr / 17;
-            j = cr - i * 17;
+            const int k = cid - cr * 17, i = cr / 17, j = cr - i * 17;
             uint32_t vb, qx, qy, qz;
             cube_row_bits(s_neg, i, j, upper, vb, qx, qy, qz);
             qm = ((qx >> k) & 1u) | (((qy >> k) & 1u) << 1) | (((qz >> k) & 1u) << 2);
         }
         uint32_t total;
-        uint32_t qoff = qbase + block_prefix(__popc(qm), s_wsum, tid, total);
-        qbase += total;
+        uint32_t slot = block_prefix(__popc(qm), s_wsum, tid, total);  // (ends with a barrier: the previous batch's list is consumed)
 #pragma unroll
-        for (int axis = 0; axis < 3; ++axis) {
-            if (!((qm >> axis) & 1u)) continue;
+        for (uint32_t axis = 0; axis < 3; ++axis)
+            if ((qm >> axis) & 1u) s_quad[slot++] = (uint16_t)(cid | (axis << 13));
+        __syncthreads();
+        for (uint32_t q = tid; q < total; q += 256) {
+            const uint32_t qd = s_quad[q];
+            const int axis = (int)(qd >> 13);
+            const int qcid = (int)(qd & 0x1FFFu);
+            const int cr = qcid / 17;
+            const int k = qcid - cr * 17, i = cr / 17, j = cr - i * 17;
             // neighbouring cubes across the two other axes: (axis_b, axis_c) = (Y,Z), (Z,X), (X,Y)
             const int ab = axis == 0 ? 17 : (axis == 1 ? 1 : 289);
             const int ac = axis == 0 ? 1 : (axis == 1 ? 289 : 17);
             const bool n1 = (int8_t)s_sd[tix(i, j, k)] < 0;
             const bool negative_face = !n1;  // (false,true) => negative face (surface_nets.rs:348-352)
-            const uint32_t v1 = s_map[cid], v2 = s_map[cid - ab], v3 = s_map[cid - ac], v4 = s_map[cid - ab - ac];
+            const uint32_t v1 = s_map[qcid], v2 = s_map[qcid - ab], v3 = s_map[qcid - ac], v4 = s_map[qcid - ab - ac];
             const float* P = positions + 3 * (size_t)voff;
             const V3 q1 = mk(P[3 * v1], P[3 * v1 + 1], P[3 * v1 + 2]), q2 = mk(P[3 * v2], P[3 * v2 + 1], P[3 * v2 + 2]);
             const V3 q3 = mk(P[3 * v3], P[3 * v3 + 1], P[3 * v3 + 2]), q4 = mk(P[3 * v4], P[3 * v4 + 1], P[3 * v4 + 2]);
@@ -679,7 +693,7 @@ __global__ __launch_bounds__(256) void k_sn_emit(SnParams p, const uint32_t* __r
                 else { quad[0] = v1; quad[1] = v2; quad[2] = v4; quad[3] = v1; quad[4] = v4; quad[5] = v3; }
             } else if (negative_face) { quad[0] = v2; quad[1] = v3; quad[2] = v4; quad[3] = v2; quad[4] = v1; quad[5] = v3; }
             else { quad[0] = v2; quad[1] = v4; quad[2] = v3; quad[3] = v2; quad[4] = v3; quad[5] = v1; }
-            const size_t io = (size_t)ioff + (size_t)qoff * 6;
+            const size_t io = (size_t)ioff + (size_t)(qbase + q) * 6;
 #pragma unroll
             for (int t = 0; t < 6; ++t) indices[io + t] = voff + quad[t];
 #pragma unroll
@@ -687,7 +701,7 @@ __global__ __launch_bounds__(256) void k_sn_emit(SnParams p, const uint32_t* __r
                 VMat vm[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    uint4 raw = vmats[(size_t)voff + quad[3 * tri + c]];
+                    const uint4 raw = vmats[(size_t)voff + quad[3 * tri + c]];
                     vm[c].ind = (unsigned long long)raw.x | ((unsigned long long)raw.y << 32);
                     vm[c].wgt = (unsigned long long)raw.z | ((unsigned long long)raw.w << 32);
                 }
@@ -697,9 +711,10 @@ __global__ __launch_bounds__(256) void k_sn_emit(SnParams p, const uint32_t* __r
                 imats[io + 3 * tri + 1] = im[1];
                 imats[io + 3 * tri + 2] = im[2];
             }
-            qoff += 1;
         }
+        qbase += total;
     }
+    IVX_T(g, li, 5);  // quads written
     }
 }
 
@@ -726,17 +741,17 @@ int ivx_launch_sn_scan(ivx_grid* g) {
     // ranks are stored after the offsets/totals block
     hipLaunchKernelGGL(k_sn_scan, dim3((g->n_chunks + 255u) / 256u), dim3(256), 0, g->ctx->stream, g->n_chunks, g->chunk_counts,
                        g->group_sums + (g->n_chunks + 255u) / 256u,
-                       g->chunk_offsets, g->chunk_offsets + 2 * (size_t)g->n_chunks + 4, g->sn_list);
+                       g->chunk_offsets, g->chunk_offsets + 2 * (size_t)g->n_chunks + 4, reinterpret_cast<uint4*>(g->sn_list));
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 
 int ivx_launch_sn_emit(ivx_grid* g) {
     const uint32_t blocks = g->n_chunks < 4096u ? g->n_chunks : 4096u;
-    hipLaunchKernelGGL(k_sn_emit, dim3(blocks), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts, g->chunk_offsets,
-                       g->chunk_offsets + 2 * (size_t)g->n_chunks + 4, g->positions, g->normals, g->indices,
+    hipLaunchKernelGGL(k_sn_emit, dim3(blocks), dim3(256), 0, g->ctx->stream, make_params(g), g->positions, g->normals, g->indices,
                        reinterpret_cast<unsigned long long*>(g->index_materials), reinterpret_cast<uint4*>(g->vertex_materials), g->submeshes,
-                       g->chunk_offsets + 2 * (size_t)g->n_chunks + 2, g->sn_list, (uint32_t)g->vcap, (uint32_t)g->icap, (uint32_t)g->scap);
+                       g->chunk_offsets + 2 * (size_t)g->n_chunks + 2, reinterpret_cast<const uint4*>(g->sn_list), (uint32_t)g->vcap, (uint32_t)g->icap,
+                       (uint32_t)g->scap);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
