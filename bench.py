@@ -36,33 +36,36 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 
 STAGE_KERNELS = {  # which kernels make up a timed stage (names as rocprofv3 reports them)
     "sdf_sample": ["k_sdf_prepass", "k_sdf_fill", "k_sdf_eval"],
-    "derive": ["k_chunk_pre", "k_derive"],
+    "derive": ["k_chunk_pre", "k_derive"],  # k_derive also labels the chunk-local regions and leaves the chunk moments (fused sweep)
     "occupied": ["k_occupied_reduce"],
-    "ccl_local": ["k_ccl_local", "k_ccl_local_exact"],
+    "ccl_local": ["k_ccl_local_exact"],  # what is left of the stage after the fusion
     "ccl_merge": ["k_ccl_merge_columns", "k_ccl_merge_multi"],
     "ccl_resolve": ["k_ccl_flatten", "k_scan_groups", "k_ccl_assign"],
     "sn_count": ["k_sn_count"],
     "sn_scan": ["k_sn_scan"],
     "sn_emit": ["k_sn_emit"],
-    "inertia": ["k_inertia_dense", "k_inertia_sum", "k_inertia_final"],
+    "inertia": ["k_inertia_sum", "k_inertia_final"],
 }
 
 
 def stage_bytes(n_voxels, n_chunks, exposed_chunks, n_vertices, n_indices):
-    """Algorithmic HBM bytes per launch of each stage: SURVEY.md §8(d)'s per-voxel figures x the voxels of the launch for the
-    plane sweeps; the mesher is charged only for the padded tiles of the chunks it meshes (it skips the others by their
-    8-byte chunk record) plus its output."""
+    """Algorithmic HBM bytes per launch of each timed stage: SURVEY.md §8(d)'s per-voxel figures x the stored voxels of the
+    launch for the plane sweeps (the figures are per voxel of the GRID, whether or not a chunk's planes are materialised: see
+    DESIGN.md §4 on compact planes — measured traffic is therefore far below these numbers for a solid body); the mesher is
+    charged for the padded tiles of the chunks it meshes plus its output. The derive stage runs the chunk-local region
+    labelling and the chunk moments in the same sweep (R sdf + type, W flags + label = 4 B/voxel, SURVEY's fused-sweep
+    accounting), so the `ccl_local` and `inertia` stages are left with their list / reduction kernels only."""
     return {
         "sdf_sample": 2.0 * n_voxels,                        # W sdf + type
-        "derive": 2.0 * n_voxels,                            # R sdf, W flags
+        "derive": 4.0 * n_voxels,                            # R sdf + type, W flags + label (fused sweep)
         "occupied": 4.0 * n_chunks,                          # R one packed box per chunk
-        "ccl_local": 2.0 * n_voxels,                         # R flags, W label
-        "ccl_merge": 3 * 2 * 256.0 * n_chunks,               # label face pairs across +x,+y,+z
+        "ccl_local": 0.0,                                    # fused into derive; k_ccl_local_exact walks a (usually empty) list
+        "ccl_merge": 9.0 * 3 * n_chunks,                     # chunk records + touch bytes of a chunk column and its two neighbours
         "ccl_resolve": 16.0 * n_chunks,                      # (chunk, region) table entries in use, a few per chunk
-        "sn_count": 1.0 * 5832 * exposed_chunks,             # 18^3 padded sdf per exposed chunk
-        "sn_scan": 20.0 * n_chunks,                          # counts in, offsets/ranks out
+        "sn_count": 1.0 * 5832 / 8 * exposed_chunks,         # 18^3 sign bits per exposed chunk
+        "sn_scan": 36.0 * n_chunks,                          # counts in, offsets/ranks/records out
         "sn_emit": 2.0 * 5832 * exposed_chunks + 40.0 * n_vertices + 12.0 * n_indices,  # tile + (pos,nrm,vmat) + (idx u32, imat 8B)
-        "inertia": 2.0 * n_voxels,                           # R flags + type
+        "inertia": 88.0 * n_chunks,                          # chunk records + per-chunk moment slots
     }
 
 
@@ -303,7 +306,7 @@ def main():
             "remesh_tris_per_s": tris_rank / (remesh_ms * 1e-3) if remesh_ms > 0 else None,
             "remesh_ms": remesh_ms,
             "stage_ms": {capi.STAGE_NAMES[i]: round(float(stage_ms[i]), 4) for i in range(capi.N_TIMED_STAGES)},
-            "stage_gbs": {capi.STAGE_NAMES[i]: round(sb[capi.STAGE_NAMES[i]] / (stage_ms[i] * 1e-3) / 1e9, 1) if stage_ms[i] > 0 else None
+            "stage_gbs": {capi.STAGE_NAMES[i]: round(sb[capi.STAGE_NAMES[i]] / (stage_ms[i] * 1e-3) / 1e9, 1) if stage_ms[i] > 0 and sb[capi.STAGE_NAMES[i]] > 0 else None
                           for i in range(capi.N_TIMED_STAGES)},
             "roofline": {"bound": "hbm", "kernel": "+".join(STAGE_KERNELS[name]), "stage": name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes": sb[name],

@@ -17,32 +17,9 @@
 // atomicMin unions over the small (chunk,region) table; voxels never carry a 32-bit label in HBM.
 // Traffic: level 1 reads 1 B/voxel (flags) and writes 1 B/voxel (label); level 2 reads only the six
 // face planes of labels per chunk.
-#include "ivx_internal.hpp"
+#include "chunk_passes.hpp"
 
 namespace {
-
-#define NODE_NONE 0xFFFFFFFFu
-
-__device__ __forceinline__ uint32_t lds_find(volatile uint32_t* par, uint32_t x) {
-    uint32_t p;
-    while ((p = par[x]) != x) x = p;
-    return x;
-}
-__device__ __forceinline__ void lds_union(uint32_t* par, uint32_t a, uint32_t b) {
-    for (int guard = 0; guard < 8192; ++guard) {
-        a = lds_find(par, a);
-        b = lds_find(par, b);
-        if (a == b) return;
-        if (a < b) {
-            uint32_t t = a;
-            a = b;
-            b = t;
-        }
-        uint32_t old = atomicMin(&par[a], b);  // attach the larger root under the smaller
-        if (old == a) return;
-        a = old;
-    }
-}
 
 __device__ __forceinline__ uint32_t flags_mask(uint4 f) {
     uint32_t w[4] = {f.x, f.y, f.z, f.w};
@@ -70,129 +47,26 @@ __device__ __forceinline__ uint32_t prefix_ordered(uint32_t val, uint32_t* s_wsu
     return wbase + incl - val;
 }
 
-// Level 1, parallel part: decides for every chunk whether it holds 0, 1 or several regions. One region (the
-// overwhelmingly common case) needs no numbering: label 0 on every non-empty voxel. Chunks with several regions
-// go on a list for k_ccl_local_exact, which owns their labels, counts and region table.
-// Union-find over the RUNS of non-empty voxels along k (a thread owns the <= 8 runs of its 16-voxel row); the node of a
-// run is the voxel index of its first voxel, links go through LDS atomicMin (root = smallest index).
+// Level 1 as a kernel of its own (the step path runs it fused into k_derive, see chunk_passes.hpp): walks the active list;
+// the non-empty masks come from the flags plane.
 __global__ __launch_bounds__(256) void k_ccl_local(GridView g, const uint8_t* __restrict__ flags, uint8_t* __restrict__ labels,
                                                    ivx_chunk_info* __restrict__ info, uint32_t* __restrict__ rparent,
                                                    uint32_t* __restrict__ rscalar, uint32_t* __restrict__ multi_list,
-                                                   const uint8_t* __restrict__ chunk_class, const uint32_t* __restrict__ work_counts,
-                                                   const uint32_t* __restrict__ active_list) {
-    __shared__ uint32_t s_par[IVX_CHUNK_VOXELS];
-    __shared__ uint32_t s_mask[256];
-    __shared__ uint32_t s_cnt;
+                                                   const uint32_t* __restrict__ work_counts, const uint32_t* __restrict__ active_list) {
+    __shared__ CclShared sh;
     const uint32_t tid = threadIdx.x;
-    const uint32_t n_chunks = g.cx * g.cy * g.cz;
-    const int ti = tid >> 4, tj = tid & 15;
-    // prologue, one thread per chunk of the grid: the chunks k_chunk_pre settled (Void: no region; Uniform: one region that is
-    // its own node until the merge pass links it) have no voxels to look at
-    {
-        const uint32_t c = blockIdx.x * 256u + tid;
-        if (c < n_chunks && chunk_class[c] && g.info[c].kind == KIND_UNIFORM) rparent[(size_t)c * 256] = c * 256u;
-    }
     const uint32_t n_active = work_counts[0];
     for (uint32_t li = ivx_xcd_remap(blockIdx.x, gridDim.x); li < n_active; li += gridDim.x) {
-    __syncthreads();  // the previous chunk's LDS use is over
-    const uint32_t entry = active_list[li];  // chunk + kinds (written by k_derive): no trip to the chunk record
-    const uint32_t chunk = IVX_LIST_CHUNK(entry);
-    const size_t base = (size_t)chunk * IVX_CHUNK_VOXELS + (size_t)tid * 16;
-    const uint32_t kind = IVX_LIST_KIND(entry);
-    uint32_t* rp = rparent + (size_t)chunk * 256;
-
-    // a Void chunk has no voxels and a chunk generated Uniform is one solid region whether or not it was demoted
-    // since: neither needs its flags
-    const bool known = kind == KIND_VOID || IVX_LIST_GEN(entry) == KIND_UNIFORM;
-    const uint32_t m = known ? 0u : flags_mask(*reinterpret_cast<const uint4*>(flags + base));
-    const int all_full = known ? (kind != KIND_VOID) : __syncthreads_and(m == 0xFFFFu);
-    const int any = known ? (kind != KIND_VOID) : __syncthreads_or(m != 0);
-    if (!any || all_full) {
-        // no voxels, or one solid region touching every face
-        const uint32_t lab = any ? 0u : 0xFFFFFFFFu;
-        if (kind == KIND_NONUNIFORM) *reinterpret_cast<uint4*>(labels + base) = make_uint4(lab, lab, lab, lab);  // else: compact planes
-        // only slots below region_count are ever read (flatten / assign / find walk valid nodes only)
+        __syncthreads();  // the previous chunk's LDS use is over
+        const uint32_t entry = active_list[li];  // chunk + kinds (written by k_derive): no trip to the chunk record
+        const uint32_t chunk = IVX_LIST_CHUNK(entry);
+        const uint32_t m = flags_mask(*reinterpret_cast<const uint4*>(flags + (size_t)chunk * IVX_CHUNK_VOXELS + (size_t)tid * 16));
+        uint32_t rc, brc;
+        ccl_local_chunk(sh, tid, chunk, IVX_LIST_KIND(entry), IVX_LIST_GEN(entry), m, labels, rparent, rscalar, multi_list, rc, brc);
         if (tid == 0) {
-            rp[0] = any ? chunk * 256u : NODE_NONE;
-            info[chunk].region_count = any ? 1 : 0;
-            info[chunk].boundary_region_count = any ? 1 : 0;
+            info[chunk].region_count = (uint8_t)rc;
+            info[chunk].boundary_region_count = (uint8_t)brc;
         }
-        continue;
-    }
-
-    // 1. one node per run, keyed by the voxel index of its first voxel
-    s_mask[tid] = m;
-    const uint32_t starts = m & ~(m << 1);
-    {
-        uint32_t r = starts;
-        while (r) {
-            const int k = __ffs(r) - 1;
-            r &= r - 1;
-            s_par[tid * 16 + k] = tid * 16 + k;
-        }
-    }
-    __syncthreads();
-    // 2. join runs across +x and +y: one union per run of the overlap between the two rows
-    {
-        const uint32_t mx = ti < 15 ? s_mask[tid + 16] : 0u;
-        const uint32_t my = tj < 15 ? s_mask[tid + 1] : 0u;
-        const uint32_t sx = mx & ~(mx << 1), sy = my & ~(my << 1);
-        uint32_t bx = m & mx, by = m & my;
-        bx &= ~(bx << 1);
-        by &= ~(by << 1);
-        while (bx) {
-            const int k = __ffs(bx) - 1;
-            bx &= bx - 1;
-            const uint32_t lowk = (2u << k) - 1u;  // bits 0..k
-            const uint32_t a = tid * 16 + (31 - __clz(starts & lowk)), b = (tid + 16) * 16 + (31 - __clz(sx & lowk));
-            lds_union(s_par, a, b);
-        }
-        while (by) {
-            const int k = __ffs(by) - 1;
-            by &= by - 1;
-            const uint32_t lowk = (2u << k) - 1u;
-            const uint32_t a = tid * 16 + (31 - __clz(starts & lowk)), b = (tid + 1) * 16 + (31 - __clz(sy & lowk));
-            lds_union(s_par, a, b);
-        }
-    }
-    __syncthreads();
-    // 3. count the roots; does any voxel lie on the chunk boundary?
-    uint32_t n_roots = 0;
-    {
-        uint32_t r = starts;
-        while (r) {
-            const int k = __ffs(r) - 1;
-            r &= r - 1;
-            n_roots += s_par[tid * 16 + k] == tid * 16 + (uint32_t)k;
-        }
-    }
-    const bool edge_row = ti == 0 || ti == 15 || tj == 0 || tj == 15;
-    const int touches = __syncthreads_or(edge_row ? (m != 0) : ((m & 0x8001u) != 0));
-    // (a root keeps itself as parent, every other node points somewhere else, so no flattening is needed to count)
-    if (tid == 0) s_cnt = 0;
-    __syncthreads();
-    {
-        const uint32_t wr = ivx_wave_sum(n_roots);
-        if ((tid & 63u) == 0 && wr) atomicAdd(&s_cnt, wr);
-    }
-    __syncthreads();
-    const uint32_t rc = s_cnt;
-    if (rc == 1u) {
-        uint32_t w[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-            if (!((m >> k) & 1u)) w[k >> 2] |= 0xFFu << (8 * (k & 3));
-        *reinterpret_cast<uint4*>(labels + base) = make_uint4(w[0], w[1], w[2], w[3]);
-        if (tid == 0) {
-            rp[0] = chunk * 256u;
-            info[chunk].region_count = 1;
-            info[chunk].boundary_region_count = touches ? 1 : 0;
-        }
-    } else if (tid == 0) {
-        // several regions: the reference's numbering is reproduced by k_ccl_local_exact
-        info[chunk].region_count = (uint8_t)(rc < 254u ? rc : 254u);
-        multi_list[atomicAdd(&rscalar[2], 1u)] = chunk;
-    }
     }
 }
 
@@ -733,13 +607,14 @@ __global__ __launch_bounds__(256) void k_region_stats(GridView g, uint32_t x_off
 
 }  // namespace
 
-int ivx_launch_ccl_local(ivx_grid* g) {
+int ivx_launch_ccl_local(ivx_grid* g, int fused) {
     GridView v = ivx_view(g);
-    if (!g->scratch_preset) IVX_HIP_CHECK(hipMemsetAsync(g->rscalar, 0, 16 * sizeof(uint32_t), g->ctx->stream));
+    if (!g->scratch_preset && !fused) IVX_HIP_CHECK(hipMemsetAsync(g->rscalar, 0, 16 * sizeof(uint32_t), g->ctx->stream));
     uint32_t* multi_list = g->ccl_scratch;  // reused by the resolve pass afterwards
     g->planes_compact = 1;
-    hipLaunchKernelGGL(k_ccl_local, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->flags, g->llabel, g->info, g->rparent, g->rscalar, multi_list,
-                       g->chunk_class, g->work_counts, g->active_list);
+    if (!fused)  // else k_derive labelled the chunks in the same sweep
+        hipLaunchKernelGGL(k_ccl_local, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->flags, g->llabel, g->info, g->rparent, g->rscalar,
+                           multi_list, g->work_counts, g->active_list);
     const uint32_t exact_blocks = g->n_chunks < 2048u ? g->n_chunks : 2048u;
     hipLaunchKernelGGL(k_ccl_local_exact, dim3(exact_blocks), dim3(64), 0, g->ctx->stream, v, g->flags, g->llabel, g->info, g->rparent, g->rscalar,
                        multi_list);

@@ -18,7 +18,7 @@
 //
 // Traffic: reads 1 B/voxel (sdf sign) + six neighbour faces, writes 1 B/voxel (flags). Emptiness of the
 // 16 voxels of a row is a 16-bit mask; the 18x18 halo of masks sits in LDS.
-#include "ivx_internal.hpp"
+#include "chunk_passes.hpp"
 
 namespace {
 
@@ -54,7 +54,7 @@ __device__ __forceinline__ uint32_t nbr_row_mask(const GridView& g, const ivx_ch
 // their per-step state is the record, the occupied sub-box, one region and empty mesh counts.
 __global__ __launch_bounds__(256) void k_chunk_pre(GridView g, ivx_chunk_info* __restrict__ info, uint32_t* __restrict__ bbox,
                                                    uint32_t* __restrict__ mesh_counts, uint8_t* __restrict__ chunk_class, uint8_t* __restrict__ touch,
-                                                   uint32_t* __restrict__ work_counts, uint32_t* __restrict__ active_list) {
+                                                   uint32_t* __restrict__ rparent, uint32_t* __restrict__ work_counts, uint32_t* __restrict__ active_list) {
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_base;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void k_chunk_pre(GridView g, ivx_chunk_info* _
             mesh_counts[2 * chunk] = 0;
             mesh_counts[2 * chunk + 1] = 0;
             touch[chunk] = solid ? 7 : 0;  // a settled solid chunk touches its three upper neighbours (all solid)
+            if (solid) rparent[(size_t)chunk * 256] = chunk * 256u;  // its one region: its own node until the merge pass links it
         }
         chunk_class[chunk] = settled ? 1 : 0;
     }
@@ -108,23 +109,45 @@ __global__ __launch_bounds__(256) void k_chunk_pre(GridView g, ivx_chunk_info* _
     }
 }
 
-__global__ __launch_bounds__(256) void k_derive(GridView g, int8_t* __restrict__ sdf_rw, uint8_t* __restrict__ type_rw, uint8_t* __restrict__ flags_out,
+// What the later per-chunk passes need is in this kernel's registers already, so it can run them in the same sweep (`parts`):
+// the chunk-local region labelling needs only the chunk's own non-empty masks, and so do its moments (plus the type row).
+struct DeriveFused {
+    uint32_t parts;             // IVX_PART_*
+    uint32_t x_off;             // slab offset in chunks (moments are about the global origin)
+    uint8_t* labels;            // regions
+    uint32_t* rparent;
+    uint32_t* rscalar;
+    uint32_t* multi_list;
+    const float* dens;          // moments
+    double* chunk_moments;
+};
+
+// (amdgpu_waves_per_eu(7): seven workgroups per CU is what the 20 KB of LDS allow; the workgroups are latency-bound, so
+// residency is throughput, and the register budget is set to match.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_derive(GridView g, int8_t* __restrict__ sdf_rw, uint8_t* __restrict__ type_rw, uint8_t* __restrict__ flags_out,
                                                 ivx_chunk_info* __restrict__ info, uint32_t* __restrict__ bbox, uint8_t* __restrict__ touch,
                                                 uint16_t* __restrict__ signs,
-                                                const uint32_t* __restrict__ work_counts, uint32_t* __restrict__ active_list) {
+                                                const uint32_t* __restrict__ work_counts, uint32_t* __restrict__ active_list, DeriveFused fz) {
     __shared__ uint32_t occ[18][18];  // non-empty masks of rows (i+1, j+1); halo rows from neighbour chunks
     __shared__ uint32_t cnt[13];      // own face non-empty counts [0..6), neighbour face non-empty counts [6..12), [12] touch bits
+    __shared__ CclShared s_ccl;
+    __shared__ float s_dens[256];
+    __shared__ double s_red[4][10];
     const uint32_t tid = threadIdx.x;
+    if (fz.parts & IVX_PART_MOMENTS) s_dens[tid] = fz.dens[tid];  // (the first barrier of the loop publishes it)
     const int ti = tid >> 4, tj = tid & 15;
     const uint32_t n_active = work_counts[0];
     // bounded walk over the active list (virtual block ids give each XCD a contiguous stretch of it)
     for (uint32_t li = ivx_xcd_remap(blockIdx.x, gridDim.x); li < n_active; li += gridDim.x) {
     __syncthreads();  // the previous chunk's LDS use is over
+    IVX_T(g, li, 0);
     const uint32_t chunk = IVX_LIST_CHUNK(active_list[li]);
     const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
     const size_t base = (size_t)chunk * IVX_CHUNK_VOXELS;
     const ivx_chunk_info own_info = info[chunk];
     const uint32_t own_row_mask = row_mask(*reinterpret_cast<const uint4*>(g.sdf + base + (size_t)tid * 16));  // used only if the chunk has planes
+    uint4 own_types = make_uint4(0, 0, 0, 0);
+    if (fz.parts & IVX_PART_MOMENTS) own_types = *reinterpret_cast<const uint4*>(g.type + base + (size_t)tid * 16);  // likewise
     if (tid < 13) cnt[tid] = 0;
     const bool own_uniform = own_info.gen_kind == KIND_UNIFORM;
     const uint32_t m = own_uniform ? 0xFFFFu : own_row_mask;
@@ -190,6 +213,7 @@ __global__ __launch_bounds__(256) void k_derive(GridView g, int8_t* __restrict__
         }
     }
 
+    IVX_T(g, li, 1);  // rows loaded, sub-box done
     // face populations: own faces and adjoining neighbour faces
     {
         // All counts are reduced in registers (DPP rows of 16 lanes = one i each, ballots, scalar lane reads); one lane per
@@ -238,6 +262,7 @@ __global__ __launch_bounds__(256) void k_derive(GridView g, int8_t* __restrict__
     }
     __syncthreads();
 
+    IVX_T(g, li, 2);  // face counts done
     uint32_t own_fd[6], nbr_full = 0, own_mixed = 0;
 #pragma unroll
     for (int f = 0; f < 6; ++f) {
@@ -289,6 +314,19 @@ __global__ __launch_bounds__(256) void k_derive(GridView g, int8_t* __restrict__
         }
     }
 
+    IVX_T(g, li, 3);  // flags written
+    // ---- fused passes over the same chunk (uniform branches: `parts` and `kind` are the same for the whole workgroup)
+    uint32_t rc = own_info.region_count, brc = own_info.boundary_region_count;
+    if (fz.parts & IVX_PART_REGIONS) ccl_local_chunk(s_ccl, tid, chunk, kind, gen, m, fz.labels, fz.rparent, fz.rscalar, fz.multi_list, rc, brc);
+    IVX_T(g, li, 4);  // regions labelled
+    if ((fz.parts & IVX_PART_MOMENTS) && kind == KIND_NONUNIFORM) {
+        // (a chunk demoted in this pass has no type plane yet: its voxels all have the record's type)
+        const uint32_t ut = utype * 0x01010101u;
+        const bool fresh = own_uniform && own_info.kind != KIND_NONUNIFORM;
+        const uint32_t tw[4] = {fresh ? ut : own_types.x, fresh ? ut : own_types.y, fresh ? ut : own_types.z, fresh ? ut : own_types.w};
+        chunk_moments_rows(tid, m, tw, s_dens, s_red, (ci + (int)fz.x_off) * 16 + ti, cj * 16 + tj, ck * 16, fz.chunk_moments + (size_t)chunk * 10);
+    }
+
     if (tid == 0) {
         touch[chunk] = (uint8_t)cnt[12];
         {  // the list entry carries what the later stages need from the record
@@ -297,6 +335,8 @@ __global__ __launch_bounds__(256) void k_derive(GridView g, int8_t* __restrict__
         }
         ivx_chunk_info ci_ = own_info;
         ci_.kind = (uint8_t)kind;
+        ci_.region_count = (uint8_t)rc;
+        ci_.boundary_region_count = (uint8_t)brc;
         if (kind == KIND_NONUNIFORM) {
             // bit layout: X_DN,Y_DN,Z_DN,X_UP,Y_UP,Z_UP <- faces f = 2*dim+side
             uint32_t ob = 0;
@@ -320,6 +360,7 @@ __global__ __launch_bounds__(256) void k_derive(GridView g, int8_t* __restrict__
         }
         info[chunk] = ci_;
     }
+    IVX_T(g, li, 5);
     }
 }
 
@@ -438,13 +479,23 @@ int ivx_launch_step_preset(ivx_grid* g, uint32_t stages) {
     return IVX_OK;
 }
 
-int ivx_launch_derive(ivx_grid* g) {
+int ivx_launch_derive(ivx_grid* g, uint32_t parts) {
     GridView v = ivx_view(g);
+    DeriveFused fz;
+    fz.parts = parts;
+    fz.x_off = g->x_off;
+    fz.labels = g->llabel;
+    fz.rparent = g->rparent;
+    fz.rscalar = g->rscalar;
+    fz.multi_list = g->ccl_scratch;  // as ivx_launch_ccl_local
+    fz.dens = g->dens_dev;
+    fz.chunk_moments = g->chunk_moments;
+    if ((parts & IVX_PART_REGIONS) && !g->scratch_preset) IVX_HIP_CHECK(hipMemsetAsync(g->rscalar, 0, 16 * sizeof(uint32_t), g->ctx->stream));
     if (!g->scratch_preset) IVX_HIP_CHECK(hipMemsetAsync(g->work_counts, 0, sizeof(uint32_t), g->ctx->stream));
     hipLaunchKernelGGL(k_chunk_pre, dim3((g->n_chunks + 255u) / 256u), dim3(256), 0, g->ctx->stream, v, g->info, g->chunk_bbox, g->chunk_counts,
-                       g->chunk_class, g->chunk_touch, g->work_counts, g->active_list);
+                       g->chunk_class, g->chunk_touch, g->rparent, g->work_counts, g->active_list);
     hipLaunchKernelGGL(k_derive, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->sdf, g->type, g->flags, g->info, g->chunk_bbox,
-                       g->chunk_touch, g->chunk_signs, g->work_counts, g->active_list);
+                       g->chunk_touch, g->chunk_signs, g->work_counts, g->active_list, fz);
     g->planes_compact = 1;
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;

@@ -12,7 +12,7 @@
 // Sweep: NonUniform chunks (the active list) one workgroup each, one thread per (i,j) row, 2 B/voxel read (flags + type
 // as two 16-byte loads per thread) into a per-chunk slot; Uniform chunks are closed forms; the slots and closed forms
 // are summed in chunk order by k_inertia_sum and a fixed-order final launch (bitwise reproducible, no float atomics).
-#include "ivx_internal.hpp"
+#include "chunk_passes.hpp"
 
 namespace {
 
@@ -22,31 +22,8 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// Sum over the wave on the VALU's DPP path (the shuffle form above goes through the LDS crossbar, two ds_bpermute per step
-// and double; ten of those chains per chunk made k_inertia_dense wait on LDS for a third of its time). Rows of 16 lanes
-// are summed with row_shr 1/2/4/8 (lanes shifted in from outside the row read zero), lane 15 of each row then holds the
-// row total; the four row totals are read as scalars and added in a fixed order. Every lane returns the wave total.
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_sum_dpp(double v) {
-    v += dpp_f64<0x111>(v);  // row_shr:1
-    v += dpp_f64<0x112>(v);  // row_shr:2
-    v += dpp_f64<0x114>(v);  // row_shr:4
-    v += dpp_f64<0x118>(v);  // row_shr:8
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    double r[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) r[q] = __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * q + 15), __builtin_amdgcn_readlane(lo, 16 * q + 15));
-    return (r[0] + r[1]) + (r[2] + r[3]);
-}
-
-// Moments of the NonUniform chunks, one workgroup per listed chunk, into the chunk's own slot (so the order of the
-// final sum does not depend on the order of the list).
+// Moments of the NonUniform chunks as a kernel of its own (the step path computes them inside k_derive's sweep): one workgroup
+// per listed chunk, into the chunk's own slot, so the order of the final sum does not depend on the order of the list.
 __global__ __launch_bounds__(256) void k_inertia_dense(GridView g, uint32_t x_off, const uint8_t* __restrict__ flags,
                                                        const float* __restrict__ dens, double* __restrict__ chunk_moments,
                                                        const uint32_t* __restrict__ work_counts, const uint32_t* __restrict__ active_list) {
@@ -66,30 +43,11 @@ __global__ __launch_bounds__(256) void k_inertia_dense(GridView g, uint32_t x_of
         const uint4 f = *reinterpret_cast<const uint4*>(flags + o);
         const uint4 t = *reinterpret_cast<const uint4*>(g.type + o);
         const uint32_t fw[4] = {f.x, f.y, f.z, f.w}, tw[4] = {t.x, t.y, t.z, t.w};
-        const double I = (double)((ci + (int)x_off) * 16 + ti), J = (double)(cj * 16 + tj);
-        const double qx = 2.0 * I + 1.0, qy = 2.0 * J + 1.0;
-        const double cx = 3.0 * I * I + 3.0 * I + 1.0, cy = 3.0 * J * J + 3.0 * J + 1.0;
-        double D = 0.0, Dz1 = 0.0, Dz2 = 0.0;
+        uint32_t m = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const uint32_t fl = (fw[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-            if (!(fl & VF_EMPTY)) {
-                const double d = (double)s_dens[(tw[k >> 2] >> (8 * (k & 3))) & 0xFFu];
-                const double K = (double)(ck * 16 + k);
-                D += d;
-                Dz1 += d * (2.0 * K + 1.0);
-                Dz2 += d * (3.0 * K * K + 3.0 * K + 1.0);
-            }
-        }
-        const double s[10] = {D, D * qx, D * qy, Dz1, D * cy + Dz2, D * cx + Dz2, D * (cx + cy), D * qx * qy, qy * Dz1, qx * Dz1};
-        const uint32_t lane = tid & 63u, wave = tid >> 6;
-#pragma unroll
-        for (int m = 0; m < 10; ++m) {
-            const double v = wave_sum_dpp(s[m]);
-            if (lane == 0) s_red[wave][m] = v;
-        }
-        __syncthreads();
-        if (tid < 10) chunk_moments[(size_t)chunk * 10 + tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+        for (int k = 0; k < 16; ++k)
+            if (!((fw[k >> 2] >> (8 * (k & 3))) & VF_EMPTY)) m |= 1u << k;
+        chunk_moments_rows(tid, m, tw, s_dens, s_red, (ci + (int)x_off) * 16 + ti, cj * 16 + tj, ck * 16, chunk_moments + (size_t)chunk * 10);
     }
 }
 
@@ -152,11 +110,12 @@ __global__ __launch_bounds__(640) void k_inertia_final(uint32_t n_blocks, float 
 
 }  // namespace
 
-int ivx_launch_inertia(ivx_grid* g, const float* d_dens, double* d_out10) {
+int ivx_launch_inertia(ivx_grid* g, const float* d_dens, double* d_out10, int fused) {
     uint32_t blocks = (g->n_chunks + 255u) / 256u;
     if (blocks > g->partial_blocks) blocks = (uint32_t)g->partial_blocks;
     GridView v = ivx_view(g);
-    hipLaunchKernelGGL(k_inertia_dense, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->x_off, g->flags, d_dens, g->chunk_moments, g->work_counts,
+    if (!fused)  // else k_derive left the chunk moments in the same sweep
+        hipLaunchKernelGGL(k_inertia_dense, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->x_off, g->flags, d_dens, g->chunk_moments, g->work_counts,
                        g->active_list);
     hipLaunchKernelGGL(k_inertia_sum, dim3(blocks), dim3(256), 0, g->ctx->stream, v, g->x_off, d_dens, g->chunk_moments, g->partials);
     hipLaunchKernelGGL(k_inertia_final, dim3(1), dim3(640), 0, g->ctx->stream, blocks, g->extent, g->partials, d_out10);

@@ -363,7 +363,7 @@ int ivx_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* nodes, size_t n_no
 
 int ivx_derive_state(ivx_grid* g) {
     IVX_REQUIRE(g, IVX_ERR_INVALID, "ivx_derive_state: null grid");
-    int rc = ivx_launch_derive(g);
+    int rc = ivx_launch_derive(g, 0);
     if (rc) return rc;
     g->mesh_valid = 0;
     g->regions_valid = 0;
@@ -431,7 +431,7 @@ int ivx_inertia(ivx_grid* g, const float densities[256], ivx_moments* out) {
     double* out_dev = g->partials + g->partial_blocks * 10;
     int rc;
     if ((rc = h2d(g, g->dens_dev, densities, 256 * sizeof(float)))) return rc;
-    if ((rc = ivx_launch_inertia(g, g->dens_dev, out_dev))) return rc;
+    if ((rc = ivx_launch_inertia(g, g->dens_dev, out_dev, 0))) return rc;
     if ((rc = d2h(g, out->m64, out_dev, 10 * sizeof(double)))) return rc;
     for (int i = 0; i < 10; ++i) out->m32[i] = (float)out->m64[i];
     out->reserved[0] = out->reserved[1] = 0;
@@ -441,7 +441,7 @@ int ivx_inertia(ivx_grid* g, const float densities[256], ivx_moments* out) {
 int ivx_label_regions(ivx_grid* g, uint32_t* region_count) {
     IVX_REQUIRE(g && region_count, IVX_ERR_INVALID, "ivx_label_regions: null argument");
     int rc;
-    if ((rc = ivx_launch_ccl_local(g))) return rc;
+    if ((rc = ivx_launch_ccl_local(g, 0))) return rc;
     if ((rc = ivx_launch_ccl_merge(g))) return rc;
     if ((rc = ivx_launch_ccl_resolve(g))) return rc;
     uint32_t sc[2];
@@ -525,8 +525,8 @@ int ivx_regions_describe(ivx_grid* g, const float densities[256], ivx_region_des
 
 static int rederive(ivx_grid* g) {
     int rc;
-    if ((rc = ivx_launch_derive(g))) return rc;
-    if ((rc = ivx_launch_ccl_local(g))) return rc;
+    if ((rc = ivx_launch_derive(g, IVX_PART_REGIONS))) return rc;  // flags and chunk-local regions in one sweep
+    if ((rc = ivx_launch_ccl_local(g, 1))) return rc;
     if ((rc = ivx_launch_ccl_merge(g))) return rc;
     if ((rc = ivx_launch_ccl_resolve(g))) return rc;
     uint32_t sc[2];
@@ -621,7 +621,7 @@ static int complete_extracted(ivx_grid* parent, ivx_grid** pc, uint32_t origin[3
     uint32_t uniform_count = 0;
     for (const ivx_chunk_info& i : info) uniform_count += i.gen_kind == KIND_UNIFORM;
     // non-empty voxel count and tight voxel box of the child: derive (flags + per-chunk boxes), unit-density mass
-    if ((rc = ivx_launch_derive(c))) return rc;
+    if ((rc = ivx_launch_derive(c, 0))) return rc;
     uint32_t* d_occ = c->rscalar + 16;
     if ((rc = ivx_launch_occupied(c, d_occ))) return rc;
     uint32_t occ[12], occ_raw[12];
@@ -631,7 +631,7 @@ static int complete_extracted(ivx_grid* parent, ivx_grid** pc, uint32_t origin[3
     for (float& x : ones) x = 1.0f;
     if ((rc = h2d(c, c->dens_dev, ones, sizeof(ones)))) return rc;
     double* out_dev = c->partials + c->partial_blocks * 10;
-    if ((rc = ivx_launch_inertia(c, c->dens_dev, out_dev))) return rc;
+    if ((rc = ivx_launch_inertia(c, c->dens_dev, out_dev, 0))) return rc;
     double m0 = 0.0;
     if ((rc = d2h(c, &m0, out_dev, sizeof(double)))) return rc;
     const double e = (double)c->extent;
@@ -831,6 +831,11 @@ int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
     IVX_HIP_CHECK(hipEventRecord(g->ev[2 * (i) + 1], s));      \
     last_stop = &g->ev[2 * (i) + 1];                           \
     g->timed_mask |= 1u << (i)
+    // derive runs the chunk-local region labelling and the chunk moments in the same sweep when those stages are part of this
+    // call (their stage timers then cover only what is left of them)
+    const uint32_t fused_parts = (stages & IVX_STAGE_DERIVE) ? (((stages & IVX_STAGE_REGIONS) ? IVX_PART_REGIONS : 0u) |
+                                                                 ((stages & IVX_STAGE_INERTIA) ? IVX_PART_MOMENTS : 0u))
+                                                              : 0u;
     if (stages & IVX_STAGE_SAMPLE) {
         T0(0);
         if ((rc = ivx_launch_sdf_sample(g, g->prog_nodes, g->prog_n, g->prog_stack, g->prog_shape, g->prog_center, g->prog_type))) return rc;
@@ -840,7 +845,7 @@ int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
     }
     if (stages & IVX_STAGE_DERIVE) {
         T0(1);
-        if ((rc = ivx_launch_derive(g))) return rc;
+        if ((rc = ivx_launch_derive(g, fused_parts))) return rc;
         T1(1);
     }
     if (stages & IVX_STAGE_OCCUPIED) {
@@ -850,7 +855,7 @@ int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
     }
     if (stages & IVX_STAGE_REGIONS) {
         T0(3);
-        if ((rc = ivx_launch_ccl_local(g))) return rc;
+        if ((rc = ivx_launch_ccl_local(g, (fused_parts & IVX_PART_REGIONS) != 0))) return rc;
         T1(3);
         T0(4);
         if ((rc = ivx_launch_ccl_merge(g))) return rc;
@@ -875,7 +880,7 @@ int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
     }
     if (stages & IVX_STAGE_INERTIA) {
         T0(9);
-        if ((rc = ivx_launch_inertia(g, g->dens_dev, g->partials + g->partial_blocks * 10))) return rc;
+        if ((rc = ivx_launch_inertia(g, g->dens_dev, g->partials + g->partial_blocks * 10, (fused_parts & IVX_PART_MOMENTS) != 0))) return rc;
         T1(9);
     }
 #undef T0

@@ -252,7 +252,10 @@ static inline GridView ivx_view(const ivx_grid* g) {
 int ivx_launch_classify(ivx_grid* g);
 int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, uint32_t n_nodes, uint32_t stack_size,
                           const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type);
-int ivx_launch_derive(ivx_grid* g);
+// parts of the fused sweep: k_derive can label the chunk-local regions and compute the chunk moments of the chunks it visits
+#define IVX_PART_REGIONS 1u
+#define IVX_PART_MOMENTS 2u
+int ivx_launch_derive(ivx_grid* g, uint32_t parts);
 int ivx_ensure_dense(ivx_grid* g);
 int ivx_launch_step_preset(ivx_grid* g, uint32_t stages);
 int ivx_launch_result_gather(ivx_grid* g, uint32_t* host_block_dev);
@@ -262,8 +265,8 @@ void ivx_occupied_from_raw(const ivx_grid* g, const uint32_t raw[12], uint32_t o
 int ivx_launch_sn_count(ivx_grid* g);
 int ivx_launch_sn_scan(ivx_grid* g);
 int ivx_launch_sn_emit(ivx_grid* g);
-int ivx_launch_inertia(ivx_grid* g, const float* d_dens, double* d_out10);
-int ivx_launch_ccl_local(ivx_grid* g);
+int ivx_launch_inertia(ivx_grid* g, const float* d_dens, double* d_out10, int fused);
+int ivx_launch_ccl_local(ivx_grid* g, int fused);
 int ivx_launch_ccl_merge(ivx_grid* g);
 int ivx_launch_ccl_resolve(ivx_grid* g);
 int ivx_launch_ccl_dense_labels(ivx_grid* g, uint32_t* d_labels);

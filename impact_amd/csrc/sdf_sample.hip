@@ -29,7 +29,19 @@ __device__ __forceinline__ V3 add(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.
 __device__ __forceinline__ V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ V3 scale(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 __device__ __forceinline__ float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-__device__ __forceinline__ float len3(V3 a) { return sqrtf(dot3(a, a)); }
+// Correctly rounded sqrt for the magnitudes this kernel meets (squared distances in voxel units: zero or well inside the normal
+// range). Same algorithm as the compiler's IEEE lowering of sqrtf — hardware estimate, then pick the neighbour float whose
+// residual changes sign — without its rescaling of tiny inputs and its inf/NaN class test: 9 instructions instead of 16, and
+// the evaluator is bound by VALU issue. sqrt(0) = 0 falls out (the "one ulp down" candidate is a NaN and never wins).
+__device__ __forceinline__ float sqrt_rn(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+    float r = r_dn <= 0.0f ? s_dn : s;
+    r = r_up > 0.0f ? s_up : r;
+    return r;
+}
+__device__ __forceinline__ float len3(V3 a) { return sqrt_rn(dot3(a, a)); }
 __device__ __forceinline__ float min_rs(float a, float b) { return (b < a) ? b : a; }
 __device__ __forceinline__ float max_rs(float a, float b) { return (b > a) ? b : a; }
 __device__ __forceinline__ bool sneg(float f) { return (__float_as_uint(f) >> 31) != 0; }
@@ -118,6 +130,9 @@ __device__ __forceinline__ int sd_from_f32(float v) {
 }
 
 struct SampleParams {
+#ifdef IVX_WG_TRACE
+    unsigned long long* trace;
+#endif
     uint32_t cx, cy, cz, x_off;
     uint32_t shape[3];
     float shifted_center[3];
@@ -565,6 +580,7 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
     // bounded grid-stride walk over the list of chunks to evaluate
     for (uint32_t li = blockIdx.x; li < n_eval; li += gridDim.x) {
     __syncthreads();  // the previous chunk's LDS use is over
+    IVX_T(p, li, 0);
     const uint32_t chunk = eval_list[li];
     const uint32_t ck = chunk % p.cz, cj = (chunk / p.cz) % p.cy, ci = chunk / (p.cz * p.cy);
     const uint32_t oi = (ci + p.x_off) * 16u, oj = cj * 16u, ok = ck * 16u;
@@ -606,6 +622,7 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
                 my_m[r] = nd->margin;
             }
         }
+        IVX_T(p, li, 1);  // program fetched
         for (uint32_t i = 0; i < len; ++i) {
             const uint32_t l = i & 63u;
             uint32_t w, v;
@@ -681,6 +698,8 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
         }
     }
 
+    IVX_T(p, li, 2);  // program evaluated
+    IVX_T(p, li, 3);
     const bool root_const = cmask & 1u;
     const float root_val = root_const ? s_cval[0] : 0.0f;
 #pragma unroll
@@ -689,7 +708,9 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
         bool in_grid = (oi + ti) < p.shape[0] && (oj + tj) < p.shape[1] && (ok + (uint32_t)k) < p.shape[2];
         sd[k] = in_grid ? sd_from_f32(v) : 127;
     }
+    IVX_T(p, li, 4);
     classify_and_store(sd, make_uint4(0, 0, 0, 0), true, 0, sdf_out, type_out, info_out, chunk, tid, true, p.voxel_type, true);
+    IVX_T(p, li, 5);  // classified and stored
     }
 }
 
@@ -733,6 +754,9 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
     }
     p.n_nodes = n_nodes;
     p.stack_size = stack_size;
+#ifdef IVX_WG_TRACE
+    p.trace = reinterpret_cast<unsigned long long*>(g->chunk_moments);
+#endif
     p.voxel_type = voxel_type;
     size_t lds = (size_t)(stack_size ? stack_size : 1) * IVX_CHUNK_VOXELS * sizeof(float);
     IVX_REQUIRE(lds <= 150 * 1024, IVX_ERR_CAPACITY, "SDF graph needs a forward stack of %u blocks (at most 9 fit the 160 KiB LDS)", stack_size);

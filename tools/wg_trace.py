@@ -4,7 +4,7 @@ Kernels compiled with IVX_WG_TRACE store up to six 100 MHz wall-clock stamps of 
 ivx_internal.hpp) into the grid's per-chunk moment buffer; this script runs the 512^3 bench workload up to the stage asked for,
 reads the stamps back and prints the mean time between consecutive probes, start/end percentiles and the number of entries in
 flight. Only ONE traced kernel may run in the traced step (they share the buffer), so choose the stage whose kernel has probes.
-usage: wg_trace.py {derive|remesh} [scale]"""
+usage: wg_trace.py {sample|derive|remesh} [scale]   (sample: k_sdf_eval, derive: k_derive with the region pass, remesh: k_sn_emit)"""
 import ctypes as C
 import os
 import sys
@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from impact_amd import capi, scenes  # noqa: E402
 from impact_amd.voxel import Context, SDFVoxelGenerator, VoxelObject  # noqa: E402
 
-STAGES = {"derive": capi.STAGE_SAMPLE | capi.STAGE_DERIVE, "remesh": capi.STAGE_REMESH}
+STAGES = {"sample": capi.STAGE_SAMPLE, "derive": capi.STAGE_DERIVE | capi.STAGE_REGIONS, "remesh": capi.STAGE_REMESH}
 
 
 def main():
