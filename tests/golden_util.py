@@ -27,7 +27,7 @@ def scenes_small():
         "sphere_r20": scenes.sphere_scene(20.0),
         "two_spheres_r12_sep30": scenes.two_spheres_scene(12.0, 30.0),
         "asteroid_x0.25": scenes.asteroid_scene(0.25),
-        "fracture_x0.25": scenes.fracture_scene(0.25),
+        "fracture_x0.35": scenes.fracture_scene(0.35),
     }
 
 
