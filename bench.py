@@ -191,7 +191,12 @@ def main():
         dist = dist_mod
         backend = os.environ.get("IVX_BENCH_BACKEND", "nccl")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+            except Exception as e:  # RCCL unusable on this box: keep the run alive through host staging and say so
+                print(f"[bench] rank {rank}: RCCL init failed ({e}); falling back to gloo", file=sys.stderr)
+                backend = "gloo"
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group(backend)
 

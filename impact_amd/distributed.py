@@ -43,6 +43,10 @@ NONE = 0xFFFFFFFF
 # fixed-size record every rank contributes to the final all-gather (int64 words)
 MAX_PAIRS = 4096  # IVX_MAX_FACE_PAIRS
 REC_WORDS = 2 + 12 + 4 + 10 + 2 * MAX_PAIRS  # n_regions, n_pairs | occupied[12] | mesh v,i,s,flags | moments f64 bits | pairs
+# The all-gather normally moves only the head of the record (a slab boundary is crossed by a handful of components); the full
+# record follows in a second all-gather in the rare step where some rank lists more pairs than the head holds.
+HEAD_PAIRS = 64
+HEAD_WORDS = 28 + 2 * HEAD_PAIRS
 
 
 @dataclass
@@ -58,6 +62,7 @@ class Exchange:
 @dataclass
 class AllGather:
     record: "DeviceBuffer"  # int64[REC_WORDS] on the device
+    words: int = REC_WORDS  # leading words to gather
 
 
 @dataclass
@@ -205,7 +210,9 @@ class SlabStepper:
         # 3. remesh + inertia (ghost layers in place), the slab's record, then the one small all-gather
         obj.step_enqueue(capi.STAGE_REMESH | capi.STAGE_INERTIA)
         check(L.ivx_step_record_enqueue(obj.h, C.c_void_p(self.record.ptr)))
-        records = yield AllGather(self.record)
+        records = yield AllGather(self.record, HEAD_WORDS)
+        if int(records[:, 1].max()) > HEAD_PAIRS:  # (the same decision on every rank: all see the same heads)
+            records = yield AllGather(self.record, REC_WORDS)
         r = obj.step_collect()  # the stream is already idle: stage timings + mesh-buffer check
         flags = int(records[self.rank, 17])
         if flags & 1:
@@ -255,10 +262,12 @@ class TorchComm:
         for rbuf, r_host in staged:
             rbuf.t.copy_(r_host)  # enqueued on the current (= the library's) stream
 
-    def all_gather(self, rec) -> np.ndarray:
+    def all_gather(self, rec, words=None) -> np.ndarray:
         """rec: DeviceBuffer (int64 words on the device) or a host numpy array -> (world, words) numpy"""
         torch, dist = self.torch, self.dist
         t = rec.t if isinstance(rec, DeviceBuffer) else torch.from_numpy(rec)
+        if words is not None:
+            t = t[:words]
         if self.on_device and not t.is_cuda:
             t = t.cuda()
         if not self.on_device and t.is_cuda:
@@ -278,7 +287,7 @@ class TorchComm:
                         self.exchange(req)
                         reply = None
                     else:
-                        reply = self.all_gather(req.record)
+                        reply = self.all_gather(req.record, req.words)
             except StopIteration as stop:
                 return stop.value
 
@@ -312,6 +321,6 @@ def run_slabs_in_process(steppers):
                         reqs[i + 1].recv_lo.t.copy_(r.hi.t)
                 replies = [None] * len(gens)
             else:
-                records = torch.stack([r.record.t for r in reqs]).cpu().numpy()
+                records = torch.stack([r.record.t[: r.words] for r in reqs]).cpu().numpy()
                 replies = [records] * len(gens)
     return results
