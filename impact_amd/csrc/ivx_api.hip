@@ -256,7 +256,7 @@ void ivx_grid_destroy(ivx_grid* g) {
     void* ptrs[] = {g->sdf, g->type, g->flags, g->llabel, g->info, g->ghost_sdf[0], g->ghost_sdf[1], g->ghost_type[0], g->ghost_type[1],
                     g->ghost_info[0], g->ghost_info[1], g->chunk_counts, g->chunk_offsets, g->positions, g->normals, g->indices,
                     g->index_materials, g->vertex_materials, g->submeshes, g->partials, g->rparent, g->rcompid, g->rscalar, g->ccl_scratch, g->group_sums, g->sn_list, g->dens_dev, g->dev_scratch, g->prog_nodes, g->chunk_bbox, g->samp_len, g->samp_ops, g->pairs_dev,
-                    g->work_counts, g->active_list, g->fill_list, g->chunk_class, g->chunk_moments, g->chunk_touch, g->chunk_signs};
+                    g->work_counts, g->active_list, g->fill_list, g->chunk_class, g->chunk_moments, g->chunk_touch, g->chunk_signs, g->samp_super};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->host_scratch) (void)hipHostFree(g->host_scratch);
@@ -351,7 +351,11 @@ int ivx_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* nodes, size_t n_no
     IVX_REQUIRE((uint32_t)max_depth <= stack_size || n_nodes == 0, IVX_ERR_INVALID, "ivx_sdf_sample: stack_size %u < required %d", stack_size, max_depth);
     int rc;
     if ((rc = ensure_dev_scratch(g, std::max<size_t>(n_nodes, 1) * sizeof(ivx_sdf_processed_node)))) return rc;
-    if ((rc = h2d(g, g->dev_scratch, nodes, n_nodes * sizeof(ivx_sdf_processed_node)))) return rc;
+    {
+        std::vector<ivx_sdf_processed_node> annotated(nodes, nodes + n_nodes);
+        ivx_sdf_annotate_host(annotated.data(), n_nodes);
+        if ((rc = h2d(g, g->dev_scratch, annotated.data(), n_nodes * sizeof(ivx_sdf_processed_node)))) return rc;
+    }
     rc = ivx_launch_sdf_sample(g, static_cast<const ivx_sdf_processed_node*>(g->dev_scratch), (uint32_t)n_nodes, (uint32_t)max_depth, grid_shape,
                                shifted_grid_center, voxel_type);
     if (rc) return rc;
@@ -775,7 +779,9 @@ int ivx_grid_set_sdf_program(ivx_grid* g, const ivx_sdf_processed_node* nodes, s
         if (rc) return rc;
         g->prog_cap = (uint32_t)n_nodes;
     }
-    int rc = h2d(g, g->prog_nodes, nodes, n_nodes * sizeof(ivx_sdf_processed_node));
+    std::vector<ivx_sdf_processed_node> annotated(nodes, nodes + n_nodes);
+    ivx_sdf_annotate_host(annotated.data(), n_nodes);
+    int rc = h2d(g, g->prog_nodes, annotated.data(), n_nodes * sizeof(ivx_sdf_processed_node));
     if (rc) return rc;
     g->prog_n = (uint32_t)n_nodes;
     g->prog_stack = (uint32_t)max_depth;

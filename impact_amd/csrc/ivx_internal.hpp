@@ -111,6 +111,8 @@ struct ivx_grid {
     double* moments_dev;  // [10]
     uint32_t* samp_len;   // [n_chunks] length of the chunk's compact SDF program (sampler pre-pass)
     void* samp_ops;       // [n_chunks * 128] uint2 ops
+    uint32_t* samp_super;  // [super-blocks * ceil(nodes / 32)] "node certainly outside every chunk of the super-block" bits
+    size_t samp_super_words;
     hipEvent_t ev[2 * IVX_N_TIMED_STAGES];  // start/stop per timed stage
     int ev_ready;
     uint32_t* result_host;      // 64 words of host-mapped pinned memory the gather kernel writes the step's small results to
@@ -260,6 +262,7 @@ int ivx_ensure_dense(ivx_grid* g);
 int ivx_launch_step_preset(ivx_grid* g, uint32_t stages);
 int ivx_launch_result_gather(ivx_grid* g, uint32_t* host_block_dev);
 int ivx_sampler_buffers(ivx_grid* g);
+void ivx_sdf_annotate_host(ivx_sdf_processed_node* nodes, size_t n);  // sdf_compile.cpp: reserved[] fields for the pre-pass
 int ivx_launch_occupied(ivx_grid* g, uint32_t* d_raw);
 void ivx_occupied_from_raw(const ivx_grid* g, const uint32_t raw[12], uint32_t out[12]);
 int ivx_launch_sn_count(ivx_grid* g);

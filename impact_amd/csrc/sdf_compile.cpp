@@ -279,6 +279,68 @@ extern "C" int ivx_sdf_compile(const ivx_sdf_node* nodes, size_t n_nodes, uint32
     return IVX_OK;
 }
 
+
+// ---- annotations for the sampler's pre-pass (written into the uploaded copy of the program, reserved[0..4)) ---------------
+// The program is in postfix order, so the subtree of node r is the contiguous range [first(r), r]. For every node:
+//   reserved[0]  the value of the subtree when every node of it takes its "domain lies outside the block" early-out
+//                (leaf -> +margin, atomic.rs:654-668; combination applied only if the folded value fails `>= margin`,
+//                atomic.rs:788-806): the constant a far-away body contributes, as the pre-pass would fold it node by node
+//   reserved[1]  for a leaf: the OUTERMOST subtree root whose range starts at this leaf (itself if none)
+//   reserved[2]  for a non-leaf: the root of the next smaller subtree starting at the same leaf (first operand / the child)
+//   reserved[3]  first(r)
+// With these the pre-pass can replace a whole far body by one constant instead of walking its nodes.
+static inline float rs_min(float a, float b) { return (b < a) ? b : a; }
+static inline float rs_max(float a, float b) { return (b > a) ? b : a; }
+static inline float host_smooth_union(float d1, float d2, float s, float q) {  // generation/sdf.rs:89-92
+    const float h = rs_max(s - std::fabs(d1 - d2), 0.0f);
+    return rs_min(d1, d2) - (h * h) * q;
+}
+static inline float host_combine(uint32_t kind, float a, float b, float s, float q) {
+    if (kind == 7u) return s == 0.0f ? rs_min(a, b) : host_smooth_union(a, b, s, q);
+    if (kind == 8u) return s == 0.0f ? rs_max(a, -b) : -host_smooth_union(-a, b, s, q);
+    return s == 0.0f ? rs_max(a, b) : -host_smooth_union(-a, -b, s, q);
+}
+
+void ivx_sdf_annotate_host(ivx_sdf_processed_node* nodes, size_t n) {
+    std::vector<uint32_t> root_stack;  // roots of the subtrees on the evaluation stack
+    for (size_t i = 0; i < n; ++i) {
+        ivx_sdf_processed_node& nd = nodes[i];
+        const uint32_t kind = nd.kind;
+        float f;
+        uint32_t first;
+        if (kind <= 2u) {
+            f = nd.margin;
+            first = (uint32_t)i;
+            nd.reserved[2] = (uint32_t)i;
+            root_stack.push_back((uint32_t)i);
+        } else if (kind >= 7u) {
+            const uint32_t r2 = root_stack.back();
+            root_stack.pop_back();
+            const uint32_t r1 = root_stack.back();
+            float f1, f2;
+            std::memcpy(&f1, &nodes[r1].reserved[0], 4);
+            std::memcpy(&f2, &nodes[r2].reserved[0], 4);
+            const float r = host_combine(kind, f1, f2, nd.a, nd.b);
+            f = (r >= nd.margin) ? f1 : r;  // the combination's own domain is outside too: applied only if the test fails
+            first = nodes[r1].reserved[3];
+            nd.reserved[2] = r1;
+            root_stack.back() = (uint32_t)i;
+        } else {  // translation / rotation (no-ops at evaluation time) and scaling: one operand
+            const uint32_t r1 = root_stack.back();
+            float f1;
+            std::memcpy(&f1, &nodes[r1].reserved[0], 4);
+            f = kind == 5u ? f1 * nd.a : f1;
+            first = nodes[r1].reserved[3];
+            nd.reserved[2] = r1;
+            root_stack.back() = (uint32_t)i;
+        }
+        std::memcpy(&nd.reserved[0], &f, 4);
+        nd.reserved[3] = first;
+        nd.reserved[1] = (uint32_t)i;
+        nodes[first].reserved[1] = (uint32_t)i;  // later (outer) roots overwrite earlier ones
+    }
+}
+
 extern "C" int ivx_sdf_grid_shape(const float domain[6], uint32_t grid_shape[3], float shifted_grid_center[3]) {
     IVX_REQUIRE(domain && grid_shape && shifted_grid_center, IVX_ERR_INVALID, "ivx_sdf_grid_shape: null pointer");
     float ext[3];

@@ -294,20 +294,96 @@ __device__ __forceinline__ void load_node_tile(PaddedNode* tile, const ivx_sdf_p
     for (uint32_t i = tid; i < count * 32u; i += nthreads) d[(i >> 5) * 33u + (i & 31u)] = s[i];
 }
 
+// Super-blocks of 4 x 4 x 4 chunks: bit n of a super-block's mask says that node n takes its "domain lies outside the block"
+// early-out (atomic.rs:654-668, 788-806) for EVERY chunk of the super-block. The block test is monotone — the node-space box
+// of a chunk lies inside the node-space box of its super-block — so the bit follows from the same test on the super-block,
+// taken with a safety distance that dwarfs the rounding of the two box computations. One thread per (super-block, node).
+// The pre-pass then replaces whole far bodies by their folded constant and skips the box arithmetic of single far nodes: its
+// cost no longer grows with the number of bodies in the scene.
+constexpr int SUPER = 4;
+// per super-block and node: .x = for a leaf, the root of the largest subtree starting at it whose nodes are all far (the
+// pre-pass replaces the range by one constant), else the node's own index; .y = that subtree's folded constant
+__device__ __forceinline__ bool range_all_far(const uint32_t* mask, uint32_t a, uint32_t b);
+__global__ __launch_bounds__(64) void k_sdf_super(SampleParams p, const ivx_sdf_processed_node* __restrict__ nodes, uint32_t* __restrict__ super_mask,
+                                                  uint2* __restrict__ super_skip, uint32_t words, uint32_t sy, uint32_t sz) {
+    extern __shared__ uint32_t s_mask[];  // [words]
+    const uint32_t sb = blockIdx.x, lane = threadIdx.x;
+    const uint32_t sk = sb % sz, sj = (sb / sz) % sy, si = sb / (sz * sy);
+    const V3 lo = sub(mk((float)((si * SUPER + p.x_off) * 16u), (float)(sj * SUPER * 16u), (float)(sk * SUPER * 16u)),
+                      mk(p.shifted_center[0], p.shifted_center[1], p.shifted_center[2]));
+    const Box block{lo, add(lo, mk(16.0f * SUPER, 16.0f * SUPER, 16.0f * SUPER))};
+    for (uint32_t n0 = 0; n0 < words * 32u; n0 += 64u) {
+        const uint32_t n = n0 + lane;
+        bool far = false;
+        if (n < p.n_nodes) {
+            const ivx_sdf_processed_node* nd = nodes + n;
+            const uint32_t kind = nd->kind;
+            if (kind > 2u && kind < 7u) {
+                far = true;  // translation / rotation / scaling have no test of their own
+            } else {
+                const Box bn = aabb_of_transformed(block, nd->transform);
+                const float eps = 1e-2f;
+                far = bn.hi.x - nd->domain_lo[0] < -eps || bn.hi.y - nd->domain_lo[1] < -eps || bn.hi.z - nd->domain_lo[2] < -eps ||
+                      nd->domain_hi[0] - bn.lo.x < -eps || nd->domain_hi[1] - bn.lo.y < -eps || nd->domain_hi[2] - bn.lo.z < -eps;
+            }
+        }
+        const unsigned long long b = __ballot(far);
+        if (lane == 0 && (n0 >> 5) < words) s_mask[n0 >> 5] = (uint32_t)b;
+        if (lane == 32 && (n0 >> 5) + 1u < words) s_mask[(n0 >> 5) + 1u] = (uint32_t)(b >> 32);
+    }
+    __syncthreads();
+    for (uint32_t w = lane; w < words; w += 64u) super_mask[(size_t)sb * words + w] = s_mask[w];
+    for (uint32_t n = lane; n < p.n_nodes; n += 64u) {
+        uint32_t target = n, fbits = 0;
+        if (nodes[n].kind <= 2u) {
+            uint32_t r = nodes[n].reserved[1];  // outermost subtree starting at this leaf, then inwards
+            while (r != n) {
+                if (range_all_far(s_mask, n, r)) {
+                    target = r;
+                    fbits = nodes[r].reserved[0];
+                    break;
+                }
+                r = nodes[r].reserved[2];
+            }
+        }
+        super_skip[(size_t)sb * words * 32u + n] = make_uint2(target, fbits);
+    }
+}
+
+// every node of [a, b] far?
+__device__ __forceinline__ bool range_all_far(const uint32_t* mask, uint32_t a, uint32_t b) {
+    for (uint32_t w = a >> 5; w <= (b >> 5); ++w) {
+        const uint32_t lo = w == (a >> 5) ? (a & 31u) : 0u, hi = w == (b >> 5) ? (b & 31u) : 31u;
+        const uint32_t m = (hi == 31u ? 0xFFFFFFFFu : ((1u << (hi + 1u)) - 1u)) & ~((1u << lo) - 1u);
+        if ((mask[w] & m) != m) return false;
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx_sdf_processed_node* __restrict__ nodes,
                                                        float* __restrict__ chunk_const, uint32_t* __restrict__ prog_len,
                                                        uint2* __restrict__ prog_ops, uint32_t* __restrict__ eval_count,
                                                        uint32_t* __restrict__ eval_list, ivx_chunk_info* __restrict__ info_out,
-                                                       uint32_t* __restrict__ fill_count, uint32_t* __restrict__ fill_list) {
+                                                       uint32_t* __restrict__ fill_count, uint32_t* __restrict__ fill_list,
+                                                       const uint32_t* __restrict__ super_mask, const uint2* __restrict__ super_skip, uint32_t words,
+                                                       uint32_t sy, uint32_t sz) {
+    __shared__ uint2 s_skip[NODE_TILE];
+    __shared__ uint32_t s_far[NODE_TILE / 32];
     __shared__ float s_lo[16][PRE_T];
     __shared__ float s_hi[16][PRE_T];
     __shared__ uint16_t s_start[16][PRE_T];  // op-stream position where each stack level's steps begin
     __shared__ PaddedNode s_nodes[NODE_TILE];
-    const uint32_t n_chunks = p.cx * p.cy * p.cz;
     const uint32_t tid = threadIdx.x;
-    // out-of-range threads still take part in the tile loads and barriers; they redo the last chunk
-    const uint32_t chunk = min(blockIdx.x * PRE_T + tid, n_chunks - 1u);
-    const uint32_t ck = chunk % p.cz, cj = (chunk / p.cz) % p.cy, ci = chunk / (p.cz * p.cy);
+    // one block per super-block of 4 x 4 x 4 chunks (so its threads share the super-block's far bits and skip table, staged in
+    // LDS with the node tile); threads whose chunk lies beyond the grid still take part in the tile loads and barriers: they
+    // redo a chunk of the grid and write nothing
+    static_assert(PRE_T == SUPER * SUPER * SUPER, "one thread per chunk of a super-block");
+    const uint32_t sb = blockIdx.x;
+    const uint32_t sk = sb % sz, sj = (sb / sz) % sy, si = sb / (sz * sy);
+    const uint32_t ci_raw = si * SUPER + (tid >> 4), cj_raw = sj * SUPER + ((tid >> 2) & 3u), ck_raw = sk * SUPER + (tid & 3u);
+    const bool mine = ci_raw < p.cx && cj_raw < p.cy && ck_raw < p.cz;
+    const uint32_t ci = min(ci_raw, p.cx - 1u), cj = min(cj_raw, p.cy - 1u), ck = min(ck_raw, p.cz - 1u);
+    const uint32_t chunk = (ci * p.cy + cj) * p.cz + ck;
     const uint32_t oi = (ci + p.x_off) * 16u, oj = cj * 16u, ok = ck * 16u;
     const V3 origin_root = sub(mk((float)oi, (float)oj, (float)ok), mk(p.shifted_center[0], p.shifted_center[1], p.shifted_center[2]));
     const Box block{origin_root, add(origin_root, mk(16.0f, 16.0f, 16.0f))};
@@ -320,16 +396,34 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
         if (pos < OP_CAP) ops[pos] = make_uint2(w, v);
         pos += 1;
     };
+    int skip_until = -1;  // nodes up to here belong to a subtree that was replaced by its far constant
     for (uint32_t n = 0; n < p.n_nodes; ++n) {
-        if ((n % NODE_TILE) == 0u) {  // stage the next tile of the node program in LDS (one coalesced round trip)
+        if ((n % NODE_TILE) == 0u) {  // stage the next tile of the node program (and of the super-block's tables) in LDS
             __syncthreads();
             load_node_tile(s_nodes, nodes + n, min((uint32_t)NODE_TILE, p.n_nodes - n), tid, PRE_T);
+            if (n + tid < p.n_nodes) s_skip[tid] = super_skip[(size_t)sb * words * 32u + n + tid];
+            if (tid < NODE_TILE / 32 && (n >> 5) + tid < words) s_far[tid] = super_mask[(size_t)sb * words + (n >> 5) + tid];
             __syncthreads();
         }
+        if ((int)n <= skip_until) continue;
         const ivx_sdf_processed_node* nd = &s_nodes[n % NODE_TILE].n;
         const uint32_t kind = nd->kind;
+        const bool far = (s_far[(n % NODE_TILE) >> 5] >> (n & 31u)) & 1u;  // the node's block test is known to say "outside"
         if (kind <= 2u) {
-            const uint32_t mode = node_mode(nd, block);
+            // the largest subtree that starts at this leaf and lies outside as a whole collapses to its folded constant
+            const uint2 sk2 = s_skip[n % NODE_TILE];
+            if (sk2.x != n) {
+                const float v = __uint_as_float(sk2.y);
+                s_start[top][tid] = (uint16_t)min(pos, 0xFFFFu);
+                s_lo[top][tid] = v;
+                s_hi[top][tid] = v;
+                cmask |= 1u << top;
+                emit(OP_CONST << 28, __float_as_uint(v));
+                top += 1;
+                skip_until = (int)sk2.x;
+                continue;
+            }
+            const uint32_t mode = far ? 1u : node_mode(nd, block);
             s_start[top][tid] = (uint16_t)min(pos, 0xFFFFu);
             if (mode == 1u || mode == 2u) {
                 const float v = mode == 1u ? nd->margin : -nd->margin;
@@ -360,7 +454,7 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
             const bool c1 = (cmask >> (top - 1)) & 1u, c2 = (cmask >> top) & 1u;
             const float lo1 = s_lo[top - 1][tid], hi1 = s_hi[top - 1][tid], lo2 = s_lo[top][tid], hi2 = s_hi[top][tid];
             const float s = nd->a, q = nd->b;
-            const bool must_apply = node_mode(nd, block) == 0u;
+            const bool must_apply = !far && node_mode(nd, block) == 0u;
             if (c1 && c2) {
                 const float r = combine(kind, lo1, lo2, s, q);
                 if (must_apply || !(r >= nd->margin)) {
@@ -434,7 +528,6 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
     else if (lo >= 2.54f + 0.02f) out = 1000.0f;    // every voxel quantises to +127
     else if (hi <= -2.56f - 0.02f) out = -1000.0f;  // every voxel quantises to -128
     if (oi >= p.shape[0] || oj >= p.shape[1] || ok >= p.shape[2]) out = 1000.0f;  // beyond the generator's grid: all +127
-    const bool mine = blockIdx.x * PRE_T + tid < n_chunks;  // (tail threads replay the last chunk: they must not list it twice)
     bool to_fill = false;
     if (mine) {
         chunk_const[chunk] = out;
@@ -785,8 +878,23 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
         IVX_HIP_CHECK(hipMemsetAsync(eval_count, 0, sizeof(uint32_t), g->ctx->stream));
         IVX_HIP_CHECK(hipMemsetAsync(g->work_counts + 1, 0, sizeof(uint32_t), g->ctx->stream));
     }
-    hipLaunchKernelGGL(k_sdf_prepass, dim3((g->n_chunks + PRE_T - 1) / PRE_T), dim3(PRE_T), 0, g->ctx->stream, p, d_nodes, chunk_const, g->samp_len, ops,
-                       eval_count, eval_list, g->info, g->work_counts + 1, g->fill_list);
+    const uint32_t sx = (g->cc[0] + SUPER - 1) / SUPER, sy = (g->cc[1] + SUPER - 1) / SUPER, sz = (g->cc[2] + SUPER - 1) / SUPER;
+    const uint32_t words = (n_nodes + 31u) / 32u > 0u ? (n_nodes + 31u) / 32u : 1u;
+    {
+        const size_t need = (((size_t)sx * sy * sz * words + 1u) & ~(size_t)1u) + (size_t)sx * sy * sz * words * 64u;  // far bits + a uint2 per node
+        if (need > g->samp_super_words) {
+            IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+            if (g->samp_super) (void)hipFree(g->samp_super);
+            g->samp_super = nullptr;
+            g->samp_super_words = 0;
+            IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_super), need * sizeof(uint32_t)));
+            g->samp_super_words = need;
+        }
+    }
+    uint2* super_skip = reinterpret_cast<uint2*>(g->samp_super + (((size_t)sx * sy * sz * words + 1u) & ~(size_t)1u));
+    hipLaunchKernelGGL(k_sdf_super, dim3(sx * sy * sz), dim3(64), words * sizeof(uint32_t), g->ctx->stream, p, d_nodes, g->samp_super, super_skip, words, sy, sz);
+    hipLaunchKernelGGL(k_sdf_prepass, dim3(sx * sy * sz), dim3(PRE_T), 0, g->ctx->stream, p, d_nodes, chunk_const, g->samp_len, ops, eval_count, eval_list,
+                       g->info, g->work_counts + 1, g->fill_list, g->samp_super, super_skip, words, sy, sz);
     g->planes_compact = 1;
     hipLaunchKernelGGL(k_sdf_fill, dim3(g->n_chunks < 1024u ? g->n_chunks : 1024u), dim3(256), 0, g->ctx->stream, p, chunk_const, g->work_counts + 1,
                        g->fill_list, g->sdf, g->type, g->info);
