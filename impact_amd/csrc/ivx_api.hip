@@ -302,7 +302,11 @@ int ivx_grid_stage_counters(ivx_grid* g, uint32_t out[4]) {
     IVX_REQUIRE(g && out, IVX_ERR_INVALID, "ivx_grid_stage_counters: null argument");
     for (int i = 0; i < 4; ++i) out[i] = 0;
     int rc;
-    if (g->samp_len && (rc = d2h(g, &out[0], g->samp_len + g->n_chunks, sizeof(uint32_t)))) return rc;  // chunks evaluated per voxel by the sampler
+    if (g->samp_len) {  // chunks evaluated per voxel by the sampler (three lists by LDS class)
+        uint32_t ev[3];
+        if ((rc = d2h(g, ev, g->samp_len + g->n_chunks, sizeof(ev)))) return rc;
+        out[0] = ev[0] + ev[1] + ev[2];
+    }
     if ((rc = d2h(g, &out[1], g->rscalar + 2, sizeof(uint32_t)))) return rc;                            // chunks with several local regions
     if ((rc = d2h(g, &out[2], g->chunk_offsets + 2 * (size_t)g->n_chunks + 2, sizeof(uint32_t)))) return rc;  // chunks that emitted a mesh
     out[3] = g->n_chunks;

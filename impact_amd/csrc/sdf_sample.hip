@@ -363,7 +363,7 @@ __device__ __forceinline__ bool range_all_far(const uint32_t* mask, uint32_t a, 
 __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx_sdf_processed_node* __restrict__ nodes,
                                                        float* __restrict__ chunk_const, uint32_t* __restrict__ prog_len,
                                                        uint2* __restrict__ prog_ops, uint32_t* __restrict__ eval_count,
-                                                       uint32_t* __restrict__ eval_list, ivx_chunk_info* __restrict__ info_out,
+                                                       uint32_t* __restrict__ eval_list, uint32_t list_stride, ivx_chunk_info* __restrict__ info_out,
                                                        uint32_t* __restrict__ fill_count, uint32_t* __restrict__ fill_list,
                                                        const uint32_t* __restrict__ super_mask, const uint2* __restrict__ super_skip, uint32_t words,
                                                        uint32_t sy, uint32_t sz) {
@@ -372,6 +372,7 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
     __shared__ float s_lo[16][PRE_T];
     __shared__ float s_hi[16][PRE_T];
     __shared__ uint16_t s_start[16][PRE_T];  // op-stream position where each stack level's steps begin
+    __shared__ uint8_t s_need[16][PRE_T];    // LDS levels the evaluator needs to produce this stack level (0 for a constant)
     __shared__ PaddedNode s_nodes[NODE_TILE];
     const uint32_t tid = threadIdx.x;
     // one block per super-block of 4 x 4 x 4 chunks (so its threads share the super-block's far bits and skip table, staged in
@@ -417,6 +418,7 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
                 s_start[top][tid] = (uint16_t)min(pos, 0xFFFFu);
                 s_lo[top][tid] = v;
                 s_hi[top][tid] = v;
+                s_need[top][tid] = 0;
                 cmask |= 1u << top;
                 emit(OP_CONST << 28, __float_as_uint(v));
                 top += 1;
@@ -429,6 +431,7 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
                 const float v = mode == 1u ? nd->margin : -nd->margin;
                 s_lo[top][tid] = v;
                 s_hi[top][tid] = v;
+                s_need[top][tid] = 0;
                 cmask |= 1u << top;
                 emit(OP_CONST << 28, __float_as_uint(v));
             } else {
@@ -436,6 +439,7 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
                 leaf_bounds(nd, aabb_of_transformed(block, nd->transform), lo, hi);
                 s_lo[top][tid] = lo;
                 s_hi[top][tid] = hi;
+                s_need[top][tid] = 1;
                 cmask &= ~(1u << top);
                 emit((OP_LEAF << 28) | (kind << 24) | n, 0u);
             }
@@ -462,6 +466,7 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
                     s_hi[top - 1][tid] = r;
                 }
                 pos = s_start[top - 1][tid];
+                s_need[top - 1][tid] = 0;
                 emit(OP_CONST << 28, __float_as_uint(s_lo[top - 1][tid]));
             } else {
                 // absorption: an exact constant operand that the other operand can never come within
@@ -482,6 +487,7 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
                 if (absorbed) {
                     s_lo[top - 1][tid] = av;
                     s_hi[top - 1][tid] = av;
+                    s_need[top - 1][tid] = 0;
                     cmask |= 1u << (top - 1);
                     pos = s_start[top - 1][tid];
                     emit(OP_CONST << 28, __float_as_uint(av));
@@ -501,6 +507,11 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
                     }
                 }
                 emit(((must_apply ? OP_COMBINE : OP_COMBINE_OUTSIDE) << 28) | (kind << 24) | n, 0u);
+                {  // the first operand keeps its level (if it has one) while the second is evaluated; the result needs one
+                    const uint32_t n1 = s_need[top - 1][tid], n2 = s_need[top][tid];
+                    const uint32_t nn = max(max(n1, (c1 ? 0u : 1u) + n2), 1u);
+                    s_need[top - 1][tid] = (uint8_t)nn;
+                }
                 float rlo, rhi;
                 if (kind == 8u) {  // subtraction: decreasing in the second operand
                     rlo = combine(kind, lo1, hi2, s, q);
@@ -559,15 +570,25 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
     // k_sdf_fill (order is irrelevant); one atomic per wave and list (the block is one wave)
     static_assert(PRE_T == 64, "the list appends below assume one wave per block");
     {
+        // Evaluation lists by the number of LDS levels the chunk's compact program needs (k_sdf_eval gets one launch per
+        // class, with that much LDS: residency, hence throughput, is set by LDS): class 0: <= 2 levels, 1: 3, 2: more (and
+        // the chunks whose program did not fit OP_CAP, which run the full program).
         const unsigned long long below = (1ull << tid) - 1ull;
         const bool ev = mine && out != out;
-        const unsigned long long be = __ballot(ev), bf = __ballot(to_fill);
-        uint32_t base_e = 0, base_f = 0;
-        if (tid == 0 && be) base_e = atomicAdd(eval_count, (uint32_t)__popcll(be));
+        const uint32_t need = pos <= OP_CAP ? (uint32_t)s_need[0][tid] : p.stack_size;  // (the full program may use every level)
+        const uint32_t cls = need <= 2u ? 0u : (need == 3u ? 1u : 2u);
+#pragma unroll
+        for (uint32_t c = 0; c < 3; ++c) {
+            const unsigned long long be = __ballot(ev && cls == c);
+            uint32_t base_e = 0;
+            if (tid == 0 && be) base_e = atomicAdd(eval_count + c, (uint32_t)__popcll(be));
+            base_e = __shfl(base_e, 0, 64);
+            if (ev && cls == c) eval_list[(size_t)c * list_stride + base_e + (uint32_t)__popcll(be & below)] = chunk;
+        }
+        const unsigned long long bf = __ballot(to_fill);
+        uint32_t base_f = 0;
         if (tid == 0 && bf) base_f = atomicAdd(fill_count, (uint32_t)__popcll(bf));
-        base_e = __shfl(base_e, 0, 64);
         base_f = __shfl(base_f, 0, 64);
-        if (ev) eval_list[base_e + (uint32_t)__popcll(be & below)] = chunk;
         if (to_fill) fill_list[base_f + (uint32_t)__popcll(bf & below)] = chunk;
     }
 }
@@ -613,11 +634,15 @@ __device__ __forceinline__ void eval_leaf(const ivx_sdf_processed_node* nd, uint
 // Combination of levels top-1 and top (after the caller decremented `top`). `outside` = the node's
 // domain lies outside the block, so the reference applies it only if one of the 14 distinct block test
 // positions fails `value >= margin` (atomic.rs:788-806, 1661-1797).
+// index of the LDS level that holds stack level `level`: the number of per-voxel (non-constant) levels below it
+__device__ __forceinline__ uint32_t lds_level(uint32_t cmask, uint32_t level) { return __popc(~cmask & ((1u << level) - 1u)); }
+
 __device__ __forceinline__ void combine_levels(uint32_t kind, float s, float q, float margin, bool outside, uint32_t top, float* stack,
                                                float* s_cval, uint32_t& cmask, uint32_t tid) {
-    float* d1 = stack + (size_t)(top - 1) * IVX_CHUNK_VOXELS;
-    const float* d2 = stack + (size_t)top * IVX_CHUNK_VOXELS;
+    // LDS levels are dense: a block-constant stack level is a scalar and takes none (lds_level)
     const bool c1 = (cmask >> (top - 1)) & 1u, c2 = (cmask >> top) & 1u;
+    float* d1 = stack + (size_t)lds_level(cmask, top - 1) * IVX_CHUNK_VOXELS;
+    const float* d2 = stack + (size_t)lds_level(cmask, top) * IVX_CHUNK_VOXELS;
     const float v1 = c1 ? s_cval[top - 1] : 0.0f, v2 = c2 ? s_cval[top] : 0.0f;
     bool apply = !outside;
     if (!apply) {  // workgroup-uniform branch
@@ -752,11 +777,11 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
                 top += 1;
             } else if (opc == OP_LEAF) {
                 cmask &= ~(1u << top);
-                eval_leaf(nodes + (w & 0xFFFFFFu), kind, stack + (size_t)top * IVX_CHUNK_VOXELS + tid, origin_root, ti, tj);
+                eval_leaf(nodes + (w & 0xFFFFFFu), kind, stack + (size_t)lds_level(cmask, top) * IVX_CHUNK_VOXELS + tid, origin_root, ti, tj);
                 top += 1;
             } else if (opc == OP_SCALE) {
                 // constant levels were folded by the pre-pass: the level is per-voxel here
-                float* d = stack + (size_t)(top - 1) * IVX_CHUNK_VOXELS + tid;
+                float* d = stack + (size_t)lds_level(cmask, top - 1) * IVX_CHUNK_VOXELS + tid;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) d[k * 256] *= s;
             } else {
@@ -783,7 +808,7 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
                         cmask |= 1u << top;
                     } else {
                         cmask &= ~(1u << top);
-                        eval_leaf(nd, kind, stack + (size_t)top * IVX_CHUNK_VOXELS + tid, origin_root, ti, tj);
+                        eval_leaf(nd, kind, stack + (size_t)lds_level(cmask, top) * IVX_CHUNK_VOXELS + tid, origin_root, ti, tj);
                     }
                     top += 1;
                 } else if (kind == 5u) {
@@ -791,7 +816,7 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
                     if ((cmask >> (top - 1)) & 1u) {
                         s_cval[top - 1] = s_cval[top - 1] * s;
                     } else {
-                        float* d = stack + (size_t)(top - 1) * IVX_CHUNK_VOXELS + tid;
+                        float* d = stack + (size_t)lds_level(cmask, top - 1) * IVX_CHUNK_VOXELS + tid;
 #pragma unroll
                         for (int k = 0; k < 16; ++k) d[k * 256] *= s;
                     }
@@ -841,7 +866,8 @@ __global__ __launch_bounds__(256) void k_classify(uint32_t n_chunks, int8_t* __r
 
 int ivx_sampler_buffers(ivx_grid* g) {
     if (g->samp_ops) return IVX_OK;
-    IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_len), sizeof(uint32_t) * (2 * (size_t)g->n_chunks + 4)));
+    // [n] program lengths, [4] counters of the three evaluation lists, [3 n] the lists
+    IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_len), sizeof(uint32_t) * (4 * (size_t)g->n_chunks + 4)));
     IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_ops), sizeof(uint2) * (size_t)OP_CAP * g->n_chunks));
     return IVX_OK;
 }
@@ -875,7 +901,7 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
     uint32_t* eval_count = g->samp_len + g->n_chunks;
     uint32_t* eval_list = eval_count + 4;
     if (!g->scratch_preset) {
-        IVX_HIP_CHECK(hipMemsetAsync(eval_count, 0, sizeof(uint32_t), g->ctx->stream));
+        IVX_HIP_CHECK(hipMemsetAsync(eval_count, 0, 4 * sizeof(uint32_t), g->ctx->stream));
         IVX_HIP_CHECK(hipMemsetAsync(g->work_counts + 1, 0, sizeof(uint32_t), g->ctx->stream));
     }
     const uint32_t sx = (g->cc[0] + SUPER - 1) / SUPER, sy = (g->cc[1] + SUPER - 1) / SUPER, sz = (g->cc[2] + SUPER - 1) / SUPER;
@@ -894,14 +920,21 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
     uint2* super_skip = reinterpret_cast<uint2*>(g->samp_super + (((size_t)sx * sy * sz * words + 1u) & ~(size_t)1u));
     hipLaunchKernelGGL(k_sdf_super, dim3(sx * sy * sz), dim3(64), words * sizeof(uint32_t), g->ctx->stream, p, d_nodes, g->samp_super, super_skip, words, sy, sz);
     hipLaunchKernelGGL(k_sdf_prepass, dim3(sx * sy * sz), dim3(PRE_T), 0, g->ctx->stream, p, d_nodes, chunk_const, g->samp_len, ops, eval_count, eval_list,
-                       g->info, g->work_counts + 1, g->fill_list, g->samp_super, super_skip, words, sy, sz);
+                       g->n_chunks, g->info, g->work_counts + 1, g->fill_list, g->samp_super, super_skip, words, sy, sz);
     g->planes_compact = 1;
     hipLaunchKernelGGL(k_sdf_fill, dim3(g->n_chunks < 1024u ? g->n_chunks : 1024u), dim3(256), 0, g->ctx->stream, p, chunk_const, g->work_counts + 1,
                        g->fill_list, g->sdf, g->type, g->info);
     if (n_nodes) {
+        // one launch per LDS class (see k_sdf_prepass); a class the program cannot reach is not launched
         const uint32_t eval_blocks = g->n_chunks < 4096u ? g->n_chunks : 4096u;
-        hipLaunchKernelGGL(k_sdf_eval, dim3(eval_blocks), dim3(256), lds, g->ctx->stream, p, eval_count, eval_list, g->samp_len, ops, d_nodes, g->sdf, g->type,
-                           g->info);
+        const uint32_t levels[3] = {stack_size < 2u ? stack_size : 2u, 3u, stack_size};
+        for (uint32_t c = 0; c < 3; ++c) {
+            if (c > 0 && stack_size < levels[c]) break;
+            if (c == 2 && stack_size == 3u) break;
+            const size_t lds_c = (size_t)(levels[c] ? levels[c] : 1u) * IVX_CHUNK_VOXELS * sizeof(float);
+            hipLaunchKernelGGL(k_sdf_eval, dim3(eval_blocks), dim3(256), lds_c, g->ctx->stream, p, eval_count + c, eval_list + (size_t)c * g->n_chunks,
+                               g->samp_len, ops, d_nodes, g->sdf, g->type, g->info);
+        }
     }
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
