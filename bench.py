@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 
 
 STAGE_KERNELS = {  # which kernels make up a timed stage (names as rocprofv3 reports them)
-    "sdf_sample": ["k_sdf_prepass", "k_sdf_fill", "k_sdf_eval"],
+    "sdf_sample": ["k_sdf_super", "k_sdf_prepass", "k_sdf_eval"],
     "derive": ["k_chunk_pre", "k_derive"],  # k_derive also labels the chunk-local regions and leaves the chunk moments (fused sweep)
     "occupied": ["k_occupied_reduce"],
     "ccl_local": ["k_ccl_local_exact"],  # what is left of the stage after the fusion
@@ -44,7 +44,7 @@ STAGE_KERNELS = {  # which kernels make up a timed stage (names as rocprofv3 rep
     "sn_count": ["k_sn_count"],
     "sn_scan": ["k_sn_scan"],
     "sn_emit": ["k_sn_emit"],
-    "inertia": ["k_inertia_sum", "k_inertia_final"],
+    "inertia": ["k_inertia_sum"],
 }
 
 

@@ -232,7 +232,6 @@ int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32
     A(dev_alloc(&g->dens_dev, (size_t)256));
     A(dev_alloc(&g->work_counts, (size_t)8));
     A(dev_alloc(&g->active_list, (size_t)g->n_chunks));
-    A(dev_alloc(&g->fill_list, (size_t)g->n_chunks));
     A(dev_alloc(&g->chunk_class, (size_t)g->n_chunks));
     A(dev_alloc(&g->chunk_touch, (size_t)g->n_chunks));
     A(dev_alloc(&g->chunk_signs, (size_t)g->n_chunks * 256));
@@ -256,7 +255,7 @@ void ivx_grid_destroy(ivx_grid* g) {
     void* ptrs[] = {g->sdf, g->type, g->flags, g->llabel, g->info, g->ghost_sdf[0], g->ghost_sdf[1], g->ghost_type[0], g->ghost_type[1],
                     g->ghost_info[0], g->ghost_info[1], g->chunk_counts, g->chunk_offsets, g->positions, g->normals, g->indices,
                     g->index_materials, g->vertex_materials, g->submeshes, g->partials, g->rparent, g->rcompid, g->rscalar, g->ccl_scratch, g->group_sums, g->sn_list, g->dens_dev, g->dev_scratch, g->prog_nodes, g->chunk_bbox, g->samp_len, g->samp_ops, g->pairs_dev,
-                    g->work_counts, g->active_list, g->fill_list, g->chunk_class, g->chunk_moments, g->chunk_touch, g->chunk_signs, g->samp_super};
+                    g->work_counts, g->active_list, g->chunk_class, g->chunk_moments, g->chunk_touch, g->chunk_signs, g->samp_super};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->host_scratch) (void)hipHostFree(g->host_scratch);

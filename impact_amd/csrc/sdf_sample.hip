@@ -364,7 +364,6 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
                                                        float* __restrict__ chunk_const, uint32_t* __restrict__ prog_len,
                                                        uint2* __restrict__ prog_ops, uint32_t* __restrict__ eval_count,
                                                        uint32_t* __restrict__ eval_list, uint32_t list_stride, ivx_chunk_info* __restrict__ info_out,
-                                                       uint32_t* __restrict__ fill_count, uint32_t* __restrict__ fill_list,
                                                        const uint32_t* __restrict__ super_mask, const uint2* __restrict__ super_skip, uint32_t words,
                                                        uint32_t sy, uint32_t sz) {
     __shared__ uint2 s_skip[NODE_TILE];
@@ -573,8 +572,11 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
         // Evaluation lists by the number of LDS levels the chunk's compact program needs (k_sdf_eval gets one launch per
         // class, with that much LDS: residency, hence throughput, is set by LDS): class 0: <= 2 levels, 1: 3, 2: more (and
         // the chunks whose program did not fit OP_CAP, which run the full program).
+        // A constant chunk that still has planes to write (neither Void nor Uniform, or straddling the generator's grid) is
+        // evaluated like the others: its compact program is the one folded constant (or, for the saturated-bound case, the
+        // per-voxel program, which saturates to the same bytes) and the evaluator's store path handles the grid edge.
         const unsigned long long below = (1ull << tid) - 1ull;
-        const bool ev = mine && out != out;
+        const bool ev = mine && (out != out || to_fill);
         const uint32_t need = pos <= OP_CAP ? (uint32_t)s_need[0][tid] : p.stack_size;  // (the full program may use every level)
         const uint32_t cls = need <= 2u ? 0u : (need == 3u ? 1u : 2u);
 #pragma unroll
@@ -585,11 +587,6 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
             base_e = __shfl(base_e, 0, 64);
             if (ev && cls == c) eval_list[(size_t)c * list_stride + base_e + (uint32_t)__popcll(be & below)] = chunk;
         }
-        const unsigned long long bf = __ballot(to_fill);
-        uint32_t base_f = 0;
-        if (tid == 0 && bf) base_f = atomicAdd(fill_count, (uint32_t)__popcll(bf));
-        base_f = __shfl(base_f, 0, 64);
-        if (to_fill) fill_list[base_f + (uint32_t)__popcll(bf & below)] = chunk;
     }
 }
 
@@ -671,31 +668,6 @@ __device__ __forceinline__ void combine_levels(uint32_t kind, float s, float q, 
             apply_rows_dispatch(kind, d1 + tid, d2 + tid, c1, c2, v1, v2, s, q);
             cmask &= ~(1u << (top - 1));
         }
-    }
-}
-
-// Chunks the pre-pass proved constant (and everything when the program is empty): no LDS, one 16-byte store per plane
-// and thread. Kept apart from k_sdf_eval so that these ~90 % of the workgroups are not throttled by the evaluator's
-// 48-64 KiB of LDS per workgroup.
-__global__ __launch_bounds__(256) void k_sdf_fill(SampleParams p, const float* __restrict__ chunk_const, const uint32_t* __restrict__ fill_count,
-                                                  const uint32_t* __restrict__ fill_list, int8_t* __restrict__ sdf_out,
-                                                  uint8_t* __restrict__ type_out, ivx_chunk_info* __restrict__ info_out) {
-    const uint32_t tid = threadIdx.x;
-    const uint32_t ti = tid >> 4, tj = tid & 15u;
-    const uint32_t n_fill = fill_count[0];
-    // bounded grid-stride walk over the (short) list of constant chunks that are neither Void nor Uniform
-    for (uint32_t li = blockIdx.x; li < n_fill; li += gridDim.x) {
-        const uint32_t chunk = fill_list[li];
-        const uint32_t ck = chunk % p.cz, cj = (chunk / p.cz) % p.cy, ci = chunk / (p.cz * p.cy);
-        const uint32_t oi = (ci + p.x_off) * 16u, oj = cj * 16u, ok = ck * 16u;
-        const float cv = chunk_const[chunk];
-        int sd[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            bool in_grid = (oi + ti) < p.shape[0] && (oj + tj) < p.shape[1] && (ok + (uint32_t)k) < p.shape[2];
-            sd[k] = in_grid ? sd_from_f32(cv) : 127;
-        }
-        classify_and_store(sd, make_uint4(0, 0, 0, 0), true, 0, sdf_out, type_out, info_out, chunk, tid, true, p.voxel_type, true);
     }
 }
 
@@ -902,7 +874,6 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
     uint32_t* eval_list = eval_count + 4;
     if (!g->scratch_preset) {
         IVX_HIP_CHECK(hipMemsetAsync(eval_count, 0, 4 * sizeof(uint32_t), g->ctx->stream));
-        IVX_HIP_CHECK(hipMemsetAsync(g->work_counts + 1, 0, sizeof(uint32_t), g->ctx->stream));
     }
     const uint32_t sx = (g->cc[0] + SUPER - 1) / SUPER, sy = (g->cc[1] + SUPER - 1) / SUPER, sz = (g->cc[2] + SUPER - 1) / SUPER;
     const uint32_t words = (n_nodes + 31u) / 32u > 0u ? (n_nodes + 31u) / 32u : 1u;
@@ -920,11 +891,9 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
     uint2* super_skip = reinterpret_cast<uint2*>(g->samp_super + (((size_t)sx * sy * sz * words + 1u) & ~(size_t)1u));
     hipLaunchKernelGGL(k_sdf_super, dim3(sx * sy * sz), dim3(64), words * sizeof(uint32_t), g->ctx->stream, p, d_nodes, g->samp_super, super_skip, words, sy, sz);
     hipLaunchKernelGGL(k_sdf_prepass, dim3(sx * sy * sz), dim3(PRE_T), 0, g->ctx->stream, p, d_nodes, chunk_const, g->samp_len, ops, eval_count, eval_list,
-                       g->n_chunks, g->info, g->work_counts + 1, g->fill_list, g->samp_super, super_skip, words, sy, sz);
+                       g->n_chunks, g->info, g->samp_super, super_skip, words, sy, sz);
     g->planes_compact = 1;
-    hipLaunchKernelGGL(k_sdf_fill, dim3(g->n_chunks < 1024u ? g->n_chunks : 1024u), dim3(256), 0, g->ctx->stream, p, chunk_const, g->work_counts + 1,
-                       g->fill_list, g->sdf, g->type, g->info);
-    if (n_nodes) {
+    {
         // one launch per LDS class (see k_sdf_prepass); a class the program cannot reach is not launched
         const uint32_t eval_blocks = g->n_chunks < 4096u ? g->n_chunks : 4096u;
         const uint32_t levels[3] = {stack_size < 2u ? stack_size : 2u, 3u, stack_size};
