@@ -44,7 +44,7 @@ STAGE_KERNELS = {  # which kernels make up a timed stage (names as rocprofv3 rep
     "sn_count": ["k_sn_count"],
     "sn_scan": ["k_sn_scan"],
     "sn_emit": ["k_sn_emit"],
-    "inertia": ["k_inertia_sum"],
+    "inertia": ["k_inertia_sum", "k_inertia_final"],
 }
 
 

@@ -422,7 +422,6 @@ __global__ __launch_bounds__(256) void k_step_preset(uint32_t stages, uint32_t* 
     if ((stages & IVX_STAGE_OCCUPIED) && i < 12u) rscalar[16 + i] = i < 6u ? 0xFFFFFFFFu : 0u;
     if ((stages & IVX_STAGE_REMESH) && i < n_sn) sn_sums[i] = 0u;
     if ((stages & IVX_STAGE_SAMPLE) && i < 3u && eval_count) eval_count[i] = 0u;  // the three evaluation lists
-    if ((stages & IVX_STAGE_INERTIA) && i == 0) work_counts[1] = 0u;
     if ((stages & IVX_STAGE_DERIVE) && i == 0) work_counts[0] = 0u;
 }
 

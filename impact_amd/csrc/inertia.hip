@@ -55,8 +55,7 @@ __global__ __launch_bounds__(256) void k_inertia_dense(GridView g, uint32_t x_of
 // (compute_moments_for_uniform_chunk, inertia.rs:703-754) and its moments are closed forms of its origin
 // [sum_{X=X0}^{X0+15} (2X+1) = 32 X0 + 256; sum (3X^2+3X+1) = (X0+16)^3 - X0^3]; a NonUniform chunk contributes its slot.
 __global__ __launch_bounds__(256) void k_inertia_sum(GridView g, uint32_t x_off, const float* __restrict__ dens,
-                                                     const double* __restrict__ chunk_moments, double* partials, uint32_t* __restrict__ done_count,
-                                                     float extent, double* __restrict__ out10) {
+                                                     const double* __restrict__ chunk_moments, double* __restrict__ partials) {
     __shared__ double s_red[4][10];
     const uint32_t tid = threadIdx.x;
     const uint32_t n_chunks = g.cx * g.cy * g.cz;
@@ -93,26 +92,19 @@ __global__ __launch_bounds__(256) void k_inertia_sum(GridView g, uint32_t x_off,
     }
     __syncthreads();
     if (tid < 10) partials[(size_t)blockIdx.x * 10 + tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
-    // The workgroup that finishes last adds the partials up in block order (bitwise reproducible: the order does not depend on
-    // which workgroup that is) and applies the e^3, e^4/2, e^5/3, e^5/4 factors: no second launch.
-    __shared__ uint32_t s_last;
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) s_last = atomicAdd(done_count, 1u) == gridDim.x - 1u ? 1u : 0u;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    if (wave < 3) {  // 3 waves x 4 moments (10 used): lane b sums blocks b, b+64, ... then a fixed shuffle tree
-        for (uint32_t q = wave * 4u; q < min(wave * 4u + 4u, 10u); ++q) {
-            double acc = 0.0;
-            for (uint32_t b = lane; b < gridDim.x; b += 64u) acc += __builtin_nontemporal_load(partials + (size_t)b * 10 + q);
-            acc = wave_sum(acc);
-            if (lane == 0) {
-                const double e = (double)extent, e2 = e * e, e3 = e2 * e, e4 = e2 * e2, e5 = e4 * e;
-                const double f = q == 0 ? e3 : (q <= 3 ? 0.5 * e4 : (q <= 6 ? (1.0 / 3.0) * e5 : 0.25 * e5));
-                out10[q] = acc * f;
-            }
-        }
+}
+
+// fixed-order (bitwise reproducible) reduction of the per-block partials: wave q sums moment q — every lane a
+// strided subset in index order, then a fixed shuffle tree
+__global__ __launch_bounds__(640) void k_inertia_final(uint32_t n_blocks, float extent, const double* __restrict__ partials, double* __restrict__ out) {
+    const uint32_t q = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    double s = 0.0;
+    for (uint32_t b = lane; b < n_blocks; b += 64) s += partials[(size_t)b * 10 + q];
+    s = wave_sum(s);
+    if (lane == 0) {
+        const double e = (double)extent, e2 = e * e, e3 = e2 * e, e4 = e2 * e2, e5 = e4 * e;
+        const double f = q == 0 ? e3 : (q <= 3 ? 0.5 * e4 : (q <= 6 ? (1.0 / 3.0) * e5 : 0.25 * e5));
+        out[q] = s * f;
     }
 }
 
@@ -125,9 +117,8 @@ int ivx_launch_inertia(ivx_grid* g, const float* d_dens, double* d_out10, int fu
     if (!fused)  // else k_derive left the chunk moments in the same sweep
         hipLaunchKernelGGL(k_inertia_dense, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->x_off, g->flags, d_dens, g->chunk_moments, g->work_counts,
                        g->active_list);
-    if (!g->scratch_preset) IVX_HIP_CHECK(hipMemsetAsync(g->work_counts + 1, 0, sizeof(uint32_t), g->ctx->stream));
-    hipLaunchKernelGGL(k_inertia_sum, dim3(blocks), dim3(256), 0, g->ctx->stream, v, g->x_off, d_dens, g->chunk_moments, g->partials, g->work_counts + 1,
-                       g->extent, d_out10);
+    hipLaunchKernelGGL(k_inertia_sum, dim3(blocks), dim3(256), 0, g->ctx->stream, v, g->x_off, d_dens, g->chunk_moments, g->partials);
+    hipLaunchKernelGGL(k_inertia_final, dim3(1), dim3(640), 0, g->ctx->stream, blocks, g->extent, g->partials, d_out10);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

@@ -87,7 +87,7 @@ struct ivx_grid {
     // list-driven stages: k_chunk_pre settles every chunk whose per-step state follows from the chunk records alone (Void,
     // and Uniform chunks surrounded by Uniform chunks: ~85 % of a solid body's chunks) with one THREAD each and lists the
     // rest; the workgroup-per-chunk kernels then walk that list instead of being launched once per chunk of the grid.
-    uint32_t* work_counts;  // [8]: [0] chunks on the active list, [1] workgroups of k_inertia_sum that have finished
+    uint32_t* work_counts;  // [8]: [0] chunks on the active list, [1..8) spare
     uint32_t* active_list;  // [n_chunks]
     uint8_t* chunk_class;   // [n_chunks] 1: settled by k_chunk_pre
     uint16_t* chunk_signs;  // [n_chunks * 256] active chunks: 16-bit "distance negative" mask of every (i,j) row (k_derive), what

@@ -144,3 +144,50 @@ def test_empty_and_full_objects(ctx):
         pu.assert_regions_equal(o, g)
         g.update_occupied_voxel_ranges()
         assert g.occupied_voxel_ranges == o.info()["occupied_voxel_ranges"]
+
+
+# ---- shapes that stress the list-driven / column-structured kernels ---------------------------------------------------------
+def _boxes_along(axis, centres, half=(5.0, 5.0, 5.0), long_half=None, smooth=0.0):
+    """union of boxes centred at `centres` along `axis`; `long_half` = half extent along the axis"""
+    g = SDFGraph()
+    acc = None
+    for c in centres:
+        h = list(half)
+        if long_half is not None:
+            h[axis] = long_half
+        b = g.add_node(SDFNode.new_box([2.0 * x for x in h]))
+        t = [0.0, 0.0, 0.0]
+        t[axis] = float(c)
+        tb = g.add_node(SDFNode.new_translation(b, t))
+        acc = tb if acc is None else g.add_node(SDFNode.new_union(acc, tb, smooth))
+    return g
+
+
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_long_thin_rod_more_than_64_chunks(ctx, axis):
+    """one rod of 1100 voxels: a chunk column of 70 chunks (the column merge works in segments of 64 chunks), grids of
+    1 x 1 x 70 chunks (fewer chunks than a workgroup has threads, chunk counts that are not multiples of a super-block)"""
+    full_pipeline(ctx, _boxes_along(axis, [0.0], long_half=550.0), expect_regions=1)
+
+
+def test_three_rods_in_one_column(ctx):
+    """three separate bodies stacked along z in the same chunk column, the column longer than 64 chunks: three regions, runs
+    that start and stop inside and across the 64-chunk segments"""
+    full_pipeline(ctx, _boxes_along(2, [-420.0, 0.0, 420.0], long_half=190.0), expect_regions=3)
+
+
+def test_row_of_many_small_bodies(ctx):
+    """24 bodies in a row (a long program: far bodies are replaced by their folded constants per super-block), every second
+    pair joined by a smooth union"""
+    g = SDFGraph()
+    acc = None
+    for i in range(24):
+        s = g.add_node(SDFNode.new_sphere(9.0 + (i % 3)))
+        t = g.add_node(SDFNode.new_translation(s, (26.0 * i, 3.0 * ((i * 7) % 5 - 2), 2.0 * ((i * 3) % 4))))
+        acc = t if acc is None else g.add_node(SDFNode.new_union(acc, t, 6.0 if i % 2 else 0.0))
+    full_pipeline(ctx, g)
+
+
+def test_plate_one_chunk_thick(ctx):
+    """a 300 x 300 x 6 plate: every chunk is a surface chunk, no Uniform chunks at all"""
+    full_pipeline(ctx, scenes.box_scene((300.0, 300.0, 6.0)), expect_regions=1)
