@@ -329,18 +329,25 @@ __global__ __launch_bounds__(256) void k_ccl_flatten(GridView g, uint32_t* __res
         // safe while other threads still walk the forest: the parent only moves closer to the root
         else __hip_atomic_store(rparent + node, root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (live) root_counts[chunk] = n;
-    // total of this group of 256 chunks (first level of the two-level scan)
-    uint32_t t = n;
+    // exclusive prefix of the root counts inside this group of 256 chunks (ordered) and the group's total: the two levels of
+    // the scan; k_ccl_assign adds the totals of the groups before
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = n;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
-    if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = t;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= (uint32_t)o) incl += t;
+    }
+    if (lane == 63u) s_w[wave] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) group_sums[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    const uint32_t w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
+    const uint32_t wbase = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
+    if (live) root_counts[chunk] = wbase + incl - n;  // (the count itself is not needed again)
+    if (threadIdx.x == 0) group_sums[blockIdx.x] = (w0 + w1) + (w2 + w3);
 }
 
-// Second level of the two-level exclusive scan: block b scans its 256 values on top of the sum of the group totals
-// before it (every block adds up those few totals itself, so there is no third launch).
+// Grids of more than ASSIGN_MAX_GROUPS x 256 chunks: a launch of its own adds the totals of the groups before a chunk's group to
+// the in-group prefix k_ccl_flatten left (every block adds up those totals itself).
 __global__ __launch_bounds__(256) void k_scan_groups(uint32_t n, const uint32_t* __restrict__ in, const uint32_t* __restrict__ group_sums,
                                                      uint32_t* __restrict__ out, uint32_t* __restrict__ total) {
     __shared__ uint32_t s_w[4];
@@ -356,26 +363,41 @@ __global__ __launch_bounds__(256) void k_scan_groups(uint32_t n, const uint32_t*
     __syncthreads();
     const uint32_t base = s_base;
     const uint32_t c = blockIdx.x * 256u + tid;
-    const uint32_t v = c < n ? in[c] : 0u;
-    uint32_t incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o, 64);
-        if (lane >= (uint32_t)o) incl += t;
-    }
-    __syncthreads();
-    if (lane == 63u) s_w[wave] = incl;
-    __syncthreads();
-    const uint32_t w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
-    const uint32_t wbase = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
-    if (c < n) out[c] = base + wbase + incl - v;
-    if (blockIdx.x == gridDim.x - 1 && tid == 255) *total = base + w0 + w1 + w2 + w3;
+    if (c < n) out[c] = base + in[c];
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) *total = base + group_sums[blockIdx.x];
 }
 
 // component ids: rank of the root node in (chunk, region) order; a non-root takes the id of its root, computed from the
 // root's chunk offset and the root's rank among the roots of that chunk
+#ifndef IVX_ASSIGN_MAX_GROUPS
+#define IVX_ASSIGN_MAX_GROUPS 2048
+#endif
+constexpr uint32_t ASSIGN_MAX_GROUPS = IVX_ASSIGN_MAX_GROUPS;  // 524 288 chunks; larger grids take the k_scan_groups path
+// FUSED: the scan over the group totals happens here (every block scans the few totals itself in LDS), root_offsets[c] is the
+// prefix inside c's group; otherwise root_offsets[c] is the full prefix from k_scan_groups.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void k_ccl_assign(GridView g, const uint32_t* __restrict__ rparent, const uint32_t* __restrict__ root_offsets,
-                                                    uint32_t* __restrict__ rcompid) {
+                                                    const uint32_t* __restrict__ group_sums, uint32_t n_groups, uint32_t* __restrict__ rcompid,
+                                                    uint32_t* __restrict__ total) {
+    __shared__ uint32_t s_gpre[FUSED ? ASSIGN_MAX_GROUPS : 1];
+    __shared__ uint32_t s_carry;
+    if (FUSED) {
+        // exclusive scan of the group totals, 256 at a time
+        if (threadIdx.x == 0) s_carry = 0;
+        __syncthreads();
+        for (uint32_t g0 = 0; g0 < n_groups; g0 += 256u) {
+            const uint32_t gi = g0 + threadIdx.x;
+            const uint32_t v = gi < n_groups ? group_sums[gi] : 0u;
+            uint32_t tot;
+            __shared__ uint32_t s_ws[4];
+            const uint32_t ex = prefix_ordered(v, s_ws, threadIdx.x, tot);
+            if (gi < n_groups) s_gpre[gi] = s_carry + ex;
+            __syncthreads();
+            if (threadIdx.x == 0) s_carry += tot;
+            __syncthreads();
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) *total = s_carry;
+    }
     const uint32_t chunk = blockIdx.x * 256u + threadIdx.x;
     if (chunk >= g.cx * g.cy * g.cz) return;
     const uint32_t rc = g.info[chunk].region_count;
@@ -385,7 +407,7 @@ __global__ __launch_bounds__(256) void k_ccl_assign(GridView g, const uint32_t* 
         const uint32_t rchunk = root >> 8, rr = root & 255u;
         uint32_t rank = 0;
         for (uint32_t q = 0; q < rr; ++q) rank += rparent[rchunk * 256u + q] == rchunk * 256u + q;
-        rcompid[node] = root_offsets[rchunk] + rank;
+        rcompid[node] = root_offsets[rchunk] + rank + (FUSED ? s_gpre[rchunk >> 8] : 0u);
     }
 }
 
@@ -638,8 +660,12 @@ int ivx_launch_ccl_resolve(ivx_grid* g) {
     const uint32_t nb = (g->n_chunks + 255u) / 256u;
     uint32_t* group_sums = g->group_sums;
     hipLaunchKernelGGL(k_ccl_flatten, dim3(nb), dim3(256), 0, g->ctx->stream, v, g->rparent, root_counts, group_sums);
-    hipLaunchKernelGGL(k_scan_groups, dim3(nb), dim3(256), 0, g->ctx->stream, g->n_chunks, root_counts, group_sums, root_offsets, g->rscalar);
-    hipLaunchKernelGGL(k_ccl_assign, dim3(nb), dim3(256), 0, g->ctx->stream, v, g->rparent, root_offsets, g->rcompid);
+    if (nb <= ASSIGN_MAX_GROUPS) {
+        hipLaunchKernelGGL(k_ccl_assign<true>, dim3(nb), dim3(256), 0, g->ctx->stream, v, g->rparent, root_counts, group_sums, nb, g->rcompid, g->rscalar);
+    } else {
+        hipLaunchKernelGGL(k_scan_groups, dim3(nb), dim3(256), 0, g->ctx->stream, g->n_chunks, root_counts, group_sums, root_offsets, g->rscalar);
+        hipLaunchKernelGGL(k_ccl_assign<false>, dim3(nb), dim3(256), 0, g->ctx->stream, v, g->rparent, root_offsets, group_sums, nb, g->rcompid, g->rscalar);
+    }
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

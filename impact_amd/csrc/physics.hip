@@ -125,10 +125,8 @@ __device__ __forceinline__ AngVel body_angular_velocity(const ivx_rigid_body& b)
 }
 
 // ---- per-body kernels ------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prepare_bodies(uint32_t n_dyn, uint32_t n_kin, const ivx_rigid_body* __restrict__ dyn,
-                                                        const ivx_kinematic_body* __restrict__ kin, PhysBody* __restrict__ cb,
-                                                        uint8_t* __restrict__ touched) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+__device__ __forceinline__ void prepare_body(uint32_t i, uint32_t n_dyn, uint32_t n_kin, const ivx_rigid_body* dyn, const ivx_kinematic_body* kin,
+                                             PhysBody* cb, uint8_t* touched) {
     if (i >= n_dyn + n_kin) return;
     PhysBody c;
     if (i < n_dyn) {
@@ -151,6 +149,11 @@ __global__ __launch_bounds__(256) void k_prepare_bodies(uint32_t n_dyn, uint32_t
     }
     c.pad = 0.0f;
     cb[i] = c;
+}
+__global__ __launch_bounds__(256) void k_prepare_bodies(uint32_t n_dyn, uint32_t n_kin, const ivx_rigid_body* __restrict__ dyn,
+                                                        const ivx_kinematic_body* __restrict__ kin, PhysBody* __restrict__ cb,
+                                                        uint8_t* __restrict__ touched) {
+    prepare_body(blockIdx.x * 256u + threadIdx.x, n_dyn, n_kin, dyn, kin, cb, touched);
 }
 
 __device__ __forceinline__ V3 to_world(const float* pos, const float* q, V3 p) { return qrot(ldq(q), p) + ld3(pos); }
@@ -211,8 +214,7 @@ __global__ __launch_bounds__(256) void k_prepare_contacts(uint32_t n, uint32_t n
     if (ib < n_dyn) touched[ib] = 1;
 }
 
-__global__ __launch_bounds__(256) void k_pre_solve(uint32_t n_dyn, float dt, ivx_rigid_body* __restrict__ dyn, PhysBody* __restrict__ cb) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+__device__ __forceinline__ void pre_solve_body(uint32_t i, uint32_t n_dyn, float dt, ivx_rigid_body* dyn, PhysBody* cb) {
     if (i >= n_dyn) return;
     ivx_rigid_body b = dyn[i];
     st3(b.momentum, ld3(b.momentum) + ld3(b.total_force) * dt);
@@ -223,11 +225,12 @@ __global__ __launch_bounds__(256) void k_pre_solve(uint32_t n_dyn, float dt, ivx
     st3(cb[i].v, body_velocity(b));
     st3(cb[i].w, angvel_vector(body_angular_velocity(b)));
 }
+__global__ __launch_bounds__(256) void k_pre_solve(uint32_t n_dyn, float dt, ivx_rigid_body* __restrict__ dyn, PhysBody* __restrict__ cb) {
+    pre_solve_body(blockIdx.x * 256u + threadIdx.x, n_dyn, dt, dyn, cb);
+}
 
-__global__ __launch_bounds__(256) void k_post_solve(uint32_t n_dyn, uint32_t n_kin, float dt, int write_back, int advance,
-                                                    const PhysBody* __restrict__ cb, const uint8_t* __restrict__ touched,
-                                                    ivx_rigid_body* __restrict__ dyn, ivx_kinematic_body* __restrict__ kin) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+__device__ __forceinline__ void post_solve_body(uint32_t i, uint32_t n_dyn, uint32_t n_kin, float dt, int write_back, int advance, const PhysBody* cb,
+                                                const uint8_t* touched, ivx_rigid_body* dyn, ivx_kinematic_body* kin) {
     if (i >= n_dyn + n_kin) return;
     if (i < n_dyn) {
         ivx_rigid_body b = dyn[i];
@@ -256,6 +259,21 @@ __global__ __launch_bounds__(256) void k_post_solve(uint32_t n_dyn, uint32_t n_k
         stq(k.orientation, qnormalize(qmul(Q4{im.x, im.y, im.z, co}, ldq(k.orientation))));
         kin[i - n_dyn] = k;
     }
+}
+__global__ __launch_bounds__(256) void k_post_solve(uint32_t n_dyn, uint32_t n_kin, float dt, int write_back, int advance,
+                                                    const PhysBody* __restrict__ cb, const uint8_t* __restrict__ touched,
+                                                    ivx_rigid_body* __restrict__ dyn, ivx_kinematic_body* __restrict__ kin) {
+    post_solve_body(blockIdx.x * 256u + threadIdx.x, n_dyn, n_kin, dt, write_back, advance, cb, touched, dyn, kin);
+}
+
+// A step without contacts (a free body, e.g. a voxel object's own rigid body between collisions) is three element-wise passes
+// over the bodies: one launch runs them back to back per body (each thread reads back only what it wrote itself).
+__global__ __launch_bounds__(256) void k_free_step(uint32_t n_dyn, uint32_t n_kin, float dt, ivx_rigid_body* dyn, ivx_kinematic_body* kin, PhysBody* cb,
+                                                   uint8_t* touched) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    prepare_body(i, n_dyn, n_kin, dyn, kin, cb, touched);
+    pre_solve_body(i, n_dyn, dt, dyn, cb);
+    post_solve_body(i, n_dyn, n_kin, dt, 1, 1, cb, touched, dyn, kin);
 }
 
 // ---- the solve -----------------------------------------------------------------------------------
@@ -536,6 +554,14 @@ int ivx_launch_phys_solve(ivx_world* w) {
         else rc = launch_solve<false, 1>(w, 0);
         if (rc) return rc;
     }
+    return IVX_OK;
+}
+
+int ivx_launch_phys_free_step(ivx_world* w, float dt) {
+    const uint32_t n = w->n_dyn + w->n_kin;
+    if (n == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_free_step, dim3((n + 255u) / 256u), dim3(256), 0, w->ctx->stream, w->n_dyn, w->n_kin, dt, w->dyn, w->kin, w->cb, w->touched);
+    IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 

@@ -450,6 +450,15 @@ int ivx_world_step_enqueue(ivx_world* w, float dt) {
         w->ev_ready = 1;
     }
     int rc;
+    if (w->n_contacts == 0 && !w->prepared_fresh) {
+        // no constraints this step: prepare, advance momenta and advance configurations are element-wise per body — one launch
+        w->cur ^= 1;
+        w->n_prev = 0;
+        for (int i = 0; i < 4; ++i) IVX_HIP_CHECK(hipEventRecord(w->ev[i], s));
+        if ((rc = ivx_launch_phys_free_step(w, dt))) return rc;
+        IVX_HIP_CHECK(hipEventRecord(w->ev[4], s));
+        return IVX_OK;
+    }
     IVX_HIP_CHECK(hipEventRecord(w->ev[0], s));
     if (!w->prepared_fresh)
         if ((rc = ivx_world_prepare(w))) return rc;

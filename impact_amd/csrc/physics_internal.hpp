@@ -77,4 +77,5 @@ int ivx_launch_phys_prepare_bodies(ivx_world* w);
 int ivx_launch_phys_prepare_contacts(ivx_world* w, const int32_t* d_prev_slot);
 int ivx_launch_phys_pre_solve(ivx_world* w, float dt);
 int ivx_launch_phys_solve(ivx_world* w);
+int ivx_launch_phys_free_step(ivx_world* w, float dt);
 int ivx_launch_phys_post_solve(ivx_world* w, float dt, int write_back, int advance);

@@ -177,4 +177,12 @@ def test_free_bodies_integrate_exactly_like_the_oracle(ctx):
     for _ in range(20):
         pu.step_both(w, o, none, 0.01)
     pu.assert_bodies_close(w.bodies()[0], o.bodies()[0])
+    # the contact list stays empty: `step` / `step_enqueue` without a new `prepare_constraints` take the single-launch path
+    for k in range(10):
+        o.step(none, 0.01)
+        if k % 2:
+            w.step(0.01)
+        else:
+            w.step_enqueue(0.01)
+    pu.assert_bodies_close(w.bodies()[0], o.bodies()[0])
     w.close()
