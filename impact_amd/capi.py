@@ -123,7 +123,7 @@ EXPORTED_SYMBOLS = [
     "ivx_inertia",
     "ivx_label_regions", "ivx_region_labels_download", "ivx_regions_describe", "ivx_split_off_smallest_region", "ivx_clip_polyhedron",
     "ivx_grid_set_sdf_program", "ivx_grid_set_densities", "ivx_voxel_step", "ivx_voxel_step_enqueue", "ivx_voxel_step_collect",
-    "ivx_halo_pack_enqueue", "ivx_halo_unpack_enqueue", "ivx_region_face_labels_enqueue", "ivx_region_face_pairs_enqueue",
+    "ivx_halo_pack_enqueue", "ivx_halo_unpack_enqueue", "ivx_halo_pack_both_enqueue", "ivx_region_face_labels_enqueue", "ivx_region_face_pairs_enqueue",
     "ivx_step_record_words", "ivx_step_record_enqueue",
     "ivx_halo_bytes", "ivx_halo_pack", "ivx_halo_unpack", "ivx_halo_clear",
     "ivx_region_face_bytes", "ivx_region_face_labels", "ivx_region_face_pairs",
@@ -200,6 +200,7 @@ def lib():
         "ivx_voxel_step_collect": (i32, [vp, vp]),
         "ivx_halo_pack_enqueue": (i32, [vp, i32, vp]),
         "ivx_halo_unpack_enqueue": (i32, [vp, i32, vp]),
+        "ivx_halo_pack_both_enqueue": (i32, [vp, vp, vp, i32]),
         "ivx_region_face_labels_enqueue": (i32, [vp, i32, vp]),
         "ivx_region_face_pairs_enqueue": (i32, [vp, i32, vp]),
         "ivx_step_record_words": (sz, []),

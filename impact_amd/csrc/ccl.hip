@@ -428,24 +428,55 @@ __global__ __launch_bounds__(256) void k_ccl_dense(uint32_t n_chunks, const uint
 // distinct (own component, neighbour component) pairs across that face. Together with an all-gather
 // of the pairs this is the cross-chunk connection step of the reference's global resolve
 // (split_detection.rs:323-487, 1046-1325) carried across ranks.
-__global__ __launch_bounds__(256) void k_face_ids(GridView g, uint32_t side, const uint8_t* __restrict__ labels,
-                                                  const uint32_t* __restrict__ rcompid, uint32_t* __restrict__ out) {
-    const uint32_t col = blockIdx.x, tid = threadIdx.x;
+// slab-local component id of a face voxel as 16 bits (0xFFFF = empty): what crosses the link per face voxel. A slab with
+// 65 535 or more components cannot be described this way: error bit 2 in rscalar[1].
+__device__ __forceinline__ uint32_t face_id16(const GridView& g, uint32_t side, uint32_t col, uint32_t tid, const uint8_t* labels, const uint32_t* rcompid,
+                                              uint32_t* rscalar) {
     const uint32_t chunk = (side ? g.cx - 1 : 0u) * g.cy * g.cz + col;
     const uint32_t ckind = g.info[chunk].kind;
     const uint32_t l = ckind != KIND_NONUNIFORM ? ivx_uniform_label(ckind) : labels[(size_t)chunk * IVX_CHUNK_VOXELS + ((side ? 15u : 0u) << 8) + tid];
-    out[(size_t)col * 256 + tid] = l == 255u ? NODE_NONE : rcompid[chunk * 256u + l];
+    if (l == 255u) return 0xFFFFu;
+    const uint32_t id = rcompid[chunk * 256u + l];
+    if (id >= 0xFFFFu) atomicOr(&rscalar[1], 4u);
+    return id & 0xFFFFu;
+}
+__global__ __launch_bounds__(256) void k_face_ids(GridView g, uint32_t side, const uint8_t* __restrict__ labels,
+                                                  const uint32_t* __restrict__ rcompid, uint32_t* __restrict__ rscalar, uint16_t* __restrict__ out) {
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = (uint16_t)face_id16(g, side, blockIdx.x, threadIdx.x, labels, rcompid, rscalar);
+}
+
+// Both faces of a slab in one launch (blockIdx.y = side): the one-voxel face planes of (sdf, type) + the face layer's chunk
+// records, and — after the region stages — the component ids of the face voxels right behind them. A chunk that is only its
+// record (compact planes) is expanded here.
+__global__ __launch_bounds__(256) void k_halo_pack_both(GridView g, uint8_t* __restrict__ out_lo, uint8_t* __restrict__ out_hi, uint32_t with_ids,
+                                                        const uint8_t* __restrict__ labels, const uint32_t* __restrict__ rcompid,
+                                                        uint32_t* __restrict__ rscalar) {
+    const uint32_t col = blockIdx.x, side = blockIdx.y, tid = threadIdx.x;
+    uint8_t* out = side ? out_hi : out_lo;
+    if (!out) return;
+    const size_t cols = (size_t)g.cy * g.cz;
+    const uint32_t chunk = (side ? g.cx - 1 : 0u) * g.cy * g.cz + col;
+    const size_t src = (size_t)chunk * IVX_CHUNK_VOXELS + ((side ? 15u : 0u) << 8) + tid;
+    const ivx_chunk_info rec = g.info[chunk];
+    const bool dense = rec.kind == KIND_NONUNIFORM;
+    out[(size_t)col * 256 + tid] = dense ? (uint8_t)g.sdf[src] : (uint8_t)ivx_uniform_sdf(rec.kind);
+    out[cols * 256 + (size_t)col * 256 + tid] = dense ? g.type[src] : (uint8_t)ivx_uniform_type(rec);
+    if (tid == 0) reinterpret_cast<ivx_chunk_info*>(out + cols * 512)[col] = rec;
+    if (with_ids)
+        reinterpret_cast<uint16_t*>(out + cols * (512 + sizeof(ivx_chunk_info)))[(size_t)col * 256 + tid] =
+            (uint16_t)face_id16(g, side, col, tid, labels, rcompid, rscalar);
 }
 
 __global__ __launch_bounds__(256) void k_face_pairs(GridView g, uint32_t side, const uint8_t* __restrict__ labels,
-                                                    const uint32_t* __restrict__ rcompid, const uint32_t* __restrict__ nbr,
+                                                    const uint32_t* __restrict__ rcompid, const uint16_t* __restrict__ nbr,
                                                     uint32_t* __restrict__ n_pairs, uint2* __restrict__ pairs, uint32_t cap, uint32_t* __restrict__ seen) {
     const uint32_t col = blockIdx.x, tid = threadIdx.x;
     const uint32_t chunk = (side ? g.cx - 1 : 0u) * g.cy * g.cz + col;
     const uint32_t ckind = g.info[chunk].kind;
     const uint32_t l = ckind != KIND_NONUNIFORM ? ivx_uniform_label(ckind) : labels[(size_t)chunk * IVX_CHUNK_VOXELS + ((side ? 15u : 0u) << 8) + tid];
     const uint32_t a = l == 255u ? NODE_NONE : rcompid[chunk * 256u + l];
-    const uint32_t b = nbr[(size_t)col * 256 + tid];
+    const uint32_t b16 = nbr[(size_t)col * 256 + tid];
+    const uint32_t b = b16 == 0xFFFFu ? NODE_NONE : b16;
     const bool both = a != NODE_NONE && b != NODE_NONE;
     // drop repeats along the lane order (one wave = four rows of 16 face voxels)
     const uint32_t pa = __shfl_up(a, 1, 64), pb = __shfl_up(b, 1, 64);
@@ -680,17 +711,29 @@ int ivx_launch_ccl_dense_labels(ivx_grid* g, uint32_t* d_labels) {
     return IVX_OK;
 }
 
-int ivx_launch_face_ids(ivx_grid* g, int side, uint32_t* d_out) {
+int ivx_launch_halo_pack_both(ivx_grid* g, void* buf_lo, void* buf_hi, int with_face_labels) {
     GridView v = ivx_view(g);
-    hipLaunchKernelGGL(k_face_ids, dim3(g->cc[1] * g->cc[2]), dim3(256), 0, g->ctx->stream, v, (uint32_t)side, g->llabel, g->rcompid, d_out);
+    hipLaunchKernelGGL(k_halo_pack_both, dim3(g->cc[1] * g->cc[2], 2), dim3(256), 0, g->ctx->stream, v, static_cast<uint8_t*>(buf_lo),
+                       static_cast<uint8_t*>(buf_hi), with_face_labels ? 1u : 0u, g->llabel, g->rcompid, g->rscalar);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 
-int ivx_launch_face_pairs(ivx_grid* g, int side, const uint32_t* d_nbr, uint32_t* d_count, void* d_pairs, uint32_t cap, uint32_t* d_seen) {
+int ivx_launch_face_ids(ivx_grid* g, int side, uint16_t* d_out) {
     GridView v = ivx_view(g);
-    IVX_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t), g->ctx->stream));
-    if (d_seen) IVX_HIP_CHECK(hipMemsetAsync(d_seen, 0, 128 * sizeof(uint32_t), g->ctx->stream));
+    hipLaunchKernelGGL(k_face_ids, dim3(g->cc[1] * g->cc[2]), dim3(256), 0, g->ctx->stream, v, (uint32_t)side, g->llabel, g->rcompid, g->rscalar, d_out);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+int ivx_launch_face_pairs(ivx_grid* g, int side, const uint16_t* d_nbr, uint32_t* d_count, void* d_pairs, uint32_t cap, uint32_t* d_seen) {
+    GridView v = ivx_view(g);
+    if (d_seen == d_count + 4) {  // count and seen-table are neighbours (the enqueue path): one fill
+        IVX_HIP_CHECK(hipMemsetAsync(d_count, 0, (4 + 128) * sizeof(uint32_t), g->ctx->stream));
+    } else {
+        IVX_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t), g->ctx->stream));
+        if (d_seen) IVX_HIP_CHECK(hipMemsetAsync(d_seen, 0, 128 * sizeof(uint32_t), g->ctx->stream));
+    }
     hipLaunchKernelGGL(k_face_pairs, dim3(g->cc[1] * g->cc[2]), dim3(256), 0, g->ctx->stream, v, (uint32_t)side, g->llabel, g->rcompid, d_nbr,
                        d_count, static_cast<uint2*>(d_pairs), cap, d_seen);
     IVX_HIP_CHECK(hipGetLastError());

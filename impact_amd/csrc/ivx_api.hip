@@ -714,12 +714,12 @@ int ivx_clip_polyhedron(ivx_grid* parent, const float* planes4, size_t n_planes,
     return IVX_OK;
 }
 
-size_t ivx_region_face_bytes(ivx_grid* g) { return g ? (size_t)g->cc[1] * g->cc[2] * 256 * sizeof(uint32_t) : 0; }
+size_t ivx_region_face_bytes(ivx_grid* g) { return g ? (size_t)g->cc[1] * g->cc[2] * 256 * sizeof(uint16_t) : 0; }
 
 int ivx_region_face_labels(ivx_grid* g, int side, void* device_buf) {
     IVX_REQUIRE(g && device_buf && (side == 0 || side == 1), IVX_ERR_INVALID, "ivx_region_face_labels: bad argument");
     IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "ivx_region_face_labels: call ivx_label_regions first");
-    int rc = ivx_launch_face_ids(g, side, static_cast<uint32_t*>(device_buf));
+    int rc = ivx_launch_face_ids(g, side, static_cast<uint16_t*>(device_buf));
     if (rc) return rc;
     IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
     return IVX_OK;
@@ -734,7 +734,7 @@ int ivx_region_face_pairs(ivx_grid* g, int side, const void* neighbour_face_labe
     if ((rc = ensure_dev_scratch(g, 16 + face * 8))) return rc;
     uint32_t* d_count = static_cast<uint32_t*>(g->dev_scratch);
     void* d_pairs = static_cast<char*>(g->dev_scratch) + 16;
-    if ((rc = ivx_launch_face_pairs(g, side, static_cast<const uint32_t*>(neighbour_face_labels), d_count, d_pairs, (uint32_t)face, nullptr))) return rc;
+    if ((rc = ivx_launch_face_pairs(g, side, static_cast<const uint16_t*>(neighbour_face_labels), d_count, d_pairs, (uint32_t)face, nullptr))) return rc;
     uint32_t n = 0;
     if ((rc = d2h(g, &n, d_count, sizeof(n)))) return rc;
     std::vector<uint64_t> h(n);
@@ -984,6 +984,7 @@ int ivx_halo_unpack(ivx_grid* g, int side, const void* device_buf) {
     IVX_HIP_CHECK(hipMemcpyAsync(g->ghost_type[side], b + cols * 256, cols * 256, hipMemcpyDeviceToDevice, s));
     IVX_HIP_CHECK(hipMemcpyAsync(g->ghost_info[side], b + cols * 512, cols * sizeof(ivx_chunk_info), hipMemcpyDeviceToDevice, s));
     g->has_ghost[side] = 1;
+    g->ghost_ext[side] = nullptr;
     IVX_HIP_CHECK(hipStreamSynchronize(s));
     return IVX_OK;
 }
@@ -995,19 +996,22 @@ int ivx_halo_pack_enqueue(ivx_grid* g, int side, void* device_buf) {
 
 int ivx_halo_unpack_enqueue(ivx_grid* g, int side, const void* device_buf) {
     IVX_REQUIRE(g && device_buf && (side == 0 || side == 1), IVX_ERR_INVALID, "ivx_halo_unpack_enqueue: bad argument");
-    const size_t cols = (size_t)g->cc[1] * g->cc[2];
-    hipStream_t s = g->ctx->stream;
-    const uint8_t* b = static_cast<const uint8_t*>(device_buf);
-    IVX_HIP_CHECK(hipMemcpyAsync(g->ghost_sdf[side], b, cols * 256, hipMemcpyDeviceToDevice, s));
-    IVX_HIP_CHECK(hipMemcpyAsync(g->ghost_type[side], b + cols * 256, cols * 256, hipMemcpyDeviceToDevice, s));
-    IVX_HIP_CHECK(hipMemcpyAsync(g->ghost_info[side], b + cols * 512, cols * sizeof(ivx_chunk_info), hipMemcpyDeviceToDevice, s));
+    IVX_REQUIRE((reinterpret_cast<uintptr_t>(device_buf) & 15u) == 0, IVX_ERR_INVALID, "ivx_halo_unpack_enqueue: the buffer must be 16-byte aligned");
+    // no copy: the kernels read the ghost layer in place from the receive buffer (three copies per side and exchange were a
+    // sixth of a multi-GPU step's launches); the caller keeps it untouched until it installs the next one
+    g->ghost_ext[side] = static_cast<const uint8_t*>(device_buf);
     g->has_ghost[side] = 1;
     return IVX_OK;
 }
 
+int ivx_halo_pack_both_enqueue(ivx_grid* g, void* lower_buf, void* upper_buf, int with_face_labels) {
+    IVX_REQUIRE(g && (lower_buf || upper_buf), IVX_ERR_INVALID, "ivx_halo_pack_both_enqueue: bad argument");
+    return ivx_launch_halo_pack_both(g, lower_buf, upper_buf, with_face_labels);
+}
+
 int ivx_region_face_labels_enqueue(ivx_grid* g, int side, void* device_buf) {
     IVX_REQUIRE(g && device_buf && (side == 0 || side == 1), IVX_ERR_INVALID, "ivx_region_face_labels_enqueue: bad argument");
-    return ivx_launch_face_ids(g, side, static_cast<uint32_t*>(device_buf));
+    return ivx_launch_face_ids(g, side, static_cast<uint16_t*>(device_buf));
 }
 
 static int ensure_pairs(ivx_grid* g) {
@@ -1021,7 +1025,7 @@ int ivx_region_face_pairs_enqueue(ivx_grid* g, int side, const void* neighbour_f
     IVX_REQUIRE(g && neighbour_face_labels && (side == 0 || side == 1), IVX_ERR_INVALID, "ivx_region_face_pairs_enqueue: bad argument");
     int rc = ensure_pairs(g);
     if (rc) return rc;
-    rc = ivx_launch_face_pairs(g, side, static_cast<const uint32_t*>(neighbour_face_labels), g->pairs_dev, g->pairs_dev + 4 + 128, IVX_MAX_FACE_PAIRS,
+    rc = ivx_launch_face_pairs(g, side, static_cast<const uint16_t*>(neighbour_face_labels), g->pairs_dev, g->pairs_dev + 4 + 128, IVX_MAX_FACE_PAIRS,
                                g->pairs_dev + 4);
     if (rc) return rc;
     g->pairs_enqueued = 1;
@@ -1043,6 +1047,7 @@ int ivx_step_record_enqueue(ivx_grid* g, void* device_record) {
 int ivx_halo_clear(ivx_grid* g, int side) {
     IVX_REQUIRE(g && (side == 0 || side == 1), IVX_ERR_INVALID, "ivx_halo_clear: bad argument");
     g->has_ghost[side] = 0;
+    g->ghost_ext[side] = nullptr;
     return IVX_OK;
 }
 

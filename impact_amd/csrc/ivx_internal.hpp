@@ -60,6 +60,7 @@ struct ivx_grid {
     ivx_chunk_info* ghost_info[2];
     uint32_t* ghost_rlabel[2];  // global region node of the neighbour's face voxel (0xFFFFFFFF empty)
     int has_ghost[2];
+    const uint8_t* ghost_ext[2];  // ivx_halo_unpack_enqueue: the ghost layer is read in place from the caller's receive buffer
     // mesh state
     uint32_t* chunk_counts;   // [n_chunks*2]: vertex count, index count
     uint32_t* chunk_offsets;  // [n_chunks*2 + 4]: exclusive vertex/index offsets, then totals v,i,submeshes
@@ -242,9 +243,16 @@ static inline GridView ivx_view(const ivx_grid* g) {
 #endif
     v.info = g->info;
     for (int s = 0; s < 2; ++s) {
-        v.ghost_sdf[s] = g->has_ghost[s] ? g->ghost_sdf[s] : nullptr;
-        v.ghost_type[s] = g->has_ghost[s] ? g->ghost_type[s] : nullptr;
-        v.ghost_info[s] = g->has_ghost[s] ? g->ghost_info[s] : nullptr;
+        if (g->has_ghost[s] && g->ghost_ext[s]) {  // message layout: sdf plane | type plane | chunk records
+            const size_t cols = (size_t)g->cc[1] * g->cc[2];
+            v.ghost_sdf[s] = reinterpret_cast<const int8_t*>(g->ghost_ext[s]);
+            v.ghost_type[s] = g->ghost_ext[s] + cols * 256;
+            v.ghost_info[s] = reinterpret_cast<const ivx_chunk_info*>(g->ghost_ext[s] + cols * 512);
+        } else {
+            v.ghost_sdf[s] = g->has_ghost[s] ? g->ghost_sdf[s] : nullptr;
+            v.ghost_type[s] = g->has_ghost[s] ? g->ghost_type[s] : nullptr;
+            v.ghost_info[s] = g->has_ghost[s] ? g->ghost_info[s] : nullptr;
+        }
     }
     return v;
 }
@@ -273,8 +281,9 @@ int ivx_launch_ccl_merge(ivx_grid* g);
 int ivx_launch_ccl_resolve(ivx_grid* g);
 int ivx_launch_ccl_dense_labels(ivx_grid* g, uint32_t* d_labels);
 int ivx_launch_halo_pack(ivx_grid* g, int side, void* buf);
-int ivx_launch_face_ids(ivx_grid* g, int side, uint32_t* d_out);
-int ivx_launch_face_pairs(ivx_grid* g, int side, const uint32_t* d_nbr, uint32_t* d_count, void* d_pairs, uint32_t cap, uint32_t* d_seen);
+int ivx_launch_halo_pack_both(ivx_grid* g, void* buf_lo, void* buf_hi, int with_face_labels);
+int ivx_launch_face_ids(ivx_grid* g, int side, uint16_t* d_out);
+int ivx_launch_face_pairs(ivx_grid* g, int side, const uint16_t* d_nbr, uint32_t* d_count, void* d_pairs, uint32_t cap, uint32_t* d_seen);
 int ivx_launch_step_record(ivx_grid* g, const uint32_t* d_pair_count, const void* d_pairs, uint32_t max_pairs, void* d_record);
 int ivx_launch_split_move(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], const uint32_t cc[3], uint32_t target);
 int ivx_launch_clip(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], const uint32_t cc[3], const float* planes4, uint32_t n_planes, int extract);

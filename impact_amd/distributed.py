@@ -57,6 +57,7 @@ class Exchange:
     hi: "DeviceBuffer"
     recv_lo: "DeviceBuffer"
     recv_hi: "DeviceBuffer"
+    nbytes: int = 0  # leading bytes of the buffers that carry this exchange's message (0 = all)
 
 
 @dataclass
@@ -106,11 +107,15 @@ def slab_ranges(global_x_chunks: int, world: int):
 def resolve_global_regions(records: np.ndarray):
     """All ranks' records -> (global region count, per-rank arrays mapping slab-local component ->
     global region id (ids ordered by first occurrence in rank, component order), summed moments,
-    global occupied ranges, per-rank mesh counts). Pure host code, identical on every rank."""
+    global occupied ranges, per-rank mesh counts). Pure host code, identical on every rank. (Plain Python on purpose: the
+    inputs are a handful of components and pairs, and this runs after the step's GPU work, on the critical path.)"""
     world = records.shape[0]
-    counts = [int(records[r, 0]) for r in range(world)]
-    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-    parent = np.arange(offs[-1], dtype=np.int64)
+    head = records[:, :18].tolist()
+    counts = [int(h[0]) for h in head]
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    parent = list(range(offs[-1]))
 
     def find(x):
         while parent[x] != x:
@@ -119,31 +124,39 @@ def resolve_global_regions(records: np.ndarray):
         return x
 
     for r in range(world - 1):
-        n_pairs = int(records[r, 1])
+        n_pairs = int(head[r][1])
         if n_pairs > MAX_PAIRS:
             raise capi.IvxError(capi.IVX_ERR_CAPACITY, f"rank {r}: {n_pairs} cross-slab region pairs exceed MAX_PAIRS={MAX_PAIRS}")
-        pairs = records[r, 28:28 + 2 * n_pairs].reshape(-1, 2)
-        for a, b in pairs:
-            ra, rb = find(offs[r] + int(a)), find(offs[r + 1] + int(b))
+        if n_pairs == 0:
+            continue
+        pairs = records[r, 28:28 + 2 * n_pairs].tolist()
+        for q in range(n_pairs):
+            ra, rb = find(offs[r] + pairs[2 * q]), find(offs[r + 1] + pairs[2 * q + 1])
             if ra != rb:
                 if ra < rb:
                     parent[rb] = ra
                 else:
                     parent[ra] = rb
-    roots = np.array([find(i) for i in range(offs[-1])], dtype=np.int64)
-    uniq, inv = np.unique(roots, return_inverse=True)  # roots are minimal members => ordered by first occurrence
-    region_of = [inv[offs[r]:offs[r + 1]].astype(np.uint32) for r in range(world)]
+    # roots are minimal members, so numbering them in index order = ordering the regions by first occurrence
+    region_id, ids = {}, []
+    for i in range(offs[-1]):
+        root = find(i)
+        rid = region_id.get(root)
+        if rid is None:
+            rid = region_id[root] = len(region_id)
+        ids.append(rid)
+    region_of = [np.asarray(ids[offs[r]:offs[r + 1]], dtype=np.uint32) for r in range(world)]
     moments = np.zeros(10, dtype=np.float64)
     for r in range(world):  # fixed rank order: bitwise reproducible
         moments += records[r, 18:28].view(np.float64)
-    occ = np.zeros(12, dtype=np.uint32)
-    have = [r for r in range(world) if records[r, 3] > 0]
+    occ = [0] * 12
+    have = [r for r in range(world) if head[r][3] > 0]
     if have:
-        o = np.stack([records[r, 2:14] for r in have]).astype(np.uint32)
         for q in range(12):
-            occ[q] = o[:, q].max() if (q & 1) else o[:, q].min()
-    mesh = [(int(records[r, 14]), int(records[r, 15]), int(records[r, 16])) for r in range(world)]
-    return len(uniq), region_of, moments, occ, mesh
+            vals = [int(head[r][2 + q]) for r in have]
+            occ[q] = max(vals) if (q & 1) else min(vals)
+    mesh = [(int(head[r][14]), int(head[r][15]), int(head[r][16])) for r in range(world)]
+    return len(region_id), region_of, moments, np.asarray(occ, dtype=np.uint32), mesh
 
 
 class SlabStepper:
@@ -194,21 +207,23 @@ class SlabStepper:
         res = SlabResult()
         # 1. sample, exchange face planes
         obj.step_enqueue(capi.STAGE_SAMPLE)
-        for side in (0, 1):
-            obj.halo_pack_enqueue(side, self.send[side].ptr)
-        yield Exchange(self.send[0], self.send[1], self.recv[0], self.recv[1])
+        lo_ptr = C.c_void_p(self.send[0].ptr if self.has_lo else None)
+        hi_ptr = C.c_void_p(self.send[1].ptr if self.has_hi else None)
+        if self.has_lo or self.has_hi:
+            check(L.ivx_halo_pack_both_enqueue(obj.h, lo_ptr, hi_ptr, 0))
+        yield Exchange(self.send[0], self.send[1], self.recv[0], self.recv[1], self.halo_bytes)
         self._install_ghosts()
         # 2. derived state + slab-local regions; exchange planes again (+ component ids of the faces)
-        obj.step_enqueue(capi.STAGE_DERIVE | capi.STAGE_OCCUPIED | capi.STAGE_REGIONS)
-        for side in (0, 1):
-            obj.halo_pack_enqueue(side, self.send[side].ptr)
-            check(L.ivx_region_face_labels_enqueue(obj.h, side, C.c_void_p(self.send[side].ptr + self.halo_bytes)))
-        yield Exchange(self.send[0], self.send[1], self.recv[0], self.recv[1])
+        # (the moments need nothing from the neighbours beyond what derive needs: same phase, so they ride in the derive sweep)
+        obj.step_enqueue(capi.STAGE_DERIVE | capi.STAGE_OCCUPIED | capi.STAGE_REGIONS | capi.STAGE_INERTIA)
+        if self.has_lo or self.has_hi:
+            check(L.ivx_halo_pack_both_enqueue(obj.h, lo_ptr, hi_ptr, 1))  # planes + the faces' component ids
+        yield Exchange(self.send[0], self.send[1], self.recv[0], self.recv[1], self.halo_bytes + self.face_bytes)
         self._install_ghosts()
         if self.has_hi:
             check(L.ivx_region_face_pairs_enqueue(obj.h, 1, C.c_void_p(self.recv[1].ptr + self.halo_bytes)))
-        # 3. remesh + inertia (ghost layers in place), the slab's record, then the one small all-gather
-        obj.step_enqueue(capi.STAGE_REMESH | capi.STAGE_INERTIA)
+        # 3. remesh (ghost layers in place), the slab's record, then the one small all-gather
+        obj.step_enqueue(capi.STAGE_REMESH)
         check(L.ivx_step_record_enqueue(obj.h, C.c_void_p(self.record.ptr)))
         records = yield AllGather(self.record, HEAD_WORDS)
         if int(records[:, 1].max()) > HEAD_PAIRS:  # (the same decision on every rank: all see the same heads)
@@ -217,6 +232,8 @@ class SlabStepper:
         flags = int(records[self.rank, 17])
         if flags & 1:
             raise capi.IvxError(capi.IVX_ERR_CAPACITY, "a chunk has more than 254 local regions")
+        if flags & 4:
+            raise capi.IvxError(capi.IVX_ERR_CAPACITY, "a slab has 65535 or more components: its face ids do not fit the 16-bit exchange format")
         n_regions, region_of, moments, occ, mesh = resolve_global_regions(records)
         res.region_count = n_regions
         res.local_region_count = int(records[self.rank, 0])
@@ -247,11 +264,12 @@ class TorchComm:
         for peer, sbuf, rbuf in ((self.rank - 1, req.lo, req.recv_lo), (self.rank + 1, req.hi, req.recv_hi)):
             if peer < 0 or peer >= self.world:
                 continue
+            n = req.nbytes or sbuf.t.numel()
             if self.on_device:
-                ops.append(dist.P2POp(dist.isend, sbuf.t, peer))
-                ops.append(dist.P2POp(dist.irecv, rbuf.t, peer))
+                ops.append(dist.P2POp(dist.isend, sbuf.t[:n], peer))
+                ops.append(dist.P2POp(dist.irecv, rbuf.t[:n], peer))
             else:
-                s_host = sbuf.t.cpu()
+                s_host = sbuf.t[:n].cpu()
                 r_host = torch.empty_like(s_host)
                 ops.append(dist.P2POp(dist.isend, s_host, peer))
                 ops.append(dist.P2POp(dist.irecv, r_host, peer))
@@ -260,7 +278,7 @@ class TorchComm:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
         for rbuf, r_host in staged:
-            rbuf.t.copy_(r_host)  # enqueued on the current (= the library's) stream
+            rbuf.t[: r_host.numel()].copy_(r_host)  # enqueued on the current (= the library's) stream
 
     def all_gather(self, rec, words=None) -> np.ndarray:
         """rec: DeviceBuffer (int64 words on the device) or a host numpy array -> (world, words) numpy"""
@@ -315,10 +333,11 @@ def run_slabs_in_process(steppers):
             if isinstance(reqs[0], Exchange):
                 # the send buffers are read before anything overwrites them: all copies are enqueued here, in order
                 for i, r in enumerate(reqs):
+                    n = r.nbytes or r.lo.t.numel()
                     if i > 0:
-                        reqs[i - 1].recv_hi.t.copy_(r.lo.t)
+                        reqs[i - 1].recv_hi.t[:n].copy_(r.lo.t[:n])
                     if i + 1 < len(reqs):
-                        reqs[i + 1].recv_lo.t.copy_(r.hi.t)
+                        reqs[i + 1].recv_lo.t[:n].copy_(r.hi.t[:n])
                 replies = [None] * len(gens)
             else:
                 records = torch.stack([r.record.t[: r.words] for r in reqs]).cpu().numpy()

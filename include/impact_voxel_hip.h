@@ -237,13 +237,18 @@ int ivx_halo_unpack(ivx_grid*, int side, const void* device_buf); /* install as 
 int ivx_halo_clear(ivx_grid*, int side);                          /* no neighbour: outside the grid */
 /* stream-ordered variants (no host wait): for callers whose communication runs on the context's stream */
 int ivx_halo_pack_enqueue(ivx_grid*, int side, void* device_buf);
+/* installs the buffer itself as the ghost layer (no copy): it must be 16-byte aligned and stay untouched until the next
+ * ivx_halo_unpack* / ivx_halo_clear of that side */
 int ivx_halo_unpack_enqueue(ivx_grid*, int side, const void* device_buf);
+/* both faces in one launch (either buffer may be NULL); with_face_labels != 0 appends the face planes of component ids
+ * (ivx_region_face_bytes() bytes) right behind the ivx_halo_bytes() of each message */
+int ivx_halo_pack_both_enqueue(ivx_grid*, void* lower_buf, void* upper_buf, int with_face_labels);
 
 /* Cross-slab connected regions: after ivx_label_regions on every slab, exchange the face planes of
  * component ids with the x neighbours, list the distinct (own component, neighbour component) pairs
  * that touch across the face, all-gather the pairs and finish the union on the host. This carries the
  * reference's cross-chunk region connections (object/split_detection.rs:323-487, 1046-1325) across ranks.
- * ivx_region_face_labels writes cy*cz*256 u32 (0xFFFFFFFF = empty voxel) to a DEVICE buffer;
+ * ivx_region_face_labels writes cy*cz*256 u16 (0xFFFF = empty voxel; a slab holds fewer than 65 535 components) to a DEVICE buffer;
  * ivx_region_face_pairs takes the neighbour's plane (device) and returns sorted unique pairs
  * (pairs[2i] = own id, pairs[2i+1] = neighbour id) in HOST memory. */
 size_t ivx_region_face_bytes(ivx_grid*);
