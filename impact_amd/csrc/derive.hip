@@ -68,10 +68,15 @@ __global__ __launch_bounds__(256) void k_chunk_pre(GridView g, ivx_chunk_info* _
         settled = gen == KIND_VOID;
         if (gen == KIND_UNIFORM) {
             const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
-            if (ci > 0 && cj > 0 && ck > 0 && ci + 1 < (int)g.cx && cj + 1 < (int)g.cy && ck + 1 < (int)g.cz) {
+            if (cj > 0 && ck > 0 && cj + 1 < (int)g.cy && ck + 1 < (int)g.cz) {
                 const uint32_t sx = g.cy * g.cz, sy = g.cz;
-                settled = info[chunk - sx].gen_kind == KIND_UNIFORM && info[chunk + sx].gen_kind == KIND_UNIFORM &&
-                          info[chunk - sy].gen_kind == KIND_UNIFORM && info[chunk + sy].gen_kind == KIND_UNIFORM &&
+                // across a slab face the neighbour is the ghost layer's chunk record (a slab is a few chunk planes thick: without
+                // this a quarter of a solid body's chunks would go the long way); at the end of the grid there is none
+                const bool x_lo = ci > 0 ? info[chunk - sx].gen_kind == KIND_UNIFORM
+                                         : (g.ghost_info[0] != nullptr && g.ghost_info[0][cj * g.cz + ck].gen_kind == KIND_UNIFORM);
+                const bool x_hi = ci + 1 < (int)g.cx ? info[chunk + sx].gen_kind == KIND_UNIFORM
+                                                     : (g.ghost_info[1] != nullptr && g.ghost_info[1][cj * g.cz + ck].gen_kind == KIND_UNIFORM);
+                settled = x_lo && x_hi && info[chunk - sy].gen_kind == KIND_UNIFORM && info[chunk + sy].gen_kind == KIND_UNIFORM &&
                           info[chunk - 1].gen_kind == KIND_UNIFORM && info[chunk + 1].gen_kind == KIND_UNIFORM;
             }
         }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Host-side cost of the slab protocol: wall time per step of (a) the plain single-GPU step, (b) the same grid driven through
 SlabStepper.phases as a one-slab "decomposition" in one process (all protocol calls, torch stream context, record readback, no
-neighbour traffic), (c) the N-rank workload's slab `rank` alone. usage: time_protocol.py [N RANK]"""
+neighbour traffic), (c) slab `rank` of bench.py's N-rank workload alone (no neighbour traffic). usage: time_protocol.py [N RANK]"""
 import os
 import sys
 import time
@@ -40,7 +40,7 @@ print(f"one-slab protocol in process: {wall(lambda: run_slabs_in_process([st])):
 st.close()
 if len(sys.argv) > 2:
     n, r = int(sys.argv[1]), int(sys.argv[2])
-    st = SlabStepper(ctx, scenes.asteroid_row_scene(n, 2.05), dens, r, n, torch)
+    st = SlabStepper(ctx, scenes.asteroid_scene(2.05 * n ** (1.0 / 3.0)), dens, r, n, torch)  # bench.py's N-rank workload
     st.has_lo = st.has_hi = False  # no neighbours in this process: empty ghost layers
     st.rank = 0  # (its record is the only one gathered here)
     print(f"slab {r} of {n} alone through the protocol: {wall(lambda: run_slabs_in_process([st])):.3f} ms")
