@@ -102,6 +102,7 @@ CONTACT_DTYPE = np.dtype(
         ("pad", "<u4"),
     ]
 )
+ABSORB_RESULT_DTYPE = np.dtype([("removed_moments", "<f8", (10,)), ("emptied_voxels", "<u8"), ("touched_chunks", "<u4"), ("removed_chunks", "<u4")])
 SOLVER_CONFIG_DTYPE = np.dtype(
     [("n_iterations", "<u4"), ("old_impulse_weight", "<f4"), ("n_positional_correction_iterations", "<u4"), ("positional_correction_factor", "<f4")]
 )
@@ -121,7 +122,7 @@ EXPORTED_SYMBOLS = [
     "ivx_derive_state", "ivx_occupied_ranges",
     "ivx_remesh", "ivx_mesh_download", "ivx_mesh_device_ptr",
     "ivx_inertia",
-    "ivx_label_regions", "ivx_region_labels_download", "ivx_regions_describe", "ivx_split_off_smallest_region", "ivx_clip_polyhedron",
+    "ivx_label_regions", "ivx_region_labels_download", "ivx_regions_describe", "ivx_split_off_smallest_region", "ivx_clip_polyhedron", "ivx_absorb_sphere",
     "ivx_grid_set_sdf_program", "ivx_grid_set_densities", "ivx_voxel_step", "ivx_voxel_step_enqueue", "ivx_voxel_step_collect",
     "ivx_halo_pack_enqueue", "ivx_halo_unpack_enqueue", "ivx_halo_pack_both_enqueue", "ivx_region_face_labels_enqueue", "ivx_region_face_pairs_enqueue",
     "ivx_step_record_words", "ivx_step_record_enqueue",
@@ -138,6 +139,7 @@ def extra_struct_sizes():
     return {
         "ivx_rigid_body": (RIGID_BODY_DTYPE, 152), "ivx_kinematic_body": (KINEMATIC_BODY_DTYPE, 56), "ivx_contact": (CONTACT_DTYPE, 64),
         "ivx_solver_config": (SOLVER_CONFIG_DTYPE, 16), "ivx_physics_result": (PHYSICS_RESULT_DTYPE, 48),
+        "ivx_absorb_result": (ABSORB_RESULT_DTYPE, 96),
     }
 
 
@@ -217,6 +219,7 @@ def lib():
         "ivx_world_set_bodies": (i32, [vp, vp, sz, vp, sz]),
         "ivx_world_get_bodies": (i32, [vp, vp, vp]),
         "ivx_world_set_contacts": (i32, [vp, vp, sz, C.POINTER(sz)]),
+        "ivx_absorb_sphere": (i32, [vp, vp, f32, f32, vp, vp, vp, vp]),
         "ivx_world_step": (i32, [vp, f32, vp]),
         "ivx_world_step_enqueue": (i32, [vp, f32]),
         "ivx_world_prepare": (i32, [vp]),

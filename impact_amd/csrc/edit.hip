@@ -1,0 +1,151 @@
+// Voxel edit ops: an absorbing sphere eats into a voxel object — the per-frame mutator of the reference's deformable objects
+// (SURVEY §8f item 2).
+//
+// Reference (engine/crates/impact_voxel/src):
+//   apply_sphere_absorption                                   interaction/absorption.rs:801-844
+//   VoxelAbsorbingSphere::compute_new_signed_distance         interaction/absorption.rs:170-180  (hard_sdf_subtraction, generation/sdf.rs:79-81)
+//   Voxel::set_signed_distance                                lib.rs:451-461
+//   modify_voxels_within_sphere + handle_chunk_voxels_modified  object/intersection.rs:283-395, 532-598
+//   VoxelObjectInertialPropertyUpdater::remove_voxel          object/inertia.rs:377-394
+// Per chunk of the touched chunk box: a Void chunk is skipped, a Uniform chunk becomes NonUniform (its 4096 voxels are written
+// out) whether or not the sphere reaches a voxel of it, every voxel whose centre lies inside the influence sphere gets
+// sd = quantise(max(sd, -(|p - c| - R))); a voxel that stops being negative is empty from then on and its mass moments and type
+// are reported; a chunk left with only void voxels becomes Void. Derived state is recomputed afterwards by the ordinary sweep
+// (derive.hip): it is a pure function of the voxels and the chunk kinds set here.
+//
+// One workgroup per chunk of the box, a thread owns a 16-voxel k-row.
+#include "chunk_passes.hpp"
+
+namespace {
+
+struct AbsorbParams {
+    GridView g;
+    uint32_t lo[3], cc[3];  // chunk box
+    int32_t vlo[3], vhi[3];  // touched voxel ranges
+    float c[3];
+    float r2, r_sphere;
+};
+
+__device__ __forceinline__ int quantise(float v) {  // VoxelSignedDistance::from_f32 (lib.rs:197-201)
+    float s = v * 50.0f;
+    if (s != s) return 0;
+    s = s < -128.0f ? -128.0f : (s > 127.0f ? 127.0f : s);
+    return (int)s;
+}
+
+__global__ __launch_bounds__(256) void k_absorb_sphere(AbsorbParams p, int8_t* __restrict__ sdf, uint8_t* __restrict__ type, ivx_chunk_info* __restrict__ info,
+                                                       const float* __restrict__ dens, double* __restrict__ removed10, uint32_t* __restrict__ by_type,
+                                                       uint32_t* __restrict__ counters, uint8_t* __restrict__ touched_flags) {
+    __shared__ float s_dens[256];
+    __shared__ double s_red[4][10];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    const uint32_t bk = b % p.cc[2], bj = (b / p.cc[2]) % p.cc[1], bi = b / (p.cc[2] * p.cc[1]);
+    const uint32_t ci = p.lo[0] + bi, cj = p.lo[1] + bj, ck = p.lo[2] + bk;
+    const uint32_t chunk = (ci * p.g.cy + cj) * p.g.cz + ck;
+    const ivx_chunk_info rec = info[chunk];
+    if (rec.kind == KIND_VOID) return;
+    s_dens[tid] = dens[tid];
+    const bool was_uniform = rec.kind != KIND_NONUNIFORM;
+    const size_t o = (size_t)chunk * IVX_CHUNK_VOXELS + (size_t)tid * 16;
+    uint32_t sw[4], tw[4];
+    if (was_uniform) {  // convert_to_non_uniform_if_uniform (object.rs:2530-2550)
+        sw[0] = sw[1] = sw[2] = sw[3] = 0x80808080u;
+        tw[0] = tw[1] = tw[2] = tw[3] = (uint32_t)rec.uniform_type * 0x01010101u;
+    } else {
+        const uint4 s4 = *reinterpret_cast<const uint4*>(sdf + o), t4 = *reinterpret_cast<const uint4*>(type + o);
+        sw[0] = s4.x, sw[1] = s4.y, sw[2] = s4.z, sw[3] = s4.w;
+        tw[0] = t4.x, tw[1] = t4.y, tw[2] = t4.z, tw[3] = t4.w;
+    }
+    const int gi = (int)(ci * 16u + (tid >> 4)), gj = (int)(cj * 16u + (tid & 15u));
+    const bool row_in = gi >= p.vlo[0] && gi < p.vhi[0] && gj >= p.vlo[1] && gj < p.vhi[1];
+    const float dx = ((float)gi + 0.5f) - p.c[0], dy = ((float)gj + 0.5f) - p.c[1];
+    uint32_t emptied = 0;  // bit k: the voxel was non-empty and is empty now
+    bool any_inside = false, changed = false;
+    uint32_t non_empty = 0, non_void = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int gk = (int)(ck * 16u) + k;
+        int sd = (int)(int8_t)((sw[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+        if (row_in && gk >= p.vlo[2] && gk < p.vhi[2]) {
+            const float dz = ((float)gk + 0.5f) - p.c[2];
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            if (d2 < p.r2) {
+                any_inside = true;
+                const float sphere_sd = sqrtf(d2) - p.r_sphere;
+                const float old = (float)sd * 0.02f, neg = -sphere_sd;
+                const float nv = (neg > old) ? neg : old;  // f32::max (no NaN here)
+                const int q = quantise(nv);
+                if (sd < 0 && q >= 0) emptied |= 1u << k;
+                if (q != sd) {
+                    changed = true;
+                    sd = q;
+                    sw[k >> 2] = (sw[k >> 2] & ~(0xFFu << (8 * (k & 3)))) | ((uint32_t)(q & 0xFF) << (8 * (k & 3)));
+                }
+            }
+        }
+        non_empty |= sd < 0 ? 1u : 0u;
+        non_void |= sd <= SD_VOID_LIMIT ? 1u : 0u;
+    }
+    const int touched = __syncthreads_or(any_inside ? 1 : 0);
+    const int has_non_empty = __syncthreads_or((int)non_empty);
+    const int has_non_void = __syncthreads_or((int)non_void);
+    const int any_emptied = __syncthreads_or(emptied != 0);
+    const bool becomes_void = touched && !has_non_empty && !has_non_void;
+    if (!becomes_void && (was_uniform || changed)) {
+        *reinterpret_cast<uint4*>(sdf + o) = make_uint4(sw[0], sw[1], sw[2], sw[3]);
+        if (was_uniform) *reinterpret_cast<uint4*>(type + o) = make_uint4(tw[0], tw[1], tw[2], tw[3]);
+    }
+    if (any_emptied) {
+        // what the inertial property updater removes (inertia.rs:377-394), in the integer form of inertia.hip
+        double m[10];
+        chunk_moments_rows(tid, emptied, tw, s_dens, s_red, gi, gj, (int)(ck * 16u), m);  // (every thread passes its own m; tid < 10 hold the sums)
+        if (tid < 10) atomicAdd(&removed10[tid], m[tid]);
+        uint32_t e = emptied;
+        while (e) {
+            const int k = __ffs(e) - 1;
+            e &= e - 1;
+            atomicAdd(&by_type[(tw[k >> 2] >> (8 * (k & 3))) & 0xFFu], 1u);
+        }
+    }
+    if (tid == 0) {
+        ivx_chunk_info out = rec;
+        if (becomes_void) {
+            out.kind = out.gen_kind = KIND_VOID;
+            out.flags = 0;
+            out.uniform_type = 0;
+            atomicAdd(&counters[1], 1u);
+        } else {
+            out.kind = out.gen_kind = KIND_NONUNIFORM;  // touched or not, a chunk of the box is NonUniform from now on
+            out.flags = has_non_empty ? 0 : (uint8_t)CF_ONLY_EMPTY;
+            out.uniform_type = 0;
+        }
+        info[chunk] = out;
+        if (touched) {
+            touched_flags[chunk] = 1;
+            atomicAdd(&counters[0], 1u);
+        }
+    }
+}
+
+}  // namespace
+
+int ivx_launch_absorb_sphere(ivx_grid* g, const uint32_t lo[3], const uint32_t cc[3], const int32_t vlo[3], const int32_t vhi[3], const float c[3],
+                             float influence_radius, float sphere_radius, const float* d_dens, double* d_removed10, uint32_t* d_by_type,
+                             uint32_t* d_counters, uint8_t* d_touched) {
+    AbsorbParams p;
+    p.g = ivx_view(g);
+    for (int d = 0; d < 3; ++d) {
+        p.lo[d] = lo[d];
+        p.cc[d] = cc[d];
+        p.vlo[d] = vlo[d];
+        p.vhi[d] = vhi[d];
+        p.c[d] = c[d];
+    }
+    p.r2 = influence_radius * influence_radius;
+    p.r_sphere = sphere_radius;
+    hipLaunchKernelGGL(k_absorb_sphere, dim3(cc[0] * cc[1] * cc[2]), dim3(256), 0, g->ctx->stream, p, g->sdf, g->type, g->info, d_dens, d_removed10, d_by_type,
+                       d_counters, d_touched);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}

@@ -2,6 +2,7 @@
 // the reference interfaces each function replaces). Host-side orchestration only: every compute call
 // launches the HIP kernels in this directory on the context's stream.
 #include <algorithm>
+#include <cmath>
 #include <new>
 #include <vector>
 
@@ -748,6 +749,94 @@ int ivx_region_face_pairs(ivx_grid* g, int side, const void* neighbour_face_labe
     for (size_t i = 0; i < h.size(); ++i) {
         pairs[2 * i] = (uint32_t)(h[i] >> 32);
         pairs[2 * i + 1] = (uint32_t)(h[i] & 0xFFFFFFFFu);
+    }
+    return IVX_OK;
+}
+
+int ivx_absorb_sphere(ivx_grid* g, const float center[3], float influence_radius, float sphere_radius, const float densities[256], ivx_absorb_result* out,
+                      uint32_t* emptied_by_type, uint8_t* invalidated_chunks) {
+    IVX_REQUIRE(g && center && densities && out, IVX_ERR_INVALID, "ivx_absorb_sphere: null argument");
+    IVX_REQUIRE(influence_radius >= 0.0f && sphere_radius >= 0.0f, IVX_ERR_INVALID, "ivx_absorb_sphere: negative radius");
+    IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "ivx_absorb_sphere: derived state and regions must be current (ivx_derive_state + ivx_label_regions)");
+    IVX_REQUIRE(g->x_off == 0 && g->gx == g->cc[0] && !g->has_ghost[0] && !g->has_ghost[1], IVX_ERR_STATE,
+                "ivx_absorb_sphere: not available on a slab of a decomposed grid");
+    memset(out, 0, sizeof(*out));
+    if (emptied_by_type) memset(emptied_by_type, 0, 256 * sizeof(uint32_t));
+    if (invalidated_chunks) memset(invalidated_chunks, 0, g->n_chunks);
+    int rc;
+    // the touched voxel ranges start from the object's occupied ranges (voxel_ranges_touching_aab, intersection.rs:766-782)
+    uint32_t* d_occ = g->rscalar + 16;
+    if ((rc = ivx_launch_occupied(g, d_occ))) return rc;
+    uint32_t occ_raw[12], occ[12];
+    if ((rc = d2h(g, occ_raw, d_occ, sizeof(occ_raw)))) return rc;
+    ivx_occupied_from_raw(g, occ_raw, occ);
+    int32_t vlo[3], vhi[3];
+    uint32_t lo[3], cc[3];
+    for (int d = 0; d < 3; ++d) {
+        const float a = center[d] - influence_radius, b = center[d] + influence_radius;  // Sphere::compute_aabb
+        const float fl = std::floor(a), ce = std::ceil(b);
+        const long s = (long)(fl > 0.0f ? fl : 0.0f), e = ce > 0.0f ? (long)ce : 0;  // `as usize` saturates at 0
+        vlo[d] = (int32_t)std::max<long>((long)occ[6 + 2 * d], s);
+        vhi[d] = (int32_t)std::min<long>((long)occ[7 + 2 * d], e);
+        if (vlo[d] >= vhi[d]) return IVX_OK;
+        lo[d] = (uint32_t)vlo[d] / 16u;
+        cc[d] = ((uint32_t)vhi[d] + 15u) / 16u - lo[d];
+    }
+    // scratch: [10 f64 removed moments][256 u32 by type][2 u32 counters][pad][n_chunks u8 touched]
+    const size_t off_type = 80, off_cnt = off_type + 1024, off_touch = off_cnt + 16, total = off_touch + g->n_chunks;
+    const size_t off_dens = (total + 255) & ~(size_t)255;
+    if ((rc = ensure_dev_scratch(g, off_dens + 1024))) return rc;
+    char* base = static_cast<char*>(g->dev_scratch);
+    IVX_HIP_CHECK(hipMemsetAsync(base, 0, total, g->ctx->stream));
+    float* d_dens = reinterpret_cast<float*>(base + off_dens);
+    if ((rc = h2d(g, d_dens, densities, 1024))) return rc;
+    if ((rc = ivx_launch_absorb_sphere(g, lo, cc, vlo, vhi, center, influence_radius, sphere_radius, d_dens, reinterpret_cast<double*>(base),
+                                       reinterpret_cast<uint32_t*>(base + off_type), reinterpret_cast<uint32_t*>(base + off_cnt),
+                                       reinterpret_cast<uint8_t*>(base + off_touch))))
+        return rc;
+    std::vector<char> hostbuf(total);
+    if ((rc = d2h(g, hostbuf.data(), base, total))) return rc;
+    // derived state of the edited object: flags, kinds, chunk-local regions, components (the reference patches them around the
+    // touched chunks; they are a pure function of the voxels and kinds)
+    if ((rc = rederive(g))) return rc;
+    const double* rem = reinterpret_cast<const double*>(hostbuf.data());
+    const double e = (double)g->extent, e3 = e * e * e, e4 = e3 * e, e5 = e4 * e;
+    const double f[10] = {e3, 0.5 * e4, 0.5 * e4, 0.5 * e4, e5 / 3.0, e5 / 3.0, e5 / 3.0, 0.25 * e5, 0.25 * e5, 0.25 * e5};
+    for (int q = 0; q < 10; ++q) out->removed_moments[q] = rem[q] * f[q];
+    const uint32_t* by_type = reinterpret_cast<const uint32_t*>(hostbuf.data() + off_type);
+    uint64_t emptied = 0;
+    for (int t = 0; t < 256; ++t) {
+        emptied += by_type[t];
+        if (emptied_by_type) emptied_by_type[t] = by_type[t];
+    }
+    out->emptied_voxels = emptied;
+    const uint32_t* cnt = reinterpret_cast<const uint32_t*>(hostbuf.data() + off_cnt);
+    out->touched_chunks = cnt[0];
+    out->removed_chunks = cnt[1];
+    if (invalidated_chunks) {
+        // handle_chunk_voxels_modified (intersection.rs:560-598): the touched chunk, and a neighbour when the touched voxel range
+        // comes within two voxels of the face they share
+        const uint8_t* touched = reinterpret_cast<const uint8_t*>(hostbuf.data() + off_touch);
+        for (uint32_t i = lo[0]; i < lo[0] + cc[0]; ++i)
+            for (uint32_t j = lo[1]; j < lo[1] + cc[1]; ++j)
+                for (uint32_t k = lo[2]; k < lo[2] + cc[2]; ++k) {
+                    const uint32_t c = (i * g->cc[1] + j) * g->cc[2] + k;
+                    if (!touched[c]) continue;
+                    invalidated_chunks[c] = 1;
+                    const uint32_t idx[3] = {i, j, k};
+                    for (int d = 0; d < 3; ++d) {
+                        const long cbase = (long)idx[d] * 16, rlo = std::max<long>(cbase, vlo[d]), rhi = std::min<long>(cbase + 16, vhi[d]);
+                        uint32_t a[3] = {i, j, k};
+                        if (idx[d] > 0 && rlo - cbase < 2) {
+                            a[d] = idx[d] - 1;
+                            invalidated_chunks[(a[0] * g->cc[1] + a[1]) * g->cc[2] + a[2]] = 1;
+                        }
+                        if (idx[d] + 1 < g->cc[d] && cbase + 16 - rhi < 2) {
+                            a[d] = idx[d] + 1;
+                            invalidated_chunks[(a[0] * g->cc[1] + a[1]) * g->cc[2] + a[2]] = 1;
+                        }
+                    }
+                }
     }
     return IVX_OK;
 }

@@ -334,6 +334,26 @@ class VoxelObject:
         return int(outcome.value), obj, tuple(int(x) for x in origin), moved[0]
 
     # ---- halos -----------------------------------------------------------------------------------
+    # ---- voxel edit ops ----------------------------------------------------------------------------
+    def absorb_sphere(self, center, influence_radius: float, sphere_radius: float, densities=None, want_invalidated: bool = True):
+        """`apply_sphere_absorption` (interaction/absorption.rs:801-844) with the sphere in the object's normalized space (voxel
+        units, lower grid corner at the origin): every voxel whose centre lies within `influence_radius` of `center` gets
+        sd = max(sd, -(|p - c| - sphere_radius)). Returns a dict: removed_moments (10 f64: what the inertial property updater
+        subtracts), emptied_by_type (256 counts: the absorbed-voxel tracker), invalidated (bool per chunk: the mesh chunks
+        `handle_chunk_voxels_modified` registers), touched_chunks, removed_chunks. Derived state and regions are current
+        afterwards; the mesh is not."""
+        d = np.ones(256, dtype=np.float32) if densities is None else np.ascontiguousarray(densities, dtype=np.float32)
+        c = np.ascontiguousarray(center, dtype=np.float32)
+        out = np.zeros(1, dtype=capi.ABSORB_RESULT_DTYPE)
+        by_type = np.zeros(256, dtype=np.uint32)
+        inval = np.zeros(self.n_chunks, dtype=np.uint8) if want_invalidated else None
+        check(capi.lib().ivx_absorb_sphere(self.h, ptr(c), influence_radius, sphere_radius, ptr(d), ptr(out), ptr(by_type),
+                                           ptr(inval) if inval is not None else None))
+        self._region_count = None
+        return {"removed_moments": out[0]["removed_moments"].copy(), "emptied_by_type": by_type, "emptied_voxels": int(out[0]["emptied_voxels"]),
+                "invalidated": None if inval is None else inval.astype(bool), "touched_chunks": int(out[0]["touched_chunks"]),
+                "removed_chunks": int(out[0]["removed_chunks"])}
+
     def halo_bytes(self) -> int:
         return int(capi.lib().ivx_halo_bytes(self.h))
 

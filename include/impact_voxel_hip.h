@@ -215,6 +215,25 @@ typedef struct {
     float stage_ms[IVX_N_TIMED_STAGES];
     float reserved2[2];
 } ivx_step_result;
+/* ---- voxel edit ops --------------------------------------------------------------------------------------
+ * apply_sphere_absorption (impact_voxel/src/interaction/absorption.rs:801-844) over modify_voxels_within_sphere
+ * (object/intersection.rs:283-395): an absorbing sphere eats into the object. The sphere is given in the object's normalized space
+ * (voxel units, lower grid corner at the origin): `influence_radius` = radius + 2 voxels bounds the voxels that are visited,
+ * `sphere_radius` enters the new signed distance max(sd, -(|p - c| - R)). Needs current derived state and regions; leaves
+ * them current (flags, chunk kinds, regions of the edited object). `removed_moments` are the ten moments (layout of
+ * ivx_moments.m64) of the voxels that became empty — what VoxelObjectInertialPropertyUpdater::remove_voxel subtracts
+ * (object/inertia.rs:377-394); `emptied_by_type` (256 counts, may be NULL) is what the absorbed-voxel tracker registers;
+ * `invalidated_chunks` (one byte per chunk, may be NULL) is the set handle_chunk_voxels_modified registers for remeshing
+ * (intersection.rs:532-598). */
+typedef struct {
+    double removed_moments[10];
+    uint64_t emptied_voxels;
+    uint32_t touched_chunks; /* chunks with a voxel centre inside the influence sphere */
+    uint32_t removed_chunks; /* chunks that became Void */
+} ivx_absorb_result;
+int ivx_absorb_sphere(ivx_grid*, const float center[3], float influence_radius, float sphere_radius, const float densities[256],
+                      ivx_absorb_result* out, uint32_t* emptied_by_type, uint8_t* invalidated_chunks);
+
 /* make the compiled SDF program / the voxel-type densities resident on the device */
 int ivx_grid_set_sdf_program(ivx_grid*, const ivx_sdf_processed_node* nodes, size_t n_nodes, uint32_t stack_size,
                              const uint32_t grid_shape[3], const float shifted_grid_center[3], uint8_t voxel_type);

@@ -155,6 +155,10 @@ int orc_split_off_smallest_region(orc_object* parent, orc_object** child, int or
  * displacement), aabb = lower xyz + upper xyz, both in voxel units relative to the grid corner */
 int orc_clip_polyhedron(orc_object* parent, const float* planes4, int n_planes, const float aabb[6], int mode, orc_object** child,
                         int origin_offset_in_parent[3]);
+/* an absorbing sphere eats into the object (interaction/absorption.rs:801-844 over object/intersection.rs:273-395): sphere given
+ * in the object's normalized space (voxel units, grid corner at the origin). Returns the number of chunks that became void. */
+int orc_absorb_sphere(orc_object* o, const float center[3], float influence_radius, float sphere_radius, const float densities[256],
+                      double removed64[10], uint32_t emptied_by_type[256], uint8_t* invalidated_chunks, uint32_t* touched_chunks);
 
 /* quantisation helpers (lib.rs:197-222) */
 int8_t orc_sd_from_f32(float v);

@@ -14,6 +14,8 @@ void derive_inertial_properties(const float m[10], float out[22]);
 uint32_t canonical_region_labels(const VoxelObject& obj, uint32_t* labels);
 int split_off_smallest_region(VoxelObject& parent, VoxelObject& child, int origin[3]);
 int clip_polyhedron(VoxelObject& parent, const float* planes, int n_planes, const float aabb[6], int mode, VoxelObject& child, int origin[3]);
+int absorb_sphere(VoxelObject& obj, const float center[3], float influence_radius, float sphere_radius, const float* dens, double removed64[10],
+                  uint32_t emptied_by_type[256], uint8_t* invalidated, uint32_t* touched_chunks);
 
 // OffsetBoxVoxelGenerator (object.rs:3387-3504)
 struct BoxGenerator : Generator {
@@ -354,6 +356,13 @@ int orc_clip_polyhedron(orc_object* parent, const float* planes4, int n_planes, 
         *child = nullptr;
     }
     return rc;
+}
+
+// apply_sphere_absorption (interaction/absorption.rs:801-844) with the sphere already in the object's normalized space:
+// returns the number of chunks that became void
+int orc_absorb_sphere(orc_object* o, const float center[3], float influence_radius, float sphere_radius, const float densities[256],
+                      double removed64[10], uint32_t emptied_by_type[256], uint8_t* invalidated_chunks, uint32_t* touched_chunks) {
+    return absorb_sphere(o->obj, center, influence_radius, sphere_radius, densities, removed64, emptied_by_type, invalidated_chunks, touched_chunks);
 }
 
 int8_t orc_sd_from_f32(float v) { return sd_from_f32(v); }

@@ -1,0 +1,156 @@
+// ORACLE (test infrastructure only — never linked into the product library).
+//
+// CPU restatement of the per-frame voxel edit that feeds the remesh: an absorbing sphere eating into a voxel object
+// (paths relative to /root/reference/engine/crates/impact_voxel/src):
+//   apply_sphere_absorption (influence sphere, closure)      interaction/absorption.rs:801-844
+//   VoxelAbsorbingSphere::compute_new_signed_distance        interaction/absorption.rs:170-180
+//   hard_sdf_subtraction                                      generation/sdf.rs:79-81
+//   Voxel::set_signed_distance                                lib.rs:451-461
+//   modify_voxels_within_sphere                               object/intersection.rs:273-395
+//   voxel_ranges_touching_aab                                 object/intersection.rs:766-782
+//   handle_chunk_voxels_modified (mesh invalidation rule)     object/intersection.rs:532-598
+//   VoxelObjectInertialPropertyUpdater::remove_voxel          object/inertia.rs:377-394
+// The reference then patches adjacencies around the touched chunks incrementally; as in orc_split.cpp the derived state is
+// recomputed from scratch after the voxels and chunk kinds have been changed exactly as the reference changes them (its own
+// validators show the two agree). Occupied ranges are refreshed only when a chunk became void, as in the reference.
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../include/oracle.h"
+#include "orc_math.hpp"
+#include "orc_voxel.hpp"
+
+namespace orc {
+void edit_update_all_internal_state(Chunk& c, Voxel* cv);  // orc_split.cpp
+void edit_reset_occupied_chunk_ranges(VoxelObject& obj);   // orc_split.cpp
+
+// returns the number of chunks that became void; removed64 = integer-form moments of the emptied voxels scaled like
+// inertia_moments_f64 (mass, first moments, moments and products of inertia about the grid origin)
+int absorb_sphere(VoxelObject& obj, const float center[3], float influence_radius, float sphere_radius, const float* dens, double removed64[10],
+                  uint32_t emptied_by_type[256], uint8_t* invalidated /* [n_chunks] or null */, uint32_t* touched_chunks) {
+    for (int q = 0; q < 10; ++q) removed64[q] = 0.0;
+    if (emptied_by_type) std::memset(emptied_by_type, 0, 256 * sizeof(uint32_t));
+    if (invalidated) std::memset(invalidated, 0, (size_t)obj.n_chunks());
+    *touched_chunks = 0;
+    long vlo[3], vhi[3];
+    int clo[3], chi[3];
+    for (int d = 0; d < 3; ++d) {
+        const float lo = center[d] - influence_radius, hi = center[d] + influence_radius;  // Sphere::compute_aabb
+        const float fl = std::floor(lo);
+        const float ce = std::ceil(hi);
+        const long s = (long)(fl > 0.0f ? fl : 0.0f), e = ce > 0.0f ? (long)ce : 0;  // `as usize` saturates at 0
+        vlo[d] = std::max<long>(obj.occ_voxel[d][0], s);
+        vhi[d] = std::min<long>(obj.occ_voxel[d][1], e);
+        if (vlo[d] >= vhi[d]) return 0;
+        clo[d] = (int)(vlo[d] / CHUNK);
+        chi[d] = (int)((vhi[d] + CHUNK - 1) / CHUNK);
+    }
+    const float r2 = influence_radius * influence_radius;
+    const double ext = (double)obj.extent;
+    double s[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int removed_chunks = 0;
+    for (int I = clo[0]; I < chi[0]; ++I)
+        for (int J = clo[1]; J < chi[1]; ++J)
+            for (int K = clo[2]; K < chi[2]; ++K) {
+                const int ci = obj.cidx(I, J, K);
+                Chunk& ch = obj.chunks[ci];
+                if (ch.kind == K_VOID) continue;
+                if (ch.kind == K_UNIFORM) {  // convert_to_non_uniform_if_uniform (object.rs:2530-2550)
+                    const size_t start = obj.voxels.size();
+                    obj.voxels.resize(start + CHUNK_VOXELS, ch.uniform_voxel);
+                    obj.labels.resize(start + CHUNK_VOXELS, 0);
+                    ch.kind = K_NONUNIFORM;
+                    ch.data_offset = (uint32_t)(start >> 12);
+                    for (int d = 0; d < 3; ++d) ch.face[d][0] = ch.face[d][1] = FD_FULL;
+                    ch.flags = CF_FULLY_OBSCURED;
+                    ch.region_count = 1;
+                    ch.boundary_region_count = 1;
+                }
+                Voxel* cv = &obj.voxels[(size_t)ch.data_offset << 12];
+                const long base[3] = {(long)I * CHUNK, (long)J * CHUNK, (long)K * CHUNK};
+                long rlo[3], rhi[3];
+                for (int d = 0; d < 3; ++d) {
+                    rlo[d] = std::max(base[d], vlo[d]);
+                    rhi[d] = std::min(base[d] + CHUNK, vhi[d]);
+                }
+                bool touched = false;
+                for (long i = rlo[0]; i < rhi[0]; ++i)
+                    for (long j = rlo[1]; j < rhi[1]; ++j)
+                        for (long k = rlo[2]; k < rhi[2]; ++k) {
+                            const V3 p{(float)i + 0.5f, (float)j + 0.5f, (float)k + 0.5f};
+                            const V3 dv{p.x - center[0], p.y - center[1], p.z - center[2]};
+                            const float d2 = dot(dv, dv);
+                            if (!(d2 < r2)) continue;
+                            Voxel& v = cv[((i - base[0]) << 8) | ((j - base[1]) << 4) | (k - base[2])];
+                            const bool was_empty = v.empty();
+                            const float sphere_sd = std::sqrt(d2) - sphere_radius;
+                            const float nv = fmax_rs(sd_to_f32(v.sd), -sphere_sd);  // hard_sdf_subtraction
+                            v.sd = sd_from_f32(nv);
+                            if (!(v.sd < 0)) {
+                                v.flags |= F_EMPTY;
+                                if (!was_empty) {
+                                    const double dd = (double)dens[v.type], X = (double)i, Y = (double)j, Z = (double)k;
+                                    const double qx = 2 * X + 1, qy = 2 * Y + 1, qz = 2 * Z + 1;
+                                    const double cx = 3 * X * X + 3 * X + 1, cy = 3 * Y * Y + 3 * Y + 1, cz = 3 * Z * Z + 3 * Z + 1;
+                                    s[0] += dd;
+                                    s[1] += dd * qx;
+                                    s[2] += dd * qy;
+                                    s[3] += dd * qz;
+                                    s[4] += dd * (cy + cz);
+                                    s[5] += dd * (cx + cz);
+                                    s[6] += dd * (cx + cy);
+                                    s[7] += dd * qx * qy;
+                                    s[8] += dd * qy * qz;
+                                    s[9] += dd * qx * qz;
+                                    if (emptied_by_type) emptied_by_type[v.type] += 1;
+                                }
+                            }
+                            touched = true;
+                        }
+                if (!touched) continue;
+                *touched_chunks += 1;
+                // handle_chunk_voxels_modified
+                bool only_empty = true, all_void = true;
+                for (int idx = 0; idx < CHUNK_VOXELS; ++idx) {
+                    if (!cv[idx].empty()) only_empty = false;
+                    else if (!sd_is_void(cv[idx].sd)) all_void = false;
+                }
+                if (only_empty && all_void) {
+                    for (int idx = 0; idx < CHUNK_VOXELS; ++idx) cv[idx] = voxel_max_outside();
+                    ch = Chunk{};
+                    removed_chunks += 1;
+                } else {
+                    ch.flags = 0;
+                    edit_update_all_internal_state(ch, cv);
+                }
+                if (invalidated) {
+                    invalidated[ci] = 1;
+                    const int cidx3[3] = {I, J, K};
+                    for (int d = 0; d < 3; ++d) {
+                        if (cidx3[d] > 0 && rlo[d] - base[d] < 2) {
+                            int a[3] = {I, J, K};
+                            a[d] -= 1;
+                            invalidated[obj.cidx(a[0], a[1], a[2])] = 1;
+                        }
+                        if (cidx3[d] + 1 < obj.cc[d] && base[d] + CHUNK - rhi[d] < 2) {
+                            int a[3] = {I, J, K};
+                            a[d] += 1;
+                            invalidated[obj.cidx(a[0], a[1], a[2])] = 1;
+                        }
+                    }
+                }
+            }
+    const double e3 = ext * ext * ext, e4 = e3 * ext, e5 = e4 * ext;
+    const double f[10] = {e3, 0.5 * e4, 0.5 * e4, 0.5 * e4, e5 / 3.0, e5 / 3.0, e5 / 3.0, 0.25 * e5, 0.25 * e5, 0.25 * e5};
+    for (int q = 0; q < 10; ++q) removed64[q] = s[q] * f[q];
+    for (Chunk& c : obj.chunks)
+        if (c.kind == K_NONUNIFORM) c.flags &= CF_ONLY_EMPTY;
+    compute_all_derived_state(obj);
+    if (removed_chunks) edit_reset_occupied_chunk_ranges(obj);
+    return removed_chunks;
+}
+
+}  // namespace orc

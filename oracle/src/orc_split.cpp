@@ -93,6 +93,10 @@ static void reset_occupied_chunk_ranges(VoxelObject& obj) {  // object.rs:1149-1
     update_occupied_voxel_ranges(obj);
 }
 
+// (shared with orc_edit.cpp)
+void edit_update_all_internal_state(Chunk& c, Voxel* cv) { update_all_internal_state(c, cv); }
+void edit_reset_occupied_chunk_ranges(VoxelObject& obj) { reset_occupied_chunk_ranges(obj); }
+
 // outcome: 0 nothing to split, 1 extracted into `child` (origin offset in voxels), 2 region removed but
 // discarded (fewer than NON_EMPTY_VOXEL_THRESHOLD = 8 voxels, object.rs:203)
 int split_off_smallest_region(VoxelObject& parent, VoxelObject& child, int origin[3]) {

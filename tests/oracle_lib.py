@@ -86,6 +86,8 @@ def lib():
         L.orc_split_off_smallest_region.argtypes = [vp, C.POINTER(vp), vp]
         L.orc_clip_polyhedron.restype = C.c_int
         L.orc_clip_polyhedron.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.POINTER(vp), vp]
+        L.orc_absorb_sphere.restype = C.c_int
+        L.orc_absorb_sphere.argtypes = [vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, C.POINTER(C.c_uint32)]
         L.orc_physics_create.restype = vp
         L.orc_physics_free.argtypes = [vp]
         L.orc_physics_set_config.argtypes = [vp, vp]
@@ -276,6 +278,20 @@ class OracleObject:
         origin = np.zeros(3, dtype=np.int32)
         rc = lib().orc_clip_polyhedron(self.h, _p(pl), len(pl), _p(bb), 1 if copy else 0, C.byref(child), _p(origin))
         return rc, (OracleObject(child.value) if rc == 1 else None), tuple(int(x) for x in origin)
+
+    def absorb_sphere(self, center, influence_radius, sphere_radius, densities=None):
+        """apply_sphere_absorption with the sphere in the object's normalized space -> dict(removed64, emptied_by_type,
+        invalidated (bool per chunk), touched_chunks, removed_chunks)"""
+        d = np.ones(256, dtype=np.float32) if densities is None else np.ascontiguousarray(densities, dtype=np.float32)
+        c = np.ascontiguousarray(center, dtype=np.float32)
+        cc = self.chunk_counts
+        removed = np.zeros(10, dtype=np.float64)
+        by_type = np.zeros(256, dtype=np.uint32)
+        inval = np.zeros(cc[0] * cc[1] * cc[2], dtype=np.uint8)
+        touched = C.c_uint32(0)
+        n = lib().orc_absorb_sphere(self.h, _p(c), influence_radius, sphere_radius, _p(d), _p(removed), _p(by_type), _p(inval), C.byref(touched))
+        return {"removed64": removed, "emptied_by_type": by_type, "invalidated": inval.astype(bool), "touched_chunks": int(touched.value),
+                "removed_chunks": int(n)}
 
     def inertia(self, densities=None):
         d = np.ones(256, dtype=np.float32) if densities is None else np.ascontiguousarray(densities, dtype=np.float32)

@@ -82,3 +82,24 @@ def assert_regions_equal(o: ol.OracleObject, g: VoxelObject):
     glab = ol.tiled_to_dense(g.region_labels(), g.chunk_counts)
     np.testing.assert_array_equal(ol.canonicalize_labels(glab, 0xFFFFFFFF), ol.canonicalize_labels(olab, 0xFFFFFFFF))
     return n
+
+
+def assert_edited_objects_equal(o: ol.OracleObject, g: VoxelObject, what="", densities=None):
+    """after an operation that rewrites voxels (split, clip, absorb): voxel bytes, emptiness, types and flags of non-empty voxels,
+    chunk-local labels, chunk records, regions, mesh and moments. Adjacency bits of EMPTY voxels are history artefacts in the
+    reference (oracle/src/orc_split.cpp header) and are not compared."""
+    o_sdf, o_typ, o_flg, o_lab, o_info = o.export_dense()
+    g_sdf, g_typ, g_flg, g_lab, g_info = g.download()
+    assert o.chunk_counts == g.chunk_counts, what
+    np.testing.assert_array_equal(g_sdf, o_sdf, err_msg=what + "sdf")
+    ne = (o_flg & 1) == 0
+    np.testing.assert_array_equal((g_flg & 1) == 0, ne, err_msg=what + "emptiness")
+    np.testing.assert_array_equal(g_typ[ne], o_typ[ne], err_msg=what + "types of non-empty voxels")
+    np.testing.assert_array_equal(g_flg[ne], o_flg[ne], err_msg=what + "flags of non-empty voxels")
+    np.testing.assert_array_equal(g_lab, o_lab, err_msg=what + "local labels")
+    for f in ("kind", "flags", "face_dist", "region_count", "boundary_region_count"):
+        np.testing.assert_array_equal(g_info[f], o_info[f], err_msg=what + f)
+    n = assert_regions_equal(o, g)
+    assert_mesh_equal(o, g)
+    assert_inertia_equal(o, g, densities)
+    return n

@@ -1,0 +1,122 @@
+"""GPU parity of the voxel edit op: an absorbing sphere eating into a voxel object — HIP path through the C ABI
+against the oracle (tests/test_oracle_voxel.py pins the oracle's edit against an independent numpy restatement). After every
+edit: voxel bytes, flags, chunk records, chunk-local labels bit-exact; regions equal after canonical relabelling; the mesh of
+the edited object bit-exact; removed moments within 1e-5; emptied counts, touched / removed chunks and the set of invalidated
+mesh chunks equal."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import parity_util as pu
+from impact_amd import scenes
+from impact_amd.voxel import VoxelObject
+
+pytestmark = pytest.mark.gpu
+
+
+def both(ctx, graph, extent=1.0):
+    o = pu.oracle_from_graph(graph, extent)
+    g = pu.gpu_from_graph(ctx, graph, extent)
+    o.update_occupied_voxel_ranges()
+    o.compute_all_derived_state()
+    g.compute_all_derived_state()
+    g.update_occupied_voxel_ranges()
+    g.label_regions()
+    return o, g
+
+
+def absorb_both(o, g, center, radius, dens=None):
+    ro = o.absorb_sphere(center, radius + 2.0, radius, dens)
+    rg = g.absorb_sphere(center, radius + 2.0, radius, dens)
+    assert rg["touched_chunks"] == ro["touched_chunks"] and rg["removed_chunks"] == ro["removed_chunks"]
+    np.testing.assert_array_equal(rg["emptied_by_type"], ro["emptied_by_type"])
+    np.testing.assert_array_equal(rg["invalidated"], ro["invalidated"])
+    scale = np.maximum(np.abs(ro["removed64"]), 1e-300)
+    assert np.all(np.abs(rg["removed_moments"] - ro["removed64"]) <= 1e-5 * scale + 1e-9), (rg["removed_moments"], ro["removed64"])
+    ro["regions"] = pu.assert_edited_objects_equal(o, g, densities=dens)
+    return ro
+
+
+def centre_of(o):
+    return np.array([0.5 * (a + b) for a, b in o.info()["occupied_voxel_ranges"]], dtype=np.float32)
+
+
+def test_bite_out_of_a_sphere_surface(ctx):
+    o, g = both(ctx, scenes.sphere_scene(40.0))
+    c = centre_of(o) + np.float32(40.0) * np.array([0.6, 0.0, 0.8], np.float32)
+    r = absorb_both(o, g, c, 13.0)
+    assert r["emptied_by_type"].sum() > 1000 and r["regions"] == 1
+    g.close()
+
+
+def test_cavity_inside_converts_uniform_chunks(ctx):
+    """the sphere lies wholly inside the body: Uniform chunks of the touched box become NonUniform whether or not a voxel of
+    them changes, a closed cavity appears"""
+    o, g = both(ctx, scenes.sphere_scene(60.0))
+    r = absorb_both(o, g, centre_of(o) + np.array([0.25, -0.5, 0.75], np.float32), 17.0)
+    assert r["touched_chunks"] > 8 and r["regions"] == 1
+    g.close()
+
+
+def test_drilling_through_a_rod_splits_it(ctx):
+    """successive absorbing spheres (the reference moves the absorber every frame) cut a rod in two: after the last bite the
+    object has two regions and the smaller one splits off exactly as in the reference"""
+    from impact_amd.sdf_graph import SDFGraph, SDFNode
+
+    gr = SDFGraph()
+    gr.add_node(SDFNode.new_box([120.0, 14.0, 14.0]))
+    o, g = both(ctx, gr)
+    c0 = centre_of(o)
+    for t, off in enumerate((-6.0, 0.0, 6.0)):
+        r = absorb_both(o, g, c0 + np.array([5.0, off, 0.5 * t], np.float32), 9.5)
+    assert r["regions"] == 2
+    rc_o, child_o, origin_o = o.split_off_smallest_region()
+    rc_g, child_g, origin_g, _ = g.extract_any_disconnected_region()
+    assert rc_o == 1 and rc_g == 1 and tuple(int(x) for x in origin_g) == tuple(origin_o)
+    pu.assert_edited_objects_equal(o, g)
+    pu.assert_edited_objects_equal(child_o, child_g)
+    child_g.close()
+    g.close()
+
+
+def test_absorbing_everything_leaves_an_empty_object(ctx):
+    o, g = both(ctx, scenes.sphere_scene(20.0))
+    r = absorb_both(o, g, centre_of(o), 40.0)
+    assert r["removed_chunks"] > 0
+    assert g.count_regions() == 0
+    g.close()
+
+
+def test_sphere_that_misses_changes_nothing(ctx):
+    o, g = both(ctx, scenes.sphere_scene(20.0))
+    before = g.download()
+    r = absorb_both(o, g, centre_of(o) + np.array([200.0, 0.0, 0.0], np.float32), 10.0)
+    assert r["touched_chunks"] == 0
+    after = g.download()
+    for a, b in zip(before[:4], after[:4]):
+        np.testing.assert_array_equal(a, b)
+    g.close()
+
+
+def test_multi_material_object_reports_absorbed_types(ctx):
+    """dense upload with three voxel types and non-uniform densities: the tracker's per-type counts and the removed moments"""
+    rng = np.random.default_rng(5)
+    cc = (3, 3, 3)
+    n = 48
+    x, y, z = np.meshgrid(*[np.arange(n) + 0.5] * 3, indexing="ij")
+    d = np.sqrt((x - 24) ** 2 + (y - 24) ** 2 + (z - 24) ** 2) - 19.0
+    sd = np.clip(np.trunc(d.astype(np.float32) * np.float32(50.0)), -128, 127).astype(np.int8)
+    ty = (np.floor(x / 16).astype(np.uint8) + np.floor(z / 24).astype(np.uint8)) % 3
+    ty[sd >= 0] = 255
+    sdt, tyt = ol.dense_to_tiled(sd), ol.dense_to_tiled(ty)
+    o = ol.OracleObject.from_dense(cc, sdt, tyt)
+    g = VoxelObject.from_dense(ctx, cc, sdt, tyt)
+    o.update_occupied_voxel_ranges()
+    o.compute_all_derived_state()
+    g.compute_all_derived_state()
+    g.update_occupied_voxel_ranges()
+    g.label_regions()
+    dens = rng.uniform(0.5, 3.0, 256).astype(np.float32)
+    r = absorb_both(o, g, np.array([30.0, 22.5, 26.0], np.float32), 9.0, dens)
+    assert np.count_nonzero(r["emptied_by_type"][:3]) >= 2
+    g.close()

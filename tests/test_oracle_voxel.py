@@ -489,3 +489,82 @@ def test_local_labels_follow_reference_numbering():
     assert lab[0, 8, 8] == 0 and lab[15, 3, 3] == 1 and lab[7, 0, 7] == 2 and lab[7, 7, 15] == 3 and lab[5, 5, 5] == 4
     assert info[0, 0, 0]["region_count"] == 5 and info[0, 0, 0]["boundary_region_count"] == 4
     assert (lab[cells == 0] == 255).all()
+
+
+# ---- absorbing sphere (the per-frame voxel edit) ------------------------------------------------------------------------------
+def _absorb_numpy(o, center, r_infl, r_sphere):
+    """independent restatement on dense arrays: every voxel of a non-void chunk inside the occupied ranges whose centre lies
+    inside the influence sphere gets sd = quantise(max(sd * 0.02, -(sqrt(d2) - R))) (interaction/absorption.rs:170-180, 801-844;
+    object/intersection.rs:283-395, 766-782)"""
+    cc = o.chunk_counts
+    sdf, typ, flg, _, info = o.export_dense()
+    sd = ol.tiled_to_dense(sdf, cc).astype(np.int32)
+    kind = info["kind"].reshape(cc)
+    inf = o.info()
+    f32 = np.float32
+    c = np.asarray(center, dtype=f32)
+    rng = []
+    for d in range(3):
+        lo, hi = f32(c[d] - f32(r_infl)), f32(c[d] + f32(r_infl))
+        s = max(inf["occupied_voxel_ranges"][d][0], int(max(np.floor(lo), 0)))
+        e = min(inf["occupied_voxel_ranges"][d][1], max(int(np.ceil(hi)), 0))
+        rng.append((s, e))
+    if any(s >= e for s, e in rng):
+        return sd.astype(np.int8), 0
+    ii, jj, kk = np.meshgrid(*[np.arange(s, e) for s, e in rng], indexing="ij")
+    dx = (ii.astype(f32) + f32(0.5)) - c[0]
+    dy = (jj.astype(f32) + f32(0.5)) - c[1]
+    dz = (kk.astype(f32) + f32(0.5)) - c[2]
+    d2 = (dx * dx + dy * dy) + dz * dz
+    inside = d2 < f32(r_infl) * f32(r_infl)
+    nonvoid = kind[ii >> 4, jj >> 4, kk >> 4] != 0
+    old = sd[ii, jj, kk]
+    new_f = np.maximum(old.astype(f32) * f32(0.02), -(np.sqrt(d2) - f32(r_sphere)))
+    q = np.clip(np.trunc(new_f * f32(50.0)), -128, 127).astype(np.int32)
+    m = inside & nonvoid
+    emptied = int(np.count_nonzero(m & (old < 0) & (q >= 0)))
+    out = sd.copy()
+    sub = out[rng[0][0]:rng[0][1], rng[1][0]:rng[1][1], rng[2][0]:rng[2][1]]
+    sub[m] = q[m]
+    return out.astype(np.int8), emptied
+
+
+@pytest.mark.parametrize("case", ["surface", "inside", "reference_test_geometry", "everything"])
+def test_absorbing_sphere_matches_independent_restatement(case):
+    """the setting of the reference's modifying_voxels_within_sphere_finds_correct_voxels (object/intersection.rs:1203-1245:
+    sphere of radius 10 voxels... extent 0.5, absorbing sphere 0.4 R at the corner direction) and three more placements"""
+    if case == "reference_test_geometry":
+        o = ol.OracleObject.from_sdf(scenes.sphere_scene(10.0), 0.5, 0)
+    else:
+        o = ol.OracleObject.from_sdf(scenes.sphere_scene(24.0), 1.0, 0)
+    o.update_occupied_voxel_ranges()
+    o.compute_all_derived_state()
+    inf = o.info()
+    ctr = np.array([0.5 * (a + b) for a, b in inf["occupied_voxel_ranges"]], dtype=np.float32)
+    if case == "surface":
+        center, r = ctr + np.float32(24.0) * np.array([1, 0, 0], np.float32), 9.0
+    elif case == "inside":
+        center, r = ctr + np.array([1.25, -2.5, 3.75], np.float32), 7.0
+    elif case == "reference_test_geometry":
+        center, r = ctr - np.float32(20.0 / np.sqrt(3.0)) * np.ones(3, np.float32), 8.0  # (object radius 10, extent 0.5 -> 20 voxels)
+    else:
+        center, r = ctr, 40.0
+    want_sd, want_emptied = _absorb_numpy(o, center, r + 2.0, r)
+    before = o.inertia()[1]
+    res = o.absorb_sphere(center, r + 2.0, r)
+    sdf, typ, flg, _, info = o.export_dense()
+    got = ol.tiled_to_dense(sdf, o.chunk_counts)
+    kind = np.repeat(np.repeat(np.repeat(info["kind"].reshape(o.chunk_counts), 16, 0), 16, 1), 16, 2)
+    live = kind != 0  # chunks that became void are canonicalised to maximally-outside voxels
+    np.testing.assert_array_equal(got[live], want_sd[live])
+    assert np.all(want_sd[~live] >= 0)
+    assert int(res["emptied_by_type"].sum()) == want_emptied
+    # what was removed is what is missing from the moments
+    after = o.inertia()[1]
+    np.testing.assert_allclose(before - after, res["removed64"], rtol=1e-9, atol=1e-6)
+    if case == "everything":
+        assert int(np.count_nonzero((flg & 1) == 0)) == 0 and res["removed_chunks"] > 0
+    # derived state after the edit passes the reference's validators (re-implemented above in this file)
+    validate_adjacencies(o)
+    validate_chunk_obscuredness(o)
+    validate_region_count(o)
