@@ -102,6 +102,13 @@ def cpu_baseline(scale):
     t3 = time.perf_counter()
     cc = o.chunk_counts
     nvox = cc[0] * cc[1] * cc[2] * 4096
+    # the edit op on the same object: one absorbing sphere at the surface (EDIT_* below), derived state refreshed
+    c = np.array([0.5 * (a + b_) for a, b_ in o.info()["occupied_voxel_ranges"]], dtype=np.float32) + EDIT_OFFSET * np.float32(scale)
+    t4 = time.perf_counter()
+    er = o.absorb_sphere(c, EDIT_RADIUS * scale + 2.0, EDIT_RADIUS * scale)
+    t5 = time.perf_counter()
+    global _CPU_EDIT
+    _CPU_EDIT = {"ms": 1e3 * (t5 - t4), "emptied_voxels": int(er["emptied_by_type"].sum()), "cores": 1, "kind": "port"}
     return {
         "value": nvox / (t3 - t0),
         "unit": "voxels/s",
@@ -110,6 +117,45 @@ def cpu_baseline(scale):
         "sample": f"full N=1 workload once ({cc[0] * 16}^3 stored voxels): generate+derive {t1 - t0:.2f}s, remesh {t2 - t1:.2f}s "
                   f"({m.indices.size // 3 / (t2 - t1):.3g} tris/s), inertia {t3 - t2:.2f}s; single thread",
     }
+
+
+EDIT_OFFSET = np.array([110.0, 6.0, -4.0], dtype=np.float32)  # from the centre of the body, at scale 1: inside the tip of the +x bump
+EDIT_RADIUS = 15.0
+_CPU_EDIT = None
+
+
+def edit_benchmark(ctx, scale, reps=5):
+    """SURVEY §8f item 2 on the N=1 workload: an absorbing sphere bites into the asteroid (`ivx_absorb_sphere`: the edit kernel,
+    the derived-state + region refresh of the whole object, results back on the host), then the full remesh the bite invalidates.
+    Each repetition starts from the freshly generated body."""
+    from impact_amd import capi, scenes
+    from impact_amd.voxel import SDFVoxelGenerator, VoxelObject
+
+    gen = SDFVoxelGenerator(1.0, scenes.asteroid_scene(scale), 0)
+    obj = VoxelObject(ctx, gen.chunk_counts(), 1.0)
+    obj.set_sdf_program(gen)
+    obj.set_densities(np.ones(256, dtype=np.float32))
+    t_edit, t_remesh, emptied, touched = [], [], 0, 0
+    for _ in range(reps + 1):
+        obj.step(capi.STAGE_ALL)
+        c = np.array([0.5 * (a + b) for a, b in obj.update_occupied_voxel_ranges()], dtype=np.float32) + EDIT_OFFSET * np.float32(scale)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        r = obj.absorb_sphere(c, EDIT_RADIUS * scale + 2.0, EDIT_RADIUS * scale, want_invalidated=False)
+        t1 = time.perf_counter()
+        obj.step(capi.STAGE_REMESH)
+        t2 = time.perf_counter()
+        t_edit.append(t1 - t0)
+        t_remesh.append(t2 - t1)
+        emptied, touched = r["emptied_voxels"], r["touched_chunks"]
+    obj.close()
+    out = {"workload": f"absorbing sphere r={EDIT_RADIUS * scale:.1f} voxels at the surface of the N=1 body",
+           "edit_ms": round(1e3 * float(np.mean(t_edit[1:])), 4), "remesh_after_ms": round(1e3 * float(np.mean(t_remesh[1:])), 4),
+           "emptied_voxels": emptied, "touched_chunks": touched}
+    if _CPU_EDIT is not None:
+        out["cpu_baseline"] = dict(_CPU_EDIT)
+        out["cpu_baseline"]["parity"] = "same emptied voxel count" if _CPU_EDIT["emptied_voxels"] == emptied else "MISMATCH"
+    return out
 
 
 def pile_benchmark(ctx, with_cpu, steps=10):
@@ -328,6 +374,8 @@ def main():
             out["cpu_baseline"] = None
         if not args.no_pile:
             out["pile"] = pile_benchmark(ctx, with_cpu=(world == 1 and not args.no_cpu_baseline))
+            if world == 1:
+                out["edit"] = edit_benchmark(ctx, args.scale)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
