@@ -96,9 +96,23 @@ __global__ __launch_bounds__(64) void k_ccl_local_exact(GridView g, const uint8_
     __shared__ uint16_t s_par[IVX_CHUNK_VOXELS];
     __shared__ uint8_t s_flg[IVX_CHUNK_VOXELS];
     __shared__ uint8_t s_lab[IVX_CHUNK_VOXELS];
-    __shared__ uint32_t s_counts[2];
+    __shared__ uint32_t s_ne[IVX_CHUNK_VOXELS / 32];  // non-empty bits, voxel order
+    __shared__ uint16_t s_visit[1352];                // non-empty boundary voxels in the order of Loop3::over_full_boundary
+    __shared__ uint32_t s_counts[3];
     const uint32_t tid = threadIdx.x;
     const uint32_t n_multi = rscalar[2];
+    // position n of the boundary walk (utils.rs:247-322): X-, X+ full faces; Y-, Y+ with i in 1..15, k inner; Z-, Z+ with i, j in 1..15
+    auto boundary_pos = [](uint32_t n) -> uint32_t {
+        if (n < 512u) return ((n >> 8) ? 15u << 8 : 0u) | (n & 255u);
+        n -= 512u;
+        if (n < 448u) {
+            const uint32_t side = n / 224u, r = n % 224u;
+            return ((1u + r / 16u) << 8) | ((side ? 15u : 0u) << 4) | (r % 16u);
+        }
+        n -= 448u;
+        const uint32_t side = n / 196u, r = n % 196u;
+        return ((1u + r / 14u) << 8) | ((1u + r % 14u) << 4) | (side ? 15u : 0u);
+    };
     // bounded grid-stride walk over the (usually empty) list of multi-region chunks
     for (uint32_t li = blockIdx.x; li < n_multi; li += gridDim.x) {
     const uint32_t chunk = multi_list[li];
@@ -110,28 +124,55 @@ __global__ __launch_bounds__(64) void k_ccl_local_exact(GridView g, const uint8_
         s_lab[i] = 255;
     }
     __syncthreads();
+    // The replay itself is one lane's work; everything around it is not: the wave lists the non-empty voxels (bit set) and the
+    // non-empty boundary voxels in walk order first, so the serial lane never looks at an empty voxel, and numbers the
+    // interior-only sets afterwards in parallel.
+    for (uint32_t w = tid; w < IVX_CHUNK_VOXELS / 32; w += 64u) {
+        uint32_t m = 0;
+        for (uint32_t q = 0; q < 32u; ++q)
+            if (!(s_flg[w * 32u + q] & VF_EMPTY)) m |= 1u << q;
+        s_ne[w] = m;
+    }
+    {
+        uint32_t n_visit = 0;
+        for (uint32_t n0 = 0; n0 < 1352u; n0 += 64u) {
+            const uint32_t n = n0 + tid;
+            const uint32_t idx = n < 1352u ? boundary_pos(n) : 0u;
+            const bool ne = n < 1352u && !(s_flg[idx] & VF_EMPTY);
+            const unsigned long long bal = __ballot(ne);
+            if (ne) s_visit[n_visit + (uint32_t)__popcll(bal & ((1ull << tid) - 1ull))] = (uint16_t)idx;
+            n_visit += (uint32_t)__popcll(bal);
+        }
+        if (tid == 0) s_counts[2] = n_visit;
+    }
+    __syncthreads();
     if (tid == 0) {
-        for (uint32_t idx = 0; idx < IVX_CHUNK_VOXELS; ++idx) {
-            const uint32_t f = s_flg[idx];
-            if (f & VF_EMPTY) continue;
-            const uint32_t i = idx >> 8, j = (idx >> 4) & 15u, k = idx & 15u;
-            const uint32_t root = seq_find(s_par, idx);
-            if (i < 15u && (f & VF_X_UP)) {
-                const uint32_t r = seq_find(s_par, idx + 256u);
-                if (r != root) s_par[r] = (uint16_t)root;
-            }
-            if (j < 15u && (f & VF_Y_UP)) {
-                const uint32_t r = seq_find(s_par, idx + 16u);
-                if (r != root) s_par[r] = (uint16_t)root;
-            }
-            if (k < 15u && (f & VF_Z_UP)) {
-                const uint32_t r = seq_find(s_par, idx + 1u);
-                if (r != root) s_par[r] = (uint16_t)root;
+        for (uint32_t w = 0; w < IVX_CHUNK_VOXELS / 32; ++w) {
+            uint32_t m = s_ne[w];
+            while (m) {
+                const uint32_t idx = w * 32u + (uint32_t)(__ffs(m) - 1);
+                m &= m - 1;
+                const uint32_t f = s_flg[idx];
+                const uint32_t i = idx >> 8, j = (idx >> 4) & 15u, k = idx & 15u;
+                const uint32_t root = seq_find(s_par, idx);
+                if (i < 15u && (f & VF_X_UP)) {
+                    const uint32_t r = seq_find(s_par, idx + 256u);
+                    if (r != root) s_par[r] = (uint16_t)root;
+                }
+                if (j < 15u && (f & VF_Y_UP)) {
+                    const uint32_t r = seq_find(s_par, idx + 16u);
+                    if (r != root) s_par[r] = (uint16_t)root;
+                }
+                if (k < 15u && (f & VF_Z_UP)) {
+                    const uint32_t r = seq_find(s_par, idx + 1u);
+                    if (r != root) s_par[r] = (uint16_t)root;
+                }
             }
         }
         uint32_t current = 0;
-        auto visit = [&](uint32_t idx) {
-            if (s_flg[idx] & VF_EMPTY) return;
+        const uint32_t n_visit = s_counts[2];
+        for (uint32_t v = 0; v < n_visit; ++v) {
+            const uint32_t idx = s_visit[v];
             const uint32_t set_id = seq_find(s_par, idx);
             const uint32_t si = set_id >> 8, sj = (set_id >> 4) & 15u, sk = set_id & 15u;
             const bool root_interior = si > 0 && si < 15u && sj > 0 && sj < 15u && sk > 0 && sk < 15u;
@@ -144,28 +185,22 @@ __global__ __launch_bounds__(64) void k_ccl_local_exact(GridView g, const uint8_
                 s_lab[idx] = (uint8_t)current;
                 current = min(current + 1u, 255u);
             }
-        };
-        for (uint32_t side = 0; side < 2; ++side)  // X-, X+
-            for (uint32_t j = 0; j < 16; ++j)
-                for (uint32_t k = 0; k < 16; ++k) visit(((side ? 15u : 0u) << 8) | (j << 4) | k);
-        for (uint32_t side = 0; side < 2; ++side)  // Y-, Y+ (i interior)
-            for (uint32_t i = 1; i < 15; ++i)
-                for (uint32_t k = 0; k < 16; ++k) visit((i << 8) | ((side ? 15u : 0u) << 4) | k);
-        for (uint32_t side = 0; side < 2; ++side)  // Z-, Z+ (i, j interior)
-            for (uint32_t i = 1; i < 15; ++i)
-                for (uint32_t j = 1; j < 15; ++j) visit((i << 8) | (j << 4) | (side ? 15u : 0u));
-        const uint32_t nb = current;
-        for (uint32_t i = 1; i < 15; ++i)
-            for (uint32_t j = 1; j < 15; ++j)
-                for (uint32_t k = 1; k < 15; ++k) {
-                    const uint32_t idx = (i << 8) | (j << 4) | k;
-                    if (s_par[idx] == idx && !(s_flg[idx] & VF_EMPTY)) {
-                        s_lab[idx] = (uint8_t)current;
-                        current = min(current + 1u, 255u);
-                    }
-                }
-        s_counts[0] = nb;
-        s_counts[1] = current;
+        }
+        s_counts[0] = current;
+    }
+    __syncthreads();
+    {
+        // interior-only sets in (i,j,k) order (split_detection.rs:815-831): ordered parallel numbering of the remaining roots
+        uint32_t current = s_counts[0];
+        for (uint32_t n0 = 0; n0 < 2744u; n0 += 64u) {
+            const uint32_t n = n0 + tid;
+            const uint32_t idx = n < 2744u ? (((1u + n / 196u) << 8) | ((1u + (n / 14u) % 14u) << 4) | (1u + n % 14u)) : 0u;
+            const bool root = n < 2744u && !(s_flg[idx] & VF_EMPTY) && s_par[idx] == idx;
+            const unsigned long long bal = __ballot(root);
+            if (root) s_lab[idx] = (uint8_t)min(current + (uint32_t)__popcll(bal & ((1ull << tid) - 1ull)), 255u);
+            current = min(current + (uint32_t)__popcll(bal), 255u);
+        }
+        if (tid == 0) s_counts[1] = current;
     }
     __syncthreads();
     for (uint32_t idx = tid; idx < IVX_CHUNK_VOXELS; idx += 64u) {
