@@ -1,0 +1,242 @@
+// Voxel contact generation (first part): contacts between a sphere collidable and the surface voxels of a
+// voxel object — the step immediately before the constraint solver.
+//
+// Reference (engine/crates):
+//   for_each_sphere_voxel_object_contact                    impact_voxel/src/collidable.rs:1098-1127
+//   for_each_surface_voxel_maybe_intersecting_sphere        impact_voxel/src/object/intersection.rs:51-60, 97-151
+//   voxel_ranges_touching_aab                               impact_voxel/src/object/intersection.rs:766-782
+//   VoxelFlags::placement                                   impact_voxel/src/lib.rs:330-342
+//   compute_voxel_radius                                    impact_voxel/src/collidable.rs:1453-1455
+//   determine_sphere_sphere_contact_geometry                impact_physics/src/collision/collidable/sphere.rs:105-136
+//   ContactID::from_two_u64_and_n_indices                   impact_physics/src/constraint/contact.rs:180-199
+// Every non-empty voxel with fewer than six neighbours inside the touched voxel ranges is a small sphere (radius = -sd * extent)
+// tested against the collidable. The reference emits contacts in traversal order (chunks i,j,k, then voxels i,j,k), and the
+// solver's result depends on that order, so the emit pass is an ordered compaction: counts per chunk, a scan over the chunks
+// of the box, then thread-ordered prefix sums inside each chunk.
+#include "ivx_internal.hpp"
+
+namespace {
+
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 mk(float x, float y, float z) { return {x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+struct Q4 {
+    float x, y, z, w;
+};
+// glam Quat::mul_vec3a
+__device__ __forceinline__ V3 qrot(Q4 q, V3 v) {
+    const V3 b = mk(q.x, q.y, q.z);
+    const float b2 = dot(b, b);
+    return (v * (q.w * q.w - b2) + b * (dot(v, b) * 2.0f)) + cross(b, v) * (q.w * 2.0f);
+}
+// impact_math/src/random/splitmix.rs:4-10
+__device__ __forceinline__ unsigned long long splitmix(unsigned long long state) {
+    state += 0x9E3779B97F4A7C15ull;
+    unsigned long long z = state;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+struct SvcParams {
+    GridView g;
+    uint32_t lo[3], cc[3];   // chunk box
+    int32_t vlo[3], vhi[3];  // touched voxel ranges
+    Q4 q_inv;                // inverse rotation of transform_to_object_space
+    float t[3];              // its translation
+    float c[3], r;           // the sphere (world space)
+    float extent;
+    unsigned long long id_ab;  // splitmix(a ^ splitmix(b))
+    uint32_t body_a, body_b;
+    float restitution, static_friction, dynamic_friction;
+};
+
+struct Hit {
+    V3 pos, nrm;
+    float depth;
+};
+
+// the thread's row (i, j): bit k of the result = voxel k yields a contact; hits[] filled for those (emit pass only)
+template <bool EMIT>
+__device__ __forceinline__ uint32_t row_contacts(const SvcParams& p, const int8_t* sdf, const uint8_t* flags, uint32_t chunk, uint32_t ci, uint32_t cj,
+                                                 uint32_t ck, uint32_t tid, Hit* hits) {
+    const int gi = (int)(ci * 16u + (tid >> 4)), gj = (int)(cj * 16u + (tid & 15u));
+    if (gi < p.vlo[0] || gi >= p.vhi[0] || gj < p.vlo[1] || gj >= p.vhi[1]) return 0u;
+    const size_t o = (size_t)chunk * IVX_CHUNK_VOXELS + (size_t)tid * 16;
+    const uint4 s4 = *reinterpret_cast<const uint4*>(sdf + o), f4 = *reinterpret_cast<const uint4*>(flags + o);
+    const uint32_t sw[4] = {s4.x, s4.y, s4.z, s4.w}, fw[4] = {f4.x, f4.y, f4.z, f4.w};
+    uint32_t mask = 0;
+    const V3 c = mk(p.c[0], p.c[1], p.c[2]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int gk = (int)(ck * 16u) + k;
+        if (gk < p.vlo[2] || gk >= p.vhi[2]) continue;
+        const uint32_t f = (fw[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+        if ((f & VF_EMPTY) || __popc(f & 0xFCu) == 6) continue;  // empty, or Interior (lib.rs:330-342)
+        const int sd = (int)(int8_t)((sw[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+        const V3 p_obj = mk(((float)gi + 0.5f) * p.extent, ((float)gj + 0.5f) * p.extent, ((float)gk + 0.5f) * p.extent);
+        const V3 pw = qrot(p.q_inv, p_obj - mk(p.t[0], p.t[1], p.t[2]));  // inverse_transform_point
+        const float vr = -((float)sd * 0.02f) * p.extent;                  // compute_voxel_radius
+        // determine_sphere_sphere_contact_geometry(sphere, voxel_sphere)
+        const V3 d = c - pw;
+        const float d2 = dot(d, d), maxd = p.r + vr;
+        if (d2 > maxd * maxd) continue;
+        mask |= 1u << k;
+        if (EMIT) {
+            const float dist = sqrtf(d2);
+            const float inv = 1.0f / dist;
+            const V3 n = dist > 1e-8f ? d * inv : mk(0.0f, 0.0f, 1.0f);
+            hits[k].nrm = n;
+            hits[k].pos = pw + n * vr;
+            const float pen = maxd - dist;
+            hits[k].depth = pen > 0.0f ? pen : 0.0f;
+        }
+    }
+    return mask;
+}
+
+__device__ __forceinline__ uint32_t box_chunk(const SvcParams& p, uint32_t b, uint32_t& ci, uint32_t& cj, uint32_t& ck) {
+    const uint32_t bk = b % p.cc[2], bj = (b / p.cc[2]) % p.cc[1], bi = b / (p.cc[2] * p.cc[1]);
+    ci = p.lo[0] + bi, cj = p.lo[1] + bj, ck = p.lo[2] + bk;
+    return (ci * p.g.cy + cj) * p.g.cz + ck;
+}
+
+__global__ __launch_bounds__(256) void k_svc_count(SvcParams p, const uint8_t* __restrict__ flags, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t s_w[4];
+    uint32_t ci, cj, ck;
+    const uint32_t chunk = box_chunk(p, blockIdx.x, ci, cj, ck);
+    uint32_t n = 0;
+    if (p.g.info[chunk].kind == KIND_NONUNIFORM)  // only non-uniform chunks can have surface voxels
+        n = __popc(row_contacts<false>(p, p.g.sdf, flags, chunk, ci, cj, ck, threadIdx.x, nullptr));
+    n = ivx_wave_sum(n);
+    if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+// exclusive scan over the chunks of the box (one workgroup; the box of a collidable is a few dozen chunks)
+__global__ __launch_bounds__(256) void k_svc_scan(uint32_t n, const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets, uint32_t* __restrict__ total) {
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < n; b0 += 256u) {
+        const uint32_t b = b0 + tid;
+        const uint32_t v = b < n ? counts[b] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o, 64);
+            if (lane >= (uint32_t)o) incl += t;
+        }
+        if (lane == 63u) s_w[wave] = incl;
+        __syncthreads();
+        const uint32_t w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
+        const uint32_t wbase = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
+        if (b < n) offsets[b] = s_carry + wbase + incl - v;
+        __syncthreads();
+        if (tid == 0) s_carry += (w0 + w1) + (w2 + w3);
+        __syncthreads();
+    }
+    if (tid == 0) *total = s_carry;
+}
+
+__global__ __launch_bounds__(256) void k_svc_emit(SvcParams p, const uint8_t* __restrict__ flags, const uint32_t* __restrict__ offsets, uint32_t cap,
+                                                  ivx_contact* __restrict__ out) {
+    __shared__ uint32_t s_w[4];
+    uint32_t ci, cj, ck;
+    const uint32_t chunk = box_chunk(p, blockIdx.x, ci, cj, ck);
+    if (p.g.info[chunk].kind != KIND_NONUNIFORM) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    Hit hits[16];
+    const uint32_t mask = row_contacts<true>(p, p.g.sdf, flags, chunk, ci, cj, ck, tid, hits);
+    const uint32_t v = __popc(mask);
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= (uint32_t)o) incl += t;
+    }
+    if (lane == 63u) s_w[wave] = incl;
+    __syncthreads();
+    const uint32_t w0 = s_w[0], w1 = s_w[1], w2 = s_w[2];
+    const uint32_t wbase = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
+    uint32_t slot = offsets[blockIdx.x] + wbase + incl - v;
+    const unsigned long long gi = ci * 16u + (tid >> 4), gj = cj * 16u + (tid & 15u);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (!((mask >> k) & 1u)) continue;
+        if (slot < cap) {
+            ivx_contact c;
+            unsigned long long id = p.id_ab;
+            id = splitmix(id ^ splitmix(gi));
+            id = splitmix(id ^ splitmix(gj));
+            id = splitmix(id ^ splitmix((unsigned long long)(ck * 16u + (uint32_t)k)));
+            c.id = id;
+            c.body_a = p.body_a;
+            c.body_b = p.body_b;
+            c.position[0] = hits[k].pos.x, c.position[1] = hits[k].pos.y, c.position[2] = hits[k].pos.z;
+            c.normal[0] = hits[k].nrm.x, c.normal[1] = hits[k].nrm.y, c.normal[2] = hits[k].nrm.z;
+            c.depth = hits[k].depth;
+            c.restitution = p.restitution;
+            c.static_friction = p.static_friction;
+            c.dynamic_friction = p.dynamic_friction;
+            c.flags = slot == 0 ? (uint32_t)IVX_CONTACT_MANIFOLD_START : 0u;  // one collision = one manifold
+            c.reserved = 0;
+            out[slot] = c;
+        }
+        slot += 1;
+    }
+}
+
+}  // namespace
+
+int ivx_launch_sphere_contacts(ivx_grid* g, const uint32_t lo[3], const uint32_t cc[3], const int32_t vlo[3], const int32_t vhi[3],
+                               const float rotation_xyzw[4], const float translation[3], const float center[3], float radius, uint64_t id_a, uint64_t id_b,
+                               uint32_t body_a, uint32_t body_b, const float response[3], uint32_t* d_counts, uint32_t* d_offsets, uint32_t* d_total,
+                               ivx_contact* d_out, uint32_t cap, int emit) {
+    SvcParams p;
+    p.g = ivx_view(g);
+    for (int d = 0; d < 3; ++d) {
+        p.lo[d] = lo[d];
+        p.cc[d] = cc[d];
+        p.vlo[d] = vlo[d];
+        p.vhi[d] = vhi[d];
+        p.t[d] = translation[d];
+        p.c[d] = center[d];
+    }
+    p.q_inv = Q4{-rotation_xyzw[0], -rotation_xyzw[1], -rotation_xyzw[2], rotation_xyzw[3]};
+    p.r = radius;
+    p.extent = g->extent;
+    {  // ContactID::from_two_u64_and_n_indices: the part that does not depend on the voxel
+        auto mix = [](uint64_t state) {
+            state += 0x9E3779B97F4A7C15ull;
+            uint64_t z = state;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            return z ^ (z >> 31);
+        };
+        p.id_ab = mix(id_a ^ mix(id_b));
+    }
+    p.body_a = body_a;
+    p.body_b = body_b;
+    p.restitution = response[0];
+    p.static_friction = response[1];
+    p.dynamic_friction = response[2];
+    const uint32_t n_box = cc[0] * cc[1] * cc[2];
+    if (!emit) {
+        hipLaunchKernelGGL(k_svc_count, dim3(n_box), dim3(256), 0, g->ctx->stream, p, g->flags, d_counts);
+        hipLaunchKernelGGL(k_svc_scan, dim3(1), dim3(256), 0, g->ctx->stream, n_box, d_counts, d_offsets, d_total);
+    } else {
+        hipLaunchKernelGGL(k_svc_emit, dim3(n_box), dim3(256), 0, g->ctx->stream, p, g->flags, d_offsets, cap, d_out);
+    }
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}

@@ -354,6 +354,19 @@ class VoxelObject:
                 "invalidated": None if inval is None else inval.astype(bool), "touched_chunks": int(out[0]["touched_chunks"]),
                 "removed_chunks": int(out[0]["removed_chunks"])}
 
+    # ---- contact generation ------------------------------------------------------------------------
+    def sphere_contacts(self, rotation_xyzw, translation, sphere_center, sphere_radius: float, collidable_id_a: int, collidable_id_b: int, body_a: int,
+                        body_b: int, response=(0.0, 0.0, 0.0), capacity: int = 65536) -> np.ndarray:
+        """`for_each_sphere_voxel_object_contact` (collidable.rs:1098-1127) as a contact list for `PhysicsWorld.prepare_constraints`:
+        `rotation_xyzw` + `translation` = transform_to_object_space, the sphere in world space, `response` = combined restitution,
+        static and dynamic friction."""
+        out = np.zeros(capacity, dtype=capi.CONTACT_DTYPE)
+        n = C.c_size_t(0)
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+        check(capi.lib().ivx_sphere_voxel_object_contacts(self.h, ptr(f(rotation_xyzw)), ptr(f(translation)), ptr(f(sphere_center)), sphere_radius,
+                                                          collidable_id_a, collidable_id_b, body_a, body_b, ptr(f(response)), ptr(out), capacity, C.byref(n)))
+        return out[: n.value]
+
     def halo_bytes(self) -> int:
         return int(capi.lib().ivx_halo_bytes(self.h))
 

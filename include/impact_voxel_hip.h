@@ -316,6 +316,20 @@ typedef struct {
     float restitution, static_friction, dynamic_friction;
     uint32_t flags, reserved;
 } ivx_contact;
+
+/* ---- voxel contact generation (sphere collidables) -----------------------------------------------------------
+ * for_each_sphere_voxel_object_contact (impact_voxel/src/collidable.rs:1098-1127) wrapped as generate_sphere_voxel_object_contact_manifold
+ * does (collidable.rs:1051-1096): every surface voxel (non-empty, fewer than six neighbours) in the voxel ranges the sphere's box touches
+ * is a sphere of radius -sd * extent tested against the collidable (determine_sphere_sphere_contact_geometry, impact_physics
+ * collision/collidable/sphere.rs:105-136). `rotation_xyzw` + `translation` = transform_to_object_space (Isometry3: world -> the object's
+ * model space), the sphere is in world space; `response` = the combined restitution, static and dynamic friction. Contacts come in the
+ * reference's traversal order (chunks i,j,k then voxels i,j,k) with id = ContactID::from_two_u64_and_n_indices(collidable_id_a,
+ * collidable_id_b, [i,j,k]) and the first one flagged IVX_CONTACT_MANIFOLD_START: ready for ivx_world_set_contacts. Needs current derived
+ * state. *n_out is the number found even when it exceeds `cap` (IVX_ERR_CAPACITY then). */
+int ivx_sphere_voxel_object_contacts(ivx_grid*, const float rotation_xyzw[4], const float translation[3], const float sphere_center[3],
+                                     float sphere_radius, uint64_t collidable_id_a, uint64_t collidable_id_b, uint32_t body_a, uint32_t body_b,
+                                     const float response[3], ivx_contact* out, size_t cap, size_t* n_out);
+
 #define IVX_KINEMATIC_BODY 0x80000000u
 #define IVX_CONTACT_MANIFOLD_START 1u
 /* ConstraintSolverConfig (src/constraint/solver.rs:41-57; defaults 8, 0.4, 3, 0.2 at 374-384) */

@@ -14,6 +14,8 @@ void derive_inertial_properties(const float m[10], float out[22]);
 uint32_t canonical_region_labels(const VoxelObject& obj, uint32_t* labels);
 int split_off_smallest_region(VoxelObject& parent, VoxelObject& child, int origin[3]);
 int clip_polyhedron(VoxelObject& parent, const float* planes, int n_planes, const float aabb[6], int mode, VoxelObject& child, int origin[3]);
+int sphere_voxel_object_contacts(const VoxelObject& obj, const float rot[4], const float trans[3], const float center[3], float radius, int cap,
+                                 int32_t* indices, float* position, float* normal, float* depth);
 int absorb_sphere(VoxelObject& obj, const float center[3], float influence_radius, float sphere_radius, const float* dens, double removed64[10],
                   uint32_t emptied_by_type[256], uint8_t* invalidated, uint32_t* touched_chunks);
 
@@ -363,6 +365,12 @@ int orc_clip_polyhedron(orc_object* parent, const float* planes4, int n_planes, 
 int orc_absorb_sphere(orc_object* o, const float center[3], float influence_radius, float sphere_radius, const float densities[256],
                       double removed64[10], uint32_t emptied_by_type[256], uint8_t* invalidated_chunks, uint32_t* touched_chunks) {
     return absorb_sphere(o->obj, center, influence_radius, sphere_radius, densities, removed64, emptied_by_type, invalidated_chunks, touched_chunks);
+}
+
+// for_each_sphere_voxel_object_contact (impact_voxel/src/collidable.rs:1098-1127): contacts in the reference's traversal order
+int orc_sphere_voxel_object_contacts(const orc_object* o, const float rotation_xyzw[4], const float translation[3], const float center[3], float radius,
+                                     int cap, int32_t* indices, float* position, float* normal, float* depth) {
+    return sphere_voxel_object_contacts(o->obj, rotation_xyzw, translation, center, radius, cap, indices, position, normal, depth);
 }
 
 int8_t orc_sd_from_f32(float v) { return sd_from_f32(v); }

@@ -86,6 +86,8 @@ def lib():
         L.orc_split_off_smallest_region.argtypes = [vp, C.POINTER(vp), vp]
         L.orc_clip_polyhedron.restype = C.c_int
         L.orc_clip_polyhedron.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.POINTER(vp), vp]
+        L.orc_sphere_voxel_object_contacts.restype = C.c_int
+        L.orc_sphere_voxel_object_contacts.argtypes = [vp, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, vp]
         L.orc_absorb_sphere.restype = C.c_int
         L.orc_absorb_sphere.argtypes = [vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, C.POINTER(C.c_uint32)]
         L.orc_physics_create.restype = vp
@@ -292,6 +294,18 @@ class OracleObject:
         n = lib().orc_absorb_sphere(self.h, _p(c), influence_radius, sphere_radius, _p(d), _p(removed), _p(by_type), _p(inval), C.byref(touched))
         return {"removed64": removed, "emptied_by_type": by_type, "invalidated": inval.astype(bool), "touched_chunks": int(touched.value),
                 "removed_chunks": int(n)}
+
+    def sphere_contacts(self, rotation_xyzw, translation, center, radius, cap=65536):
+        """for_each_sphere_voxel_object_contact -> (indices [n,3], position [n,3], normal [n,3], depth [n])"""
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+        idx = np.zeros((cap, 3), dtype=np.int32)
+        pos = np.zeros((cap, 3), dtype=np.float32)
+        nrm = np.zeros((cap, 3), dtype=np.float32)
+        dep = np.zeros(cap, dtype=np.float32)
+        n = lib().orc_sphere_voxel_object_contacts(self.h, _p(f(rotation_xyzw)), _p(f(translation)), _p(f(center)), radius, cap, _p(idx), _p(pos), _p(nrm),
+                                                   _p(dep))
+        assert n <= cap
+        return idx[:n], pos[:n], nrm[:n], dep[:n]
 
     def inertia(self, densities=None):
         d = np.ones(256, dtype=np.float32) if densities is None else np.ascontiguousarray(densities, dtype=np.float32)

@@ -1,0 +1,122 @@
+"""GPU parity of voxel contact generation (sphere collidables): `ivx_sphere_voxel_object_contacts` through the
+C ABI against the oracle (pinned in tests/test_oracle_voxel.py by a brute-force sweep): the same contacts in the same order
+with the same ids, geometry bit-exact; then the whole chain the reference runs every frame for a ball on a voxel body — contact
+generation -> prepare constraints -> solve -> integrate — against the oracle doing the same, step by step."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import parity_util as pu
+import physics_util as phu
+from impact_amd import scenes
+from impact_amd.capi import CONTACT_DTYPE
+
+pytestmark = pytest.mark.gpu
+
+
+def both(ctx, graph, extent):
+    o = pu.oracle_from_graph(graph, extent)
+    g = pu.gpu_from_graph(ctx, graph, extent)
+    o.update_occupied_voxel_ranges()
+    o.compute_all_derived_state()
+    g.compute_all_derived_state()
+    g.update_occupied_voxel_ranges()
+    g.label_regions()
+    return o, g
+
+
+def oracle_contact_list(o, q, t, c, r, id_a, id_b, body_a, body_b, response):
+    idx, pos, nrm, dep = o.sphere_contacts(q, t, c, r)
+    out = np.zeros(len(idx), dtype=CONTACT_DTYPE)
+    for n, (ijk, p, nn, d) in enumerate(zip(idx, pos, nrm, dep)):
+        out[n]["id"] = scenes.contact_id(id_a, id_b, *[int(x) for x in ijk])
+        out[n]["body_a"], out[n]["body_b"] = body_a, body_b
+        out[n]["position"], out[n]["normal"], out[n]["depth"] = p, nn, d
+        out[n]["restitution"], out[n]["static_friction"], out[n]["dynamic_friction"] = response
+        out[n]["flags"] = 1 if n == 0 else 0
+    return out
+
+
+def assert_contacts_equal(got, want):
+    assert len(got) == len(want)
+    for f in ("id", "body_a", "body_b", "flags"):
+        np.testing.assert_array_equal(got[f], want[f], err_msg=f)
+    for f in ("position", "normal", "depth", "restitution", "static_friction", "dynamic_friction"):
+        np.testing.assert_array_equal(got[f].view(np.uint32), want[f].view(np.uint32), err_msg=f)  # f32 bit patterns
+
+
+@pytest.mark.parametrize("extent", [1.0, 0.5])
+def test_sphere_against_rotated_voxel_body(ctx, extent):
+    o, g = both(ctx, scenes.sphere_scene(20.0), extent)
+    axis = np.array([0.3, -1.0, 0.5]) / np.linalg.norm([0.3, -1.0, 0.5])
+    q = np.array([*(axis * np.sin(0.45)), np.cos(0.45)], dtype=np.float32)
+    t = np.array([1.5, -2.25, 0.75], dtype=np.float32)
+    ctr = np.array([0.5 * (a + b) for a, b in o.info()["occupied_voxel_ranges"]], dtype=np.float64) * extent
+    resp = (0.4, 0.7, 0.5)
+    for direction, depth_in in (([1, 0, 0], 1.0), ([0.6, 0.0, 0.8], 0.2), ([-0.5, 0.5, 0.7], 3.0), ([0, 1, 0], -8.0)):
+        d = np.asarray(direction, dtype=np.float64)
+        d /= np.linalg.norm(d)
+        p_obj = ctr + d * (20.0 * extent + 4.0 - depth_in)  # ball of radius 4 pushed `depth_in` into the surface (negative: apart)
+        x, y, z, w = [float(a) for a in q]
+        b = np.array([-x, -y, -z])
+        v = p_obj - t.astype(np.float64)
+        c_world = (v * (w * w - b @ b) + b * (2 * (v @ b)) + np.cross(b, v) * (2 * w)).astype(np.float32)
+        want = oracle_contact_list(o, q, t, c_world, 4.0, 77, 1234567, 0, 1, resp)
+        got = g.sphere_contacts(q, t, c_world, 4.0, 77, 1234567, 0, 1, resp)
+        assert (len(want) > 0) == (depth_in > -1.0)
+        assert_contacts_equal(got, want)
+    g.close()
+
+
+def test_capacity_error_reports_the_count(ctx):
+    from impact_amd.capi import IvxError
+
+    o, g = both(ctx, scenes.sphere_scene(20.0), 1.0)
+    ctr = np.array([0.5 * (a + b) for a, b in o.info()["occupied_voxel_ranges"]], dtype=np.float32)
+    with pytest.raises(IvxError):
+        g.sphere_contacts((0, 0, 0, 1), (0, 0, 0), ctr + np.array([22.0, 0, 0], np.float32), 6.0, 1, 2, 0, 1, capacity=3)
+    g.close()
+
+
+def test_ball_dropped_on_a_voxel_body_steps_like_the_oracle(ctx):
+    """the per-frame chain: contacts from the voxel body's current pose -> prepare -> solve -> integrate, 60 steps; the ball
+    (dynamic) lands on a heavy voxel sphere (dynamic too, at rest); GPU contacts feed the GPU solver, oracle contacts the oracle"""
+    extent = 0.25
+    o, g = both(ctx, scenes.sphere_scene(16.0), extent)  # radius 4.0 world units
+    inf = o.info()
+    ctr = np.array([0.5 * (a + b) for a, b in inf["occupied_voxel_ranges"]], dtype=np.float64) * extent  # body centre in model space
+    ball_r = 0.75
+    # rigid bodies: 0 = the ball, 1 = the voxel body (its body frame origin = the centre of the voxel sphere)
+    ball = ol.uniform_sphere_body(ball_r, 2.0, (0.3, 4.0 + ball_r + 0.05, -0.2), (0.0, -1.0, 0.0))
+    body = ol.uniform_sphere_body(4.0, 5.0, (0.0, 0.0, 0.0))
+    dyn = np.array([ball, body])
+    dyn["total_force"][0] = (0.0, -9.81 * float(dyn["mass"][0]), 0.0)
+    w, op = phu.make_pair(ctx, dyn)
+    resp = (0.2, 0.6, 0.4)
+    had_contact = False
+    for step in range(60):
+        gd = w.bodies()[0]
+        od = op.bodies()[0]
+        lists = []
+        for src, bodies in ((g, gd), (o, od)):
+            # transform_to_object_space: world -> model space of the voxel body = translate(model centre) . inverse(body pose)
+            qb = bodies["orientation"][1].astype(np.float64)
+            pb = bodies["position"][1].astype(np.float64)
+            qi = np.array([-qb[0], -qb[1], -qb[2], qb[3]])
+            x, y, z, ww = qi
+            bv = np.array([x, y, z])
+            v = -pb
+            tr = (v * (ww * ww - bv @ bv) + bv * (2 * (v @ bv)) + np.cross(bv, v) * (2 * ww)) + ctr
+            c = bodies["position"][0]
+            if src is g:
+                lists.append(g.sphere_contacts(qi.astype(np.float32), tr.astype(np.float32), c, ball_r, 11, 22, 0, 1, resp))
+            else:
+                lists.append(oracle_contact_list(o, qi.astype(np.float32), tr.astype(np.float32), c, ball_r, 11, 22, 0, 1, resp))
+        had_contact |= len(lists[1]) > 0
+        assert len(lists[0]) == len(lists[1]), step
+        w.perform_physics_step(lists[0], 0.004)
+        op.step(lists[1], 0.004)
+        phu.assert_bodies_close(w.bodies()[0], op.bodies()[0], what=f"step {step}: ")
+    assert had_contact
+    w.close()
+    g.close()

@@ -568,3 +568,62 @@ def test_absorbing_sphere_matches_independent_restatement(case):
     validate_adjacencies(o)
     validate_chunk_obscuredness(o)
     validate_region_count(o)
+
+
+# ---- sphere vs voxel object contacts --------------------------------------------------------------------------------------------
+def test_sphere_contacts_match_brute_force_over_surface_voxels():
+    """for_each_sphere_voxel_object_contact (collidable.rs:1098-1127) against a brute-force sweep of every voxel of the object:
+    non-empty voxels with fewer than six neighbours whose sphere (radius -sd * extent) touches the collidable, in (i,j,k) order
+    per chunk; rotated + translated object, extent 0.5"""
+    ext = np.float32(0.5)
+    o = ol.OracleObject.from_sdf(scenes.sphere_scene(12.0), float(ext), 0)
+    o.update_occupied_voxel_ranges()
+    o.compute_all_derived_state()
+    axis = np.array([1.0, 2.0, -1.0]) / np.sqrt(6.0)
+    ang = 0.8
+    q = np.array([*(axis * np.sin(ang / 2)), np.cos(ang / 2)], dtype=np.float32)
+    t = np.array([3.0, -1.5, 0.25], dtype=np.float32)
+
+    def rot(qv, v):  # exact quaternion rotation in f64 (the check is geometric, to 1e-5)
+        x, y, z, w = [float(a) for a in qv]
+        b = np.array([x, y, z])
+        return v * (w * w - b @ b) + b * (2 * (v @ b)) + np.cross(b, v) * (2 * w)
+
+    # a sphere whose centre sits on the object's surface, given in world space
+    inf = o.info()
+    ctr_obj = np.array([0.5 * (a + b) for a, b in inf["occupied_voxel_ranges"]]) * float(ext)
+    p_obj = ctr_obj + np.array([12.0 * float(ext), 0.0, 0.0])  # (SDF lengths are in voxels)
+    qc = np.array([-q[0], -q[1], -q[2], q[3]])
+    c_world = rot(qc, p_obj - t.astype(np.float64))
+    R = 3.0
+    idx, pos, nrm, dep = o.sphere_contacts(q, t, c_world.astype(np.float32), R)
+    assert len(idx) > 20
+    sdf, typ, flg, _, info = o.export_dense()
+    cc = o.chunk_counts
+    sd = ol.tiled_to_dense(sdf, cc).astype(np.float64) * 0.02
+    fl = ol.tiled_to_dense(flg, cc)
+    want = []
+    ne = (fl & 1) == 0
+    surf = ne & (np.unpackbits((fl & 0xFC)[..., None], axis=-1).sum(-1) < 6)
+    for i, j, k in np.argwhere(surf):
+        p = (np.array([i, j, k]) + 0.5) * float(ext)
+        pw = rot(qc, p - t.astype(np.float64))
+        vr = -sd[i, j, k] * float(ext)
+        if np.linalg.norm(c_world - pw) <= R + vr - 1e-6:
+            want.append((i, j, k))
+    got = {tuple(int(x) for x in r) for r in idx}
+    missing = [w for w in want if w not in got]
+    assert not missing, missing[:5]
+    # whatever else was reported lies within rounding of touching
+    for r, p_, n_, d_ in zip(idx, pos, nrm, dep):
+        p = (r + 0.5) * float(ext)
+        pw = rot(qc, p - t.astype(np.float64))
+        vr = -sd[tuple(r)] * float(ext)
+        dist = np.linalg.norm(c_world - pw)
+        assert dist <= R + vr + 1e-4
+        np.testing.assert_allclose(d_, max(0.0, R + vr - dist), atol=2e-5)
+        np.testing.assert_allclose(n_, (c_world - pw) / dist, atol=2e-5)
+        np.testing.assert_allclose(p_, pw + vr * (c_world - pw) / dist, atol=2e-5)
+    # traversal order: chunks in (i,j,k) order, voxels in (i,j,k) order inside a chunk
+    key = [((r[0] >> 4, r[1] >> 4, r[2] >> 4), tuple(r)) for r in idx.tolist()]
+    assert key == sorted(key)
