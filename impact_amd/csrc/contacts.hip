@@ -50,7 +50,8 @@ struct SvcParams {
     int32_t vlo[3], vhi[3];  // touched voxel ranges
     Q4 q_inv;                // inverse rotation of transform_to_object_space
     float t[3];              // its translation
-    float c[3], r;           // the sphere (world space)
+    uint32_t mode;           // 0: sphere collidable (c, r); 1: plane collidable (unit normal c, displacement r), Corner voxels only
+    float c[3], r;           // the collidable (world space)
     float extent;
     unsigned long long id_ab;  // splitmix(a ^ splitmix(b))
     uint32_t body_a, body_b;
@@ -78,11 +79,24 @@ __device__ __forceinline__ uint32_t row_contacts(const SvcParams& p, const int8_
         const int gk = (int)(ck * 16u) + k;
         if (gk < p.vlo[2] || gk >= p.vhi[2]) continue;
         const uint32_t f = (fw[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-        if ((f & VF_EMPTY) || __popc(f & 0xFCu) == 6) continue;  // empty, or Interior (lib.rs:330-342)
+        // empty, or Interior (six neighbours, lib.rs:330-342); a plane only needs the Corner voxels (at most three, collidable.rs:1187-1191)
+        if ((f & VF_EMPTY) || __popc(f & 0xFCu) > (p.mode ? 3 : 5)) continue;
         const int sd = (int)(int8_t)((sw[k >> 2] >> (8 * (k & 3))) & 0xFFu);
         const V3 p_obj = mk(((float)gi + 0.5f) * p.extent, ((float)gj + 0.5f) * p.extent, ((float)gk + 0.5f) * p.extent);
         const V3 pw = qrot(p.q_inv, p_obj - mk(p.t[0], p.t[1], p.t[2]));  // inverse_transform_point
         const float vr = -((float)sd * 0.02f) * p.extent;                  // compute_voxel_radius
+        if (p.mode) {  // determine_sphere_plane_contact_geometry(voxel_sphere, plane) (sphere.rs:138-160)
+            const float sdist = dot(c, pw) - p.r;
+            const float pen = vr - sdist;
+            if (pen < 0.0f) continue;
+            mask |= 1u << k;
+            if (EMIT) {
+                hits[k].nrm = c;
+                hits[k].pos = pw - c * sdist;
+                hits[k].depth = pen;
+            }
+            continue;
+        }
         // determine_sphere_sphere_contact_geometry(sphere, voxel_sphere)
         const V3 d = c - pw;
         const float d2 = dot(d, d), maxd = p.r + vr;
@@ -201,9 +215,10 @@ __global__ __launch_bounds__(256) void k_svc_emit(SvcParams p, const uint8_t* __
 int ivx_launch_sphere_contacts(ivx_grid* g, const uint32_t lo[3], const uint32_t cc[3], const int32_t vlo[3], const int32_t vhi[3],
                                const float rotation_xyzw[4], const float translation[3], const float center[3], float radius, uint64_t id_a, uint64_t id_b,
                                uint32_t body_a, uint32_t body_b, const float response[3], uint32_t* d_counts, uint32_t* d_offsets, uint32_t* d_total,
-                               ivx_contact* d_out, uint32_t cap, int emit) {
+                               ivx_contact* d_out, uint32_t cap, int emit, int plane) {
     SvcParams p;
     p.g = ivx_view(g);
+    p.mode = plane ? 1u : 0u;
     for (int d = 0; d < 3; ++d) {
         p.lo[d] = lo[d];
         p.cc[d] = cc[d];

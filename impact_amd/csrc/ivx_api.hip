@@ -841,14 +841,37 @@ int ivx_absorb_sphere(ivx_grid* g, const float center[3], float influence_radius
     return IVX_OK;
 }
 
-int ivx_sphere_voxel_object_contacts(ivx_grid* g, const float rotation_xyzw[4], const float translation[3], const float sphere_center[3], float sphere_radius,
-                                     uint64_t collidable_id_a, uint64_t collidable_id_b, uint32_t body_a, uint32_t body_b, const float response[3],
-                                     ivx_contact* out, size_t cap, size_t* n_out) {
-    IVX_REQUIRE(g && rotation_xyzw && translation && sphere_center && response && n_out && (out || cap == 0), IVX_ERR_INVALID,
-                "ivx_sphere_voxel_object_contacts: null argument");
-    IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "ivx_sphere_voxel_object_contacts: derived state must be current (ivx_derive_state + ivx_label_regions)");
-    IVX_REQUIRE(g->x_off == 0 && g->gx == g->cc[0] && !g->has_ghost[0] && !g->has_ghost[1], IVX_ERR_STATE,
-                "ivx_sphere_voxel_object_contacts: not available on a slab of a decomposed grid");
+// rotate a vector by a quaternion the way glam's Quat::mul_vec3a does (host side of Isometry3::transform_point)
+static void host_qrot(const float q[4], const float v[3], float out[3]) {
+    const float qx = q[0], qy = q[1], qz = q[2], qw = q[3], vx = v[0], vy = v[1], vz = v[2];
+    const float b2 = (qx * qx + qy * qy) + qz * qz, s1 = qw * qw - b2, s2 = ((vx * qx + vy * qy) + vz * qz) * 2.0f, s3 = qw * 2.0f;
+    const float cxp = qy * vz - vy * qz, cyp = qz * vx - vz * qx, czp = qx * vy - vx * qy;  // cross(b, v)
+    out[0] = (vx * s1 + qx * s2) + cxp * s3;
+    out[1] = (vy * s1 + qy * s2) + cyp * s3;
+    out[2] = (vz * s1 + qz * s2) + czp * s3;
+}
+
+// voxel_ranges_touching_aab (intersection.rs:766-782) on the occupied ranges; false when a range is empty
+static bool touched_ranges(const uint32_t occ[12], const float lo_f[3], const float hi_f[3], int32_t vlo[3], int32_t vhi[3], uint32_t lo[3], uint32_t cc[3]) {
+    for (int d = 0; d < 3; ++d) {
+        const float fl = std::floor(lo_f[d]), ce = std::ceil(hi_f[d]);
+        const long s = (long)(fl > 0.0f ? fl : 0.0f), e = ce > 0.0f ? (long)ce : 0;  // `as usize` saturates at 0
+        vlo[d] = (int32_t)std::max<long>((long)occ[6 + 2 * d], s);
+        vhi[d] = (int32_t)std::min<long>((long)occ[7 + 2 * d], e);
+        if (vlo[d] >= vhi[d]) return false;
+        lo[d] = (uint32_t)vlo[d] / 16u;
+        cc[d] = ((uint32_t)vhi[d] + 15u) / 16u - lo[d];
+    }
+    return true;
+}
+
+static int voxel_object_contacts(ivx_grid* g, const char* who, int plane, const float rotation_xyzw[4], const float translation[3], const float shape3[3],
+                                 float shape1, uint64_t id_a, uint64_t id_b, uint32_t body_a, uint32_t body_b, const float response[3], ivx_contact* out,
+                                 size_t cap, size_t* n_out) {
+    IVX_REQUIRE(g && rotation_xyzw && translation && shape3 && response && n_out && (out || cap == 0), IVX_ERR_INVALID, "%s: null argument", who);
+    IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "%s: derived state must be current (ivx_derive_state + ivx_label_regions)", who);
+    IVX_REQUIRE(g->x_off == 0 && g->gx == g->cc[0] && !g->has_ghost[0] && !g->has_ghost[1], IVX_ERR_STATE, "%s: not available on a slab of a decomposed grid",
+                who);
     *n_out = 0;
     int rc;
     uint32_t* d_occ = g->rscalar + 16;
@@ -856,33 +879,54 @@ int ivx_sphere_voxel_object_contacts(ivx_grid* g, const float rotation_xyzw[4], 
     uint32_t occ_raw[12], occ[12];
     if ((rc = d2h(g, occ_raw, d_occ, sizeof(occ_raw)))) return rc;
     ivx_occupied_from_raw(g, occ_raw, occ);
-    // sphere.iso_transformed(transform_to_object_space).scaled(inverse_voxel_extent) and its touched voxel ranges
-    // (intersection.rs:51-60, 766-782); glam Quat::mul_vec3a for the rotation, as in physics.hip
-    float cn[3], rn;
-    {
-        const float qx = rotation_xyzw[0], qy = rotation_xyzw[1], qz = rotation_xyzw[2], qw = rotation_xyzw[3];
-        const float vx = sphere_center[0], vy = sphere_center[1], vz = sphere_center[2];
-        const float b2 = (qx * qx + qy * qy) + qz * qz, s1 = qw * qw - b2, s2 = ((vx * qx + vy * qy) + vz * qz) * 2.0f, s3 = qw * 2.0f;
-        const float cxp = qy * vz - vy * qz, cyp = qz * vx - vz * qx, czp = qx * vy - vx * qy;  // cross(b, v)
-        const float rx = (vx * s1 + qx * s2) + cxp * s3, ry = (vy * s1 + qy * s2) + cyp * s3, rz = (vz * s1 + qz * s2) + czp * s3;
-        const float inv = 1.0f / g->extent;
-        cn[0] = (rx + translation[0]) * inv;
-        cn[1] = (ry + translation[1]) * inv;
-        cn[2] = (rz + translation[2]) * inv;
-        rn = inv * sphere_radius;
+    const float inv = 1.0f / g->extent;
+    float lo_f[3], hi_f[3];
+    if (!plane) {
+        // sphere.iso_transformed(transform_to_object_space).scaled(inverse_voxel_extent) and its box (intersection.rs:51-60)
+        float rc3[3];
+        host_qrot(rotation_xyzw, shape3, rc3);
+        const float rn = inv * shape1;
+        for (int d = 0; d < 3; ++d) {
+            const float cn = (rc3[d] + translation[d]) * inv;
+            lo_f[d] = cn - rn;
+            hi_f[d] = cn + rn;
+        }
+    } else {
+        // plane.iso_transformed(..).scaled(..) (impact_geometry/src/plane.rs:170-203), then the occupied box projected onto its negative
+        // halfspace (voxel_ranges_within_plane, intersection.rs:751-761; axis_aligned_box.rs:460-488)
+        const float point[3] = {shape3[0] * shape1, shape3[1] * shape1, shape3[2] * shape1};
+        float tp[3], tn[3];
+        host_qrot(rotation_xyzw, point, tp);
+        for (int d = 0; d < 3; ++d) tp[d] += translation[d];
+        host_qrot(rotation_xyzw, shape3, tn);
+        const float disp = ((tn[0] * tp[0] + tn[1] * tp[1]) + tn[2] * tp[2]) * inv;
+        float blo[3], bhi[3];
+        for (int d = 0; d < 3; ++d) {
+            blo[d] = lo_f[d] = (float)occ[6 + 2 * d];
+            bhi[d] = hi_f[d] = (float)occ[7 + 2 * d];
+        }
+        const int perm[3][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}};
+        auto mn2 = [](float x, float y) { return (y < x) ? y : x; };
+        auto mx2 = [](float x, float y) { return (y > x) ? y : x; };
+        for (int r = 0; r < 3; ++r) {
+            const int i = perm[r][0], j = perm[r][1], k = perm[r][2];
+            if (std::fabs(tn[k]) > 1e-8f) {
+                const float a0 = tn[i] * blo[i] + tn[j] * blo[j], b0 = tn[i] * blo[i] + tn[j] * bhi[j], c0 = tn[i] * bhi[i] + tn[j] * blo[j],
+                            d0 = tn[i] * bhi[i] + tn[j] * bhi[j];
+                const float extremal = (disp - mn2(mn2(mn2(a0, b0), c0), d0)) / tn[k];
+                if (!std::signbit(tn[k])) {
+                    lo_f[k] = mn2(lo_f[k], extremal);
+                    hi_f[k] = mn2(hi_f[k], extremal);
+                } else {
+                    lo_f[k] = mx2(lo_f[k], extremal);
+                    hi_f[k] = mx2(hi_f[k], extremal);
+                }
+            }
+        }
     }
     int32_t vlo[3], vhi[3];
     uint32_t lo[3], cc[3];
-    for (int d = 0; d < 3; ++d) {
-        const float a0 = cn[d] - rn, b0 = cn[d] + rn;
-        const float fl = std::floor(a0), ce = std::ceil(b0);
-        const long s = (long)(fl > 0.0f ? fl : 0.0f), e = ce > 0.0f ? (long)ce : 0;
-        vlo[d] = (int32_t)std::max<long>((long)occ[6 + 2 * d], s);
-        vhi[d] = (int32_t)std::min<long>((long)occ[7 + 2 * d], e);
-        if (vlo[d] >= vhi[d]) return IVX_OK;
-        lo[d] = (uint32_t)vlo[d] / 16u;
-        cc[d] = ((uint32_t)vhi[d] + 15u) / 16u - lo[d];
-    }
+    if (!touched_ranges(occ, lo_f, hi_f, vlo, vhi, lo, cc)) return IVX_OK;
     const size_t n_box = (size_t)cc[0] * cc[1] * cc[2];
     const size_t off_offsets = n_box * 4, off_total = 2 * n_box * 4, off_out = (off_total + 16 + 63) & ~(size_t)63;
     if ((rc = ensure_dev_scratch(g, off_out + cap * sizeof(ivx_contact)))) return rc;
@@ -891,17 +935,30 @@ int ivx_sphere_voxel_object_contacts(ivx_grid* g, const float rotation_xyzw[4], 
     uint32_t* d_offsets = reinterpret_cast<uint32_t*>(base + off_offsets);
     uint32_t* d_total = reinterpret_cast<uint32_t*>(base + off_total);
     ivx_contact* d_out = reinterpret_cast<ivx_contact*>(base + off_out);
-    if ((rc = ivx_ensure_dense(g))) return rc;  // (flags of the NonUniform chunks are what is read; cheap no-op when already dense)
     for (int pass = 0; pass < 2; ++pass)
-        if ((rc = ivx_launch_sphere_contacts(g, lo, cc, vlo, vhi, rotation_xyzw, translation, sphere_center, sphere_radius, collidable_id_a, collidable_id_b,
-                                             body_a, body_b, response, d_counts, d_offsets, d_total, d_out, (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFu), pass)))
+        if ((rc = ivx_launch_sphere_contacts(g, lo, cc, vlo, vhi, rotation_xyzw, translation, shape3, shape1, id_a, id_b, body_a, body_b, response, d_counts,
+                                             d_offsets, d_total, d_out, (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFu), pass, plane)))
             return rc;
     uint32_t total = 0;
     if ((rc = d2h(g, &total, d_total, sizeof(total)))) return rc;
     *n_out = total;
-    IVX_REQUIRE(total <= cap, IVX_ERR_CAPACITY, "ivx_sphere_voxel_object_contacts: %u contacts exceed the capacity %zu", total, cap);
+    IVX_REQUIRE(total <= cap, IVX_ERR_CAPACITY, "%s: %u contacts exceed the capacity %zu", who, total, cap);
     if (total && (rc = d2h(g, out, d_out, (size_t)total * sizeof(ivx_contact)))) return rc;
     return IVX_OK;
+}
+
+int ivx_sphere_voxel_object_contacts(ivx_grid* g, const float rotation_xyzw[4], const float translation[3], const float sphere_center[3], float sphere_radius,
+                                     uint64_t collidable_id_a, uint64_t collidable_id_b, uint32_t body_a, uint32_t body_b, const float response[3],
+                                     ivx_contact* out, size_t cap, size_t* n_out) {
+    return voxel_object_contacts(g, "ivx_sphere_voxel_object_contacts", 0, rotation_xyzw, translation, sphere_center, sphere_radius, collidable_id_a,
+                                 collidable_id_b, body_a, body_b, response, out, cap, n_out);
+}
+
+int ivx_plane_voxel_object_contacts(ivx_grid* g, const float rotation_xyzw[4], const float translation[3], const float plane_unit_normal[3],
+                                    float plane_displacement, uint64_t collidable_id_a, uint64_t collidable_id_b, uint32_t body_a, uint32_t body_b,
+                                    const float response[3], ivx_contact* out, size_t cap, size_t* n_out) {
+    return voxel_object_contacts(g, "ivx_plane_voxel_object_contacts", 1, rotation_xyzw, translation, plane_unit_normal, plane_displacement, collidable_id_a,
+                                 collidable_id_b, body_a, body_b, response, out, cap, n_out);
 }
 
 int ivx_grid_set_sdf_program(ivx_grid* g, const ivx_sdf_processed_node* nodes, size_t n_nodes, uint32_t stack_size, const uint32_t grid_shape[3],

@@ -367,6 +367,17 @@ class VoxelObject:
                                                           collidable_id_a, collidable_id_b, body_a, body_b, ptr(f(response)), ptr(out), capacity, C.byref(n)))
         return out[: n.value]
 
+    def plane_contacts(self, rotation_xyzw, translation, plane_unit_normal, plane_displacement: float, collidable_id_a: int, collidable_id_b: int,
+                       body_a: int, body_b: int, response=(0.0, 0.0, 0.0), capacity: int = 65536) -> np.ndarray:
+        """`for_each_voxel_object_plane_contact` (collidable.rs:1176-1208): ids in the reference's hash order (plane, voxel object),
+        `body_a` = the voxel object's body (the contact normal is the plane's)."""
+        out = np.zeros(capacity, dtype=capi.CONTACT_DTYPE)
+        n = C.c_size_t(0)
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+        check(capi.lib().ivx_plane_voxel_object_contacts(self.h, ptr(f(rotation_xyzw)), ptr(f(translation)), ptr(f(plane_unit_normal)), plane_displacement,
+                                                         collidable_id_a, collidable_id_b, body_a, body_b, ptr(f(response)), ptr(out), capacity, C.byref(n)))
+        return out[: n.value]
+
     def halo_bytes(self) -> int:
         return int(capi.lib().ivx_halo_bytes(self.h))
 

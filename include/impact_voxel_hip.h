@@ -329,6 +329,13 @@ typedef struct {
 int ivx_sphere_voxel_object_contacts(ivx_grid*, const float rotation_xyzw[4], const float translation[3], const float sphere_center[3],
                                      float sphere_radius, uint64_t collidable_id_a, uint64_t collidable_id_b, uint32_t body_a, uint32_t body_b,
                                      const float response[3], ivx_contact* out, size_t cap, size_t* n_out);
+/* for_each_voxel_object_plane_contact (collidable.rs:1176-1208): the same for a plane collidable (unit normal + displacement, world space);
+ * only Corner voxels (at most three neighbours) inside the voxel ranges of the plane's negative halfspace are tested
+ * (determine_sphere_plane_contact_geometry, sphere.rs:138-160). The reference hashes the ids as (plane, voxel object) and the contact
+ * normal is the plane's: pass the collidable ids in that order and the voxel object's body as body_a. */
+int ivx_plane_voxel_object_contacts(ivx_grid*, const float rotation_xyzw[4], const float translation[3], const float plane_unit_normal[3],
+                                    float plane_displacement, uint64_t collidable_id_a, uint64_t collidable_id_b, uint32_t body_a, uint32_t body_b,
+                                    const float response[3], ivx_contact* out, size_t cap, size_t* n_out);
 
 #define IVX_KINEMATIC_BODY 0x80000000u
 #define IVX_CONTACT_MANIFOLD_START 1u

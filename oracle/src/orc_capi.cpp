@@ -16,6 +16,8 @@ int split_off_smallest_region(VoxelObject& parent, VoxelObject& child, int origi
 int clip_polyhedron(VoxelObject& parent, const float* planes, int n_planes, const float aabb[6], int mode, VoxelObject& child, int origin[3]);
 int sphere_voxel_object_contacts(const VoxelObject& obj, const float rot[4], const float trans[3], const float center[3], float radius, int cap,
                                  int32_t* indices, float* position, float* normal, float* depth);
+int plane_voxel_object_contacts(const VoxelObject& obj, const float rot[4], const float trans[3], const float plane_normal[3], float plane_displacement,
+                                int cap, int32_t* indices, float* position, float* normal, float* depth);
 int absorb_sphere(VoxelObject& obj, const float center[3], float influence_radius, float sphere_radius, const float* dens, double removed64[10],
                   uint32_t emptied_by_type[256], uint8_t* invalidated, uint32_t* touched_chunks);
 
@@ -371,6 +373,12 @@ int orc_absorb_sphere(orc_object* o, const float center[3], float influence_radi
 int orc_sphere_voxel_object_contacts(const orc_object* o, const float rotation_xyzw[4], const float translation[3], const float center[3], float radius,
                                      int cap, int32_t* indices, float* position, float* normal, float* depth) {
     return sphere_voxel_object_contacts(o->obj, rotation_xyzw, translation, center, radius, cap, indices, position, normal, depth);
+}
+
+// for_each_voxel_object_plane_contact (impact_voxel/src/collidable.rs:1176-1208)
+int orc_plane_voxel_object_contacts(const orc_object* o, const float rotation_xyzw[4], const float translation[3], const float plane_normal[3],
+                                    float plane_displacement, int cap, int32_t* indices, float* position, float* normal, float* depth) {
+    return plane_voxel_object_contacts(o->obj, rotation_xyzw, translation, plane_normal, plane_displacement, cap, indices, position, normal, depth);
 }
 
 int8_t orc_sd_from_f32(float v) { return sd_from_f32(v); }

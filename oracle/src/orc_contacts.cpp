@@ -18,6 +18,8 @@
 #include "orc_math.hpp"
 #include "orc_voxel.hpp"
 
+extern "C" int orc_sphere_plane_contact(const float c[3], float r, const float plane_normal[3], float plane_displacement, float position[3], float normal[3],
+                                        float* depth);
 extern "C" int orc_sphere_sphere_contact(const float ca[3], float ra, const float cb[3], float rb, float position[3], float normal[3], float* depth);
 
 namespace orc {
@@ -78,6 +80,85 @@ int sphere_voxel_object_contacts(const VoxelObject& obj, const float rot[4], con
                         }
             }
     return n;
+}
+
+// for_each_voxel_object_plane_contact (impact_voxel/src/collidable.rs:1176-1208): only Corner voxels (at most three neighbours) of the
+// voxel ranges inside the plane's negative halfspace (for_each_surface_voxel_maybe_intersecting_negative_halfspace_of_plane,
+// object/intersection.rs:30-38; voxel_ranges_within_plane, 751-761; AxisAlignedBox::projected_onto_negative_halfspace,
+// impact_geometry/src/axis_aligned_box.rs:460-488; Plane::iso_transformed / scaled, impact_geometry/src/plane.rs:170-203)
+int plane_voxel_object_contacts(const VoxelObject& obj, const float rot[4], const float trans[3], const float plane_normal[3], float plane_displacement,
+                                int cap, int32_t* indices, float* position, float* normal, float* depth) {
+    const Quat q{rot[0], rot[1], rot[2], rot[3]};
+    const V3 t{trans[0], trans[1], trans[2]}, n{plane_normal[0], plane_normal[1], plane_normal[2]};
+    // plane.iso_transformed(transform_to_object_space).scaled(inverse_voxel_extent)
+    const V3 point = n * plane_displacement;
+    const V3 tp = qrot(q, point) + t;
+    const V3 tn = qrot(q, n);
+    const float inv = 1.0f / obj.extent;
+    const float disp = dot(tn, tp) * inv;
+    // normalized_aabb_from_voxel_ranges(occupied) projected onto the negative halfspace
+    float lo[3], hi[3];
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = (float)obj.occ_voxel[d][0];
+        hi[d] = (float)obj.occ_voxel[d][1];
+    }
+    float flo[3] = {lo[0], lo[1], lo[2]}, fhi[3] = {hi[0], hi[1], hi[2]};
+    const float nv[3] = {tn.x, tn.y, tn.z};
+    const int perm[3][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}};
+    for (int r = 0; r < 3; ++r) {
+        const int i = perm[r][0], j = perm[r][1], k = perm[r][2];
+        if (std::fabs(nv[k]) > 1e-8f) {
+            const float a = nv[i] * lo[i] + nv[j] * lo[j], b = nv[i] * lo[i] + nv[j] * hi[j], c = nv[i] * hi[i] + nv[j] * lo[j],
+                        d = nv[i] * hi[i] + nv[j] * hi[j];
+            const float mn = fmin_rs(fmin_rs(fmin_rs(a, b), c), d);
+            const float extremal = (disp - mn) / nv[k];
+            if (!std::signbit(nv[k])) {
+                flo[k] = fmin_rs(flo[k], extremal);
+                fhi[k] = fmin_rs(fhi[k], extremal);
+            } else {
+                flo[k] = fmax_rs(flo[k], extremal);
+                fhi[k] = fmax_rs(fhi[k], extremal);
+            }
+        }
+    }
+    long vlo[3], vhi[3];
+    for (int d = 0; d < 3; ++d) {
+        const float fl = std::floor(flo[d]), ce = std::ceil(fhi[d]);
+        const long s = (long)(fl > 0.0f ? fl : 0.0f), e = ce > 0.0f ? (long)ce : 0;
+        vlo[d] = std::max<long>(obj.occ_voxel[d][0], s);
+        vhi[d] = std::min<long>(obj.occ_voxel[d][1], e);
+        if (vlo[d] >= vhi[d]) return 0;
+    }
+    int cnt = 0;
+    const Quat qi = conj(q);
+    for (long I = vlo[0] / CHUNK; I < (vhi[0] + CHUNK - 1) / CHUNK; ++I)
+        for (long J = vlo[1] / CHUNK; J < (vhi[1] + CHUNK - 1) / CHUNK; ++J)
+            for (long K = vlo[2] / CHUNK; K < (vhi[2] + CHUNK - 1) / CHUNK; ++K) {
+                const Chunk& ch = obj.chunks[obj.cidx((int)I, (int)J, (int)K)];
+                if (ch.kind != K_NONUNIFORM) continue;
+                const Voxel* cv = &obj.voxels[(size_t)ch.data_offset << 12];
+                const long base[3] = {I * CHUNK, J * CHUNK, K * CHUNK};
+                for (long i = std::max(base[0], vlo[0]); i < std::min(base[0] + CHUNK, vhi[0]); ++i)
+                    for (long j = std::max(base[1], vlo[1]); j < std::min(base[1] + CHUNK, vhi[1]); ++j)
+                        for (long k = std::max(base[2], vlo[2]); k < std::min(base[2] + CHUNK, vhi[2]); ++k) {
+                            const Voxel& v = cv[((i - base[0]) << 8) | ((j - base[1]) << 4) | (k - base[2])];
+                            if (v.empty()) continue;
+                            if (__builtin_popcount(v.flags & 0xFCu) > 3) continue;  // Corner placement only (lib.rs:330-342)
+                            const V3 p_obj{((float)i + 0.5f) * obj.extent, ((float)j + 0.5f) * obj.extent, ((float)k + 0.5f) * obj.extent};
+                            const V3 pw = qrot(qi, p_obj - t);
+                            const float vr = -sd_to_f32(v.sd) * obj.extent;
+                            const float pa[3] = {pw.x, pw.y, pw.z};
+                            float pos[3], nrm[3], dep;
+                            if (!orc_sphere_plane_contact(pa, vr, plane_normal, plane_displacement, pos, nrm, &dep)) continue;
+                            if (cnt < cap) {
+                                indices[3 * cnt] = (int32_t)i, indices[3 * cnt + 1] = (int32_t)j, indices[3 * cnt + 2] = (int32_t)k;
+                                for (int d = 0; d < 3; ++d) position[3 * cnt + d] = pos[d], normal[3 * cnt + d] = nrm[d];
+                                depth[cnt] = dep;
+                            }
+                            cnt += 1;
+                        }
+            }
+    return cnt;
 }
 
 }  // namespace orc

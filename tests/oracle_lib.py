@@ -88,6 +88,8 @@ def lib():
         L.orc_clip_polyhedron.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.POINTER(vp), vp]
         L.orc_sphere_voxel_object_contacts.restype = C.c_int
         L.orc_sphere_voxel_object_contacts.argtypes = [vp, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, vp]
+        L.orc_plane_voxel_object_contacts.restype = C.c_int
+        L.orc_plane_voxel_object_contacts.argtypes = [vp, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, vp]
         L.orc_absorb_sphere.restype = C.c_int
         L.orc_absorb_sphere.argtypes = [vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, C.POINTER(C.c_uint32)]
         L.orc_physics_create.restype = vp
@@ -304,6 +306,18 @@ class OracleObject:
         dep = np.zeros(cap, dtype=np.float32)
         n = lib().orc_sphere_voxel_object_contacts(self.h, _p(f(rotation_xyzw)), _p(f(translation)), _p(f(center)), radius, cap, _p(idx), _p(pos), _p(nrm),
                                                    _p(dep))
+        assert n <= cap
+        return idx[:n], pos[:n], nrm[:n], dep[:n]
+
+    def plane_contacts(self, rotation_xyzw, translation, normal, displacement, cap=65536):
+        """for_each_voxel_object_plane_contact -> (indices [n,3], position [n,3], normal [n,3], depth [n])"""
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+        idx = np.zeros((cap, 3), dtype=np.int32)
+        pos = np.zeros((cap, 3), dtype=np.float32)
+        nrm = np.zeros((cap, 3), dtype=np.float32)
+        dep = np.zeros(cap, dtype=np.float32)
+        n = lib().orc_plane_voxel_object_contacts(self.h, _p(f(rotation_xyzw)), _p(f(translation)), _p(f(normal)), displacement, cap, _p(idx), _p(pos),
+                                                  _p(nrm), _p(dep))
         assert n <= cap
         return idx[:n], pos[:n], nrm[:n], dep[:n]
 

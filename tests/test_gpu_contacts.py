@@ -120,3 +120,71 @@ def test_ball_dropped_on_a_voxel_body_steps_like_the_oracle(ctx):
     assert had_contact
     w.close()
     g.close()
+
+
+def oracle_plane_contact_list(o, q, t, n, disp, id_a, id_b, body_a, body_b, response):
+    idx, pos, nrm, dep = o.plane_contacts(q, t, n, disp)
+    out = np.zeros(len(idx), dtype=CONTACT_DTYPE)
+    for m, (ijk, p, nn, d) in enumerate(zip(idx, pos, nrm, dep)):
+        out[m]["id"] = scenes.contact_id(id_a, id_b, *[int(x) for x in ijk])
+        out[m]["body_a"], out[m]["body_b"] = body_a, body_b
+        out[m]["position"], out[m]["normal"], out[m]["depth"] = p, nn, d
+        out[m]["restitution"], out[m]["static_friction"], out[m]["dynamic_friction"] = response
+        out[m]["flags"] = 1 if m == 0 else 0
+    return out
+
+
+def test_plane_against_rotated_voxel_box(ctx):
+    extent = 0.5
+    o, g = both(ctx, scenes.box_scene((20.0, 14.0, 18.0)), extent)
+    axis = np.array([0.2, 1.0, -0.4]) / np.linalg.norm([0.2, 1.0, -0.4])
+    q = np.array([*(axis * np.sin(0.3)), np.cos(0.3)], dtype=np.float32)
+    t = np.array([0.5, 2.0, -1.0], dtype=np.float32)
+    resp = (0.1, 0.8, 0.6)
+    for normal, disp in (((0.0, 1.0, 0.0), -3.0), ((0.1, 1.0, 0.05), -4.2), ((0.0, 0.0, 1.0), -30.0), ((-0.6, 0.8, 0.0), -2.0)):
+        n = np.asarray(normal, dtype=np.float64)
+        n = (n / np.linalg.norm(n)).astype(np.float32)
+        want = oracle_plane_contact_list(o, q, t, n, disp, 5, 9, 0, 0x80000000, resp)
+        got = g.plane_contacts(q, t, n, disp, 5, 9, 0, 0x80000000, resp)
+        assert_contacts_equal(got, want)
+    g.close()
+
+
+def test_voxel_box_dropped_on_the_ground_steps_like_the_oracle(ctx):
+    """a voxel box (dynamic body) falls onto a static plane: corner-voxel contacts -> prepare -> solve (with positional correction) ->
+    integrate, 80 steps against the oracle running the same chain"""
+    extent = 0.25
+    o, g = both(ctx, scenes.box_scene((16.0, 12.0, 20.0)), extent)  # 4 x 3 x 5 world units
+    inf = o.info()
+    ctr = np.array([0.5 * (a + b) for a, b in inf["occupied_voxel_ranges"]], dtype=np.float64) * extent
+    mass = 4.0 * 3.0 * 5.0
+    I = np.diag([mass / 12 * (9 + 25), mass / 12 * (16 + 25), mass / 12 * (16 + 9)])
+    ang = 0.15
+    box = ol.rigid_body_new(mass, I, (0.0, 1.5 + 0.6, 0.0), (np.sin(ang / 2), 0.0, 0.0, np.cos(ang / 2)), (0.0, -0.5, 0.0), (0.0, 0.0, 0.1))
+    dyn = np.array([box])
+    dyn["total_force"][0] = (0.0, -9.81 * mass, 0.0)
+    w, op = phu.make_pair(ctx, dyn, phu.static_plane())
+    resp = (0.0, 0.7, 0.5)
+    n = np.array([0.0, 1.0, 0.0], dtype=np.float32)
+    had_contact = False
+    for step in range(80):
+        lists = []
+        for src, bodies in ((g, w.bodies()[0]), (o, op.bodies()[0])):
+            qb = bodies["orientation"][0].astype(np.float64)
+            pb = bodies["position"][0].astype(np.float64)
+            qi = np.array([-qb[0], -qb[1], -qb[2], qb[3]])
+            bv = qi[:3]
+            v = -pb
+            tr = (v * (qi[3] * qi[3] - bv @ bv) + bv * (2 * (v @ bv)) + np.cross(bv, v) * (2 * qi[3])) + ctr
+            if src is g:
+                lists.append(g.plane_contacts(qi.astype(np.float32), tr.astype(np.float32), n, 0.0, 3, 4, 0, 0x80000000, resp))
+            else:
+                lists.append(oracle_plane_contact_list(o, qi.astype(np.float32), tr.astype(np.float32), n, 0.0, 3, 4, 0, 0x80000000, resp))
+        had_contact |= len(lists[1]) > 0
+        assert len(lists[0]) == len(lists[1]), step
+        w.perform_physics_step(lists[0], 0.004)
+        op.step(lists[1], 0.004)
+        phu.assert_bodies_close(w.bodies()[0], op.bodies()[0], what=f"step {step}: ")
+    assert had_contact
+    w.close()
+    g.close()

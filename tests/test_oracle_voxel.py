@@ -627,3 +627,48 @@ def test_sphere_contacts_match_brute_force_over_surface_voxels():
     # traversal order: chunks in (i,j,k) order, voxels in (i,j,k) order inside a chunk
     key = [((r[0] >> 4, r[1] >> 4, r[2] >> 4), tuple(r)) for r in idx.tolist()]
     assert key == sorted(key)
+
+
+def test_plane_contacts_match_brute_force_over_corner_voxels():
+    """for_each_voxel_object_plane_contact (collidable.rs:1176-1208): Corner voxels (non-empty, at most three neighbours) whose
+    sphere reaches below the plane; tilted plane, rotated object"""
+    ext = 0.5
+    o = ol.OracleObject.from_sdf(scenes.box_scene((20.0, 14.0, 18.0)), ext, 0)
+    o.update_occupied_voxel_ranges()
+    o.compute_all_derived_state()
+    axis = np.array([0.2, 1.0, -0.4]) / np.linalg.norm([0.2, 1.0, -0.4])
+    q = np.array([*(axis * np.sin(0.3)), np.cos(0.3)], dtype=np.float32)
+    t = np.array([0.5, 2.0, -1.0], dtype=np.float32)
+    qc = np.array([-q[0], -q[1], -q[2], q[3]], dtype=np.float64)
+
+    def rot(qv, v):
+        x, y, z, w = [float(a) for a in qv]
+        b = np.array([x, y, z])
+        return v * (w * w - b @ b) + b * (2 * (v @ b)) + np.cross(b, v) * (2 * w)
+
+    n = np.array([0.1, 1.0, 0.05])
+    n /= np.linalg.norm(n)
+    n32 = n.astype(np.float32)
+    sdf, typ, flg, _, info = o.export_dense()
+    cc = o.chunk_counts
+    sd = ol.tiled_to_dense(sdf, cc).astype(np.float64) * 0.02
+    fl = ol.tiled_to_dense(flg, cc)
+    corner = ((fl & 1) == 0) & (np.unpackbits((fl & 0xFC)[..., None], axis=-1).sum(-1) <= 3)
+    pts = np.argwhere(corner)
+    world = np.array([rot(qc, (p + 0.5) * ext - t.astype(np.float64)) for p in pts])
+    heights = world @ n
+    disp = float(np.sort(heights)[2] + 0.01)  # a few corners dip below the plane
+    idx, pos, nrm, dep = o.plane_contacts(q, t, n32, disp)
+    want = {tuple(p) for p, hgt in zip(pts.tolist(), heights) if -sd[tuple(p)] * ext - (hgt - disp) >= 1e-6}
+    got = {tuple(int(x) for x in r) for r in idx}
+    assert want and want <= got
+    for r, p_, n_, d_ in zip(idx, pos, nrm, dep):
+        pw = rot(qc, (r + 0.5) * ext - t.astype(np.float64))
+        sdist = pw @ n - disp
+        vr = -sd[tuple(r)] * ext
+        assert vr - sdist >= -1e-4
+        np.testing.assert_allclose(d_, vr - sdist, atol=2e-5)
+        np.testing.assert_allclose(n_, n, atol=1e-6)
+        np.testing.assert_allclose(p_, pw - sdist * n, atol=2e-5)
+    key = [((r[0] >> 4, r[1] >> 4, r[2] >> 4), tuple(r)) for r in idx.tolist()]
+    assert key == sorted(key)
