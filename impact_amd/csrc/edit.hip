@@ -1,5 +1,5 @@
-// Voxel edit ops: an absorbing sphere eats into a voxel object — the per-frame mutator of the reference's deformable objects
-// (SURVEY §8f item 2).
+// Voxel edit ops: an absorbing sphere or capsule eats into a voxel object — the per-frame mutators of the reference's deformable
+// objects.
 //
 // Reference (engine/crates/impact_voxel/src):
 //   apply_sphere_absorption                                   interaction/absorption.rs:801-844
@@ -7,11 +7,18 @@
 //   Voxel::set_signed_distance                                lib.rs:451-461
 //   modify_voxels_within_sphere + handle_chunk_voxels_modified  object/intersection.rs:283-395, 532-598
 //   VoxelObjectInertialPropertyUpdater::remove_voxel          object/inertia.rs:377-394
+//   apply_capsule_absorption                                  interaction/absorption.rs:846-889
+//   modify_voxels_within_capsule                              object/intersection.rs:417-530
+//   Capsule::trim_segment_outside_aab / compute_aabb / CapsulePointContainmentTester   impact_geometry/src/capsule.rs:132-250
+//   AxisAlignedBox::find_contained_subsegment                 impact_geometry/src/axis_aligned_box.rs:385-415
 // Per chunk of the touched chunk box: a Void chunk is skipped, a Uniform chunk becomes NonUniform (its 4096 voxels are written
 // out) whether or not the sphere reaches a voxel of it, every voxel whose centre lies inside the influence sphere gets
 // sd = quantise(max(sd, -(|p - c| - R))); a voxel that stops being negative is empty from then on and its mass moments and type
 // are reported; a chunk left with only void voxels becomes Void. Derived state is recomputed afterwards by the ordinary sweep
 // (derive.hip): it is a pure function of the voxels and the chunk kinds set here.
+// The capsule differs in three places: the voxel ranges of a chunk come from the box of the capsule whose segment was clipped
+// against the chunk box grown by the radius (a chunk the clipped capsule misses is left alone, Uniform or not), the distance is
+// the one to the whole segment, and a voxel exactly on the boundary counts as inside (<=).
 //
 // One workgroup per chunk of the box, a thread owns a 16-voxel k-row.
 #include "chunk_passes.hpp"
@@ -22,8 +29,10 @@ struct AbsorbParams {
     GridView g;
     uint32_t lo[3], cc[3];  // chunk box
     int32_t vlo[3], vhi[3];  // touched voxel ranges
-    float c[3];
+    float c[3];  // sphere centre / capsule segment start
     float r2, r_sphere;
+    int32_t capsule;  // 0 sphere, 1 capsule
+    float seg[3], seg_over_len2[3], r_infl;
 };
 
 __device__ __forceinline__ int quantise(float v) {  // VoxelSignedDistance::from_f32 (lib.rs:197-201)
@@ -33,9 +42,9 @@ __device__ __forceinline__ int quantise(float v) {  // VoxelSignedDistance::from
     return (int)s;
 }
 
-__global__ __launch_bounds__(256) void k_absorb_sphere(AbsorbParams p, int8_t* __restrict__ sdf, uint8_t* __restrict__ type, ivx_chunk_info* __restrict__ info,
+__global__ __launch_bounds__(256) void k_absorb(AbsorbParams p, int8_t* __restrict__ sdf, uint8_t* __restrict__ type, ivx_chunk_info* __restrict__ info,
                                                        const float* __restrict__ dens, double* __restrict__ removed10, uint32_t* __restrict__ by_type,
-                                                       uint32_t* __restrict__ counters, uint8_t* __restrict__ touched_flags) {
+                                                       uint32_t* __restrict__ counters, uint32_t* __restrict__ touched_ranges) {
     __shared__ float s_dens[256];
     __shared__ double s_red[4][10];
     const uint32_t tid = threadIdx.x;
@@ -43,6 +52,49 @@ __global__ __launch_bounds__(256) void k_absorb_sphere(AbsorbParams p, int8_t* _
     const uint32_t bk = b % p.cc[2], bj = (b / p.cc[2]) % p.cc[1], bi = b / (p.cc[2] * p.cc[1]);
     const uint32_t ci = p.lo[0] + bi, cj = p.lo[1] + bj, ck = p.lo[2] + bk;
     const uint32_t chunk = (ci * p.g.cy + cj) * p.g.cz + ck;
+    // the voxel ranges of this chunk the shape may reach (the same in every thread)
+    const int cbase[3] = {(int)(ci * 16u), (int)(cj * 16u), (int)(ck * 16u)};
+    int rlo[3], rhi[3];
+    if (p.capsule) {
+        float t_min = 0.0f, t_max = 1.0f;
+        bool none = false;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float blo = (float)cbase[d] - p.r_infl, bhi = (float)(cbase[d] + 16) + p.r_infl;
+            if (fabsf(p.seg[d]) > 1e-8f) {
+                const float recip = 1.0f / p.seg[d];
+                const float t1 = (blo - p.c[d]) * recip, t2 = (bhi - p.c[d]) * recip;
+                const float te = t1 < t2 ? t1 : t2, tx = t1 < t2 ? t2 : t1;
+                t_min = te > t_min ? te : t_min;  // f32::max / f32::min (no NaN: recip is finite)
+                t_max = tx < t_max ? tx : t_max;
+            } else if (p.c[d] < blo || p.c[d] > bhi) {
+                none = true;
+            }
+        }
+        if (none || !(t_min <= t_max)) return;
+        bool empty = false;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float ts = p.c[d] + p.seg[d] * t_min;
+            const float tv = p.seg[d] * (t_max - t_min);
+            const float te = ts + tv;
+            const float a0 = ts - p.r_infl, a1 = te - p.r_infl, b0 = ts + p.r_infl, b1 = te + p.r_infl;
+            const float lo_f = a1 < a0 ? a1 : a0, hi_f = b1 > b0 ? b1 : b0;
+            const float fl = floorf(lo_f), ce = ceilf(hi_f);
+            // (`as usize` saturates; beyond the chunk either way the clamp below decides)
+            const int s_i = fl > 0.0f ? (fl < 2.0e9f ? (int)fl : 2000000000) : 0, e_i = ce > 0.0f ? (ce < 2.0e9f ? (int)ce : 2000000000) : 0;
+            rlo[d] = s_i > cbase[d] ? s_i : cbase[d];
+            rhi[d] = e_i < cbase[d] + 16 ? e_i : cbase[d] + 16;
+            empty |= rlo[d] >= rhi[d];
+        }
+        if (empty) return;
+    } else {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            rlo[d] = p.vlo[d] > cbase[d] ? p.vlo[d] : cbase[d];
+            rhi[d] = p.vhi[d] < cbase[d] + 16 ? p.vhi[d] : cbase[d] + 16;
+        }
+    }
     const ivx_chunk_info rec = info[chunk];
     if (rec.kind == KIND_VOID) return;
     s_dens[tid] = dens[tid];
@@ -58,8 +110,9 @@ __global__ __launch_bounds__(256) void k_absorb_sphere(AbsorbParams p, int8_t* _
         tw[0] = t4.x, tw[1] = t4.y, tw[2] = t4.z, tw[3] = t4.w;
     }
     const int gi = (int)(ci * 16u + (tid >> 4)), gj = (int)(cj * 16u + (tid & 15u));
-    const bool row_in = gi >= p.vlo[0] && gi < p.vhi[0] && gj >= p.vlo[1] && gj < p.vhi[1];
-    const float dx = ((float)gi + 0.5f) - p.c[0], dy = ((float)gj + 0.5f) - p.c[1];
+    const bool row_in = gi >= rlo[0] && gi < rhi[0] && gj >= rlo[1] && gj < rhi[1];
+    const float px = (float)gi + 0.5f, py = (float)gj + 0.5f;
+    const float dx = px - p.c[0], dy = py - p.c[1];
     uint32_t emptied = 0;  // bit k: the voxel was non-empty and is empty now
     bool any_inside = false, changed = false;
     uint32_t non_empty = 0, non_void = 0;
@@ -67,10 +120,22 @@ __global__ __launch_bounds__(256) void k_absorb_sphere(AbsorbParams p, int8_t* _
     for (int k = 0; k < 16; ++k) {
         const int gk = (int)(ck * 16u) + k;
         int sd = (int)(int8_t)((sw[k >> 2] >> (8 * (k & 3))) & 0xFFu);
-        if (row_in && gk >= p.vlo[2] && gk < p.vhi[2]) {
-            const float dz = ((float)gk + 0.5f) - p.c[2];
-            const float d2 = (dx * dx + dy * dy) + dz * dz;
-            if (d2 < p.r2) {
+        if (row_in && gk >= rlo[2] && gk < rhi[2]) {
+            const float pz = (float)gk + 0.5f;
+            const float dz = pz - p.c[2];
+            float d2;
+            bool inside;
+            if (p.capsule) {  // CapsulePointContainmentTester::shortest_squared_distance_from_point_to_segment
+                float t = (dx * p.seg_over_len2[0] + dy * p.seg_over_len2[1]) + dz * p.seg_over_len2[2];
+                t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);  // f32::clamp
+                const float ex = px - (p.c[0] + p.seg[0] * t), ey = py - (p.c[1] + p.seg[1] * t), ez = pz - (p.c[2] + p.seg[2] * t);
+                d2 = (ex * ex + ey * ey) + ez * ez;
+                inside = d2 <= p.r2;
+            } else {
+                d2 = (dx * dx + dy * dy) + dz * dz;
+                inside = d2 < p.r2;
+            }
+            if (inside) {
                 any_inside = true;
                 const float sphere_sd = sqrtf(d2) - p.r_sphere;
                 const float old = (float)sd * 0.02f, neg = -sphere_sd;
@@ -147,8 +212,10 @@ __global__ __launch_bounds__(256) void k_absorb_sphere(AbsorbParams p, int8_t* _
             out.uniform_type = 0;
         }
         info[chunk] = out;
-        if (touched) {
-            touched_flags[chunk] = 1;
+        if (touched) {  // with the voxel ranges handle_chunk_voxels_modified sees, chunk-relative: lo 0..15, hi-1 0..15
+            touched_ranges[chunk] = 0x80000000u | (uint32_t)(rlo[0] - cbase[0]) | ((uint32_t)(rlo[1] - cbase[1]) << 4) | ((uint32_t)(rlo[2] - cbase[2]) << 8) |
+                                    ((uint32_t)(rhi[0] - 1 - cbase[0]) << 12) | ((uint32_t)(rhi[1] - 1 - cbase[1]) << 16) |
+                                    ((uint32_t)(rhi[2] - 1 - cbase[2]) << 20);
             atomicAdd(&counters[0], 1u);
         }
     }
@@ -156,21 +223,27 @@ __global__ __launch_bounds__(256) void k_absorb_sphere(AbsorbParams p, int8_t* _
 
 }  // namespace
 
-int ivx_launch_absorb_sphere(ivx_grid* g, const uint32_t lo[3], const uint32_t cc[3], const int32_t vlo[3], const int32_t vhi[3], const float c[3],
-                             float influence_radius, float sphere_radius, const float* d_dens, double* d_removed10, uint32_t* d_by_type,
-                             uint32_t* d_counters, uint8_t* d_touched) {
+int ivx_launch_absorb(ivx_grid* g, int capsule, const uint32_t lo[3], const uint32_t cc[3], const int32_t vlo[3], const int32_t vhi[3], const float c[3],
+                      const float seg[3], float influence_radius, float shape_radius, const float* d_dens, double* d_removed10, uint32_t* d_by_type,
+                      uint32_t* d_counters, uint32_t* d_touched) {
     AbsorbParams p;
     p.g = ivx_view(g);
+    p.capsule = capsule;
+    const float len2 = capsule ? (seg[0] * seg[0] + seg[1] * seg[1]) + seg[2] * seg[2] : 0.0f;
+    const float inv = len2 > 1e-8f ? 1.0f / len2 : 0.0f;  // impact_math Div<f32>: multiply by the reciprocal
     for (int d = 0; d < 3; ++d) {
         p.lo[d] = lo[d];
         p.cc[d] = cc[d];
         p.vlo[d] = vlo[d];
         p.vhi[d] = vhi[d];
         p.c[d] = c[d];
+        p.seg[d] = capsule ? seg[d] : 0.0f;
+        p.seg_over_len2[d] = len2 > 1e-8f ? p.seg[d] * inv : 0.0f;
     }
     p.r2 = influence_radius * influence_radius;
-    p.r_sphere = sphere_radius;
-    hipLaunchKernelGGL(k_absorb_sphere, dim3(cc[0] * cc[1] * cc[2]), dim3(256), 0, g->ctx->stream, p, g->sdf, g->type, g->info, d_dens, d_removed10, d_by_type,
+    p.r_infl = influence_radius;
+    p.r_sphere = shape_radius;
+    hipLaunchKernelGGL(k_absorb, dim3(cc[0] * cc[1] * cc[2]), dim3(256), 0, g->ctx->stream, p, g->sdf, g->type, g->info, d_dens, d_removed10, d_by_type,
                        d_counters, d_touched);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;

@@ -753,13 +753,13 @@ int ivx_region_face_pairs(ivx_grid* g, int side, const void* neighbour_face_labe
     return IVX_OK;
 }
 
-int ivx_absorb_sphere(ivx_grid* g, const float center[3], float influence_radius, float sphere_radius, const float densities[256], ivx_absorb_result* out,
-                      uint32_t* emptied_by_type, uint8_t* invalidated_chunks) {
-    IVX_REQUIRE(g && center && densities && out, IVX_ERR_INVALID, "ivx_absorb_sphere: null argument");
-    IVX_REQUIRE(influence_radius >= 0.0f && sphere_radius >= 0.0f, IVX_ERR_INVALID, "ivx_absorb_sphere: negative radius");
-    IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "ivx_absorb_sphere: derived state and regions must be current (ivx_derive_state + ivx_label_regions)");
-    IVX_REQUIRE(g->x_off == 0 && g->gx == g->cc[0] && !g->has_ghost[0] && !g->has_ghost[1], IVX_ERR_STATE,
-                "ivx_absorb_sphere: not available on a slab of a decomposed grid");
+static int absorb_shape(ivx_grid* g, const char* who, int capsule, const float center[3], const float seg[3], float influence_radius, float shape_radius,
+                        const float densities[256], ivx_absorb_result* out, uint32_t* emptied_by_type, uint8_t* invalidated_chunks) {
+    IVX_REQUIRE(g && center && densities && out && (seg || !capsule), IVX_ERR_INVALID, "%s: null argument", who);
+    IVX_REQUIRE(influence_radius >= 0.0f && shape_radius >= 0.0f, IVX_ERR_INVALID, "%s: negative radius", who);
+    IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "%s: derived state and regions must be current (ivx_derive_state + ivx_label_regions)", who);
+    IVX_REQUIRE(g->x_off == 0 && g->gx == g->cc[0] && !g->has_ghost[0] && !g->has_ghost[1], IVX_ERR_STATE, "%s: not available on a slab of a decomposed grid",
+                who);
     memset(out, 0, sizeof(*out));
     if (emptied_by_type) memset(emptied_by_type, 0, 256 * sizeof(uint32_t));
     if (invalidated_chunks) memset(invalidated_chunks, 0, g->n_chunks);
@@ -773,26 +773,33 @@ int ivx_absorb_sphere(ivx_grid* g, const float center[3], float influence_radius
     int32_t vlo[3], vhi[3];
     uint32_t lo[3], cc[3];
     for (int d = 0; d < 3; ++d) {
-        const float a = center[d] - influence_radius, b = center[d] + influence_radius;  // Sphere::compute_aabb
+        float a = center[d] - influence_radius, b = center[d] + influence_radius;  // Sphere::compute_aabb
+        if (capsule) {  // Capsule::compute_aabb: the boxes of the two end spheres (capsule.rs:132-137)
+            const float end = center[d] + seg[d];
+            const float a1 = end - influence_radius, b1 = end + influence_radius;
+            a = a1 < a ? a1 : a;
+            b = b1 > b ? b1 : b;
+        }
         const float fl = std::floor(a), ce = std::ceil(b);
-        const long s = (long)(fl > 0.0f ? fl : 0.0f), e = ce > 0.0f ? (long)ce : 0;  // `as usize` saturates at 0
+        // `as usize` saturates at 0; the occupied ranges bound the other side
+        const long s = fl > 0.0f ? (fl < 2.0e9f ? (long)fl : 2000000000L) : 0, e = ce > 0.0f ? (ce < 2.0e9f ? (long)ce : 2000000000L) : 0;
         vlo[d] = (int32_t)std::max<long>((long)occ[6 + 2 * d], s);
         vhi[d] = (int32_t)std::min<long>((long)occ[7 + 2 * d], e);
         if (vlo[d] >= vhi[d]) return IVX_OK;
         lo[d] = (uint32_t)vlo[d] / 16u;
         cc[d] = ((uint32_t)vhi[d] + 15u) / 16u - lo[d];
     }
-    // scratch: [10 f64 removed moments][256 u32 by type][2 u32 counters][pad][n_chunks u8 touched]
-    const size_t off_type = 80, off_cnt = off_type + 1024, off_touch = off_cnt + 16, total = off_touch + g->n_chunks;
+    // scratch: [10 f64 removed moments][256 u32 by type][2 u32 counters][pad][n_chunks u32 touched ranges]
+    const size_t off_type = 80, off_cnt = off_type + 1024, off_touch = off_cnt + 16, total = off_touch + (size_t)g->n_chunks * 4;
     const size_t off_dens = (total + 255) & ~(size_t)255;
     if ((rc = ensure_dev_scratch(g, off_dens + 1024))) return rc;
     char* base = static_cast<char*>(g->dev_scratch);
     IVX_HIP_CHECK(hipMemsetAsync(base, 0, total, g->ctx->stream));
     float* d_dens = reinterpret_cast<float*>(base + off_dens);
     if ((rc = h2d(g, d_dens, densities, 1024))) return rc;
-    if ((rc = ivx_launch_absorb_sphere(g, lo, cc, vlo, vhi, center, influence_radius, sphere_radius, d_dens, reinterpret_cast<double*>(base),
-                                       reinterpret_cast<uint32_t*>(base + off_type), reinterpret_cast<uint32_t*>(base + off_cnt),
-                                       reinterpret_cast<uint8_t*>(base + off_touch))))
+    if ((rc = ivx_launch_absorb(g, capsule, lo, cc, vlo, vhi, center, seg, influence_radius, shape_radius, d_dens, reinterpret_cast<double*>(base),
+                                reinterpret_cast<uint32_t*>(base + off_type), reinterpret_cast<uint32_t*>(base + off_cnt),
+                                reinterpret_cast<uint32_t*>(base + off_touch))))
         return rc;
     std::vector<char> hostbuf(total);
     if ((rc = d2h(g, hostbuf.data(), base, total))) return rc;
@@ -815,23 +822,24 @@ int ivx_absorb_sphere(ivx_grid* g, const float center[3], float influence_radius
     out->removed_chunks = cnt[1];
     if (invalidated_chunks) {
         // handle_chunk_voxels_modified (intersection.rs:560-598): the touched chunk, and a neighbour when the touched voxel range
-        // comes within two voxels of the face they share
-        const uint8_t* touched = reinterpret_cast<const uint8_t*>(hostbuf.data() + off_touch);
+        // of the chunk comes within two voxels of the face they share
+        const uint32_t* touched = reinterpret_cast<const uint32_t*>(hostbuf.data() + off_touch);
         for (uint32_t i = lo[0]; i < lo[0] + cc[0]; ++i)
             for (uint32_t j = lo[1]; j < lo[1] + cc[1]; ++j)
                 for (uint32_t k = lo[2]; k < lo[2] + cc[2]; ++k) {
                     const uint32_t c = (i * g->cc[1] + j) * g->cc[2] + k;
-                    if (!touched[c]) continue;
+                    const uint32_t w = touched[c];
+                    if (!w) continue;
                     invalidated_chunks[c] = 1;
                     const uint32_t idx[3] = {i, j, k};
                     for (int d = 0; d < 3; ++d) {
-                        const long cbase = (long)idx[d] * 16, rlo = std::max<long>(cbase, vlo[d]), rhi = std::min<long>(cbase + 16, vhi[d]);
+                        const uint32_t rlo = (w >> (4 * d)) & 15u, rhi = ((w >> (12 + 4 * d)) & 15u) + 1u;  // chunk-relative
                         uint32_t a[3] = {i, j, k};
-                        if (idx[d] > 0 && rlo - cbase < 2) {
+                        if (idx[d] > 0 && rlo < 2) {
                             a[d] = idx[d] - 1;
                             invalidated_chunks[(a[0] * g->cc[1] + a[1]) * g->cc[2] + a[2]] = 1;
                         }
-                        if (idx[d] + 1 < g->cc[d] && cbase + 16 - rhi < 2) {
+                        if (idx[d] + 1 < g->cc[d] && 16u - rhi < 2) {
                             a[d] = idx[d] + 1;
                             invalidated_chunks[(a[0] * g->cc[1] + a[1]) * g->cc[2] + a[2]] = 1;
                         }
@@ -839,6 +847,17 @@ int ivx_absorb_sphere(ivx_grid* g, const float center[3], float influence_radius
                 }
     }
     return IVX_OK;
+}
+
+int ivx_absorb_sphere(ivx_grid* g, const float center[3], float influence_radius, float sphere_radius, const float densities[256], ivx_absorb_result* out,
+                      uint32_t* emptied_by_type, uint8_t* invalidated_chunks) {
+    return absorb_shape(g, "ivx_absorb_sphere", 0, center, nullptr, influence_radius, sphere_radius, densities, out, emptied_by_type, invalidated_chunks);
+}
+
+int ivx_absorb_capsule(ivx_grid* g, const float segment_start[3], const float segment_vector[3], float influence_radius, float capsule_radius,
+                       const float densities[256], ivx_absorb_result* out, uint32_t* emptied_by_type, uint8_t* invalidated_chunks) {
+    return absorb_shape(g, "ivx_absorb_capsule", 1, segment_start, segment_vector, influence_radius, capsule_radius, densities, out, emptied_by_type,
+                        invalidated_chunks);
 }
 
 // rotate a vector by a quaternion the way glam's Quat::mul_vec3a does (host side of Isometry3::transform_point)

@@ -288,9 +288,9 @@ int ivx_launch_step_record(ivx_grid* g, const uint32_t* d_pair_count, const void
 int ivx_launch_split_move(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], const uint32_t cc[3], uint32_t target);
 int ivx_launch_clip(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], const uint32_t cc[3], const float* planes4, uint32_t n_planes, int extract);
 int ivx_launch_split_repack(ivx_grid* src, ivx_grid* dst, const uint32_t off[3]);
-int ivx_launch_absorb_sphere(ivx_grid* g, const uint32_t lo[3], const uint32_t cc[3], const int32_t vlo[3], const int32_t vhi[3], const float c[3],
-                             float influence_radius, float sphere_radius, const float* d_dens, double* d_removed10, uint32_t* d_by_type,
-                             uint32_t* d_counters, uint8_t* d_touched);
+int ivx_launch_absorb(ivx_grid* g, int capsule, const uint32_t lo[3], const uint32_t cc[3], const int32_t vlo[3], const int32_t vhi[3], const float c[3],
+                      const float seg[3], float influence_radius, float shape_radius, const float* d_dens, double* d_removed10, uint32_t* d_by_type,
+                      uint32_t* d_counters, uint32_t* d_touched);
 int ivx_launch_sphere_contacts(ivx_grid* g, const uint32_t lo[3], const uint32_t cc[3], const int32_t vlo[3], const int32_t vhi[3],
                                const float rotation_xyzw[4], const float translation[3], const float center[3], float radius, uint64_t id_a, uint64_t id_b,
                                uint32_t body_a, uint32_t body_b, const float response[3], uint32_t* d_counts, uint32_t* d_offsets, uint32_t* d_total,

@@ -354,6 +354,23 @@ class VoxelObject:
                 "invalidated": None if inval is None else inval.astype(bool), "touched_chunks": int(out[0]["touched_chunks"]),
                 "removed_chunks": int(out[0]["removed_chunks"])}
 
+    def absorb_capsule(self, segment_start, segment_vector, influence_radius: float, capsule_radius: float, densities=None,
+                       want_invalidated: bool = True):
+        """`apply_capsule_absorption` (interaction/absorption.rs:846-889) with the capsule (segment start + vector) in the object's
+        normalized space; the result dict of `absorb_sphere`."""
+        d = np.ones(256, dtype=np.float32) if densities is None else np.ascontiguousarray(densities, dtype=np.float32)
+        a = np.ascontiguousarray(segment_start, dtype=np.float32)
+        v = np.ascontiguousarray(segment_vector, dtype=np.float32)
+        out = np.zeros(1, dtype=capi.ABSORB_RESULT_DTYPE)
+        by_type = np.zeros(256, dtype=np.uint32)
+        inval = np.zeros(self.n_chunks, dtype=np.uint8) if want_invalidated else None
+        check(capi.lib().ivx_absorb_capsule(self.h, ptr(a), ptr(v), influence_radius, capsule_radius, ptr(d), ptr(out), ptr(by_type),
+                                            ptr(inval) if inval is not None else None))
+        self._region_count = None
+        return {"removed_moments": out[0]["removed_moments"].copy(), "emptied_by_type": by_type, "emptied_voxels": int(out[0]["emptied_voxels"]),
+                "invalidated": None if inval is None else inval.astype(bool), "touched_chunks": int(out[0]["touched_chunks"]),
+                "removed_chunks": int(out[0]["removed_chunks"])}
+
     # ---- contact generation ------------------------------------------------------------------------
     def sphere_contacts(self, rotation_xyzw, translation, sphere_center, sphere_radius: float, collidable_id_a: int, collidable_id_b: int, body_a: int,
                         body_b: int, response=(0.0, 0.0, 0.0), capacity: int = 65536) -> np.ndarray:

@@ -233,6 +233,13 @@ typedef struct {
 } ivx_absorb_result;
 int ivx_absorb_sphere(ivx_grid*, const float center[3], float influence_radius, float sphere_radius, const float densities[256],
                       ivx_absorb_result* out, uint32_t* emptied_by_type, uint8_t* invalidated_chunks);
+/* apply_capsule_absorption (interaction/absorption.rs:846-889) over modify_voxels_within_capsule (object/intersection.rs:417-530):
+ * the same with an absorbing capsule — segment start + vector in the object's normalized space, `influence_radius` = radius + 2
+ * voxels. Per chunk the segment is clipped against the chunk box grown by the radius (Capsule::trim_segment_outside_aab,
+ * impact_geometry/src/capsule.rs:144-164) and only the voxel ranges under the clipped capsule's box are visited; a voxel is inside
+ * when its centre is within the radius of the whole segment, boundary included (capsule.rs:225-250). */
+int ivx_absorb_capsule(ivx_grid*, const float segment_start[3], const float segment_vector[3], float influence_radius, float capsule_radius,
+                       const float densities[256], ivx_absorb_result* out, uint32_t* emptied_by_type, uint8_t* invalidated_chunks);
 
 /* make the compiled SDF program / the voxel-type densities resident on the device */
 int ivx_grid_set_sdf_program(ivx_grid*, const ivx_sdf_processed_node* nodes, size_t n_nodes, uint32_t stack_size,

@@ -159,6 +159,9 @@ int orc_clip_polyhedron(orc_object* parent, const float* planes4, int n_planes, 
  * in the object's normalized space (voxel units, grid corner at the origin). Returns the number of chunks that became void. */
 int orc_absorb_sphere(orc_object* o, const float center[3], float influence_radius, float sphere_radius, const float densities[256],
                       double removed64[10], uint32_t emptied_by_type[256], uint8_t* invalidated_chunks, uint32_t* touched_chunks);
+/* the same for an absorbing capsule (interaction/absorption.rs:846-889 over object/intersection.rs:397-530) */
+int orc_absorb_capsule(orc_object* o, const float segment_start[3], const float segment_vector[3], float influence_radius, float capsule_radius,
+                       const float densities[256], double removed64[10], uint32_t emptied_by_type[256], uint8_t* invalidated_chunks, uint32_t* touched_chunks);
 /* contacts between a sphere collidable (world space) and the surface voxels of the object (impact_voxel/src/collidable.rs:1098-1127);
  * transform_to_object_space = rotation (xyzw) then translation. Returns the number of contacts; fills at most `cap`. */
 int orc_sphere_voxel_object_contacts(const orc_object* o, const float rotation_xyzw[4], const float translation[3], const float center[3], float radius,

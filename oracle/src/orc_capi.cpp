@@ -18,6 +18,8 @@ int sphere_voxel_object_contacts(const VoxelObject& obj, const float rot[4], con
                                  int32_t* indices, float* position, float* normal, float* depth);
 int plane_voxel_object_contacts(const VoxelObject& obj, const float rot[4], const float trans[3], const float plane_normal[3], float plane_displacement,
                                 int cap, int32_t* indices, float* position, float* normal, float* depth);
+int absorb_capsule(VoxelObject& obj, const float segment_start[3], const float segment_vector[3], float influence_radius, float capsule_radius,
+                   const float* dens, double removed64[10], uint32_t emptied_by_type[256], uint8_t* invalidated, uint32_t* touched_chunks);
 int absorb_sphere(VoxelObject& obj, const float center[3], float influence_radius, float sphere_radius, const float* dens, double removed64[10],
                   uint32_t emptied_by_type[256], uint8_t* invalidated, uint32_t* touched_chunks);
 
@@ -367,6 +369,13 @@ int orc_clip_polyhedron(orc_object* parent, const float* planes4, int n_planes, 
 int orc_absorb_sphere(orc_object* o, const float center[3], float influence_radius, float sphere_radius, const float densities[256],
                       double removed64[10], uint32_t emptied_by_type[256], uint8_t* invalidated_chunks, uint32_t* touched_chunks) {
     return absorb_sphere(o->obj, center, influence_radius, sphere_radius, densities, removed64, emptied_by_type, invalidated_chunks, touched_chunks);
+}
+
+// apply_capsule_absorption (interaction/absorption.rs:846-889)
+int orc_absorb_capsule(orc_object* o, const float segment_start[3], const float segment_vector[3], float influence_radius, float capsule_radius,
+                       const float densities[256], double removed64[10], uint32_t emptied_by_type[256], uint8_t* invalidated_chunks, uint32_t* touched_chunks) {
+    return absorb_capsule(o->obj, segment_start, segment_vector, influence_radius, capsule_radius, densities, removed64, emptied_by_type, invalidated_chunks,
+                          touched_chunks);
 }
 
 // for_each_sphere_voxel_object_contact (impact_voxel/src/collidable.rs:1098-1127): contacts in the reference's traversal order

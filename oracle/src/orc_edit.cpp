@@ -29,8 +29,13 @@ void edit_reset_occupied_chunk_ranges(VoxelObject& obj);   // orc_split.cpp
 
 // returns the number of chunks that became void; removed64 = integer-form moments of the emptied voxels scaled like
 // inertia_moments_f64 (mass, first moments, moments and products of inertia about the grid origin)
-int absorb_sphere(VoxelObject& obj, const float center[3], float influence_radius, float sphere_radius, const float* dens, double removed64[10],
-                  uint32_t emptied_by_type[256], uint8_t* invalidated /* [n_chunks] or null */, uint32_t* touched_chunks) {
+// mode 0: sphere (center, influence radius); mode 1: capsule (segment start = center, segment vector = seg, influence radius) —
+// modify_voxels_within_capsule (object/intersection.rs:397-530): the segment is trimmed per chunk against the chunk box grown by the
+// radius (Capsule::trim_segment_outside_aab, impact_geometry/src/capsule.rs:144-164; AxisAlignedBox::find_contained_subsegment,
+// axis_aligned_box.rs:385-415), the voxel ranges of a chunk come from the trimmed capsule's box, and a voxel is inside when its
+// squared distance to the UNtrimmed segment is <= r^2 (CapsulePointContainmentTester, capsule.rs:166-250).
+static int absorb_shape(VoxelObject& obj, int mode, const float center[3], const float seg[3], float influence_radius, float shape_radius, const float* dens,
+                        double removed64[10], uint32_t emptied_by_type[256], uint8_t* invalidated /* [n_chunks] or null */, uint32_t* touched_chunks) {
     for (int q = 0; q < 10; ++q) removed64[q] = 0.0;
     if (emptied_by_type) std::memset(emptied_by_type, 0, 256 * sizeof(uint32_t));
     if (invalidated) std::memset(invalidated, 0, (size_t)obj.n_chunks());
@@ -38,7 +43,12 @@ int absorb_sphere(VoxelObject& obj, const float center[3], float influence_radiu
     long vlo[3], vhi[3];
     int clo[3], chi[3];
     for (int d = 0; d < 3; ++d) {
-        const float lo = center[d] - influence_radius, hi = center[d] + influence_radius;  // Sphere::compute_aabb
+        float lo = center[d] - influence_radius, hi = center[d] + influence_radius;  // Sphere::compute_aabb
+        if (mode == 1) {  // Capsule::compute_aabb: the pair of end-sphere boxes (capsule.rs:132-137)
+            const float end = center[d] + seg[d];
+            lo = fmin_rs(lo, end - influence_radius);
+            hi = fmax_rs(hi, end + influence_radius);
+        }
         const float fl = std::floor(lo);
         const float ce = std::ceil(hi);
         const long s = (long)(fl > 0.0f ? fl : 0.0f), e = ce > 0.0f ? (long)ce : 0;  // `as usize` saturates at 0
@@ -49,6 +59,10 @@ int absorb_sphere(VoxelObject& obj, const float center[3], float influence_radiu
         chi[d] = (int)((vhi[d] + CHUNK - 1) / CHUNK);
     }
     const float r2 = influence_radius * influence_radius;
+    // CapsulePointContainmentTester
+    const V3 seg_start{center[0], center[1], center[2]}, seg_vec{seg ? seg[0] : 0.0f, seg ? seg[1] : 0.0f, seg ? seg[2] : 0.0f};
+    const float seg_len2 = dot(seg_vec, seg_vec);
+    const V3 seg_over_len2 = seg_len2 > 1e-8f ? div_recip(seg_vec, seg_len2) : V3{0.0f, 0.0f, 0.0f};
     const double ext = (double)obj.extent;
     double s[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int removed_chunks = 0;
@@ -57,6 +71,39 @@ int absorb_sphere(VoxelObject& obj, const float center[3], float influence_radiu
             for (int K = clo[2]; K < chi[2]; ++K) {
                 const int ci = obj.cidx(I, J, K);
                 Chunk& ch = obj.chunks[ci];
+                const long base[3] = {(long)I * CHUNK, (long)J * CHUNK, (long)K * CHUNK};
+                long rlo[3], rhi[3];
+                if (mode == 1) {
+                    // trim_segment_outside_aab(normalized_chunk_aabb) -> voxel_ranges_touching_aab(chunk ranges, trimmed.compute_aabb())
+                    float t_min = 0.0f, t_max = 1.0f;
+                    bool none = false;
+                    const float sv[3] = {seg_vec.x, seg_vec.y, seg_vec.z};
+                    for (int d = 0; d < 3 && !none; ++d) {
+                        const float blo = (float)base[d] - influence_radius, bhi = (float)(base[d] + CHUNK) + influence_radius;
+                        if (std::fabs(sv[d]) > 1e-8f) {
+                            const float recip = 1.0f / sv[d];
+                            const float t1 = (blo - center[d]) * recip, t2 = (bhi - center[d]) * recip;
+                            const float te = t1 < t2 ? t1 : t2, tx = t1 < t2 ? t2 : t1;
+                            t_min = fmax_rs(t_min, te);
+                            t_max = fmin_rs(t_max, tx);
+                        } else if (center[d] < blo || center[d] > bhi) {
+                            none = true;
+                        }
+                    }
+                    if (none || !(t_min <= t_max)) continue;
+                    bool empty = false;
+                    for (int d = 0; d < 3; ++d) {
+                        const float ts = center[d] + sv[d] * t_min;
+                        const float tv = sv[d] * (t_max - t_min);
+                        const float te = ts + tv;
+                        const float lo = fmin_rs(ts - influence_radius, te - influence_radius), hi = fmax_rs(ts + influence_radius, te + influence_radius);
+                        const float fl = std::floor(lo), ce = std::ceil(hi);
+                        rlo[d] = std::max<long>(base[d], (long)(fl > 0.0f ? fl : 0.0f));
+                        rhi[d] = std::min<long>(base[d] + CHUNK, ce > 0.0f ? (long)ce : 0);
+                        if (rlo[d] >= rhi[d]) empty = true;
+                    }
+                    if (empty) continue;
+                }
                 if (ch.kind == K_VOID) continue;
                 if (ch.kind == K_UNIFORM) {  // convert_to_non_uniform_if_uniform (object.rs:2530-2550)
                     const size_t start = obj.voxels.size();
@@ -70,23 +117,33 @@ int absorb_sphere(VoxelObject& obj, const float center[3], float influence_radiu
                     ch.boundary_region_count = 1;
                 }
                 Voxel* cv = &obj.voxels[(size_t)ch.data_offset << 12];
-                const long base[3] = {(long)I * CHUNK, (long)J * CHUNK, (long)K * CHUNK};
-                long rlo[3], rhi[3];
-                for (int d = 0; d < 3; ++d) {
-                    rlo[d] = std::max(base[d], vlo[d]);
-                    rhi[d] = std::min(base[d] + CHUNK, vhi[d]);
-                }
+                if (mode == 0)
+                    for (int d = 0; d < 3; ++d) {
+                        rlo[d] = std::max(base[d], vlo[d]);
+                        rhi[d] = std::min(base[d] + CHUNK, vhi[d]);
+                    }
                 bool touched = false;
                 for (long i = rlo[0]; i < rhi[0]; ++i)
                     for (long j = rlo[1]; j < rhi[1]; ++j)
                         for (long k = rlo[2]; k < rhi[2]; ++k) {
                             const V3 p{(float)i + 0.5f, (float)j + 0.5f, (float)k + 0.5f};
-                            const V3 dv{p.x - center[0], p.y - center[1], p.z - center[2]};
-                            const float d2 = dot(dv, dv);
-                            if (!(d2 < r2)) continue;
+                            float d2;
+                            if (mode == 0) {
+                                const V3 dv{p.x - center[0], p.y - center[1], p.z - center[2]};
+                                d2 = dot(dv, dv);
+                                if (!(d2 < r2)) continue;
+                            } else {
+                                const V3 sp = p - seg_start;
+                                float t = dot(sp, seg_over_len2);
+                                t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);  // f32::clamp
+                                const V3 closest = seg_start + seg_vec * t;
+                                const V3 dv = p - closest;
+                                d2 = dot(dv, dv);
+                                if (!(d2 <= r2)) continue;
+                            }
                             Voxel& v = cv[((i - base[0]) << 8) | ((j - base[1]) << 4) | (k - base[2])];
                             const bool was_empty = v.empty();
-                            const float sphere_sd = std::sqrt(d2) - sphere_radius;
+                            const float sphere_sd = std::sqrt(d2) - shape_radius;
                             const float nv = fmax_rs(sd_to_f32(v.sd), -sphere_sd);  // hard_sdf_subtraction
                             v.sd = sd_from_f32(nv);
                             if (!(v.sd < 0)) {
@@ -151,6 +208,16 @@ int absorb_sphere(VoxelObject& obj, const float center[3], float influence_radiu
     compute_all_derived_state(obj);
     if (removed_chunks) edit_reset_occupied_chunk_ranges(obj);
     return removed_chunks;
+}
+
+int absorb_sphere(VoxelObject& obj, const float center[3], float influence_radius, float sphere_radius, const float* dens, double removed64[10],
+                  uint32_t emptied_by_type[256], uint8_t* invalidated, uint32_t* touched_chunks) {
+    return absorb_shape(obj, 0, center, nullptr, influence_radius, sphere_radius, dens, removed64, emptied_by_type, invalidated, touched_chunks);
+}
+// apply_capsule_absorption (interaction/absorption.rs:846-889) with the capsule in the object's normalized space
+int absorb_capsule(VoxelObject& obj, const float segment_start[3], const float segment_vector[3], float influence_radius, float capsule_radius,
+                   const float* dens, double removed64[10], uint32_t emptied_by_type[256], uint8_t* invalidated, uint32_t* touched_chunks) {
+    return absorb_shape(obj, 1, segment_start, segment_vector, influence_radius, capsule_radius, dens, removed64, emptied_by_type, invalidated, touched_chunks);
 }
 
 }  // namespace orc

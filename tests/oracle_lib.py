@@ -90,6 +90,8 @@ def lib():
         L.orc_sphere_voxel_object_contacts.argtypes = [vp, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, vp]
         L.orc_plane_voxel_object_contacts.restype = C.c_int
         L.orc_plane_voxel_object_contacts.argtypes = [vp, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, vp]
+        L.orc_absorb_capsule.restype = C.c_int
+        L.orc_absorb_capsule.argtypes = [vp, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, C.POINTER(C.c_uint32)]
         L.orc_absorb_sphere.restype = C.c_int
         L.orc_absorb_sphere.argtypes = [vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, C.POINTER(C.c_uint32)]
         L.orc_physics_create.restype = vp
@@ -294,6 +296,20 @@ class OracleObject:
         inval = np.zeros(cc[0] * cc[1] * cc[2], dtype=np.uint8)
         touched = C.c_uint32(0)
         n = lib().orc_absorb_sphere(self.h, _p(c), influence_radius, sphere_radius, _p(d), _p(removed), _p(by_type), _p(inval), C.byref(touched))
+        return {"removed64": removed, "emptied_by_type": by_type, "invalidated": inval.astype(bool), "touched_chunks": int(touched.value),
+                "removed_chunks": int(n)}
+
+    def absorb_capsule(self, segment_start, segment_vector, influence_radius, capsule_radius, densities=None):
+        """apply_capsule_absorption with the capsule in the object's normalized space; same result dict as absorb_sphere"""
+        d = np.ones(256, dtype=np.float32) if densities is None else np.ascontiguousarray(densities, dtype=np.float32)
+        a = np.ascontiguousarray(segment_start, dtype=np.float32)
+        v = np.ascontiguousarray(segment_vector, dtype=np.float32)
+        cc = self.chunk_counts
+        removed = np.zeros(10, dtype=np.float64)
+        by_type = np.zeros(256, dtype=np.uint32)
+        inval = np.zeros(cc[0] * cc[1] * cc[2], dtype=np.uint8)
+        touched = C.c_uint32(0)
+        n = lib().orc_absorb_capsule(self.h, _p(a), _p(v), influence_radius, capsule_radius, _p(d), _p(removed), _p(by_type), _p(inval), C.byref(touched))
         return {"removed64": removed, "emptied_by_type": by_type, "invalidated": inval.astype(bool), "touched_chunks": int(touched.value),
                 "removed_chunks": int(n)}
 

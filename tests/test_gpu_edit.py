@@ -120,3 +120,91 @@ def test_multi_material_object_reports_absorbed_types(ctx):
     r = absorb_both(o, g, np.array([30.0, 22.5, 26.0], np.float32), 9.0, dens)
     assert np.count_nonzero(r["emptied_by_type"][:3]) >= 2
     g.close()
+
+
+# ---- absorbing capsule ------------------------------------------------------------------------------------------------------------
+def absorb_capsule_both(o, g, start, vec, radius, dens=None):
+    ro = o.absorb_capsule(start, vec, radius + 2.0, radius, dens)
+    rg = g.absorb_capsule(start, vec, radius + 2.0, radius, dens)
+    assert rg["touched_chunks"] == ro["touched_chunks"] and rg["removed_chunks"] == ro["removed_chunks"]
+    np.testing.assert_array_equal(rg["emptied_by_type"], ro["emptied_by_type"])
+    np.testing.assert_array_equal(rg["invalidated"], ro["invalidated"])
+    scale = np.maximum(np.abs(ro["removed64"]), 1e-300)
+    assert np.all(np.abs(rg["removed_moments"] - ro["removed64"]) <= 1e-5 * scale + 1e-9), (rg["removed_moments"], ro["removed64"])
+    ro["regions"] = pu.assert_edited_objects_equal(o, g, densities=dens)
+    return ro
+
+
+@pytest.mark.parametrize("case", ["diagonal", "axis_aligned", "point", "tiny_component", "miss"])
+def test_capsule_through_a_sphere(ctx, case):
+    """a skew capsule through the body (every chunk clips the segment differently), an axis-aligned one (zero offset components
+    take the slab test's other branch), a zero-length one (a sphere with <=), one with a 1e-9 component, and a miss"""
+    o, g = both(ctx, scenes.sphere_scene(40.0))
+    c = centre_of(o)
+    if case == "diagonal":
+        start, vec, r = c + np.array([-50.0, -37.5, -20.25], np.float32), np.array([101.0, 70.5, 44.0], np.float32), 6.0
+    elif case == "axis_aligned":
+        start, vec, r = c + np.array([0.5, -60.0, 35.0], np.float32), np.array([0.0, 120.0, 0.0], np.float32), 5.0
+    elif case == "point":
+        start, vec, r = c + np.array([30.0, 10.0, -12.0], np.float32), np.zeros(3, np.float32), 11.0
+    elif case == "tiny_component":
+        start, vec, r = c + np.array([-3.0, 2.0, -70.0], np.float32), np.array([1e-9, -1e-9, 140.0], np.float32), 9.0
+    else:
+        start, vec, r = c + np.array([90.0, 90.0, 0.0], np.float32), np.array([0.0, 0.0, 40.0], np.float32), 6.0
+    res = absorb_capsule_both(o, g, start, vec, r)
+    if case == "miss":
+        assert res["touched_chunks"] == 0
+    else:
+        assert res["emptied_by_type"].sum() > 1000 and res["regions"] == 1
+    g.close()
+
+
+def test_capsule_across_the_reference_box_geometry(ctx):
+    """modifying_voxels_within_capsule_finds_correct_voxels_across_chunks (object/intersection.rs:1301-1345): a box of 30x14x14
+    voxels (extent 0.25, capsule scaled by 4 into voxel units) skewered along z by a capsule far longer than the object"""
+    o, g = both(ctx, scenes.box_scene((30.0, 14.0, 14.0)), extent=0.25)
+    res = absorb_capsule_both(o, g, np.array([15.2, 12.0, -200.0], np.float32), np.array([0.0, 0.0, 2000.0], np.float32), 4.0)
+    assert res["emptied_by_type"].sum() > 500
+    g.close()
+
+
+def test_capsule_sweep_cuts_a_rod_in_two(ctx):
+    """the swept absorber of a moving tool: one capsule across a rod severs it; the smaller part splits off as in the reference"""
+    from impact_amd.sdf_graph import SDFGraph, SDFNode
+
+    gr = SDFGraph()
+    gr.add_node(SDFNode.new_box([120.0, 14.0, 14.0]))
+    o, g = both(ctx, gr)
+    c0 = centre_of(o)
+    r = absorb_capsule_both(o, g, c0 + np.array([7.0, -14.0, -3.0], np.float32), np.array([2.0, 28.0, 6.0], np.float32), 10.5)
+    assert r["regions"] == 2
+    rc_o, child_o, origin_o = o.split_off_smallest_region()
+    rc_g, child_g, origin_g, _ = g.extract_any_disconnected_region()
+    assert rc_o == 1 and rc_g == 1 and tuple(int(x) for x in origin_g) == tuple(origin_o)
+    pu.assert_edited_objects_equal(o, g)
+    pu.assert_edited_objects_equal(child_o, child_g)
+    child_g.close()
+    g.close()
+
+
+def test_capsule_on_multi_material_object(ctx):
+    rng = np.random.default_rng(9)
+    cc = (3, 3, 3)
+    n = 48
+    x, y, z = np.meshgrid(*[np.arange(n) + 0.5] * 3, indexing="ij")
+    d = np.sqrt((x - 24) ** 2 + (y - 24) ** 2 + (z - 24) ** 2) - 19.0
+    sd = np.clip(np.trunc(d.astype(np.float32) * np.float32(50.0)), -128, 127).astype(np.int8)
+    ty = (np.floor(y / 16).astype(np.uint8) + np.floor(x / 24).astype(np.uint8)) % 3
+    ty[sd >= 0] = 255
+    sdt, tyt = ol.dense_to_tiled(sd), ol.dense_to_tiled(ty)
+    o = ol.OracleObject.from_dense(cc, sdt, tyt)
+    g = VoxelObject.from_dense(ctx, cc, sdt, tyt)
+    o.update_occupied_voxel_ranges()
+    o.compute_all_derived_state()
+    g.compute_all_derived_state()
+    g.update_occupied_voxel_ranges()
+    g.label_regions()
+    dens = rng.uniform(0.5, 3.0, 256).astype(np.float32)
+    r = absorb_capsule_both(o, g, np.array([6.0, 10.5, 20.0], np.float32), np.array([36.0, 27.0, 9.5], np.float32), 5.0, dens)
+    assert np.count_nonzero(r["emptied_by_type"][:3]) >= 2
+    g.close()
