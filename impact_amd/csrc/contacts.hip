@@ -1,5 +1,5 @@
-// Voxel contact generation (first part): contacts between a sphere collidable and the surface voxels of a
-// voxel object — the step immediately before the constraint solver.
+// Voxel contact generation (first part): contacts between a sphere, plane or capsule collidable and the surface
+// voxels of a voxel object — the step immediately before the constraint solver.
 //
 // Reference (engine/crates):
 //   for_each_sphere_voxel_object_contact                    impact_voxel/src/collidable.rs:1098-1127
@@ -9,6 +9,9 @@
 //   compute_voxel_radius                                    impact_voxel/src/collidable.rs:1453-1455
 //   determine_sphere_sphere_contact_geometry                impact_physics/src/collision/collidable/sphere.rs:105-136
 //   ContactID::from_two_u64_and_n_indices                   impact_physics/src/constraint/contact.rs:180-199
+//   for_each_capsule_voxel_object_contact                   impact_voxel/src/collidable.rs:1257-1286
+//   determine_capsule_sphere_contact_geometry               impact_physics/src/collision/collidable/capsule.rs:212-270
+//   parameter_of_closest_point_on_line_segment_to_point     impact_geometry/src/line.rs:26-45
 // Every non-empty voxel with fewer than six neighbours inside the touched voxel ranges is a small sphere (radius = -sd * extent)
 // tested against the collidable. The reference emits contacts in traversal order (chunks i,j,k, then voxels i,j,k), and the
 // solver's result depends on that order, so the emit pass is an ordered compaction: counts per chunk, a scan over the chunks
@@ -50,8 +53,10 @@ struct SvcParams {
     int32_t vlo[3], vhi[3];  // touched voxel ranges
     Q4 q_inv;                // inverse rotation of transform_to_object_space
     float t[3];              // its translation
-    uint32_t mode;           // 0: sphere collidable (c, r); 1: plane collidable (unit normal c, displacement r), Corner voxels only
+    uint32_t mode;           // 0: sphere collidable (c, r); 1: plane collidable (unit normal c, displacement r), Corner voxels only;
+                             // 2: capsule collidable (segment start c, segment vector v, radius r)
     float c[3], r;           // the collidable (world space)
+    float v[3], len2;
     float extent;
     unsigned long long id_ab;  // splitmix(a ^ splitmix(b))
     uint32_t body_a, body_b;
@@ -80,11 +85,47 @@ __device__ __forceinline__ uint32_t row_contacts(const SvcParams& p, const int8_
         if (gk < p.vlo[2] || gk >= p.vhi[2]) continue;
         const uint32_t f = (fw[k >> 2] >> (8 * (k & 3))) & 0xFFu;
         // empty, or Interior (six neighbours, lib.rs:330-342); a plane only needs the Corner voxels (at most three, collidable.rs:1187-1191)
-        if ((f & VF_EMPTY) || __popc(f & 0xFCu) > (p.mode ? 3 : 5)) continue;
+        if ((f & VF_EMPTY) || __popc(f & 0xFCu) > (p.mode == 1u ? 3 : 5)) continue;
         const int sd = (int)(int8_t)((sw[k >> 2] >> (8 * (k & 3))) & 0xFFu);
         const V3 p_obj = mk(((float)gi + 0.5f) * p.extent, ((float)gj + 0.5f) * p.extent, ((float)gk + 0.5f) * p.extent);
         const V3 pw = qrot(p.q_inv, p_obj - mk(p.t[0], p.t[1], p.t[2]));  // inverse_transform_point
         const float vr = -((float)sd * 0.02f) * p.extent;                  // compute_voxel_radius
+        if (p.mode == 2u) {  // determine_capsule_sphere_contact_geometry(capsule, voxel_sphere)
+            const V3 sv = mk(p.v[0], p.v[1], p.v[2]);
+            float param = 0.0f;
+            if (!(p.len2 <= 1e-8f)) {
+                param = dot(sv, pw - c) / p.len2;
+                param = param < 0.0f ? 0.0f : (param > 1.0f ? 1.0f : param);  // f32::clamp
+            }
+            const V3 disp = pw - (c + sv * param);
+            const float d2 = dot(disp, disp), maxd = vr + p.r;
+            if (d2 > maxd * maxd) continue;
+            mask |= 1u << k;
+            if (EMIT) {
+                const float dist = sqrtf(d2);
+                V3 cn;
+                float pen;
+                if (dist > 1e-8f) {
+                    cn = disp * (1.0f / dist);
+                    pen = maxd - dist;
+                } else {  // the voxel centre lies on the segment: any normal to the segment (glam Vec3A::any_orthogonal_vector)
+                    const V3 o = fabsf(sv.x) > fabsf(sv.y) ? mk(-sv.z, 0.0f, sv.x) : mk(0.0f, sv.z, -sv.y);
+                    const float n2 = dot(o, o);
+                    if (n2 > 1e-8f * 1e-8f) {
+                        const float nn = sqrtf(n2);
+                        cn = mk(o.x / nn, o.y / nn, o.z / nn);
+                    } else {
+                        cn = mk(0.0f, 0.0f, 1.0f);
+                    }
+                    pen = maxd;
+                }
+                const V3 n = mk(-cn.x, -cn.y, -cn.z);
+                hits[k].nrm = n;
+                hits[k].pos = pw + n * vr;
+                hits[k].depth = pen > 0.0f ? pen : 0.0f;
+            }
+            continue;
+        }
         if (p.mode) {  // determine_sphere_plane_contact_geometry(voxel_sphere, plane) (sphere.rs:138-160)
             const float sdist = dot(c, pw) - p.r;
             const float pen = vr - sdist;
@@ -213,12 +254,14 @@ __global__ __launch_bounds__(256) void k_svc_emit(SvcParams p, const uint8_t* __
 }  // namespace
 
 int ivx_launch_sphere_contacts(ivx_grid* g, const uint32_t lo[3], const uint32_t cc[3], const int32_t vlo[3], const int32_t vhi[3],
-                               const float rotation_xyzw[4], const float translation[3], const float center[3], float radius, uint64_t id_a, uint64_t id_b,
-                               uint32_t body_a, uint32_t body_b, const float response[3], uint32_t* d_counts, uint32_t* d_offsets, uint32_t* d_total,
-                               ivx_contact* d_out, uint32_t cap, int emit, int plane) {
+                               const float rotation_xyzw[4], const float translation[3], const float center[3], const float seg_vec[3], float radius,
+                               uint64_t id_a, uint64_t id_b, uint32_t body_a, uint32_t body_b, const float response[3], uint32_t* d_counts,
+                               uint32_t* d_offsets, uint32_t* d_total, ivx_contact* d_out, uint32_t cap, int emit, int mode) {
     SvcParams p;
     p.g = ivx_view(g);
-    p.mode = plane ? 1u : 0u;
+    p.mode = (uint32_t)mode;
+    for (int d = 0; d < 3; ++d) p.v[d] = mode == 2 ? seg_vec[d] : 0.0f;
+    p.len2 = (p.v[0] * p.v[0] + p.v[1] * p.v[1]) + p.v[2] * p.v[2];
     for (int d = 0; d < 3; ++d) {
         p.lo[d] = lo[d];
         p.cc[d] = cc[d];

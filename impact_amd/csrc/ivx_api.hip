@@ -884,10 +884,13 @@ static bool touched_ranges(const uint32_t occ[12], const float lo_f[3], const fl
     return true;
 }
 
-static int voxel_object_contacts(ivx_grid* g, const char* who, int plane, const float rotation_xyzw[4], const float translation[3], const float shape3[3],
-                                 float shape1, uint64_t id_a, uint64_t id_b, uint32_t body_a, uint32_t body_b, const float response[3], ivx_contact* out,
+// mode 0: sphere (shape3 = centre, shape1 = radius); 1: plane (unit normal, displacement); 2: capsule (segment start, radius; shape3b = segment vector)
+static int voxel_object_contacts(ivx_grid* g, const char* who, int mode, const float rotation_xyzw[4], const float translation[3], const float shape3[3],
+                                 const float shape3b[3], float shape1, uint64_t id_a, uint64_t id_b, uint32_t body_a, uint32_t body_b, const float response[3], ivx_contact* out,
                                  size_t cap, size_t* n_out) {
-    IVX_REQUIRE(g && rotation_xyzw && translation && shape3 && response && n_out && (out || cap == 0), IVX_ERR_INVALID, "%s: null argument", who);
+    IVX_REQUIRE(g && rotation_xyzw && translation && shape3 && (shape3b || mode != 2) && response && n_out && (out || cap == 0), IVX_ERR_INVALID,
+                "%s: null argument", who);
+    const int plane = mode == 1;
     IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "%s: derived state must be current (ivx_derive_state + ivx_label_regions)", who);
     IVX_REQUIRE(g->x_off == 0 && g->gx == g->cc[0] && !g->has_ghost[0] && !g->has_ghost[1], IVX_ERR_STATE, "%s: not available on a slab of a decomposed grid",
                 who);
@@ -900,7 +903,21 @@ static int voxel_object_contacts(ivx_grid* g, const char* who, int plane, const 
     ivx_occupied_from_raw(g, occ_raw, occ);
     const float inv = 1.0f / g->extent;
     float lo_f[3], hi_f[3];
-    if (!plane) {
+    if (mode == 2) {
+        // capsule.iso_transformed(transform_to_object_space).scaled(inverse_voxel_extent).compute_aabb() (impact_geometry/src/capsule.rs:100-137;
+        // intersection.rs:73-82)
+        float ra[3], rv[3];
+        host_qrot(rotation_xyzw, shape3, ra);
+        host_qrot(rotation_xyzw, shape3b, rv);
+        const float rn = inv * shape1;
+        for (int d = 0; d < 3; ++d) {
+            const float an = (ra[d] + translation[d]) * inv, vn = rv[d] * inv;
+            const float en = an + vn;
+            const float la = an - rn, le = en - rn, ha = an + rn, he = en + rn;
+            lo_f[d] = le < la ? le : la;
+            hi_f[d] = he > ha ? he : ha;
+        }
+    } else if (!plane) {
         // sphere.iso_transformed(transform_to_object_space).scaled(inverse_voxel_extent) and its box (intersection.rs:51-60)
         float rc3[3];
         host_qrot(rotation_xyzw, shape3, rc3);
@@ -955,8 +972,8 @@ static int voxel_object_contacts(ivx_grid* g, const char* who, int plane, const 
     uint32_t* d_total = reinterpret_cast<uint32_t*>(base + off_total);
     ivx_contact* d_out = reinterpret_cast<ivx_contact*>(base + off_out);
     for (int pass = 0; pass < 2; ++pass)
-        if ((rc = ivx_launch_sphere_contacts(g, lo, cc, vlo, vhi, rotation_xyzw, translation, shape3, shape1, id_a, id_b, body_a, body_b, response, d_counts,
-                                             d_offsets, d_total, d_out, (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFu), pass, plane)))
+        if ((rc = ivx_launch_sphere_contacts(g, lo, cc, vlo, vhi, rotation_xyzw, translation, shape3, shape3b, shape1, id_a, id_b, body_a, body_b, response,
+                                             d_counts, d_offsets, d_total, d_out, (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFu), pass, mode)))
             return rc;
     uint32_t total = 0;
     if ((rc = d2h(g, &total, d_total, sizeof(total)))) return rc;
@@ -969,15 +986,22 @@ static int voxel_object_contacts(ivx_grid* g, const char* who, int plane, const 
 int ivx_sphere_voxel_object_contacts(ivx_grid* g, const float rotation_xyzw[4], const float translation[3], const float sphere_center[3], float sphere_radius,
                                      uint64_t collidable_id_a, uint64_t collidable_id_b, uint32_t body_a, uint32_t body_b, const float response[3],
                                      ivx_contact* out, size_t cap, size_t* n_out) {
-    return voxel_object_contacts(g, "ivx_sphere_voxel_object_contacts", 0, rotation_xyzw, translation, sphere_center, sphere_radius, collidable_id_a,
+    return voxel_object_contacts(g, "ivx_sphere_voxel_object_contacts", 0, rotation_xyzw, translation, sphere_center, nullptr, sphere_radius, collidable_id_a,
                                  collidable_id_b, body_a, body_b, response, out, cap, n_out);
 }
 
 int ivx_plane_voxel_object_contacts(ivx_grid* g, const float rotation_xyzw[4], const float translation[3], const float plane_unit_normal[3],
                                     float plane_displacement, uint64_t collidable_id_a, uint64_t collidable_id_b, uint32_t body_a, uint32_t body_b,
                                     const float response[3], ivx_contact* out, size_t cap, size_t* n_out) {
-    return voxel_object_contacts(g, "ivx_plane_voxel_object_contacts", 1, rotation_xyzw, translation, plane_unit_normal, plane_displacement, collidable_id_a,
-                                 collidable_id_b, body_a, body_b, response, out, cap, n_out);
+    return voxel_object_contacts(g, "ivx_plane_voxel_object_contacts", 1, rotation_xyzw, translation, plane_unit_normal, nullptr, plane_displacement,
+                                 collidable_id_a, collidable_id_b, body_a, body_b, response, out, cap, n_out);
+}
+
+int ivx_capsule_voxel_object_contacts(ivx_grid* g, const float rotation_xyzw[4], const float translation[3], const float segment_start[3],
+                                      const float segment_vector[3], float capsule_radius, uint64_t collidable_id_a, uint64_t collidable_id_b,
+                                      uint32_t body_a, uint32_t body_b, const float response[3], ivx_contact* out, size_t cap, size_t* n_out) {
+    return voxel_object_contacts(g, "ivx_capsule_voxel_object_contacts", 2, rotation_xyzw, translation, segment_start, segment_vector, capsule_radius,
+                                 collidable_id_a, collidable_id_b, body_a, body_b, response, out, cap, n_out);
 }
 
 int ivx_grid_set_sdf_program(ivx_grid* g, const ivx_sdf_processed_node* nodes, size_t n_nodes, uint32_t stack_size, const uint32_t grid_shape[3],

@@ -292,8 +292,8 @@ int ivx_launch_absorb(ivx_grid* g, int capsule, const uint32_t lo[3], const uint
                       const float seg[3], float influence_radius, float shape_radius, const float* d_dens, double* d_removed10, uint32_t* d_by_type,
                       uint32_t* d_counters, uint32_t* d_touched);
 int ivx_launch_sphere_contacts(ivx_grid* g, const uint32_t lo[3], const uint32_t cc[3], const int32_t vlo[3], const int32_t vhi[3],
-                               const float rotation_xyzw[4], const float translation[3], const float center[3], float radius, uint64_t id_a, uint64_t id_b,
-                               uint32_t body_a, uint32_t body_b, const float response[3], uint32_t* d_counts, uint32_t* d_offsets, uint32_t* d_total,
-                               ivx_contact* d_out, uint32_t cap, int emit, int plane);
+                               const float rotation_xyzw[4], const float translation[3], const float center[3], const float seg_vec[3], float radius,
+                               uint64_t id_a, uint64_t id_b, uint32_t body_a, uint32_t body_b, const float response[3], uint32_t* d_counts,
+                               uint32_t* d_offsets, uint32_t* d_total, ivx_contact* d_out, uint32_t cap, int emit, int mode);
 int ivx_launch_region_stats(ivx_grid* g, const float* d_dens, void* d_buf, uint32_t n);
 static inline size_t ivx_region_stats_bytes(uint32_t n) { return (size_t)n * (8 + 80 + 12 + 12 + 4 + 4 + 4); }

@@ -395,6 +395,18 @@ class VoxelObject:
                                                          collidable_id_a, collidable_id_b, body_a, body_b, ptr(f(response)), ptr(out), capacity, C.byref(n)))
         return out[: n.value]
 
+    def capsule_contacts(self, rotation_xyzw, translation, segment_start, segment_vector, capsule_radius: float, collidable_id_a: int,
+                         collidable_id_b: int, body_a: int, body_b: int, response=(0.0, 0.0, 0.0), capacity: int = 65536) -> np.ndarray:
+        """`for_each_capsule_voxel_object_contact` (collidable.rs:1257-1286): the capsule in world space, ids and bodies as for
+        `sphere_contacts` (collidable first)."""
+        out = np.zeros(capacity, dtype=capi.CONTACT_DTYPE)
+        n = C.c_size_t(0)
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+        check(capi.lib().ivx_capsule_voxel_object_contacts(self.h, ptr(f(rotation_xyzw)), ptr(f(translation)), ptr(f(segment_start)), ptr(f(segment_vector)),
+                                                           capsule_radius, collidable_id_a, collidable_id_b, body_a, body_b, ptr(f(response)), ptr(out),
+                                                           capacity, C.byref(n)))
+        return out[: n.value]
+
     def halo_bytes(self) -> int:
         return int(capi.lib().ivx_halo_bytes(self.h))
 

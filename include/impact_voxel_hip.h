@@ -343,6 +343,12 @@ int ivx_sphere_voxel_object_contacts(ivx_grid*, const float rotation_xyzw[4], co
 int ivx_plane_voxel_object_contacts(ivx_grid*, const float rotation_xyzw[4], const float translation[3], const float plane_unit_normal[3],
                                     float plane_displacement, uint64_t collidable_id_a, uint64_t collidable_id_b, uint32_t body_a, uint32_t body_b,
                                     const float response[3], ivx_contact* out, size_t cap, size_t* n_out);
+/* for_each_capsule_voxel_object_contact (collidable.rs:1257-1286): the same for a capsule collidable (segment start + vector + radius, world
+ * space); surface voxels inside the capsule's box are tested with determine_capsule_sphere_contact_geometry
+ * (impact_physics/src/collision/collidable/capsule.rs:212-270). Ids and bodies as for the sphere (collidable first). */
+int ivx_capsule_voxel_object_contacts(ivx_grid*, const float rotation_xyzw[4], const float translation[3], const float segment_start[3],
+                                      const float segment_vector[3], float capsule_radius, uint64_t collidable_id_a, uint64_t collidable_id_b,
+                                      uint32_t body_a, uint32_t body_b, const float response[3], ivx_contact* out, size_t cap, size_t* n_out);
 
 #define IVX_KINEMATIC_BODY 0x80000000u
 #define IVX_CONTACT_MANIFOLD_START 1u

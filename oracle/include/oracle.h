@@ -166,6 +166,10 @@ int orc_absorb_capsule(orc_object* o, const float segment_start[3], const float 
  * transform_to_object_space = rotation (xyzw) then translation. Returns the number of contacts; fills at most `cap`. */
 int orc_sphere_voxel_object_contacts(const orc_object* o, const float rotation_xyzw[4], const float translation[3], const float center[3], float radius,
                                      int cap, int32_t* indices, float* position, float* normal, float* depth);
+/* contacts between the surface voxels of the object and a capsule collidable (world space) (impact_voxel/src/collidable.rs:1257-1286) */
+int orc_capsule_voxel_object_contacts(const orc_object* o, const float rotation_xyzw[4], const float translation[3], const float segment_start[3],
+                                      const float segment_vector[3], float radius, int cap, int32_t* indices, float* position, float* normal,
+                                      float* depth);
 /* contacts between the Corner voxels of the object and a plane collidable (world space) (impact_voxel/src/collidable.rs:1176-1208) */
 int orc_plane_voxel_object_contacts(const orc_object* o, const float rotation_xyzw[4], const float translation[3], const float plane_normal[3],
                                     float plane_displacement, int cap, int32_t* indices, float* position, float* normal, float* depth);

@@ -16,6 +16,8 @@ int split_off_smallest_region(VoxelObject& parent, VoxelObject& child, int origi
 int clip_polyhedron(VoxelObject& parent, const float* planes, int n_planes, const float aabb[6], int mode, VoxelObject& child, int origin[3]);
 int sphere_voxel_object_contacts(const VoxelObject& obj, const float rot[4], const float trans[3], const float center[3], float radius, int cap,
                                  int32_t* indices, float* position, float* normal, float* depth);
+int capsule_voxel_object_contacts(const VoxelObject& obj, const float rot[4], const float trans[3], const float seg_start[3], const float seg_vec[3],
+                                  float radius, int cap, int32_t* indices, float* position, float* normal, float* depth);
 int plane_voxel_object_contacts(const VoxelObject& obj, const float rot[4], const float trans[3], const float plane_normal[3], float plane_displacement,
                                 int cap, int32_t* indices, float* position, float* normal, float* depth);
 int absorb_capsule(VoxelObject& obj, const float segment_start[3], const float segment_vector[3], float influence_radius, float capsule_radius,
@@ -382,6 +384,13 @@ int orc_absorb_capsule(orc_object* o, const float segment_start[3], const float 
 int orc_sphere_voxel_object_contacts(const orc_object* o, const float rotation_xyzw[4], const float translation[3], const float center[3], float radius,
                                      int cap, int32_t* indices, float* position, float* normal, float* depth) {
     return sphere_voxel_object_contacts(o->obj, rotation_xyzw, translation, center, radius, cap, indices, position, normal, depth);
+}
+
+// for_each_capsule_voxel_object_contact (impact_voxel/src/collidable.rs:1257-1286)
+int orc_capsule_voxel_object_contacts(const orc_object* o, const float rotation_xyzw[4], const float translation[3], const float segment_start[3],
+                                      const float segment_vector[3], float radius, int cap, int32_t* indices, float* position, float* normal,
+                                      float* depth) {
+    return capsule_voxel_object_contacts(o->obj, rotation_xyzw, translation, segment_start, segment_vector, radius, cap, indices, position, normal, depth);
 }
 
 // for_each_voxel_object_plane_contact (impact_voxel/src/collidable.rs:1176-1208)

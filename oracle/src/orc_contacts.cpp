@@ -161,4 +161,94 @@ int plane_voxel_object_contacts(const VoxelObject& obj, const float rot[4], cons
     return cnt;
 }
 
+// determine_capsule_sphere_contact_geometry (impact_physics/src/collision/collidable/capsule.rs:212-270) with
+// parameter_of_closest_point_on_line_segment_to_point (impact_geometry/src/line.rs:26-45). The branch for a sphere centre ON the
+// segment uses glam's Vec3A::any_orthogonal_vector and Vec3A / f32 (glam 0.30.10, not under /root/reference: restated from its
+// published source — |x| > |y| ? (-z, 0, x) : (0, z, -y); component-wise division) — parity unpinned for that branch.
+static bool capsule_sphere_contact(V3 seg_start, V3 seg_vec, float cap_radius, V3 sc, float sr, V3& position, V3& normal, float& depth) {
+    const float len2 = dot(seg_vec, seg_vec);
+    float param = 0.0f;
+    if (!(len2 <= 1e-8f)) {
+        const V3 sp = sc - seg_start;
+        param = dot(seg_vec, sp) / len2;
+        param = param < 0.0f ? 0.0f : (param > 1.0f ? 1.0f : param);
+    }
+    const V3 closest = seg_start + param * seg_vec;
+    const V3 disp = sc - closest;
+    const float d2 = dot(disp, disp);
+    const float max_d = sr + cap_radius;
+    if (d2 > max_d * max_d) return false;
+    const float dist = std::sqrt(d2);
+    V3 cap_normal;
+    if (dist > 1e-8f) {
+        cap_normal = div_recip(disp, dist);
+        depth = fmax_rs(0.0f, max_d - dist);
+    } else {
+        const V3 o = std::fabs(seg_vec.x) > std::fabs(seg_vec.y) ? V3{-seg_vec.z, 0.0f, seg_vec.x} : V3{0.0f, seg_vec.z, -seg_vec.y};
+        const float n2 = dot(o, o);
+        if (n2 > 1e-8f * 1e-8f) cap_normal = div_elem(o, std::sqrt(n2));
+        else cap_normal = V3{0.0f, 0.0f, 1.0f};
+        depth = fmax_rs(0.0f, max_d);
+    }
+    normal = -cap_normal;
+    position = sc + sr * normal;
+    return true;
+}
+
+// for_each_capsule_voxel_object_contact (impact_voxel/src/collidable.rs:1257-1286) over
+// for_each_surface_voxel_maybe_intersecting_capsule (object/intersection.rs:73-82); Capsule::iso_transformed / scaled / compute_aabb
+// (impact_geometry/src/capsule.rs:100-137)
+int capsule_voxel_object_contacts(const VoxelObject& obj, const float rot[4], const float trans[3], const float seg_start[3], const float seg_vec[3],
+                                  float radius, int cap, int32_t* indices, float* position, float* normal, float* depth) {
+    const Quat q{rot[0], rot[1], rot[2], rot[3]};
+    const V3 t{trans[0], trans[1], trans[2]}, a{seg_start[0], seg_start[1], seg_start[2]}, v{seg_vec[0], seg_vec[1], seg_vec[2]};
+    const V3 a_obj = qrot(q, a) + t, v_obj = qrot(q, v);
+    const float inv = 1.0f / obj.extent;
+    const V3 an = a_obj * inv, vn = v_obj * inv;
+    const float rn = inv * radius;
+    const V3 en = an + vn;  // segment_end
+    const float lo_a[3] = {an.x - rn, an.y - rn, an.z - rn}, hi_a[3] = {an.x + rn, an.y + rn, an.z + rn};
+    const float lo_e[3] = {en.x - rn, en.y - rn, en.z - rn}, hi_e[3] = {en.x + rn, en.y + rn, en.z + rn};
+    long vlo[3], vhi[3];
+    for (int d = 0; d < 3; ++d) {
+        const float lo = fmin_rs(lo_a[d], lo_e[d]), hi = fmax_rs(hi_a[d], hi_e[d]);
+        const float fl = std::floor(lo), ce = std::ceil(hi);
+        const long s = (long)(fl > 0.0f ? fl : 0.0f), e = ce > 0.0f ? (long)ce : 0;
+        vlo[d] = std::max<long>(obj.occ_voxel[d][0], s);
+        vhi[d] = std::min<long>(obj.occ_voxel[d][1], e);
+        if (vlo[d] >= vhi[d]) return 0;
+    }
+    int n = 0;
+    const Quat qi = conj(q);
+    for (long I = vlo[0] / CHUNK; I < (vhi[0] + CHUNK - 1) / CHUNK; ++I)
+        for (long J = vlo[1] / CHUNK; J < (vhi[1] + CHUNK - 1) / CHUNK; ++J)
+            for (long K = vlo[2] / CHUNK; K < (vhi[2] + CHUNK - 1) / CHUNK; ++K) {
+                const Chunk& ch = obj.chunks[obj.cidx((int)I, (int)J, (int)K)];
+                if (ch.kind != K_NONUNIFORM) continue;
+                const Voxel* cv = &obj.voxels[(size_t)ch.data_offset << 12];
+                const long base[3] = {I * CHUNK, J * CHUNK, K * CHUNK};
+                for (long i = std::max(base[0], vlo[0]); i < std::min(base[0] + CHUNK, vhi[0]); ++i)
+                    for (long j = std::max(base[1], vlo[1]); j < std::min(base[1] + CHUNK, vhi[1]); ++j)
+                        for (long k = std::max(base[2], vlo[2]); k < std::min(base[2] + CHUNK, vhi[2]); ++k) {
+                            const Voxel& vx = cv[((i - base[0]) << 8) | ((j - base[1]) << 4) | (k - base[2])];
+                            if (vx.empty()) continue;
+                            if (__builtin_popcount(vx.flags & 0xFCu) == 6) continue;  // Interior
+                            const V3 p_obj{((float)i + 0.5f) * obj.extent, ((float)j + 0.5f) * obj.extent, ((float)k + 0.5f) * obj.extent};
+                            const V3 p = qrot(qi, p_obj - t);
+                            const float vr = -sd_to_f32(vx.sd) * obj.extent;
+                            V3 pos, nrm;
+                            float dep;
+                            if (!capsule_sphere_contact(a, v, radius, p, vr, pos, nrm, dep)) continue;
+                            if (n < cap) {
+                                indices[3 * n] = (int32_t)i, indices[3 * n + 1] = (int32_t)j, indices[3 * n + 2] = (int32_t)k;
+                                position[3 * n] = pos.x, position[3 * n + 1] = pos.y, position[3 * n + 2] = pos.z;
+                                normal[3 * n] = nrm.x, normal[3 * n + 1] = nrm.y, normal[3 * n + 2] = nrm.z;
+                                depth[n] = dep;
+                            }
+                            n += 1;
+                        }
+            }
+    return n;
+}
+
 }  // namespace orc

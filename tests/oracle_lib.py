@@ -88,6 +88,8 @@ def lib():
         L.orc_clip_polyhedron.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.POINTER(vp), vp]
         L.orc_sphere_voxel_object_contacts.restype = C.c_int
         L.orc_sphere_voxel_object_contacts.argtypes = [vp, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, vp]
+        L.orc_capsule_voxel_object_contacts.restype = C.c_int
+        L.orc_capsule_voxel_object_contacts.argtypes = [vp, vp, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, vp]
         L.orc_plane_voxel_object_contacts.restype = C.c_int
         L.orc_plane_voxel_object_contacts.argtypes = [vp, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, vp]
         L.orc_absorb_capsule.restype = C.c_int
@@ -322,6 +324,18 @@ class OracleObject:
         dep = np.zeros(cap, dtype=np.float32)
         n = lib().orc_sphere_voxel_object_contacts(self.h, _p(f(rotation_xyzw)), _p(f(translation)), _p(f(center)), radius, cap, _p(idx), _p(pos), _p(nrm),
                                                    _p(dep))
+        assert n <= cap
+        return idx[:n], pos[:n], nrm[:n], dep[:n]
+
+    def capsule_contacts(self, rotation_xyzw, translation, segment_start, segment_vector, radius, cap=65536):
+        """for_each_capsule_voxel_object_contact -> (indices [n,3], position [n,3], normal [n,3], depth [n])"""
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+        idx = np.zeros((cap, 3), dtype=np.int32)
+        pos = np.zeros((cap, 3), dtype=np.float32)
+        nrm = np.zeros((cap, 3), dtype=np.float32)
+        dep = np.zeros(cap, dtype=np.float32)
+        n = lib().orc_capsule_voxel_object_contacts(self.h, _p(f(rotation_xyzw)), _p(f(translation)), _p(f(segment_start)), _p(f(segment_vector)), radius, cap,
+                                                    _p(idx), _p(pos), _p(nrm), _p(dep))
         assert n <= cap
         return idx[:n], pos[:n], nrm[:n], dep[:n]
 

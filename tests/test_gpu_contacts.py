@@ -188,3 +188,69 @@ def test_voxel_box_dropped_on_the_ground_steps_like_the_oracle(ctx):
     assert had_contact
     w.close()
     g.close()
+
+
+# ---- capsule collidables --------------------------------------------------------------------------------------------------------
+def oracle_capsule_contact_list(o, q, t, a, v, r, id_a, id_b, body_a, body_b, response):
+    idx, pos, nrm, dep = o.capsule_contacts(q, t, a, v, r)
+    out = np.zeros(len(idx), dtype=CONTACT_DTYPE)
+    for m, (ijk, p, nn, d) in enumerate(zip(idx, pos, nrm, dep)):
+        out[m]["id"] = scenes.contact_id(id_a, id_b, *[int(x) for x in ijk])
+        out[m]["body_a"], out[m]["body_b"] = body_a, body_b
+        out[m]["position"], out[m]["normal"], out[m]["depth"] = p, nn, d
+        out[m]["restitution"], out[m]["static_friction"], out[m]["dynamic_friction"] = response
+        out[m]["flags"] = 1 if m == 0 else 0
+    return out
+
+
+@pytest.mark.parametrize("extent", [1.0, 0.5])
+def test_capsule_against_rotated_voxel_body(ctx, extent):
+    """for_each_capsule_voxel_object_contact: capsules lying on, poking into, skewering and missing a rotated + translated body;
+    a zero-length capsule; a capsule whose segment passes exactly through voxel centres (the any-orthogonal-vector branch of
+    determine_capsule_sphere_contact_geometry)"""
+    o, g = both(ctx, scenes.sphere_scene(20.0), extent)
+    axis = np.array([0.3, -1.0, 0.5]) / np.linalg.norm([0.3, -1.0, 0.5])
+    q = np.array([*(axis * np.sin(0.45)), np.cos(0.45)], dtype=np.float32)
+    t = np.array([1.5, -2.25, 0.75], dtype=np.float32)
+    ctr = np.array([0.5 * (a + b) for a, b in o.info()["occupied_voxel_ranges"]], dtype=np.float64) * extent
+    R = 20.0 * extent
+    resp = (0.4, 0.7, 0.5)
+
+    def to_world(p_obj):
+        x, y, z, w = [float(a) for a in q]
+        b = np.array([-x, -y, -z])
+        v = p_obj - t.astype(np.float64)
+        return v * (w * w - b @ b) + b * (2 * (v @ b)) + np.cross(b, v) * (2 * w)
+
+    cases = [
+        (ctr + [-0.4 * R, R + 1.0, 0.1 * R], ctr + [0.5 * R, R + 1.4, -0.2 * R], 2.0, True),  # lying on top
+        (ctr + [2.0 * R, 0.3, 0.2], ctr + [0.7 * R, 0.1, -0.1], 1.0, True),  # poking in along x
+        (ctr + [-2.0 * R, -2.0 * R, 0.0], ctr + [2.0 * R, 2.0 * R, 0.5], 0.75, True),  # skewer through the middle
+        (ctr + [0.0, 3.0 * R, 0.0], ctr + [R, 3.0 * R, R], 2.0, False),  # miss
+        (ctr + [0.0, 0.0, R + 0.5], ctr + [0.0, 0.0, R + 0.5], 2.5, True),  # zero length
+    ]
+    for a_obj, b_obj, rad, hits in cases:
+        a_w = to_world(np.asarray(a_obj)).astype(np.float32)
+        v_w = (to_world(np.asarray(b_obj)) - to_world(np.asarray(a_obj))).astype(np.float32)
+        want = oracle_capsule_contact_list(o, q, t, a_w, v_w, rad, 31, 987654321, 2, 5, resp)
+        got = g.capsule_contacts(q, t, a_w, v_w, rad, 31, 987654321, 2, 5, resp)
+        assert (len(want) > 0) == hits
+        assert_contacts_equal(got, want)
+    g.close()
+
+
+def test_capsule_through_voxel_centres_takes_the_degenerate_branch(ctx):
+    """identity transform, a capsule along a row of voxel centres: those voxels' centres lie ON the segment (distance 0), the
+    normal comes from the segment's orthogonal vector"""
+    o, g = both(ctx, scenes.box_scene((20.0, 14.0, 18.0)), 1.0)
+    occ = o.info()["occupied_voxel_ranges"]
+    i0, j1, k0 = occ[0][0], occ[1][1] - 1, occ[2][0]
+    a = np.array([i0 + 2.5, j1 + 0.5, k0 + 4.5], np.float32)  # centres of the top layer
+    v = np.array([10.0, 0.0, 0.0], np.float32)
+    q, t = np.array([0, 0, 0, 1], np.float32), np.zeros(3, np.float32)
+    want = oracle_capsule_contact_list(o, q, t, a, v, 1.25, 3, 4, 1, 0, (0.0, 0.5, 0.5))
+    got = g.capsule_contacts(q, t, a, v, 1.25, 3, 4, 1, 0, (0.0, 0.5, 0.5))
+    on_segment = [c for c in want if abs(c["normal"][0]) < 1e-6 and abs(c["normal"][1]) < 1e-6 and abs(abs(c["normal"][2]) - 1.0) < 1e-6]
+    assert len(on_segment) >= 5
+    assert_contacts_equal(got, want)
+    g.close()

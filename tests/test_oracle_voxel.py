@@ -780,6 +780,75 @@ def test_sphere_contacts_match_brute_force_over_surface_voxels():
     assert key == sorted(key)
 
 
+def test_capsule_contacts_match_brute_force_over_surface_voxels():
+    """for_each_capsule_voxel_object_contact (collidable.rs:1257-1286) against a brute-force sweep in f64: surface voxels whose
+    sphere comes within the capsule radius of the segment; the normal points from the voxel sphere's centre to the closest
+    point of the segment (determine_capsule_sphere_contact_geometry, capsule.rs:212-270)"""
+    ext = np.float32(0.5)
+    o = ol.OracleObject.from_sdf(scenes.sphere_scene(12.0), float(ext), 0)
+    o.update_occupied_voxel_ranges()
+    o.compute_all_derived_state()
+    axis = np.array([-1.0, 0.5, 2.0]) / np.linalg.norm([-1.0, 0.5, 2.0])
+    ang = 1.1
+    q = np.array([*(axis * np.sin(ang / 2)), np.cos(ang / 2)], dtype=np.float32)
+    t = np.array([-2.0, 0.75, 1.5], dtype=np.float32)
+
+    def rot(qv, v):
+        x, y, z, w = [float(a) for a in qv]
+        b = np.array([x, y, z])
+        return v * (w * w - b @ b) + b * (2 * (v @ b)) + np.cross(b, v) * (2 * w)
+
+    inf = o.info()
+    ctr_obj = np.array([0.5 * (a + b) for a, b in inf["occupied_voxel_ranges"]]) * float(ext)
+    qc = np.array([-q[0], -q[1], -q[2], q[3]])
+    # a capsule lying across the top of the body (object space), handed over in world space
+    a_obj = ctr_obj + np.array([-8.0, 12.0 * float(ext) + 0.6, -2.0])
+    b_obj = ctr_obj + np.array([7.0, 12.0 * float(ext) + 0.2, 3.0])
+    a_w = rot(qc, a_obj - t.astype(np.float64)).astype(np.float32)
+    v_w = (rot(qc, b_obj - t.astype(np.float64)) - rot(qc, a_obj - t.astype(np.float64))).astype(np.float32)
+    R = 1.5
+    idx, pos, nrm, dep = o.capsule_contacts(q, t, a_w, v_w, R)
+    assert len(idx) > 20
+    sdf, typ, flg, _, info = o.export_dense()
+    cc = o.chunk_counts
+    sd = ol.tiled_to_dense(sdf, cc).astype(np.float64) * 0.02
+    fl = ol.tiled_to_dense(flg, cc)
+    ne = (fl & 1) == 0
+    surf = ne & (np.unpackbits((fl & 0xFC)[..., None], axis=-1).sum(-1) < 6)
+    a64, v64 = a_w.astype(np.float64), v_w.astype(np.float64)
+
+    def closest(pw):
+        tt = np.clip(v64 @ (pw - a64) / (v64 @ v64), 0.0, 1.0)
+        return a64 + tt * v64
+
+    want = []
+    for i, j, k in np.argwhere(surf):
+        pw = rot(qc, (np.array([i, j, k]) + 0.5) * float(ext) - t.astype(np.float64))
+        vr = -sd[i, j, k] * float(ext)
+        if np.linalg.norm(pw - closest(pw)) <= R + vr - 1e-6:
+            want.append((i, j, k))
+    got = {tuple(int(x) for x in r) for r in idx}
+    assert not [w for w in want if w not in got]
+    for r, p_, n_, d_ in zip(idx, pos, nrm, dep):
+        pw = rot(qc, (r + 0.5) * float(ext) - t.astype(np.float64))
+        vr = -sd[tuple(r)] * float(ext)
+        cp = closest(pw)
+        dist = np.linalg.norm(pw - cp)
+        assert dist <= R + vr + 1e-4
+        np.testing.assert_allclose(d_, max(0.0, R + vr - dist), atol=2e-5)
+        np.testing.assert_allclose(n_, (cp - pw) / dist, atol=3e-5)
+        np.testing.assert_allclose(p_, pw + vr * (cp - pw) / dist, atol=3e-5)
+    key = [((r[0] >> 4, r[1] >> 4, r[2] >> 4), tuple(r)) for r in idx.tolist()]
+    assert key == sorted(key)
+    # a zero-length capsule is a sphere collidable: the same voxels and geometry as for_each_sphere_voxel_object_contact
+    i2, p2, n2, d2 = o.capsule_contacts(q, t, a_w, np.zeros(3, np.float32), 2.5)
+    i3, p3, n3, d3 = o.sphere_contacts(q, t, a_w, 2.5)
+    assert len(i2) > 5
+    np.testing.assert_array_equal(i2, i3)
+    np.testing.assert_allclose(d2, d3, atol=1e-6)
+    np.testing.assert_allclose(n2, n3, atol=1e-6)
+
+
 def test_plane_contacts_match_brute_force_over_corner_voxels():
     """for_each_voxel_object_plane_contact (collidable.rs:1176-1208): Corner voxels (non-empty, at most three neighbours) whose
     sphere reaches below the plane; tilted plane, rotated object"""
