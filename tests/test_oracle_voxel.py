@@ -841,8 +841,9 @@ def test_capsule_contacts_match_brute_force_over_surface_voxels():
     key = [((r[0] >> 4, r[1] >> 4, r[2] >> 4), tuple(r)) for r in idx.tolist()]
     assert key == sorted(key)
     # a zero-length capsule is a sphere collidable: the same voxels and geometry as for_each_sphere_voxel_object_contact
-    i2, p2, n2, d2 = o.capsule_contacts(q, t, a_w, np.zeros(3, np.float32), 2.5)
-    i3, p3, n3, d3 = o.sphere_contacts(q, t, a_w, 2.5)
+    mid = (a_w + np.float32(0.5) * v_w).astype(np.float32)
+    i2, p2, n2, d2 = o.capsule_contacts(q, t, mid, np.zeros(3, np.float32), 2.5)
+    i3, p3, n3, d3 = o.sphere_contacts(q, t, mid, 2.5)
     assert len(i2) > 5
     np.testing.assert_array_equal(i2, i3)
     np.testing.assert_allclose(d2, d3, atol=1e-6)
