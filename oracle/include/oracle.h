@@ -166,6 +166,21 @@ int orc_absorb_capsule(orc_object* o, const float segment_start[3], const float 
  * transform_to_object_space = rotation (xyzw) then translation. Returns the number of contacts; fills at most `cap`. */
 int orc_sphere_voxel_object_contacts(const orc_object* o, const float rotation_xyzw[4], const float translation[3], const float center[3], float radius,
                                      int cap, int32_t* indices, float* position, float* normal, float* depth);
+/* collision probes of a meshed voxel object (VoxelObjectCollisionProbes::recompute_for_all_chunks, impact_voxel/src/collidable.rs:361-731): per
+ * chunk with a submesh, the mesh vertex of the most convex curvature in every block of 8^3 / 4^3 / 2^3 / 1 voxels. submeshes: 16 u32 each as in
+ * orc_mesh_get. chunk_entries: 5 u32 per chunk that got probes (ci, cj, ck, first point, end point), room for n_submeshes entries. Returns
+ * the number of points; fills at most `cap`. */
+int orc_collision_probes(const orc_object* o, const float* positions, const float* normals, const uint32_t* indices, const uint32_t* submeshes,
+                         uint32_t n_submeshes, float* points, uint32_t cap, uint32_t* chunk_entries, uint32_t* n_entries);
+/* contacts between two voxel objects (for_each_mutual_voxel_object_contact, impact_voxel/src/collidable.rs:859-1049): the probes of A sampled
+ * against the SDF of B, then the probes of B against A. com_* = centre of mass of the object in its own space (derive_center_of_mass),
+ * rotation/translation = transform_to_object_space (world -> object). which_ijk: 4 i32 per contact — 0 (A's probe) / 1 (B's probe), then the
+ * probing object's voxel indices (hashed into the ContactID as [0, i, j, k]). Chunks are walked in submesh order (the reference's hash-map
+ * order is unpinned, see orc_collide.cpp). Returns the number of contacts; fills at most `cap`. */
+int orc_mutual_voxel_object_contacts(const orc_object* a, const float* probes_a, const uint32_t* entries_a, uint32_t n_entries_a, const float com_a[3],
+                                     const float rotation_a[4], const float translation_a[3], const orc_object* b, const float* probes_b,
+                                     const uint32_t* entries_b, uint32_t n_entries_b, const float com_b[3], const float rotation_b[4],
+                                     const float translation_b[3], int cap, int32_t* which_ijk, float* position, float* normal, float* depth);
 /* contacts between the surface voxels of the object and a capsule collidable (world space) (impact_voxel/src/collidable.rs:1257-1286) */
 int orc_capsule_voxel_object_contacts(const orc_object* o, const float rotation_xyzw[4], const float translation[3], const float segment_start[3],
                                       const float segment_vector[3], float radius, int cap, int32_t* indices, float* position, float* normal,

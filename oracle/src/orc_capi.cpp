@@ -18,6 +18,12 @@ int sphere_voxel_object_contacts(const VoxelObject& obj, const float rot[4], con
                                  int32_t* indices, float* position, float* normal, float* depth);
 int capsule_voxel_object_contacts(const VoxelObject& obj, const float rot[4], const float trans[3], const float seg_start[3], const float seg_vec[3],
                                   float radius, int cap, int32_t* indices, float* position, float* normal, float* depth);
+int collision_probes(const VoxelObject& obj, const float* pos, const float* nrm, const uint32_t* idx, const uint32_t* submeshes, uint32_t n_sub,
+                     float* points, uint32_t cap, uint32_t* entries, uint32_t* n_entries);
+int mutual_contacts(const VoxelObject& A, const float* probes_a, const uint32_t* entries_a, uint32_t n_entries_a, const float com_a[3], const float rot_a[4],
+                    const float trans_a[3], const VoxelObject& B, const float* probes_b, const uint32_t* entries_b, uint32_t n_entries_b,
+                    const float com_b[3], const float rot_b[4], const float trans_b[3], int cap, int32_t* which_ijk, float* position, float* normal,
+                    float* depth);
 int plane_voxel_object_contacts(const VoxelObject& obj, const float rot[4], const float trans[3], const float plane_normal[3], float plane_displacement,
                                 int cap, int32_t* indices, float* position, float* normal, float* depth);
 int absorb_capsule(VoxelObject& obj, const float segment_start[3], const float segment_vector[3], float influence_radius, float capsule_radius,
@@ -384,6 +390,21 @@ int orc_absorb_capsule(orc_object* o, const float segment_start[3], const float 
 int orc_sphere_voxel_object_contacts(const orc_object* o, const float rotation_xyzw[4], const float translation[3], const float center[3], float radius,
                                      int cap, int32_t* indices, float* position, float* normal, float* depth) {
     return sphere_voxel_object_contacts(o->obj, rotation_xyzw, translation, center, radius, cap, indices, position, normal, depth);
+}
+
+// VoxelObjectCollisionProbes::recompute_for_all_chunks (impact_voxel/src/collidable.rs:361-392, 473-523, 614-731)
+int orc_collision_probes(const orc_object* o, const float* positions, const float* normals, const uint32_t* indices, const uint32_t* submeshes,
+                         uint32_t n_submeshes, float* points, uint32_t cap, uint32_t* chunk_entries, uint32_t* n_entries) {
+    return collision_probes(o->obj, positions, normals, indices, submeshes, n_submeshes, points, cap, chunk_entries, n_entries);
+}
+
+// for_each_mutual_voxel_object_contact (impact_voxel/src/collidable.rs:859-1049)
+int orc_mutual_voxel_object_contacts(const orc_object* a, const float* probes_a, const uint32_t* entries_a, uint32_t n_entries_a, const float com_a[3],
+                                     const float rotation_a[4], const float translation_a[3], const orc_object* b, const float* probes_b,
+                                     const uint32_t* entries_b, uint32_t n_entries_b, const float com_b[3], const float rotation_b[4],
+                                     const float translation_b[3], int cap, int32_t* which_ijk, float* position, float* normal, float* depth) {
+    return mutual_contacts(a->obj, probes_a, entries_a, n_entries_a, com_a, rotation_a, translation_a, b->obj, probes_b, entries_b, n_entries_b, com_b, rotation_b,
+                           translation_b, cap, which_ijk, position, normal, depth);
 }
 
 // for_each_capsule_voxel_object_contact (impact_voxel/src/collidable.rs:1257-1286)

@@ -88,6 +88,10 @@ def lib():
         L.orc_clip_polyhedron.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.POINTER(vp), vp]
         L.orc_sphere_voxel_object_contacts.restype = C.c_int
         L.orc_sphere_voxel_object_contacts.argtypes = [vp, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, vp]
+        L.orc_collision_probes.restype = C.c_int
+        L.orc_collision_probes.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]
+        L.orc_mutual_voxel_object_contacts.restype = C.c_int
+        L.orc_mutual_voxel_object_contacts.argtypes = [vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp, vp, C.c_int, vp, vp, vp, vp]
         L.orc_capsule_voxel_object_contacts.restype = C.c_int
         L.orc_capsule_voxel_object_contacts.argtypes = [vp, vp, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, vp]
         L.orc_plane_voxel_object_contacts.restype = C.c_int
@@ -326,6 +330,43 @@ class OracleObject:
                                                    _p(dep))
         assert n <= cap
         return idx[:n], pos[:n], nrm[:n], dep[:n]
+
+    def collision_probes(self, mesh):
+        """VoxelObjectCollisionProbes::recompute_for_all_chunks on an OracleMesh -> (points [n,3] f32, entries [m,5] u32: chunk i,j,k,
+        first point, end point)"""
+        ns = len(mesh.submeshes)
+        cap = max(1, ns * 4096)
+        while True:
+            pts = np.zeros((cap, 3), dtype=np.float32)
+            ent = np.zeros((max(1, ns), 5), dtype=np.uint32)
+            ne = C.c_uint32(0)
+            n = lib().orc_collision_probes(self.h, _p(np.ascontiguousarray(mesh.positions)), _p(np.ascontiguousarray(mesh.normals)),
+                                           _p(np.ascontiguousarray(mesh.indices)), _p(np.ascontiguousarray(mesh.submeshes)), ns, _p(pts), cap, _p(ent),
+                                           C.byref(ne))
+            if n <= cap:
+                return pts[:n].copy(), ent[: ne.value].copy()
+            cap = n
+
+    def center_of_mass(self, densities=None):
+        """derive_center_of_mass (object/inertia.rs:167-169): first moments / mass, Vector3 / f32 = multiply by the reciprocal"""
+        m32 = self.inertia(densities)[0]
+        return (m32[1:4] * (np.float32(1.0) / m32[0])).astype(np.float32)
+
+    def mutual_contacts(self, probes, com, rotation_xyzw, translation, other, other_probes, other_com, other_rotation_xyzw, other_translation, cap=65536):
+        """for_each_mutual_voxel_object_contact(self = A, other = B) -> (which_ijk [n,4] i32, position, normal [n,3], depth [n])"""
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+        pa, ea = probes
+        pb, eb = other_probes
+        wi = np.zeros((cap, 4), dtype=np.int32)
+        pos = np.zeros((cap, 3), dtype=np.float32)
+        nrm = np.zeros((cap, 3), dtype=np.float32)
+        dep = np.zeros(cap, dtype=np.float32)
+        n = lib().orc_mutual_voxel_object_contacts(self.h, _p(f(pa)), _p(np.ascontiguousarray(ea, dtype=np.uint32)), len(ea), _p(f(com)), _p(f(rotation_xyzw)),
+                                                   _p(f(translation)), other.h, _p(f(pb)), _p(np.ascontiguousarray(eb, dtype=np.uint32)), len(eb),
+                                                   _p(f(other_com)), _p(f(other_rotation_xyzw)), _p(f(other_translation)), cap, _p(wi), _p(pos), _p(nrm),
+                                                   _p(dep))
+        assert n <= cap
+        return wi[:n], pos[:n], nrm[:n], dep[:n]
 
     def capsule_contacts(self, rotation_xyzw, translation, segment_start, segment_vector, radius, cap=65536):
         """for_each_capsule_voxel_object_contact -> (indices [n,3], position [n,3], normal [n,3], depth [n])"""
