@@ -3,6 +3,8 @@
 // launches the HIP kernels in this directory on the context's stream.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
+#include <limits>
 #include <new>
 #include <vector>
 
@@ -256,7 +258,8 @@ void ivx_grid_destroy(ivx_grid* g) {
     void* ptrs[] = {g->sdf, g->type, g->flags, g->llabel, g->info, g->ghost_sdf[0], g->ghost_sdf[1], g->ghost_type[0], g->ghost_type[1],
                     g->ghost_info[0], g->ghost_info[1], g->chunk_counts, g->chunk_offsets, g->positions, g->normals, g->indices,
                     g->index_materials, g->vertex_materials, g->submeshes, g->partials, g->rparent, g->rcompid, g->rscalar, g->ccl_scratch, g->group_sums, g->sn_list, g->dens_dev, g->dev_scratch, g->prog_nodes, g->chunk_bbox, g->samp_len, g->samp_ops, g->pairs_dev,
-                    g->work_counts, g->active_list, g->chunk_class, g->chunk_moments, g->chunk_touch, g->chunk_signs, g->samp_super};
+                    g->work_counts, g->active_list, g->chunk_class, g->chunk_moments, g->chunk_touch, g->chunk_signs, g->samp_super, g->probe_points,
+                    g->probe_chunk, g->probe_entries};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->host_scratch) (void)hipHostFree(g->host_scratch);
@@ -404,6 +407,7 @@ int ivx_remesh(ivx_grid* g, ivx_mesh_counts* out) {
     g->mesh_counts.n_submeshes = totals[2];
     g->mesh_counts.reserved = 0;
     g->mesh_valid = 1;
+    g->mesh_serial += 1;
     *out = g->mesh_counts;
     IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
     return IVX_OK;
@@ -1004,6 +1008,337 @@ int ivx_capsule_voxel_object_contacts(ivx_grid* g, const float rotation_xyzw[4],
                                  collidable_id_a, collidable_id_b, body_a, body_b, response, out, cap, n_out);
 }
 
+// ---- collision probes + mutual contacts (second part) ---------------------------------------------------------
+int ivx_collision_probes_recompute(ivx_grid* g, size_t* n_points) {
+    IVX_REQUIRE(g && n_points, IVX_ERR_INVALID, "ivx_collision_probes_recompute: null argument");
+    IVX_REQUIRE(g->mesh_valid, IVX_ERR_STATE, "ivx_collision_probes_recompute: call ivx_remesh first");
+    IVX_REQUIRE(g->x_off == 0 && g->gx == g->cc[0] && !g->has_ghost[0] && !g->has_ghost[1], IVX_ERR_STATE,
+                "ivx_collision_probes_recompute: not available on a slab of a decomposed grid");
+    IVX_REQUIRE(g->cc[0] <= 1024 && g->cc[1] <= 1024 && g->cc[2] <= 1024, IVX_ERR_INVALID, "ivx_collision_probes_recompute: more than 1024 chunks along an axis");
+    *n_points = 0;
+    int rc;
+    uint32_t* d_occ = g->rscalar + 16;
+    if ((rc = ivx_launch_occupied(g, d_occ))) return rc;
+    uint32_t occ_raw[12], occ[12];
+    if ((rc = d2h(g, occ_raw, d_occ, sizeof(occ_raw)))) return rc;
+    ivx_occupied_from_raw(g, occ_raw, occ);
+    // determine_log2_block_size_for_object (collidable.rs:451-471)
+    uint32_t min_extent = 0xFFFFFFFFu;
+    for (int d = 0; d < 3; ++d) min_extent = std::min(min_extent, occ[7 + 2 * d] > occ[6 + 2 * d] ? occ[7 + 2 * d] - occ[6 + 2 * d] : 0u);
+    const uint32_t log2_bs = min_extent >= 16 ? 3 : (min_extent >= 8 ? 2 : (min_extent >= 4 ? 1 : 0));
+    const uint32_t n_blocks = 1u << (3u * (4u - log2_bs));
+    const uint32_t n_sub = g->mesh_counts.n_submeshes;
+    g->n_probe_points = 0;
+    g->n_probe_sub = n_sub;
+    g->probes_serial = g->mesh_serial;
+    if (n_sub == 0) return IVX_OK;
+    if (n_sub > g->probe_entry_cap) {
+        if (g->probe_entries) (void)hipFree(g->probe_entries);
+        g->probe_entries = nullptr;
+        g->probe_entry_cap = 0;
+        if ((rc = dev_alloc(&g->probe_entries, (size_t)n_sub * 5))) return rc;
+        g->probe_entry_cap = n_sub;
+    }
+    // scratch: [corner lists: one u32 per index][selected vertices: n_sub * n_blocks][counts n_sub][offsets n_sub + 1][error word]
+    const size_t ni = g->mesh_counts.n_indices;
+    const size_t off_sel = ni * 4, off_counts = off_sel + (size_t)n_sub * n_blocks * 4, off_offsets = off_counts + (size_t)n_sub * 4,
+                 off_err = off_offsets + ((size_t)n_sub + 1) * 4, total = off_err + 4;
+    if ((rc = ensure_dev_scratch(g, total))) return rc;
+    char* base = static_cast<char*>(g->dev_scratch);
+    uint32_t* d_counts = reinterpret_cast<uint32_t*>(base + off_counts);
+    uint32_t* d_offsets = reinterpret_cast<uint32_t*>(base + off_offsets);
+    uint32_t* d_err = reinterpret_cast<uint32_t*>(base + off_err);
+    IVX_HIP_CHECK(hipMemsetAsync(d_err, 0, 4, g->ctx->stream));
+    if ((rc = ivx_launch_probe_select(g, n_sub, log2_bs, reinterpret_cast<uint32_t*>(base), reinterpret_cast<uint32_t*>(base + off_sel), d_counts, d_offsets,
+                                      d_err)))
+        return rc;
+    uint32_t tail[2];  // offsets[n_sub] = total, error word
+    if ((rc = d2h(g, tail, d_offsets + n_sub, sizeof(tail)))) return rc;
+    IVX_REQUIRE(tail[1] == 0, IVX_ERR_CAPACITY, "ivx_collision_probes_recompute: a chunk submesh holds more vertices than a Surface Nets chunk can");
+    const uint32_t n_pts = tail[0];
+    if (n_pts > g->probe_point_cap) {
+        const size_t cap = std::max<size_t>(n_pts, g->probe_point_cap * 2);
+        if (g->probe_points) (void)hipFree(g->probe_points);
+        if (g->probe_chunk) (void)hipFree(g->probe_chunk);
+        g->probe_points = nullptr;
+        g->probe_chunk = nullptr;
+        g->probe_point_cap = 0;
+        if ((rc = dev_alloc(&g->probe_points, cap * 3))) return rc;
+        if ((rc = dev_alloc(&g->probe_chunk, cap))) return rc;
+        g->probe_point_cap = cap;
+    }
+    if ((rc = ivx_launch_probe_gather(g, n_sub, log2_bs, reinterpret_cast<uint32_t*>(base + off_sel), d_counts, d_offsets))) return rc;
+    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    g->n_probe_points = n_pts;
+    *n_points = n_pts;
+    return IVX_OK;
+}
+
+int ivx_collision_probes_download(ivx_grid* g, float* points, size_t cap_points, uint32_t* chunk_entries, size_t cap_entries, size_t* n_points,
+                                  size_t* n_entries) {
+    IVX_REQUIRE(g && n_points && n_entries, IVX_ERR_INVALID, "ivx_collision_probes_download: null argument");
+    IVX_REQUIRE(g->mesh_valid && g->probes_serial == g->mesh_serial, IVX_ERR_STATE, "ivx_collision_probes_download: call ivx_collision_probes_recompute first");
+    *n_points = g->n_probe_points;
+    *n_entries = 0;
+    int rc;
+    std::vector<uint32_t> e((size_t)g->n_probe_sub * 5);
+    if (g->n_probe_sub && (rc = d2h(g, e.data(), g->probe_entries, e.size() * 4))) return rc;
+    size_t ne = 0;  // the reference keeps no entry for a chunk without probes
+    for (uint32_t s = 0; s < g->n_probe_sub; ++s)
+        if (e[5 * (size_t)s + 4] > e[5 * (size_t)s + 3]) {
+            if (chunk_entries && ne < cap_entries) memcpy(chunk_entries + 5 * ne, &e[5 * (size_t)s], 20);
+            ne += 1;
+        }
+    *n_entries = ne;
+    IVX_REQUIRE(!points || g->n_probe_points <= cap_points, IVX_ERR_CAPACITY, "ivx_collision_probes_download: %u points exceed the capacity %zu",
+                g->n_probe_points, cap_points);
+    IVX_REQUIRE(!chunk_entries || ne <= cap_entries, IVX_ERR_CAPACITY, "ivx_collision_probes_download: %zu entries exceed the capacity %zu", ne, cap_entries);
+    if (points && g->n_probe_points && (rc = d2h(g, points, g->probe_points, (size_t)g->n_probe_points * 12))) return rc;
+    return IVX_OK;
+}
+
+namespace {
+struct HBox {
+    float lo[3], hi[3];
+};
+// AxisAlignedBox::find_contained_subsegment (impact_geometry/src/axis_aligned_box.rs:385-415)
+bool host_subsegment(const HBox& b, const float s[3], const float v[3], float* t0, float* t1) {
+    float a = 0.0f, z = 1.0f;
+    for (int d = 0; d < 3; ++d) {
+        if (std::fabs(v[d]) > 1e-8f) {
+            const float r = 1.0f / v[d];
+            const float u1 = (b.lo[d] - s[d]) * r, u2 = (b.hi[d] - s[d]) * r;
+            const float en = u1 < u2 ? u1 : u2, ex = u1 < u2 ? u2 : u1;
+            a = en > a ? en : a;
+            z = ex < z ? ex : z;
+        } else if (s[d] < b.lo[d] || s[d] > b.hi[d]) {
+            return false;
+        }
+    }
+    *t0 = a;
+    *t1 = z;
+    return a <= z;
+}
+void host_qmul(const float a[4], const float b[4], float o[4]) {  // glam Quat::mul_quat (xyzw)
+    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    o[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+    o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+// compute_box_intersection_bounds (impact_geometry/src/oriented_box.rs:315-431): box A axis-aligned, box B = (centre, orientation, half
+// extents) in A's frame; bounds of the overlap in A's frame and in B's own frame (relative to its centre)
+bool host_box_bounds(const HBox& a, const float bc[3], const float bq[4], const float bh[3], HBox* in_a, HBox* in_b) {
+    static const int E[12][2] = {{0, 1}, {2, 3}, {4, 5}, {6, 7}, {0, 2}, {1, 3}, {4, 6}, {5, 7}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+    const float inf = std::numeric_limits<float>::infinity();
+    for (int d = 0; d < 3; ++d) in_a->lo[d] = in_b->lo[d] = inf, in_a->hi[d] = in_b->hi[d] = -inf;
+    bool any = false;
+    auto grow = [&](const float pa[3], const float pb[3]) {
+        for (int d = 0; d < 3; ++d) {
+            in_a->lo[d] = pa[d] < in_a->lo[d] ? pa[d] : in_a->lo[d];
+            in_a->hi[d] = pa[d] > in_a->hi[d] ? pa[d] : in_a->hi[d];
+            in_b->lo[d] = pb[d] < in_b->lo[d] ? pb[d] : in_b->lo[d];
+            in_b->hi[d] = pb[d] > in_b->hi[d] ? pb[d] : in_b->hi[d];
+        }
+        any = true;
+    };
+    const float bqi[4] = {-bq[0], -bq[1], -bq[2], bq[3]};
+    auto to_b = [&](const float p[3], float o[3]) {  // OrientedBox::transform_point_to_box_frame
+        const float r[3] = {p[0] - bc[0], p[1] - bc[1], p[2] - bc[2]};
+        host_qrot(bqi, r, o);
+    };
+    auto from_b = [&](const float p[3], float o[3]) {
+        host_qrot(bq, p, o);
+        for (int d = 0; d < 3; ++d) o[d] = bc[d] + o[d];
+    };
+    // corners of B: centre -/+ half width -/+ half height -/+ half depth along the columns of Mat3A::from_quat
+    float ax[3][3];
+    {
+        const float x = bq[0], y = bq[1], z = bq[2], w = bq[3];
+        const float x2 = x + x, y2 = y + y, z2 = z + z, xx = x * x2, xy = x * y2, xz = x * z2, yy = y * y2, yz = y * z2, zz = z * z2, wx = w * x2, wy = w * y2,
+                    wz = w * z2;
+        ax[0][0] = 1.0f - (yy + zz), ax[0][1] = xy + wz, ax[0][2] = xz - wy;
+        ax[1][0] = xy - wz, ax[1][1] = 1.0f - (xx + zz), ax[1][2] = yz + wx;
+        ax[2][0] = xz + wy, ax[2][1] = yz - wx, ax[2][2] = 1.0f - (xx + yy);
+    }
+    float corner[8][3];
+    for (int c = 0; c < 8; ++c)
+        for (int d = 0; d < 3; ++d) {
+            const float hw = bh[0] * ax[0][d], hh = bh[1] * ax[1][d], hd = bh[2] * ax[2][d];
+            float v = (c & 4) ? bc[d] + hw : bc[d] - hw;
+            v = (c & 2) ? v + hh : v - hh;
+            corner[c][d] = (c & 1) ? v + hd : v - hd;
+        }
+    for (const auto& e : E) {
+        const float* s = corner[e[0]];
+        const float v[3] = {corner[e[1]][0] - s[0], corner[e[1]][1] - s[1], corner[e[1]][2] - s[2]};
+        float t0, t1;
+        if (!host_subsegment(a, s, v, &t0, &t1)) continue;
+        const float p0[3] = {s[0] + v[0] * t0, s[1] + v[1] * t0, s[2] + v[2] * t0}, p1[3] = {s[0] + v[0] * t1, s[1] + v[1] * t1, s[2] + v[2] * t1};
+        float q0[3], q1[3];
+        to_b(p0, q0);
+        to_b(p1, q1);
+        grow(p0, q0);
+        grow(p1, q1);
+    }
+    float acorner[8][3];
+    for (int c = 0; c < 8; ++c) {
+        const float p[3] = {(c & 4) ? a.hi[0] : a.lo[0], (c & 2) ? a.hi[1] : a.lo[1], (c & 1) ? a.hi[2] : a.lo[2]};
+        to_b(p, acorner[c]);
+    }
+    HBox self;
+    for (int d = 0; d < 3; ++d) self.lo[d] = -bh[d], self.hi[d] = bh[d];
+    for (const auto& e : E) {
+        const float* s = acorner[e[0]];
+        const float v[3] = {acorner[e[1]][0] - s[0], acorner[e[1]][1] - s[1], acorner[e[1]][2] - s[2]};
+        float t0, t1;
+        if (!host_subsegment(self, s, v, &t0, &t1)) continue;
+        const float q0[3] = {s[0] + v[0] * t0, s[1] + v[1] * t0, s[2] + v[2] * t0}, q1[3] = {s[0] + v[0] * t1, s[1] + v[1] * t1, s[2] + v[2] * t1};
+        float p0[3], p1[3];
+        from_b(q0, p0);
+        from_b(q1, p1);
+        grow(p0, q0);
+        grow(p1, q1);
+    }
+    return any;
+}
+// voxel_ranges_touching_aab on the occupied ranges, without the emptiness check the callers of `touched_ranges` want
+void host_ranges(const uint32_t occ[12], const float lo_f[3], const float hi_f[3], long lo[3], long hi[3]) {
+    for (int d = 0; d < 3; ++d) {
+        const float fl = std::floor(lo_f[d]), ce = std::ceil(hi_f[d]);
+        const long s = fl > 0.0f ? (fl < 2.0e9f ? (long)fl : 2000000000L) : 0, e = ce > 0.0f ? (ce < 2.0e9f ? (long)ce : 2000000000L) : 0;
+        lo[d] = std::max<long>((long)occ[6 + 2 * d], s);
+        hi[d] = std::min<long>((long)occ[7 + 2 * d], e);
+    }
+}
+}  // namespace
+
+int ivx_mutual_voxel_object_contacts(ivx_grid* a, const float rotation_a[4], const float translation_a[3], const float center_of_mass_a[3], ivx_grid* b,
+                                     const float rotation_b[4], const float translation_b[3], const float center_of_mass_b[3], uint64_t collidable_id_a,
+                                     uint64_t collidable_id_b, uint32_t body_a, uint32_t body_b, const float response[3], ivx_contact* out, size_t cap,
+                                     size_t* n_out) {
+    const char* who = "ivx_mutual_voxel_object_contacts";
+    IVX_REQUIRE(a && b && rotation_a && translation_a && center_of_mass_a && rotation_b && translation_b && center_of_mass_b && response && n_out &&
+                    (out || cap == 0),
+                IVX_ERR_INVALID, "%s: null argument", who);
+    IVX_REQUIRE(a != b && a->ctx == b->ctx, IVX_ERR_INVALID, "%s: two different objects of one context are needed", who);
+    for (ivx_grid* g : {a, b}) {
+        IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "%s: derived state must be current (ivx_derive_state + ivx_label_regions)", who);
+        IVX_REQUIRE(g->mesh_valid && g->probes_serial == g->mesh_serial, IVX_ERR_STATE, "%s: collision probes must be current (ivx_collision_probes_recompute)",
+                    who);
+        IVX_REQUIRE(g->x_off == 0 && g->gx == g->cc[0] && !g->has_ghost[0] && !g->has_ghost[1], IVX_ERR_STATE,
+                    "%s: not available on a slab of a decomposed grid", who);
+    }
+    *n_out = 0;
+    int rc;
+    uint32_t occ_a[12], occ_b[12];
+    for (int w = 0; w < 2; ++w) {
+        ivx_grid* g = w ? b : a;
+        uint32_t* d_occ = g->rscalar + 16;
+        if ((rc = ivx_launch_occupied(g, d_occ))) return rc;
+        uint32_t raw[12];
+        if ((rc = d2h(g, raw, d_occ, sizeof(raw)))) return rc;
+        ivx_occupied_from_raw(g, raw, w ? occ_b : occ_a);
+    }
+    // determine_voxel_ranges_encompassing_intersection (object/intersection.rs:706-746)
+    // transform_from_b_to_a = world_to_a * world_to_b.inverted() (impact_math/src/transform/isometry.rs:128-134, 200-205)
+    const float qbi[4] = {-rotation_b[0], -rotation_b[1], -rotation_b[2], rotation_b[3]};
+    float tbi[3], q_ba[4], t_ba[3];
+    host_qrot(qbi, translation_b, tbi);
+    for (int d = 0; d < 3; ++d) tbi[d] = -tbi[d];
+    host_qmul(rotation_a, qbi, q_ba);
+    host_qrot(rotation_a, tbi, t_ba);
+    for (int d = 0; d < 3; ++d) t_ba[d] += translation_a[d];
+    HBox box_a, box_b;
+    for (int d = 0; d < 3; ++d) {
+        box_a.lo[d] = a->extent * (float)occ_a[6 + 2 * d];
+        box_a.hi[d] = a->extent * (float)occ_a[7 + 2 * d];
+        box_b.lo[d] = b->extent * (float)occ_b[6 + 2 * d];
+        box_b.hi[d] = b->extent * (float)occ_b[7 + 2 * d];
+    }
+    float b_center[3], b_half[3], bc_in_a[3], bq_in_a[4];
+    for (int d = 0; d < 3; ++d) {
+        b_center[d] = 0.5f * (box_b.lo[d] + box_b.hi[d]);
+        b_half[d] = 0.5f * (box_b.hi[d] - box_b.lo[d]);
+    }
+    host_qrot(q_ba, b_center, bc_in_a);
+    for (int d = 0; d < 3; ++d) bc_in_a[d] += t_ba[d];
+    const float ident[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+    host_qmul(q_ba, ident, bq_in_a);
+    HBox in_a, in_b;
+    if (!host_box_bounds(box_a, bc_in_a, bq_in_a, b_half, &in_a, &in_b)) return IVX_OK;
+    const float inv_a = 1.0f / a->extent, inv_b = 1.0f / b->extent;
+    float na_lo[3], na_hi[3], nb_lo[3], nb_hi[3];
+    for (int d = 0; d < 3; ++d) {
+        na_lo[d] = inv_a * in_a.lo[d];
+        na_hi[d] = inv_a * in_a.hi[d];
+        nb_lo[d] = inv_b * (in_b.lo[d] + b_center[d]);
+        nb_hi[d] = inv_b * (in_b.hi[d] + b_center[d]);
+    }
+    long ra_lo[3], ra_hi[3], rb_lo[3], rb_hi[3];
+    host_ranges(occ_a, na_lo, na_hi, ra_lo, ra_hi);
+    host_ranges(occ_b, nb_lo, nb_hi, rb_lo, rb_hi);
+    ivx_mutual_pass pass[2];
+    {  // ContactID::from_two_u64_and_n_indices: the part that does not depend on the probe
+        auto mix = [](uint64_t state) {
+            state += 0x9E3779B97F4A7C15ull;
+            uint64_t z = state;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            return z ^ (z >> 31);
+        };
+        pass[0].id_ab = pass[1].id_ab = mix(collidable_id_a ^ mix(collidable_id_b));
+    }
+    for (int w = 0; w < 2; ++w) {
+        ivx_mutual_pass& p = pass[w];
+        ivx_grid* prober = w ? b : a;
+        ivx_grid* sampled = w ? a : b;
+        const long* rlo = w ? rb_lo : ra_lo;
+        const long* rhi = w ? rb_hi : ra_hi;
+        const float* com_s = w ? center_of_mass_a : center_of_mass_b;
+        const float inv_s = 1.0f / sampled->extent;
+        for (int d = 0; d < 3; ++d) {
+            p.center_s[d] = com_s[d] * inv_s;
+            p.q_s[d] = (w ? rotation_a : rotation_b)[d];
+            p.q_p[d] = (w ? rotation_b : rotation_a)[d];
+            p.t_s[d] = (w ? translation_a : translation_b)[d];
+            p.t_p[d] = (w ? translation_b : translation_a)[d];
+            // aabb_from_voxel_ranges(prober's extent, ranges).expanded_about_center(object_a.voxel_extent()) — A's extent in both passes
+            p.box_lo[d] = prober->extent * (float)rlo[d] - a->extent;
+            p.box_hi[d] = prober->extent * (float)rhi[d] + a->extent;
+            // chunk_range_encompassing_voxel_range (object.rs:3236-3240)
+            p.clo[d] = (uint32_t)(rlo[d] / 16);
+            p.chi[d] = (uint32_t)((rhi[d] + 15) / 16);
+            p.response[d] = response[d];
+        }
+        p.q_s[3] = (w ? rotation_a : rotation_b)[3];
+        p.q_p[3] = (w ? rotation_b : rotation_a)[3];
+        p.negate = w;
+        p.body_a = body_a;
+        p.body_b = body_b;
+    }
+    const uint32_t wg_a = (a->n_probe_points + 255u) / 256u, wg_b = (b->n_probe_points + 255u) / 256u, n_wg = wg_a + wg_b;
+    if (n_wg == 0) return IVX_OK;
+    // scratch (object A's): [counts n_wg][offsets n_wg + 1][contacts]
+    const size_t off_offsets = (size_t)n_wg * 4, off_out = (off_offsets + ((size_t)n_wg + 1) * 4 + 63) & ~(size_t)63;
+    if ((rc = ensure_dev_scratch(a, off_out + cap * sizeof(ivx_contact)))) return rc;
+    char* base = static_cast<char*>(a->dev_scratch);
+    uint32_t* d_counts = reinterpret_cast<uint32_t*>(base);
+    uint32_t* d_offsets = reinterpret_cast<uint32_t*>(base + off_offsets);
+    ivx_contact* d_out = reinterpret_cast<ivx_contact*>(base + off_out);
+    const uint32_t cap32 = (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFu);
+    if ((rc = ivx_launch_mutual_pass(a, b, &pass[0], d_counts, nullptr, nullptr, cap32, 0))) return rc;
+    if ((rc = ivx_launch_mutual_pass(b, a, &pass[1], d_counts + wg_a, nullptr, nullptr, cap32, 0))) return rc;
+    if ((rc = ivx_launch_scan_counts(a->ctx, n_wg, d_counts, d_offsets))) return rc;
+    if ((rc = ivx_launch_mutual_pass(a, b, &pass[0], nullptr, d_offsets, d_out, cap32, 1))) return rc;
+    if ((rc = ivx_launch_mutual_pass(b, a, &pass[1], nullptr, d_offsets + wg_a, d_out, cap32, 1))) return rc;
+    uint32_t total = 0;
+    if ((rc = d2h(a, &total, d_offsets + n_wg, sizeof(total)))) return rc;
+    *n_out = total;
+    IVX_REQUIRE(total <= cap, IVX_ERR_CAPACITY, "%s: %u contacts exceed the capacity %zu", who, total, cap);
+    if (total && (rc = d2h(a, out, d_out, (size_t)total * sizeof(ivx_contact)))) return rc;
+    return IVX_OK;
+}
+
 int ivx_grid_set_sdf_program(ivx_grid* g, const ivx_sdf_processed_node* nodes, size_t n_nodes, uint32_t stack_size, const uint32_t grid_shape[3],
                              const float shifted_grid_center[3], uint8_t voxel_type) {
     IVX_REQUIRE(g && grid_shape && shifted_grid_center && (n_nodes == 0 || nodes), IVX_ERR_INVALID, "ivx_grid_set_sdf_program: null argument");
@@ -1188,6 +1523,7 @@ int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out) {
         g->mesh_counts.n_submeshes = totals[2];
         g->mesh_counts.reserved = 0;
         g->mesh_valid = 1;
+        g->mesh_serial += 1;
     }
     if (stages & IVX_STAGE_INERTIA) {
         memcpy(out->moments.m64, sc + 32, 10 * sizeof(double));

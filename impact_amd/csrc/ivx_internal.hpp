@@ -125,6 +125,27 @@ struct ivx_grid {
     // host pinned scratch
     void* host_scratch;
     size_t host_scratch_bytes;
+    // collision probes (ivx_collision_probes_recompute): points in submesh order, the chunk of every point (ci | cj << 10 | ck << 20),
+    // one entry (ci, cj, ck, first, end) per submesh
+    float* probe_points;
+    uint32_t* probe_chunk;
+    uint32_t* probe_entries;
+    size_t probe_point_cap, probe_entry_cap;
+    uint32_t n_probe_points, n_probe_sub;
+    uint64_t mesh_serial, probes_serial;  // probes are current while they were picked from the current mesh
+};
+
+// host-side description of one pass of the mutual contact generation (see collide.hip)
+struct ivx_mutual_pass {
+    float center_s[3];        // sampled object's centre of mass, normalized
+    float q_s[4], t_s[3];     // world -> sampled object
+    float q_p[4], t_p[3];     // world -> probing object
+    float box_lo[3], box_hi[3];
+    uint32_t clo[3], chi[3];
+    int negate;
+    uint64_t id_ab;
+    uint32_t body_a, body_b;
+    float response[3];
 };
 
 void ivx_set_error(const char* fmt, ...);
@@ -288,6 +309,12 @@ int ivx_launch_step_record(ivx_grid* g, const uint32_t* d_pair_count, const void
 int ivx_launch_split_move(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], const uint32_t cc[3], uint32_t target);
 int ivx_launch_clip(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], const uint32_t cc[3], const float* planes4, uint32_t n_planes, int extract);
 int ivx_launch_split_repack(ivx_grid* src, ivx_grid* dst, const uint32_t off[3]);
+int ivx_launch_probe_select(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, uint32_t* d_corner_list, uint32_t* d_sel, uint32_t* d_counts, uint32_t* d_offsets,
+                            uint32_t* d_err);
+int ivx_launch_probe_gather(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, const uint32_t* d_sel, const uint32_t* d_counts, const uint32_t* d_offsets);
+int ivx_launch_mutual_pass(ivx_grid* prober, ivx_grid* sampled, const ivx_mutual_pass* h, uint32_t* d_counts, const uint32_t* d_offsets, ivx_contact* d_out,
+                           uint32_t cap, int emit);
+int ivx_launch_scan_counts(ivx_ctx* ctx, uint32_t n, const uint32_t* d_counts, uint32_t* d_offsets);
 int ivx_launch_absorb(ivx_grid* g, int capsule, const uint32_t lo[3], const uint32_t cc[3], const int32_t vlo[3], const int32_t vhi[3], const float c[3],
                       const float seg[3], float influence_radius, float shape_radius, const float* d_dens, double* d_removed10, uint32_t* d_by_type,
                       uint32_t* d_counters, uint32_t* d_touched);

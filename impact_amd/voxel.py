@@ -407,6 +407,35 @@ class VoxelObject:
                                                            capacity, C.byref(n)))
         return out[: n.value]
 
+    def collision_probes_recompute(self) -> int:
+        """`VoxelObjectCollisionProbes::recompute_for_all_chunks` (collidable.rs:361-731) on the current mesh; returns the number of probes"""
+        n = C.c_size_t(0)
+        check(capi.lib().ivx_collision_probes_recompute(self.h, C.byref(n)))
+        return int(n.value)
+
+    def collision_probes(self):
+        """-> (points [n,3] f32, entries [m,5] u32: chunk i, j, k, first point, end point)"""
+        n, m = C.c_size_t(0), C.c_size_t(0)
+        check(capi.lib().ivx_collision_probes_download(self.h, None, 0, None, 0, C.byref(n), C.byref(m)))
+        pts = np.zeros((max(1, n.value), 3), dtype=np.float32)
+        ent = np.zeros((max(1, m.value), 5), dtype=np.uint32)
+        check(capi.lib().ivx_collision_probes_download(self.h, ptr(pts), n.value, ptr(ent), m.value, C.byref(n), C.byref(m)))
+        return pts[: n.value], ent[: m.value]
+
+    def mutual_contacts(self, rotation_xyzw, translation, center_of_mass, other: "VoxelObject", other_rotation_xyzw, other_translation,
+                        other_center_of_mass, collidable_id_a: int, collidable_id_b: int, body_a: int, body_b: int, response=(0.0, 0.0, 0.0),
+                        capacity: int = 65536) -> np.ndarray:
+        """`for_each_mutual_voxel_object_contact` (collidable.rs:859-1049) with self = A, other = B: world -> object transforms, each
+        object's centre of mass (object space); the contact list for `PhysicsWorld.prepare_constraints`."""
+        out = np.zeros(capacity, dtype=capi.CONTACT_DTYPE)
+        n = C.c_size_t(0)
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+        check(capi.lib().ivx_mutual_voxel_object_contacts(self.h, ptr(f(rotation_xyzw)), ptr(f(translation)), ptr(f(center_of_mass)), other.h,
+                                                          ptr(f(other_rotation_xyzw)), ptr(f(other_translation)), ptr(f(other_center_of_mass)),
+                                                          collidable_id_a, collidable_id_b, body_a, body_b, ptr(f(response)), ptr(out), capacity,
+                                                          C.byref(n)))
+        return out[: n.value]
+
     def halo_bytes(self) -> int:
         return int(capi.lib().ivx_halo_bytes(self.h))
 

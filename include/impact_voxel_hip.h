@@ -350,6 +350,27 @@ int ivx_capsule_voxel_object_contacts(ivx_grid*, const float rotation_xyzw[4], c
                                       const float segment_vector[3], float capsule_radius, uint64_t collidable_id_a, uint64_t collidable_id_b,
                                       uint32_t body_a, uint32_t body_b, const float response[3], ivx_contact* out, size_t cap, size_t* n_out);
 
+/* ---- contacts between two voxel objects (second part) -------------------------------------------------------------
+ * VoxelObjectCollisionProbes::recompute_for_all_chunks (collidable.rs:361-392, 451-523, 614-731): per chunk submesh of the current mesh
+ * (ivx_remesh), the mesh vertex of the most convex curvature in every block of 8^3 / 4^3 / 2^3 / 1 voxels (block size from the object's smallest
+ * occupied extent). The probes stay on the device with the grid and go stale with the mesh. */
+int ivx_collision_probes_recompute(ivx_grid*, size_t* n_points);
+/* points: 3 floats each, in submesh order then block order; chunk_entries: 5 u32 per chunk that has probes (ci, cj, ck, first point, end point) —
+ * the reference's chunk_point_ranges, here in submesh order. Either output may be NULL; the counts are always returned. */
+int ivx_collision_probes_download(ivx_grid*, float* points, size_t cap_points, uint32_t* chunk_entries, size_t cap_entries, size_t* n_points,
+                                  size_t* n_entries);
+/* for_each_mutual_voxel_object_contact (collidable.rs:859-1049): the probes of A inside the voxel ranges where the two occupied boxes can overlap
+ * (determine_voxel_ranges_encompassing_intersection, object/intersection.rs:706-746) are sampled against B's signed distance field
+ * (determine_sdf_value_and_normal_at_point_if_intersecting, collidable.rs:1288-1440), then B's probes against A. rotation (xyzw) + translation =
+ * each object's transform_to_object_space (world -> object), center_of_mass_* = derive_center_of_mass() of the object's inertial properties
+ * (object space, world units). Every contact hashes [0, i, j, k] of the probing object's voxel with the two collidable ids; normals point from B
+ * to A. Both objects need current derived state and current probes, and must belong to the same context. The reference walks the chunks in the
+ * iteration order of a hash map (unpinned, see oracle/src/orc_collide.cpp); here they come in submesh order, A's probes first. */
+int ivx_mutual_voxel_object_contacts(ivx_grid* a, const float rotation_a[4], const float translation_a[3], const float center_of_mass_a[3], ivx_grid* b,
+                                     const float rotation_b[4], const float translation_b[3], const float center_of_mass_b[3],
+                                     uint64_t collidable_id_a, uint64_t collidable_id_b, uint32_t body_a, uint32_t body_b, const float response[3],
+                                     ivx_contact* out, size_t cap, size_t* n_out);
+
 #define IVX_KINEMATIC_BODY 0x80000000u
 #define IVX_CONTACT_MANIFOLD_START 1u
 /* ConstraintSolverConfig (src/constraint/solver.rs:41-57; defaults 8, 0.4, 3, 0.2 at 374-384) */

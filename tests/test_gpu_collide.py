@@ -1,0 +1,137 @@
+"""GPU parity of the contact generation between two voxel objects (second part): collision probes picked from
+the mesh and the mutual contacts, HIP path through the C ABI against the oracle (pinned in tests/test_oracle_collide.py): probe
+points and chunk ranges bit-exact, the same contacts in the same order with the same ids, geometry bit-exact; then two voxel
+bodies dropped onto each other, stepped through contact generation -> solver -> integration against the oracle."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import parity_util as pu
+from impact_amd import scenes
+from impact_amd.capi import CONTACT_DTYPE
+from impact_amd.voxel import VoxelObjectMesh
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def both(ctx, graph, extent=1.0):
+    o = pu.oracle_from_graph(graph, extent)
+    g = pu.gpu_from_graph(ctx, graph, extent)
+    o.update_occupied_voxel_ranges()
+    o.compute_all_derived_state()
+    g.compute_all_derived_state()
+    g.update_occupied_voxel_ranges()
+    g.label_regions()
+    g.mesh = VoxelObjectMesh.create(g)
+    return o, g
+
+
+def probes_both(o, g):
+    want_pts, want_ents = o.collision_probes(o.mesh())
+    n = g.collision_probes_recompute()
+    got_pts, got_ents = g.collision_probes()
+    assert n == len(want_pts)
+    np.testing.assert_array_equal(got_ents, want_ents)
+    np.testing.assert_array_equal(got_pts.view(np.uint32), want_pts.view(np.uint32))
+    return want_pts, want_ents
+
+
+@pytest.mark.parametrize("case", ["sphere_block8", "small_block4", "thin_block2", "sliver_block1", "half_extent", "asteroid"])
+def test_collision_probes(ctx, case):
+    graph, extent = {
+        "sphere_block8": (scenes.sphere_scene(30.0), 1.0),
+        "small_block4": (scenes.box_scene((9.0, 12.0, 20.0)), 1.0),
+        "thin_block2": (scenes.box_scene((5.0, 40.0, 18.0)), 1.0),
+        "sliver_block1": (scenes.box_scene((3.0, 20.0, 18.0)), 1.0),
+        "half_extent": (scenes.sphere_scene(11.0), 0.5),
+        "asteroid": (scenes.asteroid_scene(0.4), 1.0),
+    }[case]
+    o, g = both(ctx, graph, extent)
+    pts, ents = probes_both(o, g)
+    assert len(pts) > 8
+    g.close()
+
+
+def oracle_contact_list(A, pa, ca, qa, ta, B, pb, cb, qb, tb, id_a, id_b, body_a, body_b, response):
+    wi, pos, nrm, dep = A.mutual_contacts(pa, ca, qa, ta, B, pb, cb, qb, tb)
+    out = np.zeros(len(wi), dtype=CONTACT_DTYPE)
+    for n, (w, p, nn, d) in enumerate(zip(wi, pos, nrm, dep)):
+        out[n]["id"] = scenes.contact_id(id_a, id_b, 0, int(w[1]), int(w[2]), int(w[3]))
+        out[n]["body_a"], out[n]["body_b"] = body_a, body_b
+        out[n]["position"], out[n]["normal"], out[n]["depth"] = p, nn, d
+        out[n]["restitution"], out[n]["static_friction"], out[n]["dynamic_friction"] = response
+        out[n]["flags"] = 1 if n == 0 else 0
+    return out, wi
+
+
+def assert_contacts_equal(got, want):
+    assert len(got) == len(want)
+    for f in ("id", "body_a", "body_b", "flags"):
+        np.testing.assert_array_equal(got[f], want[f], err_msg=f)
+    for f in ("position", "normal", "depth", "restitution", "static_friction", "dynamic_friction"):
+        np.testing.assert_array_equal(got[f].view(np.uint32), want[f].view(np.uint32), err_msg=f)
+
+
+def rot64(q, v):
+    x, y, z, w = [float(a) for a in q]
+    b = np.array([x, y, z])
+    return v * (w * w - b @ b) + b * (2 * (v @ b)) + np.cross(b, v) * (2 * w)
+
+
+def placed(com, q, world_pos):
+    """world -> object translation that puts the object's centre of mass at `world_pos` with orientation q^-1"""
+    return (com.astype(np.float64) - rot64(q, np.asarray(world_pos, dtype=np.float64))).astype(f32)
+
+
+@pytest.mark.parametrize("case", ["two_spheres", "sphere_into_box_rotated", "mixed_extents", "deep", "apart", "both_rotated"])
+def test_mutual_contacts(ctx, case):
+    spec = {
+        "two_spheres": (scenes.sphere_scene(30.0), 1.0, scenes.sphere_scene(22.0), 1.0, 48.0, 0.0, 0.0),
+        "sphere_into_box_rotated": (scenes.box_scene((80.0, 24.0, 80.0)), 1.0, scenes.sphere_scene(24.0), 1.0, 33.0, 0.0, 0.6),
+        "mixed_extents": (scenes.sphere_scene(28.0), 0.5, scenes.sphere_scene(18.0), 1.0, 29.0, 0.0, -0.4),
+        "deep": (scenes.sphere_scene(40.0), 1.0, scenes.sphere_scene(20.0), 1.0, 30.0, 0.0, 0.9),  # B reaches A's uniform core
+        "apart": (scenes.sphere_scene(20.0), 1.0, scenes.sphere_scene(20.0), 1.0, 90.0, 0.2, 0.3),
+        "both_rotated": (scenes.asteroid_scene(0.3), 1.0, scenes.box_scene((30.0, 30.0, 30.0)), 1.0, 38.0, 0.7, -1.1),
+    }[case]
+    ga, ea, gb, eb, sep, ang_a, ang_b = spec
+    A, GA = both(ctx, ga, ea)
+    B, GB = both(ctx, gb, eb)
+    pa, pb = probes_both(A, GA), probes_both(B, GB)
+    ca, cb = A.center_of_mass(), B.center_of_mass()
+    ax_a = np.array([1.0, -0.2, 0.4]) / np.linalg.norm([1.0, -0.2, 0.4])
+    ax_b = np.array([0.3, 0.1, 1.0]) / np.linalg.norm([0.3, 0.1, 1.0])
+    qa = np.array([*(ax_a * np.sin(ang_a / 2)), np.cos(ang_a / 2)], dtype=f32)
+    qb = np.array([*(ax_b * np.sin(ang_b / 2)), np.cos(ang_b / 2)], dtype=f32)
+    ta = placed(ca, qa, [0.5, -0.25, 0.125])
+    tb = placed(cb, qb, [0.5, -0.25 + sep, 0.125])
+    resp = (0.3, 0.6, 0.45)
+    want, wi = oracle_contact_list(A, pa, ca, qa, ta, B, pb, cb, qb, tb, 11, 22, 0, 1, resp)
+    got = GA.mutual_contacts(qa, ta, ca, GB, qb, tb, cb, 11, 22, 0, 1, resp)
+    if case == "apart":
+        assert len(want) == 0
+    else:
+        assert len(want) > 10 and set(wi[:, 0].tolist()) == {0, 1}
+    if case == "deep":
+        assert np.isclose(want["depth"], 2.56).sum() > 3  # the capped distance with the centre-of-mass direction
+    assert_contacts_equal(got, want)
+    GA.close()
+    GB.close()
+
+
+def test_probes_go_stale_with_the_mesh(ctx):
+    from impact_amd.capi import IvxError
+
+    A, GA = both(ctx, scenes.sphere_scene(20.0))
+    B, GB = both(ctx, scenes.sphere_scene(20.0))
+    GA.collision_probes_recompute()
+    ident, zero = (0, 0, 0, 1), (0, 0, 0)
+    with pytest.raises(IvxError):  # B has no probes yet
+        GA.mutual_contacts(ident, zero, zero, GB, ident, zero, zero, 1, 2, 0, 1)
+    GB.collision_probes_recompute()
+    GA.mutual_contacts(ident, zero, zero, GB, ident, zero, zero, 1, 2, 0, 1)
+    GA.mesh.recreate()  # a new mesh: A's probes are stale
+    with pytest.raises(IvxError):
+        GA.mutual_contacts(ident, zero, zero, GB, ident, zero, zero, 1, 2, 0, 1)
+    GA.close()
+    GB.close()
