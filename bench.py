@@ -102,6 +102,23 @@ def cpu_baseline(scale):
     t3 = time.perf_counter()
     cc = o.chunk_counts
     nvox = cc[0] * cc[1] * cc[2] * 4096
+    # contact generation between two voxel bodies: probes of this body, then mutual contacts with a half-size copy
+    global _CPU_COLLIDE
+    t6 = time.perf_counter()
+    pa = o.collision_probes(m)
+    t7 = time.perf_counter()
+    ob = ol.OracleObject.from_sdf(scenes.asteroid_scene(0.5 * scale), 1.0, 0)
+    ob.update_occupied_voxel_ranges()
+    ob.compute_all_derived_state()
+    pb = ob.collision_probes(ob.mesh())
+    ca, cb = o.center_of_mass(), ob.center_of_mass()
+    qa, ta, qb, tb = collide_poses(ca, cb, scale)
+    t8 = time.perf_counter()
+    wi = o.mutual_contacts(pa, ca, qa, ta, ob, pb, cb, qb, tb, cap=1 << 20)[0]
+    t9 = time.perf_counter()
+    _CPU_COLLIDE = {"probes_ms": 1e3 * (t7 - t6), "mutual_ms": 1e3 * (t9 - t8), "probes": int(len(pa[0])), "contacts": int(len(wi)), "cores": 1,
+                    "kind": "port"}
+    del ob
     # the edit op on the same object: one absorbing sphere at the surface (EDIT_* below), derived state refreshed
     c = np.array([0.5 * (a + b_) for a, b_ in o.info()["occupied_voxel_ranges"]], dtype=np.float32) + EDIT_OFFSET * np.float32(scale)
     t4 = time.perf_counter()
@@ -119,6 +136,67 @@ def cpu_baseline(scale):
     }
 
 
+def collide_poses(com_a, com_b, scale):
+    """world -> object transforms for the collide benchmark: body A with its centre of mass at the world origin, the half-size body
+    B rotated and pushed ~4 % of its radius into A's side"""
+    qa = np.array([0.0, 0.0, 0.0, 1.0], dtype=np.float32)
+    ta = com_a.astype(np.float32)
+    axis = np.array([0.3, 0.1, 1.0]) / np.linalg.norm([0.3, 0.1, 1.0])
+    qb = np.array([*(axis * np.sin(0.35)), np.cos(0.35)], dtype=np.float32)
+    d = np.array([0.6, 0.64, 0.48])
+    centre_b = d / np.linalg.norm(d) * (96.0 + 48.0 - 4.0) * scale
+    x, y, z, w = [float(v) for v in qb]
+    b = np.array([x, y, z])
+    rot = centre_b * (w * w - b @ b) + b * (2 * (centre_b @ b)) + np.cross(b, centre_b) * (2 * w)
+    tb = (com_b.astype(np.float64) - rot).astype(np.float32)
+    return qa, ta, qb, tb
+
+
+def collide_benchmark(ctx, scale, reps=5):
+    """SURVEY §8f item 1 on the N=1 workload: collision probes of the meshed body (`ivx_collision_probes_recompute`), then the
+    contacts between it and a half-size copy pushed into its side (`ivx_mutual_voxel_object_contacts`, results on the host)."""
+    from impact_amd import capi, scenes
+    from impact_amd.voxel import SDFVoxelGenerator, VoxelObject, VoxelObjectMesh
+
+    objs = []
+    for sc in (scale, 0.5 * scale):
+        gen = SDFVoxelGenerator(1.0, scenes.asteroid_scene(sc), 0)
+        obj = VoxelObject(ctx, gen.chunk_counts(), 1.0)
+        obj.set_sdf_program(gen)
+        obj.set_densities(np.ones(256, dtype=np.float32))
+        r = obj.step(capi.STAGE_ALL)
+        m32 = np.asarray(r["moments"]["m32"], dtype=np.float32).reshape(-1)
+        com = (m32[1:4] * (np.float32(1.0) / m32[0])).astype(np.float32)  # derive_center_of_mass (object/inertia.rs:167-169)
+        VoxelObjectMesh.create(obj)
+        objs.append((obj, com))
+    (a, ca), (b, cb) = objs
+    qa, ta, qb, tb = collide_poses(ca, cb, scale)
+    t_p, t_m, n_probes, n_contacts = [], [], 0, 0
+    for _ in range(reps + 1):
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        n_probes = a.collision_probes_recompute()
+        t1 = time.perf_counter()
+        b.collision_probes_recompute()
+        ctx.synchronize()
+        t2 = time.perf_counter()
+        n_contacts = len(a.mutual_contacts(qa, ta, ca, b, qb, tb, cb, 1, 2, 0, 1, capacity=1 << 20))
+        t3 = time.perf_counter()
+        t_p.append(t1 - t0)
+        t_m.append(t3 - t2)
+    a.close()
+    b.close()
+    out = {"workload": "probes of the N=1 body; contacts between it and a half-size copy pushed into its side",
+           "probes_ms": round(1e3 * float(np.mean(t_p[1:])), 4), "mutual_ms": round(1e3 * float(np.mean(t_m[1:])), 4), "probes": n_probes,
+           "contacts": n_contacts}
+    if _CPU_COLLIDE is not None:
+        out["cpu_baseline"] = dict(_CPU_COLLIDE)
+        out["cpu_baseline"]["parity"] = ("same probe and contact counts" if (_CPU_COLLIDE["probes"], _CPU_COLLIDE["contacts"]) == (n_probes, n_contacts)
+                                         else "MISMATCH")
+    return out
+
+
+_CPU_COLLIDE = None
 EDIT_OFFSET = np.array([110.0, 6.0, -4.0], dtype=np.float32)  # from the centre of the body, at scale 1: inside the tip of the +x bump
 EDIT_RADIUS = 15.0
 _CPU_EDIT = None
@@ -376,6 +454,7 @@ def main():
             out["pile"] = pile_benchmark(ctx, with_cpu=(world == 1 and not args.no_cpu_baseline))
             if world == 1:
                 out["edit"] = edit_benchmark(ctx, args.scale)
+                out["collide"] = collide_benchmark(ctx, args.scale)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -135,3 +135,49 @@ def test_probes_go_stale_with_the_mesh(ctx):
         GA.mutual_contacts(ident, zero, zero, GB, ident, zero, zero, 1, 2, 0, 1)
     GA.close()
     GB.close()
+
+
+def world_to_object(body_q, body_p, model_centre):
+    """transform_to_object_space of a voxel body whose body frame origin sits at `model_centre` of its model space:
+    translate(model centre) . inverse(body pose), in f64 then rounded (both paths get the same f32 numbers)"""
+    q = body_q.astype(np.float64)
+    qi = np.array([-q[0], -q[1], -q[2], q[3]])
+    tr = rot64(qi, -body_p.astype(np.float64)) + model_centre
+    return qi.astype(f32), tr.astype(f32)
+
+
+def test_voxel_body_dropped_on_a_voxel_body_steps_like_the_oracle(ctx):
+    """the per-frame chain for two deformable bodies: mutual contacts from the current poses -> prepare -> solve -> integrate,
+    70 steps; a small voxel sphere falls onto a big one, both dynamic; GPU contacts feed the GPU solver, oracle contacts the
+    oracle's, rigid-body state within 1e-5 every step"""
+    import physics_util as phu
+
+    ext = 0.25
+    A, GA = both(ctx, scenes.sphere_scene(24.0), ext)  # radius 6.0 world units, below
+    B, GB = both(ctx, scenes.sphere_scene(10.0), ext)  # radius 2.5, falls
+    pa, pb = probes_both(A, GA), probes_both(B, GB)
+    ca, cb = A.center_of_mass(), B.center_of_mass()
+    big = ol.uniform_sphere_body(6.0, 5.0, (0.0, 0.0, 0.0))
+    small = ol.uniform_sphere_body(2.5, 2.0, (0.4, 6.0 + 2.5 + 0.04, -0.3), (0.0, -1.5, 0.0))
+    dyn = np.array([big, small])
+    dyn["total_force"][1] = (0.0, -9.81 * float(dyn["mass"][1]), 0.0)
+    w, op = phu.make_pair(ctx, dyn)
+    resp = (0.1, 0.6, 0.4)
+    touched = 0
+    for step in range(70):
+        gd, od = w.bodies()[0], op.bodies()[0]
+        qa_g, ta_g = world_to_object(gd["orientation"][0], gd["position"][0], ca.astype(np.float64))
+        qb_g, tb_g = world_to_object(gd["orientation"][1], gd["position"][1], cb.astype(np.float64))
+        qa_o, ta_o = world_to_object(od["orientation"][0], od["position"][0], ca.astype(np.float64))
+        qb_o, tb_o = world_to_object(od["orientation"][1], od["position"][1], cb.astype(np.float64))
+        got = GA.mutual_contacts(qa_g, ta_g, ca, GB, qb_g, tb_g, cb, 5, 6, 0, 1, resp)
+        want, _ = oracle_contact_list(A, pa, ca, qa_o, ta_o, B, pb, cb, qb_o, tb_o, 5, 6, 0, 1, resp)
+        assert len(got) == len(want), step
+        touched += len(want) > 0
+        w.perform_physics_step(got, 0.004)
+        op.step(want, 0.004)
+        phu.assert_bodies_close(w.bodies()[0], op.bodies()[0], what=f"step {step}: ")
+    assert touched > 10
+    w.close()
+    GA.close()
+    GB.close()
