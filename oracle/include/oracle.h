@@ -159,6 +159,12 @@ int orc_clip_polyhedron(orc_object* parent, const float* planes4, int n_planes, 
  * in the object's normalized space (voxel units, grid corner at the origin). Returns the number of chunks that became void. */
 int orc_absorb_sphere(orc_object* o, const float center[3], float influence_radius, float sphere_radius, const float densities[256],
                       double removed64[10], uint32_t emptied_by_type[256], uint8_t* invalidated_chunks, uint32_t* touched_chunks);
+/* two objects absorbing each other where they overlap (apply_mutual_absorption, interaction/absorption.rs:891-1079): every voxel of A's padded
+ * overlap ranges gets sdf_subtraction(sd, max(sd, B's SDF there)), every voxel of B's overlap ranges the same against A's SDF as it was before
+ * the call; rotation/translation = world -> object. stats: emptied voxels, touched chunks, removed chunks of A, then of B. */
+void orc_absorb_mutual(orc_object* a, const float rotation_a[4], const float translation_a[3], const float densities_a[256], orc_object* b,
+                       const float rotation_b[4], const float translation_b[3], const float densities_b[256], float smoothness, double removed_a[10],
+                       double removed_b[10], uint8_t* invalidated_a, uint8_t* invalidated_b, uint64_t stats[6]);
 /* the same for an absorbing capsule (interaction/absorption.rs:846-889 over object/intersection.rs:397-530) */
 int orc_absorb_capsule(orc_object* o, const float segment_start[3], const float segment_vector[3], float influence_radius, float capsule_radius,
                        const float densities[256], double removed64[10], uint32_t emptied_by_type[256], uint8_t* invalidated_chunks, uint32_t* touched_chunks);

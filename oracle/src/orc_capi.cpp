@@ -26,6 +26,9 @@ int mutual_contacts(const VoxelObject& A, const float* probes_a, const uint32_t*
                     float* depth);
 int plane_voxel_object_contacts(const VoxelObject& obj, const float rot[4], const float trans[3], const float plane_normal[3], float plane_displacement,
                                 int cap, int32_t* indices, float* position, float* normal, float* depth);
+void absorb_mutual(VoxelObject& A, const float rot_a[4], const float trans_a[3], const float* dens_a, VoxelObject& B, const float rot_b[4],
+                   const float trans_b[3], const float* dens_b, float smoothness, double removed_a[10], double removed_b[10], uint8_t* invalidated_a,
+                   uint8_t* invalidated_b, uint64_t stats[6]);
 int absorb_capsule(VoxelObject& obj, const float segment_start[3], const float segment_vector[3], float influence_radius, float capsule_radius,
                    const float* dens, double removed64[10], uint32_t emptied_by_type[256], uint8_t* invalidated, uint32_t* touched_chunks);
 int absorb_sphere(VoxelObject& obj, const float center[3], float influence_radius, float sphere_radius, const float* dens, double removed64[10],
@@ -377,6 +380,14 @@ int orc_clip_polyhedron(orc_object* parent, const float* planes4, int n_planes, 
 int orc_absorb_sphere(orc_object* o, const float center[3], float influence_radius, float sphere_radius, const float densities[256],
                       double removed64[10], uint32_t emptied_by_type[256], uint8_t* invalidated_chunks, uint32_t* touched_chunks) {
     return absorb_sphere(o->obj, center, influence_radius, sphere_radius, densities, removed64, emptied_by_type, invalidated_chunks, touched_chunks);
+}
+
+// apply_mutual_absorption (interaction/absorption.rs:891-1079)
+void orc_absorb_mutual(orc_object* a, const float rotation_a[4], const float translation_a[3], const float densities_a[256], orc_object* b,
+                       const float rotation_b[4], const float translation_b[3], const float densities_b[256], float smoothness, double removed_a[10],
+                       double removed_b[10], uint8_t* invalidated_a, uint8_t* invalidated_b, uint64_t stats[6]) {
+    absorb_mutual(a->obj, rotation_a, translation_a, densities_a, b->obj, rotation_b, translation_b, densities_b, smoothness, removed_a, removed_b,
+                  invalidated_a, invalidated_b, stats);
 }
 
 // apply_capsule_absorption (interaction/absorption.rs:846-889)

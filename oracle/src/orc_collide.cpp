@@ -252,9 +252,10 @@ int mutual_contacts(const VoxelObject& A, const float* probes_a, const uint32_t*
 
 // which_ijk [n][4]: 0 = probe of A against B / 1 = probe of B against A, then the probing object's voxel indices (the id hashes
 // [0, i, j, k] either way); returns the number of contacts (all of them, also beyond cap)
-static int mutual_contacts_impl(const VoxelObject& A, const Probes& pa, const float com_a[3], const float rot_a[4], const float trans_a[3], const VoxelObject& B,
-                                const Probes& pb, const float com_b[3], const float rot_b[4], const float trans_b[3], int cap, int32_t* which_ijk,
-                                float* position, float* normal, float* depth) {
+// VoxelObject::determine_voxel_ranges_encompassing_intersection (object/intersection.rs:706-746) for world -> object transforms of A and B;
+// also hands back transform_from_b_to_a. Ranges are NOT checked for emptiness (the reference does not either).
+bool intersection_voxel_ranges(const VoxelObject& A, const float rot_a[4], const float trans_a[3], const VoxelObject& B, const float rot_b[4],
+                               const float trans_b[3], long ra_lo[3], long ra_hi[3], long rb_lo[3], long rb_hi[3], float q_ba_out[4], float t_ba_out[3]) {
     const Quat qa{rot_a[0], rot_a[1], rot_a[2], rot_a[3]}, qb{rot_b[0], rot_b[1], rot_b[2], rot_b[3]};
     const V3 ta{trans_a[0], trans_a[1], trans_a[2]}, tb{trans_b[0], trans_b[1], trans_b[2]};
     // transform_from_b_to_a = world_to_a * world_to_b.inverted()
@@ -262,16 +263,45 @@ static int mutual_contacts_impl(const VoxelObject& A, const Probes& pa, const fl
     const V3 tbi = -qrot(qbi, tb);
     const Quat q_ba = qmul(qa, qbi);
     const V3 t_ba = qrot(qa, tbi) + ta;
+    q_ba_out[0] = q_ba.x, q_ba_out[1] = q_ba.y, q_ba_out[2] = q_ba.z, q_ba_out[3] = q_ba.w;
+    t_ba_out[0] = t_ba.x, t_ba_out[1] = t_ba.y, t_ba_out[2] = t_ba.z;
     const Aab aabb_a = occupied_aabb(A), aabb_b = occupied_aabb(B);
     const V3 b_center = 0.5f * (aabb_b.lo + aabb_b.hi);
     const Obb b_in_a{qrot(q_ba, b_center) + t_ba, qmul(q_ba, Quat{0.0f, 0.0f, 0.0f, 1.0f}), 0.5f * (aabb_b.hi - aabb_b.lo)};
     Aab in_a, in_b_rel;
-    if (!box_intersection_bounds(aabb_a, b_in_a, in_a, in_b_rel)) return 0;
+    if (!box_intersection_bounds(aabb_a, b_in_a, in_a, in_b_rel)) return false;
     const Aab in_b{in_b_rel.lo + b_center, in_b_rel.hi + b_center};
     const float inv_a = 1.0f / A.extent, inv_b = 1.0f / B.extent;
-    long ra_lo[3], ra_hi[3], rb_lo[3], rb_hi[3];
     ranges_touching(A, Aab{inv_a * in_a.lo, inv_a * in_a.hi}, ra_lo, ra_hi);
     ranges_touching(B, Aab{inv_b * in_b.lo, inv_b * in_b.hi}, rb_lo, rb_hi);
+    return true;
+}
+
+// sample_voxel_object_sdf (object/sdf.rs:636-675): trilinear SDF of the object at a normalized position, +2.54 outside the grid
+float sample_voxel_object_sdf(const VoxelObject& o, V3 p) {
+    const V3 lc = p - V3{0.5f, 0.5f, 0.5f};
+    const V3 fl{std::floor(lc.x), std::floor(lc.y), std::floor(lc.z)};
+    const V3 off = lc - fl;
+    if (std::signbit(fl.x) || std::signbit(fl.y) || std::signbit(fl.z)) return sd_to_f32(127);
+    const long i = as_usize(fl.x), j = as_usize(fl.y), k = as_usize(fl.z);
+    if (i + 1 >= (long)o.cc[0] * 16 || j + 1 >= (long)o.cc[1] * 16 || k + 1 >= (long)o.cc[2] * 16) return sd_to_f32(127);
+    float d[8];
+    for (int c = 0; c < 8; ++c) d[c] = sd_to_f32(o.voxel_at((int)(i + ((c >> 2) & 1)), (int)(j + ((c >> 1) & 1)), (int)(k + (c & 1))).sd);
+    const V3 rev = V3{1.0f, 1.0f, 1.0f} - off;
+    const float d00 = d[0] * rev.x + d[4] * off.x, d01 = d[1] * rev.x + d[5] * off.x, d10 = d[2] * rev.x + d[6] * off.x, d11 = d[3] * rev.x + d[7] * off.x;
+    const float d0 = d00 * rev.y + d10 * off.y, d1 = d01 * rev.y + d11 * off.y;
+    return d0 * rev.z + d1 * off.z;
+}
+
+static int mutual_contacts_impl(const VoxelObject& A, const Probes& pa, const float com_a[3], const float rot_a[4], const float trans_a[3], const VoxelObject& B,
+                                const Probes& pb, const float com_b[3], const float rot_b[4], const float trans_b[3], int cap, int32_t* which_ijk,
+                                float* position, float* normal, float* depth) {
+    const Quat qa{rot_a[0], rot_a[1], rot_a[2], rot_a[3]}, qb{rot_b[0], rot_b[1], rot_b[2], rot_b[3]};
+    const V3 ta{trans_a[0], trans_a[1], trans_a[2]}, tb{trans_b[0], trans_b[1], trans_b[2]};
+    long ra_lo[3], ra_hi[3], rb_lo[3], rb_hi[3];
+    float q_ba[4], t_ba[3];
+    if (!intersection_voxel_ranges(A, rot_a, trans_a, B, rot_b, trans_b, ra_lo, ra_hi, rb_lo, rb_hi, q_ba, t_ba)) return 0;
+    const float inv_a = 1.0f / A.extent, inv_b = 1.0f / B.extent;
     int n = 0;
     for (int pass = 0; pass < 2; ++pass) {
         const VoxelObject& P = pass == 0 ? A : B;  // the probing object

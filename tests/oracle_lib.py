@@ -96,6 +96,8 @@ def lib():
         L.orc_capsule_voxel_object_contacts.argtypes = [vp, vp, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, vp]
         L.orc_plane_voxel_object_contacts.restype = C.c_int
         L.orc_plane_voxel_object_contacts.argtypes = [vp, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, vp]
+        L.orc_absorb_mutual.restype = None
+        L.orc_absorb_mutual.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
         L.orc_absorb_capsule.restype = C.c_int
         L.orc_absorb_capsule.argtypes = [vp, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, C.POINTER(C.c_uint32)]
         L.orc_absorb_sphere.restype = C.c_int
@@ -318,6 +320,21 @@ class OracleObject:
         n = lib().orc_absorb_capsule(self.h, _p(a), _p(v), influence_radius, capsule_radius, _p(d), _p(removed), _p(by_type), _p(inval), C.byref(touched))
         return {"removed64": removed, "emptied_by_type": by_type, "invalidated": inval.astype(bool), "touched_chunks": int(touched.value),
                 "removed_chunks": int(n)}
+
+    def absorb_mutual(self, rotation_xyzw, translation, other, other_rotation_xyzw, other_translation, smoothness, densities=None, other_densities=None):
+        """apply_mutual_absorption(self = A, other = B), world -> object transforms -> (result dict of A, result dict of B)"""
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+        da = np.ones(256, dtype=np.float32) if densities is None else f(densities)
+        db = np.ones(256, dtype=np.float32) if other_densities is None else f(other_densities)
+        ra, rb = np.zeros(10, dtype=np.float64), np.zeros(10, dtype=np.float64)
+        cca, ccb = self.chunk_counts, other.chunk_counts
+        ia, ib = np.zeros(cca[0] * cca[1] * cca[2], dtype=np.uint8), np.zeros(ccb[0] * ccb[1] * ccb[2], dtype=np.uint8)
+        st = np.zeros(6, dtype=np.uint64)
+        lib().orc_absorb_mutual(self.h, _p(f(rotation_xyzw)), _p(f(translation)), _p(da), other.h, _p(f(other_rotation_xyzw)), _p(f(other_translation)),
+                                _p(db), smoothness, _p(ra), _p(rb), _p(ia), _p(ib), _p(st))
+        mk = lambda r, inv, o: {"removed64": r, "invalidated": inv.astype(bool), "emptied_voxels": int(st[o]), "touched_chunks": int(st[o + 1]),  # noqa: E731
+                                "removed_chunks": int(st[o + 2])}
+        return mk(ra, ia, 0), mk(rb, ib, 3)
 
     def sphere_contacts(self, rotation_xyzw, translation, center, radius, cap=65536):
         """for_each_sphere_voxel_object_contact -> (indices [n,3], position [n,3], normal [n,3], depth [n])"""

@@ -196,3 +196,116 @@ def test_mutual_contacts_match_brute_force_sdf_probe(case):
     # order: A's probes first, in probe order
     first_b = int(np.argmax(wi[:, 0] == 1))
     assert (wi[:first_b, 0] == 0).all() and (wi[first_b:, 0] == 1).all()
+
+
+# ---- mutual absorption -------------------------------------------------------------------------------------------------------------
+def qrot32(q, v):
+    """glam Quat::mul_vec3a on arrays of f32 vectors (same operation order as the restatements)"""
+    b = q[:3].astype(f32)
+    w = f32(q[3])
+    b2 = f32(f32(f32(b[0] * b[0]) + f32(b[1] * b[1])) + f32(b[2] * b[2]))
+    s1 = f32(f32(w * w) - b2)
+    vb = ((v[..., 0] * b[0] + v[..., 1] * b[1]) + v[..., 2] * b[2]).astype(f32)
+    s2 = (vb * f32(2.0)).astype(f32)
+    cr = np.stack([b[1] * v[..., 2] - v[..., 1] * b[2], b[2] * v[..., 0] - v[..., 2] * b[0], b[0] * v[..., 1] - v[..., 0] * b[1]], -1).astype(f32)
+    return ((v * s1 + b * s2[..., None]) + cr * f32(w * f32(2.0))).astype(f32)
+
+
+def trilinear32(sd, p, outside):
+    """sample_voxel_object_sdf on an array of normalized positions, f32 in the reference's operation order"""
+    lc = (p - f32(0.5)).astype(f32)
+    fl = np.floor(lc)
+    off = (lc - fl).astype(f32)
+    l = fl.astype(np.int64)
+    ok = (~np.signbit(fl)).all(-1) & (l + 1 < np.array(sd.shape)).all(-1)
+    l = np.where(ok[..., None], l, 0)
+    c = [sd[l[..., 0] + ((q >> 2) & 1), l[..., 1] + ((q >> 1) & 1), l[..., 2] + (q & 1)] for q in range(8)]
+    rev = (f32(1.0) - off).astype(f32)
+    d00, d01 = c[0] * rev[..., 0] + c[4] * off[..., 0], c[1] * rev[..., 0] + c[5] * off[..., 0]
+    d10, d11 = c[2] * rev[..., 0] + c[6] * off[..., 0], c[3] * rev[..., 0] + c[7] * off[..., 0]
+    d0, d1 = d00 * rev[..., 1] + d10 * off[..., 1], d01 * rev[..., 1] + d11 * off[..., 1]
+    return np.where(ok, d0 * rev[..., 2] + d1 * off[..., 2], f32(outside)).astype(f32)
+
+
+def subtracted32(sd, other, smooth):
+    inter = np.maximum(sd, other)
+    if smooth == 0.0:
+        return np.maximum(sd, -inter)
+    s = f32(smooth)
+    h = np.maximum(s - np.abs((-sd) - inter), f32(0.0)).astype(f32)
+    return (-(np.minimum(-sd, inter) - (h * h) * f32(f32(0.25) / s))).astype(f32)
+
+
+def dense32(o):
+    sdf, typ, flg, _, info = o.export_dense()
+    cc = o.chunk_counts
+    sd = ol.tiled_to_dense(sdf, cc).astype(np.int32)
+    kind = np.repeat(np.repeat(np.repeat(info["kind"].reshape(cc), 16, 0), 16, 1), 16, 2)
+    sd[kind == 0] = 127
+    sd[kind == 1] = -128
+    return sd, kind
+
+
+@pytest.mark.parametrize("smooth", [0.0, 1.5])
+@pytest.mark.parametrize("case", ["aligned", "rotated_mixed_extents"])
+def test_mutual_absorption_matches_formula_where_the_objects_overlap(case, smooth):
+    """apply_mutual_absorption: every voxel of the overlap gets sdf_subtraction(sd, max(sd, other's SDF)) with the other object's
+    SDF sampled trilinearly as it was BEFORE the call (numpy f32 restatement on dense arrays); away from the overlap a voxel is
+    either untouched or carries the same formula (the reference's voxel ranges decide, they are covered by the contact tests)"""
+    if case == "aligned":
+        A, B = make(scenes.sphere_scene(20.0)), make(scenes.sphere_scene(14.0))
+        qa, qb, sep = np.array([0, 0, 0, 1], f32), np.array([0, 0, 0, 1], f32), 28.0
+    else:
+        A, B = make(scenes.sphere_scene(26.0), 0.5), make(scenes.box_scene((22.0, 18.0, 30.0)), 1.0)
+        ax = np.array([0.2, -0.4, 1.0]) / np.linalg.norm([0.2, -0.4, 1.0])
+        qa = np.array([*(np.array([1.0, 0.0, 0.0]) * np.sin(0.15)), np.cos(0.15)], f32)
+        qb, sep = np.array([*(ax * np.sin(0.4)), np.cos(0.4)], f32), 19.0
+    ca, cb = A.center_of_mass(), B.center_of_mass()
+    ta = (ca.astype(np.float64) - rot64(qa, np.zeros(3))).astype(f32)
+    tb = (cb.astype(np.float64) - rot64(qb, np.array([0.0, sep, 0.0]))).astype(f32)
+    sa0, ka = dense32(A)
+    sb0, kb = dense32(B)
+    before_a, before_b = A.inertia()[1], B.inertia()[1]
+    ra, rb = A.absorb_mutual(qa, ta, B, qb, tb, smooth)
+    sa1, ka1 = dense32(A)
+    sb1, kb1 = dense32(B)
+    assert ra["emptied_voxels"] > 200 and rb["emptied_voxels"] > 200
+    # transform_from_b_to_a = world_to_a * world_to_b.inverted(), in f32 as the restatement composes it
+    qbi = np.array([-qb[0], -qb[1], -qb[2], qb[3]], f32)
+    tbi = (-qrot32(qbi, tb[None])[0]).astype(f32)
+    q_ba = np.array([qa[3] * qbi[0] + qa[0] * qbi[3] + qa[1] * qbi[2] - qa[2] * qbi[1], qa[3] * qbi[1] - qa[0] * qbi[2] + qa[1] * qbi[3] + qa[2] * qbi[0],
+                     qa[3] * qbi[2] + qa[0] * qbi[1] - qa[1] * qbi[0] + qa[2] * qbi[3], qa[3] * qbi[3] - qa[0] * qbi[0] - qa[1] * qbi[1] - qa[2] * qbi[2]], f32)
+    t_ba = (qrot32(qa, tbi[None])[0] + ta).astype(f32)
+    q_ab = np.array([-q_ba[0], -q_ba[1], -q_ba[2], q_ba[3]], f32)
+    ea, eb = f32(A.extent), f32(B.extent)
+    for which in (0, 1):
+        old, new, kind1 = (sa0, sa1, ka1) if which == 0 else (sb0, sb1, kb1)
+        other_old = (sb0 if which == 0 else sa0).astype(f32) * f32(0.02)
+        ext_p, ext_s = (ea, eb) if which == 0 else (eb, ea)
+        idx = np.stack(np.meshgrid(*[np.arange(n) for n in old.shape], indexing="ij"), -1)
+        centre = ((idx.astype(f32) + f32(0.5)) * ext_p).astype(f32)
+        if which == 0:
+            p_s = (qrot32(q_ab, (centre - t_ba).astype(f32)) * (f32(1.0) / ext_s)).astype(f32)  # inverse_transform_point, then scaled
+        else:
+            p_s = ((qrot32(q_ba, centre) + t_ba) * (f32(1.0) / ext_s)).astype(f32)
+        samp = trilinear32(other_old, p_s, 2.54)
+        inside_other = (samp * f32(ext_s * (f32(1.0) / ext_p))).astype(f32)
+        sd = old.astype(f32) * f32(0.02)
+        want = np.clip(np.trunc(subtracted32(sd, inside_other, smooth) * f32(50.0)), -128, 127).astype(np.int32)
+        live = (kind1 != 0) & (old != 127)
+        overlap = live & (samp < f32(0.0)) & (old < 0)  # solid here and inside the other object: certainly inside both occupied boxes
+        assert overlap.sum() > 300
+        np.testing.assert_array_equal(new[overlap], want[overlap])
+        rest = live & ~overlap
+        assert np.all((new[rest] == old[rest]) | (new[rest] == want[rest]))
+        # chunks that became void: every voxel of them was emptied or empty
+        gone = (kind1 == 0) & (old != 127)
+        assert np.all(want[gone] >= 0) or np.all(old[gone] >= 0)
+    np.testing.assert_allclose(before_a - A.inertia()[1], ra["removed64"], rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(before_b - B.inertia()[1], rb["removed64"], rtol=1e-9, atol=1e-6)
+    from test_oracle_voxel import validate_adjacencies, validate_chunk_obscuredness, validate_region_count
+
+    for o in (A, B):
+        validate_adjacencies(o)
+        validate_chunk_obscuredness(o)
+        validate_region_count(o)
