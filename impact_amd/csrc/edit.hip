@@ -21,6 +21,8 @@
 // the one to the whole segment, and a voxel exactly on the boundary counts as inside (<=).
 //
 // One workgroup per chunk of the box, a thread owns a 16-voxel k-row.
+#include <algorithm>
+
 #include "chunk_passes.hpp"
 
 namespace {
@@ -31,9 +33,96 @@ struct AbsorbParams {
     int32_t vlo[3], vhi[3];  // touched voxel ranges
     float c[3];  // sphere centre / capsule segment start
     float r2, r_sphere;
-    int32_t capsule;  // 0 sphere, 1 capsule
+    int32_t capsule;  // 0 sphere, 1 capsule, 2 mutual absorption against another object's grid, 3 against a dense snapshot
     float seg[3], seg_over_len2[3], r_infl;
+    // mutual absorption (interaction/absorption.rs:891-1094): where the other object's SDF is sampled
+    const int8_t* o_sdf;          // mode 2: the other grid's sdf plane; mode 3: dense i8 snapshot over [s_lo, s_hi)
+    const ivx_chunk_info* o_info;
+    uint32_t o_cy, o_cz, o_dims[3];
+    int32_t s_lo[3], s_hi[3];
+    float q[4], t[3];             // transform_from_b_to_a; mode 2 applies its inverse, mode 3 applies it
+    float ext_p, inv_s, ratio;    // own voxel extent, 1 / the other's, other's extent / own
+    float smooth, quarter_inv;
 };
+
+__device__ __forceinline__ void rot3(const float q[4], const float v[3], float o[3]) {  // glam Quat::mul_vec3a
+    const float b2 = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2], s1 = q[3] * q[3] - b2, s2 = ((v[0] * q[0] + v[1] * q[1]) + v[2] * q[2]) * 2.0f, s3 = q[3] * 2.0f;
+    const float cx = q[1] * v[2] - v[1] * q[2], cy = q[2] * v[0] - v[2] * q[0], cz = q[0] * v[1] - v[0] * q[1];
+    o[0] = (v[0] * s1 + q[0] * s2) + cx * s3;
+    o[1] = (v[1] * s1 + q[1] * s2) + cy * s3;
+    o[2] = (v[2] * s1 + q[2] * s2) + cz * s3;
+}
+
+// the other object's SDF at the centre of voxel (gi, gj, gk), in units of this object's voxels; false = the voxel is left alone
+__device__ __forceinline__ bool mutual_other_sd(const AbsorbParams& p, int gi, int gj, int gk, float* inside_other) {
+    const float c[3] = {((float)gi + 0.5f) * p.ext_p, ((float)gj + 0.5f) * p.ext_p, ((float)gk + 0.5f) * p.ext_p};
+    float ps[3];
+    if (p.capsule == 2) {  // inverse_voxel_extent_b * transform_from_b_to_a.inverse_transform_point(center_in_a)
+        const float qi[4] = {-p.q[0], -p.q[1], -p.q[2], p.q[3]}, d[3] = {c[0] - p.t[0], c[1] - p.t[1], c[2] - p.t[2]};
+        float r[3];
+        rot3(qi, d, r);
+        for (int a = 0; a < 3; ++a) ps[a] = p.inv_s * r[a];
+    } else {  // inverse_voxel_extent_a * transform_from_b_to_a.transform_point(center_in_b)
+        float r[3];
+        rot3(p.q, c, r);
+        for (int a = 0; a < 3; ++a) ps[a] = p.inv_s * (r[a] + p.t[a]);
+    }
+    float fl[3], off[3];
+    for (int a = 0; a < 3; ++a) {
+        const float lc = ps[a] - 0.5f;
+        fl[a] = floorf(lc);
+        off[a] = lc - fl[a];
+    }
+    float d[8];
+    if (p.capsule == 2) {  // sample_voxel_object_sdf (object/sdf.rs:636-675)
+        bool outside = ((__float_as_uint(fl[0]) | __float_as_uint(fl[1]) | __float_as_uint(fl[2])) & 0x80000000u) != 0;
+        uint32_t l[3];
+        for (int a = 0; a < 3; ++a) {
+            const uint32_t u = (uint32_t)fl[a];  // saturating
+            l[a] = u > 0x7FFFFFF0u ? 0x7FFFFFF0u : u;
+            outside |= l[a] + 1u >= p.o_dims[a];
+        }
+        if (outside) {
+            *inside_other = (127.0f * 0.02f) * p.ratio;
+            return true;
+        }
+#pragma unroll
+        for (int cn = 0; cn < 8; ++cn) {
+            const uint32_t i = l[0] + ((cn >> 2) & 1), j = l[1] + ((cn >> 1) & 1), k = l[2] + (cn & 1);
+            const uint32_t chunk = ((i >> 4) * p.o_cy + (j >> 4)) * p.o_cz + (k >> 4);
+            const uint32_t kind = p.o_info[chunk].kind;
+            const int sd = kind == KIND_NONUNIFORM ? (int)p.o_sdf[(size_t)chunk * IVX_CHUNK_VOXELS + (((i & 15u) << 8) | ((j & 15u) << 4) | (k & 15u))]
+                                                   : (kind == KIND_UNIFORM ? -128 : 127);
+            d[cn] = (float)sd * 0.02f;
+        }
+    } else {  // the snapshot of A's distances as they were before A was modified
+        long long l[3];
+        for (int a = 0; a < 3; ++a) {
+            l[a] = fl[a] >= 9.0e18f ? 0x7FFFFFFFFFFFFFF0ll : (fl[a] <= -9.0e18f ? -0x7FFFFFFFFFFFFFF0ll : (long long)fl[a]);  // `as isize`
+            if (l[a] < (long long)p.s_lo[a] || l[a] + 1 >= (long long)p.s_hi[a]) return false;
+        }
+        const size_t ny = (size_t)(p.s_hi[1] - p.s_lo[1]), nz = (size_t)(p.s_hi[2] - p.s_lo[2]);
+#pragma unroll
+        for (int cn = 0; cn < 8; ++cn) {
+            const size_t i = (size_t)(l[0] - p.s_lo[0]) + ((cn >> 2) & 1), j = (size_t)(l[1] - p.s_lo[1]) + ((cn >> 1) & 1), k = (size_t)(l[2] - p.s_lo[2]) + (cn & 1);
+            d[cn] = (float)(int)p.o_sdf[(i * ny + j) * nz + k] * 0.02f;
+        }
+    }
+    const float rx = 1.0f - off[0], ry = 1.0f - off[1], rz = 1.0f - off[2];  // evaluate_sdf_from_corner_samples (object/sdf.rs:579-597)
+    const float d00 = d[0] * rx + d[4] * off[0], d01 = d[1] * rx + d[5] * off[0], d10 = d[2] * rx + d[6] * off[0], d11 = d[3] * rx + d[7] * off[0];
+    const float d0 = d00 * ry + d10 * off[1], d1 = d01 * ry + d11 * off[1];
+    *inside_other = (d0 * rz + d1 * off[2]) * p.ratio;
+    return true;
+}
+
+// compute_subtracted_signed_distance (interaction/absorption.rs:1081-1094) with sdf_subtraction (generation/sdf.rs:52-102)
+__device__ __forceinline__ float subtracted_sd(const AbsorbParams& p, float sd, float inside_other) {
+    const float inter = inside_other > sd ? inside_other : sd;
+    if (p.smooth == 0.0f) return (-inter > sd) ? -inter : sd;
+    const float a = -sd, diff = fabsf(a - inter), hh = p.smooth - diff, h = hh > 0.0f ? hh : 0.0f;
+    const float mn = inter < a ? inter : a;
+    return -(mn - (h * h) * p.quarter_inv);
+}
 
 __device__ __forceinline__ int quantise(float v) {  // VoxelSignedDistance::from_f32 (lib.rs:197-201)
     float s = v * 50.0f;
@@ -55,7 +144,7 @@ __global__ __launch_bounds__(256) void k_absorb(AbsorbParams p, int8_t* __restri
     // the voxel ranges of this chunk the shape may reach (the same in every thread)
     const int cbase[3] = {(int)(ci * 16u), (int)(cj * 16u), (int)(ck * 16u)};
     int rlo[3], rhi[3];
-    if (p.capsule) {
+    if (p.capsule == 1) {
         float t_min = 0.0f, t_max = 1.0f;
         bool none = false;
 #pragma unroll
@@ -123,9 +212,11 @@ __global__ __launch_bounds__(256) void k_absorb(AbsorbParams p, int8_t* __restri
         if (row_in && gk >= rlo[2] && gk < rhi[2]) {
             const float pz = (float)gk + 0.5f;
             const float dz = pz - p.c[2];
-            float d2;
+            float d2 = 0.0f, other = 0.0f;
             bool inside;
-            if (p.capsule) {  // CapsulePointContainmentTester::shortest_squared_distance_from_point_to_segment
+            if (p.capsule >= 2) {  // mutual absorption: every voxel of the ranges that is not maximally outside
+                inside = sd != 127 && mutual_other_sd(p, gi, gj, gk, &other);
+            } else if (p.capsule) {  // CapsulePointContainmentTester::shortest_squared_distance_from_point_to_segment
                 float t = (dx * p.seg_over_len2[0] + dy * p.seg_over_len2[1]) + dz * p.seg_over_len2[2];
                 t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);  // f32::clamp
                 const float ex = px - (p.c[0] + p.seg[0] * t), ey = py - (p.c[1] + p.seg[1] * t), ez = pz - (p.c[2] + p.seg[2] * t);
@@ -137,9 +228,14 @@ __global__ __launch_bounds__(256) void k_absorb(AbsorbParams p, int8_t* __restri
             }
             if (inside) {
                 any_inside = true;
-                const float sphere_sd = sqrtf(d2) - p.r_sphere;
-                const float old = (float)sd * 0.02f, neg = -sphere_sd;
-                const float nv = (neg > old) ? neg : old;  // f32::max (no NaN here)
+                const float old = (float)sd * 0.02f;
+                float nv;
+                if (p.capsule >= 2) {
+                    nv = subtracted_sd(p, old, other);
+                } else {
+                    const float neg = -(sqrtf(d2) - p.r_sphere);
+                    nv = (neg > old) ? neg : old;  // f32::max (no NaN here)
+                }
                 const int q = quantise(nv);
                 if (sd < 0 && q >= 0) emptied |= 1u << k;
                 if (q != sd) {
@@ -221,7 +317,66 @@ __global__ __launch_bounds__(256) void k_absorb(AbsorbParams p, int8_t* __restri
     }
 }
 
+// dense copy of the object's distances over a voxel box (Void chunks read 127, Uniform ones -128), x-major
+__global__ __launch_bounds__(256) void k_sdf_snapshot(GridView g, const int8_t* __restrict__ sdf, int3 lo, int3 n, int8_t* __restrict__ out) {
+    const size_t total = (size_t)n.x * n.y * n.z;
+    for (size_t e = (size_t)blockIdx.x * 256u + threadIdx.x; e < total; e += (size_t)gridDim.x * 256u) {
+        const uint32_t k = (uint32_t)(e % n.z) + lo.z, j = (uint32_t)((e / n.z) % n.y) + lo.y, i = (uint32_t)(e / ((size_t)n.z * n.y)) + lo.x;
+        const uint32_t chunk = ((i >> 4) * g.cy + (j >> 4)) * g.cz + (k >> 4);
+        const uint32_t kind = g.info[chunk].kind;
+        out[e] = kind == KIND_NONUNIFORM ? sdf[(size_t)chunk * IVX_CHUNK_VOXELS + (((i & 15u) << 8) | ((j & 15u) << 4) | (k & 15u))]
+                                         : (int8_t)(kind == KIND_UNIFORM ? -128 : 127);
+    }
+}
+
 }  // namespace
+
+int ivx_launch_sdf_snapshot(ivx_grid* g, const int32_t lo[3], const int32_t hi[3], int8_t* d_out) {
+    const int3 l = make_int3(lo[0], lo[1], lo[2]), n = make_int3(hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]);
+    const size_t total = (size_t)n.x * n.y * n.z;
+    if (total == 0) return IVX_OK;
+    const uint32_t wgs = (uint32_t)std::min<size_t>((total + 255) / 256, 65535u * 16u);
+    hipLaunchKernelGGL(k_sdf_snapshot, dim3(wgs), dim3(256), 0, g->ctx->stream, ivx_view(g), g->sdf, l, n, d_out);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+// one side of apply_mutual_absorption: the voxels of `g` inside [vlo, vhi) against the other object's SDF — its live grid (from_snapshot 0, the
+// A side) or the dense snapshot of A taken before A was modified (from_snapshot 1, the B side)
+int ivx_launch_absorb_mutual(ivx_grid* g, int from_snapshot, const uint32_t lo[3], const uint32_t cc[3], const int32_t vlo[3], const int32_t vhi[3],
+                             ivx_grid* other, const int8_t* d_snapshot, const int32_t s_lo[3], const int32_t s_hi[3], const float q_ba[4],
+                             const float t_ba[3], float smoothness, const float* d_dens, double* d_removed10, uint32_t* d_by_type, uint32_t* d_counters,
+                             uint32_t* d_touched) {
+    AbsorbParams p;
+    p.g = ivx_view(g);
+    p.capsule = from_snapshot ? 3 : 2;
+    for (int d = 0; d < 3; ++d) {
+        p.lo[d] = lo[d];
+        p.cc[d] = cc[d];
+        p.vlo[d] = vlo[d];
+        p.vhi[d] = vhi[d];
+        p.c[d] = p.seg[d] = p.seg_over_len2[d] = 0.0f;
+        p.o_dims[d] = other->cc[d] * 16u;
+        p.s_lo[d] = s_lo[d];
+        p.s_hi[d] = s_hi[d];
+        p.t[d] = t_ba[d];
+    }
+    for (int d = 0; d < 4; ++d) p.q[d] = q_ba[d];
+    p.r2 = p.r_infl = p.r_sphere = 0.0f;
+    p.o_sdf = from_snapshot ? d_snapshot : other->sdf;
+    p.o_info = other->info;
+    p.o_cy = other->cc[1];
+    p.o_cz = other->cc[2];
+    p.ext_p = g->extent;
+    p.inv_s = 1.0f / other->extent;
+    p.ratio = other->extent * (1.0f / g->extent);
+    p.smooth = smoothness;
+    p.quarter_inv = 0.25f / smoothness;
+    hipLaunchKernelGGL(k_absorb, dim3(cc[0] * cc[1] * cc[2]), dim3(256), 0, g->ctx->stream, p, g->sdf, g->type, g->info, d_dens, d_removed10, d_by_type,
+                       d_counters, d_touched);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
 
 int ivx_launch_absorb(ivx_grid* g, int capsule, const uint32_t lo[3], const uint32_t cc[3], const int32_t vlo[3], const int32_t vhi[3], const float c[3],
                       const float seg[3], float influence_radius, float shape_radius, const float* d_dens, double* d_removed10, uint32_t* d_by_type,
@@ -243,6 +398,13 @@ int ivx_launch_absorb(ivx_grid* g, int capsule, const uint32_t lo[3], const uint
     p.r2 = influence_radius * influence_radius;
     p.r_infl = influence_radius;
     p.r_sphere = shape_radius;
+    p.o_sdf = nullptr;
+    p.o_info = nullptr;
+    p.o_cy = p.o_cz = 0;
+    for (int d = 0; d < 3; ++d) p.o_dims[d] = 0, p.s_lo[d] = p.s_hi[d] = 0, p.t[d] = 0.0f;
+    p.q[0] = p.q[1] = p.q[2] = 0.0f, p.q[3] = 1.0f;
+    p.ext_p = p.inv_s = p.ratio = 1.0f;
+    p.smooth = p.quarter_inv = 0.0f;
     hipLaunchKernelGGL(k_absorb, dim3(cc[0] * cc[1] * cc[2]), dim3(256), 0, g->ctx->stream, p, g->sdf, g->type, g->info, d_dens, d_removed10, d_by_type,
                        d_counters, d_touched);
     IVX_HIP_CHECK(hipGetLastError());

@@ -1212,6 +1212,50 @@ void host_ranges(const uint32_t occ[12], const float lo_f[3], const float hi_f[3
 }
 }  // namespace
 
+// determine_voxel_ranges_encompassing_intersection (object/intersection.rs:706-746) from the two objects' occupied ranges and world -> object
+// transforms; also transform_from_b_to_a = world_to_a * world_to_b.inverted() (impact_math/src/transform/isometry.rs:128-134, 200-205).
+// The ranges are not checked for emptiness (the reference does not either). false: the occupied boxes do not meet.
+static bool host_intersection_ranges(const ivx_grid* a, const uint32_t occ_a[12], const float rotation_a[4], const float translation_a[3], const ivx_grid* b,
+                                     const uint32_t occ_b[12], const float rotation_b[4], const float translation_b[3], long ra_lo[3], long ra_hi[3],
+                                     long rb_lo[3], long rb_hi[3], float q_ba[4], float t_ba[3]) {
+    const float qbi[4] = {-rotation_b[0], -rotation_b[1], -rotation_b[2], rotation_b[3]};
+    float tbi[3];
+    host_qrot(qbi, translation_b, tbi);
+    for (int d = 0; d < 3; ++d) tbi[d] = -tbi[d];
+    host_qmul(rotation_a, qbi, q_ba);
+    host_qrot(rotation_a, tbi, t_ba);
+    for (int d = 0; d < 3; ++d) t_ba[d] += translation_a[d];
+    HBox box_a, box_b;
+    for (int d = 0; d < 3; ++d) {
+        box_a.lo[d] = a->extent * (float)occ_a[6 + 2 * d];
+        box_a.hi[d] = a->extent * (float)occ_a[7 + 2 * d];
+        box_b.lo[d] = b->extent * (float)occ_b[6 + 2 * d];
+        box_b.hi[d] = b->extent * (float)occ_b[7 + 2 * d];
+    }
+    float b_center[3], b_half[3], bc_in_a[3], bq_in_a[4];
+    for (int d = 0; d < 3; ++d) {
+        b_center[d] = 0.5f * (box_b.lo[d] + box_b.hi[d]);
+        b_half[d] = 0.5f * (box_b.hi[d] - box_b.lo[d]);
+    }
+    host_qrot(q_ba, b_center, bc_in_a);
+    for (int d = 0; d < 3; ++d) bc_in_a[d] += t_ba[d];
+    const float ident[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+    host_qmul(q_ba, ident, bq_in_a);
+    HBox in_a, in_b;
+    if (!host_box_bounds(box_a, bc_in_a, bq_in_a, b_half, &in_a, &in_b)) return false;
+    const float inv_a = 1.0f / a->extent, inv_b = 1.0f / b->extent;
+    float na_lo[3], na_hi[3], nb_lo[3], nb_hi[3];
+    for (int d = 0; d < 3; ++d) {
+        na_lo[d] = inv_a * in_a.lo[d];
+        na_hi[d] = inv_a * in_a.hi[d];
+        nb_lo[d] = inv_b * (in_b.lo[d] + b_center[d]);
+        nb_hi[d] = inv_b * (in_b.hi[d] + b_center[d]);
+    }
+    host_ranges(occ_a, na_lo, na_hi, ra_lo, ra_hi);
+    host_ranges(occ_b, nb_lo, nb_hi, rb_lo, rb_hi);
+    return true;
+}
+
 int ivx_mutual_voxel_object_contacts(ivx_grid* a, const float rotation_a[4], const float translation_a[3], const float center_of_mass_a[3], ivx_grid* b,
                                      const float rotation_b[4], const float translation_b[3], const float center_of_mass_b[3], uint64_t collidable_id_a,
                                      uint64_t collidable_id_b, uint32_t body_a, uint32_t body_b, const float response[3], ivx_contact* out, size_t cap,
@@ -1239,44 +1283,9 @@ int ivx_mutual_voxel_object_contacts(ivx_grid* a, const float rotation_a[4], con
         if ((rc = d2h(g, raw, d_occ, sizeof(raw)))) return rc;
         ivx_occupied_from_raw(g, raw, w ? occ_b : occ_a);
     }
-    // determine_voxel_ranges_encompassing_intersection (object/intersection.rs:706-746)
-    // transform_from_b_to_a = world_to_a * world_to_b.inverted() (impact_math/src/transform/isometry.rs:128-134, 200-205)
-    const float qbi[4] = {-rotation_b[0], -rotation_b[1], -rotation_b[2], rotation_b[3]};
-    float tbi[3], q_ba[4], t_ba[3];
-    host_qrot(qbi, translation_b, tbi);
-    for (int d = 0; d < 3; ++d) tbi[d] = -tbi[d];
-    host_qmul(rotation_a, qbi, q_ba);
-    host_qrot(rotation_a, tbi, t_ba);
-    for (int d = 0; d < 3; ++d) t_ba[d] += translation_a[d];
-    HBox box_a, box_b;
-    for (int d = 0; d < 3; ++d) {
-        box_a.lo[d] = a->extent * (float)occ_a[6 + 2 * d];
-        box_a.hi[d] = a->extent * (float)occ_a[7 + 2 * d];
-        box_b.lo[d] = b->extent * (float)occ_b[6 + 2 * d];
-        box_b.hi[d] = b->extent * (float)occ_b[7 + 2 * d];
-    }
-    float b_center[3], b_half[3], bc_in_a[3], bq_in_a[4];
-    for (int d = 0; d < 3; ++d) {
-        b_center[d] = 0.5f * (box_b.lo[d] + box_b.hi[d]);
-        b_half[d] = 0.5f * (box_b.hi[d] - box_b.lo[d]);
-    }
-    host_qrot(q_ba, b_center, bc_in_a);
-    for (int d = 0; d < 3; ++d) bc_in_a[d] += t_ba[d];
-    const float ident[4] = {0.0f, 0.0f, 0.0f, 1.0f};
-    host_qmul(q_ba, ident, bq_in_a);
-    HBox in_a, in_b;
-    if (!host_box_bounds(box_a, bc_in_a, bq_in_a, b_half, &in_a, &in_b)) return IVX_OK;
-    const float inv_a = 1.0f / a->extent, inv_b = 1.0f / b->extent;
-    float na_lo[3], na_hi[3], nb_lo[3], nb_hi[3];
-    for (int d = 0; d < 3; ++d) {
-        na_lo[d] = inv_a * in_a.lo[d];
-        na_hi[d] = inv_a * in_a.hi[d];
-        nb_lo[d] = inv_b * (in_b.lo[d] + b_center[d]);
-        nb_hi[d] = inv_b * (in_b.hi[d] + b_center[d]);
-    }
     long ra_lo[3], ra_hi[3], rb_lo[3], rb_hi[3];
-    host_ranges(occ_a, na_lo, na_hi, ra_lo, ra_hi);
-    host_ranges(occ_b, nb_lo, nb_hi, rb_lo, rb_hi);
+    float q_ba[4], t_ba[3];
+    if (!host_intersection_ranges(a, occ_a, rotation_a, translation_a, b, occ_b, rotation_b, translation_b, ra_lo, ra_hi, rb_lo, rb_hi, q_ba, t_ba)) return IVX_OK;
     ivx_mutual_pass pass[2];
     {  // ContactID::from_two_u64_and_n_indices: the part that does not depend on the probe
         auto mix = [](uint64_t state) {
@@ -1336,6 +1345,138 @@ int ivx_mutual_voxel_object_contacts(ivx_grid* a, const float rotation_a[4], con
     *n_out = total;
     IVX_REQUIRE(total <= cap, IVX_ERR_CAPACITY, "%s: %u contacts exceed the capacity %zu", who, total, cap);
     if (total && (rc = d2h(a, out, d_out, (size_t)total * sizeof(ivx_contact)))) return rc;
+    return IVX_OK;
+}
+
+// apply_mutual_absorption (interaction/absorption.rs:891-1079)
+int ivx_absorb_mutual(ivx_grid* a, const float rotation_a[4], const float translation_a[3], const float densities_a[256], ivx_grid* b, const float rotation_b[4],
+                      const float translation_b[3], const float densities_b[256], float smoothness, ivx_absorb_result* out_a, ivx_absorb_result* out_b,
+                      uint8_t* invalidated_chunks_a, uint8_t* invalidated_chunks_b) {
+    const char* who = "ivx_absorb_mutual";
+    IVX_REQUIRE(a && b && rotation_a && translation_a && densities_a && rotation_b && translation_b && densities_b && out_a && out_b, IVX_ERR_INVALID,
+                "%s: null argument", who);
+    IVX_REQUIRE(a != b && a->ctx == b->ctx, IVX_ERR_INVALID, "%s: two different objects of one context are needed", who);
+    IVX_REQUIRE(smoothness >= 0.0f, IVX_ERR_INVALID, "%s: negative smoothness", who);
+    for (ivx_grid* g : {a, b}) {
+        IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "%s: derived state and regions must be current (ivx_derive_state + ivx_label_regions)", who);
+        IVX_REQUIRE(g->x_off == 0 && g->gx == g->cc[0] && !g->has_ghost[0] && !g->has_ghost[1], IVX_ERR_STATE,
+                    "%s: not available on a slab of a decomposed grid", who);
+    }
+    memset(out_a, 0, sizeof(*out_a));
+    memset(out_b, 0, sizeof(*out_b));
+    if (invalidated_chunks_a) memset(invalidated_chunks_a, 0, a->n_chunks);
+    if (invalidated_chunks_b) memset(invalidated_chunks_b, 0, b->n_chunks);
+    int rc;
+    uint32_t occ_a[12], occ_b[12];
+    for (int w = 0; w < 2; ++w) {
+        ivx_grid* g = w ? b : a;
+        uint32_t* d_occ = g->rscalar + 16;
+        if ((rc = ivx_launch_occupied(g, d_occ))) return rc;
+        uint32_t raw[12];
+        if ((rc = d2h(g, raw, d_occ, sizeof(raw)))) return rc;
+        ivx_occupied_from_raw(g, raw, w ? occ_b : occ_a);
+    }
+    long ra_lo[3], ra_hi[3], rb_lo[3], rb_hi[3];
+    float q_ba[4], t_ba[3];
+    if (!host_intersection_ranges(a, occ_a, rotation_a, translation_a, b, occ_b, rotation_b, translation_b, ra_lo, ra_hi, rb_lo, rb_hi, q_ba, t_ba)) return IVX_OK;
+    // the snapshot of A's distances covers A's overlap ranges padded by one B voxel (in A voxels), inside A's grid
+    const long pad = (long)std::ceil(b->extent * (1.0f / a->extent));
+    int32_t s_lo[3], s_hi[3], vb_lo[3], vb_hi[3];
+    bool a_runs = true, b_runs = true;
+    size_t snap_bytes = 1;
+    for (int d = 0; d < 3; ++d) {
+        s_lo[d] = (int32_t)std::max<long>(0, ra_lo[d] - pad);
+        s_hi[d] = (int32_t)std::min<long>(ra_hi[d] + pad, (long)a->cc[d] * 16);
+        vb_lo[d] = (int32_t)rb_lo[d];
+        vb_hi[d] = (int32_t)rb_hi[d];
+        a_runs = a_runs && s_lo[d] < s_hi[d];
+        b_runs = b_runs && vb_lo[d] < vb_hi[d];
+        snap_bytes *= (size_t)std::max(0, s_hi[d] - s_lo[d]);
+    }
+    if (!a_runs) snap_bytes = 0;
+    if (!a_runs && !b_runs) return IVX_OK;
+    // scratch (A's): per object [10 f64 removed moments][256 u32 by type][2 u32 counters][pad][n_chunks u32 touched ranges], then the two density
+    // tables, then the snapshot
+    const size_t off_type = 80, off_cnt = off_type + 1024, off_touch = off_cnt + 16;
+    const size_t blk_a = (off_touch + (size_t)a->n_chunks * 4 + 255) & ~(size_t)255, blk_b = (off_touch + (size_t)b->n_chunks * 4 + 255) & ~(size_t)255;
+    const size_t off_dens = blk_a + blk_b, off_snap = off_dens + 2048;
+    if ((rc = ensure_dev_scratch(a, off_snap + snap_bytes + 256))) return rc;
+    char* base = static_cast<char*>(a->dev_scratch);
+    IVX_HIP_CHECK(hipMemsetAsync(base, 0, off_dens, a->ctx->stream));
+    if ((rc = h2d(a, base + off_dens, densities_a, 1024))) return rc;
+    if ((rc = h2d(a, base + off_dens + 1024, densities_b, 1024))) return rc;
+    int8_t* d_snap = reinterpret_cast<int8_t*>(base + off_snap);
+    uint32_t lo_a[3] = {0, 0, 0}, cc_a[3] = {0, 0, 0}, lo_b[3] = {0, 0, 0}, cc_b[3] = {0, 0, 0};
+    if (a_runs) {
+        for (int d = 0; d < 3; ++d) {
+            lo_a[d] = (uint32_t)s_lo[d] / 16u;
+            cc_a[d] = ((uint32_t)s_hi[d] + 15u) / 16u - lo_a[d];
+        }
+        if ((rc = ivx_launch_sdf_snapshot(a, s_lo, s_hi, d_snap))) return rc;
+        if ((rc = ivx_launch_absorb_mutual(a, 0, lo_a, cc_a, s_lo, s_hi, b, nullptr, s_lo, s_hi, q_ba, t_ba, smoothness, reinterpret_cast<float*>(base + off_dens),
+                                           reinterpret_cast<double*>(base), reinterpret_cast<uint32_t*>(base + off_type),
+                                           reinterpret_cast<uint32_t*>(base + off_cnt), reinterpret_cast<uint32_t*>(base + off_touch))))
+            return rc;
+    }
+    if (b_runs) {
+        for (int d = 0; d < 3; ++d) {
+            lo_b[d] = (uint32_t)vb_lo[d] / 16u;
+            cc_b[d] = ((uint32_t)vb_hi[d] + 15u) / 16u - lo_b[d];
+        }
+        char* bb = base + blk_a;
+        if ((rc = ivx_launch_absorb_mutual(b, 1, lo_b, cc_b, vb_lo, vb_hi, a, d_snap, s_lo, s_hi, q_ba, t_ba, smoothness,
+                                           reinterpret_cast<float*>(base + off_dens + 1024), reinterpret_cast<double*>(bb),
+                                           reinterpret_cast<uint32_t*>(bb + off_type), reinterpret_cast<uint32_t*>(bb + off_cnt),
+                                           reinterpret_cast<uint32_t*>(bb + off_touch))))
+            return rc;
+    }
+    std::vector<char> hostbuf(off_dens);
+    if ((rc = d2h(a, hostbuf.data(), base, off_dens))) return rc;
+    if (a_runs && (rc = rederive(a))) return rc;
+    if (b_runs && (rc = rederive(b))) return rc;
+    for (int w = 0; w < 2; ++w) {
+        ivx_grid* g = w ? b : a;
+        if (!(w ? b_runs : a_runs)) continue;
+        const char* hb = hostbuf.data() + (w ? blk_a : 0);
+        ivx_absorb_result* out = w ? out_b : out_a;
+        uint8_t* inval = w ? invalidated_chunks_b : invalidated_chunks_a;
+        const uint32_t* lo = w ? lo_b : lo_a;
+        const uint32_t* cc = w ? cc_b : cc_a;
+        const double* rem = reinterpret_cast<const double*>(hb);
+        const double e = (double)g->extent, e3 = e * e * e, e4 = e3 * e, e5 = e4 * e;
+        const double f[10] = {e3, 0.5 * e4, 0.5 * e4, 0.5 * e4, e5 / 3.0, e5 / 3.0, e5 / 3.0, 0.25 * e5, 0.25 * e5, 0.25 * e5};
+        for (int q = 0; q < 10; ++q) out->removed_moments[q] = rem[q] * f[q];
+        const uint32_t* by_type = reinterpret_cast<const uint32_t*>(hb + off_type);
+        uint64_t emptied = 0;
+        for (int t = 0; t < 256; ++t) emptied += by_type[t];
+        out->emptied_voxels = emptied;
+        const uint32_t* cnt = reinterpret_cast<const uint32_t*>(hb + off_cnt);
+        out->touched_chunks = cnt[0];
+        out->removed_chunks = cnt[1];
+        if (!inval) continue;
+        const uint32_t* touched = reinterpret_cast<const uint32_t*>(hb + off_touch);  // handle_chunk_voxels_modified (intersection.rs:560-598)
+        for (uint32_t i = lo[0]; i < lo[0] + cc[0]; ++i)
+            for (uint32_t j = lo[1]; j < lo[1] + cc[1]; ++j)
+                for (uint32_t k = lo[2]; k < lo[2] + cc[2]; ++k) {
+                    const uint32_t c = (i * g->cc[1] + j) * g->cc[2] + k;
+                    const uint32_t wd = touched[c];
+                    if (!wd) continue;
+                    inval[c] = 1;
+                    const uint32_t idx[3] = {i, j, k};
+                    for (int d = 0; d < 3; ++d) {
+                        const uint32_t rlo = (wd >> (4 * d)) & 15u, rhi = ((wd >> (12 + 4 * d)) & 15u) + 1u;
+                        uint32_t n3[3] = {i, j, k};
+                        if (idx[d] > 0 && rlo < 2) {
+                            n3[d] = idx[d] - 1;
+                            inval[(n3[0] * g->cc[1] + n3[1]) * g->cc[2] + n3[2]] = 1;
+                        }
+                        if (idx[d] + 1 < g->cc[d] && 16u - rhi < 2) {
+                            n3[d] = idx[d] + 1;
+                            inval[(n3[0] * g->cc[1] + n3[1]) * g->cc[2] + n3[2]] = 1;
+                        }
+                    }
+                }
+    }
     return IVX_OK;
 }
 

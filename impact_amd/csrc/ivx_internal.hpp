@@ -315,6 +315,11 @@ int ivx_launch_probe_gather(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, const
 int ivx_launch_mutual_pass(ivx_grid* prober, ivx_grid* sampled, const ivx_mutual_pass* h, uint32_t* d_counts, const uint32_t* d_offsets, ivx_contact* d_out,
                            uint32_t cap, int emit);
 int ivx_launch_scan_counts(ivx_ctx* ctx, uint32_t n, const uint32_t* d_counts, uint32_t* d_offsets);
+int ivx_launch_sdf_snapshot(ivx_grid* g, const int32_t lo[3], const int32_t hi[3], int8_t* d_out);
+int ivx_launch_absorb_mutual(ivx_grid* g, int from_snapshot, const uint32_t lo[3], const uint32_t cc[3], const int32_t vlo[3], const int32_t vhi[3],
+                             ivx_grid* other, const int8_t* d_snapshot, const int32_t s_lo[3], const int32_t s_hi[3], const float q_ba[4],
+                             const float t_ba[3], float smoothness, const float* d_dens, double* d_removed10, uint32_t* d_by_type, uint32_t* d_counters,
+                             uint32_t* d_touched);
 int ivx_launch_absorb(ivx_grid* g, int capsule, const uint32_t lo[3], const uint32_t cc[3], const int32_t vlo[3], const int32_t vhi[3], const float c[3],
                       const float seg[3], float influence_radius, float shape_radius, const float* d_dens, double* d_removed10, uint32_t* d_by_type,
                       uint32_t* d_counters, uint32_t* d_touched);

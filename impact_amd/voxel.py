@@ -371,6 +371,23 @@ class VoxelObject:
                 "invalidated": None if inval is None else inval.astype(bool), "touched_chunks": int(out[0]["touched_chunks"]),
                 "removed_chunks": int(out[0]["removed_chunks"])}
 
+    def absorb_mutual(self, rotation_xyzw, translation, other: "VoxelObject", other_rotation_xyzw, other_translation, smoothness: float, densities=None,
+                      other_densities=None):
+        """`apply_mutual_absorption` (interaction/absorption.rs:891-1079) with self = A, other = B and world -> object transforms;
+        returns the result dicts of A and B (as `absorb_sphere`, without the per-type counts)."""
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+        da = np.ones(256, dtype=np.float32) if densities is None else f(densities)
+        db = np.ones(256, dtype=np.float32) if other_densities is None else f(other_densities)
+        oa, ob = np.zeros(1, dtype=capi.ABSORB_RESULT_DTYPE), np.zeros(1, dtype=capi.ABSORB_RESULT_DTYPE)
+        ia, ib = np.zeros(self.n_chunks, dtype=np.uint8), np.zeros(other.n_chunks, dtype=np.uint8)
+        check(capi.lib().ivx_absorb_mutual(self.h, ptr(f(rotation_xyzw)), ptr(f(translation)), ptr(da), other.h, ptr(f(other_rotation_xyzw)),
+                                           ptr(f(other_translation)), ptr(db), smoothness, ptr(oa), ptr(ob), ptr(ia), ptr(ib)))
+        self._region_count = None
+        other._region_count = None
+        mk = lambda o, inv: {"removed_moments": o[0]["removed_moments"].copy(), "emptied_voxels": int(o[0]["emptied_voxels"]),  # noqa: E731
+                             "invalidated": inv.astype(bool), "touched_chunks": int(o[0]["touched_chunks"]), "removed_chunks": int(o[0]["removed_chunks"])}
+        return mk(oa, ia), mk(ob, ib)
+
     # ---- contact generation ------------------------------------------------------------------------
     def sphere_contacts(self, rotation_xyzw, translation, sphere_center, sphere_radius: float, collidable_id_a: int, collidable_id_b: int, body_a: int,
                         body_b: int, response=(0.0, 0.0, 0.0), capacity: int = 65536) -> np.ndarray:

@@ -240,6 +240,14 @@ int ivx_absorb_sphere(ivx_grid*, const float center[3], float influence_radius, 
  * when its centre is within the radius of the whole segment, boundary included (capsule.rs:225-250). */
 int ivx_absorb_capsule(ivx_grid*, const float segment_start[3], const float segment_vector[3], float influence_radius, float capsule_radius,
                        const float densities[256], ivx_absorb_result* out, uint32_t* emptied_by_type, uint8_t* invalidated_chunks);
+/* apply_mutual_absorption (interaction/absorption.rs:891-1079): two objects eat into each other where they overlap. Every voxel of A's overlap
+ * ranges (determine_voxel_ranges_encompassing_intersection, padded by one voxel of B) that is not maximally outside gets
+ * sdf_subtraction(sd, max(sd, B's SDF at its centre), smoothness) with B's SDF sampled trilinearly (sample_voxel_object_sdf, object/sdf.rs:636-675);
+ * every voxel of B's overlap ranges the same against A's SDF as it was before the call. rotation (xyzw) + translation = each object's world -> object
+ * transform. Results per object as for ivx_absorb_sphere; both objects need current derived state and regions, and keep them current. */
+int ivx_absorb_mutual(ivx_grid* a, const float rotation_a[4], const float translation_a[3], const float densities_a[256], ivx_grid* b,
+                      const float rotation_b[4], const float translation_b[3], const float densities_b[256], float smoothness, ivx_absorb_result* out_a,
+                      ivx_absorb_result* out_b, uint8_t* invalidated_chunks_a, uint8_t* invalidated_chunks_b);
 
 /* make the compiled SDF program / the voxel-type densities resident on the device */
 int ivx_grid_set_sdf_program(ivx_grid*, const ivx_sdf_processed_node* nodes, size_t n_nodes, uint32_t stack_size,

@@ -208,3 +208,91 @@ def test_capsule_on_multi_material_object(ctx):
     r = absorb_capsule_both(o, g, np.array([6.0, 10.5, 20.0], np.float32), np.array([36.0, 27.0, 9.5], np.float32), 5.0, dens)
     assert np.count_nonzero(r["emptied_by_type"][:3]) >= 2
     g.close()
+
+
+# ---- mutual absorption ----------------------------------------------------------------------------------------------------------------
+def rot64(q, v):
+    x, y, z, w = [float(a) for a in q]
+    b = np.array([x, y, z])
+    return v * (w * w - b @ b) + b * (2 * (v @ b)) + np.cross(b, v) * (2 * w)
+
+
+def absorb_mutual_both(A, GA, qa, ta, B, GB, qb, tb, smooth, dens_a=None, dens_b=None):
+    roa, rob = A.absorb_mutual(qa, ta, B, qb, tb, smooth, dens_a, dens_b)
+    rga, rgb = GA.absorb_mutual(qa, ta, GB, qb, tb, smooth, dens_a, dens_b)
+    for ro, rg, o, g, dens in ((roa, rga, A, GA, dens_a), (rob, rgb, B, GB, dens_b)):
+        assert rg["emptied_voxels"] == ro["emptied_voxels"]
+        assert rg["touched_chunks"] == ro["touched_chunks"] and rg["removed_chunks"] == ro["removed_chunks"]
+        np.testing.assert_array_equal(rg["invalidated"], ro["invalidated"])
+        scale = np.maximum(np.abs(ro["removed64"]), 1e-300)
+        assert np.all(np.abs(rg["removed_moments"] - ro["removed64"]) <= 1e-5 * scale + 1e-9), (rg["removed_moments"], ro["removed64"])
+        ro["regions"] = pu.assert_edited_objects_equal(o, g, densities=dens)
+    return roa, rob
+
+
+@pytest.mark.parametrize("smooth", [0.0, 2.0])
+@pytest.mark.parametrize("case", ["aligned", "rotated_mixed_extents", "small_inside_big", "apart"])
+def test_mutual_absorption(ctx, case, smooth):
+    """apply_mutual_absorption: two spheres side by side, a rotated box of another voxel extent pushed into a sphere (the snapshot
+    padding is two A voxels), a small body wholly inside a big one (it disappears; the big one gets a cavity), and two bodies whose
+    boxes do not meet"""
+    if case == "aligned":
+        (A, GA), (B, GB) = both(ctx, scenes.sphere_scene(30.0)), both(ctx, scenes.sphere_scene(22.0))
+        qa, qb, centre_b = (0, 0, 0, 1), (0, 0, 0, 1), [0.25, 44.0, -0.5]
+    elif case == "rotated_mixed_extents":
+        (A, GA), (B, GB) = both(ctx, scenes.sphere_scene(40.0), 0.5), both(ctx, scenes.box_scene((22.0, 18.0, 30.0)), 1.0)
+        ax = np.array([0.2, -0.4, 1.0]) / np.linalg.norm([0.2, -0.4, 1.0])
+        qa = (np.sin(0.15), 0.0, 0.0, np.cos(0.15))
+        qb, centre_b = (*(ax * np.sin(0.4)), np.cos(0.4)), [1.0, 25.0, 2.0]
+    elif case == "small_inside_big":
+        (A, GA), (B, GB) = both(ctx, scenes.sphere_scene(40.0)), both(ctx, scenes.sphere_scene(9.0))
+        qa, qb, centre_b = (0, 0, 0, 1), (0.0, np.sin(0.3), 0.0, np.cos(0.3)), [3.0, -2.0, 5.0]
+    else:
+        (A, GA), (B, GB) = both(ctx, scenes.sphere_scene(20.0)), both(ctx, scenes.sphere_scene(20.0))
+        qa, qb, centre_b = (0, 0, 0, 1), (0, 0, 0, 1), [0.0, 90.0, 0.0]
+    qa, qb = np.asarray(qa, np.float32), np.asarray(qb, np.float32)
+    ca = centre_of(A).astype(np.float64) * (0.5 if case == "rotated_mixed_extents" else 1.0)
+    cb = centre_of(B).astype(np.float64)
+    ta = (ca - rot64(qa, np.zeros(3))).astype(np.float32)  # A's centre at the world origin
+    tb = (cb - rot64(qb, np.asarray(centre_b, dtype=np.float64))).astype(np.float32)
+    ra, rb = absorb_mutual_both(A, GA, qa, ta, B, GB, qb, tb, smooth)
+    if case == "apart":
+        assert ra["touched_chunks"] == 0 and rb["touched_chunks"] == 0
+    else:
+        assert ra["emptied_voxels"] > 500 and rb["emptied_voxels"] > 500
+    if case == "small_inside_big":
+        assert GB.count_regions() == 0  # (emptied, not void: the distances just outside the new surface are small)
+    GA.close()
+    GB.close()
+
+
+def test_mutual_absorption_with_materials(ctx):
+    """non-uniform densities on both sides: the removed moments are the inertial property updaters' (remove_voxel per emptied voxel)"""
+    rng = np.random.default_rng(21)
+    objs = []
+    for seed, cc, r in ((1, (3, 3, 3), 19.0), (2, (2, 2, 2), 13.0)):
+        n = cc[0] * 16
+        x, y, z = np.meshgrid(*[np.arange(n) + 0.5] * 3, indexing="ij")
+        d = np.sqrt((x - n / 2) ** 2 + (y - n / 2) ** 2 + (z - n / 2) ** 2) - r
+        sd = np.clip(np.trunc(d.astype(np.float32) * np.float32(50.0)), -128, 127).astype(np.int8)
+        ty = ((np.floor(x / 8) + np.floor(y / 8) * seed).astype(np.int64) % 3).astype(np.uint8)
+        ty[sd >= 0] = 255
+        sdt, tyt = ol.dense_to_tiled(sd), ol.dense_to_tiled(ty)
+        o = ol.OracleObject.from_dense(cc, sdt, tyt)
+        g = VoxelObject.from_dense(ctx, cc, sdt, tyt)
+        o.update_occupied_voxel_ranges()
+        o.compute_all_derived_state()
+        g.compute_all_derived_state()
+        g.update_occupied_voxel_ranges()
+        g.label_regions()
+        objs.append((o, g))
+    (A, GA), (B, GB) = objs
+    da, db = rng.uniform(0.5, 3.0, 256).astype(np.float32), rng.uniform(0.5, 3.0, 256).astype(np.float32)
+    qa = np.array([0, 0, 0, 1], np.float32)
+    qb = np.array([0.0, 0.0, np.sin(0.25), np.cos(0.25)], np.float32)
+    ta = np.array([24.0, 24.0, 24.0], np.float32)
+    tb = (np.array([16.0, 16.0, 16.0]) - rot64(qb, np.array([20.0, 14.0, -3.0]))).astype(np.float32)
+    ra, rb = absorb_mutual_both(A, GA, qa, ta, B, GB, qb, tb, 1.0, da, db)
+    assert ra["emptied_voxels"] > 300 and rb["emptied_voxels"] > 300
+    GA.close()
+    GB.close()
