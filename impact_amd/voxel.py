@@ -259,7 +259,10 @@ class VoxelObject:
         return self._region_count
 
     def is_effectively_empty(self) -> bool:
-        return self.count_regions() == 0
+        """`VoxelObject::is_effectively_empty` (object.rs:803-845): fewer than NON_EMPTY_VOXEL_THRESHOLD = 8 non-empty voxels"""
+        if self.count_regions() == 0:
+            return True
+        return int(self.describe_regions()["voxel_count"].sum()) < 8
 
     def region_labels(self) -> np.ndarray:
         out = np.empty(self.n_voxels, dtype=np.uint32)

@@ -396,6 +396,38 @@ typedef struct {
     uint32_t reserved[3];
 } ivx_physics_result;
 
+/* ---- a14: rigid bodies after voxels were removed (impact_voxel/src/interaction.rs:224-602) ----------------------------------------------
+ * Host arithmetic, O(1) per object. `moments` are the ten f64 moments of a VoxelObjectInertialPropertyManager about the object's grid origin
+ * (ivx_moments.m64 / ivx_region_desc.moments: mass, first moments, moments of inertia, products xy, yz, zx).
+ * apply_updated_inertial_properties_to_rigid_body (interaction.rs:405-458; preserve_momentum = 1: ..._preserving_momentum, 460-487): new mass and
+ * inertia tensor, position moved by the rotated shift of the local centre of mass, momenta re-synchronised for v + w x shift and the unchanged
+ * angular velocity. */
+int ivx_apply_updated_inertial_properties(ivx_rigid_body* body, const double moments[10], const float original_local_center_of_mass[3],
+                                          int preserve_momentum, float new_local_center_of_mass[3]);
+/* determine_extracted_voxel_object_dynamics (interaction.rs:503-585): `moments` in = the fragment's moments in the PARENT's grid frame (what
+ * ivx_split_off_smallest_region reports in `moved`), out = about the fragment's own grid origin (offset_reference_point_by, object/inertia.rs:257-267);
+ * fragment_body = DynamicRigidBody::new(mass, inertia, position of its own centre of mass, parent orientation, v + w x shift, w). */
+int ivx_extracted_object_dynamics(double moments[10], const uint32_t origin_offset_in_parent[3], float voxel_extent,
+                                  const float original_local_center_of_mass[3], const ivx_rigid_body* parent_body, ivx_rigid_body* fragment_body,
+                                  float new_local_center_of_mass[3]);
+typedef struct {
+    ivx_grid* grid; /* the new object; the caller destroys it */
+    uint32_t origin_offset_in_parent[3];
+    uint32_t reserved;
+    ivx_rigid_body body;
+    double moments[10]; /* its inertial property manager, about its own grid origin */
+    float local_center_of_mass[3];
+    float reserved2;
+} ivx_extracted_object;
+/* handle_voxel_object_after_removing_voxels (interaction.rs:224-403) without the anchor bookkeeping: while the object has disconnected regions the
+ * smallest is split off (ivx_split_off_smallest_region), its moments leave `moments` and, if it is a new object, it gets its rigid body from the
+ * parent body's state BEFORE this call; finally the parent body takes the remaining inertial properties (momentum re-synchronised unless
+ * removed_mass_destroyed is set and nothing was split off). `moments` in = the object's manager after the removal that triggered the call.
+ * original_object_empty = the object has fewer than 8 non-empty voxels left (is_effectively_empty, object.rs:803-845); its body is then left as is. */
+int ivx_handle_voxel_object_after_removing_voxels(ivx_grid*, const float densities[256], double moments[10], ivx_rigid_body* body,
+                                                  const float original_local_center_of_mass[3], int removed_mass_destroyed, ivx_extracted_object* out,
+                                                  size_t cap, size_t* n_out, int* original_object_empty, float new_local_center_of_mass[3]);
+
 /* RigidBodyManager + ConstraintManager of one simulation (src/rigid_body.rs:71-78, src/constraint.rs:33-39) */
 typedef struct ivx_world ivx_world;
 int ivx_world_create(ivx_ctx*, const ivx_solver_config*, ivx_world** out);

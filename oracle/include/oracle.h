@@ -131,6 +131,14 @@ typedef struct {
 orc_physics* orc_physics_create(void);
 void orc_physics_free(orc_physics*);
 void orc_physics_set_config(orc_physics*, const orc_solver_config*);
+/* a14: rigid bodies after voxel removal (impact_voxel/src/interaction.rs:405-602). moments = 10 f32 of a VoxelObjectInertialPropertyManager:
+ * mass, first moments, moments of inertia, products of inertia (xy, yz, zx) about the grid origin */
+void orc_offset_reference_point(float moments[10], const float offset[3]); /* object/inertia.rs:257-267 */
+void orc_apply_updated_inertial_properties(orc_rigid_body* body, const float moments[10], const float original_local_com[3], int preserve_momentum,
+                                           float new_local_com[3]);
+void orc_extracted_object_dynamics(float moments[10], const int origin_offset_in_parent[3], float voxel_extent, const float original_local_com[3],
+                                   const orc_rigid_body* parent, orc_rigid_body* fragment, float new_local_com[3]);
+
 void orc_physics_set_bodies(orc_physics*, const orc_rigid_body* dyn, int n_dyn, const orc_kinematic_body* kin, int n_kin);
 void orc_physics_get_bodies(const orc_physics*, orc_rigid_body* dyn, orc_kinematic_body* kin);
 void orc_rigid_body_new(orc_rigid_body* out, float mass, const float inertia[9], const float inv_inertia[9], const float position[3],

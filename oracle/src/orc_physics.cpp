@@ -369,6 +369,80 @@ void orc_rigid_body_motion(const orc_rigid_body* b, float velocity[3], float ang
     st3(angular_velocity, angvel_vector(body_angular_velocity(*b)));
 }
 
+// ---- a14: re-seating rigid bodies after voxels were removed (impact_voxel/src/interaction.rs:405-602) ---------------------------------
+// VoxelObjectInertialPropertyManager::offset_reference_point_by (object/inertia.rs:257-267) with
+// InertiaTensor::compute_delta_to_moments_and_products_of_inertia_defined_relative_to_point (impact_physics/src/inertia.rs:531-587)
+void orc_offset_reference_point(float m[10], const float offset[3]) {
+    const float mass = m[0];
+    const V3 off = ld3(offset);
+    const V3 com = div_recip(v3(m[1], m[2], m[3]), mass);  // derive_center_of_mass: Vector3 / f32
+    auto to_com = [&](V3 d, V3& moi, V3& poi) {
+        const V3 sq = cmul(d, d);
+        moi = (-mass) * (v3(sq.y, sq.z, sq.x) + v3(sq.z, sq.x, sq.y));
+        poi = (-mass) * cmul(d, v3(d.y, d.z, d.x));
+    };
+    V3 moi1, poi1, moi2, poi2;
+    to_com(com, moi1, poi1);
+    to_com(off - com, moi2, poi2);  // compute_delta_from_com_...: the negated deltas
+    const V3 moi = moi1 + (-moi2), poi = poi1 + (-poi2);
+    const V3 mom = v3(m[1], m[2], m[3]) - off * mass;
+    m[1] = mom.x, m[2] = mom.y, m[3] = mom.z;
+    m[4] += moi.x, m[5] += moi.y, m[6] += moi.z;
+    m[7] += poi.x, m[8] += poi.y, m[9] += poi.z;
+}
+
+// apply_updated_inertial_properties_to_rigid_body (interaction.rs:405-458) / ..._preserving_momentum (460-487): moments = the object's
+// inertial property manager (about its grid origin) after the removal
+void orc_apply_updated_inertial_properties(orc_rigid_body* b, const float moments[10], const float original_local_com[3], int preserve_momentum,
+                                           float new_local_com[3]) {
+    const V3 pos = ld3(b->position);
+    const Quat q = ldq(b->orientation);
+    const V3 vel = body_velocity(*b);
+    const AngVel av = body_angular_velocity(*b);
+    float ip[22];
+    orc_derive_inertial_properties(moments, ip);  // object/inertia.rs:288-326
+    const V3 com = v3(ip[1], ip[2], ip[3]);
+    const V3 local_disp = com - ld3(original_local_com);
+    const V3 world_disp = qrot(q, local_disp);
+    b->mass = ip[0];
+    std::memcpy(b->inertia, ip + 4, 36);
+    std::memcpy(b->inv_inertia, ip + 13, 36);
+    st3(b->position, pos + world_disp);
+    if (!preserve_momentum) {
+        const V3 dv = cross(angvel_vector(av), world_disp);
+        st3(b->momentum, (vel + dv) * b->mass);  // synchronize_momentum
+        st3(b->angular_momentum, mul(rotated(ldm(b->inertia), q), angvel_vector(av)));  // synchronize_angular_momentum
+    }
+    st3(new_local_com, com);
+}
+
+// determine_extracted_voxel_object_dynamics (interaction.rs:503-585): moments = the fragment's inertial property manager in the PARENT's grid
+// frame (what the property transferrer filled); on return they are about the fragment's own grid origin
+void orc_extracted_object_dynamics(float moments[10], const int origin_offset_in_parent[3], float voxel_extent, const float original_local_com[3],
+                                   const orc_rigid_body* parent, orc_rigid_body* fragment, float new_local_com[3]) {
+    const V3 pos = ld3(parent->position);
+    const Quat q = ldq(parent->orientation);
+    const V3 vel = body_velocity(*parent);
+    const AngVel av = body_angular_velocity(*parent);
+    const V3 local_disp = div_recip(v3(moments[1], moments[2], moments[3]), moments[0]) - ld3(original_local_com);
+    const V3 world_disp = qrot(q, local_disp);
+    const V3 dv = cross(angvel_vector(av), world_disp);
+    const float off[3] = {(float)origin_offset_in_parent[0] * voxel_extent, (float)origin_offset_in_parent[1] * voxel_extent,
+                          (float)origin_offset_in_parent[2] * voxel_extent};
+    orc_offset_reference_point(moments, off);
+    float ip[22];
+    orc_derive_inertial_properties(moments, ip);  // object/inertia.rs:288-326
+    std::memset(fragment, 0, sizeof(*fragment));
+    fragment->mass = ip[0];  // DynamicRigidBody::new (rigid_body.rs:413-441)
+    std::memcpy(fragment->inertia, ip + 4, 36);
+    std::memcpy(fragment->inv_inertia, ip + 13, 36);
+    st3(fragment->position, pos + world_disp);
+    stq(fragment->orientation, q);
+    st3(fragment->momentum, (vel + dv) * fragment->mass);
+    st3(fragment->angular_momentum, mul(rotated(ldm(fragment->inertia), q), angvel_vector(av)));
+    st3(new_local_com, v3(ip[1], ip[2], ip[3]));
+}
+
 // collision/collidable/sphere.rs:105-160. Returns 1 and fills position/normal/depth on contact.
 int orc_sphere_sphere_contact(const float ca[3], float ra, const float cb[3], float rb, float position[3], float normal[3], float* depth) {
     V3 d = ld3(ca) - ld3(cb);

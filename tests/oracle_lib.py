@@ -96,6 +96,12 @@ def lib():
         L.orc_capsule_voxel_object_contacts.argtypes = [vp, vp, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, vp]
         L.orc_plane_voxel_object_contacts.restype = C.c_int
         L.orc_plane_voxel_object_contacts.argtypes = [vp, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, vp]
+        L.orc_offset_reference_point.restype = None
+        L.orc_offset_reference_point.argtypes = [vp, vp]
+        L.orc_apply_updated_inertial_properties.restype = None
+        L.orc_apply_updated_inertial_properties.argtypes = [vp, vp, vp, C.c_int, vp]
+        L.orc_extracted_object_dynamics.restype = None
+        L.orc_extracted_object_dynamics.argtypes = [vp, vp, C.c_float, vp, vp, vp, vp]
         L.orc_absorb_mutual.restype = None
         L.orc_absorb_mutual.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
         L.orc_absorb_capsule.restype = C.c_int
@@ -421,6 +427,35 @@ class OracleObject:
         lab = np.empty((cc[0] * 16, cc[1] * 16, cc[2] * 16), dtype=np.uint32) if want_labels else None
         n = lib().orc_region_labels(self.h, _p(lab))
         return int(n), lab
+
+
+# ---- a14: rigid bodies after voxel removal (impact_voxel/src/interaction.rs:405-602) ------------------------------------------------
+def offset_reference_point(moments32, offset):
+    m = np.ascontiguousarray(moments32, dtype=np.float32).copy()
+    lib().orc_offset_reference_point(_p(m), _p(np.ascontiguousarray(offset, dtype=np.float32)))
+    return m
+
+
+def apply_updated_inertial_properties(body, moments32, original_local_com, preserve_momentum=False):
+    from impact_amd.capi import RIGID_BODY_DTYPE
+
+    b = np.ascontiguousarray(body, dtype=RIGID_BODY_DTYPE).reshape(1).copy()
+    com = np.zeros(3, dtype=np.float32)
+    lib().orc_apply_updated_inertial_properties(_p(b), _p(np.ascontiguousarray(moments32, dtype=np.float32)),
+                                                _p(np.ascontiguousarray(original_local_com, dtype=np.float32)), 1 if preserve_momentum else 0, _p(com))
+    return b[0], com
+
+
+def extracted_object_dynamics(moments32_in_parent_frame, origin_offset_in_parent, voxel_extent, original_local_com, parent_body):
+    from impact_amd.capi import RIGID_BODY_DTYPE
+
+    m = np.ascontiguousarray(moments32_in_parent_frame, dtype=np.float32).copy()
+    pb = np.ascontiguousarray(parent_body, dtype=RIGID_BODY_DTYPE).reshape(1)
+    fb = np.zeros(1, dtype=RIGID_BODY_DTYPE)
+    com = np.zeros(3, dtype=np.float32)
+    lib().orc_extracted_object_dynamics(_p(m), _p(np.ascontiguousarray(origin_offset_in_parent, dtype=np.int32)), voxel_extent,
+                                        _p(np.ascontiguousarray(original_local_com, dtype=np.float32)), _p(pb), _p(fb), _p(com))
+    return fb[0], m, com
 
 
 def sdf_compile(graph):
