@@ -72,6 +72,11 @@ void orc_export_sparse(const orc_object*, int32_t* data_offsets, uint8_t* voxels
 
 /* mesh ------------------------------------------------------------------------------------- */
 orc_mesh* orc_mesh_recreate(const orc_object*);
+/* VoxelObjectMesh::sync_with_voxel_object (mesh.rs:355-456): re-mesh the invalidated chunks (one byte per chunk), reusing freed buffer ranges
+ * through the ChunkSubmeshManager (mesh.rs:699-849) and its RangeAllocators; chunks are visited in chunk-linear order (the reference's hash-set
+ * order is unpinned). Buffers only grow; submeshes keep the manager's slot order. */
+void orc_mesh_sync(orc_mesh*, const orc_object*, const uint8_t* invalidated_chunks);
+void orc_range_allocator_script(const int64_t* ops, int n_ops, int64_t* results);
 void orc_mesh_counts(const orc_mesh*, uint32_t out[3]); /* vertices, indices, submeshes */
 /* submeshes: 16 u32 each = chunk[3], index_offset, index_count, obscured[8], vertex_offset, vertex_count, 0 */
 void orc_mesh_get(const orc_mesh*, float* positions, float* normals, uint32_t* indices, uint8_t* index_materials, uint32_t* submeshes);

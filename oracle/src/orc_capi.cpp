@@ -286,6 +286,23 @@ orc_mesh* orc_mesh_recreate(const orc_object* o) {
     mesh_recreate(o->obj, m->mesh);
     return m;
 }
+// VoxelObjectMesh::sync_with_voxel_object (mesh.rs:355-456)
+void orc_mesh_sync(orc_mesh* m, const orc_object* o, const uint8_t* invalidated_chunks) { mesh_sync(o->obj, m->mesh, invalidated_chunks); }
+// RangeAllocator (impact_containers/src/range_allocator.rs) driven by a script: ops = triples (0 free a b | 1 allocate len _ | 2 merge _ _);
+// results: two values per op (allocate: start, end or -1, -1; others 0, 0)
+void orc_range_allocator_script(const int64_t* ops, int n_ops, int64_t* results) {
+    RangeAllocator a;
+    for (int i = 0; i < n_ops; ++i) {
+        const int64_t* op = ops + 3 * i;
+        results[2 * i] = results[2 * i + 1] = 0;
+        if (op[0] == 0) a.free_range((size_t)op[1], (size_t)op[2]);
+        else if (op[0] == 1) {
+            size_t s0;
+            if (a.allocate_range((size_t)op[1], s0)) results[2 * i] = (int64_t)s0, results[2 * i + 1] = (int64_t)(s0 + (size_t)op[1]);
+            else results[2 * i] = results[2 * i + 1] = -1;
+        } else a.merge_consecutive_ranges();
+    }
+}
 void orc_mesh_counts(const orc_mesh* m, uint32_t out[3]) {
     out[0] = (uint32_t)m->mesh.positions.size();
     out[1] = (uint32_t)m->mesh.indices.size();

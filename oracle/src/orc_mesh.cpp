@@ -9,6 +9,8 @@
 //   ChunkSubmesh obscuredness table                 mesh.rs:611-635
 #include "orc_mesh.hpp"
 
+#include <algorithm>
+#include <cstdint>
 #include <cstring>
 
 namespace orc {
@@ -260,6 +262,51 @@ bool chunk_sdf_if_exposed(const VoxelObject& obj, int ci, int cj, int ck, float*
     return true;
 }
 
+bool RangeAllocator::allocate_range(size_t required_len, size_t& start) {  // range_allocator.rs:43-72: the smallest free range that fits, first on ties
+    auto best = free_ranges.end();
+    size_t best_len = SIZE_MAX;
+    for (auto it = free_ranges.begin(); it != free_ranges.end(); ++it) {
+        const size_t len = it->second - it->first;
+        if (len < best_len && len >= required_len) {
+            best = it;
+            best_len = len;
+        }
+    }
+    if (best == free_ranges.end()) return false;
+    const size_t s0 = best->first, e0 = best->second;
+    free_ranges.erase(best);
+    if (s0 + required_len < e0) free_ranges.emplace(s0 + required_len, e0);
+    start = s0;
+    return true;
+}
+
+void RangeAllocator::merge_consecutive_ranges() {  // range_allocator.rs:74-108: every run of touching ranges becomes one range
+    if (free_ranges.size() < 2) return;
+    std::map<size_t, size_t> merged;
+    auto it = free_ranges.begin();
+    size_t s0 = it->first, e0 = it->second;
+    for (++it; it != free_ranges.end(); ++it) {
+        if (it->first == e0) {
+            e0 = it->second;
+        } else {
+            merged.emplace(s0, e0);
+            s0 = it->first;
+            e0 = it->second;
+        }
+    }
+    merged.emplace(s0, e0);
+    free_ranges.swap(merged);
+}
+
+static inline uint64_t chunk_key(uint32_t i, uint32_t j, uint32_t k) { return ((uint64_t)i << 42) | ((uint64_t)j << 21) | (uint64_t)k; }
+
+static void obscured_table(uint8_t flags, uint32_t out[2][2][2]) {  // ChunkSubmesh::new (mesh.rs:611-635)
+    const uint8_t OX[2] = {CF_OBSC_X_DN, CF_OBSC_X_UP}, OY[2] = {CF_OBSC_Y_DN, CF_OBSC_Y_UP}, OZ[2] = {CF_OBSC_Z_DN, CF_OBSC_Z_UP};
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
+            for (int cc = 0; cc < 2; ++cc) out[a][b][cc] = ((flags & OX[a]) && (flags & OY[b]) && (flags & OZ[cc])) ? 1u : 0u;
+}
+
 // mesh.rs:286-354
 void mesh_recreate(const VoxelObject& obj, Mesh& mesh) {
     mesh = Mesh{};
@@ -287,17 +334,100 @@ void mesh_recreate(const VoxelObject& obj, Mesh& mesh) {
                 sm.index_count = (uint32_t)buf.indices.size();
                 sm.vertex_offset = voff;
                 sm.vertex_count = (uint32_t)buf.positions.size();
-                const uint8_t OX[2] = {CF_OBSC_X_DN, CF_OBSC_X_UP}, OY[2] = {CF_OBSC_Y_DN, CF_OBSC_Y_UP}, OZ[2] = {CF_OBSC_Z_DN, CF_OBSC_Z_UP};
-                for (int a = 0; a < 2; ++a)
-                    for (int b = 0; b < 2; ++b)
-                        for (int cc = 0; cc < 2; ++cc)
-                            sm.obscured[a][b][cc] = ((c.flags & OX[a]) && (c.flags & OY[b]) && (c.flags & OZ[cc])) ? 1u : 0u;
+                obscured_table(c.flags, sm.obscured);
+                mesh.chunk_index[chunk_key(sm.chunk[0], sm.chunk[1], sm.chunk[2])] = mesh.submeshes.size();  // push_chunk
                 mesh.submeshes.push_back(sm);
                 mesh.positions.insert(mesh.positions.end(), buf.positions.begin(), buf.positions.end());
                 mesh.normals.insert(mesh.normals.end(), buf.normals.begin(), buf.normals.end());
                 mesh.index_materials.insert(mesh.index_materials.end(), buf.imats.begin(), buf.imats.end());
                 for (uint16_t ix : buf.indices) mesh.indices.push_back(voff + (uint32_t)ix);
             }
+}
+
+static void remove_chunk_if_present(Mesh& mesh, uint64_t key) {  // mesh.rs:811-824 (swap_remove keeps the tables dense)
+    auto it = mesh.chunk_index.find(key);
+    if (it == mesh.chunk_index.end()) return;
+    const size_t idx = it->second;
+    mesh.chunk_index.erase(it);
+    const Submesh gone = mesh.submeshes[idx];
+    if (idx + 1 != mesh.submeshes.size()) {
+        mesh.submeshes[idx] = mesh.submeshes.back();
+        const Submesh& moved = mesh.submeshes[idx];
+        mesh.chunk_index[chunk_key(moved.chunk[0], moved.chunk[1], moved.chunk[2])] = idx;
+    }
+    mesh.submeshes.pop_back();
+    mesh.vertex_ranges.free_range(gone.vertex_offset, (size_t)gone.vertex_offset + gone.vertex_count);
+    mesh.index_ranges.free_range(gone.index_offset, (size_t)gone.index_offset + gone.index_count);
+}
+
+// mesh.rs:355-456 with ChunkSubmeshManager::write_chunk (mesh.rs:751-809). ORDER: the reference walks a hash set of chunk indices (unpinned
+// iteration order, it decides which freed range a chunk's data lands in); here the invalidated chunks are visited in chunk-linear order.
+void mesh_sync(const VoxelObject& obj, Mesh& mesh, const uint8_t* invalidated) {
+    static thread_local ChunkSdf sdf;
+    static thread_local SurfaceNetsBuffer buf;
+    std::memset(sdf.types, TYPE_DUMMY, sizeof(sdf.types));
+    for (int i = 0; i < GCELLS; ++i) sdf.values[i] = 0.0f;
+    const float chunk_extent = (float)CHUNK * obj.extent;
+    for (int ci = 0; ci < obj.cc[0]; ++ci)
+        for (int cj = 0; cj < obj.cc[1]; ++cj)
+            for (int ck = 0; ck < obj.cc[2]; ++ck) {
+                if (!invalidated[obj.cidx(ci, cj, ck)]) continue;
+                const Chunk& c = obj.chunks[obj.cidx(ci, cj, ck)];
+                const uint64_t key = chunk_key((uint32_t)ci, (uint32_t)cj, (uint32_t)ck);
+                if (!(c.kind == K_NONUNIFORM && (c.flags & CF_FULLY_OBSCURED) != CF_FULLY_OBSCURED)) {
+                    remove_chunk_if_present(mesh, key);
+                    continue;
+                }
+                fill_sdf(obj, ci, cj, ck, sdf);
+                const V3 offset = v3((float)ci * chunk_extent - 0.5f * obj.extent, (float)cj * chunk_extent - 0.5f * obj.extent,
+                                     (float)ck * chunk_extent - 0.5f * obj.extent);
+                compute_surface_nets_mesh(sdf, obj.extent, offset, buf);
+                if (buf.indices.empty()) {
+                    remove_chunk_if_present(mesh, key);
+                    continue;
+                }
+                const size_t total_v = mesh.positions.size(), total_i = mesh.indices.size();
+                const size_t nv = buf.positions.size(), ni = buf.indices.size();
+                // write_chunk
+                auto it = mesh.chunk_index.find(key);
+                if (it != mesh.chunk_index.end()) {
+                    const Submesh& old = mesh.submeshes[it->second];
+                    mesh.vertex_ranges.free_range(old.vertex_offset, (size_t)old.vertex_offset + old.vertex_count);
+                    mesh.index_ranges.free_range(old.index_offset, (size_t)old.index_offset + old.index_count);
+                }
+                size_t v0, i0;
+                if (!mesh.vertex_ranges.allocate_range(nv, v0)) v0 = total_v;
+                if (!mesh.index_ranges.allocate_range(ni, i0)) i0 = total_i;
+                Submesh sm{};
+                sm.chunk[0] = (uint32_t)ci, sm.chunk[1] = (uint32_t)cj, sm.chunk[2] = (uint32_t)ck;
+                sm.index_offset = (uint32_t)i0;
+                sm.index_count = (uint32_t)ni;
+                sm.vertex_offset = (uint32_t)v0;
+                sm.vertex_count = (uint32_t)nv;
+                obscured_table(c.flags, sm.obscured);
+                if (it != mesh.chunk_index.end()) {
+                    mesh.submeshes[it->second] = sm;
+                } else {
+                    mesh.chunk_index[key] = mesh.submeshes.size();
+                    mesh.submeshes.push_back(sm);
+                }
+                if (v0 == total_v) {
+                    mesh.positions.insert(mesh.positions.end(), buf.positions.begin(), buf.positions.end());
+                    mesh.normals.insert(mesh.normals.end(), buf.normals.begin(), buf.normals.end());
+                } else {
+                    std::copy(buf.positions.begin(), buf.positions.end(), mesh.positions.begin() + (std::ptrdiff_t)v0);
+                    std::copy(buf.normals.begin(), buf.normals.end(), mesh.normals.begin() + (std::ptrdiff_t)v0);
+                }
+                if (i0 == total_i) {
+                    mesh.index_materials.insert(mesh.index_materials.end(), buf.imats.begin(), buf.imats.end());
+                    for (uint16_t ix : buf.indices) mesh.indices.push_back((uint32_t)v0 + (uint32_t)ix);
+                } else {
+                    std::copy(buf.imats.begin(), buf.imats.end(), mesh.index_materials.begin() + (std::ptrdiff_t)i0);
+                    for (size_t q = 0; q < ni; ++q) mesh.indices[i0 + q] = (uint32_t)v0 + (uint32_t)buf.indices[q];
+                }
+            }
+    mesh.vertex_ranges.merge_consecutive_ranges();  // perform_maintainance
+    mesh.index_ranges.merge_consecutive_ranges();
 }
 
 }  // namespace orc

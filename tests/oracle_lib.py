@@ -102,6 +102,10 @@ def lib():
         L.orc_apply_updated_inertial_properties.argtypes = [vp, vp, vp, C.c_int, vp]
         L.orc_extracted_object_dynamics.restype = None
         L.orc_extracted_object_dynamics.argtypes = [vp, vp, C.c_float, vp, vp, vp, vp]
+        L.orc_mesh_sync.restype = None
+        L.orc_mesh_sync.argtypes = [vp, vp, vp]
+        L.orc_range_allocator_script.restype = None
+        L.orc_range_allocator_script.argtypes = [vp, C.c_int, vp]
         L.orc_absorb_mutual.restype = None
         L.orc_absorb_mutual.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
         L.orc_absorb_capsule.restype = C.c_int
@@ -168,6 +172,49 @@ class OracleMesh:
     def __init__(self, positions, normals, indices, index_materials, submeshes):
         self.positions, self.normals, self.indices = positions, normals, indices
         self.index_materials, self.submeshes = index_materials, submeshes
+
+
+class OracleMeshHandle:
+    """a VoxelObjectMesh that stays alive: recreate once, then sync_with_voxel_object after edits (mesh.rs:286-456)"""
+
+    def __init__(self, obj: "OracleObject"):
+        self.obj = obj
+        self.h = C.c_void_p(lib().orc_mesh_recreate(obj.h))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_mesh_free(self.h)
+            self.h = None
+
+    def sync(self, invalidated):
+        inv = np.ascontiguousarray(invalidated, dtype=np.uint8)
+        lib().orc_mesh_sync(self.h, self.obj.h, _p(inv))
+
+    def get(self) -> "OracleMesh":
+        L = lib()
+        cnt = np.zeros(3, dtype=np.uint32)
+        L.orc_mesh_counts(self.h, _p(cnt))
+        nv, ni, ns = (int(x) for x in cnt)
+        pos = np.empty((nv, 3), dtype=np.float32)
+        nrm = np.empty((nv, 3), dtype=np.float32)
+        idx = np.empty(ni, dtype=np.uint32)
+        im = np.empty((ni, 8), dtype=np.uint8)
+        sub = np.empty((ns, 16), dtype=np.uint32)
+        L.orc_mesh_get(self.h, _p(pos), _p(nrm), _p(idx), _p(im), _p(sub))
+        return OracleMesh(pos, nrm, idx, im, sub)
+
+
+def range_allocator_script(ops):
+    """ops: list of ("free", a, b) | ("alloc", n) | ("merge",) -> list of results (alloc: (start, end) or None)"""
+    code = {"free": 0, "alloc": 1, "merge": 2}
+    arr = np.zeros((len(ops), 3), dtype=np.int64)
+    for i, op in enumerate(ops):
+        arr[i, 0] = code[op[0]]
+        for k, v in enumerate(op[1:]):
+            arr[i, 1 + k] = v
+    res = np.zeros((len(ops), 2), dtype=np.int64)
+    lib().orc_range_allocator_script(_p(arr), len(ops), _p(res))
+    return [((int(r[0]), int(r[1])) if r[0] >= 0 else None) if op[0] == "alloc" else None for op, r in zip(ops, res)]
 
 
 class OracleObject:
