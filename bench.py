@@ -207,29 +207,35 @@ def edit_benchmark(ctx, scale, reps=5):
     the derived-state + region refresh of the whole object, results back on the host), then the full remesh the bite invalidates.
     Each repetition starts from the freshly generated body."""
     from impact_amd import capi, scenes
-    from impact_amd.voxel import SDFVoxelGenerator, VoxelObject
+    from impact_amd.voxel import SDFVoxelGenerator, VoxelObject, VoxelObjectMesh
 
     gen = SDFVoxelGenerator(1.0, scenes.asteroid_scene(scale), 0)
     obj = VoxelObject(ctx, gen.chunk_counts(), 1.0)
     obj.set_sdf_program(gen)
     obj.set_densities(np.ones(256, dtype=np.float32))
-    t_edit, t_remesh, emptied, touched = [], [], 0, 0
+    mesh = VoxelObjectMesh(obj)
+    t_edit, t_remesh, t_sync, emptied, touched, invalidated = [], [], [], 0, 0, 0
     for _ in range(reps + 1):
         obj.step(capi.STAGE_ALL)
         c = np.array([0.5 * (a + b) for a, b in obj.update_occupied_voxel_ranges()], dtype=np.float32) + EDIT_OFFSET * np.float32(scale)
+        mesh.sync_with_voxel_object(np.zeros(obj.n_chunks, dtype=np.uint8))  # (the submesh bookkeeping of the fresh mesh, once per full remesh)
         ctx.synchronize()
         t0 = time.perf_counter()
-        r = obj.absorb_sphere(c, EDIT_RADIUS * scale + 2.0, EDIT_RADIUS * scale, want_invalidated=False)
+        r = obj.absorb_sphere(c, EDIT_RADIUS * scale + 2.0, EDIT_RADIUS * scale, want_invalidated=True)
         t1 = time.perf_counter()
-        obj.step(capi.STAGE_REMESH)
+        mesh.sync_with_voxel_object(r["invalidated"])  # the incremental remesh of the invalidated chunks (mesh.rs:355-456) ...
         t2 = time.perf_counter()
+        obj.step(capi.STAGE_REMESH)  # ... and the full one, for comparison
+        t3 = time.perf_counter()
         t_edit.append(t1 - t0)
-        t_remesh.append(t2 - t1)
-        emptied, touched = r["emptied_voxels"], r["touched_chunks"]
+        t_sync.append(t2 - t1)
+        t_remesh.append(t3 - t2)
+        emptied, touched, invalidated = r["emptied_voxels"], r["touched_chunks"], int(r["invalidated"].sum())
     obj.close()
     out = {"workload": f"absorbing sphere r={EDIT_RADIUS * scale:.1f} voxels at the surface of the N=1 body",
            "edit_ms": round(1e3 * float(np.mean(t_edit[1:])), 4), "remesh_after_ms": round(1e3 * float(np.mean(t_remesh[1:])), 4),
-           "emptied_voxels": emptied, "touched_chunks": touched}
+           "sync_after_ms": round(1e3 * float(np.mean(t_sync[1:])), 4), "emptied_voxels": emptied, "touched_chunks": touched,
+           "invalidated_chunks": invalidated}
     if _CPU_EDIT is not None:
         out["cpu_baseline"] = dict(_CPU_EDIT)
         out["cpu_baseline"]["parity"] = "same emptied voxel count" if _CPU_EDIT["emptied_voxels"] == emptied else "MISMATCH"

@@ -5,6 +5,8 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <unordered_map>
 #include <new>
 #include <vector>
 
@@ -33,6 +35,7 @@ int ensure_host_scratch(ivx_grid* g, size_t bytes) {
     if (g->host_scratch_bytes >= bytes) return IVX_OK;
     if (g->host_scratch) (void)hipHostFree(g->host_scratch);
     if (g->result_host) (void)hipHostFree(g->result_host);
+    ivx_submesh_manager_free(g->submesh_manager);
     g->host_scratch = nullptr;
     g->host_scratch_bytes = 0;
     IVX_HIP_CHECK(hipHostMalloc(&g->host_scratch, bytes, hipHostMallocDefault));
@@ -130,6 +133,113 @@ int ivx_launch_halo_pack(ivx_grid* g, int side, void* buf) {
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
+
+// what the incremental remesh needs to know about the listed chunks: vertex count, index count, kind | flags << 8
+__global__ __launch_bounds__(256) void k_chunk_mesh_needs(uint32_t n, const uint32_t* __restrict__ list, const uint32_t* __restrict__ counts,
+                                                          const ivx_chunk_info* __restrict__ info, uint32_t* __restrict__ out) {
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= n) return;
+    const uint32_t c = list[e];
+    out[3 * e] = counts[2 * (size_t)c];
+    out[3 * e + 1] = counts[2 * (size_t)c + 1];
+    out[3 * e + 2] = (uint32_t)info[c].kind | ((uint32_t)info[c].flags << 8);
+}
+
+// ---- incremental remesh (row a7: VoxelObjectMesh::sync_with_voxel_object, mesh.rs:355-456) ---------------------------------------------
+// Host mirror of the ChunkSubmeshManager (mesh.rs:699-849) with its two RangeAllocators (impact_containers/src/range_allocator.rs): which slot
+// of the submesh table a chunk owns and which ranges of the vertex / index buffers are free. The mesh data stays in HBM.
+struct ivx_range_allocator {
+    std::map<size_t, size_t> free_ranges;  // start -> end; a second range with the same start is dropped, as BTreeSet::insert does
+    void free_range(size_t a, size_t b) {
+        if (a < b) free_ranges.emplace(a, b);
+    }
+    bool allocate(size_t len, size_t* start) {  // the smallest free range that fits, the first of equals
+        auto best = free_ranges.end();
+        size_t best_len = std::numeric_limits<size_t>::max();
+        for (auto it = free_ranges.begin(); it != free_ranges.end(); ++it) {
+            const size_t l = it->second - it->first;
+            if (l < best_len && l >= len) best = it, best_len = l;
+        }
+        if (best == free_ranges.end()) return false;
+        const size_t a = best->first, b = best->second;
+        free_ranges.erase(best);
+        if (a + len < b) free_ranges.emplace(a + len, b);
+        *start = a;
+        return true;
+    }
+    void merge_consecutive() {
+        if (free_ranges.size() < 2) return;
+        std::map<size_t, size_t> out;
+        auto it = free_ranges.begin();
+        size_t a = it->first, b = it->second;
+        for (++it; it != free_ranges.end(); ++it) {
+            if (it->first == b) b = it->second;
+            else out.emplace(a, b), a = it->first, b = it->second;
+        }
+        out.emplace(a, b);
+        free_ranges.swap(out);
+    }
+};
+struct ivx_submesh_manager {
+    std::vector<ivx_submesh> table;                   // slot order = the reference's chunk_submeshes order
+    std::unordered_map<uint32_t, uint32_t> slot_of;   // linear chunk index -> slot
+    ivx_range_allocator vertices, indices;
+    size_t total_vertices = 0, total_indices = 0;     // buffer lengths (freed ranges inside them stay counted)
+    uint64_t serial = 0;                              // the mesh_serial this state describes
+};
+void ivx_submesh_manager_free(ivx_submesh_manager* m) { delete m; }
+
+namespace {
+uint32_t linear_chunk(const ivx_grid* g, const uint32_t c[3]) { return (c[0] * g->cc[1] + c[1]) * g->cc[2] + c[2]; }
+void manager_remove(ivx_grid* g, ivx_submesh_manager* m, uint32_t chunk) {  // remove_chunk_if_present (mesh.rs:811-824)
+    auto it = m->slot_of.find(chunk);
+    if (it == m->slot_of.end()) return;
+    const uint32_t slot = it->second;
+    m->slot_of.erase(it);
+    const ivx_submesh gone = m->table[slot];
+    if (slot + 1 != m->table.size()) {
+        m->table[slot] = m->table.back();
+        m->slot_of[linear_chunk(g, m->table[slot].chunk_indices)] = slot;
+    }
+    m->table.pop_back();
+    m->vertices.free_range(gone.vertex_offset, (size_t)gone.vertex_offset + gone.vertex_count);
+    m->indices.free_range(gone.index_offset, (size_t)gone.index_offset + gone.index_count);
+}
+// grow the mesh buffers keeping what they hold (the full remesh may simply reallocate, a sync may not)
+template <class T>
+int grow_keep(ivx_grid* g, T** buf, size_t old_count, size_t new_count) {
+    T* fresh = nullptr;
+    int rc = dev_alloc(&fresh, new_count);
+    if (rc) return rc;
+    if (*buf && old_count) IVX_HIP_CHECK(hipMemcpyAsync(fresh, *buf, old_count * sizeof(T), hipMemcpyDeviceToDevice, g->ctx->stream));
+    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    if (*buf) (void)hipFree(*buf);
+    *buf = fresh;
+    return IVX_OK;
+}
+int ensure_mesh_capacity_keep(ivx_grid* g, size_t nv, size_t ni, size_t ns) {
+    int rc;
+    if (nv > g->vcap) {
+        const size_t cap = std::max(nv, g->vcap + g->vcap / 2);
+        if ((rc = grow_keep(g, &g->positions, g->vcap * 3, cap * 3))) return rc;
+        if ((rc = grow_keep(g, &g->normals, g->vcap * 3, cap * 3))) return rc;
+        if ((rc = grow_keep(g, &g->vertex_materials, (size_t)0, cap * 16))) return rc;  // scratch of the emit kernel
+        g->vcap = cap;
+    }
+    if (ni > g->icap) {
+        const size_t cap = std::max(ni, g->icap + g->icap / 2);
+        if ((rc = grow_keep(g, &g->indices, g->icap, cap))) return rc;
+        if ((rc = grow_keep(g, &g->index_materials, g->icap * 8, cap * 8))) return rc;
+        g->icap = cap;
+    }
+    if (ns > g->scap) {
+        const size_t cap = std::max(ns, g->scap + g->scap / 2);
+        if ((rc = grow_keep(g, &g->submeshes, g->scap, cap))) return rc;
+        g->scap = cap;
+    }
+    return IVX_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -277,6 +387,7 @@ int ivx_grid_upload_dense(ivx_grid* g, const int8_t* sdf, const uint8_t* type, s
     if ((rc = h2d(g, g->type, type, g->n_vox))) return rc;
     if ((rc = ivx_launch_classify(g))) return rc;
     g->mesh_valid = 0;
+    g->mesh_built = 0;
     g->regions_valid = 0;
     IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
     return IVX_OK;
@@ -367,6 +478,7 @@ int ivx_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* nodes, size_t n_no
                                shifted_grid_center, voxel_type);
     if (rc) return rc;
     g->mesh_valid = 0;
+    g->mesh_built = 0;
     g->regions_valid = 0;
     IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
     return IVX_OK;
@@ -407,9 +519,132 @@ int ivx_remesh(ivx_grid* g, ivx_mesh_counts* out) {
     g->mesh_counts.n_submeshes = totals[2];
     g->mesh_counts.reserved = 0;
     g->mesh_valid = 1;
+    g->mesh_built = 1;
     g->mesh_serial += 1;
     *out = g->mesh_counts;
     IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    return IVX_OK;
+}
+
+int ivx_mesh_sync(ivx_grid* g, const uint8_t* invalidated_chunks, ivx_mesh_counts* out) {
+    IVX_REQUIRE(g && invalidated_chunks && out, IVX_ERR_INVALID, "ivx_mesh_sync: null argument");
+    IVX_REQUIRE(g->mesh_built, IVX_ERR_STATE, "ivx_mesh_sync: there is no mesh to synchronise (call ivx_remesh first)");
+    IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "ivx_mesh_sync: derived state must be current (the edit ops leave it so)");
+    IVX_REQUIRE(g->x_off == 0 && g->gx == g->cc[0] && !g->has_ghost[0] && !g->has_ghost[1], IVX_ERR_STATE,
+                "ivx_mesh_sync: not available on a slab of a decomposed grid");
+    int rc;
+    if (!g->submesh_manager) g->submesh_manager = new (std::nothrow) ivx_submesh_manager();
+    IVX_REQUIRE(g->submesh_manager, IVX_ERR_HIP, "ivx_mesh_sync: out of host memory");
+    ivx_submesh_manager* m = g->submesh_manager;
+    if (m->serial != g->mesh_serial) {  // the mesh was rebuilt in full since: push_chunk for every submesh, no free ranges (mesh.rs:731-749)
+        m->table.assign(g->mesh_counts.n_submeshes, ivx_submesh{});
+        if ((rc = d2h(g, m->table.data(), g->submeshes, m->table.size() * sizeof(ivx_submesh)))) return rc;
+        m->slot_of.clear();
+        for (uint32_t s = 0; s < m->table.size(); ++s) m->slot_of[linear_chunk(g, m->table[s].chunk_indices)] = s;
+        m->vertices.free_ranges.clear();
+        m->indices.free_ranges.clear();
+        m->total_vertices = g->mesh_counts.n_vertices;
+        m->total_indices = g->mesh_counts.n_indices;
+        m->serial = g->mesh_serial;
+    }
+    // what the invalidated chunks' meshes need now (the count pass of the full remesh) and their records (exposure, obscuredness flags)
+    std::vector<uint32_t> list;
+    for (uint32_t c = 0; c < g->n_chunks; ++c)  // chunk-linear order (the reference walks a hash set: unpinned)
+        if (invalidated_chunks[c]) list.push_back(c);
+    std::vector<uint32_t> needs(3 * list.size());
+    if (!list.empty()) {
+        if ((rc = ivx_launch_sn_count(g))) return rc;
+        const size_t off_out = (list.size() * 4 + 15) & ~(size_t)15;
+        if ((rc = ensure_dev_scratch(g, off_out + needs.size() * 4))) return rc;
+        char* base = static_cast<char*>(g->dev_scratch);
+        IVX_HIP_CHECK(hipMemcpyAsync(base, list.data(), list.size() * 4, hipMemcpyHostToDevice, g->ctx->stream));
+        hipLaunchKernelGGL(k_chunk_mesh_needs, dim3(((uint32_t)list.size() + 255u) / 256u), dim3(256), 0, g->ctx->stream, (uint32_t)list.size(),
+                           reinterpret_cast<const uint32_t*>(base), g->chunk_counts, g->info, reinterpret_cast<uint32_t*>(base + off_out));
+        IVX_HIP_CHECK(hipGetLastError());
+        if ((rc = d2h(g, needs.data(), base + off_out, needs.size() * 4))) return rc;
+    }
+    std::vector<uint32_t> dirty_slots;  // slots of the device table that a removal rewrote (the emit pass writes the others)
+    const size_t table_before = m->table.size();
+    struct Rec {
+        uint32_t chunk, voff, ioff, packed;
+    };
+    std::vector<Rec> recs;
+    std::vector<uint32_t> rec_chunk;
+    for (size_t e = 0; e < list.size(); ++e) {
+        const uint32_t c = list[e];
+        const uint32_t nv = needs[3 * e], ni = needs[3 * e + 1], kind = needs[3 * e + 2] & 0xFFu, flags = (needs[3 * e + 2] >> 8) & 0xFFu;
+        const bool exposed = kind == KIND_NONUNIFORM && (flags & CF_FULLY_OBSCURED) != CF_FULLY_OBSCURED;
+        if (!exposed || ni == 0) {  // no longer exposed, or an empty mesh (mesh.rs:375-379, 447-451)
+            auto gone = m->slot_of.find(c);
+            if (gone != m->slot_of.end()) dirty_slots.push_back(gone->second);  // (the last entry moves here)
+            manager_remove(g, m, c);
+            continue;
+        }
+        // write_chunk (mesh.rs:751-809)
+        auto it = m->slot_of.find(c);
+        if (it != m->slot_of.end()) {
+            const ivx_submesh& old = m->table[it->second];
+            m->vertices.free_range(old.vertex_offset, (size_t)old.vertex_offset + old.vertex_count);
+            m->indices.free_range(old.index_offset, (size_t)old.index_offset + old.index_count);
+        }
+        size_t v0, i0;
+        if (!m->vertices.allocate(nv, &v0)) v0 = m->total_vertices, m->total_vertices += nv;
+        if (!m->indices.allocate(ni, &i0)) i0 = m->total_indices, m->total_indices += ni;
+        IVX_REQUIRE(m->total_vertices < 0xFFFFFFFFull && m->total_indices < 0xFFFFFFFFull, IVX_ERR_CAPACITY, "ivx_mesh_sync: mesh buffers exceed 2^32 elements");
+        ivx_submesh sm;
+        memset(&sm, 0, sizeof(sm));
+        sm.chunk_indices[0] = c / (g->cc[1] * g->cc[2]);
+        sm.chunk_indices[1] = (c / g->cc[2]) % g->cc[1];
+        sm.chunk_indices[2] = c % g->cc[2];
+        sm.index_offset = (uint32_t)i0;
+        sm.index_count = ni;
+        sm.vertex_offset = (uint32_t)v0;
+        sm.vertex_count = nv;
+        for (int a = 0; a < 2; ++a)  // ChunkSubmesh::new (mesh.rs:611-635): bits X_DN 0, Y_DN 1, Z_DN 2, X_UP 3, Y_UP 4, Z_UP 5
+            for (int b = 0; b < 2; ++b)
+                for (int d = 0; d < 2; ++d)
+                    sm.is_obscured_from_direction[a][b][d] =
+                        (((flags >> (3 * a)) & 1u) && ((flags >> (3 * b + 1)) & 1u) && ((flags >> (3 * d + 2)) & 1u)) ? 1u : 0u;
+        if (it != m->slot_of.end()) {
+            m->table[it->second] = sm;
+        } else {
+            m->slot_of[c] = (uint32_t)m->table.size();
+            m->table.push_back(sm);
+        }
+        recs.push_back(Rec{c, (uint32_t)v0, (uint32_t)i0, nv | ((ni / 6u) << 16)});
+        rec_chunk.push_back(c);
+    }
+    m->vertices.merge_consecutive();  // perform_maintainance
+    m->indices.merge_consecutive();
+    if ((rc = ensure_mesh_capacity_keep(g, m->total_vertices, m->total_indices, m->table.size()))) return rc;
+    if (!recs.empty()) {
+        // (slots are final only now: a removal after a write may have moved the written entry)
+        std::vector<uint32_t> slots(recs.size());
+        for (size_t r = 0; r < recs.size(); ++r) slots[r] = m->slot_of.at(rec_chunk[r]);
+        const size_t off_slots = 16 + recs.size() * sizeof(Rec), total = off_slots + recs.size() * 4;
+        if ((rc = ensure_dev_scratch(g, total))) return rc;
+        std::vector<char> stage(total);
+        const uint32_t n = (uint32_t)recs.size();
+        memcpy(stage.data(), &n, 4);
+        memcpy(stage.data() + 16, recs.data(), recs.size() * sizeof(Rec));
+        memcpy(stage.data() + off_slots, slots.data(), slots.size() * 4);
+        if ((rc = h2d(g, g->dev_scratch, stage.data(), total))) return rc;
+        char* base = static_cast<char*>(g->dev_scratch);
+        if ((rc = ivx_launch_sn_emit_list(g, n, reinterpret_cast<const uint32_t*>(base), base + 16, reinterpret_cast<const uint32_t*>(base + off_slots)))) return rc;
+    }
+    // the device table: the emit pass wrote the re-meshed chunks' entries; entries a removal moved are patched from the host mirror
+    (void)table_before;
+    for (uint32_t slot : dirty_slots)
+        if (slot < m->table.size())
+            IVX_HIP_CHECK(hipMemcpyAsync(g->submeshes + slot, &m->table[slot], sizeof(ivx_submesh), hipMemcpyHostToDevice, g->ctx->stream));
+    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    g->mesh_counts.n_vertices = (uint32_t)m->total_vertices;
+    g->mesh_counts.n_indices = (uint32_t)m->total_indices;
+    g->mesh_counts.n_submeshes = (uint32_t)m->table.size();
+    g->mesh_valid = 1;
+    g->mesh_serial += 1;  // collision probes picked from the old mesh are stale
+    m->serial = g->mesh_serial;
+    *out = g->mesh_counts;
     return IVX_OK;
 }
 
@@ -1578,6 +1813,7 @@ int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
         if ((rc = ivx_launch_sdf_sample(g, g->prog_nodes, g->prog_n, g->prog_stack, g->prog_shape, g->prog_center, g->prog_type))) return rc;
         T1(0);
         g->mesh_valid = 0;
+        g->mesh_built = 0;  // a newly sampled object: whatever mesh the buffers hold is not a stale version of this one
         g->regions_valid = 0;
     }
     if (stages & IVX_STAGE_DERIVE) {
@@ -1664,6 +1900,7 @@ int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out) {
         g->mesh_counts.n_submeshes = totals[2];
         g->mesh_counts.reserved = 0;
         g->mesh_valid = 1;
+        g->mesh_built = 1;
         g->mesh_serial += 1;
     }
     if (stages & IVX_STAGE_INERTIA) {

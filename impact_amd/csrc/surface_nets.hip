@@ -500,7 +500,8 @@ __device__ __forceinline__ void index_materials(const VMat vm[3], unsigned long 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_sn_emit(SnParams p, float* __restrict__ positions, float* __restrict__ normals,
                                                  uint32_t* __restrict__ indices, unsigned long long* __restrict__ imats,
                                                  uint4* __restrict__ vmats, ivx_submesh* __restrict__ submeshes, const uint32_t* __restrict__ emit_count,
-                                                 const uint4* __restrict__ emit_items, uint32_t vcap, uint32_t icap, uint32_t scap) {
+                                                 const uint4* __restrict__ emit_items, uint32_t vcap, uint32_t icap, uint32_t scap,
+                                                 const uint32_t* __restrict__ slots) {
     __shared__ uint16_t s_quad[768];  // quads of the current batch of 256 vertices: cube id | axis << 13
     __shared__ __attribute__((aligned(16))) uint8_t s_sd[TILE_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t s_ty[TILE_BYTES];
@@ -521,7 +522,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint32_t vcount = item.w & 0xFFFFu, icount = (item.w >> 16) * 6u;
     // the output buffers keep the capacity of earlier steps; a mesh that outgrew them is re-emitted after the host has
     // grown the buffers (ivx_voxel_step_collect) — nothing is ever written past the end
-    if ((size_t)voff + vcount > vcap || (size_t)ioff + icount > icap || li >= scap) continue;
+    const uint32_t slot = slots ? slots[li] : li;  // (incremental remesh: the submesh manager's slot of the chunk)
+    if ((size_t)voff + vcount > vcap || (size_t)ioff + icount > icap || slot >= scap) continue;
     const ivx_chunk_info info = g.info[chunk];
     const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
     load_tile(g, ci, cj, ck, s_sd, s_ty, s_neg, tid);
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         sm.vertex_offset = voff;
         sm.vertex_count = vcount;
         sm.reserved = 0;
-        submeshes[li] = sm;
+        submeshes[slot] = sm;
     }
     IVX_T(g, li, 1);  // tile loaded (this wave's part)
     __syncthreads();
@@ -751,7 +753,18 @@ int ivx_launch_sn_emit(ivx_grid* g) {
     hipLaunchKernelGGL(k_sn_emit, dim3(blocks), dim3(256), 0, g->ctx->stream, make_params(g), g->positions, g->normals, g->indices,
                        reinterpret_cast<unsigned long long*>(g->index_materials), reinterpret_cast<uint4*>(g->vertex_materials), g->submeshes,
                        g->chunk_offsets + 2 * (size_t)g->n_chunks + 2, reinterpret_cast<const uint4*>(g->sn_list), (uint32_t)g->vcap, (uint32_t)g->icap,
-                       (uint32_t)g->scap);
+                       (uint32_t)g->scap, nullptr);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+// incremental remesh: emit the listed chunks only — records (chunk, vertex offset, index offset, vertices | quads << 16) and submesh slots come
+// from the host-side submesh manager; d_count holds their number
+int ivx_launch_sn_emit_list(ivx_grid* g, uint32_t n_records, const uint32_t* d_count, const void* d_records, const uint32_t* d_slots) {
+    if (n_records == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_sn_emit, dim3(n_records < 4096u ? n_records : 4096u), dim3(256), 0, g->ctx->stream, make_params(g), g->positions, g->normals,
+                       g->indices, reinterpret_cast<unsigned long long*>(g->index_materials), reinterpret_cast<uint4*>(g->vertex_materials), g->submeshes,
+                       d_count, reinterpret_cast<const uint4*>(d_records), (uint32_t)g->vcap, (uint32_t)g->icap, (uint32_t)g->scap, d_slots);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

@@ -494,6 +494,16 @@ class VoxelObjectMesh:
         self.counts = c
         return self
 
+    def sync_with_voxel_object(self, invalidated):
+        """`VoxelObjectMesh::sync_with_voxel_object` (mesh.rs:355-456): re-mesh the invalidated chunks (bool / byte per chunk, as
+        returned by the edit ops) in place, reusing freed buffer ranges"""
+        inv = np.ascontiguousarray(np.asarray(invalidated).reshape(-1), dtype=np.uint8)
+        assert inv.size == self.object.n_chunks
+        c = np.zeros((), dtype=capi.MESH_COUNTS_DTYPE)
+        check(capi.lib().ivx_mesh_sync(self.object.h, ptr(inv), ptr(c.reshape(1))))
+        self.counts = c
+        return self
+
     def n_vertices(self):
         return int(self.counts["n_vertices"])
 

@@ -155,6 +155,12 @@ int ivx_remesh(ivx_grid*, ivx_mesh_counts* out);
  * (VoxelMeshIndexMaterials, mesh.rs:77-82); any pointer may be NULL */
 int ivx_mesh_download(ivx_grid*, float* positions, float* normals, uint32_t* indices, uint8_t* index_materials,
                       ivx_submesh* submeshes);
+/* VoxelObjectMesh::sync_with_voxel_object (mesh.rs:355-456): re-mesh only the chunks marked in `invalidated_chunks` (one byte per chunk, e.g. what
+ * ivx_absorb_* reported), placing their data through the ChunkSubmeshManager's best-fit reuse of freed buffer ranges (mesh.rs:699-849,
+ * impact_containers/src/range_allocator.rs); chunks that are no longer exposed or whose mesh is empty lose their submesh (swap_remove).
+ * Buffers only grow: counts.n_vertices / n_indices are the buffer lengths including freed ranges, the submesh table says what is live. The chunks
+ * are visited in chunk-linear order (the reference walks a hash set, an unpinned order that decides which freed range a chunk lands in). */
+int ivx_mesh_sync(ivx_grid*, const uint8_t* invalidated_chunks, ivx_mesh_counts* out);
 /* device pointers of the mesh buffers (hand-off to a renderer without a host round trip):
  * 0 positions, 1 normals, 2 indices, 3 index materials, 4 submeshes */
 void* ivx_mesh_device_ptr(ivx_grid*, int which);

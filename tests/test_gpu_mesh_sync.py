@@ -1,0 +1,101 @@
+"""GPU parity of the incremental remesh (row a7: VoxelObjectMesh::sync_with_voxel_object, mesh.rs:355-456): after every edit the synced
+mesh — submesh table in slot order, vertex / index ranges chosen by the best-fit range allocators, the data inside every live range —
+equals the oracle's (tests/test_oracle_mesh_sync.py pins the oracle), and equals a full rebuild chunk by chunk."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import parity_util as pu
+from impact_amd import scenes
+from impact_amd.voxel import VoxelObjectMesh
+
+pytestmark = pytest.mark.gpu
+
+
+def both(ctx, graph, extent=1.0):
+    o = pu.oracle_from_graph(graph, extent)
+    g = pu.gpu_from_graph(ctx, graph, extent)
+    o.update_occupied_voxel_ranges()
+    o.compute_all_derived_state()
+    g.compute_all_derived_state()
+    g.update_occupied_voxel_ranges()
+    g.label_regions()
+    return o, g
+
+
+def assert_synced_meshes_equal(om: ol.OracleMesh, gm):
+    pos, nrm, idx, im, sub = gm
+    assert len(sub) == len(om.submeshes) and len(pos) == len(om.positions) and len(idx) == len(om.indices)
+    want = om.submeshes
+    for f, col in (("index_offset", 3), ("index_count", 4), ("vertex_offset", 13), ("vertex_count", 14)):
+        np.testing.assert_array_equal(sub[f], want[:, col], err_msg=f)
+    np.testing.assert_array_equal(sub["chunk_indices"], want[:, :3])
+    np.testing.assert_array_equal(sub["is_obscured_from_direction"].reshape(len(sub), 8), want[:, 5:13])
+    for sm in want:  # the data of every live range, bit for bit
+        ioff, icnt, voff, vcnt = int(sm[3]), int(sm[4]), int(sm[13]), int(sm[14])
+        np.testing.assert_array_equal(pos[voff:voff + vcnt].view(np.uint32), om.positions[voff:voff + vcnt].view(np.uint32))
+        np.testing.assert_array_equal(nrm[voff:voff + vcnt].view(np.uint32), om.normals[voff:voff + vcnt].view(np.uint32))
+        np.testing.assert_array_equal(idx[ioff:ioff + icnt], om.indices[ioff:ioff + icnt])
+        np.testing.assert_array_equal(im[ioff:ioff + icnt], om.index_materials[ioff:ioff + icnt])
+
+
+@pytest.mark.parametrize("case", ["bites", "cut_through", "capsule_then_sphere", "eaten_whole"])
+def test_sync_after_edits(ctx, case):
+    o, g = both(ctx, scenes.sphere_scene(30.0))
+    om = ol.OracleMeshHandle(o)
+    gm = VoxelObjectMesh.create(g)
+    ctr = np.array([0.5 * (a + b) for a, b in o.info()["occupied_voxel_ranges"]], dtype=np.float32)
+    top = ctr + np.float32(30.0) * np.array([0.0, 0.0, 1.0], np.float32)
+    edits = {
+        "bites": [("s", top, 7.0), ("s", top, 20.0), ("s", ctr + np.float32(30.0) * np.array([0.6, 0.0, 0.8], np.float32), 11.0)],
+        "cut_through": [("s", ctr + np.array([0.0, float(y), 0.0], np.float32), 12.0) for y in (-24, -8, 8, 24)],
+        "capsule_then_sphere": [("c", ctr + np.array([-40.0, 3.0, 20.0], np.float32), np.array([80.0, -6.0, 4.0], np.float32), 6.0), ("s", top, 9.0)],
+        "eaten_whole": [("s", ctr, 50.0)],
+    }[case]
+    for e in edits:
+        if e[0] == "s":
+            ro = o.absorb_sphere(e[1], e[2] + 2.0, e[2])
+            rg = g.absorb_sphere(e[1], e[2] + 2.0, e[2])
+        else:
+            ro = o.absorb_capsule(e[1], e[2], e[3] + 2.0, e[3])
+            rg = g.absorb_capsule(e[1], e[2], e[3] + 2.0, e[3])
+        np.testing.assert_array_equal(rg["invalidated"], ro["invalidated"])
+        om.sync(ro["invalidated"])
+        gm.sync_with_voxel_object(rg["invalidated"])
+        assert_synced_meshes_equal(om.get(), gm.download())
+    if case == "eaten_whole":
+        assert gm.n_chunks() == 0
+    else:
+        # and a full rebuild afterwards gives the same submeshes, chunk by chunk
+        synced = {tuple(s["chunk_indices"]): s for s in gm.download()[4]}
+        pos, nrm, idx, im, _ = gm.download()
+        full = VoxelObjectMesh.create(g)
+        fpos, fnrm, fidx, fim, fsub = full.download()
+        assert len(fsub) == len(synced)
+        for s in fsub:
+            t = synced[tuple(s["chunk_indices"])]
+            assert int(t["vertex_count"]) == int(s["vertex_count"]) and int(t["index_count"]) == int(s["index_count"])
+            a0, a1, b0, b1 = int(t["vertex_offset"]), int(t["index_offset"]), int(s["vertex_offset"]), int(s["index_offset"])
+            nv, ni = int(s["vertex_count"]), int(s["index_count"])
+            np.testing.assert_array_equal(pos[a0:a0 + nv].view(np.uint32), fpos[b0:b0 + nv].view(np.uint32))
+            np.testing.assert_array_equal(idx[a1:a1 + ni].astype(np.int64) - a0, fidx[b1:b1 + ni].astype(np.int64) - b0)
+    g.close()
+
+
+def test_sync_after_full_remesh_restarts_the_bookkeeping(ctx):
+    """a full ivx_remesh between syncs drops the free ranges (recreate -> clear, mesh.rs:286-300)"""
+    o, g = both(ctx, scenes.sphere_scene(24.0))
+    gm = VoxelObjectMesh.create(g)
+    ctr = np.array([0.5 * (a + b) for a, b in o.info()["occupied_voxel_ranges"]], dtype=np.float32)
+    for r in (6.0, 12.0):
+        c = ctr + np.float32(24.0) * np.array([1.0, 0.0, 0.0], np.float32)
+        ro, rg = o.absorb_sphere(c, r + 2.0, r), g.absorb_sphere(c, r + 2.0, r)
+        gm.sync_with_voxel_object(rg["invalidated"])
+    gm.recreate()
+    om = ol.OracleMeshHandle(o)  # the oracle mesh recreated at the same point
+    c = ctr + np.float32(24.0) * np.array([0.0, 1.0, 0.0], np.float32)
+    ro, rg = o.absorb_sphere(c, 9.0, 7.0), g.absorb_sphere(c, 9.0, 7.0)
+    om.sync(ro["invalidated"])
+    gm.sync_with_voxel_object(rg["invalidated"])
+    assert_synced_meshes_equal(om.get(), gm.download())
+    g.close()

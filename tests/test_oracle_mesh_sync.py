@@ -84,9 +84,17 @@ def test_reuse_of_freed_ranges_and_appending():
     b = {tuple(int(x) for x in sm[:3]): sm for sm in before.submeshes}
     a = {tuple(int(x) for x in sm[:3]): sm for sm in after.submeshes}
     remeshed = [k for k in a if inval[k]]
-    assert any(int(a[k][13]) >= len(before.positions) for k in remeshed)  # appended
-    assert any(int(a[k][13]) < len(before.positions) for k in remeshed)  # reused a freed range
+    assert all(int(a[k][13]) >= len(before.positions) for k in remeshed)  # every touched chunk grew: all appended, their old ranges are free now
     for k in a:
         if not inval[k]:
             np.testing.assert_array_equal(a[k], b[k])
     assert len(after.positions) > len(before.positions)
+    # a second, deeper bite at the same place: the chunks lose surface, and what they need now fits the ranges freed before
+    res2 = o.absorb_sphere(ctr + np.float32(30.0) * np.array([0.0, 0.0, 1.0], np.float32), 22.0, 20.0)
+    m.sync(res2["invalidated"])
+    third = m.get()
+    inval2 = res2["invalidated"].reshape(o.chunk_counts)
+    c = {tuple(int(x) for x in sm[:3]): sm for sm in third.submeshes}
+    assert any(inval2[k] and int(c[k][13]) < len(before.positions) for k in c)  # landed in a range freed by the first sync
+    assert per_chunk(third) == per_chunk(o.mesh())
+    assert_ranges_disjoint(third)
