@@ -25,6 +25,7 @@
 namespace {
 
 constexpr uint32_t PROBE_MAXV = 4928u;  // a chunk's Surface Nets vertices: one per cube of the 17^3 the chunk owns, at most
+constexpr uint32_t PROBE_SMALLV = 1024u;
 
 struct V3 {
     float x, y, z;
@@ -77,22 +78,26 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t mine, uint32_t* s
     return wbase + incl - mine;
 }
 
+// MAXV = the most vertices a workgroup of this variant takes (its LDS footprint: 12 B per vertex). Chunk meshes have a few hundred
+// vertices, the worst case is 4913: the launcher runs a small variant (1024 vertices, 12 KB: many workgroups per CU) for the chunks that fit
+// it and the full-size one for the rest; a workgroup whose chunk belongs to the other variant leaves at once.
+template <uint32_t MAXV, bool SMALL>
 __global__ __launch_bounds__(256) void k_probe_select(const ivx_submesh* __restrict__ submeshes, const float* __restrict__ pos, const float* __restrict__ nrm,
                                                       const uint32_t* __restrict__ idx, uint32_t* __restrict__ corner_list, uint32_t log2_bs,
                                                       float inv_extent, uint32_t* __restrict__ sel, uint32_t* __restrict__ counts,
                                                       uint32_t* __restrict__ err) {
-    __shared__ unsigned long long s_mem[PROBE_MAXV];  // two u32 per vertex first, then the block table (4096 x 8 B at most)
-    __shared__ float s_curv[PROBE_MAXV];
+    __shared__ unsigned long long s_mem[MAXV];  // two u32 per vertex first, then the block table (MAXV x 8 B at most)
+    __shared__ float s_curv[MAXV];
     __shared__ uint32_t s_w[4];
     uint32_t* s_start = reinterpret_cast<uint32_t*>(s_mem);
-    uint32_t* s_fill = s_start + PROBE_MAXV;
+    uint32_t* s_fill = s_start + MAXV;
     unsigned long long* s_best = s_mem;
-    static_assert(PROBE_MAXV >= 4096, "block table must fit the two vertex arrays");
     const uint32_t tid = threadIdx.x, s = blockIdx.x;
     const ivx_submesh sm = submeshes[s];
     const uint32_t ioff = sm.index_offset, icnt = sm.index_count, voff = sm.vertex_offset, vcnt = sm.vertex_count;
     const uint32_t log2_cb = 4u - log2_bs, n_blocks = 1u << (3u * log2_cb);
-    if (vcnt > PROBE_MAXV) {  // (cannot happen for a Surface Nets chunk; never index LDS out of bounds)
+    if (SMALL ? vcnt > PROBE_SMALLV : (vcnt <= PROBE_SMALLV && n_blocks <= PROBE_SMALLV)) return;  // the other variant's chunk
+    if (vcnt > MAXV || n_blocks > MAXV) {  // (cannot happen for a Surface Nets chunk; never index LDS out of bounds)
         if (tid == 0) {
             counts[s] = 0;
             atomicOr(err, 1u);
@@ -383,8 +388,11 @@ __global__ __launch_bounds__(256) void k_mut_emit(MutParams p, const float* __re
 int ivx_launch_probe_select(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, uint32_t* d_corner_list, uint32_t* d_sel, uint32_t* d_counts, uint32_t* d_offsets,
                             uint32_t* d_err) {
     const uint32_t n_blocks = 1u << (3u * (4u - log2_bs));
-    hipLaunchKernelGGL(k_probe_select, dim3(n_sub), dim3(256), 0, g->ctx->stream, g->submeshes, g->positions, g->normals, g->indices, d_corner_list, log2_bs,
-                       1.0f / g->extent, d_sel, d_counts, d_err);
+    if (n_blocks <= PROBE_SMALLV)
+        hipLaunchKernelGGL((k_probe_select<PROBE_SMALLV, true>), dim3(n_sub), dim3(256), 0, g->ctx->stream, g->submeshes, g->positions, g->normals, g->indices,
+                           d_corner_list, log2_bs, 1.0f / g->extent, d_sel, d_counts, d_err);
+    hipLaunchKernelGGL((k_probe_select<PROBE_MAXV, false>), dim3(n_sub), dim3(256), 0, g->ctx->stream, g->submeshes, g->positions, g->normals, g->indices,
+                       d_corner_list, log2_bs, 1.0f / g->extent, d_sel, d_counts, d_err);
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(256), 0, g->ctx->stream, n_sub, d_counts, d_offsets);
     (void)n_blocks;
     IVX_HIP_CHECK(hipGetLastError());
