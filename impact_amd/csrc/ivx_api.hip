@@ -185,6 +185,8 @@ struct ivx_submesh_manager {
     std::unordered_map<uint32_t, uint32_t> slot_of;   // linear chunk index -> slot
     ivx_range_allocator vertices, indices;
     size_t total_vertices = 0, total_indices = 0;     // buffer lengths (freed ranges inside them stay counted)
+    std::vector<ivx_submesh_data_ranges> updated;     // VoxelMeshModifications (mesh.rs:113-123) since the last report
+    bool chunks_were_removed = false;
     uint64_t serial = 0;                              // the mesh_serial this state describes
 };
 void ivx_submesh_manager_free(ivx_submesh_manager* m) { delete m; }
@@ -202,6 +204,7 @@ void manager_remove(ivx_grid* g, ivx_submesh_manager* m, uint32_t chunk) {  // r
         m->slot_of[linear_chunk(g, m->table[slot].chunk_indices)] = slot;
     }
     m->table.pop_back();
+    m->chunks_were_removed = true;
     m->vertices.free_range(gone.vertex_offset, (size_t)gone.vertex_offset + gone.vertex_count);
     m->indices.free_range(gone.index_offset, (size_t)gone.index_offset + gone.index_count);
 }
@@ -545,6 +548,8 @@ int ivx_mesh_sync(ivx_grid* g, const uint8_t* invalidated_chunks, ivx_mesh_count
         m->indices.free_ranges.clear();
         m->total_vertices = g->mesh_counts.n_vertices;
         m->total_indices = g->mesh_counts.n_indices;
+        m->updated.clear();  // (recreate -> ChunkSubmeshManager::clear, mesh.rs:843-851)
+        m->chunks_were_removed = false;
         m->serial = g->mesh_serial;
     }
     // what the invalidated chunks' meshes need now (the count pass of the full remesh) and their records (exposure, obscuredness flags)
@@ -611,6 +616,7 @@ int ivx_mesh_sync(ivx_grid* g, const uint8_t* invalidated_chunks, ivx_mesh_count
             m->slot_of[c] = (uint32_t)m->table.size();
             m->table.push_back(sm);
         }
+        m->updated.push_back(ivx_submesh_data_ranges{(uint32_t)v0, (uint32_t)(v0 + nv), (uint32_t)i0, (uint32_t)(i0 + ni)});
         recs.push_back(Rec{c, (uint32_t)v0, (uint32_t)i0, nv | ((ni / 6u) << 16)});
         rec_chunk.push_back(c);
     }
@@ -645,6 +651,26 @@ int ivx_mesh_sync(ivx_grid* g, const uint8_t* invalidated_chunks, ivx_mesh_count
     g->mesh_serial += 1;  // collision probes picked from the old mesh are stale
     m->serial = g->mesh_serial;
     *out = g->mesh_counts;
+    return IVX_OK;
+}
+
+int ivx_mesh_modifications(ivx_grid* g, ivx_submesh_data_ranges* out, size_t cap, size_t* n_out, int* chunks_were_removed) {
+    IVX_REQUIRE(g && n_out && chunks_were_removed && (out || cap == 0), IVX_ERR_INVALID, "ivx_mesh_modifications: null argument");
+    const ivx_submesh_manager* m = g->submesh_manager;
+    const bool current = m && m->serial == g->mesh_serial;  // (a full remesh since the last sync: nothing pending, the whole mesh is new)
+    *n_out = current ? m->updated.size() : 0;
+    *chunks_were_removed = current && m->chunks_were_removed ? 1 : 0;
+    IVX_REQUIRE(*n_out <= cap || !out, IVX_ERR_CAPACITY, "ivx_mesh_modifications: %zu ranges exceed the capacity %zu", *n_out, cap);
+    if (out && *n_out) memcpy(out, m->updated.data(), *n_out * sizeof(ivx_submesh_data_ranges));
+    return IVX_OK;
+}
+
+int ivx_mesh_report_synchronized(ivx_grid* g) {
+    IVX_REQUIRE(g, IVX_ERR_INVALID, "ivx_mesh_report_synchronized: null grid");
+    if (g->submesh_manager) {
+        g->submesh_manager->updated.clear();
+        g->submesh_manager->chunks_were_removed = false;
+    }
     return IVX_OK;
 }
 

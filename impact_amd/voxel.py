@@ -504,6 +504,19 @@ class VoxelObjectMesh:
         self.counts = c
         return self
 
+    def mesh_modifications(self):
+        """`VoxelMeshModifications` (mesh.rs:113-123): (ranges [n,4] u32: vertex start, end, index start, end of every chunk written
+        since the last report, chunks_were_removed)"""
+        n = C.c_size_t(0)
+        removed = C.c_int(0)
+        check(capi.lib().ivx_mesh_modifications(self.object.h, None, 0, C.byref(n), C.byref(removed)))
+        out = np.zeros((max(1, n.value), 4), dtype=np.uint32)
+        check(capi.lib().ivx_mesh_modifications(self.object.h, ptr(out), n.value, C.byref(n), C.byref(removed)))
+        return out[: n.value], bool(removed.value)
+
+    def report_gpu_resources_synchronized(self):
+        check(capi.lib().ivx_mesh_report_synchronized(self.object.h))
+
     def n_vertices(self):
         return int(self.counts["n_vertices"])
 

@@ -161,6 +161,13 @@ int ivx_mesh_download(ivx_grid*, float* positions, float* normals, uint32_t* ind
  * Buffers only grow: counts.n_vertices / n_indices are the buffer lengths including freed ranges, the submesh table says what is live. The chunks
  * are visited in chunk-linear order (the reference walks a hash set, an unpinned order that decides which freed range a chunk lands in). */
 int ivx_mesh_sync(ivx_grid*, const uint8_t* invalidated_chunks, ivx_mesh_counts* out);
+/* VoxelMeshModifications (mesh.rs:113-123, 826-841), the hand-off to the renderer's buffers: the vertex / index ranges ivx_mesh_sync wrote since the
+ * last report, in the order written, and whether any chunk lost its submesh; ivx_mesh_report_synchronized = report_gpu_resources_synchronized. */
+typedef struct {
+    uint32_t vertex_start, vertex_end, index_start, index_end;
+} ivx_submesh_data_ranges;
+int ivx_mesh_modifications(ivx_grid*, ivx_submesh_data_ranges* out, size_t cap, size_t* n_out, int* chunks_were_removed);
+int ivx_mesh_report_synchronized(ivx_grid*);
 /* device pointers of the mesh buffers (hand-off to a renderer without a host round trip):
  * 0 positions, 1 normals, 2 indices, 3 index materials, 4 submeshes */
 void* ivx_mesh_device_ptr(ivx_grid*, int which);

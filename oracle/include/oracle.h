@@ -76,6 +76,8 @@ orc_mesh* orc_mesh_recreate(const orc_object*);
  * through the ChunkSubmeshManager (mesh.rs:699-849) and its RangeAllocators; chunks are visited in chunk-linear order (the reference's hash-set
  * order is unpinned). Buffers only grow; submeshes keep the manager's slot order. */
 void orc_mesh_sync(orc_mesh*, const orc_object*, const uint8_t* invalidated_chunks);
+int orc_mesh_modifications(const orc_mesh*, uint32_t* ranges4, int cap, int* chunks_were_removed); /* mesh.rs:826-836 */
+void orc_mesh_report_synchronized(orc_mesh*);                                                    /* mesh.rs:838-841 */
 void orc_range_allocator_script(const int64_t* ops, int n_ops, int64_t* results);
 void orc_mesh_counts(const orc_mesh*, uint32_t out[3]); /* vertices, indices, submeshes */
 /* submeshes: 16 u32 each = chunk[3], index_offset, index_count, obscured[8], vertex_offset, vertex_count, 0 */

@@ -303,6 +303,17 @@ void orc_range_allocator_script(const int64_t* ops, int n_ops, int64_t* results)
         } else a.merge_consecutive_ranges();
     }
 }
+// VoxelObjectMesh::mesh_modifications / report_gpu_resources_synchronized (mesh.rs:826-841): returns the number of ranges (4 u32 each)
+int orc_mesh_modifications(const orc_mesh* m, uint32_t* ranges, int cap, int* chunks_were_removed) {
+    const int n = (int)(m->mesh.updated_data_ranges.size() / 4);
+    for (int i = 0; i < n && i < cap; ++i) std::memcpy(ranges + 4 * i, &m->mesh.updated_data_ranges[4 * (size_t)i], 16);
+    *chunks_were_removed = m->mesh.chunks_were_removed ? 1 : 0;
+    return n;
+}
+void orc_mesh_report_synchronized(orc_mesh* m) {
+    m->mesh.updated_data_ranges.clear();
+    m->mesh.chunks_were_removed = false;
+}
 void orc_mesh_counts(const orc_mesh* m, uint32_t out[3]) {
     out[0] = (uint32_t)m->mesh.positions.size();
     out[1] = (uint32_t)m->mesh.indices.size();

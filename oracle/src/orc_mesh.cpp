@@ -356,6 +356,7 @@ static void remove_chunk_if_present(Mesh& mesh, uint64_t key) {  // mesh.rs:811-
         mesh.chunk_index[chunk_key(moved.chunk[0], moved.chunk[1], moved.chunk[2])] = idx;
     }
     mesh.submeshes.pop_back();
+    mesh.chunks_were_removed = true;
     mesh.vertex_ranges.free_range(gone.vertex_offset, (size_t)gone.vertex_offset + gone.vertex_count);
     mesh.index_ranges.free_range(gone.index_offset, (size_t)gone.index_offset + gone.index_count);
 }
@@ -405,6 +406,7 @@ void mesh_sync(const VoxelObject& obj, Mesh& mesh, const uint8_t* invalidated) {
                 sm.vertex_offset = (uint32_t)v0;
                 sm.vertex_count = (uint32_t)nv;
                 obscured_table(c.flags, sm.obscured);
+                mesh.updated_data_ranges.insert(mesh.updated_data_ranges.end(), {(uint32_t)v0, (uint32_t)(v0 + nv), (uint32_t)i0, (uint32_t)(i0 + ni)});
                 if (it != mesh.chunk_index.end()) {
                     mesh.submeshes[it->second] = sm;
                 } else {

@@ -43,6 +43,9 @@ struct Mesh {
     // ChunkSubmeshManager (mesh.rs:699-849): chunk -> submesh slot, free ranges of the vertex and index buffers
     std::unordered_map<uint64_t, size_t> chunk_index;
     RangeAllocator vertex_ranges, index_ranges;
+    // VoxelMeshModifications (mesh.rs:113-123): what a renderer has to re-upload; cleared by report_gpu_resources_synchronized
+    std::vector<uint32_t> updated_data_ranges;  // 4 per written chunk: vertex start, end, index start, end
+    bool chunks_were_removed = false;
 };
 
 void vertex_materials_compute(const bool has_voxel[8], const uint8_t mat[8], VertexMaterials& m);

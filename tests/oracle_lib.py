@@ -102,6 +102,10 @@ def lib():
         L.orc_apply_updated_inertial_properties.argtypes = [vp, vp, vp, C.c_int, vp]
         L.orc_extracted_object_dynamics.restype = None
         L.orc_extracted_object_dynamics.argtypes = [vp, vp, C.c_float, vp, vp, vp, vp]
+        L.orc_mesh_modifications.restype = C.c_int
+        L.orc_mesh_modifications.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
+        L.orc_mesh_report_synchronized.restype = None
+        L.orc_mesh_report_synchronized.argtypes = [vp]
         L.orc_mesh_sync.restype = None
         L.orc_mesh_sync.argtypes = [vp, vp, vp]
         L.orc_range_allocator_script.restype = None
@@ -189,6 +193,16 @@ class OracleMeshHandle:
     def sync(self, invalidated):
         inv = np.ascontiguousarray(invalidated, dtype=np.uint8)
         lib().orc_mesh_sync(self.h, self.obj.h, _p(inv))
+
+    def modifications(self):
+        removed = C.c_int(0)
+        n = lib().orc_mesh_modifications(self.h, None, 0, C.byref(removed))
+        out = np.zeros((max(1, n), 4), dtype=np.uint32)
+        lib().orc_mesh_modifications(self.h, _p(out), n, C.byref(removed))
+        return out[:n], bool(removed.value)
+
+    def report_synchronized(self):
+        lib().orc_mesh_report_synchronized(self.h)
 
     def get(self) -> "OracleMesh":
         L = lib()

@@ -63,7 +63,18 @@ def test_sync_after_edits(ctx, case):
         om.sync(ro["invalidated"])
         gm.sync_with_voxel_object(rg["invalidated"])
         assert_synced_meshes_equal(om.get(), gm.download())
+        # what the renderer is told to re-upload (VoxelMeshModifications, mesh.rs:113-123)
+        want_ranges, want_removed = om.modifications()
+        got_ranges, got_removed = gm.mesh_modifications()
+        np.testing.assert_array_equal(got_ranges, want_ranges)
+        assert got_removed == want_removed
+        if e is edits[0]:
+            assert len(got_ranges) > 0 or case == "eaten_whole"
+        if e is not edits[-1] and len(edits) > 2:  # sometimes report in between, sometimes let the ranges pile up
+            om.report_synchronized()
+            gm.report_gpu_resources_synchronized()
     if case == "eaten_whole":
+        assert gm.mesh_modifications()[1]  # every chunk lost its submesh
         assert gm.n_chunks() == 0
     else:
         # and a full rebuild afterwards gives the same submeshes, chunk by chunk
