@@ -316,7 +316,8 @@ __device__ __forceinline__ void apply_pair(const PhysContact& p, const PairStati
 }
 
 // one contact of a chain; `type` is uniform over the chain
-__device__ __forceinline__ void run_contact(uint32_t type, const PhysContact& p, const PairStatic& st, PairState& x, float factor, float4* __restrict__ acc_slot) {
+__device__ __forceinline__ void run_contact(uint32_t type, const PhysContact& p, const PairStatic& st, PairState& x, float factor, float4* __restrict__ acc_slot,
+                                            float4 acc) {
     if (type == PHYS_ITEM_POSITIONAL) {
         const V3 n = ld3(p.normal);
         const V3 pa = qrot(x.qa, ld3(p.local_a)) + x.pa, pb = qrot(x.qb, ld3(p.local_b)) + x.pb;
@@ -336,7 +337,6 @@ __device__ __forceinline__ void run_contact(uint32_t type, const PhysContact& p,
         return;
     }
     const V3 pb = qrot(st.q_b, ld3(p.local_b)) + st.pos_b;
-    const float4 acc = *acc_slot;
     if (type == PHYS_ITEM_WARM) {
         apply_pair(p, st, x, pb, acc.x, acc.y, acc.z);
         return;
@@ -365,9 +365,13 @@ __device__ __forceinline__ void run_chain(uint32_t item, uint2 bodies, uint32_t 
     const uint32_t s0 = item & 0x00FFFFFFu, len = (item >> 24) & 15u, type = item >> 28;
     const uint32_t ia = bodies.x, ib = bodies.y;
     PhysContact p[4];
+    float4 acc4[4];  // the accumulated impulses too: a load per contact between the contacts' stores would serialise on L2 latency
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-        if ((uint32_t)c < len) p[c] = pcs[s0 + c];
+        if ((uint32_t)c < len) {
+            p[c] = pcs[s0 + c];
+            if (type != PHYS_ITEM_POSITIONAL) acc4[c] = accs[s0 + c];
+        }
     const PhysBody& A = cb[ia];
     const PhysBody& B = cb[ib];
     PairStatic st;
@@ -414,10 +418,10 @@ __device__ __forceinline__ void run_chain(uint32_t item, uint2 bodies, uint32_t 
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-        if ((uint32_t)c < len) run_contact(type, p[c], st, x, factor, accs + s0 + c);
+        if ((uint32_t)c < len) run_contact(type, p[c], st, x, factor, accs + s0 + c, acc4[c]);
     for (uint32_t c = 4; c < len; ++c) {  // manifolds with more than four points
         const PhysContact q = pcs[s0 + c];
-        run_contact(type, q, st, x, factor, accs + s0 + c);
+        run_contact(type, q, st, x, factor, accs + s0 + c, type != PHYS_ITEM_POSITIONAL ? accs[s0 + c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     }
     if (PHASE == 0) {
         if (st.dyn_a) {
