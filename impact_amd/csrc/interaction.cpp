@@ -139,6 +139,13 @@ void sync_momenta(ivx_rigid_body* b, const Derived& d, const Motion& s, D3 veloc
 
 extern "C" {
 
+int ivx_offset_reference_point(double moments[10], const float offset[3]) {
+    IVX_REQUIRE(moments && offset, IVX_ERR_INVALID, "ivx_offset_reference_point: null argument");
+    IVX_REQUIRE(moments[0] > 0.0, IVX_ERR_INVALID, "ivx_offset_reference_point: the moments describe no mass");
+    offset_reference(moments, D3{offset[0], offset[1], offset[2]});
+    return IVX_OK;
+}
+
 int ivx_apply_updated_inertial_properties(ivx_rigid_body* body, const double moments[10], const float original_local_center_of_mass[3], int preserve_momentum,
                                           float new_local_center_of_mass[3]) {
     IVX_REQUIRE(body && moments && original_local_center_of_mass && new_local_center_of_mass, IVX_ERR_INVALID,

@@ -28,6 +28,13 @@ def apply_updated_inertial_properties_to_rigid_body(rigid_body: np.ndarray, mome
     return b[0], com
 
 
+def offset_reference_point(moments64, offset):
+    """`VoxelObjectInertialPropertyManager::offset_reference_point_by` (object/inertia.rs:257-267)"""
+    m = np.ascontiguousarray(moments64, dtype=np.float64).copy()
+    check(capi.lib().ivx_offset_reference_point(ptr(m), ptr(np.ascontiguousarray(offset, dtype=np.float32))))
+    return m
+
+
 def determine_extracted_voxel_object_dynamics(moments64_in_parent_frame, origin_offset_in_parent, voxel_extent, original_local_center_of_mass,
                                               parent_rigid_body):
     """`determine_extracted_voxel_object_dynamics` (interaction.rs:503-585) -> (fragment body record, moments about the fragment's own

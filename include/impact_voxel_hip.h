@@ -415,6 +415,9 @@ typedef struct {
  * apply_updated_inertial_properties_to_rigid_body (interaction.rs:405-458; preserve_momentum = 1: ..._preserving_momentum, 460-487): new mass and
  * inertia tensor, position moved by the rotated shift of the local centre of mass, momenta re-synchronised for v + w x shift and the unchanged
  * angular velocity. */
+/* VoxelObjectInertialPropertyManager::offset_reference_point_by (object/inertia.rs:257-267): the same moments about the point `offset` (e.g. a fragment's
+ * moments from its own grid frame into the parent's: offset = -origin_offset_in_parent * voxel_extent) */
+int ivx_offset_reference_point(double moments[10], const float offset[3]);
 int ivx_apply_updated_inertial_properties(ivx_rigid_body* body, const double moments[10], const float original_local_center_of_mass[3],
                                           int preserve_momentum, float new_local_center_of_mass[3]);
 /* determine_extracted_voxel_object_dynamics (interaction.rs:503-585): `moments` in = the fragment's moments in the PARENT's grid frame (what

@@ -119,3 +119,47 @@ def test_object_reduced_to_crumbs_is_reported_empty(ctx):
     for f in ("mass", "position", "momentum", "angular_momentum"):
         np.testing.assert_array_equal(res["rigid_body"][f], body[f])
     g.close()
+
+
+def test_fragments_cut_by_planes_get_their_bodies(ctx):
+    """the fracturing flow's tail (fracturing.rs:1047-1189 -> interaction.rs:503-585): polyhedra are cut out of the object with
+    `extract_polyhedron`, every fragment's moments (computed in its own grid frame) go back to the parent's frame and give its rigid
+    body; GPU path against the oracle doing the same, the octant planes of BASELINE config 3 as the fragment polyhedra"""
+    from impact_amd.interaction import determine_extracted_voxel_object_dynamics, offset_reference_point
+
+    ext = 0.25
+    dens = np.ones(256, dtype=f32) * f32(1.5)
+    o, g = both(ctx, scenes.sphere_scene(28.0), ext)
+    q = np.array([0.1, 0.3, -0.2, 0.0])
+    q[3] = np.sqrt(1 - q[:3] @ q[:3])
+    body, com0 = body_for(o, dens, (0.5, -1.0, 2.0), (0.2, 0.1, -0.3), (0.9, -0.4, 0.6), q)
+    occ = o.info()["occupied_voxel_ranges"]
+    mid = [0.5 * (a + b) for a, b in occ]
+    hi = [float(b) + 2.0 for a, b in occ]
+    for signs in ((1, 1, 1), (-1, 1, -1)):  # two octants
+        planes, lo_c, hi_c = [], [], []
+        for d in range(3):
+            n = [0.0, 0.0, 0.0]
+            n[d] = -float(signs[d])
+            planes.append((*n, -signs[d] * mid[d]))  # inner face: signs[d] * x >= signs[d] * mid[d]
+            n2 = [0.0, 0.0, 0.0]
+            n2[d] = float(signs[d])
+            far = hi[d] if signs[d] > 0 else -(float(occ[d][0]) - 2.0)
+            planes.append((*n2, far))
+            lo_c.append(mid[d] if signs[d] > 0 else float(occ[d][0]) - 2.0)
+            hi_c.append(hi[d] if signs[d] > 0 else mid[d])
+        aabb = (*lo_c, *hi_c)
+        rc_o, child_o, origin_o = o.clip_polyhedron(planes, aabb, copy=False)
+        rc_g, child_g, origin_g = g.extract_polyhedron(aabb, planes)
+        assert rc_o == 1 and rc_g == 1 and tuple(int(x) for x in origin_g) == tuple(origin_o)
+        pu.assert_edited_objects_equal(child_o, child_g, densities=dens)
+        m_own_o = child_o.inertia(dens)[0]
+        fb_o, _, com_o = ol.extracted_object_dynamics(ol.offset_reference_point(m_own_o, -np.array(origin_o, dtype=f32) * f32(ext)), origin_o, ext, com0, body)
+        m_own_g = VoxelObjectInertialPropertyManager.initialized_from(child_g, dens).m64
+        m_in_parent = offset_reference_point(m_own_g, -np.array(origin_g, dtype=f32) * f32(ext))
+        fb_g, m_back, com_g = determine_extracted_voxel_object_dynamics(m_in_parent, origin_g, ext, com0, body)
+        close(fb_g, fb_o)
+        np.testing.assert_allclose(com_g, com_o, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(m_back, m_own_g, rtol=1e-9, atol=1e-6)  # there and back again, in f64
+        child_g.close()
+    g.close()
