@@ -3,7 +3,8 @@
 reference's own known-answer tests — tests/test_oracle_voxel.py, tests/test_oracle_physics.py). The reference is Rust and this
 image has no cargo/rustc, so it cannot produce vectors itself. Fixtures are data only: digests (sha256 prefixes) of every
 output buffer of the voxel path for five small scenes, the exact f64 moments, counts and ranges; rigid-body end states of a
-few collision sequences as f32 bit patterns.
+few collision sequences as f32 bit patterns; one scripted scenario over the "next" rows (contact generation against three collidables and
+between two objects, collision probes, absorbing sphere / capsule / mutual absorption with the incremental remesh after each).
 usage: python tests/golden/make_golden.py     (from the repository root; needs oracle/liboracle.so, built by `make -C oracle`)"""
 import json
 import os
@@ -40,7 +41,10 @@ def main():
     phys = {"pile_4": physics_end_state()}
     with open(gu.PHYSICS_GOLDEN, "w") as f:
         json.dump({"_made_by": "tests/golden/make_golden.py (CPU oracle)", "cases": phys}, f, indent=1, sort_keys=True)
-    print("wrote", gu.VOXEL_GOLDEN, gu.PHYSICS_GOLDEN)
+    with open(gu.NEXT_GOLDEN, "w") as f:
+        json.dump({"_made_by": "tests/golden/make_golden.py (CPU oracle)", "script": gu.next_rows_script(), "digest": gu.oracle_next_rows_digest()}, f, indent=1,
+                  sort_keys=True)
+    print("wrote", gu.VOXEL_GOLDEN, gu.PHYSICS_GOLDEN, gu.NEXT_GOLDEN)
 
 
 if __name__ == "__main__":

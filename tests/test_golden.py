@@ -62,3 +62,14 @@ def test_hip_matches_physics_golden(ctx, physics_golden):
         scale = np.maximum(np.linalg.norm(ref, axis=1, keepdims=True), max(float(np.abs(ref).max()), 1e-30) * 1e-2)
         assert (np.abs(got - ref) / scale).max() <= 1e-5, f
     w.close()
+
+
+def test_oracle_reproduces_next_rows_golden():
+    want = gu.load(gu.NEXT_GOLDEN)
+    assert want["script"] == gu.next_rows_script()
+    gu.assert_next_rows_equal(gu.oracle_next_rows_digest(), want["digest"], exact=True)
+
+
+@pytest.mark.gpu
+def test_hip_matches_next_rows_golden(ctx):
+    gu.assert_next_rows_equal(gu.gpu_next_rows_digest(ctx), gu.load(gu.NEXT_GOLDEN)["digest"], exact=False)
