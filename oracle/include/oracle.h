@@ -8,7 +8,9 @@
  * oracle is pinned against the reference's own known-answer tests re-typed in tests/test_oracle_*.py
  * (adjacency patterns, occupied ranges, chunk flag bits, vertex/index material packing, inertia of
  * boxes/chunks, sphere-collision outcomes). Bit-level behaviour of the un-vendored glam 0.30.10 /
- * simdnoise 3.1.7 / fastrand 2.3.0 crates is "parity unpinned" (see DESIGN.md).
+ * simdnoise 3.1.7 / fastrand 2.3.0 crates is "parity unpinned" (see DESIGN.md); so are two iteration ORDERS that come from
+ * hashbrown 0.16 + rustc-hash 2.1 maps (the chunk order of the mutual voxel-object contacts and of the incremental remesh):
+ * the oracle walks chunks in chunk-linear order there.
  */
 #ifndef ORACLE_H
 #define ORACLE_H
