@@ -196,9 +196,8 @@ __global__ __launch_bounds__(256) void k_prepare_contacts(uint32_t n, uint32_t n
     p.target = fabsf(sep) >= 0.4f ? -c.restitution * sep : 0.0f;
     const float d1 = dot(rel, t1), d2 = dot(rel, t2);
     p.friction = (d1 * d1 + d2 * d2) >= 1e-4f ? c.dynamic_friction : c.static_friction;
-    p.ia = ia;
-    p.ib = ib;
-    p.pad[0] = p.pad[1] = 0;
+    st3(p.world_b, qrot(ldq(b.q), ld3(p.local_b)) + ld3(b.pos));  // (the very operations the velocity sweeps used to repeat per contact and sweep)
+    p.pad = 0;
     float4 a4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const int32_t ps = prev_slot ? prev_slot[s] : (s < n_prev ? (int32_t)s : -1);
     if (ps >= 0) {
@@ -297,7 +296,6 @@ struct PairStatic {
     float ima, imb;
     M3 iia, iib;
     V3 pos_a, pos_b;  // velocity phase only (configuration is fixed there)
-    Q4 q_b;
     bool dyn_a, dyn_b;
 };
 
@@ -336,7 +334,7 @@ __device__ __forceinline__ void run_contact(uint32_t type, const PhysContact& p,
         }
         return;
     }
-    const V3 pb = qrot(st.q_b, ld3(p.local_b)) + st.pos_b;
+    const V3 pb = ld3(p.world_b);
     if (type == PHYS_ITEM_WARM) {
         apply_pair(p, st, x, pb, acc.x, acc.y, acc.z);
         return;
@@ -385,7 +383,6 @@ __device__ __forceinline__ void run_chain(uint32_t item, uint2 bodies, uint32_t 
     if (PHASE == 0) {
         st.pos_a = ld3(A.pos);
         st.pos_b = ld3(B.pos);
-        st.q_b = ldq(B.q);
         if (LDS && st.dyn_a) {
             x.va = ld3(s_dyn + 6 * ia);
             x.wa = ld3(s_dyn + 6 * ia + 3);

@@ -24,8 +24,8 @@ static_assert(sizeof(PhysBody) == 96, "PhysBody layout");
 struct PhysContact {
     float local_a[3], local_b[3], normal[3], tangent[3], bitangent[3];
     float m_n, m_t, m_b, friction, target;
-    uint32_t ia, ib;
-    uint32_t pad[2];
+    float world_b[3];  // the contact point on body B in world space as the velocity phase sees it: qrot(q_b, local_b) + pos_b, fixed for the step
+    uint32_t pad;
 };
 static_assert(sizeof(PhysContact) == 96, "PhysContact layout");
 
