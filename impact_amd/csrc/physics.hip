@@ -314,8 +314,9 @@ __device__ __forceinline__ void apply_pair(const PhysContact& p, const PairStati
 }
 
 // one contact of a chain; `type` is uniform over the chain
-__device__ __forceinline__ void run_contact(uint32_t type, const PhysContact& p, const PairStatic& st, PairState& x, float factor, float4* __restrict__ acc_slot,
-                                            float4 acc) {
+// `acc` in: the accumulated impulses of the contact; out: what a velocity item leaves there (the caller stores it — after the whole chain: on this
+// part a store counts in vmcnt like a load, and waiting for the next contact's data would also wait for the store's acknowledgement, ~1.5 us each)
+__device__ __forceinline__ void run_contact(uint32_t type, const PhysContact& p, const PairStatic& st, PairState& x, float factor, float4& acc) {
     if (type == PHYS_ITEM_POSITIONAL) {
         const V3 n = ld3(p.normal);
         const V3 pa = qrot(x.qa, ld3(p.local_a)) + x.pa, pb = qrot(x.qb, ld3(p.local_b)) + x.pb;
@@ -350,8 +351,8 @@ __device__ __forceinline__ void run_contact(uint32_t type, const PhysContact& p,
     const float mag = sqrtf(ut * ut + ub * ub);
     const float sc = mag > max_t ? max_t / mag : 1.0f;
     const float nt = ut * sc, nb = ub * sc;
-    *acc_slot = make_float4(nn, nt, nb, 0.0f);
     apply_pair(p, st, x, pb, nn - acc.x, nt - acc.y, nb - acc.z);
+    acc = make_float4(nn, nt, nb, 0.0f);
 }
 
 // LDS = true: the phase's mutable state of the dynamic bodies lives in s_dyn (velocity: 6 floats v,w; positional: 7 floats
@@ -415,10 +416,17 @@ __device__ __forceinline__ void run_chain(uint32_t item, uint2 bodies, uint32_t 
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-        if ((uint32_t)c < len) run_contact(type, p[c], st, x, factor, accs + s0 + c, acc4[c]);
+        if ((uint32_t)c < len) run_contact(type, p[c], st, x, factor, acc4[c]);
     for (uint32_t c = 4; c < len; ++c) {  // manifolds with more than four points
         const PhysContact q = pcs[s0 + c];
-        run_contact(type, q, st, x, factor, accs + s0 + c, type != PHYS_ITEM_POSITIONAL ? accs[s0 + c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        float4 a = type != PHYS_ITEM_POSITIONAL ? accs[s0 + c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        run_contact(type, q, st, x, factor, a);
+        if (type == PHYS_ITEM_VELOCITY) accs[s0 + c] = a;
+    }
+    if (type == PHYS_ITEM_VELOCITY) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if ((uint32_t)c < len) accs[s0 + c] = acc4[c];
     }
     if (PHASE == 0) {
         if (st.dyn_a) {
