@@ -363,14 +363,17 @@ __device__ __forceinline__ void run_chain(uint32_t item, uint2 bodies, uint32_t 
                                           float4* __restrict__ accs, PhysBody* __restrict__ cb, float* s_dyn) {
     const uint32_t s0 = item & 0x00FFFFFFu, len = (item >> 24) & 15u, type = item >> 28;
     const uint32_t ia = bodies.x, ib = bodies.y;
-    PhysContact p[4];
-    float4 acc4[4];  // the accumulated impulses too: a load per contact between the contacts' stores would serialise on L2 latency
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-        if ((uint32_t)c < len) {
-            p[c] = pcs[s0 + c];
-            if (type != PHYS_ITEM_POSITIONAL) acc4[c] = accs[s0 + c];
-        }
+    // the prepared contacts (and accumulated impulses) come two at a time: contact c + 2 is requested as soon as contact c has been consumed, so
+    // its latency hides behind contact c + 1 — and the kernel keeps to the VGPR budget of 768 threads per workgroup (3 waves per SIMD)
+    PhysContact pa, pb2;
+    float4 aca = make_float4(0.0f, 0.0f, 0.0f, 0.0f), acb = aca;
+    const bool with_acc = type != PHYS_ITEM_POSITIONAL, store_acc = type == PHYS_ITEM_VELOCITY;
+    pa = pcs[s0];
+    if (with_acc) aca = accs[s0];
+    if (len > 1u) {
+        pb2 = pcs[s0 + 1u];
+        if (with_acc) acb = accs[s0 + 1u];
+    }
     const PhysBody& A = cb[ia];
     const PhysBody& B = cb[ib];
     PairStatic st;
@@ -414,19 +417,33 @@ __device__ __forceinline__ void run_chain(uint32_t item, uint2 bodies, uint32_t 
             x.qb = ldq(B.q);
         }
     }
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-        if ((uint32_t)c < len) run_contact(type, p[c], st, x, factor, acc4[c]);
+    run_contact(type, pa, st, x, factor, aca);
+    if (store_acc) accs[s0] = aca;
+    if (len > 2u) {
+        pa = pcs[s0 + 2u];
+        if (with_acc) aca = accs[s0 + 2u];
+    }
+    if (len > 1u) {
+        run_contact(type, pb2, st, x, factor, acb);
+        if (store_acc) accs[s0 + 1u] = acb;
+    }
+    if (len > 3u) {
+        pb2 = pcs[s0 + 3u];
+        if (with_acc) acb = accs[s0 + 3u];
+    }
+    if (len > 2u) {
+        run_contact(type, pa, st, x, factor, aca);
+        if (store_acc) accs[s0 + 2u] = aca;
+    }
+    if (len > 3u) {
+        run_contact(type, pb2, st, x, factor, acb);
+        if (store_acc) accs[s0 + 3u] = acb;
+    }
     for (uint32_t c = 4; c < len; ++c) {  // manifolds with more than four points
         const PhysContact q = pcs[s0 + c];
-        float4 a = type != PHYS_ITEM_POSITIONAL ? accs[s0 + c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float4 a = with_acc ? accs[s0 + c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         run_contact(type, q, st, x, factor, a);
-        if (type == PHYS_ITEM_VELOCITY) accs[s0 + c] = a;
-    }
-    if (type == PHYS_ITEM_VELOCITY) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if ((uint32_t)c < len) accs[s0 + c] = acc4[c];
+        if (store_acc) accs[s0 + c] = a;
     }
     if (PHASE == 0) {
         if (st.dyn_a) {
@@ -453,7 +470,7 @@ __device__ __forceinline__ void run_chain(uint32_t item, uint2 bodies, uint32_t 
 
 // 512 threads: a chain keeps ~150 values live (pair state, statics, the prepared contact); 1024 threads would cap the
 // kernel at 128 VGPRs and spill a third of them to scratch
-constexpr uint32_t SOLVE_THREADS = 512u;
+constexpr uint32_t SOLVE_THREADS = 768u;
 template <bool LDS, int PHASE>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(uint32_t n_dyn, float factor, const PhysContact* __restrict__ pcs, float4* __restrict__ accs,
                                                 PhysBody* __restrict__ cb, const uint32_t* __restrict__ items, const uint2* __restrict__ item_bodies,
