@@ -79,9 +79,10 @@ def measured_traffic(stage):
         return None
     total, found = 0.0, False
     for k in STAGE_KERNELS.get(stage, []):
-        if k in d:
-            total += d[k]["hbm_bytes"]
-            found = True
+        for name in d:  # (template kernels are reported as "void k_name<args>")
+            if name == k or name.startswith("void " + k + "<"):
+                total += d[name]["hbm_bytes"]
+                found = True
     return total if found else None
 
 

@@ -497,6 +497,7 @@ __device__ __forceinline__ void index_materials(const VMat vm[3], unsigned long 
 
 // (amdgpu_waves_per_eu(4): keeps the kernel at <= 128 VGPRs so that four workgroups fit a CU; the LDS footprint, ~38 KB, allows
 // four as well. The kernel is bound by the latency of a workgroup's serial phases, so residency is what buys throughput.)
+template <bool SLOTS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_sn_emit(SnParams p, float* __restrict__ positions, float* __restrict__ normals,
                                                  uint32_t* __restrict__ indices, unsigned long long* __restrict__ imats,
                                                  uint4* __restrict__ vmats, ivx_submesh* __restrict__ submeshes, const uint32_t* __restrict__ emit_count,
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint32_t vcount = item.w & 0xFFFFu, icount = (item.w >> 16) * 6u;
     // the output buffers keep the capacity of earlier steps; a mesh that outgrew them is re-emitted after the host has
     // grown the buffers (ivx_voxel_step_collect) — nothing is ever written past the end
-    const uint32_t slot = slots ? slots[li] : li;  // (incremental remesh: the submesh manager's slot of the chunk)
+    const uint32_t slot = SLOTS ? slots[li] : li;  // (incremental remesh: the submesh manager's slot of the chunk)
     if ((size_t)voff + vcount > vcap || (size_t)ioff + icount > icap || slot >= scap) continue;
     const ivx_chunk_info info = g.info[chunk];
     const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
@@ -750,7 +751,7 @@ int ivx_launch_sn_scan(ivx_grid* g) {
 
 int ivx_launch_sn_emit(ivx_grid* g) {
     const uint32_t blocks = g->n_chunks < 4096u ? g->n_chunks : 4096u;
-    hipLaunchKernelGGL(k_sn_emit, dim3(blocks), dim3(256), 0, g->ctx->stream, make_params(g), g->positions, g->normals, g->indices,
+    hipLaunchKernelGGL(k_sn_emit<false>, dim3(blocks), dim3(256), 0, g->ctx->stream, make_params(g), g->positions, g->normals, g->indices,
                        reinterpret_cast<unsigned long long*>(g->index_materials), reinterpret_cast<uint4*>(g->vertex_materials), g->submeshes,
                        g->chunk_offsets + 2 * (size_t)g->n_chunks + 2, reinterpret_cast<const uint4*>(g->sn_list), (uint32_t)g->vcap, (uint32_t)g->icap,
                        (uint32_t)g->scap, nullptr);
@@ -762,7 +763,7 @@ int ivx_launch_sn_emit(ivx_grid* g) {
 // from the host-side submesh manager; d_count holds their number
 int ivx_launch_sn_emit_list(ivx_grid* g, uint32_t n_records, const uint32_t* d_count, const void* d_records, const uint32_t* d_slots) {
     if (n_records == 0) return IVX_OK;
-    hipLaunchKernelGGL(k_sn_emit, dim3(n_records < 4096u ? n_records : 4096u), dim3(256), 0, g->ctx->stream, make_params(g), g->positions, g->normals,
+    hipLaunchKernelGGL(k_sn_emit<true>, dim3(n_records < 4096u ? n_records : 4096u), dim3(256), 0, g->ctx->stream, make_params(g), g->positions, g->normals,
                        g->indices, reinterpret_cast<unsigned long long*>(g->index_materials), reinterpret_cast<uint4*>(g->vertex_materials), g->submeshes,
                        d_count, reinterpret_cast<const uint4*>(d_records), (uint32_t)g->vcap, (uint32_t)g->icap, (uint32_t)g->scap, d_slots);
     IVX_HIP_CHECK(hipGetLastError());
