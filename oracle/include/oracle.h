@@ -22,6 +22,7 @@ extern "C" {
 
 typedef struct orc_object orc_object;
 typedef struct orc_mesh orc_mesh;
+typedef struct orc_probes orc_probes;
 
 /* SDFNode (generation/sdf/atomic.rs:62-81); same 32-byte layout as ivx_sdf_node */
 typedef struct {
@@ -195,6 +196,13 @@ int orc_sphere_voxel_object_contacts(const orc_object* o, const float rotation_x
  * the number of points; fills at most `cap`. */
 int orc_collision_probes(const orc_object* o, const float* positions, const float* normals, const uint32_t* indices, const uint32_t* submeshes,
                          uint32_t n_submeshes, float* points, uint32_t cap, uint32_t* chunk_entries, uint32_t* n_entries);
+/* the probes as a set that follows an incrementally re-meshed object: recompute_for_all_chunks, then sync_with_voxel_object_and_mesh after each
+ * orc_mesh_sync with the same invalidated chunks (collidable.rs:394-433, 524-612; point ranges from a RangeAllocator, chunk-linear visiting order).
+ * orc_probes_get: the whole point buffer (freed ranges included) and the live entries sorted by range start. */
+orc_probes* orc_probes_recompute(const orc_object*, const orc_mesh*);
+void orc_probes_sync(orc_probes*, const orc_object*, const orc_mesh*, const uint8_t* invalidated_chunks);
+uint32_t orc_probes_get(const orc_probes*, float* points, uint32_t cap_points, uint32_t* entries, uint32_t* n_entries);
+void orc_probes_free(orc_probes*);
 /* contacts between two voxel objects (for_each_mutual_voxel_object_contact, impact_voxel/src/collidable.rs:859-1049): the probes of A sampled
  * against the SDF of B, then the probes of B against A. com_* = centre of mass of the object in its own space (derive_center_of_mass),
  * rotation/translation = transform_to_object_space (world -> object). which_ijk: 4 i32 per contact — 0 (A's probe) / 1 (B's probe), then the

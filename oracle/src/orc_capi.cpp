@@ -24,6 +24,13 @@ int mutual_contacts(const VoxelObject& A, const float* probes_a, const uint32_t*
                     const float trans_a[3], const VoxelObject& B, const float* probes_b, const uint32_t* entries_b, uint32_t n_entries_b,
                     const float com_b[3], const float rot_b[4], const float trans_b[3], int cap, int32_t* which_ijk, float* position, float* normal,
                     float* depth);
+struct ProbeSet;
+ProbeSet* probes_new();
+void probes_delete(ProbeSet*);
+void probes_recompute(const VoxelObject& obj, const Mesh& mesh, ProbeSet& ps);
+void probes_sync(const VoxelObject& obj, const Mesh& mesh, ProbeSet& ps, const uint8_t* invalidated);
+uint32_t probes_entries(const ProbeSet& ps, uint32_t* out);
+uint32_t probes_points(const ProbeSet& ps, float* out, uint32_t cap);
 int plane_voxel_object_contacts(const VoxelObject& obj, const float rot[4], const float trans[3], const float plane_normal[3], float plane_displacement,
                                 int cap, int32_t* indices, float* position, float* normal, float* depth);
 void absorb_mutual(VoxelObject& A, const float rot_a[4], const float trans_a[3], const float* dens_a, VoxelObject& B, const float rot_b[4],
@@ -430,6 +437,23 @@ int orc_sphere_voxel_object_contacts(const orc_object* o, const float rotation_x
                                      int cap, int32_t* indices, float* position, float* normal, float* depth) {
     return sphere_voxel_object_contacts(o->obj, rotation_xyzw, translation, center, radius, cap, indices, position, normal, depth);
 }
+
+// probes as a living set: recompute_for_all_chunks once, then sync_with_voxel_object_and_mesh after every mesh sync (collidable.rs:361-433, 524-612)
+orc_probes* orc_probes_recompute(const orc_object* o, const orc_mesh* m) {
+    ProbeSet* p = probes_new();
+    probes_recompute(o->obj, m->mesh, *p);
+    return reinterpret_cast<orc_probes*>(p);
+}
+void orc_probes_sync(orc_probes* p, const orc_object* o, const orc_mesh* m, const uint8_t* invalidated_chunks) {
+    probes_sync(o->obj, m->mesh, *reinterpret_cast<ProbeSet*>(p), invalidated_chunks);
+}
+/* points: the whole buffer, freed ranges included; entries (5 u32: chunk i, j, k, first, end) sorted by range start; returns the number of points */
+uint32_t orc_probes_get(const orc_probes* p, float* points, uint32_t cap_points, uint32_t* entries, uint32_t* n_entries) {
+    const ProbeSet& ps = *reinterpret_cast<const ProbeSet*>(p);
+    if (entries) *n_entries = probes_entries(ps, entries);
+    return probes_points(ps, points, cap_points);
+}
+void orc_probes_free(orc_probes* p) { probes_delete(reinterpret_cast<ProbeSet*>(p)); }
 
 // VoxelObjectCollisionProbes::recompute_for_all_chunks (impact_voxel/src/collidable.rs:361-392, 473-523, 614-731)
 int orc_collision_probes(const orc_object* o, const float* positions, const float* normals, const uint32_t* indices, const uint32_t* submeshes,

@@ -20,7 +20,9 @@
 // within the manifold is "parity unpinned".
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <limits>
+#include <unordered_map>
 #include <vector>
 
 #include "../include/oracle.h"
@@ -101,6 +103,98 @@ int collision_probes(const VoxelObject& obj, const float* pos, const float* nrm,
         *n_entries += 1;
     }
     return (int)n_pts;
+}
+
+// ---- probes kept in step with an incrementally re-meshed object ---------------------------------------------------------------------
+//   VoxelObjectCollisionProbes::sync_with_voxel_object_and_mesh / update_for_chunk     impact_voxel/src/collidable.rs:394-433, 524-612
+// The point buffer only grows; a chunk's points live in a range handed out by a RangeAllocator (best fit over the ranges freed before,
+// else appended). The reference walks the invalidated chunks in hash-set order (unpinned); here chunk-linear order.
+}  // namespace orc
+#include "orc_mesh.hpp"
+namespace orc {
+struct ProbeSet {
+    std::vector<float> points;                                         // 3 per point, holes included
+    std::unordered_map<uint64_t, std::pair<uint32_t, uint32_t>> ranges;  // chunk -> [start, end)
+    RangeAllocator allocator;
+};
+static inline uint64_t probe_key(uint32_t i, uint32_t j, uint32_t k) { return ((uint64_t)i << 42) | ((uint64_t)j << 21) | (uint64_t)k; }
+static void mesh_arrays(const Mesh& m, std::vector<uint32_t>& sub16) {
+    sub16.assign(16 * m.submeshes.size(), 0u);
+    for (size_t s = 0; s < m.submeshes.size(); ++s) {
+        const Submesh& sm = m.submeshes[s];
+        uint32_t* q = &sub16[16 * s];
+        q[0] = sm.chunk[0], q[1] = sm.chunk[1], q[2] = sm.chunk[2], q[3] = sm.index_offset, q[4] = sm.index_count, q[13] = sm.vertex_offset, q[14] = sm.vertex_count;
+    }
+}
+void probes_recompute(const VoxelObject& obj, const Mesh& mesh, ProbeSet& ps) {
+    ps = ProbeSet{};
+    std::vector<uint32_t> sub16;
+    mesh_arrays(mesh, sub16);
+    const uint32_t ns = (uint32_t)mesh.submeshes.size();
+    std::vector<uint32_t> entries(5 * (size_t)std::max<uint32_t>(ns, 1));
+    uint32_t ne = 0;
+    const float* pos = mesh.positions.empty() ? nullptr : &mesh.positions[0].x;
+    const float* nrm = mesh.normals.empty() ? nullptr : &mesh.normals[0].x;
+    int n = collision_probes(obj, pos, nrm, mesh.indices.data(), sub16.data(), ns, nullptr, 0, entries.data(), &ne);
+    ps.points.assign(3 * (size_t)n, 0.0f);
+    collision_probes(obj, pos, nrm, mesh.indices.data(), sub16.data(), ns, ps.points.data(), (uint32_t)n, entries.data(), &ne);
+    for (uint32_t e = 0; e < ne; ++e) ps.ranges[probe_key(entries[5 * e], entries[5 * e + 1], entries[5 * e + 2])] = {entries[5 * e + 3], entries[5 * e + 4]};
+}
+void probes_sync(const VoxelObject& obj, const Mesh& mesh, ProbeSet& ps, const uint8_t* invalidated) {
+    std::vector<float> buf;
+    std::vector<uint32_t> entry(5);
+    for (int ci = 0; ci < obj.cc[0]; ++ci)
+        for (int cj = 0; cj < obj.cc[1]; ++cj)
+            for (int ck = 0; ck < obj.cc[2]; ++ck) {
+                if (!invalidated[obj.cidx(ci, cj, ck)]) continue;
+                const uint64_t key = probe_key((uint32_t)ci, (uint32_t)cj, (uint32_t)ck);
+                auto old = ps.ranges.find(key);
+                auto sm = mesh.chunk_index.find(key);  // (the two keys are built the same way)
+                uint32_t n = 0;
+                if (sm != mesh.chunk_index.end()) {
+                    const Submesh& m = mesh.submeshes[sm->second];
+                    uint32_t one[16] = {m.chunk[0], m.chunk[1], m.chunk[2], m.index_offset, m.index_count, 0, 0, 0, 0, 0, 0, 0, 0, m.vertex_offset, m.vertex_count, 0};
+                    buf.assign(3 * 4096, 0.0f);
+                    uint32_t ne = 0;
+                    n = (uint32_t)collision_probes(obj, &mesh.positions[0].x, &mesh.normals[0].x, mesh.indices.data(), one, 1, buf.data(), 4096, entry.data(), &ne);
+                }
+                if (n == 0) {  // no mesh, or no points: the chunk leaves the set and its range is freed
+                    if (old != ps.ranges.end()) {
+                        ps.allocator.free_range(old->second.first, old->second.second);
+                        ps.ranges.erase(old);
+                    }
+                    continue;
+                }
+                if (old != ps.ranges.end()) ps.allocator.free_range(old->second.first, old->second.second);
+                size_t start;
+                if (!ps.allocator.allocate_range(n, start)) {
+                    start = ps.points.size() / 3;
+                    ps.points.resize(ps.points.size() + 3 * (size_t)n);
+                }
+                ps.ranges[key] = {(uint32_t)start, (uint32_t)(start + n)};
+                std::copy(buf.begin(), buf.begin() + 3 * (size_t)n, ps.points.begin() + 3 * (std::ptrdiff_t)start);
+            }
+    ps.allocator.merge_consecutive_ranges();
+}
+ProbeSet* probes_new() { return new ProbeSet(); }
+void probes_delete(ProbeSet* p) { delete p; }
+uint32_t probes_points(const ProbeSet& ps, float* out, uint32_t cap) {
+    const uint32_t n = (uint32_t)(ps.points.size() / 3);
+    if (out) std::memcpy(out, ps.points.data(), 12 * (size_t)std::min(n, cap));
+    return n;
+}
+// entries sorted by range start: 5 u32 each (ci, cj, ck, start, end); returns their number
+uint32_t probes_entries(const ProbeSet& ps, uint32_t* out) {
+    std::vector<std::pair<uint32_t, uint64_t>> order;
+    for (const auto& kv : ps.ranges) order.push_back({kv.second.first, kv.first});
+    std::sort(order.begin(), order.end());
+    uint32_t n = 0;
+    for (const auto& o : order) {
+        const auto& r = ps.ranges.at(o.second);
+        uint32_t* e = out + 5 * (size_t)n++;
+        e[0] = (uint32_t)(o.second >> 42), e[1] = (uint32_t)((o.second >> 21) & 0x1FFFFFu), e[2] = (uint32_t)(o.second & 0x1FFFFFu), e[3] = r.first, e[4] = r.second;
+    }
+    return n;
 }
 
 // ---- boxes -----------------------------------------------------------------------------------------------------------------------

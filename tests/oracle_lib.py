@@ -106,6 +106,14 @@ def lib():
         L.orc_mesh_modifications.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
         L.orc_mesh_report_synchronized.restype = None
         L.orc_mesh_report_synchronized.argtypes = [vp]
+        L.orc_probes_recompute.restype = C.c_void_p
+        L.orc_probes_recompute.argtypes = [vp, vp]
+        L.orc_probes_sync.restype = None
+        L.orc_probes_sync.argtypes = [vp, vp, vp, vp]
+        L.orc_probes_get.restype = C.c_uint32
+        L.orc_probes_get.argtypes = [vp, vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]
+        L.orc_probes_free.restype = None
+        L.orc_probes_free.argtypes = [vp]
         L.orc_mesh_sync.restype = None
         L.orc_mesh_sync.argtypes = [vp, vp, vp]
         L.orc_range_allocator_script.restype = None
@@ -216,6 +224,32 @@ class OracleMeshHandle:
         sub = np.empty((ns, 16), dtype=np.uint32)
         L.orc_mesh_get(self.h, _p(pos), _p(nrm), _p(idx), _p(im), _p(sub))
         return OracleMesh(pos, nrm, idx, im, sub)
+
+
+class OracleProbes:
+    """VoxelObjectCollisionProbes kept alive next to an OracleMeshHandle: recompute, then sync after every mesh sync"""
+
+    def __init__(self, mesh: OracleMeshHandle):
+        self.mesh = mesh
+        self.h = C.c_void_p(lib().orc_probes_recompute(mesh.obj.h, mesh.h))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_probes_free(self.h)
+            self.h = None
+
+    def sync(self, invalidated):
+        lib().orc_probes_sync(self.h, self.mesh.obj.h, self.mesh.h, _p(np.ascontiguousarray(invalidated, dtype=np.uint8)))
+
+    def get(self):
+        """-> (points [n,3] incl. freed ranges, entries [m,5] sorted by range start)"""
+        n = lib().orc_probes_get(self.h, None, 0, None, None)
+        cc = self.mesh.obj.chunk_counts
+        pts = np.zeros((max(1, n), 3), dtype=np.float32)
+        ent = np.zeros((cc[0] * cc[1] * cc[2], 5), dtype=np.uint32)
+        ne = C.c_uint32(0)
+        lib().orc_probes_get(self.h, _p(pts), n, _p(ent), C.byref(ne))
+        return pts[:n], ent[: ne.value].copy()
 
 
 def range_allocator_script(ops):

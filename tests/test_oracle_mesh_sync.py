@@ -98,3 +98,36 @@ def test_reuse_of_freed_ranges_and_appending():
     assert any(inval2[k] and int(c[k][13]) < len(before.positions) for k in c)  # landed in a range freed by the first sync
     assert per_chunk(third) == per_chunk(o.mesh())
     assert_ranges_disjoint(third)
+
+
+def test_synced_probes_equal_recomputed_probes_chunk_by_chunk():
+    """sync_with_voxel_object_and_mesh (collidable.rs:394-433, 524-612) after each mesh sync: every chunk's probe points equal those of a
+    recompute over the synced mesh; ranges are disjoint; chunks that were not invalidated keep their ranges"""
+    o = ol.OracleObject.from_sdf(scenes.sphere_scene(30.0), 1.0, 0)
+    o.update_occupied_voxel_ranges()
+    o.compute_all_derived_state()
+    m = ol.OracleMeshHandle(o)
+    probes = ol.OracleProbes(m)
+    p0, e0 = probes.get()
+    assert len(e0) > 20 and int(e0[-1][4]) == len(p0)
+    ctr = np.array([0.5 * (a + b) for a, b in o.info()["occupied_voxel_ranges"]], dtype=np.float32)
+    top = ctr + np.float32(30.0) * np.array([0.0, 0.0, 1.0], np.float32)
+    prev = {tuple(int(x) for x in e[:3]): (int(e[3]), int(e[4])) for e in e0}
+    for r in (7.0, 20.0, 31.0):
+        res = o.absorb_sphere(top, r + 2.0, r)
+        m.sync(res["invalidated"])
+        probes.sync(res["invalidated"])
+        pts, ent = probes.get()
+        fresh_pts, fresh_ent = ol.OracleProbes(m).get()  # recompute over the same (synced) mesh: per-chunk ground truth
+        got = {tuple(int(x) for x in e[:3]): pts[int(e[3]):int(e[4])].tobytes() for e in ent}
+        want = {tuple(int(x) for x in e[:3]): fresh_pts[int(e[3]):int(e[4])].tobytes() for e in fresh_ent}
+        assert got == want
+        spans = sorted((int(e[3]), int(e[4])) for e in ent)
+        assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and spans[-1][1] <= len(pts)
+        inval = res["invalidated"].reshape(o.chunk_counts)
+        now = {tuple(int(x) for x in e[:3]): (int(e[3]), int(e[4])) for e in ent}
+        for k, span in now.items():
+            if not inval[k] and k in prev:
+                assert span == prev[k]
+        prev = now
+    assert len(pts) >= len(p0)
