@@ -122,7 +122,7 @@ EXPORTED_SYMBOLS = [
     "ivx_derive_state", "ivx_occupied_ranges",
     "ivx_remesh", "ivx_mesh_download", "ivx_mesh_device_ptr",
     "ivx_inertia",
-    "ivx_label_regions", "ivx_region_labels_download", "ivx_regions_describe", "ivx_split_off_smallest_region", "ivx_clip_polyhedron", "ivx_mesh_sync", "ivx_mesh_modifications", "ivx_mesh_report_synchronized", "ivx_absorb_sphere", "ivx_absorb_capsule", "ivx_absorb_mutual", "ivx_offset_reference_point", "ivx_apply_updated_inertial_properties", "ivx_extracted_object_dynamics", "ivx_handle_voxel_object_after_removing_voxels", "ivx_sphere_voxel_object_contacts", "ivx_plane_voxel_object_contacts", "ivx_capsule_voxel_object_contacts", "ivx_collision_probes_recompute", "ivx_collision_probes_download", "ivx_mutual_voxel_object_contacts",
+    "ivx_label_regions", "ivx_region_labels_download", "ivx_regions_describe", "ivx_split_off_smallest_region", "ivx_clip_polyhedron", "ivx_mesh_sync", "ivx_mesh_modifications", "ivx_mesh_report_synchronized", "ivx_absorb_sphere", "ivx_absorb_capsule", "ivx_absorb_mutual", "ivx_offset_reference_point", "ivx_apply_updated_inertial_properties", "ivx_extracted_object_dynamics", "ivx_handle_voxel_object_after_removing_voxels", "ivx_sphere_voxel_object_contacts", "ivx_plane_voxel_object_contacts", "ivx_capsule_voxel_object_contacts", "ivx_collision_probes_recompute", "ivx_collision_probes_sync", "ivx_collision_probes_download", "ivx_mutual_voxel_object_contacts",
     "ivx_grid_set_sdf_program", "ivx_grid_set_densities", "ivx_voxel_step", "ivx_voxel_step_enqueue", "ivx_voxel_step_collect",
     "ivx_halo_pack_enqueue", "ivx_halo_unpack_enqueue", "ivx_halo_pack_both_enqueue", "ivx_region_face_labels_enqueue", "ivx_region_face_pairs_enqueue",
     "ivx_step_record_words", "ivx_step_record_enqueue",
@@ -246,6 +246,7 @@ def lib():
         "ivx_sphere_voxel_object_contacts": (i32, [vp, vp, vp, vp, f32, C.c_uint64, C.c_uint64, u32, u32, vp, vp, sz, C.POINTER(sz)]),
         "ivx_plane_voxel_object_contacts": (i32, [vp, vp, vp, vp, f32, C.c_uint64, C.c_uint64, u32, u32, vp, vp, sz, C.POINTER(sz)]),
         "ivx_collision_probes_recompute": (i32, [vp, C.POINTER(sz)]),
+        "ivx_collision_probes_sync": (i32, [vp, vp, C.POINTER(sz)]),
         "ivx_collision_probes_download": (i32, [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(sz)]),
         "ivx_mutual_voxel_object_contacts": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, u32, u32, vp, vp, sz, C.POINTER(sz)]),
         "ivx_capsule_voxel_object_contacts": (i32, [vp, vp, vp, vp, vp, f32, C.c_uint64, C.c_uint64, u32, u32, vp, vp, sz, C.POINTER(sz)]),

@@ -85,15 +85,15 @@ template <uint32_t MAXV, bool SMALL>
 __global__ __launch_bounds__(256) void k_probe_select(const ivx_submesh* __restrict__ submeshes, const float* __restrict__ pos, const float* __restrict__ nrm,
                                                       const uint32_t* __restrict__ idx, uint32_t* __restrict__ corner_list, uint32_t log2_bs,
                                                       float inv_extent, uint32_t* __restrict__ sel, uint32_t* __restrict__ counts,
-                                                      uint32_t* __restrict__ err) {
+                                                      uint32_t* __restrict__ err, const uint32_t* __restrict__ slots) {
     __shared__ unsigned long long s_mem[MAXV];  // two u32 per vertex first, then the block table (MAXV x 8 B at most)
     __shared__ float s_curv[MAXV];
     __shared__ uint32_t s_w[4];
     uint32_t* s_start = reinterpret_cast<uint32_t*>(s_mem);
     uint32_t* s_fill = s_start + MAXV;
     unsigned long long* s_best = s_mem;
-    const uint32_t tid = threadIdx.x, s = blockIdx.x;
-    const ivx_submesh sm = submeshes[s];
+    const uint32_t tid = threadIdx.x, s = blockIdx.x;  // s = record: outputs are indexed by it
+    const ivx_submesh sm = submeshes[slots ? slots[s] : s];  // (incremental sync: the listed submesh slots)
     const uint32_t ioff = sm.index_offset, icnt = sm.index_count, voff = sm.vertex_offset, vcnt = sm.vertex_count;
     const uint32_t log2_cb = 4u - log2_bs, n_blocks = 1u << (3u * log2_cb);
     if (SMALL ? vcnt > PROBE_SMALLV : (vcnt <= PROBE_SMALLV && n_blocks <= PROBE_SMALLV)) return;  // the other variant's chunk
@@ -210,9 +210,10 @@ __global__ __launch_bounds__(256) void k_scan_counts(uint32_t n, const uint32_t*
 
 __global__ __launch_bounds__(64) void k_probe_gather(const ivx_submesh* __restrict__ submeshes, const float* __restrict__ pos, const uint32_t* __restrict__ sel,
                                                      const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, uint32_t n_blocks,
-                                                     float* __restrict__ points, uint32_t* __restrict__ probe_chunk, uint32_t* __restrict__ entries) {
+                                                     float* __restrict__ points, uint32_t* __restrict__ probe_chunk, uint32_t* __restrict__ entries,
+                                                     const uint32_t* __restrict__ slots) {
     const uint32_t s = blockIdx.x, n = counts[s], off = offsets[s];
-    const ivx_submesh sm = submeshes[s];
+    const ivx_submesh sm = submeshes[slots ? slots[s] : s];
     const uint32_t packed = sm.chunk_indices[0] | (sm.chunk_indices[1] << 10) | (sm.chunk_indices[2] << 20);
     for (uint32_t r = threadIdx.x; r < n; r += 64u) {
         const uint32_t v = sel[(size_t)s * n_blocks + r];
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(64) void k_probe_gather(const ivx_submesh* __restri
         points[3 * (size_t)(off + r) + 2] = pos[3 * (size_t)v + 2];
         probe_chunk[off + r] = packed;
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && entries) {
         uint32_t* e = entries + 5 * (size_t)s;
         e[0] = sm.chunk_indices[0], e[1] = sm.chunk_indices[1], e[2] = sm.chunk_indices[2], e[3] = off, e[4] = off + n;
     }
@@ -315,6 +316,7 @@ template <bool EMIT>
 __device__ __forceinline__ bool probe_contact(const MutParams& p, const float* points, const uint32_t* probe_chunk, uint32_t k, MutHit* hit) {
     if (k >= p.n_probes) return false;
     const uint32_t pc = probe_chunk[k];
+    if (pc == 0xFFFFFFFFu) return false;  // a freed range of the point buffer (incremental probe sync)
     const uint32_t c3[3] = {pc & 1023u, (pc >> 10) & 1023u, pc >> 20};
     if (c3[0] < p.clo[0] || c3[0] >= p.chi[0] || c3[1] < p.clo[1] || c3[1] >= p.chi[1] || c3[2] < p.clo[2] || c3[2] >= p.chi[2]) return false;
     const V3 pp = ld3(points + 3 * (size_t)k);
@@ -385,24 +387,26 @@ __global__ __launch_bounds__(256) void k_mut_emit(MutParams p, const float* __re
 
 }  // namespace
 
+// d_slots = nullptr: every submesh (recompute); else the listed submesh slots (incremental sync), n_sub = their number
 int ivx_launch_probe_select(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, uint32_t* d_corner_list, uint32_t* d_sel, uint32_t* d_counts, uint32_t* d_offsets,
-                            uint32_t* d_err) {
+                            uint32_t* d_err, const uint32_t* d_slots) {
     const uint32_t n_blocks = 1u << (3u * (4u - log2_bs));
     if (n_blocks <= PROBE_SMALLV)
         hipLaunchKernelGGL((k_probe_select<PROBE_SMALLV, true>), dim3(n_sub), dim3(256), 0, g->ctx->stream, g->submeshes, g->positions, g->normals, g->indices,
-                           d_corner_list, log2_bs, 1.0f / g->extent, d_sel, d_counts, d_err);
+                           d_corner_list, log2_bs, 1.0f / g->extent, d_sel, d_counts, d_err, d_slots);
     hipLaunchKernelGGL((k_probe_select<PROBE_MAXV, false>), dim3(n_sub), dim3(256), 0, g->ctx->stream, g->submeshes, g->positions, g->normals, g->indices,
-                       d_corner_list, log2_bs, 1.0f / g->extent, d_sel, d_counts, d_err);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(256), 0, g->ctx->stream, n_sub, d_counts, d_offsets);
-    (void)n_blocks;
+                       d_corner_list, log2_bs, 1.0f / g->extent, d_sel, d_counts, d_err, d_slots);
+    if (d_offsets) hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(256), 0, g->ctx->stream, n_sub, d_counts, d_offsets);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 
-int ivx_launch_probe_gather(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, const uint32_t* d_sel, const uint32_t* d_counts, const uint32_t* d_offsets) {
+// copies the selected vertices to probe_points[d_offsets[record] ...]; d_entries (optional) gets one (chunk, first, end) entry per record
+int ivx_launch_probe_gather(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, const uint32_t* d_sel, const uint32_t* d_counts, const uint32_t* d_offsets,
+                            uint32_t* d_entries, const uint32_t* d_slots) {
     const uint32_t n_blocks = 1u << (3u * (4u - log2_bs));
     hipLaunchKernelGGL(k_probe_gather, dim3(n_sub), dim3(64), 0, g->ctx->stream, g->submeshes, g->positions, d_sel, d_counts, d_offsets, n_blocks,
-                       g->probe_points, g->probe_chunk, g->probe_entries);
+                       g->probe_points, g->probe_chunk, d_entries, d_slots);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

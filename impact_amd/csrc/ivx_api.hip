@@ -36,6 +36,7 @@ int ensure_host_scratch(ivx_grid* g, size_t bytes) {
     if (g->host_scratch) (void)hipHostFree(g->host_scratch);
     if (g->result_host) (void)hipHostFree(g->result_host);
     ivx_submesh_manager_free(g->submesh_manager);
+    ivx_probe_manager_free(g->probe_manager);
     g->host_scratch = nullptr;
     g->host_scratch_bytes = 0;
     IVX_HIP_CHECK(hipHostMalloc(&g->host_scratch, bytes, hipHostMallocDefault));
@@ -190,6 +191,13 @@ struct ivx_submesh_manager {
     uint64_t serial = 0;                              // the mesh_serial this state describes
 };
 void ivx_submesh_manager_free(ivx_submesh_manager* m) { delete m; }
+// VoxelObjectCollisionProbes' bookkeeping (collidable.rs:97-101): chunk -> range of the point buffer, free ranges
+struct ivx_probe_manager {
+    std::unordered_map<uint32_t, std::pair<uint32_t, uint32_t>> range_of;  // linear chunk index -> [start, end)
+    ivx_range_allocator points;
+    size_t total = 0;  // length of the point buffer, freed ranges included
+};
+void ivx_probe_manager_free(ivx_probe_manager* m) { delete m; }
 
 namespace {
 uint32_t linear_chunk(const ivx_grid* g, const uint32_t c[3]) { return (c[0] * g->cc[1] + c[1]) * g->cc[2] + c[2]; }
@@ -1292,6 +1300,12 @@ int ivx_collision_probes_recompute(ivx_grid* g, size_t* n_points) {
     g->n_probe_points = 0;
     g->n_probe_sub = n_sub;
     g->probes_serial = g->mesh_serial;
+    if (!g->probe_manager) g->probe_manager = new (std::nothrow) ivx_probe_manager();
+    IVX_REQUIRE(g->probe_manager, IVX_ERR_HIP, "ivx_collision_probes_recompute: out of host memory");
+    ivx_probe_manager* pm = g->probe_manager;
+    pm->range_of.clear();
+    pm->points.free_ranges.clear();
+    pm->total = 0;
     if (n_sub == 0) return IVX_OK;
     if (n_sub > g->probe_entry_cap) {
         if (g->probe_entries) (void)hipFree(g->probe_entries);
@@ -1311,7 +1325,7 @@ int ivx_collision_probes_recompute(ivx_grid* g, size_t* n_points) {
     uint32_t* d_err = reinterpret_cast<uint32_t*>(base + off_err);
     IVX_HIP_CHECK(hipMemsetAsync(d_err, 0, 4, g->ctx->stream));
     if ((rc = ivx_launch_probe_select(g, n_sub, log2_bs, reinterpret_cast<uint32_t*>(base), reinterpret_cast<uint32_t*>(base + off_sel), d_counts, d_offsets,
-                                      d_err)))
+                                      d_err, nullptr)))
         return rc;
     uint32_t tail[2];  // offsets[n_sub] = total, error word
     if ((rc = d2h(g, tail, d_offsets + n_sub, sizeof(tail)))) return rc;
@@ -1328,8 +1342,19 @@ int ivx_collision_probes_recompute(ivx_grid* g, size_t* n_points) {
         if ((rc = dev_alloc(&g->probe_chunk, cap))) return rc;
         g->probe_point_cap = cap;
     }
-    if ((rc = ivx_launch_probe_gather(g, n_sub, log2_bs, reinterpret_cast<uint32_t*>(base + off_sel), d_counts, d_offsets))) return rc;
-    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    if ((rc = ivx_launch_probe_gather(g, n_sub, log2_bs, reinterpret_cast<uint32_t*>(base + off_sel), d_counts, d_offsets, g->probe_entries, nullptr))) return rc;
+    {  // the host mirror of chunk_point_ranges (clear(): no free ranges)
+        std::vector<uint32_t> e((size_t)n_sub * 5);
+        if ((rc = d2h(g, e.data(), g->probe_entries, e.size() * 4))) return rc;
+        pm->range_of.clear();
+        pm->points.free_ranges.clear();
+        for (uint32_t sidx = 0; sidx < n_sub; ++sidx)
+            if (e[5 * (size_t)sidx + 4] > e[5 * (size_t)sidx + 3]) {
+                const uint32_t c3[3] = {e[5 * (size_t)sidx], e[5 * (size_t)sidx + 1], e[5 * (size_t)sidx + 2]};
+                pm->range_of[linear_chunk(g, c3)] = {e[5 * (size_t)sidx + 3], e[5 * (size_t)sidx + 4]};
+            }
+        pm->total = n_pts;
+    }
     g->n_probe_points = n_pts;
     *n_points = n_pts;
     return IVX_OK;
@@ -1342,19 +1367,125 @@ int ivx_collision_probes_download(ivx_grid* g, float* points, size_t cap_points,
     *n_points = g->n_probe_points;
     *n_entries = 0;
     int rc;
-    std::vector<uint32_t> e((size_t)g->n_probe_sub * 5);
-    if (g->n_probe_sub && (rc = d2h(g, e.data(), g->probe_entries, e.size() * 4))) return rc;
-    size_t ne = 0;  // the reference keeps no entry for a chunk without probes
-    for (uint32_t s = 0; s < g->n_probe_sub; ++s)
-        if (e[5 * (size_t)s + 4] > e[5 * (size_t)s + 3]) {
-            if (chunk_entries && ne < cap_entries) memcpy(chunk_entries + 5 * ne, &e[5 * (size_t)s], 20);
+    size_t ne = 0;  // the live entries in the order of their ranges (= submesh order right after a recompute)
+    if (g->probe_manager) {
+        std::vector<std::pair<uint32_t, uint32_t>> order;
+        for (const auto& kv : g->probe_manager->range_of) order.push_back({kv.second.first, kv.first});
+        std::sort(order.begin(), order.end());
+        for (const auto& o : order) {
+            if (chunk_entries && ne < cap_entries) {
+                const uint32_t c = o.second;
+                const auto& r = g->probe_manager->range_of.at(c);
+                uint32_t* e = chunk_entries + 5 * ne;
+                e[0] = c / (g->cc[1] * g->cc[2]), e[1] = (c / g->cc[2]) % g->cc[1], e[2] = c % g->cc[2], e[3] = r.first, e[4] = r.second;
+            }
             ne += 1;
         }
+    }
     *n_entries = ne;
     IVX_REQUIRE(!points || g->n_probe_points <= cap_points, IVX_ERR_CAPACITY, "ivx_collision_probes_download: %u points exceed the capacity %zu",
                 g->n_probe_points, cap_points);
     IVX_REQUIRE(!chunk_entries || ne <= cap_entries, IVX_ERR_CAPACITY, "ivx_collision_probes_download: %zu entries exceed the capacity %zu", ne, cap_entries);
     if (points && g->n_probe_points && (rc = d2h(g, points, g->probe_points, (size_t)g->n_probe_points * 12))) return rc;
+    return IVX_OK;
+}
+
+// VoxelObjectCollisionProbes::sync_with_voxel_object_and_mesh (collidable.rs:394-433, 524-612): after ivx_mesh_sync, with the same invalidated chunks
+int ivx_collision_probes_sync(ivx_grid* g, const uint8_t* invalidated_chunks, size_t* n_points) {
+    const char* who = "ivx_collision_probes_sync";
+    IVX_REQUIRE(g && invalidated_chunks && n_points, IVX_ERR_INVALID, "%s: null argument", who);
+    ivx_submesh_manager* m = g->submesh_manager;
+    ivx_probe_manager* pm = g->probe_manager;
+    IVX_REQUIRE(g->mesh_valid && m && m->serial == g->mesh_serial, IVX_ERR_STATE, "%s: call ivx_mesh_sync first", who);
+    IVX_REQUIRE(pm && (g->probes_serial + 1 == g->mesh_serial || g->probes_serial == g->mesh_serial), IVX_ERR_STATE,
+                "%s: the probes must be those of the mesh before the last ivx_mesh_sync (ivx_collision_probes_recompute, or a sync per mesh sync)", who);
+    int rc;
+    uint32_t* d_occ = g->rscalar + 16;
+    if ((rc = ivx_launch_occupied(g, d_occ))) return rc;
+    uint32_t occ_raw[12], occ[12];
+    if ((rc = d2h(g, occ_raw, d_occ, sizeof(occ_raw)))) return rc;
+    ivx_occupied_from_raw(g, occ_raw, occ);
+    uint32_t min_extent = 0xFFFFFFFFu;
+    for (int d = 0; d < 3; ++d) min_extent = std::min(min_extent, occ[7 + 2 * d] > occ[6 + 2 * d] ? occ[7 + 2 * d] - occ[6 + 2 * d] : 0u);
+    const uint32_t log2_bs = min_extent >= 16 ? 3 : (min_extent >= 8 ? 2 : (min_extent >= 4 ? 1 : 0));
+    const uint32_t n_blocks = 1u << (3u * (4u - log2_bs));
+    // the invalidated chunks in chunk-linear order (the reference walks a hash set: unpinned); those that have a submesh get their points picked
+    std::vector<uint32_t> list, slots, rec_of(0);
+    for (uint32_t c = 0; c < g->n_chunks; ++c)
+        if (invalidated_chunks[c]) list.push_back(c);
+    std::vector<int32_t> rec_index(list.size(), -1);
+    for (size_t e = 0; e < list.size(); ++e) {
+        auto it = m->slot_of.find(list[e]);
+        if (it != m->slot_of.end()) {
+            rec_index[e] = (int32_t)slots.size();
+            slots.push_back(it->second);
+        }
+    }
+    const uint32_t n_rec = (uint32_t)slots.size();
+    std::vector<uint32_t> counts(n_rec);
+    // scratch: [corner lists: one u32 per index][selected vertices: n_rec * n_blocks][counts][dst offsets][slots][error word]
+    const size_t ni = m->total_indices;
+    const size_t off_sel = ni * 4, off_counts = off_sel + (size_t)n_rec * n_blocks * 4, off_dst = off_counts + (size_t)n_rec * 4, off_slots = off_dst + (size_t)n_rec * 4,
+                 off_err = off_slots + (size_t)n_rec * 4, total = off_err + 4;
+    char* base = nullptr;
+    if (n_rec) {
+        if ((rc = ensure_dev_scratch(g, total))) return rc;
+        base = static_cast<char*>(g->dev_scratch);
+        IVX_HIP_CHECK(hipMemsetAsync(base + off_err, 0, 4, g->ctx->stream));
+        if ((rc = h2d(g, base + off_slots, slots.data(), (size_t)n_rec * 4))) return rc;
+        if ((rc = ivx_launch_probe_select(g, n_rec, log2_bs, reinterpret_cast<uint32_t*>(base), reinterpret_cast<uint32_t*>(base + off_sel),
+                                          reinterpret_cast<uint32_t*>(base + off_counts), nullptr, reinterpret_cast<uint32_t*>(base + off_err),
+                                          reinterpret_cast<const uint32_t*>(base + off_slots))))
+            return rc;
+        if ((rc = d2h(g, counts.data(), base + off_counts, (size_t)n_rec * 4))) return rc;
+        uint32_t err = 0;
+        if ((rc = d2h(g, &err, base + off_err, 4))) return rc;
+        IVX_REQUIRE(err == 0, IVX_ERR_CAPACITY, "%s: a chunk submesh holds more vertices than a Surface Nets chunk can", who);
+    }
+    // update_for_chunk, chunk by chunk
+    std::vector<uint32_t> dst(n_rec, 0);
+    std::vector<std::pair<uint32_t, uint32_t>> freed;
+    for (size_t e = 0; e < list.size(); ++e) {
+        const uint32_t c = list[e];
+        const uint32_t n = rec_index[e] >= 0 ? counts[(size_t)rec_index[e]] : 0u;
+        auto old = pm->range_of.find(c);
+        if (n == 0) {  // no mesh, or no points
+            if (old != pm->range_of.end()) {
+                pm->points.free_range(old->second.first, old->second.second);
+                freed.push_back(old->second);
+                pm->range_of.erase(old);
+            }
+            continue;
+        }
+        if (old != pm->range_of.end()) {
+            pm->points.free_range(old->second.first, old->second.second);
+            freed.push_back(old->second);
+        }
+        size_t start;
+        if (!pm->points.allocate(n, &start)) start = pm->total, pm->total += n;
+        IVX_REQUIRE(pm->total < 0xFFFFFFF0ull, IVX_ERR_CAPACITY, "%s: more than 2^32 probe points", who);
+        pm->range_of[c] = {(uint32_t)start, (uint32_t)(start + n)};
+        dst[(size_t)rec_index[e]] = (uint32_t)start;
+    }
+    pm->points.merge_consecutive();
+    if (pm->total > g->probe_point_cap) {  // grow, keeping what is there
+        const size_t cap = std::max<size_t>(pm->total, g->probe_point_cap + g->probe_point_cap / 2);
+        if ((rc = grow_keep(g, &g->probe_points, g->probe_point_cap * 3, cap * 3))) return rc;
+        if ((rc = grow_keep(g, &g->probe_chunk, g->probe_point_cap, cap))) return rc;
+        g->probe_point_cap = cap;
+    }
+    for (const auto& r : freed)  // holes read as "no probe" until a later chunk takes them (the gather below overwrites what was taken now)
+        IVX_HIP_CHECK(hipMemsetAsync(g->probe_chunk + r.first, 0xFF, (size_t)(r.second - r.first) * 4, g->ctx->stream));
+    if (n_rec) {
+        if ((rc = h2d(g, base + off_dst, dst.data(), (size_t)n_rec * 4))) return rc;
+        if ((rc = ivx_launch_probe_gather(g, n_rec, log2_bs, reinterpret_cast<uint32_t*>(base + off_sel), reinterpret_cast<uint32_t*>(base + off_counts),
+                                          reinterpret_cast<uint32_t*>(base + off_dst), nullptr, reinterpret_cast<const uint32_t*>(base + off_slots))))
+            return rc;
+    }
+    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    g->n_probe_points = (uint32_t)pm->total;
+    g->probes_serial = g->mesh_serial;
+    *n_points = pm->total;
     return IVX_OK;
 }
 

@@ -134,7 +134,8 @@ struct ivx_grid {
     uint32_t n_probe_points, n_probe_sub;
     uint64_t mesh_serial, probes_serial;  // probes are current while they were picked from the current mesh
     int mesh_built;  // the mesh buffers hold a mesh of this grid, current (mesh_valid) or made stale by an edit — what ivx_mesh_sync patches
-    struct ivx_submesh_manager* submesh_manager;  // host mirror of the ChunkSubmeshManager, built by the first ivx_mesh_sync after a full remesh
+    struct ivx_submesh_manager* submesh_manager;
+    struct ivx_probe_manager* probe_manager;  // host mirror of the probes' chunk -> point range map and range allocator  // host mirror of the ChunkSubmeshManager, built by the first ivx_mesh_sync after a full remesh
 };
 
 // host-side description of one pass of the mutual contact generation (see collide.hip)
@@ -312,10 +313,12 @@ int ivx_launch_split_move(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3
 int ivx_launch_clip(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], const uint32_t cc[3], const float* planes4, uint32_t n_planes, int extract);
 int ivx_launch_split_repack(ivx_grid* src, ivx_grid* dst, const uint32_t off[3]);
 void ivx_submesh_manager_free(struct ivx_submesh_manager* m);
+void ivx_probe_manager_free(struct ivx_probe_manager* m);
 int ivx_launch_sn_emit_list(ivx_grid* g, uint32_t n_records, const uint32_t* d_count, const void* d_records, const uint32_t* d_slots);
 int ivx_launch_probe_select(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, uint32_t* d_corner_list, uint32_t* d_sel, uint32_t* d_counts, uint32_t* d_offsets,
-                            uint32_t* d_err);
-int ivx_launch_probe_gather(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, const uint32_t* d_sel, const uint32_t* d_counts, const uint32_t* d_offsets);
+                            uint32_t* d_err, const uint32_t* d_slots);
+int ivx_launch_probe_gather(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, const uint32_t* d_sel, const uint32_t* d_counts, const uint32_t* d_offsets,
+                            uint32_t* d_entries, const uint32_t* d_slots);
 int ivx_launch_mutual_pass(ivx_grid* prober, ivx_grid* sampled, const ivx_mutual_pass* h, uint32_t* d_counts, const uint32_t* d_offsets, ivx_contact* d_out,
                            uint32_t cap, int emit);
 int ivx_launch_scan_counts(ivx_ctx* ctx, uint32_t n, const uint32_t* d_counts, uint32_t* d_offsets);

@@ -433,6 +433,14 @@ class VoxelObject:
         check(capi.lib().ivx_collision_probes_recompute(self.h, C.byref(n)))
         return int(n.value)
 
+    def collision_probes_sync(self, invalidated) -> int:
+        """`VoxelObjectCollisionProbes::sync_with_voxel_object_and_mesh` (collidable.rs:394-433): after `VoxelObjectMesh.sync_with_voxel_object`
+        with the same invalidated chunks; returns the length of the point buffer"""
+        inv = np.ascontiguousarray(np.asarray(invalidated).reshape(-1), dtype=np.uint8)
+        n = C.c_size_t(0)
+        check(capi.lib().ivx_collision_probes_sync(self.h, ptr(inv), C.byref(n)))
+        return int(n.value)
+
     def collision_probes(self):
         """-> (points [n,3] f32, entries [m,5] u32: chunk i, j, k, first point, end point)"""
         n, m = C.c_size_t(0), C.c_size_t(0)

@@ -376,8 +376,14 @@ int ivx_capsule_voxel_object_contacts(ivx_grid*, const float rotation_xyzw[4], c
  * (ivx_remesh), the mesh vertex of the most convex curvature in every block of 8^3 / 4^3 / 2^3 / 1 voxels (block size from the object's smallest
  * occupied extent). The probes stay on the device with the grid and go stale with the mesh. */
 int ivx_collision_probes_recompute(ivx_grid*, size_t* n_points);
-/* points: 3 floats each, in submesh order then block order; chunk_entries: 5 u32 per chunk that has probes (ci, cj, ck, first point, end point) —
- * the reference's chunk_point_ranges, here in submesh order. Either output may be NULL; the counts are always returned. */
+/* points: 3 floats each (the whole buffer; after a sync it may contain freed ranges), in submesh order then block order after a recompute; chunk_entries:
+ * 5 u32 per chunk that has probes (ci, cj, ck, first point, end point) — the reference's chunk_point_ranges, sorted by first point. Either output may be
+ * NULL; the counts are always returned. */
+/* VoxelObjectCollisionProbes::sync_with_voxel_object_and_mesh (collidable.rs:394-433, 524-612): after ivx_mesh_sync, with the same invalidated chunks —
+ * only their probes are picked again; the point buffer keeps its length or grows, a chunk's points go to the best-fitting range freed before or to
+ * the end (RangeAllocator); chunks are visited in chunk-linear order (the reference's hash-set order is unpinned). n_points = length of the buffer,
+ * freed ranges included. */
+int ivx_collision_probes_sync(ivx_grid*, const uint8_t* invalidated_chunks, size_t* n_points);
 int ivx_collision_probes_download(ivx_grid*, float* points, size_t cap_points, uint32_t* chunk_entries, size_t cap_entries, size_t* n_points,
                                   size_t* n_entries);
 /* for_each_mutual_voxel_object_contact (collidable.rs:859-1049): the probes of A inside the voxel ranges where the two occupied boxes can overlap

@@ -110,3 +110,44 @@ def test_sync_after_full_remesh_restarts_the_bookkeeping(ctx):
     gm.sync_with_voxel_object(rg["invalidated"])
     assert_synced_meshes_equal(om.get(), gm.download())
     g.close()
+
+
+def test_probes_follow_the_incremental_remesh_and_feed_the_mutual_contacts(ctx):
+    """MeshedVoxelObject::sync_mesh_with_object in full: absorb -> mesh sync -> probe sync (collidable.rs:394-433), three times over; the
+    entries (chunk, range) and every live point equal the oracle's, and the contacts against a second body computed from the synced
+    probes equal the oracle's contacts from its synced probes"""
+    import test_gpu_collide as tc
+
+    o, g = both(ctx, scenes.sphere_scene(30.0))
+    b_o, b_g = both(ctx, scenes.sphere_scene(18.0))
+    om, gm = ol.OracleMeshHandle(o), VoxelObjectMesh.create(g)
+    VoxelObjectMesh.create(b_g)
+    op = ol.OracleProbes(om)
+    g.collision_probes_recompute()
+    b_g.collision_probes_recompute()
+    pb = b_o.collision_probes(b_o.mesh())
+    ctr = np.array([0.5 * (a + b) for a, b in o.info()["occupied_voxel_ranges"]], dtype=np.float32)
+    cb = np.array([0.5 * (a + b) for a, b in b_o.info()["occupied_voxel_ranges"]], dtype=np.float32)
+    top = ctr + np.float32(30.0) * np.array([0.0, 0.0, 1.0], np.float32)
+    ident = np.array([0, 0, 0, 1], np.float32)
+    tb = (cb.astype(np.float64) - np.array([0.0, 3.0, 41.0])).astype(np.float32)  # B sits on top of A, where the bites happen
+    n_contacts = []
+    for r in (7.0, 16.0, 24.0):
+        ro, rg = o.absorb_sphere(top, r + 2.0, r), g.absorb_sphere(top, r + 2.0, r)
+        om.sync(ro["invalidated"])
+        op.sync(ro["invalidated"])
+        gm.sync_with_voxel_object(rg["invalidated"])
+        n = g.collision_probes_sync(rg["invalidated"])
+        want_pts, want_ent = op.get()
+        got_pts, got_ent = g.collision_probes()
+        assert n == len(want_pts) == len(got_pts)
+        np.testing.assert_array_equal(got_ent, want_ent)
+        for e in want_ent:
+            np.testing.assert_array_equal(got_pts[e[3]:e[4]].view(np.uint32), want_pts[e[3]:e[4]].view(np.uint32))
+        want, wi = tc.oracle_contact_list(o, (want_pts, want_ent), ctr, ident, ctr, b_o, pb, cb, ident, tb, 3, 4, 0, 1, (0.2, 0.5, 0.4))
+        got = g.mutual_contacts(ident, ctr, ctr, b_g, ident, tb, cb, 3, 4, 0, 1, (0.2, 0.5, 0.4))
+        tc.assert_contacts_equal(got, want)
+        n_contacts.append(len(want))
+    assert len(want_ent) > 10 and max(n_contacts) > 5, n_contacts
+    g.close()
+    b_g.close()
