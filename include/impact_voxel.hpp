@@ -208,6 +208,29 @@ public:
         out.resize(n);
         return out;
     }
+    // collidable.rs:859-1049: contacts between this object (A) and `other` (B); both need current collision probes
+    std::vector<ivx_contact> mutual_contacts(const Isometry3& to_object, std::array<float, 3> center_of_mass, VoxelObject& other, const Isometry3& other_to_object,
+                                             std::array<float, 3> other_center_of_mass, uint64_t id_a, uint64_t id_b, uint32_t body_a, uint32_t body_b,
+                                             std::array<float, 3> response, size_t capacity = 65536) {
+        std::vector<ivx_contact> out(capacity);
+        size_t n = 0;
+        check(ivx_mutual_voxel_object_contacts(g_, to_object.rotation.data(), to_object.translation.data(), center_of_mass.data(), other.g_,
+                                               other_to_object.rotation.data(), other_to_object.translation.data(), other_center_of_mass.data(), id_a, id_b,
+                                               body_a, body_b, response.data(), out.data(), capacity, &n));
+        out.resize(n);
+        return out;
+    }
+    // VoxelObjectCollisionProbes (collidable.rs:361-433): recompute over the current mesh, or follow a mesh sync
+    size_t recompute_collision_probes() {
+        size_t n = 0;
+        check(ivx_collision_probes_recompute(g_, &n));
+        return n;
+    }
+    size_t sync_collision_probes(const std::vector<uint8_t>& invalidated_mesh_chunks) {
+        size_t n = 0;
+        check(ivx_collision_probes_sync(g_, invalidated_mesh_chunks.data(), &n));
+        return n;
+    }
     struct Dense {
         std::vector<int8_t> sdf;
         std::vector<uint8_t> type, flags, local_labels;
