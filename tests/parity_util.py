@@ -84,7 +84,7 @@ def assert_regions_equal(o: ol.OracleObject, g: VoxelObject):
     return n
 
 
-def assert_edited_objects_equal(o: ol.OracleObject, g: VoxelObject, what="", densities=None):
+def assert_edited_objects_equal(o: ol.OracleObject, g: VoxelObject, what="", densities=None, with_mesh=True):
     """after an operation that rewrites voxels (split, clip, absorb): voxel bytes, emptiness, types and flags of non-empty voxels,
     chunk-local labels, chunk records, regions, mesh and moments. Adjacency bits of EMPTY voxels are history artefacts in the
     reference (oracle/src/orc_split.cpp header) and are not compared."""
@@ -100,6 +100,7 @@ def assert_edited_objects_equal(o: ol.OracleObject, g: VoxelObject, what="", den
     for f in ("kind", "flags", "face_dist", "region_count", "boundary_region_count"):
         np.testing.assert_array_equal(g_info[f], o_info[f], err_msg=what + f)
     n = assert_regions_equal(o, g)
-    assert_mesh_equal(o, g)
+    if with_mesh:  # (a full remesh of the HIP object: leave it out where the incremental remesh is what is being followed)
+        assert_mesh_equal(o, g)
     assert_inertia_equal(o, g, densities)
     return n
