@@ -196,8 +196,10 @@ struct ivx_probe_manager {
     std::unordered_map<uint32_t, std::pair<uint32_t, uint32_t>> range_of;  // linear chunk index -> [start, end)
     ivx_range_allocator points;
     size_t total = 0;  // length of the point buffer, freed ranges included
+    bool built = true;  // false right after a recompute: the map is filled from the device entries when somebody needs it
 };
 void ivx_probe_manager_free(ivx_probe_manager* m) { delete m; }
+static int probe_manager_build(ivx_grid* g);
 
 namespace {
 uint32_t linear_chunk(const ivx_grid* g, const uint32_t c[3]) { return (c[0] * g->cc[1] + c[1]) * g->cc[2] + c[2]; }
@@ -1343,18 +1345,9 @@ int ivx_collision_probes_recompute(ivx_grid* g, size_t* n_points) {
         g->probe_point_cap = cap;
     }
     if ((rc = ivx_launch_probe_gather(g, n_sub, log2_bs, reinterpret_cast<uint32_t*>(base + off_sel), d_counts, d_offsets, g->probe_entries, nullptr))) return rc;
-    {  // the host mirror of chunk_point_ranges (clear(): no free ranges)
-        std::vector<uint32_t> e((size_t)n_sub * 5);
-        if ((rc = d2h(g, e.data(), g->probe_entries, e.size() * 4))) return rc;
-        pm->range_of.clear();
-        pm->points.free_ranges.clear();
-        for (uint32_t sidx = 0; sidx < n_sub; ++sidx)
-            if (e[5 * (size_t)sidx + 4] > e[5 * (size_t)sidx + 3]) {
-                const uint32_t c3[3] = {e[5 * (size_t)sidx], e[5 * (size_t)sidx + 1], e[5 * (size_t)sidx + 2]};
-                pm->range_of[linear_chunk(g, c3)] = {e[5 * (size_t)sidx + 3], e[5 * (size_t)sidx + 4]};
-            }
-        pm->total = n_pts;
-    }
+    pm->total = n_pts;
+    pm->built = false;  // (the entries stay on the device until a sync or a download asks for them)
+    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
     g->n_probe_points = n_pts;
     *n_points = n_pts;
     return IVX_OK;
@@ -1368,6 +1361,7 @@ int ivx_collision_probes_download(ivx_grid* g, float* points, size_t cap_points,
     *n_entries = 0;
     int rc;
     size_t ne = 0;  // the live entries in the order of their ranges (= submesh order right after a recompute)
+    if ((rc = probe_manager_build(g))) return rc;
     if (g->probe_manager) {
         std::vector<std::pair<uint32_t, uint32_t>> order;
         for (const auto& kv : g->probe_manager->range_of) order.push_back({kv.second.first, kv.first});
@@ -1390,6 +1384,26 @@ int ivx_collision_probes_download(ivx_grid* g, float* points, size_t cap_points,
     return IVX_OK;
 }
 
+}  // extern "C"
+// the host mirror of chunk_point_ranges after a recompute (clear(): no free ranges), from the entries the gather pass left on the device
+static int probe_manager_build(ivx_grid* g) {
+    ivx_probe_manager* pm = g->probe_manager;
+    if (!pm || pm->built) return IVX_OK;
+    std::vector<uint32_t> e((size_t)g->n_probe_sub * 5);
+    int rc;
+    if (!e.empty() && (rc = d2h(g, e.data(), g->probe_entries, e.size() * 4))) return rc;
+    pm->range_of.clear();
+    pm->range_of.reserve(g->n_probe_sub);
+    pm->points.free_ranges.clear();
+    for (uint32_t sidx = 0; sidx < g->n_probe_sub; ++sidx)
+        if (e[5 * (size_t)sidx + 4] > e[5 * (size_t)sidx + 3]) {
+            const uint32_t c3[3] = {e[5 * (size_t)sidx], e[5 * (size_t)sidx + 1], e[5 * (size_t)sidx + 2]};
+            pm->range_of[linear_chunk(g, c3)] = {e[5 * (size_t)sidx + 3], e[5 * (size_t)sidx + 4]};
+        }
+    pm->built = true;
+    return IVX_OK;
+}
+extern "C" {
 // VoxelObjectCollisionProbes::sync_with_voxel_object_and_mesh (collidable.rs:394-433, 524-612): after ivx_mesh_sync, with the same invalidated chunks
 int ivx_collision_probes_sync(ivx_grid* g, const uint8_t* invalidated_chunks, size_t* n_points) {
     const char* who = "ivx_collision_probes_sync";
@@ -1400,6 +1414,7 @@ int ivx_collision_probes_sync(ivx_grid* g, const uint8_t* invalidated_chunks, si
     IVX_REQUIRE(pm && (g->probes_serial + 1 == g->mesh_serial || g->probes_serial == g->mesh_serial), IVX_ERR_STATE,
                 "%s: the probes must be those of the mesh before the last ivx_mesh_sync (ivx_collision_probes_recompute, or a sync per mesh sync)", who);
     int rc;
+    if ((rc = probe_manager_build(g))) return rc;
     uint32_t* d_occ = g->rscalar + 16;
     if ((rc = ivx_launch_occupied(g, d_occ))) return rc;
     uint32_t occ_raw[12], occ[12];
