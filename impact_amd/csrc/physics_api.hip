@@ -135,12 +135,15 @@ int fetch_body_position(ivx_world* w, uint32_t ref, float out[3]) {
 // Chains: maximal runs (<= 15) of contacts that are consecutive in the solve order and act on the same (body_a, body_b).
 void build_chains(ivx_world* w) {
     w->chain_start.clear();
+    w->chain_bodies.clear();
     const uint32_t n = w->n_contacts;
     uint32_t s = 0;
     while (s < n) {
         uint32_t e = s + 1;
         while (e < n && e - s < 15u && w->ordered[e].body_a == w->ordered[s].body_a && w->ordered[e].body_b == w->ordered[s].body_b) ++e;
         w->chain_start.push_back(s);
+        w->chain_bodies.push_back(w->ordered[s].body_a);
+        w->chain_bodies.push_back(w->ordered[s].body_b);
         s = e;
     }
     w->chain_start.push_back(n);
@@ -167,13 +170,13 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
     size_t k = 0;
     for (uint32_t pass = 0; pass < total_passes; ++pass)
         for (uint32_t ch = 0; ch < nch; ++ch, ++k) {
-            const ivx_contact& c = w->ordered[w->chain_start[ch]];
+            const uint32_t ba = w->chain_bodies[2 * (size_t)ch], bb = w->chain_bodies[2 * (size_t)ch + 1];
             uint32_t l = 0;
-            if (!(c.body_a & IVX_KINEMATIC_BODY)) l = std::max(l, last[c.body_a]);
-            if (!(c.body_b & IVX_KINEMATIC_BODY)) l = std::max(l, last[c.body_b]);
+            if (!(ba & IVX_KINEMATIC_BODY)) l = std::max(l, last[ba]);
+            if (!(bb & IVX_KINEMATIC_BODY)) l = std::max(l, last[bb]);
             l += 1;
-            if (!(c.body_a & IVX_KINEMATIC_BODY)) last[c.body_a] = l;
-            if (!(c.body_b & IVX_KINEMATIC_BODY)) last[c.body_b] = l;
+            if (!(ba & IVX_KINEMATIC_BODY)) last[ba] = l;
+            if (!(bb & IVX_KINEMATIC_BODY)) last[bb] = l;
             lvl[k] = l;
             max_level = std::max(max_level, l);
         }
@@ -199,9 +202,9 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
             const uint32_t s0 = w->chain_start[ch], len = w->chain_start[ch + 1] - s0;
             const size_t slot = it0 + cursor[lvl[k] - 1]++;
             w->items_host[slot] = s0 | (len << 24) | (ty << 28);
-            const ivx_contact& c = w->ordered[s0];
-            w->item_bodies_host[2 * slot] = (c.body_a & IVX_KINEMATIC_BODY) ? w->n_dyn + (c.body_a & 0x7FFFFFFFu) : c.body_a;
-            w->item_bodies_host[2 * slot + 1] = (c.body_b & IVX_KINEMATIC_BODY) ? w->n_dyn + (c.body_b & 0x7FFFFFFFu) : c.body_b;
+            const uint32_t ba = w->chain_bodies[2 * (size_t)ch], bb = w->chain_bodies[2 * (size_t)ch + 1];
+            w->item_bodies_host[2 * slot] = (ba & IVX_KINEMATIC_BODY) ? w->n_dyn + (ba & 0x7FFFFFFFu) : ba;
+            w->item_bodies_host[2 * slot + 1] = (bb & IVX_KINEMATIC_BODY) ? w->n_dyn + (bb & 0x7FFFFFFFu) : bb;
         }
     }
     for (uint32_t l = 0; l < max_level; ++l) start[l] = start[l + 1];
@@ -310,7 +313,15 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
         i = j;
     }
     // 2. ConstraintCache::register_prepared_constraint + remove_unprepared_constraints (solver.rs:406-452)
-    for (uint32_t e = 0; e < w->effective.size(); ++e) {
+    // the usual frame: the same contact ids in the same order as last time — every id keeps its slot, nothing to look up or to remove
+    bool same_ids = w->cache.size() == w->effective.size();
+    for (uint32_t e = 0; same_ids && e < w->effective.size(); ++e) same_ids = w->cache[e].id == w->effective[e].id;
+    if (same_ids)
+        for (uint32_t e = 0; e < w->effective.size(); ++e) {
+            w->cache[e].src = e;
+            w->cache[e].prepared = true;
+        }
+    for (uint32_t e = 0; !same_ids && e < w->effective.size(); ++e) {
         const uint64_t id = w->effective[e].id;
         auto it = w->index_of.find(id);
         if (it != w->index_of.end()) {
@@ -347,12 +358,18 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
     w->n_prev = w->n_contacts;  // size of the state arrays written by the previous prepare
     w->n_contacts = nc;
     // 3. dependency schedules: (warm pass + velocity sweeps) and (positional sweeps)
-    w->items_host.clear();
-    w->item_bodies_host.clear();
-    w->level_start_host.clear();
     build_chains(w);
-    build_schedule(w, PHYS_ITEM_WARM, 1u, PHYS_ITEM_VELOCITY, w->cfg.n_iterations, 0);
-    build_schedule(w, PHYS_ITEM_POSITIONAL, 0u, PHYS_ITEM_POSITIONAL, w->cfg.n_positional_correction_iterations, 1);
+    // the schedule depends on the chains and their body pairs only: an unchanged contact structure keeps last frame's (host and device copies)
+    const bool same_schedule = w->schedule_valid && w->chain_start == w->prev_chain_start && w->chain_bodies == w->prev_chain_bodies;
+    if (!same_schedule) {
+        w->items_host.clear();
+        w->item_bodies_host.clear();
+        w->level_start_host.clear();
+        build_schedule(w, PHYS_ITEM_WARM, 1u, PHYS_ITEM_VELOCITY, w->cfg.n_iterations, 0);
+        build_schedule(w, PHYS_ITEM_POSITIONAL, 0u, PHYS_ITEM_POSITIONAL, w->cfg.n_positional_correction_iterations, 1);
+        w->prev_chain_start = w->chain_start;
+        w->prev_chain_bodies = w->chain_bodies;
+    }
     // 4. upload
     hipStream_t s = w->ctx->stream;
     size_t cap = w->contact_cap;
@@ -392,11 +409,13 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
         IVX_HIP_CHECK(hipMemcpy(w->contacts, w->ordered.data(), nc * sizeof(ivx_contact), hipMemcpyHostToDevice));
         IVX_HIP_CHECK(hipMemcpy(w->prev_slot, w->prev_slot_host.data(), nc * sizeof(int32_t), hipMemcpyHostToDevice));
     }
-    if (!w->items_host.empty()) {
-        IVX_HIP_CHECK(hipMemcpy(w->items, w->items_host.data(), w->items_host.size() * 4, hipMemcpyHostToDevice));
-        IVX_HIP_CHECK(hipMemcpy(w->item_bodies, w->item_bodies_host.data(), w->item_bodies_host.size() * 4, hipMemcpyHostToDevice));
+    if (!same_schedule) {
+        if (!w->items_host.empty()) {
+            IVX_HIP_CHECK(hipMemcpy(w->items, w->items_host.data(), w->items_host.size() * 4, hipMemcpyHostToDevice));
+            IVX_HIP_CHECK(hipMemcpy(w->item_bodies, w->item_bodies_host.data(), w->item_bodies_host.size() * 4, hipMemcpyHostToDevice));
+        }
+        IVX_HIP_CHECK(hipMemcpy(w->level_start, w->level_start_host.data(), w->level_start_host.size() * 4, hipMemcpyHostToDevice));
     }
-    IVX_HIP_CHECK(hipMemcpy(w->level_start, w->level_start_host.data(), w->level_start_host.size() * 4, hipMemcpyHostToDevice));
     w->schedule_valid = 1;
     // 5. device part of prepare_constraints: gather bodies, prepare every contact, warm-start bookkeeping
     w->cur ^= 1;

@@ -71,6 +71,7 @@ struct ivx_world {
     std::vector<ivx_contact> ordered;
     std::vector<int32_t> prev_slot_host;
     std::vector<uint32_t> item_bodies_host, items_host, level_start_host, scratch_level, scratch_last, chain_start;
+    std::vector<uint32_t> chain_bodies, prev_chain_start, prev_chain_bodies;  // body pair per chain; last frame's chains (an unchanged contact structure keeps its schedule)
 };
 
 int ivx_launch_phys_prepare_bodies(ivx_world* w);
