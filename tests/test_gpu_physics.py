@@ -142,6 +142,27 @@ def test_contacts_come_and_go(ctx):
     w.close()
 
 
+def test_repeated_and_changing_contact_sets_alternate(ctx):
+    """the steady-state shortcuts of ivx_world_set_contacts (same ids in the same order keep their slots without lookups; an unchanged chain
+    structure keeps its schedule) between frames that change the set, reorder it, or only move the contact geometry: every frame against
+    the oracle, contact order and warm-started impulses included"""
+    rng = np.random.default_rng(11)
+    bodies, contacts = scenes.sphere_pile_scene(4)
+    bodies["momentum"] += rng.normal(0, 0.05, bodies["momentum"].shape).astype(np.float32)
+    w, o = pu.make_pair(ctx, bodies)
+    manifolds = contacts.reshape(-1, 4)
+    full, half = np.arange(len(manifolds)), np.arange(0, len(manifolds), 2)
+    frames = [full, full, full, half, half, full, full, full[::-1], full[::-1], half, half, half]
+    for s, keep in enumerate(frames):
+        cs = manifolds[keep].reshape(-1).copy()
+        if s % 3 == 1:  # same ids and structure, other geometry: the schedule is reused, the contacts themselves are not
+            cs["depth"] = (cs["depth"] * np.float32(0.5)).astype(np.float32)
+        pu.step_both(w, o, cs, 0.004)
+        pu.assert_bodies_close(w.bodies()[0], o.bodies()[0], what=f"frame {s}: ")
+        pu.compare_contact_state(w, o)
+    w.close()
+
+
 def test_interlocked_manifold(ctx):
     """contact.rs:610-780 through the GPU path: opposing penetration vectors are replaced by one
     separating contact (needs the bodies' current positions from the device)"""
