@@ -163,3 +163,74 @@ def test_fragments_cut_by_planes_get_their_bodies(ctx):
         np.testing.assert_allclose(m_back, m_own_g, rtol=1e-9, atol=1e-6)  # there and back again, in f64
         child_g.close()
     g.close()
+
+
+def test_absorber_eating_through_a_tumbling_body_frame_by_frame(ctx):
+    """the per-frame chain of apply_absorption (interaction/absorption.rs:434-682) for one absorbing sphere and one free voxel body: world ->
+    object transform from the body pose and the local centre of mass (absorption.rs:713-722), absorb, the removed moments leave the manager,
+    handle_voxel_object_after_removing_voxels re-seats the body (fragments get their own), incremental remesh, then the rigid-body step.
+    Both pipelines take the absorber's normalized position from the oracle's body (quantised voxels must not depend on 1e-6 differences
+    in the pose); voxels, fragments and meshes bit-equal, bodies within 1e-5 / 1e-4 every frame"""
+    from impact_amd.interaction import RemovedMassFate, handle_voxel_object_after_removing_voxels
+    from impact_amd.voxel import VoxelObjectMesh
+
+    ext = 0.25
+    dens = np.ones(256, dtype=f32) * f32(3.0)
+    from impact_amd.sdf_graph import SDFGraph, SDFNode
+
+    gr = SDFGraph()
+    gr.add_node(SDFNode.new_box([70.0, 16.0, 16.0]))  # a rod: the absorber cuts it in two on its way through
+    o, g = both(ctx, gr, ext)
+    om, gm = ol.OracleMeshHandle(o), VoxelObjectMesh.create(g)
+    q0 = np.array([0.0, 0.0, np.sin(0.2), np.cos(0.2)])
+    body, com = body_for(o, dens, (0.0, 0.0, 0.0), (0.05, 0.0, 0.0), (0.0, 0.3, 0.8), q0)
+    m32 = o.inertia(dens)[0].copy()
+    m64 = VoxelObjectInertialPropertyManager.initialized_from(g, dens).m64.copy()
+    bo, bg = body.copy(), body.copy()
+    com_o, com_g = com.copy(), com.copy()
+    n_frag = 0
+    for frame in range(14):
+        # the absorber moves along world -y through the rod's middle
+        c_world = np.array([0.6, 4.0 - 0.6 * frame, 0.1])
+        R = 2.7
+        qi = np.array([-bo["orientation"][0], -bo["orientation"][1], -bo["orientation"][2], bo["orientation"][3]], dtype=np.float64)
+        x, y, z, w = qi
+        bv = np.array([x, y, z])
+        v = c_world - bo["position"].astype(np.float64)
+        c_obj = (v * (w * w - bv @ bv) + bv * (2 * (v @ bv)) + np.cross(bv, v) * (2 * w)) + com_o.astype(np.float64)
+        c_norm = (c_obj / ext).astype(f32)
+        r_norm = float(f32(R / ext))
+        ro = o.absorb_sphere(c_norm, r_norm + 2.0, r_norm, dens)
+        rg = g.absorb_sphere(c_norm, r_norm + 2.0, r_norm, dens)
+        np.testing.assert_array_equal(rg["invalidated"], ro["invalidated"])
+        om.sync(ro["invalidated"])
+        gm.sync_with_voxel_object(rg["invalidated"])
+        m32 = o.inertia(dens)[0].copy()  # (the oracle's manager after the removal = its moments from scratch, as validate_for_object checks)
+        m64 = m64 - rg["removed_moments"]
+        want_parent, want_com, want_m, want_frags = oracle_handle(o, ext, dens, bo, com_o, RemovedMassFate.TRANSFERRED)
+        res = handle_voxel_object_after_removing_voxels(g, dens, m64, bg, com_g, RemovedMassFate.TRANSFERRED)
+        assert len(res["extracted"]) == len(want_frags), frame
+        close(res["rigid_body"], want_parent)
+        m64 = res["moments64"]
+        np.testing.assert_allclose(m64, want_m.astype(np.float64), rtol=3e-5, atol=1e-3)
+        for got, want in zip(res["extracted"], want_frags):
+            close(got["rigid_body"], want["body"])
+            pu.assert_edited_objects_equal(want["object"], got["voxel_object"], densities=dens)
+            got["voxel_object"].close()
+            n_frag += 1
+        if want_frags:  # the split rewrote chunks of the parent: a full remesh on both sides (the reference recreates meshes of split objects)
+            om = ol.OracleMeshHandle(o)
+            gm.recreate()
+        pu.assert_edited_objects_equal(o, g, densities=dens, with_mesh=False)
+        bo, bg = want_parent.copy(), res["rigid_body"].copy()
+        com_o, com_g = want_com.copy(), res["new_local_center_of_mass"].copy()
+        # free flight of the parent for one step on both sides
+        wp = phu.make_pair(ctx, np.array([bg]))
+        wp[0].perform_physics_step(np.zeros(0, dtype=__import__("impact_amd.capi", fromlist=["CONTACT_DTYPE"]).CONTACT_DTYPE), 0.01)
+        po = ol.OraclePhysics(np.array([bo]), None, (8, 0.4, 3, 0.2))
+        po.step(np.zeros(0, dtype=__import__("impact_amd.capi", fromlist=["CONTACT_DTYPE"]).CONTACT_DTYPE), 0.01)
+        bg, bo = wp[0].bodies()[0][0].copy(), po.bodies()[0][0].copy()
+        wp[0].close()
+        close(bg, bo)
+    assert n_frag >= 1  # the rod was cut
+    g.close()
