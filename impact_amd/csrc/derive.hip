@@ -496,6 +496,7 @@ int ivx_launch_derive(ivx_grid* g, uint32_t parts) {
     fz.chunk_moments = g->chunk_moments;
     if ((parts & IVX_PART_REGIONS) && !g->scratch_preset) IVX_HIP_CHECK(hipMemsetAsync(g->rscalar, 0, 16 * sizeof(uint32_t), g->ctx->stream));
     if (!g->scratch_preset) IVX_HIP_CHECK(hipMemsetAsync(g->work_counts, 0, sizeof(uint32_t), g->ctx->stream));
+    g->bbox_valid = 1;
     hipLaunchKernelGGL(k_chunk_pre, dim3((g->n_chunks + 255u) / 256u), dim3(256), 0, g->ctx->stream, v, g->info, g->chunk_bbox, g->chunk_counts,
                        g->chunk_class, g->chunk_touch, g->rparent, g->work_counts, g->active_list);
     hipLaunchKernelGGL(k_derive, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->sdf, g->type, g->flags, g->info, g->chunk_bbox,

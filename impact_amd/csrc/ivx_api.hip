@@ -149,6 +149,21 @@ __global__ __launch_bounds__(256) void k_chunk_mesh_needs(uint32_t n, const uint
 // ---- incremental remesh (row a7: VoxelObjectMesh::sync_with_voxel_object, mesh.rs:355-456) ---------------------------------------------
 // Host mirror of the ChunkSubmeshManager (mesh.rs:699-849) with its two RangeAllocators (impact_containers/src/range_allocator.rs): which slot
 // of the submesh table a chunk owns and which ranges of the vertex / index buffers are free. The mesh data stays in HBM.
+// the occupied ranges in the reference's sense (see ivx_grid::occ_ref): cached, recomputed only when something invalidated them
+static int reference_occupied(ivx_grid* g, uint32_t occ[12]) {
+    if (!g->occ_ref_valid) {
+        uint32_t* d_occ = g->rscalar + 16;
+        int rc;
+        if ((rc = ivx_launch_occupied(g, d_occ))) return rc;
+        uint32_t raw[12];
+        if ((rc = d2h(g, raw, d_occ, sizeof(raw)))) return rc;
+        ivx_occupied_from_raw(g, raw, g->occ_ref);
+        g->occ_ref_valid = 1;
+    }
+    memcpy(occ, g->occ_ref, sizeof(g->occ_ref));
+    return IVX_OK;
+}
+
 struct ivx_range_allocator {
     std::map<size_t, size_t> free_ranges;  // start -> end; a second range with the same start is dropped, as BTreeSet::insert does
     void free_range(size_t a, size_t b) {
@@ -401,6 +416,8 @@ int ivx_grid_upload_dense(ivx_grid* g, const int8_t* sdf, const uint8_t* type, s
     if ((rc = ivx_launch_classify(g))) return rc;
     g->mesh_valid = 0;
     g->mesh_built = 0;
+    g->occ_ref_valid = 0;
+    g->bbox_valid = 0;
     g->regions_valid = 0;
     IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
     return IVX_OK;
@@ -492,6 +509,8 @@ int ivx_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* nodes, size_t n_no
     if (rc) return rc;
     g->mesh_valid = 0;
     g->mesh_built = 0;
+    g->occ_ref_valid = 0;
+    g->bbox_valid = 0;
     g->regions_valid = 0;
     IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
     return IVX_OK;
@@ -509,12 +528,15 @@ int ivx_derive_state(ivx_grid* g) {
 
 int ivx_occupied_ranges(ivx_grid* g, uint32_t out[12]) {
     IVX_REQUIRE(g && out, IVX_ERR_INVALID, "ivx_occupied_ranges: null argument");
+    IVX_REQUIRE(g->bbox_valid, IVX_ERR_STATE, "ivx_occupied_ranges: the chunk boxes come from the derive sweep (call ivx_derive_state first)");
     uint32_t* d = g->rscalar + 16;
     int rc;
     if ((rc = ivx_launch_occupied(g, d))) return rc;
     uint32_t raw[12];
     if ((rc = d2h(g, raw, d, 12 * sizeof(uint32_t)))) return rc;
     ivx_occupied_from_raw(g, raw, out);
+    memcpy(g->occ_ref, out, sizeof(g->occ_ref));  // VoxelObject::update_occupied_ranges: this is what the object holds from now on
+    g->occ_ref_valid = 1;
     return IVX_OK;
 }
 
@@ -881,7 +903,7 @@ int ivx_split_off_smallest_region(ivx_grid* parent, ivx_grid** child, uint32_t o
         c = single;
         for (int q = 0; q < 3; ++q) origin_offset_in_parent[q] += off[q];
     }
-    if ((rc = rederive(parent))) {
+    if ((parent->occ_ref_valid = 0, rc = rederive(parent))) {
         ivx_grid_destroy(c);
         return rc;
     }
@@ -977,7 +999,7 @@ int ivx_clip_polyhedron(ivx_grid* parent, const float* planes4, size_t n_planes,
         return rc;
     }
     for (int q = 0; q < 3; ++q) origin_offset_in_parent[q] = lo[q] * 16u;
-    if (!copy && (rc = rederive(parent))) {
+    if (!copy && (parent->occ_ref_valid = 0, rc = rederive(parent))) {
         ivx_grid_destroy(c);
         return rc;
     }
@@ -1040,11 +1062,8 @@ static int absorb_shape(ivx_grid* g, const char* who, int capsule, const float c
     if (invalidated_chunks) memset(invalidated_chunks, 0, g->n_chunks);
     int rc;
     // the touched voxel ranges start from the object's occupied ranges (voxel_ranges_touching_aab, intersection.rs:766-782)
-    uint32_t* d_occ = g->rscalar + 16;
-    if ((rc = ivx_launch_occupied(g, d_occ))) return rc;
-    uint32_t occ_raw[12], occ[12];
-    if ((rc = d2h(g, occ_raw, d_occ, sizeof(occ_raw)))) return rc;
-    ivx_occupied_from_raw(g, occ_raw, occ);
+    uint32_t occ[12];
+    if ((rc = reference_occupied(g, occ))) return rc;
     int32_t vlo[3], vhi[3];
     uint32_t lo[3], cc[3];
     for (int d = 0; d < 3; ++d) {
@@ -1095,6 +1114,7 @@ static int absorb_shape(ivx_grid* g, const char* who, int capsule, const float c
     const uint32_t* cnt = reinterpret_cast<const uint32_t*>(hostbuf.data() + off_cnt);
     out->touched_chunks = cnt[0];
     out->removed_chunks = cnt[1];
+    if (cnt[1]) g->occ_ref_valid = 0;  // `if removed_chunks { self.update_occupied_ranges() }` (intersection.rs:384-386, 520-522)
     if (invalidated_chunks) {
         // handle_chunk_voxels_modified (intersection.rs:560-598): the touched chunk, and a neighbour when the touched voxel range
         // of the chunk comes within two voxels of the face they share
@@ -1171,11 +1191,8 @@ static int voxel_object_contacts(ivx_grid* g, const char* who, int mode, const f
                 who);
     *n_out = 0;
     int rc;
-    uint32_t* d_occ = g->rscalar + 16;
-    if ((rc = ivx_launch_occupied(g, d_occ))) return rc;
-    uint32_t occ_raw[12], occ[12];
-    if ((rc = d2h(g, occ_raw, d_occ, sizeof(occ_raw)))) return rc;
-    ivx_occupied_from_raw(g, occ_raw, occ);
+    uint32_t occ[12];
+    if ((rc = reference_occupied(g, occ))) return rc;
     const float inv = 1.0f / g->extent;
     float lo_f[3], hi_f[3];
     if (mode == 2) {
@@ -1288,11 +1305,8 @@ int ivx_collision_probes_recompute(ivx_grid* g, size_t* n_points) {
     IVX_REQUIRE(g->cc[0] <= 1024 && g->cc[1] <= 1024 && g->cc[2] <= 1024, IVX_ERR_INVALID, "ivx_collision_probes_recompute: more than 1024 chunks along an axis");
     *n_points = 0;
     int rc;
-    uint32_t* d_occ = g->rscalar + 16;
-    if ((rc = ivx_launch_occupied(g, d_occ))) return rc;
-    uint32_t occ_raw[12], occ[12];
-    if ((rc = d2h(g, occ_raw, d_occ, sizeof(occ_raw)))) return rc;
-    ivx_occupied_from_raw(g, occ_raw, occ);
+    uint32_t occ[12];
+    if ((rc = reference_occupied(g, occ))) return rc;
     // determine_log2_block_size_for_object (collidable.rs:451-471)
     uint32_t min_extent = 0xFFFFFFFFu;
     for (int d = 0; d < 3; ++d) min_extent = std::min(min_extent, occ[7 + 2 * d] > occ[6 + 2 * d] ? occ[7 + 2 * d] - occ[6 + 2 * d] : 0u);
@@ -1415,11 +1429,8 @@ int ivx_collision_probes_sync(ivx_grid* g, const uint8_t* invalidated_chunks, si
                 "%s: the probes must be those of the mesh before the last ivx_mesh_sync (ivx_collision_probes_recompute, or a sync per mesh sync)", who);
     int rc;
     if ((rc = probe_manager_build(g))) return rc;
-    uint32_t* d_occ = g->rscalar + 16;
-    if ((rc = ivx_launch_occupied(g, d_occ))) return rc;
-    uint32_t occ_raw[12], occ[12];
-    if ((rc = d2h(g, occ_raw, d_occ, sizeof(occ_raw)))) return rc;
-    ivx_occupied_from_raw(g, occ_raw, occ);
+    uint32_t occ[12];
+    if ((rc = reference_occupied(g, occ))) return rc;
     uint32_t min_extent = 0xFFFFFFFFu;
     for (int d = 0; d < 3; ++d) min_extent = std::min(min_extent, occ[7 + 2 * d] > occ[6 + 2 * d] ? occ[7 + 2 * d] - occ[6 + 2 * d] : 0u);
     const uint32_t log2_bs = min_extent >= 16 ? 3 : (min_extent >= 8 ? 2 : (min_extent >= 4 ? 1 : 0));
@@ -1682,14 +1693,8 @@ int ivx_mutual_voxel_object_contacts(ivx_grid* a, const float rotation_a[4], con
     *n_out = 0;
     int rc;
     uint32_t occ_a[12], occ_b[12];
-    for (int w = 0; w < 2; ++w) {
-        ivx_grid* g = w ? b : a;
-        uint32_t* d_occ = g->rscalar + 16;
-        if ((rc = ivx_launch_occupied(g, d_occ))) return rc;
-        uint32_t raw[12];
-        if ((rc = d2h(g, raw, d_occ, sizeof(raw)))) return rc;
-        ivx_occupied_from_raw(g, raw, w ? occ_b : occ_a);
-    }
+    if ((rc = reference_occupied(a, occ_a))) return rc;
+    if ((rc = reference_occupied(b, occ_b))) return rc;
     long ra_lo[3], ra_hi[3], rb_lo[3], rb_hi[3];
     float q_ba[4], t_ba[3];
     if (!host_intersection_ranges(a, occ_a, rotation_a, translation_a, b, occ_b, rotation_b, translation_b, ra_lo, ra_hi, rb_lo, rb_hi, q_ba, t_ba)) return IVX_OK;
@@ -1775,14 +1780,8 @@ int ivx_absorb_mutual(ivx_grid* a, const float rotation_a[4], const float transl
     if (invalidated_chunks_b) memset(invalidated_chunks_b, 0, b->n_chunks);
     int rc;
     uint32_t occ_a[12], occ_b[12];
-    for (int w = 0; w < 2; ++w) {
-        ivx_grid* g = w ? b : a;
-        uint32_t* d_occ = g->rscalar + 16;
-        if ((rc = ivx_launch_occupied(g, d_occ))) return rc;
-        uint32_t raw[12];
-        if ((rc = d2h(g, raw, d_occ, sizeof(raw)))) return rc;
-        ivx_occupied_from_raw(g, raw, w ? occ_b : occ_a);
-    }
+    if ((rc = reference_occupied(a, occ_a))) return rc;
+    if ((rc = reference_occupied(b, occ_b))) return rc;
     long ra_lo[3], ra_hi[3], rb_lo[3], rb_hi[3];
     float q_ba[4], t_ba[3];
     if (!host_intersection_ranges(a, occ_a, rotation_a, translation_a, b, occ_b, rotation_b, translation_b, ra_lo, ra_hi, rb_lo, rb_hi, q_ba, t_ba)) return IVX_OK;
@@ -1860,6 +1859,7 @@ int ivx_absorb_mutual(ivx_grid* a, const float rotation_a[4], const float transl
         const uint32_t* cnt = reinterpret_cast<const uint32_t*>(hb + off_cnt);
         out->touched_chunks = cnt[0];
         out->removed_chunks = cnt[1];
+        if (cnt[1]) g->occ_ref_valid = 0;  // (intersection.rs:255-257)
         if (!inval) continue;
         const uint32_t* touched = reinterpret_cast<const uint32_t*>(hb + off_touch);  // handle_chunk_voxels_modified (intersection.rs:560-598)
         for (uint32_t i = lo[0]; i < lo[0] + cc[0]; ++i)
@@ -1984,6 +1984,8 @@ int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
         T0(0);
         if ((rc = ivx_launch_sdf_sample(g, g->prog_nodes, g->prog_n, g->prog_stack, g->prog_shape, g->prog_center, g->prog_type))) return rc;
         T1(0);
+        g->occ_ref_valid = 0;
+        g->bbox_valid = 0;
         g->mesh_valid = 0;
         g->mesh_built = 0;  // a newly sampled object: whatever mesh the buffers hold is not a stale version of this one
         g->regions_valid = 0;
@@ -2058,7 +2060,11 @@ int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out) {
         g->regions_valid = 1;
         out->region_count = sc[0];
     }
-    if (stages & IVX_STAGE_OCCUPIED) ivx_occupied_from_raw(g, sc + 16, out->occupied);
+    if (stages & IVX_STAGE_OCCUPIED) {
+        ivx_occupied_from_raw(g, sc + 16, out->occupied);
+        memcpy(g->occ_ref, out->occupied, sizeof(g->occ_ref));
+        g->occ_ref_valid = 1;
+    }
     if (stages & IVX_STAGE_REMESH) {
         const uint32_t totals[3] = {sc[28], sc[29], sc[30]};
         if (totals[0] > g->vcap || totals[1] > g->icap || totals[2] > g->scap) {

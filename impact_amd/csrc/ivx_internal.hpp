@@ -133,6 +133,12 @@ struct ivx_grid {
     size_t probe_point_cap, probe_entry_cap;
     uint32_t n_probe_points, n_probe_sub;
     uint64_t mesh_serial, probes_serial;  // probes are current while they were picked from the current mesh
+    // the object's occupied ranges as the reference keeps them (object.rs:1149-1280): refreshed by an explicit update, by split / clip, and by an
+    // edit only when it removed a chunk (intersection.rs:255-257, 384-386, 520-522) — in between they may be wider than the voxels need, and the
+    // edit, contact and probe entry points must see exactly those ranges
+    uint32_t occ_ref[12];
+    int occ_ref_valid;
+    int bbox_valid;  // the per-chunk boxes the occupied ranges are reduced from exist (written by the derive sweep; the sampler uses the buffer as scratch)
     int mesh_built;  // the mesh buffers hold a mesh of this grid, current (mesh_valid) or made stale by an edit — what ivx_mesh_sync patches
     struct ivx_submesh_manager* submesh_manager;
     struct ivx_probe_manager* probe_manager;  // host mirror of the probes' chunk -> point range map and range allocator  // host mirror of the ChunkSubmeshManager, built by the first ivx_mesh_sync after a full remesh

@@ -158,8 +158,8 @@ public:
     }
     static std::unique_ptr<VoxelObject> generate(Context& ctx, const SDFVoxelGenerator& gen) {  // object.rs:239-244
         auto o = generate_without_derived_state(ctx, gen);
-        o->update_occupied_voxel_ranges();
-        o->compute_all_derived_state();
+        o->compute_all_derived_state();       // (the reference updates the ranges first; here they are reduced from per-chunk boxes the derive
+        o->update_occupied_voxel_ranges();    //  sweep leaves, the result is the same: emptiness does not change in between)
         return o;
     }
     void compute_all_derived_state() {  // object.rs:1136-1145

@@ -144,7 +144,9 @@ int ivx_sdf_sample(ivx_grid*, const ivx_sdf_processed_node* nodes, size_t n_node
 /* VoxelObject::compute_all_derived_state minus region labelling (object.rs:1136-1145): voxel adjacency
  * flags, face distributions, chunk obscuredness, uniform-chunk demotion. */
 int ivx_derive_state(ivx_grid*);
-/* VoxelObject::update_occupied_ranges (object.rs:1149-1198): out = chunk lo/hi x3, voxel lo/hi x3 */
+/* VoxelObject::update_occupied_ranges (object.rs:1149-1198): out = chunk lo/hi x3, voxel lo/hi x3. Needs ivx_derive_state first (the ranges are reduced
+ * from per-chunk boxes the derive sweep leaves). The object keeps these ranges the way the reference does: the edit, contact and probe entry points
+ * use them as they were at the last update — an edit refreshes them only when it removed a chunk, split and clip always do. */
 int ivx_occupied_ranges(ivx_grid*, uint32_t out[12]);
 
 /* ---- a5-a7: remesh ------------------------------------------------------------------------------ */

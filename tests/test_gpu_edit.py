@@ -296,3 +296,25 @@ def test_mutual_absorption_with_materials(ctx):
     assert ra["emptied_voxels"] > 300 and rb["emptied_voxels"] > 300
     GA.close()
     GB.close()
+
+
+def test_occupied_ranges_stay_as_the_reference_keeps_them(ctx):
+    """the reference refreshes an object's occupied ranges after an edit only when a chunk was removed (intersection.rs:384-386): a bite that
+    takes the outermost voxels leaves the ranges wider than needed, and the next edit still visits (and re-quantises) the empty voxels out
+    there. Two overlapping bites at the tip of a sphere, then a capsule across it: equal to the oracle each time, and the ranges the HIP path
+    reports on an explicit update are the tight ones again"""
+    o, g = both(ctx, scenes.sphere_scene(20.0))
+    c0 = centre_of(o)
+    tip = c0 + np.float32(20.0) * np.array([0.0, 1.0, 0.0], np.float32)
+    r1 = absorb_both(o, g, tip, 6.0)
+    assert r1["removed_chunks"] == 0 and r1["emptied_by_type"].sum() > 50
+    before = o.info()["occupied_voxel_ranges"]
+    r2 = absorb_both(o, g, tip - np.array([0.0, 4.0, 0.0], np.float32), 9.0)
+    assert r2["removed_chunks"] == 0
+    assert o.info()["occupied_voxel_ranges"] == before  # (stale on purpose)
+    absorb_capsule_both(o, g, tip + np.array([-15.0, -1.0, 0.0], np.float32), np.array([30.0, 0.0, 0.0], np.float32), 5.0)
+    o.update_occupied_voxel_ranges()
+    tight = g.update_occupied_voxel_ranges()
+    assert [tuple(t) for t in tight] == [tuple(t) for t in o.info()["occupied_voxel_ranges"]]
+    assert tight[1][1] < before[1][1]  # the top rows are gone
+    g.close()
