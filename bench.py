@@ -320,7 +320,10 @@ def main():
     torch.cuda.set_device(device)
     ctx = Context(device)
     dist = None
-    if world > 1:
+    # IVX_BENCH_FORCE_SLABS=1: run the slab protocol (and its RCCL calls) even at world size 1 — a single-GPU check of the
+    # N>1 code path under torch.distributed.run; never the default
+    slabs = world > 1 or os.environ.get("IVX_BENCH_FORCE_SLABS") == "1"
+    if slabs:
         import torch.distributed as dist_mod
 
         dist = dist_mod
@@ -343,7 +346,7 @@ def main():
     body_world = PhysicsWorld(ctx)
     body_world.set_bodies(np.array([uniform_sphere_body(100.0, 1.0, (0.0, 0.0, 0.0), (0.1, 0.0, 0.0))]))
     body_world.prepare_constraints(np.zeros(0, dtype=capi.CONTACT_DTYPE))
-    if world == 1:
+    if not slabs:
         gen = SDFVoxelGenerator(1.0, scenes.asteroid_scene(args.scale), 0)
         cc = gen.chunk_counts()
         obj = VoxelObject(ctx, cc, 1.0)
