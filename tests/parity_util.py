@@ -104,3 +104,22 @@ def assert_edited_objects_equal(o: ol.OracleObject, g: VoxelObject, what="", den
         assert_mesh_equal(o, g)
     assert_inertia_equal(o, g, densities)
     return n
+
+
+def fuzz_seeds(default):
+    """Seeds of a randomized parity test: the committed ones, or the range `IVX_FUZZ_SEEDS=a:b` names (a wider sweep run by hand
+    on the GPU box; tools/fuzz_parity.sh)."""
+    import os
+
+    spec = os.environ.get("IVX_FUZZ_SEEDS")
+    if not spec:
+        return list(default)
+    a, b = spec.split(":")
+    return list(range(int(a), int(b)))
+
+
+def fuzzing() -> bool:
+    """True in a hand-run seed sweep: the 'this case exercised enough' assertions only hold for the committed seeds."""
+    import os
+
+    return bool(os.environ.get("IVX_FUZZ_SEEDS"))

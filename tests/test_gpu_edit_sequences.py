@@ -13,7 +13,7 @@ from impact_amd.voxel import VoxelObjectMesh
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("seed", pu.fuzz_seeds([1, 2, 3, 4, 5, 6]))
 def test_random_edit_sequence(ctx, seed):
     rng = np.random.default_rng(seed)
     graph = scenes.asteroid_scene(0.3) if seed % 3 else scenes.box_scene((40.0, 26.0, 33.0))
@@ -63,5 +63,5 @@ def test_random_edit_sequence(ctx, seed):
         np.testing.assert_array_equal(got_ent, want_ent)
         for e in want_ent:
             np.testing.assert_array_equal(got_pts[e[3]:e[4]].view(np.uint32), want_pts[e[3]:e[4]].view(np.uint32))
-    assert emptied > 1000
+    assert emptied > 1000 or pu.fuzzing()
     g.close()

@@ -30,7 +30,7 @@ def random_quaternion(rng, kind):
     return (q / np.linalg.norm(q)).astype(f32)
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+@pytest.mark.parametrize("seed", pu.fuzz_seeds([1, 2, 3, 4]))
 def test_random_poses(ctx, seed):
     rng = np.random.default_rng(100 + seed)
     ga = scenes.asteroid_scene(0.3) if seed % 2 else scenes.box_scene((44.0, 20.0, 30.0))
@@ -56,7 +56,7 @@ def test_random_poses(ctx, seed):
         got = GA.mutual_contacts(qa, ta, ca, GB, qb, tb, cb, 7, 9, 0, 1, (0.1, 0.2, 0.3))
         tc.assert_contacts_equal(got, want)
         n_with_contacts += len(want) > 0
-    assert n_with_contacts >= 3
+    assert n_with_contacts >= 3 or pu.fuzzing()
     # and two rounds of mutual absorption at overlapping poses (the objects change in between)
     for rnd in range(2):
         qa, qb = random_quaternion(rng, 3), random_quaternion(rng, 2 + rnd)
@@ -70,6 +70,6 @@ def test_random_poses(ctx, seed):
             assert rg["emptied_voxels"] == ro["emptied_voxels"] and rg["touched_chunks"] == ro["touched_chunks"]
             np.testing.assert_array_equal(rg["invalidated"], ro["invalidated"])
             pu.assert_edited_objects_equal(o, g)
-        assert roa["emptied_voxels"] + rob["emptied_voxels"] > 100
+        assert roa["emptied_voxels"] + rob["emptied_voxels"] > 100 or pu.fuzzing()
     GA.close()
     GB.close()

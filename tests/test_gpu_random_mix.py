@@ -18,7 +18,7 @@ def rand_q(rng):
     return (q / np.linalg.norm(q)).astype(f32)
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15])
+@pytest.mark.parametrize("seed", pu.fuzz_seeds([11, 12, 13, 14, 15]))
 def test_random_operation_mix(ctx, seed):
     rng = np.random.default_rng(seed)
     ext = [1.0, 0.5, 0.25][seed % 3]
@@ -76,7 +76,7 @@ def test_random_operation_mix(ctx, seed):
                 continue
             rc_o, child_o, origin_o = o.split_off_smallest_region()
             rc_g, child_g, origin_g, _ = g.extract_any_disconnected_region()
-            assert rc_o == rc_g and tuple(int(x) for x in origin_g) == tuple(origin_o)
+            assert rc_o == rc_g and (rc_o != 1 or tuple(int(x) for x in origin_g) == tuple(origin_o))  # the origin is the child's: only outcome 1 has one
             pu.assert_edited_objects_equal(o, g, what=f"step {step} split parent: ")
             if rc_o == 1:
                 pu.assert_edited_objects_equal(child_o, child_g, what=f"step {step} split child: ")
@@ -86,5 +86,5 @@ def test_random_operation_mix(ctx, seed):
             tight = g.update_occupied_voxel_ranges()
             assert [tuple(t) for t in tight] == [tuple(t) for t in o.info()["occupied_voxel_ranges"]]
         ops_done[kind] += 1
-    assert sum(ops_done.values()) >= 10
+    assert sum(ops_done.values()) >= 10 or pu.fuzzing()
     g.close()
