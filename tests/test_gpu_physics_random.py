@@ -1,0 +1,63 @@
+"""Random contact graphs through the sequential-impulses solver (fixed seeds): irregular chains (bodies with one contact and with a dozen,
+pairs given in either body order, manifolds of 1-4 contacts, a static plane), contact sets that persist, vanish and reappear between frames
+in shuffled order. Every frame: body state within 1e-5 relative, ContactID order identical, warm-started impulses within 1e-4."""
+import numpy as np
+import pytest
+
+import parity_util
+import physics_util as pu
+from impact_amd.capi import CONTACT_DTYPE, KINEMATIC_BIT
+from impact_amd.physics import uniform_sphere_body
+from test_gpu_physics import contact
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+@pytest.mark.parametrize("seed", parity_util.fuzz_seeds([21, 22, 23, 24]))
+def test_random_contact_graphs(ctx, seed):
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(2, 60))
+    pos = rng.uniform(-3.0, 3.0, (n, 3)).astype(f32)
+    bodies = np.array([uniform_sphere_body(float(rng.uniform(0.3, 0.8)), float(rng.uniform(0.5, 3.0)), pos[i], rng.normal(0, 0.3, 3)) for i in range(n)])
+    bodies["angular_momentum"] = rng.normal(0, 0.02, (n, 3)).astype(f32)
+    w, o = pu.make_pair(ctx, bodies, pu.static_plane())
+    n_pairs = int(rng.integers(1, 3 * n))
+    pairs = []
+    for k in range(n_pairs):
+        a = int(rng.integers(0, n))
+        if rng.random() < 0.15:
+            b = KINEMATIC_BIT | 0
+        else:
+            b = int(rng.integers(0, n))
+            if b == a:
+                b = KINEMATIC_BIT | 0
+        if rng.random() < 0.3 and not (b & KINEMATIC_BIT):
+            a, b = b, a
+        pairs.append((a, b, int(rng.integers(1, 5)), rng.random() < 0.5))
+    alive = rng.random(n_pairs) < 0.7
+    for frame in range(6):
+        gd = w.bodies()[0]
+        cs = []
+        order = rng.permutation(n_pairs)
+        for k in order:
+            if not alive[k]:
+                continue
+            a, b, m, frictional = pairs[k]
+            pa = gd[a]["position"].astype(np.float64)
+            pb = np.array([pa[0], 0.0, pa[2]]) if (b & KINEMATIC_BIT) else gd[b]["position"].astype(np.float64)
+            nrm = pa - pb
+            nrm = nrm / np.linalg.norm(nrm) if np.linalg.norm(nrm) > 1e-6 else np.array([0.0, 1.0, 0.0])
+            mid = 0.5 * (pa + pb)
+            for j in range(m):
+                jitter = rng.normal(0, 0.1, 3)
+                geom = ((mid + jitter).astype(f32), nrm.astype(f32), f32(rng.uniform(-0.01, 0.05)))
+                cs.append(contact(int(k) * 8 + j, a, b, geom, float(rng.uniform(0, 0.8)), 0.6 if frictional else 0.0, 0.4 if frictional else 0.0, first=(j == 0)))
+        arr = np.array(cs) if cs else np.zeros(0, dtype=CONTACT_DTYPE)
+        pu.step_both(w, o, arr, 0.004)
+        pu.assert_bodies_close(w.bodies()[0], o.bodies()[0], what=f"seed {seed} frame {frame}: ")
+        if len(arr):
+            pu.compare_contact_state(w, o)
+        flip = rng.random(n_pairs) < 0.25
+        alive = np.where(flip, ~alive, alive)
+    w.close()
