@@ -752,10 +752,16 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
                 eval_leaf(nodes + (w & 0xFFFFFFu), kind, stack + (size_t)lds_level(cmask, top) * IVX_CHUNK_VOXELS + tid, origin_root, ti, tj);
                 top += 1;
             } else if (opc == OP_SCALE) {
-                // constant levels were folded by the pre-pass: the level is per-voxel here
-                float* d = stack + (size_t)lds_level(cmask, top - 1) * IVX_CHUNK_VOXELS + tid;
+                // Levels the pre-pass KNEW to be constant were folded there. A level can still be a constant here: an
+                // OP_COMBINE_OUTSIDE over (constant, per-voxel) that the 14 test positions decide not to apply leaves its
+                // constant first operand standing (combine_levels), which the pre-pass cannot foresee.
+                if ((cmask >> (top - 1)) & 1u) {
+                    s_cval[top - 1] = s_cval[top - 1] * s;
+                } else {
+                    float* d = stack + (size_t)lds_level(cmask, top - 1) * IVX_CHUNK_VOXELS + tid;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) d[k * 256] *= s;
+                    for (int k = 0; k < 16; ++k) d[k * 256] *= s;
+                }
             } else {
                 top -= 1;
                 combine_levels(kind, s, q, margin, opc == OP_COMBINE_OUTSIDE, top, stack, s_cval, cmask, tid);

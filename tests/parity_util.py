@@ -123,3 +123,43 @@ def fuzzing() -> bool:
     import os
 
     return bool(os.environ.get("IVX_FUZZ_SEEDS"))
+
+
+def step_parity(o: ol.OracleObject, g: VoxelObject, res, densities=None) -> dict:
+    """What one `ivx_voxel_step(STAGE_ALL)` left on the device against the oracle object built from the same SDF (derived state
+    computed): sha-256 of the voxel bytes, chunk records, chunk-local labels, triangle index buffer, vertex positions; counts;
+    relative error of the ten moments against the f64 oracle. Used by bench.py's `parity` fields and by the 512^3 parity test —
+    the workload that is timed is the workload that is checked."""
+    import hashlib
+
+    def sha(a):
+        return hashlib.sha256(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).hexdigest()[:16]
+
+    o_sdf, o_typ, o_flg, o_lab, o_info = o.export_dense()
+    g_sdf, g_typ, g_flg, g_lab, g_info = g.download()
+    om = o.mesh()
+    gm = VoxelObjectMesh(g)
+    gm.counts = res["mesh"]
+    pos, nrm, idx, im, sub = gm.download()
+    d = np.ones(256, dtype=np.float32) if densities is None else densities
+    _, o64 = o.inertia(d)
+    g64 = np.asarray(res["moments"]["m64"], dtype=np.float64)
+    n_regions, _ = o.region_labels()
+    fields = ("kind", "gen_kind", "flags", "face_dist", "uniform_type", "region_count", "boundary_region_count")
+    rec_o = np.stack([o_info[f].astype(np.uint32) for f in fields])
+    rec_g = np.stack([g_info[f].astype(np.uint32) for f in fields])
+    out = {
+        "voxel_sha": [sha(g_sdf) + sha(g_typ) + sha(g_flg), sha(o_sdf) + sha(o_typ) + sha(o_flg)],
+        "label_sha": [sha(g_lab), sha(o_lab)],
+        "chunk_record_sha": [sha(rec_g), sha(rec_o)],
+        "index_sha": [sha(idx), sha(om.indices)],
+        "position_sha": [sha(pos), sha(om.positions)],
+        "normal_sha": [sha(nrm), sha(om.normals)],
+        "index_material_sha": [sha(im), sha(om.index_materials)],
+        "triangles": [int(idx.size // 3), int(om.indices.size // 3)],
+        "vertices": [int(pos.shape[0]), int(om.positions.shape[0])],
+        "regions": [int(res["region_count"]), int(n_regions)],
+        "moments_rel": float(np.max(np.abs(g64 - o64) / np.maximum(np.abs(o64), 1e-300))),
+    }
+    out["equal"] = bool(all(v[0] == v[1] for k, v in out.items() if isinstance(v, list)) and out["moments_rel"] <= 1e-5)
+    return out

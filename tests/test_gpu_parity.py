@@ -191,3 +191,29 @@ def test_row_of_many_small_bodies(ctx):
 def test_plate_one_chunk_thick(ctx):
     """a 300 x 300 x 6 plate: every chunk is a surface chunk, no Uniform chunks at all"""
     full_pipeline(ctx, scenes.box_scene((300.0, 300.0, 6.0)), expect_regions=1)
+
+
+def test_bench_workload_512(ctx):
+    """The workload bench.py times at N=1 — the config-2 asteroid under a root Scaling x2.05, 512^3 stored voxels — through the same
+    entry point (`ivx_voxel_step(STAGE_ALL)` over the resident program) against the oracle: voxel bytes, chunk records, raw
+    chunk-local labels, index buffer, vertex data, region count, moments."""
+    from impact_amd import capi
+    from impact_amd.voxel import SDFVoxelGenerator
+
+    graph = scenes.asteroid_scene(2.05)
+    gen = SDFVoxelGenerator(1.0, graph, 0)
+    assert gen.chunk_counts() == (32, 32, 32)
+    obj = VoxelObject(ctx, gen.chunk_counts(), 1.0)
+    obj.set_sdf_program(gen)
+    obj.set_densities(np.ones(256, dtype=np.float32))
+    obj.step(capi.STAGE_ALL)
+    res = obj.step(capi.STAGE_ALL)  # (the second step runs with the list-sized grids of a steady-state frame)
+    o = pu.oracle_from_graph(graph)
+    o.update_occupied_voxel_ranges()
+    o.compute_all_derived_state()
+    p = pu.step_parity(o, obj, res)
+    assert p["equal"], p
+    info = o.info()
+    occ = np.asarray(res["occupied"]).reshape(-1)
+    assert [(int(occ[6 + 2 * d]), int(occ[7 + 2 * d])) for d in range(3)] == info["occupied_voxel_ranges"]
+    obj.close()

@@ -122,6 +122,32 @@ def test_config4_pile_4096_bodies(ctx):
     w.close()
 
 
+def test_config4_pile_60_steps(ctx):
+    """BASELINE config 4 over 60 frames against the oracle (26 ms per oracle step): does 1e-5 survive the warm-start history?
+    The scale a body's error is measured against is its own vector norm, floored at 1e-4 of the field's largest entry (the
+    short test above floors at 1e-2)."""
+    bodies, contacts = scenes.sphere_pile_scene(16)
+    w, o = pu.make_pair(ctx, bodies)
+    worst = 0.0
+    for s in range(60):
+        if s % 7 == 3:  # resident set: the device keeps last frame's contacts
+            o.step(contacts, 0.005)
+            w.step(0.005)
+        else:
+            pu.step_both(w, o, contacts, 0.005)
+        if s in (0, 1, 9, 29, 59):
+            gd, od = w.bodies()[0], o.bodies()[0]
+            for f in pu.STATE_FIELDS:
+                g64, o64 = gd[f].astype(np.float64), od[f].astype(np.float64)
+                scale = np.maximum(np.linalg.norm(o64, axis=1, keepdims=True), max(float(np.abs(o64).max()), 1e-30) * 1e-4)
+                err = float((np.abs(g64 - o64) / scale).max())
+                worst = max(worst, err)
+                assert err <= pu.RTOL, f"step {s} {f}: {err:.3e}"
+            pu.compare_contact_state(w, o)
+    print(f"config 4, 60 steps: worst relative error {worst:.3e}")
+    w.close()
+
+
 def test_contacts_come_and_go(ctx):
     """ConstraintCache order after removals (swap_remove) and additions, with spinning / moving bodies and
     friction; ragged inputs: empty contact list, bodies without contacts"""
