@@ -2,19 +2,27 @@
 """Throughput benchmark of the voxel hot path (BASELINE.json metric:
 "voxels stepped/sec + remesh tris/sec, 512^3 grid, 1/2/4/8 MI355X").
 
-A step = one pass of the per-frame voxel path over one SDF-defined grid that is already resident in
-HBM: SDF sample -> derived state (flags, chunk state, occupied ranges) -> connected regions ->
-Surface Nets remesh -> mass/inertia reduction -> rigid-body step of the object's own body (momenta,
-constraint solve over its — empty — contact list, configuration). N = 1: the config-2 asteroid scaled
-x2.05 (502^3 grid -> 32^3 chunks = 512^3 stored voxels). N > 1 (one process per GPU, launched by
-torch.distributed.run): weak scaling — N such asteroids in a row joined by a thin bar, one per x-slab of
-32 chunk planes, one-voxel face halos and boundary chunk state exchanged over RCCL (torch.distributed
-"nccl"), cross-rank region equivalences and the 10 mass moments in one small all-gather.
+A step = one pass of the per-frame voxel path over one SDF-defined grid that is already resident in HBM: SDF sample ->
+derived state (flags, chunk state, occupied ranges) -> connected regions -> Surface Nets remesh -> mass/inertia
+reduction -> rigid-body step of the object's own body. The headline workload is the config-2 asteroid scaled x2.05
+(502^3 grid -> 32^3 chunks = 512^3 stored voxels).
 
-The rigid-body solver's own workload (BASELINE config 4: 4096 bodies, 46 080 contacts) does not scale
-with voxels; it is timed separately on rank 0 and reported under "pile" in the same JSON line.
+N > 1 (one process per GPU, launched by torch.distributed.run): the grid is cut into N chunk-aligned x-slabs, one-voxel
+face halos and boundary chunk state exchanged over RCCL, cross-rank region equivalences and the 10 mass moments in one
+small all-gather.
+  --scaling strong (default)  the SAME 512^3 grid on every N — the configuration the metric and its 1 -> 8 target are quoted on;
+  --scaling weak              BASELINE config 5: all lengths x N^(1/3), every rank keeps the 512^3 voxel count (N = 8: 1024^3).
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the byte counts behind `roofline`).
+Beside the headline, rank 0 at N = 1 reports (each with the oracle timed beside it and a parity verdict):
+  dense    all-surface workload (32 perforated plates, every chunk NonUniform and meshed): here the per-voxel byte accounting of
+           SURVEY §8d applies to the whole grid, so `roofline.frac` of this leg IS an HBM fraction
+  config2  256^3 asteroid: Surface Nets remesh + mass/inertia
+  config3  256^3 fracture: seven split-offs (8 objects), then the eight octant copies by polyhedron clip
+  pile     config 4: 4096 bodies / 46 080 contacts, exact-order sequential impulses
+  frame    voxel step + pile step back to back (the two serial stages of a frame the headline leaves out)
+  edit, collide   SURVEY §8f items 1-2 on the headline body
+
+Prints ONE JSON line on rank 0 (DESIGN.md "Measurement" explains every field).
 """
 from __future__ import annotations
 
@@ -31,16 +39,18 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0    # the guide's measured float4 copy: the practical ceiling
+VALU_PEAK_GWI = 256 * 4 * 2.4 / 2.0  # G wave-instructions/s: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz
+PROFILE_DIR = os.path.join(ROOT, "profiles", "round2")
 
 STAGE_KERNELS = {  # which kernels make up a timed stage (names as rocprofv3 reports them)
     "sdf_sample": ["k_sdf_super", "k_sdf_prepass", "k_sdf_eval"],
     "derive": ["k_chunk_pre", "k_derive"],  # k_derive also labels the chunk-local regions and leaves the chunk moments (fused sweep)
     "occupied": ["k_occupied_reduce"],
-    "ccl_local": ["k_ccl_local_exact"],  # what is left of the stage after the fusion
+    "ccl_local": ["k_ccl_local_exact"],
     "ccl_merge": ["k_ccl_merge_columns", "k_ccl_merge_multi"],
-    "ccl_resolve": ["k_ccl_flatten", "k_scan_groups", "k_ccl_assign"],
+    "ccl_resolve": ["k_ccl_flatten", "k_scan_groups", "k_ccl_assign", "k_tables"],
     "sn_count": ["k_sn_count"],
     "sn_scan": ["k_sn_scan"],
     "sn_emit": ["k_sn_emit"],
@@ -49,12 +59,11 @@ STAGE_KERNELS = {  # which kernels make up a timed stage (names as rocprofv3 rep
 
 
 def stage_bytes(n_voxels, n_chunks, exposed_chunks, n_vertices, n_indices):
-    """Algorithmic HBM bytes per launch of each timed stage: SURVEY.md §8(d)'s per-voxel figures x the stored voxels of the
-    launch for the plane sweeps (the figures are per voxel of the GRID, whether or not a chunk's planes are materialised: see
-    DESIGN.md §4 on compact planes — measured traffic is therefore far below these numbers for a solid body); the mesher is
-    charged for the padded tiles of the chunks it meshes plus its output. The derive stage runs the chunk-local region
-    labelling and the chunk moments in the same sweep (R sdf + type, W flags + label = 4 B/voxel, SURVEY's fused-sweep
-    accounting), so the `ccl_local` and `inertia` stages are left with their list / reduction kernels only."""
+    """Algorithmic HBM bytes per step of each timed stage: SURVEY.md §8(d)'s per-voxel figures x the voxels the stage is
+    charged for, the mesher for the padded tiles of the chunks it meshes plus its output. `n_voxels` is what the caller
+    decides to charge: the STORED grid for the `effective` figures (compact planes: most of a solid body's chunks are 8-byte
+    records that never touch the planes, so an effective rate can exceed what the HBM moves), or the ACTIVE voxels
+    (chunks with planes) for a figure that can be compared with the HBM peak."""
     return {
         "sdf_sample": 2.0 * n_voxels,                        # W sdf + type
         "derive": 4.0 * n_voxels,                            # R sdf + type, W flags + label (fused sweep)
@@ -69,72 +78,319 @@ def stage_bytes(n_voxels, n_chunks, exposed_chunks, n_vertices, n_indices):
     }
 
 
-def measured_traffic(stage):
-    """HBM bytes per launch of the stage's kernels from the committed PMC passes (profiles/round1/pmc_traffic.json, produced by
-    tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE rocprofv3 runs of this same workload), or None."""
-    path = os.path.join(ROOT, "profiles", "round1", "pmc_traffic.json")
+def load_profile(name):
     try:
-        d = json.load(open(path))
+        return json.load(open(os.path.join(PROFILE_DIR, name)))
     except (OSError, ValueError):
         return None
-    total, found = 0.0, False
-    for k in STAGE_KERNELS.get(stage, []):
-        for name in d:  # (template kernels are reported as "void k_name<args>")
-            if name == k or name.startswith("void " + k + "<"):
-                total += d[name]["hbm_bytes"]
-                found = True
-    return total if found else None
 
 
-def cpu_baseline(scale):
-    """The oracle (single thread, -O2) over the same workload, timed on this box's host cores."""
+def counted_traffic(workload):
+    """HBM bytes PER STEP of every kernel of the voxel step, from the committed PMC passes of the builder's own run of this
+    workload (profiles/round2/pmc_traffic_<workload>.json, written by tools/pmc_traffic.py from separate FETCH_SIZE /
+    WRITE_SIZE rocprofv3 runs: per-launch average x launches per step). A committed constant, not something this run
+    measured: `traffic_source` says so in the output."""
+    d = load_profile(f"pmc_traffic_{workload}.json")
+    if not d:
+        return None, None
+    per_stage = {}
+    for stage, kernels in STAGE_KERNELS.items():
+        tot, found = 0.0, False
+        for k in kernels:
+            for name, rec in d.items():
+                if isinstance(rec, dict) and (name == k or name.startswith("void " + k + "<") or name.startswith(k + "<")):
+                    tot += rec["hbm_bytes_per_step"]
+                    found = True
+        per_stage[stage] = tot if found else None
+    return per_stage, f"profiles/round2/pmc_traffic_{workload}.json (builder's rocprofv3 --pmc run of this workload; per-launch average x launches per step)"
+
+
+def roofline_block(stage_ms, sb_effective, sb_active, workload_key):
+    """`roofline` for the stage with the largest measured time + `step_roofline` for the whole step."""
+    from impact_amd import capi
+
+    names = capi.STAGE_NAMES
+    dom = int(np.argmax(stage_ms))
+    name = names[dom]
+    t = stage_ms[dom] * 1e-3
+    traffic, source = counted_traffic(workload_key)
+    eff = sb_effective[name] / t / 1e9
+    act = sb_active[name] / t / 1e9
+    rl = {"bound": "hbm", "kernel": "+".join(STAGE_KERNELS[name][:3]), "stage": name, "achieved": act, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+          "frac": act / HBM_PEAK_GBS, "algorithmic_bytes": sb_active[name],
+          "accounting": "SURVEY §8d bytes per voxel x ACTIVE voxels (chunks that have planes); the stored-grid figure is `effective_*`",
+          "effective_achieved": eff, "effective_frac": eff / HBM_PEAK_GBS, "effective_algorithmic_bytes": sb_effective[name],
+          "traffic": None, "traffic_source": source, "counter_frac": None}
+    if traffic and traffic.get(name) is not None:
+        rl["traffic"] = traffic[name]
+        rl["counter_frac"] = traffic[name] / t / 1e9 / HBM_PEAK_GBS
+    tt = float(stage_ms.sum()) * 1e-3
+    srl = {"algorithmic_bytes": float(sum(sb_active.values())), "achieved": float(sum(sb_active.values())) / tt / 1e9, "unit": "GB/s",
+           "frac": float(sum(sb_active.values())) / tt / 1e9 / HBM_PEAK_GBS,
+           "effective_algorithmic_bytes": float(sum(sb_effective.values())),
+           "effective_frac": float(sum(sb_effective.values())) / tt / 1e9 / HBM_PEAK_GBS, "counter_bytes": None, "counter_frac": None}
+    if traffic and all(v is not None for k, v in traffic.items() if sb_effective.get(k, 0) > 0 or k == "ccl_local"):
+        cb = float(sum(v for v in traffic.values() if v is not None))
+        srl["counter_bytes"] = cb
+        srl["counter_frac"] = cb / tt / 1e9 / HBM_PEAK_GBS
+    # the sampler is bound by VALU issue, not by HBM: its instruction count from the committed SQ pass against the issue peak
+    valu = load_profile(f"pmc_valu_{workload_key}.json")
+    vrl = None
+    if valu and stage_ms[0] > 0:
+        wi = sum(rec["SQ_INSTS_VALU_per_step"] for k, rec in valu.items() if isinstance(rec, dict) and any(
+            k == n or k.startswith("void " + n + "<") or k.startswith(n + "<") for n in STAGE_KERNELS["sdf_sample"]))
+        ach = wi / (stage_ms[0] * 1e-3) / 1e9
+        vrl = {"stage": "sdf_sample", "bound": "valu", "achieved": ach, "peak": VALU_PEAK_GWI, "unit": "G wave-instructions/s", "frac": ach / VALU_PEAK_GWI,
+               "wave_instructions_per_step": wi, "source": f"profiles/round2/pmc_valu_{workload_key}.json (SQ_INSTS_VALU, builder's run)"}
+    return rl, srl, vrl
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# CPU legs (the oracle: tests/oracle_lib.py -> oracle/liboracle.so). Only these functions touch it.
+def cpu_voxel_step(graph, threads=1):
+    """the oracle over one workload, timed: (object with derived state, mesh, timings dict)"""
     import oracle_lib as ol
-    from impact_amd import scenes
 
-    graph = scenes.asteroid_scene(scale)
     t0 = time.perf_counter()
-    o = ol.OracleObject.from_sdf(graph, 1.0, 0)
-    o.update_occupied_voxel_ranges()
-    o.compute_all_derived_state()
+    if threads > 1:
+        o = ol.OracleObject.from_sdf_parallel(graph, 1.0, 0, threads)
+    else:
+        o = ol.OracleObject.from_sdf(graph, 1.0, 0)
+        o.update_occupied_voxel_ranges()
+        o.compute_all_derived_state()
     t1 = time.perf_counter()
-    m = o.mesh()
-    t2 = time.perf_counter()
-    o.inertia()
+    m = o.mesh_parallel(threads) if threads > 1 else o.mesh()
+    t2 = t1 + o.last_mesh_seconds  # (without the export of the mesh buffers into numpy arrays)
+    t2b = time.perf_counter()
+    if threads > 1:
+        o.inertia_parallel(threads)
+    else:
+        o.inertia()
     t3 = time.perf_counter()
+    return o, m, {"generate_derive_s": t1 - t0, "remesh_s": t2 - t1, "inertia_s": t3 - t2b, "total_s": (t2 - t0) + (t3 - t2b)}
+
+
+def cpu_baseline(graph, obj, res, what, all_cores=True):
+    """`cpu_baseline` (1 thread) + `cpu_baseline_all_cores` + `parity` of the GPU step just timed against the oracle object"""
+    import oracle_lib as ol
+    import parity_util as pu
+
+    o, m, t = cpu_voxel_step(graph, 1)
     cc = o.chunk_counts
     nvox = cc[0] * cc[1] * cc[2] * 4096
-    # contact generation between two voxel bodies (SURVEY §8f item 1): probes of this body, then mutual contacts with a half-size copy
-    global _CPU_COLLIDE
-    t6 = time.perf_counter()
-    pa = o.collision_probes(m)
-    t7 = time.perf_counter()
-    ob = ol.OracleObject.from_sdf(scenes.asteroid_scene(0.5 * scale), 1.0, 0)
-    ob.update_occupied_voxel_ranges()
-    ob.compute_all_derived_state()
-    pb = ob.collision_probes(ob.mesh())
-    ca, cb = o.center_of_mass(), ob.center_of_mass()
-    qa, ta, qb, tb = collide_poses(ca, cb, scale)
-    t8 = time.perf_counter()
-    wi = o.mutual_contacts(pa, ca, qa, ta, ob, pb, cb, qb, tb, cap=1 << 20)[0]
-    t9 = time.perf_counter()
-    _CPU_COLLIDE = {"probes_ms": 1e3 * (t7 - t6), "mutual_ms": 1e3 * (t9 - t8), "probes": int(len(pa[0])), "contacts": int(len(wi)), "cores": 1,
-                    "kind": "port"}
-    del ob
-    # the edit op on the same object: one absorbing sphere at the surface (EDIT_* below), derived state refreshed
-    c = np.array([0.5 * (a + b_) for a, b_ in o.info()["occupied_voxel_ranges"]], dtype=np.float32) + EDIT_OFFSET * np.float32(scale)
-    t4 = time.perf_counter()
-    er = o.absorb_sphere(c, EDIT_RADIUS * scale + 2.0, EDIT_RADIUS * scale)
-    t5 = time.perf_counter()
-    global _CPU_EDIT
-    _CPU_EDIT = {"ms": 1e3 * (t5 - t4), "emptied_voxels": int(er["emptied_by_type"].sum()), "cores": 1, "kind": "port"}
-    return {
-        "value": nvox / (t3 - t0),
-        "unit": "voxels/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"full N=1 workload once ({cc[0] * 16}^3 stored voxels): generate+derive {t1 - t0:.2f}s, remesh {t2 - t1:.2f}s "
-                  f"({m.indices.size // 3 / (t2 - t1):.3g} tris/s), inertia {t3 - t2:.2f}s; single thread",
-    }
+    base = {"value": nvox / t["total_s"], "unit": "voxels/s", "cores": 1, "kind": "port",
+            "sample": f"{what} once ({cc[0] * 16}x{cc[1] * 16}x{cc[2] * 16} stored voxels): generate+derive {t['generate_derive_s']:.2f}s, remesh "
+                      f"{t['remesh_s']:.2f}s ({m.indices.size // 3 / max(t['remesh_s'], 1e-9):.3g} tris/s), inertia {t['inertia_s']:.2f}s; single thread"}
+    parity = pu.step_parity(o, obj, res) if obj is not None else None
+    allc = None
+    if all_cores and hasattr(ol.OracleObject, "from_sdf_parallel"):
+        n = os.cpu_count() or 1
+        try:
+            n = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            pass
+        if n > 1:
+            _, m2, t2 = cpu_voxel_step(graph, n)
+            allc = {"value": nvox / t2["total_s"], "unit": "voxels/s", "cores": n, "kind": "port",
+                    "sample": f"same workload, OpenMP over chunks ({n} threads): generate+derive {t2['generate_derive_s']:.2f}s, remesh {t2['remesh_s']:.2f}s, "
+                              f"inertia {t2['inertia_s']:.2f}s; the cross-chunk adjacency pass and the region resolve stay serial, as in the reference",
+                    "same_triangles": bool(m2.indices.size == m.indices.size)}
+    return base, allc, parity, o, m
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+def make_object(ctx, graph):
+    from impact_amd.voxel import SDFVoxelGenerator, VoxelObject
+
+    gen = SDFVoxelGenerator(1.0, graph, 0)
+    obj = VoxelObject(ctx, gen.chunk_counts(), 1.0)
+    obj.set_sdf_program(gen)
+    obj.set_densities(np.ones(256, dtype=np.float32))
+    return gen, obj
+
+
+def time_steps(ctx, obj, stages, steps, warmup):
+    from impact_amd import capi
+
+    for _ in range(warmup):
+        res = obj.step(stages)
+    ctx.synchronize()
+    acc = np.zeros(capi.N_TIMED_STAGES)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = obj.step(stages)
+        acc += res["stage_ms"]
+    ctx.synchronize()
+    return res, 1e3 * (time.perf_counter() - t0) / steps, acc / steps
+
+
+def chunk_census(obj):
+    info = obj.download(sdf=False, types=False, flags=False, labels=False)[4]
+    exposed = int(np.count_nonzero((info["kind"] == 2) & ((info["flags"] & 0x3F) != 0x3F)))
+    non_uniform = int(np.count_nonzero(info["kind"] == 2))
+    return exposed, non_uniform
+
+
+def dense_benchmark(ctx, args, with_cpu):
+    """the all-surface workload: every chunk NonUniform, every chunk meshed"""
+    from impact_amd import capi, scenes
+
+    n = args.dense_chunks
+    graph = scenes.plates_scene(n)
+    gen, obj = make_object(ctx, graph)
+    res, ms, stage_ms = time_steps(ctx, obj, capi.STAGE_ALL, max(3, args.steps // 4), 2)
+    exposed, non_uniform = chunk_census(obj)
+    counters = obj.stage_counters()
+    active = max(non_uniform, counters["evaluated_chunks"]) * 4096
+    sb_eff = stage_bytes(obj.n_voxels, obj.n_chunks, exposed, int(res["mesh"]["n_vertices"]), int(res["mesh"]["n_indices"]))
+    sb_act = stage_bytes(active, obj.n_chunks, exposed, int(res["mesh"]["n_vertices"]), int(res["mesh"]["n_indices"]))
+    rl, srl, _ = roofline_block(stage_ms, sb_eff, sb_act, "dense")
+    remesh_ms = float(stage_ms[6] + stage_ms[7] + stage_ms[8])
+    out = {"workload": f"{n} perforated plates, one per chunk layer: {gen.grid_shape()} grid = {(n * 16)}^3 stored voxels, {non_uniform} of {obj.n_chunks} chunks "
+                       f"NonUniform, {exposed} meshed",
+           "ms_per_step": ms, "voxels_per_s": obj.n_voxels / (ms * 1e-3), "active_voxels": active, "triangles": int(res["mesh"]["n_indices"]) // 3,
+           "remesh_tris_per_s": int(res["mesh"]["n_indices"]) // 3 / (remesh_ms * 1e-3), "regions": int(res["region_count"]),
+           "stage_ms": {capi.STAGE_NAMES[i]: round(float(stage_ms[i]), 4) for i in range(capi.N_TIMED_STAGES)},
+           "stage_gbs": {capi.STAGE_NAMES[i]: round(sb_act[capi.STAGE_NAMES[i]] / (stage_ms[i] * 1e-3) / 1e9, 1) if stage_ms[i] > 0 and sb_act[capi.STAGE_NAMES[i]] > 0 else None
+                         for i in range(capi.N_TIMED_STAGES)},
+           "roofline": rl, "step_roofline": srl}
+    if with_cpu:
+        # bounded CPU sample: the same scene at 1/64 of the volume (128^3), GPU and oracle both, with the parity verdict; the
+        # full-size parity check is tests/test_gpu_parity.py::test_dense_workload_512
+        small = scenes.plates_scene(max(2, n // 4))
+        _, sobj = make_object(ctx, small)
+        sres = sobj.step(capi.STAGE_ALL)
+        base, allc, parity, _, _ = cpu_baseline(small, sobj, sres, f"the same scene with {max(2, n // 4)} plates", all_cores=True)
+        out["cpu_baseline"], out["cpu_baseline_all_cores"], out["parity"] = base, allc, parity
+        sobj.close()
+    obj.close()
+    return out
+
+
+def config2_benchmark(ctx, args, with_cpu):
+    """BASELINE config 2: 256^3 SDF asteroid, Surface Nets remesh + mass/inertia recompute (the voxels already resident)"""
+    from impact_amd import capi, scenes
+
+    graph = scenes.asteroid_scene(1.0)
+    gen, obj = make_object(ctx, graph)
+    obj.step(capi.STAGE_ALL)
+    res, ms, stage_ms = time_steps(ctx, obj, capi.STAGE_REMESH | capi.STAGE_INERTIA, args.steps, 2)
+    full, ms_full, _ = time_steps(ctx, obj, capi.STAGE_ALL, args.steps, 1)
+    tris = int(res["mesh"]["n_indices"]) // 3
+    out = {"workload": f"config-2 asteroid: {gen.grid_shape()[0]}^3 grid = {obj.chunk_counts[0] * 16}^3 stored voxels; remesh + inertia of the resident object",
+           "remesh_inertia_ms": ms, "remesh_tris_per_s": tris / (float(stage_ms[6] + stage_ms[7] + stage_ms[8]) * 1e-3), "triangles": tris,
+           "full_step_ms": ms_full, "voxels_per_s_full_step": obj.n_voxels / (ms_full * 1e-3)}
+    if with_cpu:
+        base, allc, parity, _, _ = cpu_baseline(graph, obj, full, "config 2")
+        out["cpu_baseline"], out["cpu_baseline_all_cores"], out["parity"] = base, allc, parity
+    obj.close()
+    return out
+
+
+def octant_boxes(centre):
+    import itertools
+
+    for sx, sy, sz in itertools.product((-1, 1), repeat=3):
+        lo = [centre if s > 0 else -10.0 for s in (sx, sy, sz)]
+        hi = [300.0 if s > 0 else centre for s in (sx, sy, sz)]
+        planes = []
+        for d in range(3):
+            nrm = [0.0, 0.0, 0.0]
+            nrm[d] = 1.0
+            planes.append((*nrm, float(hi[d])))
+            nrm[d] = -1.0
+            planes.append((*nrm, -float(lo[d])))
+        yield np.array(planes, dtype=np.float32), np.array([*lo, *hi], dtype=np.float32)
+
+
+def config3_benchmark(ctx, args, with_cpu):
+    """BASELINE config 3: the 256^3 fracture body. (a) the split-off loop of `handle_voxel_object_after_removing_voxels`
+    (interaction.rs:256: while find_two_disconnected_regions -> extract_disconnected_region): seven extractions leave 8 objects;
+    (b) polyhedron COPY of each octant (3 cutting + 3 far planes), one call per fragment and — when the library has it — all
+    eight in one batched call (fracturing.rs:1047-1189 runs the fragments of an impact in parallel)."""
+    from impact_amd import capi, scenes
+    from impact_amd.voxel import SDFVoxelGenerator
+
+    graph = scenes.fracture_scene()
+    gen0 = SDFVoxelGenerator(1.0, graph, 0)
+    centre = float(gen0.shifted_grid_center[0]) + 0.5
+    boxes = list(octant_boxes(centre))
+    reps = 3
+    t_split, t_clip, t_batch = [], [], []
+    n_children = n_copies = 0
+    child_voxels, copy_voxels = [], []
+    for rep in range(reps):
+        _, obj = make_object(ctx, graph)
+        obj.step(capi.STAGE_ALL)
+        ctx.synchronize()
+        # copies first (they leave the parent untouched)
+        t0 = time.perf_counter()
+        kids = []
+        for planes, aabb in boxes:
+            rc, child, _ = obj.copy_polyhedron(aabb, planes)
+            if rc == 1:
+                kids.append(child)
+        ctx.synchronize()
+        t_clip.append(time.perf_counter() - t0)
+        n_copies = len(kids)
+        if rep == reps - 1:
+            copy_voxels = [int(k.describe_regions()["voxel_count"].sum()) for k in kids]
+        for k in kids:
+            k.close()
+        if hasattr(obj, "copy_polyhedra"):
+            t0 = time.perf_counter()
+            kids = obj.copy_polyhedra([b[1] for b in boxes], [b[0] for b in boxes])
+            ctx.synchronize()
+            t_batch.append(time.perf_counter() - t0)
+            for _, k, _ in kids:
+                if k is not None:
+                    k.close()
+        t0 = time.perf_counter()
+        kids = []
+        while True:
+            rc, child, _, moved = obj.extract_any_disconnected_region()
+            if rc == 0:
+                break
+            if rc == 1:
+                kids.append((child, int(moved["voxel_count"])))
+        ctx.synchronize()
+        t_split.append(time.perf_counter() - t0)
+        n_children = len(kids)
+        if rep == reps - 1:
+            child_voxels = [v for _, v in kids]
+        for k, _ in kids:
+            k.close()
+        obj.close()
+    out = {"workload": "config-3 fracture body (256^3 stored voxels, 8 octants): split-off loop until one region is left; polyhedron copy of each octant",
+           "split_loop_ms": 1e3 * float(np.mean(t_split[1:])), "split_offs": n_children, "objects_after": n_children + 1,
+           "octant_copies_ms": 1e3 * float(np.mean(t_clip[1:])), "octant_copies": n_copies,
+           "octant_copies_batched_ms": 1e3 * float(np.mean(t_batch[1:])) if t_batch else None}
+    if with_cpu:
+        import oracle_lib as ol
+
+        o = ol.OracleObject.from_sdf(graph, 1.0, 0)
+        o.update_occupied_voxel_ranges()
+        o.compute_all_derived_state()
+        t0 = time.perf_counter()
+        cvox = []
+        for planes, aabb in boxes:
+            rc, co, _ = o.clip_polyhedron(planes, aabb, copy=True)
+            if rc == 1:
+                cvox.append(int(np.count_nonzero((co.export_dense()[2] & 1) == 0)))
+        t1 = time.perf_counter()
+        svox = []
+        while True:
+            rc, co, _ = o.split_off_smallest_region()
+            if rc == 0:
+                break
+            if rc == 1:
+                svox.append(int(np.count_nonzero((co.export_dense()[2] & 1) == 0)))
+        t2 = time.perf_counter()
+        out["cpu_baseline"] = {"split_loop_ms": 1e3 * (t2 - t1), "octant_copies_ms": 1e3 * (t1 - t0), "cores": 1, "kind": "port",
+                               "sample": "the same operations once (the copies' time includes exporting each child to count its voxels)"}
+        out["parity"] = {"split_child_voxels": [child_voxels, svox], "copy_child_voxels": [copy_voxels, cvox],
+                         "equal": bool(child_voxels == svox and copy_voxels == cvox)}
+    return out
 
 
 def collide_poses(com_a, com_b, scale):
@@ -153,18 +409,15 @@ def collide_poses(com_a, com_b, scale):
     return qa, ta, qb, tb
 
 
-def collide_benchmark(ctx, scale, reps=5):
-    """SURVEY §8f item 1 on the N=1 workload: collision probes of the meshed body (`ivx_collision_probes_recompute`), then the
+def collide_benchmark(ctx, scale, o_big, m_big, reps=5):
+    """SURVEY §8f item 1 on the headline body: collision probes of the meshed body (`ivx_collision_probes_recompute`), then the
     contacts between it and a half-size copy pushed into its side (`ivx_mutual_voxel_object_contacts`, results on the host)."""
     from impact_amd import capi, scenes
-    from impact_amd.voxel import SDFVoxelGenerator, VoxelObject, VoxelObjectMesh
+    from impact_amd.voxel import VoxelObjectMesh
 
     objs = []
     for sc in (scale, 0.5 * scale):
-        gen = SDFVoxelGenerator(1.0, scenes.asteroid_scene(sc), 0)
-        obj = VoxelObject(ctx, gen.chunk_counts(), 1.0)
-        obj.set_sdf_program(gen)
-        obj.set_densities(np.ones(256, dtype=np.float32))
+        _, obj = make_object(ctx, scenes.asteroid_scene(sc))
         r = obj.step(capi.STAGE_ALL)
         m32 = np.asarray(r["moments"]["m32"], dtype=np.float32).reshape(-1)
         com = (m32[1:4] * (np.float32(1.0) / m32[0])).astype(np.float32)  # derive_center_of_mass (object/inertia.rs:167-169)
@@ -172,7 +425,7 @@ def collide_benchmark(ctx, scale, reps=5):
         objs.append((obj, com))
     (a, ca), (b, cb) = objs
     qa, ta, qb, tb = collide_poses(ca, cb, scale)
-    t_p, t_m, n_probes, n_contacts = [], [], 0, 0
+    t_p, t_m, n_probes, contacts = [], [], 0, None
     for _ in range(reps + 1):
         ctx.synchronize()
         t0 = time.perf_counter()
@@ -181,42 +434,53 @@ def collide_benchmark(ctx, scale, reps=5):
         b.collision_probes_recompute()
         ctx.synchronize()
         t2 = time.perf_counter()
-        n_contacts = len(a.mutual_contacts(qa, ta, ca, b, qb, tb, cb, 1, 2, 0, 1, capacity=1 << 20))
+        contacts = a.mutual_contacts(qa, ta, ca, b, qb, tb, cb, 1, 2, 0, 1, capacity=1 << 20)
         t3 = time.perf_counter()
         t_p.append(t1 - t0)
         t_m.append(t3 - t2)
     a.close()
     b.close()
-    out = {"workload": "probes of the N=1 body; contacts between it and a half-size copy pushed into its side",
+    out = {"workload": "probes of the headline body; contacts between it and a half-size copy pushed into its side",
            "probes_ms": round(1e3 * float(np.mean(t_p[1:])), 4), "mutual_ms": round(1e3 * float(np.mean(t_m[1:])), 4), "probes": n_probes,
-           "contacts": n_contacts}
-    if _CPU_COLLIDE is not None:
-        out["cpu_baseline"] = dict(_CPU_COLLIDE)
-        out["cpu_baseline"]["parity"] = ("same probe and contact counts" if (_CPU_COLLIDE["probes"], _CPU_COLLIDE["contacts"]) == (n_probes, n_contacts)
-                                         else "MISMATCH")
+           "contacts": int(len(contacts))}
+    if o_big is not None:
+        import oracle_lib as ol
+
+        t6 = time.perf_counter()
+        pa = o_big.collision_probes(m_big)
+        t7 = time.perf_counter()
+        ob = ol.OracleObject.from_sdf(scenes.asteroid_scene(0.5 * scale), 1.0, 0)
+        ob.update_occupied_voxel_ranges()
+        ob.compute_all_derived_state()
+        pb = ob.collision_probes(ob.mesh())
+        oca, ocb = o_big.center_of_mass(), ob.center_of_mass()
+        oqa, ota, oqb, otb = collide_poses(oca, ocb, scale)
+        t8 = time.perf_counter()
+        wi, opos, onrm, odep = o_big.mutual_contacts(pa, oca, oqa, ota, ob, pb, ocb, oqb, otb, cap=1 << 20)
+        t9 = time.perf_counter()
+        same = ((int(len(pa[0])), int(len(wi))) == (n_probes, int(len(contacts))) and bool(np.array_equal(opos.view(np.uint32), contacts["position"].view(np.uint32)))
+                and bool(np.array_equal(onrm.view(np.uint32), contacts["normal"].view(np.uint32))) and bool(np.array_equal(odep.view(np.uint32), contacts["depth"].view(np.uint32))))
+        out["cpu_baseline"] = {"probes_ms": 1e3 * (t7 - t6), "mutual_ms": 1e3 * (t9 - t8), "probes": int(len(pa[0])), "contacts": int(len(wi)), "cores": 1,
+                               "kind": "port", "parity": "same probe count; contact positions, normals, depths bit-equal" if same else "MISMATCH"}
     return out
 
 
-_CPU_COLLIDE = None
 EDIT_OFFSET = np.array([110.0, 6.0, -4.0], dtype=np.float32)  # from the centre of the body, at scale 1: inside the tip of the +x bump
 EDIT_RADIUS = 15.0
-_CPU_EDIT = None
 
 
-def edit_benchmark(ctx, scale, reps=5):
-    """SURVEY §8f item 2 on the N=1 workload: an absorbing sphere bites into the asteroid (`ivx_absorb_sphere`: the edit kernel,
-    the derived-state + region refresh of the whole object, results back on the host), then the full remesh the bite invalidates.
+def edit_benchmark(ctx, scale, o_big, reps=5):
+    """SURVEY §8f item 2 on the headline body: an absorbing sphere bites into the asteroid (`ivx_absorb_sphere`: the edit kernel,
+    the derived-state + region refresh of the whole object, results back on the host), then the remesh the bite invalidates.
     Each repetition starts from the freshly generated body."""
     from impact_amd import capi, scenes
-    from impact_amd.voxel import SDFVoxelGenerator, VoxelObject, VoxelObjectMesh
+    from impact_amd.voxel import VoxelObjectMesh
 
-    gen = SDFVoxelGenerator(1.0, scenes.asteroid_scene(scale), 0)
-    obj = VoxelObject(ctx, gen.chunk_counts(), 1.0)
-    obj.set_sdf_program(gen)
-    obj.set_densities(np.ones(256, dtype=np.float32))
+    _, obj = make_object(ctx, scenes.asteroid_scene(scale))
     mesh = VoxelObjectMesh(obj)
     t_edit, t_remesh, t_sync, emptied, touched, invalidated = [], [], [], 0, 0, 0
-    for _ in range(reps + 1):
+    sdf_after = None
+    for rep in range(reps + 1):
         obj.step(capi.STAGE_ALL)
         c = np.array([0.5 * (a + b) for a, b in obj.update_occupied_voxel_ranges()], dtype=np.float32) + EDIT_OFFSET * np.float32(scale)
         mesh.sync_with_voxel_object(np.zeros(obj.n_chunks, dtype=np.uint8))  # (the submesh bookkeeping of the fresh mesh, once per full remesh)
@@ -226,6 +490,8 @@ def edit_benchmark(ctx, scale, reps=5):
         t1 = time.perf_counter()
         mesh.sync_with_voxel_object(r["invalidated"])  # the incremental remesh of the invalidated chunks (mesh.rs:355-456) ...
         t2 = time.perf_counter()
+        if rep == reps and o_big is not None:
+            sdf_after = obj.download(types=False, flags=False, labels=True, info=False)
         obj.step(capi.STAGE_REMESH)  # ... and the full one, for comparison
         t3 = time.perf_counter()
         t_edit.append(t1 - t0)
@@ -233,13 +499,19 @@ def edit_benchmark(ctx, scale, reps=5):
         t_remesh.append(t3 - t2)
         emptied, touched, invalidated = r["emptied_voxels"], r["touched_chunks"], int(r["invalidated"].sum())
     obj.close()
-    out = {"workload": f"absorbing sphere r={EDIT_RADIUS * scale:.1f} voxels at the surface of the N=1 body",
+    out = {"workload": f"absorbing sphere r={EDIT_RADIUS * scale:.1f} voxels at the surface of the headline body",
            "edit_ms": round(1e3 * float(np.mean(t_edit[1:])), 4), "remesh_after_ms": round(1e3 * float(np.mean(t_remesh[1:])), 4),
            "sync_after_ms": round(1e3 * float(np.mean(t_sync[1:])), 4), "emptied_voxels": emptied, "touched_chunks": touched,
            "invalidated_chunks": invalidated}
-    if _CPU_EDIT is not None:
-        out["cpu_baseline"] = dict(_CPU_EDIT)
-        out["cpu_baseline"]["parity"] = "same emptied voxel count" if _CPU_EDIT["emptied_voxels"] == emptied else "MISMATCH"
+    if o_big is not None:
+        c = np.array([0.5 * (a + b_) for a, b_ in o_big.info()["occupied_voxel_ranges"]], dtype=np.float32) + EDIT_OFFSET * np.float32(scale)
+        t4 = time.perf_counter()
+        er = o_big.absorb_sphere(c, EDIT_RADIUS * scale + 2.0, EDIT_RADIUS * scale)
+        t5 = time.perf_counter()
+        o_sdf, _, _, o_lab, _ = o_big.export_dense()
+        same = int(er["emptied_by_type"].sum()) == emptied and bool(np.array_equal(o_sdf, sdf_after[0])) and bool(np.array_equal(o_lab, sdf_after[3]))
+        out["cpu_baseline"] = {"ms": 1e3 * (t5 - t4), "emptied_voxels": int(er["emptied_by_type"].sum()), "cores": 1, "kind": "port",
+                               "parity": "same voxel bytes and chunk-local labels after the edit" if same else "MISMATCH"}
     return out
 
 
@@ -267,6 +539,7 @@ def pile_benchmark(ctx, with_cpu, steps=10):
         acc += w.step(0.005)["stage_ms"]
     wall = (time.perf_counter() - t0) / steps
     r = w.step(0.005)
+    n_steps_done = 1 + 2 + steps + 1
     sweeps = 1 + 8 + 3
     out = {
         "workload": "16^3 lattice of unit-density spheres r=0.5 at spacing 0.95: 4096 bodies, 46080 contacts, dt 0.005, 8+3 sweeps + warm start",
@@ -276,19 +549,27 @@ def pile_benchmark(ctx, with_cpu, steps=10):
         "stage_ms": {k: round(float(v) / steps, 4) for k, v in zip(capi.PHYSICS_STAGE_NAMES, acc)},
         "set_contacts_next_frame_host_ms": round(host_warm_ms, 3), "set_contacts_host_ms": round(host_ms, 3),
     }
+    info = w.solver_info() if hasattr(w, "solver_info") else None
+    if info:
+        out["solver"] = info
     if with_cpu:
         import oracle_lib as ol
 
         o = ol.OraclePhysics(bodies, config=(8, 0.4, 3, 0.2))
-        o.step(contacts, 0.005)
         t0 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(n_steps_done):
             o.step(contacts, 0.005)
-        cpu = (time.perf_counter() - t0) / 5
+        cpu = (time.perf_counter() - t0) / n_steps_done
+        gd, od = w.bodies()[0], o.bodies()[0]
+        rel = 0.0
+        for f in ("position", "orientation", "momentum", "angular_momentum"):
+            g64, o64 = gd[f].astype(np.float64), od[f].astype(np.float64)
+            scale = np.maximum(np.linalg.norm(o64, axis=1, keepdims=True), max(float(np.abs(o64).max()), 1e-30) * 1e-4)
+            rel = max(rel, float((np.abs(g64 - o64) / scale).max()))
         out["cpu_baseline"] = {"value": len(contacts) * sweeps / cpu, "unit": "contact sweeps/s", "cores": 1, "kind": "port",
-                               "sample": f"same pile, 5 steps, {1e3 * cpu:.1f} ms/step, single thread"}
-    w.close()
-    return out
+                               "sample": f"same pile, {n_steps_done} steps, {1e3 * cpu:.1f} ms/step, single thread"}
+        out["parity"] = {"steps": n_steps_done, "body_state_max_rel_err": rel, "equal": bool(rel <= 1e-5)}
+    return out, w
 
 
 def main():
@@ -297,8 +578,12 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scale", type=float, default=2.05, help="asteroid scale (2.05 -> 512^3 stored grid)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1: strong = the same 512^3 grid in N x-slabs (the metric's configuration); weak = BASELINE config 5 (lengths x N^(1/3))")
+    ap.add_argument("--workload", choices=("asteroid", "dense"), default="asteroid", help="the timed step's scene (dense = all-surface plates)")
+    ap.add_argument("--dense-chunks", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pile", action="store_true", help="skip the separate rigid-body pile timing (config 4)")
+    ap.add_argument("--no-pile", action="store_true", help="skip the separate legs (dense, config2, config3, pile, frame, edit, collide)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -312,10 +597,9 @@ def main():
     import torch
 
     from impact_amd import capi, scenes
-    from impact_amd.voxel import Context, SDFVoxelGenerator, VoxelObject
+    from impact_amd.voxel import Context
 
-    # one rank per GPU; on a box with fewer GPUs than ranks (single-GPU protocol check with the gloo
-    # backend) ranks share devices
+    # one rank per GPU; on a box with fewer GPUs than ranks (single-GPU protocol check with the gloo backend) ranks share devices
     device = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(device)
     ctx = Context(device)
@@ -327,16 +611,17 @@ def main():
         import torch.distributed as dist_mod
 
         dist = dist_mod
+        # the backend is a launch-time choice, the same on every rank; an RCCL failure ends the job (no per-rank fallback:
+        # ranks on different backends would deadlock, and a host-staged number must not pass for an RCCL one)
         backend = os.environ.get("IVX_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            try:
+        try:
+            if backend == "nccl":
                 dist.init_process_group("nccl", device_id=torch.device("cuda", device))
-            except Exception as e:  # RCCL unusable on this box: keep the run alive through host staging and say so
-                print(f"[bench] rank {rank}: RCCL init failed ({e}); falling back to gloo", file=sys.stderr)
-                backend = "gloo"
-                dist.init_process_group("gloo")
-        else:
-            dist.init_process_group(backend)
+            else:
+                dist.init_process_group(backend)
+        except Exception as e:
+            print(f"[bench] rank {rank}: init_process_group({backend!r}) failed: {e}", file=sys.stderr)
+            sys.exit(3)
 
     dens = np.ones(256, dtype=np.float32)
     # the voxel object's own rigid body (setup_dynamic_rigid_body_for_voxel_object, impact_voxel/src/setup.rs:581-616):
@@ -346,12 +631,12 @@ def main():
     body_world = PhysicsWorld(ctx)
     body_world.set_bodies(np.array([uniform_sphere_body(100.0, 1.0, (0.0, 0.0, 0.0), (0.1, 0.0, 0.0))]))
     body_world.prepare_constraints(np.zeros(0, dtype=capi.CONTACT_DTYPE))
+    graph = scenes.asteroid_scene(args.scale) if args.workload == "asteroid" else scenes.plates_scene(args.dense_chunks)
+    scene_name = f"config-2 SDF asteroid x{args.scale}" if args.workload == "asteroid" else f"{args.dense_chunks} perforated plates (all-surface)"
+    scaling = "strong"
     if not slabs:
-        gen = SDFVoxelGenerator(1.0, scenes.asteroid_scene(args.scale), 0)
+        gen, obj = make_object(ctx, graph)
         cc = gen.chunk_counts()
-        obj = VoxelObject(ctx, cc, 1.0)
-        obj.set_sdf_program(gen)
-        obj.set_densities(dens)
 
         def step():
             # the voxel stages and the object's rigid-body step are enqueued back to back; one wait covers both
@@ -359,20 +644,20 @@ def main():
             body_world.step_enqueue(0.005)
             return obj.step_collect()
 
-        workload = f"config-2 SDF asteroid x{args.scale} -> {gen.grid_shape()[0]}^3 grid = {cc[0] * 16}^3 stored voxels ({obj.n_chunks} chunks)"
+        workload = f"{scene_name} -> {gen.grid_shape()[0]}^3 grid = {cc[0] * 16}^3 stored voxels ({obj.n_chunks} chunks)"
         parallelism = "single GPU"
     else:
         from impact_amd.distributed import SlabStepper, TorchComm
 
-        # weak scaling the way BASELINE.json's config 5 states it: the config-2 asteroid with all lengths scaled so that every
-        # rank keeps the 512^3 workload's voxel count (N = 8: scale x2 again -> the 1024^3 grid in 8 slabs of 128 planes)
-        mg_scale = args.scale * world ** (1.0 / 3.0)
-        stepper = SlabStepper(ctx, scenes.asteroid_scene(mg_scale), dens, rank, world, torch)
+        if args.scaling == "weak" and args.workload == "asteroid":
+            # BASELINE.json's config 5: the config-2 asteroid with all lengths scaled so that every rank keeps the 512^3
+            # workload's voxel count (N = 8: scale x2 again -> the 1024^3 grid in 8 slabs of 128 planes)
+            graph = scenes.asteroid_scene(args.scale * world ** (1.0 / 3.0))
+            scene_name = f"config-2 SDF asteroid x{args.scale * world ** (1.0 / 3.0):.3f} (config 5 at N=8)"
+            scaling = "weak"
+        stepper = SlabStepper(ctx, graph, dens, rank, world, torch)
         comm = TorchComm(dist, torch, rank, world)
         obj = stepper.obj
-
-        class _Res(dict):
-            pass
 
         def step():
             body_world.step_enqueue(0.005)  # on the same stream, ahead of the slab's kernels; the protocol's one wait covers it
@@ -380,9 +665,9 @@ def main():
             return {"stage_ms": r.stage_ms, "mesh": {"n_vertices": r.mesh_counts[0], "n_indices": r.mesh_counts[1]},
                     "region_count": r.region_count}
 
-        workload = (f"config-2 SDF asteroid x{mg_scale:.3f} -> {stepper.global_shape} stored grid (config 5 at N=8), "
-                    f"x-slabs of {obj.chunk_counts[0]} chunk planes per rank ({obj.n_chunks} chunks on rank 0)")
-        parallelism = f"x-slab domain decomposition over {world} GPUs, 1-voxel halos + region equivalences over RCCL"
+        workload = (f"{scene_name} -> {stepper.global_shape} stored grid, x-slabs of {obj.chunk_counts[0]} chunk planes per rank "
+                    f"({obj.n_chunks} chunks on rank 0)")
+        parallelism = f"x-slab domain decomposition over {world} GPUs, 1-voxel halos + region equivalences over {dist.get_backend()}"
 
     def barrier():
         if dist is not None:
@@ -406,32 +691,26 @@ def main():
         elapsed = float(t.item())
 
     n_vox_rank = obj.n_voxels
-    if dist is not None:
-        t = torch.tensor([n_vox_rank], dtype=torch.int64, device="cuda")
-        dist.all_reduce(t)
-        n_vox_total = int(t.item())
-    else:
-        n_vox_total = n_vox_rank
     tris_rank = int(res["mesh"]["n_indices"]) // 3
     if dist is not None:
-        t = torch.tensor([tris_rank], dtype=torch.int64, device="cuda")
+        t = torch.tensor([n_vox_rank, tris_rank], dtype=torch.int64, device="cuda")
         dist.all_reduce(t)
-        tris_total = int(t.item())
+        n_vox_total, tris_total = int(t[0].item()), int(t[1].item())
     else:
-        tris_total = tris_rank
+        n_vox_total, tris_total = n_vox_rank, tris_rank
     stage_ms = stage_sum / args.steps
     ms_per_step = 1e3 * elapsed / args.steps
 
     if rank == 0:
-        # roofline of the dominant kernel (largest average launch duration measured with HIP events on the
-        # library's stream), algorithmic bytes from DESIGN.md
-        _, _, _, _, info = obj.download(sdf=False, types=False, flags=False, labels=False)
-        exposed = int(np.count_nonzero((info["kind"] == 2) & ((info["flags"] & 0x3F) != 0x3F)))
+        exposed, non_uniform = chunk_census(obj)
         counters = obj.stage_counters()
-        sb = stage_bytes(n_vox_rank, obj.n_chunks, exposed, int(res["mesh"]["n_vertices"]), int(res["mesh"]["n_indices"]))
-        dom = int(np.argmax(stage_ms))
-        name = capi.STAGE_NAMES[dom]
-        achieved = sb[name] / (stage_ms[dom] * 1e-3) / 1e9
+        # chunks whose voxels are touched per step: the ones that have planes (NonUniform) and the ones the sampler evaluates per voxel
+        active = max(non_uniform, counters["evaluated_chunks"]) * 4096
+        nv, ni = int(res["mesh"]["n_vertices"]), int(res["mesh"]["n_indices"])
+        sb_eff = stage_bytes(n_vox_rank, obj.n_chunks, exposed, nv, ni)
+        sb_act = stage_bytes(active, obj.n_chunks, exposed, nv, ni)
+        key = ("headline" if abs(args.scale - 2.05) < 1e-9 else None) if args.workload == "asteroid" else ("dense" if args.dense_chunks == 32 else None)
+        rl, srl, vrl = roofline_block(stage_ms, sb_eff, sb_act, key if world == 1 else None)
         remesh_ms = float(stage_ms[6] + stage_ms[7] + stage_ms[8])
         out = {
             "metric": "voxels stepped/sec + remesh tris/sec, 512^3 grid, 1/2/4/8 MI355X",
@@ -442,33 +721,63 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "i8 voxels, f32 SDF/mesh arithmetic, f64 moments",
             "data": "synthetic",
-            "config": {"workload": workload, "parallelism": parallelism, "voxels_per_gpu": n_vox_rank, "regions": int(res["region_count"]),
-                       "triangles": tris_total, "vertices_rank0": int(res["mesh"]["n_vertices"]), "exposed_chunks_rank0": exposed,
-                       "evaluated_chunks_rank0": counters["evaluated_chunks"], "meshed_chunks_rank0": counters["meshed_chunks"]},
+            "config": {"workload": workload, "parallelism": parallelism, "voxels_per_gpu": n_vox_rank, "active_voxels_rank0": active,
+                       "regions": int(res["region_count"]), "triangles": tris_total, "vertices_rank0": nv, "exposed_chunks_rank0": exposed,
+                       "non_uniform_chunks_rank0": non_uniform, "evaluated_chunks_rank0": counters["evaluated_chunks"],
+                       "meshed_chunks_rank0": counters["meshed_chunks"]},
             "remesh_tris_per_s": tris_rank / (remesh_ms * 1e-3) if remesh_ms > 0 else None,
             "remesh_ms": remesh_ms,
+            "active_voxels_per_s": active * world / (elapsed / args.steps),
             "stage_ms": {capi.STAGE_NAMES[i]: round(float(stage_ms[i]), 4) for i in range(capi.N_TIMED_STAGES)},
-            "stage_gbs": {capi.STAGE_NAMES[i]: round(sb[capi.STAGE_NAMES[i]] / (stage_ms[i] * 1e-3) / 1e9, 1) if stage_ms[i] > 0 and sb[capi.STAGE_NAMES[i]] > 0 else None
-                          for i in range(capi.N_TIMED_STAGES)},
-            "roofline": {"bound": "hbm", "kernel": "+".join(STAGE_KERNELS[name]), "stage": name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes": sb[name],
-                         "traffic": measured_traffic(name) if world == 1 and abs(args.scale - 2.05) < 1e-9 else None},
-            "step_roofline": {"algorithmic_bytes": float(sum(sb.values())), "achieved": float(sum(sb.values())) / (float(stage_ms.sum()) * 1e-3) / 1e9,
-                              "unit": "GB/s", "frac": float(sum(sb.values())) / (float(stage_ms.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "stage_gbs": {capi.STAGE_NAMES[i]: round(sb_act[capi.STAGE_NAMES[i]] / (stage_ms[i] * 1e-3) / 1e9, 1)
+                          if stage_ms[i] > 0 and sb_act[capi.STAGE_NAMES[i]] > 0 else None for i in range(capi.N_TIMED_STAGES)},
+            "stage_gbs_accounting": "active-voxel algorithmic bytes / live HIP-event stage time (never above the 6.3 TB/s copy rate by construction of the bytes)",
+            "roofline": rl,
+            "step_roofline": srl,
         }
+        if vrl:
+            out["valu_roofline"] = vrl
+        o_big = m_big = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.scale)
+            what = "full N=1 workload" if args.workload == "asteroid" else "the timed scene"
+            if args.workload == "dense":  # (the 512^3 all-surface oracle takes half a minute: bounded sample instead, see dense_benchmark)
+                out["cpu_baseline"] = None
+            else:
+                base, allc, parity, o_big, m_big = cpu_baseline(graph, obj, res, what)
+                out["cpu_baseline"], out["cpu_baseline_all_cores"], out["parity"] = base, allc, parity
         elif world == 1:
             out["cpu_baseline"] = None
-        if not args.no_pile:
-            out["pile"] = pile_benchmark(ctx, with_cpu=(world == 1 and not args.no_cpu_baseline))
-            if world == 1:
-                out["edit"] = edit_benchmark(ctx, args.scale)
-                out["collide"] = collide_benchmark(ctx, args.scale)
+        if not args.no_pile and world == 1:
+            with_cpu = not args.no_cpu_baseline
+            out["dense"] = dense_benchmark(ctx, args, with_cpu) if args.workload == "asteroid" else None
+            out["config2"] = config2_benchmark(ctx, args, with_cpu)
+            out["config3"] = config3_benchmark(ctx, args, with_cpu)
+            pile, w = pile_benchmark(ctx, with_cpu)
+            out["pile"] = pile
+            # the full frame: the voxel step of the headline body + the pile's solve, enqueued back to back, one wait
+            for _ in range(2):
+                obj.step_enqueue(capi.STAGE_ALL)
+                w.step_enqueue(0.005)
+                obj.step_collect()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                obj.step_enqueue(capi.STAGE_ALL)
+                w.step_enqueue(0.005)
+                obj.step_collect()
+            frame_ms = 1e3 * (time.perf_counter() - t0) / 10
+            w.close()
+            out["frame"] = {"workload": "the timed voxel step + one config-4 pile step (resident contacts), enqueued back to back, one wait",
+                            "ms_per_frame": frame_ms, "voxels_per_s": n_vox_rank / (frame_ms * 1e-3)}
+            if args.workload == "asteroid":
+                out["collide"] = collide_benchmark(ctx, args.scale, o_big if with_cpu else None, m_big)
+                out["edit"] = edit_benchmark(ctx, args.scale, o_big if with_cpu else None)  # (last: the oracle's edit changes o_big)
+        elif not args.no_pile:
+            out["pile"], w = pile_benchmark(ctx, with_cpu=False)
+            w.close()
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -168,3 +168,25 @@ def sphere_pile_scene(n: int = 16, spacing: float = 0.95, radius: float = 0.5, p
             c["flags"] = CONTACT_MANIFOLD_START if q == 0 else 0
             k += 1
     return bodies, contacts
+
+
+def plates_scene(n_chunks: int = 32, thickness: float = 6.0, holes: bool = True) -> SDFGraph:
+    """All-surface workload: `n_chunks` parallel plates of `thickness` voxels, one per chunk layer along z, each spanning the
+    whole grid in x and y, perforated by a few capsule-shaped holes through the stack — every chunk of the (16 n)^3 stored grid
+    holds part of a plate's surface, so every chunk is NonUniform and meshed and the per-voxel byte accounting of SURVEY §8d
+    applies to the whole grid (the config-2 asteroid is a solid body: 85 % of its chunks are 8-byte records)."""
+    g = SDFGraph()
+    side = 16.0 * n_chunks - 3.0  # + 2 border voxels, rounded up -> exactly n_chunks chunks per axis
+    acc = None
+    for p in range(n_chunks):
+        z = 16.0 * (p - 0.5 * (n_chunks - 1))
+        plate = g.add_node(SDFNode.new_translation(g.add_node(SDFNode.new_box((side, side, thickness))), (0.0, 0.0, z)))
+        acc = plate if acc is None else g.add_node(SDFNode.new_union(acc, plate, 0.0))
+    if holes:
+        span = 16.0 * n_chunks
+        for q, (x, y, r) in enumerate(((0.21, 0.17, 0.055), (-0.27, 0.08, 0.04), (0.05, -0.3, 0.07), (-0.16, -0.22, 0.03))):
+            c = g.add_node(SDFNode.new_capsule(span, r * span))
+            c = g.add_node(SDFNode.new_rotation_from_axis_angle(c, (1.0, 0.0, 0.0), 1.5707963267948966))  # capsule axis y -> z
+            c = g.add_node(SDFNode.new_translation(c, (x * span, y * span, 0.0)))
+            acc = g.add_node(SDFNode.new_subtraction(acc, c, 0.0 if q % 2 else 2.0))
+    return g

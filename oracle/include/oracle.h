@@ -75,6 +75,11 @@ void orc_export_sparse(const orc_object*, int32_t* data_offsets, uint8_t* voxels
 
 /* mesh ------------------------------------------------------------------------------------- */
 orc_mesh* orc_mesh_recreate(const orc_object*);
+/* all-cores variants (OpenMP over chunks; bench.py's cpu_baseline_all_cores): the object comes back with occupied ranges and derived
+ * state computed; results are identical to the sequential entry points (tests/test_oracle_parallel.py) */
+orc_object* orc_object_from_sdf_parallel(const orc_sdf_node* nodes, int n, uint32_t root, float voxel_extent, uint8_t voxel_type, int threads);
+orc_mesh* orc_mesh_recreate_parallel(const orc_object*, int threads);
+void orc_inertia_parallel(const orc_object*, const float densities[256], float out32[10], int threads);
 /* VoxelObjectMesh::sync_with_voxel_object (mesh.rs:355-456): re-mesh the invalidated chunks (one byte per chunk), reusing freed buffer ranges
  * through the ChunkSubmeshManager (mesh.rs:699-849) and its RangeAllocators; chunks are visited in chunk-linear order (the reference's hash-set
  * order is unpinned). Buffers only grow; submeshes keep the manager's slot order. */

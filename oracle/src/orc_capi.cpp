@@ -10,6 +10,10 @@
 namespace orc {
 void inertia_moments_f32(const VoxelObject& obj, const float* dens, float out32[10]);
 void inertia_moments_f64(const VoxelObject& obj, const float* dens, double out[10]);
+void inertia_moments_f32_parallel(const VoxelObject& obj, const float* dens, float out32[10], int threads);
+void generate_without_derived_state_parallel(VoxelObject& obj, const Generator& gen, int threads);
+void compute_all_derived_state_parallel(VoxelObject& obj, int threads);
+void mesh_recreate_parallel(const VoxelObject& obj, Mesh& mesh, int threads);
 void derive_inertial_properties(const float m[10], float out[22]);
 uint32_t canonical_region_labels(const VoxelObject& obj, uint32_t* labels);
 int split_off_smallest_region(VoxelObject& parent, VoxelObject& child, int origin[3]);
@@ -188,6 +192,27 @@ orc_object* orc_object_from_sdf(const orc_sdf_node* nodes, int n, uint32_t root,
     if (!g.sdf.build(reinterpret_cast<const SdfNode*>(nodes), n, root)) return nullptr;
     g.init(voxel_extent, voxel_type);
     return make_object(g);
+}
+
+// all-cores variants (bench.py's cpu_baseline_all_cores; same results as the sequential entry points)
+orc_object* orc_object_from_sdf_parallel(const orc_sdf_node* nodes, int n, uint32_t root, float voxel_extent, uint8_t voxel_type, int threads) {
+    SdfVoxelGenerator g;
+    if (!g.sdf.build(reinterpret_cast<const SdfNode*>(nodes), n, root)) return nullptr;
+    g.init(voxel_extent, voxel_type);
+    orc_object* o = new orc_object();
+    g.grid_shape(o->shape);
+    generate_without_derived_state_parallel(o->obj, g, threads);
+    update_occupied_voxel_ranges(o->obj);
+    compute_all_derived_state_parallel(o->obj, threads);
+    return o;
+}
+orc_mesh* orc_mesh_recreate_parallel(const orc_object* o, int threads) {
+    orc_mesh* m = new orc_mesh();
+    mesh_recreate_parallel(o->obj, m->mesh, threads);
+    return m;
+}
+void orc_inertia_parallel(const orc_object* o, const float densities[256], float out32[10], int threads) {
+    inertia_moments_f32_parallel(o->obj, densities, out32, threads);
 }
 
 orc_object* orc_object_from_box(const int shape[3], const int offset[3], uint8_t type, int8_t sd, uint8_t flags) {

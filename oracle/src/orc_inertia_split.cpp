@@ -109,6 +109,36 @@ void inertia_moments_f32(const VoxelObject& obj, const float* dens, float out32[
     std::memcpy(out32, r, sizeof(r));
 }
 
+// all-cores variant: per-chunk moments in parallel, summed in the sequential function's chunk order (bit-identical f32 result)
+void inertia_moments_f32_parallel(const VoxelObject& obj, const float* dens, float out32[10], int threads) {
+    const int n = obj.n_chunks();
+    std::vector<Moments32> per(n);
+    std::vector<uint8_t> has(n, 0);
+#pragma omp parallel for schedule(dynamic, 32) num_threads(threads)
+    for (int c = 0; c < n; ++c) {
+        const Chunk& ch = obj.chunks[c];
+        int ci[3] = {c / (obj.cc[2] * obj.cc[1]), (c / obj.cc[2]) % obj.cc[1], c % obj.cc[2]};
+        if (ch.kind == K_NONUNIFORM) chunk_moments_non_uniform(obj.extent, &obj.voxels[(size_t)ch.data_offset << 12], dens, ci, per[c]);
+        else if (ch.kind == K_UNIFORM) chunk_moments_uniform(obj.extent, dens, ch.uniform_voxel.type, ci, per[c]);
+        else continue;
+        has[c] = 1;
+    }
+    float mass = 0.0f;
+    V3 mo{0, 0, 0}, mi{0, 0, 0}, pi{0, 0, 0};
+    for (int i = obj.occ_chunk[0][0]; i < obj.occ_chunk[0][1]; ++i)
+        for (int j = obj.occ_chunk[1][0]; j < obj.occ_chunk[1][1]; ++j)
+            for (int k = obj.occ_chunk[2][0]; k < obj.occ_chunk[2][1]; ++k) {
+                const int c = obj.cidx(i, j, k);
+                if (!has[c]) continue;
+                mass += per[c].mass;
+                mo = mo + per[c].moments;
+                mi = mi + per[c].moi;
+                pi = pi + per[c].poi;
+            }
+    float r[10] = {mass, mo.x, mo.y, mo.z, mi.x, mi.y, mi.z, pi.x, pi.y, pi.z};
+    std::memcpy(out32, r, sizeof(r));
+}
+
 // Exact cube integrals in f64: for voxel (I,J,K), x in [I e,(I+1) e]:
 //   xh^2-xl^2 = e^2 (2I+1),  xh^3-xl^3 = e^3 (3I^2+3I+1)
 void inertia_moments_f64(const VoxelObject& obj, const float* dens, double out[10]) {

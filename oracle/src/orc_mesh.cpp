@@ -7,6 +7,8 @@
 //   CUBE_CORNERS / CUBE_EDGES                       object/sdf/surface_nets.rs:639-674
 //   VoxelObjectMesh::recreate                       mesh.rs:286-354, 559-577
 //   ChunkSubmesh obscuredness table                 mesh.rs:611-635
+#include <memory>
+
 #include "orc_mesh.hpp"
 
 #include <algorithm>
@@ -342,6 +344,70 @@ void mesh_recreate(const VoxelObject& obj, Mesh& mesh) {
                 mesh.index_materials.insert(mesh.index_materials.end(), buf.imats.begin(), buf.imats.end());
                 for (uint16_t ix : buf.indices) mesh.indices.push_back(voff + (uint32_t)ix);
             }
+}
+
+// all-cores variant of mesh_recreate (bench.py's `cpu_baseline_all_cores`): the chunk meshes are computed by a pool of threads and
+// concatenated in chunk-linear order afterwards — the same buffers as the sequential function (checked by tests/test_oracle_parallel.py).
+void mesh_recreate_parallel(const VoxelObject& obj, Mesh& mesh, int threads) {
+    mesh = Mesh{};
+    const int n = obj.n_chunks();
+    const float chunk_extent = (float)CHUNK * obj.extent;
+    std::vector<int> exposed;
+    for (int c = 0; c < n; ++c) {
+        const Chunk& ch = obj.chunks[c];
+        if (ch.kind == K_NONUNIFORM && (ch.flags & CF_FULLY_OBSCURED) != CF_FULLY_OBSCURED) exposed.push_back(c);
+    }
+    std::vector<SurfaceNetsBuffer> parts(exposed.size());
+#pragma omp parallel num_threads(threads)
+    {
+        std::unique_ptr<ChunkSdf> sdf(new ChunkSdf());
+        std::memset(sdf->types, TYPE_DUMMY, sizeof(sdf->types));
+        for (int i = 0; i < GCELLS; ++i) sdf->values[i] = 0.0f;
+#pragma omp for schedule(dynamic, 8)
+        for (size_t e = 0; e < exposed.size(); ++e) {
+            const int c = exposed[e];
+            const int ci = c / (obj.cc[2] * obj.cc[1]), cj = (c / obj.cc[2]) % obj.cc[1], ck = c % obj.cc[2];
+            fill_sdf(obj, ci, cj, ck, *sdf);
+            V3 offset = v3((float)ci * chunk_extent - 0.5f * obj.extent, (float)cj * chunk_extent - 0.5f * obj.extent,
+                           (float)ck * chunk_extent - 0.5f * obj.extent);
+            compute_surface_nets_mesh(*sdf, obj.extent, offset, parts[e]);
+            parts[e].surf.clear();
+            parts[e].surf.shrink_to_fit();
+            parts[e].surf_lin.clear();
+            parts[e].surf_lin.shrink_to_fit();
+        }
+    }
+    size_t nv = 0, ni = 0;
+    for (const auto& b : parts) {
+        nv += b.positions.size();
+        ni += b.indices.size();
+    }
+    mesh.positions.reserve(nv);
+    mesh.normals.reserve(nv);
+    mesh.indices.reserve(ni);
+    mesh.index_materials.reserve(ni);
+    for (size_t e = 0; e < exposed.size(); ++e) {
+        const SurfaceNetsBuffer& buf = parts[e];
+        if (buf.indices.empty()) continue;
+        const int c = exposed[e];
+        const Chunk& ch = obj.chunks[c];
+        uint32_t voff = (uint32_t)mesh.positions.size();
+        Submesh sm{};
+        sm.chunk[0] = (uint32_t)(c / (obj.cc[2] * obj.cc[1]));
+        sm.chunk[1] = (uint32_t)((c / obj.cc[2]) % obj.cc[1]);
+        sm.chunk[2] = (uint32_t)(c % obj.cc[2]);
+        sm.index_offset = (uint32_t)mesh.indices.size();
+        sm.index_count = (uint32_t)buf.indices.size();
+        sm.vertex_offset = voff;
+        sm.vertex_count = (uint32_t)buf.positions.size();
+        obscured_table(ch.flags, sm.obscured);
+        mesh.chunk_index[chunk_key(sm.chunk[0], sm.chunk[1], sm.chunk[2])] = mesh.submeshes.size();
+        mesh.submeshes.push_back(sm);
+        mesh.positions.insert(mesh.positions.end(), buf.positions.begin(), buf.positions.end());
+        mesh.normals.insert(mesh.normals.end(), buf.normals.begin(), buf.normals.end());
+        mesh.index_materials.insert(mesh.index_materials.end(), buf.imats.begin(), buf.imats.end());
+        for (uint16_t ix : buf.indices) mesh.indices.push_back(voff + (uint32_t)ix);
+    }
 }
 
 static void remove_chunk_if_present(Mesh& mesh, uint64_t key) {  // mesh.rs:811-824 (swap_remove keeps the tables dense)

@@ -51,6 +51,11 @@ def lib():
         L.orc_sdf_compile.argtypes = [vp, C.c_int, C.c_uint32, vp, C.c_int, vp, vp]
         L.orc_object_from_sdf.restype = vp
         L.orc_object_from_sdf.argtypes = [vp, C.c_int, C.c_uint32, C.c_float, C.c_uint8]
+        L.orc_object_from_sdf_parallel.restype = vp
+        L.orc_object_from_sdf_parallel.argtypes = [vp, C.c_int, C.c_uint32, C.c_float, C.c_uint8, C.c_int]
+        L.orc_mesh_recreate_parallel.restype = vp
+        L.orc_mesh_recreate_parallel.argtypes = [vp, C.c_int]
+        L.orc_inertia_parallel.argtypes = [vp, vp, vp, C.c_int]
         L.orc_object_from_box.restype = vp
         L.orc_object_from_box.argtypes = [vp, vp, C.c_uint8, C.c_int8, C.c_uint8]
         L.orc_object_from_manual.restype = vp
@@ -285,6 +290,12 @@ class OracleObject:
         return cls(lib().orc_object_from_sdf(_p(nodes), len(nodes), graph.root_node_id, voxel_extent, voxel_type))
 
     @classmethod
+    def from_sdf_parallel(cls, graph, voxel_extent=1.0, voxel_type=0, threads=2):
+        """generate + occupied ranges + derived state over `threads` OpenMP threads (same object as the sequential path)"""
+        nodes = graph.nodes()
+        return cls(lib().orc_object_from_sdf_parallel(_p(nodes), len(nodes), graph.root_node_id, voxel_extent, voxel_type, threads))
+
+    @classmethod
     def from_box(cls, shape, offset=(0, 0, 0), voxel=(0, -128, 0)):
         s = np.asarray(shape, dtype=np.int32)
         o = np.asarray(offset, dtype=np.int32)
@@ -355,9 +366,22 @@ class OracleObject:
         f = int(flg[c * 4096 + (((i & 15) << 8) | ((j & 15) << 4) | (k & 15))])
         return None if (f & 1) else f
 
-    def mesh(self) -> OracleMesh:
+    def mesh_parallel(self, threads) -> OracleMesh:
+        return self.mesh(threads)
+
+    def inertia_parallel(self, threads, densities=None):
+        d = np.ones(256, dtype=np.float32) if densities is None else np.ascontiguousarray(densities, dtype=np.float32)
+        o32 = np.zeros(10, dtype=np.float32)
+        lib().orc_inertia_parallel(self.h, _p(d), _p(o32), threads)
+        return o32
+
+    def mesh(self, threads=1) -> OracleMesh:
+        import time
+
         L = lib()
-        m = C.c_void_p(L.orc_mesh_recreate(self.h))
+        t0 = time.perf_counter()
+        m = C.c_void_p(L.orc_mesh_recreate_parallel(self.h, threads) if threads > 1 else L.orc_mesh_recreate(self.h))
+        self.last_mesh_seconds = time.perf_counter() - t0  # the meshing alone, without the export into numpy arrays below
         cnt = np.zeros(3, dtype=np.uint32)
         L.orc_mesh_counts(m, _p(cnt))
         nv, ni, ns = (int(x) for x in cnt)

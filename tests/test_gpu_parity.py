@@ -217,3 +217,24 @@ def test_bench_workload_512(ctx):
     occ = np.asarray(res["occupied"]).reshape(-1)
     assert [(int(occ[6 + 2 * d]), int(occ[7 + 2 * d])) for d in range(3)] == info["occupied_voxel_ranges"]
     obj.close()
+
+
+def test_dense_workload_512(ctx):
+    """bench.py's all-surface workload at full size — 32 perforated plates, every chunk of the 512^3 grid NonUniform and meshed
+    (33 M triangles) — through `ivx_voxel_step(STAGE_ALL)` against the oracle."""
+    from impact_amd import capi
+    from impact_amd.voxel import SDFVoxelGenerator
+
+    graph = scenes.plates_scene(32)
+    gen = SDFVoxelGenerator(1.0, graph, 0)
+    assert gen.chunk_counts() == (32, 32, 32)
+    obj = VoxelObject(ctx, gen.chunk_counts(), 1.0)
+    obj.set_sdf_program(gen)
+    obj.set_densities(np.ones(256, dtype=np.float32))
+    obj.step(capi.STAGE_ALL)
+    res = obj.step(capi.STAGE_ALL)
+    o = ol.OracleObject.from_sdf_parallel(graph, 1.0, 0, 8)  # (identical to the sequential oracle: tests/test_oracle_parallel.py)
+    p = pu.step_parity(o, obj, res)
+    assert p["equal"], p
+    assert p["regions"][0] == 32
+    obj.close()
