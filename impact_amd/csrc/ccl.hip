@@ -17,35 +17,10 @@
 // atomicMin unions over the small (chunk,region) table; voxels never carry a 32-bit label in HBM.
 // Traffic: level 1 reads 1 B/voxel (flags) and writes 1 B/voxel (label); level 2 reads only the six
 // face planes of labels per chunk.
-#include "chunk_passes.hpp"
+#include "ccl_roles.hpp"
 
 namespace {
-
-__device__ __forceinline__ uint32_t flags_mask(uint4 f) {
-    uint32_t w[4] = {f.x, f.y, f.z, f.w};
-    uint32_t m = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-        if (!((w[k >> 2] >> (8 * (k & 3))) & VF_EMPTY)) m |= 1u << k;
-    return m;
-}
-
-__device__ __forceinline__ uint32_t prefix_ordered(uint32_t val, uint32_t* s_wsum, uint32_t tid, uint32_t& total) {
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
-    uint32_t incl = val;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t n = __shfl_up(incl, o, 64);
-        if (lane >= (uint32_t)o) incl += n;
-    }
-    if (lane == 63u) s_wsum[wave] = incl;
-    __syncthreads();
-    uint32_t w0 = s_wsum[0], w1 = s_wsum[1], w2 = s_wsum[2], w3 = s_wsum[3];
-    uint32_t wbase = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
-    total = w0 + w1 + w2 + w3;
-    __syncthreads();
-    return wbase + incl - val;
-}
+using namespace ivx_roles;
 
 // Level 1 as a kernel of its own (the step path runs it fused into k_derive, see chunk_passes.hpp): walks the active list;
 // the non-empty masks come from the flags plane.
@@ -70,380 +45,33 @@ __global__ __launch_bounds__(256) void k_ccl_local(GridView g, const uint8_t* __
     }
 }
 
-// ---- exact local numbering for chunks with several regions ----------------------------------------
-// The reference numbers the regions of a chunk in an order that depends on which voxel its sequential
-// union-find left as the root of each set (split_detection.rs:700-831: a boundary-touching set is labelled
-// when the face loops reach its ROOT voxel, or the first face voxel visited if the root is interior).
-// That root is a product of the scan order and has no parallel closed form, so for the (rare) chunks
-// that hold two or more regions one lane replays the reference's sequence in LDS: unions in (i,j,k)
-// order over the *_UP flags, the six face loops of Loop3::over_full_boundary (utils.rs:247-322), then
-// the interior sets. Chunks with a single region (label 0 everywhere) keep the parallel result. The
-// partition is the same either way; this pass makes the label VALUES equal to the reference's.
-__device__ __forceinline__ uint32_t seq_find(uint16_t* par, uint32_t x) {
-    uint32_t r = x;
-    while (par[r] != r) r = par[r];
-    while (par[x] != r) {  // full compression, as find_root_for_voxel_and_compress_path (split_detection.rs:1786-1802)
-        const uint32_t n = par[x];
-        par[x] = (uint16_t)r;
-        x = n;
-    }
-    return r;
+// The kernels below are the stand-alone forms of the roles in ccl_roles.hpp (the step path runs the same roles inside the
+// fused launches of step_fused.hip).
+__global__ __launch_bounds__(256) void k_ccl_local_exact(const uint8_t* __restrict__ flags, uint8_t* __restrict__ labels, ivx_chunk_info* __restrict__ info,
+                                                         uint32_t* __restrict__ rparent, uint32_t* __restrict__ rscalar, const uint32_t* __restrict__ multi_list) {
+    __shared__ CclShared sh;
+    role_ccl_local_exact(blockIdx.x, gridDim.x, sh, flags, labels, info, rparent, rscalar, multi_list);
 }
-
-__global__ __launch_bounds__(64) void k_ccl_local_exact(GridView g, const uint8_t* __restrict__ flags, uint8_t* __restrict__ labels,
-                                                        ivx_chunk_info* __restrict__ info, uint32_t* __restrict__ rparent,
-                                                        uint32_t* __restrict__ rscalar, const uint32_t* __restrict__ multi_list) {
-    __shared__ uint16_t s_par[IVX_CHUNK_VOXELS];
-    __shared__ uint8_t s_flg[IVX_CHUNK_VOXELS];
-    __shared__ uint8_t s_lab[IVX_CHUNK_VOXELS];
-    __shared__ uint32_t s_ne[IVX_CHUNK_VOXELS / 32];  // non-empty bits, voxel order
-    __shared__ uint16_t s_visit[1352];                // non-empty boundary voxels in the order of Loop3::over_full_boundary
-    __shared__ uint32_t s_counts[3];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t n_multi = rscalar[2];
-    // position n of the boundary walk (utils.rs:247-322): X-, X+ full faces; Y-, Y+ with i in 1..15, k inner; Z-, Z+ with i, j in 1..15
-    auto boundary_pos = [](uint32_t n) -> uint32_t {
-        if (n < 512u) return ((n >> 8) ? 15u << 8 : 0u) | (n & 255u);
-        n -= 512u;
-        if (n < 448u) {
-            const uint32_t side = n / 224u, r = n % 224u;
-            return ((1u + r / 16u) << 8) | ((side ? 15u : 0u) << 4) | (r % 16u);
-        }
-        n -= 448u;
-        const uint32_t side = n / 196u, r = n % 196u;
-        return ((1u + r / 14u) << 8) | ((1u + r % 14u) << 4) | (side ? 15u : 0u);
-    };
-    // bounded grid-stride walk over the (usually empty) list of multi-region chunks
-    for (uint32_t li = blockIdx.x; li < n_multi; li += gridDim.x) {
-    const uint32_t chunk = multi_list[li];
-    __syncthreads();
-    const size_t base = (size_t)chunk * IVX_CHUNK_VOXELS;
-    for (uint32_t i = tid; i < 256u; i += 64u) reinterpret_cast<uint4*>(s_flg)[i] = reinterpret_cast<const uint4*>(flags + base)[i];
-    for (uint32_t i = tid; i < IVX_CHUNK_VOXELS; i += 64u) {
-        s_par[i] = (uint16_t)i;
-        s_lab[i] = 255;
-    }
-    __syncthreads();
-    // The replay itself is one lane's work; everything around it is not: the wave lists the non-empty voxels (bit set) and the
-    // non-empty boundary voxels in walk order first, so the serial lane never looks at an empty voxel, and numbers the
-    // interior-only sets afterwards in parallel.
-    for (uint32_t w = tid; w < IVX_CHUNK_VOXELS / 32; w += 64u) {
-        uint32_t m = 0;
-        for (uint32_t q = 0; q < 32u; ++q)
-            if (!(s_flg[w * 32u + q] & VF_EMPTY)) m |= 1u << q;
-        s_ne[w] = m;
-    }
-    {
-        uint32_t n_visit = 0;
-        for (uint32_t n0 = 0; n0 < 1352u; n0 += 64u) {
-            const uint32_t n = n0 + tid;
-            const uint32_t idx = n < 1352u ? boundary_pos(n) : 0u;
-            const bool ne = n < 1352u && !(s_flg[idx] & VF_EMPTY);
-            const unsigned long long bal = __ballot(ne);
-            if (ne) s_visit[n_visit + (uint32_t)__popcll(bal & ((1ull << tid) - 1ull))] = (uint16_t)idx;
-            n_visit += (uint32_t)__popcll(bal);
-        }
-        if (tid == 0) s_counts[2] = n_visit;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        for (uint32_t w = 0; w < IVX_CHUNK_VOXELS / 32; ++w) {
-            uint32_t m = s_ne[w];
-            while (m) {
-                const uint32_t idx = w * 32u + (uint32_t)(__ffs(m) - 1);
-                m &= m - 1;
-                const uint32_t f = s_flg[idx];
-                const uint32_t i = idx >> 8, j = (idx >> 4) & 15u, k = idx & 15u;
-                const uint32_t root = seq_find(s_par, idx);
-                if (i < 15u && (f & VF_X_UP)) {
-                    const uint32_t r = seq_find(s_par, idx + 256u);
-                    if (r != root) s_par[r] = (uint16_t)root;
-                }
-                if (j < 15u && (f & VF_Y_UP)) {
-                    const uint32_t r = seq_find(s_par, idx + 16u);
-                    if (r != root) s_par[r] = (uint16_t)root;
-                }
-                if (k < 15u && (f & VF_Z_UP)) {
-                    const uint32_t r = seq_find(s_par, idx + 1u);
-                    if (r != root) s_par[r] = (uint16_t)root;
-                }
-            }
-        }
-        uint32_t current = 0;
-        const uint32_t n_visit = s_counts[2];
-        for (uint32_t v = 0; v < n_visit; ++v) {
-            const uint32_t idx = s_visit[v];
-            const uint32_t set_id = seq_find(s_par, idx);
-            const uint32_t si = set_id >> 8, sj = (set_id >> 4) & 15u, sk = set_id & 15u;
-            const bool root_interior = si > 0 && si < 15u && sj > 0 && sj < 15u && sk > 0 && sk < 15u;
-            if (set_id == idx) {
-                s_lab[idx] = (uint8_t)current;
-                current = min(current + 1u, 255u);
-            } else if (root_interior) {
-                s_par[set_id] = (uint16_t)idx;  // make_voxel_root (split_detection.rs:1877-1882)
-                s_par[idx] = (uint16_t)idx;
-                s_lab[idx] = (uint8_t)current;
-                current = min(current + 1u, 255u);
-            }
-        }
-        s_counts[0] = current;
-    }
-    __syncthreads();
-    {
-        // interior-only sets in (i,j,k) order (split_detection.rs:815-831): ordered parallel numbering of the remaining roots
-        uint32_t current = s_counts[0];
-        for (uint32_t n0 = 0; n0 < 2744u; n0 += 64u) {
-            const uint32_t n = n0 + tid;
-            const uint32_t idx = n < 2744u ? (((1u + n / 196u) << 8) | ((1u + (n / 14u) % 14u) << 4) | (1u + n % 14u)) : 0u;
-            const bool root = n < 2744u && !(s_flg[idx] & VF_EMPTY) && s_par[idx] == idx;
-            const unsigned long long bal = __ballot(root);
-            if (root) s_lab[idx] = (uint8_t)min(current + (uint32_t)__popcll(bal & ((1ull << tid) - 1ull)), 255u);
-            current = min(current + (uint32_t)__popcll(bal), 255u);
-        }
-        if (tid == 0) s_counts[1] = current;
-    }
-    __syncthreads();
-    for (uint32_t idx = tid; idx < IVX_CHUNK_VOXELS; idx += 64u) {
-        uint32_t lab = 255;
-        if (!(s_flg[idx] & VF_EMPTY)) {
-            uint32_t r = idx;
-            while (s_par[r] != r) r = s_par[r];
-            lab = s_lab[r];
-        }
-        labels[base + idx] = (uint8_t)lab;
-    }
-    uint32_t total = s_counts[1];
-    if (total > 254u) {
-        if (tid == 0) atomicOr(&rscalar[1], 1u);
-        total = 254u;
-    }
-    uint32_t* rp = rparent + (size_t)chunk * 256;
-    for (uint32_t r = tid; r < 256u; r += 64u) rp[r] = r < total ? chunk * 256u + r : NODE_NONE;
-    if (tid == 0) {
-        info[chunk].region_count = (uint8_t)total;
-        info[chunk].boundary_region_count = (uint8_t)(s_counts[0] < 254u ? s_counts[0] : 254u);
-    }
-    }
-}
-
-// ---- level 2 ---------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t g_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// find with path halving: a node's parent only ever moves to an ancestor, and ancestors have smaller indices (unions hang the
-// larger root under the smaller), so shortening with atomicMin is safe beside concurrent unions and other finds
-__device__ __forceinline__ uint32_t g_find(uint32_t* par, uint32_t x) {
-    uint32_t p = g_load(par + x);
-    while (p != x) {
-        const uint32_t gp = g_load(par + p);
-        if (gp != p) atomicMin(par + x, gp);
-        x = p;
-        p = gp;
-    }
-    return x;
-}
-__device__ __forceinline__ void g_union(uint32_t* par, uint32_t a, uint32_t b) {
-    for (int guard = 0; guard < (1 << 20); ++guard) {
-        a = g_find(par, a);
-        b = g_find(par, b);
-        if (a == b) return;
-        if (a < b) {
-            uint32_t t = a;
-            a = b;
-            b = t;
-        }
-        uint32_t old = atomicMin(par + a, b);
-        if (old == a) return;
-        a = old;
-    }
-}
-
-// Level 2 for single-region chunks (all but a handful). Joining chunks pairwise through the forest costs a chain of dependent
-// global loads and atomics per pair, nearly all of them on the one root of the body. They are joined by structure instead:
-// one WAVE per (ci, cj) column of chunks, lane = ck. Two single-region chunks stacked along k are linked when k_derive saw a
-// voxel pair touch across their face; a run of linked chunks hangs directly under its first chunk (plain stores: those
-// nodes are nobody's root yet). Where a chunk touches its +y / +x neighbour, the heads of the two runs are joined, once
-// per stretch over which both runs continue. Chunks with several regions are left to k_ccl_merge_multi.
 __global__ __launch_bounds__(256) void k_ccl_merge_columns(GridView g, const uint8_t* __restrict__ touch, uint32_t* __restrict__ rparent) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t col = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (col >= g.cx * g.cy) return;
-    const uint32_t cj = col % g.cy, ci = col / g.cy;
-    // heads of the runs that reach the end of the previous 64-chunk segment: this column, the +y and the +x column
-    uint32_t carry[3] = {NODE_NONE, NODE_NONE, NODE_NONE};
-    const uint32_t cols[3] = {col, col + 1u, col + g.cy};
-    const bool has[3] = {true, cj + 1 < g.cy, ci + 1 < g.cx};
-    const unsigned long long below = (1ull << lane) - 1ull;
-    for (uint32_t k0 = 0; k0 < g.cz; k0 += 64u) {
-        const uint32_t ck = k0 + lane;
-        const bool in = ck < g.cz;
-        bool single[3];
-        unsigned long long lm[3];
-        uint32_t head[3];
-        uint32_t own_touch = 0;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            single[q] = false;
-            bool linkz = false;
-            if (in && has[q]) {
-                const uint32_t c = cols[q] * g.cz + ck;
-                const uint32_t tb = touch[c];
-                single[q] = g.info[c].region_count == 1;
-                if (q == 0) own_touch = tb;
-                if (single[q] && ck + 1 < g.cz && ((tb >> 2) & 1u)) linkz = g.info[c + 1].region_count == 1;
-            }
-            lm[q] = __ballot(linkz);
-            // node of the first chunk of the run of column q that contains this lane (runs continue across segments)
-            const unsigned long long gaps = ~lm[q] & below;
-            const uint32_t hs = gaps ? 64u - (uint32_t)__clzll(gaps) : 0u;
-            head[q] = (hs == 0u && carry[q] != NODE_NONE) ? carry[q] : (cols[q] * g.cz + k0 + hs) * 256u;
-        }
-        const uint32_t node = (col * g.cz + ck) * 256u;
-        if (single[0] && head[0] != node) rparent[node] = head[0];
-#pragma unroll
-        for (int q = 1; q < 3; ++q) {
-            const bool link = single[0] && single[q] && ((own_touch >> (q == 1 ? 1 : 0)) & 1u);
-            const unsigned long long links = __ballot(link);
-            // the lane below joined the same two runs already
-            const bool dup = lane != 0 && ((links >> (lane - 1)) & 1ull) && ((lm[0] >> (lane - 1)) & 1ull) && ((lm[q] >> (lane - 1)) & 1ull);
-            if (link && !dup) g_union(rparent, head[0], head[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const uint32_t h63 = __shfl(head[q], 63, 64);
-            carry[q] = ((lm[q] >> 63) & 1ull) ? h63 : NODE_NONE;
-        }
-    }
+    role_ccl_merge_columns(blockIdx.x, gridDim.x, g, touch, rparent);
 }
-
-// Chunks with several regions (the list k_ccl_local made): one workgroup per such chunk joins its regions with those of
-// all SIX neighbours through the label planes (a single-region neighbour does not look at this pair itself).
 __global__ __launch_bounds__(256) void k_ccl_merge_multi(GridView g, const uint8_t* __restrict__ labels, uint32_t* __restrict__ rparent,
                                                          const uint32_t* __restrict__ rscalar, const uint32_t* __restrict__ multi_list) {
-    const uint32_t tid = threadIdx.x;
-    const uint32_t n_multi = rscalar[2];
-    const int a = tid >> 4, b = tid & 15;
-    for (uint32_t li = blockIdx.x; li < n_multi; li += gridDim.x) {
-        const uint32_t chunk = multi_list[li];
-        const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
-        const uint8_t* own = labels + (size_t)chunk * IVX_CHUNK_VOXELS;  // a chunk with several regions is NonUniform: it has planes
-#pragma unroll
-        for (int f = 0; f < 6; ++f) {
-            const int dim = f >> 1, up = f & 1;
-            const int ni = ci + (dim == 0 ? (up ? 1 : -1) : 0), nj = cj + (dim == 1 ? (up ? 1 : -1) : 0), nk = ck + (dim == 2 ? (up ? 1 : -1) : 0);
-            if (ni < 0 || nj < 0 || nk < 0 || ni >= (int)g.cx || nj >= (int)g.cy || nk >= (int)g.cz) continue;
-            const uint32_t nchunk = (ni * g.cy + nj) * g.cz + nk;
-            const ivx_chunk_info ninfo = g.info[nchunk];
-            if (ninfo.region_count == 0) continue;
-            const uint8_t* nb = labels + (size_t)nchunk * IVX_CHUNK_VOXELS;
-            const uint32_t so = up ? 15u : 0u, sn = up ? 0u : 15u;  // own / neighbour layer along `dim`
-            const uint32_t oo = dim == 0 ? ((so << 8) | (a << 4) | b) : (dim == 1 ? ((a << 8) | (so << 4) | b) : ((a << 8) | (b << 4) | so));
-            const uint32_t on = dim == 0 ? ((sn << 8) | (a << 4) | b) : (dim == 1 ? ((a << 8) | (sn << 4) | b) : ((a << 8) | (b << 4) | sn));
-            const uint32_t la = own[oo];
-            // a Uniform neighbour is region 0 everywhere and has no label plane (compact planes)
-            const uint32_t lb = ninfo.kind == KIND_NONUNIFORM ? (uint32_t)nb[on] : 0u;
-            const bool both = la != 255u && lb != 255u;
-            const uint32_t pair = both ? ((la << 8) | lb) : 0xFFFFFFFFu;
-            const uint32_t prev = __shfl_up(pair, 1, 64);
-            const bool dup = (tid & 63u) != 0 && prev == pair;
-            if (both && !dup) g_union(rparent, chunk * 256u + la, nchunk * 256u + lb);
-        }
-    }
+    role_ccl_merge_multi(blockIdx.x, gridDim.x, g, labels, rparent, rscalar, multi_list);
 }
-
-// flatten the forest and count the roots per chunk (one thread per chunk: almost every chunk has 0-2 regions)
 __global__ __launch_bounds__(256) void k_ccl_flatten(GridView g, uint32_t* __restrict__ rparent, uint32_t* __restrict__ root_counts,
                                                      uint32_t* __restrict__ group_sums) {
-    __shared__ uint32_t s_w[4];
-    const uint32_t chunk = blockIdx.x * 256u + threadIdx.x;
-    const bool live = chunk < g.cx * g.cy * g.cz;
-    const uint32_t rc = live ? g.info[chunk].region_count : 0u;
-    uint32_t n = 0;
-    for (uint32_t r = 0; r < rc; ++r) {
-        const uint32_t node = chunk * 256u + r;
-        const uint32_t root = g_find(rparent, node);
-        if (root == node) n += 1;
-        // safe while other threads still walk the forest: the parent only moves closer to the root
-        else __hip_atomic_store(rparent + node, root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // exclusive prefix of the root counts inside this group of 256 chunks (ordered) and the group's total: the two levels of
-    // the scan; k_ccl_assign adds the totals of the groups before
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t incl = n;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o, 64);
-        if (lane >= (uint32_t)o) incl += t;
-    }
-    if (lane == 63u) s_w[wave] = incl;
-    __syncthreads();
-    const uint32_t w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
-    const uint32_t wbase = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
-    if (live) root_counts[chunk] = wbase + incl - n;  // (the count itself is not needed again)
-    if (threadIdx.x == 0) group_sums[blockIdx.x] = (w0 + w1) + (w2 + w3);
+    role_ccl_flatten(blockIdx.x, gridDim.x, g, rparent, root_counts, group_sums);
 }
-
-// Grids of more than ASSIGN_MAX_GROUPS x 256 chunks: a launch of its own adds the totals of the groups before a chunk's group to
-// the in-group prefix k_ccl_flatten left (every block adds up those totals itself).
 __global__ __launch_bounds__(256) void k_scan_groups(uint32_t n, const uint32_t* __restrict__ in, const uint32_t* __restrict__ group_sums,
                                                      uint32_t* __restrict__ out, uint32_t* __restrict__ total) {
-    __shared__ uint32_t s_w[4];
-    __shared__ uint32_t s_base;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t part = 0;
-    for (uint32_t b = tid; b < blockIdx.x; b += 256u) part += group_sums[b];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
-    if (lane == 0) s_w[wave] = part;
-    __syncthreads();
-    if (tid == 0) s_base = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
-    __syncthreads();
-    const uint32_t base = s_base;
-    const uint32_t c = blockIdx.x * 256u + tid;
-    if (c < n) out[c] = base + in[c];
-    if (blockIdx.x == gridDim.x - 1 && tid == 0) *total = base + group_sums[blockIdx.x];
+    role_scan_groups(blockIdx.x, gridDim.x, n, in, group_sums, out, total);
 }
-
-// component ids: rank of the root node in (chunk, region) order; a non-root takes the id of its root, computed from the
-// root's chunk offset and the root's rank among the roots of that chunk
-#ifndef IVX_ASSIGN_MAX_GROUPS
-#define IVX_ASSIGN_MAX_GROUPS 2048
-#endif
-constexpr uint32_t ASSIGN_MAX_GROUPS = IVX_ASSIGN_MAX_GROUPS;  // 524 288 chunks; larger grids take the k_scan_groups path
-// FUSED: the scan over the group totals happens here (every block scans the few totals itself in LDS), root_offsets[c] is the
-// prefix inside c's group; otherwise root_offsets[c] is the full prefix from k_scan_groups.
 template <bool FUSED>
 __global__ __launch_bounds__(256) void k_ccl_assign(GridView g, const uint32_t* __restrict__ rparent, const uint32_t* __restrict__ root_offsets,
                                                     const uint32_t* __restrict__ group_sums, uint32_t n_groups, uint32_t* __restrict__ rcompid,
                                                     uint32_t* __restrict__ total) {
-    __shared__ uint32_t s_gpre[FUSED ? ASSIGN_MAX_GROUPS : 1];
-    __shared__ uint32_t s_carry;
-    if (FUSED) {
-        // exclusive scan of the group totals, 256 at a time
-        if (threadIdx.x == 0) s_carry = 0;
-        __syncthreads();
-        for (uint32_t g0 = 0; g0 < n_groups; g0 += 256u) {
-            const uint32_t gi = g0 + threadIdx.x;
-            const uint32_t v = gi < n_groups ? group_sums[gi] : 0u;
-            uint32_t tot;
-            __shared__ uint32_t s_ws[4];
-            const uint32_t ex = prefix_ordered(v, s_ws, threadIdx.x, tot);
-            if (gi < n_groups) s_gpre[gi] = s_carry + ex;
-            __syncthreads();
-            if (threadIdx.x == 0) s_carry += tot;
-            __syncthreads();
-        }
-        if (blockIdx.x == 0 && threadIdx.x == 0) *total = s_carry;
-    }
-    const uint32_t chunk = blockIdx.x * 256u + threadIdx.x;
-    if (chunk >= g.cx * g.cy * g.cz) return;
-    const uint32_t rc = g.info[chunk].region_count;
-    for (uint32_t r = 0; r < rc; ++r) {
-        const uint32_t node = chunk * 256u + r;
-        const uint32_t root = rparent[node];  // flattened: the root itself
-        const uint32_t rchunk = root >> 8, rr = root & 255u;
-        uint32_t rank = 0;
-        for (uint32_t q = 0; q < rr; ++q) rank += rparent[rchunk * 256u + q] == rchunk * 256u + q;
-        rcompid[node] = root_offsets[rchunk] + rank + (FUSED ? s_gpre[rchunk >> 8] : 0u);
-    }
+    role_ccl_assign<FUSED>(blockIdx.x, gridDim.x, g, rparent, root_offsets, group_sums, n_groups, rcompid, total);
 }
 
 __global__ __launch_bounds__(256) void k_ccl_dense(uint32_t n_chunks, const uint8_t* __restrict__ labels, const uint32_t* __restrict__ rcompid,
@@ -703,9 +331,8 @@ int ivx_launch_ccl_local(ivx_grid* g, int fused) {
     if (!fused)  // else k_derive labelled the chunks in the same sweep
         hipLaunchKernelGGL(k_ccl_local, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->flags, g->llabel, g->info, g->rparent, g->rscalar,
                            multi_list, g->work_counts, g->active_list);
-    const uint32_t exact_blocks = g->n_chunks < 2048u ? g->n_chunks : 2048u;
-    hipLaunchKernelGGL(k_ccl_local_exact, dim3(exact_blocks), dim3(64), 0, g->ctx->stream, v, g->flags, g->llabel, g->info, g->rparent, g->rscalar,
-                       multi_list);
+    const uint32_t exact_blocks = g->n_chunks < 1024u ? g->n_chunks : 1024u;
+    hipLaunchKernelGGL(k_ccl_local_exact, dim3(exact_blocks), dim3(256), 0, g->ctx->stream, g->flags, g->llabel, g->info, g->rparent, g->rscalar, multi_list);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

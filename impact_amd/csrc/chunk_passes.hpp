@@ -32,7 +32,292 @@ struct CclShared {
     uint32_t par[IVX_CHUNK_VOXELS];
     uint32_t mask[256];
     uint32_t cnt;
+    // small words of the exact numbering (ccl_exact_chunk)
+    uint32_t bm[44];  // bitmap over the 1352 positions of the boundary walk
+    uint32_t w[8];
+    uint32_t misc[4];
 };
+
+// ---- exact chunk-local numbering for chunks with several regions -------------------------------------------------------------------
+// The reference numbers the regions of a chunk in an order that depends on which voxel its SEQUENTIAL union-find leaves as the root
+// of each set (split_detection.rs:700-831): voxels in (i,j,k) order, and for every voxel v the roots of its +x, +y, +z neighbours are
+// attached under the root of v's set (assign_parent, 1776-1782) — "the set of the voxel being processed wins". A set that touches
+// the chunk boundary is numbered when the six face loops (Loop3::over_full_boundary, utils.rs:247-322) reach its ROOT voxel if the
+// root lies on the boundary, else at the first face voxel of the set they visit (761-801); sets that do not touch the boundary follow
+// in (i,j,k) order of their roots (815-831). Raw label values are compared bit for bit with the reference's, so the roots must be the
+// sequential ones. They are, without replaying the sequence voxel by voxel:
+//   * a voxel with a non-empty lower neighbour (-x, -y or -z) belongs, when its turn comes, to the set its FIRST-processed lower
+//     neighbour put it in (fp(v) = v-256, else v-16, else v-1); a voxel with none is a singleton then: a SOURCE. Every root is a source.
+//     src0(v) = the source reached along fp: pointer jumping, all voxels at once;
+//   * sets merge only when a voxel a meets an upper neighbour b that an earlier lower neighbour already put elsewhere
+//     (fp(b) != a): then a's set wins. These EVENTS, in the order of a, are a sequential union-find over the few sources; they are
+//     listed by ordered compaction (cross-basin ones only) and applied by one wave, 64 at a time: every lane looks up its two sets,
+//     the earliest event between different sets is applied, the rest look again (one round per effective merge);
+//   * numbering: a key per set (walk position of the boundary root, else the smallest walk position of its boundary voxels), ranks
+//     from a bitmap over the 1352 walk positions; interior-only sets by rank of their root voxel.
+// All of it reuses the 16 KB of `sh.par`: ptr u16[4096] | spar u16[2048] (sources are never adjacent along k: one slot per voxel
+// pair) | events 2 x u16[768] | key u32[256].
+__device__ __forceinline__ uint32_t ivx_walk_pos(uint32_t idx) {  // position of a boundary voxel in Loop3::over_full_boundary; 0xFFFF inside
+    const uint32_t i = idx >> 8, j = (idx >> 4) & 15u, k = idx & 15u;
+    if (i == 0u) return idx & 255u;
+    if (i == 15u) return 256u + (idx & 255u);
+    if (j == 0u) return 512u + (i - 1u) * 16u + k;
+    if (j == 15u) return 736u + (i - 1u) * 16u + k;
+    if (k == 0u) return 960u + (i - 1u) * 14u + (j - 1u);
+    if (k == 15u) return 1156u + (i - 1u) * 14u + (j - 1u);
+    return 0xFFFFu;
+}
+
+// All 256 threads; sh.mask[] holds the non-empty masks of the 256 rows (thread = row (i,j), bit = k). Writes the label plane, the
+// chunk's region table and returns (region_count, boundary_region_count), both saturated at 254 with error bit 1 set beyond.
+__device__ __forceinline__ void ccl_exact_chunk(CclShared& sh, uint32_t tid, uint32_t chunk, uint8_t* __restrict__ labels, uint32_t* __restrict__ rparent,
+                                                uint32_t* __restrict__ rscalar, uint32_t& rc_out, uint32_t& brc_out) {
+    constexpr uint32_t EV_CAP = 768u;
+    uint16_t* ptr = reinterpret_cast<uint16_t*>(sh.par);          // [4096]
+    uint16_t* spar = ptr + IVX_CHUNK_VOXELS;                      // [2048], slot v >> 1
+    uint16_t* ev_a = spar + 2048;                                 // [768]
+    uint16_t* ev_b = ev_a + EV_CAP;                               // [768]
+    uint32_t* key = reinterpret_cast<uint32_t*>(ev_b + EV_CAP);   // [256]
+    const uint32_t ti = tid >> 4, tj = tid & 15u, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t m = sh.mask[tid];
+    const uint32_t mx = ti > 0u ? sh.mask[tid - 16u] : 0u;  // row below in x, in y
+    const uint32_t my = tj > 0u ? sh.mask[tid - 1u] : 0u;
+    const uint32_t base_v = tid * 16u;
+    __syncthreads();  // everybody has read what it needs from the union-find of ccl_local_chunk: sh.par is free
+    // fp pointers; sources point to themselves (empty voxels too: never followed)
+    const uint32_t has_xd = m & mx, has_yd = m & my & ~mx, has_zd = m & (m << 1) & ~mx & ~my;
+    const uint32_t sources = m & ~mx & ~my & ~(m << 1);
+#pragma unroll
+    for (uint32_t k = 0; k < 16u; ++k) {
+        const uint32_t v = base_v + k;
+        uint32_t p = v;
+        if ((has_xd >> k) & 1u) p = v - 256u;
+        else if ((has_yd >> k) & 1u) p = v - 16u;
+        else if ((has_zd >> k) & 1u) p = v - 1u;
+        ptr[v] = (uint16_t)p;
+    }
+    {
+        uint32_t s = sources;
+        while (s) {
+            const uint32_t k = (uint32_t)__ffs(s) - 1u;
+            s &= s - 1u;
+            spar[(base_v + k) >> 1] = (uint16_t)(base_v + k);
+        }
+    }
+    if (tid < 44u) sh.bm[tid] = 0u;
+    key[tid] = 0xFFFFFFFFu;
+    __syncthreads();
+    // pointer jumping (in place: a pointer only ever moves to an ancestor): chains are at most 45 long
+    for (int round = 0; round < 6; ++round) {
+        uint32_t mm = m & ~sources;
+        while (mm) {
+            const uint32_t k = (uint32_t)__ffs(mm) - 1u;
+            mm &= mm - 1u;
+            const uint32_t v = base_v + k;
+            ptr[v] = ptr[ptr[v]];
+        }
+        __syncthreads();
+    }
+    // events of this row, in order: (a, b = a + 16) when b also has a -x neighbour; (a, b = a + 1) when b has a -x or -y neighbour
+    const uint32_t m_yu = tj < 15u ? sh.mask[tid + 1u] : 0u;                 // row above in y
+    const uint32_t ev_y_geom = m & m_yu & (ti > 0u ? sh.mask[tid - 16u + 1u] : 0u) & (tj < 15u ? 0xFFFFu : 0u);  // b = a + 16 has b - 256
+    const uint32_t ev_z_geom = m & (m >> 1) & ((mx | my) >> 1);              // b = a + 1 has b - 256 or b - 16
+    uint32_t evy = 0, evz = 0;
+    {
+        uint32_t c = ev_y_geom;
+        while (c) {
+            const uint32_t k = (uint32_t)__ffs(c) - 1u;
+            c &= c - 1u;
+            if (ptr[base_v + k] != ptr[base_v + k + 16u]) evy |= 1u << k;
+        }
+        c = ev_z_geom;
+        while (c) {
+            const uint32_t k = (uint32_t)__ffs(c) - 1u;
+            c &= c - 1u;
+            if (ptr[base_v + k] != ptr[base_v + k + 1u]) evz |= 1u << k;
+        }
+    }
+    uint32_t n_mine = __popc(evy) + __popc(evz), first, total;
+    {   // ordered block prefix (thread order = voxel order)
+        uint32_t incl = n_mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o, 64);
+            if (lane >= (uint32_t)o) incl += t;
+        }
+        if (lane == 63u) sh.w[wave] = incl;
+        __syncthreads();
+        const uint32_t w0 = sh.w[0], w1 = sh.w[1], w2 = sh.w[2], w3 = sh.w[3];
+        first = (wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2))) + incl - n_mine;
+        total = (w0 + w1) + (w2 + w3);
+    }
+    for (uint32_t win = 0; win < total; win += EV_CAP) {
+        __syncthreads();  // the previous window is consumed
+        {
+            uint32_t slot = first;  // global index of this thread's next event
+#pragma unroll 1
+            for (uint32_t k = 0; k < 16u; ++k) {  // per voxel: y before z (the reference's order inside a voxel; either way the same winner)
+                if ((evy >> k) & 1u) {
+                    if (slot >= win && slot < win + EV_CAP) {
+                        ev_a[slot - win] = ptr[base_v + k];
+                        ev_b[slot - win] = ptr[base_v + k + 16u];
+                    }
+                    slot += 1u;
+                }
+                if ((evz >> k) & 1u) {
+                    if (slot >= win && slot < win + EV_CAP) {
+                        ev_a[slot - win] = ptr[base_v + k];
+                        ev_b[slot - win] = ptr[base_v + k + 1u];
+                    }
+                    slot += 1u;
+                }
+            }
+        }
+        __syncthreads();
+        if (wave == 0u) {
+            const uint32_t n_win = min(EV_CAP, total - win);
+            for (uint32_t e0 = 0; e0 < n_win; e0 += 64u) {
+                const bool valid = e0 + lane < n_win;
+                const uint32_t pa = valid ? ev_a[e0 + lane] : 0u, pb = valid ? ev_b[e0 + lane] : 0u;
+                for (int guard = 0; guard < 4096; ++guard) {
+                    uint32_t ra = pa, rb = pb;
+                    if (valid) {
+                        for (uint32_t p; (p = spar[ra >> 1]) != ra;) ra = p;
+                        for (uint32_t p; (p = spar[rb >> 1]) != rb;) rb = p;
+                    }
+                    const unsigned long long pending = __ballot(valid && ra != rb);
+                    if (!pending) break;
+                    if (lane == (uint32_t)__ffsll((long long)pending) - 1u) spar[rb >> 1] = (uint16_t)ra;  // a's set wins
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // flatten: ptr[source] = root source, so that root(v) = ptr[ptr[v]] for every non-empty voxel
+    {
+        uint32_t s = sources;
+        while (s) {
+            const uint32_t k = (uint32_t)__ffs(s) - 1u;
+            s &= s - 1u;
+            uint32_t r = base_v + k;
+            for (uint32_t p; (p = spar[r >> 1]) != r;) r = p;
+            ptr[base_v + k] = (uint16_t)r;
+        }
+    }
+    __syncthreads();
+    // dense ids of the roots in voxel order (spar is free now: id of root r at spar[r >> 1])
+    uint32_t roots = 0;
+    {
+        uint32_t s = sources;
+        while (s) {
+            const uint32_t k = (uint32_t)__ffs(s) - 1u;
+            s &= s - 1u;
+            if (ptr[base_v + k] == base_v + k) roots |= 1u << k;
+        }
+    }
+    uint32_t id0, n_sets;
+    {
+        const uint32_t n_r = __popc(roots);
+        uint32_t incl = n_r;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o, 64);
+            if (lane >= (uint32_t)o) incl += t;
+        }
+        __syncthreads();
+        if (lane == 63u) sh.w[wave] = incl;
+        __syncthreads();
+        const uint32_t w0 = sh.w[0], w1 = sh.w[1], w2 = sh.w[2], w3 = sh.w[3];
+        id0 = (wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2))) + incl - n_r;
+        n_sets = (w0 + w1) + (w2 + w3);
+        uint32_t r = roots, id = id0;
+        while (r) {
+            const uint32_t k = (uint32_t)__ffs(r) - 1u;
+            r &= r - 1u;
+            spar[(base_v + k) >> 1] = (uint16_t)min(id, 255u);  // (more than 254 sets is an error; ids stay inside the tables)
+            id += 1u;
+        }
+    }
+    __syncthreads();
+    // keys: the boundary voxels of this row
+    {
+        const bool edge_row = ti == 0u || ti == 15u || tj == 0u || tj == 15u;
+        uint32_t bnd = m & (edge_row ? 0xFFFFu : 0x8001u);
+        uint32_t prev_id = 0xFFFFFFFFu;
+        while (bnd) {
+            const uint32_t k = (uint32_t)__ffs(bnd) - 1u;
+            bnd &= bnd - 1u;
+            const uint32_t v = base_v + k;
+            const uint32_t r = ptr[ptr[v]];
+            const uint32_t id = spar[r >> 1];
+            const bool root_on_boundary = ivx_walk_pos(r) != 0xFFFFu;
+            if (root_on_boundary) {
+                if (r == v) key[id] = ivx_walk_pos(v);  // numbered when the walk reaches the root itself
+            } else if (id != prev_id) {  // (walk positions grow with k inside a row: the first voxel of a stretch of one set has the smallest)
+                atomicMin(&key[id], ivx_walk_pos(v));
+            }
+            prev_id = id;
+        }
+    }
+    __syncthreads();
+    // numbers: thread = set id
+    const uint32_t my_key = tid < n_sets ? key[tid] : 0xFFFFFFFFu;
+    const bool touches = my_key != 0xFFFFFFFFu;
+    if (touches) atomicOr(&sh.bm[my_key >> 5], 1u << (my_key & 31u));
+    uint32_t inner_rank, n_inner;
+    {   // rank of the interior-only sets among themselves (ids are in root order)
+        const uint32_t is_inner = (tid < n_sets && !touches) ? 1u : 0u;
+        uint32_t incl = is_inner;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o, 64);
+            if (lane >= (uint32_t)o) incl += t;
+        }
+        __syncthreads();
+        if (lane == 63u) sh.w[wave] = incl;
+        __syncthreads();
+        const uint32_t w0 = sh.w[0], w1 = sh.w[1], w2 = sh.w[2], w3 = sh.w[3];
+        inner_rank = (wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2))) + incl - is_inner;
+        n_inner = (w0 + w1) + (w2 + w3);
+    }
+    uint32_t n_boundary = 0;
+    {
+        uint32_t below = 0;
+        for (uint32_t wd = 0; wd < 43u; ++wd) {
+            const uint32_t bits = sh.bm[wd];
+            n_boundary += __popc(bits);
+            if (touches && wd < (my_key >> 5)) below += __popc(bits);
+            else if (touches && wd == (my_key >> 5)) below += __popc(bits & ((1u << (my_key & 31u)) - 1u));
+        }
+        // label of the set: saturating like the reference's counter (min(current + 1, 255))
+        const uint32_t number = touches ? below : n_boundary + inner_rank;
+        __syncthreads();  // every thread has read its key: the table now holds the numbers
+        if (tid < n_sets) key[tid] = min(number, 255u);
+    }
+    (void)n_inner;
+    __syncthreads();
+    {
+        uint32_t w4[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        uint32_t mm = m;
+        while (mm) {
+            const uint32_t k = (uint32_t)__ffs(mm) - 1u;
+            mm &= mm - 1u;
+            const uint32_t lab = key[spar[ptr[ptr[base_v + k]] >> 1]];
+            w4[k >> 2] = (w4[k >> 2] & ~(0xFFu << (8u * (k & 3u)))) | (lab << (8u * (k & 3u)));
+        }
+        *reinterpret_cast<uint4*>(labels + (size_t)chunk * IVX_CHUNK_VOXELS + (size_t)tid * 16) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+    }
+    uint32_t total_sets = n_sets;
+    if (total_sets > 254u) {
+        if (tid == 0) atomicOr(&rscalar[1], 1u);
+        total_sets = 254u;
+    }
+    rparent[(size_t)chunk * 256 + tid] = tid < total_sets ? chunk * 256u + tid : NODE_NONE;
+    rc_out = total_sets;
+    brc_out = n_boundary < 254u ? n_boundary : 254u;
+    __syncthreads();  // sh is reused by the caller's next chunk
+}
 
 // Level 1 of the region labelling for one chunk (split_detection.rs:662-891), all 256 threads of the workgroup: decides
 // whether the chunk holds 0, 1 or several regions. One region (the overwhelmingly common case) needs no numbering: label 0
@@ -128,7 +413,8 @@ __device__ __forceinline__ void ccl_local_chunk(CclShared& sh, uint32_t tid, uin
         rc_out = 1u;
         brc_out = touches ? 1u : 0u;
     } else {
-        // several regions: the reference's numbering is reproduced by k_ccl_local_exact (which also sets the boundary count)
+        // several regions: the reference's numbering is reproduced by role_ccl_local_exact right after this sweep (it also sets the
+        // boundary count); the list also names the chunks whose regions k_ccl_merge_multi joins with all six neighbours
         if (tid == 0) multi_list[atomicAdd(&rscalar[2], 1u)] = chunk;
         rc_out = rc < 254u ? rc : 254u;
         brc_out = 0u;
