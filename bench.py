@@ -44,38 +44,36 @@ HBM_COPY_GBS = 6290.0    # the guide's measured float4 copy: the practical ceili
 VALU_PEAK_GWI = 256 * 4 * 2.4 / 2.0  # G wave-instructions/s: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz
 PROFILE_DIR = os.path.join(ROOT, "profiles", "round2")
 
-STAGE_KERNELS = {  # which kernels make up a timed stage (names as rocprofv3 reports them)
+STAGE_KERNELS = {  # which kernels make up a timed slot (names as rocprofv3 reports them); include/impact_voxel_hip.h, IVX_N_TIMED_STAGES
     "sdf_sample": ["k_sdf_super", "k_sdf_prepass", "k_sdf_eval"],
     "derive": ["k_chunk_pre", "k_derive"],  # k_derive also labels the chunk-local regions and leaves the chunk moments (fused sweep)
-    "occupied": ["k_occupied_reduce"],
-    "ccl_local": ["k_ccl_local_exact"],
-    "ccl_merge": ["k_ccl_merge_columns", "k_ccl_merge_multi"],
-    "ccl_resolve": ["k_ccl_flatten", "k_scan_groups", "k_ccl_assign", "k_tables"],
-    "sn_count": ["k_sn_count"],
-    "sn_scan": ["k_sn_scan"],
-    "sn_emit": ["k_sn_emit"],
-    "inertia": ["k_inertia_sum", "k_inertia_final"],
+    "post1": ["k_step_post1"],    # roles: mesher count | region merge by chunk columns | exact local numbering | occupied slots | moment partials
+    "post2": ["k_step_post2"],    # roles: multi-region merge | mesher scan | moments and occupied ranges final
+    "emit": ["k_step_emit"],      # roles: region forest flatten | mesher emit
+    "assign": ["k_step_assign"],  # component ids
 }
 
 
 def stage_bytes(n_voxels, n_chunks, exposed_chunks, n_vertices, n_indices):
-    """Algorithmic HBM bytes per step of each timed stage: SURVEY.md §8(d)'s per-voxel figures x the voxels the stage is
+    """Algorithmic HBM bytes per step of each timed slot: SURVEY.md §8(d)'s per-voxel figures x the voxels the slot is
     charged for, the mesher for the padded tiles of the chunks it meshes plus its output. `n_voxels` is what the caller
     decides to charge: the STORED grid for the `effective` figures (compact planes: most of a solid body's chunks are 8-byte
     records that never touch the planes, so an effective rate can exceed what the HBM moves), or the ACTIVE voxels
     (chunks with planes) for a figure that can be compared with the HBM peak."""
-    return {
+    out = {
         "sdf_sample": 2.0 * n_voxels,                        # W sdf + type
         "derive": 4.0 * n_voxels,                            # R sdf + type, W flags + label (fused sweep)
-        "occupied": 4.0 * n_chunks,                          # R one packed box per chunk
-        "ccl_local": 0.0,                                    # fused into derive; k_ccl_local_exact walks a (usually empty) list
-        "ccl_merge": 9.0 * 3 * n_chunks,                     # chunk records + touch bytes of a chunk column and its two neighbours
-        "ccl_resolve": 16.0 * n_chunks,                      # (chunk, region) table entries in use, a few per chunk
-        "sn_count": 1.0 * 5832 / 8 * exposed_chunks,         # 18^3 sign bits per exposed chunk
-        "sn_scan": 36.0 * n_chunks,                          # counts in, offsets/ranks/records out
-        "sn_emit": 2.0 * 5832 * exposed_chunks + 40.0 * n_vertices + 12.0 * n_indices,  # tile + (pos,nrm,vmat) + (idx u32, imat 8B)
-        "inertia": 88.0 * n_chunks,                          # chunk records + per-chunk moment slots
+        # 18^3 sign bits per exposed chunk (mesher count) + chunk records and touch bytes of a chunk column and its two neighbours
+        # (region merge) + one packed box per chunk (occupied) + chunk records and per-chunk moment slots (moment sums)
+        "post1": 5832.0 / 8 * exposed_chunks + (27.0 + 4.0 + 88.0) * n_chunks,
+        "post2": 36.0 * n_chunks,                            # mesher scan: counts in, offsets / ranks / emit records out
+        # mesher emit: tile + (pos, nrm, vmat) + (idx u32, imat 8 B); flatten: (chunk, region) table entries in use
+        "emit": 2.0 * 5832 * exposed_chunks + 40.0 * n_vertices + 12.0 * n_indices + 8.0 * n_chunks,
+        "assign": 8.0 * n_chunks,
     }
+    for k in ("unused6", "unused7", "unused8", "unused9"):
+        out[k] = 0.0
+    return out
 
 
 def load_profile(name):
@@ -129,7 +127,7 @@ def roofline_block(stage_ms, sb_effective, sb_active, workload_key):
            "frac": float(sum(sb_active.values())) / tt / 1e9 / HBM_PEAK_GBS,
            "effective_algorithmic_bytes": float(sum(sb_effective.values())),
            "effective_frac": float(sum(sb_effective.values())) / tt / 1e9 / HBM_PEAK_GBS, "counter_bytes": None, "counter_frac": None}
-    if traffic and all(v is not None for k, v in traffic.items() if sb_effective.get(k, 0) > 0 or k == "ccl_local"):
+    if traffic and all(v is not None for k, v in traffic.items() if sb_effective.get(k, 0) > 0):
         cb = float(sum(v for v in traffic.values() if v is not None))
         srl["counter_bytes"] = cb
         srl["counter_frac"] = cb / tt / 1e9 / HBM_PEAK_GBS
@@ -224,6 +222,14 @@ def time_steps(ctx, obj, stages, steps, warmup):
     return res, 1e3 * (time.perf_counter() - t0) / steps, acc / steps
 
 
+def remesh_only_ms(ctx, obj, steps=10):
+    """Surface Nets alone (count + scan + emit) over the resident, derived object: the sum of the three launches' HIP-event times"""
+    from impact_amd import capi
+
+    _, _, sm = time_steps(ctx, obj, capi.STAGE_REMESH, steps, 2)
+    return float(sm[2] + sm[3] + sm[4])
+
+
 def chunk_census(obj):
     info = obj.download(sdf=False, types=False, flags=False, labels=False)[4]
     exposed = int(np.count_nonzero((info["kind"] == 2) & ((info["flags"] & 0x3F) != 0x3F)))
@@ -245,7 +251,7 @@ def dense_benchmark(ctx, args, with_cpu):
     sb_eff = stage_bytes(obj.n_voxels, obj.n_chunks, exposed, int(res["mesh"]["n_vertices"]), int(res["mesh"]["n_indices"]))
     sb_act = stage_bytes(active, obj.n_chunks, exposed, int(res["mesh"]["n_vertices"]), int(res["mesh"]["n_indices"]))
     rl, srl, _ = roofline_block(stage_ms, sb_eff, sb_act, "dense")
-    remesh_ms = float(stage_ms[6] + stage_ms[7] + stage_ms[8])
+    remesh_ms = remesh_only_ms(ctx, obj, max(3, args.steps // 4))
     out = {"workload": f"{n} perforated plates, one per chunk layer: {gen.grid_shape()} grid = {(n * 16)}^3 stored voxels, {non_uniform} of {obj.n_chunks} chunks "
                        f"NonUniform, {exposed} meshed",
            "ms_per_step": ms, "voxels_per_s": obj.n_voxels / (ms * 1e-3), "active_voxels": active, "triangles": int(res["mesh"]["n_indices"]) // 3,
@@ -278,7 +284,7 @@ def config2_benchmark(ctx, args, with_cpu):
     full, ms_full, _ = time_steps(ctx, obj, capi.STAGE_ALL, args.steps, 1)
     tris = int(res["mesh"]["n_indices"]) // 3
     out = {"workload": f"config-2 asteroid: {gen.grid_shape()[0]}^3 grid = {obj.chunk_counts[0] * 16}^3 stored voxels; remesh + inertia of the resident object",
-           "remesh_inertia_ms": ms, "remesh_tris_per_s": tris / (float(stage_ms[6] + stage_ms[7] + stage_ms[8]) * 1e-3), "triangles": tris,
+           "remesh_inertia_ms": ms, "remesh_tris_per_s": tris / (remesh_only_ms(ctx, obj) * 1e-3), "triangles": tris,
            "full_step_ms": ms_full, "voxels_per_s_full_step": obj.n_voxels / (ms_full * 1e-3)}
     if with_cpu:
         base, allc, parity, _, _ = cpu_baseline(graph, obj, full, "config 2")
@@ -690,6 +696,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the same steps without the per-slot event records (two records per timed slot on the stream): what the step costs a caller
+    # that does not ask for stage timings
+    ms_untimed = None
+    if not slabs:
+        obj.set_stage_timing(False)
+        for _ in range(2):
+            step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        ms_untimed = 1e3 * (time.perf_counter() - t1) / args.steps
+        obj.set_stage_timing(True)
+        res = step()
     n_vox_rank = obj.n_voxels
     tris_rank = int(res["mesh"]["n_indices"]) // 3
     if dist is not None:
@@ -711,7 +732,9 @@ def main():
         sb_act = stage_bytes(active, obj.n_chunks, exposed, nv, ni)
         key = ("headline" if abs(args.scale - 2.05) < 1e-9 else None) if args.workload == "asteroid" else ("dense" if args.dense_chunks == 32 else None)
         rl, srl, vrl = roofline_block(stage_ms, sb_eff, sb_act, key if world == 1 else None)
-        remesh_ms = float(stage_ms[6] + stage_ms[7] + stage_ms[8])
+        # N = 1: Surface Nets timed alone over the resident object; N > 1: the three launches that host it inside the step (they
+        # also carry the region / moment table roles)
+        remesh_ms = remesh_only_ms(ctx, obj) if not slabs else float(stage_ms[2] + stage_ms[3] + stage_ms[4])
         out = {
             "metric": "voxels stepped/sec + remesh tris/sec, 512^3 grid, 1/2/4/8 MI355X",
             "value": n_vox_total / (elapsed / args.steps),
@@ -720,6 +743,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "ms_per_step_without_stage_events": ms_untimed,
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,

@@ -53,7 +53,9 @@ REGION_DESC_DTYPE = np.dtype(
 )
 MESH_COUNTS_DTYPE = np.dtype([("n_vertices", "<u4"), ("n_indices", "<u4"), ("n_submeshes", "<u4"), ("reserved", "<u4")])
 N_TIMED_STAGES = 10
-STAGE_NAMES = ["sdf_sample", "derive", "occupied", "ccl_local", "ccl_merge", "ccl_resolve", "sn_count", "sn_scan", "sn_emit", "inertia"]
+# timed slots of a step (include/impact_voxel_hip.h, IVX_N_TIMED_STAGES): the table-sized passes after the derive sweep run as roles of
+# four fused launches; 6..9 are unused
+STAGE_NAMES = ["sdf_sample", "derive", "post1", "post2", "emit", "assign", "unused6", "unused7", "unused8", "unused9"]
 STAGE_SAMPLE, STAGE_DERIVE, STAGE_OCCUPIED, STAGE_REGIONS, STAGE_REMESH, STAGE_INERTIA, STAGE_ALL = 1, 2, 4, 8, 16, 32, 63
 STEP_RESULT_DTYPE = np.dtype(
     [
@@ -123,7 +125,7 @@ EXPORTED_SYMBOLS = [
     "ivx_remesh", "ivx_mesh_download", "ivx_mesh_device_ptr",
     "ivx_inertia",
     "ivx_label_regions", "ivx_region_labels_download", "ivx_regions_describe", "ivx_split_off_smallest_region", "ivx_clip_polyhedron", "ivx_mesh_sync", "ivx_mesh_modifications", "ivx_mesh_report_synchronized", "ivx_absorb_sphere", "ivx_absorb_capsule", "ivx_absorb_mutual", "ivx_offset_reference_point", "ivx_apply_updated_inertial_properties", "ivx_extracted_object_dynamics", "ivx_handle_voxel_object_after_removing_voxels", "ivx_sphere_voxel_object_contacts", "ivx_plane_voxel_object_contacts", "ivx_capsule_voxel_object_contacts", "ivx_collision_probes_recompute", "ivx_collision_probes_sync", "ivx_collision_probes_download", "ivx_mutual_voxel_object_contacts",
-    "ivx_grid_set_sdf_program", "ivx_grid_set_densities", "ivx_voxel_step", "ivx_voxel_step_enqueue", "ivx_voxel_step_collect",
+    "ivx_grid_set_sdf_program", "ivx_grid_set_densities", "ivx_voxel_step", "ivx_voxel_step_enqueue", "ivx_voxel_step_collect", "ivx_grid_set_stage_timing",
     "ivx_halo_pack_enqueue", "ivx_halo_unpack_enqueue", "ivx_halo_pack_both_enqueue", "ivx_region_face_labels_enqueue", "ivx_region_face_pairs_enqueue",
     "ivx_step_record_words", "ivx_step_record_enqueue",
     "ivx_halo_bytes", "ivx_halo_pack", "ivx_halo_unpack", "ivx_halo_clear",
@@ -214,6 +216,7 @@ def lib():
         "ivx_voxel_step": (i32, [vp, u32, vp]),
         "ivx_voxel_step_enqueue": (i32, [vp, u32]),
         "ivx_voxel_step_collect": (i32, [vp, vp]),
+        "ivx_grid_set_stage_timing": (i32, [vp, i32]),
         "ivx_halo_pack_enqueue": (i32, [vp, i32, vp]),
         "ivx_halo_unpack_enqueue": (i32, [vp, i32, vp]),
         "ivx_halo_pack_both_enqueue": (i32, [vp, vp, vp, i32]),

@@ -325,14 +325,25 @@ __global__ __launch_bounds__(256) void k_region_stats(GridView g, uint32_t x_off
 
 int ivx_launch_ccl_local(ivx_grid* g, int fused) {
     GridView v = ivx_view(g);
-    if (!g->scratch_preset && !fused) IVX_HIP_CHECK(hipMemsetAsync(g->rscalar, 0, 16 * sizeof(uint32_t), g->ctx->stream));
+    if (!fused) IVX_HIP_CHECK(hipMemsetAsync(g->rscalar, 0, 16 * sizeof(uint32_t), g->ctx->stream));
+    g->scratch_dirty |= IVX_SCRATCH_REGIONS;
     uint32_t* multi_list = g->ccl_scratch;  // reused by the resolve pass afterwards
     g->planes_compact = 1;
     if (!fused)  // else k_derive labelled the chunks in the same sweep
         hipLaunchKernelGGL(k_ccl_local, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->flags, g->llabel, g->info, g->rparent, g->rscalar,
-                           multi_list, g->work_counts, g->active_list);
+                           multi_list, ivx_wc(g), g->active_list);
     const uint32_t exact_blocks = g->n_chunks < 1024u ? g->n_chunks : 1024u;
     hipLaunchKernelGGL(k_ccl_local_exact, dim3(exact_blocks), dim3(256), 0, g->ctx->stream, g->flags, g->llabel, g->info, g->rparent, g->rscalar, multi_list);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+int ivx_launch_ccl_local_only(ivx_grid* g) {
+    GridView v = ivx_view(g);
+    g->planes_compact = 1;
+    g->scratch_dirty |= IVX_SCRATCH_REGIONS;
+    hipLaunchKernelGGL(k_ccl_local, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->flags, g->llabel, g->info, g->rparent, g->rscalar, g->ccl_scratch,
+                       ivx_wc(g), g->active_list);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

@@ -19,6 +19,7 @@
 // Traffic: reads 1 B/voxel (sdf sign) + six neighbour faces, writes 1 B/voxel (flags). Emptiness of the
 // 16 voxels of a row is a 16-bit mask; the 18x18 halo of masks sits in LDS.
 #include "chunk_passes.hpp"
+#include "table_roles.hpp"
 
 namespace {
 
@@ -54,10 +55,15 @@ __device__ __forceinline__ uint32_t nbr_row_mask(const GridView& g, const ivx_ch
 // their per-step state is the record, the occupied sub-box, one region and empty mesh counts.
 __global__ __launch_bounds__(256) void k_chunk_pre(GridView g, ivx_chunk_info* __restrict__ info, uint32_t* __restrict__ bbox,
                                                    uint32_t* __restrict__ mesh_counts, uint8_t* __restrict__ chunk_class, uint8_t* __restrict__ touch,
-                                                   uint32_t* __restrict__ rparent, uint32_t* __restrict__ work_counts, uint32_t* __restrict__ active_list) {
+                                                   uint32_t* __restrict__ rparent, uint32_t* __restrict__ work_counts, uint32_t* __restrict__ next_work_count,
+                                                   uint32_t* __restrict__ active_list, ivx_roles::PresetArgs preset) {
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_base;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // this launch is the first of the derive stages: it also presets the scratch words the later stages of the call start from,
+    // and zeroes the counter the NEXT sweep will append under (the two counters alternate)
+    ivx_roles::role_preset(preset, blockIdx.x * 256u + tid);
+    if (blockIdx.x == 0 && tid == 0) next_work_count[0] = 0u;
     const uint32_t n_chunks = g.cx * g.cy * g.cz;
     const uint32_t chunk = blockIdx.x * 256u + tid;
     const bool live = chunk < n_chunks;
@@ -418,29 +424,9 @@ __global__ __launch_bounds__(256) void k_occupied_reduce(uint32_t cx, uint32_t c
     }
 }
 
-// One launch that presets every small scratch word the stages of a whole step start from (instead of five memsets):
-// region scalars, occupied-range minima/maxima, Surface-Nets group totals + list counter, the sampler's list counter.
-__global__ __launch_bounds__(256) void k_step_preset(uint32_t stages, uint32_t* __restrict__ rscalar, uint32_t* __restrict__ sn_sums, uint32_t n_sn,
-                                                     uint32_t* __restrict__ eval_count, uint32_t* __restrict__ work_counts) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if ((stages & IVX_STAGE_REGIONS) && i < 16u) rscalar[i] = 0u;
-    if ((stages & IVX_STAGE_OCCUPIED) && i < 12u) rscalar[16 + i] = i < 6u ? 0xFFFFFFFFu : 0u;
-    if ((stages & IVX_STAGE_REMESH) && i < n_sn) sn_sums[i] = 0u;
-    if ((stages & IVX_STAGE_SAMPLE) && i < 3u && eval_count) eval_count[i] = 0u;  // the three evaluation lists
-    if ((stages & IVX_STAGE_DERIVE) && i == 0) work_counts[0] = 0u;
-}
-
-// gathers the small results of a step into one host-mapped block: [0..28) region scalars + occupied minima/maxima,
-// [28..31) mesh totals, [31] active chunks, [32..52) the 10 moments (f64 as two words each)
-__global__ __launch_bounds__(64) void k_result_gather(const uint32_t* __restrict__ rscalar, const uint32_t* __restrict__ mesh_totals,
-                                                      const double* __restrict__ moments, const uint32_t* __restrict__ work_counts,
-                                                      uint32_t* __restrict__ host_block) {
-    const uint32_t t = threadIdx.x;
-    if (t == 31u) host_block[31] = work_counts[0];  // length of the active list (sizes the next step's list-driven grids)
-    if (t < 28u) host_block[t] = rscalar[t];
-    if (t < 3u) host_block[28 + t] = mesh_totals[t];
-    if (t < 20u) host_block[32 + t] = reinterpret_cast<const uint32_t*>(moments)[t];
-}
+// The preset of the scratch word groups as a launch of its own: only for a step call that starts with neither the sampler nor the
+// derive sweep (their first kernels host this role otherwise).
+__global__ __launch_bounds__(256) void k_step_preset(ivx_roles::PresetArgs preset) { ivx_roles::role_preset(preset, blockIdx.x * 256u + threadIdx.x); }
 
 // writes out the planes of the chunks that are only a record (Void / Uniform), for callers that want whole planes
 __global__ __launch_bounds__(256) void k_materialize(uint32_t n_chunks, const ivx_chunk_info* __restrict__ info, int8_t* __restrict__ sdf,
@@ -467,23 +453,29 @@ int ivx_ensure_dense(ivx_grid* g) {
     return IVX_OK;
 }
 
-int ivx_launch_result_gather(ivx_grid* g, uint32_t* host_block_dev) {
-    hipLaunchKernelGGL(k_result_gather, dim3(1), dim3(64), 0, g->ctx->stream, g->rscalar, g->chunk_offsets + 2 * (size_t)g->n_chunks,
-                       g->partials + g->partial_blocks * 10, g->work_counts, host_block_dev);
+ivx_roles::PresetArgs ivx_preset_args(ivx_grid* g, uint32_t groups) {
+    const uint32_t n_groups = (g->n_chunks + 255u) / 256u;
+    ivx_roles::PresetArgs a;
+    a.groups = groups;
+    a.rscalar = g->rscalar;
+    a.sn_sums = g->group_sums + n_groups;
+    a.n_sn = 3 * n_groups + 1;
+    a.eval_count = g->samp_len ? g->samp_len + g->n_chunks : nullptr;
+    return a;
+}
+
+int ivx_launch_step_preset(ivx_grid* g, uint32_t groups) {
+    if (!groups) return IVX_OK;
+    const ivx_roles::PresetArgs a = ivx_preset_args(g, groups);
+    hipLaunchKernelGGL(k_step_preset, dim3((a.n_sn + 255u) / 256u), dim3(256), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
+    g->scratch_dirty &= ~groups;
     return IVX_OK;
 }
 
-int ivx_launch_step_preset(ivx_grid* g, uint32_t stages) {
-    const uint32_t groups = (g->n_chunks + 255u) / 256u;
-    const uint32_t n_sn = 3 * groups + 1;
-    hipLaunchKernelGGL(k_step_preset, dim3((n_sn + 255u) / 256u), dim3(256), 0, g->ctx->stream, stages, g->rscalar, g->group_sums + groups, n_sn,
-                       g->samp_len ? g->samp_len + g->n_chunks : nullptr, g->work_counts);
-    IVX_HIP_CHECK(hipGetLastError());
-    return IVX_OK;
-}
-
-int ivx_launch_derive(ivx_grid* g, uint32_t parts) {
+// `preset_groups`: scratch word groups k_chunk_pre presets on the way (the fused step path; 0 elsewhere: stand-alone callers
+// memset what they need themselves)
+int ivx_launch_derive(ivx_grid* g, uint32_t parts, uint32_t preset_groups) {
     GridView v = ivx_view(g);
     DeriveFused fz;
     fz.parts = parts;
@@ -494,23 +486,24 @@ int ivx_launch_derive(ivx_grid* g, uint32_t parts) {
     fz.multi_list = g->ccl_scratch;  // as ivx_launch_ccl_local
     fz.dens = g->dens_dev;
     fz.chunk_moments = g->chunk_moments;
-    if ((parts & IVX_PART_REGIONS) && !g->scratch_preset) IVX_HIP_CHECK(hipMemsetAsync(g->rscalar, 0, 16 * sizeof(uint32_t), g->ctx->stream));
-    if (!g->scratch_preset) IVX_HIP_CHECK(hipMemsetAsync(g->work_counts, 0, sizeof(uint32_t), g->ctx->stream));
+    if ((parts & IVX_PART_REGIONS) && !(preset_groups & IVX_SCRATCH_REGIONS)) IVX_HIP_CHECK(hipMemsetAsync(g->rscalar, 0, 16 * sizeof(uint32_t), g->ctx->stream));
+    if (parts & IVX_PART_REGIONS) g->scratch_dirty |= IVX_SCRATCH_REGIONS;
     g->bbox_valid = 1;
+    uint32_t* next_count = ivx_wc(g);  // the counter of the sweep before: zeroed by this one for the sweep after
+    g->wc_cur ^= 1u;
     hipLaunchKernelGGL(k_chunk_pre, dim3((g->n_chunks + 255u) / 256u), dim3(256), 0, g->ctx->stream, v, g->info, g->chunk_bbox, g->chunk_counts,
-                       g->chunk_class, g->chunk_touch, g->rparent, g->work_counts, g->active_list);
+                       g->chunk_class, g->chunk_touch, g->rparent, ivx_wc(g), next_count, g->active_list, ivx_preset_args(g, preset_groups));
+    g->scratch_dirty &= ~preset_groups;
     hipLaunchKernelGGL(k_derive, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->sdf, g->type, g->flags, g->info, g->chunk_bbox,
-                       g->chunk_touch, g->chunk_signs, g->work_counts, g->active_list, fz);
+                       g->chunk_touch, g->chunk_signs, ivx_wc(g), g->active_list, fz);
     g->planes_compact = 1;
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 
 int ivx_launch_occupied(ivx_grid* g, uint32_t* d_raw) {
-    if (!g->scratch_preset) {
-        IVX_HIP_CHECK(hipMemsetAsync(d_raw, 0xFF, 6 * sizeof(uint32_t), g->ctx->stream));
-        IVX_HIP_CHECK(hipMemsetAsync(d_raw + 6, 0, 6 * sizeof(uint32_t), g->ctx->stream));
-    }
+    IVX_HIP_CHECK(hipMemsetAsync(d_raw, 0xFF, 6 * sizeof(uint32_t), g->ctx->stream));
+    IVX_HIP_CHECK(hipMemsetAsync(d_raw + 6, 0, 6 * sizeof(uint32_t), g->ctx->stream));
     hipLaunchKernelGGL(k_occupied_reduce, dim3((g->n_chunks + 255u) / 256u), dim3(256), 0, g->ctx->stream, g->cc[0], g->cc[1], g->cc[2], g->chunk_bbox, d_raw);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;

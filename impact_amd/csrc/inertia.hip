@@ -110,12 +110,20 @@ __global__ __launch_bounds__(640) void k_inertia_final(uint32_t n_blocks, float 
 
 }  // namespace
 
+int ivx_launch_inertia_dense(ivx_grid* g) {
+    GridView v = ivx_view(g);
+    hipLaunchKernelGGL(k_inertia_dense, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->x_off, g->flags, g->dens_dev, g->chunk_moments, ivx_wc(g),
+                       g->active_list);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
 int ivx_launch_inertia(ivx_grid* g, const float* d_dens, double* d_out10, int fused) {
     uint32_t blocks = (g->n_chunks + 255u) / 256u;
     if (blocks > g->partial_blocks) blocks = (uint32_t)g->partial_blocks;
     GridView v = ivx_view(g);
     if (!fused)  // else k_derive left the chunk moments in the same sweep
-        hipLaunchKernelGGL(k_inertia_dense, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->x_off, g->flags, d_dens, g->chunk_moments, g->work_counts,
+        hipLaunchKernelGGL(k_inertia_dense, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->x_off, g->flags, d_dens, g->chunk_moments, ivx_wc(g),
                        g->active_list);
     hipLaunchKernelGGL(k_inertia_sum, dim3(blocks), dim3(256), 0, g->ctx->stream, v, g->x_off, d_dens, g->chunk_moments, g->partials);
     hipLaunchKernelGGL(k_inertia_final, dim3(1), dim3(640), 0, g->ctx->stream, blocks, g->extent, g->partials, d_out10);

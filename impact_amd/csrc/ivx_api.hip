@@ -33,27 +33,45 @@ int dev_alloc(T** p, size_t count) {
 
 int ensure_host_scratch(ivx_grid* g, size_t bytes) {
     if (g->host_scratch_bytes >= bytes) return IVX_OK;
+    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
     if (g->host_scratch) (void)hipHostFree(g->host_scratch);
-    if (g->result_host) (void)hipHostFree(g->result_host);
-    ivx_submesh_manager_free(g->submesh_manager);
-    ivx_probe_manager_free(g->probe_manager);
     g->host_scratch = nullptr;
     g->host_scratch_bytes = 0;
+    if (bytes < (64u << 10)) bytes = 64u << 10;
     IVX_HIP_CHECK(hipHostMalloc(&g->host_scratch, bytes, hipHostMallocDefault));
     g->host_scratch_bytes = bytes;
     return IVX_OK;
 }
 
-// Host<->device copies: the stream is idle at every API boundary, so plain blocking copies are the
-// simplest correct form (pageable host memory; no stream-ordered allocator involved).
+// Host<->device copies. Small ones (the scalars and tables the entry points hand back: up to a few hundred KB) go through the
+// grid's pinned staging buffer as ONE stream-ordered copy and ONE wait (a blocking copy from pageable memory costs a wait for
+// the stream, a staging copy inside the runtime and a second wait); large ones (whole planes) stay plain blocking copies.
+constexpr size_t STAGED_COPY_MAX = 1u << 20;
 int d2h(ivx_grid* g, void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return IVX_OK;
+    if (bytes <= STAGED_COPY_MAX) {
+        int rc = ensure_host_scratch(g, bytes);
+        if (rc) return rc;
+        IVX_HIP_CHECK(hipMemcpyAsync(g->host_scratch, src, bytes, hipMemcpyDeviceToHost, g->ctx->stream));
+        IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+        memcpy(dst, g->host_scratch, bytes);
+        return IVX_OK;
+    }
     IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
     IVX_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return IVX_OK;
 }
 int h2d(ivx_grid* g, void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return IVX_OK;
+    if (bytes <= STAGED_COPY_MAX) {
+        int rc = ensure_host_scratch(g, bytes);
+        if (rc) return rc;
+        IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));  // the staging buffer may still feed an earlier copy
+        memcpy(g->host_scratch, src, bytes);
+        IVX_HIP_CHECK(hipMemcpyAsync(dst, g->host_scratch, bytes, hipMemcpyHostToDevice, g->ctx->stream));
+        IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+        return IVX_OK;
+    }
     IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
     IVX_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
     return IVX_OK;
@@ -372,6 +390,7 @@ int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32
     A(dev_alloc(&g->group_sums, (size_t)((g->n_chunks + 255u) / 256u) * 4 + 4));
     A(dev_alloc(&g->dens_dev, (size_t)256));
     A(dev_alloc(&g->work_counts, (size_t)8));
+    A(dev_alloc(&g->occ_part, (size_t)((g->n_chunks + 255u) / 256u) * 12 + 12));
     A(dev_alloc(&g->active_list, (size_t)g->n_chunks));
     A(dev_alloc(&g->chunk_class, (size_t)g->n_chunks));
     A(dev_alloc(&g->chunk_touch, (size_t)g->n_chunks));
@@ -381,7 +400,8 @@ int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32
         ivx_grid_destroy(g);
         return rc;
     }
-    if (hipMemsetAsync(g->info, 0, sizeof(ivx_chunk_info) * g->n_chunks, c->stream) != hipSuccess) {
+    if (hipMemsetAsync(g->info, 0, sizeof(ivx_chunk_info) * g->n_chunks, c->stream) != hipSuccess ||
+        hipMemsetAsync(g->work_counts, 0, 8 * sizeof(uint32_t), c->stream) != hipSuccess) {
         ivx_set_error("ivx_grid_create: memset failed");
         ivx_grid_destroy(g);
         return IVX_ERR_HIP;
@@ -396,7 +416,7 @@ void ivx_grid_destroy(ivx_grid* g) {
     void* ptrs[] = {g->sdf, g->type, g->flags, g->llabel, g->info, g->ghost_sdf[0], g->ghost_sdf[1], g->ghost_type[0], g->ghost_type[1],
                     g->ghost_info[0], g->ghost_info[1], g->chunk_counts, g->chunk_offsets, g->positions, g->normals, g->indices,
                     g->index_materials, g->vertex_materials, g->submeshes, g->partials, g->rparent, g->rcompid, g->rscalar, g->ccl_scratch, g->group_sums, g->sn_list, g->dens_dev, g->dev_scratch, g->prog_nodes, g->chunk_bbox, g->samp_len, g->samp_ops, g->pairs_dev,
-                    g->work_counts, g->active_list, g->chunk_class, g->chunk_moments, g->chunk_touch, g->chunk_signs, g->samp_super, g->probe_points,
+                    g->work_counts, g->occ_part, g->active_list, g->chunk_class, g->chunk_moments, g->chunk_touch, g->chunk_signs, g->samp_super, g->probe_points,
                     g->probe_chunk, g->probe_entries};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -1090,7 +1110,8 @@ static int absorb_shape(ivx_grid* g, const char* who, int capsule, const float c
     char* base = static_cast<char*>(g->dev_scratch);
     IVX_HIP_CHECK(hipMemsetAsync(base, 0, total, g->ctx->stream));
     float* d_dens = reinterpret_cast<float*>(base + off_dens);
-    if ((rc = h2d(g, d_dens, densities, 1024))) return rc;
+    if (g->has_dens && memcmp(g->dens_host, densities, sizeof(g->dens_host)) == 0) d_dens = g->dens_dev;  // the resident table
+    else if ((rc = h2d(g, d_dens, densities, 1024))) return rc;
     if ((rc = ivx_launch_absorb(g, capsule, lo, cc, vlo, vhi, center, seg, influence_radius, shape_radius, d_dens, reinterpret_cast<double*>(base),
                                 reinterpret_cast<uint32_t*>(base + off_type), reinterpret_cast<uint32_t*>(base + off_cnt),
                                 reinterpret_cast<uint32_t*>(base + off_touch))))
@@ -1935,13 +1956,16 @@ int ivx_grid_set_densities(ivx_grid* g, const float densities[256]) {
     IVX_REQUIRE(g && densities, IVX_ERR_INVALID, "ivx_grid_set_densities: null argument");
     int rc = h2d(g, g->dens_dev, densities, 256 * sizeof(float));
     if (rc) return rc;
+    memcpy(g->dens_host, densities, sizeof(g->dens_host));
     g->has_dens = 1;
     return IVX_OK;
 }
 
-static const uint32_t kStageOfTimed[IVX_N_TIMED_STAGES] = {IVX_STAGE_SAMPLE, IVX_STAGE_DERIVE, IVX_STAGE_OCCUPIED, IVX_STAGE_REGIONS, IVX_STAGE_REGIONS,
-                                                           IVX_STAGE_REGIONS, IVX_STAGE_REMESH,  IVX_STAGE_REMESH,   IVX_STAGE_REMESH,  IVX_STAGE_INERTIA};
-
+// Timed slots of a step (ivx_step_result::stage_ms): 0 sample (k_sdf_super, k_sdf_prepass, k_sdf_eval), 1 derive (k_chunk_pre, k_derive:
+// flags, chunk state, chunk-local regions, chunk moments), 2 k_step_post1 (mesher count | region merge by columns | exact local
+// numbering | occupied slots | moment partial sums), 3 k_step_post2 (multi-region merge | mesher scan | moments and occupied ranges
+// final), 4 k_step_emit (region forest flatten | mesher emit), 5 k_step_assign (component ids); 6..9 unused. Stage timing costs two
+// event records per slot on the stream; ivx_grid_set_stage_timing(g, 0) turns it off.
 int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
     IVX_REQUIRE(g, IVX_ERR_INVALID, "ivx_voxel_step_enqueue: null grid");
     IVX_REQUIRE(!(stages & IVX_STAGE_SAMPLE) || g->prog_n > 0, IVX_ERR_STATE, "ivx_voxel_step: no SDF program resident (ivx_grid_set_sdf_program)");
@@ -1951,38 +1975,48 @@ int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
         for (int i = 0; i < 2 * IVX_N_TIMED_STAGES; ++i) IVX_HIP_CHECK(hipEventCreate(&g->ev[i]));
         g->ev_ready = 1;
     }
+    if (!g->result_host) {
+        IVX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&g->result_host), 64 * sizeof(uint32_t), hipHostMallocMapped));
+        IVX_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&g->result_host_dev), g->result_host, 0));
+    }
     int rc;
-    uint32_t* d_occ = g->rscalar + 16;
     if (stages & IVX_STAGE_SAMPLE)
         if ((rc = ivx_sampler_buffers(g))) return rc;
-    // one launch presets the scratch words of the stages in this call (a phase of the multi-GPU protocol must not wipe
-    // what an earlier phase of the same step left: only the requested stages' words are touched)
-    if ((rc = ivx_launch_step_preset(g, stages))) return rc;
-    g->scratch_preset = 1;
-    struct PresetGuard {
-        ivx_grid* g;
-        ~PresetGuard() { g->scratch_preset = 0; }
-    } preset_guard{g};
-    // a stage's duration runs from the stop event of the stage enqueued just before it, when there is one
+    // Scratch word groups the stages of this call start from. They are preset by the call's first kernel (k_sdf_super or
+    // k_chunk_pre host that role); a call that starts with neither gets a preset launch of its own. Only the requested stages'
+    // groups are touched: a phase of the multi-GPU protocol must not wipe what an earlier phase of the same step left.
+    uint32_t need = 0;
+    if (stages & IVX_STAGE_SAMPLE) need |= IVX_SCRATCH_EVAL;
+    if (stages & IVX_STAGE_REGIONS) need |= IVX_SCRATCH_REGIONS;
+    if (stages & IVX_STAGE_REMESH) need |= IVX_SCRATCH_SN;
+    uint32_t preset_in_sample = 0, preset_in_derive = 0;
+    if (stages & IVX_STAGE_SAMPLE) preset_in_sample = need;
+    else if (stages & IVX_STAGE_DERIVE) preset_in_derive = need;
+    else if ((rc = ivx_launch_step_preset(g, need))) return rc;
+    // a slot's duration runs from the stop event of the slot enqueued just before it, when there is one
+    const bool timing = g->stage_timing_off == 0;
     hipEvent_t* last_stop = nullptr;
-#define T0(i)                                                  \
-    if (last_stop) g->ev_start_ref[i] = last_stop;             \
-    else {                                                     \
-        IVX_HIP_CHECK(hipEventRecord(g->ev[2 * (i)], s));      \
-        g->ev_start_ref[i] = &g->ev[2 * (i)];                  \
+#define T0(i)                                                      \
+    if (timing) {                                                  \
+        if (last_stop) g->ev_start_ref[i] = last_stop;             \
+        else {                                                     \
+            IVX_HIP_CHECK(hipEventRecord(g->ev[2 * (i)], s));      \
+            g->ev_start_ref[i] = &g->ev[2 * (i)];                  \
+        }                                                          \
     }
-#define T1(i)                                                  \
-    IVX_HIP_CHECK(hipEventRecord(g->ev[2 * (i) + 1], s));      \
-    last_stop = &g->ev[2 * (i) + 1];                           \
-    g->timed_mask |= 1u << (i)
-    // derive runs the chunk-local region labelling and the chunk moments in the same sweep when those stages are part of this
-    // call (their stage timers then cover only what is left of them)
+#define T1(i)                                                      \
+    if (timing) {                                                  \
+        IVX_HIP_CHECK(hipEventRecord(g->ev[2 * (i) + 1], s));      \
+        last_stop = &g->ev[2 * (i) + 1];                           \
+        g->timed_mask |= 1u << (i);                                \
+    }
+    // derive runs the chunk-local region labelling and the chunk moments in the same sweep when those stages are part of this call
     const uint32_t fused_parts = (stages & IVX_STAGE_DERIVE) ? (((stages & IVX_STAGE_REGIONS) ? IVX_PART_REGIONS : 0u) |
                                                                  ((stages & IVX_STAGE_INERTIA) ? IVX_PART_MOMENTS : 0u))
                                                               : 0u;
     if (stages & IVX_STAGE_SAMPLE) {
         T0(0);
-        if ((rc = ivx_launch_sdf_sample(g, g->prog_nodes, g->prog_n, g->prog_stack, g->prog_shape, g->prog_center, g->prog_type))) return rc;
+        if ((rc = ivx_launch_sdf_sample(g, g->prog_nodes, g->prog_n, g->prog_stack, g->prog_shape, g->prog_center, g->prog_type, preset_in_sample))) return rc;
         T1(0);
         g->occ_ref_valid = 0;
         g->bbox_valid = 0;
@@ -1992,47 +2026,58 @@ int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
     }
     if (stages & IVX_STAGE_DERIVE) {
         T0(1);
-        if ((rc = ivx_launch_derive(g, fused_parts))) return rc;
+        if ((rc = ivx_launch_derive(g, fused_parts, preset_in_derive))) return rc;
         T1(1);
     }
-    if (stages & IVX_STAGE_OCCUPIED) {
+    const uint32_t post = stages & (IVX_STAGE_OCCUPIED | IVX_STAGE_REGIONS | IVX_STAGE_REMESH | IVX_STAGE_INERTIA);
+    if (post) {
+        // stages that were not swept inside k_derive get their stand-alone per-chunk kernels first (a call without the derive stage)
+        if ((stages & IVX_STAGE_REGIONS) && !(fused_parts & IVX_PART_REGIONS)) {
+            // (level 1 over the active list; the exact numbering of multi-region chunks is a role of k_step_post1 below, so
+            // only the list-driven labelling kernel is launched here: ivx_launch_ccl_local would run both)
+            if ((rc = ivx_launch_ccl_local_only(g))) return rc;
+        }
+        if ((stages & IVX_STAGE_INERTIA) && !(fused_parts & IVX_PART_MOMENTS))
+            if ((rc = ivx_launch_inertia_dense(g))) return rc;
+        const bool fused_assign = ivx_step_assign_fits(g);
         T0(2);
-        if ((rc = ivx_launch_occupied(g, d_occ))) return rc;
+        if ((rc = ivx_launch_step_post1(g, post))) return rc;
         T1(2);
-    }
-    if (stages & IVX_STAGE_REGIONS) {
         T0(3);
-        if ((rc = ivx_launch_ccl_local(g, (fused_parts & IVX_PART_REGIONS) != 0))) return rc;
+        if ((rc = ivx_launch_step_post2(g, post))) return rc;
         T1(3);
-        T0(4);
-        if ((rc = ivx_launch_ccl_merge(g))) return rc;
-        T1(4);
-        T0(5);
-        if ((rc = ivx_launch_ccl_resolve(g))) return rc;
-        T1(5);
-    }
-    if (stages & IVX_STAGE_REMESH) {
-        T0(6);
-        if ((rc = ivx_launch_sn_count(g))) return rc;
-        T1(6);
-        T0(7);
-        if ((rc = ivx_launch_sn_scan(g))) return rc;
-        T1(7);
         // no host round trip for the mesh sizes: the emit pass writes into the buffers of the previous step and skips what
         // does not fit; ivx_voxel_step_collect grows the buffers and repeats the pass in that (rare) case
-        T0(8);
-        if ((rc = ivx_launch_sn_emit(g))) return rc;
-        T1(8);
-        g->mesh_valid = 0;
-    }
-    if (stages & IVX_STAGE_INERTIA) {
-        T0(9);
-        if ((rc = ivx_launch_inertia(g, g->dens_dev, g->partials + g->partial_blocks * 10, (fused_parts & IVX_PART_MOMENTS) != 0))) return rc;
-        T1(9);
+        if (post & (IVX_STAGE_REGIONS | IVX_STAGE_REMESH)) {
+            T0(4);
+            if (fused_assign) {
+                if ((rc = ivx_launch_step_emit(g, post))) return rc;
+            } else {  // more than 524 288 chunks: the region resolve takes its stand-alone path
+                if ((post & IVX_STAGE_REMESH) && (rc = ivx_launch_step_emit(g, IVX_STAGE_REMESH))) return rc;
+                if ((post & IVX_STAGE_REGIONS) && (rc = ivx_launch_ccl_resolve(g))) return rc;
+            }
+            T1(4);
+        }
+        if ((post & IVX_STAGE_REGIONS) && fused_assign) {
+            T0(5);
+            if ((rc = ivx_launch_step_assign(g))) return rc;
+            T1(5);
+        }
+        if (post & IVX_STAGE_REMESH) {
+            g->mesh_valid = 0;
+            g->scratch_dirty |= IVX_SCRATCH_SN;
+        }
+        if (post & IVX_STAGE_REGIONS) g->scratch_dirty |= IVX_SCRATCH_REGIONS;
     }
 #undef T0
 #undef T1
     g->pending_stages |= stages;
+    return IVX_OK;
+}
+
+int ivx_grid_set_stage_timing(ivx_grid* g, int enabled) {
+    IVX_REQUIRE(g, IVX_ERR_INVALID, "ivx_grid_set_stage_timing: null grid");
+    g->stage_timing_off = enabled ? 0 : 1;
     return IVX_OK;
 }
 
@@ -2048,7 +2093,7 @@ int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out) {
         IVX_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&g->result_host_dev), g->result_host, 0));
     }
     {
-        int rc = ivx_launch_result_gather(g, g->result_host_dev);
+        int rc = ivx_launch_step_gather(g);
         if (rc) return rc;
     }
     IVX_HIP_CHECK(hipStreamSynchronize(s));
@@ -2092,7 +2137,6 @@ int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out) {
             if (hipEventElapsedTime(&ms, *g->ev_start_ref[i], g->ev[2 * i + 1]) != hipSuccess) ms = 0.0f;
         out->stage_ms[i] = ms;
     }
-    (void)kStageOfTimed;
     g->pending_stages = 0;
     g->timed_mask = 0;
     return IVX_OK;

@@ -88,7 +88,10 @@ struct ivx_grid {
     // list-driven stages: k_chunk_pre settles every chunk whose per-step state follows from the chunk records alone (Void,
     // and Uniform chunks surrounded by Uniform chunks: ~85 % of a solid body's chunks) with one THREAD each and lists the
     // rest; the workgroup-per-chunk kernels then walk that list instead of being launched once per chunk of the grid.
-    uint32_t* work_counts;  // [8]: [0] chunks on the active list, [1..8) spare
+    uint32_t* work_counts;  // [8]: [wc_cur] chunks on the active list; [wc_cur ^ 1] is zero, ready to be the next derive sweep's counter
+    uint32_t wc_cur;        // k_chunk_pre appends under the counter it is handed and zeroes the other one: no preset, no memset
+    uint32_t scratch_dirty; // IVX_SCRATCH_* groups of small scratch words that a stage has used since they were last preset
+    uint32_t* occ_part;     // [12 * ceil(n_chunks / 256)] per-block minima/maxima of the occupied-range reduction (fused step path)
     uint32_t* active_list;  // [n_chunks]
     uint8_t* chunk_class;   // [n_chunks] 1: settled by k_chunk_pre
     uint16_t* chunk_signs;  // [n_chunks * 256] active chunks: 16-bit "distance negative" mask of every (i,j) row (k_derive), what
@@ -97,8 +100,9 @@ struct ivx_grid {
     double* chunk_moments;  // [n_chunks * 10] moments of the NonUniform chunks (fixed summation order whatever the list order)
     uint32_t last_active;   // host: active-list length seen by the last collect (sizes the list-driven grids)
     int planes_compact;  // planes of Void/Uniform chunks may be stale (see ivx_ensure_dense)
-    int scratch_preset;  // inside ivx_voxel_step: k_step_preset already initialised the stages' scratch words
+    int stage_timing_off;  // ivx_grid_set_stage_timing(g, 0): no event records around the timed slots of a step
     float* dens_dev;        // [256] voxel type densities
+    float dens_host[256];   // what dens_dev holds (entry points that are handed the same table again skip the upload)
     void* dev_scratch;      // grown on demand (node programs, dense label export, region statistics)
     size_t dev_scratch_bytes;
     // resident SDF program (ivx_grid_set_sdf_program)
@@ -260,6 +264,12 @@ static inline uint32_t ivx_list_grid(const ivx_grid* g) {
     return n < lo ? lo : n;
 }
 
+static inline uint32_t* ivx_wc(const ivx_grid* g) { return g->work_counts + g->wc_cur; }
+// groups of small scratch words that must hold their preset value when a stage starts
+#define IVX_SCRATCH_REGIONS 1u  // rscalar[0..16): region count, error flags, multi-region chunk count
+#define IVX_SCRATCH_SN 2u       // Surface-Nets group totals
+#define IVX_SCRATCH_EVAL 4u     // lengths of the sampler's evaluation lists
+
 static inline GridView ivx_view(const ivx_grid* g) {
     GridView v;
     v.cx = g->cc[0];
@@ -290,14 +300,19 @@ static inline GridView ivx_view(const ivx_grid* g) {
 // kernels (one launcher per stage; all asynchronous on ctx->stream)
 int ivx_launch_classify(ivx_grid* g);
 int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, uint32_t n_nodes, uint32_t stack_size,
-                          const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type);
+                          const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type, uint32_t preset_groups = 0);
 // parts of the fused sweep: k_derive can label the chunk-local regions and compute the chunk moments of the chunks it visits
 #define IVX_PART_REGIONS 1u
 #define IVX_PART_MOMENTS 2u
-int ivx_launch_derive(ivx_grid* g, uint32_t parts);
+int ivx_launch_derive(ivx_grid* g, uint32_t parts, uint32_t preset_groups = 0);
 int ivx_ensure_dense(ivx_grid* g);
-int ivx_launch_step_preset(ivx_grid* g, uint32_t stages);
-int ivx_launch_result_gather(ivx_grid* g, uint32_t* host_block_dev);
+int ivx_launch_step_preset(ivx_grid* g, uint32_t groups);
+int ivx_launch_step_post1(ivx_grid* g, uint32_t stages);
+int ivx_launch_step_post2(ivx_grid* g, uint32_t stages);
+int ivx_launch_step_emit(ivx_grid* g, uint32_t stages);
+int ivx_launch_step_assign(ivx_grid* g);
+int ivx_launch_step_gather(ivx_grid* g);
+bool ivx_step_assign_fits(const ivx_grid* g);
 int ivx_sampler_buffers(ivx_grid* g);
 void ivx_sdf_annotate_host(ivx_sdf_processed_node* nodes, size_t n);  // sdf_compile.cpp: reserved[] fields for the pre-pass
 int ivx_launch_occupied(ivx_grid* g, uint32_t* d_raw);
@@ -307,6 +322,8 @@ int ivx_launch_sn_scan(ivx_grid* g);
 int ivx_launch_sn_emit(ivx_grid* g);
 int ivx_launch_inertia(ivx_grid* g, const float* d_dens, double* d_out10, int fused);
 int ivx_launch_ccl_local(ivx_grid* g, int fused);
+int ivx_launch_ccl_local_only(ivx_grid* g);  // level 1 over the active list without the exact numbering of multi-region chunks
+int ivx_launch_inertia_dense(ivx_grid* g);   // chunk moments of the listed NonUniform chunks into their slots
 int ivx_launch_ccl_merge(ivx_grid* g);
 int ivx_launch_ccl_resolve(ivx_grid* g);
 int ivx_launch_ccl_dense_labels(ivx_grid* g, uint32_t* d_labels);

@@ -18,6 +18,7 @@
 // The row is written back as one 16-byte store per plane per thread (4 KiB contiguous per workgroup).
 // HBM traffic: 2 B/voxel written (sdf + type), nothing read.
 #include "ivx_internal.hpp"
+#include "table_roles.hpp"
 
 namespace {
 
@@ -305,9 +306,10 @@ constexpr int SUPER = 4;
 // pre-pass replaces the range by one constant), else the node's own index; .y = that subtree's folded constant
 __device__ __forceinline__ bool range_all_far(const uint32_t* mask, uint32_t a, uint32_t b);
 __global__ __launch_bounds__(64) void k_sdf_super(SampleParams p, const ivx_sdf_processed_node* __restrict__ nodes, uint32_t* __restrict__ super_mask,
-                                                  uint2* __restrict__ super_skip, uint32_t words, uint32_t sy, uint32_t sz) {
+                                                  uint2* __restrict__ super_skip, uint32_t words, uint32_t sy, uint32_t sz, ivx_roles::PresetArgs preset) {
     extern __shared__ uint32_t s_mask[];  // [words]
     const uint32_t sb = blockIdx.x, lane = threadIdx.x;
+    ivx_roles::role_preset(preset, sb * 64u + lane);  // the step's first kernel also presets the scratch words of the step's stages
     const uint32_t sk = sb % sz, sj = (sb / sz) % sy, si = sb / (sz * sy);
     const V3 lo = sub(mk((float)((si * SUPER + p.x_off) * 16u), (float)(sj * SUPER * 16u), (float)(sk * SUPER * 16u)),
                       mk(p.shifted_center[0], p.shifted_center[1], p.shifted_center[2]));
@@ -850,8 +852,10 @@ int ivx_sampler_buffers(ivx_grid* g) {
     return IVX_OK;
 }
 
+ivx_roles::PresetArgs ivx_preset_args(ivx_grid* g, uint32_t groups);  // derive.hip
+
 int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, uint32_t n_nodes, uint32_t stack_size,
-                          const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type) {
+                          const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type, uint32_t preset_groups) {
     SampleParams p;
     p.cx = g->cc[0];
     p.cy = g->cc[1];
@@ -878,9 +882,7 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
     uint2* ops = reinterpret_cast<uint2*>(g->samp_ops);
     uint32_t* eval_count = g->samp_len + g->n_chunks;
     uint32_t* eval_list = eval_count + 4;
-    if (!g->scratch_preset) {
-        IVX_HIP_CHECK(hipMemsetAsync(eval_count, 0, 4 * sizeof(uint32_t), g->ctx->stream));
-    }
+    if (!(preset_groups & IVX_SCRATCH_EVAL)) IVX_HIP_CHECK(hipMemsetAsync(eval_count, 0, 4 * sizeof(uint32_t), g->ctx->stream));
     const uint32_t sx = (g->cc[0] + SUPER - 1) / SUPER, sy = (g->cc[1] + SUPER - 1) / SUPER, sz = (g->cc[2] + SUPER - 1) / SUPER;
     const uint32_t words = (n_nodes + 31u) / 32u > 0u ? (n_nodes + 31u) / 32u : 1u;
     {
@@ -895,7 +897,9 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
         }
     }
     uint2* super_skip = reinterpret_cast<uint2*>(g->samp_super + (((size_t)sx * sy * sz * words + 1u) & ~(size_t)1u));
-    hipLaunchKernelGGL(k_sdf_super, dim3(sx * sy * sz), dim3(64), words * sizeof(uint32_t), g->ctx->stream, p, d_nodes, g->samp_super, super_skip, words, sy, sz);
+    hipLaunchKernelGGL(k_sdf_super, dim3(sx * sy * sz), dim3(64), words * sizeof(uint32_t), g->ctx->stream, p, d_nodes, g->samp_super, super_skip, words, sy, sz,
+                       ivx_preset_args(g, preset_groups));
+    g->scratch_dirty = (g->scratch_dirty & ~preset_groups) | IVX_SCRATCH_EVAL;
     hipLaunchKernelGGL(k_sdf_prepass, dim3(sx * sy * sz), dim3(PRE_T), 0, g->ctx->stream, p, d_nodes, chunk_const, g->samp_len, ops, eval_count, eval_list,
                        g->n_chunks, g->info, g->samp_super, super_skip, words, sy, sz);
     g->planes_compact = 1;

@@ -1,0 +1,711 @@
+// Device-side bodies ("roles") of the Surface Nets kernels, shared by surface_nets.hip's stand-alone kernels and the fused step
+// launches (step_fused.hip): a role is what one workgroup of the original kernel does, with its block index and block count passed
+// in (`bid`, `nb`). Algorithm notes and reference citations: surface_nets.hip.
+#pragma once
+#include "ivx_internal.hpp"
+
+namespace ivx_roles {
+namespace sn {
+
+
+constexpr int G = 18, NROWS = 324, NCROWS = 289, NCUBES = 4913;
+// LDS tile: 18 x 18 rows of 18 bytes along k; a row occupies RS = 24 bytes with cell c at byte 3 + c, so the 16
+// interior cells (c = 1..16, the chunk's own k-row) sit 4-byte aligned and are written as four words.
+constexpr int RS = 24, TILE_BYTES = NROWS * RS;
+__device__ __forceinline__ int tix(int a, int b, int c) { return (a * G + b) * RS + 3 + c; }
+
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 add(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 mul(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ V3 scale(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float len3(V3 a) { return sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z); }
+__device__ __forceinline__ bool sneg(float f) { return (__float_as_uint(f) >> 31) != 0; }
+// VoxelSignedDistance::to_f32 (lib.rs:220-222)
+__device__ __forceinline__ float decode(int8_t e) { return (float)e * 0.02f; }
+
+struct SnParams {
+    GridView g;
+    float extent;
+    uint32_t x_off;
+};
+
+// One padded row (fixed gi, gj; cells gk = ck*16 - 1 .. ck*16 + 16) of the object, relative to this slab. Outside the
+// grid / void -> (127, 255) (object/sdf.rs:410-508: void neighbours pad with +2.54).
+__device__ __forceinline__ void fetch_row(const GridView& g, int gi, int gj, int ck, uint32_t sd[6], uint32_t ty[6]) {
+    // sd/ty: [0] = cell 0 (byte), [1..4] = the 16 interior cells (words), [5] = cell 17 (byte)
+    sd[0] = sd[5] = 0x7Fu;
+    ty[0] = ty[5] = 0xFFu;
+    sd[1] = sd[2] = sd[3] = sd[4] = 0x7F7F7F7Fu;
+    ty[1] = ty[2] = ty[3] = ty[4] = 0xFFFFFFFFu;
+    if (gj < 0 || gj >= (int)g.cy * 16) return;
+    const int8_t* ps;
+    const uint8_t* pt;
+    size_t row;        // offset of (.., gj, k = 0) inside the chunk / ghost column
+    size_t kstride;    // offset between consecutive chunks along k
+    if (gi < 0 || gi >= (int)g.cx * 16) {
+        const int side = gi < 0 ? 0 : 1;
+        if (!g.ghost_sdf[side]) return;
+        ps = g.ghost_sdf[side];
+        pt = g.ghost_type[side];
+        row = (size_t)((gj >> 4) * g.cz) * 256 + ((gj & 15) << 4);
+        kstride = 256;
+    } else {
+        ps = g.sdf;
+        pt = g.type;
+        row = ((size_t)(((gi >> 4) * g.cy + (gj >> 4)) * g.cz) << 12) + (((gi & 15) << 8) | ((gj & 15) << 4));
+        kstride = IVX_CHUNK_VOXELS;
+    }
+    const size_t o = row + (size_t)ck * kstride;
+    if (kstride == IVX_CHUNK_VOXELS) {
+        // inside the slab a Void / Uniform chunk is its record, not its planes (compact planes)
+        // (record and plane rows are fetched side by side and the record picks afterwards: the planes exist for every
+        // chunk, only their content may be stale, and a dependent load chain costs more here than the extra bytes)
+        const ivx_chunk_info* ip = g.info + (o >> 12);
+        const ivx_chunk_info c1 = ip[0];
+        const uint4 s4 = *reinterpret_cast<const uint4*>(ps + o);
+        const uint4 t4 = *reinterpret_cast<const uint4*>(pt + o);
+        const bool d1 = c1.kind == KIND_NONUNIFORM;
+        const uint32_t us = ivx_uniform_sdf(c1.kind) * 0x01010101u, ut = ivx_uniform_type(c1) * 0x01010101u;
+        sd[1] = d1 ? s4.x : us, sd[2] = d1 ? s4.y : us, sd[3] = d1 ? s4.z : us, sd[4] = d1 ? s4.w : us;
+        ty[1] = d1 ? t4.x : ut, ty[2] = d1 ? t4.y : ut, ty[3] = d1 ? t4.z : ut, ty[4] = d1 ? t4.w : ut;
+        if (ck > 0) {
+            const ivx_chunk_info c0 = ip[-1];
+            const uint32_t bs = (uint8_t)ps[o - kstride + 15], bt = pt[o - kstride + 15];
+            const bool dense = c0.kind == KIND_NONUNIFORM;
+            sd[0] = dense ? bs : ivx_uniform_sdf(c0.kind);
+            ty[0] = dense ? bt : ivx_uniform_type(c0);
+        }
+        if (ck + 1 < (int)g.cz) {
+            const ivx_chunk_info c2 = ip[1];
+            const uint32_t bs = (uint8_t)ps[o + kstride], bt = pt[o + kstride];
+            const bool dense = c2.kind == KIND_NONUNIFORM;
+            sd[5] = dense ? bs : ivx_uniform_sdf(c2.kind);
+            ty[5] = dense ? bt : ivx_uniform_type(c2);
+        }
+        return;
+    }
+    const uint4 s4 = *reinterpret_cast<const uint4*>(ps + o);
+    const uint4 t4 = *reinterpret_cast<const uint4*>(pt + o);
+    sd[1] = s4.x, sd[2] = s4.y, sd[3] = s4.z, sd[4] = s4.w;
+    ty[1] = t4.x, ty[2] = t4.y, ty[3] = t4.z, ty[4] = t4.w;
+    if (ck > 0) {
+        sd[0] = (uint8_t)ps[o - kstride + 15];
+        ty[0] = pt[o - kstride + 15];
+    }
+    if (ck + 1 < (int)g.cz) {
+        sd[5] = (uint8_t)ps[o + kstride];
+        ty[5] = pt[o + kstride];
+    }
+}
+
+// sign bits of 16 packed i8 -> 16-bit mask
+__device__ __forceinline__ uint32_t neg16(const uint32_t w[4]) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t sb = w[q] & 0x80808080u;
+        m |= (((sb >> 7) & 1u) | ((sb >> 14) & 2u) | ((sb >> 21) & 4u) | ((sb >> 28) & 8u)) << (4 * q);
+    }
+    return m;
+}
+
+// The 18 sign bits of one padded row from the per-row masks k_derive left (count pass): bit 0 = cell -1 (bit 15 of the row in
+// the chunk below along k), bits 1..16 the row itself, bit 17 = cell 16 (bit 0 of the chunk above). A chunk that is not
+// NonUniform has no masks: all negative when Uniform, none when Void. Rows of a ghost layer come from the ghost planes.
+__device__ __forceinline__ uint32_t fetch_row_signs(const GridView& g, int gi, int gj, int ck) {
+    if (gj < 0 || gj >= (int)g.cy * 16) return 0u;
+    if (gi < 0 || gi >= (int)g.cx * 16) {
+        uint32_t sd[6], ty[6];
+        fetch_row(g, gi, gj, ck, sd, ty);
+        return ((sd[0] >> 7) & 1u) | (neg16(sd + 1) << 1) | (((sd[5] >> 7) & 1u) << 17);
+    }
+    const uint32_t chunk = ((gi >> 4) * g.cy + (gj >> 4)) * g.cz + ck;
+    const uint32_t row = ((gi & 15) << 4) | (gj & 15);
+    const ivx_chunk_info* ip = g.info + chunk;
+    const uint16_t* sp = g.signs + (size_t)chunk * 256 + row;
+    // (records and masks are fetched side by side; the record picks afterwards)
+    const uint32_t k1 = ip[0].kind, m1 = sp[0];
+    uint32_t bits = (k1 == KIND_NONUNIFORM ? m1 : (k1 == KIND_UNIFORM ? 0xFFFFu : 0u)) << 1;
+    if (ck > 0) {
+        const uint32_t k0 = ip[-1].kind, m0 = sp[-256];
+        bits |= k0 == KIND_NONUNIFORM ? ((m0 >> 15) & 1u) : (k0 == KIND_UNIFORM ? 1u : 0u);
+    }
+    if (ck + 1 < (int)g.cz) {
+        const uint32_t k2 = ip[1].kind, m2 = sp[256];
+        bits |= (k2 == KIND_NONUNIFORM ? (m2 & 1u) : (k2 == KIND_UNIFORM ? 1u : 0u)) << 17;
+    }
+    return bits;
+}
+
+__device__ __forceinline__ uint32_t neighbour_kind(const GridView& g, int ci, int cj, int ck) {
+    if (cj < 0 || ck < 0 || cj >= (int)g.cy || ck >= (int)g.cz) return KIND_VOID;
+    if (ci < 0) return g.ghost_info[0] ? g.ghost_info[0][cj * g.cz + ck].kind : (uint32_t)KIND_VOID;
+    if (ci >= (int)g.cx) return g.ghost_info[1] ? g.ghost_info[1][cj * g.cz + ck].kind : (uint32_t)KIND_VOID;
+    return g.info[(ci * g.cy + cj) * g.cz + ck].kind;
+}
+
+// Stage the 18^3 padded tile: 324 rows, one 16-byte plane load each (+ two halo bytes). s_neg[r] = 18-bit mask of
+// negative distances (decoded 0 is +0.0 => outside, surface_nets.rs:209-224). s_sd / s_ty may be null (count pass).
+__device__ __forceinline__ void load_tile(const GridView& g, int ci, int cj, int ck, uint8_t* s_sd, uint8_t* s_ty, uint32_t* s_neg, uint32_t tid) {
+#pragma unroll
+    for (int it = 0; it < (NROWS + 255) / 256; ++it) {  // unrolled: the loads of both rounds are in flight together
+        const int r = (int)tid + 256 * it;
+        if (r >= NROWS) break;
+        const int a = r / G, b = r - a * G;
+        if (!s_sd) {  // count pass: signs only
+            s_neg[r] = fetch_row_signs(g, ci * 16 + a - 1, cj * 16 + b - 1, ck);
+            continue;
+        }
+        uint32_t sd[6], ty[6];
+        fetch_row(g, ci * 16 + a - 1, cj * 16 + b - 1, ck, sd, ty);
+        s_neg[r] = ((sd[0] >> 7) & 1u) | (neg16(sd + 1) << 1) | (((sd[5] >> 7) & 1u) << 17);
+        if (s_sd) {
+            uint8_t* ds = s_sd + r * RS;
+            uint8_t* dt = s_ty + r * RS;
+            ds[3] = (uint8_t)sd[0];
+            dt[3] = (uint8_t)ty[0];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                reinterpret_cast<uint32_t*>(ds + 4)[q] = sd[1 + q];
+                reinterpret_cast<uint32_t*>(dt + 4)[q] = ty[1 + q];
+            }
+            ds[20] = (uint8_t)sd[5];
+            dt[20] = (uint8_t)ty[5];
+        }
+    }
+}
+
+// Ordered block-wide exclusive prefix of `val` in thread order; `total` = block sum (same in every thread).
+__device__ __forceinline__ uint32_t block_prefix(uint32_t val, uint32_t* s_wsum, uint32_t tid, uint32_t& total) {
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    uint32_t incl = val;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t n = __shfl_up(incl, o, 64);
+        if (lane >= (uint32_t)o) incl += n;
+    }
+    if (lane == 63u) s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t w0 = s_wsum[0], w1 = s_wsum[1], w2 = s_wsum[2], w3 = s_wsum[3];
+    uint32_t wbase = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
+    total = w0 + w1 + w2 + w3;
+    __syncthreads();
+    return wbase + incl - val;
+}
+
+// Bit k of the results refers to the cube (i, j, k) of cube row cr = i*17 + j (k = 0..16):
+//   vbits: the cube holds a vertex (its 8 corner signs are mixed, surface_nets.rs:209-224)
+//   qx/qy/qz: it emits the quad of its X / Y / Z edge (maybe_make_surface_nets_quad, surface_nets.rs:251-334)
+__device__ __forceinline__ void cube_row_bits(const uint32_t* s_neg, int i, int j, const int* upper, uint32_t& vbits, uint32_t& qx, uint32_t& qy,
+                                              uint32_t& qz) {
+    const uint32_t r00 = s_neg[i * G + j], r01 = s_neg[i * G + j + 1], r10 = s_neg[(i + 1) * G + j], r11 = s_neg[(i + 1) * G + j + 1];
+    const uint32_t o = r00 | r01 | r10 | r11, a = r00 & r01 & r10 & r11;
+    vbits = ((o | (o >> 1)) & ~(a & (a >> 1))) & 0x1FFFFu;
+    const uint32_t knz = 0x1FFFEu;  // k != 0
+    qx = (j != 0 && i < upper[0]) ? ((r00 ^ r10) & knz) : 0u;
+    qy = (i != 0 && j < upper[1]) ? ((r00 ^ r01) & knz) : 0u;
+    qz = (i != 0 && j != 0) ? ((r00 ^ (r00 >> 1)) & ((1u << upper[2]) - 1u)) : 0u;
+}
+
+__device__ __forceinline__ bool chunk_exposed(const ivx_chunk_info& ci) {
+    return ci.kind == KIND_NONUNIFORM && (ci.flags & CF_FULLY_OBSCURED) != CF_FULLY_OBSCURED;
+}
+
+__device__ __forceinline__ void upper_limits(const GridView& g, int ci, int cj, int ck, int* upper) {
+    // the upper layer of cubes belongs to the upper neighbour chunk when that chunk is non-uniform (surface_nets.rs:252-261)
+    upper[0] = upper[1] = upper[2] = G - 1;
+    if (neighbour_kind(g, ci + 1, cj, ck) == KIND_NONUNIFORM) upper[0] -= 1;
+    if (neighbour_kind(g, ci, cj + 1, ck) == KIND_NONUNIFORM) upper[1] -= 1;
+    if (neighbour_kind(g, ci, cj, ck + 1) == KIND_NONUNIFORM) upper[2] -= 1;
+}
+
+// Walks the active list (the chunks k_chunk_pre settled have no mesh and got their zero counts there).
+__device__ __forceinline__ void role_sn_count(uint32_t bid, uint32_t nb, SnParams p, uint32_t* __restrict__ counts, uint32_t* __restrict__ group_sums,
+
+                                                  const uint32_t* __restrict__ work_counts, const uint32_t* __restrict__ active_list) {
+    __shared__ uint32_t s_neg[NROWS];
+    __shared__ uint32_t s_acc[2];
+    const GridView& g = p.g;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_active = work_counts[0];
+    for (uint32_t li = ivx_xcd_remap(bid, nb); li < n_active; li += nb) {
+    __syncthreads();  // the previous chunk's LDS use is over
+    const uint32_t entry = active_list[li];
+    const uint32_t chunk = IVX_LIST_CHUNK(entry);
+    if (!IVX_LIST_EXPOSED(entry)) {
+        if (tid == 0) {
+            counts[2 * chunk] = 0;
+            counts[2 * chunk + 1] = 0;
+        }
+        continue;
+    }
+    const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
+    if (tid < 2) s_acc[tid] = 0;
+    load_tile(g, ci, cj, ck, nullptr, nullptr, s_neg, tid);
+    int upper[3];
+    upper_limits(g, ci, cj, ck, upper);
+    __syncthreads();
+    uint32_t nv = 0, nq = 0;
+    for (int cr = tid; cr < NCROWS; cr += 256) {
+        uint32_t vb, qx, qy, qz;
+        cube_row_bits(s_neg, cr / 17, cr % 17, upper, vb, qx, qy, qz);
+        nv += __popc(vb);
+        nq += __popc(qx) + __popc(qy) + __popc(qz);
+    }
+    {  // wave totals in registers, one LDS add per wave (same-address LDS atomics of many lanes are very slow)
+        const uint32_t wv = ivx_wave_sum(nv), wq = ivx_wave_sum(nq);
+        if ((tid & 63u) == 0) {
+            atomicAdd(&s_acc[0], wv);
+            atomicAdd(&s_acc[1], wq);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        counts[2 * chunk] = s_acc[0];
+        counts[2 * chunk + 1] = s_acc[1] * 6u;
+        if (s_acc[1]) {  // first level of the scan over chunks: totals per group of 256 chunks (vertices, indices, submeshes)
+            uint32_t* gs = group_sums + 3 * (chunk >> 8);
+            atomicAdd(gs, s_acc[0]);
+            atomicAdd(gs + 1, s_acc[1] * 6u);
+            atomicAdd(gs + 2, 1u);
+        }
+    }
+    }
+}
+
+// Exclusive scan over chunks in chunk-linear order of (vertices, indices, submesh) with chunks whose
+// index count is zero contributing nothing (mesh.rs:321-323). offsets[2c], offsets[2c+1]; totals at
+// offsets[2n..2n+3); submesh rank at ranks[c].
+__device__ __forceinline__ void role_sn_scan(uint32_t bid, uint32_t nb, uint32_t n_chunks, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ group_sums,
+                                                 uint32_t* __restrict__ offsets, uint32_t* __restrict__ ranks, uint4* __restrict__ emit_items) {
+    // block b = chunks [256 b, 256 b + 256): base = totals of the groups before it, then an ordered block prefix
+    __shared__ uint32_t s_w[3][4];
+    __shared__ uint32_t s_base[3];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t p0 = 0, p1 = 0, p2 = 0;
+    for (uint32_t b = tid; b < bid; b += 256u) {
+        p0 += group_sums[3 * b];
+        p1 += group_sums[3 * b + 1];
+        p2 += group_sums[3 * b + 2];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        p0 += __shfl_down(p0, o, 64);
+        p1 += __shfl_down(p1, o, 64);
+        p2 += __shfl_down(p2, o, 64);
+    }
+    if (lane == 0) {
+        s_w[0][wave] = p0;
+        s_w[1][wave] = p1;
+        s_w[2][wave] = p2;
+    }
+    __syncthreads();
+    if (tid < 3) s_base[tid] = (s_w[tid][0] + s_w[tid][1]) + (s_w[tid][2] + s_w[tid][3]);
+    __syncthreads();
+    const uint32_t b0 = s_base[0], b1 = s_base[1], b2 = s_base[2];
+    const uint32_t c = bid * 256u + tid;
+    uint2 vi = make_uint2(0u, 0u);
+    if (c < n_chunks) vi = reinterpret_cast<const uint2*>(counts)[c];
+    const uint32_t on = vi.y != 0u;
+    const uint32_t sv = on ? vi.x : 0u, si = vi.y, ss = on;
+    uint32_t iv = sv, ii = si, is = ss;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t a0 = __shfl_up(iv, o, 64), a1 = __shfl_up(ii, o, 64), a2 = __shfl_up(is, o, 64);
+        if (lane >= (uint32_t)o) {
+            iv += a0;
+            ii += a1;
+            is += a2;
+        }
+    }
+    __syncthreads();
+    if (lane == 63u) {
+        s_w[0][wave] = iv;
+        s_w[1][wave] = ii;
+        s_w[2][wave] = is;
+    }
+    __syncthreads();
+    uint32_t wv = 0, wi = 0, ws = 0, tv = 0, ti = 0, ts = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; ++w) {
+        if (w < wave) {
+            wv += s_w[0][w];
+            wi += s_w[1][w];
+            ws += s_w[2][w];
+        }
+        tv += s_w[0][w];
+        ti += s_w[1][w];
+        ts += s_w[2][w];
+    }
+    if (c < n_chunks) {
+        reinterpret_cast<uint2*>(offsets)[c] = make_uint2(b0 + wv + iv - sv, b1 + wi + ii - si);
+        ranks[c] = b2 + ws + is - ss;
+        // the chunks with a mesh, in chunk order, for k_sn_emit (a list built here costs nothing; appending to it from the
+        // count pass meant thousands of returning atomics on one address)
+        // one record per meshed chunk: chunk, vertex offset, index offset, vertex count | quads << 16 — everything the emit
+        // pass needs to start loading its tile after a single fetch
+        if (on) emit_items[b2 + ws + is - ss] = make_uint4(c, b0 + wv + iv - sv, b1 + wi + ii - si, vi.x | ((vi.y / 6u) << 16));
+    }
+    if (bid == nb - 1 && tid == 0) {
+        offsets[2 * n_chunks] = b0 + tv;
+        offsets[2 * n_chunks + 1] = b1 + ti;
+        offsets[2 * n_chunks + 2] = b2 + ts;
+    }
+}
+
+// ---- vertex / index materials ----------------------------------------------------------------
+struct VMat {
+    unsigned long long ind, wgt;  // 8 material indices (byte 7 = count) and 8 weights, byte e at bits 8e
+};
+
+__device__ __forceinline__ VMat vertex_materials(const bool* has, const uint8_t* mat) {
+    uint32_t ind[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wgt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t count = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        if (has[c]) {
+            int found = -1;
+#pragma unroll
+            for (int e = 0; e < 7; ++e)
+                if (found < 0 && (uint32_t)e < count && ind[e] == mat[c]) found = e;
+            if (found < 0) {
+#pragma unroll
+                for (int e = 0; e < 7; ++e)
+                    if ((uint32_t)e == count) {
+                        ind[e] = mat[c];
+                        wgt[e] = 1;
+                    }
+                count += 1;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 7; ++e)
+                    if (e == found) wgt[e] += 1;
+            }
+        }
+    }
+    ind[7] = count;
+    // sorting_network_7 (surface_nets.rs:428-446) on weights, descending, 17 compare-and-swaps
+#define CSWAP(i, j)                  \
+    if (wgt[i] < wgt[j]) {           \
+        uint32_t t = wgt[i];         \
+        wgt[i] = wgt[j];             \
+        wgt[j] = t;                  \
+        t = ind[i];                  \
+        ind[i] = ind[j];             \
+        ind[j] = t;                  \
+    }
+    CSWAP(0, 6) CSWAP(1, 5) CSWAP(2, 4) CSWAP(0, 3) CSWAP(1, 2) CSWAP(4, 5) CSWAP(0, 1) CSWAP(2, 3) CSWAP(4, 6) CSWAP(5, 6)
+    CSWAP(1, 4) CSWAP(3, 5) CSWAP(1, 2) CSWAP(3, 4) CSWAP(5, 6) CSWAP(2, 3) CSWAP(4, 5)
+#undef CSWAP
+    VMat r{0ull, 0ull};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        r.ind |= (unsigned long long)(ind[e] & 0xFF) << (8 * e);
+        r.wgt |= (unsigned long long)(wgt[e] & 0xFF) << (8 * e);
+    }
+    return r;
+}
+
+__device__ __forceinline__ uint32_t byte_at(unsigned long long v, uint32_t e) { return (uint32_t)(v >> (8 * e)) & 0xFFu; }
+
+// calculate_index_materials_for_triangle (surface_nets.rs:559-637): out[3] = 8 bytes each (indices[4], weights[4])
+__device__ __forceinline__ void index_materials(const VMat vm[3], unsigned long long out[3]) {
+    const uint32_t cnt0 = byte_at(vm[0].ind, 7), cnt1 = byte_at(vm[1].ind, 7), cnt2 = byte_at(vm[2].ind, 7);
+    if (cnt0 == 1 && cnt1 == 1 && cnt2 == 1) {
+        const uint32_t index = byte_at(vm[0].ind, 0);
+        if (byte_at(vm[1].ind, 0) == index && byte_at(vm[2].ind, 0) == index) {
+            unsigned long long im = (unsigned long long)index | (1ull << 32);
+            out[0] = out[1] = out[2] = im;
+            return;
+        }
+    }
+    const uint32_t cnt[3] = {cnt0, cnt1, cnt2};
+    uint32_t top[4] = {0, 0, 0, 0};
+    uint32_t n_top = 0;
+    uint32_t off[3] = {0, 0, 0};
+    bool done = false;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (!done) {
+            uint32_t w[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) w[i] = byte_at(vm[i].wgt, off[i]);
+            int mx = (w[0] >= w[1]) ? ((w[0] >= w[2]) ? 0 : 2) : ((w[1] >= w[2]) ? 1 : 2);
+            uint32_t wmx = mx == 0 ? w[0] : (mx == 1 ? w[1] : w[2]);
+            if (wmx == 0) {
+                done = true;
+            } else {
+                uint32_t ti = mx == 0 ? byte_at(vm[0].ind, off[0]) : (mx == 1 ? byte_at(vm[1].ind, off[1]) : byte_at(vm[2].ind, off[2]));
+                top[t] = ti;
+                n_top = t + 1;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    for (int guard = 0; guard < 8; ++guard) {
+                        if (off[i] >= cnt[i]) break;
+                        uint32_t x = byte_at(vm[i].ind, off[i]);
+                        bool is_top = false;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) is_top |= ((uint32_t)u < n_top && top[u] == x);
+                        if (!is_top) break;
+                        off[i] += 1;
+                    }
+                }
+            }
+        }
+    }
+    const unsigned long long tops = (unsigned long long)top[0] | ((unsigned long long)top[1] << 8) | ((unsigned long long)top[2] << 16) |
+                                    ((unsigned long long)top[3] << 24);
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        unsigned long long wts = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if ((uint32_t)i < n_top) {
+                uint32_t wv = 0;
+                bool found = false;
+                for (uint32_t j = 0; j < cnt[v]; ++j) {
+                    if (!found && byte_at(vm[v].ind, j) == top[i]) {
+                        wv = byte_at(vm[v].wgt, j);
+                        found = true;
+                    }
+                }
+                wts |= (unsigned long long)wv << (8 * i);
+            }
+        }
+        out[v] = tops | (wts << 32);
+    }
+}
+
+// (amdgpu_waves_per_eu(4): keeps the kernel at <= 128 VGPRs so that four workgroups fit a CU; the LDS footprint, ~38 KB, allows
+// four as well. The kernel is bound by the latency of a workgroup's serial phases, so residency is what buys throughput.)
+template <bool SLOTS>
+__device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams p, float* __restrict__ positions, float* __restrict__ normals,
+                                                 uint32_t* __restrict__ indices, unsigned long long* __restrict__ imats,
+                                                 uint4* __restrict__ vmats, ivx_submesh* __restrict__ submeshes, const uint32_t* __restrict__ emit_count,
+                                                 const uint4* __restrict__ emit_items, uint32_t vcap, uint32_t icap, uint32_t scap,
+                                                 const uint32_t* __restrict__ slots) {
+    __shared__ uint16_t s_quad[768];  // quads of the current batch of 256 vertices: cube id | axis << 13
+    __shared__ __attribute__((aligned(16))) uint8_t s_sd[TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ty[TILE_BYTES];
+    __shared__ uint32_t s_neg[NROWS];
+    __shared__ uint32_t s_vbase[NCROWS + 1];  // first vertex of every cube row
+    __shared__ uint16_t s_surf[NCUBES];       // vertex -> cube id (cube row * 17 + k)
+    __shared__ uint16_t s_map[NCUBES];        // cube id -> vertex
+    __shared__ uint32_t s_wsum[4];
+    const GridView& g = p.g;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_emit = emit_count[0];  // = number of submeshes (k_sn_scan's third total)
+    // bounded grid-stride walk over the chunks that have a mesh
+    for (uint32_t li = bid; li < n_emit; li += nb) {
+    __syncthreads();
+    IVX_T(g, li, 0);
+    const uint4 item = emit_items[li];  // the list is in submesh order: entry li is submesh li
+    const uint32_t chunk = item.x, voff = item.y, ioff = item.z;
+    const uint32_t vcount = item.w & 0xFFFFu, icount = (item.w >> 16) * 6u;
+    // the output buffers keep the capacity of earlier steps; a mesh that outgrew them is re-emitted after the host has
+    // grown the buffers (ivx_voxel_step_collect) — nothing is ever written past the end
+    const uint32_t slot = SLOTS ? slots[li] : li;  // (incremental remesh: the submesh manager's slot of the chunk)
+    if ((size_t)voff + vcount > vcap || (size_t)ioff + icount > icap || slot >= scap) continue;
+    const ivx_chunk_info info = g.info[chunk];
+    const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
+    load_tile(g, ci, cj, ck, s_sd, s_ty, s_neg, tid);
+    int upper[3];
+    upper_limits(g, ci, cj, ck, upper);
+
+    if (tid == 0) {
+        ivx_submesh sm;
+        sm.chunk_indices[0] = (uint32_t)ci + p.x_off;
+        sm.chunk_indices[1] = (uint32_t)cj;
+        sm.chunk_indices[2] = (uint32_t)ck;
+        sm.index_offset = ioff;
+        sm.index_count = icount;
+        // bits: X_DN 0, Y_DN 1, Z_DN 2, X_UP 3, Y_UP 4, Z_UP 5 (mesh.rs:611-635)
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b)
+                for (int c = 0; c < 2; ++c)
+                    sm.is_obscured_from_direction[a][b][c] =
+                        (((info.flags >> (3 * a)) & 1u) && ((info.flags >> (3 * b + 1)) & 1u) && ((info.flags >> (3 * c + 2)) & 1u)) ? 1u : 0u;
+        sm.vertex_offset = voff;
+        sm.vertex_count = vcount;
+        sm.reserved = 0;
+        submeshes[slot] = sm;
+    }
+    IVX_T(g, li, 1);  // tile loaded (this wave's part)
+    __syncthreads();
+    IVX_T(g, li, 2);
+
+    // ---- vertex order: cubes in (i,j,k) scan order (surface_nets.rs:158-185) = cube rows in order, bits ascending.
+    // Thread t owns cube rows 2t and 2t+1 so that thread order = row order for the ordered prefix.
+    {
+        uint32_t vb[2] = {0, 0};
+        const int r0 = 2 * (int)tid;
+        for (int q = 0; q < 2; ++q) {
+            const int cr = r0 + q;
+            if (cr < NCROWS) {
+                uint32_t qx, qy, qz;
+                cube_row_bits(s_neg, cr / 17, cr % 17, upper, vb[q], qx, qy, qz);
+            }
+        }
+        uint32_t total;
+        uint32_t base = block_prefix(__popc(vb[0]) + __popc(vb[1]), s_wsum, tid, total);
+        for (int q = 0; q < 2; ++q) {
+            const int cr = r0 + q;
+            if (cr < NCROWS) {
+                s_vbase[cr] = base;
+                uint32_t m = vb[q];
+                while (m) {
+                    const int k = __ffs(m) - 1;
+                    m &= m - 1;
+                    s_surf[base] = (uint16_t)(cr * 17 + k);
+                    s_map[cr * 17 + k] = (uint16_t)base;
+                    base += 1;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    IVX_T(g, li, 3);  // vertex order built
+
+    // mesh.rs:559-577
+    const float chunk_extent = p.extent * 16.0f;
+    const V3 pos_offset = mk((float)(ci + (int)p.x_off) * chunk_extent - 0.5f * p.extent, (float)cj * chunk_extent - 0.5f * p.extent,
+                             (float)ck * chunk_extent - 0.5f * p.extent);
+
+    // ---- phase A: one thread per vertex (dense) -------------------------------------------------
+    for (uint32_t v = tid; v < vcount; v += 256) {
+        const int cid = s_surf[v];
+        const int cr = cid / 17, k = cid - cr * 17, i = cr / 17, j = cr - i * 17;
+        const int t0 = tix(i, j, k);
+        const int co[8] = {0, 1, RS, RS + 1, G * RS, G * RS + 1, G * RS + RS, G * RS + RS + 1};
+        float d[8];
+        bool has[8];
+        uint8_t mats[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int8_t e = (int8_t)s_sd[t0 + co[c]];
+            d[c] = decode(e);
+            has[c] = e < 0;
+            mats[c] = s_ty[t0 + co[c]];
+        }
+        // centroid of edge intersections (surface_nets.rs:384-418)
+        const int E1[12] = {0, 0, 0, 1, 1, 2, 2, 3, 4, 4, 5, 6};
+        const int E2[12] = {1, 2, 4, 3, 5, 3, 6, 7, 5, 6, 7, 7};
+        int count = 0;
+        V3 sum = mk(0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+            const int c1 = E1[e], c2 = E2[e];
+            const float d1 = d[c1], d2 = d[c2];
+            if (sneg(d1) != sneg(d2)) {
+                count += 1;
+                const float interp1 = d1 / (d1 - d2);
+                const float interp2 = 1.0f - interp1;
+                const V3 p1 = mk((float)((c1 >> 2) & 1), (float)((c1 >> 1) & 1), (float)(c1 & 1));
+                const V3 p2 = mk((float)((c2 >> 2) & 1), (float)((c2 >> 1) & 1), (float)(c2 & 1));
+                sum = add(sum, add(scale(p1, interp2), scale(p2, interp1)));
+            }
+        }
+        const float rc = 1.0f / (float)count;
+        const V3 centroid = scale(sum, rc);
+        // trilinear gradient (object/sdf.rs:603-633)
+        const V3 d00 = sub(mk(d[4], d[2], d[1]), mk(d[0], d[0], d[0]));
+        const V3 d01 = sub(mk(d[5], d[6], d[3]), mk(d[1], d[4], d[2]));
+        const V3 d10 = sub(mk(d[6], d[3], d[5]), mk(d[2], d[1], d[4]));
+        const V3 d11 = sub(mk(d[7], d[7], d[7]), mk(d[3], d[5], d[6]));
+        const V3 o = centroid;
+        const V3 r = sub(mk(1.0f, 1.0f, 1.0f), o);
+        const V3 r_yzx = mk(r.y, r.z, r.x), r_zxy = mk(r.z, r.x, r.y), o_yzx = mk(o.y, o.z, o.x), o_zxy = mk(o.z, o.x, o.y);
+        const V3 grad = add(add(add(mul(mul(r_yzx, r_zxy), d00), mul(mul(r_yzx, o_zxy), d01)), mul(mul(o_yzx, r_zxy), d10)),
+                            mul(mul(o_yzx, o_zxy), d11));
+        const float gl = len3(grad);
+        const V3 normal = mk(grad.x / gl, grad.y / gl, grad.z / gl);
+        const V3 position = add(scale(add(centroid, mk((float)i, (float)j, (float)k)), p.extent), pos_offset);
+        const VMat vm = vertex_materials(has, mats);
+        const size_t gv = (size_t)voff + v;
+        positions[3 * gv + 0] = position.x;
+        positions[3 * gv + 1] = position.y;
+        positions[3 * gv + 2] = position.z;
+        normals[3 * gv + 0] = normal.x;
+        normals[3 * gv + 1] = normal.y;
+        normals[3 * gv + 2] = normal.z;
+        vmats[gv] = make_uint4((uint32_t)vm.ind, (uint32_t)(vm.ind >> 32), (uint32_t)vm.wgt, (uint32_t)(vm.wgt >> 32));
+    }
+    __threadfence_block();
+    __syncthreads();
+    IVX_T(g, li, 4);  // vertices written
+
+    // ---- phase B: quads in surface-point order, X then Y then Z edge (surface_nets.rs:263-301). Per batch of 256 vertices
+    // the quads are first listed in that order (ordered prefix over the vertices' quad counts), then handled one THREAD per
+    // quad: a vertex emits up to three quads, and walking them inside its thread made every pass three quads long.
+    uint32_t qbase = 0;
+    for (uint32_t v0 = 0; v0 < vcount; v0 += 256) {
+        const uint32_t v = v0 + tid;
+        uint32_t qm = 0;
+        uint32_t cid = 0;
+        if (v < vcount) {
+            cid = s_surf[v];
+            const int cr = cid / 17;
+            const int k = cid - cr * 17, i = cr / 17, j = cr - i * 17;
+            uint32_t vb, qx, qy, qz;
+            cube_row_bits(s_neg, i, j, upper, vb, qx, qy, qz);
+            qm = ((qx >> k) & 1u) | (((qy >> k) & 1u) << 1) | (((qz >> k) & 1u) << 2);
+        }
+        uint32_t total;
+        uint32_t slot = block_prefix(__popc(qm), s_wsum, tid, total);  // (ends with a barrier: the previous batch's list is consumed)
+#pragma unroll
+        for (uint32_t axis = 0; axis < 3; ++axis)
+            if ((qm >> axis) & 1u) s_quad[slot++] = (uint16_t)(cid | (axis << 13));
+        __syncthreads();
+        for (uint32_t q = tid; q < total; q += 256) {
+            const uint32_t qd = s_quad[q];
+            const int axis = (int)(qd >> 13);
+            const int qcid = (int)(qd & 0x1FFFu);
+            const int cr = qcid / 17;
+            const int k = qcid - cr * 17, i = cr / 17, j = cr - i * 17;
+            // neighbouring cubes across the two other axes: (axis_b, axis_c) = (Y,Z), (Z,X), (X,Y)
+            const int ab = axis == 0 ? 17 : (axis == 1 ? 1 : 289);
+            const int ac = axis == 0 ? 1 : (axis == 1 ? 289 : 17);
+            const bool n1 = (int8_t)s_sd[tix(i, j, k)] < 0;
+            const bool negative_face = !n1;  // (false,true) => negative face (surface_nets.rs:348-352)
+            const uint32_t v1 = s_map[qcid], v2 = s_map[qcid - ab], v3 = s_map[qcid - ac], v4 = s_map[qcid - ab - ac];
+            const float* P = positions + 3 * (size_t)voff;
+            const V3 q1 = mk(P[3 * v1], P[3 * v1 + 1], P[3 * v1 + 2]), q2 = mk(P[3 * v2], P[3 * v2 + 1], P[3 * v2 + 2]);
+            const V3 q3 = mk(P[3 * v3], P[3 * v3 + 1], P[3 * v3 + 2]), q4 = mk(P[3 * v4], P[3 * v4 + 1], P[3 * v4 + 2]);
+            uint32_t quad[6];
+            if (len3(sub(q1, q4)) < len3(sub(q2, q3))) {
+                if (negative_face) { quad[0] = v1; quad[1] = v4; quad[2] = v2; quad[3] = v1; quad[4] = v3; quad[5] = v4; }
+                else { quad[0] = v1; quad[1] = v2; quad[2] = v4; quad[3] = v1; quad[4] = v4; quad[5] = v3; }
+            } else if (negative_face) { quad[0] = v2; quad[1] = v3; quad[2] = v4; quad[3] = v2; quad[4] = v1; quad[5] = v3; }
+            else { quad[0] = v2; quad[1] = v4; quad[2] = v3; quad[3] = v2; quad[4] = v3; quad[5] = v1; }
+            const size_t io = (size_t)ioff + (size_t)(qbase + q) * 6;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) indices[io + t] = voff + quad[t];
+#pragma unroll
+            for (int tri = 0; tri < 2; ++tri) {
+                VMat vm[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const uint4 raw = vmats[(size_t)voff + quad[3 * tri + c]];
+                    vm[c].ind = (unsigned long long)raw.x | ((unsigned long long)raw.y << 32);
+                    vm[c].wgt = (unsigned long long)raw.z | ((unsigned long long)raw.w << 32);
+                }
+                unsigned long long im[3];
+                index_materials(vm, im);
+                imats[io + 3 * tri + 0] = im[0];
+                imats[io + 3 * tri + 1] = im[1];
+                imats[io + 3 * tri + 2] = im[2];
+            }
+        }
+        qbase += total;
+    }
+    IVX_T(g, li, 5);  // quads written
+    }
+}
+
+
+}  // namespace sn
+}  // namespace ivx_roles

@@ -1,0 +1,263 @@
+// The fused launches of a voxel step (ivx_voxel_step_enqueue): after the derive sweep a step is a dozen table-sized passes over the
+// chunk records (32 768 at 512^3) — occupied ranges, the cross-chunk region merge, flatten, assign, the mesher's count and scan,
+// the sum of the chunk moments, the step's small results — plus the mesher's emit pass. Launched one by one, each of the small ones
+// costs a launch boundary (~4 us as a kernel, ~1.5 us of gap) for a few hundred KB of work: a third of the 512^3 step. Passes
+// that do not depend on each other are therefore hosted as ROLES of one launch: a role owns a range of the launch's block
+// indices and runs exactly the code of its stand-alone kernel (ccl_roles.hpp, sn_roles.hpp, table_roles.hpp).
+//
+//   k_step_post1  after k_derive:   mesher count | region merge by chunk columns | exact local numbering | occupied (per-block
+//                                   slots) | moment partial sums
+//   k_step_post2  after post1:      region merge of multi-region chunks | mesher scan | moments final | occupied final
+//                                   (+ the step's results when the call has no region stage)
+//   k_step_emit   after post2:      region forest flatten | mesher emit
+//   k_step_assign after emit:       component ids (+ the step's results into the host-mapped block)
+//
+// Dependencies inside a launch: none (roles only read what earlier launches wrote). The scratch words the stages start from are
+// preset by the step's first kernel (k_sdf_super or k_chunk_pre), not by a launch of their own.
+#include "ccl_roles.hpp"
+#include "sn_roles.hpp"
+#include "table_roles.hpp"
+
+namespace {
+using namespace ivx_roles;
+
+struct StepArgs {
+    GridView g;
+    float extent;
+    uint32_t x_off;
+    uint32_t n_chunks;
+    // block ranges of the roles (0 = the role is not part of this launch)
+    uint32_t nb[6];
+    // regions
+    const uint8_t* flags;
+    uint8_t* labels;
+    ivx_chunk_info* info;
+    uint32_t* rparent;
+    uint32_t* rcompid;
+    uint32_t* rscalar;
+    uint32_t* multi_list;     // = root_counts of the resolve pass afterwards
+    uint32_t* ccl_group_sums;
+    const uint8_t* touch;
+    // mesher
+    uint32_t* counts;
+    uint32_t* sn_group_sums;
+    uint32_t* offsets;
+    uint32_t* ranks;
+    uint4* emit_items;
+    const uint32_t* work_count;
+    const uint32_t* active_list;
+    float* positions;
+    float* normals;
+    uint32_t* indices;
+    unsigned long long* imats;
+    uint4* vmats;
+    ivx_submesh* submeshes;
+    uint32_t vcap, icap, scap;
+    // occupied / moments
+    const uint32_t* bbox;
+    uint32_t* occ_part;
+    uint32_t n_occ_slots;
+    const float* dens;
+    const double* chunk_moments;
+    double* partials;
+    uint32_t n_partials;
+    double* moments_out;
+    // results
+    uint32_t* host_block;     // null: no gather in this launch
+    const uint32_t* eval_count;
+};
+
+__device__ __forceinline__ sn::SnParams sn_params(const StepArgs& a) {
+    sn::SnParams p;
+    p.g = a.g;
+    p.extent = a.extent;
+    p.x_off = a.x_off;
+    return p;
+}
+
+// roles: 0 mesher count (list-driven), 1 region merge by columns, 2 exact numbering, 3 occupied slots, 4 moment partial sums
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_step_post1(StepArgs a) {
+    uint32_t b = blockIdx.x;
+    if (b < a.nb[0]) {
+        sn::role_sn_count(b, a.nb[0], sn_params(a), a.counts, a.sn_group_sums, a.work_count, a.active_list);
+        return;
+    }
+    b -= a.nb[0];
+    if (b < a.nb[1]) {
+        role_ccl_merge_columns(b, a.nb[1], a.g, a.touch, a.rparent);
+        return;
+    }
+    b -= a.nb[1];
+    if (b < a.nb[2]) {
+        __shared__ CclShared sh;
+        role_ccl_local_exact(b, a.nb[2], sh, a.flags, a.labels, a.info, a.rparent, a.rscalar, a.multi_list);
+        return;
+    }
+    b -= a.nb[2];
+    if (b < a.nb[3]) {
+        role_occupied_partial(b, a.g.cx, a.g.cy, a.g.cz, a.bbox, a.occ_part);
+        return;
+    }
+    b -= a.nb[3];
+    if (b < a.nb[4]) role_inertia_sum(b, a.nb[4], a.g, a.x_off, a.dens, a.chunk_moments, a.partials);
+}
+
+// roles: 0 region merge of multi-region chunks, 1 mesher scan, 2 moments final (1 block), 3 occupied final (1 block),
+// 4 results (1 block; only when the call has no region stage: else k_step_assign gathers)
+__global__ __launch_bounds__(256) void k_step_post2(StepArgs a) {
+    uint32_t b = blockIdx.x;
+    if (b < a.nb[0]) {
+        role_ccl_merge_multi(b, a.nb[0], a.g, a.labels, a.rparent, a.rscalar, a.multi_list);
+        return;
+    }
+    b -= a.nb[0];
+    if (b < a.nb[1]) {
+        sn::role_sn_scan(b, a.nb[1], a.n_chunks, a.counts, a.sn_group_sums, a.offsets, a.ranks, a.emit_items);
+        return;
+    }
+    b -= a.nb[1];
+    if (b < a.nb[2]) {
+        role_inertia_final(a.n_partials, a.extent, a.partials, a.moments_out);
+        return;
+    }
+    b -= a.nb[2];
+    if (b < a.nb[3]) role_occupied_final(a.n_occ_slots, a.occ_part, a.rscalar + 16);
+}
+
+// roles: 0 flatten the region forest, 1 mesher emit
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_step_emit(StepArgs a) {
+    uint32_t b = blockIdx.x;
+    if (b < a.nb[0]) {
+        role_ccl_flatten(b, a.nb[0], a.g, a.rparent, a.multi_list /* root counts */, a.ccl_group_sums);
+        return;
+    }
+    b -= a.nb[0];
+    if (b < a.nb[1])
+        sn::role_sn_emit<false>(b, a.nb[1], sn_params(a), a.positions, a.normals, a.indices, a.imats, a.vmats, a.submeshes, a.offsets + 2 * (size_t)a.n_chunks + 2,
+                                a.emit_items, a.vcap, a.icap, a.scap, nullptr);
+}
+
+// component ids; block 0 also hands the step's small results to the host block
+__global__ __launch_bounds__(256) void k_step_assign(StepArgs a) {
+    role_ccl_assign<true>(blockIdx.x, gridDim.x, a.g, a.rparent, a.multi_list /* root offsets inside a group */, a.ccl_group_sums, a.nb[0], a.rcompid,
+                          a.rscalar);
+}
+
+// the results as a launch of their own (one block), ordered after everything enqueued so far
+__global__ __launch_bounds__(64) void k_step_gather(StepArgs a) {
+    role_result_gather(a.rscalar, a.offsets + 2 * (size_t)a.n_chunks, a.moments_out, a.work_count, a.eval_count, a.host_block, false, 0u);
+}
+
+}  // namespace
+
+static StepArgs make_args(ivx_grid* g) {
+    StepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g = ivx_view(g);
+    a.extent = g->extent;
+    a.x_off = g->x_off;
+    a.n_chunks = g->n_chunks;
+    const uint32_t groups = (g->n_chunks + 255u) / 256u;
+    a.flags = g->flags;
+    a.labels = g->llabel;
+    a.info = g->info;
+    a.rparent = g->rparent;
+    a.rcompid = g->rcompid;
+    a.rscalar = g->rscalar;
+    a.multi_list = g->ccl_scratch;
+    a.ccl_group_sums = g->group_sums;
+    a.touch = g->chunk_touch;
+    a.counts = g->chunk_counts;
+    a.sn_group_sums = g->group_sums + groups;
+    a.offsets = g->chunk_offsets;
+    a.ranks = g->chunk_offsets + 2 * (size_t)g->n_chunks + 4;
+    a.emit_items = reinterpret_cast<uint4*>(g->sn_list);
+    a.work_count = ivx_wc(g);
+    a.active_list = g->active_list;
+    a.positions = g->positions;
+    a.normals = g->normals;
+    a.indices = g->indices;
+    a.imats = reinterpret_cast<unsigned long long*>(g->index_materials);
+    a.vmats = reinterpret_cast<uint4*>(g->vertex_materials);
+    a.submeshes = g->submeshes;
+    a.vcap = (uint32_t)g->vcap;
+    a.icap = (uint32_t)g->icap;
+    a.scap = (uint32_t)g->scap;
+    a.bbox = g->chunk_bbox;
+    a.occ_part = g->occ_part;
+    a.n_occ_slots = groups;
+    a.dens = g->dens_dev;
+    a.chunk_moments = g->chunk_moments;
+    a.partials = g->partials;
+    a.moments_out = g->partials + g->partial_blocks * 10;
+    a.host_block = g->result_host_dev;
+    a.eval_count = g->samp_len ? g->samp_len + g->n_chunks : nullptr;
+    return a;
+}
+
+// `stages`: IVX_STAGE_* of this enqueue call (derive already launched when it is part of the call)
+int ivx_launch_step_post1(ivx_grid* g, uint32_t stages) {
+    StepArgs a = make_args(g);
+    const uint32_t groups = (g->n_chunks + 255u) / 256u;
+    if (stages & IVX_STAGE_REMESH) a.nb[0] = ivx_list_grid(g);
+    if (stages & IVX_STAGE_REGIONS) {
+        a.nb[1] = (g->cc[0] * g->cc[1] + 3u) / 4u;
+        a.nb[2] = g->n_chunks < 128u ? g->n_chunks : 128u;
+    }
+    if (stages & IVX_STAGE_OCCUPIED) a.nb[3] = groups;
+    if (stages & IVX_STAGE_INERTIA) {
+        a.nb[4] = groups < (uint32_t)g->partial_blocks ? groups : (uint32_t)g->partial_blocks;
+        a.n_partials = a.nb[4];
+    }
+    const uint32_t total = a.nb[0] + a.nb[1] + a.nb[2] + a.nb[3] + a.nb[4];
+    if (total == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_step_post1, dim3(total), dim3(256), 0, g->ctx->stream, a);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+int ivx_launch_step_post2(ivx_grid* g, uint32_t stages) {
+    StepArgs a = make_args(g);
+    const uint32_t groups = (g->n_chunks + 255u) / 256u;
+    if (stages & IVX_STAGE_REGIONS) a.nb[0] = g->n_chunks < 64u ? g->n_chunks : 64u;
+    if (stages & IVX_STAGE_REMESH) a.nb[1] = groups;
+    if (stages & IVX_STAGE_INERTIA) {
+        a.nb[2] = 1;
+        a.n_partials = groups < (uint32_t)g->partial_blocks ? groups : (uint32_t)g->partial_blocks;
+    }
+    if (stages & IVX_STAGE_OCCUPIED) a.nb[3] = 1;
+    const uint32_t total = a.nb[0] + a.nb[1] + a.nb[2] + a.nb[3];
+    if (total == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_step_post2, dim3(total), dim3(256), 0, g->ctx->stream, a);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+int ivx_launch_step_emit(ivx_grid* g, uint32_t stages) {
+    StepArgs a = make_args(g);
+    if (stages & IVX_STAGE_REGIONS) a.nb[0] = (g->n_chunks + 255u) / 256u;
+    if (stages & IVX_STAGE_REMESH) a.nb[1] = g->n_chunks < 4096u ? g->n_chunks : 4096u;
+    const uint32_t total = a.nb[0] + a.nb[1];
+    if (total == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_step_emit, dim3(total), dim3(256), 0, g->ctx->stream, a);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+// groups of 256 chunks beyond what the fused assign scans in LDS take the stand-alone resolve path (ivx_launch_ccl_resolve)
+bool ivx_step_assign_fits(const ivx_grid* g) { return (g->n_chunks + 255u) / 256u <= ASSIGN_MAX_GROUPS; }
+
+int ivx_launch_step_assign(ivx_grid* g) {
+    StepArgs a = make_args(g);
+    a.nb[0] = (g->n_chunks + 255u) / 256u;
+    hipLaunchKernelGGL(k_step_assign, dim3(a.nb[0]), dim3(256), 0, g->ctx->stream, a);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+int ivx_launch_step_gather(ivx_grid* g) {
+    StepArgs a = make_args(g);
+    hipLaunchKernelGGL(k_step_gather, dim3(1), dim3(64), 0, g->ctx->stream, a);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}

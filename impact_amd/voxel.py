@@ -202,6 +202,10 @@ class VoxelObject:
             self._region_count = int(out[0]["region_count"])
         return out[0]
 
+    def set_stage_timing(self, enabled: bool):
+        """event records around the timed slots of a step on/off (`ivx_grid_set_stage_timing`)"""
+        check(capi.lib().ivx_grid_set_stage_timing(self.h, 1 if enabled else 0))
+
     def stage_counters(self):
         out = np.zeros(4, dtype=np.uint32)
         check(capi.lib().ivx_grid_stage_counters(self.h, ptr(out)))

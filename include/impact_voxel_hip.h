@@ -220,7 +220,11 @@ int ivx_clip_polyhedron(ivx_grid* parent, const float* planes4, size_t n_planes,
 #define IVX_STAGE_REMESH 16u
 #define IVX_STAGE_INERTIA 32u
 #define IVX_STAGE_ALL 63u
-#define IVX_N_TIMED_STAGES 10 /* sample, derive, occupied, ccl_local, ccl_merge, ccl_resolve, sn_count, sn_scan, sn_emit, inertia */
+/* timed slots of a step: 0 sample (k_sdf_super, k_sdf_prepass, k_sdf_eval), 1 derive (k_chunk_pre, k_derive: flags, chunk state, chunk-local
+ * regions, chunk moments), 2 post1 (one launch: mesher count | region merge by chunk columns | exact local numbering | occupied slots |
+ * moment partial sums), 3 post2 (one launch: multi-region merge | mesher scan | moments and occupied ranges final), 4 emit (one launch:
+ * region forest flatten | mesher emit), 5 assign (component ids), 6..9 unused */
+#define IVX_N_TIMED_STAGES 10
 typedef struct {
     ivx_mesh_counts mesh;
     uint32_t region_count;
@@ -275,6 +279,9 @@ int ivx_voxel_step(ivx_grid*, uint32_t stages, ivx_step_result* out);
  * grows them and repeats the emit pass. */
 int ivx_voxel_step_enqueue(ivx_grid*, uint32_t stages);
 int ivx_voxel_step_collect(ivx_grid*, ivx_step_result* out);
+/* Stage timing (ivx_step_result::stage_ms) records two events per timed slot on the stream; enabled = 0 turns the records off (stage_ms
+ * then reads 0), enabled = 1 (the default) turns them back on. */
+int ivx_grid_set_stage_timing(ivx_grid*, int enabled);
 
 /* ---- multi-GPU: x-slab halos ----------------------------------------------------- */
 /* Face planes of (sdf,type) and boundary chunk info, packed contiguously for torch.distributed /
