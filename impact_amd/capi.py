@@ -132,7 +132,7 @@ EXPORTED_SYMBOLS = [
     "ivx_region_face_bytes", "ivx_region_face_labels", "ivx_region_face_pairs",
     "ivx_world_create", "ivx_world_destroy", "ivx_world_set_bodies", "ivx_world_get_bodies", "ivx_world_set_contacts",
     "ivx_world_step", "ivx_world_step_enqueue", "ivx_world_prepare", "ivx_world_advance_momenta", "ivx_world_solve", "ivx_world_advance_configurations",
-    "ivx_world_contact_state",
+    "ivx_world_set_solver_groups", "ivx_world_solver_info", "ivx_world_contact_state",
 ]
 
 
@@ -216,7 +216,7 @@ def lib():
         "ivx_voxel_step": (i32, [vp, u32, vp]),
         "ivx_voxel_step_enqueue": (i32, [vp, u32]),
         "ivx_voxel_step_collect": (i32, [vp, vp]),
-        "ivx_grid_set_stage_timing": (i32, [vp, i32]),
+        "ivx_grid_set_stage_timing": (i32, [vp, u32]),
         "ivx_halo_pack_enqueue": (i32, [vp, i32, vp]),
         "ivx_halo_unpack_enqueue": (i32, [vp, i32, vp]),
         "ivx_halo_pack_both_enqueue": (i32, [vp, vp, vp, i32]),
@@ -260,6 +260,8 @@ def lib():
         "ivx_world_solve": (i32, [vp]),
         "ivx_world_advance_configurations": (i32, [vp, f32]),
         "ivx_world_contact_state": (i32, [vp, vp, vp, sz, C.POINTER(sz)]),
+        "ivx_world_set_solver_groups": (i32, [vp, u32]),
+        "ivx_world_solver_info": (i32, [vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

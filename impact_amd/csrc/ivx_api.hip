@@ -1994,10 +1994,11 @@ int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
     else if (stages & IVX_STAGE_DERIVE) preset_in_derive = need;
     else if ((rc = ivx_launch_step_preset(g, need))) return rc;
     // a slot's duration runs from the stop event of the slot enqueued just before it, when there is one
-    const bool timing = g->stage_timing_off == 0;
+    const uint32_t timing = ~g->stage_timing_off;  // slots with event records
     hipEvent_t* last_stop = nullptr;
 #define T0(i)                                                      \
-    if (timing) {                                                  \
+    if (!((timing >> (i)) & 1u)) last_stop = nullptr;              \
+    else {                                                         \
         if (last_stop) g->ev_start_ref[i] = last_stop;             \
         else {                                                     \
             IVX_HIP_CHECK(hipEventRecord(g->ev[2 * (i)], s));      \
@@ -2005,7 +2006,7 @@ int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
         }                                                          \
     }
 #define T1(i)                                                      \
-    if (timing) {                                                  \
+    if ((timing >> (i)) & 1u) {                                    \
         IVX_HIP_CHECK(hipEventRecord(g->ev[2 * (i) + 1], s));      \
         last_stop = &g->ev[2 * (i) + 1];                           \
         g->timed_mask |= 1u << (i);                                \
@@ -2075,9 +2076,9 @@ int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
     return IVX_OK;
 }
 
-int ivx_grid_set_stage_timing(ivx_grid* g, int enabled) {
+int ivx_grid_set_stage_timing(ivx_grid* g, uint32_t slot_mask) {
     IVX_REQUIRE(g, IVX_ERR_INVALID, "ivx_grid_set_stage_timing: null grid");
-    g->stage_timing_off = enabled ? 0 : 1;
+    g->stage_timing_off = ~slot_mask;
     return IVX_OK;
 }
 

@@ -100,7 +100,7 @@ struct ivx_grid {
     double* chunk_moments;  // [n_chunks * 10] moments of the NonUniform chunks (fixed summation order whatever the list order)
     uint32_t last_active;   // host: active-list length seen by the last collect (sizes the list-driven grids)
     int planes_compact;  // planes of Void/Uniform chunks may be stale (see ivx_ensure_dense)
-    int stage_timing_off;  // ivx_grid_set_stage_timing(g, 0): no event records around the timed slots of a step
+    uint32_t stage_timing_off;  // timed slots WITHOUT event records (ivx_grid_set_stage_timing; zero-initialised: every slot is timed)
     float* dens_dev;        // [256] voxel type densities
     float dens_host[256];   // what dens_dev holds (entry points that are handed the same table again skip the upload)
     void* dev_scratch;      // grown on demand (node programs, dense label export, region statistics)

@@ -24,6 +24,8 @@
 // One workgroup of 1024 threads walks the levels (a level is ~10^2 contacts; the chain of levels is
 // the critical path, so more workgroups would only add grid-wide barriers). f32 throughout, no FMA
 // contraction, IEEE sqrt/div — same operation order as the oracle.
+#include <cstdlib>
+
 #include "ivx_internal.hpp"
 #include "physics_internal.hpp"
 
@@ -528,6 +530,220 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(uint32_t n_dyn, float f
         }
 }
 
+
+// ---- the solve on several workgroups ------------------------------------------------------------------------------------------------
+// One workgroup runs a level of ~570 chains as 9 waves on 4 SIMDs, three to a SIMD, and a chain is ~1000 dependent f32 instructions:
+// each wave gets a third of its SIMD's issue slots, so the level's critical path is three times what the chain itself costs. Spread
+// over G workgroups of 256 threads (one wave per SIMD, G CUs) the chains run at full issue rate; the price is a grid-wide barrier per
+// level and the bodies' mutable state in memory instead of LDS. Every word another workgroup may read next level — the phase's body
+// state (a 32-byte record per body in `dynst`: v, w | pos, q) and the accumulated impulses — is stored write-through (sc1) and loaded
+// past the L1 (sc1); a storing wave drains its stores (s_waitcnt vmcnt(0)) before the workgroup's barrier, one lane then adds to a
+// monotonic agent-scope counter and polls it with sc1 loads; a workgroup barrier stands between that poll and every load of the next
+// level (MI355X_MICROARCH.md, "Hand-offs measured with sc1 loads in place of the acquire", first row; all G workgroups are resident:
+// G <= 16 blocks of 256 threads on 256 CUs). The schedule, the chain arithmetic and hence the results are those of the
+// single-workgroup kernel, operation for operation.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld16_sc1(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 16);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, float4 f) {
+    u32x4 v;
+    v.x = __float_as_uint(f.x), v.y = __float_as_uint(f.y), v.z = __float_as_uint(f.z), v.w = __float_as_uint(f.w);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byte_off, 0, 16);
+}
+
+// the (up to) four prepared contacts of a chain: they never change during the solve, so the next level's are requested while the
+// current level computes (one wave per SIMD: registers are plentiful)
+struct ChainContacts {
+    PhysContact p0, p1, p2, p3;
+};
+__device__ __forceinline__ void load_chain_contacts(uint32_t item, const PhysContact* __restrict__ pcs, ChainContacts& c) {
+    const uint32_t s0 = item & 0x00FFFFFFu, len = (item >> 24) & 15u;
+    c.p0 = pcs[s0];
+    if (len > 1u) c.p1 = pcs[s0 + 1u];
+    if (len > 2u) c.p2 = pcs[s0 + 2u];
+    if (len > 3u) c.p3 = pcs[s0 + 3u];
+}
+
+// `nxt_item` != 0xFFFFFFFF: the contacts of the thread's item of the next level are loaded into `nxt` behind this chain's own loads
+template <int PHASE>
+__device__ __forceinline__ void run_chain_mg(uint32_t item, uint2 bodies, uint32_t n_dyn, float factor, const PhysContact* __restrict__ pcs,
+                                             __amdgpu_buffer_rsrc_t rs_acc, const PhysBody* __restrict__ cb, __amdgpu_buffer_rsrc_t rs_dyn,
+                                             const ChainContacts& cc, uint32_t nxt_item, ChainContacts& nxt) {
+    const uint32_t s0 = item & 0x00FFFFFFu, len = (item >> 24) & 15u, type = item >> 28;
+    const uint32_t ia = bodies.x, ib = bodies.y;
+    const bool with_acc = type != PHYS_ITEM_POSITIONAL, store_acc = type == PHYS_ITEM_VELOCITY;
+    const PhysBody& A = cb[ia];
+    const PhysBody& B = cb[ib];
+    PairStatic st;
+    st.dyn_a = ia < n_dyn;
+    st.dyn_b = ib < n_dyn;
+    // the mutable state first (it is what the level waited for), then everything that never changes during the solve
+    float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
+    if (st.dyn_a) {
+        a0 = ld16_sc1(rs_dyn, ia * 32u);
+        a1 = ld16_sc1(rs_dyn, ia * 32u + 16u);
+    }
+    if (st.dyn_b) {
+        b0 = ld16_sc1(rs_dyn, ib * 32u);
+        b1 = ld16_sc1(rs_dyn, ib * 32u + 16u);
+    }
+    float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0, c2 = c0, c3 = c0;
+    if (with_acc) {
+        c0 = ld16_sc1(rs_acc, s0 * 16u);
+        if (len > 1u) c1 = ld16_sc1(rs_acc, (s0 + 1u) * 16u);
+        if (len > 2u) c2 = ld16_sc1(rs_acc, (s0 + 2u) * 16u);
+        if (len > 3u) c3 = ld16_sc1(rs_acc, (s0 + 3u) * 16u);
+    }
+    st.ima = A.inv_mass;
+    st.imb = B.inv_mass;
+    st.iia = ldm(A.inv_inertia);
+    st.iib = ldm(B.inv_inertia);
+    PairState x;
+    if (PHASE == 0) {
+        st.pos_a = ld3(A.pos);
+        st.pos_b = ld3(B.pos);
+    }
+    const V3 kva = ld3(A.v), kwa = ld3(A.w), kvb = ld3(B.v), kwb = ld3(B.w);  // (what a kinematic body moves with; unused for dynamic ones)
+    if (nxt_item != 0xFFFFFFFFu) load_chain_contacts(nxt_item, pcs, nxt);
+    if (PHASE == 0) {
+        x.va = st.dyn_a ? mk(a0.x, a0.y, a0.z) : kva;
+        x.wa = st.dyn_a ? mk(a1.x, a1.y, a1.z) : kwa;
+        x.vb = st.dyn_b ? mk(b0.x, b0.y, b0.z) : kvb;
+        x.wb = st.dyn_b ? mk(b1.x, b1.y, b1.z) : kwb;
+    } else {
+        x.pa = st.dyn_a ? mk(a0.x, a0.y, a0.z) : ld3(A.pos);
+        x.qa = st.dyn_a ? Q4{a1.x, a1.y, a1.z, a1.w} : ldq(A.q);
+        x.pb = st.dyn_b ? mk(b0.x, b0.y, b0.z) : ld3(B.pos);
+        x.qb = st.dyn_b ? Q4{b1.x, b1.y, b1.z, b1.w} : ldq(B.q);
+    }
+    run_contact(type, cc.p0, st, x, factor, c0);
+    if (len > 1u) run_contact(type, cc.p1, st, x, factor, c1);
+    if (len > 2u) run_contact(type, cc.p2, st, x, factor, c2);
+    if (len > 3u) run_contact(type, cc.p3, st, x, factor, c3);
+    for (uint32_t c = 4; c < len; ++c) {  // manifolds with more than four points
+        const PhysContact q = pcs[s0 + c];
+        float4 a = with_acc ? ld16_sc1(rs_acc, (s0 + c) * 16u) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        run_contact(type, q, st, x, factor, a);
+        if (store_acc) st16_sc1(rs_acc, (s0 + c) * 16u, a);
+    }
+    if (store_acc) {
+        st16_sc1(rs_acc, s0 * 16u, c0);
+        if (len > 1u) st16_sc1(rs_acc, (s0 + 1u) * 16u, c1);
+        if (len > 2u) st16_sc1(rs_acc, (s0 + 2u) * 16u, c2);
+        if (len > 3u) st16_sc1(rs_acc, (s0 + 3u) * 16u, c3);
+    }
+    if (PHASE == 0) {
+        if (st.dyn_a) {
+            st16_sc1(rs_dyn, ia * 32u, make_float4(x.va.x, x.va.y, x.va.z, 0.0f));
+            st16_sc1(rs_dyn, ia * 32u + 16u, make_float4(x.wa.x, x.wa.y, x.wa.z, 0.0f));
+        }
+        if (st.dyn_b) {
+            st16_sc1(rs_dyn, ib * 32u, make_float4(x.vb.x, x.vb.y, x.vb.z, 0.0f));
+            st16_sc1(rs_dyn, ib * 32u + 16u, make_float4(x.wb.x, x.wb.y, x.wb.z, 0.0f));
+        }
+    } else {
+        if (st.dyn_a) {
+            st16_sc1(rs_dyn, ia * 32u, make_float4(x.pa.x, x.pa.y, x.pa.z, 0.0f));
+            st16_sc1(rs_dyn, ia * 32u + 16u, make_float4(x.qa.x, x.qa.y, x.qa.z, x.qa.w));
+        }
+        if (st.dyn_b) {
+            st16_sc1(rs_dyn, ib * 32u, make_float4(x.pb.x, x.pb.y, x.pb.z, 0.0f));
+            st16_sc1(rs_dyn, ib * 32u + 16u, make_float4(x.qb.x, x.qb.y, x.qb.z, x.qb.w));
+        }
+    }
+}
+
+constexpr uint32_t MG_THREADS = 256u;
+constexpr uint32_t MG_SPIN_LIMIT = 1u << 22;  // a poll loop that never sees its count gives up and flags the launch (every spin is bounded)
+
+// grid-wide barrier of the G resident workgroups: `target` arrivals on the monotonic counter
+__device__ __forceinline__ void mg_barrier(uint32_t* counter, uint32_t target, uint32_t* error) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have landed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t spins = 0;
+        while ((int32_t)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > MG_SPIN_LIMIT) {
+                __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <int PHASE>
+__global__ __launch_bounds__(MG_THREADS) void k_solve_mg(uint32_t n_dyn, float factor, const PhysContact* __restrict__ pcs, float4* __restrict__ accs,
+                                                         uint32_t n_contacts, PhysBody* __restrict__ cb, float4* __restrict__ dynst,
+                                                         const uint32_t* __restrict__ items, const uint2* __restrict__ item_bodies,
+                                                         const uint32_t* __restrict__ level_start, uint32_t n_levels, uint32_t* __restrict__ counter,
+                                                         uint32_t counter_base, uint32_t* __restrict__ error, uint32_t dry) {
+    const uint32_t tid = threadIdx.x, G = gridDim.x, slot = blockIdx.x * MG_THREADS + tid, stride = G * MG_THREADS;
+    const __amdgpu_buffer_rsrc_t rs_dyn = __builtin_amdgcn_make_buffer_rsrc(dynst, 0, n_dyn * 32u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_acc = __builtin_amdgcn_make_buffer_rsrc(accs, 0, n_contacts * 16u, 0x00020000);
+    // the phase's mutable state of the dynamic bodies into the shared records
+    for (uint32_t i = slot; i < n_dyn; i += stride) {
+        const PhysBody& b = cb[i];
+        if (PHASE == 0) {
+            st16_sc1(rs_dyn, i * 32u, make_float4(b.v[0], b.v[1], b.v[2], 0.0f));
+            st16_sc1(rs_dyn, i * 32u + 16u, make_float4(b.w[0], b.w[1], b.w[2], 0.0f));
+        } else {
+            st16_sc1(rs_dyn, i * 32u, make_float4(b.pos[0], b.pos[1], b.pos[2], 0.0f));
+            st16_sc1(rs_dyn, i * 32u + 16u, make_float4(b.q[0], b.q[1], b.q[2], b.q[3]));
+        }
+    }
+    uint32_t arrivals = counter_base + G;
+    mg_barrier(counter, arrivals, error);
+    // the item word and body pair of this thread's chain of the next level are fetched one level ahead (they never change).
+    // (Fetching the next level's prepared contacts ahead as well was tried and measured slower: a level is bound by the chain's
+    // dependent arithmetic and the barrier, not by these loads.)
+    uint32_t lb = level_start[0], le = level_start[1];
+    uint32_t nxt_item = 0xFFFFFFFFu;
+    uint2 nxt_bodies = make_uint2(0u, 0u);
+    if (lb + slot < le) {
+        nxt_item = items[lb + slot];
+        nxt_bodies = item_bodies[lb + slot];
+    }
+    for (uint32_t l = 0; l < n_levels; ++l) {
+        const uint32_t b = lb, e = le;
+        const uint32_t cur_item = nxt_item;
+        const uint2 cur_bodies = nxt_bodies;
+        nxt_item = 0xFFFFFFFFu;
+        if (l + 1 < n_levels) {
+            lb = e;
+            le = level_start[l + 2];
+            if (lb + slot < le) {
+                nxt_item = items[lb + slot];
+                nxt_bodies = item_bodies[lb + slot];
+            }
+        }
+        for (uint32_t i = b + slot; i < e && !(dry & 1u); i += stride) {
+            ChainContacts cc, unused;
+            const uint32_t it = i == b + slot ? cur_item : items[i];
+            const uint2 bo = i == b + slot ? cur_bodies : item_bodies[i];
+            load_chain_contacts(it, pcs, cc);
+            run_chain_mg<PHASE>(it, bo, n_dyn, factor, pcs, rs_acc, cb, rs_dyn, cc, 0xFFFFFFFFu, unused);
+        }
+        arrivals += G;
+        if (!(dry & 2u)) mg_barrier(counter, arrivals, error);
+    }
+    for (uint32_t i = slot; i < n_dyn; i += stride) {
+        PhysBody& b = cb[i];
+        const float4 r0 = ld16_sc1(rs_dyn, i * 32u), r1 = ld16_sc1(rs_dyn, i * 32u + 16u);
+        if (PHASE == 0) {
+            st3(b.v, mk(r0.x, r0.y, r0.z));
+            st3(b.w, mk(r1.x, r1.y, r1.z));
+        } else {
+            st3(b.pos, mk(r0.x, r0.y, r0.z));
+            stq(b.q, Q4{r1.x, r1.y, r1.z, r1.w});
+        }
+    }
+}
+
 }  // namespace
 
 int ivx_launch_phys_prepare_bodies(ivx_world* w) {
@@ -565,9 +781,49 @@ static int launch_solve(ivx_world* w, size_t lds) {
     return IVX_OK;
 }
 
+// number of workgroups the solve is spread over: as many as the widest level fills with one chain per thread, at most 16 (all
+// resident: 256 CUs); 1 = the single-workgroup kernel with the bodies in LDS. ivx_world_set_solver_groups overrides (tests force
+// either path on small scenes).
+static uint32_t solver_groups(const ivx_world* w) {
+    if (w->solver_groups_forced) return w->solver_groups_forced;
+    const uint32_t widest = w->max_level_items[0] > w->max_level_items[1] ? w->max_level_items[0] : w->max_level_items[1];
+    if (widest <= 256u) return 1u;  // (a level that fits one workgroup at one wave per SIMD gains nothing from more)
+    const uint32_t g = (widest + MG_THREADS - 1u) / MG_THREADS;
+    return g < 16u ? g : 16u;
+}
+
+// developer switch (never set in production): IVX_SOLVER_DRY bit 0 = walk the levels without running the chains, bit 1 = without the grid
+// barrier — how tools/time_pile.py splits a level's time into arithmetic and synchronisation (results are garbage with either)
+static uint32_t ivx_solver_dry() {
+    static const uint32_t v = [] {
+        const char* e = getenv("IVX_SOLVER_DRY");
+        return e ? (uint32_t)atoi(e) : 0u;
+    }();
+    return v;
+}
+
+template <int PHASE>
+static int launch_solve_mg(ivx_world* w, uint32_t groups) {
+    const uint32_t base = w->barrier_count;
+    w->barrier_count += groups * (w->n_levels[PHASE] + 1u);
+    hipLaunchKernelGGL((k_solve_mg<PHASE>), dim3(groups), dim3(MG_THREADS), 0, w->ctx->stream, w->n_dyn, w->cfg.positional_correction_factor, w->pc[w->cur],
+                       reinterpret_cast<float4*>(w->acc[w->cur]), w->n_contacts, w->cb, reinterpret_cast<float4*>(w->dynst), w->items + w->item_offset[PHASE],
+                       reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], w->level_start + w->level_offset[PHASE],
+                       w->n_levels[PHASE], w->barrier_words, base, w->barrier_words + 1, ivx_solver_dry());
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
 int ivx_launch_phys_solve(ivx_world* w) {
     if (w->n_contacts == 0) return IVX_OK;
     int rc;
+    const uint32_t groups = solver_groups(w);
+    w->solver_groups_used = groups;
+    if (groups > 1u) {
+        if (w->n_levels[0] && (rc = launch_solve_mg<0>(w, groups))) return rc;
+        if (w->n_levels[1] && (rc = launch_solve_mg<1>(w, groups))) return rc;
+        return IVX_OK;
+    }
     // the phase's mutable body state (24 / 28 bytes per dynamic body) goes to LDS when it fits one CU
     const size_t lds0 = (size_t)w->n_dyn * 24, lds1 = (size_t)w->n_dyn * 28;
     if (w->n_levels[0]) {

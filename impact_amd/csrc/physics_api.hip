@@ -158,6 +158,7 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
     const uint32_t total_passes = n_first + n_passes;
     const size_t total = (size_t)total_passes * nch;
     w->n_levels[phase] = 0;
+    w->max_level_items[phase] = 0;
     if (total == 0) {
         w->level_start_host.push_back(0);
         return;
@@ -210,6 +211,9 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
     for (uint32_t l = 0; l < max_level; ++l) start[l] = start[l + 1];
     start[max_level] = (uint32_t)total;
     w->n_levels[phase] = max_level;
+    uint32_t widest = 0;
+    for (uint32_t l = 0; l < max_level; ++l) widest = std::max(widest, start[l + 1] - start[l]);
+    w->max_level_items[phase] = widest;
 }
 
 }  // namespace
@@ -225,6 +229,12 @@ int ivx_world_create(ivx_ctx* c, const ivx_solver_config* cfg, ivx_world** out) 
     if (cfg) w->cfg = *cfg;
     else w->cfg = ivx_solver_config{8u, 0.4f, 3u, 0.2f};  // ConstraintSolverConfig::default (solver.rs:374-384)
     IVX_REQUIRE(w->cfg.n_iterations + w->cfg.n_positional_correction_iterations < 4096, IVX_ERR_INVALID, "ivx_world_create: too many iterations");
+    if (hipMalloc(reinterpret_cast<void**>(&w->barrier_words), 4 * sizeof(uint32_t)) != hipSuccess ||
+        hipMemsetAsync(w->barrier_words, 0, 4 * sizeof(uint32_t), c->stream) != hipSuccess) {
+        ivx_set_error("ivx_world_create: device allocation failed");
+        delete w;
+        return IVX_ERR_HIP;
+    }
     *out = w;
     return IVX_OK;
 }
@@ -232,7 +242,8 @@ int ivx_world_create(ivx_ctx* c, const ivx_solver_config* cfg, ivx_world** out) 
 void ivx_world_destroy(ivx_world* w) {
     if (!w) return;
     (void)hipStreamSynchronize(w->ctx->stream);
-    void* ptrs[] = {w->dyn, w->kin, w->cb, w->touched, w->contacts, w->prev_slot, w->pc[0], w->pc[1], w->acc[0], w->acc[1], w->items, w->item_bodies, w->level_start};
+    void* ptrs[] = {w->dyn, w->kin, w->cb, w->touched, w->contacts, w->prev_slot, w->pc[0], w->pc[1], w->acc[0], w->acc[1], w->items, w->item_bodies, w->level_start,
+                    w->dynst, w->barrier_words};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (w->ev_ready)
@@ -248,16 +259,17 @@ int ivx_world_set_bodies(ivx_world* w, const ivx_rigid_body* dyn, size_t n_dyn, 
     IVX_HIP_CHECK(hipStreamSynchronize(s));
     const size_t need = n_dyn + n_kin;
     if (need > w->body_cap) {
-        void* ptrs[] = {w->dyn, w->kin, w->cb, w->touched};
+        void* ptrs[] = {w->dyn, w->kin, w->cb, w->touched, w->dynst};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
-        w->dyn = nullptr, w->kin = nullptr, w->cb = nullptr, w->touched = nullptr;
+        w->dyn = nullptr, w->kin = nullptr, w->cb = nullptr, w->touched = nullptr, w->dynst = nullptr;
         w->body_cap = 0;
         const size_t cap = std::max<size_t>(need, 64);
         IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->dyn), cap * sizeof(ivx_rigid_body)));
         IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->kin), cap * sizeof(ivx_kinematic_body)));
         IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->cb), cap * sizeof(PhysBody)));
         IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->touched), cap));
+        IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->dynst), cap * 32));
         w->body_cap = cap;
     }
     if (n_dyn) IVX_HIP_CHECK(hipMemcpy(w->dyn, dyn, n_dyn * sizeof(ivx_rigid_body), hipMemcpyHostToDevice));
@@ -501,6 +513,11 @@ int ivx_world_step(ivx_world* w, float dt, ivx_physics_result* out) {
         out->n_contacts = w->n_contacts;
         out->n_levels[0] = w->n_levels[0];
         out->n_levels[1] = w->n_levels[1];
+        if (w->solver_groups_used > 1u) {
+            uint32_t err = 0;
+            IVX_HIP_CHECK(hipMemcpy(&err, w->barrier_words + 1, sizeof(err), hipMemcpyDeviceToHost));
+            IVX_REQUIRE(err == 0, IVX_ERR_HIP, "ivx_world_step: the solver's grid barrier timed out (a workgroup of the solve was not resident)");
+        }
         uint32_t nb = 0;
         {
             std::vector<uint8_t> t(w->n_dyn);
@@ -518,6 +535,25 @@ int ivx_world_step(ivx_world* w, float dt, ivx_physics_result* out) {
             if (hipEventElapsedTime(&out->stage_ms[i], w->ev[i], w->ev[i + 1]) != hipSuccess) out->stage_ms[i] = 0.0f;
         if (hipEventElapsedTime(&out->stage_ms[4], w->ev[0], w->ev[4]) != hipSuccess) out->stage_ms[4] = 0.0f;
     }
+    return IVX_OK;
+}
+
+int ivx_world_set_solver_groups(ivx_world* w, uint32_t groups) {
+    IVX_REQUIRE(w && groups <= 16u, IVX_ERR_INVALID, "ivx_world_set_solver_groups: at most 16 workgroups");
+    w->solver_groups_forced = groups;
+    return IVX_OK;
+}
+
+int ivx_world_solver_info(ivx_world* w, uint32_t out[8]) {
+    IVX_REQUIRE(w && out, IVX_ERR_INVALID, "ivx_world_solver_info: null argument");
+    out[0] = w->solver_groups_used;
+    out[1] = w->n_levels[0];
+    out[2] = w->n_levels[1];
+    out[3] = w->max_level_items[0];
+    out[4] = w->max_level_items[1];
+    out[5] = (uint32_t)w->chain_start.size() > 0 ? (uint32_t)w->chain_start.size() - 1u : 0u;
+    out[6] = w->n_contacts;
+    out[7] = 0;
     return IVX_OK;
 }
 

@@ -55,6 +55,13 @@ struct ivx_world {
     uint32_t* item_bodies;  // uint2 per item: constrained-body indices of the chain's pair
     uint32_t* level_start;
     uint32_t n_levels[2], item_offset[2], level_offset[2];
+    uint32_t max_level_items[2];  // widest level of each phase's schedule
+    // the solve on several workgroups (physics.hip, k_solve_mg): the phase's mutable body state as shared 32-byte records, the
+    // monotonic arrival counter of the grid barrier + an error word (a bounded poll gave up), how many arrivals have been used up
+    float* dynst;
+    uint32_t* barrier_words;
+    uint32_t barrier_count;
+    uint32_t solver_groups_forced, solver_groups_used;
     int schedule_valid, prepared_fresh;
     hipEvent_t ev[5];
     int ev_ready;

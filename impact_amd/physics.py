@@ -107,6 +107,16 @@ class PhysicsWorld:
         check(capi.lib().ivx_world_contact_state(self.h, ptr(ids), ptr(imp), len(ids), C.byref(n)))
         return ids[: n.value], imp[: n.value]
 
+    def set_solver_groups(self, groups: int = 0):
+        """workgroups the solve is spread over (`ivx_world_set_solver_groups`): 0 = automatic, 1 = one workgroup with the bodies in LDS"""
+        check(capi.lib().ivx_world_set_solver_groups(self.h, int(groups)))
+
+    def solver_info(self) -> dict:
+        out = np.zeros(8, dtype=np.uint32)
+        check(capi.lib().ivx_world_solver_info(self.h, ptr(out)))
+        return {"workgroups": int(out[0]), "levels": [int(out[1]), int(out[2])], "widest_level": [int(out[3]), int(out[4])], "chains": int(out[5]),
+                "contacts": int(out[6])}
+
     # ---- perform_physics_step ------------------------------------------------------------------
     def step(self, step_duration: float) -> np.ndarray:
         """one physics step over the resident bodies and contacts (`ivx_world_step`)"""

@@ -202,9 +202,9 @@ class VoxelObject:
             self._region_count = int(out[0]["region_count"])
         return out[0]
 
-    def set_stage_timing(self, enabled: bool):
-        """event records around the timed slots of a step on/off (`ivx_grid_set_stage_timing`)"""
-        check(capi.lib().ivx_grid_set_stage_timing(self.h, 1 if enabled else 0))
+    def set_stage_timing(self, slot_mask: int = 0xFFFFFFFF):
+        """which timed slots of a step get event records (`ivx_grid_set_stage_timing`): all by default, 0 = none"""
+        check(capi.lib().ivx_grid_set_stage_timing(self.h, int(slot_mask) & 0xFFFFFFFF))
 
     def stage_counters(self):
         out = np.zeros(4, dtype=np.uint32)

@@ -279,9 +279,9 @@ int ivx_voxel_step(ivx_grid*, uint32_t stages, ivx_step_result* out);
  * grows them and repeats the emit pass. */
 int ivx_voxel_step_enqueue(ivx_grid*, uint32_t stages);
 int ivx_voxel_step_collect(ivx_grid*, ivx_step_result* out);
-/* Stage timing (ivx_step_result::stage_ms) records two events per timed slot on the stream; enabled = 0 turns the records off (stage_ms
- * then reads 0), enabled = 1 (the default) turns them back on. */
-int ivx_grid_set_stage_timing(ivx_grid*, int enabled);
+/* Stage timing (ivx_step_result::stage_ms) costs event records on the stream (about 2 us each on the GPU's queue): slot_mask bit i = time
+ * slot i. Default: every slot. 0 turns timing off (stage_ms reads 0); a single bit times one slot with two records per step. */
+int ivx_grid_set_stage_timing(ivx_grid*, uint32_t slot_mask);
 
 /* ---- multi-GPU: x-slab halos ----------------------------------------------------- */
 /* Face planes of (sdf,type) and boundary chunk info, packed contiguously for torch.distributed /
@@ -483,6 +483,12 @@ int ivx_world_advance_momenta(ivx_world*, float dt);
 int ivx_world_solve(ivx_world*);
 int ivx_world_advance_configurations(ivx_world*, float dt);
 /* ContactIDs in solve order and their accumulated (normal, tangent, bitangent) impulses after the last solve */
+/* The solve walks the dependency levels of the exact-order schedule on `groups` workgroups (one chain per thread, a grid-wide barrier per
+ * level) — 0 (default): chosen from the widest level (1 when a level fits one workgroup: the bodies then live in LDS), at most 16. Same
+ * results whatever the number. ivx_world_solver_info: out[0] workgroups used by the last solve, [1..2] levels of the velocity / positional
+ * schedule, [3..4] widest level of each, [5] chains (manifolds), [6] contacts. */
+int ivx_world_set_solver_groups(ivx_world*, uint32_t groups);
+int ivx_world_solver_info(ivx_world*, uint32_t out[8]);
 int ivx_world_contact_state(ivx_world*, uint64_t* ids, float* impulses3, size_t cap, size_t* n_out);
 
 #ifdef __cplusplus

@@ -148,6 +148,34 @@ def test_config4_pile_60_steps(ctx):
     w.close()
 
 
+@pytest.mark.parametrize("groups", [2, 5, 16])
+def test_solve_on_several_workgroups_is_the_same_solve(ctx, groups):
+    """the level schedule walked by `groups` workgroups with a grid barrier per level (k_solve_mg) against the single-workgroup
+    kernel (bodies in LDS): bit-identical bodies and impulses, frame after frame, with contacts that come and go; and against the oracle"""
+    rng = np.random.default_rng(11)
+    bodies, contacts = scenes.sphere_pile_scene(6)
+    bodies["momentum"] += rng.normal(0, 0.05, bodies["momentum"].shape).astype(np.float32)
+    bodies["angular_momentum"] += rng.normal(0, 0.01, bodies["angular_momentum"].shape).astype(np.float32)
+    w1, o = pu.make_pair(ctx, bodies)
+    wg, _ = pu.make_pair(ctx, bodies)
+    w1.set_solver_groups(1)
+    wg.set_solver_groups(groups)
+    manifolds = contacts.reshape(-1, 4)
+    full, half = np.arange(len(manifolds)), np.arange(0, len(manifolds), 2)
+    for s, keep in enumerate([full, full, half, full[::-1], full, half, full, full]):
+        cs = manifolds[keep].reshape(-1).copy()
+        pu.step_both(w1, o, cs, 0.004)
+        wg.perform_physics_step(cs, 0.004)
+        assert wg.solver_info()["workgroups"] == groups and w1.solver_info()["workgroups"] == 1
+        d1, dg = w1.bodies()[0], wg.bodies()[0]
+        for f in pu.STATE_FIELDS:
+            np.testing.assert_array_equal(dg[f].view(np.uint32), d1[f].view(np.uint32), err_msg=f"frame {s} {f}")
+        np.testing.assert_array_equal(wg.contact_state()[1].view(np.uint32), w1.contact_state()[1].view(np.uint32))
+        pu.assert_bodies_close(dg, o.bodies()[0], what=f"frame {s}: ")
+    w1.close()
+    wg.close()
+
+
 def test_contacts_come_and_go(ctx):
     """ConstraintCache order after removals (swap_remove) and additions, with spinning / moving bodies and
     friction; ragged inputs: empty contact list, bodies without contacts"""

@@ -17,6 +17,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 ctx = Context(0)
 bodies, contacts = scenes.sphere_pile_scene(n)
 w = PhysicsWorld(ctx)
+if "--groups" in sys.argv:
+    w.set_solver_groups(int(sys.argv[sys.argv.index("--groups") + 1]))
 w.set_bodies(bodies)
 t0 = time.perf_counter()
 w.prepare_constraints(contacts)
@@ -31,7 +33,7 @@ for _ in range(K):
     acc += r["stage_ms"]
 t3 = time.perf_counter()
 print(f"n={n} bodies={len(bodies)} contacts={len(contacts)} levels={r['n_levels']} set_contacts(host)={1e3 * (t1 - t0):.2f} ms "
-      f"step wall={1e3 * (t3 - t2) / K:.3f} ms", {k: round(float(v) / K, 4) for k, v in zip(capi.PHYSICS_STAGE_NAMES, acc)})
+      f"step wall={1e3 * (t3 - t2) / K:.3f} ms", {k: round(float(v) / K, 4) for k, v in zip(capi.PHYSICS_STAGE_NAMES, acc)}, w.solver_info())
 if "--oracle" in sys.argv:
     import oracle_lib as ol
 
