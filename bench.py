@@ -653,7 +653,7 @@ def main():
         workload = f"{scene_name} -> {gen.grid_shape()[0]}^3 grid = {cc[0] * 16}^3 stored voxels ({obj.n_chunks} chunks)"
         parallelism = "single GPU"
     else:
-        from impact_amd.distributed import SlabStepper, TorchComm
+        from impact_amd.distributed import NativeComm, NativeSlabStepper, SlabStepper, TorchComm, native_step
 
         if args.scaling == "weak" and args.workload == "asteroid":
             # BASELINE.json's config 5: the config-2 asteroid with all lengths scaled so that every rank keeps the 512^3
@@ -661,19 +661,37 @@ def main():
             graph = scenes.asteroid_scene(args.scale * world ** (1.0 / 3.0))
             scene_name = f"config-2 SDF asteroid x{args.scale * world ** (1.0 / 3.0):.3f} (config 5 at N=8)"
             scaling = "weak"
-        stepper = SlabStepper(ctx, graph, dens, rank, world, torch)
-        comm = TorchComm(dist, torch, rank, world)
-        obj = stepper.obj
+        if dist.get_backend() == "nccl":
+            # the per-step protocol runs inside the library (ivx_slabs_step_*: grouped ncclSend / ncclRecv + one ncclAllGather on the
+            # library's stream); this script only hands the communicator's unique id from rank 0 to the others
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(NativeComm.unique_id()), dtype=torch.uint8))
+            if world > 1:
+                dist.broadcast(uid, 0)
+            comm = NativeComm(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()))
+            stepper = NativeSlabStepper(ctx, comm, graph, dens, rank)
+            obj = stepper.obj
+            transport = "RCCL (ncclSend / ncclRecv / ncclAllGather inside the library)"
 
-        def step():
-            body_world.step_enqueue(0.005)  # on the same stream, ahead of the slab's kernels; the protocol's one wait covers it
-            r = comm.run(stepper)
-            return {"stage_ms": r.stage_ms, "mesh": {"n_vertices": r.mesh_counts[0], "n_indices": r.mesh_counts[1]},
-                    "region_count": r.region_count}
+            def step():
+                body_world.step_enqueue(0.005)  # on the same stream, ahead of the slab's kernels; the protocol's one wait covers it
+                r = native_step([stepper])[0]
+                return {"stage_ms": r.stage_ms, "mesh": {"n_vertices": r.mesh_counts[0], "n_indices": r.mesh_counts[1]}, "region_count": r.region_count}
+        else:  # host-staged protocol check (IVX_BENCH_BACKEND=gloo): the same phases driven from Python over torch.distributed
+            stepper = SlabStepper(ctx, graph, dens, rank, world, torch)
+            comm = TorchComm(dist, torch, rank, world)
+            obj = stepper.obj
+            transport = f"torch.distributed {dist.get_backend()} (host-staged protocol check)"
+
+            def step():
+                body_world.step_enqueue(0.005)
+                r = comm.run(stepper)
+                return {"stage_ms": r.stage_ms, "mesh": {"n_vertices": r.mesh_counts[0], "n_indices": r.mesh_counts[1]}, "region_count": r.region_count}
 
         workload = (f"{scene_name} -> {stepper.global_shape} stored grid, x-slabs of {obj.chunk_counts[0]} chunk planes per rank "
                     f"({obj.n_chunks} chunks on rank 0)")
-        parallelism = f"x-slab domain decomposition over {world} GPUs, 1-voxel halos + region equivalences over {dist.get_backend()}"
+        parallelism = f"x-slab domain decomposition over {world} GPUs, 1-voxel halos + region equivalences over {transport}"
 
     def barrier():
         if dist is not None:
@@ -811,7 +829,12 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     body_world.close()
-    obj.close()
+    if slabs:
+        stepper.close()  # (the slab's buffers, then its grid)
+        if hasattr(comm, "close"):
+            comm.close()
+    else:
+        obj.close()
     ctx.close()
 
 

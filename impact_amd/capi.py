@@ -53,6 +53,11 @@ REGION_DESC_DTYPE = np.dtype(
 )
 MESH_COUNTS_DTYPE = np.dtype([("n_vertices", "<u4"), ("n_indices", "<u4"), ("n_submeshes", "<u4"), ("reserved", "<u4")])
 N_TIMED_STAGES = 10
+SLAB_RESULT_DTYPE = np.dtype(
+    [("region_count", "<u4"), ("local_region_count", "<u4"), ("first_local_component", "<u4"), ("reserved", "<u4"), ("moments", "<f8", (10,)),
+     ("occupied", "<u4", (12,)), ("mesh", MESH_COUNTS_DTYPE), ("vertex_offset", "<u8"), ("index_offset", "<u8"), ("total_triangles", "<u8"),
+     ("stage_ms", "<f4", (10,)), ("reserved2", "<f4", (2,))]
+)
 # timed slots of a step (include/impact_voxel_hip.h, IVX_N_TIMED_STAGES): the table-sized passes after the derive sweep run as roles of
 # four fused launches; 6..9 are unused
 STAGE_NAMES = ["sdf_sample", "derive", "post1", "post2", "emit", "assign", "unused6", "unused7", "unused8", "unused9"]
@@ -132,6 +137,8 @@ EXPORTED_SYMBOLS = [
     "ivx_region_face_bytes", "ivx_region_face_labels", "ivx_region_face_pairs",
     "ivx_world_create", "ivx_world_destroy", "ivx_world_set_bodies", "ivx_world_get_bodies", "ivx_world_set_contacts",
     "ivx_world_step", "ivx_world_step_enqueue", "ivx_world_prepare", "ivx_world_advance_momenta", "ivx_world_solve", "ivx_world_advance_configurations",
+    "ivx_comm_unique_id", "ivx_comm_init", "ivx_comm_init_local", "ivx_comm_destroy", "ivx_slab_create", "ivx_slab_destroy",
+    "ivx_slabs_step_enqueue", "ivx_slabs_step_collect", "ivx_slab_region_map",
     "ivx_world_set_solver_groups", "ivx_world_solver_info", "ivx_world_contact_state",
 ]
 
@@ -260,6 +267,15 @@ def lib():
         "ivx_world_solve": (i32, [vp]),
         "ivx_world_advance_configurations": (i32, [vp, f32]),
         "ivx_world_contact_state": (i32, [vp, vp, vp, sz, C.POINTER(sz)]),
+        "ivx_comm_unique_id": (i32, [vp]),
+        "ivx_comm_init": (i32, [vp, i32, i32, vp, C.POINTER(vp)]),
+        "ivx_comm_init_local": (i32, [vp, i32, C.POINTER(vp)]),
+        "ivx_comm_destroy": (None, [vp]),
+        "ivx_slab_create": (i32, [vp, vp, i32, C.POINTER(vp)]),
+        "ivx_slab_destroy": (None, [vp]),
+        "ivx_slabs_step_enqueue": (i32, [vp, sz]),
+        "ivx_slabs_step_collect": (i32, [vp, sz, vp]),
+        "ivx_slab_region_map": (i32, [vp, i32, vp, sz, C.POINTER(sz)]),
         "ivx_world_set_solver_groups": (i32, [vp, u32]),
         "ivx_world_solver_info": (i32, [vp, vp]),
     }

@@ -1,0 +1,450 @@
+// (e) multi-GPU — the per-step protocol of the x-slab decomposition behind the C ABI (no reference counterpart:
+// lars-frogner/Impact runs this path in one process). One process per GPU owns one slab (ivx_grid with an x chunk offset); per step
+//   1. sample                                 -> one-voxel x-face planes (sdf, type) + the face layer's chunk records to both neighbours
+//   2. derive (+ regions, moments, occupied)  -> the planes again (post-demotion chunk kinds) + the faces' slab-local component ids
+//   3. remesh, the slab's record              -> ONE all-gather of the records' heads; every rank finishes the same union-find
+// everything stream-ordered on the context's stream: kernels, packing, RCCL traffic (grouped ncclSend / ncclRecv over the two
+// xGMI links to the neighbours, one small ncclAllGather); the host waits once per step. Ghost layers are read in place from the
+// receive buffers (ivx_halo_unpack_enqueue).
+//
+// Two transports behind one driver:
+//   * RCCL (ivx_comm_init): librccl is opened at run time (the copy already loaded in the process — e.g. the one PyTorch bundles —
+//     else librccl.so from the loader path / IVX_RCCL_LIB); the library has no link-time dependency on it, and a missing RCCL fails
+//     loudly when a communicator is asked for;
+//   * in-process (ivx_comm_init_local): all ranks are slabs of ONE process on ONE GPU, neighbour exchange and all-gather are
+//     device-to-device copies on the same stream. This is how the decomposition is checked bit for bit against the oracle on the
+//     single GPU the test box has (tests/test_gpu_slabs.py), through exactly the driver code the RCCL ranks run.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+#include "ivx_internal.hpp"
+
+namespace {
+
+constexpr size_t HEAD_PAIRS = 64;  // pairs that ride in the first all-gather (a slab boundary is crossed by a handful of components)
+constexpr size_t HEAD_WORDS = 28 + 2 * HEAD_PAIRS;
+
+// the part of the RCCL API the protocol uses (types as in rccl.h; resolved with dlsym)
+typedef struct ncclComm* ncclComm_t;
+struct ncclUniqueId_ {
+    char internal[128];
+};
+typedef int ncclResult_t;
+enum { NCCL_INT8 = 0, NCCL_UINT8 = 1, NCCL_INT64 = 4 };
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId_*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId_, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
+int load_rccl() {
+    if (g_rccl.handle) return IVX_OK;
+    void* h = nullptr;
+    if (const char* e = getenv("IVX_RCCL_LIB")) h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);    // a copy the process has loaded already (PyTorch's)
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    IVX_REQUIRE(h, IVX_ERR_HIP, "RCCL is not available: %s", dlerror());
+    RcclApi a;
+    a.handle = h;
+#define SYM(field, name)                                                              \
+    *reinterpret_cast<void**>(&a.field) = dlsym(h, name);                             \
+    IVX_REQUIRE(a.field, IVX_ERR_HIP, "RCCL symbol %s not found", name)
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(Send, "ncclSend");
+    SYM(Recv, "ncclRecv");
+    SYM(AllGather, "ncclAllGather");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl = a;
+    return IVX_OK;
+}
+
+#define IVX_NCCL_CHECK(expr)                                                                                   \
+    do {                                                                                                       \
+        const ncclResult_t _r = (expr);                                                                        \
+        if (_r != 0) {                                                                                         \
+            ivx_set_error("%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(_r), __FILE__, __LINE__);     \
+            return IVX_ERR_HIP;                                                                                \
+        }                                                                                                      \
+    } while (0)
+
+}  // namespace
+
+struct ivx_comm {
+    ivx_ctx* ctx;
+    int nranks, rank;  // rank = -1: in-process communicator (every rank lives here)
+    ncclComm_t nccl;
+};
+
+struct ivx_slab {
+    ivx_comm* comm;
+    ivx_grid* grid;
+    int rank;
+    size_t halo_bytes, face_bytes, rec_words;
+    uint8_t* send[2];
+    uint8_t* recv[2];
+    unsigned long long* record;    // this slab's record (device)
+    unsigned long long* gathered;  // nranks records (device)
+    std::vector<unsigned long long> host_records;
+    bool has_lo, has_hi;
+    int enqueued;
+};
+
+namespace {
+
+int exchange(ivx_slab** slabs, size_t n, size_t nbytes) {
+    ivx_comm* c = slabs[0]->comm;
+    hipStream_t s = c->ctx->stream;
+    if (c->rank >= 0) {  // RCCL: one slab per process, its two neighbours
+        ivx_slab* sl = slabs[0];
+        if (!sl->has_lo && !sl->has_hi) return IVX_OK;
+        IVX_NCCL_CHECK(g_rccl.GroupStart());
+        if (sl->has_lo) {
+            IVX_NCCL_CHECK(g_rccl.Send(sl->send[0], nbytes, NCCL_UINT8, sl->rank - 1, c->nccl, s));
+            IVX_NCCL_CHECK(g_rccl.Recv(sl->recv[0], nbytes, NCCL_UINT8, sl->rank - 1, c->nccl, s));
+        }
+        if (sl->has_hi) {
+            IVX_NCCL_CHECK(g_rccl.Send(sl->send[1], nbytes, NCCL_UINT8, sl->rank + 1, c->nccl, s));
+            IVX_NCCL_CHECK(g_rccl.Recv(sl->recv[1], nbytes, NCCL_UINT8, sl->rank + 1, c->nccl, s));
+        }
+        IVX_NCCL_CHECK(g_rccl.GroupEnd());
+        return IVX_OK;
+    }
+    // in-process: the send buffers are read before anything overwrites them (all copies are enqueued here, in order)
+    for (size_t i = 0; i + 1 < n; ++i) {
+        IVX_HIP_CHECK(hipMemcpyAsync(slabs[i]->recv[1], slabs[i + 1]->send[0], nbytes, hipMemcpyDeviceToDevice, s));
+        IVX_HIP_CHECK(hipMemcpyAsync(slabs[i + 1]->recv[0], slabs[i]->send[1], nbytes, hipMemcpyDeviceToDevice, s));
+    }
+    return IVX_OK;
+}
+
+int all_gather(ivx_slab** slabs, size_t n, size_t words) {
+    ivx_comm* c = slabs[0]->comm;
+    hipStream_t s = c->ctx->stream;
+    if (c->rank >= 0) {
+        ivx_slab* sl = slabs[0];
+        if (c->nranks == 1) {
+            IVX_HIP_CHECK(hipMemcpyAsync(sl->gathered, sl->record, words * 8, hipMemcpyDeviceToDevice, s));
+            return IVX_OK;
+        }
+        IVX_NCCL_CHECK(g_rccl.AllGather(sl->record, sl->gathered, words, NCCL_INT64, c->nccl, s));
+        return IVX_OK;
+    }
+    for (size_t i = 0; i < n; ++i)  // every rank's view is the same: one gathered block, kept by rank 0's slab
+        IVX_HIP_CHECK(hipMemcpyAsync(slabs[0]->gathered + i * words, slabs[i]->record, words * 8, hipMemcpyDeviceToDevice, s));
+    return IVX_OK;
+}
+
+void install_ghosts(ivx_slab* sl) {
+    for (int side = 0; side < 2; ++side) {
+        const bool has = side ? sl->has_hi : sl->has_lo;
+        if (has) (void)ivx_halo_unpack_enqueue(sl->grid, side, sl->recv[side]);
+        else (void)ivx_halo_clear(sl->grid, side);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ivx_comm_unique_id(void* out128) {
+    IVX_REQUIRE(out128, IVX_ERR_INVALID, "ivx_comm_unique_id: null argument");
+    int rc = load_rccl();
+    if (rc) return rc;
+    ncclUniqueId_ id;
+    IVX_NCCL_CHECK(g_rccl.GetUniqueId(&id));
+    memcpy(out128, &id, sizeof(id));
+    return IVX_OK;
+}
+
+int ivx_comm_init(ivx_ctx* c, int nranks, int rank, const void* unique_id128, ivx_comm** out) {
+    IVX_REQUIRE(c && out && nranks >= 1 && rank >= 0 && rank < nranks && (unique_id128 || nranks == 1), IVX_ERR_INVALID, "ivx_comm_init: bad argument");
+    *out = nullptr;
+    ivx_comm* m = new (std::nothrow) ivx_comm();
+    IVX_REQUIRE(m, IVX_ERR_CAPACITY, "ivx_comm_init: out of host memory");
+    m->ctx = c;
+    m->nranks = nranks;
+    m->rank = rank;
+    m->nccl = nullptr;
+    if (nranks > 1) {
+        int rc = load_rccl();
+        if (rc) {
+            delete m;
+            return rc;
+        }
+        ncclUniqueId_ id;
+        memcpy(&id, unique_id128, sizeof(id));
+        if (hipSetDevice(c->device) != hipSuccess || g_rccl.CommInitRank(&m->nccl, nranks, id, rank) != 0) {
+            ivx_set_error("ivx_comm_init: ncclCommInitRank failed (rank %d of %d)", rank, nranks);
+            delete m;
+            return IVX_ERR_HIP;
+        }
+    }
+    *out = m;
+    return IVX_OK;
+}
+
+int ivx_comm_init_local(ivx_ctx* c, int nranks, ivx_comm** out) {
+    IVX_REQUIRE(c && out && nranks >= 1, IVX_ERR_INVALID, "ivx_comm_init_local: bad argument");
+    ivx_comm* m = new (std::nothrow) ivx_comm();
+    IVX_REQUIRE(m, IVX_ERR_CAPACITY, "ivx_comm_init_local: out of host memory");
+    m->ctx = c;
+    m->nranks = nranks;
+    m->rank = -1;
+    m->nccl = nullptr;
+    *out = m;
+    return IVX_OK;
+}
+
+void ivx_comm_destroy(ivx_comm* m) {
+    if (!m) return;
+    if (m->nccl) (void)g_rccl.CommDestroy(m->nccl);
+    delete m;
+}
+
+int ivx_slab_create(ivx_comm* m, ivx_grid* g, int rank, ivx_slab** out) {
+    IVX_REQUIRE(m && g && out && rank >= 0 && rank < m->nranks && (m->rank < 0 || rank == m->rank), IVX_ERR_INVALID, "ivx_slab_create: bad argument");
+    IVX_REQUIRE(g->ctx == m->ctx, IVX_ERR_INVALID, "ivx_slab_create: grid and communicator belong to different contexts");
+    *out = nullptr;
+    ivx_slab* sl = new (std::nothrow) ivx_slab();
+    IVX_REQUIRE(sl, IVX_ERR_CAPACITY, "ivx_slab_create: out of host memory");
+    sl->comm = m;
+    sl->grid = g;
+    sl->rank = rank;
+    sl->halo_bytes = ivx_halo_bytes(g);
+    sl->face_bytes = ivx_region_face_bytes(g);
+    sl->rec_words = ivx_step_record_words();
+    sl->has_lo = rank > 0;
+    sl->has_hi = rank + 1 < m->nranks;
+    sl->enqueued = 0;
+    const size_t msg = (sl->halo_bytes + sl->face_bytes + 255) & ~(size_t)255;
+    bool ok = true;
+    for (int s = 0; s < 2; ++s) {
+        ok = ok && hipMalloc(reinterpret_cast<void**>(&sl->send[s]), msg) == hipSuccess;
+        ok = ok && hipMalloc(reinterpret_cast<void**>(&sl->recv[s]), msg) == hipSuccess;
+    }
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl->record), sl->rec_words * 8) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&sl->gathered), sl->rec_words * 8 * (size_t)m->nranks) == hipSuccess;
+    if (!ok) {
+        ivx_set_error("ivx_slab_create: device allocation failed");
+        ivx_slab_destroy(sl);
+        return IVX_ERR_HIP;
+    }
+    *out = sl;
+    return IVX_OK;
+}
+
+void ivx_slab_destroy(ivx_slab* sl) {
+    if (!sl) return;
+    (void)hipStreamSynchronize(sl->comm->ctx->stream);
+    (void)ivx_halo_clear(sl->grid, 0);
+    (void)ivx_halo_clear(sl->grid, 1);
+    for (int s = 0; s < 2; ++s) {
+        if (sl->send[s]) (void)hipFree(sl->send[s]);
+        if (sl->recv[s]) (void)hipFree(sl->recv[s]);
+    }
+    if (sl->record) (void)hipFree(sl->record);
+    if (sl->gathered) (void)hipFree(sl->gathered);
+    delete sl;
+}
+
+// One step of the protocol for the slabs of this process (RCCL: exactly one; in-process communicator: all ranks, in rank order).
+// Nothing in here waits for the GPU.
+int ivx_slabs_step_enqueue(ivx_slab** slabs, size_t n) {
+    IVX_REQUIRE(slabs && n >= 1 && slabs[0], IVX_ERR_INVALID, "ivx_slabs_step_enqueue: null argument");
+    ivx_comm* c = slabs[0]->comm;
+    IVX_REQUIRE(c->rank >= 0 ? n == 1 : n == (size_t)c->nranks, IVX_ERR_INVALID, "ivx_slabs_step_enqueue: %zu slabs for a communicator of %d ranks (%s)", n,
+                c->nranks, c->rank >= 0 ? "RCCL: one slab per process" : "in-process: all of them");
+    for (size_t i = 0; i < n; ++i)
+        IVX_REQUIRE(slabs[i] && slabs[i]->comm == c && (c->rank >= 0 || slabs[i]->rank == (int)i), IVX_ERR_INVALID, "ivx_slabs_step_enqueue: slab %zu out of order", i);
+    int rc;
+    // 1. sample, exchange the face planes
+    for (size_t i = 0; i < n; ++i) {
+        ivx_slab* sl = slabs[i];
+        if ((rc = ivx_voxel_step_enqueue(sl->grid, IVX_STAGE_SAMPLE))) return rc;
+        if (sl->has_lo || sl->has_hi)
+            if ((rc = ivx_halo_pack_both_enqueue(sl->grid, sl->has_lo ? sl->send[0] : nullptr, sl->has_hi ? sl->send[1] : nullptr, 0))) return rc;
+    }
+    if ((rc = exchange(slabs, n, slabs[0]->halo_bytes))) return rc;
+    // 2. derived state + slab-local regions (+ moments and occupied ranges: they need nothing more from the neighbours); the planes
+    // again, now with the post-demotion chunk kinds the mesher's upper-layer rule needs, and the faces' component ids behind them
+    for (size_t i = 0; i < n; ++i) {
+        ivx_slab* sl = slabs[i];
+        install_ghosts(sl);
+        if ((rc = ivx_voxel_step_enqueue(sl->grid, IVX_STAGE_DERIVE | IVX_STAGE_OCCUPIED | IVX_STAGE_REGIONS | IVX_STAGE_INERTIA))) return rc;
+        if (sl->has_lo || sl->has_hi)
+            if ((rc = ivx_halo_pack_both_enqueue(sl->grid, sl->has_lo ? sl->send[0] : nullptr, sl->has_hi ? sl->send[1] : nullptr, 1))) return rc;
+    }
+    if ((rc = exchange(slabs, n, slabs[0]->halo_bytes + slabs[0]->face_bytes))) return rc;
+    // 3. remesh (ghost layers in place), the slab's record, the one small all-gather
+    for (size_t i = 0; i < n; ++i) {
+        ivx_slab* sl = slabs[i];
+        install_ghosts(sl);
+        if (sl->has_hi)
+            if ((rc = ivx_region_face_pairs_enqueue(sl->grid, 1, sl->recv[1] + sl->halo_bytes))) return rc;
+        if ((rc = ivx_voxel_step_enqueue(sl->grid, IVX_STAGE_REMESH))) return rc;
+        if ((rc = ivx_step_record_enqueue(sl->grid, sl->record))) return rc;
+    }
+    if ((rc = all_gather(slabs, n, HEAD_WORDS))) return rc;
+    for (size_t i = 0; i < n; ++i) slabs[i]->enqueued = 1;
+    return IVX_OK;
+}
+
+// Waits once, finishes the cross-slab union-find on the host (a handful of components and pairs) and fills the global results of
+// every slab of this process. The same arithmetic on every rank: all see the same records.
+int ivx_slabs_step_collect(ivx_slab** slabs, size_t n, ivx_slab_result* out) {
+    IVX_REQUIRE(slabs && n >= 1 && out && slabs[0] && slabs[0]->enqueued, IVX_ERR_STATE, "ivx_slabs_step_collect: nothing enqueued");
+    ivx_comm* c = slabs[0]->comm;
+    hipStream_t s = c->ctx->stream;
+    const int world = c->nranks;
+    ivx_slab* keeper = slabs[0];
+    std::vector<unsigned long long>& rec = keeper->host_records;
+    size_t words = HEAD_WORDS;
+    rec.resize((size_t)world * keeper->rec_words);
+    IVX_HIP_CHECK(hipMemcpyAsync(rec.data(), keeper->gathered, (size_t)world * words * 8, hipMemcpyDeviceToHost, s));
+    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    unsigned long long max_pairs = 0;
+    for (int r = 0; r < world; ++r) max_pairs = std::max(max_pairs, rec[(size_t)r * words + 1]);
+    if (max_pairs > HEAD_PAIRS) {  // (the same decision on every rank) a rank lists more pairs than the head holds: the full records
+        words = keeper->rec_words;
+        int rc = all_gather(slabs, n, words);
+        if (rc) return rc;
+        IVX_HIP_CHECK(hipMemcpyAsync(rec.data(), keeper->gathered, (size_t)world * words * 8, hipMemcpyDeviceToHost, s));
+        IVX_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    // error flags: decided on the gathered data every rank holds, so that all ranks fail together
+    unsigned long long flags = 0;
+    for (int r = 0; r < world; ++r) flags |= rec[(size_t)r * words + 17];
+    std::vector<size_t> offs(world + 1, 0);
+    for (int r = 0; r < world; ++r) offs[r + 1] = offs[r] + (size_t)rec[(size_t)r * words];
+    std::vector<uint32_t> parent(offs[world]);
+    for (size_t i = 0; i < parent.size(); ++i) parent[i] = (uint32_t)i;
+    auto find = [&](uint32_t x) {
+        while (parent[x] != x) {
+            parent[x] = parent[parent[x]];
+            x = parent[x];
+        }
+        return x;
+    };
+    bool pair_overflow = false;
+    for (int r = 0; r + 1 < world; ++r) {
+        const unsigned long long* q = rec.data() + (size_t)r * words;
+        const size_t np = (size_t)q[1];
+        if (np > IVX_MAX_FACE_PAIRS) {
+            pair_overflow = true;
+            continue;
+        }
+        for (size_t k = 0; k < np; ++k) {
+            const uint32_t a = find((uint32_t)(offs[r] + q[28 + 2 * k])), b = find((uint32_t)(offs[r + 1] + q[29 + 2 * k]));
+            if (a != b) parent[std::max(a, b)] = std::min(a, b);
+        }
+    }
+    // roots are minimal members, so numbering them in index order = ordering the regions by first occurrence
+    std::vector<uint32_t> region_id(parent.size(), 0xFFFFFFFFu), ids(parent.size());
+    uint32_t n_regions = 0;
+    for (size_t i = 0; i < parent.size(); ++i) {
+        const uint32_t root = find((uint32_t)i);
+        if (region_id[root] == 0xFFFFFFFFu) region_id[root] = n_regions++;
+        ids[i] = region_id[root];
+    }
+    double moments[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = 0; r < world; ++r)  // fixed rank order: bitwise reproducible
+        for (int q = 0; q < 10; ++q) {
+            double v;
+            memcpy(&v, &rec[(size_t)r * words + 18 + q], 8);
+            moments[q] += v;
+        }
+    uint32_t occ[12] = {0};
+    bool any = false;
+    for (int r = 0; r < world; ++r) {
+        const unsigned long long* q = rec.data() + (size_t)r * words;
+        if (q[3] == 0) continue;  // (hi of the chunk range along x: zero = the slab holds no voxel)
+        for (int k = 0; k < 12; ++k) {
+            const uint32_t v = (uint32_t)q[2 + k];
+            occ[k] = !any ? v : ((k & 1) ? std::max(occ[k], v) : std::min(occ[k], v));
+        }
+        any = true;
+    }
+    unsigned long long tri_total = 0, voff = 0, ioff = 0;
+    std::vector<unsigned long long> voffs(world), ioffs(world);
+    for (int r = 0; r < world; ++r) {
+        voffs[r] = voff;
+        ioffs[r] = ioff;
+        voff += rec[(size_t)r * words + 14];
+        ioff += rec[(size_t)r * words + 15];
+        tri_total += rec[(size_t)r * words + 15] / 3;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        ivx_slab* sl = slabs[i];
+        ivx_slab_result& o = out[i];
+        memset(&o, 0, sizeof(o));
+        ivx_step_result local;
+        int rc = ivx_voxel_step_collect(sl->grid, &local);  // the stream is idle: stage timings + the mesh-buffer check
+        if (rc) return rc;
+        const int r = sl->rank;
+        const unsigned long long* q = rec.data() + (size_t)r * words;
+        o.region_count = n_regions;
+        o.local_region_count = (uint32_t)q[0];
+        o.first_local_component = (uint32_t)offs[r];
+        memcpy(o.moments, moments, sizeof(moments));
+        memcpy(o.occupied, occ, sizeof(occ));
+        o.mesh.n_vertices = (uint32_t)q[14];
+        o.mesh.n_indices = (uint32_t)q[15];
+        o.mesh.n_submeshes = (uint32_t)q[16];
+        o.vertex_offset = voffs[r];
+        o.index_offset = ioffs[r];
+        o.total_triangles = tri_total;
+        memcpy(o.stage_ms, local.stage_ms, sizeof(o.stage_ms));
+        sl->enqueued = 0;
+    }
+    // the map slab-local component -> global region of every rank stays with the keeper for ivx_slab_region_map
+    keeper->host_records.resize((size_t)world * words + ids.size() + (size_t)world + 1);
+    unsigned long long* tail = keeper->host_records.data() + (size_t)world * words;
+    for (int r = 0; r <= world; ++r) tail[r] = offs[r];
+    for (size_t i = 0; i < ids.size(); ++i) tail[world + 1 + i] = ids[i];
+    IVX_REQUIRE((flags & 1u) == 0, IVX_ERR_CAPACITY, "ivx_slabs_step_collect: a chunk has more than 254 local regions");
+    IVX_REQUIRE((flags & 4u) == 0, IVX_ERR_CAPACITY, "ivx_slabs_step_collect: a slab has 65535 or more components: its face ids do not fit the 16-bit exchange format");
+    IVX_REQUIRE(!pair_overflow, IVX_ERR_CAPACITY, "ivx_slabs_step_collect: more than %d cross-slab region pairs on one face", IVX_MAX_FACE_PAIRS);
+    return IVX_OK;
+}
+
+// global region id of every slab-local component of rank `rank` (after ivx_slabs_step_collect on the communicator's first slab
+// of this process): out[k] for k < local_region_count
+int ivx_slab_region_map(ivx_slab* keeper, int rank, uint32_t* out, size_t cap, size_t* n_out) {
+    IVX_REQUIRE(keeper && n_out && rank >= 0 && rank < keeper->comm->nranks, IVX_ERR_INVALID, "ivx_slab_region_map: bad argument");
+    const int world = keeper->comm->nranks;
+    const std::vector<unsigned long long>& h = keeper->host_records;
+    size_t base = 0;
+    // the tail sits behind world * words record words: find it from the vector's size (offs[world] entries + world + 1 offsets)
+    for (size_t words : {HEAD_WORDS, keeper->rec_words}) {
+        const size_t b = (size_t)world * words;
+        if (h.size() >= b + (size_t)world + 1 && h.size() == b + (size_t)world + 1 + (size_t)h[b + world]) base = b;
+    }
+    IVX_REQUIRE(base, IVX_ERR_STATE, "ivx_slab_region_map: no collected step");
+    const size_t lo = (size_t)h[base + rank], hi = (size_t)h[base + rank + 1];
+    *n_out = hi - lo;
+    IVX_REQUIRE(hi - lo <= cap || !out, IVX_ERR_CAPACITY, "ivx_slab_region_map: %zu components exceed capacity %zu", hi - lo, cap);
+    if (out)
+        for (size_t k = lo; k < hi; ++k) out[k - lo] = (uint32_t)h[base + world + 1 + k];
+    return IVX_OK;
+}
+
+}  // extern "C"

@@ -343,3 +343,88 @@ def run_slabs_in_process(steppers):
                 records = torch.stack([r.record.t[: r.words] for r in reqs]).cpu().numpy()
                 replies = [records] * len(gens)
     return results
+
+
+# ---- the protocol behind the C ABI (impact_amd/csrc/slab_comm.cpp) ------------------------------------------------------------------------
+# `ivx_comm_*` / `ivx_slab*`: the same phases as SlabStepper.phases, driven inside the library on its own stream with RCCL opened at
+# run time (or, for several slabs in one process, device copies). Python keeps the launcher: who is which rank, how the unique id
+# travels.
+class NativeComm:
+    """`ivx_comm`: RCCL communicator of this rank (`unique_id` = the 128 bytes rank 0 made with `NativeComm.unique_id()`), or — with
+    `local=True` — an in-process communicator whose `world` slabs all live in this process on one GPU."""
+
+    def __init__(self, ctx: Context, world: int, rank: int = 0, unique_id: bytes | None = None, local: bool = False):
+        self.ctx, self.world, self.rank, self.local = ctx, world, rank, local
+        h = C.c_void_p()
+        if local:
+            check(capi.lib().ivx_comm_init_local(ctx.h, world, C.byref(h)))
+        else:
+            buf = (C.c_char * 128).from_buffer_copy(unique_id) if unique_id is not None else None
+            check(capi.lib().ivx_comm_init(ctx.h, world, rank, buf, C.byref(h)))
+        self.h = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_char * 128)()
+        check(capi.lib().ivx_comm_unique_id(buf))
+        return bytes(buf)
+
+    def close(self):
+        if getattr(self, "h", None):
+            capi.lib().ivx_comm_destroy(self.h)
+            self.h = None
+
+
+class NativeSlabStepper:
+    """One x-slab stepped through `ivx_slabs_step_enqueue` / `ivx_slabs_step_collect`."""
+
+    def __init__(self, ctx: Context, comm: NativeComm, graph, densities, rank: int, voxel_extent: float = 1.0, voxel_type: int = 0):
+        self.comm, self.rank, self.world = comm, rank, comm.world
+        self.gen = SDFVoxelGenerator(voxel_extent, graph, voxel_type)
+        cc = self.gen.chunk_counts()
+        if cc[0] < self.world:
+            raise ValueError(f"{cc[0]} chunk planes cannot be split over {self.world} ranks")
+        self.global_chunk_counts = cc
+        self.global_shape = tuple(c * 16 for c in cc)
+        x0, x1 = slab_ranges(cc[0], self.world)[rank]
+        self.x_range = (x0, x1)
+        self.obj = VoxelObject(ctx, (x1 - x0, cc[1], cc[2]), voxel_extent, x0, cc[0])
+        self.obj.set_sdf_program(self.gen)
+        self.obj.set_densities(densities)
+        h = C.c_void_p()
+        check(capi.lib().ivx_slab_create(comm.h, self.obj.h, rank, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            capi.lib().ivx_slab_destroy(self.h)
+            self.h = None
+        self.obj.close()
+
+
+def native_step(steppers):
+    """one step of the slabs of this process (RCCL: one; in-process communicator: all ranks in order) -> list of SlabResult"""
+    n = len(steppers)
+    arr = (C.c_void_p * n)(*[s.h for s in steppers])
+    check(capi.lib().ivx_slabs_step_enqueue(arr, n))
+    out = np.zeros(n, dtype=capi.SLAB_RESULT_DTYPE)
+    check(capi.lib().ivx_slabs_step_collect(arr, n, ptr(out)))
+    results = []
+    for s, o in zip(steppers, out):
+        cap = max(1, int(o["local_region_count"]))
+        m = np.zeros(cap, dtype=np.uint32)
+        got = C.c_size_t(0)
+        check(capi.lib().ivx_slab_region_map(steppers[0].h, s.rank, ptr(m), cap, C.byref(got)))
+        r = SlabResult()
+        r.region_count = int(o["region_count"])
+        r.local_region_count = int(o["local_region_count"])
+        r.region_of_local = m[: got.value]
+        r.moments = np.array(o["moments"], dtype=np.float64)
+        r.occupied = np.array(o["occupied"], dtype=np.uint32)
+        r.mesh_counts = (int(o["mesh"]["n_vertices"]), int(o["mesh"]["n_indices"]), int(o["mesh"]["n_submeshes"]))
+        r.vertex_offset, r.index_offset = int(o["vertex_offset"]), int(o["index_offset"])
+        r.total_triangles = int(o["total_triangles"])
+        r.stage_ms = np.asarray(o["stage_ms"], dtype=np.float64)
+        s.obj._region_count = r.local_region_count
+        results.append(r)
+    return results

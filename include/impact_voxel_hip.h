@@ -319,6 +319,43 @@ int ivx_region_face_pairs_enqueue(ivx_grid*, int side, const void* neighbour_fac
 size_t ivx_step_record_words(void);
 int ivx_step_record_enqueue(ivx_grid*, void* device_record);
 
+/* ---- multi-GPU: the whole per-step protocol behind the C ABI ----------------------------------------------------------------------
+ * One process per GPU owns one x-slab (an ivx_grid created with its chunk offset) and an RCCL communicator; ivx_slabs_step_enqueue
+ * runs sample -> face exchange -> derive + regions + moments -> face exchange (+ component ids) -> remesh -> record all-gather, all
+ * stream-ordered on the context's stream (grouped ncclSend / ncclRecv with the two x neighbours, one small ncclAllGather);
+ * ivx_slabs_step_collect waits once, finishes the cross-slab union-find of the region equivalences and hands back the global results.
+ * A Rust host binds these five entry points and keeps only the launcher (who is rank r, how the 128-byte unique id reaches the ranks).
+ *   ivx_comm_unique_id   rank 0 makes the id (ncclGetUniqueId) and distributes it by its own means
+ *   ivx_comm_init        ncclCommInitRank on the context's device; librccl is opened at run time (no link-time dependency)
+ *   ivx_comm_init_local  an in-process communicator: all `nranks` slabs live in THIS process on one GPU and exchange by device copies —
+ *                        the same driver code, used to check the decomposition on a single-GPU box
+ * slabs: RCCL communicator -> exactly one slab (this rank's); in-process communicator -> all of them, in rank order. */
+typedef struct ivx_comm ivx_comm;
+typedef struct ivx_slab ivx_slab;
+typedef struct {
+    uint32_t region_count;           /* connected regions of the whole grid */
+    uint32_t local_region_count;     /* components of this slab */
+    uint32_t first_local_component;  /* index of this slab's component 0 in the concatenation over ranks */
+    uint32_t reserved;
+    double moments[10];              /* of the whole grid, summed in rank order */
+    uint32_t occupied[12];           /* global occupied chunk / voxel ranges (layout of ivx_step_result::occupied) */
+    ivx_mesh_counts mesh;            /* this slab's mesh */
+    uint64_t vertex_offset, index_offset; /* of this slab's mesh in the concatenation over ranks */
+    uint64_t total_triangles;
+    float stage_ms[IVX_N_TIMED_STAGES];
+    float reserved2[2];
+} ivx_slab_result;
+int ivx_comm_unique_id(void* out128);
+int ivx_comm_init(ivx_ctx*, int nranks, int rank, const void* unique_id128, ivx_comm** out);
+int ivx_comm_init_local(ivx_ctx*, int nranks, ivx_comm** out);
+void ivx_comm_destroy(ivx_comm*);
+int ivx_slab_create(ivx_comm*, ivx_grid* slab_grid, int rank, ivx_slab** out);
+void ivx_slab_destroy(ivx_slab*);
+int ivx_slabs_step_enqueue(ivx_slab** slabs, size_t n);
+int ivx_slabs_step_collect(ivx_slab** slabs, size_t n, ivx_slab_result* out /* n results */);
+/* global region id of every slab-local component of `rank` (after a collect; `first_slab` = slabs[0] of that call) */
+int ivx_slab_region_map(ivx_slab* first_slab, int rank, uint32_t* out, size_t cap, size_t* n_out);
+
 /* ---- a15-a19: rigid bodies + sequential-impulses contact solve (engine/crates/impact_physics) ----- */
 /* DynamicRigidBody, #[repr(C)], 152 bytes (src/rigid_body.rs:94-103). Matrices are Matrix3C (column-major),
  * orientation is UnitQuaternionC (x, y, z, w). */

@@ -8,22 +8,34 @@ import pytest
 
 import oracle_lib as ol
 from impact_amd import capi, scenes
-from impact_amd.distributed import SlabStepper, run_slabs_in_process
+from impact_amd.distributed import NativeComm, NativeSlabStepper, SlabStepper, native_step, run_slabs_in_process
 
 pytestmark = pytest.mark.gpu
 
 
-def run_and_compare(ctx, graph, world, expect_regions=None, extent=1.0):
+@pytest.fixture(params=["native", "python"])
+def driver(request):
+    """native: the protocol inside the library (`ivx_slabs_step_*` over an in-process communicator: the code the RCCL ranks run, with
+    device copies for transport); python: the same phases driven from impact_amd/distributed.py (what the gloo protocol test shares)"""
+    return request.param
+
+
+def run_and_compare(ctx, graph, world, expect_regions=None, extent=1.0, driver="native"):
     import torch
 
     dens = np.linspace(0.5, 2.0, 256).astype(np.float32)
     o = ol.OracleObject.from_sdf(graph, extent, 0)
     o.update_occupied_voxel_ranges()
     o.compute_all_derived_state()
-    steppers = [SlabStepper(ctx, graph, dens, r, world, torch, extent) for r in range(world)]
+    comm = None
+    if driver == "native":
+        comm = NativeComm(ctx, world, local=True)
+        steppers = [NativeSlabStepper(ctx, comm, graph, dens, r, extent) for r in range(world)]
+    else:
+        steppers = [SlabStepper(ctx, graph, dens, r, world, torch, extent) for r in range(world)]
     try:
         for _ in range(2):  # twice: the second pass starts from a dirty state (ghosts, labels, mesh buffers)
-            results = run_slabs_in_process(steppers)
+            results = native_step(steppers) if driver == "native" else run_slabs_in_process(steppers)
         cc = o.chunk_counts
         assert steppers[0].global_chunk_counts == cc
         o_sdf, o_typ, o_flg, o_lab, o_info = o.export_dense()
@@ -92,24 +104,62 @@ def run_and_compare(ctx, graph, world, expect_regions=None, extent=1.0):
     finally:
         for s in steppers:
             s.close()
+        if comm is not None:
+            comm.close()
 
 
 @pytest.mark.parametrize("world", [2, 4])
-def test_asteroid_256_in_slabs(ctx, world):
+def test_asteroid_256_in_slabs(ctx, world, driver):
     """BASELINE config 2 body, split in 2 and 4 x-slabs (config 5's decomposition at 1/4 scale)"""
-    run_and_compare(ctx, scenes.asteroid_scene(), world, expect_regions=1)
+    run_and_compare(ctx, scenes.asteroid_scene(), world, expect_regions=1, driver=driver)
 
 
-def test_fracture_256_in_3_slabs(ctx):
+def test_fracture_256_in_3_slabs(ctx, driver):
     """config 3: 8 octants; an uneven 3-way split puts a slab boundary inside four of them"""
-    run_and_compare(ctx, scenes.fracture_scene(), 3, expect_regions=8)
+    run_and_compare(ctx, scenes.fracture_scene(), 3, expect_regions=8, driver=driver)
 
 
-def test_asteroid_row_in_slabs(ctx):
+def test_asteroid_row_in_slabs(ctx, driver):
     """the weak-scaling bench workload at small scale: one body per slab joined by a bar"""
-    run_and_compare(ctx, scenes.asteroid_row_scene(3, 0.25), 3, expect_regions=1)
+    run_and_compare(ctx, scenes.asteroid_row_scene(3, 0.25), 3, expect_regions=1, driver=driver)
 
 
-def test_two_spheres_cut_between(ctx):
+def test_two_spheres_cut_between(ctx, driver):
     """a slab boundary in the gap between two bodies: empty ghost planes, two regions"""
-    run_and_compare(ctx, scenes.two_spheres_scene(25.0, 60.0), 2, expect_regions=2, extent=0.5)
+    run_and_compare(ctx, scenes.two_spheres_scene(25.0, 60.0), 2, expect_regions=2, extent=0.5, driver=driver)
+
+
+def test_headline_512_in_8_slabs(ctx):
+    """the strong-scaling configuration of the metric — the 512^3 asteroid in 8 x-slabs of 4 chunk planes — through the native driver,
+    all eight slabs on this one GPU: global results against the single-grid step of the same scene"""
+    from impact_amd.voxel import SDFVoxelGenerator, VoxelObject
+
+    graph = scenes.asteroid_scene(2.05)
+    dens = np.ones(256, dtype=np.float32)
+    gen = SDFVoxelGenerator(1.0, graph, 0)
+    whole = VoxelObject(ctx, gen.chunk_counts(), 1.0)
+    whole.set_sdf_program(gen)
+    whole.set_densities(dens)
+    ref = whole.step(capi.STAGE_ALL)
+    comm = NativeComm(ctx, 8, local=True)
+    steppers = [NativeSlabStepper(ctx, comm, graph, dens, r) for r in range(8)]
+    try:
+        results = native_step(steppers)
+        assert results[0].region_count == int(ref["region_count"]) == 1
+        assert results[0].total_triangles == int(ref["mesh"]["n_indices"]) // 3
+        assert sum(r.mesh_counts[0] for r in results) == int(ref["mesh"]["n_vertices"])
+        np.testing.assert_allclose(results[0].moments, np.asarray(ref["moments"]["m64"]), rtol=1e-12)
+        np.testing.assert_array_equal(results[0].occupied, np.asarray(ref["occupied"]))
+        # every slab's voxel bytes equal the whole grid's
+        w_sdf, w_typ, w_flg, _, _ = whole.download(labels=False, info=False)
+        per = gen.chunk_counts()[1] * gen.chunk_counts()[2] * 4096
+        for s in steppers:
+            x0, x1 = s.x_range
+            g_sdf, g_typ, g_flg, _, _ = s.obj.download(labels=False, info=False)
+            np.testing.assert_array_equal(g_sdf, w_sdf[x0 * per:x1 * per])
+            np.testing.assert_array_equal(g_flg, w_flg[x0 * per:x1 * per])
+    finally:
+        for s in steppers:
+            s.close()
+        comm.close()
+        whole.close()
