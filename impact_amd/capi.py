@@ -129,7 +129,7 @@ EXPORTED_SYMBOLS = [
     "ivx_derive_state", "ivx_occupied_ranges",
     "ivx_remesh", "ivx_mesh_download", "ivx_mesh_device_ptr",
     "ivx_inertia",
-    "ivx_label_regions", "ivx_region_labels_download", "ivx_regions_describe", "ivx_split_off_smallest_region", "ivx_clip_polyhedron", "ivx_mesh_sync", "ivx_mesh_modifications", "ivx_mesh_report_synchronized", "ivx_absorb_sphere", "ivx_absorb_capsule", "ivx_absorb_mutual", "ivx_offset_reference_point", "ivx_apply_updated_inertial_properties", "ivx_extracted_object_dynamics", "ivx_handle_voxel_object_after_removing_voxels", "ivx_sphere_voxel_object_contacts", "ivx_plane_voxel_object_contacts", "ivx_capsule_voxel_object_contacts", "ivx_collision_probes_recompute", "ivx_collision_probes_sync", "ivx_collision_probes_download", "ivx_mutual_voxel_object_contacts",
+    "ivx_label_regions", "ivx_region_labels_download", "ivx_regions_describe", "ivx_split_off_smallest_region", "ivx_clip_polyhedron", "ivx_copy_polyhedra", "ivx_mesh_sync", "ivx_mesh_modifications", "ivx_mesh_report_synchronized", "ivx_absorb_sphere", "ivx_absorb_capsule", "ivx_absorb_mutual", "ivx_offset_reference_point", "ivx_apply_updated_inertial_properties", "ivx_extracted_object_dynamics", "ivx_handle_voxel_object_after_removing_voxels", "ivx_sphere_voxel_object_contacts", "ivx_plane_voxel_object_contacts", "ivx_capsule_voxel_object_contacts", "ivx_collision_probes_recompute", "ivx_collision_probes_sync", "ivx_collision_probes_download", "ivx_mutual_voxel_object_contacts",
     "ivx_grid_set_sdf_program", "ivx_grid_set_densities", "ivx_voxel_step", "ivx_voxel_step_enqueue", "ivx_voxel_step_collect", "ivx_grid_set_stage_timing",
     "ivx_halo_pack_enqueue", "ivx_halo_unpack_enqueue", "ivx_halo_pack_both_enqueue", "ivx_region_face_labels_enqueue", "ivx_region_face_pairs_enqueue",
     "ivx_step_record_words", "ivx_step_record_enqueue",
@@ -218,6 +218,7 @@ def lib():
         "ivx_regions_describe": (i32, [vp, vp, vp, sz, C.POINTER(sz)]),
         "ivx_split_off_smallest_region": (i32, [vp, C.POINTER(vp), vp, C.POINTER(i32), vp]),
         "ivx_clip_polyhedron": (i32, [vp, vp, sz, vp, i32, C.POINTER(vp), vp, C.POINTER(i32)]),
+        "ivx_copy_polyhedra": (i32, [vp, vp, vp, vp, sz, vp, vp, vp]),
         "ivx_grid_set_sdf_program": (i32, [vp, vp, sz, u32, vp, vp, C.c_uint8]),
         "ivx_grid_set_densities": (i32, [vp, vp]),
         "ivx_voxel_step": (i32, [vp, u32, vp]),

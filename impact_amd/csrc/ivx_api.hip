@@ -10,6 +10,8 @@
 #include <new>
 #include <vector>
 
+#include <type_traits>
+
 #include "ivx_internal.hpp"
 
 static thread_local char g_error[512] = "";
@@ -364,42 +366,58 @@ int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32
     g->gx = global_x_chunks ? global_x_chunks : cc[0];
     const size_t cols = (size_t)cc[1] * cc[2];
     int rc = IVX_OK;
-    auto A = [&](int r) {
-        if (rc == IVX_OK && r != IVX_OK) rc = r;
+    // ONE device allocation for everything whose size follows from the chunk counts, carved at 256-byte boundaries: a grid used to
+    // cost ~45 hipMalloc calls, which was most of the price of creating the small grids that split-off and polyhedron clips make
+    // (one per fragment). Pass 1 sizes the arena, pass 2 hands out the pointers.
+    size_t arena_bytes = 0;
+    char* arena = nullptr;
+    auto carve = [&](auto** p, size_t count) {
+        using T = std::remove_pointer_t<std::remove_pointer_t<decltype(p)>>;
+        const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+        if (arena) *p = reinterpret_cast<T*>(arena + arena_bytes);
+        arena_bytes += bytes;
     };
-    A(dev_alloc(&g->sdf, g->n_vox));
-    A(dev_alloc(&g->type, g->n_vox));
-    A(dev_alloc(&g->flags, g->n_vox));
-    A(dev_alloc(&g->llabel, g->n_vox));
-    A(dev_alloc(&g->info, (size_t)g->n_chunks));
-    A(dev_alloc(&g->chunk_bbox, (size_t)g->n_chunks));
-    for (int s = 0; s < 2; ++s) {
-        A(dev_alloc(&g->ghost_sdf[s], cols * 256));
-        A(dev_alloc(&g->ghost_type[s], cols * 256));
-        A(dev_alloc(&g->ghost_info[s], cols));
-    }
-    A(dev_alloc(&g->chunk_counts, (size_t)g->n_chunks * 2));
-    A(dev_alloc(&g->chunk_offsets, (size_t)g->n_chunks * 3 + 8));
     g->partial_blocks = 2048;
-    A(dev_alloc(&g->partials, g->partial_blocks * 10 + 16));
-    A(dev_alloc(&g->rparent, (size_t)g->n_chunks * 256));
-    A(dev_alloc(&g->rcompid, (size_t)g->n_chunks * 256));
-    A(dev_alloc(&g->rscalar, (size_t)64));
-    A(dev_alloc(&g->ccl_scratch, (size_t)g->n_chunks * 2));
-    A(dev_alloc(&g->sn_list, (size_t)g->n_chunks * 4));  // one uint4 record per meshed chunk
-    A(dev_alloc(&g->group_sums, (size_t)((g->n_chunks + 255u) / 256u) * 4 + 4));
-    A(dev_alloc(&g->dens_dev, (size_t)256));
-    A(dev_alloc(&g->work_counts, (size_t)8));
-    A(dev_alloc(&g->occ_part, (size_t)((g->n_chunks + 255u) / 256u) * 12 + 12));
-    A(dev_alloc(&g->active_list, (size_t)g->n_chunks));
-    A(dev_alloc(&g->chunk_class, (size_t)g->n_chunks));
-    A(dev_alloc(&g->chunk_touch, (size_t)g->n_chunks));
-    A(dev_alloc(&g->chunk_signs, (size_t)g->n_chunks * 256));
-    A(dev_alloc(&g->chunk_moments, (size_t)g->n_chunks * 10));
-    if (rc != IVX_OK) {
-        ivx_grid_destroy(g);
-        return rc;
+    for (int pass = 0; pass < 2; ++pass) {
+        arena_bytes = 0;
+        carve(&g->sdf, g->n_vox);
+        carve(&g->type, g->n_vox);
+        carve(&g->flags, g->n_vox);
+        carve(&g->llabel, g->n_vox);
+        carve(&g->info, (size_t)g->n_chunks);
+        carve(&g->chunk_bbox, (size_t)g->n_chunks);
+        for (int sd = 0; sd < 2; ++sd) {
+            carve(&g->ghost_sdf[sd], cols * 256);
+            carve(&g->ghost_type[sd], cols * 256);
+            carve(&g->ghost_info[sd], cols);
+        }
+        carve(&g->chunk_counts, (size_t)g->n_chunks * 2);
+        carve(&g->chunk_offsets, (size_t)g->n_chunks * 3 + 8);
+        carve(&g->partials, g->partial_blocks * 10 + 16);
+        carve(&g->rparent, (size_t)g->n_chunks * 256);
+        carve(&g->rcompid, (size_t)g->n_chunks * 256);
+        carve(&g->rscalar, (size_t)64);
+        carve(&g->ccl_scratch, (size_t)g->n_chunks * 2);
+        carve(&g->sn_list, (size_t)g->n_chunks * 4);  // one uint4 record per meshed chunk
+        carve(&g->group_sums, (size_t)((g->n_chunks + 255u) / 256u) * 4 + 4);
+        carve(&g->dens_dev, (size_t)256);
+        carve(&g->work_counts, (size_t)8);
+        carve(&g->occ_part, (size_t)((g->n_chunks + 255u) / 256u) * 12 + 12);
+        carve(&g->active_list, (size_t)g->n_chunks);
+        carve(&g->chunk_class, (size_t)g->n_chunks);
+        carve(&g->chunk_touch, (size_t)g->n_chunks);
+        carve(&g->chunk_signs, (size_t)g->n_chunks * 256);
+        carve(&g->chunk_moments, (size_t)g->n_chunks * 10);
+        if (pass == 0) {
+            if (hipMalloc(reinterpret_cast<void**>(&arena), arena_bytes) != hipSuccess) {
+                ivx_set_error("ivx_grid_create: device allocation of %zu bytes failed", arena_bytes);
+                delete g;
+                return IVX_ERR_HIP;
+            }
+            g->arena = arena;
+        }
     }
+    (void)rc;
     if (hipMemsetAsync(g->info, 0, sizeof(ivx_chunk_info) * g->n_chunks, c->stream) != hipSuccess ||
         hipMemsetAsync(g->work_counts, 0, 8 * sizeof(uint32_t), c->stream) != hipSuccess) {
         ivx_set_error("ivx_grid_create: memset failed");
@@ -413,11 +431,9 @@ int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32
 void ivx_grid_destroy(ivx_grid* g) {
     if (!g) return;
     (void)hipStreamSynchronize(g->ctx->stream);
-    void* ptrs[] = {g->sdf, g->type, g->flags, g->llabel, g->info, g->ghost_sdf[0], g->ghost_sdf[1], g->ghost_type[0], g->ghost_type[1],
-                    g->ghost_info[0], g->ghost_info[1], g->chunk_counts, g->chunk_offsets, g->positions, g->normals, g->indices,
-                    g->index_materials, g->vertex_materials, g->submeshes, g->partials, g->rparent, g->rcompid, g->rscalar, g->ccl_scratch, g->group_sums, g->sn_list, g->dens_dev, g->dev_scratch, g->prog_nodes, g->chunk_bbox, g->samp_len, g->samp_ops, g->pairs_dev,
-                    g->work_counts, g->occ_part, g->active_list, g->chunk_class, g->chunk_moments, g->chunk_touch, g->chunk_signs, g->samp_super, g->probe_points,
-                    g->probe_chunk, g->probe_entries};
+    // (everything sized by the chunk counts lives in the arena; the rest grew on demand)
+    void* ptrs[] = {g->arena, g->positions, g->normals, g->indices, g->index_materials, g->vertex_materials, g->submeshes, g->dev_scratch, g->prog_nodes,
+                    g->samp_len, g->samp_ops, g->pairs_dev, g->samp_super, g->probe_points, g->probe_chunk, g->probe_entries};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->host_scratch) (void)hipHostFree(g->host_scratch);
@@ -1029,6 +1045,161 @@ int ivx_clip_polyhedron(ivx_grid* parent, const float* planes4, size_t n_planes,
     }
     *child = c;
     *outcome = c ? 1 : 2;
+    return IVX_OK;
+}
+
+// Batched polyhedron COPY: every fragment of one impact in one call (FracturingProcess::execute_in_parallel, fracturing.rs:1047-1189, runs
+// copy_polyhedron_with_property_computer, extraction.rs:1301-1768, for all Voronoi cells of an impact over a thread pool; the object itself
+// is not changed). The looped form pays per fragment: an occupied-range reduction with a host read, the child's record download, three more
+// host reads for its voxel count / box / regions. Here the parent's ranges are reduced once, all clip kernels and all children's derive /
+// range / voxel-count passes are enqueued back to back and read with ONE wait, the discard / repack decisions are taken on the host, then
+// all region passes follow with a second wait. Per fragment the results are those of ivx_clip_polyhedron(copy = 1).
+int ivx_copy_polyhedra(ivx_grid* parent, const float* planes4, const uint32_t* plane_counts, const float* aabbs6, size_t n_sets, ivx_grid** children,
+                       uint32_t* origins3, int* outcomes) {
+    IVX_REQUIRE(parent && planes4 && plane_counts && aabbs6 && children && origins3 && outcomes, IVX_ERR_INVALID, "ivx_copy_polyhedra: null argument");
+    IVX_REQUIRE(parent->regions_valid, IVX_ERR_STATE, "ivx_copy_polyhedra: the object needs its derived state (ivx_derive_state + ivx_label_regions)");
+    IVX_REQUIRE(parent->x_off == 0 && parent->gx == parent->cc[0] && !parent->has_ghost[0] && !parent->has_ghost[1], IVX_ERR_STATE,
+                "ivx_copy_polyhedra: not available on a slab of a decomposed grid");
+    for (size_t f = 0; f < n_sets; ++f) {
+        children[f] = nullptr;
+        outcomes[f] = 0;
+        IVX_REQUIRE(plane_counts[f] >= 1 && plane_counts[f] <= 64, IVX_ERR_CAPACITY, "ivx_copy_polyhedra: 1..64 planes per polyhedron, set %zu has %u", f, plane_counts[f]);
+    }
+    if (n_sets == 0) return IVX_OK;
+    int rc;
+    hipStream_t s = parent->ctx->stream;
+    uint32_t* d_occ = parent->rscalar + 16;
+    if ((rc = ivx_launch_occupied(parent, d_occ))) return rc;
+    uint32_t occ[12], occ_raw[12];
+    if ((rc = d2h(parent, occ_raw, d_occ, sizeof(occ_raw)))) return rc;
+    ivx_occupied_from_raw(parent, occ_raw, occ);
+    if (occ[1] == 0) return IVX_OK;
+    struct Frag {
+        ivx_grid* c = nullptr;
+        size_t info_off = 0;
+    };
+    std::vector<Frag> fr(n_sets);
+    auto fail = [&](int code) {
+        for (Frag& f : fr)
+            if (f.c) ivx_grid_destroy(f.c);
+        for (size_t f = 0; f < n_sets; ++f) children[f] = nullptr;
+        return code;
+    };
+    // 1. the children's chunk boxes, their grids, the clip kernels
+    size_t plane_off = 0, info_total = 0;
+    float ones[256];
+    for (float& x : ones) x = 1.0f;
+    for (size_t f = 0; f < n_sets; plane_off += plane_counts[f], ++f) {
+        const float* aabb = aabbs6 + 6 * f;
+        uint32_t lo[3], cc[3];
+        bool hit = true;
+        for (int q = 0; q < 3 && hit; ++q) {
+            const float l = aabb[q] - 2.54f, h = aabb[3 + q] + 2.54f;
+            const float fl = floorf(l);
+            const long st = (long)(fl > 0.0f ? fl : 0.0f), e = (long)ceilf(h);
+            const long vlo = std::max<long>((long)occ[6 + 2 * q], st), vhi = std::min<long>((long)occ[7 + 2 * q], std::max<long>(e, 0));
+            if (vlo >= vhi) hit = false;
+            else {
+                lo[q] = (uint32_t)(vlo / 16);
+                cc[q] = (uint32_t)((vhi + 15) / 16) - lo[q];
+            }
+        }
+        if (!hit) continue;
+        if ((rc = ivx_grid_create(parent->ctx, cc, parent->extent, 0, 0, &fr[f].c))) return fail(rc);
+        if ((rc = ivx_launch_clip(parent, fr[f].c, lo, cc, planes4 + 4 * plane_off, plane_counts[f], 0))) return fail(rc);
+        for (int q = 0; q < 3; ++q) origins3[3 * f + q] = lo[q] * 16u;
+        fr[f].info_off = info_total;
+        info_total += fr[f].c->n_chunks;
+    }
+    // 2. per child: flags + per-chunk boxes, voxel box, unit-density mass (= voxel count); all enqueued, one wait
+    const size_t per_child = 12 * sizeof(uint32_t) + sizeof(double);
+    const size_t stage_bytes = info_total * sizeof(ivx_chunk_info) + n_sets * per_child + 1024;
+    if ((rc = ensure_host_scratch(parent, stage_bytes))) return fail(rc);
+    char* stage = static_cast<char*>(parent->host_scratch);
+    memcpy(stage, ones, sizeof(ones));
+    ivx_grid* first = nullptr;
+    for (size_t f = 0; f < n_sets; ++f) {
+        ivx_grid* c = fr[f].c;
+        if (!c) continue;
+        if (!first) {
+            first = c;
+            if (hipMemcpyAsync(c->dens_dev, stage, sizeof(ones), hipMemcpyHostToDevice, s) != hipSuccess) return fail(IVX_ERR_HIP);
+        } else if (hipMemcpyAsync(c->dens_dev, first->dens_dev, sizeof(ones), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            return fail(IVX_ERR_HIP);
+        }
+        if ((rc = ivx_launch_derive(c, 0))) return fail(rc);
+        if ((rc = ivx_launch_occupied(c, c->rscalar + 16))) return fail(rc);
+        if ((rc = ivx_launch_inertia(c, c->dens_dev, c->partials + c->partial_blocks * 10, 0))) return fail(rc);
+        char* dst = stage + 1024 + fr[f].info_off * sizeof(ivx_chunk_info);
+        bool ok = hipMemcpyAsync(dst, c->info, c->n_chunks * sizeof(ivx_chunk_info), hipMemcpyDeviceToHost, s) == hipSuccess;
+        char* tail = stage + 1024 + info_total * sizeof(ivx_chunk_info) + f * per_child;
+        ok = ok && hipMemcpyAsync(tail, c->rscalar + 16, 12 * sizeof(uint32_t), hipMemcpyDeviceToHost, s) == hipSuccess;
+        ok = ok && hipMemcpyAsync(tail + 12 * sizeof(uint32_t), c->partials + c->partial_blocks * 10, sizeof(double), hipMemcpyDeviceToHost, s) == hipSuccess;
+        if (!ok) {
+            ivx_set_error("ivx_copy_polyhedra: copy failed");
+            return fail(IVX_ERR_HIP);
+        }
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) return fail(IVX_ERR_HIP);
+    // 3. discard crumbs, repack small children into one chunk (complete_extracted_voxel_object, extraction.rs:1902-2142), then the
+    // region passes of every survivor, again with one wait
+    for (size_t f = 0; f < n_sets; ++f) {
+        ivx_grid* c = fr[f].c;
+        if (!c) continue;
+        const ivx_chunk_info* info = reinterpret_cast<const ivx_chunk_info*>(stage + 1024) + fr[f].info_off;
+        uint32_t uniform_count = 0;
+        for (uint32_t i = 0; i < c->n_chunks; ++i) uniform_count += info[i].gen_kind == KIND_UNIFORM;
+        const char* tail = stage + 1024 + info_total * sizeof(ivx_chunk_info) + f * per_child;
+        uint32_t raw[12], cocc[12];
+        memcpy(raw, tail, sizeof(raw));
+        double m0;
+        memcpy(&m0, tail + sizeof(raw), sizeof(double));
+        ivx_occupied_from_raw(c, raw, cocc);
+        const double e = (double)c->extent;
+        const unsigned long long non_empty = (unsigned long long)(m0 / (e * e * e) + 0.5);
+        if (uniform_count == 0 && non_empty < 8) {  // NON_EMPTY_VOXEL_THRESHOLD (object.rs:203)
+            ivx_grid_destroy(c);
+            fr[f].c = nullptr;
+            outcomes[f] = 2;
+            continue;
+        }
+        if (c->cc[0] <= 2 && c->cc[1] <= 2 && c->cc[2] <= 2 && uniform_count == 0 && c->n_chunks > 1 && cocc[1] != 0 && cocc[7] - cocc[6] <= 14 &&
+            cocc[9] - cocc[8] <= 14 && cocc[11] - cocc[10] <= 14) {
+            uint32_t off[3];
+            for (int q = 0; q < 3; ++q) off[q] = cocc[6 + 2 * q] > 0 ? cocc[6 + 2 * q] - 1u : 0u;
+            const uint32_t one[3] = {1, 1, 1};
+            ivx_grid* single = nullptr;
+            if ((rc = ivx_grid_create(parent->ctx, one, parent->extent, 0, 0, &single))) return fail(rc);
+            if ((rc = ivx_launch_split_repack(c, single, off))) {
+                ivx_grid_destroy(single);
+                return fail(rc);
+            }
+            ivx_grid_destroy(c);  // (waits for the stream: the repack has read its source)
+            c = fr[f].c = single;
+            for (int q = 0; q < 3; ++q) origins3[3 * f + q] += off[q];
+        }
+        if ((rc = ivx_launch_derive(c, IVX_PART_REGIONS))) return fail(rc);
+        if ((rc = ivx_launch_ccl_local(c, 1))) return fail(rc);
+        if ((rc = ivx_launch_ccl_merge(c))) return fail(rc);
+        if ((rc = ivx_launch_ccl_resolve(c))) return fail(rc);
+        if (hipMemcpyAsync(stage + 1024 + f * 8, c->rscalar, 8, hipMemcpyDeviceToHost, s) != hipSuccess) return fail(IVX_ERR_HIP);
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) return fail(IVX_ERR_HIP);
+    for (size_t f = 0; f < n_sets; ++f) {
+        ivx_grid* c = fr[f].c;
+        if (!c) continue;
+        uint32_t sc[2];
+        memcpy(sc, stage + 1024 + f * 8, 8);
+        if (sc[1] & 1u) {
+            ivx_set_error("ivx_copy_polyhedra: a chunk has more than 254 local regions");
+            return fail(IVX_ERR_CAPACITY);
+        }
+        c->region_count = sc[0];
+        c->regions_valid = 1;
+        c->mesh_valid = 0;
+        children[f] = c;
+        outcomes[f] = 1;
+    }
     return IVX_OK;
 }
 

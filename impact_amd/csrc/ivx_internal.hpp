@@ -47,6 +47,7 @@ struct ivx_grid {
     size_t n_vox;
     float extent;
     uint32_t x_off, gx;  // slab offset in chunks and global chunk count along x
+    char* arena;  // the one device allocation the buffers below (all sized by the chunk counts) are carved from
     // planes
     int8_t* sdf;
     uint8_t* type;

@@ -325,6 +325,24 @@ class VoxelObject:
         """`VoxelObject::copy_polyhedron` (object/extraction.rs:1278-1291)"""
         return self._clip(normalized_aabb, normalized_face_planes, True)
 
+    def copy_polyhedra(self, normalized_aabbs, plane_sets):
+        """all fragments of one impact in one call (`ivx_copy_polyhedra`; FracturingProcess::execute_in_parallel, fracturing.rs:1047-1189):
+        -> list of (outcome, child VoxelObject or None, origin offset) as `copy_polyhedron` returns them one by one"""
+        n = len(plane_sets)
+        sets = [np.ascontiguousarray(p, dtype=np.float32).reshape(-1, 4) for p in plane_sets]
+        planes = np.ascontiguousarray(np.concatenate(sets)) if n else np.zeros((0, 4), dtype=np.float32)
+        counts = np.array([len(p) for p in sets], dtype=np.uint32)
+        bbs = np.ascontiguousarray(np.asarray(normalized_aabbs, dtype=np.float32).reshape(-1, 6))
+        children = (C.c_void_p * max(n, 1))()
+        origins = np.zeros((max(n, 1), 3), dtype=np.uint32)
+        outcomes = np.zeros(max(n, 1), dtype=np.int32)
+        check(capi.lib().ivx_copy_polyhedra(self.h, ptr(planes), ptr(counts), ptr(bbs), n, children, ptr(origins), ptr(outcomes)))
+        out = []
+        for f in range(n):
+            obj = self._wrap_child(C.c_void_p(children[f])) if outcomes[f] == 1 else None
+            out.append((int(outcomes[f]), obj, tuple(int(x) for x in origins[f])))
+        return out
+
     def extract_any_disconnected_region(self):
         """`VoxelObject::extract_any_disconnected_region` (object/extraction.rs:78-119). Returns
         (outcome, child VoxelObject or None, origin_offset_in_parent, descriptor of the removed region):

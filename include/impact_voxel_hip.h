@@ -206,6 +206,13 @@ int ivx_split_off_smallest_region(ivx_grid* parent, ivx_grid** child, uint32_t o
  * Outcome and child conventions as for ivx_split_off_smallest_region; outcome 0 = the AABB misses the object. */
 int ivx_clip_polyhedron(ivx_grid* parent, const float* planes4, size_t n_planes, const float aabb[6], int copy, ivx_grid** child,
                         uint32_t origin_offset_in_parent[3], int* outcome);
+/* Batched COPY of several polyhedra out of one object — all fragments of one impact (FracturingProcess::execute_in_parallel,
+ * fracturing.rs:1047-1189, over copy_polyhedron_with_property_computer, extraction.rs:1301-1768): `planes4` holds the plane sets one after the
+ * other (plane_counts[f] planes of 4 floats each), `aabbs6` six floats per set. children[f] / origins3[3 f ..] / outcomes[f] are what
+ * ivx_clip_polyhedron(copy = 1) returns for set f (outcome 0 = no overlap, 1 = object, 2 = fewer than 8 voxels: no object); the work of all
+ * fragments is enqueued back to back and read with two host waits in all. */
+int ivx_copy_polyhedra(ivx_grid* parent, const float* planes4, const uint32_t* plane_counts, const float* aabbs6, size_t n_sets, ivx_grid** children,
+                       uint32_t* origins3, int* outcomes);
 
 /* ---- whole voxel step (resident inputs, minimal host synchronisation) ---------------------------- */
 /* The per-frame chain the engine runs for a voxel object — generate (engine/src/setup/scene/voxel.rs:33 ->

@@ -120,3 +120,32 @@ def test_config3_copy_each_octant(ctx):
         total += int(np.count_nonzero((co.export_dense()[2] & 1) == 0))
         cg.close()
     assert total == int(np.count_nonzero((o.export_dense()[2] & 1) == 0))
+
+
+def test_batched_copies_equal_the_looped_ones(ctx):
+    """`ivx_copy_polyhedra` (all fragments of an impact in one call) against `copy_polyhedron` one by one and against the oracle: config 3's
+    eight octants plus an oriented box, a box that misses the object and a crumb"""
+    o, g = build(ctx, scenes.fracture_scene())
+    from impact_amd.voxel import SDFVoxelGenerator
+
+    centre = float(SDFVoxelGenerator(1.0, scenes.fracture_scene()).shifted_grid_center[0]) + 0.5
+    sets = []
+    for sx, sy, sz in itertools.product((-1, 1), repeat=3):
+        lo = [centre if s > 0 else -10.0 for s in (sx, sy, sz)]
+        hi = [300.0 if s > 0 else centre for s in (sx, sy, sz)]
+        sets.append((box_planes(lo, hi), np.array([*lo, *hi], dtype=np.float32)))
+    sets.append(rotated_box((90.0, 120.0, 140.0), np.array([30.0, 22.0, 41.0]), (1.0, 2.0, 0.5), 0.6))
+    sets.append(rotated_box((900.0, 900.0, 900.0), np.array([5.0, 5.0, 5.0]), (1, 0, 0), 0.3))  # misses
+    sets.append(rotated_box((centre + 40.0, centre + 40.0, centre + 40.0), np.array([0.6, 0.6, 0.4]), (0, 0, 1), 0.0))  # 4 voxel centres
+    batched = g.copy_polyhedra([s[1] for s in sets], [s[0] for s in sets])
+    assert [b[0] for b in batched] == [1] * 9 + [0, 2]
+    for (planes, aabb), (rc_b, child_b, org_b) in zip(sets, batched):
+        rc_o, co, org_o = o.clip_polyhedron(planes, aabb, copy=True)
+        rc_l, child_l, org_l = g.copy_polyhedron(aabb, planes)
+        assert rc_b == rc_o == rc_l
+        if rc_o == 1:
+            assert org_b == org_o == org_l
+            assert_objects_equal(co, child_b, "batched child: ")
+            child_l.close()
+            child_b.close()
+    assert_objects_equal(o, g, "parent untouched: ")
