@@ -53,6 +53,15 @@ REGION_DESC_DTYPE = np.dtype(
 )
 MESH_COUNTS_DTYPE = np.dtype([("n_vertices", "<u4"), ("n_indices", "<u4"), ("n_submeshes", "<u4"), ("reserved", "<u4")])
 N_TIMED_STAGES = 10
+IMPACT_FRACTURING_CONFIG_DTYPE = np.dtype(
+    [("boundary_polar_grid_size", "<u4"), ("boundary_azimuthal_grid_size", "<u4"), ("boundary_angular_jitter", "<f4"), ("boundary_radial_jitter", "<f4"),
+     ("max_fragment_count", "<u8"), ("radial_falloff_power", "<f4"), ("angular_falloff_power", "<f4"), ("radial_grid_size", "<u4"),
+     ("angular_grid_size", "<u4"), ("max_position_rejections_per_sample", "<u8"), ("seed", "<u8")]
+)
+FRACTURING_PROPERTIES_DTYPE = np.dtype(
+    [("fracturing_force", "<f4"), ("shattering_pressure", "<f4"), ("fragment_scale", "<f4"), ("min_fragment_extent", "<f4"), ("max_fragment_extent", "<f4")]
+)
+assert IMPACT_FRACTURING_CONFIG_DTYPE.itemsize == 56 and FRACTURING_PROPERTIES_DTYPE.itemsize == 20
 SLAB_RESULT_DTYPE = np.dtype(
     [("region_count", "<u4"), ("local_region_count", "<u4"), ("first_local_component", "<u4"), ("reserved", "<u4"), ("moments", "<f8", (10,)),
      ("occupied", "<u4", (12,)), ("mesh", MESH_COUNTS_DTYPE), ("vertex_offset", "<u8"), ("index_offset", "<u8"), ("total_triangles", "<u8"),
@@ -137,6 +146,8 @@ EXPORTED_SYMBOLS = [
     "ivx_region_face_bytes", "ivx_region_face_labels", "ivx_region_face_pairs",
     "ivx_world_create", "ivx_world_destroy", "ivx_world_set_bodies", "ivx_world_get_bodies", "ivx_world_set_contacts",
     "ivx_world_step", "ivx_world_step_enqueue", "ivx_world_prepare", "ivx_world_advance_momenta", "ivx_world_solve", "ivx_world_advance_configurations",
+    "ivx_impact_fracturing_config_default", "ivx_generate_impact_fracture_points", "ivx_delaunay_construct", "ivx_delaunay_destroy", "ivx_delaunay_counts",
+    "ivx_delaunay_download", "ivx_delaunay_aabb", "ivx_delaunay_boundary_face_planes", "ivx_voronoi_polyhedron", "ivx_voronoi_bounded_aabb",
     "ivx_comm_unique_id", "ivx_comm_init", "ivx_comm_init_local", "ivx_comm_destroy", "ivx_slab_create", "ivx_slab_destroy",
     "ivx_slabs_step_enqueue", "ivx_slabs_step_collect", "ivx_slab_region_map",
     "ivx_world_set_solver_groups", "ivx_world_solver_info", "ivx_world_contact_state",
@@ -268,6 +279,16 @@ def lib():
         "ivx_world_solve": (i32, [vp]),
         "ivx_world_advance_configurations": (i32, [vp, f32]),
         "ivx_world_contact_state": (i32, [vp, vp, vp, sz, C.POINTER(sz)]),
+        "ivx_impact_fracturing_config_default": (None, [vp]),
+        "ivx_generate_impact_fracture_points": (i32, [vp, vp, f32, vp, vp, vp, vp, vp, f32, vp, vp, sz, C.POINTER(sz), vp, sz, C.POINTER(sz)]),
+        "ivx_delaunay_construct": (i32, [vp, sz, C.POINTER(vp)]),
+        "ivx_delaunay_destroy": (None, [vp]),
+        "ivx_delaunay_counts": (i32, [vp, vp]),
+        "ivx_delaunay_download": (i32, [vp, vp, vp, vp]),
+        "ivx_delaunay_aabb": (i32, [vp, vp]),
+        "ivx_delaunay_boundary_face_planes": (i32, [vp, vp, sz, C.POINTER(sz)]),
+        "ivx_voronoi_polyhedron": (i32, [vp, u32, vp, sz, vp, sz, vp, sz, vp]),
+        "ivx_voronoi_bounded_aabb": (i32, [vp, sz, vp, sz, vp, vp, C.POINTER(i32)]),
         "ivx_comm_unique_id": (i32, [vp]),
         "ivx_comm_init": (i32, [vp, i32, i32, vp, C.POINTER(vp)]),
         "ivx_comm_init_local": (i32, [vp, i32, C.POINTER(vp)]),

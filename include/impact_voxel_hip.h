@@ -326,6 +326,45 @@ int ivx_region_face_pairs_enqueue(ivx_grid*, int side, const void* neighbour_fac
 size_t ivx_step_record_words(void);
 int ivx_step_record_enqueue(ivx_grid*, void* device_record);
 
+/* ---- a13 / §8f-3: from an impact to fragment plane sets (host code: a few hundred points per impact) ------------------------------------
+ * generate_impact_fracture_points (impact_voxel/src/interaction/fracturing.rs:1710-2015), DelaunayTetrahedralization
+ * (impact_tesselation/src/delaunay.rs), VoronoiPolyhedron (impact_tesselation/src/voronoi.rs). The fragments of an impact are then
+ *   region   = ivx_clip_polyhedron(object, ivx_delaunay_boundary_face_planes(Delaunay(boundary points)), its aabb, extract)   fracturing.rs:1537-1632
+ *   cells    = for v in 4 .. vertices(Delaunay(fracture points - region origin)): ivx_voronoi_polyhedron(v), ivx_voronoi_bounded_aabb
+ *   fragments= ivx_copy_polyhedra(region, planes displaced by -0.1, boxes)                                                   fracturing.rs:1190-1240
+ * Vertex indices: 0..3 are the ad-hoc bounding tetrahedron, the points follow in input order (near-coincident points are skipped). */
+typedef struct {                 /* VoxelImpactFracturingConfig (fracturing.rs:855-871: the defaults ivx_impact_fracturing_config_default fills in) */
+    uint32_t boundary_polar_grid_size, boundary_azimuthal_grid_size;
+    float boundary_angular_jitter, boundary_radial_jitter;
+    uint64_t max_fragment_count;
+    float radial_falloff_power, angular_falloff_power;
+    uint32_t radial_grid_size, angular_grid_size;
+    uint64_t max_position_rejections_per_sample;
+    uint64_t seed;
+} ivx_impact_fracturing_config;  /* 56 bytes */
+typedef struct {                 /* FracturingProperties, #[repr(C)] Pod (fracturing.rs:61-86) */
+    float fracturing_force, shattering_pressure, fragment_scale, min_fragment_extent, max_fragment_extent;
+} ivx_fracturing_properties;     /* 20 bytes */
+void ivx_impact_fracturing_config_default(ivx_impact_fracturing_config*);
+/* Points in the object's normalized space (voxel units). rng_state: in/out state of the frame's generator (first impact: the seed). The
+ * stream is fastrand 2.3.0's wyrand restated from its published source: the crate is not vendored, no reference test pins it. */
+int ivx_generate_impact_fracture_points(const ivx_impact_fracturing_config*, const ivx_fracturing_properties*, float inverse_voxel_extent,
+                                        const float world_to_object_rotation_xyzw[4], const float world_to_object_translation[3], const float object_aabb[6],
+                                        const float force_position[3], const float force_unit_direction[3], float force_magnitude, uint64_t* rng_state,
+                                        float* boundary_points3, size_t cap_boundary, size_t* n_boundary, float* fracture_points3, size_t cap_fracture,
+                                        size_t* n_fracture);
+typedef struct ivx_delaunay ivx_delaunay;
+#define IVX_NO_TETRAHEDRON 0xFFFFFFFFu
+int ivx_delaunay_construct(const float* points3, size_t n_points, ivx_delaunay** out);
+void ivx_delaunay_destroy(ivx_delaunay*);
+int ivx_delaunay_counts(const ivx_delaunay*, uint32_t counts[2] /* vertices incl. the 4 ad-hoc ones, tetrahedra */);
+int ivx_delaunay_download(const ivx_delaunay*, float* vertices3, uint32_t* tet_vertices4, uint32_t* tet_neighbors4 /* across the face opposite corner c */);
+int ivx_delaunay_aabb(const ivx_delaunay*, float aabb[6]);
+int ivx_delaunay_boundary_face_planes(const ivx_delaunay*, float* planes4 /* outward unit normal, displacement */, size_t cap, size_t* n_out);
+int ivx_voronoi_polyhedron(const ivx_delaunay*, uint32_t vertex, float* vertices3, size_t cap_vertices, float* rays6 /* origin, unit direction */, size_t cap_rays,
+                           float* planes4, size_t cap_planes, size_t n_out[3] /* vertices, rays, planes */);
+int ivx_voronoi_bounded_aabb(const float* vertices3, size_t n_vertices, const float* rays6, size_t n_rays, const float bounding_aabb[6], float out_aabb[6], int* has);
+
 /* ---- multi-GPU: the whole per-step protocol behind the C ABI ----------------------------------------------------------------------
  * One process per GPU owns one x-slab (an ivx_grid created with its chunk offset) and an RCCL communicator; ivx_slabs_step_enqueue
  * runs sample -> face exchange -> derive + regions + moments -> face exchange (+ component ids) -> remesh -> record all-gather, all

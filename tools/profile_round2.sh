@@ -13,8 +13,9 @@ if [ "${2:-}" != "skip-tests" ]; then
   tail -2 "$out/${tag}_pytest_gpu.log"
 fi
 python bench.py 2> "$out/bench_stderr.log" | tail -1 > "$out/${tag}_bench_n1.json"
-STEPS="--steps 10 --warmup 2 --no-cpu-baseline --no-pile"
-NST=12
+# --plain: full steps only: 2 warm-up + 10 timed + 10 with every slot timed = 22 steps
+STEPS="--steps 10 --warmup 2 --no-cpu-baseline --no-pile --plain"
+NST=22
 for wl in headline dense; do
   if [ $wl = dense ]; then W="--workload dense"; else W=""; fi
   rocprofv3 --kernel-trace --stats -d "$out/trace_$wl" -o trace -- python3 bench.py $STEPS $W > "$out/${tag}_bench_step_only_$wl.json" 2> "$out/trace_${wl}_stderr.log"
