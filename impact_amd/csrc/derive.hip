@@ -137,7 +137,7 @@ struct DeriveFused {
 // residency is throughput, and the register budget is set to match.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_derive(GridView g, int8_t* __restrict__ sdf_rw, uint8_t* __restrict__ type_rw, uint8_t* __restrict__ flags_out,
                                                 ivx_chunk_info* __restrict__ info, uint32_t* __restrict__ bbox, uint8_t* __restrict__ touch,
-                                                uint16_t* __restrict__ signs,
+                                                uint16_t* __restrict__ signs, uint8_t* __restrict__ kface_out,
                                                 const uint32_t* __restrict__ work_counts, uint32_t* __restrict__ active_list, DeriveFused fz) {
     __shared__ uint32_t occ[18][18];  // non-empty masks of rows (i+1, j+1); halo rows from neighbour chunks
     __shared__ uint32_t cnt[13];      // own face non-empty counts [0..6), neighbour face non-empty counts [6..12), [12] touch bits
@@ -155,49 +155,74 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     const uint32_t chunk = IVX_LIST_CHUNK(active_list[li]);
     const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
     const size_t base = (size_t)chunk * IVX_CHUNK_VOXELS;
-    const ivx_chunk_info own_info = info[chunk];
-    const uint32_t own_row_mask = row_mask(*reinterpret_cast<const uint4*>(g.sdf + base + (size_t)tid * 16));  // used only if the chunk has planes
-    uint4 own_types = make_uint4(0, 0, 0, 0);
-    if (fz.parts & IVX_PART_MOMENTS) own_types = *reinterpret_cast<const uint4*>(g.type + base + (size_t)tid * 16);  // likewise
+    // ---- every global load of the chunk's first phase goes out here, back to back, before the first of them is used: the chunk's own
+    // record and rows; across each z face one byte per thread; (threads 0..63) one 16-byte row across an x or y face; the three
+    // neighbours' records. Addresses are clamped to valid ones and the records select afterwards. Written as "record, then the byte
+    // if the neighbour is dense" the compiler sinks each load under the branch that consumes it, and the phase is seven dependent
+    // memory round trips instead of one (measured on the mesher's tile load, sn_roles.hpp RowLoads).
+    const bool has_zlo = ck > 0, has_zhi = ck + 1 < (int)g.cz;
+    const size_t c_lo = has_zlo ? (size_t)chunk - 1 : (size_t)chunk, c_hi = has_zhi ? (size_t)chunk + 1 : (size_t)chunk;
+    // x / y faces: f: 0 x-, 1 x+, 2 y-, 3 y+ (threads >= 64 repeat thread (tid & 63)'s loads and drop them)
+    const int nf = (tid >> 4) & 3, nr = tid & 15;
+    bool n_present, n_ghost = false;
+    size_t nc;
+    uint32_t noff;
+    {
+        const size_t plane = (size_t)g.cy * g.cz;
+        const int8_t* gp = nf == 0 ? g.ghost_sdf[0] : g.ghost_sdf[1];  // (selected, not indexed: the view lives in the kernel arguments)
+        if (nf == 0) n_present = ci > 0, nc = (size_t)chunk - plane, noff = 15 * 256 + nr * 16, n_ghost = !n_present && gp != nullptr;
+        else if (nf == 1) n_present = ci + 1 < (int)g.cx, nc = (size_t)chunk + plane, noff = nr * 16, n_ghost = !n_present && gp != nullptr;
+        else if (nf == 2) n_present = cj > 0, nc = (size_t)chunk - g.cz, noff = nr * 256 + 15 * 16;
+        else n_present = cj + 1 < (int)g.cy, nc = (size_t)chunk + g.cz, noff = nr * 256;
+        if (!n_present) nc = chunk;
+    }
+    const int8_t* nrp = g.sdf + (nc << 12) + noff;
+    if (n_ghost) nrp = (nf == 0 ? g.ghost_sdf[0] : g.ghost_sdf[1]) + ((size_t)(cj * g.cz + ck) * 256 + nr * 16);
+    uint2 own_rec = reinterpret_cast<const uint2*>(info)[chunk];
+    uint4 own_sd = *reinterpret_cast<const uint4*>(g.sdf + base + (size_t)tid * 16);  // used only if the chunk has planes
+    uint4 own_types = *reinterpret_cast<const uint4*>(g.type + base + (size_t)tid * 16);  // likewise
+    uint32_t gen_lo = info[c_lo].gen_kind, gen_hi = info[c_hi].gen_kind;
+    uint32_t by_lo = (uint8_t)g.sdf[(c_lo << 12) + tid * 16 + 15], by_hi = (uint8_t)g.sdf[(c_hi << 12) + tid * 16];
+    uint32_t ngen = info[nc].gen_kind;
+    uint4 nrow = *reinterpret_cast<const uint4*>(nrp);
+    asm volatile("" : "+v"(own_rec.x), "+v"(own_rec.y), "+v"(own_sd.x), "+v"(own_sd.y), "+v"(own_sd.z), "+v"(own_sd.w));
+    asm volatile("" : "+v"(own_types.x), "+v"(own_types.y), "+v"(own_types.z), "+v"(own_types.w));
+    asm volatile("" : "+v"(gen_lo), "+v"(gen_hi), "+v"(by_lo), "+v"(by_hi), "+v"(ngen), "+v"(nrow.x), "+v"(nrow.y), "+v"(nrow.z), "+v"(nrow.w));
+    ivx_chunk_info own_info;
+    own_info.kind = (uint8_t)(own_rec.x & 0xFFu);
+    own_info.gen_kind = (uint8_t)((own_rec.x >> 8) & 0xFFu);
+    own_info.flags = (uint8_t)((own_rec.x >> 16) & 0xFFu);
+    own_info.uniform_type = (uint8_t)(own_rec.x >> 24);
+    own_info.face_dist = (uint16_t)(own_rec.y & 0xFFFFu);
+    own_info.region_count = (uint8_t)((own_rec.y >> 16) & 0xFFu);
+    own_info.boundary_region_count = (uint8_t)(own_rec.y >> 24);
+    const uint32_t own_row_mask = row_mask(own_sd);
+    {
+        // the row's bytes on the two k faces, rows side by side, for the mesher's halo (GridView::kface)
+        uint8_t* kf = kface_out + (size_t)chunk * 1024 + tid;
+        kf[0] = (uint8_t)(own_sd.x & 0xFFu);
+        kf[256] = (uint8_t)(own_sd.w >> 24);
+        kf[512] = (uint8_t)(own_types.x & 0xFFu);
+        kf[768] = (uint8_t)(own_types.w >> 24);
+    }
     if (tid < 13) cnt[tid] = 0;
     const bool own_uniform = own_info.gen_kind == KIND_UNIFORM;
     const uint32_t m = own_uniform ? 0xFFFFu : own_row_mask;
     occ[ti + 1][tj + 1] = m;
     signs[(size_t)chunk * 256 + tid] = (uint16_t)m;  // for the mesher's count pass
 
-    // neighbour rows across the x and y faces: 16 threads each load one 16-byte row
     uint32_t zlo = 0, zhi = 0;  // neighbour voxel across the z faces for this (i,j)
-    {
-        // z faces: one byte per thread from the adjacent chunk in k
-        if (ck > 0) {
-            const uint32_t gen = info[chunk - 1].gen_kind;
-            const uint32_t bit = ((uint8_t)g.sdf[base - IVX_CHUNK_VOXELS + tid * 16 + 15] >> 7) & 1u;
-            zlo = gen == KIND_NONUNIFORM ? bit : (gen == KIND_UNIFORM ? 1u : 0u);
-        }
-        if (ck + 1 < (int)g.cz) {
-            const uint32_t gen = info[chunk + 1].gen_kind;
-            const uint32_t bit = ((uint8_t)g.sdf[base + IVX_CHUNK_VOXELS + tid * 16] >> 7) & 1u;
-            zhi = gen == KIND_NONUNIFORM ? bit : (gen == KIND_UNIFORM ? 1u : 0u);
-        }
-    }
+    if (has_zlo) zlo = gen_lo == KIND_NONUNIFORM ? ((by_lo >> 7) & 1u) : (gen_lo == KIND_UNIFORM ? 1u : 0u);
+    if (has_zhi) zhi = gen_hi == KIND_NONUNIFORM ? ((by_hi >> 7) & 1u) : (gen_hi == KIND_UNIFORM ? 1u : 0u);
     if (tid < 64) {
-        const int f = tid >> 4, r = tid & 15;  // f: 0 x-, 1 x+, 2 y-, 3 y+
+        const uint32_t rm = row_mask(nrow);
         uint32_t nm = 0;
-        if (f == 0) {
-            if (ci > 0) nm = nbr_row_mask(g, info, (size_t)chunk - (size_t)g.cy * g.cz, 15 * 256 + r * 16);
-            else if (g.ghost_sdf[0]) nm = row_mask(*reinterpret_cast<const uint4*>(g.ghost_sdf[0] + ((size_t)(cj * g.cz + ck) * 256 + r * 16)));
-            occ[0][r + 1] = nm;
-        } else if (f == 1) {
-            if (ci + 1 < (int)g.cx) nm = nbr_row_mask(g, info, (size_t)chunk + (size_t)g.cy * g.cz, r * 16);
-            else if (g.ghost_sdf[1]) nm = row_mask(*reinterpret_cast<const uint4*>(g.ghost_sdf[1] + ((size_t)(cj * g.cz + ck) * 256 + r * 16)));
-            occ[17][r + 1] = nm;
-        } else if (f == 2) {
-            if (cj > 0) nm = nbr_row_mask(g, info, (size_t)chunk - g.cz, r * 256 + 15 * 16);
-            occ[r + 1][0] = nm;
-        } else {
-            if (cj + 1 < (int)g.cy) nm = nbr_row_mask(g, info, (size_t)chunk + g.cz, r * 256);
-            occ[r + 1][17] = nm;
-        }
+        if (n_present) nm = ngen == KIND_NONUNIFORM ? rm : (ngen == KIND_UNIFORM ? 0xFFFFu : 0u);
+        else if (n_ghost) nm = rm;
+        if (nf == 0) occ[0][nr + 1] = nm;
+        else if (nf == 1) occ[17][nr + 1] = nm;
+        else if (nf == 2) occ[nr + 1][0] = nm;
+        else occ[nr + 1][17] = nm;
     }
     __syncthreads();
 
@@ -495,7 +520,7 @@ int ivx_launch_derive(ivx_grid* g, uint32_t parts, uint32_t preset_groups) {
                        g->chunk_class, g->chunk_touch, g->rparent, ivx_wc(g), next_count, g->active_list, ivx_preset_args(g, preset_groups));
     g->scratch_dirty &= ~preset_groups;
     hipLaunchKernelGGL(k_derive, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->sdf, g->type, g->flags, g->info, g->chunk_bbox,
-                       g->chunk_touch, g->chunk_signs, ivx_wc(g), g->active_list, fz);
+                       g->chunk_touch, g->chunk_signs, g->kface, ivx_wc(g), g->active_list, fz);
     g->planes_compact = 1;
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;

@@ -3,6 +3,8 @@
 // launches the HIP kernels in this directory on the context's stream.
 #include <algorithm>
 #include <cmath>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -407,6 +409,7 @@ int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32
         carve(&g->chunk_class, (size_t)g->n_chunks);
         carve(&g->chunk_touch, (size_t)g->n_chunks);
         carve(&g->chunk_signs, (size_t)g->n_chunks * 256);
+        carve(&g->kface, (size_t)g->n_chunks * 1024);
         carve(&g->chunk_moments, (size_t)g->n_chunks * 10);
         if (pass == 0) {
             if (hipMalloc(reinterpret_cast<void**>(&arena), arena_bytes) != hipSuccess) {
@@ -506,6 +509,8 @@ void* ivx_grid_device_ptr(ivx_grid* g, int which) {
 #ifdef IVX_WG_TRACE
         case 6: return g->chunk_moments;
 #endif
+        case 7: return g->samp_len;  // developer tools (tools/prog_stats.py): per-chunk compact program lengths, then the three list counters and lists
+        case 8: return g->samp_ops;  // ... and the programs, OP_CAP (128) uint2 per chunk
         default: return nullptr;
     }
 }
@@ -2148,6 +2153,7 @@ int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
     }
     if (!g->result_host) {
         IVX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&g->result_host), 64 * sizeof(uint32_t), hipHostMallocMapped));
+        memset(g->result_host, 0, 64 * sizeof(uint32_t));
         IVX_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&g->result_host_dev), g->result_host, 0));
     }
     int rc;
@@ -2253,6 +2259,17 @@ int ivx_grid_set_stage_timing(ivx_grid* g, uint32_t slot_mask) {
     return IVX_OK;
 }
 
+// How long ivx_voxel_step_collect polls the doorbell before it falls back to hipStreamSynchronize (IVX_COLLECT_SPIN_US, default 2000;
+// 0 = never poll).
+static uint64_t collect_spin_ns() {
+    static const uint64_t ns = [] {
+        const char* e = getenv("IVX_COLLECT_SPIN_US");
+        const long us = e ? strtol(e, nullptr, 10) : 2000;
+        return (uint64_t)(us < 0 ? 0 : us) * 1000ull;
+    }();
+    return ns;
+}
+
 int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out) {
     IVX_REQUIRE(g && out, IVX_ERR_INVALID, "ivx_voxel_step_collect: null argument");
     hipStream_t s = g->ctx->stream;
@@ -2262,13 +2279,34 @@ int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out) {
     // host-mapped block written by a last tiny kernel: one wait, no copies
     if (!g->result_host) {
         IVX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&g->result_host), 64 * sizeof(uint32_t), hipHostMallocMapped));
+        memset(g->result_host, 0, 64 * sizeof(uint32_t));
         IVX_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&g->result_host_dev), g->result_host, 0));
     }
     {
         int rc = ivx_launch_step_gather(g);
         if (rc) return rc;
     }
-    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    // A short step is over before the runtime's blocking wait has gone to sleep and been woken again: poll the doorbell word the
+    // gather kernel writes last (in-order stream: everything enqueued before it is complete too) for a bounded time first.
+    {
+        const volatile uint32_t* bell = g->result_host + 63;
+        const uint32_t want = g->result_seq;
+        const uint64_t budget_ns = collect_spin_ns();
+        bool rung = false;
+        if (budget_ns) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (uint32_t it = 0;; ++it) {
+                if (*bell == want) {
+                    rung = true;
+                    break;
+                }
+                __builtin_ia32_pause();
+                if ((it & 255u) == 255u && (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() > budget_ns) break;
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
+        if (!rung) IVX_HIP_CHECK(hipStreamSynchronize(s));
+    }
     const uint32_t* sc = g->result_host;
     if (sc[31]) g->last_active = sc[31];
     if (stages & IVX_STAGE_REGIONS) {

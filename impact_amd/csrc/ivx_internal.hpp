@@ -95,6 +95,9 @@ struct ivx_grid {
     uint32_t* occ_part;     // [12 * ceil(n_chunks / 256)] per-block minima/maxima of the occupied-range reduction (fused step path)
     uint32_t* active_list;  // [n_chunks]
     uint8_t* chunk_class;   // [n_chunks] 1: settled by k_chunk_pre
+    uint8_t* kface;         // [n_chunks][4][256] active chunks: the bytes of every (i,j) row on the chunk's two k faces — sdf at k = 0, sdf at
+                            // k = 15, type at k = 0, type at k = 15 (k_derive). The mesher's tile load takes its k halo from here: the
+                            // planes hold those bytes 16 apart (one cache line per four rows), here consecutive rows are consecutive bytes
     uint16_t* chunk_signs;  // [n_chunks * 256] active chunks: 16-bit "distance negative" mask of every (i,j) row (k_derive), what
                             // the mesher's count pass needs of the 18^3 tile (2 B per row instead of 16 B + two halo bytes)
     uint8_t* chunk_touch;   // [n_chunks] active chunks: bit d set = a voxel pair touches across the +x/+y/+z face (k_derive)
@@ -122,6 +125,7 @@ struct ivx_grid {
     int ev_ready;
     uint32_t* result_host;      // 64 words of host-mapped pinned memory the gather kernel writes the step's small results to
     uint32_t* result_host_dev;  // its device-side address
+    uint32_t result_seq;        // sequence number of the last gather launch (word 63 of the block = the completion doorbell)
     hipEvent_t* ev_start_ref[IVX_N_TIMED_STAGES];  // the event a stage's duration starts from (the previous stage's stop when adjacent)
     uint32_t pending_stages;  // stages enqueued since the last collect
     uint32_t timed_mask;      // timed stages whose events were recorded since the last collect
@@ -236,6 +240,7 @@ struct GridView {
     const int8_t* sdf;
     const uint8_t* type;
     const uint16_t* signs;
+    const uint8_t* kface;
 #ifdef IVX_WG_TRACE
     unsigned long long* trace;  // developer build (make TRACE=1): 8 timestamps per list entry, see tools/wg_trace.py
 #endif
@@ -279,6 +284,7 @@ static inline GridView ivx_view(const ivx_grid* g) {
     v.sdf = g->sdf;
     v.type = g->type;
     v.signs = g->chunk_signs;
+    v.kface = g->kface;
 #ifdef IVX_WG_TRACE
     v.trace = reinterpret_cast<unsigned long long*>(g->chunk_moments);  // (the inertia stage is not run while tracing)
 #endif

@@ -473,39 +473,51 @@ int ivx_world_advance_configurations(ivx_world* w, float dt) {
     return ivx_launch_phys_post_solve(w, dt, 0, 1);
 }
 
-int ivx_world_step_enqueue(ivx_world* w, float dt) {
-    IVX_REQUIRE(w, IVX_ERR_INVALID, "ivx_world_step_enqueue: null world");
+// `timed`: bracket the phases with event records for stage_ms. Only the synchronous ivx_world_step asks for them: an event record
+// is a packet of its own on the queue (~2-3 us each), and a frame that enqueues this step between other work has no use for them.
+static int world_step_enqueue(ivx_world* w, float dt, bool timed) {
     hipStream_t s = w->ctx->stream;
-    if (!w->ev_ready) {
+    if (timed && !w->ev_ready) {
         for (int i = 0; i < 5; ++i) IVX_HIP_CHECK(hipEventCreate(&w->ev[i]));
         w->ev_ready = 1;
     }
+#define EV(i)                                              \
+    do {                                                   \
+        if (timed) IVX_HIP_CHECK(hipEventRecord(w->ev[i], s)); \
+    } while (0)
     int rc;
     if (w->n_contacts == 0 && !w->prepared_fresh) {
         // no constraints this step: prepare, advance momenta and advance configurations are element-wise per body — one launch
         w->cur ^= 1;
         w->n_prev = 0;
-        for (int i = 0; i < 4; ++i) IVX_HIP_CHECK(hipEventRecord(w->ev[i], s));
+        for (int i = 0; i < 4; ++i) EV(i);
         if ((rc = ivx_launch_phys_free_step(w, dt))) return rc;
-        IVX_HIP_CHECK(hipEventRecord(w->ev[4], s));
+        EV(4);
         return IVX_OK;
     }
-    IVX_HIP_CHECK(hipEventRecord(w->ev[0], s));
+    EV(0);
     if (!w->prepared_fresh)
         if ((rc = ivx_world_prepare(w))) return rc;
-    IVX_HIP_CHECK(hipEventRecord(w->ev[1], s));
+    EV(1);
     if ((rc = ivx_launch_phys_pre_solve(w, dt))) return rc;
-    IVX_HIP_CHECK(hipEventRecord(w->ev[2], s));
+    EV(2);
     if ((rc = ivx_launch_phys_solve(w))) return rc;
-    IVX_HIP_CHECK(hipEventRecord(w->ev[3], s));
+    EV(3);
     if ((rc = ivx_launch_phys_post_solve(w, dt, 1, 1))) return rc;
-    IVX_HIP_CHECK(hipEventRecord(w->ev[4], s));
+    EV(4);
+#undef EV
     w->prepared_fresh = 0;
     return IVX_OK;
 }
 
+int ivx_world_step_enqueue(ivx_world* w, float dt) {
+    IVX_REQUIRE(w, IVX_ERR_INVALID, "ivx_world_step_enqueue: null world");
+    return world_step_enqueue(w, dt, false);
+}
+
 int ivx_world_step(ivx_world* w, float dt, ivx_physics_result* out) {
-    int rc = ivx_world_step_enqueue(w, dt);
+    IVX_REQUIRE(w, IVX_ERR_INVALID, "ivx_world_step: null world");
+    int rc = world_step_enqueue(w, dt, out != nullptr);
     if (rc) return rc;
     IVX_HIP_CHECK(hipStreamSynchronize(w->ctx->stream));
     if (out) {

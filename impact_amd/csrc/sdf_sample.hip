@@ -649,16 +649,24 @@ __device__ __forceinline__ void combine_levels(uint32_t kind, float s, float q, 
             apply = __builtin_amdgcn_readfirstlane(!(combine(kind, v1, v2, s, q) >= margin) ? 1 : 0) != 0;
         } else {
             __syncthreads();
-            // distinct flat indices of the 26 test positions: 8 corners + 6 face centres
-            const int TI[14] = {0, 15, 0, 0, 15, 15, 0, 15, 0, 15, 8, 8, 8, 8};
-            const int TJ[14] = {0, 0, 15, 0, 15, 0, 15, 15, 8, 8, 0, 15, 8, 8};
-            const int TK[14] = {0, 0, 0, 15, 0, 15, 15, 15, 8, 8, 8, 8, 0, 15};
-            bool all_pass = true;
-#pragma unroll
-            for (int t = 0; t < 14; ++t) {
-                int off = TK[t] * 256 + (TI[t] * 16 + TJ[t]);
-                all_pass = all_pass && (combine(kind, c1 ? v1 : d1[off], c2 ? v2 : d2[off], s, q) >= margin);
+            // The 26 test positions fall on 14 distinct voxels: 8 corners + 6 face centres. One LANE per voxel (every wave repeats it:
+            // the decision has to be known to all of them) instead of every thread walking all 14 — the conjunction does not depend on
+            // the order. Lanes 0..7: corner with bit b of the lane choosing 0 or 15 along axis b; lanes 8..13: axis (l - 8) / 2 at 0 or
+            // 15, the other two at 8.
+            const uint32_t l = tid & 63u;
+            uint32_t pi, pj, pk;
+            if (l < 8u) {
+                pi = (l & 1u) ? 15u : 0u, pj = (l & 2u) ? 15u : 0u, pk = (l & 4u) ? 15u : 0u;
+            } else {
+                const uint32_t axis = (l - 8u) >> 1, side = ((l - 8u) & 1u) ? 15u : 0u;
+                pi = axis == 0u ? side : 8u, pj = axis == 1u ? side : 8u, pk = axis == 2u ? side : 8u;
             }
+            bool pass = true;
+            if (l < 14u) {
+                const uint32_t off = pk * 256u + (pi * 16u + pj);
+                pass = combine(kind, c1 ? v1 : d1[off], c2 ? v2 : d2[off], s, q) >= margin;
+            }
+            const bool all_pass = __all(pass ? 1 : 0) != 0;
             apply = __builtin_amdgcn_readfirstlane(all_pass ? 0 : 1) != 0;
             __syncthreads();
         }

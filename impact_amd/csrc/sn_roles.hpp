@@ -33,9 +33,102 @@ struct SnParams {
     uint32_t x_off;
 };
 
-// One padded row (fixed gi, gj; cells gk = ck*16 - 1 .. ck*16 + 16) of the object, relative to this slab. Outside the
-// grid / void -> (127, 255) (object/sdf.rs:410-508: void neighbours pad with +2.54).
+// What one padded row needs from memory, with every load ISSUED before any of them is used. Written the obvious way (record, then
+// "if the neighbour is dense, its byte") the compiler sinks each load under the branch that consumes it and the row costs five
+// dependent memory round trips; a tile is two rows per thread, i.e. ten round trips = most of the mesher's tile phase (measured:
+// 7 us of a workgroup's 20). Here the addresses are clamped to valid ones, all loads go out back to back, `row_pin` keeps them from
+// being sunk, and the records only select afterwards.
+struct RowLoads {
+    uint2 c0, c1, c2;      // chunk records below / own / above along k (8 bytes each)
+    uint4 s4, t4;          // the 16 interior cells
+    uint32_t b0s, b0t, b2s, b2t;  // k-halo bytes from the neighbours' face arrays
+    uint32_t mode;         // 0: outside the grid (padding), 1: in the slab (fields above), 2: ghost layer / other (serial path)
+    uint32_t has_lo, has_hi;
+};
+__device__ __forceinline__ void row_issue(const GridView& g, int gi, int gj, int ck, RowLoads& L) {
+    L.mode = 0u;
+    if (gj < 0 || gj >= (int)g.cy * 16) return;
+    if (gi < 0 || gi >= (int)g.cx * 16) {
+        L.mode = 2u;
+        return;
+    }
+    L.mode = 1u;
+    const size_t cidx = (size_t)(((gi >> 4) * g.cy + (gj >> 4)) * g.cz) + (size_t)ck;
+    const uint32_t rix = (uint32_t)(((gi & 15) << 4) | (gj & 15));
+    const size_t o = (cidx << 12) + ((size_t)rix << 4);
+    L.has_lo = ck > 0 ? 1u : 0u;
+    L.has_hi = ck + 1 < (int)g.cz ? 1u : 0u;
+    const uint2* ip = reinterpret_cast<const uint2*>(g.info) + cidx;
+    const uint8_t* kf = g.kface + cidx * 1024 + rix;
+    const uint2* ip0 = L.has_lo ? ip - 1 : ip;
+    const uint2* ip2 = L.has_hi ? ip + 1 : ip;
+    const uint8_t* kf0 = L.has_lo ? kf - 1024 : kf;
+    const uint8_t* kf2 = L.has_hi ? kf + 1024 : kf;
+    L.c1 = *ip;
+    L.s4 = *reinterpret_cast<const uint4*>(g.sdf + o);
+    L.t4 = *reinterpret_cast<const uint4*>(g.type + o);
+    L.c0 = *ip0;
+    L.c2 = *ip2;
+    L.b0s = kf0[256];
+    L.b0t = kf0[768];
+    L.b2s = kf2[0];
+    L.b2t = kf2[512];
+}
+// (an empty asm that "modifies" the loaded registers: the loads cannot move below it)
+__device__ __forceinline__ void row_pin(RowLoads& L) {
+    asm volatile("" : "+v"(L.c0.x), "+v"(L.c1.x), "+v"(L.c2.x), "+v"(L.c0.y), "+v"(L.c1.y), "+v"(L.c2.y));
+    asm volatile("" : "+v"(L.s4.x), "+v"(L.s4.y), "+v"(L.s4.z), "+v"(L.s4.w), "+v"(L.t4.x), "+v"(L.t4.y), "+v"(L.t4.z), "+v"(L.t4.w));
+    asm volatile("" : "+v"(L.b0s), "+v"(L.b0t), "+v"(L.b2s), "+v"(L.b2t));
+}
+__device__ __forceinline__ ivx_chunk_info record_of(uint2 w) {
+    ivx_chunk_info c;
+    c.kind = (uint8_t)(w.x & 0xFFu);
+    c.gen_kind = (uint8_t)((w.x >> 8) & 0xFFu);
+    c.flags = (uint8_t)((w.x >> 16) & 0xFFu);
+    c.uniform_type = (uint8_t)(w.x >> 24);
+    c.face_dist = (uint16_t)(w.y & 0xFFFFu);
+    c.region_count = (uint8_t)((w.y >> 16) & 0xFFu);
+    c.boundary_region_count = (uint8_t)(w.y >> 24);
+    return c;
+}
+__device__ __forceinline__ void fetch_row_serial(const GridView& g, int gi, int gj, int ck, uint32_t sd[6], uint32_t ty[6]);
+// sd/ty: [0] = cell 0 (byte), [1..4] = the 16 interior cells (words), [5] = cell 17 (byte). Outside the grid / void -> (127, 255)
+// (object/sdf.rs:410-508: void neighbours pad with +2.54). Inside the slab a Void / Uniform chunk is its record, not its planes.
+__device__ __forceinline__ void row_finish(const GridView& g, int gi, int gj, int ck, const RowLoads& L, uint32_t sd[6], uint32_t ty[6]) {
+    sd[0] = sd[5] = 0x7Fu;
+    ty[0] = ty[5] = 0xFFu;
+    sd[1] = sd[2] = sd[3] = sd[4] = 0x7F7F7F7Fu;
+    ty[1] = ty[2] = ty[3] = ty[4] = 0xFFFFFFFFu;
+    if (L.mode == 0u) return;
+    if (L.mode == 2u) {
+        fetch_row_serial(g, gi, gj, ck, sd, ty);
+        return;
+    }
+    const ivx_chunk_info c1 = record_of(L.c1), c0 = record_of(L.c0), c2 = record_of(L.c2);
+    const bool d1 = c1.kind == KIND_NONUNIFORM;
+    const uint32_t us = ivx_uniform_sdf(c1.kind) * 0x01010101u, ut = ivx_uniform_type(c1) * 0x01010101u;
+    sd[1] = d1 ? L.s4.x : us, sd[2] = d1 ? L.s4.y : us, sd[3] = d1 ? L.s4.z : us, sd[4] = d1 ? L.s4.w : us;
+    ty[1] = d1 ? L.t4.x : ut, ty[2] = d1 ? L.t4.y : ut, ty[3] = d1 ? L.t4.z : ut, ty[4] = d1 ? L.t4.w : ut;
+    if (L.has_lo) {
+        const bool dense = c0.kind == KIND_NONUNIFORM;
+        sd[0] = dense ? L.b0s : ivx_uniform_sdf(c0.kind);
+        ty[0] = dense ? L.b0t : ivx_uniform_type(c0);
+    }
+    if (L.has_hi) {
+        const bool dense = c2.kind == KIND_NONUNIFORM;
+        sd[5] = dense ? L.b2s : ivx_uniform_sdf(c2.kind);
+        ty[5] = dense ? L.b2t : ivx_uniform_type(c2);
+    }
+}
 __device__ __forceinline__ void fetch_row(const GridView& g, int gi, int gj, int ck, uint32_t sd[6], uint32_t ty[6]) {
+    RowLoads L;
+    row_issue(g, gi, gj, ck, L);
+    if (L.mode == 1u) row_pin(L);
+    row_finish(g, gi, gj, ck, L, sd, ty);
+}
+
+// The same row by the plain dependent path: rows of a ghost layer (a slab's x halo) and, inside the slab, the reference form of the above.
+__device__ __forceinline__ void fetch_row_serial(const GridView& g, int gi, int gj, int ck, uint32_t sd[6], uint32_t ty[6]) {
     // sd/ty: [0] = cell 0 (byte), [1..4] = the 16 interior cells (words), [5] = cell 17 (byte)
     sd[0] = sd[5] = 0x7Fu;
     ty[0] = ty[5] = 0xFFu;
@@ -72,16 +165,19 @@ __device__ __forceinline__ void fetch_row(const GridView& g, int gi, int gj, int
         const uint32_t us = ivx_uniform_sdf(c1.kind) * 0x01010101u, ut = ivx_uniform_type(c1) * 0x01010101u;
         sd[1] = d1 ? s4.x : us, sd[2] = d1 ? s4.y : us, sd[3] = d1 ? s4.z : us, sd[4] = d1 ? s4.w : us;
         ty[1] = d1 ? t4.x : ut, ty[2] = d1 ? t4.y : ut, ty[3] = d1 ? t4.z : ut, ty[4] = d1 ? t4.w : ut;
+        // the k halo comes from the face bytes k_derive set side by side (kface): in the planes they sit 16 bytes apart, a cache
+        // line for every four rows and plane — three times the lines of the tile's interior
+        const uint8_t* kf = g.kface + (o >> 12) * 1024 + ((uint32_t)(o & 4095u) >> 4);
         if (ck > 0) {
             const ivx_chunk_info c0 = ip[-1];
-            const uint32_t bs = (uint8_t)ps[o - kstride + 15], bt = pt[o - kstride + 15];
+            const uint32_t bs = kf[-1024 + 256], bt = kf[-1024 + 768];
             const bool dense = c0.kind == KIND_NONUNIFORM;
             sd[0] = dense ? bs : ivx_uniform_sdf(c0.kind);
             ty[0] = dense ? bt : ivx_uniform_type(c0);
         }
         if (ck + 1 < (int)g.cz) {
             const ivx_chunk_info c2 = ip[1];
-            const uint32_t bs = (uint8_t)ps[o + kstride], bt = pt[o + kstride];
+            const uint32_t bs = kf[1024], bt = kf[1024 + 512];
             const bool dense = c2.kind == KIND_NONUNIFORM;
             sd[5] = dense ? bs : ivx_uniform_sdf(c2.kind);
             ty[5] = dense ? bt : ivx_uniform_type(c2);
@@ -151,31 +247,50 @@ __device__ __forceinline__ uint32_t neighbour_kind(const GridView& g, int ci, in
 // Stage the 18^3 padded tile: 324 rows, one 16-byte plane load each (+ two halo bytes). s_neg[r] = 18-bit mask of
 // negative distances (decoded 0 is +0.0 => outside, surface_nets.rs:209-224). s_sd / s_ty may be null (count pass).
 __device__ __forceinline__ void load_tile(const GridView& g, int ci, int cj, int ck, uint8_t* s_sd, uint8_t* s_ty, uint32_t* s_neg, uint32_t tid) {
+    constexpr int ROUNDS = (NROWS + 255) / 256;
+    if (!s_sd) {  // count pass: signs only
 #pragma unroll
-    for (int it = 0; it < (NROWS + 255) / 256; ++it) {  // unrolled: the loads of both rounds are in flight together
+        for (int it = 0; it < ROUNDS; ++it) {
+            const int r = (int)tid + 256 * it;
+            if (r >= NROWS) break;
+            const int a = r / G, b = r - a * G;
+            s_neg[r] = fetch_row_signs(g, ci * 16 + a - 1, cj * 16 + b - 1, ck);
+        }
+        return;
+    }
+    // the loads of all of the thread's rows go out before the first of them is looked at (see RowLoads)
+    RowLoads L[ROUNDS];
+#pragma unroll
+    for (int it = 0; it < ROUNDS; ++it) {
+        const int r = (int)tid + 256 * it;
+        L[it].mode = 0u;
+        if (r < NROWS) {
+            const int a = r / G, b = r - a * G;
+            row_issue(g, ci * 16 + a - 1, cj * 16 + b - 1, ck, L[it]);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < ROUNDS; ++it)
+        if (L[it].mode == 1u) row_pin(L[it]);
+#pragma unroll
+    for (int it = 0; it < ROUNDS; ++it) {
         const int r = (int)tid + 256 * it;
         if (r >= NROWS) break;
         const int a = r / G, b = r - a * G;
-        if (!s_sd) {  // count pass: signs only
-            s_neg[r] = fetch_row_signs(g, ci * 16 + a - 1, cj * 16 + b - 1, ck);
-            continue;
-        }
         uint32_t sd[6], ty[6];
-        fetch_row(g, ci * 16 + a - 1, cj * 16 + b - 1, ck, sd, ty);
+        row_finish(g, ci * 16 + a - 1, cj * 16 + b - 1, ck, L[it], sd, ty);
         s_neg[r] = ((sd[0] >> 7) & 1u) | (neg16(sd + 1) << 1) | (((sd[5] >> 7) & 1u) << 17);
-        if (s_sd) {
-            uint8_t* ds = s_sd + r * RS;
-            uint8_t* dt = s_ty + r * RS;
-            ds[3] = (uint8_t)sd[0];
-            dt[3] = (uint8_t)ty[0];
+        uint8_t* ds = s_sd + r * RS;
+        uint8_t* dt = s_ty + r * RS;
+        ds[3] = (uint8_t)sd[0];
+        dt[3] = (uint8_t)ty[0];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                reinterpret_cast<uint32_t*>(ds + 4)[q] = sd[1 + q];
-                reinterpret_cast<uint32_t*>(dt + 4)[q] = ty[1 + q];
-            }
-            ds[20] = (uint8_t)sd[5];
-            dt[20] = (uint8_t)ty[5];
+        for (int q = 0; q < 4; ++q) {
+            reinterpret_cast<uint32_t*>(ds + 4)[q] = sd[1 + q];
+            reinterpret_cast<uint32_t*>(dt + 4)[q] = ty[1 + q];
         }
+        ds[20] = (uint8_t)sd[5];
+        dt[20] = (uint8_t)ty[5];
     }
 }
 

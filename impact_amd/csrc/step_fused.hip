@@ -65,6 +65,7 @@ struct StepArgs {
     // results
     uint32_t* host_block;     // null: no gather in this launch
     const uint32_t* eval_count;
+    uint32_t seq;             // k_step_gather: the step's sequence number, written last (the host's completion doorbell)
 };
 
 __device__ __forceinline__ sn::SnParams sn_params(const StepArgs& a) {
@@ -146,6 +147,11 @@ __global__ __launch_bounds__(256) void k_step_assign(StepArgs a) {
 // the results as a launch of their own (one block), ordered after everything enqueued so far
 __global__ __launch_bounds__(64) void k_step_gather(StepArgs a) {
     role_result_gather(a.rscalar, a.offsets + 2 * (size_t)a.n_chunks, a.moments_out, a.work_count, a.eval_count, a.host_block, false, 0u);
+    // Doorbell: the sequence number lands after every result word of this (single-wave) block. The stream is in order, so a host that
+    // sees it also knows that everything enqueued before this launch is complete (ivx_voxel_step_collect polls it instead of paying
+    // the runtime's blocking wait when the step is short).
+    __threadfence_system();
+    if (threadIdx.x == 0u) __hip_atomic_store(a.host_block + 63, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace
@@ -257,6 +263,7 @@ int ivx_launch_step_assign(ivx_grid* g) {
 
 int ivx_launch_step_gather(ivx_grid* g) {
     StepArgs a = make_args(g);
+    a.seq = ++g->result_seq;
     hipLaunchKernelGGL(k_step_gather, dim3(1), dim3(64), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;

@@ -213,14 +213,31 @@ class VoxelObject:
 
     def step_enqueue(self, stages: int = capi.STAGE_ALL):
         """launch the kernels of `stages` without waiting (`ivx_voxel_step_enqueue`)"""
-        check(capi.lib().ivx_voxel_step_enqueue(self.h, stages))
+        if getattr(self, "_fn_enqueue", None) is None:
+            self._step_buffers()
+        rc = self._fn_enqueue(self.h, stages)
+        if rc:
+            check(rc)
+
+    def _step_buffers(self):
+        # the step pair is called once per frame: keep the foreign functions and the result record instead of looking them up and
+        # allocating per call (tens of microseconds of interpreter time the GPU would sit idle for)
+        lib = capi.lib()
+        self._fn_enqueue, self._fn_collect = lib.ivx_voxel_step_enqueue, lib.ivx_voxel_step_collect
+        self._res = np.zeros(1, dtype=capi.STEP_RESULT_DTYPE)
+        self._res_ptr = ptr(self._res)
 
     def step_collect(self) -> np.ndarray:
-        """wait once and fetch the results of everything enqueued since the last collect (`ivx_voxel_step_collect`)"""
-        out = np.zeros(1, dtype=capi.STEP_RESULT_DTYPE)
-        check(capi.lib().ivx_voxel_step_collect(self.h, ptr(out)))
-        self._region_count = int(out[0]["region_count"])
-        return out[0]
+        """wait once and fetch the results of everything enqueued since the last collect (`ivx_voxel_step_collect`). The record that comes
+        back is this object's own buffer: it is overwritten by the next collect."""
+        if getattr(self, "_fn_enqueue", None) is None:
+            self._step_buffers()
+        rc = self._fn_collect(self.h, self._res_ptr)
+        if rc:
+            check(rc)
+        r = self._res[0]
+        self._region_count = int(r["region_count"])
+        return r
 
     # ---- derived state ----------------------------------------------------------------------
     def derive_state(self):

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Developer tool: what the sampler's pre-pass left for the per-voxel evaluator on the 512^3 bench workload — per evaluated chunk the number of
+leaf evaluations, combinations (applied unconditionally / behind the 14-position test) and folded constants of its compact program.
+usage: prog_stats.py [scale]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from impact_amd import capi, scenes  # noqa: E402
+from impact_amd.voxel import Context, SDFVoxelGenerator, VoxelObject  # noqa: E402
+
+
+def main():
+    scale = float(sys.argv[1]) if len(sys.argv) > 1 else 2.05
+    ctx = Context(0)
+    gen = SDFVoxelGenerator(1.0, scenes.asteroid_scene(scale), 0)
+    obj = VoxelObject(ctx, gen.chunk_counts(), 1.0)
+    obj.set_sdf_program(gen)
+    obj.set_densities(np.ones(256, dtype=np.float32))
+    obj.step(capi.STAGE_ALL)
+    lib = capi.lib()
+    lib.ivx_grid_device_ptr.restype = C.c_void_p
+    n = obj.n_chunks
+    hip = C.CDLL("libamdhip64.so")
+    lens = np.zeros(4 * n + 4, dtype=np.uint32)
+    ops = np.zeros((n, 128, 2), dtype=np.uint32)
+    hip.hipDeviceSynchronize()
+    assert hip.hipMemcpy(lens.ctypes.data_as(C.c_void_p), C.c_void_p(lib.ivx_grid_device_ptr(obj.h, 7)), lens.nbytes, 2) == 0
+    assert hip.hipMemcpy(ops.ctypes.data_as(C.c_void_p), C.c_void_p(lib.ivx_grid_device_ptr(obj.h, 8)), ops.nbytes, 2) == 0
+    counts = lens[n:n + 3]
+    print("evaluation lists (<=2 levels, 3, more):", counts.tolist())
+    names = {}
+    tot = np.zeros(16, dtype=np.int64)
+    per_chunk = []
+    for c in range(3):
+        lst = lens[n + 4 + c * n:n + 4 + c * n + counts[c]]
+        for ch in lst:
+            ln = lens[ch]
+            if ln > 128:
+                continue
+            opc = ops[ch, :ln, 0] >> 28
+            h = np.bincount(opc, minlength=16)
+            tot += h
+            per_chunk.append(h)
+    per_chunk = np.array(per_chunk)
+    print("chunks", len(per_chunk), "ops per chunk by opcode (mean):", {i: round(float(per_chunk[:, i].mean()), 2) for i in range(16) if tot[i]})
+    print("program length percentiles:", [int(np.percentile(per_chunk.sum(1), q)) for q in (10, 50, 90, 100)])
+
+
+if __name__ == "__main__":
+    main()

@@ -42,12 +42,24 @@ def main():
     med = np.median(buf[: n // 4, 0].astype(np.float64))
     ok = np.all(np.abs(buf[:, :6].astype(np.float64) - med) < 1e6, axis=1)  # slots of entries that were not written hold old data
     v = buf[ok]
+    # the buffer is shared by every traced kernel: entries beyond this kernel's list keep an earlier kernel's stamps. Keep the LAST
+    # cluster of start times (the traced kernel ran last), split at the widest gap of more than 30 us.
+    order = np.argsort(v[:, 0])
+    v = v[order]
+    gaps = np.diff(v[:, 0].astype(np.int64))
+    if len(gaps) and gaps.max() > 3000:
+        v = v[int(np.argmax(gaps)) + 1:]
     t0 = int(v[:, 0].min())
     d = (v[:, :6].astype(np.int64) - t0) * 0.01  # us
     print(f"entries {len(v)}, span {d[:, 5].max():.1f} us")
     print("mean us between probes:", " ".join(f"{(d[:, i + 1] - d[:, i]).mean():.2f}" for i in range(5)), f"| total {(d[:, 5] - d[:, 0]).mean():.2f}")
+    if v[:, 6].max() > 0:
+        e = (v[:, 6:8].astype(np.int64) - t0) * 0.01
+        print("extra probes after probe 0 (us): 6:", round(float((e[:, 0] - d[:, 0]).mean()), 2), " 7:", round(float((e[:, 1] - d[:, 0]).mean()), 2))
     print("start percentiles us", [round(float(np.percentile(d[:, 0], q)), 1) for q in (0, 10, 25, 50, 75, 90, 100)])
     print("end percentiles us", [round(float(np.percentile(d[:, 5], q)), 1) for q in (0, 10, 25, 50, 75, 90, 100)])
+    dur = d[:, 5] - d[:, 0]
+    print("entry duration percentiles us", [round(float(np.percentile(dur, q)), 1) for q in (0, 10, 50, 90, 100)])
     for t in (5, 10, 20, 40, 60, 80):
         print(f"in flight at {t} us: {int(np.sum((d[:, 0] <= t) & (d[:, 5] > t)))}")
 
