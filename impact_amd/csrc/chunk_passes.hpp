@@ -182,12 +182,35 @@ __device__ __forceinline__ void ccl_exact_chunk(CclShared& sh, uint32_t tid, uin
                 for (int guard = 0; guard < 4096; ++guard) {
                     uint32_t ra = pa, rb = pb;
                     if (valid) {
-                        for (uint32_t p; (p = spar[ra >> 1]) != ra;) ra = p;
-                        for (uint32_t p; (p = spar[rb >> 1]) != rb;) rb = p;
+                        // (path halving: a set that keeps winning grows a chain as long as the number of sets it swallowed; a parent only
+                        // ever moves to an ancestor, so the roots — all that the numbering depends on — are untouched)
+                        for (uint32_t p; (p = spar[ra >> 1]) != ra;) {
+                            const uint32_t gp = spar[p >> 1];
+                            spar[ra >> 1] = (uint16_t)gp;
+                            ra = gp;
+                        }
+                        for (uint32_t p; (p = spar[rb >> 1]) != rb;) {
+                            const uint32_t gp = spar[p >> 1];
+                            spar[rb >> 1] = (uint16_t)gp;
+                            rb = gp;
+                        }
                     }
-                    const unsigned long long pending = __ballot(valid && ra != rb);
+                    const bool mine = valid && ra != rb;
+                    const unsigned long long pending = __ballot(mine);
                     if (!pending) break;
-                    if (lane == (uint32_t)__ffsll((long long)pending) - 1u) spar[rb >> 1] = (uint16_t)ra;  // a's set wins
+                    // In event order a's set wins: the root of b's set becomes a LOSER (it gets a parent), and which root a merged set ends up
+                    // with is settled by which of its roots never loses. Several pending events are applied in one round when that cannot
+                    // change any event's loser: an event waits only for an earlier pending event whose loser is its loser or its winner, or
+                    // whose winner is its loser (the first pending event never waits). Events that share a WINNER — the usual case, one
+                    // big set swallowing many small ones — all go at once. Losers of a round are distinct and none is a winner of the
+                    // round, so the forest stays a forest; the sets and their roots are those of the one-at-a-time order.
+                    bool blocked = false;
+                    for (unsigned long long pm = pending; pm; pm &= pm - 1ull) {
+                        const uint32_t j = (uint32_t)__ffsll((long long)pm) - 1u;  // (wave-uniform)
+                        const uint32_t raj = (uint32_t)__builtin_amdgcn_readlane((int)ra, (int)j), rbj = (uint32_t)__builtin_amdgcn_readlane((int)rb, (int)j);
+                        blocked = blocked || (j < lane && (rbj == rb || rbj == ra || raj == rb));
+                    }
+                    if (mine && !blocked) spar[rb >> 1] = (uint16_t)ra;
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 }
             }

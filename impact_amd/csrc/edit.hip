@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void k_absorb(AbsorbParams p, int8_t* __restri
         }
         info[chunk] = out;
         if (touched) {  // with the voxel ranges handle_chunk_voxels_modified sees, chunk-relative: lo 0..15, hi-1 0..15
-            touched_ranges[chunk] = 0x80000000u | (uint32_t)(rlo[0] - cbase[0]) | ((uint32_t)(rlo[1] - cbase[1]) << 4) | ((uint32_t)(rlo[2] - cbase[2]) << 8) |
+            touched_ranges[b] = 0x80000000u | (uint32_t)(rlo[0] - cbase[0]) | ((uint32_t)(rlo[1] - cbase[1]) << 4) | ((uint32_t)(rlo[2] - cbase[2]) << 8) |
                                     ((uint32_t)(rhi[0] - 1 - cbase[0]) << 12) | ((uint32_t)(rhi[1] - 1 - cbase[1]) << 16) |
                                     ((uint32_t)(rhi[2] - 1 - cbase[2]) << 20);
             atomicAdd(&counters[0], 1u);

@@ -869,19 +869,28 @@ int ivx_regions_describe(ivx_grid* g, const float densities[256], ivx_region_des
     return IVX_OK;
 }
 
-static int rederive(ivx_grid* g) {
-    int rc;
-    if ((rc = ivx_launch_derive(g, IVX_PART_REGIONS))) return rc;  // flags and chunk-local regions in one sweep
-    if ((rc = ivx_launch_ccl_local(g, 1))) return rc;
-    if ((rc = ivx_launch_ccl_merge(g))) return rc;
-    if ((rc = ivx_launch_ccl_resolve(g))) return rc;
-    uint32_t sc[2];
-    if ((rc = d2h(g, sc, g->rscalar, sizeof(sc)))) return rc;
-    IVX_REQUIRE((sc[1] & 1u) == 0, IVX_ERR_CAPACITY, "a chunk has more than 254 local regions");
-    g->region_count = sc[0];
-    g->regions_valid = 1;
+// Derived state + regions of an object whose voxels changed, through the fused step path (ivx_voxel_step_enqueue: five launches and the
+// results block instead of the stand-alone passes' ten launches and a blocking copy). `rederive_enqueue` only puts the work on the
+// stream — a caller with results of its own still in flight waits for both with the one `rederive_collect`.
+int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages);
+int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out);
+static int rederive_enqueue(ivx_grid* g) {
+    const uint32_t keep = g->stage_timing_off;
+    g->stage_timing_off = 0xFFFFFFFFu;  // (no event records around the slots: nobody reads this call's stage times)
+    const int rc = ivx_voxel_step_enqueue(g, IVX_STAGE_DERIVE | IVX_STAGE_REGIONS);
+    g->stage_timing_off = keep;
+    return rc;
+}
+static int rederive_collect(ivx_grid* g) {
+    ivx_step_result res;
+    const int rc = ivx_voxel_step_collect(g, &res);
+    if (rc) return rc;
     g->mesh_valid = 0;
     return IVX_OK;
+}
+static int rederive(ivx_grid* g) {
+    const int rc = rederive_enqueue(g);
+    return rc ? rc : rederive_collect(g);
 }
 
 int ivx_split_off_smallest_region(ivx_grid* parent, ivx_grid** child, uint32_t origin_offset_in_parent[3], int* outcome, ivx_region_desc* moved) {
@@ -1279,8 +1288,9 @@ static int absorb_shape(ivx_grid* g, const char* who, int capsule, const float c
         lo[d] = (uint32_t)vlo[d] / 16u;
         cc[d] = ((uint32_t)vhi[d] + 15u) / 16u - lo[d];
     }
-    // scratch: [10 f64 removed moments][256 u32 by type][2 u32 counters][pad][n_chunks u32 touched ranges]
-    const size_t off_type = 80, off_cnt = off_type + 1024, off_touch = off_cnt + 16, total = off_touch + (size_t)g->n_chunks * 4;
+    // scratch: [10 f64 removed moments][256 u32 by type][2 u32 counters][pad][u32 touched ranges of the box's chunks]
+    const size_t box_chunks = (size_t)cc[0] * cc[1] * cc[2];  // (touched ranges are indexed by the chunk's position in the box)
+    const size_t off_type = 80, off_cnt = off_type + 1024, off_touch = off_cnt + 16, total = off_touch + box_chunks * 4;
     const size_t off_dens = (total + 255) & ~(size_t)255;
     if ((rc = ensure_dev_scratch(g, off_dens + 1024))) return rc;
     char* base = static_cast<char*>(g->dev_scratch);
@@ -1292,11 +1302,20 @@ static int absorb_shape(ivx_grid* g, const char* who, int capsule, const float c
                                 reinterpret_cast<uint32_t*>(base + off_type), reinterpret_cast<uint32_t*>(base + off_cnt),
                                 reinterpret_cast<uint32_t*>(base + off_touch))))
         return rc;
+    // the edit's small results start their way to the host, the derived state of the edited object (flags, kinds, chunk-local regions,
+    // components: the reference patches them around the touched chunks; they are a pure function of the voxels and kinds) follows on
+    // the stream, and ONE wait covers both
     std::vector<char> hostbuf(total);
-    if ((rc = d2h(g, hostbuf.data(), base, total))) return rc;
-    // derived state of the edited object: flags, kinds, chunk-local regions, components (the reference patches them around the
-    // touched chunks; they are a pure function of the voxels and kinds)
-    if ((rc = rederive(g))) return rc;
+    const bool staged = total <= STAGED_COPY_MAX;
+    if (staged) {
+        if ((rc = ensure_host_scratch(g, total))) return rc;
+        IVX_HIP_CHECK(hipMemcpyAsync(g->host_scratch, base, total, hipMemcpyDeviceToHost, g->ctx->stream));
+    } else if ((rc = d2h(g, hostbuf.data(), base, total))) {
+        return rc;
+    }
+    if ((rc = rederive_enqueue(g))) return rc;
+    if ((rc = rederive_collect(g))) return rc;
+    if (staged) memcpy(hostbuf.data(), g->host_scratch, total);
     const double* rem = reinterpret_cast<const double*>(hostbuf.data());
     const double e = (double)g->extent, e3 = e * e * e, e4 = e3 * e, e5 = e4 * e;
     const double f[10] = {e3, 0.5 * e4, 0.5 * e4, 0.5 * e4, e5 / 3.0, e5 / 3.0, e5 / 3.0, 0.25 * e5, 0.25 * e5, 0.25 * e5};
@@ -1320,7 +1339,7 @@ static int absorb_shape(ivx_grid* g, const char* who, int capsule, const float c
             for (uint32_t j = lo[1]; j < lo[1] + cc[1]; ++j)
                 for (uint32_t k = lo[2]; k < lo[2] + cc[2]; ++k) {
                     const uint32_t c = (i * g->cc[1] + j) * g->cc[2] + k;
-                    const uint32_t w = touched[c];
+                    const uint32_t w = touched[((i - lo[0]) * cc[1] + (j - lo[1])) * cc[2] + (k - lo[2])];
                     if (!w) continue;
                     invalidated_chunks[c] = 1;
                     const uint32_t idx[3] = {i, j, k};
@@ -2001,6 +2020,7 @@ int ivx_absorb_mutual(ivx_grid* a, const float rotation_a[4], const float transl
     // scratch (A's): per object [10 f64 removed moments][256 u32 by type][2 u32 counters][pad][n_chunks u32 touched ranges], then the two density
     // tables, then the snapshot
     const size_t off_type = 80, off_cnt = off_type + 1024, off_touch = off_cnt + 16;
+    // (the touched ranges are indexed by the chunk's position in the object's chunk box; the boxes are known further down, a whole grid bounds them)
     const size_t blk_a = (off_touch + (size_t)a->n_chunks * 4 + 255) & ~(size_t)255, blk_b = (off_touch + (size_t)b->n_chunks * 4 + 255) & ~(size_t)255;
     const size_t off_dens = blk_a + blk_b, off_snap = off_dens + 2048;
     if ((rc = ensure_dev_scratch(a, off_snap + snap_bytes + 256))) return rc;
@@ -2063,7 +2083,7 @@ int ivx_absorb_mutual(ivx_grid* a, const float rotation_a[4], const float transl
             for (uint32_t j = lo[1]; j < lo[1] + cc[1]; ++j)
                 for (uint32_t k = lo[2]; k < lo[2] + cc[2]; ++k) {
                     const uint32_t c = (i * g->cc[1] + j) * g->cc[2] + k;
-                    const uint32_t wd = touched[c];
+                    const uint32_t wd = touched[((i - lo[0]) * cc[1] + (j - lo[1])) * cc[2] + (k - lo[2])];
                     if (!wd) continue;
                     inval[c] = 1;
                     const uint32_t idx[3] = {i, j, k};

@@ -282,6 +282,7 @@ constexpr int NODE_TILE = 64;
 // Compact per-chunk program emitted by the pre-pass: op word = opcode<<28 | node kind<<24 | node index;
 // OP_CONST carries the folded constant in the second word.
 constexpr uint32_t OP_CAP = 128u, OP_OVERFLOW = 0xFFFFFFFFu;
+constexpr uint32_t LONG_OPS = 10u;  // compact programs longer than this are evaluated first (see k_sdf_prepass's list appends)
 constexpr uint32_t OP_CONST = 0u, OP_LEAF = 1u, OP_SCALE = 2u, OP_COMBINE = 3u, OP_COMBINE_OUTSIDE = 4u;
 constexpr int PRE_T = 64;
 struct PaddedNode {
@@ -581,13 +582,31 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
         const bool ev = mine && (out != out || to_fill);
         const uint32_t need = pos <= OP_CAP ? (uint32_t)s_need[0][tid] : p.stack_size;  // (the full program may use every level)
         const uint32_t cls = need <= 2u ? 0u : (need == 3u ? 1u : 2u);
+        // The first class (nearly every chunk of a smooth body) is listed longest program first: programs of more than LONG_OPS steps from
+        // the front of its list, the others from the back. Workgroups start in list order, so the evaluator's last workgroups are short
+        // ones and its tail — a tenth of the kernel with the chunks in arbitrary order — shrinks. Counters: [c] = entries of class c,
+        // [3] = long entries of class 0, [4] = short entries of class 0.
+        const bool is_long = pos > LONG_OPS;
 #pragma unroll
         for (uint32_t c = 0; c < 3; ++c) {
             const unsigned long long be = __ballot(ev && cls == c);
             uint32_t base_e = 0;
             if (tid == 0 && be) base_e = atomicAdd(eval_count + c, (uint32_t)__popcll(be));
             base_e = __shfl(base_e, 0, 64);
-            if (ev && cls == c) eval_list[(size_t)c * list_stride + base_e + (uint32_t)__popcll(be & below)] = chunk;
+            if (c == 0u) {
+                const unsigned long long bl = __ballot(ev && cls == 0u && is_long), bs = be & ~bl;
+                uint32_t base_l = 0, base_s = 0;
+                if (tid == 0 && bl) base_l = atomicAdd(eval_count + 3, (uint32_t)__popcll(bl));
+                if (tid == 0 && bs) base_s = atomicAdd(eval_count + 4, (uint32_t)__popcll(bs));
+                base_l = __shfl(base_l, 0, 64);
+                base_s = __shfl(base_s, 0, 64);
+                if (ev && cls == 0u) {
+                    if (is_long) eval_list[base_l + (uint32_t)__popcll(bl & below)] = chunk;
+                    else eval_list[list_stride - 1u - (base_s + (uint32_t)__popcll(bs & below))] = chunk;
+                }
+            } else if (ev && cls == c) {
+                eval_list[(size_t)c * list_stride + base_e + (uint32_t)__popcll(be & below)] = chunk;
+            }
         }
     }
 }
@@ -682,6 +701,7 @@ __device__ __forceinline__ void combine_levels(uint32_t kind, float s, float q, 
 }
 
 __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t* __restrict__ eval_count, const uint32_t* __restrict__ eval_list,
+                                                  const uint32_t* __restrict__ long_count, uint32_t list_len,
                                                   const uint32_t* __restrict__ prog_len, const uint2* __restrict__ prog_ops,
                                                   const ivx_sdf_processed_node* __restrict__ nodes, int8_t* __restrict__ sdf_out,
                                                   uint8_t* __restrict__ type_out, ivx_chunk_info* __restrict__ info_out) {
@@ -689,11 +709,12 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
     const uint32_t tid = threadIdx.x;
     const uint32_t ti = tid >> 4, tj = tid & 15u;
     const uint32_t n_eval = eval_count[0];
+    const uint32_t n_long = long_count ? long_count[0] : n_eval;  // (a list with a long / short split keeps its short entries at the back)
     // bounded grid-stride walk over the list of chunks to evaluate
     for (uint32_t li = blockIdx.x; li < n_eval; li += gridDim.x) {
     __syncthreads();  // the previous chunk's LDS use is over
     IVX_T(p, li, 0);
-    const uint32_t chunk = eval_list[li];
+    const uint32_t chunk = eval_list[li < n_long ? li : list_len - 1u - (li - n_long)];
     const uint32_t ck = chunk % p.cz, cj = (chunk / p.cz) % p.cy, ci = chunk / (p.cz * p.cy);
     const uint32_t oi = (ci + p.x_off) * 16u, oj = cj * 16u, ok = ck * 16u;
     int sd[16];
@@ -854,8 +875,8 @@ __global__ __launch_bounds__(256) void k_classify(uint32_t n_chunks, int8_t* __r
 
 int ivx_sampler_buffers(ivx_grid* g) {
     if (g->samp_ops) return IVX_OK;
-    // [n] program lengths, [4] counters of the three evaluation lists, [3 n] the lists
-    IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_len), sizeof(uint32_t) * (4 * (size_t)g->n_chunks + 4)));
+    // [n] program lengths, [8] counters of the three evaluation lists (+ the long / short split of the first), [3 n] the lists
+    IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_len), sizeof(uint32_t) * (4 * (size_t)g->n_chunks + 8)));
     IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_ops), sizeof(uint2) * (size_t)OP_CAP * g->n_chunks));
     return IVX_OK;
 }
@@ -889,8 +910,8 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
     }
     uint2* ops = reinterpret_cast<uint2*>(g->samp_ops);
     uint32_t* eval_count = g->samp_len + g->n_chunks;
-    uint32_t* eval_list = eval_count + 4;
-    if (!(preset_groups & IVX_SCRATCH_EVAL)) IVX_HIP_CHECK(hipMemsetAsync(eval_count, 0, 4 * sizeof(uint32_t), g->ctx->stream));
+    uint32_t* eval_list = eval_count + 8;
+    if (!(preset_groups & IVX_SCRATCH_EVAL)) IVX_HIP_CHECK(hipMemsetAsync(eval_count, 0, 8 * sizeof(uint32_t), g->ctx->stream));
     const uint32_t sx = (g->cc[0] + SUPER - 1) / SUPER, sy = (g->cc[1] + SUPER - 1) / SUPER, sz = (g->cc[2] + SUPER - 1) / SUPER;
     const uint32_t words = (n_nodes + 31u) / 32u > 0u ? (n_nodes + 31u) / 32u : 1u;
     {
@@ -920,7 +941,7 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
             if (c == 2 && stack_size == 3u) break;
             const size_t lds_c = (size_t)(levels[c] ? levels[c] : 1u) * IVX_CHUNK_VOXELS * sizeof(float);
             hipLaunchKernelGGL(k_sdf_eval, dim3(eval_blocks), dim3(256), lds_c, g->ctx->stream, p, eval_count + c, eval_list + (size_t)c * g->n_chunks,
-                               g->samp_len, ops, d_nodes, g->sdf, g->type, g->info);
+                               c == 0 ? eval_count + 3 : nullptr, g->n_chunks, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info);
         }
     }
     IVX_HIP_CHECK(hipGetLastError());

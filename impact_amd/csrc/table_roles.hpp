@@ -167,12 +167,12 @@ struct PresetArgs {
     uint32_t* rscalar;      // [0..16) region scalars
     uint32_t* sn_sums;      // [n_sn] Surface-Nets group totals + list counter
     uint32_t n_sn;
-    uint32_t* eval_count;   // [3] sampler evaluation lists (may be null)
+    uint32_t* eval_count;   // [5] sampler evaluation list counters (may be null)
 };
 __device__ __forceinline__ void role_preset(const PresetArgs& a, uint32_t gid) {
     if ((a.groups & IVX_SCRATCH_REGIONS) && gid < 16u) a.rscalar[gid] = 0u;
     if ((a.groups & IVX_SCRATCH_SN) && gid < a.n_sn) a.sn_sums[gid] = 0u;
-    if ((a.groups & IVX_SCRATCH_EVAL) && gid < 3u && a.eval_count) a.eval_count[gid] = 0u;
+    if ((a.groups & IVX_SCRATCH_EVAL) && gid < 5u && a.eval_count) a.eval_count[gid] = 0u;
 }
 
 }  // namespace ivx_roles

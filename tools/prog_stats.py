@@ -25,7 +25,7 @@ def main():
     lib.ivx_grid_device_ptr.restype = C.c_void_p
     n = obj.n_chunks
     hip = C.CDLL("libamdhip64.so")
-    lens = np.zeros(4 * n + 4, dtype=np.uint32)
+    lens = np.zeros(4 * n + 8, dtype=np.uint32)
     ops = np.zeros((n, 128, 2), dtype=np.uint32)
     hip.hipDeviceSynchronize()
     assert hip.hipMemcpy(lens.ctypes.data_as(C.c_void_p), C.c_void_p(lib.ivx_grid_device_ptr(obj.h, 7)), lens.nbytes, 2) == 0
@@ -36,7 +36,8 @@ def main():
     tot = np.zeros(16, dtype=np.int64)
     per_chunk = []
     for c in range(3):
-        lst = lens[n + 4 + c * n:n + 4 + c * n + counts[c]]
+        seg = lens[n + 8 + c * n:n + 8 + (c + 1) * n]
+        lst = np.concatenate([seg[:lens[n + 3]], seg[n - lens[n + 4]:]]) if c == 0 else seg[:counts[c]]
         for ch in lst:
             ln = lens[ch]
             if ln > 128:
