@@ -655,7 +655,7 @@ def main():
         workload = f"{scene_name} -> {gen.grid_shape()[0]}^3 grid = {cc[0] * 16}^3 stored voxels ({obj.n_chunks} chunks)"
         parallelism = "single GPU"
     else:
-        from impact_amd.distributed import NativeComm, NativeSlabStepper, SlabStepper, TorchComm, native_step
+        from impact_amd.distributed import NativeComm, NativeSlabStepper, NativeStepGroup, SlabStepper, TorchComm
 
         if args.scaling == "weak" and args.workload == "asteroid":
             # BASELINE.json's config 5: the config-2 asteroid with all lengths scaled so that every rank keeps the 512^3
@@ -676,10 +676,12 @@ def main():
             obj = stepper.obj
             transport = "RCCL (ncclSend / ncclRecv / ncclAllGather inside the library)"
 
+            group = NativeStepGroup([stepper])
+
             def step():
                 body_world.step_enqueue(0.005)  # on the same stream, ahead of the slab's kernels; the protocol's one wait covers it
-                r = native_step([stepper])[0]
-                return {"stage_ms": r.stage_ms, "mesh": {"n_vertices": r.mesh_counts[0], "n_indices": r.mesh_counts[1]}, "region_count": r.region_count}
+                o = group.step()[0]
+                return {"stage_ms": o["stage_ms"], "mesh": o["mesh"], "region_count": o["region_count"]}
         else:  # host-staged protocol check (IVX_BENCH_BACKEND=gloo): the same phases driven from Python over torch.distributed
             stepper = SlabStepper(ctx, graph, dens, rank, world, torch)
             comm = TorchComm(dist, torch, rank, world)

@@ -17,7 +17,10 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "ivx_internal.hpp"
@@ -103,12 +106,25 @@ struct ivx_slab {
     uint8_t* recv[2];
     unsigned long long* record;    // this slab's record (device)
     unsigned long long* gathered;  // nranks records (device)
+    unsigned long long* host_head;      // host-mapped pinned block: the nranks record heads + one doorbell word (the keeper's only)
+    unsigned long long* host_head_dev;  // its device-side address
+    unsigned long long head_seq;        // sequence number of the last publish
     std::vector<unsigned long long> host_records;
     bool has_lo, has_hi;
     int enqueued;
 };
 
 namespace {
+
+// The gathered record heads into the host-mapped block, the sequence number behind them: the step's completion doorbell (the host polls
+// it instead of a copy + blocking wait; see ivx_voxel_step_collect). One block; every wave drains its stores before the barrier.
+__global__ __launch_bounds__(256) void k_slab_publish(const unsigned long long* __restrict__ gathered, unsigned long long* __restrict__ host, uint32_t n_words,
+                                                      unsigned long long seq) {
+    for (uint32_t i = threadIdx.x; i < n_words; i += 256u) host[i] = gathered[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0u) __hip_atomic_store(host + n_words, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 int exchange(ivx_slab** slabs, size_t n, size_t nbytes) {
     ivx_comm* c = slabs[0]->comm;
@@ -243,6 +259,14 @@ int ivx_slab_create(ivx_comm* m, ivx_grid* g, int rank, ivx_slab** out) {
     }
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl->record), sl->rec_words * 8) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl->gathered), sl->rec_words * 8 * (size_t)m->nranks) == hipSuccess;
+    sl->host_head = sl->host_head_dev = nullptr;
+    sl->head_seq = 0;
+    {
+        const size_t head_bytes = ((size_t)m->nranks * HEAD_WORDS + 1) * 8;
+        ok = ok && hipHostMalloc(reinterpret_cast<void**>(&sl->host_head), head_bytes, hipHostMallocMapped) == hipSuccess;
+        if (ok) memset(sl->host_head, 0, head_bytes);
+        ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&sl->host_head_dev), sl->host_head, 0) == hipSuccess;
+    }
     if (!ok) {
         ivx_set_error("ivx_slab_create: device allocation failed");
         ivx_slab_destroy(sl);
@@ -263,6 +287,7 @@ void ivx_slab_destroy(ivx_slab* sl) {
     }
     if (sl->record) (void)hipFree(sl->record);
     if (sl->gathered) (void)hipFree(sl->gathered);
+    if (sl->host_head) (void)hipHostFree(sl->host_head);
     delete sl;
 }
 
@@ -319,8 +344,26 @@ int ivx_slabs_step_collect(ivx_slab** slabs, size_t n, ivx_slab_result* out) {
     std::vector<unsigned long long>& rec = keeper->host_records;
     size_t words = HEAD_WORDS;
     rec.resize((size_t)world * keeper->rec_words);
-    IVX_HIP_CHECK(hipMemcpyAsync(rec.data(), keeper->gathered, (size_t)world * words * 8, hipMemcpyDeviceToHost, s));
-    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    {
+        const uint32_t n_words = (uint32_t)((size_t)world * HEAD_WORDS);
+        const unsigned long long want = ++keeper->head_seq;
+        hipLaunchKernelGGL(k_slab_publish, dim3(1), dim3(256), 0, s, keeper->gathered, keeper->host_head_dev, n_words, want);
+        IVX_HIP_CHECK(hipGetLastError());
+        const volatile unsigned long long* bell = keeper->host_head + n_words;
+        bool rung = false;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t it = 0;; ++it) {  // bounded poll (2 ms), then the runtime's blocking wait
+            if (*bell == want) {
+                rung = true;
+                break;
+            }
+            __builtin_ia32_pause();
+            if ((it & 255u) == 255u && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > 2000) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (!rung) IVX_HIP_CHECK(hipStreamSynchronize(s));
+        memcpy(rec.data(), keeper->host_head, (size_t)n_words * 8);
+    }
     unsigned long long max_pairs = 0;
     for (int r = 0; r < world; ++r) max_pairs = std::max(max_pairs, rec[(size_t)r * words + 1]);
     if (max_pairs > HEAD_PAIRS) {  // (the same decision on every rank) a rank lists more pairs than the head holds: the full records

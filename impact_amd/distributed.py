@@ -402,29 +402,59 @@ class NativeSlabStepper:
         self.obj.close()
 
 
+class NativeStepGroup:
+    """The slabs of this process as one steppable unit: the argument array, the result records and the foreign functions are made
+    once — a step is two calls into the library and nothing else on the host (the per-step Python of `native_step`, tens of
+    microseconds of allocation and conversion, is time the GPU of every rank would sit idle for)."""
+
+    def __init__(self, steppers):
+        self.steppers = list(steppers)
+        n = len(self.steppers)
+        self.n = n
+        self.arr = (C.c_void_p * n)(*[s.h for s in self.steppers])
+        self.out = np.zeros(n, dtype=capi.SLAB_RESULT_DTYPE)
+        self._out_ptr = ptr(self.out)
+        lib = capi.lib()
+        self._enqueue, self._collect = lib.ivx_slabs_step_enqueue, lib.ivx_slabs_step_collect
+
+    def step(self) -> np.ndarray:
+        """one step; the record array that comes back is this object's own buffer (overwritten by the next step)"""
+        rc = self._enqueue(self.arr, self.n)
+        if rc:
+            check(rc)
+        rc = self._collect(self.arr, self.n, self._out_ptr)
+        if rc:
+            check(rc)
+        return self.out
+
+    def results(self):
+        """the last step's records as SlabResult objects, with every slab's local -> global region map"""
+        results = []
+        for s, o in zip(self.steppers, self.out):
+            cap = max(1, int(o["local_region_count"]))
+            m = np.zeros(cap, dtype=np.uint32)
+            got = C.c_size_t(0)
+            check(capi.lib().ivx_slab_region_map(self.steppers[0].h, s.rank, ptr(m), cap, C.byref(got)))
+            r = SlabResult()
+            r.region_count = int(o["region_count"])
+            r.local_region_count = int(o["local_region_count"])
+            r.region_of_local = m[: got.value]
+            r.moments = np.array(o["moments"], dtype=np.float64)
+            r.occupied = np.array(o["occupied"], dtype=np.uint32)
+            r.mesh_counts = (int(o["mesh"]["n_vertices"]), int(o["mesh"]["n_indices"]), int(o["mesh"]["n_submeshes"]))
+            r.vertex_offset, r.index_offset = int(o["vertex_offset"]), int(o["index_offset"])
+            r.total_triangles = int(o["total_triangles"])
+            r.stage_ms = np.asarray(o["stage_ms"], dtype=np.float64)
+            s.obj._region_count = r.local_region_count
+            results.append(r)
+        return results
+
+
 def native_step(steppers):
     """one step of the slabs of this process (RCCL: one; in-process communicator: all ranks in order) -> list of SlabResult"""
-    n = len(steppers)
-    arr = (C.c_void_p * n)(*[s.h for s in steppers])
-    check(capi.lib().ivx_slabs_step_enqueue(arr, n))
-    out = np.zeros(n, dtype=capi.SLAB_RESULT_DTYPE)
-    check(capi.lib().ivx_slabs_step_collect(arr, n, ptr(out)))
-    results = []
-    for s, o in zip(steppers, out):
-        cap = max(1, int(o["local_region_count"]))
-        m = np.zeros(cap, dtype=np.uint32)
-        got = C.c_size_t(0)
-        check(capi.lib().ivx_slab_region_map(steppers[0].h, s.rank, ptr(m), cap, C.byref(got)))
-        r = SlabResult()
-        r.region_count = int(o["region_count"])
-        r.local_region_count = int(o["local_region_count"])
-        r.region_of_local = m[: got.value]
-        r.moments = np.array(o["moments"], dtype=np.float64)
-        r.occupied = np.array(o["occupied"], dtype=np.uint32)
-        r.mesh_counts = (int(o["mesh"]["n_vertices"]), int(o["mesh"]["n_indices"]), int(o["mesh"]["n_submeshes"]))
-        r.vertex_offset, r.index_offset = int(o["vertex_offset"]), int(o["index_offset"])
-        r.total_triangles = int(o["total_triangles"])
-        r.stage_ms = np.asarray(o["stage_ms"], dtype=np.float64)
-        s.obj._region_count = r.local_region_count
-        results.append(r)
-    return results
+    g = getattr(steppers[0], "_group", None)
+    if g is None or g.steppers != list(steppers):
+        g = NativeStepGroup(steppers)
+        steppers[0]._group = g
+    g.step()
+    return g.results()
