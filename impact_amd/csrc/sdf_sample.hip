@@ -142,6 +142,20 @@ __device__ __forceinline__ int sd_from_f32(float v) {
     return (int)s;
 }
 
+// developer trace probes (make TRACE=1): the evaluator's by default; `make TRACE=1 EXTRA=-DIVX_TRACE_PREPASS` traces the pre-pass
+// instead (both kernels run in the sample stage and share the trace buffer)
+#if defined(IVX_WG_TRACE) && defined(IVX_TRACE_PREPASS)
+#define IVX_TP(g, entry, slot) IVX_T(g, entry, slot)
+#define IVX_TE(g, entry, slot) \
+    do {                       \
+    } while (0)
+#else
+#define IVX_TP(g, entry, slot) \
+    do {                       \
+    } while (0)
+#define IVX_TE(g, entry, slot) IVX_T(g, entry, slot)
+#endif
+
 struct SampleParams {
 #ifdef IVX_WG_TRACE
     unsigned long long* trace;
@@ -284,7 +298,8 @@ constexpr int NODE_TILE = 64;
 constexpr uint32_t OP_CAP = 128u, OP_OVERFLOW = 0xFFFFFFFFu;
 constexpr uint32_t LONG_OPS = 10u;  // compact programs longer than this are evaluated first (see k_sdf_prepass's list appends)
 constexpr uint32_t OP_CONST = 0u, OP_LEAF = 1u, OP_SCALE = 2u, OP_COMBINE = 3u, OP_COMBINE_OUTSIDE = 4u;
-constexpr int PRE_T = 64;
+constexpr int PRE_T = 64;      // chunks per pre-pass block: one per lane
+constexpr int PRE_WAVES = 8;   // waves per pre-pass block: all of them take the nodes' box tests, the first walks the program
 struct PaddedNode {
     ivx_sdf_processed_node n;
     uint32_t pad;
@@ -363,7 +378,7 @@ __device__ __forceinline__ bool range_all_far(const uint32_t* mask, uint32_t a, 
     return true;
 }
 
-__global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx_sdf_processed_node* __restrict__ nodes,
+__global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams p, const ivx_sdf_processed_node* __restrict__ nodes,
                                                        float* __restrict__ chunk_const, uint32_t* __restrict__ prog_len,
                                                        uint2* __restrict__ prog_ops, uint32_t* __restrict__ eval_count,
                                                        uint32_t* __restrict__ eval_list, uint32_t list_stride, ivx_chunk_info* __restrict__ info_out,
@@ -376,7 +391,15 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
     __shared__ uint16_t s_start[16][PRE_T];  // op-stream position where each stack level's steps begin
     __shared__ uint8_t s_need[16][PRE_T];    // LDS levels the evaluator needs to produce this stack level (0 for a constant)
     __shared__ PaddedNode s_nodes[NODE_TILE];
-    const uint32_t tid = threadIdx.x;
+    // What a node's step needs from the node's and the chunk's geometry alone — the block test (node_mode) and an evaluated leaf's
+    // distance bounds — does not depend on the stack: the block's waves work it out for a tile of nodes side by side (wave w takes
+    // nodes w, w + PRE_WAVES, ...), then the first wave walks the program with these tables. One wave doing both spent most of the kernel,
+    // 33 nodes one after the other at one wave per SIMD, in this arithmetic.
+    __shared__ uint8_t t_mode[NODE_TILE][PRE_T];  // leaf: 0 evaluate, 1 / 2 constant +-margin; combination: 1 = must apply
+    __shared__ float t_lo[NODE_TILE][PRE_T];
+    __shared__ float t_hi[NODE_TILE][PRE_T];
+    const uint32_t tid = threadIdx.x & (PRE_T - 1u);  // lane = chunk of the super-block
+    const uint32_t wv = threadIdx.x / PRE_T;
     // one block per super-block of 4 x 4 x 4 chunks (so its threads share the super-block's far bits and skip table, staged in
     // LDS with the node tile); threads whose chunk lies beyond the grid still take part in the tile loads and barriers: they
     // redo a chunk of the grid and write nothing
@@ -400,18 +423,40 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
         pos += 1;
     };
     int skip_until = -1;  // nodes up to here belong to a subtree that was replaced by its far constant
+    IVX_TP(p, sb, 0);
     for (uint32_t n = 0; n < p.n_nodes; ++n) {
         if ((n % NODE_TILE) == 0u) {  // stage the next tile of the node program (and of the super-block's tables) in LDS
             __syncthreads();
-            load_node_tile(s_nodes, nodes + n, min((uint32_t)NODE_TILE, p.n_nodes - n), tid, PRE_T);
-            if (n + tid < p.n_nodes) s_skip[tid] = super_skip[(size_t)sb * words * 32u + n + tid];
-            if (tid < NODE_TILE / 32 && (n >> 5) + tid < words) s_far[tid] = super_mask[(size_t)sb * words + (n >> 5) + tid];
+            const uint32_t tile_cnt = min((uint32_t)NODE_TILE, p.n_nodes - n);
+            load_node_tile(s_nodes, nodes + n, tile_cnt, threadIdx.x, PRE_T * PRE_WAVES);
+            if (wv == 0u) {
+                if (n + tid < p.n_nodes) s_skip[tid] = super_skip[(size_t)sb * words * 32u + n + tid];
+                if (tid < NODE_TILE / 32 && (n >> 5) + tid < words) s_far[tid] = super_mask[(size_t)sb * words + (n >> 5) + tid];
+            }
             __syncthreads();
+            for (uint32_t q = wv; q < tile_cnt; q += PRE_WAVES) {
+                const ivx_sdf_processed_node* tn = &s_nodes[q].n;
+                const uint32_t tk = tn->kind;
+                const bool tfar = (s_far[q >> 5] >> (q & 31u)) & 1u;
+                uint32_t mode = 0u;
+                float blo = 0.0f, bhi = 0.0f;
+                if (tk <= 2u) {
+                    mode = tfar ? 1u : node_mode(tn, block);
+                    if (mode == 0u) leaf_bounds(tn, aabb_of_transformed(block, tn->transform), blo, bhi);
+                } else if (tk >= 7u) {
+                    mode = (!tfar && node_mode(tn, block) == 0u) ? 1u : 0u;
+                }
+                t_mode[q][tid] = (uint8_t)mode;
+                t_lo[q][tid] = blo;
+                t_hi[q][tid] = bhi;
+            }
+            __syncthreads();
+            if (n == 0u) IVX_TP(p, sb, 1);  // first tile staged, box tests done
         }
+        if (wv != 0u) continue;  // (the other waves only meet the first at the tile boundaries)
         if ((int)n <= skip_until) continue;
         const ivx_sdf_processed_node* nd = &s_nodes[n % NODE_TILE].n;
         const uint32_t kind = nd->kind;
-        const bool far = (s_far[(n % NODE_TILE) >> 5] >> (n & 31u)) & 1u;  // the node's block test is known to say "outside"
         if (kind <= 2u) {
             // the largest subtree that starts at this leaf and lies outside as a whole collapses to its folded constant
             const uint2 sk2 = s_skip[n % NODE_TILE];
@@ -427,7 +472,7 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
                 skip_until = (int)sk2.x;
                 continue;
             }
-            const uint32_t mode = far ? 1u : node_mode(nd, block);
+            const uint32_t mode = t_mode[n % NODE_TILE][tid];
             s_start[top][tid] = (uint16_t)min(pos, 0xFFFFu);
             if (mode == 1u || mode == 2u) {
                 const float v = mode == 1u ? nd->margin : -nd->margin;
@@ -437,8 +482,7 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
                 cmask |= 1u << top;
                 emit(OP_CONST << 28, __float_as_uint(v));
             } else {
-                float lo, hi;
-                leaf_bounds(nd, aabb_of_transformed(block, nd->transform), lo, hi);
+                const float lo = t_lo[n % NODE_TILE][tid], hi = t_hi[n % NODE_TILE][tid];
                 s_lo[top][tid] = lo;
                 s_hi[top][tid] = hi;
                 s_need[top][tid] = 1;
@@ -460,7 +504,7 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
             const bool c1 = (cmask >> (top - 1)) & 1u, c2 = (cmask >> top) & 1u;
             const float lo1 = s_lo[top - 1][tid], hi1 = s_hi[top - 1][tid], lo2 = s_lo[top][tid], hi2 = s_hi[top][tid];
             const float s = nd->a, q = nd->b;
-            const bool must_apply = !far && node_mode(nd, block) == 0u;
+            const bool must_apply = t_mode[n % NODE_TILE][tid] != 0u;
             if (c1 && c2) {
                 const float r = combine(kind, lo1, lo2, s, q);
                 if (must_apply || !(r >= nd->margin)) {
@@ -534,6 +578,8 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
             }
         }
     }
+    if (wv != 0u) return;  // (no barrier below this line)
+    IVX_TP(p, sb, 2);  // program walked
     const float lo = p.n_nodes ? s_lo[0][tid] : 1000.0f, hi = p.n_nodes ? s_hi[0][tid] : 1000.0f;  // no program: empty space
     float out = __uint_as_float(0x7FC00000u);  // NaN = evaluate per voxel
     if (p.n_nodes == 0u) cmask = 1u;
@@ -570,7 +616,7 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
     }
     // chunks that need per-voxel evaluation go on a list for k_sdf_eval, constant chunks with planes to write on one for
     // k_sdf_fill (order is irrelevant); one atomic per wave and list (the block is one wave)
-    static_assert(PRE_T == 64, "the list appends below assume one wave per block");
+    static_assert(PRE_T == 64, "the list appends below assume one wave (the first of the block) doing them");
     {
         // Evaluation lists by the number of LDS levels the chunk's compact program needs (k_sdf_eval gets one launch per
         // class, with that much LDS: residency, hence throughput, is set by LDS): class 0: <= 2 levels, 1: 3, 2: more (and
@@ -609,6 +655,9 @@ __global__ __launch_bounds__(PRE_T) void k_sdf_prepass(SampleParams p, const ivx
             }
         }
     }
+    IVX_TP(p, sb, 3);
+    IVX_TP(p, sb, 4);
+    IVX_TP(p, sb, 5);
 }
 
 // ---- per-voxel evaluation ----------------------------------------------------------------------
@@ -713,7 +762,7 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
     // bounded grid-stride walk over the list of chunks to evaluate
     for (uint32_t li = blockIdx.x; li < n_eval; li += gridDim.x) {
     __syncthreads();  // the previous chunk's LDS use is over
-    IVX_T(p, li, 0);
+    IVX_TE(p, li, 0);
     const uint32_t chunk = eval_list[li < n_long ? li : list_len - 1u - (li - n_long)];
     const uint32_t ck = chunk % p.cz, cj = (chunk / p.cz) % p.cy, ci = chunk / (p.cz * p.cy);
     const uint32_t oi = (ci + p.x_off) * 16u, oj = cj * 16u, ok = ck * 16u;
@@ -755,7 +804,7 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
                 my_m[r] = nd->margin;
             }
         }
-        IVX_T(p, li, 1);  // program fetched
+        IVX_TE(p, li, 1);  // program fetched
         for (uint32_t i = 0; i < len; ++i) {
             const uint32_t l = i & 63u;
             uint32_t w, v;
@@ -837,8 +886,8 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
         }
     }
 
-    IVX_T(p, li, 2);  // program evaluated
-    IVX_T(p, li, 3);
+    IVX_TE(p, li, 2);  // program evaluated
+    IVX_TE(p, li, 3);
     const bool root_const = cmask & 1u;
     const float root_val = root_const ? s_cval[0] : 0.0f;
 #pragma unroll
@@ -847,9 +896,9 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
         bool in_grid = (oi + ti) < p.shape[0] && (oj + tj) < p.shape[1] && (ok + (uint32_t)k) < p.shape[2];
         sd[k] = in_grid ? sd_from_f32(v) : 127;
     }
-    IVX_T(p, li, 4);
+    IVX_TE(p, li, 4);
     classify_and_store(sd, make_uint4(0, 0, 0, 0), true, 0, sdf_out, type_out, info_out, chunk, tid, true, p.voxel_type, true);
-    IVX_T(p, li, 5);  // classified and stored
+    IVX_TE(p, li, 5);  // classified and stored
     }
 }
 
@@ -929,7 +978,7 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
     hipLaunchKernelGGL(k_sdf_super, dim3(sx * sy * sz), dim3(64), words * sizeof(uint32_t), g->ctx->stream, p, d_nodes, g->samp_super, super_skip, words, sy, sz,
                        ivx_preset_args(g, preset_groups));
     g->scratch_dirty = (g->scratch_dirty & ~preset_groups) | IVX_SCRATCH_EVAL;
-    hipLaunchKernelGGL(k_sdf_prepass, dim3(sx * sy * sz), dim3(PRE_T), 0, g->ctx->stream, p, d_nodes, chunk_const, g->samp_len, ops, eval_count, eval_list,
+    hipLaunchKernelGGL(k_sdf_prepass, dim3(sx * sy * sz), dim3(PRE_T * PRE_WAVES), 0, g->ctx->stream, p, d_nodes, chunk_const, g->samp_len, ops, eval_count, eval_list,
                        g->n_chunks, g->info, g->samp_super, super_skip, words, sy, sz);
     g->planes_compact = 1;
     {

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from impact_amd import capi, scenes  # noqa: E402
 from impact_amd.voxel import Context, SDFVoxelGenerator, VoxelObject  # noqa: E402
 
-STAGES = {"sample": capi.STAGE_SAMPLE, "derive": capi.STAGE_DERIVE | capi.STAGE_REGIONS, "remesh": capi.STAGE_REMESH}
+STAGES = {"prepass": capi.STAGE_SAMPLE, "sample": capi.STAGE_SAMPLE, "derive": capi.STAGE_DERIVE | capi.STAGE_REGIONS, "remesh": capi.STAGE_REMESH}
 
 
 def main():
@@ -39,7 +39,10 @@ def main():
     buf = np.zeros((n, 8), dtype=np.uint64)
     hip.hipDeviceSynchronize()
     assert hip.hipMemcpy(buf.ctypes.data_as(C.c_void_p), C.c_void_p(p), buf.nbytes, 2) == 0
-    med = np.median(buf[: n // 4, 0].astype(np.float64))
+    if which == "prepass":  # entries = super-blocks of 4^3 chunks
+        n = int(np.prod([(c + 3) // 4 for c in obj.chunk_counts]))
+        buf = buf[:n]
+    med = np.median(buf[: max(n // 4, 1), 0].astype(np.float64))
     ok = np.all(np.abs(buf[:, :6].astype(np.float64) - med) < 1e6, axis=1)  # slots of entries that were not written hold old data
     v = buf[ok]
     # the buffer is shared by every traced kernel: entries beyond this kernel's list keep an earlier kernel's stamps. Keep the LAST
