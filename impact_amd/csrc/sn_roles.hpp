@@ -212,28 +212,48 @@ __device__ __forceinline__ uint32_t neg16(const uint32_t w[4]) {
 // The 18 sign bits of one padded row from the per-row masks k_derive left (count pass): bit 0 = cell -1 (bit 15 of the row in
 // the chunk below along k), bits 1..16 the row itself, bit 17 = cell 16 (bit 0 of the chunk above). A chunk that is not
 // NonUniform has no masks: all negative when Uniform, none when Void. Rows of a ghost layer come from the ghost planes.
-__device__ __forceinline__ uint32_t fetch_row_signs(const GridView& g, int gi, int gj, int ck) {
-    if (gj < 0 || gj >= (int)g.cy * 16) return 0u;
+// (split like RowLoads: every load issued, then pinned, then the records select)
+struct SignLoads {
+    uint32_t k0, k1, k2, m0, m1, m2;
+    uint32_t mode;  // 0: outside the grid, 1: in the slab, 2: ghost layer (serial path)
+    uint32_t has_lo, has_hi;
+};
+__device__ __forceinline__ void signs_issue(const GridView& g, int gi, int gj, int ck, SignLoads& L) {
+    L.mode = 0u;
+    if (gj < 0 || gj >= (int)g.cy * 16) return;
     if (gi < 0 || gi >= (int)g.cx * 16) {
+        L.mode = 2u;
+        return;
+    }
+    L.mode = 1u;
+    const uint32_t chunk = ((gi >> 4) * g.cy + (gj >> 4)) * g.cz + ck;
+    const uint32_t row = ((gi & 15) << 4) | (gj & 15);
+    L.has_lo = ck > 0 ? 1u : 0u;
+    L.has_hi = ck + 1 < (int)g.cz ? 1u : 0u;
+    const ivx_chunk_info* ip = g.info + chunk;
+    const uint16_t* sp = g.signs + (size_t)chunk * 256 + row;
+    const ivx_chunk_info* ip0 = L.has_lo ? ip - 1 : ip;
+    const ivx_chunk_info* ip2 = L.has_hi ? ip + 1 : ip;
+    const uint16_t* sp0 = L.has_lo ? sp - 256 : sp;
+    const uint16_t* sp2 = L.has_hi ? sp + 256 : sp;
+    L.k1 = ip->kind;
+    L.m1 = *sp;
+    L.k0 = ip0->kind;
+    L.m0 = *sp0;
+    L.k2 = ip2->kind;
+    L.m2 = *sp2;
+}
+__device__ __forceinline__ void signs_pin(SignLoads& L) { asm volatile("" : "+v"(L.k0), "+v"(L.k1), "+v"(L.k2), "+v"(L.m0), "+v"(L.m1), "+v"(L.m2)); }
+__device__ __forceinline__ uint32_t signs_finish(const GridView& g, int gi, int gj, int ck, const SignLoads& L) {
+    if (L.mode == 0u) return 0u;
+    if (L.mode == 2u) {
         uint32_t sd[6], ty[6];
         fetch_row(g, gi, gj, ck, sd, ty);
         return ((sd[0] >> 7) & 1u) | (neg16(sd + 1) << 1) | (((sd[5] >> 7) & 1u) << 17);
     }
-    const uint32_t chunk = ((gi >> 4) * g.cy + (gj >> 4)) * g.cz + ck;
-    const uint32_t row = ((gi & 15) << 4) | (gj & 15);
-    const ivx_chunk_info* ip = g.info + chunk;
-    const uint16_t* sp = g.signs + (size_t)chunk * 256 + row;
-    // (records and masks are fetched side by side; the record picks afterwards)
-    const uint32_t k1 = ip[0].kind, m1 = sp[0];
-    uint32_t bits = (k1 == KIND_NONUNIFORM ? m1 : (k1 == KIND_UNIFORM ? 0xFFFFu : 0u)) << 1;
-    if (ck > 0) {
-        const uint32_t k0 = ip[-1].kind, m0 = sp[-256];
-        bits |= k0 == KIND_NONUNIFORM ? ((m0 >> 15) & 1u) : (k0 == KIND_UNIFORM ? 1u : 0u);
-    }
-    if (ck + 1 < (int)g.cz) {
-        const uint32_t k2 = ip[1].kind, m2 = sp[256];
-        bits |= (k2 == KIND_NONUNIFORM ? (m2 & 1u) : (k2 == KIND_UNIFORM ? 1u : 0u)) << 17;
-    }
+    uint32_t bits = (L.k1 == KIND_NONUNIFORM ? L.m1 : (L.k1 == KIND_UNIFORM ? 0xFFFFu : 0u)) << 1;
+    if (L.has_lo) bits |= L.k0 == KIND_NONUNIFORM ? ((L.m0 >> 15) & 1u) : (L.k0 == KIND_UNIFORM ? 1u : 0u);
+    if (L.has_hi) bits |= (L.k2 == KIND_NONUNIFORM ? (L.m2 & 1u) : (L.k2 == KIND_UNIFORM ? 1u : 0u)) << 17;
     return bits;
 }
 
@@ -249,12 +269,25 @@ __device__ __forceinline__ uint32_t neighbour_kind(const GridView& g, int ci, in
 __device__ __forceinline__ void load_tile(const GridView& g, int ci, int cj, int ck, uint8_t* s_sd, uint8_t* s_ty, uint32_t* s_neg, uint32_t tid) {
     constexpr int ROUNDS = (NROWS + 255) / 256;
     if (!s_sd) {  // count pass: signs only
+        SignLoads S[ROUNDS];
+#pragma unroll
+        for (int it = 0; it < ROUNDS; ++it) {
+            const int r = (int)tid + 256 * it;
+            S[it].mode = 0u;
+            if (r < NROWS) {
+                const int a = r / G, b = r - a * G;
+                signs_issue(g, ci * 16 + a - 1, cj * 16 + b - 1, ck, S[it]);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < ROUNDS; ++it)
+            if (S[it].mode == 1u) signs_pin(S[it]);
 #pragma unroll
         for (int it = 0; it < ROUNDS; ++it) {
             const int r = (int)tid + 256 * it;
             if (r >= NROWS) break;
             const int a = r / G, b = r - a * G;
-            s_neg[r] = fetch_row_signs(g, ci * 16 + a - 1, cj * 16 + b - 1, ck);
+            s_neg[r] = signs_finish(g, ci * 16 + a - 1, cj * 16 + b - 1, ck, S[it]);
         }
         return;
     }
@@ -330,12 +363,31 @@ __device__ __forceinline__ bool chunk_exposed(const ivx_chunk_info& ci) {
     return ci.kind == KIND_NONUNIFORM && (ci.flags & CF_FULLY_OBSCURED) != CF_FULLY_OBSCURED;
 }
 
-__device__ __forceinline__ void upper_limits(const GridView& g, int ci, int cj, int ck, int* upper) {
+// (issued before the tile's loads and looked at after them: the three records ride along instead of costing round trips of their own)
+struct UpperLoads {
+    uint32_t k[3];
+};
+__device__ __forceinline__ void upper_issue(const GridView& g, int ci, int cj, int ck, UpperLoads& U) {
+    const uint32_t own = (uint32_t)((ci * (int)g.cy + cj) * (int)g.cz + ck);
+    const ivx_chunk_info* px = g.info + own;  // clamped to the chunk itself where there is no neighbour record to read
+    bool gx = false;
+    if (ci + 1 < (int)g.cx) px = g.info + own + g.cy * g.cz;
+    else if (g.ghost_info[1]) px = g.ghost_info[1] + (cj * (int)g.cz + ck), gx = true;
+    const ivx_chunk_info* py = cj + 1 < (int)g.cy ? g.info + own + g.cz : g.info + own;
+    const ivx_chunk_info* pz = ck + 1 < (int)g.cz ? g.info + own + 1 : g.info + own;
+    U.k[0] = px->kind;
+    U.k[1] = py->kind;
+    U.k[2] = pz->kind;
+    (void)gx;
+}
+__device__ __forceinline__ void upper_finish(const GridView& g, int ci, int cj, int ck, UpperLoads& U, int* upper) {
     // the upper layer of cubes belongs to the upper neighbour chunk when that chunk is non-uniform (surface_nets.rs:252-261)
+    asm volatile("" : "+v"(U.k[0]), "+v"(U.k[1]), "+v"(U.k[2]));
+    const bool hx = ci + 1 < (int)g.cx || g.ghost_info[1] != nullptr, hy = cj + 1 < (int)g.cy, hz = ck + 1 < (int)g.cz;
     upper[0] = upper[1] = upper[2] = G - 1;
-    if (neighbour_kind(g, ci + 1, cj, ck) == KIND_NONUNIFORM) upper[0] -= 1;
-    if (neighbour_kind(g, ci, cj + 1, ck) == KIND_NONUNIFORM) upper[1] -= 1;
-    if (neighbour_kind(g, ci, cj, ck + 1) == KIND_NONUNIFORM) upper[2] -= 1;
+    if (hx && U.k[0] == KIND_NONUNIFORM) upper[0] -= 1;
+    if (hy && U.k[1] == KIND_NONUNIFORM) upper[1] -= 1;
+    if (hz && U.k[2] == KIND_NONUNIFORM) upper[2] -= 1;
 }
 
 // Walks the active list (the chunks k_chunk_pre settled have no mesh and got their zero counts there).
@@ -360,9 +412,11 @@ __device__ __forceinline__ void role_sn_count(uint32_t bid, uint32_t nb, SnParam
     }
     const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
     if (tid < 2) s_acc[tid] = 0;
+    UpperLoads ul;
+    upper_issue(g, ci, cj, ck, ul);
     load_tile(g, ci, cj, ck, nullptr, nullptr, s_neg, tid);
     int upper[3];
-    upper_limits(g, ci, cj, ck, upper);
+    upper_finish(g, ci, cj, ck, ul, upper);
     __syncthreads();
     uint32_t nv = 0, nq = 0;
     for (int cr = tid; cr < NCROWS; cr += 256) {
@@ -627,9 +681,11 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
     if ((size_t)voff + vcount > vcap || (size_t)ioff + icount > icap || slot >= scap) continue;
     const ivx_chunk_info info = g.info[chunk];
     const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
+    UpperLoads ul;
+    upper_issue(g, ci, cj, ck, ul);
     load_tile(g, ci, cj, ck, s_sd, s_ty, s_neg, tid);
     int upper[3];
-    upper_limits(g, ci, cj, ck, upper);
+    upper_finish(g, ci, cj, ck, ul, upper);
 
     if (tid == 0) {
         ivx_submesh sm;
