@@ -846,6 +846,11 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
             const float* P = positions + 3 * (size_t)voff;
             const V3 q1 = mk(P[3 * v1], P[3 * v1 + 1], P[3 * v1 + 2]), q2 = mk(P[3 * v2], P[3 * v2 + 1], P[3 * v2 + 2]);
             const V3 q3 = mk(P[3 * v3], P[3 * v3 + 1], P[3 * v3 + 2]), q4 = mk(P[3 * v4], P[3 * v4 + 1], P[3 * v4 + 2]);
+            // the four corners' vertex materials travel with their positions: fetched per triangle corner after the diagonal is
+            // chosen they were a second dependent round trip to memory
+            uint4 vm1 = vmats[(size_t)voff + v1], vm2 = vmats[(size_t)voff + v2], vm3 = vmats[(size_t)voff + v3], vm4 = vmats[(size_t)voff + v4];
+            asm volatile("" : "+v"(vm1.x), "+v"(vm1.y), "+v"(vm1.z), "+v"(vm1.w), "+v"(vm2.x), "+v"(vm2.y), "+v"(vm2.z), "+v"(vm2.w));
+            asm volatile("" : "+v"(vm3.x), "+v"(vm3.y), "+v"(vm3.z), "+v"(vm3.w), "+v"(vm4.x), "+v"(vm4.y), "+v"(vm4.z), "+v"(vm4.w));
             uint32_t quad[6];
             if (len3(sub(q1, q4)) < len3(sub(q2, q3))) {
                 if (negative_face) { quad[0] = v1; quad[1] = v4; quad[2] = v2; quad[3] = v1; quad[4] = v3; quad[5] = v4; }
@@ -860,7 +865,8 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
                 VMat vm[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const uint4 raw = vmats[(size_t)voff + quad[3 * tri + c]];
+                    const uint32_t vq = quad[3 * tri + c];
+                    const uint4 raw = vq == v1 ? vm1 : (vq == v2 ? vm2 : (vq == v3 ? vm3 : vm4));
                     vm[c].ind = (unsigned long long)raw.x | ((unsigned long long)raw.y << 32);
                     vm[c].wgt = (unsigned long long)raw.z | ((unsigned long long)raw.w << 32);
                 }
