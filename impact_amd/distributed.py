@@ -229,7 +229,7 @@ class SlabStepper:
         if int(records[:, 1].max()) > HEAD_PAIRS:  # (the same decision on every rank: all see the same heads)
             records = yield AllGather(self.record, REC_WORDS)
         r = obj.step_collect()  # the stream is already idle: stage timings + mesh-buffer check
-        flags = int(records[self.rank, 17])
+        flags = int(np.bitwise_or.reduce(records[:, 17]))  # decided on the gathered data: every rank raises together (a lone raise would leave the others in the next exchange)
         if flags & 1:
             raise capi.IvxError(capi.IVX_ERR_CAPACITY, "a chunk has more than 254 local regions")
         if flags & 4:
