@@ -795,7 +795,27 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
         const float gl = len3(grad);
         const V3 normal = mk(grad.x / gl, grad.y / gl, grad.z / gl);
         const V3 position = add(scale(add(centroid, mk((float)i, (float)j, (float)k)), p.extent), pos_offset);
-        const VMat vm = vertex_materials(has, mats);
+        // Most bodies are of one material around most vertices: when every lane's non-empty corners agree on theirs (a wave vote), the
+        // table is that one entry — what the general construction (first-seen table, counts, the 17-swap sorting network: ~400 predicated
+        // instructions) returns for this input
+        VMat vm;
+        {
+            uint32_t m0 = 0xFFFFFFFFu, n_in = 0u;
+            bool single = true;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (has[c]) {
+                    if (m0 == 0xFFFFFFFFu) m0 = mats[c];
+                    single = single && mats[c] == m0;
+                    n_in += 1u;
+                }
+            if (__all(single ? 1 : 0)) {
+                vm.ind = (unsigned long long)(m0 & 0xFFu) | (1ull << 56);
+                vm.wgt = (unsigned long long)n_in;
+            } else {
+                vm = vertex_materials(has, mats);
+            }
+        }
         const size_t gv = (size_t)voff + v;
         positions[3 * gv + 0] = position.x;
         positions[3 * gv + 1] = position.y;
