@@ -516,9 +516,12 @@ int ivx_launch_derive(ivx_grid* g, uint32_t parts, uint32_t preset_groups) {
     g->bbox_valid = 1;
     uint32_t* next_count = ivx_wc(g);  // the counter of the sweep before: zeroed by this one for the sweep after
     g->wc_cur ^= 1u;
+    // (the sampler's list counters have had their last reader by now: rolled over on the way, see role_preset)
+    const uint32_t roll = ((g->scratch_dirty & IVX_SCRATCH_EVAL) && g->samp_len) ? IVX_SCRATCH_EVAL_ROLL : 0u;
     hipLaunchKernelGGL(k_chunk_pre, dim3((g->n_chunks + 255u) / 256u), dim3(256), 0, g->ctx->stream, v, g->info, g->chunk_bbox, g->chunk_counts,
-                       g->chunk_class, g->chunk_touch, g->rparent, ivx_wc(g), next_count, g->active_list, ivx_preset_args(g, preset_groups));
+                       g->chunk_class, g->chunk_touch, g->rparent, ivx_wc(g), next_count, g->active_list, ivx_preset_args(g, preset_groups | roll));
     g->scratch_dirty &= ~preset_groups;
+    if (roll) g->scratch_dirty &= ~IVX_SCRATCH_EVAL;
     hipLaunchKernelGGL(k_derive, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->sdf, g->type, g->flags, g->info, g->chunk_bbox,
                        g->chunk_touch, g->chunk_signs, g->kface, ivx_wc(g), g->active_list, fz);
     g->planes_compact = 1;

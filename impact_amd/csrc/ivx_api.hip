@@ -487,7 +487,8 @@ int ivx_grid_stage_counters(ivx_grid* g, uint32_t out[4]) {
     int rc;
     if (g->samp_len) {  // chunks evaluated per voxel by the sampler (three lists by LDS class)
         uint32_t ev[3];
-        if ((rc = d2h(g, ev, g->samp_len + g->n_chunks, sizeof(ev)))) return rc;
+        // (the live counters until the derive sweep has rolled them over into their statistics words, role_preset)
+        if ((rc = d2h(g, ev, g->samp_len + g->n_chunks + ((g->scratch_dirty & IVX_SCRATCH_EVAL) ? 0 : 8), sizeof(ev)))) return rc;
         out[0] = ev[0] + ev[1] + ev[2];
     }
     if ((rc = d2h(g, &out[1], g->rscalar + 2, sizeof(uint32_t)))) return rc;                            // chunks with several local regions
@@ -546,7 +547,7 @@ int ivx_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* nodes, size_t n_no
         if ((rc = h2d(g, g->dev_scratch, annotated.data(), n_nodes * sizeof(ivx_sdf_processed_node)))) return rc;
     }
     rc = ivx_launch_sdf_sample(g, static_cast<const ivx_sdf_processed_node*>(g->dev_scratch), (uint32_t)n_nodes, (uint32_t)max_depth, grid_shape,
-                               shifted_grid_center, voxel_type);
+                               shifted_grid_center, voxel_type, 0, 0);
     if (rc) return rc;
     g->mesh_valid = 0;
     g->mesh_built = 0;
@@ -2134,6 +2135,7 @@ int ivx_grid_set_sdf_program(ivx_grid* g, const ivx_sdf_processed_node* nodes, s
         if (rc) return rc;
         g->prog_cap = (uint32_t)n_nodes;
     }
+    g->super_valid = 0;  // (the super-block tables of the program that was resident so far)
     std::vector<ivx_sdf_processed_node> annotated(nodes, nodes + n_nodes);
     ivx_sdf_annotate_host(annotated.data(), n_nodes);
     int rc = h2d(g, g->prog_nodes, annotated.data(), n_nodes * sizeof(ivx_sdf_processed_node));
@@ -2214,7 +2216,7 @@ int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
                                                               : 0u;
     if (stages & IVX_STAGE_SAMPLE) {
         T0(0);
-        if ((rc = ivx_launch_sdf_sample(g, g->prog_nodes, g->prog_n, g->prog_stack, g->prog_shape, g->prog_center, g->prog_type, preset_in_sample))) return rc;
+        if ((rc = ivx_launch_sdf_sample(g, g->prog_nodes, g->prog_n, g->prog_stack, g->prog_shape, g->prog_center, g->prog_type, preset_in_sample, 1))) return rc;
         T1(0);
         g->occ_ref_valid = 0;
         g->bbox_valid = 0;

@@ -383,7 +383,10 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
                                                        uint2* __restrict__ prog_ops, uint32_t* __restrict__ eval_count,
                                                        uint32_t* __restrict__ eval_list, uint32_t list_stride, ivx_chunk_info* __restrict__ info_out,
                                                        const uint32_t* __restrict__ super_mask, const uint2* __restrict__ super_skip, uint32_t words,
-                                                       uint32_t sy, uint32_t sz) {
+                                                       uint32_t sy, uint32_t sz, ivx_roles::PresetArgs preset) {
+    // (when the super-block tables are kept from an earlier step this is the step's first kernel and hosts the presets of the later
+    // stages' scratch words; the sampler's own counters are never among them: other blocks of this launch are adding to those)
+    ivx_roles::role_preset(preset, blockIdx.x * (uint32_t)(PRE_T * PRE_WAVES) + threadIdx.x);
     __shared__ uint2 s_skip[NODE_TILE];
     __shared__ uint32_t s_far[NODE_TILE / 32];
     __shared__ float s_lo[16][PRE_T];
@@ -924,8 +927,9 @@ __global__ __launch_bounds__(256) void k_classify(uint32_t n_chunks, int8_t* __r
 
 int ivx_sampler_buffers(ivx_grid* g) {
     if (g->samp_ops) return IVX_OK;
-    // [n] program lengths, [8] counters of the three evaluation lists (+ the long / short split of the first), [3 n] the lists
-    IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_len), sizeof(uint32_t) * (4 * (size_t)g->n_chunks + 8)));
+    // [n] program lengths, [16] counters of the three evaluation lists (+ the long / short split of the first; [8..13) their rolled copy), [3 n] the lists
+    IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_len), sizeof(uint32_t) * (4 * (size_t)g->n_chunks + 16)));
+    IVX_HIP_CHECK(hipMemsetAsync(g->samp_len + g->n_chunks, 0, 16 * sizeof(uint32_t), g->ctx->stream));  // the counters start at zero
     IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_ops), sizeof(uint2) * (size_t)OP_CAP * g->n_chunks));
     return IVX_OK;
 }
@@ -933,7 +937,7 @@ int ivx_sampler_buffers(ivx_grid* g) {
 ivx_roles::PresetArgs ivx_preset_args(ivx_grid* g, uint32_t groups);  // derive.hip
 
 int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, uint32_t n_nodes, uint32_t stack_size,
-                          const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type, uint32_t preset_groups) {
+                          const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type, uint32_t preset_groups, int cache_super) {
     SampleParams p;
     p.cx = g->cc[0];
     p.cy = g->cc[1];
@@ -959,8 +963,17 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
     }
     uint2* ops = reinterpret_cast<uint2*>(g->samp_ops);
     uint32_t* eval_count = g->samp_len + g->n_chunks;
-    uint32_t* eval_list = eval_count + 8;
-    if (!(preset_groups & IVX_SCRATCH_EVAL)) IVX_HIP_CHECK(hipMemsetAsync(eval_count, 0, 8 * sizeof(uint32_t), g->ctx->stream));
+    uint32_t* eval_list = eval_count + 16;
+    // The super-block tables depend on the program and the grid only: a step over the resident program computes them once
+    // (`cache_super`: the caller vouches that `d_nodes` is the grid's resident program; ivx_grid_set_sdf_program drops them).
+    const bool have_super = cache_super && g->super_valid;
+    // the list counters must be zero: rolled over by the derive sweep of the step before (IVX_SCRATCH_EVAL clean), else cleared here —
+    // by k_sdf_super's preset role when it runs and hosts presets, by a memset otherwise
+    const bool eval_dirty = (g->scratch_dirty & IVX_SCRATCH_EVAL) != 0u;
+    uint32_t super_presets = have_super ? 0u : preset_groups;
+    uint32_t prepass_presets = have_super ? (preset_groups & ~IVX_SCRATCH_EVAL) : 0u;
+    if (eval_dirty && !(super_presets & IVX_SCRATCH_EVAL)) IVX_HIP_CHECK(hipMemsetAsync(eval_count, 0, 8 * sizeof(uint32_t), g->ctx->stream));
+    if (!eval_dirty) super_presets &= ~IVX_SCRATCH_EVAL;
     const uint32_t sx = (g->cc[0] + SUPER - 1) / SUPER, sy = (g->cc[1] + SUPER - 1) / SUPER, sz = (g->cc[2] + SUPER - 1) / SUPER;
     const uint32_t words = (n_nodes + 31u) / 32u > 0u ? (n_nodes + 31u) / 32u : 1u;
     {
@@ -970,16 +983,20 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
             if (g->samp_super) (void)hipFree(g->samp_super);
             g->samp_super = nullptr;
             g->samp_super_words = 0;
+            g->super_valid = 0;
             IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_super), need * sizeof(uint32_t)));
             g->samp_super_words = need;
         }
     }
     uint2* super_skip = reinterpret_cast<uint2*>(g->samp_super + (((size_t)sx * sy * sz * words + 1u) & ~(size_t)1u));
-    hipLaunchKernelGGL(k_sdf_super, dim3(sx * sy * sz), dim3(64), words * sizeof(uint32_t), g->ctx->stream, p, d_nodes, g->samp_super, super_skip, words, sy, sz,
-                       ivx_preset_args(g, preset_groups));
+    if (!have_super) {
+        hipLaunchKernelGGL(k_sdf_super, dim3(sx * sy * sz), dim3(64), words * sizeof(uint32_t), g->ctx->stream, p, d_nodes, g->samp_super, super_skip, words, sy, sz,
+                           ivx_preset_args(g, super_presets));
+        g->super_valid = cache_super ? 1 : 0;
+    }
     g->scratch_dirty = (g->scratch_dirty & ~preset_groups) | IVX_SCRATCH_EVAL;
     hipLaunchKernelGGL(k_sdf_prepass, dim3(sx * sy * sz), dim3(PRE_T * PRE_WAVES), 0, g->ctx->stream, p, d_nodes, chunk_const, g->samp_len, ops, eval_count, eval_list,
-                       g->n_chunks, g->info, g->samp_super, super_skip, words, sy, sz);
+                       g->n_chunks, g->info, g->samp_super, super_skip, words, sy, sz, ivx_preset_args(g, prepass_presets));
     g->planes_compact = 1;
     {
         // one launch per LDS class (see k_sdf_prepass); a class the program cannot reach is not launched

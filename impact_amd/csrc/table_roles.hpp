@@ -157,7 +157,7 @@ __device__ __forceinline__ void role_result_gather(const uint32_t* __restrict__ 
     if (t < 28u) host_block[t] = (t == 0u && region_total_known) ? region_total : rscalar[t];
     if (t < 3u) host_block[28 + t] = mesh_totals[t];
     if (t < 20u) host_block[32 + t] = reinterpret_cast<const uint32_t*>(moments)[t];
-    if (t < 3u && eval_count) host_block[52 + t] = eval_count[t];
+    if (t < 3u && eval_count) host_block[52 + t] = eval_count[8u + t];  // (the rolled copy, see role_preset)
 }
 
 // Preset of the scratch words a step's stages start from (what k_step_preset did in a launch of its own), as a role of the
@@ -173,6 +173,12 @@ __device__ __forceinline__ void role_preset(const PresetArgs& a, uint32_t gid) {
     if ((a.groups & IVX_SCRATCH_REGIONS) && gid < 16u) a.rscalar[gid] = 0u;
     if ((a.groups & IVX_SCRATCH_SN) && gid < a.n_sn) a.sn_sums[gid] = 0u;
     if ((a.groups & IVX_SCRATCH_EVAL) && gid < 5u && a.eval_count) a.eval_count[gid] = 0u;
+    // the sampler's list counters rolled over after their last reader (k_sdf_eval): kept as statistics in words [8..13), zero for the
+    // next step's pre-pass — the step after needs no kernel ahead of the pre-pass just to clear five words
+    if ((a.groups & IVX_SCRATCH_EVAL_ROLL) && gid < 5u && a.eval_count) {
+        a.eval_count[8u + gid] = a.eval_count[gid];
+        a.eval_count[gid] = 0u;
+    }
 }
 
 }  // namespace ivx_roles

@@ -238,3 +238,42 @@ def test_dense_workload_512(ctx):
     assert p["equal"], p
     assert p["regions"][0] == 32
     obj.close()
+
+
+def test_program_swap_on_a_resident_grid(ctx):
+    """the super-block tables of the sampler are kept from step to step for the resident program: a new program on the same grid must
+    drop them (ivx_grid_set_sdf_program), and stepping the same program repeatedly must keep giving the same object"""
+    from impact_amd import capi
+    from impact_amd.voxel import SDFVoxelGenerator
+
+    def two_bodies(offset):
+        g = SDFGraph()
+        a = g.add_node(SDFNode.new_sphere(20.0))
+        b = g.add_node(SDFNode.new_translation(g.add_node(SDFNode.new_box((9.0, 14.0, 7.0))), (offset, 3.0, -4.0)))
+        g.add_node(SDFNode.new_union(a, b, 2.0))
+        return g
+
+    gen_a, gen_b = SDFVoxelGenerator(1.0, two_bodies(12.0), 0), SDFVoxelGenerator(1.0, two_bodies(-15.0), 0)
+    cc = tuple(max(x, y) for x, y in zip(gen_a.chunk_counts(), gen_b.chunk_counts()))
+    dens = np.ones(256, dtype=np.float32)
+    obj = VoxelObject(ctx, cc, 1.0)
+    obj.set_densities(dens)
+    fresh = {}
+    for name, gen in (("a", gen_a), ("b", gen_b)):
+        f = VoxelObject(ctx, cc, 1.0)
+        f.set_densities(dens)
+        f.set_sdf_program(gen)
+        r = f.step(capi.STAGE_ALL)
+        fresh[name] = (f.download(), int(r["mesh"]["n_indices"]), int(r["region_count"]), np.array(r["moments"]["m64"]))
+        f.close()
+    for name, gen in (("a", gen_a), ("a", gen_a), ("b", gen_b), ("b", gen_b), ("a", gen_a)):
+        obj.set_sdf_program(gen) if name != getattr(obj, "_last", None) else None
+        obj._last = name
+        r = obj.step(capi.STAGE_ALL)
+        want = fresh[name]
+        got = obj.download()
+        for x, y in zip(got[:4], want[0][:4]):
+            np.testing.assert_array_equal(x, y)
+        assert int(r["mesh"]["n_indices"]) == want[1] and int(r["region_count"]) == want[2]
+        np.testing.assert_array_equal(np.array(r["moments"]["m64"]), want[3])
+    obj.close()
