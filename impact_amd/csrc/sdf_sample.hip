@@ -966,7 +966,8 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
     uint32_t* eval_list = eval_count + 16;
     // The super-block tables depend on the program and the grid only: a step over the resident program computes them once
     // (`cache_super`: the caller vouches that `d_nodes` is the grid's resident program; ivx_grid_set_sdf_program drops them).
-    const bool have_super = cache_super && g->super_valid;
+    static const bool super_every_step = getenv("IVX_SUPER_EVERY_STEP") != nullptr;  // measurement switch: rebuild the tables on every call
+    const bool have_super = cache_super && g->super_valid && !super_every_step;
     // the list counters must be zero: rolled over by the derive sweep of the step before (IVX_SCRATCH_EVAL clean), else cleared here —
     // by k_sdf_super's preset role when it runs and hosts presets, by a memset otherwise
     const bool eval_dirty = (g->scratch_dirty & IVX_SCRATCH_EVAL) != 0u;
