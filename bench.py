@@ -771,9 +771,6 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
-            "sampler_tables": ("the sampler's super-block tables (which program nodes are far from a 4^3-chunk block; a function of the resident SDF program and the grid, like the "
-                              "host-side compile) are computed on the first step and kept; the per-chunk interval pre-pass and the per-voxel evaluation run every step. "
-                              "IVX_SUPER_EVERY_STEP=1 rebuilds them every step (+7 us)"),
             "stage_timing": f"timed region: events around slot {dom} ({capi.STAGE_NAMES[dom]}) only; `stage_ms` of the other slots from {n_stage_pass} further steps with every slot timed",
             "higher_is_better": True,
             "scaling": scaling,

@@ -547,7 +547,7 @@ int ivx_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* nodes, size_t n_no
         if ((rc = h2d(g, g->dev_scratch, annotated.data(), n_nodes * sizeof(ivx_sdf_processed_node)))) return rc;
     }
     rc = ivx_launch_sdf_sample(g, static_cast<const ivx_sdf_processed_node*>(g->dev_scratch), (uint32_t)n_nodes, (uint32_t)max_depth, grid_shape,
-                               shifted_grid_center, voxel_type, 0, 0);
+                               shifted_grid_center, voxel_type);
     if (rc) return rc;
     g->mesh_valid = 0;
     g->mesh_built = 0;
@@ -2135,7 +2135,6 @@ int ivx_grid_set_sdf_program(ivx_grid* g, const ivx_sdf_processed_node* nodes, s
         if (rc) return rc;
         g->prog_cap = (uint32_t)n_nodes;
     }
-    g->super_valid = 0;  // (the super-block tables of the program that was resident so far)
     std::vector<ivx_sdf_processed_node> annotated(nodes, nodes + n_nodes);
     ivx_sdf_annotate_host(annotated.data(), n_nodes);
     int rc = h2d(g, g->prog_nodes, annotated.data(), n_nodes * sizeof(ivx_sdf_processed_node));
@@ -2216,7 +2215,7 @@ int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
                                                               : 0u;
     if (stages & IVX_STAGE_SAMPLE) {
         T0(0);
-        if ((rc = ivx_launch_sdf_sample(g, g->prog_nodes, g->prog_n, g->prog_stack, g->prog_shape, g->prog_center, g->prog_type, preset_in_sample, 1))) return rc;
+        if ((rc = ivx_launch_sdf_sample(g, g->prog_nodes, g->prog_n, g->prog_stack, g->prog_shape, g->prog_center, g->prog_type, preset_in_sample))) return rc;
         T1(0);
         g->occ_ref_valid = 0;
         g->bbox_valid = 0;

@@ -118,7 +118,6 @@ struct ivx_grid {
     int has_dens;
     double* moments_dev;  // [10]
     uint32_t* samp_len;   // [n_chunks] length of the chunk's compact SDF program (sampler pre-pass)
-    int super_valid;      // the super-block tables (far bits, skip table) were computed for the resident program on this grid
     void* samp_ops;       // [n_chunks * 128] uint2 ops
     uint32_t* samp_super;  // [super-blocks * ceil(nodes / 32)] "node certainly outside every chunk of the super-block" bits
     size_t samp_super_words;
@@ -309,7 +308,7 @@ static inline GridView ivx_view(const ivx_grid* g) {
 // kernels (one launcher per stage; all asynchronous on ctx->stream)
 int ivx_launch_classify(ivx_grid* g);
 int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, uint32_t n_nodes, uint32_t stack_size,
-                          const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type, uint32_t preset_groups, int cache_super);
+                          const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type, uint32_t preset_groups = 0);
 // parts of the fused sweep: k_derive can label the chunk-local regions and compute the chunk moments of the chunks it visits
 #define IVX_PART_REGIONS 1u
 #define IVX_PART_MOMENTS 2u

@@ -318,9 +318,35 @@ __device__ __forceinline__ void load_node_tile(PaddedNode* tile, const ivx_sdf_p
 // The pre-pass then replaces whole far bodies by their folded constant and skips the box arithmetic of single far nodes: its
 // cost no longer grows with the number of bodies in the scene.
 constexpr int SUPER = 4;
+constexpr uint32_t SUPER_MAX_WORDS = 64;  // programs of up to 2048 nodes get their super-block tables inside the pre-pass (k_sdf_super beyond)
 // per super-block and node: .x = for a leaf, the root of the largest subtree starting at it whose nodes are all far (the
 // pre-pass replaces the range by one constant), else the node's own index; .y = that subtree's folded constant
 __device__ __forceinline__ bool range_all_far(const uint32_t* mask, uint32_t a, uint32_t b);
+// the node takes its "domain lies outside the block" early-out for every chunk of the super-block `block`
+__device__ __forceinline__ bool super_far(const ivx_sdf_processed_node* nd, Box block) {
+    const uint32_t kind = nd->kind;
+    if (kind > 2u && kind < 7u) return true;  // translation / rotation / scaling have no test of their own
+    const Box bn = aabb_of_transformed(block, nd->transform);
+    const float eps = 1e-2f;
+    return bn.hi.x - nd->domain_lo[0] < -eps || bn.hi.y - nd->domain_lo[1] < -eps || bn.hi.z - nd->domain_lo[2] < -eps ||
+           nd->domain_hi[0] - bn.lo.x < -eps || nd->domain_hi[1] - bn.lo.y < -eps || nd->domain_hi[2] - bn.lo.z < -eps;
+}
+// skip-table entry of node n from the super-block's far bits `mask`
+__device__ __forceinline__ uint2 super_skip_of(const ivx_sdf_processed_node* nodes, const uint32_t* mask, uint32_t n) {
+    uint32_t target = n, fbits = 0;
+    if (nodes[n].kind <= 2u) {
+        uint32_t r = nodes[n].reserved[1];  // outermost subtree starting at this leaf, then inwards
+        while (r != n) {
+            if (range_all_far(mask, n, r)) {
+                target = r;
+                fbits = nodes[r].reserved[0];
+                break;
+            }
+            r = nodes[r].reserved[2];
+        }
+    }
+    return make_uint2(target, fbits);
+}
 __global__ __launch_bounds__(64) void k_sdf_super(SampleParams p, const ivx_sdf_processed_node* __restrict__ nodes, uint32_t* __restrict__ super_mask,
                                                   uint2* __restrict__ super_skip, uint32_t words, uint32_t sy, uint32_t sz, ivx_roles::PresetArgs preset) {
     extern __shared__ uint32_t s_mask[];  // [words]
@@ -333,39 +359,14 @@ __global__ __launch_bounds__(64) void k_sdf_super(SampleParams p, const ivx_sdf_
     for (uint32_t n0 = 0; n0 < words * 32u; n0 += 64u) {
         const uint32_t n = n0 + lane;
         bool far = false;
-        if (n < p.n_nodes) {
-            const ivx_sdf_processed_node* nd = nodes + n;
-            const uint32_t kind = nd->kind;
-            if (kind > 2u && kind < 7u) {
-                far = true;  // translation / rotation / scaling have no test of their own
-            } else {
-                const Box bn = aabb_of_transformed(block, nd->transform);
-                const float eps = 1e-2f;
-                far = bn.hi.x - nd->domain_lo[0] < -eps || bn.hi.y - nd->domain_lo[1] < -eps || bn.hi.z - nd->domain_lo[2] < -eps ||
-                      nd->domain_hi[0] - bn.lo.x < -eps || nd->domain_hi[1] - bn.lo.y < -eps || nd->domain_hi[2] - bn.lo.z < -eps;
-            }
-        }
+        if (n < p.n_nodes) far = super_far(nodes + n, block);
         const unsigned long long b = __ballot(far);
         if (lane == 0 && (n0 >> 5) < words) s_mask[n0 >> 5] = (uint32_t)b;
         if (lane == 32 && (n0 >> 5) + 1u < words) s_mask[(n0 >> 5) + 1u] = (uint32_t)(b >> 32);
     }
     __syncthreads();
     for (uint32_t w = lane; w < words; w += 64u) super_mask[(size_t)sb * words + w] = s_mask[w];
-    for (uint32_t n = lane; n < p.n_nodes; n += 64u) {
-        uint32_t target = n, fbits = 0;
-        if (nodes[n].kind <= 2u) {
-            uint32_t r = nodes[n].reserved[1];  // outermost subtree starting at this leaf, then inwards
-            while (r != n) {
-                if (range_all_far(s_mask, n, r)) {
-                    target = r;
-                    fbits = nodes[r].reserved[0];
-                    break;
-                }
-                r = nodes[r].reserved[2];
-            }
-        }
-        super_skip[(size_t)sb * words * 32u + n] = make_uint2(target, fbits);
-    }
+    for (uint32_t n = lane; n < p.n_nodes; n += 64u) super_skip[(size_t)sb * words * 32u + n] = super_skip_of(nodes, s_mask, n);
 }
 
 // every node of [a, b] far?
@@ -383,10 +384,11 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
                                                        uint2* __restrict__ prog_ops, uint32_t* __restrict__ eval_count,
                                                        uint32_t* __restrict__ eval_list, uint32_t list_stride, ivx_chunk_info* __restrict__ info_out,
                                                        const uint32_t* __restrict__ super_mask, const uint2* __restrict__ super_skip, uint32_t words,
-                                                       uint32_t sy, uint32_t sz, ivx_roles::PresetArgs preset) {
-    // (when the super-block tables are kept from an earlier step this is the step's first kernel and hosts the presets of the later
-    // stages' scratch words; the sampler's own counters are never among them: other blocks of this launch are adding to those)
+                                                       uint32_t sy, uint32_t sz, uint32_t fused_super, ivx_roles::PresetArgs preset) {
+    // (with `fused_super` this is the step's first kernel and hosts the presets of the later stages' scratch words; the sampler's own
+    // counters are never among them: other blocks of this launch are adding to those)
     ivx_roles::role_preset(preset, blockIdx.x * (uint32_t)(PRE_T * PRE_WAVES) + threadIdx.x);
+    __shared__ uint32_t s_mask_all[SUPER_MAX_WORDS];  // fused_super: the super-block's far bit of every node of the program
     __shared__ uint2 s_skip[NODE_TILE];
     __shared__ uint32_t s_far[NODE_TILE / 32];
     __shared__ float s_lo[16][PRE_T];
@@ -416,6 +418,22 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
     const uint32_t oi = (ci + p.x_off) * 16u, oj = cj * 16u, ok = ck * 16u;
     const V3 origin_root = sub(mk((float)oi, (float)oj, (float)ok), mk(p.shifted_center[0], p.shifted_center[1], p.shifted_center[2]));
     const Box block{origin_root, add(origin_root, mk(16.0f, 16.0f, 16.0f))};
+    if (fused_super) {
+        // k_sdf_super's far test for this block's own super-block, all nodes, 64 per wave and round (the tables are a function of the
+        // program and the grid; building them here instead of in a launch of their own costs the block ~2 us and the step one launch less)
+        const V3 slo = sub(mk((float)((si * SUPER + p.x_off) * 16u), (float)(sj * SUPER * 16u), (float)(sk * SUPER * 16u)),
+                           mk(p.shifted_center[0], p.shifted_center[1], p.shifted_center[2]));
+        const Box sblock{slo, add(slo, mk(16.0f * SUPER, 16.0f * SUPER, 16.0f * SUPER))};
+        for (uint32_t n0 = wv * 64u; n0 < words * 32u; n0 += 64u * PRE_WAVES) {
+            const uint32_t n = n0 + tid;
+            bool far = false;
+            if (n < p.n_nodes) far = super_far(nodes + n, sblock);
+            const unsigned long long b = __ballot(far);
+            if (tid == 0 && (n0 >> 5) < words) s_mask_all[n0 >> 5] = (uint32_t)b;
+            if (tid == 32 && (n0 >> 5) + 1u < words) s_mask_all[(n0 >> 5) + 1u] = (uint32_t)(b >> 32);
+        }
+        __syncthreads();
+    }
     uint32_t top = 0, cmask = 0;  // cmask bit: level is an EXACT block constant (lo == hi == value)
     // Compact program of this chunk: steps of constant sub-expressions collapse into one OP_CONST (the
     // steps of a stack level are a contiguous tail of the stream, so folding = truncate + re-emit).
@@ -433,8 +451,13 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
             const uint32_t tile_cnt = min((uint32_t)NODE_TILE, p.n_nodes - n);
             load_node_tile(s_nodes, nodes + n, tile_cnt, threadIdx.x, PRE_T * PRE_WAVES);
             if (wv == 0u) {
-                if (n + tid < p.n_nodes) s_skip[tid] = super_skip[(size_t)sb * words * 32u + n + tid];
-                if (tid < NODE_TILE / 32 && (n >> 5) + tid < words) s_far[tid] = super_mask[(size_t)sb * words + (n >> 5) + tid];
+                if (fused_super) {
+                    if (n + tid < p.n_nodes) s_skip[tid] = super_skip_of(nodes, s_mask_all, n + tid);
+                    if (tid < NODE_TILE / 32 && (n >> 5) + tid < words) s_far[tid] = s_mask_all[(n >> 5) + tid];
+                } else {
+                    if (n + tid < p.n_nodes) s_skip[tid] = super_skip[(size_t)sb * words * 32u + n + tid];
+                    if (tid < NODE_TILE / 32 && (n >> 5) + tid < words) s_far[tid] = super_mask[(size_t)sb * words + (n >> 5) + tid];
+                }
             }
             __syncthreads();
             for (uint32_t q = wv; q < tile_cnt; q += PRE_WAVES) {
@@ -937,7 +960,7 @@ int ivx_sampler_buffers(ivx_grid* g) {
 ivx_roles::PresetArgs ivx_preset_args(ivx_grid* g, uint32_t groups);  // derive.hip
 
 int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, uint32_t n_nodes, uint32_t stack_size,
-                          const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type, uint32_t preset_groups, int cache_super) {
+                          const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type, uint32_t preset_groups) {
     SampleParams p;
     p.cx = g->cc[0];
     p.cy = g->cc[1];
@@ -964,40 +987,35 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
     uint2* ops = reinterpret_cast<uint2*>(g->samp_ops);
     uint32_t* eval_count = g->samp_len + g->n_chunks;
     uint32_t* eval_list = eval_count + 16;
-    // The super-block tables depend on the program and the grid only: a step over the resident program computes them once
-    // (`cache_super`: the caller vouches that `d_nodes` is the grid's resident program; ivx_grid_set_sdf_program drops them).
-    static const bool super_every_step = getenv("IVX_SUPER_EVERY_STEP") != nullptr;  // measurement switch: rebuild the tables on every call
-    const bool have_super = cache_super && g->super_valid && !super_every_step;
-    // the list counters must be zero: rolled over by the derive sweep of the step before (IVX_SCRATCH_EVAL clean), else cleared here —
-    // by k_sdf_super's preset role when it runs and hosts presets, by a memset otherwise
+    // Programs of up to SUPER_MAX_WORDS * 32 nodes get their super-block tables inside the pre-pass (no launch of their own); the
+    // pre-pass is then the call's first kernel and hosts the presets of the later stages' scratch words. The sampler's own list
+    // counters are zero already when the derive sweep of the step before rolled them over (role_preset), else cleared here.
+    const uint32_t words = (n_nodes + 31u) / 32u > 0u ? (n_nodes + 31u) / 32u : 1u;
+    const bool fused_super = words <= SUPER_MAX_WORDS;
     const bool eval_dirty = (g->scratch_dirty & IVX_SCRATCH_EVAL) != 0u;
-    uint32_t super_presets = have_super ? 0u : preset_groups;
-    uint32_t prepass_presets = have_super ? (preset_groups & ~IVX_SCRATCH_EVAL) : 0u;
+    uint32_t super_presets = fused_super ? 0u : preset_groups;
+    const uint32_t prepass_presets = fused_super ? (preset_groups & ~IVX_SCRATCH_EVAL) : 0u;
     if (eval_dirty && !(super_presets & IVX_SCRATCH_EVAL)) IVX_HIP_CHECK(hipMemsetAsync(eval_count, 0, 8 * sizeof(uint32_t), g->ctx->stream));
     if (!eval_dirty) super_presets &= ~IVX_SCRATCH_EVAL;
     const uint32_t sx = (g->cc[0] + SUPER - 1) / SUPER, sy = (g->cc[1] + SUPER - 1) / SUPER, sz = (g->cc[2] + SUPER - 1) / SUPER;
-    const uint32_t words = (n_nodes + 31u) / 32u > 0u ? (n_nodes + 31u) / 32u : 1u;
-    {
+    uint2* super_skip = nullptr;
+    if (!fused_super) {
         const size_t need = (((size_t)sx * sy * sz * words + 1u) & ~(size_t)1u) + (size_t)sx * sy * sz * words * 64u;  // far bits + a uint2 per node
         if (need > g->samp_super_words) {
             IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
             if (g->samp_super) (void)hipFree(g->samp_super);
             g->samp_super = nullptr;
             g->samp_super_words = 0;
-            g->super_valid = 0;
             IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_super), need * sizeof(uint32_t)));
             g->samp_super_words = need;
         }
-    }
-    uint2* super_skip = reinterpret_cast<uint2*>(g->samp_super + (((size_t)sx * sy * sz * words + 1u) & ~(size_t)1u));
-    if (!have_super) {
+        super_skip = reinterpret_cast<uint2*>(g->samp_super + (((size_t)sx * sy * sz * words + 1u) & ~(size_t)1u));
         hipLaunchKernelGGL(k_sdf_super, dim3(sx * sy * sz), dim3(64), words * sizeof(uint32_t), g->ctx->stream, p, d_nodes, g->samp_super, super_skip, words, sy, sz,
                            ivx_preset_args(g, super_presets));
-        g->super_valid = cache_super ? 1 : 0;
     }
     g->scratch_dirty = (g->scratch_dirty & ~preset_groups) | IVX_SCRATCH_EVAL;
     hipLaunchKernelGGL(k_sdf_prepass, dim3(sx * sy * sz), dim3(PRE_T * PRE_WAVES), 0, g->ctx->stream, p, d_nodes, chunk_const, g->samp_len, ops, eval_count, eval_list,
-                       g->n_chunks, g->info, g->samp_super, super_skip, words, sy, sz, ivx_preset_args(g, prepass_presets));
+                       g->n_chunks, g->info, g->samp_super, super_skip, words, sy, sz, fused_super ? 1u : 0u, ivx_preset_args(g, prepass_presets));
     g->planes_compact = 1;
     {
         // one launch per LDS class (see k_sdf_prepass); a class the program cannot reach is not launched

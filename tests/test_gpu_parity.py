@@ -241,8 +241,8 @@ def test_dense_workload_512(ctx):
 
 
 def test_program_swap_on_a_resident_grid(ctx):
-    """the super-block tables of the sampler are kept from step to step for the resident program: a new program on the same grid must
-    drop them (ivx_grid_set_sdf_program), and stepping the same program repeatedly must keep giving the same object"""
+    """a new program on a resident grid, and the same program stepped repeatedly (the sampler's list counters are rolled over by the
+    derive sweep of the step before, its scratch presets ride in the pre-pass): every step must give the object a fresh grid gives"""
     from impact_amd import capi
     from impact_amd.voxel import SDFVoxelGenerator
 
