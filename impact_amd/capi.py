@@ -145,7 +145,7 @@ EXPORTED_SYMBOLS = [
     "ivx_halo_bytes", "ivx_halo_pack", "ivx_halo_unpack", "ivx_halo_clear",
     "ivx_region_face_bytes", "ivx_region_face_labels", "ivx_region_face_pairs",
     "ivx_world_create", "ivx_world_destroy", "ivx_world_set_bodies", "ivx_world_get_bodies", "ivx_world_set_contacts",
-    "ivx_world_step", "ivx_world_step_enqueue", "ivx_world_prepare", "ivx_world_advance_momenta", "ivx_world_solve", "ivx_world_advance_configurations",
+    "ivx_world_set_spherical_joints", "ivx_world_step", "ivx_world_step_enqueue", "ivx_world_prepare", "ivx_world_advance_momenta", "ivx_world_solve", "ivx_world_advance_configurations",
     "ivx_impact_fracturing_config_default", "ivx_generate_impact_fracture_points", "ivx_delaunay_construct", "ivx_delaunay_destroy", "ivx_delaunay_counts",
     "ivx_delaunay_download", "ivx_delaunay_aabb", "ivx_delaunay_boundary_face_planes", "ivx_voronoi_polyhedron", "ivx_voronoi_bounded_aabb",
     "ivx_comm_unique_id", "ivx_comm_init", "ivx_comm_init_local", "ivx_comm_destroy", "ivx_slab_create", "ivx_slab_destroy",
@@ -274,6 +274,7 @@ def lib():
         "ivx_capsule_voxel_object_contacts": (i32, [vp, vp, vp, vp, vp, f32, C.c_uint64, C.c_uint64, u32, u32, vp, vp, sz, C.POINTER(sz)]),
         "ivx_world_step": (i32, [vp, f32, vp]),
         "ivx_world_step_enqueue": (i32, [vp, f32]),
+        "ivx_world_set_spherical_joints": (i32, [vp, vp, sz]),
         "ivx_world_prepare": (i32, [vp]),
         "ivx_world_advance_momenta": (i32, [vp, f32]),
         "ivx_world_solve": (i32, [vp]),

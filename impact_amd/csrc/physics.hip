@@ -744,6 +744,14 @@ __global__ __launch_bounds__(MG_THREADS) void k_solve_mg(uint32_t n_dyn, float f
     }
 }
 
+// dynamic bodies a joint is anchored to are constrained bodies of the step (prepare_spherical_joint -> add_body_pair, solver.rs:182-215)
+__global__ __launch_bounds__(256) void k_mark_bodies(uint32_t n, const uint32_t* __restrict__ refs, uint32_t n_dyn, uint8_t* __restrict__ touched) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = refs[i];
+    if (!(r & IVX_KINEMATIC_BODY) && r < n_dyn) touched[r] = 1;
+}
+
 }  // namespace
 
 int ivx_launch_phys_prepare_bodies(ivx_world* w) {
@@ -759,6 +767,13 @@ int ivx_launch_phys_prepare_contacts(ivx_world* w, const int32_t* d_prev_slot) {
     hipLaunchKernelGGL(k_prepare_contacts, dim3((w->n_contacts + 255u) / 256u), dim3(256), 0, w->ctx->stream, w->n_contacts, w->n_dyn, w->contacts,
                        d_prev_slot, w->cb, w->pc[w->cur ^ 1], reinterpret_cast<const float4*>(w->acc[w->cur ^ 1]), w->n_prev,
                        w->cfg.old_impulse_weight, w->pc[w->cur], reinterpret_cast<float4*>(w->acc[w->cur]), w->touched);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+int ivx_launch_phys_mark_joint_bodies(ivx_world* w) {
+    if (w->n_joint_refs == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_mark_bodies, dim3((w->n_joint_refs + 255u) / 256u), dim3(256), 0, w->ctx->stream, w->n_joint_refs, w->joint_refs, w->n_dyn, w->touched);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

@@ -243,12 +243,37 @@ void ivx_world_destroy(ivx_world* w) {
     if (!w) return;
     (void)hipStreamSynchronize(w->ctx->stream);
     void* ptrs[] = {w->dyn, w->kin, w->cb, w->touched, w->contacts, w->prev_slot, w->pc[0], w->pc[1], w->acc[0], w->acc[1], w->items, w->item_bodies, w->level_start,
-                    w->dynst, w->barrier_words};
+                    w->dynst, w->barrier_words, w->joint_refs};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (w->ev_ready)
         for (int i = 0; i < 5; ++i) (void)hipEventDestroy(w->ev[i]);
     delete w;
+}
+
+// ConstraintManager::add_spherical_joint + the joints' share of prepare_constraints (constraint.rs:183-190, 252-255). The reference's
+// PreparedSphericalJoint is a placeholder: `compute_impulses` returns 0, `apply_impulses_to_body_pair` and
+// `apply_positional_correction_to_body_pair` are empty (constraint/spherical_joint.rs:62-88), so a joint adds no item to the sweeps.
+// What it does do is make its two bodies constrained bodies of the step (`prepare_spherical_joint` -> `add_body_pair`): their velocities
+// are synchronised before the solve and written back after it — momentum = mass x (momentum / mass) — like those of bodies in contact.
+int ivx_world_set_spherical_joints(ivx_world* w, const uint32_t* body_pairs, size_t n_joints) {
+    IVX_REQUIRE(w && (body_pairs || n_joints == 0), IVX_ERR_INVALID, "ivx_world_set_spherical_joints: null argument");
+    IVX_REQUIRE(n_joints < (1u << 24), IVX_ERR_CAPACITY, "ivx_world_set_spherical_joints: too many joints");
+    for (size_t i = 0; i < 2 * n_joints; ++i) {
+        const uint32_t r = body_pairs[i];
+        IVX_REQUIRE((r & 0x7FFFFFFFu) < ((r & IVX_KINEMATIC_BODY) ? w->n_kin : w->n_dyn), IVX_ERR_INVALID,
+                    "ivx_world_set_spherical_joints: anchor %zu refers to a missing body", i);
+    }
+    IVX_HIP_CHECK(hipStreamSynchronize(w->ctx->stream));
+    if (w->joint_refs) (void)hipFree(w->joint_refs);
+    w->joint_refs = nullptr;
+    w->n_joint_refs = 0;
+    if (n_joints) {
+        IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->joint_refs), 2 * n_joints * sizeof(uint32_t)));
+        IVX_HIP_CHECK(hipMemcpy(w->joint_refs, body_pairs, 2 * n_joints * sizeof(uint32_t), hipMemcpyHostToDevice));
+        w->n_joint_refs = (uint32_t)(2 * n_joints);
+    }
+    return IVX_OK;
 }
 
 int ivx_world_set_bodies(ivx_world* w, const ivx_rigid_body* dyn, size_t n_dyn, const ivx_kinematic_body* kin, size_t n_kin) {
@@ -433,6 +458,7 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
     w->cur ^= 1;
     if ((rc = ivx_launch_phys_prepare_bodies(w))) return rc;
     if ((rc = ivx_launch_phys_prepare_contacts(w, w->prev_slot))) return rc;
+    if ((rc = ivx_launch_phys_mark_joint_bodies(w))) return rc;
     w->prepared_fresh = 1;
     IVX_HIP_CHECK(hipStreamSynchronize(s));
     if (n_prepared) *n_prepared = nc;
@@ -449,6 +475,7 @@ int ivx_world_prepare(ivx_world* w) {
     w->n_prev = w->n_contacts;
     if ((rc = ivx_launch_phys_prepare_bodies(w))) return rc;
     if ((rc = ivx_launch_phys_prepare_contacts(w, nullptr))) return rc;
+    if ((rc = ivx_launch_phys_mark_joint_bodies(w))) return rc;
     w->prepared_fresh = 1;
     return IVX_OK;
 }
@@ -486,7 +513,7 @@ static int world_step_enqueue(ivx_world* w, float dt, bool timed) {
         if (timed) IVX_HIP_CHECK(hipEventRecord(w->ev[i], s)); \
     } while (0)
     int rc;
-    if (w->n_contacts == 0 && !w->prepared_fresh) {
+    if (w->n_contacts == 0 && !w->prepared_fresh && w->n_joint_refs == 0) {
         // no constraints this step: prepare, advance momenta and advance configurations are element-wise per body — one launch
         w->cur ^= 1;
         w->n_prev = 0;

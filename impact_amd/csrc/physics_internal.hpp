@@ -58,6 +58,10 @@ struct ivx_world {
     uint32_t max_level_items[2];  // widest level of each phase's schedule
     // the solve on several workgroups (physics.hip, k_solve_mg): the phase's mutable body state as shared 32-byte records, the
     // monotonic arrival counter of the grid barrier + an error word (a bounded poll gave up), how many arrivals have been used up
+    // SphericalJoint constraints (constraint/spherical_joint.rs): the reference's joint computes no impulse and no correction (:62-88);
+    // all it does is register its two bodies as constrained bodies, which get their velocities written back after the solve
+    uint32_t* joint_refs;  // device: body references (IVX_KINEMATIC_BODY flag) of all joints' anchors
+    uint32_t n_joint_refs;
     float* dynst;
     uint32_t* barrier_words;
     uint32_t barrier_count;
@@ -83,6 +87,7 @@ struct ivx_world {
 
 int ivx_launch_phys_prepare_bodies(ivx_world* w);
 int ivx_launch_phys_prepare_contacts(ivx_world* w, const int32_t* d_prev_slot);
+int ivx_launch_phys_mark_joint_bodies(ivx_world* w);
 int ivx_launch_phys_pre_solve(ivx_world* w, float dt);
 int ivx_launch_phys_solve(ivx_world* w);
 int ivx_launch_phys_free_step(ivx_world* w, float dt);

@@ -124,6 +124,12 @@ class PhysicsWorld:
         check(capi.lib().ivx_world_step(self.h, step_duration, ptr(out)))
         return out[0]
 
+    def set_spherical_joints(self, body_pairs) -> None:
+        """`ConstraintManager::add_spherical_joint` for all joints at once: (n, 2) body references (KINEMATIC_BODY flag for kinematic bodies).
+        The reference's joint applies no impulse (constraint/spherical_joint.rs:62-88); its bodies become constrained bodies of every step."""
+        bp = np.ascontiguousarray(np.asarray(body_pairs, dtype=np.uint32).reshape(-1, 2))
+        check(capi.lib().ivx_world_set_spherical_joints(self.h, ptr(bp) if len(bp) else None, len(bp)))
+
     def step_enqueue(self, step_duration: float) -> None:
         """the same step, only enqueued on the context's stream (`ivx_world_step_enqueue`); read the bodies back with
         `get_bodies` after the next wait on the stream"""

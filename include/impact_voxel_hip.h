@@ -553,6 +553,12 @@ int ivx_world_get_bodies(ivx_world*, ivx_rigid_body* dynamic, ivx_kinematic_body
  * the solve order and the warm-start source of every contact (solver.rs:386-452), and the dependency
  * schedule that lets the GPU run the reference's sequential sweeps in parallel with identical results. */
 int ivx_world_set_contacts(ivx_world*, const ivx_contact*, size_t n, size_t* n_prepared);
+/* SphericalJoint constraints (src/constraint/spherical_joint.rs, ConstraintManager::add_spherical_joint src/constraint.rs:183-190): two body
+ * references per joint (IVX_KINEMATIC_BODY flag as in ivx_contact). The reference's joint is a placeholder that applies no impulse and no
+ * positional correction (spherical_joint.rs:62-88); preparing it only registers its bodies as constrained bodies of the step, whose
+ * velocities are written back after the solve — which is all this entry point makes happen. Stays in force until replaced; call it after
+ * ivx_world_set_bodies. */
+int ivx_world_set_spherical_joints(ivx_world*, const uint32_t* body_pairs, size_t n_joints);
 /* perform_physics_step (src/lib.rs:31-110) without force generators / motion drivers: prepare constraints ->
  * advance momenta -> synchronise velocities, warm start, n_iterations sweeps, positional correction,
  * write back -> advance configurations. The stages are also exposed one by one. */

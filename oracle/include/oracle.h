@@ -163,6 +163,7 @@ int orc_sphere_sphere_contact(const float ca[3], float ra, const float cb[3], fl
 int orc_sphere_plane_contact(const float c[3], float r, const float plane_normal[3], float plane_displacement, float position[3],
                              float normal[3], float* depth);
 int orc_physics_prepare(orc_physics*, const orc_contact*, int n);
+void orc_physics_set_joints(orc_physics*, const uint32_t* body_pairs, int n_joints); /* SphericalJoint: a placeholder in the reference (no impulses); its bodies become constrained bodies */
 int orc_physics_prepared_body_count(const orc_physics*);
 void orc_physics_contact_order(const orc_physics*, uint64_t* ids);
 void orc_physics_accumulated_impulses(const orc_physics*, float* out3n);

@@ -300,6 +300,7 @@ struct orc_physics {
     std::vector<uint32_t> body_ref;  // rigid body reference (bit31 = kinematic) per constrained body
     std::unordered_map<uint32_t, uint32_t> body_index;
     orc_solver_config cfg{8, 0.4f, 3, 0.2f};
+    std::vector<uint32_t> joint_refs;  // SphericalJoint anchors' bodies, two per joint (constraint.rs:36, 183-190)
 };
 
 static uint32_t add_body(orc_physics* w, uint32_t ref) {  // constraint.rs:442-467
@@ -489,6 +490,13 @@ int orc_physics_prepare(orc_physics* w, const orc_contact* contacts, int n) {
         }
         i = j;
     }
+    // the spherical joints (constraint.rs:252-255 -> solver.rs:182-215): prepare_spherical_joint makes the pair constrained bodies and
+    // registers a PreparedSphericalJoint whose impulses and corrections are all zero / empty (constraint/spherical_joint.rs:62-88):
+    // nothing to solve, but the bodies take part in the velocity synchronisation and write-back
+    for (size_t j = 0; j + 1 < w->joint_refs.size(); j += 2) {
+        add_body(w, w->joint_refs[j]);
+        add_body(w, w->joint_refs[j + 1]);
+    }
     // remove_unprepared_constraints_and_reset_flags (solver.rs:434-452)
     size_t idx = 0, len = w->cache.size();
     while (idx < len) {
@@ -507,6 +515,7 @@ int orc_physics_prepare(orc_physics* w, const orc_contact* contacts, int n) {
     }
     return (int)w->cache.size();
 }
+void orc_physics_set_joints(orc_physics* w, const uint32_t* body_pairs, int n_joints) { w->joint_refs.assign(body_pairs, body_pairs + 2 * (size_t)(n_joints > 0 ? n_joints : 0)); }
 int orc_physics_prepared_body_count(const orc_physics* w) { return (int)w->bodies.size(); }
 // ids of the cached contacts in solve order
 void orc_physics_contact_order(const orc_physics* w, uint64_t* ids) { std::memcpy(ids, w->keys.data(), w->keys.size() * 8); }

@@ -142,6 +142,7 @@ def lib():
         L.orc_sphere_plane_contact.argtypes = [vp, C.c_float, vp, C.c_float, vp, vp, vp]
         L.orc_physics_prepare.restype = C.c_int
         L.orc_physics_prepare.argtypes = [vp, vp, C.c_int]
+        L.orc_physics_set_joints.argtypes = [vp, vp, C.c_int]
         L.orc_physics_prepared_body_count.restype = C.c_int
         L.orc_physics_prepared_body_count.argtypes = [vp]
         L.orc_physics_contact_order.argtypes = [vp, vp]
@@ -678,6 +679,10 @@ class OraclePhysics:
         c = np.ascontiguousarray(contacts)
         self.n_prepared = lib().orc_physics_prepare(self.h, _p(c), len(c))
         return self.n_prepared
+
+    def set_spherical_joints(self, body_pairs):
+        bp = np.ascontiguousarray(np.asarray(body_pairs, dtype=np.uint32).reshape(-1, 2))
+        lib().orc_physics_set_joints(self.h, bp.ctypes.data_as(C.c_void_p) if len(bp) else None, len(bp))
 
     def prepared_body_count(self):
         return lib().orc_physics_prepared_body_count(self.h)

@@ -261,3 +261,43 @@ def test_free_bodies_integrate_exactly_like_the_oracle(ctx):
             w.step_enqueue(0.01)
     pu.assert_bodies_close(w.bodies()[0], o.bodies()[0])
     w.close()
+
+
+def test_spherical_joints_only_register_their_bodies(ctx):
+    """The reference's SphericalJoint is a placeholder: no impulse, no positional correction (constraint/spherical_joint.rs:62-88). Preparing
+    it makes its two bodies constrained bodies of the step — velocities synchronised before the solve and written back after it (momentum =
+    mass x (momentum / mass), an f32 round trip) — and that is all. Jointed bodies without contacts, jointed bodies with contacts, a joint to a
+    kinematic body, free bodies beside them: bit-equal to the oracle; the free bodies keep their momenta to the bit."""
+    rng = np.random.default_rng(5)
+    n = 24
+    dyn = []
+    for i in range(n):
+        I = np.diag(rng.uniform(0.5, 2.0, 3))
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        dyn.append(ol.rigid_body_new(rng.uniform(0.37, 3.1), I, rng.normal(size=3) * 5, q, rng.normal(size=3), rng.normal(size=3)))
+    dyn = np.array(dyn)
+    from impact_amd.capi import KINEMATIC_BODY_DTYPE
+
+    kin = np.zeros(1, dtype=KINEMATIC_BODY_DTYPE)
+    kin["velocity"] = (0.5, 0.0, -0.25)
+    kin["angular_axis"] = (0.0, 0.0, 1.0)
+    w, o = pu.make_pair(ctx, dyn, kin)
+    joints = [(0, 1), (1, 2), (5, 9), (11, KINEMATIC_BIT | 0)]
+    w.set_spherical_joints(joints)
+    o.set_spherical_joints(joints)
+    none = np.zeros(0, dtype=CONTACT_DTYPE)
+    before = w.bodies()[0].copy()
+    for _ in range(5):
+        pu.step_both(w, o, none, 0.01)
+    got, want = w.bodies()[0], o.bodies()[0]
+    for f in ("momentum", "angular_momentum", "position", "orientation"):
+        np.testing.assert_array_equal(got[f].view(np.uint32), want[f].view(np.uint32), err_msg=f)
+    free = [i for i in range(n) if i not in (0, 1, 2, 5, 9, 11)]
+    np.testing.assert_array_equal(got["momentum"][free].view(np.uint32), before["momentum"][free].view(np.uint32))
+    # with a contact in the same step
+    c = np.array([contact(77, 2, 3, ((0.0, 0.0, 0.0), (1.0, 0.0, 0.0), 0.01), 0.5)], dtype=CONTACT_DTYPE)
+    for _ in range(3):
+        pu.step_both(w, o, c, 0.01)
+    pu.assert_bodies_close(w.bodies()[0], o.bodies()[0])
+    w.close()

@@ -208,3 +208,28 @@ def test_interlocked_manifold_is_replaced_by_one_separating_contact():
     cs2["normal"] = (0, 1, 0)
     w2 = ol.OraclePhysics(dyn, config=DEFAULT)
     assert w2.prepare(cs2) == 4
+
+
+def test_spherical_joint_is_the_placeholder_the_reference_has():
+    """constraint/spherical_joint.rs:62-88: zero impulse, empty apply / positional correction. A joint therefore only makes its bodies
+    constrained bodies (prepared-body count, velocity write-back = one f32 round trip of the momenta); positions, orientations and everything
+    about bodies outside joints and contacts stay as they were"""
+    dyn = np.array([ol.uniform_sphere_body(0.5, 1.7 + 0.3 * i, (3.0 * i, 0.0, 0.0), (0.123 + i, -0.456, 0.789)) for i in range(4)])
+    w = ol.OraclePhysics(dyn, None, DEFAULT)
+    w.set_spherical_joints([(0, 1)])
+    n = w.prepare(np.zeros(0, dtype=CONTACT_DTYPE))
+    assert n == 0 and w.prepared_body_count() == 2
+    before = w.bodies()[0].copy()
+    w.solve()
+    after = w.bodies()[0]
+    np.testing.assert_array_equal(after["position"], before["position"])
+    np.testing.assert_array_equal(after["orientation"], before["orientation"])
+    np.testing.assert_array_equal(after["momentum"][2:], before["momentum"][2:])  # not in a joint: untouched, to the bit
+    m = before["mass"][:2, None]
+    np.testing.assert_allclose(after["momentum"][:2], before["momentum"][:2], rtol=3e-7)  # mass * (momentum / mass)
+    expect = (m * (before["momentum"][:2] * (np.float32(1.0) / m).astype(np.float32)).astype(np.float32)).astype(np.float32)
+    assert np.all(np.abs(after["momentum"][:2] - expect) <= np.abs(expect) * 2e-7)
+    # joints stay in force for the following steps; an empty list removes them
+    w.set_spherical_joints([])
+    w.prepare(np.zeros(0, dtype=CONTACT_DTYPE))
+    assert w.prepared_body_count() == 0
