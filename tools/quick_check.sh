@@ -1,4 +1,5 @@
 #!/bin/bash
+# quick GPU check used while tuning: the plain bench lines of both 512^3 workloads, then the whole GPU test suite
 set -u
 out=$PWD/gpurun_out/r2m
 mkdir -p "$out"
