@@ -181,7 +181,7 @@ __device__ __forceinline__ uint4 pack16(const int* v) {
 // maximally-outside voxels (the reference drops their data, object/sdf.rs:486-489) and store.
 __device__ __forceinline__ void classify_and_store(int* sd, uint4 types, bool types_uniform_in, uint8_t first_type, int8_t* sdf_out,
                                                    uint8_t* type_out, ivx_chunk_info* info_out, uint32_t chunk, uint32_t tid,
-                                                   bool set_type, uint32_t voxel_type, bool compact) {
+                                                   bool set_type, uint32_t voxel_type, bool compact, uint32_t* s_votes) {
     bool any_nonempty = false, any_nonvoid = false, all_inside = true;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -189,9 +189,14 @@ __device__ __forceinline__ void classify_and_store(int* sd, uint4 types, bool ty
         any_nonvoid |= sd[k] <= SD_VOID_LIMIT;
         all_inside &= sd[k] == -128;
     }
-    int only_empty = !__syncthreads_or(any_nonempty ? 1 : 0);
-    int is_void = !__syncthreads_or(any_nonvoid ? 1 : 0);
-    int uniform = __syncthreads_and((all_inside && types_uniform_in) ? 1 : 0);
+    // the three workgroup votes through four words of LDS the caller lends (`s_votes`: in k_sdf_eval the tail of the stack, dead by now —
+    // the kernel keeps no LDS of its own, so that five 32 KB stacks fit a CU), one barrier pair instead of three
+    const uint32_t mine = (__ballot(any_nonempty) ? 1u : 0u) | (__ballot(any_nonvoid) ? 2u : 0u) | (__ballot(!(all_inside && types_uniform_in)) ? 4u : 0u);
+    __syncthreads();  // every wave is past its last use of the memory the votes go to
+    if ((tid & 63u) == 0u) s_votes[tid >> 6] = mine;
+    __syncthreads();
+    const uint32_t votes = (s_votes[0] | s_votes[1]) | (s_votes[2] | s_votes[3]);
+    const int only_empty = !(votes & 1u), is_void = !(votes & 2u), uniform = !(votes & 4u);
     uint32_t kind = is_void ? KIND_VOID : ((!only_empty && uniform) ? KIND_UNIFORM : KIND_NONUNIFORM);
     if (is_void) {
 #pragma unroll
@@ -730,13 +735,17 @@ __device__ __forceinline__ void eval_leaf(const ivx_sdf_processed_node* nd, uint
 // index of the LDS level that holds stack level `level`: the number of per-voxel (non-constant) levels below it
 __device__ __forceinline__ uint32_t lds_level(uint32_t cmask, uint32_t level) { return __popc(~cmask & ((1u << level) - 1u)); }
 
+// The block-constant stack levels' values: lane l of one VGPR holds level l's (workgroup-uniform; every wave keeps its own copy)
+__device__ __forceinline__ float cv_get(float cv, uint32_t level) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(cv), (int)level)); }
+__device__ __forceinline__ void cv_set(float& cv, uint32_t level, float x) { cv = (threadIdx.x & 63u) == level ? x : cv; }
+
 __device__ __forceinline__ void combine_levels(uint32_t kind, float s, float q, float margin, bool outside, uint32_t top, float* stack,
-                                               float* s_cval, uint32_t& cmask, uint32_t tid) {
+                                               float& cv, uint32_t& cmask, uint32_t tid) {
     // LDS levels are dense: a block-constant stack level is a scalar and takes none (lds_level)
     const bool c1 = (cmask >> (top - 1)) & 1u, c2 = (cmask >> top) & 1u;
     float* d1 = stack + (size_t)lds_level(cmask, top - 1) * IVX_CHUNK_VOXELS;
     const float* d2 = stack + (size_t)lds_level(cmask, top) * IVX_CHUNK_VOXELS;
-    const float v1 = c1 ? s_cval[top - 1] : 0.0f, v2 = c2 ? s_cval[top] : 0.0f;
+    const float v1 = c1 ? cv_get(cv, top - 1) : 0.0f, v2 = c2 ? cv_get(cv, top) : 0.0f;
     bool apply = !outside;
     if (!apply) {  // workgroup-uniform branch
         if (c1 && c2) {
@@ -767,7 +776,7 @@ __device__ __forceinline__ void combine_levels(uint32_t kind, float s, float q, 
     }
     if (apply) {
         if (c1 && c2) {
-            s_cval[top - 1] = combine(kind, v1, v2, s, q);
+            cv_set(cv, top - 1, combine(kind, v1, v2, s, q));
         } else {
             apply_rows_dispatch(kind, d1 + tid, d2 + tid, c1, c2, v1, v2, s, q);
             cmask &= ~(1u << (top - 1));
@@ -776,7 +785,7 @@ __device__ __forceinline__ void combine_levels(uint32_t kind, float s, float q, 
 }
 
 __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t* __restrict__ eval_count, const uint32_t* __restrict__ eval_list,
-                                                  const uint32_t* __restrict__ long_count, uint32_t list_len,
+                                                  const uint32_t* __restrict__ long_count, uint32_t list_len, uint32_t lds_levels,
                                                   const uint32_t* __restrict__ prog_len, const uint2* __restrict__ prog_ops,
                                                   const ivx_sdf_processed_node* __restrict__ nodes, int8_t* __restrict__ sdf_out,
                                                   uint8_t* __restrict__ type_out, ivx_chunk_info* __restrict__ info_out) {
@@ -800,11 +809,10 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
     // Control flow is wave-uniform and scalar. Block-constant propagation: a stack level whose 4096
     // values are all equal (`fill(+-margin)`) is kept as one scalar; combining two constants yields a
     // constant. Element-wise results are unchanged (same op on equal inputs).
-    __shared__ float s_cval_all[4][16];  // one copy per wave: waves drift apart between barriers
-    float* s_cval = s_cval_all[tid >> 6];
+    float cv = 0.0f;  // values of the block-constant levels (cv_get / cv_set)
     const uint32_t lane = tid & 63u;
     uint32_t top = 0;
-    uint32_t cmask = 0;  // bit l set: level l is block-constant, value in s_cval[l]
+    uint32_t cmask = 0;  // bit l set: level l is block-constant, value in lane l of cv
 
     const uint32_t len = __builtin_amdgcn_readfirstlane(prog_len[chunk]);
     if (len != OP_OVERFLOW) {
@@ -850,7 +858,7 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
             }
             const uint32_t opc = w >> 28, kind = (w >> 24) & 15u;
             if (opc == OP_CONST) {
-                s_cval[top] = __uint_as_float(v);
+                cv_set(cv, top, __uint_as_float(v));
                 cmask |= 1u << top;
                 top += 1;
             } else if (opc == OP_LEAF) {
@@ -862,7 +870,7 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
                 // OP_COMBINE_OUTSIDE over (constant, per-voxel) that the 14 test positions decide not to apply leaves its
                 // constant first operand standing (combine_levels), which the pre-pass cannot foresee.
                 if ((cmask >> (top - 1)) & 1u) {
-                    s_cval[top - 1] = s_cval[top - 1] * s;
+                    cv_set(cv, top - 1, cv_get(cv, top - 1) * s);
                 } else {
                     float* d = stack + (size_t)lds_level(cmask, top - 1) * IVX_CHUNK_VOXELS + tid;
 #pragma unroll
@@ -870,7 +878,7 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
                 }
             } else {
                 top -= 1;
-                combine_levels(kind, s, q, margin, opc == OP_COMBINE_OUTSIDE, top, stack, s_cval, cmask, tid);
+                combine_levels(kind, s, q, margin, opc == OP_COMBINE_OUTSIDE, top, stack, cv, cmask, tid);
             }
         }
     } else {
@@ -888,7 +896,7 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
                 const uint32_t mode = ((mk1 >> j) & 1ull) ? 1u : (((mk2 >> j) & 1ull) ? 2u : 0u);
                 if (kind <= 2u) {
                     if (mode != 0u) {
-                        s_cval[top] = mode == 1u ? nd->margin : -nd->margin;
+                        cv_set(cv, top, mode == 1u ? nd->margin : -nd->margin);
                         cmask |= 1u << top;
                     } else {
                         cmask &= ~(1u << top);
@@ -898,7 +906,7 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
                 } else if (kind == 5u) {
                     const float s = nd->a;
                     if ((cmask >> (top - 1)) & 1u) {
-                        s_cval[top - 1] = s_cval[top - 1] * s;
+                        cv_set(cv, top - 1, cv_get(cv, top - 1) * s);
                     } else {
                         float* d = stack + (size_t)lds_level(cmask, top - 1) * IVX_CHUNK_VOXELS + tid;
 #pragma unroll
@@ -906,7 +914,7 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
                     }
                 } else if (kind >= 7u) {
                     top -= 1;
-                    combine_levels(kind, nd->a, nd->b, nd->margin, mode != 0u, top, stack, s_cval, cmask, tid);
+                    combine_levels(kind, nd->a, nd->b, nd->margin, mode != 0u, top, stack, cv, cmask, tid);
                 }
             }
         }
@@ -915,7 +923,7 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
     IVX_TE(p, li, 2);  // program evaluated
     IVX_TE(p, li, 3);
     const bool root_const = cmask & 1u;
-    const float root_val = root_const ? s_cval[0] : 0.0f;
+    const float root_val = root_const ? cv_get(cv, 0u) : 0.0f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         float v = root_const ? root_val : stack[k * 256 + tid];
@@ -923,7 +931,8 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
         sd[k] = in_grid ? sd_from_f32(v) : 127;
     }
     IVX_TE(p, li, 4);
-    classify_and_store(sd, make_uint4(0, 0, 0, 0), true, 0, sdf_out, type_out, info_out, chunk, tid, true, p.voxel_type, true);
+    classify_and_store(sd, make_uint4(0, 0, 0, 0), true, 0, sdf_out, type_out, info_out, chunk, tid, true, p.voxel_type, true,
+                       reinterpret_cast<uint32_t*>(stack) + (size_t)lds_levels * IVX_CHUNK_VOXELS - 4u);
     IVX_TE(p, li, 5);  // classified and stored
     }
 }
@@ -943,7 +952,8 @@ __global__ __launch_bounds__(256) void k_classify(uint32_t n_chunks, int8_t* __r
     for (int k = 0; k < 16; ++k) sd[k] = (int)(int8_t)((sw[k >> 2] >> (8 * (k & 3))) & 0xFF);
     uint32_t ft = first_type * 0x01010101u;
     bool types_uniform = t.x == ft && t.y == ft && t.z == ft && t.w == ft;
-    classify_and_store(sd, t, types_uniform, first_type, sdf, type, info, chunk, tid, false, 0, false);
+    __shared__ uint32_t s_votes[4];
+    classify_and_store(sd, t, types_uniform, first_type, sdf, type, info, chunk, tid, false, 0, false, s_votes);
 }
 
 }  // namespace
@@ -1026,7 +1036,7 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
             if (c == 2 && stack_size == 3u) break;
             const size_t lds_c = (size_t)(levels[c] ? levels[c] : 1u) * IVX_CHUNK_VOXELS * sizeof(float);
             hipLaunchKernelGGL(k_sdf_eval, dim3(eval_blocks), dim3(256), lds_c, g->ctx->stream, p, eval_count + c, eval_list + (size_t)c * g->n_chunks,
-                               c == 0 ? eval_count + 3 : nullptr, g->n_chunks, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info);
+                               c == 0 ? eval_count + 3 : nullptr, g->n_chunks, levels[c] ? levels[c] : 1u, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info);
         }
     }
     IVX_HIP_CHECK(hipGetLastError());
