@@ -6,9 +6,15 @@
 
 #define NODE_NONE 0xFFFFFFFFu
 
+// (path halving on the way: the larger root always goes under the smaller, so every parent is an ancestor with a smaller index and a
+// parent may be replaced by any of its own ancestors at any time; the roots, all that is counted afterwards, are untouched)
 __device__ __forceinline__ uint32_t lds_find(volatile uint32_t* par, uint32_t x) {
     uint32_t p;
-    while ((p = par[x]) != x) x = p;
+    while ((p = par[x]) != x) {
+        const uint32_t gp = par[p];
+        if (gp != p) par[x] = gp;
+        x = gp;
+    }
     return x;
 }
 __device__ __forceinline__ void lds_union(uint32_t* par, uint32_t a, uint32_t b) {
@@ -359,8 +365,20 @@ __device__ __forceinline__ void ccl_local_chunk(CclShared& sh, uint32_t tid, uin
     // a Void chunk has no voxels and a chunk generated Uniform is one solid region whether or not it was demoted since
     const bool known = kind == KIND_VOID || gen == KIND_UNIFORM;
     const uint32_t m = known ? 0u : m_in;
-    const int all_full = known ? (kind != KIND_VOID) : __syncthreads_and(m == 0xFFFFu);
-    const int any = known ? (kind != KIND_VOID) : __syncthreads_or(m != 0);
+    // three workgroup votes in one round (a ballot per wave, four words of LDS, one barrier — the previous user of these words is at
+    // least one barrier back): every row full? any voxel at all? any voxel on the chunk's boundary?
+    const bool edge_row = ti == 0 || ti == 15 || tj == 0 || tj == 15;
+    int all_full = kind != KIND_VOID, any = all_full, touches = 0;
+    if (!known) {
+        const uint32_t mine = (__ballot(m != 0xFFFFu) ? 1u : 0u) | (__ballot(m != 0u) ? 2u : 0u) |
+                              (__ballot(edge_row ? (m != 0u) : ((m & 0x8001u) != 0u)) ? 4u : 0u);
+        if ((tid & 63u) == 0u) sh.w[tid >> 6] = mine;
+        __syncthreads();
+        const uint32_t votes = (sh.w[0] | sh.w[1]) | (sh.w[2] | sh.w[3]);
+        all_full = !(votes & 1u);
+        any = (votes & 2u) != 0u;
+        touches = (votes & 4u) != 0u;
+    }
     if (!any || all_full) {
         // no voxels, or one solid region touching every face
         const uint32_t lab = any ? 0u : 0xFFFFFFFFu;
@@ -423,8 +441,7 @@ __device__ __forceinline__ void ccl_local_chunk(CclShared& sh, uint32_t tid, uin
         const uint32_t wr = ivx_wave_sum(n_roots);
         if ((tid & 63u) == 0 && wr) atomicAdd(&sh.cnt, wr);
     }
-    const bool edge_row = ti == 0 || ti == 15 || tj == 0 || tj == 15;
-    const int touches = __syncthreads_or(edge_row ? (m != 0) : ((m & 0x8001u) != 0));
+    __syncthreads();
     const uint32_t rc = sh.cnt;
     if (rc == 1u) {
         uint32_t w[4] = {0, 0, 0, 0};
