@@ -649,6 +649,8 @@ __device__ __forceinline__ void index_materials(const VMat vm[3], unsigned long 
     }
 }
 
+__device__ __forceinline__ uint32_t vertex_of(uint32_t vrow, int k) { return (vrow >> 17) + (uint32_t)__popc(vrow & ((1u << k) - 1u)); }
+
 // (amdgpu_waves_per_eu(4): keeps the kernel at <= 128 VGPRs so that four workgroups fit a CU; the LDS footprint, ~38 KB, allows
 // four as well. The kernel is bound by the latency of a workgroup's serial phases, so residency is what buys throughput.)
 template <bool SLOTS>
@@ -661,9 +663,8 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
     __shared__ __attribute__((aligned(16))) uint8_t s_sd[TILE_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t s_ty[TILE_BYTES];
     __shared__ uint32_t s_neg[NROWS];
-    __shared__ uint32_t s_vbase[NCROWS + 1];  // first vertex of every cube row
-    __shared__ uint16_t s_surf[NCUBES];       // vertex -> cube id (cube row * 17 + k)
-    __shared__ uint16_t s_map[NCUBES];        // cube id -> vertex
+    __shared__ uint32_t s_vrow[NCROWS];   // per cube row: first vertex << 17 | which of its 17 cubes have a vertex (cube -> vertex: vertex_of)
+    __shared__ uint16_t s_surf[NCUBES];   // vertex -> cube id (cube row * 17 + k)
     __shared__ uint32_t s_wsum[4];
     const GridView& g = p.g;
     const uint32_t tid = threadIdx.x;
@@ -726,13 +727,12 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
         for (int q = 0; q < 2; ++q) {
             const int cr = r0 + q;
             if (cr < NCROWS) {
-                s_vbase[cr] = base;
+                s_vrow[cr] = (base << 17) | vb[q];
                 uint32_t m = vb[q];
                 while (m) {
                     const int k = __ffs(m) - 1;
                     m &= m - 1;
                     s_surf[base] = (uint16_t)(cr * 17 + k);
-                    s_map[cr * 17 + k] = (uint16_t)base;
                     base += 1;
                 }
             }
@@ -862,7 +862,11 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
             const int ac = axis == 0 ? 1 : (axis == 1 ? 289 : 17);
             const bool n1 = (int8_t)s_sd[tix(i, j, k)] < 0;
             const bool negative_face = !n1;  // (false,true) => negative face (surface_nets.rs:348-352)
-            const uint32_t v1 = s_map[qcid], v2 = s_map[qcid - ab], v3 = s_map[qcid - ac], v4 = s_map[qcid - ab - ac];
+            // cube -> vertex: the row's first vertex plus the vertices below k in the row (ab, ac step the row by 0, 1 or 17 and k by 0 or 1)
+            const int rb = ab == 1 ? 0 : (ab == 17 ? 1 : 17), rc = ac == 1 ? 0 : (ac == 17 ? 1 : 17);
+            const int kb = ab == 1 ? 1 : 0, kc = ac == 1 ? 1 : 0;
+            const uint32_t v1 = vertex_of(s_vrow[cr], k), v2 = vertex_of(s_vrow[cr - rb], k - kb), v3 = vertex_of(s_vrow[cr - rc], k - kc),
+                           v4 = vertex_of(s_vrow[cr - rb - rc], k - kb - kc);
             const float* P = positions + 3 * (size_t)voff;
             const V3 q1 = mk(P[3 * v1], P[3 * v1 + 1], P[3 * v1 + 2]), q2 = mk(P[3 * v2], P[3 * v2 + 1], P[3 * v2 + 2]);
             const V3 q3 = mk(P[3 * v3], P[3 * v3 + 1], P[3 * v3 + 2]), q4 = mk(P[3 * v4], P[3 * v4 + 1], P[3 * v4 + 2]);
