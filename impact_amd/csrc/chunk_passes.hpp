@@ -365,10 +365,23 @@ __device__ __forceinline__ void ccl_local_chunk(CclShared& sh, uint32_t tid, uin
     // a Void chunk has no voxels and a chunk generated Uniform is one solid region whether or not it was demoted since
     const bool known = kind == KIND_VOID || gen == KIND_UNIFORM;
     const uint32_t m = known ? 0u : m_in;
-    // three workgroup votes in one round (a ballot per wave, four words of LDS, one barrier — the previous user of these words is at
-    // least one barrier back): every row full? any voxel at all? any voxel on the chunk's boundary?
+    // One barrier publishes three things: the workgroup's three votes (a ballot per wave, four words of LDS — the previous user of these
+    // words is at least one barrier back): every row full? any voxel at all? any voxel on the chunk's boundary?; the rows' masks; and
+    // the union-find's nodes — one per run, keyed by the voxel index of its first voxel (a chunk that the votes settle wrote its few
+    // nodes for nothing).
     const bool edge_row = ti == 0 || ti == 15 || tj == 0 || tj == 15;
+    const uint32_t starts = m & ~(m << 1);
     int all_full = kind != KIND_VOID, any = all_full, touches = 0;
+    sh.mask[tid] = m;
+    {
+        uint32_t r = starts;  // (none for a chunk that is known)
+        while (r) {
+            const int k = __ffs(r) - 1;
+            r &= r - 1;
+            sh.par[tid * 16 + k] = tid * 16 + k;
+        }
+    }
+    if (tid == 0) sh.cnt = 0;
     if (!known) {
         const uint32_t mine = (__ballot(m != 0xFFFFu) ? 1u : 0u) | (__ballot(m != 0u) ? 2u : 0u) |
                               (__ballot(edge_row ? (m != 0u) : ((m & 0x8001u) != 0u)) ? 4u : 0u);
@@ -389,19 +402,6 @@ __device__ __forceinline__ void ccl_local_chunk(CclShared& sh, uint32_t tid, uin
         brc_out = any ? 1u : 0u;
         return;
     }
-    // 1. one node per run, keyed by the voxel index of its first voxel
-    sh.mask[tid] = m;
-    const uint32_t starts = m & ~(m << 1);
-    {
-        uint32_t r = starts;
-        while (r) {
-            const int k = __ffs(r) - 1;
-            r &= r - 1;
-            sh.par[tid * 16 + k] = tid * 16 + k;
-        }
-    }
-    if (tid == 0) sh.cnt = 0;
-    __syncthreads();
     // 2. join runs across +x and +y: one union per run of the overlap between the two rows
     {
         const uint32_t mx = ti < 15 ? sh.mask[tid + 16] : 0u;

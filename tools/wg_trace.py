@@ -4,7 +4,7 @@ Kernels compiled with IVX_WG_TRACE store up to six 100 MHz wall-clock stamps of 
 ivx_internal.hpp) into the grid's per-chunk moment buffer; this script runs the 512^3 bench workload up to the stage asked for,
 reads the stamps back and prints the mean time between consecutive probes, start/end percentiles and the number of entries in
 flight. Only ONE traced kernel may run in the traced step (they share the buffer), so choose the stage whose kernel has probes.
-usage: wg_trace.py {sample|derive|remesh} [scale]   (sample: k_sdf_eval, derive: k_derive with the region pass, remesh: k_sn_emit)"""
+usage: wg_trace.py {prepass|sample|derive|remesh} [scale|dense]   (sample: k_sdf_eval, derive: k_derive with the region pass, remesh: k_sn_emit)"""
 import ctypes as C
 import os
 import sys
@@ -20,9 +20,10 @@ STAGES = {"prepass": capi.STAGE_SAMPLE, "sample": capi.STAGE_SAMPLE, "derive": c
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "remesh"
-    scale = float(sys.argv[2]) if len(sys.argv) > 2 else 2.05
+    dense = len(sys.argv) > 2 and sys.argv[2] == "dense"  # the all-surface workload (32 perforated plates) instead of the asteroid
+    scale = float(sys.argv[2]) if len(sys.argv) > 2 and not dense else 2.05
     ctx = Context(0)
-    gen = SDFVoxelGenerator(1.0, scenes.asteroid_scene(scale), 0)
+    gen = SDFVoxelGenerator(1.0, scenes.plates_scene(32) if dense else scenes.asteroid_scene(scale), 0)
     obj = VoxelObject(ctx, gen.chunk_counts(), 1.0)
     obj.set_sdf_program(gen)
     obj.set_densities(np.ones(256, dtype=np.float32))
@@ -35,7 +36,7 @@ def main():
     if not p:
         raise SystemExit("the library was not built with TRACE=1")
     hip = C.CDLL("libamdhip64.so")
-    n = min(obj.n_chunks, 20000)
+    n = min(obj.n_chunks, 40000)
     buf = np.zeros((n, 8), dtype=np.uint64)
     hip.hipDeviceSynchronize()
     assert hip.hipMemcpy(buf.ctypes.data_as(C.c_void_p), C.c_void_p(p), buf.nbytes, 2) == 0
@@ -63,7 +64,7 @@ def main():
     print("end percentiles us", [round(float(np.percentile(d[:, 5], q)), 1) for q in (0, 10, 25, 50, 75, 90, 100)])
     dur = d[:, 5] - d[:, 0]
     print("entry duration percentiles us", [round(float(np.percentile(dur, q)), 1) for q in (0, 10, 50, 90, 100)])
-    for t in (5, 10, 20, 40, 60, 80):
+    for t in (5, 10, 20, 40, 60, 80) + ((200, 400, 600) if dense else ()):
         print(f"in flight at {t} us: {int(np.sum((d[:, 0] <= t) & (d[:, 5] > t)))}")
 
 
