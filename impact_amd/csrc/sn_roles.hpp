@@ -12,6 +12,7 @@ constexpr int G = 18, NROWS = 324, NCROWS = 289, NCUBES = 4913;
 // LDS tile: 18 x 18 rows of 18 bytes along k; a row occupies RS = 24 bytes with cell c at byte 3 + c, so the 16
 // interior cells (c = 1..16, the chunk's own k-row) sit 4-byte aligned and are written as four words.
 constexpr int RS = 24, TILE_BYTES = NROWS * RS;
+constexpr uint32_t VPC = 864;  // vertices a mesher workgroup keeps in LDS for its quad phase (role_sn_emit)
 __device__ __forceinline__ int tix(int a, int b, int c) { return (a * G + b) * RS + 3 + c; }
 
 struct V3 {
@@ -665,6 +666,11 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
     __shared__ uint32_t s_neg[NROWS];
     __shared__ uint32_t s_vrow[NCROWS];   // per cube row: first vertex << 17 | which of its 17 cubes have a vertex (cube -> vertex: vertex_of)
     __shared__ uint16_t s_surf[NCUBES];   // vertex -> cube id (cube row * 17 + k)
+    // the chunk's vertices for the quad phase, when there are at most VPC of them (else that phase reads them back from memory):
+    // positions, and the one material around the vertex (0xFF: several) — with these 11 KB the workgroup takes 40 656 bytes of LDS,
+    // four to a CU like its 128 registers
+    __shared__ float s_vpos[3][VPC];
+    __shared__ uint8_t s_vsm[VPC];
     __shared__ uint32_t s_wsum[4];
     const GridView& g = p.g;
     const uint32_t tid = threadIdx.x;
@@ -815,6 +821,12 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
             } else {
                 vm = vertex_materials(has, mats);
             }
+            if (v < VPC) {
+                s_vpos[0][v] = position.x;
+                s_vpos[1][v] = position.y;
+                s_vpos[2][v] = position.z;
+                s_vsm[v] = single ? (uint8_t)m0 : (uint8_t)0xFFu;  // (0xFF is the type of empty voxels, never a vertex material)
+            }
         }
         const size_t gv = (size_t)voff + v;
         positions[3 * gv + 0] = position.x;
@@ -833,6 +845,7 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
     // the quads are first listed in that order (ordered prefix over the vertices' quad counts), then handled one THREAD per
     // quad: a vertex emits up to three quads, and walking them inside its thread made every pass three quads long.
     uint32_t qbase = 0;
+    const bool cached = vcount <= VPC;  // (the same for the whole workgroup)
     for (uint32_t v0 = 0; v0 < vcount; v0 += 256) {
         const uint32_t v = v0 + tid;
         uint32_t qm = 0;
@@ -867,14 +880,30 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
             const int kb = ab == 1 ? 1 : 0, kc = ac == 1 ? 1 : 0;
             const uint32_t v1 = vertex_of(s_vrow[cr], k), v2 = vertex_of(s_vrow[cr - rb], k - kb), v3 = vertex_of(s_vrow[cr - rc], k - kc),
                            v4 = vertex_of(s_vrow[cr - rb - rc], k - kb - kc);
-            const float* P = positions + 3 * (size_t)voff;
-            const V3 q1 = mk(P[3 * v1], P[3 * v1 + 1], P[3 * v1 + 2]), q2 = mk(P[3 * v2], P[3 * v2 + 1], P[3 * v2 + 2]);
-            const V3 q3 = mk(P[3 * v3], P[3 * v3 + 1], P[3 * v3 + 2]), q4 = mk(P[3 * v4], P[3 * v4 + 1], P[3 * v4 + 2]);
-            // the four corners' vertex materials travel with their positions: fetched per triangle corner after the diagonal is
-            // chosen they were a second dependent round trip to memory
-            uint4 vm1 = vmats[(size_t)voff + v1], vm2 = vmats[(size_t)voff + v2], vm3 = vmats[(size_t)voff + v3], vm4 = vmats[(size_t)voff + v4];
-            asm volatile("" : "+v"(vm1.x), "+v"(vm1.y), "+v"(vm1.z), "+v"(vm1.w), "+v"(vm2.x), "+v"(vm2.y), "+v"(vm2.z), "+v"(vm2.w));
-            asm volatile("" : "+v"(vm3.x), "+v"(vm3.y), "+v"(vm3.z), "+v"(vm3.w), "+v"(vm4.x), "+v"(vm4.y), "+v"(vm4.z), "+v"(vm4.w));
+            // The four corners and their vertex materials: from LDS when the chunk's vertices fit there; a wave whose quads each have one
+            // material at all four corners (nearly every wave of nearly every body) then needs nothing from memory. Otherwise positions
+            // and materials are read back from the buffers, all loads issued together (the materials travel with the positions: fetched
+            // per triangle corner after the diagonal is chosen they were a second dependent round trip to memory).
+            V3 q1, q2, q3, q4;
+            uint4 vm1 = make_uint4(0, 0, 0, 0), vm2 = vm1, vm3 = vm1, vm4 = vm1;
+            uint32_t one_mat = 0xFFu;
+            bool fast = false;
+            if (cached) {
+                q1 = mk(s_vpos[0][v1], s_vpos[1][v1], s_vpos[2][v1]), q2 = mk(s_vpos[0][v2], s_vpos[1][v2], s_vpos[2][v2]);
+                q3 = mk(s_vpos[0][v3], s_vpos[1][v3], s_vpos[2][v3]), q4 = mk(s_vpos[0][v4], s_vpos[1][v4], s_vpos[2][v4]);
+                const uint32_t b1 = s_vsm[v1], b2 = s_vsm[v2], b3 = s_vsm[v3], b4 = s_vsm[v4];
+                one_mat = b1;
+                fast = __all((b1 != 0xFFu && b1 == b2 && b1 == b3 && b1 == b4) ? 1 : 0) != 0;
+            } else {
+                const float* P = positions + 3 * (size_t)voff;
+                q1 = mk(P[3 * v1], P[3 * v1 + 1], P[3 * v1 + 2]), q2 = mk(P[3 * v2], P[3 * v2 + 1], P[3 * v2 + 2]);
+                q3 = mk(P[3 * v3], P[3 * v3 + 1], P[3 * v3 + 2]), q4 = mk(P[3 * v4], P[3 * v4 + 1], P[3 * v4 + 2]);
+            }
+            if (!fast) {
+                vm1 = vmats[(size_t)voff + v1], vm2 = vmats[(size_t)voff + v2], vm3 = vmats[(size_t)voff + v3], vm4 = vmats[(size_t)voff + v4];
+                asm volatile("" : "+v"(vm1.x), "+v"(vm1.y), "+v"(vm1.z), "+v"(vm1.w), "+v"(vm2.x), "+v"(vm2.y), "+v"(vm2.z), "+v"(vm2.w));
+                asm volatile("" : "+v"(vm3.x), "+v"(vm3.y), "+v"(vm3.z), "+v"(vm3.w), "+v"(vm4.x), "+v"(vm4.y), "+v"(vm4.z), "+v"(vm4.w));
+            }
             uint32_t quad[6];
             if (len3(sub(q1, q4)) < len3(sub(q2, q3))) {
                 if (negative_face) { quad[0] = v1; quad[1] = v4; quad[2] = v2; quad[3] = v1; quad[4] = v3; quad[5] = v4; }
@@ -884,6 +913,12 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
             const size_t io = (size_t)ioff + (size_t)(qbase + q) * 6;
 #pragma unroll
             for (int t = 0; t < 6; ++t) indices[io + t] = voff + quad[t];
+            if (fast) {  // calculate_index_materials_for_triangle's first case (surface_nets.rs:559-637): one entry, weight 1
+                const unsigned long long im = (unsigned long long)one_mat | (1ull << 32);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) imats[io + t] = im;
+                continue;
+            }
 #pragma unroll
             for (int tri = 0; tri < 2; ++tri) {
                 VMat vm[3];
