@@ -824,6 +824,33 @@ def main():
             w.close()
             out["frame"] = {"workload": "the timed voxel step + one config-4 pile step (resident contacts), enqueued back to back, one wait",
                             "ms_per_frame": frame_ms, "voxels_per_s": n_vox_rank / (frame_ms * 1e-3)}
+            # the same frame with the rigid-body world on a context (HIP stream) of its own: the solve keeps a handful of CUs busy
+            # (one workgroup per 256 chains of the widest level), the voxel step runs beside it on the rest of the chip
+            from impact_amd import scenes as _scenes
+            from impact_amd.physics import PhysicsWorld as _World
+            ctx2 = Context(device)
+            pb, pc = _scenes.sphere_pile_scene(16)
+            w2 = _World(ctx2)
+            w2.set_bodies(pb)
+            w2.prepare_constraints(pc)
+            w2.step(0.005)
+            w2.prepare_constraints(pc)
+            for _ in range(2):
+                w2.step_enqueue(0.005)
+                obj.step_enqueue(capi.STAGE_ALL)
+                obj.step_collect()
+                ctx2.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                w2.step_enqueue(0.005)
+                obj.step_enqueue(capi.STAGE_ALL)
+                obj.step_collect()
+                ctx2.synchronize()
+            frame2_ms = 1e3 * (time.perf_counter() - t0) / 10
+            w2.close()
+            ctx2.close()
+            out["frame"]["ms_per_frame_two_streams"] = frame2_ms
+            out["frame"]["two_streams"] = "the pile's world on a second ivx_ctx (its own stream): solve and voxel step overlap, two waits"
             if args.workload == "asteroid":
                 out["collide"] = collide_benchmark(ctx, args.scale, o_big if with_cpu else None, m_big)
                 out["edit"] = edit_benchmark(ctx, args.scale, o_big if with_cpu else None)  # (last: the oracle's edit changes o_big)

@@ -301,3 +301,41 @@ def test_spherical_joints_only_register_their_bodies(ctx):
         pu.step_both(w, o, c, 0.01)
     pu.assert_bodies_close(w.bodies()[0], o.bodies()[0])
     w.close()
+
+
+def test_world_and_voxel_step_on_two_contexts_overlap(ctx):
+    """the rigid-body world on a context (HIP stream) of its own while a voxel object steps on another (bench.py's two-stream frame):
+    the multi-workgroup solve shares the chip with the voxel kernels and both give what they give alone, bit for bit"""
+    from impact_amd import capi
+    from impact_amd.voxel import Context, SDFVoxelGenerator, VoxelObject
+
+    rng = np.random.default_rng(3)
+    bodies, contacts = scenes.sphere_pile_scene(8)
+    bodies["momentum"] += rng.normal(0, 0.05, bodies["momentum"].shape).astype(np.float32)
+    ctx2 = Context(0)
+    alone, beside = PhysicsWorld(ctx), PhysicsWorld(ctx2)
+    for w in (alone, beside):
+        w.set_bodies(bodies)
+        w.prepare_constraints(contacts)
+        w.set_solver_groups(4)
+    gen = SDFVoxelGenerator(1.0, scenes.asteroid_scene(1.0), 0)
+    obj = VoxelObject(ctx, gen.chunk_counts(), 1.0)
+    obj.set_sdf_program(gen)
+    obj.set_densities(np.ones(256, dtype=np.float32))
+    want = obj.step(capi.STAGE_ALL).copy()
+    for frame in range(4):
+        alone.step(0.004)
+        beside.step_enqueue(0.004)
+        obj.step_enqueue(capi.STAGE_ALL)
+        got = obj.step_collect()
+        ctx2.synchronize()
+        for f in ("region_count", "mesh", "moments", "occupied"):
+            assert np.atleast_1d(got[f]).tobytes() == np.atleast_1d(want[f]).tobytes(), f"frame {frame} {f}"
+        da, db = alone.bodies()[0], beside.bodies()[0]
+        for f in pu.STATE_FIELDS:
+            np.testing.assert_array_equal(db[f].view(np.uint32), da[f].view(np.uint32), err_msg=f"frame {frame} {f}")
+    assert beside.solver_info()["workgroups"] == 4
+    for w in (alone, beside):
+        w.close()
+    obj.close()
+    ctx2.close()
