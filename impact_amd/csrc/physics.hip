@@ -553,29 +553,86 @@ __device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t rs, uint32_t byt
     __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byte_off, 0, 16);
 }
 
-// the (up to) four prepared contacts of a chain: they never change during the solve, so the next level's are requested while the
-// current level computes (one wave per SIMD: registers are plentiful)
-struct ChainContacts {
-    PhysContact p0, p1, p2, p3;
+// What a chain reads that does not change during the solve — its (up to) four prepared contacts and the two bodies' constants — comes from a
+// PACKED copy made once per step (k_pack_items): one record per item of the schedule, stored tile by tile of 64 consecutive items of a level,
+// field-major inside the tile, so that lane l's j-th 16 bytes lie next to lane l+1's. Gathered from the contact and body arrays every lane
+// reads lines of its own: ~34 load instructions x 64 lines per wave and level, and the cycle counters put the larger half of a velocity
+// level there. A chain appears in 9 velocity and 3 positional items, hence as many copies (~70 MB for the 46 080-contact pile).
+template <int PHASE>
+struct Packed {
+    static constexpr uint32_t CJ = PHASE == 0 ? 5u : 3u;  // float4s per contact
+    static constexpr uint32_t BJ = PHASE == 0 ? 5u : 3u;  // float4s per body
+    static constexpr uint32_t NJ = 4u * CJ + 2u * BJ;
 };
-__device__ __forceinline__ void load_chain_contacts(uint32_t item, const PhysContact* __restrict__ pcs, ChainContacts& c) {
+template <int PHASE>
+__device__ __forceinline__ void pack_contact(const PhysContact& p, float4* out /* stride 64 */) {
+    if (PHASE == 0) {
+        out[0] = make_float4(p.normal[0], p.normal[1], p.normal[2], p.tangent[0]);
+        out[64] = make_float4(p.tangent[1], p.tangent[2], p.bitangent[0], p.bitangent[1]);
+        out[128] = make_float4(p.bitangent[2], p.m_n, p.m_t, p.m_b);
+        out[192] = make_float4(p.friction, p.target, p.world_b[0], p.world_b[1]);
+        out[256] = make_float4(p.world_b[2], 0.0f, 0.0f, 0.0f);
+    } else {
+        out[0] = make_float4(p.normal[0], p.normal[1], p.normal[2], p.local_a[0]);
+        out[64] = make_float4(p.local_a[1], p.local_a[2], p.local_b[0], p.local_b[1]);
+        out[128] = make_float4(p.local_b[2], 0.0f, 0.0f, 0.0f);
+    }
+}
+template <int PHASE>
+__device__ __forceinline__ PhysContact unpack_contact(const float4* in /* stride 64 */) {
+    PhysContact p = {};
+    const float4 a = in[0], b = in[64], c = in[128];
+    p.normal[0] = a.x, p.normal[1] = a.y, p.normal[2] = a.z;
+    if (PHASE == 0) {
+        const float4 d = in[192], e = in[256];
+        p.tangent[0] = a.w, p.tangent[1] = b.x, p.tangent[2] = b.y;
+        p.bitangent[0] = b.z, p.bitangent[1] = b.w, p.bitangent[2] = c.x;
+        p.m_n = c.y, p.m_t = c.z, p.m_b = c.w;
+        p.friction = d.x, p.target = d.y;
+        p.world_b[0] = d.z, p.world_b[1] = d.w, p.world_b[2] = e.x;
+    } else {
+        p.local_a[0] = a.w, p.local_a[1] = b.x, p.local_a[2] = b.y;
+        p.local_b[0] = b.z, p.local_b[1] = b.w, p.local_b[2] = c.x;
+    }
+    return p;
+}
+template <int PHASE>
+__device__ __forceinline__ void pack_body(const PhysBody& b, float4* out) {
+    out[0] = make_float4(b.inv_mass, b.inv_inertia[0], b.inv_inertia[1], b.inv_inertia[2]);
+    out[64] = make_float4(b.inv_inertia[3], b.inv_inertia[4], b.inv_inertia[5], b.inv_inertia[6]);
+    if (PHASE == 0) {
+        out[128] = make_float4(b.inv_inertia[7], b.inv_inertia[8], b.pos[0], b.pos[1]);
+        out[192] = make_float4(b.pos[2], b.v[0], b.v[1], b.v[2]);
+        out[256] = make_float4(b.w[0], b.w[1], b.w[2], 0.0f);
+    } else {
+        out[128] = make_float4(b.inv_inertia[7], b.inv_inertia[8], 0.0f, 0.0f);
+    }
+}
+// one thread per item, one block per tile of 64 items (tile_first: index of the tile's first item | (items in the tile - 1) << 26)
+template <int PHASE>
+__global__ __launch_bounds__(64) void k_pack_items(const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ items,
+                                                   const uint2* __restrict__ item_bodies, const PhysContact* __restrict__ pcs,
+                                                   const PhysBody* __restrict__ cb, float4* __restrict__ packed) {
+    const uint32_t tf = tile_first[blockIdx.x], first = tf & 0x03FFFFFFu, cnt = (tf >> 26) + 1u, lane = threadIdx.x;
+    if (lane >= cnt) return;
+    const uint32_t item = items[first + lane];
+    const uint2 bo = item_bodies[first + lane];
     const uint32_t s0 = item & 0x00FFFFFFu, len = (item >> 24) & 15u;
-    c.p0 = pcs[s0];
-    if (len > 1u) c.p1 = pcs[s0 + 1u];
-    if (len > 2u) c.p2 = pcs[s0 + 2u];
-    if (len > 3u) c.p3 = pcs[s0 + 3u];
+    float4* out = packed + (size_t)blockIdx.x * Packed<PHASE>::NJ * 64u + lane;
+#pragma unroll
+    for (uint32_t c = 0; c < 4u; ++c) pack_contact<PHASE>(pcs[s0 + (c < len ? c : len - 1u)], out + (size_t)c * Packed<PHASE>::CJ * 64u);
+    pack_body<PHASE>(cb[bo.x], out + (size_t)4u * Packed<PHASE>::CJ * 64u);
+    pack_body<PHASE>(cb[bo.y], out + (size_t)(4u * Packed<PHASE>::CJ + Packed<PHASE>::BJ) * 64u);
 }
 
-// `nxt_item` != 0xFFFFFFFF: the contacts of the thread's item of the next level are loaded into `nxt` behind this chain's own loads
+// `pk`: the item's packed record (its tile's base + the lane)
 template <int PHASE>
 __device__ __forceinline__ void run_chain_mg(uint32_t item, uint2 bodies, uint32_t n_dyn, float factor, const PhysContact* __restrict__ pcs,
                                              __amdgpu_buffer_rsrc_t rs_acc, const PhysBody* __restrict__ cb, __amdgpu_buffer_rsrc_t rs_dyn,
-                                             const ChainContacts& cc, uint32_t nxt_item, ChainContacts& nxt) {
+                                             const float4* __restrict__ pk) {
     const uint32_t s0 = item & 0x00FFFFFFu, len = (item >> 24) & 15u, type = item >> 28;
     const uint32_t ia = bodies.x, ib = bodies.y;
     const bool with_acc = type != PHYS_ITEM_POSITIONAL, store_acc = type == PHYS_ITEM_VELOCITY;
-    const PhysBody& A = cb[ia];
-    const PhysBody& B = cb[ib];
     PairStatic st;
     st.dyn_a = ia < n_dyn;
     st.dyn_b = ib < n_dyn;
@@ -596,32 +653,37 @@ __device__ __forceinline__ void run_chain_mg(uint32_t item, uint2 bodies, uint32
         if (len > 2u) c2 = ld16_sc1(rs_acc, (s0 + 2u) * 16u);
         if (len > 3u) c3 = ld16_sc1(rs_acc, (s0 + 3u) * 16u);
     }
-    st.ima = A.inv_mass;
-    st.imb = B.inv_mass;
-    st.iia = ldm(A.inv_inertia);
-    st.iib = ldm(B.inv_inertia);
+    constexpr uint32_t CJ = Packed<PHASE>::CJ, BJ = Packed<PHASE>::BJ;
+    const PhysContact p0 = unpack_contact<PHASE>(pk), p1 = unpack_contact<PHASE>(pk + CJ * 64u), p2 = unpack_contact<PHASE>(pk + 2u * CJ * 64u),
+                      p3 = unpack_contact<PHASE>(pk + 3u * CJ * 64u);
+    const float4* ba = pk + 4u * CJ * 64u;
+    const float4* bb = ba + BJ * 64u;
+    const float4 ak0 = ba[0], ak1 = ba[64], ak2 = ba[128], bk0 = bb[0], bk1 = bb[64], bk2 = bb[128];
+    st.ima = ak0.x;
+    st.imb = bk0.x;
+    st.iia = M3{mk(ak0.y, ak0.z, ak0.w), mk(ak1.x, ak1.y, ak1.z), mk(ak1.w, ak2.x, ak2.y)};
+    st.iib = M3{mk(bk0.y, bk0.z, bk0.w), mk(bk1.x, bk1.y, bk1.z), mk(bk1.w, bk2.x, bk2.y)};
     PairState x;
     if (PHASE == 0) {
-        st.pos_a = ld3(A.pos);
-        st.pos_b = ld3(B.pos);
-    }
-    const V3 kva = ld3(A.v), kwa = ld3(A.w), kvb = ld3(B.v), kwb = ld3(B.w);  // (what a kinematic body moves with; unused for dynamic ones)
-    if (nxt_item != 0xFFFFFFFFu) load_chain_contacts(nxt_item, pcs, nxt);
-    if (PHASE == 0) {
+        const float4 ak3 = ba[192], ak4 = ba[256], bk3 = bb[192], bk4 = bb[256];
+        st.pos_a = mk(ak2.z, ak2.w, ak3.x);
+        st.pos_b = mk(bk2.z, bk2.w, bk3.x);
+        // (what a kinematic body moves with; unused for dynamic ones)
+        const V3 kva = mk(ak3.y, ak3.z, ak3.w), kwa = mk(ak4.x, ak4.y, ak4.z), kvb = mk(bk3.y, bk3.z, bk3.w), kwb = mk(bk4.x, bk4.y, bk4.z);
         x.va = st.dyn_a ? mk(a0.x, a0.y, a0.z) : kva;
         x.wa = st.dyn_a ? mk(a1.x, a1.y, a1.z) : kwa;
         x.vb = st.dyn_b ? mk(b0.x, b0.y, b0.z) : kvb;
         x.wb = st.dyn_b ? mk(b1.x, b1.y, b1.z) : kwb;
     } else {
-        x.pa = st.dyn_a ? mk(a0.x, a0.y, a0.z) : ld3(A.pos);
-        x.qa = st.dyn_a ? Q4{a1.x, a1.y, a1.z, a1.w} : ldq(A.q);
-        x.pb = st.dyn_b ? mk(b0.x, b0.y, b0.z) : ld3(B.pos);
-        x.qb = st.dyn_b ? Q4{b1.x, b1.y, b1.z, b1.w} : ldq(B.q);
+        x.pa = st.dyn_a ? mk(a0.x, a0.y, a0.z) : ld3(cb[ia].pos);
+        x.qa = st.dyn_a ? Q4{a1.x, a1.y, a1.z, a1.w} : ldq(cb[ia].q);
+        x.pb = st.dyn_b ? mk(b0.x, b0.y, b0.z) : ld3(cb[ib].pos);
+        x.qb = st.dyn_b ? Q4{b1.x, b1.y, b1.z, b1.w} : ldq(cb[ib].q);
     }
-    run_contact(type, cc.p0, st, x, factor, c0);
-    if (len > 1u) run_contact(type, cc.p1, st, x, factor, c1);
-    if (len > 2u) run_contact(type, cc.p2, st, x, factor, c2);
-    if (len > 3u) run_contact(type, cc.p3, st, x, factor, c3);
+    run_contact(type, p0, st, x, factor, c0);
+    if (len > 1u) run_contact(type, p1, st, x, factor, c1);
+    if (len > 2u) run_contact(type, p2, st, x, factor, c2);
+    if (len > 3u) run_contact(type, p3, st, x, factor, c3);
     for (uint32_t c = 4; c < len; ++c) {  // manifolds with more than four points
         const PhysContact q = pcs[s0 + c];
         float4 a = with_acc ? ld16_sc1(rs_acc, (s0 + c) * 16u) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -680,7 +742,8 @@ template <int PHASE>
 __global__ __launch_bounds__(MG_THREADS) void k_solve_mg(uint32_t n_dyn, float factor, const PhysContact* __restrict__ pcs, float4* __restrict__ accs,
                                                          uint32_t n_contacts, PhysBody* __restrict__ cb, float4* __restrict__ dynst,
                                                          const uint32_t* __restrict__ items, const uint2* __restrict__ item_bodies,
-                                                         const uint32_t* __restrict__ level_start, uint32_t n_levels, uint32_t* __restrict__ counter,
+                                                         const uint32_t* __restrict__ level_start, const uint32_t* __restrict__ tile_base,
+                                                         const float4* __restrict__ packed, uint32_t n_levels, uint32_t* __restrict__ counter,
                                                          uint32_t counter_base, uint32_t* __restrict__ error, uint32_t dry) {
     const uint32_t tid = threadIdx.x, G = gridDim.x, slot = blockIdx.x * MG_THREADS + tid, stride = G * MG_THREADS;
     const __amdgpu_buffer_rsrc_t rs_dyn = __builtin_amdgcn_make_buffer_rsrc(dynst, 0, n_dyn * 32u, 0x00020000);
@@ -698,10 +761,9 @@ __global__ __launch_bounds__(MG_THREADS) void k_solve_mg(uint32_t n_dyn, float f
     }
     uint32_t arrivals = counter_base + G;
     mg_barrier(counter, arrivals, error);
-    // the item word and body pair of this thread's chain of the next level are fetched one level ahead (they never change).
-    // (Fetching the next level's prepared contacts ahead as well was tried and measured slower: a level is bound by the chain's
-    // dependent arithmetic and the barrier, not by these loads.)
+    // the item word and body pair of this thread's chain of the next level are fetched one level ahead (they never change)
     uint32_t lb = level_start[0], le = level_start[1];
+    uint32_t tb = tile_base[0], tb_next = 0u;
     uint32_t nxt_item = 0xFFFFFFFFu;
     uint2 nxt_bodies = make_uint2(0u, 0u);
     if (lb + slot < le) {
@@ -713,7 +775,9 @@ __global__ __launch_bounds__(MG_THREADS) void k_solve_mg(uint32_t n_dyn, float f
         const uint32_t cur_item = nxt_item;
         const uint2 cur_bodies = nxt_bodies;
         nxt_item = 0xFFFFFFFFu;
+        const uint32_t tiles = tb;
         if (l + 1 < n_levels) {
+            tb_next = tile_base[l + 1];
             lb = e;
             le = level_start[l + 2];
             if (lb + slot < le) {
@@ -722,12 +786,12 @@ __global__ __launch_bounds__(MG_THREADS) void k_solve_mg(uint32_t n_dyn, float f
             }
         }
         for (uint32_t i = b + slot; i < e && !(dry & 1u); i += stride) {
-            ChainContacts cc, unused;
             const uint32_t it = i == b + slot ? cur_item : items[i];
             const uint2 bo = i == b + slot ? cur_bodies : item_bodies[i];
-            load_chain_contacts(it, pcs, cc);
-            run_chain_mg<PHASE>(it, bo, n_dyn, factor, pcs, rs_acc, cb, rs_dyn, cc, 0xFFFFFFFFu, unused);
+            const float4* pk = packed + (size_t)(tiles + ((i - b) >> 6)) * (Packed<PHASE>::NJ * 64u) + (tid & 63u);  // ((i - b) & 63 == tid & 63)
+            run_chain_mg<PHASE>(it, bo, n_dyn, factor, pcs, rs_acc, cb, rs_dyn, pk);
         }
+        tb = tb_next;
         arrivals += G;
         if (!(dry & 2u)) mg_barrier(counter, arrivals, error);
     }
@@ -819,11 +883,27 @@ static uint32_t ivx_solver_dry() {
 
 template <int PHASE>
 static int launch_solve_mg(ivx_world* w, uint32_t groups) {
+    {
+        const size_t need = (size_t)w->n_tiles[PHASE] * Packed<PHASE>::NJ * 64u * sizeof(float4);
+        if (need > w->packed_cap[PHASE]) {
+            IVX_HIP_CHECK(hipStreamSynchronize(w->ctx->stream));
+            if (w->packed[PHASE]) (void)hipFree(w->packed[PHASE]);
+            w->packed[PHASE] = nullptr;
+            w->packed_cap[PHASE] = 0;
+            IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->packed[PHASE]), need + need / 8));
+            w->packed_cap[PHASE] = need + need / 8;
+        }
+    }
     const uint32_t base = w->barrier_count;
     w->barrier_count += groups * (w->n_levels[PHASE] + 1u);
+    // this step's prepared contacts and body constants into the schedule's packed records (run_chain_mg)
+    hipLaunchKernelGGL((k_pack_items<PHASE>), dim3(w->n_tiles[PHASE]), dim3(64), 0, w->ctx->stream, w->tile_first + w->tile_offset[PHASE],
+                       w->items + w->item_offset[PHASE], reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], w->pc[w->cur], w->cb,
+                       reinterpret_cast<float4*>(w->packed[PHASE]));
     hipLaunchKernelGGL((k_solve_mg<PHASE>), dim3(groups), dim3(MG_THREADS), 0, w->ctx->stream, w->n_dyn, w->cfg.positional_correction_factor, w->pc[w->cur],
                        reinterpret_cast<float4*>(w->acc[w->cur]), w->n_contacts, w->cb, reinterpret_cast<float4*>(w->dynst), w->items + w->item_offset[PHASE],
                        reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], w->level_start + w->level_offset[PHASE],
+                       w->tile_base + w->level_offset[PHASE], reinterpret_cast<const float4*>(w->packed[PHASE]),
                        w->n_levels[PHASE], w->barrier_words, base, w->barrier_words + 1, ivx_solver_dry());
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;

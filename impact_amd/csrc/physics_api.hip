@@ -155,12 +155,15 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
     const uint32_t nch = (uint32_t)w->chain_start.size() - 1u, nb = w->n_dyn;
     w->item_offset[phase] = (uint32_t)w->items_host.size();
     w->level_offset[phase] = (uint32_t)w->level_start_host.size();
+    w->tile_offset[phase] = (uint32_t)w->tile_first_host.size();
+    w->n_tiles[phase] = 0;
     const uint32_t total_passes = n_first + n_passes;
     const size_t total = (size_t)total_passes * nch;
     w->n_levels[phase] = 0;
     w->max_level_items[phase] = 0;
     if (total == 0) {
         w->level_start_host.push_back(0);
+        w->tile_base_host.push_back(0);
         return;
     }
     std::vector<uint32_t>& lvl = w->scratch_level;
@@ -214,6 +217,18 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
     uint32_t widest = 0;
     for (uint32_t l = 0; l < max_level; ++l) widest = std::max(widest, start[l + 1] - start[l]);
     w->max_level_items[phase] = widest;
+    // tiles of 64 consecutive items of a level (the packed records of the multi-workgroup solve); tile_base runs parallel to level_start
+    w->tile_base_host.resize(ls0 + max_level + 1, 0u);
+    uint32_t n_tiles = 0;
+    for (uint32_t l = 0; l < max_level; ++l) {
+        w->tile_base_host[ls0 + l] = n_tiles;
+        for (uint32_t i = start[l]; i < start[l + 1]; i += 64u) {
+            w->tile_first_host.push_back(i | ((std::min(64u, start[l + 1] - i) - 1u) << 26));
+            n_tiles += 1;
+        }
+    }
+    w->tile_base_host[ls0 + max_level] = n_tiles;
+    w->n_tiles[phase] = n_tiles;
 }
 
 }  // namespace
@@ -243,7 +258,7 @@ void ivx_world_destroy(ivx_world* w) {
     if (!w) return;
     (void)hipStreamSynchronize(w->ctx->stream);
     void* ptrs[] = {w->dyn, w->kin, w->cb, w->touched, w->contacts, w->prev_slot, w->pc[0], w->pc[1], w->acc[0], w->acc[1], w->items, w->item_bodies, w->level_start,
-                    w->dynst, w->barrier_words, w->joint_refs};
+                    w->dynst, w->barrier_words, w->joint_refs, w->tile_base, w->tile_first, w->packed[0], w->packed[1]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (w->ev_ready)
@@ -396,12 +411,16 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
     w->n_contacts = nc;
     // 3. dependency schedules: (warm pass + velocity sweeps) and (positional sweeps)
     build_chains(w);
+    IVX_REQUIRE((uint64_t)(w->chain_start.size() - 1u) * (std::max(w->cfg.n_iterations + 1u, w->cfg.n_positional_correction_iterations)) < (1ull << 26), IVX_ERR_CAPACITY,
+                "ivx_world_set_contacts: more than 2^26 schedule items in one phase");
     // the schedule depends on the chains and their body pairs only: an unchanged contact structure keeps last frame's (host and device copies)
     const bool same_schedule = w->schedule_valid && w->chain_start == w->prev_chain_start && w->chain_bodies == w->prev_chain_bodies;
     if (!same_schedule) {
         w->items_host.clear();
         w->item_bodies_host.clear();
         w->level_start_host.clear();
+        w->tile_base_host.clear();
+        w->tile_first_host.clear();
         build_schedule(w, PHYS_ITEM_WARM, 1u, PHYS_ITEM_VELOCITY, w->cfg.n_iterations, 0);
         build_schedule(w, PHYS_ITEM_POSITIONAL, 0u, PHYS_ITEM_POSITIONAL, w->cfg.n_positional_correction_iterations, 1);
         w->prev_chain_start = w->chain_start;
@@ -441,6 +460,8 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
     if ((rc = grow(&w->items, &w->item_cap, w->items_host.size(), s))) return rc;
     if ((rc = grow(&w->item_bodies, &w->item_bodies_cap, w->item_bodies_host.size(), s))) return rc;
     if ((rc = grow(&w->level_start, &w->level_cap, w->level_start_host.size(), s))) return rc;
+    if ((rc = grow(&w->tile_base, &w->tile_base_cap, w->tile_base_host.size(), s))) return rc;
+    if ((rc = grow(&w->tile_first, &w->tile_first_cap, w->tile_first_host.size(), s))) return rc;
     IVX_HIP_CHECK(hipStreamSynchronize(s));
     if (nc) {
         IVX_HIP_CHECK(hipMemcpy(w->contacts, w->ordered.data(), nc * sizeof(ivx_contact), hipMemcpyHostToDevice));
@@ -452,6 +473,9 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
             IVX_HIP_CHECK(hipMemcpy(w->item_bodies, w->item_bodies_host.data(), w->item_bodies_host.size() * 4, hipMemcpyHostToDevice));
         }
         IVX_HIP_CHECK(hipMemcpy(w->level_start, w->level_start_host.data(), w->level_start_host.size() * 4, hipMemcpyHostToDevice));
+        IVX_HIP_CHECK(hipMemcpy(w->tile_base, w->tile_base_host.data(), w->tile_base_host.size() * 4, hipMemcpyHostToDevice));
+        if (!w->tile_first_host.empty())
+            IVX_HIP_CHECK(hipMemcpy(w->tile_first, w->tile_first_host.data(), w->tile_first_host.size() * 4, hipMemcpyHostToDevice));
     }
     w->schedule_valid = 1;
     // 5. device part of prepare_constraints: gather bodies, prepare every contact, warm-start bookkeeping

@@ -56,6 +56,15 @@ struct ivx_world {
     uint32_t* level_start;
     uint32_t n_levels[2], item_offset[2], level_offset[2];
     uint32_t max_level_items[2];  // widest level of each phase's schedule
+    // packed per-item records of the multi-workgroup solve (physics.hip, k_pack_items): tiles of 64 consecutive items of a level.
+    // tile_base: per level (indexed like level_start) the phase-relative index of its first tile; tile_first: per tile the phase-relative
+    // index of its first item | (items in the tile - 1) << 26
+    uint32_t* tile_base;
+    uint32_t* tile_first;
+    size_t tile_base_cap, tile_first_cap;
+    uint32_t n_tiles[2], tile_offset[2];
+    float* packed[2];
+    size_t packed_cap[2];
     // the solve on several workgroups (physics.hip, k_solve_mg): the phase's mutable body state as shared 32-byte records, the
     // monotonic arrival counter of the grid barrier + an error word (a bounded poll gave up), how many arrivals have been used up
     // SphericalJoint constraints (constraint/spherical_joint.rs): the reference's joint computes no impulse and no correction (:62-88);
@@ -81,7 +90,7 @@ struct ivx_world {
     std::vector<ivx_contact> effective;  // contacts of this step after interlock replacement
     std::vector<ivx_contact> ordered;
     std::vector<int32_t> prev_slot_host;
-    std::vector<uint32_t> item_bodies_host, items_host, level_start_host, scratch_level, scratch_last, chain_start;
+    std::vector<uint32_t> item_bodies_host, items_host, level_start_host, tile_base_host, tile_first_host, scratch_level, scratch_last, chain_start;
     std::vector<uint32_t> chain_bodies, prev_chain_start, prev_chain_bodies;  // body pair per chain; last frame's chains (an unchanged contact structure keeps its schedule)
 };
 
