@@ -294,6 +294,42 @@ def config2_benchmark(ctx, args, with_cpu):
     return out
 
 
+def config5_benchmark(ctx, args):
+    """BASELINE config 5 on the ONE GPU there is: the 1024^3 grid (config-2 asteroid x4.2, 64^3 chunks) as one resident grid, and
+    domain-decomposed in 8 x-slabs of 8 chunk planes with all eight slabs on this GPU (the in-process communicator: neighbour exchange
+    and all-gather are device copies; the driver code is what 8 RCCL ranks run). tests/test_gpu_slabs.py::test_config5_1024_in_8_slabs
+    holds the two equal, voxel byte for voxel byte."""
+    from impact_amd import capi, scenes
+    from impact_amd.distributed import NativeComm, NativeSlabStepper, NativeStepGroup
+
+    graph = scenes.asteroid_scene(4.2)
+    gen, obj = make_object(ctx, graph)
+    steps = max(5, args.steps // 10)
+    res, ms, stage_ms = time_steps(ctx, obj, capi.STAGE_ALL, steps, 2)
+    tris = int(res["mesh"]["n_indices"]) // 3
+    n_vox = obj.n_voxels
+    out = {"workload": f"config-2 asteroid x4.2: {obj.chunk_counts[0] * 16}^3 stored voxels, one GPU", "single_grid_ms": ms,
+           "single_grid_voxels_per_s": n_vox / (ms * 1e-3), "triangles": tris, "stage_ms": {capi.STAGE_NAMES[i]: round(float(stage_ms[i]), 4) for i in range(capi.N_TIMED_STAGES) if stage_ms[i] > 0}}
+    obj.close()
+    comm = NativeComm(ctx, 8, local=True)
+    steppers = [NativeSlabStepper(ctx, comm, graph, np.ones(256, dtype=np.float32), r) for r in range(8)]
+    group = NativeStepGroup(steppers)
+    for _ in range(2):
+        group.step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rec = group.step()
+    slab_ms = 1e3 * (time.perf_counter() - t0) / steps
+    out["eight_slabs_one_gpu_ms"] = slab_ms
+    out["eight_slabs_triangles"] = int(sum(int(r["mesh"]["n_indices"]) for r in rec)) // 3
+    out["eight_slabs_regions"] = int(rec[0]["region_count"])
+    out["same_triangles"] = out["eight_slabs_triangles"] == tris
+    for s_ in steppers:
+        s_.close()
+    comm.close()
+    return out
+
+
 def octant_boxes(centre):
     import itertools
 
@@ -808,6 +844,7 @@ def main():
             out["dense"] = dense_benchmark(ctx, args, with_cpu) if args.workload == "asteroid" else None
             out["config2"] = config2_benchmark(ctx, args, with_cpu)
             out["config3"] = config3_benchmark(ctx, args, with_cpu)
+            out["config5_one_gpu"] = config5_benchmark(ctx, args)
             pile, w = pile_benchmark(ctx, with_cpu)
             out["pile"] = pile
             # the full frame: the voxel step of the headline body + the pile's solve, enqueued back to back, one wait
