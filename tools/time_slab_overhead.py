@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """World-1 overhead of the slab protocol: the 512^3 bench workload stepped as a plain grid and as the single slab of an in-process
-communicator (same kernels + packing-free protocol + record publish), steps timed back to back. usage: time_slab_overhead.py [steps]"""
+communicator (same kernels + packing-free protocol + record publish), steps timed back to back; with a world size > 1 all slabs run in
+this process on this GPU, one after the other on one stream — time / world is the GPU time ONE rank of that decomposition needs per step
+(no link latency in it). usage: time_slab_overhead.py [steps] [world]"""
 import os
 import sys
 import time
@@ -21,10 +23,12 @@ obj = VoxelObject(ctx, gen.chunk_counts(), 1.0)
 obj.set_sdf_program(gen)
 obj.set_densities(dens)
 obj.set_stage_timing(0)
-comm = NativeComm(ctx, 1, local=True)
-st = NativeSlabStepper(ctx, comm, graph, dens, 0)
-st.obj.set_stage_timing(0)
-group = NativeStepGroup([st])
+world = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+comm = NativeComm(ctx, world, local=True)
+sts = [NativeSlabStepper(ctx, comm, graph, dens, r) for r in range(world)]
+for st in sts:
+    st.obj.set_stage_timing(0)
+group = NativeStepGroup(sts)
 
 
 def plain():
@@ -40,4 +44,5 @@ for name, fn in (("plain", plain), ("slab", group.step), ("plain", plain), ("sla
     for _ in range(steps):
         fn()
     ctx.synchronize()
-    print(name, "ms/step", round(1e3 * (time.perf_counter() - t0) / steps, 4))
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    print(name, "ms/step", round(ms, 4), *(("| per rank", round(ms / world, 4)) if name == "slab" and world > 1 else ()))
