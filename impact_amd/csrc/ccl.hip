@@ -148,8 +148,11 @@ __global__ __launch_bounds__(256) void k_face_pairs(GridView g, uint32_t side, c
         // pairs of small ids (the usual case: a handful of components per slab) are listed once, via a 64 x 64 bit table
         bool fresh = true;
         if (seen && a < 64u && b < 64u) {
+            // (a look before the atomic: a face inside one body is thousands of times the same pair, and that many atomics on one
+            // word queue for ~20 us; the look goes past the L1, and a 0 that is no longer true only costs the atomic it would have cost anyway)
             const uint32_t bit = a * 64u + b;
-            fresh = !((atomicOr(&seen[bit >> 5], 1u << (bit & 31u)) >> (bit & 31u)) & 1u);
+            fresh = !((__hip_atomic_load(&seen[bit >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (bit & 31u)) & 1u);
+            if (fresh) fresh = !((atomicOr(&seen[bit >> 5], 1u << (bit & 31u)) >> (bit & 31u)) & 1u);
         }
         if (fresh) {
             const uint32_t slot = atomicAdd(n_pairs, 1u);
