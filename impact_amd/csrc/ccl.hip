@@ -113,8 +113,10 @@ __global__ __launch_bounds__(256) void k_face_ids(GridView g, uint32_t side, con
 // record (compact planes) is expanded here.
 __global__ __launch_bounds__(256) void k_halo_pack_both(GridView g, uint8_t* __restrict__ out_lo, uint8_t* __restrict__ out_hi, uint32_t with_ids,
                                                         const uint8_t* __restrict__ labels, const uint32_t* __restrict__ rcompid,
-                                                        uint32_t* __restrict__ rscalar) {
+                                                        uint32_t* __restrict__ rscalar, uint32_t* __restrict__ pair_words) {
     const uint32_t col = blockIdx.x, side = blockIdx.y, tid = threadIdx.x;
+    // (the face-pair count and seen table of the pass that follows the exchange start at zero: cleared here instead of by a fill of their own)
+    if (pair_words && col == 0 && side == 0 && tid < 4u + 128u) pair_words[tid] = 0u;
     uint8_t* out = side ? out_hi : out_lo;
     if (!out) return;
     const size_t cols = (size_t)g.cy * g.cz;
@@ -390,8 +392,10 @@ int ivx_launch_ccl_dense_labels(ivx_grid* g, uint32_t* d_labels) {
 int ivx_launch_halo_pack_both(ivx_grid* g, void* buf_lo, void* buf_hi, int with_face_labels) {
     GridView v = ivx_view(g);
     hipLaunchKernelGGL(k_halo_pack_both, dim3(g->cc[1] * g->cc[2], 2), dim3(256), 0, g->ctx->stream, v, static_cast<uint8_t*>(buf_lo),
-                       static_cast<uint8_t*>(buf_hi), with_face_labels ? 1u : 0u, g->llabel, g->rcompid, g->rscalar);
+                       static_cast<uint8_t*>(buf_hi), with_face_labels ? 1u : 0u, g->llabel, g->rcompid, g->rscalar,
+                       (with_face_labels && g->pairs_dev) ? g->pairs_dev : nullptr);
     IVX_HIP_CHECK(hipGetLastError());
+    g->pairs_zeroed = (with_face_labels && g->pairs_dev) ? 1 : 0;
     return IVX_OK;
 }
 
@@ -404,8 +408,9 @@ int ivx_launch_face_ids(ivx_grid* g, int side, uint16_t* d_out) {
 
 int ivx_launch_face_pairs(ivx_grid* g, int side, const uint16_t* d_nbr, uint32_t* d_count, void* d_pairs, uint32_t cap, uint32_t* d_seen) {
     GridView v = ivx_view(g);
-    if (d_seen == d_count + 4) {  // count and seen-table are neighbours (the enqueue path): one fill
-        IVX_HIP_CHECK(hipMemsetAsync(d_count, 0, (4 + 128) * sizeof(uint32_t), g->ctx->stream));
+    if (d_seen == d_count + 4) {  // count and seen-table are neighbours (the enqueue path): one fill, unless the pack kernel before cleared them
+        if (!(g->pairs_zeroed && d_count == g->pairs_dev)) IVX_HIP_CHECK(hipMemsetAsync(d_count, 0, (4 + 128) * sizeof(uint32_t), g->ctx->stream));
+        g->pairs_zeroed = 0;
     } else {
         IVX_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t), g->ctx->stream));
         if (d_seen) IVX_HIP_CHECK(hipMemsetAsync(d_seen, 0, 128 * sizeof(uint32_t), g->ctx->stream));

@@ -2187,10 +2187,20 @@ int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
     if (stages & IVX_STAGE_SAMPLE) need |= IVX_SCRATCH_EVAL;
     if (stages & IVX_STAGE_REGIONS) need |= IVX_SCRATCH_REGIONS;
     if (stages & IVX_STAGE_REMESH) need |= IVX_SCRATCH_SN;
+    // (ivx_step_preset_ahead: groups of the NEXT call, preset by this call's first kernel so that a call without one of its own — the
+    // remesh phase of the slab protocol — needs no preset launch)
+    const uint32_t fresh = g->preset_fresh;
+    g->preset_fresh = 0;
+    uint32_t ahead = 0;
+    if (stages & (IVX_STAGE_SAMPLE | IVX_STAGE_DERIVE)) {
+        ahead = g->preset_ahead & ~need;
+        g->preset_ahead = 0;
+    }
     uint32_t preset_in_sample = 0, preset_in_derive = 0;
-    if (stages & IVX_STAGE_SAMPLE) preset_in_sample = need;
-    else if (stages & IVX_STAGE_DERIVE) preset_in_derive = need;
-    else if ((rc = ivx_launch_step_preset(g, need))) return rc;
+    if (stages & IVX_STAGE_SAMPLE) preset_in_sample = need | ahead;
+    else if (stages & IVX_STAGE_DERIVE) preset_in_derive = need | ahead;
+    else if ((rc = ivx_launch_step_preset(g, need & ~fresh))) return rc;
+    g->preset_fresh = ahead;
     // a slot's duration runs from the stop event of the slot enqueued just before it, when there is one
     const uint32_t timing = ~g->stage_timing_off;  // slots with event records
     hipEvent_t* last_stop = nullptr;

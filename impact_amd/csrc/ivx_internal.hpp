@@ -131,6 +131,9 @@ struct ivx_grid {
     uint32_t timed_mask;      // timed stages whose events were recorded since the last collect
     uint32_t* pairs_dev;      // [4 + 128 + 2 * IVX_MAX_FACE_PAIRS]: count, seen table, (own, neighbour) component pairs across the upper x face
     int pairs_enqueued;
+    int pairs_zeroed;         // the label pass of ivx_halo_pack_both_enqueue cleared count + seen table for the face-pair pass that follows
+    // scratch groups a caller that knows its next call (the slab protocol) has preset one call ahead, by a kernel that is launched anyway
+    uint32_t preset_ahead, preset_fresh;
     // host pinned scratch
     void* host_scratch;
     size_t host_scratch_bytes;
@@ -315,6 +318,8 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
 int ivx_launch_derive(ivx_grid* g, uint32_t parts, uint32_t preset_groups = 0);
 int ivx_ensure_dense(ivx_grid* g);
 int ivx_launch_step_preset(ivx_grid* g, uint32_t groups);
+// scratch groups of the caller's NEXT ivx_voxel_step_enqueue, to be preset by the first kernel of the one before it (slab_comm.cpp)
+static inline void ivx_step_preset_ahead(ivx_grid* g, uint32_t groups) { g->preset_ahead |= groups; }
 int ivx_launch_step_post1(ivx_grid* g, uint32_t stages);
 int ivx_launch_step_post2(ivx_grid* g, uint32_t stages);
 int ivx_launch_step_emit(ivx_grid* g, uint32_t stages);

@@ -314,6 +314,7 @@ int ivx_slabs_step_enqueue(ivx_slab** slabs, size_t n) {
     for (size_t i = 0; i < n; ++i) {
         ivx_slab* sl = slabs[i];
         install_ghosts(sl);
+        ivx_step_preset_ahead(sl->grid, IVX_SCRATCH_SN);  // the remesh phase below has no first kernel to host its preset
         if ((rc = ivx_voxel_step_enqueue(sl->grid, IVX_STAGE_DERIVE | IVX_STAGE_OCCUPIED | IVX_STAGE_REGIONS | IVX_STAGE_INERTIA))) return rc;
         if (sl->has_lo || sl->has_hi)
             if ((rc = ivx_halo_pack_both_enqueue(sl->grid, sl->has_lo ? sl->send[0] : nullptr, sl->has_hi ? sl->send[1] : nullptr, 1))) return rc;

@@ -59,6 +59,7 @@ int ivx_launch_sn_count(ivx_grid* g) {
     uint32_t* gs = g->group_sums + groups;  // the first `groups` words belong to the region resolve
     IVX_HIP_CHECK(hipMemsetAsync(gs, 0, sizeof(uint32_t) * (3 * groups + 1), g->ctx->stream));  // (stand-alone path; the fused step path presets in its first kernel)
     g->scratch_dirty |= IVX_SCRATCH_SN;
+    g->preset_fresh &= ~IVX_SCRATCH_SN;
     hipLaunchKernelGGL(k_sn_count, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts, gs, ivx_wc(g), g->active_list);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
