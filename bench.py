@@ -41,7 +41,11 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0    # the guide's measured float4 copy: the practical ceiling
-VALU_PEAK_GWI = 256 * 4 * 2.4 / 2.0  # G wave-instructions/s: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz
+# G wave-instructions/s: 256 CUs x 4 SIMDs, one wave64 VALU instruction per FOUR cycles at 2.4 GHz. The counters say so: on every kernel of the
+# step SQ_ACTIVE_INST_VALU (quad-cycles) / SQ_INSTS_VALU = 1.00-1.06 (profiles/round2/pmc_valu_*.json), i.e. an instruction holds its SIMD for one
+# quad-cycle; the chip's 157 TFLOP/s f32 figure is for packed-f32 instructions (two lanes' worth per instruction), which this accounting counts as one.
+# (Rounds before this correction divided by twice this peak and reported half the fraction.)
+VALU_PEAK_GWI = 256 * 4 * 2.4 / 4.0
 PROFILE_DIR = os.path.join(ROOT, "profiles", "round2")
 
 STAGE_KERNELS = {  # which kernels make up a timed slot (names as rocprofv3 reports them); include/impact_voxel_hip.h, IVX_N_TIMED_STAGES
@@ -138,8 +142,12 @@ def roofline_block(stage_ms, sb_effective, sb_active, workload_key):
         wi = sum(rec["SQ_INSTS_VALU_per_step"] for k, rec in valu.items() if isinstance(rec, dict) and any(
             k == n or k.startswith("void " + n + "<") or k.startswith(n + "<") for n in STAGE_KERNELS["sdf_sample"]))
         ach = wi / (stage_ms[0] * 1e-3) / 1e9
+        act = sum(rec.get("SQ_ACTIVE_INST_VALU_per_step", 0.0) for k, rec in valu.items() if isinstance(rec, dict) and any(
+            k == n or k.startswith("void " + n + "<") or k.startswith(n + "<") for n in STAGE_KERNELS["sdf_sample"]))
         vrl = {"stage": "sdf_sample", "bound": "valu", "achieved": ach, "peak": VALU_PEAK_GWI, "unit": "G wave-instructions/s", "frac": ach / VALU_PEAK_GWI,
-               "wave_instructions_per_step": wi, "source": f"profiles/round2/pmc_valu_{workload_key}.json (SQ_INSTS_VALU, builder's run)"}
+               "wave_instructions_per_step": wi, "active_quad_cycles_per_step": act,
+               "busy_frac_at_2.4GHz": 4.0 * act / (1024.0 * stage_ms[0] * 1e-3 * 2.4e9) if act else None,
+               "source": f"profiles/round2/pmc_valu_{workload_key}.json (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU; builder's run)"}
     return rl, srl, vrl
 
 
