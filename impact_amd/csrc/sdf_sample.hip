@@ -972,11 +972,16 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
     IVX_TE(p, li, 3);
     const bool root_const = cmask & 1u;
     const float root_val = root_const ? cv_get(cv, 0u) : 0.0f;
+    if (oi + 16u <= p.shape[0] && oj + 16u <= p.shape[1] && ok + 16u <= p.shape[2]) {  // (workgroup-uniform) the chunk lies inside the grid
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        float v = root_const ? root_val : stack[k * 256 + tid];
-        bool in_grid = (oi + ti) < p.shape[0] && (oj + tj) < p.shape[1] && (ok + (uint32_t)k) < p.shape[2];
-        sd[k] = in_grid ? sd_from_f32(v) : 127;
+        for (int k = 0; k < 16; ++k) sd[k] = sd_from_f32(root_const ? root_val : stack[k * 256 + tid]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float v = root_const ? root_val : stack[k * 256 + tid];
+            bool in_grid = (oi + ti) < p.shape[0] && (oj + tj) < p.shape[1] && (ok + (uint32_t)k) < p.shape[2];
+            sd[k] = in_grid ? sd_from_f32(v) : 127;
+        }
     }
     IVX_TE(p, li, 4);
     classify_and_store(sd, make_uint4(0, 0, 0, 0), true, 0, sdf_out, type_out, info_out, chunk, tid, true, p.voxel_type, true,
