@@ -473,6 +473,14 @@ __device__ __forceinline__ double ivx_dpp_f64(double v) {
     hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
+// inclusive sums along every DPP row of 16 lanes; lane 15 of a row holds the row's total
+__device__ __forceinline__ double ivx_row16_sum_f64(double v) {
+    v += ivx_dpp_f64<0x111>(v);  // row_shr:1
+    v += ivx_dpp_f64<0x112>(v);  // row_shr:2
+    v += ivx_dpp_f64<0x114>(v);  // row_shr:4
+    v += ivx_dpp_f64<0x118>(v);  // row_shr:8
+    return v;
+}
 __device__ __forceinline__ double ivx_wave_sum_f64(double v) {
     v += ivx_dpp_f64<0x111>(v);  // row_shr:1
     v += ivx_dpp_f64<0x112>(v);  // row_shr:2
@@ -486,7 +494,7 @@ __device__ __forceinline__ double ivx_wave_sum_f64(double v) {
 }
 
 // all 256 threads; `m` non-empty mask of the thread's row, `tw` its 16 type bytes, (gi, gj) the row's global voxel indices,
-// k0 the chunk's first k; s_dens the 256 densities and s_red[4][10] scratch in LDS. Ends with the ten sums in `out10`.
+// k0 the chunk's first k; s_dens the 256 densities and s_red[16][10] scratch in LDS. Ends with the ten sums in `out10`.
 __device__ __forceinline__ void chunk_moments_rows(uint32_t tid, uint32_t m, const uint32_t tw[4], const float* s_dens, double (*s_red)[10], int gi, int gj,
                                                    int k0, double* __restrict__ out10) {
     const double I = (double)gi, J = (double)gj;
@@ -503,13 +511,30 @@ __device__ __forceinline__ void chunk_moments_rows(uint32_t tid, uint32_t m, con
             Dz2 += d * (3.0 * K * K + 3.0 * K + 1.0);
         }
     }
-    const double s[10] = {D, D * qx, D * qy, Dz1, D * cy + Dz2, D * cx + Dz2, D * (cx + cy), D * qx * qy, qy * Dz1, qx * Dz1};
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
-#pragma unroll
-    for (int q = 0; q < 10; ++q) {
-        const double v = ivx_wave_sum_f64(s[q]);
-        if (lane == 0) s_red[wave][q] = v;
+    // The ten sums are linear in (D, Dz1, Dz2) with factors of i and of j. A DPP row of 16 lanes is one i: six row totals carry the
+    // j-dependent parts (lane 15 of the row ends up with them), the i-dependent factors multiply the totals, and the 16 rows of the
+    // workgroup meet in LDS — 72 DPP steps and 10 LDS words per wave where ten whole-wave sums took 120 steps and 80 lane reads
+    // (this pass was half of k_derive's vector instructions, and those are what seven resident workgroups per CU queue for).
+    const double r0 = ivx_row16_sum_f64(D), r1 = ivx_row16_sum_f64(D * qy), r2 = ivx_row16_sum_f64(D * cy);
+    const double r3 = ivx_row16_sum_f64(Dz1), r4 = ivx_row16_sum_f64(qy * Dz1), r5 = ivx_row16_sum_f64(Dz2);
+    if ((tid & 15u) == 15u) {
+        double* o = s_red[tid >> 4];
+        o[0] = r0;
+        o[1] = r0 * qx;
+        o[2] = r1;
+        o[3] = r3;
+        o[4] = r2 + r5;
+        o[5] = r0 * cx + r5;
+        o[6] = r0 * cx + r2;
+        o[7] = r1 * qx;
+        o[8] = r4;
+        o[9] = r3 * qx;
     }
     __syncthreads();
-    if (tid < 10) out10[tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+    if (tid < 10) {
+        double t = s_red[0][tid];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) t += s_red[r][tid];  // fixed order: the same bits every time
+        out10[tid] = t;
+    }
 }

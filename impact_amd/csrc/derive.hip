@@ -143,7 +143,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     __shared__ uint32_t cnt[13];      // own face non-empty counts [0..6), neighbour face non-empty counts [6..12), [12] touch bits
     __shared__ CclShared s_ccl;
     __shared__ float s_dens[256];
-    __shared__ double s_red[4][10];
+    // (the moment pass's 16 x 10 row totals borrow the union-find's node array: the region pass is over when they are written, and the
+    // next chunk's starts behind the loop's barrier — an array of their own would be the kilobyte that takes the seventh workgroup off a CU)
+    double (*s_red)[10] = reinterpret_cast<double (*)[10]>(s_ccl.par);
     const uint32_t tid = threadIdx.x;
     if (fz.parts & IVX_PART_MOMENTS) s_dens[tid] = fz.dens[tid];  // (the first barrier of the loop publishes it)
     const int ti = tid >> 4, tj = tid & 15;

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_absorb(AbsorbParams p, int8_t* __restri
                                                        const float* __restrict__ dens, double* __restrict__ removed10, uint32_t* __restrict__ by_type,
                                                        uint32_t* __restrict__ counters, uint32_t* __restrict__ touched_ranges) {
     __shared__ float s_dens[256];
-    __shared__ double s_red[4][10];
+    __shared__ double s_red[16][10];
     const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.x;
     const uint32_t bk = b % p.cc[2], bj = (b / p.cc[2]) % p.cc[1], bi = b / (p.cc[2] * p.cc[1]);

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void k_inertia_dense(GridView g, uint32_t x_of
                                                        const float* __restrict__ dens, double* __restrict__ chunk_moments,
                                                        const uint32_t* __restrict__ work_counts, const uint32_t* __restrict__ active_list) {
     __shared__ float s_dens[256];
-    __shared__ double s_red[4][10];
+    __shared__ double s_red[16][10];
     const uint32_t tid = threadIdx.x;
     s_dens[tid] = dens[tid];
     const int ti = tid >> 4, tj = tid & 15;
