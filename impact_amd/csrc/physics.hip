@@ -744,8 +744,12 @@ __global__ __launch_bounds__(MG_THREADS) void k_solve_mg(uint32_t n_dyn, float f
                                                          const uint32_t* __restrict__ items, const uint2* __restrict__ item_bodies,
                                                          const uint32_t* __restrict__ level_start, const uint32_t* __restrict__ tile_base,
                                                          const float4* __restrict__ packed, uint32_t n_levels, uint32_t* __restrict__ counter,
-                                                         uint32_t counter_base, uint32_t* __restrict__ error, uint32_t dry) {
-    const uint32_t tid = threadIdx.x, G = gridDim.x, slot = blockIdx.x * MG_THREADS + tid, stride = G * MG_THREADS;
+                                                         uint32_t counter_base, uint32_t* __restrict__ error, uint32_t dry, uint32_t spread) {
+    // `spread` = 8: the launch holds 8 G blocks of which every eighth works — workgroups are handed to the XCDs round robin, so the G that
+    // work share one XCD (its L2, its fabric port); 1: G blocks, all working. Where they land changes times only, never results.
+    if (spread > 1u && (blockIdx.x % spread) != 0u) return;
+    const uint32_t blk = blockIdx.x / spread;
+    const uint32_t tid = threadIdx.x, G = gridDim.x / spread, slot = blk * MG_THREADS + tid, stride = G * MG_THREADS;
     const __amdgpu_buffer_rsrc_t rs_dyn = __builtin_amdgcn_make_buffer_rsrc(dynst, 0, n_dyn * 32u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_acc = __builtin_amdgcn_make_buffer_rsrc(accs, 0, n_contacts * 16u, 0x00020000);
     // the phase's mutable state of the dynamic bodies into the shared records
@@ -900,11 +904,12 @@ static int launch_solve_mg(ivx_world* w, uint32_t groups) {
     hipLaunchKernelGGL((k_pack_items<PHASE>), dim3(w->n_tiles[PHASE]), dim3(64), 0, w->ctx->stream, w->tile_first + w->tile_offset[PHASE],
                        w->items + w->item_offset[PHASE], reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], w->pc[w->cur], w->cb,
                        reinterpret_cast<float4*>(w->packed[PHASE]));
-    hipLaunchKernelGGL((k_solve_mg<PHASE>), dim3(groups), dim3(MG_THREADS), 0, w->ctx->stream, w->n_dyn, w->cfg.positional_correction_factor, w->pc[w->cur],
+    static const uint32_t spread = getenv("IVX_SOLVER_SPREAD") ? (uint32_t)atoi(getenv("IVX_SOLVER_SPREAD")) : 8u;  // (developer switch; 8 = one XCD, see k_solve_mg)
+    hipLaunchKernelGGL((k_solve_mg<PHASE>), dim3(groups * spread), dim3(MG_THREADS), 0, w->ctx->stream, w->n_dyn, w->cfg.positional_correction_factor, w->pc[w->cur],
                        reinterpret_cast<float4*>(w->acc[w->cur]), w->n_contacts, w->cb, reinterpret_cast<float4*>(w->dynst), w->items + w->item_offset[PHASE],
                        reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], w->level_start + w->level_offset[PHASE],
                        w->tile_base + w->level_offset[PHASE], reinterpret_cast<const float4*>(w->packed[PHASE]),
-                       w->n_levels[PHASE], w->barrier_words, base, w->barrier_words + 1, ivx_solver_dry());
+                       w->n_levels[PHASE], w->barrier_words, base, w->barrier_words + 1, ivx_solver_dry(), spread);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
