@@ -230,6 +230,60 @@ int ivx_comm_init_local(ivx_ctx* c, int nranks, ivx_comm** out) {
     return IVX_OK;
 }
 
+int ivx_comm_selftest(ivx_ctx* c) {
+    IVX_REQUIRE(c, IVX_ERR_INVALID, "ivx_comm_selftest: null context");
+    int rc = load_rccl();
+    if (rc) return rc;
+    IVX_HIP_CHECK(hipSetDevice(c->device));
+    ncclUniqueId_ id;
+    IVX_NCCL_CHECK(g_rccl.GetUniqueId(&id));
+    ncclComm_t comm = nullptr;
+    IVX_NCCL_CHECK(g_rccl.CommInitRank(&comm, 1, id, 0));
+    constexpr size_t N = 4096;  // bytes per message
+    uint8_t* dev = nullptr;     // [send | recv | gathered]
+    if (hipMalloc(reinterpret_cast<void**>(&dev), 3 * N) != hipSuccess) {
+        (void)g_rccl.CommDestroy(comm);
+        ivx_set_error("ivx_comm_selftest: device allocation failed");
+        return IVX_ERR_HIP;
+    }
+    std::vector<uint8_t> host(3 * N, 0);
+    for (size_t i = 0; i < N; ++i) host[i] = (uint8_t)(i * 31u + 7u);
+    hipStream_t s = c->stream;
+    int result = IVX_OK;
+    do {
+        if (hipMemcpyAsync(dev, host.data(), 3 * N, hipMemcpyHostToDevice, s) != hipSuccess) {
+            result = IVX_ERR_HIP;
+            break;
+        }
+        // the neighbour exchange's call pattern, with this rank as its own neighbour
+        if (g_rccl.GroupStart() != 0 || g_rccl.Send(dev, N, NCCL_UINT8, 0, comm, s) != 0 || g_rccl.Recv(dev + N, N, NCCL_UINT8, 0, comm, s) != 0 ||
+            g_rccl.GroupEnd() != 0) {
+            ivx_set_error("ivx_comm_selftest: grouped ncclSend / ncclRecv failed");
+            result = IVX_ERR_HIP;
+            break;
+        }
+        // the record all-gather's (64-bit words)
+        if (g_rccl.AllGather(dev + N, dev + 2 * N, N / 8, NCCL_INT64, comm, s) != 0) {
+            ivx_set_error("ivx_comm_selftest: ncclAllGather failed");
+            result = IVX_ERR_HIP;
+            break;
+        }
+        if (hipMemcpyAsync(host.data(), dev, 3 * N, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            result = IVX_ERR_HIP;
+            break;
+        }
+        for (size_t i = 0; i < N && result == IVX_OK; ++i)
+            if (host[N + i] != host[i] || host[2 * N + i] != host[i]) {
+                ivx_set_error("ivx_comm_selftest: byte %zu came back as %u / %u, sent %u", i, (unsigned)host[N + i], (unsigned)host[2 * N + i], (unsigned)host[i]);
+                result = IVX_ERR_STATE;
+            }
+    } while (false);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(dev);
+    (void)g_rccl.CommDestroy(comm);
+    return result;
+}
+
 void ivx_comm_destroy(ivx_comm* m) {
     if (!m) return;
     if (m->nccl) (void)g_rccl.CommDestroy(m->nccl);

@@ -395,6 +395,11 @@ int ivx_comm_unique_id(void* out128);
 int ivx_comm_init(ivx_ctx*, int nranks, int rank, const void* unique_id128, ivx_comm** out);
 int ivx_comm_init_local(ivx_ctx*, int nranks, ivx_comm** out);
 void ivx_comm_destroy(ivx_comm*);
+/* Diagnostic (no reference counterpart): runs every RCCL call the protocol makes — ncclGetUniqueId, ncclCommInitRank, a grouped
+ * ncclSend / ncclRecv pair, ncclAllGather — on a ONE-rank communicator of this context's device and stream (the send goes to the rank
+ * itself) and checks the bytes that come back. A single-GPU box can so prove that the run-time binding to librccl (dlopen, symbols,
+ * argument layouts, the library's stream) works before a multi-rank job depends on it. IVX_OK = all of it worked. */
+int ivx_comm_selftest(ivx_ctx*);
 int ivx_slab_create(ivx_comm*, ivx_grid* slab_grid, int rank, ivx_slab** out);
 void ivx_slab_destroy(ivx_slab*);
 int ivx_slabs_step_enqueue(ivx_slab** slabs, size_t n);

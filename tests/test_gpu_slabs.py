@@ -199,3 +199,11 @@ def test_config5_1024_in_8_slabs(ctx):
             s.close()
         comm.close()
         whole.close()
+
+
+def test_rccl_binding_selftest(ctx):
+    """the run-time binding to librccl on the one GPU there is: unique id, a one-rank communicator on the context's device, the grouped
+    send / receive pair of the neighbour exchange (to the rank itself) and the record all-gather on the library's stream, bytes checked"""
+    from impact_amd.capi import check, lib
+
+    check(lib().ivx_comm_selftest(ctx.h))
