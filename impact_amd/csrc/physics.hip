@@ -904,7 +904,11 @@ static int launch_solve_mg(ivx_world* w, uint32_t groups) {
     hipLaunchKernelGGL((k_pack_items<PHASE>), dim3(w->n_tiles[PHASE]), dim3(64), 0, w->ctx->stream, w->tile_first + w->tile_offset[PHASE],
                        w->items + w->item_offset[PHASE], reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], w->pc[w->cur], w->cb,
                        reinterpret_cast<float4*>(w->packed[PHASE]));
-    static const uint32_t spread = getenv("IVX_SOLVER_SPREAD") ? (uint32_t)atoi(getenv("IVX_SOLVER_SPREAD")) : 8u;  // (developer switch; 8 = one XCD, see k_solve_mg)
+    static const uint32_t spread = [] {  // (developer switch; 8 = the working workgroups share one XCD, 1 = consecutive blocks; see k_solve_mg)
+        const char* e = getenv("IVX_SOLVER_SPREAD");
+        const int v = e ? atoi(e) : 8;
+        return (uint32_t)(v < 1 ? 1 : (v > 8 ? 8 : v));
+    }();
     hipLaunchKernelGGL((k_solve_mg<PHASE>), dim3(groups * spread), dim3(MG_THREADS), 0, w->ctx->stream, w->n_dyn, w->cfg.positional_correction_factor, w->pc[w->cur],
                        reinterpret_cast<float4*>(w->acc[w->cur]), w->n_contacts, w->cb, reinterpret_cast<float4*>(w->dynst), w->items + w->item_offset[PHASE],
                        reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], w->level_start + w->level_offset[PHASE],
