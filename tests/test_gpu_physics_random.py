@@ -61,3 +61,60 @@ def test_random_contact_graphs(ctx, seed):
         flip = rng.random(n_pairs) < 0.25
         alive = np.where(flip, ~alive, alive)
     w.close()
+
+
+@pytest.mark.parametrize("seed", parity_util.fuzz_seeds([31, 32, 33]))
+def test_random_graphs_on_several_workgroups(ctx, seed):
+    """the multi-workgroup solve (packed item records, grid barrier per level) on irregular input — manifolds of 1 to 9 contacts (chains
+    shorter and longer than the four a packed record holds), a kinematic plane, pairs in either order, contact sets that change from
+    frame to frame — against the single-workgroup kernel bit for bit, and that one against the oracle"""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(8, 60))
+    pos = rng.uniform(-3.0, 3.0, (n, 3)).astype(f32)
+    bodies = np.array([uniform_sphere_body(float(rng.uniform(0.3, 0.8)), float(rng.uniform(0.5, 3.0)), pos[i], rng.normal(0, 0.3, 3)) for i in range(n)])
+    bodies["angular_momentum"] = rng.normal(0, 0.02, (n, 3)).astype(f32)
+    w1, o = pu.make_pair(ctx, bodies, pu.static_plane())
+    wg, _ = pu.make_pair(ctx, bodies, pu.static_plane())
+    groups = int(rng.integers(2, 5))
+    w1.set_solver_groups(1)
+    wg.set_solver_groups(groups)
+    n_pairs = int(rng.integers(4, 3 * n))
+    pairs = []
+    for k in range(n_pairs):
+        a = int(rng.integers(0, n))
+        b = (KINEMATIC_BIT | 0) if rng.random() < 0.2 else int(rng.integers(0, n))
+        if b == a:
+            b = KINEMATIC_BIT | 0
+        if rng.random() < 0.3 and not (b & KINEMATIC_BIT):
+            a, b = b, a
+        pairs.append((a, b, int(rng.integers(1, 10)), rng.random() < 0.5))
+    alive = rng.random(n_pairs) < 0.8
+    for frame in range(5):
+        gd = w1.bodies()[0]
+        cs = []
+        for k in rng.permutation(n_pairs):
+            if not alive[k]:
+                continue
+            a, b, m, frictional = pairs[k]
+            pa = gd[a]["position"].astype(np.float64)
+            pb = np.array([pa[0], 0.0, pa[2]]) if (b & KINEMATIC_BIT) else gd[b]["position"].astype(np.float64)
+            nrm = pa - pb
+            nrm = nrm / np.linalg.norm(nrm) if np.linalg.norm(nrm) > 1e-6 else np.array([0.0, 1.0, 0.0])
+            mid = 0.5 * (pa + pb)
+            for j in range(m):
+                geom = ((mid + rng.normal(0, 0.1, 3)).astype(f32), nrm.astype(f32), f32(rng.uniform(-0.01, 0.05)))
+                cs.append(contact(int(k) * 16 + j, a, b, geom, float(rng.uniform(0, 0.8)), 0.6 if frictional else 0.0, 0.4 if frictional else 0.0, first=(j == 0)))
+        arr = np.array(cs) if cs else np.zeros(0, dtype=CONTACT_DTYPE)
+        pu.step_both(w1, o, arr, 0.004)
+        wg.perform_physics_step(arr, 0.004)
+        if len(arr):
+            assert wg.solver_info()["workgroups"] == groups and w1.solver_info()["workgroups"] == 1
+        d1, dg = w1.bodies()[0], wg.bodies()[0]
+        for f in pu.STATE_FIELDS:
+            np.testing.assert_array_equal(dg[f].view(np.uint32), d1[f].view(np.uint32), err_msg=f"seed {seed} frame {frame} {f}")
+        if len(arr):
+            np.testing.assert_array_equal(wg.contact_state()[1].view(np.uint32), w1.contact_state()[1].view(np.uint32))
+        pu.assert_bodies_close(d1, o.bodies()[0], what=f"seed {seed} frame {frame}: ")
+        alive = np.where(rng.random(n_pairs) < 0.25, ~alive, alive)
+    w1.close()
+    wg.close()
