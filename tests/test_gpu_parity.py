@@ -97,10 +97,11 @@ def test_config3_fracture_256(ctx):
     np.testing.assert_array_equal(np.sort(r["voxel_count"]), np.sort(counts))
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2])
-def test_random_dense_upload(ctx, seed):
+@pytest.mark.parametrize("seed,level", [(0, 0.5), (1, 0.5), (2, 0.5), (3, 0.56), (4, 0.6)])
+def test_random_dense_upload(ctx, seed, level):
     """ragged random voxels through the dense upload path: many local regions, mixed faces, the
-    empty-voxel outward-flag case, multiple voxel types."""
+    empty-voxel outward-flag case, multiple voxel types. `level` 0.5: chunks with thousands of mesh vertices of several materials
+    (the mesher's quad phase reads its vertices back from memory); higher: sparse chunks of several materials (it keeps them in LDS)."""
     rng = np.random.default_rng(seed)
     cc = (3, 2, 3)
     n = cc[0] * cc[1] * cc[2] * 4096
@@ -108,7 +109,7 @@ def test_random_dense_upload(ctx, seed):
     # smooth a little so that regions are not single voxels
     for ax in range(3):
         blobs = 0.5 * blobs + 0.25 * (np.roll(blobs, 1, ax) + np.roll(blobs, -1, ax))
-    sd = np.where(blobs > 0.5, -128, np.where(blobs > 0.47, rng.integers(-60, -1, blobs.shape), rng.integers(0, 127, blobs.shape))).astype(np.int8)
+    sd = np.where(blobs > level, -128, np.where(blobs > level - 0.03, rng.integers(-60, -1, blobs.shape), rng.integers(0, 127, blobs.shape))).astype(np.int8)
     sd[16:32, :, 0:16] = -128  # a solid chunk (uniform) next to ragged neighbours
     sd[32:48, 16:32, 32:48] = 127  # a void chunk
     ty = rng.integers(0, 5, blobs.shape).astype(np.uint8)
