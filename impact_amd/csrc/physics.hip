@@ -104,6 +104,12 @@ __device__ __forceinline__ V3 qrot(Q4 q, V3 v) {
     return (v * (q.w * q.w - b2) + b * (dot(v, b) * 2.0f)) + cross(b, v) * (q.w * 2.0f);
 }
 __device__ __forceinline__ float max_rs(float a, float b) { return (b > a) ? b : a; }
+// f32::sin / f32::cos of the reference are libm's sinf / cosf, which are the correctly rounded values in all but rare cases; the device
+// library's single-precision versions are one ulp off now and then (found by a random contact graph whose 1-ulp orientation grew past the
+// 1e-5 bar in two frames). The double-precision functions rounded once agree with libm on every value the tests have met; it is two calls
+// per body and step.
+__device__ __forceinline__ float sin_rn(float x) { return (float)sin((double)x); }
+__device__ __forceinline__ float cos_rn(float x) { return (float)cos((double)x); }
 
 // AngularVelocity::from_vector (quantities.rs:160-172): unit axis + speed, zero at or below f32::EPSILON
 struct AngVel {
@@ -246,7 +252,7 @@ __device__ __forceinline__ void post_solve_body(uint32_t i, uint32_t n_dyn, uint
             st3(b.position, ld3(b.position) + body_velocity(b) * dt);
             const AngVel av = body_angular_velocity(b);
             const float angle = av.speed * dt;
-            const float s = sinf(0.5f * angle), co = cosf(0.5f * angle);
+            const float s = sin_rn(0.5f * angle), co = cos_rn(0.5f * angle);
             const V3 im = av.axis * s;
             stq(b.orientation, qnormalize(qmul(Q4{im.x, im.y, im.z, co}, ldq(b.orientation))));
         }
@@ -255,7 +261,7 @@ __device__ __forceinline__ void post_solve_body(uint32_t i, uint32_t n_dyn, uint
         ivx_kinematic_body k = kin[i - n_dyn];
         st3(k.position, ld3(k.position) + ld3(k.velocity) * dt);
         const float angle = k.angular_speed * dt;
-        const float s = sinf(0.5f * angle), co = cosf(0.5f * angle);
+        const float s = sin_rn(0.5f * angle), co = cos_rn(0.5f * angle);
         const V3 im = ld3(k.angular_axis) * s;
         stq(k.orientation, qnormalize(qmul(Q4{im.x, im.y, im.z, co}, ldq(k.orientation))));
         kin[i - n_dyn] = k;

@@ -12,6 +12,7 @@ from test_gpu_physics import contact
 
 pytestmark = pytest.mark.gpu
 f32 = np.float32
+BIT_REPORT = []  # (seed, words of body state that differed from the oracle) of test_random_graphs_on_several_workgroups
 
 
 @pytest.mark.parametrize("seed", parity_util.fuzz_seeds([21, 22, 23, 24]))
@@ -89,6 +90,7 @@ def test_random_graphs_on_several_workgroups(ctx, seed):
             a, b = b, a
         pairs.append((a, b, int(rng.integers(1, 10)), rng.random() < 0.5))
     alive = rng.random(n_pairs) < 0.8
+    differing = 0
     for frame in range(5):
         gd = w1.bodies()[0]
         cs = []
@@ -114,7 +116,21 @@ def test_random_graphs_on_several_workgroups(ctx, seed):
             np.testing.assert_array_equal(dg[f].view(np.uint32), d1[f].view(np.uint32), err_msg=f"seed {seed} frame {frame} {f}")
         if len(arr):
             np.testing.assert_array_equal(wg.contact_state()[1].view(np.uint32), w1.contact_state()[1].view(np.uint32))
-        pu.assert_bodies_close(d1, o.bodies()[0], what=f"seed {seed} frame {frame}: ")
+        od = o.bodies()[0]
+        pu.assert_bodies_close(d1, od, what=f"seed {seed} frame {frame}: ")
+        # The bar is 1e-5 relative; what is observed is more: every word of the state equal to the oracle's, frame after frame (the
+        # orientation advance takes its sine and cosine from the double-precision functions rounded once, which is what libm's sinf /
+        # cosf return). Counted, not required: a libm that rounds one argument differently must not fail the suite.
+        differing += sum(int((d1[f].view(np.uint32) != od[f].view(np.uint32)).sum()) for f in pu.STATE_FIELDS)
         alive = np.where(rng.random(n_pairs) < 0.25, ~alive, alive)
     w1.close()
     wg.close()
+    BIT_REPORT.append((seed, differing))
+
+
+def test_state_words_differing_from_the_oracle_are_reported():
+    """(runs after the sweep above) how many words of body state differed from the oracle's, over all seeds and frames: 0 on the build
+    and libm this was written on"""
+    total = sum(d for _, d in BIT_REPORT)
+    print(f"random contact graphs: {len(BIT_REPORT)} seeds, {total} state words differing from the oracle")
+    assert len(BIT_REPORT) > 0
