@@ -207,3 +207,23 @@ def test_rccl_binding_selftest(ctx):
     from impact_amd.capi import check, lib
 
     check(lib().ivx_comm_selftest(ctx.h))
+
+
+@pytest.mark.parametrize("seed", __import__("parity_util").fuzz_seeds([41, 42, 43, 44]))
+def test_random_sdf_program_in_slabs(ctx, seed):
+    """random SDF programs (tests/test_gpu_random_sdf.py's trees) cut into 2-4 x-slabs wherever the cuts happen to fall — through bodies,
+    through gaps, through smooth blends — against the oracle's whole grid: voxel bytes, chunk state, the concatenated mesh, moments,
+    occupied ranges and the partition into regions"""
+    from impact_amd.sdf_graph import SDFGraph
+    from impact_amd.voxel import SDFVoxelGenerator
+    from test_gpu_random_sdf import random_tree
+
+    rng = np.random.default_rng(seed)
+    g = SDFGraph()
+    random_tree(g, rng, int(rng.integers(1, 4)))
+    extent = [1.0, 0.5][seed % 2]
+    cx = SDFVoxelGenerator(extent, g, 0).chunk_counts()[0]
+    if cx < 2:  # degenerate or one chunk plane thick: nothing to decompose
+        return
+    world = int(min(cx, rng.integers(2, 5)))
+    run_and_compare(ctx, g, world, extent=extent, driver="native")
