@@ -254,3 +254,64 @@ def test_capsule_through_voxel_centres_takes_the_degenerate_branch(ctx):
     assert len(on_segment) >= 5
     assert_contacts_equal(got, want)
     g.close()
+
+
+@pytest.mark.parametrize("seed", pu.fuzz_seeds([51, 52, 53, 54]))
+def test_random_collidables_against_random_bodies(ctx, seed):
+    """random SDF bodies (tests/test_gpu_random_sdf.py's trees) under a random rigid transform, hit by random spheres, planes and
+    capsules around their surface: the same contacts in the same order with the same ids, geometry bit for bit"""
+    from impact_amd.sdf_graph import SDFGraph
+    from impact_amd.voxel import SDFVoxelGenerator
+    from test_gpu_random_sdf import random_tree
+
+    rng = np.random.default_rng(seed)
+    gr = SDFGraph()
+    random_tree(gr, rng, int(rng.integers(1, 4)))
+    extent = [1.0, 0.5, 0.25][seed % 3]
+    if min(SDFVoxelGenerator(extent, gr, 0).chunk_counts()) == 0:
+        return
+    o, g = both(ctx, gr, extent)
+    info = o.info()
+    lo = np.array([a for a, _ in info["occupied_voxel_ranges"]], dtype=np.float64) * extent
+    hi = np.array([b for _, b in info["occupied_voxel_ranges"]], dtype=np.float64) * extent
+    if np.any(hi <= lo):
+        g.close()
+        return
+    axis = rng.normal(size=3)
+    axis /= np.linalg.norm(axis)
+    ang = float(rng.uniform(0, 3.1))
+    q = np.array([*(axis * np.sin(0.5 * ang)), np.cos(0.5 * ang)], dtype=np.float32)
+    t = rng.uniform(-5.0, 5.0, 3).astype(np.float32)
+    resp = (float(rng.uniform(0, 1)), float(rng.uniform(0, 1)), float(rng.uniform(0, 1)))
+
+    def to_world(p_obj):
+        x, y, z, w = [float(a) for a in q]
+        b = np.array([-x, -y, -z])
+        v = np.asarray(p_obj, dtype=np.float64) - t.astype(np.float64)
+        return v * (w * w - b @ b) + b * (2 * (v @ b)) + np.cross(b, v) * (2 * w)
+
+    n_hits = 0
+    for _ in range(6):
+        p = rng.uniform(lo - 2.0 * extent, hi + 2.0 * extent)
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            r = float(rng.uniform(0.5, 6.0) * extent)
+            c = to_world(p).astype(np.float32)
+            want = oracle_contact_list(o, q, t, c, r, 7, 99, 0, 1, resp)
+            got = g.sphere_contacts(q, t, c, r, 7, 99, 0, 1, resp)
+        elif kind == 1:
+            n = rng.normal(size=3)
+            n = (n / np.linalg.norm(n)).astype(np.float32)
+            disp = float(np.dot(n.astype(np.float64), to_world(p)))
+            want = oracle_plane_contact_list(o, q, t, n, disp, 5, 9, 0, 0x80000000, resp)
+            got = g.plane_contacts(q, t, n, disp, 5, 9, 0, 0x80000000, resp)
+        else:
+            p2 = p + rng.normal(0, 6.0 * extent, 3)
+            a_w = to_world(p).astype(np.float32)
+            v_w = (to_world(p2) - to_world(p)).astype(np.float32)
+            r = float(rng.uniform(0.5, 3.0) * extent)
+            want = oracle_capsule_contact_list(o, q, t, a_w, v_w, r, 31, 4242, 2, 5, resp)
+            got = g.capsule_contacts(q, t, a_w, v_w, r, 31, 4242, 2, 5, resp)
+        assert_contacts_equal(got, want)
+        n_hits += len(want) > 0
+    g.close()
