@@ -149,3 +149,32 @@ def test_batched_copies_equal_the_looped_ones(ctx):
             child_l.close()
             child_b.close()
     assert_objects_equal(o, g, "parent untouched: ")
+
+
+@pytest.mark.parametrize("seed", pu.fuzz_seeds([61, 62, 63, 64]))
+def test_random_oriented_box_through_random_body(ctx, seed):
+    """random SDF bodies (tests/test_gpu_random_sdf.py's trees) cut by a random oriented box somewhere in their grid — missing the body,
+    swallowing it, slicing through blends and thin parts: first the copy, then the extraction, polyhedron object and what is left of the
+    parent against the oracle (voxel bytes, chunk state, derived state, meshes, moments)"""
+    from impact_amd.voxel import SDFVoxelGenerator
+    from test_gpu_random_sdf import random_tree
+
+    rng = np.random.default_rng(seed)
+    gr = SDFGraph()
+    random_tree(gr, rng, int(rng.integers(1, 4)))
+    extent = [1.0, 0.5][seed % 2]
+    cc = SDFVoxelGenerator(extent, gr, 0).chunk_counts()
+    if min(cc) == 0:
+        return
+    o, g = build(ctx, gr, extent=extent)
+    size = np.array(cc, dtype=np.float64) * 16.0 * extent
+    centre = rng.uniform(0.1, 0.9, 3) * size
+    half = rng.uniform(0.08, 0.6, 3) * size.min()
+    planes, aabb = rotated_box(centre, half, rng.normal(size=3), float(rng.uniform(0, 3.1)))
+    rc, co, cg = clip_both(ctx, o, g, planes, aabb, copy=True)
+    if rc == 1:
+        cg.close()
+    rc, co, cg = clip_both(ctx, o, g, planes, aabb, copy=False)
+    if rc == 1:
+        cg.close()
+    g.close()
