@@ -145,7 +145,6 @@ __device__ __forceinline__ void prepare_body(uint32_t i, uint32_t n_dyn, uint32_
         stq(c.q, ldq(b.orientation));
         st3(c.v, body_velocity(b));
         st3(c.w, angvel_vector(body_angular_velocity(b)));
-        touched[i] = 0;
     } else {
         const ivx_kinematic_body k = kin[i - n_dyn];
         c.inv_mass = 0.0f;
@@ -155,7 +154,8 @@ __device__ __forceinline__ void prepare_body(uint32_t i, uint32_t n_dyn, uint32_
         st3(c.v, ld3(k.velocity));
         st3(c.w, ld3(k.angular_axis) * k.angular_speed);
     }
-    c.pad = 0.0f;
+    touched[i] = 0;
+    c.pad = 0.0f;  // (a kinematic body: the count of positional corrections applied to it, see post_solve_body)
     cb[i] = c;
 }
 __global__ __launch_bounds__(256) void k_prepare_bodies(uint32_t n_dyn, uint32_t n_kin, const ivx_rigid_body* __restrict__ dyn,
@@ -217,8 +217,8 @@ __global__ __launch_bounds__(256) void k_prepare_contacts(uint32_t n, uint32_t n
     }
     pc[s] = p;
     acc[s] = a4;
-    if (ia < n_dyn) touched[ia] = 1;
-    if (ib < n_dyn) touched[ib] = 1;
+    touched[ia] = 1;  // (kinematic bodies too: the reference writes every constrained body back after the solve, post_solve_body)
+    touched[ib] = 1;
 }
 
 __device__ __forceinline__ void pre_solve_body(uint32_t i, uint32_t n_dyn, float dt, ivx_rigid_body* dyn, PhysBody* cb) {
@@ -257,8 +257,27 @@ __device__ __forceinline__ void post_solve_body(uint32_t i, uint32_t n_dyn, uint
             stq(b.orientation, qnormalize(qmul(Q4{im.x, im.y, im.z, co}, ldq(b.orientation))));
         }
         dyn[i] = b;
-    } else if (advance) {
+    } else if (advance || (write_back && touched[i])) {
         ivx_kinematic_body k = kin[i - n_dyn];
+        if (write_back && touched[i]) {
+            // apply_constrained_velocities_and_corrected_configurations (solver.rs:571-602) writes kinematic constrained bodies back too.
+            // Impulses and corrections leave them where they were (zero inverse mass and inertia), but two things change in the last
+            // bits: the angular velocity goes through vector form (axis * speed -> AngularVelocity::from_vector), and the orientation
+            // has been re-normalised once per positional correction applied to the body (run_contact counts them; a normalised
+            // quaternion is a fixed point of the re-normalisation only two times in three).
+            const AngVel av = angvel_from_vector(ld3(k.angular_axis) * k.angular_speed);
+            st3(k.angular_axis, av.axis);
+            k.angular_speed = av.speed;
+            uint32_t count = __float_as_uint(cb[i].pad);
+            if (count > 64u) count = 64u + (count & 1u);  // (a fixed point, or a cycle of two, long before)
+            Q4 q = ldq(k.orientation);
+            for (uint32_t n = 0; n < count; ++n) q = qnormalize(q);
+            stq(k.orientation, q);
+        }
+        if (!advance) {
+            kin[i - n_dyn] = k;
+            return;
+        }
         st3(k.position, ld3(k.position) + ld3(k.velocity) * dt);
         const float angle = k.angular_speed * dt;
         const float s = sin_rn(0.5f * angle), co = cos_rn(0.5f * angle);
@@ -305,6 +324,8 @@ struct PairStatic {
     M3 iia, iib;
     V3 pos_a, pos_b;  // velocity phase only (configuration is fixed there)
     bool dyn_a, dyn_b;
+    uint32_t* kcount_a = nullptr;  // positional phase, kinematic body: its count of applied corrections (PhysBody::pad)
+    uint32_t* kcount_b = nullptr;
 };
 
 __device__ __forceinline__ void apply_pair(const PhysContact& p, const PairStatic& st, PairState& x, V3 pb, float in, float it, float ib_) {
@@ -341,6 +362,11 @@ __device__ __forceinline__ void run_contact(uint32_t type, const PhysContact& p,
             x.pb = x.pb + dp * (-st.imb);
             x.qb = pseudo_advanced(x.qb, mul(M3{-st.iib.c0, -st.iib.c1, -st.iib.c2}, cross(db, dp)));
         }
+        // A kinematic body takes no correction (zero inverse mass and inertia), but the reference still runs pseudo_advanced on it:
+        // its orientation is re-normalised once per applied correction and written back after the solve (solver.rs:571-602). The
+        // schedule keeps kinematic bodies read-only; the count is all the write-back needs (post_solve_body).
+        if (!st.dyn_a && st.kcount_a) atomicAdd(st.kcount_a, 1u);
+        if (!st.dyn_b && st.kcount_b) atomicAdd(st.kcount_b, 1u);
         return;
     }
     const V3 pb = ld3(p.world_b);
@@ -391,6 +417,10 @@ __device__ __forceinline__ void run_chain(uint32_t item, uint2 bodies, uint32_t 
     st.iib = ldm(B.inv_inertia);
     st.dyn_a = ia < n_dyn;
     st.dyn_b = ib < n_dyn;
+    if (PHASE == 1) {
+        st.kcount_a = reinterpret_cast<uint32_t*>(&cb[ia].pad);
+        st.kcount_b = reinterpret_cast<uint32_t*>(&cb[ib].pad);
+    }
     PairState x;
     if (PHASE == 0) {
         st.pos_a = ld3(A.pos);
@@ -642,6 +672,10 @@ __device__ __forceinline__ void run_chain_mg(uint32_t item, uint2 bodies, uint32
     PairStatic st;
     st.dyn_a = ia < n_dyn;
     st.dyn_b = ib < n_dyn;
+    if (PHASE == 1) {
+        st.kcount_a = reinterpret_cast<uint32_t*>(const_cast<float*>(&cb[ia].pad));
+        st.kcount_b = reinterpret_cast<uint32_t*>(const_cast<float*>(&cb[ib].pad));
+    }
     // the mutable state first (it is what the level waited for), then everything that never changes during the solve
     float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
     if (st.dyn_a) {
@@ -824,6 +858,7 @@ __global__ __launch_bounds__(256) void k_mark_bodies(uint32_t n, const uint32_t*
     if (i >= n) return;
     const uint32_t r = refs[i];
     if (!(r & IVX_KINEMATIC_BODY) && r < n_dyn) touched[r] = 1;
+    if (r & IVX_KINEMATIC_BODY) touched[n_dyn + (r & 0x7FFFFFFFu)] = 1;  // (kinematic anchors are constrained bodies as well)
 }
 
 }  // namespace

@@ -12,6 +12,7 @@ from test_gpu_physics import contact
 
 pytestmark = pytest.mark.gpu
 f32 = np.float32
+BIT_REPORT_TURNED = []
 BIT_REPORT = []  # (seed, words of body state that differed from the oracle) of test_random_graphs_on_several_workgroups
 
 
@@ -74,8 +75,21 @@ def test_random_graphs_on_several_workgroups(ctx, seed):
     pos = rng.uniform(-3.0, 3.0, (n, 3)).astype(f32)
     bodies = np.array([uniform_sphere_body(float(rng.uniform(0.3, 0.8)), float(rng.uniform(0.5, 3.0)), pos[i], rng.normal(0, 0.3, 3)) for i in range(n)])
     bodies["angular_momentum"] = rng.normal(0, 0.02, (n, 3)).astype(f32)
-    w1, o = pu.make_pair(ctx, bodies, pu.static_plane())
-    wg, _ = pu.make_pair(ctx, bodies, pu.static_plane())
+    plane = pu.static_plane()
+    if seed % 2:  # a kinematic body that is turned, turns and moves (its orientation is not a fixed point of the re-normalisation
+        # the reference applies to it in positional correction, see DESIGN section 4: a last-bit effect the schedule does not reproduce)
+        qk = np.random.default_rng(seed + 1_000_000).normal(size=4)
+        qk = (qk / np.linalg.norm(qk)).astype(f32)
+        if seed % 4 == 1:  # ... unless it IS a fixed point (re-normalised in f32, the solver's operation order, until it stays): exact in the
+            # first frame; the body spins, so later frames start from a new orientation (five times fewer words end up a last bit off)
+            for _ in range(8):
+                ln = np.sqrt(((qk[0] * qk[0] + qk[1] * qk[1]) + qk[2] * qk[2]) + qk[3] * qk[3], dtype=f32)
+                qk = (qk / ln).astype(f32)
+        plane["orientation"] = qk
+        plane["angular_speed"] = 0.3
+        plane["velocity"] = (0.05, 0.0, -0.02)
+    w1, o = pu.make_pair(ctx, bodies, plane)
+    wg, _ = pu.make_pair(ctx, bodies, plane)
     groups = int(rng.integers(2, 5))
     w1.set_solver_groups(1)
     wg.set_solver_groups(groups)
@@ -117,20 +131,34 @@ def test_random_graphs_on_several_workgroups(ctx, seed):
         if len(arr):
             np.testing.assert_array_equal(wg.contact_state()[1].view(np.uint32), w1.contact_state()[1].view(np.uint32))
         od = o.bodies()[0]
-        pu.assert_bodies_close(d1, od, what=f"seed {seed} frame {frame}: ")
+        # (odd seeds: the turned kinematic body. The reference re-normalises a kinematic body's orientation at every positional correction
+        # applied to it and uses the result for the corrections that follow; the schedule keeps kinematic bodies read-only during the solve
+        # and applies the re-normalisations afterwards. When the orientation is not a fixed point of the re-normalisation
+        # — one in three — contact points on that body differ in the last bit for the rest of the phase: ~4 % of the state words of such a
+        # scene end up a last bit off, and in 2 of 150 random scenes a clamp somewhere flips within five frames and the difference grows
+        # to 1e-4. The 1e-5 bar is asserted where the schedule is exact; the turned-kinematic scenes are held to 1e-3 and counted.)
+        pu.assert_bodies_close(d1, od, rtol=pu.RTOL if seed % 2 == 0 else 1e-3, what=f"seed {seed} frame {frame}: ")
         # The bar is 1e-5 relative; what is observed is more: every word of the state equal to the oracle's, frame after frame (the
         # orientation advance takes its sine and cosine from the double-precision functions rounded once, which is what libm's sinf /
         # cosf return). Counted, not required: a libm that rounds one argument differently must not fail the suite.
         differing += sum(int((d1[f].view(np.uint32) != od[f].view(np.uint32)).sum()) for f in pu.STATE_FIELDS)
+        k1, ok = w1.bodies()[1], o.bodies()[1]  # the kinematic body is written back after the solve as well (solver.rs:571-602)
+        for f in ("position", "orientation", "velocity", "angular_axis", "angular_speed"):
+            np.testing.assert_allclose(k1[f], ok[f], rtol=1e-6, atol=1e-7, err_msg=f"seed {seed} frame {frame} kinematic {f}")
+            differing += int((np.atleast_1d(k1[f]).view(np.uint32) != np.atleast_1d(ok[f]).view(np.uint32)).sum())
         alive = np.where(rng.random(n_pairs) < 0.25, ~alive, alive)
     w1.close()
     wg.close()
     BIT_REPORT.append((seed, differing))
+    if seed % 4 == 3:
+        BIT_REPORT_TURNED.append((seed, differing))
 
 
 def test_state_words_differing_from_the_oracle_are_reported():
     """(runs after the sweep above) how many words of body state differed from the oracle's, over all seeds and frames: 0 on the build
     and libm this was written on"""
     total = sum(d for _, d in BIT_REPORT)
-    print(f"random contact graphs: {len(BIT_REPORT)} seeds, {total} state words differing from the oracle")
+    turned = sum(d for _, d in BIT_REPORT_TURNED)
+    print(f"random contact graphs: {len(BIT_REPORT)} seeds, {total} state words differing from the oracle "
+          f"({turned} of them in the {len(BIT_REPORT_TURNED)} scenes whose kinematic orientation is not a fixed point of its re-normalisation)")
     assert len(BIT_REPORT) > 0
