@@ -269,7 +269,7 @@ __device__ __forceinline__ void post_solve_body(uint32_t i, uint32_t n_dyn, uint
             st3(k.angular_axis, av.axis);
             k.angular_speed = av.speed;
             uint32_t count = __float_as_uint(cb[i].pad);
-            if (count > 64u) count = 64u + (count & 1u);  // (a fixed point, or a cycle of two, long before)
+            if (count > 4096u) count = 4096u + (count & 1u);  // (a fixed point long before; cycles met so far have period two)
             Q4 q = ldq(k.orientation);
             for (uint32_t n = 0; n < count; ++n) q = qnormalize(q);
             stq(k.orientation, q);
@@ -311,6 +311,7 @@ struct PairState {  // the part of the two bodies a phase changes
     V3 va, wa, vb, wb;  // velocity phase
     V3 pa, pb;          // positional phase
     Q4 qa, qb;
+    uint32_t applied = 0u;  // positional phase: corrections this chain applied (ReplayView)
 };
 
 __device__ __forceinline__ Q4 pseudo_advanced(Q4 q, V3 w) {  // contact.rs:835-843, quantities.rs:372-378
@@ -324,9 +325,29 @@ struct PairStatic {
     M3 iia, iib;
     V3 pos_a, pos_b;  // velocity phase only (configuration is fixed there)
     bool dyn_a, dyn_b;
-    uint32_t* kcount_a = nullptr;  // positional phase, kinematic body: its count of applied corrections (PhysBody::pad)
-    uint32_t* kcount_b = nullptr;
 };
+
+// The positional phase and kinematic bodies. A kinematic body takes no correction (zero inverse mass and inertia), but the reference runs the
+// same arithmetic on it: every correction applied to a pair re-normalises the kinematic partner's orientation (pseudo_advanced with a zero
+// rotation), the corrections that follow — anywhere in the sweep order — see the result, and the body is written back after the solve
+// (solver.rs:571-602). A normalised f32 quaternion is a fixed point of that only two times in three. The schedule keeps kinematic bodies out
+// of the dependency levels, so their orientation during the phase is REPLAYED: pass 1 runs with the orientation the phase starts from and
+// records how many corrections every chain applied; k_kin_prefix turns that, per kinematic body and in solve order, into the number of
+// re-normalisations each chain starts from, and tabulates the orientation after 0, 1, 2 ... of them; where a body's orientation actually
+// moves, pass 2 runs the phase again from the saved state with every chain starting from its own table entry. (Inside a chain the orientation
+// evolves in the thread, by the reference's own arithmetic on the zeros.)
+struct ReplayView {
+    const uint32_t* c0 = nullptr;   // [2 * item]: re-normalisations of body a / b before the chain (pass 2); null in pass 1
+    const float4* traj = nullptr;   // [kinematic body][KIN_TRAJ]: its orientation after 0, 1, 2 ... re-normalisations
+    uint32_t* applied = nullptr;    // [item]: corrections the chain applied (written in pass 1 for chains with a kinematic body)
+};
+constexpr uint32_t KIN_TRAJ = 64u;  // entries per body: 63 orientations + (first index of the cycle the sequence ends in, its period)
+__device__ __forceinline__ Q4 kin_traj_at(const float4* traj, uint32_t body, uint32_t c) {
+    const float4* t = traj + (size_t)body * KIN_TRAJ;
+    const uint32_t start = __float_as_uint(t[KIN_TRAJ - 1u].x), period = __float_as_uint(t[KIN_TRAJ - 1u].y);
+    const float4 v = t[c < start ? c : start + (c - start) % period];
+    return Q4{v.x, v.y, v.z, v.w};
+}
 
 __device__ __forceinline__ void apply_pair(const PhysContact& p, const PairStatic& st, PairState& x, V3 pb, float in, float it, float ib_) {
     const V3 dp = (ld3(p.normal) * in + ld3(p.tangent) * it) + ld3(p.bitangent) * ib_;
@@ -354,19 +375,13 @@ __device__ __forceinline__ void run_contact(uint32_t type, const PhysContact& p,
         const V3 da = pb - x.pa, db = pb - x.pb;
         const float m = effective_mass(st.ima, st.iia, st.imb, st.iib, da, db, n);
         const V3 dp = n * (m * factor * depth);
-        if (st.dyn_a) {
-            x.pa = x.pa + dp * st.ima;
-            x.qa = pseudo_advanced(x.qa, mul(st.iia, cross(da, dp)));
-        }
-        if (st.dyn_b) {
-            x.pb = x.pb + dp * (-st.imb);
-            x.qb = pseudo_advanced(x.qb, mul(M3{-st.iib.c0, -st.iib.c1, -st.iib.c2}, cross(db, dp)));
-        }
-        // A kinematic body takes no correction (zero inverse mass and inertia), but the reference still runs pseudo_advanced on it:
-        // its orientation is re-normalised once per applied correction and written back after the solve (solver.rs:571-602). The
-        // schedule keeps kinematic bodies read-only; the count is all the write-back needs (post_solve_body).
-        if (!st.dyn_a && st.kcount_a) atomicAdd(st.kcount_a, 1u);
-        if (!st.dyn_b && st.kcount_b) atomicAdd(st.kcount_b, 1u);
+        // (both bodies, dynamic or not: on a kinematic body's zeros this leaves the position and re-normalises the orientation, as in the
+        // reference; only dynamic bodies are ever stored)
+        x.pa = x.pa + dp * st.ima;
+        x.qa = pseudo_advanced(x.qa, mul(st.iia, cross(da, dp)));
+        x.pb = x.pb + dp * (-st.imb);
+        x.qb = pseudo_advanced(x.qb, mul(M3{-st.iib.c0, -st.iib.c1, -st.iib.c2}, cross(db, dp)));
+        x.applied += 1u;
         return;
     }
     const V3 pb = ld3(p.world_b);
@@ -394,7 +409,7 @@ __device__ __forceinline__ void run_contact(uint32_t type, const PhysContact& p,
 // fetched four at a time so that their HBM latencies overlap each other and the loads of the pair's static data.
 template <bool LDS, int PHASE>
 __device__ __forceinline__ void run_chain(uint32_t item, uint2 bodies, uint32_t n_dyn, float factor, const PhysContact* __restrict__ pcs,
-                                          float4* __restrict__ accs, PhysBody* __restrict__ cb, float* s_dyn) {
+                                          float4* __restrict__ accs, PhysBody* __restrict__ cb, float* s_dyn, uint32_t item_index, const ReplayView& rv) {
     const uint32_t s0 = item & 0x00FFFFFFu, len = (item >> 24) & 15u, type = item >> 28;
     const uint32_t ia = bodies.x, ib = bodies.y;
     // the prepared contacts (and accumulated impulses) come two at a time: contact c + 2 is requested as soon as contact c has been consumed, so
@@ -417,10 +432,6 @@ __device__ __forceinline__ void run_chain(uint32_t item, uint2 bodies, uint32_t 
     st.iib = ldm(B.inv_inertia);
     st.dyn_a = ia < n_dyn;
     st.dyn_b = ib < n_dyn;
-    if (PHASE == 1) {
-        st.kcount_a = reinterpret_cast<uint32_t*>(&cb[ia].pad);
-        st.kcount_b = reinterpret_cast<uint32_t*>(&cb[ib].pad);
-    }
     PairState x;
     if (PHASE == 0) {
         st.pos_a = ld3(A.pos);
@@ -454,6 +465,14 @@ __device__ __forceinline__ void run_chain(uint32_t item, uint2 bodies, uint32_t 
             x.pb = ld3(B.pos);
             x.qb = ldq(B.q);
         }
+        if (rv.c0) {  // pass 2: a kinematic body's orientation as the chains before this one left it
+            if (!st.dyn_a) {
+                x.qa = kin_traj_at(rv.traj, ia - n_dyn, rv.c0[2u * item_index]);
+            }
+            if (!st.dyn_b) {
+                x.qb = kin_traj_at(rv.traj, ib - n_dyn, rv.c0[2u * item_index + 1u]);
+            }
+        }
     }
     run_contact(type, pa, st, x, factor, aca);
     if (store_acc) accs[s0] = aca;
@@ -483,6 +502,7 @@ __device__ __forceinline__ void run_chain(uint32_t item, uint2 bodies, uint32_t 
         run_contact(type, q, st, x, factor, a);
         if (store_acc) accs[s0 + c] = a;
     }
+    if (PHASE == 1 && rv.applied && !(st.dyn_a && st.dyn_b)) rv.applied[item_index] = x.applied;
     if (PHASE == 0) {
         if (st.dyn_a) {
             float* d = LDS ? s_dyn + 6 * ia : cb[ia].v;
@@ -512,10 +532,12 @@ constexpr uint32_t SOLVE_THREADS = 768u;
 template <bool LDS, int PHASE>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(uint32_t n_dyn, float factor, const PhysContact* __restrict__ pcs, float4* __restrict__ accs,
                                                 PhysBody* __restrict__ cb, const uint32_t* __restrict__ items, const uint2* __restrict__ item_bodies,
-                                                const uint32_t* __restrict__ level_start, uint32_t n_levels) {
+                                                const uint32_t* __restrict__ level_start, uint32_t n_levels, ReplayView rv,
+                                                const uint32_t* __restrict__ replay_flag) {
     extern __shared__ float s_dyn[];
     __shared__ uint32_t s_start[PHYS_LEVEL_TILE + 1];
     const uint32_t tid = threadIdx.x;
+    if (replay_flag && *replay_flag == 0u) return;  // (pass 2 of the positional phase: no kinematic orientation moved)
     if (LDS)
         for (uint32_t i = tid; i < n_dyn; i += SOLVE_THREADS) {
             const PhysBody& b = cb[i];
@@ -547,9 +569,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(uint32_t n_dyn, float f
                 nxt_item = items[e + tid];
                 nxt_bodies = item_bodies[e + tid];
             }
-            if (b + tid < e) run_chain<LDS, PHASE>(cur_item, cur_bodies, n_dyn, factor, pcs, accs, cb, s_dyn);
+            if (b + tid < e) run_chain<LDS, PHASE>(cur_item, cur_bodies, n_dyn, factor, pcs, accs, cb, s_dyn, b + tid, rv);
             for (uint32_t i = b + tid + SOLVE_THREADS; i < e; i += SOLVE_THREADS)
-                run_chain<LDS, PHASE>(items[i], item_bodies[i], n_dyn, factor, pcs, accs, cb, s_dyn);
+                run_chain<LDS, PHASE>(items[i], item_bodies[i], n_dyn, factor, pcs, accs, cb, s_dyn, i, rv);
             __syncthreads();  // workgroup-scope release/acquire of the body state before the next level
         }
     }
@@ -665,17 +687,13 @@ __global__ __launch_bounds__(64) void k_pack_items(const uint32_t* __restrict__ 
 template <int PHASE>
 __device__ __forceinline__ void run_chain_mg(uint32_t item, uint2 bodies, uint32_t n_dyn, float factor, const PhysContact* __restrict__ pcs,
                                              __amdgpu_buffer_rsrc_t rs_acc, const PhysBody* __restrict__ cb, __amdgpu_buffer_rsrc_t rs_dyn,
-                                             const float4* __restrict__ pk) {
+                                             const float4* __restrict__ pk, uint32_t item_index, const ReplayView& rv) {
     const uint32_t s0 = item & 0x00FFFFFFu, len = (item >> 24) & 15u, type = item >> 28;
     const uint32_t ia = bodies.x, ib = bodies.y;
     const bool with_acc = type != PHYS_ITEM_POSITIONAL, store_acc = type == PHYS_ITEM_VELOCITY;
     PairStatic st;
     st.dyn_a = ia < n_dyn;
     st.dyn_b = ib < n_dyn;
-    if (PHASE == 1) {
-        st.kcount_a = reinterpret_cast<uint32_t*>(const_cast<float*>(&cb[ia].pad));
-        st.kcount_b = reinterpret_cast<uint32_t*>(const_cast<float*>(&cb[ib].pad));
-    }
     // the mutable state first (it is what the level waited for), then everything that never changes during the solve
     float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
     if (st.dyn_a) {
@@ -719,6 +737,14 @@ __device__ __forceinline__ void run_chain_mg(uint32_t item, uint2 bodies, uint32
         x.qa = st.dyn_a ? Q4{a1.x, a1.y, a1.z, a1.w} : ldq(cb[ia].q);
         x.pb = st.dyn_b ? mk(b0.x, b0.y, b0.z) : ld3(cb[ib].pos);
         x.qb = st.dyn_b ? Q4{b1.x, b1.y, b1.z, b1.w} : ldq(cb[ib].q);
+        if (rv.c0) {  // pass 2: a kinematic body's orientation as the chains before this one left it (ReplayView)
+            if (!st.dyn_a) {
+                x.qa = kin_traj_at(rv.traj, ia - n_dyn, rv.c0[2u * item_index]);
+            }
+            if (!st.dyn_b) {
+                x.qb = kin_traj_at(rv.traj, ib - n_dyn, rv.c0[2u * item_index + 1u]);
+            }
+        }
     }
     run_contact(type, p0, st, x, factor, c0);
     if (len > 1u) run_contact(type, p1, st, x, factor, c1);
@@ -736,6 +762,7 @@ __device__ __forceinline__ void run_chain_mg(uint32_t item, uint2 bodies, uint32
         if (len > 2u) st16_sc1(rs_acc, (s0 + 2u) * 16u, c2);
         if (len > 3u) st16_sc1(rs_acc, (s0 + 3u) * 16u, c3);
     }
+    if (PHASE == 1 && rv.applied && !(st.dyn_a && st.dyn_b)) rv.applied[item_index] = x.applied;
     if (PHASE == 0) {
         if (st.dyn_a) {
             st16_sc1(rs_dyn, ia * 32u, make_float4(x.va.x, x.va.y, x.va.z, 0.0f));
@@ -784,10 +811,16 @@ __global__ __launch_bounds__(MG_THREADS) void k_solve_mg(uint32_t n_dyn, float f
                                                          const uint32_t* __restrict__ items, const uint2* __restrict__ item_bodies,
                                                          const uint32_t* __restrict__ level_start, const uint32_t* __restrict__ tile_base,
                                                          const float4* __restrict__ packed, uint32_t n_levels, uint32_t* __restrict__ counter,
-                                                         uint32_t counter_base, uint32_t* __restrict__ error, uint32_t dry, uint32_t spread) {
+                                                         uint32_t counter_base, uint32_t* __restrict__ error, uint32_t dry, uint32_t spread, ReplayView rv,
+                                                         const uint32_t* __restrict__ replay_flag) {
     // `spread` = 8: the launch holds 8 G blocks of which every eighth works — workgroups are handed to the XCDs round robin, so the G that
     // work share one XCD (its L2, its fabric port); 1: G blocks, all working. Where they land changes times only, never results.
     if (spread > 1u && (blockIdx.x % spread) != 0u) return;
+    if (replay_flag && *replay_flag == 0u) {  // pass 2 of the positional phase with no kinematic orientation that moved: nothing to do
+        // (uniform over the launch; the host has already counted this launch's arrivals at the grid barrier: make them)
+        if (threadIdx.x == 0u) __hip_atomic_fetch_add(counter, n_levels + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     const uint32_t blk = blockIdx.x / spread;
     const uint32_t tid = threadIdx.x, G = gridDim.x / spread, slot = blk * MG_THREADS + tid, stride = G * MG_THREADS;
     const __amdgpu_buffer_rsrc_t rs_dyn = __builtin_amdgcn_make_buffer_rsrc(dynst, 0, n_dyn * 32u, 0x00020000);
@@ -833,7 +866,7 @@ __global__ __launch_bounds__(MG_THREADS) void k_solve_mg(uint32_t n_dyn, float f
             const uint32_t it = i == b + slot ? cur_item : items[i];
             const uint2 bo = i == b + slot ? cur_bodies : item_bodies[i];
             const float4* pk = packed + (size_t)(tiles + ((i - b) >> 6)) * (Packed<PHASE>::NJ * 64u) + (tid & 63u);  // ((i - b) & 63 == tid & 63)
-            run_chain_mg<PHASE>(it, bo, n_dyn, factor, pcs, rs_acc, cb, rs_dyn, pk);
+            run_chain_mg<PHASE>(it, bo, n_dyn, factor, pcs, rs_acc, cb, rs_dyn, pk, i, rv);
         }
         tb = tb_next;
         arrivals += G;
@@ -850,6 +883,57 @@ __global__ __launch_bounds__(MG_THREADS) void k_solve_mg(uint32_t n_dyn, float f
             stq(b.q, Q4{r1.x, r1.y, r1.z, r1.w});
         }
     }
+}
+
+// ---- kinematic orientations in the positional phase (ReplayView) --------------------------------------------------------------------
+// the dynamic bodies' configuration as the phase finds it, for pass 2 to start from again
+__global__ __launch_bounds__(256) void k_kin_snapshot(uint32_t n_dyn, const PhysBody* __restrict__ cb, float4* __restrict__ snap) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_dyn) return;
+    snap[2u * i] = make_float4(cb[i].pos[0], cb[i].pos[1], cb[i].pos[2], 0.0f);
+    snap[2u * i + 1u] = make_float4(cb[i].q[0], cb[i].q[1], cb[i].q[2], cb[i].q[3]);
+}
+__global__ __launch_bounds__(256) void k_kin_restore(uint32_t n_dyn, PhysBody* __restrict__ cb, const float4* __restrict__ snap, const uint32_t* __restrict__ replay_flag) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_dyn || *replay_flag == 0u) return;
+    const float4 a = snap[2u * i], b = snap[2u * i + 1u];
+    st3(cb[i].pos, mk(a.x, a.y, a.z));
+    stq(cb[i].q, Q4{b.x, b.y, b.z, b.w});
+}
+// one thread per kinematic body: its positional chains in solve order (kin_list: item | side << 31, CSR by kin_offsets) get the number of
+// re-normalisations they start from; the total goes to the body's record (post_solve_body applies it); the orientation after 0, 1, 2 ...
+// re-normalisations is tabulated; the flag says whether any body's orientation moves at all (else pass 2 has nothing to change)
+__global__ __launch_bounds__(64) void k_kin_prefix(uint32_t n_kin, uint32_t n_dyn, const uint32_t* __restrict__ kin_offsets, const uint32_t* __restrict__ kin_list,
+                                                   const uint32_t* __restrict__ applied, uint32_t* __restrict__ c0, float4* __restrict__ traj,
+                                                   PhysBody* __restrict__ cb, uint32_t* __restrict__ replay_flag) {
+    const uint32_t k = blockIdx.x * 64u + threadIdx.x;
+    if (k >= n_kin) return;
+    uint32_t c = 0;
+    for (uint32_t j = kin_offsets[k]; j < kin_offsets[k + 1u]; ++j) {
+        const uint32_t e = kin_list[j], item = e & 0x7FFFFFFFu, side = e >> 31;
+        c0[2u * item + side] = c;
+        c += applied[item];
+    }
+    cb[n_dyn + k].pad = __uint_as_float(c);
+    // the orientation after 0, 1, 2 ... re-normalisations, until it repeats (a fixed point after one or two steps as a rule; cycles exist)
+    float4* t = traj + (size_t)k * KIN_TRAJ;
+    Q4 q = ldq(cb[n_dyn + k].q);
+    uint32_t start = KIN_TRAJ - 2u, period = 1u;  // (no repeat within the table: hold the last entry)
+    bool found = false;
+    for (uint32_t n = 0; n < KIN_TRAJ - 1u; ++n) {
+        t[n] = make_float4(q.x, q.y, q.z, q.w);
+        for (uint32_t m = 0; m < n && !found; ++m) {
+            const float4 o = t[m];
+            if (__float_as_uint(o.x) == __float_as_uint(q.x) && __float_as_uint(o.y) == __float_as_uint(q.y) && __float_as_uint(o.z) == __float_as_uint(q.z) &&
+                __float_as_uint(o.w) == __float_as_uint(q.w)) {
+                start = m, period = n - m, found = true;
+            }
+        }
+        q = qnormalize(q);
+    }
+    t[KIN_TRAJ - 1u] = make_float4(__uint_as_float(start), __uint_as_float(period), 0.0f, 0.0f);
+    const bool moves = !(start == 0u && period == 1u);
+    if (moves && c > 0u) atomicOr(replay_flag, 1u);
 }
 
 // dynamic bodies a joint is anchored to are constrained bodies of the step (prepare_spherical_joint -> add_body_pair, solver.rs:182-215)
@@ -895,12 +979,12 @@ int ivx_launch_phys_pre_solve(ivx_world* w, float dt) {
 }
 
 template <bool LDS, int PHASE>
-static int launch_solve(ivx_world* w, size_t lds) {
+static int launch_solve(ivx_world* w, size_t lds, ReplayView rv = ReplayView(), const uint32_t* replay_flag = nullptr) {
     if (LDS) IVX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve<LDS, PHASE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_solve<LDS, PHASE>), dim3(1), dim3(SOLVE_THREADS), LDS ? lds : 0, w->ctx->stream, w->n_dyn, w->cfg.positional_correction_factor, w->pc[w->cur],
                        reinterpret_cast<float4*>(w->acc[w->cur]), w->cb, w->items + w->item_offset[PHASE],
                        reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], w->level_start + w->level_offset[PHASE],
-                       w->n_levels[PHASE]);
+                       w->n_levels[PHASE], rv, replay_flag);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -927,7 +1011,7 @@ static uint32_t ivx_solver_dry() {
 }
 
 template <int PHASE>
-static int launch_solve_mg(ivx_world* w, uint32_t groups) {
+static int launch_solve_mg(ivx_world* w, uint32_t groups, ReplayView rv = ReplayView(), const uint32_t* replay_flag = nullptr) {
     {
         const size_t need = (size_t)w->n_tiles[PHASE] * Packed<PHASE>::NJ * 64u * sizeof(float4);
         if (need > w->packed_cap[PHASE]) {
@@ -941,8 +1025,8 @@ static int launch_solve_mg(ivx_world* w, uint32_t groups) {
     }
     const uint32_t base = w->barrier_count;
     w->barrier_count += groups * (w->n_levels[PHASE] + 1u);
-    // this step's prepared contacts and body constants into the schedule's packed records (run_chain_mg)
-    hipLaunchKernelGGL((k_pack_items<PHASE>), dim3(w->n_tiles[PHASE]), dim3(64), 0, w->ctx->stream, w->tile_first + w->tile_offset[PHASE],
+    // this step's prepared contacts and body constants into the schedule's packed records (run_chain_mg; pass 2 reads pass 1's)
+    if (!replay_flag) hipLaunchKernelGGL((k_pack_items<PHASE>), dim3(w->n_tiles[PHASE]), dim3(64), 0, w->ctx->stream, w->tile_first + w->tile_offset[PHASE],
                        w->items + w->item_offset[PHASE], reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], w->pc[w->cur], w->cb,
                        reinterpret_cast<float4*>(w->packed[PHASE]));
     static const uint32_t spread = [] {  // (developer switch; 8 = the working workgroups share one XCD, 1 = consecutive blocks; see k_solve_mg)
@@ -954,7 +1038,7 @@ static int launch_solve_mg(ivx_world* w, uint32_t groups) {
                        reinterpret_cast<float4*>(w->acc[w->cur]), w->n_contacts, w->cb, reinterpret_cast<float4*>(w->dynst), w->items + w->item_offset[PHASE],
                        reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], w->level_start + w->level_offset[PHASE],
                        w->tile_base + w->level_offset[PHASE], reinterpret_cast<const float4*>(w->packed[PHASE]),
-                       w->n_levels[PHASE], w->barrier_words, base, w->barrier_words + 1, ivx_solver_dry(), spread);
+                       w->n_levels[PHASE], w->barrier_words, base, w->barrier_words + 1, ivx_solver_dry(), spread, rv, replay_flag);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -964,9 +1048,39 @@ int ivx_launch_phys_solve(ivx_world* w) {
     int rc;
     const uint32_t groups = solver_groups(w);
     w->solver_groups_used = groups;
+    // the positional phase runs twice when kinematic bodies take part in it (ReplayView): counts, then — where an orientation moves — again
+    const bool replay = w->n_levels[1] && w->n_kin_items > 0;
+    uint32_t* flag = w->barrier_words + 2;
+    ReplayView pass1, pass2;
+    if (replay) {
+        pass1.applied = w->kin_applied;
+        pass2.c0 = w->kin_c0;
+        pass2.traj = reinterpret_cast<const float4*>(w->kin_traj);
+    }
+    auto before_positional = [&]() -> int {
+        if (!replay) return IVX_OK;
+        IVX_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(uint32_t), w->ctx->stream));
+        hipLaunchKernelGGL(k_kin_snapshot, dim3((w->n_dyn + 255u) / 256u + 1u), dim3(256), 0, w->ctx->stream, w->n_dyn, w->cb, reinterpret_cast<float4*>(w->kin_snap));
+        IVX_HIP_CHECK(hipGetLastError());
+        return IVX_OK;
+    };
+    auto between_passes = [&]() -> int {
+        hipLaunchKernelGGL(k_kin_prefix, dim3((w->n_kin + 63u) / 64u), dim3(64), 0, w->ctx->stream, w->n_kin, w->n_dyn, w->kin_offsets, w->kin_list, w->kin_applied,
+                           w->kin_c0, reinterpret_cast<float4*>(w->kin_traj), w->cb, flag);
+        hipLaunchKernelGGL(k_kin_restore, dim3((w->n_dyn + 255u) / 256u + 1u), dim3(256), 0, w->ctx->stream, w->n_dyn, w->cb, reinterpret_cast<const float4*>(w->kin_snap), flag);
+        IVX_HIP_CHECK(hipGetLastError());
+        return IVX_OK;
+    };
     if (groups > 1u) {
         if (w->n_levels[0] && (rc = launch_solve_mg<0>(w, groups))) return rc;
-        if (w->n_levels[1] && (rc = launch_solve_mg<1>(w, groups))) return rc;
+        if (w->n_levels[1]) {
+            if ((rc = before_positional())) return rc;
+            if ((rc = launch_solve_mg<1>(w, groups, pass1))) return rc;
+            if (replay) {
+                if ((rc = between_passes())) return rc;
+                if ((rc = launch_solve_mg<1>(w, groups, pass2, flag))) return rc;
+            }
+        }
         return IVX_OK;
     }
     // the phase's mutable body state (24 / 28 bytes per dynamic body) goes to LDS when it fits one CU
@@ -977,9 +1091,16 @@ int ivx_launch_phys_solve(ivx_world* w) {
         if (rc) return rc;
     }
     if (w->n_levels[1]) {
-        if (lds1 <= 140 * 1024) rc = launch_solve<true, 1>(w, lds1);
-        else rc = launch_solve<false, 1>(w, 0);
+        if ((rc = before_positional())) return rc;
+        if (lds1 <= 140 * 1024) rc = launch_solve<true, 1>(w, lds1, pass1);
+        else rc = launch_solve<false, 1>(w, 0, pass1);
         if (rc) return rc;
+        if (replay) {
+            if ((rc = between_passes())) return rc;
+            if (lds1 <= 140 * 1024) rc = launch_solve<true, 1>(w, lds1, pass2, flag);
+            else rc = launch_solve<false, 1>(w, 0, pass2, flag);
+            if (rc) return rc;
+        }
     }
     return IVX_OK;
 }

@@ -164,6 +164,11 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
     if (total == 0) {
         w->level_start_host.push_back(0);
         w->tile_base_host.push_back(0);
+        if (phase == 1) {
+            w->kin_offsets_host.assign((size_t)w->n_kin + 1, 0u);
+            w->kin_list_host.clear();
+            w->n_kin_items = 0;
+        }
         return;
     }
     std::vector<uint32_t>& lvl = w->scratch_level;
@@ -199,6 +204,8 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
     w->items_host.resize(it0 + total);
     w->item_bodies_host.resize(2 * (it0 + total));
     std::vector<uint32_t> cursor(start + 1, start + max_level + 1);
+    std::vector<std::vector<uint32_t>> kin_items;  // positional phase: every kinematic body's chains in solve order (ReplayView)
+    if (phase == 1) kin_items.resize(w->n_kin);
     k = 0;
     for (uint32_t pass = 0; pass < total_passes; ++pass) {
         const uint32_t ty = pass < n_first ? first_type : type;
@@ -209,7 +216,20 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
             const uint32_t ba = w->chain_bodies[2 * (size_t)ch], bb = w->chain_bodies[2 * (size_t)ch + 1];
             w->item_bodies_host[2 * slot] = (ba & IVX_KINEMATIC_BODY) ? w->n_dyn + (ba & 0x7FFFFFFFu) : ba;
             w->item_bodies_host[2 * slot + 1] = (bb & IVX_KINEMATIC_BODY) ? w->n_dyn + (bb & 0x7FFFFFFFu) : bb;
+            if (phase == 1) {
+                if (ba & IVX_KINEMATIC_BODY) kin_items[ba & 0x7FFFFFFFu].push_back((uint32_t)(slot - it0));
+                if (bb & IVX_KINEMATIC_BODY) kin_items[bb & 0x7FFFFFFFu].push_back((uint32_t)(slot - it0) | 0x80000000u);
+            }
         }
+    }
+    if (phase == 1) {
+        w->kin_offsets_host.assign(1, 0u);
+        w->kin_list_host.clear();
+        for (const auto& v : kin_items) {
+            w->kin_list_host.insert(w->kin_list_host.end(), v.begin(), v.end());
+            w->kin_offsets_host.push_back((uint32_t)w->kin_list_host.size());
+        }
+        w->n_kin_items = (uint32_t)w->kin_list_host.size();
     }
     for (uint32_t l = 0; l < max_level; ++l) start[l] = start[l + 1];
     start[max_level] = (uint32_t)total;
@@ -258,7 +278,8 @@ void ivx_world_destroy(ivx_world* w) {
     if (!w) return;
     (void)hipStreamSynchronize(w->ctx->stream);
     void* ptrs[] = {w->dyn, w->kin, w->cb, w->touched, w->contacts, w->prev_slot, w->pc[0], w->pc[1], w->acc[0], w->acc[1], w->items, w->item_bodies, w->level_start,
-                    w->dynst, w->barrier_words, w->joint_refs, w->tile_base, w->tile_first, w->packed[0], w->packed[1]};
+                    w->dynst, w->barrier_words, w->joint_refs, w->tile_base, w->tile_first, w->packed[0], w->packed[1], w->kin_offsets, w->kin_list,
+                    w->kin_applied, w->kin_c0, w->kin_traj, w->kin_snap};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (w->ev_ready)
@@ -462,6 +483,15 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
     if ((rc = grow(&w->level_start, &w->level_cap, w->level_start_host.size(), s))) return rc;
     if ((rc = grow(&w->tile_base, &w->tile_base_cap, w->tile_base_host.size(), s))) return rc;
     if ((rc = grow(&w->tile_first, &w->tile_first_cap, w->tile_first_host.size(), s))) return rc;
+    if (w->n_kin_items) {
+        const size_t n_pos_items = w->items_host.size() - w->item_offset[1];
+        if ((rc = grow(&w->kin_offsets, &w->kin_offsets_cap, w->kin_offsets_host.size(), s))) return rc;
+        if ((rc = grow(&w->kin_list, &w->kin_list_cap, w->kin_list_host.size(), s))) return rc;
+        if ((rc = grow(&w->kin_applied, &w->kin_applied_cap, n_pos_items, s))) return rc;
+        if ((rc = grow(&w->kin_c0, &w->kin_c0_cap, 2 * n_pos_items, s))) return rc;
+        if ((rc = grow(&w->kin_traj, &w->kin_traj_cap, (size_t)w->n_kin * 64 * 4, s))) return rc;
+        if ((rc = grow(&w->kin_snap, &w->kin_snap_cap, (size_t)std::max<uint32_t>(w->n_dyn, 1u) * 8, s))) return rc;
+    }
     IVX_HIP_CHECK(hipStreamSynchronize(s));
     if (nc) {
         IVX_HIP_CHECK(hipMemcpy(w->contacts, w->ordered.data(), nc * sizeof(ivx_contact), hipMemcpyHostToDevice));
@@ -476,6 +506,10 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
         IVX_HIP_CHECK(hipMemcpy(w->tile_base, w->tile_base_host.data(), w->tile_base_host.size() * 4, hipMemcpyHostToDevice));
         if (!w->tile_first_host.empty())
             IVX_HIP_CHECK(hipMemcpy(w->tile_first, w->tile_first_host.data(), w->tile_first_host.size() * 4, hipMemcpyHostToDevice));
+        if (w->n_kin_items) {
+            IVX_HIP_CHECK(hipMemcpy(w->kin_offsets, w->kin_offsets_host.data(), w->kin_offsets_host.size() * 4, hipMemcpyHostToDevice));
+            IVX_HIP_CHECK(hipMemcpy(w->kin_list, w->kin_list_host.data(), w->kin_list_host.size() * 4, hipMemcpyHostToDevice));
+        }
     }
     w->schedule_valid = 1;
     // 5. device part of prepare_constraints: gather bodies, prepare every contact, warm-start bookkeeping

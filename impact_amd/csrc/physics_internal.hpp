@@ -65,6 +65,16 @@ struct ivx_world {
     uint32_t n_tiles[2], tile_offset[2];
     float* packed[2];
     size_t packed_cap[2];
+    // kinematic orientations in the positional phase (physics.hip, ReplayView): the positional chains of every kinematic body in solve order
+    // (CSR: kin_offsets[n_kin + 1], kin_list: phase-relative item | side << 31), per-item counts and tables of the two passes
+    uint32_t* kin_offsets;
+    uint32_t* kin_list;
+    uint32_t* kin_applied;
+    uint32_t* kin_c0;
+    float* kin_traj;
+    float* kin_snap;
+    size_t kin_offsets_cap, kin_list_cap, kin_applied_cap, kin_c0_cap, kin_traj_cap, kin_snap_cap;
+    uint32_t n_kin_items;  // positional items that involve a kinematic body (0: the phase runs once, as without kinematic bodies)
     // the solve on several workgroups (physics.hip, k_solve_mg): the phase's mutable body state as shared 32-byte records, the
     // monotonic arrival counter of the grid barrier + an error word (a bounded poll gave up), how many arrivals have been used up
     // SphericalJoint constraints (constraint/spherical_joint.rs): the reference's joint computes no impulse and no correction (:62-88);
@@ -91,6 +101,7 @@ struct ivx_world {
     std::vector<ivx_contact> ordered;
     std::vector<int32_t> prev_slot_host;
     std::vector<uint32_t> item_bodies_host, items_host, level_start_host, tile_base_host, tile_first_host, scratch_level, scratch_last, chain_start;
+    std::vector<uint32_t> kin_offsets_host, kin_list_host;
     std::vector<uint32_t> chain_bodies, prev_chain_start, prev_chain_bodies;  // body pair per chain; last frame's chains (an unchanged contact structure keeps its schedule)
 };
 
