@@ -263,16 +263,12 @@ __device__ __forceinline__ void post_solve_body(uint32_t i, uint32_t n_dyn, uint
             // apply_constrained_velocities_and_corrected_configurations (solver.rs:571-602) writes kinematic constrained bodies back too.
             // Impulses and corrections leave them where they were (zero inverse mass and inertia), but two things change in the last
             // bits: the angular velocity goes through vector form (axis * speed -> AngularVelocity::from_vector), and the orientation
-            // has been re-normalised once per positional correction applied to the body (run_contact counts them; a normalised
-            // quaternion is a fixed point of the re-normalisation only two times in three).
+            // has been re-normalised once per positional correction applied to the body (ReplayView; a normalised quaternion is a
+            // fixed point of the re-normalisation only two times in three).
             const AngVel av = angvel_from_vector(ld3(k.angular_axis) * k.angular_speed);
             st3(k.angular_axis, av.axis);
             k.angular_speed = av.speed;
-            uint32_t count = __float_as_uint(cb[i].pad);
-            if (count > 4096u) count = 4096u + (count & 1u);  // (a fixed point long before; cycles met so far have period two)
-            Q4 q = ldq(k.orientation);
-            for (uint32_t n = 0; n < count; ++n) q = qnormalize(q);
-            stq(k.orientation, q);
+            stq(k.orientation, ldq(cb[i].q));  // (k_kin_prefix left the re-normalised orientation there; untouched otherwise)
         }
         if (!advance) {
             kin[i - n_dyn] = k;
@@ -337,17 +333,9 @@ struct PairStatic {
 // moves, pass 2 runs the phase again from the saved state with every chain starting from its own table entry. (Inside a chain the orientation
 // evolves in the thread, by the reference's own arithmetic on the zeros.)
 struct ReplayView {
-    const uint32_t* c0 = nullptr;   // [2 * item]: re-normalisations of body a / b before the chain (pass 2); null in pass 1
-    const float4* traj = nullptr;   // [kinematic body][KIN_TRAJ]: its orientation after 0, 1, 2 ... re-normalisations
-    uint32_t* applied = nullptr;    // [item]: corrections the chain applied (written in pass 1 for chains with a kinematic body)
+    const float4* qstart = nullptr;  // [2 * item + side]: the orientation a kinematic body a / b has when the chain starts (pass 2); null in pass 1
+    uint32_t* applied = nullptr;     // [item]: corrections the chain applied (written in pass 1 for chains with a kinematic body)
 };
-constexpr uint32_t KIN_TRAJ = 64u;  // entries per body: 63 orientations + (first index of the cycle the sequence ends in, its period)
-__device__ __forceinline__ Q4 kin_traj_at(const float4* traj, uint32_t body, uint32_t c) {
-    const float4* t = traj + (size_t)body * KIN_TRAJ;
-    const uint32_t start = __float_as_uint(t[KIN_TRAJ - 1u].x), period = __float_as_uint(t[KIN_TRAJ - 1u].y);
-    const float4 v = t[c < start ? c : start + (c - start) % period];
-    return Q4{v.x, v.y, v.z, v.w};
-}
 
 __device__ __forceinline__ void apply_pair(const PhysContact& p, const PairStatic& st, PairState& x, V3 pb, float in, float it, float ib_) {
     const V3 dp = (ld3(p.normal) * in + ld3(p.tangent) * it) + ld3(p.bitangent) * ib_;
@@ -465,12 +453,14 @@ __device__ __forceinline__ void run_chain(uint32_t item, uint2 bodies, uint32_t 
             x.pb = ld3(B.pos);
             x.qb = ldq(B.q);
         }
-        if (rv.c0) {  // pass 2: a kinematic body's orientation as the chains before this one left it
+        if (rv.qstart) {  // pass 2: a kinematic body's orientation as the chains before this one left it
             if (!st.dyn_a) {
-                x.qa = kin_traj_at(rv.traj, ia - n_dyn, rv.c0[2u * item_index]);
+                const float4 t = rv.qstart[2u * item_index];
+                x.qa = Q4{t.x, t.y, t.z, t.w};
             }
             if (!st.dyn_b) {
-                x.qb = kin_traj_at(rv.traj, ib - n_dyn, rv.c0[2u * item_index + 1u]);
+                const float4 t = rv.qstart[2u * item_index + 1u];
+                x.qb = Q4{t.x, t.y, t.z, t.w};
             }
         }
     }
@@ -737,12 +727,14 @@ __device__ __forceinline__ void run_chain_mg(uint32_t item, uint2 bodies, uint32
         x.qa = st.dyn_a ? Q4{a1.x, a1.y, a1.z, a1.w} : ldq(cb[ia].q);
         x.pb = st.dyn_b ? mk(b0.x, b0.y, b0.z) : ld3(cb[ib].pos);
         x.qb = st.dyn_b ? Q4{b1.x, b1.y, b1.z, b1.w} : ldq(cb[ib].q);
-        if (rv.c0) {  // pass 2: a kinematic body's orientation as the chains before this one left it (ReplayView)
+        if (rv.qstart) {  // pass 2: a kinematic body's orientation as the chains before this one left it (ReplayView)
             if (!st.dyn_a) {
-                x.qa = kin_traj_at(rv.traj, ia - n_dyn, rv.c0[2u * item_index]);
+                const float4 t = rv.qstart[2u * item_index];
+                x.qa = Q4{t.x, t.y, t.z, t.w};
             }
             if (!st.dyn_b) {
-                x.qb = kin_traj_at(rv.traj, ib - n_dyn, rv.c0[2u * item_index + 1u]);
+                const float4 t = rv.qstart[2u * item_index + 1u];
+                x.qb = Q4{t.x, t.y, t.z, t.w};
             }
         }
     }
@@ -900,40 +892,31 @@ __global__ __launch_bounds__(256) void k_kin_restore(uint32_t n_dyn, PhysBody* _
     st3(cb[i].pos, mk(a.x, a.y, a.z));
     stq(cb[i].q, Q4{b.x, b.y, b.z, b.w});
 }
-// one thread per kinematic body: its positional chains in solve order (kin_list: item | side << 31, CSR by kin_offsets) get the number of
-// re-normalisations they start from; the total goes to the body's record (post_solve_body applies it); the orientation after 0, 1, 2 ...
-// re-normalisations is tabulated; the flag says whether any body's orientation moves at all (else pass 2 has nothing to change)
+// one thread per kinematic body: walks its positional chains in solve order (kin_list: item | side << 31, CSR by kin_offsets) with the
+// body's orientation in hand — every chain gets the orientation it starts from, then the orientation takes the re-normalisations the chain
+// applied in pass 1 (a fixed point ends the work: two times in three it is one from the start, else after a step or two as a rule; sequences
+// that keep moving for hundreds of steps exist and are followed to the end). What is left is the orientation the reference writes back
+// (post_solve_body reads it from the body's record); the flag says whether any orientation moved at all (else pass 2 has nothing to change).
 __global__ __launch_bounds__(64) void k_kin_prefix(uint32_t n_kin, uint32_t n_dyn, const uint32_t* __restrict__ kin_offsets, const uint32_t* __restrict__ kin_list,
-                                                   const uint32_t* __restrict__ applied, uint32_t* __restrict__ c0, float4* __restrict__ traj,
-                                                   PhysBody* __restrict__ cb, uint32_t* __restrict__ replay_flag) {
+                                                   const uint32_t* __restrict__ applied, float4* __restrict__ qstart, PhysBody* __restrict__ cb,
+                                                   uint32_t* __restrict__ replay_flag) {
     const uint32_t k = blockIdx.x * 64u + threadIdx.x;
     if (k >= n_kin) return;
-    uint32_t c = 0;
+    Q4 q = ldq(cb[n_dyn + k].q);
+    bool fixed = false, moved = false;
     for (uint32_t j = kin_offsets[k]; j < kin_offsets[k + 1u]; ++j) {
         const uint32_t e = kin_list[j], item = e & 0x7FFFFFFFu, side = e >> 31;
-        c0[2u * item + side] = c;
-        c += applied[item];
-    }
-    cb[n_dyn + k].pad = __uint_as_float(c);
-    // the orientation after 0, 1, 2 ... re-normalisations, until it repeats (a fixed point after one or two steps as a rule; cycles exist)
-    float4* t = traj + (size_t)k * KIN_TRAJ;
-    Q4 q = ldq(cb[n_dyn + k].q);
-    uint32_t start = KIN_TRAJ - 2u, period = 1u;  // (no repeat within the table: hold the last entry)
-    bool found = false;
-    for (uint32_t n = 0; n < KIN_TRAJ - 1u; ++n) {
-        t[n] = make_float4(q.x, q.y, q.z, q.w);
-        for (uint32_t m = 0; m < n && !found; ++m) {
-            const float4 o = t[m];
-            if (__float_as_uint(o.x) == __float_as_uint(q.x) && __float_as_uint(o.y) == __float_as_uint(q.y) && __float_as_uint(o.z) == __float_as_uint(q.z) &&
-                __float_as_uint(o.w) == __float_as_uint(q.w)) {
-                start = m, period = n - m, found = true;
-            }
+        qstart[2u * item + side] = make_float4(q.x, q.y, q.z, q.w);
+        for (uint32_t n = applied[item]; n > 0u && !fixed; --n) {
+            const Q4 r = qnormalize(q);
+            fixed = __float_as_uint(r.x) == __float_as_uint(q.x) && __float_as_uint(r.y) == __float_as_uint(q.y) && __float_as_uint(r.z) == __float_as_uint(q.z) &&
+                    __float_as_uint(r.w) == __float_as_uint(q.w);
+            moved = moved || !fixed;
+            q = r;
         }
-        q = qnormalize(q);
     }
-    t[KIN_TRAJ - 1u] = make_float4(__uint_as_float(start), __uint_as_float(period), 0.0f, 0.0f);
-    const bool moves = !(start == 0u && period == 1u);
-    if (moves && c > 0u) atomicOr(replay_flag, 1u);
+    stq(cb[n_dyn + k].q, q);
+    if (moved) atomicOr(replay_flag, 1u);
 }
 
 // dynamic bodies a joint is anchored to are constrained bodies of the step (prepare_spherical_joint -> add_body_pair, solver.rs:182-215)
@@ -1054,8 +1037,7 @@ int ivx_launch_phys_solve(ivx_world* w) {
     ReplayView pass1, pass2;
     if (replay) {
         pass1.applied = w->kin_applied;
-        pass2.c0 = w->kin_c0;
-        pass2.traj = reinterpret_cast<const float4*>(w->kin_traj);
+        pass2.qstart = reinterpret_cast<const float4*>(w->kin_qstart);
     }
     auto before_positional = [&]() -> int {
         if (!replay) return IVX_OK;
@@ -1066,7 +1048,7 @@ int ivx_launch_phys_solve(ivx_world* w) {
     };
     auto between_passes = [&]() -> int {
         hipLaunchKernelGGL(k_kin_prefix, dim3((w->n_kin + 63u) / 64u), dim3(64), 0, w->ctx->stream, w->n_kin, w->n_dyn, w->kin_offsets, w->kin_list, w->kin_applied,
-                           w->kin_c0, reinterpret_cast<float4*>(w->kin_traj), w->cb, flag);
+                           reinterpret_cast<float4*>(w->kin_qstart), w->cb, flag);
         hipLaunchKernelGGL(k_kin_restore, dim3((w->n_dyn + 255u) / 256u + 1u), dim3(256), 0, w->ctx->stream, w->n_dyn, w->cb, reinterpret_cast<const float4*>(w->kin_snap), flag);
         IVX_HIP_CHECK(hipGetLastError());
         return IVX_OK;

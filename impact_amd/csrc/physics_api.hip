@@ -279,7 +279,7 @@ void ivx_world_destroy(ivx_world* w) {
     (void)hipStreamSynchronize(w->ctx->stream);
     void* ptrs[] = {w->dyn, w->kin, w->cb, w->touched, w->contacts, w->prev_slot, w->pc[0], w->pc[1], w->acc[0], w->acc[1], w->items, w->item_bodies, w->level_start,
                     w->dynst, w->barrier_words, w->joint_refs, w->tile_base, w->tile_first, w->packed[0], w->packed[1], w->kin_offsets, w->kin_list,
-                    w->kin_applied, w->kin_c0, w->kin_traj, w->kin_snap};
+                    w->kin_applied, w->kin_qstart, w->kin_snap};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (w->ev_ready)
@@ -488,8 +488,7 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
         if ((rc = grow(&w->kin_offsets, &w->kin_offsets_cap, w->kin_offsets_host.size(), s))) return rc;
         if ((rc = grow(&w->kin_list, &w->kin_list_cap, w->kin_list_host.size(), s))) return rc;
         if ((rc = grow(&w->kin_applied, &w->kin_applied_cap, n_pos_items, s))) return rc;
-        if ((rc = grow(&w->kin_c0, &w->kin_c0_cap, 2 * n_pos_items, s))) return rc;
-        if ((rc = grow(&w->kin_traj, &w->kin_traj_cap, (size_t)w->n_kin * 64 * 4, s))) return rc;
+        if ((rc = grow(&w->kin_qstart, &w->kin_qstart_cap, 8 * n_pos_items, s))) return rc;  // float4 per (item, side)
         if ((rc = grow(&w->kin_snap, &w->kin_snap_cap, (size_t)std::max<uint32_t>(w->n_dyn, 1u) * 8, s))) return rc;
     }
     IVX_HIP_CHECK(hipStreamSynchronize(s));

@@ -70,10 +70,9 @@ struct ivx_world {
     uint32_t* kin_offsets;
     uint32_t* kin_list;
     uint32_t* kin_applied;
-    uint32_t* kin_c0;
-    float* kin_traj;
+    float* kin_qstart;  // float4 per (item, side): the orientation a kinematic body has when the chain starts (pass 2)
     float* kin_snap;
-    size_t kin_offsets_cap, kin_list_cap, kin_applied_cap, kin_c0_cap, kin_traj_cap, kin_snap_cap;
+    size_t kin_offsets_cap, kin_list_cap, kin_applied_cap, kin_qstart_cap, kin_snap_cap;
     uint32_t n_kin_items;  // positional items that involve a kinematic body (0: the phase runs once, as without kinematic bodies)
     // the solve on several workgroups (physics.hip, k_solve_mg): the phase's mutable body state as shared 32-byte records, the
     // monotonic arrival counter of the grid barrier + an error word (a bounded poll gave up), how many arrivals have been used up
