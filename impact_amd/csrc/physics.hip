@@ -892,31 +892,45 @@ __global__ __launch_bounds__(256) void k_kin_restore(uint32_t n_dyn, PhysBody* _
     st3(cb[i].pos, mk(a.x, a.y, a.z));
     stq(cb[i].q, Q4{b.x, b.y, b.z, b.w});
 }
-// one thread per kinematic body: walks its positional chains in solve order (kin_list: item | side << 31, CSR by kin_offsets) with the
+// one WAVE per kinematic body: walks its positional chains in solve order (kin_list: item | side << 31, CSR by kin_offsets) with the
 // body's orientation in hand — every chain gets the orientation it starts from, then the orientation takes the re-normalisations the chain
-// applied in pass 1 (a fixed point ends the work: two times in three it is one from the start, else after a step or two as a rule; sequences
-// that keep moving for hundreds of steps exist and are followed to the end). What is left is the orientation the reference writes back
-// (post_solve_body reads it from the body's record); the flag says whether any orientation moved at all (else pass 2 has nothing to change).
+// applied in pass 1. 64 chains are fetched at a time; while the orientation still moves they are taken one by one (every lane follows the
+// same orientation), and once it has reached a fixed point — two times in three it is one from the start, else after a step or two as a
+// rule; sequences that keep moving for hundreds of steps exist and are followed to the end — the remaining chains all start from it and
+// are written 64 at a time (a ground plane under a pile has thousands of chains). What is left is the orientation the reference writes
+// back (post_solve_body reads it from the body's record); the flag says whether any orientation moved at all (else pass 2 changes nothing).
 __global__ __launch_bounds__(64) void k_kin_prefix(uint32_t n_kin, uint32_t n_dyn, const uint32_t* __restrict__ kin_offsets, const uint32_t* __restrict__ kin_list,
                                                    const uint32_t* __restrict__ applied, float4* __restrict__ qstart, PhysBody* __restrict__ cb,
                                                    uint32_t* __restrict__ replay_flag) {
-    const uint32_t k = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t k = blockIdx.x, lane = threadIdx.x;
     if (k >= n_kin) return;
     Q4 q = ldq(cb[n_dyn + k].q);
     bool fixed = false, moved = false;
-    for (uint32_t j = kin_offsets[k]; j < kin_offsets[k + 1u]; ++j) {
-        const uint32_t e = kin_list[j], item = e & 0x7FFFFFFFu, side = e >> 31;
-        qstart[2u * item + side] = make_float4(q.x, q.y, q.z, q.w);
-        for (uint32_t n = applied[item]; n > 0u && !fixed; --n) {
-            const Q4 r = qnormalize(q);
-            fixed = __float_as_uint(r.x) == __float_as_uint(q.x) && __float_as_uint(r.y) == __float_as_uint(q.y) && __float_as_uint(r.z) == __float_as_uint(q.z) &&
-                    __float_as_uint(r.w) == __float_as_uint(q.w);
-            moved = moved || !fixed;
-            q = r;
+    const uint32_t j0 = kin_offsets[k], j1 = kin_offsets[k + 1u];
+    for (uint32_t base = j0; base < j1; base += 64u) {
+        const uint32_t j = base + lane;
+        const bool live = j < j1;
+        const uint32_t e = live ? kin_list[j] : 0u;
+        const uint32_t slot = 2u * (e & 0x7FFFFFFFu) + (e >> 31);
+        const uint32_t n_app = live ? applied[e & 0x7FFFFFFFu] : 0u;
+        const uint32_t cnt = min(64u, j1 - base);
+        uint32_t l = 0;
+        for (; l < cnt && !fixed; ++l) {  // (uniform: every lane carries the same q)
+            if (lane == l) qstart[slot] = make_float4(q.x, q.y, q.z, q.w);
+            for (uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)n_app, (int)l); n > 0u && !fixed; --n) {
+                const Q4 r = qnormalize(q);
+                fixed = __float_as_uint(r.x) == __float_as_uint(q.x) && __float_as_uint(r.y) == __float_as_uint(q.y) && __float_as_uint(r.z) == __float_as_uint(q.z) &&
+                        __float_as_uint(r.w) == __float_as_uint(q.w);
+                moved = moved || !fixed;
+                q = r;
+            }
         }
+        if (live && lane >= l) qstart[slot] = make_float4(q.x, q.y, q.z, q.w);  // (the orientation no longer moves)
     }
-    stq(cb[n_dyn + k].q, q);
-    if (moved) atomicOr(replay_flag, 1u);
+    if (lane == 0u) {
+        stq(cb[n_dyn + k].q, q);
+        if (moved) atomicOr(replay_flag, 1u);
+    }
 }
 
 // dynamic bodies a joint is anchored to are constrained bodies of the step (prepare_spherical_joint -> add_body_pair, solver.rs:182-215)
@@ -1047,7 +1061,7 @@ int ivx_launch_phys_solve(ivx_world* w) {
         return IVX_OK;
     };
     auto between_passes = [&]() -> int {
-        hipLaunchKernelGGL(k_kin_prefix, dim3((w->n_kin + 63u) / 64u), dim3(64), 0, w->ctx->stream, w->n_kin, w->n_dyn, w->kin_offsets, w->kin_list, w->kin_applied,
+        hipLaunchKernelGGL(k_kin_prefix, dim3(w->n_kin), dim3(64), 0, w->ctx->stream, w->n_kin, w->n_dyn, w->kin_offsets, w->kin_list, w->kin_applied,
                            reinterpret_cast<float4*>(w->kin_qstart), w->cb, flag);
         hipLaunchKernelGGL(k_kin_restore, dim3((w->n_dyn + 255u) / 256u + 1u), dim3(256), 0, w->ctx->stream, w->n_dyn, w->cb, reinterpret_cast<const float4*>(w->kin_snap), flag);
         IVX_HIP_CHECK(hipGetLastError());
