@@ -402,6 +402,7 @@ int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32
         carve(&g->ccl_scratch, (size_t)g->n_chunks * 2);
         carve(&g->sn_list, (size_t)g->n_chunks * 4);  // one uint4 record per meshed chunk
         carve(&g->group_sums, (size_t)((g->n_chunks + 255u) / 256u) * 4 + 4);
+        carve(&g->sn_hard, (size_t)g->n_chunks);
         carve(&g->dens_dev, (size_t)256);
         carve(&g->work_counts, (size_t)8);
         carve(&g->occ_part, (size_t)((g->n_chunks + 255u) / 256u) * 12 + 12);

@@ -83,7 +83,8 @@ struct ivx_grid {
     uint32_t* rscalar;   // small scalars: [0] region count, [1] error flags
     uint32_t* ccl_scratch;  // [2*n_chunks]: per-chunk root counts and exclusive offsets
     uint32_t* sn_list;      // [n_chunks] uint4 records of the chunks that emit a mesh this remesh, in submesh order (written by k_sn_scan)
-    uint32_t* group_sums;   // [4 * ceil(n_chunks/256)]: first-level totals of the two-level scans
+    uint32_t* group_sums;   // [4 * ceil(n_chunks/256) + 4]: first-level totals of the two-level scans; then the count of sn_hard
+    uint32_t* sn_hard;      // [n_chunks] list entries (submesh order) of the chunks the mesher's main pass hands to its general pass
     uint32_t region_count;
     int regions_valid;
     // list-driven stages: k_chunk_pre settles every chunk whose per-step state follows from the chunk records alone (Void,
@@ -333,6 +334,8 @@ void ivx_occupied_from_raw(const ivx_grid* g, const uint32_t raw[12], uint32_t o
 int ivx_launch_sn_count(ivx_grid* g);
 int ivx_launch_sn_scan(ivx_grid* g);
 int ivx_launch_sn_emit(ivx_grid* g);
+int ivx_launch_sn_emit_general(ivx_grid* g);
+uint32_t* ivx_sn_hard_count(ivx_grid* g);
 int ivx_launch_inertia(ivx_grid* g, const float* d_dens, double* d_out10, int fused);
 int ivx_launch_ccl_local(ivx_grid* g, int fused);
 int ivx_launch_ccl_local_only(ivx_grid* g);  // level 1 over the active list without the exact numbering of multi-region chunks

@@ -12,9 +12,15 @@ constexpr int G = 18, NROWS = 324, NCROWS = 289, NCUBES = 4913;
 // LDS tile: 18 x 18 rows of 18 bytes along k; a row occupies RS = 24 bytes with cell c at byte 3 + c, so the 16
 // interior cells (c = 1..16, the chunk's own k-row) sit 4-byte aligned and are written as four words.
 constexpr int RS = 24, TILE_BYTES = NROWS * RS;
-constexpr uint32_t VPC = 864;  // vertices a mesher workgroup keeps in LDS for its quad phase (role_sn_emit)
+constexpr uint32_t VPC = 800;  // vertices a mesher workgroup keeps in LDS for its quad phase (role_sn_emit)
 __device__ __forceinline__ int tix(int a, int b, int c) { return (a * G + b) * RS + 3 + c; }
 
+// (an empty asm the compiler must assume changes x: what is computed from the result cannot be hoisted out of the surrounding loop and held
+// in registers across all of it — the mesher's per-thread row and cube-row constants were, and pushed the loads in flight out to scratch)
+__device__ __forceinline__ uint32_t opaque(uint32_t x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
 struct V3 {
     float x, y, z;
 };
@@ -40,31 +46,29 @@ struct SnParams {
 // 7 us of a workgroup's 20). Here the addresses are clamped to valid ones, all loads go out back to back, `row_pin` keeps them from
 // being sunk, and the records only select afterwards.
 struct RowLoads {
-    uint2 c0, c1, c2;      // chunk records below / own / above along k (8 bytes each)
+    uint32_t c0, c1, c2;   // first word of the chunk records below / own / above along k (kind, generated kind, flags, uniform type)
     uint4 s4, t4;          // the 16 interior cells
     uint32_t b0s, b0t, b2s, b2t;  // k-halo bytes from the neighbours' face arrays
-    uint32_t mode;         // 0: outside the grid (padding), 1: in the slab (fields above), 2: ghost layer / other (serial path)
-    uint32_t has_lo, has_hi;
 };
+// 0: the row lies outside the grid (padding), 1: in the slab (RowLoads holds it), 2: ghost layer / other (serial path). Recomputed where it is
+// needed instead of being carried beside the loads: a row in flight should hold registers for its data only.
+__device__ __forceinline__ uint32_t row_mode(const GridView& g, int gi, int gj) {
+    if (gj < 0 || gj >= (int)g.cy * 16) return 0u;
+    if (gi < 0 || gi >= (int)g.cx * 16) return 2u;
+    return 1u;
+}
 __device__ __forceinline__ void row_issue(const GridView& g, int gi, int gj, int ck, RowLoads& L) {
-    L.mode = 0u;
-    if (gj < 0 || gj >= (int)g.cy * 16) return;
-    if (gi < 0 || gi >= (int)g.cx * 16) {
-        L.mode = 2u;
-        return;
-    }
-    L.mode = 1u;
+    if (row_mode(g, gi, gj) != 1u) return;
     const size_t cidx = (size_t)(((gi >> 4) * g.cy + (gj >> 4)) * g.cz) + (size_t)ck;
     const uint32_t rix = (uint32_t)(((gi & 15) << 4) | (gj & 15));
     const size_t o = (cidx << 12) + ((size_t)rix << 4);
-    L.has_lo = ck > 0 ? 1u : 0u;
-    L.has_hi = ck + 1 < (int)g.cz ? 1u : 0u;
-    const uint2* ip = reinterpret_cast<const uint2*>(g.info) + cidx;
+    const bool has_lo = ck > 0, has_hi = ck + 1 < (int)g.cz;
+    const uint32_t* ip = reinterpret_cast<const uint32_t*>(g.info + cidx);
     const uint8_t* kf = g.kface + cidx * 1024 + rix;
-    const uint2* ip0 = L.has_lo ? ip - 1 : ip;
-    const uint2* ip2 = L.has_hi ? ip + 1 : ip;
-    const uint8_t* kf0 = L.has_lo ? kf - 1024 : kf;
-    const uint8_t* kf2 = L.has_hi ? kf + 1024 : kf;
+    const uint32_t* ip0 = has_lo ? ip - 2 : ip;
+    const uint32_t* ip2 = has_hi ? ip + 2 : ip;
+    const uint8_t* kf0 = has_lo ? kf - 1024 : kf;
+    const uint8_t* kf2 = has_hi ? kf + 1024 : kf;
     L.c1 = *ip;
     L.s4 = *reinterpret_cast<const uint4*>(g.sdf + o);
     L.t4 = *reinterpret_cast<const uint4*>(g.type + o);
@@ -77,19 +81,19 @@ __device__ __forceinline__ void row_issue(const GridView& g, int gi, int gj, int
 }
 // (an empty asm that "modifies" the loaded registers: the loads cannot move below it)
 __device__ __forceinline__ void row_pin(RowLoads& L) {
-    asm volatile("" : "+v"(L.c0.x), "+v"(L.c1.x), "+v"(L.c2.x), "+v"(L.c0.y), "+v"(L.c1.y), "+v"(L.c2.y));
+    asm volatile("" : "+v"(L.c0), "+v"(L.c1), "+v"(L.c2));
     asm volatile("" : "+v"(L.s4.x), "+v"(L.s4.y), "+v"(L.s4.z), "+v"(L.s4.w), "+v"(L.t4.x), "+v"(L.t4.y), "+v"(L.t4.z), "+v"(L.t4.w));
     asm volatile("" : "+v"(L.b0s), "+v"(L.b0t), "+v"(L.b2s), "+v"(L.b2t));
 }
-__device__ __forceinline__ ivx_chunk_info record_of(uint2 w) {
+__device__ __forceinline__ ivx_chunk_info record_of(uint32_t w) {  // (the fields of the record's first word; the rest zero)
     ivx_chunk_info c;
-    c.kind = (uint8_t)(w.x & 0xFFu);
-    c.gen_kind = (uint8_t)((w.x >> 8) & 0xFFu);
-    c.flags = (uint8_t)((w.x >> 16) & 0xFFu);
-    c.uniform_type = (uint8_t)(w.x >> 24);
-    c.face_dist = (uint16_t)(w.y & 0xFFFFu);
-    c.region_count = (uint8_t)((w.y >> 16) & 0xFFu);
-    c.boundary_region_count = (uint8_t)(w.y >> 24);
+    c.kind = (uint8_t)(w & 0xFFu);
+    c.gen_kind = (uint8_t)((w >> 8) & 0xFFu);
+    c.flags = (uint8_t)((w >> 16) & 0xFFu);
+    c.uniform_type = (uint8_t)(w >> 24);
+    c.face_dist = 0;
+    c.region_count = 0;
+    c.boundary_region_count = 0;
     return c;
 }
 __device__ __forceinline__ void fetch_row_serial(const GridView& g, int gi, int gj, int ck, uint32_t sd[6], uint32_t ty[6]);
@@ -100,8 +104,9 @@ __device__ __forceinline__ void row_finish(const GridView& g, int gi, int gj, in
     ty[0] = ty[5] = 0xFFu;
     sd[1] = sd[2] = sd[3] = sd[4] = 0x7F7F7F7Fu;
     ty[1] = ty[2] = ty[3] = ty[4] = 0xFFFFFFFFu;
-    if (L.mode == 0u) return;
-    if (L.mode == 2u) {
+    const uint32_t mode = row_mode(g, gi, gj);
+    if (mode == 0u) return;
+    if (mode == 2u) {
         fetch_row_serial(g, gi, gj, ck, sd, ty);
         return;
     }
@@ -110,12 +115,12 @@ __device__ __forceinline__ void row_finish(const GridView& g, int gi, int gj, in
     const uint32_t us = ivx_uniform_sdf(c1.kind) * 0x01010101u, ut = ivx_uniform_type(c1) * 0x01010101u;
     sd[1] = d1 ? L.s4.x : us, sd[2] = d1 ? L.s4.y : us, sd[3] = d1 ? L.s4.z : us, sd[4] = d1 ? L.s4.w : us;
     ty[1] = d1 ? L.t4.x : ut, ty[2] = d1 ? L.t4.y : ut, ty[3] = d1 ? L.t4.z : ut, ty[4] = d1 ? L.t4.w : ut;
-    if (L.has_lo) {
+    if (ck > 0) {
         const bool dense = c0.kind == KIND_NONUNIFORM;
         sd[0] = dense ? L.b0s : ivx_uniform_sdf(c0.kind);
         ty[0] = dense ? L.b0t : ivx_uniform_type(c0);
     }
-    if (L.has_hi) {
+    if (ck + 1 < (int)g.cz) {
         const bool dense = c2.kind == KIND_NONUNIFORM;
         sd[5] = dense ? L.b2s : ivx_uniform_sdf(c2.kind);
         ty[5] = dense ? L.b2t : ivx_uniform_type(c2);
@@ -124,7 +129,7 @@ __device__ __forceinline__ void row_finish(const GridView& g, int gi, int gj, in
 __device__ __forceinline__ void fetch_row(const GridView& g, int gi, int gj, int ck, uint32_t sd[6], uint32_t ty[6]) {
     RowLoads L;
     row_issue(g, gi, gj, ck, L);
-    if (L.mode == 1u) row_pin(L);
+    if (row_mode(g, gi, gj) == 1u) row_pin(L);
     row_finish(g, gi, gj, ck, L, sd, ty);
 }
 
@@ -297,15 +302,17 @@ __device__ __forceinline__ void load_tile(const GridView& g, int ci, int cj, int
 #pragma unroll
     for (int it = 0; it < ROUNDS; ++it) {
         const int r = (int)tid + 256 * it;
-        L[it].mode = 0u;
         if (r < NROWS) {
             const int a = r / G, b = r - a * G;
             row_issue(g, ci * 16 + a - 1, cj * 16 + b - 1, ck, L[it]);
         }
     }
 #pragma unroll
-    for (int it = 0; it < ROUNDS; ++it)
-        if (L[it].mode == 1u) row_pin(L[it]);
+    for (int it = 0; it < ROUNDS; ++it) {
+        const int r = (int)tid + 256 * it;
+        const int a = r / G, b = r - a * G;
+        if (r < NROWS && row_mode(g, ci * 16 + a - 1, cj * 16 + b - 1) == 1u) row_pin(L[it]);
+    }
 #pragma unroll
     for (int it = 0; it < ROUNDS; ++it) {
         const int r = (int)tid + 256 * it;
@@ -376,19 +383,23 @@ __device__ __forceinline__ void upper_issue(const GridView& g, int ci, int cj, i
     else if (g.ghost_info[1]) px = g.ghost_info[1] + (cj * (int)g.cz + ck), gx = true;
     const ivx_chunk_info* py = cj + 1 < (int)g.cy ? g.info + own + g.cz : g.info + own;
     const ivx_chunk_info* pz = ck + 1 < (int)g.cz ? g.info + own + 1 : g.info + own;
-    U.k[0] = px->kind;
-    U.k[1] = py->kind;
-    U.k[2] = pz->kind;
+    // the records' first words, untouched (kind = low byte, taken in upper_finish): an operation on a loaded value here would wait for the load
+    // here; and through an index that is zero but not to the compiler, so that they are not moved to scalar registers at once either
+    const uint32_t z = opaque(0u);
+    U.k[0] = reinterpret_cast<const uint32_t*>(px)[z];
+    U.k[1] = reinterpret_cast<const uint32_t*>(py)[z];
+    U.k[2] = reinterpret_cast<const uint32_t*>(pz)[z];
     (void)gx;
 }
+template <bool PIN = true>
 __device__ __forceinline__ void upper_finish(const GridView& g, int ci, int cj, int ck, UpperLoads& U, int* upper) {
     // the upper layer of cubes belongs to the upper neighbour chunk when that chunk is non-uniform (surface_nets.rs:252-261)
-    asm volatile("" : "+v"(U.k[0]), "+v"(U.k[1]), "+v"(U.k[2]));
+    if (PIN) asm volatile("" : "+v"(U.k[0]), "+v"(U.k[1]), "+v"(U.k[2]));
     const bool hx = ci + 1 < (int)g.cx || g.ghost_info[1] != nullptr, hy = cj + 1 < (int)g.cy, hz = ck + 1 < (int)g.cz;
     upper[0] = upper[1] = upper[2] = G - 1;
-    if (hx && U.k[0] == KIND_NONUNIFORM) upper[0] -= 1;
-    if (hy && U.k[1] == KIND_NONUNIFORM) upper[1] -= 1;
-    if (hz && U.k[2] == KIND_NONUNIFORM) upper[2] -= 1;
+    if (hx && (U.k[0] & 0xFFu) == KIND_NONUNIFORM) upper[0] -= 1;
+    if (hy && (U.k[1] & 0xFFu) == KIND_NONUNIFORM) upper[1] -= 1;
+    if (hz && (U.k[2] & 0xFFu) == KIND_NONUNIFORM) upper[2] -= 1;
 }
 
 // Walks the active list (the chunks k_chunk_pre settled have no mesh and got their zero counts there).
@@ -652,14 +663,437 @@ __device__ __forceinline__ void index_materials(const VMat vm[3], unsigned long 
 
 __device__ __forceinline__ uint32_t vertex_of(uint32_t vrow, int k) { return (vrow >> 17) + (uint32_t)__popc(vrow & ((1u << k) - 1u)); }
 
-// (amdgpu_waves_per_eu(4): keeps the kernel at <= 128 VGPRs so that four workgroups fit a CU; the LDS footprint, ~38 KB, allows
-// four as well. The kernel is bound by the latency of a workgroup's serial phases, so residency is what buys throughput.)
+// a / b, correctly rounded, for operands far from the exponent limits and b != 0 (no scaling, no special cases): the hardware
+// reciprocal refined once, the quotient corrected once (Markstein's sequence; the general division costs about twice as many
+// instructions for its scaling and fix-ups). Used on the mesher's decoded distances and edge counts only; `ivx_selftest_mesher_division`
+// compares it with the `/` operator over that whole operand set on the device (tests/test_gpu_parity.py).
+__device__ __forceinline__ float div_ranged(float a, float b) {
+    float y = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, y, 1.0f);
+    y = __builtin_fmaf(e, y, y);
+    const float q = a * y;
+    const float r = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(r, y, q);
+}
+
+// centroid_of_edge_intersections (surface_nets.rs:384-418) over the 12 CUBE_EDGES (661-674) of one cube. The reference adds, per crossed
+// edge (c1, c2) in list order, p1 * (1 - t) + p2 * t with t = d1 / (d1 - d2) and p the corners' 0/1 coordinates. Component by component
+// that term is: t along the edge's own axis (0 * (1 - t) + 1 * t), (1 - t) + t where both corners have the coordinate 1, +0 where both
+// have 0 — and adding +0 leaves a non-negative sum as it is. So an edge costs one division, (1 - t) + t, and the additions of the
+// components that can be non-zero, instead of six multiplications and six additions by constants the compiler may not fold
+// (0 * x is not 0 for every x). Same values, same order of the additions that matter. `neg`: bit c = corner c's distance is negative.
+__device__ __forceinline__ void edge_centroid(const float d[8], uint32_t neg, V3& sum, int& count) {
+    sum = mk(0.0f, 0.0f, 0.0f);
+    count = 0;
+    constexpr int E1[12] = {0, 0, 0, 1, 1, 2, 2, 3, 4, 4, 5, 6};
+    constexpr int E2[12] = {1, 2, 4, 3, 5, 3, 6, 7, 5, 6, 7, 7};
+#pragma unroll
+    for (int e = 0; e < 12; ++e) {
+        const int c1 = E1[e], c2 = E2[e];
+        const bool crossed = (((neg >> c1) ^ (neg >> c2)) & 1u) != 0u;
+        const float q = div_ranged(d[c1], d[c1] - d[c2]);
+        const float t = crossed ? q : 0.0f;
+        const float s = crossed ? ((1.0f - q) + q) : 0.0f;
+        count += crossed ? 1 : 0;
+        const int axis = c1 ^ c2;  // 4: x, 2: y, 1: z
+        sum.x += axis == 4 ? t : ((c1 & 4) ? s : 0.0f);
+        sum.y += axis == 2 ? t : ((c1 & 2) ? s : 0.0f);
+        sum.z += axis == 1 ? t : ((c1 & 1) ? s : 0.0f);
+    }
+}
+
+// The loads of one chunk's padded tile, in flight: two rows per thread (324 rows: the 16 interior cells of both planes and the four k-halo
+// bytes), and — in the first 27 threads — the first word of one chunk record of the 3 x 3 x 3 neighbourhood (kind, generated kind, flags,
+// uniform type: what the rows need of their three chunks, the upper-layer rule of its three, the submesh of the chunk itself). A mesher
+// workgroup issues them for its NEXT chunk before the quad phase of the current one (tile_issue), passes the records through LDS
+// (tile_records) and looks at the rows when that chunk's turn comes (tile_finish): the tile's trip to memory — a third of a workgroup's time
+// per chunk when it was taken at the start of the chunk — is then covered by the quad phase. 25 registers per thread while in flight.
+struct RowData {
+    uint4 s4, t4;
+    uint32_t b0s, b0t, b2s, b2t;
+};
+struct TileLoads {
+    RowData L[2];
+    uint32_t rec;
+};
+__device__ __forceinline__ void tile_issue(const GridView& g, uint32_t chunk, TileLoads& T, uint32_t tid) {
+    tid = opaque(tid);
+    const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
+    T.rec = 0u;  // (a chunk that is not there reads as Void; nothing consults it)
+    if (tid < 27u) {  // first in the queue: tile_records asks for it before the quad phase's stores have retired
+        const int di = (int)(tid / 9u) - 1, dj = (int)((tid / 3u) % 3u) - 1, dk = (int)(tid % 3u) - 1;
+        const int ni = ci + di, nj = cj + dj, nk = ck + dk;
+        if (nj >= 0 && nj < (int)g.cy && nk >= 0 && nk < (int)g.cz) {
+            const ivx_chunk_info* rp = nullptr;
+            if (ni >= 0 && ni < (int)g.cx) rp = g.info + (size_t)((ni * (int)g.cy + nj) * (int)g.cz + nk);
+            else if (g.ghost_info[ni < 0 ? 0 : 1]) rp = g.ghost_info[ni < 0 ? 0 : 1] + (nj * (int)g.cz + nk);
+            if (rp) T.rec = *reinterpret_cast<const uint32_t*>(rp);
+        }
+    }
+    // (straight-line: a row that is not fetched — beyond the 324, outside the grid, in a ghost layer — loads the chunk's own first row instead;
+    // with the loads under conditions the compiler merged the two rounds' registers and waited for the first round to copy it aside)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int r = (int)tid + 256 * it;
+        const int a = r / G, b = r - a * G;
+        int gi = ci * 16 + a - 1, gj = cj * 16 + b - 1;
+        const bool real = r < NROWS && row_mode(g, gi, gj) == 1u;
+        gi = real ? gi : ci * 16;
+        gj = real ? gj : cj * 16;
+        RowData& L = T.L[it];
+        const size_t cidx = (size_t)(((gi >> 4) * g.cy + (gj >> 4)) * g.cz) + (size_t)ck;
+        const uint32_t rix = (uint32_t)(((gi & 15) << 4) | (gj & 15));
+        const size_t o = (cidx << 12) + ((size_t)rix << 4);
+        const uint8_t* kf = g.kface + cidx * 1024 + rix;
+        const uint8_t* kf0 = ck > 0 ? kf - 1024 : kf;  // (clamped to the chunk itself where there is no neighbour; not consulted then)
+        const uint8_t* kf2 = ck + 1 < (int)g.cz ? kf + 1024 : kf;
+        L.s4 = *reinterpret_cast<const uint4*>(g.sdf + o);
+        L.t4 = *reinterpret_cast<const uint4*>(g.type + o);
+        L.b0s = kf0[256];
+        L.b0t = kf0[768];
+        L.b2s = kf2[0];
+        L.b2t = kf2[512];
+    }
+}
+// the records into LDS, ahead of the barrier that precedes tile_finish
+__device__ __forceinline__ void tile_records(TileLoads& T, uint32_t* s_rec, uint32_t tid) {
+    if (tid < 27u) s_rec[tid] = T.rec;
+}
+__device__ __forceinline__ void tile_finish(const GridView& g, uint32_t chunk, TileLoads& T, const uint32_t* s_rec, uint8_t* s_sd, uint8_t* s_ty, uint32_t* s_neg,
+                                            uint32_t tid, int* upper) {
+    tid = opaque(tid);
+    const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int r = (int)tid + 256 * it;
+        if (r >= NROWS) break;
+        const int a = r / G, b = r - a * G;
+        const int gi = ci * 16 + a - 1, gj = cj * 16 + b - 1;
+        uint32_t sd[6], ty[6];
+        sd[0] = sd[5] = 0x7Fu;
+        ty[0] = ty[5] = 0xFFu;
+        sd[1] = sd[2] = sd[3] = sd[4] = 0x7F7F7F7Fu;
+        ty[1] = ty[2] = ty[3] = ty[4] = 0xFFFFFFFFu;
+        const uint32_t mode = row_mode(g, gi, gj);
+        if (mode == 2u) {
+            fetch_row_serial(g, gi, gj, ck, sd, ty);
+        } else if (mode == 1u) {
+            RowData& L = T.L[it];
+            // (the loaded registers pass through an empty asm first: the compiler may otherwise move the first operation on a loaded value — a
+            // mask, a shift — up to the load, a phase ago, and wait for the load there)
+            asm volatile("" : "+v"(L.s4.x), "+v"(L.s4.y), "+v"(L.s4.z), "+v"(L.s4.w), "+v"(L.t4.x), "+v"(L.t4.y), "+v"(L.t4.z), "+v"(L.t4.w));
+            asm volatile("" : "+v"(L.b0s), "+v"(L.b0t), "+v"(L.b2s), "+v"(L.b2t));
+            // the row's chunk column in the neighbourhood: (gi >> 4) - ci and (gj >> 4) - cj are -1, 0 or 1
+            const int col = (((gi >> 4) - ci + 1) * 3 + ((gj >> 4) - cj + 1)) * 3;
+            const ivx_chunk_info c0 = record_of(s_rec[col]), c1 = record_of(s_rec[col + 1]), c2 = record_of(s_rec[col + 2]);
+            const bool d1 = c1.kind == KIND_NONUNIFORM;
+            const uint32_t us = ivx_uniform_sdf(c1.kind) * 0x01010101u, ut = ivx_uniform_type(c1) * 0x01010101u;
+            sd[1] = d1 ? L.s4.x : us, sd[2] = d1 ? L.s4.y : us, sd[3] = d1 ? L.s4.z : us, sd[4] = d1 ? L.s4.w : us;
+            ty[1] = d1 ? L.t4.x : ut, ty[2] = d1 ? L.t4.y : ut, ty[3] = d1 ? L.t4.z : ut, ty[4] = d1 ? L.t4.w : ut;
+            if (ck > 0) {
+                const bool dense = c0.kind == KIND_NONUNIFORM;
+                sd[0] = dense ? L.b0s : ivx_uniform_sdf(c0.kind);
+                ty[0] = dense ? L.b0t : ivx_uniform_type(c0);
+            }
+            if (ck + 1 < (int)g.cz) {
+                const bool dense = c2.kind == KIND_NONUNIFORM;
+                sd[5] = dense ? L.b2s : ivx_uniform_sdf(c2.kind);
+                ty[5] = dense ? L.b2t : ivx_uniform_type(c2);
+            }
+        }
+        s_neg[r] = ((sd[0] >> 7) & 1u) | (neg16(sd + 1) << 1) | (((sd[5] >> 7) & 1u) << 17);
+        uint8_t* ds = s_sd + r * RS;
+        uint8_t* dt = s_ty + r * RS;
+        ds[3] = (uint8_t)sd[0];
+        dt[3] = (uint8_t)ty[0];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            reinterpret_cast<uint32_t*>(ds + 4)[q] = sd[1 + q];
+            reinterpret_cast<uint32_t*>(dt + 4)[q] = ty[1 + q];
+        }
+        ds[20] = (uint8_t)sd[5];
+        dt[20] = (uint8_t)ty[5];
+    }
+    // the upper layer of cubes belongs to the upper neighbour chunk when that chunk is non-uniform (surface_nets.rs:252-261); neighbourhood
+    // entries (di, dj, dk) = (1,0,0), (0,1,0), (0,0,1); a chunk that is not there reads as Void
+    upper[0] = upper[1] = upper[2] = G - 1;
+    if ((s_rec[22] & 0xFFu) == KIND_NONUNIFORM) upper[0] -= 1;
+    if ((s_rec[16] & 0xFFu) == KIND_NONUNIFORM) upper[1] -= 1;
+    if ((s_rec[14] & 0xFFu) == KIND_NONUNIFORM) upper[2] -= 1;
+}
+
+// Workgroups of a mesher launch: as many as stay resident (four per CU: 128 VGPRs, < 40 KB of LDS), each walking its share of the list —
+// only a workgroup that goes on to another chunk can fetch that chunk's tile ahead.
+static inline uint32_t ivx_emit_grid(const ivx_grid* g, uint32_t n_entries) {
+    const uint32_t resident = (uint32_t)g->ctx->n_cu * 4u;
+    return n_entries < resident ? (n_entries ? n_entries : 1u) : resident;
+}
+static inline uint32_t ivx_emit_general_grid(const ivx_grid* g, uint32_t n_entries) {
+    const uint32_t cap = (uint32_t)g->ctx->n_cu * 2u;
+    return n_entries < cap ? (n_entries ? n_entries : 1u) : cap;
+}
+
+// The mesher's main pass. One workgroup (256 threads, four per CU: <= 128 VGPRs by amdgpu_waves_per_eu(4) on the kernels) walks its share of
+// the chunks that have a mesh, as a two-stage pipeline over chunks — the tile of the walk's NEXT chunk is fetched while the current chunk is
+// meshed from the tile in LDS:
+//   0. next tile out  the loads of the next chunk's padded tile are issued (TileLoads: 25 registers per thread)
+//   1. order          cube rows in scan order, one ordered prefix for vertices and quads  (tile signs -> s_vrow, s_qrow, s_surf)
+//   2. vertices       one thread per vertex: position, normal, the one material; the vertex lists its quads (tile -> buffers, s_vpos, s_vsm, s_quad)
+//   4. quads          one thread per quad: diagonal, winding, indices, index materials    (reads nothing of the tile but its sign rows)
+//   5. next tile in   the rows that arrived meanwhile go into the LDS tile
+// The tile's trip to memory, a third of a workgroup's time per chunk when it was taken at the start of the chunk, is covered by phases 1-4.
+// This pass does the common case only — every vertex with one material around it, every quad with one material at its four corners, at most
+// VPC vertices — and hands any other chunk on (`hard`) to role_sn_emit_general, which meshes that chunk again in full: kept apart so that
+// the general paths' registers are not live beside the loads in flight (with them in the same kernel the compiler sent the loaded rows to
+// scratch the moment they arrived, i.e. waited for them where they were issued).
 template <bool SLOTS>
 __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams p, float* __restrict__ positions, float* __restrict__ normals,
+                                                 uint32_t* __restrict__ indices, unsigned long long* __restrict__ imats, ivx_submesh* __restrict__ submeshes,
+                                                 const uint32_t* __restrict__ emit_count, const uint4* __restrict__ emit_items, uint32_t vcap, uint32_t icap,
+                                                 uint32_t scap, const uint32_t* __restrict__ slots, uint32_t* __restrict__ hard_count,
+                                                 uint32_t* __restrict__ hard_list) {
+    __shared__ uint16_t s_quad[3 * VPC];  // the chunk's quads in emission order: cube id | axis << 13
+    __shared__ __attribute__((aligned(16))) uint8_t s_sd[TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ty[TILE_BYTES];
+    __shared__ uint32_t s_neg[NROWS];
+    __shared__ uint32_t s_vrow[NCROWS];   // per cube row: first vertex << 17 | which of its 17 cubes have a vertex (cube -> vertex: vertex_of)
+    __shared__ uint16_t s_qrow[NCROWS];   // per cube row: its first quad
+    __shared__ uint32_t s_nq;             // the chunk's quads
+    __shared__ uint16_t s_surf[VPC];      // vertex -> cube id (cube row * 17 + k)
+    __shared__ float s_vpos[3][VPC];      // the chunk's vertex positions and materials for the quad phase
+    __shared__ uint8_t s_vsm[VPC];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_hard;  // this chunk needs the general pass
+    __shared__ uint32_t s_rec[27];  // first words of the chunk records of the tile's 3 x 3 x 3 neighbourhood
+    const GridView& g = p.g;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_emit = emit_count[0];  // = number of submeshes (k_sn_scan's third total)
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    uint32_t li = NONE, li_next = bid;      // the list is in submesh order: entry li is submesh li
+    if (li_next >= n_emit) return;
+    uint4 item = make_uint4(0u, 0u, 0u, 0u), item_next = emit_items[li_next];
+    int upper[3] = {G - 1, G - 1, G - 1};  // of the tile in LDS
+    uint32_t info_w = 0u;
+    for (;;) {
+    const bool have = li != NONE, have_next = li_next < n_emit;
+    const uint32_t chunk = item.x, voff = item.y, ioff = item.z;
+    const uint32_t icount = (item.w >> 16) * 6u;
+    const uint32_t slot = have ? (SLOTS ? slots[li] : li) : 0u;  // (incremental remesh: the submesh manager's slot of the chunk)
+    // The output buffers keep the capacity of earlier steps; a mesh that outgrew them is re-emitted after the host has grown the
+    // buffers (ivx_voxel_step_collect) — nothing is ever written past the end: such a chunk is passed over.
+    const bool fits = have && !((size_t)voff + (item.w & 0xFFFFu) > vcap || (size_t)ioff + icount > icap || slot >= scap);
+    const bool large = fits && (item.w & 0xFFFFu) > VPC;
+    const uint32_t vcount = (fits && !large) ? (item.w & 0xFFFFu) : 0u;
+    const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
+    if (tid == 0) s_hard = large ? 1u : 0u;
+    if (have) IVX_T(g, li, 0);
+    if (tid == 0 && fits) {
+        const uint32_t cflags = (info_w >> 16) & 0xFFu;
+        ivx_submesh sm;
+        sm.chunk_indices[0] = (uint32_t)ci + p.x_off;
+        sm.chunk_indices[1] = (uint32_t)cj;
+        sm.chunk_indices[2] = (uint32_t)ck;
+        sm.index_offset = ioff;
+        sm.index_count = icount;
+        // bits: X_DN 0, Y_DN 1, Z_DN 2, X_UP 3, Y_UP 4, Z_UP 5 (mesh.rs:611-635)
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b)
+                for (int c = 0; c < 2; ++c)
+                    sm.is_obscured_from_direction[a][b][c] =
+                        (((cflags >> (3 * a)) & 1u) && ((cflags >> (3 * b + 1)) & 1u) && ((cflags >> (3 * c + 2)) & 1u)) ? 1u : 0u;
+        sm.vertex_offset = voff;
+        sm.vertex_count = item.w & 0xFFFFu;
+        sm.reserved = 0;
+        submeshes[slot] = sm;
+    }
+    __syncthreads();  // the chunk's tile is in LDS (phase 5 of the previous round)
+    if (have) IVX_T(g, li, 1);
+
+    // ---- 0. the next chunk's tile: its loads travel while this chunk is meshed
+    TileLoads T;
+    if (have_next) tile_issue(g, item_next.x, T, tid);
+    if (vcount) {
+    // ---- 1. vertex and quad order: cubes in (i,j,k) scan order (surface_nets.rs:158-185) = cube rows in order, bits ascending; a cube's
+    // quads X, Y, Z (surface_nets.rs:263-301). Thread t owns cube rows 2t and 2t+1 so that thread order = row order; ONE ordered prefix
+    // carries both counts (vertices in the low half, quads in the high half: at most 4913 and 14 739).
+    {
+        uint32_t vb[2] = {0, 0}, nq[2] = {0, 0};
+        const int r0 = 2 * (int)opaque(tid);
+        for (int q = 0; q < 2; ++q) {
+            const int cr = r0 + q;
+            if (cr < NCROWS) {
+                uint32_t qx, qy, qz;
+                cube_row_bits(s_neg, cr / 17, cr % 17, upper, vb[q], qx, qy, qz);
+                nq[q] = __popc(qx) + __popc(qy) + __popc(qz);
+            }
+        }
+        uint32_t total;
+        const uint32_t pre = block_prefix((__popc(vb[0]) + __popc(vb[1])) | ((nq[0] + nq[1]) << 16), s_wsum, tid, total);
+        uint32_t base = pre & 0xFFFFu, qb = pre >> 16;
+        if (tid == 0) s_nq = total >> 16;
+        for (int q = 0; q < 2; ++q) {
+            const int cr = r0 + q;
+            if (cr < NCROWS) {
+                s_vrow[cr] = (base << 17) | vb[q];
+                s_qrow[cr] = (uint16_t)qb;
+                qb += nq[q];
+                uint32_t m = vb[q];
+                while (m) {
+                    const int k = __ffs(m) - 1;
+                    m &= m - 1;
+                    if (base < VPC) s_surf[base] = (uint16_t)(cr * 17 + k);
+                    base += 1;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    IVX_T(g, li, 2);  // vertex order built
+
+    // mesh.rs:559-577
+    const float chunk_extent = p.extent * 16.0f;
+    const V3 pos_offset = mk((float)(ci + (int)p.x_off) * chunk_extent - 0.5f * p.extent, (float)cj * chunk_extent - 0.5f * p.extent,
+                             (float)ck * chunk_extent - 0.5f * p.extent);
+
+    // ---- 2. vertices: one thread per vertex ------------------------------------------------------
+    for (uint32_t v = opaque(tid); v < vcount; v += 256) {
+        const int cid = s_surf[v];
+        const int cr = cid / 17, k = cid - cr * 17, i = cr / 17, j = cr - i * 17;
+        const int t0 = tix(i, j, k);
+        const int co[8] = {0, 1, RS, RS + 1, G * RS, G * RS + 1, G * RS + RS, G * RS + RS + 1};
+        float d[8];
+        uint32_t neg = 0u;
+        uint8_t mats[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int8_t e = (int8_t)s_sd[t0 + co[c]];
+            d[c] = decode(e);
+            neg |= (e < 0 ? 1u : 0u) << c;
+            mats[c] = s_ty[t0 + co[c]];
+        }
+        int count;
+        V3 sum;
+        edge_centroid(d, neg, sum, count);
+        const float rc = div_ranged(1.0f, (float)count);
+        const V3 centroid = scale(sum, rc);
+        // trilinear gradient (object/sdf.rs:603-633)
+        const V3 d00 = sub(mk(d[4], d[2], d[1]), mk(d[0], d[0], d[0]));
+        const V3 d01 = sub(mk(d[5], d[6], d[3]), mk(d[1], d[4], d[2]));
+        const V3 d10 = sub(mk(d[6], d[3], d[5]), mk(d[2], d[1], d[4]));
+        const V3 d11 = sub(mk(d[7], d[7], d[7]), mk(d[3], d[5], d[6]));
+        const V3 o = centroid;
+        const V3 r = sub(mk(1.0f, 1.0f, 1.0f), o);
+        const V3 r_yzx = mk(r.y, r.z, r.x), r_zxy = mk(r.z, r.x, r.y), o_yzx = mk(o.y, o.z, o.x), o_zxy = mk(o.z, o.x, o.y);
+        const V3 grad = add(add(add(mul(mul(r_yzx, r_zxy), d00), mul(mul(r_yzx, o_zxy), d01)), mul(mul(o_yzx, r_zxy), d10)),
+                            mul(mul(o_yzx, o_zxy), d11));
+        const float gl = len3(grad);
+        const V3 normal = mk(grad.x / gl, grad.y / gl, grad.z / gl);
+        const V3 position = add(scale(add(centroid, mk((float)i, (float)j, (float)k)), p.extent), pos_offset);
+        const size_t gv = (size_t)voff + v;
+        positions[3 * gv + 0] = position.x;
+        positions[3 * gv + 1] = position.y;
+        positions[3 * gv + 2] = position.z;
+        normals[3 * gv + 0] = normal.x;
+        normals[3 * gv + 1] = normal.y;
+        normals[3 * gv + 2] = normal.z;
+        // the one material of the cube's negative corners; a vertex with several hands the chunk to the general pass
+        uint32_t m0 = 0xFFFFFFFFu;
+        bool single = true;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if ((neg >> c) & 1u) {
+                if (m0 == 0xFFFFFFFFu) m0 = mats[c];
+                single = single && mats[c] == m0;
+            }
+        s_vpos[0][v] = position.x;
+        s_vpos[1][v] = position.y;
+        s_vpos[2][v] = position.z;
+        s_vsm[v] = (uint8_t)m0;
+        if (!single) s_hard = 1u;
+        // the vertex's quads into the chunk's list, at the row's first quad + the quads of the row's cubes below this one
+        {
+            uint32_t vb, qx, qy, qz;
+            cube_row_bits(s_neg, i, j, upper, vb, qx, qy, qz);
+            const uint32_t below = (1u << k) - 1u;
+            uint32_t qslot = (uint32_t)s_qrow[cr] + __popc(qx & below) + __popc(qy & below) + __popc(qz & below);
+            if ((qx >> k) & 1u) s_quad[qslot++] = (uint16_t)cid;
+            if ((qy >> k) & 1u) s_quad[qslot++] = (uint16_t)(cid | (1 << 13));
+            if ((qz >> k) & 1u) s_quad[qslot] = (uint16_t)(cid | (2 << 13));
+        }
+    }
+    }  // vcount
+    __syncthreads();
+    if (have) IVX_T(g, li, 3);  // vertices written
+
+
+    // ---- 4. quads, one THREAD per quad of the list the vertices left (a vertex emits up to three quads: walking them inside its thread
+    // made every pass three quads long). No barrier inside: the waves drift apart and cover each other's LDS and store latencies.
+    if (vcount && !s_hard) {
+        const uint32_t n_quads = s_nq;
+        for (uint32_t q = opaque(tid); q < n_quads; q += 256) {
+            const uint32_t qd = s_quad[q];
+            const int axis = (int)(qd >> 13);
+            const int qcid = (int)(qd & 0x1FFFu);
+            const int cr = qcid / 17;
+            const int k = qcid - cr * 17, i = cr / 17, j = cr - i * 17;
+            // neighbouring cubes across the two other axes: (axis_b, axis_c) = (Y,Z), (Z,X), (X,Y)
+            const int ab = axis == 0 ? 17 : (axis == 1 ? 1 : 289);
+            const int ac = axis == 0 ? 1 : (axis == 1 ? 289 : 17);
+            const bool n1 = ((s_neg[i * G + j] >> k) & 1u) != 0u;  // the cube's first corner is inside
+            const bool negative_face = !n1;  // (false,true) => negative face (surface_nets.rs:348-352)
+            // cube -> vertex: the row's first vertex plus the vertices below k in the row (ab, ac step the row by 0, 1 or 17 and k by 0 or 1)
+            const int rb = ab == 1 ? 0 : (ab == 17 ? 1 : 17), rc = ac == 1 ? 0 : (ac == 17 ? 1 : 17);
+            const int kb = ab == 1 ? 1 : 0, kc = ac == 1 ? 1 : 0;
+            const uint32_t v1 = vertex_of(s_vrow[cr], k), v2 = vertex_of(s_vrow[cr - rb], k - kb), v3 = vertex_of(s_vrow[cr - rc], k - kc),
+                           v4 = vertex_of(s_vrow[cr - rb - rc], k - kb - kc);
+            const V3 q1 = mk(s_vpos[0][v1], s_vpos[1][v1], s_vpos[2][v1]), q2 = mk(s_vpos[0][v2], s_vpos[1][v2], s_vpos[2][v2]);
+            const V3 q3 = mk(s_vpos[0][v3], s_vpos[1][v3], s_vpos[2][v3]), q4 = mk(s_vpos[0][v4], s_vpos[1][v4], s_vpos[2][v4]);
+            const uint32_t b1 = s_vsm[v1], b2 = s_vsm[v2], b3 = s_vsm[v3], b4 = s_vsm[v4];
+            uint32_t quad[6];
+            if (len3(sub(q1, q4)) < len3(sub(q2, q3))) {
+                if (negative_face) { quad[0] = v1; quad[1] = v4; quad[2] = v2; quad[3] = v1; quad[4] = v3; quad[5] = v4; }
+                else { quad[0] = v1; quad[1] = v2; quad[2] = v4; quad[3] = v1; quad[4] = v4; quad[5] = v3; }
+            } else if (negative_face) { quad[0] = v2; quad[1] = v3; quad[2] = v4; quad[3] = v2; quad[4] = v1; quad[5] = v3; }
+            else { quad[0] = v2; quad[1] = v4; quad[2] = v3; quad[3] = v2; quad[4] = v3; quad[5] = v1; }
+            const size_t io = (size_t)ioff + (size_t)q * 6;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) indices[io + t] = voff + quad[t];
+            // calculate_index_materials_for_triangle's first case (surface_nets.rs:559-637): one entry, weight 1
+            const unsigned long long im = (unsigned long long)b1 | (1ull << 32);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) imats[io + t] = im;
+            if (!(b1 == b2 && b1 == b3 && b1 == b4)) s_hard = 1u;  // (corners of different materials: the general pass redoes the chunk)
+        }
+    }
+    if (have_next) tile_records(T, s_rec, tid);
+    __syncthreads();
+    if (have) IVX_T(g, li, 4);  // quads written
+
+    // ---- 5. the next chunk's tile into LDS
+    if (have_next) {
+        tile_finish(g, item_next.x, T, s_rec, s_sd, s_ty, s_neg, tid, upper);
+        info_w = s_rec[13];
+    }
+    if (tid == 0 && s_hard) hard_list[atomicAdd(hard_count, 1u)] = li;
+    if (have) IVX_T(g, li, 5);
+    if (!have_next) break;
+    li = li_next;
+    item = item_next;
+    li_next += nb;
+    if (li_next < n_emit) item_next = emit_items[li_next];
+    }
+}
+
+// The general mesher: one workgroup per listed chunk, every case of the reference's vertex and index materials (vertices with up to seven
+// materials around them, the sorting network, calculate_index_materials_for_triangle's ranking), chunks of any vertex count. It runs after
+// role_sn_emit over the chunks that one handed on (`hard` = count, then submesh-order list entries) and writes the whole chunk again.
+template <bool SLOTS>
+__device__ __forceinline__ void role_sn_emit_general(uint32_t bid, uint32_t nb, SnParams p, float* __restrict__ positions, float* __restrict__ normals,
                                                  uint32_t* __restrict__ indices, unsigned long long* __restrict__ imats,
                                                  uint4* __restrict__ vmats, ivx_submesh* __restrict__ submeshes, const uint32_t* __restrict__ emit_count,
                                                  const uint4* __restrict__ emit_items, uint32_t vcap, uint32_t icap, uint32_t scap,
-                                                 const uint32_t* __restrict__ slots) {
+                                                 const uint32_t* __restrict__ slots, const uint32_t* __restrict__ hard_count,
+                                                 const uint32_t* __restrict__ hard_list) {
     __shared__ uint16_t s_quad[768];  // quads of the current batch of 256 vertices: cube id | axis << 13
     __shared__ __attribute__((aligned(16))) uint8_t s_sd[TILE_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t s_ty[TILE_BYTES];
@@ -675,10 +1109,11 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
     const GridView& g = p.g;
     const uint32_t tid = threadIdx.x;
     const uint32_t n_emit = emit_count[0];  // = number of submeshes (k_sn_scan's third total)
-    // bounded grid-stride walk over the chunks that have a mesh
-    for (uint32_t li = bid; li < n_emit; li += nb) {
+    const uint32_t n_hard = hard_count[0] < n_emit ? hard_count[0] : n_emit;
+    for (uint32_t hi = bid; hi < n_hard; hi += nb) {
+    const uint32_t li = hard_list[hi];
     __syncthreads();
-    IVX_T(g, li, 0);
+    if (li >= n_emit) continue;
     const uint4 item = emit_items[li];  // the list is in submesh order: entry li is submesh li
     const uint32_t chunk = item.x, voff = item.y, ioff = item.z;
     const uint32_t vcount = item.w & 0xFFFFu, icount = (item.w >> 16) * 6u;
@@ -712,9 +1147,7 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
         sm.reserved = 0;
         submeshes[slot] = sm;
     }
-    IVX_T(g, li, 1);  // tile loaded (this wave's part)
     __syncthreads();
-    IVX_T(g, li, 2);
 
     // ---- vertex order: cubes in (i,j,k) scan order (surface_nets.rs:158-185) = cube rows in order, bits ascending.
     // Thread t owns cube rows 2t and 2t+1 so that thread order = row order for the ordered prefix.
@@ -745,7 +1178,6 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
         }
     }
     __syncthreads();
-    IVX_T(g, li, 3);  // vertex order built
 
     // mesh.rs:559-577
     const float chunk_extent = p.extent * 16.0f;
@@ -839,7 +1271,6 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
     }
     __threadfence_block();
     __syncthreads();
-    IVX_T(g, li, 4);  // vertices written
 
     // ---- phase B: quads in surface-point order, X then Y then Z edge (surface_nets.rs:263-301). Per batch of 256 vertices
     // the quads are first listed in that order (ordered prefix over the vertices' quad counts), then handled one THREAD per
@@ -938,7 +1369,6 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
         }
         qbase += total;
     }
-    IVX_T(g, li, 5);  // quads written
     }
 }
 

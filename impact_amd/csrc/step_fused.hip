@@ -51,6 +51,8 @@ struct StepArgs {
     uint32_t* indices;
     unsigned long long* imats;
     uint4* vmats;
+    uint32_t* hard_count;  // chunks the mesher's main pass hands to the general pass: counter, list
+    uint32_t* hard_list;
     ivx_submesh* submeshes;
     uint32_t vcap, icap, scap;
     // occupied / moments
@@ -136,8 +138,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     b -= a.nb[0];
     if (b < a.nb[1])
-        sn::role_sn_emit<false>(b, a.nb[1], sn_params(a), a.positions, a.normals, a.indices, a.imats, a.vmats, a.submeshes, a.offsets + 2 * (size_t)a.n_chunks + 2,
-                                a.emit_items, a.vcap, a.icap, a.scap, nullptr);
+        sn::role_sn_emit<false>(b, a.nb[1], sn_params(a), a.positions, a.normals, a.indices, a.imats, a.submeshes, a.offsets + 2 * (size_t)a.n_chunks + 2,
+                                a.emit_items, a.vcap, a.icap, a.scap, nullptr, a.hard_count, a.hard_list);
 }
 
 // component ids; block 0 also hands the step's small results to the host block
@@ -187,6 +189,8 @@ static StepArgs make_args(ivx_grid* g) {
     a.indices = g->indices;
     a.imats = reinterpret_cast<unsigned long long*>(g->index_materials);
     a.vmats = reinterpret_cast<uint4*>(g->vertex_materials);
+    a.hard_count = ivx_sn_hard_count(g);
+    a.hard_list = g->sn_hard;
     a.submeshes = g->submeshes;
     a.vcap = (uint32_t)g->vcap;
     a.icap = (uint32_t)g->icap;
@@ -244,11 +248,12 @@ int ivx_launch_step_post2(ivx_grid* g, uint32_t stages) {
 int ivx_launch_step_emit(ivx_grid* g, uint32_t stages) {
     StepArgs a = make_args(g);
     if (stages & IVX_STAGE_REGIONS) a.nb[0] = (g->n_chunks + 255u) / 256u;
-    if (stages & IVX_STAGE_REMESH) a.nb[1] = g->n_chunks < 4096u ? g->n_chunks : 4096u;
+    if (stages & IVX_STAGE_REMESH) a.nb[1] = sn::ivx_emit_grid(g, g->n_chunks);
     const uint32_t total = a.nb[0] + a.nb[1];
     if (total == 0) return IVX_OK;
     hipLaunchKernelGGL(k_step_emit, dim3(total), dim3(256), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
+    if (stages & IVX_STAGE_REMESH) return ivx_launch_sn_emit_general(g);
     return IVX_OK;
 }
 

@@ -37,14 +37,58 @@ __global__ __launch_bounds__(256) void k_sn_scan(uint32_t n_chunks, const uint32
 // four as well. The kernel is bound by the latency of a workgroup's serial phases, so residency is what buys throughput.)
 template <bool SLOTS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_sn_emit(SnParams p, float* __restrict__ positions, float* __restrict__ normals,
+                                                 uint32_t* __restrict__ indices, unsigned long long* __restrict__ imats, ivx_submesh* __restrict__ submeshes,
+                                                 const uint32_t* __restrict__ emit_count, const uint4* __restrict__ emit_items, uint32_t vcap, uint32_t icap,
+                                                 uint32_t scap, const uint32_t* __restrict__ slots, uint32_t* __restrict__ hard_count,
+                                                 uint32_t* __restrict__ hard_list) {
+    role_sn_emit<SLOTS>(blockIdx.x, gridDim.x, p, positions, normals, indices, imats, submeshes, emit_count, emit_items, vcap, icap, scap, slots, hard_count, hard_list);
+}
+// the chunks the main pass handed on (several materials around a vertex or a quad, more vertices than its LDS cache holds)
+template <bool SLOTS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_sn_emit_general(SnParams p, float* __restrict__ positions, float* __restrict__ normals,
                                                  uint32_t* __restrict__ indices, unsigned long long* __restrict__ imats,
                                                  uint4* __restrict__ vmats, ivx_submesh* __restrict__ submeshes, const uint32_t* __restrict__ emit_count,
                                                  const uint4* __restrict__ emit_items, uint32_t vcap, uint32_t icap, uint32_t scap,
-                                                 const uint32_t* __restrict__ slots) {
-    role_sn_emit<SLOTS>(blockIdx.x, gridDim.x, p, positions, normals, indices, imats, vmats, submeshes, emit_count, emit_items, vcap, icap, scap, slots);
+                                                 const uint32_t* __restrict__ slots, const uint32_t* __restrict__ hard_count,
+                                                 const uint32_t* __restrict__ hard_list) {
+    role_sn_emit_general<SLOTS>(blockIdx.x, gridDim.x, p, positions, normals, indices, imats, vmats, submeshes, emit_count, emit_items, vcap, icap, scap, slots,
+                                hard_count, hard_list);
+}
+
+// div_ranged against the `/` operator over the whole operand set the mesher hands it: t = d1 / (d1 - d2) for every pair of decoded
+// distances of opposite sign (surface_nets.rs:396-404; decoded 0 is +0.0 and counts as positive), and 1 / n for the edge counts.
+__global__ __launch_bounds__(256) void k_selftest_division(uint32_t* __restrict__ mismatches) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;  // 65 536 pairs + 256 counts
+    uint32_t bad = 0u;
+    if (t < 65536u) {
+        const int8_t e1 = (int8_t)(t & 0xFFu), e2 = (int8_t)(t >> 8);
+        if ((e1 < 0) != (e2 < 0)) {
+            const float d1 = decode(e1), d2 = decode(e2);
+            const float a = d1 / (d1 - d2), b = div_ranged(d1, d1 - d2);
+            bad = __float_as_uint(a) != __float_as_uint(b) ? 1u : 0u;
+        }
+    } else {
+        const float n = (float)(t - 65536u + 1u);
+        bad = __float_as_uint(1.0f / n) != __float_as_uint(div_ranged(1.0f, n)) ? 1u : 0u;
+    }
+    if (bad) atomicAdd(mismatches, 1u);
 }
 
 }  // namespace
+
+// (test hook, include/impact_voxel_hip.h)
+int ivx_selftest_mesher_division(ivx_ctx* ctx, uint32_t* mismatches) {
+    IVX_REQUIRE(ctx && mismatches, IVX_ERR_INVALID, "ivx_selftest_mesher_division: null argument");
+    uint32_t* d = nullptr;
+    IVX_HIP_CHECK(hipMalloc(&d, sizeof(uint32_t)));
+    IVX_HIP_CHECK(hipMemsetAsync(d, 0, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(k_selftest_division, dim3(257), dim3(256), 0, ctx->stream, d);
+    IVX_HIP_CHECK(hipGetLastError());
+    IVX_HIP_CHECK(hipMemcpyAsync(mismatches, d, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    IVX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    IVX_HIP_CHECK(hipFree(d));
+    return IVX_OK;
+}
 
 static SnParams make_params(ivx_grid* g) {
     SnParams p;
@@ -74,12 +118,25 @@ int ivx_launch_sn_scan(ivx_grid* g) {
     return IVX_OK;
 }
 
+// the counter of the chunks handed to the general pass: the word behind the Surface-Nets group totals (zeroed with them ahead of every count pass)
+uint32_t* ivx_sn_hard_count(ivx_grid* g) { return g->group_sums + 4 * (size_t)((g->n_chunks + 255u) / 256u); }
+
 int ivx_launch_sn_emit(ivx_grid* g) {
-    const uint32_t blocks = g->n_chunks < 4096u ? g->n_chunks : 4096u;
+    const uint32_t blocks = ivx_emit_grid(g, g->n_chunks);
     hipLaunchKernelGGL(k_sn_emit<false>, dim3(blocks), dim3(256), 0, g->ctx->stream, make_params(g), g->positions, g->normals, g->indices,
-                       reinterpret_cast<unsigned long long*>(g->index_materials), reinterpret_cast<uint4*>(g->vertex_materials), g->submeshes,
+                       reinterpret_cast<unsigned long long*>(g->index_materials), g->submeshes,
                        g->chunk_offsets + 2 * (size_t)g->n_chunks + 2, reinterpret_cast<const uint4*>(g->sn_list), (uint32_t)g->vcap, (uint32_t)g->icap,
-                       (uint32_t)g->scap, nullptr);
+                       (uint32_t)g->scap, nullptr, ivx_sn_hard_count(g), g->sn_hard);
+    IVX_HIP_CHECK(hipGetLastError());
+    return ivx_launch_sn_emit_general(g);
+}
+
+// after the main pass (full remesh): the chunks it handed on
+int ivx_launch_sn_emit_general(ivx_grid* g) {
+    hipLaunchKernelGGL(k_sn_emit_general<false>, dim3(ivx_emit_general_grid(g, g->n_chunks)), dim3(256), 0, g->ctx->stream, make_params(g), g->positions, g->normals,
+                       g->indices, reinterpret_cast<unsigned long long*>(g->index_materials), reinterpret_cast<uint4*>(g->vertex_materials), g->submeshes,
+                       g->chunk_offsets + 2 * (size_t)g->n_chunks + 2, reinterpret_cast<const uint4*>(g->sn_list), (uint32_t)g->vcap, (uint32_t)g->icap,
+                       (uint32_t)g->scap, nullptr, ivx_sn_hard_count(g), g->sn_hard);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -88,9 +145,15 @@ int ivx_launch_sn_emit(ivx_grid* g) {
 // from the host-side submesh manager; d_count holds their number
 int ivx_launch_sn_emit_list(ivx_grid* g, uint32_t n_records, const uint32_t* d_count, const void* d_records, const uint32_t* d_slots) {
     if (n_records == 0) return IVX_OK;
-    hipLaunchKernelGGL(k_sn_emit<true>, dim3(n_records < 4096u ? n_records : 4096u), dim3(256), 0, g->ctx->stream, make_params(g), g->positions, g->normals,
+    hipLaunchKernelGGL(k_sn_emit<true>, dim3(ivx_emit_grid(g, n_records)), dim3(256), 0, g->ctx->stream, make_params(g), g->positions, g->normals,
+                       g->indices, reinterpret_cast<unsigned long long*>(g->index_materials), g->submeshes,
+                       d_count, reinterpret_cast<const uint4*>(d_records), (uint32_t)g->vcap, (uint32_t)g->icap, (uint32_t)g->scap, d_slots, ivx_sn_hard_count(g),
+                       g->sn_hard);
+    IVX_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_sn_emit_general<true>, dim3(ivx_emit_general_grid(g, n_records)), dim3(256), 0, g->ctx->stream, make_params(g), g->positions, g->normals,
                        g->indices, reinterpret_cast<unsigned long long*>(g->index_materials), reinterpret_cast<uint4*>(g->vertex_materials), g->submeshes,
-                       d_count, reinterpret_cast<const uint4*>(d_records), (uint32_t)g->vcap, (uint32_t)g->icap, (uint32_t)g->scap, d_slots);
+                       d_count, reinterpret_cast<const uint4*>(d_records), (uint32_t)g->vcap, (uint32_t)g->icap, (uint32_t)g->scap, d_slots, ivx_sn_hard_count(g),
+                       g->sn_hard);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

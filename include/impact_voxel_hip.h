@@ -400,6 +400,10 @@ void ivx_comm_destroy(ivx_comm*);
  * itself) and checks the bytes that come back. A single-GPU box can so prove that the run-time binding to librccl (dlopen, symbols,
  * argument layouts, the library's stream) works before a multi-rank job depends on it. IVX_OK = all of it worked. */
 int ivx_comm_selftest(ivx_ctx*);
+/* Diagnostic (no reference counterpart): the mesher divides decoded distances (surface_nets.rs:396-404, t = d1 / (d1 - d2)) and edge counts
+ * with a short correctly-rounding sequence instead of the general f32 division; this runs both over the whole operand set (every pair of
+ * decoded i8 distances of opposite sign, 1 / n for n = 1..256) on the device and returns the number of results that differ: must be 0. */
+int ivx_selftest_mesher_division(ivx_ctx*, uint32_t* mismatches);
 int ivx_slab_create(ivx_comm*, ivx_grid* slab_grid, int rank, ivx_slab** out);
 void ivx_slab_destroy(ivx_slab*);
 int ivx_slabs_step_enqueue(ivx_slab** slabs, size_t n);
