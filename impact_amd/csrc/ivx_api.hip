@@ -401,7 +401,7 @@ int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32
         carve(&g->rscalar, (size_t)64);
         carve(&g->ccl_scratch, (size_t)g->n_chunks * 2);
         carve(&g->sn_list, (size_t)g->n_chunks * 4);  // one uint4 record per meshed chunk
-        carve(&g->group_sums, (size_t)((g->n_chunks + 255u) / 256u) * 4 + 4);
+        carve(&g->group_sums, (size_t)((g->n_chunks + 255u) / 256u) * 4 + IVX_SN_TAIL_WORDS);
         carve(&g->sn_hard, (size_t)g->n_chunks);
         carve(&g->dens_dev, (size_t)256);
         carve(&g->work_counts, (size_t)8);
@@ -2261,7 +2261,7 @@ int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
         if (post & (IVX_STAGE_REGIONS | IVX_STAGE_REMESH)) {
             T0(4);
             if (fused_assign) {
-                if ((rc = ivx_launch_step_emit(g, post))) return rc;
+                if ((rc = ivx_launch_step_emit(g, post, (post & IVX_STAGE_REGIONS) != 0))) return rc;
             } else {  // more than 524 288 chunks: the region resolve takes its stand-alone path
                 if ((post & IVX_STAGE_REMESH) && (rc = ivx_launch_step_emit(g, IVX_STAGE_REMESH))) return rc;
                 if ((post & IVX_STAGE_REGIONS) && (rc = ivx_launch_ccl_resolve(g))) return rc;
@@ -2270,7 +2270,7 @@ int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
         }
         if ((post & IVX_STAGE_REGIONS) && fused_assign) {
             T0(5);
-            if ((rc = ivx_launch_step_assign(g))) return rc;
+            if ((rc = ivx_launch_step_assign(g, (post & IVX_STAGE_REMESH) != 0))) return rc;
             T1(5);
         }
         if (post & IVX_STAGE_REMESH) {

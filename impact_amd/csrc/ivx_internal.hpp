@@ -83,7 +83,7 @@ struct ivx_grid {
     uint32_t* rscalar;   // small scalars: [0] region count, [1] error flags
     uint32_t* ccl_scratch;  // [2*n_chunks]: per-chunk root counts and exclusive offsets
     uint32_t* sn_list;      // [n_chunks] uint4 records of the chunks that emit a mesh this remesh, in submesh order (written by k_sn_scan)
-    uint32_t* group_sums;   // [4 * ceil(n_chunks/256) + 4]: first-level totals of the two-level scans; then the count of sn_hard
+    uint32_t* group_sums;   // [4 * ceil(n_chunks/256) + IVX_SN_TAIL_WORDS]: first-level totals of the two-level scans; then the count of sn_hard and the mesher's list cursors
     uint32_t* sn_hard;      // [n_chunks] list entries (submesh order) of the chunks the mesher's main pass hands to its general pass
     uint32_t region_count;
     int regions_valid;
@@ -279,6 +279,8 @@ static inline uint32_t* ivx_wc(const ivx_grid* g) { return g->work_counts + g->w
 #define IVX_SCRATCH_EVAL_ROLL 8u  // role_preset: copy the sampler's list counters to their statistics words and zero them
 #define IVX_SCRATCH_REGIONS 1u  // rscalar[0..16): region count, error flags, multi-region chunk count
 #define IVX_SCRATCH_SN 2u       // Surface-Nets group totals
+// words behind the Surface-Nets group totals: the general pass's counter, then the main pass's eight list cursors at a stride of 32 words
+#define IVX_SN_TAIL_WORDS 288u
 #define IVX_SCRATCH_EVAL 4u     // lengths of the sampler's evaluation lists
 
 static inline GridView ivx_view(const ivx_grid* g) {
@@ -323,8 +325,8 @@ int ivx_launch_step_preset(ivx_grid* g, uint32_t groups);
 static inline void ivx_step_preset_ahead(ivx_grid* g, uint32_t groups) { g->preset_ahead |= groups; }
 int ivx_launch_step_post1(ivx_grid* g, uint32_t stages);
 int ivx_launch_step_post2(ivx_grid* g, uint32_t stages);
-int ivx_launch_step_emit(ivx_grid* g, uint32_t stages);
-int ivx_launch_step_assign(ivx_grid* g);
+int ivx_launch_step_emit(ivx_grid* g, uint32_t stages, bool general_in_assign = false);
+int ivx_launch_step_assign(ivx_grid* g, bool with_mesher_general = false);
 int ivx_launch_step_gather(ivx_grid* g);
 bool ivx_step_assign_fits(const ivx_grid* g);
 int ivx_sampler_buffers(ivx_grid* g);

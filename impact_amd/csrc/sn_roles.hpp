@@ -851,7 +851,7 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
                                                  uint32_t* __restrict__ indices, unsigned long long* __restrict__ imats, ivx_submesh* __restrict__ submeshes,
                                                  const uint32_t* __restrict__ emit_count, const uint4* __restrict__ emit_items, uint32_t vcap, uint32_t icap,
                                                  uint32_t scap, const uint32_t* __restrict__ slots, uint32_t* __restrict__ hard_count,
-                                                 uint32_t* __restrict__ hard_list) {
+                                                 uint32_t* __restrict__ hard_list, uint32_t* __restrict__ cursor) {
     __shared__ uint16_t s_quad[3 * VPC];  // the chunk's quads in emission order: cube id | axis << 13
     __shared__ __attribute__((aligned(16))) uint8_t s_sd[TILE_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t s_ty[TILE_BYTES];
@@ -865,11 +865,19 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_hard;  // this chunk needs the general pass
     __shared__ uint32_t s_rec[27];  // first words of the chunk records of the tile's 3 x 3 x 3 neighbourhood
+    __shared__ uint32_t s_ticket[5];  // the list entry this workgroup takes after the next one: index, record
     const GridView& g = p.g;
     const uint32_t tid = threadIdx.x;
     const uint32_t n_emit = emit_count[0];  // = number of submeshes (k_sn_scan's third total)
     constexpr uint32_t NONE = 0xFFFFFFFFu;
-    uint32_t li = NONE, li_next = bid;      // the list is in submesh order: entry li is submesh li
+    // The list (submesh order: entry li is submesh li) is handed out by counters: a workgroup starts on entry `bid` and draws every further one.
+    // Equal shares did not end together — identical chunks took 9 to 21 us (10th to 90th percentile) depending on what else the CU was doing,
+    // and the launch waited 150 us of its 600 for the slowest shares. Eight counters, each on a cache line of its own, one per residue of the
+    // block index mod 8 (blocks of one residue share an XCD): counter s hands out the entries nb + 8 t + s, so a thousand workgroups drawing
+    // at once queue on eight words, not one (one word serves ~90 draws per microsecond). The draw runs two rounds ahead (the entry after the
+    // next, whose tile is already being fetched), by thread 0 only: ticket at the top of a round, the entry's record when the ticket has come
+    // back, both through LDS at the round's last barrier — no other wave ever waits for either.
+    uint32_t li = NONE, li_next = bid;
     if (li_next >= n_emit) return;
     uint4 item = make_uint4(0u, 0u, 0u, 0u), item_next = emit_items[li_next];
     int upper[3] = {G - 1, G - 1, G - 1};  // of the tile in LDS
@@ -909,6 +917,8 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
     __syncthreads();  // the chunk's tile is in LDS (phase 5 of the previous round)
     if (have) IVX_T(g, li, 1);
 
+    uint32_t ticket = 0u;
+    if (tid == 0 && have_next) ticket = nb + 8u * atomicAdd(cursor + 32u * (bid & 7u), 1u) + (bid & 7u);
     // ---- 0. the next chunk's tile: its loads travel while this chunk is meshed
     TileLoads T;
     if (have_next) tile_issue(g, item_next.x, T, tid);
@@ -1022,6 +1032,8 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
         }
     }
     }  // vcount
+    uint4 drawn = make_uint4(0u, 0u, 0u, 0u);
+    if (tid == 0 && have_next && ticket < n_emit) drawn = emit_items[ticket];
     __syncthreads();
     if (have) IVX_T(g, li, 3);  // vertices written
 
@@ -1066,6 +1078,10 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
         }
     }
     if (have_next) tile_records(T, s_rec, tid);
+    if (tid == 0 && have_next) {
+        s_ticket[0] = ticket;
+        s_ticket[1] = drawn.x, s_ticket[2] = drawn.y, s_ticket[3] = drawn.z, s_ticket[4] = drawn.w;
+    }
     __syncthreads();
     if (have) IVX_T(g, li, 4);  // quads written
 
@@ -1079,8 +1095,10 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
     if (!have_next) break;
     li = li_next;
     item = item_next;
-    li_next += nb;
-    if (li_next < n_emit) item_next = emit_items[li_next];
+    li_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket[0]);
+    item_next = make_uint4((uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket[1]), (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket[2]),
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket[3]), (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket[4]));
+    __syncthreads();  // (s_ticket, s_rec, s_hard are rewritten in the next round)
     }
 }
 

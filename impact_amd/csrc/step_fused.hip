@@ -139,13 +139,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     b -= a.nb[0];
     if (b < a.nb[1])
         sn::role_sn_emit<false>(b, a.nb[1], sn_params(a), a.positions, a.normals, a.indices, a.imats, a.submeshes, a.offsets + 2 * (size_t)a.n_chunks + 2,
-                                a.emit_items, a.vcap, a.icap, a.scap, nullptr, a.hard_count, a.hard_list);
+                                a.emit_items, a.vcap, a.icap, a.scap, nullptr, a.hard_count, a.hard_list, a.hard_count + 32);
 }
 
-// component ids; block 0 also hands the step's small results to the host block
-__global__ __launch_bounds__(256) void k_step_assign(StepArgs a) {
-    role_ccl_assign<true>(blockIdx.x, gridDim.x, a.g, a.rparent, a.multi_list /* root offsets inside a group */, a.ccl_group_sums, a.nb[0], a.rcompid,
-                          a.rscalar);
+// roles: 0 component ids, 1 the mesher's general pass over the chunks the main pass (k_step_emit) handed on — the launch after the main pass
+// anyway; as a launch of its own the general pass cost the step 4 us whether it had a chunk to do or not
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_step_assign(StepArgs a) {
+    const uint32_t b = blockIdx.x;
+    if (b < a.nb[0]) {
+        role_ccl_assign<true>(b, a.nb[0], a.g, a.rparent, a.multi_list /* root offsets inside a group */, a.ccl_group_sums, a.nb[0], a.rcompid, a.rscalar);
+        return;
+    }
+    sn::role_sn_emit_general<false>(b - a.nb[0], a.nb[1], sn_params(a), a.positions, a.normals, a.indices, a.imats, a.vmats, a.submeshes,
+                                    a.offsets + 2 * (size_t)a.n_chunks + 2, a.emit_items, a.vcap, a.icap, a.scap, nullptr, a.hard_count, a.hard_list);
 }
 
 // the results as a launch of their own (one block), ordered after everything enqueued so far
@@ -245,7 +251,7 @@ int ivx_launch_step_post2(ivx_grid* g, uint32_t stages) {
     return IVX_OK;
 }
 
-int ivx_launch_step_emit(ivx_grid* g, uint32_t stages) {
+int ivx_launch_step_emit(ivx_grid* g, uint32_t stages, bool general_in_assign) {
     StepArgs a = make_args(g);
     if (stages & IVX_STAGE_REGIONS) a.nb[0] = (g->n_chunks + 255u) / 256u;
     if (stages & IVX_STAGE_REMESH) a.nb[1] = sn::ivx_emit_grid(g, g->n_chunks);
@@ -253,17 +259,19 @@ int ivx_launch_step_emit(ivx_grid* g, uint32_t stages) {
     if (total == 0) return IVX_OK;
     hipLaunchKernelGGL(k_step_emit, dim3(total), dim3(256), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
-    if (stages & IVX_STAGE_REMESH) return ivx_launch_sn_emit_general(g);
+    // the chunks the main pass hands on: a role of k_step_assign when that launch follows (the caller says so), else a launch of its own
+    if ((stages & IVX_STAGE_REMESH) && !general_in_assign) return ivx_launch_sn_emit_general(g);
     return IVX_OK;
 }
 
 // groups of 256 chunks beyond what the fused assign scans in LDS take the stand-alone resolve path (ivx_launch_ccl_resolve)
 bool ivx_step_assign_fits(const ivx_grid* g) { return (g->n_chunks + 255u) / 256u <= ASSIGN_MAX_GROUPS; }
 
-int ivx_launch_step_assign(ivx_grid* g) {
+int ivx_launch_step_assign(ivx_grid* g, bool with_mesher_general) {
     StepArgs a = make_args(g);
     a.nb[0] = (g->n_chunks + 255u) / 256u;
-    hipLaunchKernelGGL(k_step_assign, dim3(a.nb[0]), dim3(256), 0, g->ctx->stream, a);
+    a.nb[1] = with_mesher_general ? sn::ivx_emit_general_grid(g, g->n_chunks) : 0u;
+    hipLaunchKernelGGL(k_step_assign, dim3(a.nb[0] + a.nb[1]), dim3(256), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

@@ -40,8 +40,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                  uint32_t* __restrict__ indices, unsigned long long* __restrict__ imats, ivx_submesh* __restrict__ submeshes,
                                                  const uint32_t* __restrict__ emit_count, const uint4* __restrict__ emit_items, uint32_t vcap, uint32_t icap,
                                                  uint32_t scap, const uint32_t* __restrict__ slots, uint32_t* __restrict__ hard_count,
-                                                 uint32_t* __restrict__ hard_list) {
-    role_sn_emit<SLOTS>(blockIdx.x, gridDim.x, p, positions, normals, indices, imats, submeshes, emit_count, emit_items, vcap, icap, scap, slots, hard_count, hard_list);
+                                                 uint32_t* __restrict__ hard_list, uint32_t* __restrict__ cursor) {
+    role_sn_emit<SLOTS>(blockIdx.x, gridDim.x, p, positions, normals, indices, imats, submeshes, emit_count, emit_items, vcap, icap, scap, slots, hard_count, hard_list,
+                        cursor);
 }
 // the chunks the main pass handed on (several materials around a vertex or a quad, more vertices than its LDS cache holds)
 template <bool SLOTS>
@@ -101,7 +102,7 @@ static SnParams make_params(ivx_grid* g) {
 int ivx_launch_sn_count(ivx_grid* g) {
     const uint32_t groups = (g->n_chunks + 255u) / 256u;
     uint32_t* gs = g->group_sums + groups;  // the first `groups` words belong to the region resolve
-    IVX_HIP_CHECK(hipMemsetAsync(gs, 0, sizeof(uint32_t) * (3 * groups + 1), g->ctx->stream));  // (stand-alone path; the fused step path presets in its first kernel)
+    IVX_HIP_CHECK(hipMemsetAsync(gs, 0, sizeof(uint32_t) * (3 * groups + IVX_SN_TAIL_WORDS), g->ctx->stream));  // (stand-alone path; the fused step path presets in its first kernel)
     g->scratch_dirty |= IVX_SCRATCH_SN;
     g->preset_fresh &= ~IVX_SCRATCH_SN;
     hipLaunchKernelGGL(k_sn_count, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts, gs, ivx_wc(g), g->active_list);
@@ -118,15 +119,18 @@ int ivx_launch_sn_scan(ivx_grid* g) {
     return IVX_OK;
 }
 
-// the counter of the chunks handed to the general pass: the word behind the Surface-Nets group totals (zeroed with them ahead of every count pass)
+// the counter of the chunks handed to the general pass: the word behind the Surface-Nets group totals (zeroed with them ahead of every count pass);
+// the main pass's eight list cursors follow at a stride of 32 words (a cache line each)
 uint32_t* ivx_sn_hard_count(ivx_grid* g) { return g->group_sums + 4 * (size_t)((g->n_chunks + 255u) / 256u); }
 
 int ivx_launch_sn_emit(ivx_grid* g) {
+    // (stand-alone path, also the re-emit after the buffers grew: the two words may hold an earlier emit's counts; the fused step presets them)
+    IVX_HIP_CHECK(hipMemsetAsync(ivx_sn_hard_count(g), 0, IVX_SN_TAIL_WORDS * sizeof(uint32_t), g->ctx->stream));
     const uint32_t blocks = ivx_emit_grid(g, g->n_chunks);
     hipLaunchKernelGGL(k_sn_emit<false>, dim3(blocks), dim3(256), 0, g->ctx->stream, make_params(g), g->positions, g->normals, g->indices,
                        reinterpret_cast<unsigned long long*>(g->index_materials), g->submeshes,
                        g->chunk_offsets + 2 * (size_t)g->n_chunks + 2, reinterpret_cast<const uint4*>(g->sn_list), (uint32_t)g->vcap, (uint32_t)g->icap,
-                       (uint32_t)g->scap, nullptr, ivx_sn_hard_count(g), g->sn_hard);
+                       (uint32_t)g->scap, nullptr, ivx_sn_hard_count(g), g->sn_hard, ivx_sn_hard_count(g) + 32);
     IVX_HIP_CHECK(hipGetLastError());
     return ivx_launch_sn_emit_general(g);
 }
@@ -145,10 +149,11 @@ int ivx_launch_sn_emit_general(ivx_grid* g) {
 // from the host-side submesh manager; d_count holds their number
 int ivx_launch_sn_emit_list(ivx_grid* g, uint32_t n_records, const uint32_t* d_count, const void* d_records, const uint32_t* d_slots) {
     if (n_records == 0) return IVX_OK;
+    IVX_HIP_CHECK(hipMemsetAsync(ivx_sn_hard_count(g), 0, IVX_SN_TAIL_WORDS * sizeof(uint32_t), g->ctx->stream));
     hipLaunchKernelGGL(k_sn_emit<true>, dim3(ivx_emit_grid(g, n_records)), dim3(256), 0, g->ctx->stream, make_params(g), g->positions, g->normals,
                        g->indices, reinterpret_cast<unsigned long long*>(g->index_materials), g->submeshes,
                        d_count, reinterpret_cast<const uint4*>(d_records), (uint32_t)g->vcap, (uint32_t)g->icap, (uint32_t)g->scap, d_slots, ivx_sn_hard_count(g),
-                       g->sn_hard);
+                       g->sn_hard, ivx_sn_hard_count(g) + 1);
     IVX_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(k_sn_emit_general<true>, dim3(ivx_emit_general_grid(g, n_records)), dim3(256), 0, g->ctx->stream, make_params(g), g->positions, g->normals,
                        g->indices, reinterpret_cast<unsigned long long*>(g->index_materials), reinterpret_cast<uint4*>(g->vertex_materials), g->submeshes,

@@ -162,6 +162,7 @@ __device__ __forceinline__ void role_result_gather(const uint32_t* __restrict__ 
 
 // Preset of the scratch words a step's stages start from (what k_step_preset did in a launch of its own), as a role of the
 // step's first kernel: `gid` = global thread index of that launch (it must have at least max(28, n_sn) threads).
+// n_sn = the group totals proper (3 per group of 256 chunks).
 struct PresetArgs {
     uint32_t groups;        // IVX_SCRATCH_* bits to preset
     uint32_t* rscalar;      // [0..16) region scalars
@@ -172,6 +173,8 @@ struct PresetArgs {
 __device__ __forceinline__ void role_preset(const PresetArgs& a, uint32_t gid) {
     if ((a.groups & IVX_SCRATCH_REGIONS) && gid < 16u) a.rscalar[gid] = 0u;
     if ((a.groups & IVX_SCRATCH_SN) && gid < a.n_sn) a.sn_sums[gid] = 0u;
+    // behind the group totals: the general mesher pass's counter and the main pass's eight list cursors, a cache line apart (IVX_SN_TAIL_WORDS)
+    if ((a.groups & IVX_SCRATCH_SN) && gid < 9u) a.sn_sums[a.n_sn + 32u * gid] = 0u;
     if ((a.groups & IVX_SCRATCH_EVAL) && gid < 5u && a.eval_count) a.eval_count[gid] = 0u;
     // the sampler's list counters rolled over after their last reader (k_sdf_eval): kept as statistics in words [8..13), zero for the
     // next step's pre-pass — the step after needs no kernel ahead of the pre-pass just to clear five words
