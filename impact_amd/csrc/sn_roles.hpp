@@ -458,6 +458,159 @@ __device__ __forceinline__ void role_sn_count(uint32_t bid, uint32_t nb, SnParam
     }
 }
 
+// The count pass with one WAVE per listed chunk (four chunks per workgroup, no workgroup barrier): the pass is a chain of two trips to memory
+// (list entry, then the sign rows) around a few hundred instructions, so what it needs is chunks in flight — 32 per CU this way against 8
+// with a workgroup per chunk. Lanes 0..26 fetch the first word of the 27 chunk records of the tile's neighbourhood and the rows take their
+// three kinds from those lanes (ds_bpermute) instead of loading them per row; a lane holds the three 16-bit sign masks of each of its six rows.
+// `lds`: 4 x NROWS words of the caller's LDS (the fused launch lends the exact-numbering role's block: a role of its own LDS on top would push
+// the launch past the eight workgroups per CU its register budget is set for).
+__device__ __forceinline__ void role_sn_count_waves(uint32_t bid, uint32_t nb, SnParams p, uint32_t* __restrict__ counts, uint32_t* __restrict__ group_sums,
+                                                    const uint32_t* __restrict__ work_counts, const uint32_t* __restrict__ active_list, uint32_t* lds, uint32_t COUNT_RUN) {
+    constexpr int WC = (NCROWS + 63) / 64;
+    const GridView& g = p.g;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* s_neg = lds + wave * NROWS;
+    const uint32_t n_active = work_counts[0];
+    // A wave takes runs of COUNT_RUN consecutive list entries and adds a run's totals to the group sums once per group it met, not once per
+    // chunk: 256 consecutive chunks share the three words of a group, and three atomics per chunk on one cache line — 97 000 on the all-surface
+    // 512^3 grid — were what the pass took its 0.22 ms for, whatever the rest of it did.
+    uint32_t acc_group = 0xFFFFFFFFu, acc_v = 0u, acc_i = 0u, acc_s = 0u;  // (lane 0)
+    auto flush = [&]() {
+        if (lane == 0 && acc_group != 0xFFFFFFFFu) {
+            uint32_t* gs = group_sums + 3 * acc_group;
+            atomicAdd(gs, acc_v);
+            atomicAdd(gs + 1, acc_i);
+            atomicAdd(gs + 2, acc_s);
+        }
+        acc_v = acc_i = acc_s = 0u;
+    };
+    for (uint32_t run = ivx_xcd_remap(bid, nb) * 4u + wave; run * COUNT_RUN < n_active; run += nb * 4u)
+    for (uint32_t li = run * COUNT_RUN; li < run * COUNT_RUN + COUNT_RUN && li < n_active; ++li) {
+        const uint32_t entry = active_list[li];
+        const uint32_t chunk = IVX_LIST_CHUNK(entry);
+        if (!IVX_LIST_EXPOSED(entry)) {
+            if (lane == 0) reinterpret_cast<uint2*>(counts)[chunk] = make_uint2(0u, 0u);
+            continue;
+        }
+        const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
+        // the neighbourhood's records (a chunk that is not there reads as Void: kind 0)
+        uint32_t rec = 0u;
+        if (lane < 27u) {
+            const int ni = ci + (int)(lane / 9u) - 1, nj = cj + (int)((lane / 3u) % 3u) - 1, nk = ck + (int)(lane % 3u) - 1;
+            if (nj >= 0 && nj < (int)g.cy && nk >= 0 && nk < (int)g.cz) {
+                const ivx_chunk_info* rp = nullptr;
+                if (ni >= 0 && ni < (int)g.cx) rp = g.info + (size_t)((ni * (int)g.cy + nj) * (int)g.cz + nk);
+                else if (g.ghost_info[ni < 0 ? 0 : 1]) rp = g.ghost_info[ni < 0 ? 0 : 1] + (nj * (int)g.cz + nk);
+                if (rp) rec = *reinterpret_cast<const uint32_t*>(rp);
+            }
+        }
+        // Every load is issued before any is looked at. The chunk's OWN 256 rows first, four per lane: row = lane + 64 t is row (i, j) =
+        // (row >> 4, row & 15) of the chunk and of the chunks below / above along k, at a uniform base + 2 row — no per-row chunk arithmetic,
+        // and their three kinds are the same for all (scalars). Then the 68 rows of the tile's rim, which belong to eight other chunk
+        // columns: the general form, two turns (64 + 4 rows).
+        const uint16_t* own = g.signs + (size_t)chunk * 256;
+        const uint16_t* own_lo = ck > 0 ? own - 256 : own;  // (clamped to the chunk itself where there is no neighbour; not consulted then)
+        const uint16_t* own_hi = ck + 1 < (int)g.cz ? own + 256 : own;
+        uint32_t a0[4], a1[4], a2[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t row = lane + 64u * (uint32_t)t;
+            a1[t] = own[row];
+            a0[t] = own_lo[row];
+            a2[t] = own_hi[row];
+        }
+        uint32_t m0[2], m1[2], m2[2];
+        int ra[2], rb[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int h = (int)lane + 64 * t;  // rim row h: the two i-faces (18 rows each), then the two j-faces (16 + 16, interleaved)
+            ra[t] = h < 18 ? 0 : (h < 36 ? G - 1 : 1 + ((h - 36) >> 1));
+            rb[t] = h < 18 ? h : (h < 36 ? h - 18 : ((h & 1) ? G - 1 : 0));
+            int gi = ci * 16 + ra[t] - 1, gj = cj * 16 + rb[t] - 1;
+            const bool real = h < 68 && row_mode(g, gi, gj) == 1u;
+            gi = real ? gi : ci * 16;
+            gj = real ? gj : cj * 16;
+            const uint32_t ch = ((gi >> 4) * g.cy + (gj >> 4)) * g.cz + ck;
+            const uint16_t* sp = g.signs + (size_t)ch * 256 + (((gi & 15) << 4) | (gj & 15));
+            m1[t] = *sp;
+            m0[t] = *(ck > 0 ? sp - 256 : sp);
+            m2[t] = *(ck + 1 < (int)g.cz ? sp + 256 : sp);
+        }
+        {
+            const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)rec, 12) & 0xFFu, k1 = (uint32_t)__builtin_amdgcn_readlane((int)rec, 13) & 0xFFu,
+                           k2 = (uint32_t)__builtin_amdgcn_readlane((int)rec, 14) & 0xFFu;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t row = lane + 64u * (uint32_t)t;
+                uint32_t bits = (k1 == KIND_NONUNIFORM ? a1[t] : (k1 == KIND_UNIFORM ? 0xFFFFu : 0u)) << 1;
+                if (ck > 0) bits |= k0 == KIND_NONUNIFORM ? ((a0[t] >> 15) & 1u) : (k0 == KIND_UNIFORM ? 1u : 0u);
+                if (ck + 1 < (int)g.cz) bits |= (k2 == KIND_NONUNIFORM ? (a2[t] & 1u) : (k2 == KIND_UNIFORM ? 1u : 0u)) << 17;
+                s_neg[((row >> 4) + 1u) * G + (row & 15u) + 1u] = bits;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int h = (int)lane + 64 * t;
+            const int gi = ci * 16 + ra[t] - 1, gj = cj * 16 + rb[t] - 1;
+            const uint32_t mode = h < 68 ? row_mode(g, gi, gj) : 0u;
+            // (every lane takes part in the exchange; the column of a row that is not fetched is the chunk's own)
+            const int col = mode == 1u ? (((gi >> 4) - ci + 1) * 3 + ((gj >> 4) - cj + 1)) * 3 : 12;
+            const uint32_t k0 = (uint32_t)__shfl((int)rec, col, 64) & 0xFFu, k1 = (uint32_t)__shfl((int)rec, col + 1, 64) & 0xFFu,
+                           k2 = (uint32_t)__shfl((int)rec, col + 2, 64) & 0xFFu;
+            uint32_t bits = 0u;
+            if (mode == 1u) {
+                bits = (k1 == KIND_NONUNIFORM ? m1[t] : (k1 == KIND_UNIFORM ? 0xFFFFu : 0u)) << 1;
+                if (ck > 0) bits |= k0 == KIND_NONUNIFORM ? ((m0[t] >> 15) & 1u) : (k0 == KIND_UNIFORM ? 1u : 0u);
+                if (ck + 1 < (int)g.cz) bits |= (k2 == KIND_NONUNIFORM ? (m2[t] & 1u) : (k2 == KIND_UNIFORM ? 1u : 0u)) << 17;
+            } else if (mode == 2u) {  // a row of a ghost layer: from the ghost planes
+                uint32_t sd[6], ty[6];
+                fetch_row_serial(g, gi, gj, ck, sd, ty);
+                bits = ((sd[0] >> 7) & 1u) | (neg16(sd + 1) << 1) | (((sd[5] >> 7) & 1u) << 17);
+            }
+            if (h < 68) s_neg[ra[t] * G + rb[t]] = bits;
+        }
+        // the upper layer of cubes belongs to the upper neighbour chunk when that chunk is non-uniform (surface_nets.rs:252-261)
+        int upper[3] = {G - 1, G - 1, G - 1};
+        if (((uint32_t)__shfl((int)rec, 22, 64) & 0xFFu) == KIND_NONUNIFORM) upper[0] -= 1;
+        if (((uint32_t)__shfl((int)rec, 16, 64) & 0xFFu) == KIND_NONUNIFORM) upper[1] -= 1;
+        if (((uint32_t)__shfl((int)rec, 14, 64) & 0xFFu) == KIND_NONUNIFORM) upper[2] -= 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t nv = 0, nq = 0;
+#pragma unroll
+        for (int it = 0; it < WC; ++it) {
+            const int cr = (int)lane + 64 * it;
+            if (cr < NCROWS) {
+                uint32_t vb, qx, qy, qz;
+                cube_row_bits(s_neg, cr / 17, cr % 17, upper, vb, qx, qy, qz);
+                nv += __popc(vb);
+                nq += __popc(qx) + __popc(qy) + __popc(qz);
+            }
+        }
+        const uint32_t wv = ivx_wave_sum(nv), wq = ivx_wave_sum(nq);
+        if (lane == 0) {
+            reinterpret_cast<uint2*>(counts)[chunk] = make_uint2(wv, wq * 6u);
+        }
+        if (wq) {  // first level of the scan over chunks: totals per group of 256 chunks (vertices, indices, submeshes)
+            if ((chunk >> 8) != acc_group) {
+                flush();
+                acc_group = chunk >> 8;
+            }
+            acc_v += wv, acc_i += wq * 6u, acc_s += 1u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // (the rows in LDS are rewritten for the wave's next chunk)
+    }
+    flush();
+}
+
+// consecutive list entries a wave of the count pass takes per turn: 1 while that still fills the chip (32 waves per CU), more for longer lists
+static inline uint32_t ivx_count_run(const ivx_grid* g) {
+    const uint32_t r = ivx_list_grid(g) / ((uint32_t)g->ctx->n_cu * 32u);
+    return r < 1u ? 1u : (r > 8u ? 8u : r);
+}
+
 // Exclusive scan over chunks in chunk-linear order of (vertices, indices, submesh) with chunks whose
 // index count is zero contributing nothing (mesh.rs:321-323). offsets[2c], offsets[2c+1]; totals at
 // offsets[2n..2n+3); submesh rank at ranks[c].

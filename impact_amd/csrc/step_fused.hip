@@ -67,6 +67,7 @@ struct StepArgs {
     // results
     uint32_t* host_block;     // null: no gather in this launch
     const uint32_t* eval_count;
+    uint32_t count_run;       // k_step_post1: list entries per wave and turn of the mesher's count role
     uint32_t seq;             // k_step_gather: the step's sequence number, written last (the host's completion doorbell)
 };
 
@@ -82,9 +83,10 @@ __device__ __forceinline__ sn::SnParams sn_params(const StepArgs& a) {
 // (amdgpu_waves_per_eu(8): 64 VGPRs. The count role is a latency-bound gather with little state and wants all eight workgroups a CU can
 // hold; the exact numbering, which would take 127 registers, spills ~60 words instead — measured: count pass -3 us, edit leg unchanged.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_step_post1(StepArgs a) {
+    __shared__ CclShared sh;  // (the exact numbering's block; the count role borrows its first 5 KB)
     uint32_t b = blockIdx.x;
     if (b < a.nb[0]) {
-        sn::role_sn_count(b, a.nb[0], sn_params(a), a.counts, a.sn_group_sums, a.work_count, a.active_list);
+        sn::role_sn_count_waves(b, a.nb[0], sn_params(a), a.counts, a.sn_group_sums, a.work_count, a.active_list, sh.par, a.count_run);
         return;
     }
     b -= a.nb[0];
@@ -94,7 +96,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     b -= a.nb[1];
     if (b < a.nb[2]) {
-        __shared__ CclShared sh;
         role_ccl_local_exact(b, a.nb[2], sh, a.flags, a.labels, a.info, a.rparent, a.rscalar, a.multi_list);
         return;
     }
@@ -217,7 +218,10 @@ static StepArgs make_args(ivx_grid* g) {
 int ivx_launch_step_post1(ivx_grid* g, uint32_t stages) {
     StepArgs a = make_args(g);
     const uint32_t groups = (g->n_chunks + 255u) / 256u;
-    if (stages & IVX_STAGE_REMESH) a.nb[0] = ivx_list_grid(g);
+    if (stages & IVX_STAGE_REMESH) {  // (a wave per run of listed chunks)
+        a.count_run = sn::ivx_count_run(g);
+        a.nb[0] = (ivx_list_grid(g) + 4u * a.count_run - 1u) / (4u * a.count_run);
+    }
     if (stages & IVX_STAGE_REGIONS) {
         a.nb[1] = (g->cc[0] * g->cc[1] + 3u) / 4u;
         a.nb[2] = g->n_chunks < 128u ? g->n_chunks : 128u;

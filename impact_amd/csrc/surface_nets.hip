@@ -26,8 +26,9 @@ using namespace ivx_roles::sn;
 
 // stand-alone forms of the roles in sn_roles.hpp
 __global__ __launch_bounds__(256) void k_sn_count(SnParams p, uint32_t* __restrict__ counts, uint32_t* __restrict__ group_sums,
-                                                  const uint32_t* __restrict__ work_counts, const uint32_t* __restrict__ active_list) {
-    role_sn_count(blockIdx.x, gridDim.x, p, counts, group_sums, work_counts, active_list);
+                                                  const uint32_t* __restrict__ work_counts, const uint32_t* __restrict__ active_list, uint32_t run) {
+    __shared__ uint32_t s_rows[4 * NROWS];
+    role_sn_count_waves(blockIdx.x, gridDim.x, p, counts, group_sums, work_counts, active_list, s_rows, run);
 }
 __global__ __launch_bounds__(256) void k_sn_scan(uint32_t n_chunks, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ group_sums,
                                                  uint32_t* __restrict__ offsets, uint32_t* __restrict__ ranks, uint4* __restrict__ emit_items) {
@@ -105,7 +106,9 @@ int ivx_launch_sn_count(ivx_grid* g) {
     IVX_HIP_CHECK(hipMemsetAsync(gs, 0, sizeof(uint32_t) * (3 * groups + IVX_SN_TAIL_WORDS), g->ctx->stream));  // (stand-alone path; the fused step path presets in its first kernel)
     g->scratch_dirty |= IVX_SCRATCH_SN;
     g->preset_fresh &= ~IVX_SCRATCH_SN;
-    hipLaunchKernelGGL(k_sn_count, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts, gs, ivx_wc(g), g->active_list);
+    const uint32_t run = ivx_count_run(g);
+    hipLaunchKernelGGL(k_sn_count, dim3((ivx_list_grid(g) + 4u * run - 1u) / (4u * run)), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts, gs, ivx_wc(g),
+                       g->active_list, run);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
