@@ -844,6 +844,9 @@ __device__ __forceinline__ void edge_centroid(const float d[8], uint32_t neg, V3
     for (int e = 0; e < 12; ++e) {
         const int c1 = E1[e], c2 = E2[e];
         const bool crossed = (((neg >> c1) ^ (neg >> c2)) & 1u) != 0u;
+        // (an edge that no vertex of the wave crosses adds +0 to every sum: skipped for the wave — on a locally flat surface that is
+        // most of the twelve, e.g. every edge along the surface)
+        if (__builtin_amdgcn_ballot_w64(crossed) == 0ull) continue;
         const float q = div_ranged(d[c1], d[c1] - d[c2]);
         const float t = crossed ? q : 0.0f;
         const float s = crossed ? ((1.0f - q) + q) : 0.0f;
@@ -869,6 +872,14 @@ struct TileLoads {
     RowData L[2];
     uint32_t rec;
 };
+// rim row h (0..67) of the 18 x 18 rows of a tile: the two i-faces (18 rows each), then the two j-faces (16 + 16, interleaved)
+__device__ __forceinline__ void rim_row(int h, int& a, int& b) {
+    a = h < 18 ? 0 : (h < 36 ? G - 1 : 1 + ((h - 36) >> 1));
+    b = h < 18 ? h : (h < 36 ? h - 18 : ((h & 1) ? G - 1 : 0));
+}
+// Thread t takes the chunk's OWN row t — row (i, j) = (t >> 4, t & 15), tile row (i + 1, j + 1): its planes at a uniform base + 16 t, its k-halo
+// bytes at a uniform base + t, its three chunk kinds the same for all 256 rows — and threads 0..67 a row of the tile's rim as well, which
+// belongs to one of eight other chunk columns and takes the per-row arithmetic (half of the instructions of both steps when every row did).
 __device__ __forceinline__ void tile_issue(const GridView& g, uint32_t chunk, TileLoads& T, uint32_t tid) {
     tid = opaque(tid);
     const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
@@ -883,44 +894,102 @@ __device__ __forceinline__ void tile_issue(const GridView& g, uint32_t chunk, Ti
             if (rp) T.rec = *reinterpret_cast<const uint32_t*>(rp);
         }
     }
-    // (straight-line: a row that is not fetched — beyond the 324, outside the grid, in a ghost layer — loads the chunk's own first row instead;
-    // with the loads under conditions the compiler merged the two rounds' registers and waited for the first round to copy it aside)
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int r = (int)tid + 256 * it;
-        const int a = r / G, b = r - a * G;
+    {  // the own row
+        RowData& L = T.L[0];
+        const size_t o = ((size_t)chunk << 12) + ((size_t)tid << 4);
+        // (the k-halo bytes as the aligned WORDS around them, the byte taken in tile_finish: a byte load is a load and an extension to the
+        // compiler, and it moved the extension — an operation on the loaded register — up to the load, i.e. waited for the load here)
+        const uint32_t* kf = reinterpret_cast<const uint32_t*>(g.kface + (size_t)chunk * 1024) + (tid >> 2);
+        const uint32_t* kf0 = ck > 0 ? kf - 256 : kf;  // (clamped to the chunk itself where there is no neighbour; not consulted then)
+        const uint32_t* kf2 = ck + 1 < (int)g.cz ? kf + 256 : kf;
+        L.s4 = *reinterpret_cast<const uint4*>(g.sdf + o);
+        L.t4 = *reinterpret_cast<const uint4*>(g.type + o);
+        L.b0s = kf0[64];
+        L.b0t = kf0[192];
+        L.b2s = kf2[0];
+        L.b2t = kf2[128];
+    }
+    {  // a rim row (straight-line: a thread without one, or whose row lies outside the grid or in a ghost layer, loads the chunk's own first
+       // row instead; with the loads under conditions the compiler merged the two rows' registers and waited for the first to copy it aside)
+        RowData& L = T.L[1];
+        int a, b;
+        rim_row((int)tid, a, b);
         int gi = ci * 16 + a - 1, gj = cj * 16 + b - 1;
-        const bool real = r < NROWS && row_mode(g, gi, gj) == 1u;
+        const bool real = tid < 68u && row_mode(g, gi, gj) == 1u;
         gi = real ? gi : ci * 16;
         gj = real ? gj : cj * 16;
-        RowData& L = T.L[it];
         const size_t cidx = (size_t)(((gi >> 4) * g.cy + (gj >> 4)) * g.cz) + (size_t)ck;
         const uint32_t rix = (uint32_t)(((gi & 15) << 4) | (gj & 15));
         const size_t o = (cidx << 12) + ((size_t)rix << 4);
-        const uint8_t* kf = g.kface + cidx * 1024 + rix;
-        const uint8_t* kf0 = ck > 0 ? kf - 1024 : kf;  // (clamped to the chunk itself where there is no neighbour; not consulted then)
-        const uint8_t* kf2 = ck + 1 < (int)g.cz ? kf + 1024 : kf;
+        const uint32_t* kf = reinterpret_cast<const uint32_t*>(g.kface + cidx * 1024) + (rix >> 2);
+        const uint32_t* kf0 = ck > 0 ? kf - 256 : kf;
+        const uint32_t* kf2 = ck + 1 < (int)g.cz ? kf + 256 : kf;
         L.s4 = *reinterpret_cast<const uint4*>(g.sdf + o);
         L.t4 = *reinterpret_cast<const uint4*>(g.type + o);
-        L.b0s = kf0[256];
-        L.b0t = kf0[768];
+        L.b0s = kf0[64];
+        L.b0t = kf0[192];
         L.b2s = kf2[0];
-        L.b2t = kf2[512];
+        L.b2t = kf2[128];
     }
 }
 // the records into LDS, ahead of the barrier that precedes tile_finish
 __device__ __forceinline__ void tile_records(TileLoads& T, uint32_t* s_rec, uint32_t tid) {
     if (tid < 27u) s_rec[tid] = T.rec;
 }
+// one padded row into the LDS tile: `k0, k1, k2` the first record words of the row's chunks below / own / above along k
+// `rix`: the row's index in its chunk (its k-halo bytes are byte rix & 3 of the words fetched)
+__device__ __forceinline__ void tile_row_store(RowData& L, uint32_t rix, uint32_t w0, uint32_t w1, uint32_t w2, bool has_lo, bool has_hi, uint32_t sd[6],
+                                               uint32_t ty[6]) {
+    // (the loaded registers pass through an empty asm first: the compiler may otherwise move the first operation on a loaded value — a
+    // mask, a shift — up to the load, a phase ago, and wait for the load there)
+    asm volatile("" : "+v"(L.s4.x), "+v"(L.s4.y), "+v"(L.s4.z), "+v"(L.s4.w), "+v"(L.t4.x), "+v"(L.t4.y), "+v"(L.t4.z), "+v"(L.t4.w));
+    asm volatile("" : "+v"(L.b0s), "+v"(L.b0t), "+v"(L.b2s), "+v"(L.b2t));
+    const ivx_chunk_info c0 = record_of(w0), c1 = record_of(w1), c2 = record_of(w2);
+    const bool d1 = c1.kind == KIND_NONUNIFORM;
+    const uint32_t us = ivx_uniform_sdf(c1.kind) * 0x01010101u, ut = ivx_uniform_type(c1) * 0x01010101u;
+    sd[1] = d1 ? L.s4.x : us, sd[2] = d1 ? L.s4.y : us, sd[3] = d1 ? L.s4.z : us, sd[4] = d1 ? L.s4.w : us;
+    ty[1] = d1 ? L.t4.x : ut, ty[2] = d1 ? L.t4.y : ut, ty[3] = d1 ? L.t4.z : ut, ty[4] = d1 ? L.t4.w : ut;
+    const uint32_t sh = 8u * (rix & 3u);
+    if (has_lo) {
+        const bool dense = c0.kind == KIND_NONUNIFORM;
+        sd[0] = dense ? ((L.b0s >> sh) & 0xFFu) : ivx_uniform_sdf(c0.kind);
+        ty[0] = dense ? ((L.b0t >> sh) & 0xFFu) : ivx_uniform_type(c0);
+    }
+    if (has_hi) {
+        const bool dense = c2.kind == KIND_NONUNIFORM;
+        sd[5] = dense ? ((L.b2s >> sh) & 0xFFu) : ivx_uniform_sdf(c2.kind);
+        ty[5] = dense ? ((L.b2t >> sh) & 0xFFu) : ivx_uniform_type(c2);
+    }
+}
+__device__ __forceinline__ void tile_row_write(int r, const uint32_t sd[6], const uint32_t ty[6], uint8_t* s_sd, uint8_t* s_ty, uint32_t* s_neg) {
+    s_neg[r] = ((sd[0] >> 7) & 1u) | (neg16(sd + 1) << 1) | (((sd[5] >> 7) & 1u) << 17);
+    uint8_t* ds = s_sd + r * RS;
+    uint8_t* dt = s_ty + r * RS;
+    ds[3] = (uint8_t)sd[0];
+    dt[3] = (uint8_t)ty[0];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        reinterpret_cast<uint32_t*>(ds + 4)[q] = sd[1 + q];
+        reinterpret_cast<uint32_t*>(dt + 4)[q] = ty[1 + q];
+    }
+    ds[20] = (uint8_t)sd[5];
+    dt[20] = (uint8_t)ty[5];
+}
 __device__ __forceinline__ void tile_finish(const GridView& g, uint32_t chunk, TileLoads& T, const uint32_t* s_rec, uint8_t* s_sd, uint8_t* s_ty, uint32_t* s_neg,
                                             uint32_t tid, int* upper) {
     tid = opaque(tid);
     const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int r = (int)tid + 256 * it;
-        if (r >= NROWS) break;
-        const int a = r / G, b = r - a * G;
+    const bool has_lo = ck > 0, has_hi = ck + 1 < (int)g.cz;
+    {  // the own row (always in the grid; chunk column (0, 0) of the neighbourhood: records 12, 13, 14)
+        uint32_t sd[6], ty[6];
+        sd[0] = sd[5] = 0x7Fu;
+        ty[0] = ty[5] = 0xFFu;
+        tile_row_store(T.L[0], tid, s_rec[12], s_rec[13], s_rec[14], has_lo, has_hi, sd, ty);
+        tile_row_write((int)(((tid >> 4) + 1u) * G + (tid & 15u) + 1u), sd, ty, s_sd, s_ty, s_neg);
+    }
+    if (tid < 68u) {  // a rim row
+        int a, b;
+        rim_row((int)tid, a, b);
         const int gi = ci * 16 + a - 1, gj = cj * 16 + b - 1;
         uint32_t sd[6], ty[6];
         sd[0] = sd[5] = 0x7Fu;
@@ -931,41 +1000,11 @@ __device__ __forceinline__ void tile_finish(const GridView& g, uint32_t chunk, T
         if (mode == 2u) {
             fetch_row_serial(g, gi, gj, ck, sd, ty);
         } else if (mode == 1u) {
-            RowData& L = T.L[it];
-            // (the loaded registers pass through an empty asm first: the compiler may otherwise move the first operation on a loaded value — a
-            // mask, a shift — up to the load, a phase ago, and wait for the load there)
-            asm volatile("" : "+v"(L.s4.x), "+v"(L.s4.y), "+v"(L.s4.z), "+v"(L.s4.w), "+v"(L.t4.x), "+v"(L.t4.y), "+v"(L.t4.z), "+v"(L.t4.w));
-            asm volatile("" : "+v"(L.b0s), "+v"(L.b0t), "+v"(L.b2s), "+v"(L.b2t));
             // the row's chunk column in the neighbourhood: (gi >> 4) - ci and (gj >> 4) - cj are -1, 0 or 1
             const int col = (((gi >> 4) - ci + 1) * 3 + ((gj >> 4) - cj + 1)) * 3;
-            const ivx_chunk_info c0 = record_of(s_rec[col]), c1 = record_of(s_rec[col + 1]), c2 = record_of(s_rec[col + 2]);
-            const bool d1 = c1.kind == KIND_NONUNIFORM;
-            const uint32_t us = ivx_uniform_sdf(c1.kind) * 0x01010101u, ut = ivx_uniform_type(c1) * 0x01010101u;
-            sd[1] = d1 ? L.s4.x : us, sd[2] = d1 ? L.s4.y : us, sd[3] = d1 ? L.s4.z : us, sd[4] = d1 ? L.s4.w : us;
-            ty[1] = d1 ? L.t4.x : ut, ty[2] = d1 ? L.t4.y : ut, ty[3] = d1 ? L.t4.z : ut, ty[4] = d1 ? L.t4.w : ut;
-            if (ck > 0) {
-                const bool dense = c0.kind == KIND_NONUNIFORM;
-                sd[0] = dense ? L.b0s : ivx_uniform_sdf(c0.kind);
-                ty[0] = dense ? L.b0t : ivx_uniform_type(c0);
-            }
-            if (ck + 1 < (int)g.cz) {
-                const bool dense = c2.kind == KIND_NONUNIFORM;
-                sd[5] = dense ? L.b2s : ivx_uniform_sdf(c2.kind);
-                ty[5] = dense ? L.b2t : ivx_uniform_type(c2);
-            }
+            tile_row_store(T.L[1], (uint32_t)(((gi & 15) << 4) | (gj & 15)), s_rec[col], s_rec[col + 1], s_rec[col + 2], has_lo, has_hi, sd, ty);
         }
-        s_neg[r] = ((sd[0] >> 7) & 1u) | (neg16(sd + 1) << 1) | (((sd[5] >> 7) & 1u) << 17);
-        uint8_t* ds = s_sd + r * RS;
-        uint8_t* dt = s_ty + r * RS;
-        ds[3] = (uint8_t)sd[0];
-        dt[3] = (uint8_t)ty[0];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            reinterpret_cast<uint32_t*>(ds + 4)[q] = sd[1 + q];
-            reinterpret_cast<uint32_t*>(dt + 4)[q] = ty[1 + q];
-        }
-        ds[20] = (uint8_t)sd[5];
-        dt[20] = (uint8_t)ty[5];
+        tile_row_write(a * G + b, sd, ty, s_sd, s_ty, s_neg);
     }
     // the upper layer of cubes belongs to the upper neighbour chunk when that chunk is non-uniform (surface_nets.rs:252-261); neighbourhood
     // entries (di, dj, dk) = (1,0,0), (0,1,0), (0,0,1); a chunk that is not there reads as Void
@@ -1215,7 +1254,14 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
             const V3 q3 = mk(s_vpos[0][v3], s_vpos[1][v3], s_vpos[2][v3]), q4 = mk(s_vpos[0][v4], s_vpos[1][v4], s_vpos[2][v4]);
             const uint32_t b1 = s_vsm[v1], b2 = s_vsm[v2], b3 = s_vsm[v3], b4 = s_vsm[v4];
             uint32_t quad[6];
-            if (len3(sub(q1, q4)) < len3(sub(q2, q3))) {
+            // the shorter diagonal: |q1 - q4| < |q2 - q3| on the rounded lengths (surface_nets.rs:360-381). Where the SQUARED lengths already
+            // say "not shorter" the (correctly rounded, hence monotonic) roots cannot say otherwise; only a wave with a quad whose squared
+            // lengths differ the other way takes the roots — none on a flat piece of surface, where the diagonals are equal.
+            const V3 e14 = sub(q1, q4), e23 = sub(q2, q3);
+            const float sq14 = (e14.x * e14.x + e14.y * e14.y) + e14.z * e14.z, sq23 = (e23.x * e23.x + e23.y * e23.y) + e23.z * e23.z;
+            bool first = sq14 < sq23;
+            if (__builtin_amdgcn_ballot_w64(first) != 0ull) first = sqrtf(sq14) < sqrtf(sq23);
+            if (first) {
                 if (negative_face) { quad[0] = v1; quad[1] = v4; quad[2] = v2; quad[3] = v1; quad[4] = v3; quad[5] = v4; }
                 else { quad[0] = v1; quad[1] = v2; quad[2] = v4; quad[3] = v1; quad[4] = v4; quad[5] = v3; }
             } else if (negative_face) { quad[0] = v2; quad[1] = v3; quad[2] = v4; quad[3] = v2; quad[4] = v1; quad[5] = v3; }

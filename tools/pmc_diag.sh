@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 i=0
 for grp in "$@"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp -d "$out/p$i" -o p -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-pile > "$out/p$i.log" 2>&1
+  rocprofv3 --kernel-trace --pmc $grp -d "$out/p$i" -o p -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-pile --plain ${IVX_DIAG_ARGS:-} > "$out/p$i.log" 2>&1
   python - "$(ls "$out"/p$i/*.db | tail -1)" <<'PY'
 import sqlite3, sys, re, collections
 db = sqlite3.connect(sys.argv[1])

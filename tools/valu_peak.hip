@@ -7,6 +7,8 @@
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_fma(float* out, int iters, float a, float b) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p0 = {(float)threadIdx.x, 1.0f}, p1 = p0 + 1.0f, p2 = p0 + 2.0f, p3 = p0 + 3.0f, pa = {a, a}, pb = {b, b};
     float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
@@ -21,6 +23,26 @@ __global__ __launch_bounds__(256) void k_fma(float* out, int iters, float a, flo
                              "v_mul_f32 %4, %4, %8\n v_add_f32 %5, %5, %9\n v_mul_f32 %6, %6, %8\n v_add_f32 %7, %7, %9\n"
                              : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
                              : "v"(a), "v"(b));
+            } else if (MODE == 3) {  // packed f32: two lanes' worth per instruction (counted as ONE wave-instruction below)
+                asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
+                             "v_pk_mul_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %5\n v_pk_mul_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %5\n"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3)
+                             : "v"(pa), "v"(pb));
+            } else if (MODE == 4) {  // single ops of the integer mix, one kind at a time would go here; this one: v_cndmask only
+                asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %9, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %9, vcc\n"
+                             "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %9, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %9, vcc\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+                             : "v"(a), "v"(b));
+            } else if (MODE == 5) {  // v_and / v_or / v_xor / v_add_u32 only
+                asm volatile("v_and_b32 %0, %0, %8\n v_or_b32 %1, %1, %9\n v_xor_b32 %2, %2, %8\n v_add_u32 %3, %3, %9\n"
+                             "v_and_b32 %4, %4, %8\n v_or_b32 %5, %5, %9\n v_xor_b32 %6, %6, %8\n v_add_u32 %7, %7, %9\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+                             : "v"(a), "v"(b));
+            } else if (MODE == 6) {  // shifts / bit-field extracts
+                asm volatile("v_lshlrev_b32 %0, 1, %0\n v_lshrrev_b32 %1, 1, %1\n v_bfe_u32 %2, %2, 1, 30\n v_lshlrev_b32 %3, 1, %3\n"
+                             "v_lshrrev_b32 %4, 1, %4\n v_bfe_u32 %5, %5, 1, 30\n v_lshl_add_u32 %6, %6, 1, %8\n v_lshl_or_b32 %7, %7, 1, %9\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+                             : "v"(a), "v"(b));
             } else {  // integer ops (and/or/shift mix)
                 asm volatile("v_and_b32 %0, %0, %8\n v_or_b32 %1, %1, %9\n v_lshlrev_b32 %2, 1, %2\n v_add_u32 %3, %3, %9\n"
                              "v_xor_b32 %4, %4, %8\n v_bfe_u32 %5, %5, 1, 30\n v_cndmask_b32 %6, %6, %8, vcc\n v_max_u32 %7, %7, %9\n"
@@ -29,7 +51,7 @@ __global__ __launch_bounds__(256) void k_fma(float* out, int iters, float a, flo
             }
         }
     }
-    out[blockIdx.x * 256 + threadIdx.x] = ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7));
+    out[blockIdx.x * 256 + threadIdx.x] = ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7)) + (p0.x + p1.y + p2.x + p3.y);
 }
 
 template <int MODE>
@@ -40,7 +62,7 @@ static void run(const char* name) {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const int iters = 4000;
-    for (int wg_per_cu = 1; wg_per_cu <= 8; ++wg_per_cu) {  // 256 threads = 4 waves = one per SIMD, so wg_per_cu = waves per SIMD
+    for (int wg_per_cu = 1; wg_per_cu <= 8; wg_per_cu *= 2) {  // 256 threads = 4 waves = one per SIMD, so wg_per_cu = waves per SIMD
         const int blocks = 256 * wg_per_cu;
         k_fma<MODE><<<blocks, 256>>>(d, 10, 1.0001f, 0.5f);
         hipDeviceSynchronize();
@@ -61,5 +83,9 @@ int main() {
     run<0>("fma    ");
     run<1>("mul+add");
     run<2>("integer");
+    run<3>("packed ");
+    run<4>("cndmask");
+    run<5>("logic  ");
+    run<6>("shifts ");
     return 0;
 }
