@@ -46,7 +46,15 @@ HBM_COPY_GBS = 6290.0    # the guide's measured float4 copy: the practical ceili
 # quad-cycle; the chip's 157 TFLOP/s f32 figure is for packed-f32 instructions (two lanes' worth per instruction), which this accounting counts as one.
 # (Rounds before this correction divided by twice this peak and reported half the fraction.)
 VALU_PEAK_GWI = 256 * 4 * 2.4 / 4.0
-PROFILE_DIR = os.path.join(ROOT, "profiles", "round2")
+def _default_profile_dir():
+    """the newest profiles/round* directory that holds PMC traffic summaries (or --profiles)"""
+    import glob
+
+    dirs = sorted(d for d in glob.glob(os.path.join(ROOT, "profiles", "round*")) if glob.glob(os.path.join(d, "pmc_traffic_*.json")))
+    return dirs[-1] if dirs else os.path.join(ROOT, "profiles", "round2")
+
+
+PROFILE_DIR = _default_profile_dir()
 
 STAGE_KERNELS = {  # which kernels make up a timed slot (names as rocprofv3 reports them); include/impact_voxel_hip.h, IVX_N_TIMED_STAGES
     "sdf_sample": ["k_sdf_super", "k_sdf_prepass", "k_sdf_eval"],
@@ -71,8 +79,9 @@ def stage_bytes(n_voxels, n_chunks, exposed_chunks, n_vertices, n_indices):
         # (region merge) + one packed box per chunk (occupied) + chunk records and per-chunk moment slots (moment sums)
         "post1": 5832.0 / 8 * exposed_chunks + (27.0 + 4.0 + 88.0) * n_chunks,
         "post2": 36.0 * n_chunks,                            # mesher scan: counts in, offsets / ranks / emit records out
-        # mesher emit: tile + (pos, nrm, vmat) + (idx u32, imat 8 B); flatten: (chunk, region) table entries in use
-        "emit": 2.0 * 5832 * exposed_chunks + 40.0 * n_vertices + 12.0 * n_indices + 8.0 * n_chunks,
+        # mesher emit: tile + (pos, nrm) + (idx u32, imat 8 B); flatten: (chunk, region) table entries in use
+        # (24 B per vertex. Rounds 1-2 charged 40: the mesher wrote a 16-byte material record per vertex as scratch; it no longer does)
+        "emit": 2.0 * 5832 * exposed_chunks + 24.0 * n_vertices + 12.0 * n_indices + 8.0 * n_chunks,
         "assign": 8.0 * n_chunks,
     }
     for k in ("unused6", "unused7", "unused8", "unused9"):
@@ -87,14 +96,31 @@ def load_profile(name):
         return None
 
 
+def _profile_rel():
+    return os.path.relpath(PROFILE_DIR, ROOT)
+
+
+def _profile_current(d):
+    """a committed PMC summary is quoted only for the kernels it was measured on: the summary carries the hash of the kernel sources
+    (tools/source_sha.py); another tree's numbers are not this tree's traffic"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from source_sha import source_sha16
+
+    return d.get("_source_sha16") == source_sha16()
+
+
 def counted_traffic(workload):
     """HBM bytes PER STEP of every kernel of the voxel step, from the committed PMC passes of the builder's own run of this
-    workload (profiles/round2/pmc_traffic_<workload>.json, written by tools/pmc_traffic.py from separate FETCH_SIZE /
+    workload (<profile dir>/pmc_traffic_<workload>.json, written by tools/pmc_traffic.py from separate FETCH_SIZE /
     WRITE_SIZE rocprofv3 runs: per-launch average x launches per step). A committed constant, not something this run
-    measured: `traffic_source` says so in the output."""
+    measured: `traffic_source` says so in the output. A summary that lacks a kernel of a timed slot is an error (the kernels were
+    renamed or re-split and the summary is of something else); a summary measured on other kernel sources is not quoted."""
     d = load_profile(f"pmc_traffic_{workload}.json")
     if not d:
         return None, None
+    if not _profile_current(d):
+        return None, (f"{_profile_rel()}/pmc_traffic_{workload}.json was measured on other kernel sources (source hash {d.get('_source_sha16')}): not quoted; "
+                      "tools/profile_round.sh regenerates it")
     per_stage = {}
     for stage, kernels in STAGE_KERNELS.items():
         tot, found = 0.0, False
@@ -103,8 +129,12 @@ def counted_traffic(workload):
                 if isinstance(rec, dict) and (name == k or name.startswith("void " + k + "<") or name.startswith(k + "<")):
                     tot += rec["hbm_bytes_per_step"]
                     found = True
+        if not found and stage != "sdf_sample":  # (k_sdf_super runs only for programs of more than 2048 nodes)
+            raise RuntimeError(f"{_profile_rel()}/pmc_traffic_{workload}.json has none of the kernels {kernels} of the timed slot '{stage}': "
+                               "STAGE_KERNELS and the summary are out of step (re-run tools/profile_round.sh)")
         per_stage[stage] = tot if found else None
-    return per_stage, f"profiles/round2/pmc_traffic_{workload}.json (builder's rocprofv3 --pmc run of this workload; per-launch average x launches per step)"
+    return per_stage, (f"{_profile_rel()}/pmc_traffic_{workload}.json (builder's rocprofv3 --pmc run of this workload on these kernel sources; per-launch average x "
+                       "launches per step)")
 
 
 def roofline_block(stage_ms, sb_effective, sb_active, workload_key):
@@ -138,7 +168,7 @@ def roofline_block(stage_ms, sb_effective, sb_active, workload_key):
     # the sampler is bound by VALU issue, not by HBM: its instruction count from the committed SQ pass against the issue peak
     valu = load_profile(f"pmc_valu_{workload_key}.json")
     vrl = None
-    if valu and stage_ms[0] > 0:
+    if valu and stage_ms[0] > 0 and _profile_current(valu):
         wi = sum(rec["SQ_INSTS_VALU_per_step"] for k, rec in valu.items() if isinstance(rec, dict) and any(
             k == n or k.startswith("void " + n + "<") or k.startswith(n + "<") for n in STAGE_KERNELS["sdf_sample"]))
         ach = wi / (stage_ms[0] * 1e-3) / 1e9
@@ -147,7 +177,7 @@ def roofline_block(stage_ms, sb_effective, sb_active, workload_key):
         vrl = {"stage": "sdf_sample", "bound": "valu", "achieved": ach, "peak": VALU_PEAK_GWI, "unit": "G wave-instructions/s", "frac": ach / VALU_PEAK_GWI,
                "wave_instructions_per_step": wi, "active_quad_cycles_per_step": act,
                "busy_frac_at_2.4GHz": 4.0 * act / (1024.0 * stage_ms[0] * 1e-3 * 2.4e9) if act else None,
-               "source": f"profiles/round2/pmc_valu_{workload_key}.json (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU; builder's run)"}
+               "source": f"{_profile_rel()}/pmc_valu_{workload_key}.json (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU; builder's run on these kernel sources)"}
     return rl, srl, vrl
 
 
@@ -635,10 +665,14 @@ def main():
                     help="N > 1: strong = the same 512^3 grid in N x-slabs (the metric's configuration); weak = BASELINE config 5 (lengths x N^(1/3))")
     ap.add_argument("--workload", choices=("asteroid", "dense"), default="asteroid", help="the timed step's scene (dense = all-surface plates)")
     ap.add_argument("--dense-chunks", type=int, default=32)
+    ap.add_argument("--profiles", default=None, help="directory of the committed PMC summaries `roofline.traffic` is quoted from (default: the newest profiles/round* that has them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pile", action="store_true", help="skip the separate legs (dense, config2, config3, pile, frame, edit, collide)")
     ap.add_argument("--plain", action="store_true", help="profiling runs: nothing but full steps (no remesh-only timing pass), so that every kernel launch rocprofv3 sees belongs to a step")
     args = ap.parse_args()
+    if args.profiles:
+        global PROFILE_DIR
+        PROFILE_DIR = os.path.abspath(args.profiles)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

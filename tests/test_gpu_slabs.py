@@ -165,39 +165,78 @@ def test_headline_512_in_8_slabs(ctx):
         whole.close()
 
 
-def test_config5_1024_in_8_slabs(ctx):
-    """BASELINE config 5 — the 1024^3 grid (config-2 asteroid x4.2: 64^3 chunks) domain-decomposed in 8 x-slabs of 8 chunk planes — through the native
-    driver with all eight slabs on this one GPU, against the single-grid step of the same scene: global results and every voxel byte"""
-    from impact_amd.voxel import SDFVoxelGenerator, VoxelObject
+def _sha16(a):
+    import hashlib
 
+    return hashlib.sha256(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).hexdigest()[:16]
+
+
+def test_config5_1024_in_8_slabs(ctx):
+    """BASELINE config 5 — the 1024^3 grid (config-2 asteroid x4.2: 64^3 chunks) — as one grid and domain-decomposed in 8 x-slabs of 8 chunk
+    planes through the native driver (all eight slabs on this one GPU), BOTH against the oracle's digests of that grid
+    (tests/golden/config5_golden.json, written by tests/golden/make_golden_config5.py): voxel planes, chunk-local labels, chunk records, every mesh
+    buffer, counts, moments, regions, occupied ranges for the single grid; every slab's voxel planes and the protocol's global results for the slabs"""
+    import json
+    import os
+
+    from impact_amd.voxel import SDFVoxelGenerator, VoxelObject, VoxelObjectMesh
+
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config5_golden.json")))
+    m64 = np.array([float.fromhex(x) for x in gold["moments64"]])
     graph = scenes.asteroid_scene(4.2)
     dens = np.ones(256, dtype=np.float32)
     gen = SDFVoxelGenerator(1.0, graph, 0)
-    assert tuple(gen.chunk_counts()) == (64, 64, 64)
+    assert tuple(gen.chunk_counts()) == (64, 64, 64) == tuple(gold["chunk_counts"])
     whole = VoxelObject(ctx, gen.chunk_counts(), 1.0)
     whole.set_sdf_program(gen)
     whole.set_densities(dens)
     ref = whole.step(capi.STAGE_ALL)
-    comm = NativeComm(ctx, 8, local=True)
-    steppers = [NativeSlabStepper(ctx, comm, graph, dens, r) for r in range(8)]
     try:
-        results = native_step(steppers)
-        assert results[0].region_count == int(ref["region_count"]) == 1
-        assert results[0].total_triangles == int(ref["mesh"]["n_indices"]) // 3
-        assert sum(r.mesh_counts[0] for r in results) == int(ref["mesh"]["n_vertices"])
-        np.testing.assert_allclose(results[0].moments, np.asarray(ref["moments"]["m64"]), rtol=1e-12)
-        np.testing.assert_array_equal(results[0].occupied, np.asarray(ref["occupied"]))
-        w_sdf, w_typ, w_flg, _, _ = whole.download(labels=False, info=False)
-        per = gen.chunk_counts()[1] * gen.chunk_counts()[2] * 4096
-        for s in steppers:
-            x0, x1 = s.x_range
-            g_sdf, g_typ, g_flg, _, _ = s.obj.download(labels=False, info=False)
-            assert np.array_equal(g_sdf, w_sdf[x0 * per:x1 * per]) and np.array_equal(g_flg, w_flg[x0 * per:x1 * per]), f"slab {x0}:{x1}"
-            del g_sdf, g_typ, g_flg
+        # ---- the single grid against the oracle
+        w_sdf, w_typ, w_flg, w_lab, w_info = whole.download()
+        assert _sha16(w_sdf) + _sha16(w_typ) + _sha16(w_flg) == gold["voxel_sha"]
+        assert _sha16(w_lab) == gold["label_sha"]
+        fields = ("kind", "gen_kind", "flags", "face_dist", "uniform_type", "region_count", "boundary_region_count")
+        assert _sha16(np.stack([w_info[f].astype(np.uint32) for f in fields])) == gold["chunk_record_sha"]
+        assert int(np.count_nonzero((w_flg & 1) == 0)) == gold["non_empty_voxels"]
+        del w_lab, w_info
+        gm = VoxelObjectMesh(whole)
+        gm.counts = ref["mesh"]
+        pos, nrm, idx, im, sub = gm.download()
+        assert (idx.size // 3, pos.shape[0], sub.shape[0]) == (gold["triangles"], gold["vertices"], gold["submeshes"])
+        assert _sha16(idx) == gold["index_sha"] and _sha16(im) == gold["index_material_sha"]
+        assert _sha16(pos) == gold["position_sha"] and _sha16(nrm) == gold["normal_sha"]
+        del pos, nrm, idx, im, sub
+        assert int(ref["region_count"]) == gold["regions"]
+        g64 = np.asarray(ref["moments"]["m64"], dtype=np.float64)
+        assert float(np.max(np.abs(g64 - m64) / np.maximum(np.abs(m64), 1e-300))) <= 1e-5
+        occ = np.asarray(ref["occupied"]).reshape(-1)
+        want_occ = np.array([x for r in gold["occupied_chunk_ranges"] for x in r] + [x for r in gold["occupied_voxel_ranges"] for x in r])  # (lo, hi) per axis
+        np.testing.assert_array_equal(occ, want_occ)
+        # ---- the eight slabs against the oracle (and against the single grid, voxel byte for voxel byte)
+        comm = NativeComm(ctx, 8, local=True)
+        steppers = [NativeSlabStepper(ctx, comm, graph, dens, r) for r in range(8)]
+        try:
+            results = native_step(steppers)
+            assert results[0].region_count == gold["regions"]
+            assert results[0].total_triangles == gold["triangles"]
+            assert sum(r.mesh_counts[0] for r in results) == gold["vertices"]
+            rm = np.asarray(results[0].moments, dtype=np.float64)
+            assert float(np.max(np.abs(rm - m64) / np.maximum(np.abs(m64), 1e-300))) <= 1e-5
+            np.testing.assert_allclose(results[0].moments, g64, rtol=1e-12)
+            np.testing.assert_array_equal(np.asarray(results[0].occupied).reshape(-1), want_occ)
+            per = gen.chunk_counts()[1] * gen.chunk_counts()[2] * 4096
+            for r, s in enumerate(steppers):
+                x0, x1 = s.x_range
+                g_sdf, g_typ, g_flg, _, _ = s.obj.download(labels=False, info=False)
+                assert _sha16(g_sdf) + _sha16(g_typ) + _sha16(g_flg) == gold["slab_voxel_sha"][r], f"slab {r}"
+                assert np.array_equal(g_sdf, w_sdf[x0 * per:x1 * per]) and np.array_equal(g_flg, w_flg[x0 * per:x1 * per]), f"slab {x0}:{x1}"
+                del g_sdf, g_typ, g_flg
+        finally:
+            for s in steppers:
+                s.close()
+            comm.close()
     finally:
-        for s in steppers:
-            s.close()
-        comm.close()
         whole.close()
 
 

@@ -8,7 +8,11 @@ usage: pmc_traffic.py fetch_results.db write_results.db out.json <steps in the p
 import json
 import re
 import sqlite3
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_sha import source_sha16  # noqa: E402
 
 
 def per_kernel(path, counter):
@@ -36,7 +40,7 @@ def main():
         res[k]["hbm_bytes_per_step"] = res[k]["hbm_bytes"] * n / steps
     meta = {"_note": "bytes per launch and per step; fetch = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB; separate --pmc passes. "
                      + (sys.argv[5] if len(sys.argv) > 5 else ""),
-            "_step_total_bytes": sum(r["hbm_bytes_per_step"] for r in res.values())}
+            "_step_total_bytes": sum(r["hbm_bytes_per_step"] for r in res.values()), "_source_sha16": source_sha16()}
     meta.update(res)
     json.dump(meta, open(sys.argv[3], "w"), indent=1)
 

@@ -5,7 +5,11 @@ usage: pmc_valu.py results.db out.json <steps in the profiled run>"""
 import json
 import re
 import sqlite3
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_sha import source_sha16  # noqa: E402
 
 
 def main():
@@ -20,6 +24,7 @@ def main():
         r[counter] = avg
         r[counter + "_per_step"] = avg * n / steps
     out = {"_note": "per-launch averages and per-step totals; SQ_INSTS_VALU = wave-instructions, SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES as rocprofv3 reports them"}
+    out["_source_sha16"] = source_sha16()
     out.update(res)
     json.dump(out, open(sys.argv[2], "w"), indent=1)
 

@@ -1,24 +1,31 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): GPU parity tests, the default bench line, the rocprofv3 kernel trace of the same bench
-# command and the two PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, no other trace domains). Summaries land in
-# gpurun_out/<tag>/ and are copied into profiles/<round>/ by hand afterwards.
-# usage: tools/profile_round.sh <tag>
+# Runs on the GPU box (via gpurun): the default bench line, the rocprofv3 kernel trace of the step-only bench command (headline and
+# all-surface workloads) and the PMC passes (FETCH_SIZE, WRITE_SIZE, SQ VALU counters; separate runs, no other trace domains).
+# Summaries land in gpurun_out/<tag>/ and are copied into profiles/roundN/ by hand afterwards (they carry the hash of the kernel sources: tools/source_sha.py).
+# usage: tools/profile_round.sh <tag> [skip-tests]
 set -u
 tag=${1:-run}
 out=$PWD/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -x -q > "$out/${tag}_pytest_gpu.log" 2>&1
-tail -2 "$out/${tag}_pytest_gpu.log"
+if [ "${2:-}" != "skip-tests" ]; then
+  python -m pytest tests -m gpu -x -q > "$out/${tag}_pytest_gpu.log" 2>&1
+  tail -2 "$out/${tag}_pytest_gpu.log"
+fi
 python bench.py 2> "$out/bench_stderr.log" | tail -1 > "$out/${tag}_bench_n1.json"
-rocprofv3 --kernel-trace --stats -d "$out/trace" -o trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > "$out/trace_stdout.log" 2>&1
-python tools/rocpd_stats.py "$(ls "$out"/trace/*.db | tail -1)" > "$out/${tag}_kernel_stats_bench_steps10.csv"
-# the step workload alone (no pile / edit / collide legs): every launch of a step kernel is a step launch, so the averages
-# here are the ones bench.py's per-stage HIP-event times must agree with
-rocprofv3 --kernel-trace --stats -d "$out/trace_step" -o trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pile > "$out/${tag}_bench_step_only.json" 2> "$out/trace_step_stderr.log"
-python tools/rocpd_stats.py "$(ls "$out"/trace_step/*.db | tail -1)" > "$out/${tag}_kernel_stats_step_only.csv"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_fetch" -o fetch -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pile > "$out/pmc_fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/pmc_write" -o write -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pile > "$out/pmc_write.log" 2>&1
-python tools/pmc_traffic.py "$(ls "$out"/pmc_fetch/*.db | tail -1)" "$(ls "$out"/pmc_write/*.db | tail -1)" "$out/pmc_traffic.json"
-rm -rf "$out/trace" "$out/trace_step" "$out/pmc_fetch" "$out/pmc_write"
-head -12 "$out/${tag}_kernel_stats_bench_steps10.csv"
+# --plain: full steps only: 2 warm-up + 10 timed + 10 with every slot timed = 22 steps
+STEPS="--steps 10 --warmup 2 --no-cpu-baseline --no-pile --plain"
+NST=22
+for wl in headline dense; do
+  if [ $wl = dense ]; then W="--workload dense"; else W=""; fi
+  rocprofv3 --kernel-trace --stats -d "$out/trace_$wl" -o trace -- python3 bench.py $STEPS $W > "$out/${tag}_bench_step_only_$wl.json" 2> "$out/trace_${wl}_stderr.log"
+  python tools/rocpd_stats.py "$(ls "$out"/trace_$wl/*.db | tail -1)" > "$out/${tag}_kernel_stats_step_only_$wl.csv"
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_fetch_$wl" -o fetch -- python3 bench.py $STEPS $W > "$out/pmc_fetch_$wl.log" 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/pmc_write_$wl" -o write -- python3 bench.py $STEPS $W > "$out/pmc_write_$wl.log" 2>&1
+  python tools/pmc_traffic.py "$(ls "$out"/pmc_fetch_$wl/*.db | tail -1)" "$(ls "$out"/pmc_write_$wl/*.db | tail -1)" "$out/pmc_traffic_$wl.json" $NST "bench.py $STEPS $W"
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES -d "$out/pmc_valu_$wl" -o valu -- python3 bench.py $STEPS $W > "$out/pmc_valu_$wl.log" 2>&1
+  python tools/pmc_valu.py "$(ls "$out"/pmc_valu_$wl/*.db | tail -1)" "$out/pmc_valu_$wl.json" $NST
+  rm -rf "$out/trace_$wl" "$out/pmc_fetch_$wl" "$out/pmc_write_$wl" "$out/pmc_valu_$wl"
+done
+head -14 "$out/${tag}_kernel_stats_step_only_headline.csv"
+head -14 "$out/${tag}_kernel_stats_step_only_dense.csv"
