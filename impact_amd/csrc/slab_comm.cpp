@@ -7,14 +7,22 @@
 // xGMI links to the neighbours, one small ncclAllGather); the host waits once per step. Ghost layers are read in place from the
 // receive buffers (ivx_halo_unpack_enqueue).
 //
-// Two transports behind one driver:
+// Three transports behind one driver:
 //   * RCCL (ivx_comm_init): librccl is opened at run time (the copy already loaded in the process — e.g. the one PyTorch bundles —
 //     else librccl.so from the loader path / IVX_RCCL_LIB); the library has no link-time dependency on it, and a missing RCCL fails
 //     loudly when a communicator is asked for;
 //   * in-process (ivx_comm_init_local): all ranks are slabs of ONE process on ONE GPU, neighbour exchange and all-gather are
 //     device-to-device copies on the same stream. This is how the decomposition is checked bit for bit against the oracle on the
-//     single GPU the test box has (tests/test_gpu_slabs.py), through exactly the driver code the RCCL ranks run.
+//     single GPU the test box has (tests/test_gpu_slabs.py), through exactly the driver code the RCCL ranks run;
+//   * shared device, several PROCESSES (ivx_comm_init_ipc): one process per rank as under RCCL, all on one GPU (RCCL refuses two ranks on
+//     one device). A rank writes its face planes straight into its neighbour's receive buffer (hipIpcGetMemHandle / hipIpcOpenMemHandle),
+//     arrival and buffer reuse are sequence numbers in a POSIX shared-memory block, the records are gathered through that block. The host
+//     waits at every exchange — a transport for checking the driver's sequencing as separate processes where there is one GPU, not for speed.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -91,10 +99,34 @@ int load_rccl() {
 
 }  // namespace
 
+constexpr int IPC_MAX_RANKS = 16;
+constexpr size_t IPC_MAX_REC_WORDS = 28 + 2 * (size_t)IVX_MAX_FACE_PAIRS;
+// the rendezvous block of the shared-device transport (POSIX shared memory; created and zeroed by rank 0)
+struct IpcRank {
+    hipIpcMemHandle_t recv[2];               // this rank's receive buffers, for its neighbours to open
+    std::atomic<unsigned long long> posted;  // slabs created: handles are valid
+    std::atomic<unsigned long long> sent[2];      // messages that have fully arrived in recv[side]
+    std::atomic<unsigned long long> consumed[2];  // messages of recv[side] whose readers have finished (the buffer may be overwritten)
+    std::atomic<unsigned long long> rec_seq;      // records published
+    std::atomic<unsigned long long> rec_read;     // gathers this rank has finished reading (the others may overwrite their slots)
+    unsigned long long record[IPC_MAX_REC_WORDS];
+};
+struct IpcShared {
+    std::atomic<unsigned long long> magic;  // set last by rank 0
+    std::atomic<unsigned long long> attached;
+    IpcRank ranks[IPC_MAX_RANKS];
+};
+constexpr unsigned long long IPC_MAGIC = 0x4956585F49504331ull;
+
 struct ivx_comm {
     ivx_ctx* ctx;
     int nranks, rank;  // rank = -1: in-process communicator (every rank lives here)
     ncclComm_t nccl;
+    // shared-device transport
+    IpcShared* ipc;
+    char ipc_name[96];
+    unsigned long long ipc_recv_seq[2], ipc_send_seq[2], ipc_rec_seq;  // messages expected in / put from this rank, records gathered
+    void* ipc_peer_recv[2];  // neighbour rank - 1's recv[1], neighbour rank + 1's recv[0], opened in this process
 };
 
 struct ivx_slab {
@@ -126,9 +158,92 @@ __global__ __launch_bounds__(256) void k_slab_publish(const unsigned long long* 
     if (threadIdx.x == 0u) __hip_atomic_store(host + n_words, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// bounded wait on a word of the rendezvous block (another PROCESS advances it): a peer that died must not hang this one for ever
+template <typename F>
+bool ipc_wait(F&& done, const char* what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t it = 0;; ++it) {
+        if (done()) return true;
+        if ((it & 63u) == 63u) {
+            usleep(20);
+            if (std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t0).count() > 60) {
+                ivx_set_error("shared-device transport: waited 60 s for %s", what);
+                return false;
+            }
+        } else {
+            __builtin_ia32_pause();
+        }
+    }
+}
+
+// neighbour exchange of the shared-device transport: this rank's stream is drained (the kernels that read the receive buffers in place are
+// through: the buffers are free), each send buffer is copied into the neighbour's receive buffer once the neighbour has said the same of
+// its own, and the copies are waited for before the arrival counters move
+int ipc_exchange(ivx_slab* sl, size_t nbytes) {
+    ivx_comm* c = sl->comm;
+    hipStream_t s = c->ctx->stream;
+    IpcShared* sh = c->ipc;
+    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    for (int side = 0; side < 2; ++side) sh->ranks[c->rank].consumed[side].store(c->ipc_recv_seq[side], std::memory_order_release);
+    for (int side = 0; side < 2; ++side) {
+        if (!(side ? sl->has_hi : sl->has_lo)) continue;
+        const int peer = side ? c->rank + 1 : c->rank - 1, peer_side = side ? 0 : 1;
+        const unsigned long long want = c->ipc_send_seq[side];
+        if (!ipc_wait([&] { return sh->ranks[peer].consumed[peer_side].load(std::memory_order_acquire) >= want; }, "a neighbour to release its receive buffer"))
+            return IVX_ERR_STATE;
+        IVX_HIP_CHECK(hipMemcpyAsync(c->ipc_peer_recv[side], sl->send[side], nbytes, hipMemcpyDeviceToDevice, s));
+    }
+    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    for (int side = 0; side < 2; ++side) {
+        if (!(side ? sl->has_hi : sl->has_lo)) continue;
+        const int peer = side ? c->rank + 1 : c->rank - 1, peer_side = side ? 0 : 1;
+        c->ipc_send_seq[side] += 1;
+        sh->ranks[peer].sent[peer_side].store(c->ipc_send_seq[side], std::memory_order_release);
+    }
+    for (int side = 0; side < 2; ++side) {
+        if (!(side ? sl->has_hi : sl->has_lo)) continue;
+        const unsigned long long want = c->ipc_recv_seq[side] + 1;
+        if (!ipc_wait([&] { return sh->ranks[c->rank].sent[side].load(std::memory_order_acquire) >= want; }, "a neighbour's face planes")) return IVX_ERR_STATE;
+        c->ipc_recv_seq[side] = want;
+    }
+    return IVX_OK;
+}
+
+// record gather of the shared-device transport: through the host and the rendezvous block
+int ipc_all_gather(ivx_slab* sl, size_t words) {
+    ivx_comm* c = sl->comm;
+    hipStream_t s = c->ctx->stream;
+    IpcShared* sh = c->ipc;
+    IVX_REQUIRE(words <= IPC_MAX_REC_WORDS, IVX_ERR_CAPACITY, "shared-device transport: record of %zu words", words);
+    IpcRank& me = sh->ranks[c->rank];
+    // (the slot is rewritten only after every rank has copied the previous record out of it)
+    const unsigned long long last = c->ipc_rec_seq;
+    if (!ipc_wait([&] {
+            for (int r = 0; r < c->nranks; ++r)
+                if (sh->ranks[r].rec_read.load(std::memory_order_acquire) < last) return false;
+            return true;
+        }, "the other ranks to read the previous record")) return IVX_ERR_STATE;
+    IVX_HIP_CHECK(hipMemcpyAsync(me.record, sl->record, words * 8, hipMemcpyDeviceToHost, s));
+    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    c->ipc_rec_seq += 1;
+    me.rec_seq.store(c->ipc_rec_seq, std::memory_order_release);
+    const unsigned long long want = c->ipc_rec_seq;
+    if (!ipc_wait([&] {
+            for (int r = 0; r < c->nranks; ++r)
+                if (sh->ranks[r].rec_seq.load(std::memory_order_acquire) < want) return false;
+            return true;
+        }, "the other ranks' record")) return IVX_ERR_STATE;
+    for (int r = 0; r < c->nranks; ++r) IVX_HIP_CHECK(hipMemcpyAsync(sl->gathered + (size_t)r * words, sh->ranks[r].record, words * 8, hipMemcpyHostToDevice, s));
+    // (the copies above read the block asynchronously: waited for before this rank reports the gather as read)
+    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    me.rec_read.store(want, std::memory_order_release);
+    return IVX_OK;
+}
+
 int exchange(ivx_slab** slabs, size_t n, size_t nbytes) {
     ivx_comm* c = slabs[0]->comm;
     hipStream_t s = c->ctx->stream;
+    if (c->ipc) return ipc_exchange(slabs[0], nbytes);
     if (c->rank >= 0) {  // RCCL: one slab per process, its two neighbours
         ivx_slab* sl = slabs[0];
         if (!sl->has_lo && !sl->has_hi) return IVX_OK;
@@ -155,6 +270,7 @@ int exchange(ivx_slab** slabs, size_t n, size_t nbytes) {
 int all_gather(ivx_slab** slabs, size_t n, size_t words) {
     ivx_comm* c = slabs[0]->comm;
     hipStream_t s = c->ctx->stream;
+    if (c->ipc) return ipc_all_gather(slabs[0], words);
     if (c->rank >= 0) {
         ivx_slab* sl = slabs[0];
         if (c->nranks == 1) {
@@ -200,6 +316,7 @@ int ivx_comm_init(ivx_ctx* c, int nranks, int rank, const void* unique_id128, iv
     m->nranks = nranks;
     m->rank = rank;
     m->nccl = nullptr;
+    m->ipc = nullptr;
     if (nranks > 1) {
         int rc = load_rccl();
         if (rc) {
@@ -226,6 +343,71 @@ int ivx_comm_init_local(ivx_ctx* c, int nranks, ivx_comm** out) {
     m->nranks = nranks;
     m->rank = -1;
     m->nccl = nullptr;
+    m->ipc = nullptr;
+    *out = m;
+    return IVX_OK;
+}
+
+// One process per rank on ONE device: `name` is a POSIX shared-memory name ("/something") all ranks pass; rank 0 creates the block.
+int ivx_comm_init_ipc(ivx_ctx* c, int nranks, int rank, const char* name, ivx_comm** out) {
+    IVX_REQUIRE(c && out && name && name[0] == '/' && strlen(name) < 90 && nranks >= 1 && nranks <= IPC_MAX_RANKS && rank >= 0 && rank < nranks, IVX_ERR_INVALID,
+                "ivx_comm_init_ipc: bad argument");
+    *out = nullptr;
+    ivx_comm* m = new (std::nothrow) ivx_comm();
+    IVX_REQUIRE(m, IVX_ERR_CAPACITY, "ivx_comm_init_ipc: out of host memory");
+    m->ctx = c;
+    m->nranks = nranks;
+    m->rank = rank;
+    m->nccl = nullptr;
+    m->ipc = nullptr;
+    snprintf(m->ipc_name, sizeof(m->ipc_name), "%s", name);
+    for (int s = 0; s < 2; ++s) m->ipc_recv_seq[s] = m->ipc_send_seq[s] = 0, m->ipc_peer_recv[s] = nullptr;
+    m->ipc_rec_seq = 0;
+    int fd = -1;
+    if (rank == 0) {
+        (void)shm_unlink(name);
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd >= 0 && ftruncate(fd, (off_t)sizeof(IpcShared)) != 0) {
+            close(fd);
+            fd = -1;
+        }
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (fd < 0) {  // until rank 0 has made it
+            fd = shm_open(name, O_RDWR, 0600);
+            struct stat st;
+            if (fd >= 0 && (fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof(IpcShared))) {
+                close(fd);
+                fd = -1;
+            }
+            if (fd < 0) {
+                usleep(1000);
+                if (std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t0).count() > 60) break;
+            }
+        }
+    }
+    if (fd < 0) {
+        ivx_set_error("ivx_comm_init_ipc: shared memory %s not available (rank %d)", name, rank);
+        delete m;
+        return IVX_ERR_STATE;
+    }
+    void* p = mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) {
+        ivx_set_error("ivx_comm_init_ipc: mmap failed");
+        delete m;
+        return IVX_ERR_STATE;
+    }
+    m->ipc = static_cast<IpcShared*>(p);
+    if (rank == 0) {
+        memset(p, 0, sizeof(IpcShared));  // (all-zero is the initial state of every counter)
+        m->ipc->magic.store(IPC_MAGIC, std::memory_order_release);
+    } else if (!ipc_wait([&] { return m->ipc->magic.load(std::memory_order_acquire) == IPC_MAGIC; }, "rank 0 to initialise the rendezvous block")) {
+        munmap(p, sizeof(IpcShared));
+        delete m;
+        return IVX_ERR_STATE;
+    }
+    m->ipc->attached.fetch_add(1);
     *out = m;
     return IVX_OK;
 }
@@ -287,6 +469,12 @@ int ivx_comm_selftest(ivx_ctx* c) {
 void ivx_comm_destroy(ivx_comm* m) {
     if (!m) return;
     if (m->nccl) (void)g_rccl.CommDestroy(m->nccl);
+    if (m->ipc) {
+        for (int s = 0; s < 2; ++s)
+            if (m->ipc_peer_recv[s]) (void)hipIpcCloseMemHandle(m->ipc_peer_recv[s]);
+        munmap(m->ipc, sizeof(IpcShared));
+        if (m->rank == 0) (void)shm_unlink(m->ipc_name);
+    }
     delete m;
 }
 
@@ -325,6 +513,29 @@ int ivx_slab_create(ivx_comm* m, ivx_grid* g, int rank, ivx_slab** out) {
         ivx_set_error("ivx_slab_create: device allocation failed");
         ivx_slab_destroy(sl);
         return IVX_ERR_HIP;
+    }
+    if (m->ipc) {  // shared-device transport (collective: every rank creates its slab): publish the receive buffers, open the neighbours'
+        IpcRank& me = m->ipc->ranks[rank];
+        for (int s = 0; s < 2; ++s)
+            if (hipIpcGetMemHandle(&me.recv[s], sl->recv[s]) != hipSuccess) {
+                ivx_set_error("ivx_slab_create: hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 must be set on this pool)");
+                ivx_slab_destroy(sl);
+                return IVX_ERR_HIP;
+            }
+        me.posted.store(1, std::memory_order_release);
+        for (int s = 0; s < 2; ++s) {
+            if (!(s ? sl->has_hi : sl->has_lo)) continue;
+            const int peer = s ? rank + 1 : rank - 1;
+            if (!ipc_wait([&] { return m->ipc->ranks[peer].posted.load(std::memory_order_acquire) == 1; }, "a neighbour's slab")) {
+                ivx_slab_destroy(sl);
+                return IVX_ERR_STATE;
+            }
+            if (hipIpcOpenMemHandle(&m->ipc_peer_recv[s], m->ipc->ranks[peer].recv[s ? 0 : 1], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+                ivx_set_error("ivx_slab_create: hipIpcOpenMemHandle failed (rank %d -> %d)", rank, peer);
+                ivx_slab_destroy(sl);
+                return IVX_ERR_HIP;
+            }
+        }
     }
     *out = sl;
     return IVX_OK;

@@ -353,11 +353,13 @@ class NativeComm:
     """`ivx_comm`: RCCL communicator of this rank (`unique_id` = the 128 bytes rank 0 made with `NativeComm.unique_id()`), or — with
     `local=True` — an in-process communicator whose `world` slabs all live in this process on one GPU."""
 
-    def __init__(self, ctx: Context, world: int, rank: int = 0, unique_id: bytes | None = None, local: bool = False):
+    def __init__(self, ctx: Context, world: int, rank: int = 0, unique_id: bytes | None = None, local: bool = False, ipc_name: str | None = None):
         self.ctx, self.world, self.rank, self.local = ctx, world, rank, local
         h = C.c_void_p()
         if local:
             check(capi.lib().ivx_comm_init_local(ctx.h, world, C.byref(h)))
+        elif ipc_name is not None:  # one process per rank on one device (`ivx_comm_init_ipc`): POSIX shared-memory name all ranks pass
+            check(capi.lib().ivx_comm_init_ipc(ctx.h, world, rank, ipc_name.encode(), C.byref(h)))
         else:
             buf = (C.c_char * 128).from_buffer_copy(unique_id) if unique_id is not None else None
             check(capi.lib().ivx_comm_init(ctx.h, world, rank, buf, C.byref(h)))

@@ -394,6 +394,11 @@ typedef struct {
 int ivx_comm_unique_id(void* out128);
 int ivx_comm_init(ivx_ctx*, int nranks, int rank, const void* unique_id128, ivx_comm** out);
 int ivx_comm_init_local(ivx_ctx*, int nranks, ivx_comm** out);
+/* One PROCESS per rank on ONE device (RCCL refuses two ranks on a device): a rank copies its face planes straight into its neighbour's receive
+ * buffer (hipIpcGetMemHandle / hipIpcOpenMemHandle), sequence numbers and the record gather go through the POSIX shared-memory block `name`
+ * ("/..."; rank 0 creates it). The host waits at every exchange: a transport for running the protocol's driver as separate processes where
+ * there is one GPU (tests/test_gpu_slabs_ipc.py), not for speed. ivx_slab_create is collective on such a communicator. */
+int ivx_comm_init_ipc(ivx_ctx*, int nranks, int rank, const char* name, ivx_comm** out);
 void ivx_comm_destroy(ivx_comm*);
 /* Diagnostic (no reference counterpart): runs every RCCL call the protocol makes — ncclGetUniqueId, ncclCommInitRank, a grouped
  * ncclSend / ncclRecv pair, ncclAllGather — on a ONE-rank communicator of this context's device and stream (the send goes to the rank

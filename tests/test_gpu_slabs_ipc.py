@@ -1,0 +1,83 @@
+"""The NATIVE slab protocol (impact_amd/csrc/slab_comm.cpp: ivx_slabs_step_enqueue / _collect — three partial enqueues, the record kernel,
+the doorbell, error flags decided on the gathered records) as separate PROCESSES, one per rank, on the one GPU a test box has: RCCL refuses
+two ranks on one device, the shared-device transport (ivx_comm_init_ipc: face planes copied straight into the neighbour's receive buffer
+through hipIpc handles, sequence numbers and the record gather through POSIX shared memory) does not. Every rank is a fresh Python process;
+what the ranks end with is compared with the oracle on the WHOLE grid, as tests/test_gpu_slabs.py does for slabs that share a process."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from impact_amd import scenes
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("scene,world,regions", [("asteroid", 2, 1), ("fracture", 3, 8)])
+def test_native_protocol_as_separate_processes(scene, world, regions):
+    graph = {"asteroid": scenes.asteroid_scene, "fracture": scenes.fracture_scene}[scene]()
+    dens = np.linspace(0.5, 2.0, 256).astype(np.float32)
+    with tempfile.TemporaryDirectory() as tmp:
+        name = f"/ivx_ipc_{os.getpid()}_{scene}"
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "ipc_slab_worker.py"), str(r), str(world), name, scene, "2", os.path.join(tmp, f"r{r}.npz")],
+                                  env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+        outs = []
+        for p in procs:
+            try:
+                outs.append(p.communicate(timeout=300)[0])
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+        assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+        ranks = [np.load(os.path.join(tmp, f"r{r}.npz")) for r in range(world)]
+        # ---- against the oracle on the whole grid
+        o = ol.OracleObject.from_sdf(graph, 1.0, 0)
+        o.update_occupied_voxel_ranges()
+        o.compute_all_derived_state()
+        cc = o.chunk_counts
+        assert tuple(ranks[0]["chunk_counts"]) == tuple(cc)
+        o_sdf, o_typ, o_flg, o_lab, o_info = o.export_dense()
+        per_chunk = cc[1] * cc[2]
+        for d in ranks:
+            x0, x1 = (int(v) for v in d["x_range"])
+            sl = slice(x0 * per_chunk * 4096, x1 * per_chunk * 4096)
+            np.testing.assert_array_equal(d["sdf"], o_sdf[sl])
+            np.testing.assert_array_equal(d["typ"], o_typ[sl])
+            np.testing.assert_array_equal(d["flg"], o_flg[sl])
+            oi = o_info[x0 * per_chunk:x1 * per_chunk]
+            for f in ("kind", "gen_kind", "flags", "face_dist", "uniform_type", "region_count", "boundary_region_count"):
+                np.testing.assert_array_equal(d["info"][f], oi[f], err_msg=f)
+        om = o.mesh()
+        idx = np.concatenate([d["idx"] + np.uint32(int(d["vertex_offset"])) for d in ranks])
+        np.testing.assert_array_equal(idx, om.indices)
+        np.testing.assert_array_equal(np.concatenate([d["pos"] for d in ranks]).view(np.uint32), om.positions.view(np.uint32))
+        np.testing.assert_array_equal(np.concatenate([d["nrm"] for d in ranks]).view(np.uint32), om.normals.view(np.uint32))
+        np.testing.assert_array_equal(np.concatenate([d["im"] for d in ranks]), om.index_materials)
+        assert int(ranks[0]["total_triangles"]) == om.indices.size // 3
+        _, o64 = o.inertia(dens)
+        for d in ranks:
+            np.testing.assert_allclose(d["moments"], o64, rtol=1e-5)
+            np.testing.assert_array_equal(d["moments"], ranks[0]["moments"])  # identical on every rank
+            np.testing.assert_array_equal(d["occupied"], ranks[0]["occupied"])
+        info = o.info()
+        occ = ranks[0]["occupied"]
+        assert [(int(occ[2 * k]), int(occ[2 * k + 1])) for k in range(3)] == info["occupied_chunk_ranges"]
+        assert [(int(occ[6 + 2 * k]), int(occ[7 + 2 * k])) for k in range(3)] == info["occupied_voxel_ranges"]
+        n_o, olab = o.region_labels()
+        assert n_o == regions and all(int(d["region_count"]) == n_o for d in ranks)
+        glab = []
+        for d in ranks:
+            loc = d["loc"]
+            out = np.full(loc.shape, 0xFFFFFFFF, dtype=np.uint32)
+            m = loc != 0xFFFFFFFF
+            out[m] = d["region_of_local"][loc[m]]
+            glab.append(out)
+        glab = ol.tiled_to_dense(np.concatenate(glab), cc)
+        np.testing.assert_array_equal(ol.canonicalize_labels(glab, 0xFFFFFFFF), ol.canonicalize_labels(olab, 0xFFFFFFFF))
