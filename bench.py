@@ -737,12 +737,7 @@ def main():
     else:
         from impact_amd.distributed import NativeComm, NativeSlabStepper, NativeStepGroup, SlabStepper, TorchComm
 
-        if args.scaling == "weak" and args.workload == "asteroid":
-            # BASELINE.json's config 5: the config-2 asteroid with all lengths scaled so that every rank keeps the 512^3
-            # workload's voxel count (N = 8: scale x2 again -> the 1024^3 grid in 8 slabs of 128 planes)
-            graph = scenes.asteroid_scene(args.scale * world ** (1.0 / 3.0))
-            scene_name = f"config-2 SDF asteroid x{args.scale * world ** (1.0 / 3.0):.3f} (config 5 at N=8)"
-            scaling = "weak"
+        native_comm = None
         if dist.get_backend() == "nccl":
             # the per-step protocol runs inside the library (ivx_slabs_step_*: grouped ncclSend / ncclRecv + one ncclAllGather on the
             # library's stream); this script only hands the communicator's unique id from rank 0 to the others
@@ -751,28 +746,39 @@ def main():
                 uid.copy_(torch.frombuffer(bytearray(NativeComm.unique_id()), dtype=torch.uint8))
             if world > 1:
                 dist.broadcast(uid, 0)
-            comm = NativeComm(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()))
-            stepper = NativeSlabStepper(ctx, comm, graph, dens, rank)
-            obj = stepper.obj
-            transport = "RCCL (ncclSend / ncclRecv / ncclAllGather inside the library)"
+            native_comm = NativeComm(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()))
 
-            group = NativeStepGroup([stepper])
+        def slab_leg(mode):
+            """(graph, scene name, stepper, voxel object, step function, transport) of the x-slab decomposition: `strong` = the SAME 512^3 grid of the
+            metric on every N; `weak` = BASELINE.json's config 5, the config-2 asteroid with all lengths scaled so that every rank keeps the 512^3
+            workload's voxel count (N = 8: scale x2 again -> the 1024^3 grid in 8 slabs of 128 planes)"""
+            g, nm = graph, scene_name
+            if mode == "weak" and args.workload == "asteroid":
+                g = scenes.asteroid_scene(args.scale * world ** (1.0 / 3.0))
+                nm = f"config-2 SDF asteroid x{args.scale * world ** (1.0 / 3.0):.3f} (config 5 at N=8)"
+            if native_comm is not None:
+                st = NativeSlabStepper(ctx, native_comm, g, dens, rank)
+                group = NativeStepGroup([st])
 
-            def step():
-                body_world.step_enqueue(0.005)  # on the same stream, ahead of the slab's kernels; the protocol's one wait covers it
-                o = group.step()[0]
-                return {"stage_ms": o["stage_ms"], "mesh": o["mesh"], "region_count": o["region_count"]}
-        else:  # host-staged protocol check (IVX_BENCH_BACKEND=gloo): the same phases driven from Python over torch.distributed
-            stepper = SlabStepper(ctx, graph, dens, rank, world, torch)
-            comm = TorchComm(dist, torch, rank, world)
-            obj = stepper.obj
-            transport = f"torch.distributed {dist.get_backend()} (host-staged protocol check)"
+                def fn():
+                    body_world.step_enqueue(0.005)  # on the same stream, ahead of the slab's kernels; the protocol's one wait covers it
+                    o = group.step()[0]
+                    return {"stage_ms": o["stage_ms"], "mesh": o["mesh"], "region_count": o["region_count"]}
 
-            def step():
+                return g, nm, st, st.obj, fn, "RCCL (ncclSend / ncclRecv / ncclAllGather inside the library)"
+            # host-staged protocol check (IVX_BENCH_BACKEND=gloo): the same phases driven from Python over torch.distributed
+            st = SlabStepper(ctx, g, dens, rank, world, torch)
+            tc = TorchComm(dist, torch, rank, world)
+
+            def fn():
                 body_world.step_enqueue(0.005)
-                r = comm.run(stepper)
+                r = tc.run(st)
                 return {"stage_ms": r.stage_ms, "mesh": {"n_vertices": r.mesh_counts[0], "n_indices": r.mesh_counts[1]}, "region_count": r.region_count}
 
+            return g, nm, st, st.obj, fn, f"torch.distributed {dist.get_backend()} (host-staged protocol check)"
+
+        scaling = args.scaling if args.workload == "asteroid" else "strong"
+        graph, scene_name, stepper, obj, step, transport = slab_leg(scaling)
         workload = (f"{scene_name} -> {stepper.global_shape} stored grid, x-slabs of {obj.chunk_counts[0]} chunk planes per rank "
                     f"({obj.n_chunks} chunks on rank 0)")
         parallelism = f"x-slab domain decomposition over {world} GPUs, 1-voxel halos + region equivalences over {transport}"
@@ -815,6 +821,30 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # N > 1: the other scaling mode in the same run (the metric's 1 -> 8 target is about the strong leg, config 5 is the weak one)
+    other_leg = None
+    if slabs and args.workload == "asteroid":
+        mode2 = "weak" if scaling == "strong" else "strong"
+        _, nm2, st2, obj2, step2, _ = slab_leg(mode2)
+        for _ in range(max(2, min(args.warmup, 5))):
+            r2 = step2()
+        n2 = max(5, min(args.steps, 50))
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(n2):
+            r2 = step2()
+        barrier()
+        e2 = time.perf_counter() - t2
+        t = torch.tensor([e2], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        e2 = float(t.item())
+        t = torch.tensor([obj2.n_voxels, int(r2["mesh"]["n_indices"]) // 3], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t)
+        other_leg = {"scaling": mode2, "workload": f"{nm2} -> {st2.global_shape} stored grid, x-slabs of {obj2.chunk_counts[0]} chunk planes per rank",
+                     "steps": n2, "ms_per_step": 1e3 * e2 / n2, "value": int(t[0].item()) / (e2 / n2), "unit": "voxels/s", "triangles": int(t[1].item()),
+                     "regions": int(r2["region_count"])}
+        st2.close()
 
     n_vox_rank = obj.n_voxels
     tris_rank = int(res["mesh"]["n_indices"]) // 3
@@ -871,6 +901,16 @@ def main():
         }
         if vrl:
             out["valu_roofline"] = vrl
+        if slabs:
+            # both scaling modes of this N in one line (`value` / `scaling` above are the mode asked for: strong unless --scaling weak)
+            main_leg = {"scaling": scaling, "workload": workload, "steps": args.steps, "ms_per_step": ms_per_step, "value": out["value"], "unit": "voxels/s",
+                        "triangles": tris_total, "regions": int(res["region_count"])}
+            out["scaling_legs"] = {main_leg["scaling"]: main_leg}
+            if other_leg:
+                out["scaling_legs"][other_leg["scaling"]] = other_leg
+            out["ranks"] = {"world_size": world, "backend": dist.get_backend(),
+                            "communicator_ranks": (native_comm.info()["nranks"] if native_comm is not None else dist.get_world_size()),
+                            "communicator": ("RCCL communicator made by the library (ncclCommCount)" if native_comm is not None else "torch.distributed process group")}
         o_big = m_big = None
         if world == 1 and not args.no_cpu_baseline:
             what = "full N=1 workload" if args.workload == "asteroid" else "the timed scene"
@@ -943,8 +983,8 @@ def main():
     body_world.close()
     if slabs:
         stepper.close()  # (the slab's buffers, then its grid)
-        if hasattr(comm, "close"):
-            comm.close()
+        if native_comm is not None:
+            native_comm.close()
     else:
         obj.close()
     ctx.close()

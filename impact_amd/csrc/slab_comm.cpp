@@ -50,6 +50,8 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId_*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId_, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -77,6 +79,8 @@ int load_rccl() {
     SYM(GetUniqueId, "ncclGetUniqueId");
     SYM(CommInitRank, "ncclCommInitRank");
     SYM(CommDestroy, "ncclCommDestroy");
+    SYM(CommCount, "ncclCommCount");
+    SYM(CommUserRank, "ncclCommUserRank");
     SYM(Send, "ncclSend");
     SYM(Recv, "ncclRecv");
     SYM(AllGather, "ncclAllGather");
@@ -464,6 +468,20 @@ int ivx_comm_selftest(ivx_ctx* c) {
     (void)hipFree(dev);
     (void)g_rccl.CommDestroy(comm);
     return result;
+}
+
+// what the communicator itself says it is: transport (0 RCCL, 1 in-process, 2 shared device), ranks and this process's rank — for RCCL as
+// ncclCommCount / ncclCommUserRank report them (a one-rank RCCL communicator makes no library communicator: 1 and 0)
+int ivx_comm_info(ivx_comm* m, int* transport, int* nranks, int* rank) {
+    IVX_REQUIRE(m && transport && nranks && rank, IVX_ERR_INVALID, "ivx_comm_info: null argument");
+    *transport = m->ipc ? 2 : (m->rank < 0 ? 1 : 0);
+    *nranks = m->nranks;
+    *rank = m->rank;
+    if (m->nccl) {
+        IVX_NCCL_CHECK(g_rccl.CommCount(m->nccl, nranks));
+        IVX_NCCL_CHECK(g_rccl.CommUserRank(m->nccl, rank));
+    }
+    return IVX_OK;
 }
 
 void ivx_comm_destroy(ivx_comm* m) {

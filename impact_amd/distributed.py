@@ -365,6 +365,12 @@ class NativeComm:
             check(capi.lib().ivx_comm_init(ctx.h, world, rank, buf, C.byref(h)))
         self.h = h
 
+    def info(self) -> dict:
+        """transport, rank count and rank as the communicator itself reports them (RCCL: ncclCommCount / ncclCommUserRank)"""
+        t, n, r = C.c_int32(), C.c_int32(), C.c_int32()
+        check(capi.lib().ivx_comm_info(self.h, C.byref(t), C.byref(n), C.byref(r)))
+        return {"transport": ("rccl", "in-process", "shared-device")[t.value], "nranks": n.value, "rank": r.value}
+
     @staticmethod
     def unique_id() -> bytes:
         buf = (C.c_char * 128)()

@@ -399,6 +399,9 @@ int ivx_comm_init_local(ivx_ctx*, int nranks, ivx_comm** out);
  * ("/..."; rank 0 creates it). The host waits at every exchange: a transport for running the protocol's driver as separate processes where
  * there is one GPU (tests/test_gpu_slabs_ipc.py), not for speed. ivx_slab_create is collective on such a communicator. */
 int ivx_comm_init_ipc(ivx_ctx*, int nranks, int rank, const char* name, ivx_comm** out);
+/* transport (0 RCCL, 1 in-process, 2 shared device), rank count and this process's rank as the communicator reports them (RCCL: ncclCommCount,
+ * ncclCommUserRank) */
+int ivx_comm_info(ivx_comm*, int* transport, int* nranks, int* rank);
 void ivx_comm_destroy(ivx_comm*);
 /* Diagnostic (no reference counterpart): runs every RCCL call the protocol makes — ncclGetUniqueId, ncclCommInitRank, a grouped
  * ncclSend / ncclRecv pair, ncclAllGather — on a ONE-rank communicator of this context's device and stream (the send goes to the rank
