@@ -138,7 +138,7 @@ EXPORTED_SYMBOLS = [
     "ivx_derive_state", "ivx_occupied_ranges",
     "ivx_remesh", "ivx_mesh_download", "ivx_mesh_device_ptr",
     "ivx_inertia",
-    "ivx_label_regions", "ivx_region_labels_download", "ivx_regions_describe", "ivx_split_off_smallest_region", "ivx_clip_polyhedron", "ivx_copy_polyhedra", "ivx_mesh_sync", "ivx_mesh_modifications", "ivx_mesh_report_synchronized", "ivx_absorb_sphere", "ivx_absorb_capsule", "ivx_absorb_mutual", "ivx_offset_reference_point", "ivx_apply_updated_inertial_properties", "ivx_extracted_object_dynamics", "ivx_handle_voxel_object_after_removing_voxels", "ivx_sphere_voxel_object_contacts", "ivx_plane_voxel_object_contacts", "ivx_capsule_voxel_object_contacts", "ivx_collision_probes_recompute", "ivx_collision_probes_sync", "ivx_collision_probes_download", "ivx_mutual_voxel_object_contacts",
+    "ivx_label_regions", "ivx_region_labels_download", "ivx_regions_describe", "ivx_split_off_smallest_region", "ivx_clip_polyhedron", "ivx_copy_polyhedra", "ivx_mesh_sync", "ivx_mesh_export", "ivx_mesh_generation", "ivx_mesh_import_open", "ivx_mesh_import_close", "ivx_mesh_modifications", "ivx_mesh_report_synchronized", "ivx_absorb_sphere", "ivx_absorb_capsule", "ivx_absorb_mutual", "ivx_offset_reference_point", "ivx_apply_updated_inertial_properties", "ivx_extracted_object_dynamics", "ivx_handle_voxel_object_after_removing_voxels", "ivx_sphere_voxel_object_contacts", "ivx_plane_voxel_object_contacts", "ivx_capsule_voxel_object_contacts", "ivx_collision_probes_recompute", "ivx_collision_probes_sync", "ivx_collision_probes_download", "ivx_mutual_voxel_object_contacts",
     "ivx_grid_set_sdf_program", "ivx_grid_set_densities", "ivx_voxel_step", "ivx_voxel_step_enqueue", "ivx_voxel_step_collect", "ivx_grid_set_stage_timing",
     "ivx_halo_pack_enqueue", "ivx_halo_unpack_enqueue", "ivx_halo_pack_both_enqueue", "ivx_region_face_labels_enqueue", "ivx_region_face_pairs_enqueue",
     "ivx_step_record_words", "ivx_step_record_enqueue",
@@ -153,6 +153,9 @@ EXPORTED_SYMBOLS = [
     "ivx_world_set_solver_groups", "ivx_world_solver_info", "ivx_world_contact_state",
 ]
 
+
+MESH_EXPORT_DTYPE = np.dtype([("ipc_handle", "u1", (64,)), ("dmabuf_fd", "<i4"), ("element_bytes", "<u4"), ("bytes", "<u8"), ("capacity_bytes", "<u8"),
+                              ("generation", "<u8"), ("device_ptr", "<u8")])
 
 EXTRACTED_OBJECT_DTYPE = np.dtype(
     [
@@ -294,6 +297,10 @@ def lib():
         "ivx_comm_init": (i32, [vp, i32, i32, vp, C.POINTER(vp)]),
         "ivx_comm_init_local": (i32, [vp, i32, C.POINTER(vp)]),
         "ivx_comm_init_ipc": (i32, [vp, i32, i32, C.c_char_p, C.POINTER(vp)]),
+        "ivx_mesh_export": (i32, [vp, i32, vp]),
+        "ivx_mesh_generation": (i32, [vp, C.POINTER(C.c_uint64)]),
+        "ivx_mesh_import_open": (i32, [vp, i32, C.POINTER(vp)]),
+        "ivx_mesh_import_close": (i32, [vp]),
         "ivx_comm_info": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "ivx_comm_selftest": (i32, [vp]),
         "ivx_selftest_mesher_division": (i32, [vp, C.POINTER(u32)]),

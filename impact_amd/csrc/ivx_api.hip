@@ -92,6 +92,7 @@ int ensure_dev_scratch(ivx_grid* g, size_t bytes) {
 }
 
 int ensure_mesh_capacity(ivx_grid* g, size_t nv, size_t ni, size_t ns) {
+    if (nv > g->vcap || ni > g->icap || ns > g->scap) g->mesh_generation += 1;
     if (nv > g->vcap) {
         size_t cap = std::max(nv, g->vcap * 2);
         if (g->positions) (void)hipFree(g->positions);
@@ -269,6 +270,7 @@ int grow_keep(ivx_grid* g, T** buf, size_t old_count, size_t new_count) {
 }
 int ensure_mesh_capacity_keep(ivx_grid* g, size_t nv, size_t ni, size_t ns) {
     int rc;
+    if (nv > g->vcap || ni > g->icap || ns > g->scap) g->mesh_generation += 1;
     if (nv > g->vcap) {
         const size_t cap = std::max(nv, g->vcap + g->vcap / 2);
         if ((rc = grow_keep(g, &g->positions, g->vcap * 3, cap * 3))) return rc;
@@ -772,6 +774,66 @@ void* ivx_mesh_device_ptr(ivx_grid* g, int which) {
         case 4: return g->submeshes;
         default: return nullptr;
     }
+}
+
+// §8f-4: handles of a mesh buffer another process or another API can import (gpu_resource.rs:498-530, 729-907 fill wgpu buffers from these
+// arrays; mesh.rs:94-123). The buffers are plain hipMalloc allocations of their own, so the IPC handle names exactly the buffer.
+int ivx_mesh_export(ivx_grid* g, int which, ivx_mesh_export_info* out) {
+    IVX_REQUIRE(g && out && which >= 0 && which <= 4, IVX_ERR_INVALID, "ivx_mesh_export: bad argument");
+    IVX_REQUIRE(g->mesh_valid || g->mesh_built, IVX_ERR_STATE, "ivx_mesh_export: the grid has no mesh");
+    memset(out, 0, sizeof(*out));
+    out->dmabuf_fd = -1;
+    void* p = nullptr;
+    size_t elem = 0, count = 0, cap = 0;
+    switch (which) {
+        case 0: p = g->positions, elem = 12, count = g->mesh_counts.n_vertices, cap = g->vcap; break;
+        case 1: p = g->normals, elem = 12, count = g->mesh_counts.n_vertices, cap = g->vcap; break;
+        case 2: p = g->indices, elem = 4, count = g->mesh_counts.n_indices, cap = g->icap; break;
+        case 3: p = g->index_materials, elem = 8, count = g->mesh_counts.n_indices, cap = g->icap; break;
+        default: p = g->submeshes, elem = sizeof(ivx_submesh), count = g->mesh_counts.n_submeshes, cap = g->scap; break;
+    }
+    if (g->submesh_manager) {  // after an incremental sync the live ranges are scattered over the buffers: everything up to the capacity may be in use
+        count = cap;
+    }
+    IVX_REQUIRE(p && cap, IVX_ERR_STATE, "ivx_mesh_export: the buffer is empty");
+    out->bytes = (uint64_t)count * elem;
+    out->capacity_bytes = (uint64_t)cap * elem;
+    out->element_bytes = (uint32_t)elem;
+    out->generation = g->mesh_generation;
+    out->device_ptr = (uint64_t)(uintptr_t)p;
+    hipIpcMemHandle_t h;
+    static_assert(sizeof(h) == sizeof(out->ipc_handle), "hipIpcMemHandle_t is 64 bytes");
+    IVX_HIP_CHECK(hipIpcGetMemHandle(&h, p));
+    memcpy(out->ipc_handle, &h, sizeof(h));
+    // a dma-buf file descriptor for APIs that import those (Vulkan VK_EXT_external_memory_dma_buf under wgpu): optional, -1 where the
+    // runtime cannot make one; the caller owns the descriptor (close it)
+    int fd = -1;
+    const size_t page = 4096, span = ((size_t)out->capacity_bytes + page - 1) / page * page;
+    if (hipMemGetHandleForAddressRange(&fd, p, span, hipMemRangeHandleTypeDmaBufFd, 0) == hipSuccess && fd >= 0) out->dmabuf_fd = fd;
+    else (void)hipGetLastError();
+    return IVX_OK;
+}
+
+// the importing side for a HIP process: the 64-byte handle of ivx_mesh_export -> a device pointer in THIS process (no context needed beyond
+// the device being usable); ivx_mesh_import_close gives it back
+int ivx_mesh_import_open(const uint8_t ipc_handle[64], int device, void** device_ptr) {
+    IVX_REQUIRE(ipc_handle && device_ptr, IVX_ERR_INVALID, "ivx_mesh_import_open: null argument");
+    IVX_HIP_CHECK(hipSetDevice(device));
+    hipIpcMemHandle_t h;
+    memcpy(&h, ipc_handle, sizeof(h));
+    IVX_HIP_CHECK(hipIpcOpenMemHandle(device_ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return IVX_OK;
+}
+int ivx_mesh_import_close(void* device_ptr) {
+    IVX_REQUIRE(device_ptr, IVX_ERR_INVALID, "ivx_mesh_import_close: null argument");
+    IVX_HIP_CHECK(hipIpcCloseMemHandle(device_ptr));
+    return IVX_OK;
+}
+
+int ivx_mesh_generation(ivx_grid* g, uint64_t* generation) {
+    IVX_REQUIRE(g && generation, IVX_ERR_INVALID, "ivx_mesh_generation: null argument");
+    *generation = g->mesh_generation;
+    return IVX_OK;
 }
 
 int ivx_inertia(ivx_grid* g, const float densities[256], ivx_moments* out) {

@@ -146,6 +146,7 @@ struct ivx_grid {
     size_t probe_point_cap, probe_entry_cap;
     uint32_t n_probe_points, n_probe_sub;
     uint64_t mesh_serial, probes_serial;  // probes are current while they were picked from the current mesh
+    uint64_t mesh_generation;  // bumped whenever a mesh buffer is reallocated: handles exported earlier (ivx_mesh_export) are stale
     // the object's occupied ranges as the reference keeps them (object.rs:1149-1280): refreshed by an explicit update, by split / clip, and by an
     // edit only when it removed a chunk (intersection.rs:255-257, 384-386, 520-522) — in between they may be wider than the voxels need, and the
     // edit, contact and probe entry points must see exactly those ranges

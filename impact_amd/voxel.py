@@ -551,6 +551,23 @@ class VoxelObjectMesh:
         self.counts = c
         return self
 
+    MESH_BUFFERS = ("positions", "normals", "indices", "index_materials", "submeshes")
+
+    def export(self, which):
+        """`ivx_mesh_export`: handles of one mesh buffer (name or number, see MESH_BUFFERS) for another process / API — dict with `ipc_handle`
+        (64 bytes, hipIpcOpenMemHandle), `dmabuf_fd` (-1 if the runtime makes none; the caller closes it), `bytes`, `capacity_bytes`,
+        `element_bytes`, `generation`"""
+        w = self.MESH_BUFFERS.index(which) if isinstance(which, str) else int(which)
+        e = np.zeros((), dtype=capi.MESH_EXPORT_DTYPE)
+        check(capi.lib().ivx_mesh_export(self.object.h, w, ptr(e.reshape(1))))
+        return {"ipc_handle": bytes(e["ipc_handle"].tobytes()), "dmabuf_fd": int(e["dmabuf_fd"]), "bytes": int(e["bytes"]), "capacity_bytes": int(e["capacity_bytes"]),
+                "element_bytes": int(e["element_bytes"]), "generation": int(e["generation"]), "device_ptr": int(e["device_ptr"])}
+
+    def generation(self) -> int:
+        g = C.c_uint64()
+        check(capi.lib().ivx_mesh_generation(self.object.h, C.byref(g)))
+        return int(g.value)
+
     def mesh_modifications(self):
         """`VoxelMeshModifications` (mesh.rs:113-123): (ranges [n,4] u32: vertex start, end, index start, end of every chunk written
         since the last report, chunks_were_removed)"""

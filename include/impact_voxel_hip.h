@@ -173,6 +173,24 @@ int ivx_mesh_report_synchronized(ivx_grid*);
 /* device pointers of the mesh buffers (hand-off to a renderer without a host round trip):
  * 0 positions, 1 normals, 2 indices, 3 index materials, 4 submeshes */
 void* ivx_mesh_device_ptr(ivx_grid*, int which);
+/* The same buffers as handles another process or another graphics / compute API can import, so that the renderer (gpu_resource.rs:498-530,
+ * 729-907 fills wgpu vertex / index / storage buffers from exactly these arrays; mesh.rs:94-123) takes the mesh without a host round trip:
+ * `ipc_handle` = hipIpcMemHandle_t of the buffer (another HIP process: hipIpcOpenMemHandle), `dmabuf_fd` = a dma-buf file descriptor of it
+ * (Vulkan / wgpu external memory: VK_EXT_external_memory_dma_buf; -1 where the runtime cannot make one; the caller closes it). `bytes` = the
+ * part in use (after ivx_mesh_sync: the capacity, the live ranges are scattered), `generation` changes whenever a buffer was reallocated
+ * (growth in ivx_remesh / ivx_voxel_step_collect / ivx_mesh_sync): handles of an older generation name freed memory — ask
+ * ivx_mesh_generation every frame (no device work) and export again when it moved. which: as ivx_mesh_device_ptr. */
+typedef struct {
+    uint8_t ipc_handle[64];
+    int32_t dmabuf_fd;
+    uint32_t element_bytes;
+    uint64_t bytes, capacity_bytes, generation, device_ptr;
+} ivx_mesh_export_info;
+int ivx_mesh_export(ivx_grid*, int which, ivx_mesh_export_info* out);
+int ivx_mesh_generation(ivx_grid*, uint64_t* generation);
+/* the importing side for a HIP consumer in another process: handle -> device pointer valid in the calling process, and back */
+int ivx_mesh_import_open(const uint8_t ipc_handle[64], int device, void** device_ptr);
+int ivx_mesh_import_close(void* device_ptr);
 
 /* ---- a8: mass / inertia ------------------------------------------------------------------------- */
 /* VoxelObjectInertialPropertyManager::initialized_from (object/inertia.rs:125-136, 615-790) */
