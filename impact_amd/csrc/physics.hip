@@ -789,7 +789,7 @@ __device__ __forceinline__ void mg_barrier(uint32_t* counter, uint32_t target, u
         while ((int32_t)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > MG_SPIN_LIMIT) {
-                __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (a host-mapped word: ivx_world_check_solve)
                 break;
             }
         }
@@ -989,12 +989,25 @@ static int launch_solve(ivx_world* w, size_t lds, ReplayView rv = ReplayView(), 
 // number of workgroups the solve is spread over: as many as the widest level fills with one chain per thread, at most 16 (all
 // resident: 256 CUs); 1 = the single-workgroup kernel with the bodies in LDS. ivx_world_set_solver_groups overrides (tests force
 // either path on small scenes).
+// (co-residency of the G working workgroups is what the grid barrier rests on: G x spread blocks must fit the device beside nothing else of
+// this launch — checked against the occupancy query; a world whose barrier ever timed out stays on one workgroup)
 static uint32_t solver_groups(const ivx_world* w) {
-    if (w->solver_groups_forced) return w->solver_groups_forced;
+    if (w->mg_disabled) return 1u;
+    static const int resident = [] {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_solve_mg<0>, (int)MG_THREADS, 0) != hipSuccess) per_cu = 0;
+        int per_cu1 = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu1, k_solve_mg<1>, (int)MG_THREADS, 0) != hipSuccess) per_cu1 = 0;
+        return per_cu < per_cu1 ? per_cu : per_cu1;
+    }();
+    const uint32_t fit = (uint32_t)(resident > 0 ? resident : 0) * (uint32_t)w->ctx->n_cu / 8u;  // (/ 8: every eighth block works, see k_solve_mg)
+    if (fit < 2u) return 1u;
+    if (w->solver_groups_forced) return w->solver_groups_forced < fit ? w->solver_groups_forced : fit;
     const uint32_t widest = w->max_level_items[0] > w->max_level_items[1] ? w->max_level_items[0] : w->max_level_items[1];
     if (widest <= 256u) return 1u;  // (a level that fits one workgroup at one wave per SIMD gains nothing from more)
-    const uint32_t g = (widest + MG_THREADS - 1u) / MG_THREADS;
-    return g < 16u ? g : 16u;
+    uint32_t g = (widest + MG_THREADS - 1u) / MG_THREADS;
+    g = g < 16u ? g : 16u;
+    return g < fit ? g : fit;
 }
 
 // developer switch (never set in production): IVX_SOLVER_DRY bit 0 = walk the levels without running the chains, bit 1 = without the grid
@@ -1035,7 +1048,7 @@ static int launch_solve_mg(ivx_world* w, uint32_t groups, ReplayView rv = Replay
                        reinterpret_cast<float4*>(w->acc[w->cur]), w->n_contacts, w->cb, reinterpret_cast<float4*>(w->dynst), w->items + w->item_offset[PHASE],
                        reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], w->level_start + w->level_offset[PHASE],
                        w->tile_base + w->level_offset[PHASE], reinterpret_cast<const float4*>(w->packed[PHASE]),
-                       w->n_levels[PHASE], w->barrier_words, base, w->barrier_words + 1, ivx_solver_dry(), spread, rv, replay_flag);
+                       w->n_levels[PHASE], w->barrier_words, base, w->mg_err_dev, ivx_solver_dry(), spread, rv, replay_flag);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

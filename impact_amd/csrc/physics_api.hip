@@ -253,6 +253,19 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
 
 }  // namespace
 
+// The multi-workgroup solve's grid barrier is hand-rolled and bounded: a workgroup that never sees the others arrive gives up, sets this word
+// and the phase goes on unsynchronised — the bodies of that step are wrong. Every entry point that waits on the world's stream looks at the
+// word afterwards (it is host-mapped: no copy), reports the step as failed, clears the word, and keeps the world on the single-workgroup
+// kernel from then on.
+static int ivx_world_check_solve(ivx_world* w, const char* who) {
+    if (!w->mg_err_host || w->mg_err_host[0] == 0u) return IVX_OK;
+    w->mg_err_host[0] = 0u;
+    w->mg_disabled = 1;
+    ivx_set_error("%s: the solver's grid barrier timed out in an earlier step of this world (a workgroup of the solve was not resident): that step's "
+                  "bodies are invalid; the world now solves on one workgroup", who);
+    return IVX_ERR_HIP;
+}
+
 extern "C" {
 
 int ivx_world_create(ivx_ctx* c, const ivx_solver_config* cfg, ivx_world** out) {
@@ -270,6 +283,16 @@ int ivx_world_create(ivx_ctx* c, const ivx_solver_config* cfg, ivx_world** out) 
         delete w;
         return IVX_ERR_HIP;
     }
+    if (hipHostMalloc(reinterpret_cast<void**>(&w->mg_err_host), 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&w->mg_err_dev), w->mg_err_host, 0) != hipSuccess) {
+        ivx_set_error("ivx_world_create: host-mapped allocation failed");
+        if (w->mg_err_host) (void)hipHostFree(w->mg_err_host);
+        (void)hipFree(w->barrier_words);
+        delete w;
+        return IVX_ERR_HIP;
+    }
+    w->mg_err_host[0] = 0u;
+    w->mg_disabled = 0;
     *out = w;
     return IVX_OK;
 }
@@ -282,6 +305,7 @@ void ivx_world_destroy(ivx_world* w) {
                     w->kin_applied, w->kin_qstart, w->kin_snap};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (w->mg_err_host) (void)hipHostFree(w->mg_err_host);
     if (w->ev_ready)
         for (int i = 0; i < 5; ++i) (void)hipEventDestroy(w->ev[i]);
     delete w;
@@ -346,6 +370,7 @@ int ivx_world_set_bodies(ivx_world* w, const ivx_rigid_body* dyn, size_t n_dyn, 
 int ivx_world_get_bodies(ivx_world* w, ivx_rigid_body* dyn, ivx_kinematic_body* kin) {
     IVX_REQUIRE(w, IVX_ERR_INVALID, "ivx_world_get_bodies: null world");
     IVX_HIP_CHECK(hipStreamSynchronize(w->ctx->stream));
+    if (int rc = ivx_world_check_solve(w, "ivx_world_get_bodies")) return rc;
     if (dyn && w->n_dyn) IVX_HIP_CHECK(hipMemcpy(dyn, w->dyn, w->n_dyn * sizeof(ivx_rigid_body), hipMemcpyDeviceToHost));
     if (kin && w->n_kin) IVX_HIP_CHECK(hipMemcpy(kin, w->kin, w->n_kin * sizeof(ivx_kinematic_body), hipMemcpyDeviceToHost));
     return IVX_OK;
@@ -353,6 +378,7 @@ int ivx_world_get_bodies(ivx_world* w, ivx_rigid_body* dyn, ivx_kinematic_body* 
 
 int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, size_t* n_prepared) {
     IVX_REQUIRE(w && (contacts || n == 0), IVX_ERR_INVALID, "ivx_world_set_contacts: null argument");
+    if (int rc = ivx_world_check_solve(w, "ivx_world_set_contacts")) return rc;  // (no wait here: a flag that is already up)
     IVX_REQUIRE(n < (1u << 24), IVX_ERR_CAPACITY, "ivx_world_set_contacts: more than 2^24 contacts");
     for (size_t i = 0; i < n; ++i) {
         const ivx_contact& c = contacts[i];
@@ -596,6 +622,7 @@ static int world_step_enqueue(ivx_world* w, float dt, bool timed) {
 
 int ivx_world_step_enqueue(ivx_world* w, float dt) {
     IVX_REQUIRE(w, IVX_ERR_INVALID, "ivx_world_step_enqueue: null world");
+    if (int rc = ivx_world_check_solve(w, "ivx_world_step_enqueue")) return rc;  // (an earlier step's flag, if it is up by now)
     return world_step_enqueue(w, dt, false);
 }
 
@@ -604,16 +631,12 @@ int ivx_world_step(ivx_world* w, float dt, ivx_physics_result* out) {
     int rc = world_step_enqueue(w, dt, out != nullptr);
     if (rc) return rc;
     IVX_HIP_CHECK(hipStreamSynchronize(w->ctx->stream));
+    if ((rc = ivx_world_check_solve(w, "ivx_world_step"))) return rc;
     if (out) {
         memset(out, 0, sizeof(*out));
         out->n_contacts = w->n_contacts;
         out->n_levels[0] = w->n_levels[0];
         out->n_levels[1] = w->n_levels[1];
-        if (w->solver_groups_used > 1u) {
-            uint32_t err = 0;
-            IVX_HIP_CHECK(hipMemcpy(&err, w->barrier_words + 1, sizeof(err), hipMemcpyDeviceToHost));
-            IVX_REQUIRE(err == 0, IVX_ERR_HIP, "ivx_world_step: the solver's grid barrier timed out (a workgroup of the solve was not resident)");
-        }
         uint32_t nb = 0;
         {
             std::vector<uint8_t> t(w->n_dyn);
@@ -661,6 +684,7 @@ int ivx_world_contact_state(ivx_world* w, uint64_t* ids, float* impulses3, size_
         for (uint32_t s = 0; s < w->n_contacts; ++s) ids[s] = w->cache[s].id;
     if (impulses3 && w->n_contacts) {
         IVX_HIP_CHECK(hipStreamSynchronize(w->ctx->stream));
+        if (int rc = ivx_world_check_solve(w, "ivx_world_contact_state")) return rc;
         std::vector<float> a((size_t)w->n_contacts * 4);
         IVX_HIP_CHECK(hipMemcpy(a.data(), w->acc[w->cur], a.size() * 4, hipMemcpyDeviceToHost));
         for (uint32_t s = 0; s < w->n_contacts; ++s)

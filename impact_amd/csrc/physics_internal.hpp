@@ -82,6 +82,9 @@ struct ivx_world {
     uint32_t n_joint_refs;
     float* dynst;
     uint32_t* barrier_words;
+    uint32_t* mg_err_host;  // host-mapped word the multi-workgroup solve sets when its grid barrier gave up (checked at every wait on the stream)
+    uint32_t* mg_err_dev;   // its device-side address
+    int mg_disabled;        // a barrier timed out in this world before: the solve stays on the single-workgroup kernel
     uint32_t barrier_count;
     uint32_t solver_groups_forced, solver_groups_used;
     int schedule_valid, prepared_fresh;
