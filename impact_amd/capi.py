@@ -147,7 +147,7 @@ EXPORTED_SYMBOLS = [
     "ivx_world_create", "ivx_world_destroy", "ivx_world_set_bodies", "ivx_world_get_bodies", "ivx_world_set_contacts",
     "ivx_world_set_spherical_joints", "ivx_world_step", "ivx_world_step_enqueue", "ivx_world_prepare", "ivx_world_advance_momenta", "ivx_world_solve", "ivx_world_advance_configurations",
     "ivx_impact_fracturing_config_default", "ivx_generate_impact_fracture_points", "ivx_delaunay_construct", "ivx_delaunay_destroy", "ivx_delaunay_counts",
-    "ivx_delaunay_download", "ivx_delaunay_aabb", "ivx_delaunay_boundary_face_planes", "ivx_voronoi_polyhedron", "ivx_voronoi_bounded_aabb",
+    "ivx_delaunay_download", "ivx_delaunay_aabb", "ivx_delaunay_displace_vertices", "ivx_delaunay_boundary_face_planes", "ivx_voronoi_polyhedron", "ivx_voronoi_bounded_aabb",
     "ivx_comm_unique_id", "ivx_comm_init", "ivx_comm_init_local", "ivx_comm_init_ipc", "ivx_comm_info", "ivx_comm_selftest", "ivx_selftest_mesher_division", "ivx_comm_destroy", "ivx_slab_create", "ivx_slab_destroy",
     "ivx_slabs_step_enqueue", "ivx_slabs_step_collect", "ivx_slab_region_map",
     "ivx_world_set_solver_groups", "ivx_world_solver_info", "ivx_world_contact_state",
@@ -290,6 +290,7 @@ def lib():
         "ivx_delaunay_counts": (i32, [vp, vp]),
         "ivx_delaunay_download": (i32, [vp, vp, vp, vp]),
         "ivx_delaunay_aabb": (i32, [vp, vp]),
+        "ivx_delaunay_displace_vertices": (i32, [vp, vp]),
         "ivx_delaunay_boundary_face_planes": (i32, [vp, vp, sz, C.POINTER(sz)]),
         "ivx_voronoi_polyhedron": (i32, [vp, u32, vp, sz, vp, sz, vp, sz, vp]),
         "ivx_voronoi_bounded_aabb": (i32, [vp, sz, vp, sz, vp, vp, C.POINTER(i32)]),

@@ -1191,7 +1191,9 @@ int ivx_copy_polyhedra(ivx_grid* parent, const float* planes4, const uint32_t* p
     }
     // 2. per child: flags + per-chunk boxes, voxel box, unit-density mass (= voxel count); all enqueued, one wait
     const size_t per_child = 12 * sizeof(uint32_t) + sizeof(double);
-    const size_t stage_bytes = info_total * sizeof(ivx_chunk_info) + n_sets * per_child + 1024;
+    // (the region scalars of step 3 get a slot of their own behind the per-child tails: written while the chunk records ahead of them are still being read)
+    const size_t scalars_off = 1024 + info_total * sizeof(ivx_chunk_info) + n_sets * per_child;
+    const size_t stage_bytes = scalars_off + n_sets * 8;
     if ((rc = ensure_host_scratch(parent, stage_bytes))) return fail(rc);
     char* stage = static_cast<char*>(parent->host_scratch);
     memcpy(stage, ones, sizeof(ones));
@@ -1260,14 +1262,14 @@ int ivx_copy_polyhedra(ivx_grid* parent, const float* planes4, const uint32_t* p
         if ((rc = ivx_launch_ccl_local(c, 1))) return fail(rc);
         if ((rc = ivx_launch_ccl_merge(c))) return fail(rc);
         if ((rc = ivx_launch_ccl_resolve(c))) return fail(rc);
-        if (hipMemcpyAsync(stage + 1024 + f * 8, c->rscalar, 8, hipMemcpyDeviceToHost, s) != hipSuccess) return fail(IVX_ERR_HIP);
+        if (hipMemcpyAsync(stage + scalars_off + f * 8, c->rscalar, 8, hipMemcpyDeviceToHost, s) != hipSuccess) return fail(IVX_ERR_HIP);
     }
     if (hipStreamSynchronize(s) != hipSuccess) return fail(IVX_ERR_HIP);
     for (size_t f = 0; f < n_sets; ++f) {
         ivx_grid* c = fr[f].c;
         if (!c) continue;
         uint32_t sc[2];
-        memcpy(sc, stage + 1024 + f * 8, 8);
+        memcpy(sc, stage + scalars_off + f * 8, 8);
         if (sc[1] & 1u) {
             ivx_set_error("ivx_copy_polyhedra: a chunk has more than 254 local regions");
             return fail(IVX_ERR_CAPACITY);

@@ -934,12 +934,14 @@ __global__ __launch_bounds__(64) void k_kin_prefix(uint32_t n_kin, uint32_t n_dy
 }
 
 // dynamic bodies a joint is anchored to are constrained bodies of the step (prepare_spherical_joint -> add_body_pair, solver.rs:182-215)
-__global__ __launch_bounds__(256) void k_mark_bodies(uint32_t n, const uint32_t* __restrict__ refs, uint32_t n_dyn, uint8_t* __restrict__ touched) {
+// (both kinds bounds-checked here too: the references outlive the body set they were validated against only until ivx_world_set_bodies,
+// which drops them when a count shrinks below one of them)
+__global__ __launch_bounds__(256) void k_mark_bodies(uint32_t n, const uint32_t* __restrict__ refs, uint32_t n_dyn, uint32_t n_kin, uint8_t* __restrict__ touched) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const uint32_t r = refs[i];
     if (!(r & IVX_KINEMATIC_BODY) && r < n_dyn) touched[r] = 1;
-    if (r & IVX_KINEMATIC_BODY) touched[n_dyn + (r & 0x7FFFFFFFu)] = 1;  // (kinematic anchors are constrained bodies as well)
+    if ((r & IVX_KINEMATIC_BODY) && (r & 0x7FFFFFFFu) < n_kin) touched[n_dyn + (r & 0x7FFFFFFFu)] = 1;  // (kinematic anchors are constrained bodies as well)
 }
 
 }  // namespace
@@ -963,7 +965,7 @@ int ivx_launch_phys_prepare_contacts(ivx_world* w, const int32_t* d_prev_slot) {
 
 int ivx_launch_phys_mark_joint_bodies(ivx_world* w) {
     if (w->n_joint_refs == 0) return IVX_OK;
-    hipLaunchKernelGGL(k_mark_bodies, dim3((w->n_joint_refs + 255u) / 256u), dim3(256), 0, w->ctx->stream, w->n_joint_refs, w->joint_refs, w->n_dyn, w->touched);
+    hipLaunchKernelGGL(k_mark_bodies, dim3((w->n_joint_refs + 255u) / 256u), dim3(256), 0, w->ctx->stream, w->n_joint_refs, w->joint_refs, w->n_dyn, w->n_kin, w->touched);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

@@ -360,6 +360,12 @@ int ivx_world_set_bodies(ivx_world* w, const ivx_rigid_body* dyn, size_t n_dyn, 
     if (n_dyn) IVX_HIP_CHECK(hipMemcpy(w->dyn, dyn, n_dyn * sizeof(ivx_rigid_body), hipMemcpyHostToDevice));
     if (n_kin) IVX_HIP_CHECK(hipMemcpy(w->kin, kin, n_kin * sizeof(ivx_kinematic_body), hipMemcpyHostToDevice));
     const bool resized = w->n_dyn != n_dyn || w->n_kin != n_kin;
+    if ((n_dyn < w->n_dyn || n_kin < w->n_kin) && w->n_joint_refs) {
+        // joints name bodies by index and were validated against the old counts: a set that shrank drops them (the caller sets them again)
+        (void)hipFree(w->joint_refs);
+        w->joint_refs = nullptr;
+        w->n_joint_refs = 0;
+    }
     w->n_dyn = (uint32_t)n_dyn;
     w->n_kin = (uint32_t)n_kin;
     if (resized) w->schedule_valid = 0;

@@ -146,6 +146,8 @@ struct ivx_slab {
     unsigned long long* host_head_dev;  // its device-side address
     unsigned long long head_seq;        // sequence number of the last publish
     std::vector<unsigned long long> host_records;
+    size_t map_offset;                  // where the region map starts in host_records (0: no collected step)
+    int local_err;                      // first error of this rank's last enqueue (reported by collect, after the step's collectives)
     bool has_lo, has_hi;
     int enqueued;
 };
@@ -442,8 +444,12 @@ int ivx_comm_selftest(ivx_ctx* c) {
             break;
         }
         // the neighbour exchange's call pattern, with this rank as its own neighbour
-        if (g_rccl.GroupStart() != 0 || g_rccl.Send(dev, N, NCCL_UINT8, 0, comm, s) != 0 || g_rccl.Recv(dev + N, N, NCCL_UINT8, 0, comm, s) != 0 ||
-            g_rccl.GroupEnd() != 0) {
+        bool group_ok = g_rccl.GroupStart() == 0;
+        if (group_ok) {  // (a group that was opened is always closed, whatever the calls inside it returned)
+            const bool sent = g_rccl.Send(dev, N, NCCL_UINT8, 0, comm, s) == 0 && g_rccl.Recv(dev + N, N, NCCL_UINT8, 0, comm, s) == 0;
+            group_ok = (g_rccl.GroupEnd() == 0) && sent;
+        }
+        if (!group_ok) {
             ivx_set_error("ivx_comm_selftest: grouped ncclSend / ncclRecv failed");
             result = IVX_ERR_HIP;
             break;
@@ -511,6 +517,8 @@ int ivx_slab_create(ivx_comm* m, ivx_grid* g, int rank, ivx_slab** out) {
     sl->has_lo = rank > 0;
     sl->has_hi = rank + 1 < m->nranks;
     sl->enqueued = 0;
+    sl->map_offset = 0;
+    sl->local_err = IVX_OK;
     const size_t msg = (sl->halo_bytes + sl->face_bytes + 255) & ~(size_t)255;
     bool ok = true;
     for (int s = 0; s < 2; ++s) {
@@ -584,12 +592,19 @@ int ivx_slabs_step_enqueue(ivx_slab** slabs, size_t n) {
     for (size_t i = 0; i < n; ++i)
         IVX_REQUIRE(slabs[i] && slabs[i]->comm == c && (c->rank >= 0 || slabs[i]->rank == (int)i), IVX_ERR_INVALID, "ivx_slabs_step_enqueue: slab %zu out of order", i);
     int rc;
+    // A LOCAL failure between the collectives (a stage that cannot be enqueued: capacity, a bad program) must not leave the other ranks waiting
+    // inside ncclGroupEnd / ncclAllGather for a rank that has returned: the rank notes its first error, goes on through every exchange of the
+    // step with whatever its buffers hold, and raises bit 3 of the flags word of its record; collect then fails on EVERY rank (the flags are
+    // OR-ed over the gathered records), the failing rank with its own code. Only a failing exchange itself still returns at once.
+    int local_err = IVX_OK;
+    auto note = [&](int code) {
+        if (code && !local_err) local_err = code;
+    };
     // 1. sample, exchange the face planes
     for (size_t i = 0; i < n; ++i) {
         ivx_slab* sl = slabs[i];
-        if ((rc = ivx_voxel_step_enqueue(sl->grid, IVX_STAGE_SAMPLE))) return rc;
-        if (sl->has_lo || sl->has_hi)
-            if ((rc = ivx_halo_pack_both_enqueue(sl->grid, sl->has_lo ? sl->send[0] : nullptr, sl->has_hi ? sl->send[1] : nullptr, 0))) return rc;
+        note(ivx_voxel_step_enqueue(sl->grid, IVX_STAGE_SAMPLE));
+        if (sl->has_lo || sl->has_hi) note(ivx_halo_pack_both_enqueue(sl->grid, sl->has_lo ? sl->send[0] : nullptr, sl->has_hi ? sl->send[1] : nullptr, 0));
     }
     if ((rc = exchange(slabs, n, slabs[0]->halo_bytes))) return rc;
     // 2. derived state + slab-local regions (+ moments and occupied ranges: they need nothing more from the neighbours); the planes
@@ -598,19 +613,25 @@ int ivx_slabs_step_enqueue(ivx_slab** slabs, size_t n) {
         ivx_slab* sl = slabs[i];
         install_ghosts(sl);
         ivx_step_preset_ahead(sl->grid, IVX_SCRATCH_SN);  // the remesh phase below has no first kernel to host its preset
-        if ((rc = ivx_voxel_step_enqueue(sl->grid, IVX_STAGE_DERIVE | IVX_STAGE_OCCUPIED | IVX_STAGE_REGIONS | IVX_STAGE_INERTIA))) return rc;
-        if (sl->has_lo || sl->has_hi)
-            if ((rc = ivx_halo_pack_both_enqueue(sl->grid, sl->has_lo ? sl->send[0] : nullptr, sl->has_hi ? sl->send[1] : nullptr, 1))) return rc;
+        if (!local_err) note(ivx_voxel_step_enqueue(sl->grid, IVX_STAGE_DERIVE | IVX_STAGE_OCCUPIED | IVX_STAGE_REGIONS | IVX_STAGE_INERTIA));
+        if (sl->has_lo || sl->has_hi) note(ivx_halo_pack_both_enqueue(sl->grid, sl->has_lo ? sl->send[0] : nullptr, sl->has_hi ? sl->send[1] : nullptr, 1));
     }
     if ((rc = exchange(slabs, n, slabs[0]->halo_bytes + slabs[0]->face_bytes))) return rc;
     // 3. remesh (ghost layers in place), the slab's record, the one small all-gather
     for (size_t i = 0; i < n; ++i) {
         ivx_slab* sl = slabs[i];
         install_ghosts(sl);
-        if (sl->has_hi)
-            if ((rc = ivx_region_face_pairs_enqueue(sl->grid, 1, sl->recv[1] + sl->halo_bytes))) return rc;
-        if ((rc = ivx_voxel_step_enqueue(sl->grid, IVX_STAGE_REMESH))) return rc;
-        if ((rc = ivx_step_record_enqueue(sl->grid, sl->record))) return rc;
+        if (sl->has_hi && !local_err) note(ivx_region_face_pairs_enqueue(sl->grid, 1, sl->recv[1] + sl->halo_bytes));
+        if (!local_err) note(ivx_voxel_step_enqueue(sl->grid, IVX_STAGE_REMESH));
+        if (!local_err) note(ivx_step_record_enqueue(sl->grid, sl->record));
+        if (local_err) {  // a record that says so (words 0, 1: no components, no pairs; word 17: the flags)
+            unsigned long long head[18];
+            memset(head, 0, sizeof(head));
+            head[17] = 8ull;
+            IVX_HIP_CHECK(hipMemcpyAsync(sl->record, head, sizeof(head), hipMemcpyHostToDevice, c->ctx->stream));
+            IVX_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));  // (`head` is a local)
+        }
+        sl->local_err = local_err;
     }
     if ((rc = all_gather(slabs, n, HEAD_WORDS))) return rc;
     for (size_t i = 0; i < n; ++i) slabs[i]->enqueued = 1;
@@ -719,6 +740,18 @@ int ivx_slabs_step_collect(ivx_slab** slabs, size_t n, ivx_slab_result* out) {
         ioff += rec[(size_t)r * words + 15];
         tri_total += rec[(size_t)r * words + 15] / 3;
     }
+    if (flags & 8u) {  // a rank could not enqueue its step: every rank fails here, after the step's collectives, the failing one with its own code
+        int mine = IVX_OK;
+        for (size_t i = 0; i < n; ++i) {
+            if (slabs[i]->local_err && !mine) mine = slabs[i]->local_err;
+            slabs[i]->enqueued = 0;
+            slabs[i]->grid->pending_stages = 0;
+        }
+        IVX_HIP_CHECK(hipStreamSynchronize(s));
+        if (mine) return mine;  // (ivx_last_error holds the stage's own message)
+        ivx_set_error("ivx_slabs_step_collect: another rank could not enqueue its step");
+        return IVX_ERR_STATE;
+    }
     for (size_t i = 0; i < n; ++i) {
         ivx_slab* sl = slabs[i];
         ivx_slab_result& o = out[i];
@@ -744,6 +777,7 @@ int ivx_slabs_step_collect(ivx_slab** slabs, size_t n, ivx_slab_result* out) {
     }
     // the map slab-local component -> global region of every rank stays with the keeper for ivx_slab_region_map
     keeper->host_records.resize((size_t)world * words + ids.size() + (size_t)world + 1);
+    keeper->map_offset = (size_t)world * words;
     unsigned long long* tail = keeper->host_records.data() + (size_t)world * words;
     for (int r = 0; r <= world; ++r) tail[r] = offs[r];
     for (size_t i = 0; i < ids.size(); ++i) tail[world + 1 + i] = ids[i];
@@ -759,12 +793,7 @@ int ivx_slab_region_map(ivx_slab* keeper, int rank, uint32_t* out, size_t cap, s
     IVX_REQUIRE(keeper && n_out && rank >= 0 && rank < keeper->comm->nranks, IVX_ERR_INVALID, "ivx_slab_region_map: bad argument");
     const int world = keeper->comm->nranks;
     const std::vector<unsigned long long>& h = keeper->host_records;
-    size_t base = 0;
-    // the tail sits behind world * words record words: find it from the vector's size (offs[world] entries + world + 1 offsets)
-    for (size_t words : {HEAD_WORDS, keeper->rec_words}) {
-        const size_t b = (size_t)world * words;
-        if (h.size() >= b + (size_t)world + 1 && h.size() == b + (size_t)world + 1 + (size_t)h[b + world]) base = b;
-    }
+    const size_t base = keeper->map_offset;
     IVX_REQUIRE(base, IVX_ERR_STATE, "ivx_slab_region_map: no collected step");
     const size_t lo = (size_t)h[base + rank], hi = (size_t)h[base + rank + 1];
     *n_out = hi - lo;

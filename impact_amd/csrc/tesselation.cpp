@@ -14,8 +14,9 @@
 //   fragment = copy of the cell shrunk by 0.1 voxel                  fracturing.rs:1190-1240; region = hull of the boundary points 1537-1632
 //
 // The reference builds the tetrahedralisation by incremental insertion with Lawson flips and the `robust` crate's adaptive
-// predicates; here it is Bowyer–Watson with the predicates evaluated in binary128 (exact for every input whose coordinate
-// differences fit ~35 bits, and far below f32 resolution otherwise) and a cavity that is widened across faces the new point lies
+// predicates; here it is Bowyer–Watson with the predicates evaluated in binary128 (the orientation test, degree 3, is exact for inputs whose
+// coordinate differences fit ~35 bits and the in-sphere test, degree 5, for ~21 bits — lattice-like inputs; otherwise the rounding is 2^-113
+// relative, far below f32 resolution, but not a guaranteed sign for exactly co-spherical points, where `robust::insphere` returns 0) and a cavity that is widened across faces the new point lies
 // on, so no flat tetrahedron is ever created. For points in general position the Delaunay tetrahedralisation is unique, so both
 // constructions give the same tetrahedra; for degenerate inputs (regular grids) both give A Delaunay tetrahedralisation, not
 // necessarily the same one — and the order of tetrahedra, of a cell's planes and vertices is this implementation's own (the
@@ -293,6 +294,15 @@ int ivx_delaunay_download(const ivx_delaunay* d, float* vertices3, uint32_t* tet
 }
 
 // compute_aabb (delaunay.rs:500-505): of the real points; returns IVX_ERR_STATE when there are none
+// DelaunayTetrahedralization::displace_vertices (delaunay.rs; FracturingProcess::offset_tetrahedralization_to_fracture_region_object,
+// fracturing.rs:996-1002): every vertex, the four ad-hoc ones included, moves by `offset` in f32 — AFTER the construction, which has seen the
+// points where they were given (their bounding sphere, the minimum point separation, every predicate).
+int ivx_delaunay_displace_vertices(ivx_delaunay* d, const float offset[3]) {
+    IVX_REQUIRE(d && offset, IVX_ERR_INVALID, "ivx_delaunay_displace_vertices: null argument");
+    for (P3& v : d->vertices) v = v + P3{offset[0], offset[1], offset[2]};
+    return IVX_OK;
+}
+
 int ivx_delaunay_aabb(const ivx_delaunay* d, float aabb[6]) {
     IVX_REQUIRE(d && aabb, IVX_ERR_INVALID, "ivx_delaunay_aabb: null argument");
     IVX_REQUIRE(d->vertices.size() > 4, IVX_ERR_STATE, "ivx_delaunay_aabb: empty tetrahedralization");

@@ -66,6 +66,14 @@ class DelaunayTetrahedralization:
             check(capi.lib().ivx_delaunay_download(self.h, ptr(self.vertices), ptr(self.tetrahedra) if self.n_tetrahedra else None,
                                                    ptr(self.neighbors) if self.n_tetrahedra else None))
 
+    def displace_vertices(self, offset):
+        """`displace_vertices` (fracturing.rs:996-1002): move every vertex by `offset` (f32) after the construction"""
+        o = np.ascontiguousarray(offset, dtype=np.float32).reshape(3)
+        check(capi.lib().ivx_delaunay_displace_vertices(self.h, ptr(o)))
+        if self.n_vertices:
+            check(capi.lib().ivx_delaunay_download(self.h, ptr(self.vertices), ptr(self.tetrahedra) if self.n_tetrahedra else None,
+                                                   ptr(self.neighbors) if self.n_tetrahedra else None))
+
     def close(self):
         if getattr(self, "h", None):
             capi.lib().ivx_delaunay_destroy(self.h)
@@ -113,10 +121,14 @@ def compute_bounded_aabb(polyhedron, bounding_aabb):
     return out if has.value else None
 
 
-def fragment_plane_sets(fracture_points, bounding_aabb, shift: float = -0.1):
+def fragment_plane_sets(fracture_points, bounding_aabb, shift: float = -0.1, displacement=None):
     """Delaunay of the fracture points -> per point its Voronoi cell as (planes displaced by `shift`, bounded box), cells without
-    overlap left out (FracturingProcess::initialize + generate_fragment, fracturing.rs:976-994, 1190-1207). -> (list of (vertex, planes, aabb), tetrahedralization)"""
+    overlap left out (FracturingProcess::initialize + generate_fragment, fracturing.rs:976-994, 1190-1207). `displacement`: moved by that much
+    AFTER the construction (offset_tetrahedralization_to_fracture_region_object, fracturing.rs:996-1002: the reference builds on the points as
+    sampled and then displaces the vertices). -> (list of (vertex, planes, aabb), tetrahedralization)"""
     d = DelaunayTetrahedralization(fracture_points)
+    if displacement is not None:
+        d.displace_vertices(displacement)
     out = []
     for v in d.internal_vertex_indices():
         poly = d.voronoi_polyhedron(v)
@@ -146,9 +158,10 @@ def fracture_voxel_object(obj, boundary_points, fracture_points):
     if outcome != 1:
         return {"region_outcome": outcome, "fragments": []}
     # the fracture points in the region object's frame (offset_tetrahedralization_to_fracture_region_object, fracturing.rs:996-1002)
-    pts = np.asarray(fracture_points, dtype=np.float32) - np.asarray(origin, dtype=np.float32)
+    # (built on the points as given, THEN displaced: the bounding sphere, the minimum point separation and the predicates see the original coordinates)
     rcc = np.asarray(region.chunk_counts, dtype=np.float32) * 16.0
-    sets, tets = fragment_plane_sets(pts, np.array([0.0, 0.0, 0.0, rcc[0], rcc[1], rcc[2]], dtype=np.float32))
+    sets, tets = fragment_plane_sets(np.asarray(fracture_points, dtype=np.float32), np.array([0.0, 0.0, 0.0, rcc[0], rcc[1], rcc[2]], dtype=np.float32),
+                                     displacement=-np.asarray(origin, dtype=np.float32))
     frags = []
     if sets:
         res = region.copy_polyhedra([s[2] for s in sets], [s[1] for s in sets])

@@ -377,6 +377,8 @@ int ivx_delaunay_construct(const float* points3, size_t n_points, ivx_delaunay**
 void ivx_delaunay_destroy(ivx_delaunay*);
 int ivx_delaunay_counts(const ivx_delaunay*, uint32_t counts[2] /* vertices incl. the 4 ad-hoc ones, tetrahedra */);
 int ivx_delaunay_download(const ivx_delaunay*, float* vertices3, uint32_t* tet_vertices4, uint32_t* tet_neighbors4 /* across the face opposite corner c */);
+/* displace_vertices (fracturing.rs:996-1002: the tetrahedralization built on the points as given is moved into the region object's frame) */
+int ivx_delaunay_displace_vertices(ivx_delaunay*, const float offset[3]);
 int ivx_delaunay_aabb(const ivx_delaunay*, float aabb[6]);
 int ivx_delaunay_boundary_face_planes(const ivx_delaunay*, float* planes4 /* outward unit normal, displacement */, size_t cap, size_t* n_out);
 int ivx_voronoi_polyhedron(const ivx_delaunay*, uint32_t vertex, float* vertices3, size_t cap_vertices, float* rays6 /* origin, unit direction */, size_t cap_rays,
