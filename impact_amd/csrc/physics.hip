@@ -600,6 +600,17 @@ __device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t rs, uint32_t byt
     v.x = __float_as_uint(f.x), v.y = __float_as_uint(f.y), v.z = __float_as_uint(f.z), v.w = __float_as_uint(f.w);
     __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byte_off, 0, 16);
 }
+// The hand-off store of the multi-workgroup solve. A write-through (sc1) store is what another workgroup ANYWHERE on the chip can read back with
+// an sc1 load — but it also drops the line from the XCD's L2, so the reader's load goes to the memory side: ~2 us of every level. When all
+// working workgroups sit on ONE XCD (k_solve_mg places them so and CHECKS it, `one_xcd`), their common L2 is the point of coherence: a plain
+// store (acknowledged by that L2: the storing wave's s_waitcnt vmcnt(0) still stands before the barrier) and an L1-bypassing load (sc1) meet
+// there. Placement decides the form, never the result.
+__device__ __forceinline__ void st16_shared(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, float4 f, bool one_xcd) {
+    u32x4 v;
+    v.x = __float_as_uint(f.x), v.y = __float_as_uint(f.y), v.z = __float_as_uint(f.z), v.w = __float_as_uint(f.w);
+    if (one_xcd) __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byte_off, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byte_off, 0, 16);
+}
 
 // What a chain reads that does not change during the solve — its (up to) four prepared contacts and the two bodies' constants — comes from a
 // PACKED copy made once per step (k_pack_items): one record per item of the schedule, stored tile by tile of 64 consecutive items of a level,
@@ -627,12 +638,12 @@ __device__ __forceinline__ void pack_contact(const PhysContact& p, float4* out /
     }
 }
 template <int PHASE>
-__device__ __forceinline__ PhysContact unpack_contact(const float4* in /* stride 64 */) {
+__device__ __forceinline__ PhysContact unpack_contact(const float4* in /* the contact's CJ words of the item's record, in registers */) {
     PhysContact p = {};
-    const float4 a = in[0], b = in[64], c = in[128];
+    const float4 a = in[0], b = in[1], c = in[2];
     p.normal[0] = a.x, p.normal[1] = a.y, p.normal[2] = a.z;
     if (PHASE == 0) {
-        const float4 d = in[192], e = in[256];
+        const float4 d = in[3], e = in[4];
         p.tangent[0] = a.w, p.tangent[1] = b.x, p.tangent[2] = b.y;
         p.bitangent[0] = b.z, p.bitangent[1] = b.w, p.bitangent[2] = c.x;
         p.m_n = c.y, p.m_t = c.z, p.m_b = c.w;
@@ -643,6 +654,12 @@ __device__ __forceinline__ PhysContact unpack_contact(const float4* in /* stride
         p.local_b[0] = b.z, p.local_b[1] = b.w, p.local_b[2] = c.x;
     }
     return p;
+}
+// an item's packed record into registers: NJ fully coalesced 16-byte loads (lane l's j-th word lies next to lane l+1's)
+template <int PHASE>
+__device__ __forceinline__ void load_packed(const float4* __restrict__ pk /* the tile's base + the lane */, float4 (&rec)[Packed<PHASE>::NJ]) {
+#pragma unroll
+    for (uint32_t j = 0; j < Packed<PHASE>::NJ; ++j) rec[j] = pk[(size_t)j * 64u];
 }
 template <int PHASE>
 __device__ __forceinline__ void pack_body(const PhysBody& b, float4* out) {
@@ -673,11 +690,11 @@ __global__ __launch_bounds__(64) void k_pack_items(const uint32_t* __restrict__ 
     pack_body<PHASE>(cb[bo.y], out + (size_t)(4u * Packed<PHASE>::CJ + Packed<PHASE>::BJ) * 64u);
 }
 
-// `pk`: the item's packed record (its tile's base + the lane)
+// `rec`: the item's packed record, already in registers (load_packed: fetched a level ahead, behind the grid barrier's arrival)
 template <int PHASE>
 __device__ __forceinline__ void run_chain_mg(uint32_t item, uint2 bodies, uint32_t n_dyn, float factor, const PhysContact* __restrict__ pcs,
                                              __amdgpu_buffer_rsrc_t rs_acc, const PhysBody* __restrict__ cb, __amdgpu_buffer_rsrc_t rs_dyn,
-                                             const float4* __restrict__ pk, uint32_t item_index, const ReplayView& rv) {
+                                             const float4 (&rec)[Packed<PHASE>::NJ], uint32_t item_index, const ReplayView& rv, bool one_xcd) {
     const uint32_t s0 = item & 0x00FFFFFFu, len = (item >> 24) & 15u, type = item >> 28;
     const uint32_t ia = bodies.x, ib = bodies.y;
     const bool with_acc = type != PHYS_ITEM_POSITIONAL, store_acc = type == PHYS_ITEM_VELOCITY;
@@ -702,18 +719,18 @@ __device__ __forceinline__ void run_chain_mg(uint32_t item, uint2 bodies, uint32
         if (len > 3u) c3 = ld16_sc1(rs_acc, (s0 + 3u) * 16u);
     }
     constexpr uint32_t CJ = Packed<PHASE>::CJ, BJ = Packed<PHASE>::BJ;
-    const PhysContact p0 = unpack_contact<PHASE>(pk), p1 = unpack_contact<PHASE>(pk + CJ * 64u), p2 = unpack_contact<PHASE>(pk + 2u * CJ * 64u),
-                      p3 = unpack_contact<PHASE>(pk + 3u * CJ * 64u);
-    const float4* ba = pk + 4u * CJ * 64u;
-    const float4* bb = ba + BJ * 64u;
-    const float4 ak0 = ba[0], ak1 = ba[64], ak2 = ba[128], bk0 = bb[0], bk1 = bb[64], bk2 = bb[128];
+    const PhysContact p0 = unpack_contact<PHASE>(rec), p1 = unpack_contact<PHASE>(rec + CJ), p2 = unpack_contact<PHASE>(rec + 2u * CJ),
+                      p3 = unpack_contact<PHASE>(rec + 3u * CJ);
+    const float4* ba = rec + 4u * CJ;
+    const float4* bb = ba + BJ;
+    const float4 ak0 = ba[0], ak1 = ba[1], ak2 = ba[2], bk0 = bb[0], bk1 = bb[1], bk2 = bb[2];
     st.ima = ak0.x;
     st.imb = bk0.x;
     st.iia = M3{mk(ak0.y, ak0.z, ak0.w), mk(ak1.x, ak1.y, ak1.z), mk(ak1.w, ak2.x, ak2.y)};
     st.iib = M3{mk(bk0.y, bk0.z, bk0.w), mk(bk1.x, bk1.y, bk1.z), mk(bk1.w, bk2.x, bk2.y)};
     PairState x;
     if (PHASE == 0) {
-        const float4 ak3 = ba[192], ak4 = ba[256], bk3 = bb[192], bk4 = bb[256];
+        const float4 ak3 = ba[3], ak4 = ba[4], bk3 = bb[3], bk4 = bb[4];
         st.pos_a = mk(ak2.z, ak2.w, ak3.x);
         st.pos_b = mk(bk2.z, bk2.w, bk3.x);
         // (what a kinematic body moves with; unused for dynamic ones)
@@ -746,32 +763,32 @@ __device__ __forceinline__ void run_chain_mg(uint32_t item, uint2 bodies, uint32
         const PhysContact q = pcs[s0 + c];
         float4 a = with_acc ? ld16_sc1(rs_acc, (s0 + c) * 16u) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         run_contact(type, q, st, x, factor, a);
-        if (store_acc) st16_sc1(rs_acc, (s0 + c) * 16u, a);
+        if (store_acc) st16_shared(rs_acc, (s0 + c) * 16u, a, one_xcd);
     }
     if (store_acc) {
-        st16_sc1(rs_acc, s0 * 16u, c0);
-        if (len > 1u) st16_sc1(rs_acc, (s0 + 1u) * 16u, c1);
-        if (len > 2u) st16_sc1(rs_acc, (s0 + 2u) * 16u, c2);
-        if (len > 3u) st16_sc1(rs_acc, (s0 + 3u) * 16u, c3);
+        st16_shared(rs_acc, s0 * 16u, c0, one_xcd);
+        if (len > 1u) st16_shared(rs_acc, (s0 + 1u) * 16u, c1, one_xcd);
+        if (len > 2u) st16_shared(rs_acc, (s0 + 2u) * 16u, c2, one_xcd);
+        if (len > 3u) st16_shared(rs_acc, (s0 + 3u) * 16u, c3, one_xcd);
     }
     if (PHASE == 1 && rv.applied && !(st.dyn_a && st.dyn_b)) rv.applied[item_index] = x.applied;
     if (PHASE == 0) {
         if (st.dyn_a) {
-            st16_sc1(rs_dyn, ia * 32u, make_float4(x.va.x, x.va.y, x.va.z, 0.0f));
-            st16_sc1(rs_dyn, ia * 32u + 16u, make_float4(x.wa.x, x.wa.y, x.wa.z, 0.0f));
+            st16_shared(rs_dyn, ia * 32u, make_float4(x.va.x, x.va.y, x.va.z, 0.0f), one_xcd);
+            st16_shared(rs_dyn, ia * 32u + 16u, make_float4(x.wa.x, x.wa.y, x.wa.z, 0.0f), one_xcd);
         }
         if (st.dyn_b) {
-            st16_sc1(rs_dyn, ib * 32u, make_float4(x.vb.x, x.vb.y, x.vb.z, 0.0f));
-            st16_sc1(rs_dyn, ib * 32u + 16u, make_float4(x.wb.x, x.wb.y, x.wb.z, 0.0f));
+            st16_shared(rs_dyn, ib * 32u, make_float4(x.vb.x, x.vb.y, x.vb.z, 0.0f), one_xcd);
+            st16_shared(rs_dyn, ib * 32u + 16u, make_float4(x.wb.x, x.wb.y, x.wb.z, 0.0f), one_xcd);
         }
     } else {
         if (st.dyn_a) {
-            st16_sc1(rs_dyn, ia * 32u, make_float4(x.pa.x, x.pa.y, x.pa.z, 0.0f));
-            st16_sc1(rs_dyn, ia * 32u + 16u, make_float4(x.qa.x, x.qa.y, x.qa.z, x.qa.w));
+            st16_shared(rs_dyn, ia * 32u, make_float4(x.pa.x, x.pa.y, x.pa.z, 0.0f), one_xcd);
+            st16_shared(rs_dyn, ia * 32u + 16u, make_float4(x.qa.x, x.qa.y, x.qa.z, x.qa.w), one_xcd);
         }
         if (st.dyn_b) {
-            st16_sc1(rs_dyn, ib * 32u, make_float4(x.pb.x, x.pb.y, x.pb.z, 0.0f));
-            st16_sc1(rs_dyn, ib * 32u + 16u, make_float4(x.qb.x, x.qb.y, x.qb.z, x.qb.w));
+            st16_shared(rs_dyn, ib * 32u, make_float4(x.pb.x, x.pb.y, x.pb.z, 0.0f), one_xcd);
+            st16_shared(rs_dyn, ib * 32u + 16u, make_float4(x.qb.x, x.qb.y, x.qb.z, x.qb.w), one_xcd);
         }
     }
 }
@@ -779,12 +796,16 @@ __device__ __forceinline__ void run_chain_mg(uint32_t item, uint2 bodies, uint32
 constexpr uint32_t MG_THREADS = 256u;
 constexpr uint32_t MG_SPIN_LIMIT = 1u << 22;  // a poll loop that never sees its count gives up and flags the launch (every spin is bounded)
 
-// grid-wide barrier of the G resident workgroups: `target` arrivals on the monotonic counter
-__device__ __forceinline__ void mg_barrier(uint32_t* counter, uint32_t target, uint32_t* error) {
+// grid-wide barrier of the G resident workgroups: `target` arrivals on the monotonic counter. In two halves, so that loads which do not
+// depend on the other workgroups (the next level's packed records) can be issued between a workgroup's arrival and its wait: their trip to
+// memory then runs beside the wait instead of after it.
+__device__ __forceinline__ void mg_arrive(uint32_t* counter) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have landed
     __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mg_wait(uint32_t* counter, uint32_t target, uint32_t* error) {
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t spins = 0;
         while ((int32_t)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
             __builtin_amdgcn_s_sleep(1);
@@ -796,6 +817,10 @@ __device__ __forceinline__ void mg_barrier(uint32_t* counter, uint32_t target, u
     }
     __syncthreads();
 }
+__device__ __forceinline__ void mg_barrier(uint32_t* counter, uint32_t target, uint32_t* error) {
+    mg_arrive(counter);
+    mg_wait(counter, target, error);
+}
 
 template <int PHASE>
 __global__ __launch_bounds__(MG_THREADS) void k_solve_mg(uint32_t n_dyn, float factor, const PhysContact* __restrict__ pcs, float4* __restrict__ accs,
@@ -804,13 +829,15 @@ __global__ __launch_bounds__(MG_THREADS) void k_solve_mg(uint32_t n_dyn, float f
                                                          const uint32_t* __restrict__ level_start, const uint32_t* __restrict__ tile_base,
                                                          const float4* __restrict__ packed, uint32_t n_levels, uint32_t* __restrict__ counter,
                                                          uint32_t counter_base, uint32_t* __restrict__ error, uint32_t dry, uint32_t spread, ReplayView rv,
-                                                         const uint32_t* __restrict__ replay_flag) {
+                                                         const uint32_t* __restrict__ replay_flag, uint32_t* __restrict__ xcc_table,
+                                                         const uint32_t* __restrict__ tile_first, uint32_t n_tiles, const uint32_t* __restrict__ dep_start,
+                                                         const uint32_t* __restrict__ deps, uint32_t* __restrict__ tile_done, uint32_t tag) {
     // `spread` = 8: the launch holds 8 G blocks of which every eighth works — workgroups are handed to the XCDs round robin, so the G that
     // work share one XCD (its L2, its fabric port); 1: G blocks, all working. Where they land changes times only, never results.
     if (spread > 1u && (blockIdx.x % spread) != 0u) return;
     if (replay_flag && *replay_flag == 0u) {  // pass 2 of the positional phase with no kinematic orientation that moved: nothing to do
         // (uniform over the launch; the host has already counted this launch's arrivals at the grid barrier: make them)
-        if (threadIdx.x == 0u) __hip_atomic_fetch_add(counter, n_levels + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0u) __hip_atomic_fetch_add(counter, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     const uint32_t blk = blockIdx.x / spread;
@@ -828,42 +855,74 @@ __global__ __launch_bounds__(MG_THREADS) void k_solve_mg(uint32_t n_dyn, float f
             st16_sc1(rs_dyn, i * 32u + 16u, make_float4(b.q[0], b.q[1], b.q[2], b.q[3]));
         }
     }
+    // census: which XCD is every working workgroup on? (table entry = this launch's counter base | XCC_ID; read back behind the first barrier)
+    const uint32_t xcc_tag = (counter_base << 4) | (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFu);  // hwreg(HW_REG_XCC_ID, 0, 4)
+    if (tid == 0u) __hip_atomic_store(xcc_table + blk, xcc_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t arrivals = counter_base + G;
     mg_barrier(counter, arrivals, error);
-    // the item word and body pair of this thread's chain of the next level are fetched one level ahead (they never change)
-    uint32_t lb = level_start[0], le = level_start[1];
-    uint32_t tb = tile_base[0], tb_next = 0u;
-    uint32_t nxt_item = 0xFFFFFFFFu;
+    bool one_xcd = G <= 16u;
+    for (uint32_t q = 0; q < G && q < 16u; ++q) one_xcd = one_xcd && __hip_atomic_load(xcc_table + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == xcc_tag;
+    if (dry & 4u) one_xcd = false;  // (developer switch: the write-through form wherever the workgroups sit)
+    // ---- the schedule, TILE by tile. A tile is 64 consecutive items of a level (mutually independent chains) and the unit a wave runs; wave w
+    // of the launch's W = 4 G waves runs the tiles w, w + W, ... in the schedule's order. A level-wide grid barrier made every wave wait for the
+    // slowest chain of the whole level and cost a counter round trip on top (2 us of a level's 6-7); here a tile waits only for the tiles that
+    // hold the previous item of one of its bodies (host-built lists, `deps`): its lanes poll those tiles' completion words, one word per lane,
+    // until all hold this launch's tag. Every dependency points to an earlier tile and every wave takes its tiles in order, so the earliest
+    // unfinished tile can always run: no deadlock while the launch's workgroups are resident (checked by the host, bounded polls besides).
+    // The hand-off is the per-wave form of MI355X_MICROARCH.md's first table row: the wave's shared stores (write-through, or plain when all
+    // working workgroups sit on one XCD), s_waitcnt vmcnt(0), then one lane's completion word; the consumer's lanes poll with L1-bypassing loads
+    // and load the bodies' state (L1-bypassing) only after the poll has matched.
+    // The item words, the body pairs, the PACKED RECORD and the dependency list of a wave's next tile are fetched while it finishes the current
+    // one (they never change during the solve): a tile's critical path holds only the poll and the 8 loads of shared state.
+    const uint32_t lane = tid & 63u, W = G * (MG_THREADS / 64u), wv = blk * (MG_THREADS / 64u) + (tid >> 6);
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    uint32_t t = wv;
+    uint32_t nxt_item = NONE, nxt_index = 0u, nxt_dep = NONE, nxt_dep_more = 0u;
     uint2 nxt_bodies = make_uint2(0u, 0u);
-    if (lb + slot < le) {
-        nxt_item = items[lb + slot];
-        nxt_bodies = item_bodies[lb + slot];
-    }
-    for (uint32_t l = 0; l < n_levels; ++l) {
-        const uint32_t b = lb, e = le;
-        const uint32_t cur_item = nxt_item;
-        const uint2 cur_bodies = nxt_bodies;
-        nxt_item = 0xFFFFFFFFu;
-        const uint32_t tiles = tb;
-        if (l + 1 < n_levels) {
-            tb_next = tile_base[l + 1];
-            lb = e;
-            le = level_start[l + 2];
-            if (lb + slot < le) {
-                nxt_item = items[lb + slot];
-                nxt_bodies = item_bodies[lb + slot];
+    float4 rec[Packed<PHASE>::NJ];
+    auto fetch_tile = [&](uint32_t tt) {
+        nxt_item = NONE, nxt_dep = NONE, nxt_dep_more = 0u;
+        if (tt >= n_tiles) return;
+        const uint32_t tf = tile_first[tt], first = tf & 0x03FFFFFFu, cnt = (tf >> 26) + 1u;
+        const uint32_t d0 = dep_start[tt], d1 = dep_start[tt + 1u];
+        if (d0 + lane < d1) nxt_dep = deps[d0 + lane];
+        nxt_dep_more = d1 - d0 > 64u ? 1u : 0u;
+        if (lane < cnt) {
+            nxt_item = items[first + lane];
+            nxt_bodies = item_bodies[first + lane];
+            nxt_index = first + lane;
+            load_packed<PHASE>(packed + (size_t)tt * (Packed<PHASE>::NJ * 64u) + lane, rec);
+        }
+    };
+    auto all_done = [&](uint32_t dep) {  // this lane's producer tile (NONE: none) — true in every lane once all lanes' tiles are done
+        uint32_t spins = 0;
+        for (;;) {
+            const bool ok = dep == NONE || __hip_atomic_load(tile_done + dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag;
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) return;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > MG_SPIN_LIMIT) {
+                if (lane == 0u) __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (host-mapped: ivx_world_check_solve)
+                return;
             }
         }
-        for (uint32_t i = b + slot; i < e && !(dry & 1u); i += stride) {
-            const uint32_t it = i == b + slot ? cur_item : items[i];
-            const uint2 bo = i == b + slot ? cur_bodies : item_bodies[i];
-            const float4* pk = packed + (size_t)(tiles + ((i - b) >> 6)) * (Packed<PHASE>::NJ * 64u) + (tid & 63u);  // ((i - b) & 63 == tid & 63)
-            run_chain_mg<PHASE>(it, bo, n_dyn, factor, pcs, rs_acc, cb, rs_dyn, pk, i, rv);
+    };
+    fetch_tile(t);
+    for (; t < n_tiles; t += W) {
+        const uint32_t cur_item = nxt_item, cur_index = nxt_index, cur_dep = nxt_dep, more = nxt_dep_more;
+        const uint2 cur_bodies = nxt_bodies;
+        if (!(dry & 2u)) {
+            all_done(cur_dep);
+            if (more)  // (a tile with more than 64 producer tiles: the rest of its list, 64 at a time)
+                for (uint32_t d = dep_start[t] + 64u; d < dep_start[t + 1u]; d += 64u) all_done(d + lane < dep_start[t + 1u] ? deps[d + lane] : NONE);
         }
-        tb = tb_next;
-        arrivals += G;
-        if (!(dry & 2u)) mg_barrier(counter, arrivals, error);
+        if (cur_item != NONE && !(dry & 1u)) run_chain_mg<PHASE>(cur_item, cur_bodies, n_dyn, factor, pcs, rs_acc, cb, rs_dyn, rec, cur_index, rv, one_xcd);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's shared stores have landed (in the common L2, or written through)
+        if (lane == 0u) __hip_atomic_store(tile_done + t, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fetch_tile(t + W);
     }
+    // every tile of the launch done (one grid barrier) before the shared records go back to the body array
+    arrivals += G;
+    mg_barrier(counter, arrivals, error);
     for (uint32_t i = slot; i < n_dyn; i += stride) {
         PhysBody& b = cb[i];
         const float4 r0 = ld16_sc1(rs_dyn, i * 32u), r1 = ld16_sc1(rs_dyn, i * 32u + 16u);
@@ -1036,7 +1095,9 @@ static int launch_solve_mg(ivx_world* w, uint32_t groups, ReplayView rv = Replay
         }
     }
     const uint32_t base = w->barrier_count;
-    w->barrier_count += groups * (w->n_levels[PHASE] + 1u);
+    w->barrier_count += groups * 2u;  // (two grid barriers per launch: behind the set-up and census, and before the write-back)
+    w->tile_tag += 1u;
+    if (w->tile_tag == 0u) w->tile_tag = 1u;  // (0 is what a fresh completion word holds)
     // this step's prepared contacts and body constants into the schedule's packed records (run_chain_mg; pass 2 reads pass 1's)
     if (!replay_flag) hipLaunchKernelGGL((k_pack_items<PHASE>), dim3(w->n_tiles[PHASE]), dim3(64), 0, w->ctx->stream, w->tile_first + w->tile_offset[PHASE],
                        w->items + w->item_offset[PHASE], reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], w->pc[w->cur], w->cb,
@@ -1050,7 +1111,8 @@ static int launch_solve_mg(ivx_world* w, uint32_t groups, ReplayView rv = Replay
                        reinterpret_cast<float4*>(w->acc[w->cur]), w->n_contacts, w->cb, reinterpret_cast<float4*>(w->dynst), w->items + w->item_offset[PHASE],
                        reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], w->level_start + w->level_offset[PHASE],
                        w->tile_base + w->level_offset[PHASE], reinterpret_cast<const float4*>(w->packed[PHASE]),
-                       w->n_levels[PHASE], w->barrier_words, base, w->mg_err_dev, ivx_solver_dry(), spread, rv, replay_flag);
+                       w->n_levels[PHASE], w->barrier_words, base, w->mg_err_dev, ivx_solver_dry(), spread, rv, replay_flag, w->barrier_words + 4, w->tile_first + w->tile_offset[PHASE], w->n_tiles[PHASE],
+                       w->dep_start + w->dep_start_offset[PHASE], w->deps + w->dep_offset[PHASE], w->tile_done, w->tile_tag);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

@@ -249,6 +249,42 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
     }
     w->tile_base_host[ls0 + max_level] = n_tiles;
     w->n_tiles[phase] = n_tiles;
+    // What every tile waits for: the tiles that hold, for each of its items' dynamic bodies, the previous item touching that body (the
+    // item's level is one more than the latest of them, so they all lie in earlier levels = earlier tiles). Walk the items in sequence
+    // order again with the slot of each body's latest item in hand.
+    {
+        std::vector<uint32_t> tile_of(total);
+        for (uint32_t l = 0; l < max_level; ++l)
+            for (uint32_t i = start[l]; i < start[l + 1]; ++i) tile_of[i] = w->tile_base_host[ls0 + l] + (i - start[l]) / 64u;
+        std::vector<std::vector<uint32_t>> need(n_tiles);
+        std::vector<uint32_t> last_slot(nb, 0xFFFFFFFFu);
+        std::vector<uint32_t> cur2(max_level);
+        for (uint32_t l = 0; l < max_level; ++l) cur2[l] = start[l];
+        size_t kk = 0;
+        for (uint32_t pass = 0; pass < total_passes; ++pass)
+            for (uint32_t ch = 0; ch < nch; ++ch, ++kk) {
+                const uint32_t slot = cur2[lvl[kk] - 1]++;  // (the same stable placement as above)
+                const uint32_t t = tile_of[slot];
+                const uint32_t bs[2] = {w->chain_bodies[2 * (size_t)ch], w->chain_bodies[2 * (size_t)ch + 1]};
+                for (uint32_t b : bs) {
+                    if (b & IVX_KINEMATIC_BODY) continue;
+                    if (last_slot[b] != 0xFFFFFFFFu) need[t].push_back(tile_of[last_slot[b]]);
+                    last_slot[b] = slot;
+                }
+            }
+        w->dep_start_offset[phase] = (uint32_t)w->dep_start_host.size();
+        w->dep_offset[phase] = (uint32_t)w->deps_host.size();
+        uint32_t run2 = 0;
+        for (uint32_t t = 0; t < n_tiles; ++t) {
+            std::vector<uint32_t>& v = need[t];
+            std::sort(v.begin(), v.end());
+            v.erase(std::unique(v.begin(), v.end()), v.end());
+            w->dep_start_host.push_back(run2);
+            w->deps_host.insert(w->deps_host.end(), v.begin(), v.end());
+            run2 += (uint32_t)v.size();
+        }
+        w->dep_start_host.push_back(run2);
+    }
 }
 
 }  // namespace
@@ -277,8 +313,8 @@ int ivx_world_create(ivx_ctx* c, const ivx_solver_config* cfg, ivx_world** out) 
     if (cfg) w->cfg = *cfg;
     else w->cfg = ivx_solver_config{8u, 0.4f, 3u, 0.2f};  // ConstraintSolverConfig::default (solver.rs:374-384)
     IVX_REQUIRE(w->cfg.n_iterations + w->cfg.n_positional_correction_iterations < 4096, IVX_ERR_INVALID, "ivx_world_create: too many iterations");
-    if (hipMalloc(reinterpret_cast<void**>(&w->barrier_words), 4 * sizeof(uint32_t)) != hipSuccess ||
-        hipMemsetAsync(w->barrier_words, 0, 4 * sizeof(uint32_t), c->stream) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void**>(&w->barrier_words), 20 * sizeof(uint32_t)) != hipSuccess ||
+        hipMemsetAsync(w->barrier_words, 0, 20 * sizeof(uint32_t), c->stream) != hipSuccess) {
         ivx_set_error("ivx_world_create: device allocation failed");
         delete w;
         return IVX_ERR_HIP;
@@ -301,7 +337,7 @@ void ivx_world_destroy(ivx_world* w) {
     if (!w) return;
     (void)hipStreamSynchronize(w->ctx->stream);
     void* ptrs[] = {w->dyn, w->kin, w->cb, w->touched, w->contacts, w->prev_slot, w->pc[0], w->pc[1], w->acc[0], w->acc[1], w->items, w->item_bodies, w->level_start,
-                    w->dynst, w->barrier_words, w->joint_refs, w->tile_base, w->tile_first, w->packed[0], w->packed[1], w->kin_offsets, w->kin_list,
+                    w->dynst, w->barrier_words, w->joint_refs, w->tile_base, w->tile_first, w->dep_start, w->deps, w->tile_done, w->packed[0], w->packed[1], w->kin_offsets, w->kin_list,
                     w->kin_applied, w->kin_qstart, w->kin_snap};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -474,6 +510,8 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
         w->level_start_host.clear();
         w->tile_base_host.clear();
         w->tile_first_host.clear();
+        w->dep_start_host.clear();
+        w->deps_host.clear();
         build_schedule(w, PHYS_ITEM_WARM, 1u, PHYS_ITEM_VELOCITY, w->cfg.n_iterations, 0);
         build_schedule(w, PHYS_ITEM_POSITIONAL, 0u, PHYS_ITEM_POSITIONAL, w->cfg.n_positional_correction_iterations, 1);
         w->prev_chain_start = w->chain_start;
@@ -515,6 +553,13 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
     if ((rc = grow(&w->level_start, &w->level_cap, w->level_start_host.size(), s))) return rc;
     if ((rc = grow(&w->tile_base, &w->tile_base_cap, w->tile_base_host.size(), s))) return rc;
     if ((rc = grow(&w->tile_first, &w->tile_first_cap, w->tile_first_host.size(), s))) return rc;
+    if ((rc = grow(&w->dep_start, &w->dep_start_cap, w->dep_start_host.size() + 2, s))) return rc;
+    if ((rc = grow(&w->deps, &w->deps_cap, w->deps_host.size() + 1, s))) return rc;
+    {
+        const size_t had = w->tile_done_cap;
+        if ((rc = grow(&w->tile_done, &w->tile_done_cap, (size_t)std::max(w->n_tiles[0], w->n_tiles[1]) + 1, s))) return rc;
+        if (w->tile_done_cap != had) IVX_HIP_CHECK(hipMemsetAsync(w->tile_done, 0, w->tile_done_cap * sizeof(uint32_t), s));  // (no tag is ever 0)
+    }
     if (w->n_kin_items) {
         const size_t n_pos_items = w->items_host.size() - w->item_offset[1];
         if ((rc = grow(&w->kin_offsets, &w->kin_offsets_cap, w->kin_offsets_host.size(), s))) return rc;
@@ -537,6 +582,9 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
         IVX_HIP_CHECK(hipMemcpy(w->tile_base, w->tile_base_host.data(), w->tile_base_host.size() * 4, hipMemcpyHostToDevice));
         if (!w->tile_first_host.empty())
             IVX_HIP_CHECK(hipMemcpy(w->tile_first, w->tile_first_host.data(), w->tile_first_host.size() * 4, hipMemcpyHostToDevice));
+        if (!w->dep_start_host.empty())
+            IVX_HIP_CHECK(hipMemcpy(w->dep_start, w->dep_start_host.data(), w->dep_start_host.size() * 4, hipMemcpyHostToDevice));
+        if (!w->deps_host.empty()) IVX_HIP_CHECK(hipMemcpy(w->deps, w->deps_host.data(), w->deps_host.size() * 4, hipMemcpyHostToDevice));
         if (w->n_kin_items) {
             IVX_HIP_CHECK(hipMemcpy(w->kin_offsets, w->kin_offsets_host.data(), w->kin_offsets_host.size() * 4, hipMemcpyHostToDevice));
             IVX_HIP_CHECK(hipMemcpy(w->kin_list, w->kin_list_host.data(), w->kin_list_host.size() * 4, hipMemcpyHostToDevice));
