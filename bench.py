@@ -966,10 +966,53 @@ def main():
                 obj.step_collect()
                 ctx2.synchronize()
             frame2_ms = 1e3 * (time.perf_counter() - t0) / 10
-            w2.close()
-            ctx2.close()
             out["frame"]["ms_per_frame_two_streams"] = frame2_ms
             out["frame"]["two_streams"] = "the pile's world on a second ivx_ctx (its own stream): solve and voxel step overlap, two waits"
+            # The whole per-frame pipeline, host work on the clock (engine/src/tasks.rs:405-434, 515-550 in the reference's order): contact generation
+            # of the voxel body against a ground plane (f1, ivx_plane_voxel_object_contacts) -> this frame's contacts into the solver
+            # (ivx_world_set_contacts: the pile's 46 080, same ids as the frame before -> its one-pass path) -> solve + integrate -> voxel step ->
+            # one voxel edit (an absorbing sphere, ivx_absorb_sphere: edit + re-derive). The world runs on its own stream; nothing is resident
+            # from a frame before except what the engine keeps resident (bodies, the SDF program, the solver's schedule).
+            m32 = np.asarray(res["moments"]["m32"], dtype=np.float32).reshape(-1)
+            com = (m32[1:4] * (np.float32(1.0) / m32[0])).astype(np.float32)
+            lo = np.array([a for a, _ in obj.update_occupied_voxel_ranges()], dtype=np.float32)
+            hi = np.array([b for _, b in obj.update_occupied_voxel_ranges()], dtype=np.float32)
+            ident = np.array([0.0, 0.0, 0.0, 1.0], dtype=np.float32)
+            plane_n = np.array([0.0, 1.0, 0.0], dtype=np.float32)
+            plane_d = float(lo[1] + 3.0)  # a ground plane three voxels into the body's underside
+            edit_c = np.array([com[0], hi[1], com[2]], dtype=np.float32)  # a bite at the top (the first frame removes it, the rest re-run the path)
+            t_parts = np.zeros(5)
+            n_frames, n_plane = 10, 0
+            for it in range(2 + n_frames):
+                if it == 2:
+                    ctx.synchronize()
+                    ctx2.synchronize()
+                    t_parts[:] = 0.0
+                    t0 = time.perf_counter()
+                ta = time.perf_counter()
+                pcs = obj.plane_contacts(ident, np.zeros(3, dtype=np.float32), plane_n, plane_d, 7, 8, 0, 0x80000000)
+                tb = time.perf_counter()
+                w2.prepare_constraints(pc)
+                tc = time.perf_counter()
+                w2.step_enqueue(0.005)
+                obj.step_enqueue(capi.STAGE_ALL)
+                td = time.perf_counter()
+                obj.step_collect()
+                te = time.perf_counter()
+                obj.absorb_sphere(edit_c, 10.0, 8.0, want_invalidated=False)
+                ctx2.synchronize()
+                tf = time.perf_counter()
+                t_parts += (tb - ta, tc - tb, td - tc, te - td, tf - te)
+                n_plane = len(pcs)
+            pipe_ms = 1e3 * (time.perf_counter() - t0) / n_frames
+            obj.step(capi.STAGE_ALL)  # (the body as generated again for the legs below)
+            w2.close()
+            ctx2.close()
+            out["frame"]["pipeline"] = {
+                "what": "per frame, host work included: voxel-body contacts against a ground plane (f1) -> ivx_world_set_contacts(46 080 pile contacts, same ids) "
+                        "-> solve + integrate (own stream) -> voxel step -> one absorbing-sphere edit with its re-derive; two contexts",
+                "ms_per_frame": pipe_ms, "voxels_per_s": n_vox_rank / (pipe_ms * 1e-3), "plane_contacts": n_plane,
+                "host_ms": {k: round(1e3 * float(v) / n_frames, 4) for k, v in zip(("contact_generation", "set_contacts", "enqueue", "wait_voxel_step", "edit_and_wait_world"), t_parts)}}
             if args.workload == "asteroid":
                 out["collide"] = collide_benchmark(ctx, args.scale, o_big if with_cpu else None, m_big)
                 out["edit"] = edit_benchmark(ctx, args.scale, o_big if with_cpu else None)  # (last: the oracle's edit changes o_big)

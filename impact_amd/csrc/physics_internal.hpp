@@ -110,6 +110,11 @@ struct ivx_world {
     std::unordered_map<uint64_t, uint32_t> index_of;
     std::vector<ivx_contact> effective;  // contacts of this step after interlock replacement
     std::vector<ivx_contact> ordered;
+    // the usual frame's upload (same ids, order and body pairs as the frame before): pinned staging copy, sent by an asynchronous copy
+    ivx_contact* stage_contacts;
+    size_t stage_contacts_cap;
+    hipEvent_t stage_ev;
+    int stage_ev_ready, stage_busy;
     std::vector<int32_t> prev_slot_host;
     std::vector<uint32_t> item_bodies_host, items_host, level_start_host, tile_base_host, tile_first_host, scratch_level, scratch_last, chain_start;
     std::vector<uint32_t> kin_offsets_host, kin_list_host;
