@@ -720,6 +720,40 @@ __device__ __forceinline__ void eval_leaf(const ivx_sdf_processed_node* nd, uint
     const V3 opx = add(origin, scale(dx, (float)ti));
     V3 pos = add(opx, scale(dy, (float)tj));
     const float pa = nd->a, pb = nd->b, pc = nd->c;
+    // A transform without rotation or shear (translations and scalings: most nodes) moves only z along the column: `pos.x + 0` and
+    // `pos.y + 0` are `pos.x` and `pos.y` again (a -0 may become +0, which no term below can tell apart), so every term in x and y alone
+    // is the column's — and the sums keep the reference's order, ((x^2 + y^2) + z^2). Five of a sphere's nineteen instructions per voxel,
+    // nine of a box's twenty-seven, in a kernel bound by VALU issue. (wave-uniform branch: the transform is the node's)
+    if (dz.x == 0.0f && dz.y == 0.0f) {
+        float z = pos.z;
+        if (kind == 0u || kind == 1u) {
+            float y = pos.y, r = pa;
+            if (kind == 1u) {
+                float c = y;
+                if (c < -pa) c = -pa;
+                if (c > pa) c = pa;
+                y -= c;
+                r = pb;
+            }
+            const float cxy = pos.x * pos.x + y * y;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                IVX_LV_SET(d, k, t15, r15, sqrt_rn(cxy + z * z) - r);
+                z += dz.z;
+            }
+        } else {
+            const float qx = fabsf(pos.x) - pa, qy = fabsf(pos.y) - pb;
+            const float px = max_rs(qx, 0.0f), py = max_rs(qy, 0.0f);
+            const float cxy = px * px + py * py, mxy = max_rs(qx, qy);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float qz = fabsf(z) - pc, pz = max_rs(qz, 0.0f);
+                IVX_LV_SET(d, k, t15, r15, sqrt_rn(cxy + pz * pz) + min_rs(max_rs(mxy, qz), 0.0f));
+                z += dz.z;
+            }
+        }
+        return;
+    }
     if (kind == 0u) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
