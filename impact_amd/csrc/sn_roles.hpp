@@ -829,6 +829,35 @@ __device__ __forceinline__ float div_ranged(float a, float b) {
     return __builtin_fmaf(r, y, q);
 }
 
+// g / |g| as the reference takes it — the correctly rounded length, then three correctly rounded divisions by it — for the gradients
+// the mesher meets: the general forms cost 16 instructions for the root (rescaling of tiny inputs, class test) and 11 per division
+// (scaling of both operands, fix-ups), which was a quarter of a vertex's instructions. With the squared length away from the exponent
+// limits none of that can trigger: the root is the hardware estimate moved to the neighbour whose residual changes sign, a division is
+// the compiler's own sequence (reciprocal refined once — shared by the three —, quotient corrected twice) without its scaling. A
+// component is 0 or at least 2^-77 in magnitude (a sum of products of two centroid weights >= 2^-24 and a distance difference, all
+// multiples of 2^-77), so no residual underflows; a zero numerator is +0 throughout (the weights are non-negative and one of each pair
+// o, 1 - o is positive) and comes out +0 as from `/`. The caller takes this path only when every lane of the wave has
+// `len2 >= 2^-100` (else the general forms: a zero gradient must come out as their NaN). Compared with `/` and sqrtf over random
+// gradients by `ivx_selftest_mesher_division`.
+__device__ __forceinline__ void normalize_ranged(float gx, float gy, float gz, float len2, float& nx, float& ny, float& nz) {
+    const float s = __builtin_amdgcn_sqrtf(len2);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, len2), r_up = __builtin_fmaf(-s_up, s, len2);
+    float b = r_dn <= 0.0f ? s_dn : s;
+    b = r_up > 0.0f ? s_up : b;
+    float y = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, y, 1.0f);
+    y = __builtin_fmaf(e, y, y);
+    auto quot = [&](float a) {
+        float q = a * y;
+        float r = __builtin_fmaf(-b, q, a);
+        q = __builtin_fmaf(r, y, q);
+        r = __builtin_fmaf(-b, q, a);
+        return __builtin_fmaf(r, y, q);
+    };
+    nx = quot(gx), ny = quot(gy), nz = quot(gz);
+}
+
 // centroid_of_edge_intersections (surface_nets.rs:384-418) over the 12 CUBE_EDGES (661-674) of one cube. The reference adds, per crossed
 // edge (c1, c2) in list order, p1 * (1 - t) + p2 * t with t = d1 / (d1 - d2) and p the corners' 0/1 coordinates. Component by component
 // that term is: t along the edge's own axis (0 * (1 - t) + 1 * t), (1 - t) + t where both corners have the coordinate 1, +0 where both
@@ -1058,8 +1087,10 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
     __shared__ uint32_t s_hard;  // this chunk needs the general pass
     __shared__ uint32_t s_rec[27];  // first words of the chunk records of the tile's 3 x 3 x 3 neighbourhood
     __shared__ uint32_t s_ticket[5];  // the list entry this workgroup takes after the next one: index, record
+    __shared__ float s_rcount[13];    // 1 / n for a cube's 1..12 crossed edges: a read instead of a division per vertex
     const GridView& g = p.g;
     const uint32_t tid = threadIdx.x;
+    if (tid >= 1u && tid < 13u) s_rcount[tid] = 1.0f / (float)tid;  // (visible after the first round's first barrier)
     const uint32_t n_emit = emit_count[0];  // = number of submeshes (k_sn_scan's third total)
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     // The list (submesh order: entry li is submesh li) is handed out by counters: a workgroup starts on entry `bid` and draws every further one.
@@ -1176,7 +1207,7 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
         int count;
         V3 sum;
         edge_centroid(d, neg, sum, count);
-        const float rc = div_ranged(1.0f, (float)count);
+        const float rc = s_rcount[count];
         const V3 centroid = scale(sum, rc);
         // trilinear gradient (object/sdf.rs:603-633)
         const V3 d00 = sub(mk(d[4], d[2], d[1]), mk(d[0], d[0], d[0]));
@@ -1188,8 +1219,14 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
         const V3 r_yzx = mk(r.y, r.z, r.x), r_zxy = mk(r.z, r.x, r.y), o_yzx = mk(o.y, o.z, o.x), o_zxy = mk(o.z, o.x, o.y);
         const V3 grad = add(add(add(mul(mul(r_yzx, r_zxy), d00), mul(mul(r_yzx, o_zxy), d01)), mul(mul(o_yzx, r_zxy), d10)),
                             mul(mul(o_yzx, o_zxy), d11));
-        const float gl = len3(grad);
-        const V3 normal = mk(grad.x / gl, grad.y / gl, grad.z / gl);
+        const float gl2 = (grad.x * grad.x + grad.y * grad.y) + grad.z * grad.z;
+        V3 normal;
+        if (__builtin_amdgcn_ballot_w64(!(gl2 >= 0x1p-100f)) == 0ull) {
+            normalize_ranged(grad.x, grad.y, grad.z, gl2, normal.x, normal.y, normal.z);
+        } else {
+            const float gl = sqrtf(gl2);
+            normal = mk(grad.x / gl, grad.y / gl, grad.z / gl);
+        }
         const V3 position = add(scale(add(centroid, mk((float)i, (float)j, (float)k)), p.extent), pos_offset);
         const size_t gv = (size_t)voff + v;
         positions[3 * gv + 0] = position.x;

@@ -76,6 +76,39 @@ __global__ __launch_bounds__(256) void k_selftest_division(uint32_t* __restrict_
     if (bad) atomicAdd(mismatches, 1u);
 }
 
+// normalize_ranged against sqrtf and `/` over pseudo-random gradients: components with random signs and mantissas, exponents spread over
+// 2^-40 .. 2^8 (one component in eight an exact zero), 16 per thread; triples outside the function's domain (len2 < 2^-100) are skipped as
+// the mesher skips them.
+__global__ __launch_bounds__(256) void k_selftest_normalize(uint32_t* __restrict__ mismatches) {
+    uint32_t h = (blockIdx.x * 256u + threadIdx.x) * 0x9E3779B9u + 0x7F4A7C15u;
+    auto next = [&]() {
+        h ^= h << 13;
+        h ^= h >> 17;
+        h ^= h << 5;
+        return h;
+    };
+    uint32_t bad = 0u;
+    for (int it = 0; it < 16; ++it) {
+        float g[3];
+        const uint32_t spread = next();
+        for (int c = 0; c < 3; ++c) {
+            const uint32_t r = next(), r2 = next();
+            const uint32_t ex = 127u - 40u + (r2 % 49u);
+            g[c] = (r2 >> 29) == 0u ? 0.0f : __uint_as_float((r & 0x807FFFFFu) | (ex << 23));
+            if (spread & (1u << c)) g[c] = __uint_as_float((r & 0x807FFFFFu) | ((120u + ((r2 >> 8) & 7u)) << 23));  // all of one magnitude: the usual case
+        }
+        const float len2 = (g[0] * g[0] + g[1] * g[1]) + g[2] * g[2];
+        if (!(len2 >= 0x1p-100f)) continue;
+        float nx, ny, nz;
+        normalize_ranged(g[0], g[1], g[2], len2, nx, ny, nz);
+        const float gl = sqrtf(len2);
+        if (__float_as_uint(nx) != __float_as_uint(g[0] / gl) || __float_as_uint(ny) != __float_as_uint(g[1] / gl) ||
+            __float_as_uint(nz) != __float_as_uint(g[2] / gl))
+            bad += 1u;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 }  // namespace
 
 // (test hook, include/impact_voxel_hip.h)
@@ -85,6 +118,8 @@ int ivx_selftest_mesher_division(ivx_ctx* ctx, uint32_t* mismatches) {
     IVX_HIP_CHECK(hipMalloc(&d, sizeof(uint32_t)));
     IVX_HIP_CHECK(hipMemsetAsync(d, 0, sizeof(uint32_t), ctx->stream));
     hipLaunchKernelGGL(k_selftest_division, dim3(257), dim3(256), 0, ctx->stream, d);
+    IVX_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_selftest_normalize, dim3(65536), dim3(256), 0, ctx->stream, d);  // 2^28 gradients
     IVX_HIP_CHECK(hipGetLastError());
     IVX_HIP_CHECK(hipMemcpyAsync(mismatches, d, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     IVX_HIP_CHECK(hipStreamSynchronize(ctx->stream));

@@ -9,6 +9,10 @@
                  : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)                                           \
                  : "v"(a), "v"(b), "s"(m))
 
+#define UNARY8(OP)                                                                                                                      \
+    asm volatile(OP " %0, %0\n" OP " %1, %1\n" OP " %2, %2\n" OP " %3, %3\n" OP " %4, %4\n" OP " %5, %5\n" OP " %6, %6\n" OP " %7, %7\n" \
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7))
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float* out, int iters, float a, float b, unsigned long long m) {
     float t0 = 0, t1 = 0;
@@ -31,6 +35,19 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a, float b
             if (MODE == 11) CHAIN8("v_bfe_u32", "%8, %9");
             if (MODE == 12) CHAIN8("v_mul_f32", "%8");
             if (MODE == 13) CHAIN8("v_min_u32", "%8");
+            if (MODE == 30) UNARY8("v_sqrt_f32");
+            if (MODE == 31) UNARY8("v_rcp_f32");
+            if (MODE == 32) UNARY8("v_rsq_f32");
+            if (MODE == 33) UNARY8("v_cvt_i32_f32");
+            if (MODE == 34) CHAIN8("v_fma_f32", "%8, %9");
+            if (MODE == 35) {  // the shape of a correctly rounded square root: one v_sqrt_f32 and eight plain operations, two chains (18 per 2)
+                asm volatile("v_sqrt_f32 %0, %0\n v_sqrt_f32 %1, %1\n"
+                             "v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n"
+                             "v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                             "v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n"
+                             "v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+            }
             if (MODE == 20) {  // compare + select through vcc, 8 independent selects
                 asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32_e32 %0, %0, %9, vcc\n v_cmp_lt_f32 vcc, %1, %8\n v_cndmask_b32_e32 %1, %1, %9, vcc\n"
                              "v_cmp_lt_f32 vcc, %2, %8\n v_cndmask_b32_e32 %2, %2, %9, vcc\n v_cmp_lt_f32 vcc, %3, %8\n v_cndmask_b32_e32 %3, %3, %9, vcc\n"
@@ -105,6 +122,12 @@ int main() {
     run<9>("v_max3_f32");
     run<10>("v_add3_u32");
     run<13>("v_min_u32");
+    run<34>("v_fma_f32");
+    run<30>("v_sqrt_f32");
+    run<31>("v_rcp_f32");
+    run<32>("v_rsq_f32");
+    run<33>("v_cvt_i32_f32");
+    run<35>("2 sqrt + 16 plain (x18/8)");
     run<20>("cmp+cndmask vcc (x2)");
     run<21>("cmp+cndmask sgpr (x2)");
     run<22>("sub+ashr+bfi (x3)");
