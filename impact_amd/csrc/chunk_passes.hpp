@@ -8,11 +8,14 @@
 
 // (path halving on the way: the larger root always goes under the smaller, so every parent is an ancestor with a smaller index and a
 // parent may be replaced by any of its own ancestors at any time; the roots, all that is counted afterwards, are untouched)
-__device__ __forceinline__ uint32_t lds_find(volatile uint32_t* par, uint32_t x) {
+// (relaxed workgroup-scope atomics, not `volatile`: every access is made, none is reordered against the union's atomicMin on the same word,
+// and — unlike a volatile access, which the compiler brackets with a wait for EVERY outstanding memory operation — a read waits for LDS
+// only: k_derive has the next chunk's global loads in flight across this pass)
+__device__ __forceinline__ uint32_t lds_find(uint32_t* par, uint32_t x) {
     uint32_t p;
-    while ((p = par[x]) != x) {
-        const uint32_t gp = par[p];
-        if (gp != p) par[x] = gp;
+    while ((p = __hip_atomic_load(par + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != x) {
+        const uint32_t gp = __hip_atomic_load(par + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (gp != p) __hip_atomic_store(par + x, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         x = gp;
     }
     return x;
@@ -495,12 +498,9 @@ __device__ __forceinline__ double ivx_wave_sum_f64(double v) {
 
 // all 256 threads; `m` non-empty mask of the thread's row, `tw` its 16 type bytes, (gi, gj) the row's global voxel indices,
 // k0 the chunk's first k; s_dens the 256 densities and s_red[16][10] scratch in LDS. Ends with the ten sums in `out10`.
-__device__ __forceinline__ void chunk_moments_rows(uint32_t tid, uint32_t m, const uint32_t tw[4], const float* s_dens, double (*s_red)[10], int gi, int gj,
-                                                   int k0, double* __restrict__ out10) {
-    const double I = (double)gi, J = (double)gj;
-    const double qx = 2.0 * I + 1.0, qy = 2.0 * J + 1.0;
-    const double cx = 3.0 * I * I + 3.0 * I + 1.0, cy = 3.0 * J * J + 3.0 * J + 1.0;
-    double D = 0.0, Dz1 = 0.0, Dz2 = 0.0;
+// the row's three sums over its non-empty voxels k: density, density * (2K + 1), density * (3K^2 + 3K + 1), K = k0 + k
+__device__ __forceinline__ void moments_row_sums(uint32_t m, const uint32_t tw[4], const float* s_dens, int k0, double& D, double& Dz1, double& Dz2) {
+    D = 0.0, Dz1 = 0.0, Dz2 = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         if ((m >> k) & 1u) {
@@ -511,6 +511,57 @@ __device__ __forceinline__ void chunk_moments_rows(uint32_t tid, uint32_t m, con
             Dz2 += d * (3.0 * K * K + 3.0 * K + 1.0);
         }
     }
+}
+// The same three sums of a row whose 16 voxels have ONE type (nearly every row): d * (number of voxels), d * sum(2K + 1), d * sum(3K^2 + 3K
+// + 1) — the integer sums from the row's bit mask (per byte of the mask a table holds the sum of the set bits' positions and of their
+// squares), assembled in doubles that stay integers below 2^53, one product each. While the loop's sums are exact (grids of up to ~4000
+// voxels along k for a density with a full mantissa; any size for a density like 1.0) this is the loop's result bit for bit, beyond that it
+// rounds once where the loop rounds per term. Sixteen table reads, conversions and pairs of double multiply-adds less per row: the moment
+// pass was a quarter of k_derive's vector instructions, and k_derive is bound by their issue.
+// `tab`: moments_table_entry of every byte value.
+__device__ __forceinline__ uint16_t moments_table_entry(uint32_t b) {
+    uint32_t a1 = 0, a2 = 0;
+    for (uint32_t k = 0; k < 8; ++k)
+        if ((b >> k) & 1u) a1 += k, a2 += k * k;
+    return (uint16_t)(a1 | (a2 << 8));  // <= 28, <= 140
+}
+__device__ __forceinline__ void moments_row_sums_one_type(uint32_t m, uint32_t type, const float* s_dens, const uint16_t* tab, int k0, double& D, double& Dz1,
+                                                           double& Dz2) {
+    const uint32_t lo = m & 0xFFu, hi = (m >> 8) & 0xFFu;
+    const uint32_t tl = tab[lo], th = tab[hi], nh = __popc(hi);
+    const uint32_t a1 = (tl & 0xFFu) + (th & 0xFFu) + 8u * nh;                       // sum of k
+    const uint32_t a2 = (tl >> 8) + (th >> 8) + 16u * (th & 0xFFu) + 64u * nh;       // sum of k^2: (8 + k')^2 = 64 + 16 k' + k'^2 in the high byte
+    const double d = (double)s_dens[type];
+    const double S0 = (double)__popc(m), A1 = (double)a1, A2 = (double)a2, K0 = (double)k0;
+    const double P1 = K0 * S0 + A1;                                                  // sum of K
+    const double S1 = 2.0 * P1 + S0;
+    const double S2 = (3.0 * (K0 * (K0 * S0 + 2.0 * A1) + A2) + 3.0 * P1) + S0;      // 3 sum K^2 + 3 sum K + n
+    D = d * S0, Dz1 = d * S1, Dz2 = d * S2;
+}
+
+__device__ __forceinline__ void moments_reduce_rows(uint32_t tid, double D, double Dz1, double Dz2, double (*s_red)[10], int gi, int gj, double* __restrict__ out10);
+
+__device__ __forceinline__ void chunk_moments_rows(uint32_t tid, uint32_t m, const uint32_t tw[4], const float* s_dens, double (*s_red)[10], int gi, int gj,
+                                                   int k0, double* __restrict__ out10) {
+    double D, Dz1, Dz2;
+    moments_row_sums(m, tw, s_dens, k0, D, Dz1, Dz2);
+    moments_reduce_rows(tid, D, Dz1, Dz2, s_red, gi, gj, out10);
+}
+// (with the byte table in LDS: the wave takes the one-type form unless one of its rows mixes types)
+__device__ __forceinline__ void chunk_moments_rows_tab(uint32_t tid, uint32_t m, const uint32_t tw[4], const float* s_dens, const uint16_t* tab,
+                                                       double (*s_red)[10], int gi, int gj, int k0, double* __restrict__ out10) {
+    const uint32_t splat = (tw[0] & 0xFFu) * 0x01010101u;
+    const bool mixed = ((tw[0] ^ splat) | (tw[1] ^ splat) | (tw[2] ^ splat) | (tw[3] ^ splat)) != 0u;
+    double D, Dz1, Dz2;
+    if (__builtin_amdgcn_ballot_w64(mixed) == 0ull) moments_row_sums_one_type(m, tw[0] & 0xFFu, s_dens, tab, k0, D, Dz1, Dz2);
+    else moments_row_sums(m, tw, s_dens, k0, D, Dz1, Dz2);
+    moments_reduce_rows(tid, D, Dz1, Dz2, s_red, gi, gj, out10);
+}
+
+__device__ __forceinline__ void moments_reduce_rows(uint32_t tid, double D, double Dz1, double Dz2, double (*s_red)[10], int gi, int gj, double* __restrict__ out10) {
+    const double I = (double)gi, J = (double)gj;
+    const double qx = 2.0 * I + 1.0, qy = 2.0 * J + 1.0;
+    const double cx = 3.0 * I * I + 3.0 * I + 1.0, cy = 3.0 * J * J + 3.0 * J + 1.0;
     // The ten sums are linear in (D, Dz1, Dz2) with factors of i and of j. A DPP row of 16 lanes is one i: six row totals carry the
     // j-dependent parts (lane 15 of the row ends up with them), the i-dependent factors multiply the totals, and the 16 rows of the
     // workgroup meet in LDS — 72 DPP steps and 10 LDS words per wave where ten whole-wave sums took 120 steps and 80 lane reads

@@ -143,11 +143,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     __shared__ uint32_t cnt[13];      // own face non-empty counts [0..6), neighbour face non-empty counts [6..12), [12] touch bits
     __shared__ CclShared s_ccl;
     __shared__ float s_dens[256];
+    __shared__ uint16_t s_mtab[256];  // moments_table_entry of every byte value (moments_row_sums_one_type)
     // (the moment pass's 16 x 10 row totals borrow the union-find's node array: the region pass is over when they are written, and the
     // next chunk's starts behind the loop's barrier — an array of their own would be the kilobyte that takes the seventh workgroup off a CU)
     double (*s_red)[10] = reinterpret_cast<double (*)[10]>(s_ccl.par);
     const uint32_t tid = threadIdx.x;
-    if (fz.parts & IVX_PART_MOMENTS) s_dens[tid] = fz.dens[tid];  // (the first barrier of the loop publishes it)
+    if (fz.parts & IVX_PART_MOMENTS) s_dens[tid] = fz.dens[tid], s_mtab[tid] = moments_table_entry(tid);  // (the first barrier of the loop publishes them)
     const int ti = tid >> 4, tj = tid & 15;
     const uint32_t n_active = work_counts[0];
     // bounded walk over the active list (virtual block ids give each XCD a contiguous stretch of it)
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         const uint32_t ut = utype * 0x01010101u;
         const bool fresh = own_uniform && own_info.kind != KIND_NONUNIFORM;
         const uint32_t tw[4] = {fresh ? ut : own_types.x, fresh ? ut : own_types.y, fresh ? ut : own_types.z, fresh ? ut : own_types.w};
-        chunk_moments_rows(tid, m, tw, s_dens, s_red, (ci + (int)fz.x_off) * 16 + ti, cj * 16 + tj, ck * 16, fz.chunk_moments + (size_t)chunk * 10);
+        chunk_moments_rows_tab(tid, m, tw, s_dens, s_mtab, s_red, (ci + (int)fz.x_off) * 16 + ti, cj * 16 + tj, ck * 16, fz.chunk_moments + (size_t)chunk * 10);
     }
 
     if (tid == 0) {

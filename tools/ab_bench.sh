@@ -1,10 +1,10 @@
 #!/bin/bash
-# A/B of two builds of the library on ONE box (boxes differ by a few per cent): build/lib_a.so against build/lib_b.so, step-only bench, both workloads,
+# A/B of builds of the library on ONE box (boxes differ by a few per cent): every build/lib_*.so, step-only bench, both workloads,
 # interleaved twice. usage: tools/ab_bench.sh [dense|headline|both]
 set -u
 which=${1:-both}
 for rep in 1 2; do
-  for v in a b; do
+  for v in $(ls build/lib_*.so | sed 's/.*lib_//; s/\.so//'); do
     for wl in headline dense; do
       if [ "$which" != both ] && [ "$which" != $wl ]; then continue; fi
       if [ $wl = dense ]; then W="--workload dense"; else W=""; fi
