@@ -385,15 +385,45 @@ __device__ __forceinline__ void ccl_local_chunk(CclShared& sh, uint32_t tid, uin
         }
     }
     if (tid == 0) sh.cnt = 0;
+    bool slab = false;  // one region by the layer test below
     if (!known) {
-        const uint32_t mine = (__ballot(m != 0xFFFFu) ? 1u : 0u) | (__ballot(m != 0u) ? 2u : 0u) |
-                              (__ballot(edge_row ? (m != 0u) : ((m & 0x8001u) != 0u)) ? 4u : 0u);
-        if ((tid & 63u) == 0u) sh.w[tid >> 6] = mine;
+        // (with the votes: does a row hold several runs? which layers k does some non-empty row lack? which rows are non-empty?)
+        const unsigned long long occ_b = __ballot(m != 0u);
+        const uint32_t mine = (__ballot(m != 0xFFFFu) ? 1u : 0u) | (occ_b ? 2u : 0u) |
+                              (__ballot(edge_row ? (m != 0u) : ((m & 0x8001u) != 0u)) ? 4u : 0u) | (__ballot((starts & (starts - 1u)) != 0u) ? 8u : 0u);
+        uint32_t lack = m ? (~m & 0xFFFFu) : 0u;
+        lack |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lack, 0x111, 0xF, 0xF, true);  // row_shr:1 .. 8: lane 15 of a DPP row has the row's OR
+        lack |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lack, 0x112, 0xF, 0xF, true);
+        lack |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lack, 0x114, 0xF, 0xF, true);
+        lack |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lack, 0x118, 0xF, 0xF, true);
+        const uint32_t wave_lack = ((uint32_t)__builtin_amdgcn_readlane((int)lack, 15) | (uint32_t)__builtin_amdgcn_readlane((int)lack, 31)) |
+                                   ((uint32_t)__builtin_amdgcn_readlane((int)lack, 47) | (uint32_t)__builtin_amdgcn_readlane((int)lack, 63));
+        if ((tid & 63u) == 0u) {
+            sh.w[tid >> 6] = mine;
+            sh.w[4 + (tid >> 6)] = wave_lack;
+            sh.bm[2 * (tid >> 6)] = (uint32_t)occ_b;  // (the walk bitmap of the exact numbering: not in use in this pass)
+            sh.bm[2 * (tid >> 6) + 1] = (uint32_t)(occ_b >> 32);
+        }
         __syncthreads();
         const uint32_t votes = (sh.w[0] | sh.w[1]) | (sh.w[2] | sh.w[3]);
         all_full = !(votes & 1u);
         any = (votes & 2u) != 0u;
         touches = (votes & 4u) != 0u;
+        // One region without the union-find: every non-empty row is ONE run, some layer k is in all of them — so two non-empty rows next to
+        // each other always touch, and the region is connected when the SET of non-empty rows is, as a figure in the (i, j) plane — and that
+        // set is one run of j per i, overlapping from each i to the next, over one run of i (sufficient, not necessary: anything else takes
+        // the general path). A slab of material crossing the chunk — a floor, a wall's face, a plate — is this case; the union-find with its
+        // two barriers was a third of such a chunk's time in the sweep.
+        const uint32_t lack_all = (sh.w[4] | sh.w[5]) | (sh.w[6] | sh.w[7]);
+        if (any && !all_full && !(votes & 8u) && (~lack_all & 0xFFFFu) != 0u) {  // (workgroup-uniform)
+            const uint32_t i = tid & 15u, i1 = i < 15u ? i + 1u : 15u;
+            const uint32_t b = (sh.bm[i >> 1] >> (16u * (i & 1u))) & 0xFFFFu;                            // non-empty rows j of line i
+            const uint32_t bn = i < 15u ? ((sh.bm[i1 >> 1] >> (16u * (i1 & 1u))) & 0xFFFFu) : 0u;       // ... of line i + 1
+            const uint32_t runs = b & ~(b << 1);
+            const bool ok = b == 0u || ((runs & (runs - 1u)) == 0u && (bn == 0u || (b & bn) != 0u));
+            const uint32_t lines = (uint32_t)__ballot(b != 0u) & 0xFFFFu, line_runs = lines & ~(lines << 1);
+            slab = __ballot(!ok) == 0ull && (line_runs & (line_runs - 1u)) == 0u;
+        }
     }
     if (!any || all_full) {
         // no voxels, or one solid region touching every face
@@ -406,7 +436,7 @@ __device__ __forceinline__ void ccl_local_chunk(CclShared& sh, uint32_t tid, uin
         return;
     }
     // 2. join runs across +x and +y: one union per run of the overlap between the two rows
-    {
+    if (!slab) {
         const uint32_t mx = ti < 15 ? sh.mask[tid + 16] : 0u;
         const uint32_t my = tj < 15 ? sh.mask[tid + 1] : 0u;
         const uint32_t sx = mx & ~(mx << 1), sy = my & ~(my << 1);
@@ -428,6 +458,8 @@ __device__ __forceinline__ void ccl_local_chunk(CclShared& sh, uint32_t tid, uin
             lds_union(sh.par, a, b);
         }
     }
+    uint32_t rc = 1u;
+    if (!slab) {  // (workgroup-uniform)
     __syncthreads();
     // 3. count the roots (a root keeps itself as parent, every other node points somewhere else, so no flattening is needed
     // to count); does any voxel lie on the chunk boundary?
@@ -445,7 +477,8 @@ __device__ __forceinline__ void ccl_local_chunk(CclShared& sh, uint32_t tid, uin
         if ((tid & 63u) == 0 && wr) atomicAdd(&sh.cnt, wr);
     }
     __syncthreads();
-    const uint32_t rc = sh.cnt;
+    rc = sh.cnt;
+    }
     if (rc == 1u) {
         uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll

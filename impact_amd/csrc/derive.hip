@@ -23,19 +23,21 @@
 
 namespace {
 
+#ifndef IVX_DERIVE_WG_PER_CU
+#define IVX_DERIVE_WG_PER_CU 4u  // resident workgroups per CU of the pipelined form (its registers: 119)
+#endif
 struct DeriveParams {
     uint32_t cx, cy, cz;
 };
 
 __device__ __forceinline__ uint32_t row_mask(uint4 s) {
     // bit k set <=> voxel k non-empty <=> sd < 0 (sign bit of byte k)
+    // (the four sign bits of a word, moved to bits 0, 8, 16, 24, meet in bits 21..24 of a product with 2^21 + 2^14 + 2^7 + 1: byte i's bit
+    // lands on 8 i + 21 - 7 j, the wanted ones (i = j) side by side, the other twelve on distinct bits elsewhere, so nothing carries)
     uint32_t w[4] = {s.x, s.y, s.z, s.w};
     uint32_t m = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        uint32_t sb = w[q] & 0x80808080u;
-        m |= (((sb >> 7) & 1u) | ((sb >> 14) & 2u) | ((sb >> 21) & 4u) | ((sb >> 28) & 8u)) << (4 * q);
-    }
+    for (int q = 0; q < 4; ++q) m |= ((((w[q] >> 7) & 0x01010101u) * 0x00204081u >> 21) & 0xFu) << (4 * q);
     return m;
 }
 
@@ -120,6 +122,50 @@ __global__ __launch_bounds__(256) void k_chunk_pre(GridView g, ivx_chunk_info* _
     }
 }
 
+// The global loads of a chunk's first phase, in flight: the chunk's own record and rows; across each z face one byte per thread; (threads
+// 0..63) one 16-byte row across an x or y face; the three neighbours' generated kinds. Addresses are clamped to valid ones and the
+// records select afterwards — written as "record, then the byte if the neighbour is dense" the compiler sinks each load under the branch
+// that consumes it, and the phase is seven dependent memory round trips instead of one (measured on the mesher's tile load). Byte loads
+// come as the aligned word's load and a shift at the use: the `load + extend` pair of a byte load is one the compiler keeps together,
+// i.e. a wait where the load was issued.
+struct DeriveLoads {
+    uint2 own_rec;
+    uint4 own_sd, own_types, nrow;
+    uint32_t gen_lo, gen_hi, by_lo, by_hi, ngen, type0;
+};
+__device__ __forceinline__ void derive_issue(const GridView& g, const ivx_chunk_info* __restrict__ info, uint32_t chunk, uint32_t tid, DeriveLoads& L) {
+    const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
+    const size_t base = (size_t)chunk * IVX_CHUNK_VOXELS;
+    const bool has_zlo = ck > 0, has_zhi = ck + 1 < (int)g.cz;
+    const size_t c_lo = has_zlo ? (size_t)chunk - 1 : (size_t)chunk, c_hi = has_zhi ? (size_t)chunk + 1 : (size_t)chunk;
+    const int nf = (tid >> 4) & 3, nr = tid & 15;
+    bool n_present, n_ghost = false;
+    size_t nc;
+    uint32_t noff;
+    {
+        const size_t plane = (size_t)g.cy * g.cz;
+        const int8_t* gp = nf == 0 ? g.ghost_sdf[0] : g.ghost_sdf[1];
+        if (nf == 0) n_present = ci > 0, nc = (size_t)chunk - plane, noff = 15 * 256 + nr * 16, n_ghost = !n_present && gp != nullptr;
+        else if (nf == 1) n_present = ci + 1 < (int)g.cx, nc = (size_t)chunk + plane, noff = nr * 16, n_ghost = !n_present && gp != nullptr;
+        else if (nf == 2) n_present = cj > 0, nc = (size_t)chunk - g.cz, noff = nr * 256 + 15 * 16;
+        else n_present = cj + 1 < (int)g.cy, nc = (size_t)chunk + g.cz, noff = nr * 256;
+        if (!n_present) nc = chunk;
+    }
+    const int8_t* nrp = g.sdf + (nc << 12) + noff;
+    if (n_ghost) nrp = (nf == 0 ? g.ghost_sdf[0] : g.ghost_sdf[1]) + ((size_t)(cj * g.cz + ck) * 256 + nr * 16);
+    L.own_rec = reinterpret_cast<const uint2*>(info)[chunk];
+    L.own_sd = *reinterpret_cast<const uint4*>(g.sdf + base + (size_t)tid * 16);      // used only if the chunk has planes
+    L.own_types = *reinterpret_cast<const uint4*>(g.type + base + (size_t)tid * 16);  // likewise
+    // (gen_kind is the second byte of a record's first word; the face bytes are the last / first of the row's 16)
+    L.gen_lo = reinterpret_cast<const uint32_t*>(info)[2 * c_lo];
+    L.gen_hi = reinterpret_cast<const uint32_t*>(info)[2 * c_hi];
+    L.by_lo = *reinterpret_cast<const uint32_t*>(g.sdf + (c_lo << 12) + tid * 16 + 12);
+    L.by_hi = *reinterpret_cast<const uint32_t*>(g.sdf + (c_hi << 12) + tid * 16);
+    L.ngen = reinterpret_cast<const uint32_t*>(info)[2 * nc];
+    L.nrow = *reinterpret_cast<const uint4*>(nrp);
+    L.type0 = *reinterpret_cast<const uint32_t*>(g.type + base);  // (voxel 0's type: the type of a Uniform chunk that was demoted before)
+}
+
 // What the later per-chunk passes need is in this kernel's registers already, so it can run them in the same sweep (`parts`):
 // the chunk-local region labelling needs only the chunk's own non-empty masks, and so do its moments (plus the type row).
 struct DeriveFused {
@@ -133,12 +179,16 @@ struct DeriveFused {
     double* chunk_moments;
 };
 
-// (amdgpu_waves_per_eu(7): seven workgroups per CU is what the 20 KB of LDS allow; the workgroups are latency-bound, so
-// residency is throughput, and the register budget is set to match.)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_derive(GridView g, int8_t* __restrict__ sdf_rw, uint8_t* __restrict__ type_rw, uint8_t* __restrict__ flags_out,
+// Two forms. PIPE = false: about one workgroup per listed chunk, seven resident per CU (what the 20 KB of LDS allow; the register budget is
+// set to match): the hardware overlaps the chunks' dependent phases. PIPE = true, for long lists: a resident set of four workgroups per CU,
+// each walking its share of the list with the next chunk's loads in flight (119 registers) — 4 % faster on the all-surface 512^3 grid, slower
+// on short lists, where the shares are a handful of chunks.
+template <bool PIPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE ? 4 : 7, 8))) void k_derive(GridView g, int8_t* __restrict__ sdf_rw, uint8_t* __restrict__ type_rw, uint8_t* __restrict__ flags_out,
                                                 ivx_chunk_info* __restrict__ info, uint32_t* __restrict__ bbox, uint8_t* __restrict__ touch,
                                                 uint16_t* __restrict__ signs, uint8_t* __restrict__ kface_out,
-                                                const uint32_t* __restrict__ work_counts, uint32_t* __restrict__ active_list, DeriveFused fz) {
+                                                const uint32_t* __restrict__ work_counts, uint32_t* __restrict__ active_list,
+                                                const uint32_t* __restrict__ list_in, DeriveFused fz) {
     __shared__ uint32_t occ[18][18];  // non-empty masks of rows (i+1, j+1); halo rows from neighbour chunks
     __shared__ uint32_t cnt[13];      // own face non-empty counts [0..6), neighbour face non-empty counts [6..12), [12] touch bits
     __shared__ CclShared s_ccl;
@@ -151,46 +201,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     if (fz.parts & IVX_PART_MOMENTS) s_dens[tid] = fz.dens[tid], s_mtab[tid] = moments_table_entry(tid);  // (the first barrier of the loop publishes them)
     const int ti = tid >> 4, tj = tid & 15;
     const uint32_t n_active = work_counts[0];
-    // bounded walk over the active list (virtual block ids give each XCD a contiguous stretch of it)
-    for (uint32_t li = ivx_xcd_remap(blockIdx.x, gridDim.x); li < n_active; li += gridDim.x) {
+    // Bounded walk over the active list (virtual block ids give each XCD a contiguous stretch of it), one chunk ahead: the loads of a
+    // chunk's first phase — 4.5 of a workgroup's 11 us per chunk when they were taken at the start of the chunk, and the kernel is bound by
+    // what its resident workgroups wait for — go out at the top of the round BEFORE, travel while that round's chunk is swept, and are
+    // first touched a round later (the mesher's tile prefetch, sn_roles.hpp tile_issue). The list entry is read two rounds ahead.
+    // (`list_in` IS `active_list`, through a read-only pointer so that the entry two rounds ahead comes by a scalar load: a workgroup reads
+    // only entries it alone rewrites — later, and never the chunk index in their low bits)
+    uint32_t li = ivx_xcd_remap(blockIdx.x, gridDim.x);
+    if (li >= n_active) return;
+    DeriveLoads L;
+    uint32_t chunk = IVX_LIST_CHUNK(list_in[li]);
+    uint32_t chunk_next = chunk;
+    if (PIPE) {
+        derive_issue(g, info, chunk, tid, L);
+        if (li + gridDim.x < n_active) chunk_next = IVX_LIST_CHUNK(list_in[li + gridDim.x]);
+    }
+    for (;;) {
     __syncthreads();  // the previous chunk's LDS use is over
     IVX_T(g, li, 0);
-    const uint32_t chunk = IVX_LIST_CHUNK(active_list[li]);
+    const bool have_next = li + gridDim.x < n_active;
+    if (!PIPE) derive_issue(g, info, chunk, tid, L);
     const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
     const size_t base = (size_t)chunk * IVX_CHUNK_VOXELS;
-    // ---- every global load of the chunk's first phase goes out here, back to back, before the first of them is used: the chunk's own
-    // record and rows; across each z face one byte per thread; (threads 0..63) one 16-byte row across an x or y face; the three
-    // neighbours' records. Addresses are clamped to valid ones and the records select afterwards. Written as "record, then the byte
-    // if the neighbour is dense" the compiler sinks each load under the branch that consumes it, and the phase is seven dependent
-    // memory round trips instead of one (measured on the mesher's tile load, sn_roles.hpp RowLoads).
     const bool has_zlo = ck > 0, has_zhi = ck + 1 < (int)g.cz;
-    const size_t c_lo = has_zlo ? (size_t)chunk - 1 : (size_t)chunk, c_hi = has_zhi ? (size_t)chunk + 1 : (size_t)chunk;
     // x / y faces: f: 0 x-, 1 x+, 2 y-, 3 y+ (threads >= 64 repeat thread (tid & 63)'s loads and drop them)
     const int nf = (tid >> 4) & 3, nr = tid & 15;
     bool n_present, n_ghost = false;
-    size_t nc;
-    uint32_t noff;
     {
-        const size_t plane = (size_t)g.cy * g.cz;
         const int8_t* gp = nf == 0 ? g.ghost_sdf[0] : g.ghost_sdf[1];  // (selected, not indexed: the view lives in the kernel arguments)
-        if (nf == 0) n_present = ci > 0, nc = (size_t)chunk - plane, noff = 15 * 256 + nr * 16, n_ghost = !n_present && gp != nullptr;
-        else if (nf == 1) n_present = ci + 1 < (int)g.cx, nc = (size_t)chunk + plane, noff = nr * 16, n_ghost = !n_present && gp != nullptr;
-        else if (nf == 2) n_present = cj > 0, nc = (size_t)chunk - g.cz, noff = nr * 256 + 15 * 16;
-        else n_present = cj + 1 < (int)g.cy, nc = (size_t)chunk + g.cz, noff = nr * 256;
-        if (!n_present) nc = chunk;
+        if (nf == 0) n_present = ci > 0, n_ghost = !n_present && gp != nullptr;
+        else if (nf == 1) n_present = ci + 1 < (int)g.cx, n_ghost = !n_present && gp != nullptr;
+        else if (nf == 2) n_present = cj > 0;
+        else n_present = cj + 1 < (int)g.cy;
     }
-    const int8_t* nrp = g.sdf + (nc << 12) + noff;
-    if (n_ghost) nrp = (nf == 0 ? g.ghost_sdf[0] : g.ghost_sdf[1]) + ((size_t)(cj * g.cz + ck) * 256 + nr * 16);
-    uint2 own_rec = reinterpret_cast<const uint2*>(info)[chunk];
-    uint4 own_sd = *reinterpret_cast<const uint4*>(g.sdf + base + (size_t)tid * 16);  // used only if the chunk has planes
-    uint4 own_types = *reinterpret_cast<const uint4*>(g.type + base + (size_t)tid * 16);  // likewise
-    uint32_t gen_lo = info[c_lo].gen_kind, gen_hi = info[c_hi].gen_kind;
-    uint32_t by_lo = (uint8_t)g.sdf[(c_lo << 12) + tid * 16 + 15], by_hi = (uint8_t)g.sdf[(c_hi << 12) + tid * 16];
-    uint32_t ngen = info[nc].gen_kind;
-    uint4 nrow = *reinterpret_cast<const uint4*>(nrp);
+    uint2 own_rec = L.own_rec;
+    uint4 own_sd = L.own_sd, own_types = L.own_types, nrow = L.nrow;
+    uint32_t gen_lo = L.gen_lo, gen_hi = L.gen_hi, by_lo = L.by_lo, by_hi = L.by_hi, ngen = L.ngen, type0 = L.type0;
     asm volatile("" : "+v"(own_rec.x), "+v"(own_rec.y), "+v"(own_sd.x), "+v"(own_sd.y), "+v"(own_sd.z), "+v"(own_sd.w));
     asm volatile("" : "+v"(own_types.x), "+v"(own_types.y), "+v"(own_types.z), "+v"(own_types.w));
-    asm volatile("" : "+v"(gen_lo), "+v"(gen_hi), "+v"(by_lo), "+v"(by_hi), "+v"(ngen), "+v"(nrow.x), "+v"(nrow.y), "+v"(nrow.z), "+v"(nrow.w));
+    asm volatile("" : "+v"(gen_lo), "+v"(gen_hi), "+v"(by_lo), "+v"(by_hi), "+v"(ngen), "+v"(nrow.x), "+v"(nrow.y), "+v"(nrow.z), "+v"(nrow.w), "+v"(type0));
+    by_lo >>= 24, by_hi &= 0xFFu, gen_lo = (gen_lo >> 8) & 0xFFu, gen_hi = (gen_hi >> 8) & 0xFFu, ngen = (ngen >> 8) & 0xFFu;
     ivx_chunk_info own_info;
     own_info.kind = (uint8_t)(own_rec.x & 0xFFu);
     own_info.gen_kind = (uint8_t)((own_rec.x >> 8) & 0xFFu);
@@ -328,21 +378,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     dm[3] = (m & xup) | ((ti == 15 && (quirk & 2u)) ? e : 0u);
     dm[4] = (m & yup) | ((tj == 15 && (quirk & 8u)) ? e : 0u);
     dm[5] = (m & zup) | ((quirk & 32u) ? (e & 0x8000u) : 0u);
+    // The flags byte of voxel k is column k of an 8 x 16 bit matrix whose rows are the masks (row 0: VF_EMPTY, row 1: none, rows 2..7:
+    // VF_X_DN = 1 << 2 ... VF_Z_UP = 1 << 7): two 8 x 8 transposes — low and high byte of the masks — of three rounds of masked swaps each
+    // (7, 14 and 28 bits apart; the first two stay inside a 32-bit half), ~60 instructions where spreading 7 x 4 nibbles by multiplication
+    // took 110.
     uint32_t w[4];
+    {
+        const uint32_t p01 = dm[0] | (dm[1] << 16), p23 = dm[2] | (dm[3] << 16), p45 = dm[4] | (dm[5] << 16);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        auto spread = [](uint32_t nib) { return __umul24(nib, 0x00204081u) & 0x01010101u; };
-        uint32_t v = spread((e >> (4 * q)) & 0xFu);  // VF_EMPTY = bit 0
-#pragma unroll
-        for (int d = 0; d < 6; ++d) v |= spread((dm[d] >> (4 * q)) & 0xFu) << (2 + d);  // VF_X_DN = 1 << 2, ... VF_Z_UP = 1 << 7
-        w[q] = v;
+        for (int h = 0; h < 2; ++h) {
+            // bytes of the 64-bit matrix, row r in byte r: (e, 0, dm0, dm1 | dm2, dm3, dm4, dm5), byte h of each mask
+            uint32_t lo = __builtin_amdgcn_perm(p01, e, h ? 0x07050C01u : 0x06040C00u);  // selector bytes 0-3: second operand's, 4-7: first's, 0x0C: zero
+            uint32_t hi = __builtin_amdgcn_perm(p45, p23, h ? 0x07050301u : 0x06040200u);
+            uint32_t t;
+            t = (lo ^ (lo >> 7)) & 0x00AA00AAu, lo = lo ^ t ^ (t << 7);
+            t = (hi ^ (hi >> 7)) & 0x00AA00AAu, hi = hi ^ t ^ (t << 7);
+            t = (lo ^ (lo >> 14)) & 0x0000CCCCu, lo = lo ^ t ^ (t << 14);
+            t = (hi ^ (hi >> 14)) & 0x0000CCCCu, hi = hi ^ t ^ (t << 14);
+            t = (lo ^ ((hi << 4) | (lo >> 28))) & 0xF0F0F0F0u, lo ^= t, hi ^= t >> 4;
+            w[2 * h] = lo, w[2 * h + 1] = hi;
+        }
     }
     // (cnt[] and the record's gen_kind are the same for every thread, so is `kind`)
     const uint32_t gen = own_info.gen_kind;
     uint32_t kind = gen;
     if (gen == KIND_UNIFORM && nbr_full != 0x3Fu) kind = KIND_NONUNIFORM;
     // the planes of a Uniform chunk that was demoted before hold its voxels already; its record no longer has the type
-    const uint32_t utype = own_uniform ? (own_info.kind == KIND_NONUNIFORM ? (uint32_t)g.type[base] : (uint32_t)own_info.uniform_type) : 0u;
+    const uint32_t utype = own_uniform ? (own_info.kind == KIND_NONUNIFORM ? (type0 & 0xFFu) : (uint32_t)own_info.uniform_type) : 0u;
     if (kind == KIND_NONUNIFORM) {
         *reinterpret_cast<uint4*>(flags_out + base + (size_t)tid * 16) = make_uint4(w[0], w[1], w[2], w[3]);
         if (own_uniform && own_info.kind != KIND_NONUNIFORM) {
@@ -354,6 +416,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     }
 
     IVX_T(g, li, 3);  // flags written
+    // ---- the next chunk's loads: out before the region and moment passes, which no longer hold this chunk's rows
+    DeriveLoads Ln;
+    uint32_t chunk_next2 = chunk;
+    if (PIPE) {
+        if (have_next) derive_issue(g, info, chunk_next, tid, Ln);
+        const uint32_t li2 = li + 2u * gridDim.x;
+        if (li2 < n_active) chunk_next2 = IVX_LIST_CHUNK(list_in[li2]);
+    }
     // ---- fused passes over the same chunk (uniform branches: `parts` and `kind` are the same for the whole workgroup)
     uint32_t rc = own_info.region_count, brc = own_info.boundary_region_count;
     if (fz.parts & IVX_PART_REGIONS) ccl_local_chunk(s_ccl, tid, chunk, kind, gen, m, fz.labels, fz.rparent, fz.rscalar, fz.multi_list, rc, brc);
@@ -400,6 +470,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         info[chunk] = ci_;
     }
     IVX_T(g, li, 5);
+    if (!have_next) break;
+    li += gridDim.x;
+    if (PIPE) {
+        chunk = chunk_next;
+        chunk_next = chunk_next2;
+        L = Ln;
+    } else {
+        chunk = IVX_LIST_CHUNK(list_in[li]);
+    }
     }
 }
 
@@ -525,8 +604,14 @@ int ivx_launch_derive(ivx_grid* g, uint32_t parts, uint32_t preset_groups) {
                        g->chunk_class, g->chunk_touch, g->rparent, ivx_wc(g), next_count, g->active_list, ivx_preset_args(g, preset_groups | roll));
     g->scratch_dirty &= ~preset_groups;
     if (roll) g->scratch_dirty &= ~IVX_SCRATCH_EVAL;
-    hipLaunchKernelGGL(k_derive, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->sdf, g->type, g->flags, g->info, g->chunk_bbox,
-                       g->chunk_touch, g->chunk_signs, g->kface, ivx_wc(g), g->active_list, fz);
+    // long lists: a resident set of workgroups, each walking its share of the list one chunk ahead (see the kernel)
+    const uint32_t resident = (uint32_t)g->ctx->n_cu * IVX_DERIVE_WG_PER_CU;
+    if (ivx_list_grid(g) >= 16u * resident)
+        hipLaunchKernelGGL(k_derive<true>, dim3(resident), dim3(256), 0, g->ctx->stream, v, g->sdf, g->type, g->flags, g->info, g->chunk_bbox,
+                           g->chunk_touch, g->chunk_signs, g->kface, ivx_wc(g), g->active_list, g->active_list, fz);
+    else
+        hipLaunchKernelGGL(k_derive<false>, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->sdf, g->type, g->flags, g->info, g->chunk_bbox,
+                           g->chunk_touch, g->chunk_signs, g->kface, ivx_wc(g), g->active_list, g->active_list, fz);
     g->planes_compact = 1;
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
