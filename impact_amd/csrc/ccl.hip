@@ -132,33 +132,66 @@ __global__ __launch_bounds__(256) void k_halo_pack_both(GridView g, uint8_t* __r
             (uint16_t)face_id16(g, side, col, tid, labels, rcompid, rscalar);
 }
 
+// The distinct (own component, neighbour's component) pairs across one x face. A workgroup takes FACE_COLS chunk columns — every thread the
+// same face voxel of each, the columns' three dependent loads (chunk kind, label, component id) side by side — and collects the pairs of small
+// ids (the usual case: a handful of components per slab) in a 64 x 64 bit table in LDS; one thread per table word then merges it into the
+// slab's table with one atomic and lists the pairs whose bit it set first. (One workgroup per column and one atomic per wave on the slab's
+// table was 16 us for a 32 x 32 face: a face inside one body is thousands of times the same pair, a thousand workgroups find the bit clear
+// at the same moment, and that many atomics on one word queue.)
+constexpr uint32_t FACE_COLS = 8;
 __global__ __launch_bounds__(256) void k_face_pairs(GridView g, uint32_t side, const uint8_t* __restrict__ labels,
                                                     const uint32_t* __restrict__ rcompid, const uint16_t* __restrict__ nbr,
                                                     uint32_t* __restrict__ n_pairs, uint2* __restrict__ pairs, uint32_t cap, uint32_t* __restrict__ seen) {
-    const uint32_t col = blockIdx.x, tid = threadIdx.x;
-    const uint32_t chunk = (side ? g.cx - 1 : 0u) * g.cy * g.cz + col;
-    const uint32_t ckind = g.info[chunk].kind;
-    const uint32_t l = ckind != KIND_NONUNIFORM ? ivx_uniform_label(ckind) : labels[(size_t)chunk * IVX_CHUNK_VOXELS + ((side ? 15u : 0u) << 8) + tid];
-    const uint32_t a = l == 255u ? NODE_NONE : rcompid[chunk * 256u + l];
-    const uint32_t b16 = nbr[(size_t)col * 256 + tid];
-    const uint32_t b = b16 == 0xFFFFu ? NODE_NONE : b16;
-    const bool both = a != NODE_NONE && b != NODE_NONE;
-    // drop repeats along the lane order (one wave = four rows of 16 face voxels)
-    const uint32_t pa = __shfl_up(a, 1, 64), pb = __shfl_up(b, 1, 64);
-    const bool dup = (tid & 63u) != 0 && pa == a && pb == b;
-    if (both && !dup) {
-        // pairs of small ids (the usual case: a handful of components per slab) are listed once, via a 64 x 64 bit table
-        bool fresh = true;
-        if (seen && a < 64u && b < 64u) {
-            // (a look before the atomic: a face inside one body is thousands of times the same pair, and that many atomics on one
-            // word queue for ~20 us; the look goes past the L1, and a 0 that is no longer true only costs the atomic it would have cost anyway)
-            const uint32_t bit = a * 64u + b;
-            fresh = !((__hip_atomic_load(&seen[bit >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (bit & 31u)) & 1u);
-            if (fresh) fresh = !((atomicOr(&seen[bit >> 5], 1u << (bit & 31u)) >> (bit & 31u)) & 1u);
+    __shared__ uint32_t s_seen[128];
+    const uint32_t tid = threadIdx.x, cols = g.cy * g.cz;
+    if (tid < 128u) s_seen[tid] = 0u;
+    uint32_t col[FACE_COLS], chunk[FACE_COLS], kind[FACE_COLS], l[FACE_COLS], a[FACE_COLS], b[FACE_COLS];
+#pragma unroll
+    for (uint32_t c = 0; c < FACE_COLS; ++c) {
+        col[c] = min(blockIdx.x * FACE_COLS + c, cols - 1u);  // (a column past the end repeats the last one's loads and lists nothing)
+        chunk[c] = (side ? g.cx - 1 : 0u) * cols + col[c];
+        kind[c] = g.info[chunk[c]].kind;
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < FACE_COLS; ++c) {
+        l[c] = labels[(size_t)chunk[c] * IVX_CHUNK_VOXELS + ((side ? 15u : 0u) << 8) + tid];  // (the plane is there whatever the kind; only its content may be stale)
+        b[c] = nbr[(size_t)col[c] * 256 + tid];
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < FACE_COLS; ++c) {
+        if (kind[c] != KIND_NONUNIFORM) l[c] = ivx_uniform_label(kind[c]);
+        a[c] = rcompid[chunk[c] * 256u + l[c]];
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t c = 0; c < FACE_COLS; ++c) {
+        const uint32_t ca = l[c] == 255u ? NODE_NONE : a[c], cb = b[c] == 0xFFFFu ? NODE_NONE : b[c];
+        const bool both = ca != NODE_NONE && cb != NODE_NONE && blockIdx.x * FACE_COLS + c < cols;
+        // drop repeats along the lane order (one wave = four rows of 16 face voxels)
+        const uint32_t pa = __shfl_up(ca, 1, 64), pb = __shfl_up(cb, 1, 64);
+        const bool dup = (tid & 63u) != 0 && pa == ca && pb == cb;
+        if (both && !dup) {
+            if (seen && ca < 64u && cb < 64u) {
+                const uint32_t bit = ca * 64u + cb;
+                if (!((__hip_atomic_load(&s_seen[bit >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> (bit & 31u)) & 1u)) atomicOr(&s_seen[bit >> 5], 1u << (bit & 31u));
+            } else {
+                const uint32_t slot = atomicAdd(n_pairs, 1u);
+                if (slot < cap) pairs[slot] = make_uint2(ca, cb);
+            }
         }
-        if (fresh) {
-            const uint32_t slot = atomicAdd(n_pairs, 1u);
-            if (slot < cap) pairs[slot] = make_uint2(a, b);
+    }
+    __syncthreads();
+    if (tid < 128u && seen) {
+        const uint32_t mine = s_seen[tid];
+        if (mine) {
+            uint32_t fresh = mine & ~__hip_atomic_load(&seen[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (a look before the atomic)
+            if (fresh) fresh &= ~atomicOr(&seen[tid], fresh);
+            while (fresh) {
+                const uint32_t bit = tid * 32u + (uint32_t)(__ffs(fresh) - 1);
+                fresh &= fresh - 1u;
+                const uint32_t slot = atomicAdd(n_pairs, 1u);
+                if (slot < cap) pairs[slot] = make_uint2(bit >> 6, bit & 63u);
+            }
         }
     }
 }
@@ -415,7 +448,7 @@ int ivx_launch_face_pairs(ivx_grid* g, int side, const uint16_t* d_nbr, uint32_t
         IVX_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t), g->ctx->stream));
         if (d_seen) IVX_HIP_CHECK(hipMemsetAsync(d_seen, 0, 128 * sizeof(uint32_t), g->ctx->stream));
     }
-    hipLaunchKernelGGL(k_face_pairs, dim3(g->cc[1] * g->cc[2]), dim3(256), 0, g->ctx->stream, v, (uint32_t)side, g->llabel, g->rcompid, d_nbr,
+    hipLaunchKernelGGL(k_face_pairs, dim3((g->cc[1] * g->cc[2] + FACE_COLS - 1u) / FACE_COLS), dim3(256), 0, g->ctx->stream, v, (uint32_t)side, g->llabel, g->rcompid, d_nbr,
                        d_count, static_cast<uint2*>(d_pairs), cap, d_seen);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;

@@ -2211,6 +2211,8 @@ int ivx_grid_set_sdf_program(ivx_grid* g, const ivx_sdf_processed_node* nodes, s
         g->prog_center[d] = shifted_grid_center[d];
     }
     g->prog_type = voxel_type;
+    g->eval_len_valid = 0;
+    g->eval_len_pending = 0;
     return IVX_OK;
 }
 
@@ -2292,6 +2294,7 @@ int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
         T0(0);
         if ((rc = ivx_launch_sdf_sample(g, g->prog_nodes, g->prog_n, g->prog_stack, g->prog_shape, g->prog_center, g->prog_type, preset_in_sample))) return rc;
         T1(0);
+        g->eval_len_pending = 1;  // (the list lengths reach the result block once a derive sweep has rolled the counters over)
         g->occ_ref_valid = 0;
         g->bbox_valid = 0;
         g->mesh_valid = 0;
@@ -2302,6 +2305,7 @@ int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
         T0(1);
         if ((rc = ivx_launch_derive(g, fused_parts, preset_in_derive))) return rc;
         T1(1);
+        if (g->eval_len_pending == 1) g->eval_len_pending = 2;
     }
     const uint32_t post = stages & (IVX_STAGE_OCCUPIED | IVX_STAGE_REGIONS | IVX_STAGE_REMESH | IVX_STAGE_INERTIA);
     if (post) {
@@ -2405,6 +2409,11 @@ int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out) {
     }
     const uint32_t* sc = g->result_host;
     if (sc[31]) g->last_active = sc[31];
+    if (g->eval_len_pending == 2 && g->samp_len) {  // a sample stage and a derive sweep behind it have run under the resident program
+        for (int c = 0; c < 3; ++c) g->eval_len[c] = sc[52 + c];
+        g->eval_len_valid = 1;
+    }
+    g->eval_len_pending = 0;
     if (stages & IVX_STAGE_REGIONS) {
         IVX_REQUIRE((sc[1] & 1u) == 0, IVX_ERR_CAPACITY, "ivx_voxel_step: a chunk has more than 254 local regions");
         g->region_count = sc[0];

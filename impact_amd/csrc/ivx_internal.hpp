@@ -116,6 +116,10 @@ struct ivx_grid {
     uint32_t prog_shape[3];
     float prog_center[3];
     uint8_t prog_type;
+    // lengths of the sampler's three evaluation lists under the resident program, as the last collected step with a derive sweep reported them
+    // (`eval_len_valid`; a function of the program and the grid alone): a class whose list is known to be empty is not launched
+    uint32_t eval_len[3];
+    int eval_len_valid, eval_len_pending;
     int has_dens;
     double* moments_dev;  // [10]
     uint32_t* samp_len;   // [n_chunks] length of the chunk's compact SDF program (sampler pre-pass)

@@ -1121,6 +1121,8 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
         for (uint32_t c = 0; c < 3; ++c) {
             if (c > 0 && stack_size < levels[c]) break;
             if (c == 2 && stack_size == 3u) break;
+            // (nor a class whose list the last step under this program found empty: the lists are a function of the program and the grid)
+            if (c > 0 && g->eval_len_valid && g->eval_len[c] == 0u) continue;
             const uint32_t lv = levels[c] ? levels[c] : 1u;
             if (c == 0 && lv == 2u) {
                 // two levels, the second one 15 rows long + 64 words of scratch: 32 000 bytes = 25 LDS granules, five workgroups per CU

@@ -140,6 +140,10 @@ struct ivx_slab {
     size_t halo_bytes, face_bytes, rec_words;
     uint8_t* send[2];
     uint8_t* recv[2];
+    // in-process transport: no copies — a slab reads its ghost layers straight from the neighbour's send buffer, so the second exchange of a step
+    // packs into a second pair (the first pair is still being read by slabs later in the stream's order)
+    uint8_t* send2[2];
+    const uint8_t* ghost[2];  // where this slab's ghost layers of the last exchange are (recv[side], or a neighbour's send buffer)
     unsigned long long* record;    // this slab's record (device)
     unsigned long long* gathered;  // nranks records (device)
     unsigned long long* host_head;      // host-mapped pinned block: the nranks record heads + one doorbell word (the keeper's only)
@@ -246,9 +250,11 @@ int ipc_all_gather(ivx_slab* sl, size_t words) {
     return IVX_OK;
 }
 
-int exchange(ivx_slab** slabs, size_t n, size_t nbytes) {
+// (`second`: the step's second exchange — the in-process transport packs it into its second pair of send buffers, see pack_bufs)
+int exchange(ivx_slab** slabs, size_t n, size_t nbytes, bool second) {
     ivx_comm* c = slabs[0]->comm;
     hipStream_t s = c->ctx->stream;
+    for (size_t i = 0; i < n; ++i) slabs[i]->ghost[0] = slabs[i]->recv[0], slabs[i]->ghost[1] = slabs[i]->recv[1];
     if (c->ipc) return ipc_exchange(slabs[0], nbytes);
     if (c->rank >= 0) {  // RCCL: one slab per process, its two neighbours
         ivx_slab* sl = slabs[0];
@@ -265,13 +271,18 @@ int exchange(ivx_slab** slabs, size_t n, size_t nbytes) {
         IVX_NCCL_CHECK(g_rccl.GroupEnd());
         return IVX_OK;
     }
-    // in-process: the send buffers are read before anything overwrites them (all copies are enqueued here, in order)
+    // in-process: nothing moves. Every slab's kernels are on the one stream, the packs of this exchange ahead of its readers; the buffers of
+    // the step's first exchange are packed again in the next step's first phase, those of the second in its second — after their last reader.
+    (void)s;
+    (void)nbytes;
     for (size_t i = 0; i + 1 < n; ++i) {
-        IVX_HIP_CHECK(hipMemcpyAsync(slabs[i]->recv[1], slabs[i + 1]->send[0], nbytes, hipMemcpyDeviceToDevice, s));
-        IVX_HIP_CHECK(hipMemcpyAsync(slabs[i + 1]->recv[0], slabs[i]->send[1], nbytes, hipMemcpyDeviceToDevice, s));
+        slabs[i]->ghost[1] = (second ? slabs[i + 1]->send2 : slabs[i + 1]->send)[0];
+        slabs[i + 1]->ghost[0] = (second ? slabs[i]->send2 : slabs[i]->send)[1];
     }
     return IVX_OK;
 }
+// the buffers a slab packs its faces into for the step's first / second exchange
+uint8_t** pack_bufs(ivx_slab* sl, bool second) { return (second && sl->comm->rank < 0) ? sl->send2 : sl->send; }
 
 int all_gather(ivx_slab** slabs, size_t n, size_t words) {
     ivx_comm* c = slabs[0]->comm;
@@ -294,7 +305,7 @@ int all_gather(ivx_slab** slabs, size_t n, size_t words) {
 void install_ghosts(ivx_slab* sl) {
     for (int side = 0; side < 2; ++side) {
         const bool has = side ? sl->has_hi : sl->has_lo;
-        if (has) (void)ivx_halo_unpack_enqueue(sl->grid, side, sl->recv[side]);
+        if (has) (void)ivx_halo_unpack_enqueue(sl->grid, side, sl->ghost[side]);
         else (void)ivx_halo_clear(sl->grid, side);
     }
 }
@@ -524,6 +535,9 @@ int ivx_slab_create(ivx_comm* m, ivx_grid* g, int rank, ivx_slab** out) {
     for (int s = 0; s < 2; ++s) {
         ok = ok && hipMalloc(reinterpret_cast<void**>(&sl->send[s]), msg) == hipSuccess;
         ok = ok && hipMalloc(reinterpret_cast<void**>(&sl->recv[s]), msg) == hipSuccess;
+        sl->send2[s] = nullptr;
+        if (m->rank < 0) ok = ok && hipMalloc(reinterpret_cast<void**>(&sl->send2[s]), msg) == hipSuccess;
+        sl->ghost[s] = sl->recv[s];
     }
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl->record), sl->rec_words * 8) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&sl->gathered), sl->rec_words * 8 * (size_t)m->nranks) == hipSuccess;
@@ -575,6 +589,7 @@ void ivx_slab_destroy(ivx_slab* sl) {
     for (int s = 0; s < 2; ++s) {
         if (sl->send[s]) (void)hipFree(sl->send[s]);
         if (sl->recv[s]) (void)hipFree(sl->recv[s]);
+        if (sl->send2[s]) (void)hipFree(sl->send2[s]);
     }
     if (sl->record) (void)hipFree(sl->record);
     if (sl->gathered) (void)hipFree(sl->gathered);
@@ -606,7 +621,7 @@ int ivx_slabs_step_enqueue(ivx_slab** slabs, size_t n) {
         note(ivx_voxel_step_enqueue(sl->grid, IVX_STAGE_SAMPLE));
         if (sl->has_lo || sl->has_hi) note(ivx_halo_pack_both_enqueue(sl->grid, sl->has_lo ? sl->send[0] : nullptr, sl->has_hi ? sl->send[1] : nullptr, 0));
     }
-    if ((rc = exchange(slabs, n, slabs[0]->halo_bytes))) return rc;
+    if ((rc = exchange(slabs, n, slabs[0]->halo_bytes, false))) return rc;
     // 2. derived state + slab-local regions (+ moments and occupied ranges: they need nothing more from the neighbours); the planes
     // again, now with the post-demotion chunk kinds the mesher's upper-layer rule needs, and the faces' component ids behind them
     for (size_t i = 0; i < n; ++i) {
@@ -614,14 +629,15 @@ int ivx_slabs_step_enqueue(ivx_slab** slabs, size_t n) {
         install_ghosts(sl);
         ivx_step_preset_ahead(sl->grid, IVX_SCRATCH_SN);  // the remesh phase below has no first kernel to host its preset
         if (!local_err) note(ivx_voxel_step_enqueue(sl->grid, IVX_STAGE_DERIVE | IVX_STAGE_OCCUPIED | IVX_STAGE_REGIONS | IVX_STAGE_INERTIA));
-        if (sl->has_lo || sl->has_hi) note(ivx_halo_pack_both_enqueue(sl->grid, sl->has_lo ? sl->send[0] : nullptr, sl->has_hi ? sl->send[1] : nullptr, 1));
+        uint8_t** pb = pack_bufs(sl, true);
+        if (sl->has_lo || sl->has_hi) note(ivx_halo_pack_both_enqueue(sl->grid, sl->has_lo ? pb[0] : nullptr, sl->has_hi ? pb[1] : nullptr, 1));
     }
-    if ((rc = exchange(slabs, n, slabs[0]->halo_bytes + slabs[0]->face_bytes))) return rc;
+    if ((rc = exchange(slabs, n, slabs[0]->halo_bytes + slabs[0]->face_bytes, true))) return rc;
     // 3. remesh (ghost layers in place), the slab's record, the one small all-gather
     for (size_t i = 0; i < n; ++i) {
         ivx_slab* sl = slabs[i];
         install_ghosts(sl);
-        if (sl->has_hi && !local_err) note(ivx_region_face_pairs_enqueue(sl->grid, 1, sl->recv[1] + sl->halo_bytes));
+        if (sl->has_hi && !local_err) note(ivx_region_face_pairs_enqueue(sl->grid, 1, sl->ghost[1] + sl->halo_bytes));
         if (!local_err) note(ivx_voxel_step_enqueue(sl->grid, IVX_STAGE_REMESH));
         if (!local_err) note(ivx_step_record_enqueue(sl->grid, sl->record));
         if (local_err) {  // a record that says so (words 0, 1: no components, no pairs; word 17: the flags)
