@@ -141,7 +141,7 @@ EXPORTED_SYMBOLS = [
     "ivx_label_regions", "ivx_region_labels_download", "ivx_regions_describe", "ivx_split_off_smallest_region", "ivx_clip_polyhedron", "ivx_copy_polyhedra", "ivx_mesh_sync", "ivx_mesh_export", "ivx_mesh_generation", "ivx_mesh_import_open", "ivx_mesh_import_close", "ivx_mesh_modifications", "ivx_mesh_report_synchronized", "ivx_absorb_sphere", "ivx_absorb_capsule", "ivx_absorb_mutual", "ivx_offset_reference_point", "ivx_apply_updated_inertial_properties", "ivx_extracted_object_dynamics", "ivx_handle_voxel_object_after_removing_voxels", "ivx_sphere_voxel_object_contacts", "ivx_plane_voxel_object_contacts", "ivx_capsule_voxel_object_contacts", "ivx_collision_probes_recompute", "ivx_collision_probes_sync", "ivx_collision_probes_download", "ivx_mutual_voxel_object_contacts",
     "ivx_grid_set_sdf_program", "ivx_grid_set_densities", "ivx_voxel_step", "ivx_voxel_step_enqueue", "ivx_voxel_step_collect", "ivx_grid_set_stage_timing",
     "ivx_halo_pack_enqueue", "ivx_halo_unpack_enqueue", "ivx_halo_pack_both_enqueue", "ivx_region_face_labels_enqueue", "ivx_region_face_pairs_enqueue",
-    "ivx_step_record_words", "ivx_step_record_enqueue",
+    "ivx_step_record_words", "ivx_step_record_enqueue", "ivx_slab_remesh_enqueue",
     "ivx_halo_bytes", "ivx_halo_pack", "ivx_halo_unpack", "ivx_halo_clear",
     "ivx_region_face_bytes", "ivx_region_face_labels", "ivx_region_face_pairs",
     "ivx_world_create", "ivx_world_destroy", "ivx_world_set_bodies", "ivx_world_get_bodies", "ivx_world_set_contacts",
@@ -246,6 +246,7 @@ def lib():
         "ivx_region_face_pairs_enqueue": (i32, [vp, i32, vp]),
         "ivx_step_record_words": (sz, []),
         "ivx_step_record_enqueue": (i32, [vp, vp]),
+        "ivx_slab_remesh_enqueue": (i32, [vp, vp, vp]),
         "ivx_halo_bytes": (sz, [vp]),
         "ivx_halo_pack": (i32, [vp, i32, vp]),
         "ivx_halo_unpack": (i32, [vp, i32, vp]),

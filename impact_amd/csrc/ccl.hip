@@ -18,6 +18,7 @@
 // Traffic: level 1 reads 1 B/voxel (flags) and writes 1 B/voxel (label); level 2 reads only the six
 // face planes of labels per chunk.
 #include "ccl_roles.hpp"
+#include "table_roles.hpp"
 
 namespace {
 using namespace ivx_roles;
@@ -132,104 +133,22 @@ __global__ __launch_bounds__(256) void k_halo_pack_both(GridView g, uint8_t* __r
             (uint16_t)face_id16(g, side, col, tid, labels, rcompid, rscalar);
 }
 
-// The distinct (own component, neighbour's component) pairs across one x face. A workgroup takes FACE_COLS chunk columns — every thread the
-// same face voxel of each, the columns' three dependent loads (chunk kind, label, component id) side by side — and collects the pairs of small
-// ids (the usual case: a handful of components per slab) in a 64 x 64 bit table in LDS; one thread per table word then merges it into the
-// slab's table with one atomic and lists the pairs whose bit it set first. (One workgroup per column and one atomic per wave on the slab's
-// table was 16 us for a 32 x 32 face: a face inside one body is thousands of times the same pair, a thousand workgroups find the bit clear
-// at the same moment, and that many atomics on one word queue.)
-constexpr uint32_t FACE_COLS = 8;
+// (bodies: role_face_pairs / role_step_record in ccl_roles.hpp — the slab protocol's remesh phase hosts them in the step's fused launches)
 __global__ __launch_bounds__(256) void k_face_pairs(GridView g, uint32_t side, const uint8_t* __restrict__ labels,
                                                     const uint32_t* __restrict__ rcompid, const uint16_t* __restrict__ nbr,
                                                     uint32_t* __restrict__ n_pairs, uint2* __restrict__ pairs, uint32_t cap, uint32_t* __restrict__ seen) {
     __shared__ uint32_t s_seen[128];
-    const uint32_t tid = threadIdx.x, cols = g.cy * g.cz;
-    if (tid < 128u) s_seen[tid] = 0u;
-    uint32_t col[FACE_COLS], chunk[FACE_COLS], kind[FACE_COLS], l[FACE_COLS], a[FACE_COLS], b[FACE_COLS];
-#pragma unroll
-    for (uint32_t c = 0; c < FACE_COLS; ++c) {
-        col[c] = min(blockIdx.x * FACE_COLS + c, cols - 1u);  // (a column past the end repeats the last one's loads and lists nothing)
-        chunk[c] = (side ? g.cx - 1 : 0u) * cols + col[c];
-        kind[c] = g.info[chunk[c]].kind;
-    }
-#pragma unroll
-    for (uint32_t c = 0; c < FACE_COLS; ++c) {
-        l[c] = labels[(size_t)chunk[c] * IVX_CHUNK_VOXELS + ((side ? 15u : 0u) << 8) + tid];  // (the plane is there whatever the kind; only its content may be stale)
-        b[c] = nbr[(size_t)col[c] * 256 + tid];
-    }
-#pragma unroll
-    for (uint32_t c = 0; c < FACE_COLS; ++c) {
-        if (kind[c] != KIND_NONUNIFORM) l[c] = ivx_uniform_label(kind[c]);
-        a[c] = rcompid[chunk[c] * 256u + l[c]];
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t c = 0; c < FACE_COLS; ++c) {
-        const uint32_t ca = l[c] == 255u ? NODE_NONE : a[c], cb = b[c] == 0xFFFFu ? NODE_NONE : b[c];
-        const bool both = ca != NODE_NONE && cb != NODE_NONE && blockIdx.x * FACE_COLS + c < cols;
-        // drop repeats along the lane order (one wave = four rows of 16 face voxels)
-        const uint32_t pa = __shfl_up(ca, 1, 64), pb = __shfl_up(cb, 1, 64);
-        const bool dup = (tid & 63u) != 0 && pa == ca && pb == cb;
-        if (both && !dup) {
-            if (seen && ca < 64u && cb < 64u) {
-                const uint32_t bit = ca * 64u + cb;
-                if (!((__hip_atomic_load(&s_seen[bit >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> (bit & 31u)) & 1u)) atomicOr(&s_seen[bit >> 5], 1u << (bit & 31u));
-            } else {
-                const uint32_t slot = atomicAdd(n_pairs, 1u);
-                if (slot < cap) pairs[slot] = make_uint2(ca, cb);
-            }
-        }
-    }
-    __syncthreads();
-    if (tid < 128u && seen) {
-        const uint32_t mine = s_seen[tid];
-        if (mine) {
-            uint32_t fresh = mine & ~__hip_atomic_load(&seen[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (a look before the atomic)
-            if (fresh) fresh &= ~atomicOr(&seen[tid], fresh);
-            while (fresh) {
-                const uint32_t bit = tid * 32u + (uint32_t)(__ffs(fresh) - 1);
-                fresh &= fresh - 1u;
-                const uint32_t slot = atomicAdd(n_pairs, 1u);
-                if (slot < cap) pairs[slot] = make_uint2(bit >> 6, bit & 63u);
-            }
-        }
-    }
+    role_face_pairs(blockIdx.x, g, side, labels, rcompid, nbr, n_pairs, pairs, cap, seen, s_seen);
 }
 
-// Everything the other ranks need from this slab after a step, as one fixed-size record of 64-bit words written on the
-// device so that it can go straight into an all-gather (impact_amd/distributed.py): [0] components, [1] pairs across the
-// upper face, [2..14) occupied ranges (public layout, global coordinates), [14..17) mesh totals, [18..28) moments (f64
-// bit patterns), [28..28+2*max_pairs) the pairs.
 __global__ __launch_bounds__(256) void k_step_record(const uint32_t* __restrict__ rscalar, const uint32_t* __restrict__ pair_count,
                                                      const uint2* __restrict__ pairs, const uint32_t* __restrict__ mesh_totals,
                                                      const double* __restrict__ moments, uint32_t x_off, uint32_t max_pairs,
-                                                     unsigned long long* __restrict__ rec) {
-    const uint32_t tid = threadIdx.x;
-    const uint32_t np = pair_count ? min(pair_count[0], 0xFFFFFFFFu) : 0u;
-    if (tid == 0) {
-        rec[0] = rscalar[0];
-        rec[1] = np;  // may exceed max_pairs: the reader reports the overflow
-        const uint32_t* raw = rscalar + 16;
-        if (raw[6] == 0) {
-            for (int i = 0; i < 12; ++i) rec[2 + i] = 0;
-        } else {
-            for (int d = 0; d < 3; ++d) {
-                rec[2 + 2 * d] = raw[d] + (d == 0 ? x_off : 0u);
-                rec[3 + 2 * d] = raw[6 + d] + (d == 0 ? x_off : 0u);
-                rec[8 + 2 * d] = raw[3 + d] + (d == 0 ? x_off * 16u : 0u);
-                rec[9 + 2 * d] = raw[9 + d] + (d == 0 ? x_off * 16u : 0u);
-            }
-        }
-        rec[14] = mesh_totals[0];
-        rec[15] = mesh_totals[1];
-        rec[16] = mesh_totals[2];
-        rec[17] = rscalar[1];  // error flags
-    }
-    if (tid < 10) rec[18 + tid] = (unsigned long long)__double_as_longlong(moments[tid]);
-    for (uint32_t i = tid; i < min(np, max_pairs); i += 256u) {
-        rec[28 + 2 * i] = pairs[i].x;
-        rec[29 + 2 * i] = pairs[i].y;
-    }
+                                                     unsigned long long* __restrict__ rec, const uint32_t* __restrict__ work_count,
+                                                     const uint32_t* __restrict__ eval_count, uint32_t* __restrict__ host_block) {
+    role_step_record(rscalar, pair_count, pairs, mesh_totals, moments, x_off, max_pairs, rec);
+    // (with `host_block`: the step's small results where ivx_voxel_step_collect looks for them, so that it needs no launch of its own)
+    if (host_block && threadIdx.x < 64u) role_result_gather(rscalar, mesh_totals, moments, work_count, eval_count, host_block, false, 0u);
 }
 
 // ---- per-region statistics (what extract_disconnected_region needs to pick and size a fragment,
@@ -454,10 +373,11 @@ int ivx_launch_face_pairs(ivx_grid* g, int side, const uint16_t* d_nbr, uint32_t
     return IVX_OK;
 }
 
-int ivx_launch_step_record(ivx_grid* g, const uint32_t* d_pair_count, const void* d_pairs, uint32_t max_pairs, void* d_record) {
+int ivx_launch_step_record(ivx_grid* g, const uint32_t* d_pair_count, const void* d_pairs, uint32_t max_pairs, void* d_record, bool with_results) {
     hipLaunchKernelGGL(k_step_record, dim3(1), dim3(256), 0, g->ctx->stream, g->rscalar, d_pair_count, static_cast<const uint2*>(d_pairs),
                        g->chunk_offsets + 2 * (size_t)g->n_chunks, g->partials + g->partial_blocks * 10, g->x_off, max_pairs,
-                       static_cast<unsigned long long*>(d_record));
+                       static_cast<unsigned long long*>(d_record), ivx_wc(g), g->samp_len ? g->samp_len + g->n_chunks : nullptr,
+                       with_results ? g->result_host_dev : nullptr);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

@@ -275,4 +275,104 @@ __device__ __forceinline__ void role_ccl_assign(uint32_t bid, uint32_t nb, GridV
     }
 }
 
+// The distinct (own component, neighbour's component) pairs across one x face. A workgroup takes FACE_COLS chunk columns — every thread the
+// same face voxel of each, the columns' three dependent loads (chunk kind, label, component id) side by side — and collects the pairs of small
+// ids (the usual case: a handful of components per slab) in a 64 x 64 bit table in LDS; one thread per table word then merges it into the
+// slab's table with one atomic and lists the pairs whose bit it set first. (One workgroup per column and one atomic per wave on the slab's
+// table was 16 us for a 32 x 32 face: a face inside one body is thousands of times the same pair, a thousand workgroups find the bit clear
+// at the same moment, and that many atomics on one word queue.)
+// `bid`: the workgroup's index among the role's (FACE_COLS columns each); `s_seen`: 128 words of LDS the caller lends.
+constexpr uint32_t FACE_COLS = 8;
+__device__ __forceinline__ void role_face_pairs(uint32_t bid, const GridView& g, uint32_t side, const uint8_t* __restrict__ labels,
+                                                const uint32_t* __restrict__ rcompid, const uint16_t* __restrict__ nbr, uint32_t* __restrict__ n_pairs,
+                                                uint2* __restrict__ pairs, uint32_t cap, uint32_t* __restrict__ seen, uint32_t* s_seen) {
+    const uint32_t tid = threadIdx.x, cols = g.cy * g.cz;
+    if (tid < 128u) s_seen[tid] = 0u;
+    uint32_t col[FACE_COLS], chunk[FACE_COLS], kind[FACE_COLS], l[FACE_COLS], a[FACE_COLS], b[FACE_COLS];
+#pragma unroll
+    for (uint32_t c = 0; c < FACE_COLS; ++c) {
+        col[c] = min(bid * FACE_COLS + c, cols - 1u);  // (a column past the end repeats the last one's loads and lists nothing)
+        chunk[c] = (side ? g.cx - 1 : 0u) * cols + col[c];
+        kind[c] = g.info[chunk[c]].kind;
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < FACE_COLS; ++c) {
+        l[c] = labels[(size_t)chunk[c] * IVX_CHUNK_VOXELS + ((side ? 15u : 0u) << 8) + tid];  // (the plane is there whatever the kind; only its content may be stale)
+        b[c] = nbr[(size_t)col[c] * 256 + tid];
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < FACE_COLS; ++c) {
+        if (kind[c] != KIND_NONUNIFORM) l[c] = ivx_uniform_label(kind[c]);
+        a[c] = rcompid[chunk[c] * 256u + l[c]];
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t c = 0; c < FACE_COLS; ++c) {
+        const uint32_t ca = l[c] == 255u ? NODE_NONE : a[c], cb = b[c] == 0xFFFFu ? NODE_NONE : b[c];
+        const bool both = ca != NODE_NONE && cb != NODE_NONE && bid * FACE_COLS + c < cols;
+        // drop repeats along the lane order (one wave = four rows of 16 face voxels)
+        const uint32_t pa = __shfl_up(ca, 1, 64), pb = __shfl_up(cb, 1, 64);
+        const bool dup = (tid & 63u) != 0 && pa == ca && pb == cb;
+        if (both && !dup) {
+            if (seen && ca < 64u && cb < 64u) {
+                const uint32_t bit = ca * 64u + cb;
+                if (!((__hip_atomic_load(&s_seen[bit >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> (bit & 31u)) & 1u)) atomicOr(&s_seen[bit >> 5], 1u << (bit & 31u));
+            } else {
+                const uint32_t slot = atomicAdd(n_pairs, 1u);
+                if (slot < cap) pairs[slot] = make_uint2(ca, cb);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 128u && seen) {
+        const uint32_t mine = s_seen[tid];
+        if (mine) {
+            uint32_t fresh = mine & ~__hip_atomic_load(&seen[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (a look before the atomic)
+            if (fresh) fresh &= ~atomicOr(&seen[tid], fresh);
+            while (fresh) {
+                const uint32_t bit = tid * 32u + (uint32_t)(__ffs(fresh) - 1);
+                fresh &= fresh - 1u;
+                const uint32_t slot = atomicAdd(n_pairs, 1u);
+                if (slot < cap) pairs[slot] = make_uint2(bit >> 6, bit & 63u);
+            }
+        }
+    }
+}
+
+// Everything the other ranks need from this slab after a step, as one fixed-size record of 64-bit words written on the
+// device so that it can go straight into an all-gather (impact_amd/distributed.py): [0] components, [1] pairs across the
+// upper face, [2..14) occupied ranges (public layout, global coordinates), [14..17) mesh totals, [18..28) moments (f64
+// bit patterns), [28..28+2*max_pairs) the pairs.
+__device__ __forceinline__ void role_step_record(const uint32_t* __restrict__ rscalar, const uint32_t* __restrict__ pair_count,
+                                                 const uint2* __restrict__ pairs, const uint32_t* __restrict__ mesh_totals,
+                                                 const double* __restrict__ moments, uint32_t x_off, uint32_t max_pairs,
+                                                 unsigned long long* __restrict__ rec) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t np = pair_count ? min(pair_count[0], 0xFFFFFFFFu) : 0u;
+    if (tid == 0) {
+        rec[0] = rscalar[0];
+        rec[1] = np;  // may exceed max_pairs: the reader reports the overflow
+        const uint32_t* raw = rscalar + 16;
+        if (raw[6] == 0) {
+            for (int i = 0; i < 12; ++i) rec[2 + i] = 0;
+        } else {
+            for (int d = 0; d < 3; ++d) {
+                rec[2 + 2 * d] = raw[d] + (d == 0 ? x_off : 0u);
+                rec[3 + 2 * d] = raw[6 + d] + (d == 0 ? x_off : 0u);
+                rec[8 + 2 * d] = raw[3 + d] + (d == 0 ? x_off * 16u : 0u);
+                rec[9 + 2 * d] = raw[9 + d] + (d == 0 ? x_off * 16u : 0u);
+            }
+        }
+        rec[14] = mesh_totals[0];
+        rec[15] = mesh_totals[1];
+        rec[16] = mesh_totals[2];
+        rec[17] = rscalar[1];  // error flags
+    }
+    if (tid < 10) rec[18 + tid] = (unsigned long long)__double_as_longlong(moments[tid]);
+    for (uint32_t i = tid; i < min(np, max_pairs); i += 256u) {
+        rec[28 + 2 * i] = pairs[i].x;
+        rec[29 + 2 * i] = pairs[i].y;
+    }
+}
+
 }  // namespace ivx_roles

@@ -593,7 +593,10 @@ int ivx_launch_derive(ivx_grid* g, uint32_t parts, uint32_t preset_groups) {
     fz.multi_list = g->ccl_scratch;  // as ivx_launch_ccl_local
     fz.dens = g->dens_dev;
     fz.chunk_moments = g->chunk_moments;
-    if ((parts & IVX_PART_REGIONS) && !(preset_groups & IVX_SCRATCH_REGIONS)) IVX_HIP_CHECK(hipMemsetAsync(g->rscalar, 0, 16 * sizeof(uint32_t), g->ctx->stream));
+    // (the region scalars start from zero: preset by this launch's k_chunk_pre, or by the step's first kernel — the sampler's — in which case
+    // nothing has used them since; only a caller outside a step finds them dirty)
+    if ((parts & IVX_PART_REGIONS) && !(preset_groups & IVX_SCRATCH_REGIONS) && (g->scratch_dirty & IVX_SCRATCH_REGIONS))
+        IVX_HIP_CHECK(hipMemsetAsync(g->rscalar, 0, 16 * sizeof(uint32_t), g->ctx->stream));
     if (parts & IVX_PART_REGIONS) g->scratch_dirty |= IVX_SCRATCH_REGIONS;
     g->bbox_valid = 1;
     uint32_t* next_count = ivx_wc(g);  // the counter of the sweep before: zeroed by this one for the sweep after

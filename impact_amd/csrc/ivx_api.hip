@@ -2230,7 +2230,10 @@ int ivx_grid_set_densities(ivx_grid* g, const float densities[256]) {
 // numbering | occupied slots | moment partial sums), 3 k_step_post2 (multi-region merge | mesher scan | moments and occupied ranges
 // final), 4 k_step_emit (region forest flatten | mesher emit), 5 k_step_assign (component ids); 6..9 unused. Stage timing costs two
 // event records per slot on the stream; ivx_grid_set_stage_timing(g, 0) turns it off.
-int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
+static int ensure_pairs(ivx_grid* g);
+// `slab_nbr_ids` / `slab_record`: the slab protocol's remesh phase (ivx_slab_remesh_enqueue) — the pass over the neighbour's face ids and the
+// slab's record ride in the phase's own launches instead of taking two more
+static int step_enqueue(ivx_grid* g, uint32_t stages, const uint16_t* slab_nbr_ids, void* slab_record) {
     IVX_REQUIRE(g, IVX_ERR_INVALID, "ivx_voxel_step_enqueue: null grid");
     IVX_REQUIRE(!(stages & IVX_STAGE_SAMPLE) || g->prog_n > 0, IVX_ERR_STATE, "ivx_voxel_step: no SDF program resident (ivx_grid_set_sdf_program)");
     IVX_REQUIRE(!(stages & IVX_STAGE_INERTIA) || g->has_dens, IVX_ERR_STATE, "ivx_voxel_step: no densities resident (ivx_grid_set_densities)");
@@ -2322,14 +2325,20 @@ int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
         if ((rc = ivx_launch_step_post1(g, post))) return rc;
         T1(2);
         T0(3);
-        if ((rc = ivx_launch_step_post2(g, post))) return rc;
+        if (slab_record) {
+            if ((rc = ensure_pairs(g))) return rc;
+            if (slab_nbr_ids && !g->pairs_zeroed) IVX_HIP_CHECK(hipMemsetAsync(g->pairs_dev, 0, (4 + 128) * sizeof(uint32_t), s));
+            g->pairs_zeroed = 0;
+        }
+        if ((rc = ivx_launch_step_post2(g, post, slab_nbr_ids))) return rc;
         T1(3);
         // no host round trip for the mesh sizes: the emit pass writes into the buffers of the previous step and skips what
         // does not fit; ivx_voxel_step_collect grows the buffers and repeats the pass in that (rare) case
         if (post & (IVX_STAGE_REGIONS | IVX_STAGE_REMESH)) {
             T0(4);
             if (fused_assign) {
-                if ((rc = ivx_launch_step_emit(g, post, (post & IVX_STAGE_REGIONS) != 0))) return rc;
+                if ((rc = ivx_launch_step_emit(g, post, (post & IVX_STAGE_REGIONS) != 0, slab_record, slab_nbr_ids != nullptr))) return rc;
+                if (slab_record) g->results_in_block = 1;
             } else {  // more than 524 288 chunks: the region resolve takes its stand-alone path
                 if ((post & IVX_STAGE_REMESH) && (rc = ivx_launch_step_emit(g, IVX_STAGE_REMESH))) return rc;
                 if ((post & IVX_STAGE_REGIONS) && (rc = ivx_launch_ccl_resolve(g))) return rc;
@@ -2351,6 +2360,25 @@ int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) {
 #undef T1
     g->pending_stages |= stages;
     return IVX_OK;
+}
+
+int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) { return step_enqueue(g, stages, nullptr, nullptr); }
+
+// The remesh phase of the slab protocol in the step's own launches: count | — then scan | the component pairs across the upper x face (from
+// `neighbour_face_ids`, the ids behind the neighbour's face planes of the second exchange; null for the last slab) — then emit | the slab's
+// record into `device_record` and the step's small results into the grid's host-mapped block — then the mesher's general pass. Four launches
+// where face pairs, the remesh stage and the record took six; ivx_voxel_step_collect then has its results without a launch of its own (the
+// caller waits for the stream first: the slab protocol's doorbell).
+int ivx_slab_remesh_enqueue(ivx_grid* g, const void* neighbour_face_ids, void* device_record) {
+    IVX_REQUIRE(g && device_record, IVX_ERR_INVALID, "ivx_slab_remesh_enqueue: null argument");
+    if (!ivx_step_assign_fits(g)) {  // (grids beyond the fused launches' reach: the separate passes)
+        int rc;
+        if (neighbour_face_ids && (rc = ivx_region_face_pairs_enqueue(g, 1, neighbour_face_ids))) return rc;
+        if ((rc = step_enqueue(g, IVX_STAGE_REMESH, nullptr, nullptr))) return rc;
+        return ivx_step_record_enqueue(g, device_record);
+    }
+    g->pairs_enqueued = 0;
+    return step_enqueue(g, IVX_STAGE_REMESH, static_cast<const uint16_t*>(neighbour_face_ids), device_record);
 }
 
 int ivx_grid_set_stage_timing(ivx_grid* g, uint32_t slot_mask) {
@@ -2382,13 +2410,17 @@ int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out) {
         memset(g->result_host, 0, 64 * sizeof(uint32_t));
         IVX_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&g->result_host_dev), g->result_host, 0));
     }
-    {
+    const bool have_results = g->results_in_block != 0;  // (ivx_slab_remesh_enqueue: the block is written, the caller has waited for the stream)
+    g->results_in_block = 0;
+    if (!have_results) {
         int rc = ivx_launch_step_gather(g);
         if (rc) return rc;
+    } else if (hipStreamQuery(s) != hipSuccess) {
+        IVX_HIP_CHECK(hipStreamSynchronize(s));
     }
     // A short step is over before the runtime's blocking wait has gone to sleep and been woken again: poll the doorbell word the
     // gather kernel writes last (in-order stream: everything enqueued before it is complete too) for a bounded time first.
-    {
+    if (!have_results) {
         const volatile uint32_t* bell = g->result_host + 63;
         const uint32_t want = g->result_seq;
         const uint64_t budget_ns = collect_spin_ns();
@@ -2541,8 +2573,9 @@ int ivx_step_record_enqueue(ivx_grid* g, void* device_record) {
     IVX_REQUIRE(g && device_record, IVX_ERR_INVALID, "ivx_step_record_enqueue: null argument");
     int rc = ensure_pairs(g);
     if (rc) return rc;
-    if (!g->pairs_enqueued) IVX_HIP_CHECK(hipMemsetAsync(g->pairs_dev, 0, sizeof(uint32_t), g->ctx->stream));
-    rc = ivx_launch_step_record(g, g->pairs_dev, g->pairs_dev + 4 + 128, IVX_MAX_FACE_PAIRS, device_record);
+    // (no face-pair pass since the last record: the record lists none — a null count, not a fill of the counter)
+    rc = ivx_launch_step_record(g, g->pairs_enqueued ? g->pairs_dev : nullptr, g->pairs_dev + 4 + 128, IVX_MAX_FACE_PAIRS, device_record, g->result_host_dev != nullptr);
+    if (!rc && g->result_host_dev) g->results_in_block = 1;
     g->pairs_enqueued = 0;
     return rc;
 }

@@ -135,6 +135,7 @@ struct ivx_grid {
     uint32_t pending_stages;  // stages enqueued since the last collect
     uint32_t timed_mask;      // timed stages whose events were recorded since the last collect
     uint32_t* pairs_dev;      // [4 + 128 + 2 * IVX_MAX_FACE_PAIRS]: count, seen table, (own, neighbour) component pairs across the upper x face
+    int results_in_block;     // the step's small results are in the host-mapped block already (written by the slab record role): collect launches no gather
     int pairs_enqueued;
     int pairs_zeroed;         // the label pass of ivx_halo_pack_both_enqueue cleared count + seen table for the face-pair pass that follows
     // scratch groups a caller that knows its next call (the slab protocol) has preset one call ahead, by a kernel that is launched anyway
@@ -329,8 +330,8 @@ int ivx_launch_step_preset(ivx_grid* g, uint32_t groups);
 // scratch groups of the caller's NEXT ivx_voxel_step_enqueue, to be preset by the first kernel of the one before it (slab_comm.cpp)
 static inline void ivx_step_preset_ahead(ivx_grid* g, uint32_t groups) { g->preset_ahead |= groups; }
 int ivx_launch_step_post1(ivx_grid* g, uint32_t stages);
-int ivx_launch_step_post2(ivx_grid* g, uint32_t stages);
-int ivx_launch_step_emit(ivx_grid* g, uint32_t stages, bool general_in_assign = false);
+int ivx_launch_step_post2(ivx_grid* g, uint32_t stages, const uint16_t* face_pair_ids = nullptr);
+int ivx_launch_step_emit(ivx_grid* g, uint32_t stages, bool general_in_assign = false, void* slab_record = nullptr, bool record_has_pairs = false);
 int ivx_launch_step_assign(ivx_grid* g, bool with_mesher_general = false);
 int ivx_launch_step_gather(ivx_grid* g);
 bool ivx_step_assign_fits(const ivx_grid* g);
@@ -354,7 +355,7 @@ int ivx_launch_halo_pack(ivx_grid* g, int side, void* buf);
 int ivx_launch_halo_pack_both(ivx_grid* g, void* buf_lo, void* buf_hi, int with_face_labels);
 int ivx_launch_face_ids(ivx_grid* g, int side, uint16_t* d_out);
 int ivx_launch_face_pairs(ivx_grid* g, int side, const uint16_t* d_nbr, uint32_t* d_count, void* d_pairs, uint32_t cap, uint32_t* d_seen);
-int ivx_launch_step_record(ivx_grid* g, const uint32_t* d_pair_count, const void* d_pairs, uint32_t max_pairs, void* d_record);
+int ivx_launch_step_record(ivx_grid* g, const uint32_t* d_pair_count, const void* d_pairs, uint32_t max_pairs, void* d_record, bool with_results = false);
 int ivx_launch_split_move(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], const uint32_t cc[3], uint32_t target);
 int ivx_launch_clip(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], const uint32_t cc[3], const float* planes4, uint32_t n_planes, int extract);
 int ivx_launch_split_repack(ivx_grid* src, ivx_grid* dst, const uint32_t off[3]);

@@ -287,6 +287,7 @@ uint8_t** pack_bufs(ivx_slab* sl, bool second) { return (second && sl->comm->ran
 int all_gather(ivx_slab** slabs, size_t n, size_t words) {
     ivx_comm* c = slabs[0]->comm;
     hipStream_t s = c->ctx->stream;
+    if (c->nranks == 1) return IVX_OK;  // (the one record was written in place, ivx_slabs_step_enqueue)
     if (c->ipc) return ipc_all_gather(slabs[0], words);
     if (c->rank >= 0) {
         ivx_slab* sl = slabs[0];
@@ -615,6 +616,25 @@ int ivx_slabs_step_enqueue(ivx_slab** slabs, size_t n) {
     auto note = [&](int code) {
         if (code && !local_err) local_err = code;
     };
+    if (c->nranks == 1) {
+        // a world of one has nobody to wait for between the phases: the whole step as one enqueue, then the record (written where the gather would
+        // put it, with the step's small results on the way)
+        ivx_slab* sl = slabs[0];
+        (void)ivx_halo_clear(sl->grid, 0);
+        (void)ivx_halo_clear(sl->grid, 1);
+        note(ivx_voxel_step_enqueue(sl->grid, IVX_STAGE_SAMPLE | IVX_STAGE_DERIVE | IVX_STAGE_OCCUPIED | IVX_STAGE_REGIONS | IVX_STAGE_INERTIA | IVX_STAGE_REMESH));
+        if (!local_err) note(ivx_step_record_enqueue(sl->grid, sl->gathered));
+        if (local_err) {
+            unsigned long long head[18];
+            memset(head, 0, sizeof(head));
+            head[17] = 8ull;
+            IVX_HIP_CHECK(hipMemcpyAsync(sl->gathered, head, sizeof(head), hipMemcpyHostToDevice, c->ctx->stream));
+            IVX_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));  // (`head` is a local)
+        }
+        sl->local_err = local_err;
+        sl->enqueued = 1;
+        return IVX_OK;
+    }
     // 1. sample, exchange the face planes
     for (size_t i = 0; i < n; ++i) {
         ivx_slab* sl = slabs[i];
@@ -637,14 +657,15 @@ int ivx_slabs_step_enqueue(ivx_slab** slabs, size_t n) {
     for (size_t i = 0; i < n; ++i) {
         ivx_slab* sl = slabs[i];
         install_ghosts(sl);
-        if (sl->has_hi && !local_err) note(ivx_region_face_pairs_enqueue(sl->grid, 1, sl->ghost[1] + sl->halo_bytes));
-        if (!local_err) note(ivx_voxel_step_enqueue(sl->grid, IVX_STAGE_REMESH));
-        if (!local_err) note(ivx_step_record_enqueue(sl->grid, sl->record));
+        // (the pass over the neighbour's face ids and the record ride in the remesh stage's launches; a world of one writes its record where the
+        // gather would put it)
+        unsigned long long* rec = c->nranks == 1 ? sl->gathered : sl->record;
+        if (!local_err) note(ivx_slab_remesh_enqueue(sl->grid, sl->has_hi ? sl->ghost[1] + sl->halo_bytes : nullptr, rec));
         if (local_err) {  // a record that says so (words 0, 1: no components, no pairs; word 17: the flags)
             unsigned long long head[18];
             memset(head, 0, sizeof(head));
             head[17] = 8ull;
-            IVX_HIP_CHECK(hipMemcpyAsync(sl->record, head, sizeof(head), hipMemcpyHostToDevice, c->ctx->stream));
+            IVX_HIP_CHECK(hipMemcpyAsync(rec, head, sizeof(head), hipMemcpyHostToDevice, c->ctx->stream));
             IVX_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));  // (`head` is a local)
         }
         sl->local_err = local_err;

@@ -69,6 +69,15 @@ struct StepArgs {
     const uint32_t* eval_count;
     uint32_t count_run;       // k_step_post1: list entries per wave and turn of the mesher's count role
     uint32_t seq;             // k_step_gather: the step's sequence number, written last (the host's completion doorbell)
+    // slab protocol, remesh phase (ivx_slab_remesh_enqueue): the face-pair pass as a role of k_step_post2, the slab's record (and the step's
+    // results into the host-mapped block) as a role of k_step_emit
+    uint32_t fp_side, fp_cap;
+    const uint16_t* fp_nbr;
+    uint32_t* fp_count;  // (null for a slab without an upper neighbour: the record then lists no pairs)
+    uint2* fp_pairs;
+    uint32_t* fp_seen;
+    unsigned long long* record;
+    uint32_t record_max_pairs;
 };
 
 __device__ __forceinline__ sn::SnParams sn_params(const StepArgs& a) {
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 }
 
 // roles: 0 region merge of multi-region chunks, 1 mesher scan, 2 moments final (1 block), 3 occupied final (1 block),
-// 4 results (1 block; only when the call has no region stage: else k_step_assign gathers)
+// 4 the slab protocol's face pairs (component pairs across the upper x face, from the neighbour's ids of the exchange before)
 __global__ __launch_bounds__(256) void k_step_post2(StepArgs a) {
     uint32_t b = blockIdx.x;
     if (b < a.nb[0]) {
@@ -127,10 +136,18 @@ __global__ __launch_bounds__(256) void k_step_post2(StepArgs a) {
         return;
     }
     b -= a.nb[2];
-    if (b < a.nb[3]) role_occupied_final(a.n_occ_slots, a.occ_part, a.rscalar + 16);
+    if (b < a.nb[3]) {
+        role_occupied_final(a.n_occ_slots, a.occ_part, a.rscalar + 16);
+        return;
+    }
+    b -= a.nb[3];
+    if (b < a.nb[4]) {
+        __shared__ uint32_t s_seen[128];
+        role_face_pairs(b, a.g, a.fp_side, a.labels, a.rcompid, a.fp_nbr, a.fp_count, a.fp_pairs, a.fp_cap, a.fp_seen, s_seen);
+    }
 }
 
-// roles: 0 flatten the region forest, 1 mesher emit
+// roles: 0 flatten the region forest, 1 mesher emit, 2 the slab protocol's record
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_step_emit(StepArgs a) {
     uint32_t b = blockIdx.x;
     if (b < a.nb[0]) {
@@ -138,9 +155,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         return;
     }
     b -= a.nb[0];
-    if (b < a.nb[1])
+    if (b < a.nb[1]) {
         sn::role_sn_emit<false>(b, a.nb[1], sn_params(a), a.positions, a.normals, a.indices, a.imats, a.submeshes, a.offsets + 2 * (size_t)a.n_chunks + 2,
                                 a.emit_items, a.vcap, a.icap, a.scap, nullptr, a.hard_count, a.hard_list, a.hard_count + 32);
+        return;
+    }
+    b -= a.nb[1];
+    if (b < a.nb[2]) {  // (one block) the slab's record for the all-gather; the step's small results where ivx_voxel_step_collect looks for them
+        role_step_record(a.rscalar, a.fp_count, a.fp_pairs, a.offsets + 2 * (size_t)a.n_chunks, a.moments_out, a.x_off, a.record_max_pairs, a.record);
+        if (threadIdx.x < 64u) role_result_gather(a.rscalar, a.offsets + 2 * (size_t)a.n_chunks, a.moments_out, a.work_count, a.eval_count, a.host_block, false, 0u);
+    }
 }
 
 // roles: 0 component ids, 1 the mesher's general pass over the chunks the main pass (k_step_emit) handed on — the launch after the main pass
@@ -238,8 +262,22 @@ int ivx_launch_step_post1(ivx_grid* g, uint32_t stages) {
     return IVX_OK;
 }
 
-int ivx_launch_step_post2(ivx_grid* g, uint32_t stages) {
+// (slab protocol) the face-pair role's arguments: the neighbour's face ids, count + seen table + pair list in g->pairs_dev
+static void face_pair_args(StepArgs& a, ivx_grid* g, const uint16_t* nbr_ids) {
+    a.fp_side = 1u;
+    a.fp_cap = IVX_MAX_FACE_PAIRS;
+    a.fp_nbr = nbr_ids;
+    a.fp_count = nbr_ids ? g->pairs_dev : nullptr;
+    a.fp_seen = g->pairs_dev + 4;
+    a.fp_pairs = reinterpret_cast<uint2*>(g->pairs_dev + 4 + 128);
+}
+
+int ivx_launch_step_post2(ivx_grid* g, uint32_t stages, const uint16_t* face_pair_ids) {
     StepArgs a = make_args(g);
+    if (face_pair_ids) {
+        face_pair_args(a, g, face_pair_ids);
+        a.nb[4] = (g->cc[1] * g->cc[2] + FACE_COLS - 1u) / FACE_COLS;
+    }
     const uint32_t groups = (g->n_chunks + 255u) / 256u;
     if (stages & IVX_STAGE_REGIONS) a.nb[0] = g->n_chunks < 64u ? g->n_chunks : 64u;
     if (stages & IVX_STAGE_REMESH) a.nb[1] = groups;
@@ -248,18 +286,24 @@ int ivx_launch_step_post2(ivx_grid* g, uint32_t stages) {
         a.n_partials = groups < (uint32_t)g->partial_blocks ? groups : (uint32_t)g->partial_blocks;
     }
     if (stages & IVX_STAGE_OCCUPIED) a.nb[3] = 1;
-    const uint32_t total = a.nb[0] + a.nb[1] + a.nb[2] + a.nb[3];
+    const uint32_t total = a.nb[0] + a.nb[1] + a.nb[2] + a.nb[3] + a.nb[4];
     if (total == 0) return IVX_OK;
     hipLaunchKernelGGL(k_step_post2, dim3(total), dim3(256), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 
-int ivx_launch_step_emit(ivx_grid* g, uint32_t stages, bool general_in_assign) {
+int ivx_launch_step_emit(ivx_grid* g, uint32_t stages, bool general_in_assign, void* slab_record, bool record_has_pairs) {
     StepArgs a = make_args(g);
     if (stages & IVX_STAGE_REGIONS) a.nb[0] = (g->n_chunks + 255u) / 256u;
     if (stages & IVX_STAGE_REMESH) a.nb[1] = sn::ivx_emit_grid(g, g->n_chunks);
-    const uint32_t total = a.nb[0] + a.nb[1];
+    if (slab_record) {
+        face_pair_args(a, g, record_has_pairs ? reinterpret_cast<const uint16_t*>(g->pairs_dev) /* (any non-null value: only the count pointer matters) */ : nullptr);
+        a.record = static_cast<unsigned long long*>(slab_record);
+        a.record_max_pairs = IVX_MAX_FACE_PAIRS;
+        a.nb[2] = 1;
+    }
+    const uint32_t total = a.nb[0] + a.nb[1] + a.nb[2];
     if (total == 0) return IVX_OK;
     hipLaunchKernelGGL(k_step_emit, dim3(total), dim3(256), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());

@@ -343,6 +343,11 @@ int ivx_region_face_labels_enqueue(ivx_grid*, int side, void* device_buf);
 int ivx_region_face_pairs_enqueue(ivx_grid*, int side, const void* neighbour_face_labels_device);
 size_t ivx_step_record_words(void);
 int ivx_step_record_enqueue(ivx_grid*, void* device_record);
+/* The three calls a slab's last phase makes — the pairs across its upper face (from the neighbour's face ids; null: no upper neighbour),
+ * ivx_voxel_step_enqueue(IVX_STAGE_REMESH), the record — in the remesh stage's own four launches. The step's small results land in the
+ * grid's host-mapped block on the way: once the stream is idle (the protocol's doorbell) ivx_voxel_step_collect returns them without a
+ * launch of its own. (What ivx_slabs_step_enqueue calls) */
+int ivx_slab_remesh_enqueue(ivx_grid*, const void* neighbour_face_ids_device, void* device_record);
 
 /* ---- a13 / §8f-3: from an impact to fragment plane sets (host code: a few hundred points per impact) ------------------------------------
  * generate_impact_fracture_points (impact_voxel/src/interaction/fracturing.rs:1710-2015), DelaunayTetrahedralization
