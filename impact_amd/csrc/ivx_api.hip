@@ -361,6 +361,7 @@ int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32
     ivx_grid* g = new (std::nothrow) ivx_grid();
     IVX_REQUIRE(g, IVX_ERR_CAPACITY, "ivx_grid_create: out of host memory");
     memset(g, 0, sizeof(*g));
+    g->scratch_dirty = IVX_SCRATCH_REGIONS;  // (the pool is not cleared: the region scalars' first user outside a step must zero them, ivx_launch_derive)
     g->ctx = c;
     for (int d = 0; d < 3; ++d) g->cc[d] = cc[d];
     g->n_chunks = (uint32_t)n64;
