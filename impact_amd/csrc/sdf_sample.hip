@@ -603,9 +603,11 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
                     }
                 }
                 emit(((must_apply ? OP_COMBINE : OP_COMBINE_OUTSIDE) << 28) | (kind << 24) | n, 0u);
-                {  // the first operand keeps its level (if it has one) while the second is evaluated; the result needs one
+                {  // the first operand keeps its level (if it has one) while the second is evaluated; the result needs one — unless the second
+                    // is one bare leaf and the combination unconditional: the evaluator then combines it from registers (eval_leaf_fused)
                     const uint32_t n1 = s_need[top - 1][tid], n2 = s_need[top][tid];
-                    const uint32_t nn = max(max(n1, (c1 ? 0u : 1u) + n2), 1u);
+                    const bool fused = must_apply && !c2 && pos == (uint32_t)s_start[top][tid] + 2u;  // (pos: behind the combination just emitted)
+                    const uint32_t nn = fused ? max(n1, 1u) : max(max(n1, (c1 ? 0u : 1u) + n2), 1u);
                     s_need[top - 1][tid] = (uint8_t)nn;
                 }
                 float rlo, rhi;
@@ -669,15 +671,15 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
     static_assert(PRE_T == 64, "the list appends below assume one wave (the first of the block) doing them");
     {
         // Evaluation lists by the number of LDS levels the chunk's compact program needs (k_sdf_eval gets one launch per
-        // class, with that much LDS: residency, hence throughput, is set by LDS): class 0: <= 2 levels, 1: 3, 2: more (and
-        // the chunks whose program did not fit OP_CAP, which run the full program).
+        // class, with that much LDS: residency, hence throughput, is set by LDS): class 0: one level, 1: two (and the chunks whose
+        // program did not fit OP_CAP, which run the full program, when that fits two), 2: more.
         // A constant chunk that still has planes to write (neither Void nor Uniform, or straddling the generator's grid) is
         // evaluated like the others: its compact program is the one folded constant (or, for the saturated-bound case, the
         // per-voxel program, which saturates to the same bytes) and the evaluator's store path handles the grid edge.
         const unsigned long long below = (1ull << tid) - 1ull;
         const bool ev = mine && (out != out || to_fill);
-        const uint32_t need = pos <= OP_CAP ? (uint32_t)s_need[0][tid] : p.stack_size;  // (the full program may use every level)
-        const uint32_t cls = need <= 2u ? 0u : (need == 3u ? 1u : 2u);
+        const uint32_t need = pos <= OP_CAP ? (uint32_t)s_need[0][tid] : max(p.stack_size, 2u);  // (the full program may use every level, unfused)
+        const uint32_t cls = need <= 1u ? 0u : (need == 2u ? 1u : 2u);
         // The first class (nearly every chunk of a smooth body) is listed longest program first: programs of more than LONG_OPS steps from
         // the front of its list, the others from the back. Workgroups start in list order, so the evaluator's last workgroups are short
         // ones and its tail — a tenth of the kernel with the chunks in arbitrary order — shrinks. Counters: [c] = entries of class c,
@@ -782,9 +784,6 @@ __device__ __forceinline__ void eval_leaf(const ivx_sdf_processed_node* nd, uint
     }
 }
 
-// Combination of levels top-1 and top (after the caller decremented `top`). `outside` = the node's
-// domain lies outside the block, so the reference applies it only if one of the 14 distinct block test
-// positions fails `value >= margin` (atomic.rs:788-806, 1661-1797).
 // index of the LDS level that holds stack level `level`: the number of per-voxel (non-constant) levels below it
 __device__ __forceinline__ uint32_t lds_level(uint32_t cmask, uint32_t level) { return __popc(~cmask & ((1u << level) - 1u)); }
 
@@ -792,6 +791,149 @@ __device__ __forceinline__ uint32_t lds_level(uint32_t cmask, uint32_t level) { 
 __device__ __forceinline__ float cv_get(float cv, uint32_t level) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(cv), (int)level)); }
 __device__ __forceinline__ void cv_set(float& cv, uint32_t level, float x) { cv = (threadIdx.x & 63u) == level ? x : cv; }
 
+// ---- a leaf combined straight into the level below it ------------------------------------------------------------------------------
+// Most combinations take a bare leaf as their second operand (three out of four on the 512^3 asteroid, all on the plates): written to an LDS
+// level of its own only to be read back by the next step. Evaluated into registers and combined on the spot, eight voxels of the column at a
+// time, the leaf needs no level — many programs then fit ONE 16 KB level, which is what decides how many workgroups a CU holds
+// (k_sdf_eval<2>) — and the program runs one step less: the evaluator's scalar bookkeeping per step weighs as much as its vector arithmetic
+// (SQ_INSTS_SALU: one scalar instruction per two vector ones, and a CU issues one scalar instruction per cycle). Same arithmetic per voxel,
+// in the same order; only combinations that are applied unconditionally (OP_COMBINE) are fused — one behind the 14-position test needs
+// its operand's values before it knows whether to apply. (Keeping the leaf's sixteen values in registers ACROSS steps, so that combinations
+// with constants could be folded in as well, was tried: every program fitted one level then, but the copies and flags it took cost more
+// vector and scalar instructions than the levels it saved.)
+struct LeafRun {  // a leaf's evaluation along a thread's column, resumable
+    uint32_t kind;
+    bool zonly;
+    V3 pos, dz;
+    float c0, c1, c2;  // zonly: [kind 0/1] x^2 + y'^2, radius; [kind 2] px^2 + py^2, max(qx, qy), half extent z — else the node's a, b, c
+};
+__device__ __forceinline__ LeafRun leaf_begin(const ivx_sdf_processed_node* nd, uint32_t kind, V3 origin_root, uint32_t ti, uint32_t tj) {
+    const float* m = nd->transform;
+    const V3 origin = xform_point(m, origin_root);
+    const V3 dx = mk(m[0], m[1], m[2]), dy = mk(m[4], m[5], m[6]);
+    LeafRun r;
+    r.kind = kind;
+    r.dz = mk(m[8], m[9], m[10]);
+    const V3 opx = add(origin, scale(dx, (float)ti));
+    r.pos = add(opx, scale(dy, (float)tj));
+    r.zonly = r.dz.x == 0.0f && r.dz.y == 0.0f;
+    const float pa = nd->a, pb = nd->b, pc = nd->c;
+    r.c0 = pa, r.c1 = pb, r.c2 = pc;
+    if (r.zonly) {  // (eval_leaf's column constants)
+        if (kind == 2u) {
+            const float qx = fabsf(r.pos.x) - pa, qy = fabsf(r.pos.y) - pb;
+            const float px = max_rs(qx, 0.0f), py = max_rs(qy, 0.0f);
+            r.c0 = px * px + py * py, r.c1 = max_rs(qx, qy), r.c2 = pc;
+        } else {
+            float y = r.pos.y, rad = pa;
+            if (kind == 1u) {
+                float c = y;
+                if (c < -pa) c = -pa;
+                if (c > pa) c = pa;
+                y -= c;
+                rad = pb;
+            }
+            r.c0 = r.pos.x * r.pos.x + y * y, r.c1 = rad;
+        }
+    }
+    return r;
+}
+// the next eight voxels of the column
+__device__ __forceinline__ void leaf_next8(LeafRun& r, float* v) {
+    if (r.zonly) {
+        float z = r.pos.z;
+        if (r.kind == 2u) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float qz = fabsf(z) - r.c2, pz = max_rs(qz, 0.0f);
+                v[k] = sqrt_rn(r.c0 + pz * pz) + min_rs(max_rs(r.c1, qz), 0.0f);
+                z += r.dz.z;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                v[k] = sqrt_rn(r.c0 + z * z) - r.c1;
+                z += r.dz.z;
+            }
+        }
+        r.pos.z = z;
+        return;
+    }
+    V3 pos = r.pos;
+    if (r.kind == 0u) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = len3(pos) - r.c0;
+            pos = add(pos, r.dz);
+        }
+    } else if (r.kind == 1u) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            V3 q = pos;
+            float c = q.y;
+            if (c < -r.c0) c = -r.c0;
+            if (c > r.c0) c = r.c0;
+            q.y -= c;
+            v[k] = len3(q) - r.c1;
+            pos = add(pos, r.dz);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            V3 q = mk(fabsf(pos.x) - r.c0, fabsf(pos.y) - r.c1, fabsf(pos.z) - r.c2);
+            V3 qp = mk(max_rs(q.x, 0.0f), max_rs(q.y, 0.0f), max_rs(q.z, 0.0f));
+            v[k] = len3(qp) + min_rs(max_rs(max_rs(q.x, q.y), q.z), 0.0f);
+            pos = add(pos, r.dz);
+        }
+    }
+    r.pos = pos;
+}
+// eight voxels (rows 8 h .. 8 h + 7 of the column at d) of `first operand (combination) leaf`: the first operand the constant v1 (`c1`) or the
+// level at d, the result to d. `t15`: the level keeps its row 15 in the register r15 (IVX_LV_GET).
+template <int KIND, bool SMOOTH>
+__device__ __forceinline__ void fused_rows8(float* d, int h, bool t15, float& r15, bool c1, float v1, const float* v, float s, float q) {
+    float* dd = d + h * (8 * 256);
+    if (c1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float res = combine_t<KIND, SMOOTH>(v1, v[k], s, q);
+            if (k == 7 && h == 1 && t15) r15 = res;
+            else dd[k * 256] = res;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float a = (k == 7 && h == 1 && t15) ? r15 : dd[k * 256];
+            const float res = combine_t<KIND, SMOOTH>(a, v[k], s, q);
+            if (k == 7 && h == 1 && t15) r15 = res;
+            else dd[k * 256] = res;
+        }
+    }
+}
+__device__ __forceinline__ void eval_leaf_fused(const ivx_sdf_processed_node* nd, uint32_t leaf_kind, uint32_t kind, float s, float q, bool c1, float v1, float* d,
+                                                bool t15, float& r15, V3 origin_root, uint32_t ti, uint32_t tj) {
+    LeafRun run = leaf_begin(nd, leaf_kind, origin_root, ti, tj);
+    const bool smooth = s != 0.0f;
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        float v[8];
+        leaf_next8(run, v);
+        if (kind == 7u) {
+            if (smooth) fused_rows8<7, true>(d, h, t15, r15, c1, v1, v, s, q);
+            else fused_rows8<7, false>(d, h, t15, r15, c1, v1, v, s, q);
+        } else if (kind == 8u) {
+            if (smooth) fused_rows8<8, true>(d, h, t15, r15, c1, v1, v, s, q);
+            else fused_rows8<8, false>(d, h, t15, r15, c1, v1, v, s, q);
+        } else {
+            if (smooth) fused_rows8<9, true>(d, h, t15, r15, c1, v1, v, s, q);
+            else fused_rows8<9, false>(d, h, t15, r15, c1, v1, v, s, q);
+        }
+    }
+}
+
+// Combination of levels top-1 and top (after the caller decremented `top`). `outside` = the node's
+// domain lies outside the block, so the reference applies it only if one of the 14 distinct block test
+// positions fails `value >= margin` (atomic.rs:788-806, 1661-1797).
 template <bool TRIM>
 __device__ __forceinline__ void combine_levels(uint32_t kind, float s, float q, float margin, bool outside, uint32_t top, float* stack,
                                                float& cv, uint32_t& cmask, uint32_t tid, float& r15, float* s_pub) {
@@ -853,22 +995,30 @@ __device__ __forceinline__ void combine_levels(uint32_t kind, float s, float q, 
 
 // TRIM: the two-level class, with row 15 of the second dense level in registers (IVX_LV_GET); `scratch_off`: offset (floats) of sixteen
 // words of LDS behind / at the tail of the stack: [0..5) the published test voxels of a register row, [8..12) the classification's votes
-template <bool TRIM>
+// MODE 2: the one-level class (programs whose only operands with a level of their own are fused away, see eval_leaf_fused): 16 KB + the
+// scratch words, eight workgroups per CU.
+template <int MODE>
 __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t* __restrict__ eval_count, const uint32_t* __restrict__ eval_list,
-                                                  const uint32_t* __restrict__ long_count, uint32_t list_len, uint32_t scratch_off,
+                                                  const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ first_count,
+                                                  const uint32_t* __restrict__ first_list, uint32_t list_len, uint32_t scratch_off,
                                                   const uint32_t* __restrict__ prog_len, const uint2* __restrict__ prog_ops,
                                                   const ivx_sdf_processed_node* __restrict__ nodes, int8_t* __restrict__ sdf_out,
                                                   uint8_t* __restrict__ type_out, ivx_chunk_info* __restrict__ info_out) {
     extern __shared__ float stack[];  // [stack_size][16][256]
+    constexpr bool TRIM = MODE == 1;
     const uint32_t tid = threadIdx.x;
     const uint32_t ti = tid >> 4, tj = tid & 15u;
-    const uint32_t n_eval = eval_count[0];
-    const uint32_t n_long = long_count ? long_count[0] : n_eval;  // (a list with a long / short split keeps its short entries at the back)
+    // (`first_list`: a second list walked ahead of the launch's own — the host merges two classes into one launch when one of them is too
+    // short to fill the chip on its own, see ivx_launch_sdf_sample)
+    const uint32_t n_first = first_count ? first_count[0] : 0u;
+    const uint32_t n_eval = n_first + eval_count[0];
+    const uint32_t n_long = long_count ? long_count[0] : eval_count[0];  // (a list with a long / short split keeps its short entries at the back)
     // bounded grid-stride walk over the list of chunks to evaluate
     for (uint32_t li = blockIdx.x; li < n_eval; li += gridDim.x) {
     __syncthreads();  // the previous chunk's LDS use is over
     IVX_TE(p, li, 0);
-    const uint32_t chunk = eval_list[li < n_long ? li : list_len - 1u - (li - n_long)];
+    const uint32_t lj = li - n_first;
+    const uint32_t chunk = li < n_first ? first_list[li] : eval_list[lj < n_long ? lj : list_len - 1u - (lj - n_long)];
     const uint32_t ck = chunk % p.cz, cj = (chunk / p.cz) % p.cy, ci = chunk / (p.cz * p.cy);
     const uint32_t oi = (ci + p.x_off) * 16u, oj = cj * 16u, ok = ck * 16u;
     int sd[16];
@@ -934,12 +1084,38 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
                 cmask |= 1u << top;
                 top += 1;
             } else if (opc == OP_LEAF) {
-                cmask &= ~(1u << top);
-                {
-                    const uint32_t dl = lds_level(cmask, top);
-                    eval_leaf(nodes + (w & 0xFFFFFFu), kind, stack + (size_t)dl * IVX_CHUNK_VOXELS + tid, TRIM && dl == 1u, r15, origin_root, ti, tj);
+                // a leaf that the next step combines unconditionally with the level below is combined from registers (eval_leaf_fused; the
+                // pre-pass counted the chunk's levels on the same rule)
+                uint32_t wn = 0u;
+                float sn = 0.0f, qn = 0.0f;
+                if (i + 1u < len) {
+                    const uint32_t l1 = (i + 1u) & 63u;
+                    if (i + 1u < 64u) {
+                        wn = __builtin_amdgcn_readlane(my_w[0], l1);
+                        sn = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s[0]), l1));
+                        qn = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_q[0]), l1));
+                    } else {
+                        wn = __builtin_amdgcn_readlane(my_w[1], l1);
+                        sn = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s[1]), l1));
+                        qn = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_q[1]), l1));
+                    }
                 }
-                top += 1;
+                if ((wn >> 28) == OP_COMBINE && top >= 1u) {
+                    const bool c1 = (cmask >> (top - 1)) & 1u;
+                    const float v1 = c1 ? cv_get(cv, top - 1) : 0.0f;
+                    cmask &= ~(1u << (top - 1));  // the result is per voxel, in the first operand's place
+                    const uint32_t dl = lds_level(cmask, top - 1);
+                    eval_leaf_fused(nodes + (w & 0xFFFFFFu), kind, (wn >> 24) & 15u, sn, qn, c1, v1, stack + (size_t)dl * IVX_CHUNK_VOXELS + tid, TRIM && dl == 1u, r15,
+                                    origin_root, ti, tj);
+                    i += 1u;  // (the combination is done)
+                } else {
+                    cmask &= ~(1u << top);
+                    {
+                        const uint32_t dl = lds_level(cmask, top);
+                        eval_leaf(nodes + (w & 0xFFFFFFu), kind, stack + (size_t)dl * IVX_CHUNK_VOXELS + tid, TRIM && dl == 1u, r15, origin_root, ti, tj);
+                    }
+                    top += 1;
+                }
             } else if (opc == OP_SCALE) {
                 // Levels the pre-pass KNEW to be constant were folded there. A level can still be a constant here: an
                 // OP_COMBINE_OUTSIDE over (constant, per-voxel) that the 14 test positions decide not to apply leaves its
@@ -1075,7 +1251,7 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
     p.voxel_type = voxel_type;
     size_t lds = (size_t)(stack_size ? stack_size : 1) * IVX_CHUNK_VOXELS * sizeof(float);
     IVX_REQUIRE(lds <= 150 * 1024, IVX_ERR_CAPACITY, "SDF graph needs a forward stack of %u blocks (at most 9 fit the 160 KiB LDS)", stack_size);
-    IVX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sdf_eval<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    IVX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sdf_eval<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     float* chunk_const = reinterpret_cast<float*>(g->chunk_bbox);  // scratch: rewritten by ivx_derive_state afterwards
     {
         int rc_b = ivx_sampler_buffers(g);
@@ -1115,28 +1291,39 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
                        g->n_chunks, g->info, g->samp_super, super_skip, words, sy, sz, fused_super ? 1u : 0u, ivx_preset_args(g, prepass_presets));
     g->planes_compact = 1;
     {
-        // one launch per LDS class (see k_sdf_prepass); a class the program cannot reach is not launched
+        // One launch per LDS class (see k_sdf_prepass); a class the program cannot reach is not launched, nor one whose list the last step
+        // under this program found empty (the lists are a function of the program and the grid). Two launches one after the other each pay
+        // their own ramp and tail: when both of the first two classes have work and one of them is too short to fill the chip a few times
+        // over, the two-level kernel takes both lists in one launch (the one-level programs run there as well, five workgroups per CU).
         const uint32_t eval_blocks = g->n_chunks < 4096u ? g->n_chunks : 4096u;
-        const uint32_t levels[3] = {stack_size < 2u ? stack_size : 2u, 3u, stack_size};
-        for (uint32_t c = 0; c < 3; ++c) {
-            if (c > 0 && stack_size < levels[c]) break;
-            if (c == 2 && stack_size == 3u) break;
-            // (nor a class whose list the last step under this program found empty: the lists are a function of the program and the grid)
-            if (c > 0 && g->eval_len_valid && g->eval_len[c] == 0u) continue;
-            const uint32_t lv = levels[c] ? levels[c] : 1u;
-            if (c == 0 && lv == 2u) {
-                // two levels, the second one 15 rows long + 64 words of scratch: 32 000 bytes = 25 LDS granules, five workgroups per CU
-                const uint32_t scratch_off = IVX_CHUNK_VOXELS + 15u * 256u;
-                hipLaunchKernelGGL(k_sdf_eval<true>, dim3(eval_blocks), dim3(256), (size_t)(scratch_off + 64u) * sizeof(float), g->ctx->stream, p, eval_count + c,
-                                   eval_list + (size_t)c * g->n_chunks, eval_count + 3, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info);
-            } else {
-                // (the scratch words are the last sixteen of the stack: rows 15 of the last level's threads 240..255, dead when they are used
-                // — the votes — and never used as published test voxels, which only the trimmed launch has)
-                const uint32_t scratch_off = lv * IVX_CHUNK_VOXELS - 16u;
-                hipLaunchKernelGGL(k_sdf_eval<false>, dim3(eval_blocks), dim3(256), (size_t)lv * IVX_CHUNK_VOXELS * sizeof(float), g->ctx->stream, p, eval_count + c,
-                                   eval_list + (size_t)c * g->n_chunks, c == 0 ? eval_count + 3 : nullptr, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf,
-                                   g->type, g->info);
-            }
+        const bool known = g->eval_len_valid != 0;
+        const uint32_t fill = 4u * 5u * (uint32_t)g->ctx->n_cu;
+        const bool merge01 = known && g->eval_len[0] && g->eval_len[1] && (g->eval_len[0] < fill || g->eval_len[1] < fill);
+        uint32_t* const list0 = eval_list;
+        uint32_t* const list1 = eval_list + (size_t)g->n_chunks;
+        if (!merge01 && !(known && g->eval_len[0] == 0u)) {
+            // one level + 64 words of scratch: 16 640 bytes = 13 LDS granules, eight workgroups per CU (the waves a SIMD holds)
+            const uint32_t scratch_off = IVX_CHUNK_VOXELS;
+            hipLaunchKernelGGL(k_sdf_eval<2>, dim3(eval_blocks), dim3(256), (size_t)(scratch_off + 64u) * sizeof(float), g->ctx->stream, p, eval_count + 0, list0,
+                               eval_count + 3, nullptr, nullptr, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info);
+        }
+        if (merge01 || !(known && g->eval_len[1] == 0u)) {
+            // two levels, the second one 15 rows long + 64 words of scratch: 32 000 bytes = 25 LDS granules, five workgroups per CU
+            const uint32_t scratch_off = IVX_CHUNK_VOXELS + 15u * 256u;
+            if (merge01)
+                hipLaunchKernelGGL(k_sdf_eval<1>, dim3(eval_blocks), dim3(256), (size_t)(scratch_off + 64u) * sizeof(float), g->ctx->stream, p, eval_count + 0, list0,
+                                   eval_count + 3, eval_count + 1, list1, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info);
+            else
+                hipLaunchKernelGGL(k_sdf_eval<1>, dim3(eval_blocks), dim3(256), (size_t)(scratch_off + 64u) * sizeof(float), g->ctx->stream, p, eval_count + 1, list1,
+                                   nullptr, nullptr, nullptr, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info);
+        }
+        if (stack_size >= 3u && !(known && g->eval_len[2] == 0u)) {
+            // (the scratch words are the last sixteen of the stack: rows 15 of the last level's threads 240..255, dead when they are used
+            // — the votes — and never used as published test voxels, which only the trimmed launch has)
+            const uint32_t lv = stack_size;
+            const uint32_t scratch_off = lv * IVX_CHUNK_VOXELS - 16u;
+            hipLaunchKernelGGL(k_sdf_eval<0>, dim3(eval_blocks), dim3(256), (size_t)lv * IVX_CHUNK_VOXELS * sizeof(float), g->ctx->stream, p, eval_count + 2,
+                               eval_list + 2 * (size_t)g->n_chunks, nullptr, nullptr, nullptr, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info);
         }
     }
     IVX_HIP_CHECK(hipGetLastError());
