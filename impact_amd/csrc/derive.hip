@@ -23,9 +23,6 @@
 
 namespace {
 
-#ifndef IVX_DERIVE_WG_PER_CU
-#define IVX_DERIVE_WG_PER_CU 4u  // resident workgroups per CU of the pipelined form (its registers: 119)
-#endif
 struct DeriveParams {
     uint32_t cx, cy, cz;
 };
@@ -179,12 +176,11 @@ struct DeriveFused {
     double* chunk_moments;
 };
 
-// Two forms. PIPE = false: about one workgroup per listed chunk, seven resident per CU (what the 20 KB of LDS allow; the register budget is
-// set to match): the hardware overlaps the chunks' dependent phases. PIPE = true, for long lists: a resident set of four workgroups per CU,
-// each walking its share of the list with the next chunk's loads in flight (119 registers) — 4 % faster on the all-surface 512^3 grid, slower
-// on short lists, where the shares are a handful of chunks.
-template <bool PIPE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE ? 4 : 7, 8))) void k_derive(GridView g, int8_t* __restrict__ sdf_rw, uint8_t* __restrict__ type_rw, uint8_t* __restrict__ flags_out,
+// (amdgpu_waves_per_eu(7): seven workgroups per CU is what the 20 KB of LDS allow; the workgroups are latency-bound, so residency is
+// throughput, and the register budget is set to match. A software pipeline over a resident set of workgroups — the next chunk's loads in
+// flight across the region and moment passes, as the mesher does — was tried: its 119 registers leave four workgroups per CU, and four
+// pipelined ones were no faster than seven plain ones; what did help is the grid's size, see ivx_launch_derive.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_derive(GridView g, int8_t* __restrict__ sdf_rw, uint8_t* __restrict__ type_rw, uint8_t* __restrict__ flags_out,
                                                 ivx_chunk_info* __restrict__ info, uint32_t* __restrict__ bbox, uint8_t* __restrict__ touch,
                                                 uint16_t* __restrict__ signs, uint8_t* __restrict__ kface_out,
                                                 const uint32_t* __restrict__ work_counts, uint32_t* __restrict__ active_list,
@@ -201,26 +197,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE ? 4 : 
     if (fz.parts & IVX_PART_MOMENTS) s_dens[tid] = fz.dens[tid], s_mtab[tid] = moments_table_entry(tid);  // (the first barrier of the loop publishes them)
     const int ti = tid >> 4, tj = tid & 15;
     const uint32_t n_active = work_counts[0];
-    // Bounded walk over the active list (virtual block ids give each XCD a contiguous stretch of it), one chunk ahead: the loads of a
-    // chunk's first phase — 4.5 of a workgroup's 11 us per chunk when they were taken at the start of the chunk, and the kernel is bound by
-    // what its resident workgroups wait for — go out at the top of the round BEFORE, travel while that round's chunk is swept, and are
-    // first touched a round later (the mesher's tile prefetch, sn_roles.hpp tile_issue). The list entry is read two rounds ahead.
-    // (`list_in` IS `active_list`, through a read-only pointer so that the entry two rounds ahead comes by a scalar load: a workgroup reads
-    // only entries it alone rewrites — later, and never the chunk index in their low bits)
-    uint32_t li = ivx_xcd_remap(blockIdx.x, gridDim.x);
-    if (li >= n_active) return;
-    DeriveLoads L;
-    uint32_t chunk = IVX_LIST_CHUNK(list_in[li]);
-    uint32_t chunk_next = chunk;
-    if (PIPE) {
-        derive_issue(g, info, chunk, tid, L);
-        if (li + gridDim.x < n_active) chunk_next = IVX_LIST_CHUNK(list_in[li + gridDim.x]);
-    }
-    for (;;) {
+    // bounded walk over the active list (virtual block ids give each XCD a contiguous stretch of it). (`list_in` IS `active_list`, through a
+    // read-only pointer so that the entry comes by a scalar load: a workgroup reads only entries it alone rewrites — later, and never the chunk
+    // index in their low bits)
+    for (uint32_t li = ivx_xcd_remap(blockIdx.x, gridDim.x); li < n_active; li += gridDim.x) {
     __syncthreads();  // the previous chunk's LDS use is over
     IVX_T(g, li, 0);
-    const bool have_next = li + gridDim.x < n_active;
-    if (!PIPE) derive_issue(g, info, chunk, tid, L);
+    const uint32_t chunk = IVX_LIST_CHUNK(list_in[li]);
+    DeriveLoads L;
+    derive_issue(g, info, chunk, tid, L);
     const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
     const size_t base = (size_t)chunk * IVX_CHUNK_VOXELS;
     const bool has_zlo = ck > 0, has_zhi = ck + 1 < (int)g.cz;
@@ -416,14 +401,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE ? 4 : 
     }
 
     IVX_T(g, li, 3);  // flags written
-    // ---- the next chunk's loads: out before the region and moment passes, which no longer hold this chunk's rows
-    DeriveLoads Ln;
-    uint32_t chunk_next2 = chunk;
-    if (PIPE) {
-        if (have_next) derive_issue(g, info, chunk_next, tid, Ln);
-        const uint32_t li2 = li + 2u * gridDim.x;
-        if (li2 < n_active) chunk_next2 = IVX_LIST_CHUNK(list_in[li2]);
-    }
     // ---- fused passes over the same chunk (uniform branches: `parts` and `kind` are the same for the whole workgroup)
     uint32_t rc = own_info.region_count, brc = own_info.boundary_region_count;
     if (fz.parts & IVX_PART_REGIONS) ccl_local_chunk(s_ccl, tid, chunk, kind, gen, m, fz.labels, fz.rparent, fz.rscalar, fz.multi_list, rc, brc);
@@ -470,15 +447,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE ? 4 : 
         info[chunk] = ci_;
     }
     IVX_T(g, li, 5);
-    if (!have_next) break;
-    li += gridDim.x;
-    if (PIPE) {
-        chunk = chunk_next;
-        chunk_next = chunk_next2;
-        L = Ln;
-    } else {
-        chunk = IVX_LIST_CHUNK(list_in[li]);
-    }
     }
 }
 
@@ -607,14 +575,21 @@ int ivx_launch_derive(ivx_grid* g, uint32_t parts, uint32_t preset_groups) {
                        g->chunk_class, g->chunk_touch, g->rparent, ivx_wc(g), next_count, g->active_list, ivx_preset_args(g, preset_groups | roll));
     g->scratch_dirty &= ~preset_groups;
     if (roll) g->scratch_dirty &= ~IVX_SCRATCH_EVAL;
-    // long lists: a resident set of workgroups, each walking its share of the list one chunk ahead (see the kernel)
-    const uint32_t resident = (uint32_t)g->ctx->n_cu * IVX_DERIVE_WG_PER_CU;
-    if (ivx_list_grid(g) >= 16u * resident)
-        hipLaunchKernelGGL(k_derive<true>, dim3(resident), dim3(256), 0, g->ctx->stream, v, g->sdf, g->type, g->flags, g->info, g->chunk_bbox,
-                           g->chunk_touch, g->chunk_signs, g->kface, ivx_wc(g), g->active_list, g->active_list, fz);
-    else
-        hipLaunchKernelGGL(k_derive<false>, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->sdf, g->type, g->flags, g->info, g->chunk_bbox,
-                           g->chunk_touch, g->chunk_signs, g->kface, ivx_wc(g), g->active_list, g->active_list, fz);
+    // The grid: a whole number of list entries per workgroup. Workgroups start in waves of seven per CU and a wave that is not full costs as
+    // much as a full one: measured on 512^3, 5 388 entries ran in 53 us with the 6 125 workgroups of ivx_list_grid (an eighth of slack
+    // against a growing list) and in 47 with 5 376; 32 416 entries in 261 us one to a workgroup, 242 with 8 192 workgroups of four entries
+    // each, 259 with 7 168 (4.5 each). So: as many entries each as brings the grid nearest to 32 workgroups per CU, and exactly that many
+    // workgroups; a list that has grown since the last step is covered by the walk's stride.
+    uint32_t derive_grid = ivx_list_grid(g);
+    if (g->last_active) {
+        const uint32_t per_round = (uint32_t)g->ctx->n_cu * 32u;
+        const uint32_t each = (g->last_active + per_round / 2u) / per_round > 1u ? (g->last_active + per_round / 2u) / per_round : 1u;
+        derive_grid = (g->last_active + each - 1u) / each;
+        const uint32_t lo = (g->n_chunks + 255u) / 256u;  // (ivx_list_grid's floor)
+        if (derive_grid < lo) derive_grid = lo;
+    }
+    hipLaunchKernelGGL(k_derive, dim3(derive_grid), dim3(256), 0, g->ctx->stream, v, g->sdf, g->type, g->flags, g->info, g->chunk_bbox,
+                       g->chunk_touch, g->chunk_signs, g->kface, ivx_wc(g), g->active_list, g->active_list, fz);
     g->planes_compact = 1;
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
