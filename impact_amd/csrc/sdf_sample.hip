@@ -1295,8 +1295,15 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
         // under this program found empty (the lists are a function of the program and the grid). Two launches one after the other each pay
         // their own ramp and tail: when both of the first two classes have work and one of them is too short to fill the chip a few times
         // over, the two-level kernel takes both lists in one launch (the one-level programs run there as well, five workgroups per CU).
-        const uint32_t eval_blocks = g->n_chunks < 4096u ? g->n_chunks : 4096u;
         const bool known = g->eval_len_valid != 0;
+        // (grids: a whole number of list entries per workgroup once the lists' lengths are known — a launch's last wave of workgroups costs as
+        // much as a full one, see ivx_launch_derive)
+        auto fit = [&](uint32_t n) {
+            const uint32_t cap = g->n_chunks < 16384u ? g->n_chunks : 16384u;  // (measured on 512^3: 4 096 and 32 768 are both slower on the all-surface grid)
+            if (!known || n == 0u) return cap;
+            const uint32_t each = (n + cap - 1u) / cap;
+            return (n + each - 1u) / each;
+        };
         const uint32_t fill = 4u * 5u * (uint32_t)g->ctx->n_cu;
         const bool merge01 = known && g->eval_len[0] && g->eval_len[1] && (g->eval_len[0] < fill || g->eval_len[1] < fill);
         uint32_t* const list0 = eval_list;
@@ -1304,17 +1311,17 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
         if (!merge01 && !(known && g->eval_len[0] == 0u)) {
             // one level + 64 words of scratch: 16 640 bytes = 13 LDS granules, eight workgroups per CU (the waves a SIMD holds)
             const uint32_t scratch_off = IVX_CHUNK_VOXELS;
-            hipLaunchKernelGGL(k_sdf_eval<2>, dim3(eval_blocks), dim3(256), (size_t)(scratch_off + 64u) * sizeof(float), g->ctx->stream, p, eval_count + 0, list0,
+            hipLaunchKernelGGL(k_sdf_eval<2>, dim3(fit(g->eval_len[0])), dim3(256), (size_t)(scratch_off + 64u) * sizeof(float), g->ctx->stream, p, eval_count + 0, list0,
                                eval_count + 3, nullptr, nullptr, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info);
         }
         if (merge01 || !(known && g->eval_len[1] == 0u)) {
             // two levels, the second one 15 rows long + 64 words of scratch: 32 000 bytes = 25 LDS granules, five workgroups per CU
             const uint32_t scratch_off = IVX_CHUNK_VOXELS + 15u * 256u;
             if (merge01)
-                hipLaunchKernelGGL(k_sdf_eval<1>, dim3(eval_blocks), dim3(256), (size_t)(scratch_off + 64u) * sizeof(float), g->ctx->stream, p, eval_count + 0, list0,
+                hipLaunchKernelGGL(k_sdf_eval<1>, dim3(fit(g->eval_len[0] + g->eval_len[1])), dim3(256), (size_t)(scratch_off + 64u) * sizeof(float), g->ctx->stream, p, eval_count + 0, list0,
                                    eval_count + 3, eval_count + 1, list1, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info);
             else
-                hipLaunchKernelGGL(k_sdf_eval<1>, dim3(eval_blocks), dim3(256), (size_t)(scratch_off + 64u) * sizeof(float), g->ctx->stream, p, eval_count + 1, list1,
+                hipLaunchKernelGGL(k_sdf_eval<1>, dim3(fit(g->eval_len[1])), dim3(256), (size_t)(scratch_off + 64u) * sizeof(float), g->ctx->stream, p, eval_count + 1, list1,
                                    nullptr, nullptr, nullptr, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info);
         }
         if (stack_size >= 3u && !(known && g->eval_len[2] == 0u)) {
@@ -1322,7 +1329,7 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
             // — the votes — and never used as published test voxels, which only the trimmed launch has)
             const uint32_t lv = stack_size;
             const uint32_t scratch_off = lv * IVX_CHUNK_VOXELS - 16u;
-            hipLaunchKernelGGL(k_sdf_eval<0>, dim3(eval_blocks), dim3(256), (size_t)lv * IVX_CHUNK_VOXELS * sizeof(float), g->ctx->stream, p, eval_count + 2,
+            hipLaunchKernelGGL(k_sdf_eval<0>, dim3(fit(g->eval_len[2])), dim3(256), (size_t)lv * IVX_CHUNK_VOXELS * sizeof(float), g->ctx->stream, p, eval_count + 2,
                                eval_list + 2 * (size_t)g->n_chunks, nullptr, nullptr, nullptr, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info);
         }
     }
