@@ -1081,38 +1081,49 @@ static uint32_t ivx_solver_dry() {
     return v;
 }
 
+// this step's prepared contacts and body constants into the schedule's packed records (run_chain_mg; the positional phase's second pass reads
+// the first's). Reads the body array only: both phases' records are packed before either phase runs.
 template <int PHASE>
-static int launch_solve_mg(ivx_world* w, uint32_t groups, ReplayView rv = ReplayView(), const uint32_t* replay_flag = nullptr) {
-    {
-        const size_t need = (size_t)w->n_tiles[PHASE] * Packed<PHASE>::NJ * 64u * sizeof(float4);
-        if (need > w->packed_cap[PHASE]) {
-            IVX_HIP_CHECK(hipStreamSynchronize(w->ctx->stream));
-            if (w->packed[PHASE]) (void)hipFree(w->packed[PHASE]);
-            w->packed[PHASE] = nullptr;
-            w->packed_cap[PHASE] = 0;
-            IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->packed[PHASE]), need + need / 8));
-            w->packed_cap[PHASE] = need + need / 8;
-        }
+static int pack_items_mg(ivx_world* w, hipStream_t stream) {
+    const size_t need = (size_t)w->n_tiles[PHASE] * Packed<PHASE>::NJ * 64u * sizeof(float4);
+    if (need > w->packed_cap[PHASE]) {
+        IVX_HIP_CHECK(hipStreamSynchronize(w->ctx->stream));
+        if (w->side_stream) IVX_HIP_CHECK(hipStreamSynchronize(w->side_stream));
+        if (w->packed[PHASE]) (void)hipFree(w->packed[PHASE]);
+        w->packed[PHASE] = nullptr;
+        w->packed_cap[PHASE] = 0;
+        IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->packed[PHASE]), need + need / 8));
+        w->packed_cap[PHASE] = need + need / 8;
     }
-    const uint32_t base = w->barrier_count;
-    w->barrier_count += groups * 2u;  // (two grid barriers per launch: behind the set-up and census, and before the write-back)
+    hipLaunchKernelGGL((k_pack_items<PHASE>), dim3(w->n_tiles[PHASE]), dim3(64), 0, stream, w->tile_first + w->tile_offset[PHASE], w->items + w->item_offset[PHASE],
+                       reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], w->pc[w->cur], w->cb, reinterpret_cast<float4*>(w->packed[PHASE]));
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+// One phase's solve on `stream`. Everything a launch shares between its workgroups is the phase's own — barrier counter and census table
+// (barrier_words[PHASE], + 4 + 20 PHASE), shared body records (dynst, second half for the positional phase), completion words (tile_done, the
+// positional phase's behind the velocity phase's) — because the two phases run side by side (ivx_launch_phys_solve).
+template <int PHASE>
+static int launch_solve_mg(ivx_world* w, uint32_t groups, hipStream_t stream, ReplayView rv = ReplayView(), const uint32_t* replay_flag = nullptr) {
+    uint32_t& count = PHASE ? w->barrier_count1 : w->barrier_count;
+    const uint32_t base = count;
+    count += groups * 2u;  // (two grid barriers per launch: behind the set-up and census, and before the write-back)
     w->tile_tag += 1u;
     if (w->tile_tag == 0u) w->tile_tag = 1u;  // (0 is what a fresh completion word holds)
-    // this step's prepared contacts and body constants into the schedule's packed records (run_chain_mg; pass 2 reads pass 1's)
-    if (!replay_flag) hipLaunchKernelGGL((k_pack_items<PHASE>), dim3(w->n_tiles[PHASE]), dim3(64), 0, w->ctx->stream, w->tile_first + w->tile_offset[PHASE],
-                       w->items + w->item_offset[PHASE], reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], w->pc[w->cur], w->cb,
-                       reinterpret_cast<float4*>(w->packed[PHASE]));
     static const uint32_t spread = [] {  // (developer switch; 8 = the working workgroups share one XCD, 1 = consecutive blocks; see k_solve_mg)
         const char* e = getenv("IVX_SOLVER_SPREAD");
         const int v = e ? atoi(e) : 8;
         return (uint32_t)(v < 1 ? 1 : (v > 8 ? 8 : v));
     }();
-    hipLaunchKernelGGL((k_solve_mg<PHASE>), dim3(groups * spread), dim3(MG_THREADS), 0, w->ctx->stream, w->n_dyn, w->cfg.positional_correction_factor, w->pc[w->cur],
-                       reinterpret_cast<float4*>(w->acc[w->cur]), w->n_contacts, w->cb, reinterpret_cast<float4*>(w->dynst), w->items + w->item_offset[PHASE],
+    hipLaunchKernelGGL((k_solve_mg<PHASE>), dim3(groups * spread), dim3(MG_THREADS), 0, stream, w->n_dyn, w->cfg.positional_correction_factor, w->pc[w->cur],
+                       reinterpret_cast<float4*>(w->acc[w->cur]), w->n_contacts, w->cb, reinterpret_cast<float4*>(w->dynst + (PHASE ? w->body_cap * 8 : 0)),
+                       w->items + w->item_offset[PHASE],
                        reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], w->level_start + w->level_offset[PHASE],
                        w->tile_base + w->level_offset[PHASE], reinterpret_cast<const float4*>(w->packed[PHASE]),
-                       w->n_levels[PHASE], w->barrier_words, base, w->mg_err_dev, ivx_solver_dry(), spread, rv, replay_flag, w->barrier_words + 4, w->tile_first + w->tile_offset[PHASE], w->n_tiles[PHASE],
-                       w->dep_start + w->dep_start_offset[PHASE], w->deps + w->dep_offset[PHASE], w->tile_done, w->tile_tag);
+                       w->n_levels[PHASE], w->barrier_words + PHASE, base, w->mg_err_dev, ivx_solver_dry(), spread, rv, replay_flag, w->barrier_words + 4 + 20 * PHASE,
+                       w->tile_first + w->tile_offset[PHASE], w->n_tiles[PHASE],
+                       w->dep_start + w->dep_start_offset[PHASE], w->deps + w->dep_offset[PHASE], w->tile_done + (PHASE ? w->n_tiles[0] + 1u : 0u), w->tile_tag);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -1130,30 +1141,66 @@ int ivx_launch_phys_solve(ivx_world* w) {
         pass1.applied = w->kin_applied;
         pass2.qstart = reinterpret_cast<const float4*>(w->kin_qstart);
     }
-    auto before_positional = [&]() -> int {
+    auto before_positional = [&](hipStream_t st) -> int {
         if (!replay) return IVX_OK;
-        IVX_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(uint32_t), w->ctx->stream));
-        hipLaunchKernelGGL(k_kin_snapshot, dim3((w->n_dyn + 255u) / 256u + 1u), dim3(256), 0, w->ctx->stream, w->n_dyn, w->cb, reinterpret_cast<float4*>(w->kin_snap));
+        IVX_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_kin_snapshot, dim3((w->n_dyn + 255u) / 256u + 1u), dim3(256), 0, st, w->n_dyn, w->cb, reinterpret_cast<float4*>(w->kin_snap));
         IVX_HIP_CHECK(hipGetLastError());
         return IVX_OK;
     };
-    auto between_passes = [&]() -> int {
-        hipLaunchKernelGGL(k_kin_prefix, dim3(w->n_kin), dim3(64), 0, w->ctx->stream, w->n_kin, w->n_dyn, w->kin_offsets, w->kin_list, w->kin_applied,
+    auto between_passes = [&](hipStream_t st) -> int {
+        hipLaunchKernelGGL(k_kin_prefix, dim3(w->n_kin), dim3(64), 0, st, w->n_kin, w->n_dyn, w->kin_offsets, w->kin_list, w->kin_applied,
                            reinterpret_cast<float4*>(w->kin_qstart), w->cb, flag);
-        hipLaunchKernelGGL(k_kin_restore, dim3((w->n_dyn + 255u) / 256u + 1u), dim3(256), 0, w->ctx->stream, w->n_dyn, w->cb, reinterpret_cast<const float4*>(w->kin_snap), flag);
+        hipLaunchKernelGGL(k_kin_restore, dim3((w->n_dyn + 255u) / 256u + 1u), dim3(256), 0, st, w->n_dyn, w->cb, reinterpret_cast<const float4*>(w->kin_snap), flag);
         IVX_HIP_CHECK(hipGetLastError());
         return IVX_OK;
     };
     if (groups > 1u) {
-        if (w->n_levels[0] && (rc = launch_solve_mg<0>(w, groups))) return rc;
-        if (w->n_levels[1]) {
-            if ((rc = before_positional())) return rc;
-            if ((rc = launch_solve_mg<1>(w, groups, pass1))) return rc;
+        // THE TWO PHASES SIDE BY SIDE. The velocity phase reads and writes velocities (and the accumulated impulses); the positional phase reads
+        // and writes positions and orientations; what either reads of the other's — the configuration the velocity items are linearised
+        // about, inverse masses and inertia — is in its packed records, taken from the body array before either starts (the reference runs the
+        // positional correction on the configuration the step began with, solver.rs:496-602, and integrates afterwards). Each phase is a chain
+        // of dependent tiles a handful of waves deep — 183 and 147 levels on the 4096-body pile, of which 135 are the fill of one sweep over
+        // the lattice —, so one after the other they cost the sum, on two streams the longer one.
+        hipStream_t s0 = w->ctx->stream, s1 = s0;
+        static const bool serial = [] {
+            const char* e = getenv("IVX_SOLVER_SERIAL");  // (developer switch: the phases one after the other on the context's stream)
+            return e && atoi(e) != 0;
+        }();
+        const bool both = w->n_levels[0] && w->n_levels[1] && !serial;
+        if (both) {
+            if (!w->side_stream) {
+                IVX_HIP_CHECK(hipStreamCreateWithFlags(&w->side_stream, hipStreamNonBlocking));
+                IVX_HIP_CHECK(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
+                IVX_HIP_CHECK(hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming));
+            }
+            s1 = w->side_stream;
+        }
+        if (w->n_levels[0] && (rc = pack_items_mg<0>(w, s0))) return rc;
+        if (w->n_levels[1] && (rc = pack_items_mg<1>(w, s0))) return rc;
+        if (both) {
+            IVX_HIP_CHECK(hipEventRecord(w->ev_fork, s0));
+            IVX_HIP_CHECK(hipStreamWaitEvent(s1, w->ev_fork, 0));
+        }
+        if (w->n_levels[1] && both) {  // (the side stream first: its launches are in flight while the host enqueues the velocity phase)
+            if ((rc = before_positional(s1))) return rc;
+            if ((rc = launch_solve_mg<1>(w, groups, s1, pass1))) return rc;
             if (replay) {
-                if ((rc = between_passes())) return rc;
-                if ((rc = launch_solve_mg<1>(w, groups, pass2, flag))) return rc;
+                if ((rc = between_passes(s1))) return rc;
+                if ((rc = launch_solve_mg<1>(w, groups, s1, pass2, flag))) return rc;
+            }
+            IVX_HIP_CHECK(hipEventRecord(w->ev_join, s1));
+        }
+        if (w->n_levels[0] && (rc = launch_solve_mg<0>(w, groups, s0))) return rc;
+        if (w->n_levels[1] && !both) {
+            if ((rc = before_positional(s0))) return rc;
+            if ((rc = launch_solve_mg<1>(w, groups, s0, pass1))) return rc;
+            if (replay) {
+                if ((rc = between_passes(s0))) return rc;
+                if ((rc = launch_solve_mg<1>(w, groups, s0, pass2, flag))) return rc;
             }
         }
+        if (both) IVX_HIP_CHECK(hipStreamWaitEvent(s0, w->ev_join, 0));
         return IVX_OK;
     }
     // the phase's mutable body state (24 / 28 bytes per dynamic body) goes to LDS when it fits one CU
@@ -1164,12 +1211,12 @@ int ivx_launch_phys_solve(ivx_world* w) {
         if (rc) return rc;
     }
     if (w->n_levels[1]) {
-        if ((rc = before_positional())) return rc;
+        if ((rc = before_positional(w->ctx->stream))) return rc;
         if (lds1 <= 140 * 1024) rc = launch_solve<true, 1>(w, lds1, pass1);
         else rc = launch_solve<false, 1>(w, 0, pass1);
         if (rc) return rc;
         if (replay) {
-            if ((rc = between_passes())) return rc;
+            if ((rc = between_passes(w->ctx->stream))) return rc;
             if (lds1 <= 140 * 1024) rc = launch_solve<true, 1>(w, lds1, pass2, flag);
             else rc = launch_solve<false, 1>(w, 0, pass2, flag);
             if (rc) return rc;

@@ -313,8 +313,8 @@ int ivx_world_create(ivx_ctx* c, const ivx_solver_config* cfg, ivx_world** out) 
     if (cfg) w->cfg = *cfg;
     else w->cfg = ivx_solver_config{8u, 0.4f, 3u, 0.2f};  // ConstraintSolverConfig::default (solver.rs:374-384)
     IVX_REQUIRE(w->cfg.n_iterations + w->cfg.n_positional_correction_iterations < 4096, IVX_ERR_INVALID, "ivx_world_create: too many iterations");
-    if (hipMalloc(reinterpret_cast<void**>(&w->barrier_words), 20 * sizeof(uint32_t)) != hipSuccess ||
-        hipMemsetAsync(w->barrier_words, 0, 20 * sizeof(uint32_t), c->stream) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void**>(&w->barrier_words), 40 * sizeof(uint32_t)) != hipSuccess ||
+        hipMemsetAsync(w->barrier_words, 0, 40 * sizeof(uint32_t), c->stream) != hipSuccess) {
         ivx_set_error("ivx_world_create: device allocation failed");
         delete w;
         return IVX_ERR_HIP;
@@ -323,6 +323,12 @@ int ivx_world_create(ivx_ctx* c, const ivx_solver_config* cfg, ivx_world** out) 
         hipHostGetDevicePointer(reinterpret_cast<void**>(&w->mg_err_dev), w->mg_err_host, 0) != hipSuccess) {
         ivx_set_error("ivx_world_create: host-mapped allocation failed");
         if (w->mg_err_host) (void)hipHostFree(w->mg_err_host);
+    if (w->side_stream) {
+        (void)hipStreamSynchronize(w->side_stream);
+        (void)hipEventDestroy(w->ev_fork);
+        (void)hipEventDestroy(w->ev_join);
+        (void)hipStreamDestroy(w->side_stream);
+    }
     if (w->stage_contacts) (void)hipHostFree(w->stage_contacts);
     if (w->stage_ev_ready) (void)hipEventDestroy(w->stage_ev);
         (void)hipFree(w->barrier_words);
@@ -392,7 +398,7 @@ int ivx_world_set_bodies(ivx_world* w, const ivx_rigid_body* dyn, size_t n_dyn, 
         IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->kin), cap * sizeof(ivx_kinematic_body)));
         IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->cb), cap * sizeof(PhysBody)));
         IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->touched), cap));
-        IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->dynst), cap * 32));
+        IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->dynst), 2 * cap * 32));  // (the shared records of the velocity phase, then of the positional phase)
         w->body_cap = cap;
     }
     if (n_dyn) IVX_HIP_CHECK(hipMemcpy(w->dyn, dyn, n_dyn * sizeof(ivx_rigid_body), hipMemcpyHostToDevice));
@@ -598,7 +604,7 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
     if ((rc = grow(&w->deps, &w->deps_cap, w->deps_host.size() + 1, s))) return rc;
     {
         const size_t had = w->tile_done_cap;
-        if ((rc = grow(&w->tile_done, &w->tile_done_cap, (size_t)std::max(w->n_tiles[0], w->n_tiles[1]) + 1, s))) return rc;
+        if ((rc = grow(&w->tile_done, &w->tile_done_cap, (size_t)w->n_tiles[0] + w->n_tiles[1] + 2, s))) return rc;
         if (w->tile_done_cap != had) IVX_HIP_CHECK(hipMemsetAsync(w->tile_done, 0, w->tile_done_cap * sizeof(uint32_t), s));  // (no tag is ever 0)
     }
     if (w->n_kin_items) {

@@ -67,7 +67,7 @@ struct ivx_world {
     // hold the previous item of one of its dynamic bodies — CSR: dep_start[tile_offset + t .. + 1] (phase-relative offsets into deps + dep_offset)
     uint32_t* dep_start;
     uint32_t* deps;
-    uint32_t* tile_done;  // [max tiles of a phase] launch tag of the tile's last completion
+    uint32_t* tile_done;  // [tiles of the velocity phase | tiles of the positional phase] launch tag of the tile's last completion
     size_t dep_start_cap, deps_cap, tile_done_cap;
     uint32_t dep_offset[2], dep_start_offset[2];
     uint32_t tile_tag;    // bumped per launch of the solve (a tile is done when its word holds the launch's tag)
@@ -94,7 +94,10 @@ struct ivx_world {
     uint32_t* mg_err_host;  // host-mapped word the multi-workgroup solve sets when its grid barrier gave up (checked at every wait on the stream)
     uint32_t* mg_err_dev;   // its device-side address
     int mg_disabled;        // a barrier timed out in this world before: the solve stays on the single-workgroup kernel
-    uint32_t barrier_count;
+    uint32_t barrier_count;   // arrivals counted so far on the velocity phase's grid-barrier counter (barrier_words[0])
+    uint32_t barrier_count1;  // ... on the positional phase's (barrier_words[1]): the two phases run side by side, each on its own counter
+    hipStream_t side_stream;  // the positional phase's stream (ivx_launch_phys_solve); created on first use
+    hipEvent_t ev_fork, ev_join;
     uint32_t solver_groups_forced, solver_groups_used;
     int schedule_valid, prepared_fresh;
     hipEvent_t ev[5];
