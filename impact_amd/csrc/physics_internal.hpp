@@ -89,6 +89,9 @@ struct ivx_world {
     // all it does is register its two bodies as constrained bodies, which get their velocities written back after the solve
     uint32_t* joint_refs;  // device: body references (IVX_KINEMATIC_BODY flag) of all joints' anchors
     uint32_t n_joint_refs;
+    std::vector<uint32_t> joint_refs_host;  // the same references on the host (the step's body count, ivx_world_step)
+    uint32_t n_bodies_stat;   // constrained bodies of the resident contacts and joints (ivx_physics_result::n_bodies), while `n_bodies_stat_valid`
+    int n_bodies_stat_valid;  // (a function of the contact list, the joints and the body counts: recounted on the host when one of them changes)
     float* dynst;
     uint32_t* barrier_words;
     uint32_t* mg_err_host;  // host-mapped word the multi-workgroup solve sets when its grid barrier gave up (checked at every wait on the stream)
