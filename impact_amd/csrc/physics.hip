@@ -661,63 +661,107 @@ __device__ __forceinline__ void load_packed(const float4* __restrict__ pk /* the
 #pragma unroll
     for (uint32_t j = 0; j < Packed<PHASE>::NJ; ++j) rec[j] = pk[(size_t)j * 64u];
 }
+// (`version`: the hand-off tag the item waits for on this body's shared record, run_chain_mg — a schedule constant riding in a free slot)
 template <int PHASE>
-__device__ __forceinline__ void pack_body(const PhysBody& b, float4* out) {
+__device__ __forceinline__ void pack_body(const PhysBody& b, float4* out, uint32_t version) {
     out[0] = make_float4(b.inv_mass, b.inv_inertia[0], b.inv_inertia[1], b.inv_inertia[2]);
     out[64] = make_float4(b.inv_inertia[3], b.inv_inertia[4], b.inv_inertia[5], b.inv_inertia[6]);
     if (PHASE == 0) {
         out[128] = make_float4(b.inv_inertia[7], b.inv_inertia[8], b.pos[0], b.pos[1]);
         out[192] = make_float4(b.pos[2], b.v[0], b.v[1], b.v[2]);
-        out[256] = make_float4(b.w[0], b.w[1], b.w[2], 0.0f);
+        out[256] = make_float4(b.w[0], b.w[1], b.w[2], __uint_as_float(version));
     } else {
-        out[128] = make_float4(b.inv_inertia[7], b.inv_inertia[8], 0.0f, 0.0f);
+        out[128] = make_float4(b.inv_inertia[7], b.inv_inertia[8], __uint_as_float(version), 0.0f);
     }
 }
 // one thread per item, one block per tile of 64 items (tile_first: index of the tile's first item | (items in the tile - 1) << 26)
 template <int PHASE>
 __global__ __launch_bounds__(64) void k_pack_items(const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ items,
-                                                   const uint2* __restrict__ item_bodies, const PhysContact* __restrict__ pcs,
-                                                   const PhysBody* __restrict__ cb, float4* __restrict__ packed) {
+                                                   const uint2* __restrict__ item_bodies, const uint4* __restrict__ item_tags,
+                                                   const PhysContact* __restrict__ pcs, const PhysBody* __restrict__ cb, float4* __restrict__ packed) {
     const uint32_t tf = tile_first[blockIdx.x], first = tf & 0x03FFFFFFu, cnt = (tf >> 26) + 1u, lane = threadIdx.x;
     if (lane >= cnt) return;
     const uint32_t item = items[first + lane];
     const uint2 bo = item_bodies[first + lane];
+    const uint4 tg = item_tags[first + lane];
     const uint32_t s0 = item & 0x00FFFFFFu, len = (item >> 24) & 15u;
     float4* out = packed + (size_t)blockIdx.x * Packed<PHASE>::NJ * 64u + lane;
 #pragma unroll
     for (uint32_t c = 0; c < 4u; ++c) pack_contact<PHASE>(pcs[s0 + (c < len ? c : len - 1u)], out + (size_t)c * Packed<PHASE>::CJ * 64u);
-    pack_body<PHASE>(cb[bo.x], out + (size_t)4u * Packed<PHASE>::CJ * 64u);
-    pack_body<PHASE>(cb[bo.y], out + (size_t)(4u * Packed<PHASE>::CJ + Packed<PHASE>::BJ) * 64u);
+    if (PHASE == 0) {  // the sweep tags of the accumulated impulses (found, left) beside the first contact's last word
+        float4 e = out[256];
+        e.y = __uint_as_float(tg.z), e.z = __uint_as_float(tg.w);
+        out[256] = e;
+    }
+    pack_body<PHASE>(cb[bo.x], out + (size_t)4u * Packed<PHASE>::CJ * 64u, tg.x);
+    pack_body<PHASE>(cb[bo.y], out + (size_t)(4u * Packed<PHASE>::CJ + Packed<PHASE>::BJ) * 64u, tg.y);
 }
+
+constexpr uint32_t MG_THREADS = 256u;
+constexpr uint32_t MG_SPIN_LIMIT = 1u << 22;  // a poll loop that never sees its count gives up and flags the launch (every spin is bounded)
 
 // `rec`: the item's packed record, already in registers (load_packed: fetched a level ahead, behind the grid barrier's arrival)
 template <int PHASE>
 __device__ __forceinline__ void run_chain_mg(uint32_t item, uint2 bodies, uint32_t n_dyn, float factor, const PhysContact* __restrict__ pcs,
                                              __amdgpu_buffer_rsrc_t rs_acc, const PhysBody* __restrict__ cb, __amdgpu_buffer_rsrc_t rs_dyn,
-                                             const float4 (&rec)[Packed<PHASE>::NJ], uint32_t item_index, const ReplayView& rv, bool one_xcd) {
+                                             const float4 (&rec)[Packed<PHASE>::NJ], uint32_t item_index, const ReplayView& rv, bool one_xcd, bool live,
+                                             bool no_wait, bool dry_chain, uint32_t* error) {
     const uint32_t s0 = item & 0x00FFFFFFu, len = (item >> 24) & 15u, type = item >> 28;
     const uint32_t ia = bodies.x, ib = bodies.y;
     const bool with_acc = type != PHYS_ITEM_POSITIONAL, store_acc = type == PHYS_ITEM_VELOCITY;
     PairStatic st;
     st.dyn_a = ia < n_dyn;
     st.dyn_b = ib < n_dyn;
-    // the mutable state first (it is what the level waited for), then everything that never changes during the solve
-    float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
-    if (st.dyn_a) {
-        a0 = ld16_sc1(rs_dyn, ia * 32u);
-        a1 = ld16_sc1(rs_dyn, ia * 32u + 16u);
-    }
-    if (st.dyn_b) {
-        b0 = ld16_sc1(rs_dyn, ib * 32u);
-        b1 = ld16_sc1(rs_dyn, ib * 32u + 16u);
-    }
+    // THE HAND-OFF. Every shared 16-byte record carries a tag in a slot its data do not use: a body's records the number of items that have
+    // touched the body this phase (the launch's set-up writes 0), a contact's accumulated impulses the number of velocity sweeps that have
+    // written them (0: as prepared). The item knows from the schedule which tags it must find (in the packed record: pack_body, k_pack_items)
+    // and simply loads its operands, past the L1, until all of them carry those tags: the load that sees the producer's store IS the load of
+    // the data. No completion word per tile, no wait for the stores' acknowledgement before it, no second trip for the data behind it —
+    // a third of a level's time in the tile-flag form. Every dependency of an item is an earlier item touching one of its bodies (the
+    // accumulated impulses are its own chain's, one sweep back, and that item touched the same bodies), so what is waited for here is exactly
+    // the schedule's partial order; lanes of a wave (one level, mutually independent items) wait together.
+    constexpr uint32_t CJ0 = Packed<PHASE>::CJ, BJ0 = Packed<PHASE>::BJ;
+    const uint32_t DST = PHASE == 0 ? 32u : 48u;  // bytes of a body's shared records
+    const uint32_t ver_a = __float_as_uint(PHASE == 0 ? rec[4u * CJ0 + 4u].w : rec[4u * CJ0 + 2u].z);
+    const uint32_t ver_b = __float_as_uint(PHASE == 0 ? rec[4u * CJ0 + BJ0 + 4u].w : rec[4u * CJ0 + BJ0 + 2u].z);
+    const uint32_t acc_in = PHASE == 0 ? __float_as_uint(rec[4].y) : 0u, acc_out = PHASE == 0 ? __float_as_uint(rec[4].z) : 0u;
+    float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0, b0 = a0, b1 = a0, b2 = a0;
     float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0, c2 = c0, c3 = c0;
-    if (with_acc) {
-        c0 = ld16_sc1(rs_acc, s0 * 16u);
-        if (len > 1u) c1 = ld16_sc1(rs_acc, (s0 + 1u) * 16u);
-        if (len > 2u) c2 = ld16_sc1(rs_acc, (s0 + 2u) * 16u);
-        if (len > 3u) c3 = ld16_sc1(rs_acc, (s0 + 3u) * 16u);
+    for (uint32_t spins = 0;; ++spins) {
+        bool ok = true;
+        if (live && st.dyn_a) {
+            a0 = ld16_sc1(rs_dyn, ia * DST);
+            a1 = ld16_sc1(rs_dyn, ia * DST + 16u);
+            ok = ok && __float_as_uint(a0.w) == ver_a && __float_as_uint(a1.w) == ver_a;
+            if (PHASE == 1) {
+                a2 = ld16_sc1(rs_dyn, ia * DST + 32u);
+                ok = ok && __float_as_uint(a2.w) == ver_a;
+            }
+        }
+        if (live && st.dyn_b) {
+            b0 = ld16_sc1(rs_dyn, ib * DST);
+            b1 = ld16_sc1(rs_dyn, ib * DST + 16u);
+            ok = ok && __float_as_uint(b0.w) == ver_b && __float_as_uint(b1.w) == ver_b;
+            if (PHASE == 1) {
+                b2 = ld16_sc1(rs_dyn, ib * DST + 32u);
+                ok = ok && __float_as_uint(b2.w) == ver_b;
+            }
+        }
+        if (live && with_acc) {
+            c0 = ld16_sc1(rs_acc, s0 * 16u);
+            ok = ok && __float_as_uint(c0.w) == acc_in;
+            if (len > 1u) c1 = ld16_sc1(rs_acc, (s0 + 1u) * 16u), ok = ok && __float_as_uint(c1.w) == acc_in;
+            if (len > 2u) c2 = ld16_sc1(rs_acc, (s0 + 2u) * 16u), ok = ok && __float_as_uint(c2.w) == acc_in;
+            if (len > 3u) c3 = ld16_sc1(rs_acc, (s0 + 3u) * 16u), ok = ok && __float_as_uint(c3.w) == acc_in;
+        }
+        if (no_wait || __builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (spins > MG_SPIN_LIMIT) {
+            if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (host-mapped: ivx_world_check_solve)
+            break;
+        }
     }
+    if (!live || dry_chain) return;
     constexpr uint32_t CJ = Packed<PHASE>::CJ, BJ = Packed<PHASE>::BJ;
     const PhysContact p0 = unpack_contact<PHASE>(rec), p1 = unpack_contact<PHASE>(rec + CJ), p2 = unpack_contact<PHASE>(rec + 2u * CJ),
                       p3 = unpack_contact<PHASE>(rec + 3u * CJ);
@@ -741,9 +785,9 @@ __device__ __forceinline__ void run_chain_mg(uint32_t item, uint2 bodies, uint32
         x.wb = st.dyn_b ? mk(b1.x, b1.y, b1.z) : kwb;
     } else {
         x.pa = st.dyn_a ? mk(a0.x, a0.y, a0.z) : ld3(cb[ia].pos);
-        x.qa = st.dyn_a ? Q4{a1.x, a1.y, a1.z, a1.w} : ldq(cb[ia].q);
+        x.qa = st.dyn_a ? Q4{a1.x, a1.y, a1.z, a2.x} : ldq(cb[ia].q);
         x.pb = st.dyn_b ? mk(b0.x, b0.y, b0.z) : ld3(cb[ib].pos);
-        x.qb = st.dyn_b ? Q4{b1.x, b1.y, b1.z, b1.w} : ldq(cb[ib].q);
+        x.qb = st.dyn_b ? Q4{b1.x, b1.y, b1.z, b2.x} : ldq(cb[ib].q);
         if (rv.qstart) {  // pass 2: a kinematic body's orientation as the chains before this one left it (ReplayView)
             if (!st.dyn_a) {
                 const float4 t = rv.qstart[2u * item_index];
@@ -759,42 +803,55 @@ __device__ __forceinline__ void run_chain_mg(uint32_t item, uint2 bodies, uint32
     if (len > 1u) run_contact(type, p1, st, x, factor, c1);
     if (len > 2u) run_contact(type, p2, st, x, factor, c2);
     if (len > 3u) run_contact(type, p3, st, x, factor, c3);
-    for (uint32_t c = 4; c < len; ++c) {  // manifolds with more than four points
+    const float tag_acc = __uint_as_float(acc_out);
+    for (uint32_t c = 4; c < len; ++c) {  // manifolds with more than four points (their accumulated impulses: the same wait, contact by contact)
         const PhysContact q = pcs[s0 + c];
-        float4 a = with_acc ? ld16_sc1(rs_acc, (s0 + c) * 16u) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (with_acc)
+            for (uint32_t spins = 0; spins <= MG_SPIN_LIMIT; ++spins) {
+                a = ld16_sc1(rs_acc, (s0 + c) * 16u);
+                if (no_wait || __float_as_uint(a.w) == acc_in) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
         run_contact(type, q, st, x, factor, a);
-        if (store_acc) st16_shared(rs_acc, (s0 + c) * 16u, a, one_xcd);
+        if (store_acc) {
+            a.w = tag_acc;
+            st16_shared(rs_acc, (s0 + c) * 16u, a, one_xcd);
+        }
     }
     if (store_acc) {
+        c0.w = c1.w = c2.w = c3.w = tag_acc;  // (run_contact leaves 0 there)
         st16_shared(rs_acc, s0 * 16u, c0, one_xcd);
         if (len > 1u) st16_shared(rs_acc, (s0 + 1u) * 16u, c1, one_xcd);
         if (len > 2u) st16_shared(rs_acc, (s0 + 2u) * 16u, c2, one_xcd);
         if (len > 3u) st16_shared(rs_acc, (s0 + 3u) * 16u, c3, one_xcd);
     }
     if (PHASE == 1 && rv.applied && !(st.dyn_a && st.dyn_b)) rv.applied[item_index] = x.applied;
+    // the bodies' records, one version on (the accumulated impulses above may land after them: whoever needs those waits for their own tags)
+    const float na = __uint_as_float(ver_a + 1u), nb = __uint_as_float(ver_b + 1u);
     if (PHASE == 0) {
         if (st.dyn_a) {
-            st16_shared(rs_dyn, ia * 32u, make_float4(x.va.x, x.va.y, x.va.z, 0.0f), one_xcd);
-            st16_shared(rs_dyn, ia * 32u + 16u, make_float4(x.wa.x, x.wa.y, x.wa.z, 0.0f), one_xcd);
+            st16_shared(rs_dyn, ia * DST, make_float4(x.va.x, x.va.y, x.va.z, na), one_xcd);
+            st16_shared(rs_dyn, ia * DST + 16u, make_float4(x.wa.x, x.wa.y, x.wa.z, na), one_xcd);
         }
         if (st.dyn_b) {
-            st16_shared(rs_dyn, ib * 32u, make_float4(x.vb.x, x.vb.y, x.vb.z, 0.0f), one_xcd);
-            st16_shared(rs_dyn, ib * 32u + 16u, make_float4(x.wb.x, x.wb.y, x.wb.z, 0.0f), one_xcd);
+            st16_shared(rs_dyn, ib * DST, make_float4(x.vb.x, x.vb.y, x.vb.z, nb), one_xcd);
+            st16_shared(rs_dyn, ib * DST + 16u, make_float4(x.wb.x, x.wb.y, x.wb.z, nb), one_xcd);
         }
     } else {
         if (st.dyn_a) {
-            st16_shared(rs_dyn, ia * 32u, make_float4(x.pa.x, x.pa.y, x.pa.z, 0.0f), one_xcd);
-            st16_shared(rs_dyn, ia * 32u + 16u, make_float4(x.qa.x, x.qa.y, x.qa.z, x.qa.w), one_xcd);
+            st16_shared(rs_dyn, ia * DST, make_float4(x.pa.x, x.pa.y, x.pa.z, na), one_xcd);
+            st16_shared(rs_dyn, ia * DST + 16u, make_float4(x.qa.x, x.qa.y, x.qa.z, na), one_xcd);
+            st16_shared(rs_dyn, ia * DST + 32u, make_float4(x.qa.w, 0.0f, 0.0f, na), one_xcd);
         }
         if (st.dyn_b) {
-            st16_shared(rs_dyn, ib * 32u, make_float4(x.pb.x, x.pb.y, x.pb.z, 0.0f), one_xcd);
-            st16_shared(rs_dyn, ib * 32u + 16u, make_float4(x.qb.x, x.qb.y, x.qb.z, x.qb.w), one_xcd);
+            st16_shared(rs_dyn, ib * DST, make_float4(x.pb.x, x.pb.y, x.pb.z, nb), one_xcd);
+            st16_shared(rs_dyn, ib * DST + 16u, make_float4(x.qb.x, x.qb.y, x.qb.z, nb), one_xcd);
+            st16_shared(rs_dyn, ib * DST + 32u, make_float4(x.qb.w, 0.0f, 0.0f, nb), one_xcd);
         }
     }
 }
 
-constexpr uint32_t MG_THREADS = 256u;
-constexpr uint32_t MG_SPIN_LIMIT = 1u << 22;  // a poll loop that never sees its count gives up and flags the launch (every spin is bounded)
 
 // grid-wide barrier of the G resident workgroups: `target` arrivals on the monotonic counter. In two halves, so that loads which do not
 // depend on the other workgroups (the next level's packed records) can be issued between a workgroup's arrival and its wait: their trip to
@@ -830,8 +887,7 @@ __global__ __launch_bounds__(MG_THREADS) void k_solve_mg(uint32_t n_dyn, float f
                                                          const float4* __restrict__ packed, uint32_t n_levels, uint32_t* __restrict__ counter,
                                                          uint32_t counter_base, uint32_t* __restrict__ error, uint32_t dry, uint32_t spread, ReplayView rv,
                                                          const uint32_t* __restrict__ replay_flag, uint32_t* __restrict__ xcc_table,
-                                                         const uint32_t* __restrict__ tile_first, uint32_t n_tiles, const uint32_t* __restrict__ dep_start,
-                                                         const uint32_t* __restrict__ deps, uint32_t* __restrict__ tile_done, uint32_t tag) {
+                                                         const uint32_t* __restrict__ tile_first, uint32_t n_tiles) {
     // `spread` = 8: the launch holds 8 G blocks of which every eighth works — workgroups are handed to the XCDs round robin, so the G that
     // work share one XCD (its L2, its fabric port); 1: G blocks, all working. Where they land changes times only, never results.
     if (spread > 1u && (blockIdx.x % spread) != 0u) return;
@@ -842,17 +898,19 @@ __global__ __launch_bounds__(MG_THREADS) void k_solve_mg(uint32_t n_dyn, float f
     }
     const uint32_t blk = blockIdx.x / spread;
     const uint32_t tid = threadIdx.x, G = gridDim.x / spread, slot = blk * MG_THREADS + tid, stride = G * MG_THREADS;
-    const __amdgpu_buffer_rsrc_t rs_dyn = __builtin_amdgcn_make_buffer_rsrc(dynst, 0, n_dyn * 32u, 0x00020000);
+    const uint32_t DST = PHASE == 0 ? 32u : 48u;  // bytes of a body's shared records: (v | tag)(w | tag) — (p | tag)(q.xyz | tag)(q.w, -, - | tag)
+    const __amdgpu_buffer_rsrc_t rs_dyn = __builtin_amdgcn_make_buffer_rsrc(dynst, 0, n_dyn * DST, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_acc = __builtin_amdgcn_make_buffer_rsrc(accs, 0, n_contacts * 16u, 0x00020000);
     // the phase's mutable state of the dynamic bodies into the shared records
     for (uint32_t i = slot; i < n_dyn; i += stride) {
         const PhysBody& b = cb[i];
-        if (PHASE == 0) {
-            st16_sc1(rs_dyn, i * 32u, make_float4(b.v[0], b.v[1], b.v[2], 0.0f));
-            st16_sc1(rs_dyn, i * 32u + 16u, make_float4(b.w[0], b.w[1], b.w[2], 0.0f));
+        if (PHASE == 0) {  // (tag 0 in every record's last word: no item has touched the body yet, run_chain_mg)
+            st16_sc1(rs_dyn, i * DST, make_float4(b.v[0], b.v[1], b.v[2], 0.0f));
+            st16_sc1(rs_dyn, i * DST + 16u, make_float4(b.w[0], b.w[1], b.w[2], 0.0f));
         } else {
-            st16_sc1(rs_dyn, i * 32u, make_float4(b.pos[0], b.pos[1], b.pos[2], 0.0f));
-            st16_sc1(rs_dyn, i * 32u + 16u, make_float4(b.q[0], b.q[1], b.q[2], b.q[3]));
+            st16_sc1(rs_dyn, i * DST, make_float4(b.pos[0], b.pos[1], b.pos[2], 0.0f));
+            st16_sc1(rs_dyn, i * DST + 16u, make_float4(b.q[0], b.q[1], b.q[2], 0.0f));
+            st16_sc1(rs_dyn, i * DST + 32u, make_float4(b.q[3], 0.0f, 0.0f, 0.0f));
         }
     }
     // census: which XCD is every working workgroup on? (table entry = this launch's counter base | XCC_ID; read back behind the first barrier)
@@ -864,29 +922,25 @@ __global__ __launch_bounds__(MG_THREADS) void k_solve_mg(uint32_t n_dyn, float f
     for (uint32_t q = 0; q < G && q < 16u; ++q) one_xcd = one_xcd && __hip_atomic_load(xcc_table + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == xcc_tag;
     if (dry & 4u) one_xcd = false;  // (developer switch: the write-through form wherever the workgroups sit)
     // ---- the schedule, TILE by tile. A tile is 64 consecutive items of a level (mutually independent chains) and the unit a wave runs; wave w
-    // of the launch's W = 4 G waves runs the tiles w, w + W, ... in the schedule's order. A level-wide grid barrier made every wave wait for the
-    // slowest chain of the whole level and cost a counter round trip on top (2 us of a level's 6-7); here a tile waits only for the tiles that
-    // hold the previous item of one of its bodies (host-built lists, `deps`): its lanes poll those tiles' completion words, one word per lane,
-    // until all hold this launch's tag. Every dependency points to an earlier tile and every wave takes its tiles in order, so the earliest
-    // unfinished tile can always run: no deadlock while the launch's workgroups are resident (checked by the host, bounded polls besides).
-    // The hand-off is the per-wave form of MI355X_MICROARCH.md's first table row: the wave's shared stores (write-through, or plain when all
-    // working workgroups sit on one XCD), s_waitcnt vmcnt(0), then one lane's completion word; the consumer's lanes poll with L1-bypassing loads
-    // and load the bodies' state (L1-bypassing) only after the poll has matched.
-    // The item words, the body pairs, the PACKED RECORD and the dependency list of a wave's next tile are fetched while it finishes the current
-    // one (they never change during the solve): a tile's critical path holds only the poll and the 8 loads of shared state.
+    // of the launch's W = 4 G waves runs the tiles w, w + W, ... in the schedule's order. What a tile waits for is in the data itself: every
+    // shared record carries a version tag and an item loads its operands until they carry the tags the schedule says (run_chain_mg) — no grid
+    // barrier per level (it made every wave wait for the slowest chain of the whole level), and no completion words per tile either (they cost
+    // the producer a wait for its stores' acknowledgement and the consumer a second trip for the data). Every dependency points to an earlier
+    // item and every wave takes its tiles in order, so the earliest unfinished tile can always run: no deadlock while the launch's workgroups
+    // are resident (checked by the host, bounded polls besides). The item words, the body pairs and the PACKED RECORD of a wave's next tile are
+    // fetched while it finishes the current one (they never change during the solve).
     const uint32_t lane = tid & 63u, W = G * (MG_THREADS / 64u), wv = blk * (MG_THREADS / 64u) + (tid >> 6);
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     uint32_t t = wv;
-    uint32_t nxt_item = NONE, nxt_index = 0u, nxt_dep = NONE, nxt_dep_more = 0u;
+    uint32_t nxt_item = NONE, nxt_index = 0u;
     uint2 nxt_bodies = make_uint2(0u, 0u);
     float4 rec[Packed<PHASE>::NJ];
+#pragma unroll
+    for (uint32_t j = 0; j < Packed<PHASE>::NJ; ++j) rec[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     auto fetch_tile = [&](uint32_t tt) {
-        nxt_item = NONE, nxt_dep = NONE, nxt_dep_more = 0u;
+        nxt_item = NONE;
         if (tt >= n_tiles) return;
         const uint32_t tf = tile_first[tt], first = tf & 0x03FFFFFFu, cnt = (tf >> 26) + 1u;
-        const uint32_t d0 = dep_start[tt], d1 = dep_start[tt + 1u];
-        if (d0 + lane < d1) nxt_dep = deps[d0 + lane];
-        nxt_dep_more = d1 - d0 > 64u ? 1u : 0u;
         if (lane < cnt) {
             nxt_item = items[first + lane];
             nxt_bodies = item_bodies[first + lane];
@@ -894,30 +948,12 @@ __global__ __launch_bounds__(MG_THREADS) void k_solve_mg(uint32_t n_dyn, float f
             load_packed<PHASE>(packed + (size_t)tt * (Packed<PHASE>::NJ * 64u) + lane, rec);
         }
     };
-    auto all_done = [&](uint32_t dep) {  // this lane's producer tile (NONE: none) — true in every lane once all lanes' tiles are done
-        uint32_t spins = 0;
-        for (;;) {
-            const bool ok = dep == NONE || __hip_atomic_load(tile_done + dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag;
-            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) return;
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > MG_SPIN_LIMIT) {
-                if (lane == 0u) __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (host-mapped: ivx_world_check_solve)
-                return;
-            }
-        }
-    };
     fetch_tile(t);
     for (; t < n_tiles; t += W) {
-        const uint32_t cur_item = nxt_item, cur_index = nxt_index, cur_dep = nxt_dep, more = nxt_dep_more;
+        const uint32_t cur_item = nxt_item, cur_index = nxt_index;
         const uint2 cur_bodies = nxt_bodies;
-        if (!(dry & 2u)) {
-            all_done(cur_dep);
-            if (more)  // (a tile with more than 64 producer tiles: the rest of its list, 64 at a time)
-                for (uint32_t d = dep_start[t] + 64u; d < dep_start[t + 1u]; d += 64u) all_done(d + lane < dep_start[t + 1u] ? deps[d + lane] : NONE);
-        }
-        if (cur_item != NONE && !(dry & 1u)) run_chain_mg<PHASE>(cur_item, cur_bodies, n_dyn, factor, pcs, rs_acc, cb, rs_dyn, rec, cur_index, rv, one_xcd);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's shared stores have landed (in the common L2, or written through)
-        if (lane == 0u) __hip_atomic_store(tile_done + t, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        run_chain_mg<PHASE>(cur_item, cur_bodies, n_dyn, factor, pcs, rs_acc, cb, rs_dyn, rec, cur_index, rv, one_xcd, cur_item != NONE, (dry & 3u) != 0u,
+                            (dry & 1u) != 0u, error);
         fetch_tile(t + W);
     }
     // every tile of the launch done (one grid barrier) before the shared records go back to the body array
@@ -925,13 +961,14 @@ __global__ __launch_bounds__(MG_THREADS) void k_solve_mg(uint32_t n_dyn, float f
     mg_barrier(counter, arrivals, error);
     for (uint32_t i = slot; i < n_dyn; i += stride) {
         PhysBody& b = cb[i];
-        const float4 r0 = ld16_sc1(rs_dyn, i * 32u), r1 = ld16_sc1(rs_dyn, i * 32u + 16u);
+        const float4 r0 = ld16_sc1(rs_dyn, i * DST), r1 = ld16_sc1(rs_dyn, i * DST + 16u);
         if (PHASE == 0) {
             st3(b.v, mk(r0.x, r0.y, r0.z));
             st3(b.w, mk(r1.x, r1.y, r1.z));
         } else {
+            const float4 r2 = ld16_sc1(rs_dyn, i * DST + 32u);
             st3(b.pos, mk(r0.x, r0.y, r0.z));
-            stq(b.q, Q4{r1.x, r1.y, r1.z, r1.w});
+            stq(b.q, Q4{r1.x, r1.y, r1.z, r2.x});
         }
     }
 }
@@ -1066,7 +1103,7 @@ static uint32_t solver_groups(const ivx_world* w) {
     if (w->solver_groups_forced) return w->solver_groups_forced < fit ? w->solver_groups_forced : fit;
     const uint32_t widest = w->max_level_items[0] > w->max_level_items[1] ? w->max_level_items[0] : w->max_level_items[1];
     if (widest <= 256u) return 1u;  // (a level that fits one workgroup at one wave per SIMD gains nothing from more)
-    uint32_t g = (widest + MG_THREADS - 1u) / MG_THREADS;
+    uint32_t g = (widest + 159u) / 160u;  // (a few more waves than the widest level has tiles: measured on the 4096-body pile, 8 workgroups 0.85 ms, 5: 0.89, 16: 0.86)
     g = g < 16u ? g : 16u;
     return g < fit ? g : fit;
 }
@@ -1096,34 +1133,32 @@ static int pack_items_mg(ivx_world* w, hipStream_t stream) {
         w->packed_cap[PHASE] = need + need / 8;
     }
     hipLaunchKernelGGL((k_pack_items<PHASE>), dim3(w->n_tiles[PHASE]), dim3(64), 0, stream, w->tile_first + w->tile_offset[PHASE], w->items + w->item_offset[PHASE],
-                       reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], w->pc[w->cur], w->cb, reinterpret_cast<float4*>(w->packed[PHASE]));
+                       reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], reinterpret_cast<const uint4*>(w->item_tags) + w->item_offset[PHASE],
+                       w->pc[w->cur], w->cb, reinterpret_cast<float4*>(w->packed[PHASE]));
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 
 // One phase's solve on `stream`. Everything a launch shares between its workgroups is the phase's own — barrier counter and census table
-// (barrier_words[PHASE], + 4 + 20 PHASE), shared body records (dynst, second half for the positional phase), completion words (tile_done, the
-// positional phase's behind the velocity phase's) — because the two phases run side by side (ivx_launch_phys_solve).
+// (barrier_words[PHASE], + 4 + 20 PHASE), shared body records (dynst, second half for the positional phase) — because the two phases run side
+// by side (ivx_launch_phys_solve).
 template <int PHASE>
 static int launch_solve_mg(ivx_world* w, uint32_t groups, hipStream_t stream, ReplayView rv = ReplayView(), const uint32_t* replay_flag = nullptr) {
     uint32_t& count = PHASE ? w->barrier_count1 : w->barrier_count;
     const uint32_t base = count;
     count += groups * 2u;  // (two grid barriers per launch: behind the set-up and census, and before the write-back)
-    w->tile_tag += 1u;
-    if (w->tile_tag == 0u) w->tile_tag = 1u;  // (0 is what a fresh completion word holds)
     static const uint32_t spread = [] {  // (developer switch; 8 = the working workgroups share one XCD, 1 = consecutive blocks; see k_solve_mg)
         const char* e = getenv("IVX_SOLVER_SPREAD");
         const int v = e ? atoi(e) : 8;
         return (uint32_t)(v < 1 ? 1 : (v > 8 ? 8 : v));
     }();
     hipLaunchKernelGGL((k_solve_mg<PHASE>), dim3(groups * spread), dim3(MG_THREADS), 0, stream, w->n_dyn, w->cfg.positional_correction_factor, w->pc[w->cur],
-                       reinterpret_cast<float4*>(w->acc[w->cur]), w->n_contacts, w->cb, reinterpret_cast<float4*>(w->dynst + (PHASE ? w->body_cap * 8 : 0)),
+                       reinterpret_cast<float4*>(w->acc[w->cur]), w->n_contacts, w->cb, reinterpret_cast<float4*>(w->dynst + (PHASE ? w->body_cap * 16 : 0)),
                        w->items + w->item_offset[PHASE],
                        reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], w->level_start + w->level_offset[PHASE],
                        w->tile_base + w->level_offset[PHASE], reinterpret_cast<const float4*>(w->packed[PHASE]),
                        w->n_levels[PHASE], w->barrier_words + PHASE, base, w->mg_err_dev, ivx_solver_dry(), spread, rv, replay_flag, w->barrier_words + 4 + 20 * PHASE,
-                       w->tile_first + w->tile_offset[PHASE], w->n_tiles[PHASE],
-                       w->dep_start + w->dep_start_offset[PHASE], w->deps + w->dep_offset[PHASE], w->tile_done + (PHASE ? w->n_tiles[0] + 1u : 0u), w->tile_tag);
+                       w->tile_first + w->tile_offset[PHASE], w->n_tiles[PHASE]);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

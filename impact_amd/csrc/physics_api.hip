@@ -203,6 +203,9 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
     const size_t it0 = w->items_host.size();
     w->items_host.resize(it0 + total);
     w->item_bodies_host.resize(2 * (it0 + total));
+    w->item_tags_host.resize(4 * (it0 + total));
+    std::vector<uint32_t>& seen = w->scratch_count;  // per dynamic body: items of this phase that have touched it so far
+    seen.assign(nb, 0u);
     std::vector<uint32_t> cursor(start + 1, start + max_level + 1);
     std::vector<std::vector<uint32_t>> kin_items;  // positional phase: every kinematic body's chains in solve order (ReplayView)
     if (phase == 1) kin_items.resize(w->n_kin);
@@ -216,6 +219,14 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
             const uint32_t ba = w->chain_bodies[2 * (size_t)ch], bb = w->chain_bodies[2 * (size_t)ch + 1];
             w->item_bodies_host[2 * slot] = (ba & IVX_KINEMATIC_BODY) ? w->n_dyn + (ba & 0x7FFFFFFFu) : ba;
             w->item_bodies_host[2 * slot + 1] = (bb & IVX_KINEMATIC_BODY) ? w->n_dyn + (bb & 0x7FFFFFFFu) : bb;
+            // the hand-off tags (k_solve_mg): the versions of the two bodies' records this item waits for (it leaves them one higher), and the
+            // sweep tag on the accumulated impulses — written by the velocity sweeps only: sweep q finds q (0: as prepared) and leaves q + 1
+            uint32_t* tg = &w->item_tags_host[4 * slot];
+            tg[0] = (ba & IVX_KINEMATIC_BODY) ? 0u : seen[ba]++;
+            tg[1] = (bb & IVX_KINEMATIC_BODY) ? 0u : seen[bb]++;
+            const uint32_t sweep = pass < n_first ? 0u : pass - n_first;
+            tg[2] = sweep;
+            tg[3] = sweep + 1u;
             if (phase == 1) {
                 if (ba & IVX_KINEMATIC_BODY) kin_items[ba & 0x7FFFFFFFu].push_back((uint32_t)(slot - it0));
                 if (bb & IVX_KINEMATIC_BODY) kin_items[bb & 0x7FFFFFFFu].push_back((uint32_t)(slot - it0) | 0x80000000u);
@@ -249,42 +260,6 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
     }
     w->tile_base_host[ls0 + max_level] = n_tiles;
     w->n_tiles[phase] = n_tiles;
-    // What every tile waits for: the tiles that hold, for each of its items' dynamic bodies, the previous item touching that body (the
-    // item's level is one more than the latest of them, so they all lie in earlier levels = earlier tiles). Walk the items in sequence
-    // order again with the slot of each body's latest item in hand.
-    {
-        std::vector<uint32_t> tile_of(total);
-        for (uint32_t l = 0; l < max_level; ++l)
-            for (uint32_t i = start[l]; i < start[l + 1]; ++i) tile_of[i] = w->tile_base_host[ls0 + l] + (i - start[l]) / 64u;
-        std::vector<std::vector<uint32_t>> need(n_tiles);
-        std::vector<uint32_t> last_slot(nb, 0xFFFFFFFFu);
-        std::vector<uint32_t> cur2(max_level);
-        for (uint32_t l = 0; l < max_level; ++l) cur2[l] = start[l];
-        size_t kk = 0;
-        for (uint32_t pass = 0; pass < total_passes; ++pass)
-            for (uint32_t ch = 0; ch < nch; ++ch, ++kk) {
-                const uint32_t slot = cur2[lvl[kk] - 1]++;  // (the same stable placement as above)
-                const uint32_t t = tile_of[slot];
-                const uint32_t bs[2] = {w->chain_bodies[2 * (size_t)ch], w->chain_bodies[2 * (size_t)ch + 1]};
-                for (uint32_t b : bs) {
-                    if (b & IVX_KINEMATIC_BODY) continue;
-                    if (last_slot[b] != 0xFFFFFFFFu) need[t].push_back(tile_of[last_slot[b]]);
-                    last_slot[b] = slot;
-                }
-            }
-        w->dep_start_offset[phase] = (uint32_t)w->dep_start_host.size();
-        w->dep_offset[phase] = (uint32_t)w->deps_host.size();
-        uint32_t run2 = 0;
-        for (uint32_t t = 0; t < n_tiles; ++t) {
-            std::vector<uint32_t>& v = need[t];
-            std::sort(v.begin(), v.end());
-            v.erase(std::unique(v.begin(), v.end()), v.end());
-            w->dep_start_host.push_back(run2);
-            w->deps_host.insert(w->deps_host.end(), v.begin(), v.end());
-            run2 += (uint32_t)v.size();
-        }
-        w->dep_start_host.push_back(run2);
-    }
 }
 
 }  // namespace
@@ -344,8 +319,8 @@ int ivx_world_create(ivx_ctx* c, const ivx_solver_config* cfg, ivx_world** out) 
 void ivx_world_destroy(ivx_world* w) {
     if (!w) return;
     (void)hipStreamSynchronize(w->ctx->stream);
-    void* ptrs[] = {w->dyn, w->kin, w->cb, w->touched, w->contacts, w->prev_slot, w->pc[0], w->pc[1], w->acc[0], w->acc[1], w->items, w->item_bodies, w->level_start,
-                    w->dynst, w->barrier_words, w->joint_refs, w->tile_base, w->tile_first, w->dep_start, w->deps, w->tile_done, w->packed[0], w->packed[1], w->kin_offsets, w->kin_list,
+    void* ptrs[] = {w->dyn, w->kin, w->cb, w->touched, w->contacts, w->prev_slot, w->pc[0], w->pc[1], w->acc[0], w->acc[1], w->items, w->item_bodies, w->item_tags, w->level_start,
+                    w->dynst, w->barrier_words, w->joint_refs, w->tile_base, w->tile_first, w->packed[0], w->packed[1], w->kin_offsets, w->kin_list,
                     w->kin_applied, w->kin_qstart, w->kin_snap};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -401,7 +376,7 @@ int ivx_world_set_bodies(ivx_world* w, const ivx_rigid_body* dyn, size_t n_dyn, 
         IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->kin), cap * sizeof(ivx_kinematic_body)));
         IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->cb), cap * sizeof(PhysBody)));
         IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->touched), cap));
-        IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->dynst), 2 * cap * 32));  // (the shared records of the velocity phase, then of the positional phase)
+        IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->dynst), 2 * cap * 64));  // (the shared records of the velocity phase: 32 bytes per body; then, cap * 64 bytes in, of the positional phase: 48)
         w->body_cap = cap;
     }
     if (n_dyn) IVX_HIP_CHECK(hipMemcpy(w->dyn, dyn, n_dyn * sizeof(ivx_rigid_body), hipMemcpyHostToDevice));
@@ -559,11 +534,10 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
     if (!same_schedule) {
         w->items_host.clear();
         w->item_bodies_host.clear();
+        w->item_tags_host.clear();
         w->level_start_host.clear();
         w->tile_base_host.clear();
         w->tile_first_host.clear();
-        w->dep_start_host.clear();
-        w->deps_host.clear();
         build_schedule(w, PHYS_ITEM_WARM, 1u, PHYS_ITEM_VELOCITY, w->cfg.n_iterations, 0);
         build_schedule(w, PHYS_ITEM_POSITIONAL, 0u, PHYS_ITEM_POSITIONAL, w->cfg.n_positional_correction_iterations, 1);
         w->prev_chain_start = w->chain_start;
@@ -602,16 +576,10 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
     }
     if ((rc = grow(&w->items, &w->item_cap, w->items_host.size(), s))) return rc;
     if ((rc = grow(&w->item_bodies, &w->item_bodies_cap, w->item_bodies_host.size(), s))) return rc;
+    if ((rc = grow(&w->item_tags, &w->item_tags_cap, w->item_tags_host.size(), s))) return rc;
     if ((rc = grow(&w->level_start, &w->level_cap, w->level_start_host.size(), s))) return rc;
     if ((rc = grow(&w->tile_base, &w->tile_base_cap, w->tile_base_host.size(), s))) return rc;
     if ((rc = grow(&w->tile_first, &w->tile_first_cap, w->tile_first_host.size(), s))) return rc;
-    if ((rc = grow(&w->dep_start, &w->dep_start_cap, w->dep_start_host.size() + 2, s))) return rc;
-    if ((rc = grow(&w->deps, &w->deps_cap, w->deps_host.size() + 1, s))) return rc;
-    {
-        const size_t had = w->tile_done_cap;
-        if ((rc = grow(&w->tile_done, &w->tile_done_cap, (size_t)w->n_tiles[0] + w->n_tiles[1] + 2, s))) return rc;
-        if (w->tile_done_cap != had) IVX_HIP_CHECK(hipMemsetAsync(w->tile_done, 0, w->tile_done_cap * sizeof(uint32_t), s));  // (no tag is ever 0)
-    }
     if (w->n_kin_items) {
         const size_t n_pos_items = w->items_host.size() - w->item_offset[1];
         if ((rc = grow(&w->kin_offsets, &w->kin_offsets_cap, w->kin_offsets_host.size(), s))) return rc;
@@ -642,14 +610,12 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
         if (!w->items_host.empty()) {
             IVX_HIP_CHECK(hipMemcpy(w->items, w->items_host.data(), w->items_host.size() * 4, hipMemcpyHostToDevice));
             IVX_HIP_CHECK(hipMemcpy(w->item_bodies, w->item_bodies_host.data(), w->item_bodies_host.size() * 4, hipMemcpyHostToDevice));
+            IVX_HIP_CHECK(hipMemcpy(w->item_tags, w->item_tags_host.data(), w->item_tags_host.size() * 4, hipMemcpyHostToDevice));
         }
         IVX_HIP_CHECK(hipMemcpy(w->level_start, w->level_start_host.data(), w->level_start_host.size() * 4, hipMemcpyHostToDevice));
         IVX_HIP_CHECK(hipMemcpy(w->tile_base, w->tile_base_host.data(), w->tile_base_host.size() * 4, hipMemcpyHostToDevice));
         if (!w->tile_first_host.empty())
             IVX_HIP_CHECK(hipMemcpy(w->tile_first, w->tile_first_host.data(), w->tile_first_host.size() * 4, hipMemcpyHostToDevice));
-        if (!w->dep_start_host.empty())
-            IVX_HIP_CHECK(hipMemcpy(w->dep_start, w->dep_start_host.data(), w->dep_start_host.size() * 4, hipMemcpyHostToDevice));
-        if (!w->deps_host.empty()) IVX_HIP_CHECK(hipMemcpy(w->deps, w->deps_host.data(), w->deps_host.size() * 4, hipMemcpyHostToDevice));
         if (w->n_kin_items) {
             IVX_HIP_CHECK(hipMemcpy(w->kin_offsets, w->kin_offsets_host.data(), w->kin_offsets_host.size() * 4, hipMemcpyHostToDevice));
             IVX_HIP_CHECK(hipMemcpy(w->kin_list, w->kin_list_host.data(), w->kin_list_host.size() * 4, hipMemcpyHostToDevice));

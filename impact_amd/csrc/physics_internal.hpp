@@ -51,6 +51,10 @@ struct ivx_world {
     PhysContact* pc[2];
     float* acc[2];  // float4 per contact
     int cur;
+    uint32_t* item_tags;  // [4 * items] per item: the versions it finds its bodies a and b at (a body's record carries the number of items that
+                          // have touched it this phase), the sweep tag it finds on its contacts' accumulated impulses, the tag it leaves there
+    size_t item_tags_cap;
+    std::vector<uint32_t> item_tags_host, scratch_count;
     uint32_t* items;
     uint32_t* item_bodies;  // uint2 per item: constrained-body indices of the chain's pair
     uint32_t* level_start;
@@ -63,15 +67,7 @@ struct ivx_world {
     uint32_t* tile_first;
     size_t tile_base_cap, tile_first_cap;
     uint32_t n_tiles[2], tile_offset[2];
-    // what a tile waits for (the multi-workgroup solve synchronises tile by tile, not level by level): per tile the phase-relative tiles that
-    // hold the previous item of one of its dynamic bodies — CSR: dep_start[tile_offset + t .. + 1] (phase-relative offsets into deps + dep_offset)
-    uint32_t* dep_start;
-    uint32_t* deps;
-    uint32_t* tile_done;  // [tiles of the velocity phase | tiles of the positional phase] launch tag of the tile's last completion
-    size_t dep_start_cap, deps_cap, tile_done_cap;
-    uint32_t dep_offset[2], dep_start_offset[2];
-    uint32_t tile_tag;    // bumped per launch of the solve (a tile is done when its word holds the launch's tag)
-    std::vector<uint32_t> dep_start_host, deps_host;
+    // (what an item waits for is in the shared records themselves: version tags, item_tags below)
     float* packed[2];
     size_t packed_cap[2];
     // kinematic orientations in the positional phase (physics.hip, ReplayView): the positional chains of every kinematic body in solve order
