@@ -622,7 +622,7 @@ def pile_benchmark(ctx, with_cpu, steps=10):
         acc += w.step(0.005)["stage_ms"]
     wall = (time.perf_counter() - t0) / steps
     r = w.step(0.005)
-    n_steps_done = 1 + 2 + steps + 1
+    n_steps_done = 1 + len(host_warm) + steps + 1
     sweeps = 1 + 8 + 3
     out = {
         "workload": "16^3 lattice of unit-density spheres r=0.5 at spacing 0.95: 4096 bodies, 46080 contacts, dt 0.005, 8+3 sweeps + warm start",
