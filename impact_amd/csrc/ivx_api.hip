@@ -2376,7 +2376,10 @@ int ivx_slab_remesh_enqueue(ivx_grid* g, const void* neighbour_face_ids, void* d
         int rc;
         if (neighbour_face_ids && (rc = ivx_region_face_pairs_enqueue(g, 1, neighbour_face_ids))) return rc;
         if ((rc = step_enqueue(g, IVX_STAGE_REMESH, nullptr, nullptr))) return rc;
-        return ivx_step_record_enqueue(g, device_record);
+        if ((rc = ivx_step_record_enqueue(g, device_record))) return rc;
+        if (g->record_head_copy)
+            IVX_HIP_CHECK(hipMemcpyAsync(g->record_head_copy, device_record, (size_t)g->record_head_words * 8, hipMemcpyDeviceToDevice, g->ctx->stream));
+        return IVX_OK;
     }
     g->pairs_enqueued = 0;
     return step_enqueue(g, IVX_STAGE_REMESH, static_cast<const uint16_t*>(neighbour_face_ids), device_record);

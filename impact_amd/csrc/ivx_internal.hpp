@@ -135,6 +135,8 @@ struct ivx_grid {
     uint32_t pending_stages;  // stages enqueued since the last collect
     uint32_t timed_mask;      // timed stages whose events were recorded since the last collect
     uint32_t* pairs_dev;      // [4 + 128 + 2 * IVX_MAX_FACE_PAIRS]: count, seen table, (own, neighbour) component pairs across the upper x face
+    unsigned long long* record_head_copy;  // (in-process slab transport) where the record role also puts the record's first `record_head_words` words:
+    uint32_t record_head_words;            // this slab's place in the gathered block — the gather of the heads is then no copy at all
     int results_in_block;     // the step's small results are in the host-mapped block already (written by the slab record role): collect launches no gather
     int pairs_enqueued;
     int pairs_zeroed;         // the label pass of ivx_halo_pack_both_enqueue cleared count + seen table for the face-pair pass that follows

@@ -298,6 +298,7 @@ int all_gather(ivx_slab** slabs, size_t n, size_t words) {
         IVX_NCCL_CHECK(g_rccl.AllGather(sl->record, sl->gathered, words, NCCL_INT64, c->nccl, s));
         return IVX_OK;
     }
+    if (words == HEAD_WORDS) return IVX_OK;  // (in-process: the record roles wrote the heads in place, ivx_slabs_step_enqueue)
     for (size_t i = 0; i < n; ++i)  // every rank's view is the same: one gathered block, kept by rank 0's slab
         IVX_HIP_CHECK(hipMemcpyAsync(slabs[0]->gathered + i * words, slabs[i]->record, words * 8, hipMemcpyDeviceToDevice, s));
     return IVX_OK;
@@ -660,12 +661,16 @@ int ivx_slabs_step_enqueue(ivx_slab** slabs, size_t n) {
         // (the pass over the neighbour's face ids and the record ride in the remesh stage's launches; a world of one writes its record where the
         // gather would put it)
         unsigned long long* rec = c->nranks == 1 ? sl->gathered : sl->record;
+        // (in-process: the record role also writes the record's head straight into its place in the gathered block)
+        sl->grid->record_head_copy = (c->rank < 0 && !c->ipc && c->nranks > 1) ? slabs[0]->gathered + i * HEAD_WORDS : nullptr;
+        sl->grid->record_head_words = (uint32_t)HEAD_WORDS;
         if (!local_err) note(ivx_slab_remesh_enqueue(sl->grid, sl->has_hi ? sl->ghost[1] + sl->halo_bytes : nullptr, rec));
         if (local_err) {  // a record that says so (words 0, 1: no components, no pairs; word 17: the flags)
             unsigned long long head[18];
             memset(head, 0, sizeof(head));
             head[17] = 8ull;
             IVX_HIP_CHECK(hipMemcpyAsync(rec, head, sizeof(head), hipMemcpyHostToDevice, c->ctx->stream));
+            if (sl->grid->record_head_copy) IVX_HIP_CHECK(hipMemcpyAsync(sl->grid->record_head_copy, head, sizeof(head), hipMemcpyHostToDevice, c->ctx->stream));
             IVX_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));  // (`head` is a local)
         }
         sl->local_err = local_err;

@@ -78,6 +78,8 @@ struct StepArgs {
     uint32_t* fp_seen;
     unsigned long long* record;
     uint32_t record_max_pairs;
+    unsigned long long* record_head;  // (optional) a second place for the record's first record_head_words words
+    uint32_t record_head_words;
 };
 
 __device__ __forceinline__ sn::SnParams sn_params(const StepArgs& a) {
@@ -163,6 +165,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     b -= a.nb[1];
     if (b < a.nb[2]) {  // (one block) the slab's record for the all-gather; the step's small results where ivx_voxel_step_collect looks for them
         role_step_record(a.rscalar, a.fp_count, a.fp_pairs, a.offsets + 2 * (size_t)a.n_chunks, a.moments_out, a.x_off, a.record_max_pairs, a.record);
+        if (a.record_head) {  // (the block's own stores, read back behind a barrier)
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < a.record_head_words; i += 256u) a.record_head[i] = a.record[i];
+        }
         if (threadIdx.x < 64u) role_result_gather(a.rscalar, a.offsets + 2 * (size_t)a.n_chunks, a.moments_out, a.work_count, a.eval_count, a.host_block, false, 0u);
     }
 }
@@ -301,6 +307,8 @@ int ivx_launch_step_emit(ivx_grid* g, uint32_t stages, bool general_in_assign, v
         face_pair_args(a, g, record_has_pairs ? reinterpret_cast<const uint16_t*>(g->pairs_dev) /* (any non-null value: only the count pointer matters) */ : nullptr);
         a.record = static_cast<unsigned long long*>(slab_record);
         a.record_max_pairs = IVX_MAX_FACE_PAIRS;
+        a.record_head = g->record_head_copy;
+        a.record_head_words = g->record_head_words;
         a.nb[2] = 1;
     }
     const uint32_t total = a.nb[0] + a.nb[1] + a.nb[2];
