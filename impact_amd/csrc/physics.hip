@@ -582,14 +582,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(uint32_t n_dyn, float f
 // ---- the solve on several workgroups ------------------------------------------------------------------------------------------------
 // One workgroup runs a level of ~570 chains as 9 waves on 4 SIMDs, three to a SIMD, and a chain is ~1000 dependent f32 instructions:
 // each wave gets a third of its SIMD's issue slots, so the level's critical path is three times what the chain itself costs. Spread
-// over G workgroups of 256 threads (one wave per SIMD, G CUs) the chains run at full issue rate; the price is a grid-wide barrier per
-// level and the bodies' mutable state in memory instead of LDS. Every word another workgroup may read next level — the phase's body
-// state (a 32-byte record per body in `dynst`: v, w | pos, q) and the accumulated impulses — is stored write-through (sc1) and loaded
-// past the L1 (sc1); a storing wave drains its stores (s_waitcnt vmcnt(0)) before the workgroup's barrier, one lane then adds to a
-// monotonic agent-scope counter and polls it with sc1 loads; a workgroup barrier stands between that poll and every load of the next
-// level (MI355X_MICROARCH.md, "Hand-offs measured with sc1 loads in place of the acquire", first row; all G workgroups are resident:
-// G <= 16 blocks of 256 threads on 256 CUs). The schedule, the chain arithmetic and hence the results are those of the
-// single-workgroup kernel, operation for operation.
+// over G workgroups of 256 threads (one wave per SIMD, G CUs) the chains run at full issue rate; the price is the bodies' mutable state in
+// memory instead of LDS and a hand-off between workgroups. Every word another workgroup may read — the phase's body state (tagged 16-byte
+// records per body in `dynst`: v, w | pos, q.xyz, q.w) and the accumulated impulses — is stored write-through (sc1; plain when all working
+// workgroups share one XCD) and loaded past the L1 (sc1); what an item waits for are version tags in those records (run_chain_mg), two grid
+// barriers per launch stand behind the set-up and before the write-back (a monotonic agent-scope counter, polled with sc1 loads:
+// MI355X_MICROARCH.md, "Hand-offs measured with sc1 loads in place of the acquire", first row; all G workgroups are resident: G <= 16 blocks
+// of 256 threads on 256 CUs). The schedule, the chain arithmetic and hence the results are those of the single-workgroup kernel, operation
+// for operation.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld16_sc1(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 16);

@@ -107,7 +107,7 @@ __device__ __forceinline__ float combine_t(float a, float b, float s, float q) {
     return SMOOTH ? -smooth_union(-a, -b, s, q) : max_rs(a, b);
 }
 // Element k of a thread's column of a stack level: LDS at d[k * 256] — except, in the trimmed launch of the two-level class
-// (k_sdf_eval<true>), row 15 of the second dense level, which every thread keeps in a register (`r15`; `t` says that this level is
+// (k_sdf_eval<1>), row 15 of the second dense level, which every thread keeps in a register (`r15`; `t` says that this level is
 // that one, wave-uniform). The 768 bytes this saves bring a workgroup's stack from 32 768 to 32 000 bytes, and five of them fit a CU
 // instead of four (LDS is handed out in 1 280-byte granules on this part: measured, sample stage 0.117 -> 0.108 ms).
 #define IVX_LV_GET(d, k, t, r15) (((k) == 15 && (t)) ? (r15) : (d)[(k) * 256])
@@ -993,7 +993,7 @@ __device__ __forceinline__ void combine_levels(uint32_t kind, float s, float q, 
     }
 }
 
-// TRIM: the two-level class, with row 15 of the second dense level in registers (IVX_LV_GET); `scratch_off`: offset (floats) of sixteen
+// MODE 0: the general class (as many levels as the program's stack). MODE 1 (TRIM): the two-level class, with row 15 of the second dense level in registers (IVX_LV_GET); `scratch_off`: offset (floats) of sixteen
 // words of LDS behind / at the tail of the stack: [0..5) the published test voxels of a register row, [8..12) the classification's votes
 // MODE 2: the one-level class (programs whose only operands with a level of their own are fused away, see eval_leaf_fused): 16 KB + the
 // scratch words, eight workgroups per CU.

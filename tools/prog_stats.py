@@ -35,7 +35,7 @@ def main():
     assert hip.hipMemcpy(ops.ctypes.data_as(C.c_void_p), C.c_void_p(lib.ivx_grid_device_ptr(obj.h, 8)), ops.nbytes, 2) == 0
     cnt = lens[n + 8:n + 16]  # (the counters as the derive sweep rolled them over: [0..3) lists, [3] long, [4] short entries of the first)
     counts = cnt[:3]
-    print("evaluation lists (<=2 levels, 3, more):", counts.tolist())
+    print("evaluation lists (one level, two, more):", counts.tolist())
     names = {}
     tot = np.zeros(16, dtype=np.int64)
     per_chunk = []
@@ -79,7 +79,7 @@ def main():
     per_chunk = np.array(per_chunk)
     print("chunks", len(per_chunk), "ops per chunk by opcode (mean):", {i: round(float(per_chunk[:, i].mean()), 2) for i in range(16) if tot[i]})
     print("combinations with a bare leaf as second operand: applied", int(fus[0]), "behind the test", int(fus[1]), "| other", int(fus[2]))
-    print("LDS levels needed now:", np.bincount(need_now).tolist(), "with leaf + combination fused:", np.bincount(need_fused).tolist())
+    print("LDS levels without the leaf + combination fusion:", np.bincount(need_now).tolist(), "with it (what the pre-pass counts):", np.bincount(need_fused).tolist())
     print("programs that would still need >= 2 levels:", sorted(shapes.items(), key=lambda kv: -kv[1])[:12])
     print("program length percentiles:", [int(np.percentile(per_chunk.sum(1), q)) for q in (10, 50, 90, 100)])
 
