@@ -2239,6 +2239,9 @@ static int step_enqueue(ivx_grid* g, uint32_t stages, const uint16_t* slab_nbr_i
     IVX_REQUIRE(!(stages & IVX_STAGE_SAMPLE) || g->prog_n > 0, IVX_ERR_STATE, "ivx_voxel_step: no SDF program resident (ivx_grid_set_sdf_program)");
     IVX_REQUIRE(!(stages & IVX_STAGE_INERTIA) || g->has_dens, IVX_ERR_STATE, "ivx_voxel_step: no densities resident (ivx_grid_set_densities)");
     hipStream_t s = g->ctx->stream;
+    // stages enqueued after a record change the step's results: the block the record role wrote is stale (this call sets the flag again
+    // further down when it carries the slab record itself)
+    g->results_in_block = 0;
     if (!g->ev_ready) {
         for (int i = 0; i < 2 * IVX_N_TIMED_STAGES; ++i) IVX_HIP_CHECK(hipEventCreate(&g->ev[i]));
         g->ev_ready = 1;
@@ -2296,7 +2299,7 @@ static int step_enqueue(ivx_grid* g, uint32_t stages, const uint16_t* slab_nbr_i
                                                               : 0u;
     if (stages & IVX_STAGE_SAMPLE) {
         T0(0);
-        if ((rc = ivx_launch_sdf_sample(g, g->prog_nodes, g->prog_n, g->prog_stack, g->prog_shape, g->prog_center, g->prog_type, preset_in_sample))) return rc;
+        if ((rc = ivx_launch_sdf_sample(g, g->prog_nodes, g->prog_n, g->prog_stack, g->prog_shape, g->prog_center, g->prog_type, preset_in_sample, true))) return rc;
         T1(0);
         g->eval_len_pending = 1;  // (the list lengths reach the result block once a derive sweep has rolled the counters over)
         g->occ_ref_valid = 0;

@@ -322,7 +322,8 @@ static inline GridView ivx_view(const ivx_grid* g) {
 // kernels (one launcher per stage; all asynchronous on ctx->stream)
 int ivx_launch_classify(ivx_grid* g);
 int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, uint32_t n_nodes, uint32_t stack_size,
-                          const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type, uint32_t preset_groups = 0);
+                          const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type, uint32_t preset_groups = 0,
+                          bool resident_program = false);
 // parts of the fused sweep: k_derive can label the chunk-local regions and compute the chunk moments of the chunks it visits
 #define IVX_PART_REGIONS 1u
 #define IVX_PART_MOMENTS 2u

@@ -808,10 +808,14 @@ __device__ __forceinline__ void run_chain_mg(uint32_t item, uint2 bodies, uint32
         const PhysContact q = pcs[s0 + c];
         float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (with_acc)
-            for (uint32_t spins = 0; spins <= MG_SPIN_LIMIT; ++spins) {
+            for (uint32_t spins = 0;; ++spins) {
                 a = ld16_sc1(rs_acc, (s0 + c) * 16u);
                 if (no_wait || __float_as_uint(a.w) == acc_in) break;
                 __builtin_amdgcn_s_sleep(1);
+                if (spins > MG_SPIN_LIMIT) {  // like the other bounded spins: give up, flag the launch (ivx_world_check_solve)
+                    __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
             }
         run_contact(type, q, st, x, factor, a);
         if (store_acc) {

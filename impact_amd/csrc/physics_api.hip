@@ -298,14 +298,6 @@ int ivx_world_create(ivx_ctx* c, const ivx_solver_config* cfg, ivx_world** out) 
         hipHostGetDevicePointer(reinterpret_cast<void**>(&w->mg_err_dev), w->mg_err_host, 0) != hipSuccess) {
         ivx_set_error("ivx_world_create: host-mapped allocation failed");
         if (w->mg_err_host) (void)hipHostFree(w->mg_err_host);
-    if (w->side_stream) {
-        (void)hipStreamSynchronize(w->side_stream);
-        (void)hipEventDestroy(w->ev_fork);
-        (void)hipEventDestroy(w->ev_join);
-        (void)hipStreamDestroy(w->side_stream);
-    }
-    if (w->stage_contacts) (void)hipHostFree(w->stage_contacts);
-    if (w->stage_ev_ready) (void)hipEventDestroy(w->stage_ev);
         (void)hipFree(w->barrier_words);
         delete w;
         return IVX_ERR_HIP;
@@ -319,6 +311,14 @@ int ivx_world_create(ivx_ctx* c, const ivx_solver_config* cfg, ivx_world** out) 
 void ivx_world_destroy(ivx_world* w) {
     if (!w) return;
     (void)hipStreamSynchronize(w->ctx->stream);
+    if (w->side_stream) {  // the positional phase's stream and its fork / join events (created on the first multi-workgroup solve)
+        (void)hipStreamSynchronize(w->side_stream);
+        (void)hipEventDestroy(w->ev_fork);
+        (void)hipEventDestroy(w->ev_join);
+        (void)hipStreamDestroy(w->side_stream);
+    }
+    if (w->stage_contacts) (void)hipHostFree(w->stage_contacts);  // pinned staging of the set_contacts fast path
+    if (w->stage_ev_ready) (void)hipEventDestroy(w->stage_ev);
     void* ptrs[] = {w->dyn, w->kin, w->cb, w->touched, w->contacts, w->prev_slot, w->pc[0], w->pc[1], w->acc[0], w->acc[1], w->items, w->item_bodies, w->item_tags, w->level_start,
                     w->dynst, w->barrier_words, w->joint_refs, w->tile_base, w->tile_first, w->packed[0], w->packed[1], w->kin_offsets, w->kin_list,
                     w->kin_applied, w->kin_qstart, w->kin_snap};
@@ -387,6 +387,7 @@ int ivx_world_set_bodies(ivx_world* w, const ivx_rigid_body* dyn, size_t n_dyn, 
         (void)hipFree(w->joint_refs);
         w->joint_refs = nullptr;
         w->n_joint_refs = 0;
+        w->joint_refs_host.clear();
     }
     w->n_dyn = (uint32_t)n_dyn;
     w->n_kin = (uint32_t)n_kin;

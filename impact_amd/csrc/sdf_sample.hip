@@ -1233,7 +1233,8 @@ int ivx_sampler_buffers(ivx_grid* g) {
 ivx_roles::PresetArgs ivx_preset_args(ivx_grid* g, uint32_t groups);  // derive.hip
 
 int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, uint32_t n_nodes, uint32_t stack_size,
-                          const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type, uint32_t preset_groups) {
+                          const uint32_t shape[3], const float shifted_center[3], uint8_t voxel_type, uint32_t preset_groups,
+                          bool resident_program) {
     SampleParams p;
     p.cx = g->cc[0];
     p.cy = g->cc[1];
@@ -1295,7 +1296,9 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
         // under this program found empty (the lists are a function of the program and the grid). Two launches one after the other each pay
         // their own ramp and tail: when both of the first two classes have work and one of them is too short to fill the chip a few times
         // over, the two-level kernel takes both lists in one launch (the one-level programs run there as well, five workgroups per CU).
-        const bool known = g->eval_len_valid != 0;
+        // (`resident_program`: the step path. The remembered lengths are the RESIDENT program's; ivx_sdf_sample runs any program through
+        // this launcher and must launch every class that program can reach)
+        const bool known = resident_program && g->eval_len_valid != 0;
         // (grids: a whole number of list entries per workgroup once the lists' lengths are known — a launch's last wave of workgroups costs as
         // much as a full one, see ivx_launch_derive)
         auto fit = [&](uint32_t n) {

@@ -28,7 +28,9 @@
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "ivx_internal.hpp"
@@ -114,10 +116,14 @@ struct IpcRank {
     std::atomic<unsigned long long> rec_seq;      // records published
     std::atomic<unsigned long long> rec_read;     // gathers this rank has finished reading (the others may overwrite their slots)
     unsigned long long record[IPC_MAX_REC_WORDS];
+    // rendezvous handshake: a rank writes a fresh random token into `hello`; rank 0 — the creator of THIS block — echoes it into
+    // `hello_ack`. A stale block of the same name left by a crashed run never echoes a fresh token: the rank re-opens the name until it sits
+    // on the block rank 0 made for this run.
+    std::atomic<unsigned long long> hello, hello_ack;
+    std::atomic<unsigned long long> opened;  // handle imports of this rank's `posted` generations that its neighbours have finished
 };
 struct IpcShared {
     std::atomic<unsigned long long> magic;  // set last by rank 0
-    std::atomic<unsigned long long> attached;
     IpcRank ranks[IPC_MAX_RANKS];
 };
 constexpr unsigned long long IPC_MAGIC = 0x4956585F49504331ull;
@@ -131,6 +137,9 @@ struct ivx_comm {
     char ipc_name[96];
     unsigned long long ipc_recv_seq[2], ipc_send_seq[2], ipc_rec_seq;  // messages expected in / put from this rank, records gathered
     void* ipc_peer_recv[2];  // neighbour rank - 1's recv[1], neighbour rank + 1's recv[0], opened in this process
+    unsigned long long ipc_slab_gen;  // slabs created on this communicator (ivx_slab_create is collective: every rank counts alike)
+    std::thread* ipc_acker;           // rank 0: answers the other ranks' hellos (they may arrive at any time before their first exchange)
+    std::atomic<int> ipc_acker_stop;
 };
 
 struct ivx_slab {
@@ -382,18 +391,70 @@ int ivx_comm_init_ipc(ivx_ctx* c, int nranks, int rank, const char* name, ivx_co
     snprintf(m->ipc_name, sizeof(m->ipc_name), "%s", name);
     for (int s = 0; s < 2; ++s) m->ipc_recv_seq[s] = m->ipc_send_seq[s] = 0, m->ipc_peer_recv[s] = nullptr;
     m->ipc_rec_seq = 0;
-    int fd = -1;
+    m->ipc_slab_gen = 0;
+    m->ipc_acker = nullptr;
+    m->ipc_acker_stop.store(0);
+    auto map_block = [&](int fd) -> IpcShared* {
+        void* p = mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        return p == MAP_FAILED ? nullptr : static_cast<IpcShared*>(p);
+    };
     if (rank == 0) {
-        (void)shm_unlink(name);
-        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        // the block is made under a private name, initialised, and only then given the name the others open: nobody ever maps a
+        // half-made block, and a stale one of the same name is replaced atomically
+        char tmp[128];
+        snprintf(tmp, sizeof(tmp), "%s.%ld.tmp", name, (long)getpid());
+        (void)shm_unlink(tmp);
+        int fd = shm_open(tmp, O_CREAT | O_EXCL | O_RDWR, 0600);
         if (fd >= 0 && ftruncate(fd, (off_t)sizeof(IpcShared)) != 0) {
             close(fd);
             fd = -1;
         }
+        IpcShared* sh = fd >= 0 ? map_block(fd) : nullptr;
+        if (fd >= 0) close(fd);
+        if (!sh) {
+            (void)shm_unlink(tmp);
+            ivx_set_error("ivx_comm_init_ipc: shared memory %s not available (rank 0)", name);
+            delete m;
+            return IVX_ERR_STATE;
+        }
+        memset(static_cast<void*>(sh), 0, sizeof(IpcShared));  // (all-zero is the initial state of every counter)
+        sh->magic.store(IPC_MAGIC, std::memory_order_release);
+        char from[160], to[160];
+        snprintf(from, sizeof(from), "/dev/shm%s", tmp);
+        snprintf(to, sizeof(to), "/dev/shm%s", name);
+        if (rename(from, to) != 0) {  // (POSIX shared memory lives under /dev/shm on Linux; rename replaces a stale block in one step)
+            munmap(sh, sizeof(IpcShared));
+            (void)shm_unlink(tmp);
+            ivx_set_error("ivx_comm_init_ipc: could not publish the rendezvous block %s", name);
+            delete m;
+            return IVX_ERR_STATE;
+        }
+        m->ipc = sh;
+        if (nranks > 1) {
+            m->ipc_acker = new (std::nothrow) std::thread([m, nranks] {
+                int acked = 1;
+                while (!m->ipc_acker_stop.load(std::memory_order_acquire) && acked < nranks) {
+                    acked = 1;
+                    for (int r = 1; r < nranks; ++r) {
+                        const unsigned long long h = m->ipc->ranks[r].hello.load(std::memory_order_acquire);
+                        if (h && m->ipc->ranks[r].hello_ack.load(std::memory_order_relaxed) != h) m->ipc->ranks[r].hello_ack.store(h, std::memory_order_release);
+                        if (h) acked += 1;
+                    }
+                    usleep(50);
+                }
+            });
+        }
     } else {
+        // open by name, say hello with a token no earlier run can have used, wait for rank 0's echo; no echo within a moment = this may be a
+        // stale block: look the name up again
         const auto t0 = std::chrono::steady_clock::now();
-        while (fd < 0) {  // until rank 0 has made it
-            fd = shm_open(name, O_RDWR, 0600);
+        unsigned long long token = ((unsigned long long)getpid() << 32) ^ (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
+        token |= 1ull;
+        IpcShared* sh = nullptr;
+        ino_t ino = 0;
+        for (;;) {
+            if (std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t0).count() > 60) break;
+            int fd = shm_open(name, O_RDWR, 0600);
             struct stat st;
             if (fd >= 0 && (fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof(IpcShared))) {
                 close(fd);
@@ -401,32 +462,38 @@ int ivx_comm_init_ipc(ivx_ctx* c, int nranks, int rank, const char* name, ivx_co
             }
             if (fd < 0) {
                 usleep(1000);
-                if (std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t0).count() > 60) break;
+                continue;
+            }
+            if (sh && st.st_ino == ino) {  // still the block we are waiting on
+                close(fd);
+            } else {
+                if (sh) munmap(sh, sizeof(IpcShared));
+                sh = map_block(fd);
+                close(fd);
+                if (!sh) break;
+                ino = st.st_ino;
+                if (sh->magic.load(std::memory_order_acquire) == IPC_MAGIC) sh->ranks[rank].hello.store(token, std::memory_order_release);
+            }
+            bool ok = false;
+            for (int it = 0; it < 200 && !ok; ++it) {  // ~20 ms on this block, then check the name again
+                if (sh->magic.load(std::memory_order_acquire) == IPC_MAGIC) {
+                    if (sh->ranks[rank].hello.load(std::memory_order_relaxed) != token) sh->ranks[rank].hello.store(token, std::memory_order_release);
+                    ok = sh->ranks[rank].hello_ack.load(std::memory_order_acquire) == token;
+                }
+                if (!ok) usleep(100);
+            }
+            if (ok) {
+                m->ipc = sh;
+                break;
             }
         }
+        if (!m->ipc) {
+            if (sh) munmap(sh, sizeof(IpcShared));
+            ivx_set_error("ivx_comm_init_ipc: rank 0 did not answer on shared memory %s within 60 s (rank %d)", name, rank);
+            delete m;
+            return IVX_ERR_STATE;
+        }
     }
-    if (fd < 0) {
-        ivx_set_error("ivx_comm_init_ipc: shared memory %s not available (rank %d)", name, rank);
-        delete m;
-        return IVX_ERR_STATE;
-    }
-    void* p = mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (p == MAP_FAILED) {
-        ivx_set_error("ivx_comm_init_ipc: mmap failed");
-        delete m;
-        return IVX_ERR_STATE;
-    }
-    m->ipc = static_cast<IpcShared*>(p);
-    if (rank == 0) {
-        memset(p, 0, sizeof(IpcShared));  // (all-zero is the initial state of every counter)
-        m->ipc->magic.store(IPC_MAGIC, std::memory_order_release);
-    } else if (!ipc_wait([&] { return m->ipc->magic.load(std::memory_order_acquire) == IPC_MAGIC; }, "rank 0 to initialise the rendezvous block")) {
-        munmap(p, sizeof(IpcShared));
-        delete m;
-        return IVX_ERR_STATE;
-    }
-    m->ipc->attached.fetch_add(1);
     *out = m;
     return IVX_OK;
 }
@@ -507,6 +574,11 @@ void ivx_comm_destroy(ivx_comm* m) {
     if (!m) return;
     if (m->nccl) (void)g_rccl.CommDestroy(m->nccl);
     if (m->ipc) {
+        if (m->ipc_acker) {
+            m->ipc_acker_stop.store(1, std::memory_order_release);
+            m->ipc_acker->join();
+            delete m->ipc_acker;
+        }
         for (int s = 0; s < 2; ++s)
             if (m->ipc_peer_recv[s]) (void)hipIpcCloseMemHandle(m->ipc_peer_recv[s]);
         munmap(m->ipc, sizeof(IpcShared));
@@ -558,17 +630,30 @@ int ivx_slab_create(ivx_comm* m, ivx_grid* g, int rank, ivx_slab** out) {
     }
     if (m->ipc) {  // shared-device transport (collective: every rank creates its slab): publish the receive buffers, open the neighbours'
         IpcRank& me = m->ipc->ranks[rank];
+        // a further slab on the same communicator: the handles of the last one must have been imported by every neighbour before they are
+        // replaced, and the neighbours' imports of that generation are closed here
+        const unsigned long long gen = ++m->ipc_slab_gen;
+        const unsigned long long n_nbr = (sl->has_lo ? 1u : 0u) + (sl->has_hi ? 1u : 0u);
+        if (!ipc_wait([&] { return me.opened.load(std::memory_order_acquire) >= n_nbr * (gen - 1); }, "the neighbours to import the previous slab's buffers")) {
+            ivx_slab_destroy(sl);
+            return IVX_ERR_STATE;
+        }
+        for (int s = 0; s < 2; ++s)
+            if (m->ipc_peer_recv[s]) {
+                (void)hipIpcCloseMemHandle(m->ipc_peer_recv[s]);
+                m->ipc_peer_recv[s] = nullptr;
+            }
         for (int s = 0; s < 2; ++s)
             if (hipIpcGetMemHandle(&me.recv[s], sl->recv[s]) != hipSuccess) {
                 ivx_set_error("ivx_slab_create: hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 must be set on this pool)");
                 ivx_slab_destroy(sl);
                 return IVX_ERR_HIP;
             }
-        me.posted.store(1, std::memory_order_release);
+        me.posted.store(gen, std::memory_order_release);
         for (int s = 0; s < 2; ++s) {
             if (!(s ? sl->has_hi : sl->has_lo)) continue;
             const int peer = s ? rank + 1 : rank - 1;
-            if (!ipc_wait([&] { return m->ipc->ranks[peer].posted.load(std::memory_order_acquire) == 1; }, "a neighbour's slab")) {
+            if (!ipc_wait([&] { return m->ipc->ranks[peer].posted.load(std::memory_order_acquire) >= gen; }, "a neighbour's slab")) {
                 ivx_slab_destroy(sl);
                 return IVX_ERR_STATE;
             }
@@ -577,6 +662,7 @@ int ivx_slab_create(ivx_comm* m, ivx_grid* g, int rank, ivx_slab** out) {
                 ivx_slab_destroy(sl);
                 return IVX_ERR_HIP;
             }
+            m->ipc->ranks[peer].opened.fetch_add(1, std::memory_order_release);
         }
     }
     *out = sl;

@@ -310,3 +310,45 @@ def test_step_results_with_and_without_stage_events(ctx, scene):
         got = obj.step_collect()
         for f in fields:
             np.testing.assert_array_equal(np.asarray(got[f]), np.asarray(want[f]), err_msg=f)
+
+
+def test_sample_of_another_program_after_a_stepped_object(ctx):
+    """`ivx_sdf_sample` runs ANY program through the sampler's launcher; the list lengths the step path remembers belong to the
+    resident program (A: one sphere, every chunk in the one-level class) and must not decide which evaluation classes a different
+    program (B: nested smooth unions that need three levels) gets launched with."""
+    from impact_amd import capi
+    from impact_amd.voxel import SDFVoxelGenerator
+
+    def offset_sphere(g, r, t):
+        return g.add_node(SDFNode.new_translation(g.add_node(SDFNode.new_sphere(r)), t))
+
+    gb = SDFGraph()
+    c = offset_sphere(gb, 20.0, (-6.0, 0.0, 0.0))
+    d = offset_sphere(gb, 20.0, (6.0, 0.0, 0.0))
+    cd = gb.add_node(SDFNode.new_union(c, d, 6.0))
+    e = offset_sphere(gb, 20.0, (0.0, 6.0, 0.0))
+    f = offset_sphere(gb, 20.0, (0.0, -6.0, 0.0))
+    h = offset_sphere(gb, 20.0, (0.0, 0.0, 6.0))
+    fh = gb.add_node(SDFNode.new_union(f, h, 6.0))
+    efh = gb.add_node(SDFNode.new_union(e, fh, 6.0))
+    gb.add_node(SDFNode.new_union(cd, efh, 6.0))
+    gen_b = SDFVoxelGenerator(1.0, gb, 0)
+    gen_a = SDFVoxelGenerator(1.0, scenes.sphere_scene(18.0), 0)
+    assert all(a <= b for a, b in zip(gen_a.grid_shape(), gen_b.grid_shape()))
+    obj = VoxelObject(ctx, gen_b.chunk_counts(), 1.0)
+    obj.set_sdf_program(gen_a)
+    obj.set_densities(np.ones(256, dtype=np.float32))
+    for _ in range(2):  # the lengths of A's lists are known after a collected sample + derive
+        obj.step(capi.STAGE_ALL)
+    obj.sample(gen_b)
+    o = pu.oracle_from_graph(gb)
+    pu.assert_generated_equal(o, obj)
+    o.compute_all_derived_state()
+    obj.compute_all_derived_state()
+    pu.assert_derived_equal(o, obj)
+    # and the resident program still steps to its own result afterwards
+    obj.step(capi.STAGE_ALL)
+    oa = ol.OracleObject.from_sdf(scenes.sphere_scene(18.0), 1.0, 0)
+    sdf_a = oa.export_dense()[0]
+    assert int((obj.download()[0] < 0).sum()) == int((sdf_a < 0).sum())
+    obj.close()
