@@ -155,7 +155,7 @@ EXPORTED_SYMBOLS = [
 
 
 MESH_EXPORT_DTYPE = np.dtype([("ipc_handle", "u1", (64,)), ("dmabuf_fd", "<i4"), ("element_bytes", "<u4"), ("bytes", "<u8"), ("capacity_bytes", "<u8"),
-                              ("generation", "<u8"), ("device_ptr", "<u8")])
+                              ("generation", "<u8"), ("device_ptr", "<u8"), ("dmabuf_offset", "<u8"), ("dmabuf_bytes", "<u8")])
 
 EXTRACTED_OBJECT_DTYPE = np.dtype(
     [

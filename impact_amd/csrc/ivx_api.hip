@@ -14,6 +14,8 @@
 
 #include <type_traits>
 
+#include <dlfcn.h>
+
 #include "ivx_internal.hpp"
 
 static thread_local char g_error[512] = "";
@@ -809,9 +811,25 @@ int ivx_mesh_export(ivx_grid* g, int which, ivx_mesh_export_info* out) {
     // a dma-buf file descriptor for APIs that import those (Vulkan VK_EXT_external_memory_dma_buf under wgpu): optional, -1 where the
     // runtime cannot make one; the caller owns the descriptor (close it)
     int fd = -1;
-    const size_t page = 4096, span = ((size_t)out->capacity_bytes + page - 1) / page * page;
-    if (hipMemGetHandleForAddressRange(&fd, p, span, hipMemRangeHandleTypeDmaBufFd, 0) == hipSuccess && fd >= 0) out->dmabuf_fd = fd;
-    else (void)hipGetLastError();
+    const size_t page = 4096;
+    // The HSA runtime's export names the offset of the range inside the dma-buf object (the HIP call drops it): taken from there when the
+    // symbol is in the process (it is wherever libamdhip64 is: libhsa-runtime64 is its dependency), page-aligned range around the buffer.
+    typedef int (*export_fn)(const void*, size_t, int*, uint64_t*);
+    static export_fn hsa_export = reinterpret_cast<export_fn>(dlsym(RTLD_DEFAULT, "hsa_amd_portable_export_dmabuf"));
+    const uintptr_t lo = (uintptr_t)p & ~(uintptr_t)(page - 1), hi = ((uintptr_t)p + (size_t)out->capacity_bytes + page - 1) & ~(uintptr_t)(page - 1);
+    uint64_t off = 0;
+    if (hsa_export && hsa_export(reinterpret_cast<const void*>(lo), hi - lo, &fd, &off) == 0 && fd >= 0) {
+        out->dmabuf_fd = fd;
+        out->dmabuf_offset = off + ((uintptr_t)p - lo);
+        out->dmabuf_bytes = hi - lo;
+    } else if (hipMemGetHandleForAddressRange(&fd, reinterpret_cast<void*>(lo), hi - lo, hipMemRangeHandleTypeDmaBufFd, 0) == hipSuccess && fd >= 0) {
+        out->dmabuf_fd = fd;
+        out->dmabuf_offset = (uintptr_t)p - lo;  // (the range's own start: this call does not say where the range lies in the object)
+        out->dmabuf_bytes = hi - lo;
+    } else {
+        const hipError_t e = hipGetLastError();
+        ivx_set_error("ivx_mesh_export: no dma-buf descriptor for the buffer (%s); the hipIpc handle is valid", hipGetErrorString(e));
+    }
     return IVX_OK;
 }
 

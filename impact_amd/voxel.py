@@ -556,12 +556,14 @@ class VoxelObjectMesh:
     def export(self, which):
         """`ivx_mesh_export`: handles of one mesh buffer (name or number, see MESH_BUFFERS) for another process / API — dict with `ipc_handle`
         (64 bytes, hipIpcOpenMemHandle), `dmabuf_fd` (-1 if the runtime makes none; the caller closes it), `bytes`, `capacity_bytes`,
-        `element_bytes`, `generation`"""
+        `element_bytes`, `generation`, `dmabuf_offset` / `dmabuf_bytes` (where the buffer lies inside the dma-buf object, how much the
+        descriptor covers)"""
         w = self.MESH_BUFFERS.index(which) if isinstance(which, str) else int(which)
         e = np.zeros((), dtype=capi.MESH_EXPORT_DTYPE)
         check(capi.lib().ivx_mesh_export(self.object.h, w, ptr(e.reshape(1))))
         return {"ipc_handle": bytes(e["ipc_handle"].tobytes()), "dmabuf_fd": int(e["dmabuf_fd"]), "bytes": int(e["bytes"]), "capacity_bytes": int(e["capacity_bytes"]),
-                "element_bytes": int(e["element_bytes"]), "generation": int(e["generation"]), "device_ptr": int(e["device_ptr"])}
+                "element_bytes": int(e["element_bytes"]), "generation": int(e["generation"]), "device_ptr": int(e["device_ptr"]),
+                "dmabuf_offset": int(e["dmabuf_offset"]), "dmabuf_bytes": int(e["dmabuf_bytes"])}
 
     def generation(self) -> int:
         g = C.c_uint64()

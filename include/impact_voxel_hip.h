@@ -179,12 +179,16 @@ void* ivx_mesh_device_ptr(ivx_grid*, int which);
  * (Vulkan / wgpu external memory: VK_EXT_external_memory_dma_buf; -1 where the runtime cannot make one; the caller closes it). `bytes` = the
  * part in use (after ivx_mesh_sync: the capacity, the live ranges are scattered), `generation` changes whenever a buffer was reallocated
  * (growth in ivx_remesh / ivx_voxel_step_collect / ivx_mesh_sync): handles of an older generation name freed memory — ask
- * ivx_mesh_generation every frame (no device work) and export again when it moved. which: as ivx_mesh_device_ptr. */
+ * ivx_mesh_generation every frame (no device work) and export again when it moved. which: as ivx_mesh_device_ptr.
+ * `dmabuf_offset` / `dmabuf_bytes`: where the buffer lies inside the exported dma-buf object and how many bytes of it the descriptor
+ * covers — the runtime exports whole pages of the underlying allocation, so a consumer binds [dmabuf_offset, dmabuf_offset + capacity_bytes)
+ * of the imported memory (VkBindBufferMemory's memoryOffset). */
 typedef struct {
     uint8_t ipc_handle[64];
     int32_t dmabuf_fd;
     uint32_t element_bytes;
     uint64_t bytes, capacity_bytes, generation, device_ptr;
+    uint64_t dmabuf_offset, dmabuf_bytes;
 } ivx_mesh_export_info;
 int ivx_mesh_export(ivx_grid*, int which, ivx_mesh_export_info* out);
 int ivx_mesh_generation(ivx_grid*, uint64_t* generation);

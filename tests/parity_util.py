@@ -125,7 +125,7 @@ def fuzzing() -> bool:
     return bool(os.environ.get("IVX_FUZZ_SEEDS"))
 
 
-def step_parity(o: ol.OracleObject, g: VoxelObject, res, densities=None) -> dict:
+def step_parity(o: ol.OracleObject, g: VoxelObject, res, densities=None, mesh=None) -> dict:
     """What one `ivx_voxel_step(STAGE_ALL)` left on the device against the oracle object built from the same SDF (derived state
     computed): sha-256 of the voxel bytes, chunk records, chunk-local labels, triangle index buffer, vertex positions; counts;
     relative error of the ten moments against the f64 oracle. Used by bench.py's `parity` fields and by the 512^3 parity test —
@@ -137,7 +137,7 @@ def step_parity(o: ol.OracleObject, g: VoxelObject, res, densities=None) -> dict
 
     o_sdf, o_typ, o_flg, o_lab, o_info = o.export_dense()
     g_sdf, g_typ, g_flg, g_lab, g_info = g.download()
-    om = o.mesh()
+    om = mesh if mesh is not None else o.mesh()  # (`mesh`: the oracle mesh the caller already has, e.g. from the all-cores entry point)
     gm = VoxelObjectMesh(g)
     gm.counts = res["mesh"]
     pos, nrm, idx, im, sub = gm.download()

@@ -9,7 +9,7 @@ import tempfile
 import numpy as np
 import pytest
 
-from impact_amd import scenes
+from impact_amd import capi, scenes
 from impact_amd.voxel import SDFVoxelGenerator, VoxelObject, VoxelObjectMesh
 
 pytestmark = pytest.mark.gpu
@@ -31,6 +31,27 @@ def import_in_another_process(mesh, tmp, tag):
     return exp, np.load(out)
 
 
+def import_through_libdrm(exp, tmp, tag):
+    """the dma-buf leg: a process without HIP (tests/cpp/dmabuf_import: libdrm_amdgpu's amdgpu_bo_import + amdgpu_bo_cpu_map, the kernel graphics
+    driver's own API — what a Vulkan driver does underneath VK_EXT_external_memory_dma_buf) inherits the descriptor, imports it and returns the
+    buffer's bytes [dmabuf_offset, dmabuf_offset + bytes)"""
+    exe = os.path.join(HERE, "cpp", "dmabuf_import")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(HERE, "cpp"), "dmabuf_import"])
+    got = {}
+    for n in NAMES:
+        fd = exp[n]["dmabuf_fd"]
+        assert fd >= 0, f"ivx_mesh_export made no dma-buf descriptor for {n} on this box: {capi.lib().ivx_last_error().decode()}"
+        assert "dmabuf" in os.readlink(f"/proc/self/fd/{fd}")
+        assert exp[n]["dmabuf_bytes"] >= exp[n]["dmabuf_offset"] % 4096 + exp[n]["capacity_bytes"]
+        out = os.path.join(tmp, f"drm_{tag}_{n}.bin")
+        r = subprocess.run([exe, str(fd), str(exp[n]["dmabuf_offset"]), str(exp[n]["bytes"]), out], pass_fds=(fd,), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, f"non-HIP import of {n} failed:\n{r.stderr[-3000:]}"
+        got[n] = np.fromfile(out, dtype=np.uint8)
+        os.close(fd)
+    return got
+
+
 def test_mesh_buffers_imported_by_another_process(ctx):
     g = VoxelObject.generate(ctx, SDFVoxelGenerator(1.0, scenes.sphere_scene(30.0), 0))
     try:
@@ -41,11 +62,10 @@ def test_mesh_buffers_imported_by_another_process(ctx):
             for n in NAMES:
                 assert exp[n]["bytes"] == want[n].nbytes and exp[n]["capacity_bytes"] >= exp[n]["bytes"]
                 np.testing.assert_array_equal(got[n], np.ascontiguousarray(want[n]).view(np.uint8).reshape(-1), err_msg=n)
-                fd = exp[n]["dmabuf_fd"]
-                if fd >= 0:  # a dma-buf descriptor where the runtime makes one: it is one, and it covers the buffer
-                    assert "dmabuf" in os.readlink(f"/proc/self/fd/{fd}")
-                    assert os.fstat(fd).st_size == 0 or os.fstat(fd).st_size >= exp[n]["bytes"]
-                    os.close(fd)
+            # ... and the same bytes through the dma-buf descriptor, imported WITHOUT HIP (the renderer's leg)
+            drm = import_through_libdrm(exp, tmp, "full")
+            for n in NAMES:
+                np.testing.assert_array_equal(drm[n], np.ascontiguousarray(want[n]).view(np.uint8).reshape(-1), err_msg=n + " through the dma-buf descriptor")
             gen0 = mesh.generation()
             assert all(exp[n]["generation"] == gen0 for n in NAMES)
             # an edit and the incremental remesh: live ranges move inside the (possibly regrown) buffers; the renderer re-imports when the
@@ -59,7 +79,9 @@ def test_mesh_buffers_imported_by_another_process(ctx):
             for n, w in zip(NAMES, (pos, nrm, idx, im, sub)):
                 wb = np.ascontiguousarray(w).view(np.uint8).reshape(-1)
                 np.testing.assert_array_equal(got2[n][:wb.size], wb, err_msg=n + " after sync")
-                if exp2[n]["dmabuf_fd"] >= 0:
-                    os.close(exp2[n]["dmabuf_fd"])
+            drm2 = import_through_libdrm(exp2, tmp, "sync")
+            for n, w in zip(NAMES, (pos, nrm, idx, im, sub)):
+                wb = np.ascontiguousarray(w).view(np.uint8).reshape(-1)
+                np.testing.assert_array_equal(drm2[n][:wb.size], wb, err_msg=n + " after sync, through the dma-buf descriptor")
     finally:
         g.close()
