@@ -110,6 +110,7 @@ constexpr size_t IPC_MAX_REC_WORDS = 28 + 2 * (size_t)IVX_MAX_FACE_PAIRS;
 // the rendezvous block of the shared-device transport (POSIX shared memory; created and zeroed by rank 0)
 struct IpcRank {
     hipIpcMemHandle_t recv[2];               // this rank's receive buffers, for its neighbours to open
+    unsigned long long pid, recv_ptr[2];     // ... and as plain pointers for a neighbour rank living in the same process (a handle is not opened by its maker)
     std::atomic<unsigned long long> posted;  // slabs created: handles are valid
     std::atomic<unsigned long long> sent[2];      // messages that have fully arrived in recv[side]
     std::atomic<unsigned long long> consumed[2];  // messages of recv[side] whose readers have finished (the buffer may be overwritten)
@@ -137,6 +138,7 @@ struct ivx_comm {
     char ipc_name[96];
     unsigned long long ipc_recv_seq[2], ipc_send_seq[2], ipc_rec_seq;  // messages expected in / put from this rank, records gathered
     void* ipc_peer_recv[2];  // neighbour rank - 1's recv[1], neighbour rank + 1's recv[0], opened in this process
+    int ipc_peer_same_process[2];     // ipc_peer_recv[s] is the neighbour's own pointer (same process): nothing to close
     unsigned long long ipc_slab_gen;  // slabs created on this communicator (ivx_slab_create is collective: every rank counts alike)
     std::thread* ipc_acker;           // rank 0: answers the other ranks' hellos (they may arrive at any time before their first exchange)
     std::atomic<int> ipc_acker_stop;
@@ -389,7 +391,7 @@ int ivx_comm_init_ipc(ivx_ctx* c, int nranks, int rank, const char* name, ivx_co
     m->nccl = nullptr;
     m->ipc = nullptr;
     snprintf(m->ipc_name, sizeof(m->ipc_name), "%s", name);
-    for (int s = 0; s < 2; ++s) m->ipc_recv_seq[s] = m->ipc_send_seq[s] = 0, m->ipc_peer_recv[s] = nullptr;
+    for (int s = 0; s < 2; ++s) m->ipc_recv_seq[s] = m->ipc_send_seq[s] = 0, m->ipc_peer_recv[s] = nullptr, m->ipc_peer_same_process[s] = 0;
     m->ipc_rec_seq = 0;
     m->ipc_slab_gen = 0;
     m->ipc_acker = nullptr;
@@ -580,7 +582,7 @@ void ivx_comm_destroy(ivx_comm* m) {
             delete m->ipc_acker;
         }
         for (int s = 0; s < 2; ++s)
-            if (m->ipc_peer_recv[s]) (void)hipIpcCloseMemHandle(m->ipc_peer_recv[s]);
+            if (m->ipc_peer_recv[s] && !m->ipc_peer_same_process[s]) (void)hipIpcCloseMemHandle(m->ipc_peer_recv[s]);
         munmap(m->ipc, sizeof(IpcShared));
         if (m->rank == 0) (void)shm_unlink(m->ipc_name);
     }
@@ -640,8 +642,9 @@ int ivx_slab_create(ivx_comm* m, ivx_grid* g, int rank, ivx_slab** out) {
         }
         for (int s = 0; s < 2; ++s)
             if (m->ipc_peer_recv[s]) {
-                (void)hipIpcCloseMemHandle(m->ipc_peer_recv[s]);
+                if (!m->ipc_peer_same_process[s]) (void)hipIpcCloseMemHandle(m->ipc_peer_recv[s]);
                 m->ipc_peer_recv[s] = nullptr;
+                m->ipc_peer_same_process[s] = 0;
             }
         for (int s = 0; s < 2; ++s)
             if (hipIpcGetMemHandle(&me.recv[s], sl->recv[s]) != hipSuccess) {
@@ -649,6 +652,8 @@ int ivx_slab_create(ivx_comm* m, ivx_grid* g, int rank, ivx_slab** out) {
                 ivx_slab_destroy(sl);
                 return IVX_ERR_HIP;
             }
+        me.pid = (unsigned long long)getpid();
+        for (int s = 0; s < 2; ++s) me.recv_ptr[s] = (unsigned long long)(uintptr_t)sl->recv[s];
         me.posted.store(gen, std::memory_order_release);
         for (int s = 0; s < 2; ++s) {
             if (!(s ? sl->has_hi : sl->has_lo)) continue;
@@ -657,7 +662,10 @@ int ivx_slab_create(ivx_comm* m, ivx_grid* g, int rank, ivx_slab** out) {
                 ivx_slab_destroy(sl);
                 return IVX_ERR_STATE;
             }
-            if (hipIpcOpenMemHandle(&m->ipc_peer_recv[s], m->ipc->ranks[peer].recv[s ? 0 : 1], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+            if (m->ipc->ranks[peer].pid == (unsigned long long)getpid()) {  // several ranks of one process (one context each): the pointer itself
+                m->ipc_peer_recv[s] = reinterpret_cast<void*>((uintptr_t)m->ipc->ranks[peer].recv_ptr[s ? 0 : 1]);
+                m->ipc_peer_same_process[s] = 1;
+            } else if (hipIpcOpenMemHandle(&m->ipc_peer_recv[s], m->ipc->ranks[peer].recv[s ? 0 : 1], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
                 ivx_set_error("ivx_slab_create: hipIpcOpenMemHandle failed (rank %d -> %d)", rank, peer);
                 ivx_slab_destroy(sl);
                 return IVX_ERR_HIP;

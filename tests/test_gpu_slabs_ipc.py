@@ -81,3 +81,45 @@ def test_native_protocol_as_separate_processes(scene, world, regions):
             glab.append(out)
         glab = ol.tiled_to_dense(np.concatenate(glab), cc)
         np.testing.assert_array_equal(ol.canonicalize_labels(glab, 0xFFFFFFFF), ol.canonicalize_labels(olab, 0xFFFFFFFF))
+
+
+def test_config5_1024_as_8_ranks():
+    """BASELINE config 5 (the 1024^3 grid, 8 x-slabs of 8 chunk planes) through the native protocol as EIGHT ranks across process boundaries:
+    four fresh processes of two ranks each (one thread and one context per rank; the GPU box allows six processes on its card), every rank's
+    voxel planes and the protocol's global results against the oracle's digests of that grid (tests/golden/config5_golden.json)."""
+    import json
+
+    gold = json.load(open(os.path.join(HERE, "golden", "config5_golden.json")))
+    m64 = np.array([float.fromhex(x) for x in gold["moments64"]])
+    world, per_proc = 8, 2
+    with tempfile.TemporaryDirectory() as tmp:
+        name = f"/ivx_ipc_{os.getpid()}_config5"
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "ipc_slab_worker8.py"), str(f), str(per_proc), str(world), name, "4.2", "2",
+                                   os.path.join(tmp, f"p{f}.json")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                 for f in range(0, world, per_proc)]
+        outs = []
+        for p in procs:
+            try:
+                outs.append(p.communicate(timeout=900)[0])
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+        assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+        ranks = [r for f in range(0, world, per_proc) for r in json.load(open(os.path.join(tmp, f"p{f}.json")))]
+    assert [r["rank"] for r in ranks] == list(range(world))
+    want_occ = [x for r in gold["occupied_chunk_ranges"] for x in r] + [x for r in gold["occupied_voxel_ranges"] for x in r]
+    voff = ioff = 0
+    for r in ranks:
+        assert r["comm"] == {"transport": "shared-device", "nranks": world, "rank": r["rank"]}
+        assert r["x_range"] == [8 * r["rank"], 8 * r["rank"] + 8]
+        assert r["voxel_sha"] == gold["slab_voxel_sha"][r["rank"]], f"slab {r['rank']}"
+        assert r["region_count"] == gold["regions"] and r["total_triangles"] == gold["triangles"]
+        assert r["occupied"] == want_occ
+        assert r["moments"] == ranks[0]["moments"]  # the same bits on every rank
+        assert (r["vertex_offset"], r["index_offset"]) == (voff, ioff)  # this slab's place in the concatenated mesh
+        voff, ioff = voff + r["vertices"], ioff + r["indices"]
+    assert voff == gold["vertices"] and ioff == 3 * gold["triangles"]
+    g64 = np.array([float.fromhex(x) for x in ranks[0]["moments"]])
+    assert float(np.max(np.abs(g64 - m64) / np.maximum(np.abs(m64), 1e-300))) <= 1e-5
