@@ -130,6 +130,10 @@ struct DeriveLoads {
     uint4 own_sd, own_types, nrow;
     uint32_t gen_lo, gen_hi, by_lo, by_hi, ngen, type0;
 };
+// SIGNS: the sampler left the sign rows of every chunk that has planes (ivx_grid::signs_current): the chunk's own row and its neighbours' face
+// rows are 2 bytes each in `g.signs` — a row's bit 0 / bit 15 are its voxels on the k faces — and no voxel plane is read (`own_sd.x`,
+// `by_lo`, `by_hi`, `nrow.x` then hold sign rows; a ghost layer's face rows still come from its planes).
+template <bool SIGNS>
 __device__ __forceinline__ void derive_issue(const GridView& g, const ivx_chunk_info* __restrict__ info, uint32_t chunk, uint32_t tid, DeriveLoads& L) {
     const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
     const size_t base = (size_t)chunk * IVX_CHUNK_VOXELS;
@@ -151,16 +155,27 @@ __device__ __forceinline__ void derive_issue(const GridView& g, const ivx_chunk_
     const int8_t* nrp = g.sdf + (nc << 12) + noff;
     if (n_ghost) nrp = (nf == 0 ? g.ghost_sdf[0] : g.ghost_sdf[1]) + ((size_t)(cj * g.cz + ck) * 256 + nr * 16);
     L.own_rec = reinterpret_cast<const uint2*>(info)[chunk];
-    L.own_sd = *reinterpret_cast<const uint4*>(g.sdf + base + (size_t)tid * 16);      // used only if the chunk has planes
-    L.own_types = *reinterpret_cast<const uint4*>(g.type + base + (size_t)tid * 16);  // likewise
     // (gen_kind is the second byte of a record's first word; the face bytes are the last / first of the row's 16)
     L.gen_lo = reinterpret_cast<const uint32_t*>(info)[2 * c_lo];
     L.gen_hi = reinterpret_cast<const uint32_t*>(info)[2 * c_hi];
-    L.by_lo = *reinterpret_cast<const uint32_t*>(g.sdf + (c_lo << 12) + tid * 16 + 12);
-    L.by_hi = *reinterpret_cast<const uint32_t*>(g.sdf + (c_hi << 12) + tid * 16);
     L.ngen = reinterpret_cast<const uint32_t*>(info)[2 * nc];
-    L.nrow = *reinterpret_cast<const uint4*>(nrp);
     L.type0 = *reinterpret_cast<const uint32_t*>(g.type + base);  // (voxel 0's type: the type of a Uniform chunk that was demoted before)
+    if (SIGNS) {
+        // (sign rows as the aligned words around them, the half taken at the use: see the byte loads of the other form)
+        const uint32_t* sw = reinterpret_cast<const uint32_t*>(g.signs);
+        L.own_sd = make_uint4(sw[((size_t)chunk * 256 + tid) >> 1], 0u, 0u, 0u);
+        L.own_types = make_uint4(0u, 0u, 0u, 0u);
+        L.by_lo = sw[(c_lo * 256 + tid) >> 1];
+        L.by_hi = sw[(c_hi * 256 + tid) >> 1];
+        if (n_ghost) L.nrow = *reinterpret_cast<const uint4*>(nrp);
+        else L.nrow = make_uint4(sw[(nc * 256 + (noff >> 4)) >> 1], 0u, 0u, 0u);  // (noff >> 4: the face row's index in its chunk)
+    } else {
+        L.own_sd = *reinterpret_cast<const uint4*>(g.sdf + base + (size_t)tid * 16);      // used only if the chunk has planes
+        L.own_types = *reinterpret_cast<const uint4*>(g.type + base + (size_t)tid * 16);  // likewise
+        L.by_lo = *reinterpret_cast<const uint32_t*>(g.sdf + (c_lo << 12) + tid * 16 + 12);
+        L.by_hi = *reinterpret_cast<const uint32_t*>(g.sdf + (c_hi << 12) + tid * 16);
+        L.nrow = *reinterpret_cast<const uint4*>(nrp);
+    }
 }
 
 // What the later per-chunk passes need is in this kernel's registers already, so it can run them in the same sweep (`parts`):
@@ -180,11 +195,12 @@ struct DeriveFused {
 // throughput, and the register budget is set to match. A software pipeline over a resident set of workgroups — the next chunk's loads in
 // flight across the region and moment passes, as the mesher does — was tried: its 119 registers leave four workgroups per CU, and four
 // pipelined ones were no faster than seven plain ones; what did help is the grid's size, see ivx_launch_derive.)
+template <bool SIGNS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_derive(GridView g, int8_t* __restrict__ sdf_rw, uint8_t* __restrict__ type_rw, uint8_t* __restrict__ flags_out,
                                                 ivx_chunk_info* __restrict__ info, uint32_t* __restrict__ bbox, uint8_t* __restrict__ touch,
                                                 uint16_t* __restrict__ signs, uint8_t* __restrict__ kface_out,
                                                 const uint32_t* __restrict__ work_counts, uint32_t* __restrict__ active_list,
-                                                const uint32_t* __restrict__ list_in, DeriveFused fz) {
+                                                const uint32_t* __restrict__ list_in, DeriveFused fz, uint32_t signs_type) {
     __shared__ uint32_t occ[18][18];  // non-empty masks of rows (i+1, j+1); halo rows from neighbour chunks
     __shared__ uint32_t cnt[13];      // own face non-empty counts [0..6), neighbour face non-empty counts [6..12), [12] touch bits
     __shared__ CclShared s_ccl;
@@ -205,7 +221,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     IVX_T(g, li, 0);
     const uint32_t chunk = IVX_LIST_CHUNK(list_in[li]);
     DeriveLoads L;
-    derive_issue(g, info, chunk, tid, L);
+    derive_issue<SIGNS>(g, info, chunk, tid, L);
     const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
     const size_t base = (size_t)chunk * IVX_CHUNK_VOXELS;
     const bool has_zlo = ck > 0, has_zhi = ck + 1 < (int)g.cz;
@@ -225,7 +241,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     asm volatile("" : "+v"(own_rec.x), "+v"(own_rec.y), "+v"(own_sd.x), "+v"(own_sd.y), "+v"(own_sd.z), "+v"(own_sd.w));
     asm volatile("" : "+v"(own_types.x), "+v"(own_types.y), "+v"(own_types.z), "+v"(own_types.w));
     asm volatile("" : "+v"(gen_lo), "+v"(gen_hi), "+v"(by_lo), "+v"(by_hi), "+v"(ngen), "+v"(nrow.x), "+v"(nrow.y), "+v"(nrow.z), "+v"(nrow.w), "+v"(type0));
-    by_lo >>= 24, by_hi &= 0xFFu, gen_lo = (gen_lo >> 8) & 0xFFu, gen_hi = (gen_hi >> 8) & 0xFFu, ngen = (ngen >> 8) & 0xFFu;
+    gen_lo = (gen_lo >> 8) & 0xFFu, gen_hi = (gen_hi >> 8) & 0xFFu, ngen = (ngen >> 8) & 0xFFu;
+    if (SIGNS) {  // the row's half of the word it came in; the face voxel's bit where the byte's sign bit is expected below (bit 7)
+        by_lo = (((by_lo >> (16u * (tid & 1u))) >> 15) & 1u) << 7;
+        by_hi = ((by_hi >> (16u * (tid & 1u))) & 1u) << 7;
+    } else {
+        by_lo >>= 24, by_hi &= 0xFFu;
+    }
     ivx_chunk_info own_info;
     own_info.kind = (uint8_t)(own_rec.x & 0xFFu);
     own_info.gen_kind = (uint8_t)((own_rec.x >> 8) & 0xFFu);
@@ -234,8 +256,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     own_info.face_dist = (uint16_t)(own_rec.y & 0xFFFFu);
     own_info.region_count = (uint8_t)((own_rec.y >> 16) & 0xFFu);
     own_info.boundary_region_count = (uint8_t)(own_rec.y >> 24);
-    const uint32_t own_row_mask = row_mask(own_sd);
-    {
+    const uint32_t own_row_mask = SIGNS ? ((own_sd.x >> (16u * (tid & 1u))) & 0xFFFFu) : row_mask(own_sd);
+    const bool own_uniform = own_info.gen_kind == KIND_UNIFORM;
+    if (!SIGNS) {
         // the row's bytes on the two k faces, rows side by side, for the mesher's halo (GridView::kface)
         uint8_t* kf = kface_out + (size_t)chunk * 1024 + tid;
         kf[0] = (uint8_t)(own_sd.x & 0xFFu);
@@ -244,16 +267,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         kf[768] = (uint8_t)(own_types.w >> 24);
     }
     if (tid < 13) cnt[tid] = 0;
-    const bool own_uniform = own_info.gen_kind == KIND_UNIFORM;
     const uint32_t m = own_uniform ? 0xFFFFu : own_row_mask;
     occ[ti + 1][tj + 1] = m;
-    signs[(size_t)chunk * 256 + tid] = (uint16_t)m;  // for the mesher's count pass
+    if (!SIGNS) signs[(size_t)chunk * 256 + tid] = (uint16_t)m;  // for the mesher's count pass (SIGNS: the sampler's, and a demoted chunk's below)
 
     uint32_t zlo = 0, zhi = 0;  // neighbour voxel across the z faces for this (i,j)
     if (has_zlo) zlo = gen_lo == KIND_NONUNIFORM ? ((by_lo >> 7) & 1u) : (gen_lo == KIND_UNIFORM ? 1u : 0u);
     if (has_zhi) zhi = gen_hi == KIND_NONUNIFORM ? ((by_hi >> 7) & 1u) : (gen_hi == KIND_UNIFORM ? 1u : 0u);
     if (tid < 64) {
-        const uint32_t rm = row_mask(nrow);
+        // (SIGNS: the face row's sign mask itself — row index noff >> 4 = 240 + nr, nr, 16 nr + 15, 16 nr by face: odd exactly for f = 2 and for
+        // odd nr on the x faces —, a ghost layer's row still from its plane)
+        const uint32_t nrow_odd = nf == 2 ? 1u : (nf == 3 ? 0u : ((uint32_t)nr & 1u));
+        const uint32_t rm = (SIGNS && !n_ghost) ? ((nrow.x >> (16u * nrow_odd)) & 0xFFFFu) : row_mask(nrow);
         uint32_t nm = 0;
         if (n_present) nm = ngen == KIND_NONUNIFORM ? rm : (ngen == KIND_UNIFORM ? 0xFFFFu : 0u);
         else if (n_ghost) nm = rm;
@@ -398,6 +423,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             *reinterpret_cast<uint4*>(sdf_rw + base + (size_t)tid * 16) = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
             *reinterpret_cast<uint4*>(type_rw + base + (size_t)tid * 16) = make_uint4(t4, t4, t4, t4);
         }
+        if (SIGNS && own_uniform) {  // a chunk that is NonUniform by demotion (now or earlier): the sampler left it no sign rows or face bytes
+            signs[(size_t)chunk * 256 + tid] = (uint16_t)0xFFFFu;
+            uint8_t* kf = kface_out + (size_t)chunk * 1024 + tid;
+            kf[0] = (uint8_t)0x80u;
+            kf[256] = (uint8_t)0x80u;
+            kf[512] = (uint8_t)utype;
+            kf[768] = (uint8_t)utype;
+        }
     }
 
     IVX_T(g, li, 3);  // flags written
@@ -409,7 +442,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         // (a chunk demoted in this pass has no type plane yet: its voxels all have the record's type)
         const uint32_t ut = utype * 0x01010101u;
         const bool fresh = own_uniform && own_info.kind != KIND_NONUNIFORM;
-        const uint32_t tw[4] = {fresh ? ut : own_types.x, fresh ? ut : own_types.y, fresh ? ut : own_types.z, fresh ? ut : own_types.w};
+        // (SIGNS: every voxel of a chunk the sampler gave planes has the generator's one type)
+        const uint32_t st = signs_type * 0x01010101u;
+        const uint32_t tw[4] = {fresh ? ut : (SIGNS ? st : own_types.x), fresh ? ut : (SIGNS ? st : own_types.y), fresh ? ut : (SIGNS ? st : own_types.z),
+                                fresh ? ut : (SIGNS ? st : own_types.w)};
         chunk_moments_rows_tab(tid, m, tw, s_dens, s_mtab, s_red, (ci + (int)fz.x_off) * 16 + ti, cj * 16 + tj, ck * 16, fz.chunk_moments + (size_t)chunk * 10);
     }
 
@@ -588,8 +624,13 @@ int ivx_launch_derive(ivx_grid* g, uint32_t parts, uint32_t preset_groups) {
         const uint32_t lo = (g->n_chunks + 255u) / 256u;  // (ivx_list_grid's floor)
         if (derive_grid < lo) derive_grid = lo;
     }
-    hipLaunchKernelGGL(k_derive, dim3(derive_grid), dim3(256), 0, g->ctx->stream, v, g->sdf, g->type, g->flags, g->info, g->chunk_bbox,
-                       g->chunk_touch, g->chunk_signs, g->kface, ivx_wc(g), g->active_list, g->active_list, fz);
+    // (two forms of the sweep: from the sign rows the sampler left, while nothing else has rewritten voxels — no plane is read —, else from the planes)
+    if (g->signs_current)
+        hipLaunchKernelGGL(k_derive<true>, dim3(derive_grid), dim3(256), 0, g->ctx->stream, v, g->sdf, g->type, g->flags, g->info, g->chunk_bbox,
+                           g->chunk_touch, g->chunk_signs, g->kface, ivx_wc(g), g->active_list, g->active_list, fz, (uint32_t)g->signs_type);
+    else
+        hipLaunchKernelGGL(k_derive<false>, dim3(derive_grid), dim3(256), 0, g->ctx->stream, v, g->sdf, g->type, g->flags, g->info, g->chunk_bbox,
+                           g->chunk_touch, g->chunk_signs, g->kface, ivx_wc(g), g->active_list, g->active_list, fz, 0u);
     g->planes_compact = 1;
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;

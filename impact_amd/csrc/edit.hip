@@ -347,6 +347,7 @@ int ivx_launch_absorb_mutual(ivx_grid* g, int from_snapshot, const uint32_t lo[3
                              ivx_grid* other, const int8_t* d_snapshot, const int32_t s_lo[3], const int32_t s_hi[3], const float q_ba[4],
                              const float t_ba[3], float smoothness, const float* d_dens, double* d_removed10, uint32_t* d_by_type, uint32_t* d_counters,
                              uint32_t* d_touched) {
+    ivx_planes_touched(g);
     AbsorbParams p;
     p.g = ivx_view(g);
     p.capsule = from_snapshot ? 3 : 2;
@@ -381,6 +382,7 @@ int ivx_launch_absorb_mutual(ivx_grid* g, int from_snapshot, const uint32_t lo[3
 int ivx_launch_absorb(ivx_grid* g, int capsule, const uint32_t lo[3], const uint32_t cc[3], const int32_t vlo[3], const int32_t vhi[3], const float c[3],
                       const float seg[3], float influence_radius, float shape_radius, const float* d_dens, double* d_removed10, uint32_t* d_by_type,
                       uint32_t* d_counters, uint32_t* d_touched) {
+    ivx_planes_touched(g);
     AbsorbParams p;
     p.g = ivx_view(g);
     p.capsule = capsule;

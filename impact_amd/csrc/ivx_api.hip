@@ -506,6 +506,7 @@ int ivx_grid_stage_counters(ivx_grid* g, uint32_t out[4]) {
 void* ivx_grid_device_ptr(ivx_grid* g, int which) {
     if (!g) return nullptr;
     if (which >= 0 && which < 4 && ivx_ensure_dense(g) != IVX_OK) return nullptr;  // whole planes for the caller (stream-ordered)
+    if (which == 0 || which == 1 || which == 4) ivx_planes_touched(g);  // (the caller may write through the pointer)
     switch (which) {
         case 0: return g->sdf;
         case 1: return g->type;

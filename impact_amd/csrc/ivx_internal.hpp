@@ -105,6 +105,10 @@ struct ivx_grid {
     double* chunk_moments;  // [n_chunks * 10] moments of the NonUniform chunks (fixed summation order whatever the list order)
     uint32_t last_active;   // host: active-list length seen by the last collect (sizes the list-driven grids)
     int planes_compact;  // planes of Void/Uniform chunks may be stale (see ivx_ensure_dense)
+    // the sampler wrote `chunk_signs` and `kface` of every chunk it gave planes, all voxels of such a chunk have the type `signs_type`, and
+    // nothing has rewritten voxels since (ivx_planes_touched): the derive sweep then reads those 2 + 4 bytes per row instead of the planes
+    int signs_current;
+    uint8_t signs_type;
     uint32_t stage_timing_off;  // timed slots WITHOUT event records (ivx_grid_set_stage_timing; zero-initialised: every slot is timed)
     float* dens_dev;        // [256] voxel type densities
     float dens_host[256];   // what dens_dev holds (entry points that are handed the same table again skip the upload)
@@ -283,6 +287,8 @@ static inline uint32_t ivx_list_grid(const ivx_grid* g) {
 }
 
 static inline uint32_t* ivx_wc(const ivx_grid* g) { return g->work_counts + g->wc_cur; }
+// to be called by everything that writes voxel planes other than the sampler (uploads, edits, split / clip / repack, raw plane pointers handed out)
+static inline void ivx_planes_touched(ivx_grid* g) { g->signs_current = 0; }
 // groups of small scratch words that must hold their preset value when a stage starts
 #define IVX_SCRATCH_EVAL_ROLL 8u  // role_preset: copy the sampler's list counters to their statistics words and zero them
 #define IVX_SCRATCH_REGIONS 1u  // rscalar[0..16): region count, error flags, multi-region chunk count

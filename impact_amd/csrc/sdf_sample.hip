@@ -198,7 +198,8 @@ __device__ __forceinline__ uint4 pack16(const int* v) {
 // maximally-outside voxels (the reference drops their data, object/sdf.rs:486-489) and store.
 __device__ __forceinline__ void classify_and_store(int* sd, uint4 types, bool types_uniform_in, uint8_t first_type, int8_t* sdf_out,
                                                    uint8_t* type_out, ivx_chunk_info* info_out, uint32_t chunk, uint32_t tid,
-                                                   bool set_type, uint32_t voxel_type, bool compact, uint32_t* s_votes) {
+                                                   bool set_type, uint32_t voxel_type, bool compact, uint32_t* s_votes,
+                                                   uint16_t* signs_out = nullptr, uint8_t* kface_out = nullptr) {
     // the three per-thread predicates from the smallest and the largest of the 16 distances (v_min3 / v_max3: 16 instructions where
     // the per-voxel comparisons were ~100)
     int lo = sd[0], hi = sd[0];
@@ -230,8 +231,24 @@ __device__ __forceinline__ void classify_and_store(int* sd, uint4 types, bool ty
     }
     if (kind == KIND_NONUNIFORM || !compact) {  // Void / Uniform chunks are their 8-byte record (compact planes)
         size_t base = (size_t)chunk * IVX_CHUNK_VOXELS + (size_t)tid * 16;
-        *reinterpret_cast<uint4*>(sdf_out + base) = pack16(sd);
+        const uint4 packed = pack16(sd);
+        *reinterpret_cast<uint4*>(sdf_out + base) = packed;
         *reinterpret_cast<uint4*>(type_out + base) = types;
+        if (signs_out && kind == KIND_NONUNIFORM) {
+            // What the derive sweep and the mesher need of this chunk besides its planes, while the row is in registers: the row's 16-bit
+            // "distance negative" mask (GridView::signs) and its bytes on the two k faces (GridView::kface). With them in place the sweep
+            // reads no voxel plane at all — its own rows and its six neighbours' faces are 2 bytes per row (ivx_launch_derive, k_derive<true>).
+            const uint32_t w[4] = {packed.x, packed.y, packed.z, packed.w};
+            uint32_t m = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) m |= ((((w[q] >> 7) & 0x01010101u) * 0x00204081u >> 21) & 0xFu) << (4 * q);  // (row_mask of derive.hip)
+            signs_out[(size_t)chunk * 256 + tid] = (uint16_t)m;
+            uint8_t* kf = kface_out + (size_t)chunk * 1024 + tid;
+            kf[0] = (uint8_t)(packed.x & 0xFFu);
+            kf[256] = (uint8_t)(packed.w >> 24);
+            kf[512] = (uint8_t)(types.x & 0xFFu);
+            kf[768] = (uint8_t)(types.w >> 24);
+        }
     }
     if (tid == 0) {
         ivx_chunk_info ci;
@@ -1003,7 +1020,8 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
                                                   const uint32_t* __restrict__ first_list, uint32_t list_len, uint32_t scratch_off,
                                                   const uint32_t* __restrict__ prog_len, const uint2* __restrict__ prog_ops,
                                                   const ivx_sdf_processed_node* __restrict__ nodes, int8_t* __restrict__ sdf_out,
-                                                  uint8_t* __restrict__ type_out, ivx_chunk_info* __restrict__ info_out) {
+                                                  uint8_t* __restrict__ type_out, ivx_chunk_info* __restrict__ info_out,
+                                                  uint16_t* __restrict__ signs_out, uint8_t* __restrict__ kface_out) {
     extern __shared__ float stack[];  // [stack_size][16][256]
     constexpr bool TRIM = MODE == 1;
     const uint32_t tid = threadIdx.x;
@@ -1195,7 +1213,7 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
     }
     IVX_TE(p, li, 4);
     classify_and_store(sd, make_uint4(0, 0, 0, 0), true, 0, sdf_out, type_out, info_out, chunk, tid, true, p.voxel_type, true,
-                       reinterpret_cast<uint32_t*>(s_pub) + 8);
+                       reinterpret_cast<uint32_t*>(s_pub) + 8, signs_out, kface_out);
     IVX_TE(p, li, 5);  // classified and stored
     }
 }
@@ -1315,17 +1333,17 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
             // one level + 64 words of scratch: 16 640 bytes = 13 LDS granules, eight workgroups per CU (the waves a SIMD holds)
             const uint32_t scratch_off = IVX_CHUNK_VOXELS;
             hipLaunchKernelGGL(k_sdf_eval<2>, dim3(fit(g->eval_len[0])), dim3(256), (size_t)(scratch_off + 64u) * sizeof(float), g->ctx->stream, p, eval_count + 0, list0,
-                               eval_count + 3, nullptr, nullptr, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info);
+                               eval_count + 3, nullptr, nullptr, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info, g->chunk_signs, g->kface);
         }
         if (merge01 || !(known && g->eval_len[1] == 0u)) {
             // two levels, the second one 15 rows long + 64 words of scratch: 32 000 bytes = 25 LDS granules, five workgroups per CU
             const uint32_t scratch_off = IVX_CHUNK_VOXELS + 15u * 256u;
             if (merge01)
                 hipLaunchKernelGGL(k_sdf_eval<1>, dim3(fit(g->eval_len[0] + g->eval_len[1])), dim3(256), (size_t)(scratch_off + 64u) * sizeof(float), g->ctx->stream, p, eval_count + 0, list0,
-                                   eval_count + 3, eval_count + 1, list1, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info);
+                                   eval_count + 3, eval_count + 1, list1, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info, g->chunk_signs, g->kface);
             else
                 hipLaunchKernelGGL(k_sdf_eval<1>, dim3(fit(g->eval_len[1])), dim3(256), (size_t)(scratch_off + 64u) * sizeof(float), g->ctx->stream, p, eval_count + 1, list1,
-                                   nullptr, nullptr, nullptr, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info);
+                                   nullptr, nullptr, nullptr, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info, g->chunk_signs, g->kface);
         }
         if (stack_size >= 3u && !(known && g->eval_len[2] == 0u)) {
             // (the scratch words are the last sixteen of the stack: rows 15 of the last level's threads 240..255, dead when they are used
@@ -1333,14 +1351,19 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
             const uint32_t lv = stack_size;
             const uint32_t scratch_off = lv * IVX_CHUNK_VOXELS - 16u;
             hipLaunchKernelGGL(k_sdf_eval<0>, dim3(fit(g->eval_len[2])), dim3(256), (size_t)lv * IVX_CHUNK_VOXELS * sizeof(float), g->ctx->stream, p, eval_count + 2,
-                               eval_list + 2 * (size_t)g->n_chunks, nullptr, nullptr, nullptr, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info);
+                               eval_list + 2 * (size_t)g->n_chunks, nullptr, nullptr, nullptr, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info, g->chunk_signs, g->kface);
         }
     }
     IVX_HIP_CHECK(hipGetLastError());
+    // every chunk that has planes now has its sign rows and k-face bytes too, and one type throughout (SameVoxelTypeGenerator): the derive
+    // sweep may work from those (until something else rewrites voxels: ivx_planes_touched)
+    g->signs_current = 1;
+    g->signs_type = voxel_type;
     return IVX_OK;
 }
 
 int ivx_launch_classify(ivx_grid* g) {
+    ivx_planes_touched(g);
     hipLaunchKernelGGL(k_classify, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, g->n_chunks, g->sdf, g->type, g->info);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;

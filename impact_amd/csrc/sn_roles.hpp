@@ -336,6 +336,8 @@ __device__ __forceinline__ void load_tile(const GridView& g, int ci, int cj, int
 }
 
 // Ordered block-wide exclusive prefix of `val` in thread order; `total` = block sum (same in every thread).
+// (TRAILING = false: no barrier behind the read of the wave sums — for a caller that does not write them again before another barrier)
+template <bool TRAILING = true>
 __device__ __forceinline__ uint32_t block_prefix(uint32_t val, uint32_t* s_wsum, uint32_t tid, uint32_t& total) {
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     uint32_t incl = val;
@@ -349,7 +351,7 @@ __device__ __forceinline__ uint32_t block_prefix(uint32_t val, uint32_t* s_wsum,
     uint32_t w0 = s_wsum[0], w1 = s_wsum[1], w2 = s_wsum[2], w3 = s_wsum[3];
     uint32_t wbase = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
     total = w0 + w1 + w2 + w3;
-    __syncthreads();
+    if (TRAILING) __syncthreads();
     return wbase + incl - val;
 }
 
@@ -866,21 +868,35 @@ __device__ __forceinline__ void normalize_ranged(float gx, float gy, float gz, f
 // (0 * x is not 0 for every x). Same values, same order of the additions that matter. `neg`: bit c = corner c's distance is negative.
 __device__ __forceinline__ void edge_centroid(const float d[8], uint32_t neg, V3& sum, int& count) {
     sum = mk(0.0f, 0.0f, 0.0f);
-    count = 0;
     constexpr int E1[12] = {0, 0, 0, 1, 1, 2, 2, 3, 4, 4, 5, 6};
     constexpr int E2[12] = {1, 2, 4, 3, 5, 3, 6, 7, 5, 6, 7, 7};
+    // Which of the twelve edges are crossed, all at once: corners c and c + a (a = 4, 2, 1: the edge's axis) differ in sign where bit c of
+    // neg ^ (neg >> a) is set. Bit c1 of `cx` / `cy` / `cz` = the edge from corner c1 along x / y / z. The wave's union of the three masks
+    // (DPP ORs, then four lane reads) is a SCALAR: an edge that no vertex of the wave crosses — on a locally flat surface most of the twelve,
+    // e.g. every edge along the surface — is passed over by a scalar bit test and branch, without a vector instruction (the twelve per-edge
+    // sign tests and ballots were a fifth of a vertex's vector instructions).
+    const uint32_t cx = (neg ^ (neg >> 4)) & 0x0Fu, cy = (neg ^ (neg >> 2)) & 0x33u, cz = (neg ^ (neg >> 1)) & 0x55u;
+    const uint32_t cm = cx | (cy << 8) | (cz << 16);
+    count = (int)__popc(cm);
+    uint32_t wm = cm;
+    wm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wm, 0x111, 0xF, 0xF, true);  // row_shr:1 .. 8: lane 15 of a DPP row has the row's OR
+    wm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wm, 0x112, 0xF, 0xF, true);
+    wm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wm, 0x114, 0xF, 0xF, true);
+    wm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wm, 0x118, 0xF, 0xF, true);
+    const uint32_t any = ((uint32_t)__builtin_amdgcn_readlane((int)wm, 15) | (uint32_t)__builtin_amdgcn_readlane((int)wm, 31)) |
+                         ((uint32_t)__builtin_amdgcn_readlane((int)wm, 47) | (uint32_t)__builtin_amdgcn_readlane((int)wm, 63));
 #pragma unroll
     for (int e = 0; e < 12; ++e) {
         const int c1 = E1[e], c2 = E2[e];
-        const bool crossed = (((neg >> c1) ^ (neg >> c2)) & 1u) != 0u;
-        // (an edge that no vertex of the wave crosses adds +0 to every sum: skipped for the wave — on a locally flat surface that is
-        // most of the twelve, e.g. every edge along the surface)
-        if (__builtin_amdgcn_ballot_w64(crossed) == 0ull) continue;
+        const int axis = c1 ^ c2;  // 4: x, 2: y, 1: z
+        const uint32_t bit = 1u << (c1 + (axis == 4 ? 0 : (axis == 2 ? 8 : 16)));
+        // (an edge that no vertex of the wave crosses adds +0 to every sum: skipped for the wave. Lanes of an inactive tail of the loop's last
+        // round take no part in the DPP ORs — their contribution reads as 0)
+        if ((any & bit) == 0u) continue;
+        const bool crossed = (cm & bit) != 0u;
         const float q = div_ranged(d[c1], d[c1] - d[c2]);
         const float t = crossed ? q : 0.0f;
         const float s = crossed ? ((1.0f - q) + q) : 0.0f;
-        count += crossed ? 1 : 0;
-        const int axis = c1 ^ c2;  // 4: x, 2: y, 1: z
         sum.x += axis == 4 ? t : ((c1 & 4) ? s : 0.0f);
         sum.y += axis == 2 ? t : ((c1 & 2) ? s : 0.0f);
         sum.z += axis == 1 ? t : ((c1 & 1) ? s : 0.0f);
@@ -960,6 +976,16 @@ __device__ __forceinline__ void tile_issue(const GridView& g, uint32_t chunk, Ti
         L.b2s = kf2[0];
         L.b2t = kf2[128];
     }
+}
+// the loads have to be in: the compiler's wait goes where this is called
+__device__ __forceinline__ void tile_pin(TileLoads& T) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        RowData& L = T.L[r];
+        asm volatile("" : "+v"(L.s4.x), "+v"(L.s4.y), "+v"(L.s4.z), "+v"(L.s4.w), "+v"(L.t4.x), "+v"(L.t4.y), "+v"(L.t4.z), "+v"(L.t4.w));
+        asm volatile("" : "+v"(L.b0s), "+v"(L.b0t), "+v"(L.b2s), "+v"(L.b2t));
+    }
+    asm volatile("" : "+v"(T.rec));
 }
 // the records into LDS, ahead of the barrier that precedes tile_finish
 __device__ __forceinline__ void tile_records(TileLoads& T, uint32_t* s_rec, uint32_t tid) {
@@ -1076,9 +1102,10 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
     __shared__ uint16_t s_quad[3 * VPC];  // the chunk's quads in emission order: cube id | axis << 13
     __shared__ __attribute__((aligned(16))) uint8_t s_sd[TILE_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t s_ty[TILE_BYTES];
-    __shared__ uint32_t s_neg[NROWS];
+    __shared__ uint32_t s_neg2[2][NROWS];  // the tile's sign rows, double-buffered (see the barriers of a round)
     __shared__ uint32_t s_vrow[NCROWS];   // per cube row: first vertex << 17 | which of its 17 cubes have a vertex (cube -> vertex: vertex_of)
     __shared__ uint16_t s_qrow[NCROWS];   // per cube row: its first quad
+    __shared__ uint2 s_qbits[NCROWS];     // per cube row: which cubes emit their X / Y / Z quad — x = qx | qy << 17, y = qy >> 15 | qz << 2 (17 bits each)
     __shared__ uint32_t s_nq;             // the chunk's quads
     __shared__ uint16_t s_surf[VPC];      // vertex -> cube id (cube row * 17 + k)
     __shared__ float s_vpos[3][VPC];      // the chunk's vertex positions and materials for the quad phase
@@ -1100,13 +1127,21 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
     // at once queue on eight words, not one (one word serves ~90 draws per microsecond). The draw runs two rounds ahead (the entry after the
     // next, whose tile is already being fetched), by thread 0 only: ticket at the top of a round, the entry's record when the ticket has come
     // back, both through LDS at the round's last barrier — no other wave ever waits for either.
-    uint32_t li = NONE, li_next = bid;
+    uint32_t li = NONE, li_next = bid, li_prev = NONE;
     if (li_next >= n_emit) return;
     uint4 item = make_uint4(0u, 0u, 0u, 0u), item_next = emit_items[li_next];
     int upper[3] = {G - 1, G - 1, G - 1};  // of the tile in LDS
     uint32_t info_w = 0u;
+    uint32_t buf = 0u;         // s_neg2[buf]: the sign rows of the tile in LDS (the next tile's go to the other half while this chunk's quads still read these)
+    bool from_ticket = false;  // (li_next, item_next) wait in s_ticket
+    constexpr uint32_t TK = 192u;  // the thread that draws the tickets: lane 0 of the last wave, the one with the fewest vertex rounds
+    // Barriers of a round: (1) top — the tile, the drawn entry and the previous chunk's `hard` verdict are published; (2) inside the ordered
+    // prefix; (3) the vertex order is built; (4) the vertices are in LDS, and so are the next tile's records. Nothing after the quads: a wave
+    // goes from its quads straight to putting the next tile into LDS (the tile's planes are dead after the vertex phase, its sign rows are
+    // double-buffered) and on to the next round's first barrier — seven barriers per chunk came down to four.
     for (;;) {
-    const bool have = li != NONE, have_next = li_next < n_emit;
+    const bool have = li != NONE;
+    const uint32_t* s_neg = s_neg2[buf];
     const uint32_t chunk = item.x, voff = item.y, ioff = item.z;
     const uint32_t icount = (item.w >> 16) * 6u;
     const uint32_t slot = have ? (SLOTS ? slots[li] : li) : 0u;  // (incremental remesh: the submesh manager's slot of the chunk)
@@ -1116,7 +1151,6 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
     const bool large = fits && (item.w & 0xFFFFu) > VPC;
     const uint32_t vcount = (fits && !large) ? (item.w & 0xFFFFu) : 0u;
     const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
-    if (tid == 0) s_hard = large ? 1u : 0u;
     if (have) IVX_T(g, li, 0);
     if (tid == 0 && fits) {
         const uint32_t cflags = (info_w >> 16) & 0xFFu;
@@ -1137,15 +1171,28 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
         sm.reserved = 0;
         submeshes[slot] = sm;
     }
-    __syncthreads();  // the chunk's tile is in LDS (phase 5 of the previous round)
+    __syncthreads();  // (1) the chunk's tile is in LDS (phase 5 of the previous round); every wave is through the previous chunk's quads
     if (have) IVX_T(g, li, 1);
+    if (from_ticket) {
+        li_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket[0]);
+        item_next = make_uint4((uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket[1]), (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket[2]),
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket[3]), (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket[4]));
+    }
+    const bool have_next = li_next < n_emit;
+    if (tid == 0) {  // the previous chunk's verdict (its quad phase is over everywhere), then this chunk's starting value
+        if (li_prev != NONE && s_hard) hard_list[atomicAdd(hard_count, 1u)] = li_prev;
+        s_hard = large ? 1u : 0u;
+    }
 
     uint32_t ticket = 0u;
-    if (tid == 0 && have_next) ticket = nb + 8u * atomicAdd(cursor + 32u * (bid & 7u), 1u) + (bid & 7u);
-    // ---- 0. the next chunk's tile: its loads travel while this chunk is meshed
+    if (tid == TK && have_next) ticket = nb + 8u * atomicAdd(cursor + 32u * (bid & 7u), 1u) + (bid & 7u);
+    // ---- 0. the next chunk's tile: its loads travel while this chunk's vertex order is built
     TileLoads T;
     if (have_next) tile_issue(g, item_next.x, T, tid);
-    if (vcount) {
+    uint4 drawn = make_uint4(0u, 0u, 0u, 0u);
+    // (straight-line from here to the vertices, also in a round without any — the first one, a chunk passed over —, where the order is built
+    // from whatever the tile's LDS holds and nobody looks at it: with the phases under a condition the two paths kept the loads in flight in
+    // different registers and met behind a full drain)
     // ---- 1. vertex and quad order: cubes in (i,j,k) scan order (surface_nets.rs:158-185) = cube rows in order, bits ascending; a cube's
     // quads X, Y, Z (surface_nets.rs:263-301). Thread t owns cube rows 2t and 2t+1 so that thread order = row order; ONE ordered prefix
     // carries both counts (vertices in the low half, quads in the high half: at most 4913 and 14 739).
@@ -1158,10 +1205,11 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
                 uint32_t qx, qy, qz;
                 cube_row_bits(s_neg, cr / 17, cr % 17, upper, vb[q], qx, qy, qz);
                 nq[q] = __popc(qx) + __popc(qy) + __popc(qz);
+                s_qbits[cr] = make_uint2(qx | (qy << 17), (qy >> 15) | (qz << 2));  // (for the vertices' quad lists: visible behind the prefix's barrier)
             }
         }
         uint32_t total;
-        const uint32_t pre = block_prefix((__popc(vb[0]) + __popc(vb[1])) | ((nq[0] + nq[1]) << 16), s_wsum, tid, total);
+        const uint32_t pre = block_prefix<false>((__popc(vb[0]) + __popc(vb[1])) | ((nq[0] + nq[1]) << 16), s_wsum, tid, total);  // (2)
         uint32_t base = pre & 0xFFFFu, qb = pre >> 16;
         if (tid == 0) s_nq = total >> 16;
         for (int q = 0; q < 2; ++q) {
@@ -1180,8 +1228,22 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
             }
         }
     }
-    __syncthreads();
-    IVX_T(g, li, 2);  // vertex order built
+    // The next tile's loads are waited for HERE, before this round's first store. The counter of outstanding vector-memory operations is
+    // in order: behind the vertex and quad phases' stores — whose number the compiler cannot know, the loops' trip counts being data — the
+    // wait for these loads was a wait for every store of the round to be acknowledged, once per chunk, in every wave. Here only the previous
+    // round's quad stores are older, and the order phase has covered most of their trip and of the loads'.
+    if (have_next) tile_pin(T);
+    __syncthreads();  // (3)
+    if (have) IVX_T(g, li, 2);  // vertex order built
+    // the entry behind the ticket (the atomic is older than the tile's loads: it has returned): one wave's uniform load, waited for before that
+    // wave's first store for the same reason
+    if ((tid >> 6) == (TK >> 6)) {
+        const uint32_t tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+        if (have_next && tk < n_emit) {
+            drawn = emit_items[tk];
+            asm volatile("" : "+v"(drawn.x), "+v"(drawn.y), "+v"(drawn.z), "+v"(drawn.w));
+        }
+    }
 
     // mesh.rs:559-577
     const float chunk_extent = p.extent * 16.0f;
@@ -1189,7 +1251,13 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
                              (float)ck * chunk_extent - 0.5f * p.extent);
 
     // ---- 2. vertices: one thread per vertex ------------------------------------------------------
-    for (uint32_t v = opaque(tid); v < vcount; v += 256) {
+    // (Rounds of 64 vertices per wave with EVERY lane at work — a lane beyond the chunk's last vertex redoes that vertex and stores nothing —,
+    // so that the wave-wide edge mask of edge_centroid can be taken with DPP and lane reads; a wave with no vertex in a round skips it: the
+    // bound is wave-uniform.)
+    for (uint32_t v0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid & ~63u)); v0 < vcount; v0 += 256) {
+        const uint32_t v_raw = v0 + (opaque(tid) & 63u);
+        const bool v_live = v_raw < vcount;
+        const uint32_t v = v_live ? v_raw : vcount - 1u;
         const int cid = s_surf[v];
         const int cr = cid / 17, k = cid - cr * 17, i = cr / 17, j = cr - i * 17;
         const int t0 = tix(i, j, k);
@@ -1228,13 +1296,6 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
             normal = mk(grad.x / gl, grad.y / gl, grad.z / gl);
         }
         const V3 position = add(scale(add(centroid, mk((float)i, (float)j, (float)k)), p.extent), pos_offset);
-        const size_t gv = (size_t)voff + v;
-        positions[3 * gv + 0] = position.x;
-        positions[3 * gv + 1] = position.y;
-        positions[3 * gv + 2] = position.z;
-        normals[3 * gv + 0] = normal.x;
-        normals[3 * gv + 1] = normal.y;
-        normals[3 * gv + 2] = normal.z;
         // the one material of the cube's negative corners; a vertex with several hands the chunk to the general pass
         uint32_t m0 = 0xFFFFFFFFu;
         bool single = true;
@@ -1244,34 +1305,47 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
                 if (m0 == 0xFFFFFFFFu) m0 = mats[c];
                 single = single && mats[c] == m0;
             }
-        s_vpos[0][v] = position.x;
-        s_vpos[1][v] = position.y;
-        s_vpos[2][v] = position.z;
-        s_vsm[v] = (uint8_t)m0;
-        if (!single) s_hard = 1u;
-        // the vertex's quads into the chunk's list, at the row's first quad + the quads of the row's cubes below this one
-        {
-            uint32_t vb, qx, qy, qz;
-            cube_row_bits(s_neg, i, j, upper, vb, qx, qy, qz);
-            const uint32_t below = (1u << k) - 1u;
-            uint32_t qslot = (uint32_t)s_qrow[cr] + __popc(qx & below) + __popc(qy & below) + __popc(qz & below);
-            if ((qx >> k) & 1u) s_quad[qslot++] = (uint16_t)cid;
-            if ((qy >> k) & 1u) s_quad[qslot++] = (uint16_t)(cid | (1 << 13));
-            if ((qz >> k) & 1u) s_quad[qslot] = (uint16_t)(cid | (2 << 13));
+        // the vertex's quads: at the row's first quad + the quads of the row's cubes below this one (the row's three masks from the order phase)
+        const uint2 qb = s_qbits[cr];
+        const uint32_t below = (1u << k) - 1u;
+        const uint32_t qslot0 = (uint32_t)s_qrow[cr] + __popc(qb.x & (below | (below << 17))) + __popc(qb.y & ((below >> 15) | (below << 2)));
+        if (v_live) {
+            const size_t gv = (size_t)voff + v;
+            positions[3 * gv + 0] = position.x;
+            positions[3 * gv + 1] = position.y;
+            positions[3 * gv + 2] = position.z;
+            normals[3 * gv + 0] = normal.x;
+            normals[3 * gv + 1] = normal.y;
+            normals[3 * gv + 2] = normal.z;
+            s_vpos[0][v] = position.x;
+            s_vpos[1][v] = position.y;
+            s_vpos[2][v] = position.z;
+            s_vsm[v] = (uint8_t)m0;
+            if (!single) s_hard = 1u;
+            uint32_t qslot = qslot0;
+            if ((qb.x >> k) & 1u) s_quad[qslot++] = (uint16_t)cid;                                            // X
+            if (k < 15 ? ((qb.x >> (17 + k)) & 1u) : ((qb.y >> (k - 15)) & 1u)) s_quad[qslot++] = (uint16_t)(cid | (1 << 13));  // Y
+            if ((qb.y >> (2 + k)) & 1u) s_quad[qslot] = (uint16_t)(cid | (2 << 13));                              // Z
         }
     }
-    }  // vcount
-    uint4 drawn = make_uint4(0u, 0u, 0u, 0u);
-    if (tid == 0 && have_next && ticket < n_emit) drawn = emit_items[ticket];
-    __syncthreads();
+    if (have_next) tile_records(T, s_rec, tid);  // (published by the barrier below: every wave needs them right after its quads)
+    __syncthreads();  // (4)
     if (have) IVX_T(g, li, 3);  // vertices written
 
 
     // ---- 4. quads, one THREAD per quad of the list the vertices left (a vertex emits up to three quads: walking them inside its thread
-    // made every pass three quads long). No barrier inside: the waves drift apart and cover each other's LDS and store latencies.
+    // made every pass three quads long). No barrier inside or behind: the waves drift apart and cover each other's LDS and store latencies.
+    // Rounds of 64 quads per wave with every lane at work, like the vertices': the index materials of a wave's 64 quads — 384 entries of
+    // 8 bytes, the same entry six times per quad — go out as three stores of 1 KiB of CONSECUTIVE bytes each (lane l writes entries 2x and
+    // 2x + 1, x = l, l + 64, l + 128, of quad x / 3, whose material it fetches from that quad's lane) instead of three stores that each cover
+    // a third of every cache line of the 3 KiB: a third of the write requests for two thirds of a quad's bytes.
     if (vcount && !s_hard) {
         const uint32_t n_quads = s_nq;
-        for (uint32_t q = opaque(tid); q < n_quads; q += 256) {
+        for (uint32_t q0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid & ~63u)); q0 < n_quads; q0 += 256) {
+            const uint32_t lane = opaque(tid) & 63u;
+            const uint32_t q_raw = q0 + lane;
+            const bool q_live = q_raw < n_quads;
+            const uint32_t q = q_live ? q_raw : n_quads - 1u;
             const uint32_t qd = s_quad[q];
             const int axis = (int)(qd >> 13);
             const int qcid = (int)(qd & 0x1FFFu);
@@ -1303,39 +1377,46 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
                 else { quad[0] = v1; quad[1] = v2; quad[2] = v4; quad[3] = v1; quad[4] = v4; quad[5] = v3; }
             } else if (negative_face) { quad[0] = v2; quad[1] = v3; quad[2] = v4; quad[3] = v2; quad[4] = v1; quad[5] = v3; }
             else { quad[0] = v2; quad[1] = v4; quad[2] = v3; quad[3] = v2; quad[4] = v3; quad[5] = v1; }
-            const size_t io = (size_t)ioff + (size_t)q * 6;
+            if (q_live) {
+                const size_t io = (size_t)ioff + (size_t)q * 6;
 #pragma unroll
-            for (int t = 0; t < 6; ++t) indices[io + t] = voff + quad[t];
+                for (int t = 0; t < 6; ++t) indices[io + t] = voff + quad[t];
+                if (!(b1 == b2 && b1 == b3 && b1 == b4)) s_hard = 1u;  // (corners of different materials: the general pass redoes the chunk)
+            }
             // calculate_index_materials_for_triangle's first case (surface_nets.rs:559-637): one entry, weight 1
-            const unsigned long long im = (unsigned long long)b1 | (1ull << 32);
+            const uint32_t rem3 = 3u * min(n_quads - q0, 64u);  // pairs of entries of this wave's quads
+            uint4* imw = reinterpret_cast<uint4*>(imats + (size_t)ioff + (size_t)q0 * 6);
 #pragma unroll
-            for (int t = 0; t < 6; ++t) imats[io + t] = im;
-            if (!(b1 == b2 && b1 == b3 && b1 == b4)) s_hard = 1u;  // (corners of different materials: the general pass redoes the chunk)
+            for (int jx = 0; jx < 3; ++jx) {
+                const uint32_t x = lane + 64u * (uint32_t)jx;
+                const uint32_t src = (x * 171u) >> 9;  // x / 3 for x < 192
+                const uint32_t bm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)b1);
+                if (x < rem3) imw[x] = make_uint4(bm, 1u, bm, 1u);
+            }
         }
     }
-    if (have_next) tile_records(T, s_rec, tid);
-    if (tid == 0 && have_next) {
+    if (tid == TK && have_next) {
         s_ticket[0] = ticket;
         s_ticket[1] = drawn.x, s_ticket[2] = drawn.y, s_ticket[3] = drawn.z, s_ticket[4] = drawn.w;
     }
-    __syncthreads();
-    if (have) IVX_T(g, li, 4);  // quads written
+    if (have) IVX_T(g, li, 4);  // (wave 0's) quads written
 
     // ---- 5. the next chunk's tile into LDS
     if (have_next) {
-        tile_finish(g, item_next.x, T, s_rec, s_sd, s_ty, s_neg, tid, upper);
+        tile_finish(g, item_next.x, T, s_rec, s_sd, s_ty, s_neg2[buf ^ 1u], tid, upper);
         info_w = s_rec[13];
     }
-    if (tid == 0 && s_hard) hard_list[atomicAdd(hard_count, 1u)] = li;
     if (have) IVX_T(g, li, 5);
     if (!have_next) break;
+    li_prev = li;
     li = li_next;
     item = item_next;
-    li_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket[0]);
-    item_next = make_uint4((uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket[1]), (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket[2]),
-                           (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket[3]), (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket[4]));
-    __syncthreads();  // (s_ticket, s_rec, s_hard are rewritten in the next round)
+    from_ticket = true;
+    buf ^= 1u;
     }
+    // the last chunk's verdict
+    __syncthreads();
+    if (tid == 0 && li != NONE && s_hard) hard_list[atomicAdd(hard_count, 1u)] = li;
 }
 
 // The general mesher: one workgroup per listed chunk, every case of the reference's vertex and index materials (vertices with up to seven

@@ -310,6 +310,8 @@ __global__ __launch_bounds__(256) void k_clip(ClipParams cp, int8_t* __restrict_
 }  // namespace
 
 int ivx_launch_split_move(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], const uint32_t cc[3], uint32_t target) {
+    ivx_planes_touched(parent);
+    ivx_planes_touched(child);
     SplitParams sp;
     sp.p = ivx_view(parent);
     for (int d = 0; d < 3; ++d) {
@@ -329,6 +331,7 @@ int ivx_launch_split_move(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3
 }
 
 int ivx_launch_split_repack(ivx_grid* src, ivx_grid* dst, const uint32_t off[3]) {
+    ivx_planes_touched(dst);
     {
         int rc = ivx_ensure_dense(src);
         if (rc) return rc;
@@ -340,6 +343,8 @@ int ivx_launch_split_repack(ivx_grid* src, ivx_grid* dst, const uint32_t off[3])
 }
 
 int ivx_launch_clip(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], const uint32_t cc[3], const float* planes4, uint32_t n_planes, int extract) {
+    ivx_planes_touched(parent);
+    ivx_planes_touched(child);
     ClipParams cp;
     cp.p = ivx_view(parent);
     for (int d = 0; d < 3; ++d) {
