@@ -1080,6 +1080,13 @@ static inline uint32_t ivx_emit_general_grid(const ivx_grid* g, uint32_t n_entri
     return n_entries < cap ? (n_entries ? n_entries : 1u) : cap;
 }
 
+// The mesh buffers' stores go out as NONTEMPORAL ones: written once, read by nobody in this launch (the quad phase takes its vertices from
+// LDS), 1.6 GB of them per all-surface step that would otherwise push the tiles' lines — which neighbouring chunks are about to read — out of
+// the L2. Measured side by side on one box (tools/ab_bench.sh): mesher 0.470-0.480 -> 0.453-0.457 ms on the all-surface grid, 57.5 -> 55.9 us
+// on the asteroid. (The same run: staging a wave's indices through LDS so that they too leave as consecutive 16-byte stores changed nothing;
+// with NO mesh store at all the launch takes 0.32 ms — the stores cost 0.13 ms although the memory side is at 0.55 of its peak: loads queue
+// behind a CU's own stores.)
+#define IVX_MESH_ST(p, v) __builtin_nontemporal_store((v), (p))
 // The mesher's main pass. One workgroup (256 threads, four per CU: <= 128 VGPRs by amdgpu_waves_per_eu(4) on the kernels) walks its share of
 // the chunks that have a mesh, as a two-stage pipeline over chunks — the tile of the walk's NEXT chunk is fetched while the current chunk is
 // meshed from the tile in LDS:
@@ -1233,6 +1240,7 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
     // wait for these loads was a wait for every store of the round to be acknowledged, once per chunk, in every wave. Here only the previous
     // round's quad stores are older, and the order phase has covered most of their trip and of the loads'.
     if (have_next) tile_pin(T);
+    if (have) IVX_T(g, li, 6);  // (order built and the next tile's loads in, this wave)
     __syncthreads();  // (3)
     if (have) IVX_T(g, li, 2);  // vertex order built
     // the entry behind the ticket (the atomic is older than the tile's loads: it has returned): one wave's uniform load, waited for before that
@@ -1311,12 +1319,12 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
         const uint32_t qslot0 = (uint32_t)s_qrow[cr] + __popc(qb.x & (below | (below << 17))) + __popc(qb.y & ((below >> 15) | (below << 2)));
         if (v_live) {
             const size_t gv = (size_t)voff + v;
-            positions[3 * gv + 0] = position.x;
-            positions[3 * gv + 1] = position.y;
-            positions[3 * gv + 2] = position.z;
-            normals[3 * gv + 0] = normal.x;
-            normals[3 * gv + 1] = normal.y;
-            normals[3 * gv + 2] = normal.z;
+            IVX_MESH_ST(positions + 3 * gv + 0, position.x);
+            IVX_MESH_ST(positions + 3 * gv + 1, position.y);
+            IVX_MESH_ST(positions + 3 * gv + 2, position.z);
+            IVX_MESH_ST(normals + 3 * gv + 0, normal.x);
+            IVX_MESH_ST(normals + 3 * gv + 1, normal.y);
+            IVX_MESH_ST(normals + 3 * gv + 2, normal.z);
             s_vpos[0][v] = position.x;
             s_vpos[1][v] = position.y;
             s_vpos[2][v] = position.z;
@@ -1328,6 +1336,7 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
             if ((qb.y >> (2 + k)) & 1u) s_quad[qslot] = (uint16_t)(cid | (2 << 13));                              // Z
         }
     }
+    if (have) IVX_T(g, li, 7);  // (wave 0's vertices written)
     if (have_next) tile_records(T, s_rec, tid);  // (published by the barrier below: every wave needs them right after its quads)
     __syncthreads();  // (4)
     if (have) IVX_T(g, li, 3);  // vertices written
@@ -1380,7 +1389,7 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
             if (q_live) {
                 const size_t io = (size_t)ioff + (size_t)q * 6;
 #pragma unroll
-                for (int t = 0; t < 6; ++t) indices[io + t] = voff + quad[t];
+                for (int t = 0; t < 6; ++t) IVX_MESH_ST(indices + io + t, voff + quad[t]);
                 if (!(b1 == b2 && b1 == b3 && b1 == b4)) s_hard = 1u;  // (corners of different materials: the general pass redoes the chunk)
             }
             // calculate_index_materials_for_triangle's first case (surface_nets.rs:559-637): one entry, weight 1
@@ -1391,7 +1400,10 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
                 const uint32_t x = lane + 64u * (uint32_t)jx;
                 const uint32_t src = (x * 171u) >> 9;  // x / 3 for x < 192
                 const uint32_t bm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)b1);
-                if (x < rem3) imw[x] = make_uint4(bm, 1u, bm, 1u);
+                if (x < rem3) {
+                    uint32_t* w_ = reinterpret_cast<uint32_t*>(imw + x);
+                    IVX_MESH_ST(w_, bm), IVX_MESH_ST(w_ + 1, 1u), IVX_MESH_ST(w_ + 2, bm), IVX_MESH_ST(w_ + 3, 1u);
+                }
             }
         }
     }

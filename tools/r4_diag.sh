@@ -1,17 +1,17 @@
 #!/bin/bash
 # round-4 diagnostic pass on one box: workgroup timelines of the mesher / derive sweep / evaluator on the all-surface grid (trace build:
-# build/lib_trace.so) and the SQ wait-state counters of the step's kernels. usage: tools/r4_diag.sh <tag> [headline|dense]
+# build/trace_lib.so) and the SQ wait-state counters of the step's kernels. usage: tools/r4_diag.sh <tag> [headline|dense]
 set -u
 tag=${1:-d}
 wl=${2:-dense}
 out=$PWD/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-if [ -f build/lib_trace.so ]; then
+if [ -f build/trace_lib.so ]; then
   for st in remesh derive sample; do
     echo "== wg_trace $st $wl" >> "$out/wg_trace.log"
     if [ $wl = dense ]; then A=dense; else A=""; fi
-    IMPACT_VOXEL_HIP_LIB=$PWD/build/lib_trace.so python tools/wg_trace.py $st $A >> "$out/wg_trace.log" 2>&1
+    IMPACT_VOXEL_HIP_LIB=$PWD/build/trace_lib.so python tools/wg_trace.py $st $A >> "$out/wg_trace.log" 2>&1
   done
 fi
 if [ $wl = dense ]; then export IVX_DIAG_ARGS="--workload dense"; fi
