@@ -612,7 +612,8 @@ def edit_benchmark(ctx, scale, o_big, reps=5):
     obj.close()
     out = {"workload": f"absorbing sphere r={EDIT_RADIUS * scale:.1f} voxels at the surface of the headline body",
            "edit_ms": round(1e3 * float(np.mean(t_edit[1:])), 4), "remesh_after_ms": round(1e3 * float(np.mean(t_remesh[1:])), 4),
-           "sync_after_ms": round(1e3 * float(np.mean(t_sync[1:])), 4), "emptied_voxels": emptied, "touched_chunks": touched,
+           "sync_after_ms": round(1e3 * float(np.mean(t_sync[1:])), 4),
+           "edit_plus_sync_ms": round(1e3 * float(np.mean(t_edit[1:]) + np.mean(t_sync[1:])), 4), "emptied_voxels": emptied, "touched_chunks": touched,
            "invalidated_chunks": invalidated}
     if o_big is not None:
         c = np.array([0.5 * (a + b_) for a, b_ in o_big.info()["occupied_voxel_ranges"]], dtype=np.float32) + EDIT_OFFSET * np.float32(scale)
@@ -623,6 +624,154 @@ def edit_benchmark(ctx, scale, o_big, reps=5):
         same = int(er["emptied_by_type"].sum()) == emptied and bool(np.array_equal(o_sdf, sdf_after[0])) and bool(np.array_equal(o_lab, sdf_after[3]))
         out["cpu_baseline"] = {"ms": 1e3 * (t5 - t4), "emptied_voxels": int(er["emptied_by_type"].sum()), "cores": 1, "kind": "port",
                                "parity": "same voxel bytes and chunk-local labels after the edit" if same else "MISMATCH"}
+    return out
+
+
+def fragments_benchmark(ctx, with_cpu, n_axis=5, frames=4):
+    """Many objects per frame (the reference's manager loops over every voxel object each frame: impact_voxel/src/lib.rs:729-733; fragments
+    come into being together: interaction/fracturing.rs:1047-1189). The config-2 body (256^3) is cut into the Voronoi cells of a jittered
+    n^3 lattice of fracture points (`ivx_copy_polyhedra`); then, per frame and per fragment: one absorbing-sphere edit, the incremental remesh
+    of what it invalidated, the moments — once object by object (the single-object calls, a wait each) and once through the `_many` calls
+    (one launch per chain position for ALL objects, csrc/many.hpp), on two identical sets of fragments; the oracle does the same per object
+    on the host cores."""
+    from impact_amd import capi, many, scenes
+    from impact_amd import fracturing as fr
+    from impact_amd.voxel import VoxelObjectMesh
+
+    graph = scenes.asteroid_scene(1.0)
+    dens = np.ones(256, dtype=np.float32)
+    _, body = make_object(ctx, graph)
+    body.step(capi.STAGE_ALL)
+    cc = np.asarray(body.chunk_counts, dtype=np.float32) * 16.0
+    rng = np.random.default_rng(11)
+    ax = [(np.arange(n_axis) + 0.5) * (c / n_axis) for c in cc]
+    pts = (np.stack(np.meshgrid(*ax, indexing="ij"), axis=-1).reshape(-1, 3) + rng.uniform(-4.0, 4.0, (n_axis ** 3, 3))).astype(np.float32)
+    sets, tets = fr.fragment_plane_sets(pts, np.array([0, 0, 0, cc[0], cc[1], cc[2]], dtype=np.float32))
+
+    def cut():
+        res = body.copy_polyhedra([s_[2] for s_ in sets], [s_[1] for s_ in sets])
+        objs = [child for rc, child, _ in res if rc == 1]
+        for o_ in objs:
+            o_.set_densities(dens)
+        return objs, [k for k, (rc, _, _) in enumerate(res) if rc == 1]
+
+    t0 = time.perf_counter()
+    a_objs, kept = cut()
+    ctx.synchronize()
+    t_cut = time.perf_counter() - t0
+    b_objs, _ = cut()
+    n = len(a_objs)
+    stages0 = capi.STAGE_ALL & ~capi.STAGE_SAMPLE
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ra = [o_.step(stages0) for o_ in a_objs]
+    ctx.synchronize()
+    t1 = time.perf_counter()
+    rb = many.voxel_step_many(b_objs, stages0)
+    ctx.synchronize()
+    t2 = time.perf_counter()
+    first_loop_ms, first_many_ms = 1e3 * (t1 - t0), 1e3 * (t2 - t1)
+    a_mesh, b_mesh = [], []
+    for o_, r_ in zip(a_objs, ra):
+        m_ = VoxelObjectMesh(o_)
+        m_.counts = r_["mesh"].copy()
+        a_mesh.append(m_)
+    for o_, r_ in zip(b_objs, rb):
+        m_ = VoxelObjectMesh(o_)
+        m_.counts = r_["mesh"].copy()
+        b_mesh.append(m_)
+    occ = [np.asarray(r_["occupied"], dtype=np.float32).reshape(-1)[6:].reshape(3, 2) for r_ in rb]
+    zero = [np.zeros(o_.n_chunks, dtype=np.uint8) for o_ in a_objs]
+    for m_, z in zip(a_mesh, zero):  # (the submesh bookkeeping of the fresh meshes, once per full remesh)
+        m_.sync_with_voxel_object(z)
+    many.mesh_sync_many(b_mesh, zero)
+
+    def frame_edits(f):
+        cs, rs = [], []
+        for oc in occ:
+            c = 0.5 * (oc[:, 0] + oc[:, 1])
+            c[f % 3] = oc[f % 3, 1] - 1.0 - 2.0 * (f // 3)
+            cs.append(c.astype(np.float32))
+            rs.append(4.0 + (f % 3))
+        return cs, rs
+
+    t_loop, t_many = [], []
+    for f in range(frames + 1):
+        cs, rs = frame_edits(f)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for o_, m_, c, r in zip(a_objs, a_mesh, cs, rs):
+            e_ = o_.absorb_sphere(c, r + 2.0, r, dens)
+            m_.sync_with_voxel_object(e_["invalidated"])
+            o_.step(capi.STAGE_INERTIA)
+        t1 = time.perf_counter()
+        eb = many.absorb_sphere_many(b_objs, cs, [r + 2.0 for r in rs], rs, dens)
+        many.mesh_sync_many(b_mesh, [e_["invalidated"] for e_ in eb])
+        mom = many.voxel_step_many(b_objs, capi.STAGE_INERTIA)
+        t2 = time.perf_counter()
+        if f:
+            t_loop.append(t1 - t0)
+            t_many.append(t2 - t1)
+    # looped and batched objects hold the same bytes
+    same = True
+    for x, y, mx, my in zip(a_objs, b_objs, a_mesh, b_mesh):
+        for u, v in zip(x.download(), y.download()):
+            same = same and bool(np.array_equal(u, v))
+        for u, v in zip(mx.download(), my.download()):
+            same = same and bool(np.array_equal(np.ascontiguousarray(u).view(np.uint8), np.ascontiguousarray(v).view(np.uint8)))
+    loop_ms, many_ms = 1e3 * float(np.mean(t_loop)), 1e3 * float(np.mean(t_many))
+    out = {"workload": f"config-2 body (256^3) cut into the Voronoi cells of a jittered {n_axis}^3 lattice: {n} fragments of "
+                       f"{int(np.median([o_.n_chunks for o_ in a_objs]))} chunks (median); per frame and fragment: one absorbing sphere (r 4-6 voxels), the "
+                       "incremental remesh of what it invalidated, the ten moments",
+           "objects": n, "frames": frames, "cut_ms": round(1e3 * t_cut, 3),
+           "first_step_looped_ms": round(first_loop_ms, 3), "first_step_many_ms": round(first_many_ms, 3),
+           "frame_looped_ms": round(loop_ms, 4), "frame_many_ms": round(many_ms, 4), "speedup": round(loop_ms / many_ms, 2),
+           "objects_per_s_looped": n / (loop_ms * 1e-3), "objects_per_s_many": n / (many_ms * 1e-3),
+           "parity": {"looped_equals_many": same}}
+    if with_cpu:
+        import oracle_lib as ol
+        import parity_util as pu
+
+        o_body = ol.OracleObject.from_sdf(graph, 1.0, 0)
+        o_body.update_occupied_voxel_ranges()
+        o_body.compute_all_derived_state()
+        o_objs = []
+        for k in kept:
+            rc, co, _ = o_body.clip_polyhedron(sets[k][1], sets[k][2], copy=True)
+            assert rc == 1
+            co.update_occupied_voxel_ranges()
+            o_objs.append(co)
+        o_mesh = [ol.OracleMeshHandle(o_) for o_ in o_objs]
+        t_cpu = []
+        for f in range(frames + 1):
+            cs, rs = frame_edits(f)
+            t0 = time.perf_counter()
+            for o_, m_, c, r in zip(o_objs, o_mesh, cs, rs):
+                e_ = o_.absorb_sphere(c, r + 2.0, r, dens)
+                m_.sync(e_["invalidated"])
+                o_.inertia(dens)
+            t_cpu.append(time.perf_counter() - t0)
+        equal = True
+        for o_, g_, om, gm in zip(o_objs, b_objs, o_mesh, b_mesh):
+            o_sdf, o_typ, o_flg, o_lab, _ = o_.export_dense()
+            g_sdf, g_typ, g_flg, g_lab, _ = g_.download()
+            ne = (o_flg & 1) == 0
+            equal = equal and bool(np.array_equal(o_sdf, g_sdf)) and bool(np.array_equal(o_lab, g_lab)) and bool(np.array_equal(o_flg[ne], g_flg[ne]))
+            want = om.get()
+            pos, nrm, idx, im, sub = gm.download()
+            equal = equal and len(sub) == len(want.submeshes) and bool(np.array_equal(sub["index_offset"], want.submeshes[:, 3]))
+            for sm in want.submeshes:
+                io, ic, vo, vc = int(sm[3]), int(sm[4]), int(sm[13]), int(sm[14])
+                equal = equal and bool(np.array_equal(idx[io:io + ic], want.indices[io:io + ic])) and bool(
+                    np.array_equal(pos[vo:vo + vc].view(np.uint32), want.positions[vo:vo + vc].view(np.uint32)))
+        out["parity"]["every_object_equals_the_oracle"] = equal
+        cpu_ms = 1e3 * float(np.mean(t_cpu[1:]))
+        out["cpu_baseline"] = {"frame_ms": cpu_ms, "objects_per_s": n / (cpu_ms * 1e-3), "cores": 1, "kind": "port",
+                               "sample": f"the same {frames} frames over the same {n} fragments, object by object, single thread"}
+    for o_ in a_objs + b_objs:
+        o_.close()
+    tets.close()
+    body.close()
     return out
 
 
@@ -962,6 +1111,7 @@ def main():
             out["config2"] = config2_benchmark(ctx, args, with_cpu)
             out["config3"] = config3_benchmark(ctx, args, with_cpu)
             out["config5_one_gpu"] = config5_benchmark(ctx, args)
+            out["fragments"] = fragments_benchmark(ctx, with_cpu)
             pile, w = pile_benchmark(ctx, with_cpu)
             out["pile"] = pile
             # the full frame: the voxel step of the headline body + the pile's solve, enqueued back to back, one wait

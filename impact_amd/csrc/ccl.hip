@@ -281,25 +281,27 @@ __global__ __launch_bounds__(256) void k_region_stats(GridView g, uint32_t x_off
 }  // namespace
 
 int ivx_launch_ccl_local(ivx_grid* g, int fused) {
+    if (int rc_l = ivx_ensure_active_list(g)) return rc_l;
     GridView v = ivx_view(g);
-    if (!fused) IVX_HIP_CHECK(hipMemsetAsync(g->rscalar, 0, 16 * sizeof(uint32_t), g->ctx->stream));
+    if (!fused) IVX_HIP_CHECK(ivx_memset_async(g->rscalar, 0, 16 * sizeof(uint32_t), g->ctx->stream));
     g->scratch_dirty |= IVX_SCRATCH_REGIONS;
     uint32_t* multi_list = g->ccl_scratch;  // reused by the resolve pass afterwards
     g->planes_compact = 1;
     if (!fused)  // else k_derive labelled the chunks in the same sweep
-        hipLaunchKernelGGL(k_ccl_local, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->flags, g->llabel, g->info, g->rparent, g->rscalar,
+        IVX_KLAUNCH(k_ccl_local, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->flags, g->llabel, g->info, g->rparent, g->rscalar,
                            multi_list, ivx_wc(g), g->active_list);
     const uint32_t exact_blocks = g->n_chunks < 1024u ? g->n_chunks : 1024u;
-    hipLaunchKernelGGL(k_ccl_local_exact, dim3(exact_blocks), dim3(256), 0, g->ctx->stream, g->flags, g->llabel, g->info, g->rparent, g->rscalar, multi_list);
+    IVX_KLAUNCH(k_ccl_local_exact, dim3(exact_blocks), dim3(256), 0, g->ctx->stream, g->flags, g->llabel, g->info, g->rparent, g->rscalar, multi_list);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 
 int ivx_launch_ccl_local_only(ivx_grid* g) {
+    if (int rc_l = ivx_ensure_active_list(g)) return rc_l;
     GridView v = ivx_view(g);
     g->planes_compact = 1;
     g->scratch_dirty |= IVX_SCRATCH_REGIONS;
-    hipLaunchKernelGGL(k_ccl_local, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->flags, g->llabel, g->info, g->rparent, g->rscalar, g->ccl_scratch,
+    IVX_KLAUNCH(k_ccl_local, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->flags, g->llabel, g->info, g->rparent, g->rscalar, g->ccl_scratch,
                        ivx_wc(g), g->active_list);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
@@ -307,9 +309,9 @@ int ivx_launch_ccl_local_only(ivx_grid* g) {
 
 int ivx_launch_ccl_merge(ivx_grid* g) {
     GridView v = ivx_view(g);
-    hipLaunchKernelGGL(k_ccl_merge_columns, dim3((g->cc[0] * g->cc[1] + 3u) / 4u), dim3(256), 0, g->ctx->stream, v, g->chunk_touch, g->rparent);
+    IVX_KLAUNCH(k_ccl_merge_columns, dim3((g->cc[0] * g->cc[1] + 3u) / 4u), dim3(256), 0, g->ctx->stream, v, g->chunk_touch, g->rparent);
     const uint32_t multi_blocks = g->n_chunks < 256u ? g->n_chunks : 256u;
-    hipLaunchKernelGGL(k_ccl_merge_multi, dim3(multi_blocks), dim3(256), 0, g->ctx->stream, v, g->llabel, g->rparent, g->rscalar, g->ccl_scratch);
+    IVX_KLAUNCH(k_ccl_merge_multi, dim3(multi_blocks), dim3(256), 0, g->ctx->stream, v, g->llabel, g->rparent, g->rscalar, g->ccl_scratch);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -320,12 +322,12 @@ int ivx_launch_ccl_resolve(ivx_grid* g) {
     uint32_t* root_offsets = g->ccl_scratch + g->n_chunks;
     const uint32_t nb = (g->n_chunks + 255u) / 256u;
     uint32_t* group_sums = g->group_sums;
-    hipLaunchKernelGGL(k_ccl_flatten, dim3(nb), dim3(256), 0, g->ctx->stream, v, g->rparent, root_counts, group_sums);
+    IVX_KLAUNCH(k_ccl_flatten, dim3(nb), dim3(256), 0, g->ctx->stream, v, g->rparent, root_counts, group_sums);
     if (nb <= ASSIGN_MAX_GROUPS) {
-        hipLaunchKernelGGL(k_ccl_assign<true>, dim3(nb), dim3(256), 0, g->ctx->stream, v, g->rparent, root_counts, group_sums, nb, g->rcompid, g->rscalar);
+        IVX_KLAUNCH(k_ccl_assign<true>, dim3(nb), dim3(256), 0, g->ctx->stream, v, g->rparent, root_counts, group_sums, nb, g->rcompid, g->rscalar);
     } else {
-        hipLaunchKernelGGL(k_scan_groups, dim3(nb), dim3(256), 0, g->ctx->stream, g->n_chunks, root_counts, group_sums, root_offsets, g->rscalar);
-        hipLaunchKernelGGL(k_ccl_assign<false>, dim3(nb), dim3(256), 0, g->ctx->stream, v, g->rparent, root_offsets, group_sums, nb, g->rcompid, g->rscalar);
+        IVX_KLAUNCH(k_scan_groups, dim3(nb), dim3(256), 0, g->ctx->stream, g->n_chunks, root_counts, group_sums, root_offsets, g->rscalar);
+        IVX_KLAUNCH(k_ccl_assign<false>, dim3(nb), dim3(256), 0, g->ctx->stream, v, g->rparent, root_offsets, group_sums, nb, g->rcompid, g->rscalar);
     }
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
@@ -336,14 +338,14 @@ int ivx_launch_ccl_dense_labels(ivx_grid* g, uint32_t* d_labels) {
         int rc = ivx_ensure_dense(g);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_ccl_dense, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, g->n_chunks, g->llabel, g->rcompid, d_labels);
+    IVX_KLAUNCH(k_ccl_dense, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, g->n_chunks, g->llabel, g->rcompid, d_labels);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 
 int ivx_launch_halo_pack_both(ivx_grid* g, void* buf_lo, void* buf_hi, int with_face_labels) {
     GridView v = ivx_view(g);
-    hipLaunchKernelGGL(k_halo_pack_both, dim3(g->cc[1] * g->cc[2], 2), dim3(256), 0, g->ctx->stream, v, static_cast<uint8_t*>(buf_lo),
+    IVX_KLAUNCH(k_halo_pack_both, dim3(g->cc[1] * g->cc[2], 2), dim3(256), 0, g->ctx->stream, v, static_cast<uint8_t*>(buf_lo),
                        static_cast<uint8_t*>(buf_hi), with_face_labels ? 1u : 0u, g->llabel, g->rcompid, g->rscalar,
                        (with_face_labels && g->pairs_dev) ? g->pairs_dev : nullptr);
     IVX_HIP_CHECK(hipGetLastError());
@@ -353,7 +355,7 @@ int ivx_launch_halo_pack_both(ivx_grid* g, void* buf_lo, void* buf_hi, int with_
 
 int ivx_launch_face_ids(ivx_grid* g, int side, uint16_t* d_out) {
     GridView v = ivx_view(g);
-    hipLaunchKernelGGL(k_face_ids, dim3(g->cc[1] * g->cc[2]), dim3(256), 0, g->ctx->stream, v, (uint32_t)side, g->llabel, g->rcompid, g->rscalar, d_out);
+    IVX_KLAUNCH(k_face_ids, dim3(g->cc[1] * g->cc[2]), dim3(256), 0, g->ctx->stream, v, (uint32_t)side, g->llabel, g->rcompid, g->rscalar, d_out);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -361,20 +363,20 @@ int ivx_launch_face_ids(ivx_grid* g, int side, uint16_t* d_out) {
 int ivx_launch_face_pairs(ivx_grid* g, int side, const uint16_t* d_nbr, uint32_t* d_count, void* d_pairs, uint32_t cap, uint32_t* d_seen) {
     GridView v = ivx_view(g);
     if (d_seen == d_count + 4) {  // count and seen-table are neighbours (the enqueue path): one fill, unless the pack kernel before cleared them
-        if (!(g->pairs_zeroed && d_count == g->pairs_dev)) IVX_HIP_CHECK(hipMemsetAsync(d_count, 0, (4 + 128) * sizeof(uint32_t), g->ctx->stream));
+        if (!(g->pairs_zeroed && d_count == g->pairs_dev)) IVX_HIP_CHECK(ivx_memset_async(d_count, 0, (4 + 128) * sizeof(uint32_t), g->ctx->stream));
         g->pairs_zeroed = 0;
     } else {
-        IVX_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t), g->ctx->stream));
-        if (d_seen) IVX_HIP_CHECK(hipMemsetAsync(d_seen, 0, 128 * sizeof(uint32_t), g->ctx->stream));
+        IVX_HIP_CHECK(ivx_memset_async(d_count, 0, sizeof(uint32_t), g->ctx->stream));
+        if (d_seen) IVX_HIP_CHECK(ivx_memset_async(d_seen, 0, 128 * sizeof(uint32_t), g->ctx->stream));
     }
-    hipLaunchKernelGGL(k_face_pairs, dim3((g->cc[1] * g->cc[2] + FACE_COLS - 1u) / FACE_COLS), dim3(256), 0, g->ctx->stream, v, (uint32_t)side, g->llabel, g->rcompid, d_nbr,
+    IVX_KLAUNCH(k_face_pairs, dim3((g->cc[1] * g->cc[2] + FACE_COLS - 1u) / FACE_COLS), dim3(256), 0, g->ctx->stream, v, (uint32_t)side, g->llabel, g->rcompid, d_nbr,
                        d_count, static_cast<uint2*>(d_pairs), cap, d_seen);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 
 int ivx_launch_step_record(ivx_grid* g, const uint32_t* d_pair_count, const void* d_pairs, uint32_t max_pairs, void* d_record, bool with_results) {
-    hipLaunchKernelGGL(k_step_record, dim3(1), dim3(256), 0, g->ctx->stream, g->rscalar, d_pair_count, static_cast<const uint2*>(d_pairs),
+    IVX_KLAUNCH(k_step_record, dim3(1), dim3(256), 0, g->ctx->stream, g->rscalar, d_pair_count, static_cast<const uint2*>(d_pairs),
                        g->chunk_offsets + 2 * (size_t)g->n_chunks, g->partials + g->partial_blocks * 10, g->x_off, max_pairs,
                        static_cast<unsigned long long*>(d_record), ivx_wc(g), g->samp_len ? g->samp_len + g->n_chunks : nullptr,
                        with_results ? g->result_host_dev : nullptr);
@@ -400,15 +402,15 @@ int ivx_launch_region_stats(ivx_grid* g, const float* d_dens, void* d_buf, uint3
     p += sizeof(uint32_t) * n;
     o.root = reinterpret_cast<uint32_t*>(p);
     const size_t head = (sizeof(unsigned long long) + sizeof(double) * 10) * n;
-    IVX_HIP_CHECK(hipMemsetAsync(d_buf, 0, head, g->ctx->stream));
-    IVX_HIP_CHECK(hipMemsetAsync(o.lo, 0xFF, sizeof(uint32_t) * 3 * n, g->ctx->stream));
-    IVX_HIP_CHECK(hipMemsetAsync(o.hi, 0, sizeof(uint32_t) * (3 + 1 + 1 + 1) * n, g->ctx->stream));
+    IVX_HIP_CHECK(ivx_memset_async(d_buf, 0, head, g->ctx->stream));
+    IVX_HIP_CHECK(ivx_memset_async(o.lo, 0xFF, sizeof(uint32_t) * 3 * n, g->ctx->stream));
+    IVX_HIP_CHECK(ivx_memset_async(o.hi, 0, sizeof(uint32_t) * (3 + 1 + 1 + 1) * n, g->ctx->stream));
     GridView v = ivx_view(g);
     {
         int rc = ivx_ensure_dense(g);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_region_stats, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, v, g->x_off, g->llabel, g->rparent, g->rcompid, d_dens, o);
+    IVX_KLAUNCH(k_region_stats, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, v, g->x_off, g->llabel, g->rparent, g->rcompid, d_dens, o);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

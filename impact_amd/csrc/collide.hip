@@ -392,11 +392,11 @@ int ivx_launch_probe_select(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, uint3
                             uint32_t* d_err, const uint32_t* d_slots) {
     const uint32_t n_blocks = 1u << (3u * (4u - log2_bs));
     if (n_blocks <= PROBE_SMALLV)
-        hipLaunchKernelGGL((k_probe_select<PROBE_SMALLV, true>), dim3(n_sub), dim3(256), 0, g->ctx->stream, g->submeshes, g->positions, g->normals, g->indices,
+        IVX_KLAUNCH((k_probe_select<PROBE_SMALLV, true>), dim3(n_sub), dim3(256), 0, g->ctx->stream, g->submeshes, g->positions, g->normals, g->indices,
                            d_corner_list, log2_bs, 1.0f / g->extent, d_sel, d_counts, d_err, d_slots);
-    hipLaunchKernelGGL((k_probe_select<PROBE_MAXV, false>), dim3(n_sub), dim3(256), 0, g->ctx->stream, g->submeshes, g->positions, g->normals, g->indices,
+    IVX_KLAUNCH((k_probe_select<PROBE_MAXV, false>), dim3(n_sub), dim3(256), 0, g->ctx->stream, g->submeshes, g->positions, g->normals, g->indices,
                        d_corner_list, log2_bs, 1.0f / g->extent, d_sel, d_counts, d_err, d_slots);
-    if (d_offsets) hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(256), 0, g->ctx->stream, n_sub, d_counts, d_offsets);
+    if (d_offsets) IVX_KLAUNCH(k_scan_counts, dim3(1), dim3(256), 0, g->ctx->stream, n_sub, d_counts, d_offsets);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -405,7 +405,7 @@ int ivx_launch_probe_select(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, uint3
 int ivx_launch_probe_gather(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, const uint32_t* d_sel, const uint32_t* d_counts, const uint32_t* d_offsets,
                             uint32_t* d_entries, const uint32_t* d_slots) {
     const uint32_t n_blocks = 1u << (3u * (4u - log2_bs));
-    hipLaunchKernelGGL(k_probe_gather, dim3(n_sub), dim3(64), 0, g->ctx->stream, g->submeshes, g->positions, d_sel, d_counts, d_offsets, n_blocks,
+    IVX_KLAUNCH(k_probe_gather, dim3(n_sub), dim3(64), 0, g->ctx->stream, g->submeshes, g->positions, d_sel, d_counts, d_offsets, n_blocks,
                        g->probe_points, g->probe_chunk, d_entries, d_slots);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
@@ -445,14 +445,14 @@ int ivx_launch_mutual_pass(ivx_grid* prober, ivx_grid* sampled, const ivx_mutual
     p.dynamic_friction = h->response[2];
     const uint32_t n_wg = (prober->n_probe_points + 255u) / 256u;
     if (n_wg == 0) return IVX_OK;
-    if (!emit) hipLaunchKernelGGL(k_mut_count, dim3(n_wg), dim3(256), 0, prober->ctx->stream, p, prober->probe_points, prober->probe_chunk, d_counts);
-    else hipLaunchKernelGGL(k_mut_emit, dim3(n_wg), dim3(256), 0, prober->ctx->stream, p, prober->probe_points, prober->probe_chunk, d_offsets, cap, d_out);
+    if (!emit) IVX_KLAUNCH(k_mut_count, dim3(n_wg), dim3(256), 0, prober->ctx->stream, p, prober->probe_points, prober->probe_chunk, d_counts);
+    else IVX_KLAUNCH(k_mut_emit, dim3(n_wg), dim3(256), 0, prober->ctx->stream, p, prober->probe_points, prober->probe_chunk, d_offsets, cap, d_out);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 
 int ivx_launch_scan_counts(ivx_ctx* ctx, uint32_t n, const uint32_t* d_counts, uint32_t* d_offsets) {
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(256), 0, ctx->stream, n, d_counts, d_offsets);
+    IVX_KLAUNCH(k_scan_counts, dim3(1), dim3(256), 0, ctx->stream, n, d_counts, d_offsets);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

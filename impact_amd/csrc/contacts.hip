@@ -290,10 +290,10 @@ int ivx_launch_sphere_contacts(ivx_grid* g, const uint32_t lo[3], const uint32_t
     p.dynamic_friction = response[2];
     const uint32_t n_box = cc[0] * cc[1] * cc[2];
     if (!emit) {
-        hipLaunchKernelGGL(k_svc_count, dim3(n_box), dim3(256), 0, g->ctx->stream, p, g->flags, d_counts);
-        hipLaunchKernelGGL(k_svc_scan, dim3(1), dim3(256), 0, g->ctx->stream, n_box, d_counts, d_offsets, d_total);
+        IVX_KLAUNCH(k_svc_count, dim3(n_box), dim3(256), 0, g->ctx->stream, p, g->flags, d_counts);
+        IVX_KLAUNCH(k_svc_scan, dim3(1), dim3(256), 0, g->ctx->stream, n_box, d_counts, d_offsets, d_total);
     } else {
-        hipLaunchKernelGGL(k_svc_emit, dim3(n_box), dim3(256), 0, g->ctx->stream, p, g->flags, d_offsets, cap, d_out);
+        IVX_KLAUNCH(k_svc_emit, dim3(n_box), dim3(256), 0, g->ctx->stream, p, g->flags, d_offsets, cap, d_out);
     }
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;

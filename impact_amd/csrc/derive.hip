@@ -20,6 +20,7 @@
 // 16 voxels of a row is a 16-bit mask; the 18x18 halo of masks sits in LDS.
 #include "chunk_passes.hpp"
 #include "table_roles.hpp"
+#include "many.hpp"
 
 namespace {
 
@@ -52,19 +53,39 @@ __device__ __forceinline__ uint32_t nbr_row_mask(const GridView& g, const ivx_ch
 // (the "active" chunks) for the workgroup-per-chunk kernels. A Void chunk has no voxels; a chunk generated Uniform whose six
 // neighbours were generated Uniform too is solid all round and stays Uniform. Neither has planes (compact planes), so all of
 // their per-step state is the record, the occupied sub-box, one region and empty mesh counts.
-__global__ __launch_bounds__(256) void k_chunk_pre(GridView g, ivx_chunk_info* __restrict__ info, uint32_t* __restrict__ bbox,
-                                                   uint32_t* __restrict__ mesh_counts, uint8_t* __restrict__ chunk_class, uint8_t* __restrict__ touch,
-                                                   uint32_t* __restrict__ rparent, uint32_t* __restrict__ work_counts, uint32_t* __restrict__ next_work_count,
-                                                   uint32_t* __restrict__ active_list, ivx_roles::PresetArgs preset) {
+struct ChunkPreArgs {
+    GridView g;
+    ivx_chunk_info* info;
+    uint32_t* bbox;
+    uint32_t* mesh_counts;
+    uint8_t* chunk_class;
+    uint8_t* touch;
+    uint32_t* rparent;
+    uint32_t* work_counts;
+    uint32_t* next_work_count;
+    uint32_t* active_list;
+    ivx_roles::PresetArgs preset;
+};
+__device__ __forceinline__ void chunk_pre_body(const ChunkPreArgs& a, uint32_t bid, uint32_t) {
+    const GridView& g = a.g;
+    ivx_chunk_info* __restrict__ info = a.info;
+    uint32_t* __restrict__ bbox = a.bbox;
+    uint32_t* __restrict__ mesh_counts = a.mesh_counts;
+    uint8_t* __restrict__ chunk_class = a.chunk_class;
+    uint8_t* __restrict__ touch = a.touch;
+    uint32_t* __restrict__ rparent = a.rparent;
+    uint32_t* __restrict__ work_counts = a.work_counts;
+    uint32_t* __restrict__ next_work_count = a.next_work_count;
+    uint32_t* __restrict__ active_list = a.active_list;
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_base;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     // this launch is the first of the derive stages: it also presets the scratch words the later stages of the call start from,
     // and zeroes the counter the NEXT sweep will append under (the two counters alternate)
-    ivx_roles::role_preset(preset, blockIdx.x * 256u + tid);
-    if (blockIdx.x == 0 && tid == 0) next_work_count[0] = 0u;
+    ivx_roles::role_preset(a.preset, bid * 256u + tid);
+    if (bid == 0 && tid == 0) next_work_count[0] = 0u;
     const uint32_t n_chunks = g.cx * g.cy * g.cz;
-    const uint32_t chunk = blockIdx.x * 256u + tid;
+    const uint32_t chunk = bid * 256u + tid;
     const bool live = chunk < n_chunks;
     bool settled = false;
     if (live) {
@@ -118,6 +139,9 @@ __global__ __launch_bounds__(256) void k_chunk_pre(GridView g, ivx_chunk_info* _
         active_list[off] = chunk;
     }
 }
+__global__ __launch_bounds__(256) void k_chunk_pre(ChunkPreArgs a) { chunk_pre_body(a, blockIdx.x, gridDim.x); }
+IVX_MANY_TWIN(k_chunk_pre_many, ChunkPreArgs, chunk_pre_body, __launch_bounds__(256))
+IVX_MANY_LAUNCHER(many_chunk_pre, k_chunk_pre_many, ChunkPreArgs, 256)
 
 // The global loads of a chunk's first phase, in flight: the chunk's own record and rows; across each z face one byte per thread; (threads
 // 0..63) one 16-byte row across an x or y face; the three neighbours' generated kinds. Addresses are clamped to valid ones and the
@@ -191,16 +215,67 @@ struct DeriveFused {
     double* chunk_moments;
 };
 
+// BOX MODE (the sweep after an edit: ivx_launch_derive_box). The reference patches derived state around the chunks an edit touched
+// (handle_chunk_voxels_modified + update_upper_boundary_adjacencies_for_chunks_in_ranges, object/intersection.rs:255-262, 532-598); derived state
+// being a pure function of the voxels and the generated kinds, the same result comes from sweeping the box of touched chunks grown by one
+// chunk each way — a few hundred chunks instead of the object's whole active list. `n` > 0: entry li of the walk is chunk li of the box
+// (any kind: a Void chunk is settled on the spot), its list entry goes to `out_list`. The launch's blocks beyond `derive_blocks` reset the
+// region forest of every chunk OUTSIDE the box (the global resolve that follows starts from one root per local region everywhere) and list
+// the chunks with several regions among them (role_region_reset).
+struct DeriveBox {
+    uint32_t n, derive_blocks;
+    uint32_t lo[3], cc[3];
+    uint32_t* out_list;
+};
+__device__ __forceinline__ void role_region_reset(uint32_t bid, const GridView& g, const DeriveBox& box, const ivx_chunk_info* __restrict__ info,
+                                                  uint32_t* __restrict__ rparent, uint32_t* __restrict__ rscalar, uint32_t* __restrict__ multi_list) {
+    const uint32_t chunk = bid * 256u + threadIdx.x;
+    if (chunk >= g.cx * g.cy * g.cz) return;
+    const uint32_t ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
+    if (ci - box.lo[0] < box.cc[0] && cj - box.lo[1] < box.cc[1] && ck - box.lo[2] < box.cc[2]) return;  // (unsigned: inside the box)
+    const uint32_t rc = info[chunk].region_count;
+    for (uint32_t r = 0; r < rc; ++r) rparent[(size_t)chunk * 256 + r] = chunk * 256u + r;
+    if (rc > 1u) multi_list[atomicAdd(&rscalar[2], 1u)] = chunk;  // (as ccl_local_chunk lists them: role_ccl_merge_multi joins their regions)
+}
+
 // (amdgpu_waves_per_eu(7): seven workgroups per CU is what the 20 KB of LDS allow; the workgroups are latency-bound, so residency is
 // throughput, and the register budget is set to match. A software pipeline over a resident set of workgroups — the next chunk's loads in
 // flight across the region and moment passes, as the mesher does — was tried: its 119 registers leave four workgroups per CU, and four
 // pipelined ones were no faster than seven plain ones; what did help is the grid's size, see ivx_launch_derive.)
+struct DeriveArgs {
+    GridView g;
+    int8_t* sdf_rw;
+    uint8_t* type_rw;
+    uint8_t* flags_out;
+    ivx_chunk_info* info;
+    uint32_t* bbox;
+    uint8_t* touch;
+    uint16_t* signs;
+    uint8_t* kface_out;
+    const uint32_t* work_counts;
+    uint32_t* active_list;
+    const uint32_t* list_in;
+    DeriveFused fz;
+    uint32_t signs_type, pad_;
+    DeriveBox box;
+};
 template <bool SIGNS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_derive(GridView g, int8_t* __restrict__ sdf_rw, uint8_t* __restrict__ type_rw, uint8_t* __restrict__ flags_out,
-                                                ivx_chunk_info* __restrict__ info, uint32_t* __restrict__ bbox, uint8_t* __restrict__ touch,
-                                                uint16_t* __restrict__ signs, uint8_t* __restrict__ kface_out,
-                                                const uint32_t* __restrict__ work_counts, uint32_t* __restrict__ active_list,
-                                                const uint32_t* __restrict__ list_in, DeriveFused fz, uint32_t signs_type) {
+__device__ __forceinline__ void derive_body(const DeriveArgs& a_, uint32_t bid_, uint32_t nb_) {
+    const GridView& g = a_.g;
+    int8_t* __restrict__ sdf_rw = a_.sdf_rw;
+    uint8_t* __restrict__ type_rw = a_.type_rw;
+    uint8_t* __restrict__ flags_out = a_.flags_out;
+    ivx_chunk_info* __restrict__ info = a_.info;
+    uint32_t* __restrict__ bbox = a_.bbox;
+    uint8_t* __restrict__ touch = a_.touch;
+    uint16_t* __restrict__ signs = a_.signs;
+    uint8_t* __restrict__ kface_out = a_.kface_out;
+    const uint32_t* __restrict__ work_counts = a_.work_counts;
+    uint32_t* __restrict__ active_list = a_.active_list;
+    const uint32_t* __restrict__ list_in = a_.list_in;
+    const DeriveFused& fz = a_.fz;
+    const uint32_t signs_type = a_.signs_type;
+    const DeriveBox& box = a_.box;
     __shared__ uint32_t occ[18][18];  // non-empty masks of rows (i+1, j+1); halo rows from neighbour chunks
     __shared__ uint32_t cnt[13];      // own face non-empty counts [0..6), neighbour face non-empty counts [6..12), [12] touch bits
     __shared__ CclShared s_ccl;
@@ -210,16 +285,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     // next chunk's starts behind the loop's barrier — an array of their own would be the kilobyte that takes the seventh workgroup off a CU)
     double (*s_red)[10] = reinterpret_cast<double (*)[10]>(s_ccl.par);
     const uint32_t tid = threadIdx.x;
+    if (!SIGNS && box.n && bid_ >= box.derive_blocks) {  // (box mode: the blocks behind the sweep's)
+        role_region_reset(bid_ - box.derive_blocks, g, box, info, fz.rparent, fz.rscalar, fz.multi_list);
+        return;
+    }
     if (fz.parts & IVX_PART_MOMENTS) s_dens[tid] = fz.dens[tid], s_mtab[tid] = moments_table_entry(tid);  // (the first barrier of the loop publishes them)
     const int ti = tid >> 4, tj = tid & 15;
-    const uint32_t n_active = work_counts[0];
+    const bool in_box = !SIGNS && box.n != 0u;
+    const uint32_t n_active = in_box ? box.n : work_counts[0];
+    const uint32_t n_walk = in_box ? box.derive_blocks : nb_;
     // bounded walk over the active list (virtual block ids give each XCD a contiguous stretch of it). (`list_in` IS `active_list`, through a
     // read-only pointer so that the entry comes by a scalar load: a workgroup reads only entries it alone rewrites — later, and never the chunk
     // index in their low bits)
-    for (uint32_t li = ivx_xcd_remap(blockIdx.x, gridDim.x); li < n_active; li += gridDim.x) {
+    for (uint32_t li = ivx_xcd_remap(bid_, n_walk); li < n_active; li += n_walk) {
     __syncthreads();  // the previous chunk's LDS use is over
     IVX_T(g, li, 0);
-    const uint32_t chunk = IVX_LIST_CHUNK(list_in[li]);
+    uint32_t chunk;
+    if (in_box) {
+        const uint32_t bk = li % box.cc[2], bj = (li / box.cc[2]) % box.cc[1], bi = li / (box.cc[2] * box.cc[1]);
+        chunk = ((box.lo[0] + bi) * g.cy + (box.lo[1] + bj)) * g.cz + (box.lo[2] + bk);
+    } else {
+        chunk = IVX_LIST_CHUNK(list_in[li]);
+    }
     DeriveLoads L;
     derive_issue<SIGNS>(g, info, chunk, tid, L);
     const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
@@ -267,7 +354,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         kf[768] = (uint8_t)(own_types.w >> 24);
     }
     if (tid < 13) cnt[tid] = 0;
-    const uint32_t m = own_uniform ? 0xFFFFu : own_row_mask;
+    // (a Void chunk reaches the sweep in box mode only: no voxels whatever its stale planes hold)
+    const uint32_t m = own_uniform ? 0xFFFFu : (own_info.gen_kind == KIND_VOID ? 0u : own_row_mask);
     occ[ti + 1][tj + 1] = m;
     if (!SIGNS) signs[(size_t)chunk * 256 + tid] = (uint16_t)m;  // for the mesher's count pass (SIGNS: the sampler's, and a demoted chunk's below)
 
@@ -453,7 +541,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         touch[chunk] = (uint8_t)cnt[12];
         {  // the list entry carries what the later stages need from the record
             const bool obscured = kind == KIND_NONUNIFORM && nbr_full == 0x3Fu;
-            active_list[li] = chunk | (kind << 24) | (gen << 26) | ((kind == KIND_NONUNIFORM && !obscured) ? (1u << 28) : 0u);
+            const uint32_t entry = chunk | (kind << 24) | (gen << 26) | ((kind == KIND_NONUNIFORM && !obscured) ? (1u << 28) : 0u);
+            if (!in_box) active_list[li] = entry;
+            else if (box.out_list) box.out_list[li] = entry;
         }
         ivx_chunk_info ci_ = own_info;
         ci_.kind = (uint8_t)kind;
@@ -485,6 +575,81 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     IVX_T(g, li, 5);
     }
 }
+template <bool SIGNS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_derive(DeriveArgs a) {
+    derive_body<SIGNS>(a, blockIdx.x, gridDim.x);
+}
+IVX_MANY_TWIN(k_derive_planes_many, DeriveArgs, derive_body<false>, __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))))
+IVX_MANY_TWIN(k_derive_signs_many, DeriveArgs, derive_body<true>, __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))))
+IVX_MANY_LAUNCHER(many_derive_planes, k_derive_planes_many, DeriveArgs, 256)
+IVX_MANY_LAUNCHER(many_derive_signs, k_derive_signs_many, DeriveArgs, 256)
+
+// The active list anew from the chunk records alone (after a box sweep changed kinds: ivx_ensure_active_list): k_chunk_pre's rule for what is
+// settled — Void, or generated Uniform among six chunks generated Uniform —, entries with the kinds and the exposure bit the derive sweep would
+// have added, in chunk order. Writes nothing but the list and its counter: every chunk's per-step words are current (the box sweep kept them so).
+struct ListRebuildArgs {
+    GridView g;
+    const ivx_chunk_info* info;
+    uint32_t* work_counts;
+    uint32_t* next_work_count;
+    uint32_t* active_list;
+    uint32_t* mesh_counts;
+};
+__device__ __forceinline__ void list_rebuild_body(const ListRebuildArgs& a, uint32_t bid, uint32_t) {
+    const GridView& g = a.g;
+    const ivx_chunk_info* __restrict__ info = a.info;
+    uint32_t* __restrict__ work_counts = a.work_counts;
+    uint32_t* __restrict__ next_work_count = a.next_work_count;
+    uint32_t* __restrict__ active_list = a.active_list;
+    uint32_t* __restrict__ mesh_counts = a.mesh_counts;
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_base;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (bid == 0 && tid == 0) next_work_count[0] = 0u;
+    const uint32_t n_chunks = g.cx * g.cy * g.cz;
+    const uint32_t chunk = bid * 256u + tid;
+    const bool live = chunk < n_chunks;
+    bool settled = false;
+    uint32_t entry = 0;
+    if (live) {
+        const ivx_chunk_info own = info[chunk];
+        const uint32_t gen = own.gen_kind;
+        settled = gen == KIND_VOID;
+        if (gen == KIND_UNIFORM) {
+            const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
+            if (cj > 0 && ck > 0 && cj + 1 < (int)g.cy && ck + 1 < (int)g.cz) {
+                const uint32_t sx = g.cy * g.cz, sy = g.cz;
+                const bool x_lo = ci > 0 ? info[chunk - sx].gen_kind == KIND_UNIFORM
+                                         : (g.ghost_info[0] != nullptr && g.ghost_info[0][cj * g.cz + ck].gen_kind == KIND_UNIFORM);
+                const bool x_hi = ci + 1 < (int)g.cx ? info[chunk + sx].gen_kind == KIND_UNIFORM
+                                                     : (g.ghost_info[1] != nullptr && g.ghost_info[1][cj * g.cz + ck].gen_kind == KIND_UNIFORM);
+                settled = x_lo && x_hi && info[chunk - sy].gen_kind == KIND_UNIFORM && info[chunk + sy].gen_kind == KIND_UNIFORM &&
+                          info[chunk - 1].gen_kind == KIND_UNIFORM && info[chunk + 1].gen_kind == KIND_UNIFORM;
+            }
+        }
+        const uint32_t kind = own.kind;
+        const bool exposed = kind == KIND_NONUNIFORM && (own.flags & CF_FULLY_OBSCURED) != CF_FULLY_OBSCURED;
+        entry = chunk | (kind << 24) | (gen << 26) | (exposed ? (1u << 28) : 0u);
+        if (settled) {  // (as k_chunk_pre: a chunk off the list has no mesh — one that an edit emptied still has its old counts here)
+            mesh_counts[2 * chunk] = 0;
+            mesh_counts[2 * chunk + 1] = 0;
+        }
+    }
+    const bool active = live && !settled;
+    const unsigned long long bal = __ballot(active);
+    if (lane == 0) s_w[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (tid == 0) s_base = atomicAdd(&work_counts[0], (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
+    __syncthreads();
+    if (active) {
+        uint32_t off = s_base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        for (uint32_t w = 0; w < wave; ++w) off += s_w[w];
+        active_list[off] = entry;
+    }
+}
+__global__ __launch_bounds__(256) void k_list_rebuild(ListRebuildArgs a) { list_rebuild_body(a, blockIdx.x, gridDim.x); }
+IVX_MANY_TWIN(k_list_rebuild_many, ListRebuildArgs, list_rebuild_body, __launch_bounds__(256))
+IVX_MANY_LAUNCHER(many_list_rebuild, k_list_rebuild_many, ListRebuildArgs, 256)
 
 // update_occupied_ranges (object.rs:1149-1280): tight [lo,hi) ranges of non-empty chunks and voxels from
 // the per-chunk boxes written by k_derive. raw[0..6) = minima (chunk lo xyz, voxel lo xyz), raw[6..12) = maxima
@@ -554,11 +719,23 @@ __global__ __launch_bounds__(256) void k_materialize(uint32_t n_chunks, const iv
     *reinterpret_cast<uint4*>(labels + o) = make_uint4(l, l, l, l);
 }
 
+static DeriveArgs derive_args(ivx_grid* g, const GridView& v, const DeriveFused& fz) {
+    DeriveArgs da;
+    memset(&da, 0, sizeof(da));
+    da.g = v, da.sdf_rw = g->sdf, da.type_rw = g->type, da.flags_out = g->flags, da.info = g->info, da.bbox = g->chunk_bbox, da.touch = g->chunk_touch;
+    da.signs = g->chunk_signs, da.kface_out = g->kface, da.work_counts = ivx_wc(g), da.active_list = g->active_list, da.list_in = g->active_list, da.fz = fz;
+    return da;
+}
+static_assert(sizeof(DeriveArgs) % 8 == 0 && sizeof(ChunkPreArgs) % 8 == 0 && sizeof(ListRebuildArgs) % 8 == 0, "argument blocks travel as 8-byte words");
+static const int s_many_registered_derive =
+    (ivx_many_register(IVX_MK_DERIVE_PLANES, many_derive_planes, sizeof(DeriveArgs)), ivx_many_register(IVX_MK_DERIVE_SIGNS, many_derive_signs, sizeof(DeriveArgs)),
+     ivx_many_register(IVX_MK_CHUNK_PRE, many_chunk_pre, sizeof(ChunkPreArgs)), ivx_many_register(IVX_MK_LIST_REBUILD, many_list_rebuild, sizeof(ListRebuildArgs)), 0);
+
 }  // namespace
 
 int ivx_ensure_dense(ivx_grid* g) {
     if (!g->planes_compact) return IVX_OK;
-    hipLaunchKernelGGL(k_materialize, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, g->n_chunks, g->info, g->sdf, g->type, g->flags, g->llabel);
+    IVX_KLAUNCH(k_materialize, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, g->n_chunks, g->info, g->sdf, g->type, g->flags, g->llabel);
     IVX_HIP_CHECK(hipGetLastError());
     g->planes_compact = 0;
     return IVX_OK;
@@ -578,7 +755,7 @@ ivx_roles::PresetArgs ivx_preset_args(ivx_grid* g, uint32_t groups) {
 int ivx_launch_step_preset(ivx_grid* g, uint32_t groups) {
     if (!groups) return IVX_OK;
     const ivx_roles::PresetArgs a = ivx_preset_args(g, groups);
-    hipLaunchKernelGGL(k_step_preset, dim3((a.n_sn + 255u) / 256u), dim3(256), 0, g->ctx->stream, a);
+    IVX_KLAUNCH(k_step_preset, dim3((a.n_sn + 255u) / 256u), dim3(256), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
     g->scratch_dirty &= ~groups;
     return IVX_OK;
@@ -600,15 +777,22 @@ int ivx_launch_derive(ivx_grid* g, uint32_t parts, uint32_t preset_groups) {
     // (the region scalars start from zero: preset by this launch's k_chunk_pre, or by the step's first kernel — the sampler's — in which case
     // nothing has used them since; only a caller outside a step finds them dirty)
     if ((parts & IVX_PART_REGIONS) && !(preset_groups & IVX_SCRATCH_REGIONS) && (g->scratch_dirty & IVX_SCRATCH_REGIONS))
-        IVX_HIP_CHECK(hipMemsetAsync(g->rscalar, 0, 16 * sizeof(uint32_t), g->ctx->stream));
+        IVX_HIP_CHECK(ivx_memset_async(g->rscalar, 0, 16 * sizeof(uint32_t), g->ctx->stream));
     if (parts & IVX_PART_REGIONS) g->scratch_dirty |= IVX_SCRATCH_REGIONS;
     g->bbox_valid = 1;
     uint32_t* next_count = ivx_wc(g);  // the counter of the sweep before: zeroed by this one for the sweep after
     g->wc_cur ^= 1u;
     // (the sampler's list counters have had their last reader by now: rolled over on the way, see role_preset)
     const uint32_t roll = ((g->scratch_dirty & IVX_SCRATCH_EVAL) && g->samp_len) ? IVX_SCRATCH_EVAL_ROLL : 0u;
-    hipLaunchKernelGGL(k_chunk_pre, dim3((g->n_chunks + 255u) / 256u), dim3(256), 0, g->ctx->stream, v, g->info, g->chunk_bbox, g->chunk_counts,
-                       g->chunk_class, g->chunk_touch, g->rparent, ivx_wc(g), next_count, g->active_list, ivx_preset_args(g, preset_groups | roll));
+    {
+        ChunkPreArgs pa;
+        memset(&pa, 0, sizeof(pa));
+        pa.g = v, pa.info = g->info, pa.bbox = g->chunk_bbox, pa.mesh_counts = g->chunk_counts, pa.chunk_class = g->chunk_class, pa.touch = g->chunk_touch;
+        pa.rparent = g->rparent, pa.work_counts = ivx_wc(g), pa.next_work_count = next_count, pa.active_list = g->active_list;
+        pa.preset = ivx_preset_args(g, preset_groups | roll);
+        const uint32_t blocks = (g->n_chunks + 255u) / 256u;
+        if (!ivx_many_try(IVX_MK_CHUNK_PRE, blocks, pa)) IVX_KLAUNCH(k_chunk_pre, dim3(blocks), dim3(256), 0, g->ctx->stream, pa);
+    }
     g->scratch_dirty &= ~preset_groups;
     if (roll) g->scratch_dirty &= ~IVX_SCRATCH_EVAL;
     // The grid: a whole number of list entries per workgroup. Workgroups start in waves of seven per CU and a wave that is not full costs as
@@ -625,21 +809,69 @@ int ivx_launch_derive(ivx_grid* g, uint32_t parts, uint32_t preset_groups) {
         if (derive_grid < lo) derive_grid = lo;
     }
     // (two forms of the sweep: from the sign rows the sampler left, while nothing else has rewritten voxels — no plane is read —, else from the planes)
-    if (g->signs_current)
-        hipLaunchKernelGGL(k_derive<true>, dim3(derive_grid), dim3(256), 0, g->ctx->stream, v, g->sdf, g->type, g->flags, g->info, g->chunk_bbox,
-                           g->chunk_touch, g->chunk_signs, g->kface, ivx_wc(g), g->active_list, g->active_list, fz, (uint32_t)g->signs_type);
-    else
-        hipLaunchKernelGGL(k_derive<false>, dim3(derive_grid), dim3(256), 0, g->ctx->stream, v, g->sdf, g->type, g->flags, g->info, g->chunk_bbox,
-                           g->chunk_touch, g->chunk_signs, g->kface, ivx_wc(g), g->active_list, g->active_list, fz, 0u);
+    DeriveArgs da = derive_args(g, v, fz);
+    if (g->signs_current) {
+        da.signs_type = (uint32_t)g->signs_type;
+        if (!ivx_many_try(IVX_MK_DERIVE_SIGNS, derive_grid, da)) IVX_KLAUNCH(k_derive<true>, dim3(derive_grid), dim3(256), 0, g->ctx->stream, da);
+    } else {
+        if (!ivx_many_try(IVX_MK_DERIVE_PLANES, derive_grid, da)) IVX_KLAUNCH(k_derive<false>, dim3(derive_grid), dim3(256), 0, g->ctx->stream, da);
+    }
+    g->active_list_stale = 0;
     g->planes_compact = 1;
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 
+// The sweep over a box of chunks after an edit (DeriveBox above): derived state, chunk-local regions and (parts) chunk moments of the box's
+// chunks from the planes, list entries to `d_out_list` (box order; may be null), the region forest of every other chunk reset for the resolve
+// that follows. The caller zeroes g->rscalar first (region scalars; [2] counts the listed multi-region chunks). The object's active list is
+// not touched — and is stale afterwards wherever a chunk of the box changed its kind (ivx_grid::active_list_stale).
+int ivx_launch_derive_box(ivx_grid* g, uint32_t parts, const uint32_t lo[3], const uint32_t cc[3], uint32_t* d_out_list) {
+    GridView v = ivx_view(g);
+    DeriveFused fz;
+    fz.parts = parts;
+    fz.x_off = g->x_off;
+    fz.labels = g->llabel;
+    fz.rparent = g->rparent;
+    fz.rscalar = g->rscalar;
+    fz.multi_list = g->ccl_scratch;
+    fz.dens = g->dens_dev;
+    fz.chunk_moments = g->chunk_moments;
+    DeriveBox box;
+    box.n = cc[0] * cc[1] * cc[2];
+    box.derive_blocks = box.n;
+    for (int d = 0; d < 3; ++d) box.lo[d] = lo[d], box.cc[d] = cc[d];
+    box.out_list = d_out_list;
+    if (box.n == 0) return IVX_OK;
+    g->scratch_dirty |= IVX_SCRATCH_REGIONS;
+    g->active_list_stale = 1;
+    g->planes_compact = 1;  // (a chunk the edit emptied is its record from now on: its planes are stale until ivx_ensure_dense)
+    DeriveArgs da = derive_args(g, v, fz);
+    da.box = box;
+    const uint32_t blocks = box.derive_blocks + (g->n_chunks + 255u) / 256u;
+    if (!ivx_many_try(IVX_MK_DERIVE_PLANES, blocks, da)) IVX_KLAUNCH(k_derive<false>, dim3(blocks), dim3(256), 0, g->ctx->stream, da);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+int ivx_ensure_active_list(ivx_grid* g) {
+    if (!g->active_list_stale) return IVX_OK;
+    uint32_t* next_count = ivx_wc(g);  // (the counters alternate as in ivx_launch_derive: this sweep zeroes the old one for the sweep after)
+    g->wc_cur ^= 1u;
+    ListRebuildArgs la;
+    memset(&la, 0, sizeof(la));
+    la.g = ivx_view(g), la.info = g->info, la.work_counts = ivx_wc(g), la.next_work_count = next_count, la.active_list = g->active_list, la.mesh_counts = g->chunk_counts;
+    const uint32_t blocks = (g->n_chunks + 255u) / 256u;
+    if (!ivx_many_try(IVX_MK_LIST_REBUILD, blocks, la)) IVX_KLAUNCH(k_list_rebuild, dim3(blocks), dim3(256), 0, g->ctx->stream, la);
+    IVX_HIP_CHECK(hipGetLastError());
+    g->active_list_stale = 0;
+    return IVX_OK;
+}
+
 int ivx_launch_occupied(ivx_grid* g, uint32_t* d_raw) {
-    IVX_HIP_CHECK(hipMemsetAsync(d_raw, 0xFF, 6 * sizeof(uint32_t), g->ctx->stream));
-    IVX_HIP_CHECK(hipMemsetAsync(d_raw + 6, 0, 6 * sizeof(uint32_t), g->ctx->stream));
-    hipLaunchKernelGGL(k_occupied_reduce, dim3((g->n_chunks + 255u) / 256u), dim3(256), 0, g->ctx->stream, g->cc[0], g->cc[1], g->cc[2], g->chunk_bbox, d_raw);
+    IVX_HIP_CHECK(ivx_memset_async(d_raw, 0xFF, 6 * sizeof(uint32_t), g->ctx->stream));
+    IVX_HIP_CHECK(ivx_memset_async(d_raw + 6, 0, 6 * sizeof(uint32_t), g->ctx->stream));
+    IVX_KLAUNCH(k_occupied_reduce, dim3((g->n_chunks + 255u) / 256u), dim3(256), 0, g->ctx->stream, g->cc[0], g->cc[1], g->cc[2], g->chunk_bbox, d_raw);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

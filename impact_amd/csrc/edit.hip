@@ -24,6 +24,7 @@
 #include <algorithm>
 
 #include "chunk_passes.hpp"
+#include "many.hpp"
 
 namespace {
 
@@ -131,13 +132,34 @@ __device__ __forceinline__ int quantise(float v) {  // VoxelSignedDistance::from
     return (int)s;
 }
 
-__global__ __launch_bounds__(256) void k_absorb(AbsorbParams p, int8_t* __restrict__ sdf, uint8_t* __restrict__ type, ivx_chunk_info* __restrict__ info,
-                                                       const float* __restrict__ dens, double* __restrict__ removed10, uint32_t* __restrict__ by_type,
-                                                       uint32_t* __restrict__ counters, uint32_t* __restrict__ touched_ranges) {
+struct AbsorbArgs {
+    AbsorbParams p;
+    int8_t* sdf;
+    uint8_t* type;
+    ivx_chunk_info* info;
+    const float* dens;
+    double* removed10;
+    uint32_t* by_type;
+    uint32_t* counters;
+    uint32_t* touched_ranges;
+    uint32_t* zero16;
+};
+__device__ __forceinline__ void absorb_body(const AbsorbArgs& a_, uint32_t b, uint32_t) {
+    const AbsorbParams& p = a_.p;
+    int8_t* __restrict__ sdf = a_.sdf;
+    uint8_t* __restrict__ type = a_.type;
+    ivx_chunk_info* __restrict__ info = a_.info;
+    const float* __restrict__ dens = a_.dens;
+    double* __restrict__ removed10 = a_.removed10;
+    uint32_t* __restrict__ by_type = a_.by_type;
+    uint32_t* __restrict__ counters = a_.counters;
+    uint32_t* __restrict__ touched_ranges = a_.touched_ranges;
+    uint32_t* __restrict__ zero16 = a_.zero16;
     __shared__ float s_dens[256];
     __shared__ double s_red[16][10];
     const uint32_t tid = threadIdx.x;
-    const uint32_t b = blockIdx.x;
+    // (the region scalars the sweep behind this launch starts from: sixteen words the edit path would otherwise spend a stream operation on)
+    if (zero16 && b == 0u && tid < 16u) zero16[tid] = 0u;
     const uint32_t bk = b % p.cc[2], bj = (b / p.cc[2]) % p.cc[1], bi = b / (p.cc[2] * p.cc[1]);
     const uint32_t ci = p.lo[0] + bi, cj = p.lo[1] + bj, ck = p.lo[2] + bk;
     const uint32_t chunk = (ci * p.g.cy + cj) * p.g.cz + ck;
@@ -317,6 +339,12 @@ __global__ __launch_bounds__(256) void k_absorb(AbsorbParams p, int8_t* __restri
     }
 }
 
+__global__ __launch_bounds__(256) void k_absorb(AbsorbArgs a) { absorb_body(a, blockIdx.x, gridDim.x); }
+IVX_MANY_TWIN(k_absorb_many, AbsorbArgs, absorb_body, __launch_bounds__(256))
+IVX_MANY_LAUNCHER(many_absorb, k_absorb_many, AbsorbArgs, 256)
+static_assert(sizeof(AbsorbArgs) % 8 == 0, "argument blocks travel as 8-byte words");
+static const int s_many_registered_absorb = (ivx_many_register(IVX_MK_ABSORB, many_absorb, sizeof(AbsorbArgs)), 0);
+
 // dense copy of the object's distances over a voxel box (Void chunks read 127, Uniform ones -128), x-major
 __global__ __launch_bounds__(256) void k_sdf_snapshot(GridView g, const int8_t* __restrict__ sdf, int3 lo, int3 n, int8_t* __restrict__ out) {
     const size_t total = (size_t)n.x * n.y * n.z;
@@ -336,7 +364,7 @@ int ivx_launch_sdf_snapshot(ivx_grid* g, const int32_t lo[3], const int32_t hi[3
     const size_t total = (size_t)n.x * n.y * n.z;
     if (total == 0) return IVX_OK;
     const uint32_t wgs = (uint32_t)std::min<size_t>((total + 255) / 256, 65535u * 16u);
-    hipLaunchKernelGGL(k_sdf_snapshot, dim3(wgs), dim3(256), 0, g->ctx->stream, ivx_view(g), g->sdf, l, n, d_out);
+    IVX_KLAUNCH(k_sdf_snapshot, dim3(wgs), dim3(256), 0, g->ctx->stream, ivx_view(g), g->sdf, l, n, d_out);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -347,6 +375,7 @@ int ivx_launch_absorb_mutual(ivx_grid* g, int from_snapshot, const uint32_t lo[3
                              ivx_grid* other, const int8_t* d_snapshot, const int32_t s_lo[3], const int32_t s_hi[3], const float q_ba[4],
                              const float t_ba[3], float smoothness, const float* d_dens, double* d_removed10, uint32_t* d_by_type, uint32_t* d_counters,
                              uint32_t* d_touched) {
+    uint32_t* const d_zero16 = nullptr;
     ivx_planes_touched(g);
     AbsorbParams p;
     p.g = ivx_view(g);
@@ -373,15 +402,21 @@ int ivx_launch_absorb_mutual(ivx_grid* g, int from_snapshot, const uint32_t lo[3
     p.ratio = other->extent * (1.0f / g->extent);
     p.smooth = smoothness;
     p.quarter_inv = 0.25f / smoothness;
-    hipLaunchKernelGGL(k_absorb, dim3(cc[0] * cc[1] * cc[2]), dim3(256), 0, g->ctx->stream, p, g->sdf, g->type, g->info, d_dens, d_removed10, d_by_type,
-                       d_counters, d_touched);
+    {
+        AbsorbArgs aa;
+        memset(&aa, 0, sizeof(aa));
+        aa.p = p, aa.sdf = g->sdf, aa.type = g->type, aa.info = g->info, aa.dens = d_dens, aa.removed10 = d_removed10, aa.by_type = d_by_type;
+        aa.counters = d_counters, aa.touched_ranges = d_touched, aa.zero16 = d_zero16;
+        const uint32_t blocks = cc[0] * cc[1] * cc[2];
+        if (!ivx_many_try(IVX_MK_ABSORB, blocks, aa)) IVX_KLAUNCH(k_absorb, dim3(blocks), dim3(256), 0, g->ctx->stream, aa);
+    }
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 
 int ivx_launch_absorb(ivx_grid* g, int capsule, const uint32_t lo[3], const uint32_t cc[3], const int32_t vlo[3], const int32_t vhi[3], const float c[3],
                       const float seg[3], float influence_radius, float shape_radius, const float* d_dens, double* d_removed10, uint32_t* d_by_type,
-                      uint32_t* d_counters, uint32_t* d_touched) {
+                      uint32_t* d_counters, uint32_t* d_touched, uint32_t* d_zero16) {
     ivx_planes_touched(g);
     AbsorbParams p;
     p.g = ivx_view(g);
@@ -407,8 +442,14 @@ int ivx_launch_absorb(ivx_grid* g, int capsule, const uint32_t lo[3], const uint
     p.q[0] = p.q[1] = p.q[2] = 0.0f, p.q[3] = 1.0f;
     p.ext_p = p.inv_s = p.ratio = 1.0f;
     p.smooth = p.quarter_inv = 0.0f;
-    hipLaunchKernelGGL(k_absorb, dim3(cc[0] * cc[1] * cc[2]), dim3(256), 0, g->ctx->stream, p, g->sdf, g->type, g->info, d_dens, d_removed10, d_by_type,
-                       d_counters, d_touched);
+    {
+        AbsorbArgs aa;
+        memset(&aa, 0, sizeof(aa));
+        aa.p = p, aa.sdf = g->sdf, aa.type = g->type, aa.info = g->info, aa.dens = d_dens, aa.removed10 = d_removed10, aa.by_type = d_by_type;
+        aa.counters = d_counters, aa.touched_ranges = d_touched, aa.zero16 = d_zero16;
+        const uint32_t blocks = cc[0] * cc[1] * cc[2];
+        if (!ivx_many_try(IVX_MK_ABSORB, blocks, aa)) IVX_KLAUNCH(k_absorb, dim3(blocks), dim3(256), 0, g->ctx->stream, aa);
+    }
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

@@ -13,6 +13,7 @@
 // as two 16-byte loads per thread) into a per-chunk slot; Uniform chunks are closed forms; the slots and closed forms
 // are summed in chunk order by k_inertia_sum and a fixed-order final launch (bitwise reproducible, no float atomics).
 #include "chunk_passes.hpp"
+#include "many.hpp"
 
 namespace {
 
@@ -24,16 +25,30 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // Moments of the NonUniform chunks as a kernel of its own (the step path computes them inside k_derive's sweep): one workgroup
 // per listed chunk, into the chunk's own slot, so the order of the final sum does not depend on the order of the list.
-__global__ __launch_bounds__(256) void k_inertia_dense(GridView g, uint32_t x_off, const uint8_t* __restrict__ flags,
-                                                       const float* __restrict__ dens, double* __restrict__ chunk_moments,
-                                                       const uint32_t* __restrict__ work_counts, const uint32_t* __restrict__ active_list) {
+struct InertiaDenseArgs {
+    GridView g;
+    const uint8_t* flags;
+    const float* dens;
+    double* chunk_moments;
+    const uint32_t* work_counts;
+    const uint32_t* active_list;
+    uint32_t x_off, pad_;
+};
+__device__ __forceinline__ void inertia_dense_body(const InertiaDenseArgs& a, uint32_t bid, uint32_t nb) {
+    const GridView& g = a.g;
+    const uint32_t x_off = a.x_off;
+    const uint8_t* __restrict__ flags = a.flags;
+    const float* __restrict__ dens = a.dens;
+    double* __restrict__ chunk_moments = a.chunk_moments;
+    const uint32_t* __restrict__ work_counts = a.work_counts;
+    const uint32_t* __restrict__ active_list = a.active_list;
     __shared__ float s_dens[256];
     __shared__ double s_red[16][10];
     const uint32_t tid = threadIdx.x;
     s_dens[tid] = dens[tid];
     const int ti = tid >> 4, tj = tid & 15;
     const uint32_t n_active = work_counts[0];
-    for (uint32_t li = ivx_xcd_remap(blockIdx.x, gridDim.x); li < n_active; li += gridDim.x) {
+    for (uint32_t li = ivx_xcd_remap(bid, nb); li < n_active; li += nb) {
         __syncthreads();  // s_dens ready / the previous chunk's s_red use is over
         const uint32_t entry = active_list[li];
         const uint32_t chunk = IVX_LIST_CHUNK(entry);
@@ -50,6 +65,11 @@ __global__ __launch_bounds__(256) void k_inertia_dense(GridView g, uint32_t x_of
         chunk_moments_rows(tid, m, tw, s_dens, s_red, (ci + (int)x_off) * 16 + ti, cj * 16 + tj, ck * 16, chunk_moments + (size_t)chunk * 10);
     }
 }
+__global__ __launch_bounds__(256) void k_inertia_dense(InertiaDenseArgs a) { inertia_dense_body(a, blockIdx.x, gridDim.x); }
+IVX_MANY_TWIN(k_inertia_dense_many, InertiaDenseArgs, inertia_dense_body, __launch_bounds__(256))
+IVX_MANY_LAUNCHER(many_inertia_dense, k_inertia_dense_many, InertiaDenseArgs, 256)
+static_assert(sizeof(InertiaDenseArgs) % 8 == 0, "argument blocks travel as 8-byte words");
+static const int s_many_registered_inertia = (ivx_many_register(IVX_MK_INERTIA_DENSE, many_inertia_dense, sizeof(InertiaDenseArgs)), 0);
 
 // Sum over chunks in chunk order, one THREAD per chunk: a Uniform chunk is 4096 voxels of one type
 // (compute_moments_for_uniform_chunk, inertia.rs:703-754) and its moments are closed forms of its origin
@@ -110,23 +130,31 @@ __global__ __launch_bounds__(640) void k_inertia_final(uint32_t n_blocks, float 
 
 }  // namespace
 
+static void launch_inertia_dense(ivx_grid* g, const GridView& v, const float* d_dens) {
+    InertiaDenseArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g = v, a.x_off = g->x_off, a.flags = g->flags, a.dens = d_dens, a.chunk_moments = g->chunk_moments, a.work_counts = ivx_wc(g), a.active_list = g->active_list;
+    const uint32_t blocks = ivx_list_grid(g);
+    if (!ivx_many_try(IVX_MK_INERTIA_DENSE, blocks, a)) IVX_KLAUNCH(k_inertia_dense, dim3(blocks), dim3(256), 0, g->ctx->stream, a);
+}
+
 int ivx_launch_inertia_dense(ivx_grid* g) {
+    if (int rc_l = ivx_ensure_active_list(g)) return rc_l;
     GridView v = ivx_view(g);
-    hipLaunchKernelGGL(k_inertia_dense, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->x_off, g->flags, g->dens_dev, g->chunk_moments, ivx_wc(g),
-                       g->active_list);
+    launch_inertia_dense(g, v, g->dens_dev);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 
 int ivx_launch_inertia(ivx_grid* g, const float* d_dens, double* d_out10, int fused) {
+    if (int rc_l = ivx_ensure_active_list(g)) return rc_l;
     uint32_t blocks = (g->n_chunks + 255u) / 256u;
     if (blocks > g->partial_blocks) blocks = (uint32_t)g->partial_blocks;
     GridView v = ivx_view(g);
     if (!fused)  // else k_derive left the chunk moments in the same sweep
-        hipLaunchKernelGGL(k_inertia_dense, dim3(ivx_list_grid(g)), dim3(256), 0, g->ctx->stream, v, g->x_off, g->flags, d_dens, g->chunk_moments, ivx_wc(g),
-                       g->active_list);
-    hipLaunchKernelGGL(k_inertia_sum, dim3(blocks), dim3(256), 0, g->ctx->stream, v, g->x_off, d_dens, g->chunk_moments, g->partials);
-    hipLaunchKernelGGL(k_inertia_final, dim3(1), dim3(640), 0, g->ctx->stream, blocks, g->extent, g->partials, d_out10);
+        launch_inertia_dense(g, v, d_dens);
+    IVX_KLAUNCH(k_inertia_sum, dim3(blocks), dim3(256), 0, g->ctx->stream, v, g->x_off, d_dens, g->chunk_moments, g->partials);
+    IVX_KLAUNCH(k_inertia_final, dim3(1), dim3(640), 0, g->ctx->stream, blocks, g->extent, g->partials, d_out10);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

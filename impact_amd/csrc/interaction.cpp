@@ -195,6 +195,8 @@ int ivx_handle_voxel_object_after_removing_voxels(ivx_grid* g, const float densi
     *original_object_empty = 0;
     for (int d = 0; d < 3; ++d) new_local_center_of_mass[d] = original_local_center_of_mass[d];
     int rc;
+    // (the split-offs below take the moments that leave the object from the object's resident density table: this one)
+    if ((rc = ivx_grid_set_densities(g, densities))) return rc;
     uint32_t n_regions = 0;
     if ((rc = ivx_label_regions(g, &n_regions))) return rc;
     std::vector<ivx_region_desc> desc(n_regions ? n_regions : 1);

@@ -2,6 +2,8 @@
 // the reference interfaces each function replaces). Host-side orchestration only: every compute call
 // launches the HIP kernels in this directory on the context's stream.
 #include <algorithm>
+#include <array>
+#include <functional>
 #include <cmath>
 #include <atomic>
 #include <chrono>
@@ -39,7 +41,7 @@ int dev_alloc(T** p, size_t count) {
 
 int ensure_host_scratch(ivx_grid* g, size_t bytes) {
     if (g->host_scratch_bytes >= bytes) return IVX_OK;
-    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
     if (g->host_scratch) (void)hipHostFree(g->host_scratch);
     g->host_scratch = nullptr;
     g->host_scratch_bytes = 0;
@@ -58,13 +60,13 @@ int d2h(ivx_grid* g, void* dst, const void* src, size_t bytes) {
     if (bytes <= STAGED_COPY_MAX) {
         int rc = ensure_host_scratch(g, bytes);
         if (rc) return rc;
-        IVX_HIP_CHECK(hipMemcpyAsync(g->host_scratch, src, bytes, hipMemcpyDeviceToHost, g->ctx->stream));
-        IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+        IVX_HIP_CHECK(ivx_memcpy_async(g->host_scratch, src, bytes, hipMemcpyDeviceToHost, g->ctx->stream));
+        IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
         memcpy(dst, g->host_scratch, bytes);
         return IVX_OK;
     }
-    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
-    IVX_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
+    IVX_HIP_CHECK(ivx_memcpy_sync(dst, src, bytes, hipMemcpyDeviceToHost));
     return IVX_OK;
 }
 int h2d(ivx_grid* g, void* dst, const void* src, size_t bytes) {
@@ -72,19 +74,19 @@ int h2d(ivx_grid* g, void* dst, const void* src, size_t bytes) {
     if (bytes <= STAGED_COPY_MAX) {
         int rc = ensure_host_scratch(g, bytes);
         if (rc) return rc;
-        IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));  // the staging buffer may still feed an earlier copy
+        IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));  // the staging buffer may still feed an earlier copy
         memcpy(g->host_scratch, src, bytes);
-        IVX_HIP_CHECK(hipMemcpyAsync(dst, g->host_scratch, bytes, hipMemcpyHostToDevice, g->ctx->stream));
-        IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+        IVX_HIP_CHECK(ivx_memcpy_async(dst, g->host_scratch, bytes, hipMemcpyHostToDevice, g->ctx->stream));
+        IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
         return IVX_OK;
     }
-    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
-    IVX_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
+    IVX_HIP_CHECK(ivx_memcpy_sync(dst, src, bytes, hipMemcpyHostToDevice));
     return IVX_OK;
 }
 int ensure_dev_scratch(ivx_grid* g, size_t bytes) {
     if (g->dev_scratch_bytes >= bytes) return IVX_OK;
-    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
     if (g->dev_scratch) (void)hipFree(g->dev_scratch);
     g->dev_scratch = nullptr;
     g->dev_scratch_bytes = 0;
@@ -155,7 +157,7 @@ int ivx_launch_halo_pack(ivx_grid* g, int side, void* buf) {
     uint8_t* o_type = static_cast<uint8_t*>(buf) + cols * 256;
     ivx_chunk_info* o_info = reinterpret_cast<ivx_chunk_info*>(static_cast<uint8_t*>(buf) + cols * 512);
     GridView v = ivx_view(g);
-    hipLaunchKernelGGL(k_halo_pack, dim3((uint32_t)cols), dim3(256), 0, g->ctx->stream, v, (uint32_t)side, o_sdf, o_type, o_info);
+    IVX_KLAUNCH(k_halo_pack, dim3((uint32_t)cols), dim3(256), 0, g->ctx->stream, v, (uint32_t)side, o_sdf, o_type, o_info);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -264,8 +266,8 @@ int grow_keep(ivx_grid* g, T** buf, size_t old_count, size_t new_count) {
     T* fresh = nullptr;
     int rc = dev_alloc(&fresh, new_count);
     if (rc) return rc;
-    if (*buf && old_count) IVX_HIP_CHECK(hipMemcpyAsync(fresh, *buf, old_count * sizeof(T), hipMemcpyDeviceToDevice, g->ctx->stream));
-    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    if (*buf && old_count) IVX_HIP_CHECK(ivx_memcpy_async(fresh, *buf, old_count * sizeof(T), hipMemcpyDeviceToDevice, g->ctx->stream));
+    IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
     if (*buf) (void)hipFree(*buf);
     *buf = fresh;
     return IVX_OK;
@@ -338,14 +340,14 @@ int ivx_init(int device_id, void* stream, ivx_ctx** out) {
 
 void ivx_shutdown(ivx_ctx* c) {
     if (!c) return;
-    (void)hipStreamSynchronize(c->stream);
+    (void)ivx_stream_sync(c->stream);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
 int ivx_synchronize(ivx_ctx* c) {
     IVX_REQUIRE(c, IVX_ERR_INVALID, "ivx_synchronize: null context");
-    IVX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    IVX_HIP_CHECK(ivx_stream_sync(c->stream));
     return IVX_OK;
 }
 
@@ -427,8 +429,8 @@ int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32
         }
     }
     (void)rc;
-    if (hipMemsetAsync(g->info, 0, sizeof(ivx_chunk_info) * g->n_chunks, c->stream) != hipSuccess ||
-        hipMemsetAsync(g->work_counts, 0, 8 * sizeof(uint32_t), c->stream) != hipSuccess) {
+    if (ivx_memset_async(g->info, 0, sizeof(ivx_chunk_info) * g->n_chunks, c->stream) != hipSuccess ||
+        ivx_memset_async(g->work_counts, 0, 8 * sizeof(uint32_t), c->stream) != hipSuccess) {
         ivx_set_error("ivx_grid_create: memset failed");
         ivx_grid_destroy(g);
         return IVX_ERR_HIP;
@@ -437,10 +439,17 @@ int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32
     return IVX_OK;
 }
 
+static void ivx_edit_state_free(struct ivx_edit_state* e);
 void ivx_grid_destroy(ivx_grid* g) {
     if (!g) return;
-    (void)hipStreamSynchronize(g->ctx->stream);
+    (void)ivx_stream_sync(g->ctx->stream);
+    ivx_edit_state_free(g->edit);
+    g->edit = nullptr;
+    ivx_submesh_manager_free(g->submesh_manager);  // (host mirrors of the incremental remesh and of the probes' ranges)
+    ivx_probe_manager_free(g->probe_manager);
+    g->submesh_manager = nullptr, g->probe_manager = nullptr;
     // (everything sized by the chunk counts lives in the arena; the rest grew on demand)
+    if (g->dens_call) (void)hipFree(g->dens_call);
     void* ptrs[] = {g->arena, g->positions, g->normals, g->indices, g->index_materials, g->vertex_materials, g->submeshes, g->dev_scratch, g->prog_nodes,
                     g->samp_len, g->samp_ops, g->pairs_dev, g->samp_super, g->probe_points, g->probe_chunk, g->probe_entries};
     for (void* p : ptrs)
@@ -464,7 +473,7 @@ int ivx_grid_upload_dense(ivx_grid* g, const int8_t* sdf, const uint8_t* type, s
     g->occ_ref_valid = 0;
     g->bbox_valid = 0;
     g->regions_valid = 0;
-    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
     return IVX_OK;
 }
 
@@ -561,7 +570,7 @@ int ivx_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* nodes, size_t n_no
     g->occ_ref_valid = 0;
     g->bbox_valid = 0;
     g->regions_valid = 0;
-    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
     return IVX_OK;
 }
 
@@ -571,7 +580,7 @@ int ivx_derive_state(ivx_grid* g) {
     if (rc) return rc;
     g->mesh_valid = 0;
     g->regions_valid = 0;
-    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
     return IVX_OK;
 }
 
@@ -606,12 +615,26 @@ int ivx_remesh(ivx_grid* g, ivx_mesh_counts* out) {
     g->mesh_built = 1;
     g->mesh_serial += 1;
     *out = g->mesh_counts;
-    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
     return IVX_OK;
 }
 
-int ivx_mesh_sync(ivx_grid* g, const uint8_t* invalidated_chunks, ivx_mesh_counts* out) {
-    IVX_REQUIRE(g && invalidated_chunks && out, IVX_ERR_INVALID, "ivx_mesh_sync: null argument");
+static void ivx_edit_state_free(struct ivx_edit_state* e);
+struct ivx_edit_state;
+static ivx_edit_state* edit_state(ivx_grid* g);
+static bool edit_needs_lookup(ivx_grid* g, uint32_t chunk, uint32_t out3[3]);
+static int edit_sync_upload(ivx_grid* g, const void* src, size_t bytes, void* d_dst);
+static void edit_sync_mark(ivx_grid* g, int pending);
+static int edit_sync_pending(ivx_grid* g);
+
+// VoxelObjectMesh::sync_with_voxel_object (mesh.rs:355-456) in two halves. ENQUEUE: the sizes the invalidated chunks' meshes need come from the
+// last edit's result block when the set is that edit's (ivx_absorb_collect: no count pass, no read-back) — else from a count over just these
+// chunks and one read-back —; the host mirror of the ChunkSubmeshManager places them; records and slots go up from pinned memory and the
+// emit pass for the listed chunks follows on the stream. COLLECT: the wait. (Round 3 counted the whole object, read the sizes back, uploaded
+// through a blocking copy and waited again: two round trips and ~25 us of counting for ~100 chunks.)
+static int mesh_sync_enqueue(ivx_grid* g, const uint8_t* invalidated_chunks, const char* who) {
+    IVX_REQUIRE(g && invalidated_chunks, IVX_ERR_INVALID, "%s: null argument", who);
+    IVX_REQUIRE(!edit_sync_pending(g), IVX_ERR_STATE, "%s: a sync of this object is in flight (ivx_mesh_sync_collect first)", who);
     IVX_REQUIRE(g->mesh_built, IVX_ERR_STATE, "ivx_mesh_sync: there is no mesh to synchronise (call ivx_remesh first)");
     IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "ivx_mesh_sync: derived state must be current (the edit ops leave it so)");
     IVX_REQUIRE(g->x_off == 0 && g->gx == g->cc[0] && !g->has_ghost[0] && !g->has_ghost[1], IVX_ERR_STATE,
@@ -633,21 +656,22 @@ int ivx_mesh_sync(ivx_grid* g, const uint8_t* invalidated_chunks, ivx_mesh_count
         m->chunks_were_removed = false;
         m->serial = g->mesh_serial;
     }
-    // what the invalidated chunks' meshes need now (the count pass of the full remesh) and their records (exposure, obscuredness flags)
+    // what the invalidated chunks' meshes need now and their records (exposure, obscuredness flags)
     std::vector<uint32_t> list;
     for (uint32_t c = 0; c < g->n_chunks; ++c)  // chunk-linear order (the reference walks a hash set: unpinned)
         if (invalidated_chunks[c]) list.push_back(c);
     std::vector<uint32_t> needs(3 * list.size());
-    if (!list.empty()) {
-        if ((rc = ivx_launch_sn_count(g))) return rc;
+    bool cached = g->needs_current != 0;
+    for (size_t e = 0; e < list.size() && cached; ++e) cached = edit_needs_lookup(g, list[e], &needs[3 * e]);
+    if (!list.empty() && !cached) {
         const size_t off_out = (list.size() * 4 + 15) & ~(size_t)15;
-        if ((rc = ensure_dev_scratch(g, off_out + needs.size() * 4))) return rc;
+        if ((rc = ensure_dev_scratch(g, off_out + list.size() * 16))) return rc;
         char* base = static_cast<char*>(g->dev_scratch);
-        IVX_HIP_CHECK(hipMemcpyAsync(base, list.data(), list.size() * 4, hipMemcpyHostToDevice, g->ctx->stream));
-        hipLaunchKernelGGL(k_chunk_mesh_needs, dim3(((uint32_t)list.size() + 255u) / 256u), dim3(256), 0, g->ctx->stream, (uint32_t)list.size(),
-                           reinterpret_cast<const uint32_t*>(base), g->chunk_counts, g->info, reinterpret_cast<uint32_t*>(base + off_out));
-        IVX_HIP_CHECK(hipGetLastError());
-        if ((rc = d2h(g, needs.data(), base + off_out, needs.size() * 4))) return rc;
+        if ((rc = edit_sync_upload(g, list.data(), list.size() * 4, base))) return rc;
+        if ((rc = ivx_launch_list_mesh_needs(g, (uint32_t)list.size(), reinterpret_cast<const uint32_t*>(base), reinterpret_cast<uint32_t*>(base + off_out)))) return rc;
+        std::vector<uint32_t> raw(4 * list.size());
+        if ((rc = d2h(g, raw.data(), base + off_out, raw.size() * 4))) return rc;
+        for (size_t e = 0; e < list.size(); ++e) needs[3 * e] = raw[4 * e + 1], needs[3 * e + 1] = raw[4 * e + 2], needs[3 * e + 2] = raw[4 * e] & 0xFFFFu;
     }
     std::vector<uint32_t> dirty_slots;  // slots of the device table that a removal rewrote (the emit pass writes the others)
     const size_t table_before = m->table.size();
@@ -715,24 +739,40 @@ int ivx_mesh_sync(ivx_grid* g, const uint8_t* invalidated_chunks, ivx_mesh_count
         memcpy(stage.data(), &n, 4);
         memcpy(stage.data() + 16, recs.data(), recs.size() * sizeof(Rec));
         memcpy(stage.data() + off_slots, slots.data(), slots.size() * 4);
-        if ((rc = h2d(g, g->dev_scratch, stage.data(), total))) return rc;
         char* base = static_cast<char*>(g->dev_scratch);
+        if ((rc = edit_sync_upload(g, stage.data(), total, base))) return rc;
         if ((rc = ivx_launch_sn_emit_list(g, n, reinterpret_cast<const uint32_t*>(base), base + 16, reinterpret_cast<const uint32_t*>(base + off_slots)))) return rc;
     }
     // the device table: the emit pass wrote the re-meshed chunks' entries; entries a removal moved are patched from the host mirror
     (void)table_before;
     for (uint32_t slot : dirty_slots)
-        if (slot < m->table.size())
-            IVX_HIP_CHECK(hipMemcpyAsync(g->submeshes + slot, &m->table[slot], sizeof(ivx_submesh), hipMemcpyHostToDevice, g->ctx->stream));
-    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+        if (slot < m->table.size() && !ivx_many_upload(g->submeshes + slot, &m->table[slot], sizeof(ivx_submesh)))
+            IVX_HIP_CHECK(ivx_memcpy_async(g->submeshes + slot, &m->table[slot], sizeof(ivx_submesh), hipMemcpyHostToDevice, g->ctx->stream));
     g->mesh_counts.n_vertices = (uint32_t)m->total_vertices;
     g->mesh_counts.n_indices = (uint32_t)m->total_indices;
     g->mesh_counts.n_submeshes = (uint32_t)m->table.size();
-    g->mesh_valid = 1;
     g->mesh_serial += 1;  // collision probes picked from the old mesh are stale
     m->serial = g->mesh_serial;
+    edit_sync_mark(g, 1);
+    return IVX_OK;
+}
+
+static int mesh_sync_collect(ivx_grid* g, ivx_mesh_counts* out, const char* who, bool stream_is_drained = false) {
+    IVX_REQUIRE(g && out, IVX_ERR_INVALID, "%s: null argument", who);
+    IVX_REQUIRE(edit_sync_pending(g), IVX_ERR_STATE, "%s: no sync of this object is in flight", who);
+    edit_sync_mark(g, 0);
+    if (!stream_is_drained) IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
+    g->mesh_valid = 1;
     *out = g->mesh_counts;
     return IVX_OK;
+}
+
+int ivx_mesh_sync_enqueue(ivx_grid* g, const uint8_t* invalidated_chunks) { return mesh_sync_enqueue(g, invalidated_chunks, "ivx_mesh_sync_enqueue"); }
+int ivx_mesh_sync_collect(ivx_grid* g, ivx_mesh_counts* out) { return mesh_sync_collect(g, out, "ivx_mesh_sync_collect"); }
+int ivx_mesh_sync(ivx_grid* g, const uint8_t* invalidated_chunks, ivx_mesh_counts* out) {
+    IVX_REQUIRE(out, IVX_ERR_INVALID, "ivx_mesh_sync: null argument");
+    const int rc = mesh_sync_enqueue(g, invalidated_chunks, "ivx_mesh_sync");
+    return rc ? rc : mesh_sync_collect(g, out, "ivx_mesh_sync");
 }
 
 int ivx_mesh_modifications(ivx_grid* g, ivx_submesh_data_ranges* out, size_t cap, size_t* n_out, int* chunks_were_removed) {
@@ -856,12 +896,28 @@ int ivx_mesh_generation(ivx_grid* g, uint64_t* generation) {
     return IVX_OK;
 }
 
+// a density table for ONE call: the resident copy when it is the resident table (ivx_grid_set_densities), else a copy of its own behind the
+// resident one — the object's resident table is what its steps and edits use and is never replaced on the side (round 3 overwrote the device
+// copy here and left the host mirror saying otherwise: an edit handed the resident table again then ran on this call's)
+static int densities_on_device(ivx_grid* g, const float densities[256], const float** d_out) {
+    if (g->has_dens && memcmp(g->dens_host, densities, sizeof(g->dens_host)) == 0) {
+        *d_out = g->dens_dev;
+        return IVX_OK;
+    }
+    if (!g->dens_call) IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->dens_call), 256 * sizeof(float)));
+    int rc = h2d(g, g->dens_call, densities, 256 * sizeof(float));
+    if (rc) return rc;
+    *d_out = g->dens_call;
+    return IVX_OK;
+}
+
 int ivx_inertia(ivx_grid* g, const float densities[256], ivx_moments* out) {
     IVX_REQUIRE(g && densities && out, IVX_ERR_INVALID, "ivx_inertia: null argument");
     double* out_dev = g->partials + g->partial_blocks * 10;
     int rc;
-    if ((rc = h2d(g, g->dens_dev, densities, 256 * sizeof(float)))) return rc;
-    if ((rc = ivx_launch_inertia(g, g->dens_dev, out_dev, 0))) return rc;
+    const float* d_dens = nullptr;
+    if ((rc = densities_on_device(g, densities, &d_dens))) return rc;
+    if ((rc = ivx_launch_inertia(g, d_dens, out_dev, 0))) return rc;
     if ((rc = d2h(g, out->m64, out_dev, 10 * sizeof(double)))) return rc;
     for (int i = 0; i < 10; ++i) out->m32[i] = (float)out->m64[i];
     out->reserved[0] = out->reserved[1] = 0;
@@ -945,10 +1001,10 @@ int ivx_regions_describe(ivx_grid* g, const float densities[256], ivx_region_des
     *n_out = n;
     IVX_REQUIRE(n <= cap, IVX_ERR_CAPACITY, "ivx_regions_describe: %u regions exceed capacity %zu", n, cap);
     int rc;
-    if ((rc = h2d(g, g->dens_dev, densities, 256 * sizeof(float)))) return rc;
-    g->has_dens = 1;
+    const float* d_dens = nullptr;
+    if ((rc = densities_on_device(g, densities, &d_dens))) return rc;
     std::vector<ivx_region_desc> d;
-    if ((rc = describe_regions_internal(g, g->dens_dev, d))) return rc;
+    if ((rc = describe_regions_internal(g, d_dens, d))) return rc;
     for (uint32_t r = 0; r < n; ++r) out[r] = d[r];
     return IVX_OK;
 }
@@ -990,6 +1046,7 @@ int ivx_split_off_smallest_region(ivx_grid* parent, ivx_grid** child, uint32_t o
         float ones[256];
         for (float& x : ones) x = 1.0f;
         if ((rc = h2d(parent, parent->dens_dev, ones, sizeof(ones)))) return rc;
+        memcpy(parent->dens_host, ones, sizeof(ones));
         parent->has_dens = 1;
     }
     std::vector<ivx_region_desc> d;
@@ -1069,6 +1126,8 @@ static int complete_extracted(ivx_grid* parent, ivx_grid** pc, uint32_t origin[3
     float ones[256];
     for (float& x : ones) x = 1.0f;
     if ((rc = h2d(c, c->dens_dev, ones, sizeof(ones)))) return rc;
+    memcpy(c->dens_host, ones, sizeof(ones));
+    c->has_dens = 1;
     double* out_dev = c->partials + c->partial_blocks * 10;
     if ((rc = ivx_launch_inertia(c, c->dens_dev, out_dev, 0))) return rc;
     double m0 = 0.0;
@@ -1223,24 +1282,26 @@ int ivx_copy_polyhedra(ivx_grid* parent, const float* planes4, const uint32_t* p
         if (!c) continue;
         if (!first) {
             first = c;
-            if (hipMemcpyAsync(c->dens_dev, stage, sizeof(ones), hipMemcpyHostToDevice, s) != hipSuccess) return fail(IVX_ERR_HIP);
-        } else if (hipMemcpyAsync(c->dens_dev, first->dens_dev, sizeof(ones), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            if (ivx_memcpy_async(c->dens_dev, stage, sizeof(ones), hipMemcpyHostToDevice, s) != hipSuccess) return fail(IVX_ERR_HIP);
+        } else if (ivx_memcpy_async(c->dens_dev, first->dens_dev, sizeof(ones), hipMemcpyDeviceToDevice, s) != hipSuccess) {
             return fail(IVX_ERR_HIP);
         }
+        memcpy(c->dens_host, ones, sizeof(ones));
+        c->has_dens = 1;
         if ((rc = ivx_launch_derive(c, 0))) return fail(rc);
         if ((rc = ivx_launch_occupied(c, c->rscalar + 16))) return fail(rc);
         if ((rc = ivx_launch_inertia(c, c->dens_dev, c->partials + c->partial_blocks * 10, 0))) return fail(rc);
         char* dst = stage + 1024 + fr[f].info_off * sizeof(ivx_chunk_info);
-        bool ok = hipMemcpyAsync(dst, c->info, c->n_chunks * sizeof(ivx_chunk_info), hipMemcpyDeviceToHost, s) == hipSuccess;
+        bool ok = ivx_memcpy_async(dst, c->info, c->n_chunks * sizeof(ivx_chunk_info), hipMemcpyDeviceToHost, s) == hipSuccess;
         char* tail = stage + 1024 + info_total * sizeof(ivx_chunk_info) + f * per_child;
-        ok = ok && hipMemcpyAsync(tail, c->rscalar + 16, 12 * sizeof(uint32_t), hipMemcpyDeviceToHost, s) == hipSuccess;
-        ok = ok && hipMemcpyAsync(tail + 12 * sizeof(uint32_t), c->partials + c->partial_blocks * 10, sizeof(double), hipMemcpyDeviceToHost, s) == hipSuccess;
+        ok = ok && ivx_memcpy_async(tail, c->rscalar + 16, 12 * sizeof(uint32_t), hipMemcpyDeviceToHost, s) == hipSuccess;
+        ok = ok && ivx_memcpy_async(tail + 12 * sizeof(uint32_t), c->partials + c->partial_blocks * 10, sizeof(double), hipMemcpyDeviceToHost, s) == hipSuccess;
         if (!ok) {
             ivx_set_error("ivx_copy_polyhedra: copy failed");
             return fail(IVX_ERR_HIP);
         }
     }
-    if (hipStreamSynchronize(s) != hipSuccess) return fail(IVX_ERR_HIP);
+    if (ivx_stream_sync(s) != hipSuccess) return fail(IVX_ERR_HIP);
     // 3. discard crumbs, repack small children into one chunk (complete_extracted_voxel_object, extraction.rs:1902-2142), then the
     // region passes of every survivor, again with one wait
     for (size_t f = 0; f < n_sets; ++f) {
@@ -1282,9 +1343,9 @@ int ivx_copy_polyhedra(ivx_grid* parent, const float* planes4, const uint32_t* p
         if ((rc = ivx_launch_ccl_local(c, 1))) return fail(rc);
         if ((rc = ivx_launch_ccl_merge(c))) return fail(rc);
         if ((rc = ivx_launch_ccl_resolve(c))) return fail(rc);
-        if (hipMemcpyAsync(stage + scalars_off + f * 8, c->rscalar, 8, hipMemcpyDeviceToHost, s) != hipSuccess) return fail(IVX_ERR_HIP);
+        if (ivx_memcpy_async(stage + scalars_off + f * 8, c->rscalar, 8, hipMemcpyDeviceToHost, s) != hipSuccess) return fail(IVX_ERR_HIP);
     }
-    if (hipStreamSynchronize(s) != hipSuccess) return fail(IVX_ERR_HIP);
+    if (ivx_stream_sync(s) != hipSuccess) return fail(IVX_ERR_HIP);
     for (size_t f = 0; f < n_sets; ++f) {
         ivx_grid* c = fr[f].c;
         if (!c) continue;
@@ -1310,7 +1371,7 @@ int ivx_region_face_labels(ivx_grid* g, int side, void* device_buf) {
     IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "ivx_region_face_labels: call ivx_label_regions first");
     int rc = ivx_launch_face_ids(g, side, static_cast<uint16_t*>(device_buf));
     if (rc) return rc;
-    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
     return IVX_OK;
 }
 
@@ -1341,22 +1402,102 @@ int ivx_region_face_pairs(ivx_grid* g, int side, const void* neighbour_face_labe
     return IVX_OK;
 }
 
-static int absorb_shape(ivx_grid* g, const char* who, int capsule, const float center[3], const float seg[3], float influence_radius, float shape_radius,
-                        const float densities[256], ivx_absorb_result* out, uint32_t* emptied_by_type, uint8_t* invalidated_chunks) {
-    IVX_REQUIRE(g && center && densities && out && (seg || !capsule), IVX_ERR_INVALID, "%s: null argument", who);
+// ---- the edit path (§8f-2): ONE wait per edit, and only the chunks the edit can have changed are swept -------------------------------------
+// ivx_absorb_*_enqueue puts on the stream: the edit kernel over the touched chunk box; the derive sweep over that box grown by one chunk
+// each way (ivx_launch_derive_box: what the reference patches chunk by chunk, object/intersection.rs:255-262, 532-598) with the region
+// forest of all other chunks reset; the global region resolve (interaction/absorption.rs:631); the count pass of the remesh for the chunks
+// whose meshes the edit invalidates (ivx_launch_box_mesh_needs); one copy of all small results into pinned memory. ivx_absorb_collect waits
+// for the doorbell behind them. Round 3 swept the whole object's active list (5 388 chunks of the 512^3 body for a bite that touches 80)
+// and ivx_mesh_sync counted the whole object again and read its sizes back.
+struct ivx_edit_state {
+    // the edit in flight
+    int pending = 0, nothing = 0, staged = 0;
+    uint32_t lo[3] = {0, 0, 0}, cc[3] = {0, 0, 0}, blo[3] = {0, 0, 0}, bcc[3] = {0, 0, 0};
+    size_t off_type = 0, off_cnt = 0, off_touch = 0, off_needs = 0, total = 0;
+    void* pinned = nullptr;  // results of the edit in flight: host-mapped, written by the step's gather launch ahead of the doorbell
+    void* pinned_dev = nullptr;
+    size_t pinned_bytes = 0;
+    char* d_results = nullptr;  // the edit's accumulators on the device (its own allocation: zero between edits — cleared behind every collect)
+    size_t d_results_bytes = 0;
+    // what the meshes of the last edit's invalidated chunks need (chunk -> vertices, indices, kind | flags << 8): valid until voxels change again
+    std::unordered_map<uint32_t, std::array<uint32_t, 3>> needs;
+    // the sync in flight
+    int sync_pending = 0;
+    void* pinned_up = nullptr;
+    size_t pinned_up_bytes = 0;
+    hipEvent_t up_done = nullptr;  // the last upload from pinned_up has been read
+    int up_busy = 0;
+};
+static void ivx_edit_state_free(ivx_edit_state* e) {
+    if (!e) return;
+    if (e->pinned) (void)hipHostFree(e->pinned);
+    if (e->d_results) (void)hipFree(e->d_results);
+    if (e->pinned_up) (void)hipHostFree(e->pinned_up);
+    if (e->up_done) (void)hipEventDestroy(e->up_done);
+    delete e;
+}
+static ivx_edit_state* edit_state(ivx_grid* g) {
+    if (!g->edit) g->edit = new (std::nothrow) ivx_edit_state();
+    return g->edit;
+}
+static bool edit_needs_lookup(ivx_grid* g, uint32_t chunk, uint32_t out3[3]) {
+    if (!g->edit) return false;
+    const auto it = g->edit->needs.find(chunk);
+    if (it == g->edit->needs.end()) return false;
+    out3[0] = it->second[0], out3[1] = it->second[1], out3[2] = it->second[2];
+    return true;
+}
+static void edit_sync_mark(ivx_grid* g, int pending) {
+    if (ivx_edit_state* e = edit_state(g)) e->sync_pending = pending;
+}
+static int edit_sync_pending(ivx_grid* g) { return g->edit ? g->edit->sync_pending : 0; }
+static int ensure_pinned(void** p, size_t* have, size_t bytes);
+// host -> device from the sync's own pinned block, asynchronously (the block is free again once the event behind the copy has passed)
+static int edit_sync_upload(ivx_grid* g, const void* src, size_t bytes, void* d_dst) {
+    if (ivx_many_upload(d_dst, src, (bytes + 3) & ~(size_t)3)) return IVX_OK;  // (a batch is being recorded: the words ride in its staging copy)
+    ivx_edit_state* e = edit_state(g);
+    IVX_REQUIRE(e, IVX_ERR_CAPACITY, "ivx_mesh_sync: out of host memory");
+    if (!e->up_done) IVX_HIP_CHECK(hipEventCreateWithFlags(&e->up_done, hipEventDisableTiming));
+    if (e->up_busy) {
+        IVX_HIP_CHECK(hipEventSynchronize(e->up_done));
+        e->up_busy = 0;
+    }
+    int rc = ensure_pinned(&e->pinned_up, &e->pinned_up_bytes, bytes);
+    if (rc) return rc;
+    memcpy(e->pinned_up, src, bytes);
+    IVX_HIP_CHECK(ivx_memcpy_async(d_dst, e->pinned_up, bytes, hipMemcpyHostToDevice, g->ctx->stream));
+    IVX_HIP_CHECK(ivx_event_record(e->up_done, g->ctx->stream));
+    e->up_busy = 1;
+    return IVX_OK;
+}
+static int ensure_pinned(void** p, size_t* have, size_t bytes) {
+    if (*have >= bytes) return IVX_OK;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr;
+    *have = 0;
+    const size_t cap = std::max<size_t>(bytes, 1 << 16);
+    IVX_HIP_CHECK(hipHostMalloc(p, cap, hipHostMallocDefault));
+    *have = cap;
+    return IVX_OK;
+}
+
+static int absorb_enqueue(ivx_grid* g, const char* who, int capsule, const float center[3], const float seg[3], float influence_radius, float shape_radius,
+                          const float densities[256]) {
+    IVX_REQUIRE(g && center && densities && (seg || !capsule), IVX_ERR_INVALID, "%s: null argument", who);
     IVX_REQUIRE(influence_radius >= 0.0f && shape_radius >= 0.0f, IVX_ERR_INVALID, "%s: negative radius", who);
     IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "%s: derived state and regions must be current (ivx_derive_state + ivx_label_regions)", who);
     IVX_REQUIRE(g->x_off == 0 && g->gx == g->cc[0] && !g->has_ghost[0] && !g->has_ghost[1], IVX_ERR_STATE, "%s: not available on a slab of a decomposed grid",
                 who);
-    memset(out, 0, sizeof(*out));
-    if (emptied_by_type) memset(emptied_by_type, 0, 256 * sizeof(uint32_t));
-    if (invalidated_chunks) memset(invalidated_chunks, 0, g->n_chunks);
+    ivx_edit_state* e = edit_state(g);
+    IVX_REQUIRE(e, IVX_ERR_CAPACITY, "%s: out of host memory", who);
+    IVX_REQUIRE(!e->pending, IVX_ERR_STATE, "%s: an edit of this object is in flight (ivx_absorb_collect first)", who);
     int rc;
     // the touched voxel ranges start from the object's occupied ranges (voxel_ranges_touching_aab, intersection.rs:766-782)
     uint32_t occ[12];
     if ((rc = reference_occupied(g, occ))) return rc;
     int32_t vlo[3], vhi[3];
     uint32_t lo[3], cc[3];
+    e->nothing = 0;
     for (int d = 0; d < 3; ++d) {
         float a = center[d] - influence_radius, b = center[d] + influence_radius;  // Sphere::compute_aabb
         if (capsule) {  // Capsule::compute_aabb: the boxes of the two end spheres (capsule.rs:132-137)
@@ -1367,95 +1508,167 @@ static int absorb_shape(ivx_grid* g, const char* who, int capsule, const float c
         }
         const float fl = std::floor(a), ce = std::ceil(b);
         // `as usize` saturates at 0; the occupied ranges bound the other side
-        const long s = fl > 0.0f ? (fl < 2.0e9f ? (long)fl : 2000000000L) : 0, e = ce > 0.0f ? (ce < 2.0e9f ? (long)ce : 2000000000L) : 0;
-        vlo[d] = (int32_t)std::max<long>((long)occ[6 + 2 * d], s);
-        vhi[d] = (int32_t)std::min<long>((long)occ[7 + 2 * d], e);
-        if (vlo[d] >= vhi[d]) return IVX_OK;
+        const long s_ = fl > 0.0f ? (fl < 2.0e9f ? (long)fl : 2000000000L) : 0, e_ = ce > 0.0f ? (ce < 2.0e9f ? (long)ce : 2000000000L) : 0;
+        vlo[d] = (int32_t)std::max<long>((long)occ[6 + 2 * d], s_);
+        vhi[d] = (int32_t)std::min<long>((long)occ[7 + 2 * d], e_);
+        if (vlo[d] >= vhi[d]) {
+            e->nothing = 1;  // nothing touched: the collect reports zeros
+            e->pending = 1;
+            return IVX_OK;
+        }
         lo[d] = (uint32_t)vlo[d] / 16u;
         cc[d] = ((uint32_t)vhi[d] + 15u) / 16u - lo[d];
     }
-    // scratch: [10 f64 removed moments][256 u32 by type][2 u32 counters][pad][u32 touched ranges of the box's chunks]
-    const size_t box_chunks = (size_t)cc[0] * cc[1] * cc[2];  // (touched ranges are indexed by the chunk's position in the box)
-    const size_t off_type = 80, off_cnt = off_type + 1024, off_touch = off_cnt + 16, total = off_touch + box_chunks * 4;
-    const size_t off_dens = (total + 255) & ~(size_t)255;
-    if ((rc = ensure_dev_scratch(g, off_dens + 1024))) return rc;
-    char* base = static_cast<char*>(g->dev_scratch);
-    IVX_HIP_CHECK(hipMemsetAsync(base, 0, total, g->ctx->stream));
-    float* d_dens = reinterpret_cast<float*>(base + off_dens);
-    if (g->has_dens && memcmp(g->dens_host, densities, sizeof(g->dens_host)) == 0) d_dens = g->dens_dev;  // the resident table
-    else if ((rc = h2d(g, d_dens, densities, 1024))) return rc;
-    if ((rc = ivx_launch_absorb(g, capsule, lo, cc, vlo, vhi, center, seg, influence_radius, shape_radius, d_dens, reinterpret_cast<double*>(base),
-                                reinterpret_cast<uint32_t*>(base + off_type), reinterpret_cast<uint32_t*>(base + off_cnt),
-                                reinterpret_cast<uint32_t*>(base + off_touch))))
-        return rc;
-    // the edit's small results start their way to the host, the derived state of the edited object (flags, kinds, chunk-local regions,
-    // components: the reference patches them around the touched chunks; they are a pure function of the voxels and kinds) follows on
-    // the stream, and ONE wait covers both
-    std::vector<char> hostbuf(total);
-    const bool staged = total <= STAGED_COPY_MAX;
-    if (staged) {
-        if ((rc = ensure_host_scratch(g, total))) return rc;
-        IVX_HIP_CHECK(hipMemcpyAsync(g->host_scratch, base, total, hipMemcpyDeviceToHost, g->ctx->stream));
-    } else if ((rc = d2h(g, hostbuf.data(), base, total))) {
-        return rc;
+    uint32_t blo[3], bcc[3];  // the box the derive sweep goes over: one chunk more each way
+    for (int d = 0; d < 3; ++d) {
+        blo[d] = lo[d] > 0u ? lo[d] - 1u : 0u;
+        const uint32_t bhi = std::min(lo[d] + cc[d] + 1u, g->cc[d]);
+        bcc[d] = bhi - blo[d];
+        e->lo[d] = lo[d], e->cc[d] = cc[d], e->blo[d] = blo[d], e->bcc[d] = bcc[d];
     }
-    if ((rc = rederive_enqueue(g))) return rc;
-    if ((rc = rederive_collect(g))) return rc;
-    if (staged) memcpy(hostbuf.data(), g->host_scratch, total);
-    const double* rem = reinterpret_cast<const double*>(hostbuf.data());
-    const double e = (double)g->extent, e3 = e * e * e, e4 = e3 * e, e5 = e4 * e;
+    // scratch: [10 f64 removed moments][256 u32 by type][2 u32 counters][pad][u32 touched ranges of the box's chunks][uint4 needs of the grown box's]
+    const size_t box_chunks = (size_t)cc[0] * cc[1] * cc[2], grown = (size_t)bcc[0] * bcc[1] * bcc[2];
+    e->off_type = 80, e->off_cnt = e->off_type + 1024, e->off_touch = e->off_cnt + 16;
+    e->off_needs = (e->off_touch + box_chunks * 4 + 15) & ~(size_t)15;
+    e->total = e->off_needs + grown * 16;
+    hipStream_t s = g->ctx->stream;
+    const size_t off_dens = (e->total + 255) & ~(size_t)255, need_bytes = off_dens + 1024;  // (a density table other than the resident one rides behind the results)
+    if (e->d_results_bytes < need_bytes) {  // (grown on demand; a fresh block starts zeroed, later ones are cleared behind every collect)
+        IVX_HIP_CHECK(ivx_stream_sync(s));
+        if (e->d_results) (void)hipFree(e->d_results);
+        e->d_results = nullptr, e->d_results_bytes = 0;
+        const size_t cap = std::max<size_t>(2 * need_bytes, 1 << 16);
+        IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->d_results), cap));
+        IVX_HIP_CHECK(ivx_memset_async(e->d_results, 0, cap, s));
+        e->d_results_bytes = cap;
+    }
+    char* base = e->d_results;
+    const float* d_dens = g->dens_dev;
+    if (!(g->has_dens && memcmp(g->dens_host, densities, sizeof(g->dens_host)) == 0)) {  // another table than the resident one
+        if ((rc = h2d(g, base + off_dens, densities, 1024))) return rc;
+        d_dens = reinterpret_cast<const float*>(base + off_dens);
+    }
+    // the edit; its first block also zeroes the region scalars the sweep behind it starts from
+    if ((rc = ivx_launch_absorb(g, capsule, lo, cc, vlo, vhi, center, seg, influence_radius, shape_radius, d_dens, reinterpret_cast<double*>(base),
+                                reinterpret_cast<uint32_t*>(base + e->off_type), reinterpret_cast<uint32_t*>(base + e->off_cnt),
+                                reinterpret_cast<uint32_t*>(base + e->off_touch), g->rscalar)))
+        return rc;
+    e->needs.clear();  // (voxels change: what an earlier edit's chunks needed is history)
+    // derived state and chunk-local regions of the grown box, the other chunks' region nodes reset; then the global resolve, whose first
+    // launch also counts what the invalidated chunks' meshes need, and whose last (the gather of ivx_absorb_collect) copies the edit's small
+    // results to the host ahead of the doorbell: seven launches, no copy or fill operation on the stream
+    if ((rc = ivx_launch_derive_box(g, IVX_PART_REGIONS, blo, bcc, nullptr))) return rc;
+    e->staged = e->total <= STAGED_COPY_MAX;
+    if (e->staged && e->pinned_bytes < e->total) {
+        IVX_HIP_CHECK(ivx_stream_sync(s));
+        if (e->pinned) (void)hipHostFree(e->pinned);
+        e->pinned = e->pinned_dev = nullptr, e->pinned_bytes = 0;
+        const size_t cap = std::max<size_t>(2 * e->total, 1 << 16);
+        IVX_HIP_CHECK(hipHostMalloc(&e->pinned, cap, hipHostMallocMapped));
+        IVX_HIP_CHECK(hipHostGetDevicePointer(&e->pinned_dev, e->pinned, 0));
+        e->pinned_bytes = cap;
+    }
+    for (int d = 0; d < 3; ++d) g->post1_needs_box[d] = lo[d], g->post1_needs_box[3 + d] = cc[d], g->post1_needs_box[6 + d] = blo[d], g->post1_needs_box[9 + d] = bcc[d];
+    g->post1_needs_touched = reinterpret_cast<const uint32_t*>(base + e->off_touch);
+    g->post1_needs_out = reinterpret_cast<uint32_t*>(base + e->off_needs);
+    {
+        const uint32_t keep = g->stage_timing_off;
+        g->stage_timing_off = 0xFFFFFFFFu;       // (no event records around the slots: nobody reads this call's stage times)
+        g->preset_fresh |= IVX_SCRATCH_REGIONS;  // (the region scalars were zeroed by the edit kernel, before the box sweep listed its multi-region chunks)
+        g->regions_labelled_locally = 1;         // (... and the sweep labelled the box: no stand-alone local pass in front of the resolve)
+        rc = ivx_voxel_step_enqueue(g, IVX_STAGE_REGIONS);
+        g->regions_labelled_locally = 0;
+        g->stage_timing_off = keep;
+        if (rc) return rc;
+    }
+    if (e->staged) {
+        g->gather_copy_src = reinterpret_cast<const uint32_t*>(base);
+        g->gather_copy_dst = static_cast<uint32_t*>(e->pinned_dev);
+        g->gather_copy_words = (uint32_t)((e->total + 3) / 4);
+    }
+    e->pending = 1;
+    return IVX_OK;
+}
+
+static int absorb_collect(ivx_grid* g, const char* who, ivx_absorb_result* out, uint32_t* emptied_by_type, uint8_t* invalidated_chunks) {
+    IVX_REQUIRE(g && out, IVX_ERR_INVALID, "%s: null argument", who);
+    ivx_edit_state* e = g->edit;
+    IVX_REQUIRE(e && e->pending, IVX_ERR_STATE, "%s: no edit of this object is in flight", who);
+    e->pending = 0;
+    memset(out, 0, sizeof(*out));
+    if (emptied_by_type) memset(emptied_by_type, 0, 256 * sizeof(uint32_t));
+    if (invalidated_chunks) memset(invalidated_chunks, 0, g->n_chunks);
+    if (e->nothing) return IVX_OK;
+    int rc;
+    if ((rc = rederive_collect(g))) return rc;  // (the doorbell behind everything enqueued: one wait)
+    std::vector<char> hostbuf;
+    const char* hb;
+    if (e->staged) {
+        hb = static_cast<const char*>(e->pinned);
+    } else {
+        hostbuf.resize(e->total);
+        if ((rc = d2h(g, hostbuf.data(), e->d_results, e->total))) return rc;
+        hb = hostbuf.data();
+    }
+    // (the accumulators and the touched words start the next edit from zero — and that edit's box may be larger than this one's: everything this
+    // edit wrote is cleared now, off the next edit's path; the block beyond has never been written)
+    if (!ivx_many_zero(e->d_results, (e->total + 3) & ~(size_t)3)) IVX_HIP_CHECK(ivx_memset_async(e->d_results, 0, e->total, g->ctx->stream));
+    const double* rem = reinterpret_cast<const double*>(hb);
+    const double ex = (double)g->extent, e3 = ex * ex * ex, e4 = e3 * ex, e5 = e4 * ex;
     const double f[10] = {e3, 0.5 * e4, 0.5 * e4, 0.5 * e4, e5 / 3.0, e5 / 3.0, e5 / 3.0, 0.25 * e5, 0.25 * e5, 0.25 * e5};
     for (int q = 0; q < 10; ++q) out->removed_moments[q] = rem[q] * f[q];
-    const uint32_t* by_type = reinterpret_cast<const uint32_t*>(hostbuf.data() + off_type);
+    const uint32_t* by_type = reinterpret_cast<const uint32_t*>(hb + e->off_type);
     uint64_t emptied = 0;
     for (int t = 0; t < 256; ++t) {
         emptied += by_type[t];
         if (emptied_by_type) emptied_by_type[t] = by_type[t];
     }
     out->emptied_voxels = emptied;
-    const uint32_t* cnt = reinterpret_cast<const uint32_t*>(hostbuf.data() + off_cnt);
+    const uint32_t* cnt = reinterpret_cast<const uint32_t*>(hb + e->off_cnt);
     out->touched_chunks = cnt[0];
     out->removed_chunks = cnt[1];
     if (cnt[1]) g->occ_ref_valid = 0;  // `if removed_chunks { self.update_occupied_ranges() }` (intersection.rs:384-386, 520-522)
-    if (invalidated_chunks) {
-        // handle_chunk_voxels_modified (intersection.rs:560-598): the touched chunk, and a neighbour when the touched voxel range
-        // of the chunk comes within two voxels of the face they share
-        const uint32_t* touched = reinterpret_cast<const uint32_t*>(hostbuf.data() + off_touch);
-        for (uint32_t i = lo[0]; i < lo[0] + cc[0]; ++i)
-            for (uint32_t j = lo[1]; j < lo[1] + cc[1]; ++j)
-                for (uint32_t k = lo[2]; k < lo[2] + cc[2]; ++k) {
-                    const uint32_t c = (i * g->cc[1] + j) * g->cc[2] + k;
-                    const uint32_t w = touched[((i - lo[0]) * cc[1] + (j - lo[1])) * cc[2] + (k - lo[2])];
-                    if (!w) continue;
-                    invalidated_chunks[c] = 1;
-                    const uint32_t idx[3] = {i, j, k};
-                    for (int d = 0; d < 3; ++d) {
-                        const uint32_t rlo = (w >> (4 * d)) & 15u, rhi = ((w >> (12 + 4 * d)) & 15u) + 1u;  // chunk-relative
-                        uint32_t a[3] = {i, j, k};
-                        if (idx[d] > 0 && rlo < 2) {
-                            a[d] = idx[d] - 1;
-                            invalidated_chunks[(a[0] * g->cc[1] + a[1]) * g->cc[2] + a[2]] = 1;
-                        }
-                        if (idx[d] + 1 < g->cc[d] && 16u - rhi < 2) {
-                            a[d] = idx[d] + 1;
-                            invalidated_chunks[(a[0] * g->cc[1] + a[1]) * g->cc[2] + a[2]] = 1;
-                        }
-                    }
-                }
+    // handle_chunk_voxels_modified (intersection.rs:560-598): the touched chunk, and a neighbour when the touched voxel range of the chunk
+    // comes within two voxels of the face they share — decided on the device per chunk of the grown box, with what its mesh needs now
+    const uint32_t* needs = reinterpret_cast<const uint32_t*>(hb + e->off_needs);
+    const size_t grown = (size_t)e->bcc[0] * e->bcc[1] * e->bcc[2];
+    for (size_t b = 0; b < grown; ++b) {
+        const uint32_t w = needs[4 * b];
+        if (!(w & 0x80000000u)) continue;
+        const uint32_t c = needs[4 * b + 3];
+        if (invalidated_chunks) invalidated_chunks[c] = 1;
+        e->needs[c] = {needs[4 * b + 1], needs[4 * b + 2], w & 0xFFFFu};
     }
+    g->needs_current = 1;
     return IVX_OK;
+}
+
+extern "C" {
+int ivx_absorb_sphere_enqueue(ivx_grid* g, const float center[3], float influence_radius, float sphere_radius, const float densities[256]) {
+    return absorb_enqueue(g, "ivx_absorb_sphere_enqueue", 0, center, nullptr, influence_radius, sphere_radius, densities);
+}
+int ivx_absorb_capsule_enqueue(ivx_grid* g, const float segment_start[3], const float segment_vector[3], float influence_radius, float capsule_radius,
+                               const float densities[256]) {
+    return absorb_enqueue(g, "ivx_absorb_capsule_enqueue", 1, segment_start, segment_vector, influence_radius, capsule_radius, densities);
+}
+int ivx_absorb_collect(ivx_grid* g, ivx_absorb_result* out, uint32_t* emptied_by_type, uint8_t* invalidated_chunks) {
+    return absorb_collect(g, "ivx_absorb_collect", out, emptied_by_type, invalidated_chunks);
 }
 
 int ivx_absorb_sphere(ivx_grid* g, const float center[3], float influence_radius, float sphere_radius, const float densities[256], ivx_absorb_result* out,
                       uint32_t* emptied_by_type, uint8_t* invalidated_chunks) {
-    return absorb_shape(g, "ivx_absorb_sphere", 0, center, nullptr, influence_radius, sphere_radius, densities, out, emptied_by_type, invalidated_chunks);
+    IVX_REQUIRE(out, IVX_ERR_INVALID, "ivx_absorb_sphere: null argument");
+    const int rc = absorb_enqueue(g, "ivx_absorb_sphere", 0, center, nullptr, influence_radius, sphere_radius, densities);
+    return rc ? rc : absorb_collect(g, "ivx_absorb_sphere", out, emptied_by_type, invalidated_chunks);
 }
 
 int ivx_absorb_capsule(ivx_grid* g, const float segment_start[3], const float segment_vector[3], float influence_radius, float capsule_radius,
                        const float densities[256], ivx_absorb_result* out, uint32_t* emptied_by_type, uint8_t* invalidated_chunks) {
-    return absorb_shape(g, "ivx_absorb_capsule", 1, segment_start, segment_vector, influence_radius, capsule_radius, densities, out, emptied_by_type,
-                        invalidated_chunks);
+    IVX_REQUIRE(out, IVX_ERR_INVALID, "ivx_absorb_capsule: null argument");
+    const int rc = absorb_enqueue(g, "ivx_absorb_capsule", 1, segment_start, segment_vector, influence_radius, capsule_radius, densities);
+    return rc ? rc : absorb_collect(g, "ivx_absorb_capsule", out, emptied_by_type, invalidated_chunks);
 }
+}  // extern "C"
 
 // rotate a vector by a quaternion the way glam's Quat::mul_vec3a does (host side of Isometry3::transform_point)
 static void host_qrot(const float q[4], const float v[3], float out[3]) {
@@ -1641,7 +1854,7 @@ int ivx_collision_probes_recompute(ivx_grid* g, size_t* n_points) {
     uint32_t* d_counts = reinterpret_cast<uint32_t*>(base + off_counts);
     uint32_t* d_offsets = reinterpret_cast<uint32_t*>(base + off_offsets);
     uint32_t* d_err = reinterpret_cast<uint32_t*>(base + off_err);
-    IVX_HIP_CHECK(hipMemsetAsync(d_err, 0, 4, g->ctx->stream));
+    IVX_HIP_CHECK(ivx_memset_async(d_err, 0, 4, g->ctx->stream));
     if ((rc = ivx_launch_probe_select(g, n_sub, log2_bs, reinterpret_cast<uint32_t*>(base), reinterpret_cast<uint32_t*>(base + off_sel), d_counts, d_offsets,
                                       d_err, nullptr)))
         return rc;
@@ -1663,7 +1876,7 @@ int ivx_collision_probes_recompute(ivx_grid* g, size_t* n_points) {
     if ((rc = ivx_launch_probe_gather(g, n_sub, log2_bs, reinterpret_cast<uint32_t*>(base + off_sel), d_counts, d_offsets, g->probe_entries, nullptr))) return rc;
     pm->total = n_pts;
     pm->built = false;  // (the entries stay on the device until a sync or a download asks for them)
-    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
     g->n_probe_points = n_pts;
     *n_points = n_pts;
     return IVX_OK;
@@ -1759,7 +1972,7 @@ int ivx_collision_probes_sync(ivx_grid* g, const uint8_t* invalidated_chunks, si
     if (n_rec) {
         if ((rc = ensure_dev_scratch(g, total))) return rc;
         base = static_cast<char*>(g->dev_scratch);
-        IVX_HIP_CHECK(hipMemsetAsync(base + off_err, 0, 4, g->ctx->stream));
+        IVX_HIP_CHECK(ivx_memset_async(base + off_err, 0, 4, g->ctx->stream));
         if ((rc = h2d(g, base + off_slots, slots.data(), (size_t)n_rec * 4))) return rc;
         if ((rc = ivx_launch_probe_select(g, n_rec, log2_bs, reinterpret_cast<uint32_t*>(base), reinterpret_cast<uint32_t*>(base + off_sel),
                                           reinterpret_cast<uint32_t*>(base + off_counts), nullptr, reinterpret_cast<uint32_t*>(base + off_err),
@@ -1803,14 +2016,14 @@ int ivx_collision_probes_sync(ivx_grid* g, const uint8_t* invalidated_chunks, si
         g->probe_point_cap = cap;
     }
     for (const auto& r : freed)  // holes read as "no probe" until a later chunk takes them (the gather below overwrites what was taken now)
-        IVX_HIP_CHECK(hipMemsetAsync(g->probe_chunk + r.first, 0xFF, (size_t)(r.second - r.first) * 4, g->ctx->stream));
+        IVX_HIP_CHECK(ivx_memset_async(g->probe_chunk + r.first, 0xFF, (size_t)(r.second - r.first) * 4, g->ctx->stream));
     if (n_rec) {
         if ((rc = h2d(g, base + off_dst, dst.data(), (size_t)n_rec * 4))) return rc;
         if ((rc = ivx_launch_probe_gather(g, n_rec, log2_bs, reinterpret_cast<uint32_t*>(base + off_sel), reinterpret_cast<uint32_t*>(base + off_counts),
                                           reinterpret_cast<uint32_t*>(base + off_dst), nullptr, reinterpret_cast<const uint32_t*>(base + off_slots))))
             return rc;
     }
-    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
     g->n_probe_points = (uint32_t)pm->total;
     g->probes_serial = g->mesh_serial;
     *n_points = pm->total;
@@ -2111,7 +2324,7 @@ int ivx_absorb_mutual(ivx_grid* a, const float rotation_a[4], const float transl
     const size_t off_dens = blk_a + blk_b, off_snap = off_dens + 2048;
     if ((rc = ensure_dev_scratch(a, off_snap + snap_bytes + 256))) return rc;
     char* base = static_cast<char*>(a->dev_scratch);
-    IVX_HIP_CHECK(hipMemsetAsync(base, 0, off_dens, a->ctx->stream));
+    IVX_HIP_CHECK(ivx_memset_async(base, 0, off_dens, a->ctx->stream));
     if ((rc = h2d(a, base + off_dens, densities_a, 1024))) return rc;
     if ((rc = h2d(a, base + off_dens + 1024, densities_b, 1024))) return rc;
     int8_t* d_snap = reinterpret_cast<int8_t*>(base + off_snap);
@@ -2212,7 +2425,7 @@ int ivx_grid_set_sdf_program(ivx_grid* g, const ivx_sdf_processed_node* nodes, s
         IVX_REQUIRE(grid_shape[d] <= cap, IVX_ERR_INVALID, "ivx_grid_set_sdf_program: grid shape exceeds the chunk grid along axis %d", d);
     }
     if (n_nodes > g->prog_cap) {
-        IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+        IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
         if (g->prog_nodes) (void)hipFree(g->prog_nodes);
         g->prog_nodes = nullptr;
         g->prog_cap = 0;
@@ -2302,13 +2515,13 @@ static int step_enqueue(ivx_grid* g, uint32_t stages, const uint16_t* slab_nbr_i
     else {                                                         \
         if (last_stop) g->ev_start_ref[i] = last_stop;             \
         else {                                                     \
-            IVX_HIP_CHECK(hipEventRecord(g->ev[2 * (i)], s));      \
+            IVX_HIP_CHECK(ivx_event_record(g->ev[2 * (i)], s));      \
             g->ev_start_ref[i] = &g->ev[2 * (i)];                  \
         }                                                          \
     }
 #define T1(i)                                                      \
     if ((timing >> (i)) & 1u) {                                    \
-        IVX_HIP_CHECK(hipEventRecord(g->ev[2 * (i) + 1], s));      \
+        IVX_HIP_CHECK(ivx_event_record(g->ev[2 * (i) + 1], s));      \
         last_stop = &g->ev[2 * (i) + 1];                           \
         g->timed_mask |= 1u << (i);                                \
     }
@@ -2339,7 +2552,7 @@ static int step_enqueue(ivx_grid* g, uint32_t stages, const uint16_t* slab_nbr_i
         if ((stages & IVX_STAGE_REGIONS) && !(fused_parts & IVX_PART_REGIONS)) {
             // (level 1 over the active list; the exact numbering of multi-region chunks is a role of k_step_post1 below, so
             // only the list-driven labelling kernel is launched here: ivx_launch_ccl_local would run both)
-            if ((rc = ivx_launch_ccl_local_only(g))) return rc;
+            if (!g->regions_labelled_locally && (rc = ivx_launch_ccl_local_only(g))) return rc;
         }
         if ((stages & IVX_STAGE_INERTIA) && !(fused_parts & IVX_PART_MOMENTS))
             if ((rc = ivx_launch_inertia_dense(g))) return rc;
@@ -2350,7 +2563,7 @@ static int step_enqueue(ivx_grid* g, uint32_t stages, const uint16_t* slab_nbr_i
         T0(3);
         if (slab_record) {
             if ((rc = ensure_pairs(g))) return rc;
-            if (slab_nbr_ids && !g->pairs_zeroed) IVX_HIP_CHECK(hipMemsetAsync(g->pairs_dev, 0, (4 + 128) * sizeof(uint32_t), s));
+            if (slab_nbr_ids && !g->pairs_zeroed) IVX_HIP_CHECK(ivx_memset_async(g->pairs_dev, 0, (4 + 128) * sizeof(uint32_t), s));
             g->pairs_zeroed = 0;
         }
         if ((rc = ivx_launch_step_post2(g, post, slab_nbr_ids))) return rc;
@@ -2400,7 +2613,7 @@ int ivx_slab_remesh_enqueue(ivx_grid* g, const void* neighbour_face_ids, void* d
         if ((rc = step_enqueue(g, IVX_STAGE_REMESH, nullptr, nullptr))) return rc;
         if ((rc = ivx_step_record_enqueue(g, device_record))) return rc;
         if (g->record_head_copy)
-            IVX_HIP_CHECK(hipMemcpyAsync(g->record_head_copy, device_record, (size_t)g->record_head_words * 8, hipMemcpyDeviceToDevice, g->ctx->stream));
+            IVX_HIP_CHECK(ivx_memcpy_async(g->record_head_copy, device_record, (size_t)g->record_head_words * 8, hipMemcpyDeviceToDevice, g->ctx->stream));
         return IVX_OK;
     }
     g->pairs_enqueued = 0;
@@ -2424,6 +2637,21 @@ static uint64_t collect_spin_ns() {
     return ns;
 }
 
+// the launch half of ivx_voxel_step_collect: the gather of the step's results (and whatever rides on it) goes on the stream — or into the
+// batch being recorded —, the wait is left to the collect
+static int ivx_step_collect_launch(ivx_grid* g) {
+    if (g->results_in_block || g->gather_launched) return IVX_OK;
+    if (!g->result_host) {
+        IVX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&g->result_host), 64 * sizeof(uint32_t), hipHostMallocMapped));
+        memset(g->result_host, 0, 64 * sizeof(uint32_t));
+        IVX_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&g->result_host_dev), g->result_host, 0));
+    }
+    g->gather_flush_id = ivx_many_flush_count();
+    const int rc = ivx_launch_step_gather(g);
+    if (!rc) g->gather_launched = 1;
+    return rc;
+}
+
 int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out) {
     IVX_REQUIRE(g && out, IVX_ERR_INVALID, "ivx_voxel_step_collect: null argument");
     hipStream_t s = g->ctx->stream;
@@ -2439,10 +2667,16 @@ int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out) {
     const bool have_results = g->results_in_block != 0;  // (ivx_slab_remesh_enqueue: the block is written, the caller has waited for the stream)
     g->results_in_block = 0;
     if (!have_results) {
-        int rc = ivx_launch_step_gather(g);
-        if (rc) return rc;
+        if (!g->gather_launched) {  // (else ivx_step_collect_launch has put it on the stream: the many-object calls launch all objects' gathers as one)
+            int rc = ivx_launch_step_gather(g);
+            if (rc) return rc;
+            (void)ivx_many_break();
+        }
+        // (a gather that was only recorded has to be on the stream before anybody polls its doorbell: flushed now unless a flush has gone by since)
+        if (g->gather_launched && ivx_many_recording() && g->gather_flush_id == ivx_many_flush_count()) (void)ivx_many_break();
+        g->gather_launched = 0;
     } else if (hipStreamQuery(s) != hipSuccess) {
-        IVX_HIP_CHECK(hipStreamSynchronize(s));
+        IVX_HIP_CHECK(ivx_stream_sync(s));
     }
     // A short step is over before the runtime's blocking wait has gone to sleep and been woken again: poll the doorbell word the
     // gather kernel writes last (in-order stream: everything enqueued before it is complete too) for a bounded time first.
@@ -2463,7 +2697,7 @@ int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out) {
             }
             std::atomic_thread_fence(std::memory_order_acquire);
         }
-        if (!rung) IVX_HIP_CHECK(hipStreamSynchronize(s));
+        if (!rung) IVX_HIP_CHECK(ivx_stream_sync(s));
     }
     const uint32_t* sc = g->result_host;
     if (sc[31]) g->last_active = sc[31];
@@ -2489,7 +2723,7 @@ int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out) {
             int rc;
             if ((rc = ensure_mesh_capacity(g, totals[0], totals[1], totals[2]))) return rc;
             if ((rc = ivx_launch_sn_emit(g))) return rc;
-            IVX_HIP_CHECK(hipStreamSynchronize(s));
+            IVX_HIP_CHECK(ivx_stream_sync(s));
         }
         g->mesh_counts.n_vertices = totals[0];
         g->mesh_counts.n_indices = totals[1];
@@ -2532,7 +2766,7 @@ int ivx_halo_pack(ivx_grid* g, int side, void* device_buf) {
     IVX_REQUIRE(g && device_buf && (side == 0 || side == 1), IVX_ERR_INVALID, "ivx_halo_pack: bad argument");
     int rc = ivx_launch_halo_pack(g, side, device_buf);
     if (rc) return rc;
-    IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
     return IVX_OK;
 }
 
@@ -2541,12 +2775,12 @@ int ivx_halo_unpack(ivx_grid* g, int side, const void* device_buf) {
     const size_t cols = (size_t)g->cc[1] * g->cc[2];
     hipStream_t s = g->ctx->stream;
     const uint8_t* b = static_cast<const uint8_t*>(device_buf);
-    IVX_HIP_CHECK(hipMemcpyAsync(g->ghost_sdf[side], b, cols * 256, hipMemcpyDeviceToDevice, s));
-    IVX_HIP_CHECK(hipMemcpyAsync(g->ghost_type[side], b + cols * 256, cols * 256, hipMemcpyDeviceToDevice, s));
-    IVX_HIP_CHECK(hipMemcpyAsync(g->ghost_info[side], b + cols * 512, cols * sizeof(ivx_chunk_info), hipMemcpyDeviceToDevice, s));
+    IVX_HIP_CHECK(ivx_memcpy_async(g->ghost_sdf[side], b, cols * 256, hipMemcpyDeviceToDevice, s));
+    IVX_HIP_CHECK(ivx_memcpy_async(g->ghost_type[side], b + cols * 256, cols * 256, hipMemcpyDeviceToDevice, s));
+    IVX_HIP_CHECK(ivx_memcpy_async(g->ghost_info[side], b + cols * 512, cols * sizeof(ivx_chunk_info), hipMemcpyDeviceToDevice, s));
     g->has_ghost[side] = 1;
     g->ghost_ext[side] = nullptr;
-    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    IVX_HIP_CHECK(ivx_stream_sync(s));
     return IVX_OK;
 }
 
@@ -2578,7 +2812,7 @@ int ivx_region_face_labels_enqueue(ivx_grid* g, int side, void* device_buf) {
 static int ensure_pairs(ivx_grid* g) {
     if (g->pairs_dev) return IVX_OK;
     IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->pairs_dev), sizeof(uint32_t) * (4 + 128 + 2 * (size_t)IVX_MAX_FACE_PAIRS)));
-    IVX_HIP_CHECK(hipMemsetAsync(g->pairs_dev, 0, sizeof(uint32_t) * (4 + 128), g->ctx->stream));
+    IVX_HIP_CHECK(ivx_memset_async(g->pairs_dev, 0, sizeof(uint32_t) * (4 + 128), g->ctx->stream));
     return IVX_OK;
 }
 
@@ -2604,6 +2838,86 @@ int ivx_step_record_enqueue(ivx_grid* g, void* device_record) {
     if (!rc && g->result_host_dev) g->results_in_block = 1;
     g->pairs_enqueued = 0;
     return rc;
+}
+
+// ---- many objects per call (many.hpp) ---------------------------------------------------------------------------------------------------
+// The per-object host code runs object after object while the launches are recorded; one flush issues a launch per chain position for all of
+// them; the results come back through every object's own host-mapped block, their gathers launched as one.
+int ivx_many_begin(ivx_ctx* c);
+int ivx_many_flush(ivx_ctx* c);
+static int many_check(ivx_grid* const* grids, size_t n, const char* who) {
+    IVX_REQUIRE(grids && n > 0 && grids[0], IVX_ERR_INVALID, "%s: no objects", who);
+    for (size_t i = 0; i < n; ++i) {
+        IVX_REQUIRE(grids[i] && grids[i]->ctx == grids[0]->ctx, IVX_ERR_INVALID, "%s: object %zu is null or belongs to another context", who, i);
+        for (size_t j = 0; j < i; ++j) IVX_REQUIRE(grids[j] != grids[i], IVX_ERR_INVALID, "%s: object %zu is listed twice", who, i);
+    }
+    return IVX_OK;
+}
+// runs `f(i)` for every object under the recorder and flushes; the first error ends the batch (what was recorded still goes out, so that no
+// object is left half enqueued)
+static int many_phase(ivx_grid* const* grids, size_t n, const std::function<int(size_t)>& f) {
+    ivx_ctx* c = grids[0]->ctx;
+    int rc = ivx_many_begin(c);
+    if (rc) return rc;
+    int first = IVX_OK;
+    for (size_t i = 0; i < n && !first; ++i) {
+        ivx_many_object((uint32_t)i);
+        first = f(i);
+    }
+    rc = ivx_many_flush(c);
+    return first ? first : rc;
+}
+
+int ivx_voxel_step_many(ivx_grid* const* grids, size_t n, uint32_t stages, ivx_step_result* out) {
+    int rc = many_check(grids, n, "ivx_voxel_step_many");
+    if (rc) return rc;
+    IVX_REQUIRE(out, IVX_ERR_INVALID, "ivx_voxel_step_many: null result array");
+    // (no event records around the stage slots: an event is a stream operation of its own and would end the merging after every object;
+    // `stage_ms` of a merged step is zero — the launches are shared, their times are not an object's)
+    if ((rc = many_phase(grids, n, [&](size_t i) {
+             const uint32_t keep = grids[i]->stage_timing_off;
+             grids[i]->stage_timing_off = 0xFFFFFFFFu;
+             const int r = step_enqueue(grids[i], stages, nullptr, nullptr);
+             grids[i]->stage_timing_off = keep;
+             return r;
+         })))
+        return rc;
+    if ((rc = many_phase(grids, n, [&](size_t i) { return ivx_step_collect_launch(grids[i]); }))) return rc;
+    for (size_t i = 0; i < n; ++i)
+        if ((rc = ivx_voxel_step_collect(grids[i], &out[i]))) return rc;
+    return IVX_OK;
+}
+
+int ivx_absorb_sphere_many(ivx_grid* const* grids, size_t n, const float* centers3, const float* influence_radii, const float* sphere_radii,
+                           const float densities[256], ivx_absorb_result* out, uint8_t* const* invalidated_chunks) {
+    int rc = many_check(grids, n, "ivx_absorb_sphere_many");
+    if (rc) return rc;
+    IVX_REQUIRE(centers3 && influence_radii && sphere_radii && densities && out, IVX_ERR_INVALID, "ivx_absorb_sphere_many: null argument");
+    // (what an object's enqueue may have to wait for — its occupied ranges, a density table that is not the resident one — before the recording starts)
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t occ[12];
+        if (grids[i]->regions_valid && (rc = reference_occupied(grids[i], occ))) return rc;
+    }
+    if ((rc = many_phase(grids, n, [&](size_t i) {
+             return absorb_enqueue(grids[i], "ivx_absorb_sphere_many", 0, centers3 + 3 * i, nullptr, influence_radii[i], sphere_radii[i], densities);
+         })))
+        return rc;
+    if ((rc = many_phase(grids, n, [&](size_t i) { return (grids[i]->edit && grids[i]->edit->pending && !grids[i]->edit->nothing) ? ivx_step_collect_launch(grids[i]) : IVX_OK; })))
+        return rc;
+    return many_phase(grids, n, [&](size_t i) {
+        return absorb_collect(grids[i], "ivx_absorb_sphere_many", &out[i], nullptr, invalidated_chunks ? invalidated_chunks[i] : nullptr);
+    });
+}
+
+int ivx_mesh_sync_many(ivx_grid* const* grids, size_t n, const uint8_t* const* invalidated_chunks, ivx_mesh_counts* out) {
+    int rc = many_check(grids, n, "ivx_mesh_sync_many");
+    if (rc) return rc;
+    IVX_REQUIRE(invalidated_chunks && out, IVX_ERR_INVALID, "ivx_mesh_sync_many: null argument");
+    if ((rc = many_phase(grids, n, [&](size_t i) { return mesh_sync_enqueue(grids[i], invalidated_chunks[i], "ivx_mesh_sync_many"); }))) return rc;
+    IVX_HIP_CHECK(ivx_stream_sync(grids[0]->ctx->stream));  // (one wait for all)
+    for (size_t i = 0; i < n; ++i)
+        if ((rc = mesh_sync_collect(grids[i], &out[i], "ivx_mesh_sync_many", true))) return rc;
+    return IVX_OK;
 }
 
 int ivx_halo_clear(ivx_grid* g, int side) {

@@ -8,6 +8,30 @@
 #include <cstring>
 
 #include "../../include/impact_voxel_hip.h"
+#include "many.hpp"
+
+// Every stream operation of the library goes through these: while a batch of objects is being recorded (many.hpp) whatever has been
+// recorded is issued first, so that the stream sees the operations in program order whether or not they have a merged form.
+static inline hipError_t ivx_memset_async(void* p, int v, size_t n, hipStream_t s) {
+    (void)ivx_many_break();
+    return hipMemsetAsync(p, v, n, s);
+}
+static inline hipError_t ivx_memcpy_async(void* d, const void* src, size_t n, hipMemcpyKind k, hipStream_t s) {
+    (void)ivx_many_break();
+    return hipMemcpyAsync(d, src, n, k, s);
+}
+static inline hipError_t ivx_stream_sync(hipStream_t s) {
+    (void)ivx_many_break();
+    return hipStreamSynchronize(s);
+}
+static inline hipError_t ivx_memcpy_sync(void* d, const void* src, size_t n, hipMemcpyKind k) {
+    (void)ivx_many_break();
+    return hipMemcpy(d, src, n, k);
+}
+static inline hipError_t ivx_event_record(hipEvent_t e, hipStream_t s) {
+    (void)ivx_many_break();
+    return hipEventRecord(e, s);
+}
 
 #define IVX_CHUNK 16
 #define IVX_CHUNK_VOXELS 4096
@@ -109,7 +133,23 @@ struct ivx_grid {
     // nothing has rewritten voxels since (ivx_planes_touched): the derive sweep then reads those 2 + 4 bytes per row instead of the planes
     int signs_current;
     uint8_t signs_type;
+    // a box sweep after an edit (ivx_launch_derive_box) has changed chunk kinds since the active list was made: whoever walks the list without
+    // a derive sweep of its own rebuilds it first (ivx_ensure_active_list)
+    int active_list_stale;
+    int regions_labelled_locally;  // (set around the resolve stage of an edit: the box sweep has labelled the chunk-local regions)
+    struct ivx_edit_state* edit;   // host state of the edit path (ivx_absorb_*_enqueue / _collect, ivx_mesh_sync_enqueue / _collect)
+    // handed to the next k_step_post1 / k_step_gather launch and consumed by it (the edit path's riders on the step's launches)
+    uint32_t post1_needs_box[12];         // touched box lo, cc; grown box lo, cc
+    const uint32_t* post1_needs_touched;
+    uint32_t* post1_needs_out;            // non-null: the next post1 launch hosts the mesh-needs role
+    const uint32_t* gather_copy_src;
+    uint32_t* gather_copy_dst;            // (device address of host-mapped memory)
+    uint32_t gather_copy_words;
+    uint64_t gather_flush_id;      // the recorder's flush count when the gather was recorded (many.hpp)
+    int gather_launched;           // the step's gather is on the stream (or recorded): ivx_voxel_step_collect only waits
+    int needs_current;             // edit->needs holds what the last edit's invalidated chunks' meshes need (no voxel has changed since)
     uint32_t stage_timing_off;  // timed slots WITHOUT event records (ivx_grid_set_stage_timing; zero-initialised: every slot is timed)
+    float* dens_call;       // [256] a density table handed to one call (ivx_inertia, ivx_regions_describe) that is not the resident one
     float* dens_dev;        // [256] voxel type densities
     float dens_host[256];   // what dens_dev holds (entry points that are handed the same table again skip the upload)
     void* dev_scratch;      // grown on demand (node programs, dense label export, region statistics)
@@ -288,7 +328,10 @@ static inline uint32_t ivx_list_grid(const ivx_grid* g) {
 
 static inline uint32_t* ivx_wc(const ivx_grid* g) { return g->work_counts + g->wc_cur; }
 // to be called by everything that writes voxel planes other than the sampler (uploads, edits, split / clip / repack, raw plane pointers handed out)
-static inline void ivx_planes_touched(ivx_grid* g) { g->signs_current = 0; }
+static inline void ivx_planes_touched(ivx_grid* g) {
+    g->signs_current = 0;
+    g->needs_current = 0;
+}
 // groups of small scratch words that must hold their preset value when a stage starts
 #define IVX_SCRATCH_EVAL_ROLL 8u  // role_preset: copy the sampler's list counters to their statistics words and zero them
 #define IVX_SCRATCH_REGIONS 1u  // rscalar[0..16): region count, error flags, multi-region chunk count
@@ -334,6 +377,8 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
 #define IVX_PART_REGIONS 1u
 #define IVX_PART_MOMENTS 2u
 int ivx_launch_derive(ivx_grid* g, uint32_t parts, uint32_t preset_groups = 0);
+int ivx_launch_derive_box(ivx_grid* g, uint32_t parts, const uint32_t lo[3], const uint32_t cc[3], uint32_t* d_out_list);
+int ivx_ensure_active_list(ivx_grid* g);
 int ivx_ensure_dense(ivx_grid* g);
 int ivx_launch_step_preset(ivx_grid* g, uint32_t groups);
 // scratch groups of the caller's NEXT ivx_voxel_step_enqueue, to be preset by the first kernel of the one before it (slab_comm.cpp)
@@ -349,6 +394,9 @@ void ivx_sdf_annotate_host(ivx_sdf_processed_node* nodes, size_t n);  // sdf_com
 int ivx_launch_occupied(ivx_grid* g, uint32_t* d_raw);
 void ivx_occupied_from_raw(const ivx_grid* g, const uint32_t raw[12], uint32_t out[12]);
 int ivx_launch_sn_count(ivx_grid* g);
+int ivx_launch_list_mesh_needs(ivx_grid* g, uint32_t n, const uint32_t* d_list, uint32_t* d_out);
+int ivx_launch_box_mesh_needs(ivx_grid* g, const uint32_t t_lo[3], const uint32_t t_cc[3], const uint32_t b_lo[3], const uint32_t b_cc[3], const uint32_t* d_touched,
+                              uint32_t* d_out);
 int ivx_launch_sn_scan(ivx_grid* g);
 int ivx_launch_sn_emit(ivx_grid* g);
 int ivx_launch_sn_emit_general(ivx_grid* g);
@@ -385,7 +433,7 @@ int ivx_launch_absorb_mutual(ivx_grid* g, int from_snapshot, const uint32_t lo[3
                              uint32_t* d_touched);
 int ivx_launch_absorb(ivx_grid* g, int capsule, const uint32_t lo[3], const uint32_t cc[3], const int32_t vlo[3], const int32_t vhi[3], const float c[3],
                       const float seg[3], float influence_radius, float shape_radius, const float* d_dens, double* d_removed10, uint32_t* d_by_type,
-                      uint32_t* d_counters, uint32_t* d_touched);
+                      uint32_t* d_counters, uint32_t* d_touched, uint32_t* d_zero16 = nullptr);
 int ivx_launch_sphere_contacts(ivx_grid* g, const uint32_t lo[3], const uint32_t cc[3], const int32_t vlo[3], const int32_t vhi[3],
                                const float rotation_xyzw[4], const float translation[3], const float center[3], const float seg_vec[3], float radius,
                                uint64_t id_a, uint64_t id_b, uint32_t body_a, uint32_t body_b, const float response[3], uint32_t* d_counts,

@@ -1049,14 +1049,14 @@ __global__ __launch_bounds__(256) void k_mark_bodies(uint32_t n, const uint32_t*
 int ivx_launch_phys_prepare_bodies(ivx_world* w) {
     const uint32_t n = w->n_dyn + w->n_kin;
     if (n == 0) return IVX_OK;
-    hipLaunchKernelGGL(k_prepare_bodies, dim3((n + 255u) / 256u), dim3(256), 0, w->ctx->stream, w->n_dyn, w->n_kin, w->dyn, w->kin, w->cb, w->touched);
+    IVX_KLAUNCH(k_prepare_bodies, dim3((n + 255u) / 256u), dim3(256), 0, w->ctx->stream, w->n_dyn, w->n_kin, w->dyn, w->kin, w->cb, w->touched);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 
 int ivx_launch_phys_prepare_contacts(ivx_world* w, const int32_t* d_prev_slot) {
     if (w->n_contacts == 0) return IVX_OK;
-    hipLaunchKernelGGL(k_prepare_contacts, dim3((w->n_contacts + 255u) / 256u), dim3(256), 0, w->ctx->stream, w->n_contacts, w->n_dyn, w->contacts,
+    IVX_KLAUNCH(k_prepare_contacts, dim3((w->n_contacts + 255u) / 256u), dim3(256), 0, w->ctx->stream, w->n_contacts, w->n_dyn, w->contacts,
                        d_prev_slot, w->cb, w->pc[w->cur ^ 1], reinterpret_cast<const float4*>(w->acc[w->cur ^ 1]), w->n_prev,
                        w->cfg.old_impulse_weight, w->pc[w->cur], reinterpret_cast<float4*>(w->acc[w->cur]), w->touched);
     IVX_HIP_CHECK(hipGetLastError());
@@ -1065,14 +1065,14 @@ int ivx_launch_phys_prepare_contacts(ivx_world* w, const int32_t* d_prev_slot) {
 
 int ivx_launch_phys_mark_joint_bodies(ivx_world* w) {
     if (w->n_joint_refs == 0) return IVX_OK;
-    hipLaunchKernelGGL(k_mark_bodies, dim3((w->n_joint_refs + 255u) / 256u), dim3(256), 0, w->ctx->stream, w->n_joint_refs, w->joint_refs, w->n_dyn, w->n_kin, w->touched);
+    IVX_KLAUNCH(k_mark_bodies, dim3((w->n_joint_refs + 255u) / 256u), dim3(256), 0, w->ctx->stream, w->n_joint_refs, w->joint_refs, w->n_dyn, w->n_kin, w->touched);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 
 int ivx_launch_phys_pre_solve(ivx_world* w, float dt) {
     if (w->n_dyn == 0) return IVX_OK;
-    hipLaunchKernelGGL(k_pre_solve, dim3((w->n_dyn + 255u) / 256u), dim3(256), 0, w->ctx->stream, w->n_dyn, dt, w->dyn, w->cb);
+    IVX_KLAUNCH(k_pre_solve, dim3((w->n_dyn + 255u) / 256u), dim3(256), 0, w->ctx->stream, w->n_dyn, dt, w->dyn, w->cb);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -1080,7 +1080,7 @@ int ivx_launch_phys_pre_solve(ivx_world* w, float dt) {
 template <bool LDS, int PHASE>
 static int launch_solve(ivx_world* w, size_t lds, ReplayView rv = ReplayView(), const uint32_t* replay_flag = nullptr) {
     if (LDS) IVX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve<LDS, PHASE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_solve<LDS, PHASE>), dim3(1), dim3(SOLVE_THREADS), LDS ? lds : 0, w->ctx->stream, w->n_dyn, w->cfg.positional_correction_factor, w->pc[w->cur],
+    IVX_KLAUNCH((k_solve<LDS, PHASE>), dim3(1), dim3(SOLVE_THREADS), LDS ? lds : 0, w->ctx->stream, w->n_dyn, w->cfg.positional_correction_factor, w->pc[w->cur],
                        reinterpret_cast<float4*>(w->acc[w->cur]), w->cb, w->items + w->item_offset[PHASE],
                        reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], w->level_start + w->level_offset[PHASE],
                        w->n_levels[PHASE], rv, replay_flag);
@@ -1128,15 +1128,15 @@ template <int PHASE>
 static int pack_items_mg(ivx_world* w, hipStream_t stream) {
     const size_t need = (size_t)w->n_tiles[PHASE] * Packed<PHASE>::NJ * 64u * sizeof(float4);
     if (need > w->packed_cap[PHASE]) {
-        IVX_HIP_CHECK(hipStreamSynchronize(w->ctx->stream));
-        if (w->side_stream) IVX_HIP_CHECK(hipStreamSynchronize(w->side_stream));
+        IVX_HIP_CHECK(ivx_stream_sync(w->ctx->stream));
+        if (w->side_stream) IVX_HIP_CHECK(ivx_stream_sync(w->side_stream));
         if (w->packed[PHASE]) (void)hipFree(w->packed[PHASE]);
         w->packed[PHASE] = nullptr;
         w->packed_cap[PHASE] = 0;
         IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->packed[PHASE]), need + need / 8));
         w->packed_cap[PHASE] = need + need / 8;
     }
-    hipLaunchKernelGGL((k_pack_items<PHASE>), dim3(w->n_tiles[PHASE]), dim3(64), 0, stream, w->tile_first + w->tile_offset[PHASE], w->items + w->item_offset[PHASE],
+    IVX_KLAUNCH((k_pack_items<PHASE>), dim3(w->n_tiles[PHASE]), dim3(64), 0, stream, w->tile_first + w->tile_offset[PHASE], w->items + w->item_offset[PHASE],
                        reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], reinterpret_cast<const uint4*>(w->item_tags) + w->item_offset[PHASE],
                        w->pc[w->cur], w->cb, reinterpret_cast<float4*>(w->packed[PHASE]));
     IVX_HIP_CHECK(hipGetLastError());
@@ -1156,7 +1156,7 @@ static int launch_solve_mg(ivx_world* w, uint32_t groups, hipStream_t stream, Re
         const int v = e ? atoi(e) : 8;
         return (uint32_t)(v < 1 ? 1 : (v > 8 ? 8 : v));
     }();
-    hipLaunchKernelGGL((k_solve_mg<PHASE>), dim3(groups * spread), dim3(MG_THREADS), 0, stream, w->n_dyn, w->cfg.positional_correction_factor, w->pc[w->cur],
+    IVX_KLAUNCH((k_solve_mg<PHASE>), dim3(groups * spread), dim3(MG_THREADS), 0, stream, w->n_dyn, w->cfg.positional_correction_factor, w->pc[w->cur],
                        reinterpret_cast<float4*>(w->acc[w->cur]), w->n_contacts, w->cb, reinterpret_cast<float4*>(w->dynst + (PHASE ? w->body_cap * 16 : 0)),
                        w->items + w->item_offset[PHASE],
                        reinterpret_cast<const uint2*>(w->item_bodies) + w->item_offset[PHASE], w->level_start + w->level_offset[PHASE],
@@ -1182,15 +1182,15 @@ int ivx_launch_phys_solve(ivx_world* w) {
     }
     auto before_positional = [&](hipStream_t st) -> int {
         if (!replay) return IVX_OK;
-        IVX_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(uint32_t), st));
-        hipLaunchKernelGGL(k_kin_snapshot, dim3((w->n_dyn + 255u) / 256u + 1u), dim3(256), 0, st, w->n_dyn, w->cb, reinterpret_cast<float4*>(w->kin_snap));
+        IVX_HIP_CHECK(ivx_memset_async(flag, 0, sizeof(uint32_t), st));
+        IVX_KLAUNCH(k_kin_snapshot, dim3((w->n_dyn + 255u) / 256u + 1u), dim3(256), 0, st, w->n_dyn, w->cb, reinterpret_cast<float4*>(w->kin_snap));
         IVX_HIP_CHECK(hipGetLastError());
         return IVX_OK;
     };
     auto between_passes = [&](hipStream_t st) -> int {
-        hipLaunchKernelGGL(k_kin_prefix, dim3(w->n_kin), dim3(64), 0, st, w->n_kin, w->n_dyn, w->kin_offsets, w->kin_list, w->kin_applied,
+        IVX_KLAUNCH(k_kin_prefix, dim3(w->n_kin), dim3(64), 0, st, w->n_kin, w->n_dyn, w->kin_offsets, w->kin_list, w->kin_applied,
                            reinterpret_cast<float4*>(w->kin_qstart), w->cb, flag);
-        hipLaunchKernelGGL(k_kin_restore, dim3((w->n_dyn + 255u) / 256u + 1u), dim3(256), 0, st, w->n_dyn, w->cb, reinterpret_cast<const float4*>(w->kin_snap), flag);
+        IVX_KLAUNCH(k_kin_restore, dim3((w->n_dyn + 255u) / 256u + 1u), dim3(256), 0, st, w->n_dyn, w->cb, reinterpret_cast<const float4*>(w->kin_snap), flag);
         IVX_HIP_CHECK(hipGetLastError());
         return IVX_OK;
     };
@@ -1218,7 +1218,7 @@ int ivx_launch_phys_solve(ivx_world* w) {
         if (w->n_levels[0] && (rc = pack_items_mg<0>(w, s0))) return rc;
         if (w->n_levels[1] && (rc = pack_items_mg<1>(w, s0))) return rc;
         if (both) {
-            IVX_HIP_CHECK(hipEventRecord(w->ev_fork, s0));
+            IVX_HIP_CHECK(ivx_event_record(w->ev_fork, s0));
             IVX_HIP_CHECK(hipStreamWaitEvent(s1, w->ev_fork, 0));
         }
         if (w->n_levels[1] && both) {  // (the side stream first: its launches are in flight while the host enqueues the velocity phase)
@@ -1228,7 +1228,7 @@ int ivx_launch_phys_solve(ivx_world* w) {
                 if ((rc = between_passes(s1))) return rc;
                 if ((rc = launch_solve_mg<1>(w, groups, s1, pass2, flag))) return rc;
             }
-            IVX_HIP_CHECK(hipEventRecord(w->ev_join, s1));
+            IVX_HIP_CHECK(ivx_event_record(w->ev_join, s1));
         }
         if (w->n_levels[0] && (rc = launch_solve_mg<0>(w, groups, s0))) return rc;
         if (w->n_levels[1] && !both) {
@@ -1267,7 +1267,7 @@ int ivx_launch_phys_solve(ivx_world* w) {
 int ivx_launch_phys_free_step(ivx_world* w, float dt) {
     const uint32_t n = w->n_dyn + w->n_kin;
     if (n == 0) return IVX_OK;
-    hipLaunchKernelGGL(k_free_step, dim3((n + 255u) / 256u), dim3(256), 0, w->ctx->stream, w->n_dyn, w->n_kin, dt, w->dyn, w->kin, w->cb, w->touched);
+    IVX_KLAUNCH(k_free_step, dim3((n + 255u) / 256u), dim3(256), 0, w->ctx->stream, w->n_dyn, w->n_kin, dt, w->dyn, w->kin, w->cb, w->touched);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -1275,7 +1275,7 @@ int ivx_launch_phys_free_step(ivx_world* w, float dt) {
 int ivx_launch_phys_post_solve(ivx_world* w, float dt, int write_back, int advance) {
     const uint32_t n = w->n_dyn + w->n_kin;
     if (n == 0) return IVX_OK;
-    hipLaunchKernelGGL(k_post_solve, dim3((n + 255u) / 256u), dim3(256), 0, w->ctx->stream, w->n_dyn, w->n_kin, dt, write_back, advance, w->cb, w->touched,
+    IVX_KLAUNCH(k_post_solve, dim3((n + 255u) / 256u), dim3(256), 0, w->ctx->stream, w->n_dyn, w->n_kin, dt, write_back, advance, w->cb, w->touched,
                        w->dyn, w->kin);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;

@@ -17,7 +17,7 @@ template <class T>
 int grow(T** p, size_t* cap, size_t need, hipStream_t s) {
     if (need <= *cap) return IVX_OK;
     size_t ncap = std::max(need, *cap * 2);
-    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    IVX_HIP_CHECK(ivx_stream_sync(s));
     if (*p) (void)hipFree(*p);
     *p = nullptr;
     *cap = 0;
@@ -125,10 +125,10 @@ bool separating_contact(H3 com_a_minus_b, const ivx_contact* c, size_t n, ivx_co
 }
 
 int fetch_body_position(ivx_world* w, uint32_t ref, float out[3]) {
-    IVX_HIP_CHECK(hipStreamSynchronize(w->ctx->stream));
+    IVX_HIP_CHECK(ivx_stream_sync(w->ctx->stream));
     const void* src = (ref & IVX_KINEMATIC_BODY) ? static_cast<const void*>(w->kin[ref & 0x7FFFFFFFu].position)
                                                  : static_cast<const void*>(w->dyn[ref].position);
-    IVX_HIP_CHECK(hipMemcpy(out, src, 12, hipMemcpyDeviceToHost));
+    IVX_HIP_CHECK(ivx_memcpy_sync(out, src, 12, hipMemcpyDeviceToHost));
     return IVX_OK;
 }
 
@@ -289,7 +289,7 @@ int ivx_world_create(ivx_ctx* c, const ivx_solver_config* cfg, ivx_world** out) 
     else w->cfg = ivx_solver_config{8u, 0.4f, 3u, 0.2f};  // ConstraintSolverConfig::default (solver.rs:374-384)
     IVX_REQUIRE(w->cfg.n_iterations + w->cfg.n_positional_correction_iterations < 4096, IVX_ERR_INVALID, "ivx_world_create: too many iterations");
     if (hipMalloc(reinterpret_cast<void**>(&w->barrier_words), 40 * sizeof(uint32_t)) != hipSuccess ||
-        hipMemsetAsync(w->barrier_words, 0, 40 * sizeof(uint32_t), c->stream) != hipSuccess) {
+        ivx_memset_async(w->barrier_words, 0, 40 * sizeof(uint32_t), c->stream) != hipSuccess) {
         ivx_set_error("ivx_world_create: device allocation failed");
         delete w;
         return IVX_ERR_HIP;
@@ -310,9 +310,9 @@ int ivx_world_create(ivx_ctx* c, const ivx_solver_config* cfg, ivx_world** out) 
 
 void ivx_world_destroy(ivx_world* w) {
     if (!w) return;
-    (void)hipStreamSynchronize(w->ctx->stream);
+    (void)ivx_stream_sync(w->ctx->stream);
     if (w->side_stream) {  // the positional phase's stream and its fork / join events (created on the first multi-workgroup solve)
-        (void)hipStreamSynchronize(w->side_stream);
+        (void)ivx_stream_sync(w->side_stream);
         (void)hipEventDestroy(w->ev_fork);
         (void)hipEventDestroy(w->ev_join);
         (void)hipStreamDestroy(w->side_stream);
@@ -343,7 +343,7 @@ int ivx_world_set_spherical_joints(ivx_world* w, const uint32_t* body_pairs, siz
         IVX_REQUIRE((r & 0x7FFFFFFFu) < ((r & IVX_KINEMATIC_BODY) ? w->n_kin : w->n_dyn), IVX_ERR_INVALID,
                     "ivx_world_set_spherical_joints: anchor %zu refers to a missing body", i);
     }
-    IVX_HIP_CHECK(hipStreamSynchronize(w->ctx->stream));
+    IVX_HIP_CHECK(ivx_stream_sync(w->ctx->stream));
     if (w->joint_refs) (void)hipFree(w->joint_refs);
     w->joint_refs = nullptr;
     w->n_joint_refs = 0;
@@ -351,7 +351,7 @@ int ivx_world_set_spherical_joints(ivx_world* w, const uint32_t* body_pairs, siz
     w->n_bodies_stat_valid = 0;
     if (n_joints) {
         IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->joint_refs), 2 * n_joints * sizeof(uint32_t)));
-        IVX_HIP_CHECK(hipMemcpy(w->joint_refs, body_pairs, 2 * n_joints * sizeof(uint32_t), hipMemcpyHostToDevice));
+        IVX_HIP_CHECK(ivx_memcpy_sync(w->joint_refs, body_pairs, 2 * n_joints * sizeof(uint32_t), hipMemcpyHostToDevice));
         w->n_joint_refs = (uint32_t)(2 * n_joints);
         w->joint_refs_host.assign(body_pairs, body_pairs + 2 * n_joints);
     }
@@ -363,7 +363,7 @@ int ivx_world_set_bodies(ivx_world* w, const ivx_rigid_body* dyn, size_t n_dyn, 
     IVX_REQUIRE(n_dyn < IVX_KINEMATIC_BODY && n_kin < IVX_KINEMATIC_BODY, IVX_ERR_CAPACITY, "ivx_world_set_bodies: too many bodies");
     for (size_t i = 0; i < n_dyn; ++i) IVX_REQUIRE(dyn[i].mass > 0.0f, IVX_ERR_INVALID, "ivx_world_set_bodies: body %zu has non-positive mass", i);
     hipStream_t s = w->ctx->stream;
-    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    IVX_HIP_CHECK(ivx_stream_sync(s));
     const size_t need = n_dyn + n_kin;
     if (need > w->body_cap) {
         void* ptrs[] = {w->dyn, w->kin, w->cb, w->touched, w->dynst};
@@ -379,8 +379,8 @@ int ivx_world_set_bodies(ivx_world* w, const ivx_rigid_body* dyn, size_t n_dyn, 
         IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w->dynst), 2 * cap * 64));  // (the shared records of the velocity phase: 32 bytes per body; then, cap * 64 bytes in, of the positional phase: 48)
         w->body_cap = cap;
     }
-    if (n_dyn) IVX_HIP_CHECK(hipMemcpy(w->dyn, dyn, n_dyn * sizeof(ivx_rigid_body), hipMemcpyHostToDevice));
-    if (n_kin) IVX_HIP_CHECK(hipMemcpy(w->kin, kin, n_kin * sizeof(ivx_kinematic_body), hipMemcpyHostToDevice));
+    if (n_dyn) IVX_HIP_CHECK(ivx_memcpy_sync(w->dyn, dyn, n_dyn * sizeof(ivx_rigid_body), hipMemcpyHostToDevice));
+    if (n_kin) IVX_HIP_CHECK(ivx_memcpy_sync(w->kin, kin, n_kin * sizeof(ivx_kinematic_body), hipMemcpyHostToDevice));
     const bool resized = w->n_dyn != n_dyn || w->n_kin != n_kin;
     if ((n_dyn < w->n_dyn || n_kin < w->n_kin) && w->n_joint_refs) {
         // joints name bodies by index and were validated against the old counts: a set that shrank drops them (the caller sets them again)
@@ -399,10 +399,10 @@ int ivx_world_set_bodies(ivx_world* w, const ivx_rigid_body* dyn, size_t n_dyn, 
 
 int ivx_world_get_bodies(ivx_world* w, ivx_rigid_body* dyn, ivx_kinematic_body* kin) {
     IVX_REQUIRE(w, IVX_ERR_INVALID, "ivx_world_get_bodies: null world");
-    IVX_HIP_CHECK(hipStreamSynchronize(w->ctx->stream));
+    IVX_HIP_CHECK(ivx_stream_sync(w->ctx->stream));
     if (int rc = ivx_world_check_solve(w, "ivx_world_get_bodies")) return rc;
-    if (dyn && w->n_dyn) IVX_HIP_CHECK(hipMemcpy(dyn, w->dyn, w->n_dyn * sizeof(ivx_rigid_body), hipMemcpyDeviceToHost));
-    if (kin && w->n_kin) IVX_HIP_CHECK(hipMemcpy(kin, w->kin, w->n_kin * sizeof(ivx_kinematic_body), hipMemcpyDeviceToHost));
+    if (dyn && w->n_dyn) IVX_HIP_CHECK(ivx_memcpy_sync(dyn, w->dyn, w->n_dyn * sizeof(ivx_rigid_body), hipMemcpyDeviceToHost));
+    if (kin && w->n_kin) IVX_HIP_CHECK(ivx_memcpy_sync(kin, w->kin, w->n_kin * sizeof(ivx_kinematic_body), hipMemcpyDeviceToHost));
     return IVX_OK;
 }
 
@@ -436,8 +436,8 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
         if (same) {
             hipStream_t s = w->ctx->stream;
             w->n_prev = w->n_contacts;
-            IVX_HIP_CHECK(hipMemcpyAsync(w->contacts, w->stage_contacts, n * sizeof(ivx_contact), hipMemcpyHostToDevice, s));
-            IVX_HIP_CHECK(hipEventRecord(w->stage_ev, s));
+            IVX_HIP_CHECK(ivx_memcpy_async(w->contacts, w->stage_contacts, n * sizeof(ivx_contact), hipMemcpyHostToDevice, s));
+            IVX_HIP_CHECK(ivx_event_record(w->stage_ev, s));
             w->stage_busy = 1;
             int rc;
             w->cur ^= 1;
@@ -548,7 +548,7 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
     hipStream_t s = w->ctx->stream;
     size_t cap = w->contact_cap;
     if (nc > cap) {
-        IVX_HIP_CHECK(hipStreamSynchronize(s));
+        IVX_HIP_CHECK(ivx_stream_sync(s));
         const size_t ncap = std::max<size_t>(nc, std::max<size_t>(cap * 2, 256));
         // the previous state (pc/acc of the last solve) must survive the growth
         ivx_contact* nc_buf = nullptr;
@@ -561,8 +561,8 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
             IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&npc[b]), ncap * sizeof(PhysContact)));
             IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&nacc[b]), ncap * 4 * sizeof(float)));
             if (w->pc[b] && w->n_prev) {
-                IVX_HIP_CHECK(hipMemcpy(npc[b], w->pc[b], w->n_prev * sizeof(PhysContact), hipMemcpyDeviceToDevice));
-                IVX_HIP_CHECK(hipMemcpy(nacc[b], w->acc[b], w->n_prev * 4 * sizeof(float), hipMemcpyDeviceToDevice));
+                IVX_HIP_CHECK(ivx_memcpy_sync(npc[b], w->pc[b], w->n_prev * sizeof(PhysContact), hipMemcpyDeviceToDevice));
+                IVX_HIP_CHECK(ivx_memcpy_sync(nacc[b], w->acc[b], w->n_prev * 4 * sizeof(float), hipMemcpyDeviceToDevice));
             }
             if (w->pc[b]) (void)hipFree(w->pc[b]);
             if (w->acc[b]) (void)hipFree(w->acc[b]);
@@ -589,7 +589,7 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
         if ((rc = grow(&w->kin_qstart, &w->kin_qstart_cap, 8 * n_pos_items, s))) return rc;  // float4 per (item, side)
         if ((rc = grow(&w->kin_snap, &w->kin_snap_cap, (size_t)std::max<uint32_t>(w->n_dyn, 1u) * 8, s))) return rc;
     }
-    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    IVX_HIP_CHECK(ivx_stream_sync(s));
     w->stage_busy = 0;
     if (nc > w->stage_contacts_cap) {  // the staging buffer of the usual frame's fast path (step 0)
         if (w->stage_contacts) (void)hipHostFree(w->stage_contacts);
@@ -604,22 +604,22 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
         w->stage_ev_ready = 1;
     }
     if (nc) {
-        IVX_HIP_CHECK(hipMemcpy(w->contacts, w->ordered.data(), nc * sizeof(ivx_contact), hipMemcpyHostToDevice));
-        IVX_HIP_CHECK(hipMemcpy(w->prev_slot, w->prev_slot_host.data(), nc * sizeof(int32_t), hipMemcpyHostToDevice));
+        IVX_HIP_CHECK(ivx_memcpy_sync(w->contacts, w->ordered.data(), nc * sizeof(ivx_contact), hipMemcpyHostToDevice));
+        IVX_HIP_CHECK(ivx_memcpy_sync(w->prev_slot, w->prev_slot_host.data(), nc * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     if (!same_schedule) {
         if (!w->items_host.empty()) {
-            IVX_HIP_CHECK(hipMemcpy(w->items, w->items_host.data(), w->items_host.size() * 4, hipMemcpyHostToDevice));
-            IVX_HIP_CHECK(hipMemcpy(w->item_bodies, w->item_bodies_host.data(), w->item_bodies_host.size() * 4, hipMemcpyHostToDevice));
-            IVX_HIP_CHECK(hipMemcpy(w->item_tags, w->item_tags_host.data(), w->item_tags_host.size() * 4, hipMemcpyHostToDevice));
+            IVX_HIP_CHECK(ivx_memcpy_sync(w->items, w->items_host.data(), w->items_host.size() * 4, hipMemcpyHostToDevice));
+            IVX_HIP_CHECK(ivx_memcpy_sync(w->item_bodies, w->item_bodies_host.data(), w->item_bodies_host.size() * 4, hipMemcpyHostToDevice));
+            IVX_HIP_CHECK(ivx_memcpy_sync(w->item_tags, w->item_tags_host.data(), w->item_tags_host.size() * 4, hipMemcpyHostToDevice));
         }
-        IVX_HIP_CHECK(hipMemcpy(w->level_start, w->level_start_host.data(), w->level_start_host.size() * 4, hipMemcpyHostToDevice));
-        IVX_HIP_CHECK(hipMemcpy(w->tile_base, w->tile_base_host.data(), w->tile_base_host.size() * 4, hipMemcpyHostToDevice));
+        IVX_HIP_CHECK(ivx_memcpy_sync(w->level_start, w->level_start_host.data(), w->level_start_host.size() * 4, hipMemcpyHostToDevice));
+        IVX_HIP_CHECK(ivx_memcpy_sync(w->tile_base, w->tile_base_host.data(), w->tile_base_host.size() * 4, hipMemcpyHostToDevice));
         if (!w->tile_first_host.empty())
-            IVX_HIP_CHECK(hipMemcpy(w->tile_first, w->tile_first_host.data(), w->tile_first_host.size() * 4, hipMemcpyHostToDevice));
+            IVX_HIP_CHECK(ivx_memcpy_sync(w->tile_first, w->tile_first_host.data(), w->tile_first_host.size() * 4, hipMemcpyHostToDevice));
         if (w->n_kin_items) {
-            IVX_HIP_CHECK(hipMemcpy(w->kin_offsets, w->kin_offsets_host.data(), w->kin_offsets_host.size() * 4, hipMemcpyHostToDevice));
-            IVX_HIP_CHECK(hipMemcpy(w->kin_list, w->kin_list_host.data(), w->kin_list_host.size() * 4, hipMemcpyHostToDevice));
+            IVX_HIP_CHECK(ivx_memcpy_sync(w->kin_offsets, w->kin_offsets_host.data(), w->kin_offsets_host.size() * 4, hipMemcpyHostToDevice));
+            IVX_HIP_CHECK(ivx_memcpy_sync(w->kin_list, w->kin_list_host.data(), w->kin_list_host.size() * 4, hipMemcpyHostToDevice));
         }
     }
     w->schedule_valid = 1;
@@ -629,7 +629,7 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
     if ((rc = ivx_launch_phys_prepare_contacts(w, w->prev_slot))) return rc;
     if ((rc = ivx_launch_phys_mark_joint_bodies(w))) return rc;
     w->prepared_fresh = 1;
-    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    IVX_HIP_CHECK(ivx_stream_sync(s));
     if (n_prepared) *n_prepared = nc;
     return IVX_OK;
 }
@@ -679,7 +679,7 @@ static int world_step_enqueue(ivx_world* w, float dt, bool timed) {
     }
 #define EV(i)                                              \
     do {                                                   \
-        if (timed) IVX_HIP_CHECK(hipEventRecord(w->ev[i], s)); \
+        if (timed) IVX_HIP_CHECK(ivx_event_record(w->ev[i], s)); \
     } while (0)
     int rc;
     if (w->n_contacts == 0 && !w->prepared_fresh && w->n_joint_refs == 0) {
@@ -716,7 +716,7 @@ int ivx_world_step(ivx_world* w, float dt, ivx_physics_result* out) {
     IVX_REQUIRE(w, IVX_ERR_INVALID, "ivx_world_step: null world");
     int rc = world_step_enqueue(w, dt, out != nullptr);
     if (rc) return rc;
-    IVX_HIP_CHECK(hipStreamSynchronize(w->ctx->stream));
+    IVX_HIP_CHECK(ivx_stream_sync(w->ctx->stream));
     if ((rc = ivx_world_check_solve(w, "ivx_world_step"))) return rc;
     if (out) {
         memset(out, 0, sizeof(*out));
@@ -776,10 +776,10 @@ int ivx_world_contact_state(ivx_world* w, uint64_t* ids, float* impulses3, size_
     if (ids)
         for (uint32_t s = 0; s < w->n_contacts; ++s) ids[s] = w->cache[s].id;
     if (impulses3 && w->n_contacts) {
-        IVX_HIP_CHECK(hipStreamSynchronize(w->ctx->stream));
+        IVX_HIP_CHECK(ivx_stream_sync(w->ctx->stream));
         if (int rc = ivx_world_check_solve(w, "ivx_world_contact_state")) return rc;
         std::vector<float> a((size_t)w->n_contacts * 4);
-        IVX_HIP_CHECK(hipMemcpy(a.data(), w->acc[w->cur], a.size() * 4, hipMemcpyDeviceToHost));
+        IVX_HIP_CHECK(ivx_memcpy_sync(a.data(), w->acc[w->cur], a.size() * 4, hipMemcpyDeviceToHost));
         for (uint32_t s = 0; s < w->n_contacts; ++s)
             for (int q = 0; q < 3; ++q) impulses3[3 * (size_t)s + q] = a[4 * (size_t)s + q];
     }

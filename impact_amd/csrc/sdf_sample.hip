@@ -1243,7 +1243,7 @@ int ivx_sampler_buffers(ivx_grid* g) {
     if (g->samp_ops) return IVX_OK;
     // [n] program lengths, [16] counters of the three evaluation lists (+ the long / short split of the first; [8..13) their rolled copy), [3 n] the lists
     IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_len), sizeof(uint32_t) * (4 * (size_t)g->n_chunks + 16)));
-    IVX_HIP_CHECK(hipMemsetAsync(g->samp_len + g->n_chunks, 0, 16 * sizeof(uint32_t), g->ctx->stream));  // the counters start at zero
+    IVX_HIP_CHECK(ivx_memset_async(g->samp_len + g->n_chunks, 0, 16 * sizeof(uint32_t), g->ctx->stream));  // the counters start at zero
     IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_ops), sizeof(uint2) * (size_t)OP_CAP * g->n_chunks));
     return IVX_OK;
 }
@@ -1287,14 +1287,14 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
     const bool eval_dirty = (g->scratch_dirty & IVX_SCRATCH_EVAL) != 0u;
     uint32_t super_presets = fused_super ? 0u : preset_groups;
     const uint32_t prepass_presets = fused_super ? (preset_groups & ~IVX_SCRATCH_EVAL) : 0u;
-    if (eval_dirty && !(super_presets & IVX_SCRATCH_EVAL)) IVX_HIP_CHECK(hipMemsetAsync(eval_count, 0, 8 * sizeof(uint32_t), g->ctx->stream));
+    if (eval_dirty && !(super_presets & IVX_SCRATCH_EVAL)) IVX_HIP_CHECK(ivx_memset_async(eval_count, 0, 8 * sizeof(uint32_t), g->ctx->stream));
     if (!eval_dirty) super_presets &= ~IVX_SCRATCH_EVAL;
     const uint32_t sx = (g->cc[0] + SUPER - 1) / SUPER, sy = (g->cc[1] + SUPER - 1) / SUPER, sz = (g->cc[2] + SUPER - 1) / SUPER;
     uint2* super_skip = nullptr;
     if (!fused_super) {
         const size_t need = (((size_t)sx * sy * sz * words + 1u) & ~(size_t)1u) + (size_t)sx * sy * sz * words * 64u;  // far bits + a uint2 per node
         if (need > g->samp_super_words) {
-            IVX_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+            IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
             if (g->samp_super) (void)hipFree(g->samp_super);
             g->samp_super = nullptr;
             g->samp_super_words = 0;
@@ -1302,11 +1302,11 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
             g->samp_super_words = need;
         }
         super_skip = reinterpret_cast<uint2*>(g->samp_super + (((size_t)sx * sy * sz * words + 1u) & ~(size_t)1u));
-        hipLaunchKernelGGL(k_sdf_super, dim3(sx * sy * sz), dim3(64), words * sizeof(uint32_t), g->ctx->stream, p, d_nodes, g->samp_super, super_skip, words, sy, sz,
+        IVX_KLAUNCH(k_sdf_super, dim3(sx * sy * sz), dim3(64), words * sizeof(uint32_t), g->ctx->stream, p, d_nodes, g->samp_super, super_skip, words, sy, sz,
                            ivx_preset_args(g, super_presets));
     }
     g->scratch_dirty = (g->scratch_dirty & ~preset_groups) | IVX_SCRATCH_EVAL;
-    hipLaunchKernelGGL(k_sdf_prepass, dim3(sx * sy * sz), dim3(PRE_T * PRE_WAVES), 0, g->ctx->stream, p, d_nodes, chunk_const, g->samp_len, ops, eval_count, eval_list,
+    IVX_KLAUNCH(k_sdf_prepass, dim3(sx * sy * sz), dim3(PRE_T * PRE_WAVES), 0, g->ctx->stream, p, d_nodes, chunk_const, g->samp_len, ops, eval_count, eval_list,
                        g->n_chunks, g->info, g->samp_super, super_skip, words, sy, sz, fused_super ? 1u : 0u, ivx_preset_args(g, prepass_presets));
     g->planes_compact = 1;
     {
@@ -1332,17 +1332,17 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
         if (!merge01 && !(known && g->eval_len[0] == 0u)) {
             // one level + 64 words of scratch: 16 640 bytes = 13 LDS granules, eight workgroups per CU (the waves a SIMD holds)
             const uint32_t scratch_off = IVX_CHUNK_VOXELS;
-            hipLaunchKernelGGL(k_sdf_eval<2>, dim3(fit(g->eval_len[0])), dim3(256), (size_t)(scratch_off + 64u) * sizeof(float), g->ctx->stream, p, eval_count + 0, list0,
+            IVX_KLAUNCH(k_sdf_eval<2>, dim3(fit(g->eval_len[0])), dim3(256), (size_t)(scratch_off + 64u) * sizeof(float), g->ctx->stream, p, eval_count + 0, list0,
                                eval_count + 3, nullptr, nullptr, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info, g->chunk_signs, g->kface);
         }
         if (merge01 || !(known && g->eval_len[1] == 0u)) {
             // two levels, the second one 15 rows long + 64 words of scratch: 32 000 bytes = 25 LDS granules, five workgroups per CU
             const uint32_t scratch_off = IVX_CHUNK_VOXELS + 15u * 256u;
             if (merge01)
-                hipLaunchKernelGGL(k_sdf_eval<1>, dim3(fit(g->eval_len[0] + g->eval_len[1])), dim3(256), (size_t)(scratch_off + 64u) * sizeof(float), g->ctx->stream, p, eval_count + 0, list0,
+                IVX_KLAUNCH(k_sdf_eval<1>, dim3(fit(g->eval_len[0] + g->eval_len[1])), dim3(256), (size_t)(scratch_off + 64u) * sizeof(float), g->ctx->stream, p, eval_count + 0, list0,
                                    eval_count + 3, eval_count + 1, list1, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info, g->chunk_signs, g->kface);
             else
-                hipLaunchKernelGGL(k_sdf_eval<1>, dim3(fit(g->eval_len[1])), dim3(256), (size_t)(scratch_off + 64u) * sizeof(float), g->ctx->stream, p, eval_count + 1, list1,
+                IVX_KLAUNCH(k_sdf_eval<1>, dim3(fit(g->eval_len[1])), dim3(256), (size_t)(scratch_off + 64u) * sizeof(float), g->ctx->stream, p, eval_count + 1, list1,
                                    nullptr, nullptr, nullptr, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info, g->chunk_signs, g->kface);
         }
         if (stack_size >= 3u && !(known && g->eval_len[2] == 0u)) {
@@ -1350,7 +1350,7 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
             // — the votes — and never used as published test voxels, which only the trimmed launch has)
             const uint32_t lv = stack_size;
             const uint32_t scratch_off = lv * IVX_CHUNK_VOXELS - 16u;
-            hipLaunchKernelGGL(k_sdf_eval<0>, dim3(fit(g->eval_len[2])), dim3(256), (size_t)lv * IVX_CHUNK_VOXELS * sizeof(float), g->ctx->stream, p, eval_count + 2,
+            IVX_KLAUNCH(k_sdf_eval<0>, dim3(fit(g->eval_len[2])), dim3(256), (size_t)lv * IVX_CHUNK_VOXELS * sizeof(float), g->ctx->stream, p, eval_count + 2,
                                eval_list + 2 * (size_t)g->n_chunks, nullptr, nullptr, nullptr, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info, g->chunk_signs, g->kface);
         }
     }
@@ -1364,7 +1364,7 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
 
 int ivx_launch_classify(ivx_grid* g) {
     ivx_planes_touched(g);
-    hipLaunchKernelGGL(k_classify, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, g->n_chunks, g->sdf, g->type, g->info);
+    IVX_KLAUNCH(k_classify, dim3(g->n_chunks), dim3(256), 0, g->ctx->stream, g->n_chunks, g->sdf, g->type, g->info);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

@@ -204,7 +204,7 @@ int ipc_exchange(ivx_slab* sl, size_t nbytes) {
     ivx_comm* c = sl->comm;
     hipStream_t s = c->ctx->stream;
     IpcShared* sh = c->ipc;
-    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    IVX_HIP_CHECK(ivx_stream_sync(s));
     for (int side = 0; side < 2; ++side) sh->ranks[c->rank].consumed[side].store(c->ipc_recv_seq[side], std::memory_order_release);
     for (int side = 0; side < 2; ++side) {
         if (!(side ? sl->has_hi : sl->has_lo)) continue;
@@ -212,9 +212,9 @@ int ipc_exchange(ivx_slab* sl, size_t nbytes) {
         const unsigned long long want = c->ipc_send_seq[side];
         if (!ipc_wait([&] { return sh->ranks[peer].consumed[peer_side].load(std::memory_order_acquire) >= want; }, "a neighbour to release its receive buffer"))
             return IVX_ERR_STATE;
-        IVX_HIP_CHECK(hipMemcpyAsync(c->ipc_peer_recv[side], sl->send[side], nbytes, hipMemcpyDeviceToDevice, s));
+        IVX_HIP_CHECK(ivx_memcpy_async(c->ipc_peer_recv[side], sl->send[side], nbytes, hipMemcpyDeviceToDevice, s));
     }
-    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    IVX_HIP_CHECK(ivx_stream_sync(s));
     for (int side = 0; side < 2; ++side) {
         if (!(side ? sl->has_hi : sl->has_lo)) continue;
         const int peer = side ? c->rank + 1 : c->rank - 1, peer_side = side ? 0 : 1;
@@ -244,8 +244,8 @@ int ipc_all_gather(ivx_slab* sl, size_t words) {
                 if (sh->ranks[r].rec_read.load(std::memory_order_acquire) < last) return false;
             return true;
         }, "the other ranks to read the previous record")) return IVX_ERR_STATE;
-    IVX_HIP_CHECK(hipMemcpyAsync(me.record, sl->record, words * 8, hipMemcpyDeviceToHost, s));
-    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    IVX_HIP_CHECK(ivx_memcpy_async(me.record, sl->record, words * 8, hipMemcpyDeviceToHost, s));
+    IVX_HIP_CHECK(ivx_stream_sync(s));
     c->ipc_rec_seq += 1;
     me.rec_seq.store(c->ipc_rec_seq, std::memory_order_release);
     const unsigned long long want = c->ipc_rec_seq;
@@ -254,9 +254,9 @@ int ipc_all_gather(ivx_slab* sl, size_t words) {
                 if (sh->ranks[r].rec_seq.load(std::memory_order_acquire) < want) return false;
             return true;
         }, "the other ranks' record")) return IVX_ERR_STATE;
-    for (int r = 0; r < c->nranks; ++r) IVX_HIP_CHECK(hipMemcpyAsync(sl->gathered + (size_t)r * words, sh->ranks[r].record, words * 8, hipMemcpyHostToDevice, s));
+    for (int r = 0; r < c->nranks; ++r) IVX_HIP_CHECK(ivx_memcpy_async(sl->gathered + (size_t)r * words, sh->ranks[r].record, words * 8, hipMemcpyHostToDevice, s));
     // (the copies above read the block asynchronously: waited for before this rank reports the gather as read)
-    IVX_HIP_CHECK(hipStreamSynchronize(s));
+    IVX_HIP_CHECK(ivx_stream_sync(s));
     me.rec_read.store(want, std::memory_order_release);
     return IVX_OK;
 }
@@ -303,7 +303,7 @@ int all_gather(ivx_slab** slabs, size_t n, size_t words) {
     if (c->rank >= 0) {
         ivx_slab* sl = slabs[0];
         if (c->nranks == 1) {
-            IVX_HIP_CHECK(hipMemcpyAsync(sl->gathered, sl->record, words * 8, hipMemcpyDeviceToDevice, s));
+            IVX_HIP_CHECK(ivx_memcpy_async(sl->gathered, sl->record, words * 8, hipMemcpyDeviceToDevice, s));
             return IVX_OK;
         }
         IVX_NCCL_CHECK(g_rccl.AllGather(sl->record, sl->gathered, words, NCCL_INT64, c->nccl, s));
@@ -311,7 +311,7 @@ int all_gather(ivx_slab** slabs, size_t n, size_t words) {
     }
     if (words == HEAD_WORDS) return IVX_OK;  // (in-process: the record roles wrote the heads in place, ivx_slabs_step_enqueue)
     for (size_t i = 0; i < n; ++i)  // every rank's view is the same: one gathered block, kept by rank 0's slab
-        IVX_HIP_CHECK(hipMemcpyAsync(slabs[0]->gathered + i * words, slabs[i]->record, words * 8, hipMemcpyDeviceToDevice, s));
+        IVX_HIP_CHECK(ivx_memcpy_async(slabs[0]->gathered + i * words, slabs[i]->record, words * 8, hipMemcpyDeviceToDevice, s));
     return IVX_OK;
 }
 
@@ -521,7 +521,7 @@ int ivx_comm_selftest(ivx_ctx* c) {
     hipStream_t s = c->stream;
     int result = IVX_OK;
     do {
-        if (hipMemcpyAsync(dev, host.data(), 3 * N, hipMemcpyHostToDevice, s) != hipSuccess) {
+        if (ivx_memcpy_async(dev, host.data(), 3 * N, hipMemcpyHostToDevice, s) != hipSuccess) {
             result = IVX_ERR_HIP;
             break;
         }
@@ -542,7 +542,7 @@ int ivx_comm_selftest(ivx_ctx* c) {
             result = IVX_ERR_HIP;
             break;
         }
-        if (hipMemcpyAsync(host.data(), dev, 3 * N, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        if (ivx_memcpy_async(host.data(), dev, 3 * N, hipMemcpyDeviceToHost, s) != hipSuccess || ivx_stream_sync(s) != hipSuccess) {
             result = IVX_ERR_HIP;
             break;
         }
@@ -552,7 +552,7 @@ int ivx_comm_selftest(ivx_ctx* c) {
                 result = IVX_ERR_STATE;
             }
     } while (false);
-    (void)hipStreamSynchronize(s);
+    (void)ivx_stream_sync(s);
     (void)hipFree(dev);
     (void)g_rccl.CommDestroy(comm);
     return result;
@@ -679,7 +679,7 @@ int ivx_slab_create(ivx_comm* m, ivx_grid* g, int rank, ivx_slab** out) {
 
 void ivx_slab_destroy(ivx_slab* sl) {
     if (!sl) return;
-    (void)hipStreamSynchronize(sl->comm->ctx->stream);
+    (void)ivx_stream_sync(sl->comm->ctx->stream);
     (void)ivx_halo_clear(sl->grid, 0);
     (void)ivx_halo_clear(sl->grid, 1);
     for (int s = 0; s < 2; ++s) {
@@ -723,8 +723,8 @@ int ivx_slabs_step_enqueue(ivx_slab** slabs, size_t n) {
             unsigned long long head[18];
             memset(head, 0, sizeof(head));
             head[17] = 8ull;
-            IVX_HIP_CHECK(hipMemcpyAsync(sl->gathered, head, sizeof(head), hipMemcpyHostToDevice, c->ctx->stream));
-            IVX_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));  // (`head` is a local)
+            IVX_HIP_CHECK(ivx_memcpy_async(sl->gathered, head, sizeof(head), hipMemcpyHostToDevice, c->ctx->stream));
+            IVX_HIP_CHECK(ivx_stream_sync(c->ctx->stream));  // (`head` is a local)
         }
         sl->local_err = local_err;
         sl->enqueued = 1;
@@ -763,9 +763,9 @@ int ivx_slabs_step_enqueue(ivx_slab** slabs, size_t n) {
             unsigned long long head[18];
             memset(head, 0, sizeof(head));
             head[17] = 8ull;
-            IVX_HIP_CHECK(hipMemcpyAsync(rec, head, sizeof(head), hipMemcpyHostToDevice, c->ctx->stream));
-            if (sl->grid->record_head_copy) IVX_HIP_CHECK(hipMemcpyAsync(sl->grid->record_head_copy, head, sizeof(head), hipMemcpyHostToDevice, c->ctx->stream));
-            IVX_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));  // (`head` is a local)
+            IVX_HIP_CHECK(ivx_memcpy_async(rec, head, sizeof(head), hipMemcpyHostToDevice, c->ctx->stream));
+            if (sl->grid->record_head_copy) IVX_HIP_CHECK(ivx_memcpy_async(sl->grid->record_head_copy, head, sizeof(head), hipMemcpyHostToDevice, c->ctx->stream));
+            IVX_HIP_CHECK(ivx_stream_sync(c->ctx->stream));  // (`head` is a local)
         }
         sl->local_err = local_err;
     }
@@ -788,7 +788,7 @@ int ivx_slabs_step_collect(ivx_slab** slabs, size_t n, ivx_slab_result* out) {
     {
         const uint32_t n_words = (uint32_t)((size_t)world * HEAD_WORDS);
         const unsigned long long want = ++keeper->head_seq;
-        hipLaunchKernelGGL(k_slab_publish, dim3(1), dim3(256), 0, s, keeper->gathered, keeper->host_head_dev, n_words, want);
+        IVX_KLAUNCH(k_slab_publish, dim3(1), dim3(256), 0, s, keeper->gathered, keeper->host_head_dev, n_words, want);
         IVX_HIP_CHECK(hipGetLastError());
         const volatile unsigned long long* bell = keeper->host_head + n_words;
         bool rung = false;
@@ -802,7 +802,7 @@ int ivx_slabs_step_collect(ivx_slab** slabs, size_t n, ivx_slab_result* out) {
             if ((it & 255u) == 255u && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > 2000) break;
         }
         std::atomic_thread_fence(std::memory_order_acquire);
-        if (!rung) IVX_HIP_CHECK(hipStreamSynchronize(s));
+        if (!rung) IVX_HIP_CHECK(ivx_stream_sync(s));
         memcpy(rec.data(), keeper->host_head, (size_t)n_words * 8);
     }
     unsigned long long max_pairs = 0;
@@ -811,8 +811,8 @@ int ivx_slabs_step_collect(ivx_slab** slabs, size_t n, ivx_slab_result* out) {
         words = keeper->rec_words;
         int rc = all_gather(slabs, n, words);
         if (rc) return rc;
-        IVX_HIP_CHECK(hipMemcpyAsync(rec.data(), keeper->gathered, (size_t)world * words * 8, hipMemcpyDeviceToHost, s));
-        IVX_HIP_CHECK(hipStreamSynchronize(s));
+        IVX_HIP_CHECK(ivx_memcpy_async(rec.data(), keeper->gathered, (size_t)world * words * 8, hipMemcpyDeviceToHost, s));
+        IVX_HIP_CHECK(ivx_stream_sync(s));
     }
     // error flags: decided on the gathered data every rank holds, so that all ranks fail together
     unsigned long long flags = 0;
@@ -883,7 +883,7 @@ int ivx_slabs_step_collect(ivx_slab** slabs, size_t n, ivx_slab_result* out) {
             slabs[i]->enqueued = 0;
             slabs[i]->grid->pending_stages = 0;
         }
-        IVX_HIP_CHECK(hipStreamSynchronize(s));
+        IVX_HIP_CHECK(ivx_stream_sync(s));
         if (mine) return mine;  // (ivx_last_error holds the stage's own message)
         ivx_set_error("ivx_slabs_step_collect: another rank could not enqueue its step");
         return IVX_ERR_STATE;

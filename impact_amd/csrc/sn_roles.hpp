@@ -460,6 +460,80 @@ __device__ __forceinline__ void role_sn_count(uint32_t bid, uint32_t nb, SnParam
     }
 }
 
+// After an edit: which chunks of the touched box grown by one chunk each way (the box the derive sweep has just gone over) have a mesh to
+// renew — handle_chunk_voxels_modified (object/intersection.rs:560-598): a touched chunk, and a neighbour when the touched voxel range of
+// the chunk comes within two voxels of the face they share —, and what their meshes need now (the count pass of the remesh for just these
+// chunks). One workgroup per chunk of the grown box; out[4 b ..]: bit 31 = invalidated | flags << 8 | kind, vertices, indices, 0. With this
+// in the edit's result block ivx_mesh_sync has its sizes without a count pass over the object and without a round trip of its own.
+struct BoxNeeds {
+    uint32_t t_lo[3], t_cc[3];  // the touched box (chunks) the ranges are indexed by
+    uint32_t b_lo[3], b_cc[3];  // the grown box
+};
+// (`list` != null: the chunks named there instead of a box, every one of them taken as invalidated — ivx_mesh_sync's own count when the
+// invalidated set is not the last edit's)
+__device__ __forceinline__ void role_box_mesh_needs(uint32_t b, const SnParams& p, const BoxNeeds& bx, const uint32_t* __restrict__ touched,
+                                                    const uint32_t* __restrict__ list, uint32_t* __restrict__ out, uint32_t* lds) {
+    uint32_t* s_neg = lds;           // [NROWS]
+    uint32_t* s_acc = lds + NROWS;   // [2]
+    const GridView& g = p.g;
+    const uint32_t tid = threadIdx.x;
+    uint32_t bk = b % bx.b_cc[2], bj = (b / bx.b_cc[2]) % bx.b_cc[1], bi = b / (bx.b_cc[2] * bx.b_cc[1]);
+    if (list) {
+        const uint32_t c = list[b];
+        bk = c % g.cz, bj = (c / g.cz) % g.cy, bi = c / (g.cz * g.cy);
+    }
+    const uint32_t idx[3] = {bx.b_lo[0] + bi, bx.b_lo[1] + bj, bx.b_lo[2] + bk};
+    auto word = [&](int di, int dj, int dk) -> uint32_t {  // the touched word of the chunk at idx + d; 0 outside the touched box
+        const uint32_t a[3] = {idx[0] + (uint32_t)di - bx.t_lo[0], idx[1] + (uint32_t)dj - bx.t_lo[1], idx[2] + (uint32_t)dk - bx.t_lo[2]};
+        if (a[0] >= bx.t_cc[0] || a[1] >= bx.t_cc[1] || a[2] >= bx.t_cc[2]) return 0u;  // (unsigned: also below the box)
+        return touched[(a[0] * bx.t_cc[1] + a[1]) * bx.t_cc[2] + a[2]];
+    };
+    bool inval = list != nullptr || word(0, 0, 0) != 0u;
+#pragma unroll
+    for (int d = 0; d < 3 && !list; ++d) {
+        const uint32_t up = word(d == 0, d == 1, d == 2), dn = word(-(d == 0), -(d == 1), -(d == 2));
+        if (up && ((up >> (4 * d)) & 15u) < 2u) inval = true;                     // the upper neighbour's touched range starts within two voxels of our face
+        if (dn && 16u - (((dn >> (12 + 4 * d)) & 15u) + 1u) < 2u) inval = true;  // the lower neighbour's ends within two voxels of it
+    }
+    const uint32_t chunk = (idx[0] * g.cy + idx[1]) * g.cz + idx[2];
+    if (!inval) {
+        if (tid == 0) out[4 * b] = 0u, out[4 * b + 1] = 0u, out[4 * b + 2] = 0u, out[4 * b + 3] = chunk;
+        return;
+    }
+    const ivx_chunk_info rec = g.info[chunk];
+    const bool exposed = chunk_exposed(rec);
+    uint32_t nv = 0, nq = 0;
+    if (exposed) {  // (workgroup-uniform)
+        const int ci = (int)idx[0], cj = (int)idx[1], ck = (int)idx[2];
+        if (tid < 2) s_acc[tid] = 0;
+        UpperLoads ul;
+        upper_issue(g, ci, cj, ck, ul);
+        load_tile(g, ci, cj, ck, nullptr, nullptr, s_neg, tid);
+        int upper[3];
+        upper_finish(g, ci, cj, ck, ul, upper);
+        __syncthreads();
+        for (int cr = tid; cr < NCROWS; cr += 256) {
+            uint32_t vb, qx, qy, qz;
+            cube_row_bits(s_neg, cr / 17, cr % 17, upper, vb, qx, qy, qz);
+            nv += __popc(vb);
+            nq += __popc(qx) + __popc(qy) + __popc(qz);
+        }
+        const uint32_t wv = ivx_wave_sum(nv), wq = ivx_wave_sum(nq);
+        if ((tid & 63u) == 0) {
+            atomicAdd(&s_acc[0], wv);
+            atomicAdd(&s_acc[1], wq);
+        }
+        __syncthreads();
+        nv = s_acc[0], nq = s_acc[1];
+    }
+    if (tid == 0) {
+        out[4 * b] = 0x80000000u | ((uint32_t)rec.flags << 8) | (uint32_t)rec.kind;
+        out[4 * b + 1] = nv;
+        out[4 * b + 2] = nq * 6u;
+        out[4 * b + 3] = chunk;
+    }
+}
+
 // The count pass with one WAVE per listed chunk (four chunks per workgroup, no workgroup barrier): the pass is a chain of two trips to memory
 // (list entry, then the sign rows) around a few hundred instructions, so what it needs is chunks in flight — 32 per CU this way against 8
 // with a workgroup per chunk. Lanes 0..26 fetch the first word of the 27 chunk records of the tile's neighbourhood and the rows take their

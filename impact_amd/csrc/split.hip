@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void k_clip(ClipParams cp, int8_t* __restrict_
 
 int ivx_launch_split_move(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], const uint32_t cc[3], uint32_t target) {
     ivx_planes_touched(parent);
-    ivx_planes_touched(child);
+    if (child) ivx_planes_touched(child);  // (no child: the region is discarded)
     SplitParams sp;
     sp.p = ivx_view(parent);
     for (int d = 0; d < 3; ++d) {
@@ -324,7 +324,7 @@ int ivx_launch_split_move(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3
         if (rc) return rc;
     }
     const uint32_t n = cc[0] * cc[1] * cc[2];
-    hipLaunchKernelGGL(k_split_move, dim3(n), dim3(256), 0, parent->ctx->stream, sp, parent->llabel, parent->rcompid, parent->sdf, parent->type,
+    IVX_KLAUNCH(k_split_move, dim3(n), dim3(256), 0, parent->ctx->stream, sp, parent->llabel, parent->rcompid, parent->sdf, parent->type,
                        parent->info, child ? child->sdf : nullptr, child ? child->type : nullptr, child ? child->info : nullptr);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
@@ -336,7 +336,7 @@ int ivx_launch_split_repack(ivx_grid* src, ivx_grid* dst, const uint32_t off[3])
         int rc = ivx_ensure_dense(src);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_split_repack, dim3(1), dim3(256), 0, src->ctx->stream, src->cc[0], src->cc[1], src->cc[2], off[0], off[1], off[2], src->sdf,
+    IVX_KLAUNCH(k_split_repack, dim3(1), dim3(256), 0, src->ctx->stream, src->cc[0], src->cc[1], src->cc[2], off[0], off[1], off[2], src->sdf,
                        src->type, dst->sdf, dst->type, dst->info);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
@@ -344,7 +344,7 @@ int ivx_launch_split_repack(ivx_grid* src, ivx_grid* dst, const uint32_t off[3])
 
 int ivx_launch_clip(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], const uint32_t cc[3], const float* planes4, uint32_t n_planes, int extract) {
     ivx_planes_touched(parent);
-    ivx_planes_touched(child);
+    if (child) ivx_planes_touched(child);  // (no child: the region is discarded)
     ClipParams cp;
     cp.p = ivx_view(parent);
     for (int d = 0; d < 3; ++d) {
@@ -359,7 +359,7 @@ int ivx_launch_clip(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], con
     }
     memset(cp.planes, 0, sizeof(cp.planes));
     memcpy(cp.planes, planes4, sizeof(float) * 4 * n_planes);
-    hipLaunchKernelGGL(k_clip, dim3(cc[0] * cc[1] * cc[2]), dim3(256), 0, parent->ctx->stream, cp, parent->sdf, parent->type, parent->info, child->sdf,
+    IVX_KLAUNCH(k_clip, dim3(cc[0] * cc[1] * cc[2]), dim3(256), 0, parent->ctx->stream, cp, parent->sdf, parent->type, parent->info, child->sdf,
                        child->type, child->info);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;

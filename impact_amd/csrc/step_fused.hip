@@ -17,6 +17,7 @@
 #include "ccl_roles.hpp"
 #include "sn_roles.hpp"
 #include "table_roles.hpp"
+#include "many.hpp"
 
 namespace {
 using namespace ivx_roles;
@@ -80,6 +81,14 @@ struct StepArgs {
     uint32_t record_max_pairs;
     unsigned long long* record_head;  // (optional) a second place for the record's first record_head_words words
     uint32_t record_head_words;
+    // edit path: what the meshes of the chunks an edit invalidates need, as a role of k_step_post1 (ivx_grid::post1_needs); a block of small
+    // results copied to host-mapped memory by k_step_gather ahead of the doorbell (ivx_grid::gather_copy_*)
+    sn::BoxNeeds needs_box;
+    const uint32_t* needs_touched;
+    uint32_t* needs_out;
+    const uint32_t* copy_src;
+    uint32_t* copy_dst;
+    uint32_t copy_words;
 };
 
 __device__ __forceinline__ sn::SnParams sn_params(const StepArgs& a) {
@@ -90,12 +99,12 @@ __device__ __forceinline__ sn::SnParams sn_params(const StepArgs& a) {
     return p;
 }
 
-// roles: 0 mesher count (list-driven), 1 region merge by columns, 2 exact numbering, 3 occupied slots, 4 moment partial sums
+// roles: 0 mesher count (list-driven), 1 region merge by columns, 2 exact numbering, 3 occupied slots, 4 moment partial sums,
+// 5 (edit path) mesh needs of the chunks the edit invalidates
 // (amdgpu_waves_per_eu(8): 64 VGPRs. The count role is a latency-bound gather with little state and wants all eight workgroups a CU can
 // hold; the exact numbering, which would take 127 registers, spills ~60 words instead — measured: count pass -3 us, edit leg unchanged.)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_step_post1(StepArgs a) {
+__device__ __forceinline__ void step_post1_body(const StepArgs& a, uint32_t b, uint32_t) {
     __shared__ CclShared sh;  // (the exact numbering's block; the count role borrows its first 5 KB)
-    uint32_t b = blockIdx.x;
     if (b < a.nb[0]) {
         sn::role_sn_count_waves(b, a.nb[0], sn_params(a), a.counts, a.sn_group_sums, a.work_count, a.active_list, sh.par, a.count_run);
         return;
@@ -116,13 +125,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         return;
     }
     b -= a.nb[3];
-    if (b < a.nb[4]) role_inertia_sum(b, a.nb[4], a.g, a.x_off, a.dens, a.chunk_moments, a.partials);
+    if (b < a.nb[4]) {
+        role_inertia_sum(b, a.nb[4], a.g, a.x_off, a.dens, a.chunk_moments, a.partials);
+        return;
+    }
+    b -= a.nb[4];
+    if (b < a.nb[5]) sn::role_box_mesh_needs(b, sn_params(a), a.needs_box, a.needs_touched, nullptr, a.needs_out, sh.par);
 }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_step_post1(StepArgs a) { step_post1_body(a, blockIdx.x, gridDim.x); }
+IVX_MANY_TWIN(k_step_post1_many, StepArgs, step_post1_body, __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))))
 
 // roles: 0 region merge of multi-region chunks, 1 mesher scan, 2 moments final (1 block), 3 occupied final (1 block),
 // 4 the slab protocol's face pairs (component pairs across the upper x face, from the neighbour's ids of the exchange before)
-__global__ __launch_bounds__(256) void k_step_post2(StepArgs a) {
-    uint32_t b = blockIdx.x;
+__device__ __forceinline__ void step_post2_body(const StepArgs& a, uint32_t b, uint32_t) {
     if (b < a.nb[0]) {
         role_ccl_merge_multi(b, a.nb[0], a.g, a.labels, a.rparent, a.rscalar, a.multi_list);
         return;
@@ -148,10 +163,11 @@ __global__ __launch_bounds__(256) void k_step_post2(StepArgs a) {
         role_face_pairs(b, a.g, a.fp_side, a.labels, a.rcompid, a.fp_nbr, a.fp_count, a.fp_pairs, a.fp_cap, a.fp_seen, s_seen);
     }
 }
+__global__ __launch_bounds__(256) void k_step_post2(StepArgs a) { step_post2_body(a, blockIdx.x, gridDim.x); }
+IVX_MANY_TWIN(k_step_post2_many, StepArgs, step_post2_body, __launch_bounds__(256))
 
 // roles: 0 flatten the region forest, 1 mesher emit, 2 the slab protocol's record
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_step_emit(StepArgs a) {
-    uint32_t b = blockIdx.x;
+__device__ __forceinline__ void step_emit_body(const StepArgs& a, uint32_t b, uint32_t) {
     if (b < a.nb[0]) {
         role_ccl_flatten(b, a.nb[0], a.g, a.rparent, a.multi_list /* root counts */, a.ccl_group_sums);
         return;
@@ -172,11 +188,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (threadIdx.x < 64u) role_result_gather(a.rscalar, a.offsets + 2 * (size_t)a.n_chunks, a.moments_out, a.work_count, a.eval_count, a.host_block, false, 0u);
     }
 }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_step_emit(StepArgs a) { step_emit_body(a, blockIdx.x, gridDim.x); }
+IVX_MANY_TWIN(k_step_emit_many, StepArgs, step_emit_body, __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))))
 
 // roles: 0 component ids, 1 the mesher's general pass over the chunks the main pass (k_step_emit) handed on — the launch after the main pass
 // anyway; as a launch of its own the general pass cost the step 4 us whether it had a chunk to do or not
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_step_assign(StepArgs a) {
-    const uint32_t b = blockIdx.x;
+__device__ __forceinline__ void step_assign_body(const StepArgs& a, uint32_t b, uint32_t) {
     if (b < a.nb[0]) {
         role_ccl_assign<true>(b, a.nb[0], a.g, a.rparent, a.multi_list /* root offsets inside a group */, a.ccl_group_sums, a.nb[0], a.rcompid, a.rscalar);
         return;
@@ -184,18 +201,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     sn::role_sn_emit_general<false>(b - a.nb[0], a.nb[1], sn_params(a), a.positions, a.normals, a.indices, a.imats, a.vmats, a.submeshes,
                                     a.offsets + 2 * (size_t)a.n_chunks + 2, a.emit_items, a.vcap, a.icap, a.scap, nullptr, a.hard_count, a.hard_list);
 }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_step_assign(StepArgs a) { step_assign_body(a, blockIdx.x, gridDim.x); }
+IVX_MANY_TWIN(k_step_assign_many, StepArgs, step_assign_body, __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))))
 
 // the results as a launch of their own (one block), ordered after everything enqueued so far
-__global__ __launch_bounds__(64) void k_step_gather(StepArgs a) {
+__device__ __forceinline__ void step_gather_body(const StepArgs& a, uint32_t, uint32_t) {
     role_result_gather(a.rscalar, a.offsets + 2 * (size_t)a.n_chunks, a.moments_out, a.work_count, a.eval_count, a.host_block, false, 0u);
+    for (uint32_t i = threadIdx.x; i < a.copy_words; i += 64u) a.copy_dst[i] = a.copy_src[i];  // (the edit path's small results, into pinned host memory)
     // Doorbell: the sequence number lands after every result word of this (single-wave) block. The stream is in order, so a host that
     // sees it also knows that everything enqueued before this launch is complete (ivx_voxel_step_collect polls it instead of paying
     // the runtime's blocking wait when the step is short).
     __threadfence_system();
     if (threadIdx.x == 0u) __hip_atomic_store(a.host_block + 63, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+__global__ __launch_bounds__(64) void k_step_gather(StepArgs a) { step_gather_body(a, 0u, 1u); }
+IVX_MANY_TWIN(k_step_gather_many, StepArgs, step_gather_body, __launch_bounds__(64))
+IVX_MANY_LAUNCHER(many_post1, k_step_post1_many, StepArgs, 256)
+IVX_MANY_LAUNCHER(many_post2, k_step_post2_many, StepArgs, 256)
+IVX_MANY_LAUNCHER(many_emit, k_step_emit_many, StepArgs, 256)
+IVX_MANY_LAUNCHER(many_assign, k_step_assign_many, StepArgs, 256)
+IVX_MANY_LAUNCHER(many_gather, k_step_gather_many, StepArgs, 64)
 
 }  // namespace
+
+static_assert(sizeof(StepArgs) % 8 == 0, "argument blocks travel as 8-byte words");
+static const int s_many_registered = (ivx_many_register(IVX_MK_POST1, many_post1, sizeof(StepArgs)), ivx_many_register(IVX_MK_POST2, many_post2, sizeof(StepArgs)),
+                                      ivx_many_register(IVX_MK_EMIT, many_emit, sizeof(StepArgs)), ivx_many_register(IVX_MK_ASSIGN, many_assign, sizeof(StepArgs)),
+                                      ivx_many_register(IVX_MK_GATHER, many_gather, sizeof(StepArgs)), 0);
 
 static StepArgs make_args(ivx_grid* g) {
     StepArgs a;
@@ -246,6 +278,8 @@ static StepArgs make_args(ivx_grid* g) {
 
 // `stages`: IVX_STAGE_* of this enqueue call (derive already launched when it is part of the call)
 int ivx_launch_step_post1(ivx_grid* g, uint32_t stages) {
+    if (stages & IVX_STAGE_REMESH)  // (the count role walks the active list)
+        if (int rc_l = ivx_ensure_active_list(g)) return rc_l;
     StepArgs a = make_args(g);
     const uint32_t groups = (g->n_chunks + 255u) / 256u;
     if (stages & IVX_STAGE_REMESH) {  // (a wave per run of listed chunks)
@@ -261,9 +295,19 @@ int ivx_launch_step_post1(ivx_grid* g, uint32_t stages) {
         a.nb[4] = groups < (uint32_t)g->partial_blocks ? groups : (uint32_t)g->partial_blocks;
         a.n_partials = a.nb[4];
     }
-    const uint32_t total = a.nb[0] + a.nb[1] + a.nb[2] + a.nb[3] + a.nb[4];
+    if (g->post1_needs_out) {  // (edit path: consumed by this launch)
+        for (int d = 0; d < 3; ++d) {
+            a.needs_box.t_lo[d] = g->post1_needs_box[d], a.needs_box.t_cc[d] = g->post1_needs_box[3 + d];
+            a.needs_box.b_lo[d] = g->post1_needs_box[6 + d], a.needs_box.b_cc[d] = g->post1_needs_box[9 + d];
+        }
+        a.needs_touched = g->post1_needs_touched;
+        a.needs_out = g->post1_needs_out;
+        a.nb[5] = a.needs_box.b_cc[0] * a.needs_box.b_cc[1] * a.needs_box.b_cc[2];
+        g->post1_needs_out = nullptr;
+    }
+    const uint32_t total = a.nb[0] + a.nb[1] + a.nb[2] + a.nb[3] + a.nb[4] + a.nb[5];
     if (total == 0) return IVX_OK;
-    hipLaunchKernelGGL(k_step_post1, dim3(total), dim3(256), 0, g->ctx->stream, a);
+    if (!ivx_many_try(IVX_MK_POST1, total, a)) IVX_KLAUNCH(k_step_post1, dim3(total), dim3(256), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -294,7 +338,7 @@ int ivx_launch_step_post2(ivx_grid* g, uint32_t stages, const uint16_t* face_pai
     if (stages & IVX_STAGE_OCCUPIED) a.nb[3] = 1;
     const uint32_t total = a.nb[0] + a.nb[1] + a.nb[2] + a.nb[3] + a.nb[4];
     if (total == 0) return IVX_OK;
-    hipLaunchKernelGGL(k_step_post2, dim3(total), dim3(256), 0, g->ctx->stream, a);
+    if (!ivx_many_try(IVX_MK_POST2, total, a)) IVX_KLAUNCH(k_step_post2, dim3(total), dim3(256), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -313,7 +357,7 @@ int ivx_launch_step_emit(ivx_grid* g, uint32_t stages, bool general_in_assign, v
     }
     const uint32_t total = a.nb[0] + a.nb[1] + a.nb[2];
     if (total == 0) return IVX_OK;
-    hipLaunchKernelGGL(k_step_emit, dim3(total), dim3(256), 0, g->ctx->stream, a);
+    if (!ivx_many_try(IVX_MK_EMIT, total, a)) IVX_KLAUNCH(k_step_emit, dim3(total), dim3(256), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
     // the chunks the main pass hands on: a role of k_step_assign when that launch follows (the caller says so), else a launch of its own
     if ((stages & IVX_STAGE_REMESH) && !general_in_assign) return ivx_launch_sn_emit_general(g);
@@ -327,7 +371,7 @@ int ivx_launch_step_assign(ivx_grid* g, bool with_mesher_general) {
     StepArgs a = make_args(g);
     a.nb[0] = (g->n_chunks + 255u) / 256u;
     a.nb[1] = with_mesher_general ? sn::ivx_emit_general_grid(g, g->n_chunks) : 0u;
-    hipLaunchKernelGGL(k_step_assign, dim3(a.nb[0] + a.nb[1]), dim3(256), 0, g->ctx->stream, a);
+    if (!ivx_many_try(IVX_MK_ASSIGN, a.nb[0] + a.nb[1], a)) IVX_KLAUNCH(k_step_assign, dim3(a.nb[0] + a.nb[1]), dim3(256), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -335,7 +379,9 @@ int ivx_launch_step_assign(ivx_grid* g, bool with_mesher_general) {
 int ivx_launch_step_gather(ivx_grid* g) {
     StepArgs a = make_args(g);
     a.seq = ++g->result_seq;
-    hipLaunchKernelGGL(k_step_gather, dim3(1), dim3(64), 0, g->ctx->stream, a);
+    a.copy_src = g->gather_copy_src, a.copy_dst = g->gather_copy_dst, a.copy_words = g->gather_copy_words;  // (consumed by this launch)
+    g->gather_copy_words = 0;
+    if (!ivx_many_try(IVX_MK_GATHER, 1u, a)) IVX_KLAUNCH(k_step_gather, dim3(1), dim3(64), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

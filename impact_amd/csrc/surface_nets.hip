@@ -20,6 +20,7 @@
 // Exact f32 arithmetic (no FMA, IEEE div/sqrt) keeps the diagonal choice and hence the index buffer
 // bit-identical to the reference.
 #include "sn_roles.hpp"
+#include "many.hpp"
 
 namespace {
 using namespace ivx_roles::sn;
@@ -56,6 +57,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     role_sn_emit_general<SLOTS>(blockIdx.x, gridDim.x, p, positions, normals, indices, imats, vmats, submeshes, emit_count, emit_items, vcap, icap, scap, slots,
                                 hard_count, hard_list);
 }
+
+__global__ __launch_bounds__(256) void k_box_mesh_needs(SnParams p, BoxNeeds bx, const uint32_t* __restrict__ touched, const uint32_t* __restrict__ list,
+                                                        uint32_t* __restrict__ out) {
+    __shared__ uint32_t s_lds[NROWS + 2];
+    role_box_mesh_needs(blockIdx.x, p, bx, touched, list, out, s_lds);
+}
+
+// the incremental remesh's two launches (ivx_launch_sn_emit_list) with their arguments as one block each: the twins of the many-object path
+struct SnEmitArgs {
+    SnParams p;
+    float* positions;
+    float* normals;
+    uint32_t* indices;
+    unsigned long long* imats;
+    uint4* vmats;
+    ivx_submesh* submeshes;
+    const uint32_t* emit_count;
+    const uint4* emit_items;
+    const uint32_t* slots;
+    uint32_t* hard_count;
+    uint32_t* hard_list;
+    uint32_t* cursor;
+    uint32_t vcap, icap, scap, pad_;
+};
+__device__ __forceinline__ void sn_emit_slots_body(const SnEmitArgs& a, uint32_t bid, uint32_t nb) {
+    role_sn_emit<true>(bid, nb, a.p, a.positions, a.normals, a.indices, a.imats, a.submeshes, a.emit_count, a.emit_items, a.vcap, a.icap, a.scap, a.slots, a.hard_count,
+                       a.hard_list, a.cursor);
+}
+__device__ __forceinline__ void sn_emit_general_slots_body(const SnEmitArgs& a, uint32_t bid, uint32_t nb) {
+    role_sn_emit_general<true>(bid, nb, a.p, a.positions, a.normals, a.indices, a.imats, a.vmats, a.submeshes, a.emit_count, a.emit_items, a.vcap, a.icap, a.scap, a.slots,
+                               a.hard_count, a.hard_list);
+}
+IVX_MANY_TWIN(k_sn_emit_slots_many, SnEmitArgs, sn_emit_slots_body, __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))))
+IVX_MANY_TWIN(k_sn_emit_general_slots_many, SnEmitArgs, sn_emit_general_slots_body, __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))))
+IVX_MANY_LAUNCHER(many_sn_emit_slots, k_sn_emit_slots_many, SnEmitArgs, 256)
+IVX_MANY_LAUNCHER(many_sn_emit_general_slots, k_sn_emit_general_slots_many, SnEmitArgs, 256)
+static_assert(sizeof(SnEmitArgs) % 8 == 0, "argument blocks travel as 8-byte words");
+static const int s_many_registered_sn = (ivx_many_register(IVX_MK_SN_EMIT_SLOTS, many_sn_emit_slots, sizeof(SnEmitArgs)),
+                                         ivx_many_register(IVX_MK_SN_EMIT_GENERAL_SLOTS, many_sn_emit_general_slots, sizeof(SnEmitArgs)), 0);
 
 // div_ranged against the `/` operator over the whole operand set the mesher hands it: t = d1 / (d1 - d2) for every pair of decoded
 // distances of opposite sign (surface_nets.rs:396-404; decoded 0 is +0.0 and counts as positive), and 1 / n for the edge counts.
@@ -116,13 +156,13 @@ int ivx_selftest_mesher_division(ivx_ctx* ctx, uint32_t* mismatches) {
     IVX_REQUIRE(ctx && mismatches, IVX_ERR_INVALID, "ivx_selftest_mesher_division: null argument");
     uint32_t* d = nullptr;
     IVX_HIP_CHECK(hipMalloc(&d, sizeof(uint32_t)));
-    IVX_HIP_CHECK(hipMemsetAsync(d, 0, sizeof(uint32_t), ctx->stream));
-    hipLaunchKernelGGL(k_selftest_division, dim3(257), dim3(256), 0, ctx->stream, d);
+    IVX_HIP_CHECK(ivx_memset_async(d, 0, sizeof(uint32_t), ctx->stream));
+    IVX_KLAUNCH(k_selftest_division, dim3(257), dim3(256), 0, ctx->stream, d);
     IVX_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_selftest_normalize, dim3(65536), dim3(256), 0, ctx->stream, d);  // 2^28 gradients
+    IVX_KLAUNCH(k_selftest_normalize, dim3(65536), dim3(256), 0, ctx->stream, d);  // 2^28 gradients
     IVX_HIP_CHECK(hipGetLastError());
-    IVX_HIP_CHECK(hipMemcpyAsync(mismatches, d, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    IVX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    IVX_HIP_CHECK(ivx_memcpy_async(mismatches, d, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    IVX_HIP_CHECK(ivx_stream_sync(ctx->stream));
     IVX_HIP_CHECK(hipFree(d));
     return IVX_OK;
 }
@@ -136,21 +176,42 @@ static SnParams make_params(ivx_grid* g) {
 }
 
 int ivx_launch_sn_count(ivx_grid* g) {
+    if (int rc_l = ivx_ensure_active_list(g)) return rc_l;
     const uint32_t groups = (g->n_chunks + 255u) / 256u;
     uint32_t* gs = g->group_sums + groups;  // the first `groups` words belong to the region resolve
-    IVX_HIP_CHECK(hipMemsetAsync(gs, 0, sizeof(uint32_t) * (3 * groups + IVX_SN_TAIL_WORDS), g->ctx->stream));  // (stand-alone path; the fused step path presets in its first kernel)
+    IVX_HIP_CHECK(ivx_memset_async(gs, 0, sizeof(uint32_t) * (3 * groups + IVX_SN_TAIL_WORDS), g->ctx->stream));  // (stand-alone path; the fused step path presets in its first kernel)
     g->scratch_dirty |= IVX_SCRATCH_SN;
     g->preset_fresh &= ~IVX_SCRATCH_SN;
     const uint32_t run = ivx_count_run(g);
-    hipLaunchKernelGGL(k_sn_count, dim3((ivx_list_grid(g) + 4u * run - 1u) / (4u * run)), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts, gs, ivx_wc(g),
+    IVX_KLAUNCH(k_sn_count, dim3((ivx_list_grid(g) + 4u * run - 1u) / (4u * run)), dim3(256), 0, g->ctx->stream, make_params(g), g->chunk_counts, gs, ivx_wc(g),
                        g->active_list, run);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+
+int ivx_launch_box_mesh_needs(ivx_grid* g, const uint32_t t_lo[3], const uint32_t t_cc[3], const uint32_t b_lo[3], const uint32_t b_cc[3], const uint32_t* d_touched,
+                              uint32_t* d_out) {
+    BoxNeeds bx;
+    for (int d = 0; d < 3; ++d) bx.t_lo[d] = t_lo[d], bx.t_cc[d] = t_cc[d], bx.b_lo[d] = b_lo[d], bx.b_cc[d] = b_cc[d];
+    const uint32_t n = b_cc[0] * b_cc[1] * b_cc[2];
+    if (n == 0) return IVX_OK;
+    IVX_KLAUNCH(k_box_mesh_needs, dim3(n), dim3(256), 0, g->ctx->stream, make_params(g), bx, d_touched, nullptr, d_out);
+    IVX_HIP_CHECK(hipGetLastError());
+    return IVX_OK;
+}
+int ivx_launch_list_mesh_needs(ivx_grid* g, uint32_t n, const uint32_t* d_list, uint32_t* d_out) {
+    if (n == 0) return IVX_OK;
+    BoxNeeds bx;
+    memset(&bx, 0, sizeof(bx));
+    bx.b_cc[0] = bx.b_cc[1] = bx.b_cc[2] = 1u;  // (unused divisors)
+    IVX_KLAUNCH(k_box_mesh_needs, dim3(n), dim3(256), 0, g->ctx->stream, make_params(g), bx, nullptr, d_list, d_out);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 
 int ivx_launch_sn_scan(ivx_grid* g) {
     // ranks are stored after the offsets/totals block
-    hipLaunchKernelGGL(k_sn_scan, dim3((g->n_chunks + 255u) / 256u), dim3(256), 0, g->ctx->stream, g->n_chunks, g->chunk_counts,
+    IVX_KLAUNCH(k_sn_scan, dim3((g->n_chunks + 255u) / 256u), dim3(256), 0, g->ctx->stream, g->n_chunks, g->chunk_counts,
                        g->group_sums + (g->n_chunks + 255u) / 256u,
                        g->chunk_offsets, g->chunk_offsets + 2 * (size_t)g->n_chunks + 4, reinterpret_cast<uint4*>(g->sn_list));
     IVX_HIP_CHECK(hipGetLastError());
@@ -163,9 +224,9 @@ uint32_t* ivx_sn_hard_count(ivx_grid* g) { return g->group_sums + 4 * (size_t)((
 
 int ivx_launch_sn_emit(ivx_grid* g) {
     // (stand-alone path, also the re-emit after the buffers grew: the two words may hold an earlier emit's counts; the fused step presets them)
-    IVX_HIP_CHECK(hipMemsetAsync(ivx_sn_hard_count(g), 0, IVX_SN_TAIL_WORDS * sizeof(uint32_t), g->ctx->stream));
+    IVX_HIP_CHECK(ivx_memset_async(ivx_sn_hard_count(g), 0, IVX_SN_TAIL_WORDS * sizeof(uint32_t), g->ctx->stream));
     const uint32_t blocks = ivx_emit_grid(g, g->n_chunks);
-    hipLaunchKernelGGL(k_sn_emit<false>, dim3(blocks), dim3(256), 0, g->ctx->stream, make_params(g), g->positions, g->normals, g->indices,
+    IVX_KLAUNCH(k_sn_emit<false>, dim3(blocks), dim3(256), 0, g->ctx->stream, make_params(g), g->positions, g->normals, g->indices,
                        reinterpret_cast<unsigned long long*>(g->index_materials), g->submeshes,
                        g->chunk_offsets + 2 * (size_t)g->n_chunks + 2, reinterpret_cast<const uint4*>(g->sn_list), (uint32_t)g->vcap, (uint32_t)g->icap,
                        (uint32_t)g->scap, nullptr, ivx_sn_hard_count(g), g->sn_hard, ivx_sn_hard_count(g) + 32);
@@ -175,7 +236,7 @@ int ivx_launch_sn_emit(ivx_grid* g) {
 
 // after the main pass (full remesh): the chunks it handed on
 int ivx_launch_sn_emit_general(ivx_grid* g) {
-    hipLaunchKernelGGL(k_sn_emit_general<false>, dim3(ivx_emit_general_grid(g, g->n_chunks)), dim3(256), 0, g->ctx->stream, make_params(g), g->positions, g->normals,
+    IVX_KLAUNCH(k_sn_emit_general<false>, dim3(ivx_emit_general_grid(g, g->n_chunks)), dim3(256), 0, g->ctx->stream, make_params(g), g->positions, g->normals,
                        g->indices, reinterpret_cast<unsigned long long*>(g->index_materials), reinterpret_cast<uint4*>(g->vertex_materials), g->submeshes,
                        g->chunk_offsets + 2 * (size_t)g->n_chunks + 2, reinterpret_cast<const uint4*>(g->sn_list), (uint32_t)g->vcap, (uint32_t)g->icap,
                        (uint32_t)g->scap, nullptr, ivx_sn_hard_count(g), g->sn_hard);
@@ -187,16 +248,24 @@ int ivx_launch_sn_emit_general(ivx_grid* g) {
 // from the host-side submesh manager; d_count holds their number
 int ivx_launch_sn_emit_list(ivx_grid* g, uint32_t n_records, const uint32_t* d_count, const void* d_records, const uint32_t* d_slots) {
     if (n_records == 0) return IVX_OK;
-    IVX_HIP_CHECK(hipMemsetAsync(ivx_sn_hard_count(g), 0, IVX_SN_TAIL_WORDS * sizeof(uint32_t), g->ctx->stream));
-    hipLaunchKernelGGL(k_sn_emit<true>, dim3(ivx_emit_grid(g, n_records)), dim3(256), 0, g->ctx->stream, make_params(g), g->positions, g->normals,
-                       g->indices, reinterpret_cast<unsigned long long*>(g->index_materials), g->submeshes,
-                       d_count, reinterpret_cast<const uint4*>(d_records), (uint32_t)g->vcap, (uint32_t)g->icap, (uint32_t)g->scap, d_slots, ivx_sn_hard_count(g),
-                       g->sn_hard, ivx_sn_hard_count(g) + 1);
+    if (!ivx_many_zero(ivx_sn_hard_count(g), IVX_SN_TAIL_WORDS * sizeof(uint32_t))) {
+        (void)ivx_many_break();
+        IVX_HIP_CHECK(ivx_memset_async(ivx_sn_hard_count(g), 0, IVX_SN_TAIL_WORDS * sizeof(uint32_t), g->ctx->stream));
+    }
+    SnEmitArgs a;
+    memset(&a, 0, sizeof(a));
+    a.p = make_params(g), a.positions = g->positions, a.normals = g->normals, a.indices = g->indices;
+    a.imats = reinterpret_cast<unsigned long long*>(g->index_materials), a.vmats = reinterpret_cast<uint4*>(g->vertex_materials), a.submeshes = g->submeshes;
+    a.emit_count = d_count, a.emit_items = reinterpret_cast<const uint4*>(d_records), a.slots = d_slots, a.hard_count = ivx_sn_hard_count(g), a.hard_list = g->sn_hard;
+    a.cursor = ivx_sn_hard_count(g) + 1, a.vcap = (uint32_t)g->vcap, a.icap = (uint32_t)g->icap, a.scap = (uint32_t)g->scap;
+    const uint32_t b_main = ivx_emit_grid(g, n_records), b_gen = ivx_emit_general_grid(g, n_records);
+    if (!ivx_many_try(IVX_MK_SN_EMIT_SLOTS, b_main, a))
+        IVX_KLAUNCH(k_sn_emit<true>, dim3(b_main), dim3(256), 0, g->ctx->stream, a.p, a.positions, a.normals, a.indices, a.imats, a.submeshes, a.emit_count, a.emit_items,
+                    a.vcap, a.icap, a.scap, a.slots, a.hard_count, a.hard_list, a.cursor);
     IVX_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_sn_emit_general<true>, dim3(ivx_emit_general_grid(g, n_records)), dim3(256), 0, g->ctx->stream, make_params(g), g->positions, g->normals,
-                       g->indices, reinterpret_cast<unsigned long long*>(g->index_materials), reinterpret_cast<uint4*>(g->vertex_materials), g->submeshes,
-                       d_count, reinterpret_cast<const uint4*>(d_records), (uint32_t)g->vcap, (uint32_t)g->icap, (uint32_t)g->scap, d_slots, ivx_sn_hard_count(g),
-                       g->sn_hard);
+    if (!ivx_many_try(IVX_MK_SN_EMIT_GENERAL_SLOTS, b_gen, a))
+        IVX_KLAUNCH(k_sn_emit_general<true>, dim3(b_gen), dim3(256), 0, g->ctx->stream, a.p, a.positions, a.normals, a.indices, a.imats, a.vmats, a.submeshes, a.emit_count,
+                    a.emit_items, a.vcap, a.icap, a.scap, a.slots, a.hard_count, a.hard_list);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

@@ -1,0 +1,71 @@
+"""Many voxel objects per call (`ivx_*_many`, csrc/many.hpp): the reference's per-frame unit is the manager — every object's mesh is synced each
+frame (impact_voxel/src/lib.rs:729-733), the fragments of an impact come into being together (interaction/fracturing.rs:1047-1189) — and one
+small object's step, edit or sync is all launch latency. These calls run the same per-object work for N objects of one context in the launches
+of one. Nothing here computes."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import check, ptr
+
+
+def _handles(objects):
+    arr = (C.c_void_p * len(objects))()
+    for i, o in enumerate(objects):
+        arr[i] = o.h.value if isinstance(o.h, C.c_void_p) else o.h
+    return arr
+
+
+def voxel_step_many(objects, stages: int):
+    """`ivx_voxel_step_many`: `VoxelObject.step(stages)` of every object -> array of step results"""
+    out = np.zeros(len(objects), dtype=capi.STEP_RESULT_DTYPE)
+    check(capi.lib().ivx_voxel_step_many(_handles(objects), len(objects), stages, ptr(out)))
+    for o, r in zip(objects, out):
+        if stages & capi.STAGE_REGIONS:
+            o._region_count = int(r["region_count"])
+    return out
+
+
+def absorb_sphere_many(objects, centers, influence_radii, sphere_radii, densities=None, want_invalidated: bool = True):
+    """`ivx_absorb_sphere_many`: one absorbing sphere per object (object-normalized coordinates) -> list of result dicts as `VoxelObject.absorb_sphere`
+    returns them (without the per-type counts; `invalidated` is a uint8 view — one byte per chunk, 1 = invalidated — into one buffer for all objects)"""
+    n = len(objects)
+    d = np.ones(256, dtype=np.float32) if densities is None else np.ascontiguousarray(densities, dtype=np.float32)
+    c = np.ascontiguousarray(np.asarray(centers, dtype=np.float32).reshape(n, 3))
+    ri = np.ascontiguousarray(np.asarray(influence_radii, dtype=np.float32).reshape(n))
+    rs = np.ascontiguousarray(np.asarray(sphere_radii, dtype=np.float32).reshape(n))
+    out = np.zeros(n, dtype=capi.ABSORB_RESULT_DTYPE)
+    inval = iv = None
+    if want_invalidated:  # one buffer, one pointer per object into it
+        sizes = np.fromiter((o.n_chunks for o in objects), dtype=np.int64, count=n)
+        offs = np.concatenate(([0], np.cumsum(sizes)))
+        buf = np.zeros(int(offs[-1]), dtype=np.uint8)
+        iv = (buf.ctypes.data + offs[:-1]).astype(np.uint64)
+        inval = [buf[offs[i]:offs[i + 1]] for i in range(n)]
+    check(capi.lib().ivx_absorb_sphere_many(_handles(objects), n, ptr(c), ptr(ri), ptr(rs), ptr(d), ptr(out), ptr(iv) if iv is not None else None))
+    res = []
+    for i, o in enumerate(objects):
+        o._region_count = None
+        r = out[i]
+        res.append({"removed_moments": r["removed_moments"], "emptied_voxels": int(r["emptied_voxels"]), "invalidated": None if inval is None else inval[i],
+                    "touched_chunks": int(r["touched_chunks"]), "removed_chunks": int(r["removed_chunks"])})
+    return res
+
+
+def mesh_sync_many(meshes, invalidated):
+    """`ivx_mesh_sync_many`: `VoxelObjectMesh.sync_with_voxel_object` of every mesh with its own invalidated set (one byte or bool per chunk)"""
+    n = len(meshes)
+    objs = [m.object for m in meshes]
+    inv = [a if (isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]) else np.ascontiguousarray(np.asarray(a).reshape(-1), dtype=np.uint8)
+           for a in invalidated]
+    iv = np.fromiter((a.ctypes.data for a in inv), dtype=np.uint64, count=n)
+    for a, o in zip(inv, objs):
+        assert a.size == o.n_chunks
+    out = np.zeros(n, dtype=capi.MESH_COUNTS_DTYPE)
+    check(capi.lib().ivx_mesh_sync_many(_handles(objs), n, ptr(iv), ptr(out)))
+    for m, c in zip(meshes, out):
+        m.counts = c
+    return meshes

@@ -396,6 +396,23 @@ class VoxelObject:
                 "invalidated": None if inval is None else inval.astype(bool), "touched_chunks": int(out[0]["touched_chunks"]),
                 "removed_chunks": int(out[0]["removed_chunks"])}
 
+    def absorb_sphere_enqueue(self, center, influence_radius: float, sphere_radius: float, densities=None):
+        """`ivx_absorb_sphere_enqueue`: the edit and everything that follows it on the stream, without waiting; `absorb_collect` delivers"""
+        d = np.ones(256, dtype=np.float32) if densities is None else np.ascontiguousarray(densities, dtype=np.float32)
+        c = np.ascontiguousarray(center, dtype=np.float32)
+        check(capi.lib().ivx_absorb_sphere_enqueue(self.h, ptr(c), influence_radius, sphere_radius, ptr(d)))
+
+    def absorb_collect(self, want_invalidated: bool = True):
+        """`ivx_absorb_collect`: the one wait of an enqueued edit; the result dict of `absorb_sphere`"""
+        out = np.zeros(1, dtype=capi.ABSORB_RESULT_DTYPE)
+        by_type = np.zeros(256, dtype=np.uint32)
+        inval = np.zeros(self.n_chunks, dtype=np.uint8) if want_invalidated else None
+        check(capi.lib().ivx_absorb_collect(self.h, ptr(out), ptr(by_type), ptr(inval) if inval is not None else None))
+        self._region_count = None
+        return {"removed_moments": out[0]["removed_moments"].copy(), "emptied_by_type": by_type, "emptied_voxels": int(out[0]["emptied_voxels"]),
+                "invalidated": None if inval is None else inval.astype(bool), "touched_chunks": int(out[0]["touched_chunks"]),
+                "removed_chunks": int(out[0]["removed_chunks"])}
+
     def absorb_capsule(self, segment_start, segment_vector, influence_radius: float, capsule_radius: float, densities=None,
                        want_invalidated: bool = True):
         """`apply_capsule_absorption` (interaction/absorption.rs:846-889) with the capsule (segment start + vector) in the object's
@@ -548,6 +565,19 @@ class VoxelObjectMesh:
         assert inv.size == self.object.n_chunks
         c = np.zeros((), dtype=capi.MESH_COUNTS_DTYPE)
         check(capi.lib().ivx_mesh_sync(self.object.h, ptr(inv), ptr(c.reshape(1))))
+        self.counts = c
+        return self
+
+    def sync_enqueue(self, invalidated):
+        """`ivx_mesh_sync_enqueue`: place and launch the re-mesh of the invalidated chunks without waiting"""
+        inv = np.ascontiguousarray(np.asarray(invalidated).reshape(-1), dtype=np.uint8)
+        assert inv.size == self.object.n_chunks
+        check(capi.lib().ivx_mesh_sync_enqueue(self.object.h, ptr(inv)))
+
+    def sync_collect(self):
+        """`ivx_mesh_sync_collect`: the wait of an enqueued sync"""
+        c = np.zeros((), dtype=capi.MESH_COUNTS_DTYPE)
+        check(capi.lib().ivx_mesh_sync_collect(self.object.h, ptr(c.reshape(1))))
         self.counts = c
         return self
 

@@ -163,6 +163,10 @@ int ivx_mesh_download(ivx_grid*, float* positions, float* normals, uint32_t* ind
  * Buffers only grow: counts.n_vertices / n_indices are the buffer lengths including freed ranges, the submesh table says what is live. The chunks
  * are visited in chunk-linear order (the reference walks a hash set, an unpinned order that decides which freed range a chunk lands in). */
 int ivx_mesh_sync(ivx_grid*, const uint8_t* invalidated_chunks, ivx_mesh_counts* out);
+/* ... in two halves: `_enqueue` places the invalidated chunks' meshes (their sizes come with the last edit's results when the set is that
+ * edit's: no count pass, no read-back) and launches their emit pass; `_collect` waits and returns the buffer lengths. */
+int ivx_mesh_sync_enqueue(ivx_grid*, const uint8_t* invalidated_chunks);
+int ivx_mesh_sync_collect(ivx_grid*, ivx_mesh_counts* out);
 /* VoxelMeshModifications (mesh.rs:113-123, 826-841), the hand-off to the renderer's buffers: the vertex / index ranges ivx_mesh_sync wrote since the
  * last report, in the order written, and whether any chunk lost its submesh; ivx_mesh_report_synchronized = report_gpu_resources_synchronized. */
 typedef struct {
@@ -288,6 +292,14 @@ int ivx_absorb_sphere(ivx_grid*, const float center[3], float influence_radius, 
  * when its centre is within the radius of the whole segment, boundary included (capsule.rs:225-250). */
 int ivx_absorb_capsule(ivx_grid*, const float segment_start[3], const float segment_vector[3], float influence_radius, float capsule_radius,
                        const float densities[256], ivx_absorb_result* out, uint32_t* emptied_by_type, uint8_t* invalidated_chunks);
+/* The same edits in two halves, for a frame that has other work to put on the stream (or other objects to edit) before it waits:
+ * `_enqueue` launches the edit, the sweep over the touched chunks and their neighbours, the region resolve and the count of what the
+ * invalidated meshes need, and returns; ivx_absorb_collect waits ONCE and delivers what ivx_absorb_sphere / _capsule return. One edit per
+ * object in flight; every other call on the object waits for the collect. */
+int ivx_absorb_sphere_enqueue(ivx_grid*, const float center[3], float influence_radius, float sphere_radius, const float densities[256]);
+int ivx_absorb_capsule_enqueue(ivx_grid*, const float segment_start[3], const float segment_vector[3], float influence_radius, float capsule_radius,
+                               const float densities[256]);
+int ivx_absorb_collect(ivx_grid*, ivx_absorb_result* out, uint32_t* emptied_by_type, uint8_t* invalidated_chunks);
 /* apply_mutual_absorption (interaction/absorption.rs:891-1079): two objects eat into each other where they overlap. Every voxel of A's overlap
  * ranges (determine_voxel_ranges_encompassing_intersection, padded by one voxel of B) that is not maximally outside gets
  * sdf_subtraction(sd, max(sd, B's SDF at its centre), smoothness) with B's SDF sampled trilinearly (sample_voxel_object_sdf, object/sdf.rs:636-675);
@@ -296,6 +308,25 @@ int ivx_absorb_capsule(ivx_grid*, const float segment_start[3], const float segm
 int ivx_absorb_mutual(ivx_grid* a, const float rotation_a[4], const float translation_a[3], const float densities_a[256], ivx_grid* b,
                       const float rotation_b[4], const float translation_b[3], const float densities_b[256], float smoothness, ivx_absorb_result* out_a,
                       ivx_absorb_result* out_b, uint8_t* invalidated_chunks_a, uint8_t* invalidated_chunks_b);
+
+/* ---- many objects per call ----------------------------------------------------------------------------------------------------------
+ * The reference's per-frame unit is the manager, not the object: every voxel object's mesh is synced each frame (impact_voxel/src/lib.rs:729-733,
+ * engine/src/tasks.rs:376-399), the fragments of an impact come into being together (interaction/fracturing.rs:1047-1189), its stress scene holds
+ * a thousand small objects. One object's step, edit or sync is about ten launches of a few microseconds — for a small object all of its cost.
+ * These calls run the same per-object work for N objects of one context in the launches of ONE: each launch of the chain is issued once for
+ * all objects (csrc/many.hpp), their results arrive together, the host waits once. Same results per object as the single-object calls.
+ *   ivx_voxel_step_many      ivx_voxel_step for every object (stages without IVX_STAGE_SAMPLE merge; a sample stage runs object by object)
+ *   ivx_absorb_sphere_many   ivx_absorb_sphere, one sphere per object (centers3: 3 floats per object); `invalidated_chunks`: NULL, or one
+ *                            array per object (entries may be NULL)
+ *   ivx_mesh_sync_many       ivx_mesh_sync for every object
+ * ivx_many_begin / ivx_many_flush expose the mechanism itself: between them the `_enqueue` calls of objects of the context are recorded
+ * (call ivx_many_object-free: chains are merged front by front in the order the calls were made) and the flush issues them merged. */
+int ivx_many_begin(ivx_ctx*);
+int ivx_many_flush(ivx_ctx*);
+int ivx_voxel_step_many(ivx_grid* const* grids, size_t n, uint32_t stages, ivx_step_result* out);
+int ivx_absorb_sphere_many(ivx_grid* const* grids, size_t n, const float* centers3, const float* influence_radii, const float* sphere_radii,
+                           const float densities[256], ivx_absorb_result* out, uint8_t* const* invalidated_chunks);
+int ivx_mesh_sync_many(ivx_grid* const* grids, size_t n, const uint8_t* const* invalidated_chunks, ivx_mesh_counts* out);
 
 /* make the compiled SDF program / the voxel-type densities resident on the device */
 int ivx_grid_set_sdf_program(ivx_grid*, const ivx_sdf_processed_node* nodes, size_t n_nodes, uint32_t stack_size,

@@ -1,0 +1,121 @@
+"""Many objects per call (`ivx_voxel_step_many`, `ivx_absorb_sphere_many`, `ivx_mesh_sync_many`; csrc/many.hpp): the fragments of one body —
+Voronoi cells of a lattice of fracture points, copied out with `ivx_copy_polyhedra` — stepped, edited and re-meshed TOGETHER, every object
+against the oracle's result for that object on its own (the reference loops over its objects: impact_voxel/src/lib.rs:729-733) and against
+the single-object calls."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import parity_util as pu
+from impact_amd import capi, many, scenes
+from impact_amd import fracturing as fr
+from impact_amd.voxel import VoxelObjectMesh
+from test_gpu_mesh_sync import assert_synced_meshes_equal
+from test_gpu_split import assert_objects_equal, build
+
+pytestmark = pytest.mark.gpu
+
+
+def lattice_fragments(ctx, graph, n_per_axis, jitter_seed=7):
+    """the body's grid box cut into the Voronoi cells of a jittered lattice: (oracle object, gpu object) per non-empty cell"""
+    o, g = build(ctx, graph)
+    cc = np.asarray(o.chunk_counts, dtype=np.float32) * 16.0
+    rng = np.random.default_rng(jitter_seed)
+    ax = [(np.arange(n_per_axis) + 0.5) * (c / n_per_axis) for c in cc]
+    pts = np.stack(np.meshgrid(*ax, indexing="ij"), axis=-1).reshape(-1, 3) + rng.uniform(-3.0, 3.0, (n_per_axis ** 3, 3))
+    sets, tets = fr.fragment_plane_sets(pts.astype(np.float32), np.array([0, 0, 0, cc[0], cc[1], cc[2]], dtype=np.float32))
+    res = g.copy_polyhedra([s[2] for s in sets], [s[1] for s in sets])
+    pairs = []
+    for (v, planes, bb), (rc, child, off) in zip(sets, res):
+        rco, co, org = o.clip_polyhedron(planes, bb, copy=True)
+        assert rc == rco
+        if rc == 1:
+            assert tuple(off) == tuple(org)
+            pairs.append((co, child))
+    tets.close()
+    g.close()
+    return pairs
+
+
+def test_fragments_stepped_edited_and_synced_together(ctx):
+    pairs = lattice_fragments(ctx, scenes.sphere_scene(44.0), 3)
+    assert len(pairs) >= 20
+    os_, gs = [p[0] for p in pairs], [p[1] for p in pairs]
+    dens = np.linspace(0.5, 2.0, 256).astype(np.float32)
+    for g in gs:
+        g.set_densities(dens)
+    # ---- one step for all: derived state, regions, occupied ranges, mesh, moments
+    res = many.voxel_step_many(gs, capi.STAGE_ALL & ~capi.STAGE_SAMPLE)
+    oms, gms = [], []
+    for k, (o, g) in enumerate(pairs):
+        assert_objects_equal(o, g, f"fragment {k} after the step of all: ")
+        om = o.mesh()
+        assert (int(res[k]["mesh"]["n_vertices"]), int(res[k]["mesh"]["n_indices"])) == (om.positions.shape[0], om.indices.shape[0])
+        _, o64 = o.inertia(dens)
+        g64 = np.asarray(res[k]["moments"]["m64"], dtype=np.float64)
+        assert np.all(np.abs(g64 - o64) <= 1e-5 * np.maximum(np.abs(o64), 1e-300) + 1e-12), k
+        n_regions, _ = o.region_labels()
+        assert int(res[k]["region_count"]) == n_regions
+        gm = VoxelObjectMesh(g)
+        gm.counts = res[k]["mesh"].copy()
+        pos, nrm, idx, im, sub = gm.download()
+        np.testing.assert_array_equal(idx, om.indices)
+        np.testing.assert_array_equal(pos.view(np.uint32), om.positions.view(np.uint32))
+        np.testing.assert_array_equal(nrm.view(np.uint32), om.normals.view(np.uint32))
+        np.testing.assert_array_equal(im, om.index_materials)
+        oms.append(ol.OracleMeshHandle(o))
+        gms.append(gm)
+    # ---- frames: one absorbing sphere per object, the incremental remesh of what it invalidated, the moments — all objects per call
+    for o in os_:
+        o.update_occupied_voxel_ranges()
+    for frame in range(3):
+        centers, radii = [], []
+        for o in os_:
+            occ = np.array(o.info()["occupied_voxel_ranges"], dtype=np.float32)
+            c = 0.5 * (occ[:, 0] + occ[:, 1])
+            c[frame % 3] = occ[frame % 3, 1] - 1.0  # at the object's upper face along the frame's axis
+            centers.append(c)
+            radii.append(3.0 + frame)
+        ros = [o.absorb_sphere(c, r + 2.0, r, dens) for o, c, r in zip(os_, centers, radii)]
+        rgs = many.absorb_sphere_many(gs, centers, [r + 2.0 for r in radii], radii, dens)
+        for k, (ro, rg) in enumerate(zip(ros, rgs)):
+            np.testing.assert_array_equal(rg["invalidated"], ro["invalidated"], err_msg=f"fragment {k}, frame {frame}")
+            assert (rg["touched_chunks"], rg["removed_chunks"], rg["emptied_voxels"]) == (ro["touched_chunks"], ro["removed_chunks"], int(ro["emptied_by_type"].sum()))
+            scale = np.maximum(np.abs(ro["removed64"]), 1e-300)
+            assert np.all(np.abs(rg["removed_moments"] - ro["removed64"]) <= 1e-5 * scale + 1e-9), (k, frame, rg["emptied_voxels"], rg["removed_moments"][0], ro["removed64"][0])
+            pu.assert_edited_objects_equal(os_[k], gs[k], f"fragment {k}, frame {frame}: ", with_mesh=False)
+        for om, ro in zip(oms, ros):
+            om.sync(ro["invalidated"])
+        many.mesh_sync_many(gms, [rg["invalidated"] for rg in rgs])
+        for k in range(len(gs)):
+            assert_synced_meshes_equal(oms[k].get(), gms[k].download())
+        mom = many.voxel_step_many(gs, capi.STAGE_INERTIA)
+        for k, o in enumerate(os_):
+            _, o64 = o.inertia(dens)
+            g64 = np.asarray(mom[k]["moments"]["m64"], dtype=np.float64)
+            assert np.all(np.abs(g64 - o64) <= 1e-5 * np.maximum(np.abs(o64), 1e-300) + 1e-12), (k, frame)
+    for g in gs:
+        g.close()
+
+
+def test_many_calls_equal_the_single_object_calls(ctx):
+    """the same objects twice: one set through the `_many` calls, the other object by object — every buffer equal"""
+    a = lattice_fragments(ctx, scenes.asteroid_scene(0.4), 2, jitter_seed=3)
+    b = lattice_fragments(ctx, scenes.asteroid_scene(0.4), 2, jitter_seed=3)
+    ga, gb = [p[1] for p in a], [p[1] for p in b]
+    assert len(ga) == len(gb) >= 4
+    stages = capi.STAGE_ALL & ~capi.STAGE_SAMPLE & ~capi.STAGE_INERTIA
+    ra = many.voxel_step_many(ga, stages)
+    rb = [g.step(stages) for g in gb]
+    for k in range(len(ga)):
+        for f in ("region_count",):
+            assert int(ra[k][f]) == int(rb[k][f])
+        np.testing.assert_array_equal(np.asarray(ra[k]["occupied"]), np.asarray(rb[k]["occupied"]))
+        for x, y in zip(ga[k].download(), gb[k].download()):
+            np.testing.assert_array_equal(x, y)
+        ma, mb = VoxelObjectMesh(ga[k]), VoxelObjectMesh(gb[k])
+        ma.counts, mb.counts = ra[k]["mesh"].copy(), rb[k]["mesh"].copy()
+        for x, y in zip(ma.download(), mb.download()):
+            np.testing.assert_array_equal(np.ascontiguousarray(x).view(np.uint8), np.ascontiguousarray(y).view(np.uint8))
+    for g in ga + gb:
+        g.close()

@@ -6,7 +6,7 @@ import pytest
 
 import oracle_lib as ol
 import parity_util as pu
-from impact_amd import scenes
+from impact_amd import capi, scenes
 from impact_amd.voxel import VoxelObjectMesh
 
 pytestmark = pytest.mark.gpu
@@ -151,3 +151,52 @@ def test_probes_follow_the_incremental_remesh_and_feed_the_mutual_contacts(ctx):
     assert len(want_ent) > 10 and max(n_contacts) > 5, n_contacts
     g.close()
     b_g.close()
+
+
+def test_edit_and_sync_in_two_halves(ctx):
+    """ivx_absorb_sphere_enqueue / ivx_absorb_collect and ivx_mesh_sync_enqueue / _collect: the edit's kernels, the sweep over the touched
+    chunks and their neighbours, the region resolve and the count of what the invalidated meshes need on the stream behind ONE wait; the sync
+    placed from those sizes without a count pass or a read-back of its own. Same results as the oracle's, edit after edit."""
+    o, g = both(ctx, scenes.asteroid_scene(0.5))
+    om = ol.OracleMeshHandle(o)
+    gm = VoxelObjectMesh.create(g)
+    ctr = np.array([0.5 * (a + b) for a, b in o.info()["occupied_voxel_ranges"]], dtype=np.float32)
+    for step, (d, r) in enumerate([((0.0, 0.0, 48.0), 14.0), ((30.0, 5.0, 30.0), 9.0), ((0.0, 0.0, 40.0), 22.0), ((-50.0, 0.0, 0.0), 30.0)]):
+        c = ctr + np.asarray(d, dtype=np.float32)
+        ro = o.absorb_sphere(c, r + 2.0, r)
+        g.absorb_sphere_enqueue(c, r + 2.0, r)
+        rg = g.absorb_collect()
+        np.testing.assert_array_equal(rg["invalidated"], ro["invalidated"])
+        np.testing.assert_array_equal(rg["emptied_by_type"], ro["emptied_by_type"])
+        assert (rg["touched_chunks"], rg["removed_chunks"]) == (ro["touched_chunks"], ro["removed_chunks"])
+        scale = np.maximum(np.abs(ro["removed64"]), 1e-300)
+        assert np.all(np.abs(rg["removed_moments"] - ro["removed64"]) <= 1e-5 * scale + 1e-9)
+        pu.assert_edited_objects_equal(o, g, f"edit {step}: ", with_mesh=False)
+        om.sync(ro["invalidated"])
+        gm.sync_enqueue(rg["invalidated"])
+        gm.sync_collect()
+        assert_synced_meshes_equal(om.get(), gm.download())
+    with pytest.raises(capi.IvxError):
+        g.absorb_collect()  # nothing in flight
+    g.close()
+
+
+def test_sync_of_several_edits_at_once(ctx):
+    """two edits, then ONE sync over the union of what they invalidated (the reference syncs once per frame, lib.rs:729-733): the sizes of the
+    first edit's chunks are not the last edit's — the sync counts the listed chunks itself"""
+    o, g = both(ctx, scenes.sphere_scene(30.0))
+    om = ol.OracleMeshHandle(o)
+    gm = VoxelObjectMesh.create(g)
+    ctr = np.array([0.5 * (a + b) for a, b in o.info()["occupied_voxel_ranges"]], dtype=np.float32)
+    inv_o = np.zeros(g.n_chunks, dtype=bool)
+    inv_g = np.zeros(g.n_chunks, dtype=bool)
+    for d, r in (((0.0, 0.0, 30.0), 8.0), ((0.0, 30.0, 0.0), 10.0), ((4.0, 0.0, 26.0), 6.0)):
+        c = ctr + np.asarray(d, dtype=np.float32)
+        inv_o |= o.absorb_sphere(c, r + 2.0, r)["invalidated"]
+        inv_g |= g.absorb_sphere(c, r + 2.0, r)["invalidated"]
+    np.testing.assert_array_equal(inv_g, inv_o)
+    om.sync(inv_o)
+    gm.sync_with_voxel_object(inv_g)
+    assert_synced_meshes_equal(om.get(), gm.download())
+    pu.assert_edited_objects_equal(o, g, "after three edits: ")  # (a full remesh behind box sweeps: the active list is rebuilt first)
+    g.close()
