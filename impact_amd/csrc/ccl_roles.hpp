@@ -186,12 +186,35 @@ __device__ __forceinline__ void role_ccl_flatten(uint32_t bid, uint32_t nb, Grid
     const bool live = chunk < g.cx * g.cy * g.cz;
     const uint32_t rc = live ? g.info[chunk].region_count : 0u;
     uint32_t n = 0;
-    for (uint32_t r = 0; r < rc; ++r) {
+    // A chunk with many regions (an edit's rough surface: a few hundred) is taken by its whole wave, a region per lane — one thread walking
+    // 250 chains one after the other was 50 us of the edit's resolve, with the other 63 lanes of its wave done after two.
+    constexpr uint32_t WIDE = 8u;
+    for (uint32_t r = 0; r < (rc > WIDE ? 0u : rc); ++r) {
         const uint32_t node = chunk * 256u + r;
         const uint32_t root = g_find(rparent, node);
         if (root == node) n += 1;
         // safe while other threads still walk the forest: the parent only moves closer to the root
         else __hip_atomic_store(rparent + node, root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    {
+        const uint32_t lane_ = threadIdx.x & 63u;
+        for (unsigned long long wide = __ballot(rc > WIDE); wide; wide &= wide - 1ull) {  // (wave-uniform)
+            const uint32_t owner = (uint32_t)__ffsll((long long)wide) - 1u;
+            const uint32_t oc = (uint32_t)__shfl((int)chunk, (int)owner, 64), orc = (uint32_t)__shfl((int)rc, (int)owner, 64);
+            uint32_t roots = 0;
+            for (uint32_t r0 = 0; r0 < orc; r0 += 64u) {
+                const uint32_t r = r0 + lane_;
+                bool is_root = false;
+                if (r < orc) {
+                    const uint32_t node = oc * 256u + r;
+                    const uint32_t root = g_find(rparent, node);
+                    is_root = root == node;
+                    if (!is_root) __hip_atomic_store(rparent + node, root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                roots += (uint32_t)__popcll(__ballot(is_root));
+            }
+            if (lane_ == owner) n = roots;
+        }
     }
     // exclusive prefix of the root counts inside this group of 256 chunks (ordered) and the group's total: the two levels of
     // the scan; k_ccl_assign adds the totals of the groups before

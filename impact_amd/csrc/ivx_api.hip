@@ -89,7 +89,9 @@ int ensure_dev_scratch(ivx_grid* g, size_t bytes) {
     IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
     if (g->dev_scratch) (void)hipFree(g->dev_scratch);
     g->dev_scratch = nullptr;
+    const size_t had = g->dev_scratch_bytes;
     g->dev_scratch_bytes = 0;
+    bytes = std::max<size_t>(std::max<size_t>(bytes, 2 * had), 64u << 10);  // (a growth is a wait on the stream: rare by construction)
     IVX_HIP_CHECK(hipMalloc(&g->dev_scratch, bytes));
     g->dev_scratch_bytes = bytes;
     return IVX_OK;
@@ -98,7 +100,7 @@ int ensure_dev_scratch(ivx_grid* g, size_t bytes) {
 int ensure_mesh_capacity(ivx_grid* g, size_t nv, size_t ni, size_t ns) {
     if (nv > g->vcap || ni > g->icap || ns > g->scap) g->mesh_generation += 1;
     if (nv > g->vcap) {
-        size_t cap = std::max(nv, g->vcap * 2);
+        size_t cap = std::max(nv + nv / 4 + 1024, g->vcap * 2);  // (slack: the edits that follow a full remesh grow the mesh by a few chunks' worth)
         if (g->positions) (void)hipFree(g->positions);
         if (g->normals) (void)hipFree(g->normals);
         if (g->vertex_materials) (void)hipFree(g->vertex_materials);
@@ -112,7 +114,7 @@ int ensure_mesh_capacity(ivx_grid* g, size_t nv, size_t ni, size_t ns) {
         g->vcap = cap;
     }
     if (ni > g->icap) {
-        size_t cap = std::max(ni, g->icap * 2);
+        size_t cap = std::max(ni + ni / 4 + 6144, g->icap * 2);
         if (g->indices) (void)hipFree(g->indices);
         if (g->index_materials) (void)hipFree(g->index_materials);
         g->indices = nullptr;
@@ -124,7 +126,7 @@ int ensure_mesh_capacity(ivx_grid* g, size_t nv, size_t ni, size_t ns) {
         g->icap = cap;
     }
     if (ns > g->scap) {
-        size_t cap = std::max(ns, g->scap * 2);
+        size_t cap = std::max(ns + ns / 4 + 16, g->scap * 2);
         if (g->submeshes) (void)hipFree(g->submeshes);
         g->submeshes = nullptr;
         g->scap = 0;
@@ -210,17 +212,18 @@ struct ivx_range_allocator {
         *start = a;
         return true;
     }
-    void merge_consecutive() {
+    void merge_consecutive() {  // (in place: a range that starts where the one before it ends is folded into that one)
         if (free_ranges.size() < 2) return;
-        std::map<size_t, size_t> out;
-        auto it = free_ranges.begin();
-        size_t a = it->first, b = it->second;
-        for (++it; it != free_ranges.end(); ++it) {
-            if (it->first == b) b = it->second;
-            else out.emplace(a, b), a = it->first, b = it->second;
+        auto prev = free_ranges.begin();
+        for (auto it = std::next(prev); it != free_ranges.end();) {
+            if (it->first == prev->second) {
+                prev->second = it->second;
+                it = free_ranges.erase(it);
+            } else {
+                prev = it;
+                ++it;
+            }
         }
-        out.emplace(a, b);
-        free_ranges.swap(out);
     }
 };
 struct ivx_submesh_manager {
@@ -275,21 +278,23 @@ int grow_keep(ivx_grid* g, T** buf, size_t old_count, size_t new_count) {
 int ensure_mesh_capacity_keep(ivx_grid* g, size_t nv, size_t ni, size_t ns) {
     int rc;
     if (nv > g->vcap || ni > g->icap || ns > g->scap) g->mesh_generation += 1;
+    // (growth by copy costs an allocation, a device copy and a wait — the price of hundreds of small objects' syncs when each of them outgrows
+    // its buffers by a few vertices per frame: double, and never by less than a few thousand elements; memory is not what this part is short of)
     if (nv > g->vcap) {
-        const size_t cap = std::max(nv, g->vcap + g->vcap / 2);
+        const size_t cap = std::max(nv + nv / 2 + 4096, 2 * g->vcap);
         if ((rc = grow_keep(g, &g->positions, g->vcap * 3, cap * 3))) return rc;
         if ((rc = grow_keep(g, &g->normals, g->vcap * 3, cap * 3))) return rc;
         if ((rc = grow_keep(g, &g->vertex_materials, (size_t)0, cap * 16))) return rc;  // scratch of the emit kernel
         g->vcap = cap;
     }
     if (ni > g->icap) {
-        const size_t cap = std::max(ni, g->icap + g->icap / 2);
+        const size_t cap = std::max(ni + ni / 2 + 24576, 2 * g->icap);
         if ((rc = grow_keep(g, &g->indices, g->icap, cap))) return rc;
         if ((rc = grow_keep(g, &g->index_materials, g->icap * 8, cap * 8))) return rc;
         g->icap = cap;
     }
     if (ns > g->scap) {
-        const size_t cap = std::max(ns, g->scap + g->scap / 2);
+        const size_t cap = std::max(ns + ns / 2 + 64, 2 * g->scap);
         if ((rc = grow_keep(g, &g->submeshes, g->scap, cap))) return rc;
         g->scap = cap;
     }
@@ -640,6 +645,16 @@ static int mesh_sync_enqueue(ivx_grid* g, const uint8_t* invalidated_chunks, con
     IVX_REQUIRE(g->x_off == 0 && g->gx == g->cc[0] && !g->has_ghost[0] && !g->has_ghost[1], IVX_ERR_STATE,
                 "ivx_mesh_sync: not available on a slab of a decomposed grid");
     int rc;
+    static const bool trace_ = getenv("IVX_MANY_TRACE") != nullptr;
+    static thread_local double acc_[6];
+    static thread_local int calls_ = 0;
+    auto tp_ = std::chrono::steady_clock::now();
+    auto lap_ = [&](int slot) {
+        if (!trace_) return;
+        const auto t = std::chrono::steady_clock::now();
+        acc_[slot] += 1e-3 * (double)std::chrono::duration_cast<std::chrono::nanoseconds>(t - tp_).count();
+        tp_ = t;
+    };
     if (!g->submesh_manager) g->submesh_manager = new (std::nothrow) ivx_submesh_manager();
     IVX_REQUIRE(g->submesh_manager, IVX_ERR_HIP, "ivx_mesh_sync: out of host memory");
     ivx_submesh_manager* m = g->submesh_manager;
@@ -656,11 +671,15 @@ static int mesh_sync_enqueue(ivx_grid* g, const uint8_t* invalidated_chunks, con
         m->chunks_were_removed = false;
         m->serial = g->mesh_serial;
     }
+    lap_(0);
     // what the invalidated chunks' meshes need now and their records (exposure, obscuredness flags)
-    std::vector<uint32_t> list;
+    // (the call's work lists live on across calls: with a hundred objects per frame their allocations were a third of the host's time here)
+    static thread_local std::vector<uint32_t> list, needs, dirty_slots, rec_chunk, slots;
+    static thread_local std::vector<char> stage;
+    list.clear();
     for (uint32_t c = 0; c < g->n_chunks; ++c)  // chunk-linear order (the reference walks a hash set: unpinned)
         if (invalidated_chunks[c]) list.push_back(c);
-    std::vector<uint32_t> needs(3 * list.size());
+    needs.assign(3 * list.size(), 0u);
     bool cached = g->needs_current != 0;
     for (size_t e = 0; e < list.size() && cached; ++e) cached = edit_needs_lookup(g, list[e], &needs[3 * e]);
     if (!list.empty() && !cached) {
@@ -673,13 +692,15 @@ static int mesh_sync_enqueue(ivx_grid* g, const uint8_t* invalidated_chunks, con
         if ((rc = d2h(g, raw.data(), base + off_out, raw.size() * 4))) return rc;
         for (size_t e = 0; e < list.size(); ++e) needs[3 * e] = raw[4 * e + 1], needs[3 * e + 1] = raw[4 * e + 2], needs[3 * e + 2] = raw[4 * e] & 0xFFFFu;
     }
-    std::vector<uint32_t> dirty_slots;  // slots of the device table that a removal rewrote (the emit pass writes the others)
+    lap_(1);
+    dirty_slots.clear();  // slots of the device table that a removal rewrote (the emit pass writes the others)
     const size_t table_before = m->table.size();
     struct Rec {
         uint32_t chunk, voff, ioff, packed;
     };
-    std::vector<Rec> recs;
-    std::vector<uint32_t> rec_chunk;
+    static thread_local std::vector<Rec> recs;
+    recs.clear();
+    rec_chunk.clear();
     for (size_t e = 0; e < list.size(); ++e) {
         const uint32_t c = list[e];
         const uint32_t nv = needs[3 * e], ni = needs[3 * e + 1], kind = needs[3 * e + 2] & 0xFFu, flags = (needs[3 * e + 2] >> 8) & 0xFFu;
@@ -725,16 +746,18 @@ static int mesh_sync_enqueue(ivx_grid* g, const uint8_t* invalidated_chunks, con
         recs.push_back(Rec{c, (uint32_t)v0, (uint32_t)i0, nv | ((ni / 6u) << 16)});
         rec_chunk.push_back(c);
     }
+    lap_(2);
     m->vertices.merge_consecutive();  // perform_maintainance
     m->indices.merge_consecutive();
     if ((rc = ensure_mesh_capacity_keep(g, m->total_vertices, m->total_indices, m->table.size()))) return rc;
+    lap_(3);
     if (!recs.empty()) {
         // (slots are final only now: a removal after a write may have moved the written entry)
-        std::vector<uint32_t> slots(recs.size());
+        slots.resize(recs.size());
         for (size_t r = 0; r < recs.size(); ++r) slots[r] = m->slot_of.at(rec_chunk[r]);
         const size_t off_slots = 16 + recs.size() * sizeof(Rec), total = off_slots + recs.size() * 4;
         if ((rc = ensure_dev_scratch(g, total))) return rc;
-        std::vector<char> stage(total);
+        stage.assign(total, 0);
         const uint32_t n = (uint32_t)recs.size();
         memcpy(stage.data(), &n, 4);
         memcpy(stage.data() + 16, recs.data(), recs.size() * sizeof(Rec));
@@ -743,6 +766,7 @@ static int mesh_sync_enqueue(ivx_grid* g, const uint8_t* invalidated_chunks, con
         if ((rc = edit_sync_upload(g, stage.data(), total, base))) return rc;
         if ((rc = ivx_launch_sn_emit_list(g, n, reinterpret_cast<const uint32_t*>(base), base + 16, reinterpret_cast<const uint32_t*>(base + off_slots)))) return rc;
     }
+    lap_(4);
     // the device table: the emit pass wrote the re-meshed chunks' entries; entries a removal moved are patched from the host mirror
     (void)table_before;
     for (uint32_t slot : dirty_slots)
@@ -754,6 +778,12 @@ static int mesh_sync_enqueue(ivx_grid* g, const uint8_t* invalidated_chunks, con
     g->mesh_serial += 1;  // collision probes picked from the old mesh are stale
     m->serial = g->mesh_serial;
     edit_sync_mark(g, 1);
+    lap_(5);
+    if (trace_ && ++calls_ % 81 == 0) {
+        fprintf(stderr, "[ivx many]   sync enqueue laps (us per 81): setup %.1f list+needs %.1f allocator %.1f capacity %.1f upload+emit %.1f tail %.1f\n", acc_[0], acc_[1], acc_[2],
+                acc_[3], acc_[4], acc_[5]);
+        for (double& a : acc_) a = 0.0;
+    }
     return IVX_OK;
 }
 
@@ -2860,11 +2890,16 @@ static int many_phase(ivx_grid* const* grids, size_t n, const std::function<int(
     int rc = ivx_many_begin(c);
     if (rc) return rc;
     int first = IVX_OK;
+    const auto t0 = std::chrono::steady_clock::now();
     for (size_t i = 0; i < n && !first; ++i) {
         ivx_many_object((uint32_t)i);
         first = f(i);
     }
+    const auto t1 = std::chrono::steady_clock::now();
     rc = ivx_many_flush(c);
+    if (getenv("IVX_MANY_TRACE"))
+        fprintf(stderr, "[ivx many]   phase: objects %.1f us, flush %.1f us\n", 1e-3 * (double)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count(),
+                1e-3 * (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t1).count());
     return first ? first : rc;
 }
 
@@ -2888,33 +2923,59 @@ int ivx_voxel_step_many(ivx_grid* const* grids, size_t n, uint32_t stages, ivx_s
     return IVX_OK;
 }
 
+// developer aid: IVX_MANY_TRACE=1 prints the host time of every phase of the many-object calls
+static bool many_trace() {
+    static const bool on = getenv("IVX_MANY_TRACE") != nullptr;
+    return on;
+}
+struct ManyClock {
+    const char* what;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit ManyClock(const char* w) : what(w) {}
+    void lap(const char* phase) {
+        if (!many_trace()) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ivx many] %s %s: %.1f us\n", what, phase, 1e-3 * (double)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 int ivx_absorb_sphere_many(ivx_grid* const* grids, size_t n, const float* centers3, const float* influence_radii, const float* sphere_radii,
                            const float densities[256], ivx_absorb_result* out, uint8_t* const* invalidated_chunks) {
     int rc = many_check(grids, n, "ivx_absorb_sphere_many");
     if (rc) return rc;
+    ManyClock clk("absorb");
     IVX_REQUIRE(centers3 && influence_radii && sphere_radii && densities && out, IVX_ERR_INVALID, "ivx_absorb_sphere_many: null argument");
     // (what an object's enqueue may have to wait for — its occupied ranges, a density table that is not the resident one — before the recording starts)
     for (size_t i = 0; i < n; ++i) {
         uint32_t occ[12];
         if (grids[i]->regions_valid && (rc = reference_occupied(grids[i], occ))) return rc;
     }
+    clk.lap("prepare");
     if ((rc = many_phase(grids, n, [&](size_t i) {
              return absorb_enqueue(grids[i], "ivx_absorb_sphere_many", 0, centers3 + 3 * i, nullptr, influence_radii[i], sphere_radii[i], densities);
          })))
         return rc;
+    clk.lap("enqueue + flush");
     if ((rc = many_phase(grids, n, [&](size_t i) { return (grids[i]->edit && grids[i]->edit->pending && !grids[i]->edit->nothing) ? ivx_step_collect_launch(grids[i]) : IVX_OK; })))
         return rc;
-    return many_phase(grids, n, [&](size_t i) {
+    clk.lap("gathers");
+    rc = many_phase(grids, n, [&](size_t i) {
         return absorb_collect(grids[i], "ivx_absorb_sphere_many", &out[i], nullptr, invalidated_chunks ? invalidated_chunks[i] : nullptr);
     });
+    clk.lap("collect");
+    return rc;
 }
 
 int ivx_mesh_sync_many(ivx_grid* const* grids, size_t n, const uint8_t* const* invalidated_chunks, ivx_mesh_counts* out) {
     int rc = many_check(grids, n, "ivx_mesh_sync_many");
     if (rc) return rc;
     IVX_REQUIRE(invalidated_chunks && out, IVX_ERR_INVALID, "ivx_mesh_sync_many: null argument");
+    ManyClock clk("sync");
     if ((rc = many_phase(grids, n, [&](size_t i) { return mesh_sync_enqueue(grids[i], invalidated_chunks[i], "ivx_mesh_sync_many"); }))) return rc;
+    clk.lap("enqueue + flush");
     IVX_HIP_CHECK(ivx_stream_sync(grids[0]->ctx->stream));  // (one wait for all)
+    clk.lap("wait");
     for (size_t i = 0; i < n; ++i)
         if ((rc = mesh_sync_collect(grids[i], &out[i], "ivx_mesh_sync_many", true))) return rc;
     return IVX_OK;
