@@ -27,6 +27,7 @@ Prints ONE JSON line on rank 0 (DESIGN.md "Measurement" explains every field).
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -275,15 +276,22 @@ def make_object(ctx, graph):
 def time_steps(ctx, obj, stages, steps, warmup):
     from impact_amd import capi
 
+    gc.collect()  # (the collector itself is off for the whole run, see main(): collections happen here, between timed regions)
+
     for _ in range(warmup):
         res = obj.step(stages)
     ctx.synchronize()
     acc = np.zeros(capi.N_TIMED_STAGES)
     t0 = time.perf_counter()
+    walls = []
     for _ in range(steps):
+        tw = time.perf_counter()
         res = obj.step(stages)
+        walls.append(time.perf_counter() - tw)
         acc += res["stage_ms"]
     ctx.synchronize()
+    if os.environ.get("IVX_BENCH_TRACE"):
+        print("[bench] time_steps walls (ms):", np.round(1e3 * np.array(walls), 3).tolist(), file=sys.stderr)
     return res, 1e3 * (time.perf_counter() - t0) / steps, acc / steps
 
 
@@ -627,7 +635,7 @@ def edit_benchmark(ctx, scale, o_big, reps=5):
     return out
 
 
-def fragments_benchmark(ctx, with_cpu, n_axis=5, frames=4):
+def fragments_benchmark(ctx, with_cpu, n_axis=5, frames=6, warm=2):
     """Many objects per frame (the reference's manager loops over every voxel object each frame: impact_voxel/src/lib.rs:729-733; fragments
     come into being together: interaction/fracturing.rs:1047-1189). The config-2 body (256^3) is cut into the Voronoi cells of a jittered
     n^3 lattice of fracture points (`ivx_copy_polyhedra`); then, per frame and per fragment: one absorbing-sphere edit, the incremental remesh
@@ -696,7 +704,7 @@ def fragments_benchmark(ctx, with_cpu, n_axis=5, frames=4):
         return cs, rs
 
     t_loop, t_many = [], []
-    for f in range(frames + 1):
+    for f in range(frames + warm):  # (the first frames grow each object's edit scratch and mesh buffers once: warm-up, for both loops)
         cs, rs = frame_edits(f)
         ctx.synchronize()
         t0 = time.perf_counter()
@@ -709,7 +717,7 @@ def fragments_benchmark(ctx, with_cpu, n_axis=5, frames=4):
         many.mesh_sync_many(b_mesh, [e_["invalidated"] for e_ in eb])
         mom = many.voxel_step_many(b_objs, capi.STAGE_INERTIA)
         t2 = time.perf_counter()
-        if f:
+        if f >= warm:
             t_loop.append(t1 - t0)
             t_many.append(t2 - t1)
     # looped and batched objects hold the same bytes
@@ -723,7 +731,7 @@ def fragments_benchmark(ctx, with_cpu, n_axis=5, frames=4):
     out = {"workload": f"config-2 body (256^3) cut into the Voronoi cells of a jittered {n_axis}^3 lattice: {n} fragments of "
                        f"{int(np.median([o_.n_chunks for o_ in a_objs]))} chunks (median); per frame and fragment: one absorbing sphere (r 4-6 voxels), the "
                        "incremental remesh of what it invalidated, the ten moments",
-           "objects": n, "frames": frames, "cut_ms": round(1e3 * t_cut, 3),
+           "objects": n, "frames": frames, "warmup_frames": warm, "cut_ms": round(1e3 * t_cut, 3),
            "first_step_looped_ms": round(first_loop_ms, 3), "first_step_many_ms": round(first_many_ms, 3),
            "frame_looped_ms": round(loop_ms, 4), "frame_many_ms": round(many_ms, 4), "speedup": round(loop_ms / many_ms, 2),
            "objects_per_s_looped": n / (loop_ms * 1e-3), "objects_per_s_many": n / (many_ms * 1e-3),
@@ -743,7 +751,7 @@ def fragments_benchmark(ctx, with_cpu, n_axis=5, frames=4):
             o_objs.append(co)
         o_mesh = [ol.OracleMeshHandle(o_) for o_ in o_objs]
         t_cpu = []
-        for f in range(frames + 1):
+        for f in range(frames + warm):
             cs, rs = frame_edits(f)
             t0 = time.perf_counter()
             for o_, m_, c, r in zip(o_objs, o_mesh, cs, rs):
@@ -765,7 +773,7 @@ def fragments_benchmark(ctx, with_cpu, n_axis=5, frames=4):
                 equal = equal and bool(np.array_equal(idx[io:io + ic], want.indices[io:io + ic])) and bool(
                     np.array_equal(pos[vo:vo + vc].view(np.uint32), want.positions[vo:vo + vc].view(np.uint32)))
         out["parity"]["every_object_equals_the_oracle"] = equal
-        cpu_ms = 1e3 * float(np.mean(t_cpu[1:]))
+        cpu_ms = 1e3 * float(np.mean(t_cpu[warm:]))
         out["cpu_baseline"] = {"frame_ms": cpu_ms, "objects_per_s": n / (cpu_ms * 1e-3), "cores": 1, "kind": "port",
                                "sample": f"the same {frames} frames over the same {n} fragments, object by object, single thread"}
     for o_ in a_objs + b_objs:
@@ -835,6 +843,10 @@ def pile_benchmark(ctx, with_cpu, steps=10):
 
 
 def main():
+    # Python's cyclic collector stays off while the bench runs (as `timeit` keeps it): with torch imported a full collection walks ~170 000
+    # objects in 36 ms, and one of them landed in the all-surface leg's 50 steps on every run (+0.8 ms per step on paper). Collections are
+    # made by hand between the timed regions (time_steps, and in front of every leg below).
+    gc.disable()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # (a step is a third of a millisecond: 200 of them are 0.06 s, and short runs measure the clocks ramping up — 0.312 ms per step
@@ -1107,13 +1119,20 @@ def main():
             out["cpu_baseline"] = None
         if not args.no_pile and world == 1:
             with_cpu = not args.no_cpu_baseline
+            gc.collect()
             out["dense"] = dense_benchmark(ctx, args, with_cpu) if args.workload == "asteroid" else None
+            gc.collect()
             out["config2"] = config2_benchmark(ctx, args, with_cpu)
+            gc.collect()
             out["config3"] = config3_benchmark(ctx, args, with_cpu)
+            gc.collect()
             out["config5_one_gpu"] = config5_benchmark(ctx, args)
+            gc.collect()
             out["fragments"] = fragments_benchmark(ctx, with_cpu)
+            gc.collect()
             pile, w = pile_benchmark(ctx, with_cpu)
             out["pile"] = pile
+            gc.collect()
             # the full frame: the voxel step of the headline body + the pile's solve, enqueued back to back, one wait
             for _ in range(2):
                 obj.step_enqueue(capi.STAGE_ALL)
