@@ -732,6 +732,18 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
 // ---- per-voxel evaluation ----------------------------------------------------------------------
 // One stack-machine step each; shared by the compact per-chunk program (normal path) and the full
 // node program (fallback when a chunk's compact program overflows OP_CAP).
+// A box leaf under a transform that moves only z along the column: where the whole WAVE's columns lie inside the box's footprint in x and y
+// (px = py = 0, i.e. cxy = +0 — the inside of a slab, a wall, a floor: most columns of a box-built scene) the length sqrt((0 + 0) + pz^2)
+// is pz itself: 0 + t = t, and in binary floating point a correctly rounded square root of a correctly rounded square gives the number back
+// when the square neither underflows nor overflows. Guard for that: a half extent of at least 2^-20 makes |z| - c either non-positive
+// (pz = 0: sqrt(0) = 0) or at least 2^-45 (within a factor two of c the subtraction is exact and a multiple of c's last place; beyond, it is
+// at least c/2), and coordinates below 2^40 keep the square finite. Eleven of the box's seventeen instructions per voxel, in a kernel bound by
+// VALU issue. (The test is per wave: a divergent branch would run both loops.)
+__device__ __forceinline__ bool box_column_inside(float cxy, float z0, float dzz, float half_z) {
+    const bool ok = cxy == 0.0f && fabsf(z0) < 1.0e12f;
+    return __all(ok ? 1 : 0) != 0 && half_z >= 9.5367431640625e-7f && fabsf(dzz) < 1.0e9f;
+}
+
 __device__ __forceinline__ void eval_leaf(const ivx_sdf_processed_node* nd, uint32_t kind, float* d, bool t15, float& r15, V3 origin_root, uint32_t ti, uint32_t tj) {
     const float* m = nd->transform;
     const V3 origin = xform_point(m, origin_root);
@@ -764,6 +776,15 @@ __device__ __forceinline__ void eval_leaf(const ivx_sdf_processed_node* nd, uint
             const float qx = fabsf(pos.x) - pa, qy = fabsf(pos.y) - pb;
             const float px = max_rs(qx, 0.0f), py = max_rs(qy, 0.0f);
             const float cxy = px * px + py * py, mxy = max_rs(qx, qy);
+            if (box_column_inside(cxy, z, dz.z, pc)) {  // (wave-uniform) sqrt(0 + pz^2) is pz, see box_column_inside
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float qz = fabsf(z) - pc, pz = max_rs(qz, 0.0f);
+                    IVX_LV_SET(d, k, t15, r15, pz + min_rs(max_rs(mxy, qz), 0.0f));
+                    z += dz.z;
+                }
+                return;
+            }
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const float qz = fabsf(z) - pc, pz = max_rs(qz, 0.0f);
@@ -823,6 +844,7 @@ struct LeafRun {  // a leaf's evaluation along a thread's column, resumable
     bool zonly;
     V3 pos, dz;
     float c0, c1, c2;  // zonly: [kind 0/1] x^2 + y'^2, radius; [kind 2] px^2 + py^2, max(qx, qy), half extent z — else the node's a, b, c
+    bool inside;       // zonly box: the wave's columns all lie inside the box's footprint (box_column_inside)
 };
 __device__ __forceinline__ LeafRun leaf_begin(const ivx_sdf_processed_node* nd, uint32_t kind, V3 origin_root, uint32_t ti, uint32_t tj) {
     const float* m = nd->transform;
@@ -836,11 +858,13 @@ __device__ __forceinline__ LeafRun leaf_begin(const ivx_sdf_processed_node* nd, 
     r.zonly = r.dz.x == 0.0f && r.dz.y == 0.0f;
     const float pa = nd->a, pb = nd->b, pc = nd->c;
     r.c0 = pa, r.c1 = pb, r.c2 = pc;
+    r.inside = false;
     if (r.zonly) {  // (eval_leaf's column constants)
         if (kind == 2u) {
             const float qx = fabsf(r.pos.x) - pa, qy = fabsf(r.pos.y) - pb;
             const float px = max_rs(qx, 0.0f), py = max_rs(qy, 0.0f);
             r.c0 = px * px + py * py, r.c1 = max_rs(qx, qy), r.c2 = pc;
+            r.inside = box_column_inside(r.c0, r.pos.z, r.dz.z, pc);
         } else {
             float y = r.pos.y, rad = pa;
             if (kind == 1u) {
@@ -859,7 +883,14 @@ __device__ __forceinline__ LeafRun leaf_begin(const ivx_sdf_processed_node* nd, 
 __device__ __forceinline__ void leaf_next8(LeafRun& r, float* v) {
     if (r.zonly) {
         float z = r.pos.z;
-        if (r.kind == 2u) {
+        if (r.kind == 2u && r.inside) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float qz = fabsf(z) - r.c2, pz = max_rs(qz, 0.0f);
+                v[k] = pz + min_rs(max_rs(r.c1, qz), 0.0f);
+                z += r.dz.z;
+            }
+        } else if (r.kind == 2u) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float qz = fabsf(z) - r.c2, pz = max_rs(qz, 0.0f);

@@ -94,3 +94,33 @@ def test_nested_scalings_over_a_far_combination(ctx, s_outer, s_inner, op, smoot
     info = obj.download(flags=False, labels=False)[4]
     assert (info["kind"] == 0).sum() > 0
     obj.close()
+
+
+def _slab_scene(rng):
+    """walls, floors and pillars: boxes under translations and scalings only (no rotation), joined by hard and smooth unions and cut by a
+    box-shaped subtraction — most voxel columns lie inside some box's footprint in x and y, where the evaluator takes the length of
+    (0, 0, pz) as pz (box_column_inside, csrc/sdf_sample.hip) instead of the rounded square root the reference computes"""
+    g = SDFGraph()
+    acc = None
+    for _ in range(int(rng.integers(3, 7))):
+        ext = [float(x) for x in rng.uniform(3.0, 60.0, 3)]
+        ext[int(rng.integers(0, 3))] = float(rng.uniform(0.7, 6.0))  # a slab along one axis
+        n = g.add_node(SDFNode.new_box(ext))
+        if rng.random() < 0.5:
+            n = g.add_node(SDFNode.new_scaling(n, float(rng.uniform(0.37, 1.9))))
+        n = g.add_node(SDFNode.new_translation(n, [float(x) for x in rng.uniform(-25.0, 25.0, 3)]))
+        acc = n if acc is None else g.add_node(SDFNode.new_union(acc, n, 0.0 if rng.random() < 0.6 else float(rng.uniform(0.5, 3.0))))
+    hole = g.add_node(SDFNode.new_translation(g.add_node(SDFNode.new_box([float(x) for x in rng.uniform(2.0, 9.0, 3)])), [float(x) for x in rng.uniform(-10.0, 10.0, 3)]))
+    acc = g.add_node(SDFNode.new_subtraction(acc, hole, 0.0 if rng.random() < 0.5 else 1.5))
+    if rng.random() < 0.5:
+        g.add_node(SDFNode.new_scaling(acc, float(rng.uniform(0.8, 1.3))))
+    return g
+
+
+@pytest.mark.parametrize("seed", pu.fuzz_seeds([61, 62, 63, 64, 65, 66, 67, 68]))
+def test_box_built_scenes(ctx, seed):
+    rng = np.random.default_rng(seed)
+    g = _slab_scene(rng)
+    extent = [1.0, 0.5, 0.37, 1.0 / 3.0][seed % 4]
+    _, obj = full_pipeline(ctx, g, extent)
+    obj.close()
