@@ -77,8 +77,77 @@ __device__ __forceinline__ uint32_t ivx_walk_pos(uint32_t idx) {  // position of
     return 0xFFFFu;
 }
 
+// developer probes of the exact numbering (make TRACE=1; read back by ivx_debug_exact_trace of the translation unit whose kernel ran it)
+#ifdef IVX_WG_TRACE
+static __device__ unsigned long long ivx_exact_trace_buf[64 * 8];
+#define IVX_XT(slot)                                                                                  \
+    do {                                                                                              \
+        if (threadIdx.x == 0) ivx_exact_trace_buf[(chunk & 63u) * 8 + (slot)] = wall_clock64();       \
+    } while (0)
+#else
+#define IVX_XT(slot) \
+    do {             \
+    } while (0)
+#endif
+
+// ---- helpers of ccl_exact_chunk: a thread's row of sixteen u16 entries as eight packed words ------------------------------------------
+__device__ __forceinline__ uint32_t ivx_h16(const uint32_t* w, int k) { return (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xFFFFu); }
+__device__ __forceinline__ void ivx_row16_load(const uint16_t* row, uint32_t* w) {
+    const uint4 lo = reinterpret_cast<const uint4*>(row)[0], hi = reinterpret_cast<const uint4*>(row)[1];
+    w[0] = lo.x, w[1] = lo.y, w[2] = lo.z, w[3] = lo.w, w[4] = hi.x, w[5] = hi.y, w[6] = hi.z, w[7] = hi.w;
+}
+__device__ __forceinline__ void ivx_row16_store(uint16_t* row, const uint32_t* w) {
+    reinterpret_cast<uint4*>(row)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    reinterpret_cast<uint4*>(row)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+// out[k] = table[in[k] >> shift] for the sixteen entries (independent loads: one LDS latency for the row instead of sixteen)
+__device__ __forceinline__ void ivx_row16_gather(const uint16_t* table, const uint32_t* in, uint32_t shift, uint32_t* out) {
+    uint32_t t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = table[ivx_h16(in, k) >> shift];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = t[2 * i] | (t[2 * i + 1] << 16);
+}
+
+// The merge events of a chunk with at most 64 K sources, applied in order by ONE wave with the sets in registers: lane l of R[q] holds the
+// set (the index of its root source) of source 64 q + l. An event (a, b) between different sets makes a's root the root of the union
+// (assign_parent, split_detection.rs:1776-1782): every source of b's set takes a's root — one compare-and-select over the lanes, no chain to
+// follow, nothing in memory. Per round every lane looks up its event's two sets (a lane permute each); the EARLIEST event between different
+// sets is the next the sequential order would apply (the ones before it join equal sets: nothing to do), so it is applied and the lanes
+// look again: one round per effective merge, ~100 cycles each. (The union-find in LDS this replaces — finds with path halving, a ballot
+// and a conflict scan among the pending lanes per round — took 63 us for a chunk of 65 sources and 796 events; this takes ~5.)
+template <int K>
+__device__ __forceinline__ uint32_t ivx_exact_set_of(const uint32_t* R, uint32_t s) {
+    uint32_t v = (uint32_t)__shfl((int)R[0], (int)(s & 63u), 64);
+#pragma unroll
+    for (int q = 1; q < K; ++q) {
+        const uint32_t t = (uint32_t)__shfl((int)R[q], (int)(s & 63u), 64);
+        v = (s >> 6) == (uint32_t)q ? t : v;
+    }
+    return v;
+}
+template <int K>
+__device__ __forceinline__ void ivx_exact_apply_events(uint32_t* R, const uint16_t* ev_a, const uint16_t* ev_b, uint32_t n_win, uint32_t lane) {
+    for (uint32_t e0 = 0; e0 < n_win; e0 += 64u) {
+        const bool valid = e0 + lane < n_win;
+        const uint32_t sa = valid ? ev_a[e0 + lane] : 0u, sb = valid ? ev_b[e0 + lane] : 0u;
+        for (int guard = 0; guard < 64 * K + 2; ++guard) {  // (a merge takes a set away: at most 64 K - 1 of them in all)
+            const uint32_t ra = ivx_exact_set_of<K>(R, sa), rb = ivx_exact_set_of<K>(R, sb);
+            const unsigned long long pending = __ballot(valid && ra != rb);
+            if (!pending) break;
+            const int j = __ffsll((long long)pending) - 1;  // (wave-uniform)
+            const uint32_t win = (uint32_t)__builtin_amdgcn_readlane((int)ra, j), lose = (uint32_t)__builtin_amdgcn_readlane((int)rb, j);
+#pragma unroll
+            for (int q = 0; q < K; ++q) R[q] = R[q] == lose ? win : R[q];
+        }
+    }
+}
+
 // All 256 threads; sh.mask[] holds the non-empty masks of the 256 rows (thread = row (i,j), bit = k). Writes the label plane, the
 // chunk's region table and returns (region_count, boundary_region_count), both saturated at 254 with error bit 1 set beyond.
+// A thread keeps its row's sixteen pointers in eight packed registers and follows them by GATHERS — sixteen independent LDS loads, one
+// latency — wherever the straightforward loop over the set bits of its mask would chain two to four dependent loads per voxel (the kernel
+// that hosts this is held to 64 VGPRs: the rows stay packed).
 __device__ __forceinline__ void ccl_exact_chunk(CclShared& sh, uint32_t tid, uint32_t chunk, uint8_t* __restrict__ labels, uint32_t* __restrict__ rparent,
                                                 uint32_t* __restrict__ rscalar, uint32_t& rc_out, uint32_t& brc_out) {
     constexpr uint32_t EV_CAP = 768u;
@@ -87,64 +156,81 @@ __device__ __forceinline__ void ccl_exact_chunk(CclShared& sh, uint32_t tid, uin
     uint16_t* ev_a = spar + 2048;                                 // [768]
     uint16_t* ev_b = ev_a + EV_CAP;                               // [768]
     uint32_t* key = reinterpret_cast<uint32_t*>(ev_b + EV_CAP);   // [256]
+    uint16_t* src_voxel = reinterpret_cast<uint16_t*>(sh.mask);   // [256] voxel of source number s (once every thread has its masks)
     const uint32_t ti = tid >> 4, tj = tid & 15u, lane = tid & 63u, wave = tid >> 6;
     const uint32_t m = sh.mask[tid];
     const uint32_t mx = ti > 0u ? sh.mask[tid - 16u] : 0u;  // row below in x, in y
     const uint32_t my = tj > 0u ? sh.mask[tid - 1u] : 0u;
+    const uint32_t m_yu = tj < 15u ? sh.mask[tid + 1u] : 0u;                   // row above in y
+    const uint32_t m_xd_yu = (ti > 0u && tj < 15u) ? sh.mask[tid - 15u] : 0u;  // ... and the row below that one in x
     const uint32_t base_v = tid * 16u;
-    __syncthreads();  // everybody has read what it needs from the union-find of ccl_local_chunk: sh.par is free
+    __syncthreads();  // everybody has read what it needs from the union-find of ccl_local_chunk and its masks: sh.par and sh.mask are free
+    IVX_XT(0);
     // fp pointers; sources point to themselves (empty voxels too: never followed)
     const uint32_t has_xd = m & mx, has_yd = m & my & ~mx, has_zd = m & (m << 1) & ~mx & ~my;
     const uint32_t sources = m & ~mx & ~my & ~(m << 1);
-#pragma unroll
-    for (uint32_t k = 0; k < 16u; ++k) {
-        const uint32_t v = base_v + k;
-        uint32_t p = v;
-        if ((has_xd >> k) & 1u) p = v - 256u;
-        else if ((has_yd >> k) & 1u) p = v - 16u;
-        else if ((has_zd >> k) & 1u) p = v - 1u;
-        ptr[v] = (uint16_t)p;
-    }
+    uint32_t pp[8];  // the row's pointers, packed
     {
-        uint32_t s = sources;
+        uint32_t p[16];
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; ++k) {
+            const uint32_t v = base_v + k;
+            p[k] = ((has_xd >> k) & 1u) ? v - 256u : (((has_yd >> k) & 1u) ? v - 16u : (((has_zd >> k) & 1u) ? v - 1u : v));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pp[i] = p[2 * i] | (p[2 * i + 1] << 16);
+        ivx_row16_store(ptr + base_v, pp);
+    }
+    // the sources, numbered in voxel order
+    uint32_t src_first, n_sources;
+    {
+        const uint32_t n_s = __popc(sources);
+        uint32_t incl = n_s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o, 64);
+            if (lane >= (uint32_t)o) incl += t;
+        }
+        if (lane == 63u) sh.w[wave] = incl;
+        __syncthreads();
+        const uint32_t w0 = sh.w[0], w1 = sh.w[1], w2 = sh.w[2], w3 = sh.w[3];
+        src_first = (wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2))) + incl - n_s;
+        n_sources = (w0 + w1) + (w2 + w3);
+    }
+    // up to 256 sources: the sets live in one wave's registers while the events are applied (spar: the source's number); beyond: the
+    // union-find over spar (a source's parent source)
+    const bool fast = n_sources <= 256u;
+    {
+        uint32_t s = sources, idx = src_first;
         while (s) {
             const uint32_t k = (uint32_t)__ffs(s) - 1u;
             s &= s - 1u;
-            spar[(base_v + k) >> 1] = (uint16_t)(base_v + k);
+            spar[(base_v + k) >> 1] = (uint16_t)(fast ? idx : base_v + k);
+            if (fast) src_voxel[idx] = (uint16_t)(base_v + k);
+            idx += 1u;
         }
     }
     if (tid < 44u) sh.bm[tid] = 0u;
     key[tid] = 0xFFFFFFFFu;
     __syncthreads();
-    // pointer jumping (in place: a pointer only ever moves to an ancestor): chains are at most 45 long
+    // pointer jumping (in place: a pointer only ever moves to an ancestor; a thread's own entries change by its own stores only, so its
+    // registers stay current): chains are at most 45 long
     for (int round = 0; round < 6; ++round) {
-        uint32_t mm = m & ~sources;
-        while (mm) {
-            const uint32_t k = (uint32_t)__ffs(mm) - 1u;
-            mm &= mm - 1u;
-            const uint32_t v = base_v + k;
-            ptr[v] = ptr[ptr[v]];
-        }
+        ivx_row16_gather(ptr, pp, 0u, pp);
+        ivx_row16_store(ptr + base_v, pp);
         __syncthreads();
     }
+    IVX_XT(1);
     // events of this row, in order: (a, b = a + 16) when b also has a -x neighbour; (a, b = a + 1) when b has a -x or -y neighbour
-    const uint32_t m_yu = tj < 15u ? sh.mask[tid + 1u] : 0u;                 // row above in y
-    const uint32_t ev_y_geom = m & m_yu & (ti > 0u ? sh.mask[tid - 16u + 1u] : 0u) & (tj < 15u ? 0xFFFFu : 0u);  // b = a + 16 has b - 256
-    const uint32_t ev_z_geom = m & (m >> 1) & ((mx | my) >> 1);              // b = a + 1 has b - 256 or b - 16
+    const uint32_t ev_y_geom = m & m_yu & m_xd_yu;               // b = a + 16 has b - 256
+    const uint32_t ev_z_geom = m & (m >> 1) & ((mx | my) >> 1);  // b = a + 1 has b - 256 or b - 16
     uint32_t evy = 0, evz = 0;
-    {
-        uint32_t c = ev_y_geom;
-        while (c) {
-            const uint32_t k = (uint32_t)__ffs(c) - 1u;
-            c &= c - 1u;
-            if (ptr[base_v + k] != ptr[base_v + k + 16u]) evy |= 1u << k;
-        }
-        c = ev_z_geom;
-        while (c) {
-            const uint32_t k = (uint32_t)__ffs(c) - 1u;
-            c &= c - 1u;
-            if (ptr[base_v + k] != ptr[base_v + k + 1u]) evz |= 1u << k;
-        }
+    uint32_t qq[8];  // the pointers of the row above in y
+    ivx_row16_load(ptr + (tj < 15u ? base_v + 16u : base_v), qq);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (((ev_y_geom >> k) & 1u) && ivx_h16(pp, k) != ivx_h16(qq, k)) evy |= 1u << k;
+        if (k < 15 && ((ev_z_geom >> k) & 1u) && ivx_h16(pp, k) != ivx_h16(pp, k + 1)) evz |= 1u << k;
     }
     uint32_t n_mine = __popc(evy) + __popc(evz), first, total;
     {   // ordered block prefix (thread order = voxel order)
@@ -154,78 +240,114 @@ __device__ __forceinline__ void ccl_exact_chunk(CclShared& sh, uint32_t tid, uin
             const uint32_t t = __shfl_up(incl, o, 64);
             if (lane >= (uint32_t)o) incl += t;
         }
-        if (lane == 63u) sh.w[wave] = incl;
+        if (lane == 63u) sh.w[4 + wave] = incl;
         __syncthreads();
-        const uint32_t w0 = sh.w[0], w1 = sh.w[1], w2 = sh.w[2], w3 = sh.w[3];
+        const uint32_t w0 = sh.w[4], w1 = sh.w[5], w2 = sh.w[6], w3 = sh.w[7];
         first = (wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2))) + incl - n_mine;
         total = (w0 + w1) + (w2 + w3);
     }
-    for (uint32_t win = 0; win < total; win += EV_CAP) {
-        __syncthreads();  // the previous window is consumed
-        {
-            uint32_t slot = first;  // global index of this thread's next event
-#pragma unroll 1
-            for (uint32_t k = 0; k < 16u; ++k) {  // per voxel: y before z (the reference's order inside a voxel; either way the same winner)
-                if ((evy >> k) & 1u) {
-                    if (slot >= win && slot < win + EV_CAP) {
-                        ev_a[slot - win] = ptr[base_v + k];
-                        ev_b[slot - win] = ptr[base_v + k + 16u];
+    IVX_XT(2);
+    if (total) {  // (workgroup-uniform)
+        // what an event names: the sets' source numbers (fast) or source voxels
+        uint32_t ea[8], eb[8];
+        if (fast) {
+            ivx_row16_gather(spar, pp, 1u, ea);
+            ivx_row16_gather(spar, qq, 1u, eb);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ea[i] = pp[i], eb[i] = qq[i];
+        }
+        uint32_t R[4] = {lane, 64u + lane, 128u + lane, 192u + lane};  // (wave 0's: the sets, see ivx_exact_apply_events)
+        for (uint32_t win = 0; win < total; win += EV_CAP) {
+            __syncthreads();  // the previous window is consumed
+            {
+                uint32_t slot = first;  // global index of this thread's next event
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {  // per voxel: y before z (the reference's order inside a voxel; either way the same winner)
+                    if ((evy >> k) & 1u) {
+                        if (slot >= win && slot < win + EV_CAP) {
+                            ev_a[slot - win] = (uint16_t)ivx_h16(ea, k);
+                            ev_b[slot - win] = (uint16_t)ivx_h16(eb, k);
+                        }
+                        slot += 1u;
                     }
-                    slot += 1u;
+                    if (k < 15 && ((evz >> k) & 1u)) {
+                        if (slot >= win && slot < win + EV_CAP) {
+                            ev_a[slot - win] = (uint16_t)ivx_h16(ea, k);
+                            ev_b[slot - win] = (uint16_t)ivx_h16(ea, k + 1);
+                        }
+                        slot += 1u;
+                    }
                 }
-                if ((evz >> k) & 1u) {
-                    if (slot >= win && slot < win + EV_CAP) {
-                        ev_a[slot - win] = ptr[base_v + k];
-                        ev_b[slot - win] = ptr[base_v + k + 1u];
+            }
+            __syncthreads();
+            if (wave == 0u) {
+                const uint32_t n_win = min(EV_CAP, total - win);
+                if (fast) {
+                    if (n_sources <= 64u) ivx_exact_apply_events<1>(R, ev_a, ev_b, n_win, lane);
+                    else ivx_exact_apply_events<4>(R, ev_a, ev_b, n_win, lane);
+                } else {
+                    for (uint32_t e0 = 0; e0 < n_win; e0 += 64u) {
+                        const bool valid = e0 + lane < n_win;
+                        const uint32_t pa = valid ? ev_a[e0 + lane] : 0u, pb = valid ? ev_b[e0 + lane] : 0u;
+                        for (int guard = 0; guard < 4096; ++guard) {
+                            uint32_t ra = pa, rb = pb;
+                            if (valid) {
+                                // (path halving: a set that keeps winning grows a chain as long as the number of sets it swallowed; a parent only
+                                // ever moves to an ancestor, so the roots — all that the numbering depends on — are untouched)
+                                for (uint32_t p; (p = spar[ra >> 1]) != ra;) {
+                                    const uint32_t gp = spar[p >> 1];
+                                    spar[ra >> 1] = (uint16_t)gp;
+                                    ra = gp;
+                                }
+                                for (uint32_t p; (p = spar[rb >> 1]) != rb;) {
+                                    const uint32_t gp = spar[p >> 1];
+                                    spar[rb >> 1] = (uint16_t)gp;
+                                    rb = gp;
+                                }
+                            }
+                            const bool mine = valid && ra != rb;
+                            const unsigned long long pending = __ballot(mine);
+                            if (!pending) break;
+                            // In event order a's set wins: the root of b's set becomes a LOSER (it gets a parent), and which root a merged set ends up
+                            // with is settled by which of its roots never loses. Several pending events are applied in one round when that cannot
+                            // change any event's loser: an event waits only for an earlier pending event whose loser is its loser or its winner, or
+                            // whose winner is its loser (the first pending event never waits). Events that share a WINNER — the usual case, one
+                            // big set swallowing many small ones — all go at once. Losers of a round are distinct and none is a winner of the
+                            // round, so the forest stays a forest; the sets and their roots are those of the one-at-a-time order.
+                            bool blocked = false;
+                            for (unsigned long long pm = pending; pm; pm &= pm - 1ull) {
+                                const uint32_t j = (uint32_t)__ffsll((long long)pm) - 1u;  // (wave-uniform)
+                                const uint32_t raj = (uint32_t)__builtin_amdgcn_readlane((int)ra, (int)j), rbj = (uint32_t)__builtin_amdgcn_readlane((int)rb, (int)j);
+                                blocked = blocked || (j < lane && (rbj == rb || rbj == ra || raj == rb));
+                            }
+                            if (mine && !blocked) spar[rb >> 1] = (uint16_t)ra;
+                            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                        }
                     }
-                    slot += 1u;
                 }
             }
         }
-        __syncthreads();
-        if (wave == 0u) {
-            const uint32_t n_win = min(EV_CAP, total - win);
-            for (uint32_t e0 = 0; e0 < n_win; e0 += 64u) {
-                const bool valid = e0 + lane < n_win;
-                const uint32_t pa = valid ? ev_a[e0 + lane] : 0u, pb = valid ? ev_b[e0 + lane] : 0u;
-                for (int guard = 0; guard < 4096; ++guard) {
-                    uint32_t ra = pa, rb = pb;
-                    if (valid) {
-                        // (path halving: a set that keeps winning grows a chain as long as the number of sets it swallowed; a parent only
-                        // ever moves to an ancestor, so the roots — all that the numbering depends on — are untouched)
-                        for (uint32_t p; (p = spar[ra >> 1]) != ra;) {
-                            const uint32_t gp = spar[p >> 1];
-                            spar[ra >> 1] = (uint16_t)gp;
-                            ra = gp;
-                        }
-                        for (uint32_t p; (p = spar[rb >> 1]) != rb;) {
-                            const uint32_t gp = spar[p >> 1];
-                            spar[rb >> 1] = (uint16_t)gp;
-                            rb = gp;
-                        }
-                    }
-                    const bool mine = valid && ra != rb;
-                    const unsigned long long pending = __ballot(mine);
-                    if (!pending) break;
-                    // In event order a's set wins: the root of b's set becomes a LOSER (it gets a parent), and which root a merged set ends up
-                    // with is settled by which of its roots never loses. Several pending events are applied in one round when that cannot
-                    // change any event's loser: an event waits only for an earlier pending event whose loser is its loser or its winner, or
-                    // whose winner is its loser (the first pending event never waits). Events that share a WINNER — the usual case, one
-                    // big set swallowing many small ones — all go at once. Losers of a round are distinct and none is a winner of the
-                    // round, so the forest stays a forest; the sets and their roots are those of the one-at-a-time order.
-                    bool blocked = false;
-                    for (unsigned long long pm = pending; pm; pm &= pm - 1ull) {
-                        const uint32_t j = (uint32_t)__ffsll((long long)pm) - 1u;  // (wave-uniform)
-                        const uint32_t raj = (uint32_t)__builtin_amdgcn_readlane((int)ra, (int)j), rbj = (uint32_t)__builtin_amdgcn_readlane((int)rb, (int)j);
-                        blocked = blocked || (j < lane && (rbj == rb || rbj == ra || raj == rb));
-                    }
-                    if (mine && !blocked) spar[rb >> 1] = (uint16_t)ra;
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                }
+        if (fast && wave == 0u) {  // a source's parent: the root source of its set, directly
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t s = 64u * q + lane;
+                if (s < n_sources) spar[src_voxel[s] >> 1] = src_voxel[R[q]];
             }
+        }
+    } else if (fast) {  // no events: every source is its own root
+        uint32_t s = sources;
+        while (s) {
+            const uint32_t k = (uint32_t)__ffs(s) - 1u;
+            s &= s - 1u;
+            spar[(base_v + k) >> 1] = (uint16_t)(base_v + k);
         }
     }
     __syncthreads();
+    IVX_XT(3);
+#ifdef IVX_WG_TRACE
+    if (threadIdx.x == 0) ivx_exact_trace_buf[(chunk & 63u) * 8 + 7] = total | (n_sources << 16);
+#endif
     // flatten: ptr[source] = root source, so that root(v) = ptr[ptr[v]] for every non-empty voxel
     {
         uint32_t s = sources;
@@ -272,24 +394,30 @@ __device__ __forceinline__ void ccl_exact_chunk(CclShared& sh, uint32_t tid, uin
         }
     }
     __syncthreads();
+    IVX_XT(4);
+    // the root and the set id of each of the row's voxels (pp: a voxel's source, or the voxel itself when it is one — or empty, which nobody asks)
+    uint32_t rr[8], idw[8];
+    ivx_row16_gather(ptr, pp, 0u, rr);
+    ivx_row16_gather(spar, rr, 1u, idw);
     // keys: the boundary voxels of this row
     {
         const bool edge_row = ti == 0u || ti == 15u || tj == 0u || tj == 15u;
-        uint32_t bnd = m & (edge_row ? 0xFFFFu : 0x8001u);
+        const uint32_t bnd = m & (edge_row ? 0xFFFFu : 0x8001u);
         uint32_t prev_id = 0xFFFFFFFFu;
-        while (bnd) {
-            const uint32_t k = (uint32_t)__ffs(bnd) - 1u;
-            bnd &= bnd - 1u;
-            const uint32_t v = base_v + k;
-            const uint32_t r = ptr[ptr[v]];
-            const uint32_t id = spar[r >> 1];
-            const bool root_on_boundary = ivx_walk_pos(r) != 0xFFFFu;
-            if (root_on_boundary) {
-                if (r == v) key[id] = ivx_walk_pos(v);  // numbered when the walk reaches the root itself
-            } else if (id != prev_id) {  // (walk positions grow with k inside a row: the first voxel of a stretch of one set has the smallest)
-                atomicMin(&key[id], ivx_walk_pos(v));
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (!edge_row && k != 0 && k != 15) continue;  // (compile-time k: interior rows have their two end voxels only)
+            if ((bnd >> k) & 1u) {
+                const uint32_t v = base_v + (uint32_t)k;
+                const uint32_t r = ivx_h16(rr, k), id = ivx_h16(idw, k) & 255u;
+                const bool root_on_boundary = ivx_walk_pos(r) != 0xFFFFu;
+                if (root_on_boundary) {
+                    if (r == v) key[id] = ivx_walk_pos(v);  // numbered when the walk reaches the root itself
+                } else if (id != prev_id) {  // (walk positions grow with k inside a row: the first voxel of a stretch of one set has the smallest)
+                    atomicMin(&key[id], ivx_walk_pos(v));
+                }
+                prev_id = id;
             }
-            prev_id = id;
         }
     }
     __syncthreads();
@@ -316,6 +444,7 @@ __device__ __forceinline__ void ccl_exact_chunk(CclShared& sh, uint32_t tid, uin
     uint32_t n_boundary = 0;
     {
         uint32_t below = 0;
+#pragma unroll
         for (uint32_t wd = 0; wd < 43u; ++wd) {
             const uint32_t bits = sh.bm[wd];
             n_boundary += __popc(bits);
@@ -330,13 +459,15 @@ __device__ __forceinline__ void ccl_exact_chunk(CclShared& sh, uint32_t tid, uin
     (void)n_inner;
     __syncthreads();
     {
-        uint32_t w4[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        uint32_t mm = m;
-        while (mm) {
-            const uint32_t k = (uint32_t)__ffs(mm) - 1u;
-            mm &= mm - 1u;
-            const uint32_t lab = key[spar[ptr[ptr[base_v + k]] >> 1]];
-            w4[k >> 2] = (w4[k >> 2] & ~(0xFFu << (8u * (k & 3u)))) | (lab << (8u * (k & 3u)));
+        uint32_t lab[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lab[k] = key[ivx_h16(idw, k) & 255u];
+        uint32_t w4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            w4[q] = 0u;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) w4[q] |= (((m >> (4 * q + b)) & 1u) ? (lab[4 * q + b] & 0xFFu) : 0xFFu) << (8 * b);
         }
         *reinterpret_cast<uint4*>(labels + (size_t)chunk * IVX_CHUNK_VOXELS + (size_t)tid * 16) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
     }
@@ -348,6 +479,7 @@ __device__ __forceinline__ void ccl_exact_chunk(CclShared& sh, uint32_t tid, uin
     rparent[(size_t)chunk * 256 + tid] = tid < total_sets ? chunk * 256u + tid : NODE_NONE;
     rc_out = total_sets;
     brc_out = n_boundary < 254u ? n_boundary : 254u;
+    IVX_XT(5);
     __syncthreads();  // sh is reused by the caller's next chunk
 }
 

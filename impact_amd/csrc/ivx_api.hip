@@ -1385,6 +1385,10 @@ int ivx_copy_polyhedra(ivx_grid* parent, const float* planes4, const uint32_t* p
             ivx_set_error("ivx_copy_polyhedra: a chunk has more than 254 local regions");
             return fail(IVX_ERR_CAPACITY);
         }
+        if (sc[1] & 8u) {
+            ivx_set_error("ivx_copy_polyhedra: the region merge gave up waiting for the numbering of the multi-region chunks (k_step_post2)");
+            return fail(IVX_ERR_HIP);
+        }
         c->region_count = sc[0];
         c->regions_valid = 1;
         c->mesh_valid = 0;
@@ -2738,6 +2742,7 @@ int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out) {
     g->eval_len_pending = 0;
     if (stages & IVX_STAGE_REGIONS) {
         IVX_REQUIRE((sc[1] & 1u) == 0, IVX_ERR_CAPACITY, "ivx_voxel_step: a chunk has more than 254 local regions");
+        IVX_REQUIRE((sc[1] & 8u) == 0, IVX_ERR_HIP, "ivx_voxel_step: the region merge gave up waiting for the numbering of the multi-region chunks (k_step_post2)");
         g->region_count = sc[0];
         g->regions_valid = 1;
         out->region_count = sc[0];

@@ -5,14 +5,13 @@
 // that do not depend on each other are therefore hosted as ROLES of one launch: a role owns a range of the launch's block
 // indices and runs exactly the code of its stand-alone kernel (ccl_roles.hpp, sn_roles.hpp, table_roles.hpp).
 //
-//   k_step_post1  after k_derive:   mesher count | region merge by chunk columns | exact local numbering | occupied (per-block
-//                                   slots) | moment partial sums
-//   k_step_post2  after post1:      region merge of multi-region chunks | mesher scan | moments final | occupied final
+//   k_step_post1  after k_derive:   mesher count | region merge by chunk columns | occupied (per-block slots) | moment partial sums
+//   k_step_post2  after post1:      exact local numbering -> region merge of multi-region chunks | mesher scan | moments final | occupied final
 //                                   (+ the step's results when the call has no region stage)
 //   k_step_emit   after post2:      region forest flatten | mesher emit
 //   k_step_assign after emit:       component ids (+ the step's results into the host-mapped block)
 //
-// Dependencies inside a launch: none (roles only read what earlier launches wrote). The scratch words the stages start from are
+// Dependencies inside a launch: none (roles only read what earlier launches wrote) — but for one, in k_step_post2 (see step_post2_body). The scratch words the stages start from are
 // preset by the step's first kernel (k_sdf_super or k_chunk_pre), not by a launch of their own.
 #include "ccl_roles.hpp"
 #include "sn_roles.hpp"
@@ -99,12 +98,14 @@ __device__ __forceinline__ sn::SnParams sn_params(const StepArgs& a) {
     return p;
 }
 
-// roles: 0 mesher count (list-driven), 1 region merge by columns, 2 exact numbering, 3 occupied slots, 4 moment partial sums,
+// roles: 0 mesher count (list-driven), 1 region merge by columns, 3 occupied slots, 4 moment partial sums,
 // 5 (edit path) mesh needs of the chunks the edit invalidates
 // (amdgpu_waves_per_eu(8): 64 VGPRs. The count role is a latency-bound gather with little state and wants all eight workgroups a CU can
-// hold; the exact numbering, which would take 127 registers, spills ~60 words instead — measured: count pass -3 us, edit leg unchanged.)
+// hold. The exact numbering of multi-region chunks was a role of this launch until round 4: held to 64 registers it spilled 160 words and
+// a chunk took 15-90 us — it now leads k_step_post2, see there.)
 __device__ __forceinline__ void step_post1_body(const StepArgs& a, uint32_t b, uint32_t) {
-    __shared__ CclShared sh;  // (the exact numbering's block; the count role borrows its first 5 KB)
+    __shared__ uint32_t sh_words[4 * sn::NROWS + 16];  // (tile sign rows: a wave each in the count role, one set in the needs role)
+    struct { uint32_t* par; } sh{sh_words};
     if (b < a.nb[0]) {
         sn::role_sn_count_waves(b, a.nb[0], sn_params(a), a.counts, a.sn_group_sums, a.work_count, a.active_list, sh.par, a.count_run);
         return;
@@ -115,11 +116,6 @@ __device__ __forceinline__ void step_post1_body(const StepArgs& a, uint32_t b, u
         return;
     }
     b -= a.nb[1];
-    if (b < a.nb[2]) {
-        role_ccl_local_exact(b, a.nb[2], sh, a.flags, a.labels, a.info, a.rparent, a.rscalar, a.multi_list);
-        return;
-    }
-    b -= a.nb[2];
     if (b < a.nb[3]) {
         role_occupied_partial(b, a.g.cx, a.g.cy, a.g.cz, a.bbox, a.occ_part);
         return;
@@ -135,10 +131,43 @@ __device__ __forceinline__ void step_post1_body(const StepArgs& a, uint32_t b, u
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_step_post1(StepArgs a) { step_post1_body(a, blockIdx.x, gridDim.x); }
 IVX_MANY_TWIN(k_step_post1_many, StepArgs, step_post1_body, __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))))
 
-// roles: 0 region merge of multi-region chunks, 1 mesher scan, 2 moments final (1 block), 3 occupied final (1 block),
-// 4 the slab protocol's face pairs (component pairs across the upper x face, from the neighbour's ids of the exchange before)
+// roles: 5 (the launch's FIRST blocks) exact numbering of the multi-region chunks, 0 region merge of multi-region chunks, 1 mesher scan,
+// 2 moments final (1 block), 3 occupied final (1 block), 4 the slab protocol's face pairs (component pairs across the upper x face, from the
+// neighbour's ids of the exchange before).
+// The one dependency inside a launch: the merge of the multi-region chunks reads the labels and region tables the exact numbering writes.
+// The numbering's blocks are the first of the grid — workgroups start in index order, and they wait for nothing — and each adds one to
+// rscalar[3] (zero at the start of a step, with the other region scalars) behind a release fence when it is through; a merge block that has
+// work (rscalar[2] != 0: most steps have no such chunk and nobody waits) spins on that word until all have, bounded, then acquires. The
+// numbering needs ~120 registers; this launch is a few hundred blocks of table work and can afford them, k_step_post1 (where the role lived,
+// spilling, for a tenth of the speed) cannot.
 __device__ __forceinline__ void step_post2_body(const StepArgs& a, uint32_t b, uint32_t) {
+    if (b < a.nb[5]) {
+        __shared__ CclShared sh;
+        if (a.rscalar[2] == 0u) return;  // (no such chunk, as in most steps: nobody waits for this block's word either)
+        role_ccl_local_exact(b, a.nb[5], sh, a.flags, a.labels, a.info, a.rparent, a.rscalar, a.multi_list);
+        __syncthreads();
+        if (threadIdx.x == 0u) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(a.rscalar + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    b -= a.nb[5];
     if (b < a.nb[0]) {
+        if (a.nb[5] && __hip_atomic_load(a.rscalar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            if (threadIdx.x == 0u) {
+                uint32_t spins = 0;
+                while (__hip_atomic_load(a.rscalar + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.nb[5]) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1u << 24)) {  // (seconds: something is badly wrong — flag the step instead of hanging the queue)
+                        atomicOr(a.rscalar + 1, 8u);
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
         role_ccl_merge_multi(b, a.nb[0], a.g, a.labels, a.rparent, a.rscalar, a.multi_list);
         return;
     }
@@ -286,10 +315,7 @@ int ivx_launch_step_post1(ivx_grid* g, uint32_t stages) {
         a.count_run = sn::ivx_count_run(g);
         a.nb[0] = (ivx_list_grid(g) + 4u * a.count_run - 1u) / (4u * a.count_run);
     }
-    if (stages & IVX_STAGE_REGIONS) {
-        a.nb[1] = (g->cc[0] * g->cc[1] + 3u) / 4u;
-        a.nb[2] = g->n_chunks < 128u ? g->n_chunks : 128u;
-    }
+    if (stages & IVX_STAGE_REGIONS) a.nb[1] = (g->cc[0] * g->cc[1] + 3u) / 4u;
     if (stages & IVX_STAGE_OCCUPIED) a.nb[3] = groups;
     if (stages & IVX_STAGE_INERTIA) {
         a.nb[4] = groups < (uint32_t)g->partial_blocks ? groups : (uint32_t)g->partial_blocks;
@@ -305,7 +331,7 @@ int ivx_launch_step_post1(ivx_grid* g, uint32_t stages) {
         a.nb[5] = a.needs_box.b_cc[0] * a.needs_box.b_cc[1] * a.needs_box.b_cc[2];
         g->post1_needs_out = nullptr;
     }
-    const uint32_t total = a.nb[0] + a.nb[1] + a.nb[2] + a.nb[3] + a.nb[4] + a.nb[5];
+    const uint32_t total = a.nb[0] + a.nb[1] + a.nb[3] + a.nb[4] + a.nb[5];
     if (total == 0) return IVX_OK;
     if (!ivx_many_try(IVX_MK_POST1, total, a)) IVX_KLAUNCH(k_step_post1, dim3(total), dim3(256), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
@@ -329,14 +355,20 @@ int ivx_launch_step_post2(ivx_grid* g, uint32_t stages, const uint16_t* face_pai
         a.nb[4] = (g->cc[1] * g->cc[2] + FACE_COLS - 1u) / FACE_COLS;
     }
     const uint32_t groups = (g->n_chunks + 255u) / 256u;
-    if (stages & IVX_STAGE_REGIONS) a.nb[0] = g->n_chunks < 64u ? g->n_chunks : 64u;
+    if (stages & IVX_STAGE_REGIONS) {
+        a.nb[0] = g->n_chunks < 64u ? g->n_chunks : 64u;
+        // (the exact numbering: the launch's first blocks, see step_post2_body; a block per sixteen chunks of the grid, 8..128 — a small
+        // fragment rarely has more than a handful of such chunks, and with hundreds of objects in one launch idle blocks add up)
+        const uint32_t want = g->n_chunks / 16u;
+        a.nb[5] = want < 8u ? (g->n_chunks < 8u ? g->n_chunks : 8u) : (want > 128u ? 128u : want);
+    }
     if (stages & IVX_STAGE_REMESH) a.nb[1] = groups;
     if (stages & IVX_STAGE_INERTIA) {
         a.nb[2] = 1;
         a.n_partials = groups < (uint32_t)g->partial_blocks ? groups : (uint32_t)g->partial_blocks;
     }
     if (stages & IVX_STAGE_OCCUPIED) a.nb[3] = 1;
-    const uint32_t total = a.nb[0] + a.nb[1] + a.nb[2] + a.nb[3] + a.nb[4];
+    const uint32_t total = a.nb[0] + a.nb[1] + a.nb[2] + a.nb[3] + a.nb[4] + a.nb[5];
     if (total == 0) return IVX_OK;
     if (!ivx_many_try(IVX_MK_POST2, total, a)) IVX_KLAUNCH(k_step_post2, dim3(total), dim3(256), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
@@ -385,3 +417,10 @@ int ivx_launch_step_gather(ivx_grid* g) {
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
+
+#ifdef IVX_WG_TRACE
+// developer build: the probes of the exact numbering as k_step_post2 last ran it (64 chunks x 8 words, chunk & 63)
+extern "C" int ivx_debug_exact_trace(unsigned long long* out512) {
+    return hipMemcpyFromSymbol(out512, HIP_SYMBOL(ivx_exact_trace_buf), 512 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
