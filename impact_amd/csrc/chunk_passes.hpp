@@ -114,7 +114,7 @@ __device__ __forceinline__ void ivx_row16_gather(const uint16_t* table, const ui
 // (assign_parent, split_detection.rs:1776-1782): every source of b's set takes a's root — one compare-and-select over the lanes, no chain to
 // follow, nothing in memory. Per round every lane looks up its event's two sets (a lane permute each); the EARLIEST event between different
 // sets is the next the sequential order would apply (the ones before it join equal sets: nothing to do), so it is applied and the lanes
-// look again: one round per effective merge, ~100 cycles each. (The union-find in LDS this replaces — finds with path halving, a ballot
+// follow the merge in their own registers: one round per effective merge, a few dozen cycles each. (The union-find in LDS this replaces — finds with path halving, a ballot
 // and a conflict scan among the pending lanes per round — took 63 us for a chunk of 65 sources and 796 events; this takes ~5.)
 template <int K>
 __device__ __forceinline__ uint32_t ivx_exact_set_of(const uint32_t* R, uint32_t s) {
@@ -131,12 +131,16 @@ __device__ __forceinline__ void ivx_exact_apply_events(uint32_t* R, const uint16
     for (uint32_t e0 = 0; e0 < n_win; e0 += 64u) {
         const bool valid = e0 + lane < n_win;
         const uint32_t sa = valid ? ev_a[e0 + lane] : 0u, sb = valid ? ev_b[e0 + lane] : 0u;
+        // (the lanes look their events' sets up once per batch — a lane permute per register of R — and from then on follow the merges
+        // themselves: whoever holds the loser holds the winner afterwards)
+        uint32_t ra = ivx_exact_set_of<K>(R, sa), rb = ivx_exact_set_of<K>(R, sb);
         for (int guard = 0; guard < 64 * K + 2; ++guard) {  // (a merge takes a set away: at most 64 K - 1 of them in all)
-            const uint32_t ra = ivx_exact_set_of<K>(R, sa), rb = ivx_exact_set_of<K>(R, sb);
             const unsigned long long pending = __ballot(valid && ra != rb);
             if (!pending) break;
             const int j = __ffsll((long long)pending) - 1;  // (wave-uniform)
             const uint32_t win = (uint32_t)__builtin_amdgcn_readlane((int)ra, j), lose = (uint32_t)__builtin_amdgcn_readlane((int)rb, j);
+            ra = ra == lose ? win : ra;
+            rb = rb == lose ? win : rb;
 #pragma unroll
             for (int q = 0; q < K; ++q) R[q] = R[q] == lose ? win : R[q];
         }
@@ -229,7 +233,11 @@ __device__ __forceinline__ void ccl_exact_chunk(CclShared& sh, uint32_t tid, uin
     ivx_row16_load(ptr + (tj < 15u ? base_v + 16u : base_v), qq);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        if (((ev_y_geom >> k) & 1u) && ivx_h16(pp, k) != ivx_h16(qq, k)) evy |= 1u << k;
+        // (an event between the same two basins as the row's event just before it joins what that one joined: dropped — along the contact
+        // of two basins every voxel pair would list one)
+        if (((ev_y_geom >> k) & 1u) && ivx_h16(pp, k) != ivx_h16(qq, k) &&
+            !(k > 0 && ((evy >> (k > 0 ? k - 1 : 0)) & 1u) && ivx_h16(pp, k) == ivx_h16(pp, k > 0 ? k - 1 : 0) && ivx_h16(qq, k) == ivx_h16(qq, k > 0 ? k - 1 : 0)))
+            evy |= 1u << k;
         if (k < 15 && ((ev_z_geom >> k) & 1u) && ivx_h16(pp, k) != ivx_h16(pp, k + 1)) evz |= 1u << k;
     }
     uint32_t n_mine = __popc(evy) + __popc(evz), first, total;

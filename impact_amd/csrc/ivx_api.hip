@@ -533,6 +533,8 @@ void* ivx_grid_device_ptr(ivx_grid* g, int which) {
 #endif
         case 7: return g->samp_len;  // developer tools (tools/prog_stats.py): per-chunk compact program lengths, then the three list counters and lists
         case 8: return g->samp_ops;  // ... and the programs, OP_CAP (128) uint2 per chunk
+        case 10: return g->sn_hard;  // ... and which (entries of the emit list)
+        case 9: return ivx_sn_hard_count(g);  // developer tools: [0] how many chunks the mesher's last main pass handed to the general pass
         default: return nullptr;
     }
 }
@@ -677,8 +679,18 @@ static int mesh_sync_enqueue(ivx_grid* g, const uint8_t* invalidated_chunks, con
     static thread_local std::vector<uint32_t> list, needs, dirty_slots, rec_chunk, slots;
     static thread_local std::vector<char> stage;
     list.clear();
-    for (uint32_t c = 0; c < g->n_chunks; ++c)  // chunk-linear order (the reference walks a hash set: unpinned)
-        if (invalidated_chunks[c]) list.push_back(c);
+    {   // chunk-linear order (the reference walks a hash set: unpinned); eight flags a look — nearly all of them are zero
+        uint32_t c = 0;
+        for (; c + 8u <= g->n_chunks; c += 8u) {
+            uint64_t w;
+            memcpy(&w, invalidated_chunks + c, 8);
+            if (!w) continue;
+            for (uint32_t b = 0; b < 8u; ++b)
+                if (invalidated_chunks[c + b]) list.push_back(c + b);
+        }
+        for (; c < g->n_chunks; ++c)
+            if (invalidated_chunks[c]) list.push_back(c);
+    }
     needs.assign(3 * list.size(), 0u);
     bool cached = g->needs_current != 0;
     for (size_t e = 0; e < list.size() && cached; ++e) cached = edit_needs_lookup(g, list[e], &needs[3 * e]);
@@ -751,27 +763,41 @@ static int mesh_sync_enqueue(ivx_grid* g, const uint8_t* invalidated_chunks, con
     m->indices.merge_consecutive();
     if ((rc = ensure_mesh_capacity_keep(g, m->total_vertices, m->total_indices, m->table.size()))) return rc;
     lap_(3);
+    // the device table: the emit pass writes the re-meshed chunks' entries; entries a removal moved are patched from the host mirror — by the
+    // emit pass's first workgroup when there is one (they ride in its upload), else by a small copy each
+    size_t n_patch = 0;
+    for (uint32_t slot : dirty_slots) n_patch += slot < m->table.size() ? 1u : 0u;
     if (!recs.empty()) {
         // (slots are final only now: a removal after a write may have moved the written entry)
         slots.resize(recs.size());
         for (size_t r = 0; r < recs.size(); ++r) slots[r] = m->slot_of.at(rec_chunk[r]);
-        const size_t off_slots = 16 + recs.size() * sizeof(Rec), total = off_slots + recs.size() * 4;
+        const size_t off_slots = 16 + recs.size() * sizeof(Rec), off_pslots = off_slots + recs.size() * 4;
+        const size_t off_pent = (off_pslots + n_patch * 4 + 15) & ~(size_t)15, total = off_pent + n_patch * sizeof(ivx_submesh);
         if ((rc = ensure_dev_scratch(g, total))) return rc;
         stage.assign(total, 0);
         const uint32_t n = (uint32_t)recs.size();
         memcpy(stage.data(), &n, 4);
         memcpy(stage.data() + 16, recs.data(), recs.size() * sizeof(Rec));
         memcpy(stage.data() + off_slots, slots.data(), slots.size() * 4);
+        size_t e = 0;
+        for (uint32_t slot : dirty_slots)
+            if (slot < m->table.size()) {
+                memcpy(stage.data() + off_pslots + 4 * e, &slot, 4);
+                memcpy(stage.data() + off_pent + e * sizeof(ivx_submesh), &m->table[slot], sizeof(ivx_submesh));
+                e += 1;
+            }
         char* base = static_cast<char*>(g->dev_scratch);
         if ((rc = edit_sync_upload(g, stage.data(), total, base))) return rc;
-        if ((rc = ivx_launch_sn_emit_list(g, n, reinterpret_cast<const uint32_t*>(base), base + 16, reinterpret_cast<const uint32_t*>(base + off_slots)))) return rc;
+        if ((rc = ivx_launch_sn_emit_list(g, n, reinterpret_cast<const uint32_t*>(base), base + 16, reinterpret_cast<const uint32_t*>(base + off_slots), (uint32_t)n_patch,
+                                          base + off_pent, reinterpret_cast<const uint32_t*>(base + off_pslots))))
+            return rc;
     }
     lap_(4);
-    // the device table: the emit pass wrote the re-meshed chunks' entries; entries a removal moved are patched from the host mirror
     (void)table_before;
-    for (uint32_t slot : dirty_slots)
-        if (slot < m->table.size() && !ivx_many_upload(g->submeshes + slot, &m->table[slot], sizeof(ivx_submesh)))
-            IVX_HIP_CHECK(ivx_memcpy_async(g->submeshes + slot, &m->table[slot], sizeof(ivx_submesh), hipMemcpyHostToDevice, g->ctx->stream));
+    if (recs.empty())
+        for (uint32_t slot : dirty_slots)
+            if (slot < m->table.size() && !ivx_many_upload(g->submeshes + slot, &m->table[slot], sizeof(ivx_submesh)))
+                IVX_HIP_CHECK(ivx_memcpy_async(g->submeshes + slot, &m->table[slot], sizeof(ivx_submesh), hipMemcpyHostToDevice, g->ctx->stream));
     g->mesh_counts.n_vertices = (uint32_t)m->total_vertices;
     g->mesh_counts.n_indices = (uint32_t)m->total_indices;
     g->mesh_counts.n_submeshes = (uint32_t)m->table.size();
@@ -779,8 +805,9 @@ static int mesh_sync_enqueue(ivx_grid* g, const uint8_t* invalidated_chunks, con
     m->serial = g->mesh_serial;
     edit_sync_mark(g, 1);
     lap_(5);
-    if (trace_ && ++calls_ % 81 == 0) {
-        fprintf(stderr, "[ivx many]   sync enqueue laps (us per 81): setup %.1f list+needs %.1f allocator %.1f capacity %.1f upload+emit %.1f tail %.1f\n", acc_[0], acc_[1], acc_[2],
+    static const int period_ = trace_ && atoi(getenv("IVX_MANY_TRACE")) > 1 ? atoi(getenv("IVX_MANY_TRACE")) : 81;
+    if (trace_ && ++calls_ % period_ == 0) {
+        fprintf(stderr, "[ivx many]   sync enqueue laps (us per period): setup %.1f list+needs %.1f allocator %.1f capacity %.1f upload+emit %.1f tail %.1f\n", acc_[0], acc_[1], acc_[2],
                 acc_[3], acc_[4], acc_[5]);
         for (double& a : acc_) a = 0.0;
     }

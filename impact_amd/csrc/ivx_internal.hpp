@@ -147,6 +147,7 @@ struct ivx_grid {
     uint32_t gather_copy_words;
     uint64_t gather_flush_id;      // the recorder's flush count when the gather was recorded (many.hpp)
     int gather_launched;           // the step's gather is on the stream (or recorded): ivx_voxel_step_collect only waits
+    int sn_tail_zero;  // the mesher's hand-off counter, list cursors and census word (IVX_SN_TAIL_WORDS) are known to be zero (ivx_launch_sn_emit_list)
     int needs_current;             // edit->needs holds what the last edit's invalidated chunks' meshes need (no voxel has changed since)
     uint32_t stage_timing_off;  // timed slots WITHOUT event records (ivx_grid_set_stage_timing; zero-initialised: every slot is timed)
     float* dens_call;       // [256] a density table handed to one call (ivx_inertia, ivx_regions_describe) that is not the resident one
@@ -418,7 +419,8 @@ int ivx_launch_clip(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], con
 int ivx_launch_split_repack(ivx_grid* src, ivx_grid* dst, const uint32_t off[3]);
 void ivx_submesh_manager_free(struct ivx_submesh_manager* m);
 void ivx_probe_manager_free(struct ivx_probe_manager* m);
-int ivx_launch_sn_emit_list(ivx_grid* g, uint32_t n_records, const uint32_t* d_count, const void* d_records, const uint32_t* d_slots);
+int ivx_launch_sn_emit_list(ivx_grid* g, uint32_t n_records, const uint32_t* d_count, const void* d_records, const uint32_t* d_slots, uint32_t n_patch = 0,
+                            const void* d_patch_entries = nullptr, const uint32_t* d_patch_slots = nullptr);
 int ivx_launch_probe_select(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, uint32_t* d_corner_list, uint32_t* d_sel, uint32_t* d_counts, uint32_t* d_offsets,
                             uint32_t* d_err, const uint32_t* d_slots);
 int ivx_launch_probe_gather(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, const uint32_t* d_sel, const uint32_t* d_counts, const uint32_t* d_offsets,

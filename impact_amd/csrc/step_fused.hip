@@ -378,7 +378,10 @@ int ivx_launch_step_post2(ivx_grid* g, uint32_t stages, const uint16_t* face_pai
 int ivx_launch_step_emit(ivx_grid* g, uint32_t stages, bool general_in_assign, void* slab_record, bool record_has_pairs) {
     StepArgs a = make_args(g);
     if (stages & IVX_STAGE_REGIONS) a.nb[0] = (g->n_chunks + 255u) / 256u;
-    if (stages & IVX_STAGE_REMESH) a.nb[1] = sn::ivx_emit_grid(g, g->n_chunks);
+    if (stages & IVX_STAGE_REMESH) {
+        a.nb[1] = sn::ivx_emit_grid(g, g->n_chunks);
+        g->sn_tail_zero = 0;  // (the mesher's counter and cursors: the next incremental remesh clears them itself)
+    }
     if (slab_record) {
         face_pair_args(a, g, record_has_pairs ? reinterpret_cast<const uint16_t*>(g->pairs_dev) /* (any non-null value: only the count pointer matters) */ : nullptr);
         a.record = static_cast<unsigned long long*>(slab_record);

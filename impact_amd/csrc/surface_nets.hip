@@ -79,15 +79,39 @@ struct SnEmitArgs {
     uint32_t* hard_count;
     uint32_t* hard_list;
     uint32_t* cursor;
-    uint32_t vcap, icap, scap, pad_;
+    uint32_t vcap, icap, scap, n_patch;
+    // (incremental remesh) entries of the submesh table that a removal moved: `n_patch` of them, written to their slots by the main pass's first
+    // block — five small copies of their own cost the host 20 us
+    const ivx_submesh* patch_entries;
+    const uint32_t* patch_slots;
 };
 __device__ __forceinline__ void sn_emit_slots_body(const SnEmitArgs& a, uint32_t bid, uint32_t nb) {
+    if (bid == 0u && a.n_patch) {
+        constexpr uint32_t W = (uint32_t)(sizeof(ivx_submesh) / sizeof(uint32_t));
+        for (uint32_t i = threadIdx.x; i < a.n_patch * W; i += 256u)
+            reinterpret_cast<uint32_t*>(a.submeshes + a.patch_slots[i / W])[i % W] = reinterpret_cast<const uint32_t*>(a.patch_entries)[i];
+    }
     role_sn_emit<true>(bid, nb, a.p, a.positions, a.normals, a.indices, a.imats, a.submeshes, a.emit_count, a.emit_items, a.vcap, a.icap, a.scap, a.slots, a.hard_count,
                        a.hard_list, a.cursor);
 }
 __device__ __forceinline__ void sn_emit_general_slots_body(const SnEmitArgs& a, uint32_t bid, uint32_t nb) {
     role_sn_emit_general<true>(bid, nb, a.p, a.positions, a.normals, a.indices, a.imats, a.vmats, a.submeshes, a.emit_count, a.emit_items, a.vcap, a.icap, a.scap, a.slots,
                                a.hard_count, a.hard_list);
+    // The last workgroup through leaves the counter, the main pass's list cursors and its own census word zero for the next incremental
+    // remesh (every workgroup has read the counter by then): that one's host does not enqueue a fill of 288 words ahead of its main pass.
+    __shared__ uint32_t s_last;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        __threadfence();
+        s_last = atomicAdd(a.hard_count + (IVX_SN_TAIL_WORDS - 1u), 1u) == nb - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last)
+        for (uint32_t w = threadIdx.x; w < IVX_SN_TAIL_WORDS; w += 256u) a.hard_count[w] = 0u;
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_sn_emit_slots(SnEmitArgs a) { sn_emit_slots_body(a, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_sn_emit_general_slots(SnEmitArgs a) {
+    sn_emit_general_slots_body(a, blockIdx.x, gridDim.x);
 }
 IVX_MANY_TWIN(k_sn_emit_slots_many, SnEmitArgs, sn_emit_slots_body, __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))))
 IVX_MANY_TWIN(k_sn_emit_general_slots_many, SnEmitArgs, sn_emit_general_slots_body, __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))))
@@ -223,6 +247,7 @@ int ivx_launch_sn_scan(ivx_grid* g) {
 uint32_t* ivx_sn_hard_count(ivx_grid* g) { return g->group_sums + 4 * (size_t)((g->n_chunks + 255u) / 256u); }
 
 int ivx_launch_sn_emit(ivx_grid* g) {
+    g->sn_tail_zero = 0;
     // (stand-alone path, also the re-emit after the buffers grew: the two words may hold an earlier emit's counts; the fused step presets them)
     IVX_HIP_CHECK(ivx_memset_async(ivx_sn_hard_count(g), 0, IVX_SN_TAIL_WORDS * sizeof(uint32_t), g->ctx->stream));
     const uint32_t blocks = ivx_emit_grid(g, g->n_chunks);
@@ -246,26 +271,26 @@ int ivx_launch_sn_emit_general(ivx_grid* g) {
 
 // incremental remesh: emit the listed chunks only — records (chunk, vertex offset, index offset, vertices | quads << 16) and submesh slots come
 // from the host-side submesh manager; d_count holds their number
-int ivx_launch_sn_emit_list(ivx_grid* g, uint32_t n_records, const uint32_t* d_count, const void* d_records, const uint32_t* d_slots) {
+int ivx_launch_sn_emit_list(ivx_grid* g, uint32_t n_records, const uint32_t* d_count, const void* d_records, const uint32_t* d_slots, uint32_t n_patch,
+                            const void* d_patch_entries, const uint32_t* d_patch_slots) {
     if (n_records == 0) return IVX_OK;
-    if (!ivx_many_zero(ivx_sn_hard_count(g), IVX_SN_TAIL_WORDS * sizeof(uint32_t))) {
+    // (the general pass of the incremental remesh before this one left the words zero, unless a step's mesher has used them since)
+    if (!g->sn_tail_zero && !ivx_many_zero(ivx_sn_hard_count(g), IVX_SN_TAIL_WORDS * sizeof(uint32_t))) {
         (void)ivx_many_break();
         IVX_HIP_CHECK(ivx_memset_async(ivx_sn_hard_count(g), 0, IVX_SN_TAIL_WORDS * sizeof(uint32_t), g->ctx->stream));
     }
+    g->sn_tail_zero = 1;
     SnEmitArgs a;
     memset(&a, 0, sizeof(a));
     a.p = make_params(g), a.positions = g->positions, a.normals = g->normals, a.indices = g->indices;
     a.imats = reinterpret_cast<unsigned long long*>(g->index_materials), a.vmats = reinterpret_cast<uint4*>(g->vertex_materials), a.submeshes = g->submeshes;
     a.emit_count = d_count, a.emit_items = reinterpret_cast<const uint4*>(d_records), a.slots = d_slots, a.hard_count = ivx_sn_hard_count(g), a.hard_list = g->sn_hard;
     a.cursor = ivx_sn_hard_count(g) + 1, a.vcap = (uint32_t)g->vcap, a.icap = (uint32_t)g->icap, a.scap = (uint32_t)g->scap;
+    a.n_patch = n_patch, a.patch_entries = static_cast<const ivx_submesh*>(d_patch_entries), a.patch_slots = d_patch_slots;
     const uint32_t b_main = ivx_emit_grid(g, n_records), b_gen = ivx_emit_general_grid(g, n_records);
-    if (!ivx_many_try(IVX_MK_SN_EMIT_SLOTS, b_main, a))
-        IVX_KLAUNCH(k_sn_emit<true>, dim3(b_main), dim3(256), 0, g->ctx->stream, a.p, a.positions, a.normals, a.indices, a.imats, a.submeshes, a.emit_count, a.emit_items,
-                    a.vcap, a.icap, a.scap, a.slots, a.hard_count, a.hard_list, a.cursor);
+    if (!ivx_many_try(IVX_MK_SN_EMIT_SLOTS, b_main, a)) IVX_KLAUNCH(k_sn_emit_slots, dim3(b_main), dim3(256), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
-    if (!ivx_many_try(IVX_MK_SN_EMIT_GENERAL_SLOTS, b_gen, a))
-        IVX_KLAUNCH(k_sn_emit_general<true>, dim3(b_gen), dim3(256), 0, g->ctx->stream, a.p, a.positions, a.normals, a.indices, a.imats, a.vmats, a.submeshes, a.emit_count,
-                    a.emit_items, a.vcap, a.icap, a.scap, a.slots, a.hard_count, a.hard_list);
+    if (!ivx_many_try(IVX_MK_SN_EMIT_GENERAL_SLOTS, b_gen, a)) IVX_KLAUNCH(k_sn_emit_general_slots, dim3(b_gen), dim3(256), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
