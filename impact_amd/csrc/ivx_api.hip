@@ -2982,6 +2982,21 @@ int ivx_absorb_sphere_many(ivx_grid* const* grids, size_t n, const float* center
     for (size_t i = 0; i < n; ++i) {
         uint32_t occ[12];
         if (grids[i]->regions_valid && (rc = reference_occupied(grids[i], occ))) return rc;
+        // (... and the object's edit buffers, which its first edit would otherwise allocate — with a wait on the stream — in the middle of the batch)
+        ivx_edit_state* e = edit_state(grids[i]);
+        IVX_REQUIRE(e, IVX_ERR_CAPACITY, "ivx_absorb_sphere_many: out of host memory");
+        if (!e->d_results) {
+            const size_t cap = 1 << 16;
+            IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->d_results), cap));
+            IVX_HIP_CHECK(ivx_memset_async(e->d_results, 0, cap, grids[i]->ctx->stream));
+            e->d_results_bytes = cap;
+        }
+        if (!e->pinned) {
+            const size_t cap = 1 << 16;
+            IVX_HIP_CHECK(hipHostMalloc(&e->pinned, cap, hipHostMallocMapped));
+            IVX_HIP_CHECK(hipHostGetDevicePointer(&e->pinned_dev, e->pinned, 0));
+            e->pinned_bytes = cap;
+        }
     }
     clk.lap("prepare");
     if ((rc = many_phase(grids, n, [&](size_t i) {

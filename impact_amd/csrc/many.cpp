@@ -1,6 +1,7 @@
 // The recorder behind ivx_many_begin / ivx_many_flush (many.hpp): per object of the batch the chain of captured launches; the flush merges,
 // front by front, the entries of one kernel into one launch of its twin.
 #include "many.hpp"
+#include <execinfo.h>
 
 #include <algorithm>
 #include <new>
@@ -212,6 +213,14 @@ bool ivx_many_capture(int kernel, uint32_t blocks, const void* args, uint32_t ar
 int ivx_many_break() {
     Recorder* r = t_rec;
     if (!r || !r->on || r->n_entries == 0) return IVX_OK;
+    // developer aid (IVX_MANY_TRACE=3): who cuts a batch short — a stream operation without a twin in the middle of a recorded phase
+    static const bool where = getenv("IVX_MANY_TRACE") && atoi(getenv("IVX_MANY_TRACE")) == 3;
+    if (where) {
+        void* frames[12];
+        const int n = backtrace(frames, 12);
+        fprintf(stderr, "[ivx many] break with %u recorded launches, from:\n", (unsigned)r->n_entries);
+        backtrace_symbols_fd(frames, n, 2);
+    }
     return flush_recorded(r);
 }
 

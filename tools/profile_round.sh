@@ -27,5 +27,11 @@ for wl in headline dense; do
   python tools/pmc_valu.py "$(ls "$out"/pmc_valu_$wl/*.db | tail -1)" "$out/pmc_valu_$wl.json" $NST
   rm -rf "$out/trace_$wl" "$out/pmc_fetch_$wl" "$out/pmc_write_$wl" "$out/pmc_valu_$wl"
 done
+# the edit path, the incremental remesh and the many-object frame under the kernel trace (their own timing lines + kernel tables)
+bash tools/prof_edit.sh $tag > "$out/prof_edit.log" 2>&1
+bash tools/prof_sync.sh $tag > "$out/prof_sync.log" 2>&1
+bash tools/prof_many.sh $tag > "$out/prof_many.log" 2>&1
+python3 tools/time_pile.py > "$out/${tag}_time_pile.log" 2>&1
+grep -h "C call\|edit enqueue\|^frame\|step_many" "$out/time_edit.log" "$out/time_sync.log" "$out/time_many.log"
 head -14 "$out/${tag}_kernel_stats_step_only_headline.csv"
 head -14 "$out/${tag}_kernel_stats_step_only_dense.csv"
