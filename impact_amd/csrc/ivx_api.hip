@@ -2908,10 +2908,13 @@ int ivx_step_record_enqueue(ivx_grid* g, void* device_record) {
 int ivx_many_begin(ivx_ctx* c);
 int ivx_many_flush(ivx_ctx* c);
 static int many_check(ivx_grid* const* grids, size_t n, const char* who) {
-    IVX_REQUIRE(grids && n > 0 && grids[0], IVX_ERR_INVALID, "%s: no objects", who);
+    IVX_REQUIRE(grids && grids[0], IVX_ERR_INVALID, "%s: null object list", who);
+    static thread_local std::vector<const ivx_grid*> seen;  // (a thousand objects a call: no quadratic search for the duplicate)
+    seen.assign(grids, grids + n);
+    std::sort(seen.begin(), seen.end());
     for (size_t i = 0; i < n; ++i) {
         IVX_REQUIRE(grids[i] && grids[i]->ctx == grids[0]->ctx, IVX_ERR_INVALID, "%s: object %zu is null or belongs to another context", who, i);
-        for (size_t j = 0; j < i; ++j) IVX_REQUIRE(grids[j] != grids[i], IVX_ERR_INVALID, "%s: object %zu is listed twice", who, i);
+        IVX_REQUIRE(i == 0 || seen[i] != seen[i - 1], IVX_ERR_INVALID, "%s: an object is listed twice", who);
     }
     return IVX_OK;
 }
@@ -2936,6 +2939,7 @@ static int many_phase(ivx_grid* const* grids, size_t n, const std::function<int(
 }
 
 int ivx_voxel_step_many(ivx_grid* const* grids, size_t n, uint32_t stages, ivx_step_result* out) {
+    if (n == 0) return IVX_OK;  // (a manager without voxel objects)
     int rc = many_check(grids, n, "ivx_voxel_step_many");
     if (rc) return rc;
     IVX_REQUIRE(out, IVX_ERR_INVALID, "ivx_voxel_step_many: null result array");
@@ -2974,6 +2978,7 @@ struct ManyClock {
 
 int ivx_absorb_sphere_many(ivx_grid* const* grids, size_t n, const float* centers3, const float* influence_radii, const float* sphere_radii,
                            const float densities[256], ivx_absorb_result* out, uint8_t* const* invalidated_chunks) {
+    if (n == 0) return IVX_OK;  // (a manager without voxel objects)
     int rc = many_check(grids, n, "ivx_absorb_sphere_many");
     if (rc) return rc;
     ManyClock clk("absorb");
@@ -3015,6 +3020,7 @@ int ivx_absorb_sphere_many(ivx_grid* const* grids, size_t n, const float* center
 }
 
 int ivx_mesh_sync_many(ivx_grid* const* grids, size_t n, const uint8_t* const* invalidated_chunks, ivx_mesh_counts* out) {
+    if (n == 0) return IVX_OK;  // (a manager without voxel objects)
     int rc = many_check(grids, n, "ivx_mesh_sync_many");
     if (rc) return rc;
     IVX_REQUIRE(invalidated_chunks && out, IVX_ERR_INVALID, "ivx_mesh_sync_many: null argument");

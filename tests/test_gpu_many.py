@@ -119,3 +119,97 @@ def test_many_calls_equal_the_single_object_calls(ctx):
             np.testing.assert_array_equal(np.ascontiguousarray(x).view(np.uint8), np.ascontiguousarray(y).view(np.uint8))
     for g in ga + gb:
         g.close()
+
+
+def test_many_calls_at_the_edges(ctx):
+    """no object at all, one object, an object listed twice, spheres that miss their objects next to spheres that hit, and a step with the
+    sample stage (which runs object by object inside the call)"""
+    lib = capi.lib()
+    # nothing to do is not an error (a manager without voxel objects)
+    assert many.voxel_step_many([], capi.STAGE_ALL).size == 0
+    assert many.absorb_sphere_many([], np.zeros((0, 3)), [], []) == []
+    assert many.mesh_sync_many([], []) == []
+    pairs = lattice_fragments(ctx, scenes.sphere_scene(30.0), 2, jitter_seed=5)
+    os_, gs = [p[0] for p in pairs], [p[1] for p in pairs]
+    assert len(gs) >= 4
+    stages = capi.STAGE_ALL & ~capi.STAGE_SAMPLE
+    # one object: the same as the single-object call
+    r1 = many.voxel_step_many(gs[:1], stages)
+    assert_objects_equal(os_[0], gs[0], "one object: ")
+    assert int(r1[0]["region_count"]) == os_[0].region_labels()[0]
+    # an object listed twice is refused before anything is enqueued
+    with pytest.raises(capi.IvxError):
+        many.voxel_step_many([gs[0], gs[1], gs[0]], stages)
+    res = many.voxel_step_many(gs, stages)
+    gms = []
+    for g, r in zip(gs, res):
+        m = VoxelObjectMesh(g)
+        m.counts = r["mesh"].copy()
+        gms.append(m)
+    oms = [ol.OracleMeshHandle(o) for o in os_]
+    for o in os_:
+        o.update_occupied_voxel_ranges()
+    # every other sphere lies far outside its object: those objects report an edit that touched nothing, the others are edited
+    centers, radii = [], []
+    for k, o in enumerate(os_):
+        occ = np.array(o.info()["occupied_voxel_ranges"], dtype=np.float32)
+        c = 0.5 * (occ[:, 0] + occ[:, 1])
+        if k % 2:
+            c = c + 500.0
+        else:
+            c[0] = occ[0, 1] - 1.0
+        centers.append(c)
+        radii.append(4.0)
+    ros = [o.absorb_sphere(c, r + 2.0, r) for o, c, r in zip(os_, centers, radii)]
+    rgs = many.absorb_sphere_many(gs, centers, [r + 2.0 for r in radii], radii)
+    for k, (ro, rg) in enumerate(zip(ros, rgs)):
+        np.testing.assert_array_equal(rg["invalidated"], ro["invalidated"], err_msg=f"object {k}")
+        assert (rg["touched_chunks"], rg["emptied_voxels"]) == (ro["touched_chunks"], int(ro["emptied_by_type"].sum()))
+        if k % 2:
+            assert rg["touched_chunks"] == 0 and not rg["invalidated"].any()
+        pu.assert_edited_objects_equal(os_[k], gs[k], f"object {k}: ", with_mesh=False)
+    for om, ro in zip(oms, ros):
+        om.sync(ro["invalidated"])
+    many.mesh_sync_many(gms, [rg["invalidated"] for rg in rgs])
+    for k in range(len(gs)):
+        assert_synced_meshes_equal(oms[k].get(), gms[k].download())
+    # the recorder by hand around the single-object halves: the same results as the blocking calls
+    ctr = []
+    for o in os_:
+        occ = np.array(o.info()["occupied_voxel_ranges"], dtype=np.float32)
+        c = 0.5 * (occ[:, 0] + occ[:, 1])
+        c[1] = occ[1, 1] - 1.0
+        ctr.append(c)
+    ros = [o.absorb_sphere(c, 5.0, 3.0) for o, c in zip(os_, ctr)]
+    capi.check(lib.ivx_many_begin(ctx.h))
+    for g, c in zip(gs, ctr):
+        g.absorb_sphere_enqueue(c, 5.0, 3.0)
+    capi.check(lib.ivx_many_flush(ctx.h))
+    for k, (g, ro) in enumerate(zip(gs, ros)):
+        rg = g.absorb_collect()
+        np.testing.assert_array_equal(rg["invalidated"], ro["invalidated"], err_msg=f"object {k}")
+        pu.assert_edited_objects_equal(os_[k], g, f"recorded by hand, object {k}: ", with_mesh=False)
+    for g in gs:
+        g.close()
+
+
+def test_step_many_with_the_sample_stage(ctx):
+    """`ivx_voxel_step_many` with IVX_STAGE_SAMPLE: the sample stage has no twin and runs object by object inside the call; the rest merges"""
+    from impact_amd.voxel import SDFVoxelGenerator, VoxelObject
+
+    graphs = [scenes.sphere_scene(20.0), scenes.asteroid_scene(0.3), scenes.box_scene((30.0, 30.0, 30.0))]
+    objs, refs = [], []
+    for gr in graphs:
+        gen = SDFVoxelGenerator(1.0, gr, 0)
+        o = VoxelObject(ctx, gen.chunk_counts(), 1.0)
+        o.set_sdf_program(gen)
+        o.set_densities(np.ones(256, dtype=np.float32))
+        objs.append(o)
+        refs.append(pu.oracle_from_graph(gr, 1.0))
+    res = many.voxel_step_many(objs, capi.STAGE_ALL)
+    for k, (o, g) in enumerate(zip(refs, objs)):
+        o.update_occupied_voxel_ranges()
+        o.compute_all_derived_state()
+        parity = pu.step_parity(o, g, res[k])
+        assert parity["equal"], (k, parity)
+        g.close()
