@@ -100,7 +100,7 @@ int ensure_dev_scratch(ivx_grid* g, size_t bytes) {
 int ensure_mesh_capacity(ivx_grid* g, size_t nv, size_t ni, size_t ns) {
     if (nv > g->vcap || ni > g->icap || ns > g->scap) g->mesh_generation += 1;
     if (nv > g->vcap) {
-        size_t cap = std::max(nv + nv / 4 + 1024, g->vcap * 2);  // (slack: the edits that follow a full remesh grow the mesh by a few chunks' worth)
+        size_t cap = std::max(2 * nv + 4096, g->vcap * 2);  // (slack: under the reference's range allocator an edited mesh's buffers grow — a re-meshed chunk that needs a little more than it had goes to the end — by about as much again before freed ranges start to be reused; 2 x 48 B per vertex is nothing next to 288 GB)
         if (g->positions) (void)hipFree(g->positions);
         if (g->normals) (void)hipFree(g->normals);
         if (g->vertex_materials) (void)hipFree(g->vertex_materials);
@@ -114,7 +114,7 @@ int ensure_mesh_capacity(ivx_grid* g, size_t nv, size_t ni, size_t ns) {
         g->vcap = cap;
     }
     if (ni > g->icap) {
-        size_t cap = std::max(ni + ni / 4 + 6144, g->icap * 2);
+        size_t cap = std::max(2 * ni + 24576, g->icap * 2);
         if (g->indices) (void)hipFree(g->indices);
         if (g->index_materials) (void)hipFree(g->index_materials);
         g->indices = nullptr;
@@ -126,7 +126,7 @@ int ensure_mesh_capacity(ivx_grid* g, size_t nv, size_t ni, size_t ns) {
         g->icap = cap;
     }
     if (ns > g->scap) {
-        size_t cap = std::max(ns + ns / 4 + 16, g->scap * 2);
+        size_t cap = std::max(2 * ns + 64, g->scap * 2);
         if (g->submeshes) (void)hipFree(g->submeshes);
         g->submeshes = nullptr;
         g->scap = 0;
@@ -263,41 +263,50 @@ void manager_remove(ivx_grid* g, ivx_submesh_manager* m, uint32_t chunk) {  // r
     m->vertices.free_range(gone.vertex_offset, (size_t)gone.vertex_offset + gone.vertex_count);
     m->indices.free_range(gone.index_offset, (size_t)gone.index_offset + gone.index_count);
 }
-// grow the mesh buffers keeping what they hold (the full remesh may simply reallocate, a sync may not)
+// grow the mesh buffers keeping what they hold (the full remesh may simply reallocate, a sync may not): every array that has to grow gets its
+// new block and its copy on the stream, then ONE wait, then the old blocks go (a wait per array was most of what a growth cost)
+struct GrowKeep {
+    void** slot;
+    void* fresh;
+};
 template <class T>
-int grow_keep(ivx_grid* g, T** buf, size_t old_count, size_t new_count) {
+int grow_keep_enqueue(ivx_grid* g, T** buf, size_t old_count, size_t new_count, std::vector<GrowKeep>& pending) {
     T* fresh = nullptr;
     int rc = dev_alloc(&fresh, new_count);
     if (rc) return rc;
     if (*buf && old_count) IVX_HIP_CHECK(ivx_memcpy_async(fresh, *buf, old_count * sizeof(T), hipMemcpyDeviceToDevice, g->ctx->stream));
-    IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
-    if (*buf) (void)hipFree(*buf);
-    *buf = fresh;
+    pending.push_back(GrowKeep{reinterpret_cast<void**>(buf), fresh});
     return IVX_OK;
 }
 int ensure_mesh_capacity_keep(ivx_grid* g, size_t nv, size_t ni, size_t ns) {
     int rc;
-    if (nv > g->vcap || ni > g->icap || ns > g->scap) g->mesh_generation += 1;
-    // (growth by copy costs an allocation, a device copy and a wait — the price of hundreds of small objects' syncs when each of them outgrows
+    if (!(nv > g->vcap || ni > g->icap || ns > g->scap)) return IVX_OK;
+    g->mesh_generation += 1;
+    // (growth by copy costs allocations, device copies and a wait — the price of hundreds of small objects' syncs when each of them outgrows
     // its buffers by a few vertices per frame: double, and never by less than a few thousand elements; memory is not what this part is short of)
+    std::vector<GrowKeep> pending;
+    size_t vcap = g->vcap, icap = g->icap, scap = g->scap;
     if (nv > g->vcap) {
-        const size_t cap = std::max(nv + nv / 2 + 4096, 2 * g->vcap);
-        if ((rc = grow_keep(g, &g->positions, g->vcap * 3, cap * 3))) return rc;
-        if ((rc = grow_keep(g, &g->normals, g->vcap * 3, cap * 3))) return rc;
-        if ((rc = grow_keep(g, &g->vertex_materials, (size_t)0, cap * 16))) return rc;  // scratch of the emit kernel
-        g->vcap = cap;
+        vcap = std::max(nv + nv / 2 + 4096, 2 * g->vcap);
+        if ((rc = grow_keep_enqueue(g, &g->positions, g->vcap * 3, vcap * 3, pending))) return rc;
+        if ((rc = grow_keep_enqueue(g, &g->normals, g->vcap * 3, vcap * 3, pending))) return rc;
+        if ((rc = grow_keep_enqueue(g, &g->vertex_materials, (size_t)0, vcap * 16, pending))) return rc;  // scratch of the emit kernel
     }
     if (ni > g->icap) {
-        const size_t cap = std::max(ni + ni / 2 + 24576, 2 * g->icap);
-        if ((rc = grow_keep(g, &g->indices, g->icap, cap))) return rc;
-        if ((rc = grow_keep(g, &g->index_materials, g->icap * 8, cap * 8))) return rc;
-        g->icap = cap;
+        icap = std::max(ni + ni / 2 + 24576, 2 * g->icap);
+        if ((rc = grow_keep_enqueue(g, &g->indices, g->icap, icap, pending))) return rc;
+        if ((rc = grow_keep_enqueue(g, &g->index_materials, g->icap * 8, icap * 8, pending))) return rc;
     }
     if (ns > g->scap) {
-        const size_t cap = std::max(ns + ns / 2 + 64, 2 * g->scap);
-        if ((rc = grow_keep(g, &g->submeshes, g->scap, cap))) return rc;
-        g->scap = cap;
+        scap = std::max(ns + ns / 2 + 64, 2 * g->scap);
+        if ((rc = grow_keep_enqueue(g, &g->submeshes, g->scap, scap, pending))) return rc;
     }
+    IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
+    for (GrowKeep& k : pending) {
+        if (*k.slot) (void)hipFree(*k.slot);
+        *k.slot = k.fresh;
+    }
+    g->vcap = vcap, g->icap = icap, g->scap = scap;
     return IVX_OK;
 }
 }  // namespace
@@ -2071,9 +2080,15 @@ int ivx_collision_probes_sync(ivx_grid* g, const uint8_t* invalidated_chunks, si
     }
     pm->points.merge_consecutive();
     if (pm->total > g->probe_point_cap) {  // grow, keeping what is there
-        const size_t cap = std::max<size_t>(pm->total, g->probe_point_cap + g->probe_point_cap / 2);
-        if ((rc = grow_keep(g, &g->probe_points, g->probe_point_cap * 3, cap * 3))) return rc;
-        if ((rc = grow_keep(g, &g->probe_chunk, g->probe_point_cap, cap))) return rc;
+        const size_t cap = std::max<size_t>(pm->total + pm->total / 2 + 4096, 2 * g->probe_point_cap);
+        std::vector<GrowKeep> pending;
+        if ((rc = grow_keep_enqueue(g, &g->probe_points, g->probe_point_cap * 3, cap * 3, pending))) return rc;
+        if ((rc = grow_keep_enqueue(g, &g->probe_chunk, g->probe_point_cap, cap, pending))) return rc;
+        IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
+        for (GrowKeep& k : pending) {
+            if (*k.slot) (void)hipFree(*k.slot);
+            *k.slot = k.fresh;
+        }
         g->probe_point_cap = cap;
     }
     for (const auto& r : freed)  // holes read as "no probe" until a later chunk takes them (the gather below overwrites what was taken now)
