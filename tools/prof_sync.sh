@@ -8,5 +8,5 @@ python3 tools/time_sync.py > "$out/time_sync.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$out/trace" -o trace -- python3 tools/time_sync.py > "$out/time_sync_prof.log" 2>&1
 python tools/rocpd_stats.py "$(ls "$out"/trace/*.db | tail -1)" > "$out/kernel_stats_sync.csv"
 rm -rf "$out/trace"
-tail -1 "$out/time_sync.log"
+grep "edit enqueue" "$out/time_sync.log"
 cut -c1-120 "$out/kernel_stats_sync.csv" | head -24

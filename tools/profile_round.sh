@@ -12,7 +12,6 @@ if [ "${2:-}" != "skip-tests" ]; then
   python -m pytest tests -m gpu -x -q > "$out/${tag}_pytest_gpu.log" 2>&1
   tail -2 "$out/${tag}_pytest_gpu.log"
 fi
-python bench.py 2> "$out/bench_stderr.log" | tail -1 > "$out/${tag}_bench_n1.json"
 # --plain: full steps only: 2 warm-up + 10 timed + 10 with every slot timed = 22 steps
 STEPS="--steps 10 --warmup 2 --no-cpu-baseline --no-pile --plain"
 NST=22
@@ -27,6 +26,8 @@ for wl in headline dense; do
   python tools/pmc_valu.py "$(ls "$out"/pmc_valu_$wl/*.db | tail -1)" "$out/pmc_valu_$wl.json" $NST
   rm -rf "$out/trace_$wl" "$out/pmc_fetch_$wl" "$out/pmc_write_$wl" "$out/pmc_valu_$wl"
 done
+# the default bench line LAST, quoting the counter summaries just made (same kernel sources: `roofline.traffic` is live)
+python bench.py --profiles "$out" 2> "$out/bench_stderr.log" | tail -1 > "$out/${tag}_bench_n1.json"
 # the edit path, the incremental remesh and the many-object frame under the kernel trace (their own timing lines + kernel tables)
 bash tools/prof_edit.sh $tag > "$out/prof_edit.log" 2>&1
 bash tools/prof_sync.sh $tag > "$out/prof_sync.log" 2>&1
