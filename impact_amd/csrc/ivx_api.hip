@@ -2535,8 +2535,8 @@ int ivx_grid_set_densities(ivx_grid* g, const float densities[256]) {
 }
 
 // Timed slots of a step (ivx_step_result::stage_ms): 0 sample (k_sdf_super, k_sdf_prepass, k_sdf_eval), 1 derive (k_chunk_pre, k_derive:
-// flags, chunk state, chunk-local regions, chunk moments), 2 k_step_post1 (mesher count | region merge by columns | exact local
-// numbering | occupied slots | moment partial sums), 3 k_step_post2 (multi-region merge | mesher scan | moments and occupied ranges
+// flags, chunk state, chunk-local regions, chunk moments), 2 k_step_post1 (mesher count | region merge by columns | occupied slots
+// | moment partial sums), 3 k_step_post2 (exact local numbering -> multi-region merge | mesher scan | moments and occupied ranges
 // final), 4 k_step_emit (region forest flatten | mesher emit), 5 k_step_assign (component ids); 6..9 unused. Stage timing costs two
 // event records per slot on the stream; ivx_grid_set_stage_timing(g, 0) turns it off.
 static int ensure_pairs(ivx_grid* g);
@@ -2626,7 +2626,7 @@ static int step_enqueue(ivx_grid* g, uint32_t stages, const uint16_t* slab_nbr_i
     if (post) {
         // stages that were not swept inside k_derive get their stand-alone per-chunk kernels first (a call without the derive stage)
         if ((stages & IVX_STAGE_REGIONS) && !(fused_parts & IVX_PART_REGIONS)) {
-            // (level 1 over the active list; the exact numbering of multi-region chunks is a role of k_step_post1 below, so
+            // (level 1 over the active list; the exact numbering of multi-region chunks leads k_step_post2 below, so
             // only the list-driven labelling kernel is launched here: ivx_launch_ccl_local would run both)
             if (!g->regions_labelled_locally && (rc = ivx_launch_ccl_local_only(g))) return rc;
         }

@@ -254,8 +254,8 @@ int ivx_copy_polyhedra(ivx_grid* parent, const float* planes4, const uint32_t* p
 #define IVX_STAGE_INERTIA 32u
 #define IVX_STAGE_ALL 63u
 /* timed slots of a step: 0 sample (k_sdf_super, k_sdf_prepass, k_sdf_eval), 1 derive (k_chunk_pre, k_derive: flags, chunk state, chunk-local
- * regions, chunk moments), 2 post1 (one launch: mesher count | region merge by chunk columns | exact local numbering | occupied slots |
- * moment partial sums), 3 post2 (one launch: multi-region merge | mesher scan | moments and occupied ranges final), 4 emit (one launch:
+ * regions, chunk moments), 2 post1 (one launch: mesher count | region merge by chunk columns | occupied slots | moment partial sums),
+ * 3 post2 (one launch: exact local numbering, then multi-region merge | mesher scan | moments and occupied ranges final), 4 emit (one launch:
  * region forest flatten | mesher emit), 5 assign (component ids), 6..9 unused */
 #define IVX_N_TIMED_STAGES 10
 typedef struct {
