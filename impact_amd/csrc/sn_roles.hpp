@@ -12,7 +12,7 @@ constexpr int G = 18, NROWS = 324, NCROWS = 289, NCUBES = 4913;
 // LDS tile: 18 x 18 rows of 18 bytes along k; a row occupies RS = 24 bytes with cell c at byte 3 + c, so the 16
 // interior cells (c = 1..16, the chunk's own k-row) sit 4-byte aligned and are written as four words.
 constexpr int RS = 24, TILE_BYTES = NROWS * RS;
-constexpr uint32_t VPC = 800;  // vertices a mesher workgroup keeps in LDS for its quad phase (role_sn_emit)
+constexpr uint32_t VPC = 864;  // vertices a mesher workgroup keeps in LDS for its quad phase (role_sn_emit)
 __device__ __forceinline__ int tix(int a, int b, int c) { return (a * G + b) * RS + 3 + c; }
 
 // (an empty asm the compiler must assume changes x: what is computed from the result cannot be hoisted out of the surrounding loop and held
