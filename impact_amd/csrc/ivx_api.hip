@@ -2991,20 +2991,21 @@ struct ManyClock {
     }
 };
 
-int ivx_absorb_sphere_many(ivx_grid* const* grids, size_t n, const float* centers3, const float* influence_radii, const float* sphere_radii,
-                           const float densities[256], ivx_absorb_result* out, uint8_t* const* invalidated_chunks) {
+// one absorber per object: spheres (segments3 == NULL) or capsules (segment vectors, 3 floats per object)
+static int absorb_many(ivx_grid* const* grids, size_t n, const char* who, const float* points3, const float* segments3, const float* influence_radii,
+                       const float* shape_radii, const float densities[256], ivx_absorb_result* out, uint8_t* const* invalidated_chunks) {
     if (n == 0) return IVX_OK;  // (a manager without voxel objects)
-    int rc = many_check(grids, n, "ivx_absorb_sphere_many");
+    int rc = many_check(grids, n, who);
     if (rc) return rc;
     ManyClock clk("absorb");
-    IVX_REQUIRE(centers3 && influence_radii && sphere_radii && densities && out, IVX_ERR_INVALID, "ivx_absorb_sphere_many: null argument");
+    IVX_REQUIRE(points3 && influence_radii && shape_radii && densities && out, IVX_ERR_INVALID, "%s: null argument", who);
     // (what an object's enqueue may have to wait for — its occupied ranges, a density table that is not the resident one — before the recording starts)
     for (size_t i = 0; i < n; ++i) {
         uint32_t occ[12];
         if (grids[i]->regions_valid && (rc = reference_occupied(grids[i], occ))) return rc;
         // (... and the object's edit buffers, which its first edit would otherwise allocate — with a wait on the stream — in the middle of the batch)
         ivx_edit_state* e = edit_state(grids[i]);
-        IVX_REQUIRE(e, IVX_ERR_CAPACITY, "ivx_absorb_sphere_many: out of host memory");
+        IVX_REQUIRE(e, IVX_ERR_CAPACITY, "%s: out of host memory", who);
         if (!e->d_results) {
             const size_t cap = 1 << 16;
             IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->d_results), cap));
@@ -3020,18 +3021,25 @@ int ivx_absorb_sphere_many(ivx_grid* const* grids, size_t n, const float* center
     }
     clk.lap("prepare");
     if ((rc = many_phase(grids, n, [&](size_t i) {
-             return absorb_enqueue(grids[i], "ivx_absorb_sphere_many", 0, centers3 + 3 * i, nullptr, influence_radii[i], sphere_radii[i], densities);
+             return absorb_enqueue(grids[i], who, segments3 ? 1 : 0, points3 + 3 * i, segments3 ? segments3 + 3 * i : nullptr, influence_radii[i], shape_radii[i], densities);
          })))
         return rc;
     clk.lap("enqueue + flush");
     if ((rc = many_phase(grids, n, [&](size_t i) { return (grids[i]->edit && grids[i]->edit->pending && !grids[i]->edit->nothing) ? ivx_step_collect_launch(grids[i]) : IVX_OK; })))
         return rc;
     clk.lap("gathers");
-    rc = many_phase(grids, n, [&](size_t i) {
-        return absorb_collect(grids[i], "ivx_absorb_sphere_many", &out[i], nullptr, invalidated_chunks ? invalidated_chunks[i] : nullptr);
-    });
+    rc = many_phase(grids, n, [&](size_t i) { return absorb_collect(grids[i], who, &out[i], nullptr, invalidated_chunks ? invalidated_chunks[i] : nullptr); });
     clk.lap("collect");
     return rc;
+}
+int ivx_absorb_sphere_many(ivx_grid* const* grids, size_t n, const float* centers3, const float* influence_radii, const float* sphere_radii,
+                           const float densities[256], ivx_absorb_result* out, uint8_t* const* invalidated_chunks) {
+    return absorb_many(grids, n, "ivx_absorb_sphere_many", centers3, nullptr, influence_radii, sphere_radii, densities, out, invalidated_chunks);
+}
+int ivx_absorb_capsule_many(ivx_grid* const* grids, size_t n, const float* segment_starts3, const float* segment_vectors3, const float* influence_radii,
+                            const float* capsule_radii, const float densities[256], ivx_absorb_result* out, uint8_t* const* invalidated_chunks) {
+    IVX_REQUIRE(n == 0 || segment_vectors3, IVX_ERR_INVALID, "ivx_absorb_capsule_many: null argument");
+    return absorb_many(grids, n, "ivx_absorb_capsule_many", segment_starts3, segment_vectors3, influence_radii, capsule_radii, densities, out, invalidated_chunks);
 }
 
 int ivx_mesh_sync_many(ivx_grid* const* grids, size_t n, const uint8_t* const* invalidated_chunks, ivx_mesh_counts* out) {

@@ -32,9 +32,19 @@ def voxel_step_many(objects, stages: int):
 def absorb_sphere_many(objects, centers, influence_radii, sphere_radii, densities=None, want_invalidated: bool = True):
     """`ivx_absorb_sphere_many`: one absorbing sphere per object (object-normalized coordinates) -> list of result dicts as `VoxelObject.absorb_sphere`
     returns them (without the per-type counts; `invalidated` is a uint8 view — one byte per chunk, 1 = invalidated — into one buffer for all objects)"""
+    return _absorb_many(objects, centers, None, influence_radii, sphere_radii, densities, want_invalidated)
+
+
+def absorb_capsule_many(objects, segment_starts, segment_vectors, influence_radii, capsule_radii, densities=None, want_invalidated: bool = True):
+    """`ivx_absorb_capsule_many`: one absorbing capsule per object (segment start + segment vector, object-normalized coordinates)"""
+    return _absorb_many(objects, segment_starts, segment_vectors, influence_radii, capsule_radii, densities, want_invalidated)
+
+
+def _absorb_many(objects, centers, segments, influence_radii, sphere_radii, densities, want_invalidated):
     n = len(objects)
     d = np.ones(256, dtype=np.float32) if densities is None else np.ascontiguousarray(densities, dtype=np.float32)
     c = np.ascontiguousarray(np.asarray(centers, dtype=np.float32).reshape(n, 3))
+    sg = None if segments is None else np.ascontiguousarray(np.asarray(segments, dtype=np.float32).reshape(n, 3))
     ri = np.ascontiguousarray(np.asarray(influence_radii, dtype=np.float32).reshape(n))
     rs = np.ascontiguousarray(np.asarray(sphere_radii, dtype=np.float32).reshape(n))
     out = np.zeros(n, dtype=capi.ABSORB_RESULT_DTYPE)
@@ -45,7 +55,10 @@ def absorb_sphere_many(objects, centers, influence_radii, sphere_radii, densitie
         buf = np.zeros(int(offs[-1]), dtype=np.uint8)
         iv = (buf.ctypes.data + offs[:-1]).astype(np.uint64)
         inval = [buf[offs[i]:offs[i + 1]] for i in range(n)]
-    check(capi.lib().ivx_absorb_sphere_many(_handles(objects), n, ptr(c), ptr(ri), ptr(rs), ptr(d), ptr(out), ptr(iv) if iv is not None else None))
+    if sg is None:
+        check(capi.lib().ivx_absorb_sphere_many(_handles(objects), n, ptr(c), ptr(ri), ptr(rs), ptr(d), ptr(out), ptr(iv) if iv is not None else None))
+    else:
+        check(capi.lib().ivx_absorb_capsule_many(_handles(objects), n, ptr(c), ptr(sg), ptr(ri), ptr(rs), ptr(d), ptr(out), ptr(iv) if iv is not None else None))
     res = []
     for i, o in enumerate(objects):
         o._region_count = None

@@ -318,6 +318,7 @@ int ivx_absorb_mutual(ivx_grid* a, const float rotation_a[4], const float transl
  *   ivx_voxel_step_many      ivx_voxel_step for every object (stages without IVX_STAGE_SAMPLE merge; a sample stage runs object by object)
  *   ivx_absorb_sphere_many   ivx_absorb_sphere, one sphere per object (centers3: 3 floats per object); `invalidated_chunks`: NULL, or one
  *                            array per object (entries may be NULL)
+ *   ivx_absorb_capsule_many  ivx_absorb_capsule, one capsule per object (segment start and segment vector: 3 floats each per object)
  *   ivx_mesh_sync_many       ivx_mesh_sync for every object
  * ivx_many_begin / ivx_many_flush expose the mechanism itself: between them the `_enqueue` calls of objects of the context are recorded
  * (call ivx_many_object-free: chains are merged front by front in the order the calls were made) and the flush issues them merged. */
@@ -326,6 +327,8 @@ int ivx_many_flush(ivx_ctx*);
 int ivx_voxel_step_many(ivx_grid* const* grids, size_t n, uint32_t stages, ivx_step_result* out);
 int ivx_absorb_sphere_many(ivx_grid* const* grids, size_t n, const float* centers3, const float* influence_radii, const float* sphere_radii,
                            const float densities[256], ivx_absorb_result* out, uint8_t* const* invalidated_chunks);
+int ivx_absorb_capsule_many(ivx_grid* const* grids, size_t n, const float* segment_starts3, const float* segment_vectors3, const float* influence_radii,
+                            const float* capsule_radii, const float densities[256], ivx_absorb_result* out, uint8_t* const* invalidated_chunks);
 int ivx_mesh_sync_many(ivx_grid* const* grids, size_t n, const uint8_t* const* invalidated_chunks, ivx_mesh_counts* out);
 
 /* make the compiled SDF program / the voxel-type densities resident on the device */

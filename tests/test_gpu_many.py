@@ -173,6 +173,25 @@ def test_many_calls_at_the_edges(ctx):
     many.mesh_sync_many(gms, [rg["invalidated"] for rg in rgs])
     for k in range(len(gs)):
         assert_synced_meshes_equal(oms[k].get(), gms[k].download())
+    # one capsule per object through the batched call
+    segs, vecs = [], []
+    for o in os_:
+        occ = np.array(o.info()["occupied_voxel_ranges"], dtype=np.float32)
+        a = 0.5 * (occ[:, 0] + occ[:, 1])
+        a[2] = occ[2, 1] - 1.0
+        segs.append(a)
+        vecs.append(np.array([3.0, -2.0, 0.5], dtype=np.float32))
+    ros = [o.absorb_capsule(a, v, 4.5, 2.5) for o, a, v in zip(os_, segs, vecs)]
+    rgs = many.absorb_capsule_many(gs, segs, vecs, [4.5] * len(gs), [2.5] * len(gs))
+    for k, (ro, rg) in enumerate(zip(ros, rgs)):
+        np.testing.assert_array_equal(rg["invalidated"], ro["invalidated"], err_msg=f"capsule, object {k}")
+        assert (rg["touched_chunks"], rg["emptied_voxels"]) == (ro["touched_chunks"], int(ro["emptied_by_type"].sum()))
+        pu.assert_edited_objects_equal(os_[k], gs[k], f"capsule, object {k}: ", with_mesh=False)
+    for om, ro in zip(oms, ros):
+        om.sync(ro["invalidated"])
+    many.mesh_sync_many(gms, [rg["invalidated"] for rg in rgs])
+    for k in range(len(gs)):
+        assert_synced_meshes_equal(oms[k].get(), gms[k].download())
     # the recorder by hand around the single-object halves: the same results as the blocking calls
     ctr = []
     for o in os_:
