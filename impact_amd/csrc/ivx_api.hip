@@ -1490,7 +1490,9 @@ struct ivx_edit_state {
     char* d_results = nullptr;  // the edit's accumulators on the device (its own allocation: zero between edits — cleared behind every collect)
     size_t d_results_bytes = 0;
     // what the meshes of the last edit's invalidated chunks need (chunk -> vertices, indices, kind | flags << 8): valid until voxels change again
-    std::unordered_map<uint32_t, std::array<uint32_t, 3>> needs;
+    // (ascending by chunk — the grown box is walked in chunk-linear order —, looked up by binary search: a hash map's insertions were most of an
+    // edit's collect for the small objects of a many-object frame)
+    std::vector<std::array<uint32_t, 4>> needs;  // chunk, vertices, indices, kind | flags << 8
     // the sync in flight
     int sync_pending = 0;
     void* pinned_up = nullptr;
@@ -1512,9 +1514,10 @@ static ivx_edit_state* edit_state(ivx_grid* g) {
 }
 static bool edit_needs_lookup(ivx_grid* g, uint32_t chunk, uint32_t out3[3]) {
     if (!g->edit) return false;
-    const auto it = g->edit->needs.find(chunk);
-    if (it == g->edit->needs.end()) return false;
-    out3[0] = it->second[0], out3[1] = it->second[1], out3[2] = it->second[2];
+    const auto& v = g->edit->needs;
+    const auto it = std::lower_bound(v.begin(), v.end(), chunk, [](const std::array<uint32_t, 4>& a, uint32_t c) { return a[0] < c; });
+    if (it == v.end() || (*it)[0] != chunk) return false;
+    out3[0] = (*it)[1], out3[1] = (*it)[2], out3[2] = (*it)[3];
     return true;
 }
 static void edit_sync_mark(ivx_grid* g, int pending) {
@@ -1707,8 +1710,10 @@ static int absorb_collect(ivx_grid* g, const char* who, ivx_absorb_result* out, 
         if (!(w & 0x80000000u)) continue;
         const uint32_t c = needs[4 * b + 3];
         if (invalidated_chunks) invalidated_chunks[c] = 1;
-        e->needs[c] = {needs[4 * b + 1], needs[4 * b + 2], w & 0xFFFFu};
+        e->needs.push_back({c, needs[4 * b + 1], needs[4 * b + 2], w & 0xFFFFu});
     }
+    if (!std::is_sorted(e->needs.begin(), e->needs.end(), [](const std::array<uint32_t, 4>& a, const std::array<uint32_t, 4>& b) { return a[0] < b[0]; }))
+        std::sort(e->needs.begin(), e->needs.end(), [](const std::array<uint32_t, 4>& a, const std::array<uint32_t, 4>& b) { return a[0] < b[0]; });
     g->needs_current = 1;
     return IVX_OK;
 }
