@@ -285,6 +285,14 @@ int ensure_mesh_capacity_keep(ivx_grid* g, size_t nv, size_t ni, size_t ns) {
     // (growth by copy costs allocations, device copies and a wait — the price of hundreds of small objects' syncs when each of them outgrows
     // its buffers by a few vertices per frame: double, and never by less than a few thousand elements; memory is not what this part is short of)
     std::vector<GrowKeep> pending;
+    struct FreeOnError {  // (a failed allocation further down must not leak the blocks made so far)
+        std::vector<GrowKeep>& p;
+        bool armed = true;
+        ~FreeOnError() {
+            if (armed)
+                for (GrowKeep& k : p) (void)hipFree(k.fresh);
+        }
+    } guard{pending};
     size_t vcap = g->vcap, icap = g->icap, scap = g->scap;
     if (nv > g->vcap) {
         vcap = std::max(nv + nv / 2 + 4096, 2 * g->vcap);
@@ -302,6 +310,7 @@ int ensure_mesh_capacity_keep(ivx_grid* g, size_t nv, size_t ni, size_t ns) {
         if ((rc = grow_keep_enqueue(g, &g->submeshes, g->scap, scap, pending))) return rc;
     }
     IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
+    guard.armed = false;
     for (GrowKeep& k : pending) {
         if (*k.slot) (void)hipFree(*k.slot);
         *k.slot = k.fresh;
@@ -650,6 +659,7 @@ static int edit_sync_pending(ivx_grid* g);
 // through a blocking copy and waited again: two round trips and ~25 us of counting for ~100 chunks.)
 static int mesh_sync_enqueue(ivx_grid* g, const uint8_t* invalidated_chunks, const char* who) {
     IVX_REQUIRE(g && invalidated_chunks, IVX_ERR_INVALID, "%s: null argument", who);
+    ivx_many_other_context other_(g->ctx);
     IVX_REQUIRE(!edit_sync_pending(g), IVX_ERR_STATE, "%s: a sync of this object is in flight (ivx_mesh_sync_collect first)", who);
     IVX_REQUIRE(g->mesh_built, IVX_ERR_STATE, "ivx_mesh_sync: there is no mesh to synchronise (call ivx_remesh first)");
     IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "ivx_mesh_sync: derived state must be current (the edit ops leave it so)");
@@ -1557,6 +1567,7 @@ static int ensure_pinned(void** p, size_t* have, size_t bytes) {
 static int absorb_enqueue(ivx_grid* g, const char* who, int capsule, const float center[3], const float seg[3], float influence_radius, float shape_radius,
                           const float densities[256]) {
     IVX_REQUIRE(g && center && densities && (seg || !capsule), IVX_ERR_INVALID, "%s: null argument", who);
+    ivx_many_other_context other_(g->ctx);
     IVX_REQUIRE(influence_radius >= 0.0f && shape_radius >= 0.0f, IVX_ERR_INVALID, "%s: negative radius", who);
     IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "%s: derived state and regions must be current (ivx_derive_state + ivx_label_regions)", who);
     IVX_REQUIRE(g->x_off == 0 && g->gx == g->cc[0] && !g->has_ghost[0] && !g->has_ghost[1], IVX_ERR_STATE, "%s: not available on a slab of a decomposed grid",
@@ -1665,6 +1676,7 @@ static int absorb_enqueue(ivx_grid* g, const char* who, int capsule, const float
 
 static int absorb_collect(ivx_grid* g, const char* who, ivx_absorb_result* out, uint32_t* emptied_by_type, uint8_t* invalidated_chunks) {
     IVX_REQUIRE(g && out, IVX_ERR_INVALID, "%s: null argument", who);
+    ivx_many_other_context other_(g->ctx);
     ivx_edit_state* e = g->edit;
     IVX_REQUIRE(e && e->pending, IVX_ERR_STATE, "%s: no edit of this object is in flight", who);
     e->pending = 0;
@@ -2549,6 +2561,7 @@ static int ensure_pairs(ivx_grid* g);
 // slab's record ride in the phase's own launches instead of taking two more
 static int step_enqueue(ivx_grid* g, uint32_t stages, const uint16_t* slab_nbr_ids, void* slab_record) {
     IVX_REQUIRE(g, IVX_ERR_INVALID, "ivx_voxel_step_enqueue: null grid");
+    ivx_many_other_context other_(g->ctx);
     IVX_REQUIRE(!(stages & IVX_STAGE_SAMPLE) || g->prog_n > 0, IVX_ERR_STATE, "ivx_voxel_step: no SDF program resident (ivx_grid_set_sdf_program)");
     IVX_REQUIRE(!(stages & IVX_STAGE_INERTIA) || g->has_dens, IVX_ERR_STATE, "ivx_voxel_step: no densities resident (ivx_grid_set_densities)");
     hipStream_t s = g->ctx->stream;
@@ -2735,6 +2748,7 @@ static int ivx_step_collect_launch(ivx_grid* g) {
 
 int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out) {
     IVX_REQUIRE(g && out, IVX_ERR_INVALID, "ivx_voxel_step_collect: null argument");
+    ivx_many_other_context other_(g->ctx);
     hipStream_t s = g->ctx->stream;
     memset(out, 0, sizeof(*out));
     const uint32_t stages = g->pending_stages;
@@ -2952,7 +2966,8 @@ static int many_phase(ivx_grid* const* grids, size_t n, const std::function<int(
     }
     const auto t1 = std::chrono::steady_clock::now();
     rc = ivx_many_flush(c);
-    if (getenv("IVX_MANY_TRACE"))
+    static const bool trace_phase_ = getenv("IVX_MANY_TRACE") != nullptr;
+    if (trace_phase_)
         fprintf(stderr, "[ivx many]   phase: objects %.1f us, flush %.1f us\n", 1e-3 * (double)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count(),
                 1e-3 * (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t1).count());
     return first ? first : rc;

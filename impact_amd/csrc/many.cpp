@@ -54,8 +54,15 @@ struct Recorder {
 };
 thread_local Recorder* t_rec = nullptr;
 
+// whatever happens to a flush, what was recorded is gone afterwards: a failed flush must not leave entries for the next batch to issue
+struct ClearOnExit {
+    Recorder* r;
+    ~ClearOnExit();
+};
+
 int flush_recorded(Recorder* r) {
     if (r->n_entries == 0) return IVX_OK;
+    ClearOnExit clear_{r};
     r->flushes += 1;
     hipStream_t s = r->ctx->stream;
     // plan the merged launches: (kernel, members...) in issue order
@@ -153,10 +160,12 @@ int flush_recorded(Recorder* r) {
         const int rc = reg.fn(s, d + off_args[p], reinterpret_cast<const uint32_t*>(d + off_ends[p]), (uint32_t)plan[p].members.size(), totals[p]);
         IVX_REQUIRE(rc == 0, IVX_ERR_HIP, "ivx_many: launch of twin %d failed", plan[p].kernel);
     }
+    return IVX_OK;
+}
+ClearOnExit::~ClearOnExit() {
     for (auto& c : r->chains) c.clear();
     r->arena.clear();
     r->n_entries = 0;
-    return IVX_OK;
 }
 
 }  // namespace
@@ -168,6 +177,20 @@ void ivx_many_register(int kernel, ivx_many_launch_fn fn, uint32_t arg_bytes) {
 }
 
 bool ivx_many_recording() { return t_rec && t_rec->on; }
+
+// A call on an object of ANOTHER context than the one the batch is recorded for must not be recorded (its launches belong on that context's
+// stream): what has been recorded goes out, and recording is off until the call returns.
+ivx_many_other_context::ivx_many_other_context(const ivx_ctx* c) : suspended(false) {
+    Recorder* r = t_rec;
+    if (r && r->on && r->ctx != c) {
+        (void)ivx_many_break();
+        r->on = false;
+        suspended = true;
+    }
+}
+ivx_many_other_context::~ivx_many_other_context() {
+    if (suspended && t_rec) t_rec->on = true;
+}
 uint64_t ivx_many_flush_count() { return t_rec ? t_rec->flushes : 0; }
 
 static bool capture_range(int kernel, void* d_dst, const void* h_src, size_t bytes) {

@@ -50,6 +50,12 @@ void ivx_many_register(int kernel, ivx_many_launch_fn fn, uint32_t arg_bytes);
 
 // recording state of the calling thread: null = launches are issued as they come
 bool ivx_many_recording();
+// at the top of every entry point that enqueues work for an object: see many.cpp
+struct ivx_many_other_context {
+    explicit ivx_many_other_context(const ivx_ctx* c);
+    ~ivx_many_other_context();
+    bool suspended;
+};
 // true: written down (nothing was launched); false: not recording — the caller launches
 bool ivx_many_capture(int kernel, uint32_t blocks, const void* args, uint32_t arg_bytes);
 // in front of every launch / stream operation that has no twin: what has been recorded goes out first

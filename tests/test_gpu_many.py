@@ -212,6 +212,42 @@ def test_many_calls_at_the_edges(ctx):
         g.close()
 
 
+def test_a_call_on_another_context_is_not_recorded(ctx):
+    """between ivx_many_begin(ctx A) and its flush, a call on an object of context B goes out on B's own stream (what A has recorded is
+    flushed first, recording resumes afterwards): results of both as if nothing had been recorded"""
+    from impact_amd.voxel import Context
+
+    lib = capi.lib()
+    other = Context(0)
+    try:
+        from test_gpu_mesh_sync import both
+
+        oa, ga = both(ctx, scenes.sphere_scene(22.0))
+        ob, gb = both(other, scenes.sphere_scene(18.0))
+
+        def top(o):
+            occ = np.array(o.info()["occupied_voxel_ranges"], dtype=np.float32)
+            c = 0.5 * (occ[:, 0] + occ[:, 1])
+            c[0] = occ[0, 1] - 1.0
+            return c
+
+        ca, cb = top(oa), top(ob)
+        ra, rb = oa.absorb_sphere(ca, 6.0, 4.0), ob.absorb_sphere(cb, 5.0, 3.0)
+        capi.check(lib.ivx_many_begin(ctx.h))
+        ga.absorb_sphere_enqueue(ca, 6.0, 4.0)   # recorded for context A
+        gb.absorb_sphere_enqueue(cb, 5.0, 3.0)   # context B: flushes A's, runs unrecorded
+        capi.check(lib.ivx_many_flush(ctx.h))
+        xa, xb = ga.absorb_collect(), gb.absorb_collect()
+        np.testing.assert_array_equal(xa["invalidated"], ra["invalidated"])
+        np.testing.assert_array_equal(xb["invalidated"], rb["invalidated"])
+        pu.assert_edited_objects_equal(oa, ga, "context A: ", with_mesh=False)
+        pu.assert_edited_objects_equal(ob, gb, "context B: ", with_mesh=False)
+        ga.close()
+        gb.close()
+    finally:
+        other.close()
+
+
 def test_step_many_with_the_sample_stage(ctx):
     """`ivx_voxel_step_many` with IVX_STAGE_SAMPLE: the sample stage has no twin and runs object by object inside the call; the rest merges"""
     from impact_amd.voxel import SDFVoxelGenerator, VoxelObject
