@@ -13,19 +13,17 @@ from .capi import check, ptr
 
 
 def _handles(objects):
-    arr = (C.c_void_p * len(objects))()
-    for i, o in enumerate(objects):
-        arr[i] = o.h.value if isinstance(o.h, C.c_void_p) else o.h
-    return arr
+    """the objects' handles as a C array of pointers (a uint64 array: one conversion for all instead of a ctypes assignment each)"""
+    return np.fromiter((o.h.value if isinstance(o.h, C.c_void_p) else o.h for o in objects), dtype=np.uint64, count=len(objects))
 
 
 def voxel_step_many(objects, stages: int):
     """`ivx_voxel_step_many`: `VoxelObject.step(stages)` of every object -> array of step results"""
     out = np.zeros(len(objects), dtype=capi.STEP_RESULT_DTYPE)
-    check(capi.lib().ivx_voxel_step_many(_handles(objects), len(objects), stages, ptr(out)))
-    for o, r in zip(objects, out):
-        if stages & capi.STAGE_REGIONS:
-            o._region_count = int(r["region_count"])
+    check(capi.lib().ivx_voxel_step_many(ptr(_handles(objects)), len(objects), stages, ptr(out)))
+    if stages & capi.STAGE_REGIONS:
+        for o, n in zip(objects, out["region_count"].tolist()):
+            o._region_count = n
     return out
 
 
@@ -56,16 +54,15 @@ def _absorb_many(objects, centers, segments, influence_radii, sphere_radii, dens
         iv = (buf.ctypes.data + offs[:-1]).astype(np.uint64)
         inval = [buf[offs[i]:offs[i + 1]] for i in range(n)]
     if sg is None:
-        check(capi.lib().ivx_absorb_sphere_many(_handles(objects), n, ptr(c), ptr(ri), ptr(rs), ptr(d), ptr(out), ptr(iv) if iv is not None else None))
+        check(capi.lib().ivx_absorb_sphere_many(ptr(_handles(objects)), n, ptr(c), ptr(ri), ptr(rs), ptr(d), ptr(out), ptr(iv) if iv is not None else None))
     else:
-        check(capi.lib().ivx_absorb_capsule_many(_handles(objects), n, ptr(c), ptr(sg), ptr(ri), ptr(rs), ptr(d), ptr(out), ptr(iv) if iv is not None else None))
-    res = []
-    for i, o in enumerate(objects):
+        check(capi.lib().ivx_absorb_capsule_many(ptr(_handles(objects)), n, ptr(c), ptr(sg), ptr(ri), ptr(rs), ptr(d), ptr(out), ptr(iv) if iv is not None else None))
+    for o in objects:
         o._region_count = None
-        r = out[i]
-        res.append({"removed_moments": r["removed_moments"], "emptied_voxels": int(r["emptied_voxels"]), "invalidated": None if inval is None else inval[i],
-                    "touched_chunks": int(r["touched_chunks"]), "removed_chunks": int(r["removed_chunks"])})
-    return res
+    # (columns converted once: a structured-array field access per object costs more than the call's share of that object)
+    rm, ev, tc, rc = out["removed_moments"], out["emptied_voxels"].tolist(), out["touched_chunks"].tolist(), out["removed_chunks"].tolist()
+    return [{"removed_moments": rm[i], "emptied_voxels": ev[i], "invalidated": None if inval is None else inval[i], "touched_chunks": tc[i], "removed_chunks": rc[i]}
+            for i in range(n)]
 
 
 def mesh_sync_many(meshes, invalidated):
@@ -74,11 +71,11 @@ def mesh_sync_many(meshes, invalidated):
     objs = [m.object for m in meshes]
     inv = [a if (isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]) else np.ascontiguousarray(np.asarray(a).reshape(-1), dtype=np.uint8)
            for a in invalidated]
-    iv = np.fromiter((a.ctypes.data for a in inv), dtype=np.uint64, count=n)
+    iv = np.fromiter((a.__array_interface__["data"][0] for a in inv), dtype=np.uint64, count=n)  # (`.ctypes.data` builds a ctypes object per array)
     for a, o in zip(inv, objs):
         assert a.size == o.n_chunks
     out = np.zeros(n, dtype=capi.MESH_COUNTS_DTYPE)
-    check(capi.lib().ivx_mesh_sync_many(_handles(objs), n, ptr(iv), ptr(out)))
-    for m, c in zip(meshes, out):
-        m.counts = c
+    check(capi.lib().ivx_mesh_sync_many(ptr(_handles(objs)), n, ptr(iv), ptr(out)))
+    for i, m in enumerate(meshes):
+        m.counts = out[i]
     return meshes
