@@ -24,7 +24,9 @@
 // One workgroup of 1024 threads walks the levels (a level is ~10^2 contacts; the chain of levels is
 // the critical path, so more workgroups would only add grid-wide barriers). f32 throughout, no FMA
 // contraction, IEEE sqrt/div — same operation order as the oracle.
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "ivx_internal.hpp"
 #include "physics_internal.hpp"
@@ -337,59 +339,70 @@ struct ReplayView {
     uint32_t* applied = nullptr;     // [item]: corrections the chain applied (written in pass 1 for chains with a kinematic body)
 };
 
-__device__ __forceinline__ void apply_pair(const PhysContact& p, const PairStatic& st, PairState& x, V3 pb, float in, float it, float ib_) {
-    const V3 dp = (ld3(p.normal) * in + ld3(p.tangent) * it) + ld3(p.bitangent) * ib_;
+// a prepared contact as the velocity phase uses it: the pair's lever arms to the contact point (world_b - position: the configuration is
+// fixed during the phase) in place of the point itself
+struct ContactV {
+    V3 n, t, b;
+    float m_n, m_t, m_b, friction, target;
+    V3 da, db;
+};
+__device__ __forceinline__ ContactV contact_v(const PhysContact& p, V3 pos_a, V3 pos_b) {
+    const V3 pb = ld3(p.world_b);
+    return ContactV{ld3(p.normal), ld3(p.tangent), ld3(p.bitangent), p.m_n, p.m_t, p.m_b, p.friction, p.target, pb - pos_a, pb - pos_b};
+}
+__device__ __forceinline__ void apply_pair(const ContactV& c, const PairStatic& st, PairState& x, float in, float it, float ib_) {
+    const V3 dp = (c.n * in + c.t * it) + c.b * ib_;
     if (st.dyn_a) {
-        const V3 da = pb - st.pos_a;
         x.va = x.va + dp * st.ima;
-        x.wa = x.wa + mul(st.iia, cross(da, dp));
+        x.wa = x.wa + mul(st.iia, cross(c.da, dp));
     }
     if (st.dyn_b) {
-        const V3 db = pb - st.pos_b;
         x.vb = x.vb - dp * st.imb;
-        x.wb = x.wb - mul(st.iib, cross(db, dp));
+        x.wb = x.wb - mul(st.iib, cross(c.db, dp));
     }
+}
+// one contact of a warm-start or velocity item. `acc` in: the accumulated impulses of the contact; out: what a velocity item leaves there
+__device__ __forceinline__ void run_contact_v(uint32_t type, const ContactV& c, const PairStatic& st, PairState& x, float4& acc) {
+    if (type == PHYS_ITEM_WARM) {
+        apply_pair(c, st, x, acc.x, acc.y, acc.z);
+        return;
+    }
+    // compute_impulses -> clamp -> apply the difference (solver.rs:496-528)
+    const V3 rel = point_velocity(x.va, x.wa, c.da) - point_velocity(x.vb, x.wb, c.db);
+    const float sep = dot(c.n, rel);
+    const float cn = -c.m_n * (sep - c.target), ct = -c.m_t * dot(c.t, rel), cbi = -c.m_b * dot(c.b, rel);
+    const float un = acc.x + cn, ut = acc.y + ct, ub = acc.z + cbi;
+    const float nn = max_rs(0.0f, un);
+    const float max_t = c.friction * nn;
+    const float mag = sqrtf(ut * ut + ub * ub);
+    const float sc = mag > max_t ? max_t / mag : 1.0f;
+    const float nt = ut * sc, nb = ub * sc;
+    apply_pair(c, st, x, nn - acc.x, nt - acc.y, nb - acc.z);
+    acc = make_float4(nn, nt, nb, 0.0f);
+}
+// one contact of a positional item
+__device__ __forceinline__ void run_contact_p(V3 n, V3 local_a, V3 local_b, const PairStatic& st, PairState& x, float factor) {
+    const V3 pa = qrot(x.qa, local_a) + x.pa, pb = qrot(x.qb, local_b) + x.pb;
+    const float depth = dot(n, pb - pa);
+    if (depth <= 0.0f) return;
+    const V3 da = pb - x.pa, db = pb - x.pb;
+    const float m = effective_mass(st.ima, st.iia, st.imb, st.iib, da, db, n);
+    const V3 dp = n * (m * factor * depth);
+    // (both bodies, dynamic or not: on a kinematic body's zeros this leaves the position and re-normalises the orientation, as in the
+    // reference; only dynamic bodies are ever stored)
+    x.pa = x.pa + dp * st.ima;
+    x.qa = pseudo_advanced(x.qa, mul(st.iia, cross(da, dp)));
+    x.pb = x.pb + dp * (-st.imb);
+    x.qb = pseudo_advanced(x.qb, mul(M3{-st.iib.c0, -st.iib.c1, -st.iib.c2}, cross(db, dp)));
+    x.applied += 1u;
 }
 
 // one contact of a chain; `type` is uniform over the chain
 // `acc` in: the accumulated impulses of the contact; out: what a velocity item leaves there (the caller stores it — after the whole chain: on this
 // part a store counts in vmcnt like a load, and waiting for the next contact's data would also wait for the store's acknowledgement, ~1.5 us each)
 __device__ __forceinline__ void run_contact(uint32_t type, const PhysContact& p, const PairStatic& st, PairState& x, float factor, float4& acc) {
-    if (type == PHYS_ITEM_POSITIONAL) {
-        const V3 n = ld3(p.normal);
-        const V3 pa = qrot(x.qa, ld3(p.local_a)) + x.pa, pb = qrot(x.qb, ld3(p.local_b)) + x.pb;
-        const float depth = dot(n, pb - pa);
-        if (depth <= 0.0f) return;
-        const V3 da = pb - x.pa, db = pb - x.pb;
-        const float m = effective_mass(st.ima, st.iia, st.imb, st.iib, da, db, n);
-        const V3 dp = n * (m * factor * depth);
-        // (both bodies, dynamic or not: on a kinematic body's zeros this leaves the position and re-normalises the orientation, as in the
-        // reference; only dynamic bodies are ever stored)
-        x.pa = x.pa + dp * st.ima;
-        x.qa = pseudo_advanced(x.qa, mul(st.iia, cross(da, dp)));
-        x.pb = x.pb + dp * (-st.imb);
-        x.qb = pseudo_advanced(x.qb, mul(M3{-st.iib.c0, -st.iib.c1, -st.iib.c2}, cross(db, dp)));
-        x.applied += 1u;
-        return;
-    }
-    const V3 pb = ld3(p.world_b);
-    if (type == PHYS_ITEM_WARM) {
-        apply_pair(p, st, x, pb, acc.x, acc.y, acc.z);
-        return;
-    }
-    // compute_impulses -> clamp -> apply the difference (solver.rs:496-528)
-    const V3 da = pb - st.pos_a, db = pb - st.pos_b;
-    const V3 rel = point_velocity(x.va, x.wa, da) - point_velocity(x.vb, x.wb, db);
-    const float sep = dot(ld3(p.normal), rel);
-    const float cn = -p.m_n * (sep - p.target), ct = -p.m_t * dot(ld3(p.tangent), rel), cbi = -p.m_b * dot(ld3(p.bitangent), rel);
-    const float un = acc.x + cn, ut = acc.y + ct, ub = acc.z + cbi;
-    const float nn = max_rs(0.0f, un);
-    const float max_t = p.friction * nn;
-    const float mag = sqrtf(ut * ut + ub * ub);
-    const float sc = mag > max_t ? max_t / mag : 1.0f;
-    const float nt = ut * sc, nb = ub * sc;
-    apply_pair(p, st, x, pb, nn - acc.x, nt - acc.y, nb - acc.z);
-    acc = make_float4(nn, nt, nb, 0.0f);
+    if (type == PHYS_ITEM_POSITIONAL) run_contact_p(ld3(p.normal), ld3(p.local_a), ld3(p.local_b), st, x, factor);
+    else run_contact_v(type, contact_v(p, st.pos_a, st.pos_b), st, x, acc);
 }
 
 // LDS = true: the phase's mutable state of the dynamic bodies lives in s_dyn (velocity: 6 floats v,w; positional: 7 floats
@@ -977,6 +990,298 @@ __global__ __launch_bounds__(MG_THREADS) void k_solve_mg(uint32_t n_dyn, float f
     }
 }
 
+// ---- the chain-stationary solve ------------------------------------------------------------------------------------------------------
+// k_solve_mg hands tiles of the level schedule to whichever wave is next: every item fetches its packed record (480 bytes), its accumulated
+// impulses and its two bodies, and leaves impulses and bodies behind — and a level costs ~2.6 us of work + ~2 us of hand-off, 183 times.
+// Here a chain STAYS in one lane of one wave for the whole phase (host: build_stationary). What never changes during the solve — the chain's
+// prepared contacts, the pair's inverse masses and inertia — is gathered once into the lane's registers, the accumulated impulses live there
+// from the warm start to the last sweep, and the only thing that travels between items is what has to: the two bodies' mutable state, through
+// the same version-tagged 16-byte records as k_solve_mg's (a body's record carries the number of items that have touched it; sweep s of a
+// chain finds s * degree + rank there, two per-chain constants). A wave walks its tile's ROUNDS — the distinct levels its items lie on, a
+// lane mask each — in level order; the lanes of a round load their operands past the L1 until they carry the expected tags, run the chain,
+// store the pair's new state one version on. The arithmetic per item is run_contact's, so the result is the sequential loop's, operation
+// for operation.
+// One launch runs BOTH phases: blocks with blockIdx % spread == 0 are the velocity phase's workgroups, == 1 the positional phase's (under the
+// observed round-robin placement two XCDs with a phase each; the census decides the form of the stores, never the result). All working
+// workgroups must be resident (512 threads at up to 256 registers: one per CU, at most PHYS_CS_MAX_GROUPS per phase); every poll is bounded
+// and flags the launch.
+struct CsPhase {
+    const uint32_t* item;         // [tile * 64 + lane] first contact | length << 24, ~0: no chain
+    const uint2* bodies;          // constrained-body indices of the pair
+    const uint2* vers;            // degree | rank << 16 of the chain on body a, b
+    const uint32_t* round_start;  // [tile] first round of the tile (n_tiles + 1 entries)
+    const uint64_t* round_mask;   // lanes of the round
+    const uint32_t* round_level;  // level its items lie on (from 1)
+    float4* dynst;                // the phase's shared body records
+    uint32_t* counter;            // grid barrier of the phase's workgroups (monotonic)
+    uint32_t* xcc_table;
+    const uint32_t* slot_of;      // positional phase with kinematic bodies: [(tile * 64 + lane) * n_passes + sweep] -> the index ReplayView goes by
+    const uint32_t* replay_flag;
+    unsigned long long* trace;    // developer switch IVX_SOLVER_TRACE: per round 4 stamps of the 100 MHz clock (round begins, operands there, chain run, stores issued)
+    ReplayView rv;
+    uint32_t n_tiles, n_groups, n_first, counter_base, n_passes;
+    uint32_t nap;  // tenths of a level a wave starts polling ahead of its round's expected time (0: polls from the end of its last round)
+};
+constexpr uint32_t CS_THREADS = PHYS_CS_WAVES * 64u;
+
+template <int PHASE>
+__device__ __forceinline__ void solve_cs_phase(const uint32_t wg, const uint32_t n_dyn, const float factor, const PhysContact* __restrict__ pcs,
+                                               float4* __restrict__ accs, const uint32_t n_contacts, const PhysBody* __restrict__ cb, const CsPhase& ph,
+                                               uint32_t* __restrict__ error, const uint32_t dry) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t tile = __builtin_amdgcn_readfirstlane(wg * PHYS_CS_WAVES + (tid >> 6));
+    const uint32_t G = ph.n_groups;
+    if (ph.replay_flag && *ph.replay_flag == 0u) {  // pass 2 of the positional phase with no kinematic orientation that moved (uniform over the launch)
+        if (tid == 0u) __hip_atomic_fetch_add(ph.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the host has counted this launch's arrivals)
+        return;
+    }
+    constexpr uint32_t DST = PHASE == 0 ? 32u : 48u;
+    const __amdgpu_buffer_rsrc_t rs_dyn = __builtin_amdgcn_make_buffer_rsrc(ph.dynst, 0, n_dyn * DST, 0x00020000);
+    // census (as in k_solve_mg): which XCD is every working workgroup of the phase on?
+    const uint32_t xcc_tag = (ph.counter_base << 4) | (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFu);
+    if (tid == 0u) __hip_atomic_store(ph.xcc_table + wg, xcc_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mg_arrive(ph.counter);
+    // ---- the lane's chain, once: prepared contacts, the pair's constants, the accumulated impulses (their trips to memory run beside the barrier)
+    const bool in_tile = tile < ph.n_tiles;
+    const uint32_t slot = tile * 64u + lane;
+    const uint32_t item = in_tile ? ph.item[slot] : 0xFFFFFFFFu;
+    const bool has = item != 0xFFFFFFFFu;
+    const uint32_t s0 = has ? (item & 0x00FFFFFFu) : 0u, len = has ? ((item >> 24) & 15u) : 0u;
+    const uint2 bodies = has ? ph.bodies[slot] : make_uint2(0u, 0u);
+    const uint2 vr = has ? ph.vers[slot] : make_uint2(0u, 0u);
+    const uint32_t ia = bodies.x, ib = bodies.y;
+    const uint32_t deg_a = vr.x & 0xFFFFu, rank_a = vr.x >> 16, deg_b = vr.y & 0xFFFFu, rank_b = vr.y >> 16;
+    ContactV cv0 = {}, cv1 = {}, cv2 = {}, cv3 = {};  // velocity phase: the chain's prepared contacts
+    struct ContactP {
+        V3 n, la, lb;
+    } cp0 = {}, cp1 = {}, cp2 = {}, cp3 = {};  // positional phase
+    float4 ac0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), ac1 = ac0, ac2 = ac0, ac3 = ac0;
+    PairStatic st = {};
+    if (has) {
+        const PhysBody& A = cb[ia];
+        const PhysBody& B = cb[ib];
+        st.ima = A.inv_mass;
+        st.imb = B.inv_mass;
+        st.iia = ldm(A.inv_inertia);
+        st.iib = ldm(B.inv_inertia);
+        st.dyn_a = ia < n_dyn;
+        st.dyn_b = ib < n_dyn;
+        if (PHASE == 0) {
+            const V3 pos_a = ld3(A.pos), pos_b = ld3(B.pos);
+            cv0 = contact_v(pcs[s0], pos_a, pos_b);
+            ac0 = accs[s0];
+            if (len > 1u) cv1 = contact_v(pcs[s0 + 1u], pos_a, pos_b), ac1 = accs[s0 + 1u];
+            if (len > 2u) cv2 = contact_v(pcs[s0 + 2u], pos_a, pos_b), ac2 = accs[s0 + 2u];
+            if (len > 3u) cv3 = contact_v(pcs[s0 + 3u], pos_a, pos_b), ac3 = accs[s0 + 3u];
+        } else {
+            auto cp = [&](uint32_t c) {
+                const PhysContact& p = pcs[s0 + c];
+                return ContactP{ld3(p.normal), ld3(p.local_a), ld3(p.local_b)};
+            };
+            cp0 = cp(0u);
+            if (len > 1u) cp1 = cp(1u);
+            if (len > 2u) cp2 = cp(2u);
+            if (len > 3u) cp3 = cp(3u);
+        }
+    }
+    mg_wait(ph.counter, ph.counter_base + G, error);
+    bool one_xcd = G <= PHYS_CS_MAX_GROUPS;
+    for (uint32_t q = 0; q < G && q < PHYS_CS_MAX_GROUPS; ++q)
+        one_xcd = one_xcd && __hip_atomic_load(ph.xcc_table + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == xcc_tag;
+    if (dry & 4u) one_xcd = false;  // (developer switch: the write-through form wherever the workgroups sit)
+    if (!in_tile) return;
+    // ---- the rounds
+    // (the masks through the scalar cache: everything that addresses them is uniform over the wave; a round's mask is fetched a round ahead)
+    const uint32_t r0 = __builtin_amdgcn_readfirstlane(ph.round_start[tile]), r1 = __builtin_amdgcn_readfirstlane(ph.round_start[tile + 1u]);
+    uint32_t sweep = 0u;
+    typedef const uint64_t __attribute__((address_space(4))) * scalar_u64_ptr;  // (constant address space: s_load, counted apart from the vector loads)
+    const scalar_u64_ptr masks = (scalar_u64_ptr)(uintptr_t)ph.round_mask;
+    typedef const uint32_t __attribute__((address_space(4))) * scalar_u32_ptr;
+    const scalar_u32_ptr levels = (scalar_u32_ptr)(uintptr_t)ph.round_level;
+    uint64_t mask_next = r0 < r1 ? masks[r0] : 0ull;
+    uint32_t level_next = r0 < r1 ? levels[r0] : 0u;
+    // NAPS. A chain runs once per sweep, a wave a handful of rounds per sweep: most of the time a wave's next round is levels away, and hundreds
+    // of waves polling all that time fill the L2's request queues in front of the few whose operands are about to arrive (measured: 5.4 us per
+    // level with everyone polling). Levels pass at a steady pace for all waves, so a wave sleeps until `nap` tenths of a level before its
+    // round is due, counted from the end of its last round at nine tenths of the pace so far by its own clock, (now - start) / level, never
+    // taken below what a level's arithmetic alone costs. A wrong guess costs time, never correctness: the poll below decides.
+    const unsigned long long t_start = wall_clock64();  // (100 MHz)
+    unsigned long long t_last = t_start;
+    uint32_t level_last = 0u;
+    uint32_t pace = PHASE == 0 ? 150u : 250u;  // 10 ns ticks per level, lower bound
+    for (uint32_t r = r0; r < r1; ++r) {
+        const uint64_t mask = mask_next;
+        const uint32_t level = level_next;
+        mask_next = masks[r + 1u < r1 ? r + 1u : r];
+        level_next = levels[r + 1u < r1 ? r + 1u : r];
+        if (ph.nap) {
+            const uint32_t gap10 = (level - level_last) * 10u;
+            const unsigned long long due = t_last + (unsigned long long)(gap10 > ph.nap ? gap10 - ph.nap : 0u) * pace / 10ull;
+            while (wall_clock64() < due) __builtin_amdgcn_s_sleep(8);
+        }
+        if (ph.trace && lane == 0u) ph.trace[4u * r] = wall_clock64();
+        const bool active = has && ((mask >> lane) & 1ull) != 0ull;
+        const uint32_t type = PHASE == 1 ? PHYS_ITEM_POSITIONAL : (sweep < ph.n_first ? PHYS_ITEM_WARM : PHYS_ITEM_VELOCITY);
+        const uint32_t ver_a = sweep * deg_a + rank_a, ver_b = sweep * deg_b + rank_b;
+        // (a kinematic body of the pair: what it moves with / where it stands comes from the body array every round — constant during the
+        // solve, so these are plain loads that the L1 serves after the first, issued ahead of the wait for the dynamic bodies)
+        PairState x;
+        if (active && !st.dyn_a) {
+            if (PHASE == 0) x.va = ld3(cb[ia].v), x.wa = ld3(cb[ia].w);
+            else x.pa = ld3(cb[ia].pos), x.qa = ldq(cb[ia].q);
+        }
+        if (active && !st.dyn_b) {
+            if (PHASE == 0) x.vb = ld3(cb[ib].v), x.wb = ld3(cb[ib].w);
+            else x.pb = ld3(cb[ib].pos), x.qb = ldq(cb[ib].q);
+        }
+        // THE HAND-OFF: the pair's records, past the L1, until they carry the versions this sweep of the chain starts from. All loads of a
+        // poll are issued back to back by every lane (a lane with nothing to wait for reads record 0 and ignores it): one trip per poll.
+        const bool need_a = active && st.dyn_a, need_b = active && st.dyn_b;
+        const uint32_t off_a = need_a ? ia * DST : 0u, off_b = need_b ? ib * DST : 0u;
+        float4 a0, a1, a2 = make_float4(0, 0, 0, 0), b0, b1, b2 = a2;
+        for (uint32_t spins = 0;; ++spins) {
+            a0 = ld16_sc1(rs_dyn, off_a);
+            a1 = ld16_sc1(rs_dyn, off_a + 16u);
+            b0 = ld16_sc1(rs_dyn, off_b);
+            b1 = ld16_sc1(rs_dyn, off_b + 16u);
+            uint32_t ok_a = (uint32_t)(__float_as_uint(a0.w) == ver_a) & (uint32_t)(__float_as_uint(a1.w) == ver_a);
+            uint32_t ok_b = (uint32_t)(__float_as_uint(b0.w) == ver_b) & (uint32_t)(__float_as_uint(b1.w) == ver_b);
+            if (PHASE == 1) {
+                a2 = ld16_sc1(rs_dyn, off_a + 32u);
+                b2 = ld16_sc1(rs_dyn, off_b + 32u);
+                ok_a = ok_a & (uint32_t)(__float_as_uint(a2.w) == ver_a);
+                ok_b = ok_b & (uint32_t)(__float_as_uint(b2.w) == ver_b);
+            }
+            const bool ok = (((uint32_t)!need_a | ok_a) & ((uint32_t)!need_b | ok_b)) != 0u;
+            if ((dry & 2u) || __builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (spins > MG_SPIN_LIMIT) {
+                if (lane == 0u) __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (host-mapped: ivx_world_check_solve)
+                break;
+            }
+        }
+        if (ph.trace && lane == 0u) ph.trace[4u * r + 1u] = wall_clock64();
+        if (active) {
+        uint32_t rv_index = 0u;
+        if (PHASE == 0) {
+            if (st.dyn_a) x.va = mk(a0.x, a0.y, a0.z), x.wa = mk(a1.x, a1.y, a1.z);
+            if (st.dyn_b) x.vb = mk(b0.x, b0.y, b0.z), x.wb = mk(b1.x, b1.y, b1.z);
+            run_contact_v(type, cv0, st, x, ac0);
+            if (len > 1u) run_contact_v(type, cv1, st, x, ac1);
+            if (len > 2u) run_contact_v(type, cv2, st, x, ac2);
+            if (len > 3u) run_contact_v(type, cv3, st, x, ac3);
+        } else {
+            if (st.dyn_a) x.pa = mk(a0.x, a0.y, a0.z), x.qa = Q4{a1.x, a1.y, a1.z, a2.x};
+            if (st.dyn_b) x.pb = mk(b0.x, b0.y, b0.z), x.qb = Q4{b1.x, b1.y, b1.z, b2.x};
+            if ((ph.rv.qstart || ph.rv.applied) && !(st.dyn_a && st.dyn_b)) rv_index = ph.slot_of[slot * ph.n_passes + sweep];
+            if (ph.rv.qstart) {  // pass 2: a kinematic body's orientation as the chains before this one left it (ReplayView)
+                if (!st.dyn_a) {
+                    const float4 t = ph.rv.qstart[2u * rv_index];
+                    x.qa = Q4{t.x, t.y, t.z, t.w};
+                }
+                if (!st.dyn_b) {
+                    const float4 t = ph.rv.qstart[2u * rv_index + 1u];
+                    x.qb = Q4{t.x, t.y, t.z, t.w};
+                }
+            }
+            run_contact_p(cp0.n, cp0.la, cp0.lb, st, x, factor);
+            if (len > 1u) run_contact_p(cp1.n, cp1.la, cp1.lb, st, x, factor);
+            if (len > 2u) run_contact_p(cp2.n, cp2.la, cp2.lb, st, x, factor);
+            if (len > 3u) run_contact_p(cp3.n, cp3.la, cp3.lb, st, x, factor);
+        }
+        if (PHASE == 1 && ph.rv.applied && !(st.dyn_a && st.dyn_b)) ph.rv.applied[rv_index] = x.applied;
+        if (ph.trace && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) ph.trace[4u * r + 2u] = wall_clock64();
+        const float na = __uint_as_float(ver_a + 1u), nb = __uint_as_float(ver_b + 1u);
+        if (PHASE == 0) {
+            if (st.dyn_a) {
+                st16_shared(rs_dyn, ia * DST, make_float4(x.va.x, x.va.y, x.va.z, na), one_xcd);
+                st16_shared(rs_dyn, ia * DST + 16u, make_float4(x.wa.x, x.wa.y, x.wa.z, na), one_xcd);
+            }
+            if (st.dyn_b) {
+                st16_shared(rs_dyn, ib * DST, make_float4(x.vb.x, x.vb.y, x.vb.z, nb), one_xcd);
+                st16_shared(rs_dyn, ib * DST + 16u, make_float4(x.wb.x, x.wb.y, x.wb.z, nb), one_xcd);
+            }
+        } else {
+            if (st.dyn_a) {
+                st16_shared(rs_dyn, ia * DST, make_float4(x.pa.x, x.pa.y, x.pa.z, na), one_xcd);
+                st16_shared(rs_dyn, ia * DST + 16u, make_float4(x.qa.x, x.qa.y, x.qa.z, na), one_xcd);
+                st16_shared(rs_dyn, ia * DST + 32u, make_float4(x.qa.w, 0.0f, 0.0f, na), one_xcd);
+            }
+            if (st.dyn_b) {
+                st16_shared(rs_dyn, ib * DST, make_float4(x.pb.x, x.pb.y, x.pb.z, nb), one_xcd);
+                st16_shared(rs_dyn, ib * DST + 16u, make_float4(x.qb.x, x.qb.y, x.qb.z, nb), one_xcd);
+                st16_shared(rs_dyn, ib * DST + 32u, make_float4(x.qb.w, 0.0f, 0.0f, nb), one_xcd);
+            }
+        }
+        if (ph.trace && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) ph.trace[4u * r + 3u] = wall_clock64();
+        sweep += 1u;
+        }  // (active)
+        // the pace so far, by this wave's clock
+        t_last = wall_clock64();
+        level_last = level;
+        const uint32_t measured = __builtin_amdgcn_readfirstlane((uint32_t)(t_last - t_start)) * 9u / (level * 10u);
+        pace = measured > pace ? measured : pace;
+    }
+    // the accumulated impulses as the last sweep left them (next frame's warm start, ivx_world_contact_state)
+    if (PHASE == 0 && has && sweep > ph.n_first) {
+        ac0.w = ac1.w = ac2.w = ac3.w = 0.0f;
+        accs[s0] = ac0;
+        if (len > 1u) accs[s0 + 1u] = ac1;
+        if (len > 2u) accs[s0 + 2u] = ac2;
+        if (len > 3u) accs[s0 + 3u] = ac3;
+    }
+}
+
+__global__ __launch_bounds__(CS_THREADS) void k_solve_cs(uint32_t n_dyn, float factor, const PhysContact* __restrict__ pcs, float4* __restrict__ accs,
+                                                         uint32_t n_contacts, const PhysBody* __restrict__ cb, CsPhase vel, CsPhase pos,
+                                                         uint32_t* __restrict__ error, uint32_t dry, uint32_t spread) {
+    // spread > 1: block b is workgroup b / spread of the velocity phase when b % spread == 0, of the positional phase when b % spread == 1, and
+    // nothing otherwise; spread == 1 (developer switch): the velocity phase's workgroups first, then the positional phase's
+    uint32_t phase, wg;
+    if (spread > 1u) {
+        phase = blockIdx.x % spread;
+        wg = blockIdx.x / spread;
+    } else {
+        phase = blockIdx.x < vel.n_groups ? 0u : 1u;
+        wg = phase ? blockIdx.x - vel.n_groups : blockIdx.x;
+    }
+    if (phase == 0u && wg < vel.n_groups) solve_cs_phase<0>(wg, n_dyn, factor, pcs, accs, n_contacts, cb, vel, error, dry);
+    else if (phase == 1u && wg < pos.n_groups) solve_cs_phase<1>(wg, n_dyn, factor, pcs, accs, n_contacts, cb, pos, error, dry);
+}
+
+// the phases' shared body records before the solve (tag 0: no item has touched the body) ...
+__global__ __launch_bounds__(256) void k_cs_init(uint32_t n_dyn, const PhysBody* __restrict__ cb, float4* __restrict__ dyn_vel, float4* __restrict__ dyn_pos,
+                                                 const uint32_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_dyn || (flag && *flag == 0u)) return;
+    const PhysBody& b = cb[i];
+    if (dyn_vel) {
+        dyn_vel[2u * i] = make_float4(b.v[0], b.v[1], b.v[2], 0.0f);
+        dyn_vel[2u * i + 1u] = make_float4(b.w[0], b.w[1], b.w[2], 0.0f);
+    }
+    if (dyn_pos) {
+        dyn_pos[3u * i] = make_float4(b.pos[0], b.pos[1], b.pos[2], 0.0f);
+        dyn_pos[3u * i + 1u] = make_float4(b.q[0], b.q[1], b.q[2], 0.0f);
+        dyn_pos[3u * i + 2u] = make_float4(b.q[3], 0.0f, 0.0f, 0.0f);
+    }
+}
+// ... and back into the constrained bodies after it (the array the write-back reads)
+__global__ __launch_bounds__(256) void k_cs_finish(uint32_t n_dyn, PhysBody* __restrict__ cb, const float4* __restrict__ dyn_vel, const float4* __restrict__ dyn_pos) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_dyn) return;
+    PhysBody& b = cb[i];
+    if (dyn_vel) {
+        const float4 r0 = dyn_vel[2u * i], r1 = dyn_vel[2u * i + 1u];
+        st3(b.v, mk(r0.x, r0.y, r0.z));
+        st3(b.w, mk(r1.x, r1.y, r1.z));
+    }
+    if (dyn_pos) {
+        const float4 r0 = dyn_pos[3u * i], r1 = dyn_pos[3u * i + 1u], r2 = dyn_pos[3u * i + 2u];
+        st3(b.pos, mk(r0.x, r0.y, r0.z));
+        stq(b.q, Q4{r1.x, r1.y, r1.z, r2.x});
+    }
+}
+
 // ---- kinematic orientations in the positional phase (ReplayView) --------------------------------------------------------------------
 // the dynamic bodies' configuration as the phase finds it, for pass 2 to start from again
 __global__ __launch_bounds__(256) void k_kin_snapshot(uint32_t n_dyn, const PhysBody* __restrict__ cb, float4* __restrict__ snap) {
@@ -1104,7 +1409,7 @@ static uint32_t solver_groups(const ivx_world* w) {
     }();
     const uint32_t fit = (uint32_t)(resident > 0 ? resident : 0) * (uint32_t)w->ctx->n_cu / 8u;  // (/ 8: every eighth block works, see k_solve_mg)
     if (fit < 2u) return 1u;
-    if (w->solver_groups_forced) return w->solver_groups_forced < fit ? w->solver_groups_forced : fit;
+    if (w->solver_groups_forced && w->solver_groups_forced <= 16u) return w->solver_groups_forced < fit ? w->solver_groups_forced : fit;
     const uint32_t widest = w->max_level_items[0] > w->max_level_items[1] ? w->max_level_items[0] : w->max_level_items[1];
     if (widest <= 256u) return 1u;  // (a level that fits one workgroup at one wave per SIMD gains nothing from more)
     uint32_t g = (widest + 159u) / 160u;  // (a few more waves than the widest level has tiles: measured on the 4096-body pile, 8 workgroups 0.85 ms, 5: 0.89, 16: 0.86)
@@ -1167,11 +1472,141 @@ static int launch_solve_mg(ivx_world* w, uint32_t groups, hipStream_t stream, Re
     return IVX_OK;
 }
 
+// The chain-stationary solve: can this world's schedule run on it, and should it? Needs every phase that has levels in stationary form
+// (build_stationary), one workgroup of CS_THREADS per CU and an eighth of the CUs (one XCD's worth) per phase for its workgroups.
+static bool solver_stationary(const ivx_world* w) {
+    if (w->mg_disabled || w->solver_groups_forced == 1u || (w->solver_groups_forced >= 2u && w->solver_groups_forced <= 16u)) return false;
+    for (int p = 0; p < 2; ++p)
+        if (w->n_levels[p] && !w->cs[p].n_tiles) return false;
+    if (!w->n_levels[0] && !w->n_levels[1]) return false;
+    static const int per_cu = [] {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_solve_cs, (int)CS_THREADS, 0) != hipSuccess) n = 0;
+        return n;
+    }();
+    if (per_cu < 1) return false;
+    for (int p = 0; p < 2; ++p)
+        if (w->n_levels[p] && (w->cs[p].n_tiles + PHYS_CS_WAVES - 1u) / PHYS_CS_WAVES > (uint32_t)w->ctx->n_cu / 8u) return false;
+    if (w->solver_groups_forced == PHYS_SOLVER_STATIONARY) return true;
+    const uint32_t widest = w->max_level_items[0] > w->max_level_items[1] ? w->max_level_items[0] : w->max_level_items[1];
+    return widest > 256u;  // (a level that fits one workgroup: k_solve with the bodies in LDS)
+}
+
+static int launch_solve_cs(ivx_world* w) {
+    hipStream_t s = w->ctx->stream;
+    const bool replay = w->n_levels[1] && w->n_kin_items > 0;
+    uint32_t* flag = w->barrier_words + 2;
+    float4* dyn_vel = reinterpret_cast<float4*>(w->dynst);
+    float4* dyn_pos = reinterpret_cast<float4*>(w->dynst + w->body_cap * 16);
+    static const uint32_t spread = [] {  // (developer switch; 8 = a phase's workgroups share one XCD under round-robin placement, 1 = consecutive blocks)
+        const char* e = getenv("IVX_SOLVER_SPREAD");
+        const int v = e ? atoi(e) : 8;
+        return (uint32_t)(v < 2 ? 1 : 8);
+    }();
+    // developer switch: IVX_SOLVER_TRACE=<file> — every round's four clock stamps of the first solve launch of each step, dumped as
+    // [phase][round][4] u64 behind a header of {rounds of phase 0, rounds of phase 1} (tools/solver_trace.py reads it); the step then waits
+    static const char* trace_path = getenv("IVX_SOLVER_TRACE");
+    static unsigned long long* trace_dev = nullptr;
+    static size_t trace_cap = 0;
+    const size_t n_rounds[2] = {w->n_levels[0] ? w->cs_round_start_host[w->cs[0].round_start_offset + w->cs[0].n_tiles] : 0u,
+                                w->n_levels[1] ? w->cs_round_start_host[w->cs[1].round_start_offset + w->cs[1].n_tiles] : 0u};
+    if (trace_path && 4 * (n_rounds[0] + n_rounds[1]) > trace_cap) {
+        if (trace_dev) (void)hipFree(trace_dev);
+        trace_cap = 4 * (n_rounds[0] + n_rounds[1]);
+        IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&trace_dev), trace_cap * 8));
+    }
+    if (trace_path) IVX_HIP_CHECK(ivx_memset_async(trace_dev, 0, trace_cap * 8, s));
+    static const uint32_t nap = [] {  // (developer switch: IVX_SOLVER_NAP = tenths of a level a wave wakes ahead of its round; 0 = never sleeps)
+        const char* e = getenv("IVX_SOLVER_NAP");
+        return (uint32_t)(e ? atoi(e) : 20);
+    }();
+    auto phase_args = [&](int p, bool on, const ReplayView& rv, const uint32_t* replay_flag) {
+        CsPhase a = {};
+        if (!on || !w->n_levels[p]) return a;
+        const ivx_world::CsSchedule& cs = w->cs[p];
+        a.item = w->cs_item + cs.slot_offset;
+        a.bodies = reinterpret_cast<const uint2*>(w->cs_bodies) + cs.slot_offset;
+        a.vers = reinterpret_cast<const uint2*>(w->cs_vers) + cs.slot_offset;
+        a.round_start = w->cs_round_start + cs.round_start_offset;
+        a.round_mask = w->cs_round_mask + cs.round_offset;
+        a.round_level = w->cs_round_level + cs.round_offset;
+        a.nap = nap;
+        a.dynst = p ? dyn_pos : dyn_vel;
+        a.counter = w->barrier_words + p;
+        a.xcc_table = w->barrier_words + 64 + 32 * p;
+        a.slot_of = w->cs_slot_of;
+        a.replay_flag = replay_flag;
+        a.trace = trace_path && !replay_flag ? trace_dev + (p ? 4 * n_rounds[0] : 0) : nullptr;
+        a.rv = rv;
+        a.n_tiles = cs.n_tiles;
+        a.n_groups = (cs.n_tiles + PHYS_CS_WAVES - 1u) / PHYS_CS_WAVES;
+        a.n_first = p ? 0u : 1u;
+        a.n_passes = p ? w->cfg.n_positional_correction_iterations : w->cfg.n_iterations + 1u;
+        uint32_t& count = p ? w->barrier_count1 : w->barrier_count;
+        a.counter_base = count;
+        count += a.n_groups;  // (one grid barrier per launch: behind the census)
+        return a;
+    };
+    auto launch = [&](const CsPhase& v, const CsPhase& p) -> int {
+        const uint32_t blocks = spread > 1u ? spread * (v.n_groups > p.n_groups ? v.n_groups : p.n_groups) : v.n_groups + p.n_groups;
+        if (!blocks) return IVX_OK;
+        IVX_KLAUNCH(k_solve_cs, dim3(blocks), dim3(CS_THREADS), 0, s, w->n_dyn, w->cfg.positional_correction_factor, w->pc[w->cur],
+                    reinterpret_cast<float4*>(w->acc[w->cur]), w->n_contacts, w->cb, v, p, w->mg_err_dev, ivx_solver_dry(), spread);
+        IVX_HIP_CHECK(hipGetLastError());
+        return IVX_OK;
+    };
+    const uint32_t body_blocks = (w->n_dyn + 255u) / 256u;
+    ReplayView pass1, pass2;
+    if (replay) {
+        pass1.applied = w->kin_applied;
+        pass2.qstart = reinterpret_cast<const float4*>(w->kin_qstart);
+        IVX_HIP_CHECK(ivx_memset_async(flag, 0, sizeof(uint32_t), s));
+    }
+    if (body_blocks) {
+        IVX_KLAUNCH(k_cs_init, dim3(body_blocks), dim3(256), 0, s, w->n_dyn, w->cb, w->n_levels[0] ? dyn_vel : nullptr, w->n_levels[1] ? dyn_pos : nullptr, nullptr);
+        IVX_HIP_CHECK(hipGetLastError());
+    }
+    const CsPhase v = phase_args(0, true, ReplayView(), nullptr), p1 = phase_args(1, true, pass1, nullptr);
+    w->solver_groups_used = v.n_groups + p1.n_groups;
+    int rc;
+    if ((rc = launch(v, p1))) return rc;
+    if (replay) {  // the positional phase again where a kinematic orientation moved (ReplayView): its bodies' records from the untouched body array
+        IVX_KLAUNCH(k_kin_prefix, dim3(w->n_kin), dim3(64), 0, s, w->n_kin, w->n_dyn, w->kin_offsets, w->kin_list, w->kin_applied,
+                    reinterpret_cast<float4*>(w->kin_qstart), w->cb, flag);
+        if (body_blocks) IVX_KLAUNCH(k_cs_init, dim3(body_blocks), dim3(256), 0, s, w->n_dyn, w->cb, nullptr, dyn_pos, flag);
+        IVX_HIP_CHECK(hipGetLastError());
+        const CsPhase none = phase_args(0, false, ReplayView(), nullptr), p2 = phase_args(1, true, pass2, flag);
+        if ((rc = launch(none, p2))) return rc;
+    }
+    if (trace_path) {
+        IVX_HIP_CHECK(ivx_stream_sync(s));
+        std::vector<unsigned long long> host(trace_cap + 2);
+        host[0] = n_rounds[0], host[1] = n_rounds[1];
+        IVX_HIP_CHECK(ivx_memcpy_sync(host.data() + 2, trace_dev, trace_cap * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(trace_path, "wb")) {
+            fwrite(host.data(), 8, 2 + 4 * (n_rounds[0] + n_rounds[1]), f);
+            for (int p = 0; p < 2; ++p)
+                if (n_rounds[p]) fwrite(w->cs_round_level_host.data() + w->cs[p].round_offset, 4, n_rounds[p], f);
+            fclose(f);
+        }
+    }
+    if (body_blocks) {
+        IVX_KLAUNCH(k_cs_finish, dim3(body_blocks), dim3(256), 0, s, w->n_dyn, w->cb, w->n_levels[0] ? dyn_vel : nullptr, w->n_levels[1] ? dyn_pos : nullptr);
+        IVX_HIP_CHECK(hipGetLastError());
+    }
+    return IVX_OK;
+}
+
 int ivx_launch_phys_solve(ivx_world* w) {
     if (w->n_contacts == 0) return IVX_OK;
     int rc;
+    if (solver_stationary(w)) {
+        w->solver_kind_used = 2u;
+        return launch_solve_cs(w);
+    }
     const uint32_t groups = solver_groups(w);
     w->solver_groups_used = groups;
+    w->solver_kind_used = groups > 1u ? 1u : 0u;
     // the positional phase runs twice when kinematic bodies take part in it (ReplayView): counts, then — where an orientation moves — again
     const bool replay = w->n_levels[1] && w->n_kin_items > 0;
     uint32_t* flag = w->barrier_words + 2;

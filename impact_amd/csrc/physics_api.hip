@@ -132,7 +132,7 @@ int fetch_body_position(ivx_world* w, uint32_t ref, float out[3]) {
     return IVX_OK;
 }
 
-// Chains: maximal runs (<= 15) of contacts that are consecutive in the solve order and act on the same (body_a, body_b).
+// Chains: maximal runs (<= PHYS_CHAIN_MAX) of contacts that are consecutive in the solve order and act on the same (body_a, body_b).
 void build_chains(ivx_world* w) {
     w->chain_start.clear();
     w->chain_bodies.clear();
@@ -140,13 +140,84 @@ void build_chains(ivx_world* w) {
     uint32_t s = 0;
     while (s < n) {
         uint32_t e = s + 1;
-        while (e < n && e - s < 15u && w->ordered[e].body_a == w->ordered[s].body_a && w->ordered[e].body_b == w->ordered[s].body_b) ++e;
+        while (e < n && e - s < PHYS_CHAIN_MAX && w->ordered[e].body_a == w->ordered[s].body_a && w->ordered[e].body_b == w->ordered[s].body_b) ++e;
         w->chain_start.push_back(s);
         w->chain_bodies.push_back(w->ordered[s].body_a);
         w->chain_bodies.push_back(w->ordered[s].body_b);
         s = e;
     }
     w->chain_start.push_back(n);
+}
+
+// The chain-stationary form of a phase's schedule (physics.hip, k_solve_cs): every chain gets one lane of one wave for the whole phase. Tiles
+// are 64 consecutive chains in the order (level of the chain's first item, solve order) — the chains of a level are mutually independent
+// and tend to stay so in every sweep —, a workgroup is PHYS_CS_WAVES consecutive tiles. A tile's rounds are the distinct levels its items
+// lie on, in level order, each a mask of the lanes whose next item it is: a round's items are of one level, so they depend on lower levels
+// only and every wave walks its rounds in level order — the lowest unfinished level can always run while all workgroups are resident.
+// `lvl`: level (from 1) of item pass * nch + chain.
+void build_stationary(ivx_world* w, int phase, uint32_t nch, uint32_t passes, const std::vector<uint32_t>& lvl) {
+    ivx_world::CsSchedule& cs = w->cs[phase];
+    cs = ivx_world::CsSchedule();
+    cs.slot_offset = (uint32_t)w->cs_item_host.size();
+    cs.round_start_offset = (uint32_t)w->cs_round_start_host.size();
+    cs.round_offset = (uint32_t)w->cs_round_mask_host.size();
+    const uint32_t n_tiles = (nch + 63u) / 64u;
+    if (nch == 0 || passes == 0 || n_tiles > PHYS_CS_WAVES * PHYS_CS_MAX_GROUPS) return;
+    // degree of every dynamic body (chains that touch it) and a chain's rank among them: before sweep s of the chain the body's record has
+    // been written s * degree + rank times (every sweep walks the chains in the same order)
+    std::vector<uint32_t>& deg = w->scratch_count;
+    deg.assign(w->n_dyn, 0u);
+    std::vector<uint32_t> vers(2 * (size_t)nch);
+    for (uint32_t ch = 0; ch < nch; ++ch)
+        for (int side = 0; side < 2; ++side) {
+            const uint32_t b = w->chain_bodies[2 * (size_t)ch + side];
+            vers[2 * (size_t)ch + side] = (b & IVX_KINEMATIC_BODY) ? 0u : deg[b]++;
+        }
+    for (uint32_t b = 0; b < w->n_dyn; ++b)
+        if (deg[b] > 0xFFFFu) return;
+    std::vector<uint32_t> order(nch);
+    for (uint32_t ch = 0; ch < nch; ++ch) order[ch] = ch;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return lvl[a] < lvl[b]; });
+    const size_t slot0 = cs.slot_offset;
+    w->cs_item_host.resize(slot0 + (size_t)n_tiles * 64u, 0xFFFFFFFFu);
+    w->cs_bodies_host.resize(2 * (slot0 + (size_t)n_tiles * 64u), 0u);
+    w->cs_vers_host.resize(2 * (slot0 + (size_t)n_tiles * 64u), 0u);
+    std::vector<std::pair<uint32_t, uint32_t>> ev;  // (level, lane) of a tile's items
+    for (uint32_t t = 0; t < n_tiles; ++t) {
+        const uint32_t first = t * 64u, cnt = std::min(64u, nch - first);
+        ev.clear();
+        for (uint32_t l = 0; l < cnt; ++l) {
+            const uint32_t ch = order[first + l];
+            const size_t slot = slot0 + (size_t)t * 64u + l;
+            const uint32_t s0 = w->chain_start[ch], len = w->chain_start[ch + 1] - s0;
+            w->cs_item_host[slot] = s0 | (len << 24);
+            for (int side = 0; side < 2; ++side) {
+                const uint32_t b = w->chain_bodies[2 * (size_t)ch + side];
+                const bool kin = (b & IVX_KINEMATIC_BODY) != 0u;
+                w->cs_bodies_host[2 * slot + side] = kin ? w->n_dyn + (b & 0x7FFFFFFFu) : b;
+                w->cs_vers_host[2 * slot + side] = kin ? 0u : (deg[b] | (vers[2 * (size_t)ch + side] << 16));
+            }
+            for (uint32_t p = 0; p < passes; ++p) ev.emplace_back(lvl[(size_t)p * nch + ch], l);
+        }
+        std::sort(ev.begin(), ev.end());
+        w->cs_round_start_host.push_back((uint32_t)(w->cs_round_mask_host.size() - cs.round_offset));
+        for (size_t i = 0; i < ev.size();) {
+            uint64_t mask = 0;
+            size_t j = i;
+            for (; j < ev.size() && ev[j].first == ev[i].first; ++j) mask |= 1ull << ev[j].second;
+            w->cs_round_mask_host.push_back(mask);
+            w->cs_round_level_host.push_back(ev[i].first);
+            i = j;
+        }
+    }
+    w->cs_round_start_host.push_back((uint32_t)(w->cs_round_mask_host.size() - cs.round_offset));
+    if (phase == 1 && !w->cs_slot_of_host.empty()) {  // ReplayView's item indices, by slot and sweep instead of by pass and chain
+        std::vector<uint32_t> by_slot((size_t)n_tiles * 64u * passes, 0u);
+        for (uint32_t i = 0; i < nch; ++i)
+            for (uint32_t p = 0; p < passes; ++p) by_slot[(size_t)i * passes + p] = w->cs_slot_of_host[(size_t)p * nch + order[i]];
+        w->cs_slot_of_host.swap(by_slot);
+    }
+    cs.n_tiles = n_tiles;
 }
 
 // Dependency levels of the item sequence (pass-major, chains in cache order inside a pass); items of one level touch
@@ -209,12 +280,14 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
     std::vector<uint32_t> cursor(start + 1, start + max_level + 1);
     std::vector<std::vector<uint32_t>> kin_items;  // positional phase: every kinematic body's chains in solve order (ReplayView)
     if (phase == 1) kin_items.resize(w->n_kin);
+    if (phase == 1) w->cs_slot_of_host.assign(w->n_kin ? total : 0, 0u);
     k = 0;
     for (uint32_t pass = 0; pass < total_passes; ++pass) {
         const uint32_t ty = pass < n_first ? first_type : type;
         for (uint32_t ch = 0; ch < nch; ++ch, ++k) {
             const uint32_t s0 = w->chain_start[ch], len = w->chain_start[ch + 1] - s0;
             const size_t slot = it0 + cursor[lvl[k] - 1]++;
+            if (phase == 1 && w->n_kin) w->cs_slot_of_host[k] = (uint32_t)(slot - it0);
             w->items_host[slot] = s0 | (len << 24) | (ty << 28);
             const uint32_t ba = w->chain_bodies[2 * (size_t)ch], bb = w->chain_bodies[2 * (size_t)ch + 1];
             w->item_bodies_host[2 * slot] = (ba & IVX_KINEMATIC_BODY) ? w->n_dyn + (ba & 0x7FFFFFFFu) : ba;
@@ -260,6 +333,7 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
     }
     w->tile_base_host[ls0 + max_level] = n_tiles;
     w->n_tiles[phase] = n_tiles;
+    build_stationary(w, phase, nch, total_passes, lvl);
 }
 
 }  // namespace
@@ -288,8 +362,8 @@ int ivx_world_create(ivx_ctx* c, const ivx_solver_config* cfg, ivx_world** out) 
     if (cfg) w->cfg = *cfg;
     else w->cfg = ivx_solver_config{8u, 0.4f, 3u, 0.2f};  // ConstraintSolverConfig::default (solver.rs:374-384)
     IVX_REQUIRE(w->cfg.n_iterations + w->cfg.n_positional_correction_iterations < 4096, IVX_ERR_INVALID, "ivx_world_create: too many iterations");
-    if (hipMalloc(reinterpret_cast<void**>(&w->barrier_words), 40 * sizeof(uint32_t)) != hipSuccess ||
-        ivx_memset_async(w->barrier_words, 0, 40 * sizeof(uint32_t), c->stream) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void**>(&w->barrier_words), 128 * sizeof(uint32_t)) != hipSuccess ||
+        ivx_memset_async(w->barrier_words, 0, 128 * sizeof(uint32_t), c->stream) != hipSuccess) {
         ivx_set_error("ivx_world_create: device allocation failed");
         delete w;
         return IVX_ERR_HIP;
@@ -321,7 +395,7 @@ void ivx_world_destroy(ivx_world* w) {
     if (w->stage_ev_ready) (void)hipEventDestroy(w->stage_ev);
     void* ptrs[] = {w->dyn, w->kin, w->cb, w->touched, w->contacts, w->prev_slot, w->pc[0], w->pc[1], w->acc[0], w->acc[1], w->items, w->item_bodies, w->item_tags, w->level_start,
                     w->dynst, w->barrier_words, w->joint_refs, w->tile_base, w->tile_first, w->packed[0], w->packed[1], w->kin_offsets, w->kin_list,
-                    w->kin_applied, w->kin_qstart, w->kin_snap};
+                    w->kin_applied, w->kin_qstart, w->kin_snap, w->cs_item, w->cs_bodies, w->cs_vers, w->cs_round_start, w->cs_round_mask, w->cs_round_level, w->cs_slot_of};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (w->mg_err_host) (void)hipHostFree(w->mg_err_host);
@@ -539,6 +613,12 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
         w->level_start_host.clear();
         w->tile_base_host.clear();
         w->tile_first_host.clear();
+        w->cs_item_host.clear();
+        w->cs_bodies_host.clear();
+        w->cs_vers_host.clear();
+        w->cs_round_start_host.clear();
+        w->cs_round_mask_host.clear();
+        w->cs_round_level_host.clear();
         build_schedule(w, PHYS_ITEM_WARM, 1u, PHYS_ITEM_VELOCITY, w->cfg.n_iterations, 0);
         build_schedule(w, PHYS_ITEM_POSITIONAL, 0u, PHYS_ITEM_POSITIONAL, w->cfg.n_positional_correction_iterations, 1);
         w->prev_chain_start = w->chain_start;
@@ -581,6 +661,13 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
     if ((rc = grow(&w->level_start, &w->level_cap, w->level_start_host.size(), s))) return rc;
     if ((rc = grow(&w->tile_base, &w->tile_base_cap, w->tile_base_host.size(), s))) return rc;
     if ((rc = grow(&w->tile_first, &w->tile_first_cap, w->tile_first_host.size(), s))) return rc;
+    if ((rc = grow(&w->cs_item, &w->cs_item_cap, w->cs_item_host.size(), s))) return rc;
+    if ((rc = grow(&w->cs_bodies, &w->cs_bodies_cap, w->cs_bodies_host.size(), s))) return rc;
+    if ((rc = grow(&w->cs_vers, &w->cs_vers_cap, w->cs_vers_host.size(), s))) return rc;
+    if ((rc = grow(&w->cs_round_start, &w->cs_round_start_cap, w->cs_round_start_host.size(), s))) return rc;
+    if ((rc = grow(&w->cs_round_mask, &w->cs_round_mask_cap, w->cs_round_mask_host.size(), s))) return rc;
+    if ((rc = grow(&w->cs_round_level, &w->cs_round_level_cap, w->cs_round_level_host.size(), s))) return rc;
+    if (w->n_kin_items && (rc = grow(&w->cs_slot_of, &w->cs_slot_of_cap, w->cs_slot_of_host.size(), s))) return rc;
     if (w->n_kin_items) {
         const size_t n_pos_items = w->items_host.size() - w->item_offset[1];
         if ((rc = grow(&w->kin_offsets, &w->kin_offsets_cap, w->kin_offsets_host.size(), s))) return rc;
@@ -617,6 +704,16 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
         IVX_HIP_CHECK(ivx_memcpy_sync(w->tile_base, w->tile_base_host.data(), w->tile_base_host.size() * 4, hipMemcpyHostToDevice));
         if (!w->tile_first_host.empty())
             IVX_HIP_CHECK(ivx_memcpy_sync(w->tile_first, w->tile_first_host.data(), w->tile_first_host.size() * 4, hipMemcpyHostToDevice));
+        if (!w->cs_item_host.empty()) {
+            IVX_HIP_CHECK(ivx_memcpy_sync(w->cs_item, w->cs_item_host.data(), w->cs_item_host.size() * 4, hipMemcpyHostToDevice));
+            IVX_HIP_CHECK(ivx_memcpy_sync(w->cs_bodies, w->cs_bodies_host.data(), w->cs_bodies_host.size() * 4, hipMemcpyHostToDevice));
+            IVX_HIP_CHECK(ivx_memcpy_sync(w->cs_vers, w->cs_vers_host.data(), w->cs_vers_host.size() * 4, hipMemcpyHostToDevice));
+            IVX_HIP_CHECK(ivx_memcpy_sync(w->cs_round_start, w->cs_round_start_host.data(), w->cs_round_start_host.size() * 4, hipMemcpyHostToDevice));
+            IVX_HIP_CHECK(ivx_memcpy_sync(w->cs_round_mask, w->cs_round_mask_host.data(), w->cs_round_mask_host.size() * 8, hipMemcpyHostToDevice));
+            IVX_HIP_CHECK(ivx_memcpy_sync(w->cs_round_level, w->cs_round_level_host.data(), w->cs_round_level_host.size() * 4, hipMemcpyHostToDevice));
+        }
+        if (w->n_kin_items && !w->cs_slot_of_host.empty())
+            IVX_HIP_CHECK(ivx_memcpy_sync(w->cs_slot_of, w->cs_slot_of_host.data(), w->cs_slot_of_host.size() * 4, hipMemcpyHostToDevice));
         if (w->n_kin_items) {
             IVX_HIP_CHECK(ivx_memcpy_sync(w->kin_offsets, w->kin_offsets_host.data(), w->kin_offsets_host.size() * 4, hipMemcpyHostToDevice));
             IVX_HIP_CHECK(ivx_memcpy_sync(w->kin_list, w->kin_list_host.data(), w->kin_list_host.size() * 4, hipMemcpyHostToDevice));
@@ -751,7 +848,8 @@ int ivx_world_step(ivx_world* w, float dt, ivx_physics_result* out) {
 }
 
 int ivx_world_set_solver_groups(ivx_world* w, uint32_t groups) {
-    IVX_REQUIRE(w && groups <= 16u, IVX_ERR_INVALID, "ivx_world_set_solver_groups: at most 16 workgroups");
+    IVX_REQUIRE(w && (groups <= 16u || groups == PHYS_SOLVER_STATIONARY), IVX_ERR_INVALID,
+                "ivx_world_set_solver_groups: at most 16 workgroups (or 255: the chain-stationary solve)");
     w->solver_groups_forced = groups;
     return IVX_OK;
 }
@@ -765,7 +863,7 @@ int ivx_world_solver_info(ivx_world* w, uint32_t out[8]) {
     out[4] = w->max_level_items[1];
     out[5] = (uint32_t)w->chain_start.size() > 0 ? (uint32_t)w->chain_start.size() - 1u : 0u;
     out[6] = w->n_contacts;
-    out[7] = 0;
+    out[7] = w->solver_kind_used;
     return IVX_OK;
 }
 

@@ -33,6 +33,14 @@ static_assert(sizeof(PhysContact) == 96, "PhysContact layout");
 #define PHYS_ITEM_VELOCITY 1u
 #define PHYS_ITEM_POSITIONAL 2u
 #define PHYS_LEVEL_TILE 4096
+// A chain is at most this many contacts: what the chain-stationary solve keeps of a chain in one lane's registers (longer manifolds are
+// consecutive chains on the same pair; the dependency schedule orders them like any two items that share a body)
+#define PHYS_CHAIN_MAX 4u
+// the chain-stationary solve (physics.hip, k_solve_cs): waves per workgroup, and the most workgroups one phase may ask for (its working
+// workgroups share one XCD: 32 CUs, one workgroup of 8 x 64 threads at up to 256 registers on each)
+#define PHYS_CS_WAVES 8u
+#define PHYS_CS_MAX_GROUPS 32u
+#define PHYS_SOLVER_STATIONARY 255u  // ivx_world_set_solver_groups: force the chain-stationary solve where the schedule allows it
 
 struct ivx_world {
     ivx_ctx* ctx;
@@ -72,6 +80,26 @@ struct ivx_world {
     size_t packed_cap[2];
     // kinematic orientations in the positional phase (physics.hip, ReplayView): the positional chains of every kinematic body in solve order
     // (CSR: kin_offsets[n_kin + 1], kin_list: phase-relative item | side << 31), per-item counts and tables of the two passes
+    // the chain-stationary solve (physics.hip, k_solve_cs): every chain lives in one lane of one wave for the whole phase. Per phase: tiles of
+    // 64 chains in the order of their first level; per slot (tile * 64 + lane) the chain word (first contact | length << 24, ~0 = empty),
+    // the pair's constrained-body indices, and (degree | rank << 16) of the chain on each of its bodies — the version a body's record has
+    // when sweep s of the chain starts is s * degree + rank; per tile its rounds in level order (64-bit lane masks). cs_slot_of: positional
+    // phase with kinematic bodies only, [sweep * chains + chain] -> the item's index in the level schedule (what ReplayView is indexed by).
+    struct CsSchedule {
+        uint32_t n_tiles = 0;  // 0: this phase cannot run chain-stationary (too many chains, a body with more than 65535 chains)
+        uint32_t slot_offset = 0, round_start_offset = 0, round_offset = 0;  // into cs_item / cs_bodies / cs_vers, cs_round_start, cs_round_mask
+    } cs[2];
+    uint32_t* cs_item;
+    uint32_t* cs_bodies;
+    uint32_t* cs_vers;
+    uint32_t* cs_round_start;
+    uint64_t* cs_round_mask;
+    uint32_t* cs_round_level;  // the level a round's items lie on (from 1): what a wave naps by until its round comes near
+    uint32_t* cs_slot_of;
+    size_t cs_item_cap, cs_bodies_cap, cs_vers_cap, cs_round_start_cap, cs_round_mask_cap, cs_round_level_cap, cs_slot_of_cap;
+    std::vector<uint32_t> cs_item_host, cs_bodies_host, cs_vers_host, cs_round_start_host, cs_round_level_host, cs_slot_of_host;
+    std::vector<uint64_t> cs_round_mask_host;
+    uint32_t solver_kind_used;  // 0: one workgroup, 1: tile dataflow on several (k_solve_mg), 2: chain-stationary (k_solve_cs)
     uint32_t* kin_offsets;
     uint32_t* kin_list;
     uint32_t* kin_applied;

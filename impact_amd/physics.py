@@ -36,6 +36,9 @@ class ConstraintSolverConfig:
         return r
 
 
+SOLVER_STATIONARY = 255  # `ivx_world_set_solver_groups`: the chain-stationary solve wherever the schedule allows it
+
+
 class PhysicsWorld:
     """RigidBodyManager + ConstraintManager living in HBM (`ivx_world`)."""
 
@@ -108,14 +111,15 @@ class PhysicsWorld:
         return ids[: n.value], imp[: n.value]
 
     def set_solver_groups(self, groups: int = 0):
-        """workgroups the solve is spread over (`ivx_world_set_solver_groups`): 0 = automatic, 1 = one workgroup with the bodies in LDS"""
+        """workgroups the solve is spread over (`ivx_world_set_solver_groups`): 0 = automatic, 1 = one workgroup with the bodies in LDS,
+        2..16 = tiles of the level schedule handed to that many workgroups, 255 (`SOLVER_STATIONARY`) = the chain-stationary solve"""
         check(capi.lib().ivx_world_set_solver_groups(self.h, int(groups)))
 
     def solver_info(self) -> dict:
         out = np.zeros(8, dtype=np.uint32)
         check(capi.lib().ivx_world_solver_info(self.h, ptr(out)))
         return {"workgroups": int(out[0]), "levels": [int(out[1]), int(out[2])], "widest_level": [int(out[3]), int(out[4])], "chains": int(out[5]),
-                "contacts": int(out[6])}
+                "contacts": int(out[6]), "kernel": ("one_workgroup", "tile_dataflow", "chain_stationary")[min(int(out[7]), 2)]}
 
     # ---- perform_physics_step ------------------------------------------------------------------
     def step(self, step_duration: float) -> np.ndarray:

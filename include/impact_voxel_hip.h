@@ -652,10 +652,13 @@ int ivx_world_advance_momenta(ivx_world*, float dt);
 int ivx_world_solve(ivx_world*);
 int ivx_world_advance_configurations(ivx_world*, float dt);
 /* ContactIDs in solve order and their accumulated (normal, tangent, bitangent) impulses after the last solve */
-/* The solve walks the dependency levels of the exact-order schedule on `groups` workgroups (one chain per thread, a grid-wide barrier per
- * level) — 0 (default): chosen from the widest level (1 when a level fits one workgroup: the bodies then live in LDS), at most 16. Same
- * results whatever the number. ivx_world_solver_info: out[0] workgroups used by the last solve, [1..2] levels of the velocity / positional
- * schedule, [3..4] widest level of each, [5] chains (manifolds), [6] contacts. */
+/* How the solve walks the exact-order schedule. groups = 0 (default): chosen from the schedule — one workgroup with the bodies in LDS when the
+ * widest dependency level fits it, else the chain-stationary solve (every chain of contacts keeps one lane of one wave for the whole phase with
+ * its prepared contacts and accumulated impulses in registers; only the two bodies' state travels, through version-tagged records; both phases
+ * in one launch), else tiles of the level schedule handed to up to 16 workgroups. 1: one workgroup. 2..16: the tile form on that many
+ * workgroups. 255: the chain-stationary solve whatever the widths (tests). Same results whichever runs. ivx_world_solver_info: out[0]
+ * workgroups used by the last solve, [1..2] levels of the velocity / positional schedule, [3..4] widest level of each, [5] chains (runs of
+ * up to 4 contacts of one manifold), [6] contacts, [7] the kernel that ran (0 one workgroup, 1 tiles, 2 chain-stationary). */
 int ivx_world_set_solver_groups(ivx_world*, uint32_t groups);
 int ivx_world_solver_info(ivx_world*, uint32_t out[8]);
 int ivx_world_contact_state(ivx_world*, uint64_t* ids, float* impulses3, size_t cap, size_t* n_out);

@@ -148,9 +148,9 @@ def test_config4_pile_60_steps(ctx):
     w.close()
 
 
-@pytest.mark.parametrize("groups", [2, 5, 16])
+@pytest.mark.parametrize("groups", [2, 5, 16, 255])
 def test_solve_on_several_workgroups_is_the_same_solve(ctx, groups):
-    """the level schedule walked by `groups` workgroups with a grid barrier per level (k_solve_mg) against the single-workgroup
+    """the level schedule walked by `groups` workgroups (k_solve_mg; 255: the chain-stationary solve, k_solve_cs) against the single-workgroup
     kernel (bodies in LDS): bit-identical bodies and impulses, frame after frame, with contacts that come and go; and against the oracle"""
     rng = np.random.default_rng(11)
     bodies, contacts = scenes.sphere_pile_scene(6)
@@ -166,7 +166,10 @@ def test_solve_on_several_workgroups_is_the_same_solve(ctx, groups):
         cs = manifolds[keep].reshape(-1).copy()
         pu.step_both(w1, o, cs, 0.004)
         wg.perform_physics_step(cs, 0.004)
-        assert wg.solver_info()["workgroups"] == groups and w1.solver_info()["workgroups"] == 1
+        if groups == 255:
+            assert wg.solver_info()["kernel"] == "chain_stationary" and w1.solver_info()["kernel"] == "one_workgroup"
+        else:
+            assert wg.solver_info()["workgroups"] == groups and w1.solver_info()["workgroups"] == 1
         d1, dg = w1.bodies()[0], wg.bodies()[0]
         for f in pu.STATE_FIELDS:
             np.testing.assert_array_equal(dg[f].view(np.uint32), d1[f].view(np.uint32), err_msg=f"frame {s} {f}")

@@ -90,9 +90,11 @@ def test_random_graphs_on_several_workgroups(ctx, seed):
         plane["velocity"] = (0.05, 0.0, -0.02)
     w1, o = pu.make_pair(ctx, bodies, plane)
     wg, _ = pu.make_pair(ctx, bodies, plane)
+    wc, _ = pu.make_pair(ctx, bodies, plane)  # (and the chain-stationary solve, k_solve_cs)
     groups = int(rng.integers(2, 5))
     w1.set_solver_groups(1)
     wg.set_solver_groups(groups)
+    wc.set_solver_groups(255)
     n_pairs = int(rng.integers(4, 3 * n))
     pairs = []
     for k in range(n_pairs):
@@ -123,13 +125,20 @@ def test_random_graphs_on_several_workgroups(ctx, seed):
         arr = np.array(cs) if cs else np.zeros(0, dtype=CONTACT_DTYPE)
         pu.step_both(w1, o, arr, 0.004)
         wg.perform_physics_step(arr, 0.004)
+        wc.perform_physics_step(arr, 0.004)
         if len(arr):
             assert wg.solver_info()["workgroups"] == groups and w1.solver_info()["workgroups"] == 1
-        d1, dg = w1.bodies()[0], wg.bodies()[0]
+            assert wc.solver_info()["kernel"] == "chain_stationary" and w1.solver_info()["kernel"] == "one_workgroup"
+        d1, dg, dc = w1.bodies()[0], wg.bodies()[0], wc.bodies()[0]
         for f in pu.STATE_FIELDS:
             np.testing.assert_array_equal(dg[f].view(np.uint32), d1[f].view(np.uint32), err_msg=f"seed {seed} frame {frame} {f}")
+            np.testing.assert_array_equal(dc[f].view(np.uint32), d1[f].view(np.uint32), err_msg=f"seed {seed} frame {frame} {f} (chain-stationary)")
         if len(arr):
             np.testing.assert_array_equal(wg.contact_state()[1].view(np.uint32), w1.contact_state()[1].view(np.uint32))
+            np.testing.assert_array_equal(wc.contact_state()[1].view(np.uint32), w1.contact_state()[1].view(np.uint32))
+        if w1.n_kinematic:
+            for f in ("position", "orientation"):
+                np.testing.assert_array_equal(wc.bodies()[1][f].view(np.uint32), w1.bodies()[1][f].view(np.uint32), err_msg=f"seed {seed} frame {frame} kinematic {f}")
         od = o.bodies()[0]
         # (odd seeds: the turned kinematic body. The reference re-normalises a kinematic body's orientation at every positional correction
         # applied to it and uses the result for the corrections that follow; the schedule replays that — counts in a first pass, the
@@ -146,6 +155,7 @@ def test_random_graphs_on_several_workgroups(ctx, seed):
         alive = np.where(rng.random(n_pairs) < 0.25, ~alive, alive)
     w1.close()
     wg.close()
+    wc.close()
     BIT_REPORT.append((seed, differing))
     if seed % 4 == 3:
         BIT_REPORT_TURNED.append((seed, differing))
