@@ -993,29 +993,32 @@ __global__ __launch_bounds__(MG_THREADS) void k_solve_mg(uint32_t n_dyn, float f
 // ---- the chain-stationary solve ------------------------------------------------------------------------------------------------------
 // k_solve_mg hands tiles of the level schedule to whichever wave is next: every item fetches its packed record (480 bytes), its accumulated
 // impulses and its two bodies, and leaves impulses and bodies behind — and a level costs ~2.6 us of work + ~2 us of hand-off, 183 times.
-// Here a chain STAYS in one lane of one wave for the whole phase (host: build_stationary). What never changes during the solve — the chain's
-// prepared contacts, the pair's inverse masses and inertia — is gathered once into the lane's registers, the accumulated impulses live there
-// from the warm start to the last sweep, and the only thing that travels between items is what has to: the two bodies' mutable state, through
-// the same version-tagged 16-byte records as k_solve_mg's (a body's record carries the number of items that have touched it; sweep s of a
-// chain finds s * degree + rank there, two per-chain constants). A wave walks its tile's ROUNDS — the distinct levels its items lie on, a
-// lane mask each — in level order; the lanes of a round load their operands past the L1 until they carry the expected tags, run the chain,
-// store the pair's new state one version on. The arithmetic per item is run_contact's, so the result is the sequential loop's, operation
-// for operation.
+// Here a chain STAYS where it is for the whole phase (host: build_stationary): a PAIR OF LANES of one wave, the even lane body A's side,
+// the odd lane body B's. What never changes during the solve — the chain's prepared contacts, the own body's inverse mass and inertia — is
+// gathered once into the lane's registers, the accumulated impulses live there from the warm start to the last sweep, and the only thing that
+// travels between items is what has to: a body's mutable state, through the same version-tagged 16-byte records as k_solve_mg's (a body's
+// record carries the number of items that have touched it; sweep s of a chain finds s * degree + rank there, two per-lane constants). Each
+// lane waits for, carries and stores its OWN body only; what an item needs of the other side — the contact point's velocity or position,
+// one term of the effective mass — crosses to the neighbouring lane by a DPP swap, and the two halves of apply_pair / the positional
+// correction, which are independent of each other, run side by side: ~130 instructions per velocity contact on the critical lane instead
+// of 165, ~230 per positional contact instead of 420. Every float operation is one the sequential code performs, on the same operands in
+// the same order (B's half uses -x where the sequential code subtracts x: a + (-x) = a - x, (-x) y = -(x y) and the cross product of a
+// negated vector is the negated cross product, all exactly), so the result is the sequential loop's bit for bit.
+// A wave walks its tile's ROUNDS — the distinct levels its items lie on, a lane mask each — in level order.
 // One launch runs BOTH phases: blocks with blockIdx % spread == 0 are the velocity phase's workgroups, == 1 the positional phase's (under the
 // observed round-robin placement two XCDs with a phase each; the census decides the form of the stores, never the result). All working
-// workgroups must be resident (512 threads at up to 256 registers: one per CU, at most PHYS_CS_MAX_GROUPS per phase); every poll is bounded
-// and flags the launch.
+// workgroups must be resident (one per CU, at most PHYS_CS_MAX_GROUPS per phase); every poll is bounded and flags the launch.
 struct CsPhase {
-    const uint32_t* item;         // [tile * 64 + lane] first contact | length << 24, ~0: no chain
-    const uint2* bodies;          // constrained-body indices of the pair
-    const uint2* vers;            // degree | rank << 16 of the chain on body a, b
+    const uint32_t* item;         // [tile * 64 + lane] first contact | length << 24, ~0: no chain (both lanes of a pair hold the same word)
+    const uint2* bodies;          // the lane's own body and the other one of the pair (constrained-body indices)
+    const uint32_t* vers;         // degree | rank << 16 of the chain on the lane's own body
     const uint32_t* round_start;  // [tile] first round of the tile (n_tiles + 1 entries)
     const uint64_t* round_mask;   // lanes of the round
     const uint32_t* round_level;  // level its items lie on (from 1)
     float4* dynst;                // the phase's shared body records
     uint32_t* counter;            // grid barrier of the phase's workgroups (monotonic)
     uint32_t* xcc_table;
-    const uint32_t* slot_of;      // positional phase with kinematic bodies: [(tile * 64 + lane) * n_passes + sweep] -> the index ReplayView goes by
+    const uint32_t* slot_of;      // positional phase with kinematic bodies: [(tile * 32 + pair) * n_passes + sweep] -> the index ReplayView goes by
     const uint32_t* replay_flag;
     unsigned long long* trace;    // developer switch IVX_SOLVER_TRACE: per round 4 stamps of the 100 MHz clock (round begins, operands there, chain run, stores issued)
     ReplayView rv;
@@ -1024,11 +1027,72 @@ struct CsPhase {
 };
 constexpr uint32_t CS_THREADS = PHYS_CS_WAVES * 64u;
 
+// the neighbouring lane's value (lanes 2k and 2k + 1 swap): DPP quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ float swap1(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false)); }
+__device__ __forceinline__ V3 swap1(V3 v) { return {swap1(v.x), swap1(v.y), swap1(v.z)}; }
+// x on A's lane, -x on B's (`flip`: 0 / the sign bit)
+__device__ __forceinline__ float flipf(float x, uint32_t flip) { return __uint_as_float(__float_as_uint(x) ^ flip); }
+__device__ __forceinline__ V3 flipv(V3 v, uint32_t flip) { return {flipf(v.x, flip), flipf(v.y, flip), flipf(v.z, flip)}; }
+
+// a prepared contact as one side's lane keeps it during the velocity phase (`d`: the own body's lever arm, world_b - position)
+struct LaneV {
+    V3 n, t, b;
+    float m_n, m_t, m_b, friction, target;
+    V3 d;
+};
+// the own body's half of apply_pair
+__device__ __forceinline__ void lane_apply(const LaneV& c, float im, const M3& ii, uint32_t flip, bool dyn, V3& v, V3& w, float in, float it, float ib_) {
+    const V3 dp = flipv((c.n * in + c.t * it) + c.b * ib_, flip);
+    if (dyn) {
+        v = v + dp * im;
+        w = w + mul(ii, cross(c.d, dp));
+    }
+}
+// one contact of a warm-start or velocity item on a pair of lanes (run_contact_v's operations; both lanes end with the same `acc`)
+__device__ __forceinline__ void lane_contact_v(uint32_t type, const LaneV& c, float im, const M3& ii, uint32_t flip, bool dyn, V3& v, V3& w, float4& acc) {
+    if (type == PHYS_ITEM_WARM) {
+        lane_apply(c, im, ii, flip, dyn, v, w, acc.x, acc.y, acc.z);
+        return;
+    }
+    const V3 pv = point_velocity(v, w, c.d);
+    const V3 rel = flipv(pv - swap1(pv), flip);  // A: own - other; B: -(own - other) = other - own: point velocity of A minus that of B on both
+    const float sep = dot(c.n, rel);
+    const float cn = -c.m_n * (sep - c.target), ct = -c.m_t * dot(c.t, rel), cbi = -c.m_b * dot(c.b, rel);
+    const float un = acc.x + cn, ut = acc.y + ct, ub = acc.z + cbi;
+    const float nn = max_rs(0.0f, un);
+    const float max_t = c.friction * nn;
+    const float mag = sqrtf(ut * ut + ub * ub);
+    const float sc = mag > max_t ? max_t / mag : 1.0f;
+    const float nt = ut * sc, nb = ub * sc;
+    lane_apply(c, im, ii, flip, dyn, v, w, nn - acc.x, nt - acc.y, nb - acc.z);
+    acc = make_float4(nn, nt, nb, 0.0f);
+}
+// one contact of a positional item on a pair of lanes (run_contact_p's operations). `local`: the contact point in the own body's frame, `im`:
+// the own body's inverse mass, `im_sum`: ima + imb, `ii`: the own body's inverse inertia (world space)
+__device__ __forceinline__ void lane_contact_p(V3 n, V3 local, float im, float im_sum, const M3& ii, uint32_t flip, bool side_b, V3& p, Q4& q, float factor,
+                                               uint32_t& applied) {
+    const V3 pw = qrot(q, local) + p, po = swap1(pw);
+    const float depth = dot(n, flipv(po - pw, flip));  // A: pb - pa; B: -(pa - pb)
+    if (depth <= 0.0f) return;  // (the same decision on both lanes)
+    const V3 pb = side_b ? pw : po;
+    const V3 d = pb - p;
+    const V3 c = cross(d, n);
+    const float t_own = dot(c, mul(ii, c)), t_oth = swap1(t_own);
+    const float m = 1.0f / ((im_sum + (side_b ? t_oth : t_own)) + (side_b ? t_own : t_oth));
+    const V3 dp = n * (m * factor * depth);
+    // A: pa + dp ima, rotation iia (da x dp); B: pb + dp (-imb), rotation (-iib) (db x dp) = -(iib (db x dp))
+    p = p + dp * flipf(im, flip);
+    q = pseudo_advanced(q, flipv(mul(ii, cross(d, dp)), flip));
+    applied += 1u;
+}
+
 template <int PHASE>
 __device__ __forceinline__ void solve_cs_phase(const uint32_t wg, const uint32_t n_dyn, const float factor, const PhysContact* __restrict__ pcs,
                                                float4* __restrict__ accs, const uint32_t n_contacts, const PhysBody* __restrict__ cb, const CsPhase& ph,
                                                uint32_t* __restrict__ error, const uint32_t dry) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const bool side_b = (lane & 1u) != 0u;
+    const uint32_t flip = side_b ? 0x80000000u : 0u;
     const uint32_t tile = __builtin_amdgcn_readfirstlane(wg * PHYS_CS_WAVES + (tid >> 6));
     const uint32_t G = ph.n_groups;
     if (ph.replay_flag && *ph.replay_flag == 0u) {  // pass 2 of the positional phase with no kinematic orientation that moved (uniform over the launch)
@@ -1041,42 +1105,45 @@ __device__ __forceinline__ void solve_cs_phase(const uint32_t wg, const uint32_t
     const uint32_t xcc_tag = (ph.counter_base << 4) | (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFu);
     if (tid == 0u) __hip_atomic_store(ph.xcc_table + wg, xcc_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     mg_arrive(ph.counter);
-    // ---- the lane's chain, once: prepared contacts, the pair's constants, the accumulated impulses (their trips to memory run beside the barrier)
+    // ---- the lane's side of its chain, once: prepared contacts, the own body's constants, the accumulated impulses (their trips to memory run
+    // beside the barrier)
     const bool in_tile = tile < ph.n_tiles;
     const uint32_t slot = tile * 64u + lane;
     const uint32_t item = in_tile ? ph.item[slot] : 0xFFFFFFFFu;
     const bool has = item != 0xFFFFFFFFu;
     const uint32_t s0 = has ? (item & 0x00FFFFFFu) : 0u, len = has ? ((item >> 24) & 15u) : 0u;
     const uint2 bodies = has ? ph.bodies[slot] : make_uint2(0u, 0u);
-    const uint2 vr = has ? ph.vers[slot] : make_uint2(0u, 0u);
-    const uint32_t ia = bodies.x, ib = bodies.y;
-    const uint32_t deg_a = vr.x & 0xFFFFu, rank_a = vr.x >> 16, deg_b = vr.y & 0xFFFFu, rank_b = vr.y >> 16;
-    ContactV cv0 = {}, cv1 = {}, cv2 = {}, cv3 = {};  // velocity phase: the chain's prepared contacts
-    struct ContactP {
-        V3 n, la, lb;
+    const uint32_t vr = has ? ph.vers[slot] : 0u;
+    const uint32_t own = bodies.x;
+    const uint32_t deg = vr & 0xFFFFu, rank = vr >> 16;
+    const bool dyn = has && own < n_dyn, both_dyn = dyn && bodies.y < n_dyn;
+    LaneV cv0 = {}, cv1 = {}, cv2 = {}, cv3 = {};  // velocity phase: the chain's prepared contacts, this side's view
+    struct LaneP {
+        V3 n, local;
     } cp0 = {}, cp1 = {}, cp2 = {}, cp3 = {};  // positional phase
     float4 ac0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), ac1 = ac0, ac2 = ac0, ac3 = ac0;
-    PairStatic st = {};
+    float im = 0.0f, im_sum = 0.0f;
+    M3 ii = {};
     if (has) {
-        const PhysBody& A = cb[ia];
-        const PhysBody& B = cb[ib];
-        st.ima = A.inv_mass;
-        st.imb = B.inv_mass;
-        st.iia = ldm(A.inv_inertia);
-        st.iib = ldm(B.inv_inertia);
-        st.dyn_a = ia < n_dyn;
-        st.dyn_b = ib < n_dyn;
+        const PhysBody& O = cb[own];
+        im = O.inv_mass;
+        ii = ldm(O.inv_inertia);
         if (PHASE == 0) {
-            const V3 pos_a = ld3(A.pos), pos_b = ld3(B.pos);
-            cv0 = contact_v(pcs[s0], pos_a, pos_b);
-            ac0 = accs[s0];
-            if (len > 1u) cv1 = contact_v(pcs[s0 + 1u], pos_a, pos_b), ac1 = accs[s0 + 1u];
-            if (len > 2u) cv2 = contact_v(pcs[s0 + 2u], pos_a, pos_b), ac2 = accs[s0 + 2u];
-            if (len > 3u) cv3 = contact_v(pcs[s0 + 3u], pos_a, pos_b), ac3 = accs[s0 + 3u];
+            const V3 pos = ld3(O.pos);
+            auto cv = [&](uint32_t c) {
+                const PhysContact& p = pcs[s0 + c];
+                return LaneV{ld3(p.normal), ld3(p.tangent), ld3(p.bitangent), p.m_n, p.m_t, p.m_b, p.friction, p.target, ld3(p.world_b) - pos};
+            };
+            cv0 = cv(0u), ac0 = accs[s0];
+            if (len > 1u) cv1 = cv(1u), ac1 = accs[s0 + 1u];
+            if (len > 2u) cv2 = cv(2u), ac2 = accs[s0 + 2u];
+            if (len > 3u) cv3 = cv(3u), ac3 = accs[s0 + 3u];
         } else {
+            const float im_a = side_b ? cb[bodies.y].inv_mass : im, im_b = side_b ? im : cb[bodies.y].inv_mass;
+            im_sum = im_a + im_b;
             auto cp = [&](uint32_t c) {
                 const PhysContact& p = pcs[s0 + c];
-                return ContactP{ld3(p.normal), ld3(p.local_a), ld3(p.local_b)};
+                return LaneP{ld3(p.normal), side_b ? ld3(p.local_b) : ld3(p.local_a)};
             };
             cp0 = cp(0u);
             if (len > 1u) cp1 = cp(1u);
@@ -1102,13 +1169,14 @@ __device__ __forceinline__ void solve_cs_phase(const uint32_t wg, const uint32_t
     uint32_t level_next = r0 < r1 ? levels[r0] : 0u;
     // NAPS. A chain runs once per sweep, a wave a handful of rounds per sweep: most of the time a wave's next round is levels away, and hundreds
     // of waves polling all that time fill the L2's request queues in front of the few whose operands are about to arrive (measured: 5.4 us per
-    // level with everyone polling). Levels pass at a steady pace for all waves, so a wave sleeps until `nap` tenths of a level before its
-    // round is due, counted from the end of its last round at nine tenths of the pace so far by its own clock, (now - start) / level, never
-    // taken below what a level's arithmetic alone costs. A wrong guess costs time, never correctness: the poll below decides.
+    // level with everyone polling, 4.2 with naps). Levels pass at a steady pace for all waves, so a wave sleeps until `nap` tenths of a level
+    // before its round is due, counted from the end of its last round at nine tenths of the pace so far by its own clock, (now - start) /
+    // level, never taken below what a level of one-contact chains costs. A wrong guess costs time, never correctness: the poll below decides.
     const unsigned long long t_start = wall_clock64();  // (100 MHz)
     unsigned long long t_last = t_start;
     uint32_t level_last = 0u;
-    uint32_t pace = PHASE == 0 ? 150u : 250u;  // 10 ns ticks per level, lower bound
+    constexpr uint32_t PACE_MIN = 40u;  // 10 ns ticks per level: below what a one-contact chain's arithmetic costs
+    uint32_t pace = PACE_MIN;
     for (uint32_t r = r0; r < r1; ++r) {
         const uint64_t mask = mask_next;
         const uint32_t level = level_next;
@@ -1122,38 +1190,37 @@ __device__ __forceinline__ void solve_cs_phase(const uint32_t wg, const uint32_t
         if (ph.trace && lane == 0u) ph.trace[4u * r] = wall_clock64();
         const bool active = has && ((mask >> lane) & 1ull) != 0ull;
         const uint32_t type = PHASE == 1 ? PHYS_ITEM_POSITIONAL : (sweep < ph.n_first ? PHYS_ITEM_WARM : PHYS_ITEM_VELOCITY);
-        const uint32_t ver_a = sweep * deg_a + rank_a, ver_b = sweep * deg_b + rank_b;
-        // (a kinematic body of the pair: what it moves with / where it stands comes from the body array every round — constant during the
-        // solve, so these are plain loads that the L1 serves after the first, issued ahead of the wait for the dynamic bodies)
-        PairState x;
-        if (active && !st.dyn_a) {
-            if (PHASE == 0) x.va = ld3(cb[ia].v), x.wa = ld3(cb[ia].w);
-            else x.pa = ld3(cb[ia].pos), x.qa = ldq(cb[ia].q);
-        }
-        if (active && !st.dyn_b) {
-            if (PHASE == 0) x.vb = ld3(cb[ib].v), x.wb = ld3(cb[ib].w);
-            else x.pb = ld3(cb[ib].pos), x.qb = ldq(cb[ib].q);
-        }
-        // THE HAND-OFF: the pair's records, past the L1, until they carry the versions this sweep of the chain starts from. All loads of a
-        // poll are issued back to back by every lane (a lane with nothing to wait for reads record 0 and ignores it): one trip per poll.
-        const bool need_a = active && st.dyn_a, need_b = active && st.dyn_b;
-        const uint32_t off_a = need_a ? ia * DST : 0u, off_b = need_b ? ib * DST : 0u;
-        float4 a0, a1, a2 = make_float4(0, 0, 0, 0), b0, b1, b2 = a2;
-        for (uint32_t spins = 0;; ++spins) {
-            a0 = ld16_sc1(rs_dyn, off_a);
-            a1 = ld16_sc1(rs_dyn, off_a + 16u);
-            b0 = ld16_sc1(rs_dyn, off_b);
-            b1 = ld16_sc1(rs_dyn, off_b + 16u);
-            uint32_t ok_a = (uint32_t)(__float_as_uint(a0.w) == ver_a) & (uint32_t)(__float_as_uint(a1.w) == ver_a);
-            uint32_t ok_b = (uint32_t)(__float_as_uint(b0.w) == ver_b) & (uint32_t)(__float_as_uint(b1.w) == ver_b);
-            if (PHASE == 1) {
-                a2 = ld16_sc1(rs_dyn, off_a + 32u);
-                b2 = ld16_sc1(rs_dyn, off_b + 32u);
-                ok_a = ok_a & (uint32_t)(__float_as_uint(a2.w) == ver_a);
-                ok_b = ok_b & (uint32_t)(__float_as_uint(b2.w) == ver_b);
+        const uint32_t ver = sweep * deg + rank;
+        // a kinematic own body: what it moves with / where it stands comes from the body array every round — constant during the solve, so
+        // these are plain loads that the L1 serves after the first, issued ahead of the wait for the dynamic bodies
+        V3 v = {}, w = {}, p = {};
+        Q4 q = {};
+        uint32_t rv_index = 0u;
+        if (active && !dyn) {
+            if (PHASE == 0) v = ld3(cb[own].v), w = ld3(cb[own].w);
+            else {
+                p = ld3(cb[own].pos), q = ldq(cb[own].q);
+                if (ph.rv.qstart) {  // pass 2: the orientation as the chains before this one left it (ReplayView)
+                    rv_index = ph.slot_of[(slot >> 1) * ph.n_passes + sweep];
+                    const float4 t = ph.rv.qstart[2u * rv_index + (side_b ? 1u : 0u)];
+                    q = Q4{t.x, t.y, t.z, t.w};
+                }
             }
-            const bool ok = (((uint32_t)!need_a | ok_a) & ((uint32_t)!need_b | ok_b)) != 0u;
-            if ((dry & 2u) || __builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+        }
+        // THE HAND-OFF: the own body's records, past the L1, until they carry the version this sweep of the chain starts from. The loads of a
+        // poll are issued back to back by every lane (a lane with nothing to wait for reads record 0 and ignores it): one trip per poll.
+        const bool need = active && dyn;
+        const uint32_t off = need ? own * DST : 0u;
+        float4 a0, a1, a2 = make_float4(0, 0, 0, 0);
+        for (uint32_t spins = 0;; ++spins) {
+            a0 = ld16_sc1(rs_dyn, off);
+            a1 = ld16_sc1(rs_dyn, off + 16u);
+            uint32_t ok = (uint32_t)(__float_as_uint(a0.w) == ver) & (uint32_t)(__float_as_uint(a1.w) == ver);
+            if (PHASE == 1) {
+                a2 = ld16_sc1(rs_dyn, off + 32u);
+                ok = ok & (uint32_t)(__float_as_uint(a2.w) == ver);
+            }
+            if ((dry & 2u) || __builtin_amdgcn_ballot_w64(need && !ok) == 0ull) break;
             __builtin_amdgcn_s_sleep(1);
             if (spins > MG_SPIN_LIMIT) {
                 if (lane == 0u) __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (host-mapped: ivx_world_check_solve)
@@ -1162,68 +1229,45 @@ __device__ __forceinline__ void solve_cs_phase(const uint32_t wg, const uint32_t
         }
         if (ph.trace && lane == 0u) ph.trace[4u * r + 1u] = wall_clock64();
         if (active) {
-        uint32_t rv_index = 0u;
-        if (PHASE == 0) {
-            if (st.dyn_a) x.va = mk(a0.x, a0.y, a0.z), x.wa = mk(a1.x, a1.y, a1.z);
-            if (st.dyn_b) x.vb = mk(b0.x, b0.y, b0.z), x.wb = mk(b1.x, b1.y, b1.z);
-            run_contact_v(type, cv0, st, x, ac0);
-            if (len > 1u) run_contact_v(type, cv1, st, x, ac1);
-            if (len > 2u) run_contact_v(type, cv2, st, x, ac2);
-            if (len > 3u) run_contact_v(type, cv3, st, x, ac3);
-        } else {
-            if (st.dyn_a) x.pa = mk(a0.x, a0.y, a0.z), x.qa = Q4{a1.x, a1.y, a1.z, a2.x};
-            if (st.dyn_b) x.pb = mk(b0.x, b0.y, b0.z), x.qb = Q4{b1.x, b1.y, b1.z, b2.x};
-            if ((ph.rv.qstart || ph.rv.applied) && !(st.dyn_a && st.dyn_b)) rv_index = ph.slot_of[slot * ph.n_passes + sweep];
-            if (ph.rv.qstart) {  // pass 2: a kinematic body's orientation as the chains before this one left it (ReplayView)
-                if (!st.dyn_a) {
-                    const float4 t = ph.rv.qstart[2u * rv_index];
-                    x.qa = Q4{t.x, t.y, t.z, t.w};
+            const float nv = __uint_as_float(ver + 1u);
+            if (PHASE == 0) {
+                if (dyn) v = mk(a0.x, a0.y, a0.z), w = mk(a1.x, a1.y, a1.z);
+                lane_contact_v(type, cv0, im, ii, flip, dyn, v, w, ac0);
+                if (len > 1u) lane_contact_v(type, cv1, im, ii, flip, dyn, v, w, ac1);
+                if (len > 2u) lane_contact_v(type, cv2, im, ii, flip, dyn, v, w, ac2);
+                if (len > 3u) lane_contact_v(type, cv3, im, ii, flip, dyn, v, w, ac3);
+                if (ph.trace && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) ph.trace[4u * r + 2u] = wall_clock64();
+                if (dyn) {
+                    st16_shared(rs_dyn, own * DST, make_float4(v.x, v.y, v.z, nv), one_xcd);
+                    st16_shared(rs_dyn, own * DST + 16u, make_float4(w.x, w.y, w.z, nv), one_xcd);
                 }
-                if (!st.dyn_b) {
-                    const float4 t = ph.rv.qstart[2u * rv_index + 1u];
-                    x.qb = Q4{t.x, t.y, t.z, t.w};
+            } else {
+                if (dyn) p = mk(a0.x, a0.y, a0.z), q = Q4{a1.x, a1.y, a1.z, a2.x};
+                uint32_t applied = 0u;
+                lane_contact_p(cp0.n, cp0.local, im, im_sum, ii, flip, side_b, p, q, factor, applied);
+                if (len > 1u) lane_contact_p(cp1.n, cp1.local, im, im_sum, ii, flip, side_b, p, q, factor, applied);
+                if (len > 2u) lane_contact_p(cp2.n, cp2.local, im, im_sum, ii, flip, side_b, p, q, factor, applied);
+                if (len > 3u) lane_contact_p(cp3.n, cp3.local, im, im_sum, ii, flip, side_b, p, q, factor, applied);
+                if (ph.trace && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) ph.trace[4u * r + 2u] = wall_clock64();
+                if (ph.rv.applied && !both_dyn && !side_b)  // pass 1: corrections a chain with a kinematic body applied (A's lane reports)
+                    ph.rv.applied[ph.slot_of[(slot >> 1) * ph.n_passes + sweep]] = applied;
+                if (dyn) {
+                    st16_shared(rs_dyn, own * DST, make_float4(p.x, p.y, p.z, nv), one_xcd);
+                    st16_shared(rs_dyn, own * DST + 16u, make_float4(q.x, q.y, q.z, nv), one_xcd);
+                    st16_shared(rs_dyn, own * DST + 32u, make_float4(q.w, 0.0f, 0.0f, nv), one_xcd);
                 }
             }
-            run_contact_p(cp0.n, cp0.la, cp0.lb, st, x, factor);
-            if (len > 1u) run_contact_p(cp1.n, cp1.la, cp1.lb, st, x, factor);
-            if (len > 2u) run_contact_p(cp2.n, cp2.la, cp2.lb, st, x, factor);
-            if (len > 3u) run_contact_p(cp3.n, cp3.la, cp3.lb, st, x, factor);
+            if (ph.trace && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) ph.trace[4u * r + 3u] = wall_clock64();
+            sweep += 1u;
         }
-        if (PHASE == 1 && ph.rv.applied && !(st.dyn_a && st.dyn_b)) ph.rv.applied[rv_index] = x.applied;
-        if (ph.trace && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) ph.trace[4u * r + 2u] = wall_clock64();
-        const float na = __uint_as_float(ver_a + 1u), nb = __uint_as_float(ver_b + 1u);
-        if (PHASE == 0) {
-            if (st.dyn_a) {
-                st16_shared(rs_dyn, ia * DST, make_float4(x.va.x, x.va.y, x.va.z, na), one_xcd);
-                st16_shared(rs_dyn, ia * DST + 16u, make_float4(x.wa.x, x.wa.y, x.wa.z, na), one_xcd);
-            }
-            if (st.dyn_b) {
-                st16_shared(rs_dyn, ib * DST, make_float4(x.vb.x, x.vb.y, x.vb.z, nb), one_xcd);
-                st16_shared(rs_dyn, ib * DST + 16u, make_float4(x.wb.x, x.wb.y, x.wb.z, nb), one_xcd);
-            }
-        } else {
-            if (st.dyn_a) {
-                st16_shared(rs_dyn, ia * DST, make_float4(x.pa.x, x.pa.y, x.pa.z, na), one_xcd);
-                st16_shared(rs_dyn, ia * DST + 16u, make_float4(x.qa.x, x.qa.y, x.qa.z, na), one_xcd);
-                st16_shared(rs_dyn, ia * DST + 32u, make_float4(x.qa.w, 0.0f, 0.0f, na), one_xcd);
-            }
-            if (st.dyn_b) {
-                st16_shared(rs_dyn, ib * DST, make_float4(x.pb.x, x.pb.y, x.pb.z, nb), one_xcd);
-                st16_shared(rs_dyn, ib * DST + 16u, make_float4(x.qb.x, x.qb.y, x.qb.z, nb), one_xcd);
-                st16_shared(rs_dyn, ib * DST + 32u, make_float4(x.qb.w, 0.0f, 0.0f, nb), one_xcd);
-            }
-        }
-        if (ph.trace && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) ph.trace[4u * r + 3u] = wall_clock64();
-        sweep += 1u;
-        }  // (active)
         // the pace so far, by this wave's clock
         t_last = wall_clock64();
         level_last = level;
         const uint32_t measured = __builtin_amdgcn_readfirstlane((uint32_t)(t_last - t_start)) * 9u / (level * 10u);
-        pace = measured > pace ? measured : pace;
+        pace = measured > PACE_MIN ? measured : PACE_MIN;
     }
-    // the accumulated impulses as the last sweep left them (next frame's warm start, ivx_world_contact_state)
-    if (PHASE == 0 && has && sweep > ph.n_first) {
+    // the accumulated impulses as the last sweep left them (next frame's warm start, ivx_world_contact_state): A's lane stores them
+    if (PHASE == 0 && has && !side_b && sweep > ph.n_first) {
         ac0.w = ac1.w = ac2.w = ac3.w = 0.0f;
         accs[s0] = ac0;
         if (len > 1u) accs[s0 + 1u] = ac1;
@@ -1526,7 +1570,7 @@ static int launch_solve_cs(ivx_world* w) {
         const ivx_world::CsSchedule& cs = w->cs[p];
         a.item = w->cs_item + cs.slot_offset;
         a.bodies = reinterpret_cast<const uint2*>(w->cs_bodies) + cs.slot_offset;
-        a.vers = reinterpret_cast<const uint2*>(w->cs_vers) + cs.slot_offset;
+        a.vers = w->cs_vers + cs.slot_offset;
         a.round_start = w->cs_round_start + cs.round_start_offset;
         a.round_mask = w->cs_round_mask + cs.round_offset;
         a.round_level = w->cs_round_level + cs.round_offset;

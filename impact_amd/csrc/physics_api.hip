@@ -149,29 +149,29 @@ void build_chains(ivx_world* w) {
     w->chain_start.push_back(n);
 }
 
-// The chain-stationary form of a phase's schedule (physics.hip, k_solve_cs): every chain gets one lane of one wave for the whole phase. Tiles
-// are 64 consecutive chains in the order (level of the chain's first item, solve order) — the chains of a level are mutually independent
-// and tend to stay so in every sweep —, a workgroup is PHYS_CS_WAVES consecutive tiles. A tile's rounds are the distinct levels its items
-// lie on, in level order, each a mask of the lanes whose next item it is: a round's items are of one level, so they depend on lower levels
-// only and every wave walks its rounds in level order — the lowest unfinished level can always run while all workgroups are resident.
-// `lvl`: level (from 1) of item pass * nch + chain.
+// The chain-stationary form of a phase's schedule (physics.hip, k_solve_cs): every chain gets a pair of lanes of one wave for the whole phase
+// (even lane: body A's side, odd lane: body B's). Tiles are 32 consecutive chains in the order (level of the chain's first item, solve
+// order) — the chains of a level are mutually independent and tend to stay so in every sweep —, a workgroup is PHYS_CS_WAVES consecutive
+// tiles. A tile's rounds are the distinct levels its items lie on, in level order, each a mask of the lanes whose next item it is: a round's
+// items are of one level, so they depend on lower levels only and every wave walks its rounds in level order — the lowest unfinished level
+// can always run while all workgroups are resident. `lvl`: level (from 1) of item pass * nch + chain.
 void build_stationary(ivx_world* w, int phase, uint32_t nch, uint32_t passes, const std::vector<uint32_t>& lvl) {
     ivx_world::CsSchedule& cs = w->cs[phase];
     cs = ivx_world::CsSchedule();
     cs.slot_offset = (uint32_t)w->cs_item_host.size();
     cs.round_start_offset = (uint32_t)w->cs_round_start_host.size();
     cs.round_offset = (uint32_t)w->cs_round_mask_host.size();
-    const uint32_t n_tiles = (nch + 63u) / 64u;
+    const uint32_t n_tiles = (nch + 31u) / 32u;
     if (nch == 0 || passes == 0 || n_tiles > PHYS_CS_WAVES * PHYS_CS_MAX_GROUPS) return;
     // degree of every dynamic body (chains that touch it) and a chain's rank among them: before sweep s of the chain the body's record has
     // been written s * degree + rank times (every sweep walks the chains in the same order)
     std::vector<uint32_t>& deg = w->scratch_count;
     deg.assign(w->n_dyn, 0u);
-    std::vector<uint32_t> vers(2 * (size_t)nch);
+    std::vector<uint32_t> rank(2 * (size_t)nch);
     for (uint32_t ch = 0; ch < nch; ++ch)
         for (int side = 0; side < 2; ++side) {
             const uint32_t b = w->chain_bodies[2 * (size_t)ch + side];
-            vers[2 * (size_t)ch + side] = (b & IVX_KINEMATIC_BODY) ? 0u : deg[b]++;
+            rank[2 * (size_t)ch + side] = (b & IVX_KINEMATIC_BODY) ? 0u : deg[b]++;
         }
     for (uint32_t b = 0; b < w->n_dyn; ++b)
         if (deg[b] > 0xFFFFu) return;
@@ -181,21 +181,26 @@ void build_stationary(ivx_world* w, int phase, uint32_t nch, uint32_t passes, co
     const size_t slot0 = cs.slot_offset;
     w->cs_item_host.resize(slot0 + (size_t)n_tiles * 64u, 0xFFFFFFFFu);
     w->cs_bodies_host.resize(2 * (slot0 + (size_t)n_tiles * 64u), 0u);
-    w->cs_vers_host.resize(2 * (slot0 + (size_t)n_tiles * 64u), 0u);
-    std::vector<std::pair<uint32_t, uint32_t>> ev;  // (level, lane) of a tile's items
+    w->cs_vers_host.resize(slot0 + (size_t)n_tiles * 64u, 0u);
+    std::vector<std::pair<uint32_t, uint32_t>> ev;  // (level, pair of lanes) of a tile's items
     for (uint32_t t = 0; t < n_tiles; ++t) {
-        const uint32_t first = t * 64u, cnt = std::min(64u, nch - first);
+        const uint32_t first = t * 32u, cnt = std::min(32u, nch - first);
         ev.clear();
         for (uint32_t l = 0; l < cnt; ++l) {
             const uint32_t ch = order[first + l];
-            const size_t slot = slot0 + (size_t)t * 64u + l;
             const uint32_t s0 = w->chain_start[ch], len = w->chain_start[ch + 1] - s0;
-            w->cs_item_host[slot] = s0 | (len << 24);
+            uint32_t body[2];
             for (int side = 0; side < 2; ++side) {
                 const uint32_t b = w->chain_bodies[2 * (size_t)ch + side];
-                const bool kin = (b & IVX_KINEMATIC_BODY) != 0u;
-                w->cs_bodies_host[2 * slot + side] = kin ? w->n_dyn + (b & 0x7FFFFFFFu) : b;
-                w->cs_vers_host[2 * slot + side] = kin ? 0u : (deg[b] | (vers[2 * (size_t)ch + side] << 16));
+                body[side] = (b & IVX_KINEMATIC_BODY) ? w->n_dyn + (b & 0x7FFFFFFFu) : b;
+            }
+            for (int side = 0; side < 2; ++side) {
+                const size_t slot = slot0 + (size_t)t * 64u + 2u * l + side;
+                const uint32_t b = w->chain_bodies[2 * (size_t)ch + side];
+                w->cs_item_host[slot] = s0 | (len << 24);
+                w->cs_bodies_host[2 * slot] = body[side];
+                w->cs_bodies_host[2 * slot + 1] = body[side ^ 1];
+                w->cs_vers_host[slot] = (b & IVX_KINEMATIC_BODY) ? 0u : (deg[b] | (rank[2 * (size_t)ch + side] << 16));
             }
             for (uint32_t p = 0; p < passes; ++p) ev.emplace_back(lvl[(size_t)p * nch + ch], l);
         }
@@ -204,18 +209,18 @@ void build_stationary(ivx_world* w, int phase, uint32_t nch, uint32_t passes, co
         for (size_t i = 0; i < ev.size();) {
             uint64_t mask = 0;
             size_t j = i;
-            for (; j < ev.size() && ev[j].first == ev[i].first; ++j) mask |= 1ull << ev[j].second;
+            for (; j < ev.size() && ev[j].first == ev[i].first; ++j) mask |= 3ull << (2u * ev[j].second);
             w->cs_round_mask_host.push_back(mask);
             w->cs_round_level_host.push_back(ev[i].first);
             i = j;
         }
     }
     w->cs_round_start_host.push_back((uint32_t)(w->cs_round_mask_host.size() - cs.round_offset));
-    if (phase == 1 && !w->cs_slot_of_host.empty()) {  // ReplayView's item indices, by slot and sweep instead of by pass and chain
-        std::vector<uint32_t> by_slot((size_t)n_tiles * 64u * passes, 0u);
+    if (phase == 1 && !w->cs_slot_of_host.empty()) {  // ReplayView's item indices, by pair of lanes and sweep instead of by pass and chain
+        std::vector<uint32_t> by_pair((size_t)n_tiles * 32u * passes, 0u);
         for (uint32_t i = 0; i < nch; ++i)
-            for (uint32_t p = 0; p < passes; ++p) by_slot[(size_t)i * passes + p] = w->cs_slot_of_host[(size_t)p * nch + order[i]];
-        w->cs_slot_of_host.swap(by_slot);
+            for (uint32_t p = 0; p < passes; ++p) by_pair[(size_t)i * passes + p] = w->cs_slot_of_host[(size_t)p * nch + order[i]];
+        w->cs_slot_of_host.swap(by_pair);
     }
     cs.n_tiles = n_tiles;
 }

@@ -37,8 +37,8 @@ static_assert(sizeof(PhysContact) == 96, "PhysContact layout");
 // consecutive chains on the same pair; the dependency schedule orders them like any two items that share a body)
 #define PHYS_CHAIN_MAX 4u
 // the chain-stationary solve (physics.hip, k_solve_cs): waves per workgroup, and the most workgroups one phase may ask for (its working
-// workgroups share one XCD: 32 CUs, one workgroup of 8 x 64 threads at up to 256 registers on each)
-#define PHYS_CS_WAVES 8u
+// workgroups share one XCD: 32 CUs, one workgroup of 12 x 64 threads — three waves per SIMD at up to 168 registers — on each)
+#define PHYS_CS_WAVES 12u
 #define PHYS_CS_MAX_GROUPS 32u
 #define PHYS_SOLVER_STATIONARY 255u  // ivx_world_set_solver_groups: force the chain-stationary solve where the schedule allows it
 
@@ -80,11 +80,12 @@ struct ivx_world {
     size_t packed_cap[2];
     // kinematic orientations in the positional phase (physics.hip, ReplayView): the positional chains of every kinematic body in solve order
     // (CSR: kin_offsets[n_kin + 1], kin_list: phase-relative item | side << 31), per-item counts and tables of the two passes
-    // the chain-stationary solve (physics.hip, k_solve_cs): every chain lives in one lane of one wave for the whole phase. Per phase: tiles of
-    // 64 chains in the order of their first level; per slot (tile * 64 + lane) the chain word (first contact | length << 24, ~0 = empty),
-    // the pair's constrained-body indices, and (degree | rank << 16) of the chain on each of its bodies — the version a body's record has
-    // when sweep s of the chain starts is s * degree + rank; per tile its rounds in level order (64-bit lane masks). cs_slot_of: positional
-    // phase with kinematic bodies only, [sweep * chains + chain] -> the item's index in the level schedule (what ReplayView is indexed by).
+    // the chain-stationary solve (physics.hip, k_solve_cs): every chain lives in a pair of lanes of one wave for the whole phase (even lane: body
+    // A's side, odd: B's). Per phase: tiles of 32 chains in the order of their first level; per slot (tile * 64 + lane) the chain word (first
+    // contact | length << 24, ~0 = empty), the lane's own body and the other one (constrained-body indices), and degree | rank << 16 of the
+    // chain on the own body — the version that body's record has when sweep s of the chain starts is s * degree + rank; per tile its rounds
+    // in level order (64-bit lane masks, the level beside each). cs_slot_of: positional phase with kinematic bodies only, [(tile * 32 + pair)
+    // * passes + sweep] -> the item's index in the level schedule (what ReplayView is indexed by).
     struct CsSchedule {
         uint32_t n_tiles = 0;  // 0: this phase cannot run chain-stationary (too many chains, a body with more than 65535 chains)
         uint32_t slot_offset = 0, round_start_offset = 0, round_offset = 0;  // into cs_item / cs_bodies / cs_vers, cs_round_start, cs_round_mask
