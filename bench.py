@@ -152,7 +152,8 @@ def roofline_block(stage_ms, sb_effective, sb_active, workload_key):
     traffic, source = counted_traffic(workload_key)
     eff = sb_effective[name] / t / 1e9
     act = sb_active[name] / t / 1e9
-    rl = {"bound": "hbm", "kernel": "+".join(STAGE_KERNELS[name][:3]), "stage": name, "achieved": act, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    ran = [k for k in STAGE_KERNELS[name] if k != "k_sdf_super"]  # (k_sdf_super runs only for programs of more than 2048 nodes: none of the bench's)
+    rl = {"bound": "hbm", "kernel": "+".join(ran), "stage": name, "achieved": act, "peak": HBM_PEAK_GBS, "unit": "GB/s",
           "frac": act / HBM_PEAK_GBS, "algorithmic_bytes": sb_active[name],
           "accounting": "SURVEY §8d bytes per voxel x ACTIVE voxels (chunks that have planes); the stored-grid figure is `effective_*`",
           "effective_achieved": eff, "effective_frac": eff / HBM_PEAK_GBS, "effective_algorithmic_bytes": sb_effective[name],
@@ -160,6 +161,17 @@ def roofline_block(stage_ms, sb_effective, sb_active, workload_key):
     if traffic and traffic.get(name) is not None:
         rl["traffic"] = traffic[name]
         rl["counter_frac"] = traffic[name] / t / 1e9 / HBM_PEAK_GBS
+    if name == "sdf_sample":
+        # the slot is two launches: the interval pre-pass (latency of one workgroup, no voxel bytes) and the evaluator, which is bound by
+        # VALU issue — an HBM fraction says nothing about it; `valu_roofline` carries the figure that does (1228.8 G wave-instructions/s by
+        # the guide, 880 measured for simple ops). The dominant KERNEL's own HBM fraction by its share of the slot's time in the committed trace:
+        ks = load_profile(f"kernel_share_{workload_key}.json") if workload_key else None
+        if ks and _profile_current(ks) and ks.get("k_sdf_eval_share_of_sdf_sample"):
+            share = float(ks["k_sdf_eval_share_of_sdf_sample"])
+            rl["dominant_kernel"] = "k_sdf_eval"
+            rl["dominant_kernel_frac"] = act / share / HBM_PEAK_GBS
+            rl["dominant_kernel_source"] = f"{_profile_rel()}/kernel_share_{workload_key}.json (k_sdf_eval's share of the slot's time in the rocprofv3 kernel trace: {share:.3f})"
+        rl["bound_note"] = "the evaluator is VALU-bound: see `valu_roofline` (bound: valu); the HBM fraction here is the contract's figure for the dominant slot"
     tt = float(stage_ms.sum()) * 1e-3
     srl = {"algorithmic_bytes": float(sum(sb_active.values())), "achieved": float(sum(sb_active.values())) / tt / 1e9, "unit": "GB/s",
            "frac": float(sum(sb_active.values())) / tt / 1e9 / HBM_PEAK_GBS,
@@ -262,6 +274,63 @@ def cpu_baseline_all_cores(graph, obj, res, what):
     return base, parity
 
 
+def compact_parity(p):
+    """a `parity` block as the line prints it: the verdict, ONE digest over everything the GPU side was compared on, and the names of what
+    differed (none when equal) — the per-buffer digest pairs are what tests/test_gpu_parity.py asserts on; the line only has to carry the verdict"""
+    if not isinstance(p, dict) or "voxel_sha" not in p:
+        return p
+    import hashlib
+
+    pairs = {k: v for k, v in p.items() if isinstance(v, list) and len(v) == 2}
+    digest = hashlib.sha256("|".join(f"{k}={v[0]}" for k, v in sorted(pairs.items())).encode()).hexdigest()[:16]
+    return {"equal": bool(p.get("equal")), "digest": digest, "compared": sorted(pairs), "differing": sorted(k for k, v in pairs.items() if v[0] != v[1]),
+            "triangles": p["triangles"][0], "moments_rel": p.get("moments_rel")}
+
+
+def compact_parities(x):
+    if isinstance(x, dict):
+        return {k: (compact_parity(v) if isinstance(v, dict) and "voxel_sha" in v else compact_parities(v)) for k, v in x.items()}
+    return x
+
+
+def summary_block(out):
+    """the figures a reader of the line's tail needs, as its LAST key (the driver's record keeps the tail of the line)"""
+    def g(*path):
+        x = out
+        for k in path:
+            if not isinstance(x, dict) or x.get(k) is None:
+                return None
+            x = x[k]
+        return round(x, 4) if isinstance(x, float) else x
+
+    parities = []
+
+    def walk(x):
+        if isinstance(x, dict):
+            for k, v in x.items():
+                if k in ("parity", "parity_sample") and isinstance(v, dict) and "equal" in v:
+                    parities.append(bool(v["equal"]))
+                elif k == "parity" and isinstance(v, dict):
+                    parities.extend(bool(b) for b in v.values() if isinstance(b, bool))
+                else:
+                    walk(v)
+
+    walk(out)
+    return {"ms_per_step": g("ms_per_step"), "sdf_sample_ms": g("stage_ms", "sdf_sample"), "roofline_frac": g("roofline", "frac"),
+            "valu_frac": g("valu_roofline", "frac"), "step_counter_frac": g("step_roofline", "counter_frac"),
+            "dense": {"ms_per_step": g("dense", "ms_per_step"), "emit_ms": g("dense", "emit_ms"), "roofline_kernel": g("dense", "roofline", "kernel"),
+                      "roofline_frac": g("dense", "roofline", "frac"), "counter_frac": g("dense", "roofline", "counter_frac"),
+                      "step_counter_frac": g("dense", "step_roofline", "counter_frac")},
+            "pile": {"ms_per_step": g("pile", "ms_per_step"), "solve_ms": g("pile", "stage_ms", "solve"), "kernel": g("pile", "solver", "kernel")},
+            "frame_pipeline_ms": g("frame", "pipeline", "ms_per_frame"), "frame_two_streams_ms": g("frame", "ms_per_frame_two_streams"),
+            "edit_plus_sync_ms": g("edit", "edit_plus_sync_ms"),
+            "fragments": {"cut_ms": g("fragments", "cut_ms"), "first_step_many_ms": g("fragments", "first_step_many_ms"), "frame_many_ms": g("fragments", "frame_many_ms"),
+                          "frame_looped_ms": g("fragments", "frame_looped_ms")},
+            "config3_split_loop_ms": g("config3", "split_loop_ms"), "config5_single_grid_ms": g("config5_one_gpu", "single_grid_ms"),
+            "config5_eight_slabs_one_gpu_ms": g("config5_one_gpu", "eight_slabs_one_gpu_ms"),
+            "cpu_baseline_voxels_per_s": g("cpu_baseline", "value"), "parity_all_equal": (all(parities) if parities else None), "parity_blocks": len(parities)}
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 def make_object(ctx, graph):
     from impact_amd.voxel import SDFVoxelGenerator, VoxelObject
@@ -283,13 +352,15 @@ def time_steps(ctx, obj, stages, steps, warmup):
     ctx.synchronize()
     acc = np.zeros(capi.N_TIMED_STAGES)
     t0 = time.perf_counter()
-    walls = []
+    walls, samples = [], []
     for _ in range(steps):
         tw = time.perf_counter()
         res = obj.step(stages)
         walls.append(time.perf_counter() - tw)
         acc += res["stage_ms"]
+        samples.append(np.array(res["stage_ms"], dtype=np.float64))
     ctx.synchronize()
+    time_steps.last_samples = np.array(samples)  # [step][slot] ms: min / median / max of a slot over the timed steps (dense_benchmark)
     if os.environ.get("IVX_BENCH_TRACE"):
         print("[bench] time_steps walls (ms):", np.round(1e3 * np.array(walls), 3).tolist(), file=sys.stderr)
     return res, 1e3 * (time.perf_counter() - t0) / steps, acc / steps
@@ -326,6 +397,8 @@ def dense_benchmark(ctx, args, with_cpu):
     sb_eff = stage_bytes(obj.n_voxels, obj.n_chunks, exposed, int(res["mesh"]["n_vertices"]), int(res["mesh"]["n_indices"]))
     sb_act = stage_bytes(active, obj.n_chunks, exposed, int(res["mesh"]["n_vertices"]), int(res["mesh"]["n_indices"]))
     rl, srl, _ = roofline_block(stage_ms, sb_eff, sb_act, "dense")
+    emit = time_steps.last_samples[:, 4]  # the mesher's launch, step by step: which of its two run-to-run modes this process has
+    emit_ms = {"min": round(float(emit.min()), 4), "median": round(float(np.median(emit)), 4), "max": round(float(emit.max()), 4), "steps": int(emit.size)}
     remesh_ms = remesh_only_ms(ctx, obj, max(3, args.steps // 4))
     out = {"workload": f"{n} perforated plates, one per chunk layer: {gen.grid_shape()} grid = {(n * 16)}^3 stored voxels, {non_uniform} of {obj.n_chunks} chunks "
                        f"NonUniform, {exposed} meshed",
@@ -334,7 +407,7 @@ def dense_benchmark(ctx, args, with_cpu):
            "stage_ms": {capi.STAGE_NAMES[i]: round(float(stage_ms[i]), 4) for i in range(capi.N_TIMED_STAGES)},
            "stage_gbs": {capi.STAGE_NAMES[i]: round(sb_act[capi.STAGE_NAMES[i]] / (stage_ms[i] * 1e-3) / 1e9, 1) if stage_ms[i] > 0 and sb_act[capi.STAGE_NAMES[i]] > 0 else None
                          for i in range(capi.N_TIMED_STAGES)},
-           "roofline": rl, "step_roofline": srl}
+           "emit_ms": emit_ms, "roofline": rl, "step_roofline": srl}
     if with_cpu:
         # bounded CPU sample: the same scene at 1/64 of the volume (128^3), GPU and oracle both, with the parity verdict; the
         # full-size parity check is tests/test_gpu_parity.py::test_dense_workload_512
@@ -1225,6 +1298,8 @@ def main():
         elif not args.no_pile:
             out["pile"], w = pile_benchmark(ctx, with_cpu=False)
             w.close()
+        out = compact_parities(out)
+        out["summary"] = summary_block(out)  # (last key: the tail of the line)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
