@@ -791,7 +791,7 @@ int ivx_launch_derive(ivx_grid* g, uint32_t parts, uint32_t preset_groups) {
         pa.rparent = g->rparent, pa.work_counts = ivx_wc(g), pa.next_work_count = next_count, pa.active_list = g->active_list;
         pa.preset = ivx_preset_args(g, preset_groups | roll);
         const uint32_t blocks = (g->n_chunks + 255u) / 256u;
-        if (!ivx_many_try(IVX_MK_CHUNK_PRE, blocks, pa)) IVX_KLAUNCH(k_chunk_pre, dim3(blocks), dim3(256), 0, g->ctx->stream, pa);
+        if (!ivx_many_try(g->ctx, g, IVX_MK_CHUNK_PRE, blocks, pa)) IVX_KLAUNCH(k_chunk_pre, dim3(blocks), dim3(256), 0, g->ctx->stream, pa);
     }
     g->scratch_dirty &= ~preset_groups;
     if (roll) g->scratch_dirty &= ~IVX_SCRATCH_EVAL;
@@ -812,9 +812,9 @@ int ivx_launch_derive(ivx_grid* g, uint32_t parts, uint32_t preset_groups) {
     DeriveArgs da = derive_args(g, v, fz);
     if (g->signs_current) {
         da.signs_type = (uint32_t)g->signs_type;
-        if (!ivx_many_try(IVX_MK_DERIVE_SIGNS, derive_grid, da)) IVX_KLAUNCH(k_derive<true>, dim3(derive_grid), dim3(256), 0, g->ctx->stream, da);
+        if (!ivx_many_try(g->ctx, g, IVX_MK_DERIVE_SIGNS, derive_grid, da)) IVX_KLAUNCH(k_derive<true>, dim3(derive_grid), dim3(256), 0, g->ctx->stream, da);
     } else {
-        if (!ivx_many_try(IVX_MK_DERIVE_PLANES, derive_grid, da)) IVX_KLAUNCH(k_derive<false>, dim3(derive_grid), dim3(256), 0, g->ctx->stream, da);
+        if (!ivx_many_try(g->ctx, g, IVX_MK_DERIVE_PLANES, derive_grid, da)) IVX_KLAUNCH(k_derive<false>, dim3(derive_grid), dim3(256), 0, g->ctx->stream, da);
     }
     g->active_list_stale = 0;
     g->planes_compact = 1;
@@ -849,7 +849,7 @@ int ivx_launch_derive_box(ivx_grid* g, uint32_t parts, const uint32_t lo[3], con
     DeriveArgs da = derive_args(g, v, fz);
     da.box = box;
     const uint32_t blocks = box.derive_blocks + (g->n_chunks + 255u) / 256u;
-    if (!ivx_many_try(IVX_MK_DERIVE_PLANES, blocks, da)) IVX_KLAUNCH(k_derive<false>, dim3(blocks), dim3(256), 0, g->ctx->stream, da);
+    if (!ivx_many_try(g->ctx, g, IVX_MK_DERIVE_PLANES, blocks, da)) IVX_KLAUNCH(k_derive<false>, dim3(blocks), dim3(256), 0, g->ctx->stream, da);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -862,7 +862,7 @@ int ivx_ensure_active_list(ivx_grid* g) {
     memset(&la, 0, sizeof(la));
     la.g = ivx_view(g), la.info = g->info, la.work_counts = ivx_wc(g), la.next_work_count = next_count, la.active_list = g->active_list, la.mesh_counts = g->chunk_counts;
     const uint32_t blocks = (g->n_chunks + 255u) / 256u;
-    if (!ivx_many_try(IVX_MK_LIST_REBUILD, blocks, la)) IVX_KLAUNCH(k_list_rebuild, dim3(blocks), dim3(256), 0, g->ctx->stream, la);
+    if (!ivx_many_try(g->ctx, g, IVX_MK_LIST_REBUILD, blocks, la)) IVX_KLAUNCH(k_list_rebuild, dim3(blocks), dim3(256), 0, g->ctx->stream, la);
     IVX_HIP_CHECK(hipGetLastError());
     g->active_list_stale = 0;
     return IVX_OK;

@@ -408,7 +408,7 @@ int ivx_launch_absorb_mutual(ivx_grid* g, int from_snapshot, const uint32_t lo[3
         aa.p = p, aa.sdf = g->sdf, aa.type = g->type, aa.info = g->info, aa.dens = d_dens, aa.removed10 = d_removed10, aa.by_type = d_by_type;
         aa.counters = d_counters, aa.touched_ranges = d_touched, aa.zero16 = d_zero16;
         const uint32_t blocks = cc[0] * cc[1] * cc[2];
-        if (!ivx_many_try(IVX_MK_ABSORB, blocks, aa)) IVX_KLAUNCH(k_absorb, dim3(blocks), dim3(256), 0, g->ctx->stream, aa);
+        if (!ivx_many_try(g->ctx, g, IVX_MK_ABSORB, blocks, aa)) IVX_KLAUNCH(k_absorb, dim3(blocks), dim3(256), 0, g->ctx->stream, aa);
     }
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
@@ -448,7 +448,7 @@ int ivx_launch_absorb(ivx_grid* g, int capsule, const uint32_t lo[3], const uint
         aa.p = p, aa.sdf = g->sdf, aa.type = g->type, aa.info = g->info, aa.dens = d_dens, aa.removed10 = d_removed10, aa.by_type = d_by_type;
         aa.counters = d_counters, aa.touched_ranges = d_touched, aa.zero16 = d_zero16;
         const uint32_t blocks = cc[0] * cc[1] * cc[2];
-        if (!ivx_many_try(IVX_MK_ABSORB, blocks, aa)) IVX_KLAUNCH(k_absorb, dim3(blocks), dim3(256), 0, g->ctx->stream, aa);
+        if (!ivx_many_try(g->ctx, g, IVX_MK_ABSORB, blocks, aa)) IVX_KLAUNCH(k_absorb, dim3(blocks), dim3(256), 0, g->ctx->stream, aa);
     }
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;

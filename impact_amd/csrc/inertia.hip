@@ -135,7 +135,7 @@ static void launch_inertia_dense(ivx_grid* g, const GridView& v, const float* d_
     memset(&a, 0, sizeof(a));
     a.g = v, a.x_off = g->x_off, a.flags = g->flags, a.dens = d_dens, a.chunk_moments = g->chunk_moments, a.work_counts = ivx_wc(g), a.active_list = g->active_list;
     const uint32_t blocks = ivx_list_grid(g);
-    if (!ivx_many_try(IVX_MK_INERTIA_DENSE, blocks, a)) IVX_KLAUNCH(k_inertia_dense, dim3(blocks), dim3(256), 0, g->ctx->stream, a);
+    if (!ivx_many_try(g->ctx, g, IVX_MK_INERTIA_DENSE, blocks, a)) IVX_KLAUNCH(k_inertia_dense, dim3(blocks), dim3(256), 0, g->ctx->stream, a);
 }
 
 int ivx_launch_inertia_dense(ivx_grid* g) {

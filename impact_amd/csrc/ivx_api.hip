@@ -97,15 +97,124 @@ int ensure_dev_scratch(ivx_grid* g, size_t bytes) {
     return IVX_OK;
 }
 
+// Shared allocations (ivx_block, ivx_internal.hpp): released by the last grid that holds a part.
+void block_release(ivx_block* b) {
+    if (!b || --b->refs > 0) return;
+    if (b->dev) (void)hipFree(b->dev);
+    if (b->pinned) (void)hipHostFree(b->pinned);
+    delete b;
+}
+// the mesh arrays of a group (1: positions, normals, vertex scratch; 2: indices, index materials; 4: submeshes) given up: freed, or — parts of a
+// shared block — just let go, the block with its last part
+void mesh_group_free(ivx_grid* g, uint32_t group) {
+    const bool pooled = (g->mesh_pooled & group) != 0u;
+    auto drop = [&](auto*& p) {
+        if (p && !pooled) (void)hipFree(p);
+        p = nullptr;
+    };
+    if (group == 1u) drop(g->positions), drop(g->normals), drop(g->vertex_materials);
+    if (group == 2u) drop(g->indices), drop(g->index_materials);
+    if (group == 4u) drop(g->submeshes);
+    if (pooled) {
+        g->mesh_pooled &= ~group;
+        if (!g->mesh_pooled) {
+            block_release(g->mesh_block);
+            g->mesh_block = nullptr;
+        }
+    }
+}
+// Mesh arrays for several grids from ONE device allocation (the fragments of an impact meet their first mesh together): capacities
+// `vcaps` / `icaps` / `scaps` per grid; whatever the grids held before is given up. Every array starts on a 256-byte boundary.
+int mesh_pool_assign(ivx_grid* const* grids, size_t n, const size_t* vcaps, const size_t* icaps, const size_t* scaps) {
+    if (n == 0) return IVX_OK;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t total = 0;
+    for (size_t i = 0; i < n; ++i) total += 2 * up(vcaps[i] * 12) + up(vcaps[i] * 16) + up(icaps[i] * 4) + up(icaps[i] * 8) + up(scaps[i] * sizeof(ivx_submesh));
+    ivx_block* blk = new (std::nothrow) ivx_block();
+    IVX_REQUIRE(blk, IVX_ERR_CAPACITY, "mesh buffers: out of host memory");
+    blk->dev = blk->pinned = nullptr;
+    blk->refs = 0;
+    if (hipMalloc(&blk->dev, total) != hipSuccess) {
+        delete blk;
+        ivx_set_error("mesh buffers: device allocation of %zu bytes for %zu objects failed", total, n);
+        return IVX_ERR_HIP;
+    }
+    char* b = static_cast<char*>(blk->dev);
+    for (size_t i = 0; i < n; ++i) {
+        ivx_grid* g = grids[i];
+        mesh_group_free(g, 1u), mesh_group_free(g, 2u), mesh_group_free(g, 4u);
+        auto take = [&](auto*& p, size_t bytes) {
+            p = reinterpret_cast<std::remove_reference_t<decltype(p)>>(b);
+            b += up(bytes);
+        };
+        take(g->positions, vcaps[i] * 12), take(g->normals, vcaps[i] * 12), take(g->vertex_materials, vcaps[i] * 16);
+        take(g->indices, icaps[i] * 4), take(g->index_materials, icaps[i] * 8), take(g->submeshes, scaps[i] * sizeof(ivx_submesh));
+        g->vcap = vcaps[i], g->icap = icaps[i], g->scap = scaps[i];
+        g->mesh_block = blk;
+        g->mesh_pooled = 7u;
+        g->mesh_generation += 1;
+        blk->refs += 1;
+    }
+    return IVX_OK;
+}
+
+// Developer experiment (IVX_MESH_ARENA=<mode>, IVX_MESH_PHASE=<bytes>): the mesher's four output arrays (+ the vertex scratch) carved from ONE
+// allocation at chosen relative offsets — array k starts `k * phase` bytes past its 2 MiB-aligned place. mode 1: hipMalloc; 2: one physically
+// contiguous block (hipExtMallocWithFlags(hipDeviceMallocContiguous)). What the mesher's run-to-run modes do NOT depend on.
+static int mesh_arena_mode() {
+    static const int m = [] {
+        const char* e = getenv("IVX_MESH_ARENA");
+        return e ? atoi(e) : 0;
+    }();
+    return m;
+}
+static int ensure_mesh_block(ivx_grid* g, size_t nv, size_t ni) {
+    if (nv <= g->vcap && ni <= g->icap) return IVX_OK;
+    IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
+    static const size_t phase = [] {
+        const char* e = getenv("IVX_MESH_PHASE");
+        return (size_t)(e ? strtoull(e, nullptr, 0) : 0ull);
+    }();
+    const size_t vcap = std::max(2 * nv + 4096, g->vcap * 2), icap = std::max(2 * ni + 24576, g->icap * 2);
+    const size_t sizes[5] = {vcap * 12, vcap * 12, icap * 4, icap * 8, vcap * 16};
+    size_t off[5], total = 0;
+    for (int k = 0; k < 5; ++k) {
+        total = (total + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+        off[k] = total + (size_t)k * phase;
+        total = off[k] + sizes[k];
+    }
+    mesh_group_free(g, 1u), mesh_group_free(g, 2u);
+    g->vcap = g->icap = 0;
+    ivx_block* blk = new (std::nothrow) ivx_block();
+    IVX_REQUIRE(blk, IVX_ERR_CAPACITY, "mesh buffers: out of host memory");
+    blk->dev = blk->pinned = nullptr;
+    blk->refs = 1;
+    if ((mesh_arena_mode() == 2 ? hipExtMallocWithFlags(&blk->dev, total, hipDeviceMallocContiguous) : hipMalloc(&blk->dev, total)) != hipSuccess) {
+        delete blk;
+        ivx_set_error("mesh buffers: device allocation of %zu bytes failed", total);
+        return IVX_ERR_HIP;
+    }
+    char* b = static_cast<char*>(blk->dev);
+    g->positions = reinterpret_cast<float*>(b + off[0]);
+    g->normals = reinterpret_cast<float*>(b + off[1]);
+    g->indices = reinterpret_cast<uint32_t*>(b + off[2]);
+    g->index_materials = reinterpret_cast<uint8_t*>(b + off[3]);
+    g->vertex_materials = reinterpret_cast<uint8_t*>(b + off[4]);
+    g->vcap = vcap, g->icap = icap;
+    if (g->mesh_block) block_release(g->mesh_block);  // (only the submeshes of an earlier shared block can still be there: they move out below)
+    g->mesh_block = blk;
+    g->mesh_pooled = 3u;
+    g->mesh_generation += 1;
+    return IVX_OK;
+}
+
 int ensure_mesh_capacity(ivx_grid* g, size_t nv, size_t ni, size_t ns) {
+    if (mesh_arena_mode())
+        if (int rc = ensure_mesh_block(g, nv, ni)) return rc;
     if (nv > g->vcap || ni > g->icap || ns > g->scap) g->mesh_generation += 1;
     if (nv > g->vcap) {
         size_t cap = std::max(2 * nv + 4096, g->vcap * 2);  // (slack: under the reference's range allocator an edited mesh's buffers grow — a re-meshed chunk that needs a little more than it had goes to the end — by about as much again before freed ranges start to be reused; 2 x 48 B per vertex is nothing next to 288 GB)
-        if (g->positions) (void)hipFree(g->positions);
-        if (g->normals) (void)hipFree(g->normals);
-        if (g->vertex_materials) (void)hipFree(g->vertex_materials);
-        g->positions = g->normals = nullptr;
-        g->vertex_materials = nullptr;
+        mesh_group_free(g, 1u);
         g->vcap = 0;
         int rc;
         if ((rc = dev_alloc(&g->positions, cap * 3))) return rc;
@@ -115,10 +224,7 @@ int ensure_mesh_capacity(ivx_grid* g, size_t nv, size_t ni, size_t ns) {
     }
     if (ni > g->icap) {
         size_t cap = std::max(2 * ni + 24576, g->icap * 2);
-        if (g->indices) (void)hipFree(g->indices);
-        if (g->index_materials) (void)hipFree(g->index_materials);
-        g->indices = nullptr;
-        g->index_materials = nullptr;
+        mesh_group_free(g, 2u);
         g->icap = 0;
         int rc;
         if ((rc = dev_alloc(&g->indices, cap))) return rc;
@@ -127,8 +233,7 @@ int ensure_mesh_capacity(ivx_grid* g, size_t nv, size_t ni, size_t ns) {
     }
     if (ns > g->scap) {
         size_t cap = std::max(2 * ns + 64, g->scap * 2);
-        if (g->submeshes) (void)hipFree(g->submeshes);
-        g->submeshes = nullptr;
+        mesh_group_free(g, 4u);
         g->scap = 0;
         int rc;
         if ((rc = dev_alloc(&g->submeshes, cap))) return rc;
@@ -268,14 +373,15 @@ void manager_remove(ivx_grid* g, ivx_submesh_manager* m, uint32_t chunk) {  // r
 struct GrowKeep {
     void** slot;
     void* fresh;
+    uint32_t group;  // the mesh group the array belongs to (mesh_group_free)
 };
 template <class T>
-int grow_keep_enqueue(ivx_grid* g, T** buf, size_t old_count, size_t new_count, std::vector<GrowKeep>& pending) {
+int grow_keep_enqueue(ivx_grid* g, T** buf, size_t old_count, size_t new_count, std::vector<GrowKeep>& pending, uint32_t group) {
     T* fresh = nullptr;
     int rc = dev_alloc(&fresh, new_count);
     if (rc) return rc;
     if (*buf && old_count) IVX_HIP_CHECK(ivx_memcpy_async(fresh, *buf, old_count * sizeof(T), hipMemcpyDeviceToDevice, g->ctx->stream));
-    pending.push_back(GrowKeep{reinterpret_cast<void**>(buf), fresh});
+    pending.push_back(GrowKeep{reinterpret_cast<void**>(buf), fresh, group});
     return IVX_OK;
 }
 int ensure_mesh_capacity_keep(ivx_grid* g, size_t nv, size_t ni, size_t ns) {
@@ -296,25 +402,26 @@ int ensure_mesh_capacity_keep(ivx_grid* g, size_t nv, size_t ni, size_t ns) {
     size_t vcap = g->vcap, icap = g->icap, scap = g->scap;
     if (nv > g->vcap) {
         vcap = std::max(nv + nv / 2 + 4096, 2 * g->vcap);
-        if ((rc = grow_keep_enqueue(g, &g->positions, g->vcap * 3, vcap * 3, pending))) return rc;
-        if ((rc = grow_keep_enqueue(g, &g->normals, g->vcap * 3, vcap * 3, pending))) return rc;
-        if ((rc = grow_keep_enqueue(g, &g->vertex_materials, (size_t)0, vcap * 16, pending))) return rc;  // scratch of the emit kernel
+        if ((rc = grow_keep_enqueue(g, &g->positions, g->vcap * 3, vcap * 3, pending, 1u))) return rc;
+        if ((rc = grow_keep_enqueue(g, &g->normals, g->vcap * 3, vcap * 3, pending, 1u))) return rc;
+        if ((rc = grow_keep_enqueue(g, &g->vertex_materials, (size_t)0, vcap * 16, pending, 1u))) return rc;  // scratch of the emit kernel
     }
     if (ni > g->icap) {
         icap = std::max(ni + ni / 2 + 24576, 2 * g->icap);
-        if ((rc = grow_keep_enqueue(g, &g->indices, g->icap, icap, pending))) return rc;
-        if ((rc = grow_keep_enqueue(g, &g->index_materials, g->icap * 8, icap * 8, pending))) return rc;
+        if ((rc = grow_keep_enqueue(g, &g->indices, g->icap, icap, pending, 2u))) return rc;
+        if ((rc = grow_keep_enqueue(g, &g->index_materials, g->icap * 8, icap * 8, pending, 2u))) return rc;
     }
     if (ns > g->scap) {
         scap = std::max(ns + ns / 2 + 64, 2 * g->scap);
-        if ((rc = grow_keep_enqueue(g, &g->submeshes, g->scap, scap, pending))) return rc;
+        if ((rc = grow_keep_enqueue(g, &g->submeshes, g->scap, scap, pending, 4u))) return rc;
     }
     IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
     guard.armed = false;
-    for (GrowKeep& k : pending) {
-        if (*k.slot) (void)hipFree(*k.slot);
-        *k.slot = k.fresh;
-    }
+    uint32_t groups = 0;
+    for (GrowKeep& k : pending) groups |= k.group;
+    for (uint32_t grp = 1u; grp <= 4u; grp <<= 1)
+        if (groups & grp) mesh_group_free(g, grp);  // (the old arrays: freed, or let go of as parts of a shared block)
+    for (GrowKeep& k : pending) *k.slot = k.fresh;
     g->vcap = vcap, g->icap = icap, g->scap = scap;
     return IVX_OK;
 }
@@ -364,6 +471,7 @@ int ivx_init(int device_id, void* stream, ivx_ctx** out) {
 void ivx_shutdown(ivx_ctx* c) {
     if (!c) return;
     (void)ivx_stream_sync(c->stream);
+    ivx_many_release(c);  // (the launch recorder of the many-object calls and its staging ring)
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -376,7 +484,52 @@ int ivx_synchronize(ivx_ctx* c) {
 
 void* ivx_stream(ivx_ctx* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
 
-int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32_t x_chunk_offset, uint32_t global_x_chunks, ivx_grid** out) {
+// ONE device allocation for everything of a grid whose size follows from the chunk counts, carved at 256-byte boundaries: a grid used to
+// cost ~45 hipMalloc calls, which was most of the price of creating the small grids that split-off and polyhedron clips make (one per
+// fragment). `arena` null: sizes only. Returns the arena's bytes.
+static size_t grid_carve(ivx_grid* g, char* arena) {
+    size_t arena_bytes = 0;
+    const size_t cols = (size_t)g->cc[1] * g->cc[2];
+    auto carve = [&](auto** p, size_t count) {
+        using T = std::remove_pointer_t<std::remove_pointer_t<decltype(p)>>;
+        const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+        if (arena) *p = reinterpret_cast<T*>(arena + arena_bytes);
+        arena_bytes += bytes;
+    };
+    carve(&g->sdf, g->n_vox);
+    carve(&g->type, g->n_vox);
+    carve(&g->flags, g->n_vox);
+    carve(&g->llabel, g->n_vox);
+    carve(&g->info, (size_t)g->n_chunks);
+    carve(&g->chunk_bbox, (size_t)g->n_chunks);
+    for (int sd = 0; sd < 2; ++sd) {
+        carve(&g->ghost_sdf[sd], cols * 256);
+        carve(&g->ghost_type[sd], cols * 256);
+        carve(&g->ghost_info[sd], cols);
+    }
+    carve(&g->chunk_counts, (size_t)g->n_chunks * 2);
+    carve(&g->chunk_offsets, (size_t)g->n_chunks * 3 + 8);
+    carve(&g->partials, g->partial_blocks * 10 + 16);
+    carve(&g->rparent, (size_t)g->n_chunks * 256);
+    carve(&g->rcompid, (size_t)g->n_chunks * 256);
+    carve(&g->rscalar, (size_t)64);
+    carve(&g->ccl_scratch, (size_t)g->n_chunks * 2);
+    carve(&g->sn_list, (size_t)g->n_chunks * 4);  // one uint4 record per meshed chunk
+    carve(&g->group_sums, (size_t)((g->n_chunks + 255u) / 256u) * 4 + IVX_SN_TAIL_WORDS);
+    carve(&g->sn_hard, (size_t)g->n_chunks);
+    carve(&g->dens_dev, (size_t)256);
+    carve(&g->work_counts, (size_t)8);
+    carve(&g->occ_part, (size_t)((g->n_chunks + 255u) / 256u) * 12 + 12);
+    carve(&g->active_list, (size_t)g->n_chunks);
+    carve(&g->chunk_class, (size_t)g->n_chunks);
+    carve(&g->chunk_touch, (size_t)g->n_chunks);
+    carve(&g->chunk_signs, (size_t)g->n_chunks * 256);
+    carve(&g->kface, (size_t)g->n_chunks * 1024);
+    carve(&g->chunk_moments, (size_t)g->n_chunks * 10);
+    return arena_bytes;
+}
+// the host side of a new grid (no device memory yet)
+static int grid_new(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32_t x_chunk_offset, uint32_t global_x_chunks, ivx_grid** out) {
     IVX_REQUIRE(c && cc && out, IVX_ERR_INVALID, "ivx_grid_create: null argument");
     *out = nullptr;
     IVX_REQUIRE(cc[0] > 0 && cc[1] > 0 && cc[2] > 0, IVX_ERR_INVALID, "ivx_grid_create: empty chunk grid");
@@ -384,7 +537,6 @@ int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32
     const uint64_t n64 = (uint64_t)cc[0] * cc[1] * cc[2];
     // GlobalRegionLabel packs the chunk index in 24 bits (split_detection.rs:1539-1571)
     IVX_REQUIRE(n64 <= (1u << 24), IVX_ERR_CAPACITY, "ivx_grid_create: more than 2^24 chunks");
-    IVX_HIP_CHECK(hipSetDevice(c->device));
     ivx_grid* g = new (std::nothrow) ivx_grid();
     IVX_REQUIRE(g, IVX_ERR_CAPACITY, "ivx_grid_create: out of host memory");
     memset(g, 0, sizeof(*g));
@@ -396,62 +548,27 @@ int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32
     g->extent = voxel_extent;
     g->x_off = x_chunk_offset;
     g->gx = global_x_chunks ? global_x_chunks : cc[0];
-    const size_t cols = (size_t)cc[1] * cc[2];
-    int rc = IVX_OK;
-    // ONE device allocation for everything whose size follows from the chunk counts, carved at 256-byte boundaries: a grid used to
-    // cost ~45 hipMalloc calls, which was most of the price of creating the small grids that split-off and polyhedron clips make
-    // (one per fragment). Pass 1 sizes the arena, pass 2 hands out the pointers.
-    size_t arena_bytes = 0;
-    char* arena = nullptr;
-    auto carve = [&](auto** p, size_t count) {
-        using T = std::remove_pointer_t<std::remove_pointer_t<decltype(p)>>;
-        const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
-        if (arena) *p = reinterpret_cast<T*>(arena + arena_bytes);
-        arena_bytes += bytes;
-    };
     g->partial_blocks = 2048;
-    for (int pass = 0; pass < 2; ++pass) {
-        arena_bytes = 0;
-        carve(&g->sdf, g->n_vox);
-        carve(&g->type, g->n_vox);
-        carve(&g->flags, g->n_vox);
-        carve(&g->llabel, g->n_vox);
-        carve(&g->info, (size_t)g->n_chunks);
-        carve(&g->chunk_bbox, (size_t)g->n_chunks);
-        for (int sd = 0; sd < 2; ++sd) {
-            carve(&g->ghost_sdf[sd], cols * 256);
-            carve(&g->ghost_type[sd], cols * 256);
-            carve(&g->ghost_info[sd], cols);
-        }
-        carve(&g->chunk_counts, (size_t)g->n_chunks * 2);
-        carve(&g->chunk_offsets, (size_t)g->n_chunks * 3 + 8);
-        carve(&g->partials, g->partial_blocks * 10 + 16);
-        carve(&g->rparent, (size_t)g->n_chunks * 256);
-        carve(&g->rcompid, (size_t)g->n_chunks * 256);
-        carve(&g->rscalar, (size_t)64);
-        carve(&g->ccl_scratch, (size_t)g->n_chunks * 2);
-        carve(&g->sn_list, (size_t)g->n_chunks * 4);  // one uint4 record per meshed chunk
-        carve(&g->group_sums, (size_t)((g->n_chunks + 255u) / 256u) * 4 + IVX_SN_TAIL_WORDS);
-        carve(&g->sn_hard, (size_t)g->n_chunks);
-        carve(&g->dens_dev, (size_t)256);
-        carve(&g->work_counts, (size_t)8);
-        carve(&g->occ_part, (size_t)((g->n_chunks + 255u) / 256u) * 12 + 12);
-        carve(&g->active_list, (size_t)g->n_chunks);
-        carve(&g->chunk_class, (size_t)g->n_chunks);
-        carve(&g->chunk_touch, (size_t)g->n_chunks);
-        carve(&g->chunk_signs, (size_t)g->n_chunks * 256);
-        carve(&g->kface, (size_t)g->n_chunks * 1024);
-        carve(&g->chunk_moments, (size_t)g->n_chunks * 10);
-        if (pass == 0) {
-            if (hipMalloc(reinterpret_cast<void**>(&arena), arena_bytes) != hipSuccess) {
-                ivx_set_error("ivx_grid_create: device allocation of %zu bytes failed", arena_bytes);
-                delete g;
-                return IVX_ERR_HIP;
-            }
-            g->arena = arena;
-        }
+    *out = g;
+    return IVX_OK;
+}
+
+static void ivx_block_release(ivx_block* b) { block_release(b); }
+
+int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32_t x_chunk_offset, uint32_t global_x_chunks, ivx_grid** out) {
+    ivx_grid* g = nullptr;
+    int rc = grid_new(c, cc, voxel_extent, x_chunk_offset, global_x_chunks, &g);
+    if (rc) return rc;
+    IVX_HIP_CHECK(hipSetDevice(c->device));
+    const size_t arena_bytes = grid_carve(g, nullptr);
+    char* arena = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&arena), arena_bytes) != hipSuccess) {
+        ivx_set_error("ivx_grid_create: device allocation of %zu bytes failed", arena_bytes);
+        delete g;
+        return IVX_ERR_HIP;
     }
-    (void)rc;
+    g->arena = arena;
+    (void)grid_carve(g, arena);
     if (ivx_memset_async(g->info, 0, sizeof(ivx_chunk_info) * g->n_chunks, c->stream) != hipSuccess ||
         ivx_memset_async(g->work_counts, 0, 8 * sizeof(uint32_t), c->stream) != hipSuccess) {
         ivx_set_error("ivx_grid_create: memset failed");
@@ -459,6 +576,59 @@ int ivx_grid_create(ivx_ctx* c, const uint32_t cc[3], float voxel_extent, uint32
         return IVX_ERR_HIP;
     }
     *out = g;
+    return IVX_OK;
+}
+
+// Grids that come into being together (the fragments of an impact, fracturing.rs:1047-1189; docs/voxel_gpu_buffer_pooling.md:44-66): their
+// arenas from ONE device allocation and their host-mapped result blocks from ONE pinned allocation, both released with the last of them.
+// The chunk records and work counters start zeroed by ONE fill over the whole block. `ccs`: 3 chunk counts per grid.
+static int grid_create_pooled(ivx_ctx* c, const uint32_t* ccs, size_t n, float voxel_extent, ivx_grid** out) {
+    for (size_t i = 0; i < n; ++i) out[i] = nullptr;
+    if (n == 0) return IVX_OK;
+    IVX_HIP_CHECK(hipSetDevice(c->device));
+    auto fail = [&](int rc) {
+        for (size_t i = 0; i < n; ++i) {
+            if (out[i]) {  // (nothing of the blocks is theirs yet)
+                out[i]->arena = nullptr, out[i]->arena_block = nullptr, out[i]->result_host = nullptr, out[i]->host_block = nullptr;
+                delete out[i];
+            }
+            out[i] = nullptr;
+        }
+        return rc;
+    };
+    std::vector<size_t> off(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) {
+        int rc = grid_new(c, ccs + 3 * i, voxel_extent, 0, 0, &out[i]);
+        if (rc) return fail(rc);
+        off[i + 1] = off[i] + ((grid_carve(out[i], nullptr) + 4095) & ~(size_t)4095);
+    }
+    ivx_block* blk = new (std::nothrow) ivx_block();
+    if (!blk) return fail(IVX_ERR_CAPACITY);
+    blk->dev = blk->pinned = nullptr;
+    blk->refs = 0;
+    if (hipMalloc(&blk->dev, off[n]) != hipSuccess || hipHostMalloc(&blk->pinned, n * 256, hipHostMallocMapped) != hipSuccess) {
+        ivx_set_error("ivx_copy_polyhedra: allocation of %zu bytes for %zu grids failed", off[n], n);
+        blk->refs = 1;
+        ivx_block_release(blk);
+        return fail(IVX_ERR_HIP);
+    }
+    memset(blk->pinned, 0, n * 256);
+    void* pinned_dev = nullptr;
+    if (hipHostGetDevicePointer(&pinned_dev, blk->pinned, 0) != hipSuccess) {
+        blk->refs = 1;
+        ivx_block_release(blk);
+        return fail(IVX_ERR_HIP);
+    }
+    for (size_t i = 0; i < n; ++i) {
+        ivx_grid* g = out[i];
+        g->arena = static_cast<char*>(blk->dev) + off[i];
+        (void)grid_carve(g, g->arena);
+        g->arena_block = blk;
+        g->result_host = reinterpret_cast<uint32_t*>(static_cast<char*>(blk->pinned) + i * 256);
+        g->result_host_dev = reinterpret_cast<uint32_t*>(static_cast<char*>(pinned_dev) + i * 256);
+        g->host_block = blk;
+        blk->refs += 2;
+    }
     return IVX_OK;
 }
 
@@ -473,6 +643,15 @@ void ivx_grid_destroy(ivx_grid* g) {
     g->submesh_manager = nullptr, g->probe_manager = nullptr;
     // (everything sized by the chunk counts lives in the arena; the rest grew on demand)
     if (g->dens_call) (void)hipFree(g->dens_call);
+    mesh_group_free(g, 1u), mesh_group_free(g, 2u), mesh_group_free(g, 4u);  // (allocations of their own, or parts of a shared block)
+    if (g->arena_block) {  // (the arena is a part of a block shared with the grids that came into being with this one)
+        ivx_block_release(g->arena_block);
+        g->arena = nullptr;
+    }
+    if (g->host_block) {
+        ivx_block_release(g->host_block);
+        g->result_host = nullptr;
+    }
     void* ptrs[] = {g->arena, g->positions, g->normals, g->indices, g->index_materials, g->vertex_materials, g->submeshes, g->dev_scratch, g->prog_nodes,
                     g->samp_len, g->samp_ops, g->pairs_dev, g->samp_super, g->probe_points, g->probe_chunk, g->probe_entries};
     for (void* p : ptrs)
@@ -815,7 +994,7 @@ static int mesh_sync_enqueue(ivx_grid* g, const uint8_t* invalidated_chunks, con
     (void)table_before;
     if (recs.empty())
         for (uint32_t slot : dirty_slots)
-            if (slot < m->table.size() && !ivx_many_upload(g->submeshes + slot, &m->table[slot], sizeof(ivx_submesh)))
+            if (slot < m->table.size() && !ivx_many_upload(g->ctx, g, g->submeshes + slot, &m->table[slot], sizeof(ivx_submesh)))
                 IVX_HIP_CHECK(ivx_memcpy_async(g->submeshes + slot, &m->table[slot], sizeof(ivx_submesh), hipMemcpyHostToDevice, g->ctx->stream));
     g->mesh_counts.n_vertices = (uint32_t)m->total_vertices;
     g->mesh_counts.n_indices = (uint32_t)m->total_indices;
@@ -1287,6 +1466,8 @@ int ivx_clip_polyhedron(ivx_grid* parent, const float* planes4, size_t n_planes,
 // host reads for its voxel count / box / regions. Here the parent's ranges are reduced once, all clip kernels and all children's derive /
 // range / voxel-count passes are enqueued back to back and read with ONE wait, the discard / repack decisions are taken on the host, then
 // all region passes follow with a second wait. Per fragment the results are those of ivx_clip_polyhedron(copy = 1).
+static int step_enqueue(ivx_grid* g, uint32_t stages, const uint16_t* slab_nbr_ids, void* slab_record);
+static int ivx_step_collect_launch(ivx_grid* g);
 int ivx_copy_polyhedra(ivx_grid* parent, const float* planes4, const uint32_t* plane_counts, const float* aabbs6, size_t n_sets, ivx_grid** children,
                        uint32_t* origins3, int* outcomes) {
     IVX_REQUIRE(parent && planes4 && plane_counts && aabbs6 && children && origins3 && outcomes, IVX_ERR_INVALID, "ivx_copy_polyhedra: null argument");
@@ -1307,22 +1488,12 @@ int ivx_copy_polyhedra(ivx_grid* parent, const float* planes4, const uint32_t* p
     if ((rc = d2h(parent, occ_raw, d_occ, sizeof(occ_raw)))) return rc;
     ivx_occupied_from_raw(parent, occ_raw, occ);
     if (occ[1] == 0) return IVX_OK;
-    struct Frag {
-        ivx_grid* c = nullptr;
-        size_t info_off = 0;
-    };
-    std::vector<Frag> fr(n_sets);
-    auto fail = [&](int code) {
-        for (Frag& f : fr)
-            if (f.c) ivx_grid_destroy(f.c);
-        for (size_t f = 0; f < n_sets; ++f) children[f] = nullptr;
-        return code;
-    };
-    // 1. the children's chunk boxes, their grids, the clip kernels
-    size_t plane_off = 0, info_total = 0;
-    float ones[256];
-    for (float& x : ones) x = 1.0f;
+    // 1. the children's chunk boxes; their grids from ONE device block and ONE pinned block (grid_create_pooled)
+    std::vector<uint32_t> live, ccs, los;
+    size_t plane_off = 0;
+    std::vector<size_t> plane_offs(n_sets);
     for (size_t f = 0; f < n_sets; plane_off += plane_counts[f], ++f) {
+        plane_offs[f] = plane_off;
         const float* aabb = aabbs6 + 6 * f;
         uint32_t lo[3], cc[3];
         bool hit = true;
@@ -1338,70 +1509,81 @@ int ivx_copy_polyhedra(ivx_grid* parent, const float* planes4, const uint32_t* p
             }
         }
         if (!hit) continue;
-        if ((rc = ivx_grid_create(parent->ctx, cc, parent->extent, 0, 0, &fr[f].c))) return fail(rc);
-        if ((rc = ivx_launch_clip(parent, fr[f].c, lo, cc, planes4 + 4 * plane_off, plane_counts[f], 0))) return fail(rc);
-        for (int q = 0; q < 3; ++q) origins3[3 * f + q] = lo[q] * 16u;
-        fr[f].info_off = info_total;
-        info_total += fr[f].c->n_chunks;
+        live.push_back((uint32_t)f);
+        for (int q = 0; q < 3; ++q) ccs.push_back(cc[q]), los.push_back(lo[q]), origins3[3 * f + q] = lo[q] * 16u;
     }
-    // 2. per child: flags + per-chunk boxes, voxel box, unit-density mass (= voxel count); all enqueued, one wait
-    const size_t per_child = 12 * sizeof(uint32_t) + sizeof(double);
-    // (the region scalars of step 3 get a slot of their own behind the per-child tails: written while the chunk records ahead of them are still being read)
-    const size_t scalars_off = 1024 + info_total * sizeof(ivx_chunk_info) + n_sets * per_child;
-    const size_t stage_bytes = scalars_off + n_sets * 8;
-    if ((rc = ensure_host_scratch(parent, stage_bytes))) return fail(rc);
-    char* stage = static_cast<char*>(parent->host_scratch);
-    memcpy(stage, ones, sizeof(ones));
-    ivx_grid* first = nullptr;
-    for (size_t f = 0; f < n_sets; ++f) {
-        ivx_grid* c = fr[f].c;
-        if (!c) continue;
-        if (!first) {
-            first = c;
-            if (ivx_memcpy_async(c->dens_dev, stage, sizeof(ones), hipMemcpyHostToDevice, s) != hipSuccess) return fail(IVX_ERR_HIP);
-        } else if (ivx_memcpy_async(c->dens_dev, first->dens_dev, sizeof(ones), hipMemcpyDeviceToDevice, s) != hipSuccess) {
-            return fail(IVX_ERR_HIP);
-        }
+    const size_t n_live = live.size();
+    if (n_live == 0) return IVX_OK;
+    std::vector<ivx_grid*> kids(n_live, nullptr);
+    if ((rc = grid_create_pooled(parent->ctx, ccs.data(), n_live, parent->extent, kids.data()))) return rc;
+    auto fail = [&](int code) {
+        (void)ivx_stream_sync(s);
+        for (ivx_grid*& c : kids)
+            if (c) {
+                c->pending_stages = 0, c->gather_launched = 0;
+                ivx_grid_destroy(c);
+                c = nullptr;
+            }
+        for (size_t f = 0; f < n_sets; ++f) children[f] = nullptr, outcomes[f] = 0;
+        return code;
+    };
+    if ((rc = ivx_ensure_dense(parent))) return fail(rc);  // (what the clips read; ahead of the recording: it may launch)
+    // 2. per child, RECORDED (many.hpp) and issued as one launch per chain position for all of them: the clip, then a step of the child without
+    // the sample and remesh stages — derived state, regions, occupied ranges, unit-density mass (= voxel count) — and the gather of its small
+    // results into its host-mapped block. One wait for all.
+    float ones[256];
+    for (float& x : ones) x = 1.0f;
+    const uint32_t child_stages = IVX_STAGE_DERIVE | IVX_STAGE_REGIONS | IVX_STAGE_OCCUPIED | IVX_STAGE_INERTIA;
+    auto enqueue_child = [&](size_t i) -> int {
+        ivx_grid* c = kids[i];
+        const size_t f = live[i];
+        int r;
+        if (!ivx_many_zero(c->ctx, c, c->work_counts, 8 * sizeof(uint32_t))) IVX_HIP_CHECK(ivx_memset_async(c->work_counts, 0, 8 * sizeof(uint32_t), s));
+        if ((r = ivx_launch_clip(parent, c, &los[3 * i], &ccs[3 * i], planes4 + 4 * plane_offs[f], plane_counts[f], 0))) return r;
+        if (!ivx_many_upload(c->ctx, c, c->dens_dev, ones, sizeof(ones))) IVX_HIP_CHECK(ivx_memcpy_async(c->dens_dev, ones, sizeof(ones), hipMemcpyHostToDevice, s));
         memcpy(c->dens_host, ones, sizeof(ones));
         c->has_dens = 1;
-        if ((rc = ivx_launch_derive(c, 0))) return fail(rc);
-        if ((rc = ivx_launch_occupied(c, c->rscalar + 16))) return fail(rc);
-        if ((rc = ivx_launch_inertia(c, c->dens_dev, c->partials + c->partial_blocks * 10, 0))) return fail(rc);
-        char* dst = stage + 1024 + fr[f].info_off * sizeof(ivx_chunk_info);
-        bool ok = ivx_memcpy_async(dst, c->info, c->n_chunks * sizeof(ivx_chunk_info), hipMemcpyDeviceToHost, s) == hipSuccess;
-        char* tail = stage + 1024 + info_total * sizeof(ivx_chunk_info) + f * per_child;
-        ok = ok && ivx_memcpy_async(tail, c->rscalar + 16, 12 * sizeof(uint32_t), hipMemcpyDeviceToHost, s) == hipSuccess;
-        ok = ok && ivx_memcpy_async(tail + 12 * sizeof(uint32_t), c->partials + c->partial_blocks * 10, sizeof(double), hipMemcpyDeviceToHost, s) == hipSuccess;
-        if (!ok) {
-            ivx_set_error("ivx_copy_polyhedra: copy failed");
-            return fail(IVX_ERR_HIP);
+        const uint32_t keep = c->stage_timing_off;
+        c->stage_timing_off = 0xFFFFFFFFu;  // (no event records: they would cut the merged launches between every two children)
+        r = step_enqueue(c, child_stages, nullptr, nullptr);
+        c->stage_timing_off = keep;
+        if (r) return r;
+        return ivx_step_collect_launch(c);
+    };
+    if (ivx_many_recording()) {  // (inside somebody else's bracket: in order on the stream, unmerged)
+        (void)ivx_many_break();
+        for (size_t i = 0; i < n_live; ++i)
+            if ((rc = enqueue_child(i))) return fail(rc);
+    } else {
+        if ((rc = ivx_many_begin(parent->ctx))) return fail(rc);
+        int first = IVX_OK;
+        for (size_t i = 0; i < n_live && !first; ++i) {
+            ivx_many_object((uint32_t)i);
+            first = enqueue_child(i);
         }
+        rc = ivx_many_flush(parent->ctx);
+        if (first || rc) return fail(first ? first : rc);
     }
-    if (ivx_stream_sync(s) != hipSuccess) return fail(IVX_ERR_HIP);
-    // 3. discard crumbs, repack small children into one chunk (complete_extracted_voxel_object, extraction.rs:1902-2142), then the
-    // region passes of every survivor, again with one wait
-    for (size_t f = 0; f < n_sets; ++f) {
-        ivx_grid* c = fr[f].c;
-        if (!c) continue;
-        const ivx_chunk_info* info = reinterpret_cast<const ivx_chunk_info*>(stage + 1024) + fr[f].info_off;
-        uint32_t uniform_count = 0;
-        for (uint32_t i = 0; i < c->n_chunks; ++i) uniform_count += info[i].gen_kind == KIND_UNIFORM;
-        const char* tail = stage + 1024 + info_total * sizeof(ivx_chunk_info) + f * per_child;
-        uint32_t raw[12], cocc[12];
-        memcpy(raw, tail, sizeof(raw));
-        double m0;
-        memcpy(&m0, tail + sizeof(raw), sizeof(double));
-        ivx_occupied_from_raw(c, raw, cocc);
+    std::vector<ivx_step_result> res(n_live);
+    for (size_t i = 0; i < n_live; ++i)
+        if ((rc = ivx_voxel_step_collect(kids[i], &res[i]))) return fail(rc);
+    // 3. discard crumbs, repack small children into one chunk (complete_extracted_voxel_object, extraction.rs:1902-2142)
+    for (size_t i = 0; i < n_live; ++i) {
+        ivx_grid* c = kids[i];
+        const size_t f = live[i];
+        const uint32_t* cocc = res[i].occupied;
         const double e = (double)c->extent;
-        const unsigned long long non_empty = (unsigned long long)(m0 / (e * e * e) + 0.5);
-        if (uniform_count == 0 && non_empty < 8) {  // NON_EMPTY_VOXEL_THRESHOLD (object.rs:203)
+        const unsigned long long non_empty = (unsigned long long)(res[i].moments.m64[0] / (e * e * e) + 0.5);
+        // (a chunk filled with one type — gen_kind Uniform — holds 4096 voxels and spans 16 along every axis: neither test below can pass with
+        // one, which is what the reference's `uniform_chunk_count == 0` conditions say)
+        if (non_empty < 8) {  // NON_EMPTY_VOXEL_THRESHOLD (object.rs:203)
             ivx_grid_destroy(c);
-            fr[f].c = nullptr;
+            kids[i] = nullptr;
             outcomes[f] = 2;
             continue;
         }
-        if (c->cc[0] <= 2 && c->cc[1] <= 2 && c->cc[2] <= 2 && uniform_count == 0 && c->n_chunks > 1 && cocc[1] != 0 && cocc[7] - cocc[6] <= 14 &&
-            cocc[9] - cocc[8] <= 14 && cocc[11] - cocc[10] <= 14) {
+        if (c->cc[0] <= 2 && c->cc[1] <= 2 && c->cc[2] <= 2 && c->n_chunks > 1 && cocc[1] != 0 && cocc[7] - cocc[6] <= 14 && cocc[9] - cocc[8] <= 14 &&
+            cocc[11] - cocc[10] <= 14) {
             uint32_t off[3];
             for (int q = 0; q < 3; ++q) off[q] = cocc[6 + 2 * q] > 0 ? cocc[6 + 2 * q] - 1u : 0u;
             const uint32_t one[3] = {1, 1, 1};
@@ -1412,31 +1594,11 @@ int ivx_copy_polyhedra(ivx_grid* parent, const float* planes4, const uint32_t* p
                 return fail(rc);
             }
             ivx_grid_destroy(c);  // (waits for the stream: the repack has read its source)
-            c = fr[f].c = single;
+            c = kids[i] = single;
             for (int q = 0; q < 3; ++q) origins3[3 * f + q] += off[q];
+            ivx_step_result again;
+            if ((rc = ivx_grid_set_densities(single, ones)) || (rc = ivx_voxel_step(single, child_stages, &again))) return fail(rc);
         }
-        if ((rc = ivx_launch_derive(c, IVX_PART_REGIONS))) return fail(rc);
-        if ((rc = ivx_launch_ccl_local(c, 1))) return fail(rc);
-        if ((rc = ivx_launch_ccl_merge(c))) return fail(rc);
-        if ((rc = ivx_launch_ccl_resolve(c))) return fail(rc);
-        if (ivx_memcpy_async(stage + scalars_off + f * 8, c->rscalar, 8, hipMemcpyDeviceToHost, s) != hipSuccess) return fail(IVX_ERR_HIP);
-    }
-    if (ivx_stream_sync(s) != hipSuccess) return fail(IVX_ERR_HIP);
-    for (size_t f = 0; f < n_sets; ++f) {
-        ivx_grid* c = fr[f].c;
-        if (!c) continue;
-        uint32_t sc[2];
-        memcpy(sc, stage + scalars_off + f * 8, 8);
-        if (sc[1] & 1u) {
-            ivx_set_error("ivx_copy_polyhedra: a chunk has more than 254 local regions");
-            return fail(IVX_ERR_CAPACITY);
-        }
-        if (sc[1] & 8u) {
-            ivx_set_error("ivx_copy_polyhedra: the region merge gave up waiting for the numbering of the multi-region chunks (k_step_post2)");
-            return fail(IVX_ERR_HIP);
-        }
-        c->region_count = sc[0];
-        c->regions_valid = 1;
         c->mesh_valid = 0;
         children[f] = c;
         outcomes[f] = 1;
@@ -1537,7 +1699,7 @@ static int edit_sync_pending(ivx_grid* g) { return g->edit ? g->edit->sync_pendi
 static int ensure_pinned(void** p, size_t* have, size_t bytes);
 // host -> device from the sync's own pinned block, asynchronously (the block is free again once the event behind the copy has passed)
 static int edit_sync_upload(ivx_grid* g, const void* src, size_t bytes, void* d_dst) {
-    if (ivx_many_upload(d_dst, src, (bytes + 3) & ~(size_t)3)) return IVX_OK;  // (a batch is being recorded: the words ride in its staging copy)
+    if (ivx_many_upload(g->ctx, g, d_dst, src, (bytes + 3) & ~(size_t)3)) return IVX_OK;  // (a batch is being recorded: the words ride in its staging copy)
     ivx_edit_state* e = edit_state(g);
     IVX_REQUIRE(e, IVX_ERR_CAPACITY, "ivx_mesh_sync: out of host memory");
     if (!e->up_done) IVX_HIP_CHECK(hipEventCreateWithFlags(&e->up_done, hipEventDisableTiming));
@@ -1697,7 +1859,7 @@ static int absorb_collect(ivx_grid* g, const char* who, ivx_absorb_result* out, 
     }
     // (the accumulators and the touched words start the next edit from zero — and that edit's box may be larger than this one's: everything this
     // edit wrote is cleared now, off the next edit's path; the block beyond has never been written)
-    if (!ivx_many_zero(e->d_results, (e->total + 3) & ~(size_t)3)) IVX_HIP_CHECK(ivx_memset_async(e->d_results, 0, e->total, g->ctx->stream));
+    if (!ivx_many_zero(g->ctx, g, e->d_results, (e->total + 3) & ~(size_t)3)) IVX_HIP_CHECK(ivx_memset_async(e->d_results, 0, e->total, g->ctx->stream));
     const double* rem = reinterpret_cast<const double*>(hb);
     const double ex = (double)g->extent, e3 = ex * ex * ex, e4 = e3 * ex, e5 = e4 * ex;
     const double f[10] = {e3, 0.5 * e4, 0.5 * e4, 0.5 * e4, e5 / 3.0, e5 / 3.0, e5 / 3.0, 0.25 * e5, 0.25 * e5, 0.25 * e5};
@@ -2099,8 +2261,8 @@ int ivx_collision_probes_sync(ivx_grid* g, const uint8_t* invalidated_chunks, si
     if (pm->total > g->probe_point_cap) {  // grow, keeping what is there
         const size_t cap = std::max<size_t>(pm->total + pm->total / 2 + 4096, 2 * g->probe_point_cap);
         std::vector<GrowKeep> pending;
-        if ((rc = grow_keep_enqueue(g, &g->probe_points, g->probe_point_cap * 3, cap * 3, pending))) return rc;
-        if ((rc = grow_keep_enqueue(g, &g->probe_chunk, g->probe_point_cap, cap, pending))) return rc;
+        if ((rc = grow_keep_enqueue(g, &g->probe_points, g->probe_point_cap * 3, cap * 3, pending, 0u))) return rc;
+        if ((rc = grow_keep_enqueue(g, &g->probe_chunk, g->probe_point_cap, cap, pending, 0u))) return rc;
         IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
         for (GrowKeep& k : pending) {
             if (*k.slot) (void)hipFree(*k.slot);
@@ -2792,7 +2954,18 @@ int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out) {
             }
             std::atomic_thread_fence(std::memory_order_acquire);
         }
-        if (!rung) IVX_HIP_CHECK(ivx_stream_sync(s));
+        if (!rung) {
+            IVX_HIP_CHECK(ivx_stream_sync(s));
+            // the stream is empty and the doorbell has not rung: the gather never reached the stream (a flush of recorded launches failed and
+            // dropped it, many.hpp) — what the block holds is an earlier step's
+            std::atomic_thread_fence(std::memory_order_acquire);
+            if (*bell != want) {
+                const int dropped = ivx_many_error(g->ctx, true);
+                g->pending_stages = 0;
+                ivx_set_error("ivx_voxel_step_collect: the step's results never arrived (%s)", dropped ? "a flush of recorded launches failed" : "the gather did not run");
+                return IVX_ERR_HIP;
+            }
+        }
     }
     const uint32_t* sc = g->result_host;
     if (sc[31]) g->last_active = sc[31];
@@ -2815,19 +2988,27 @@ int ivx_voxel_step_collect(ivx_grid* g, ivx_step_result* out) {
     }
     if (stages & IVX_STAGE_REMESH) {
         const uint32_t totals[3] = {sc[28], sc[29], sc[30]};
+        bool grown_later = false;
         if (totals[0] > g->vcap || totals[1] > g->icap || totals[2] > g->scap) {
-            int rc;
-            if ((rc = ensure_mesh_capacity(g, totals[0], totals[1], totals[2]))) return rc;
-            if ((rc = ivx_launch_sn_emit(g))) return rc;
-            IVX_HIP_CHECK(ivx_stream_sync(s));
+            if (g->defer_mesh_growth) {
+                grown_later = true;  // (ivx_voxel_step_many: the buffers of all objects that outgrew theirs from one allocation, their emit passes as one launch)
+            } else {
+                int rc;
+                if ((rc = ensure_mesh_capacity(g, totals[0], totals[1], totals[2]))) return rc;
+                if ((rc = ivx_launch_sn_emit(g))) return rc;
+                IVX_HIP_CHECK(ivx_stream_sync(s));
+            }
         }
         g->mesh_counts.n_vertices = totals[0];
         g->mesh_counts.n_indices = totals[1];
         g->mesh_counts.n_submeshes = totals[2];
         g->mesh_counts.reserved = 0;
-        g->mesh_valid = 1;
-        g->mesh_built = 1;
-        g->mesh_serial += 1;
+        g->mesh_growth_pending = grown_later ? 1 : 0;
+        if (!grown_later) {
+            g->mesh_valid = 1;
+            g->mesh_built = 1;
+            g->mesh_serial += 1;
+        }
     }
     if (stages & IVX_STAGE_INERTIA) {
         memcpy(out->moments.m64, sc + 32, 10 * sizeof(double));
@@ -2952,8 +3133,42 @@ static int many_check(ivx_grid* const* grids, size_t n, const char* who) {
     }
     return IVX_OK;
 }
-// runs `f(i)` for every object under the recorder and flushes; the first error ends the batch (what was recorded still goes out, so that no
-// object is left half enqueued)
+// A many-object call that fails half way — an object's enqueue refused, a flush failed — must not leave the objects before it "in flight":
+// the stream is drained, every object's collect half runs with its results discarded, and whatever flag still says "pending" is cleared, so
+// that the next call on any of these objects starts clean (their derived state is what the launches that did run left: step them again).
+static int many_fail(ivx_grid* const* grids, size_t n, int rc) {
+    if (!rc || !n) return rc;
+    char keep[512];
+    snprintf(keep, sizeof(keep), "%s", ivx_last_error());  // (the collects below may set messages of their own: the caller gets the first failure's)
+    (void)ivx_stream_sync(grids[0]->ctx->stream);
+    (void)ivx_many_error(grids[0]->ctx, true);
+    for (size_t i = 0; i < n; ++i) {
+        ivx_grid* g = grids[i];
+        if (!g) continue;
+        if (g->edit && g->edit->pending) {
+            ivx_absorb_result tmp;
+            (void)absorb_collect(g, "ivx_*_many (drain)", &tmp, nullptr, nullptr);
+        }
+        if (g->edit && g->edit->sync_pending) {
+            ivx_mesh_counts mc;
+            (void)mesh_sync_collect(g, &mc, "ivx_*_many (drain)", true);
+        }
+        if (g->pending_stages || g->gather_launched) {
+            ivx_step_result tmp;
+            (void)ivx_voxel_step_collect(g, &tmp);
+        }
+        if (g->edit) g->edit->pending = 0, g->edit->sync_pending = 0;
+        g->pending_stages = 0;
+        g->gather_launched = 0;
+        g->results_in_block = 0;
+        g->defer_mesh_growth = 0;
+        if (g->mesh_growth_pending) g->mesh_growth_pending = 0, g->mesh_valid = 0;
+    }
+    ivx_set_error("%s", keep);
+    return rc;
+}
+// runs `f(i)` for every object under the recorder and flushes; the first error ends the batch (what was recorded still goes out; the caller
+// drains: many_fail)
 static int many_phase(ivx_grid* const* grids, size_t n, const std::function<int(size_t)>& f) {
     ivx_ctx* c = grids[0]->ctx;
     int rc = ivx_many_begin(c);
@@ -2987,10 +3202,49 @@ int ivx_voxel_step_many(ivx_grid* const* grids, size_t n, uint32_t stages, ivx_s
              grids[i]->stage_timing_off = keep;
              return r;
          })))
-        return rc;
-    if ((rc = many_phase(grids, n, [&](size_t i) { return ivx_step_collect_launch(grids[i]); }))) return rc;
+        return many_fail(grids, n, rc);
+    if ((rc = many_phase(grids, n, [&](size_t i) { return ivx_step_collect_launch(grids[i]); }))) return many_fail(grids, n, rc);
+    for (size_t i = 0; i < n; ++i) {
+        grids[i]->defer_mesh_growth = 1;
+        rc = ivx_voxel_step_collect(grids[i], &out[i]);
+        grids[i]->defer_mesh_growth = 0;
+        if (rc) return many_fail(grids, n, rc);
+    }
+    // Objects whose meshes outgrew their buffers (all of them, when the fragments of an impact are stepped for the first time): the new buffers
+    // of all from ONE allocation at twice what each needs (docs/voxel_gpu_buffer_pooling.md:44-66), their emit passes again as one launch
+    // each, one wait — where the single-object collect pays six allocations, a launch and a wait per object.
+    static thread_local std::vector<ivx_grid*> grow;
+    static thread_local std::vector<size_t> caps;
+    grow.clear(), caps.clear();
     for (size_t i = 0; i < n; ++i)
-        if ((rc = ivx_voxel_step_collect(grids[i], &out[i]))) return rc;
+        if (grids[i]->mesh_growth_pending) grow.push_back(grids[i]);
+    if (!grow.empty()) {
+        const size_t m = grow.size();
+        caps.resize(3 * m);
+        for (size_t k = 0; k < m; ++k) {
+            const ivx_mesh_counts& mc = grow[k]->mesh_counts;
+            caps[k] = std::max<size_t>(2 * (size_t)mc.n_vertices + 4096, grow[k]->vcap * 2);
+            caps[m + k] = std::max<size_t>(2 * (size_t)mc.n_indices + 24576, grow[k]->icap * 2);
+            caps[2 * m + k] = std::max<size_t>(2 * (size_t)mc.n_submeshes + 64, grow[k]->scap * 2);
+        }
+        if ((rc = mesh_pool_assign(grow.data(), m, caps.data(), caps.data() + m, caps.data() + 2 * m))) return many_fail(grids, n, rc);
+        if ((rc = many_phase(grow.data(), m, [&](size_t k) -> int {
+                 ivx_grid* g = grow[k];
+                 if (!ivx_many_zero(g->ctx, g, ivx_sn_hard_count(g), IVX_SN_TAIL_WORDS * sizeof(uint32_t)))
+                     IVX_HIP_CHECK(ivx_memset_async(ivx_sn_hard_count(g), 0, IVX_SN_TAIL_WORDS * sizeof(uint32_t), g->ctx->stream));
+                 int r = ivx_launch_step_emit(g, IVX_STAGE_REMESH, true, nullptr, false);
+                 if (r) return r;
+                 return ivx_launch_step_assign(g, true, false);
+             })))
+            return many_fail(grids, n, rc);
+        IVX_HIP_CHECK(ivx_stream_sync(grids[0]->ctx->stream));
+        for (ivx_grid* g : grow) {
+            g->mesh_growth_pending = 0;
+            g->mesh_valid = 1;
+            g->mesh_built = 1;
+            g->mesh_serial += 1;
+        }
+    }
     return IVX_OK;
 }
 
@@ -3043,14 +3297,14 @@ static int absorb_many(ivx_grid* const* grids, size_t n, const char* who, const 
     if ((rc = many_phase(grids, n, [&](size_t i) {
              return absorb_enqueue(grids[i], who, segments3 ? 1 : 0, points3 + 3 * i, segments3 ? segments3 + 3 * i : nullptr, influence_radii[i], shape_radii[i], densities);
          })))
-        return rc;
+        return many_fail(grids, n, rc);
     clk.lap("enqueue + flush");
     if ((rc = many_phase(grids, n, [&](size_t i) { return (grids[i]->edit && grids[i]->edit->pending && !grids[i]->edit->nothing) ? ivx_step_collect_launch(grids[i]) : IVX_OK; })))
-        return rc;
+        return many_fail(grids, n, rc);
     clk.lap("gathers");
     rc = many_phase(grids, n, [&](size_t i) { return absorb_collect(grids[i], who, &out[i], nullptr, invalidated_chunks ? invalidated_chunks[i] : nullptr); });
     clk.lap("collect");
-    return rc;
+    return many_fail(grids, n, rc);
 }
 int ivx_absorb_sphere_many(ivx_grid* const* grids, size_t n, const float* centers3, const float* influence_radii, const float* sphere_radii,
                            const float densities[256], ivx_absorb_result* out, uint8_t* const* invalidated_chunks) {
@@ -3068,12 +3322,12 @@ int ivx_mesh_sync_many(ivx_grid* const* grids, size_t n, const uint8_t* const* i
     if (rc) return rc;
     IVX_REQUIRE(invalidated_chunks && out, IVX_ERR_INVALID, "ivx_mesh_sync_many: null argument");
     ManyClock clk("sync");
-    if ((rc = many_phase(grids, n, [&](size_t i) { return mesh_sync_enqueue(grids[i], invalidated_chunks[i], "ivx_mesh_sync_many"); }))) return rc;
+    if ((rc = many_phase(grids, n, [&](size_t i) { return mesh_sync_enqueue(grids[i], invalidated_chunks[i], "ivx_mesh_sync_many"); }))) return many_fail(grids, n, rc);
     clk.lap("enqueue + flush");
     IVX_HIP_CHECK(ivx_stream_sync(grids[0]->ctx->stream));  // (one wait for all)
     clk.lap("wait");
     for (size_t i = 0; i < n; ++i)
-        if ((rc = mesh_sync_collect(grids[i], &out[i], "ivx_mesh_sync_many", true))) return rc;
+        if ((rc = mesh_sync_collect(grids[i], &out[i], "ivx_mesh_sync_many", true))) return many_fail(grids, n, rc);
     return IVX_OK;
 }
 

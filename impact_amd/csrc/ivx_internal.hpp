@@ -62,6 +62,16 @@ struct ivx_ctx {
     hipStream_t stream;
     bool own_stream;
     int n_cu;  // compute units of the device
+    void* many_recorder;  // the launch recorder of ivx_many_begin / _flush and its staging ring (many.cpp); made on first use, freed by ivx_shutdown
+    int many_error;       // a flush of recorded launches failed on this context (sticky until reported: ivx_many_error)
+};
+
+// A device allocation (and / or a pinned host allocation) shared by several grids that came into being together — the fragments of an impact
+// (fracturing.rs:1047-1189; docs/voxel_gpu_buffer_pooling.md:44-66: arenas, objects hold a part) —, freed by the last holder (ivx_block_release, ivx_api.hip).
+struct ivx_block {
+    void* dev;
+    void* pinned;
+    int refs;
 };
 
 struct ivx_grid {
@@ -72,6 +82,8 @@ struct ivx_grid {
     float extent;
     uint32_t x_off, gx;  // slab offset in chunks and global chunk count along x
     char* arena;  // the one device allocation the buffers below (all sized by the chunk counts) are carved from
+    ivx_block* arena_block;  // non-null: the arena is a part of this shared block (ivx_copy_polyhedra), not an allocation of its own
+    ivx_block* host_block;   // non-null: result_host is a part of this shared pinned block
     // planes
     int8_t* sdf;
     uint8_t* type;
@@ -198,6 +210,13 @@ struct ivx_grid {
     size_t probe_point_cap, probe_entry_cap;
     uint32_t n_probe_points, n_probe_sub;
     uint64_t mesh_serial, probes_serial;  // probes are current while they were picked from the current mesh
+    // mesh arrays that are parts of a shared block instead of allocations of their own (the first mesh of fragments stepped together,
+    // ivx_voxel_step_many; the developer experiment IVX_MESH_ARENA): bit 0 positions + normals + vertex scratch, bit 1 indices + index materials,
+    // bit 2 submeshes. A group that grows moves out into allocations of its own; the block goes with its last part (mesh_group_free).
+    ivx_block* mesh_block;
+    uint32_t mesh_pooled;
+    int defer_mesh_growth;  // ivx_voxel_step_collect leaves buffers that are too small to the caller (ivx_voxel_step_many grows all objects' at once)
+    int mesh_growth_pending;
     uint64_t mesh_generation;  // bumped whenever a mesh buffer is reallocated: handles exported earlier (ivx_mesh_export) are stale
     // the object's occupied ranges as the reference keeps them (object.rs:1149-1280): refreshed by an explicit update, by split / clip, and by an
     // edit only when it removed a chunk (intersection.rs:255-257, 384-386, 520-522) — in between they may be wider than the voxels need, and the
@@ -387,7 +406,7 @@ static inline void ivx_step_preset_ahead(ivx_grid* g, uint32_t groups) { g->pres
 int ivx_launch_step_post1(ivx_grid* g, uint32_t stages);
 int ivx_launch_step_post2(ivx_grid* g, uint32_t stages, const uint16_t* face_pair_ids = nullptr);
 int ivx_launch_step_emit(ivx_grid* g, uint32_t stages, bool general_in_assign = false, void* slab_record = nullptr, bool record_has_pairs = false);
-int ivx_launch_step_assign(ivx_grid* g, bool with_mesher_general = false);
+int ivx_launch_step_assign(ivx_grid* g, bool with_mesher_general = false, bool with_ccl = true);
 int ivx_launch_step_gather(ivx_grid* g);
 bool ivx_step_assign_fits(const ivx_grid* g);
 int ivx_sampler_buffers(ivx_grid* g);

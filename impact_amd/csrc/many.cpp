@@ -50,9 +50,26 @@ struct Recorder {
     bool busy[RING] = {false, false, false, false};
     int slot = 0;
     std::vector<uint32_t> cursor;
-    uint64_t flushes = 0;
+    uint64_t flushes = 0, launches = 0, recorded = 0;  // (ivx_many_stats)
+    // the bare bracket: chains by owner in order of first appearance (`explicit_cur`: the caller numbers its objects itself, ivx_many_object)
+    bool explicit_cur = false;
+    std::vector<const void*> owners;
 };
+// The recorder belongs to its context (ivx_ctx::many_recorder: made by the first ivx_many_begin, its staging ring allocated on the context's
+// device, freed by ivx_shutdown). What the calling thread holds is only which recorder it is recording into, if any.
 thread_local Recorder* t_rec = nullptr;
+
+// the context's device for the lifetime of the object (allocations and events of the ring belong to it)
+struct OnDevice {
+    int prev = -1, want;
+    explicit OnDevice(int device) : want(device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != want) (void)hipSetDevice(want);
+    }
+    ~OnDevice() {
+        if (prev >= 0 && prev != want) (void)hipSetDevice(prev);
+    }
+};
 
 // whatever happens to a flush, what was recorded is gone afterwards: a failed flush must not leave entries for the next batch to issue
 struct ClearOnExit {
@@ -60,63 +77,76 @@ struct ClearOnExit {
     ~ClearOnExit();
 };
 
-int flush_recorded(Recorder* r) {
+// The merged launches of a flush, in issue order: launch p takes the members [first[p], first[p + 1]) of `members` ((object, entry index)
+// pairs). Flat vectors kept in the recorder: the same chains recur frame after frame and nothing is allocated after the first.
+struct Plan {
+    std::vector<int> kernel;
+    std::vector<uint32_t> first;
+    std::vector<std::pair<uint32_t, uint32_t>> members;
+    std::vector<size_t> off_args, off_ends, off_payload;  // (off_payload: per member, uploads only)
+    std::vector<uint32_t> totals;
+    void clear() {
+        kernel.clear(), first.clear(), members.clear(), off_args.clear(), off_ends.clear(), off_payload.clear(), totals.clear();
+    }
+};
+thread_local Plan t_plan;
+
+int flush_recorded_checked(Recorder* r) {
     if (r->n_entries == 0) return IVX_OK;
     ClearOnExit clear_{r};
+    OnDevice dev_{r->ctx->device};
     r->flushes += 1;
     hipStream_t s = r->ctx->stream;
-    // plan the merged launches: (kernel, members...) in issue order
-    struct Launch {
-        int kernel;
-        std::vector<std::pair<uint32_t, uint32_t>> members;  // (object, entry index)
-    };
-    std::vector<Launch> plan;
+    Plan& plan = t_plan;
+    plan.clear();
     const size_t n_obj = r->chains.size();
     r->cursor.assign(n_obj, 0u);
     size_t left = r->n_entries;
+    // the front of the chains, position by position: the first unfinished object's next kernel, and everybody whose next entry is that kernel.
+    // `lowest`: no object below it has entries left (the scan for the next kernel starts there instead of at object 0)
+    size_t lowest = 0;
     while (left) {
-        int k = -1;
-        for (size_t i = 0; i < n_obj && k < 0; ++i)
-            if (r->cursor[i] < r->chains[i].size()) k = r->chains[i][r->cursor[i]].kernel;
-        Launch L;
-        L.kernel = k;
-        for (size_t i = 0; i < n_obj; ++i) {
+        while (lowest < n_obj && r->cursor[lowest] >= r->chains[lowest].size()) ++lowest;
+        const int k = r->chains[lowest][r->cursor[lowest]].kernel;
+        plan.kernel.push_back(k);
+        plan.first.push_back((uint32_t)plan.members.size());
+        for (size_t i = lowest; i < n_obj; ++i) {
             // (an object's consecutive entries of this kernel merge as well)
             while (r->cursor[i] < r->chains[i].size() && r->chains[i][r->cursor[i]].kernel == k) {
-                L.members.emplace_back((uint32_t)i, r->cursor[i]);
+                plan.members.emplace_back((uint32_t)i, r->cursor[i]);
                 r->cursor[i] += 1u;
                 left -= 1;
                 if (k != IVX_MK_ZERO && k != IVX_MK_UPLOAD) break;  // (range operations of one object may all go together; kernels of one object stay in order)
             }
         }
-        plan.push_back(std::move(L));
     }
+    const size_t n_launch = plan.kernel.size();
+    plan.first.push_back((uint32_t)plan.members.size());
     // lay out argument blocks and running block counts of every launch in one staging block (+ the words of the recorded uploads)
     size_t bytes = 0;
-    std::vector<size_t> off_args(plan.size()), off_ends(plan.size());
-    std::vector<std::vector<size_t>> off_payload(plan.size());
-    for (size_t p = 0; p < plan.size(); ++p) {
-        if (plan[p].kernel != IVX_MK_UPLOAD) continue;
-        off_payload[p].resize(plan[p].members.size());
-        for (size_t m = 0; m < plan[p].members.size(); ++m) {
-            const Entry& e = r->chains[plan[p].members[m].first][plan[p].members[m].second];
-            off_payload[p][m] = bytes;
+    plan.off_args.resize(n_launch), plan.off_ends.resize(n_launch), plan.totals.resize(n_launch);
+    plan.off_payload.assign(plan.members.size(), 0);
+    for (size_t p = 0; p < n_launch; ++p) {
+        if (plan.kernel[p] != IVX_MK_UPLOAD) continue;
+        for (uint32_t m = plan.first[p]; m < plan.first[p + 1]; ++m) {
+            const Entry& e = r->chains[plan.members[m].first][plan.members[m].second];
+            plan.off_payload[m] = bytes;
             bytes += (e.payload_bytes + 15u) & ~15u;
         }
     }
-    for (size_t p = 0; p < plan.size(); ++p) {
-        const uint32_t ab = g_regs[plan[p].kernel].arg_bytes;
-        off_args[p] = bytes;
-        bytes += (size_t)ab * plan[p].members.size();
+    for (size_t p = 0; p < n_launch; ++p) {
+        const uint32_t ab = g_regs[plan.kernel[p]].arg_bytes, nm = plan.first[p + 1] - plan.first[p];
+        plan.off_args[p] = bytes;
+        bytes += (size_t)ab * nm;
         bytes = (bytes + 15) & ~(size_t)15;
-        off_ends[p] = bytes;
-        bytes += 4 * plan[p].members.size();
+        plan.off_ends[p] = bytes;
+        bytes += 4 * (size_t)nm;
         bytes = (bytes + 15) & ~(size_t)15;
     }
     const int sl = r->slot;
     r->slot = (r->slot + 1) % RING;
     if (!r->ev[sl]) IVX_HIP_CHECK(hipEventCreateWithFlags(&r->ev[sl], hipEventDisableTiming));
-    if (r->busy[sl]) {
+    if (r->busy[sl]) {  // (the slot's last flush: its copy AND the twins that read the device block, see below)
         IVX_HIP_CHECK(hipEventSynchronize(r->ev[sl]));
         r->busy[sl] = false;
     }
@@ -131,36 +161,54 @@ int flush_recorded(Recorder* r) {
         r->cap[sl] = cap;
     }
     unsigned char* h = static_cast<unsigned char*>(r->pinned[sl]);
-    std::vector<uint32_t> totals(plan.size());
-    for (size_t p = 0; p < plan.size(); ++p) {
-        const uint32_t ab = g_regs[plan[p].kernel].arg_bytes;
+    for (size_t p = 0; p < n_launch; ++p) {
+        const uint32_t ab = g_regs[plan.kernel[p]].arg_bytes;
         uint32_t run = 0;
-        uint32_t* ends = reinterpret_cast<uint32_t*>(h + off_ends[p]);
-        for (size_t m = 0; m < plan[p].members.size(); ++m) {
-            const Entry& e = r->chains[plan[p].members[m].first][plan[p].members[m].second];
-            memcpy(h + off_args[p] + m * ab, r->arena.data() + e.off, ab);
-            if (plan[p].kernel == IVX_MK_UPLOAD) {  // the words, and where the twin finds them on the device
-                memcpy(h + off_payload[p][m], r->arena.data() + e.payload_off, e.payload_bytes);
-                RangeArgs* ra = reinterpret_cast<RangeArgs*>(h + off_args[p] + m * ab);
-                ra->src = reinterpret_cast<const uint32_t*>(static_cast<const unsigned char*>(r->dev[sl]) + off_payload[p][m]);
+        uint32_t* ends = reinterpret_cast<uint32_t*>(h + plan.off_ends[p]);
+        for (uint32_t m = plan.first[p]; m < plan.first[p + 1]; ++m) {
+            const Entry& e = r->chains[plan.members[m].first][plan.members[m].second];
+            const size_t mi = m - plan.first[p];
+            memcpy(h + plan.off_args[p] + mi * ab, r->arena.data() + e.off, ab);
+            if (plan.kernel[p] == IVX_MK_UPLOAD) {  // the words, and where the twin finds them on the device
+                memcpy(h + plan.off_payload[m], r->arena.data() + e.payload_off, e.payload_bytes);
+                RangeArgs* ra = reinterpret_cast<RangeArgs*>(h + plan.off_args[p] + mi * ab);
+                ra->src = reinterpret_cast<const uint32_t*>(static_cast<const unsigned char*>(r->dev[sl]) + plan.off_payload[m]);
             }
             run += e.blocks;
-            ends[m] = run;
+            ends[mi] = run;
         }
-        totals[p] = run;
+        plan.totals[p] = run;
     }
     IVX_HIP_CHECK(hipMemcpyAsync(r->dev[sl], h, bytes, hipMemcpyHostToDevice, s));
-    IVX_HIP_CHECK(hipEventRecord(r->ev[sl], s));
-    r->busy[sl] = true;
+    r->busy[sl] = true;  // (from here on the slot is in use by the stream, whatever happens below: the event goes behind the last twin issued)
     const unsigned char* d = static_cast<const unsigned char*>(r->dev[sl]);
-    for (size_t p = 0; p < plan.size(); ++p) {
-        if (totals[p] == 0) continue;
-        const ivx_many_reg& reg = g_regs[plan[p].kernel];
-        IVX_REQUIRE(reg.fn, IVX_ERR_STATE, "ivx_many: kernel %d has no twin registered", plan[p].kernel);
-        const int rc = reg.fn(s, d + off_args[p], reinterpret_cast<const uint32_t*>(d + off_ends[p]), (uint32_t)plan[p].members.size(), totals[p]);
-        IVX_REQUIRE(rc == 0, IVX_ERR_HIP, "ivx_many: launch of twin %d failed", plan[p].kernel);
+    int rc = IVX_OK;
+    for (size_t p = 0; p < n_launch && rc == IVX_OK; ++p) {
+        if (plan.totals[p] == 0) continue;
+        const ivx_many_reg& reg = g_regs[plan.kernel[p]];
+        if (!reg.fn) {
+            ivx_set_error("ivx_many: kernel %d has no twin registered", plan.kernel[p]);
+            rc = IVX_ERR_STATE;
+        } else if (reg.fn(s, d + plan.off_args[p], reinterpret_cast<const uint32_t*>(d + plan.off_ends[p]), plan.first[p + 1] - plan.first[p], plan.totals[p]) != 0) {
+            ivx_set_error("ivx_many: launch of twin %d failed", plan.kernel[p]);
+            rc = IVX_ERR_HIP;
+        } else {
+            r->launches += 1;
+        }
     }
-    return IVX_OK;
+    // the slot is free again when the twins that read its device block have run, not when the copy into it has landed
+    if (hipEventRecord(r->ev[sl], s) != hipSuccess && rc == IVX_OK) {
+        ivx_set_error("ivx_many: event record behind a flush failed");
+        rc = IVX_ERR_HIP;
+    }
+    return rc;
+}
+// A flush that fails has dropped launches the caller believes to be on the stream (every wrapper in front of a stream operation ignores the
+// break's status): the failure stays on the context until somebody who waits for results picks it up (ivx_many_error).
+int flush_recorded(Recorder* r) {
+    const int rc = flush_recorded_checked(r);
+    if (rc != IVX_OK && r->ctx->many_error == IVX_OK) r->ctx->many_error = rc;
+    return rc;
 }
 ClearOnExit::~ClearOnExit() {
     for (auto& c : r->chains) c.clear();
@@ -179,7 +227,8 @@ void ivx_many_register(int kernel, ivx_many_launch_fn fn, uint32_t arg_bytes) {
 bool ivx_many_recording() { return t_rec && t_rec->on; }
 
 // A call on an object of ANOTHER context than the one the batch is recorded for must not be recorded (its launches belong on that context's
-// stream): what has been recorded goes out, and recording is off until the call returns.
+// stream): what has been recorded goes out, and recording is off until the call returns. (Entry points that enqueue whole chains use this;
+// every single capture checks its context as well, ivx_many_capture.)
 ivx_many_other_context::ivx_many_other_context(const ivx_ctx* c) : suspended(false) {
     Recorder* r = t_rec;
     if (r && r->on && r->ctx != c) {
@@ -193,7 +242,31 @@ ivx_many_other_context::~ivx_many_other_context() {
 }
 uint64_t ivx_many_flush_count() { return t_rec ? t_rec->flushes : 0; }
 
-static bool capture_range(int kernel, void* d_dst, const void* h_src, size_t bytes) {
+int ivx_many_error(ivx_ctx* c, bool clear) {
+    if (!c) return IVX_OK;
+    const int rc = c->many_error;
+    if (clear) c->many_error = IVX_OK;
+    return rc;
+}
+
+void ivx_many_release(ivx_ctx* c) {
+    if (!c || !c->many_recorder) return;
+    Recorder* r = static_cast<Recorder*>(c->many_recorder);
+    if (t_rec == r) t_rec = nullptr;
+    OnDevice dev_{c->device};
+    for (int sl = 0; sl < RING; ++sl) {
+        if (r->ev[sl]) {
+            if (r->busy[sl]) (void)hipEventSynchronize(r->ev[sl]);
+            (void)hipEventDestroy(r->ev[sl]);
+        }
+        if (r->pinned[sl]) (void)hipHostFree(r->pinned[sl]);
+        if (r->dev[sl]) (void)hipFree(r->dev[sl]);
+    }
+    delete r;
+    c->many_recorder = nullptr;
+}
+
+static bool capture_range(const ivx_ctx* c, const void* owner, int kernel, void* d_dst, const void* h_src, size_t bytes) {
     Recorder* r = t_rec;
     if (!r || !r->on || (bytes & 3u) || bytes == 0 || bytes > (64u << 20)) return false;
     RangeArgs a;
@@ -201,7 +274,7 @@ static bool capture_range(int kernel, void* d_dst, const void* h_src, size_t byt
     a.src = nullptr;
     a.words = bytes / 4;
     const uint32_t blocks = (uint32_t)std::min<size_t>((a.words + 1023) / 1024, 64);
-    if (!ivx_many_capture(kernel, blocks, &a, (uint32_t)sizeof(a))) return false;
+    if (!ivx_many_capture(c, owner, kernel, blocks, &a, (uint32_t)sizeof(a))) return false;
     Entry& e = r->chains[r->cur].back();
     e.payload_off = e.payload_bytes = 0;
     if (h_src) {
@@ -212,14 +285,28 @@ static bool capture_range(int kernel, void* d_dst, const void* h_src, size_t byt
     }
     return true;
 }
-bool ivx_many_zero(void* d_ptr, size_t bytes) { return capture_range(IVX_MK_ZERO, d_ptr, nullptr, bytes); }
-bool ivx_many_upload(void* d_dst, const void* h_src, size_t bytes) { return capture_range(IVX_MK_UPLOAD, d_dst, h_src, bytes); }
+bool ivx_many_zero(const ivx_ctx* c, const void* owner, void* d_ptr, size_t bytes) { return capture_range(c, owner, IVX_MK_ZERO, d_ptr, nullptr, bytes); }
+bool ivx_many_upload(const ivx_ctx* c, const void* owner, void* d_dst, const void* h_src, size_t bytes) {
+    return capture_range(c, owner, IVX_MK_UPLOAD, d_dst, h_src, bytes);
+}
 
-bool ivx_many_capture(int kernel, uint32_t blocks, const void* args, uint32_t arg_bytes) {
+bool ivx_many_capture(const ivx_ctx* c, const void* owner, int kernel, uint32_t blocks, const void* args, uint32_t arg_bytes) {
     Recorder* r = t_rec;
     if (!r || !r->on) return false;
+    if (r->ctx != c) {  // an object of another context inside the bracket: its launch belongs on its own stream (and device), unrecorded
+        (void)ivx_many_break();
+        return false;
+    }
     if (g_regs[kernel].arg_bytes != arg_bytes || !g_regs[kernel].fn) return false;  // (no twin: the caller launches — behind a break)
+    if (!r->explicit_cur && (r->cur >= r->owners.size() || r->owners[r->cur] != owner)) {
+        // a batch recorded through the bare bracket: the captures of an object go to that object's chain (chains in order of first appearance)
+        size_t i = 0;
+        while (i < r->owners.size() && r->owners[i] != owner) ++i;
+        if (i == r->owners.size()) r->owners.push_back(owner);
+        r->cur = (uint32_t)i;
+    }
     if (r->cur >= r->chains.size()) r->chains.resize(r->cur + 1u);
+    r->recorded += 1;
     Entry e;
     e.kernel = kernel;
     e.blocks = blocks;
@@ -248,26 +335,49 @@ int ivx_many_break() {
 }
 
 void ivx_many_object(uint32_t i) {
-    if (t_rec) t_rec->cur = i;
+    if (!t_rec) return;
+    t_rec->cur = i;
+    t_rec->explicit_cur = true;
 }
 
 extern "C" {
 
 int ivx_many_begin(ivx_ctx* c) {
     IVX_REQUIRE(c, IVX_ERR_INVALID, "ivx_many_begin: null context");
-    if (!t_rec) t_rec = new (std::nothrow) Recorder();
-    IVX_REQUIRE(t_rec, IVX_ERR_CAPACITY, "ivx_many_begin: out of host memory");
-    IVX_REQUIRE(!t_rec->on, IVX_ERR_STATE, "ivx_many_begin: a batch is being recorded on this thread already");
-    t_rec->ctx = c;
-    t_rec->on = true;
-    t_rec->cur = 0;
+    IVX_REQUIRE(!t_rec, IVX_ERR_STATE, "ivx_many_begin: a batch is being recorded on this thread already");
+    if (!c->many_recorder) c->many_recorder = new (std::nothrow) Recorder();
+    Recorder* r = static_cast<Recorder*>(c->many_recorder);
+    IVX_REQUIRE(r, IVX_ERR_CAPACITY, "ivx_many_begin: out of host memory");
+    IVX_REQUIRE(!r->on, IVX_ERR_STATE, "ivx_many_begin: a batch is being recorded on this context already (another thread's)");
+    r->ctx = c;
+    r->on = true;
+    r->cur = 0;
+    r->explicit_cur = false;
+    r->owners.clear();
+    t_rec = r;
+    return IVX_OK;
+}
+
+// launches recorded / merged launches issued / flushes made by this context's recorder so far (tests: do hand-recorded batches merge?)
+int ivx_many_stats(ivx_ctx* c, uint64_t out[3]) {
+    IVX_REQUIRE(c && out, IVX_ERR_INVALID, "ivx_many_stats: null argument");
+    const Recorder* r = static_cast<const Recorder*>(c->many_recorder);
+    out[0] = r ? r->recorded : 0;
+    out[1] = r ? r->launches : 0;
+    out[2] = r ? r->flushes : 0;
     return IVX_OK;
 }
 
 int ivx_many_flush(ivx_ctx* c) {
-    IVX_REQUIRE(c && t_rec && t_rec->on && t_rec->ctx == c, IVX_ERR_STATE, "ivx_many_flush: no batch is being recorded on this context");
-    const int rc = flush_recorded(t_rec);
-    t_rec->on = false;
+    IVX_REQUIRE(c && t_rec && t_rec->ctx == c, IVX_ERR_STATE, "ivx_many_flush: no batch is being recorded on this context");
+    Recorder* r = t_rec;
+    r->on = true;  // (a bracket suspended by a call on another context that never returned cannot be: the guard's destructor has run)
+    int rc = flush_recorded(r);
+    r->on = false;
+    t_rec = nullptr;
+    // a break inside the bracket that failed has dropped launches too: the bracket as a whole failed (reported once, here)
+    const int sticky = ivx_many_error(c, true);
+    if (rc == IVX_OK) rc = sticky;
     return rc;
 }
 

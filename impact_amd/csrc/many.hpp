@@ -35,6 +35,7 @@ enum ivx_many_kernel : int {
     IVX_MK_SN_EMIT_SLOTS,
     IVX_MK_SN_EMIT_GENERAL_SLOTS,
     IVX_MK_INERTIA_DENSE,
+    IVX_MK_CLIP,
     IVX_MK_ZERO,    // fill a device range with zeros (the twin of a hipMemsetAsync(..., 0, ...))
     IVX_MK_UPLOAD,  // host words to a device range (the twin of a small hipMemcpyAsync host -> device): the words ride in the flush's one staging copy
     IVX_MK_COUNT
@@ -56,10 +57,18 @@ struct ivx_many_other_context {
     ~ivx_many_other_context();
     bool suspended;
 };
-// true: written down (nothing was launched); false: not recording — the caller launches
-bool ivx_many_capture(int kernel, uint32_t blocks, const void* args, uint32_t arg_bytes);
-// in front of every launch / stream operation that has no twin: what has been recorded goes out first
+// true: written down (nothing was launched); false: not recording, or `c` is not the context the batch is recorded for (what has been
+// recorded goes out first; the launch belongs on c's stream) — the caller launches
+// `owner`: the object the launch belongs to (its grid). A batch recorded through the bare bracket (ivx_many_begin ... _flush, no
+// ivx_many_object) keeps a chain per owner, in the order the owners first appear, so that its objects merge front by front as well.
+bool ivx_many_capture(const ivx_ctx* c, const void* owner, int kernel, uint32_t blocks, const void* args, uint32_t arg_bytes);
+// in front of every launch / stream operation that has no twin: what has been recorded goes out first. A flush that fails is remembered on
+// the batch's context (ivx_many_error): the launches it dropped never reach the stream, and whoever waits for their results must say so
 int ivx_many_break();
+// the sticky error of a failed flush on this context (IVX_OK if none); `clear`: reported now, forget it
+int ivx_many_error(ivx_ctx* c, bool clear);
+// the context's recorder and its staging ring (ivx_shutdown)
+void ivx_many_release(ivx_ctx* c);
 // how many flushes (explicit or by a break) this thread's recorder has made: whoever recorded something and later needs it ON the stream
 // compares the count at recording time with the count now instead of forcing a flush that may have happened long ago
 uint64_t ivx_many_flush_count();
@@ -67,14 +76,14 @@ uint64_t ivx_many_flush_count();
 void ivx_many_object(uint32_t i);
 
 // zero `bytes` (a multiple of 4) at d_ptr / copy `bytes` (a multiple of 4) from host memory to d_dst: recorded when a batch is being recorded
-// (true), else the caller issues the stream operation itself
-bool ivx_many_zero(void* d_ptr, size_t bytes);
-bool ivx_many_upload(void* d_dst, const void* h_src, size_t bytes);
+// on context `c` (true), else the caller issues the stream operation itself
+bool ivx_many_zero(const ivx_ctx* c, const void* owner, void* d_ptr, size_t bytes);
+bool ivx_many_upload(const ivx_ctx* c, const void* owner, void* d_dst, const void* h_src, size_t bytes);
 
 template <typename A>
-static inline bool ivx_many_try(int kernel, uint32_t blocks, const A& a) {
+static inline bool ivx_many_try(const ivx_ctx* c, const void* owner, int kernel, uint32_t blocks, const A& a) {
     static_assert(sizeof(A) % 8 == 0, "argument blocks are copied as 8-byte words");
-    return ivx_many_capture(kernel, blocks, &a, (uint32_t)sizeof(A));
+    return ivx_many_capture(c, owner, kernel, blocks, &a, (uint32_t)sizeof(A));
 }
 
 // (what stands in front of every launch and asynchronous stream operation of the library that has no twin)

@@ -180,10 +180,9 @@ __device__ __forceinline__ int sd_complement(int e) {  // lib.rs:266-268
     return a == -128 ? 127 : -a;
 }
 
-__global__ __launch_bounds__(256) void k_clip(ClipParams cp, int8_t* __restrict__ p_sdf, uint8_t* __restrict__ p_type, ivx_chunk_info* __restrict__ p_info,
-                                              int8_t* __restrict__ c_sdf, uint8_t* __restrict__ c_type, ivx_chunk_info* __restrict__ c_info) {
+__device__ __forceinline__ void clip_body(const ClipParams& cp, int8_t* __restrict__ p_sdf, uint8_t* __restrict__ p_type, ivx_chunk_info* __restrict__ p_info,
+                                          int8_t* __restrict__ c_sdf, uint8_t* __restrict__ c_type, ivx_chunk_info* __restrict__ c_info, const uint32_t cchunk) {
     const uint32_t tid = threadIdx.x;
-    const uint32_t cchunk = blockIdx.x;
     const uint32_t ck = cchunk % cp.cc[2], cj = (cchunk / cp.cc[2]) % cp.cc[1], ci = cchunk / (cp.cc[2] * cp.cc[1]);
     const uint32_t I = ci + cp.lo[0], J = cj + cp.lo[1], K = ck + cp.lo[2];
     const uint32_t pchunk = (I * cp.p.cy + J) * cp.p.cz + K;
@@ -306,6 +305,29 @@ __global__ __launch_bounds__(256) void k_clip(ClipParams cp, int8_t* __restrict_
         }
     }
 }
+__global__ __launch_bounds__(256) void k_clip(ClipParams cp, int8_t* __restrict__ p_sdf, uint8_t* __restrict__ p_type, ivx_chunk_info* __restrict__ p_info,
+                                              int8_t* __restrict__ c_sdf, uint8_t* __restrict__ c_type, ivx_chunk_info* __restrict__ c_info) {
+    clip_body(cp, p_sdf, p_type, p_info, c_sdf, c_type, c_info, blockIdx.x);
+}
+// All fragments of an impact in one launch (many.hpp): a block finds its fragment by the running block counts; the fragment's parameters —
+// a kilobyte of planes — stay in memory and are read through the scalar cache as the body asks for them.
+struct ClipManyArgs {
+    ClipParams cp;
+    int8_t* p_sdf;
+    uint8_t* p_type;
+    ivx_chunk_info* p_info;
+    int8_t* c_sdf;
+    uint8_t* c_type;
+    ivx_chunk_info* c_info;
+};
+static_assert(sizeof(ClipManyArgs) % 8 == 0, "argument blocks travel as 8-byte words");
+__global__ __launch_bounds__(256) void k_clip_many(const ClipManyArgs* __restrict__ argv, const uint32_t* __restrict__ block_end, uint32_t n) {
+    const uint32_t i = ivx_many_find(block_end, n, blockIdx.x);
+    const uint32_t b0 = i ? block_end[i - 1u] : 0u;
+    const ClipManyArgs& a = argv[i];
+    clip_body(a.cp, a.p_sdf, a.p_type, a.p_info, a.c_sdf, a.c_type, a.c_info, blockIdx.x - b0);
+}
+IVX_MANY_LAUNCHER(many_clip, k_clip_many, ClipManyArgs, 256)
 
 }  // namespace
 
@@ -342,6 +364,8 @@ int ivx_launch_split_repack(ivx_grid* src, ivx_grid* dst, const uint32_t off[3])
     return IVX_OK;
 }
 
+static const int s_clip_many_registered = (ivx_many_register(IVX_MK_CLIP, many_clip, sizeof(ClipManyArgs)), 0);
+
 int ivx_launch_clip(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], const uint32_t cc[3], const float* planes4, uint32_t n_planes, int extract) {
     ivx_planes_touched(parent);
     if (child) ivx_planes_touched(child);  // (no child: the region is discarded)
@@ -359,6 +383,13 @@ int ivx_launch_clip(ivx_grid* parent, ivx_grid* child, const uint32_t lo[3], con
     }
     memset(cp.planes, 0, sizeof(cp.planes));
     memcpy(cp.planes, planes4, sizeof(float) * 4 * n_planes);
+    ClipManyArgs ma;
+    memset(&ma, 0, sizeof(ma));
+    ma.cp = cp;
+    ma.p_sdf = parent->sdf, ma.p_type = parent->type, ma.p_info = parent->info;
+    ma.c_sdf = child->sdf, ma.c_type = child->type, ma.c_info = child->info;
+    // (recorded when the fragments of an impact are made together, ivx_copy_polyhedra: the clip belongs to the CHILD's chain)
+    if (!extract && ivx_many_try(child->ctx, child, IVX_MK_CLIP, cc[0] * cc[1] * cc[2], ma)) return IVX_OK;
     IVX_KLAUNCH(k_clip, dim3(cc[0] * cc[1] * cc[2]), dim3(256), 0, parent->ctx->stream, cp, parent->sdf, parent->type, parent->info, child->sdf,
                        child->type, child->info);
     IVX_HIP_CHECK(hipGetLastError());

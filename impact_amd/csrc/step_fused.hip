@@ -333,7 +333,7 @@ int ivx_launch_step_post1(ivx_grid* g, uint32_t stages) {
     }
     const uint32_t total = a.nb[0] + a.nb[1] + a.nb[3] + a.nb[4] + a.nb[5];
     if (total == 0) return IVX_OK;
-    if (!ivx_many_try(IVX_MK_POST1, total, a)) IVX_KLAUNCH(k_step_post1, dim3(total), dim3(256), 0, g->ctx->stream, a);
+    if (!ivx_many_try(g->ctx, g, IVX_MK_POST1, total, a)) IVX_KLAUNCH(k_step_post1, dim3(total), dim3(256), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -370,7 +370,7 @@ int ivx_launch_step_post2(ivx_grid* g, uint32_t stages, const uint16_t* face_pai
     if (stages & IVX_STAGE_OCCUPIED) a.nb[3] = 1;
     const uint32_t total = a.nb[0] + a.nb[1] + a.nb[2] + a.nb[3] + a.nb[4] + a.nb[5];
     if (total == 0) return IVX_OK;
-    if (!ivx_many_try(IVX_MK_POST2, total, a)) IVX_KLAUNCH(k_step_post2, dim3(total), dim3(256), 0, g->ctx->stream, a);
+    if (!ivx_many_try(g->ctx, g, IVX_MK_POST2, total, a)) IVX_KLAUNCH(k_step_post2, dim3(total), dim3(256), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -392,7 +392,7 @@ int ivx_launch_step_emit(ivx_grid* g, uint32_t stages, bool general_in_assign, v
     }
     const uint32_t total = a.nb[0] + a.nb[1] + a.nb[2];
     if (total == 0) return IVX_OK;
-    if (!ivx_many_try(IVX_MK_EMIT, total, a)) IVX_KLAUNCH(k_step_emit, dim3(total), dim3(256), 0, g->ctx->stream, a);
+    if (!ivx_many_try(g->ctx, g, IVX_MK_EMIT, total, a)) IVX_KLAUNCH(k_step_emit, dim3(total), dim3(256), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
     // the chunks the main pass hands on: a role of k_step_assign when that launch follows (the caller says so), else a launch of its own
     if ((stages & IVX_STAGE_REMESH) && !general_in_assign) return ivx_launch_sn_emit_general(g);
@@ -402,11 +402,13 @@ int ivx_launch_step_emit(ivx_grid* g, uint32_t stages, bool general_in_assign, v
 // groups of 256 chunks beyond what the fused assign scans in LDS take the stand-alone resolve path (ivx_launch_ccl_resolve)
 bool ivx_step_assign_fits(const ivx_grid* g) { return (g->n_chunks + 255u) / 256u <= ASSIGN_MAX_GROUPS; }
 
-int ivx_launch_step_assign(ivx_grid* g, bool with_mesher_general) {
+// (`with_ccl` false: the mesher's general pass alone, through this launch's twin — the re-emit of many objects whose buffers grew together)
+int ivx_launch_step_assign(ivx_grid* g, bool with_mesher_general, bool with_ccl) {
     StepArgs a = make_args(g);
-    a.nb[0] = (g->n_chunks + 255u) / 256u;
+    a.nb[0] = with_ccl ? (g->n_chunks + 255u) / 256u : 0u;
     a.nb[1] = with_mesher_general ? sn::ivx_emit_general_grid(g, g->n_chunks) : 0u;
-    if (!ivx_many_try(IVX_MK_ASSIGN, a.nb[0] + a.nb[1], a)) IVX_KLAUNCH(k_step_assign, dim3(a.nb[0] + a.nb[1]), dim3(256), 0, g->ctx->stream, a);
+    if (a.nb[0] + a.nb[1] == 0u) return IVX_OK;
+    if (!ivx_many_try(g->ctx, g, IVX_MK_ASSIGN, a.nb[0] + a.nb[1], a)) IVX_KLAUNCH(k_step_assign, dim3(a.nb[0] + a.nb[1]), dim3(256), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -416,7 +418,7 @@ int ivx_launch_step_gather(ivx_grid* g) {
     a.seq = ++g->result_seq;
     a.copy_src = g->gather_copy_src, a.copy_dst = g->gather_copy_dst, a.copy_words = g->gather_copy_words;  // (consumed by this launch)
     g->gather_copy_words = 0;
-    if (!ivx_many_try(IVX_MK_GATHER, 1u, a)) IVX_KLAUNCH(k_step_gather, dim3(1), dim3(64), 0, g->ctx->stream, a);
+    if (!ivx_many_try(g->ctx, g, IVX_MK_GATHER, 1u, a)) IVX_KLAUNCH(k_step_gather, dim3(1), dim3(64), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

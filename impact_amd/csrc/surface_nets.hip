@@ -275,7 +275,7 @@ int ivx_launch_sn_emit_list(ivx_grid* g, uint32_t n_records, const uint32_t* d_c
                             const void* d_patch_entries, const uint32_t* d_patch_slots) {
     if (n_records == 0) return IVX_OK;
     // (the general pass of the incremental remesh before this one left the words zero, unless a step's mesher has used them since)
-    if (!g->sn_tail_zero && !ivx_many_zero(ivx_sn_hard_count(g), IVX_SN_TAIL_WORDS * sizeof(uint32_t))) {
+    if (!g->sn_tail_zero && !ivx_many_zero(g->ctx, g, ivx_sn_hard_count(g), IVX_SN_TAIL_WORDS * sizeof(uint32_t))) {
         (void)ivx_many_break();
         IVX_HIP_CHECK(ivx_memset_async(ivx_sn_hard_count(g), 0, IVX_SN_TAIL_WORDS * sizeof(uint32_t), g->ctx->stream));
     }
@@ -288,9 +288,9 @@ int ivx_launch_sn_emit_list(ivx_grid* g, uint32_t n_records, const uint32_t* d_c
     a.cursor = ivx_sn_hard_count(g) + 1, a.vcap = (uint32_t)g->vcap, a.icap = (uint32_t)g->icap, a.scap = (uint32_t)g->scap;
     a.n_patch = n_patch, a.patch_entries = static_cast<const ivx_submesh*>(d_patch_entries), a.patch_slots = d_patch_slots;
     const uint32_t b_main = ivx_emit_grid(g, n_records), b_gen = ivx_emit_general_grid(g, n_records);
-    if (!ivx_many_try(IVX_MK_SN_EMIT_SLOTS, b_main, a)) IVX_KLAUNCH(k_sn_emit_slots, dim3(b_main), dim3(256), 0, g->ctx->stream, a);
+    if (!ivx_many_try(g->ctx, g, IVX_MK_SN_EMIT_SLOTS, b_main, a)) IVX_KLAUNCH(k_sn_emit_slots, dim3(b_main), dim3(256), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
-    if (!ivx_many_try(IVX_MK_SN_EMIT_GENERAL_SLOTS, b_gen, a)) IVX_KLAUNCH(k_sn_emit_general_slots, dim3(b_gen), dim3(256), 0, g->ctx->stream, a);
+    if (!ivx_many_try(g->ctx, g, IVX_MK_SN_EMIT_GENERAL_SLOTS, b_gen, a)) IVX_KLAUNCH(k_sn_emit_general_slots, dim3(b_gen), dim3(256), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

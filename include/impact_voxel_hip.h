@@ -320,10 +320,17 @@ int ivx_absorb_mutual(ivx_grid* a, const float rotation_a[4], const float transl
  *                            array per object (entries may be NULL)
  *   ivx_absorb_capsule_many  ivx_absorb_capsule, one capsule per object (segment start and segment vector: 3 floats each per object)
  *   ivx_mesh_sync_many       ivx_mesh_sync for every object
- * ivx_many_begin / ivx_many_flush expose the mechanism itself: between them the `_enqueue` calls of objects of the context are recorded
- * (call ivx_many_object-free: chains are merged front by front in the order the calls were made) and the flush issues them merged. */
+ * A call that fails half way (an object refused, a launch failed) drains the stream and discards what the objects before it had in flight:
+ * no object is left "pending"; step the objects again before using their derived state.
+ * ivx_many_begin / ivx_many_flush expose the mechanism itself: between them the `_enqueue` calls of objects of the context are recorded — a
+ * chain per object, in the order the objects first appear — and the flush issues them merged, front by front. A call on an object of another
+ * context inside the bracket is issued on that context's stream, unrecorded. ivx_many_flush reports a failure of any flush since the begin
+ * (launches that a failed flush dropped never run; `_collect` calls that wait for them fail with IVX_ERR_HIP). The recorder and its staging
+ * blocks belong to the context and go with ivx_shutdown. ivx_many_stats: out[0] launches recorded, [1] merged launches issued, [2] flushes
+ * made on this context so far. */
 int ivx_many_begin(ivx_ctx*);
 int ivx_many_flush(ivx_ctx*);
+int ivx_many_stats(ivx_ctx*, uint64_t out[3]);
 int ivx_voxel_step_many(ivx_grid* const* grids, size_t n, uint32_t stages, ivx_step_result* out);
 int ivx_absorb_sphere_many(ivx_grid* const* grids, size_t n, const float* centers3, const float* influence_radii, const float* sphere_radii,
                            const float densities[256], ivx_absorb_result* out, uint8_t* const* invalidated_chunks);

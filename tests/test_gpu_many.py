@@ -268,3 +268,159 @@ def test_step_many_with_the_sample_stage(ctx):
         parity = pu.step_parity(o, g, res[k])
         assert parity["equal"], (k, parity)
         g.close()
+
+
+def _stats(ctx):
+    out = np.zeros(3, dtype=np.uint64)
+    capi.check(capi.lib().ivx_many_stats(ctx.h, capi.ptr(out)))
+    return [int(x) for x in out]
+
+
+def test_a_batch_recorded_by_hand_merges(ctx):
+    """the bare bracket (ivx_many_begin ... ivx_many_flush around `_enqueue` calls) keeps a chain per object and merges them front by front:
+    far fewer launches issued than recorded, results as the blocking calls give them"""
+    from test_gpu_mesh_sync import both
+
+    lib = capi.lib()
+    pairs = [both(ctx, scenes.sphere_scene(16.0 + 2.0 * k)) for k in range(6)]
+    ctr = []
+    for o, _ in pairs:
+        occ = np.array(o.info()["occupied_voxel_ranges"], dtype=np.float32)
+        c = 0.5 * (occ[:, 0] + occ[:, 1])
+        c[2] = occ[2, 1] - 1.0
+        ctr.append(c)
+    for (o, g), c in zip(pairs, ctr):  # (an object's first edit allocates its edit buffers, with waits on the stream: not what is measured here;
+        # nor is the upload of a density table other than the resident one, a copy in the middle of the chain)
+        g.set_densities(np.ones(256, dtype=np.float32))
+        o.absorb_sphere(c + np.float32(1.5), 4.0, 2.0)
+        g.absorb_sphere(c + np.float32(1.5), 4.0, 2.0)
+    ros = [o.absorb_sphere(c, 5.0, 3.0) for (o, _), c in zip(pairs, ctr)]
+    rec0, iss0, _ = _stats(ctx)
+    capi.check(lib.ivx_many_begin(ctx.h))
+    for (_, g), c in zip(pairs, ctr):
+        g.absorb_sphere_enqueue(c, 5.0, 3.0)
+    capi.check(lib.ivx_many_flush(ctx.h))
+    rec1, iss1, _ = _stats(ctx)
+    recorded, issued = rec1 - rec0, iss1 - iss0
+    assert recorded >= 6 * 5, (recorded, issued)  # (every object records its chain of five or more launches)
+    assert issued * 3 <= recorded, f"{recorded} launches recorded, {issued} issued: the objects' chains did not merge"
+    for k, ((o, g), ro) in enumerate(zip(pairs, ros)):
+        rg = g.absorb_collect()
+        np.testing.assert_array_equal(rg["invalidated"], ro["invalidated"], err_msg=f"object {k}")
+        pu.assert_edited_objects_equal(o, g, f"recorded by hand, object {k}: ", with_mesh=False)
+        g.close()
+
+
+def test_calls_without_a_guard_on_another_context_are_not_recorded(ctx):
+    """ivx_inertia / ivx_derive_state / ivx_label_regions of an object of context B between ivx_many_begin(A) and its flush: their twinned launches
+    (moment sweep, chunk pre-pass, derive sweep) must go out on B's stream, not into A's batch — the check sits at the capture itself"""
+    from impact_amd.voxel import Context, VoxelObjectInertialPropertyManager
+    from test_gpu_mesh_sync import both
+
+    lib = capi.lib()
+    other = Context(0)
+    try:
+        oa, ga = both(ctx, scenes.sphere_scene(20.0))
+        ob, gb = both(other, scenes.asteroid_scene(0.25))
+        dens = np.linspace(0.5, 2.0, 256).astype(np.float32)
+        occ = np.array(oa.info()["occupied_voxel_ranges"], dtype=np.float32)
+        ca = 0.5 * (occ[:, 0] + occ[:, 1])
+        ca[0] = occ[0, 1] - 1.0
+        ra = oa.absorb_sphere(ca, 6.0, 4.0)
+        _, want = ob.inertia(dens)
+        rec0 = _stats(ctx)[0]
+        capi.check(lib.ivx_many_begin(ctx.h))
+        ga.absorb_sphere_enqueue(ca, 6.0, 4.0)  # recorded for A
+        gb.compute_all_derived_state()          # B: chunk pre-pass + derive sweep + regions, on B's stream
+        got = VoxelObjectInertialPropertyManager.initialized_from(gb, dens).m64  # B: moment sweep
+        capi.check(lib.ivx_many_flush(ctx.h))
+        assert np.all(np.abs(got - want) <= 1e-5 * np.maximum(np.abs(want), 1e-300) + 1e-12)
+        xa = ga.absorb_collect()
+        np.testing.assert_array_equal(xa["invalidated"], ra["invalidated"])
+        pu.assert_edited_objects_equal(oa, ga, "context A: ", with_mesh=False)
+        assert_objects_equal(ob, gb, "context B: ")
+        assert _stats(other)[0] == 0, "launches of context B's object were recorded"
+        assert _stats(ctx)[0] > rec0
+        ga.close()
+        gb.close()
+    finally:
+        other.close()
+
+
+def test_an_object_that_fails_in_the_middle_leaves_nobody_pending(ctx):
+    """`ivx_mesh_sync_many` / `ivx_absorb_sphere_many` with an object the call refuses in the middle of the list: the call fails, and every
+    object — the ones enqueued before the failure too — takes the next call as if nothing had happened"""
+    from test_gpu_mesh_sync import both
+
+    pairs = [both(ctx, scenes.sphere_scene(15.0 + 2.0 * k)) for k in range(5)]
+    gs = [g for _, g in pairs]
+    ctr = []
+    for o, _ in pairs:
+        occ = np.array(o.info()["occupied_voxel_ranges"], dtype=np.float32)
+        c = 0.5 * (occ[:, 0] + occ[:, 1])
+        c[1] = occ[1, 1] - 1.0
+        ctr.append(c)
+    bad_radius = [5.0, 5.0, -1.0, 5.0, 5.0]  # (object 2: a radius the edit refuses)
+    with pytest.raises(Exception):
+        many.absorb_sphere_many(gs, ctr, bad_radius, [3.0] * 5)
+    # objects 0 and 1 were enqueued before the failure: their edits ran (the oracle follows), their results were discarded — and nobody is
+    # "in flight": the same edit, valid this time, goes through for all five
+    for k in (0, 1):
+        pairs[k][0].absorb_sphere(ctr[k], 5.0, 3.0)
+    ros = [o.absorb_sphere(c, 5.0, 3.0) for (o, _), c in zip(pairs, ctr)]
+    rs = many.absorb_sphere_many(gs, ctr, [5.0] * 5, [3.0] * 5)
+    for k, ((o, g), ro, rg) in enumerate(zip(pairs, ros, rs)):
+        np.testing.assert_array_equal(rg["invalidated"], ro["invalidated"], err_msg=f"object {k}")
+        pu.assert_edited_objects_equal(o, g, f"after the failed batch, object {k}: ", with_mesh=False)
+    # a second failure kind: an object listed twice is refused before anything is enqueued
+    with pytest.raises(Exception):
+        many.mesh_sync_many([VoxelObjectMesh(gs[0]), VoxelObjectMesh(gs[0])], [rs[0]["invalidated"], rs[0]["invalidated"]])
+    for g in gs:
+        g.close()
+
+
+def test_contexts_come_and_go_around_many_calls(ctx):
+    """fifty contexts made, used for many-object calls and shut down: the recorder and its staging ring belong to the context and go with it
+    (device and pinned memory flat), and a context made afterwards records on blocks of its own"""
+    import ctypes
+
+    from impact_amd.voxel import Context
+    from test_gpu_mesh_sync import both
+
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+        return f.value
+
+    def round_trip():
+        c = Context(0)
+        try:
+            pairs = [both(c, scenes.sphere_scene(14.0 + k)) for k in range(3)]
+            gs = [g for _, g in pairs]
+            ctr = []
+            for o, _ in pairs:
+                occ = np.array(o.info()["occupied_voxel_ranges"], dtype=np.float32)
+                x = 0.5 * (occ[:, 0] + occ[:, 1])
+                x[1] = occ[1, 1] - 1.0
+                ctr.append(x)
+            ros = [o.absorb_sphere(x, 4.0, 2.5) for (o, _), x in zip(pairs, ctr)]
+            rs = many.absorb_sphere_many(gs, ctr, [4.0] * 3, [2.5] * 3)
+            for ro, rg in zip(ros, rs):
+                np.testing.assert_array_equal(rg["invalidated"], ro["invalidated"])
+            for g in gs:
+                g.set_densities(np.ones(256, dtype=np.float32))
+            many.voxel_step_many(gs, capi.STAGE_ALL & ~capi.STAGE_SAMPLE)
+            for g in gs:
+                g.close()
+        finally:
+            c.close()
+
+    for _ in range(3):  # (first uses: code objects, the runtime's own pools)
+        round_trip()
+    before = free_bytes()
+    for _ in range(50):
+        round_trip()
+    after = free_bytes()
+    assert before - after < (8 << 20), f"device memory shrank by {before - after} bytes over 50 contexts"
