@@ -510,9 +510,9 @@ def config3_benchmark(ctx, args, with_cpu):
     centre = float(gen0.shifted_grid_center[0]) + 0.5
     boxes = list(octant_boxes(centre))
     reps = 3
-    t_split, t_clip, t_batch = [], [], []
+    t_split, t_clip, t_batch, t_all = [], [], [], []
     n_children = n_copies = 0
-    child_voxels, copy_voxels = [], []
+    child_voxels, copy_voxels, all_voxels = [], [], []
     for rep in range(reps):
         _, obj = make_object(ctx, graph)
         obj.step(capi.STAGE_ALL)
@@ -555,8 +555,24 @@ def config3_benchmark(ctx, args, with_cpu):
         for k, _ in kids:
             k.close()
         obj.close()
+        if hasattr(obj, "extract_all_disconnected_regions"):  # the same loop as ONE call (ivx_split_off_all) on a fresh body
+            _, obj2 = make_object(ctx, graph)
+            obj2.step(capi.STAGE_ALL)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            got = obj2.extract_all_disconnected_regions()
+            ctx.synchronize()
+            t_all.append(time.perf_counter() - t0)
+            if rep == reps - 1:
+                all_voxels = [int(m["voxel_count"]) for rc, _, _, m in got if rc == 1]
+            for _, k, _, _ in got:
+                if k is not None:
+                    k.close()
+            obj2.close()
     out = {"workload": "config-3 fracture body (256^3 stored voxels, 8 octants): split-off loop until one region is left; polyhedron copy of each octant",
-           "split_loop_ms": 1e3 * float(np.mean(t_split[1:])), "split_offs": n_children, "objects_after": n_children + 1,
+           "split_loop_ms": 1e3 * float(np.mean(t_all[1:])) if t_all else 1e3 * float(np.mean(t_split[1:])),
+           "split_loop_call": "ivx_split_off_all (the loop as one call)" if t_all else "ivx_split_off_smallest_region, looped",
+           "split_loop_one_by_one_ms": 1e3 * float(np.mean(t_split[1:])), "split_offs": n_children, "objects_after": n_children + 1,
            "octant_copies_ms": 1e3 * float(np.mean(t_clip[1:])), "octant_copies": n_copies,
            "octant_copies_batched_ms": 1e3 * float(np.mean(t_batch[1:])) if t_batch else None}
     if with_cpu:
@@ -582,8 +598,9 @@ def config3_benchmark(ctx, args, with_cpu):
         t2 = time.perf_counter()
         out["cpu_baseline"] = {"split_loop_ms": 1e3 * (t2 - t1), "octant_copies_ms": 1e3 * (t1 - t0), "cores": 1, "kind": "port",
                                "sample": "the same operations once (the copies' time includes exporting each child to count its voxels)"}
-        out["parity"] = {"split_child_voxels": [child_voxels, svox], "copy_child_voxels": [copy_voxels, cvox],
-                         "equal": bool(child_voxels == svox and copy_voxels == cvox)}
+        out["parity"] = {"split_child_voxels": [child_voxels, svox], "split_all_child_voxels": [all_voxels, svox] if t_all else None,
+                         "copy_child_voxels": [copy_voxels, cvox],
+                         "equal": bool(child_voxels == svox and copy_voxels == cvox and (not t_all or all_voxels == svox))}
     return out
 
 
@@ -738,10 +755,22 @@ def fragments_benchmark(ctx, with_cpu, n_axis=5, frames=6, warm=2):
             o_.set_densities(dens)
         return objs, [k for k, (rc, _, _) in enumerate(res) if rc == 1]
 
+    # the cut: the first one of the process pays what a first use pays (the body's compact planes written out for the clips to read, the
+    # merged kernels' code objects, the allocator's first big block) — reported apart; `cut_ms` is the median of the three after it
     t0 = time.perf_counter()
     a_objs, kept = cut()
     ctx.synchronize()
-    t_cut = time.perf_counter() - t0
+    t_cut_first = time.perf_counter() - t0
+    t_cuts = []
+    for _ in range(3):
+        for o_ in a_objs:
+            o_.close()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        a_objs, kept = cut()
+        ctx.synchronize()
+        t_cuts.append(time.perf_counter() - t0)
+    t_cut = float(np.median(t_cuts))
     b_objs, _ = cut()
     n = len(a_objs)
     stages0 = capi.STAGE_ALL & ~capi.STAGE_SAMPLE
@@ -806,7 +835,9 @@ def fragments_benchmark(ctx, with_cpu, n_axis=5, frames=6, warm=2):
     out = {"workload": f"config-2 body (256^3) cut into the Voronoi cells of a jittered {n_axis}^3 lattice: {n} fragments of "
                        f"{int(np.median([o_.n_chunks for o_ in a_objs]))} chunks (median); per frame and fragment: one absorbing sphere (r 4-6 voxels), the "
                        "incremental remesh of what it invalidated, the ten moments",
-           "objects": n, "frames": frames, "warmup_frames": warm, "cut_ms": round(1e3 * t_cut, 3),
+           "objects": n, "frames": frames, "warmup_frames": warm, "cut_ms": round(1e3 * t_cut, 3), "cut_first_ms": round(1e3 * t_cut_first, 3),
+           "cut_what": "ivx_copy_polyhedra (children's grids from one block; clip, derived state, regions, occupied ranges and mass of all recorded and issued as one "
+                       "launch per chain position) + the children's wrappers and density tables; median of 3 cuts of the same body, the process's first apart",
            "first_step_looped_ms": round(first_loop_ms, 3), "first_step_many_ms": round(first_many_ms, 3),
            "frame_looped_ms": round(loop_ms, 4), "frame_many_ms": round(many_ms, 4), "speedup": round(loop_ms / many_ms, 2),
            "objects_per_s_looped": n / (loop_ms * 1e-3), "objects_per_s_many": n / (many_ms * 1e-3),
@@ -851,6 +882,24 @@ def fragments_benchmark(ctx, with_cpu, n_axis=5, frames=6, warm=2):
         cpu_ms = 1e3 * float(np.mean(t_cpu[warm:]))
         out["cpu_baseline"] = {"frame_ms": cpu_ms, "objects_per_s": n / (cpu_ms * 1e-3), "cores": 1, "kind": "port",
                                "sample": f"the same {frames} frames over the same {n} fragments, object by object, single thread"}
+        # the cut itself on the host cores, fragments in parallel as FracturingProcess::execute_in_parallel runs them (fracturing.rs:1047-1189)
+        from concurrent.futures import ThreadPoolExecutor
+
+        workers = 1
+        try:
+            workers = max(1, min(16, len(os.sched_getaffinity(0))))
+        except (AttributeError, OSError):
+            pass
+
+        def one_cut(k):
+            return o_body.clip_polyhedron(sets[k][1], sets[k][2], copy=True)[0]
+
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(workers) as ex:
+            rcs = list(ex.map(one_cut, range(len(sets))))
+        cut_cpu = time.perf_counter() - t0
+        out["cpu_baseline_cut"] = {"cut_ms": round(1e3 * cut_cpu, 2), "cores": workers, "kind": "port", "fragments": int(sum(1 for r_ in rcs if r_ == 1)),
+                                   "sample": f"the same {len(sets)} polyhedron copies of the same body, in parallel on {workers} host threads"}
     for o_ in a_objs + b_objs:
         o_.close()
     tets.close()

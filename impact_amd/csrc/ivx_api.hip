@@ -1362,6 +1362,165 @@ int ivx_split_off_smallest_region(ivx_grid* parent, ivx_grid** child, uint32_t o
     return IVX_OK;
 }
 
+static int step_enqueue(ivx_grid* g, uint32_t stages, const uint16_t* slab_nbr_ids, void* slab_record);
+static int ivx_step_collect_launch(ivx_grid* g);
+// The reference's split-off LOOP in one call (interaction.rs:256: `while let Some(..) = find_two_disconnected_regions` ->
+// extract the smaller of the FIRST TWO regions in scan order, extraction.rs:255-271): the regions of the object are described once; what a
+// region is — voxels, box, chunk counts — does not change when another region leaves (regions share no voxel, and a chunk that holds two of
+// them stays NonUniform for the one that remains), nor does their scan order, so the loop's picks follow from the one description: the host
+// plays the loop over the descriptors, every region that goes is moved out by its own launch into a grid from one shared block, the parent
+// is re-derived ONCE and the children together (recorded, many.hpp). `children` / `origins3` / `outcomes` / `moved` in the order the loop
+// extracts them (outcome 1: a child object, 2: discarded as a crumb); *n_out = number of split-offs (regions - 1).
+int ivx_split_off_all(ivx_grid* parent, size_t cap, ivx_grid** children, uint32_t* origins3, int* outcomes, ivx_region_desc* moved, size_t* n_out) {
+    IVX_REQUIRE(parent && n_out && (cap == 0 || (children && origins3 && outcomes)), IVX_ERR_INVALID, "ivx_split_off_all: null argument");
+    *n_out = 0;
+    IVX_REQUIRE(parent->regions_valid, IVX_ERR_STATE, "ivx_split_off_all: call ivx_label_regions first");
+    IVX_REQUIRE(parent->x_off == 0 && parent->gx == parent->cc[0] && !parent->has_ghost[0] && !parent->has_ghost[1], IVX_ERR_STATE,
+                "ivx_split_off_all: not available on a slab of a decomposed grid");
+    if (parent->region_count < 2) return IVX_OK;
+    const size_t n = parent->region_count - 1u;
+    *n_out = n;
+    IVX_REQUIRE(n <= cap, IVX_ERR_CAPACITY, "ivx_split_off_all: %zu split-offs exceed capacity %zu", n, cap);
+    int rc;
+    hipStream_t s = parent->ctx->stream;
+    float ones[256];
+    for (float& x : ones) x = 1.0f;
+    if (!parent->has_dens) {
+        if ((rc = h2d(parent, parent->dens_dev, ones, sizeof(ones)))) return rc;
+        memcpy(parent->dens_host, ones, sizeof(ones));
+        parent->has_dens = 1;
+    }
+    std::vector<ivx_region_desc> d;
+    if ((rc = describe_regions_internal(parent, parent->dens_dev, d))) return rc;
+    // the loop over the descriptors: `front` is the first region still there, `second` the next one
+    std::vector<uint32_t> order;
+    order.reserve(n);
+    {
+        uint32_t front = 0;
+        for (uint32_t second = 1; second < (uint32_t)d.size(); ++second) {
+            const ivx_region_desc &a = d[front], &b = d[second];
+            bool take_first;
+            if (a.non_uniform_chunk_count != b.non_uniform_chunk_count) take_first = a.non_uniform_chunk_count < b.non_uniform_chunk_count;
+            else take_first = a.chunk_count < b.chunk_count;
+            if (take_first) {
+                order.push_back(front);
+                front = second;
+            } else {
+                order.push_back(second);
+            }
+        }
+    }
+    // the children's boxes and grids (crumbs get none: their voxels are just emptied)
+    std::vector<uint32_t> ccs, los;
+    std::vector<size_t> slot(n, (size_t)-1);
+    std::vector<char> repack(n, 0);
+    for (size_t k = 0; k < n; ++k) {
+        const ivx_region_desc& r = d[order[k]];
+        if (moved) moved[k] = r;
+        children[k] = nullptr;
+        const uint32_t uniform_count = r.chunk_count - r.non_uniform_chunk_count;
+        uint32_t lo[3], cc[3];
+        for (int q = 0; q < 3; ++q) {
+            lo[q] = r.lo[q] >> 4;
+            cc[q] = ((r.hi[q] - 1u) >> 4) - lo[q] + 1u;
+            origins3[3 * k + q] = lo[q] * 16u;
+        }
+        const bool discard = uniform_count == 0 && r.voxel_count < 8;  // NON_EMPTY_VOXEL_THRESHOLD (object.rs:203)
+        outcomes[k] = discard ? 2 : 1;
+        if (!discard) {
+            slot[k] = ccs.size() / 3;
+            repack[k] = cc[0] <= 2 && cc[1] <= 2 && cc[2] <= 2 && uniform_count == 0 && cc[0] * cc[1] * cc[2] > 1 && r.hi[0] - r.lo[0] <= 14 && r.hi[1] - r.lo[1] <= 14 &&
+                        r.hi[2] - r.lo[2] <= 14;
+        }
+        for (int q = 0; q < 3; ++q) {
+            if (!discard) ccs.push_back(cc[q]);
+            los.push_back(lo[q]);
+        }
+    }
+    const size_t n_kids = ccs.size() / 3;
+    std::vector<ivx_grid*> kids(n_kids, nullptr);
+    if ((rc = grid_create_pooled(parent->ctx, ccs.data(), n_kids, parent->extent, kids.data()))) return rc;
+    auto fail = [&](int code) {
+        (void)ivx_stream_sync(s);
+        for (ivx_grid*& c : kids)
+            if (c) {
+                c->pending_stages = 0, c->gather_launched = 0;
+                ivx_grid_destroy(c);
+                c = nullptr;
+            }
+        for (size_t k = 0; k < n; ++k) children[k] = nullptr;
+        parent->regions_valid = 0;  // (voxels may have left: the caller derives the object again)
+        return code;
+    };
+    // every region that goes, by its own launch (they read the labelling the parent has now; none of them changes it)
+    for (size_t k = 0; k < n; ++k) {
+        ivx_grid* c = slot[k] == (size_t)-1 ? nullptr : kids[slot[k]];
+        uint32_t cc[3];
+        if (c) memcpy(cc, c->cc, sizeof(cc));
+        else {
+            const ivx_region_desc& r = d[order[k]];
+            for (int q = 0; q < 3; ++q) cc[q] = ((r.hi[q] - 1u) >> 4) - los[3 * k + q] + 1u;
+        }
+        if ((rc = ivx_launch_split_move(parent, c, &los[3 * k], cc, order[k]))) return fail(rc);
+    }
+    // small children into one chunk (complete_extracted_voxel_object, extraction.rs:1902-2142)
+    for (size_t k = 0; k < n; ++k) {
+        if (!repack[k]) continue;
+        ivx_grid*& c = kids[slot[k]];
+        const ivx_region_desc& r = d[order[k]];
+        uint32_t off[3];
+        for (int q = 0; q < 3; ++q) {
+            const uint32_t rel = r.lo[q] - los[3 * k + q] * 16u;
+            off[q] = rel > 0 ? rel - 1u : 0u;
+        }
+        const uint32_t one[3] = {1, 1, 1};
+        ivx_grid* single = nullptr;
+        if ((rc = ivx_grid_create(parent->ctx, one, parent->extent, 0, 0, &single))) return fail(rc);
+        if ((rc = ivx_launch_split_repack(c, single, off))) {
+            ivx_grid_destroy(single);
+            return fail(rc);
+        }
+        ivx_grid_destroy(c);  // (waits for the stream: the repack has read its source)
+        c = single;
+        for (int q = 0; q < 3; ++q) origins3[3 * k + q] += off[q];
+    }
+    // derived state and regions: the parent and every child, recorded and issued together; one wait
+    parent->occ_ref_valid = 0;
+    std::vector<ivx_grid*> all(kids);
+    all.push_back(parent);
+    auto enqueue_one = [&](size_t i) -> int {
+        ivx_grid* g = all[i];
+        if (g != parent && !g->arena_block) return IVX_OK;  // (a repacked child: own allocation, zeroed at creation)
+        if (g != parent && !ivx_many_zero(g->ctx, g, g->work_counts, 8 * sizeof(uint32_t))) IVX_HIP_CHECK(ivx_memset_async(g->work_counts, 0, 8 * sizeof(uint32_t), s));
+        return IVX_OK;
+    };
+    auto derive_one = [&](size_t i) -> int {
+        int r = enqueue_one(i);
+        if (r) return r;
+        if ((r = rederive_enqueue(all[i]))) return r;
+        return ivx_step_collect_launch(all[i]);
+    };
+    if (ivx_many_recording()) {
+        (void)ivx_many_break();
+        for (size_t i = 0; i < all.size(); ++i)
+            if ((rc = derive_one(i))) return fail(rc);
+    } else {
+        if ((rc = ivx_many_begin(parent->ctx))) return fail(rc);
+        int first = IVX_OK;
+        for (size_t i = 0; i < all.size() && !first; ++i) {
+            ivx_many_object((uint32_t)i);
+            first = derive_one(i);
+        }
+        rc = ivx_many_flush(parent->ctx);
+        if (first || rc) return fail(first ? first : rc);
+    }
+    for (ivx_grid* g : all)
+        if ((rc = rederive_collect(g))) return fail(rc);
+    for (size_t k = 0; k < n; ++k)
+        if (slot[k] != (size_t)-1) children[k] = kids[slot[k]];
+    return IVX_OK;
+}
+
 // complete_extracted_voxel_object (extraction.rs:1901-2123) for a freshly filled child grid: discard rule, single-chunk
 // repack, derived state. On return *pc is the final child (or nullptr when discarded).
 static int complete_extracted(ivx_grid* parent, ivx_grid** pc, uint32_t origin[3]) {
@@ -1466,8 +1625,6 @@ int ivx_clip_polyhedron(ivx_grid* parent, const float* planes4, size_t n_planes,
 // host reads for its voxel count / box / regions. Here the parent's ranges are reduced once, all clip kernels and all children's derive /
 // range / voxel-count passes are enqueued back to back and read with ONE wait, the discard / repack decisions are taken on the host, then
 // all region passes follow with a second wait. Per fragment the results are those of ivx_clip_polyhedron(copy = 1).
-static int step_enqueue(ivx_grid* g, uint32_t stages, const uint16_t* slab_nbr_ids, void* slab_record);
-static int ivx_step_collect_launch(ivx_grid* g);
 int ivx_copy_polyhedra(ivx_grid* parent, const float* planes4, const uint32_t* plane_counts, const float* aabbs6, size_t n_sets, ivx_grid** children,
                        uint32_t* origins3, int* outcomes) {
     IVX_REQUIRE(parent && planes4 && plane_counts && aabbs6 && children && origins3 && outcomes, IVX_ERR_INVALID, "ivx_copy_polyhedra: null argument");
@@ -2706,9 +2863,12 @@ int ivx_grid_set_sdf_program(ivx_grid* g, const ivx_sdf_processed_node* nodes, s
 
 int ivx_grid_set_densities(ivx_grid* g, const float densities[256]) {
     IVX_REQUIRE(g && densities, IVX_ERR_INVALID, "ivx_grid_set_densities: null argument");
-    int rc = h2d(g, g->dens_dev, densities, 256 * sizeof(float));
-    if (rc) return rc;
+    // (stream-ordered, no wait: the copy reads the grid's own host copy of the table, which lives as long as the grid — a table set again
+    // before the copy has run may reach the device twice, in the right order. Setting the tables of the fragments of an impact used to cost a
+    // pinned allocation and two waits each.)
     memcpy(g->dens_host, densities, sizeof(g->dens_host));
+    if (!ivx_many_upload(g->ctx, g, g->dens_dev, g->dens_host, sizeof(g->dens_host)))
+        IVX_HIP_CHECK(ivx_memcpy_async(g->dens_dev, g->dens_host, sizeof(g->dens_host), hipMemcpyHostToDevice, g->ctx->stream));
     g->has_dens = 1;
     return IVX_OK;
 }

@@ -42,11 +42,16 @@ __global__ __launch_bounds__(256) void k_split_move(SplitParams sp, const uint8_
     uint4 l4 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
     if (pinfo.kind != KIND_VOID) l4 = *reinterpret_cast<const uint4*>(p_labels + pb);
     const uint32_t lw[4] = {l4.x, l4.y, l4.z, l4.w};
+    // (several regions may leave one after the other on ONE labelling, ivx_split_off_all: a voxel an earlier move has taken still carries its
+    // label but is maximally outside now — it counts for nobody)
+    uint4 s4 = void_sd;
+    if (pinfo.kind != KIND_VOID) s4 = *reinterpret_cast<const uint4*>(p_sdf + pb);
+    const uint32_t sdw[4] = {s4.x, s4.y, s4.z, s4.w};
     uint32_t in_region = 0, other = 0;  // bit k
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const uint32_t lab = (lw[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-        if (lab != 255u) {
+        if (lab != 255u && ((sdw[k >> 2] >> (8 * (k & 3))) & 0xFFu) != 0x7Fu) {
             if (s_comp[lab] == sp.target) in_region |= 1u << k;
             else other |= 1u << k;
         }
@@ -67,7 +72,6 @@ __global__ __launch_bounds__(256) void k_split_move(SplitParams sp, const uint8_
         }
         return;
     }
-    const uint4 s4 = *reinterpret_cast<const uint4*>(p_sdf + pb);
     const uint4 t4 = *reinterpret_cast<const uint4*>(p_type + pb);
     if (!has_other) {
         // whole chunk changes owner

@@ -375,6 +375,27 @@ class VoxelObject:
             obj = self._wrap_child(child)
         return int(outcome.value), obj, tuple(int(x) for x in origin), moved[0]
 
+    def extract_all_disconnected_regions(self):
+        """the whole loop `while find_two_disconnected_regions { extract_disconnected_region }` (impact_voxel/src/interaction.rs:256) in one
+        call (`ivx_split_off_all`): a list of (outcome, child VoxelObject or None, origin_offset_in_parent, descriptor) in the order the loop
+        extracts them; the object keeps its last region"""
+        n_regions = self.count_regions()
+        cap = max(n_regions - 1, 0)
+        if cap == 0:
+            return []
+        kids = (C.c_void_p * cap)()
+        origins = np.zeros((cap, 3), dtype=np.uint32)
+        outcomes = np.zeros(cap, dtype=np.int32)
+        moved = np.zeros(cap, dtype=capi.REGION_DESC_DTYPE)
+        n = C.c_size_t(0)
+        check(capi.lib().ivx_split_off_all(self.h, cap, kids, ptr(origins), ptr(outcomes), ptr(moved), C.byref(n)))
+        self._region_count = None
+        out = []
+        for k in range(n.value):
+            child = self._wrap_child(C.c_void_p(kids[k])) if outcomes[k] == 1 else None
+            out.append((int(outcomes[k]), child, tuple(int(x) for x in origins[k]), moved[k]))
+        return out
+
     # ---- halos -----------------------------------------------------------------------------------
     # ---- voxel edit ops ----------------------------------------------------------------------------
     def absorb_sphere(self, center, influence_radius: float, sphere_radius: float, densities=None, want_invalidated: bool = True):

@@ -224,6 +224,14 @@ int ivx_regions_describe(ivx_grid*, const float densities[256], ivx_region_desc*
  * the mass moments the reference's PropertyTransferrer would have carried over (object/inertia.rs:341-560), for the
  * densities last set with ivx_grid_set_densities / ivx_regions_describe (1.0 if never set). */
 int ivx_split_off_smallest_region(ivx_grid* parent, ivx_grid** child, uint32_t origin_offset_in_parent[3], int* outcome, ivx_region_desc* moved);
+/* The whole loop in one call — `while find_two_disconnected_regions { extract the smaller of the first two }` (impact_voxel/src/interaction.rs:256,
+ * object/extraction.rs:255-271): the object's regions are described once, the host plays the loop over the descriptors (a region's voxel
+ * count, box and chunk counts do not change when another region leaves, nor does the scan order), every region that goes is moved into a grid
+ * of its own (all from one device block), and the parent and all children are re-derived together. Results in the order the loop extracts
+ * them: children[k] (NULL for a discarded crumb), origins3 (3 per split-off), outcomes (1 object, 2 crumb), moved (optional descriptors);
+ * *n_out = split-offs made = regions - 1 (IVX_ERR_CAPACITY when cap is smaller; nothing is changed then). Same objects, voxel for voxel, as
+ * the loop over ivx_split_off_smallest_region. */
+int ivx_split_off_all(ivx_grid* parent, size_t cap, ivx_grid** children, uint32_t* origins3, int* outcomes, ivx_region_desc* moved, size_t* n_out);
 
 /* VoxelObject::extract_polyhedron / copy_polyhedron (object/extraction.rs:604-1768): the part of the object inside the convex
  * polyhedron given by `n_planes` face planes (planes4 = n x {unit normal x,y,z, displacement}, outward normals) and its AABB

@@ -131,3 +131,79 @@ def test_random_blobs(ctx, seed):
             cg.close()
     assert_objects_equal(o, g, "final parent: ")
     assert children >= 2
+
+
+def split_all_at_once(ctx, o, g, expect):
+    """`ivx_split_off_all` against the oracle's loop: the same objects in the same order, parent included"""
+    want = []
+    while True:
+        rc_o, co, org_o = o.split_off_smallest_region()
+        if rc_o == 0:
+            break
+        want.append((rc_o, co, org_o))
+    got = g.extract_all_disconnected_regions()
+    assert [w[0] for w in want] == [x[0] for x in got]
+    assert sum(1 for w in want if w[0] == 1) == expect
+    assert_objects_equal(o, g, "parent after all split-offs: ")
+    for k, ((rc_o, co, org_o), (rc_g, cg, org_g, moved)) in enumerate(zip(want, got)):
+        if rc_o == 1:
+            assert org_g == org_o, k
+            assert_objects_equal(co, cg, f"child {k}: ")
+            assert int(moved["voxel_count"]) == int(np.count_nonzero((co.export_dense()[2] & 1) == 0))
+            cg.close()
+    assert g.count_regions() <= 1
+    assert g.extract_all_disconnected_regions() == []
+
+
+def test_all_split_offs_in_one_call(ctx):
+    """config 3 (seven split-offs leave 8 objects), two spheres, and the body with satellites (a repacked blob, a discarded crumb)"""
+    o, g = build(ctx, scenes.fracture_scene())
+    split_all_at_once(ctx, o, g, 7)
+    g.close()
+    o, g = build(ctx, scenes.two_spheres_scene())
+    split_all_at_once(ctx, o, g, 1)
+    g.close()
+    gr = SDFGraph()
+    acc = gr.add_node(SDFNode.new_box((20.0, 20.0, 20.0)))
+    for pos, r in (((17.0, 3.0, 2.0), 3.0), ((-17.5, -4.0, 9.0), 2.2), ((2.0, 16.5, -3.0), 0.8)):
+        t = gr.add_node(SDFNode.new_translation(gr.add_node(SDFNode.new_sphere(r)), pos))
+        acc = gr.add_node(SDFNode.new_union(acc, t, 0.0))
+    o, g = build(ctx, gr)
+    split_all_at_once(ctx, o, g, 2)
+    g.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_all_split_offs_of_random_blobs(ctx, seed):
+    """ragged random blobs — many small regions per chunk, chunks shared by several regions that all leave, discards and repacks — in one call"""
+    rng = np.random.default_rng(100 + seed)
+    cc = (2, 2, 3)
+    blobs = rng.random((32, 32, 48))
+    for ax in range(3):
+        blobs = 0.5 * blobs + 0.25 * (np.roll(blobs, 1, ax) + np.roll(blobs, -1, ax))
+    sd = np.where(blobs > 0.53, -128, np.where(blobs > 0.5, -40, 60)).astype(np.int8)
+    sd[:, :, 22:26] = 90
+    ty = rng.integers(0, 3, blobs.shape).astype(np.uint8)
+    sd_t, ty_t = ol.dense_to_tiled(sd), ol.dense_to_tiled(ty)
+    o = ol.OracleObject.from_dense(cc, sd_t, ty_t, 0.5)
+    g = VoxelObject.from_dense(ctx, cc, sd_t, ty_t, 0.5)
+    o.update_occupied_voxel_ranges()
+    o.compute_all_derived_state()
+    g.compute_all_derived_state()
+    n_regions, _ = o.region_labels(False)
+    want = []
+    while True:
+        rc_o, co, org_o = o.split_off_smallest_region()
+        if rc_o == 0:
+            break
+        want.append((rc_o, co, org_o))
+    assert len(want) == n_regions - 1
+    got = g.extract_all_disconnected_regions()
+    assert [w[0] for w in want] == [x[0] for x in got]
+    assert_objects_equal(o, g, f"seed {seed} parent: ")
+    for k, ((rc_o, co, org_o), (rc_g, cg, org_g, _)) in enumerate(zip(want, got)):
+        if rc_o == 1:
+            assert org_g == org_o, k
+            assert_objects_equal(co, cg, f"seed {seed} child {k}: ")
+            cg.close()
+    g.close()
