@@ -326,6 +326,7 @@ def summary_block(out):
             "edit_plus_sync_ms": g("edit", "edit_plus_sync_ms"),
             "fragments": {"cut_ms": g("fragments", "cut_ms"), "first_step_many_ms": g("fragments", "first_step_many_ms"), "frame_many_ms": g("fragments", "frame_many_ms"),
                           "frame_looped_ms": g("fragments", "frame_looped_ms")},
+            "fragments_frame": {"ms_batched": g("fragments_frame", "ms_batched"), "ms_looped": g("fragments_frame", "ms_looped")},
             "config3_split_loop_ms": g("config3", "split_loop_ms"), "config5_single_grid_ms": g("config5_one_gpu", "single_grid_ms"),
             "config5_eight_slabs_one_gpu_ms": g("config5_one_gpu", "eight_slabs_one_gpu_ms"),
             "cpu_baseline_voxels_per_s": g("cpu_baseline", "value"), "parity_all_equal": (all(parities) if parities else None), "parity_blocks": len(parities)}
@@ -907,6 +908,175 @@ def fragments_benchmark(ctx, with_cpu, n_axis=5, frames=6, warm=2):
     return out
 
 
+def fragments_frame_benchmark(ctx, with_cpu, n_axis=5, frames=6, warm=2):
+    """A FRAME of many objects with the rigid-body side in it (engine/src/tasks.rs:376-434 in the reference's order): the fragments of the
+    `fragments` leg, each a rigid body lying on a ground plane — per frame: contact generation of every fragment against the plane (f1,
+    collidable.rs:1176-1208) -> this frame's contacts into the solver (ivx_world_set_contacts) -> solve + integrate -> one absorbing-sphere edit
+    per fragment -> incremental remesh -> moments. Once object by object (the single-object calls, a wait or two each) and once through the
+    many-object calls (`ivx_voxel_object_contacts_many`, `ivx_absorb_sphere_many`, `ivx_mesh_sync_many`, `ivx_voxel_step_many`); the oracle
+    does the same frame on one host thread. The bodies' poses are not fed back into the voxel objects' transforms (every frame finds the same
+    geometry: the figure is the cost of the frame's calls, not a simulation)."""
+    from impact_amd import capi, many, scenes
+    from impact_amd import fracturing as fr
+    from impact_amd.physics import PhysicsWorld, uniform_sphere_body
+    from impact_amd.voxel import VoxelObjectMesh
+
+    graph = scenes.asteroid_scene(1.0)
+    dens = np.ones(256, dtype=np.float32)
+    _, body = make_object(ctx, graph)
+    body.step(capi.STAGE_ALL)
+    cc = np.asarray(body.chunk_counts, dtype=np.float32) * 16.0
+    rng = np.random.default_rng(11)
+    ax = [(np.arange(n_axis) + 0.5) * (c / n_axis) for c in cc]
+    pts = (np.stack(np.meshgrid(*ax, indexing="ij"), axis=-1).reshape(-1, 3) + rng.uniform(-4.0, 4.0, (n_axis ** 3, 3))).astype(np.float32)
+    sets, tets = fr.fragment_plane_sets(pts, np.array([0, 0, 0, cc[0], cc[1], cc[2]], dtype=np.float32))
+
+    def cut():
+        res = body.copy_polyhedra([s_[2] for s_ in sets], [s_[1] for s_ in sets])
+        objs = [child for rc, child, _ in res if rc == 1]
+        for o_ in objs:
+            o_.set_densities(dens)
+        return objs, [k for k, (rc, _, _) in enumerate(res) if rc == 1]
+
+    a_objs, kept = cut()
+    b_objs, _ = cut()
+    n = len(a_objs)
+    stages0 = capi.STAGE_ALL & ~capi.STAGE_SAMPLE
+    rb = many.voxel_step_many(b_objs, stages0)
+    ra = many.voxel_step_many(a_objs, stages0)
+    a_mesh, b_mesh = [], []
+    for objs, rs_, meshes in ((a_objs, ra, a_mesh), (b_objs, rb, b_mesh)):
+        for o_, r_ in zip(objs, rs_):
+            m_ = VoxelObjectMesh(o_)
+            m_.counts = r_["mesh"].copy()
+            meshes.append(m_)
+    zero = [np.zeros(o_.n_chunks, dtype=np.uint8) for o_ in a_objs]
+    many.mesh_sync_many(a_mesh, zero)
+    many.mesh_sync_many(b_mesh, zero)
+    occ = [np.asarray(r_["occupied"], dtype=np.float32).reshape(-1)[6:].reshape(3, 2) for r_ in rb]
+    # every fragment a dynamic body (a sphere's inertia of its size: the solver does not care), the ground a kinematic one
+    bodies = np.array([uniform_sphere_body(8.0, 1.0, (20.0 * (k % 9), 0.0, 20.0 * (k // 9))) for k in range(n)])
+    bodies["total_force"][:, 1] = np.float32(-9.81) * bodies["mass"]
+    ground = np.zeros(1, dtype=capi.KINEMATIC_BODY_DTYPE)
+    ground["orientation"] = (0, 0, 0, 1)
+    ground["angular_axis"] = (0, 1, 0)
+    ident = np.array([0.0, 0.0, 0.0, 1.0], dtype=np.float32)
+    zero3 = np.zeros(3, dtype=np.float32)
+    up = np.array([0.0, 1.0, 0.0], dtype=np.float32)
+    resp = (0.2, 0.7, 0.5)
+    disp = [float(oc[1, 0] + 3.0) for oc in occ]  # a ground plane three voxels into each fragment's underside (its own frame)
+    q = many.collidable_queries(n)
+    for k in range(n):
+        q[k]["mode"], q[k]["shape3"], q[k]["shape1"], q[k]["response"] = 1, up, disp[k], resp
+        q[k]["collidable_id_a"], q[k]["collidable_id_b"], q[k]["body_a"], q[k]["body_b"] = 1000 + k, 7, k, 0x80000000
+    wa, wb = PhysicsWorld(ctx), PhysicsWorld(ctx)
+    for w in (wa, wb):
+        w.set_bodies(bodies, ground)
+
+    def frame_edits(f):
+        cs, rs = [], []
+        for oc in occ:
+            c = 0.5 * (oc[:, 0] + oc[:, 1])
+            c[1] = oc[1, 1] - 1.0 - 2.0 * f
+            cs.append(c.astype(np.float32))
+            rs.append(4.0 + (f % 3))
+        return cs, rs
+
+    t_loop, t_many = [], []
+    n_contacts = 0
+    same_contacts = True
+    for f in range(frames + warm):
+        cs, rs = frame_edits(f)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        lists = [o_.plane_contacts(ident, zero3, up, disp[k], 1000 + k, 7, k, 0x80000000, resp, capacity=4096) for k, o_ in enumerate(a_objs)]
+        ca = np.concatenate(lists) if lists else np.zeros(0, dtype=capi.CONTACT_DTYPE)
+        wa.prepare_constraints(ca)
+        wa.step_enqueue(0.005)
+        for o_, m_, c, r in zip(a_objs, a_mesh, cs, rs):
+            e_ = o_.absorb_sphere(c, r + 2.0, r, dens)
+            m_.sync_with_voxel_object(e_["invalidated"])
+            o_.step(capi.STAGE_INERTIA)
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        cb, off = many.voxel_object_contacts_many(b_objs, q)
+        wb.prepare_constraints(cb)
+        wb.step_enqueue(0.005)
+        eb = many.absorb_sphere_many(b_objs, cs, [r + 2.0 for r in rs], rs, dens)
+        many.mesh_sync_many(b_mesh, [e_["invalidated"] for e_ in eb])
+        many.voxel_step_many(b_objs, capi.STAGE_INERTIA)
+        ctx.synchronize()
+        t2 = time.perf_counter()
+        same_contacts = same_contacts and ca.tobytes() == cb.tobytes()
+        n_contacts = len(cb)
+        if f >= warm:
+            t_loop.append(t1 - t0)
+            t_many.append(t2 - t1)
+    same = same_contacts
+    for x, y in zip(a_objs, b_objs):
+        for u, v in zip(x.download(), y.download()):
+            same = same and bool(np.array_equal(u, v))
+    da, db = wa.bodies()[0], wb.bodies()[0]
+    same_bodies = all(np.array_equal(da[f_].view(np.uint32), db[f_].view(np.uint32)) for f_ in ("position", "orientation", "momentum", "angular_momentum"))
+    loop_ms, many_ms = 1e3 * float(np.mean(t_loop)), 1e3 * float(np.mean(t_many))
+    out = {"workload": f"{n} fragments (the `fragments` leg's) as rigid bodies on a ground plane; per frame: plane contacts of every fragment (f1) -> "
+                       "ivx_world_set_contacts -> solve + integrate -> an absorbing sphere per fragment -> incremental remesh -> moments",
+           "objects": n, "contacts_per_frame": n_contacts, "frames": frames, "ms_looped": round(loop_ms, 4), "ms_batched": round(many_ms, 4),
+           "speedup": round(loop_ms / many_ms, 2),
+           "parity": {"looped_equals_batched": bool(same), "bodies_equal": bool(same_bodies)}}
+    if with_cpu:
+        import oracle_lib as ol
+        from test_gpu_contacts import oracle_plane_contact_list
+
+        o_body = ol.OracleObject.from_sdf(graph, 1.0, 0)
+        o_body.update_occupied_voxel_ranges()
+        o_body.compute_all_derived_state()
+        o_objs = []
+        for k in kept:
+            rc, co, _ = o_body.clip_polyhedron(sets[k][1], sets[k][2], copy=True)
+            co.update_occupied_voxel_ranges()
+            o_objs.append(co)
+        o_mesh = [ol.OracleMeshHandle(o_) for o_ in o_objs]
+        op = ol.OraclePhysics(bodies, ground, config=(8, 0.4, 3, 0.2))
+        t_cpu, equal = [], True
+        for f in range(frames + warm):
+            cs, rs = frame_edits(f)
+            t0 = time.perf_counter()
+            lists = [oracle_plane_contact_list(o_, ident, zero3, up, disp[k], 1000 + k, 7, k, 0x80000000, resp) for k, o_ in enumerate(o_objs)]
+            co_ = np.concatenate(lists)
+            op.step(co_, 0.005)
+            for o_, m_, c, r in zip(o_objs, o_mesh, cs, rs):
+                e_ = o_.absorb_sphere(c, r + 2.0, r, dens)
+                m_.sync(e_["invalidated"])
+                o_.inertia(dens)
+            t_cpu.append(time.perf_counter() - t0)
+            if f == frames + warm - 1:
+                equal = co_.tobytes() == cb.tobytes()
+        od = op.bodies()[0]
+        rel = 0.0
+        for f_ in ("position", "orientation", "momentum", "angular_momentum"):
+            g64, o64 = db[f_].astype(np.float64), od[f_].astype(np.float64)
+            scale = np.maximum(np.linalg.norm(o64, axis=1, keepdims=True), max(float(np.abs(o64).max()), 1e-30) * 1e-4)
+            rel = max(rel, float((np.abs(g64 - o64) / scale).max()))
+        for o_, g_ in zip(o_objs, b_objs):
+            o_sdf, o_typ, o_flg, o_lab, _ = o_.export_dense()
+            g_sdf, g_typ, g_flg, g_lab, _ = g_.download()
+            equal = equal and bool(np.array_equal(o_sdf, g_sdf)) and bool(np.array_equal(o_lab, g_lab))
+        out["parity"]["last_frame_contacts_and_voxels_equal_the_oracle"] = bool(equal)
+        out["parity"]["body_state_max_rel_err"] = rel
+        out["parity"]["equal"] = bool(same and same_bodies and equal and rel <= 1e-5)
+        cpu_ms = 1e3 * float(np.mean(t_cpu[warm:]))
+        out["cpu_baseline"] = {"frame_ms": round(cpu_ms, 2), "cores": 1, "kind": "port",
+                               "sample": f"the same {frames} frames (contacts built into records by a Python loop over the oracle's hits: part of the time), single thread"}
+    for w in (wa, wb):
+        w.close()
+    for o_ in a_objs + b_objs:
+        o_.close()
+    tets.close()
+    body.close()
+    return out
+
+
 def pile_benchmark(ctx, with_cpu, steps=10):
     """BASELINE config 4 on one GPU: 16^3 spheres, 46 080 contacts resident in HBM, 8 velocity + 3 positional
     sweeps per step in the reference's exact order (dependency-level schedule)."""
@@ -1253,6 +1423,8 @@ def main():
             out["config5_one_gpu"] = config5_benchmark(ctx, args)
             gc.collect()
             out["fragments"] = fragments_benchmark(ctx, with_cpu)
+            gc.collect()
+            out["fragments_frame"] = fragments_frame_benchmark(ctx, with_cpu)
             gc.collect()
             pile, w = pile_benchmark(ctx, with_cpu)
             out["pile"] = pile

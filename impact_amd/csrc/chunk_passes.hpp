@@ -2,6 +2,14 @@
 // chunk-local connected regions and the chunk's moments need nothing but the chunk's own non-empty row masks (and types),
 // which k_derive holds in registers anyway.
 #pragma once
+// developer build (make EXTRA=-DIVX_DERIVE_DEBUG, tools/derive_budget.sh): store groups of the derive sweep switched off one by one at run time
+// (IVX_DERIVE_SKIP, a bit per group) — what each of them costs in counter traffic. Production builds compile the test away.
+#ifdef IVX_DERIVE_DEBUG
+static __device__ uint32_t ivx_dbg_derive_skip = 0u;
+#define IVX_DBG_KEEP(bit) (!(ivx_dbg_derive_skip & (bit)))
+#else
+#define IVX_DBG_KEEP(bit) true
+#endif
 #include "ivx_internal.hpp"
 
 #define NODE_NONE 0xFFFFFFFFu
@@ -568,7 +576,7 @@ __device__ __forceinline__ void ccl_local_chunk(CclShared& sh, uint32_t tid, uin
     if (!any || all_full) {
         // no voxels, or one solid region touching every face
         const uint32_t lab = any ? 0u : 0xFFFFFFFFu;
-        if (kind == KIND_NONUNIFORM) *reinterpret_cast<uint4*>(labels + base) = make_uint4(lab, lab, lab, lab);  // else: compact planes
+        if (kind == KIND_NONUNIFORM && IVX_DBG_KEEP(8u)) *reinterpret_cast<uint4*>(labels + base) = make_uint4(lab, lab, lab, lab);  // else: compact planes
         // only slots below region_count are ever read (flatten / assign / find walk valid nodes only)
         if (tid == 0) rp[0] = any ? chunk * 256u : NODE_NONE;
         rc_out = any ? 1u : 0u;
@@ -624,7 +632,7 @@ __device__ __forceinline__ void ccl_local_chunk(CclShared& sh, uint32_t tid, uin
 #pragma unroll
         for (int k = 0; k < 16; ++k)
             if (!((m >> k) & 1u)) w[k >> 2] |= 0xFFu << (8 * (k & 3));
-        *reinterpret_cast<uint4*>(labels + base) = make_uint4(w[0], w[1], w[2], w[3]);
+        if (IVX_DBG_KEEP(8u)) *reinterpret_cast<uint4*>(labels + base) = make_uint4(w[0], w[1], w[2], w[3]);
         if (tid == 0) rp[0] = chunk * 256u;
         rc_out = 1u;
         brc_out = touches ? 1u : 0u;

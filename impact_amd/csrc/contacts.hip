@@ -162,21 +162,50 @@ __device__ __forceinline__ uint32_t box_chunk(const SvcParams& p, uint32_t b, ui
     return (ci * p.g.cy + cj) * p.g.cz + ck;
 }
 
-__global__ __launch_bounds__(256) void k_svc_count(SvcParams p, const uint8_t* __restrict__ flags, uint32_t* __restrict__ counts) {
+// (the three passes as bodies over an argument block: the single-object kernels and their many-object twins, many.hpp, run the same code)
+struct SvcCountArgs {
+    SvcParams p;
+    const uint8_t* flags;
+    uint32_t* counts;
+};
+struct SvcScanArgs {
+    const uint32_t* counts;
+    uint32_t* offsets;
+    uint32_t* total;
+    uint32_t n, pad;
+};
+struct SvcEmitArgs {
+    SvcParams p;
+    const uint8_t* flags;
+    const uint32_t* offsets;
+    ivx_contact* out;
+    uint32_t cap, pad;
+};
+__device__ __forceinline__ void svc_count_body(const SvcCountArgs& a, uint32_t bid, uint32_t) {
+    const SvcParams& p = a.p;
+    const uint8_t* __restrict__ flags = a.flags;
+    uint32_t* __restrict__ counts = a.counts;
     __shared__ uint32_t s_w[4];
     uint32_t ci, cj, ck;
-    const uint32_t chunk = box_chunk(p, blockIdx.x, ci, cj, ck);
+    const uint32_t chunk = box_chunk(p, bid, ci, cj, ck);
     uint32_t n = 0;
     if (p.g.info[chunk].kind == KIND_NONUNIFORM)  // only non-uniform chunks can have surface voxels
         n = __popc(row_contacts<false>(p, p.g.sdf, flags, chunk, ci, cj, ck, threadIdx.x, nullptr));
     n = ivx_wave_sum(n);
     if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = n;
     __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    if (threadIdx.x == 0) counts[bid] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
+__global__ __launch_bounds__(256) void k_svc_count(SvcCountArgs a) { svc_count_body(a, blockIdx.x, gridDim.x); }
+IVX_MANY_TWIN(k_svc_count_many, SvcCountArgs, svc_count_body, __launch_bounds__(256))
+IVX_MANY_LAUNCHER(many_svc_count, k_svc_count_many, SvcCountArgs, 256)
 
 // exclusive scan over the chunks of the box (one workgroup; the box of a collidable is a few dozen chunks)
-__global__ __launch_bounds__(256) void k_svc_scan(uint32_t n, const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets, uint32_t* __restrict__ total) {
+__device__ __forceinline__ void svc_scan_body(const SvcScanArgs& a, uint32_t, uint32_t) {
+    const uint32_t n = a.n;
+    const uint32_t* __restrict__ counts = a.counts;
+    uint32_t* __restrict__ offsets = a.offsets;
+    uint32_t* __restrict__ total = a.total;
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_carry;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -202,12 +231,19 @@ __global__ __launch_bounds__(256) void k_svc_scan(uint32_t n, const uint32_t* __
     }
     if (tid == 0) *total = s_carry;
 }
+__global__ __launch_bounds__(256) void k_svc_scan(SvcScanArgs a) { svc_scan_body(a, 0u, 1u); }
+IVX_MANY_TWIN(k_svc_scan_many, SvcScanArgs, svc_scan_body, __launch_bounds__(256))
+IVX_MANY_LAUNCHER(many_svc_scan, k_svc_scan_many, SvcScanArgs, 256)
 
-__global__ __launch_bounds__(256) void k_svc_emit(SvcParams p, const uint8_t* __restrict__ flags, const uint32_t* __restrict__ offsets, uint32_t cap,
-                                                  ivx_contact* __restrict__ out) {
+__device__ __forceinline__ void svc_emit_body(const SvcEmitArgs& a, uint32_t bid, uint32_t) {
+    const SvcParams& p = a.p;
+    const uint8_t* __restrict__ flags = a.flags;
+    const uint32_t* __restrict__ offsets = a.offsets;
+    const uint32_t cap = a.cap;
+    ivx_contact* __restrict__ out = a.out;
     __shared__ uint32_t s_w[4];
     uint32_t ci, cj, ck;
-    const uint32_t chunk = box_chunk(p, blockIdx.x, ci, cj, ck);
+    const uint32_t chunk = box_chunk(p, bid, ci, cj, ck);
     if (p.g.info[chunk].kind != KIND_NONUNIFORM) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     Hit hits[16];
@@ -223,7 +259,7 @@ __global__ __launch_bounds__(256) void k_svc_emit(SvcParams p, const uint8_t* __
     __syncthreads();
     const uint32_t w0 = s_w[0], w1 = s_w[1], w2 = s_w[2];
     const uint32_t wbase = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
-    uint32_t slot = offsets[blockIdx.x] + wbase + incl - v;
+    uint32_t slot = offsets[bid] + wbase + incl - v;
     const unsigned long long gi = ci * 16u + (tid >> 4), gj = cj * 16u + (tid & 15u);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -250,8 +286,16 @@ __global__ __launch_bounds__(256) void k_svc_emit(SvcParams p, const uint8_t* __
         slot += 1;
     }
 }
+__global__ __launch_bounds__(256) void k_svc_emit(SvcEmitArgs a) { svc_emit_body(a, blockIdx.x, gridDim.x); }
+IVX_MANY_TWIN(k_svc_emit_many, SvcEmitArgs, svc_emit_body, __launch_bounds__(256))
+IVX_MANY_LAUNCHER(many_svc_emit, k_svc_emit_many, SvcEmitArgs, 256)
+static_assert(sizeof(SvcCountArgs) % 8 == 0 && sizeof(SvcScanArgs) % 8 == 0 && sizeof(SvcEmitArgs) % 8 == 0, "argument blocks travel as 8-byte words");
 
 }  // namespace
+
+static const int s_svc_many_registered = (ivx_many_register(IVX_MK_SVC_COUNT, many_svc_count, sizeof(SvcCountArgs)),
+                                          ivx_many_register(IVX_MK_SVC_SCAN, many_svc_scan, sizeof(SvcScanArgs)),
+                                          ivx_many_register(IVX_MK_SVC_EMIT, many_svc_emit, sizeof(SvcEmitArgs)), 0);
 
 int ivx_launch_sphere_contacts(ivx_grid* g, const uint32_t lo[3], const uint32_t cc[3], const int32_t vlo[3], const int32_t vhi[3],
                                const float rotation_xyzw[4], const float translation[3], const float center[3], const float seg_vec[3], float radius,
@@ -290,10 +334,19 @@ int ivx_launch_sphere_contacts(ivx_grid* g, const uint32_t lo[3], const uint32_t
     p.dynamic_friction = response[2];
     const uint32_t n_box = cc[0] * cc[1] * cc[2];
     if (!emit) {
-        IVX_KLAUNCH(k_svc_count, dim3(n_box), dim3(256), 0, g->ctx->stream, p, g->flags, d_counts);
-        IVX_KLAUNCH(k_svc_scan, dim3(1), dim3(256), 0, g->ctx->stream, n_box, d_counts, d_offsets, d_total);
+        SvcCountArgs ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.p = p, ca.flags = g->flags, ca.counts = d_counts;
+        if (!ivx_many_try(g->ctx, g, IVX_MK_SVC_COUNT, n_box, ca)) IVX_KLAUNCH(k_svc_count, dim3(n_box), dim3(256), 0, g->ctx->stream, ca);
+        SvcScanArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.counts = d_counts, sa.offsets = d_offsets, sa.total = d_total, sa.n = n_box;
+        if (!ivx_many_try(g->ctx, g, IVX_MK_SVC_SCAN, 1u, sa)) IVX_KLAUNCH(k_svc_scan, dim3(1), dim3(256), 0, g->ctx->stream, sa);
     } else {
-        IVX_KLAUNCH(k_svc_emit, dim3(n_box), dim3(256), 0, g->ctx->stream, p, g->flags, d_offsets, cap, d_out);
+        SvcEmitArgs ea;
+        memset(&ea, 0, sizeof(ea));
+        ea.p = p, ea.flags = g->flags, ea.offsets = d_offsets, ea.out = d_out, ea.cap = cap;
+        if (!ivx_many_try(g->ctx, g, IVX_MK_SVC_EMIT, n_box, ea)) IVX_KLAUNCH(k_svc_emit, dim3(n_box), dim3(256), 0, g->ctx->stream, ea);
     }
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;

@@ -22,6 +22,15 @@
 #include "table_roles.hpp"
 #include "many.hpp"
 
+// Waves per SIMD the derive sweep is compiled for, i.e. its register budget: 7 -> 72 VGPRs (13 spilled per lane), 6 -> 80 (4 spilled), 5 -> 96
+// (none). Seven was round 3's choice for the residency (LDS allows seven workgroups per CU) — but every spilled dword is a store to memory
+// (stores leave the L2 on this part), per lane and chunk: with all of the sweep's own store groups switched off the headline launch still wrote
+// 52 of its 91 MB (tools/derive_budget.sh). Measured (tools/derive_waves.sh, profiles/round5): headline 39.5 us / 103.7 MB written at seven,
+// 37.6 us / 45.6 MB at six, 38.3 us / 32.8 MB at five; all-surface 188 us / 378 MB, 181 us / 302 MB, 187 us / 270 MB. Six it is.
+#ifndef IVX_DERIVE_WAVES
+#define IVX_DERIVE_WAVES 6
+#endif
+
 namespace {
 
 struct DeriveParams {
@@ -345,7 +354,7 @@ __device__ __forceinline__ void derive_body(const DeriveArgs& a_, uint32_t bid_,
     own_info.boundary_region_count = (uint8_t)(own_rec.y >> 24);
     const uint32_t own_row_mask = SIGNS ? ((own_sd.x >> (16u * (tid & 1u))) & 0xFFFFu) : row_mask(own_sd);
     const bool own_uniform = own_info.gen_kind == KIND_UNIFORM;
-    if (!SIGNS) {
+    if (!SIGNS && IVX_DBG_KEEP(128u)) {
         // the row's bytes on the two k faces, rows side by side, for the mesher's halo (GridView::kface)
         uint8_t* kf = kface_out + (size_t)chunk * 1024 + tid;
         kf[0] = (uint8_t)(own_sd.x & 0xFFu);
@@ -357,7 +366,7 @@ __device__ __forceinline__ void derive_body(const DeriveArgs& a_, uint32_t bid_,
     // (a Void chunk reaches the sweep in box mode only: no voxels whatever its stale planes hold)
     const uint32_t m = own_uniform ? 0xFFFFu : (own_info.gen_kind == KIND_VOID ? 0u : own_row_mask);
     occ[ti + 1][tj + 1] = m;
-    if (!SIGNS) signs[(size_t)chunk * 256 + tid] = (uint16_t)m;  // for the mesher's count pass (SIGNS: the sampler's, and a demoted chunk's below)
+    if (!SIGNS && IVX_DBG_KEEP(128u)) signs[(size_t)chunk * 256 + tid] = (uint16_t)m;  // for the mesher's count pass (SIGNS: the sampler's, and a demoted chunk's below)
 
     uint32_t zlo = 0, zhi = 0;  // neighbour voxel across the z faces for this (i,j)
     if (has_zlo) zlo = gen_lo == KIND_NONUNIFORM ? ((by_lo >> 7) & 1u) : (gen_lo == KIND_UNIFORM ? 1u : 0u);
@@ -396,7 +405,7 @@ __device__ __forceinline__ void derive_body(const DeriveArgs& a_, uint32_t bid_,
                 packed = 0x80000000u | (uint32_t)(__ffs(bi) - 1) | ((uint32_t)(31 - __clz(bi)) << 4) | ((uint32_t)(__ffs(bj) - 1) << 8) |
                          ((uint32_t)(31 - __clz(bj)) << 12) | ((uint32_t)(__ffs(ku) - 1) << 16) | ((uint32_t)(31 - __clz(ku)) << 20);
             }
-            bbox[chunk] = packed;
+            if (IVX_DBG_KEEP(64u)) bbox[chunk] = packed;
         }
     }
 
@@ -504,14 +513,14 @@ __device__ __forceinline__ void derive_body(const DeriveArgs& a_, uint32_t bid_,
     // the planes of a Uniform chunk that was demoted before hold its voxels already; its record no longer has the type
     const uint32_t utype = own_uniform ? (own_info.kind == KIND_NONUNIFORM ? (type0 & 0xFFu) : (uint32_t)own_info.uniform_type) : 0u;
     if (kind == KIND_NONUNIFORM) {
-        *reinterpret_cast<uint4*>(flags_out + base + (size_t)tid * 16) = make_uint4(w[0], w[1], w[2], w[3]);
-        if (own_uniform && own_info.kind != KIND_NONUNIFORM) {
+        if (IVX_DBG_KEEP(1u)) *reinterpret_cast<uint4*>(flags_out + base + (size_t)tid * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+        if (own_uniform && own_info.kind != KIND_NONUNIFORM && IVX_DBG_KEEP(2u)) {
             // convert_to_non_uniform_if_uniform (object.rs:2530-2550): the demoted chunk gets its 4096 voxels
             const uint32_t t4 = utype * 0x01010101u;
             *reinterpret_cast<uint4*>(sdf_rw + base + (size_t)tid * 16) = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
             *reinterpret_cast<uint4*>(type_rw + base + (size_t)tid * 16) = make_uint4(t4, t4, t4, t4);
         }
-        if (SIGNS && own_uniform) {  // a chunk that is NonUniform by demotion (now or earlier): the sampler left it no sign rows or face bytes
+        if (SIGNS && own_uniform && IVX_DBG_KEEP(4u)) {  // a chunk that is NonUniform by demotion (now or earlier): the sampler left it no sign rows or face bytes
             signs[(size_t)chunk * 256 + tid] = (uint16_t)0xFFFFu;
             uint8_t* kf = kface_out + (size_t)chunk * 1024 + tid;
             kf[0] = (uint8_t)0x80u;
@@ -526,7 +535,7 @@ __device__ __forceinline__ void derive_body(const DeriveArgs& a_, uint32_t bid_,
     uint32_t rc = own_info.region_count, brc = own_info.boundary_region_count;
     if (fz.parts & IVX_PART_REGIONS) ccl_local_chunk(s_ccl, tid, chunk, kind, gen, m, fz.labels, fz.rparent, fz.rscalar, fz.multi_list, rc, brc);
     IVX_T(g, li, 4);  // regions labelled
-    if ((fz.parts & IVX_PART_MOMENTS) && kind == KIND_NONUNIFORM) {
+    if ((fz.parts & IVX_PART_MOMENTS) && kind == KIND_NONUNIFORM && IVX_DBG_KEEP(16u)) {
         // (a chunk demoted in this pass has no type plane yet: its voxels all have the record's type)
         const uint32_t ut = utype * 0x01010101u;
         const bool fresh = own_uniform && own_info.kind != KIND_NONUNIFORM;
@@ -537,7 +546,7 @@ __device__ __forceinline__ void derive_body(const DeriveArgs& a_, uint32_t bid_,
         chunk_moments_rows_tab(tid, m, tw, s_dens, s_mtab, s_red, (ci + (int)fz.x_off) * 16 + ti, cj * 16 + tj, ck * 16, fz.chunk_moments + (size_t)chunk * 10);
     }
 
-    if (tid == 0) {
+    if (tid == 0 && IVX_DBG_KEEP(32u)) {
         touch[chunk] = (uint8_t)cnt[12];
         {  // the list entry carries what the later stages need from the record
             const bool obscured = kind == KIND_NONUNIFORM && nbr_full == 0x3Fu;
@@ -576,11 +585,11 @@ __device__ __forceinline__ void derive_body(const DeriveArgs& a_, uint32_t bid_,
     }
 }
 template <bool SIGNS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_derive(DeriveArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IVX_DERIVE_WAVES, 8))) void k_derive(DeriveArgs a) {
     derive_body<SIGNS>(a, blockIdx.x, gridDim.x);
 }
-IVX_MANY_TWIN(k_derive_planes_many, DeriveArgs, derive_body<false>, __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))))
-IVX_MANY_TWIN(k_derive_signs_many, DeriveArgs, derive_body<true>, __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))))
+IVX_MANY_TWIN(k_derive_planes_many, DeriveArgs, derive_body<false>, __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IVX_DERIVE_WAVES, 8))))
+IVX_MANY_TWIN(k_derive_signs_many, DeriveArgs, derive_body<true>, __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IVX_DERIVE_WAVES, 8))))
 IVX_MANY_LAUNCHER(many_derive_planes, k_derive_planes_many, DeriveArgs, 256)
 IVX_MANY_LAUNCHER(many_derive_signs, k_derive_signs_many, DeriveArgs, 256)
 
@@ -763,7 +772,20 @@ int ivx_launch_step_preset(ivx_grid* g, uint32_t groups) {
 
 // `preset_groups`: scratch word groups k_chunk_pre presets on the way (the fused step path; 0 elsewhere: stand-alone callers
 // memset what they need themselves)
+#ifdef IVX_DERIVE_DEBUG
+static void derive_debug_mask() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    const char* e = getenv("IVX_DERIVE_SKIP");
+    const uint32_t v = e ? (uint32_t)strtoul(e, nullptr, 0) : 0u;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(ivx_dbg_derive_skip), &v, sizeof(v));
+}
+#endif
 int ivx_launch_derive(ivx_grid* g, uint32_t parts, uint32_t preset_groups) {
+#ifdef IVX_DERIVE_DEBUG
+    derive_debug_mask();
+#endif
     GridView v = ivx_view(g);
     DeriveFused fz;
     fz.parts = parts;

@@ -472,6 +472,7 @@ void ivx_shutdown(ivx_ctx* c) {
     if (!c) return;
     (void)ivx_stream_sync(c->stream);
     ivx_many_release(c);  // (the launch recorder of the many-object calls and its staging ring)
+    if (c->pinned_scratch) (void)hipHostFree(c->pinned_scratch);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -2101,19 +2102,12 @@ static bool touched_ranges(const uint32_t occ[12], const float lo_f[3], const fl
 }
 
 // mode 0: sphere (shape3 = centre, shape1 = radius); 1: plane (unit normal, displacement); 2: capsule (segment start, radius; shape3b = segment vector)
-static int voxel_object_contacts(ivx_grid* g, const char* who, int mode, const float rotation_xyzw[4], const float translation[3], const float shape3[3],
-                                 const float shape3b[3], float shape1, uint64_t id_a, uint64_t id_b, uint32_t body_a, uint32_t body_b, const float response[3], ivx_contact* out,
-                                 size_t cap, size_t* n_out) {
-    IVX_REQUIRE(g && rotation_xyzw && translation && shape3 && (shape3b || mode != 2) && response && n_out && (out || cap == 0), IVX_ERR_INVALID,
-                "%s: null argument", who);
+static int many_phase(ivx_grid* const* grids, size_t n, const std::function<int(size_t)>& f);
+// the chunk box and voxel ranges a collidable touches of an object (mode 0 sphere: centre shape3, radius shape1; 1 plane: unit normal shape3,
+// displacement shape1; 2 capsule: segment start shape3, segment vector shape3b, radius shape1); false: nothing touched
+static bool contacts_box(const ivx_grid* g, int mode, const float rotation_xyzw[4], const float translation[3], const float shape3[3], const float shape3b[3],
+                         float shape1, const uint32_t occ[12], int32_t vlo[3], int32_t vhi[3], uint32_t lo[3], uint32_t cc[3]) {
     const int plane = mode == 1;
-    IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "%s: derived state must be current (ivx_derive_state + ivx_label_regions)", who);
-    IVX_REQUIRE(g->x_off == 0 && g->gx == g->cc[0] && !g->has_ghost[0] && !g->has_ghost[1], IVX_ERR_STATE, "%s: not available on a slab of a decomposed grid",
-                who);
-    *n_out = 0;
-    int rc;
-    uint32_t occ[12];
-    if ((rc = reference_occupied(g, occ))) return rc;
     const float inv = 1.0f / g->extent;
     float lo_f[3], hi_f[3];
     if (mode == 2) {
@@ -2173,9 +2167,24 @@ static int voxel_object_contacts(ivx_grid* g, const char* who, int mode, const f
             }
         }
     }
+    return touched_ranges(occ, lo_f, hi_f, vlo, vhi, lo, cc);
+}
+
+static int voxel_object_contacts(ivx_grid* g, const char* who, int mode, const float rotation_xyzw[4], const float translation[3], const float shape3[3],
+                                 const float shape3b[3], float shape1, uint64_t id_a, uint64_t id_b, uint32_t body_a, uint32_t body_b, const float response[3], ivx_contact* out,
+                                 size_t cap, size_t* n_out) {
+    IVX_REQUIRE(g && rotation_xyzw && translation && shape3 && (shape3b || mode != 2) && response && n_out && (out || cap == 0), IVX_ERR_INVALID,
+                "%s: null argument", who);
+    IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "%s: derived state must be current (ivx_derive_state + ivx_label_regions)", who);
+    IVX_REQUIRE(g->x_off == 0 && g->gx == g->cc[0] && !g->has_ghost[0] && !g->has_ghost[1], IVX_ERR_STATE, "%s: not available on a slab of a decomposed grid",
+                who);
+    *n_out = 0;
+    int rc;
+    uint32_t occ[12];
+    if ((rc = reference_occupied(g, occ))) return rc;
     int32_t vlo[3], vhi[3];
     uint32_t lo[3], cc[3];
-    if (!touched_ranges(occ, lo_f, hi_f, vlo, vhi, lo, cc)) return IVX_OK;
+    if (!contacts_box(g, mode, rotation_xyzw, translation, shape3, shape3b, shape1, occ, vlo, vhi, lo, cc)) return IVX_OK;
     const size_t n_box = (size_t)cc[0] * cc[1] * cc[2];
     const size_t off_offsets = n_box * 4, off_total = 2 * n_box * 4, off_out = (off_total + 16 + 63) & ~(size_t)63;
     if ((rc = ensure_dev_scratch(g, off_out + cap * sizeof(ivx_contact)))) return rc;
@@ -2193,6 +2202,92 @@ static int voxel_object_contacts(ivx_grid* g, const char* who, int mode, const f
     *n_out = total;
     IVX_REQUIRE(total <= cap, IVX_ERR_CAPACITY, "%s: %u contacts exceed the capacity %zu", who, total, cap);
     if (total && (rc = d2h(g, out, d_out, (size_t)total * sizeof(ivx_contact)))) return rc;
+    return IVX_OK;
+}
+
+// One collidable per object, N objects, in the launches of one (many.hpp): the reference's collision pass walks every voxel object of the
+// scene against the collidables near it (impact_voxel/src/collidable.rs:1051-1286: the per-pair dispatch) — here the pairs (object i,
+// collidable i) of one call. Two recorded phases, two waits for ALL objects where the single-object call has two per object: (1) count + scan
+// per object, the totals written by the scan straight into host-mapped memory; (2) the emit passes, each object's contacts at its offset of one
+// host-mapped buffer, copied to `out` by the host. out_offsets[i] .. out_offsets[i + 1]: object i's contacts, in the order the single-object
+// call returns them (a manifold each).
+int ivx_voxel_object_contacts_many(ivx_grid* const* grids, size_t n, const ivx_collidable_query* queries, ivx_contact* out, size_t cap, uint32_t* out_offsets) {
+    const char* who = "ivx_voxel_object_contacts_many";
+    IVX_REQUIRE(out_offsets, IVX_ERR_INVALID, "%s: null argument", who);
+    out_offsets[0] = 0;
+    if (n == 0) return IVX_OK;
+    IVX_REQUIRE(grids && queries && (out || cap == 0), IVX_ERR_INVALID, "%s: null argument", who);
+    ivx_ctx* c = grids[0] ? grids[0]->ctx : nullptr;
+    for (size_t i = 0; i < n; ++i) {
+        ivx_grid* g = grids[i];
+        IVX_REQUIRE(g && g->ctx == c, IVX_ERR_INVALID, "%s: object %zu is null or belongs to another context", who, i);
+        IVX_REQUIRE(queries[i].mode >= 0 && queries[i].mode <= 2, IVX_ERR_INVALID, "%s: query %zu: mode %d", who, i, queries[i].mode);
+        IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "%s: derived state of object %zu must be current (ivx_derive_state + ivx_label_regions)", who, i);
+        IVX_REQUIRE(g->x_off == 0 && g->gx == g->cc[0] && !g->has_ghost[0] && !g->has_ghost[1], IVX_ERR_STATE, "%s: not available on a slab of a decomposed grid", who);
+    }
+    IVX_REQUIRE(!ivx_many_recording(), IVX_ERR_STATE, "%s: not inside an ivx_many_begin bracket (the call waits for its own phases)", who);
+    int rc;
+    hipStream_t s = c->stream;
+    struct Box {
+        int32_t vlo[3], vhi[3];
+        uint32_t lo[3], cc[3];
+        bool hit;
+    };
+    static thread_local std::vector<Box> box;
+    box.assign(n, Box{});
+    // what may wait or allocate, ahead of the recording: occupied ranges, the objects' scratch for counts and offsets, the pinned block
+    for (size_t i = 0; i < n; ++i) {
+        const ivx_collidable_query& q = queries[i];
+        uint32_t occ[12];
+        if ((rc = reference_occupied(grids[i], occ))) return rc;
+        Box& b = box[i];
+        b.hit = contacts_box(grids[i], q.mode, q.rotation_xyzw, q.translation, q.shape3, q.shape3b, q.shape1, occ, b.vlo, b.vhi, b.lo, b.cc);
+        if (b.hit && (rc = ensure_dev_scratch(grids[i], 2 * (size_t)b.cc[0] * b.cc[1] * b.cc[2] * 4 + 64))) return rc;
+    }
+    auto ensure_pinned_scratch = [&](size_t bytes) -> int {
+        if (c->pinned_scratch_bytes >= bytes) return IVX_OK;
+        IVX_HIP_CHECK(ivx_stream_sync(s));
+        if (c->pinned_scratch) (void)hipHostFree(c->pinned_scratch);
+        c->pinned_scratch = c->pinned_scratch_dev = nullptr;
+        c->pinned_scratch_bytes = 0;
+        const size_t want = std::max<size_t>(2 * bytes, 1 << 20);
+        IVX_HIP_CHECK(hipHostMalloc(&c->pinned_scratch, want, hipHostMallocMapped));
+        IVX_HIP_CHECK(hipHostGetDevicePointer(&c->pinned_scratch_dev, c->pinned_scratch, 0));
+        c->pinned_scratch_bytes = want;
+        return IVX_OK;
+    };
+    const size_t totals_bytes = (n * 4 + 63) & ~(size_t)63;
+    if ((rc = ensure_pinned_scratch(totals_bytes + 4096))) return rc;
+    uint32_t* totals = static_cast<uint32_t*>(c->pinned_scratch);
+    memset(totals, 0, n * 4);
+    auto launch = [&](size_t i, int pass, uint32_t* d_total, ivx_contact* d_out, uint32_t cap_i) -> int {
+        const ivx_collidable_query& q = queries[i];
+        const Box& b = box[i];
+        ivx_grid* g = grids[i];
+        const size_t n_box = (size_t)b.cc[0] * b.cc[1] * b.cc[2];
+        char* base = static_cast<char*>(g->dev_scratch);
+        return ivx_launch_sphere_contacts(g, b.lo, b.cc, b.vlo, b.vhi, q.rotation_xyzw, q.translation, q.shape3, q.shape3b, q.shape1, q.collidable_id_a, q.collidable_id_b,
+                                          q.body_a, q.body_b, q.response, reinterpret_cast<uint32_t*>(base), reinterpret_cast<uint32_t*>(base + n_box * 4), d_total, d_out,
+                                          cap_i, pass, q.mode);
+    };
+    uint32_t* totals_dev = static_cast<uint32_t*>(c->pinned_scratch_dev);
+    if ((rc = many_phase(grids, n, [&](size_t i) -> int { return box[i].hit ? launch(i, 0, totals_dev + i, nullptr, 0u) : IVX_OK; }))) return rc;
+    IVX_HIP_CHECK(ivx_stream_sync(s));
+    size_t run = 0;
+    for (size_t i = 0; i < n; ++i) {
+        out_offsets[i] = (uint32_t)run;
+        run += totals[i];
+    }
+    out_offsets[n] = (uint32_t)run;
+    IVX_REQUIRE(run <= cap, IVX_ERR_CAPACITY, "%s: %zu contacts exceed the capacity %zu", who, run, cap);
+    if (run == 0) return IVX_OK;
+    static thread_local std::vector<uint32_t> counts;
+    counts.assign(totals, totals + n);  // (the pinned block may move when it grows)
+    if ((rc = ensure_pinned_scratch(run * sizeof(ivx_contact)))) return rc;
+    ivx_contact* list_dev = static_cast<ivx_contact*>(c->pinned_scratch_dev);
+    if ((rc = many_phase(grids, n, [&](size_t i) -> int { return counts[i] ? launch(i, 1, nullptr, list_dev + out_offsets[i], counts[i]) : IVX_OK; }))) return rc;
+    IVX_HIP_CHECK(ivx_stream_sync(s));
+    memcpy(out, c->pinned_scratch, run * sizeof(ivx_contact));
     return IVX_OK;
 }
 

@@ -62,6 +62,11 @@ struct ivx_ctx {
     hipStream_t stream;
     bool own_stream;
     int n_cu;  // compute units of the device
+    // pinned, device-visible scratch of the many-object calls that bring lists back (ivx_voxel_object_contacts_many: per-object totals, then the
+    // contacts themselves, written by the kernels straight into host memory); grown on demand, freed by ivx_shutdown
+    void* pinned_scratch;
+    void* pinned_scratch_dev;
+    size_t pinned_scratch_bytes;
     void* many_recorder;  // the launch recorder of ivx_many_begin / _flush and its staging ring (many.cpp); made on first use, freed by ivx_shutdown
     int many_error;       // a flush of recorded launches failed on this context (sticky until reported: ivx_many_error)
 };

@@ -36,6 +36,9 @@ enum ivx_many_kernel : int {
     IVX_MK_SN_EMIT_GENERAL_SLOTS,
     IVX_MK_INERTIA_DENSE,
     IVX_MK_CLIP,
+    IVX_MK_SVC_COUNT,  // collidable-against-voxel-object contacts: count | scan | emit (contacts.hip)
+    IVX_MK_SVC_SCAN,
+    IVX_MK_SVC_EMIT,
     IVX_MK_ZERO,    // fill a device range with zeros (the twin of a hipMemsetAsync(..., 0, ...))
     IVX_MK_UPLOAD,  // host words to a device range (the twin of a small hipMemcpyAsync host -> device): the words ride in the flush's one staging copy
     IVX_MK_COUNT

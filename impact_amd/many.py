@@ -79,3 +79,23 @@ def mesh_sync_many(meshes, invalidated):
     for i, m in enumerate(meshes):
         m.counts = out[i]
     return meshes
+
+
+def collidable_queries(n: int) -> np.ndarray:
+    """`n` zeroed `ivx_collidable_query` records (mode 0 sphere: shape3 centre, shape1 radius; 1 plane: shape3 unit normal, shape1 displacement;
+    2 capsule: shape3 segment start, shape3b segment vector, shape1 radius; rotation / translation: the object's transform_to_object_space)"""
+    q = np.zeros(n, dtype=capi.COLLIDABLE_QUERY_DTYPE)
+    q["rotation_xyzw"][:, 3] = 1.0
+    return q
+
+
+def voxel_object_contacts_many(objects, queries, capacity: int = 1 << 18):
+    """`ivx_voxel_object_contacts_many`: collidable i against object i for all objects in the launches of one -> (contacts, offsets): object i's
+    contacts are contacts[offsets[i]:offsets[i + 1]], as the single-object `sphere_contacts` / `plane_contacts` / `capsule_contacts` return them"""
+    n = len(objects)
+    assert len(queries) == n and queries.dtype == capi.COLLIDABLE_QUERY_DTYPE
+    out = np.zeros(capacity, dtype=capi.CONTACT_DTYPE)
+    offsets = np.zeros(n + 1, dtype=np.uint32)
+    q = np.ascontiguousarray(queries)
+    check(capi.lib().ivx_voxel_object_contacts_many(ptr(_handles(objects)) if n else None, n, ptr(q) if n else None, ptr(out), capacity, ptr(offsets)))
+    return out[: int(offsets[n])], offsets

@@ -557,6 +557,24 @@ int ivx_plane_voxel_object_contacts(ivx_grid*, const float rotation_xyzw[4], con
 int ivx_capsule_voxel_object_contacts(ivx_grid*, const float rotation_xyzw[4], const float translation[3], const float segment_start[3],
                                       const float segment_vector[3], float capsule_radius, uint64_t collidable_id_a, uint64_t collidable_id_b,
                                       uint32_t body_a, uint32_t body_b, const float response[3], ivx_contact* out, size_t cap, size_t* n_out);
+/* The same three generators for MANY objects in one call — the reference's collision pass visits every voxel object of the scene with the
+ * collidables near it (impact_voxel/src/collidable.rs:1051-1286) —, one collidable per object: query i goes with grids[i]. The per-object
+ * launches are merged (csrc/many.hpp) and the host waits twice for ALL objects (totals, then contacts) instead of twice per object.
+ * out_offsets has n + 1 entries: object i's contacts are out[out_offsets[i] .. out_offsets[i + 1]), the very list the single-object call
+ * returns (one manifold each). IVX_ERR_CAPACITY when the contacts of all objects exceed `cap` (out_offsets then holds the sizes needed). */
+typedef struct ivx_collidable_query {
+    int32_t mode;             /* 0 sphere, 1 plane, 2 capsule */
+    float rotation_xyzw[4];   /* transform_to_object_space of the voxel object, as in the single-object calls */
+    float translation[3];
+    float shape3[3];          /* sphere centre | plane unit normal | capsule segment start (world space) */
+    float shape3b[3];         /* capsule segment vector (unused otherwise) */
+    float shape1;             /* sphere radius | plane displacement | capsule radius */
+    uint32_t body_a, body_b;
+    uint64_t collidable_id_a, collidable_id_b;
+    float response[3];        /* restitution, static friction, dynamic friction */
+    uint32_t reserved;
+} ivx_collidable_query;
+int ivx_voxel_object_contacts_many(ivx_grid* const* grids, size_t n, const ivx_collidable_query* queries, ivx_contact* out, size_t cap, uint32_t* out_offsets);
 
 /* ---- contacts between two voxel objects (second part) -------------------------------------------------------------
  * VoxelObjectCollisionProbes::recompute_for_all_chunks (collidable.rs:361-392, 451-523, 614-731): per chunk submesh of the current mesh

@@ -315,3 +315,54 @@ def test_random_collidables_against_random_bodies(ctx, seed):
         assert_contacts_equal(got, want)
         n_hits += len(want) > 0
     g.close()
+
+
+def test_many_objects_against_a_collidable_each(ctx):
+    """`ivx_voxel_object_contacts_many`: several bodies, each against its own sphere, plane or capsule — one object's box misses, one has
+    no contacts at all —: object by object the very list of the single-object call (same order, ids, flags, geometry bit for bit)"""
+    from impact_amd import many
+
+    bodies = [both(ctx, scenes.sphere_scene(12.0 + 3.0 * k), 1.0)[1] for k in range(4)] + [both(ctx, scenes.box_scene((20.0, 14.0, 18.0)), 0.5)[1],
+                                                                                       both(ctx, scenes.asteroid_scene(0.25), 1.0)[1]]
+    rng = np.random.default_rng(5)
+    q = many.collidable_queries(len(bodies))
+    want = []
+    for i, g in enumerate(bodies):
+        occ = np.array(g.update_occupied_voxel_ranges(), dtype=np.float64) * g.voxel_extent
+        lo, hi = occ[:, 0], occ[:, 1]
+        axis = rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        ang = float(rng.uniform(0, 1.0))
+        rot = np.array([*(axis * np.sin(0.5 * ang)), np.cos(0.5 * ang)], dtype=np.float32)
+        t = rng.uniform(-1.0, 1.0, 3).astype(np.float32)
+        resp = (0.1 * i, 0.5, 0.4)
+        q[i]["rotation_xyzw"], q[i]["translation"], q[i]["response"] = rot, t, resp
+        q[i]["collidable_id_a"], q[i]["collidable_id_b"], q[i]["body_a"], q[i]["body_b"] = 7 + i, 99, i, 0x80000000
+        kind = i % 3
+        centre = 0.5 * (lo + hi)
+        top = centre.copy()
+        top[1] = hi[1] if i != 3 else hi[1] + 500.0  # (object 3: a sphere far away — nothing touched)
+        q[i]["mode"] = kind
+        if kind == 0:
+            q[i]["shape3"], q[i]["shape1"] = top.astype(np.float32), 4.0 * g.voxel_extent
+            want.append(g.sphere_contacts(rot, t, q[i]["shape3"], float(q[i]["shape1"]), 7 + i, 99, i, 0x80000000, resp))
+        elif kind == 1:
+            n = np.array([0.05, 1.0, 0.02])
+            n = (n / np.linalg.norm(n)).astype(np.float32)
+            q[i]["shape3"], q[i]["shape1"] = n, float(lo[1] + 2.0 * g.voxel_extent)
+            want.append(g.plane_contacts(rot, t, n, float(q[i]["shape1"]), 7 + i, 99, i, 0x80000000, resp))
+        else:
+            q[i]["shape3"], q[i]["shape3b"], q[i]["shape1"] = top.astype(np.float32), np.array([3.0, 1.0, -2.0], dtype=np.float32), 3.0 * g.voxel_extent
+            want.append(g.capsule_contacts(rot, t, q[i]["shape3"], q[i]["shape3b"], float(q[i]["shape1"]), 7 + i, 99, i, 0x80000000, resp))
+    got, off = many.voxel_object_contacts_many(bodies, q)
+    assert int(off[-1]) == sum(len(w) for w in want) and len(want[3]) == 0 and sum(len(w) for w in want) > 50
+    for i, w in enumerate(want):
+        assert_contacts_equal(got[off[i]:off[i + 1]], w)
+    # too small a capacity: the error, and the sizes it would have taken
+    with pytest.raises(Exception):
+        many.voxel_object_contacts_many(bodies, q, capacity=8)
+    # empty list
+    got0, off0 = many.voxel_object_contacts_many([], many.collidable_queries(0))
+    assert len(got0) == 0 and list(off0) == [0]
+    for g in bodies:
+        g.close()
