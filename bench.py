@@ -983,6 +983,7 @@ def fragments_frame_benchmark(ctx, with_cpu, n_axis=5, frames=6, warm=2):
         return cs, rs
 
     t_loop, t_many = [], []
+    parts = np.zeros(6)
     n_contacts = 0
     same_contacts = True
     for f in range(frames + warm):
@@ -1000,13 +1001,20 @@ def fragments_frame_benchmark(ctx, with_cpu, n_axis=5, frames=6, warm=2):
         ctx.synchronize()
         t1 = time.perf_counter()
         cb, off = many.voxel_object_contacts_many(b_objs, q)
+        ta = time.perf_counter()
         wb.prepare_constraints(cb)
+        tb = time.perf_counter()
         wb.step_enqueue(0.005)
+        tc = time.perf_counter()
         eb = many.absorb_sphere_many(b_objs, cs, [r + 2.0 for r in rs], rs, dens)
+        td = time.perf_counter()
         many.mesh_sync_many(b_mesh, [e_["invalidated"] for e_ in eb])
+        te = time.perf_counter()
         many.voxel_step_many(b_objs, capi.STAGE_INERTIA)
         ctx.synchronize()
         t2 = time.perf_counter()
+        if f >= warm:
+            parts += (ta - t1, tb - ta, tc - tb, td - tc, te - td, t2 - te)
         same_contacts = same_contacts and ca.tobytes() == cb.tobytes()
         n_contacts = len(cb)
         if f >= warm:
@@ -1023,7 +1031,18 @@ def fragments_frame_benchmark(ctx, with_cpu, n_axis=5, frames=6, warm=2):
                        "ivx_world_set_contacts -> solve + integrate -> an absorbing sphere per fragment -> incremental remesh -> moments",
            "objects": n, "contacts_per_frame": n_contacts, "frames": frames, "ms_looped": round(loop_ms, 4), "ms_batched": round(many_ms, 4),
            "speedup": round(loop_ms / many_ms, 2),
+           "batched_host_ms": {k_: round(1e3 * float(v_) / frames, 4) for k_, v_ in zip(("contacts_many", "set_contacts", "step_enqueue", "absorb_many (waits for the solve too)",
+                                                                                        "mesh_sync_many", "moments_many"), parts)},
            "parity": {"looped_equals_batched": bool(same), "bodies_equal": bool(same_bodies)}}
+    # the solve of this contact set by itself, on the kernel the schedule picks and on the chain-stationary one
+    wb.prepare_constraints(cb)
+    r_ = wb.step(0.005)
+    out["solver"] = dict(wb.solver_info(), solve_ms=round(float(r_["stage_ms"][2]), 4))
+    wb.set_solver_groups(255)
+    wb.prepare_constraints(cb)
+    r_ = wb.step(0.005)
+    out["solver_chain_stationary"] = {"kernel": wb.solver_info()["kernel"], "solve_ms": round(float(r_["stage_ms"][2]), 4)}
+    wb.set_solver_groups(0)
     if with_cpu:
         import oracle_lib as ol
         from test_gpu_contacts import oracle_plane_contact_list

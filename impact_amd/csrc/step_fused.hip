@@ -100,9 +100,12 @@ __device__ __forceinline__ sn::SnParams sn_params(const StepArgs& a) {
 
 // roles: 0 mesher count (list-driven), 1 region merge by columns, 3 occupied slots, 4 moment partial sums,
 // 5 (edit path) mesh needs of the chunks the edit invalidates
-// (amdgpu_waves_per_eu(8): 64 VGPRs. The count role is a latency-bound gather with little state and wants all eight workgroups a CU can
-// hold. The exact numbering of multi-region chunks was a role of this launch until round 4: held to 64 registers it spilled 160 words and
-// a chunk took 15-90 us — it now leads k_step_post2, see there.)
+// (Registers: the count role is a latency-bound gather with little state and was given all eight workgroups a CU can hold — 64 VGPRs — in
+// round 3. Held to 64 the launch spills 17 registers per lane, and a spilled dword is a store to memory on this part: 24 MB of writes per
+// headline launch, 44 MB on the all-surface grid, for a kernel whose own output is a few hundred KB. At six waves per SIMD (80 registers,
+// nothing spilled) it writes 0.8 / 9 MB and takes 23.4 instead of 25.2 us, 63.5 instead of 75.5 (tools/post1_waves.sh, profiles/round5).
+// The exact numbering of multi-region chunks was a role of this launch until round 4: held to 64 registers it spilled 160 words and a chunk
+// took 15-90 us — it now leads k_step_post2, see there.)
 __device__ __forceinline__ void step_post1_body(const StepArgs& a, uint32_t b, uint32_t) {
     __shared__ uint32_t sh_words[4 * sn::NROWS + 16];  // (tile sign rows: a wave each in the count role, one set in the needs role)
     struct { uint32_t* par; } sh{sh_words};
@@ -128,8 +131,11 @@ __device__ __forceinline__ void step_post1_body(const StepArgs& a, uint32_t b, u
     b -= a.nb[4];
     if (b < a.nb[5]) sn::role_box_mesh_needs(b, sn_params(a), a.needs_box, a.needs_touched, nullptr, a.needs_out, sh.par);
 }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_step_post1(StepArgs a) { step_post1_body(a, blockIdx.x, gridDim.x); }
-IVX_MANY_TWIN(k_step_post1_many, StepArgs, step_post1_body, __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))))
+#ifndef IVX_POST1_WAVES
+#define IVX_POST1_WAVES 6
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IVX_POST1_WAVES, 8))) void k_step_post1(StepArgs a) { step_post1_body(a, blockIdx.x, gridDim.x); }
+IVX_MANY_TWIN(k_step_post1_many, StepArgs, step_post1_body, __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IVX_POST1_WAVES, 8))))
 
 // roles: 5 (the launch's FIRST blocks) exact numbering of the multi-region chunks, 0 region merge of multi-region chunks, 1 mesher scan,
 // 2 moments final (1 block), 3 occupied final (1 block), 4 the slab protocol's face pairs (component pairs across the upper x face, from the
