@@ -1532,8 +1532,12 @@ static bool solver_stationary(const ivx_world* w) {
     for (int p = 0; p < 2; ++p)
         if (w->n_levels[p] && (w->cs[p].n_tiles + PHYS_CS_WAVES - 1u) / PHYS_CS_WAVES > (uint32_t)w->ctx->n_cu / 8u) return false;
     if (w->solver_groups_forced == PHYS_SOLVER_STATIONARY) return true;
+    // One workgroup with the bodies in LDS (k_solve) walks a level in ~4-5 us whatever its width — a barrier and the contacts' trip from memory —,
+    // the chain-stationary solve in ~2.3 (velocity) / ~3.5 (positional) plus ~25 us of launches and census around it: it wins wherever the chain of
+    // levels is long, wide or not (81 bodies of 48 contacts each on a ground plane: 297 + 99 levels of at most 79 chains, 0.55 -> 0.21 ms;
+    // tools/time_world_frames.py). A handful of levels stays with the one workgroup.
     const uint32_t widest = w->max_level_items[0] > w->max_level_items[1] ? w->max_level_items[0] : w->max_level_items[1];
-    return widest > 256u;  // (a level that fits one workgroup: k_solve with the bodies in LDS)
+    return widest > 256u || w->n_levels[0] + w->n_levels[1] >= 48u;
 }
 
 static int launch_solve_cs(ivx_world* w) {

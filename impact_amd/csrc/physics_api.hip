@@ -6,6 +6,8 @@
 // — runs here once per contact set; all arithmetic on body state runs in the kernels of physics.hip.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -356,6 +358,52 @@ static int ivx_world_check_solve(ivx_world* w, const char* who) {
     return IVX_ERR_HIP;
 }
 
+// Host arrays on their way to the device, all through ONE pinned staging block of the world and asynchronous copies on its stream (the block is
+// free again when the event behind the last copy has passed).
+struct StagedUploads {
+    ivx_world* w;
+    struct Item {
+        void* dst;
+        const void* src;
+        size_t bytes, off;
+    };
+    std::vector<Item> items;
+    size_t total = 0;
+    explicit StagedUploads(ivx_world* world) : w(world) {}
+    void add(void* dst, const void* src, size_t bytes) {
+        if (!bytes) return;
+        items.push_back(Item{dst, src, bytes, total});
+        total += (bytes + 63) & ~(size_t)63;
+    }
+    int flush() {
+        if (items.empty()) return IVX_OK;
+        hipStream_t s = w->ctx->stream;
+        if (w->stage_sched_busy) {
+            IVX_HIP_CHECK(hipEventSynchronize(w->stage_sched_ev));
+            w->stage_sched_busy = 0;
+        }
+        if (total > w->stage_sched_cap) {
+            if (w->stage_sched) (void)hipHostFree(w->stage_sched);
+            w->stage_sched = nullptr;
+            w->stage_sched_cap = 0;
+            const size_t cap = total + total / 2 + 4096;
+            IVX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&w->stage_sched), cap, hipHostMallocDefault));
+            w->stage_sched_cap = cap;
+        }
+        if (!w->stage_sched_ev_ready) {
+            IVX_HIP_CHECK(hipEventCreateWithFlags(&w->stage_sched_ev, hipEventDisableTiming));
+            w->stage_sched_ev_ready = 1;
+        }
+        for (const Item& it : items) memcpy(w->stage_sched + it.off, it.src, it.bytes);
+        for (const Item& it : items) IVX_HIP_CHECK(ivx_memcpy_async(it.dst, w->stage_sched + it.off, it.bytes, hipMemcpyHostToDevice, s));
+        IVX_HIP_CHECK(ivx_event_record(w->stage_sched_ev, s));
+        w->stage_sched_busy = 1;
+        items.clear();
+        total = 0;
+        return IVX_OK;
+    }
+};
+
 extern "C" {
 
 int ivx_world_create(ivx_ctx* c, const ivx_solver_config* cfg, ivx_world** out) {
@@ -396,6 +444,8 @@ void ivx_world_destroy(ivx_world* w) {
         (void)hipEventDestroy(w->ev_join);
         (void)hipStreamDestroy(w->side_stream);
     }
+    if (w->stage_sched) (void)hipHostFree(w->stage_sched);  // pinned staging of the general path's uploads
+    if (w->stage_sched_ev_ready) (void)hipEventDestroy(w->stage_sched_ev);
     if (w->stage_contacts) (void)hipHostFree(w->stage_contacts);  // pinned staging of the set_contacts fast path
     if (w->stage_ev_ready) (void)hipEventDestroy(w->stage_ev);
     void* ptrs[] = {w->dyn, w->kin, w->cb, w->touched, w->contacts, w->prev_slot, w->pc[0], w->pc[1], w->acc[0], w->acc[1], w->items, w->item_bodies, w->item_tags, w->level_start,
@@ -527,6 +577,12 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
             if (n_prepared) *n_prepared = n;
             return IVX_OK;
         }
+    }
+    {  // developer aid (IVX_WORLD_TRACE=1): a frame that leaves the one-pass path says why
+        static const bool trace = getenv("IVX_WORLD_TRACE") != nullptr;
+        if (trace)
+            fprintf(stderr, "[ivx world] set_contacts: general path (schedule_valid %d, n %zu, resident %u, cache %zu, ordered %zu, staging cap %zu)\n", w->schedule_valid, n,
+                    w->n_contacts, w->cache.size(), w->ordered.size(), w->stage_contacts_cap);
     }
     for (size_t i = 0; i < n; ++i) {
         const ivx_contact& c = contacts[i];
@@ -681,8 +737,11 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
         if ((rc = grow(&w->kin_qstart, &w->kin_qstart_cap, 8 * n_pos_items, s))) return rc;  // float4 per (item, side)
         if ((rc = grow(&w->kin_snap, &w->kin_snap_cap, (size_t)std::max<uint32_t>(w->n_dyn, 1u) * 8, s))) return rc;
     }
-    IVX_HIP_CHECK(ivx_stream_sync(s));
-    w->stage_busy = 0;
+    // (no wait here: the copies below are stream-ordered behind whatever still reads these buffers; a buffer that grew was waited for in grow())
+    if (w->stage_busy) {  // the fast path's staging block: reallocated below only when its last copy has passed
+        IVX_HIP_CHECK(hipEventSynchronize(w->stage_ev));
+        w->stage_busy = 0;
+    }
     if (nc > w->stage_contacts_cap) {  // the staging buffer of the usual frame's fast path (step 0)
         if (w->stage_contacts) (void)hipHostFree(w->stage_contacts);
         w->stage_contacts = nullptr;
@@ -695,35 +754,35 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
         IVX_HIP_CHECK(hipEventCreateWithFlags(&w->stage_ev, hipEventDisableTiming));
         w->stage_ev_ready = 1;
     }
+    StagedUploads up(w);
     if (nc) {
-        IVX_HIP_CHECK(ivx_memcpy_sync(w->contacts, w->ordered.data(), nc * sizeof(ivx_contact), hipMemcpyHostToDevice));
-        IVX_HIP_CHECK(ivx_memcpy_sync(w->prev_slot, w->prev_slot_host.data(), nc * sizeof(int32_t), hipMemcpyHostToDevice));
+        up.add(w->contacts, w->ordered.data(), nc * sizeof(ivx_contact));
+        up.add(w->prev_slot, w->prev_slot_host.data(), nc * sizeof(int32_t));
     }
     if (!same_schedule) {
         if (!w->items_host.empty()) {
-            IVX_HIP_CHECK(ivx_memcpy_sync(w->items, w->items_host.data(), w->items_host.size() * 4, hipMemcpyHostToDevice));
-            IVX_HIP_CHECK(ivx_memcpy_sync(w->item_bodies, w->item_bodies_host.data(), w->item_bodies_host.size() * 4, hipMemcpyHostToDevice));
-            IVX_HIP_CHECK(ivx_memcpy_sync(w->item_tags, w->item_tags_host.data(), w->item_tags_host.size() * 4, hipMemcpyHostToDevice));
+            up.add(w->items, w->items_host.data(), w->items_host.size() * 4);
+            up.add(w->item_bodies, w->item_bodies_host.data(), w->item_bodies_host.size() * 4);
+            up.add(w->item_tags, w->item_tags_host.data(), w->item_tags_host.size() * 4);
         }
-        IVX_HIP_CHECK(ivx_memcpy_sync(w->level_start, w->level_start_host.data(), w->level_start_host.size() * 4, hipMemcpyHostToDevice));
-        IVX_HIP_CHECK(ivx_memcpy_sync(w->tile_base, w->tile_base_host.data(), w->tile_base_host.size() * 4, hipMemcpyHostToDevice));
-        if (!w->tile_first_host.empty())
-            IVX_HIP_CHECK(ivx_memcpy_sync(w->tile_first, w->tile_first_host.data(), w->tile_first_host.size() * 4, hipMemcpyHostToDevice));
+        up.add(w->level_start, w->level_start_host.data(), w->level_start_host.size() * 4);
+        up.add(w->tile_base, w->tile_base_host.data(), w->tile_base_host.size() * 4);
+        up.add(w->tile_first, w->tile_first_host.data(), w->tile_first_host.size() * 4);
         if (!w->cs_item_host.empty()) {
-            IVX_HIP_CHECK(ivx_memcpy_sync(w->cs_item, w->cs_item_host.data(), w->cs_item_host.size() * 4, hipMemcpyHostToDevice));
-            IVX_HIP_CHECK(ivx_memcpy_sync(w->cs_bodies, w->cs_bodies_host.data(), w->cs_bodies_host.size() * 4, hipMemcpyHostToDevice));
-            IVX_HIP_CHECK(ivx_memcpy_sync(w->cs_vers, w->cs_vers_host.data(), w->cs_vers_host.size() * 4, hipMemcpyHostToDevice));
-            IVX_HIP_CHECK(ivx_memcpy_sync(w->cs_round_start, w->cs_round_start_host.data(), w->cs_round_start_host.size() * 4, hipMemcpyHostToDevice));
-            IVX_HIP_CHECK(ivx_memcpy_sync(w->cs_round_mask, w->cs_round_mask_host.data(), w->cs_round_mask_host.size() * 8, hipMemcpyHostToDevice));
-            IVX_HIP_CHECK(ivx_memcpy_sync(w->cs_round_level, w->cs_round_level_host.data(), w->cs_round_level_host.size() * 4, hipMemcpyHostToDevice));
+            up.add(w->cs_item, w->cs_item_host.data(), w->cs_item_host.size() * 4);
+            up.add(w->cs_bodies, w->cs_bodies_host.data(), w->cs_bodies_host.size() * 4);
+            up.add(w->cs_vers, w->cs_vers_host.data(), w->cs_vers_host.size() * 4);
+            up.add(w->cs_round_start, w->cs_round_start_host.data(), w->cs_round_start_host.size() * 4);
+            up.add(w->cs_round_mask, w->cs_round_mask_host.data(), w->cs_round_mask_host.size() * 8);
+            up.add(w->cs_round_level, w->cs_round_level_host.data(), w->cs_round_level_host.size() * 4);
         }
-        if (w->n_kin_items && !w->cs_slot_of_host.empty())
-            IVX_HIP_CHECK(ivx_memcpy_sync(w->cs_slot_of, w->cs_slot_of_host.data(), w->cs_slot_of_host.size() * 4, hipMemcpyHostToDevice));
+        if (w->n_kin_items && !w->cs_slot_of_host.empty()) up.add(w->cs_slot_of, w->cs_slot_of_host.data(), w->cs_slot_of_host.size() * 4);
         if (w->n_kin_items) {
-            IVX_HIP_CHECK(ivx_memcpy_sync(w->kin_offsets, w->kin_offsets_host.data(), w->kin_offsets_host.size() * 4, hipMemcpyHostToDevice));
-            IVX_HIP_CHECK(ivx_memcpy_sync(w->kin_list, w->kin_list_host.data(), w->kin_list_host.size() * 4, hipMemcpyHostToDevice));
+            up.add(w->kin_offsets, w->kin_offsets_host.data(), w->kin_offsets_host.size() * 4);
+            up.add(w->kin_list, w->kin_list_host.data(), w->kin_list_host.size() * 4);
         }
     }
+    if ((rc = up.flush())) return rc;
     w->schedule_valid = 1;
     // 5. device part of prepare_constraints: gather bodies, prepare every contact, warm-start bookkeeping
     w->cur ^= 1;
@@ -731,7 +790,6 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
     if ((rc = ivx_launch_phys_prepare_contacts(w, w->prev_slot))) return rc;
     if ((rc = ivx_launch_phys_mark_joint_bodies(w))) return rc;
     w->prepared_fresh = 1;
-    IVX_HIP_CHECK(ivx_stream_sync(s));
     if (n_prepared) *n_prepared = nc;
     return IVX_OK;
 }

@@ -146,6 +146,12 @@ struct ivx_world {
     size_t stage_contacts_cap;
     hipEvent_t stage_ev;
     int stage_ev_ready, stage_busy;
+    // the general path's uploads (contacts in cache order, warm-start sources, a new schedule): one pinned staging block, asynchronous copies
+    // behind an event — the path used to make seventeen blocking copies and two waits per frame whose contact set had changed
+    char* stage_sched;
+    size_t stage_sched_cap;
+    hipEvent_t stage_sched_ev;
+    int stage_sched_ev_ready, stage_sched_busy;
     std::vector<int32_t> prev_slot_host;
     std::vector<uint32_t> item_bodies_host, items_host, level_start_host, tile_base_host, tile_first_host, scratch_level, scratch_last, chain_start;
     std::vector<uint32_t> kin_offsets_host, kin_list_host;
