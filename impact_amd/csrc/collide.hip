@@ -189,7 +189,16 @@ __global__ __launch_bounds__(256) void k_probe_select(const ivx_submesh* __restr
 }
 
 // exclusive scan over n counts (one workgroup); offsets[n] = total
-__global__ __launch_bounds__(256) void k_scan_counts(uint32_t n, const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets) {
+struct ScanCountsArgs {
+    const uint32_t* counts;
+    uint32_t* offsets;
+    uint32_t* total_out;  // (optional) the total a second time: host-mapped memory, for a host that waits for many scans at once
+    uint32_t n, pad;
+};
+__device__ __forceinline__ void scan_counts_body(const ScanCountsArgs& a, uint32_t, uint32_t) {
+    const uint32_t n = a.n;
+    const uint32_t* __restrict__ counts = a.counts;
+    uint32_t* __restrict__ offsets = a.offsets;
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_carry;
     const uint32_t tid = threadIdx.x;
@@ -205,8 +214,14 @@ __global__ __launch_bounds__(256) void k_scan_counts(uint32_t n, const uint32_t*
         if (tid == 0) s_carry += total;
         __syncthreads();
     }
-    if (tid == 0) offsets[n] = s_carry;
+    if (tid == 0) {
+        offsets[n] = s_carry;
+        if (a.total_out) *a.total_out = s_carry;
+    }
 }
+__global__ __launch_bounds__(256) void k_scan_counts(ScanCountsArgs a) { scan_counts_body(a, 0u, 1u); }
+IVX_MANY_TWIN(k_scan_counts_many, ScanCountsArgs, scan_counts_body, __launch_bounds__(256))
+IVX_MANY_LAUNCHER(many_scan_counts, k_scan_counts_many, ScanCountsArgs, 256)
 
 __global__ __launch_bounds__(64) void k_probe_gather(const ivx_submesh* __restrict__ submeshes, const float* __restrict__ pos, const uint32_t* __restrict__ sel,
                                                      const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, uint32_t n_blocks,
@@ -341,21 +356,40 @@ __device__ __forceinline__ bool probe_contact(const MutParams& p, const float* p
     return true;
 }
 
-__global__ __launch_bounds__(256) void k_mut_count(MutParams p, const float* __restrict__ points, const uint32_t* __restrict__ probe_chunk,
-                                                   uint32_t* __restrict__ counts) {
+struct MutCountArgs {
+    MutParams p;
+    const float* points;
+    const uint32_t* probe_chunk;
+    uint32_t* counts;
+};
+struct MutEmitArgs {
+    MutParams p;
+    const float* points;
+    const uint32_t* probe_chunk;
+    const uint32_t* offsets;
+    ivx_contact* out;
+    uint32_t cap, pad;
+};
+__device__ __forceinline__ void mut_count_body(const MutCountArgs& a, uint32_t bid, uint32_t) {
     __shared__ uint32_t s_w[4];
-    const bool hit = probe_contact<false>(p, points, probe_chunk, blockIdx.x * 256u + threadIdx.x, nullptr);
+    const bool hit = probe_contact<false>(a.p, a.points, a.probe_chunk, bid * 256u + threadIdx.x, nullptr);
     const uint32_t n = (uint32_t)__popcll(__ballot(hit));
     if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = n;
     __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    if (threadIdx.x == 0) a.counts[bid] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
+__global__ __launch_bounds__(256) void k_mut_count(MutCountArgs a) { mut_count_body(a, blockIdx.x, gridDim.x); }
+IVX_MANY_TWIN(k_mut_count_many, MutCountArgs, mut_count_body, __launch_bounds__(256))
+IVX_MANY_LAUNCHER(many_mut_count, k_mut_count_many, MutCountArgs, 256)
 
-__global__ __launch_bounds__(256) void k_mut_emit(MutParams p, const float* __restrict__ points, const uint32_t* __restrict__ probe_chunk,
-                                                  const uint32_t* __restrict__ offsets, uint32_t cap, ivx_contact* __restrict__ out) {
+__device__ __forceinline__ void mut_emit_body(const MutEmitArgs& a, uint32_t bid, uint32_t) {
+    const MutParams& p = a.p;
+    const uint32_t* __restrict__ offsets = a.offsets;
+    const uint32_t cap = a.cap;
+    ivx_contact* __restrict__ out = a.out;
     __shared__ uint32_t s_w[4];
     MutHit h;
-    const bool hit = probe_contact<true>(p, points, probe_chunk, blockIdx.x * 256u + threadIdx.x, &h);
+    const bool hit = probe_contact<true>(p, a.points, a.probe_chunk, bid * 256u + threadIdx.x, &h);
     const unsigned long long ballot = __ballot(hit);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (lane == 0) s_w[wave] = (uint32_t)__popcll(ballot);
@@ -363,7 +397,7 @@ __global__ __launch_bounds__(256) void k_mut_emit(MutParams p, const float* __re
     if (!hit) return;
     const uint32_t w0 = s_w[0], w1 = s_w[1], w2 = s_w[2];
     const uint32_t wbase = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
-    const uint32_t slot = offsets[blockIdx.x] + wbase + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+    const uint32_t slot = offsets[bid] + wbase + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
     if (slot >= cap) return;
     ivx_contact c;
     unsigned long long id = p.id_ab;  // contact_id_from_collidable_ids_and_indices(a, b, [0, i, j, k])
@@ -384,8 +418,16 @@ __global__ __launch_bounds__(256) void k_mut_emit(MutParams p, const float* __re
     c.reserved = 0;
     out[slot] = c;
 }
+__global__ __launch_bounds__(256) void k_mut_emit(MutEmitArgs a) { mut_emit_body(a, blockIdx.x, gridDim.x); }
+IVX_MANY_TWIN(k_mut_emit_many, MutEmitArgs, mut_emit_body, __launch_bounds__(256))
+IVX_MANY_LAUNCHER(many_mut_emit, k_mut_emit_many, MutEmitArgs, 256)
+static_assert(sizeof(ScanCountsArgs) % 8 == 0 && sizeof(MutCountArgs) % 8 == 0 && sizeof(MutEmitArgs) % 8 == 0, "argument blocks travel as 8-byte words");
 
 }  // namespace
+
+static const int s_collide_many_registered = (ivx_many_register(IVX_MK_SCAN_COUNTS, many_scan_counts, sizeof(ScanCountsArgs)),
+                                              ivx_many_register(IVX_MK_MUT_COUNT, many_mut_count, sizeof(MutCountArgs)),
+                                              ivx_many_register(IVX_MK_MUT_EMIT, many_mut_emit, sizeof(MutEmitArgs)), 0);
 
 // d_slots = nullptr: every submesh (recompute); else the listed submesh slots (incremental sync), n_sub = their number
 int ivx_launch_probe_select(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, uint32_t* d_corner_list, uint32_t* d_sel, uint32_t* d_counts, uint32_t* d_offsets,
@@ -396,7 +438,12 @@ int ivx_launch_probe_select(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, uint3
                            d_corner_list, log2_bs, 1.0f / g->extent, d_sel, d_counts, d_err, d_slots);
     IVX_KLAUNCH((k_probe_select<PROBE_MAXV, false>), dim3(n_sub), dim3(256), 0, g->ctx->stream, g->submeshes, g->positions, g->normals, g->indices,
                        d_corner_list, log2_bs, 1.0f / g->extent, d_sel, d_counts, d_err, d_slots);
-    if (d_offsets) IVX_KLAUNCH(k_scan_counts, dim3(1), dim3(256), 0, g->ctx->stream, n_sub, d_counts, d_offsets);
+    if (d_offsets) {
+        ScanCountsArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.counts = d_counts, sa.offsets = d_offsets, sa.n = n_sub;
+        IVX_KLAUNCH(k_scan_counts, dim3(1), dim3(256), 0, g->ctx->stream, sa);
+    }
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
@@ -445,14 +492,27 @@ int ivx_launch_mutual_pass(ivx_grid* prober, ivx_grid* sampled, const ivx_mutual
     p.dynamic_friction = h->response[2];
     const uint32_t n_wg = (prober->n_probe_points + 255u) / 256u;
     if (n_wg == 0) return IVX_OK;
-    if (!emit) IVX_KLAUNCH(k_mut_count, dim3(n_wg), dim3(256), 0, prober->ctx->stream, p, prober->probe_points, prober->probe_chunk, d_counts);
-    else IVX_KLAUNCH(k_mut_emit, dim3(n_wg), dim3(256), 0, prober->ctx->stream, p, prober->probe_points, prober->probe_chunk, d_offsets, cap, d_out);
+    if (!emit) {
+        MutCountArgs a;
+        memset(&a, 0, sizeof(a));
+        a.p = p, a.points = prober->probe_points, a.probe_chunk = prober->probe_chunk, a.counts = d_counts;
+        if (!ivx_many_try(prober->ctx, prober, IVX_MK_MUT_COUNT, n_wg, a)) IVX_KLAUNCH(k_mut_count, dim3(n_wg), dim3(256), 0, prober->ctx->stream, a);
+    } else {
+        MutEmitArgs a;
+        memset(&a, 0, sizeof(a));
+        a.p = p, a.points = prober->probe_points, a.probe_chunk = prober->probe_chunk, a.offsets = d_offsets, a.out = d_out, a.cap = cap;
+        if (!ivx_many_try(prober->ctx, prober, IVX_MK_MUT_EMIT, n_wg, a)) IVX_KLAUNCH(k_mut_emit, dim3(n_wg), dim3(256), 0, prober->ctx->stream, a);
+    }
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }
 
-int ivx_launch_scan_counts(ivx_ctx* ctx, uint32_t n, const uint32_t* d_counts, uint32_t* d_offsets) {
-    IVX_KLAUNCH(k_scan_counts, dim3(1), dim3(256), 0, ctx->stream, n, d_counts, d_offsets);
+int ivx_launch_scan_counts(ivx_ctx* ctx, uint32_t n, const uint32_t* d_counts, uint32_t* d_offsets, uint32_t* d_total_out, const void* owner) {
+    ScanCountsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.counts = d_counts, a.offsets = d_offsets, a.total_out = d_total_out, a.n = n;
+    if (owner && ivx_many_try(ctx, owner, IVX_MK_SCAN_COUNTS, 1u, a)) return IVX_OK;
+    IVX_KLAUNCH(k_scan_counts, dim3(1), dim3(256), 0, ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

@@ -473,6 +473,7 @@ void ivx_shutdown(ivx_ctx* c) {
     (void)ivx_stream_sync(c->stream);
     ivx_many_release(c);  // (the launch recorder of the many-object calls and its staging ring)
     if (c->pinned_scratch) (void)hipHostFree(c->pinned_scratch);
+    if (c->dev_scratch) (void)hipFree(c->dev_scratch);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -2205,6 +2206,20 @@ static int voxel_object_contacts(ivx_grid* g, const char* who, int mode, const f
     return IVX_OK;
 }
 
+// the context's pinned, device-visible scratch (ivx_ctx::pinned_scratch): at least `bytes`
+static int ctx_pinned_scratch(ivx_ctx* c, size_t bytes) {
+    if (c->pinned_scratch_bytes >= bytes) return IVX_OK;
+    IVX_HIP_CHECK(ivx_stream_sync(c->stream));
+    if (c->pinned_scratch) (void)hipHostFree(c->pinned_scratch);
+    c->pinned_scratch = c->pinned_scratch_dev = nullptr;
+    c->pinned_scratch_bytes = 0;
+    const size_t want = std::max<size_t>(2 * bytes, 1 << 20);
+    IVX_HIP_CHECK(hipHostMalloc(&c->pinned_scratch, want, hipHostMallocMapped));
+    IVX_HIP_CHECK(hipHostGetDevicePointer(&c->pinned_scratch_dev, c->pinned_scratch, 0));
+    c->pinned_scratch_bytes = want;
+    return IVX_OK;
+}
+
 // One collidable per object, N objects, in the launches of one (many.hpp): the reference's collision pass walks every voxel object of the
 // scene against the collidables near it (impact_voxel/src/collidable.rs:1051-1286: the per-pair dispatch) — here the pairs (object i,
 // collidable i) of one call. Two recorded phases, two waits for ALL objects where the single-object call has two per object: (1) count + scan
@@ -2244,20 +2259,8 @@ int ivx_voxel_object_contacts_many(ivx_grid* const* grids, size_t n, const ivx_c
         b.hit = contacts_box(grids[i], q.mode, q.rotation_xyzw, q.translation, q.shape3, q.shape3b, q.shape1, occ, b.vlo, b.vhi, b.lo, b.cc);
         if (b.hit && (rc = ensure_dev_scratch(grids[i], 2 * (size_t)b.cc[0] * b.cc[1] * b.cc[2] * 4 + 64))) return rc;
     }
-    auto ensure_pinned_scratch = [&](size_t bytes) -> int {
-        if (c->pinned_scratch_bytes >= bytes) return IVX_OK;
-        IVX_HIP_CHECK(ivx_stream_sync(s));
-        if (c->pinned_scratch) (void)hipHostFree(c->pinned_scratch);
-        c->pinned_scratch = c->pinned_scratch_dev = nullptr;
-        c->pinned_scratch_bytes = 0;
-        const size_t want = std::max<size_t>(2 * bytes, 1 << 20);
-        IVX_HIP_CHECK(hipHostMalloc(&c->pinned_scratch, want, hipHostMallocMapped));
-        IVX_HIP_CHECK(hipHostGetDevicePointer(&c->pinned_scratch_dev, c->pinned_scratch, 0));
-        c->pinned_scratch_bytes = want;
-        return IVX_OK;
-    };
     const size_t totals_bytes = (n * 4 + 63) & ~(size_t)63;
-    if ((rc = ensure_pinned_scratch(totals_bytes + 4096))) return rc;
+    if ((rc = ctx_pinned_scratch(c, totals_bytes + 4096))) return rc;
     uint32_t* totals = static_cast<uint32_t*>(c->pinned_scratch);
     memset(totals, 0, n * 4);
     auto launch = [&](size_t i, int pass, uint32_t* d_total, ivx_contact* d_out, uint32_t cap_i) -> int {
@@ -2283,7 +2286,7 @@ int ivx_voxel_object_contacts_many(ivx_grid* const* grids, size_t n, const ivx_c
     if (run == 0) return IVX_OK;
     static thread_local std::vector<uint32_t> counts;
     counts.assign(totals, totals + n);  // (the pinned block may move when it grows)
-    if ((rc = ensure_pinned_scratch(run * sizeof(ivx_contact)))) return rc;
+    if ((rc = ctx_pinned_scratch(c, run * sizeof(ivx_contact)))) return rc;
     ivx_contact* list_dev = static_cast<ivx_contact*>(c->pinned_scratch_dev);
     if ((rc = many_phase(grids, n, [&](size_t i) -> int { return counts[i] ? launch(i, 1, nullptr, list_dev + out_offsets[i], counts[i]) : IVX_OK; }))) return rc;
     IVX_HIP_CHECK(ivx_stream_sync(s));
@@ -2696,31 +2699,22 @@ static bool host_intersection_ranges(const ivx_grid* a, const uint32_t occ_a[12]
     return true;
 }
 
-int ivx_mutual_voxel_object_contacts(ivx_grid* a, const float rotation_a[4], const float translation_a[3], const float center_of_mass_a[3], ivx_grid* b,
-                                     const float rotation_b[4], const float translation_b[3], const float center_of_mass_b[3], uint64_t collidable_id_a,
-                                     uint64_t collidable_id_b, uint32_t body_a, uint32_t body_b, const float response[3], ivx_contact* out, size_t cap,
-                                     size_t* n_out) {
-    const char* who = "ivx_mutual_voxel_object_contacts";
-    IVX_REQUIRE(a && b && rotation_a && translation_a && center_of_mass_a && rotation_b && translation_b && center_of_mass_b && response && n_out &&
-                    (out || cap == 0),
-                IVX_ERR_INVALID, "%s: null argument", who);
-    IVX_REQUIRE(a != b && a->ctx == b->ctx, IVX_ERR_INVALID, "%s: two different objects of one context are needed", who);
-    for (ivx_grid* g : {a, b}) {
-        IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "%s: derived state must be current (ivx_derive_state + ivx_label_regions)", who);
-        IVX_REQUIRE(g->mesh_valid && g->probes_serial == g->mesh_serial, IVX_ERR_STATE, "%s: collision probes must be current (ivx_collision_probes_recompute)",
-                    who);
-        IVX_REQUIRE(g->x_off == 0 && g->gx == g->cc[0] && !g->has_ghost[0] && !g->has_ghost[1], IVX_ERR_STATE,
-                    "%s: not available on a slab of a decomposed grid", who);
-    }
-    *n_out = 0;
+// what the two passes of a pair's mutual contacts need (for_each_mutual_voxel_object_contact, collidable.rs:859-1049): the intersection ranges of
+// the two objects' occupied boxes in each other's frames, the probers' chunk ranges, the id prefix. *hit false: the boxes do not meet.
+static int mutual_prepare(ivx_grid* a, const float rotation_a[4], const float translation_a[3], const float center_of_mass_a[3], ivx_grid* b,
+                          const float rotation_b[4], const float translation_b[3], const float center_of_mass_b[3], uint64_t collidable_id_a,
+                          uint64_t collidable_id_b, uint32_t body_a, uint32_t body_b, const float response[3], ivx_mutual_pass pass[2], bool* hit) {
     int rc;
+    *hit = true;
     uint32_t occ_a[12], occ_b[12];
     if ((rc = reference_occupied(a, occ_a))) return rc;
     if ((rc = reference_occupied(b, occ_b))) return rc;
     long ra_lo[3], ra_hi[3], rb_lo[3], rb_hi[3];
     float q_ba[4], t_ba[3];
-    if (!host_intersection_ranges(a, occ_a, rotation_a, translation_a, b, occ_b, rotation_b, translation_b, ra_lo, ra_hi, rb_lo, rb_hi, q_ba, t_ba)) return IVX_OK;
-    ivx_mutual_pass pass[2];
+    if (!host_intersection_ranges(a, occ_a, rotation_a, translation_a, b, occ_b, rotation_b, translation_b, ra_lo, ra_hi, rb_lo, rb_hi, q_ba, t_ba)) {
+        *hit = false;
+        return IVX_OK;
+    }
     {  // ContactID::from_two_u64_and_n_indices: the part that does not depend on the probe
         auto mix = [](uint64_t state) {
             state += 0x9E3779B97F4A7C15ull;
@@ -2759,6 +2753,33 @@ int ivx_mutual_voxel_object_contacts(ivx_grid* a, const float rotation_a[4], con
         p.body_a = body_a;
         p.body_b = body_b;
     }
+    return IVX_OK;
+}
+
+int ivx_mutual_voxel_object_contacts(ivx_grid* a, const float rotation_a[4], const float translation_a[3], const float center_of_mass_a[3], ivx_grid* b,
+                                     const float rotation_b[4], const float translation_b[3], const float center_of_mass_b[3], uint64_t collidable_id_a,
+                                     uint64_t collidable_id_b, uint32_t body_a, uint32_t body_b, const float response[3], ivx_contact* out, size_t cap,
+                                     size_t* n_out) {
+    const char* who = "ivx_mutual_voxel_object_contacts";
+    IVX_REQUIRE(a && b && rotation_a && translation_a && center_of_mass_a && rotation_b && translation_b && center_of_mass_b && response && n_out &&
+                    (out || cap == 0),
+                IVX_ERR_INVALID, "%s: null argument", who);
+    IVX_REQUIRE(a != b && a->ctx == b->ctx, IVX_ERR_INVALID, "%s: two different objects of one context are needed", who);
+    for (ivx_grid* g : {a, b}) {
+        IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "%s: derived state must be current (ivx_derive_state + ivx_label_regions)", who);
+        IVX_REQUIRE(g->mesh_valid && g->probes_serial == g->mesh_serial, IVX_ERR_STATE, "%s: collision probes must be current (ivx_collision_probes_recompute)",
+                    who);
+        IVX_REQUIRE(g->x_off == 0 && g->gx == g->cc[0] && !g->has_ghost[0] && !g->has_ghost[1], IVX_ERR_STATE,
+                    "%s: not available on a slab of a decomposed grid", who);
+    }
+    *n_out = 0;
+    int rc;
+    ivx_mutual_pass pass[2];
+    bool hit = false;
+    if ((rc = mutual_prepare(a, rotation_a, translation_a, center_of_mass_a, b, rotation_b, translation_b, center_of_mass_b, collidable_id_a, collidable_id_b, body_a,
+                             body_b, response, pass, &hit)))
+        return rc;
+    if (!hit) return IVX_OK;
     const uint32_t wg_a = (a->n_probe_points + 255u) / 256u, wg_b = (b->n_probe_points + 255u) / 256u, n_wg = wg_a + wg_b;
     if (n_wg == 0) return IVX_OK;
     // scratch (object A's): [counts n_wg][offsets n_wg + 1][contacts]
@@ -2779,6 +2800,107 @@ int ivx_mutual_voxel_object_contacts(ivx_grid* a, const float rotation_a[4], con
     *n_out = total;
     IVX_REQUIRE(total <= cap, IVX_ERR_CAPACITY, "%s: %u contacts exceed the capacity %zu", who, total, cap);
     if (total && (rc = d2h(a, out, d_out, (size_t)total * sizeof(ivx_contact)))) return rc;
+    return IVX_OK;
+}
+
+// The same for a LIST of pairs in the launches of one (many.hpp) — the reference's narrow phase visits every pair of voxel objects the broad
+// phase hands it (collidable.rs:859-1049 per pair) —: per pair count (A's probes in B's field) | count (B's in A's) | scan, recorded for all
+// pairs and issued merged, the totals written by the scans into host-mapped memory; one wait; then the emit passes of all pairs into one
+// host-mapped list; one wait. out_offsets[i] .. out_offsets[i + 1]: pair i's manifold, the list the single-pair call returns.
+int ivx_mutual_voxel_object_contacts_many(const ivx_mutual_query* queries, size_t n, ivx_contact* out, size_t cap, uint32_t* out_offsets) {
+    const char* who = "ivx_mutual_voxel_object_contacts_many";
+    IVX_REQUIRE(out_offsets, IVX_ERR_INVALID, "%s: null argument", who);
+    out_offsets[0] = 0;
+    if (n == 0) return IVX_OK;
+    IVX_REQUIRE(queries && (out || cap == 0), IVX_ERR_INVALID, "%s: null argument", who);
+    ivx_ctx* c = queries[0].a ? queries[0].a->ctx : nullptr;
+    for (size_t i = 0; i < n; ++i) {
+        const ivx_mutual_query& q = queries[i];
+        IVX_REQUIRE(q.a && q.b && q.a != q.b && q.a->ctx == c && q.b->ctx == c, IVX_ERR_INVALID, "%s: pair %zu: two different objects of the call's context are needed", who, i);
+        for (ivx_grid* g : {q.a, q.b}) {
+            IVX_REQUIRE(g->regions_valid, IVX_ERR_STATE, "%s: pair %zu: derived state must be current (ivx_derive_state + ivx_label_regions)", who, i);
+            IVX_REQUIRE(g->mesh_valid && g->probes_serial == g->mesh_serial, IVX_ERR_STATE, "%s: pair %zu: collision probes must be current (ivx_collision_probes_recompute)", who, i);
+            IVX_REQUIRE(g->x_off == 0 && g->gx == g->cc[0] && !g->has_ghost[0] && !g->has_ghost[1], IVX_ERR_STATE, "%s: not available on a slab of a decomposed grid", who);
+        }
+    }
+    IVX_REQUIRE(!ivx_many_recording(), IVX_ERR_STATE, "%s: not inside an ivx_many_begin bracket (the call waits for its own phases)", who);
+    int rc;
+    hipStream_t s = c->stream;
+    struct Pair {
+        ivx_mutual_pass pass[2];
+        uint32_t wg_a, wg_b;
+        size_t off;  // of the pair's counts / offsets in the context's scratch (u32 words)
+        bool hit;
+    };
+    static thread_local std::vector<Pair> pr;
+    pr.assign(n, Pair{});
+    size_t words = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const ivx_mutual_query& q = queries[i];
+        Pair& p = pr[i];
+        if ((rc = mutual_prepare(q.a, q.rotation_a, q.translation_a, q.center_of_mass_a, q.b, q.rotation_b, q.translation_b, q.center_of_mass_b, q.collidable_id_a,
+                                 q.collidable_id_b, q.body_a, q.body_b, q.response, p.pass, &p.hit)))
+            return rc;
+        p.wg_a = (q.a->n_probe_points + 255u) / 256u, p.wg_b = (q.b->n_probe_points + 255u) / 256u;
+        if (p.wg_a + p.wg_b == 0) p.hit = false;
+        p.off = words;
+        if (p.hit) words += 2 * (size_t)(p.wg_a + p.wg_b) + 16;
+    }
+    // counts and offsets of all pairs: one block of the context's device scratch; totals and contacts: its pinned block
+    if (c->dev_scratch_bytes < words * 4 + 64) {
+        IVX_HIP_CHECK(ivx_stream_sync(s));
+        if (c->dev_scratch) (void)hipFree(c->dev_scratch);
+        c->dev_scratch = nullptr;
+        c->dev_scratch_bytes = 0;
+        const size_t want = std::max<size_t>(2 * (words * 4 + 64), 1 << 20);
+        IVX_HIP_CHECK(hipMalloc(&c->dev_scratch, want));
+        c->dev_scratch_bytes = want;
+    }
+    if ((rc = ctx_pinned_scratch(c, ((n * 4 + 63) & ~(size_t)63) + 4096))) return rc;
+    uint32_t* totals = static_cast<uint32_t*>(c->pinned_scratch);
+    memset(totals, 0, n * 4);
+    uint32_t* totals_dev = static_cast<uint32_t*>(c->pinned_scratch_dev);
+    uint32_t* base = static_cast<uint32_t*>(c->dev_scratch);
+    std::vector<ivx_grid*> chain(n);  // (the recorder's chains go by pair: the first object of each stands for it)
+    for (size_t i = 0; i < n; ++i) chain[i] = queries[i].a;
+    if ((rc = many_phase(chain.data(), n, [&](size_t i) -> int {
+             const Pair& p = pr[i];
+             if (!p.hit) return IVX_OK;
+             const ivx_mutual_query& q = queries[i];
+             const uint32_t n_wg = p.wg_a + p.wg_b;
+             uint32_t* d_counts = base + p.off;
+             uint32_t* d_offsets = d_counts + n_wg;
+             int r;
+             if ((r = ivx_launch_mutual_pass(q.a, q.b, &p.pass[0], d_counts, nullptr, nullptr, 0u, 0))) return r;
+             if ((r = ivx_launch_mutual_pass(q.b, q.a, &p.pass[1], d_counts + p.wg_a, nullptr, nullptr, 0u, 0))) return r;
+             return ivx_launch_scan_counts(c, n_wg, d_counts, d_offsets, totals_dev + i, q.a);
+         })))
+        return rc;
+    IVX_HIP_CHECK(ivx_stream_sync(s));
+    size_t run = 0;
+    for (size_t i = 0; i < n; ++i) {
+        out_offsets[i] = (uint32_t)run;
+        run += totals[i];
+    }
+    out_offsets[n] = (uint32_t)run;
+    IVX_REQUIRE(run <= cap, IVX_ERR_CAPACITY, "%s: %zu contacts exceed the capacity %zu", who, run, cap);
+    if (run == 0) return IVX_OK;
+    static thread_local std::vector<uint32_t> counts;
+    counts.assign(totals, totals + n);
+    if ((rc = ctx_pinned_scratch(c, run * sizeof(ivx_contact)))) return rc;
+    ivx_contact* list_dev = static_cast<ivx_contact*>(c->pinned_scratch_dev);
+    if ((rc = many_phase(chain.data(), n, [&](size_t i) -> int {
+             const Pair& p = pr[i];
+             if (!counts[i]) return IVX_OK;
+             const ivx_mutual_query& q = queries[i];
+             const uint32_t* d_offsets = base + p.off + (p.wg_a + p.wg_b);
+             int r;
+             if ((r = ivx_launch_mutual_pass(q.a, q.b, &p.pass[0], nullptr, d_offsets, list_dev + out_offsets[i], counts[i], 1))) return r;
+             return ivx_launch_mutual_pass(q.b, q.a, &p.pass[1], nullptr, d_offsets + p.wg_a, list_dev + out_offsets[i], counts[i], 1);
+         })))
+        return rc;
+    IVX_HIP_CHECK(ivx_stream_sync(s));
+    memcpy(out, c->pinned_scratch, run * sizeof(ivx_contact));
     return IVX_OK;
 }
 

@@ -67,6 +67,8 @@ struct ivx_ctx {
     void* pinned_scratch;
     void* pinned_scratch_dev;
     size_t pinned_scratch_bytes;
+    void* dev_scratch;  // device scratch of the same calls (counts and offsets of every pair of ivx_mutual_voxel_object_contacts_many)
+    size_t dev_scratch_bytes;
     void* many_recorder;  // the launch recorder of ivx_many_begin / _flush and its staging ring (many.cpp); made on first use, freed by ivx_shutdown
     int many_error;       // a flush of recorded launches failed on this context (sticky until reported: ivx_many_error)
 };
@@ -451,7 +453,7 @@ int ivx_launch_probe_gather(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, const
                             uint32_t* d_entries, const uint32_t* d_slots);
 int ivx_launch_mutual_pass(ivx_grid* prober, ivx_grid* sampled, const ivx_mutual_pass* h, uint32_t* d_counts, const uint32_t* d_offsets, ivx_contact* d_out,
                            uint32_t cap, int emit);
-int ivx_launch_scan_counts(ivx_ctx* ctx, uint32_t n, const uint32_t* d_counts, uint32_t* d_offsets);
+int ivx_launch_scan_counts(ivx_ctx* ctx, uint32_t n, const uint32_t* d_counts, uint32_t* d_offsets, uint32_t* d_total_out = nullptr, const void* owner = nullptr);
 int ivx_launch_sdf_snapshot(ivx_grid* g, const int32_t lo[3], const int32_t hi[3], int8_t* d_out);
 int ivx_launch_absorb_mutual(ivx_grid* g, int from_snapshot, const uint32_t lo[3], const uint32_t cc[3], const int32_t vlo[3], const int32_t vhi[3],
                              ivx_grid* other, const int8_t* d_snapshot, const int32_t s_lo[3], const int32_t s_hi[3], const float q_ba[4],

@@ -39,6 +39,9 @@ enum ivx_many_kernel : int {
     IVX_MK_SVC_COUNT,  // collidable-against-voxel-object contacts: count | scan | emit (contacts.hip)
     IVX_MK_SVC_SCAN,
     IVX_MK_SVC_EMIT,
+    IVX_MK_SCAN_COUNTS,  // contacts between two voxel objects: count (probes of one against the other's field) | scan | emit (collide.hip)
+    IVX_MK_MUT_COUNT,
+    IVX_MK_MUT_EMIT,
     IVX_MK_ZERO,    // fill a device range with zeros (the twin of a hipMemsetAsync(..., 0, ...))
     IVX_MK_UPLOAD,  // host words to a device range (the twin of a small hipMemcpyAsync host -> device): the words ride in the flush's one staging copy
     IVX_MK_COUNT

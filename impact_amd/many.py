@@ -99,3 +99,29 @@ def voxel_object_contacts_many(objects, queries, capacity: int = 1 << 18):
     q = np.ascontiguousarray(queries)
     check(capi.lib().ivx_voxel_object_contacts_many(ptr(_handles(objects)) if n else None, n, ptr(q) if n else None, ptr(out), capacity, ptr(offsets)))
     return out[: int(offsets[n])], offsets
+
+
+def mutual_queries(pairs) -> np.ndarray:
+    """the `ivx_mutual_query` array of a list of pairs, each a dict with a, b (VoxelObject), rotation_a/b (xyzw), translation_a/b (world -> object),
+    center_of_mass_a/b (object space), collidable_id_a/b, body_a/b, response (restitution, static, dynamic friction) — the arguments of
+    `VoxelObject.mutual_contacts`"""
+    q = np.zeros(len(pairs), dtype=capi.MUTUAL_QUERY_DTYPE)
+    for i, p in enumerate(pairs):
+        q[i]["a"], q[i]["b"] = p["a"].h.value, p["b"].h.value
+        for k in ("rotation_a", "translation_a", "center_of_mass_a", "rotation_b", "translation_b", "center_of_mass_b", "collidable_id_a", "collidable_id_b",
+                  "body_a", "body_b"):
+            q[i][k] = p[k]
+        q[i]["response"] = p.get("response", (0.0, 0.0, 0.0))
+    return q
+
+
+def mutual_voxel_object_contacts_many(queries, capacity: int = 1 << 18):
+    """`ivx_mutual_voxel_object_contacts_many`: the mutual contacts of every pair in merged launches -> (contacts, offsets): pair i's manifold is
+    contacts[offsets[i]:offsets[i + 1]], as `VoxelObject.mutual_contacts` returns it"""
+    n = len(queries)
+    assert queries.dtype == capi.MUTUAL_QUERY_DTYPE
+    out = np.zeros(capacity, dtype=capi.CONTACT_DTYPE)
+    offsets = np.zeros(n + 1, dtype=np.uint32)
+    q = np.ascontiguousarray(queries)
+    check(capi.lib().ivx_mutual_voxel_object_contacts_many(ptr(q) if n else None, n, ptr(out), capacity, ptr(offsets)))
+    return out[: int(offsets[n])], offsets

@@ -602,6 +602,20 @@ int ivx_mutual_voxel_object_contacts(ivx_grid* a, const float rotation_a[4], con
                                      const float rotation_b[4], const float translation_b[3], const float center_of_mass_b[3],
                                      uint64_t collidable_id_a, uint64_t collidable_id_b, uint32_t body_a, uint32_t body_b, const float response[3],
                                      ivx_contact* out, size_t cap, size_t* n_out);
+/* The same for a list of pairs in merged launches with two waits for all (cf. ivx_voxel_object_contacts_many): the pairs the broad phase found
+ * this frame. Pair i's manifold is out[out_offsets[i] .. out_offsets[i + 1]) (n + 1 offsets), the list the single-pair call returns. An object
+ * may appear in any number of pairs; the probes of every object must be current. */
+typedef struct ivx_mutual_query {
+    ivx_grid* a;
+    ivx_grid* b;
+    float rotation_a[4], translation_a[3], center_of_mass_a[3];
+    float rotation_b[4], translation_b[3], center_of_mass_b[3];
+    uint64_t collidable_id_a, collidable_id_b;
+    uint32_t body_a, body_b;
+    float response[3];
+    uint32_t reserved;
+} ivx_mutual_query;
+int ivx_mutual_voxel_object_contacts_many(const ivx_mutual_query* queries, size_t n, ivx_contact* out, size_t cap, uint32_t* out_offsets);
 
 #define IVX_KINEMATIC_BODY 0x80000000u
 #define IVX_CONTACT_MANIFOLD_START 1u

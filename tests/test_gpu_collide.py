@@ -119,6 +119,57 @@ def test_mutual_contacts(ctx, case):
     GB.close()
 
 
+def test_mutual_contacts_of_many_pairs(ctx):
+    """the pairs list (ivx_mutual_voxel_object_contacts_many) against the single-pair call: a row of five bodies of different shapes and extents,
+    neighbours touching, one pair far apart, one body in three pairs; the manifolds must be the single-pair lists, byte for byte"""
+    from impact_amd import many
+    from impact_amd.capi import IvxError
+
+    shapes = [(scenes.sphere_scene(24.0), 1.0), (scenes.box_scene((30.0, 30.0, 30.0)), 1.0), (scenes.sphere_scene(28.0), 0.5), (scenes.asteroid_scene(0.3), 1.0),
+              (scenes.sphere_scene(16.0), 1.0)]
+    objs = [both(ctx, g, e) for g, e in shapes]
+    for o, g in objs:
+        probes_both(o, g)
+    rng = np.random.default_rng(5)
+    pose = []
+    x = 0.0
+    for i, (o, g) in enumerate(objs):
+        ax = rng.normal(size=3)
+        ax /= np.linalg.norm(ax)
+        ang = rng.uniform(-1.0, 1.0)
+        q = np.array([*(ax * np.sin(ang / 2)), np.cos(ang / 2)], dtype=f32)
+        com = o.center_of_mass()
+        pose.append((q, placed(com, q, [x, 0.25, -0.5]), com))
+        x += 24.0
+    pair_ids = [(0, 1), (1, 2), (2, 3), (3, 4), (0, 4), (1, 3), (2, 1)]  # (0, 4): apart; body 1 in four pairs, once as B
+    resp = (0.2, 0.5, 0.4)
+    pairs, want = [], []
+    for n, (i, j) in enumerate(pair_ids):
+        (qa, ta, ca), (qb, tb, cb) = pose[i], pose[j]
+        pairs.append(dict(a=objs[i][1], b=objs[j][1], rotation_a=qa, translation_a=ta, center_of_mass_a=ca, rotation_b=qb, translation_b=tb, center_of_mass_b=cb,
+                          collidable_id_a=100 + i, collidable_id_b=100 + j, body_a=i, body_b=j, response=resp))
+        want.append(objs[i][1].mutual_contacts(qa, ta, ca, objs[j][1], qb, tb, cb, 100 + i, 100 + j, i, j, resp))
+    assert sum(len(w) > 10 for w in want) >= 4 and len(want[4]) == 0
+    got, off = many.mutual_voxel_object_contacts_many(many.mutual_queries(pairs))
+    assert off[0] == 0 and off[-1] == len(got) == sum(len(w) for w in want)
+    for n, w in enumerate(want):
+        assert_contacts_equal(got[off[n] : off[n + 1]], w)
+    # twice the same list: nothing kept between calls; and the empty list
+    got2, off2 = many.mutual_voxel_object_contacts_many(many.mutual_queries(pairs))
+    np.testing.assert_array_equal(off2, off)
+    assert got2.tobytes() == got.tobytes()
+    e, eo = many.mutual_voxel_object_contacts_many(many.mutual_queries([]))
+    assert len(e) == 0 and eo.tolist() == [0]
+    with pytest.raises(IvxError):  # too small a list is an error, not a truncation
+        many.mutual_voxel_object_contacts_many(many.mutual_queries(pairs), capacity=8)
+    with pytest.raises(IvxError):  # an object against itself
+        bad = dict(pairs[0])
+        bad["b"] = bad["a"]
+        many.mutual_voxel_object_contacts_many(many.mutual_queries([bad]))
+    for o, g in objs:
+        g.close()
+
+
 def test_probes_go_stale_with_the_mesh(ctx):
     from impact_amd.capi import IvxError
 
