@@ -908,6 +908,77 @@ def fragments_benchmark(ctx, with_cpu, n_axis=5, frames=6, warm=2):
     return out
 
 
+def fragments_probes_and_pairs(ctx, a_objs, b_objs, a_mesh, b_mesh, occ, dens, rounds=4):
+    """The two other per-object loops of a frame (collidable.rs:394-433 probe sync behind every mesh sync; collidable.rs:859-1049 mutual contacts
+    of every pair the broad phase found) on the fragments of `fragments_frame`: object by object (`a`) and through `ivx_collision_probes_sync_many`
+    / `ivx_mutual_voxel_object_contacts_many` (`b`, the twins in the same state). Pairs: fragment k against fragment k + 1, B pushed against A's
+    high-x side two voxels deep (each in its own frame). Timed apart from `ms_looped` / `ms_batched`."""
+    from impact_amd import many
+
+    n = len(a_objs)
+    for o_ in a_objs + b_objs:
+        o_.collision_probes_recompute()
+    t_sync = np.zeros(2)
+    for f in range(rounds):
+        cs, rs = [], []
+        for oc in occ:
+            c = 0.5 * (oc[:, 0] + oc[:, 1])
+            c[0] = oc[0, 1] - 1.0 - 1.5 * f  # bites into the high-x side, where the neighbour touches
+            cs.append(c.astype(np.float32))
+            rs.append(3.0 + (f % 2))
+        inv_a = []
+        for o_, m_, c, r in zip(a_objs, a_mesh, cs, rs):
+            e_ = o_.absorb_sphere(c, r + 2.0, r, dens)
+            m_.sync_with_voxel_object(e_["invalidated"])
+            inv_a.append(e_["invalidated"])
+        eb = many.absorb_sphere_many(b_objs, cs, [r + 2.0 for r in rs], rs, dens)
+        inv_b = [e_["invalidated"] for e_ in eb]
+        many.mesh_sync_many(b_mesh, inv_b)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for o_, iv in zip(a_objs, inv_a):
+            o_.collision_probes_sync(iv)
+        t1 = time.perf_counter()
+        many.collision_probes_sync_many(b_objs, inv_b)
+        t2 = time.perf_counter()
+        if f:
+            t_sync += (t1 - t0, t2 - t1)
+    same_probes = True
+    for x, y in zip(a_objs, b_objs):
+        (pa, ea), (pb, eb_) = x.collision_probes(), y.collision_probes()
+        same_probes = same_probes and np.array_equal(ea, eb_) and all(np.array_equal(pa[e[3]:e[4]].view(np.uint32), pb[e[3]:e[4]].view(np.uint32)) for e in ea)
+    ident = np.array([0.0, 0.0, 0.0, 1.0], dtype=np.float32)
+    zero3 = np.zeros(3, dtype=np.float32)
+    resp = (0.2, 0.7, 0.5)
+    pairs_a, pairs_b, args = [], [], []
+    for k in range(n - 1):
+        ca, cb = 0.5 * (occ[k][:, 0] + occ[k][:, 1]), 0.5 * (occ[k + 1][:, 0] + occ[k + 1][:, 1])
+        tb = np.array([occ[k + 1][0, 0] - occ[k][0, 1] + 6.0, cb[1] - ca[1], cb[2] - ca[2]], dtype=np.float32)  # world (= A's frame) -> B's frame
+        args.append((ident, zero3, ca.astype(np.float32), ident, tb, cb.astype(np.float32), 500 + k, 501 + k, k, k + 1, resp))
+        for objs, pairs in ((a_objs, pairs_a), (b_objs, pairs_b)):
+            pairs.append(dict(a=objs[k], b=objs[k + 1], rotation_a=ident, translation_a=zero3, center_of_mass_a=ca, rotation_b=ident, translation_b=tb,
+                              center_of_mass_b=cb, collidable_id_a=500 + k, collidable_id_b=501 + k, body_a=k, body_b=k + 1, response=resp))
+    qb = many.mutual_queries(pairs_b)
+    t_pairs = np.zeros(2)
+    same_pairs, n_contacts = True, 0
+    for f in range(rounds):
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        lists = [a_objs[k].mutual_contacts(g[0], g[1], g[2], a_objs[k + 1], *g[3:], capacity=8192) for k, g in enumerate(args)]
+        t1 = time.perf_counter()
+        got, off = many.mutual_voxel_object_contacts_many(qb)
+        t2 = time.perf_counter()
+        if f:
+            t_pairs += (t1 - t0, t2 - t1)
+        want = np.concatenate(lists) if lists else got[:0]
+        same_pairs = same_pairs and want.tobytes() == got.tobytes()
+        n_contacts = len(got)
+    d = max(rounds - 1, 1)
+    return {"probes_sync": {"ms_looped": round(1e3 * t_sync[0] / d, 4), "ms_batched": round(1e3 * t_sync[1] / d, 4)},
+            "mutual_pairs": {"pairs": n - 1, "contacts": int(n_contacts), "ms_looped": round(1e3 * t_pairs[0] / d, 4), "ms_batched": round(1e3 * t_pairs[1] / d, 4)},
+            "parity": {"probes_looped_equal_batched": bool(same_probes), "pairs_looped_equal_batched": bool(same_pairs)}}
+
+
 def fragments_frame_benchmark(ctx, with_cpu, n_axis=5, frames=6, warm=2):
     """A FRAME of many objects with the rigid-body side in it (engine/src/tasks.rs:376-434 in the reference's order): the fragments of the
     `fragments` leg, each a rigid body lying on a ground plane — per frame: contact generation of every fragment against the plane (f1,
@@ -1043,6 +1114,7 @@ def fragments_frame_benchmark(ctx, with_cpu, n_axis=5, frames=6, warm=2):
     r_ = wb.step(0.005)
     out["solver_chain_stationary"] = {"kernel": wb.solver_info()["kernel"], "solve_ms": round(float(r_["stage_ms"][2]), 4)}
     wb.set_solver_groups(0)
+    out["probes_and_pairs"] = fragments_probes_and_pairs(ctx, a_objs, b_objs, a_mesh, b_mesh, occ, dens)
     if with_cpu:
         import oracle_lib as ol
         from test_gpu_contacts import oracle_plane_contact_list

@@ -81,18 +81,39 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t mine, uint32_t* s
 // MAXV = the most vertices a workgroup of this variant takes (its LDS footprint: 12 B per vertex). Chunk meshes have a few hundred
 // vertices, the worst case is 4913: the launcher runs a small variant (1024 vertices, 12 KB: many workgroups per CU) for the chunks that fit
 // it and the full-size one for the rest; a workgroup whose chunk belongs to the other variant leaves at once.
+struct ProbeSelectArgs {
+    const ivx_submesh* submeshes;
+    const float* pos;
+    const float* nrm;
+    const uint32_t* idx;
+    uint32_t* corner_list;
+    uint32_t* sel;
+    uint32_t* counts;
+    uint32_t* counts_host;  // (optional) the counts a second time: host-mapped memory, for a host that waits for many objects at once
+    uint32_t* err;          // set to 1 by plain stores (may be host-mapped)
+    const uint32_t* slots;
+    uint32_t log2_bs;
+    float inv_extent;
+};
 template <uint32_t MAXV, bool SMALL>
-__global__ __launch_bounds__(256) void k_probe_select(const ivx_submesh* __restrict__ submeshes, const float* __restrict__ pos, const float* __restrict__ nrm,
-                                                      const uint32_t* __restrict__ idx, uint32_t* __restrict__ corner_list, uint32_t log2_bs,
-                                                      float inv_extent, uint32_t* __restrict__ sel, uint32_t* __restrict__ counts,
-                                                      uint32_t* __restrict__ err, const uint32_t* __restrict__ slots) {
+__device__ __forceinline__ void probe_select_body(const ProbeSelectArgs& a, uint32_t bid, uint32_t) {
+    const ivx_submesh* __restrict__ submeshes = a.submeshes;
+    const float* __restrict__ pos = a.pos;
+    const float* __restrict__ nrm = a.nrm;
+    const uint32_t* __restrict__ idx = a.idx;
+    uint32_t* __restrict__ corner_list = a.corner_list;
+    uint32_t* __restrict__ sel = a.sel;
+    uint32_t* __restrict__ counts = a.counts;
+    const uint32_t* __restrict__ slots = a.slots;
+    const uint32_t log2_bs = a.log2_bs;
+    const float inv_extent = a.inv_extent;
     __shared__ unsigned long long s_mem[MAXV];  // two u32 per vertex first, then the block table (MAXV x 8 B at most)
     __shared__ float s_curv[MAXV];
     __shared__ uint32_t s_w[4];
     uint32_t* s_start = reinterpret_cast<uint32_t*>(s_mem);
     uint32_t* s_fill = s_start + MAXV;
     unsigned long long* s_best = s_mem;
-    const uint32_t tid = threadIdx.x, s = blockIdx.x;  // s = record: outputs are indexed by it
+    const uint32_t tid = threadIdx.x, s = bid;  // s = record: outputs are indexed by it
     const ivx_submesh sm = submeshes[slots ? slots[s] : s];  // (incremental sync: the listed submesh slots)
     const uint32_t ioff = sm.index_offset, icnt = sm.index_count, voff = sm.vertex_offset, vcnt = sm.vertex_count;
     const uint32_t log2_cb = 4u - log2_bs, n_blocks = 1u << (3u * log2_cb);
@@ -100,7 +121,8 @@ __global__ __launch_bounds__(256) void k_probe_select(const ivx_submesh* __restr
     if (vcnt > MAXV || n_blocks > MAXV) {  // (cannot happen for a Surface Nets chunk; never index LDS out of bounds)
         if (tid == 0) {
             counts[s] = 0;
-            atomicOr(err, 1u);
+            if (a.counts_host) a.counts_host[s] = 0;
+            *reinterpret_cast<volatile uint32_t*>(a.err) = 1u;
         }
         return;
     }
@@ -184,9 +206,22 @@ __global__ __launch_bounds__(256) void k_probe_select(const ivx_submesh* __restr
             const unsigned long long k = s_best[b];
             if (k != ~0ull) sel[(size_t)s * n_blocks + run++] = voff + (uint32_t)(k & 0xFFFFFFFFull);
         }
-        if (tid == 0) counts[s] = total;
+        if (tid == 0) {
+            counts[s] = total;
+            if (a.counts_host) a.counts_host[s] = total;
+        }
     }
 }
+template <uint32_t MAXV, bool SMALL>
+__global__ __launch_bounds__(256) void k_probe_select(ProbeSelectArgs a) {
+    probe_select_body<MAXV, SMALL>(a, blockIdx.x, gridDim.x);
+}
+__device__ __forceinline__ void probe_select_small_body(const ProbeSelectArgs& a, uint32_t bid, uint32_t nb) { probe_select_body<PROBE_SMALLV, true>(a, bid, nb); }
+__device__ __forceinline__ void probe_select_full_body(const ProbeSelectArgs& a, uint32_t bid, uint32_t nb) { probe_select_body<PROBE_MAXV, false>(a, bid, nb); }
+IVX_MANY_TWIN(k_probe_select_small_many, ProbeSelectArgs, probe_select_small_body, __launch_bounds__(256))
+IVX_MANY_LAUNCHER(many_probe_select_small, k_probe_select_small_many, ProbeSelectArgs, 256)
+IVX_MANY_TWIN(k_probe_select_full_many, ProbeSelectArgs, probe_select_full_body, __launch_bounds__(256))
+IVX_MANY_LAUNCHER(many_probe_select_full, k_probe_select_full_many, ProbeSelectArgs, 256)
 
 // exclusive scan over n counts (one workgroup); offsets[n] = total
 struct ScanCountsArgs {
@@ -223,11 +258,30 @@ __global__ __launch_bounds__(256) void k_scan_counts(ScanCountsArgs a) { scan_co
 IVX_MANY_TWIN(k_scan_counts_many, ScanCountsArgs, scan_counts_body, __launch_bounds__(256))
 IVX_MANY_LAUNCHER(many_scan_counts, k_scan_counts_many, ScanCountsArgs, 256)
 
-__global__ __launch_bounds__(64) void k_probe_gather(const ivx_submesh* __restrict__ submeshes, const float* __restrict__ pos, const uint32_t* __restrict__ sel,
-                                                     const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, uint32_t n_blocks,
-                                                     float* __restrict__ points, uint32_t* __restrict__ probe_chunk, uint32_t* __restrict__ entries,
-                                                     const uint32_t* __restrict__ slots) {
-    const uint32_t s = blockIdx.x, n = counts[s], off = offsets[s];
+struct ProbeGatherArgs {
+    const ivx_submesh* submeshes;
+    const float* pos;
+    const uint32_t* sel;
+    const uint32_t* counts;
+    const uint32_t* offsets;
+    float* points;
+    uint32_t* probe_chunk;
+    uint32_t* entries;
+    const uint32_t* slots;
+    uint32_t n_blocks, pad;
+};
+__device__ __forceinline__ void probe_gather_body(const ProbeGatherArgs& a, uint32_t bid, uint32_t) {
+    const ivx_submesh* __restrict__ submeshes = a.submeshes;
+    const float* __restrict__ pos = a.pos;
+    const uint32_t* __restrict__ sel = a.sel;
+    const uint32_t* __restrict__ counts = a.counts;
+    const uint32_t* __restrict__ offsets = a.offsets;
+    float* __restrict__ points = a.points;
+    uint32_t* __restrict__ probe_chunk = a.probe_chunk;
+    uint32_t* __restrict__ entries = a.entries;
+    const uint32_t* __restrict__ slots = a.slots;
+    const uint32_t n_blocks = a.n_blocks;
+    const uint32_t s = bid, n = counts[s], off = offsets[s];
     const ivx_submesh sm = submeshes[slots ? slots[s] : s];
     const uint32_t packed = sm.chunk_indices[0] | (sm.chunk_indices[1] << 10) | (sm.chunk_indices[2] << 20);
     for (uint32_t r = threadIdx.x; r < n; r += 64u) {
@@ -242,6 +296,11 @@ __global__ __launch_bounds__(64) void k_probe_gather(const ivx_submesh* __restri
         e[0] = sm.chunk_indices[0], e[1] = sm.chunk_indices[1], e[2] = sm.chunk_indices[2], e[3] = off, e[4] = off + n;
     }
 }
+
+__global__ __launch_bounds__(64) void k_probe_gather(ProbeGatherArgs a) { probe_gather_body(a, blockIdx.x, gridDim.x); }
+IVX_MANY_TWIN(k_probe_gather_many, ProbeGatherArgs, probe_gather_body, __launch_bounds__(64))
+IVX_MANY_LAUNCHER(many_probe_gather, k_probe_gather_many, ProbeGatherArgs, 64)
+static_assert(sizeof(ProbeSelectArgs) % 8 == 0 && sizeof(ProbeGatherArgs) % 8 == 0, "argument blocks travel as 8-byte words");
 
 // ---- mutual contacts -------------------------------------------------------------------------------------------------------------
 struct MutParams {
@@ -427,17 +486,23 @@ static_assert(sizeof(ScanCountsArgs) % 8 == 0 && sizeof(MutCountArgs) % 8 == 0 &
 
 static const int s_collide_many_registered = (ivx_many_register(IVX_MK_SCAN_COUNTS, many_scan_counts, sizeof(ScanCountsArgs)),
                                               ivx_many_register(IVX_MK_MUT_COUNT, many_mut_count, sizeof(MutCountArgs)),
-                                              ivx_many_register(IVX_MK_MUT_EMIT, many_mut_emit, sizeof(MutEmitArgs)), 0);
+                                              ivx_many_register(IVX_MK_MUT_EMIT, many_mut_emit, sizeof(MutEmitArgs)),
+                                              ivx_many_register(IVX_MK_PROBE_SELECT_SMALL, many_probe_select_small, sizeof(ProbeSelectArgs)),
+                                              ivx_many_register(IVX_MK_PROBE_SELECT_FULL, many_probe_select_full, sizeof(ProbeSelectArgs)),
+                                              ivx_many_register(IVX_MK_PROBE_GATHER, many_probe_gather, sizeof(ProbeGatherArgs)), 0);
 
-// d_slots = nullptr: every submesh (recompute); else the listed submesh slots (incremental sync), n_sub = their number
+// d_slots = nullptr: every submesh (recompute); else the listed submesh slots (incremental sync), n_sub = their number. d_counts_host: optional
+// host-mapped copy of the counts (ivx_collision_probes_sync_many). Inside a recorded batch the launches are captured.
 int ivx_launch_probe_select(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, uint32_t* d_corner_list, uint32_t* d_sel, uint32_t* d_counts, uint32_t* d_offsets,
-                            uint32_t* d_err, const uint32_t* d_slots) {
+                            uint32_t* d_err, const uint32_t* d_slots, uint32_t* d_counts_host) {
     const uint32_t n_blocks = 1u << (3u * (4u - log2_bs));
-    if (n_blocks <= PROBE_SMALLV)
-        IVX_KLAUNCH((k_probe_select<PROBE_SMALLV, true>), dim3(n_sub), dim3(256), 0, g->ctx->stream, g->submeshes, g->positions, g->normals, g->indices,
-                           d_corner_list, log2_bs, 1.0f / g->extent, d_sel, d_counts, d_err, d_slots);
-    IVX_KLAUNCH((k_probe_select<PROBE_MAXV, false>), dim3(n_sub), dim3(256), 0, g->ctx->stream, g->submeshes, g->positions, g->normals, g->indices,
-                       d_corner_list, log2_bs, 1.0f / g->extent, d_sel, d_counts, d_err, d_slots);
+    ProbeSelectArgs a;
+    memset(&a, 0, sizeof(a));
+    a.submeshes = g->submeshes, a.pos = g->positions, a.nrm = g->normals, a.idx = g->indices, a.corner_list = d_corner_list, a.sel = d_sel, a.counts = d_counts;
+    a.counts_host = d_counts_host, a.err = d_err, a.slots = d_slots, a.log2_bs = log2_bs, a.inv_extent = 1.0f / g->extent;
+    if (n_blocks <= PROBE_SMALLV && !ivx_many_try(g->ctx, g, IVX_MK_PROBE_SELECT_SMALL, n_sub, a))
+        IVX_KLAUNCH((k_probe_select<PROBE_SMALLV, true>), dim3(n_sub), dim3(256), 0, g->ctx->stream, a);
+    if (!ivx_many_try(g->ctx, g, IVX_MK_PROBE_SELECT_FULL, n_sub, a)) IVX_KLAUNCH((k_probe_select<PROBE_MAXV, false>), dim3(n_sub), dim3(256), 0, g->ctx->stream, a);
     if (d_offsets) {
         ScanCountsArgs sa;
         memset(&sa, 0, sizeof(sa));
@@ -451,9 +516,11 @@ int ivx_launch_probe_select(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, uint3
 // copies the selected vertices to probe_points[d_offsets[record] ...]; d_entries (optional) gets one (chunk, first, end) entry per record
 int ivx_launch_probe_gather(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, const uint32_t* d_sel, const uint32_t* d_counts, const uint32_t* d_offsets,
                             uint32_t* d_entries, const uint32_t* d_slots) {
-    const uint32_t n_blocks = 1u << (3u * (4u - log2_bs));
-    IVX_KLAUNCH(k_probe_gather, dim3(n_sub), dim3(64), 0, g->ctx->stream, g->submeshes, g->positions, d_sel, d_counts, d_offsets, n_blocks,
-                       g->probe_points, g->probe_chunk, d_entries, d_slots);
+    ProbeGatherArgs a;
+    memset(&a, 0, sizeof(a));
+    a.submeshes = g->submeshes, a.pos = g->positions, a.sel = d_sel, a.counts = d_counts, a.offsets = d_offsets, a.points = g->probe_points;
+    a.probe_chunk = g->probe_chunk, a.entries = d_entries, a.slots = d_slots, a.n_blocks = 1u << (3u * (4u - log2_bs));
+    if (!ivx_many_try(g->ctx, g, IVX_MK_PROBE_GATHER, n_sub, a)) IVX_KLAUNCH(k_probe_gather, dim3(n_sub), dim3(64), 0, g->ctx->stream, a);
     IVX_HIP_CHECK(hipGetLastError());
     return IVX_OK;
 }

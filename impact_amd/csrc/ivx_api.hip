@@ -2104,6 +2104,8 @@ static bool touched_ranges(const uint32_t occ[12], const float lo_f[3], const fl
 
 // mode 0: sphere (shape3 = centre, shape1 = radius); 1: plane (unit normal, displacement); 2: capsule (segment start, radius; shape3b = segment vector)
 static int many_phase(ivx_grid* const* grids, size_t n, const std::function<int(size_t)>& f);
+static int many_check(ivx_grid* const* grids, size_t n, const char* who);
+static int many_fail(ivx_grid* const* grids, size_t n, int rc);
 // the chunk box and voxel ranges a collidable touches of an object (mode 0 sphere: centre shape3, radius shape1; 1 plane: unit normal shape3,
 // displacement shape1; 2 capsule: segment start shape3, segment vector shape3b, radius shape1); false: nothing touched
 static bool contacts_box(const ivx_grid* g, int mode, const float rotation_xyzw[4], const float translation[3], const float shape3[3], const float shape3b[3],
@@ -2437,10 +2439,24 @@ static int probe_manager_build(ivx_grid* g) {
     return IVX_OK;
 }
 extern "C" {
-// VoxelObjectCollisionProbes::sync_with_voxel_object_and_mesh (collidable.rs:394-433, 524-612): after ivx_mesh_sync, with the same invalidated chunks
-int ivx_collision_probes_sync(ivx_grid* g, const uint8_t* invalidated_chunks, size_t* n_points) {
-    const char* who = "ivx_collision_probes_sync";
-    IVX_REQUIRE(g && invalidated_chunks && n_points, IVX_ERR_INVALID, "%s: null argument", who);
+}  // extern "C"
+// VoxelObjectCollisionProbes::sync_with_voxel_object_and_mesh (collidable.rs:394-433, 524-612) in the stages the single-object call and the
+// many-objects call share: prepare (host: which chunks, which submesh slots, scratch) | select (device: the points of the listed submeshes
+// picked again, their counts) | allocate (host: update_for_chunk chunk by chunk, the RangeAllocator) | gather (device: freed ranges marked,
+// the picked points copied to their ranges).
+namespace {
+struct ProbeSyncJob {
+    ivx_grid* g = nullptr;
+    uint32_t log2_bs = 0, n_blocks = 0, n_rec = 0;
+    std::vector<uint32_t> list, slots, dst;
+    std::vector<int32_t> rec_index;
+    std::vector<std::pair<uint32_t, uint32_t>> freed;
+    size_t off_sel = 0, off_counts = 0, off_dst = 0, off_slots = 0, off_err = 0;
+    char* base = nullptr;
+};
+}  // namespace
+static int probe_sync_prepare(ivx_grid* g, const uint8_t* invalidated_chunks, const char* who, ProbeSyncJob& j) {
+    IVX_REQUIRE(g && invalidated_chunks, IVX_ERR_INVALID, "%s: null argument", who);
     ivx_submesh_manager* m = g->submesh_manager;
     ivx_probe_manager* pm = g->probe_manager;
     IVX_REQUIRE(g->mesh_valid && m && m->serial == g->mesh_serial, IVX_ERR_STATE, "%s: call ivx_mesh_sync first", who);
@@ -2452,91 +2468,189 @@ int ivx_collision_probes_sync(ivx_grid* g, const uint8_t* invalidated_chunks, si
     if ((rc = reference_occupied(g, occ))) return rc;
     uint32_t min_extent = 0xFFFFFFFFu;
     for (int d = 0; d < 3; ++d) min_extent = std::min(min_extent, occ[7 + 2 * d] > occ[6 + 2 * d] ? occ[7 + 2 * d] - occ[6 + 2 * d] : 0u);
-    const uint32_t log2_bs = min_extent >= 16 ? 3 : (min_extent >= 8 ? 2 : (min_extent >= 4 ? 1 : 0));
-    const uint32_t n_blocks = 1u << (3u * (4u - log2_bs));
+    j.g = g;
+    j.log2_bs = min_extent >= 16 ? 3 : (min_extent >= 8 ? 2 : (min_extent >= 4 ? 1 : 0));
+    j.n_blocks = 1u << (3u * (4u - j.log2_bs));
     // the invalidated chunks in chunk-linear order (the reference walks a hash set: unpinned); those that have a submesh get their points picked
-    std::vector<uint32_t> list, slots, rec_of(0);
+    j.list.clear(), j.slots.clear(), j.freed.clear();
     for (uint32_t c = 0; c < g->n_chunks; ++c)
-        if (invalidated_chunks[c]) list.push_back(c);
-    std::vector<int32_t> rec_index(list.size(), -1);
-    for (size_t e = 0; e < list.size(); ++e) {
-        auto it = m->slot_of.find(list[e]);
+        if (invalidated_chunks[c]) j.list.push_back(c);
+    j.rec_index.assign(j.list.size(), -1);
+    for (size_t e = 0; e < j.list.size(); ++e) {
+        auto it = m->slot_of.find(j.list[e]);
         if (it != m->slot_of.end()) {
-            rec_index[e] = (int32_t)slots.size();
-            slots.push_back(it->second);
+            j.rec_index[e] = (int32_t)j.slots.size();
+            j.slots.push_back(it->second);
         }
     }
-    const uint32_t n_rec = (uint32_t)slots.size();
-    std::vector<uint32_t> counts(n_rec);
+    j.n_rec = (uint32_t)j.slots.size();
+    j.dst.assign(j.n_rec, 0u);
     // scratch: [corner lists: one u32 per index][selected vertices: n_rec * n_blocks][counts][dst offsets][slots][error word]
-    const size_t ni = m->total_indices;
-    const size_t off_sel = ni * 4, off_counts = off_sel + (size_t)n_rec * n_blocks * 4, off_dst = off_counts + (size_t)n_rec * 4, off_slots = off_dst + (size_t)n_rec * 4,
-                 off_err = off_slots + (size_t)n_rec * 4, total = off_err + 4;
-    char* base = nullptr;
+    const size_t ni = m->total_indices, n_rec = j.n_rec;
+    j.off_sel = ni * 4, j.off_counts = j.off_sel + n_rec * j.n_blocks * 4, j.off_dst = j.off_counts + n_rec * 4, j.off_slots = j.off_dst + n_rec * 4;
+    j.off_err = j.off_slots + n_rec * 4;
+    j.base = nullptr;
     if (n_rec) {
-        if ((rc = ensure_dev_scratch(g, total))) return rc;
-        base = static_cast<char*>(g->dev_scratch);
-        IVX_HIP_CHECK(ivx_memset_async(base + off_err, 0, 4, g->ctx->stream));
-        if ((rc = h2d(g, base + off_slots, slots.data(), (size_t)n_rec * 4))) return rc;
-        if ((rc = ivx_launch_probe_select(g, n_rec, log2_bs, reinterpret_cast<uint32_t*>(base), reinterpret_cast<uint32_t*>(base + off_sel),
-                                          reinterpret_cast<uint32_t*>(base + off_counts), nullptr, reinterpret_cast<uint32_t*>(base + off_err),
-                                          reinterpret_cast<const uint32_t*>(base + off_slots))))
-            return rc;
-        if ((rc = d2h(g, counts.data(), base + off_counts, (size_t)n_rec * 4))) return rc;
-        uint32_t err = 0;
-        if ((rc = d2h(g, &err, base + off_err, 4))) return rc;
-        IVX_REQUIRE(err == 0, IVX_ERR_CAPACITY, "%s: a chunk submesh holds more vertices than a Surface Nets chunk can", who);
+        if ((rc = ensure_dev_scratch(g, j.off_err + 4))) return rc;
+        j.base = static_cast<char*>(g->dev_scratch);
     }
-    // update_for_chunk, chunk by chunk
-    std::vector<uint32_t> dst(n_rec, 0);
-    std::vector<std::pair<uint32_t, uint32_t>> freed;
-    for (size_t e = 0; e < list.size(); ++e) {
-        const uint32_t c = list[e];
-        const uint32_t n = rec_index[e] >= 0 ? counts[(size_t)rec_index[e]] : 0u;
+    return IVX_OK;
+}
+// d_err: the error word the select pass sets (zeroed by the caller); d_counts_host: optional host-mapped copy of the counts
+static int probe_sync_select(ProbeSyncJob& j, uint32_t* d_err, uint32_t* d_counts_host) {
+    if (!j.n_rec) return IVX_OK;
+    ivx_grid* g = j.g;
+    int rc;
+    if (!ivx_many_upload(g->ctx, g, j.base + j.off_slots, j.slots.data(), (size_t)j.n_rec * 4) && (rc = h2d(g, j.base + j.off_slots, j.slots.data(), (size_t)j.n_rec * 4)))
+        return rc;
+    return ivx_launch_probe_select(g, j.n_rec, j.log2_bs, reinterpret_cast<uint32_t*>(j.base), reinterpret_cast<uint32_t*>(j.base + j.off_sel),
+                                   reinterpret_cast<uint32_t*>(j.base + j.off_counts), nullptr, d_err, reinterpret_cast<const uint32_t*>(j.base + j.off_slots),
+                                   d_counts_host);
+}
+// update_for_chunk, chunk by chunk (collidable.rs:524-612); *grow: the point buffers must hold pm->total points before the gather
+static int probe_sync_allocate(ProbeSyncJob& j, const uint32_t* counts, const char* who, bool* grow) {
+    ivx_grid* g = j.g;
+    ivx_probe_manager* pm = g->probe_manager;
+    for (size_t e = 0; e < j.list.size(); ++e) {
+        const uint32_t c = j.list[e];
+        const uint32_t n = j.rec_index[e] >= 0 ? counts[(size_t)j.rec_index[e]] : 0u;
         auto old = pm->range_of.find(c);
         if (n == 0) {  // no mesh, or no points
             if (old != pm->range_of.end()) {
                 pm->points.free_range(old->second.first, old->second.second);
-                freed.push_back(old->second);
+                j.freed.push_back(old->second);
                 pm->range_of.erase(old);
             }
             continue;
         }
         if (old != pm->range_of.end()) {
             pm->points.free_range(old->second.first, old->second.second);
-            freed.push_back(old->second);
+            j.freed.push_back(old->second);
         }
         size_t start;
         if (!pm->points.allocate(n, &start)) start = pm->total, pm->total += n;
         IVX_REQUIRE(pm->total < 0xFFFFFFF0ull, IVX_ERR_CAPACITY, "%s: more than 2^32 probe points", who);
         pm->range_of[c] = {(uint32_t)start, (uint32_t)(start + n)};
-        dst[(size_t)rec_index[e]] = (uint32_t)start;
+        j.dst[(size_t)j.rec_index[e]] = (uint32_t)start;
     }
     pm->points.merge_consecutive();
-    if (pm->total > g->probe_point_cap) {  // grow, keeping what is there
-        const size_t cap = std::max<size_t>(pm->total + pm->total / 2 + 4096, 2 * g->probe_point_cap);
-        std::vector<GrowKeep> pending;
-        if ((rc = grow_keep_enqueue(g, &g->probe_points, g->probe_point_cap * 3, cap * 3, pending, 0u))) return rc;
-        if ((rc = grow_keep_enqueue(g, &g->probe_chunk, g->probe_point_cap, cap, pending, 0u))) return rc;
-        IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
-        for (GrowKeep& k : pending) {
-            if (*k.slot) (void)hipFree(*k.slot);
-            *k.slot = k.fresh;
-        }
-        g->probe_point_cap = cap;
+    *grow = pm->total > g->probe_point_cap;
+    return IVX_OK;
+}
+// grow the point buffers of the listed jobs, keeping what is there: the copies of all, one wait, then the old buffers go
+static int probe_sync_grow(ProbeSyncJob* const* jobs, size_t n) {
+    if (n == 0) return IVX_OK;
+    std::vector<GrowKeep> pending;
+    std::vector<size_t> caps(n);
+    int rc;
+    for (size_t i = 0; i < n; ++i) {
+        ivx_grid* g = jobs[i]->g;
+        const size_t total = g->probe_manager->total;
+        caps[i] = std::max<size_t>(total + total / 2 + 4096, 2 * g->probe_point_cap);
+        if ((rc = grow_keep_enqueue(g, &g->probe_points, g->probe_point_cap * 3, caps[i] * 3, pending, 0u))) return rc;
+        if ((rc = grow_keep_enqueue(g, &g->probe_chunk, g->probe_point_cap, caps[i], pending, 0u))) return rc;
     }
-    for (const auto& r : freed)  // holes read as "no probe" until a later chunk takes them (the gather below overwrites what was taken now)
-        IVX_HIP_CHECK(ivx_memset_async(g->probe_chunk + r.first, 0xFF, (size_t)(r.second - r.first) * 4, g->ctx->stream));
-    if (n_rec) {
-        if ((rc = h2d(g, base + off_dst, dst.data(), (size_t)n_rec * 4))) return rc;
-        if ((rc = ivx_launch_probe_gather(g, n_rec, log2_bs, reinterpret_cast<uint32_t*>(base + off_sel), reinterpret_cast<uint32_t*>(base + off_counts),
-                                          reinterpret_cast<uint32_t*>(base + off_dst), nullptr, reinterpret_cast<const uint32_t*>(base + off_slots))))
+    IVX_HIP_CHECK(ivx_stream_sync(jobs[0]->g->ctx->stream));
+    for (GrowKeep& k : pending) {
+        if (*k.slot) (void)hipFree(*k.slot);
+        *k.slot = k.fresh;
+    }
+    for (size_t i = 0; i < n; ++i) jobs[i]->g->probe_point_cap = caps[i];
+    return IVX_OK;
+}
+static int probe_sync_gather(ProbeSyncJob& j) {
+    ivx_grid* g = j.g;
+    int rc;
+    for (const auto& r : j.freed) {  // holes read as "no probe" until a later chunk takes them (the gather below overwrites what was taken now)
+        const size_t bytes = (size_t)(r.second - r.first) * 4;
+        if (!ivx_many_fill(g->ctx, g, g->probe_chunk + r.first, 0xFFFFFFFFu, bytes)) IVX_HIP_CHECK(ivx_memset_async(g->probe_chunk + r.first, 0xFF, bytes, g->ctx->stream));
+    }
+    if (j.n_rec) {
+        if (!ivx_many_upload(g->ctx, g, j.base + j.off_dst, j.dst.data(), (size_t)j.n_rec * 4) && (rc = h2d(g, j.base + j.off_dst, j.dst.data(), (size_t)j.n_rec * 4)))
+            return rc;
+        if ((rc = ivx_launch_probe_gather(g, j.n_rec, j.log2_bs, reinterpret_cast<uint32_t*>(j.base + j.off_sel), reinterpret_cast<uint32_t*>(j.base + j.off_counts),
+                                          reinterpret_cast<uint32_t*>(j.base + j.off_dst), nullptr, reinterpret_cast<const uint32_t*>(j.base + j.off_slots))))
             return rc;
     }
+    return IVX_OK;
+}
+extern "C" {
+int ivx_collision_probes_sync(ivx_grid* g, const uint8_t* invalidated_chunks, size_t* n_points) {
+    const char* who = "ivx_collision_probes_sync";
+    IVX_REQUIRE(g && invalidated_chunks && n_points, IVX_ERR_INVALID, "%s: null argument", who);
+    IVX_REQUIRE(!ivx_many_recording(), IVX_ERR_STATE, "%s: not inside an ivx_many_begin bracket (the call waits for the device twice)", who);
+    ProbeSyncJob j;
+    int rc;
+    if ((rc = probe_sync_prepare(g, invalidated_chunks, who, j))) return rc;
+    std::vector<uint32_t> counts(j.n_rec);
+    if (j.n_rec) {
+        uint32_t* d_err = reinterpret_cast<uint32_t*>(j.base + j.off_err);
+        IVX_HIP_CHECK(ivx_memset_async(d_err, 0, 4, g->ctx->stream));
+        if ((rc = probe_sync_select(j, d_err, nullptr))) return rc;
+        if ((rc = d2h(g, counts.data(), j.base + j.off_counts, (size_t)j.n_rec * 4))) return rc;
+        uint32_t err = 0;
+        if ((rc = d2h(g, &err, d_err, 4))) return rc;
+        IVX_REQUIRE(err == 0, IVX_ERR_CAPACITY, "%s: a chunk submesh holds more vertices than a Surface Nets chunk can", who);
+    }
+    bool grow = false;
+    if ((rc = probe_sync_allocate(j, counts.data(), who, &grow))) return rc;
+    ProbeSyncJob* one = &j;
+    if (grow && (rc = probe_sync_grow(&one, 1))) return rc;
+    if ((rc = probe_sync_gather(j))) return rc;
     IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
-    g->n_probe_points = (uint32_t)pm->total;
+    g->n_probe_points = (uint32_t)g->probe_manager->total;
     g->probes_serial = g->mesh_serial;
-    *n_points = pm->total;
+    *n_points = g->probe_manager->total;
+    return IVX_OK;
+}
+
+// The same for N objects of one context in the launches of one (many.hpp) — every voxel object's probes follow its mesh each frame
+// (impact_voxel/src/lib.rs:729-733 with collidable.rs:394-433) —: the select passes of all objects merged, their counts and error words written
+// into host-mapped memory, ONE wait; the allocators of all objects on the host; the fills and gathers of all objects merged, ONE wait.
+int ivx_collision_probes_sync_many(ivx_grid* const* grids, size_t n, const uint8_t* const* invalidated_chunks, size_t* n_points) {
+    const char* who = "ivx_collision_probes_sync_many";
+    if (n == 0) return IVX_OK;
+    IVX_REQUIRE(grids && invalidated_chunks && n_points, IVX_ERR_INVALID, "%s: null argument", who);
+    int rc = many_check(grids, n, who);
+    if (rc) return rc;
+    IVX_REQUIRE(!ivx_many_recording(), IVX_ERR_STATE, "%s: not inside an ivx_many_begin bracket (the call waits for its own phases)", who);
+    ivx_ctx* c = grids[0]->ctx;
+    static thread_local std::vector<ProbeSyncJob> jobs;
+    if (jobs.size() < n) jobs.resize(n);
+    size_t words = 0;
+    static thread_local std::vector<size_t> off;
+    off.assign(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+        if ((rc = probe_sync_prepare(grids[i], invalidated_chunks[i], who, jobs[i]))) return rc;
+        off[i] = n + words;  // [error word per object][counts of every object]
+        words += jobs[i].n_rec;
+    }
+    if ((rc = ctx_pinned_scratch(c, (n + words) * 4 + 64))) return rc;
+    uint32_t* host = static_cast<uint32_t*>(c->pinned_scratch);
+    uint32_t* host_dev = static_cast<uint32_t*>(c->pinned_scratch_dev);
+    memset(host, 0, (n + words) * 4);
+    if (words) {
+        if ((rc = many_phase(grids, n, [&](size_t i) -> int { return probe_sync_select(jobs[i], host_dev + i, host_dev + off[i]); }))) return many_fail(grids, n, rc);
+        IVX_HIP_CHECK(ivx_stream_sync(c->stream));
+    }
+    for (size_t i = 0; i < n; ++i)
+        IVX_REQUIRE(host[i] == 0, IVX_ERR_CAPACITY, "%s: object %zu: a chunk submesh holds more vertices than a Surface Nets chunk can", who, i);
+    static thread_local std::vector<ProbeSyncJob*> growing;
+    growing.clear();
+    for (size_t i = 0; i < n; ++i) {
+        bool grow = false;
+        if ((rc = probe_sync_allocate(jobs[i], host + off[i], who, &grow))) return rc;
+        if (grow) growing.push_back(&jobs[i]);
+    }
+    if ((rc = probe_sync_grow(growing.data(), growing.size()))) return rc;
+    if ((rc = many_phase(grids, n, [&](size_t i) -> int { return probe_sync_gather(jobs[i]); }))) return many_fail(grids, n, rc);
+    IVX_HIP_CHECK(ivx_stream_sync(c->stream));
+    for (size_t i = 0; i < n; ++i) {
+        ivx_grid* g = grids[i];
+        g->n_probe_points = (uint32_t)g->probe_manager->total;
+        g->probes_serial = g->mesh_serial;
+        n_points[i] = g->probe_manager->total;
+    }
     return IVX_OK;
 }
 

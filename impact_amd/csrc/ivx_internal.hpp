@@ -448,7 +448,7 @@ void ivx_probe_manager_free(struct ivx_probe_manager* m);
 int ivx_launch_sn_emit_list(ivx_grid* g, uint32_t n_records, const uint32_t* d_count, const void* d_records, const uint32_t* d_slots, uint32_t n_patch = 0,
                             const void* d_patch_entries = nullptr, const uint32_t* d_patch_slots = nullptr);
 int ivx_launch_probe_select(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, uint32_t* d_corner_list, uint32_t* d_sel, uint32_t* d_counts, uint32_t* d_offsets,
-                            uint32_t* d_err, const uint32_t* d_slots);
+                            uint32_t* d_err, const uint32_t* d_slots, uint32_t* d_counts_host = nullptr);
 int ivx_launch_probe_gather(ivx_grid* g, uint32_t n_sub, uint32_t log2_bs, const uint32_t* d_sel, const uint32_t* d_counts, const uint32_t* d_offsets,
                             uint32_t* d_entries, const uint32_t* d_slots);
 int ivx_launch_mutual_pass(ivx_grid* prober, ivx_grid* sampled, const ivx_mutual_pass* h, uint32_t* d_counts, const uint32_t* d_offsets, ivx_contact* d_out,

@@ -22,12 +22,13 @@ struct RangeArgs {  // IVX_MK_ZERO / IVX_MK_UPLOAD
     uint32_t* dst;
     const uint32_t* src;
     unsigned long long words;
+    uint32_t fill, pad;  // (no src: the word every element gets)
 };
 __global__ __launch_bounds__(256) void k_range_many(const RangeArgs* __restrict__ argv, const uint32_t* __restrict__ block_end, uint32_t n) {
     const uint32_t i = ivx_many_find(block_end, n, blockIdx.x);
     const uint32_t b0 = i ? block_end[i - 1u] : 0u, nb = block_end[i] - b0, bid = blockIdx.x - b0;
     const RangeArgs a = argv[i];
-    for (unsigned long long w = (unsigned long long)bid * 256u + threadIdx.x; w < a.words; w += (unsigned long long)nb * 256u) a.dst[w] = a.src ? a.src[w] : 0u;
+    for (unsigned long long w = (unsigned long long)bid * 256u + threadIdx.x; w < a.words; w += (unsigned long long)nb * 256u) a.dst[w] = a.src ? a.src[w] : a.fill;
 }
 int many_range(hipStream_t s, const void* d_argv, const uint32_t* d_block_end, uint32_t n, uint32_t total) {
     hipLaunchKernelGGL(k_range_many, dim3(total), dim3(256), 0, s, static_cast<const RangeArgs*>(d_argv), d_block_end, n);
@@ -266,13 +267,14 @@ void ivx_many_release(ivx_ctx* c) {
     c->many_recorder = nullptr;
 }
 
-static bool capture_range(const ivx_ctx* c, const void* owner, int kernel, void* d_dst, const void* h_src, size_t bytes) {
+static bool capture_range(const ivx_ctx* c, const void* owner, int kernel, void* d_dst, const void* h_src, size_t bytes, uint32_t fill = 0u) {
     Recorder* r = t_rec;
     if (!r || !r->on || (bytes & 3u) || bytes == 0 || bytes > (64u << 20)) return false;
     RangeArgs a;
     a.dst = static_cast<uint32_t*>(d_dst);
     a.src = nullptr;
     a.words = bytes / 4;
+    a.fill = fill, a.pad = 0;
     const uint32_t blocks = (uint32_t)std::min<size_t>((a.words + 1023) / 1024, 64);
     if (!ivx_many_capture(c, owner, kernel, blocks, &a, (uint32_t)sizeof(a))) return false;
     Entry& e = r->chains[r->cur].back();
@@ -286,6 +288,9 @@ static bool capture_range(const ivx_ctx* c, const void* owner, int kernel, void*
     return true;
 }
 bool ivx_many_zero(const ivx_ctx* c, const void* owner, void* d_ptr, size_t bytes) { return capture_range(c, owner, IVX_MK_ZERO, d_ptr, nullptr, bytes); }
+bool ivx_many_fill(const ivx_ctx* c, const void* owner, void* d_ptr, uint32_t word, size_t bytes) {
+    return capture_range(c, owner, IVX_MK_ZERO, d_ptr, nullptr, bytes, word);
+}
 bool ivx_many_upload(const ivx_ctx* c, const void* owner, void* d_dst, const void* h_src, size_t bytes) {
     return capture_range(c, owner, IVX_MK_UPLOAD, d_dst, h_src, bytes);
 }

@@ -42,7 +42,10 @@ enum ivx_many_kernel : int {
     IVX_MK_SCAN_COUNTS,  // contacts between two voxel objects: count (probes of one against the other's field) | scan | emit (collide.hip)
     IVX_MK_MUT_COUNT,
     IVX_MK_MUT_EMIT,
-    IVX_MK_ZERO,    // fill a device range with zeros (the twin of a hipMemsetAsync(..., 0, ...))
+    IVX_MK_PROBE_SELECT_SMALL,  // collision probes of the listed chunk submeshes: select (two LDS sizes) | gather (collide.hip)
+    IVX_MK_PROBE_SELECT_FULL,
+    IVX_MK_PROBE_GATHER,
+    IVX_MK_ZERO,    // fill a device range with one word (the twin of a hipMemsetAsync of 0x00 or 0xFF bytes)
     IVX_MK_UPLOAD,  // host words to a device range (the twin of a small hipMemcpyAsync host -> device): the words ride in the flush's one staging copy
     IVX_MK_COUNT
 };
@@ -84,6 +87,7 @@ void ivx_many_object(uint32_t i);
 // zero `bytes` (a multiple of 4) at d_ptr / copy `bytes` (a multiple of 4) from host memory to d_dst: recorded when a batch is being recorded
 // on context `c` (true), else the caller issues the stream operation itself
 bool ivx_many_zero(const ivx_ctx* c, const void* owner, void* d_ptr, size_t bytes);
+bool ivx_many_fill(const ivx_ctx* c, const void* owner, void* d_ptr, uint32_t word, size_t bytes);  // (every 4-byte word of the range = `word`)
 bool ivx_many_upload(const ivx_ctx* c, const void* owner, void* d_dst, const void* h_src, size_t bytes);
 
 template <typename A>

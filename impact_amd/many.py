@@ -81,6 +81,21 @@ def mesh_sync_many(meshes, invalidated):
     return meshes
 
 
+def collision_probes_sync_many(objects, invalidated):
+    """`ivx_collision_probes_sync_many`: `VoxelObject.collision_probes_sync` of every object with its own invalidated set (the sets its mesh was
+    synced with) -> the lengths of the point buffers"""
+    n = len(objects)
+    inv = [a if (isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]) else np.ascontiguousarray(np.asarray(a).reshape(-1), dtype=np.uint8)
+           for a in invalidated]
+    for a, o in zip(inv, objects):
+        assert a.size == o.n_chunks
+    iv = np.fromiter((a.__array_interface__["data"][0] for a in inv), dtype=np.uint64, count=n)
+    out = np.zeros(n, dtype=np.uint64)
+    assert np.dtype(np.uintp).itemsize == 8
+    check(capi.lib().ivx_collision_probes_sync_many(ptr(_handles(objects)) if n else None, n, ptr(iv) if n else None, ptr(out)))
+    return out
+
+
 def collidable_queries(n: int) -> np.ndarray:
     """`n` zeroed `ivx_collidable_query` records (mode 0 sphere: shape3 centre, shape1 radius; 1 plane: shape3 unit normal, shape1 displacement;
     2 capsule: shape3 segment start, shape3b segment vector, shape1 radius; rotation / translation: the object's transform_to_object_space)"""
@@ -89,16 +104,28 @@ def collidable_queries(n: int) -> np.ndarray:
     return q
 
 
+_contact_buffers = {}
+
+
+def _contact_buffer(capacity: int) -> np.ndarray:
+    """the list a contact call writes into, kept between calls (a fresh 16 MB array per call costs more than the call: the C side fills the
+    first n records, the caller gets a copy of those)"""
+    buf = _contact_buffers.get(capacity)
+    if buf is None:
+        buf = _contact_buffers[capacity] = np.empty(capacity, dtype=capi.CONTACT_DTYPE)
+    return buf
+
+
 def voxel_object_contacts_many(objects, queries, capacity: int = 1 << 18):
     """`ivx_voxel_object_contacts_many`: collidable i against object i for all objects in the launches of one -> (contacts, offsets): object i's
     contacts are contacts[offsets[i]:offsets[i + 1]], as the single-object `sphere_contacts` / `plane_contacts` / `capsule_contacts` return them"""
     n = len(objects)
     assert len(queries) == n and queries.dtype == capi.COLLIDABLE_QUERY_DTYPE
-    out = np.zeros(capacity, dtype=capi.CONTACT_DTYPE)
+    out = _contact_buffer(capacity)
     offsets = np.zeros(n + 1, dtype=np.uint32)
     q = np.ascontiguousarray(queries)
     check(capi.lib().ivx_voxel_object_contacts_many(ptr(_handles(objects)) if n else None, n, ptr(q) if n else None, ptr(out), capacity, ptr(offsets)))
-    return out[: int(offsets[n])], offsets
+    return out[: int(offsets[n])].copy(), offsets
 
 
 def mutual_queries(pairs) -> np.ndarray:
@@ -120,8 +147,8 @@ def mutual_voxel_object_contacts_many(queries, capacity: int = 1 << 18):
     contacts[offsets[i]:offsets[i + 1]], as `VoxelObject.mutual_contacts` returns it"""
     n = len(queries)
     assert queries.dtype == capi.MUTUAL_QUERY_DTYPE
-    out = np.zeros(capacity, dtype=capi.CONTACT_DTYPE)
+    out = _contact_buffer(capacity)
     offsets = np.zeros(n + 1, dtype=np.uint32)
     q = np.ascontiguousarray(queries)
     check(capi.lib().ivx_mutual_voxel_object_contacts_many(ptr(q) if n else None, n, ptr(out), capacity, ptr(offsets)))
-    return out[: int(offsets[n])], offsets
+    return out[: int(offsets[n])].copy(), offsets

@@ -589,6 +589,9 @@ int ivx_collision_probes_recompute(ivx_grid*, size_t* n_points);
  * the end (RangeAllocator); chunks are visited in chunk-linear order (the reference's hash-set order is unpinned). n_points = length of the buffer,
  * freed ranges included. */
 int ivx_collision_probes_sync(ivx_grid*, const uint8_t* invalidated_chunks, size_t* n_points);
+/* ivx_collision_probes_sync for N objects of one context in merged launches (cf. ivx_mesh_sync_many, whose invalidated sets these are): the select
+ * passes of all objects, one wait, the range allocators on the host, the gathers of all objects, one wait. n_points: one length per object. */
+int ivx_collision_probes_sync_many(ivx_grid* const* grids, size_t n, const uint8_t* const* invalidated_chunks, size_t* n_points);
 int ivx_collision_probes_download(ivx_grid*, float* points, size_t cap_points, uint32_t* chunk_entries, size_t cap_entries, size_t* n_points,
                                   size_t* n_entries);
 /* for_each_mutual_voxel_object_contact (collidable.rs:859-1049): the probes of A inside the voxel ranges where the two occupied boxes can overlap

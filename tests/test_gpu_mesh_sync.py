@@ -153,6 +153,68 @@ def test_probes_follow_the_incremental_remesh_and_feed_the_mutual_contacts(ctx):
     b_g.close()
 
 
+def test_probes_of_many_objects_follow_their_meshes(ctx):
+    """ivx_collision_probes_sync_many: four objects of different sizes (block sizes 8 and 4, one with buffers that must grow, one whose round
+    invalidates nothing), three rounds of absorb -> mesh sync -> probe sync for all in one call; entries and live points of every object equal
+    the oracle's after every round, and equal what the single-object call leaves on a twin of the object"""
+    from impact_amd import many
+
+    specs = [(scenes.sphere_scene(30.0), 1.0), (scenes.box_scene((9.0, 12.0, 20.0)), 1.0), (scenes.asteroid_scene(0.4), 1.0), (scenes.sphere_scene(20.0), 1.0)]
+    objs = [both(ctx, gr, ex) for gr, ex in specs]
+    twins = [both(ctx, gr, ex)[1] for gr, ex in specs]
+    oms = [ol.OracleMeshHandle(o) for o, _ in objs]
+    ops = [ol.OracleProbes(om) for om in oms]
+    gms = [VoxelObjectMesh.create(g) for _, g in objs]
+    tms = [VoxelObjectMesh.create(t) for t in twins]
+    for (_, g), t in zip(objs, twins):
+        g.collision_probes_recompute()
+        t.collision_probes_recompute()
+    ctrs = [np.array([0.5 * (a + b) for a, b in o.info()["occupied_voxel_ranges"]], dtype=np.float32) for o, _ in objs]
+    half = [np.array([0.5 * (b - a) for a, b in o.info()["occupied_voxel_ranges"]], dtype=np.float32) for o, _ in objs]
+    for rnd, (frac, r) in enumerate([(1.0, 5.0), (0.8, 9.0), (0.6, 4.0)]):
+        inv = []
+        for i, ((o, g), t) in enumerate(zip(objs, twins)):
+            c = ctrs[i] + np.float32(frac) * half[i] * np.array([0.0, 0.0, 1.0], np.float32)
+            rr = np.float32(r if i != 1 else 2.0)
+            if i == 3 and rnd == 1:
+                c = ctrs[i] + np.float32(100.0)  # far away: nothing invalidated this round
+            ro, rg, rt = o.absorb_sphere(c, rr + 2.0, rr), g.absorb_sphere(c, rr + 2.0, rr), t.absorb_sphere(c, rr + 2.0, rr)
+            np.testing.assert_array_equal(rg["invalidated"], ro["invalidated"])
+            oms[i].sync(ro["invalidated"])
+            ops[i].sync(ro["invalidated"])
+            tms[i].sync_with_voxel_object(rt["invalidated"])
+            t.collision_probes_sync(rt["invalidated"])
+            inv.append(rg["invalidated"])
+        many.mesh_sync_many(gms, inv)
+        st0 = np.zeros(3, dtype=np.uint64)
+        st1 = np.zeros(3, dtype=np.uint64)
+        capi.check(capi.lib().ivx_many_stats(ctx.h, capi.ptr(st0)))
+        ns = many.collision_probes_sync_many([g for _, g in objs], inv)
+        capi.check(capi.lib().ivx_many_stats(ctx.h, capi.ptr(st1)))
+        rec, iss = int(st1[0] - st0[0]), int(st1[1] - st0[1])
+        assert rec >= 3 * iss // 2 and iss <= 9, (rec, iss)  # (upload | select x2 merged over the objects, then fills | upload | gather)
+        for i, ((o, g), t) in enumerate(zip(objs, twins)):
+            want_pts, want_ent = ops[i].get()
+            got_pts, got_ent = g.collision_probes()
+            assert int(ns[i]) == len(want_pts) == len(got_pts), (rnd, i)
+            np.testing.assert_array_equal(got_ent, want_ent)
+            for e in want_ent:
+                np.testing.assert_array_equal(got_pts[e[3]:e[4]].view(np.uint32), want_pts[e[3]:e[4]].view(np.uint32))
+            tw_pts, tw_ent = t.collision_probes()
+            np.testing.assert_array_equal(got_ent, tw_ent)
+            assert len(tw_pts) == len(got_pts)
+    assert sum(len(ops[i].get()[1]) for i in range(4)) > 30
+    # the empty list, and an object listed twice
+    from impact_amd.capi import IvxError
+
+    assert len(many.collision_probes_sync_many([], [])) == 0
+    with pytest.raises(IvxError):
+        many.collision_probes_sync_many([objs[0][1], objs[0][1]], [inv[0], inv[0]])
+    for (_, g), t in zip(objs, twins):
+        g.close()
+        t.close()
+
+
 def test_edit_and_sync_in_two_halves(ctx):
     """ivx_absorb_sphere_enqueue / ivx_absorb_collect and ivx_mesh_sync_enqueue / _collect: the edit's kernels, the sweep over the touched
     chunks and their neighbours, the region resolve and the count of what the invalidated meshes need on the stream behind ONE wait; the sync
