@@ -187,7 +187,7 @@ EXPORTED_SYMBOLS = [
     "ivx_world_set_spherical_joints", "ivx_world_step", "ivx_world_step_enqueue", "ivx_world_prepare", "ivx_world_advance_momenta", "ivx_world_solve", "ivx_world_advance_configurations",
     "ivx_impact_fracturing_config_default", "ivx_generate_impact_fracture_points", "ivx_delaunay_construct", "ivx_delaunay_destroy", "ivx_delaunay_counts",
     "ivx_delaunay_download", "ivx_delaunay_aabb", "ivx_delaunay_displace_vertices", "ivx_delaunay_boundary_face_planes", "ivx_voronoi_polyhedron", "ivx_voronoi_bounded_aabb",
-    "ivx_comm_unique_id", "ivx_comm_init", "ivx_comm_init_local", "ivx_comm_init_ipc", "ivx_comm_info", "ivx_comm_selftest", "ivx_selftest_mesher_division", "ivx_comm_destroy", "ivx_slab_create", "ivx_slab_destroy",
+    "ivx_comm_unique_id", "ivx_comm_init", "ivx_comm_init_local", "ivx_comm_init_ipc", "ivx_comm_info", "ivx_comm_set_local_copies", "ivx_comm_selftest", "ivx_selftest_mesher_division", "ivx_comm_destroy", "ivx_slab_create", "ivx_slab_destroy",
     "ivx_slabs_step_enqueue", "ivx_slabs_step_collect", "ivx_slab_region_map",
     "ivx_world_set_solver_groups", "ivx_world_solver_info", "ivx_world_contact_state",
 ]
@@ -359,6 +359,7 @@ def lib():
         "ivx_mesh_import_open": (i32, [vp, i32, C.POINTER(vp)]),
         "ivx_mesh_import_close": (i32, [vp]),
         "ivx_comm_info": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+        "ivx_comm_set_local_copies": (i32, [vp, i32]),
         "ivx_comm_selftest": (i32, [vp]),
         "ivx_selftest_mesher_division": (i32, [vp, C.POINTER(u32)]),
         "ivx_comm_destroy": (None, [vp]),

@@ -123,11 +123,13 @@ __global__ __launch_bounds__(256) void k_halo_pack_both(GridView g, uint8_t* __r
     const size_t cols = (size_t)g.cy * g.cz;
     const uint32_t chunk = (side ? g.cx - 1 : 0u) * g.cy * g.cz + col;
     const size_t src = (size_t)chunk * IVX_CHUNK_VOXELS + ((side ? 15u : 0u) << 8) + tid;
-    const ivx_chunk_info rec = g.info[chunk];
-    const bool dense = rec.kind == KIND_NONUNIFORM;
-    out[(size_t)col * 256 + tid] = dense ? (uint8_t)g.sdf[src] : (uint8_t)ivx_uniform_sdf(rec.kind);
-    out[cols * 256 + (size_t)col * 256 + tid] = dense ? g.type[src] : (uint8_t)ivx_uniform_type(rec);
-    if (tid == 0) reinterpret_cast<ivx_chunk_info*>(out + cols * 512)[col] = rec;
+    if (!(with_ids & 2u)) {  // (2: the ids alone — the planes went ahead, slab_comm.cpp)
+        const ivx_chunk_info rec = g.info[chunk];
+        const bool dense = rec.kind == KIND_NONUNIFORM;
+        out[(size_t)col * 256 + tid] = dense ? (uint8_t)g.sdf[src] : (uint8_t)ivx_uniform_sdf(rec.kind);
+        out[cols * 256 + (size_t)col * 256 + tid] = dense ? g.type[src] : (uint8_t)ivx_uniform_type(rec);
+        if (tid == 0) reinterpret_cast<ivx_chunk_info*>(out + cols * 512)[col] = rec;
+    }
     if (with_ids)
         reinterpret_cast<uint16_t*>(out + cols * (512 + sizeof(ivx_chunk_info)))[(size_t)col * 256 + tid] =
             (uint16_t)face_id16(g, side, col, tid, labels, rcompid, rscalar);
@@ -350,6 +352,17 @@ int ivx_launch_halo_pack_both(ivx_grid* g, void* buf_lo, void* buf_hi, int with_
                        (with_face_labels && g->pairs_dev) ? g->pairs_dev : nullptr);
     IVX_HIP_CHECK(hipGetLastError());
     g->pairs_zeroed = (with_face_labels && g->pairs_dev) ? 1 : 0;
+    return IVX_OK;
+}
+
+int ivx_launch_halo_pack_parts(ivx_grid* g, void* buf_lo, void* buf_hi, uint32_t what) {
+    if (what == 3u) return ivx_launch_halo_pack_both(g, buf_lo, buf_hi, 1);
+    if (what == 1u) return ivx_launch_halo_pack_both(g, buf_lo, buf_hi, 0);
+    GridView v = ivx_view(g);
+    IVX_KLAUNCH(k_halo_pack_both, dim3(g->cc[1] * g->cc[2], 2), dim3(256), 0, g->ctx->stream, v, static_cast<uint8_t*>(buf_lo), static_cast<uint8_t*>(buf_hi), 2u, g->llabel,
+                g->rcompid, g->rscalar, g->pairs_dev ? g->pairs_dev : nullptr);
+    IVX_HIP_CHECK(hipGetLastError());
+    g->pairs_zeroed = g->pairs_dev ? 1 : 0;
     return IVX_OK;
 }
 

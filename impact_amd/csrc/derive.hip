@@ -74,7 +74,29 @@ struct ChunkPreArgs {
     uint32_t* next_work_count;
     uint32_t* active_list;
     ivx_roles::PresetArgs preset;
+    // (slab protocol, the sweep split around the arrival of the ghost layers) 1: a Uniform chunk of a face plane that only the ghost layer's
+    // record can settle is left PENDING (class 2: neither settled nor listed) for k_face_settle, which runs behind the wait
+    uint32_t defer_ghost, pad_;
 };
+// the record of a chunk that needs no sweep: Void, or Uniform among Uniform neighbours
+__device__ __forceinline__ void chunk_settle(const GridView& g, const ChunkPreArgs& a, uint32_t chunk, const ivx_chunk_info& own) {
+    const uint32_t gen = own.gen_kind;
+    const bool solid = gen == KIND_UNIFORM;
+    ivx_chunk_info rec = own;
+    rec.kind = (uint8_t)gen;
+    rec.flags = 0;
+    rec.face_dist = solid ? 0x555 : 0;
+    // a chunk demoted by an earlier pass has its planes written out and its record's type cleared
+    rec.uniform_type = solid ? (own.kind == KIND_NONUNIFORM ? g.type[(size_t)chunk * IVX_CHUNK_VOXELS] : own.uniform_type) : (uint8_t)0;
+    rec.region_count = solid ? 1 : 0;
+    rec.boundary_region_count = solid ? 1 : 0;
+    a.info[chunk] = rec;
+    a.bbox[chunk] = solid ? (0x80000000u | (15u << 4) | (15u << 12) | (15u << 20)) : 0u;
+    a.mesh_counts[2 * chunk] = 0;
+    a.mesh_counts[2 * chunk + 1] = 0;
+    a.touch[chunk] = solid ? 7 : 0;  // a settled solid chunk touches its three upper neighbours (all solid)
+    if (solid) a.rparent[(size_t)chunk * 256] = chunk * 256u;  // its one region: its own node until the merge pass links it
+}
 __device__ __forceinline__ void chunk_pre_body(const ChunkPreArgs& a, uint32_t bid, uint32_t) {
     const GridView& g = a.g;
     ivx_chunk_info* __restrict__ info = a.info;
@@ -96,7 +118,7 @@ __device__ __forceinline__ void chunk_pre_body(const ChunkPreArgs& a, uint32_t b
     const uint32_t n_chunks = g.cx * g.cy * g.cz;
     const uint32_t chunk = bid * 256u + tid;
     const bool live = chunk < n_chunks;
-    bool settled = false;
+    bool settled = false, pending = false;
     if (live) {
         const ivx_chunk_info own = info[chunk];
         const uint32_t gen = own.gen_kind;
@@ -107,36 +129,22 @@ __device__ __forceinline__ void chunk_pre_body(const ChunkPreArgs& a, uint32_t b
                 const uint32_t sx = g.cy * g.cz, sy = g.cz;
                 // across a slab face the neighbour is the ghost layer's chunk record (a slab is a few chunk planes thick: without
                 // this a quarter of a solid body's chunks would go the long way); at the end of the grid there is none
-                const bool x_lo = ci > 0 ? info[chunk - sx].gen_kind == KIND_UNIFORM
-                                         : (g.ghost_info[0] != nullptr && g.ghost_info[0][cj * g.cz + ck].gen_kind == KIND_UNIFORM);
-                const bool x_hi = ci + 1 < (int)g.cx ? info[chunk + sx].gen_kind == KIND_UNIFORM
-                                                     : (g.ghost_info[1] != nullptr && g.ghost_info[1][cj * g.cz + ck].gen_kind == KIND_UNIFORM);
+                const bool ghost_lo = ci == 0 && g.ghost_info[0] != nullptr, ghost_hi = ci + 1 == (int)g.cx && g.ghost_info[1] != nullptr;
+                const bool defer = a.defer_ghost != 0u && (ghost_lo || ghost_hi);
+                const bool x_lo = ci > 0 ? info[chunk - sx].gen_kind == KIND_UNIFORM : (ghost_lo && (defer || g.ghost_info[0][cj * g.cz + ck].gen_kind == KIND_UNIFORM));
+                const bool x_hi =
+                    ci + 1 < (int)g.cx ? info[chunk + sx].gen_kind == KIND_UNIFORM : (ghost_hi && (defer || g.ghost_info[1][cj * g.cz + ck].gen_kind == KIND_UNIFORM));
                 settled = x_lo && x_hi && info[chunk - sy].gen_kind == KIND_UNIFORM && info[chunk + sy].gen_kind == KIND_UNIFORM &&
                           info[chunk - 1].gen_kind == KIND_UNIFORM && info[chunk + 1].gen_kind == KIND_UNIFORM;
+                if (settled && defer) settled = false, pending = true;  // (all but the ghost layer's word: k_face_settle asks for that behind the wait)
             }
         }
-        if (settled) {
-            const bool solid = gen == KIND_UNIFORM;
-            ivx_chunk_info rec = own;
-            rec.kind = (uint8_t)gen;
-            rec.flags = 0;
-            rec.face_dist = solid ? 0x555 : 0;
-            // a chunk demoted by an earlier pass has its planes written out and its record's type cleared
-            rec.uniform_type = solid ? (own.kind == KIND_NONUNIFORM ? g.type[(size_t)chunk * IVX_CHUNK_VOXELS] : own.uniform_type) : (uint8_t)0;
-            rec.region_count = solid ? 1 : 0;
-            rec.boundary_region_count = solid ? 1 : 0;
-            info[chunk] = rec;
-            bbox[chunk] = solid ? (0x80000000u | (15u << 4) | (15u << 12) | (15u << 20)) : 0u;
-            mesh_counts[2 * chunk] = 0;
-            mesh_counts[2 * chunk + 1] = 0;
-            touch[chunk] = solid ? 7 : 0;  // a settled solid chunk touches its three upper neighbours (all solid)
-            if (solid) rparent[(size_t)chunk * 256] = chunk * 256u;  // its one region: its own node until the merge pass links it
-        }
-        chunk_class[chunk] = settled ? 1 : 0;
+        if (settled) chunk_settle(g, a, chunk, own);
+        chunk_class[chunk] = pending ? 2 : (settled ? 1 : 0);
     }
     // ordered append of this block's active chunks (one atomic per block; the list stays nearly sorted, so neighbouring
     // list entries are neighbouring chunks)
-    const bool active = live && !settled;
+    const bool active = live && !settled && !pending;
     const unsigned long long bal = __ballot(active);
     if (lane == 0) s_w[wave] = (uint32_t)__popcll(bal);
     __syncthreads();
@@ -151,6 +159,30 @@ __device__ __forceinline__ void chunk_pre_body(const ChunkPreArgs& a, uint32_t b
 __global__ __launch_bounds__(256) void k_chunk_pre(ChunkPreArgs a) { chunk_pre_body(a, blockIdx.x, gridDim.x); }
 IVX_MANY_TWIN(k_chunk_pre_many, ChunkPreArgs, chunk_pre_body, __launch_bounds__(256))
 IVX_MANY_LAUNCHER(many_chunk_pre, k_chunk_pre_many, ChunkPreArgs, 256)
+
+// (slab protocol) the chunks k_chunk_pre left pending, once the ghost layers are in: one thread per chunk of the two face planes. A pending chunk
+// whose ghost neighbour is Uniform is settled as k_chunk_pre would have settled it; any other joins the end of the active list — ahead of the
+// sweep's second part, which reads the list's length when it starts.
+__global__ __launch_bounds__(256) void k_face_settle(ChunkPreArgs a) {
+    const GridView& g = a.g;
+    const uint32_t cols = g.cy * g.cz, t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= 2u * cols) return;
+    const uint32_t side = t / cols, col = t % cols;
+    if (side == 1u && g.cx == 1u) return;  // (one plane: both its faces are thread `col` of side 0)
+    const uint32_t chunk = (side ? g.cx - 1u : 0u) * cols + col;
+    if (a.chunk_class[chunk] != 2) return;
+    const ivx_chunk_info own = a.info[chunk];
+    bool uniform = true;
+    if (chunk < cols && g.ghost_info[0]) uniform = uniform && g.ghost_info[0][col].gen_kind == KIND_UNIFORM;
+    if (chunk >= (g.cx - 1u) * cols && g.ghost_info[1]) uniform = uniform && g.ghost_info[1][col].gen_kind == KIND_UNIFORM;
+    if (uniform) {
+        chunk_settle(g, a, chunk, own);
+        a.chunk_class[chunk] = 1;
+    } else {
+        a.chunk_class[chunk] = 0;
+        a.active_list[atomicAdd(&a.work_counts[0], 1u)] = chunk;
+    }
+}
 
 // The global loads of a chunk's first phase, in flight: the chunk's own record and rows; across each z face one byte per thread; (threads
 // 0..63) one 16-byte row across an x or y face; the three neighbours' generated kinds. Addresses are clamped to valid ones and the
@@ -265,7 +297,7 @@ struct DeriveArgs {
     uint32_t* active_list;
     const uint32_t* list_in;
     DeriveFused fz;
-    uint32_t signs_type, pad_;
+    uint32_t signs_type, x_part;  // (x_part: IVX_XPART_*, the slab protocol's split around the arrival of the ghost layers)
     DeriveBox box;
 };
 template <bool SIGNS>
@@ -315,6 +347,7 @@ __device__ __forceinline__ void derive_body(const DeriveArgs& a_, uint32_t bid_,
         chunk = ((box.lo[0] + bi) * g.cy + (box.lo[1] + bj)) * g.cz + (box.lo[2] + bk);
     } else {
         chunk = IVX_LIST_CHUNK(list_in[li]);
+        if (ivx_xpart_skip(g, a_.x_part, chunk / (g.cz * g.cy))) continue;  // (the other part's chunk: workgroup-uniform)
     }
     DeriveLoads L;
     derive_issue<SIGNS>(g, info, chunk, tid, L);
@@ -806,14 +839,19 @@ int ivx_launch_derive(ivx_grid* g, uint32_t parts, uint32_t preset_groups) {
     g->wc_cur ^= 1u;
     // (the sampler's list counters have had their last reader by now: rolled over on the way, see role_preset)
     const uint32_t roll = ((g->scratch_dirty & IVX_SCRATCH_EVAL) && g->samp_len) ? IVX_SCRATCH_EVAL_ROLL : 0u;
+    ChunkPreArgs face_settle;  // (the arguments of k_face_settle: k_chunk_pre's)
     {
         ChunkPreArgs pa;
         memset(&pa, 0, sizeof(pa));
         pa.g = v, pa.info = g->info, pa.bbox = g->chunk_bbox, pa.mesh_counts = g->chunk_counts, pa.chunk_class = g->chunk_class, pa.touch = g->chunk_touch;
         pa.rparent = g->rparent, pa.work_counts = ivx_wc(g), pa.next_work_count = next_count, pa.active_list = g->active_list;
         pa.preset = ivx_preset_args(g, preset_groups | roll);
+        // (a slab whose ghost layers are still on their way, the sweep split around their arrival: this kernel runs ahead of the wait and must
+        // not look at the ghost layers' chunk records — a Uniform chunk of a face plane that only such a record can settle is left pending)
+        if (g->ghost_event && g->ghost_split && ivx_has_interior_planes(g)) pa.defer_ghost = 1u;
         const uint32_t blocks = (g->n_chunks + 255u) / 256u;
         if (!ivx_many_try(g->ctx, g, IVX_MK_CHUNK_PRE, blocks, pa)) IVX_KLAUNCH(k_chunk_pre, dim3(blocks), dim3(256), 0, g->ctx->stream, pa);
+        face_settle = pa;
     }
     g->scratch_dirty &= ~preset_groups;
     if (roll) g->scratch_dirty &= ~IVX_SCRATCH_EVAL;
@@ -832,11 +870,29 @@ int ivx_launch_derive(ivx_grid* g, uint32_t parts, uint32_t preset_groups) {
     }
     // (two forms of the sweep: from the sign rows the sampler left, while nothing else has rewritten voxels — no plane is read —, else from the planes)
     DeriveArgs da = derive_args(g, v, fz);
-    if (g->signs_current) {
-        da.signs_type = (uint32_t)g->signs_type;
-        if (!ivx_many_try(g->ctx, g, IVX_MK_DERIVE_SIGNS, derive_grid, da)) IVX_KLAUNCH(k_derive<true>, dim3(derive_grid), dim3(256), 0, g->ctx->stream, da);
+    if (g->signs_current) da.signs_type = (uint32_t)g->signs_type;
+    auto sweep = [&](uint32_t x_part) {
+        da.x_part = x_part;
+        if (g->signs_current) {
+            if (!ivx_many_try(g->ctx, g, IVX_MK_DERIVE_SIGNS, derive_grid, da)) IVX_KLAUNCH(k_derive<true>, dim3(derive_grid), dim3(256), 0, g->ctx->stream, da);
+        } else {
+            if (!ivx_many_try(g->ctx, g, IVX_MK_DERIVE_PLANES, derive_grid, da)) IVX_KLAUNCH(k_derive<false>, dim3(derive_grid), dim3(256), 0, g->ctx->stream, da);
+        }
+    };
+    if (g->ghost_event) {
+        // a slab whose ghost layers are still on their way (slab_comm.cpp: the exchange runs on the communicator's stream): the chunk planes
+        // that read nothing of them first, the stream then waits for the arrival, the planes beside the ghost layers last
+        const bool interior = g->ghost_split && ivx_has_interior_planes(g);
+        if (interior) sweep(IVX_XPART_INTERIOR);
+        (void)ivx_many_break();
+        // (IVX_DEBUG_SKIP_GHOST_WAIT: developer switch — the wait left out, to show that the slab tests notice, tools/slab_overlap_check.sh)
+        static const bool skip_wait = getenv("IVX_DEBUG_SKIP_GHOST_WAIT") && atoi(getenv("IVX_DEBUG_SKIP_GHOST_WAIT")) == 1;
+        if (!skip_wait) IVX_HIP_CHECK(hipStreamWaitEvent(g->ctx->stream, static_cast<hipEvent_t>(g->ghost_event), 0));
+        g->ghost_event = nullptr;
+        if (face_settle.defer_ghost) IVX_KLAUNCH(k_face_settle, dim3((2u * g->cc[1] * g->cc[2] + 255u) / 256u), dim3(256), 0, g->ctx->stream, face_settle);
+        sweep(interior ? IVX_XPART_FACES : IVX_XPART_ALL);
     } else {
-        if (!ivx_many_try(g->ctx, g, IVX_MK_DERIVE_PLANES, derive_grid, da)) IVX_KLAUNCH(k_derive<false>, dim3(derive_grid), dim3(256), 0, g->ctx->stream, da);
+        sweep(IVX_XPART_ALL);
     }
     g->active_list_stale = 0;
     g->planes_compact = 1;

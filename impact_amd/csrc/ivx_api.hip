@@ -1364,7 +1364,7 @@ int ivx_split_off_smallest_region(ivx_grid* parent, ivx_grid** child, uint32_t o
     return IVX_OK;
 }
 
-static int step_enqueue(ivx_grid* g, uint32_t stages, const uint16_t* slab_nbr_ids, void* slab_record);
+static int step_enqueue(ivx_grid* g, uint32_t stages, const uint16_t* slab_nbr_ids, void* slab_record, uint32_t part = 3u);
 static int ivx_step_collect_launch(ivx_grid* g);
 // The reference's split-off LOOP in one call (interaction.rs:256: `while let Some(..) = find_two_disconnected_regions` ->
 // extract the smaller of the FIRST TWO regions in scan order, extraction.rs:255-271): the regions of the object are described once; what a
@@ -3212,8 +3212,11 @@ int ivx_grid_set_densities(ivx_grid* g, const float densities[256]) {
 static int ensure_pairs(ivx_grid* g);
 // `slab_nbr_ids` / `slab_record`: the slab protocol's remesh phase (ivx_slab_remesh_enqueue) — the pass over the neighbour's face ids and the
 // slab's record ride in the phase's own launches instead of taking two more
-static int step_enqueue(ivx_grid* g, uint32_t stages, const uint16_t* slab_nbr_ids, void* slab_record) {
+// `part` (slab protocol, ivx_voxel_step_enqueue_part): bit 0 = the call's sample and derive sweeps, bit 1 = everything behind them; the two
+// halves of ONE call enqueued apart, so that the slab's face planes can be packed and sent between them.
+static int step_enqueue(ivx_grid* g, uint32_t stages, const uint16_t* slab_nbr_ids, void* slab_record, uint32_t part) {
     IVX_REQUIRE(g, IVX_ERR_INVALID, "ivx_voxel_step_enqueue: null grid");
+    const bool front = (part & 1u) != 0u, back = (part & 2u) != 0u;
     ivx_many_other_context other_(g->ctx);
     IVX_REQUIRE(!(stages & IVX_STAGE_SAMPLE) || g->prog_n > 0, IVX_ERR_STATE, "ivx_voxel_step: no SDF program resident (ivx_grid_set_sdf_program)");
     IVX_REQUIRE(!(stages & IVX_STAGE_INERTIA) || g->has_dens, IVX_ERR_STATE, "ivx_voxel_step: no densities resident (ivx_grid_set_densities)");
@@ -3236,24 +3239,26 @@ static int step_enqueue(ivx_grid* g, uint32_t stages, const uint16_t* slab_nbr_i
     // Scratch word groups the stages of this call start from. They are preset by the call's first kernel (k_sdf_super or
     // k_chunk_pre host that role); a call that starts with neither gets a preset launch of its own. Only the requested stages'
     // groups are touched: a phase of the multi-GPU protocol must not wipe what an earlier phase of the same step left.
-    uint32_t need = 0;
-    if (stages & IVX_STAGE_SAMPLE) need |= IVX_SCRATCH_EVAL;
-    if (stages & IVX_STAGE_REGIONS) need |= IVX_SCRATCH_REGIONS;
-    if (stages & IVX_STAGE_REMESH) need |= IVX_SCRATCH_SN;
-    // (ivx_step_preset_ahead: groups of the NEXT call, preset by this call's first kernel so that a call without one of its own — the
-    // remesh phase of the slab protocol — needs no preset launch)
-    const uint32_t fresh = g->preset_fresh;
-    g->preset_fresh = 0;
-    uint32_t ahead = 0;
-    if (stages & (IVX_STAGE_SAMPLE | IVX_STAGE_DERIVE)) {
-        ahead = g->preset_ahead & ~need;
-        g->preset_ahead = 0;
-    }
     uint32_t preset_in_sample = 0, preset_in_derive = 0;
-    if (stages & IVX_STAGE_SAMPLE) preset_in_sample = need | ahead;
-    else if (stages & IVX_STAGE_DERIVE) preset_in_derive = need | ahead;
-    else if ((rc = ivx_launch_step_preset(g, need & ~fresh))) return rc;
-    g->preset_fresh = ahead;
+    if (front) {  // (the second half of a call enqueued in two parts finds its groups preset by the first half's kernels)
+        uint32_t need = 0;
+        if (stages & IVX_STAGE_SAMPLE) need |= IVX_SCRATCH_EVAL;
+        if (stages & IVX_STAGE_REGIONS) need |= IVX_SCRATCH_REGIONS;
+        if (stages & IVX_STAGE_REMESH) need |= IVX_SCRATCH_SN;
+        // (ivx_step_preset_ahead: groups of the NEXT call, preset by this call's first kernel so that a call without one of its own — the
+        // remesh phase of the slab protocol — needs no preset launch)
+        const uint32_t fresh = g->preset_fresh;
+        g->preset_fresh = 0;
+        uint32_t ahead = 0;
+        if (stages & (IVX_STAGE_SAMPLE | IVX_STAGE_DERIVE)) {
+            ahead = g->preset_ahead & ~need;
+            g->preset_ahead = 0;
+        }
+        if (stages & IVX_STAGE_SAMPLE) preset_in_sample = need | ahead;
+        else if (stages & IVX_STAGE_DERIVE) preset_in_derive = need | ahead;
+        else if ((rc = ivx_launch_step_preset(g, need & ~fresh))) return rc;
+        g->preset_fresh = ahead;
+    }
     // a slot's duration runs from the stop event of the slot enqueued just before it, when there is one
     const uint32_t timing = ~g->stage_timing_off;  // slots with event records
     hipEvent_t* last_stop = nullptr;
@@ -3276,7 +3281,7 @@ static int step_enqueue(ivx_grid* g, uint32_t stages, const uint16_t* slab_nbr_i
     const uint32_t fused_parts = (stages & IVX_STAGE_DERIVE) ? (((stages & IVX_STAGE_REGIONS) ? IVX_PART_REGIONS : 0u) |
                                                                  ((stages & IVX_STAGE_INERTIA) ? IVX_PART_MOMENTS : 0u))
                                                               : 0u;
-    if (stages & IVX_STAGE_SAMPLE) {
+    if (front && (stages & IVX_STAGE_SAMPLE)) {
         T0(0);
         if ((rc = ivx_launch_sdf_sample(g, g->prog_nodes, g->prog_n, g->prog_stack, g->prog_shape, g->prog_center, g->prog_type, preset_in_sample, true))) return rc;
         T1(0);
@@ -3287,13 +3292,13 @@ static int step_enqueue(ivx_grid* g, uint32_t stages, const uint16_t* slab_nbr_i
         g->mesh_built = 0;  // a newly sampled object: whatever mesh the buffers hold is not a stale version of this one
         g->regions_valid = 0;
     }
-    if (stages & IVX_STAGE_DERIVE) {
+    if (front && (stages & IVX_STAGE_DERIVE)) {
         T0(1);
         if ((rc = ivx_launch_derive(g, fused_parts, preset_in_derive))) return rc;
         T1(1);
         if (g->eval_len_pending == 1) g->eval_len_pending = 2;
     }
-    const uint32_t post = stages & (IVX_STAGE_OCCUPIED | IVX_STAGE_REGIONS | IVX_STAGE_REMESH | IVX_STAGE_INERTIA);
+    const uint32_t post = back ? stages & (IVX_STAGE_OCCUPIED | IVX_STAGE_REGIONS | IVX_STAGE_REMESH | IVX_STAGE_INERTIA) : 0u;
     if (post) {
         // stages that were not swept inside k_derive get their stand-alone per-chunk kernels first (a call without the derive stage)
         if ((stages & IVX_STAGE_REGIONS) && !(fused_parts & IVX_PART_REGIONS)) {
@@ -3346,6 +3351,10 @@ static int step_enqueue(ivx_grid* g, uint32_t stages, const uint16_t* slab_nbr_i
 }
 
 int ivx_voxel_step_enqueue(ivx_grid* g, uint32_t stages) { return step_enqueue(g, stages, nullptr, nullptr); }
+}  // extern "C"
+// (slab_comm.cpp) one call's launches in two parts: 1 = its sample and derive sweeps, 2 = what follows them
+int ivx_voxel_step_enqueue_part(ivx_grid* g, uint32_t stages, uint32_t part) { return step_enqueue(g, stages, nullptr, nullptr, part); }
+extern "C" {
 
 // The remesh phase of the slab protocol in the step's own launches: count | — then scan | the component pairs across the upper x face (from
 // `neighbour_face_ids`, the ids behind the neighbour's face planes of the second exchange; null for the last slab) — then emit | the slab's

@@ -104,6 +104,11 @@ struct ivx_grid {
     ivx_chunk_info* ghost_info[2];
     uint32_t* ghost_rlabel[2];  // global region node of the neighbour's face voxel (0xFFFFFFFF empty)
     int has_ghost[2];
+    // (slab protocol) the event behind the exchange that fills the ghost layers, while nobody has waited for it yet: the next derive sweep /
+    // mesher count runs its ghost-free part, makes the stream wait, then runs the rest (a hipEvent_t of the communicator; null: nothing pending)
+    void* ghost_event;
+    int ghost_split;         // ... in two parts around the wait (else the wait alone, ahead of the sweep)
+    void* face_ids_event;    // the same for the neighbour's face ids (the second message of the step's second exchange): waited for by the face-pair pass
     const uint8_t* ghost_ext[2];  // ivx_halo_unpack_enqueue: the ghost layer is read in place from the caller's receive buffer
     // mesh state
     uint32_t* chunk_counts;   // [n_chunks*2]: vertex count, index count
@@ -333,6 +338,20 @@ struct GridView {
     const ivx_chunk_info* ghost_info[2];
 };
 
+// A slab's step in two parts around the arrival of its ghost layers (slab_comm.cpp: the exchange runs on a stream of its own): `x_part` of a
+// list-driven launch. 0: every listed chunk; IVX_XPART_INTERIOR: the chunks whose x neighbours are all the slab's own (nothing of a ghost
+// layer is read); IVX_XPART_FACES: the chunk planes that adjoin a ghost layer.
+#define IVX_XPART_ALL 0u
+#define IVX_XPART_INTERIOR 1u
+#define IVX_XPART_FACES 2u
+#ifdef __HIPCC__
+__device__ __forceinline__ bool ivx_xpart_skip(const GridView& g, uint32_t x_part, uint32_t ci) {
+    if (x_part == IVX_XPART_ALL) return false;
+    const bool face = (ci == 0u && g.ghost_sdf[0] != nullptr) || (ci + 1u == g.cx && g.ghost_sdf[1] != nullptr);
+    return face != (x_part == IVX_XPART_FACES);
+}
+#endif
+
 // Entry of the active list: chunk index in the low 24 bits (ivx_grid_create caps the chunk count at 2^24). k_derive adds what
 // the later stages would otherwise fetch from the chunk record first (one dependent memory round trip less per workgroup):
 // kind, generated kind, "exposed" (NonUniform and not fully obscured: the chunk has a mesh).
@@ -353,6 +372,8 @@ static inline uint32_t ivx_list_grid(const ivx_grid* g) {
     return n < lo ? lo : n;
 }
 
+// chunk planes of a slab that adjoin no ghost layer
+static inline bool ivx_has_interior_planes(const ivx_grid* g) { return (int)g->cc[0] - (g->has_ghost[0] ? 1 : 0) - (g->has_ghost[1] ? 1 : 0) > 0; }
 static inline uint32_t* ivx_wc(const ivx_grid* g) { return g->work_counts + g->wc_cur; }
 // to be called by everything that writes voxel planes other than the sampler (uploads, edits, split / clip / repack, raw plane pointers handed out)
 static inline void ivx_planes_touched(ivx_grid* g) {
@@ -410,6 +431,9 @@ int ivx_ensure_dense(ivx_grid* g);
 int ivx_launch_step_preset(ivx_grid* g, uint32_t groups);
 // scratch groups of the caller's NEXT ivx_voxel_step_enqueue, to be preset by the first kernel of the one before it (slab_comm.cpp)
 static inline void ivx_step_preset_ahead(ivx_grid* g, uint32_t groups) { g->preset_ahead |= groups; }
+int ivx_voxel_step_enqueue_part(ivx_grid* g, uint32_t stages, uint32_t part);  // (1: the sample and derive sweeps of the call, 2: the rest)
+// both faces of a slab into the two message buffers: `what` bit 0 = face planes + chunk records, bit 1 = the face voxels' component ids
+int ivx_launch_halo_pack_parts(ivx_grid* g, void* buf_lo, void* buf_hi, uint32_t what);
 int ivx_launch_step_post1(ivx_grid* g, uint32_t stages);
 int ivx_launch_step_post2(ivx_grid* g, uint32_t stages, const uint16_t* face_pair_ids = nullptr);
 int ivx_launch_step_emit(ivx_grid* g, uint32_t stages, bool general_in_assign = false, void* slab_record = nullptr, bool record_has_pairs = false);

@@ -3,9 +3,12 @@
 //   1. sample                                 -> one-voxel x-face planes (sdf, type) + the face layer's chunk records to both neighbours
 //   2. derive (+ regions, moments, occupied)  -> the planes again (post-demotion chunk kinds) + the faces' slab-local component ids
 //   3. remesh, the slab's record              -> ONE all-gather of the records' heads; every rank finishes the same union-find
-// everything stream-ordered on the context's stream: kernels, packing, RCCL traffic (grouped ncclSend / ncclRecv over the two
-// xGMI links to the neighbours, one small ncclAllGather); the host waits once per step. Ghost layers are read in place from the
-// receive buffers (ivx_halo_unpack_enqueue).
+// Kernels, packing and the one small ncclAllGather go on the context's stream; the two neighbour exchanges (grouped ncclSend / ncclRecv over
+// the two xGMI links to the neighbours) go on a stream of the communicator's, behind an event that follows the packing — and the slab's next
+// sweep is split around their arrival: the derive sweep (after exchange 1) and the mesher's count (after exchange 2) first take the chunk
+// planes that read nothing of a ghost layer, the context's stream then waits for the exchange's event, the two face planes follow
+// (ivx_grid::ghost_event; derive.hip, step_fused.hip). Interior work so overlaps the link; IVX_SLAB_OVERLAP=0 puts the exchanges back on the
+// context's stream. The host waits once per step. Ghost layers are read in place from the receive buffers (ivx_halo_unpack_enqueue).
 //
 // Three transports behind one driver:
 //   * RCCL (ivx_comm_init): librccl is opened at run time (the copy already loaded in the process — e.g. the one PyTorch bundles —
@@ -142,6 +145,12 @@ struct ivx_comm {
     unsigned long long ipc_slab_gen;  // slabs created on this communicator (ivx_slab_create is collective: every rank counts alike)
     std::thread* ipc_acker;           // rank 0: answers the other ranks' hellos (they may arrive at any time before their first exchange)
     std::atomic<int> ipc_acker_stop;
+    // exchanges beside the compute stream: a stream of the communicator's, per exchange of a step an event behind the packing (recorded on the
+    // context's stream) and one behind the arrival (recorded on this stream). `overlap`: in use (RCCL with neighbours; the in-process
+    // transport when it is told to move its messages by copies, ivx_comm_set_local_copies — the same choreography on the one GPU of a test box)
+    hipStream_t comm_stream;
+    hipEvent_t ev_packed[3], ev_arrived[3];  // (exchange 1; exchange 2: the face planes, the face ids)
+    int overlap, local_copies;
 };
 
 struct ivx_slab {
@@ -261,34 +270,97 @@ int ipc_all_gather(ivx_slab* sl, size_t words) {
     return IVX_OK;
 }
 
+// (test mode of the in-process transport) a link that takes its time: the copies of an exchange wait behind this on the communicator's stream,
+// so that a sweep which does not wait for the arrival event is sure to read the receive buffers before the message is in them
+__global__ void k_slow_link(unsigned long long ticks_100mhz) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks_100mhz) __builtin_amdgcn_s_sleep(32);
+}
+
+// the communicator's own stream and the events of its exchanges, made when first needed
+int comm_overlap_ready(ivx_comm* c) {
+    if (c->comm_stream) return IVX_OK;
+    IVX_HIP_CHECK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 3; ++k) {
+        IVX_HIP_CHECK(hipEventCreateWithFlags(&c->ev_packed[k], hipEventDisableTiming));
+        IVX_HIP_CHECK(hipEventCreateWithFlags(&c->ev_arrived[k], hipEventDisableTiming));
+    }
+    return IVX_OK;
+}
+
 // (`second`: the step's second exchange — the in-process transport packs it into its second pair of send buffers, see pack_bufs)
-int exchange(ivx_slab** slabs, size_t n, size_t nbytes, bool second) {
+// With `overlap` the messages move on the communicator's stream behind the packing; the slabs' grids are handed the arrival event and make
+// the context's stream wait for it where they first read what arrived (ivx_grid::ghost_event / face_ids_event). The second exchange then
+// goes in two messages: `what` 1 = the face planes + chunk records (bytes [0, halo_bytes) of the buffers), 2 = the face ids behind them,
+// 3 = both as one.
+int exchange(ivx_slab** slabs, size_t n, bool second, uint32_t what = 3u) {
     ivx_comm* c = slabs[0]->comm;
     hipStream_t s = c->ctx->stream;
     for (size_t i = 0; i < n; ++i) slabs[i]->ghost[0] = slabs[i]->recv[0], slabs[i]->ghost[1] = slabs[i]->recv[1];
+    const size_t halo = slabs[0]->halo_bytes, face = slabs[0]->face_bytes;
+    const size_t off = what == 2u ? halo : 0u;
+    const size_t nbytes = !second ? halo : (what == 3u ? halo + face : (what == 1u ? halo : face));
     if (c->ipc) return ipc_exchange(slabs[0], nbytes);
+    const int k = !second ? 0 : (what == 2u ? 2 : 1);
+    hipStream_t xs = s;  // the stream the messages move on
+    const bool moves = c->rank >= 0 ? (slabs[0]->has_lo || slabs[0]->has_hi) : (c->local_copies && n > 1);
+    if (c->overlap && moves) {
+        int rc = comm_overlap_ready(c);
+        if (rc) return rc;
+        IVX_HIP_CHECK(ivx_event_record(c->ev_packed[k], s));
+        IVX_HIP_CHECK(hipStreamWaitEvent(c->comm_stream, c->ev_packed[k], 0));
+        xs = c->comm_stream;
+    }
     if (c->rank >= 0) {  // RCCL: one slab per process, its two neighbours
         ivx_slab* sl = slabs[0];
         if (!sl->has_lo && !sl->has_hi) return IVX_OK;
         IVX_NCCL_CHECK(g_rccl.GroupStart());
         if (sl->has_lo) {
-            IVX_NCCL_CHECK(g_rccl.Send(sl->send[0], nbytes, NCCL_UINT8, sl->rank - 1, c->nccl, s));
-            IVX_NCCL_CHECK(g_rccl.Recv(sl->recv[0], nbytes, NCCL_UINT8, sl->rank - 1, c->nccl, s));
+            IVX_NCCL_CHECK(g_rccl.Send(sl->send[0] + off, nbytes, NCCL_UINT8, sl->rank - 1, c->nccl, xs));
+            IVX_NCCL_CHECK(g_rccl.Recv(sl->recv[0] + off, nbytes, NCCL_UINT8, sl->rank - 1, c->nccl, xs));
         }
         if (sl->has_hi) {
-            IVX_NCCL_CHECK(g_rccl.Send(sl->send[1], nbytes, NCCL_UINT8, sl->rank + 1, c->nccl, s));
-            IVX_NCCL_CHECK(g_rccl.Recv(sl->recv[1], nbytes, NCCL_UINT8, sl->rank + 1, c->nccl, s));
+            IVX_NCCL_CHECK(g_rccl.Send(sl->send[1] + off, nbytes, NCCL_UINT8, sl->rank + 1, c->nccl, xs));
+            IVX_NCCL_CHECK(g_rccl.Recv(sl->recv[1] + off, nbytes, NCCL_UINT8, sl->rank + 1, c->nccl, xs));
         }
         IVX_NCCL_CHECK(g_rccl.GroupEnd());
+    } else if (c->local_copies) {
+        // in-process, messages moved as a rank's would be: every send buffer into the neighbour's receive buffer (in the overlapped test mode
+        // behind 150 us of nothing: a link slower than any sweep that might run ahead of it)
+        if (xs != s) {
+            static const unsigned long long link_us = [] {
+                const char* e = getenv("IVX_SLAB_TEST_LINK_US");  // (0: no delay — for timing the choreography itself, tools/slab_timeline.py)
+                return e ? strtoull(e, nullptr, 10) : 150ull;
+            }();
+            if (link_us) hipLaunchKernelGGL(k_slow_link, dim3(1), dim3(1), 0, xs, link_us * 100ull);
+        }
+        for (size_t i = 0; i + 1 < n; ++i) {
+            IVX_HIP_CHECK(hipMemcpyAsync(slabs[i]->recv[1] + off, (second ? slabs[i + 1]->send2 : slabs[i + 1]->send)[0] + off, nbytes, hipMemcpyDeviceToDevice, xs));
+            IVX_HIP_CHECK(hipMemcpyAsync(slabs[i + 1]->recv[0] + off, (second ? slabs[i]->send2 : slabs[i]->send)[1] + off, nbytes, hipMemcpyDeviceToDevice, xs));
+        }
+    } else {
+        // in-process: nothing moves. Every slab's kernels are on the one stream, the packs of this exchange ahead of its readers; the buffers of
+        // the step's first exchange are packed again in the next step's first phase, those of the second in its second — after their last reader.
+        for (size_t i = 0; i + 1 < n; ++i) {
+            slabs[i]->ghost[1] = (second ? slabs[i + 1]->send2 : slabs[i + 1]->send)[0];
+            slabs[i + 1]->ghost[0] = (second ? slabs[i]->send2 : slabs[i]->send)[1];
+        }
         return IVX_OK;
     }
-    // in-process: nothing moves. Every slab's kernels are on the one stream, the packs of this exchange ahead of its readers; the buffers of
-    // the step's first exchange are packed again in the next step's first phase, those of the second in its second — after their last reader.
-    (void)s;
-    (void)nbytes;
-    for (size_t i = 0; i + 1 < n; ++i) {
-        slabs[i]->ghost[1] = (second ? slabs[i + 1]->send2 : slabs[i + 1]->send)[0];
-        slabs[i + 1]->ghost[0] = (second ? slabs[i]->send2 : slabs[i]->send)[1];
+    if (xs != s) {
+        IVX_HIP_CHECK(hipEventRecord(c->ev_arrived[k], xs));
+        for (size_t i = 0; i < n; ++i) {
+            ivx_grid* g = slabs[i]->grid;
+            if (what == 2u) {
+                g->face_ids_event = c->ev_arrived[k];
+            } else {
+                g->ghost_event = c->ev_arrived[k];
+                // the sweep that reads the planes first: split around the wait where the message has had no time to arrive (the derive sweep
+                // right behind exchange 1); the planes of exchange 2 travel behind the region stages — a plain wait ahead of the mesher's count
+                g->ghost_split = second ? 0 : 1;
+                if (what == 3u) g->face_ids_event = nullptr;
+            }
+        }
     }
     return IVX_OK;
 }
@@ -347,6 +419,10 @@ int ivx_comm_init(ivx_ctx* c, int nranks, int rank, const void* unique_id128, iv
     m->rank = rank;
     m->nccl = nullptr;
     m->ipc = nullptr;
+    {
+        const char* e = getenv("IVX_SLAB_OVERLAP");
+        m->overlap = !(e && e[0] == '0');
+    }
     if (nranks > 1) {
         int rc = load_rccl();
         if (rc) {
@@ -572,8 +648,28 @@ int ivx_comm_info(ivx_comm* m, int* transport, int* nranks, int* rank) {
     return IVX_OK;
 }
 
+// (test boxes have one GPU) the in-process transport moves its messages as a rank's would be moved — device copies on the communicator's
+// stream behind the packing, the slabs' sweeps split around their arrival — instead of reading the neighbour's send buffer in place: the
+// choreography of the RCCL transport (events, second stream, split sweeps) on one device, checked bit for bit by tests/test_gpu_slabs.py
+int ivx_comm_set_local_copies(ivx_comm* m, int on) {
+    IVX_REQUIRE(m && m->rank < 0 && !m->ipc, IVX_ERR_INVALID, "ivx_comm_set_local_copies: an in-process communicator is needed");
+    (void)ivx_stream_sync(m->ctx->stream);
+    if (m->comm_stream) (void)hipStreamSynchronize(m->comm_stream);
+    m->local_copies = on ? 1 : 0;
+    m->overlap = on == 1 ? 1 : 0;  // (2: copies on the context's own stream, unsplit sweeps)
+    return IVX_OK;
+}
+
 void ivx_comm_destroy(ivx_comm* m) {
     if (!m) return;
+    if (m->comm_stream) {
+        (void)hipStreamSynchronize(m->comm_stream);
+        for (int k = 0; k < 3; ++k) {
+            (void)hipEventDestroy(m->ev_packed[k]);
+            (void)hipEventDestroy(m->ev_arrived[k]);
+        }
+        (void)hipStreamDestroy(m->comm_stream);
+    }
     if (m->nccl) (void)g_rccl.CommDestroy(m->nccl);
     if (m->ipc) {
         if (m->ipc_acker) {
@@ -680,6 +776,8 @@ int ivx_slab_create(ivx_comm* m, ivx_grid* g, int rank, ivx_slab** out) {
 void ivx_slab_destroy(ivx_slab* sl) {
     if (!sl) return;
     (void)ivx_stream_sync(sl->comm->ctx->stream);
+    if (sl->comm->comm_stream) (void)hipStreamSynchronize(sl->comm->comm_stream);
+    if (sl->grid) sl->grid->ghost_event = nullptr;
     (void)ivx_halo_clear(sl->grid, 0);
     (void)ivx_halo_clear(sl->grid, 1);
     for (int s = 0; s < 2; ++s) {
@@ -730,24 +828,58 @@ int ivx_slabs_step_enqueue(ivx_slab** slabs, size_t n) {
         sl->enqueued = 1;
         return IVX_OK;
     }
+    // (the in-process transport moving its messages like RCCL does, a test mode: what a slab's receive buffers hold from the exchanges before is
+    // overwritten first — a static scene sends the same bytes step after step, and a sweep that read a ghost layer ahead of its arrival would
+    // go unnoticed)
+    const bool scribble = c->rank < 0 && c->local_copies == 1 && c->overlap;
+    if (scribble)
+        for (size_t i = 0; i < n; ++i)
+            for (int side = 0; side < 2; ++side) IVX_HIP_CHECK(ivx_memset_async(slabs[i]->recv[side], 0xA5, slabs[i]->halo_bytes + slabs[i]->face_bytes, c->ctx->stream));
     // 1. sample, exchange the face planes
     for (size_t i = 0; i < n; ++i) {
         ivx_slab* sl = slabs[i];
         note(ivx_voxel_step_enqueue(sl->grid, IVX_STAGE_SAMPLE));
         if (sl->has_lo || sl->has_hi) note(ivx_halo_pack_both_enqueue(sl->grid, sl->has_lo ? sl->send[0] : nullptr, sl->has_hi ? sl->send[1] : nullptr, 0));
     }
-    if ((rc = exchange(slabs, n, slabs[0]->halo_bytes, false))) return rc;
+    if ((rc = exchange(slabs, n, false))) return rc;
     // 2. derived state + slab-local regions (+ moments and occupied ranges: they need nothing more from the neighbours); the planes
-    // again, now with the post-demotion chunk kinds the mesher's upper-layer rule needs, and the faces' component ids behind them
+    // again, now with the post-demotion chunk kinds the mesher's upper-layer rule needs, and the faces' component ids behind them.
+    // (Exchanges on the communicator's stream: the planes are packed and sent as soon as the derive sweep is through — they travel while the
+    // region stages run —, the ids, which need the region stages, in a message of their own.)
+    const uint32_t stages2 = IVX_STAGE_DERIVE | IVX_STAGE_OCCUPIED | IVX_STAGE_REGIONS | IVX_STAGE_INERTIA;
+    const bool early = c->overlap && !c->ipc && (c->rank >= 0 || c->local_copies);
     for (size_t i = 0; i < n; ++i) {
         ivx_slab* sl = slabs[i];
         install_ghosts(sl);
         ivx_step_preset_ahead(sl->grid, IVX_SCRATCH_SN);  // the remesh phase below has no first kernel to host its preset
-        if (!local_err) note(ivx_voxel_step_enqueue(sl->grid, IVX_STAGE_DERIVE | IVX_STAGE_OCCUPIED | IVX_STAGE_REGIONS | IVX_STAGE_INERTIA));
         uint8_t** pb = pack_bufs(sl, true);
-        if (sl->has_lo || sl->has_hi) note(ivx_halo_pack_both_enqueue(sl->grid, sl->has_lo ? pb[0] : nullptr, sl->has_hi ? pb[1] : nullptr, 1));
+        const bool faces = sl->has_lo || sl->has_hi;
+        if (!early) {
+            if (!local_err) note(ivx_voxel_step_enqueue(sl->grid, stages2));
+            if (faces) note(ivx_halo_pack_both_enqueue(sl->grid, sl->has_lo ? pb[0] : nullptr, sl->has_hi ? pb[1] : nullptr, 1));
+            continue;
+        }
+        if (!local_err) note(ivx_voxel_step_enqueue_part(sl->grid, stages2, 1u));
+        if (faces) note(ivx_launch_halo_pack_parts(sl->grid, sl->has_lo ? pb[0] : nullptr, sl->has_hi ? pb[1] : nullptr, 1u));
+        if (c->rank >= 0) {  // (one slab per process: its planes leave now; the in-process transport sends all slabs' planes below)
+            if ((rc = exchange(slabs, n, true, 1u))) return rc;
+            if (!local_err) note(ivx_voxel_step_enqueue_part(sl->grid, stages2, 2u));
+            if (faces) note(ivx_launch_halo_pack_parts(sl->grid, sl->has_lo ? pb[0] : nullptr, sl->has_hi ? pb[1] : nullptr, 2u));
+        }
     }
-    if ((rc = exchange(slabs, n, slabs[0]->halo_bytes + slabs[0]->face_bytes, true))) return rc;
+    if (early && c->rank < 0) {
+        if (scribble)  // (every reader of the first exchange's planes is through)
+            for (size_t i = 0; i < n; ++i)
+                for (int side = 0; side < 2; ++side) IVX_HIP_CHECK(ivx_memset_async(slabs[i]->recv[side], 0x5A, slabs[i]->halo_bytes, c->ctx->stream));
+        if ((rc = exchange(slabs, n, true, 1u))) return rc;
+        for (size_t i = 0; i < n; ++i) {
+            ivx_slab* sl = slabs[i];
+            uint8_t** pb = pack_bufs(sl, true);
+            if (!local_err) note(ivx_voxel_step_enqueue_part(sl->grid, stages2, 2u));
+            if (sl->has_lo || sl->has_hi) note(ivx_launch_halo_pack_parts(sl->grid, sl->has_lo ? pb[0] : nullptr, sl->has_hi ? pb[1] : nullptr, 2u));
+        }
+    }
+    if ((rc = exchange(slabs, n, true, early ? 2u : 3u))) return rc;
     // 3. remesh (ghost layers in place), the slab's record, the one small all-gather
     for (size_t i = 0; i < n; ++i) {
         ivx_slab* sl = slabs[i];
@@ -828,7 +960,7 @@ int ivx_slabs_step_collect(ivx_slab** slabs, size_t n, ivx_slab_result* out) {
         }
         return x;
     };
-    bool pair_overflow = false;
+    bool pair_overflow = false, bad_pair = false;
     for (int r = 0; r + 1 < world; ++r) {
         const unsigned long long* q = rec.data() + (size_t)r * words;
         const size_t np = (size_t)q[1];
@@ -837,6 +969,12 @@ int ivx_slabs_step_collect(ivx_slab** slabs, size_t n, ivx_slab_result* out) {
             continue;
         }
         for (size_t k = 0; k < np; ++k) {
+            // (a pair names a component of this slab and one of the next by their slab-local ids: ids beyond the slabs' component counts can only
+            // come from a message that was read before it had arrived or was damaged on the way — an error, not an index)
+            if (q[28 + 2 * k] >= rec[(size_t)r * words] || q[29 + 2 * k] >= rec[(size_t)(r + 1) * words]) {
+                bad_pair = true;
+                continue;
+            }
             const uint32_t a = find((uint32_t)(offs[r] + q[28 + 2 * k])), b = find((uint32_t)(offs[r + 1] + q[29 + 2 * k]));
             if (a != b) parent[std::max(a, b)] = std::min(a, b);
         }
@@ -920,6 +1058,7 @@ int ivx_slabs_step_collect(ivx_slab** slabs, size_t n, ivx_slab_result* out) {
     IVX_REQUIRE((flags & 1u) == 0, IVX_ERR_CAPACITY, "ivx_slabs_step_collect: a chunk has more than 254 local regions");
     IVX_REQUIRE((flags & 4u) == 0, IVX_ERR_CAPACITY, "ivx_slabs_step_collect: a slab has 65535 or more components: its face ids do not fit the 16-bit exchange format");
     IVX_REQUIRE(!pair_overflow, IVX_ERR_CAPACITY, "ivx_slabs_step_collect: more than %d cross-slab region pairs on one face", IVX_MAX_FACE_PAIRS);
+    IVX_REQUIRE(!bad_pair, IVX_ERR_STATE, "ivx_slabs_step_collect: a cross-slab region pair names a component its slab does not have (a neighbour's face ids were damaged or read before they arrived)");
     return IVX_OK;
 }
 

@@ -541,7 +541,8 @@ __device__ __forceinline__ void role_box_mesh_needs(uint32_t b, const SnParams& 
 // `lds`: 4 x NROWS words of the caller's LDS (the fused launch lends the exact-numbering role's block: a role of its own LDS on top would push
 // the launch past the eight workgroups per CU its register budget is set for).
 __device__ __forceinline__ void role_sn_count_waves(uint32_t bid, uint32_t nb, SnParams p, uint32_t* __restrict__ counts, uint32_t* __restrict__ group_sums,
-                                                    const uint32_t* __restrict__ work_counts, const uint32_t* __restrict__ active_list, uint32_t* lds, uint32_t COUNT_RUN) {
+                                                    const uint32_t* __restrict__ work_counts, const uint32_t* __restrict__ active_list, uint32_t* lds, uint32_t COUNT_RUN,
+                                                    uint32_t x_part = 0u) {
     constexpr int WC = (NCROWS + 63) / 64;
     const GridView& g = p.g;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -564,6 +565,7 @@ __device__ __forceinline__ void role_sn_count_waves(uint32_t bid, uint32_t nb, S
     for (uint32_t li = run * COUNT_RUN; li < run * COUNT_RUN + COUNT_RUN && li < n_active; ++li) {
         const uint32_t entry = active_list[li];
         const uint32_t chunk = IVX_LIST_CHUNK(entry);
+        if (ivx_xpart_skip(g, x_part, chunk / (g.cz * g.cy))) continue;  // (the other part's chunk)
         if (!IVX_LIST_EXPOSED(entry)) {
             if (lane == 0) reinterpret_cast<uint2*>(counts)[chunk] = make_uint2(0u, 0u);
             continue;

@@ -68,6 +68,7 @@ struct StepArgs {
     uint32_t* host_block;     // null: no gather in this launch
     const uint32_t* eval_count;
     uint32_t count_run;       // k_step_post1: list entries per wave and turn of the mesher's count role
+    uint32_t x_part;          // k_step_post1, count role: IVX_XPART_* (the slab protocol's split around the arrival of the ghost layers)
     uint32_t seq;             // k_step_gather: the step's sequence number, written last (the host's completion doorbell)
     // slab protocol, remesh phase (ivx_slab_remesh_enqueue): the face-pair pass as a role of k_step_post2, the slab's record (and the step's
     // results into the host-mapped block) as a role of k_step_emit
@@ -110,7 +111,7 @@ __device__ __forceinline__ void step_post1_body(const StepArgs& a, uint32_t b, u
     __shared__ uint32_t sh_words[4 * sn::NROWS + 16];  // (tile sign rows: a wave each in the count role, one set in the needs role)
     struct { uint32_t* par; } sh{sh_words};
     if (b < a.nb[0]) {
-        sn::role_sn_count_waves(b, a.nb[0], sn_params(a), a.counts, a.sn_group_sums, a.work_count, a.active_list, sh.par, a.count_run);
+        sn::role_sn_count_waves(b, a.nb[0], sn_params(a), a.counts, a.sn_group_sums, a.work_count, a.active_list, sh.par, a.count_run, a.x_part);
         return;
     }
     b -= a.nb[0];
@@ -337,6 +338,21 @@ int ivx_launch_step_post1(ivx_grid* g, uint32_t stages) {
         a.nb[5] = a.needs_box.b_cc[0] * a.needs_box.b_cc[1] * a.needs_box.b_cc[2];
         g->post1_needs_out = nullptr;
     }
+    if ((stages & IVX_STAGE_REMESH) && g->ghost_event) {
+        // a slab whose ghost layers are still on their way (slab_comm.cpp): the count of the chunk planes that read nothing of them as a launch
+        // of its own ahead of the wait; the planes beside the ghost layers — and the launch's other roles — behind it
+        if (g->ghost_split && ivx_has_interior_planes(g) && a.nb[0]) {
+            StepArgs ai = a;
+            ai.nb[1] = ai.nb[3] = ai.nb[4] = ai.nb[5] = 0;
+            ai.x_part = IVX_XPART_INTERIOR;
+            a.x_part = IVX_XPART_FACES;
+            if (!ivx_many_try(g->ctx, g, IVX_MK_POST1, ai.nb[0], ai)) IVX_KLAUNCH(k_step_post1, dim3(ai.nb[0]), dim3(256), 0, g->ctx->stream, ai);
+        }
+        (void)ivx_many_break();
+        static const bool skip_wait = getenv("IVX_DEBUG_SKIP_GHOST_WAIT") && atoi(getenv("IVX_DEBUG_SKIP_GHOST_WAIT")) == 2;  // (developer switch, derive.hip)
+        if (!skip_wait) IVX_HIP_CHECK(hipStreamWaitEvent(g->ctx->stream, static_cast<hipEvent_t>(g->ghost_event), 0));
+        g->ghost_event = nullptr;
+    }
     const uint32_t total = a.nb[0] + a.nb[1] + a.nb[3] + a.nb[4] + a.nb[5];
     if (total == 0) return IVX_OK;
     if (!ivx_many_try(g->ctx, g, IVX_MK_POST1, total, a)) IVX_KLAUNCH(k_step_post1, dim3(total), dim3(256), 0, g->ctx->stream, a);
@@ -355,6 +371,12 @@ static void face_pair_args(StepArgs& a, ivx_grid* g, const uint16_t* nbr_ids) {
 }
 
 int ivx_launch_step_post2(ivx_grid* g, uint32_t stages, const uint16_t* face_pair_ids) {
+    if (g->face_ids_event) {  // (slab protocol: the neighbour's face ids travel apart from its face planes; this launch is their first reader)
+        (void)ivx_many_break();
+        static const bool skip_wait = getenv("IVX_DEBUG_SKIP_GHOST_WAIT") && atoi(getenv("IVX_DEBUG_SKIP_GHOST_WAIT")) == 3;  // (developer switch, derive.hip)
+        if (!skip_wait) IVX_HIP_CHECK(hipStreamWaitEvent(g->ctx->stream, static_cast<hipEvent_t>(g->face_ids_event), 0));
+        g->face_ids_event = nullptr;
+    }
     StepArgs a = make_args(g);
     if (face_pair_ids) {
         face_pair_args(a, g, face_pair_ids);

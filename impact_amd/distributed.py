@@ -371,6 +371,11 @@ class NativeComm:
         check(capi.lib().ivx_comm_info(self.h, C.byref(t), C.byref(n), C.byref(r)))
         return {"transport": ("rccl", "in-process", "shared-device")[t.value], "nranks": n.value, "rank": r.value}
 
+    def set_local_copies(self, mode: int = 1):
+        """`ivx_comm_set_local_copies` (in-process communicator): 1 = the messages move by copies on the communicator's own stream and the
+        slabs' sweeps are split around their arrival, as under RCCL; 2 = copies on the context's stream, sweeps unsplit; 0 = read in place"""
+        check(capi.lib().ivx_comm_set_local_copies(self.h, int(mode)))
+
     @staticmethod
     def unique_id() -> bytes:
         buf = (C.c_char * 128)()

@@ -480,6 +480,11 @@ int ivx_comm_init_ipc(ivx_ctx*, int nranks, int rank, const char* name, ivx_comm
 /* transport (0 RCCL, 1 in-process, 2 shared device), rank count and this process's rank as the communicator reports them (RCCL: ncclCommCount,
  * ncclCommUserRank) */
 int ivx_comm_info(ivx_comm*, int* transport, int* nranks, int* rank);
+/* Diagnostic (no reference counterpart): the in-process transport normally moves nothing (a slab reads its neighbour's send buffer in place).
+ * on = 1: it moves its messages as the RCCL transport does — copies on the communicator's own stream behind the packing, the slabs' derive
+ * sweep and mesher count split around their arrival (interior chunk planes first, the planes beside the ghost layers after the wait) — so
+ * that a one-GPU box exercises the overlapped protocol; on = 2: the copies on the context's stream, sweeps unsplit; 0: back to in place. */
+int ivx_comm_set_local_copies(ivx_comm*, int on);
 void ivx_comm_destroy(ivx_comm*);
 /* Diagnostic (no reference counterpart): runs every RCCL call the protocol makes — ncclGetUniqueId, ncclCommInitRank, a grouped
  * ncclSend / ncclRecv pair, ncclAllGather — on a ONE-rank communicator of this context's device and stream (the send goes to the rank

@@ -13,10 +13,13 @@ from impact_amd.distributed import NativeComm, NativeSlabStepper, SlabStepper, n
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["native", "python"])
+@pytest.fixture(params=["native", "native_overlap", "native_copies", "python"])
 def driver(request):
-    """native: the protocol inside the library (`ivx_slabs_step_*` over an in-process communicator: the code the RCCL ranks run, with
-    device copies for transport); python: the same phases driven from impact_amd/distributed.py (what the gloo protocol test shares)"""
+    """native: the protocol inside the library (`ivx_slabs_step_*` over an in-process communicator: the code the RCCL ranks run, the slabs
+    reading their neighbours' send buffers in place); native_overlap: the same with the messages MOVED as under RCCL — copies on the
+    communicator's own stream behind the packing, derive sweep and mesher count split around their arrival (`ivx_comm_set_local_copies(1)`);
+    native_copies: copies on the context's stream, sweeps unsplit; python: the same phases driven from impact_amd/distributed.py (what the
+    gloo protocol test shares)"""
     return request.param
 
 
@@ -28,14 +31,16 @@ def run_and_compare(ctx, graph, world, expect_regions=None, extent=1.0, driver="
     o.update_occupied_voxel_ranges()
     o.compute_all_derived_state()
     comm = None
-    if driver == "native":
+    if driver.startswith("native"):
         comm = NativeComm(ctx, world, local=True)
+        if driver != "native":
+            comm.set_local_copies(1 if driver == "native_overlap" else 2)
         steppers = [NativeSlabStepper(ctx, comm, graph, dens, r, extent) for r in range(world)]
     else:
         steppers = [SlabStepper(ctx, graph, dens, r, world, torch, extent) for r in range(world)]
     try:
-        for _ in range(2):  # twice: the second pass starts from a dirty state (ghosts, labels, mesh buffers)
-            results = native_step(steppers) if driver == "native" else run_slabs_in_process(steppers)
+        for _ in range(3 if driver == "native_overlap" else 2):  # again: a later pass starts from a dirty state (ghosts, labels, mesh buffers, receive buffers)
+            results = native_step(steppers) if driver.startswith("native") else run_slabs_in_process(steppers)
         cc = o.chunk_counts
         assert steppers[0].global_chunk_counts == cc
         o_sdf, o_typ, o_flg, o_lab, o_info = o.export_dense()
@@ -129,9 +134,11 @@ def test_two_spheres_cut_between(ctx, driver):
     run_and_compare(ctx, scenes.two_spheres_scene(25.0, 60.0), 2, expect_regions=2, extent=0.5, driver=driver)
 
 
-def test_headline_512_in_8_slabs(ctx):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_headline_512_in_8_slabs(ctx, overlap):
     """the strong-scaling configuration of the metric — the 512^3 asteroid in 8 x-slabs of 4 chunk planes — through the native driver,
-    all eight slabs on this one GPU: global results against the single-grid step of the same scene"""
+    all eight slabs on this one GPU: global results against the single-grid step of the same scene. `overlap`: the messages moved on the
+    communicator's stream and the sweeps split around their arrival, as under RCCL (three steps: the receive buffers are reused)"""
     from impact_amd.voxel import SDFVoxelGenerator, VoxelObject
 
     graph = scenes.asteroid_scene(2.05)
@@ -142,9 +149,12 @@ def test_headline_512_in_8_slabs(ctx):
     whole.set_densities(dens)
     ref = whole.step(capi.STAGE_ALL)
     comm = NativeComm(ctx, 8, local=True)
+    if overlap:
+        comm.set_local_copies(1)
     steppers = [NativeSlabStepper(ctx, comm, graph, dens, r) for r in range(8)]
     try:
-        results = native_step(steppers)
+        for _ in range(3 if overlap else 1):
+            results = native_step(steppers)
         assert results[0].region_count == int(ref["region_count"]) == 1
         assert results[0].total_triangles == int(ref["mesh"]["n_indices"]) // 3
         assert sum(r.mesh_counts[0] for r in results) == int(ref["mesh"]["n_vertices"])
