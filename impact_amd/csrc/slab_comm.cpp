@@ -612,6 +612,31 @@ int ivx_comm_selftest(ivx_ctx* c) {
             result = IVX_ERR_HIP;
             break;
         }
+        // the same exchange the way the protocol runs it: on a second stream, behind an event recorded on the context's stream, an event behind
+        // the arrival that the context's stream waits for (second halves of the buffers; the all-gather below reads what arrived)
+        {
+            hipStream_t xs = nullptr;
+            hipEvent_t packed = nullptr, arrived = nullptr;
+            bool ok = hipStreamCreateWithFlags(&xs, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&packed, hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&arrived, hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventRecord(packed, s) == hipSuccess && hipStreamWaitEvent(xs, packed, 0) == hipSuccess;
+            if (ok && g_rccl.GroupStart() == 0) {
+                const bool sent = g_rccl.Send(dev + N / 2, N / 2, NCCL_UINT8, 0, comm, xs) == 0 && g_rccl.Recv(dev + N + N / 2, N / 2, NCCL_UINT8, 0, comm, xs) == 0;
+                ok = (g_rccl.GroupEnd() == 0) && sent;
+            } else {
+                ok = false;
+            }
+            ok = ok && hipEventRecord(arrived, xs) == hipSuccess && hipStreamWaitEvent(s, arrived, 0) == hipSuccess;
+            if (xs) (void)hipStreamSynchronize(xs);
+            if (packed) (void)hipEventDestroy(packed);
+            if (arrived) (void)hipEventDestroy(arrived);
+            if (xs) (void)hipStreamDestroy(xs);
+            if (!ok) {
+                ivx_set_error("ivx_comm_selftest: grouped ncclSend / ncclRecv on a second stream between two events failed");
+                result = IVX_ERR_HIP;
+                break;
+            }
+        }
         // the record all-gather's (64-bit words)
         if (g_rccl.AllGather(dev + N, dev + 2 * N, N / 8, NCCL_INT64, comm, s) != 0) {
             ivx_set_error("ivx_comm_selftest: ncclAllGather failed");
