@@ -158,7 +158,17 @@ void build_chains(ivx_world* w) {
 // tiles. A tile's rounds are the distinct levels its items lie on, in level order, each a mask of the lanes whose next item it is: a round's
 // items are of one level, so they depend on lower levels only and every wave walks its rounds in level order — the lowest unfinished level
 // can always run while all workgroups are resident. `lvl`: level (from 1) of item pass * nch + chain.
+#define IVX_SLAP(what)                                                                                                             \
+    do {                                                                                                                            \
+        static const bool tr_ = getenv("IVX_WORLD_TRACE") && atoi(getenv("IVX_WORLD_TRACE")) >= 2;                                  \
+        if (tr_) {                                                                                                                  \
+            const auto t1_ = std::chrono::steady_clock::now();                                                                      \
+            fprintf(stderr, "[ivx world]     %s: %.1f us\n", what, 1e-3 * (double)std::chrono::duration_cast<std::chrono::nanoseconds>(t1_ - slap_t0).count()); \
+            slap_t0 = t1_;                                                                                                          \
+        }                                                                                                                           \
+    } while (0)
 void build_stationary(ivx_world* w, int phase, uint32_t nch, uint32_t passes, const std::vector<uint32_t>& lvl) {
+    auto slap_t0 = std::chrono::steady_clock::now();
     ivx_world::CsSchedule& cs = w->cs[phase];
     cs = ivx_world::CsSchedule();
     cs.slot_offset = (uint32_t)w->cs_item_host.size();
@@ -178,17 +188,28 @@ void build_stationary(ivx_world* w, int phase, uint32_t nch, uint32_t passes, co
         }
     for (uint32_t b = 0; b < w->n_dyn; ++b)
         if (deg[b] > 0xFFFFu) return;
+    IVX_SLAP("stationary: degrees");
+    // the chains by the level of their first item, solve order inside a level: a counting sort (levels are small integers)
+    uint32_t max_level = 0;
+    for (size_t i = 0; i < (size_t)passes * nch; ++i) max_level = std::max(max_level, lvl[i]);
     std::vector<uint32_t> order(nch);
-    for (uint32_t ch = 0; ch < nch; ++ch) order[ch] = ch;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return lvl[a] < lvl[b]; });
+    {
+        std::vector<uint32_t> first(max_level + 2u, 0u);
+        for (uint32_t ch = 0; ch < nch; ++ch) first[lvl[ch] + 1u] += 1u;
+        for (uint32_t l = 1; l <= max_level + 1u; ++l) first[l] += first[l - 1u];
+        for (uint32_t ch = 0; ch < nch; ++ch) order[first[lvl[ch]]++] = ch;
+    }
+    IVX_SLAP("stationary: order");
     const size_t slot0 = cs.slot_offset;
     w->cs_item_host.resize(slot0 + (size_t)n_tiles * 64u, 0xFFFFFFFFu);
     w->cs_bodies_host.resize(2 * (slot0 + (size_t)n_tiles * 64u), 0u);
     w->cs_vers_host.resize(slot0 + (size_t)n_tiles * 64u, 0u);
-    std::vector<std::pair<uint32_t, uint32_t>> ev;  // (level, pair of lanes) of a tile's items
+    // a tile's rounds: the lanes of every level its items lie on (a table over the levels, reset through the list of the levels touched)
+    std::vector<uint64_t> mask_of(max_level + 1u, 0ull);
+    std::vector<uint32_t> touched;
     for (uint32_t t = 0; t < n_tiles; ++t) {
         const uint32_t first = t * 32u, cnt = std::min(32u, nch - first);
-        ev.clear();
+        touched.clear();
         for (uint32_t l = 0; l < cnt; ++l) {
             const uint32_t ch = order[first + l];
             const uint32_t s0 = w->chain_start[ch], len = w->chain_start[ch + 1] - s0;
@@ -205,20 +226,22 @@ void build_stationary(ivx_world* w, int phase, uint32_t nch, uint32_t passes, co
                 w->cs_bodies_host[2 * slot + 1] = body[side ^ 1];
                 w->cs_vers_host[slot] = (b & IVX_KINEMATIC_BODY) ? 0u : (deg[b] | (rank[2 * (size_t)ch + side] << 16));
             }
-            for (uint32_t p = 0; p < passes; ++p) ev.emplace_back(lvl[(size_t)p * nch + ch], l);
+            for (uint32_t p = 0; p < passes; ++p) {
+                const uint32_t lv = lvl[(size_t)p * nch + ch];
+                if (!mask_of[lv]) touched.push_back(lv);
+                mask_of[lv] |= 3ull << (2u * l);
+            }
         }
-        std::sort(ev.begin(), ev.end());
+        std::sort(touched.begin(), touched.end());
         w->cs_round_start_host.push_back((uint32_t)(w->cs_round_mask_host.size() - cs.round_offset));
-        for (size_t i = 0; i < ev.size();) {
-            uint64_t mask = 0;
-            size_t j = i;
-            for (; j < ev.size() && ev[j].first == ev[i].first; ++j) mask |= 3ull << (2u * ev[j].second);
-            w->cs_round_mask_host.push_back(mask);
-            w->cs_round_level_host.push_back(ev[i].first);
-            i = j;
+        for (const uint32_t lv : touched) {
+            w->cs_round_mask_host.push_back(mask_of[lv]);
+            w->cs_round_level_host.push_back(lv);
+            mask_of[lv] = 0ull;
         }
     }
     w->cs_round_start_host.push_back((uint32_t)(w->cs_round_mask_host.size() - cs.round_offset));
+    IVX_SLAP("stationary: tiles");
     if (phase == 1 && !w->cs_slot_of_host.empty()) {  // ReplayView's item indices, by pair of lanes and sweep instead of by pass and chain
         std::vector<uint32_t> by_pair((size_t)n_tiles * 32u * passes, 0u);
         for (uint32_t i = 0; i < nch; ++i)
@@ -231,6 +254,7 @@ void build_stationary(ivx_world* w, int phase, uint32_t nch, uint32_t passes, co
 // Dependency levels of the item sequence (pass-major, chains in cache order inside a pass); items of one level touch
 // pairwise different dynamic bodies. Appends to items/level_start.
 void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_t type, uint32_t n_passes, int phase) {
+    auto slap_t0 = std::chrono::steady_clock::now();
     const uint32_t nch = (uint32_t)w->chain_start.size() - 1u, nb = w->n_dyn;
     w->item_offset[phase] = (uint32_t)w->items_host.size();
     w->level_offset[phase] = (uint32_t)w->level_start_host.size();
@@ -268,6 +292,7 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
             lvl[k] = l;
             max_level = std::max(max_level, l);
         }
+    IVX_SLAP("schedule: levels");
     // counting sort by level (stable)
     const size_t ls0 = w->level_start_host.size();
     w->level_start_host.resize(ls0 + max_level + 1, 0u);
@@ -314,6 +339,7 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
             }
         }
     }
+    IVX_SLAP("schedule: items");
     if (phase == 1) {
         w->kin_offsets_host.assign(1, 0u);
         w->kin_list_host.clear();
@@ -341,7 +367,9 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
     }
     w->tile_base_host[ls0 + max_level] = n_tiles;
     w->n_tiles[phase] = n_tiles;
+    IVX_SLAP("schedule: tiles");
     build_stationary(w, phase, nch, total_passes, lvl);
+    IVX_SLAP("schedule: stationary");
 }
 
 }  // namespace
@@ -807,6 +835,7 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
     if ((rc = ivx_launch_phys_prepare_bodies(w))) return rc;
     if ((rc = ivx_launch_phys_prepare_contacts(w, w->prev_slot))) return rc;
     if ((rc = ivx_launch_phys_mark_joint_bodies(w))) return rc;
+    lap("prepare launches");
     w->prepared_fresh = 1;
     if (n_prepared) *n_prepared = nc;
     return IVX_OK;
