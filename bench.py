@@ -326,7 +326,11 @@ def summary_block(out):
             "edit_plus_sync_ms": g("edit", "edit_plus_sync_ms"),
             "fragments": {"cut_ms": g("fragments", "cut_ms"), "first_step_many_ms": g("fragments", "first_step_many_ms"), "frame_many_ms": g("fragments", "frame_many_ms"),
                           "frame_looped_ms": g("fragments", "frame_looped_ms")},
-            "fragments_frame": {"ms_batched": g("fragments_frame", "ms_batched"), "ms_looped": g("fragments_frame", "ms_looped")},
+            "fragments_frame": {"ms_batched": g("fragments_frame", "ms_batched"), "ms_looped": g("fragments_frame", "ms_looped"),
+                                "probes_sync_ms": [g("fragments_frame", "probes_and_pairs", "probes_sync", "ms_batched"),
+                                                   g("fragments_frame", "probes_and_pairs", "probes_sync", "ms_looped")],
+                                "mutual_pairs_ms": [g("fragments_frame", "probes_and_pairs", "mutual_pairs", "ms_batched"),
+                                                    g("fragments_frame", "probes_and_pairs", "mutual_pairs", "ms_looped")]},
             "config3_split_loop_ms": g("config3", "split_loop_ms"), "config5_single_grid_ms": g("config5_one_gpu", "single_grid_ms"),
             "config5_eight_slabs_one_gpu_ms": g("config5_one_gpu", "eight_slabs_one_gpu_ms"),
             "cpu_baseline_voxels_per_s": g("cpu_baseline", "value"), "parity_all_equal": (all(parities) if parities else None), "parity_blocks": len(parities)}
