@@ -323,7 +323,7 @@ def summary_block(out):
                       "step_counter_frac": g("dense", "step_roofline", "counter_frac")},
             "pile": {"ms_per_step": g("pile", "ms_per_step"), "solve_ms": g("pile", "stage_ms", "solve"), "kernel": g("pile", "solver", "kernel")},
             "frame_pipeline_ms": g("frame", "pipeline", "ms_per_frame"), "frame_two_streams_ms": g("frame", "ms_per_frame_two_streams"),
-            "edit_plus_sync_ms": g("edit", "edit_plus_sync_ms"),
+            "edit_plus_sync_ms": g("edit", "edit_plus_sync_ms"), "edit_and_sync_overlapped_ms": g("edit", "edit_and_sync_overlapped_ms"),
             "fragments": {"cut_ms": g("fragments", "cut_ms"), "first_step_many_ms": g("fragments", "first_step_many_ms"), "frame_many_ms": g("fragments", "frame_many_ms"),
                           "frame_looped_ms": g("fragments", "frame_looped_ms")},
             "fragments_frame": {"ms_batched": g("fragments_frame", "ms_batched"), "ms_looped": g("fragments_frame", "ms_looped"),
@@ -709,6 +709,7 @@ def edit_benchmark(ctx, scale, o_big, reps=5):
         t1 = time.perf_counter()
         mesh.sync_with_voxel_object(r["invalidated"])  # the incremental remesh of the invalidated chunks (mesh.rs:355-456) ...
         t2 = time.perf_counter()
+        n_idx_sync, n_vtx_sync = int(mesh.counts["n_indices"]), int(mesh.counts["n_vertices"])
         obj.step(capi.STAGE_REMESH)  # ... and the full one, for comparison
         t3 = time.perf_counter()
         if rep == reps and o_big is not None:  # (a remesh changes neither voxels nor labels)
@@ -717,8 +718,26 @@ def edit_benchmark(ctx, scale, o_big, reps=5):
         t_sync.append(t2 - t1)
         t_remesh.append(t3 - t2)
         emptied, touched, invalidated = r["emptied_voxels"], r["touched_chunks"], int(r["invalidated"].sum())
+    # the same edit and sync with the sync enqueued while the edit is in flight (ivx_mesh_sync_enqueue(NULL): placed from the mesh needs the
+    # edit's count role delivers early): edit enqueue -> sync enqueue -> edit collect -> sync collect
+    t_over = []
+    obj.set_early_mesh_needs(True)
+    for rep in range(reps + 1):
+        obj.step(capi.STAGE_ALL)
+        c = np.array([0.5 * (a + b) for a, b in obj.update_occupied_voxel_ranges()], dtype=np.float32) + EDIT_OFFSET * np.float32(scale)
+        mesh.sync_with_voxel_object(np.zeros(obj.n_chunks, dtype=np.uint8))
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        obj.absorb_sphere_enqueue(c, EDIT_RADIUS * scale + 2.0, EDIT_RADIUS * scale)
+        mesh.sync_enqueue(None)
+        r2 = obj.absorb_collect(want_invalidated=True)
+        mesh.sync_collect()
+        t_over.append(time.perf_counter() - t0)
+    same_overlapped = (r2["emptied_voxels"], r2["touched_chunks"], int(r2["invalidated"].sum())) == (emptied, touched, invalidated) and \
+        int(mesh.counts["n_indices"]) == n_idx_sync and int(mesh.counts["n_vertices"]) == n_vtx_sync
     obj.close()
     out = {"workload": f"absorbing sphere r={EDIT_RADIUS * scale:.1f} voxels at the surface of the headline body",
+           "edit_and_sync_overlapped_ms": round(1e3 * float(np.mean(t_over[1:])), 4), "overlapped_equals_sequential": bool(same_overlapped),
            "edit_ms": round(1e3 * float(np.mean(t_edit[1:])), 4), "remesh_after_ms": round(1e3 * float(np.mean(t_remesh[1:])), 4),
            "sync_after_ms": round(1e3 * float(np.mean(t_sync[1:])), 4),
            "edit_plus_sync_ms": round(1e3 * float(np.mean(t_edit[1:]) + np.mean(t_sync[1:])), 4), "emptied_voxels": emptied, "touched_chunks": touched,

@@ -832,14 +832,20 @@ static bool edit_needs_lookup(ivx_grid* g, uint32_t chunk, uint32_t out3[3]);
 static int edit_sync_upload(ivx_grid* g, const void* src, size_t bytes, void* d_dst);
 static void edit_sync_mark(ivx_grid* g, int pending);
 static int edit_sync_pending(ivx_grid* g);
+static bool edit_sync_drained_take(ivx_grid* g);  // (and clears it)
 
 // VoxelObjectMesh::sync_with_voxel_object (mesh.rs:355-456) in two halves. ENQUEUE: the sizes the invalidated chunks' meshes need come from the
 // last edit's result block when the set is that edit's (ivx_absorb_collect: no count pass, no read-back) — else from a count over just these
 // chunks and one read-back —; the host mirror of the ChunkSubmeshManager places them; records and slots go up from pinned memory and the
 // emit pass for the listed chunks follows on the stream. COLLECT: the wait. (Round 3 counted the whole object, read the sizes back, uploaded
 // through a blocking copy and waited again: two round trips and ~25 us of counting for ~100 chunks.)
+// what the edit in flight invalidates and what those meshes need, from the records its count role delivers early (ivx_edit_state::early_*):
+// waits for the role's bell — a third of the way down the edit's chain —, not for the edit
+static int edit_early_needs(ivx_grid* g, const char* who, std::vector<uint32_t>& list);
+static int edit_sync_stage(ivx_grid* g, const void* src, size_t bytes, void** dev_view);
+static int edit_sync_stage_done(ivx_grid* g);
 static int mesh_sync_enqueue(ivx_grid* g, const uint8_t* invalidated_chunks, const char* who) {
-    IVX_REQUIRE(g && invalidated_chunks, IVX_ERR_INVALID, "%s: null argument", who);
+    IVX_REQUIRE(g, IVX_ERR_INVALID, "%s: null argument", who);
     ivx_many_other_context other_(g->ctx);
     IVX_REQUIRE(!edit_sync_pending(g), IVX_ERR_STATE, "%s: a sync of this object is in flight (ivx_mesh_sync_collect first)", who);
     IVX_REQUIRE(g->mesh_built, IVX_ERR_STATE, "ivx_mesh_sync: there is no mesh to synchronise (call ivx_remesh first)");
@@ -879,7 +885,9 @@ static int mesh_sync_enqueue(ivx_grid* g, const uint8_t* invalidated_chunks, con
     static thread_local std::vector<uint32_t> list, needs, dirty_slots, rec_chunk, slots;
     static thread_local std::vector<char> stage;
     list.clear();
-    {   // chunk-linear order (the reference walks a hash set: unpinned); eight flags a look — nearly all of them are zero
+    if (!invalidated_chunks) {  // the set of the edit in flight
+        if ((rc = edit_early_needs(g, who, list))) return rc;
+    } else {   // chunk-linear order (the reference walks a hash set: unpinned); eight flags a look — nearly all of them are zero
         uint32_t c = 0;
         for (; c + 8u <= g->n_chunks; c += 8u) {
             uint64_t w;
@@ -986,11 +994,17 @@ static int mesh_sync_enqueue(ivx_grid* g, const uint8_t* invalidated_chunks, con
                 memcpy(stage.data() + off_pent + e * sizeof(ivx_submesh), &m->table[slot], sizeof(ivx_submesh));
                 e += 1;
             }
+        // (records, slots and patches are a few KB the passes only read: from host-mapped memory in place — a copy ahead of the passes is a
+        // stream operation of 4 us and a gap; a recorded batch carries them in its one staging copy instead)
         char* base = static_cast<char*>(g->dev_scratch);
-        if ((rc = edit_sync_upload(g, stage.data(), total, base))) return rc;
+        void* view = nullptr;
+        if ((rc = edit_sync_stage(g, stage.data(), total, &view))) return rc;
+        if (view) base = static_cast<char*>(view);
+        else if ((rc = edit_sync_upload(g, stage.data(), total, base))) return rc;
         if ((rc = ivx_launch_sn_emit_list(g, n, reinterpret_cast<const uint32_t*>(base), base + 16, reinterpret_cast<const uint32_t*>(base + off_slots), (uint32_t)n_patch,
                                           base + off_pent, reinterpret_cast<const uint32_t*>(base + off_pslots))))
             return rc;
+        if (view && (rc = edit_sync_stage_done(g))) return rc;
     }
     lap_(4);
     (void)table_before;
@@ -1004,6 +1018,7 @@ static int mesh_sync_enqueue(ivx_grid* g, const uint8_t* invalidated_chunks, con
     g->mesh_serial += 1;  // collision probes picked from the old mesh are stale
     m->serial = g->mesh_serial;
     edit_sync_mark(g, 1);
+    (void)edit_sync_drained_take(g);
     lap_(5);
     static const int period_ = trace_ && atoi(getenv("IVX_MANY_TRACE")) > 1 ? atoi(getenv("IVX_MANY_TRACE")) : 81;
     if (trace_ && ++calls_ % period_ == 0) {
@@ -1018,6 +1033,7 @@ static int mesh_sync_collect(ivx_grid* g, ivx_mesh_counts* out, const char* who,
     IVX_REQUIRE(g && out, IVX_ERR_INVALID, "%s: null argument", who);
     IVX_REQUIRE(edit_sync_pending(g), IVX_ERR_STATE, "%s: no sync of this object is in flight", who);
     edit_sync_mark(g, 0);
+    if (edit_sync_drained_take(g)) stream_is_drained = true;  // (the edit's collect waited behind this sync's launches)
     if (!stream_is_drained) IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
     g->mesh_valid = 1;
     *out = g->mesh_counts;
@@ -1025,6 +1041,11 @@ static int mesh_sync_collect(ivx_grid* g, ivx_mesh_counts* out, const char* who,
 }
 
 int ivx_mesh_sync_enqueue(ivx_grid* g, const uint8_t* invalidated_chunks) { return mesh_sync_enqueue(g, invalidated_chunks, "ivx_mesh_sync_enqueue"); }
+int ivx_grid_set_early_mesh_needs(ivx_grid* g, int on) {
+    IVX_REQUIRE(g, IVX_ERR_INVALID, "ivx_grid_set_early_mesh_needs: null grid");
+    g->early_needs_on = on ? 1 : 0;
+    return IVX_OK;
+}
 int ivx_mesh_sync_collect(ivx_grid* g, ivx_mesh_counts* out) { return mesh_sync_collect(g, out, "ivx_mesh_sync_collect"); }
 int ivx_mesh_sync(ivx_grid* g, const uint8_t* invalidated_chunks, ivx_mesh_counts* out) {
     IVX_REQUIRE(out, IVX_ERR_INVALID, "ivx_mesh_sync: null argument");
@@ -1824,10 +1845,17 @@ struct ivx_edit_state {
     // (ascending by chunk — the grown box is walked in chunk-linear order —, looked up by binary search: a hash map's insertions were most of an
     // edit's collect for the small objects of a many-object frame)
     std::vector<std::array<uint32_t, 4>> needs;  // chunk, vertices, indices, kind | flags << 8
+    // early delivery of what the invalidated meshes need (ivx_mesh_sync_enqueue with a null set while the edit is in flight): the role that
+    // counts them writes its records into the pinned block behind the results and rings a bell there
+    int early_armed = 0, early_taken = 0;
+    uint32_t early_seq = 0;
+    size_t off_early = 0, off_bell = 0;
     // the sync in flight
     int sync_pending = 0;
     void* pinned_up = nullptr;
+    void* pinned_up_dev = nullptr;  // the device's view of it (host-mapped: the sync's kernels read their small lists in place)
     size_t pinned_up_bytes = 0;
+    int sync_drained = 0;  // an edit's collect has waited for a doorbell that was rung behind this sync's launches: nothing left to wait for
     hipEvent_t up_done = nullptr;  // the last upload from pinned_up has been read
     int up_busy = 0;
 };
@@ -1855,6 +1883,12 @@ static void edit_sync_mark(ivx_grid* g, int pending) {
     if (ivx_edit_state* e = edit_state(g)) e->sync_pending = pending;
 }
 static int edit_sync_pending(ivx_grid* g) { return g->edit ? g->edit->sync_pending : 0; }
+static bool edit_sync_drained_take(ivx_grid* g) {
+    if (!g->edit) return false;
+    const bool d = g->edit->sync_drained != 0;
+    g->edit->sync_drained = 0;
+    return d;
+}
 static int ensure_pinned(void** p, size_t* have, size_t bytes);
 // host -> device from the sync's own pinned block, asynchronously (the block is free again once the event behind the copy has passed)
 static int edit_sync_upload(ivx_grid* g, const void* src, size_t bytes, void* d_dst) {
@@ -1880,8 +1914,34 @@ static int ensure_pinned(void** p, size_t* have, size_t bytes) {
     *p = nullptr;
     *have = 0;
     const size_t cap = std::max<size_t>(bytes, 1 << 16);
-    IVX_HIP_CHECK(hipHostMalloc(p, cap, hipHostMallocDefault));
+    IVX_HIP_CHECK(hipHostMalloc(p, cap, hipHostMallocMapped));
     *have = cap;
+    return IVX_OK;
+}
+// The sync's small lists where its kernels can read them WITHOUT a copy on the stream: into the pinned block, *dev_view = the device's address
+// of it. Null view: a batch is being recorded (the caller uploads as before). edit_sync_stage_done goes behind the last reader's launch.
+static int edit_sync_stage(ivx_grid* g, const void* src, size_t bytes, void** dev_view) {
+    *dev_view = nullptr;
+    if (ivx_many_recording()) return IVX_OK;
+    ivx_edit_state* e = edit_state(g);
+    IVX_REQUIRE(e, IVX_ERR_CAPACITY, "ivx_mesh_sync: out of host memory");
+    if (!e->up_done) IVX_HIP_CHECK(hipEventCreateWithFlags(&e->up_done, hipEventDisableTiming));
+    if (e->up_busy) {
+        IVX_HIP_CHECK(hipEventSynchronize(e->up_done));
+        e->up_busy = 0;
+    }
+    const size_t had = e->pinned_up_bytes;
+    int rc = ensure_pinned(&e->pinned_up, &e->pinned_up_bytes, bytes);
+    if (rc) return rc;
+    if (e->pinned_up_bytes != had || !e->pinned_up_dev) IVX_HIP_CHECK(hipHostGetDevicePointer(&e->pinned_up_dev, e->pinned_up, 0));
+    memcpy(e->pinned_up, src, bytes);
+    *dev_view = e->pinned_up_dev;
+    return IVX_OK;
+}
+static int edit_sync_stage_done(ivx_grid* g) {
+    // (no event behind the readers: the block is next written by the object's next sync, which cannot be enqueued before this one's collect has
+    // waited for them — an event record here is a stream operation between the sync's launches and whatever follows them)
+    (void)g;
     return IVX_OK;
 }
 
@@ -1964,18 +2024,33 @@ static int absorb_enqueue(ivx_grid* g, const char* who, int capsule, const float
     // results to the host ahead of the doorbell: seven launches, no copy or fill operation on the stream
     if ((rc = ivx_launch_derive_box(g, IVX_PART_REGIONS, blo, bcc, nullptr))) return rc;
     e->staged = e->total <= STAGED_COPY_MAX;
-    if (e->staged && e->pinned_bytes < e->total) {
+    e->off_early = (e->total + 63) & ~(size_t)63;
+    e->off_bell = e->off_early + grown * 16;
+    const size_t pinned_need = e->off_bell + 64;
+    if (e->staged && e->pinned_bytes < pinned_need) {
         IVX_HIP_CHECK(ivx_stream_sync(s));
         if (e->pinned) (void)hipHostFree(e->pinned);
         e->pinned = e->pinned_dev = nullptr, e->pinned_bytes = 0;
-        const size_t cap = std::max<size_t>(2 * e->total, 1 << 16);
+        const size_t cap = std::max<size_t>(2 * pinned_need, 1 << 16);
         IVX_HIP_CHECK(hipHostMalloc(&e->pinned, cap, hipHostMallocMapped));
         IVX_HIP_CHECK(hipHostGetDevicePointer(&e->pinned_dev, e->pinned, 0));
+        memset(e->pinned, 0, cap);
         e->pinned_bytes = cap;
     }
     for (int d = 0; d < 3; ++d) g->post1_needs_box[d] = lo[d], g->post1_needs_box[3 + d] = cc[d], g->post1_needs_box[6 + d] = blo[d], g->post1_needs_box[9 + d] = bcc[d];
     g->post1_needs_touched = reinterpret_cast<const uint32_t*>(base + e->off_touch);
     g->post1_needs_out = reinterpret_cast<uint32_t*>(base + e->off_needs);
+    e->early_armed = 0, e->early_taken = 0;
+    if (e->staged && g->early_needs_on) {  // (the words [2], [3] behind the two counters are the block's spare: zero between edits like the rest)
+        e->early_seq += 1u;
+        g->post1_needs_early = reinterpret_cast<uint32_t*>(static_cast<char*>(e->pinned_dev) + e->off_early);
+        g->post1_needs_counter = reinterpret_cast<uint32_t*>(base + e->off_cnt) + 2;
+        g->post1_needs_bell = reinterpret_cast<uint32_t*>(static_cast<char*>(e->pinned_dev) + e->off_bell);
+        g->post1_needs_seq = e->early_seq;
+        // (the bell's place moves with the size of the box: whatever an earlier, larger edit left there must not read as this edit's number)
+        *reinterpret_cast<volatile uint32_t*>(static_cast<char*>(e->pinned) + e->off_bell) = 0u;
+        e->early_armed = 1;
+    }
     {
         const uint32_t keep = g->stage_timing_off;
         g->stage_timing_off = 0xFFFFFFFFu;       // (no event records around the slots: nobody reads this call's stage times)
@@ -1989,7 +2064,8 @@ static int absorb_enqueue(ivx_grid* g, const char* who, int capsule, const float
     if (e->staged) {
         g->gather_copy_src = reinterpret_cast<const uint32_t*>(base);
         g->gather_copy_dst = static_cast<uint32_t*>(e->pinned_dev);
-        g->gather_copy_words = (uint32_t)((e->total + 3) / 4);
+        // (with early delivery the needs records are in the host-mapped block already: the gather copies the words in front of them only)
+        g->gather_copy_words = (uint32_t)(((e->early_armed ? e->off_needs : e->total) + 3) / 4);
     }
     e->pending = 1;
     return IVX_OK;
@@ -2007,6 +2083,7 @@ static int absorb_collect(ivx_grid* g, const char* who, ivx_absorb_result* out, 
     if (e->nothing) return IVX_OK;
     int rc;
     if ((rc = rederive_collect(g))) return rc;  // (the doorbell behind everything enqueued: one wait)
+    if (e->sync_pending) e->sync_drained = 1;   // (... a sync enqueued while this edit was in flight included)
     std::vector<char> hostbuf;
     const char* hb;
     if (e->staged) {
@@ -2036,8 +2113,9 @@ static int absorb_collect(ivx_grid* g, const char* who, ivx_absorb_result* out, 
     if (cnt[1]) g->occ_ref_valid = 0;  // `if removed_chunks { self.update_occupied_ranges() }` (intersection.rs:384-386, 520-522)
     // handle_chunk_voxels_modified (intersection.rs:560-598): the touched chunk, and a neighbour when the touched voxel range of the chunk
     // comes within two voxels of the face they share — decided on the device per chunk of the grown box, with what its mesh needs now
-    const uint32_t* needs = reinterpret_cast<const uint32_t*>(hb + e->off_needs);
+    const uint32_t* needs = reinterpret_cast<const uint32_t*>(e->early_armed ? static_cast<const char*>(e->pinned) + e->off_early : hb + e->off_needs);
     const size_t grown = (size_t)e->bcc[0] * e->bcc[1] * e->bcc[2];
+    e->needs.clear();  // (an early sync may have filled them from the same records)
     for (size_t b = 0; b < grown; ++b) {
         const uint32_t w = needs[4 * b];
         if (!(w & 0x80000000u)) continue;
@@ -2048,6 +2126,47 @@ static int absorb_collect(ivx_grid* g, const char* who, ivx_absorb_result* out, 
     if (!std::is_sorted(e->needs.begin(), e->needs.end(), [](const std::array<uint32_t, 4>& a, const std::array<uint32_t, 4>& b) { return a[0] < b[0]; }))
         std::sort(e->needs.begin(), e->needs.end(), [](const std::array<uint32_t, 4>& a, const std::array<uint32_t, 4>& b) { return a[0] < b[0]; });
     g->needs_current = 1;
+    return IVX_OK;
+}
+
+static int edit_early_needs(ivx_grid* g, const char* who, std::vector<uint32_t>& list) {
+    ivx_edit_state* e = g->edit;
+    IVX_REQUIRE(e && e->pending, IVX_ERR_STATE, "%s: a null set stands for the chunks of an edit in flight, and none is", who);
+    if (e->nothing) return IVX_OK;
+    IVX_REQUIRE(e->early_armed, IVX_ERR_STATE,
+                "%s: the edit in flight does not deliver its mesh needs early (ivx_grid_set_early_mesh_needs before the edit; or its results do not fit the "
+                "host-mapped block): collect it and pass its set",
+                who);
+    if (!e->early_taken) {
+        const volatile uint32_t* bell = reinterpret_cast<const volatile uint32_t*>(static_cast<const char*>(e->pinned) + e->off_bell);
+        (void)ivx_many_break();
+        bool rung = false;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t it = 0;; ++it) {
+            if (*bell == e->early_seq) {
+                rung = true;
+                break;
+            }
+            __builtin_ia32_pause();
+            if ((it & 255u) == 255u && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > 2000) break;
+        }
+        if (!rung) IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
+        std::atomic_thread_fence(std::memory_order_acquire);
+        IVX_REQUIRE(*bell == e->early_seq, IVX_ERR_HIP, "%s: the edit's mesh needs never arrived", who);
+        const uint32_t* needs = reinterpret_cast<const uint32_t*>(static_cast<const char*>(e->pinned) + e->off_early);
+        const size_t grown = (size_t)e->bcc[0] * e->bcc[1] * e->bcc[2];
+        e->needs.clear();
+        for (size_t b = 0; b < grown; ++b) {
+            const uint32_t w = needs[4 * b];
+            if (!(w & 0x80000000u)) continue;
+            e->needs.push_back({needs[4 * b + 3], needs[4 * b + 1], needs[4 * b + 2], w & 0xFFFFu});
+        }
+        if (!std::is_sorted(e->needs.begin(), e->needs.end(), [](const std::array<uint32_t, 4>& a, const std::array<uint32_t, 4>& b) { return a[0] < b[0]; }))
+            std::sort(e->needs.begin(), e->needs.end(), [](const std::array<uint32_t, 4>& a, const std::array<uint32_t, 4>& b) { return a[0] < b[0]; });
+        g->needs_current = 1;
+        e->early_taken = 1;
+    }
+    for (const auto& n : e->needs) list.push_back(n[0]);
     return IVX_OK;
 }
 

@@ -166,6 +166,13 @@ struct ivx_grid {
     uint32_t post1_needs_box[12];         // touched box lo, cc; grown box lo, cc
     const uint32_t* post1_needs_touched;
     uint32_t* post1_needs_out;            // non-null: the next post1 launch hosts the mesh-needs role
+    // ... which also delivers its records EARLY (ivx_mesh_sync_enqueue with a null set while the edit is in flight): straight into host-mapped
+    // memory, the role's last workgroup ringing a bell behind them — the host places the invalidated meshes while the region stages still run
+    int early_needs_on;                   // ivx_grid_set_early_mesh_needs: the edits of this object deliver early (a system-scope fence per workgroup of the role: ~4 us per edit)
+    uint32_t* post1_needs_early;          // host-mapped twin of post1_needs_out (null: no early delivery)
+    uint32_t* post1_needs_counter;        // workgroups of the role that are through (device word, zero at the start)
+    uint32_t* post1_needs_bell;           // host-mapped: post1_needs_seq once all are
+    uint32_t post1_needs_seq;
     const uint32_t* gather_copy_src;
     uint32_t* gather_copy_dst;            // (device address of host-mapped memory)
     uint32_t gather_copy_words;

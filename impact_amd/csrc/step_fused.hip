@@ -86,6 +86,10 @@ struct StepArgs {
     sn::BoxNeeds needs_box;
     const uint32_t* needs_touched;
     uint32_t* needs_out;
+    uint32_t* needs_early;    // (optional) host-mapped twin of needs_out, a counter of finished workgroups, the bell behind them and its value
+    uint32_t* needs_counter;
+    uint32_t* needs_bell;
+    uint32_t needs_seq, pad_needs_;
     const uint32_t* copy_src;
     uint32_t* copy_dst;
     uint32_t copy_words;
@@ -130,7 +134,18 @@ __device__ __forceinline__ void step_post1_body(const StepArgs& a, uint32_t b, u
         return;
     }
     b -= a.nb[4];
-    if (b < a.nb[5]) sn::role_box_mesh_needs(b, sn_params(a), a.needs_box, a.needs_touched, nullptr, a.needs_out, sh.par);
+    if (b < a.nb[5]) {
+        sn::role_box_mesh_needs(b, sn_params(a), a.needs_box, a.needs_touched, nullptr, a.needs_out, sh.par);
+        // early delivery (ivx_mesh_sync_enqueue while the edit is in flight): the chunk's record a second time, straight into host-mapped
+        // memory; the workgroup that finds all others through rings the bell. (Thread 0 wrote the record: it reads its own stores.)
+        if (a.needs_early && threadIdx.x == 0u) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a.needs_early[4u * b + q] = a.needs_out[4u * b + q];
+            __threadfence_system();
+            if (__hip_atomic_fetch_add(a.needs_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == a.nb[5])
+                __hip_atomic_store(a.needs_bell, a.needs_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 #ifndef IVX_POST1_WAVES
 #define IVX_POST1_WAVES 6
@@ -243,7 +258,15 @@ IVX_MANY_TWIN(k_step_assign_many, StepArgs, step_assign_body, __launch_bounds__(
 // the results as a launch of their own (one block), ordered after everything enqueued so far
 __device__ __forceinline__ void step_gather_body(const StepArgs& a, uint32_t, uint32_t) {
     role_result_gather(a.rscalar, a.offsets + 2 * (size_t)a.n_chunks, a.moments_out, a.work_count, a.eval_count, a.host_block, false, 0u);
-    for (uint32_t i = threadIdx.x; i < a.copy_words; i += 64u) a.copy_dst[i] = a.copy_src[i];  // (the edit path's small results, into pinned host memory)
+    // (the edit path's small results, into pinned host memory: eight loads in flight per lane — one wave copying word by word spent 6 us on 3 KB)
+    for (uint32_t i0 = threadIdx.x; i0 < a.copy_words; i0 += 512u) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t q = 0; q < 8u; ++q) v[q] = i0 + 64u * q < a.copy_words ? a.copy_src[i0 + 64u * q] : 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < 8u; ++q)
+            if (i0 + 64u * q < a.copy_words) a.copy_dst[i0 + 64u * q] = v[q];
+    }
     // Doorbell: the sequence number lands after every result word of this (single-wave) block. The stream is in order, so a host that
     // sees it also knows that everything enqueued before this launch is complete (ivx_voxel_step_collect polls it instead of paying
     // the runtime's blocking wait when the step is short).
@@ -335,6 +358,8 @@ int ivx_launch_step_post1(ivx_grid* g, uint32_t stages) {
         }
         a.needs_touched = g->post1_needs_touched;
         a.needs_out = g->post1_needs_out;
+        a.needs_early = g->post1_needs_early, a.needs_counter = g->post1_needs_counter, a.needs_bell = g->post1_needs_bell, a.needs_seq = g->post1_needs_seq;
+        g->post1_needs_early = nullptr;
         a.nb[5] = a.needs_box.b_cc[0] * a.needs_box.b_cc[1] * a.needs_box.b_cc[2];
         g->post1_needs_out = nullptr;
     }

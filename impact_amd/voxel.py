@@ -417,6 +417,11 @@ class VoxelObject:
                 "invalidated": None if inval is None else inval.astype(bool), "touched_chunks": int(out[0]["touched_chunks"]),
                 "removed_chunks": int(out[0]["removed_chunks"])}
 
+    def set_early_mesh_needs(self, on: bool = True):
+        """`ivx_grid_set_early_mesh_needs`: the edits of this object deliver what their invalidated meshes need ahead of their other results, so
+        that `VoxelObjectMesh.sync_enqueue(None)` can place the re-mesh while an edit is still in flight"""
+        check(capi.lib().ivx_grid_set_early_mesh_needs(self.h, 1 if on else 0))
+
     def absorb_sphere_enqueue(self, center, influence_radius: float, sphere_radius: float, densities=None):
         """`ivx_absorb_sphere_enqueue`: the edit and everything that follows it on the stream, without waiting; `absorb_collect` delivers"""
         d = np.ones(256, dtype=np.float32) if densities is None else np.ascontiguousarray(densities, dtype=np.float32)
@@ -589,8 +594,13 @@ class VoxelObjectMesh:
         self.counts = c
         return self
 
-    def sync_enqueue(self, invalidated):
-        """`ivx_mesh_sync_enqueue`: place and launch the re-mesh of the invalidated chunks without waiting"""
+    def sync_enqueue(self, invalidated=None):
+        """`ivx_mesh_sync_enqueue`: place and launch the re-mesh of the invalidated chunks without waiting. `None`: the chunks of the edit that
+        is in flight (`absorb_*_enqueue` without its `absorb_collect` yet) — the call waits for the edit's mesh needs, which arrive a third of
+        the way down the edit's chain, places the meshes while the region stages still run and puts its launches behind them"""
+        if invalidated is None:
+            check(capi.lib().ivx_mesh_sync_enqueue(self.object.h, None))
+            return
         inv = np.ascontiguousarray(np.asarray(invalidated).reshape(-1), dtype=np.uint8)
         assert inv.size == self.object.n_chunks
         check(capi.lib().ivx_mesh_sync_enqueue(self.object.h, ptr(inv)))

@@ -164,7 +164,15 @@ int ivx_mesh_download(ivx_grid*, float* positions, float* normals, uint32_t* ind
  * are visited in chunk-linear order (the reference walks a hash set, an unpinned order that decides which freed range a chunk lands in). */
 int ivx_mesh_sync(ivx_grid*, const uint8_t* invalidated_chunks, ivx_mesh_counts* out);
 /* ... in two halves: `_enqueue` places the invalidated chunks' meshes (their sizes come with the last edit's results when the set is that
- * edit's: no count pass, no read-back) and launches their emit pass; `_collect` waits and returns the buffer lengths. */
+ * edit's: no count pass, no read-back) and launches their emit pass; `_collect` waits and returns the buffer lengths.
+ * invalidated_chunks = NULL: the set of the edit that is IN FLIGHT (ivx_absorb_*_enqueue without its ivx_absorb_collect yet). What that edit's
+ * chunks need reaches the host a third of the way down the edit's launches (the count role rings a bell of its own); the call waits for that,
+ * places the meshes while the edit's region stages still run, and puts its launches behind them:
+ *   ivx_absorb_sphere_enqueue -> ivx_mesh_sync_enqueue(g, NULL) -> ivx_absorb_collect -> ivx_mesh_sync_collect
+ * is the edit and its re-mesh with one idle moment for the GPU less than the four calls in their usual order (same results). The edit must
+ * have been enqueued with early delivery switched on for the object (ivx_grid_set_early_mesh_needs(g, 1): off by default — the count role
+ * then pays a system-scope fence per workgroup, ~4 us per edit). */
+int ivx_grid_set_early_mesh_needs(ivx_grid*, int on);
 int ivx_mesh_sync_enqueue(ivx_grid*, const uint8_t* invalidated_chunks);
 int ivx_mesh_sync_collect(ivx_grid*, ivx_mesh_counts* out);
 /* VoxelMeshModifications (mesh.rs:113-123, 826-841), the hand-off to the renderer's buffers: the vertex / index ranges ivx_mesh_sync wrote since the

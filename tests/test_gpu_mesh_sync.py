@@ -243,6 +243,52 @@ def test_edit_and_sync_in_two_halves(ctx):
     g.close()
 
 
+def test_edit_and_sync_overlapped(ctx):
+    """ivx_absorb_sphere_enqueue -> ivx_mesh_sync_enqueue(NULL) -> ivx_absorb_collect -> ivx_mesh_sync_collect: the sync placed from the mesh
+    needs the edit's count role delivers early, its launches behind the edit's, while the edit is still in flight. Voxels, labels, edit results
+    and the synced mesh equal the oracle's, edit after edit (bites of different sizes — the early records' place in the host-mapped block moves
+    with the box —, one that touches nothing, one that removes chunks); a null set without an edit in flight is an error."""
+    o, g = both(ctx, scenes.asteroid_scene(0.5))
+    om = ol.OracleMeshHandle(o)
+    gm = VoxelObjectMesh.create(g)
+    ctr = np.array([0.5 * (a + b) for a, b in o.info()["occupied_voxel_ranges"]], dtype=np.float32)
+    with pytest.raises(capi.IvxError):
+        gm.sync_enqueue(None)  # no edit in flight
+    c0 = ctr + np.asarray((0.0, 0.0, 52.0), dtype=np.float32)
+    o.absorb_sphere(c0, 5.0, 3.0)
+    g.absorb_sphere_enqueue(c0, 5.0, 3.0)
+    with pytest.raises(capi.IvxError):
+        gm.sync_enqueue(None)  # an edit in flight, but not one that delivers early
+    r0 = g.absorb_collect()
+    om.sync(r0["invalidated"])
+    gm.sync_with_voxel_object(r0["invalidated"])
+    g.set_early_mesh_needs(True)
+    edits = [((0.0, 0.0, 48.0), 14.0), ((30.0, 5.0, 30.0), 9.0), ((0.0, 0.0, 40.0), 22.0), ((400.0, 0.0, 0.0), 5.0), ((-50.0, 0.0, 0.0), 30.0), ((0.0, 0.0, 44.0), 3.0),
+             ((10.0, -20.0, 30.0), 26.0)]
+    for step, (d, r) in enumerate(edits):
+        c = ctr + np.asarray(d, dtype=np.float32)
+        ro = o.absorb_sphere(c, r + 2.0, r)
+        g.absorb_sphere_enqueue(c, r + 2.0, r)
+        gm.sync_enqueue(None)
+        rg = g.absorb_collect()
+        gm.sync_collect()
+        np.testing.assert_array_equal(rg["invalidated"], ro["invalidated"])
+        np.testing.assert_array_equal(rg["emptied_by_type"], ro["emptied_by_type"])
+        assert (rg["touched_chunks"], rg["removed_chunks"]) == (ro["touched_chunks"], ro["removed_chunks"])
+        pu.assert_edited_objects_equal(o, g, f"edit {step}: ", with_mesh=False)
+        om.sync(ro["invalidated"])
+        assert_synced_meshes_equal(om.get(), gm.download())
+    assert sum(1 for d, r in edits if r > 20.0) >= 2
+    # the usual order still works behind it (the early records are armed on every edit, taken or not)
+    c = ctr + np.asarray((0.0, 25.0, 35.0), dtype=np.float32)
+    ro, rg = o.absorb_sphere(c, 12.0, 10.0), g.absorb_sphere(c, 12.0, 10.0)
+    om.sync(ro["invalidated"])
+    gm.sync_with_voxel_object(rg["invalidated"])
+    assert_synced_meshes_equal(om.get(), gm.download())
+    pu.assert_edited_objects_equal(o, g, "after the overlapped edits: ")
+    g.close()
+
+
 def test_sync_of_several_edits_at_once(ctx):
     """two edits, then ONE sync over the union of what they invalidated (the reference syncs once per frame, lib.rs:729-733): the sizes of the
     first edit's chunks are not the last edit's — the sync counts the listed chunks itself"""
