@@ -150,12 +150,14 @@ __device__ __forceinline__ void role_ccl_merge_multi(uint32_t bid, uint32_t nb, 
     const uint32_t tid = threadIdx.x;
     const uint32_t n_multi = rscalar[2];
     const int a = tid >> 4, b = tid & 15;
-    for (uint32_t li = bid; li < n_multi; li += nb) {
-        const uint32_t chunk = multi_list[li];
+    // (a workgroup per FACE of a listed chunk: the six faces of a chunk one after the other were six chains of dependent loads and atomics —
+    // 9 us of an edit's resolve for the five chunks a bite leaves with several regions)
+    for (uint32_t item = bid; item < n_multi * 6u; item += nb) {
+        const uint32_t chunk = multi_list[item / 6u];
         const int ck = chunk % g.cz, cj = (chunk / g.cz) % g.cy, ci = chunk / (g.cz * g.cy);
         const uint8_t* own = labels + (size_t)chunk * IVX_CHUNK_VOXELS;  // a chunk with several regions is NonUniform: it has planes
-#pragma unroll
-        for (int f = 0; f < 6; ++f) {
+        {
+            const int f = (int)(item % 6u);
             const int dim = f >> 1, up = f & 1;
             const int ni = ci + (dim == 0 ? (up ? 1 : -1) : 0), nj = cj + (dim == 1 ? (up ? 1 : -1) : 0), nk = ck + (dim == 2 ? (up ? 1 : -1) : 0);
             if (ni < 0 || nj < 0 || nk < 0 || ni >= (int)g.cx || nj >= (int)g.cy || nk >= (int)g.cz) continue;
