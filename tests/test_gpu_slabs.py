@@ -275,4 +275,5 @@ def test_random_sdf_program_in_slabs(ctx, seed):
     if cx < 2:  # degenerate or one chunk plane thick: nothing to decompose
         return
     world = int(min(cx, rng.integers(2, 5)))
-    run_and_compare(ctx, g, world, extent=extent, driver="native")
+    # (every third seed with the messages moved on the communicator's stream and the sweeps split around their arrival)
+    run_and_compare(ctx, g, world, extent=extent, driver="native_overlap" if seed % 3 == 0 else "native")
