@@ -111,28 +111,48 @@ __global__ __launch_bounds__(256) void k_face_ids(GridView g, uint32_t side, con
 
 // Both faces of a slab in one launch (blockIdx.y = side): the one-voxel face planes of (sdf, type) + the face layer's chunk
 // records, and — after the region stages — the component ids of the face voxels right behind them. A chunk that is only its
-// record (compact planes) is expanded here.
+// record (compact planes) is expanded here. A wave per chunk column, four face voxels a lane (a face plane of a chunk is 256 consecutive
+// bytes of its planes): words in, words out — a thread per voxel moved single bytes and the launch was 6.5-9.5 us of every rank's step, twice.
+// with_ids: 0 the planes and records, 1 both, 2 the ids alone (the planes went ahead, slab_comm.cpp)
 __global__ __launch_bounds__(256) void k_halo_pack_both(GridView g, uint8_t* __restrict__ out_lo, uint8_t* __restrict__ out_hi, uint32_t with_ids,
                                                         const uint8_t* __restrict__ labels, const uint32_t* __restrict__ rcompid,
                                                         uint32_t* __restrict__ rscalar, uint32_t* __restrict__ pair_words) {
-    const uint32_t col = blockIdx.x, side = blockIdx.y, tid = threadIdx.x;
-    // (the face-pair count and seen table of the pass that follows the exchange start at zero: cleared here instead of by a fill of their own)
-    if (pair_words && col == 0 && side == 0 && tid < 4u + 128u) pair_words[tid] = 0u;
-    uint8_t* out = side ? out_hi : out_lo;
-    if (!out) return;
+    const uint32_t side = blockIdx.y, tid = threadIdx.x, lane = tid & 63u;
     const size_t cols = (size_t)g.cy * g.cz;
+    const uint32_t col = blockIdx.x * 4u + (tid >> 6);
+    // (the face-pair count and seen table of the pass that follows the exchange start at zero: cleared here instead of by a fill of their own)
+    if (pair_words && blockIdx.x == 0 && side == 0 && tid < 4u + 128u) pair_words[tid] = 0u;
+    uint8_t* out = side ? out_hi : out_lo;
+    if (!out || col >= cols) return;
     const uint32_t chunk = (side ? g.cx - 1 : 0u) * g.cy * g.cz + col;
-    const size_t src = (size_t)chunk * IVX_CHUNK_VOXELS + ((side ? 15u : 0u) << 8) + tid;
-    if (!(with_ids & 2u)) {  // (2: the ids alone — the planes went ahead, slab_comm.cpp)
-        const ivx_chunk_info rec = g.info[chunk];
-        const bool dense = rec.kind == KIND_NONUNIFORM;
-        out[(size_t)col * 256 + tid] = dense ? (uint8_t)g.sdf[src] : (uint8_t)ivx_uniform_sdf(rec.kind);
-        out[cols * 256 + (size_t)col * 256 + tid] = dense ? g.type[src] : (uint8_t)ivx_uniform_type(rec);
-        if (tid == 0) reinterpret_cast<ivx_chunk_info*>(out + cols * 512)[col] = rec;
+    const size_t src = (size_t)chunk * IVX_CHUNK_VOXELS + ((side ? 15u : 0u) << 8) + 4u * lane;
+    const ivx_chunk_info rec = g.info[chunk];
+    const bool dense = rec.kind == KIND_NONUNIFORM;
+    if (!(with_ids & 2u)) {
+        const uint32_t sd = dense ? *reinterpret_cast<const uint32_t*>(g.sdf + src) : ((uint32_t)ivx_uniform_sdf(rec.kind) & 0xFFu) * 0x01010101u;
+        const uint32_t ty = dense ? *reinterpret_cast<const uint32_t*>(g.type + src) : ((uint32_t)ivx_uniform_type(rec) & 0xFFu) * 0x01010101u;
+        *reinterpret_cast<uint32_t*>(out + (size_t)col * 256 + 4u * lane) = sd;
+        *reinterpret_cast<uint32_t*>(out + cols * 256 + (size_t)col * 256 + 4u * lane) = ty;
+        if (lane == 0) reinterpret_cast<ivx_chunk_info*>(out + cols * 512)[col] = rec;
     }
-    if (with_ids)
-        reinterpret_cast<uint16_t*>(out + cols * (512 + sizeof(ivx_chunk_info)))[(size_t)col * 256 + tid] =
-            (uint16_t)face_id16(g, side, col, tid, labels, rcompid, rscalar);
+    if (with_ids) {
+        // slab-local component ids of the four face voxels as 16 bits each (face_id16)
+        const uint32_t lw = dense ? *reinterpret_cast<const uint32_t*>(labels + src) : ivx_uniform_label(rec.kind) * 0x01010101u;
+        uint32_t id[4];
+        bool over = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t l = (lw >> (8 * q)) & 0xFFu;
+            id[q] = 0xFFFFu;
+            if (l != 255u) {
+                const uint32_t v = rcompid[chunk * 256u + l];
+                over = over || v >= 0xFFFFu;
+                id[q] = v & 0xFFFFu;
+            }
+        }
+        if (over) atomicOr(&rscalar[1], 4u);
+        *reinterpret_cast<uint2*>(out + cols * (512 + sizeof(ivx_chunk_info)) + ((size_t)col * 256 + 4u * lane) * 2) = make_uint2(id[0] | (id[1] << 16), id[2] | (id[3] << 16));
+    }
 }
 
 // (bodies: role_face_pairs / role_step_record in ccl_roles.hpp — the slab protocol's remesh phase hosts them in the step's fused launches)
@@ -347,7 +367,7 @@ int ivx_launch_ccl_dense_labels(ivx_grid* g, uint32_t* d_labels) {
 
 int ivx_launch_halo_pack_both(ivx_grid* g, void* buf_lo, void* buf_hi, int with_face_labels) {
     GridView v = ivx_view(g);
-    IVX_KLAUNCH(k_halo_pack_both, dim3(g->cc[1] * g->cc[2], 2), dim3(256), 0, g->ctx->stream, v, static_cast<uint8_t*>(buf_lo),
+    IVX_KLAUNCH(k_halo_pack_both, dim3((g->cc[1] * g->cc[2] + 3u) / 4u, 2), dim3(256), 0, g->ctx->stream, v, static_cast<uint8_t*>(buf_lo),
                        static_cast<uint8_t*>(buf_hi), with_face_labels ? 1u : 0u, g->llabel, g->rcompid, g->rscalar,
                        (with_face_labels && g->pairs_dev) ? g->pairs_dev : nullptr);
     IVX_HIP_CHECK(hipGetLastError());
@@ -359,7 +379,7 @@ int ivx_launch_halo_pack_parts(ivx_grid* g, void* buf_lo, void* buf_hi, uint32_t
     if (what == 3u) return ivx_launch_halo_pack_both(g, buf_lo, buf_hi, 1);
     if (what == 1u) return ivx_launch_halo_pack_both(g, buf_lo, buf_hi, 0);
     GridView v = ivx_view(g);
-    IVX_KLAUNCH(k_halo_pack_both, dim3(g->cc[1] * g->cc[2], 2), dim3(256), 0, g->ctx->stream, v, static_cast<uint8_t*>(buf_lo), static_cast<uint8_t*>(buf_hi), 2u, g->llabel,
+    IVX_KLAUNCH(k_halo_pack_both, dim3((g->cc[1] * g->cc[2] + 3u) / 4u, 2), dim3(256), 0, g->ctx->stream, v, static_cast<uint8_t*>(buf_lo), static_cast<uint8_t*>(buf_hi), 2u, g->llabel,
                 g->rcompid, g->rscalar, g->pairs_dev ? g->pairs_dev : nullptr);
     IVX_HIP_CHECK(hipGetLastError());
     g->pairs_zeroed = g->pairs_dev ? 1 : 0;
