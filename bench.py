@@ -1140,7 +1140,6 @@ def fragments_frame_benchmark(ctx, with_cpu, n_axis=5, frames=6, warm=2):
     r_ = wb.step(0.005)
     out["solver_chain_stationary"] = {"kernel": wb.solver_info()["kernel"], "solve_ms": round(float(r_["stage_ms"][2]), 4)}
     wb.set_solver_groups(0)
-    out["probes_and_pairs"] = fragments_probes_and_pairs(ctx, a_objs, b_objs, a_mesh, b_mesh, occ, dens)
     if with_cpu:
         import oracle_lib as ol
         from test_gpu_contacts import oracle_plane_contact_list
@@ -1185,6 +1184,8 @@ def fragments_frame_benchmark(ctx, with_cpu, n_axis=5, frames=6, warm=2):
         cpu_ms = 1e3 * float(np.mean(t_cpu[warm:]))
         out["cpu_baseline"] = {"frame_ms": round(cpu_ms, 2), "cores": 1, "kind": "port",
                                "sample": f"the same {frames} frames (contacts built into records by a Python loop over the oracle's hits: part of the time), single thread"}
+    # (behind the oracle's comparison: this leg edits the fragments further)
+    out["probes_and_pairs"] = fragments_probes_and_pairs(ctx, a_objs, b_objs, a_mesh, b_mesh, occ, dens)
     for w in (wa, wb):
         w.close()
     for o_ in a_objs + b_objs:
