@@ -1997,7 +1997,10 @@ static int absorb_enqueue(ivx_grid* g, const char* who, int capsule, const float
     e->off_needs = (e->off_touch + box_chunks * 4 + 15) & ~(size_t)15;
     e->total = e->off_needs + grown * 16;
     hipStream_t s = g->ctx->stream;
-    const size_t off_dens = (e->total + 255) & ~(size_t)255, need_bytes = off_dens + 1024;  // (a density table other than the resident one rides behind the results)
+    // (a density table other than the resident one rides in the block's LAST kilobyte — not right behind this edit's results: nothing clears it
+    // there, and a later, larger edit would read its floats as the touched words of its box: 1.0f is "touched, voxels 0..0, 0..0, 0..8" — five
+    // chunks invalidated for nothing in one of 3 600 random edit sequences, profiles/round5/README.md)
+    const size_t need_bytes = ((e->total + 255) & ~(size_t)255) + 1024;
     if (e->d_results_bytes < need_bytes) {  // (grown on demand; a fresh block starts zeroed, later ones are cleared behind every collect)
         IVX_HIP_CHECK(ivx_stream_sync(s));
         if (e->d_results) (void)hipFree(e->d_results);
@@ -2008,6 +2011,7 @@ static int absorb_enqueue(ivx_grid* g, const char* who, int capsule, const float
         e->d_results_bytes = cap;
     }
     char* base = e->d_results;
+    const size_t off_dens = e->d_results_bytes - 1024;
     const float* d_dens = g->dens_dev;
     if (!(g->has_dens && memcmp(g->dens_host, densities, sizeof(g->dens_host)) == 0)) {  // another table than the resident one
         if ((rc = h2d(g, base + off_dens, densities, 1024))) return rc;

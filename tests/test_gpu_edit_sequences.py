@@ -13,7 +13,9 @@ from impact_amd.voxel import VoxelObjectMesh
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", pu.fuzz_seeds([1, 2, 3, 4, 5, 6]))
+# (105940: found by round 5's sweep — a tiny edit followed by a long capsule, densities not resident: the table uploaded behind the small edit's
+# results was read as touched words by the large one, five chunks invalidated for nothing)
+@pytest.mark.parametrize("seed", pu.fuzz_seeds([1, 2, 3, 4, 5, 6, 105940]))
 def test_random_edit_sequence(ctx, seed):
     rng = np.random.default_rng(seed)
     graph = scenes.asteroid_scene(0.3) if seed % 3 else scenes.box_scene((40.0, 26.0, 33.0))
