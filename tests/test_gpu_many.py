@@ -424,3 +424,109 @@ def test_contexts_come_and_go_around_many_calls(ctx):
         round_trip()
     after = free_bytes()
     assert before - after < (8 << 20), f"device memory shrank by {before - after} bytes over 50 contexts"
+
+
+@pytest.mark.parametrize("seed", pu.fuzz_seeds([13, 14, 20, 21, 26, 28]))
+def test_random_batches_of_contacts_pairs_and_probe_syncs(ctx, seed):
+    """the batched forms of a frame's other per-object loops on random data — a handful of bodies of random shape, extent and pose; a random
+    collidable (sphere / plane / capsule) per body, a random list of pairs (bodies repeated, pairs apart, pairs deep inside one another), a
+    random bite per body with its mesh and probe sync — against the single-object calls, byte for byte (those are held to the oracle in
+    test_gpu_contacts.py, test_gpu_collide.py and test_gpu_mesh_sync.py)"""
+    import test_gpu_collide as tc
+
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(3, 7))
+    shapes = []
+    for _ in range(n):
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            shapes.append((scenes.sphere_scene(float(rng.uniform(9.0, 26.0))), [1.0, 0.5][int(rng.integers(0, 2))]))
+        elif kind == 1:
+            shapes.append((scenes.box_scene(tuple(float(x) for x in rng.uniform(6.0, 34.0, 3))), 1.0))
+        else:
+            shapes.append((scenes.asteroid_scene(float(rng.uniform(0.2, 0.35))), 1.0))
+    objs = [tc.both(ctx, g_, e_)[1] for g_, e_ in shapes]
+    for g in objs:
+        g.collision_probes_recompute()
+    # poses: centres of mass on a line with random gaps (some overlap, some do not), random rotations
+    pose, x = [], 0.0
+    for g in objs:
+        occ = np.asarray(g.update_occupied_voxel_ranges(), dtype=np.float64)
+        com = (0.5 * (occ[:, 0] + occ[:, 1]) * g.voxel_extent).astype(np.float32)
+        half = float(0.5 * (occ[:, 1] - occ[:, 0]).max() * g.voxel_extent)
+        ax = rng.normal(size=3)
+        ax /= np.linalg.norm(ax)
+        ang = rng.uniform(-1.5, 1.5)
+        q = np.array([*(ax * np.sin(ang / 2)), np.cos(ang / 2)], dtype=np.float32)
+        x += half * rng.uniform(0.3, 1.2)
+        pose.append((q, tc.placed(com, q, [x, rng.uniform(-2.0, 2.0), rng.uniform(-2.0, 2.0)]), com))
+        x += half * rng.uniform(0.3, 1.2)
+    resp = (0.25, 0.6, 0.4)
+    # ---- a collidable per body
+    qs = many.collidable_queries(n)
+    want = []
+    for k, g in enumerate(objs):
+        q, t, com = pose[k]
+        mode = int(rng.integers(0, 3))
+        qs[k]["mode"], qs[k]["rotation_xyzw"], qs[k]["translation"], qs[k]["response"] = mode, q, t, resp
+        qs[k]["collidable_id_a"], qs[k]["collidable_id_b"], qs[k]["body_a"], qs[k]["body_b"] = 40 + k, 7, k, 0x80000000
+        centre = np.array([float(rng.uniform(-5, x + 5)), float(rng.uniform(-8, 8)), float(rng.uniform(-8, 8))], dtype=np.float32)
+        if mode == 0:
+            r = float(rng.uniform(2.0, 14.0))
+            qs[k]["shape3"], qs[k]["shape1"] = centre, r
+            want.append(g.sphere_contacts(q, t, centre, r, 40 + k, 7, k, 0x80000000, resp, capacity=65536))
+        elif mode == 1:
+            nrm = rng.normal(size=3)
+            nrm = (nrm / np.linalg.norm(nrm)).astype(np.float32)
+            d = float(rng.uniform(-6.0, 6.0))
+            qs[k]["shape3"], qs[k]["shape1"] = nrm, d
+            want.append(g.plane_contacts(q, t, nrm, d, 40 + k, 7, k, 0x80000000, resp, capacity=65536))
+        else:
+            v = (rng.normal(size=3) * rng.uniform(0.0, 12.0)).astype(np.float32)
+            r = float(rng.uniform(1.5, 8.0))
+            qs[k]["shape3"], qs[k]["shape3b"], qs[k]["shape1"] = centre, v, r
+            want.append(g.capsule_contacts(q, t, centre, v, r, 40 + k, 7, k, 0x80000000, resp, capacity=65536))
+    got, off = many.voxel_object_contacts_many(objs, qs)
+    assert off[-1] == len(got) == sum(len(w) for w in want)
+    for k, w in enumerate(want):
+        assert got[off[k]:off[k + 1]].tobytes() == w.tobytes(), f"collidable of body {k}"
+    exercised = [len(got)]
+    # ---- a random list of pairs
+    pair_ids = [(int(a), int(b)) for a, b in rng.integers(0, n, (int(rng.integers(1, 10)), 2)) if a != b]
+    pairs, want = [], []
+    for i, j in pair_ids:
+        (qa, ta, ca), (qb, tb, cb) = pose[i], pose[j]
+        pairs.append(dict(a=objs[i], b=objs[j], rotation_a=qa, translation_a=ta, center_of_mass_a=ca, rotation_b=qb, translation_b=tb, center_of_mass_b=cb,
+                          collidable_id_a=100 + i, collidable_id_b=100 + j, body_a=i, body_b=j, response=resp))
+        want.append(objs[i].mutual_contacts(qa, ta, ca, objs[j], qb, tb, cb, 100 + i, 100 + j, i, j, resp))
+    got, off = many.mutual_voxel_object_contacts_many(many.mutual_queries(pairs))
+    assert off[-1] == len(got) == sum(len(w) for w in want)
+    for k, w in enumerate(want):
+        assert got[off[k]:off[k + 1]].tobytes() == w.tobytes(), f"pair {pair_ids[k]}"
+    exercised.append(len(got))
+    # ---- a bite per body, mesh and probes of all synced in one call each; twins through the single-object calls
+    twins = [tc.both(ctx, g_, e_)[1] for g_, e_ in shapes]
+    for t in twins:
+        t.collision_probes_recompute()
+    inv = []
+    for g, t in zip(objs, twins):
+        occ = np.asarray(g.update_occupied_voxel_ranges(), dtype=np.float64)
+        c = (occ[:, 0] + rng.uniform(0.0, 1.0, 3) * (occ[:, 1] - occ[:, 0])).astype(np.float32)
+        r = float(rng.uniform(1.5, 6.0))
+        rg, rt = g.absorb_sphere(c, r + 2.0, r), t.absorb_sphere(c, r + 2.0, r)
+        np.testing.assert_array_equal(rg["invalidated"], rt["invalidated"])
+        t.mesh.sync_with_voxel_object(rt["invalidated"])
+        t.collision_probes_sync(rt["invalidated"])
+        inv.append(rg["invalidated"])
+    many.mesh_sync_many([g.mesh for g in objs], inv)
+    ns = many.collision_probes_sync_many(objs, inv)
+    for k, (g, t) in enumerate(zip(objs, twins)):
+        (gp, ge), (tp, te) = g.collision_probes(), t.collision_probes()
+        assert int(ns[k]) == len(tp) == len(gp), k
+        np.testing.assert_array_equal(ge, te)
+        for e in te:
+            np.testing.assert_array_equal(gp[e[3]:e[4]].view(np.uint32), tp[e[3]:e[4]].view(np.uint32))
+    exercised.append(int(sum(int(np.asarray(i_).sum()) for i_ in inv)))
+    assert pu.fuzzing() or (exercised[0] > 100 and exercised[1] > 0 and exercised[2] > 5), exercised  # (the committed seeds are ones that meet something)
+    for g in objs + twins:
+        g.close()
