@@ -43,6 +43,32 @@ def test_struct_sizes_match_header():
         assert dt[0].itemsize == dt[1], name
 
 
+def test_struct_sizes_match_the_c_compiler(tmp_path):
+    """the numpy mirrors of the header's records against `sizeof` as gcc lays the header's own structs out (the batched contact and pair queries, the
+    result records the `_many` calls fill in arrays: a mirror one field off reads every element after the first from the wrong place)"""
+    import subprocess
+
+    pairs = {"ivx_chunk_info": capi.CHUNK_INFO_DTYPE, "ivx_submesh": capi.SUBMESH_DTYPE, "ivx_mesh_counts": capi.MESH_COUNTS_DTYPE, "ivx_moments": capi.MOMENTS_DTYPE,
+             "ivx_region_desc": capi.REGION_DESC_DTYPE, "ivx_step_result": capi.STEP_RESULT_DTYPE, "ivx_absorb_result": capi.ABSORB_RESULT_DTYPE,
+             "ivx_slab_result": capi.SLAB_RESULT_DTYPE, "ivx_rigid_body": capi.RIGID_BODY_DTYPE, "ivx_kinematic_body": capi.KINEMATIC_BODY_DTYPE,
+             "ivx_contact": capi.CONTACT_DTYPE, "ivx_collidable_query": capi.COLLIDABLE_QUERY_DTYPE, "ivx_mutual_query": capi.MUTUAL_QUERY_DTYPE,
+             "ivx_solver_config": capi.SOLVER_CONFIG_DTYPE, "ivx_physics_result": capi.PHYSICS_RESULT_DTYPE, "ivx_extracted_object": capi.EXTRACTED_OBJECT_DTYPE,
+             "ivx_mesh_export_info": capi.MESH_EXPORT_DTYPE, "ivx_impact_fracturing_config": capi.IMPACT_FRACTURING_CONFIG_DTYPE,
+             "ivx_fracturing_properties": capi.FRACTURING_PROPERTIES_DTYPE}
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "impact_voxel_hip.h"\nint main(void) {\n' +
+                   "".join(f'    printf("{n} %zu\\n", sizeof({n}));\n' for n in pairs) + "    return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run(["gcc", "-I", inc, str(src), "-o", str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for n, dt in pairs.items():
+        assert int(got[n]) == dt.itemsize, f"{n}: the header's struct is {got[n]} bytes, its numpy mirror {dt.itemsize}"
+    # offsets the device code relies on in the queries (ids 8-byte aligned behind the floats)
+    assert capi.COLLIDABLE_QUERY_DTYPE.fields["collidable_id_a"][1] == 72 and capi.COLLIDABLE_QUERY_DTYPE.fields["response"][1] == 88
+    assert capi.MUTUAL_QUERY_DTYPE.fields["collidable_id_a"][1] == 96 and capi.MUTUAL_QUERY_DTYPE.fields["response"][1] == 120
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     """In this container there is no GPU: ivx_init must return IVX_ERR_HIP with a message."""
     import torch
