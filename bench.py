@@ -303,17 +303,23 @@ def summary_block(out):
             x = x[k]
         return round(x, 4) if isinstance(x, float) else x
 
-    parities = []
+    parities, failed = [], []
 
-    def walk(x):
+    def walk(x, path=""):
         if isinstance(x, dict):
             for k, v in x.items():
                 if k in ("parity", "parity_sample") and isinstance(v, dict) and "equal" in v:
                     parities.append(bool(v["equal"]))
+                    if not v["equal"]:
+                        failed.append(f"{path}/{k}: " + ",".join(str(n) for n in (v.get("differing") or [n_ for n_, b in v.items() if b is False])))
                 elif k == "parity" and isinstance(v, dict):
-                    parities.extend(bool(b) for b in v.values() if isinstance(b, bool))
+                    for n, b in v.items():
+                        if isinstance(b, bool):
+                            parities.append(b)
+                            if not b:
+                                failed.append(f"{path}/{k}/{n}")
                 else:
-                    walk(v)
+                    walk(v, f"{path}/{k}")
 
     walk(out)
     return {"ms_per_step": g("ms_per_step"), "sdf_sample_ms": g("stage_ms", "sdf_sample"), "roofline_frac": g("roofline", "frac"),
@@ -334,7 +340,7 @@ def summary_block(out):
                                                     g("fragments_frame", "probes_and_pairs", "mutual_pairs", "ms_looped")]},
             "config3_split_loop_ms": g("config3", "split_loop_ms"), "config5_single_grid_ms": g("config5_one_gpu", "single_grid_ms"),
             "config5_eight_slabs_one_gpu_ms": g("config5_one_gpu", "eight_slabs_one_gpu_ms"),
-            "cpu_baseline_voxels_per_s": g("cpu_baseline", "value"), "parity_all_equal": (all(parities) if parities else None), "parity_blocks": len(parities)}
+            "cpu_baseline_voxels_per_s": g("cpu_baseline", "value"), "parity_all_equal": (all(parities) if parities else None), "parity_blocks": len(parities), "parity_failed": failed}
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -738,7 +744,7 @@ def edit_benchmark(ctx, scale, o_big, reps=5):
         int(mesh.counts["n_indices"]) == n_idx_sync and int(mesh.counts["n_vertices"]) == n_vtx_sync
     obj.close()
     out = {"workload": f"absorbing sphere r={EDIT_RADIUS * scale:.1f} voxels at the surface of the headline body",
-           "edit_and_sync_overlapped_ms": round(1e3 * float(np.mean(t_over[1:])), 4), "overlapped_equals_sequential": bool(same_overlapped),
+           "edit_and_sync_overlapped_ms": round(1e3 * float(np.mean(t_over[1:])), 4), "parity": {"overlapped_equals_sequential": bool(same_overlapped)},
            "edit_ms": round(1e3 * float(np.mean(t_edit[1:])), 4), "remesh_after_ms": round(1e3 * float(np.mean(t_remesh[1:])), 4),
            "sync_after_ms": round(1e3 * float(np.mean(t_sync[1:])), 4),
            "edit_plus_sync_ms": round(1e3 * float(np.mean(t_edit[1:]) + np.mean(t_sync[1:])), 4), "emptied_voxels": emptied, "touched_chunks": touched,
