@@ -318,6 +318,10 @@ def summary_block(out):
                             parities.append(b)
                             if not b:
                                 failed.append(f"{path}/{k}/{n}")
+                elif k == "parity" and isinstance(v, str):  # (the legs whose comparison is a sentence: "MISMATCH" when it failed)
+                    parities.append(v != "MISMATCH")
+                    if v == "MISMATCH":
+                        failed.append(f"{path}/{k}")
                 else:
                     walk(v, f"{path}/{k}")
 
