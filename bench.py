@@ -1430,8 +1430,9 @@ def main():
                     f"({obj.n_chunks} chunks on rank 0)")
         parallelism = f"x-slab domain decomposition over {world} GPUs, 1-voxel halos + region equivalences over {transport}"
         if native_comm is not None and world > 1:
-            parallelism += ("; neighbour exchanges on the compute stream (IVX_SLAB_OVERLAP=0)" if os.environ.get("IVX_SLAB_OVERLAP", "1")[:1] == "0"
-                            else "; neighbour exchanges on the communicator's own stream beside the slab's interior work (IVX_SLAB_OVERLAP=0 for the serial form)")
+            parallelism += ("; neighbour exchanges on the communicator's own stream beside the slab's interior work (IVX_SLAB_OVERLAP=1)"
+                            if os.environ.get("IVX_SLAB_OVERLAP", "0")[:1] == "1"
+                            else "; neighbour exchanges on the compute stream (the default; IVX_SLAB_OVERLAP=1 for the overlapped form)")
 
     def barrier():
         if dist is not None:

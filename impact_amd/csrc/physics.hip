@@ -714,8 +714,10 @@ constexpr uint32_t MG_THREADS = 256u;
 constexpr uint32_t MG_SPIN_LIMIT = 1u << 22;  // a poll loop that never sees its count gives up and flags the launch (every spin is bounded)
 
 // `rec`: the item's packed record, already in registers (load_packed: fetched a level ahead, behind the grid barrier's arrival)
+// Returns true when a poll gave up (the launch is flagged; the caller stops taking tiles: after a producer that never stored no tag can match
+// again, and every later tile would spin the full limit too).
 template <int PHASE>
-__device__ __forceinline__ void run_chain_mg(uint32_t item, uint2 bodies, uint32_t n_dyn, float factor, const PhysContact* __restrict__ pcs,
+__device__ __forceinline__ bool run_chain_mg(uint32_t item, uint2 bodies, uint32_t n_dyn, float factor, const PhysContact* __restrict__ pcs,
                                              __amdgpu_buffer_rsrc_t rs_acc, const PhysBody* __restrict__ cb, __amdgpu_buffer_rsrc_t rs_dyn,
                                              const float4 (&rec)[Packed<PHASE>::NJ], uint32_t item_index, const ReplayView& rv, bool one_xcd, bool live,
                                              bool no_wait, bool dry_chain, uint32_t* error) {
@@ -771,10 +773,10 @@ __device__ __forceinline__ void run_chain_mg(uint32_t item, uint2 bodies, uint32
         __builtin_amdgcn_s_sleep(1);
         if (spins > MG_SPIN_LIMIT) {
             if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (host-mapped: ivx_world_check_solve)
-            break;
+            return true;
         }
     }
-    if (!live || dry_chain) return;
+    if (!live || dry_chain) return false;
     constexpr uint32_t CJ = Packed<PHASE>::CJ, BJ = Packed<PHASE>::BJ;
     const PhysContact p0 = unpack_contact<PHASE>(rec), p1 = unpack_contact<PHASE>(rec + CJ), p2 = unpack_contact<PHASE>(rec + 2u * CJ),
                       p3 = unpack_contact<PHASE>(rec + 3u * CJ);
@@ -827,7 +829,7 @@ __device__ __forceinline__ void run_chain_mg(uint32_t item, uint2 bodies, uint32
                 __builtin_amdgcn_s_sleep(1);
                 if (spins > MG_SPIN_LIMIT) {  // like the other bounded spins: give up, flag the launch (ivx_world_check_solve)
                     __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    break;
+                    return true;
                 }
             }
         run_contact(type, q, st, x, factor, a);
@@ -867,6 +869,7 @@ __device__ __forceinline__ void run_chain_mg(uint32_t item, uint2 bodies, uint32
             st16_shared(rs_dyn, ib * DST + 32u, make_float4(x.qb.w, 0.0f, 0.0f, nb), one_xcd);
         }
     }
+    return false;
 }
 
 
@@ -969,8 +972,9 @@ __global__ __launch_bounds__(MG_THREADS) void k_solve_mg(uint32_t n_dyn, float f
     for (; t < n_tiles; t += W) {
         const uint32_t cur_item = nxt_item, cur_index = nxt_index;
         const uint2 cur_bodies = nxt_bodies;
-        run_chain_mg<PHASE>(cur_item, cur_bodies, n_dyn, factor, pcs, rs_acc, cb, rs_dyn, rec, cur_index, rv, one_xcd, cur_item != NONE, (dry & 3u) != 0u,
-                            (dry & 1u) != 0u, error);
+        const bool gave_up = run_chain_mg<PHASE>(cur_item, cur_bodies, n_dyn, factor, pcs, rs_acc, cb, rs_dyn, rec, cur_index, rv, one_xcd, cur_item != NONE,
+                                                 (dry & 3u) != 0u, (dry & 1u) != 0u, error);
+        if (__builtin_amdgcn_ballot_w64(gave_up) != 0ull) break;  // (the wave still makes the closing barrier's arrival below)
         fetch_tile(t + W);
     }
     // every tile of the launch done (one grid barrier) before the shared records go back to the body array
@@ -1223,8 +1227,11 @@ __device__ __forceinline__ void solve_cs_phase(const uint32_t wg, const uint32_t
             if ((dry & 2u) || __builtin_amdgcn_ballot_w64(need && !ok) == 0ull) break;
             __builtin_amdgcn_s_sleep(1);
             if (spins > MG_SPIN_LIMIT) {
+                // A producer that never stored (a working workgroup that is not resident): the versions can never match again, so every later
+                // round of this wave would spin the full limit too — hundreds of rounds, minutes. Flag the launch and leave the phase (there
+                // is no barrier below this loop): every wave gives up within one spin limit of its own and ivx_world_check_solve reports.
                 if (lane == 0u) __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (host-mapped: ivx_world_check_solve)
-                break;
+                return;
             }
         }
         if (ph.trace && lane == 0u) ph.trace[4u * r + 1u] = wall_clock64();

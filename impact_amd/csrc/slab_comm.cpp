@@ -7,8 +7,8 @@
 // the two xGMI links to the neighbours) go on a stream of the communicator's, behind an event that follows the packing — and the slab's next
 // sweep is split around their arrival: the derive sweep (after exchange 1) and the mesher's count (after exchange 2) first take the chunk
 // planes that read nothing of a ghost layer, the context's stream then waits for the exchange's event, the two face planes follow
-// (ivx_grid::ghost_event; derive.hip, step_fused.hip). Interior work so overlaps the link; IVX_SLAB_OVERLAP=0 puts the exchanges back on the
-// context's stream. The host waits once per step. Ghost layers are read in place from the receive buffers (ivx_halo_unpack_enqueue).
+// (ivx_grid::ghost_event; derive.hip, step_fused.hip). Interior work so overlaps the link. That overlapped form is OPT-IN for RCCL ranks
+// (IVX_SLAB_OVERLAP=1; ivx_comm_init says why): by default the exchanges run on the context's stream. The host waits once per step. Ghost layers are read in place from the receive buffers (ivx_halo_unpack_enqueue).
 //
 // Three transports behind one driver:
 //   * RCCL (ivx_comm_init): librccl is opened at run time (the copy already loaded in the process — e.g. the one PyTorch bundles —
@@ -420,8 +420,11 @@ int ivx_comm_init(ivx_ctx* c, int nranks, int rank, const void* unique_id128, iv
     m->nccl = nullptr;
     m->ipc = nullptr;
     {
+        // Opt-in: the overlapped choreography (exchanges on a second stream, the second exchange in two messages) has run between the in-process
+        // ranks of one GPU and as a one-rank RCCL self-test only — no box of this pool has had two GPUs. Until a run with two or more ranks is on
+        // record the serial form is what RCCL ranks get; IVX_SLAB_OVERLAP=1 turns the overlap on (tests/test_gpu_bench_multi.py runs both).
         const char* e = getenv("IVX_SLAB_OVERLAP");
-        m->overlap = !(e && e[0] == '0');
+        m->overlap = (e && e[0] == '1') ? 1 : 0;
     }
     if (nranks > 1) {
         int rc = load_rccl();
@@ -802,7 +805,10 @@ void ivx_slab_destroy(ivx_slab* sl) {
     if (!sl) return;
     (void)ivx_stream_sync(sl->comm->ctx->stream);
     if (sl->comm->comm_stream) (void)hipStreamSynchronize(sl->comm->comm_stream);
-    if (sl->grid) sl->grid->ghost_event = nullptr;
+    if (sl->grid) {  // (the events are the communicator's: a grid that outlives it must not wait on them)
+        sl->grid->ghost_event = sl->grid->face_ids_event = nullptr;
+        sl->grid->ghost_split = 0;
+    }
     (void)ivx_halo_clear(sl->grid, 0);
     (void)ivx_halo_clear(sl->grid, 1);
     for (int s = 0; s < 2; ++s) {
@@ -834,6 +840,15 @@ int ivx_slabs_step_enqueue(ivx_slab** slabs, size_t n) {
     auto note = [&](int code) {
         if (code && !local_err) local_err = code;
     };
+    // An arrival event that the step before handed to a grid and no sweep consumed (a slab with a local error skips its sweeps): the context's
+    // stream takes the wait here, before anything of this step re-packs the send buffers or reads the receive buffers those messages used.
+    for (size_t i = 0; i < n; ++i) {
+        ivx_grid* g = slabs[i]->grid;
+        if (g->ghost_event) (void)hipStreamWaitEvent(c->ctx->stream, static_cast<hipEvent_t>(g->ghost_event), 0);
+        if (g->face_ids_event) (void)hipStreamWaitEvent(c->ctx->stream, static_cast<hipEvent_t>(g->face_ids_event), 0);
+        g->ghost_event = g->face_ids_event = nullptr;
+        g->ghost_split = 0;
+    }
     if (c->nranks == 1) {
         // a world of one has nobody to wait for between the phases: the whole step as one enqueue, then the record (written where the gather would
         // put it, with the step's small results on the way)

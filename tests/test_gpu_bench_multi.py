@@ -20,13 +20,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_bench_line_on_every_gpu_of_the_box():
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_bench_line_on_every_gpu_of_the_box(overlap):
+    """Both forms of the neighbour exchange (IVX_SLAB_OVERLAP: 0 = on the context's stream, the default; 1 = on the communicator's own stream
+    beside the interior work) must give the same triangles and regions: the first box with two GPUs tests both."""
     import torch
 
     n = min(torch.cuda.device_count(), 8)  # (counting devices does not initialise the GPU)
     if n < 2:
         pytest.skip("one GPU: RCCL refuses two ranks on one device (the multi-process protocol test is tests/test_gpu_slabs_ipc.py)")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", IVX_SLAB_OVERLAP=overlap)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-pile"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
