@@ -409,6 +409,9 @@ __device__ __forceinline__ bool probe_contact(const MutParams& p, const float* p
         hit->pos = point;
         hit->nrm = sn;
         hit->depth = -sd * p.ext_s;
+#ifdef IVX_MUTATION_CHECK  // tools/mutation_check.sh: one ulp off in code the single-pair and the batched call share — only the oracle can tell
+        hit->depth = __uint_as_float(__float_as_uint(hit->depth) + 1u);
+#endif
         const V3 q = pp * p.inv_p;
         hit->ijk[0] = as_index(q.x), hit->ijk[1] = as_index(q.y), hit->ijk[2] = as_index(q.z);
     }

@@ -276,6 +276,9 @@ __device__ __forceinline__ void svc_emit_body(const SvcEmitArgs& a, uint32_t bid
             c.position[0] = hits[k].pos.x, c.position[1] = hits[k].pos.y, c.position[2] = hits[k].pos.z;
             c.normal[0] = hits[k].nrm.x, c.normal[1] = hits[k].nrm.y, c.normal[2] = hits[k].nrm.z;
             c.depth = hits[k].depth;
+#ifdef IVX_MUTATION_CHECK  // tools/mutation_check.sh (see collide.hip)
+            c.depth = __uint_as_float(__float_as_uint(c.depth) + 1u);
+#endif
             c.restitution = p.restitution;
             c.static_friction = p.static_friction;
             c.dynamic_friction = p.dynamic_friction;

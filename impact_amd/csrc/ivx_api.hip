@@ -2372,9 +2372,14 @@ int ivx_voxel_object_contacts_many(ivx_grid* const* grids, size_t n, const ivx_c
         int32_t vlo[3], vhi[3];
         uint32_t lo[3], cc[3];
         bool hit;
+        size_t off;  // where this query's counts and offsets start in its object's scratch
     };
     static thread_local std::vector<Box> box;
     box.assign(n, Box{});
+    // (an object may appear more than once — near a sphere AND the ground plane, the reference's collision pass visits every collidable near an
+    // object —: each query gets a range of its own in the object's scratch, the recorded chains of one object must not share counts)
+    static thread_local std::vector<std::pair<ivx_grid*, size_t>> scratch_need;
+    scratch_need.clear();
     // what may wait or allocate, ahead of the recording: occupied ranges, the objects' scratch for counts and offsets, the pinned block
     for (size_t i = 0; i < n; ++i) {
         const ivx_collidable_query& q = queries[i];
@@ -2382,8 +2387,18 @@ int ivx_voxel_object_contacts_many(ivx_grid* const* grids, size_t n, const ivx_c
         if ((rc = reference_occupied(grids[i], occ))) return rc;
         Box& b = box[i];
         b.hit = contacts_box(grids[i], q.mode, q.rotation_xyzw, q.translation, q.shape3, q.shape3b, q.shape1, occ, b.vlo, b.vhi, b.lo, b.cc);
-        if (b.hit && (rc = ensure_dev_scratch(grids[i], 2 * (size_t)b.cc[0] * b.cc[1] * b.cc[2] * 4 + 64))) return rc;
+        if (!b.hit) continue;
+        const size_t need = (2 * (size_t)b.cc[0] * b.cc[1] * b.cc[2] * 4 + 64 + 255) & ~(size_t)255;
+        auto it = std::find_if(scratch_need.begin(), scratch_need.end(), [&](const std::pair<ivx_grid*, size_t>& e) { return e.first == grids[i]; });
+        if (it == scratch_need.end()) {
+            scratch_need.emplace_back(grids[i], (size_t)0);
+            it = scratch_need.end() - 1;
+        }
+        b.off = it->second;
+        it->second += need;
     }
+    for (const auto& e : scratch_need)
+        if ((rc = ensure_dev_scratch(e.first, e.second))) return rc;
     const size_t totals_bytes = (n * 4 + 63) & ~(size_t)63;
     if ((rc = ctx_pinned_scratch(c, totals_bytes + 4096))) return rc;
     uint32_t* totals = static_cast<uint32_t*>(c->pinned_scratch);
@@ -2393,7 +2408,7 @@ int ivx_voxel_object_contacts_many(ivx_grid* const* grids, size_t n, const ivx_c
         const Box& b = box[i];
         ivx_grid* g = grids[i];
         const size_t n_box = (size_t)b.cc[0] * b.cc[1] * b.cc[2];
-        char* base = static_cast<char*>(g->dev_scratch);
+        char* base = static_cast<char*>(g->dev_scratch) + b.off;
         return ivx_launch_sphere_contacts(g, b.lo, b.cc, b.vlo, b.vhi, q.rotation_xyzw, q.translation, q.shape3, q.shape3b, q.shape1, q.collidable_id_a, q.collidable_id_b,
                                           q.body_a, q.body_b, q.response, reinterpret_cast<uint32_t*>(base), reinterpret_cast<uint32_t*>(base + n_box * 4), d_total, d_out,
                                           cap_i, pass, q.mode);

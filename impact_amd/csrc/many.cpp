@@ -349,7 +349,16 @@ extern "C" {
 
 int ivx_many_begin(ivx_ctx* c) {
     IVX_REQUIRE(c, IVX_ERR_INVALID, "ivx_many_begin: null context");
-    IVX_REQUIRE(!t_rec, IVX_ERR_STATE, "ivx_many_begin: a batch is being recorded on this thread already");
+    if (t_rec) {
+        // A bracket this thread opened and never closed (a caller that failed between begin and flush — a Python exception, an early return):
+        // refusing every later bracket for good would take ivx_split_off_all and ivx_copy_polyhedra down with it. The stale bracket is closed
+        // first — what it recorded goes out, nothing is dropped silently, its failure (if any) stays in the context's sticky error.
+        Recorder* stale = t_rec;
+        stale->on = true;
+        (void)flush_recorded(stale);
+        stale->on = false;
+        t_rec = nullptr;
+    }
     if (!c->many_recorder) c->many_recorder = new (std::nothrow) Recorder();
     Recorder* r = static_cast<Recorder*>(c->many_recorder);
     IVX_REQUIRE(r, IVX_ERR_CAPACITY, "ivx_many_begin: out of host memory");

@@ -5,6 +5,7 @@ of one. Nothing here computes."""
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -104,15 +105,16 @@ def collidable_queries(n: int) -> np.ndarray:
     return q
 
 
-_contact_buffers = {}
+_contact_buffers = threading.local()
 
 
 def _contact_buffer(capacity: int) -> np.ndarray:
     """the list a contact call writes into, kept between calls (a fresh 16 MB array per call costs more than the call: the C side fills the
-    first n records, the caller gets a copy of those)"""
-    buf = _contact_buffers.get(capacity)
+    first n records, the caller gets a copy of those). Per thread: ctypes releases the GIL during the call."""
+    bufs = _contact_buffers.__dict__.setdefault("by_capacity", {})
+    buf = bufs.get(capacity)
     if buf is None:
-        buf = _contact_buffers[capacity] = np.empty(capacity, dtype=capi.CONTACT_DTYPE)
+        buf = bufs[capacity] = np.empty(capacity, dtype=capi.CONTACT_DTYPE)
     return buf
 
 

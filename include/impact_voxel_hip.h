@@ -342,7 +342,8 @@ int ivx_absorb_mutual(ivx_grid* a, const float rotation_a[4], const float transl
  * chain per object, in the order the objects first appear — and the flush issues them merged, front by front. A call on an object of another
  * context inside the bracket is issued on that context's stream, unrecorded. ivx_many_flush reports a failure of any flush since the begin
  * (launches that a failed flush dropped never run; `_collect` calls that wait for them fail with IVX_ERR_HIP). The recorder and its staging
- * blocks belong to the context and go with ivx_shutdown. ivx_many_stats: out[0] launches recorded, [1] merged launches issued, [2] flushes
+ * blocks belong to the context and go with ivx_shutdown. A begin on a thread whose last bracket was never flushed (a caller that failed in
+ * between) closes that bracket first: what it recorded goes out, the thread is not left refusing brackets. ivx_many_stats: out[0] launches recorded, [1] merged launches issued, [2] flushes
  * made on this context so far. */
 int ivx_many_begin(ivx_ctx*);
 int ivx_many_flush(ivx_ctx*);

@@ -201,6 +201,18 @@ def oracle_next_rows_digest():
     qa, ta, qb, tb = _poses(s, ca, cb)
     wi, mp, mn, md = A.mutual_contacts(pa, ca, qa, ta, B, pb, cb, qb, tb)
     out["mutual_contacts"] = _contacts_digest([contact_id(ids[0], ids[1], 0, int(r[1]), int(r[2]), int(r[3])) for r in wi], mp, mn, md)
+    # the batched forms' lists (ivx_mutual_voxel_object_contacts_many, ivx_voxel_object_contacts_many): the pairs (A, B) and (B, A); A against the
+    # sphere AND the plane (one object, two collidables) and B against a sphere above it — each the concatenation of the single lists, in order
+    wi2, mp2, mn2, md2 = B.mutual_contacts(pb, cb, qb, tb, A, pa, ca, qa, ta)
+    out["pairs_list"] = {"offsets": [0, int(len(wi)), int(len(wi) + len(wi2))],
+                         **_contacts_digest([contact_id(ids[0], ids[1], 0, int(r[1]), int(r[2]), int(r[3])) for r in wi] +
+                                            [contact_id(ids[1], ids[0], 0, int(r[1]), int(r[2]), int(r[3])) for r in wi2],
+                                            np.concatenate([mp, mp2]), np.concatenate([mn, mn2]), np.concatenate([md, md2]))}
+    ctr_b = np.array([0.5 * (a + b) for a, b in B.info()["occupied_voxel_ranges"]], dtype=np.float32)
+    i4, p4, n4, d4 = B.sphere_contacts(qb, tb, _f32(s["b_centre_in_world"]) + _f32(cs["offset"]) * np.float32(0.5), cs["radius"])
+    out["collidables_list"] = {"offsets": [0, int(len(i1)), int(len(i1) + len(i2)), int(len(i1) + len(i2) + len(i4))],
+                               **_contacts_digest(cid(i1) + cid(i2) + cid(i4), np.concatenate([p1, p2, p4]), np.concatenate([n1, n2, n4]),
+                                                  np.concatenate([d1, d2, d4]))}
     r1 = A.absorb_sphere(ctr + _f32(s["bite"]["offset"]), s["bite"]["radius"] + 2.0, s["bite"]["radius"])
     out["bite"] = _edit_digest(r1, "removed64")
     mesh.sync(r1["invalidated"])
@@ -257,6 +269,23 @@ def gpu_next_rows_digest(ctx):
     qa, ta, qb, tb = _poses(s, ca, cb)
     mc = A.mutual_contacts(qa, ta, ca, B, qb, tb, cb, ids[0], ids[1], bodies[0], bodies[1], resp)
     out["mutual_contacts"] = cdig(mc)
+    from impact_amd import many
+
+    pair = dict(rotation_a=qa, translation_a=ta, center_of_mass_a=ca, rotation_b=qb, translation_b=tb, center_of_mass_b=cb, response=resp)
+    pairs = [dict(pair, a=A, b=B, collidable_id_a=ids[0], collidable_id_b=ids[1], body_a=bodies[0], body_b=bodies[1]),
+             dict(a=B, b=A, rotation_a=qb, translation_a=tb, center_of_mass_a=cb, rotation_b=qa, translation_b=ta, center_of_mass_b=ca, response=resp,
+                  collidable_id_a=ids[1], collidable_id_b=ids[0], body_a=bodies[1], body_b=bodies[0])]
+    pl, po = many.mutual_voxel_object_contacts_many(many.mutual_queries(pairs))
+    out["pairs_list"] = {"offsets": [int(x) for x in po], **cdig(pl)}
+    q = many.collidable_queries(3)
+    for k in range(3):
+        q[k]["collidable_id_a"], q[k]["collidable_id_b"], q[k]["body_a"], q[k]["body_b"], q[k]["response"] = ids[0], ids[1], bodies[0], bodies[1], resp
+    q[0]["mode"], q[0]["shape3"], q[0]["shape1"] = 0, ctr + _f32(cs["offset"]), cs["radius"]
+    q[1]["mode"], q[1]["shape3"], q[1]["shape1"] = 1, _f32(cp["normal"]), float(ctr[1]) - cp["below_centre"]
+    q[2]["mode"], q[2]["shape3"], q[2]["shape1"] = 0, _f32(s["b_centre_in_world"]) + _f32(cs["offset"]) * np.float32(0.5), cs["radius"]
+    q[2]["rotation_xyzw"], q[2]["translation"] = qb, tb
+    cl, co = many.voxel_object_contacts_many([A, A, B], q)
+    out["collidables_list"] = {"offsets": [int(x) for x in co], **cdig(cl)}
     r1 = A.absorb_sphere(ctr + _f32(s["bite"]["offset"]), s["bite"]["radius"] + 2.0, s["bite"]["radius"])
     out["bite"] = _edit_digest(r1, "removed_moments")
     mesh_a.sync_with_voxel_object(r1["invalidated"])

@@ -128,8 +128,7 @@ def test_mutual_contacts_of_many_pairs(ctx):
     shapes = [(scenes.sphere_scene(24.0), 1.0), (scenes.box_scene((30.0, 30.0, 30.0)), 1.0), (scenes.sphere_scene(28.0), 0.5), (scenes.asteroid_scene(0.3), 1.0),
               (scenes.sphere_scene(16.0), 1.0)]
     objs = [both(ctx, g, e) for g, e in shapes]
-    for o, g in objs:
-        probes_both(o, g)
+    probes = [probes_both(o, g) for o, g in objs]
     rng = np.random.default_rng(5)
     pose = []
     x = 0.0
@@ -154,6 +153,12 @@ def test_mutual_contacts_of_many_pairs(ctx):
     assert off[0] == 0 and off[-1] == len(got) == sum(len(w) for w in want)
     for n, w in enumerate(want):
         assert_contacts_equal(got[off[n] : off[n + 1]], w)
+    # ... and against the ORACLE's lists (the batched form's scan / count / emit code is the single-pair call's: a defect the two share would
+    # pass the comparison above)
+    for n, (i, j) in enumerate(pair_ids):
+        (qa, ta, ca), (qb, tb, cb) = pose[i], pose[j]
+        o_want, _ = oracle_contact_list(objs[i][0], probes[i], ca, qa, ta, objs[j][0], probes[j], cb, qb, tb, 100 + i, 100 + j, i, j, resp)
+        assert_contacts_equal(got[off[n] : off[n + 1]], o_want)
     # twice the same list: nothing kept between calls; and the empty list
     got2, off2 = many.mutual_voxel_object_contacts_many(many.mutual_queries(pairs))
     np.testing.assert_array_equal(off2, off)

@@ -322,11 +322,12 @@ def test_many_objects_against_a_collidable_each(ctx):
     no contacts at all —: object by object the very list of the single-object call (same order, ids, flags, geometry bit for bit)"""
     from impact_amd import many
 
-    bodies = [both(ctx, scenes.sphere_scene(12.0 + 3.0 * k), 1.0)[1] for k in range(4)] + [both(ctx, scenes.box_scene((20.0, 14.0, 18.0)), 0.5)[1],
-                                                                                       both(ctx, scenes.asteroid_scene(0.25), 1.0)[1]]
+    pairs = [both(ctx, scenes.sphere_scene(12.0 + 3.0 * k), 1.0) for k in range(4)] + [both(ctx, scenes.box_scene((20.0, 14.0, 18.0)), 0.5),
+                                                                                   both(ctx, scenes.asteroid_scene(0.25), 1.0)]
+    oracles, bodies = [p[0] for p in pairs], [p[1] for p in pairs]
     rng = np.random.default_rng(5)
     q = many.collidable_queries(len(bodies))
-    want = []
+    want, o_want = [], []  # the single-object calls' lists and the ORACLE's (the batched form shares its device code with the former)
     for i, g in enumerate(bodies):
         occ = np.array(g.update_occupied_voxel_ranges(), dtype=np.float64) * g.voxel_extent
         lo, hi = occ[:, 0], occ[:, 1]
@@ -346,18 +347,39 @@ def test_many_objects_against_a_collidable_each(ctx):
         if kind == 0:
             q[i]["shape3"], q[i]["shape1"] = top.astype(np.float32), 4.0 * g.voxel_extent
             want.append(g.sphere_contacts(rot, t, q[i]["shape3"], float(q[i]["shape1"]), 7 + i, 99, i, 0x80000000, resp))
+            o_want.append(oracle_contact_list(oracles[i], rot, t, q[i]["shape3"], float(q[i]["shape1"]), 7 + i, 99, i, 0x80000000, resp))
         elif kind == 1:
             n = np.array([0.05, 1.0, 0.02])
             n = (n / np.linalg.norm(n)).astype(np.float32)
             q[i]["shape3"], q[i]["shape1"] = n, float(lo[1] + 2.0 * g.voxel_extent)
             want.append(g.plane_contacts(rot, t, n, float(q[i]["shape1"]), 7 + i, 99, i, 0x80000000, resp))
+            o_want.append(oracle_plane_contact_list(oracles[i], rot, t, n, float(q[i]["shape1"]), 7 + i, 99, i, 0x80000000, resp))
         else:
             q[i]["shape3"], q[i]["shape3b"], q[i]["shape1"] = top.astype(np.float32), np.array([3.0, 1.0, -2.0], dtype=np.float32), 3.0 * g.voxel_extent
             want.append(g.capsule_contacts(rot, t, q[i]["shape3"], q[i]["shape3b"], float(q[i]["shape1"]), 7 + i, 99, i, 0x80000000, resp))
+            o_want.append(oracle_capsule_contact_list(oracles[i], rot, t, q[i]["shape3"], q[i]["shape3b"], float(q[i]["shape1"]), 7 + i, 99, i, 0x80000000, resp))
     got, off = many.voxel_object_contacts_many(bodies, q)
     assert int(off[-1]) == sum(len(w) for w in want) and len(want[3]) == 0 and sum(len(w) for w in want) > 50
     for i, w in enumerate(want):
         assert_contacts_equal(got[off[i]:off[i + 1]], w)
+        assert_contacts_equal(got[off[i]:off[i + 1]], o_want[i])
+    # one object against several collidables in one call (the reference's collision pass visits every collidable near an object): objects 0 and
+    # 1 twice more each, with the other's kind of collidable swapped in — every query its own list, the oracle's
+    idx = [0, 1, 0, 1, 4]
+    q2 = q[idx].copy()
+    lo0 = float(np.array(bodies[0].update_occupied_voxel_ranges(), dtype=np.float64)[1, 0] * bodies[0].voxel_extent)
+    q2[2]["mode"], q2[2]["shape3"], q2[2]["shape1"] = q[1]["mode"], q[1]["shape3"], lo0 + 2.0 * bodies[0].voxel_extent  # the plane, two voxels into body 0
+    q2[3]["mode"], q2[3]["shape3"], q2[3]["shape1"] = q[0]["mode"], q[0]["shape3"], q[0]["shape1"]  # body 0's sphere against body 1
+    got2, off2 = many.voxel_object_contacts_many([bodies[k] for k in idx], q2)
+    lists2 = [o_want[0], o_want[1],
+              oracle_plane_contact_list(oracles[0], q2[2]["rotation_xyzw"], q2[2]["translation"], q2[2]["shape3"], float(q2[2]["shape1"]), 7, 99, 0, 0x80000000,
+                                        tuple(float(x) for x in q2[2]["response"])),
+              oracle_contact_list(oracles[1], q2[3]["rotation_xyzw"], q2[3]["translation"], q2[3]["shape3"], float(q2[3]["shape1"]), 8, 99, 1, 0x80000000,
+                                  tuple(float(x) for x in q2[3]["response"])),
+              o_want[4]]
+    assert int(off2[-1]) == sum(len(w) for w in lists2) and len(lists2[2]) > 0
+    for i, w in enumerate(lists2):
+        assert_contacts_equal(got2[off2[i]:off2[i + 1]], w)
     # too small a capacity: the error, and the sizes it would have taken
     with pytest.raises(Exception):
         many.voxel_object_contacts_many(bodies, q, capacity=8)

@@ -445,9 +445,14 @@ def test_random_batches_of_contacts_pairs_and_probe_syncs(ctx, seed):
             shapes.append((scenes.box_scene(tuple(float(x) for x in rng.uniform(6.0, 34.0, 3))), 1.0))
         else:
             shapes.append((scenes.asteroid_scene(float(rng.uniform(0.2, 0.35))), 1.0))
-    objs = [tc.both(ctx, g_, e_)[1] for g_, e_ in shapes]
-    for g in objs:
+    import test_gpu_contacts as tcon
+
+    both_ = [tc.both(ctx, g_, e_) for g_, e_ in shapes]
+    orcs, objs = [b[0] for b in both_], [b[1] for b in both_]
+    o_probes = []  # (the oracle's probe lists: its mutual contacts take them as inputs)
+    for o, g in both_:
         g.collision_probes_recompute()
+        o_probes.append(o.collision_probes(o.mesh()))
     # poses: centres of mass on a line with random gaps (some overlap, some do not), random rotations
     pose, x = [], 0.0
     for g in objs:
@@ -464,7 +469,7 @@ def test_random_batches_of_contacts_pairs_and_probe_syncs(ctx, seed):
     resp = (0.25, 0.6, 0.4)
     # ---- a collidable per body
     qs = many.collidable_queries(n)
-    want = []
+    want, o_want = [], []  # the single-object calls' lists and the ORACLE's (the batched forms share device code with the former)
     for k, g in enumerate(objs):
         q, t, com = pose[k]
         mode = int(rng.integers(0, 3))
@@ -475,21 +480,25 @@ def test_random_batches_of_contacts_pairs_and_probe_syncs(ctx, seed):
             r = float(rng.uniform(2.0, 14.0))
             qs[k]["shape3"], qs[k]["shape1"] = centre, r
             want.append(g.sphere_contacts(q, t, centre, r, 40 + k, 7, k, 0x80000000, resp, capacity=65536))
+            o_want.append(tcon.oracle_contact_list(orcs[k], q, t, centre, r, 40 + k, 7, k, 0x80000000, resp))
         elif mode == 1:
             nrm = rng.normal(size=3)
             nrm = (nrm / np.linalg.norm(nrm)).astype(np.float32)
             d = float(rng.uniform(-6.0, 6.0))
             qs[k]["shape3"], qs[k]["shape1"] = nrm, d
             want.append(g.plane_contacts(q, t, nrm, d, 40 + k, 7, k, 0x80000000, resp, capacity=65536))
+            o_want.append(tcon.oracle_plane_contact_list(orcs[k], q, t, nrm, d, 40 + k, 7, k, 0x80000000, resp))
         else:
             v = (rng.normal(size=3) * rng.uniform(0.0, 12.0)).astype(np.float32)
             r = float(rng.uniform(1.5, 8.0))
             qs[k]["shape3"], qs[k]["shape3b"], qs[k]["shape1"] = centre, v, r
             want.append(g.capsule_contacts(q, t, centre, v, r, 40 + k, 7, k, 0x80000000, resp, capacity=65536))
+            o_want.append(tcon.oracle_capsule_contact_list(orcs[k], q, t, centre, v, r, 40 + k, 7, k, 0x80000000, resp))
     got, off = many.voxel_object_contacts_many(objs, qs)
     assert off[-1] == len(got) == sum(len(w) for w in want)
     for k, w in enumerate(want):
         assert got[off[k]:off[k + 1]].tobytes() == w.tobytes(), f"collidable of body {k}"
+        tcon.assert_contacts_equal(got[off[k]:off[k + 1]], o_want[k])
     exercised = [len(got)]
     # ---- a random list of pairs
     pair_ids = [(int(a), int(b)) for a, b in rng.integers(0, n, (int(rng.integers(1, 10)), 2)) if a != b]
@@ -503,6 +512,10 @@ def test_random_batches_of_contacts_pairs_and_probe_syncs(ctx, seed):
     assert off[-1] == len(got) == sum(len(w) for w in want)
     for k, w in enumerate(want):
         assert got[off[k]:off[k + 1]].tobytes() == w.tobytes(), f"pair {pair_ids[k]}"
+        i, j = pair_ids[k]
+        (qa, ta, ca), (qb, tb, cb) = pose[i], pose[j]
+        ow, _ = tc.oracle_contact_list(orcs[i], o_probes[i], ca, qa, ta, orcs[j], o_probes[j], cb, qb, tb, 100 + i, 100 + j, i, j, resp)
+        tc.assert_contacts_equal(got[off[k]:off[k + 1]], ow)
     exercised.append(len(got))
     # ---- a bite per body, mesh and probes of all synced in one call each; twins through the single-object calls
     twins = [tc.both(ctx, g_, e_)[1] for g_, e_ in shapes]
