@@ -1528,7 +1528,7 @@ static int launch_solve_mg(ivx_world* w, uint32_t groups, hipStream_t stream, Re
 static bool solver_stationary(const ivx_world* w) {
     if (w->mg_disabled || w->solver_groups_forced == 1u || (w->solver_groups_forced >= 2u && w->solver_groups_forced <= 16u)) return false;
     for (int p = 0; p < 2; ++p)
-        if (w->n_levels[p] && !w->cs[p].n_tiles) return false;
+        if (w->n_levels[p] && !w->cs_feasible[p]) return false;
     if (!w->n_levels[0] && !w->n_levels[1]) return false;
     static const int per_cu = [] {
         int n = 0;
@@ -1537,7 +1537,7 @@ static bool solver_stationary(const ivx_world* w) {
     }();
     if (per_cu < 1) return false;
     for (int p = 0; p < 2; ++p)
-        if (w->n_levels[p] && (w->cs[p].n_tiles + PHYS_CS_WAVES - 1u) / PHYS_CS_WAVES > (uint32_t)w->ctx->n_cu / 8u) return false;
+        if (w->n_levels[p] && (((uint32_t)w->chain_start.size() - 1u + 31u) / 32u + PHYS_CS_WAVES - 1u) / PHYS_CS_WAVES > (uint32_t)w->ctx->n_cu / 8u) return false;
     if (w->solver_groups_forced == PHYS_SOLVER_STATIONARY) return true;
     // One workgroup with the bodies in LDS (k_solve) walks a level in ~4-5 us whatever its width — a barrier and the contacts' trip from memory —,
     // the chain-stationary solve in ~2.3 (velocity) / ~3.5 (positional) plus ~25 us of launches and census around it: it wins wherever the chain of
@@ -1656,9 +1656,11 @@ int ivx_launch_phys_solve(ivx_world* w) {
     if (w->n_contacts == 0) return IVX_OK;
     int rc;
     if (solver_stationary(w)) {
+        if ((rc = ivx_world_ensure_form(w, 2u))) return rc;
         w->solver_kind_used = 2u;
         return launch_solve_cs(w);
     }
+    if ((rc = ivx_world_ensure_form(w, 1u))) return rc;
     const uint32_t groups = solver_groups(w);
     w->solver_groups_used = groups;
     w->solver_kind_used = groups > 1u ? 1u : 0u;

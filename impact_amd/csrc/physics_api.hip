@@ -143,10 +143,12 @@ void build_chains(ivx_world* w) {
     uint32_t s = 0;
     while (s < n) {
         uint32_t e = s + 1;
-        while (e < n && e - s < PHYS_CHAIN_MAX && w->ordered[e].body_a == w->ordered[s].body_a && w->ordered[e].body_b == w->ordered[s].body_b) ++e;
+        while (e < n && e - s < PHYS_CHAIN_MAX && w->slot_bodies[2 * (size_t)e] == w->slot_bodies[2 * (size_t)s] &&
+               w->slot_bodies[2 * (size_t)e + 1] == w->slot_bodies[2 * (size_t)s + 1])
+            ++e;
         w->chain_start.push_back(s);
-        w->chain_bodies.push_back(w->ordered[s].body_a);
-        w->chain_bodies.push_back(w->ordered[s].body_b);
+        w->chain_bodies.push_back(w->slot_bodies[2 * (size_t)s]);
+        w->chain_bodies.push_back(w->slot_bodies[2 * (size_t)s + 1]);
         s = e;
     }
     w->chain_start.push_back(n);
@@ -167,6 +169,21 @@ void build_chains(ivx_world* w) {
             slap_t0 = t1_;                                                                                                          \
         }                                                                                                                           \
     } while (0)
+// can this phase run chain-stationary at all? (its tiles fit the working workgroups, no body with more than 65535 chains)
+bool stationary_feasible(ivx_world* w, uint32_t nch, uint32_t passes) {
+    const uint32_t n_tiles = (nch + 31u) / 32u;
+    if (nch == 0 || passes == 0 || n_tiles > PHYS_CS_WAVES * PHYS_CS_MAX_GROUPS) return false;
+    std::vector<uint32_t>& deg = w->scratch_count;
+    deg.assign(w->n_dyn, 0u);
+    for (uint32_t ch = 0; ch < nch; ++ch)
+        for (int side = 0; side < 2; ++side) {
+            const uint32_t b = w->chain_bodies[2 * (size_t)ch + side];
+            if (!(b & IVX_KINEMATIC_BODY)) deg[b] += 1u;
+        }
+    for (uint32_t b = 0; b < w->n_dyn; ++b)
+        if (deg[b] > 0xFFFFu) return false;
+    return true;
+}
 void build_stationary(ivx_world* w, int phase, uint32_t nch, uint32_t passes, const std::vector<uint32_t>& lvl) {
     auto slap_t0 = std::chrono::steady_clock::now();
     ivx_world::CsSchedule& cs = w->cs[phase];
@@ -175,26 +192,26 @@ void build_stationary(ivx_world* w, int phase, uint32_t nch, uint32_t passes, co
     cs.round_start_offset = (uint32_t)w->cs_round_start_host.size();
     cs.round_offset = (uint32_t)w->cs_round_mask_host.size();
     const uint32_t n_tiles = (nch + 31u) / 32u;
-    if (nch == 0 || passes == 0 || n_tiles > PHYS_CS_WAVES * PHYS_CS_MAX_GROUPS) return;
+    if (!w->cs_feasible[phase]) return;
     // degree of every dynamic body (chains that touch it) and a chain's rank among them: before sweep s of the chain the body's record has
     // been written s * degree + rank times (every sweep walks the chains in the same order)
     std::vector<uint32_t>& deg = w->scratch_count;
     deg.assign(w->n_dyn, 0u);
-    std::vector<uint32_t> rank(2 * (size_t)nch);
+    std::vector<uint32_t>& rank = w->scratch_rank;
+    rank.resize(2 * (size_t)nch);
     for (uint32_t ch = 0; ch < nch; ++ch)
         for (int side = 0; side < 2; ++side) {
             const uint32_t b = w->chain_bodies[2 * (size_t)ch + side];
             rank[2 * (size_t)ch + side] = (b & IVX_KINEMATIC_BODY) ? 0u : deg[b]++;
         }
-    for (uint32_t b = 0; b < w->n_dyn; ++b)
-        if (deg[b] > 0xFFFFu) return;
     IVX_SLAP("stationary: degrees");
     // the chains by the level of their first item, solve order inside a level: a counting sort (levels are small integers)
-    uint32_t max_level = 0;
-    for (size_t i = 0; i < (size_t)passes * nch; ++i) max_level = std::max(max_level, lvl[i]);
-    std::vector<uint32_t> order(nch);
+    const uint32_t max_level = w->n_levels[phase];
+    std::vector<uint32_t>& order = w->scratch_order;
+    order.resize(nch);
     {
-        std::vector<uint32_t> first(max_level + 2u, 0u);
+        std::vector<uint32_t>& first = w->scratch_first;
+        first.assign(max_level + 2u, 0u);
         for (uint32_t ch = 0; ch < nch; ++ch) first[lvl[ch] + 1u] += 1u;
         for (uint32_t l = 1; l <= max_level + 1u; ++l) first[l] += first[l - 1u];
         for (uint32_t ch = 0; ch < nch; ++ch) order[first[lvl[ch]]++] = ch;
@@ -204,12 +221,17 @@ void build_stationary(ivx_world* w, int phase, uint32_t nch, uint32_t passes, co
     w->cs_item_host.resize(slot0 + (size_t)n_tiles * 64u, 0xFFFFFFFFu);
     w->cs_bodies_host.resize(2 * (slot0 + (size_t)n_tiles * 64u), 0u);
     w->cs_vers_host.resize(slot0 + (size_t)n_tiles * 64u, 0u);
-    // a tile's rounds: the lanes of every level its items lie on (a table over the levels, reset through the list of the levels touched)
-    std::vector<uint64_t> mask_of(max_level + 1u, 0ull);
-    std::vector<uint32_t> touched;
+    // a tile's rounds: the lanes of every level its items lie on — a table of lane masks over the levels and a bitmap of the levels touched,
+    // walked in ascending order afterwards (no sort: the levels are small integers)
+    std::vector<uint64_t>& mask_of = w->scratch_mask;
+    mask_of.assign(max_level + 1u, 0ull);
+    std::vector<uint64_t>& bits = w->scratch_bits;
+    bits.assign((max_level + 64u) / 64u, 0ull);
+    w->cs_round_mask_host.reserve(w->cs_round_mask_host.size() + (size_t)n_tiles * 64u);
+    w->cs_round_level_host.reserve(w->cs_round_level_host.size() + (size_t)n_tiles * 64u);
     for (uint32_t t = 0; t < n_tiles; ++t) {
         const uint32_t first = t * 32u, cnt = std::min(32u, nch - first);
-        touched.clear();
+        uint32_t lo_w = 0xFFFFFFFFu, hi_w = 0u;
         for (uint32_t l = 0; l < cnt; ++l) {
             const uint32_t ch = order[first + l];
             const uint32_t s0 = w->chain_start[ch], len = w->chain_start[ch + 1] - s0;
@@ -226,55 +248,67 @@ void build_stationary(ivx_world* w, int phase, uint32_t nch, uint32_t passes, co
                 w->cs_bodies_host[2 * slot + 1] = body[side ^ 1];
                 w->cs_vers_host[slot] = (b & IVX_KINEMATIC_BODY) ? 0u : (deg[b] | (rank[2 * (size_t)ch + side] << 16));
             }
+            const uint64_t lanes = 3ull << (2u * l);
             for (uint32_t p = 0; p < passes; ++p) {
                 const uint32_t lv = lvl[(size_t)p * nch + ch];
-                if (!mask_of[lv]) touched.push_back(lv);
-                mask_of[lv] |= 3ull << (2u * l);
+                mask_of[lv] |= lanes;
+                bits[lv >> 6] |= 1ull << (lv & 63u);
+                lo_w = std::min(lo_w, lv >> 6);
+                hi_w = std::max(hi_w, lv >> 6);
             }
         }
-        std::sort(touched.begin(), touched.end());
         w->cs_round_start_host.push_back((uint32_t)(w->cs_round_mask_host.size() - cs.round_offset));
-        for (const uint32_t lv : touched) {
-            w->cs_round_mask_host.push_back(mask_of[lv]);
-            w->cs_round_level_host.push_back(lv);
-            mask_of[lv] = 0ull;
+        for (uint32_t wd = lo_w; wd <= hi_w && lo_w != 0xFFFFFFFFu; ++wd) {
+            uint64_t m = bits[wd];
+            bits[wd] = 0ull;
+            while (m) {
+                const uint32_t lv = wd * 64u + (uint32_t)__builtin_ctzll(m);
+                m &= m - 1ull;
+                w->cs_round_mask_host.push_back(mask_of[lv]);
+                w->cs_round_level_host.push_back(lv);
+                mask_of[lv] = 0ull;
+            }
         }
     }
     w->cs_round_start_host.push_back((uint32_t)(w->cs_round_mask_host.size() - cs.round_offset));
     IVX_SLAP("stationary: tiles");
-    if (phase == 1 && !w->cs_slot_of_host.empty()) {  // ReplayView's item indices, by pair of lanes and sweep instead of by pass and chain
-        std::vector<uint32_t> by_pair((size_t)n_tiles * 32u * passes, 0u);
+    if (phase == 1 && !w->cs_slot_of_level.empty()) {  // ReplayView's item indices, by pair of lanes and sweep instead of by pass and chain
+        w->cs_slot_of_host.assign((size_t)n_tiles * 32u * passes, 0u);
         for (uint32_t i = 0; i < nch; ++i)
-            for (uint32_t p = 0; p < passes; ++p) by_pair[(size_t)i * passes + p] = w->cs_slot_of_host[(size_t)p * nch + order[i]];
-        w->cs_slot_of_host.swap(by_pair);
+            for (uint32_t p = 0; p < passes; ++p) w->cs_slot_of_host[(size_t)i * passes + p] = w->cs_slot_of_level[(size_t)p * nch + order[i]];
     }
     cs.n_tiles = n_tiles;
 }
 
-// Dependency levels of the item sequence (pass-major, chains in cache order inside a pass); items of one level touch
-// pairwise different dynamic bodies. Appends to items/level_start.
-void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_t type, uint32_t n_passes, int phase) {
+// Dependency levels of the item sequence (pass-major, chains in cache order inside a pass); items of one level touch pairwise different
+// dynamic bodies. This is all ivx_world_set_contacts builds of a phase's schedule: the level of every item (`lvl_host`), the levels' extents
+// (`level_start_host`) and what the launcher needs to choose a kernel (levels, widest level, whether the chain-stationary form exists). The
+// two forms the kernels read — the level-ordered item list with its hand-off tags and tiles (k_solve, k_solve_mg) and the chain-stationary
+// tiles and rounds (k_solve_cs) — are built and uploaded by the solve's launcher, the one it is about to use only (ivx_world_ensure_form):
+// a frame whose contact set changed used to build and upload both, 1.4 of its 2.6 ms on the host at 41 472 contacts.
+void build_levels(ivx_world* w, uint32_t n_first, uint32_t n_passes, int phase) {
     auto slap_t0 = std::chrono::steady_clock::now();
     const uint32_t nch = (uint32_t)w->chain_start.size() - 1u, nb = w->n_dyn;
-    w->item_offset[phase] = (uint32_t)w->items_host.size();
-    w->level_offset[phase] = (uint32_t)w->level_start_host.size();
-    w->tile_offset[phase] = (uint32_t)w->tile_first_host.size();
-    w->n_tiles[phase] = 0;
     const uint32_t total_passes = n_first + n_passes;
     const size_t total = (size_t)total_passes * nch;
+    w->phase_items[phase] = (uint32_t)total;
+    w->item_offset[phase] = phase ? w->phase_items[0] : 0u;
+    w->level_offset[phase] = (uint32_t)w->level_start_host.size();
     w->n_levels[phase] = 0;
     w->max_level_items[phase] = 0;
+    w->cs_feasible[phase] = 0;
+    std::vector<uint32_t>& lvl = w->lvl_host[phase];
+    lvl.clear();
+    if (phase == 1) {
+        w->kin_offsets_host.assign((size_t)w->n_kin + 1, 0u);
+        w->kin_list_host.clear();
+        w->cs_slot_of_level.clear();
+        w->n_kin_items = 0;
+    }
     if (total == 0) {
         w->level_start_host.push_back(0);
-        w->tile_base_host.push_back(0);
-        if (phase == 1) {
-            w->kin_offsets_host.assign((size_t)w->n_kin + 1, 0u);
-            w->kin_list_host.clear();
-            w->n_kin_items = 0;
-        }
         return;
     }
-    std::vector<uint32_t>& lvl = w->scratch_level;
     std::vector<uint32_t>& last = w->scratch_last;
     lvl.resize(total);
     last.assign(nb, 0u);
@@ -293,34 +327,73 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
             max_level = std::max(max_level, l);
         }
     IVX_SLAP("schedule: levels");
-    // counting sort by level (stable)
+    // counting sort by level (stable): level l (from 1) holds the items [start[l - 1], start[l])
     const size_t ls0 = w->level_start_host.size();
     w->level_start_host.resize(ls0 + max_level + 1, 0u);
     uint32_t* start = w->level_start_host.data() + ls0;
     for (size_t i = 0; i < total; ++i) start[lvl[i]] += 1;  // start[l] = count of level l (l >= 1), start[0] = 0
-    uint32_t run = 0;
+    uint32_t run = 0, widest = 0;
     for (uint32_t l = 1; l <= max_level; ++l) {
         const uint32_t c = start[l];
-        start[l] = run;  // begin of level l (1-based)
+        widest = std::max(widest, c);
         run += c;
+        start[l] = run;  // end of level l = begin of level l + 1
     }
+    w->n_levels[phase] = max_level;
+    w->max_level_items[phase] = widest;
+    w->cs_feasible[phase] = stationary_feasible(w, nch, total_passes) ? 1 : 0;
+    if (phase == 1 && w->n_kin) {
+        // positional phase with kinematic bodies (ReplayView): every kinematic body's chains in solve order, by the items' places in the level order
+        std::vector<uint32_t> cursor(start, start + max_level);
+        std::vector<std::vector<uint32_t>> kin_items(w->n_kin);
+        w->cs_slot_of_level.assign(total, 0u);
+        k = 0;
+        for (uint32_t pass = 0; pass < total_passes; ++pass)
+            for (uint32_t ch = 0; ch < nch; ++ch, ++k) {
+                const uint32_t slot = cursor[lvl[k] - 1]++;
+                w->cs_slot_of_level[k] = slot;
+                const uint32_t ba = w->chain_bodies[2 * (size_t)ch], bb = w->chain_bodies[2 * (size_t)ch + 1];
+                if (ba & IVX_KINEMATIC_BODY) kin_items[ba & 0x7FFFFFFFu].push_back(slot);
+                if (bb & IVX_KINEMATIC_BODY) kin_items[bb & 0x7FFFFFFFu].push_back(slot | 0x80000000u);
+            }
+        w->kin_offsets_host.assign(1, 0u);
+        for (const auto& v : kin_items) {
+            w->kin_list_host.insert(w->kin_list_host.end(), v.begin(), v.end());
+            w->kin_offsets_host.push_back((uint32_t)w->kin_list_host.size());
+        }
+        w->n_kin_items = (uint32_t)w->kin_list_host.size();
+        if (w->n_kin_items == 0) w->cs_slot_of_level.clear();
+    }
+    IVX_SLAP("schedule: extents");
+}
+
+// the level-ordered item list of a phase, its hand-off tags and tiles (k_solve, k_solve_mg); appends to the host arrays (phase 0 first)
+void build_items(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_t type, uint32_t n_passes, int phase) {
+    auto slap_t0 = std::chrono::steady_clock::now();
+    const uint32_t nch = (uint32_t)w->chain_start.size() - 1u, nb = w->n_dyn;
+    const uint32_t total_passes = n_first + n_passes;
+    const size_t total = (size_t)total_passes * nch;
+    const std::vector<uint32_t>& lvl = w->lvl_host[phase];
+    const uint32_t max_level = w->n_levels[phase];
+    const size_t ls0 = w->level_offset[phase];
+    w->tile_offset[phase] = (uint32_t)w->tile_first_host.size();
+    w->n_tiles[phase] = 0;
+    w->tile_base_host.resize(ls0 + max_level + 1, 0u);
+    if (total == 0) return;
+    const uint32_t* start = w->level_start_host.data() + ls0;
     const size_t it0 = w->items_host.size();
     w->items_host.resize(it0 + total);
     w->item_bodies_host.resize(2 * (it0 + total));
     w->item_tags_host.resize(4 * (it0 + total));
     std::vector<uint32_t>& seen = w->scratch_count;  // per dynamic body: items of this phase that have touched it so far
     seen.assign(nb, 0u);
-    std::vector<uint32_t> cursor(start + 1, start + max_level + 1);
-    std::vector<std::vector<uint32_t>> kin_items;  // positional phase: every kinematic body's chains in solve order (ReplayView)
-    if (phase == 1) kin_items.resize(w->n_kin);
-    if (phase == 1) w->cs_slot_of_host.assign(w->n_kin ? total : 0, 0u);
-    k = 0;
+    std::vector<uint32_t> cursor(start, start + max_level);
+    size_t k = 0;
     for (uint32_t pass = 0; pass < total_passes; ++pass) {
         const uint32_t ty = pass < n_first ? first_type : type;
         for (uint32_t ch = 0; ch < nch; ++ch, ++k) {
             const uint32_t s0 = w->chain_start[ch], len = w->chain_start[ch + 1] - s0;
             const size_t slot = it0 + cursor[lvl[k] - 1]++;
-            if (phase == 1 && w->n_kin) w->cs_slot_of_host[k] = (uint32_t)(slot - it0);
             w->items_host[slot] = s0 | (len << 24) | (ty << 28);
             const uint32_t ba = w->chain_bodies[2 * (size_t)ch], bb = w->chain_bodies[2 * (size_t)ch + 1];
             w->item_bodies_host[2 * slot] = (ba & IVX_KINEMATIC_BODY) ? w->n_dyn + (ba & 0x7FFFFFFFu) : ba;
@@ -333,30 +406,10 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
             const uint32_t sweep = pass < n_first ? 0u : pass - n_first;
             tg[2] = sweep;
             tg[3] = sweep + 1u;
-            if (phase == 1) {
-                if (ba & IVX_KINEMATIC_BODY) kin_items[ba & 0x7FFFFFFFu].push_back((uint32_t)(slot - it0));
-                if (bb & IVX_KINEMATIC_BODY) kin_items[bb & 0x7FFFFFFFu].push_back((uint32_t)(slot - it0) | 0x80000000u);
-            }
         }
     }
     IVX_SLAP("schedule: items");
-    if (phase == 1) {
-        w->kin_offsets_host.assign(1, 0u);
-        w->kin_list_host.clear();
-        for (const auto& v : kin_items) {
-            w->kin_list_host.insert(w->kin_list_host.end(), v.begin(), v.end());
-            w->kin_offsets_host.push_back((uint32_t)w->kin_list_host.size());
-        }
-        w->n_kin_items = (uint32_t)w->kin_list_host.size();
-    }
-    for (uint32_t l = 0; l < max_level; ++l) start[l] = start[l + 1];
-    start[max_level] = (uint32_t)total;
-    w->n_levels[phase] = max_level;
-    uint32_t widest = 0;
-    for (uint32_t l = 0; l < max_level; ++l) widest = std::max(widest, start[l + 1] - start[l]);
-    w->max_level_items[phase] = widest;
     // tiles of 64 consecutive items of a level (the packed records of the multi-workgroup solve); tile_base runs parallel to level_start
-    w->tile_base_host.resize(ls0 + max_level + 1, 0u);
     uint32_t n_tiles = 0;
     for (uint32_t l = 0; l < max_level; ++l) {
         w->tile_base_host[ls0 + l] = n_tiles;
@@ -368,8 +421,48 @@ void build_schedule(ivx_world* w, uint32_t first_type, uint32_t n_first, uint32_
     w->tile_base_host[ls0 + max_level] = n_tiles;
     w->n_tiles[phase] = n_tiles;
     IVX_SLAP("schedule: tiles");
-    build_stationary(w, phase, nch, total_passes, lvl);
-    IVX_SLAP("schedule: stationary");
+}
+
+// id -> slot of the host-side ConstraintCache: open addressing, linear probing, deletion by backward shift. (The std::unordered_map it replaces
+// cost 0.7-1.0 ms per frame at 41 472 contacts of which a tenth had changed: a node allocation per insert, a pointer chase per find.)
+inline uint32_t id_hash(uint64_t id) { return (uint32_t)((id * 0x9E3779B97F4A7C15ull) >> 32); }
+void id_table_reset(ivx_world* w, size_t want) {
+    size_t cap = 1024;
+    while (cap < 2 * want) cap *= 2;
+    w->id_keys.assign(cap, 0ull);
+    w->id_vals.assign(cap, 0xFFFFFFFFu);
+    w->id_used = 0;
+    for (uint32_t s = 0; s < w->cache.size(); ++s) {
+        size_t h = id_hash(w->cache[s].id) & (cap - 1);
+        while (w->id_vals[h] != 0xFFFFFFFFu) h = (h + 1) & (cap - 1);
+        w->id_keys[h] = w->cache[s].id;
+        w->id_vals[h] = s;
+        w->id_used += 1;
+    }
+}
+inline size_t id_find_pos(const ivx_world* w, uint64_t id) {  // position of the id's entry, or of the empty entry its probe ends at
+    const size_t mask = w->id_keys.size() - 1;
+    size_t h = id_hash(id) & mask;
+    while (w->id_vals[h] != 0xFFFFFFFFu && w->id_keys[h] != id) h = (h + 1) & mask;
+    return h;
+}
+inline void id_erase(ivx_world* w, uint64_t id) {
+    const size_t mask = w->id_keys.size() - 1;
+    size_t h = id_find_pos(w, id);
+    if (w->id_vals[h] == 0xFFFFFFFFu) return;
+    size_t hole = h;
+    for (size_t j = (h + 1) & mask; w->id_vals[j] != 0xFFFFFFFFu; j = (j + 1) & mask) {
+        const size_t home = id_hash(w->id_keys[j]) & mask;
+        // the entry at j may move into the hole unless its home lies (cyclically) in (hole, j]
+        const bool stays = hole <= j ? (home > hole && home <= j) : (home > hole || home <= j);
+        if (!stays) {
+            w->id_keys[hole] = w->id_keys[j];
+            w->id_vals[hole] = w->id_vals[j];
+            hole = j;
+        }
+    }
+    w->id_vals[hole] = 0xFFFFFFFFu;
+    w->id_used -= 1;
 }
 
 }  // namespace
@@ -432,6 +525,68 @@ struct StagedUploads {
         return IVX_OK;
     }
 };
+
+// The schedule form the solve is about to use — 1: the level-ordered item list, tags and tiles (k_solve, k_solve_mg), 2: the chain-stationary
+// tiles and rounds (k_solve_cs) — built from the levels (build_levels) and uploaded if this contact structure has not had it yet.
+int ivx_world_ensure_form(ivx_world* w, uint32_t form) {
+    if (w->forms_built & form) return IVX_OK;
+    hipStream_t s = w->ctx->stream;
+    int rc;
+    StagedUploads up(w);
+    if (form == 1u) {
+        w->items_host.clear();
+        w->item_bodies_host.clear();
+        w->item_tags_host.clear();
+        w->tile_base_host.clear();
+        w->tile_first_host.clear();
+        build_items(w, PHYS_ITEM_WARM, 1u, PHYS_ITEM_VELOCITY, w->cfg.n_iterations, 0);
+        build_items(w, PHYS_ITEM_POSITIONAL, 0u, PHYS_ITEM_POSITIONAL, w->cfg.n_positional_correction_iterations, 1);
+        if ((rc = grow(&w->items, &w->item_cap, w->items_host.size(), s))) return rc;
+        if ((rc = grow(&w->item_bodies, &w->item_bodies_cap, w->item_bodies_host.size(), s))) return rc;
+        if ((rc = grow(&w->item_tags, &w->item_tags_cap, w->item_tags_host.size(), s))) return rc;
+        if ((rc = grow(&w->level_start, &w->level_cap, w->level_start_host.size(), s))) return rc;
+        if ((rc = grow(&w->tile_base, &w->tile_base_cap, w->tile_base_host.size(), s))) return rc;
+        if ((rc = grow(&w->tile_first, &w->tile_first_cap, w->tile_first_host.size(), s))) return rc;
+        if (!w->items_host.empty()) {
+            up.add(w->items, w->items_host.data(), w->items_host.size() * 4);
+            up.add(w->item_bodies, w->item_bodies_host.data(), w->item_bodies_host.size() * 4);
+            up.add(w->item_tags, w->item_tags_host.data(), w->item_tags_host.size() * 4);
+        }
+        up.add(w->level_start, w->level_start_host.data(), w->level_start_host.size() * 4);
+        up.add(w->tile_base, w->tile_base_host.data(), w->tile_base_host.size() * 4);
+        up.add(w->tile_first, w->tile_first_host.data(), w->tile_first_host.size() * 4);
+    } else {
+        w->cs_item_host.clear();
+        w->cs_bodies_host.clear();
+        w->cs_vers_host.clear();
+        w->cs_round_start_host.clear();
+        w->cs_round_mask_host.clear();
+        w->cs_round_level_host.clear();
+        w->cs_slot_of_host.clear();
+        const uint32_t nch = (uint32_t)w->chain_start.size() - 1u;
+        build_stationary(w, 0, nch, w->cfg.n_iterations + 1u, w->lvl_host[0]);
+        build_stationary(w, 1, nch, w->cfg.n_positional_correction_iterations, w->lvl_host[1]);
+        if ((rc = grow(&w->cs_item, &w->cs_item_cap, w->cs_item_host.size(), s))) return rc;
+        if ((rc = grow(&w->cs_bodies, &w->cs_bodies_cap, w->cs_bodies_host.size(), s))) return rc;
+        if ((rc = grow(&w->cs_vers, &w->cs_vers_cap, w->cs_vers_host.size(), s))) return rc;
+        if ((rc = grow(&w->cs_round_start, &w->cs_round_start_cap, w->cs_round_start_host.size(), s))) return rc;
+        if ((rc = grow(&w->cs_round_mask, &w->cs_round_mask_cap, w->cs_round_mask_host.size(), s))) return rc;
+        if ((rc = grow(&w->cs_round_level, &w->cs_round_level_cap, w->cs_round_level_host.size(), s))) return rc;
+        if (w->n_kin_items && (rc = grow(&w->cs_slot_of, &w->cs_slot_of_cap, w->cs_slot_of_host.size(), s))) return rc;
+        if (!w->cs_item_host.empty()) {
+            up.add(w->cs_item, w->cs_item_host.data(), w->cs_item_host.size() * 4);
+            up.add(w->cs_bodies, w->cs_bodies_host.data(), w->cs_bodies_host.size() * 4);
+            up.add(w->cs_vers, w->cs_vers_host.data(), w->cs_vers_host.size() * 4);
+            up.add(w->cs_round_start, w->cs_round_start_host.data(), w->cs_round_start_host.size() * 4);
+            up.add(w->cs_round_mask, w->cs_round_mask_host.data(), w->cs_round_mask_host.size() * 8);
+            up.add(w->cs_round_level, w->cs_round_level_host.data(), w->cs_round_level_host.size() * 4);
+        }
+        if (w->n_kin_items && !w->cs_slot_of_host.empty()) up.add(w->cs_slot_of, w->cs_slot_of_host.data(), w->cs_slot_of_host.size() * 4);
+    }
+    if ((rc = up.flush())) return rc;
+    w->forms_built |= form;
+    return IVX_OK;
+}
 
 extern "C" {
 
@@ -572,7 +727,7 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
     // interlocked. Then everything the steps below would compute is what they computed last time: every id keeps its slot (warm start from the
     // same slot: prev_slot = identity), the chains and the dependency schedule stand. One pass over the input decides that and copies it into
     // a pinned staging buffer; the upload is an asynchronous copy and nothing here waits for the GPU (46 080 contacts: 0.1 ms instead of 0.45).
-    if (w->schedule_valid && n > 0 && n == w->n_contacts && n == w->cache.size() && n == w->ordered.size() && w->stage_contacts_cap >= n) {
+    if (w->schedule_valid && n > 0 && n == w->n_contacts && n == w->cache.size() && 2 * n == w->slot_bodies.size() && w->stage_contacts_cap >= n) {
         if (w->stage_busy) {  // the previous frame's copy out of the staging buffer
             IVX_HIP_CHECK(hipEventSynchronize(w->stage_ev));
             w->stage_busy = 0;
@@ -585,8 +740,8 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
             if (manifold_interlocked(contacts + i, j - i)) same = false;
             for (size_t k = i; k < j && same; ++k) {
                 const ivx_contact& c = contacts[k];
-                const ivx_contact& o = w->ordered[k];
-                same = c.id == o.id && c.body_a == o.body_a && c.body_b == o.body_b;  // (o's body references were validated when it came in)
+                // (the resident body references were validated when they came in)
+                same = c.id == w->cache[k].id && c.body_a == w->slot_bodies[2 * k] && c.body_b == w->slot_bodies[2 * k + 1];
                 w->stage_contacts[k] = c;
             }
             i = j;
@@ -618,117 +773,149 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
     {  // developer aid (IVX_WORLD_TRACE=1): a frame that leaves the one-pass path says why
         static const bool trace = getenv("IVX_WORLD_TRACE") != nullptr;
         if (trace)
-            fprintf(stderr, "[ivx world] set_contacts: general path (schedule_valid %d, n %zu, resident %u, cache %zu, ordered %zu, staging cap %zu)\n", w->schedule_valid, n,
-                    w->n_contacts, w->cache.size(), w->ordered.size(), w->stage_contacts_cap);
-    }
-    for (size_t i = 0; i < n; ++i) {
-        const ivx_contact& c = contacts[i];
-        const uint32_t la = (c.body_a & IVX_KINEMATIC_BODY) ? w->n_kin : w->n_dyn, lb = (c.body_b & IVX_KINEMATIC_BODY) ? w->n_kin : w->n_dyn;
-        IVX_REQUIRE((c.body_a & 0x7FFFFFFFu) < la && (c.body_b & 0x7FFFFFFFu) < lb, IVX_ERR_INVALID, "ivx_world_set_contacts: contact %zu refers to a missing body", i);
-        IVX_REQUIRE(c.body_a != c.body_b, IVX_ERR_INVALID, "ivx_world_set_contacts: contact %zu joins a body with itself", i);
+            fprintf(stderr, "[ivx world] set_contacts: general path (schedule_valid %d, n %zu, resident %u, cache %zu, staging cap %zu)\n", w->schedule_valid, n, w->n_contacts,
+                    w->cache.size(), w->stage_contacts_cap);
     }
     int rc;
-    // 1. manifolds: interlock replacement (constraint.rs:237-249)
-    w->effective.clear();
-    size_t i = 0;
-    while (i < n) {
-        size_t j = i + 1;
-        while (j < n && !(contacts[j].flags & IVX_CONTACT_MANIFOLD_START)) ++j;
-        const ivx_contact* m = contacts + i;
-        const size_t cnt = j - i;
-        bool replaced = false;
-        if (manifold_interlocked(m, cnt)) {
-            float pa[3], pb[3];
-            if ((rc = fetch_body_position(w, m[0].body_a, pa))) return rc;
-            if ((rc = fetch_body_position(w, m[0].body_b, pb))) return rc;
-            ivx_contact sep;
-            if (separating_contact(h3(pa) - h3(pb), m, cnt, sep)) {
-                sep.body_a = m[0].body_a;
-                sep.body_b = m[0].body_b;
-                w->effective.push_back(sep);
-                replaced = true;
-            }
+    // 1. one pass over the input: the body references, and is any manifold interlocked (constraint.rs:237-249)? Only then is a copy of the
+    // list made, with those manifolds replaced by their separating contact (needs the bodies' positions from the device: rare, and slow)
+    bool any_interlocked = false;
+    {
+        size_t i = 0;
+        while (i < n) {
+            size_t j = i;
+            do {
+                const ivx_contact& c = contacts[j];
+                const uint32_t la = (c.body_a & IVX_KINEMATIC_BODY) ? w->n_kin : w->n_dyn, lb = (c.body_b & IVX_KINEMATIC_BODY) ? w->n_kin : w->n_dyn;
+                IVX_REQUIRE((c.body_a & 0x7FFFFFFFu) < la && (c.body_b & 0x7FFFFFFFu) < lb, IVX_ERR_INVALID, "ivx_world_set_contacts: contact %zu refers to a missing body", j);
+                IVX_REQUIRE(c.body_a != c.body_b, IVX_ERR_INVALID, "ivx_world_set_contacts: contact %zu joins a body with itself", j);
+                ++j;
+            } while (j < n && !(contacts[j].flags & IVX_CONTACT_MANIFOLD_START));
+            if (manifold_interlocked(contacts + i, j - i)) any_interlocked = true;
+            i = j;
         }
-        if (!replaced) w->effective.insert(w->effective.end(), m, m + cnt);
-        i = j;
+    }
+    const ivx_contact* eff = contacts;
+    size_t n_eff = n;
+    if (any_interlocked) {
+        w->effective.clear();
+        size_t i = 0;
+        while (i < n) {
+            size_t j = i + 1;
+            while (j < n && !(contacts[j].flags & IVX_CONTACT_MANIFOLD_START)) ++j;
+            const ivx_contact* m = contacts + i;
+            const size_t cnt = j - i;
+            bool replaced = false;
+            if (manifold_interlocked(m, cnt)) {
+                float pa[3], pb[3];
+                if ((rc = fetch_body_position(w, m[0].body_a, pa))) return rc;
+                if ((rc = fetch_body_position(w, m[0].body_b, pb))) return rc;
+                ivx_contact sep;
+                if (separating_contact(h3(pa) - h3(pb), m, cnt, sep)) {
+                    sep.body_a = m[0].body_a;
+                    sep.body_b = m[0].body_b;
+                    w->effective.push_back(sep);
+                    replaced = true;
+                }
+            }
+            if (!replaced) w->effective.insert(w->effective.end(), m, m + cnt);
+            i = j;
+        }
+        eff = w->effective.data();
+        n_eff = w->effective.size();
     }
     lap("validate + interlock");
-    // 2. ConstraintCache::register_prepared_constraint + remove_unprepared_constraints (solver.rs:406-452)
-    // the usual frame: the same contact ids in the same order as last time — every id keeps its slot, nothing to look up or to remove
-    bool same_ids = w->cache.size() == w->effective.size();
-    for (uint32_t e = 0; same_ids && e < w->effective.size(); ++e) same_ids = w->cache[e].id == w->effective[e].id;
-    if (same_ids)
-        for (uint32_t e = 0; e < w->effective.size(); ++e) {
-            w->cache[e].src = e;
-            w->cache[e].prepared = true;
+    // 2. ConstraintCache::register_prepared_constraint + remove_unprepared_constraints (solver.rs:406-452): every id keeps its slot, new ids
+    // are appended, ids that did not come are swap-removed in slot order. An id is looked for at the slot behind the one its predecessor in
+    // the input had first (a run of contacts that stayed together costs a comparison each), then in the id table.
+    if (w->id_keys.empty() || 2 * (w->cache.size() + n_eff) > w->id_keys.size()) id_table_reset(w, w->cache.size() + n_eff);
+    {
+        const size_t old_len = w->cache.size();
+        size_t cursor = 0;
+        w->cache.reserve(old_len + n_eff);
+        for (uint32_t e = 0; e < n_eff; ++e) {
+            const uint64_t id = eff[e].id;
+            if (cursor < old_len && w->cache[cursor].id == id) {
+                w->cache[cursor].src = e;
+                w->cache[cursor].prepared = true;
+                cursor += 1;
+                continue;
+            }
+            const size_t h = id_find_pos(w, id);
+            if (w->id_vals[h] != 0xFFFFFFFFu) {
+                ivx_world::Entry& en = w->cache[w->id_vals[h]];
+                en.src = e;
+                en.prepared = true;
+                cursor = (size_t)w->id_vals[h] + 1;
+            } else {
+                w->id_keys[h] = id;
+                w->id_vals[h] = (uint32_t)w->cache.size();
+                w->id_used += 1;
+                w->cache.push_back(ivx_world::Entry{id, -1, e, true});
+            }
         }
-    if (!same_ids) {
-        w->index_of.reserve(w->effective.size() + w->cache.size());  // (no rehash on the way: a first frame of 46 080 contacts spent 1 ms in them)
-        w->cache.reserve(w->effective.size() + w->cache.size());
-    }
-    for (uint32_t e = 0; !same_ids && e < w->effective.size(); ++e) {
-        const uint64_t id = w->effective[e].id;
-        auto it = w->index_of.find(id);
-        if (it != w->index_of.end()) {
-            ivx_world::Entry& en = w->cache[it->second];
-            en.src = e;
-            en.prepared = true;
-        } else {
-            w->index_of.emplace(id, (uint32_t)w->cache.size());
-            w->cache.push_back(ivx_world::Entry{id, -1, e, true});
-        }
-    }
-    size_t idx = 0, len = w->cache.size();
-    while (idx < len) {
-        if (w->cache[idx].prepared) {
-            ++idx;
-        } else {
-            w->index_of.erase(w->cache[idx].id);
-            w->cache[idx] = w->cache[len - 1];
-            w->cache.pop_back();
-            --len;
-            if (idx < len) w->index_of[w->cache[idx].id] = (uint32_t)idx;
+        size_t idx = 0, len = w->cache.size();
+        while (idx < len) {
+            if (w->cache[idx].prepared) {
+                ++idx;
+            } else {
+                id_erase(w, w->cache[idx].id);
+                w->cache[idx] = w->cache[len - 1];
+                w->cache.pop_back();
+                --len;
+                if (idx < len) w->id_vals[id_find_pos(w, w->cache[idx].id)] = (uint32_t)idx;
+            }
         }
     }
     const uint32_t nc = (uint32_t)w->cache.size();
     w->n_bodies_stat_valid = 0;
-    w->ordered.resize(nc);
+    // the contacts in slot order go straight into the pinned block their upload is made from (one copy of each contact on the host)
+    if (w->stage_busy) {  // the previous frame's copy out of the staging block
+        IVX_HIP_CHECK(hipEventSynchronize(w->stage_ev));
+        w->stage_busy = 0;
+    }
+    if (nc > w->stage_contacts_cap) {
+        if (w->stage_contacts) (void)hipHostFree(w->stage_contacts);
+        w->stage_contacts = nullptr;
+        w->stage_contacts_cap = 0;
+        const size_t cap2 = (size_t)nc + nc / 4 + 64;
+        IVX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&w->stage_contacts), cap2 * sizeof(ivx_contact), hipHostMallocDefault));
+        w->stage_contacts_cap = cap2;
+    }
+    if (!w->stage_ev_ready) {
+        IVX_HIP_CHECK(hipEventCreateWithFlags(&w->stage_ev, hipEventDisableTiming));
+        w->stage_ev_ready = 1;
+    }
     w->prev_slot_host.resize(nc);
-    for (uint32_t s = 0; s < nc; ++s) {
-        ivx_world::Entry& en = w->cache[s];
-        w->ordered[s] = w->effective[en.src];
-        w->prev_slot_host[s] = en.prev_slot;
-        en.prev_slot = (int32_t)s;
+    w->slot_bodies.resize(2 * (size_t)nc);
+    for (uint32_t sl = 0; sl < nc; ++sl) {
+        ivx_world::Entry& en = w->cache[sl];
+        const ivx_contact& c = eff[en.src];
+        w->stage_contacts[sl] = c;
+        w->slot_bodies[2 * (size_t)sl] = c.body_a;
+        w->slot_bodies[2 * (size_t)sl + 1] = c.body_b;
+        w->prev_slot_host[sl] = en.prev_slot;
+        en.prev_slot = (int32_t)sl;
         en.prepared = false;
     }
     w->n_prev = w->n_contacts;  // size of the state arrays written by the previous prepare
     w->n_contacts = nc;
     lap("constraint cache");
-    // 3. dependency schedules: (warm pass + velocity sweeps) and (positional sweeps)
+    // 3. chains and the levels of the two phases' items: (warm pass + velocity sweeps) and (positional sweeps)
     build_chains(w);
     IVX_REQUIRE((uint64_t)(w->chain_start.size() - 1u) * (std::max(w->cfg.n_iterations + 1u, w->cfg.n_positional_correction_iterations)) < (1ull << 26), IVX_ERR_CAPACITY,
                 "ivx_world_set_contacts: more than 2^26 schedule items in one phase");
     // the schedule depends on the chains and their body pairs only: an unchanged contact structure keeps last frame's (host and device copies)
     const bool same_schedule = w->schedule_valid && w->chain_start == w->prev_chain_start && w->chain_bodies == w->prev_chain_bodies;
     if (!same_schedule) {
-        w->items_host.clear();
-        w->item_bodies_host.clear();
-        w->item_tags_host.clear();
         w->level_start_host.clear();
-        w->tile_base_host.clear();
-        w->tile_first_host.clear();
-        w->cs_item_host.clear();
-        w->cs_bodies_host.clear();
-        w->cs_vers_host.clear();
-        w->cs_round_start_host.clear();
-        w->cs_round_mask_host.clear();
-        w->cs_round_level_host.clear();
-        build_schedule(w, PHYS_ITEM_WARM, 1u, PHYS_ITEM_VELOCITY, w->cfg.n_iterations, 0);
-        build_schedule(w, PHYS_ITEM_POSITIONAL, 0u, PHYS_ITEM_POSITIONAL, w->cfg.n_positional_correction_iterations, 1);
+        build_levels(w, 1u, w->cfg.n_iterations, 0);
+        build_levels(w, 0u, w->cfg.n_positional_correction_iterations, 1);
+        w->forms_built = 0;
         w->prev_chain_start = w->chain_start;
         w->prev_chain_bodies = w->chain_bodies;
     }
-    lap("chains + schedules");
+    lap("chains + levels");
     // 4. upload
     hipStream_t s = w->ctx->stream;
     size_t cap = w->contact_cap;
@@ -760,21 +947,8 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
         w->prev_slot = np;
         w->contact_cap = ncap;
     }
-    if ((rc = grow(&w->items, &w->item_cap, w->items_host.size(), s))) return rc;
-    if ((rc = grow(&w->item_bodies, &w->item_bodies_cap, w->item_bodies_host.size(), s))) return rc;
-    if ((rc = grow(&w->item_tags, &w->item_tags_cap, w->item_tags_host.size(), s))) return rc;
-    if ((rc = grow(&w->level_start, &w->level_cap, w->level_start_host.size(), s))) return rc;
-    if ((rc = grow(&w->tile_base, &w->tile_base_cap, w->tile_base_host.size(), s))) return rc;
-    if ((rc = grow(&w->tile_first, &w->tile_first_cap, w->tile_first_host.size(), s))) return rc;
-    if ((rc = grow(&w->cs_item, &w->cs_item_cap, w->cs_item_host.size(), s))) return rc;
-    if ((rc = grow(&w->cs_bodies, &w->cs_bodies_cap, w->cs_bodies_host.size(), s))) return rc;
-    if ((rc = grow(&w->cs_vers, &w->cs_vers_cap, w->cs_vers_host.size(), s))) return rc;
-    if ((rc = grow(&w->cs_round_start, &w->cs_round_start_cap, w->cs_round_start_host.size(), s))) return rc;
-    if ((rc = grow(&w->cs_round_mask, &w->cs_round_mask_cap, w->cs_round_mask_host.size(), s))) return rc;
-    if ((rc = grow(&w->cs_round_level, &w->cs_round_level_cap, w->cs_round_level_host.size(), s))) return rc;
-    if (w->n_kin_items && (rc = grow(&w->cs_slot_of, &w->cs_slot_of_cap, w->cs_slot_of_host.size(), s))) return rc;
     if (w->n_kin_items) {
-        const size_t n_pos_items = w->items_host.size() - w->item_offset[1];
+        const size_t n_pos_items = w->phase_items[1];
         if ((rc = grow(&w->kin_offsets, &w->kin_offsets_cap, w->kin_offsets_host.size(), s))) return rc;
         if ((rc = grow(&w->kin_list, &w->kin_list_cap, w->kin_list_host.size(), s))) return rc;
         if ((rc = grow(&w->kin_applied, &w->kin_applied_cap, n_pos_items, s))) return rc;
@@ -782,49 +956,16 @@ int ivx_world_set_contacts(ivx_world* w, const ivx_contact* contacts, size_t n, 
         if ((rc = grow(&w->kin_snap, &w->kin_snap_cap, (size_t)std::max<uint32_t>(w->n_dyn, 1u) * 8, s))) return rc;
     }
     // (no wait here: the copies below are stream-ordered behind whatever still reads these buffers; a buffer that grew was waited for in grow())
-    if (w->stage_busy) {  // the fast path's staging block: reallocated below only when its last copy has passed
-        IVX_HIP_CHECK(hipEventSynchronize(w->stage_ev));
-        w->stage_busy = 0;
-    }
-    if (nc > w->stage_contacts_cap) {  // the staging buffer of the usual frame's fast path (step 0)
-        if (w->stage_contacts) (void)hipHostFree(w->stage_contacts);
-        w->stage_contacts = nullptr;
-        w->stage_contacts_cap = 0;
-        const size_t cap2 = nc + nc / 4;
-        IVX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&w->stage_contacts), cap2 * sizeof(ivx_contact), hipHostMallocDefault));
-        w->stage_contacts_cap = cap2;
-    }
-    if (!w->stage_ev_ready) {
-        IVX_HIP_CHECK(hipEventCreateWithFlags(&w->stage_ev, hipEventDisableTiming));
-        w->stage_ev_ready = 1;
+    if (nc) {
+        IVX_HIP_CHECK(ivx_memcpy_async(w->contacts, w->stage_contacts, (size_t)nc * sizeof(ivx_contact), hipMemcpyHostToDevice, s));
+        IVX_HIP_CHECK(ivx_event_record(w->stage_ev, s));
+        w->stage_busy = 1;
     }
     StagedUploads up(w);
-    if (nc) {
-        up.add(w->contacts, w->ordered.data(), nc * sizeof(ivx_contact));
-        up.add(w->prev_slot, w->prev_slot_host.data(), nc * sizeof(int32_t));
-    }
-    if (!same_schedule) {
-        if (!w->items_host.empty()) {
-            up.add(w->items, w->items_host.data(), w->items_host.size() * 4);
-            up.add(w->item_bodies, w->item_bodies_host.data(), w->item_bodies_host.size() * 4);
-            up.add(w->item_tags, w->item_tags_host.data(), w->item_tags_host.size() * 4);
-        }
-        up.add(w->level_start, w->level_start_host.data(), w->level_start_host.size() * 4);
-        up.add(w->tile_base, w->tile_base_host.data(), w->tile_base_host.size() * 4);
-        up.add(w->tile_first, w->tile_first_host.data(), w->tile_first_host.size() * 4);
-        if (!w->cs_item_host.empty()) {
-            up.add(w->cs_item, w->cs_item_host.data(), w->cs_item_host.size() * 4);
-            up.add(w->cs_bodies, w->cs_bodies_host.data(), w->cs_bodies_host.size() * 4);
-            up.add(w->cs_vers, w->cs_vers_host.data(), w->cs_vers_host.size() * 4);
-            up.add(w->cs_round_start, w->cs_round_start_host.data(), w->cs_round_start_host.size() * 4);
-            up.add(w->cs_round_mask, w->cs_round_mask_host.data(), w->cs_round_mask_host.size() * 8);
-            up.add(w->cs_round_level, w->cs_round_level_host.data(), w->cs_round_level_host.size() * 4);
-        }
-        if (w->n_kin_items && !w->cs_slot_of_host.empty()) up.add(w->cs_slot_of, w->cs_slot_of_host.data(), w->cs_slot_of_host.size() * 4);
-        if (w->n_kin_items) {
-            up.add(w->kin_offsets, w->kin_offsets_host.data(), w->kin_offsets_host.size() * 4);
-            up.add(w->kin_list, w->kin_list_host.data(), w->kin_list_host.size() * 4);
-        }
+    if (nc) up.add(w->prev_slot, w->prev_slot_host.data(), nc * sizeof(int32_t));
+    if (!same_schedule && w->n_kin_items) {
+        up.add(w->kin_offsets, w->kin_offsets_host.data(), w->kin_offsets_host.size() * 4);
+        up.add(w->kin_list, w->kin_list_host.data(), w->kin_list_host.size() * 4);
     }
     lap("buffers");
     if ((rc = up.flush())) return rc;
@@ -935,8 +1076,8 @@ int ivx_world_step(ivx_world* w, float dt, ivx_physics_result* out) {
             // the joints' dynamic anchors) and the kinematic bodies of the contacts — counted from the host's copies of the same lists, once per
             // contact list (a read-back of the marks and a walk over 46 080 contacts every step were 60 us of a 1 ms step)
             std::vector<uint8_t> t((size_t)w->n_dyn + w->n_kin, 0);
-            for (const ivx_contact& c : w->ordered) {
-                const uint32_t a = c.body_a, b = c.body_b;
+            for (size_t sl = 0; sl + 1 < w->slot_bodies.size(); sl += 2) {
+                const uint32_t a = w->slot_bodies[sl], b = w->slot_bodies[sl + 1];
                 if (a & IVX_KINEMATIC_BODY) t[w->n_dyn + (a & 0x7FFFFFFFu)] = 1;
                 else if (a < w->n_dyn) t[a] = 1;
                 if (b & IVX_KINEMATIC_BODY) t[w->n_dyn + (b & 0x7FFFFFFFu)] = 1;

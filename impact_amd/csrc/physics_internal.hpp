@@ -2,7 +2,6 @@
 // (a15-a19). See physics.hip for the kernels and physics_api.hip for the bookkeeping.
 #pragma once
 #include <cstdint>
-#include <unordered_map>
 #include <vector>
 
 #include "ivx_internal.hpp"
@@ -138,10 +137,13 @@ struct ivx_world {
         bool prepared;
     };
     std::vector<Entry> cache;
-    std::unordered_map<uint64_t, uint32_t> index_of;
-    std::vector<ivx_contact> effective;  // contacts of this step after interlock replacement
-    std::vector<ivx_contact> ordered;
-    // the usual frame's upload (same ids, order and body pairs as the frame before): pinned staging copy, sent by an asynchronous copy
+    // id -> slot: open addressing (physics_api.hip, id_find_pos); a value of ~0 marks an empty entry
+    std::vector<uint64_t> id_keys;
+    std::vector<uint32_t> id_vals;
+    size_t id_used;
+    std::vector<ivx_contact> effective;  // contacts of this step after interlock replacement (only when a manifold is interlocked)
+    std::vector<uint32_t> slot_bodies;   // (body_a, body_b) of every resident contact in slot order (the contacts themselves: stage_contacts)
+    // the resident contacts in slot order on the host: a pinned block, the source of their upload (an asynchronous copy; `stage_ev` follows it)
     ivx_contact* stage_contacts;
     size_t stage_contacts_cap;
     hipEvent_t stage_ev;
@@ -155,6 +157,14 @@ struct ivx_world {
     std::vector<int32_t> prev_slot_host;
     std::vector<uint32_t> item_bodies_host, items_host, level_start_host, tile_base_host, tile_first_host, scratch_level, scratch_last, chain_start;
     std::vector<uint32_t> kin_offsets_host, kin_list_host;
+    // what ivx_world_set_contacts builds of the schedule (build_levels): per phase the level of every item (pass-major, chains in solve order)
+    // and whether the chain-stationary form exists; the forms the kernels read are built on demand (ivx_world_ensure_form: bit 0 the level-
+    // ordered items and tiles, bit 1 the chain-stationary tiles)
+    std::vector<uint32_t> lvl_host[2], cs_slot_of_level, scratch_rank, scratch_order, scratch_first;
+    std::vector<uint64_t> scratch_mask, scratch_bits;
+    uint32_t phase_items[2];
+    int cs_feasible[2];
+    uint32_t forms_built;
     std::vector<uint32_t> chain_bodies, prev_chain_start, prev_chain_bodies;  // body pair per chain; last frame's chains (an unchanged contact structure keeps its schedule)
 };
 
@@ -164,4 +174,5 @@ int ivx_launch_phys_mark_joint_bodies(ivx_world* w);
 int ivx_launch_phys_pre_solve(ivx_world* w, float dt);
 int ivx_launch_phys_solve(ivx_world* w);
 int ivx_launch_phys_free_step(ivx_world* w, float dt);
+int ivx_world_ensure_form(ivx_world* w, uint32_t form);  // physics_api.hip
 int ivx_launch_phys_post_solve(ivx_world* w, float dt, int write_back, int advance);
