@@ -331,7 +331,8 @@ def summary_block(out):
             "dense": {"ms_per_step": g("dense", "ms_per_step"), "emit_ms": g("dense", "emit_ms"), "roofline_kernel": g("dense", "roofline", "kernel"),
                       "roofline_frac": g("dense", "roofline", "frac"), "counter_frac": g("dense", "roofline", "counter_frac"),
                       "step_counter_frac": g("dense", "step_roofline", "counter_frac")},
-            "pile": {"ms_per_step": g("pile", "ms_per_step"), "solve_ms": g("pile", "stage_ms", "solve"), "kernel": g("pile", "solver", "kernel")},
+            "pile": {"ms_per_step": g("pile", "ms_per_step"), "solve_ms": g("pile", "stage_ms", "solve"), "kernel": g("pile", "solver", "kernel"),
+                     "churn_ms_per_frame": g("pile", "churn", "ms_per_frame_spread"), "churn_set_contacts_host_ms": g("pile", "churn", "set_contacts_host_ms_spread")},
             "frame_pipeline_ms": g("frame", "pipeline", "ms_per_frame"), "frame_two_streams_ms": g("frame", "ms_per_frame_two_streams"),
             "edit_plus_sync_ms": g("edit", "edit_plus_sync_ms"), "edit_and_sync_overlapped_ms": g("edit", "edit_and_sync_overlapped_ms"),
             "fragments": {"cut_ms": g("fragments", "cut_ms"), "first_step_many_ms": g("fragments", "first_step_many_ms"), "frame_many_ms": g("fragments", "frame_many_ms"),
@@ -340,9 +341,16 @@ def summary_block(out):
                                 "ms_batched_world_on_own_context": g("fragments_frame", "ms_batched_world_on_own_context"),
                                 "probes_sync_ms": [g("fragments_frame", "probes_and_pairs", "probes_sync", "ms_batched"),
                                                    g("fragments_frame", "probes_and_pairs", "probes_sync", "ms_looped")],
+                                "host_spreads_ms": {"probes_sync": g("fragments_frame", "probes_and_pairs", "probes_sync", "ms_batched_spread"),
+                                                    "mutual_pairs": g("fragments_frame", "probes_and_pairs", "mutual_pairs", "ms_batched_spread"),
+                                                    "contacts_many": g("fragments_frame", "batched_host_ms_spread", "contacts_many"),
+                                                    "set_contacts": g("fragments_frame", "batched_host_ms_spread", "set_contacts"),
+                                                    "frame": g("fragments_frame", "batched_host_ms_spread", "frame"), "cut": g("fragments", "cut_ms_spread")},
                                 "mutual_pairs_ms": [g("fragments_frame", "probes_and_pairs", "mutual_pairs", "ms_batched"),
                                                     g("fragments_frame", "probes_and_pairs", "mutual_pairs", "ms_looped")]},
             "config3_split_loop_ms": g("config3", "split_loop_ms"), "config5_single_grid_ms": g("config5_one_gpu", "single_grid_ms"),
+            "strong_scaling_bound": {"512": g("strong_512", "strong_scaling_bound"), "1024": g("config5_one_gpu", "strong_scaling_bound"),
+                                     "strong_512_eight_slabs_one_gpu_ms": g("strong_512", "eight_slabs_one_gpu_ms")},
             "config5_eight_slabs_one_gpu_ms": g("config5_one_gpu", "eight_slabs_one_gpu_ms"),
             "cpu_baseline_voxels_per_s": g("cpu_baseline", "value"), "parity_all_equal": (all(parities) if parities else None), "parity_blocks": len(parities), "parity_failed": failed}
 
@@ -493,6 +501,38 @@ def config5_benchmark(ctx, args):
     out["eight_slabs_note"] = "stage-slot event records off (round 4 timed this leg with all twelve per slab on: 0.3 ms of the 1.84)"
     out["eight_slabs_triangles"] = int(sum(int(r["mesh"]["n_indices"]) for r in rec)) // 3
     out["eight_slabs_regions"] = int(rec[0]["region_count"])
+    out["same_triangles"] = out["eight_slabs_triangles"] == tris
+    out["strong_scaling_bound"] = round(ms / (slab_ms / 8.0), 2)
+    out["strong_scaling_bound_what"] = ("single_grid_ms / (eight_slabs_one_gpu_ms / 8): the speed-up eight GPUs could reach on this grid if the links were free — what one "
+                                        "rank's launches, waits and exchanges cost by themselves, measured with all eight ranks taking turns on one GPU")
+    for s_ in steppers:
+        s_.close()
+    comm.close()
+    return out
+
+
+def strong_512_benchmark(ctx, args, single_ms, tris):
+    """The metric's own 512^3 grid cut into 8 x-slabs of 4 chunk planes, all eight on this GPU (the in-process communicator): what one rank of the
+    strong-scaling leg costs before any link is involved."""
+    from impact_amd import scenes
+    from impact_amd.distributed import NativeComm, NativeSlabStepper, NativeStepGroup
+
+    graph = scenes.asteroid_scene(2.05)
+    comm = NativeComm(ctx, 8, local=True)
+    steppers = [NativeSlabStepper(ctx, comm, graph, np.ones(256, dtype=np.float32), r) for r in range(8)]
+    group = NativeStepGroup(steppers)
+    for s_ in steppers:
+        s_.obj.set_stage_timing(0)
+    steps = max(10, args.steps // 10)
+    for _ in range(3):
+        group.step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rec = group.step()
+    slab_ms = 1e3 * (time.perf_counter() - t0) / steps
+    out = {"workload": "the headline 512^3 grid as 8 x-slabs of 4 chunk planes, all on one GPU (in-process communicator: exchanges are device copies)",
+           "single_grid_ms": single_ms, "eight_slabs_one_gpu_ms": slab_ms, "per_rank_ms": slab_ms / 8.0, "strong_scaling_bound": round(single_ms / (slab_ms / 8.0), 2),
+           "eight_slabs_triangles": int(sum(int(r["mesh"]["n_indices"]) for r in rec)) // 3, "eight_slabs_regions": int(rec[0]["region_count"])}
     out["same_triangles"] = out["eight_slabs_triangles"] == tris
     for s_ in steppers:
         s_.close()
@@ -809,6 +849,7 @@ def fragments_benchmark(ctx, with_cpu, n_axis=5, frames=6, warm=2):
         ctx.synchronize()
         t_cuts.append(time.perf_counter() - t0)
     t_cut = float(np.median(t_cuts))
+    cut_spread = spread3([1e3 * t for t in t_cuts])
     b_objs, _ = cut()
     n = len(a_objs)
     stages0 = capi.STAGE_ALL & ~capi.STAGE_SAMPLE
@@ -873,7 +914,7 @@ def fragments_benchmark(ctx, with_cpu, n_axis=5, frames=6, warm=2):
     out = {"workload": f"config-2 body (256^3) cut into the Voronoi cells of a jittered {n_axis}^3 lattice: {n} fragments of "
                        f"{int(np.median([o_.n_chunks for o_ in a_objs]))} chunks (median); per frame and fragment: one absorbing sphere (r 4-6 voxels), the "
                        "incremental remesh of what it invalidated, the ten moments",
-           "objects": n, "frames": frames, "warmup_frames": warm, "cut_ms": round(1e3 * t_cut, 3), "cut_first_ms": round(1e3 * t_cut_first, 3),
+           "objects": n, "frames": frames, "warmup_frames": warm, "cut_ms": round(1e3 * t_cut, 3), "cut_ms_spread": cut_spread, "cut_first_ms": round(1e3 * t_cut_first, 3),
            "cut_what": "ivx_copy_polyhedra (children's grids from one block; clip, derived state, regions, occupied ranges and mass of all recorded and issued as one "
                        "launch per chain position) + the children's wrappers and density tables; median of 3 cuts of the same body, the process's first apart",
            "first_step_looped_ms": round(first_loop_ms, 3), "first_step_many_ms": round(first_many_ms, 3),
@@ -945,7 +986,7 @@ def fragments_benchmark(ctx, with_cpu, n_axis=5, frames=6, warm=2):
     return out
 
 
-def fragments_probes_and_pairs(ctx, a_objs, b_objs, a_mesh, b_mesh, occ, dens, rounds=4):
+def fragments_probes_and_pairs(ctx, a_objs, b_objs, a_mesh, b_mesh, occ, dens, rounds=6):
     """The two other per-object loops of a frame (collidable.rs:394-433 probe sync behind every mesh sync; collidable.rs:859-1049 mutual contacts
     of every pair the broad phase found) on the fragments of `fragments_frame`: object by object (`a`) and through `ivx_collision_probes_sync_many`
     / `ivx_mutual_voxel_object_contacts_many` (`b`, the twins in the same state). Pairs: fragment k against fragment k + 1, B pushed against A's
@@ -956,6 +997,7 @@ def fragments_probes_and_pairs(ctx, a_objs, b_objs, a_mesh, b_mesh, occ, dens, r
     for o_ in a_objs + b_objs:
         o_.collision_probes_recompute()
     t_sync = np.zeros(2)
+    sync_batched, pairs_batched = [], []  # (per round: the host-bound legs report min / median / max beside the mean)
     for f in range(rounds):
         cs, rs = [], []
         for oc in occ:
@@ -980,6 +1022,7 @@ def fragments_probes_and_pairs(ctx, a_objs, b_objs, a_mesh, b_mesh, occ, dens, r
         t2 = time.perf_counter()
         if f:
             t_sync += (t1 - t0, t2 - t1)
+            sync_batched.append(1e3 * (t2 - t1))
     same_probes = True
     for x, y in zip(a_objs, b_objs):
         (pa, ea), (pb, eb_) = x.collision_probes(), y.collision_probes()
@@ -1007,12 +1050,15 @@ def fragments_probes_and_pairs(ctx, a_objs, b_objs, a_mesh, b_mesh, occ, dens, r
         t2 = time.perf_counter()
         if f:
             t_pairs += (t1 - t0, t2 - t1)
+            pairs_batched.append(1e3 * (t2 - t1))
         want = np.concatenate(lists) if lists else got[:0]
         same_pairs = same_pairs and want.tobytes() == got.tobytes()
         n_contacts = len(got)
     d = max(rounds - 1, 1)
-    return {"probes_sync": {"ms_looped": round(1e3 * t_sync[0] / d, 4), "ms_batched": round(1e3 * t_sync[1] / d, 4)},
-            "mutual_pairs": {"pairs": n - 1, "contacts": int(n_contacts), "ms_looped": round(1e3 * t_pairs[0] / d, 4), "ms_batched": round(1e3 * t_pairs[1] / d, 4)},
+    return {"probes_sync": {"ms_looped": round(1e3 * t_sync[0] / d, 4), "ms_batched": round(1e3 * t_sync[1] / d, 4),
+                            "ms_batched_spread": spread3(sync_batched) if sync_batched else None},
+            "mutual_pairs": {"pairs": n - 1, "contacts": int(n_contacts), "ms_looped": round(1e3 * t_pairs[0] / d, 4), "ms_batched": round(1e3 * t_pairs[1] / d, 4),
+                             "ms_batched_spread": spread3(pairs_batched) if pairs_batched else None},
             "parity": {"probes_looped_equal_batched": bool(same_probes), "pairs_looped_equal_batched": bool(same_pairs)}}
 
 
@@ -1092,6 +1138,7 @@ def fragments_frame_benchmark(ctx, with_cpu, n_axis=5, frames=6, warm=2):
 
     t_loop, t_many = [], []
     parts = np.zeros(6)
+    part_samples = []
     n_contacts = 0
     same_contacts = True
     for f in range(frames + warm):
@@ -1123,6 +1170,7 @@ def fragments_frame_benchmark(ctx, with_cpu, n_axis=5, frames=6, warm=2):
         t2 = time.perf_counter()
         if f >= warm:
             parts += (ta - t1, tb - ta, tc - tb, td - tc, te - td, t2 - te)
+            part_samples.append((1e3 * (ta - t1), 1e3 * (tb - ta)))
         same_contacts = same_contacts and ca.tobytes() == cb.tobytes()
         n_contacts = len(cb)
         if f >= warm:
@@ -1141,6 +1189,8 @@ def fragments_frame_benchmark(ctx, with_cpu, n_axis=5, frames=6, warm=2):
            "speedup": round(loop_ms / many_ms, 2),
            "batched_host_ms": {k_: round(1e3 * float(v_) / frames, 4) for k_, v_ in zip(("contacts_many", "set_contacts", "step_enqueue", "absorb_many (waits for the solve too)",
                                                                                         "mesh_sync_many", "moments_many"), parts)},
+           "batched_host_ms_spread": {"contacts_many": spread3([p_[0] for p_ in part_samples]), "set_contacts": spread3([p_[1] for p_ in part_samples]),
+                                      "frame": spread3([1e3 * t_ for t_ in t_many])},
            "parity": {"looped_equals_batched": bool(same), "bodies_equal": bool(same_bodies)}}
     # the solve of this contact set by itself, on the kernel the schedule picks and on the chain-stationary one
     wb.prepare_constraints(cb)
@@ -1251,7 +1301,7 @@ def pile_benchmark(ctx, with_cpu, steps=10):
     host_ms = 1e3 * (time.perf_counter() - t0)
     w.step(0.005)
     host_warm = []
-    for _ in range(4):  # the per-frame case: the same contact ids as last frame (cache hits, buffers sized); the first such call sizes the staging buffer
+    for _ in range(8):  # the per-frame case: the same contact ids as last frame (cache hits, buffers sized); the first such call sizes the staging buffer
         t0 = time.perf_counter()
         w.prepare_constraints(contacts)
         host_warm.append(1e3 * (time.perf_counter() - t0))
@@ -1271,7 +1321,8 @@ def pile_benchmark(ctx, with_cpu, steps=10):
         "contact_sweeps_per_s": len(contacts) * sweeps / wall,
         "levels": [int(r["n_levels"][0]), int(r["n_levels"][1])],
         "stage_ms": {k: round(float(v) / steps, 4) for k, v in zip(capi.PHYSICS_STAGE_NAMES, acc)},
-        "set_contacts_next_frame_host_ms": round(host_warm_ms, 3), "set_contacts_host_ms": round(host_ms, 3),
+        "set_contacts_next_frame_host_ms": round(host_warm_ms, 3), "set_contacts_next_frame_host_ms_spread": spread3(host_warm[1:]),
+        "set_contacts_host_ms": round(host_ms, 3), "set_contacts_host_ms_what": "the world's first call: buffers allocated, every id new",
     }
     info = w.solver_info() if hasattr(w, "solver_info") else None
     if info:
@@ -1294,6 +1345,65 @@ def pile_benchmark(ctx, with_cpu, steps=10):
                                "sample": f"same pile, {n_steps_done} steps, {1e3 * cpu:.1f} ms/step, single thread"}
         out["parity"] = {"steps": n_steps_done, "body_state_max_rel_err": rel, "equal": bool(rel <= 1e-5)}
     return out, w
+
+
+def pile_churn_benchmark(ctx, with_cpu, frames=60):
+    """The config-4 pile with a contact set that CHANGES every frame (scenes.pile_churn_frames: a tenth of the manifolds leave, the tenth that
+    left the frame before returns): `ivx_world_set_contacts` takes its general path — ids looked up, slots swap-removed and appended in the
+    reference's order, the dependency schedule rebuilt — and the solve runs on the order that history leaves (more levels than the pristine
+    lattice's). Timed per frame: set_contacts + step together, host work included; the oracle steps through the same lists beside it."""
+    from impact_amd import scenes
+    from impact_amd.physics import PhysicsWorld
+
+    bodies, contacts = scenes.sphere_pile_scene(16)
+    lists = scenes.pile_churn_frames(contacts, frames + 4)
+    w = PhysicsWorld(ctx)
+    w.set_bodies(bodies)
+    w.prepare_constraints(contacts)
+    w.step(0.005)
+    t_set, t_frame, levels = [], [], []
+    for f, cs in enumerate(lists):
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        w.prepare_constraints(cs)
+        t1 = time.perf_counter()
+        r = w.step(0.005)
+        t2 = time.perf_counter()
+        if f >= 4:  # (the first frames size the buffers)
+            t_set.append(1e3 * (t1 - t0))
+            t_frame.append(1e3 * (t2 - t0))
+            levels.append(int(r["n_levels"][0]) + int(r["n_levels"][1]))
+    out = {"workload": f"the config-4 pile, {frames} frames: each frame a tenth of the 11 520 manifolds is missing, the tenth missing the frame before is back "
+                       "(41 472 of 46 080 contacts per frame); ivx_world_set_contacts (general path) + ivx_world_step per frame, one wait",
+           "ms_per_frame": round(float(np.median(t_frame)), 4), "ms_per_frame_spread": spread3(t_frame),
+           "set_contacts_host_ms": round(float(np.median(t_set)), 4), "set_contacts_host_ms_spread": spread3(t_set),
+           "levels_velocity_plus_positional": {"min": int(min(levels)), "median": int(np.median(levels)), "max": int(max(levels)), "pristine_order": 183 + 147},
+           "solver": w.solver_info()}
+    if with_cpu:
+        import oracle_lib as ol
+
+        o = ol.OraclePhysics(bodies, config=(8, 0.4, 3, 0.2))
+        o.step(contacts, 0.005)
+        t0 = time.perf_counter()
+        for cs in lists:
+            o.step(cs, 0.005)
+        cpu = (time.perf_counter() - t0) / len(lists)
+        gd, od = w.bodies()[0], o.bodies()[0]
+        rel = 0.0
+        for f_ in ("position", "orientation", "momentum", "angular_momentum"):
+            g64, o64 = gd[f_].astype(np.float64), od[f_].astype(np.float64)
+            scale = np.maximum(np.linalg.norm(o64, axis=1, keepdims=True), max(float(np.abs(o64).max()), 1e-30) * 1e-4)
+            rel = max(rel, float((np.abs(g64 - o64) / scale).max()))
+        out["cpu_baseline"] = {"ms_per_frame": round(1e3 * cpu, 2), "cores": 1, "kind": "port", "sample": f"the same {len(lists)} frames, single thread"}
+        out["parity"] = {"frames": len(lists) + 1, "body_state_max_rel_err": rel, "equal": bool(rel <= 1e-5)}
+    w.close()
+    return out
+
+
+def spread3(samples):
+    """min / median / max of a host-bound leg's per-call times (ms): the driver's run and the builder's differ by more than a median shows"""
+    a = np.asarray(samples, dtype=np.float64)
+    return {"min": round(float(a.min()), 4), "median": round(float(np.median(a)), 4), "max": round(float(a.max()), 4), "n": int(a.size)}
 
 
 def main():
@@ -1586,12 +1696,16 @@ def main():
             gc.collect()
             out["config5_one_gpu"] = config5_benchmark(ctx, args)
             gc.collect()
+            out["strong_512"] = strong_512_benchmark(ctx, args, out["ms_per_step"], int(out["config"]["triangles"]))
+            gc.collect()
             out["fragments"] = fragments_benchmark(ctx, with_cpu)
             gc.collect()
             out["fragments_frame"] = fragments_frame_benchmark(ctx, with_cpu)
             gc.collect()
             pile, w = pile_benchmark(ctx, with_cpu)
             out["pile"] = pile
+            gc.collect()
+            out["pile"]["churn"] = pile_churn_benchmark(ctx, with_cpu)
             gc.collect()
             # the full frame: the voxel step of the headline body + the pile's solve, enqueued back to back, one wait
             for _ in range(2):

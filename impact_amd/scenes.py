@@ -170,6 +170,24 @@ def sphere_pile_scene(n: int = 16, spacing: float = 0.95, radius: float = 0.5, p
     return bodies, contacts
 
 
+def pile_churn_frames(contacts, frames: int, points_per_pair: int = 4, fraction: float = 0.1, seed: int = 3):
+    """A contact set that changes every frame, as a moving pile's does (the reference prepares whatever contacts the frame produced:
+    constraint/solver.rs:386-452): frame f's list is `contacts` (manifolds of `points_per_pair` points, the generator's order) without a random
+    `fraction` of its manifolds — so the tenth that was missing the frame before is back, in its place in the generator's order, and another
+    tenth is gone. Returns the list of the frames' contact arrays."""
+    import numpy as np
+
+    man = contacts.reshape(-1, points_per_pair)
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(frames):
+        gone = rng.choice(len(man), int(fraction * len(man)), replace=False)
+        keep = np.ones(len(man), dtype=bool)
+        keep[gone] = False
+        out.append(np.ascontiguousarray(man[keep].reshape(-1)))
+    return out
+
+
 def plates_scene(n_chunks: int = 32, thickness: float = 6.0, holes: bool = True) -> SDFGraph:
     """All-surface workload: `n_chunks` parallel plates of `thickness` voxels, one per chunk layer along z, each spanning the
     whole grid in x and y, perforated by a few capsule-shaped holes through the stack — every chunk of the (16 n)^3 stored grid

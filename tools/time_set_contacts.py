@@ -17,19 +17,6 @@ from impact_amd.physics import PhysicsWorld  # noqa: E402
 from impact_amd.voxel import Context  # noqa: E402
 
 
-def churn_frames(contacts, frames, points=4, frac=0.1, seed=3):
-    """frame f's contact list: all manifolds but a random tenth; the tenth left out the frame before is back (in its place in the generator's order)"""
-    man = contacts.reshape(-1, points)
-    rng = np.random.default_rng(seed)
-    out = []
-    for _ in range(frames):
-        gone = rng.choice(len(man), int(frac * len(man)), replace=False)
-        keep = np.ones(len(man), dtype=bool)
-        keep[gone] = False
-        out.append(np.ascontiguousarray(man[keep].reshape(-1)))
-    return out
-
-
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     frames = int(sys.argv[2]) if len(sys.argv) > 2 else 30
@@ -39,7 +26,7 @@ def main():
     w.set_bodies(bodies)
     w.prepare_constraints(contacts)
     w.step(0.005)
-    lists = churn_frames(contacts, frames)
+    lists = scenes.pile_churn_frames(contacts, frames)
     t_set, t_all = [], []
     for cs in lists:
         ctx.synchronize()
