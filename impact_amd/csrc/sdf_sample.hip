@@ -339,6 +339,9 @@ constexpr int NODE_TILE = 64;
 constexpr uint32_t OP_CAP = 128u, OP_OVERFLOW = 0xFFFFFFFFu;
 constexpr uint32_t LONG_OPS = 10u;  // compact programs longer than this are evaluated first (see k_sdf_prepass's list appends)
 constexpr uint32_t OP_CONST = 0u, OP_LEAF = 1u, OP_SCALE = 2u, OP_COMBINE = 3u, OP_COMBINE_OUTSIDE = 4u;
+// OP_SKIP: the evaluator jumps `second word` ops ahead (itself included): the steps of a first operand that the pre-pass found to be out of
+// its combination's reach stay in the stream behind one (the stream is append / truncate only), dead
+constexpr uint32_t OP_SKIP = 5u;
 constexpr int PRE_T = 64;      // chunks per pre-pass block: one per lane
 constexpr int PRE_WAVES = 8;   // waves per pre-pass block: all of them take the nodes' box tests, the first walks the program
 struct PaddedNode {
@@ -476,6 +479,7 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
         __syncthreads();
     }
     uint32_t top = 0, cmask = 0;  // cmask bit: level is an EXACT block constant (lo == hi == value)
+    uint32_t bare = 0;            // bare bit: the level's live steps are one evaluated leaf (what the evaluator combines from registers)
     // Compact program of this chunk: steps of constant sub-expressions collapse into one OP_CONST (the
     // steps of a stack level are a contiguous tail of the stream, so folding = truncate + re-emit).
     uint2* ops = prog_ops + (size_t)chunk * OP_CAP;
@@ -534,6 +538,7 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
                 s_hi[top][tid] = v;
                 s_need[top][tid] = 0;
                 cmask |= 1u << top;
+                bare &= ~(1u << top);
                 emit(OP_CONST << 28, __float_as_uint(v));
                 top += 1;
                 skip_until = (int)sk2.x;
@@ -547,6 +552,7 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
                 s_hi[top][tid] = v;
                 s_need[top][tid] = 0;
                 cmask |= 1u << top;
+                bare &= ~(1u << top);
                 emit(OP_CONST << 28, __float_as_uint(v));
             } else {
                 const float lo = t_lo[n % NODE_TILE][tid], hi = t_hi[n % NODE_TILE][tid];
@@ -554,12 +560,14 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
                 s_hi[top][tid] = hi;
                 s_need[top][tid] = 1;
                 cmask &= ~(1u << top);
+                bare |= 1u << top;
                 emit((OP_LEAF << 28) | (kind << 24) | n, 0u);
             }
             top += 1;
         } else if (kind == 5u) {
             s_lo[top - 1][tid] = s_lo[top - 1][tid] * nd->a;
             s_hi[top - 1][tid] = s_hi[top - 1][tid] * nd->a;
+            bare &= ~(1u << (top - 1));
             if ((cmask >> (top - 1)) & 1u) {
                 pos = s_start[top - 1][tid];
                 emit(OP_CONST << 28, __float_as_uint(s_lo[top - 1][tid]));
@@ -572,6 +580,7 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
             const float lo1 = s_lo[top - 1][tid], hi1 = s_hi[top - 1][tid], lo2 = s_lo[top][tid], hi2 = s_hi[top][tid];
             const float s = nd->a, q = nd->b;
             const bool must_apply = t_mode[n % NODE_TILE][tid] != 0u;
+            const bool bare2 = (bare >> top) & 1u;
             if (c1 && c2) {
                 const float r = combine(kind, lo1, lo2, s, q);
                 if (must_apply || !(r >= nd->margin)) {
@@ -580,6 +589,7 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
                 }
                 pos = s_start[top - 1][tid];
                 s_need[top - 1][tid] = 0;
+                bare &= ~(1u << (top - 1));
                 emit(OP_CONST << 28, __float_as_uint(s_lo[top - 1][tid]));
             } else {
                 // absorption: an exact constant operand that the other operand can never come within
@@ -602,20 +612,39 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
                     s_hi[top - 1][tid] = av;
                     s_need[top - 1][tid] = 0;
                     cmask |= 1u << (top - 1);
+                    bare &= ~(1u << (top - 1));
                     pos = s_start[top - 1][tid];
                     emit(OP_CONST << 28, __float_as_uint(av));
                     continue;
                 }
-                // identity: a constant second operand that the first can never come within the smoothing distance of
-                // leaves the first operand unchanged, voxel for voxel (min/max picks it and h = 0), whether or not the
-                // reference applies the node — drop the operand and the combination from the chunk's program
-                if (c2) {
+                // identity: a second operand — constant or not — that the first can never come within the smoothing distance of
+                // leaves the first operand unchanged, voxel for voxel (min/max picks it and h = 0: x - 0 * q is x), whether or not the
+                // reference applies the node — drop the operand and the combination from the chunk's program. (An evaluated leaf is
+                // evaluated wherever the chunk meets its padded bounding box: around the box's corners it is tens of voxels away.)
+                {
                     bool ident;
                     if (kind == 7u) ident = hi1 <= lo2 - s - slk;
-                    else if (kind == 9u) ident = lo1 >= lo2 + s + slk;
+                    else if (kind == 9u) ident = lo1 >= hi2 + s + slk;
                     else ident = lo1 >= -lo2 + s + slk;
                     if (ident) {
                         pos = s_start[top][tid];
+                        continue;
+                    }
+                }
+                // ... and its mirror image: a first operand that never comes within the smoothing distance of the second leaves the SECOND
+                // operand, voxel for voxel, when the node is applied whatever its test voxels say (a node behind the test may also leave the first
+                // standing; a subtraction would leave the second negated). The first operand's steps cannot be cut out of the stream: an
+                // OP_SKIP over them takes the place of their first one.
+                if (must_apply && kind != 8u && !c2) {
+                    const bool mirror = kind == 7u ? lo1 >= hi2 + s + slk : hi1 <= lo2 - s - slk;
+                    if (mirror) {
+                        const uint32_t a = s_start[top - 1][tid], b = s_start[top][tid];
+                        if (a < OP_CAP) ops[a] = make_uint2(OP_SKIP << 28, b - a);
+                        s_lo[top - 1][tid] = lo2;
+                        s_hi[top - 1][tid] = hi2;
+                        s_need[top - 1][tid] = s_need[top][tid];
+                        cmask &= ~(1u << (top - 1));
+                        bare = (bare & ~(1u << (top - 1))) | ((bare2 ? 1u : 0u) << (top - 1));
                         continue;
                     }
                 }
@@ -623,7 +652,7 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
                 {  // the first operand keeps its level (if it has one) while the second is evaluated; the result needs one — unless the second
                     // is one bare leaf and the combination unconditional: the evaluator then combines it from registers (eval_leaf_fused)
                     const uint32_t n1 = s_need[top - 1][tid], n2 = s_need[top][tid];
-                    const bool fused = must_apply && !c2 && pos == (uint32_t)s_start[top][tid] + 2u;  // (pos: behind the combination just emitted)
+                    const bool fused = must_apply && !c2 && bare2;
                     const uint32_t nn = fused ? max(n1, 1u) : max(max(n1, (c1 ? 0u : 1u) + n2), 1u);
                     s_need[top - 1][tid] = (uint8_t)nn;
                 }
@@ -644,6 +673,7 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
                 s_lo[top - 1][tid] = rlo;
                 s_hi[top - 1][tid] = rhi;
                 cmask &= ~(1u << (top - 1));
+                bare &= ~(1u << (top - 1));
             }
         }
     }
@@ -1178,6 +1208,8 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
 #pragma unroll
                     for (int k = 0; k < 16; ++k) IVX_LV_SET(d, k, t15, r15, IVX_LV_GET(d, k, t15, r15) * s);
                 }
+            } else if (opc == OP_SKIP) {
+                i += v - 1u;  // (a first operand the pre-pass found out of its combination's reach)
             } else {
                 top -= 1;
                 combine_levels<TRIM>(kind, s, q, margin, opc == OP_COMBINE_OUTSIDE, top, stack, cv, cmask, tid, r15, s_pub);

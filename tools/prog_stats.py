@@ -41,6 +41,7 @@ def main():
     per_chunk = []
     fus = np.zeros(4, dtype=np.int64)  # combinations: second operand a bare leaf (applied / behind the test), other
     need_now, need_fused = [], []
+    skips = [0]
     shapes = {}  # op strings (C constant, L leaf, S scale, A combination applied, O combination behind the test) of the programs that still need two levels
     for c in range(3):
         seg = lens[n + 16 + c * n:n + 16 + (c + 1) * n]
@@ -49,7 +50,16 @@ def main():
             ln = lens[ch]
             if ln > 128:
                 continue
-            opc = ops[ch, :ln, 0] >> 28
+            opc_all = ops[ch, :ln, 0] >> 28
+            live, i = [], 0
+            while i < ln:  # (OP_SKIP = 5: the evaluator jumps over a dropped first operand's steps)
+                if opc_all[i] == 5:
+                    i += int(ops[ch, i, 1])
+                    skips[0] += 1
+                    continue
+                live.append(int(opc_all[i]))
+                i += 1
+            opc = np.array(live, dtype=np.int64)
             h = np.bincount(opc, minlength=16)
             tot += h
             per_chunk.append(h)
@@ -81,6 +91,7 @@ def main():
     print("combinations with a bare leaf as second operand: applied", int(fus[0]), "behind the test", int(fus[1]), "| other", int(fus[2]))
     print("LDS levels without the leaf + combination fusion:", np.bincount(need_now).tolist(), "with it (what the pre-pass counts):", np.bincount(need_fused).tolist())
     print("programs that would still need >= 2 levels:", sorted(shapes.items(), key=lambda kv: -kv[1])[:12])
+    print("dropped first operands (OP_SKIP):", skips[0])
     print("program length percentiles:", [int(np.percentile(per_chunk.sum(1), q)) for q in (10, 50, 90, 100)])
 
 
