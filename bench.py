@@ -326,7 +326,8 @@ def summary_block(out):
                     walk(v, f"{path}/{k}")
 
     walk(out)
-    return {"ms_per_step": g("ms_per_step"), "sdf_sample_ms": g("stage_ms", "sdf_sample"), "roofline_frac": g("roofline", "frac"),
+    return {"ms_per_step": g("ms_per_step"), "ms_per_step_isolated": g("sample_ahead", "isolated", "ms_per_step"), "sdf_sample_ms": g("stage_ms", "sdf_sample"),
+            "sdf_sample_isolated_ms": g("sample_ahead", "isolated", "sdf_sample_ms"), "roofline_frac": g("roofline", "frac"),
             "valu_frac": g("valu_roofline", "frac"), "step_counter_frac": g("step_roofline", "counter_frac"),
             "dense": {"ms_per_step": g("dense", "ms_per_step"), "emit_ms": g("dense", "emit_ms"), "roofline_kernel": g("dense", "roofline", "kernel"),
                       "roofline_frac": g("dense", "roofline", "frac"), "counter_frac": g("dense", "roofline", "counter_frac"),
@@ -1482,6 +1483,11 @@ def main():
     if not slabs:
         gen, obj = make_object(ctx, graph)
         cc = gen.chunk_counts()
+        # The step samples the same resident program every time: its interval pre-pass — which reads nothing but the program — is enqueued
+        # a step ahead, on the context's second stream behind the evaluator of the step before (ivx_grid_set_sample_ahead). All of a step's
+        # work is still done once per step; back-to-back steps just do not wait for it. `isolated` below is the same step without that.
+        sample_ahead = os.environ.get("IVX_BENCH_SAMPLE_AHEAD", "1") != "0"
+        obj.set_sample_ahead(sample_ahead)
 
         def step():
             # the voxel stages and the object's rigid-body step are enqueued back to back; one wait covers both
@@ -1582,6 +1588,27 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    isolated = None
+    if not slabs and sample_ahead:
+        # the same step with its pre-pass as its own first kernel (what a step that is not followed by another costs)
+        obj.set_sample_ahead(False)
+        n_iso = max(5, min(args.steps, 100))
+        for _ in range(3):
+            step()
+        iso_stage = np.zeros(capi.N_TIMED_STAGES, dtype=np.float64)
+        for _ in range(3):
+            iso_stage += step()["stage_ms"]
+        obj.set_stage_timing(1 << dom)  # (as in the timed region)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_iso):
+            step()
+        barrier()
+        isolated = {"ms_per_step": 1e3 * (time.perf_counter() - t1) / n_iso, "steps": n_iso, "sdf_sample_ms": round(float(iso_stage[0]) / 3, 4),
+                    "what": "ivx_grid_set_sample_ahead(0): the interval pre-pass is the sample stage's first kernel, every step waits for it"}
+        obj.set_stage_timing(0xFFFFFFFF)
+        obj.set_sample_ahead(True)
+        step()  # (the legs below find the object as the timed region left it)
 
     # N > 1: the other scaling mode in the same run (the metric's 1 -> 8 target is about the strong leg, config 5 is the weak one)
     other_leg = None
@@ -1663,6 +1690,11 @@ def main():
             "roofline": rl,
             "step_roofline": srl,
         }
+        if not slabs:
+            out["sample_ahead"] = {"on": bool(sample_ahead), "isolated": isolated,
+                                   "what": "the sample stage's interval pre-pass (k_sdf_prepass: reads only the resident program) is enqueued one step ahead on the "
+                                           "context's second stream, behind the evaluator of the step before; `stage_ms.sdf_sample` is then the evaluator's launch(es) "
+                                           "(+ the wait for the pre-pass, normally over); every step still runs one pre-pass"}
         if vrl:
             out["valu_roofline"] = vrl
         if slabs:

@@ -178,7 +178,7 @@ EXPORTED_SYMBOLS = [
     "ivx_inertia",
     "ivx_label_regions", "ivx_region_labels_download", "ivx_regions_describe", "ivx_split_off_smallest_region", "ivx_split_off_all", "ivx_clip_polyhedron", "ivx_copy_polyhedra", "ivx_mesh_sync", "ivx_mesh_export", "ivx_mesh_generation", "ivx_mesh_import_open", "ivx_mesh_import_close", "ivx_mesh_modifications", "ivx_mesh_report_synchronized", "ivx_absorb_sphere", "ivx_absorb_capsule", "ivx_absorb_mutual", "ivx_absorb_sphere_enqueue", "ivx_absorb_capsule_enqueue", "ivx_absorb_collect", "ivx_grid_set_early_mesh_needs", "ivx_mesh_sync_enqueue", "ivx_mesh_sync_collect",
     "ivx_many_begin", "ivx_many_flush", "ivx_many_stats", "ivx_voxel_step_many", "ivx_absorb_sphere_many", "ivx_absorb_capsule_many", "ivx_mesh_sync_many", "ivx_offset_reference_point", "ivx_apply_updated_inertial_properties", "ivx_extracted_object_dynamics", "ivx_handle_voxel_object_after_removing_voxels", "ivx_sphere_voxel_object_contacts", "ivx_plane_voxel_object_contacts", "ivx_capsule_voxel_object_contacts", "ivx_voxel_object_contacts_many", "ivx_collision_probes_recompute", "ivx_collision_probes_sync", "ivx_collision_probes_sync_many", "ivx_collision_probes_download", "ivx_mutual_voxel_object_contacts", "ivx_mutual_voxel_object_contacts_many",
-    "ivx_grid_set_sdf_program", "ivx_grid_set_densities", "ivx_voxel_step", "ivx_voxel_step_enqueue", "ivx_voxel_step_collect", "ivx_grid_set_stage_timing",
+    "ivx_grid_set_sdf_program", "ivx_grid_set_densities", "ivx_voxel_step", "ivx_voxel_step_enqueue", "ivx_voxel_step_collect", "ivx_grid_set_stage_timing", "ivx_grid_set_sample_ahead",
     "ivx_halo_pack_enqueue", "ivx_halo_unpack_enqueue", "ivx_halo_pack_both_enqueue", "ivx_region_face_labels_enqueue", "ivx_region_face_pairs_enqueue",
     "ivx_step_record_words", "ivx_step_record_enqueue", "ivx_slab_remesh_enqueue",
     "ivx_halo_bytes", "ivx_halo_pack", "ivx_halo_unpack", "ivx_halo_clear",
@@ -279,6 +279,7 @@ def lib():
         "ivx_voxel_step_enqueue": (i32, [vp, u32]),
         "ivx_voxel_step_collect": (i32, [vp, vp]),
         "ivx_grid_set_stage_timing": (i32, [vp, u32]),
+        "ivx_grid_set_sample_ahead": (i32, [vp, i32]),
         "ivx_halo_pack_enqueue": (i32, [vp, i32, vp]),
         "ivx_halo_unpack_enqueue": (i32, [vp, i32, vp]),
         "ivx_halo_pack_both_enqueue": (i32, [vp, vp, vp, i32]),

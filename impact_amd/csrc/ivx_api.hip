@@ -474,6 +474,10 @@ void ivx_shutdown(ivx_ctx* c) {
     ivx_many_release(c);  // (the launch recorder of the many-object calls and its staging ring)
     if (c->pinned_scratch) (void)hipHostFree(c->pinned_scratch);
     if (c->dev_scratch) (void)hipFree(c->dev_scratch);
+    if (c->aux_stream) {
+        (void)hipStreamSynchronize(c->aux_stream);
+        (void)hipStreamDestroy(c->aux_stream);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -638,6 +642,7 @@ static void ivx_edit_state_free(struct ivx_edit_state* e);
 void ivx_grid_destroy(ivx_grid* g) {
     if (!g) return;
     (void)ivx_stream_sync(g->ctx->stream);
+    ivx_sampler_ahead_free(g);  // (a pre-pass running ahead on the second stream is waited for)
     ivx_edit_state_free(g->edit);
     g->edit = nullptr;
     ivx_submesh_manager_free(g->submesh_manager);  // (host mirrors of the incremental remesh and of the probes' ranges)
@@ -3305,6 +3310,10 @@ int ivx_grid_set_sdf_program(ivx_grid* g, const ivx_sdf_processed_node* nodes, s
         const uint32_t cap = (d == 0 ? g->gx : g->cc[d]) * 16u;
         IVX_REQUIRE(grid_shape[d] <= cap, IVX_ERR_INVALID, "ivx_grid_set_sdf_program: grid shape exceeds the chunk grid along axis %d", d);
     }
+    {  // a pre-pass that runs ahead reads the resident program: wait for it, drop what it wrote
+        const int rc_a = ivx_sampler_ahead_cancel(g);
+        if (rc_a) return rc_a;
+    }
     if (n_nodes > g->prog_cap) {
         IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
         if (g->prog_nodes) (void)hipFree(g->prog_nodes);
@@ -3359,6 +3368,7 @@ static int step_enqueue(ivx_grid* g, uint32_t stages, const uint16_t* slab_nbr_i
     IVX_REQUIRE(!(stages & IVX_STAGE_SAMPLE) || g->prog_n > 0, IVX_ERR_STATE, "ivx_voxel_step: no SDF program resident (ivx_grid_set_sdf_program)");
     IVX_REQUIRE(!(stages & IVX_STAGE_INERTIA) || g->has_dens, IVX_ERR_STATE, "ivx_voxel_step: no densities resident (ivx_grid_set_densities)");
     hipStream_t s = g->ctx->stream;
+    g->ahead_unordered_ok = g->pending_stages == 0;  // (sample-ahead: whatever was enqueued before has been collected)
     // stages enqueued after a record change the step's results: the block the record role wrote is stale (this call sets the flag again
     // further down when it carries the slab record itself)
     g->results_in_block = 0;
@@ -3471,6 +3481,8 @@ static int step_enqueue(ivx_grid* g, uint32_t stages, const uint16_t* slab_nbr_i
             }
             T1(4);
         }
+        // (sample-ahead: the next sample stage's pre-pass goes behind the step's last big launch, beside the small ones that follow)
+        if (!g->ahead_unordered_ok && (rc = ivx_sampler_launch_ahead(g, true))) return rc;
         if ((post & IVX_STAGE_REGIONS) && fused_assign) {
             T0(5);
             if ((rc = ivx_launch_step_assign(g, (post & IVX_STAGE_REMESH) != 0))) return rc;
@@ -3484,6 +3496,7 @@ static int step_enqueue(ivx_grid* g, uint32_t stages, const uint16_t* slab_nbr_i
     }
 #undef T0
 #undef T1
+    if (back && (rc = ivx_sampler_launch_ahead(g, !g->ahead_unordered_ok))) return rc;  // (a call without the stages behind the derive sweep)
     g->pending_stages |= stages;
     return IVX_OK;
 }
@@ -3512,6 +3525,17 @@ int ivx_slab_remesh_enqueue(ivx_grid* g, const void* neighbour_face_ids, void* d
     }
     g->pairs_enqueued = 0;
     return step_enqueue(g, IVX_STAGE_REMESH, static_cast<const uint16_t*>(neighbour_face_ids), device_record);
+}
+
+// Sample-ahead: with `on`, every sample stage under the resident program also enqueues the NEXT sample stage's pre-pass — on the context's
+// second stream, behind its own evaluator —, and the next sample stage starts at its evaluator. For callers that sample the same program
+// step after step (the bench's headline step); the results are the same bytes either way. Off (the default): the pre-pass is the stage's
+// first kernel. Turning it off drops a pre-pass that is under way.
+int ivx_grid_set_sample_ahead(ivx_grid* g, int on) {
+    IVX_REQUIRE(g, IVX_ERR_INVALID, "ivx_grid_set_sample_ahead: null grid");
+    g->ahead_on = on ? 1 : 0;
+    if (!on) return ivx_sampler_ahead_cancel(g);
+    return IVX_OK;
 }
 
 int ivx_grid_set_stage_timing(ivx_grid* g, uint32_t slot_mask) {

@@ -69,6 +69,7 @@ struct ivx_ctx {
     size_t pinned_scratch_bytes;
     void* dev_scratch;  // device scratch of the same calls (counts and offsets of every pair of ivx_mutual_voxel_object_contacts_many)
     size_t dev_scratch_bytes;
+    hipStream_t aux_stream;  // made on first use (ivx_aux_stream): the sampler's pre-pass one step ahead (ivx_grid_set_sample_ahead)
     void* many_recorder;  // the launch recorder of ivx_many_begin / _flush and its staging ring (many.cpp); made on first use, freed by ivx_shutdown
     int many_error;       // a flush of recorded launches failed on this context (sticky until reported: ivx_many_error)
 };
@@ -200,6 +201,14 @@ struct ivx_grid {
     double* moments_dev;  // [10]
     uint32_t* samp_len;   // [n_chunks] length of the chunk's compact SDF program (sampler pre-pass)
     void* samp_ops;       // [n_chunks * 128] uint2 ops
+    // Sample-ahead (ivx_grid_set_sample_ahead, sdf_sample.hip): the pre-pass of the NEXT sample stage under the resident program runs on the
+    // context's second stream behind this step's evaluator, into a second set of the sampler's buffers; the records it would write for constant
+    // chunks wait in `info_shadow` until the next evaluator launch commits them.
+    int ahead_on, ahead_pending, ahead_wanted, ahead_unordered_ok, shadow_sel, alt_eval_dirty, ahead_events_ready;
+    uint32_t* samp_len_alt;
+    void* samp_ops_alt;
+    ivx_chunk_info* info_shadow;
+    hipEvent_t ahead_go, ahead_done;
     uint32_t* samp_super;  // [super-blocks * ceil(nodes / 32)] "node certainly outside every chunk of the super-block" bits
     size_t samp_super_words;
     hipEvent_t ev[2 * IVX_N_TIMED_STAGES];  // start/stop per timed stage
@@ -448,6 +457,9 @@ int ivx_launch_step_assign(ivx_grid* g, bool with_mesher_general = false, bool w
 int ivx_launch_step_gather(ivx_grid* g);
 bool ivx_step_assign_fits(const ivx_grid* g);
 int ivx_sampler_buffers(ivx_grid* g);
+int ivx_sampler_ahead_cancel(ivx_grid* g);  // sample-ahead (sdf_sample.hip): wait for a pre-pass that runs ahead and drop it
+void ivx_sampler_ahead_free(ivx_grid* g);
+int ivx_sampler_launch_ahead(ivx_grid* g, bool behind_stream);
 void ivx_sdf_annotate_host(ivx_sdf_processed_node* nodes, size_t n);  // sdf_compile.cpp: reserved[] fields for the pre-pass
 int ivx_launch_occupied(ivx_grid* g, uint32_t* d_raw);
 void ivx_occupied_from_raw(const ivx_grid* g, const uint32_t raw[12], uint32_t out[12]);

@@ -423,12 +423,15 @@ __device__ __forceinline__ bool range_all_far(const uint32_t* mask, uint32_t a, 
     return true;
 }
 
+// `ahead`: the launch runs a step ahead of its sample stage (ivx_grid_set_sample_ahead): `info_out` is the grid's shadow record array, where
+// a chunk that is NOT settled here gets a record of kind AHEAD_OPEN, so that the evaluator launch that commits the shadow knows which are
+constexpr uint8_t AHEAD_OPEN = 0xFFu;
 __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams p, const ivx_sdf_processed_node* __restrict__ nodes,
-                                                       float* __restrict__ chunk_const, uint32_t* __restrict__ prog_len,
+                                                       uint32_t* __restrict__ prog_len,
                                                        uint2* __restrict__ prog_ops, uint32_t* __restrict__ eval_count,
                                                        uint32_t* __restrict__ eval_list, uint32_t list_stride, ivx_chunk_info* __restrict__ info_out,
                                                        const uint32_t* __restrict__ super_mask, const uint2* __restrict__ super_skip, uint32_t words,
-                                                       uint32_t sy, uint32_t sz, uint32_t fused_super, ivx_roles::PresetArgs preset) {
+                                                       uint32_t sy, uint32_t sz, uint32_t n_sb, uint32_t fused_super, uint32_t ahead, ivx_roles::PresetArgs preset) {
     // (with `fused_super` this is the step's first kernel and hosts the presets of the later stages' scratch words; the sampler's own
     // counters are never among them: other blocks of this launch are adding to those)
     ivx_roles::role_preset(preset, blockIdx.x * (uint32_t)(PRE_T * PRE_WAVES) + threadIdx.x);
@@ -453,7 +456,10 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
     // LDS with the node tile); threads whose chunk lies beyond the grid still take part in the tile loads and barriers: they
     // redo a chunk of the grid and write nothing
     static_assert(PRE_T == SUPER * SUPER * SUPER, "one thread per chunk of a super-block");
-    const uint32_t sb = blockIdx.x;
+    // (a launch of fewer blocks than super-blocks walks them in turn: the pre-pass that runs a step ahead, beside another step's kernels,
+    // keeps to a block per CU — two of these blocks fill a CU's LDS)
+    for (uint32_t sb = blockIdx.x; sb < n_sb; sb += gridDim.x) {
+    if (sb != blockIdx.x) __syncthreads();
     const uint32_t sk = sb % sz, sj = (sb / sz) % sy, si = sb / (sz * sy);
     const uint32_t ci_raw = si * SUPER + (tid >> 4), cj_raw = sj * SUPER + ((tid >> 2) & 3u), ck_raw = sk * SUPER + (tid & 3u);
     const bool mine = ci_raw < p.cx && cj_raw < p.cy && ck_raw < p.cz;
@@ -677,7 +683,7 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
             }
         }
     }
-    if (wv != 0u) return;  // (no barrier below this line)
+    if (wv != 0u) continue;  // (no barrier below this line)
     IVX_TP(p, sb, 2);  // program walked
     const float lo = p.n_nodes ? s_lo[0][tid] : 1000.0f, hi = p.n_nodes ? s_hi[0][tid] : 1000.0f;  // no program: empty space
     float out = __uint_as_float(0x7FC00000u);  // NaN = evaluate per voxel
@@ -688,8 +694,8 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
     if (oi >= p.shape[0] || oj >= p.shape[1] || ok >= p.shape[2]) out = 1000.0f;  // beyond the generator's grid: all +127
     bool to_fill = false;
     if (mine) {
-        chunk_const[chunk] = out;
         prog_len[chunk] = pos <= OP_CAP ? pos : OP_OVERFLOW;
+        bool settled = false;
         if (out == out) {
             // A constant chunk is classified right here (create_for_generated_voxels, object.rs:1890-1964): every voxel
             // void (> +2.0) -> Void, every voxel maximally inside -> Uniform; such a chunk is its record and has no planes to
@@ -708,9 +714,18 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
                 rec.region_count = 0;
                 rec.boundary_region_count = 0;
                 info_out[chunk] = rec;
+                settled = true;
             } else {
                 to_fill = true;
             }
+        }
+        if (ahead && !settled) {
+            ivx_chunk_info rec;
+            rec.kind = rec.gen_kind = AHEAD_OPEN;
+            rec.flags = rec.uniform_type = 0;
+            rec.face_dist = 0;
+            rec.region_count = rec.boundary_region_count = 0;
+            info_out[chunk] = rec;
         }
     }
     // chunks that need per-voxel evaluation go on a list for k_sdf_eval, constant chunks with planes to write on one for
@@ -757,6 +772,7 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
     IVX_TP(p, sb, 3);
     IVX_TP(p, sb, 4);
     IVX_TP(p, sb, 5);
+    }
 }
 
 // ---- per-voxel evaluation ----------------------------------------------------------------------
@@ -1082,11 +1098,24 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
                                                   const uint32_t* __restrict__ prog_len, const uint2* __restrict__ prog_ops,
                                                   const ivx_sdf_processed_node* __restrict__ nodes, int8_t* __restrict__ sdf_out,
                                                   uint8_t* __restrict__ type_out, ivx_chunk_info* __restrict__ info_out,
-                                                  uint16_t* __restrict__ signs_out, uint8_t* __restrict__ kface_out) {
+                                                  uint16_t* __restrict__ signs_out, uint8_t* __restrict__ kface_out,
+                                                  const ivx_chunk_info* __restrict__ shadow, uint32_t n_chunks, ivx_roles::PresetArgs preset) {
     extern __shared__ float stack[];  // [stack_size][16][256]
     constexpr bool TRIM = MODE == 1;
     const uint32_t tid = threadIdx.x;
     const uint32_t ti = tid >> 4, tj = tid & 15u;
+    if (shadow) {
+        // The sample stage's pre-pass ran a step ahead (ivx_grid_set_sample_ahead) and this is the stage's first launch: it hosts what the pre-pass
+        // hosts otherwise — the presets of the later stages' scratch words — and commits the records of the chunks the pre-pass settled (Void /
+        // Uniform: they were parked in the shadow array while the step before still read the real one), a slice of the grid per workgroup.
+        for (uint32_t gid = blockIdx.x * 256u + tid; gid < max(preset.n_sn, 32u); gid += gridDim.x * 256u) ivx_roles::role_preset(preset, gid);  // (a short list's launch has few threads)
+        const uint32_t each = (n_chunks + gridDim.x - 1u) / gridDim.x;
+        const uint32_t c0 = blockIdx.x * each, c1 = min(c0 + each, n_chunks);
+        for (uint32_t c = c0 + tid; c < c1; c += 256u) {
+            const ivx_chunk_info r = shadow[c];
+            if (r.kind != AHEAD_OPEN) info_out[c] = r;
+        }
+    }
     // (`first_list`: a second list walked ahead of the launch's own — the host merges two classes into one launch when one of them is too
     // short to fill the chip on its own, see ivx_launch_sdf_sample)
     const uint32_t n_first = first_count ? first_count[0] : 0u;
@@ -1311,6 +1340,53 @@ int ivx_sampler_buffers(ivx_grid* g) {
     return IVX_OK;
 }
 
+// the context's second stream (sample-ahead), made on first use
+static int ivx_aux_stream(ivx_ctx* c, hipStream_t* out) {
+    if (!c->aux_stream) {
+        // (the lowest priority there is: what runs here rides beside the context's own work, which must not queue behind it)
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, least) != hipSuccess)
+            IVX_HIP_CHECK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    }
+    *out = c->aux_stream;
+    return IVX_OK;
+}
+// second set of the sampler's buffers + the shadow records + the two events of the hand-over
+static int ivx_sampler_ahead_buffers(ivx_grid* g, hipStream_t aux) {
+    if (!g->ahead_events_ready) {
+        IVX_HIP_CHECK(hipEventCreateWithFlags(&g->ahead_go, hipEventDisableTiming));
+        IVX_HIP_CHECK(hipEventCreateWithFlags(&g->ahead_done, hipEventDisableTiming));
+        g->ahead_events_ready = 1;
+    }
+    if (g->samp_ops_alt) return IVX_OK;
+    IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_len_alt), sizeof(uint32_t) * (4 * (size_t)g->n_chunks + 16)));
+    IVX_HIP_CHECK(hipMemsetAsync(g->samp_len_alt + g->n_chunks, 0, 16 * sizeof(uint32_t), aux));
+    g->alt_eval_dirty = 0;
+    IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_ops_alt), sizeof(uint2) * (size_t)OP_CAP * g->n_chunks));
+    IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->info_shadow), 2 * sizeof(ivx_chunk_info) * (size_t)g->n_chunks));  // (two: one being committed, one being written)
+    return IVX_OK;
+}
+// A pre-pass that runs ahead is waited for and forgotten (the resident program changes, the grid goes): what it wrote into the second set is dropped
+int ivx_sampler_ahead_cancel(ivx_grid* g) {
+    if (!g->ahead_pending) return IVX_OK;
+    g->ahead_pending = 0;
+    g->alt_eval_dirty = 1;
+    IVX_HIP_CHECK(hipEventSynchronize(g->ahead_done));
+    return IVX_OK;
+}
+void ivx_sampler_ahead_free(ivx_grid* g) {
+    (void)ivx_sampler_ahead_cancel(g);
+    if (g->samp_len_alt) (void)hipFree(g->samp_len_alt);
+    if (g->samp_ops_alt) (void)hipFree(g->samp_ops_alt);
+    if (g->info_shadow) (void)hipFree(g->info_shadow);
+    g->samp_len_alt = nullptr, g->samp_ops_alt = nullptr, g->info_shadow = nullptr;
+    if (g->ahead_events_ready) {
+        (void)hipEventDestroy(g->ahead_go);
+        (void)hipEventDestroy(g->ahead_done);
+        g->ahead_events_ready = 0;
+    }
+}
+
 ivx_roles::PresetArgs ivx_preset_args(ivx_grid* g, uint32_t groups);  // derive.hip
 
 int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, uint32_t n_nodes, uint32_t stack_size,
@@ -1334,52 +1410,78 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
     size_t lds = (size_t)(stack_size ? stack_size : 1) * IVX_CHUNK_VOXELS * sizeof(float);
     IVX_REQUIRE(lds <= 150 * 1024, IVX_ERR_CAPACITY, "SDF graph needs a forward stack of %u blocks (at most 9 fit the 160 KiB LDS)", stack_size);
     IVX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sdf_eval<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    float* chunk_const = reinterpret_cast<float*>(g->chunk_bbox);  // scratch: rewritten by ivx_derive_state afterwards
     {
         int rc_b = ivx_sampler_buffers(g);
         if (rc_b) return rc_b;
     }
-    uint2* ops = reinterpret_cast<uint2*>(g->samp_ops);
-    uint32_t* eval_count = g->samp_len + g->n_chunks;
-    uint32_t* eval_list = eval_count + 16;
     // Programs of up to SUPER_MAX_WORDS * 32 nodes get their super-block tables inside the pre-pass (no launch of their own); the
     // pre-pass is then the call's first kernel and hosts the presets of the later stages' scratch words. The sampler's own list
     // counters are zero already when the derive sweep of the step before rolled them over (role_preset), else cleared here.
     const uint32_t words = (n_nodes + 31u) / 32u > 0u ? (n_nodes + 31u) / 32u : 1u;
     const bool fused_super = words <= SUPER_MAX_WORDS;
-    const bool eval_dirty = (g->scratch_dirty & IVX_SCRATCH_EVAL) != 0u;
-    uint32_t super_presets = fused_super ? 0u : preset_groups;
-    const uint32_t prepass_presets = fused_super ? (preset_groups & ~IVX_SCRATCH_EVAL) : 0u;
-    if (eval_dirty && !(super_presets & IVX_SCRATCH_EVAL)) IVX_HIP_CHECK(ivx_memset_async(eval_count, 0, 8 * sizeof(uint32_t), g->ctx->stream));
-    if (!eval_dirty) super_presets &= ~IVX_SCRATCH_EVAL;
     const uint32_t sx = (g->cc[0] + SUPER - 1) / SUPER, sy = (g->cc[1] + SUPER - 1) / SUPER, sz = (g->cc[2] + SUPER - 1) / SUPER;
-    uint2* super_skip = nullptr;
-    if (!fused_super) {
-        const size_t need = (((size_t)sx * sy * sz * words + 1u) & ~(size_t)1u) + (size_t)sx * sy * sz * words * 64u;  // far bits + a uint2 per node
-        if (need > g->samp_super_words) {
-            IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
-            if (g->samp_super) (void)hipFree(g->samp_super);
-            g->samp_super = nullptr;
-            g->samp_super_words = 0;
-            IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_super), need * sizeof(uint32_t)));
-            g->samp_super_words = need;
+    // One evaluator launch per LDS class (see k_sdf_prepass); a class the program cannot reach is not launched, nor one whose list the last step
+    // under this program found empty (the lists are a function of the program and the grid). Two launches one after the other each pay
+    // their own ramp and tail: when both of the first two classes have work and one of them is too short to fill the chip a few times
+    // over, the two-level kernel takes both lists in one launch (the one-level programs run there as well, five workgroups per CU).
+    // (`resident_program`: the step path. The remembered lengths are the RESIDENT program's; ivx_sdf_sample runs any program through
+    // this launcher and must launch every class that program can reach)
+    const bool known = resident_program && g->eval_len_valid != 0;
+    const uint32_t fill = 4u * 5u * (uint32_t)g->ctx->n_cu;
+    const bool merge01 = known && g->eval_len[0] && g->eval_len[1] && (g->eval_len[0] < fill || g->eval_len[1] < fill);
+    const bool launch2 = !merge01 && !(known && g->eval_len[0] == 0u);            // k_sdf_eval<2>: the one-level class
+    const bool launch1 = merge01 || !(known && g->eval_len[1] == 0u);             // k_sdf_eval<1>: the two-level class (or both)
+    const bool launch0 = stack_size >= 3u && !(known && g->eval_len[2] == 0u);    // k_sdf_eval<0>: the general class
+    // Sample-ahead: this stage's pre-pass may have run already, behind the evaluator of the step before (see below); the stage then starts at
+    // its first evaluator launch, which commits the parked records and hosts the presets. Only with an evaluator launch to host them.
+    const bool ahead_fits = resident_program && fused_super && (launch0 || launch1 || launch2);
+    bool consume = resident_program && g->ahead_pending != 0;
+    if (consume && !ahead_fits) {
+        int rc_c = ivx_sampler_ahead_cancel(g);
+        if (rc_c) return rc_c;
+        consume = false;
+    }
+    const bool eval_dirty = (g->scratch_dirty & IVX_SCRATCH_EVAL) != 0u;
+    if (consume) {
+        std::swap(g->samp_len, g->samp_len_alt);
+        void* t_ops = g->samp_ops;
+        g->samp_ops = g->samp_ops_alt;
+        g->samp_ops_alt = t_ops;
+        g->alt_eval_dirty = eval_dirty ? 1 : 0;  // (the set that steps back: its counters are zero if a derive sweep rolled them over)
+        g->ahead_pending = 0;
+        // (normally long over — it was enqueued a step ago —, and then the stream need not hear of it: a wait is a packet on the queue)
+        if (hipEventQuery(g->ahead_done) != hipSuccess) IVX_HIP_CHECK(hipStreamWaitEvent(g->ctx->stream, g->ahead_done, 0));
+    }
+    uint2* ops = reinterpret_cast<uint2*>(g->samp_ops);
+    uint32_t* eval_count = g->samp_len + g->n_chunks;
+    uint32_t* eval_list = eval_count + 16;
+    const uint32_t host_presets = preset_groups & ~IVX_SCRATCH_EVAL;  // what the stage's first kernel presets for the later stages
+    if (!consume) {
+        uint32_t super_presets = fused_super ? 0u : preset_groups;
+        const uint32_t prepass_presets = fused_super ? host_presets : 0u;
+        if (eval_dirty && !(super_presets & IVX_SCRATCH_EVAL)) IVX_HIP_CHECK(ivx_memset_async(eval_count, 0, 8 * sizeof(uint32_t), g->ctx->stream));
+        if (!eval_dirty) super_presets &= ~IVX_SCRATCH_EVAL;
+        uint2* super_skip = nullptr;
+        if (!fused_super) {
+            const size_t need = (((size_t)sx * sy * sz * words + 1u) & ~(size_t)1u) + (size_t)sx * sy * sz * words * 64u;  // far bits + a uint2 per node
+            if (need > g->samp_super_words) {
+                IVX_HIP_CHECK(ivx_stream_sync(g->ctx->stream));
+                if (g->samp_super) (void)hipFree(g->samp_super);
+                g->samp_super = nullptr;
+                g->samp_super_words = 0;
+                IVX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->samp_super), need * sizeof(uint32_t)));
+                g->samp_super_words = need;
+            }
+            super_skip = reinterpret_cast<uint2*>(g->samp_super + (((size_t)sx * sy * sz * words + 1u) & ~(size_t)1u));
+            IVX_KLAUNCH(k_sdf_super, dim3(sx * sy * sz), dim3(64), words * sizeof(uint32_t), g->ctx->stream, p, d_nodes, g->samp_super, super_skip, words, sy, sz,
+                               ivx_preset_args(g, super_presets));
         }
-        super_skip = reinterpret_cast<uint2*>(g->samp_super + (((size_t)sx * sy * sz * words + 1u) & ~(size_t)1u));
-        IVX_KLAUNCH(k_sdf_super, dim3(sx * sy * sz), dim3(64), words * sizeof(uint32_t), g->ctx->stream, p, d_nodes, g->samp_super, super_skip, words, sy, sz,
-                           ivx_preset_args(g, super_presets));
+        IVX_KLAUNCH(k_sdf_prepass, dim3(sx * sy * sz), dim3(PRE_T * PRE_WAVES), 0, g->ctx->stream, p, d_nodes, g->samp_len, ops, eval_count, eval_list,
+                           g->n_chunks, g->info, g->samp_super, super_skip, words, sy, sz, sx * sy * sz, fused_super ? 1u : 0u, 0u, ivx_preset_args(g, prepass_presets));
     }
     g->scratch_dirty = (g->scratch_dirty & ~preset_groups) | IVX_SCRATCH_EVAL;
-    IVX_KLAUNCH(k_sdf_prepass, dim3(sx * sy * sz), dim3(PRE_T * PRE_WAVES), 0, g->ctx->stream, p, d_nodes, chunk_const, g->samp_len, ops, eval_count, eval_list,
-                       g->n_chunks, g->info, g->samp_super, super_skip, words, sy, sz, fused_super ? 1u : 0u, ivx_preset_args(g, prepass_presets));
     g->planes_compact = 1;
     {
-        // One launch per LDS class (see k_sdf_prepass); a class the program cannot reach is not launched, nor one whose list the last step
-        // under this program found empty (the lists are a function of the program and the grid). Two launches one after the other each pay
-        // their own ramp and tail: when both of the first two classes have work and one of them is too short to fill the chip a few times
-        // over, the two-level kernel takes both lists in one launch (the one-level programs run there as well, five workgroups per CU).
-        // (`resident_program`: the step path. The remembered lengths are the RESIDENT program's; ivx_sdf_sample runs any program through
-        // this launcher and must launch every class that program can reach)
-        const bool known = resident_program && g->eval_len_valid != 0;
         // (grids: a whole number of list entries per workgroup once the lists' lengths are known — a launch's last wave of workgroups costs as
         // much as a full one, see ivx_launch_derive)
         auto fit = [&](uint32_t n) {
@@ -1388,40 +1490,115 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
             const uint32_t each = (n + cap - 1u) / cap;
             return (n + each - 1u) / each;
         };
-        const uint32_t fill = 4u * 5u * (uint32_t)g->ctx->n_cu;
-        const bool merge01 = known && g->eval_len[0] && g->eval_len[1] && (g->eval_len[0] < fill || g->eval_len[1] < fill);
+        // (consume: the first launch commits the shadow records and hosts the presets)
+        const ivx_chunk_info* shadow = consume ? g->info_shadow + (size_t)g->shadow_sel * g->n_chunks : nullptr;
+        const ivx_roles::PresetArgs no_presets = ivx_preset_args(g, 0u), first_presets = ivx_preset_args(g, consume ? host_presets : 0u);
+        auto take_shadow = [&]() {
+            const ivx_chunk_info* s_ = shadow;
+            shadow = nullptr;
+            return s_;
+        };
         uint32_t* const list0 = eval_list;
         uint32_t* const list1 = eval_list + (size_t)g->n_chunks;
-        if (!merge01 && !(known && g->eval_len[0] == 0u)) {
+        if (launch2) {
             // one level + 64 words of scratch: 16 640 bytes = 13 LDS granules, eight workgroups per CU (the waves a SIMD holds)
             const uint32_t scratch_off = IVX_CHUNK_VOXELS;
+            const ivx_chunk_info* sh = take_shadow();
             IVX_KLAUNCH(k_sdf_eval<2>, dim3(fit(g->eval_len[0])), dim3(256), (size_t)(scratch_off + 64u) * sizeof(float), g->ctx->stream, p, eval_count + 0, list0,
-                               eval_count + 3, nullptr, nullptr, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info, g->chunk_signs, g->kface);
+                               eval_count + 3, nullptr, nullptr, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info, g->chunk_signs, g->kface,
+                               sh, g->n_chunks, sh ? first_presets : no_presets);
         }
-        if (merge01 || !(known && g->eval_len[1] == 0u)) {
+        if (launch1) {
             // two levels, the second one 15 rows long + 64 words of scratch: 32 000 bytes = 25 LDS granules, five workgroups per CU
             const uint32_t scratch_off = IVX_CHUNK_VOXELS + 15u * 256u;
+            const ivx_chunk_info* sh = take_shadow();
             if (merge01)
                 IVX_KLAUNCH(k_sdf_eval<1>, dim3(fit(g->eval_len[0] + g->eval_len[1])), dim3(256), (size_t)(scratch_off + 64u) * sizeof(float), g->ctx->stream, p, eval_count + 0, list0,
-                                   eval_count + 3, eval_count + 1, list1, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info, g->chunk_signs, g->kface);
+                                   eval_count + 3, eval_count + 1, list1, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info, g->chunk_signs, g->kface,
+                                   sh, g->n_chunks, sh ? first_presets : no_presets);
             else
                 IVX_KLAUNCH(k_sdf_eval<1>, dim3(fit(g->eval_len[1])), dim3(256), (size_t)(scratch_off + 64u) * sizeof(float), g->ctx->stream, p, eval_count + 1, list1,
-                                   nullptr, nullptr, nullptr, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info, g->chunk_signs, g->kface);
+                                   nullptr, nullptr, nullptr, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info, g->chunk_signs, g->kface,
+                                   sh, g->n_chunks, sh ? first_presets : no_presets);
         }
-        if (stack_size >= 3u && !(known && g->eval_len[2] == 0u)) {
+        if (launch0) {
             // (the scratch words are the last sixteen of the stack: rows 15 of the last level's threads 240..255, dead when they are used
             // — the votes — and never used as published test voxels, which only the trimmed launch has)
             const uint32_t lv = stack_size;
             const uint32_t scratch_off = lv * IVX_CHUNK_VOXELS - 16u;
+            const ivx_chunk_info* sh = take_shadow();
             IVX_KLAUNCH(k_sdf_eval<0>, dim3(fit(g->eval_len[2])), dim3(256), (size_t)lv * IVX_CHUNK_VOXELS * sizeof(float), g->ctx->stream, p, eval_count + 2,
-                               eval_list + 2 * (size_t)g->n_chunks, nullptr, nullptr, nullptr, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info, g->chunk_signs, g->kface);
+                               eval_list + 2 * (size_t)g->n_chunks, nullptr, nullptr, nullptr, g->n_chunks, scratch_off, g->samp_len, ops, d_nodes, g->sdf, g->type, g->info, g->chunk_signs, g->kface,
+                               sh, g->n_chunks, sh ? first_presets : no_presets);
         }
     }
     IVX_HIP_CHECK(hipGetLastError());
+    g->ahead_wanted = (g->ahead_on && ahead_fits) ? 1 : 0;
+    // (everything enqueued before this call has been collected: the sampler's other set of buffers is idle and the pre-pass needs no place in
+    // the stream's order; else the step puts it behind its last big launch)
+    if (g->ahead_wanted && g->ahead_unordered_ok) {
+        const int rc_a = ivx_sampler_launch_ahead(g, false);
+        if (rc_a) return rc_a;
+    }
     // every chunk that has planes now has its sign rows and k-face bytes too, and one type throughout (SameVoxelTypeGenerator): the derive
     // sweep may work from those (until something else rewrites voxels: ivx_planes_touched)
     g->signs_current = 1;
     g->signs_type = voxel_type;
+    return IVX_OK;
+}
+
+// The NEXT sample stage's pre-pass, a step ahead (ivx_grid_set_sample_ahead): it reads nothing but the resident program and the grid's
+// geometry, so it runs on the context's second stream beside this step's kernels — into the sampler's other set of buffers (this step's
+// lists and programs are its evaluator's) and the other shadow record array. At most two blocks per CU (what a CU's LDS holds; developer
+// knob IVX_AHEAD_BLOCKS), which walk the super-blocks of a larger grid in turn. Measured on the 512^3 step: 0.217 ms -> 0.199 with a block
+// per super-block or per CU alike; a block per four CUs no longer finishes inside the step.
+// `behind_stream`: the launch waits for what the context's stream holds now (a caller that has NOT collected its earlier steps: the other
+// set may still be read). A step that never comes costs one unused pre-pass; ivx_grid_set_sdf_program and ivx_grid_destroy wait for one
+// that is under way.
+int ivx_sampler_launch_ahead(ivx_grid* g, bool behind_stream) {
+    if (!g->ahead_wanted) return IVX_OK;
+    g->ahead_wanted = 0;
+    if (g->ahead_pending) return IVX_OK;
+    hipStream_t aux;
+    int rc = ivx_aux_stream(g->ctx, &aux);
+    if (rc) return rc;
+    if ((rc = ivx_sampler_ahead_buffers(g, aux))) return rc;
+    SampleParams p;
+    p.cx = g->cc[0];
+    p.cy = g->cc[1];
+    p.cz = g->cc[2];
+    p.x_off = g->x_off;
+    for (int d = 0; d < 3; ++d) {
+        p.shape[d] = g->prog_shape[d];
+        p.shifted_center[d] = g->prog_center[d];
+    }
+    p.n_nodes = g->prog_n;
+    p.stack_size = g->prog_stack;
+#ifdef IVX_WG_TRACE
+    p.trace = reinterpret_cast<unsigned long long*>(g->chunk_moments);
+#endif
+    p.voxel_type = g->prog_type;
+    const uint32_t words = (g->prog_n + 31u) / 32u > 0u ? (g->prog_n + 31u) / 32u : 1u;
+    const uint32_t sx = (g->cc[0] + SUPER - 1) / SUPER, sy = (g->cc[1] + SUPER - 1) / SUPER, sz = (g->cc[2] + SUPER - 1) / SUPER;
+    if (behind_stream) {
+        IVX_HIP_CHECK(hipEventRecord(g->ahead_go, g->ctx->stream));
+        IVX_HIP_CHECK(hipStreamWaitEvent(aux, g->ahead_go, 0));
+    }
+    uint32_t* alt_count = g->samp_len_alt + g->n_chunks;
+    if (g->alt_eval_dirty) IVX_HIP_CHECK(hipMemsetAsync(alt_count, 0, 8 * sizeof(uint32_t), aux));
+    g->alt_eval_dirty = 0;
+    static const uint32_t blocks_env = [] {
+        const char* e = getenv("IVX_AHEAD_BLOCKS");
+        return e ? (uint32_t)strtoul(e, nullptr, 10) : 0u;
+    }();
+    const uint32_t n_sb = sx * sy * sz, blocks = std::min(n_sb, blocks_env ? blocks_env : 2u * (uint32_t)g->ctx->n_cu);
+    g->shadow_sel ^= 1;
+    hipLaunchKernelGGL(k_sdf_prepass, dim3(blocks), dim3(PRE_T * PRE_WAVES), 0, aux, p, g->prog_nodes, g->samp_len_alt, reinterpret_cast<uint2*>(g->samp_ops_alt),
+                       alt_count, alt_count + 16, g->n_chunks, g->info_shadow + (size_t)g->shadow_sel * g->n_chunks, nullptr, nullptr, words, sy, sz, n_sb, 1u, 1u,
+                       ivx_preset_args(g, 0u));
+    IVX_HIP_CHECK(hipGetLastError());
+    IVX_HIP_CHECK(hipEventRecord(g->ahead_done, aux));
+    g->ahead_pending = 1;
     return IVX_OK;
 }
 

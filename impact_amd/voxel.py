@@ -202,6 +202,10 @@ class VoxelObject:
             self._region_count = int(out[0]["region_count"])
         return out[0]
 
+    def set_sample_ahead(self, on: bool):
+        """`ivx_grid_set_sample_ahead`: every sample stage also enqueues the next one's pre-pass on the context's second stream"""
+        check(capi.lib().ivx_grid_set_sample_ahead(self.h, 1 if on else 0))
+
     def set_stage_timing(self, slot_mask: int = 0xFFFFFFFF):
         """which timed slots of a step get event records (`ivx_grid_set_stage_timing`): all by default, 0 = none"""
         check(capi.lib().ivx_grid_set_stage_timing(self.h, int(slot_mask) & 0xFFFFFFFF))

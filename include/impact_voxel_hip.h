@@ -369,6 +369,12 @@ int ivx_voxel_step_collect(ivx_grid*, ivx_step_result* out);
 /* Stage timing (ivx_step_result::stage_ms) costs event records on the stream (about 2 us each on the GPU's queue): slot_mask bit i = time
  * slot i. Default: every slot. 0 turns timing off (stage_ms reads 0); a single bit times one slot with two records per step. */
 int ivx_grid_set_stage_timing(ivx_grid*, uint32_t slot_mask);
+/* Sample-ahead, for callers that sample the resident program step after step (the voxel generator of a streamed or re-generated object,
+ * generation.rs:293-371 per chunk — the bench's headline step): with `on`, a sample stage also enqueues the NEXT sample stage's interval
+ * pre-pass — it reads nothing but the program and the grid's geometry — on the context's second stream behind its own evaluator, and the next
+ * sample stage starts at its evaluator. Same bytes either way. A step that never comes costs one unused pre-pass;
+ * ivx_grid_set_sdf_program and ivx_grid_destroy wait for one that is under way. Off by default. */
+int ivx_grid_set_sample_ahead(ivx_grid*, int on);
 
 /* ---- multi-GPU: x-slab halos ----------------------------------------------------- */
 /* Face planes of (sdf,type) and boundary chunk info, packed contiguously for torch.distributed /
