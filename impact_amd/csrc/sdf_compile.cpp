@@ -8,6 +8,7 @@
 // -ffp-contract=off.
 #include <cmath>
 #include <cstring>
+#include <limits>
 #include <vector>
 
 #include "ivx_internal.hpp"
@@ -338,6 +339,57 @@ void ivx_sdf_annotate_host(ivx_sdf_processed_node* nodes, size_t n) {
         nd.reserved[3] = first;
         nd.reserved[1] = (uint32_t)i;
         nodes[first].reserved[1] = (uint32_t)i;  // later (outer) roots overwrite earlier ones
+    }
+    // Saturation classes, root to leaves. The root's value is stored as (v * 50) as i8 (lib.rs:197-201): every value >= 2.54 is the byte +127,
+    // every value <= -2.56 the byte -128. So at the root two values are INTERCHANGEABLE when they are equal, both >= U or both <= L (U = 2.54f
+    // — the reference's own MAX_F32, what it fills a far leaf with —, L = -2.56f: 2.54f * 50 and -2.56f * 50 round to 127 and -128 exactly, and
+    // the product is monotone). Every node inherits such a pair (U, L) for
+    // its own result from its parent — the thresholds below are those for which "operands interchangeable => results interchangeable" holds
+    // for the parent's formula (generation/sdf.rs:47-102; a smooth form moves its result by at most s / 4 and only where the operands are
+    // within s of each other, hence the 1.25 s):
+    //   scaling by a > 0:         U / a, L / a
+    //   union r = su(x, y):       U + 1.25 s, L            (both operands)
+    //   intersection:             U, L - 1.25 s            (both operands)
+    //   subtraction r = x - y:    x: U, L - 1.25 s;  y: -(L - 1.25 s), -U
+    // and with them an operand that lies in ONE class throughout a chunk can be dropped from the chunk's program when that leaves the other
+    // operand's value (the pre-pass: k_sdf_prepass). What the pre-pass needs is one number per combination, kept in the field `c` (unused by
+    // binary nodes) of this uploaded copy: union — an operand everywhere >= c goes; intersection — an operand everywhere <= c goes;
+    // subtraction — a second operand everywhere >= c goes. A scaling that is not positive switches the rule off beneath it (infinite thresholds).
+    {
+        const float inf = std::numeric_limits<float>::infinity();
+        std::vector<float> up(n, inf), lo(n, -inf);
+        if (n) up[n - 1] = 0.02f * 127.0f, lo[n - 1] = -2.56f;
+        // children of node i in postfix order: unary -> i - 1; binary -> second operand's root i - 1, first operand's root = reserved[2]
+        for (size_t i = n; i-- > 0;) {
+            ivx_sdf_processed_node& nd = nodes[i];
+            const uint32_t kind = nd.kind;
+            const float U = up[i], L = lo[i];
+            if (kind <= 2u) continue;
+            if (kind < 7u) {
+                float cu = U, cl = L;
+                if (kind == 5u) {
+                    if (nd.a > 0.0f) cu = U / nd.a * 1.00001f + 1e-6f, cl = L / nd.a * 1.00001f - 1e-6f;  // (U > 0 > L)
+                    else cu = inf, cl = -inf;
+                }
+                up[i - 1] = cu, lo[i - 1] = cl;
+                continue;
+            }
+            const size_t r2 = i - 1, r1 = nd.reserved[2];
+            const float w = 1.25f * nd.a * 1.00001f + (nd.a != 0.0f ? 1e-6f : 0.0f);
+            if (kind == 7u) {
+                up[r1] = up[r2] = U + w;
+                lo[r1] = lo[r2] = L;
+                nd.c = U + w;
+            } else if (kind == 9u) {
+                up[r1] = up[r2] = U;
+                lo[r1] = lo[r2] = L - w;
+                nd.c = L - w;
+            } else {
+                up[r1] = U, lo[r1] = L - w;
+                up[r2] = -(L - w), lo[r2] = -U;
+                nd.c = -(L - w);
+            }
+        }
     }
 }
 

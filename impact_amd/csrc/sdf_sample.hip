@@ -468,6 +468,9 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
     const uint32_t oi = (ci + p.x_off) * 16u, oj = cj * 16u, ok = ck * 16u;
     const V3 origin_root = sub(mk((float)oi, (float)oj, (float)ok), mk(p.shifted_center[0], p.shifted_center[1], p.shifted_center[2]));
     const Box block{origin_root, add(origin_root, mk(16.0f, 16.0f, 16.0f))};
+    // (the chunk's voxels themselves lie at origin + 0 .. 15: what an evaluated leaf's distance bounds are taken over — the reference's block
+    // tests use the 16-box above)
+    const Box vox_block{origin_root, add(origin_root, mk(15.0f, 15.0f, 15.0f))};
     if (fused_super) {
         // k_sdf_super's far test for this block's own super-block, all nodes, 64 per wave and round (the tables are a function of the
         // program and the grid; building them here instead of in a launch of their own costs the block ~2 us and the step one launch less)
@@ -486,6 +489,7 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
     }
     uint32_t top = 0, cmask = 0;  // cmask bit: level is an EXACT block constant (lo == hi == value)
     uint32_t bare = 0;            // bare bit: the level's live steps are one evaluated leaf (what the evaluator combines from registers)
+    bool class_dropped = false, poisoned = false;  // (saturation classes, see the combination step)
     // Compact program of this chunk: steps of constant sub-expressions collapse into one OP_CONST (the
     // steps of a stack level are a contiguous tail of the stream, so folding = truncate + re-emit).
     uint2* ops = prog_ops + (size_t)chunk * OP_CAP;
@@ -519,7 +523,7 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
                 float blo = 0.0f, bhi = 0.0f;
                 if (tk <= 2u) {
                     mode = tfar ? 1u : node_mode(tn, block);
-                    if (mode == 0u) leaf_bounds(tn, aabb_of_transformed(block, tn->transform), blo, bhi);
+                    if (mode == 0u) leaf_bounds(tn, aabb_of_transformed(vox_block, tn->transform), blo, bhi);
                 } else if (tk >= 7u) {
                     mode = (!tfar && node_mode(tn, block) == 0u) ? 1u : 0u;
                 }
@@ -654,6 +658,36 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
                         continue;
                     }
                 }
+                // Saturation classes (ivx_sdf_annotate_host): the chunk's bytes are (v * 50) as i8 of the ROOT's value, so two values of a node are
+                // interchangeable when they are equal or lie in the same saturated class of that node — and an operand that lies in one class
+                // throughout the chunk goes when that leaves the other operand (`nd->c`: union — everywhere >= c; intersection — everywhere
+                // <= c; subtraction — the second operand everywhere >= c). The lemmas hold for combinations that are applied; a node behind the
+                // 14-position test reads its operands' values at the test voxels, which a dropped operand may have changed: a chunk whose
+                // program comes to hold one AFTER such a drop is evaluated on the full program instead (`poisoned`).
+                {
+                    const float cth = nd->c;
+                    const bool drop2 = kind == 9u ? hi2 <= cth : lo2 >= cth;
+                    if (drop2) {
+                        pos = s_start[top][tid];
+                        class_dropped = true;
+                        continue;
+                    }
+                    if (must_apply && kind != 8u && !c2) {
+                        const bool drop1 = kind == 7u ? lo1 >= cth : hi1 <= cth;
+                        if (drop1) {
+                            const uint32_t a = s_start[top - 1][tid], b = s_start[top][tid];
+                            if (a < OP_CAP) ops[a] = make_uint2(OP_SKIP << 28, b - a);
+                            s_lo[top - 1][tid] = lo2;
+                            s_hi[top - 1][tid] = hi2;
+                            s_need[top - 1][tid] = s_need[top][tid];
+                            cmask &= ~(1u << (top - 1));
+                            bare = (bare & ~(1u << (top - 1))) | ((bare2 ? 1u : 0u) << (top - 1));
+                            class_dropped = true;
+                            continue;
+                        }
+                    }
+                }
+                if (!must_apply && class_dropped) poisoned = true;
                 emit(((must_apply ? OP_COMBINE : OP_COMBINE_OUTSIDE) << 28) | (kind << 24) | n, 0u);
                 {  // the first operand keeps its level (if it has one) while the second is evaluated; the result needs one — unless the second
                     // is one bare leaf and the combination unconditional: the evaluator then combines it from registers (eval_leaf_fused)
@@ -691,6 +725,7 @@ __global__ __launch_bounds__(PRE_T * PRE_WAVES) void k_sdf_prepass(SampleParams 
     if (cmask & 1u) out = lo;
     else if (lo >= 2.54f + 0.02f) out = 1000.0f;    // every voxel quantises to +127
     else if (hi <= -2.56f - 0.02f) out = -1000.0f;  // every voxel quantises to -128
+    if (poisoned) out = __uint_as_float(0x7FC00000u), pos = OP_CAP + 1u;  // (evaluated per voxel, on the full program)
     if (oi >= p.shape[0] || oj >= p.shape[1] || ok >= p.shape[2]) out = 1000.0f;  // beyond the generator's grid: all +127
     bool to_fill = false;
     if (mine) {
@@ -1139,6 +1174,12 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
     // constant. Element-wise results are unchanged (same op on equal inputs).
     float cv = 0.0f;  // values of the block-constant levels (cv_get / cv_set)
     float r15 = 0.0f;  // TRIM: row 15 of the second dense level (IVX_LV_GET)
+    // The compact program's last step, when it scales the per-voxel root level or combines it with a constant, is not run as a step of its
+    // own — a read and a write of the level for one multiplication or comparison per voxel — but applied as the root level is read for
+    // quantisation (same operations on the same values): 5 = scaling, 7 / 8 / 9 = applied combination with the constant `tail_c` as
+    // second operand. (Nearly every program ends this way: a body under a root Scaling; a far body or far holes folded to one constant.)
+    uint32_t tail = 0u;
+    float tail_c = 0.0f, tail_s = 0.0f, tail_q = 0.0f;
     float* s_pub = stack + scratch_off;
     const uint32_t lane = tid & 63u;
     uint32_t top = 0;
@@ -1188,6 +1229,17 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
             }
             const uint32_t opc = w >> 28, kind = (w >> 24) & 15u;
             if (opc == OP_CONST) {
+                if (i + 2u == len && top == 1u && !(cmask & 1u)) {  // (the last step but one, over a per-voxel root level: a tail combination?)
+                    const uint32_t l1 = (i + 1u) & 63u;
+                    const uint32_t wn = i + 1u < 64u ? __builtin_amdgcn_readlane(my_w[0], l1) : __builtin_amdgcn_readlane(my_w[1], l1);
+                    if ((wn >> 28) == OP_COMBINE) {
+                        tail = (wn >> 24) & 15u;
+                        tail_c = __uint_as_float(v);
+                        tail_s = __uint_as_float(i + 1u < 64u ? __builtin_amdgcn_readlane(__float_as_uint(my_s[0]), l1) : __builtin_amdgcn_readlane(__float_as_uint(my_s[1]), l1));
+                        tail_q = __uint_as_float(i + 1u < 64u ? __builtin_amdgcn_readlane(__float_as_uint(my_q[0]), l1) : __builtin_amdgcn_readlane(__float_as_uint(my_q[1]), l1));
+                        break;
+                    }
+                }
                 cv_set(cv, top, __uint_as_float(v));
                 cmask |= 1u << top;
                 top += 1;
@@ -1230,6 +1282,9 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
                 // constant first operand standing (combine_levels), which the pre-pass cannot foresee.
                 if ((cmask >> (top - 1)) & 1u) {
                     cv_set(cv, top - 1, cv_get(cv, top - 1) * s);
+                } else if (i + 1u == len && top == 1u) {
+                    tail = 5u;  // (the last step, over the per-voxel root level)
+                    tail_s = s;
                 } else {
                     const uint32_t dl = lds_level(cmask, top - 1);
                     float* d = stack + (size_t)dl * IVX_CHUNK_VOXELS + tid;
@@ -1292,15 +1347,37 @@ __global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t
     IVX_TE(p, li, 3);
     const bool root_const = cmask & 1u;
     const float root_val = root_const ? cv_get(cv, 0u) : 0.0f;
-    if (oi + 16u <= p.shape[0] && oj + 16u <= p.shape[1] && ok + 16u <= p.shape[2]) {  // (workgroup-uniform) the chunk lies inside the grid
+    {
+        float fv[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) sd[k] = sd_from_f32(root_const ? root_val : stack[k * 256 + tid]);
-    } else {
+        for (int k = 0; k < 16; ++k) fv[k] = root_const ? root_val : stack[k * 256 + tid];
+        if (tail == 5u) {  // (workgroup-uniform branches: one loop runs)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            float v = root_const ? root_val : stack[k * 256 + tid];
-            bool in_grid = (oi + ti) < p.shape[0] && (oj + tj) < p.shape[1] && (ok + (uint32_t)k) < p.shape[2];
-            sd[k] = in_grid ? sd_from_f32(v) : 127;
+            for (int k = 0; k < 16; ++k) fv[k] = fv[k] * tail_s;
+        } else if (tail != 0u) {
+            if (tail_s != 0.0f) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) fv[k] = combine(tail, fv[k], tail_c, tail_s, tail_q);
+            } else if (tail == 7u) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) fv[k] = min_rs(fv[k], tail_c);
+            } else if (tail == 8u) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) fv[k] = max_rs(fv[k], -tail_c);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) fv[k] = max_rs(fv[k], tail_c);
+            }
+        }
+        if (oi + 16u <= p.shape[0] && oj + 16u <= p.shape[1] && ok + 16u <= p.shape[2]) {  // (workgroup-uniform) the chunk lies inside the grid
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sd[k] = sd_from_f32(fv[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                bool in_grid = (oi + ti) < p.shape[0] && (oj + tj) < p.shape[1] && (ok + (uint32_t)k) < p.shape[2];
+                sd[k] = in_grid ? sd_from_f32(fv[k]) : 127;
+            }
         }
     }
     IVX_TE(p, li, 4);

@@ -42,6 +42,7 @@ def main():
     fus = np.zeros(4, dtype=np.int64)  # combinations: second operand a bare leaf (applied / behind the test), other
     need_now, need_fused = [], []
     skips = [0]
+    all_shapes = {}  # live steps: C constant; s / q / b sphere, capsule, box leaf; S scale; U D I union, subtraction, intersection applied; u d i behind the test
     shapes = {}  # op strings (C constant, L leaf, S scale, A combination applied, O combination behind the test) of the programs that still need two levels
     for c in range(3):
         seg = lens[n + 16 + c * n:n + 16 + (c + 1) * n]
@@ -60,6 +61,16 @@ def main():
                 live.append(int(opc_all[i]))
                 i += 1
             opc = np.array(live, dtype=np.int64)
+            kinds = (ops[ch, :ln, 0] >> 24) & 15
+            sh, i = "", 0
+            while i < ln:
+                if opc_all[i] == 5:
+                    i += int(ops[ch, i, 1])
+                    continue
+                o = int(opc_all[i])
+                sh += {0: "C", 1: "sqb"[min(int(kinds[i]), 2)], 2: "S", 3: {7: "U", 8: "D", 9: "I"}.get(int(kinds[i]), "?"), 4: {7: "u", 8: "d", 9: "i"}.get(int(kinds[i]), "?")}[o]
+                i += 1
+            all_shapes[sh] = all_shapes.get(sh, 0) + 1
             h = np.bincount(opc, minlength=16)
             tot += h
             per_chunk.append(h)
@@ -92,6 +103,7 @@ def main():
     print("LDS levels without the leaf + combination fusion:", np.bincount(need_now).tolist(), "with it (what the pre-pass counts):", np.bincount(need_fused).tolist())
     print("programs that would still need >= 2 levels:", sorted(shapes.items(), key=lambda kv: -kv[1])[:12])
     print("dropped first operands (OP_SKIP):", skips[0])
+    print("most common programs:", sorted(all_shapes.items(), key=lambda kv: -kv[1])[:16])
     print("program length percentiles:", [int(np.percentile(per_chunk.sum(1), q)) for q in (10, 50, 90, 100)])
 
 
