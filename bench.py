@@ -59,6 +59,7 @@ def _default_profile_dir():
 
 
 PROFILE_DIR = _default_profile_dir()
+AHEAD = os.environ.get("IVX_BENCH_SAMPLE_AHEAD", "1") != "0"  # legs that sample the resident program step after step run its pre-pass a step ahead
 
 STAGE_KERNELS = {  # which kernels make up a timed slot (names as rocprofv3 reports them); include/impact_voxel_hip.h, IVX_N_TIMED_STAGES
     "sdf_sample": ["k_sdf_super", "k_sdf_prepass", "k_sdf_eval"],
@@ -329,7 +330,7 @@ def summary_block(out):
     return {"ms_per_step": g("ms_per_step"), "ms_per_step_isolated": g("sample_ahead", "isolated", "ms_per_step"), "sdf_sample_ms": g("stage_ms", "sdf_sample"),
             "sdf_sample_isolated_ms": g("sample_ahead", "isolated", "sdf_sample_ms"), "roofline_frac": g("roofline", "frac"),
             "valu_frac": g("valu_roofline", "frac"), "step_counter_frac": g("step_roofline", "counter_frac"),
-            "dense": {"ms_per_step": g("dense", "ms_per_step"), "emit_ms": g("dense", "emit_ms"), "roofline_kernel": g("dense", "roofline", "kernel"),
+            "dense": {"ms_per_step": g("dense", "ms_per_step"), "ms_per_step_isolated": g("dense", "ms_per_step_isolated"), "emit_ms": g("dense", "emit_ms"), "roofline_kernel": g("dense", "roofline", "kernel"),
                       "roofline_frac": g("dense", "roofline", "frac"), "counter_frac": g("dense", "roofline", "counter_frac"),
                       "step_counter_frac": g("dense", "step_roofline", "counter_frac")},
             "pile": {"ms_per_step": g("pile", "ms_per_step"), "solve_ms": g("pile", "stage_ms", "solve"), "kernel": g("pile", "solver", "kernel"),
@@ -349,7 +350,7 @@ def summary_block(out):
                                                     "frame": g("fragments_frame", "batched_host_ms_spread", "frame"), "cut": g("fragments", "cut_ms_spread")},
                                 "mutual_pairs_ms": [g("fragments_frame", "probes_and_pairs", "mutual_pairs", "ms_batched"),
                                                     g("fragments_frame", "probes_and_pairs", "mutual_pairs", "ms_looped")]},
-            "config3_split_loop_ms": g("config3", "split_loop_ms"), "config5_single_grid_ms": g("config5_one_gpu", "single_grid_ms"),
+            "config3_split_loop_ms": g("config3", "split_loop_ms"), "config5_single_grid_ms": g("config5_one_gpu", "single_grid_ms"), "config5_single_grid_isolated_ms": g("config5_one_gpu", "single_grid_isolated_ms"),
             "strong_scaling_bound": {"512": g("strong_512", "strong_scaling_bound"), "1024": g("config5_one_gpu", "strong_scaling_bound"),
                                      "strong_512_eight_slabs_one_gpu_ms": g("strong_512", "eight_slabs_one_gpu_ms")},
             "config5_eight_slabs_one_gpu_ms": g("config5_one_gpu", "eight_slabs_one_gpu_ms"),
@@ -357,13 +358,16 @@ def summary_block(out):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
-def make_object(ctx, graph):
+def make_object(ctx, graph, sample_ahead=False):
+    """`sample_ahead`: for a leg that samples the resident program step after step (ivx_grid_set_sample_ahead, see main)"""
     from impact_amd.voxel import SDFVoxelGenerator, VoxelObject
 
     gen = SDFVoxelGenerator(1.0, graph, 0)
     obj = VoxelObject(ctx, gen.chunk_counts(), 1.0)
     obj.set_sdf_program(gen)
     obj.set_densities(np.ones(256, dtype=np.float32))
+    if sample_ahead and os.environ.get("IVX_BENCH_SAMPLE_AHEAD", "1") != "0":
+        obj.set_sample_ahead(True)
     return gen, obj
 
 
@@ -413,6 +417,9 @@ def dense_benchmark(ctx, args, with_cpu):
     n = args.dense_chunks
     graph = scenes.plates_scene(n)
     gen, obj = make_object(ctx, graph)
+    # the same step first with its pre-pass as its own first kernel (`ms_per_step_isolated`), then — the leg's figures — with the pre-pass a step ahead
+    _, ms_isolated, stage_isolated = time_steps(ctx, obj, capi.STAGE_ALL, max(3, args.steps // 4), max(3, 3 * args.warmup))
+    obj.set_sample_ahead(os.environ.get("IVX_BENCH_SAMPLE_AHEAD", "1") != "0")
     # (warm-up: this leg starts after seconds of host-side oracle work with the GPU idle — over the first ~50 steps the per-step wall still falls
     # by 6 %, clocks ramping up, so two warm-up steps as in round 3 measured the ramp)
     res, ms, stage_ms = time_steps(ctx, obj, capi.STAGE_ALL, max(3, args.steps // 2), max(3, 3 * args.warmup))
@@ -427,7 +434,8 @@ def dense_benchmark(ctx, args, with_cpu):
     remesh_ms = remesh_only_ms(ctx, obj, max(3, args.steps // 4))
     out = {"workload": f"{n} perforated plates, one per chunk layer: {gen.grid_shape()} grid = {(n * 16)}^3 stored voxels, {non_uniform} of {obj.n_chunks} chunks "
                        f"NonUniform, {exposed} meshed",
-           "ms_per_step": ms, "voxels_per_s": obj.n_voxels / (ms * 1e-3), "active_voxels": active, "triangles": int(res["mesh"]["n_indices"]) // 3,
+           "ms_per_step": ms, "ms_per_step_isolated": ms_isolated, "sdf_sample_isolated_ms": round(float(stage_isolated[0]), 4),
+           "voxels_per_s": obj.n_voxels / (ms * 1e-3), "active_voxels": active, "triangles": int(res["mesh"]["n_indices"]) // 3,
            "remesh_tris_per_s": int(res["mesh"]["n_indices"]) // 3 / (remesh_ms * 1e-3), "regions": int(res["region_count"]),
            "stage_ms": {capi.STAGE_NAMES[i]: round(float(stage_ms[i]), 4) for i in range(capi.N_TIMED_STAGES)},
            "stage_gbs": {capi.STAGE_NAMES[i]: round(sb_act[capi.STAGE_NAMES[i]] / (stage_ms[i] * 1e-3) / 1e9, 1) if stage_ms[i] > 0 and sb_act[capi.STAGE_NAMES[i]] > 0 else None
@@ -481,14 +489,16 @@ def config5_benchmark(ctx, args):
     graph = scenes.asteroid_scene(4.2)
     gen, obj = make_object(ctx, graph)
     steps = max(5, args.steps // 10)
+    _, ms_isolated, _ = time_steps(ctx, obj, capi.STAGE_ALL, steps, 2)
+    obj.set_sample_ahead(os.environ.get("IVX_BENCH_SAMPLE_AHEAD", "1") != "0")  # (the slabs below as well: sample_ahead=True)
     res, ms, stage_ms = time_steps(ctx, obj, capi.STAGE_ALL, steps, 2)
     tris = int(res["mesh"]["n_indices"]) // 3
     n_vox = obj.n_voxels
-    out = {"workload": f"config-2 asteroid x4.2: {obj.chunk_counts[0] * 16}^3 stored voxels, one GPU", "single_grid_ms": ms,
+    out = {"workload": f"config-2 asteroid x4.2: {obj.chunk_counts[0] * 16}^3 stored voxels, one GPU", "single_grid_ms": ms, "single_grid_isolated_ms": ms_isolated,
            "single_grid_voxels_per_s": n_vox / (ms * 1e-3), "triangles": tris, "stage_ms": {capi.STAGE_NAMES[i]: round(float(stage_ms[i]), 4) for i in range(capi.N_TIMED_STAGES) if stage_ms[i] > 0}}
     obj.close()
     comm = NativeComm(ctx, 8, local=True)
-    steppers = [NativeSlabStepper(ctx, comm, graph, np.ones(256, dtype=np.float32), r) for r in range(8)]
+    steppers = [NativeSlabStepper(ctx, comm, graph, np.ones(256, dtype=np.float32), r, sample_ahead=AHEAD) for r in range(8)]
     group = NativeStepGroup(steppers)
     for s_ in steppers:  # (no event records around the stage slots: 12 per slab and step, ~2-3 us each on the queue; the N > 1 timed region keeps one slot's)
         s_.obj.set_stage_timing(0)
@@ -520,7 +530,7 @@ def strong_512_benchmark(ctx, args, single_ms, tris):
 
     graph = scenes.asteroid_scene(2.05)
     comm = NativeComm(ctx, 8, local=True)
-    steppers = [NativeSlabStepper(ctx, comm, graph, np.ones(256, dtype=np.float32), r) for r in range(8)]
+    steppers = [NativeSlabStepper(ctx, comm, graph, np.ones(256, dtype=np.float32), r, sample_ahead=AHEAD) for r in range(8)]
     group = NativeStepGroup(steppers)
     for s_ in steppers:
         s_.obj.set_stage_timing(0)
@@ -1520,7 +1530,7 @@ def main():
                 g = scenes.asteroid_scene(args.scale * world ** (1.0 / 3.0))
                 nm = f"config-2 SDF asteroid x{args.scale * world ** (1.0 / 3.0):.3f} (config 5 at N=8)"
             if native_comm is not None:
-                st = NativeSlabStepper(ctx, native_comm, g, dens, rank)
+                st = NativeSlabStepper(ctx, native_comm, g, dens, rank, sample_ahead=AHEAD)
                 group = NativeStepGroup([st])
 
                 def fn():

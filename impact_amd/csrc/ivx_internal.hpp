@@ -133,6 +133,7 @@ struct ivx_grid {
     uint32_t* ccl_scratch;  // [2*n_chunks]: per-chunk root counts and exclusive offsets
     uint32_t* sn_list;      // [n_chunks] uint4 records of the chunks that emit a mesh this remesh, in submesh order (written by k_sn_scan)
     uint32_t* group_sums;   // [4 * ceil(n_chunks/256) + IVX_SN_TAIL_WORDS]: first-level totals of the two-level scans; then the count of sn_hard and the mesher's list cursors
+    uint32_t* sn_walk;      // [5 n_chunks + 2] the order the mesher's main pass walks its list in (sn::SnWalk): records, then list indices
     uint32_t* sn_hard;      // [n_chunks] list entries (submesh order) of the chunks the mesher's main pass hands to its general pass
     uint32_t region_count;
     int regions_valid;

@@ -692,8 +692,19 @@ static inline uint32_t ivx_count_run(const ivx_grid* g) {
 // Exclusive scan over chunks in chunk-linear order of (vertices, indices, submesh) with chunks whose
 // index count is zero contributing nothing (mesh.rs:321-323). offsets[2c], offsets[2c+1]; totals at
 // offsets[2n..2n+3); submesh rank at ranks[c].
+// `walk` (the fused step path; null elsewhere): the order the mesher's main pass takes the list in — the chunks with many vertices first. Its
+// workgroups draw entries as they go, a thousand at a time over a list three to four times that, and a chunk takes 4 to 20 us: with the list in
+// chunk order the launch's last quarter is a few workgroups finishing whatever long entries came up last. Two classes are enough to end
+// on short ones: entries of at least `walk_big` vertices are listed from the front of `walk`, the others from its back, records (walk[0 .. n))
+// and list indices (walk_li) side by side so that a draw is still two independent loads; the class counts in walk_count[0 / 1] (zero at the start of a step).
+struct SnWalk {
+    uint4* items;         // [n_chunks]
+    uint32_t* li;         // [n_chunks]
+    uint32_t* count;      // [2]: entries listed from the front, from the back
+    uint32_t big;         // vertices from which an entry is listed from the front
+};
 __device__ __forceinline__ void role_sn_scan(uint32_t bid, uint32_t nb, uint32_t n_chunks, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ group_sums,
-                                                 uint32_t* __restrict__ offsets, uint32_t* __restrict__ ranks, uint4* __restrict__ emit_items) {
+                                                 uint32_t* __restrict__ offsets, uint32_t* __restrict__ ranks, uint4* __restrict__ emit_items, SnWalk walk = SnWalk{nullptr, nullptr, nullptr, 0u}) {
     // block b = chunks [256 b, 256 b + 256): base = totals of the groups before it, then an ordered block prefix
     __shared__ uint32_t s_w[3][4];
     __shared__ uint32_t s_base[3];
@@ -761,6 +772,27 @@ __device__ __forceinline__ void role_sn_scan(uint32_t bid, uint32_t nb, uint32_t
         // one record per meshed chunk: chunk, vertex offset, index offset, vertex count | quads << 16 — everything the emit
         // pass needs to start loading its tile after a single fetch
         if (on) emit_items[b2 + ws + is - ss] = make_uint4(c, b0 + wv + iv - sv, b1 + wi + ii - si, vi.x | ((vi.y / 6u) << 16));
+    }
+    if (walk.items) {  // (workgroup-uniform)
+        __shared__ uint32_t s_wb[2][4];
+        __shared__ uint32_t s_wbase[2];
+        const bool big = on && vi.x >= walk.big, small = on && !big;
+        const unsigned long long bb = __ballot(big), bs = __ballot(small);
+        if (lane == 0) s_wb[0][wave] = (uint32_t)__popcll(bb), s_wb[1][wave] = (uint32_t)__popcll(bs);
+        __syncthreads();
+        if (tid < 2u) {  // one returning atomic per class and block
+            const uint32_t n = (s_wb[tid][0] + s_wb[tid][1]) + (s_wb[tid][2] + s_wb[tid][3]);
+            s_wbase[tid] = n ? atomicAdd(walk.count + tid, n) : 0u;
+        }
+        __syncthreads();
+        if (on) {
+            const uint32_t cls = big ? 0u : 1u;
+            uint32_t pos = s_wbase[cls] + (uint32_t)__popcll((big ? bb : bs) & ((1ull << lane) - 1ull));
+            for (uint32_t w = 0; w < wave; ++w) pos += s_wb[cls][w];
+            if (!big) pos = n_chunks - 1u - pos;
+            walk.items[pos] = make_uint4(c, b0 + wv + iv - sv, b1 + wi + ii - si, vi.x | ((vi.y / 6u) << 16));
+            walk.li[pos] = b2 + ws + is - ss;
+        }
     }
     if (bid == nb - 1 && tid == 0) {
         offsets[2 * n_chunks] = b0 + tv;
@@ -1181,7 +1213,8 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
                                                  uint32_t* __restrict__ indices, unsigned long long* __restrict__ imats, ivx_submesh* __restrict__ submeshes,
                                                  const uint32_t* __restrict__ emit_count, const uint4* __restrict__ emit_items, uint32_t vcap, uint32_t icap,
                                                  uint32_t scap, const uint32_t* __restrict__ slots, uint32_t* __restrict__ hard_count,
-                                                 uint32_t* __restrict__ hard_list, uint32_t* __restrict__ cursor) {
+                                                 uint32_t* __restrict__ hard_list, uint32_t* __restrict__ cursor, SnWalk walk = SnWalk{nullptr, nullptr, nullptr, 0u},
+                                                 uint32_t walk_len = 0u) {
     __shared__ uint16_t s_quad[3 * VPC];  // the chunk's quads in emission order: cube id | axis << 13
     __shared__ __attribute__((aligned(16))) uint8_t s_sd[TILE_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t s_ty[TILE_BYTES];
@@ -1210,9 +1243,19 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
     // at once queue on eight words, not one (one word serves ~90 draws per microsecond). The draw runs two rounds ahead (the entry after the
     // next, whose tile is already being fetched), by thread 0 only: ticket at the top of a round, the entry's record when the ticket has come
     // back, both through LDS at the round's last barrier — no other wave ever waits for either.
+    // (`walk`: position t of the walk is the entry walk.li[w(t)] with the record walk.items[w(t)], w(t) = t among the entries listed from the
+    // front, else counted from the back of the arrays — role_sn_scan; without it position t is entry t)
+    const uint32_t walk_front = walk.items ? walk.count[0] : 0u;
     uint32_t li = NONE, li_next = bid, li_prev = NONE;
     if (li_next >= n_emit) return;
-    uint4 item = make_uint4(0u, 0u, 0u, 0u), item_next = emit_items[li_next];
+    uint4 item = make_uint4(0u, 0u, 0u, 0u), item_next;
+    if (walk.items) {
+        const uint32_t w = bid < walk_front ? bid : walk_len - 1u - (bid - walk_front);
+        item_next = walk.items[w];
+        li_next = walk.li[w];
+    } else {
+        item_next = emit_items[li_next];
+    }
     int upper[3] = {G - 1, G - 1, G - 1};  // of the tile in LDS
     uint32_t info_w = 0u;
     uint32_t buf = 0u;         // s_neg2[buf]: the sign rows of the tile in LDS (the next tile's go to the other half while this chunk's quads still read these)
@@ -1273,6 +1316,7 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
     TileLoads T;
     if (have_next) tile_issue(g, item_next.x, T, tid);
     uint4 drawn = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t drawn_li = 0u;
     // (straight-line from here to the vertices, also in a round without any — the first one, a chunk passed over —, where the order is built
     // from whatever the tile's LDS holds and nobody looks at it: with the phases under a condition the two paths kept the loads in flight in
     // different registers and met behind a full drain)
@@ -1324,8 +1368,17 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
     if ((tid >> 6) == (TK >> 6)) {
         const uint32_t tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
         if (have_next && tk < n_emit) {
-            drawn = emit_items[tk];
-            asm volatile("" : "+v"(drawn.x), "+v"(drawn.y), "+v"(drawn.z), "+v"(drawn.w));
+            if (walk.items) {
+                const uint32_t w = tk < walk_front ? tk : walk_len - 1u - (tk - walk_front);
+                drawn = walk.items[w];
+                drawn_li = walk.li[w];
+            } else {
+                drawn = emit_items[tk];
+                drawn_li = tk;
+            }
+            asm volatile("" : "+v"(drawn.x), "+v"(drawn.y), "+v"(drawn.z), "+v"(drawn.w), "+v"(drawn_li));
+        } else {
+            drawn_li = tk;  // (beyond the list: the walk ends there)
         }
     }
 
@@ -1484,7 +1537,7 @@ __device__ __forceinline__ void role_sn_emit(uint32_t bid, uint32_t nb, SnParams
         }
     }
     if (tid == TK && have_next) {
-        s_ticket[0] = ticket;
+        s_ticket[0] = ticket < n_emit ? drawn_li : NONE;
         s_ticket[1] = drawn.x, s_ticket[2] = drawn.y, s_ticket[3] = drawn.z, s_ticket[4] = drawn.w;
     }
     if (have) IVX_T(g, li, 4);  // (wave 0's) quads written

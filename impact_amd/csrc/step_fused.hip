@@ -53,6 +53,7 @@ struct StepArgs {
     uint4* vmats;
     uint32_t* hard_count;  // chunks the mesher's main pass hands to the general pass: counter, list
     uint32_t* hard_list;
+    sn::SnWalk walk;       // the order the main pass takes its list in (role_sn_scan writes it, role_sn_emit reads it)
     ivx_submesh* submeshes;
     uint32_t vcap, icap, scap;
     // occupied / moments
@@ -115,6 +116,9 @@ __device__ __forceinline__ void step_post1_body(const StepArgs& a, uint32_t b, u
     __shared__ uint32_t sh_words[4 * sn::NROWS + 16];  // (tile sign rows: a wave each in the count role, one set in the needs role)
     struct { uint32_t* par; } sh{sh_words};
     if (b < a.nb[0]) {
+        // (the class counts of the main pass's walk order, which the scan role of the launch behind this one adds to: zero from here — words of their
+        // own, not of the mesher's tail block, which a re-emit after the buffers grew clears while the walk order still stands)
+        if (b == 0u && threadIdx.x < 2u && a.walk.items) a.walk.count[threadIdx.x] = 0u;
         sn::role_sn_count_waves(b, a.nb[0], sn_params(a), a.counts, a.sn_group_sums, a.work_count, a.active_list, sh.par, a.count_run, a.x_part);
         return;
     }
@@ -195,7 +199,7 @@ __device__ __forceinline__ void step_post2_body(const StepArgs& a, uint32_t b, u
     }
     b -= a.nb[0];
     if (b < a.nb[1]) {
-        sn::role_sn_scan(b, a.nb[1], a.n_chunks, a.counts, a.sn_group_sums, a.offsets, a.ranks, a.emit_items);
+        sn::role_sn_scan(b, a.nb[1], a.n_chunks, a.counts, a.sn_group_sums, a.offsets, a.ranks, a.emit_items, a.walk);
         return;
     }
     b -= a.nb[1];
@@ -226,7 +230,7 @@ __device__ __forceinline__ void step_emit_body(const StepArgs& a, uint32_t b, ui
     b -= a.nb[0];
     if (b < a.nb[1]) {
         sn::role_sn_emit<false>(b, a.nb[1], sn_params(a), a.positions, a.normals, a.indices, a.imats, a.submeshes, a.offsets + 2 * (size_t)a.n_chunks + 2,
-                                a.emit_items, a.vcap, a.icap, a.scap, nullptr, a.hard_count, a.hard_list, a.hard_count + 32);
+                                a.emit_items, a.vcap, a.icap, a.scap, nullptr, a.hard_count, a.hard_list, a.hard_count + 32, a.walk, a.n_chunks);
         return;
     }
     b -= a.nb[1];
@@ -319,6 +323,17 @@ static StepArgs make_args(ivx_grid* g) {
     a.vmats = reinterpret_cast<uint4*>(g->vertex_materials);
     a.hard_count = ivx_sn_hard_count(g);
     a.hard_list = g->sn_hard;
+    {
+        // (entries of at least this many vertices are walked first: above the mean of a smooth body's meshed chunks, ~260; developer knob)
+        static const uint32_t big = [] {
+            const char* e = getenv("IVX_SN_WALK_BIG");
+            return e ? (uint32_t)strtoul(e, nullptr, 10) : 288u;
+        }();
+        a.walk.items = big ? reinterpret_cast<uint4*>(g->sn_walk) : nullptr;
+        a.walk.li = g->sn_walk + 4 * (size_t)g->n_chunks;
+        a.walk.count = g->sn_walk + 5 * (size_t)g->n_chunks;  // (zeroed by the count role of k_step_post1)
+        a.walk.big = big;
+    }
     a.submeshes = g->submeshes;
     a.vcap = (uint32_t)g->vcap;
     a.icap = (uint32_t)g->icap;

@@ -391,7 +391,7 @@ class NativeComm:
 class NativeSlabStepper:
     """One x-slab stepped through `ivx_slabs_step_enqueue` / `ivx_slabs_step_collect`."""
 
-    def __init__(self, ctx: Context, comm: NativeComm, graph, densities, rank: int, voxel_extent: float = 1.0, voxel_type: int = 0):
+    def __init__(self, ctx: Context, comm: NativeComm, graph, densities, rank: int, voxel_extent: float = 1.0, voxel_type: int = 0, sample_ahead: bool = False):
         self.comm, self.rank, self.world = comm, rank, comm.world
         self.gen = SDFVoxelGenerator(voxel_extent, graph, voxel_type)
         cc = self.gen.chunk_counts()
@@ -404,6 +404,8 @@ class NativeSlabStepper:
         self.obj = VoxelObject(ctx, (x1 - x0, cc[1], cc[2]), voxel_extent, x0, cc[0])
         self.obj.set_sdf_program(self.gen)
         self.obj.set_densities(densities)
+        if sample_ahead:  # (the slab samples the resident program every step: its pre-pass runs a step ahead, ivx_grid_set_sample_ahead)
+            self.obj.set_sample_ahead(True)
         h = C.c_void_p()
         check(capi.lib().ivx_slab_create(comm.h, self.obj.h, rank, C.byref(h)))
         self.h = h

@@ -15,7 +15,7 @@ graph = scenes.asteroid_scene(4.2)
 comm = NativeComm(ctx, 8, local=True)
 if os.environ.get("SLAB_LOCAL_COPIES"):
     comm.set_local_copies(int(os.environ["SLAB_LOCAL_COPIES"]))
-steppers = [NativeSlabStepper(ctx, comm, graph, np.ones(256, dtype=np.float32), r) for r in range(8)]
+steppers = [NativeSlabStepper(ctx, comm, graph, np.ones(256, dtype=np.float32), r, sample_ahead=os.environ.get("SLAB_SAMPLE_AHEAD", "1") != "0") for r in range(8)]
 group = NativeStepGroup(steppers)
 if os.environ.get("SLAB_NO_STAGE_TIMING"):
     for s_ in steppers:
