@@ -35,7 +35,9 @@ def run_and_compare(ctx, graph, world, expect_regions=None, extent=1.0, driver="
         comm = NativeComm(ctx, world, local=True)
         if driver != "native":
             comm.set_local_copies(1 if driver == "native_overlap" else 2)
-        steppers = [NativeSlabStepper(ctx, comm, graph, dens, r, extent) for r in range(world)]
+        # (native_overlap also runs every slab's sampler pre-pass a step ahead, ivx_grid_set_sample_ahead: three steps, so the second and third
+        # find theirs done)
+        steppers = [NativeSlabStepper(ctx, comm, graph, dens, r, extent, sample_ahead=driver == "native_overlap") for r in range(world)]
     else:
         steppers = [SlabStepper(ctx, graph, dens, r, world, torch, extent) for r in range(world)]
     try:
@@ -151,7 +153,7 @@ def test_headline_512_in_8_slabs(ctx, overlap):
     comm = NativeComm(ctx, 8, local=True)
     if overlap:
         comm.set_local_copies(1)
-    steppers = [NativeSlabStepper(ctx, comm, graph, dens, r) for r in range(8)]
+    steppers = [NativeSlabStepper(ctx, comm, graph, dens, r, sample_ahead=overlap) for r in range(8)]  # (overlap: the slabs' pre-passes a step ahead too)
     try:
         for _ in range(3 if overlap else 1):
             results = native_step(steppers)
