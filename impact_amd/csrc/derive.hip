@@ -789,7 +789,7 @@ ivx_roles::PresetArgs ivx_preset_args(ivx_grid* g, uint32_t groups) {
     a.groups = groups;
     a.rscalar = g->rscalar;
     a.sn_sums = g->group_sums + n_groups;
-    a.n_sn = 3 * n_groups;  // (role_preset also clears the nine words in use behind them: the general pass's counter, the main pass's list cursors)
+    a.n_sn = IVX_SN_GROUP_WORDS * n_groups;  // (role_preset also clears the nine words in use behind them: the general pass's counter, the main pass's list cursors)
     a.eval_count = g->samp_len ? g->samp_len + g->n_chunks : nullptr;
     return a;
 }

@@ -521,7 +521,7 @@ static size_t grid_carve(ivx_grid* g, char* arena) {
     carve(&g->rscalar, (size_t)64);
     carve(&g->ccl_scratch, (size_t)g->n_chunks * 2);
     carve(&g->sn_list, (size_t)g->n_chunks * 4);  // one uint4 record per meshed chunk
-    carve(&g->group_sums, (size_t)((g->n_chunks + 255u) / 256u) * 4 + IVX_SN_TAIL_WORDS);
+    carve(&g->group_sums, (size_t)((g->n_chunks + 255u) / 256u) * (1u + IVX_SN_GROUP_WORDS) + IVX_SN_TAIL_WORDS);
     carve(&g->sn_hard, (size_t)g->n_chunks);
     carve(&g->sn_walk, (size_t)g->n_chunks * 5 + 2);  // the main pass's walk order: a uint4 record and a list index per meshed chunk, the two class counts (role_sn_scan)
     carve(&g->dens_dev, (size_t)256);

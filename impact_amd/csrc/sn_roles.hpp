@@ -554,7 +554,7 @@ __device__ __forceinline__ void role_sn_count_waves(uint32_t bid, uint32_t nb, S
     uint32_t acc_group = 0xFFFFFFFFu, acc_v = 0u, acc_i = 0u, acc_s = 0u;  // (lane 0)
     auto flush = [&]() {
         if (lane == 0 && acc_group != 0xFFFFFFFFu) {
-            uint32_t* gs = group_sums + 3 * acc_group;
+            uint32_t* gs = group_sums + IVX_SN_GROUP_WORDS * acc_group;
             atomicAdd(gs, acc_v);
             atomicAdd(gs + 1, acc_i);
             atomicAdd(gs + 2, acc_s);
@@ -711,9 +711,9 @@ __device__ __forceinline__ void role_sn_scan(uint32_t bid, uint32_t nb, uint32_t
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t p0 = 0, p1 = 0, p2 = 0;
     for (uint32_t b = tid; b < bid; b += 256u) {
-        p0 += group_sums[3 * b];
-        p1 += group_sums[3 * b + 1];
-        p2 += group_sums[3 * b + 2];
+        p0 += group_sums[IVX_SN_GROUP_WORDS * b];
+        p1 += group_sums[IVX_SN_GROUP_WORDS * b + 1];
+        p2 += group_sums[IVX_SN_GROUP_WORDS * b + 2];
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

@@ -203,7 +203,7 @@ int ivx_launch_sn_count(ivx_grid* g) {
     if (int rc_l = ivx_ensure_active_list(g)) return rc_l;
     const uint32_t groups = (g->n_chunks + 255u) / 256u;
     uint32_t* gs = g->group_sums + groups;  // the first `groups` words belong to the region resolve
-    IVX_HIP_CHECK(ivx_memset_async(gs, 0, sizeof(uint32_t) * (3 * groups + IVX_SN_TAIL_WORDS), g->ctx->stream));  // (stand-alone path; the fused step path presets in its first kernel)
+    IVX_HIP_CHECK(ivx_memset_async(gs, 0, sizeof(uint32_t) * (IVX_SN_GROUP_WORDS * groups + IVX_SN_TAIL_WORDS), g->ctx->stream));  // (stand-alone path; the fused step path presets in its first kernel)
     g->scratch_dirty |= IVX_SCRATCH_SN;
     g->preset_fresh &= ~IVX_SCRATCH_SN;
     const uint32_t run = ivx_count_run(g);
@@ -244,7 +244,7 @@ int ivx_launch_sn_scan(ivx_grid* g) {
 
 // the counter of the chunks handed to the general pass: the word behind the Surface-Nets group totals (zeroed with them ahead of every count pass);
 // the main pass's eight list cursors follow at a stride of 32 words (a cache line each)
-uint32_t* ivx_sn_hard_count(ivx_grid* g) { return g->group_sums + 4 * (size_t)((g->n_chunks + 255u) / 256u); }
+uint32_t* ivx_sn_hard_count(ivx_grid* g) { return g->group_sums + (1u + IVX_SN_GROUP_WORDS) * (size_t)((g->n_chunks + 255u) / 256u); }
 
 int ivx_launch_sn_emit(ivx_grid* g) {
     g->sn_tail_zero = 0;
