@@ -1599,7 +1599,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     isolated = None
-    if not slabs and sample_ahead:
+    if not slabs and sample_ahead and not args.plain:
         # the same step with its pre-pass as its own first kernel (what a step that is not followed by another costs)
         obj.set_sample_ahead(False)
         n_iso = max(5, min(args.steps, 100))

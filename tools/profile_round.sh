@@ -20,6 +20,10 @@ for wl in headline dense; do
   rocprofv3 --kernel-trace --stats -d "$out/trace_$wl" -o trace -- python3 bench.py $STEPS $W > "$out/${tag}_bench_step_only_$wl.json" 2> "$out/trace_${wl}_stderr.log"
   python tools/rocpd_stats.py "$(ls "$out"/trace_$wl/*.db | tail -1)" > "$out/${tag}_kernel_stats_step_only_$wl.csv"
   python tools/kernel_share.py "$out/${tag}_kernel_stats_step_only_$wl.csv" "$out/kernel_share_$wl.json" > /dev/null
+  # ... and the step as a step of its own (no pre-pass a step ahead beside the other kernels): the kernels' durations undisturbed
+  IVX_BENCH_SAMPLE_AHEAD=0 rocprofv3 --kernel-trace --stats -d "$out/trace_iso_$wl" -o trace -- python3 bench.py $STEPS $W > "$out/${tag}_bench_step_only_isolated_$wl.json" 2> "$out/trace_iso_${wl}_stderr.log"
+  python tools/rocpd_stats.py "$(ls "$out"/trace_iso_$wl/*.db | tail -1)" > "$out/${tag}_kernel_stats_step_only_isolated_$wl.csv"
+  rm -rf "$out/trace_iso_$wl"
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_fetch_$wl" -o fetch -- python3 bench.py $STEPS $W > "$out/pmc_fetch_$wl.log" 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/pmc_write_$wl" -o write -- python3 bench.py $STEPS $W > "$out/pmc_write_$wl.log" 2>&1
   python tools/pmc_traffic.py "$(ls "$out"/pmc_fetch_$wl/*.db | tail -1)" "$(ls "$out"/pmc_write_$wl/*.db | tail -1)" "$out/pmc_traffic_$wl.json" $NST "bench.py $STEPS $W"
