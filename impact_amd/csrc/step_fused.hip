@@ -115,6 +115,14 @@ __device__ __forceinline__ sn::SnParams sn_params(const StepArgs& a) {
 __device__ __forceinline__ void step_post1_body(const StepArgs& a, uint32_t b, uint32_t) {
     __shared__ uint32_t sh_words[4 * sn::NROWS + 16];  // (tile sign rows: a wave each in the count role, one set in the needs role)
     struct { uint32_t* par; } sh{sh_words};
+    // (the region merge's blocks come first: it is the role with the longest chain of dependent loads and atomics — 19 us by itself on the
+    // headline body against the count's 13 — and workgroups start in index order: behind the count role's blocks, which fill every slot
+    // of the chip, its waves used to start when the first of those were through)
+    if (b < a.nb[1]) {
+        role_ccl_merge_columns(b, a.nb[1], a.g, a.touch, a.rparent);
+        return;
+    }
+    b -= a.nb[1];
     if (b < a.nb[0]) {
         // (the class counts of the main pass's walk order, which the scan role of the launch behind this one adds to: zero from here — words of their
         // own, not of the mesher's tail block, which a re-emit after the buffers grew clears while the walk order still stands)
@@ -123,11 +131,6 @@ __device__ __forceinline__ void step_post1_body(const StepArgs& a, uint32_t b, u
         return;
     }
     b -= a.nb[0];
-    if (b < a.nb[1]) {
-        role_ccl_merge_columns(b, a.nb[1], a.g, a.touch, a.rparent);
-        return;
-    }
-    b -= a.nb[1];
     if (b < a.nb[3]) {
         role_occupied_partial(b, a.g.cx, a.g.cy, a.g.cz, a.bbox, a.occ_part);
         return;
