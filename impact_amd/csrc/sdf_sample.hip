@@ -1126,8 +1126,13 @@ __device__ __forceinline__ void combine_levels(uint32_t kind, float s, float q, 
 // words of LDS behind / at the tail of the stack: [0..5) the published test voxels of a register row, [8..12) the classification's votes
 // MODE 2: the one-level class (programs whose only operands with a level of their own are fused away, see eval_leaf_fused): 16 KB + the
 // scratch words, eight workgroups per CU.
+// (eight waves per SIMD: the compiler keeps the scalar registers under the 96 that allows — the kernel's 106 held it to seven, i.e. seven of the
+// eight workgroups a CU's LDS takes in the one-level class)
+#ifndef IVX_EVAL_WAVES
+#define IVX_EVAL_WAVES 8
+#endif
 template <int MODE>
-__global__ __launch_bounds__(256) void k_sdf_eval(SampleParams p, const uint32_t* __restrict__ eval_count, const uint32_t* __restrict__ eval_list,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IVX_EVAL_WAVES, 8))) void k_sdf_eval(SampleParams p, const uint32_t* __restrict__ eval_count, const uint32_t* __restrict__ eval_list,
                                                   const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ first_count,
                                                   const uint32_t* __restrict__ first_list, uint32_t list_len, uint32_t scratch_off,
                                                   const uint32_t* __restrict__ prog_len, const uint2* __restrict__ prog_ops,
