@@ -1424,12 +1424,9 @@ int ivx_sampler_buffers(ivx_grid* g) {
 
 // the context's second stream (sample-ahead), made on first use
 static int ivx_aux_stream(ivx_ctx* c, hipStream_t* out) {
-    if (!c->aux_stream) {
-        // (the lowest priority there is: what runs here rides beside the context's own work, which must not queue behind it)
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, least) != hipSuccess)
-            IVX_HIP_CHECK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-    }
+    // (a stream of the default priority: with the lowest priority the pre-pass was served late whenever the process held other queues — under
+    // torch.distributed + RCCL the sample stage then waited for it, 0.247 ms per slab step against 0.200 — and gained nothing elsewhere)
+    if (!c->aux_stream) IVX_HIP_CHECK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
     *out = c->aux_stream;
     return IVX_OK;
 }
@@ -1524,6 +1521,10 @@ int ivx_launch_sdf_sample(ivx_grid* g, const ivx_sdf_processed_node* d_nodes, ui
         consume = false;
     }
     const bool eval_dirty = (g->scratch_dirty & IVX_SCRATCH_EVAL) != 0u;
+    static const bool ahead_trace = getenv("IVX_AHEAD_TRACE") != nullptr;  // (developer aid: what every sample stage did about its pre-pass)
+    if (ahead_trace)
+        fprintf(stderr, "[ivx sample] grid %p: resident %d ahead_on %d pending %d fits %d (known %d launches %d%d%d) unordered_ok %d -> %s\n", (void*)g, (int)resident_program,
+                g->ahead_on, g->ahead_pending, (int)ahead_fits, (int)known, (int)launch2, (int)launch1, (int)launch0, g->ahead_unordered_ok, consume ? "consume" : "own pre-pass");
     if (consume) {
         std::swap(g->samp_len, g->samp_len_alt);
         void* t_ops = g->samp_ops;
