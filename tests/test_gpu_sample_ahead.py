@@ -119,3 +119,28 @@ def test_sample_alone_then_the_rest(ctx):
         r = obj.step(capi.STAGE_ALL)
         assert pu.step_parity(o, obj, r)["equal"]
     obj.close()
+
+
+@pytest.mark.parametrize("seed", pu.fuzz_seeds([31, 32, 33, 34, 35, 36, 210, 341]))
+def test_random_programs_with_the_pre_pass_a_step_ahead(ctx, seed):
+    """tests/test_gpu_random_sdf.py's programs as resident programs stepped three times with the pre-pass ahead: the second and third step start
+    at their evaluator, whose first launch commits the records the pre-pass parked — the chunk records and voxel bytes of every step against
+    the oracle's"""
+    from test_gpu_random_sdf import random_tree
+
+    rng = np.random.default_rng(seed)
+    g = SDFGraph()
+    random_tree(g, rng, int(rng.integers(1, 5)))
+    gen = SDFVoxelGenerator(1.0, g, 0)
+    if min(gen.chunk_counts()) == 0:
+        pytest.skip("degenerate root domain")
+    o = oracle_of(g)
+    obj = VoxelObject(ctx, gen.chunk_counts(), 1.0)
+    obj.set_sdf_program(gen)
+    obj.set_densities(np.ones(256, dtype=np.float32))
+    obj.set_sample_ahead(True)
+    for i in range(3):
+        r = obj.step(capi.STAGE_ALL)
+        p = pu.step_parity(o, obj, r)
+        assert p["equal"], (i, p)
+    obj.close()
